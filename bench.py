@@ -1,0 +1,212 @@
+#!/usr/bin/env python3
+"""bench.py — BASELINE.json's metric: rows/s of the 2-D count+mean pass on a 256x256 grid,
+1e9 float64 rows per GPU, HBM-resident, N GPUs of one node (one process per GPU, RCCL).
+
+A "step" = one full pass over this rank's rows: reset grids, ONE fused kernel pass computing
+count(*), sum(v), count(v) (= what df.count + df.mean(v) binby=[x,y] shape=256 schedules:
+vaex/agg.py:391-418 builds mean from sum and count, merged into one TaskAggregations pass),
+fold of the replicas, (N>1) RCCL all-reduce of the three grids, D2H of the results and the numpy
+finish mean = sum/count.  Inputs are synthetic N(0,1)/N(3,2) columns generated on the device
+(there is no dataset on the box); limits [-4,4].
+
+Prints ONE JSON line (rank 0) with `roofline` (HIP-event kernel time on the library's stream vs
+24 B/row of compulsory reads) and `cpu_baseline` (the reference's own C++ from oracle/_ref driven
+from a thread pool like vaex's executor, or the C port if that is absent) objects.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy)
+BYTES_PER_ROW = 24     # x, y, v float64: compulsory reads of the 2-D count+mean pass
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--rows", type=float, default=1e9, help="rows per GPU (weak scaling)")
+    ap.add_argument("--shape", type=int, default=256)
+    ap.add_argument("--cpu-rows", type=float, default=1e8, help="rows of the bounded CPU-baseline sample")
+    ap.add_argument("--no-cpu", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(x, y, v, shape, rows):
+    """The same pass on the host cores: reference C++ (oracle/_ref) when it loads, else the C port."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import oracle
+    rows = int(min(rows, len(x)))
+    xs, ys, vs = (t[:rows].cpu().numpy() for t in (x, y, v))
+    ref = oracle.ref_module("superagg")
+    cores = os.cpu_count() or 1
+    if ref is not None:
+        nthreads = cores
+        chunk = 1 << 20  # vaex's chunk size cap (vaex/settings.py:83-87)
+
+        def one_pass():
+            bx = ref.BinnerScalar_float64(nthreads, "x", -4.0, 4.0, shape)
+            by = ref.BinnerScalar_float64(nthreads, "y", -4.0, 4.0, shape)
+            grid = ref.Grid([bx, by])
+            aggs = [ref.AggCount_int64(grid, nthreads, nthreads), ref.AggSum_float64(grid, nthreads, nthreads), ref.AggCount_float64(grid, nthreads, nthreads)]
+            import queue
+            slots = queue.Queue()
+            for t in range(nthreads):
+                slots.put(t)
+
+            def work(i1):
+                t = slots.get()
+                try:
+                    i2 = min(rows, i1 + chunk)
+                    bx.set_data(t, xs[i1:i2]); by.set_data(t, ys[i1:i2])
+                    bx.clear_data_mask(t); by.clear_data_mask(t)
+                    aggs[1].set_data(t, vs[i1:i2], 0); aggs[2].set_data(t, vs[i1:i2], 0)
+                    for a in aggs:
+                        a.clear_data_mask(t)
+                    grid.bin(t, aggs, i2 - i1)
+                finally:
+                    slots.put(t)
+            with ThreadPoolExecutor(nthreads) as pool:
+                list(pool.map(work, range(0, rows, chunk)))
+            res = [a.get_result() for a in aggs]
+            return res
+        kind = "reference"
+    else:
+        nthreads = 1
+        case = dict(n=rows, binners=[dict(kind="scalar", data=xs, vmin=-4, vmax=4, bins=shape), dict(kind="scalar", data=ys, vmin=-4, vmax=4, bins=shape)],
+                    aggs=[dict(kind="count"), dict(kind="sum", data=vs), dict(kind="count", data=vs)])
+
+        def one_pass():
+            return oracle.run_case(case)
+        kind = "port"
+    best = float("inf")
+    res = None
+    t_start = time.perf_counter()
+    reps = 0
+    while reps < 3 or (time.perf_counter() - t_start < 10 and reps < 20):
+        t0 = time.perf_counter()
+        res = one_pass()
+        best = min(best, time.perf_counter() - t0)
+        reps += 1
+    return dict(value=rows / best, unit="rows/s", cores=nthreads, kind=kind,
+                sample=f"{rows:.3g} of the GPU's own rows (x,y,v float64), same 2-D {shape}x{shape} count+sum+count pass, best of {reps} passes, 1Mi-row chunks over a {nthreads}-thread pool"), res, rows
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    import torch.distributed as dist
+    import vaex_amd
+    from vaex_amd import dist as vdist
+    sa = vaex_amd.superagg
+    if not torch.cuda.is_available() or sa.device_count() == 0:
+        raise SystemExit("bench.py needs a GPU (no CPU fallback in the product path)")
+    torch.cuda.set_device(local_rank)
+    sa.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    rows = int(args.rows)
+    shape = args.shape
+
+    gen = torch.Generator(device="cuda").manual_seed(1234 + rank)
+    x = torch.randn(rows, dtype=torch.float64, device="cuda", generator=gen)
+    y = torch.randn(rows, dtype=torch.float64, device="cuda", generator=gen)
+    v = torch.randn(rows, dtype=torch.float64, device="cuda", generator=gen) * 2 + 3
+    torch.cuda.synchronize()
+
+    bx = sa.BinnerScalar_float64(1, "x", -4.0, 4.0, shape)
+    by = sa.BinnerScalar_float64(1, "y", -4.0, 4.0, shape)
+    grid = sa.Grid([bx, by])
+    count = sa.AggCount_int64(grid, 1, 1)      # count(*)
+    vsum = sa.AggSum_float64(grid, 1, 1)       # sum(v)
+    vcount = sa.AggCount_float64(grid, 1, 1)   # count(v): non-NaN v
+    aggs = [count, vsum, vcount]
+    bx.set_data(0, x); by.set_data(0, y)
+    bx.clear_data_mask(0); by.clear_data_mask(0)
+    vsum.set_data(0, v, 0); vcount.set_data(0, v, 0)
+    for a in aggs:
+        a.clear_data_mask(0)
+
+    kernel_ms = []
+
+    def step():
+        for a in aggs:
+            a.reset()
+        sa.timer_start(0)
+        grid.bin(0, aggs, rows)                # the hot path: one fused kernel pass
+        kernel_ms.append(sa.timer_stop(0))
+        if world > 1:
+            vdist.allreduce_aggs(aggs)         # RCCL all-reduce of the three grids
+        c, s, cv = (a.get_result() for a in aggs)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            mean = s / cv                      # vaex/agg.py:403-416
+        return c[2:-1, 2:-1], mean[2:-1, 2:-1]  # edges=False slice (vaex/agg.py:323-335)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    kernel_ms.clear()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        c, mean = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    total_rows = rows * world
+    assert int(count.get_result().sum()) == total_rows, "count conservation violated"
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = total_rows * args.steps / elapsed
+        k_ms = float(np.mean(kernel_ms))
+        achieved = BYTES_PER_ROW * rows / (k_ms * 1e-3) / 1e9
+        out = {
+            "metric": "rows/sec, 2-D count+mean on 256x256 grid (count(*), sum(v), count(v) fused), float64 x,y,v",
+            "value": value, "unit": "rows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic (device-generated N(0,1) x,y; N(3,2) v; limits [-4,4])",
+            "config": {"workload": f"{rows:.3g}-row float64 x,y,v per GPU: count+sum+mean on {shape}x{shape} grid, HBM-resident (BASELINE configs[1])",
+                       "rows_per_gpu": rows, "shape": shape, "kernel": sa.last_kernel(0), "parallelism": f"row-sharded x{world}, RCCL all-reduce of 3 grids"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "kernel_ms": k_ms, "bytes_per_row": BYTES_PER_ROW, "rows_per_launch": rows},
+        }
+        if world == 1 and not args.no_cpu:
+            cb, cpu_res, cpu_rows = cpu_baseline(x, y, v, shape, args.cpu_rows)
+            out["cpu_baseline"] = cb
+            # same-run parity on the CPU sample: counts bit-exact, sums to 1e-12 of sum|v|
+            for a in aggs:
+                a.reset()
+            bx.set_data(0, x[:cpu_rows]); by.set_data(0, y[:cpu_rows]); vsum.set_data(0, v[:cpu_rows], 0); vcount.set_data(0, v[:cpu_rows], 0)
+            grid.bin(0, aggs, cpu_rows)
+            g = [a.get_result() for a in aggs]
+            ok = bool(np.array_equal(g[0], cpu_res[0]) and np.array_equal(g[2], cpu_res[2]))
+            vmax = float(torch.nan_to_num(v[:cpu_rows]).abs().max().item())
+            ok = ok and bool(np.all(np.abs(g[1] - cpu_res[1]) <= 1e-12 * vmax * np.maximum(g[2], 1)))  # per cell: 1e-12 * (>= sum|v| of the cell)
+            out["cpu_baseline"]["parity_on_sample"] = ok
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

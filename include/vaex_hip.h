@@ -1,0 +1,187 @@
+/*
+ * vaex_hip.h — C-ABI of libvaexhip.so: MI355X (gfx950) kernels for vaex's N-d binned
+ * statistics / groupby-aggregation hot path.
+ *
+ * This is the drop-in boundary.  Each entry point replaces one member of the reference's
+ * native `vaex.superagg` (and, for the hash map, `vaex.superutils`) pybind11 surface; the
+ * citation after each declaration is the reference code it stands in for (paths relative to
+ * /root/reference/packages/vaex-core/).  A pybind11 shim (vaex_amd/csrc/superagg_module.cpp)
+ * re-exposes these as the Python classes vaex looks up by name (vaex/utils.py:754-791), so
+ * `vaex.superagg` can be swapped for `vaex_amd.superagg` with no change to vaex's Python
+ * (INTEGRATION.md).
+ *
+ * Conventions
+ *   - Plain C: opaque handles, pointers and sizes.  No torch / pybind types.
+ *   - Every function returning `int` returns 0 on success, non-zero on failure; the message
+ *     (same wording as the reference's std::runtime_error texts where one exists) is
+ *     available from vxh_last_error() on the calling thread.
+ *   - `thread` is the reference's per-thread slot index (agg_base.hpp:97-98): distinct slots
+ *     may be driven concurrently from different host threads; each slot owns a HIP stream.
+ *   - Data pointers are BORROWED for the duration of vxh_grid_bin (src/agg_base.hpp:166-179:
+ *     raw pointer, no incref).  `mem` says where the pointer lives:
+ *       VXH_MEM_HOST   - host memory (numpy chunk).  vxh_grid_bin stages it through pinned
+ *                        buffers + hipMemcpyAsync on the slot's stream; the host pointer is no
+ *                        longer read once vxh_grid_bin returns.
+ *       VXH_MEM_DEVICE - HBM-resident column (device pointer); used in place, nothing copied,
+ *                        vxh_grid_bin returns as soon as the kernels are enqueued.
+ *   - Grid cell layout: dim 0 fastest (src/agg.hpp:63-73); scalar binner = bins+3 cells
+ *     [nan/masked, underflow, bin0..binN-1, overflow] (src/binners.cpp:13-59); ordinal binner
+ *     = N+2 (+1) cells [0..N-1, (other), null, nan] (src/binner_ordinal.cpp:11-13, :178).
+ */
+#ifndef VAEX_HIP_H
+#define VAEX_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VXH_ABI_VERSION 1
+
+/* element types, in the order of src/create_alltypes.hpp; names as src/utils.hpp:32-90 */
+typedef enum vxh_dtype {
+    VXH_F64 = 0, VXH_F32 = 1, VXH_I64 = 2, VXH_I32 = 3, VXH_I16 = 4, VXH_I8 = 5,
+    VXH_U64 = 6, VXH_U32 = 7, VXH_U16 = 8, VXH_U8 = 9, VXH_BOOL = 10, VXH_DTYPE_COUNT = 11
+} vxh_dtype;
+
+typedef enum vxh_agg_kind {
+    VXH_AGG_COUNT = 0,      /* AggCount_<T>      src/agg_count.cpp:7-68    grid int64            */
+    VXH_AGG_SUM = 1,        /* AggSum_<T>        src/agg_sum.cpp:131-147   grid upcast<T>        */
+    VXH_AGG_SUM_MOMENT = 2, /* AggSumMoment_<T>  src/agg_sum.cpp:149-166   grid upcast<T>        */
+    VXH_AGG_MIN = 3,        /* AggMin_<T>        src/agg_minmax.cpp:77-140 grid T, fill +inf/max */
+    VXH_AGG_MAX = 4         /* AggMax_<T>        src/agg_minmax.cpp:7-75   grid T, fill -inf/min */
+} vxh_agg_kind;
+
+typedef enum vxh_mem { VXH_MEM_HOST = 0, VXH_MEM_DEVICE = 1 } vxh_mem;
+
+typedef struct vxh_binner vxh_binner;
+typedef struct vxh_grid vxh_grid;
+typedef struct vxh_agg vxh_agg;
+typedef struct vxh_hashmap vxh_hashmap;
+
+/* ---- library ------------------------------------------------------------------------- */
+int vxh_abi_version(void);
+/* message of the last failure on this thread ("" if none) */
+const char *vxh_last_error(void);
+/* number of visible HIP devices (0 and success when there is no GPU / no driver) */
+int vxh_device_count(int *count);
+/* select the device all subsequently created objects live on (one process per GPU) */
+int vxh_set_device(int device);
+/* block until all work enqueued by this library has finished */
+int vxh_synchronize(void);
+/* run slot `thread`'s work on a caller-owned hipStream_t (NULL = library-owned stream) */
+int vxh_slot_set_stream(int thread, void *hip_stream);
+/* tuning knobs ("strategy", "replicas", "block", "blocks_per_cu", "stage_bytes"); see DESIGN.md */
+int vxh_config_set(const char *key, int64_t value);
+int vxh_config_get(const char *key, int64_t *value);
+/* name of the kernel variant the last vxh_grid_bin on `thread` launched (for tests / bench) */
+const char *vxh_last_kernel(int thread);
+
+/* ---- binners ------------------------------------------------------------------------- */
+/* BinnerScalar<T,…,FlipEndian>(threads, expression, vmin, vmax, bins) — src/binners.cpp:9-12, :97 */
+int vxh_binner_scalar_create(int threads, int dtype, int flip_endian, double vmin, double vmax, uint64_t bins, vxh_binner **out);
+/* BinnerOrdinal<T,…>(threads, expression, ordinal_count, min_value, allow_other, invert) — src/binner_ordinal.cpp:15-17, :217 */
+int vxh_binner_ordinal_create(int threads, int dtype, int flip_endian, int64_t ordinal_count, int64_t min_value, int allow_other, int invert, vxh_binner **out);
+/* BinnerHash<T>(threads, expression, hash_map) — src/binner_hash.cpp:13-20, :152.  Cells
+ * [unknown key, bin0..binN-1, null]; the map must stay alive as long as the binner. */
+int vxh_binner_hash_create(int threads, int dtype, vxh_hashmap *map, vxh_binner **out);
+/* BinnerScalar::copy / BinnerOrdinal::copy — src/binners.cpp:11, binner_ordinal.cpp:18 */
+int vxh_binner_copy(const vxh_binner *binner, vxh_binner **out);
+void vxh_binner_destroy(vxh_binner *binner);
+/* shape(): bins+3 / N+2 / N+3 — src/binners.cpp:59, binner_ordinal.cpp:178 */
+uint64_t vxh_binner_shape(const vxh_binner *binner);
+/* set_data(thread, ar): n elements of the binner's dtype — src/binners.cpp:60-70 */
+int vxh_binner_set_data(vxh_binner *binner, int thread, const void *data, uint64_t n, int mem);
+/* set_data_mask(thread, ar): uint8, 1 = masked (numpy convention) — src/binners.cpp:75-82, :26 */
+int vxh_binner_set_data_mask(vxh_binner *binner, int thread, const uint8_t *mask, uint64_t n, int mem);
+/* clear_data_mask(thread) — src/binners.cpp:71-74 */
+int vxh_binner_clear_data_mask(vxh_binner *binner, int thread);
+/* data_length(thread) — src/binners.cpp:58 */
+uint64_t vxh_binner_data_length(const vxh_binner *binner, int thread);
+
+/* ---- grid ---------------------------------------------------------------------------- */
+/* Grid(binners): shapes, strides (dim 0 stride 1), length1d — src/agg.hpp:57-74.
+ * The grid keeps the binner handles (not copies); they must outlive it. */
+int vxh_grid_create(vxh_binner *const *binners, int dimensions, vxh_grid **out);
+void vxh_grid_destroy(vxh_grid *grid);
+uint64_t vxh_grid_length1d(const vxh_grid *grid);
+int vxh_grid_dimensions(const vxh_grid *grid);
+int vxh_grid_shapes(const vxh_grid *grid, uint64_t *shapes_out);
+int vxh_grid_strides(const vxh_grid *grid, uint64_t *strides_out);
+/* Grid::bin(thread, aggregators, length) — src/agg.hpp:84-137: for `length` rows compute the
+ * flat cell index from every binner's slot-`thread` data and feed every aggregator.  One
+ * fused kernel pass for all aggregators (they share the index, like the 1024-row
+ * indices1d block of the reference). */
+int vxh_grid_bin(vxh_grid *grid, int thread, vxh_agg *const *aggs, int n_aggs, uint64_t length);
+
+/* ---- aggregators --------------------------------------------------------------------- */
+/* Agg{Count,Sum,SumMoment,Min,Max}_<T>(grid, grids, threads[, moment]) —
+ * src/agg_count.cpp:201, agg_sum.cpp:218/:227, agg_minmax.cpp:146/:161.
+ * `grids` only sizes the host-visible buffer ((grids, *shapes), src/agg_base.hpp:106-125);
+ * on the device there is one logical grid plus internal replicas. */
+int vxh_agg_create(int kind, int dtype, int flip_endian, vxh_grid *grid, int grids, int threads, uint32_t moment, vxh_agg **out);
+void vxh_agg_destroy(vxh_agg *agg);
+/* set_data(thread, ar, index) — src/agg_base.hpp:166-179 (index is ignored there too) */
+int vxh_agg_set_data(vxh_agg *agg, int thread, const void *data, uint64_t n, int mem);
+/* set_data_mask(thread, ar): uint8, 1 = KEEP — src/agg_base.hpp:134-147, agg_count.cpp:50 */
+int vxh_agg_set_data_mask(vxh_agg *agg, int thread, const uint8_t *mask, uint64_t n, int mem);
+/* clear_data_mask(thread) — src/agg_base.hpp:148-151 */
+int vxh_agg_clear_data_mask(vxh_agg *agg, int thread);
+/* bytes_used() = sizeof(grid_type) * grids * length1d — src/agg_base.hpp:29 (vaex/agg.py:311-318 checks it) */
+size_t vxh_agg_bytes_used(const vxh_agg *agg);
+/* dtype of one grid cell as exposed to the host (int64 for count, upcast<T> for sums, T for min/max) */
+int vxh_agg_grid_dtype(const vxh_agg *agg);
+int vxh_agg_grids(const vxh_agg *agg);
+/* buffer protocol — src/agg_base.hpp:106-125: pointer to a host array of shape
+ * (grids, *shapes), dim-0-fastest strides.  Brings the host copy up to date (device result
+ * in grid 0, identity elsewhere); writes through the pointer are picked up by the next
+ * vxh_grid_bin (vaex/cpu.py:658 seeds initial values this way). */
+int vxh_agg_host_view(vxh_agg *agg, void **ptr_out);
+/* merge(others) — src/agg_count.cpp:15-23, agg_sum.cpp:72-79, agg_minmax.cpp:19-26 */
+int vxh_agg_merge(vxh_agg *agg, vxh_agg *const *others, int n_others);
+/* get_result(): fold and copy the length1d cells of the result into out (host) —
+ * src/agg_count.cpp:24-41, agg_sum.cpp:80-97, agg_minmax.cpp:27-43 */
+int vxh_agg_result(vxh_agg *agg, void *out);
+/* device pointer of the folded grid (length1d cells of the DEVICE cell type: int64 for count
+ * and integer sums, double for float sums; min/max of <4-byte types are widened to 4 bytes)
+ * — for an in-place RCCL all-reduce across ranks; call vxh_agg_device_touch afterwards. */
+int vxh_agg_device_grid(vxh_agg *agg, void **dev_ptr_out, int *device_dtype_out);
+int vxh_agg_device_touch(vxh_agg *agg);
+/* reset to the initial fill (initial_fill — src/agg_count.cpp:11, agg_minmax.cpp:13-18) */
+int vxh_agg_reset(vxh_agg *agg);
+
+/* ---- hash map (group keys -> dense ordinals) ----------------------------------------- */
+/* ordered_set<T>: src/hash_primitives.hpp:436-730 (update :98-295, add_new :471-479,
+ * map_ordinal :611-691, key_array :303-328).  GPU open-addressing table, splitmix64 hash
+ * (src/hash.hpp:40-45).  Ordinals are dense 0..count-1 in (nondeterministic) insertion order;
+ * parity with the reference is per key.  dtype: any integer dtype (keys widened to int64). */
+int vxh_hashmap_create(int dtype, uint64_t capacity_hint, vxh_hashmap **out);
+void vxh_hashmap_destroy(vxh_hashmap *map);
+/* update(keys): insert unseen keys (mask: 1 = null, counted once as the null ordinal) */
+int vxh_hashmap_update(vxh_hashmap *map, const void *keys, const uint8_t *mask, uint64_t n, int mem);
+/* number of distinct keys (excluding null) — size() */
+int vxh_hashmap_count(vxh_hashmap *map, int64_t *count_out);
+/* whether a null was seen, and its ordinal (= count) — null_index() src/hash.hpp:337-353 */
+int vxh_hashmap_null_index(vxh_hashmap *map, int64_t *index_out);
+/* map_ordinal(keys): int64 ordinals, -1 for unknown keys; out lives where `mem` says */
+int vxh_hashmap_map_ordinal(vxh_hashmap *map, const void *keys, uint64_t n, int mem, int64_t *out);
+/* key_array(): the distinct keys ordered by ordinal, as int64, into host memory */
+int vxh_hashmap_keys(vxh_hashmap *map, int64_t *keys_out);
+
+/* ---- legacy fused statistic (vaexfast.statisticNd) ------------------------------------ */
+/* OP_MIN_MAX on a 0-d grid — src/vaexfast.cpp:1090-1101, :1198-1203 (used by df.minmax /
+ * limits=None, vaex/dataframe.py:1520): out2 = {min, max} over non-NaN values (and, with
+ * mask, rows whose mask byte is 1); {+inf, -inf} when empty.  Any dtype, computed in double. */
+int vxh_minmax(int dtype, int flip_endian, const void *data, const uint8_t *mask, uint64_t n, int mem, double *out2);
+
+/* ---- profiling helpers ---------------------------------------------------------------- */
+/* HIP events on slot `thread`'s stream: record start/stop around vxh_grid_bin calls, read ms */
+int vxh_timer_start(int thread);
+int vxh_timer_stop(int thread, float *elapsed_ms_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VAEX_HIP_H */

@@ -1,0 +1,79 @@
+#!/usr/bin/env bash
+# TEST INFRASTRUCTURE — builds the reference's own native code, in place, as the parity oracle.
+#
+# Compiles vaex-core's superagg / superutils / vaexfast (+ superstrings for `import vaex`)
+# straight from /root/reference/packages/vaex-core/src (nothing is copied into this repo)
+# with g++ and the reference's own flags (-std=c++17 -O3 -funroll-loops -DVAEX_USE_TSL,
+# packages/vaex-core/setup.py:101-123), against the shim headers in oracle/shim that stand
+# in for the un-vendored git submodules (string-view-lite, hopscotch-map, pcre).
+#
+# Outputs ONLY into oracle/_ref/ (git-ignored, travels to the GPU box with gpurun):
+#   oracle/_ref/superagg<ext>.so  superutils<ext>.so  vaexfast<ext>.so  superstrings<ext>.so
+#   oracle/_ref/overlay/          symlink overlay of the reference's pure-Python package
+#                                 (needed only HERE by oracle/make_goldens.py; gpurun-ignored)
+#
+# Usage: oracle/build_ref.sh [--minimal]   (--minimal: superagg only)
+set -euo pipefail
+HERE="$(cd "$(dirname "$0")" && pwd)"
+REF=/root/reference/packages/vaex-core
+SRC=$REF/src
+OUT=$HERE/_ref
+OBJ=$OUT/obj
+if [ ! -d "$SRC" ]; then
+    echo "build_ref: $SRC not present (GPU box?) - using prebuilt files in $OUT if any"; exit 0
+fi
+mkdir -p "$OBJ"
+PYINC=$(python3 -c 'import sysconfig;print(sysconfig.get_paths()["include"])')
+NPINC=$(python3 -c 'import numpy;print(numpy.get_include())')
+PBINC=$(python3 -c 'import pybind11;print(pybind11.get_include())')
+EXT=$(python3 -c 'import sysconfig;print(sysconfig.get_config_var("EXT_SUFFIX"))')
+CXX="g++ -std=c++17 -O3 -funroll-loops -fPIC -w -DVAEX_USE_TSL -DNPY_NO_DEPRECATED_API=NPY_1_7_API_VERSION -I$HERE/shim -I$PYINC -I$NPINC -I$PBINC"
+
+compile() { # $1 = source path, $2 = object name; skipped when up to date
+    if [ ! -f "$OBJ/$2.o" ] || [ "$1" -nt "$OBJ/$2.o" ]; then
+        $CXX ${3:-} -c "$1" -o "$OBJ/$2.o"
+    fi
+}
+
+AGG="agg agg_count agg_sum agg_minmax agg_first agg_list agg_nunique binners binner_ordinal binner_combined binner_hash string_utils"
+pids=()
+for f in $AGG; do compile $SRC/$f.cpp $f & pids+=($!); done
+compile $HERE/stubs/stub_superagg.cpp stub_superagg & pids+=($!)
+if [ "${1:-}" != "--minimal" ]; then
+    compile $SRC/superutils.cpp superutils & pids+=($!)
+    compile $SRC/hash_primitives_pot.cpp hash_primitives_pot & pids+=($!)
+    compile $HERE/stubs/stub_superutils.cpp stub_superutils & pids+=($!)
+    compile $SRC/strings.cpp strings "-I$REF/vendor/boost" & pids+=($!)
+fi
+for p in "${pids[@]}"; do wait $p; done
+
+g++ -shared -o $OUT/superagg$EXT $(for f in $AGG stub_superagg; do echo $OBJ/$f.o; done)
+if [ "${1:-}" != "--minimal" ]; then
+    g++ -shared -o $OUT/superutils$EXT $OBJ/superutils.o $OBJ/hash_primitives_pot.o $OBJ/string_utils.o $OBJ/stub_superutils.o
+    g++ -shared -o $OUT/superstrings$EXT $OBJ/strings.o $OBJ/string_utils.o
+    if [ ! -f $OUT/vaexfast$EXT ] || [ $SRC/vaexfast.cpp -nt $OUT/vaexfast$EXT ]; then
+        $CXX -shared $SRC/vaexfast.cpp -o $OUT/vaexfast$EXT
+    fi
+    # pure-Python overlay (symlinks into /root/reference; never committed, never shipped)
+    rm -rf $OUT/overlay
+    mkdir -p $OUT/overlay
+    cp -rs $REF/vaex $OUT/overlay/vaex
+    for m in superagg superutils superstrings vaexfast; do ln -sf $OUT/$m$EXT $OUT/overlay/vaex/$m$EXT; done
+    DI=$OUT/overlay/vaex_core-4.19.0.dist-info
+    mkdir -p $DI
+    printf 'Metadata-Version: 2.1\nName: vaex-core\nVersion: 4.19.0\n' > $DI/METADATA
+    cat > $DI/entry_points.txt <<'EOF'
+[vaex.memory.tracker]
+default = vaex.memory:MemoryTracker
+
+[vaex.progressbar]
+vaex = vaex.progress:simple
+simple = vaex.progress:simple
+widget = vaex.progress:widget
+rich = vaex.progress:rich
+
+[vaex.dataframe.accessor]
+struct = vaex.struct:DataFrameAccessorStruct
+EOF
+fi
+echo "build_ref: done -> $OUT"

@@ -1,0 +1,501 @@
+// pybind11 shim: re-exposes the C-ABI of libvaexhip.so (include/vaex_hip.h) as the Python class
+// surface of the reference's native module `vaex.superagg`
+// (/root/reference/packages/vaex-core/src/agg.cpp:91-118, binners.cpp:92-146,
+// binner_ordinal.cpp:205-253, agg_base.hpp:249-261, agg_sum.cpp:213-230), so vaex's unmodified
+// Python (vaex/cpu.py:44-65, :630-845; vaex/agg.py:278-335) can drive the HIP kernels:
+//
+//     Grid, Binner, Aggregator,
+//     BinnerScalar_<T>[_non_native], BinnerOrdinal_<T>[_non_native], BinnerHash_<T>,
+//     AggCount_<T>, AggSum_<T>, AggSumMoment_<T>, AggMin_<T>, AggMax_<T>   [_non_native]
+//     ordered_set_<T>  (the subset of vaex.superutils the groupby path uses)
+//
+// for T in float64 float32 int64 int32 int16 int8 uint64 uint32 uint16 uint8 bool.
+// No computation happens here: every method forwards to one extern "C" entry point.  Extension over
+// the reference: set_data / set_data_mask also accept objects exposing __cuda_array_interface__
+// (e.g. torch tensors on the GPU) — HBM-resident columns are then used in place.
+#include <pybind11/numpy.h>
+#include <pybind11/pybind11.h>
+#include <pybind11/stl.h>
+
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "vaex_hip.h"
+
+namespace py = pybind11;
+
+namespace {
+
+const char *kTypeNames[VXH_DTYPE_COUNT] = {"float64", "float32", "int64", "int32", "int16", "int8", "uint64", "uint32", "uint16", "uint8", "bool"};
+const int kTypeSizes[VXH_DTYPE_COUNT] = {8, 4, 8, 4, 2, 1, 8, 4, 2, 1, 1};
+const char *kNumpyFormats[VXH_DTYPE_COUNT] = {"d", "f", "q", "i", "h", "b", "Q", "I", "H", "B", "?"};
+
+void check(int rc) {
+    if (rc != 0) throw std::runtime_error(vxh_last_error());
+}
+
+// a borrowed 1-d array: host buffer or device array
+struct ArrayRef {
+    const void *ptr = nullptr;
+    uint64_t n = 0;
+    int mem = VXH_MEM_HOST;
+    ssize_t itemsize = 0;
+};
+
+ArrayRef resolve_array(const py::object &obj) {
+    ArrayRef r;
+    if (py::hasattr(obj, "__cuda_array_interface__")) {
+        py::dict cai = obj.attr("__cuda_array_interface__");
+        py::tuple shape = cai["shape"];
+        if (shape.size() != 1) throw std::runtime_error("Expected a 1d array");
+        py::tuple data = cai["data"];
+        std::string typestr = py::str(cai["typestr"]);
+        r.itemsize = std::stoi(typestr.substr(2));
+        r.n = shape[0].cast<uint64_t>();
+        if (cai.contains("strides") && !cai["strides"].is_none()) {
+            py::tuple strides = cai["strides"];
+            if (strides.size() != 1 || (r.n > 1 && strides[0].cast<ssize_t>() != r.itemsize)) throw std::runtime_error("Expected a contiguous array");
+        }
+        r.ptr = reinterpret_cast<const void *>(data[0].cast<uintptr_t>());
+        r.mem = VXH_MEM_DEVICE;
+        return r;
+    }
+    py::buffer buf = py::reinterpret_borrow<py::buffer>(obj);
+    py::buffer_info info = buf.request();
+    if (info.ndim != 1) throw std::runtime_error("Expected a 1d array");
+    if (info.shape[0] > 1 && info.strides[0] != info.itemsize) throw std::runtime_error("Expected a contiguous array");
+    r.ptr = info.ptr;
+    r.n = (uint64_t)info.shape[0];
+    r.itemsize = info.itemsize;
+    r.mem = VXH_MEM_HOST;
+    return r;
+}
+
+// ------------------------------------------------------------------------------------------
+// hash map
+// ------------------------------------------------------------------------------------------
+struct PyHashMap {
+    vxh_hashmap *h = nullptr;
+    int dtype;
+    PyHashMap(int dtype, uint64_t hint) : dtype(dtype) { check(vxh_hashmap_create(dtype, hint, &h)); }
+    virtual ~PyHashMap() { vxh_hashmap_destroy(h); }
+    PyHashMap(const PyHashMap &) = delete;
+
+    void update(const py::object &keys, const py::object &mask) {
+        ArrayRef k = resolve_array(keys);
+        if (k.itemsize != kTypeSizes[dtype]) throw std::runtime_error("Itemsize of data and hash map are not equal");
+        const uint8_t *mp = nullptr;
+        if (!mask.is_none()) {
+            ArrayRef m = resolve_array(mask);
+            if (m.mem != k.mem || m.n < k.n) throw std::runtime_error("mask must live where the keys live and be as long");
+            mp = (const uint8_t *)m.ptr;
+        }
+        int rc;
+        {
+            py::gil_scoped_release release;
+            rc = vxh_hashmap_update(h, k.ptr, mp, k.n, k.mem);
+        }
+        check(rc);
+    }
+    int64_t count() {
+        int64_t c;
+        check(vxh_hashmap_count(h, &c));
+        return c;
+    }
+    int64_t null_index() {
+        int64_t c;
+        check(vxh_hashmap_null_index(h, &c));
+        return c;
+    }
+    py::array_t<int64_t> map_ordinal(const py::object &keys) {
+        ArrayRef k = resolve_array(keys);
+        if (k.mem != VXH_MEM_HOST) throw std::runtime_error("map_ordinal: host arrays only (use BinnerHash for device-resident keys)");
+        if (k.itemsize != kTypeSizes[dtype]) throw std::runtime_error("Itemsize of data and hash map are not equal");
+        py::array_t<int64_t> out((ssize_t)k.n);
+        int rc;
+        {
+            py::gil_scoped_release release;
+            rc = vxh_hashmap_map_ordinal(h, k.ptr, k.n, VXH_MEM_HOST, out.mutable_data());
+        }
+        check(rc);
+        return out;
+    }
+    py::array_t<int64_t> key_array() {
+        py::array_t<int64_t> out((ssize_t)count());
+        check(vxh_hashmap_keys(h, out.mutable_data()));
+        return out;
+    }
+};
+template <int DT>
+struct THashMap : PyHashMap {
+    explicit THashMap(uint64_t hint) : PyHashMap(DT, hint) {}
+};
+
+// ------------------------------------------------------------------------------------------
+// binners
+// ------------------------------------------------------------------------------------------
+struct PyBinner {
+    vxh_binner *h = nullptr;
+    int dtype = 0;
+    bool flip = false;
+    int threads = 1;
+    std::string expression;
+    virtual ~PyBinner() { vxh_binner_destroy(h); }
+    PyBinner() = default;
+    PyBinner(const PyBinner &o) : dtype(o.dtype), flip(o.flip), threads(o.threads), expression(o.expression) { check(vxh_binner_copy(o.h, &h)); }
+
+    void set_data(int thread, const py::object &ar) {
+        ArrayRef a = resolve_array(ar);
+        if (a.itemsize != kTypeSizes[dtype]) throw std::runtime_error("Itemsize of data and binner are not equal");
+        check(vxh_binner_set_data(h, thread, a.ptr, a.n, a.mem));
+    }
+    void set_data_mask(int thread, const py::object &ar) {
+        ArrayRef a = resolve_array(ar);
+        check(vxh_binner_set_data_mask(h, thread, (const uint8_t *)a.ptr, a.n, a.mem));
+    }
+    void clear_data_mask(int thread) { check(vxh_binner_clear_data_mask(h, thread)); }
+    uint64_t shape() const { return vxh_binner_shape(h); }
+};
+
+struct PyBinnerScalar : PyBinner {
+    double vmin, vmax;
+    uint64_t bins;
+    PyBinnerScalar(int dt, bool fl, int threads_, std::string expr, double vmin, double vmax, uint64_t bins) : vmin(vmin), vmax(vmax), bins(bins) {
+        dtype = dt; flip = fl; threads = threads_; expression = std::move(expr);
+        check(vxh_binner_scalar_create(threads, dt, fl, vmin, vmax, bins, &h));
+    }
+};
+template <int DT, bool FLIP>
+struct TBinnerScalar : PyBinnerScalar {
+    TBinnerScalar(int threads, std::string expr, double vmin, double vmax, uint64_t bins) : PyBinnerScalar(DT, FLIP, threads, std::move(expr), vmin, vmax, bins) {}
+};
+
+struct PyBinnerOrdinal : PyBinner {
+    int64_t ordinal_count, min_value;
+    bool allow_other, invert;
+    PyBinnerOrdinal(int dt, bool fl, int threads_, std::string expr, int64_t ordinal_count, int64_t min_value, bool allow_other, bool invert)
+        : ordinal_count(ordinal_count), min_value(min_value), allow_other(allow_other), invert(invert) {
+        dtype = dt; flip = fl; threads = threads_; expression = std::move(expr);
+        check(vxh_binner_ordinal_create(threads, dt, fl, ordinal_count, min_value, allow_other, invert, &h));
+    }
+};
+template <int DT, bool FLIP>
+struct TBinnerOrdinal : PyBinnerOrdinal {
+    TBinnerOrdinal(int threads, std::string expr, int64_t ordinal_count, int64_t min_value, bool allow_other, bool invert)
+        : PyBinnerOrdinal(DT, FLIP, threads, std::move(expr), ordinal_count, min_value, allow_other, invert) {}
+};
+
+struct PyBinnerHash : PyBinner {
+    py::object map_ref; // keeps the map alive
+    PyBinnerHash(int dt, int threads_, std::string expr, py::object map) : map_ref(std::move(map)) {
+        dtype = dt; threads = threads_; expression = std::move(expr);
+        PyHashMap &m = map_ref.cast<PyHashMap &>();
+        check(vxh_binner_hash_create(threads, dt, m.h, &h));
+    }
+};
+template <int DT>
+struct TBinnerHash : PyBinnerHash {
+    TBinnerHash(int threads, std::string expr, py::object map) : PyBinnerHash(DT, threads, std::move(expr), std::move(map)) {}
+};
+
+// ------------------------------------------------------------------------------------------
+// grid
+// ------------------------------------------------------------------------------------------
+struct PyAgg;
+struct PyGrid {
+    vxh_grid *h = nullptr;
+    std::vector<PyBinner *> binners;
+    explicit PyGrid(std::vector<PyBinner *> binners_) : binners(std::move(binners_)) {
+        std::vector<vxh_binner *> hs;
+        for (auto *b : binners) hs.push_back(b->h);
+        check(vxh_grid_create(hs.data(), (int)hs.size(), &h));
+    }
+    ~PyGrid() { vxh_grid_destroy(h); }
+    PyGrid(const PyGrid &) = delete;
+    std::vector<uint64_t> shapes() const {
+        std::vector<uint64_t> s(binners.size());
+        vxh_grid_shapes(h, s.data());
+        return s;
+    }
+    std::vector<uint64_t> strides() const {
+        std::vector<uint64_t> s(binners.size());
+        vxh_grid_strides(h, s.data());
+        return s;
+    }
+    void bin(int thread, const std::vector<PyAgg *> &aggs, uint64_t length);
+    void bin_all(int thread, const std::vector<PyAgg *> &aggs) {
+        if (binners.empty()) throw std::runtime_error("no binners set and no length given"); // src/agg.hpp:78
+        bin(thread, aggs, vxh_binner_data_length(binners[0]->h, thread));
+    }
+};
+
+// ------------------------------------------------------------------------------------------
+// aggregators
+// ------------------------------------------------------------------------------------------
+struct PyAgg {
+    vxh_agg *h = nullptr;
+    PyGrid *grid;
+    int kind, dtype;
+    PyAgg(int kind, int dtype, bool flip, PyGrid *grid, int grids, int threads, uint32_t moment) : grid(grid), kind(kind), dtype(dtype) {
+        check(vxh_agg_create(kind, dtype, flip, grid->h, grids, threads, moment, &h));
+    }
+    virtual ~PyAgg() { vxh_agg_destroy(h); }
+    PyAgg(const PyAgg &) = delete;
+
+    void set_data(int thread, const py::object &ar, size_t /*index*/) {
+        ArrayRef a = resolve_array(ar);
+        if (a.itemsize != kTypeSizes[dtype]) throw std::runtime_error("Itemsize of data and aggregator are not equal");
+        check(vxh_agg_set_data(h, thread, a.ptr, a.n, a.mem));
+    }
+    void set_data_mask(int thread, const py::object &ar) {
+        ArrayRef a = resolve_array(ar);
+        check(vxh_agg_set_data_mask(h, thread, (const uint8_t *)a.ptr, a.n, a.mem));
+    }
+    void clear_data_mask(int thread) { check(vxh_agg_clear_data_mask(h, thread)); }
+    size_t bytes_used() const { return vxh_agg_bytes_used(h); }
+
+    void merge(const std::vector<PyAgg *> &others) {
+        std::vector<vxh_agg *> hs;
+        for (auto *o : others) hs.push_back(o->h);
+        int rc;
+        {
+            py::gil_scoped_release release;
+            rc = vxh_agg_merge(h, hs.data(), (int)hs.size());
+        }
+        check(rc);
+    }
+
+    // fresh ndarray of `shapes`, dim 0 fastest (= numpy.array(self)[0] of the reference, src/agg_count.cpp:38-40)
+    py::array get_result() {
+        const int gdt = vxh_agg_grid_dtype(h);
+        const ssize_t isz = kTypeSizes[gdt];
+        std::vector<uint64_t> shp = grid->shapes(), str = grid->strides();
+        std::vector<ssize_t> shape(shp.begin(), shp.end()), strides;
+        for (auto s : str) strides.push_back((ssize_t)s * isz);
+        const std::string fmt = kNumpyFormats[gdt];
+        py::dtype np_dtype{fmt};
+        py::array out(np_dtype, shape, strides);
+        int rc;
+        {
+            py::gil_scoped_release release;
+            rc = vxh_agg_result(h, out.mutable_data());
+        }
+        check(rc);
+        return out;
+    }
+
+    // buffer protocol: (grids, *shapes), src/agg_base.hpp:106-125
+    py::buffer_info buffer() {
+        void *ptr = nullptr;
+        check(vxh_agg_host_view(h, &ptr));
+        const int gdt = vxh_agg_grid_dtype(h);
+        const ssize_t isz = kTypeSizes[gdt];
+        std::vector<uint64_t> shp = grid->shapes(), str = grid->strides();
+        const size_t nd = shp.size();
+        std::vector<ssize_t> shapes(nd + 1), strides(nd + 1);
+        shapes[0] = vxh_agg_grids(h);
+        for (size_t i = 0; i < nd; i++) {
+            shapes[i + 1] = (ssize_t)shp[i];
+            strides[i + 1] = (ssize_t)str[i] * isz;
+        }
+        strides[0] = nd ? strides[1] * shapes[1] : isz;
+        if (nd) strides[0] = (ssize_t)vxh_grid_length1d(grid->h) * isz;
+        return py::buffer_info(ptr, isz, kNumpyFormats[gdt], (ssize_t)nd + 1, shapes, strides);
+    }
+
+    // device pointer of the folded grid as an object with __cuda_array_interface__ (for RCCL all-reduce)
+    py::dict device_grid_interface() {
+        void *dptr = nullptr;
+        int ddt = 0;
+        check(vxh_agg_device_grid(h, &dptr, &ddt));
+        static const char *typestr[VXH_DTYPE_COUNT] = {"<f8", "<f4", "<i8", "<i4", "<i2", "|i1", "<u8", "<u4", "<u2", "|u1", "|b1"};
+        py::dict d;
+        d["shape"] = py::make_tuple((uint64_t)vxh_grid_length1d(grid->h));
+        d["typestr"] = typestr[ddt];
+        d["data"] = py::make_tuple((uintptr_t)dptr, false);
+        d["version"] = 3;
+        d["strides"] = py::none();
+        return d;
+    }
+    void device_touch() { check(vxh_agg_device_touch(h)); }
+    void reset() { check(vxh_agg_reset(h)); }
+};
+
+void PyGrid::bin(int thread, const std::vector<PyAgg *> &aggs, uint64_t length) {
+    std::vector<vxh_agg *> hs;
+    for (auto *a : aggs) hs.push_back(a->h);
+    int rc;
+    {
+        py::gil_scoped_release release; // src/agg.hpp:94-99
+        rc = vxh_grid_bin(h, thread, hs.data(), (int)hs.size(), length);
+    }
+    check(rc);
+}
+
+template <int KIND, int DT, bool FLIP>
+struct TAgg : PyAgg {
+    TAgg(PyGrid *grid, int grids, int threads) : PyAgg(KIND, DT, FLIP, grid, grids, threads, 0) {}
+    TAgg(PyGrid *grid, int grids, int threads, uint32_t moment) : PyAgg(KIND, DT, FLIP, grid, grids, threads, moment) {}
+};
+
+// ------------------------------------------------------------------------------------------
+// registration
+// ------------------------------------------------------------------------------------------
+template <int DT, bool FLIP>
+void add_binners(py::module &m, py::class_<PyBinnerScalar, PyBinner> &scalar_base, py::class_<PyBinnerOrdinal, PyBinner> &ordinal_base) {
+    const std::string postfix = std::string(kTypeNames[DT]) + (FLIP ? "_non_native" : "");
+    {
+        using T = TBinnerScalar<DT, FLIP>;
+        py::class_<T, PyBinnerScalar>(m, ("BinnerScalar_" + postfix).c_str())
+            .def(py::init<int, std::string, double, double, uint64_t>())
+            .def("copy", [](const T &b) { return new T(b); })
+            .def(py::pickle([](const T &b) { return py::make_tuple(b.threads, b.expression, b.vmin, b.vmax, b.bins); },
+                            [](py::tuple t) {
+                                if (t.size() != 5) throw std::runtime_error("Invalid state!");
+                                return new T(t[0].cast<int>(), t[1].cast<std::string>(), t[2].cast<double>(), t[3].cast<double>(), t[4].cast<uint64_t>());
+                            }));
+    }
+    {
+        using T = TBinnerOrdinal<DT, FLIP>;
+        py::class_<T, PyBinnerOrdinal>(m, ("BinnerOrdinal_" + postfix).c_str())
+            .def(py::init<int, std::string, int64_t, int64_t, bool, bool>(), py::arg("threads"), py::arg("expression"), py::arg("ordinal_count"), py::arg("min_value") = 0, py::arg("allow_other") = false,
+                 py::arg("invert") = false)
+            .def("copy", [](const T &b) { return new T(b); })
+            .def(py::pickle([](const T &b) { return py::make_tuple(b.threads, b.expression, b.ordinal_count, b.min_value, b.allow_other, b.invert); },
+                            [](py::tuple t) {
+                                if (t.size() != 6) throw std::runtime_error("Invalid state!");
+                                return new T(t[0].cast<int>(), t[1].cast<std::string>(), t[2].cast<int64_t>(), t[3].cast<int64_t>(), t[4].cast<bool>(), t[5].cast<bool>());
+                            }));
+    }
+}
+
+template <int DT, bool FLIP>
+void add_aggs(py::module &m, py::class_<PyAgg> &base) {
+    const std::string postfix = std::string(kTypeNames[DT]) + (FLIP ? "_non_native" : "");
+#define VXH_AGG3(KIND, NAME)                                                                                           \
+    py::class_<TAgg<KIND, DT, FLIP>, PyAgg>(m, (std::string(NAME) + postfix).c_str(), py::buffer_protocol())           \
+        .def(py::init<PyGrid *, int, int>(), py::keep_alive<1, 2>())                                                   \
+        .def_buffer([](TAgg<KIND, DT, FLIP> &a) { return a.buffer(); });
+    VXH_AGG3(VXH_AGG_COUNT, "AggCount_")
+    VXH_AGG3(VXH_AGG_SUM, "AggSum_")
+    VXH_AGG3(VXH_AGG_MIN, "AggMin_")
+    VXH_AGG3(VXH_AGG_MAX, "AggMax_")
+#undef VXH_AGG3
+    py::class_<TAgg<VXH_AGG_SUM_MOMENT, DT, FLIP>, PyAgg>(m, ("AggSumMoment_" + postfix).c_str(), py::buffer_protocol())
+        .def(py::init<PyGrid *, int, int, uint32_t>(), py::keep_alive<1, 2>())
+        .def_buffer([](TAgg<VXH_AGG_SUM_MOMENT, DT, FLIP> &a) { return a.buffer(); });
+}
+
+template <int DT>
+void add_hash(py::module &m, py::class_<PyHashMap> &map_base, py::class_<PyBinnerHash, PyBinner> &binner_base) {
+    py::class_<THashMap<DT>, PyHashMap>(m, (std::string("ordered_set_") + kTypeNames[DT]).c_str()).def(py::init<uint64_t>(), py::arg("capacity_hint") = 0);
+    py::class_<TBinnerHash<DT>, PyBinnerHash>(m, (std::string("BinnerHash_") + kTypeNames[DT]).c_str()).def(py::init<int, std::string, py::object>());
+}
+
+template <int DT>
+void add_type(py::module &m, py::class_<PyBinnerScalar, PyBinner> &sb, py::class_<PyBinnerOrdinal, PyBinner> &ob, py::class_<PyAgg> &ab) {
+    add_binners<DT, false>(m, sb, ob);
+    add_binners<DT, true>(m, sb, ob);
+    add_aggs<DT, false>(m, ab);
+    add_aggs<DT, true>(m, ab);
+}
+
+} // namespace
+
+PYBIND11_MODULE(superagg, m) {
+    m.doc() = "MI355X (HIP) implementation of the vaex.superagg class surface: binned statistics / groupby aggregation";
+    m.attr("__hip__") = true;
+    m.def("abi_version", &vxh_abi_version);
+    m.def("device_count", []() { int n = 0; check(vxh_device_count(&n)); return n; });
+    m.def("set_device", [](int d) { check(vxh_set_device(d)); });
+    m.def("synchronize", []() { py::gil_scoped_release r; check(vxh_synchronize()); });
+    m.def("config_set", [](const std::string &k, int64_t v) { check(vxh_config_set(k.c_str(), v)); });
+    m.def("config_get", [](const std::string &k) { int64_t v = 0; check(vxh_config_get(k.c_str(), &v)); return v; });
+    m.def("last_kernel", [](int thread) { return std::string(vxh_last_kernel(thread)); }, py::arg("thread") = 0);
+    m.def("slot_set_stream", [](int thread, uintptr_t stream) { check(vxh_slot_set_stream(thread, (void *)stream)); });
+    m.def("timer_start", [](int thread) { check(vxh_timer_start(thread)); }, py::arg("thread") = 0);
+    m.def("timer_stop", [](int thread) { float ms = 0; { py::gil_scoped_release r; check(vxh_timer_stop(thread, &ms)); } return ms; }, py::arg("thread") = 0);
+    m.def("minmax", [](const py::object &ar, const py::object &mask, int dtype, bool flip) {
+        ArrayRef a = resolve_array(ar);
+        if (a.itemsize != kTypeSizes[dtype]) throw std::runtime_error("Itemsize of data and dtype are not equal");
+        const uint8_t *mp = nullptr;
+        if (!mask.is_none()) { ArrayRef mk = resolve_array(mask); mp = (const uint8_t *)mk.ptr; }
+        double out[2];
+        int rc;
+        { py::gil_scoped_release r; rc = vxh_minmax(dtype, flip, a.ptr, mp, a.n, a.mem, out); }
+        check(rc);
+        return py::make_tuple(out[0], out[1]);
+    }, py::arg("data"), py::arg("mask") = py::none(), py::arg("dtype") = 0, py::arg("flip") = false);
+
+    py::class_<PyAgg> aggregator(m, "Aggregator", py::buffer_protocol());
+    aggregator.def("merge", &PyAgg::merge)
+        .def("get_result", &PyAgg::get_result)
+        .def("__sizeof__", &PyAgg::bytes_used)
+        .def("set_data", &PyAgg::set_data, py::arg("thread"), py::arg("ar"), py::arg("index") = 0)
+        .def("clear_data_mask", &PyAgg::clear_data_mask)
+        .def("set_data_mask", &PyAgg::set_data_mask)
+        .def("device_touch", &PyAgg::device_touch)
+        .def("reset", &PyAgg::reset)
+        .def_property_readonly("__cuda_array_interface__", &PyAgg::device_grid_interface)
+        .def_property_readonly("grid", [](const PyAgg &a) { return a.grid; }, py::return_value_policy::reference);
+
+    py::class_<PyBinner> binner(m, "Binner");
+    binner.def("set_data", &PyBinner::set_data)
+        .def("clear_data_mask", &PyBinner::clear_data_mask)
+        .def("set_data_mask", &PyBinner::set_data_mask)
+        .def("__len__", &PyBinner::shape)
+        .def_property_readonly("expression", [](const PyBinner &b) { return b.expression; });
+
+    py::class_<PyBinnerScalar, PyBinner> scalar_base(m, "BinnerScalar");
+    scalar_base.def_property_readonly("bins", [](const PyBinnerScalar &b) { return b.bins; })
+        .def_property_readonly("vmin", [](const PyBinnerScalar &b) { return b.vmin; })
+        .def_property_readonly("vmax", [](const PyBinnerScalar &b) { return b.vmax; });
+    py::class_<PyBinnerOrdinal, PyBinner> ordinal_base(m, "BinnerOrdinal");
+    ordinal_base.def_property_readonly("ordinal_count", [](const PyBinnerOrdinal &b) { return b.ordinal_count; })
+        .def_property_readonly("min_value", [](const PyBinnerOrdinal &b) { return b.min_value; })
+        .def_property_readonly("allow_other", [](const PyBinnerOrdinal &b) { return b.allow_other; })
+        .def_property_readonly("invert", [](const PyBinnerOrdinal &b) { return b.invert; });
+    py::class_<PyBinnerHash, PyBinner> hash_base(m, "BinnerHash");
+    hash_base.def_property_readonly("hash_bins", [](const PyBinnerHash &b) { return (int64_t)b.shape() - 2; });
+
+    py::class_<PyGrid>(m, "Grid")
+        .def(py::init<std::vector<PyBinner *>>(), py::keep_alive<1, 2>())
+        .def("bin", &PyGrid::bin)
+        .def("bin", &PyGrid::bin_all)
+        .def("__len__", [](const PyGrid &g) { return vxh_grid_length1d(g.h); })
+        .def_property_readonly("binners", [](const PyGrid &g) { return g.binners; }, py::return_value_policy::reference)
+        .def_property_readonly("shapes", &PyGrid::shapes)
+        .def_property_readonly("strides", &PyGrid::strides);
+
+    py::class_<PyHashMap> hashmap(m, "ordered_set");
+    hashmap.def("update", &PyHashMap::update, py::arg("keys"), py::arg("mask") = py::none())
+        .def("map_ordinal", &PyHashMap::map_ordinal)
+        .def("key_array", &PyHashMap::key_array)
+        .def("__len__", &PyHashMap::count)
+        .def_property_readonly("null_index", &PyHashMap::null_index)
+        .def_property_readonly("has_null", [](PyHashMap &h) { return h.null_index() >= 0; });
+
+    add_type<VXH_F64>(m, scalar_base, ordinal_base, aggregator);
+    add_type<VXH_F32>(m, scalar_base, ordinal_base, aggregator);
+    add_type<VXH_I64>(m, scalar_base, ordinal_base, aggregator);
+    add_type<VXH_I32>(m, scalar_base, ordinal_base, aggregator);
+    add_type<VXH_I16>(m, scalar_base, ordinal_base, aggregator);
+    add_type<VXH_I8>(m, scalar_base, ordinal_base, aggregator);
+    add_type<VXH_U64>(m, scalar_base, ordinal_base, aggregator);
+    add_type<VXH_U32>(m, scalar_base, ordinal_base, aggregator);
+    add_type<VXH_U16>(m, scalar_base, ordinal_base, aggregator);
+    add_type<VXH_U8>(m, scalar_base, ordinal_base, aggregator);
+    add_type<VXH_BOOL>(m, scalar_base, ordinal_base, aggregator);
+
+    add_hash<VXH_I64>(m, hashmap, hash_base);
+    add_hash<VXH_I32>(m, hashmap, hash_base);
+    add_hash<VXH_I16>(m, hashmap, hash_base);
+    add_hash<VXH_I8>(m, hashmap, hash_base);
+    add_hash<VXH_U64>(m, hashmap, hash_base);
+    add_hash<VXH_U32>(m, hashmap, hash_base);
+    add_hash<VXH_U16>(m, hashmap, hash_base);
+    add_hash<VXH_U8>(m, hashmap, hash_base);
+    add_hash<VXH_BOOL>(m, hashmap, hash_base);
+}

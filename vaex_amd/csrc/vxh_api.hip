@@ -1,0 +1,938 @@
+// Host side of libvaexhip.so: the object model behind the C-ABI of include/vaex_hip.h
+// (binners / grid / aggregators with per-thread data slots, like src/agg.hpp + src/agg_base.hpp),
+// device-memory management for the aggregator grids, host-chunk staging, launch planning.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <map>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "vxh_internal.hpp"
+
+// ------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------
+static thread_local std::string g_last_error;
+
+void vxh_set_error(const std::string &msg) { g_last_error = msg; }
+
+#define VXH_API_BEGIN try {
+#define VXH_API_END                                                                                                    \
+    }                                                                                                                  \
+    catch (const std::exception &e) {                                                                                  \
+        g_last_error = e.what();                                                                                       \
+        return 1;                                                                                                      \
+    }                                                                                                                  \
+    catch (...) {                                                                                                      \
+        g_last_error = "unknown error";                                                                                \
+        return 1;                                                                                                      \
+    }                                                                                                                  \
+    return 0;
+
+void vxh_hip_check(hipError_t e, const char *what, const char *file, int line) {
+    if (e != hipSuccess) {
+        char buf[512];
+        snprintf(buf, sizeof buf, "HIP error %d (%s) in %s at %s:%d", (int)e, hipGetErrorString(e), what, file, line);
+        throw std::runtime_error(buf);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// device context: one per process (one process per GPU)
+// ------------------------------------------------------------------------------------------
+Context &ctx() {
+    static Context c;
+    return c;
+}
+
+static void ensure_device_ready() {
+    Context &c = ctx();
+    std::lock_guard<std::mutex> lock(c.mutex);
+    if (c.initialised) return;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count == 0) {
+        (void)hipGetLastError();
+        throw std::runtime_error("vaex_hip: no HIP device available (libvaexhip has no CPU fallback)");
+    }
+    HIP_CHECK(hipSetDevice(c.device));
+    hipDeviceProp_t prop;
+    HIP_CHECK(hipGetDeviceProperties(&prop, c.device));
+    c.cus = prop.multiProcessorCount;
+    c.max_lds = prop.sharedMemPerBlock; // 64 KiB static limit; dynamic can be raised up to 160 KiB
+    c.initialised = true;
+}
+
+Slot &get_slot(int thread) {
+    Context &c = ctx();
+    std::lock_guard<std::mutex> lock(c.mutex);
+    if (thread < 0 || thread >= VXH_MAX_SLOTS) throw std::runtime_error("thread slot out of range");
+    Slot *&s = c.slots[thread];
+    if (!s) {
+        s = new Slot();
+        HIP_CHECK(hipSetDevice(c.device));
+        HIP_CHECK(hipStreamCreateWithFlags(&s->own_stream, hipStreamNonBlocking));
+        s->stream = s->own_stream;
+        for (auto &st : s->stage) HIP_CHECK(hipEventCreateWithFlags(&st.done, hipEventDisableTiming));
+        HIP_CHECK(hipEventCreate(&s->t0));
+        HIP_CHECK(hipEventCreate(&s->t1));
+    }
+    return *s;
+}
+
+// ------------------------------------------------------------------------------------------
+// dtype tables
+// ------------------------------------------------------------------------------------------
+static const int kDtypeSize[VXH_DTYPE_COUNT] = {8, 4, 8, 4, 2, 1, 8, 4, 2, 1, 1};
+int vxh_dtype_size(int dt) { return kDtypeSize[dt]; }
+
+static void check_dtype(int dt) {
+    if (dt < 0 || dt >= VXH_DTYPE_COUNT) throw std::runtime_error("unknown dtype code");
+}
+
+// upcast<T> of src/agg_sum.cpp:6-62
+static int upcast_dtype(int dt) {
+    switch (dt) {
+    case VXH_F64: case VXH_F32: return VXH_F64;
+    case VXH_U64: case VXH_U32: case VXH_U16: case VXH_U8: return VXH_U64;
+    default: return VXH_I64;
+    }
+}
+
+// host-visible grid dtype and device cell type of an aggregator
+static void agg_types(int kind, int dt, int *host_dtype, int *cell) {
+    switch (kind) {
+    case VXH_AGG_COUNT: *host_dtype = VXH_I64; *cell = VXH_CELL_I64; break;
+    case VXH_AGG_SUM:
+    case VXH_AGG_SUM_MOMENT: {
+        int up = upcast_dtype(dt);
+        *host_dtype = up;
+        *cell = up == VXH_F64 ? VXH_CELL_F64 : (up == VXH_U64 ? VXH_CELL_U64 : VXH_CELL_I64);
+        break;
+    }
+    default: // min / max: grid type == data type; <4-byte types are widened on the device
+        *host_dtype = dt;
+        switch (dt) {
+        case VXH_F64: *cell = VXH_CELL_F64; break;
+        case VXH_F32: *cell = VXH_CELL_F32; break;
+        case VXH_I64: *cell = VXH_CELL_I64; break;
+        case VXH_U64: *cell = VXH_CELL_U64; break;
+        case VXH_I32: case VXH_I16: case VXH_I8: *cell = VXH_CELL_I32; break;
+        default: *cell = VXH_CELL_U32; break; // u32 u16 u8 bool
+        }
+    }
+}
+
+// identity element (as 8 raw bytes of the DEVICE cell type): 0 for count/sum, type limits for
+// min/max (initial_fill: src/agg_minmax.cpp:13-18, :83-87)
+static uint64_t device_identity(int kind, int dt, int cell) {
+    if (kind != VXH_AGG_MIN && kind != VXH_AGG_MAX) return 0;
+    const bool mx = kind == VXH_AGG_MAX;
+    uint64_t out = 0;
+    switch (dt) {
+    case VXH_F64: { double v = mx ? -INFINITY : INFINITY; memcpy(&out, &v, 8); break; }
+    case VXH_F32: { float v = mx ? -INFINITY : INFINITY; memcpy(&out, &v, 4); break; }
+    case VXH_I64: { int64_t v = mx ? INT64_MIN : INT64_MAX; memcpy(&out, &v, 8); break; }
+    case VXH_U64: { uint64_t v = mx ? 0 : UINT64_MAX; out = v; break; }
+    case VXH_I32: { int32_t v = mx ? INT32_MIN : INT32_MAX; memcpy(&out, &v, 4); break; }
+    case VXH_I16: { int32_t v = mx ? INT16_MIN : INT16_MAX; memcpy(&out, &v, 4); break; }
+    case VXH_I8: { int32_t v = mx ? INT8_MIN : INT8_MAX; memcpy(&out, &v, 4); break; }
+    case VXH_U32: { uint32_t v = mx ? 0 : UINT32_MAX; memcpy(&out, &v, 4); break; }
+    case VXH_U16: { uint32_t v = mx ? 0 : UINT16_MAX; memcpy(&out, &v, 4); break; }
+    case VXH_U8: { uint32_t v = mx ? 0 : UINT8_MAX; memcpy(&out, &v, 4); break; }
+    default: { uint32_t v = mx ? 0 : 1; memcpy(&out, &v, 4); break; } // bool: numeric_limits<bool>::min()/max()
+    }
+    (void)cell;
+    return out;
+}
+
+// ------------------------------------------------------------------------------------------
+// host <-> device cell conversion (only min/max of <4-byte types differ)
+// ------------------------------------------------------------------------------------------
+template <typename H, typename D>
+static void convert_cells(const D *src, H *dst, uint64_t n) {
+    for (uint64_t i = 0; i < n; i++) dst[i] = (H)src[i];
+}
+
+static void device_to_host_cells(const void *dev_cells, int cell, void *host_cells, int host_dt, uint64_t n) {
+    const size_t hs = kDtypeSize[host_dt], ds = vxh_cell_size(cell);
+    if (hs == ds) { memcpy(host_cells, dev_cells, n * hs); return; }
+    switch (host_dt) {
+    case VXH_I16: convert_cells<int16_t, int32_t>((const int32_t *)dev_cells, (int16_t *)host_cells, n); break;
+    case VXH_I8: convert_cells<int8_t, int32_t>((const int32_t *)dev_cells, (int8_t *)host_cells, n); break;
+    case VXH_U16: convert_cells<uint16_t, uint32_t>((const uint32_t *)dev_cells, (uint16_t *)host_cells, n); break;
+    case VXH_U8: case VXH_BOOL: convert_cells<uint8_t, uint32_t>((const uint32_t *)dev_cells, (uint8_t *)host_cells, n); break;
+    default: throw std::runtime_error("internal: unexpected cell conversion");
+    }
+}
+
+static void host_to_device_cells(const void *host_cells, int host_dt, void *dev_cells, int cell, uint64_t n) {
+    const size_t hs = kDtypeSize[host_dt], ds = vxh_cell_size(cell);
+    if (hs == ds) { memcpy(dev_cells, host_cells, n * hs); return; }
+    switch (host_dt) {
+    case VXH_I16: convert_cells<int32_t, int16_t>((const int16_t *)host_cells, (int32_t *)dev_cells, n); break;
+    case VXH_I8: convert_cells<int32_t, int8_t>((const int8_t *)host_cells, (int32_t *)dev_cells, n); break;
+    case VXH_U16: convert_cells<uint32_t, uint16_t>((const uint16_t *)host_cells, (uint32_t *)dev_cells, n); break;
+    case VXH_U8: case VXH_BOOL: convert_cells<uint32_t, uint8_t>((const uint8_t *)host_cells, (uint32_t *)dev_cells, n); break;
+    default: throw std::runtime_error("internal: unexpected cell conversion");
+    }
+}
+
+// elementwise reduce of host grids: a = op(a, b) (merge / get_result fold on the host mirror)
+template <typename T>
+static void host_reduce_t(T *a, const T *b, uint64_t n, int kind) {
+    if (kind == VXH_AGG_MIN) { for (uint64_t i = 0; i < n; i++) a[i] = std::min(a[i], b[i]); }
+    else if (kind == VXH_AGG_MAX) { for (uint64_t i = 0; i < n; i++) a[i] = std::max(a[i], b[i]); }
+    else { for (uint64_t i = 0; i < n; i++) a[i] = a[i] + b[i]; }
+}
+static void host_reduce(void *a, const void *b, uint64_t n, int host_dt, int kind) {
+    switch (host_dt) {
+    case VXH_F64: host_reduce_t((double *)a, (const double *)b, n, kind); break;
+    case VXH_F32: host_reduce_t((float *)a, (const float *)b, n, kind); break;
+    case VXH_I64: host_reduce_t((int64_t *)a, (const int64_t *)b, n, kind); break;
+    case VXH_I32: host_reduce_t((int32_t *)a, (const int32_t *)b, n, kind); break;
+    case VXH_I16: host_reduce_t((int16_t *)a, (const int16_t *)b, n, kind); break;
+    case VXH_I8: host_reduce_t((int8_t *)a, (const int8_t *)b, n, kind); break;
+    case VXH_U64: host_reduce_t((uint64_t *)a, (const uint64_t *)b, n, kind); break;
+    case VXH_U32: host_reduce_t((uint32_t *)a, (const uint32_t *)b, n, kind); break;
+    case VXH_U16: host_reduce_t((uint16_t *)a, (const uint16_t *)b, n, kind); break;
+    default: host_reduce_t((uint8_t *)a, (const uint8_t *)b, n, kind); break;
+    }
+}
+
+static void host_fill_identity(void *dst, uint64_t n, int kind, int host_dt) {
+    const size_t hs = kDtypeSize[host_dt];
+    if (kind != VXH_AGG_MIN && kind != VXH_AGG_MAX) { memset(dst, 0, n * hs); return; }
+    int cell, hd;
+    agg_types(kind, host_dt, &hd, &cell);
+    uint64_t ident = device_identity(kind, host_dt, cell);
+    unsigned char elem[8];
+    device_to_host_cells(&ident, cell, elem, host_dt, 1);
+    unsigned char *p = (unsigned char *)dst;
+    for (uint64_t i = 0; i < n; i++) memcpy(p + i * hs, elem, hs);
+}
+
+// ------------------------------------------------------------------------------------------
+// aggregator device state
+// ------------------------------------------------------------------------------------------
+static void agg_alloc_device(vxh_agg *a) {
+    if (a->dev) return;
+    ensure_device_ready();
+    Context &c = ctx();
+    const uint64_t cells = a->grid->length1d;
+    int R = (int)c.cfg_replicas;
+    if (R <= 0) {
+        // auto: one replica per XCD unless the grid is huge (>= 64 Mi cells: 8 replicas of 8 B cells = 4 GiB)
+        R = cells * 8ull * 8ull <= (1ull << 32) ? 8 : 1;
+    }
+    a->replicas = R;
+    const size_t cs = vxh_cell_size(a->cell);
+    HIP_CHECK(hipMalloc(&a->dev, (size_t)R * cells * cs));
+    Slot &s0 = get_slot(0);
+    vxh_launch_fill(a->dev, (uint64_t)R * cells, a->cell, &a->identity, s0.stream);
+    HIP_CHECK(hipStreamSynchronize(s0.stream));
+    a->folded = true;
+}
+
+// fold replicas into replica 0 (device), after all slots' work has drained
+static void agg_fold_device(vxh_agg *a) {
+    if (!a->dev || a->folded) return;
+    HIP_CHECK(hipDeviceSynchronize());
+    Slot &s0 = get_slot(0);
+    vxh_launch_fold(a->dev, a->grid->length1d, a->replicas, a->cell, a->kind, &a->identity, s0.stream);
+    HIP_CHECK(hipStreamSynchronize(s0.stream));
+    a->folded = true;
+}
+
+static void agg_alloc_mirror(vxh_agg *a) {
+    if (!a->mirror.empty()) return;
+    const uint64_t cells = a->grid->length1d;
+    a->mirror.resize((size_t)a->grids * cells * kDtypeSize[a->host_dtype]);
+    host_fill_identity(a->mirror.data(), (uint64_t)a->grids * cells, a->kind, a->host_dtype);
+}
+
+// result (length1d host cells) of the current logical value
+static void agg_result_locked(vxh_agg *a, void *out) {
+    const uint64_t cells = a->grid->length1d;
+    const size_t hs = kDtypeSize[a->host_dtype];
+    if (a->auth == AUTH_DEVICE) {
+        agg_fold_device(a);
+        const size_t cs = vxh_cell_size(a->cell);
+        if (cs == hs) {
+            HIP_CHECK(hipMemcpy(out, a->dev, cells * cs, hipMemcpyDeviceToHost));
+        } else {
+            std::vector<unsigned char> tmp(cells * cs);
+            HIP_CHECK(hipMemcpy(tmp.data(), a->dev, cells * cs, hipMemcpyDeviceToHost));
+            device_to_host_cells(tmp.data(), a->cell, out, a->host_dtype, cells);
+        }
+    } else if (a->auth == AUTH_HOST) {
+        // get_result fold over the host grids (src/agg_count.cpp:24-41)
+        memcpy(out, a->mirror.data(), cells * hs);
+        for (int g = 1; g < a->grids; g++) host_reduce(out, a->mirror.data() + (size_t)g * cells * hs, cells, a->host_dtype, a->kind);
+    } else {
+        host_fill_identity(out, cells, a->kind, a->host_dtype);
+    }
+}
+
+// make the device copy authoritative (upload the host mirror if the host owns the truth)
+static void agg_ensure_device_locked(vxh_agg *a) {
+    agg_alloc_device(a);
+    if (a->auth == AUTH_DEVICE) return;
+    const uint64_t cells = a->grid->length1d;
+    const size_t cs = vxh_cell_size(a->cell);
+    if (a->auth == AUTH_HOST) {
+        std::vector<unsigned char> folded(cells * kDtypeSize[a->host_dtype]);
+        agg_result_locked(a, folded.data());
+        std::vector<unsigned char> dev_cells(cells * cs);
+        host_to_device_cells(folded.data(), a->host_dtype, dev_cells.data(), a->cell, cells);
+        HIP_CHECK(hipDeviceSynchronize());
+        HIP_CHECK(hipMemcpy(a->dev, dev_cells.data(), cells * cs, hipMemcpyHostToDevice));
+        if (a->replicas > 1) {
+            Slot &s0 = get_slot(0);
+            vxh_launch_fill((char *)a->dev + cells * cs, (uint64_t)(a->replicas - 1) * cells, a->cell, &a->identity, s0.stream);
+            HIP_CHECK(hipStreamSynchronize(s0.stream));
+        }
+        a->folded = true;
+    }
+    a->auth = AUTH_DEVICE;
+}
+
+// ------------------------------------------------------------------------------------------
+// host-chunk staging
+// ------------------------------------------------------------------------------------------
+struct Stager {
+    Slot &slot;
+    Slot::Stage &stage;
+    size_t used = 0;
+    std::map<std::pair<const void *, size_t>, const void *> seen;
+    Stager(Slot &s) : slot(s), stage(s.stage[s.cur]) {}
+
+    // total bytes are reserved up-front by the caller via reserve()
+    void reserve(size_t bytes) {
+        // the kernels of the previous use of this arena must have finished
+        HIP_CHECK(hipEventSynchronize(stage.done));
+        if (bytes > stage.cap) {
+            if (stage.dev) HIP_CHECK(hipFree(stage.dev));
+            size_t cap = std::max(bytes, (size_t)ctx().cfg_stage_bytes);
+            HIP_CHECK(hipMalloc(&stage.dev, cap));
+            stage.cap = cap;
+        }
+    }
+    const void *put(const void *host, size_t bytes) {
+        auto key = std::make_pair(host, bytes);
+        auto it = seen.find(key);
+        if (it != seen.end()) return it->second;
+        size_t off = (used + 255) & ~(size_t)255;
+        if (off + bytes > stage.cap) throw std::runtime_error("internal: staging arena overflow");
+        void *dst = (char *)stage.dev + off;
+        // pageable source: the runtime stages it through its own pinned buffers and returns once the
+        // source has been consumed, which is exactly the lifetime vaex guarantees (vaex/cpu.py:708-710)
+        HIP_CHECK(hipMemcpyAsync(dst, host, bytes, hipMemcpyHostToDevice, slot.stream));
+        used = off + bytes;
+        seen[key] = dst;
+        return dst;
+    }
+};
+
+static size_t padded(size_t b) { return (b + 255) & ~(size_t)255; }
+
+// ------------------------------------------------------------------------------------------
+// launch planning
+// ------------------------------------------------------------------------------------------
+static LaunchPlan make_plan(const BinArgs &A, BinArgs &out, uint64_t n) {
+    Context &c = ctx();
+    LaunchPlan p{};
+    out = A;
+    // fast path: every binner scalar/f64/native/unmasked, every aggregator input f64/native or absent
+    bool fast = true;
+    for (int d = 0; d < A.ndim; d++) {
+        const BinnerDesc &b = A.b[d];
+        if (b.kind != VXH_BIN_SCALAR || b.dtype != VXH_F64 || b.flip || b.mask) fast = false;
+    }
+    for (int k = 0; k < A.nagg; k++) {
+        const AggDesc &a = A.a[k];
+        if (a.data && (a.dtype != VXH_F64 || a.flip)) fast = false;
+    }
+    p.fast_f64 = fast;
+
+    // LDS footprint of workgroup-private grids
+    size_t lds = 0;
+    for (int k = 0; k < A.nagg; k++) {
+        out.a[k].lds_offset = (uint32_t)lds;
+        lds += (A.cells * vxh_lds_cell_size(A.a[k].kind, A.a[k].cell) + 15) & ~(size_t)15;
+    }
+    const size_t lds_max = 160 * 1024;
+    int strategy = (int)c.cfg_strategy;
+    if (strategy == VXH_STRAT_AUTO) {
+        // LDS pays when the per-workgroup init+flush (O(cells)) is small next to the rows it handles
+        if (lds <= lds_max && n >= 64 * A.cells) strategy = VXH_STRAT_LDS;
+        else strategy = VXH_STRAT_XCC;
+    }
+    if (strategy == VXH_STRAT_LDS && lds > lds_max) strategy = VXH_STRAT_XCC;
+    if (strategy == VXH_STRAT_XCC && (A.replicas < 8 || A.replicas % 8)) strategy = VXH_STRAT_GLOBAL;
+    p.strategy = strategy;
+    out.replicas_per_xcc = strategy == VXH_STRAT_XCC ? A.replicas / 8 : 1;
+
+    if (strategy == VXH_STRAT_LDS) {
+        p.lds_bytes = lds;
+        int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, lds_max / std::max<size_t>(lds, 1)));
+        p.block = c.cfg_block > 0 ? (int)c.cfg_block : (per_cu >= 4 ? 512 : 1024);
+        // keep <= 2048 threads per CU
+        per_cu = std::min(per_cu, 2048 / p.block);
+        if (per_cu < 1) per_cu = 1;
+        uint64_t want = (n + (uint64_t)p.block * 4 - 1) / ((uint64_t)p.block * 4);
+        uint64_t cap = (uint64_t)c.cus * per_cu;
+        if (c.cfg_blocks > 0) cap = (uint64_t)c.cfg_blocks;
+        p.blocks = (int)std::max<uint64_t>(1, std::min(want, cap));
+        p.name = fast ? "bin_lds_f64" : "bin_lds_generic";
+    } else {
+        p.lds_bytes = 0;
+        p.block = c.cfg_block > 0 ? (int)c.cfg_block : 256;
+        uint64_t want = (n + (uint64_t)p.block * 4 - 1) / ((uint64_t)p.block * 4);
+        uint64_t cap = c.cfg_blocks > 0 ? (uint64_t)c.cfg_blocks : (uint64_t)c.cus * 8;
+        p.blocks = (int)std::max<uint64_t>(1, std::min(want, cap));
+        if (strategy == VXH_STRAT_XCC) p.name = fast ? "bin_xcc_f64" : "bin_xcc_generic";
+        else p.name = fast ? "bin_global_f64" : "bin_global_generic";
+    }
+    return p;
+}
+
+// ------------------------------------------------------------------------------------------
+// C-ABI: library
+// ------------------------------------------------------------------------------------------
+extern "C" {
+
+int vxh_abi_version(void) { return VXH_ABI_VERSION; }
+const char *vxh_last_error(void) { return g_last_error.c_str(); }
+
+int vxh_device_count(int *count) {
+    VXH_API_BEGIN
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { (void)hipGetLastError(); n = 0; }
+    *count = n;
+    VXH_API_END
+}
+
+int vxh_set_device(int device) {
+    VXH_API_BEGIN
+    Context &c = ctx();
+    {
+        std::lock_guard<std::mutex> lock(c.mutex);
+        if (c.initialised && c.device != device) throw std::runtime_error("vxh_set_device: device already in use by this process");
+        c.device = device;
+    }
+    ensure_device_ready();
+    VXH_API_END
+}
+
+int vxh_synchronize(void) {
+    VXH_API_BEGIN
+    ensure_device_ready();
+    HIP_CHECK(hipDeviceSynchronize());
+    VXH_API_END
+}
+
+int vxh_slot_set_stream(int thread, void *hip_stream) {
+    VXH_API_BEGIN
+    ensure_device_ready();
+    Slot &s = get_slot(thread);
+    HIP_CHECK(hipStreamSynchronize(s.stream));
+    s.stream = hip_stream ? (hipStream_t)hip_stream : s.own_stream;
+    VXH_API_END
+}
+
+int vxh_config_set(const char *key, int64_t value) {
+    VXH_API_BEGIN
+    Context &c = ctx();
+    std::string k(key);
+    if (k == "strategy") c.cfg_strategy = value;
+    else if (k == "replicas") c.cfg_replicas = value;
+    else if (k == "block") c.cfg_block = value;
+    else if (k == "blocks") c.cfg_blocks = value;
+    else if (k == "stage_bytes") c.cfg_stage_bytes = value;
+    else throw std::runtime_error("unknown config key: " + k);
+    VXH_API_END
+}
+
+int vxh_config_get(const char *key, int64_t *value) {
+    VXH_API_BEGIN
+    Context &c = ctx();
+    std::string k(key);
+    if (k == "strategy") *value = c.cfg_strategy;
+    else if (k == "replicas") *value = c.cfg_replicas;
+    else if (k == "block") *value = c.cfg_block;
+    else if (k == "blocks") *value = c.cfg_blocks;
+    else if (k == "stage_bytes") *value = c.cfg_stage_bytes;
+    else if (k == "cus") { ensure_device_ready(); *value = c.cus; }
+    else throw std::runtime_error("unknown config key: " + k);
+    VXH_API_END
+}
+
+const char *vxh_last_kernel(int thread) {
+    Context &c = ctx();
+    std::lock_guard<std::mutex> lock(c.mutex);
+    if (thread < 0 || thread >= VXH_MAX_SLOTS || !c.slots[thread]) return "";
+    return c.slots[thread]->last_kernel;
+}
+
+// ------------------------------------------------------------------------------------------
+// binners
+// ------------------------------------------------------------------------------------------
+static vxh_binner *new_binner(int threads, int kind, int dtype, int flip) {
+    check_dtype(dtype);
+    if (threads < 1) throw std::runtime_error("threads must be >= 1");
+    vxh_binner *b = new vxh_binner();
+    b->kind = kind;
+    b->dtype = dtype;
+    b->flip = flip ? 1 : 0;
+    b->threads = threads;
+    b->data.resize(threads);
+    b->mask.resize(threads);
+    return b;
+}
+
+int vxh_binner_scalar_create(int threads, int dtype, int flip_endian, double vmin, double vmax, uint64_t bins, vxh_binner **out) {
+    VXH_API_BEGIN
+    vxh_binner *b = new_binner(threads, VXH_BIN_SCALAR, dtype, flip_endian);
+    b->vmin = vmin;
+    b->vmax = vmax;
+    b->bins = bins;
+    *out = b;
+    VXH_API_END
+}
+
+int vxh_binner_ordinal_create(int threads, int dtype, int flip_endian, int64_t ordinal_count, int64_t min_value, int allow_other, int invert, vxh_binner **out) {
+    VXH_API_BEGIN
+    vxh_binner *b = new_binner(threads, VXH_BIN_ORDINAL, dtype, flip_endian);
+    b->ordinal_count = ordinal_count;
+    b->min_value = min_value;
+    b->allow_other = allow_other != 0;
+    b->invert = invert != 0;
+    *out = b;
+    VXH_API_END
+}
+
+int vxh_binner_hash_create(int threads, int dtype, vxh_hashmap *map, vxh_binner **out) {
+    VXH_API_BEGIN
+    if (!map) throw std::runtime_error("hash map is null");
+    if (dtype == VXH_F64 || dtype == VXH_F32) throw std::runtime_error("BinnerHash: floating point keys are not supported");
+    vxh_binner *b = new_binner(threads, VXH_BIN_HASH, dtype, 0);
+    b->map = map;
+    *out = b;
+    VXH_API_END
+}
+
+int vxh_binner_copy(const vxh_binner *binner, vxh_binner **out) {
+    VXH_API_BEGIN
+    *out = new vxh_binner(*binner); // copies the slot pointers too, like `new BinnerScalar(*this)`
+    VXH_API_END
+}
+
+void vxh_binner_destroy(vxh_binner *binner) { delete binner; }
+
+uint64_t vxh_binner_shape(const vxh_binner *b) {
+    switch (b->kind) {
+    case VXH_BIN_SCALAR: return b->bins + 3;
+    case VXH_BIN_ORDINAL: return (uint64_t)b->ordinal_count + (b->allow_other ? 3 : 2);
+    default: return (uint64_t)vxh_hashmap_size_for_binner(b->map) + 2;
+    }
+}
+
+static void check_slot(int thread, size_t n, const char *what) {
+    if (thread < 0 || (size_t)thread >= n) throw std::runtime_error(std::string("thread out of bound for ") + what);
+}
+
+int vxh_binner_set_data(vxh_binner *b, int thread, const void *data, uint64_t n, int mem) {
+    VXH_API_BEGIN
+    check_slot(thread, b->data.size(), "data_ptr");
+    b->data[thread] = SlotData{data, n, mem};
+    VXH_API_END
+}
+int vxh_binner_set_data_mask(vxh_binner *b, int thread, const uint8_t *mask, uint64_t n, int mem) {
+    VXH_API_BEGIN
+    check_slot(thread, b->mask.size(), "data_mask_ptr");
+    b->mask[thread] = SlotData{mask, n, mem};
+    VXH_API_END
+}
+int vxh_binner_clear_data_mask(vxh_binner *b, int thread) {
+    VXH_API_BEGIN
+    check_slot(thread, b->mask.size(), "data_mask_ptr");
+    b->mask[thread] = SlotData{nullptr, 0, VXH_MEM_HOST};
+    VXH_API_END
+}
+uint64_t vxh_binner_data_length(const vxh_binner *b, int thread) {
+    if (thread < 0 || (size_t)thread >= b->data.size()) return 0;
+    return b->data[thread].n;
+}
+
+// ------------------------------------------------------------------------------------------
+// grid
+// ------------------------------------------------------------------------------------------
+int vxh_grid_create(vxh_binner *const *binners, int dimensions, vxh_grid **out) {
+    VXH_API_BEGIN
+    if (dimensions < 0 || dimensions > VXH_MAX_DIM) throw std::runtime_error("too many dimensions (max 16)");
+    vxh_grid *g = new vxh_grid();
+    g->binners.assign(binners, binners + dimensions);
+    g->shapes.resize(dimensions);
+    g->strides.resize(dimensions);
+    g->length1d = 1;
+    for (int i = 0; i < dimensions; i++) {
+        g->shapes[i] = vxh_binner_shape(binners[i]);
+        g->length1d *= g->shapes[i];
+    }
+    if (dimensions > 0) {
+        g->strides[0] = 1;
+        for (int i = 1; i < dimensions; i++) g->strides[i] = g->strides[i - 1] * g->shapes[i - 1];
+    }
+    *out = g;
+    VXH_API_END
+}
+void vxh_grid_destroy(vxh_grid *g) { delete g; }
+uint64_t vxh_grid_length1d(const vxh_grid *g) { return g->length1d; }
+int vxh_grid_dimensions(const vxh_grid *g) { return (int)g->binners.size(); }
+int vxh_grid_shapes(const vxh_grid *g, uint64_t *o) {
+    for (size_t i = 0; i < g->shapes.size(); i++) o[i] = g->shapes[i];
+    return 0;
+}
+int vxh_grid_strides(const vxh_grid *g, uint64_t *o) {
+    for (size_t i = 0; i < g->strides.size(); i++) o[i] = g->strides[i];
+    return 0;
+}
+
+int vxh_grid_bin(vxh_grid *grid, int thread, vxh_agg *const *aggs, int n_aggs, uint64_t length) {
+    VXH_API_BEGIN
+    ensure_device_ready();
+    if (n_aggs <= 0 || length == 0) return 0;
+    Slot &slot = get_slot(thread);
+    const int ndim = (int)grid->binners.size();
+
+    // validate slots and sizes (the reference reads out of bounds instead; we refuse)
+    size_t stage_bytes = 0;
+    for (int d = 0; d < ndim; d++) {
+        vxh_binner *b = grid->binners[d];
+        check_slot(thread, b->data.size(), "data_ptr");
+        const SlotData &sd = b->data[thread];
+        if (!sd.ptr) throw std::runtime_error("data not set");
+        if (sd.n < length) throw std::runtime_error("binner data is shorter than the requested length");
+        if (sd.mem == VXH_MEM_HOST) stage_bytes += padded(length * kDtypeSize[b->dtype]);
+        const SlotData &sm = b->mask[thread];
+        if (sm.ptr) {
+            if (sm.n < length) throw std::runtime_error("binner data mask is shorter than the requested length");
+            if (sm.mem == VXH_MEM_HOST) stage_bytes += padded(length);
+        }
+    }
+    for (int k = 0; k < n_aggs; k++) {
+        vxh_agg *a = aggs[k];
+        if (a->grid != grid) throw std::runtime_error("aggregator was created for a different grid");
+        check_slot(thread, a->data.size(), "data_ptr");
+        const SlotData &sd = a->data[thread];
+        if (!sd.ptr && a->kind != VXH_AGG_COUNT) throw std::runtime_error("data not set");
+        if (sd.ptr) {
+            if (sd.n < length) throw std::runtime_error("aggregator data is shorter than the requested length");
+            if (sd.mem == VXH_MEM_HOST) stage_bytes += padded(length * kDtypeSize[a->dtype]);
+        }
+        const SlotData &sm = a->mask[thread];
+        if (sm.ptr) {
+            if (sm.n < length) throw std::runtime_error("aggregator data mask is shorter than the requested length");
+            if (sm.mem == VXH_MEM_HOST) stage_bytes += padded(length);
+        }
+    }
+
+    // device grids must own the truth before we scatter into them
+    for (int k = 0; k < n_aggs; k++) {
+        vxh_agg *a = aggs[k];
+        std::lock_guard<std::mutex> lock(a->mutex);
+        agg_ensure_device_locked(a);
+        a->folded = a->replicas <= 1;
+    }
+
+    Stager stager(slot);
+    if (stage_bytes) stager.reserve(stage_bytes);
+    auto resolve = [&](const SlotData &sd, size_t elem) -> const void * {
+        if (!sd.ptr) return nullptr;
+        if (sd.mem == VXH_MEM_DEVICE) return sd.ptr;
+        return stager.put(sd.ptr, length * elem);
+    };
+
+    BinArgs base{};
+    base.n = length;
+    base.cells = grid->length1d;
+    base.ndim = ndim;
+    for (int d = 0; d < ndim; d++) {
+        vxh_binner *b = grid->binners[d];
+        BinnerDesc &bd = base.b[d];
+        bd.data = resolve(b->data[thread], kDtypeSize[b->dtype]);
+        bd.mask = (const uint8_t *)resolve(b->mask[thread], 1);
+        bd.kind = (uint8_t)b->kind;
+        bd.dtype = (uint8_t)b->dtype;
+        bd.flip = (uint8_t)b->flip;
+        bd.stride = grid->strides[d];
+        if (b->kind == VXH_BIN_SCALAR) {
+            bd.vmin = b->vmin;
+            bd.scale = 1. / (b->vmax - b->vmin); // src/binners.cpp:16
+            bd.binsd = (double)b->bins;
+            bd.bins = b->bins;
+        } else if (b->kind == VXH_BIN_ORDINAL) {
+            bd.bins = (uint64_t)b->ordinal_count;
+            bd.min_value = b->min_value;
+            bd.allow_other = b->allow_other;
+            bd.invert = b->invert;
+        } else {
+            vxh_hashmap_fill_binner_desc(b->map, &bd);
+        }
+    }
+
+    const uint64_t kMaxRows = 1ull << 31; // LDS count cells are u32: a workgroup never sees more rows than this
+    for (int k0 = 0; k0 < n_aggs; k0 += VXH_MAX_AGG) {
+        const int nk = std::min(VXH_MAX_AGG, n_aggs - k0);
+        BinArgs A = base;
+        A.nagg = nk;
+        int replicas = aggs[k0]->replicas;
+        for (int k = 0; k < nk; k++) {
+            vxh_agg *a = aggs[k0 + k];
+            AggDesc &ad = A.a[k];
+            ad.data = resolve(a->data[thread], kDtypeSize[a->dtype]);
+            ad.mask = (const uint8_t *)resolve(a->mask[thread], 1);
+            ad.grid = a->dev;
+            ad.moment = a->moment;
+            ad.kind = (uint8_t)a->kind;
+            ad.dtype = (uint8_t)a->dtype;
+            ad.flip = (uint8_t)a->flip;
+            ad.cell = (uint8_t)a->cell;
+            replicas = std::min(replicas, a->replicas);
+        }
+        A.replicas = replicas;
+        for (uint64_t r0 = 0; r0 < length; r0 += kMaxRows) {
+            const uint64_t rn = std::min(kMaxRows, length - r0);
+            BinArgs L = A;
+            L.n = rn;
+            if (r0) {
+                for (int d = 0; d < ndim; d++) {
+                    L.b[d].data = (const char *)L.b[d].data + r0 * kDtypeSize[L.b[d].dtype];
+                    if (L.b[d].mask) L.b[d].mask += r0;
+                }
+                for (int k = 0; k < nk; k++) {
+                    if (L.a[k].data) L.a[k].data = (const char *)L.a[k].data + r0 * kDtypeSize[L.a[k].dtype];
+                    if (L.a[k].mask) L.a[k].mask += r0;
+                }
+            }
+            BinArgs planned;
+            LaunchPlan plan = make_plan(L, planned, rn);
+            vxh_launch_bin(planned, plan, slot.stream);
+            HIP_CHECK(hipGetLastError());
+            slot.last_kernel = plan.name;
+        }
+    }
+    if (stage_bytes) {
+        HIP_CHECK(hipEventRecord(stager.stage.done, slot.stream));
+        slot.cur ^= 1;
+    }
+    VXH_API_END
+}
+
+// ------------------------------------------------------------------------------------------
+// aggregators
+// ------------------------------------------------------------------------------------------
+int vxh_agg_create(int kind, int dtype, int flip_endian, vxh_grid *grid, int grids, int threads, uint32_t moment, vxh_agg **out) {
+    VXH_API_BEGIN
+    check_dtype(dtype);
+    if (kind < VXH_AGG_COUNT || kind > VXH_AGG_MAX) throw std::runtime_error("unknown aggregator kind");
+    if (!grid) throw std::runtime_error("grid is null");
+    if (grids < 1 || threads < 1) throw std::runtime_error("grids and threads must be >= 1");
+    vxh_agg *a = new vxh_agg();
+    a->kind = kind;
+    a->dtype = dtype;
+    a->flip = flip_endian ? 1 : 0;
+    a->moment = moment;
+    a->grid = grid;
+    a->grids = grids;
+    a->threads = threads;
+    agg_types(kind, dtype, &a->host_dtype, &a->cell);
+    a->identity = device_identity(kind, dtype, a->cell);
+    a->data.resize(threads);
+    a->mask.resize(threads);
+    *out = a;
+    VXH_API_END
+}
+
+void vxh_agg_destroy(vxh_agg *a) {
+    if (!a) return;
+    if (a->dev) {
+        (void)hipDeviceSynchronize();
+        (void)hipFree(a->dev);
+    }
+    delete a;
+}
+
+int vxh_agg_set_data(vxh_agg *a, int thread, const void *data, uint64_t n, int mem) {
+    VXH_API_BEGIN
+    check_slot(thread, a->data.size(), "data_ptr");
+    a->data[thread] = SlotData{data, n, mem};
+    VXH_API_END
+}
+int vxh_agg_set_data_mask(vxh_agg *a, int thread, const uint8_t *mask, uint64_t n, int mem) {
+    VXH_API_BEGIN
+    check_slot(thread, a->mask.size(), "data_mask_ptr");
+    a->mask[thread] = SlotData{mask, n, mem};
+    VXH_API_END
+}
+int vxh_agg_clear_data_mask(vxh_agg *a, int thread) {
+    VXH_API_BEGIN
+    check_slot(thread, a->mask.size(), "data_mask_ptr");
+    a->mask[thread] = SlotData{nullptr, 0, VXH_MEM_HOST};
+    VXH_API_END
+}
+
+size_t vxh_agg_bytes_used(const vxh_agg *a) { return (size_t)kDtypeSize[a->host_dtype] * (size_t)a->grids * a->grid->length1d; }
+int vxh_agg_grid_dtype(const vxh_agg *a) { return a->host_dtype; }
+int vxh_agg_grids(const vxh_agg *a) { return a->grids; }
+
+int vxh_agg_host_view(vxh_agg *a, void **ptr_out) {
+    VXH_API_BEGIN
+    std::lock_guard<std::mutex> lock(a->mutex);
+    const uint64_t cells = a->grid->length1d;
+    const size_t hs = kDtypeSize[a->host_dtype];
+    if (a->auth == AUTH_DEVICE) {
+        std::vector<unsigned char> r(cells * hs);
+        agg_result_locked(a, r.data());
+        agg_alloc_mirror(a);
+        memcpy(a->mirror.data(), r.data(), cells * hs);
+        if (a->grids > 1) host_fill_identity(a->mirror.data() + cells * hs, (uint64_t)(a->grids - 1) * cells, a->kind, a->host_dtype);
+    } else {
+        agg_alloc_mirror(a);
+    }
+    a->auth = AUTH_HOST; // the caller may write through the pointer
+    *ptr_out = a->mirror.data();
+    VXH_API_END
+}
+
+int vxh_agg_result(vxh_agg *a, void *out) {
+    VXH_API_BEGIN
+    std::lock_guard<std::mutex> lock(a->mutex);
+    agg_result_locked(a, out);
+    VXH_API_END
+}
+
+int vxh_agg_merge(vxh_agg *a, vxh_agg *const *others, int n_others) {
+    VXH_API_BEGIN
+    const uint64_t cells = a->grid->length1d;
+    const size_t hs = kDtypeSize[a->host_dtype];
+    std::vector<unsigned char> acc(cells * hs), tmp(cells * hs);
+    {
+        std::lock_guard<std::mutex> lock(a->mutex);
+        agg_result_locked(a, acc.data());
+    }
+    for (int i = 0; i < n_others; i++) {
+        vxh_agg *o = others[i];
+        if (o->kind != a->kind || o->host_dtype != a->host_dtype || o->grid->length1d != cells) throw std::runtime_error("merge: incompatible aggregators");
+        std::lock_guard<std::mutex> lock(o->mutex);
+        agg_result_locked(o, tmp.data());
+        host_reduce(acc.data(), tmp.data(), cells, a->host_dtype, a->kind);
+    }
+    std::lock_guard<std::mutex> lock(a->mutex);
+    agg_alloc_mirror(a);
+    memcpy(a->mirror.data(), acc.data(), cells * hs);
+    if (a->grids > 1) host_fill_identity(a->mirror.data() + cells * hs, (uint64_t)(a->grids - 1) * cells, a->kind, a->host_dtype);
+    a->auth = AUTH_HOST;
+    VXH_API_END
+}
+
+int vxh_agg_device_grid(vxh_agg *a, void **dev_ptr_out, int *device_dtype_out) {
+    VXH_API_BEGIN
+    ensure_device_ready();
+    std::lock_guard<std::mutex> lock(a->mutex);
+    agg_ensure_device_locked(a);
+    agg_fold_device(a);
+    *dev_ptr_out = a->dev;
+    if (device_dtype_out) {
+        static const int cell2dt[] = {VXH_I64, VXH_F64, VXH_U64, VXH_F32, VXH_I32, VXH_U32};
+        *device_dtype_out = cell2dt[a->cell];
+    }
+    VXH_API_END
+}
+
+int vxh_agg_device_touch(vxh_agg *a) {
+    VXH_API_BEGIN
+    std::lock_guard<std::mutex> lock(a->mutex);
+    if (!a->dev) throw std::runtime_error("device grid not allocated");
+    a->auth = AUTH_DEVICE;
+    VXH_API_END
+}
+
+int vxh_agg_reset(vxh_agg *a) {
+    VXH_API_BEGIN
+    std::lock_guard<std::mutex> lock(a->mutex);
+    if (a->dev) {
+        HIP_CHECK(hipDeviceSynchronize());
+        Slot &s0 = get_slot(0);
+        vxh_launch_fill(a->dev, (uint64_t)a->replicas * a->grid->length1d, a->cell, &a->identity, s0.stream);
+        HIP_CHECK(hipStreamSynchronize(s0.stream));
+        a->folded = true;
+        a->auth = AUTH_DEVICE;
+    } else {
+        a->auth = AUTH_NONE;
+    }
+    if (!a->mirror.empty()) host_fill_identity(a->mirror.data(), (uint64_t)a->grids * a->grid->length1d, a->kind, a->host_dtype);
+    VXH_API_END
+}
+
+// ------------------------------------------------------------------------------------------
+// legacy minmax + timers
+// ------------------------------------------------------------------------------------------
+int vxh_minmax(int dtype, int flip_endian, const void *data, const uint8_t *mask, uint64_t n, int mem, double *out2) {
+    VXH_API_BEGIN
+    check_dtype(dtype);
+    ensure_device_ready();
+    Slot &slot = get_slot(0);
+    double init[2] = {INFINITY, -INFINITY};
+    double *dev_out = nullptr;
+    HIP_CHECK(hipMalloc(&dev_out, 16));
+    HIP_CHECK(hipMemcpy(dev_out, init, 16, hipMemcpyHostToDevice));
+    const void *d = data;
+    const uint8_t *m = mask;
+    void *tmp_d = nullptr, *tmp_m = nullptr;
+    if (mem == VXH_MEM_HOST && n) {
+        HIP_CHECK(hipMalloc(&tmp_d, n * kDtypeSize[dtype]));
+        HIP_CHECK(hipMemcpy(tmp_d, data, n * kDtypeSize[dtype], hipMemcpyHostToDevice));
+        d = tmp_d;
+        if (mask) {
+            HIP_CHECK(hipMalloc(&tmp_m, n));
+            HIP_CHECK(hipMemcpy(tmp_m, mask, n, hipMemcpyHostToDevice));
+            m = (const uint8_t *)tmp_m;
+        }
+    }
+    if (n) vxh_launch_minmax(dtype, flip_endian ? 1 : 0, d, m, n, dev_out, slot.stream);
+    HIP_CHECK(hipStreamSynchronize(slot.stream));
+    HIP_CHECK(hipMemcpy(out2, dev_out, 16, hipMemcpyDeviceToHost));
+    (void)hipFree(dev_out);
+    if (tmp_d) (void)hipFree(tmp_d);
+    if (tmp_m) (void)hipFree(tmp_m);
+    VXH_API_END
+}
+
+int vxh_timer_start(int thread) {
+    VXH_API_BEGIN
+    ensure_device_ready();
+    Slot &s = get_slot(thread);
+    HIP_CHECK(hipEventRecord(s.t0, s.stream));
+    VXH_API_END
+}
+int vxh_timer_stop(int thread, float *elapsed_ms_out) {
+    VXH_API_BEGIN
+    ensure_device_ready();
+    Slot &s = get_slot(thread);
+    HIP_CHECK(hipEventRecord(s.t1, s.stream));
+    HIP_CHECK(hipEventSynchronize(s.t1));
+    HIP_CHECK(hipEventElapsedTime(elapsed_ms_out, s.t0, s.t1));
+    VXH_API_END
+}
+
+} // extern "C"

@@ -1,0 +1,312 @@
+// K3 — GPU open-addressing hash map: group keys -> dense ordinals.
+//
+// Stands in for the part of vaex.superutils.ordered_set_<int> the groupby path uses
+// (src/hash_primitives.hpp:436-730): update() = insert-or-get, map_ordinal() = lookup (-1 for
+// unknown), key_array() = keys ordered by ordinal.  Same hash finaliser as the reference
+// (splitmix64, src/hash.hpp:40-45) but ONE flat table in HBM instead of `nmaps` mutex-guarded
+// hopscotch shards: slots are claimed with a 64-bit compare-and-swap on the key word and the
+// winner draws the ordinal from a device counter, so ordinals are dense 0..count-1 in
+// (nondeterministic) claim order — the reference's are shard-offset + shard-local insertion
+// order, equally nondeterministic with threads; parity is per key.
+//
+// Layout: keys[cap] int64 (EMPTY = INT64_MIN), vals[cap] int64 ordinal (-1 = empty), cap a power
+// of two, load kept <= 3/4 by host-side batching + 4x growth.  The key INT64_MIN itself and the
+// null (masked) key are tracked in four side words next to the counter.
+#include "vxh_internal.hpp"
+
+#include <stdexcept>
+
+namespace {
+
+constexpr long long EMPTY = (long long)0x8000000000000000ull;
+
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
+    x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ULL;
+    x ^= x >> 27; x *= 0x94d049bb133111ebULL;
+    x ^= x >> 31;
+    return x;
+}
+
+__device__ __forceinline__ long long load_key(const void *p, uint64_t i, int dt) {
+    switch (dt) {
+    case VXH_I64: case VXH_U64: return ((const long long *)p)[i];
+    case VXH_I32: return ((const int32_t *)p)[i];
+    case VXH_U32: return ((const uint32_t *)p)[i];
+    case VXH_I16: return ((const int16_t *)p)[i];
+    case VXH_U16: return ((const uint16_t *)p)[i];
+    case VXH_I8: return ((const int8_t *)p)[i];
+    case VXH_U8: return ((const uint8_t *)p)[i];
+    default: return ((const uint8_t *)p)[i] ? 1 : 0;
+    }
+}
+
+// side words: [0] count  [1] null seen  [2] INT64_MIN key seen  [3] ordinal of INT64_MIN key
+__global__ void __launch_bounds__(256) hm_insert(const void *data, int dt, const uint8_t *mask, uint64_t n, long long *keys, long long *vals, uint64_t hmask, unsigned long long *side) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        if (mask != nullptr && mask[i] == 1) {
+            if (side[1] == 0) atomicExch(&side[1], 1ull);
+            continue;
+        }
+        const long long key = load_key(data, i, dt);
+        if (key == EMPTY) {
+            if (side[2] == 0 && atomicCAS(&side[2], 0ull, 1ull) == 0ull) side[3] = atomicAdd(&side[0], 1ull);
+            continue;
+        }
+        uint64_t p = splitmix64((uint64_t)key) & hmask;
+        for (;;) {
+            long long cur = keys[p]; // may be a stale EMPTY (L1); the CAS below then returns the true owner
+            if (cur == key) break;
+            if (cur == EMPTY) {
+                long long old = (long long)atomicCAS((unsigned long long *)&keys[p], (unsigned long long)EMPTY, (unsigned long long)key);
+                if (old == EMPTY) {
+                    vals[p] = (long long)atomicAdd(&side[0], 1ull);
+                    break;
+                }
+                if (old == key) break;
+            }
+            p = (p + 1) & hmask;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) hm_lookup(const void *data, int dt, uint64_t n, const long long *keys, const long long *vals, uint64_t hmask, const unsigned long long *side, long long *out) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        const long long key = load_key(data, i, dt);
+        long long ord = -1;
+        if (key == EMPTY) {
+            ord = side[2] ? (long long)side[3] : -1;
+        } else {
+            uint64_t p = splitmix64((uint64_t)key) & hmask;
+            for (;;) {
+                long long cur = keys[p];
+                if (cur == key) { ord = vals[p]; break; }
+                if (cur == EMPTY) break;
+                p = (p + 1) & hmask;
+            }
+        }
+        out[i] = ord;
+    }
+}
+
+// re-insert every occupied slot of the old table into the new one, keeping its ordinal
+__global__ void __launch_bounds__(256) hm_rehash(const long long *okeys, const long long *ovals, uint64_t ocap, long long *keys, long long *vals, uint64_t hmask) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (; i < ocap; i += stride) {
+        const long long key = okeys[i];
+        if (key == EMPTY) continue;
+        uint64_t p = splitmix64((uint64_t)key) & hmask;
+        for (;;) {
+            long long old = (long long)atomicCAS((unsigned long long *)&keys[p], (unsigned long long)EMPTY, (unsigned long long)key);
+            if (old == EMPTY) { vals[p] = ovals[i]; break; }
+            p = (p + 1) & hmask;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) hm_collect(const long long *keys, const long long *vals, uint64_t cap, long long *out) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (; i < cap; i += stride)
+        if (keys[i] != EMPTY) out[vals[i]] = keys[i];
+}
+
+__global__ void hm_fill(long long *p, uint64_t n, long long v) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) p[i] = v;
+}
+
+unsigned grid_for(uint64_t n) {
+    uint64_t b = (n + 255) / 256;
+    if (b > 4096) b = 4096;
+    if (b == 0) b = 1;
+    return (unsigned)b;
+}
+
+} // namespace
+
+struct vxh_hashmap {
+    int dtype = VXH_I64;
+    uint64_t cap = 0;
+    long long *keys = nullptr;
+    long long *vals = nullptr;
+    unsigned long long *side = nullptr; // 4 words on the device
+    unsigned long long host_side[4] = {0, 0, 0, 0};
+    std::mutex mutex;
+};
+
+static void hm_alloc_table(uint64_t cap, long long **keys, long long **vals, hipStream_t st) {
+    HIP_CHECK(hipMalloc(keys, cap * 8));
+    HIP_CHECK(hipMalloc(vals, cap * 8));
+    hipLaunchKernelGGL(hm_fill, dim3(grid_for(cap)), dim3(256), 0, st, *keys, cap, EMPTY);
+    hipLaunchKernelGGL(hm_fill, dim3(grid_for(cap)), dim3(256), 0, st, *vals, cap, -1ll);
+}
+
+static void hm_refresh(vxh_hashmap *m, hipStream_t st) {
+    HIP_CHECK(hipMemcpyAsync(m->host_side, m->side, 32, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+}
+
+static void hm_grow(vxh_hashmap *m, uint64_t new_cap, hipStream_t st) {
+    long long *nk, *nv;
+    hm_alloc_table(new_cap, &nk, &nv, st);
+    hipLaunchKernelGGL(hm_rehash, dim3(grid_for(m->cap)), dim3(256), 0, st, m->keys, m->vals, m->cap, nk, nv, new_cap - 1);
+    HIP_CHECK(hipStreamSynchronize(st));
+    (void)hipFree(m->keys);
+    (void)hipFree(m->vals);
+    m->keys = nk;
+    m->vals = nv;
+    m->cap = new_cap;
+}
+
+int64_t vxh_hashmap_size_for_binner(vxh_hashmap *m) {
+    std::lock_guard<std::mutex> lock(m->mutex);
+    return (int64_t)m->host_side[0];
+}
+
+void vxh_hashmap_fill_binner_desc(vxh_hashmap *m, BinnerDesc *bd) {
+    std::lock_guard<std::mutex> lock(m->mutex);
+    bd->hkeys = (const int64_t *)m->keys;
+    bd->hvals = (const int64_t *)m->vals;
+    bd->hmask = m->cap - 1;
+    bd->bins = m->host_side[0];
+    bd->null_bin = (int64_t)m->host_side[0] + 1;
+}
+
+extern "C" {
+
+#define HM_BEGIN try {
+#define HM_END                                                                                                         \
+    }                                                                                                                  \
+    catch (const std::exception &e) {                                                                                  \
+        vxh_set_error(e.what());                                                                                       \
+        return 1;                                                                                                      \
+    }                                                                                                                  \
+    return 0;
+
+int vxh_hashmap_create(int dtype, uint64_t capacity_hint, vxh_hashmap **out) {
+    HM_BEGIN
+    if (dtype == VXH_F64 || dtype == VXH_F32 || dtype < 0 || dtype >= VXH_DTYPE_COUNT) throw std::runtime_error("hash map: only integer key dtypes are supported");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n == 0) { (void)hipGetLastError(); throw std::runtime_error("vaex_hip: no HIP device available (libvaexhip has no CPU fallback)"); }
+    Slot &s = get_slot(0);
+    vxh_hashmap *m = new vxh_hashmap();
+    m->dtype = dtype;
+    uint64_t cap = 1ull << 20;
+    while (cap < capacity_hint * 2) cap <<= 1;
+    m->cap = cap;
+    hm_alloc_table(cap, &m->keys, &m->vals, s.stream);
+    HIP_CHECK(hipMalloc(&m->side, 32));
+    HIP_CHECK(hipMemsetAsync(m->side, 0, 32, s.stream));
+    HIP_CHECK(hipStreamSynchronize(s.stream));
+    *out = m;
+    HM_END
+}
+
+void vxh_hashmap_destroy(vxh_hashmap *m) {
+    if (!m) return;
+    (void)hipDeviceSynchronize();
+    (void)hipFree(m->keys);
+    (void)hipFree(m->vals);
+    (void)hipFree(m->side);
+    delete m;
+}
+
+int vxh_hashmap_update(vxh_hashmap *m, const void *keys, const uint8_t *mask, uint64_t n, int mem) {
+    HM_BEGIN
+    std::lock_guard<std::mutex> lock(m->mutex);
+    Slot &s = get_slot(0);
+    const size_t es = (size_t)vxh_dtype_size(m->dtype);
+    const void *dkeys = keys;
+    const uint8_t *dmask = mask;
+    void *tmp_k = nullptr, *tmp_m = nullptr;
+    if (mem == VXH_MEM_HOST && n) {
+        HIP_CHECK(hipMalloc(&tmp_k, n * es));
+        HIP_CHECK(hipMemcpyAsync(tmp_k, keys, n * es, hipMemcpyHostToDevice, s.stream));
+        dkeys = tmp_k;
+        if (mask) {
+            HIP_CHECK(hipMalloc(&tmp_m, n));
+            HIP_CHECK(hipMemcpyAsync(tmp_m, mask, n, hipMemcpyHostToDevice, s.stream));
+            dmask = (const uint8_t *)tmp_m;
+        }
+    }
+    uint64_t done = 0;
+    while (done < n) {
+        // the table can take cap*3/4 - count more distinct keys before its load passes 3/4
+        uint64_t count = m->host_side[0];
+        if (count * 4 > m->cap) hm_grow(m, m->cap * 4, s.stream);
+        uint64_t room = m->cap / 4 * 3 - count;
+        uint64_t batch = std::min<uint64_t>(n - done, room);
+        hipLaunchKernelGGL(hm_insert, dim3(grid_for(batch)), dim3(256), 0, s.stream, (const char *)dkeys + done * es, m->dtype, dmask ? dmask + done : nullptr, batch, m->keys, m->vals, m->cap - 1, m->side);
+        HIP_CHECK(hipGetLastError());
+        hm_refresh(m, s.stream);
+        done += batch;
+    }
+    if (tmp_k) (void)hipFree(tmp_k);
+    if (tmp_m) (void)hipFree(tmp_m);
+    HM_END
+}
+
+int vxh_hashmap_count(vxh_hashmap *m, int64_t *count_out) {
+    HM_BEGIN
+    std::lock_guard<std::mutex> lock(m->mutex);
+    *count_out = (int64_t)m->host_side[0];
+    HM_END
+}
+
+int vxh_hashmap_null_index(vxh_hashmap *m, int64_t *index_out) {
+    HM_BEGIN
+    std::lock_guard<std::mutex> lock(m->mutex);
+    *index_out = m->host_side[1] ? (int64_t)m->host_side[0] : -1;
+    HM_END
+}
+
+int vxh_hashmap_map_ordinal(vxh_hashmap *m, const void *keys, uint64_t n, int mem, int64_t *out) {
+    HM_BEGIN
+    std::lock_guard<std::mutex> lock(m->mutex);
+    if (n == 0) return 0;
+    Slot &s = get_slot(0);
+    const size_t es = (size_t)vxh_dtype_size(m->dtype);
+    const void *dkeys = keys;
+    long long *dout = (long long *)out;
+    void *tmp_k = nullptr, *tmp_o = nullptr;
+    if (mem == VXH_MEM_HOST) {
+        HIP_CHECK(hipMalloc(&tmp_k, n * es));
+        HIP_CHECK(hipMalloc(&tmp_o, n * 8));
+        HIP_CHECK(hipMemcpyAsync(tmp_k, keys, n * es, hipMemcpyHostToDevice, s.stream));
+        dkeys = tmp_k;
+        dout = (long long *)tmp_o;
+    }
+    hipLaunchKernelGGL(hm_lookup, dim3(grid_for(n)), dim3(256), 0, s.stream, dkeys, m->dtype, n, m->keys, m->vals, m->cap - 1, m->side, dout);
+    HIP_CHECK(hipGetLastError());
+    if (mem == VXH_MEM_HOST) {
+        HIP_CHECK(hipMemcpyAsync(out, tmp_o, n * 8, hipMemcpyDeviceToHost, s.stream));
+        HIP_CHECK(hipStreamSynchronize(s.stream));
+        (void)hipFree(tmp_k);
+        (void)hipFree(tmp_o);
+    }
+    HM_END
+}
+
+int vxh_hashmap_keys(vxh_hashmap *m, int64_t *keys_out) {
+    HM_BEGIN
+    std::lock_guard<std::mutex> lock(m->mutex);
+    const uint64_t count = m->host_side[0];
+    if (count == 0) return 0;
+    Slot &s = get_slot(0);
+    long long *d = nullptr;
+    HIP_CHECK(hipMalloc(&d, count * 8));
+    hipLaunchKernelGGL(hm_collect, dim3(grid_for(m->cap)), dim3(256), 0, s.stream, m->keys, m->vals, m->cap, d);
+    HIP_CHECK(hipMemcpyAsync(keys_out, d, count * 8, hipMemcpyDeviceToHost, s.stream));
+    HIP_CHECK(hipStreamSynchronize(s.stream));
+    if (m->host_side[2]) keys_out[m->host_side[3]] = (int64_t)EMPTY; // the INT64_MIN key lives in the side words
+    (void)hipFree(d);
+    HM_END
+}
+
+} // extern "C"

@@ -1,0 +1,97 @@
+// Internal host-side types of libvaexhip.so (not part of the ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "vxh_kernels.hpp"
+
+#define VXH_MAX_SLOTS 256
+
+void vxh_hip_check(hipError_t e, const char *what, const char *file, int line);
+#define HIP_CHECK(expr) vxh_hip_check((expr), #expr, __FILE__, __LINE__)
+void vxh_set_error(const std::string &msg);
+int vxh_dtype_size(int dt);
+
+// one registered array of a per-thread slot (src/agg_base.hpp:97-98: data_ptr[thread], data_size[thread])
+struct SlotData {
+    const void *ptr = nullptr;
+    uint64_t n = 0;
+    int mem = VXH_MEM_HOST;
+};
+
+struct vxh_binner {
+    int kind = 0, dtype = 0, flip = 0, threads = 1;
+    // scalar
+    double vmin = 0, vmax = 1;
+    uint64_t bins = 0;
+    // ordinal
+    int64_t ordinal_count = 0, min_value = 0;
+    bool allow_other = false, invert = false;
+    // hash
+    vxh_hashmap *map = nullptr;
+    std::vector<SlotData> data, mask;
+};
+
+struct vxh_grid {
+    std::vector<vxh_binner *> binners;
+    std::vector<uint64_t> shapes, strides;
+    uint64_t length1d = 1;
+};
+
+enum { AUTH_NONE = 0, AUTH_DEVICE = 1, AUTH_HOST = 2 };
+
+struct vxh_agg {
+    int kind = 0, dtype = 0, flip = 0;
+    uint32_t moment = 0;
+    vxh_grid *grid = nullptr;
+    int grids = 1, threads = 1;
+    int host_dtype = 0; // dtype of a cell as the host sees it (reference grid_type)
+    int cell = 0;       // vxh_cell: device cell type
+    uint64_t identity = 0;
+    // device state
+    void *dev = nullptr; // replicas x length1d cells
+    int replicas = 1;
+    bool folded = true; // replicas 1.. hold only the identity
+    int auth = AUTH_NONE;
+    std::vector<unsigned char> mirror; // lazily allocated (grids, *shapes) host buffer
+    std::mutex mutex;
+    std::vector<SlotData> data, mask;
+};
+
+struct Slot {
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    struct Stage {
+        void *dev = nullptr;
+        size_t cap = 0;
+        hipEvent_t done = nullptr;
+    } stage[2];
+    int cur = 0;
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    const char *last_kernel = "";
+};
+
+struct Context {
+    std::mutex mutex;
+    bool initialised = false;
+    int device = 0;
+    int cus = 256;
+    size_t max_lds = 65536;
+    Slot *slots[VXH_MAX_SLOTS] = {};
+    // tuning knobs (vxh_config_set)
+    int64_t cfg_strategy = VXH_STRAT_AUTO;
+    int64_t cfg_replicas = 0; // 0 = auto
+    int64_t cfg_block = 0;
+    int64_t cfg_blocks = 0;
+    int64_t cfg_stage_bytes = 64 << 20;
+};
+
+Context &ctx();
+Slot &get_slot(int thread);
+
+// hash map hooks (vxh_hashmap.hip)
+int64_t vxh_hashmap_size_for_binner(vxh_hashmap *map);
+void vxh_hashmap_fill_binner_desc(vxh_hashmap *map, BinnerDesc *bd);

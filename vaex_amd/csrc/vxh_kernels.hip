@@ -1,0 +1,491 @@
+// HIP kernels (gfx950 / CDNA4) for vaex's binned-statistics hot path.
+//
+//   K1  bin_kernel<STRAT, FAST>  fused  [bin index of every dim] -> [every aggregator's scatter op]
+//                                restates Grid::bin_ (src/agg.hpp:106-137) + BinnerScalar::to_bins
+//                                (src/binners.cpp:13-57) + BinnerOrdinal::to_bins
+//                                (src/binner_ordinal.cpp:20-176) + the aggregate() loops of
+//                                src/agg_count.cpp:43-67, src/agg_sum.cpp:98-127, src/agg_minmax.cpp:44-74
+//   K4  fold_kernel              replica fold = get_result()'s fold over thread grids
+//                                (src/agg_count.cpp:24-41, agg_sum.cpp:80-97, agg_minmax.cpp:27-43)
+//   K5  minmax_kernel            legacy statisticNd OP_MIN_MAX on a 0-d grid (src/vaexfast.cpp:1090-1101)
+//
+// The work is a bandwidth-bound gather/scatter: no MFMA.  Rows are read coalesced (lane i ->
+// row base+i), the flat cell index is computed in fp64 with exactly the reference's operation
+// order (sub, mul, compare, mul, cvt; compiled with -ffp-contract=off), and the scatter-add goes
+//   LDS    : to a workgroup-private copy of the grids in LDS (ds_add_u32 / ds_add_f64 ...),
+//            flushed once per workgroup with device-scope atomics         (grids that fit LDS)
+//   XCC    : straight to a per-XCD replica in HBM with workgroup-scope (L2-resident) atomics:
+//            every workgroup only ever touches the replica of the XCD it runs on, so the RMW
+//            stays in that XCD's 4 MiB L2 instead of going to the memory-side atomic unit
+//   GLOBAL : straight to replica blockIdx % R with device-scope atomics
+// and the replicas are folded by K4 when the result is asked for.
+#include "vxh_kernels.hpp"
+
+#include <string.h>
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// small helpers
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t xcc_id() {
+    uint32_t v;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+    return v & 7u; // 8 XCDs on MI355X
+}
+
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x) { // src/hash.hpp:40-45
+    x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ULL;
+    x ^= x >> 27; x *= 0x94d049bb133111ebULL;
+    x ^= x >> 31;
+    return x;
+}
+
+// raw little-endian element widened to 64 bits, byte-swapped when the column is non-native
+__device__ __forceinline__ uint64_t load_raw(const void *p, uint64_t i, int dt, int flip) {
+    switch (dt) {
+    case VXH_F64: case VXH_I64: case VXH_U64: {
+        uint64_t u = ((const uint64_t *)p)[i];
+        return flip ? __builtin_bswap64(u) : u;
+    }
+    case VXH_F32: case VXH_I32: case VXH_U32: {
+        uint32_t u = ((const uint32_t *)p)[i];
+        return flip ? __builtin_bswap32(u) : u;
+    }
+    case VXH_I16: case VXH_U16: {
+        uint16_t u = ((const uint16_t *)p)[i];
+        return flip ? __builtin_bswap16(u) : u;
+    }
+    default:
+        return ((const uint8_t *)p)[i];
+    }
+}
+
+// `double value_double = value;` (src/binners.cpp:24)
+__device__ __forceinline__ double raw_as_f64(uint64_t u, int dt) {
+    switch (dt) {
+    case VXH_F64: return __longlong_as_double((long long)u);
+    case VXH_F32: return (double)__uint_as_float((uint32_t)u);
+    case VXH_I64: return (double)(int64_t)u;
+    case VXH_I32: return (double)(int32_t)(uint32_t)u;
+    case VXH_I16: return (double)(int16_t)(uint16_t)u;
+    case VXH_I8: return (double)(int8_t)(uint8_t)u;
+    case VXH_U64: return (double)u;
+    case VXH_U32: return (double)(uint32_t)u;
+    case VXH_U16: return (double)(uint16_t)u;
+    case VXH_U8: return (double)(uint8_t)u;
+    default: return u ? 1.0 : 0.0; // bool
+    }
+}
+
+__device__ __forceinline__ int64_t raw_as_i64(uint64_t u, int dt) {
+    switch (dt) {
+    case VXH_I32: return (int32_t)(uint32_t)u;
+    case VXH_I16: return (int16_t)(uint16_t)u;
+    case VXH_I8: return (int8_t)(uint8_t)u;
+    case VXH_BOOL: return u ? 1 : 0;
+    default: return (int64_t)u; // i64/u64 as bits, u32/u16/u8 zero-extended by load_raw
+    }
+}
+
+__device__ __forceinline__ bool dt_is_float(int dt) { return dt == VXH_F64 || dt == VXH_F32; }
+
+// x86-64 cvttsd2si semantics ("integer indefinite" for NaN / out of range): what the reference's
+// `int64_t value = data_ptr[i] - min_value` does for floating T on the machines it runs on
+__device__ __forceinline__ int64_t f64_to_i64_x86(double d) {
+    if (!(d >= -9223372036854775808.0 && d < 9223372036854775808.0)) return INT64_MIN;
+    return (int64_t)d;
+}
+
+// ------------------------------------------------------------------------------------------
+// bin index of one dimension
+// ------------------------------------------------------------------------------------------
+// BinnerScalar — src/binners.cpp:16-35 (exact operation order; no FMA contraction possible/allowed)
+__device__ __forceinline__ uint64_t scalar_sub_index(double v, bool masked, double vmin, double scale, double binsd, uint64_t bins) {
+    double scaled = (v - vmin) * scale;
+    uint64_t index = 0;
+    if (scaled != scaled || masked) {
+    } else if (scaled < 0) {
+        index = 1;
+    } else if (scaled >= 1) {
+        index = bins + 2;
+    } else {
+        index = (uint64_t)(int64_t)((int)(scaled * binsd) + 2);
+    }
+    return index;
+}
+
+__device__ __forceinline__ uint64_t dim_sub_index(const BinnerDesc &b, uint64_t i) {
+    bool masked = b.mask != nullptr && b.mask[i] == 1;
+    if (b.kind == VXH_BIN_SCALAR) {
+        double v = raw_as_f64(load_raw(b.data, i, b.dtype, b.flip), b.dtype);
+        return scalar_sub_index(v, masked, b.vmin, b.scale, b.binsd, b.bins);
+    } else if (b.kind == VXH_BIN_ORDINAL) {
+        // src/binner_ordinal.cpp:138-175 (and the invert / allow_other variants :22-137).  The element is
+        // NOT byte-swapped before the subtraction; the int64 difference is (reference behaviour, :25-28).
+        uint64_t u = load_raw(b.data, i, b.dtype, 0);
+        int64_t value;
+        if (b.dtype == VXH_F64) value = f64_to_i64_x86(__longlong_as_double((long long)u) - (double)b.min_value);
+        else if (b.dtype == VXH_F32) value = f64_to_i64_x86((double)(__uint_as_float((uint32_t)u) - (float)b.min_value));
+        else value = (int64_t)((uint64_t)raw_as_i64(u, b.dtype) - (uint64_t)b.min_value);
+        if (b.flip) value = (int64_t)__builtin_bswap64((uint64_t)value);
+        int64_t N = (int64_t)b.bins;
+        bool oob = value < 0 || value >= N;
+        if (b.allow_other) {
+            if (masked) return (uint64_t)N + 1;
+            if (oob) return (uint64_t)N;
+        } else {
+            if (masked || oob) return (uint64_t)N;
+        }
+        return (uint64_t)(b.invert ? N - 1 - value : value);
+    } else {
+        // hash binner: cells [unknown, bin0..binN-1, null]
+        if (masked) return (uint64_t)b.null_bin;
+        uint64_t u = load_raw(b.data, i, b.dtype, b.flip);
+        int64_t key = dt_is_float(b.dtype) ? (int64_t)u : raw_as_i64(u, b.dtype);
+        uint64_t p = splitmix64((uint64_t)key) & b.hmask;
+        for (;;) {
+            int64_t ord = b.hvals[p];
+            if (ord < 0) return 0;
+            if (b.hkeys[p] == key) return (uint64_t)ord + 1;
+            p = (p + 1) & b.hmask;
+        }
+    }
+}
+
+template <bool FAST>
+__device__ __forceinline__ uint64_t flat_index(const BinArgs &A, uint64_t i) {
+    uint64_t idx = 0;
+    for (int d = 0; d < A.ndim; ++d) {
+        const BinnerDesc &b = A.b[d];
+        uint64_t sub;
+        if (FAST) {
+            double v = ((const double *)b.data)[i];
+            sub = scalar_sub_index(v, false, b.vmin, b.scale, b.binsd, b.bins);
+        } else {
+            sub = dim_sub_index(b, i);
+        }
+        idx += sub * b.stride;
+    }
+    return idx;
+}
+
+// ------------------------------------------------------------------------------------------
+// scatter ops.  SCOPE: __HIP_MEMORY_SCOPE_AGENT (device) or __HIP_MEMORY_SCOPE_WORKGROUP
+// (for LDS, and for the XCC strategy where the RMW is performed by the XCD-local L2).
+// ------------------------------------------------------------------------------------------
+template <int SCOPE, typename T>
+__device__ __forceinline__ void at_add(T *p, T v) { (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, SCOPE); }
+template <int SCOPE, typename T>
+__device__ __forceinline__ void at_max(T *p, T v) { (void)__hip_atomic_fetch_max(p, v, __ATOMIC_RELAXED, SCOPE); }
+template <int SCOPE, typename T>
+__device__ __forceinline__ void at_min(T *p, T v) { (void)__hip_atomic_fetch_min(p, v, __ATOMIC_RELAXED, SCOPE); }
+
+// pow(b, moment) for the small unsigned moments vaex uses (var/std: 2, skew: 3, kurtosis: 4).  The
+// reference calls libm pow (src/agg_sum.cpp:159); repeated multiplication differs from it by < 1 ulp
+// per term, far inside the 1e-12 fp64 tolerance of the sums.
+__device__ __forceinline__ double pow_u(double b, uint32_t m) {
+    double r = 1.0;
+    for (uint32_t k = 0; k < m; ++k) r *= b;
+    return r;
+}
+
+// one aggregator, one row.  `cellp` = address of the cell in the chosen grid copy.
+// CT: "global" copy uses the device cell type; LDS copy uses u32 for counts.
+template <int SCOPE, bool LDS>
+__device__ __forceinline__ void agg_apply(const AggDesc &a, void *base, uint64_t idx, uint64_t raw, bool has_data) {
+    switch (a.kind) {
+    case VXH_AGG_COUNT:
+        if (LDS) at_add<SCOPE, uint32_t>((uint32_t *)base + idx, 1u);
+        else at_add<SCOPE, unsigned long long>((unsigned long long *)base + idx, 1ull);
+        break;
+    case VXH_AGG_SUM:
+    case VXH_AGG_SUM_MOMENT:
+        if (a.cell == VXH_CELL_F64) {
+            double b = raw_as_f64(raw, a.dtype);
+            if (a.kind == VXH_AGG_SUM_MOMENT) b = pow_u(b, a.moment);
+            at_add<SCOPE, double>((double *)base + idx, b);
+        } else {
+            int64_t b = raw_as_i64(raw, a.dtype);
+            if (a.kind == VXH_AGG_SUM_MOMENT) {
+                double bd = (a.cell == VXH_CELL_U64) ? (double)(uint64_t)b : (double)b;
+                double pw = pow_u(bd, a.moment);
+                b = (a.cell == VXH_CELL_U64) ? (int64_t)(uint64_t)pw : (int64_t)pw;
+            }
+            at_add<SCOPE, unsigned long long>((unsigned long long *)base + idx, (unsigned long long)b);
+        }
+        break;
+    case VXH_AGG_MIN:
+    case VXH_AGG_MAX: {
+        const bool mx = a.kind == VXH_AGG_MAX;
+        switch (a.cell) {
+        case VXH_CELL_F64: {
+            double v = raw_as_f64(raw, a.dtype);
+            if (mx) at_max<SCOPE, double>((double *)base + idx, v); else at_min<SCOPE, double>((double *)base + idx, v);
+            break;
+        }
+        case VXH_CELL_F32: {
+            float v = __uint_as_float((uint32_t)raw);
+            if (mx) at_max<SCOPE, float>((float *)base + idx, v); else at_min<SCOPE, float>((float *)base + idx, v);
+            break;
+        }
+        case VXH_CELL_I64: {
+            long long v = (long long)raw_as_i64(raw, a.dtype);
+            if (mx) at_max<SCOPE, long long>((long long *)base + idx, v); else at_min<SCOPE, long long>((long long *)base + idx, v);
+            break;
+        }
+        case VXH_CELL_U64: {
+            unsigned long long v = (unsigned long long)raw;
+            if (mx) at_max<SCOPE, unsigned long long>((unsigned long long *)base + idx, v); else at_min<SCOPE, unsigned long long>((unsigned long long *)base + idx, v);
+            break;
+        }
+        case VXH_CELL_I32: {
+            int v = (int)raw_as_i64(raw, a.dtype);
+            if (mx) at_max<SCOPE, int>((int *)base + idx, v); else at_min<SCOPE, int>((int *)base + idx, v);
+            break;
+        }
+        default: {
+            unsigned v = (unsigned)raw_as_i64(raw, a.dtype);
+            if (mx) at_max<SCOPE, unsigned>((unsigned *)base + idx, v); else at_min<SCOPE, unsigned>((unsigned *)base + idx, v);
+            break;
+        }
+        }
+        break;
+    }
+    default: break;
+    }
+}
+
+__device__ __forceinline__ size_t cell_size_dev(int cell) { return cell >= VXH_CELL_F32 ? 4 : 8; }
+__device__ __forceinline__ size_t lds_cell_size_dev(int kind, int cell) { return kind == VXH_AGG_COUNT ? 4 : cell_size_dev(cell); }
+
+// all aggregators of one row
+template <int STRAT, bool FAST>
+__device__ __forceinline__ void row_aggregate(const BinArgs &A, uint64_t i, uint64_t idx, uint64_t replica, char *lds) {
+    constexpr bool LDS = STRAT == VXH_STRAT_LDS;
+    constexpr int SCOPE = (STRAT == VXH_STRAT_GLOBAL) ? __HIP_MEMORY_SCOPE_AGENT : __HIP_MEMORY_SCOPE_WORKGROUP;
+    for (int k = 0; k < A.nagg; ++k) {
+        const AggDesc &a = A.a[k];
+        if (a.mask != nullptr && a.mask[i] != 1) continue; // aggregator mask: 1 = keep (src/agg_count.cpp:50)
+        uint64_t raw = 0;
+        if (a.data != nullptr) {
+            if (FAST) {
+                raw = ((const uint64_t *)a.data)[i];
+                double v = __longlong_as_double((long long)raw);
+                if (v != v) continue; // NaN rows are skipped (src/agg_sum.cpp:113, agg_count.cpp:56)
+            } else {
+                raw = load_raw(a.data, i, a.dtype, a.flip);
+                if (dt_is_float(a.dtype)) {
+                    double v = raw_as_f64(raw, a.dtype);
+                    if (v != v) continue;
+                }
+            }
+        }
+        void *base;
+        if (LDS) base = lds + a.lds_offset;
+        else base = (char *)a.grid + replica * A.cells * cell_size_dev(a.cell);
+        agg_apply<SCOPE, LDS>(a, base, idx, raw, a.data != nullptr);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K1
+// ------------------------------------------------------------------------------------------
+template <int STRAT, bool FAST>
+__global__ void __launch_bounds__(1024) bin_kernel(const BinArgs A) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    constexpr bool LDS = STRAT == VXH_STRAT_LDS;
+
+    uint64_t replica;
+    if (STRAT == VXH_STRAT_XCC) replica = (uint64_t)xcc_id() * A.replicas_per_xcc + (blockIdx.x >> 3) % A.replicas_per_xcc;
+    else replica = blockIdx.x % A.replicas;
+
+    if (LDS) {
+        // identity-fill the private grids: 0 for counts/sums, the min/max identity is read from replica 0's
+        // neighbour?  no: min/max identities are type limits, regenerated here from the cell type.
+        for (int k = 0; k < A.nagg; ++k) {
+            const AggDesc &a = A.a[k];
+            const size_t cs = lds_cell_size_dev(a.kind, a.cell);
+            char *base = lds + a.lds_offset;
+            uint64_t ident = 0;
+            if (a.kind == VXH_AGG_MIN || a.kind == VXH_AGG_MAX) {
+                const bool mx = a.kind == VXH_AGG_MAX;
+                switch (a.cell) {
+                case VXH_CELL_F64: ident = mx ? 0xfff0000000000000ull : 0x7ff0000000000000ull; break;
+                case VXH_CELL_F32: ident = mx ? 0xff800000u : 0x7f800000u; break;
+                case VXH_CELL_I64: ident = mx ? 0x8000000000000000ull : 0x7fffffffffffffffull; break;
+                case VXH_CELL_U64: ident = mx ? 0ull : ~0ull; break;
+                case VXH_CELL_I32: ident = mx ? 0x80000000u : 0x7fffffffu; break;
+                default: ident = mx ? 0u : 0xffffffffu; break;
+                }
+            }
+            if (cs == 4) for (uint64_t c = threadIdx.x; c < A.cells; c += blockDim.x) ((uint32_t *)base)[c] = (uint32_t)ident;
+            else for (uint64_t c = threadIdx.x; c < A.cells; c += blockDim.x) ((uint64_t *)base)[c] = ident;
+        }
+        __syncthreads();
+    }
+
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // 4 independent rows per thread per trip: 4x the loads in flight before the first dependent op
+    for (; i + 3 * stride < A.n; i += 4 * stride) {
+        uint64_t idx[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) idx[u] = flat_index<FAST>(A, i + u * stride);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) row_aggregate<STRAT, FAST>(A, i + u * stride, idx[u], replica, lds);
+    }
+    for (; i < A.n; i += stride) {
+        uint64_t idx = flat_index<FAST>(A, i);
+        row_aggregate<STRAT, FAST>(A, i, idx, replica, lds);
+    }
+
+    if (LDS) {
+        __syncthreads();
+        // flush the private grids: one device-scope atomic per touched cell
+        for (int k = 0; k < A.nagg; ++k) {
+            const AggDesc &a = A.a[k];
+            char *base = lds + a.lds_offset;
+            char *g = (char *)a.grid + replica * A.cells * cell_size_dev(a.cell);
+            for (uint64_t c = threadIdx.x; c < A.cells; c += blockDim.x) {
+                switch (a.kind) {
+                case VXH_AGG_COUNT: {
+                    uint32_t v = ((uint32_t *)base)[c];
+                    if (v) at_add<__HIP_MEMORY_SCOPE_AGENT, unsigned long long>((unsigned long long *)g + c, (unsigned long long)v);
+                    break;
+                }
+                case VXH_AGG_SUM:
+                case VXH_AGG_SUM_MOMENT:
+                    if (a.cell == VXH_CELL_F64) {
+                        double v = ((double *)base)[c];
+                        if (v != 0.0) at_add<__HIP_MEMORY_SCOPE_AGENT, double>((double *)g + c, v);
+                    } else {
+                        unsigned long long v = ((unsigned long long *)base)[c];
+                        if (v) at_add<__HIP_MEMORY_SCOPE_AGENT, unsigned long long>((unsigned long long *)g + c, v);
+                    }
+                    break;
+                default: {
+                    const bool mx = a.kind == VXH_AGG_MAX;
+                    switch (a.cell) {
+                    case VXH_CELL_F64: { double v = ((double *)base)[c]; if (mx) at_max<__HIP_MEMORY_SCOPE_AGENT, double>((double *)g + c, v); else at_min<__HIP_MEMORY_SCOPE_AGENT, double>((double *)g + c, v); break; }
+                    case VXH_CELL_F32: { float v = ((float *)base)[c]; if (mx) at_max<__HIP_MEMORY_SCOPE_AGENT, float>((float *)g + c, v); else at_min<__HIP_MEMORY_SCOPE_AGENT, float>((float *)g + c, v); break; }
+                    case VXH_CELL_I64: { long long v = ((long long *)base)[c]; if (mx) at_max<__HIP_MEMORY_SCOPE_AGENT, long long>((long long *)g + c, v); else at_min<__HIP_MEMORY_SCOPE_AGENT, long long>((long long *)g + c, v); break; }
+                    case VXH_CELL_U64: { unsigned long long v = ((unsigned long long *)base)[c]; if (mx) at_max<__HIP_MEMORY_SCOPE_AGENT, unsigned long long>((unsigned long long *)g + c, v); else at_min<__HIP_MEMORY_SCOPE_AGENT, unsigned long long>((unsigned long long *)g + c, v); break; }
+                    case VXH_CELL_I32: { int v = ((int *)base)[c]; if (mx) at_max<__HIP_MEMORY_SCOPE_AGENT, int>((int *)g + c, v); else at_min<__HIP_MEMORY_SCOPE_AGENT, int>((int *)g + c, v); break; }
+                    default: { unsigned v = ((unsigned *)base)[c]; if (mx) at_max<__HIP_MEMORY_SCOPE_AGENT, unsigned>((unsigned *)g + c, v); else at_min<__HIP_MEMORY_SCOPE_AGENT, unsigned>((unsigned *)g + c, v); break; }
+                    }
+                }
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// fill / fold
+// ------------------------------------------------------------------------------------------
+__global__ void fill_kernel(void *dst, uint64_t n, int cs, uint64_t value) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    if (cs == 4) for (; i < n; i += stride) ((uint32_t *)dst)[i] = (uint32_t)value;
+    else for (; i < n; i += stride) ((uint64_t *)dst)[i] = value;
+}
+
+template <typename T, int OP> // OP 0 add, 1 min, 2 max
+__global__ void fold_kernel(T *grid, uint64_t cells, int replicas, T identity) {
+    uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (; c < cells; c += stride) {
+        T acc = grid[c];
+        for (int r = 1; r < replicas; ++r) {
+            T v = grid[(uint64_t)r * cells + c];
+            if (OP == 0) acc += v;
+            else if (OP == 1) acc = v < acc ? v : acc;
+            else acc = v > acc ? v : acc;
+            grid[(uint64_t)r * cells + c] = identity;
+        }
+        grid[c] = acc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K5: min/max of one column (legacy statisticNd OP_MIN_MAX, 0-d grid): plain < / > so NaN never wins
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) minmax_kernel(int dtype, int flip, const void *data, const uint8_t *mask, uint64_t n, double *out2) {
+    double mn = __longlong_as_double(0x7ff0000000000000ll), mx = __longlong_as_double((long long)0xfff0000000000000ull);
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        if (mask != nullptr && mask[i] != 1) continue;
+        double v = raw_as_f64(load_raw(data, i, dtype, flip), dtype);
+        if (v < mn) mn = v;
+        if (v > mx) mx = v;
+    }
+    // wave reduce (64 lanes), then one atomic per wave
+    for (int off = 32; off > 0; off >>= 1) {
+        double omn = __shfl_down(mn, off, 64), omx = __shfl_down(mx, off, 64);
+        if (omn < mn) mn = omn;
+        if (omx > mx) mx = omx;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        at_min<__HIP_MEMORY_SCOPE_AGENT, double>(out2, mn);
+        at_max<__HIP_MEMORY_SCOPE_AGENT, double>(out2 + 1, mx);
+    }
+}
+
+} // namespace
+
+size_t vxh_cell_size(int cell) { return cell >= VXH_CELL_F32 ? 4 : 8; }
+size_t vxh_lds_cell_size(int kind, int cell) { return kind == VXH_AGG_COUNT ? 4 : vxh_cell_size(cell); }
+
+void vxh_launch_bin(const BinArgs &args, const LaunchPlan &plan, hipStream_t stream) {
+    dim3 g(plan.blocks), b(plan.block);
+#define VXH_LAUNCH(S, F) hipLaunchKernelGGL((bin_kernel<S, F>), g, b, plan.lds_bytes, stream, args)
+    if (plan.strategy == VXH_STRAT_LDS) { if (plan.fast_f64) VXH_LAUNCH(VXH_STRAT_LDS, true); else VXH_LAUNCH(VXH_STRAT_LDS, false); }
+    else if (plan.strategy == VXH_STRAT_XCC) { if (plan.fast_f64) VXH_LAUNCH(VXH_STRAT_XCC, true); else VXH_LAUNCH(VXH_STRAT_XCC, false); }
+    else { if (plan.fast_f64) VXH_LAUNCH(VXH_STRAT_GLOBAL, true); else VXH_LAUNCH(VXH_STRAT_GLOBAL, false); }
+#undef VXH_LAUNCH
+}
+
+void vxh_launch_fill(void *dst, uint64_t ncells, int cell, const void *value8, hipStream_t stream) {
+    uint64_t v;
+    memcpy(&v, value8, 8);
+    int cs = (int)vxh_cell_size(cell);
+    uint64_t blocks = (ncells + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks == 0) blocks = 1;
+    hipLaunchKernelGGL(fill_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, dst, ncells, cs, v);
+}
+
+void vxh_launch_fold(void *grid, uint64_t cells, int replicas, int cell, int kind, const void *identity8, hipStream_t stream) {
+    if (replicas <= 1) return;
+    uint64_t blocks = (cells + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks == 0) blocks = 1;
+    dim3 g((unsigned)blocks), b(256);
+    const int op = kind == VXH_AGG_MIN ? 1 : (kind == VXH_AGG_MAX ? 2 : 0);
+#define VXH_FOLD(T)                                                                                                    \
+    {                                                                                                                  \
+        T ident;                                                                                                       \
+        memcpy(&ident, identity8, sizeof(T));                                                                          \
+        if (op == 0) hipLaunchKernelGGL((fold_kernel<T, 0>), g, b, 0, stream, (T *)grid, cells, replicas, ident);       \
+        else if (op == 1) hipLaunchKernelGGL((fold_kernel<T, 1>), g, b, 0, stream, (T *)grid, cells, replicas, ident);  \
+        else hipLaunchKernelGGL((fold_kernel<T, 2>), g, b, 0, stream, (T *)grid, cells, replicas, ident);               \
+    }
+    switch (cell) {
+    case VXH_CELL_I64: VXH_FOLD(long long) break;
+    case VXH_CELL_F64: VXH_FOLD(double) break;
+    case VXH_CELL_U64: VXH_FOLD(unsigned long long) break;
+    case VXH_CELL_F32: VXH_FOLD(float) break;
+    case VXH_CELL_I32: VXH_FOLD(int) break;
+    default: VXH_FOLD(unsigned) break;
+    }
+#undef VXH_FOLD
+}
+
+void vxh_launch_minmax(int dtype, int flip, const void *data, const uint8_t *mask, uint64_t n, double *out2_dev, hipStream_t stream) {
+    uint64_t blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks == 0) blocks = 1;
+    hipLaunchKernelGGL(minmax_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, dtype, flip, data, mask, n, out2_dev);
+}

@@ -1,0 +1,77 @@
+// Kernel-side descriptors shared by the launch code (vxh_api.hip) and the kernels
+// (vxh_kernels.hip).  Everything here is passed BY VALUE in the kernarg segment so that the
+// per-dimension / per-aggregator parameters are read with scalar loads.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/vaex_hip.h"
+
+#define VXH_MAX_DIM 16 // reference: MAX_DIM = 16 (src/agg.hpp:29)
+#define VXH_MAX_AGG 12 // aggregators fused per launch; longer lists are split over several launches
+
+enum vxh_binner_kind : uint8_t { VXH_BIN_SCALAR = 0, VXH_BIN_ORDINAL = 1, VXH_BIN_HASH = 2 };
+
+// device cell type of an aggregator grid
+enum vxh_cell : uint8_t { VXH_CELL_I64 = 0, VXH_CELL_F64 = 1, VXH_CELL_U64 = 2, VXH_CELL_F32 = 3, VXH_CELL_I32 = 4, VXH_CELL_U32 = 5 };
+
+struct BinnerDesc {
+    const void *data;    // n elements of dtype
+    const uint8_t *mask; // 1 = masked, or null
+    double vmin;         // scalar
+    double scale;        // scalar: 1/(vmax-vmin), computed on the host in double like binners.cpp:16
+    double binsd;        // scalar: (double)bins
+    uint64_t bins;       // scalar: bins; ordinal/hash: ordinal_count
+    int64_t min_value;   // ordinal
+    uint64_t stride;     // cells
+    const int64_t *hkeys; // hash: table keys
+    const int64_t *hvals; // hash: table ordinals (-1 = empty)
+    uint64_t hmask;       // hash: capacity-1
+    int64_t null_bin;     // hash: cell for masked rows
+    uint8_t kind, dtype, flip, allow_other, invert;
+};
+
+struct AggDesc {
+    const void *data;    // n elements of dtype, or null (count(*))
+    const uint8_t *mask; // 1 = keep, or null
+    void *grid;          // replica 0 of the device grid; replica r at grid + r*cells
+    uint32_t moment;
+    uint32_t lds_offset; // byte offset of this aggregator's private grid in LDS (LDS variants)
+    uint8_t kind, dtype, flip, cell;
+};
+
+struct BinArgs {
+    uint64_t n;     // rows in this launch
+    uint64_t cells; // length1d
+    int32_t ndim;
+    int32_t nagg;
+    int32_t replicas;        // device grid replicas (>=1)
+    int32_t replicas_per_xcc; // XCC strategy: replicas = 8 * replicas_per_xcc
+    BinnerDesc b[VXH_MAX_DIM];
+    AggDesc a[VXH_MAX_AGG];
+};
+
+enum vxh_strategy : int {
+    VXH_STRAT_AUTO = 0,
+    VXH_STRAT_GLOBAL = 1, // device-scope atomics straight into replica (blockIdx % replicas)
+    VXH_STRAT_XCC = 2,    // L2-local (workgroup-scope) atomics into the replica set of the block's own XCD
+    VXH_STRAT_LDS = 3,    // workgroup-private grids in LDS, flushed once per block
+};
+
+struct LaunchPlan {
+    int strategy;
+    int block;     // threads per workgroup
+    int blocks;    // workgroups
+    size_t lds_bytes;
+    bool fast_f64; // all binners scalar f64 native unmasked, all aggregator inputs f64 native / absent
+    const char *name;
+};
+
+// implemented in vxh_kernels.hip
+void vxh_launch_bin(const BinArgs &args, const LaunchPlan &plan, hipStream_t stream);
+void vxh_launch_fill(void *dst, uint64_t ncells, int cell, const void *value8, hipStream_t stream);
+// dst[c] = fold(replica_0[c] .. replica_{R-1}[c]); replicas 1.. are reset to the identity
+void vxh_launch_fold(void *grid, uint64_t cells, int replicas, int cell, int kind, const void *identity8, hipStream_t stream);
+void vxh_launch_minmax(int dtype, int flip, const void *data, const uint8_t *mask, uint64_t n, double *out2_dev, hipStream_t stream);
+size_t vxh_cell_size(int cell);
+size_t vxh_lds_cell_size(int kind, int cell);

@@ -1,0 +1,92 @@
+"""Multi-GPU reduce of aggregator grids: rows are sharded over ranks (one process per GPU), every
+rank bins its shard into private grids, and the per-rank grids are combined with ONE RCCL
+all-reduce per grid over xGMI — the cross-rank form of Aggregator::merge
+(/root/reference/packages/vaex-core/src/agg_count.cpp:15-23, agg_sum.cpp:72-79,
+agg_minmax.cpp:19-26) driven by TaskPartAggregation.reduce (vaex/cpu.py:788-796).
+
+Messages are tiny (259x259 cells x 8 B = 0.5 MB per grid) against 7 x ~153 GB/s xGMI links, so the
+all-reduce is latency-bound; int64 counts reduce exactly, fp64 sums in the ring's fixed order.
+The backend is whatever torch.distributed was initialised with: "nccl" (= RCCL) on GPUs, "gloo" in
+the CPU tests (which exercise the same code path on host copies of the grids).
+"""
+import numpy as np
+
+_KIND_OP = {0: "sum", 1: "sum", 2: "sum", 3: "min", 4: "max"}
+_CLASS_KIND = {"AggCount_": 0, "AggSum_": 1, "AggSumMoment_": 2, "AggMin_": 3, "AggMax_": 4}
+
+
+def agg_reduce_op(agg):
+    """'sum' | 'min' | 'max' for an aggregator object of the superagg surface (by class name)."""
+    name = type(agg).__name__
+    for prefix, kind in sorted(_CLASS_KIND.items(), key=lambda kv: -len(kv[0])):
+        if name.startswith(prefix):
+            return _KIND_OP[kind]
+    raise TypeError(f"not an aggregator: {name}")
+
+
+def _reduce_op(name):
+    import torch.distributed as dist
+    return {"sum": dist.ReduceOp.SUM, "min": dist.ReduceOp.MIN, "max": dist.ReduceOp.MAX}[name]
+
+
+def allreduce_aggs(aggs, group=None):
+    """In-place all-reduce of the device grids of `aggs` across the process group (RCCL).
+
+    After the call every rank's aggregators hold the global result (get_result() returns it)."""
+    import torch
+    import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    works = []
+    tensors = []
+    for agg in aggs:
+        op = agg_reduce_op(agg)
+        iface = agg.__cuda_array_interface__  # folds the replicas; device pointer of the result grid
+        t = torch.as_tensor(_Wrap(iface, op), device="cuda")
+        tensors.append(t)
+        works.append(dist.all_reduce(t, op=_reduce_op(op), group=group, async_op=True))
+    for w in works:
+        w.wait()
+    torch.cuda.synchronize()
+    for agg in aggs:
+        agg.device_touch()
+
+
+class _Wrap:
+    """Adapter so torch can alias the library-owned grid: uint64 cells are presented as int64 (the sum
+    of the two's-complement bit patterns is the same)."""
+
+    def __init__(self, iface, op):
+        iface = dict(iface)
+        if iface["typestr"] == "<u8":
+            if op != "sum":
+                raise NotImplementedError("min/max all-reduce of uint64 grids: use allreduce_results()")
+            iface["typestr"] = "<i8"
+        self.__cuda_array_interface__ = iface
+
+
+def allreduce_results(results, ops, group=None):
+    """All-reduce HOST result arrays (list of ndarrays) — used by the gloo CPU tests and as the fallback
+    for cell types RCCL cannot reduce.  Returns new arrays."""
+    import torch
+    import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return [np.array(r) for r in results]
+    out = []
+    for r, op in zip(results, ops):
+        a = np.ascontiguousarray(r)
+        view = a.view(np.int64) if a.dtype == np.uint64 else a
+        t = torch.from_numpy(view.copy())
+        if dist.get_backend(group) == "nccl":
+            t = t.cuda()
+        dist.all_reduce(t, op=_reduce_op(op), group=group)
+        res = t.cpu().numpy()
+        out.append(res.view(np.uint64).reshape(r.shape) if a.dtype == np.uint64 else res.reshape(r.shape))
+    return out
+
+
+def shard_rows(n, rank, world):
+    """Contiguous row range [i1, i2) of `rank` (rows are independent: SURVEY §8e)."""
+    per = (n + world - 1) // world
+    i1 = min(n, rank * per)
+    return i1, min(n, i1 + per)
