@@ -229,8 +229,11 @@ static void agg_alloc_device(vxh_agg *a) {
     const uint64_t cells = a->grid->length1d;
     int R = (int)c.cfg_replicas;
     if (R <= 0) {
-        // auto: one replica per XCD unless the grid is huge (>= 64 Mi cells: 8 replicas of 8 B cells = 4 GiB)
-        R = cells * 8ull * 8ull <= (1ull << 32) ? 8 : 1;
+        // auto: one replica per workgroup group of the LDS strategy (plain, atomic-free flush) while that stays
+        // under 256 MiB; else one per XCD; a single one for huge grids (>= 64 Mi cells)
+        const uint64_t lds_groups = (uint64_t)std::max<int64_t>(8, c.cfg_lds_replicas > 0 ? c.cfg_lds_replicas : (int64_t)c.cus * 2);
+        if (cells * 8ull * lds_groups <= (256ull << 20)) R = (int)lds_groups;
+        else R = cells * 8ull * 8ull <= (1ull << 32) ? 8 : 1;
     }
     a->replicas = R;
     const size_t cs = vxh_cell_size(a->cell);
@@ -346,7 +349,15 @@ static size_t padded(size_t b) { return (b + 255) & ~(size_t)255; }
 // ------------------------------------------------------------------------------------------
 // launch planning
 // ------------------------------------------------------------------------------------------
-static LaunchPlan make_plan(const BinArgs &A, BinArgs &out, uint64_t n) {
+// Measured on MI355X (profiles/r01_microbench_v1.txt): the CUs ingest ~6.2 TB/s of streamed rows; HBM-side
+// atomics retire ~22e9/s chip-wide whatever their width, scope or replica count; LDS atomics keep up with
+// the stream.  So: grids (or 1/S slabs of them) live in LDS whenever S * bytes_per_row / 6.2e12 is cheaper
+// than atomics_per_row / 22e9, otherwise rows scatter straight to HBM replicas.
+static const double kIngestBytesPerSec = 6.0e12;
+static const double kHbmAtomicsPerSec = 22.0e9;
+static const size_t kLdsMax = 160 * 1024;
+
+static LaunchPlan make_plan(const BinArgs &A, BinArgs &out, uint64_t n, double bytes_per_row, bool exclusive) {
     Context &c = ctx();
     LaunchPlan p{};
     out = A;
@@ -362,36 +373,52 @@ static LaunchPlan make_plan(const BinArgs &A, BinArgs &out, uint64_t n) {
     }
     p.fast_f64 = fast;
 
-    // LDS footprint of workgroup-private grids
-    size_t lds = 0;
-    for (int k = 0; k < A.nagg; k++) {
-        out.a[k].lds_offset = (uint32_t)lds;
-        lds += (A.cells * vxh_lds_cell_size(A.a[k].kind, A.a[k].cell) + 15) & ~(size_t)15;
-    }
-    const size_t lds_max = 160 * 1024;
+    // LDS bytes per cell over all aggregators -> number of interleaved slabs S (power of two)
+    size_t per_cell = 0;
+    for (int k = 0; k < A.nagg; k++) per_cell += vxh_lds_cell_size(A.a[k].kind, A.a[k].cell);
+    const size_t lds_budget = kLdsMax - 16 * (size_t)A.nagg - 64;
+    int slab_log2 = 0;
+    while (slab_log2 < 5 && ((A.cells + (1ull << slab_log2) - 1) >> slab_log2) * per_cell > lds_budget) slab_log2++;
+    const uint64_t slab_cells = (A.cells + (1ull << slab_log2) - 1) >> slab_log2;
+    const bool lds_fits = slab_cells * per_cell <= lds_budget && A.cells < (1ull << 31);
+    if (c.cfg_slab_log2 >= 0 && c.cfg_slab_log2 >= slab_log2 && c.cfg_slab_log2 <= 5) slab_log2 = (int)c.cfg_slab_log2;
+
     int strategy = (int)c.cfg_strategy;
     if (strategy == VXH_STRAT_AUTO) {
-        // LDS pays when the per-workgroup init+flush (O(cells)) is small next to the rows it handles
-        if (lds <= lds_max && n >= 64 * A.cells) strategy = VXH_STRAT_LDS;
+        const double cost_lds = (double)(1 << slab_log2) * bytes_per_row / kIngestBytesPerSec;
+        const double cost_atomic = (double)A.nagg / kHbmAtomicsPerSec + bytes_per_row / kIngestBytesPerSec;
+        // the per-workgroup init + flush (O(cells)) must be small next to the rows a workgroup handles
+        if (lds_fits && cost_lds < cost_atomic && n >= 16 * A.cells) strategy = VXH_STRAT_LDS;
         else strategy = VXH_STRAT_XCC;
     }
-    if (strategy == VXH_STRAT_LDS && lds > lds_max) strategy = VXH_STRAT_XCC;
+    if (strategy == VXH_STRAT_LDS && !lds_fits) strategy = VXH_STRAT_XCC;
     if (strategy == VXH_STRAT_XCC && (A.replicas < 8 || A.replicas % 8)) strategy = VXH_STRAT_GLOBAL;
     p.strategy = strategy;
     out.replicas_per_xcc = strategy == VXH_STRAT_XCC ? A.replicas / 8 : 1;
 
     if (strategy == VXH_STRAT_LDS) {
+        const int S = 1 << slab_log2;
+        size_t lds = 0;
+        for (int k = 0; k < A.nagg; k++) {
+            out.a[k].lds_offset = (uint32_t)lds;
+            lds += (slab_cells * vxh_lds_cell_size(A.a[k].kind, A.a[k].cell) + 15) & ~(size_t)15;
+        }
         p.lds_bytes = lds;
-        int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, lds_max / std::max<size_t>(lds, 1)));
-        p.block = c.cfg_block > 0 ? (int)c.cfg_block : (per_cu >= 4 ? 512 : 1024);
-        // keep <= 2048 threads per CU
-        per_cu = std::min(per_cu, 2048 / p.block);
-        if (per_cu < 1) per_cu = 1;
+        // workgroups per CU: as many as LDS allows, at most 2048 threads per CU
+        int per_cu = (int)std::max<size_t>(1, std::min<size_t>(4, kLdsMax / std::max<size_t>(lds, 1)));
+        p.block = c.cfg_block > 0 ? (int)c.cfg_block : (per_cu >= 2 ? 512 : 1024);
+        per_cu = std::max(1, std::min(per_cu, 2048 / p.block));
+        // ngroups * S workgroups; ngroups a multiple of 8 (one group per XCD at least)
+        uint64_t max_blocks = c.cfg_blocks > 0 ? (uint64_t)c.cfg_blocks : (uint64_t)c.cus * per_cu;
+        uint64_t ngroups = std::max<uint64_t>(8, (max_blocks / S) / 8 * 8);
         uint64_t want = (n + (uint64_t)p.block * 4 - 1) / ((uint64_t)p.block * 4);
-        uint64_t cap = (uint64_t)c.cus * per_cu;
-        if (c.cfg_blocks > 0) cap = (uint64_t)c.cfg_blocks;
-        p.blocks = (int)std::max<uint64_t>(1, std::min(want, cap));
-        p.name = fast ? "bin_lds_f64" : "bin_lds_generic";
+        want = std::max<uint64_t>(8, (want + 7) / 8 * 8);
+        ngroups = std::min(ngroups, want);
+        p.blocks = (int)(ngroups * S);
+        out.slab_log2 = slab_log2;
+        out.ngroups = (int)ngroups;
+        out.flush_plain = (exclusive && (uint64_t)A.replicas >= ngroups) ? 1 : 0;
+        p.name = S > 1 ? (fast ? "bin_lds_slab_f64" : "bin_lds_slab_generic") : (fast ? "bin_lds_f64" : "bin_lds_generic");
     } else {
         p.lds_bytes = 0;
         p.block = c.cfg_block > 0 ? (int)c.cfg_block : 256;
@@ -458,6 +485,8 @@ int vxh_config_set(const char *key, int64_t value) {
     else if (k == "block") c.cfg_block = value;
     else if (k == "blocks") c.cfg_blocks = value;
     else if (k == "stage_bytes") c.cfg_stage_bytes = value;
+    else if (k == "slab_log2") c.cfg_slab_log2 = value;
+    else if (k == "lds_replicas") c.cfg_lds_replicas = value;
     else throw std::runtime_error("unknown config key: " + k);
     VXH_API_END
 }
@@ -471,6 +500,8 @@ int vxh_config_get(const char *key, int64_t *value) {
     else if (k == "block") *value = c.cfg_block;
     else if (k == "blocks") *value = c.cfg_blocks;
     else if (k == "stage_bytes") *value = c.cfg_stage_bytes;
+    else if (k == "slab_log2") *value = c.cfg_slab_log2;
+    else if (k == "lds_replicas") *value = c.cfg_lds_replicas;
     else if (k == "cus") { ensure_device_ready(); *value = c.cus; }
     else throw std::runtime_error("unknown config key: " + k);
     VXH_API_END
@@ -662,6 +693,25 @@ int vxh_grid_bin(vxh_grid *grid, int thread, vxh_agg *const *aggs, int n_aggs, u
         return stager.put(sd.ptr, length * elem);
     };
 
+    // distinct bytes streamed per row (an array registered twice, e.g. count(x) binby x, is read once)
+    double bytes_per_row = 0;
+    {
+        std::map<const void *, size_t> uniq;
+        for (int d = 0; d < ndim; d++) {
+            vxh_binner *b = grid->binners[d];
+            uniq[b->data[thread].ptr] = kDtypeSize[b->dtype];
+            if (b->mask[thread].ptr) uniq[b->mask[thread].ptr] = 1;
+        }
+        for (int k = 0; k < n_aggs; k++) {
+            if (aggs[k]->data[thread].ptr) uniq[aggs[k]->data[thread].ptr] = kDtypeSize[aggs[k]->dtype];
+            if (aggs[k]->mask[thread].ptr) uniq[aggs[k]->mask[thread].ptr] = 1;
+        }
+        for (auto &kv : uniq) bytes_per_row += (double)kv.second;
+    }
+    // single-slot aggregators are only ever written from one stream: their LDS flush can skip the atomics
+    bool exclusive = true;
+    for (int k = 0; k < n_aggs; k++) exclusive = exclusive && aggs[k]->threads == 1;
+
     BinArgs base{};
     base.n = length;
     base.cells = grid->length1d;
@@ -725,7 +775,7 @@ int vxh_grid_bin(vxh_grid *grid, int thread, vxh_agg *const *aggs, int n_aggs, u
                 }
             }
             BinArgs planned;
-            LaunchPlan plan = make_plan(L, planned, rn);
+            LaunchPlan plan = make_plan(L, planned, rn, bytes_per_row, exclusive);
             vxh_launch_bin(planned, plan, slot.stream);
             HIP_CHECK(hipGetLastError());
             slot.last_kernel = plan.name;

@@ -87,6 +87,8 @@ struct Context {
     int64_t cfg_block = 0;
     int64_t cfg_blocks = 0;
     int64_t cfg_stage_bytes = 64 << 20;
+    int64_t cfg_slab_log2 = -1;   // -1 = auto
+    int64_t cfg_lds_replicas = 0; // 0 = auto
 };
 
 Context &ctx();

@@ -259,11 +259,82 @@ __device__ __forceinline__ void agg_apply(const AggDesc &a, void *base, uint64_t
 __device__ __forceinline__ size_t cell_size_dev(int cell) { return cell >= VXH_CELL_F32 ? 4 : 8; }
 __device__ __forceinline__ size_t lds_cell_size_dev(int kind, int cell) { return kind == VXH_AGG_COUNT ? 4 : cell_size_dev(cell); }
 
+__device__ __forceinline__ uint64_t identity_bits(int kind, int cell) {
+    if (kind != VXH_AGG_MIN && kind != VXH_AGG_MAX) return 0;
+    const bool mx = kind == VXH_AGG_MAX;
+    switch (cell) {
+    case VXH_CELL_F64: return mx ? 0xfff0000000000000ull : 0x7ff0000000000000ull;
+    case VXH_CELL_F32: return mx ? 0xff800000u : 0x7f800000u;
+    case VXH_CELL_I64: return mx ? 0x8000000000000000ull : 0x7fffffffffffffffull;
+    case VXH_CELL_U64: return mx ? 0ull : ~0ull;
+    case VXH_CELL_I32: return mx ? 0x80000000u : 0x7fffffffu;
+    default: return mx ? 0u : 0xffffffffu;
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ void flush_minmax(T *g, T v, bool mx, bool plain) {
+    if (plain) {
+        T cur = *g;
+        *g = mx ? (v > cur ? v : cur) : (v < cur ? v : cur);
+    } else if (mx) {
+        at_max<__HIP_MEMORY_SCOPE_AGENT, T>(g, v);
+    } else {
+        at_min<__HIP_MEMORY_SCOPE_AGENT, T>(g, v);
+    }
+}
+
+// LDS cell c of aggregator a -> HBM cell gc of the chosen replica
+__device__ __forceinline__ void flush_cell(const AggDesc &a, char *lds_base, uint64_t c, char *g, uint64_t gc, bool plain) {
+    switch (a.kind) {
+    case VXH_AGG_COUNT: {
+        uint32_t v = ((uint32_t *)lds_base)[c];
+        if (v) {
+            if (plain) ((unsigned long long *)g)[gc] += v;
+            else at_add<__HIP_MEMORY_SCOPE_AGENT, unsigned long long>((unsigned long long *)g + gc, (unsigned long long)v);
+        }
+        break;
+    }
+    case VXH_AGG_SUM:
+    case VXH_AGG_SUM_MOMENT:
+        if (a.cell == VXH_CELL_F64) {
+            double v = ((double *)lds_base)[c];
+            if (v != 0.0) {
+                if (plain) ((double *)g)[gc] += v;
+                else at_add<__HIP_MEMORY_SCOPE_AGENT, double>((double *)g + gc, v);
+            }
+        } else {
+            unsigned long long v = ((unsigned long long *)lds_base)[c];
+            if (v) {
+                if (plain) ((unsigned long long *)g)[gc] += v;
+                else at_add<__HIP_MEMORY_SCOPE_AGENT, unsigned long long>((unsigned long long *)g + gc, v);
+            }
+        }
+        break;
+    default: {
+        const bool mx = a.kind == VXH_AGG_MAX;
+        switch (a.cell) {
+        case VXH_CELL_F64: flush_minmax<double>((double *)g + gc, ((double *)lds_base)[c], mx, plain); break;
+        case VXH_CELL_F32: flush_minmax<float>((float *)g + gc, ((float *)lds_base)[c], mx, plain); break;
+        case VXH_CELL_I64: flush_minmax<long long>((long long *)g + gc, ((long long *)lds_base)[c], mx, plain); break;
+        case VXH_CELL_U64: flush_minmax<unsigned long long>((unsigned long long *)g + gc, ((unsigned long long *)lds_base)[c], mx, plain); break;
+        case VXH_CELL_I32: flush_minmax<int>((int *)g + gc, ((int *)lds_base)[c], mx, plain); break;
+        default: flush_minmax<unsigned>((unsigned *)g + gc, ((unsigned *)lds_base)[c], mx, plain); break;
+        }
+    }
+    }
+}
+
 // all aggregators of one row
 template <int STRAT, bool FAST>
-__device__ __forceinline__ void row_aggregate(const BinArgs &A, uint64_t i, uint64_t idx, uint64_t replica, char *lds) {
+__device__ __forceinline__ void row_aggregate(const BinArgs &A, uint64_t i, uint64_t idx, uint64_t replica, char *lds, uint32_t slab) {
     constexpr bool LDS = STRAT == VXH_STRAT_LDS;
     constexpr int SCOPE = (STRAT == VXH_STRAT_GLOBAL) ? __HIP_MEMORY_SCOPE_AGENT : __HIP_MEMORY_SCOPE_WORKGROUP;
+    if (LDS) {
+        // this workgroup owns the cells with (cell mod S) == slab; they live at LDS index cell / S
+        if (((uint32_t)idx & ((1u << A.slab_log2) - 1u)) != slab) return;
+        idx >>= A.slab_log2;
+    }
     for (int k = 0; k < A.nagg; ++k) {
         const AggDesc &a = A.a[k];
         if (a.mask != nullptr && a.mask[i] != 1) continue; // aggregator mask: 1 = keep (src/agg_count.cpp:50)
@@ -291,91 +362,72 @@ __device__ __forceinline__ void row_aggregate(const BinArgs &A, uint64_t i, uint
 // ------------------------------------------------------------------------------------------
 // K1
 // ------------------------------------------------------------------------------------------
+// LDS strategy geometry: gridDim.x = ngroups * S workgroups, S = 2^slab_log2 interleaved slabs.  The S
+// workgroups of a group walk the SAME rows (each keeps only the cells of its slab), and are laid out so
+// that — with the dispatcher's observed round-robin of workgroups over the 8 XCDs — they share an XCD
+// and therefore its L2 (performance only; correctness never depends on placement):
+//   xcd = b & 7, local = b >> 3, slab = local & (S-1), group = (local >> slab_log2) * 8 + xcd.
 template <int STRAT, bool FAST>
 __global__ void __launch_bounds__(1024) bin_kernel(const BinArgs A) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr bool LDS = STRAT == VXH_STRAT_LDS;
 
     uint64_t replica;
-    if (STRAT == VXH_STRAT_XCC) replica = (uint64_t)xcc_id() * A.replicas_per_xcc + (blockIdx.x >> 3) % A.replicas_per_xcc;
-    else replica = blockIdx.x % A.replicas;
+    uint32_t slab = 0, group = blockIdx.x, ngroups = gridDim.x;
+    uint64_t slab_cells = A.cells;
+    if (LDS) {
+        const uint32_t local = blockIdx.x >> 3;
+        slab = local & ((1u << A.slab_log2) - 1u);
+        group = (local >> A.slab_log2) * 8u + (blockIdx.x & 7u);
+        ngroups = (uint32_t)A.ngroups;
+        slab_cells = (A.cells + (1ull << A.slab_log2) - 1) >> A.slab_log2;
+        replica = A.flush_plain ? group : group % (uint32_t)A.replicas;
+    } else if (STRAT == VXH_STRAT_XCC) {
+        replica = (uint64_t)xcc_id() * A.replicas_per_xcc + (blockIdx.x >> 3) % A.replicas_per_xcc;
+    } else {
+        replica = blockIdx.x % A.replicas;
+    }
 
     if (LDS) {
-        // identity-fill the private grids: 0 for counts/sums, the min/max identity is read from replica 0's
-        // neighbour?  no: min/max identities are type limits, regenerated here from the cell type.
+        // identity-fill the private grids: 0 for counts/sums, the type's limit for min/max
         for (int k = 0; k < A.nagg; ++k) {
             const AggDesc &a = A.a[k];
             const size_t cs = lds_cell_size_dev(a.kind, a.cell);
             char *base = lds + a.lds_offset;
-            uint64_t ident = 0;
-            if (a.kind == VXH_AGG_MIN || a.kind == VXH_AGG_MAX) {
-                const bool mx = a.kind == VXH_AGG_MAX;
-                switch (a.cell) {
-                case VXH_CELL_F64: ident = mx ? 0xfff0000000000000ull : 0x7ff0000000000000ull; break;
-                case VXH_CELL_F32: ident = mx ? 0xff800000u : 0x7f800000u; break;
-                case VXH_CELL_I64: ident = mx ? 0x8000000000000000ull : 0x7fffffffffffffffull; break;
-                case VXH_CELL_U64: ident = mx ? 0ull : ~0ull; break;
-                case VXH_CELL_I32: ident = mx ? 0x80000000u : 0x7fffffffu; break;
-                default: ident = mx ? 0u : 0xffffffffu; break;
-                }
-            }
-            if (cs == 4) for (uint64_t c = threadIdx.x; c < A.cells; c += blockDim.x) ((uint32_t *)base)[c] = (uint32_t)ident;
-            else for (uint64_t c = threadIdx.x; c < A.cells; c += blockDim.x) ((uint64_t *)base)[c] = ident;
+            const uint64_t ident = identity_bits(a.kind, a.cell);
+            if (cs == 4) for (uint64_t c = threadIdx.x; c < slab_cells; c += blockDim.x) ((uint32_t *)base)[c] = (uint32_t)ident;
+            else for (uint64_t c = threadIdx.x; c < slab_cells; c += blockDim.x) ((uint64_t *)base)[c] = ident;
         }
         __syncthreads();
     }
 
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t stride = (uint64_t)ngroups * blockDim.x;
+    uint64_t i = (uint64_t)group * blockDim.x + threadIdx.x;
     // 4 independent rows per thread per trip: 4x the loads in flight before the first dependent op
     for (; i + 3 * stride < A.n; i += 4 * stride) {
         uint64_t idx[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) idx[u] = flat_index<FAST>(A, i + u * stride);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) row_aggregate<STRAT, FAST>(A, i + u * stride, idx[u], replica, lds);
+        for (int u = 0; u < 4; ++u) row_aggregate<STRAT, FAST>(A, i + u * stride, idx[u], replica, lds, slab);
     }
     for (; i < A.n; i += stride) {
         uint64_t idx = flat_index<FAST>(A, i);
-        row_aggregate<STRAT, FAST>(A, i, idx, replica, lds);
+        row_aggregate<STRAT, FAST>(A, i, idx, replica, lds, slab);
     }
 
     if (LDS) {
         __syncthreads();
-        // flush the private grids: one device-scope atomic per touched cell
+        // flush the private slab into replica `replica` of the HBM grid: plain read-modify-write when this
+        // workgroup is the replica's only writer (flush_plain), device-scope atomics otherwise
         for (int k = 0; k < A.nagg; ++k) {
             const AggDesc &a = A.a[k];
             char *base = lds + a.lds_offset;
             char *g = (char *)a.grid + replica * A.cells * cell_size_dev(a.cell);
-            for (uint64_t c = threadIdx.x; c < A.cells; c += blockDim.x) {
-                switch (a.kind) {
-                case VXH_AGG_COUNT: {
-                    uint32_t v = ((uint32_t *)base)[c];
-                    if (v) at_add<__HIP_MEMORY_SCOPE_AGENT, unsigned long long>((unsigned long long *)g + c, (unsigned long long)v);
-                    break;
-                }
-                case VXH_AGG_SUM:
-                case VXH_AGG_SUM_MOMENT:
-                    if (a.cell == VXH_CELL_F64) {
-                        double v = ((double *)base)[c];
-                        if (v != 0.0) at_add<__HIP_MEMORY_SCOPE_AGENT, double>((double *)g + c, v);
-                    } else {
-                        unsigned long long v = ((unsigned long long *)base)[c];
-                        if (v) at_add<__HIP_MEMORY_SCOPE_AGENT, unsigned long long>((unsigned long long *)g + c, v);
-                    }
-                    break;
-                default: {
-                    const bool mx = a.kind == VXH_AGG_MAX;
-                    switch (a.cell) {
-                    case VXH_CELL_F64: { double v = ((double *)base)[c]; if (mx) at_max<__HIP_MEMORY_SCOPE_AGENT, double>((double *)g + c, v); else at_min<__HIP_MEMORY_SCOPE_AGENT, double>((double *)g + c, v); break; }
-                    case VXH_CELL_F32: { float v = ((float *)base)[c]; if (mx) at_max<__HIP_MEMORY_SCOPE_AGENT, float>((float *)g + c, v); else at_min<__HIP_MEMORY_SCOPE_AGENT, float>((float *)g + c, v); break; }
-                    case VXH_CELL_I64: { long long v = ((long long *)base)[c]; if (mx) at_max<__HIP_MEMORY_SCOPE_AGENT, long long>((long long *)g + c, v); else at_min<__HIP_MEMORY_SCOPE_AGENT, long long>((long long *)g + c, v); break; }
-                    case VXH_CELL_U64: { unsigned long long v = ((unsigned long long *)base)[c]; if (mx) at_max<__HIP_MEMORY_SCOPE_AGENT, unsigned long long>((unsigned long long *)g + c, v); else at_min<__HIP_MEMORY_SCOPE_AGENT, unsigned long long>((unsigned long long *)g + c, v); break; }
-                    case VXH_CELL_I32: { int v = ((int *)base)[c]; if (mx) at_max<__HIP_MEMORY_SCOPE_AGENT, int>((int *)g + c, v); else at_min<__HIP_MEMORY_SCOPE_AGENT, int>((int *)g + c, v); break; }
-                    default: { unsigned v = ((unsigned *)base)[c]; if (mx) at_max<__HIP_MEMORY_SCOPE_AGENT, unsigned>((unsigned *)g + c, v); else at_min<__HIP_MEMORY_SCOPE_AGENT, unsigned>((unsigned *)g + c, v); break; }
-                    }
-                }
-                }
+            for (uint64_t c = threadIdx.x; c < slab_cells; c += blockDim.x) {
+                const uint64_t gc = (c << A.slab_log2) + slab;
+                if (gc >= A.cells) continue;
+                flush_cell(a, base, c, g, gc, A.flush_plain != 0);
             }
         }
     }

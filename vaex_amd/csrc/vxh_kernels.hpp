@@ -47,6 +47,10 @@ struct BinArgs {
     int32_t nagg;
     int32_t replicas;        // device grid replicas (>=1)
     int32_t replicas_per_xcc; // XCC strategy: replicas = 8 * replicas_per_xcc
+    int32_t slab_log2;       // LDS strategy: the grid is cut into S = 2^slab_log2 interleaved slabs (cell & (S-1))
+    int32_t ngroups;         // LDS strategy: gridDim.x = ngroups * S; the S workgroups of a group read the same rows
+    int32_t flush_plain;     // LDS strategy: flush with plain read-add-write into replica `group` (exclusive owner)
+    int32_t reserved_;
     BinnerDesc b[VXH_MAX_DIM];
     AggDesc a[VXH_MAX_AGG];
 };
@@ -55,7 +59,7 @@ enum vxh_strategy : int {
     VXH_STRAT_AUTO = 0,
     VXH_STRAT_GLOBAL = 1, // device-scope atomics straight into replica (blockIdx % replicas)
     VXH_STRAT_XCC = 2,    // L2-local (workgroup-scope) atomics into the replica set of the block's own XCD
-    VXH_STRAT_LDS = 3,    // workgroup-private grids in LDS, flushed once per block
+    VXH_STRAT_LDS = 3,    // workgroup-private grids (or interleaved slabs of them) in LDS, flushed once per workgroup
 };
 
 struct LaunchPlan {
