@@ -9,16 +9,21 @@ from tests import cases
 
 pytestmark = pytest.mark.gpu
 
-STRATEGIES = {"auto": 0, "global": 1, "xcc": 2, "lds": 3}
+STRATEGIES = {"auto": 0, "global": 1, "xcc": 2, "lds": 3, "part": 4}
 
 
 @pytest.fixture(autouse=True)
 def _reset_config(sa, gpu_ready):
-    sa.config_set("strategy", 0)
-    sa.config_set("block", 0)
-    sa.config_set("blocks", 0)
+    def reset():
+        sa.config_set("strategy", 0)
+        sa.config_set("block", 0)
+        sa.config_set("blocks", 0)
+        sa.config_set("slab_log2", -1)
+        sa.config_set("part_chunk", 1 << 26)
+        sa.config_set("parts", 0)
+    reset()
     yield
-    sa.config_set("strategy", 0)
+    reset()
 
 
 def check(sa, case, **kw):
@@ -44,7 +49,7 @@ def test_count_1d_ordinal_golden(sa):
     assert got[0].tolist() == [1, 1, 0, 0, 1, 3, 0]
 
 
-@pytest.mark.parametrize("strategy", ["auto", "global", "xcc", "lds"])
+@pytest.mark.parametrize("strategy", ["auto", "global", "xcc", "lds", "part"])
 @pytest.mark.parametrize("n", [1, 63, 1000, 200_003])
 def test_2d_count_mean(sa, strategy, n):
     sa.config_set("strategy", STRATEGIES[strategy])
@@ -53,19 +58,61 @@ def test_2d_count_mean(sa, strategy, n):
     assert sa.last_kernel(0) != ""
 
 
-@pytest.mark.parametrize("strategy", ["global", "xcc"])
+@pytest.mark.parametrize("strategy", ["global", "xcc", "lds", "part"])
 def test_2d_256_count_mean_selection(sa, strategy):
     sa.config_set("strategy", STRATEGIES[strategy])
     case = cases.case_2d_count_mean(300_000, shape=256, selection=True)
     check(sa, case)
 
 
-def test_3d_selection(sa):
+@pytest.mark.parametrize("strategy", ["auto", "part"])
+def test_3d_selection(sa, strategy):
+    sa.config_set("strategy", STRATEGIES[strategy])
     case = cases.case_3d_selection(250_000, shape=32)
     check(sa, case)
 
 
-@pytest.mark.parametrize("strategy", ["auto", "global", "lds"])
+def test_part_many_slabs_3d(sa):
+    # 67^3 = 300k cells of u32 = 1.2 MB -> 8+ slabs; records are just a uint16 local index
+    sa.config_set("strategy", STRATEGIES["part"])
+    case = cases.case_3d_selection(2_000_000, shape=64)
+    check(sa, case)
+    assert sa.last_kernel(0).startswith("part_scatter")
+
+
+def test_part_mixed_masks_and_inputs(sa):
+    # aggregators with different masks / inputs -> records carry a flags byte and several value columns
+    sa.config_set("strategy", STRATEGIES["part"])
+    c = cases.gaussian_columns(400_000, seed=5)
+    m1 = c["v"] > 3
+    m2 = c["z"] < 0
+    case = dict(n=400_000, binners=[dict(kind="scalar", data=c["x"], vmin=-4, vmax=4, bins=300), dict(kind="scalar", data=c["y"], vmin=-4, vmax=4, bins=300)],
+                aggs=[dict(kind="count"), dict(kind="count", mask=m1), dict(kind="sum", data=c["v"], mask=m2), dict(kind="sum", data=c["z"], mask=m1),
+                      dict(kind="max", data=c["v"]), dict(kind="min", data=c["z"].astype("f4"), mask=m2), dict(kind="summoment", data=c["v"], moment=2)])
+    check(sa, case)
+
+
+def test_part_chunks_and_queue_overflow(sa):
+    # small chunks + every row in ONE cell: the slab queue overflows and the HBM-atomic slow path takes over
+    sa.config_set("strategy", STRATEGIES["part"])
+    sa.config_set("part_chunk", 1 << 20)
+    n = 3_000_000
+    x = np.full(n, 0.5); y = np.full(n, -0.25); v = np.arange(n, dtype="f8") % 7
+    case = dict(n=n, binners=[dict(kind="scalar", data=x, vmin=-4, vmax=4, bins=256), dict(kind="scalar", data=y, vmin=-4, vmax=4, bins=256)], aggs=[dict(kind="count"), dict(kind="sum", data=v)])
+    got = check(sa, case)
+    assert got[0].max() == n
+    case2 = cases.case_2d_count_mean(2_500_000, shape=256)
+    check(sa, case2)
+    check(sa, case2, chunk=700_000, nthreads=3)
+
+
+def test_part_groupby_100k(sa):
+    sa.config_set("strategy", STRATEGIES["part"])
+    case = cases.case_groupby(3_000_000, groups=100_000)
+    check(sa, case)
+
+
+@pytest.mark.parametrize("strategy", ["auto", "global", "lds", "part"])
 def test_groupby_ordinal(sa, strategy):
     sa.config_set("strategy", STRATEGIES[strategy])
     case = cases.case_groupby(200_000, groups=1000)
@@ -192,7 +239,7 @@ def test_full_size_properties(sa):
     v = torch.randn(n, dtype=torch.float64, device="cuda", generator=g) * 2 + 3
     torch.cuda.synchronize()
     results = {}
-    for strat in ("global", "xcc"):
+    for strat in ("global", "part", "lds"):
         sa.config_set("strategy", STRATEGIES[strat])
         bx = sa.BinnerScalar_float64(1, "x", -4, 4, 256)
         by = sa.BinnerScalar_float64(1, "y", -4, 4, 256)
@@ -206,9 +253,11 @@ def test_full_size_properties(sa):
             grid.bin(0, [c, s], hi - lo)
         results[strat] = (c.get_result(), s.get_result())
     cg, sg = results["global"]
-    cx, sx = results["xcc"]
+    cx, sx = results["part"]
     assert cg.sum() == n
     np.testing.assert_array_equal(cg, cx)
+    np.testing.assert_array_equal(cg, results["lds"][0])
+    assert np.max(np.abs(sg - results["lds"][1])) <= 1e-12 * float(v.abs().sum()) / 1000
     total = float(v.sum())
     assert abs(sg.sum() - total) <= 1e-9 * float(v.abs().sum())
     assert np.max(np.abs(sg - sx)) <= 1e-12 * float(v.abs().sum()) / 1000

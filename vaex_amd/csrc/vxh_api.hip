@@ -229,11 +229,12 @@ static void agg_alloc_device(vxh_agg *a) {
     const uint64_t cells = a->grid->length1d;
     int R = (int)c.cfg_replicas;
     if (R <= 0) {
-        // auto: one replica per workgroup group of the LDS strategy (plain, atomic-free flush) while that stays
-        // under 256 MiB; else one per XCD; a single one for huge grids (>= 64 Mi cells)
-        const uint64_t lds_groups = (uint64_t)std::max<int64_t>(8, c.cfg_lds_replicas > 0 ? c.cfg_lds_replicas : (int64_t)c.cus * 2);
-        if (cells * 8ull * lds_groups <= (256ull << 20)) R = (int)lds_groups;
-        else R = cells * 8ull * 8ull <= (1ull << 32) ? 8 : 1;
+        // capacity: up to 512 replicas (one per workgroup group, so the LDS flush needs no atomics) within a
+        // 256 MiB budget per aggregator; at least one per XCD; a single one for huge grids.  Only the replicas
+        // a launch actually used are ever folded / reset (vxh_agg::used).
+        const uint64_t fit = (256ull << 20) / std::max<uint64_t>(1, cells * 8ull);
+        if (fit >= 8) R = (int)std::min<uint64_t>(512, fit / 8 * 8);
+        else R = cells * 8ull * 8ull <= (4ull << 30) ? 8 : 1;
     }
     a->replicas = R;
     const size_t cs = vxh_cell_size(a->cell);
@@ -242,6 +243,7 @@ static void agg_alloc_device(vxh_agg *a) {
     vxh_launch_fill(a->dev, (uint64_t)R * cells, a->cell, &a->identity, s0.stream);
     HIP_CHECK(hipStreamSynchronize(s0.stream));
     a->folded = true;
+    a->used = 1;
 }
 
 // fold replicas into replica 0 (device), after all slots' work has drained
@@ -249,9 +251,10 @@ static void agg_fold_device(vxh_agg *a) {
     if (!a->dev || a->folded) return;
     HIP_CHECK(hipDeviceSynchronize());
     Slot &s0 = get_slot(0);
-    vxh_launch_fold(a->dev, a->grid->length1d, a->replicas, a->cell, a->kind, &a->identity, s0.stream);
+    vxh_launch_fold(a->dev, a->grid->length1d, a->used, a->cell, a->kind, &a->identity, s0.stream);
     HIP_CHECK(hipStreamSynchronize(s0.stream));
     a->folded = true;
+    a->used = 1;
 }
 
 static void agg_alloc_mirror(vxh_agg *a) {
@@ -297,12 +300,13 @@ static void agg_ensure_device_locked(vxh_agg *a) {
         host_to_device_cells(folded.data(), a->host_dtype, dev_cells.data(), a->cell, cells);
         HIP_CHECK(hipDeviceSynchronize());
         HIP_CHECK(hipMemcpy(a->dev, dev_cells.data(), cells * cs, hipMemcpyHostToDevice));
-        if (a->replicas > 1) {
+        if (a->used > 1) {
             Slot &s0 = get_slot(0);
-            vxh_launch_fill((char *)a->dev + cells * cs, (uint64_t)(a->replicas - 1) * cells, a->cell, &a->identity, s0.stream);
+            vxh_launch_fill((char *)a->dev + cells * cs, (uint64_t)(a->used - 1) * cells, a->cell, &a->identity, s0.stream);
             HIP_CHECK(hipStreamSynchronize(s0.stream));
         }
         a->folded = true;
+        a->used = 1;
     }
     a->auth = AUTH_DEVICE;
 }
@@ -383,18 +387,66 @@ static LaunchPlan make_plan(const BinArgs &A, BinArgs &out, uint64_t n, double b
     const bool lds_fits = slab_cells * per_cell <= lds_budget && A.cells < (1ull << 31);
     if (c.cfg_slab_log2 >= 0 && c.cfg_slab_log2 >= slab_log2 && c.cfg_slab_log2 <= 5) slab_log2 = (int)c.cfg_slab_log2;
 
+    // partition strategy: any power-of-two number of slabs up to 256 (its cost does not grow with S)
+    int part_log2 = 0;
+    while (part_log2 < 8 && ((A.cells + (1ull << part_log2) - 1) >> part_log2) * per_cell > lds_budget) part_log2++;
+    const uint64_t part_slab_cells = (A.cells + (1ull << part_log2) - 1) >> part_log2;
+    int nvals = 0, nmasks = 0;
+    {
+        const void *seen_v[VXH_MAX_AGG]; const void *seen_m[VXH_MAX_AGG];
+        for (int k = 0; k < A.nagg; k++) {
+            if (A.a[k].data) { int j = 0; while (j < nvals && seen_v[j] != A.a[k].data) j++; if (j == nvals) seen_v[nvals++] = A.a[k].data; }
+            if (A.a[k].mask) { int j = 0; while (j < nmasks && seen_m[j] != A.a[k].mask) j++; if (j == nmasks) seen_m[nmasks++] = A.a[k].mask; }
+        }
+    }
+    const bool part_ok = part_slab_cells * per_cell <= lds_budget && A.cells < (1ull << 31) && nvals <= VXH_PART_MAX_VALS && nmasks <= VXH_PART_MAX_MASKS;
+    const double rec_bytes = (part_slab_cells <= 65536 ? 2.0 : 4.0) + (nmasks ? 1.0 : 0.0) + 8.0 * nvals;
+
     int strategy = (int)c.cfg_strategy;
     if (strategy == VXH_STRAT_AUTO) {
         const double cost_lds = (double)(1 << slab_log2) * bytes_per_row / kIngestBytesPerSec;
+        const double cost_part = (bytes_per_row + 2.0 * rec_bytes) / kIngestBytesPerSec;
         const double cost_atomic = (double)A.nagg / kHbmAtomicsPerSec + bytes_per_row / kIngestBytesPerSec;
         // the per-workgroup init + flush (O(cells)) must be small next to the rows a workgroup handles
-        if (lds_fits && cost_lds < cost_atomic && n >= 16 * A.cells) strategy = VXH_STRAT_LDS;
-        else strategy = VXH_STRAT_XCC;
+        const bool big_enough = n >= 16 * A.cells;
+        double best = cost_atomic;
+        strategy = VXH_STRAT_XCC;
+        if (lds_fits && big_enough && cost_lds < best) { best = cost_lds; strategy = VXH_STRAT_LDS; }
+        if (part_ok && big_enough && n >= (1u << 20) && slab_log2 > 0 && cost_part < best) { best = cost_part; strategy = VXH_STRAT_PART; }
     }
+    if (strategy == VXH_STRAT_PART && !part_ok) strategy = VXH_STRAT_XCC;
     if (strategy == VXH_STRAT_LDS && !lds_fits) strategy = VXH_STRAT_XCC;
     if (strategy == VXH_STRAT_XCC && (A.replicas < 8 || A.replicas % 8)) strategy = VXH_STRAT_GLOBAL;
     p.strategy = strategy;
-    out.replicas_per_xcc = strategy == VXH_STRAT_XCC ? A.replicas / 8 : 1;
+    // HBM-atomic strategies spread over at most 64 of the available replicas (more buys nothing: the
+    // atomic rate is a chip-wide constant) and XCC wants a multiple of 8
+    if (strategy == VXH_STRAT_XCC) out.replicas = std::min(A.replicas, 64) / 8 * 8;
+    else if (strategy == VXH_STRAT_GLOBAL) out.replicas = std::min(A.replicas, 64);
+    out.replicas_per_xcc = strategy == VXH_STRAT_XCC ? out.replicas / 8 : 1;
+    p.use_replicas = out.replicas;
+
+    if (strategy == VXH_STRAT_PART) {
+        const int S = 1 << part_log2;
+        size_t lds = 0;
+        for (int k = 0; k < A.nagg; k++) {
+            out.a[k].lds_offset = (uint32_t)lds;
+            lds += (part_slab_cells * vxh_lds_cell_size(A.a[k].kind, A.a[k].cell) + 15) & ~(size_t)15;
+        }
+        p.lds_bytes = lds;
+        int per_cu = (int)std::max<size_t>(1, std::min<size_t>(2, kLdsMax / std::max<size_t>(lds, 1)));
+        p.block = c.cfg_block > 0 ? (int)c.cfg_block : 1024;
+        per_cu = std::max(1, std::min(per_cu, 2048 / p.block));
+        int parts = std::max(1, (int)((uint64_t)c.cus * per_cu / S));
+        if (c.cfg_parts > 0) parts = (int)c.cfg_parts;
+        out.slab_log2 = part_log2;
+        out.ngroups = parts; // pass-2 workgroups per slab
+        out.flush_plain = (exclusive && A.replicas >= parts) ? 1 : 0;
+        out.replicas = std::min(A.replicas, parts);
+        p.use_replicas = out.replicas;
+        p.blocks = parts * S;
+        p.name = fast ? "part_scatter+part_reduce_f64" : "part_scatter+part_reduce_generic";
+        return p;
+    }
 
     if (strategy == VXH_STRAT_LDS) {
         const int S = 1 << slab_log2;
@@ -418,6 +470,8 @@ static LaunchPlan make_plan(const BinArgs &A, BinArgs &out, uint64_t n, double b
         out.slab_log2 = slab_log2;
         out.ngroups = (int)ngroups;
         out.flush_plain = (exclusive && (uint64_t)A.replicas >= ngroups) ? 1 : 0;
+        out.replicas = (int)std::min<uint64_t>((uint64_t)A.replicas, ngroups);
+        p.use_replicas = out.replicas;
         p.name = S > 1 ? (fast ? "bin_lds_slab_f64" : "bin_lds_slab_generic") : (fast ? "bin_lds_f64" : "bin_lds_generic");
     } else {
         p.lds_bytes = 0;
@@ -429,6 +483,86 @@ static LaunchPlan make_plan(const BinArgs &A, BinArgs &out, uint64_t n, double b
         else p.name = fast ? "bin_global_f64" : "bin_global_generic";
     }
     return p;
+}
+
+// ------------------------------------------------------------------------------------------
+// partition strategy driver: one chunk of rows -> scatter launch + reduce launch
+// ------------------------------------------------------------------------------------------
+static void run_part_chunk(Slot &slot, const BinArgs &planned, const LaunchPlan &plan, uint64_t chunk_rows_max) {
+    Context &c = ctx();
+    PartArgs P{};
+    P.A = planned;
+    P.slab_log2 = planned.slab_log2;
+    P.parts = planned.ngroups;
+    const uint32_t S = 1u << P.slab_log2;
+    const uint64_t slab_cells = (planned.cells + S - 1) >> P.slab_log2;
+    P.idx16 = slab_cells <= 65536 ? 1 : 0;
+    bool all_masked = true;
+    for (int k = 0; k < planned.nagg; k++) {
+        const AggDesc &a = planned.a[k];
+        P.agg_vslot[k] = 0xff;
+        P.agg_mbit[k] = 0xff;
+        if (a.data) {
+            int j = 0;
+            while (j < P.nvals && P.vdata[j] != a.data) j++;
+            if (j == P.nvals) { P.vdata[j] = a.data; P.vdtype[j] = a.dtype; P.vflip[j] = a.flip; P.nvals++; }
+            P.agg_vslot[k] = (uint8_t)j;
+        }
+        if (a.mask) {
+            int j = 0;
+            while (j < P.nmasks && P.mdata[j] != a.mask) j++;
+            if (j == P.nmasks) { P.mdata[j] = a.mask; P.nmasks++; }
+            P.agg_mbit[k] = (uint8_t)j;
+        } else {
+            all_masked = false;
+        }
+    }
+    P.all_masked = (P.nmasks > 0 && all_masked) ? 1 : 0;
+    P.use_flags = (P.nmasks > 0 && !(P.nmasks == 1 && all_masked)) ? 1 : 0;
+    // the records store post-byte-swap values: pass 2 must not swap again
+    for (int k = 0; k < planned.nagg; k++) P.A.a[k].flip = 0;
+
+    // queue capacity per slab: twice the expected share (interleaved slabs are balanced for any smooth
+    // distribution); whatever does not fit takes the HBM-atomic slow path inside part_scatter
+    const uint64_t C = chunk_rows_max;
+    P.cap = S == 1 ? C : std::min<uint64_t>(C, 2 * (C / S) + 65536);
+    const size_t idx_bytes = P.idx16 ? 2 : 4;
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+    const size_t o_count = carve((size_t)S * 8), o_limit = carve((size_t)S * 8);
+    const size_t o_idx = carve((size_t)S * P.cap * idx_bytes);
+    const size_t o_flags = P.use_flags ? carve((size_t)S * P.cap) : 0;
+    size_t o_val[VXH_PART_MAX_VALS] = {0, 0, 0, 0};
+    for (int k = 0; k < P.nvals; k++) o_val[k] = carve((size_t)S * P.cap * 8);
+    if (off > slot.scratch_cap) {
+        HIP_CHECK(hipStreamSynchronize(slot.stream));
+        if (slot.scratch) HIP_CHECK(hipFree(slot.scratch));
+        HIP_CHECK(hipMalloc(&slot.scratch, off));
+        slot.scratch_cap = off;
+    }
+    char *sc = (char *)slot.scratch;
+    P.qcount = (unsigned long long *)(sc + o_count);
+    P.qlimit = (unsigned long long *)(sc + o_limit);
+    P.qidx = sc + o_idx;
+    P.qflags = P.use_flags ? (uint8_t *)(sc + o_flags) : nullptr;
+    for (int k = 0; k < P.nvals; k++) P.qval[k] = (uint64_t *)(sc + o_val[k]);
+    HIP_CHECK(hipMemsetAsync(P.qcount, 0, (size_t)S * 8, slot.stream));
+    HIP_CHECK(hipMemsetAsync(P.qlimit, 0xff, (size_t)S * 8, slot.stream));
+
+    // pass-1 tile: 512 threads x R rows, staged in LDS
+    int R = 8;
+    size_t scatter_lds = 0;
+    for (;; R >>= 1) {
+        const size_t T = 512 * (size_t)R;
+        scatter_lds = (size_t)S * 4 + ((size_t)S + 4) * 4 + (size_t)S * 8 + T * (8 * (size_t)P.nvals + 4 + 2 + 1) + 64;
+        if (scatter_lds <= 78 * 1024 || R == 2) break;
+    }
+    P.rows_per_thread = R;
+    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(4, kLdsMax / scatter_lds));
+    const uint64_t tiles = (planned.n + 512ull * R - 1) / (512ull * R);
+    const int scatter_blocks = (int)std::max<uint64_t>(1, std::min<uint64_t>(tiles, (uint64_t)c.cus * per_cu));
+    vxh_launch_part(P, plan, scatter_blocks, scatter_lds, slot.stream);
+    HIP_CHECK(hipGetLastError());
 }
 
 // ------------------------------------------------------------------------------------------
@@ -486,6 +620,8 @@ int vxh_config_set(const char *key, int64_t value) {
     else if (k == "blocks") c.cfg_blocks = value;
     else if (k == "stage_bytes") c.cfg_stage_bytes = value;
     else if (k == "slab_log2") c.cfg_slab_log2 = value;
+    else if (k == "part_chunk") c.cfg_part_chunk = value;
+    else if (k == "parts") c.cfg_parts = value;
     else if (k == "lds_replicas") c.cfg_lds_replicas = value;
     else throw std::runtime_error("unknown config key: " + k);
     VXH_API_END
@@ -501,6 +637,8 @@ int vxh_config_get(const char *key, int64_t *value) {
     else if (k == "blocks") *value = c.cfg_blocks;
     else if (k == "stage_bytes") *value = c.cfg_stage_bytes;
     else if (k == "slab_log2") *value = c.cfg_slab_log2;
+    else if (k == "part_chunk") *value = c.cfg_part_chunk;
+    else if (k == "parts") *value = c.cfg_parts;
     else if (k == "lds_replicas") *value = c.cfg_lds_replicas;
     else if (k == "cus") { ensure_device_ready(); *value = c.cus; }
     else throw std::runtime_error("unknown config key: " + k);
@@ -682,7 +820,6 @@ int vxh_grid_bin(vxh_grid *grid, int thread, vxh_agg *const *aggs, int n_aggs, u
         vxh_agg *a = aggs[k];
         std::lock_guard<std::mutex> lock(a->mutex);
         agg_ensure_device_locked(a);
-        a->folded = a->replicas <= 1;
     }
 
     Stager stager(slot);
@@ -760,8 +897,15 @@ int vxh_grid_bin(vxh_grid *grid, int thread, vxh_agg *const *aggs, int n_aggs, u
             replicas = std::min(replicas, a->replicas);
         }
         A.replicas = replicas;
-        for (uint64_t r0 = 0; r0 < length; r0 += kMaxRows) {
-            const uint64_t rn = std::min(kMaxRows, length - r0);
+        // plan once on the whole call: it fixes the strategy, hence the row step of the launches
+        uint64_t step = kMaxRows;
+        {
+            BinArgs tmp;
+            LaunchPlan whole = make_plan(A, tmp, length, bytes_per_row, exclusive);
+            if (whole.strategy == VXH_STRAT_PART) step = (uint64_t)std::max<int64_t>(1 << 20, ctx().cfg_part_chunk);
+        }
+        for (uint64_t r0 = 0; r0 < length; r0 += step) {
+            const uint64_t rn = std::min(step, length - r0);
             BinArgs L = A;
             L.n = rn;
             if (r0) {
@@ -775,9 +919,19 @@ int vxh_grid_bin(vxh_grid *grid, int thread, vxh_agg *const *aggs, int n_aggs, u
                 }
             }
             BinArgs planned;
-            LaunchPlan plan = make_plan(L, planned, rn, bytes_per_row, exclusive);
-            vxh_launch_bin(planned, plan, slot.stream);
-            HIP_CHECK(hipGetLastError());
+            LaunchPlan plan = make_plan(L, planned, step == kMaxRows ? rn : length, bytes_per_row, exclusive);
+            for (int k = 0; k < nk; k++) {
+                vxh_agg *a = aggs[k0 + k];
+                std::lock_guard<std::mutex> lock(a->mutex);
+                a->used = std::max(a->used, plan.use_replicas);
+                a->folded = a->used <= 1;
+            }
+            if (plan.strategy == VXH_STRAT_PART) {
+                run_part_chunk(slot, planned, plan, step);
+            } else {
+                vxh_launch_bin(planned, plan, slot.stream);
+                HIP_CHECK(hipGetLastError());
+            }
             slot.last_kernel = plan.name;
         }
     }
@@ -923,9 +1077,10 @@ int vxh_agg_reset(vxh_agg *a) {
     if (a->dev) {
         HIP_CHECK(hipDeviceSynchronize());
         Slot &s0 = get_slot(0);
-        vxh_launch_fill(a->dev, (uint64_t)a->replicas * a->grid->length1d, a->cell, &a->identity, s0.stream);
+        vxh_launch_fill(a->dev, (uint64_t)a->used * a->grid->length1d, a->cell, &a->identity, s0.stream);
         HIP_CHECK(hipStreamSynchronize(s0.stream));
         a->folded = true;
+        a->used = 1;
         a->auth = AUTH_DEVICE;
     } else {
         a->auth = AUTH_NONE;

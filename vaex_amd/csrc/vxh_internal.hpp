@@ -53,7 +53,8 @@ struct vxh_agg {
     uint64_t identity = 0;
     // device state
     void *dev = nullptr; // replicas x length1d cells
-    int replicas = 1;
+    int replicas = 1;    // allocated
+    int used = 1;        // replicas [0, used) may hold data; the rest are identity
     bool folded = true; // replicas 1.. hold only the identity
     int auth = AUTH_NONE;
     std::vector<unsigned char> mirror; // lazily allocated (grids, *shapes) host buffer
@@ -71,6 +72,8 @@ struct Slot {
     } stage[2];
     int cur = 0;
     hipEvent_t t0 = nullptr, t1 = nullptr;
+    void *scratch = nullptr; // partition queues
+    size_t scratch_cap = 0;
     const char *last_kernel = "";
 };
 
@@ -89,6 +92,8 @@ struct Context {
     int64_t cfg_stage_bytes = 64 << 20;
     int64_t cfg_slab_log2 = -1;   // -1 = auto
     int64_t cfg_lds_replicas = 0; // 0 = auto
+    int64_t cfg_part_chunk = 1 << 26; // rows per partition chunk
+    int64_t cfg_parts = 0;        // pass-2 workgroups per slab (0 = auto)
 };
 
 Context &ctx();

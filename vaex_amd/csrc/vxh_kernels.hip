@@ -434,6 +434,178 @@ __global__ void __launch_bounds__(1024) bin_kernel(const BinArgs A) {
 }
 
 // ------------------------------------------------------------------------------------------
+// K1b / K1c — partition strategy (see PartArgs)
+// ------------------------------------------------------------------------------------------
+// one aggregator, one record, given the record's mask flags and input values (already native-endian)
+template <int SCOPE, bool LDS>
+__device__ __forceinline__ void record_apply(const PartArgs &P, int k, void *base, uint64_t idx, uint32_t flags, const uint64_t *vals) {
+    const AggDesc &a = P.A.a[k];
+    const uint32_t mb = P.agg_mbit[k];
+    if (mb != 0xffu && !((flags >> mb) & 1u)) return;
+    uint64_t raw = 0;
+    const uint32_t vs = P.agg_vslot[k];
+    if (vs != 0xffu) {
+        raw = vals[vs];
+        if (dt_is_float(a.dtype)) {
+            double v = raw_as_f64(raw, a.dtype);
+            if (v != v) return; // NaN rows are skipped
+        }
+    }
+    agg_apply<SCOPE, LDS>(a, base, idx, raw, vs != 0xffu);
+}
+
+// pass 1: rows -> per-slab record queues.  512 threads, R rows per thread per tile.
+template <bool FAST, int R>
+__global__ void __launch_bounds__(512) part_scatter(const PartArgs P) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    constexpr uint32_t NONE = 0xffffffffu;
+    constexpr unsigned long long OVERFLOW = ~0ull;
+    const uint32_t S = 1u << P.slab_log2;
+    const uint32_t T = 512u * R;
+    // LDS carve (all offsets multiples of 16)
+    uint32_t *s_cnt = (uint32_t *)lds;                                // [S]
+    uint32_t *s_off = s_cnt + S;                                      // [S+1] (+pad)
+    unsigned long long *s_gbase = (unsigned long long *)(s_off + S + 4); // [S]
+    uint64_t *st_val = (uint64_t *)(s_gbase + S);                      // [nvals][T]
+    uint32_t *st_idx = (uint32_t *)(st_val + (size_t)P.nvals * T);     // [T]
+    uint16_t *st_slab = (uint16_t *)(st_idx + T);                      // [T]
+    uint8_t *st_flags = (uint8_t *)(st_slab + T);                      // [T]
+    const uint64_t n = P.A.n;
+
+    for (uint64_t tile = blockIdx.x; tile * T < n; tile += gridDim.x) {
+        const uint64_t base = tile * T;
+        for (uint32_t s = threadIdx.x; s < S; s += 512) s_cnt[s] = 0;
+        __syncthreads();
+
+        uint32_t slab[R], loc[R], pos[R], fl[R];
+        uint64_t val[R][VXH_PART_MAX_VALS];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const uint64_t i = base + (uint64_t)r * 512 + threadIdx.x;
+            pos[r] = NONE;
+            slab[r] = 0; loc[r] = 0; fl[r] = 0;
+            if (i < n) {
+                uint32_t flags = 0;
+                for (int m = 0; m < P.nmasks; ++m) flags |= (P.mdata[m][i] == 1 ? 1u : 0u) << m;
+                const bool keep = !(P.all_masked && flags == 0);
+                if (keep) {
+                    const uint64_t idx = flat_index<FAST>(P.A, i);
+                    slab[r] = (uint32_t)idx & (S - 1);
+                    loc[r] = (uint32_t)(idx >> P.slab_log2);
+                    fl[r] = flags;
+#pragma unroll
+                    for (int k = 0; k < VXH_PART_MAX_VALS; ++k)
+                        if (k < P.nvals) val[r][k] = FAST ? ((const uint64_t *)P.vdata[k])[i] : load_raw(P.vdata[k], i, P.vdtype[k], P.vflip[k]);
+                    pos[r] = __hip_atomic_fetch_add(&s_cnt[slab[r]], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
+        }
+        __syncthreads();
+        // exclusive prefix over the S bucket counts + reservation of queue space (one HBM atomic per slab per tile)
+        for (uint32_t s = threadIdx.x; s < S; s += 512) {
+            uint32_t off = 0;
+            for (uint32_t j = 0; j < s; ++j) off += s_cnt[j];
+            s_off[s] = off;
+            const uint32_t c = s_cnt[s];
+            if (s == S - 1) s_off[S] = off + c;
+            unsigned long long gb = 0;
+            if (c) {
+                gb = atomicAdd(&P.qcount[s], (unsigned long long)c);
+                if (gb + c > P.cap) { // does not fit: remember where the valid prefix of the queue ends
+                    atomicMin(&P.qlimit[s], gb);
+                    gb = OVERFLOW;
+                }
+            }
+            s_gbase[s] = gb;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            if (pos[r] != NONE) {
+                const uint32_t j = s_off[slab[r]] + pos[r];
+                st_idx[j] = loc[r];
+                st_slab[j] = (uint16_t)slab[r];
+                st_flags[j] = (uint8_t)fl[r];
+#pragma unroll
+                for (int k = 0; k < VXH_PART_MAX_VALS; ++k)
+                    if (k < P.nvals) st_val[(size_t)k * T + j] = val[r][k];
+            }
+        }
+        __syncthreads();
+        const uint32_t total = s_off[S];
+        for (uint32_t j = threadIdx.x; j < total; j += 512) {
+            const uint32_t s = st_slab[j];
+            const unsigned long long gb = s_gbase[s];
+            if (gb != OVERFLOW) {
+                const uint64_t dst = (uint64_t)s * P.cap + gb + (j - s_off[s]);
+                if (P.idx16) ((uint16_t *)P.qidx)[dst] = (uint16_t)st_idx[j];
+                else ((uint32_t *)P.qidx)[dst] = st_idx[j];
+                if (P.use_flags) P.qflags[dst] = st_flags[j];
+#pragma unroll
+                for (int k = 0; k < VXH_PART_MAX_VALS; ++k)
+                    if (k < P.nvals) P.qval[k][dst] = st_val[(size_t)k * T + j];
+            } else {
+                // queue full (pathologically skewed data): scatter this record straight to HBM
+                const uint64_t gidx = ((uint64_t)st_idx[j] << P.slab_log2) + s;
+                uint64_t vals[VXH_PART_MAX_VALS];
+#pragma unroll
+                for (int k = 0; k < VXH_PART_MAX_VALS; ++k) vals[k] = k < P.nvals ? st_val[(size_t)k * T + j] : 0;
+                for (int k = 0; k < P.A.nagg; ++k) record_apply<__HIP_MEMORY_SCOPE_AGENT, false>(P, k, P.A.a[k].grid, gidx, st_flags[j], vals);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// pass 2: slab queues -> LDS-private slab -> HBM replica
+__global__ void __launch_bounds__(1024) part_reduce(const PartArgs P) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const uint32_t S = 1u << P.slab_log2;
+    const uint32_t slab = blockIdx.x % S, part = blockIdx.x / S;
+    const uint64_t slab_cells = (P.A.cells + S - 1) >> P.slab_log2;
+    for (int k = 0; k < P.A.nagg; ++k) {
+        const AggDesc &a = P.A.a[k];
+        const size_t cs = lds_cell_size_dev(a.kind, a.cell);
+        char *base = lds + a.lds_offset;
+        const uint64_t ident = identity_bits(a.kind, a.cell);
+        if (cs == 4) for (uint64_t c = threadIdx.x; c < slab_cells; c += blockDim.x) ((uint32_t *)base)[c] = (uint32_t)ident;
+        else for (uint64_t c = threadIdx.x; c < slab_cells; c += blockDim.x) ((uint64_t *)base)[c] = ident;
+    }
+    __syncthreads();
+    unsigned long long len = P.qcount[slab];
+    const unsigned long long lim = P.qlimit[slab];
+    if (lim < len) len = lim;
+    const uint64_t lo = len * part / P.parts, hi = len * (part + 1) / P.parts;
+    const uint64_t qb = (uint64_t)slab * P.cap;
+    auto one = [&](uint64_t j) {
+        const uint32_t loc = P.idx16 ? ((const uint16_t *)P.qidx)[qb + j] : ((const uint32_t *)P.qidx)[qb + j];
+        const uint32_t flags = P.use_flags ? P.qflags[qb + j] : 0xffu;
+        uint64_t vals[VXH_PART_MAX_VALS];
+#pragma unroll
+        for (int k = 0; k < VXH_PART_MAX_VALS; ++k) vals[k] = k < P.nvals ? P.qval[k][qb + j] : 0;
+        for (int k = 0; k < P.A.nagg; ++k) record_apply<__HIP_MEMORY_SCOPE_WORKGROUP, true>(P, k, lds + P.A.a[k].lds_offset, loc, flags, vals);
+    };
+    uint64_t j = lo + threadIdx.x;
+    for (; j + 3ull * blockDim.x < hi; j += 4ull * blockDim.x) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) one(j + (uint64_t)u * blockDim.x);
+    }
+    for (; j < hi; j += blockDim.x) one(j);
+    __syncthreads();
+    const uint64_t replica = P.A.flush_plain ? part : part % (uint32_t)P.A.replicas;
+    for (int k = 0; k < P.A.nagg; ++k) {
+        const AggDesc &a = P.A.a[k];
+        char *base = lds + a.lds_offset;
+        char *g = (char *)a.grid + replica * P.A.cells * cell_size_dev(a.cell);
+        for (uint64_t c = threadIdx.x; c < slab_cells; c += blockDim.x) {
+            const uint64_t gc = (c << P.slab_log2) + slab;
+            if (gc >= P.A.cells) continue;
+            flush_cell(a, base, c, g, gc, P.A.flush_plain != 0);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // fill / fold
 // ------------------------------------------------------------------------------------------
 __global__ void fill_kernel(void *dst, uint64_t n, int cs, uint64_t value) {
@@ -490,9 +662,27 @@ __global__ void __launch_bounds__(256) minmax_kernel(int dtype, int flip, const 
 size_t vxh_cell_size(int cell) { return cell >= VXH_CELL_F32 ? 4 : 8; }
 size_t vxh_lds_cell_size(int kind, int cell) { return kind == VXH_AGG_COUNT ? 4 : vxh_cell_size(cell); }
 
+void vxh_launch_part(const PartArgs &args, const LaunchPlan &plan, int scatter_blocks, size_t scatter_lds, hipStream_t stream) {
+    const int R = args.rows_per_thread;
+#define VXH_SC(F, RR)                                                                                                  \
+    {                                                                                                                  \
+        if (scatter_lds > 48 * 1024) (void)hipFuncSetAttribute((const void *)part_scatter<F, RR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)scatter_lds); \
+        hipLaunchKernelGGL((part_scatter<F, RR>), dim3(scatter_blocks), dim3(512), scatter_lds, stream, args);         \
+    }
+    if (plan.fast_f64) { if (R == 8) VXH_SC(true, 8) else if (R == 4) VXH_SC(true, 4) else VXH_SC(true, 2) }
+    else { if (R == 8) VXH_SC(false, 8) else if (R == 4) VXH_SC(false, 4) else VXH_SC(false, 2) }
+#undef VXH_SC
+    if (plan.lds_bytes > 48 * 1024) (void)hipFuncSetAttribute((const void *)part_reduce, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds_bytes);
+    hipLaunchKernelGGL(part_reduce, dim3(plan.blocks), dim3(plan.block), plan.lds_bytes, stream, args);
+}
+
 void vxh_launch_bin(const BinArgs &args, const LaunchPlan &plan, hipStream_t stream) {
     dim3 g(plan.blocks), b(plan.block);
-#define VXH_LAUNCH(S, F) hipLaunchKernelGGL((bin_kernel<S, F>), g, b, plan.lds_bytes, stream, args)
+#define VXH_LAUNCH(S, F)                                                                                               \
+    do {                                                                                                               \
+        if (plan.lds_bytes > 48 * 1024) (void)hipFuncSetAttribute((const void *)bin_kernel<S, F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds_bytes); \
+        hipLaunchKernelGGL((bin_kernel<S, F>), g, b, plan.lds_bytes, stream, args);                                    \
+    } while (0)
     if (plan.strategy == VXH_STRAT_LDS) { if (plan.fast_f64) VXH_LAUNCH(VXH_STRAT_LDS, true); else VXH_LAUNCH(VXH_STRAT_LDS, false); }
     else if (plan.strategy == VXH_STRAT_XCC) { if (plan.fast_f64) VXH_LAUNCH(VXH_STRAT_XCC, true); else VXH_LAUNCH(VXH_STRAT_XCC, false); }
     else { if (plan.fast_f64) VXH_LAUNCH(VXH_STRAT_GLOBAL, true); else VXH_LAUNCH(VXH_STRAT_GLOBAL, false); }

@@ -60,6 +60,38 @@ enum vxh_strategy : int {
     VXH_STRAT_GLOBAL = 1, // device-scope atomics straight into replica (blockIdx % replicas)
     VXH_STRAT_XCC = 2,    // L2-local (workgroup-scope) atomics into the replica set of the block's own XCD
     VXH_STRAT_LDS = 3,    // workgroup-private grids (or interleaved slabs of them) in LDS, flushed once per workgroup
+    VXH_STRAT_PART = 4,   // two passes: partition rows into per-slab record queues, then aggregate each slab in LDS
+};
+
+#define VXH_PART_MAX_VALS 4
+#define VXH_PART_MAX_MASKS 8
+
+// Partition strategy (grids too large for one workgroup's LDS).  Pass 1 (part_scatter) reads the rows once,
+// computes the flat cell index, and appends a compact record {local index, [mask flags], aggregator inputs}
+// to the queue of the slab that owns the cell (slab = cell & (S-1), local = cell >> log2 S), bucketing each
+// tile in LDS so the queue writes are coalesced.  Pass 2 (part_reduce) gives every slab to `parts`
+// workgroups that aggregate their share of the queue into an LDS-private copy of the slab and flush it.
+struct PartArgs {
+    BinArgs A;
+    int32_t slab_log2;
+    int32_t nvals;      // distinct aggregator input columns carried in a record
+    int32_t nmasks;     // distinct aggregator masks
+    int32_t all_masked; // every aggregator has a mask: rows with no mask bit set emit no record
+    int32_t use_flags;  // records carry a flags byte (bit m = mask m keeps the row)
+    int32_t idx16;      // local index stored as uint16
+    int32_t parts;      // pass-2 workgroups per slab
+    int32_t rows_per_thread;
+    uint64_t cap;       // queue capacity per slab (records)
+    const void *vdata[VXH_PART_MAX_VALS];
+    const uint8_t *mdata[VXH_PART_MAX_MASKS];
+    uint8_t vdtype[VXH_PART_MAX_VALS], vflip[VXH_PART_MAX_VALS];
+    uint8_t agg_vslot[VXH_MAX_AGG]; // 0xff: no input column
+    uint8_t agg_mbit[VXH_MAX_AGG];  // 0xff: no mask
+    unsigned long long *qcount;     // [S] records reserved
+    unsigned long long *qlimit;     // [S] first reservation that did not fit (or ~0)
+    void *qidx;                     // [S][cap] uint16 / uint32
+    uint8_t *qflags;                // [S][cap]
+    uint64_t *qval[VXH_PART_MAX_VALS]; // [S][cap]
 };
 
 struct LaunchPlan {
@@ -67,11 +99,13 @@ struct LaunchPlan {
     int block;     // threads per workgroup
     int blocks;    // workgroups
     size_t lds_bytes;
+    int use_replicas; // replicas [0, use_replicas) are written by this launch
     bool fast_f64; // all binners scalar f64 native unmasked, all aggregator inputs f64 native / absent
     const char *name;
 };
 
 // implemented in vxh_kernels.hip
+void vxh_launch_part(const PartArgs &args, const LaunchPlan &plan, int scatter_blocks, size_t scatter_lds, hipStream_t stream);
 void vxh_launch_bin(const BinArgs &args, const LaunchPlan &plan, hipStream_t stream);
 void vxh_launch_fill(void *dst, uint64_t ncells, int cell, const void *value8, hipStream_t stream);
 // dst[c] = fold(replica_0[c] .. replica_{R-1}[c]); replicas 1.. are reset to the identity
