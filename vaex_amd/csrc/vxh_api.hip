@@ -388,8 +388,10 @@ static LaunchPlan make_plan(const BinArgs &A, BinArgs &out, uint64_t n, double b
     if (c.cfg_slab_log2 >= 0 && c.cfg_slab_log2 >= slab_log2 && c.cfg_slab_log2 <= 5) slab_log2 = (int)c.cfg_slab_log2;
 
     // partition strategy: any power-of-two number of slabs up to 256 (its cost does not grow with S)
+    // slabs of <= ~72 KiB so that two 1024-thread pass-2 workgroups share a CU
+    const size_t part_budget = c.cfg_part_lds > 0 ? (size_t)c.cfg_part_lds : 72 * 1024;
     int part_log2 = 0;
-    while (part_log2 < 8 && ((A.cells + (1ull << part_log2) - 1) >> part_log2) * per_cell > lds_budget) part_log2++;
+    while (part_log2 < 8 && ((A.cells + (1ull << part_log2) - 1) >> part_log2) * per_cell > part_budget) part_log2++;
     const uint64_t part_slab_cells = (A.cells + (1ull << part_log2) - 1) >> part_log2;
     int nvals = 0, nmasks = 0;
     {
@@ -525,7 +527,7 @@ static void run_part_chunk(Slot &slot, const BinArgs &planned, const LaunchPlan 
     // queue capacity per slab: twice the expected share (interleaved slabs are balanced for any smooth
     // distribution); whatever does not fit takes the HBM-atomic slow path inside part_scatter
     const uint64_t C = chunk_rows_max;
-    P.cap = S == 1 ? C : std::min<uint64_t>(C, 2 * (C / S) + 65536);
+    P.cap = (S == 1 ? C : std::min<uint64_t>(C, 2 * (C / S) + 65536) + 7) & ~(uint64_t)7;
     const size_t idx_bytes = P.idx16 ? 2 : 4;
     size_t off = 0;
     auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
@@ -622,6 +624,7 @@ int vxh_config_set(const char *key, int64_t value) {
     else if (k == "slab_log2") c.cfg_slab_log2 = value;
     else if (k == "part_chunk") c.cfg_part_chunk = value;
     else if (k == "parts") c.cfg_parts = value;
+    else if (k == "part_lds") c.cfg_part_lds = value;
     else if (k == "lds_replicas") c.cfg_lds_replicas = value;
     else throw std::runtime_error("unknown config key: " + k);
     VXH_API_END
@@ -639,6 +642,7 @@ int vxh_config_get(const char *key, int64_t *value) {
     else if (k == "slab_log2") *value = c.cfg_slab_log2;
     else if (k == "part_chunk") *value = c.cfg_part_chunk;
     else if (k == "parts") *value = c.cfg_parts;
+    else if (k == "part_lds") *value = c.cfg_part_lds;
     else if (k == "lds_replicas") *value = c.cfg_lds_replicas;
     else if (k == "cus") { ensure_device_ready(); *value = c.cus; }
     else throw std::runtime_error("unknown config key: " + k);

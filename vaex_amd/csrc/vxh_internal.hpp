@@ -94,6 +94,7 @@ struct Context {
     int64_t cfg_lds_replicas = 0; // 0 = auto
     int64_t cfg_part_chunk = 1 << 26; // rows per partition chunk
     int64_t cfg_parts = 0;        // pass-2 workgroups per slab (0 = auto)
+    int64_t cfg_part_lds = 0;     // LDS bytes per pass-2 slab (0 = auto)
 };
 
 Context &ctx();

@@ -23,6 +23,8 @@
 
 #include <string.h>
 
+#include <algorithm>
+
 namespace {
 
 // ------------------------------------------------------------------------------------------
@@ -557,7 +559,49 @@ __global__ void __launch_bounds__(512) part_scatter(const PartArgs P) {
     }
 }
 
-// pass 2: slab queues -> LDS-private slab -> HBM replica
+// pass 2: slab queues -> LDS-private slab -> HBM replica.
+// The queue is streamed with 4 records per lane per load batch and two batches in flight (the LDS atomics
+// retire at >1 record/clk/CU — profiles/r01_microbench_v3_lds_atomics.txt — so this pass is a pure stream
+// and needs the memory-level parallelism of one).
+struct RecBatch {
+    uint32_t loc[4];
+    uint32_t flags[4];
+    uint64_t vals[VXH_PART_MAX_VALS][4];
+};
+
+__device__ __forceinline__ void rec_load4(const PartArgs &P, uint64_t at, RecBatch &b) {
+    if (P.idx16) {
+        const ushort4 q = *(const ushort4 *)((const uint16_t *)P.qidx + at);
+        b.loc[0] = q.x; b.loc[1] = q.y; b.loc[2] = q.z; b.loc[3] = q.w;
+    } else {
+        const uint4 q = *(const uint4 *)((const uint32_t *)P.qidx + at);
+        b.loc[0] = q.x; b.loc[1] = q.y; b.loc[2] = q.z; b.loc[3] = q.w;
+    }
+    if (P.use_flags) {
+        const uchar4 f = *(const uchar4 *)(P.qflags + at);
+        b.flags[0] = f.x; b.flags[1] = f.y; b.flags[2] = f.z; b.flags[3] = f.w;
+    } else {
+        b.flags[0] = b.flags[1] = b.flags[2] = b.flags[3] = 0xffu;
+    }
+#pragma unroll
+    for (int k = 0; k < VXH_PART_MAX_VALS; ++k) {
+        if (k < P.nvals) {
+            const ulonglong2 a = *(const ulonglong2 *)(P.qval[k] + at), c = *(const ulonglong2 *)(P.qval[k] + at + 2);
+            b.vals[k][0] = a.x; b.vals[k][1] = a.y; b.vals[k][2] = c.x; b.vals[k][3] = c.y;
+        }
+    }
+}
+
+__device__ __forceinline__ void rec_apply4(const PartArgs &P, const RecBatch &b, char *lds) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        uint64_t vals[VXH_PART_MAX_VALS];
+#pragma unroll
+        for (int k = 0; k < VXH_PART_MAX_VALS; ++k) vals[k] = k < P.nvals ? b.vals[k][u] : 0;
+        for (int k = 0; k < P.A.nagg; ++k) record_apply<__HIP_MEMORY_SCOPE_WORKGROUP, true>(P, k, lds + P.A.a[k].lds_offset, b.loc[u], b.flags[u], vals);
+    }
+}
+
 __global__ void __launch_bounds__(1024) part_reduce(const PartArgs P) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const uint32_t S = 1u << P.slab_log2;
@@ -575,22 +619,34 @@ __global__ void __launch_bounds__(1024) part_reduce(const PartArgs P) {
     unsigned long long len = P.qcount[slab];
     const unsigned long long lim = P.qlimit[slab];
     if (lim < len) len = lim;
-    const uint64_t lo = len * part / P.parts, hi = len * (part + 1) / P.parts;
+    // this workgroup's share, cut at multiples of 4 records so the vector loads stay aligned
+    const uint64_t quads = (len + 3) / 4;
+    const uint64_t lo = quads * part / P.parts * 4, hi = std::min<uint64_t>(len, quads * (part + 1) / P.parts * 4);
     const uint64_t qb = (uint64_t)slab * P.cap;
-    auto one = [&](uint64_t j) {
-        const uint32_t loc = P.idx16 ? ((const uint16_t *)P.qidx)[qb + j] : ((const uint32_t *)P.qidx)[qb + j];
-        const uint32_t flags = P.use_flags ? P.qflags[qb + j] : 0xffu;
+    const uint64_t hi4 = lo + ((hi - lo) & ~(uint64_t)3);
+    const uint64_t step = 4ull * blockDim.x;
+    uint64_t j = lo + 4ull * threadIdx.x;
+    for (; j + step < hi4; j += 2 * step) {
+        RecBatch b0, b1;
+        rec_load4(P, qb + j, b0);
+        rec_load4(P, qb + j + step, b1);
+        rec_apply4(P, b0, lds);
+        rec_apply4(P, b1, lds);
+    }
+    for (; j < hi4; j += step) {
+        RecBatch b0;
+        rec_load4(P, qb + j, b0);
+        rec_apply4(P, b0, lds);
+    }
+    // tail (< 4 records)
+    for (uint64_t t = hi4 + threadIdx.x; t < hi; t += blockDim.x) {
+        const uint32_t loc = P.idx16 ? ((const uint16_t *)P.qidx)[qb + t] : ((const uint32_t *)P.qidx)[qb + t];
+        const uint32_t flags = P.use_flags ? P.qflags[qb + t] : 0xffu;
         uint64_t vals[VXH_PART_MAX_VALS];
 #pragma unroll
-        for (int k = 0; k < VXH_PART_MAX_VALS; ++k) vals[k] = k < P.nvals ? P.qval[k][qb + j] : 0;
+        for (int k = 0; k < VXH_PART_MAX_VALS; ++k) vals[k] = k < P.nvals ? P.qval[k][qb + t] : 0;
         for (int k = 0; k < P.A.nagg; ++k) record_apply<__HIP_MEMORY_SCOPE_WORKGROUP, true>(P, k, lds + P.A.a[k].lds_offset, loc, flags, vals);
-    };
-    uint64_t j = lo + threadIdx.x;
-    for (; j + 3ull * blockDim.x < hi; j += 4ull * blockDim.x) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) one(j + (uint64_t)u * blockDim.x);
     }
-    for (; j < hi; j += blockDim.x) one(j);
     __syncthreads();
     const uint64_t replica = P.A.flush_plain ? part : part % (uint32_t)P.A.replicas;
     for (int k = 0; k < P.A.nagg; ++k) {
