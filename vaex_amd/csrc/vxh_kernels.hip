@@ -1,24 +1,28 @@
 // HIP kernels (gfx950 / CDNA4) for vaex's binned-statistics hot path.
 //
-//   K1  bin_kernel<STRAT, FAST>  fused  [bin index of every dim] -> [every aggregator's scatter op]
-//                                restates Grid::bin_ (src/agg.hpp:106-137) + BinnerScalar::to_bins
-//                                (src/binners.cpp:13-57) + BinnerOrdinal::to_bins
-//                                (src/binner_ordinal.cpp:20-176) + the aggregate() loops of
-//                                src/agg_count.cpp:43-67, src/agg_sum.cpp:98-127, src/agg_minmax.cpp:44-74
-//   K4  fold_kernel              replica fold = get_result()'s fold over thread grids
-//                                (src/agg_count.cpp:24-41, agg_sum.cpp:80-97, agg_minmax.cpp:27-43)
-//   K5  minmax_kernel            legacy statisticNd OP_MIN_MAX on a 0-d grid (src/vaexfast.cpp:1090-1101)
+//   K1   bin_kernel<STRAT, FAST>     fused [flat cell index of a row] -> [every aggregator's scatter op]
+//                                    restates Grid::bin_ (src/agg.hpp:106-137) + BinnerScalar::to_bins
+//                                    (src/binners.cpp:13-57) + BinnerOrdinal::to_bins (src/binner_ordinal.cpp:20-176)
+//                                    + the aggregate() loops of src/agg_count.cpp:43-67, agg_sum.cpp:98-127,
+//                                    agg_minmax.cpp:44-74
+//   K1b  part_scatter<FAST, R>       partition pass: rows -> per-slab record queues (grids too big for LDS)
+//   K1c  part_reduce                 slab queues -> LDS-private slab -> HBM replica
+//   K4   fold_kernel                 replica fold = get_result()'s fold over thread grids
+//                                    (src/agg_count.cpp:24-41, agg_sum.cpp:80-97, agg_minmax.cpp:27-43)
+//   K5   minmax_kernel               legacy statisticNd OP_MIN_MAX on a 0-d grid (src/vaexfast.cpp:1090-1101)
 //
-// The work is a bandwidth-bound gather/scatter: no MFMA.  Rows are read coalesced (lane i ->
-// row base+i), the flat cell index is computed in fp64 with exactly the reference's operation
-// order (sub, mul, compare, mul, cvt; compiled with -ffp-contract=off), and the scatter-add goes
-//   LDS    : to a workgroup-private copy of the grids in LDS (ds_add_u32 / ds_add_f64 ...),
-//            flushed once per workgroup with device-scope atomics         (grids that fit LDS)
-//   XCC    : straight to a per-XCD replica in HBM with workgroup-scope (L2-resident) atomics:
-//            every workgroup only ever touches the replica of the XCD it runs on, so the RMW
-//            stays in that XCD's 4 MiB L2 instead of going to the memory-side atomic unit
-//   GLOBAL : straight to replica blockIdx % R with device-scope atomics
-// and the replicas are folded by K4 when the result is asked for.
+// The work is a bandwidth-bound gather/scatter: no MFMA.  Rows are read coalesced (lane i -> row base+i),
+// the flat cell index is computed in fp64 with exactly the reference's operation order (sub, mul, compare,
+// mul, cvt; built with -ffp-contract=off).  Where the scatter-add goes is the strategy:
+//   LDS    : workgroup-private copy of the grids in LDS (ds_add_u32 / ds_add_f64 ...), flushed once per
+//            workgroup (grids that fit the 160 KiB of a CU; optionally S interleaved slabs re-reading rows)
+//   PART   : partition rows into per-slab queues (44 B/row instead of S x 24 B/row), then LDS-aggregate
+//   XCC / GLOBAL : HBM atomics into replicas (22e9 atomics/s chip-wide: only for tiny inputs / huge grids)
+//
+// Everything is written batch-wise: N rows per lane per trip, and all per-dimension / per-aggregator
+// dispatch (binner kind, element type, aggregator kind) happens ONCE per batch with wave-uniform branches,
+// so the per-row code is straight-line.  Inputs are normalised at load time to a canonical 64-bit value
+// (fp64 bits for float columns, sign/zero-extended integer otherwise, byte-swapped if non-native).
 #include "vxh_kernels.hpp"
 
 #include <string.h>
@@ -43,54 +47,40 @@ __device__ __forceinline__ uint64_t splitmix64(uint64_t x) { // src/hash.hpp:40-
     return x;
 }
 
-// raw little-endian element widened to 64 bits, byte-swapped when the column is non-native
-__device__ __forceinline__ uint64_t load_raw(const void *p, uint64_t i, int dt, int flip) {
-    switch (dt) {
-    case VXH_F64: case VXH_I64: case VXH_U64: {
-        uint64_t u = ((const uint64_t *)p)[i];
-        return flip ? __builtin_bswap64(u) : u;
-    }
-    case VXH_F32: case VXH_I32: case VXH_U32: {
-        uint32_t u = ((const uint32_t *)p)[i];
-        return flip ? __builtin_bswap32(u) : u;
-    }
-    case VXH_I16: case VXH_U16: {
-        uint16_t u = ((const uint16_t *)p)[i];
-        return flip ? __builtin_bswap16(u) : u;
-    }
-    default:
-        return ((const uint8_t *)p)[i];
-    }
-}
-
-// `double value_double = value;` (src/binners.cpp:24)
-__device__ __forceinline__ double raw_as_f64(uint64_t u, int dt) {
-    switch (dt) {
-    case VXH_F64: return __longlong_as_double((long long)u);
-    case VXH_F32: return (double)__uint_as_float((uint32_t)u);
-    case VXH_I64: return (double)(int64_t)u;
-    case VXH_I32: return (double)(int32_t)(uint32_t)u;
-    case VXH_I16: return (double)(int16_t)(uint16_t)u;
-    case VXH_I8: return (double)(int8_t)(uint8_t)u;
-    case VXH_U64: return (double)u;
-    case VXH_U32: return (double)(uint32_t)u;
-    case VXH_U16: return (double)(uint16_t)u;
-    case VXH_U8: return (double)(uint8_t)u;
-    default: return u ? 1.0 : 0.0; // bool
-    }
-}
-
-__device__ __forceinline__ int64_t raw_as_i64(uint64_t u, int dt) {
-    switch (dt) {
-    case VXH_I32: return (int32_t)(uint32_t)u;
-    case VXH_I16: return (int16_t)(uint16_t)u;
-    case VXH_I8: return (int8_t)(uint8_t)u;
-    case VXH_BOOL: return u ? 1 : 0;
-    default: return (int64_t)u; // i64/u64 as bits, u32/u16/u8 zero-extended by load_raw
-    }
-}
-
+__device__ __forceinline__ double as_f64(uint64_t u) { return __longlong_as_double((long long)u); }
+__device__ __forceinline__ uint64_t f64_bits(double d) { return (uint64_t)__double_as_longlong(d); }
 __device__ __forceinline__ bool dt_is_float(int dt) { return dt == VXH_F64 || dt == VXH_F32; }
+__device__ __forceinline__ bool dt_is_unsigned(int dt) { return dt >= VXH_U64; } // u64 u32 u16 u8 bool
+
+// canonical 64-bit value of N elements i0 + u*stride (u with bit u of `valid` set)
+template <int N>
+__device__ __forceinline__ void load_canon(const void *p, uint64_t i0, uint64_t stride, uint32_t valid, int dt, int flip, uint64_t (&out)[N]) {
+#define VXH_CANON(T, SWAP, EXPR)                                                                                       \
+    {                                                                                                                  \
+        _Pragma("unroll") for (int u = 0; u < N; ++u) {                                                                \
+            out[u] = 0;                                                                                                \
+            if ((valid >> u) & 1u) {                                                                                   \
+                T x = ((const T *)p)[i0 + (uint64_t)u * stride];                                                       \
+                if (flip) x = SWAP(x);                                                                                 \
+                out[u] = EXPR;                                                                                         \
+            }                                                                                                          \
+        }                                                                                                              \
+    }
+#define VXH_NOSWAP(x) (x)
+    switch (dt) {
+    case VXH_F64: case VXH_I64: case VXH_U64: VXH_CANON(uint64_t, __builtin_bswap64, x) break;
+    case VXH_F32: VXH_CANON(uint32_t, __builtin_bswap32, f64_bits((double)__uint_as_float(x))) break;
+    case VXH_I32: VXH_CANON(uint32_t, __builtin_bswap32, (uint64_t)(int64_t)(int32_t)x) break;
+    case VXH_U32: VXH_CANON(uint32_t, __builtin_bswap32, (uint64_t)x) break;
+    case VXH_I16: VXH_CANON(uint16_t, __builtin_bswap16, (uint64_t)(int64_t)(int16_t)x) break;
+    case VXH_U16: VXH_CANON(uint16_t, __builtin_bswap16, (uint64_t)x) break;
+    case VXH_I8: VXH_CANON(uint8_t, VXH_NOSWAP, (uint64_t)(int64_t)(int8_t)x) break;
+    case VXH_U8: VXH_CANON(uint8_t, VXH_NOSWAP, (uint64_t)x) break;
+    default: VXH_CANON(uint8_t, VXH_NOSWAP, (uint64_t)(x ? 1 : 0)) break; // bool
+    }
+#undef VXH_CANON
+#undef VXH_NOSWAP
+}
 
 // x86-64 cvttsd2si semantics ("integer indefinite" for NaN / out of range): what the reference's
 // `int64_t value = data_ptr[i] - min_value` does for floating T on the machines it runs on
@@ -99,82 +89,98 @@ __device__ __forceinline__ int64_t f64_to_i64_x86(double d) {
     return (int64_t)d;
 }
 
-// ------------------------------------------------------------------------------------------
-// bin index of one dimension
-// ------------------------------------------------------------------------------------------
-// BinnerScalar — src/binners.cpp:16-35 (exact operation order; no FMA contraction possible/allowed)
+// BinnerScalar — src/binners.cpp:16-35, exact operation order, branch-free selects
 __device__ __forceinline__ uint64_t scalar_sub_index(double v, bool masked, double vmin, double scale, double binsd, uint64_t bins) {
-    double scaled = (v - vmin) * scale;
-    uint64_t index = 0;
-    if (scaled != scaled || masked) {
-    } else if (scaled < 0) {
-        index = 1;
-    } else if (scaled >= 1) {
-        index = bins + 2;
-    } else {
-        index = (uint64_t)(int64_t)((int)(scaled * binsd) + 2);
-    }
+    const double scaled = (v - vmin) * scale;
+    const int bin = (int)(scaled * binsd) + 2;
+    uint64_t index = (uint64_t)(int64_t)bin;
+    index = scaled >= 1 ? bins + 2 : index;
+    index = scaled < 0 ? 1 : index;
+    index = (scaled != scaled || masked) ? 0 : index;
     return index;
 }
 
-__device__ __forceinline__ uint64_t dim_sub_index(const BinnerDesc &b, uint64_t i) {
-    bool masked = b.mask != nullptr && b.mask[i] == 1;
-    if (b.kind == VXH_BIN_SCALAR) {
-        double v = raw_as_f64(load_raw(b.data, i, b.dtype, b.flip), b.dtype);
-        return scalar_sub_index(v, masked, b.vmin, b.scale, b.binsd, b.bins);
-    } else if (b.kind == VXH_BIN_ORDINAL) {
-        // src/binner_ordinal.cpp:138-175 (and the invert / allow_other variants :22-137).  The element is
-        // NOT byte-swapped before the subtraction; the int64 difference is (reference behaviour, :25-28).
-        uint64_t u = load_raw(b.data, i, b.dtype, 0);
-        int64_t value;
-        if (b.dtype == VXH_F64) value = f64_to_i64_x86(__longlong_as_double((long long)u) - (double)b.min_value);
-        else if (b.dtype == VXH_F32) value = f64_to_i64_x86((double)(__uint_as_float((uint32_t)u) - (float)b.min_value));
-        else value = (int64_t)((uint64_t)raw_as_i64(u, b.dtype) - (uint64_t)b.min_value);
-        if (b.flip) value = (int64_t)__builtin_bswap64((uint64_t)value);
-        int64_t N = (int64_t)b.bins;
-        bool oob = value < 0 || value >= N;
-        if (b.allow_other) {
-            if (masked) return (uint64_t)N + 1;
-            if (oob) return (uint64_t)N;
-        } else {
-            if (masked || oob) return (uint64_t)N;
-        }
-        return (uint64_t)(b.invert ? N - 1 - value : value);
-    } else {
-        // hash binner: cells [unknown, bin0..binN-1, null]
-        if (masked) return (uint64_t)b.null_bin;
-        uint64_t u = load_raw(b.data, i, b.dtype, b.flip);
-        int64_t key = dt_is_float(b.dtype) ? (int64_t)u : raw_as_i64(u, b.dtype);
-        uint64_t p = splitmix64((uint64_t)key) & b.hmask;
-        for (;;) {
-            int64_t ord = b.hvals[p];
-            if (ord < 0) return 0;
-            if (b.hkeys[p] == key) return (uint64_t)ord + 1;
-            p = (p + 1) & b.hmask;
-        }
-    }
-}
-
-template <bool FAST>
-__device__ __forceinline__ uint64_t flat_index(const BinArgs &A, uint64_t i) {
-    uint64_t idx = 0;
+// flat cell index of N rows: sum over dims of sub_index * stride (src/agg.hpp:63-73, :106-137)
+template <bool FAST, int N>
+__device__ __forceinline__ void flat_index_batch(const BinArgs &A, uint64_t i0, uint64_t stride, uint32_t valid, uint64_t (&idx)[N]) {
+#pragma unroll
+    for (int u = 0; u < N; ++u) idx[u] = 0;
     for (int d = 0; d < A.ndim; ++d) {
         const BinnerDesc &b = A.b[d];
-        uint64_t sub;
         if (FAST) {
-            double v = ((const double *)b.data)[i];
-            sub = scalar_sub_index(v, false, b.vmin, b.scale, b.binsd, b.bins);
-        } else {
-            sub = dim_sub_index(b, i);
+#pragma unroll
+            for (int u = 0; u < N; ++u) {
+                if ((valid >> u) & 1u) {
+                    const double v = ((const double *)b.data)[i0 + (uint64_t)u * stride];
+                    idx[u] += scalar_sub_index(v, false, b.vmin, b.scale, b.binsd, b.bins) * b.stride;
+                }
+            }
+            continue;
         }
-        idx += sub * b.stride;
+        uint32_t masked = 0;
+        if (b.mask != nullptr) {
+#pragma unroll
+            for (int u = 0; u < N; ++u)
+                if (((valid >> u) & 1u) && b.mask[i0 + (uint64_t)u * stride] == 1) masked |= 1u << u;
+        }
+        uint64_t c[N];
+        if (b.kind == VXH_BIN_SCALAR) {
+            load_canon<N>(b.data, i0, stride, valid, b.dtype, b.flip, c);
+            const int cls = dt_is_float(b.dtype) ? 0 : (dt_is_unsigned(b.dtype) ? 2 : 1);
+#pragma unroll
+            for (int u = 0; u < N; ++u) {
+                const double v = cls == 0 ? as_f64(c[u]) : (cls == 1 ? (double)(int64_t)c[u] : (double)c[u]);
+                idx[u] += scalar_sub_index(v, (masked >> u) & 1u, b.vmin, b.scale, b.binsd, b.bins) * b.stride;
+            }
+        } else if (b.kind == VXH_BIN_ORDINAL) {
+            // src/binner_ordinal.cpp:138-175 (+ the invert / allow_other variants :22-137).  The element is NOT
+            // byte-swapped before the subtraction; the int64 difference is (reference behaviour, :25-28).
+            load_canon<N>(b.data, i0, stride, valid, b.dtype, 0, c);
+            const int64_t Nord = (int64_t)b.bins;
+#pragma unroll
+            for (int u = 0; u < N; ++u) {
+                int64_t value;
+                if (b.dtype == VXH_F64) value = f64_to_i64_x86(as_f64(c[u]) - (double)b.min_value);
+                else if (b.dtype == VXH_F32) value = f64_to_i64_x86((double)((float)as_f64(c[u]) - (float)b.min_value));
+                else value = (int64_t)(c[u] - (uint64_t)b.min_value);
+                if (b.flip) value = (int64_t)__builtin_bswap64((uint64_t)value);
+                const bool m = (masked >> u) & 1u;
+                const bool oob = value < 0 || value >= Nord;
+                uint64_t sub = (uint64_t)(b.invert ? Nord - 1 - value : value);
+                if (b.allow_other) {
+                    sub = oob ? (uint64_t)Nord : sub;
+                    sub = m ? (uint64_t)Nord + 1 : sub;
+                } else {
+                    sub = (m || oob) ? (uint64_t)Nord : sub;
+                }
+                idx[u] += sub * b.stride;
+            }
+        } else {
+            // hash binner: cells [unknown, bin0..binN-1, null]
+            load_canon<N>(b.data, i0, stride, valid, b.dtype, b.flip, c);
+#pragma unroll
+            for (int u = 0; u < N; ++u) {
+                uint64_t sub = 0;
+                if ((masked >> u) & 1u) {
+                    sub = (uint64_t)b.null_bin;
+                } else if ((valid >> u) & 1u) {
+                    const int64_t key = (int64_t)c[u];
+                    uint64_t p = splitmix64((uint64_t)key) & b.hmask;
+                    for (;;) {
+                        const int64_t ord = b.hvals[p];
+                        if (ord < 0) break;
+                        if (b.hkeys[p] == key) { sub = (uint64_t)ord + 1; break; }
+                        p = (p + 1) & b.hmask;
+                    }
+                }
+                idx[u] += sub * b.stride;
+            }
+        }
     }
-    return idx;
 }
 
 // ------------------------------------------------------------------------------------------
-// scatter ops.  SCOPE: __HIP_MEMORY_SCOPE_AGENT (device) or __HIP_MEMORY_SCOPE_WORKGROUP
-// (for LDS, and for the XCC strategy where the RMW is performed by the XCD-local L2).
+// scatter ops.  SCOPE: __HIP_MEMORY_SCOPE_AGENT (device) or __HIP_MEMORY_SCOPE_WORKGROUP (LDS)
 // ------------------------------------------------------------------------------------------
 template <int SCOPE, typename T>
 __device__ __forceinline__ void at_add(T *p, T v) { (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, SCOPE); }
@@ -187,79 +193,78 @@ __device__ __forceinline__ void at_min(T *p, T v) { (void)__hip_atomic_fetch_min
 // reference calls libm pow (src/agg_sum.cpp:159); repeated multiplication differs from it by < 1 ulp
 // per term, far inside the 1e-12 fp64 tolerance of the sums.
 __device__ __forceinline__ double pow_u(double b, uint32_t m) {
+    if (m == 2) return b * b;
     double r = 1.0;
     for (uint32_t k = 0; k < m; ++k) r *= b;
     return r;
 }
 
-// one aggregator, one row.  `cellp` = address of the cell in the chosen grid copy.
-// CT: "global" copy uses the device cell type; LDS copy uses u32 for counts.
-template <int SCOPE, bool LDS>
-__device__ __forceinline__ void agg_apply(const AggDesc &a, void *base, uint64_t idx, uint64_t raw, bool has_data) {
-    switch (a.kind) {
-    case VXH_AGG_COUNT:
-        if (LDS) at_add<SCOPE, uint32_t>((uint32_t *)base + idx, 1u);
-        else at_add<SCOPE, unsigned long long>((unsigned long long *)base + idx, 1ull);
-        break;
-    case VXH_AGG_SUM:
-    case VXH_AGG_SUM_MOMENT:
-        if (a.cell == VXH_CELL_F64) {
-            double b = raw_as_f64(raw, a.dtype);
-            if (a.kind == VXH_AGG_SUM_MOMENT) b = pow_u(b, a.moment);
-            at_add<SCOPE, double>((double *)base + idx, b);
-        } else {
-            int64_t b = raw_as_i64(raw, a.dtype);
-            if (a.kind == VXH_AGG_SUM_MOMENT) {
-                double bd = (a.cell == VXH_CELL_U64) ? (double)(uint64_t)b : (double)b;
-                double pw = pow_u(bd, a.moment);
-                b = (a.cell == VXH_CELL_U64) ? (int64_t)(uint64_t)pw : (int64_t)pw;
-            }
-            at_add<SCOPE, unsigned long long>((unsigned long long *)base + idx, (unsigned long long)b);
-        }
-        break;
-    case VXH_AGG_MIN:
-    case VXH_AGG_MAX: {
-        const bool mx = a.kind == VXH_AGG_MAX;
-        switch (a.cell) {
-        case VXH_CELL_F64: {
-            double v = raw_as_f64(raw, a.dtype);
-            if (mx) at_max<SCOPE, double>((double *)base + idx, v); else at_min<SCOPE, double>((double *)base + idx, v);
-            break;
-        }
-        case VXH_CELL_F32: {
-            float v = __uint_as_float((uint32_t)raw);
-            if (mx) at_max<SCOPE, float>((float *)base + idx, v); else at_min<SCOPE, float>((float *)base + idx, v);
-            break;
-        }
-        case VXH_CELL_I64: {
-            long long v = (long long)raw_as_i64(raw, a.dtype);
-            if (mx) at_max<SCOPE, long long>((long long *)base + idx, v); else at_min<SCOPE, long long>((long long *)base + idx, v);
-            break;
-        }
-        case VXH_CELL_U64: {
-            unsigned long long v = (unsigned long long)raw;
-            if (mx) at_max<SCOPE, unsigned long long>((unsigned long long *)base + idx, v); else at_min<SCOPE, unsigned long long>((unsigned long long *)base + idx, v);
-            break;
-        }
-        case VXH_CELL_I32: {
-            int v = (int)raw_as_i64(raw, a.dtype);
-            if (mx) at_max<SCOPE, int>((int *)base + idx, v); else at_min<SCOPE, int>((int *)base + idx, v);
-            break;
-        }
-        default: {
-            unsigned v = (unsigned)raw_as_i64(raw, a.dtype);
-            if (mx) at_max<SCOPE, unsigned>((unsigned *)base + idx, v); else at_min<SCOPE, unsigned>((unsigned *)base + idx, v);
-            break;
-        }
-        }
-        break;
-    }
-    default: break;
-    }
-}
-
 __device__ __forceinline__ size_t cell_size_dev(int cell) { return cell >= VXH_CELL_F32 ? 4 : 8; }
 __device__ __forceinline__ size_t lds_cell_size_dev(int kind, int cell) { return kind == VXH_AGG_COUNT ? 4 : cell_size_dev(cell); }
+
+// one aggregator, N rows.  v[] canonical values (ignored when the aggregator has no input), keep = rows that
+// take part.  LDS copies count in uint32 (a workgroup sees < 2^32 rows), HBM grids in the device cell type.
+template <int SCOPE, bool LDS, int N, typename IDX>
+__device__ __forceinline__ void agg_batch(const AggDesc &a, void *base, const IDX (&idx)[N], const uint64_t (&v)[N], uint32_t keep, bool has_data) {
+    if (has_data && dt_is_float(a.dtype)) { // NaN rows are skipped (src/agg_sum.cpp:113, agg_count.cpp:56)
+#pragma unroll
+        for (int u = 0; u < N; ++u) {
+            const double d = as_f64(v[u]);
+            if (d != d) keep &= ~(1u << u);
+        }
+    }
+    if (keep == 0) return;
+#define VXH_EACH(STMT)                                                                                                 \
+    {                                                                                                                  \
+        _Pragma("unroll") for (int u = 0; u < N; ++u) {                                                                \
+            if ((keep >> u) & 1u) { STMT; }                                                                            \
+        }                                                                                                              \
+    }
+    const bool mx = a.kind == VXH_AGG_MAX;
+    switch (a.kind) {
+    case VXH_AGG_COUNT:
+        if (LDS) VXH_EACH((at_add<SCOPE, uint32_t>((uint32_t *)base + idx[u], 1u)))
+        else VXH_EACH((at_add<SCOPE, unsigned long long>((unsigned long long *)base + idx[u], 1ull)))
+        break;
+    case VXH_AGG_SUM:
+        if (a.cell == VXH_CELL_F64) VXH_EACH((at_add<SCOPE, double>((double *)base + idx[u], as_f64(v[u]))))
+        else VXH_EACH((at_add<SCOPE, unsigned long long>((unsigned long long *)base + idx[u], (unsigned long long)v[u])))
+        break;
+    case VXH_AGG_SUM_MOMENT:
+        if (a.cell == VXH_CELL_F64) VXH_EACH((at_add<SCOPE, double>((double *)base + idx[u], pow_u(as_f64(v[u]), a.moment))))
+        else if (a.cell == VXH_CELL_U64) VXH_EACH((at_add<SCOPE, unsigned long long>((unsigned long long *)base + idx[u], (unsigned long long)pow_u((double)v[u], a.moment))))
+        else VXH_EACH((at_add<SCOPE, unsigned long long>((unsigned long long *)base + idx[u], (unsigned long long)(long long)pow_u((double)(int64_t)v[u], a.moment))))
+        break;
+    default: // min / max
+        switch (a.cell) {
+        case VXH_CELL_F64:
+            if (mx) VXH_EACH((at_max<SCOPE, double>((double *)base + idx[u], as_f64(v[u]))))
+            else VXH_EACH((at_min<SCOPE, double>((double *)base + idx[u], as_f64(v[u]))))
+            break;
+        case VXH_CELL_F32:
+            if (mx) VXH_EACH((at_max<SCOPE, float>((float *)base + idx[u], (float)as_f64(v[u]))))
+            else VXH_EACH((at_min<SCOPE, float>((float *)base + idx[u], (float)as_f64(v[u]))))
+            break;
+        case VXH_CELL_I64:
+            if (mx) VXH_EACH((at_max<SCOPE, long long>((long long *)base + idx[u], (long long)v[u])))
+            else VXH_EACH((at_min<SCOPE, long long>((long long *)base + idx[u], (long long)v[u])))
+            break;
+        case VXH_CELL_U64:
+            if (mx) VXH_EACH((at_max<SCOPE, unsigned long long>((unsigned long long *)base + idx[u], (unsigned long long)v[u])))
+            else VXH_EACH((at_min<SCOPE, unsigned long long>((unsigned long long *)base + idx[u], (unsigned long long)v[u])))
+            break;
+        case VXH_CELL_I32:
+            if (mx) VXH_EACH((at_max<SCOPE, int>((int *)base + idx[u], (int)(int64_t)v[u])))
+            else VXH_EACH((at_min<SCOPE, int>((int *)base + idx[u], (int)(int64_t)v[u])))
+            break;
+        default:
+            if (mx) VXH_EACH((at_max<SCOPE, unsigned>((unsigned *)base + idx[u], (unsigned)v[u])))
+            else VXH_EACH((at_min<SCOPE, unsigned>((unsigned *)base + idx[u], (unsigned)v[u])))
+            break;
+        }
+    }
+#undef VXH_EACH
+}
 
 __device__ __forceinline__ uint64_t identity_bits(int kind, int cell) {
     if (kind != VXH_AGG_MIN && kind != VXH_AGG_MAX) return 0;
@@ -271,6 +276,17 @@ __device__ __forceinline__ uint64_t identity_bits(int kind, int cell) {
     case VXH_CELL_U64: return mx ? 0ull : ~0ull;
     case VXH_CELL_I32: return mx ? 0x80000000u : 0x7fffffffu;
     default: return mx ? 0u : 0xffffffffu;
+    }
+}
+
+// identity-fill the LDS-private grids of every aggregator
+__device__ __forceinline__ void lds_init(const BinArgs &A, char *lds, uint64_t slab_cells) {
+    for (int k = 0; k < A.nagg; ++k) {
+        const AggDesc &a = A.a[k];
+        char *base = lds + a.lds_offset;
+        const uint64_t ident = identity_bits(a.kind, a.cell);
+        if (lds_cell_size_dev(a.kind, a.cell) == 4) for (uint64_t c = threadIdx.x; c < slab_cells; c += blockDim.x) ((uint32_t *)base)[c] = (uint32_t)ident;
+        else for (uint64_t c = threadIdx.x; c < slab_cells; c += blockDim.x) ((uint64_t *)base)[c] = ident;
     }
 }
 
@@ -286,78 +302,53 @@ __device__ __forceinline__ void flush_minmax(T *g, T v, bool mx, bool plain) {
     }
 }
 
-// LDS cell c of aggregator a -> HBM cell gc of the chosen replica
-__device__ __forceinline__ void flush_cell(const AggDesc &a, char *lds_base, uint64_t c, char *g, uint64_t gc, bool plain) {
-    switch (a.kind) {
-    case VXH_AGG_COUNT: {
-        uint32_t v = ((uint32_t *)lds_base)[c];
-        if (v) {
-            if (plain) ((unsigned long long *)g)[gc] += v;
-            else at_add<__HIP_MEMORY_SCOPE_AGENT, unsigned long long>((unsigned long long *)g + gc, (unsigned long long)v);
-        }
-        break;
-    }
-    case VXH_AGG_SUM:
-    case VXH_AGG_SUM_MOMENT:
-        if (a.cell == VXH_CELL_F64) {
-            double v = ((double *)lds_base)[c];
-            if (v != 0.0) {
-                if (plain) ((double *)g)[gc] += v;
-                else at_add<__HIP_MEMORY_SCOPE_AGENT, double>((double *)g + gc, v);
-            }
-        } else {
-            unsigned long long v = ((unsigned long long *)lds_base)[c];
-            if (v) {
-                if (plain) ((unsigned long long *)g)[gc] += v;
-                else at_add<__HIP_MEMORY_SCOPE_AGENT, unsigned long long>((unsigned long long *)g + gc, v);
-            }
-        }
-        break;
-    default: {
-        const bool mx = a.kind == VXH_AGG_MAX;
-        switch (a.cell) {
-        case VXH_CELL_F64: flush_minmax<double>((double *)g + gc, ((double *)lds_base)[c], mx, plain); break;
-        case VXH_CELL_F32: flush_minmax<float>((float *)g + gc, ((float *)lds_base)[c], mx, plain); break;
-        case VXH_CELL_I64: flush_minmax<long long>((long long *)g + gc, ((long long *)lds_base)[c], mx, plain); break;
-        case VXH_CELL_U64: flush_minmax<unsigned long long>((unsigned long long *)g + gc, ((unsigned long long *)lds_base)[c], mx, plain); break;
-        case VXH_CELL_I32: flush_minmax<int>((int *)g + gc, ((int *)lds_base)[c], mx, plain); break;
-        default: flush_minmax<unsigned>((unsigned *)g + gc, ((unsigned *)lds_base)[c], mx, plain); break;
-        }
-    }
-    }
-}
-
-// all aggregators of one row
-template <int STRAT, bool FAST>
-__device__ __forceinline__ void row_aggregate(const BinArgs &A, uint64_t i, uint64_t idx, uint64_t replica, char *lds, uint32_t slab) {
-    constexpr bool LDS = STRAT == VXH_STRAT_LDS;
-    constexpr int SCOPE = (STRAT == VXH_STRAT_GLOBAL) ? __HIP_MEMORY_SCOPE_AGENT : __HIP_MEMORY_SCOPE_WORKGROUP;
-    if (LDS) {
-        // this workgroup owns the cells with (cell mod S) == slab; they live at LDS index cell / S
-        if (((uint32_t)idx & ((1u << A.slab_log2) - 1u)) != slab) return;
-        idx >>= A.slab_log2;
-    }
+// flush the LDS-private slab of every aggregator into replica `replica` of its HBM grid: plain
+// read-modify-write when this workgroup is the replica's only writer, device-scope atomics otherwise
+__device__ __forceinline__ void lds_flush(const BinArgs &A, char *lds, uint64_t slab_cells, uint32_t slab_log2, uint32_t slab, uint64_t replica, bool plain) {
     for (int k = 0; k < A.nagg; ++k) {
         const AggDesc &a = A.a[k];
-        if (a.mask != nullptr && a.mask[i] != 1) continue; // aggregator mask: 1 = keep (src/agg_count.cpp:50)
-        uint64_t raw = 0;
-        if (a.data != nullptr) {
-            if (FAST) {
-                raw = ((const uint64_t *)a.data)[i];
-                double v = __longlong_as_double((long long)raw);
-                if (v != v) continue; // NaN rows are skipped (src/agg_sum.cpp:113, agg_count.cpp:56)
-            } else {
-                raw = load_raw(a.data, i, a.dtype, a.flip);
-                if (dt_is_float(a.dtype)) {
-                    double v = raw_as_f64(raw, a.dtype);
-                    if (v != v) continue;
+        char *base = lds + a.lds_offset;
+        char *g = (char *)a.grid + replica * A.cells * cell_size_dev(a.cell);
+        const bool mx = a.kind == VXH_AGG_MAX;
+        for (uint64_t c = threadIdx.x; c < slab_cells; c += blockDim.x) {
+            const uint64_t gc = (c << slab_log2) + slab;
+            if (gc >= A.cells) continue;
+            switch (a.kind) {
+            case VXH_AGG_COUNT: {
+                const uint32_t v = ((uint32_t *)base)[c];
+                if (v) {
+                    if (plain) ((unsigned long long *)g)[gc] += v;
+                    else at_add<__HIP_MEMORY_SCOPE_AGENT, unsigned long long>((unsigned long long *)g + gc, (unsigned long long)v);
+                }
+                break;
+            }
+            case VXH_AGG_SUM:
+            case VXH_AGG_SUM_MOMENT:
+                if (a.cell == VXH_CELL_F64) {
+                    const double v = ((double *)base)[c];
+                    if (v != 0.0) {
+                        if (plain) ((double *)g)[gc] += v;
+                        else at_add<__HIP_MEMORY_SCOPE_AGENT, double>((double *)g + gc, v);
+                    }
+                } else {
+                    const unsigned long long v = ((unsigned long long *)base)[c];
+                    if (v) {
+                        if (plain) ((unsigned long long *)g)[gc] += v;
+                        else at_add<__HIP_MEMORY_SCOPE_AGENT, unsigned long long>((unsigned long long *)g + gc, v);
+                    }
+                }
+                break;
+            default:
+                switch (a.cell) {
+                case VXH_CELL_F64: flush_minmax<double>((double *)g + gc, ((double *)base)[c], mx, plain); break;
+                case VXH_CELL_F32: flush_minmax<float>((float *)g + gc, ((float *)base)[c], mx, plain); break;
+                case VXH_CELL_I64: flush_minmax<long long>((long long *)g + gc, ((long long *)base)[c], mx, plain); break;
+                case VXH_CELL_U64: flush_minmax<unsigned long long>((unsigned long long *)g + gc, ((unsigned long long *)base)[c], mx, plain); break;
+                case VXH_CELL_I32: flush_minmax<int>((int *)g + gc, ((int *)base)[c], mx, plain); break;
+                default: flush_minmax<unsigned>((unsigned *)g + gc, ((unsigned *)base)[c], mx, plain); break;
                 }
             }
         }
-        void *base;
-        if (LDS) base = lds + a.lds_offset;
-        else base = (char *)a.grid + replica * A.cells * cell_size_dev(a.cell);
-        agg_apply<SCOPE, LDS>(a, base, idx, raw, a.data != nullptr);
     }
 }
 
@@ -365,14 +356,16 @@ __device__ __forceinline__ void row_aggregate(const BinArgs &A, uint64_t i, uint
 // K1
 // ------------------------------------------------------------------------------------------
 // LDS strategy geometry: gridDim.x = ngroups * S workgroups, S = 2^slab_log2 interleaved slabs.  The S
-// workgroups of a group walk the SAME rows (each keeps only the cells of its slab), and are laid out so
-// that — with the dispatcher's observed round-robin of workgroups over the 8 XCDs — they share an XCD
-// and therefore its L2 (performance only; correctness never depends on placement):
+// workgroups of a group walk the SAME rows (each keeps only the cells of its slab):
 //   xcd = b & 7, local = b >> 3, slab = local & (S-1), group = (local >> slab_log2) * 8 + xcd.
+// (S > 1 re-reads every row S times — measured: no L2 sharing between the owners, profiles/r01_microbench_v2*
+//  — so the planner prefers the partition strategy; S > 1 stays as a selectable variant.)
 template <int STRAT, bool FAST>
 __global__ void __launch_bounds__(1024) bin_kernel(const BinArgs A) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr bool LDS = STRAT == VXH_STRAT_LDS;
+    constexpr int SCOPE = LDS ? __HIP_MEMORY_SCOPE_WORKGROUP : __HIP_MEMORY_SCOPE_AGENT;
+    constexpr int N = 4;
 
     uint64_t replica;
     uint32_t slab = 0, group = blockIdx.x, ngroups = gridDim.x;
@@ -384,123 +377,146 @@ __global__ void __launch_bounds__(1024) bin_kernel(const BinArgs A) {
         ngroups = (uint32_t)A.ngroups;
         slab_cells = (A.cells + (1ull << A.slab_log2) - 1) >> A.slab_log2;
         replica = A.flush_plain ? group : group % (uint32_t)A.replicas;
+        lds_init(A, lds, slab_cells);
+        __syncthreads();
     } else if (STRAT == VXH_STRAT_XCC) {
         replica = (uint64_t)xcc_id() * A.replicas_per_xcc + (blockIdx.x >> 3) % A.replicas_per_xcc;
     } else {
         replica = blockIdx.x % A.replicas;
     }
 
-    if (LDS) {
-        // identity-fill the private grids: 0 for counts/sums, the type's limit for min/max
-        for (int k = 0; k < A.nagg; ++k) {
-            const AggDesc &a = A.a[k];
-            const size_t cs = lds_cell_size_dev(a.kind, a.cell);
-            char *base = lds + a.lds_offset;
-            const uint64_t ident = identity_bits(a.kind, a.cell);
-            if (cs == 4) for (uint64_t c = threadIdx.x; c < slab_cells; c += blockDim.x) ((uint32_t *)base)[c] = (uint32_t)ident;
-            else for (uint64_t c = threadIdx.x; c < slab_cells; c += blockDim.x) ((uint64_t *)base)[c] = ident;
-        }
-        __syncthreads();
-    }
-
     const uint64_t stride = (uint64_t)ngroups * blockDim.x;
-    uint64_t i = (uint64_t)group * blockDim.x + threadIdx.x;
-    // 4 independent rows per thread per trip: 4x the loads in flight before the first dependent op
-    for (; i + 3 * stride < A.n; i += 4 * stride) {
-        uint64_t idx[4];
+    for (uint64_t i0 = (uint64_t)group * blockDim.x + threadIdx.x; i0 < A.n; i0 += N * stride) {
+        uint32_t valid = 0;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) idx[u] = flat_index<FAST>(A, i + u * stride);
+        for (int u = 0; u < N; ++u) valid |= (i0 + (uint64_t)u * stride < A.n ? 1u : 0u) << u;
+        uint64_t idx[N];
+        flat_index_batch<FAST, N>(A, i0, stride, valid, idx);
+        uint32_t mine = valid;
+        if (LDS) { // this workgroup owns the cells with (cell mod S) == slab; they live at LDS index cell / S
 #pragma unroll
-        for (int u = 0; u < 4; ++u) row_aggregate<STRAT, FAST>(A, i + u * stride, idx[u], replica, lds, slab);
-    }
-    for (; i < A.n; i += stride) {
-        uint64_t idx = flat_index<FAST>(A, i);
-        row_aggregate<STRAT, FAST>(A, i, idx, replica, lds, slab);
-    }
-
-    if (LDS) {
-        __syncthreads();
-        // flush the private slab into replica `replica` of the HBM grid: plain read-modify-write when this
-        // workgroup is the replica's only writer (flush_plain), device-scope atomics otherwise
-        for (int k = 0; k < A.nagg; ++k) {
-            const AggDesc &a = A.a[k];
-            char *base = lds + a.lds_offset;
-            char *g = (char *)a.grid + replica * A.cells * cell_size_dev(a.cell);
-            for (uint64_t c = threadIdx.x; c < slab_cells; c += blockDim.x) {
-                const uint64_t gc = (c << A.slab_log2) + slab;
-                if (gc >= A.cells) continue;
-                flush_cell(a, base, c, g, gc, A.flush_plain != 0);
+            for (int u = 0; u < N; ++u) {
+                if (((uint32_t)idx[u] & ((1u << A.slab_log2) - 1u)) != slab) mine &= ~(1u << u);
+                idx[u] >>= A.slab_log2;
             }
         }
+        for (int k = 0; k < A.nagg; ++k) {
+            const AggDesc &a = A.a[k];
+            uint32_t keep = mine;
+            if (a.mask != nullptr) { // aggregator mask: 1 = keep (src/agg_count.cpp:50)
+#pragma unroll
+                for (int u = 0; u < N; ++u)
+                    if (((keep >> u) & 1u) && a.mask[i0 + (uint64_t)u * stride] != 1) keep &= ~(1u << u);
+            }
+            uint64_t v[N];
+            const bool has_data = a.data != nullptr;
+            if (has_data) {
+                if (FAST) {
+#pragma unroll
+                    for (int u = 0; u < N; ++u) v[u] = ((keep >> u) & 1u) ? ((const uint64_t *)a.data)[i0 + (uint64_t)u * stride] : 0;
+                } else {
+                    load_canon<N>(a.data, i0, stride, keep, a.dtype, a.flip, v);
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < N; ++u) v[u] = 0;
+            }
+            void *base = LDS ? (void *)(lds + a.lds_offset) : (void *)((char *)a.grid + replica * A.cells * cell_size_dev(a.cell));
+            agg_batch<SCOPE, LDS, N>(a, base, idx, v, keep, has_data);
+        }
+    }
+
+    if (LDS) {
+        __syncthreads();
+        lds_flush(A, lds, slab_cells, A.slab_log2, slab, replica, A.flush_plain != 0);
     }
 }
 
 // ------------------------------------------------------------------------------------------
 // K1b / K1c — partition strategy (see PartArgs)
 // ------------------------------------------------------------------------------------------
-// one aggregator, one record, given the record's mask flags and input values (already native-endian)
-template <int SCOPE, bool LDS>
-__device__ __forceinline__ void record_apply(const PartArgs &P, int k, void *base, uint64_t idx, uint32_t flags, const uint64_t *vals) {
-    const AggDesc &a = P.A.a[k];
-    const uint32_t mb = P.agg_mbit[k];
-    if (mb != 0xffu && !((flags >> mb) & 1u)) return;
-    uint64_t raw = 0;
-    const uint32_t vs = P.agg_vslot[k];
-    if (vs != 0xffu) {
-        raw = vals[vs];
-        if (dt_is_float(a.dtype)) {
-            double v = raw_as_f64(raw, a.dtype);
-            if (v != v) return; // NaN rows are skipped
+// all aggregators over N records whose mask flags and canonical inputs are in registers
+template <int SCOPE, bool LDS, int N, typename IDX>
+__device__ __forceinline__ void records_apply(const PartArgs &P, char *lds, const IDX (&idx)[N], const uint32_t (&flags)[N], const uint64_t (&vals)[VXH_PART_MAX_VALS][N], uint32_t valid) {
+    for (int k = 0; k < P.A.nagg; ++k) {
+        const AggDesc &a = P.A.a[k];
+        uint32_t keep = valid;
+        const uint32_t mb = P.agg_mbit[k];
+        if (mb != 0xffu) {
+#pragma unroll
+            for (int u = 0; u < N; ++u)
+                if (!((flags[u] >> mb) & 1u)) keep &= ~(1u << u);
         }
+        const uint32_t vs = P.agg_vslot[k];
+        uint64_t v[N];
+#pragma unroll
+        for (int u = 0; u < N; ++u) v[u] = vs == 0 ? vals[0][u] : (vs == 1 ? vals[1][u] : (vs == 2 ? vals[2][u] : (vs == 3 ? vals[3][u] : 0)));
+        void *base = LDS ? (void *)(lds + a.lds_offset) : a.grid;
+        agg_batch<SCOPE, LDS, N>(a, base, idx, v, keep, vs != 0xffu);
     }
-    agg_apply<SCOPE, LDS>(a, base, idx, raw, vs != 0xffu);
 }
 
 // pass 1: rows -> per-slab record queues.  512 threads, R rows per thread per tile.
 template <bool FAST, int R>
 __global__ void __launch_bounds__(512) part_scatter(const PartArgs P) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    constexpr uint32_t NONE = 0xffffffffu;
     constexpr unsigned long long OVERFLOW = ~0ull;
     const uint32_t S = 1u << P.slab_log2;
     const uint32_t T = 512u * R;
-    // LDS carve (all offsets multiples of 16)
-    uint32_t *s_cnt = (uint32_t *)lds;                                // [S]
-    uint32_t *s_off = s_cnt + S;                                      // [S+1] (+pad)
+    // LDS carve (all offsets multiples of 8)
+    uint32_t *s_cnt = (uint32_t *)lds;                                   // [S]
+    uint32_t *s_off = s_cnt + S;                                         // [S+1] (+pad)
     unsigned long long *s_gbase = (unsigned long long *)(s_off + S + 4); // [S]
-    uint64_t *st_val = (uint64_t *)(s_gbase + S);                      // [nvals][T]
-    uint32_t *st_idx = (uint32_t *)(st_val + (size_t)P.nvals * T);     // [T]
-    uint16_t *st_slab = (uint16_t *)(st_idx + T);                      // [T]
-    uint8_t *st_flags = (uint8_t *)(st_slab + T);                      // [T]
+    uint64_t *st_val = (uint64_t *)(s_gbase + S);                        // [nvals][T]
+    uint32_t *st_idx = (uint32_t *)(st_val + (size_t)P.nvals * T);       // [T]
+    uint16_t *st_slab = (uint16_t *)(st_idx + T);                        // [T]
+    uint8_t *st_flags = (uint8_t *)(st_slab + T);                        // [T]
     const uint64_t n = P.A.n;
 
     for (uint64_t tile = blockIdx.x; tile * T < n; tile += gridDim.x) {
-        const uint64_t base = tile * T;
+        const uint64_t i0 = tile * T + threadIdx.x;
         for (uint32_t s = threadIdx.x; s < S; s += 512) s_cnt[s] = 0;
         __syncthreads();
 
-        uint32_t slab[R], loc[R], pos[R], fl[R];
-        uint64_t val[R][VXH_PART_MAX_VALS];
+        uint32_t valid = 0;
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const uint64_t i = base + (uint64_t)r * 512 + threadIdx.x;
-            pos[r] = NONE;
-            slab[r] = 0; loc[r] = 0; fl[r] = 0;
-            if (i < n) {
-                uint32_t flags = 0;
-                for (int m = 0; m < P.nmasks; ++m) flags |= (P.mdata[m][i] == 1 ? 1u : 0u) << m;
-                const bool keep = !(P.all_masked && flags == 0);
-                if (keep) {
-                    const uint64_t idx = flat_index<FAST>(P.A, i);
-                    slab[r] = (uint32_t)idx & (S - 1);
-                    loc[r] = (uint32_t)(idx >> P.slab_log2);
-                    fl[r] = flags;
+        for (int r = 0; r < R; ++r) valid |= (i0 + (uint64_t)r * 512 < n ? 1u : 0u) << r;
+        // aggregator masks -> one flag bit per distinct mask; rows no aggregator wants emit no record
+        uint32_t fl[R];
 #pragma unroll
-                    for (int k = 0; k < VXH_PART_MAX_VALS; ++k)
-                        if (k < P.nvals) val[r][k] = FAST ? ((const uint64_t *)P.vdata[k])[i] : load_raw(P.vdata[k], i, P.vdtype[k], P.vflip[k]);
-                    pos[r] = __hip_atomic_fetch_add(&s_cnt[slab[r]], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        for (int r = 0; r < R; ++r) fl[r] = 0;
+        for (int m = 0; m < P.nmasks; ++m) {
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                if (((valid >> r) & 1u) && P.mdata[m][i0 + (uint64_t)r * 512] == 1) fl[r] |= 1u << m;
+        }
+        uint32_t keep = valid;
+        if (P.all_masked) {
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                if (fl[r] == 0) keep &= ~(1u << r);
+        }
+        uint64_t idx[R];
+        flat_index_batch<FAST, R>(P.A, i0, 512, keep, idx);
+        uint64_t val[VXH_PART_MAX_VALS][R];
+#pragma unroll
+        for (int k = 0; k < VXH_PART_MAX_VALS; ++k) {
+            if (k < P.nvals) {
+                if (FAST) {
+#pragma unroll
+                    for (int r = 0; r < R; ++r) val[k][r] = ((keep >> r) & 1u) ? ((const uint64_t *)P.vdata[k])[i0 + (uint64_t)r * 512] : 0;
+                } else {
+                    load_canon<R>(P.vdata[k], i0, 512, keep, P.vdtype[k], P.vflip[k], val[k]);
                 }
             }
+        }
+        uint32_t slab[R], loc[R], pos[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            slab[r] = (uint32_t)idx[r] & (S - 1);
+            loc[r] = (uint32_t)(idx[r] >> P.slab_log2);
+            pos[r] = 0;
+            if ((keep >> r) & 1u) pos[r] = __hip_atomic_fetch_add(&s_cnt[slab[r]], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         __syncthreads();
         // exclusive prefix over the S bucket counts + reservation of queue space (one HBM atomic per slab per tile)
@@ -523,14 +539,14 @@ __global__ void __launch_bounds__(512) part_scatter(const PartArgs P) {
         __syncthreads();
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            if (pos[r] != NONE) {
+            if ((keep >> r) & 1u) {
                 const uint32_t j = s_off[slab[r]] + pos[r];
                 st_idx[j] = loc[r];
                 st_slab[j] = (uint16_t)slab[r];
                 st_flags[j] = (uint8_t)fl[r];
 #pragma unroll
                 for (int k = 0; k < VXH_PART_MAX_VALS; ++k)
-                    if (k < P.nvals) st_val[(size_t)k * T + j] = val[r][k];
+                    if (k < P.nvals) st_val[(size_t)k * T + j] = val[k][r];
             }
         }
         __syncthreads();
@@ -547,59 +563,51 @@ __global__ void __launch_bounds__(512) part_scatter(const PartArgs P) {
                 for (int k = 0; k < VXH_PART_MAX_VALS; ++k)
                     if (k < P.nvals) P.qval[k][dst] = st_val[(size_t)k * T + j];
             } else {
-                // queue full (pathologically skewed data): scatter this record straight to HBM
-                const uint64_t gidx = ((uint64_t)st_idx[j] << P.slab_log2) + s;
-                uint64_t vals[VXH_PART_MAX_VALS];
+                // queue full (pathologically skewed data): scatter this record straight to HBM replica 0
+                uint64_t gidx[1] = {((uint64_t)st_idx[j] << P.slab_log2) + s};
+                uint32_t f1[1] = {(uint32_t)st_flags[j]};
+                uint64_t v1[VXH_PART_MAX_VALS][1];
 #pragma unroll
-                for (int k = 0; k < VXH_PART_MAX_VALS; ++k) vals[k] = k < P.nvals ? st_val[(size_t)k * T + j] : 0;
-                for (int k = 0; k < P.A.nagg; ++k) record_apply<__HIP_MEMORY_SCOPE_AGENT, false>(P, k, P.A.a[k].grid, gidx, st_flags[j], vals);
+                for (int k = 0; k < VXH_PART_MAX_VALS; ++k) v1[k][0] = k < P.nvals ? st_val[(size_t)k * T + j] : 0;
+                records_apply<__HIP_MEMORY_SCOPE_AGENT, false, 1>(P, nullptr, gidx, f1, v1, 1u);
             }
         }
         __syncthreads();
     }
 }
 
-// pass 2: slab queues -> LDS-private slab -> HBM replica.
-// The queue is streamed with 4 records per lane per load batch and two batches in flight (the LDS atomics
-// retire at >1 record/clk/CU — profiles/r01_microbench_v3_lds_atomics.txt — so this pass is a pure stream
-// and needs the memory-level parallelism of one).
-struct RecBatch {
-    uint32_t loc[4];
-    uint32_t flags[4];
-    uint64_t vals[VXH_PART_MAX_VALS][4];
-};
-
-__device__ __forceinline__ void rec_load4(const PartArgs &P, uint64_t at, RecBatch &b) {
-    if (P.idx16) {
-        const ushort4 q = *(const ushort4 *)((const uint16_t *)P.qidx + at);
-        b.loc[0] = q.x; b.loc[1] = q.y; b.loc[2] = q.z; b.loc[3] = q.w;
-    } else {
-        const uint4 q = *(const uint4 *)((const uint32_t *)P.qidx + at);
-        b.loc[0] = q.x; b.loc[1] = q.y; b.loc[2] = q.z; b.loc[3] = q.w;
-    }
-    if (P.use_flags) {
-        const uchar4 f = *(const uchar4 *)(P.qflags + at);
-        b.flags[0] = f.x; b.flags[1] = f.y; b.flags[2] = f.z; b.flags[3] = f.w;
-    } else {
-        b.flags[0] = b.flags[1] = b.flags[2] = b.flags[3] = 0xffu;
-    }
+// pass 2: slab queues -> LDS-private slab -> HBM replica.  Each lane streams 4 consecutive records per
+// vector load and keeps N4 such batches in flight.
+template <int N4>
+__device__ __forceinline__ void reduce_trip(const PartArgs &P, char *lds, uint64_t at, uint64_t step) {
+    constexpr int N = 4 * N4;
+    uint32_t loc[N], flags[N];
+    uint64_t vals[VXH_PART_MAX_VALS][N];
 #pragma unroll
-    for (int k = 0; k < VXH_PART_MAX_VALS; ++k) {
-        if (k < P.nvals) {
-            const ulonglong2 a = *(const ulonglong2 *)(P.qval[k] + at), c = *(const ulonglong2 *)(P.qval[k] + at + 2);
-            b.vals[k][0] = a.x; b.vals[k][1] = a.y; b.vals[k][2] = c.x; b.vals[k][3] = c.y;
+    for (int b = 0; b < N4; ++b) {
+        const uint64_t q = at + (uint64_t)b * step;
+        if (P.idx16) {
+            const ushort4 x = *(const ushort4 *)((const uint16_t *)P.qidx + q);
+            loc[4 * b] = x.x; loc[4 * b + 1] = x.y; loc[4 * b + 2] = x.z; loc[4 * b + 3] = x.w;
+        } else {
+            const uint4 x = *(const uint4 *)((const uint32_t *)P.qidx + q);
+            loc[4 * b] = x.x; loc[4 * b + 1] = x.y; loc[4 * b + 2] = x.z; loc[4 * b + 3] = x.w;
+        }
+        if (P.use_flags) {
+            const uchar4 f = *(const uchar4 *)(P.qflags + q);
+            flags[4 * b] = f.x; flags[4 * b + 1] = f.y; flags[4 * b + 2] = f.z; flags[4 * b + 3] = f.w;
+        } else {
+            flags[4 * b] = flags[4 * b + 1] = flags[4 * b + 2] = flags[4 * b + 3] = 0xffu;
+        }
+#pragma unroll
+        for (int k = 0; k < VXH_PART_MAX_VALS; ++k) {
+            if (k < P.nvals) {
+                const ulonglong2 a = *(const ulonglong2 *)(P.qval[k] + q), c = *(const ulonglong2 *)(P.qval[k] + q + 2);
+                vals[k][4 * b] = a.x; vals[k][4 * b + 1] = a.y; vals[k][4 * b + 2] = c.x; vals[k][4 * b + 3] = c.y;
+            }
         }
     }
-}
-
-__device__ __forceinline__ void rec_apply4(const PartArgs &P, const RecBatch &b, char *lds) {
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        uint64_t vals[VXH_PART_MAX_VALS];
-#pragma unroll
-        for (int k = 0; k < VXH_PART_MAX_VALS; ++k) vals[k] = k < P.nvals ? b.vals[k][u] : 0;
-        for (int k = 0; k < P.A.nagg; ++k) record_apply<__HIP_MEMORY_SCOPE_WORKGROUP, true>(P, k, lds + P.A.a[k].lds_offset, b.loc[u], b.flags[u], vals);
-    }
+    records_apply<__HIP_MEMORY_SCOPE_WORKGROUP, true, N>(P, lds, loc, flags, vals, (1u << N) - 1u);
 }
 
 __global__ void __launch_bounds__(1024) part_reduce(const PartArgs P) {
@@ -607,14 +615,7 @@ __global__ void __launch_bounds__(1024) part_reduce(const PartArgs P) {
     const uint32_t S = 1u << P.slab_log2;
     const uint32_t slab = blockIdx.x % S, part = blockIdx.x / S;
     const uint64_t slab_cells = (P.A.cells + S - 1) >> P.slab_log2;
-    for (int k = 0; k < P.A.nagg; ++k) {
-        const AggDesc &a = P.A.a[k];
-        const size_t cs = lds_cell_size_dev(a.kind, a.cell);
-        char *base = lds + a.lds_offset;
-        const uint64_t ident = identity_bits(a.kind, a.cell);
-        if (cs == 4) for (uint64_t c = threadIdx.x; c < slab_cells; c += blockDim.x) ((uint32_t *)base)[c] = (uint32_t)ident;
-        else for (uint64_t c = threadIdx.x; c < slab_cells; c += blockDim.x) ((uint64_t *)base)[c] = ident;
-    }
+    lds_init(P.A, lds, slab_cells);
     __syncthreads();
     unsigned long long len = P.qcount[slab];
     const unsigned long long lim = P.qlimit[slab];
@@ -626,39 +627,19 @@ __global__ void __launch_bounds__(1024) part_reduce(const PartArgs P) {
     const uint64_t hi4 = lo + ((hi - lo) & ~(uint64_t)3);
     const uint64_t step = 4ull * blockDim.x;
     uint64_t j = lo + 4ull * threadIdx.x;
-    for (; j + step < hi4; j += 2 * step) {
-        RecBatch b0, b1;
-        rec_load4(P, qb + j, b0);
-        rec_load4(P, qb + j + step, b1);
-        rec_apply4(P, b0, lds);
-        rec_apply4(P, b1, lds);
-    }
-    for (; j < hi4; j += step) {
-        RecBatch b0;
-        rec_load4(P, qb + j, b0);
-        rec_apply4(P, b0, lds);
-    }
-    // tail (< 4 records)
-    for (uint64_t t = hi4 + threadIdx.x; t < hi; t += blockDim.x) {
-        const uint32_t loc = P.idx16 ? ((const uint16_t *)P.qidx)[qb + t] : ((const uint32_t *)P.qidx)[qb + t];
-        const uint32_t flags = P.use_flags ? P.qflags[qb + t] : 0xffu;
-        uint64_t vals[VXH_PART_MAX_VALS];
+    for (; j + step < hi4; j += 2 * step) reduce_trip<2>(P, lds, qb + j, step);
+    for (; j < hi4; j += step) reduce_trip<1>(P, lds, qb + j, step);
+    for (uint64_t t = hi4 + threadIdx.x; t < hi; t += blockDim.x) { // tail (< 4 records)
+        uint32_t loc[1] = {P.idx16 ? (uint32_t)((const uint16_t *)P.qidx)[qb + t] : ((const uint32_t *)P.qidx)[qb + t]};
+        uint32_t fl[1] = {P.use_flags ? (uint32_t)P.qflags[qb + t] : 0xffu};
+        uint64_t v1[VXH_PART_MAX_VALS][1];
 #pragma unroll
-        for (int k = 0; k < VXH_PART_MAX_VALS; ++k) vals[k] = k < P.nvals ? P.qval[k][qb + t] : 0;
-        for (int k = 0; k < P.A.nagg; ++k) record_apply<__HIP_MEMORY_SCOPE_WORKGROUP, true>(P, k, lds + P.A.a[k].lds_offset, loc, flags, vals);
+        for (int k = 0; k < VXH_PART_MAX_VALS; ++k) v1[k][0] = k < P.nvals ? P.qval[k][qb + t] : 0;
+        records_apply<__HIP_MEMORY_SCOPE_WORKGROUP, true, 1>(P, lds, loc, fl, v1, 1u);
     }
     __syncthreads();
     const uint64_t replica = P.A.flush_plain ? part : part % (uint32_t)P.A.replicas;
-    for (int k = 0; k < P.A.nagg; ++k) {
-        const AggDesc &a = P.A.a[k];
-        char *base = lds + a.lds_offset;
-        char *g = (char *)a.grid + replica * P.A.cells * cell_size_dev(a.cell);
-        for (uint64_t c = threadIdx.x; c < slab_cells; c += blockDim.x) {
-            const uint64_t gc = (c << P.slab_log2) + slab;
-            if (gc >= P.A.cells) continue;
-            flush_cell(a, base, c, g, gc, P.A.flush_plain != 0);
-        }
-    }
+    lds_flush(P.A, lds, slab_cells, P.slab_log2, slab, replica, P.A.flush_plain != 0);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -692,14 +673,28 @@ __global__ void fold_kernel(T *grid, uint64_t cells, int replicas, T identity) {
 // K5: min/max of one column (legacy statisticNd OP_MIN_MAX, 0-d grid): plain < / > so NaN never wins
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) minmax_kernel(int dtype, int flip, const void *data, const uint8_t *mask, uint64_t n, double *out2) {
-    double mn = __longlong_as_double(0x7ff0000000000000ll), mx = __longlong_as_double((long long)0xfff0000000000000ull);
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    double mn = as_f64(0x7ff0000000000000ull), mx = as_f64(0xfff0000000000000ull);
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (; i < n; i += stride) {
-        if (mask != nullptr && mask[i] != 1) continue;
-        double v = raw_as_f64(load_raw(data, i, dtype, flip), dtype);
-        if (v < mn) mn = v;
-        if (v > mx) mx = v;
+    const int cls = dt_is_float(dtype) ? 0 : (dt_is_unsigned(dtype) ? 2 : 1);
+    for (uint64_t i0 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < n; i0 += 4 * stride) {
+        uint32_t valid = 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) valid |= (i0 + (uint64_t)u * stride < n ? 1u : 0u) << u;
+        if (mask != nullptr) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (((valid >> u) & 1u) && mask[i0 + (uint64_t)u * stride] != 1) valid &= ~(1u << u);
+        }
+        uint64_t c[4];
+        load_canon<4>(data, i0, stride, valid, dtype, flip, c);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if ((valid >> u) & 1u) {
+                const double v = cls == 0 ? as_f64(c[u]) : (cls == 1 ? (double)(int64_t)c[u] : (double)c[u]);
+                if (v < mn) mn = v;
+                if (v > mx) mx = v;
+            }
+        }
     }
     // wave reduce (64 lanes), then one atomic per wave
     for (int off = 32; off > 0; off >>= 1) {
@@ -721,12 +716,15 @@ size_t vxh_lds_cell_size(int kind, int cell) { return kind == VXH_AGG_COUNT ? 4 
 void vxh_launch_part(const PartArgs &args, const LaunchPlan &plan, int scatter_blocks, size_t scatter_lds, hipStream_t stream) {
     const int R = args.rows_per_thread;
 #define VXH_SC(F, RR)                                                                                                  \
-    {                                                                                                                  \
+    do {                                                                                                               \
         if (scatter_lds > 48 * 1024) (void)hipFuncSetAttribute((const void *)part_scatter<F, RR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)scatter_lds); \
         hipLaunchKernelGGL((part_scatter<F, RR>), dim3(scatter_blocks), dim3(512), scatter_lds, stream, args);         \
+    } while (0)
+    if (plan.fast_f64) {
+        if (R == 8) VXH_SC(true, 8); else if (R == 4) VXH_SC(true, 4); else VXH_SC(true, 2);
+    } else {
+        if (R == 8) VXH_SC(false, 8); else if (R == 4) VXH_SC(false, 4); else VXH_SC(false, 2);
     }
-    if (plan.fast_f64) { if (R == 8) VXH_SC(true, 8) else if (R == 4) VXH_SC(true, 4) else VXH_SC(true, 2) }
-    else { if (R == 8) VXH_SC(false, 8) else if (R == 4) VXH_SC(false, 4) else VXH_SC(false, 2) }
 #undef VXH_SC
     if (plan.lds_bytes > 48 * 1024) (void)hipFuncSetAttribute((const void *)part_reduce, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds_bytes);
     hipLaunchKernelGGL(part_reduce, dim3(plan.blocks), dim3(plan.block), plan.lds_bytes, stream, args);
@@ -782,7 +780,7 @@ void vxh_launch_fold(void *grid, uint64_t cells, int replicas, int cell, int kin
 }
 
 void vxh_launch_minmax(int dtype, int flip, const void *data, const uint8_t *mask, uint64_t n, double *out2_dev, hipStream_t stream) {
-    uint64_t blocks = (n + 255) / 256;
+    uint64_t blocks = (n + 1023) / 1024;
     if (blocks > 2048) blocks = 2048;
     if (blocks == 0) blocks = 1;
     hipLaunchKernelGGL(minmax_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, dtype, flip, data, mask, n, out2_dev);
