@@ -83,6 +83,11 @@ Slot &get_slot(int thread) {
         for (auto &st : s->stage) HIP_CHECK(hipEventCreateWithFlags(&st.done, hipEventDisableTiming));
         HIP_CHECK(hipEventCreate(&s->t0));
         HIP_CHECK(hipEventCreate(&s->t1));
+        HIP_CHECK(hipStreamCreateWithFlags(&s->stream2, hipStreamNonBlocking));
+        for (auto &pb : s->part) {
+            HIP_CHECK(hipEventCreateWithFlags(&pb.scattered, hipEventDisableTiming));
+            HIP_CHECK(hipEventCreateWithFlags(&pb.reduced, hipEventDisableTiming));
+        }
     }
     return *s;
 }
@@ -536,13 +541,21 @@ static void run_part_chunk(Slot &slot, const BinArgs &planned, const LaunchPlan 
     const size_t o_flags = P.use_flags ? carve((size_t)S * P.cap) : 0;
     size_t o_val[VXH_PART_MAX_VALS] = {0, 0, 0, 0};
     for (int k = 0; k < P.nvals; k++) o_val[k] = carve((size_t)S * P.cap * 8);
-    if (off > slot.scratch_cap) {
-        HIP_CHECK(hipStreamSynchronize(slot.stream));
-        if (slot.scratch) HIP_CHECK(hipFree(slot.scratch));
-        HIP_CHECK(hipMalloc(&slot.scratch, off));
-        slot.scratch_cap = off;
+    Slot::PartBuf &pb = slot.part[slot.part_next & 1];
+    slot.part_next++;
+    // the previous user of this buffer (pass 2 of chunk i-2, on stream2) must be done before pass 1 refills it
+    if (pb.busy) {
+        HIP_CHECK(hipStreamWaitEvent(slot.stream, pb.reduced, 0));
+        pb.busy = false;
     }
-    char *sc = (char *)slot.scratch;
+    if (off > pb.cap) {
+        HIP_CHECK(hipStreamSynchronize(slot.stream));
+        HIP_CHECK(hipStreamSynchronize(slot.stream2));
+        if (pb.scratch) HIP_CHECK(hipFree(pb.scratch));
+        HIP_CHECK(hipMalloc(&pb.scratch, off));
+        pb.cap = off;
+    }
+    char *sc = (char *)pb.scratch;
     P.qcount = (unsigned long long *)(sc + o_count);
     P.qlimit = (unsigned long long *)(sc + o_limit);
     P.qidx = sc + o_idx;
@@ -552,7 +565,7 @@ static void run_part_chunk(Slot &slot, const BinArgs &planned, const LaunchPlan 
     HIP_CHECK(hipMemsetAsync(P.qlimit, 0xff, (size_t)S * 8, slot.stream));
 
     // pass-1 tile: 512 threads x R rows, staged in LDS
-    int R = 8;
+    int R = c.cfg_part_rows > 0 ? (int)c.cfg_part_rows : 8;
     size_t scatter_lds = 0;
     for (;; R >>= 1) {
         const size_t T = 512 * (size_t)R;
@@ -563,8 +576,24 @@ static void run_part_chunk(Slot &slot, const BinArgs &planned, const LaunchPlan 
     const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(4, kLdsMax / scatter_lds));
     const uint64_t tiles = (planned.n + 512ull * R - 1) / (512ull * R);
     const int scatter_blocks = (int)std::max<uint64_t>(1, std::min<uint64_t>(tiles, (uint64_t)c.cus * per_cu));
-    vxh_launch_part(P, plan, scatter_blocks, scatter_lds, slot.stream);
+    vxh_launch_part_scatter(P, plan.fast_f64, scatter_blocks, scatter_lds, slot.stream);
     HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipEventRecord(pb.scattered, slot.stream));
+    HIP_CHECK(hipStreamWaitEvent(slot.stream2, pb.scattered, 0));
+    vxh_launch_part_reduce(P, plan, slot.stream2);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipEventRecord(pb.reduced, slot.stream2));
+    pb.busy = true;
+}
+
+// make slot.stream wait for every outstanding pass 2 (end of a vxh_grid_bin call)
+static void part_join(Slot &slot) {
+    for (auto &pb : slot.part) {
+        if (pb.busy) {
+            HIP_CHECK(hipStreamWaitEvent(slot.stream, pb.reduced, 0));
+            pb.busy = false;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -625,6 +654,7 @@ int vxh_config_set(const char *key, int64_t value) {
     else if (k == "part_chunk") c.cfg_part_chunk = value;
     else if (k == "parts") c.cfg_parts = value;
     else if (k == "part_lds") c.cfg_part_lds = value;
+    else if (k == "part_rows") c.cfg_part_rows = value;
     else if (k == "lds_replicas") c.cfg_lds_replicas = value;
     else throw std::runtime_error("unknown config key: " + k);
     VXH_API_END
@@ -643,6 +673,7 @@ int vxh_config_get(const char *key, int64_t *value) {
     else if (k == "part_chunk") *value = c.cfg_part_chunk;
     else if (k == "parts") *value = c.cfg_parts;
     else if (k == "part_lds") *value = c.cfg_part_lds;
+    else if (k == "part_rows") *value = c.cfg_part_rows;
     else if (k == "lds_replicas") *value = c.cfg_lds_replicas;
     else if (k == "cus") { ensure_device_ready(); *value = c.cus; }
     else throw std::runtime_error("unknown config key: " + k);
@@ -939,6 +970,7 @@ int vxh_grid_bin(vxh_grid *grid, int thread, vxh_agg *const *aggs, int n_aggs, u
             slot.last_kernel = plan.name;
         }
     }
+    part_join(slot);
     if (stage_bytes) {
         HIP_CHECK(hipEventRecord(stager.stage.done, slot.stream));
         slot.cur ^= 1;

@@ -72,8 +72,15 @@ struct Slot {
     } stage[2];
     int cur = 0;
     hipEvent_t t0 = nullptr, t1 = nullptr;
-    void *scratch = nullptr; // partition queues
-    size_t scratch_cap = 0;
+    // partition strategy: two queue buffers so that pass 1 of chunk i+1 (on `stream`) overlaps pass 2 of chunk i (on `stream2`)
+    struct PartBuf {
+        void *scratch = nullptr;
+        size_t cap = 0;
+        hipEvent_t scattered = nullptr, reduced = nullptr;
+        bool busy = false; // `reduced` has been recorded and not yet waited for by `stream`
+    } part[2];
+    hipStream_t stream2 = nullptr;
+    unsigned part_next = 0;
     const char *last_kernel = "";
 };
 
@@ -95,6 +102,7 @@ struct Context {
     int64_t cfg_part_chunk = 1 << 26; // rows per partition chunk
     int64_t cfg_parts = 0;        // pass-2 workgroups per slab (0 = auto)
     int64_t cfg_part_lds = 0;     // LDS bytes per pass-2 slab (0 = auto)
+    int64_t cfg_part_rows = 0;    // pass-1 rows per thread per tile: 8, 4 or 2 (0 = auto)
 };
 
 Context &ctx();

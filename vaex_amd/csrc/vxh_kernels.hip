@@ -713,19 +713,22 @@ __global__ void __launch_bounds__(256) minmax_kernel(int dtype, int flip, const 
 size_t vxh_cell_size(int cell) { return cell >= VXH_CELL_F32 ? 4 : 8; }
 size_t vxh_lds_cell_size(int kind, int cell) { return kind == VXH_AGG_COUNT ? 4 : vxh_cell_size(cell); }
 
-void vxh_launch_part(const PartArgs &args, const LaunchPlan &plan, int scatter_blocks, size_t scatter_lds, hipStream_t stream) {
+void vxh_launch_part_scatter(const PartArgs &args, bool fast_f64, int scatter_blocks, size_t scatter_lds, hipStream_t stream) {
     const int R = args.rows_per_thread;
 #define VXH_SC(F, RR)                                                                                                  \
     do {                                                                                                               \
         if (scatter_lds > 48 * 1024) (void)hipFuncSetAttribute((const void *)part_scatter<F, RR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)scatter_lds); \
         hipLaunchKernelGGL((part_scatter<F, RR>), dim3(scatter_blocks), dim3(512), scatter_lds, stream, args);         \
     } while (0)
-    if (plan.fast_f64) {
+    if (fast_f64) {
         if (R == 8) VXH_SC(true, 8); else if (R == 4) VXH_SC(true, 4); else VXH_SC(true, 2);
     } else {
         if (R == 8) VXH_SC(false, 8); else if (R == 4) VXH_SC(false, 4); else VXH_SC(false, 2);
     }
 #undef VXH_SC
+}
+
+void vxh_launch_part_reduce(const PartArgs &args, const LaunchPlan &plan, hipStream_t stream) {
     if (plan.lds_bytes > 48 * 1024) (void)hipFuncSetAttribute((const void *)part_reduce, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds_bytes);
     hipLaunchKernelGGL(part_reduce, dim3(plan.blocks), dim3(plan.block), plan.lds_bytes, stream, args);
 }

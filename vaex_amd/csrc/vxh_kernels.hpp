@@ -105,7 +105,8 @@ struct LaunchPlan {
 };
 
 // implemented in vxh_kernels.hip
-void vxh_launch_part(const PartArgs &args, const LaunchPlan &plan, int scatter_blocks, size_t scatter_lds, hipStream_t stream);
+void vxh_launch_part_scatter(const PartArgs &args, bool fast_f64, int scatter_blocks, size_t scatter_lds, hipStream_t stream);
+void vxh_launch_part_reduce(const PartArgs &args, const LaunchPlan &plan, hipStream_t stream);
 void vxh_launch_bin(const BinArgs &args, const LaunchPlan &plan, hipStream_t stream);
 void vxh_launch_fill(void *dst, uint64_t ncells, int cell, const void *value8, hipStream_t stream);
 // dst[c] = fold(replica_0[c] .. replica_{R-1}[c]); replicas 1.. are reset to the identity
