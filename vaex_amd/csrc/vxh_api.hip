@@ -447,8 +447,9 @@ static LaunchPlan make_plan(const BinArgs &A, BinArgs &out, uint64_t n, double b
         if (c.cfg_parts > 0) parts = (int)c.cfg_parts;
         out.slab_log2 = part_log2;
         out.ngroups = parts; // pass-2 workgroups per slab
-        out.flush_plain = (exclusive && A.replicas >= parts) ? 1 : 0;
-        out.replicas = std::min(A.replicas, parts);
+        // plain flush: one replica per pass-2 part + one for the atomic overflow path of pass 1
+        out.flush_plain = (exclusive && A.replicas >= parts + 1) ? 1 : 0;
+        out.replicas = out.flush_plain ? parts + 1 : std::min(A.replicas, parts);
         p.use_replicas = out.replicas;
         p.blocks = parts * S;
         p.name = fast ? "part_scatter+part_reduce_f64" : "part_scatter+part_reduce_generic";

@@ -437,7 +437,7 @@ __global__ void __launch_bounds__(1024) bin_kernel(const BinArgs A) {
 // ------------------------------------------------------------------------------------------
 // all aggregators over N records whose mask flags and canonical inputs are in registers
 template <int SCOPE, bool LDS, int N, typename IDX>
-__device__ __forceinline__ void records_apply(const PartArgs &P, char *lds, const IDX (&idx)[N], const uint32_t (&flags)[N], const uint64_t (&vals)[VXH_PART_MAX_VALS][N], uint32_t valid) {
+__device__ __forceinline__ void records_apply(const PartArgs &P, char *lds, const IDX (&idx)[N], const uint32_t (&flags)[N], const uint64_t (&vals)[VXH_PART_MAX_VALS][N], uint32_t valid, uint64_t replica = 0) {
     for (int k = 0; k < P.A.nagg; ++k) {
         const AggDesc &a = P.A.a[k];
         uint32_t keep = valid;
@@ -451,7 +451,7 @@ __device__ __forceinline__ void records_apply(const PartArgs &P, char *lds, cons
         uint64_t v[N];
 #pragma unroll
         for (int u = 0; u < N; ++u) v[u] = vs == 0 ? vals[0][u] : (vs == 1 ? vals[1][u] : (vs == 2 ? vals[2][u] : (vs == 3 ? vals[3][u] : 0)));
-        void *base = LDS ? (void *)(lds + a.lds_offset) : a.grid;
+        void *base = LDS ? (void *)(lds + a.lds_offset) : (void *)((char *)a.grid + replica * P.A.cells * cell_size_dev(a.cell));
         agg_batch<SCOPE, LDS, N>(a, base, idx, v, keep, vs != 0xffu);
     }
 }
@@ -563,13 +563,15 @@ __global__ void __launch_bounds__(512) part_scatter(const PartArgs P) {
                 for (int k = 0; k < VXH_PART_MAX_VALS; ++k)
                     if (k < P.nvals) P.qval[k][dst] = st_val[(size_t)k * T + j];
             } else {
-                // queue full (pathologically skewed data): scatter this record straight to HBM replica 0
+                // queue full (pathologically skewed data): scatter this record straight to HBM with atomics — into a
+                // replica of its own when pass 2 (which may be running concurrently for the previous chunk) flushes
+                // the others with plain read-modify-write
                 uint64_t gidx[1] = {((uint64_t)st_idx[j] << P.slab_log2) + s};
                 uint32_t f1[1] = {(uint32_t)st_flags[j]};
                 uint64_t v1[VXH_PART_MAX_VALS][1];
 #pragma unroll
                 for (int k = 0; k < VXH_PART_MAX_VALS; ++k) v1[k][0] = k < P.nvals ? st_val[(size_t)k * T + j] : 0;
-                records_apply<__HIP_MEMORY_SCOPE_AGENT, false, 1>(P, nullptr, gidx, f1, v1, 1u);
+                records_apply<__HIP_MEMORY_SCOPE_AGENT, false, 1>(P, nullptr, gidx, f1, v1, 1u, P.A.flush_plain ? (uint64_t)P.parts : 0);
             }
         }
         __syncthreads();
