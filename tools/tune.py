@@ -53,7 +53,7 @@ def show(label, ms, kern, bpr=24):
 
 
 defaults = dict(strategy=0, part_rows=0, part_chunk=1 << 26, part_lds=0, parts=0)
-for pr, pc, pl in itertools.product([8, 4, 2], [1 << 24, 1 << 25, 1 << 26, 1 << 27], [0]):
+for pr, pc, pl in itertools.product([8, 4], [1 << 26, 1 << 27, 1 << 28], [0]):
     cfg = dict(defaults, part_rows=pr, part_chunk=pc, part_lds=pl)
     ms, k = run(aggs="csn", **cfg)
     show(f"count+sum+countv 256^2 part_rows={pr} chunk=2^{pc.bit_length()-1} lds={pl}", ms, k)

@@ -52,18 +52,39 @@ __device__ __forceinline__ uint64_t f64_bits(double d) { return (uint64_t)__doub
 __device__ __forceinline__ bool dt_is_float(int dt) { return dt == VXH_F64 || dt == VXH_F32; }
 __device__ __forceinline__ bool dt_is_unsigned(int dt) { return dt >= VXH_U64; } // u64 u32 u16 u8 bool
 
-// canonical 64-bit value of N elements i0 + u*stride (u with bit u of `valid` set)
+// Row indices of a batch: row u of the lane is i0 + u*stride, clamped to the last row so that EVERY load of the
+// batch can be issued unconditionally and back to back (a load under `if (valid)` gets serialised with its
+// use and leaves one load in flight per lane); `valid` only gates the scatter at the end.
 template <int N>
-__device__ __forceinline__ void load_canon(const void *p, uint64_t i0, uint64_t stride, uint32_t valid, int dt, int flip, uint64_t (&out)[N]) {
+struct Rows {
+    uint64_t i[N];
+    uint32_t valid;
+};
+template <int N>
+__device__ __forceinline__ Rows<N> make_rows(uint64_t i0, uint64_t stride, uint64_t n) {
+    Rows<N> r;
+    r.valid = 0;
+#pragma unroll
+    for (int u = 0; u < N; ++u) {
+        const uint64_t i = i0 + (uint64_t)u * stride;
+        const bool ok = i < n;
+        r.valid |= (ok ? 1u : 0u) << u;
+        r.i[u] = ok ? i : n - 1;
+    }
+    return r;
+}
+
+// canonical 64-bit value of the N rows of a batch
+template <int N>
+__device__ __forceinline__ void load_canon(const void *p, const Rows<N> &rows, int dt, int flip, uint64_t (&out)[N]) {
 #define VXH_CANON(T, SWAP, EXPR)                                                                                       \
     {                                                                                                                  \
+        T raw[N];                                                                                                      \
+        _Pragma("unroll") for (int u = 0; u < N; ++u) raw[u] = ((const T *)p)[rows.i[u]];                              \
         _Pragma("unroll") for (int u = 0; u < N; ++u) {                                                                \
-            out[u] = 0;                                                                                                \
-            if ((valid >> u) & 1u) {                                                                                   \
-                T x = ((const T *)p)[i0 + (uint64_t)u * stride];                                                       \
-                if (flip) x = SWAP(x);                                                                                 \
-                out[u] = EXPR;                                                                                         \
-            }                                                                                                          \
+            T x = raw[u];                                                                                              \
+            if (flip) x = SWAP(x);                                                                                     \
+            out[u] = EXPR;                                                                                             \
         }                                                                                                              \
     }
 #define VXH_NOSWAP(x) (x)
@@ -80,6 +101,18 @@ __device__ __forceinline__ void load_canon(const void *p, uint64_t i0, uint64_t 
     }
 #undef VXH_CANON
 #undef VXH_NOSWAP
+}
+
+// mask bytes of the N rows: bit u set when mask[row u] == 1
+template <int N>
+__device__ __forceinline__ uint32_t load_mask_bits(const uint8_t *mask, const Rows<N> &rows) {
+    uint8_t m[N];
+#pragma unroll
+    for (int u = 0; u < N; ++u) m[u] = mask[rows.i[u]];
+    uint32_t bits = 0;
+#pragma unroll
+    for (int u = 0; u < N; ++u) bits |= (m[u] == 1 ? 1u : 0u) << u;
+    return bits;
 }
 
 // x86-64 cvttsd2si semantics ("integer indefinite" for NaN / out of range): what the reference's
@@ -102,30 +135,23 @@ __device__ __forceinline__ uint64_t scalar_sub_index(double v, bool masked, doub
 
 // flat cell index of N rows: sum over dims of sub_index * stride (src/agg.hpp:63-73, :106-137)
 template <bool FAST, int N>
-__device__ __forceinline__ void flat_index_batch(const BinArgs &A, uint64_t i0, uint64_t stride, uint32_t valid, uint64_t (&idx)[N]) {
+__device__ __forceinline__ void flat_index_batch(const BinArgs &A, const Rows<N> &rows, uint64_t (&idx)[N]) {
 #pragma unroll
     for (int u = 0; u < N; ++u) idx[u] = 0;
     for (int d = 0; d < A.ndim; ++d) {
         const BinnerDesc &b = A.b[d];
         if (FAST) {
+            double v[N];
 #pragma unroll
-            for (int u = 0; u < N; ++u) {
-                if ((valid >> u) & 1u) {
-                    const double v = ((const double *)b.data)[i0 + (uint64_t)u * stride];
-                    idx[u] += scalar_sub_index(v, false, b.vmin, b.scale, b.binsd, b.bins) * b.stride;
-                }
-            }
+            for (int u = 0; u < N; ++u) v[u] = ((const double *)b.data)[rows.i[u]];
+#pragma unroll
+            for (int u = 0; u < N; ++u) idx[u] += scalar_sub_index(v[u], false, b.vmin, b.scale, b.binsd, b.bins) * b.stride;
             continue;
         }
-        uint32_t masked = 0;
-        if (b.mask != nullptr) {
-#pragma unroll
-            for (int u = 0; u < N; ++u)
-                if (((valid >> u) & 1u) && b.mask[i0 + (uint64_t)u * stride] == 1) masked |= 1u << u;
-        }
+        const uint32_t masked = b.mask != nullptr ? load_mask_bits<N>(b.mask, rows) : 0u;
         uint64_t c[N];
         if (b.kind == VXH_BIN_SCALAR) {
-            load_canon<N>(b.data, i0, stride, valid, b.dtype, b.flip, c);
+            load_canon<N>(b.data, rows, b.dtype, b.flip, c);
             const int cls = dt_is_float(b.dtype) ? 0 : (dt_is_unsigned(b.dtype) ? 2 : 1);
 #pragma unroll
             for (int u = 0; u < N; ++u) {
@@ -135,7 +161,7 @@ __device__ __forceinline__ void flat_index_batch(const BinArgs &A, uint64_t i0, 
         } else if (b.kind == VXH_BIN_ORDINAL) {
             // src/binner_ordinal.cpp:138-175 (+ the invert / allow_other variants :22-137).  The element is NOT
             // byte-swapped before the subtraction; the int64 difference is (reference behaviour, :25-28).
-            load_canon<N>(b.data, i0, stride, valid, b.dtype, 0, c);
+            load_canon<N>(b.data, rows, b.dtype, 0, c);
             const int64_t Nord = (int64_t)b.bins;
 #pragma unroll
             for (int u = 0; u < N; ++u) {
@@ -157,13 +183,13 @@ __device__ __forceinline__ void flat_index_batch(const BinArgs &A, uint64_t i0, 
             }
         } else {
             // hash binner: cells [unknown, bin0..binN-1, null]
-            load_canon<N>(b.data, i0, stride, valid, b.dtype, b.flip, c);
+            load_canon<N>(b.data, rows, b.dtype, b.flip, c);
 #pragma unroll
             for (int u = 0; u < N; ++u) {
                 uint64_t sub = 0;
                 if ((masked >> u) & 1u) {
                     sub = (uint64_t)b.null_bin;
-                } else if ((valid >> u) & 1u) {
+                } else {
                     const int64_t key = (int64_t)c[u];
                     uint64_t p = splitmix64((uint64_t)key) & b.hmask;
                     for (;;) {
@@ -387,12 +413,10 @@ __global__ void __launch_bounds__(1024) bin_kernel(const BinArgs A) {
 
     const uint64_t stride = (uint64_t)ngroups * blockDim.x;
     for (uint64_t i0 = (uint64_t)group * blockDim.x + threadIdx.x; i0 < A.n; i0 += N * stride) {
-        uint32_t valid = 0;
-#pragma unroll
-        for (int u = 0; u < N; ++u) valid |= (i0 + (uint64_t)u * stride < A.n ? 1u : 0u) << u;
+        const Rows<N> rows = make_rows<N>(i0, stride, A.n);
         uint64_t idx[N];
-        flat_index_batch<FAST, N>(A, i0, stride, valid, idx);
-        uint32_t mine = valid;
+        flat_index_batch<FAST, N>(A, rows, idx);
+        uint32_t mine = rows.valid;
         if (LDS) { // this workgroup owns the cells with (cell mod S) == slab; they live at LDS index cell / S
 #pragma unroll
             for (int u = 0; u < N; ++u) {
@@ -403,19 +427,15 @@ __global__ void __launch_bounds__(1024) bin_kernel(const BinArgs A) {
         for (int k = 0; k < A.nagg; ++k) {
             const AggDesc &a = A.a[k];
             uint32_t keep = mine;
-            if (a.mask != nullptr) { // aggregator mask: 1 = keep (src/agg_count.cpp:50)
-#pragma unroll
-                for (int u = 0; u < N; ++u)
-                    if (((keep >> u) & 1u) && a.mask[i0 + (uint64_t)u * stride] != 1) keep &= ~(1u << u);
-            }
+            if (a.mask != nullptr) keep &= load_mask_bits<N>(a.mask, rows); // aggregator mask: 1 = keep (src/agg_count.cpp:50)
             uint64_t v[N];
             const bool has_data = a.data != nullptr;
             if (has_data) {
                 if (FAST) {
 #pragma unroll
-                    for (int u = 0; u < N; ++u) v[u] = ((keep >> u) & 1u) ? ((const uint64_t *)a.data)[i0 + (uint64_t)u * stride] : 0;
+                    for (int u = 0; u < N; ++u) v[u] = ((const uint64_t *)a.data)[rows.i[u]];
                 } else {
-                    load_canon<N>(a.data, i0, stride, keep, a.dtype, a.flip, v);
+                    load_canon<N>(a.data, rows, a.dtype, a.flip, v);
                 }
             } else {
 #pragma unroll
@@ -478,35 +498,33 @@ __global__ void __launch_bounds__(512) part_scatter(const PartArgs P) {
         for (uint32_t s = threadIdx.x; s < S; s += 512) s_cnt[s] = 0;
         __syncthreads();
 
-        uint32_t valid = 0;
-#pragma unroll
-        for (int r = 0; r < R; ++r) valid |= (i0 + (uint64_t)r * 512 < n ? 1u : 0u) << r;
+        const Rows<R> rows = make_rows<R>(i0, 512, n);
         // aggregator masks -> one flag bit per distinct mask; rows no aggregator wants emit no record
         uint32_t fl[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) fl[r] = 0;
         for (int m = 0; m < P.nmasks; ++m) {
+            const uint32_t bits = load_mask_bits<R>(P.mdata[m], rows);
 #pragma unroll
-            for (int r = 0; r < R; ++r)
-                if (((valid >> r) & 1u) && P.mdata[m][i0 + (uint64_t)r * 512] == 1) fl[r] |= 1u << m;
+            for (int r = 0; r < R; ++r) fl[r] |= ((bits >> r) & 1u) << m;
         }
-        uint32_t keep = valid;
+        uint32_t keep = rows.valid;
         if (P.all_masked) {
 #pragma unroll
             for (int r = 0; r < R; ++r)
                 if (fl[r] == 0) keep &= ~(1u << r);
         }
         uint64_t idx[R];
-        flat_index_batch<FAST, R>(P.A, i0, 512, keep, idx);
+        flat_index_batch<FAST, R>(P.A, rows, idx);
         uint64_t val[VXH_PART_MAX_VALS][R];
 #pragma unroll
         for (int k = 0; k < VXH_PART_MAX_VALS; ++k) {
             if (k < P.nvals) {
                 if (FAST) {
 #pragma unroll
-                    for (int r = 0; r < R; ++r) val[k][r] = ((keep >> r) & 1u) ? ((const uint64_t *)P.vdata[k])[i0 + (uint64_t)r * 512] : 0;
+                    for (int r = 0; r < R; ++r) val[k][r] = ((const uint64_t *)P.vdata[k])[rows.i[r]];
                 } else {
-                    load_canon<R>(P.vdata[k], i0, 512, keep, P.vdtype[k], P.vflip[k], val[k]);
+                    load_canon<R>(P.vdata[k], rows, P.vdtype[k], P.vflip[k], val[k]);
                 }
             }
         }
@@ -519,22 +537,18 @@ __global__ void __launch_bounds__(512) part_scatter(const PartArgs P) {
             if ((keep >> r) & 1u) pos[r] = __hip_atomic_fetch_add(&s_cnt[slab[r]], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         __syncthreads();
-        // exclusive prefix over the S bucket counts + reservation of queue space (one HBM atomic per slab per tile)
-        for (uint32_t s = threadIdx.x; s < S; s += 512) {
+        // exclusive prefix over the S bucket counts; the reservation of queue space (one HBM atomic per slab per
+        // tile) is issued here but only consumed after the staging writes, which hides its round trip
+        unsigned long long my_gb = 0;
+        uint32_t my_cnt = 0;
+        if (threadIdx.x < S) {
+            const uint32_t s0 = threadIdx.x;
             uint32_t off = 0;
-            for (uint32_t j = 0; j < s; ++j) off += s_cnt[j];
-            s_off[s] = off;
-            const uint32_t c = s_cnt[s];
-            if (s == S - 1) s_off[S] = off + c;
-            unsigned long long gb = 0;
-            if (c) {
-                gb = atomicAdd(&P.qcount[s], (unsigned long long)c);
-                if (gb + c > P.cap) { // does not fit: remember where the valid prefix of the queue ends
-                    atomicMin(&P.qlimit[s], gb);
-                    gb = OVERFLOW;
-                }
-            }
-            s_gbase[s] = gb;
+            for (uint32_t j = 0; j < s0; ++j) off += s_cnt[j];
+            s_off[s0] = off;
+            my_cnt = s_cnt[s0];
+            if (s0 == S - 1) s_off[S] = off + my_cnt;
+            if (my_cnt) my_gb = atomicAdd(&P.qcount[s0], (unsigned long long)my_cnt);
         }
         __syncthreads();
 #pragma unroll
@@ -548,6 +562,13 @@ __global__ void __launch_bounds__(512) part_scatter(const PartArgs P) {
                 for (int k = 0; k < VXH_PART_MAX_VALS; ++k)
                     if (k < P.nvals) st_val[(size_t)k * T + j] = val[k][r];
             }
+        }
+        if (threadIdx.x < S) {
+            if (my_cnt && my_gb + my_cnt > P.cap) { // does not fit: remember where the valid prefix of the queue ends
+                atomicMin(&P.qlimit[threadIdx.x], my_gb);
+                my_gb = OVERFLOW;
+            }
+            s_gbase[threadIdx.x] = my_gb;
         }
         __syncthreads();
         const uint32_t total = s_off[S];
@@ -679,16 +700,11 @@ __global__ void __launch_bounds__(256) minmax_kernel(int dtype, int flip, const 
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     const int cls = dt_is_float(dtype) ? 0 : (dt_is_unsigned(dtype) ? 2 : 1);
     for (uint64_t i0 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < n; i0 += 4 * stride) {
-        uint32_t valid = 0;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) valid |= (i0 + (uint64_t)u * stride < n ? 1u : 0u) << u;
-        if (mask != nullptr) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (((valid >> u) & 1u) && mask[i0 + (uint64_t)u * stride] != 1) valid &= ~(1u << u);
-        }
+        const Rows<4> rows = make_rows<4>(i0, stride, n);
+        uint32_t valid = rows.valid;
+        if (mask != nullptr) valid &= load_mask_bits<4>(mask, rows);
         uint64_t c[4];
-        load_canon<4>(data, i0, stride, valid, dtype, flip, c);
+        load_canon<4>(data, rows, dtype, flip, c);
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             if ((valid >> u) & 1u) {
