@@ -19,7 +19,7 @@ def _reset_config(sa, gpu_ready):
         sa.config_set("block", 0)
         sa.config_set("blocks", 0)
         sa.config_set("slab_log2", -1)
-        sa.config_set("part_chunk", 1 << 26)
+        sa.config_set("part_chunk", 1 << 27)
         sa.config_set("parts", 0)
     reset()
     yield

@@ -393,8 +393,9 @@ static LaunchPlan make_plan(const BinArgs &A, BinArgs &out, uint64_t n, double b
     if (c.cfg_slab_log2 >= 0 && c.cfg_slab_log2 >= slab_log2 && c.cfg_slab_log2 <= 5) slab_log2 = (int)c.cfg_slab_log2;
 
     // partition strategy: any power-of-two number of slabs up to 256 (its cost does not grow with S)
-    // slabs of <= ~72 KiB so that two 1024-thread pass-2 workgroups share a CU
-    const size_t part_budget = c.cfg_part_lds > 0 ? (size_t)c.cfg_part_lds : 72 * 1024;
+    // fewest slabs that fit one CU's LDS: part_reduce is register-limited to one 1024-thread workgroup per CU
+    // anyway, and fewer, longer-lived workgroups pay the LDS init + flush less often (profiles/r01_tune2*)
+    const size_t part_budget = c.cfg_part_lds > 0 ? (size_t)c.cfg_part_lds : 150 * 1024;
     int part_log2 = 0;
     while (part_log2 < 8 && ((A.cells + (1ull << part_log2) - 1) >> part_log2) * per_cell > part_budget) part_log2++;
     const uint64_t part_slab_cells = (A.cells + (1ull << part_log2) - 1) >> part_log2;
@@ -566,7 +567,7 @@ static void run_part_chunk(Slot &slot, const BinArgs &planned, const LaunchPlan 
     HIP_CHECK(hipMemsetAsync(P.qlimit, 0xff, (size_t)S * 8, slot.stream));
 
     // pass-1 tile: 512 threads x R rows, staged in LDS
-    int R = c.cfg_part_rows > 0 ? (int)c.cfg_part_rows : 8;
+    int R = c.cfg_part_rows > 0 ? (int)c.cfg_part_rows : 4;
     size_t scatter_lds = 0;
     for (;; R >>= 1) {
         const size_t T = 512 * (size_t)R;
