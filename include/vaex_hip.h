@@ -161,6 +161,9 @@ int vxh_hashmap_create(int dtype, uint64_t capacity_hint, vxh_hashmap **out);
 void vxh_hashmap_destroy(vxh_hashmap *map);
 /* update(keys): insert unseen keys (mask: 1 = null, counted once as the null ordinal) */
 int vxh_hashmap_update(vxh_hashmap *map, const void *keys, const uint8_t *mask, uint64_t n, int mem);
+/* ordered_set::create(keys): fill an EMPTY map so that keys[i] (distinct, host int64) gets ordinal i —
+ * src/hash_primitives.hpp:486-537.  Deterministic ordinals: what ranks agree on before a grid all-reduce. */
+int vxh_hashmap_set_keys(vxh_hashmap *map, const int64_t *keys, uint64_t n);
 /* number of distinct keys (excluding null) — size() */
 int vxh_hashmap_count(vxh_hashmap *map, int64_t *count_out);
 /* whether a null was seen, and its ordinal (= count) — null_index() src/hash.hpp:337-353 */

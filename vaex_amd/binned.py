@@ -1,0 +1,433 @@
+"""Host-side driver of the hot path: the part of vaex's DataFrame API that ends in `Grid.bin`.
+
+`Frame` mirrors, for columns that are plain arrays, the call shapes of
+    df.count/sum/mean/var/std/min/max/minmax(expression, binby=, limits=, shape=, selection=, edges=)
+        (/root/reference/packages/vaex-core/vaex/dataframe.py:944-1245, _compute_agg :842-941)
+    df.groupby(by, agg={...})                                   (vaex/groupby.py:602-1017)
+and drives the `superagg` class surface exactly the way vaex's own task part does
+(vaex/cpu.py:678-786): descriptors -> primitive aggregations (count / sum / summoment / min / max,
+vaex/agg.py:386-523) -> ONE fused pass per call -> numpy finishers -> edge-cell slicing
+(vaex/agg.py:323-335).  It exists so that the parity tests and bench read like vaex code on a box
+where vaex itself is not installed; with vaex present, `vaex_amd.install()` makes vaex's unmodified
+DataFrame do the same through the same classes.
+
+Columns may be
+  * numpy arrays (host): streamed in `chunk_size`-row chunks over `nthreads` slots — each slot stages its
+    chunk to HBM on its own HIP stream, like the executor's thread pool (vaex/execution.py:432-435);
+  * device arrays (anything with __cuda_array_interface__, e.g. torch cuda tensors): used in place.
+Expressions are column names only: vaex's expression system is out of scope.
+"""
+import threading
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+
+from . import superagg as _sa
+
+_DTYPE_NAMES = {"float64", "float32", "int64", "int32", "int16", "int8", "uint64", "uint32", "uint16", "uint8", "bool"}
+
+
+def _is_device(x):
+    return hasattr(x, "__cuda_array_interface__") and not isinstance(x, np.ndarray)
+
+
+def _class_postfix(col):
+    """dtype name + '_non_native' the way vaex.utils.find_type_from_dtype builds it (vaex/utils.py:754-791)."""
+    if _is_device(col):
+        name = str(col.dtype).replace("torch.", "")
+        return {"bool": "bool"}.get(name, name)
+    dt = col.dtype
+    if dt.kind in "mM":
+        return "int64"
+    name = dt.newbyteorder("=").name
+    if name not in _DTYPE_NAMES:
+        raise TypeError(f"unsupported dtype {dt}")
+    return name + ("_non_native" if dt.byteorder == ">" else "")
+
+
+def _as_u8(mask):
+    if _is_device(mask):
+        return mask
+    m = np.ascontiguousarray(mask)
+    return m.view(np.uint8) if m.dtype == np.bool_ else m.astype(np.uint8)
+
+
+class _Prim:
+    """One native aggregation: (kind, column, selection, moment) — what AggregatorDescriptorBasic is to vaex."""
+
+    def __init__(self, kind, column=None, selection=None, moment=0, as_float64=False):
+        self.kind, self.column, self.selection, self.moment, self.as_float64 = kind, column, selection, moment, as_float64
+
+    def key(self):
+        return (self.kind, self.column, self.selection if isinstance(self.selection, (str, type(None))) else id(self.selection), self.moment, self.as_float64)
+
+
+class agg:
+    """Aggregation descriptors (the subset of vaex.agg on the hot path)."""
+
+    class _Desc:
+        def __init__(self, name, column=None, selection=None):
+            self.name, self.column, self.selection = name, column, selection
+
+        def prims(self):
+            c, s = self.column, self.selection
+            n = self.name
+            if n == "count":
+                return [_Prim("count", c, s)]
+            if n == "sum":
+                return [_Prim("sum", c, s)]
+            if n == "min":
+                return [_Prim("min", c, s)]
+            if n == "max":
+                return [_Prim("max", c, s)]
+            if n == "mean":  # vaex/agg.py:391-418
+                return [_Prim("sum", c, s), _Prim("count", c, s)]
+            if n in ("var", "std"):  # vaex/agg.py:426-455: on astype(float64); ddof is ignored by the reference
+                return [_Prim("summoment", c, s, 2, True), _Prim("sum", c, s, 0, True), _Prim("count", c, s, 0, True)]
+            raise ValueError(n)
+
+        def finish(self, parts):
+            n = self.name
+            if n in ("count", "sum", "min", "max"):
+                return parts[0]
+            with np.errstate(divide="ignore", invalid="ignore"):
+                if n == "mean":
+                    return parts[0] / parts[1]
+                mean = parts[1] / parts[2]
+                variance = parts[0] / parts[2] - mean ** 2
+                return variance if n == "var" else variance ** 0.5
+
+    @staticmethod
+    def count(column=None, selection=None):
+        return agg._Desc("count", None if column in (None, "*") else column, selection)
+
+    @staticmethod
+    def sum(column, selection=None):
+        return agg._Desc("sum", column, selection)
+
+    @staticmethod
+    def mean(column, selection=None):
+        return agg._Desc("mean", column, selection)
+
+    @staticmethod
+    def var(column, selection=None):
+        return agg._Desc("var", column, selection)
+
+    @staticmethod
+    def std(column, selection=None):
+        return agg._Desc("std", column, selection)
+
+    @staticmethod
+    def min(column, selection=None):
+        return agg._Desc("min", column, selection)
+
+    @staticmethod
+    def max(column, selection=None):
+        return agg._Desc("max", column, selection)
+
+
+_KIND_CLASS = {"count": "AggCount_", "sum": "AggSum_", "summoment": "AggSumMoment_", "min": "AggMin_", "max": "AggMax_"}
+
+
+class Frame:
+    def __init__(self, columns=None, chunk_size=1 << 20, nthreads=4, superagg=None, **kw):
+        self.columns = dict(columns or {})
+        self.columns.update(kw)
+        self.chunk_size = int(chunk_size)
+        self.nthreads = int(nthreads)
+        self.sa = superagg or _sa
+        n = {len(c) for c in self.columns.values()}
+        if len(n) > 1:
+            raise ValueError("columns differ in length")
+        self.n = n.pop() if n else 0
+        self._f64_cache = {}
+
+    def __len__(self):
+        return self.n
+
+    # ------------------------------------------------------------------ column helpers
+    def _col(self, name, as_float64=False):
+        c = self.columns[name]
+        if not as_float64:
+            return c
+        if name not in self._f64_cache:
+            if _is_device(c):
+                self._f64_cache[name] = c.double()
+            elif np.ma.isMaskedArray(c):
+                self._f64_cache[name] = np.ma.array(np.ma.getdata(c).astype("f8"), mask=np.ma.getmaskarray(c))
+            else:
+                self._f64_cache[name] = c.astype("f8") if c.dtype != np.float64 else c
+        return self._f64_cache[name]
+
+    def _selection_mask(self, selection):
+        if selection is None or selection is False:
+            return None
+        if isinstance(selection, str):
+            selection = self.columns[selection]
+        return selection
+
+    # ------------------------------------------------------------------ binners
+    def minmax(self, column, selection=None):
+        """df.minmax: the legacy statisticNd OP_MIN_MAX pass (vaex/dataframe.py:1520, vaexfast.cpp:1090-1101)."""
+        c = self.columns[column]
+        sel = self._selection_mask(selection)
+        keep = None if sel is None else _as_u8(sel)
+        if _is_device(c):
+            pf = _class_postfix(c)
+            return np.array(self.sa.minmax(c, keep, _DT_CODE[pf.replace("_non_native", "")], pf.endswith("_non_native")))
+        data, miss = (np.ma.getdata(c), np.ma.getmaskarray(c)) if np.ma.isMaskedArray(c) else (c, None)
+        if miss is not None:
+            k = ~miss if keep is None else (keep.astype(bool) & ~miss)
+            keep = _as_u8(k)
+        pf = _class_postfix(data)
+        lo, hi = self.sa.minmax(np.ascontiguousarray(data), keep, _DT_CODE[pf.replace("_non_native", "")], pf.endswith("_non_native"))
+        return np.array([lo, hi])
+
+    def _binner_specs(self, binby, limits, shape):
+        binby = [binby] if isinstance(binby, (str, tuple, dict)) else list(binby or [])
+        nd = len(binby)
+        if not isinstance(shape, (list, tuple)):
+            shape = [shape] * nd
+        if limits is not None and nd == 1 and np.ndim(limits) == 1:
+            limits = [limits]
+        specs = []
+        for d, b in enumerate(binby):
+            if isinstance(b, dict):  # explicit ordinal binner: dict(column=, count=, min_value=0, invert=False)
+                specs.append(dict(kind="ordinal", column=b["column"], count=int(b["count"]), min_value=int(b.get("min_value", 0)), invert=bool(b.get("invert", False))))
+                continue
+            lim = None if limits is None else limits[d]
+            if lim is None or (isinstance(lim, str) and lim == "minmax"):
+                lim = self.minmax(b)  # limits=None costs this extra pass in vaex too (dataframe.py:1927-1947)
+            specs.append(dict(kind="scalar", column=b, vmin=float(lim[0]), vmax=float(lim[1]), bins=int(shape[d])))
+        return specs
+
+    # ------------------------------------------------------------------ the pass
+    def _run_pass(self, specs, prims):
+        """One fused pass: every primitive aggregation shares the bin index (TaskAggregations, vaex/tasks.py:473-580)."""
+        sa = self.sa
+        nthreads = max(1, self.nthreads)
+        cols = {}
+
+        def column(name, f64=False):
+            key = (name, f64)
+            if key not in cols:
+                cols[key] = self._col(name, f64)
+            return cols[key]
+
+        bcols = [column(s["column"]) for s in specs]
+        all_device = all(_is_device(c) for c in bcols) and all(p.column is None or _is_device(column(p.column, p.as_float64)) for p in prims)
+        slots = 1 if all_device else nthreads
+        binners = []
+        for s, c in zip(specs, bcols):
+            data = np.ma.getdata(c) if np.ma.isMaskedArray(c) else c
+            pf = _class_postfix(data)
+            if s["kind"] == "scalar":
+                binners.append(getattr(sa, "BinnerScalar_" + pf)(slots, s["column"], s["vmin"], s["vmax"], s["bins"]))
+            else:
+                binners.append(getattr(sa, "BinnerOrdinal_" + pf)(slots, s["column"], s["count"], s["min_value"], False, s["invert"]))
+        grid = sa.Grid(binners)
+        aggs = []
+        for p in prims:
+            if p.column is None:
+                pf = "int64"  # count(*): vaex/agg.py:255-257
+            else:
+                c = column(p.column, p.as_float64)
+                pf = _class_postfix(np.ma.getdata(c) if np.ma.isMaskedArray(c) else c)
+            cls = getattr(sa, _KIND_CLASS[p.kind] + pf)
+            aggs.append(cls(grid, slots, slots, p.moment) if p.kind == "summoment" else cls(grid, slots, slots))
+
+        def process(slot, i1, i2):
+            refs = []
+            for b, c in zip(binners, bcols):
+                if np.ma.isMaskedArray(c):
+                    d, m = np.ascontiguousarray(np.ma.getdata(c)[i1:i2]), _as_u8(np.ma.getmaskarray(c)[i1:i2])
+                    b.set_data(slot, d); b.set_data_mask(slot, m); refs += [d, m]
+                else:
+                    d = c[i1:i2] if _is_device(c) else np.ascontiguousarray(c[i1:i2])
+                    b.set_data(slot, d); b.clear_data_mask(slot); refs.append(d)
+            for a, p in zip(aggs, prims):
+                sel = self._selection_mask(p.selection)
+                mask = None if sel is None else sel[i1:i2]
+                if p.column is not None:
+                    c = column(p.column, p.as_float64)
+                    if np.ma.isMaskedArray(c):  # missing values: selection & ~mask (vaex/cpu.py:770-784)
+                        d, miss = np.ascontiguousarray(np.ma.getdata(c)[i1:i2]), np.ma.getmaskarray(c)[i1:i2]
+                        mask = ~miss if mask is None else (np.asarray(mask).astype(bool) & ~miss)
+                    else:
+                        d = c[i1:i2] if _is_device(c) else np.ascontiguousarray(c[i1:i2])
+                    a.set_data(slot, d, 0); refs.append(d)
+                if mask is not None:
+                    m = _as_u8(mask)
+                    a.set_data_mask(slot, m); refs.append(m)
+                else:
+                    a.clear_data_mask(slot)
+            grid.bin(slot, aggs, i2 - i1)
+            return refs
+
+        n = self.n
+        if n:
+            if all_device:
+                process(0, 0, n)
+            else:
+                free = list(range(slots))
+                lock = threading.Lock()
+
+                def work(i1):
+                    with lock:
+                        slot = free.pop()
+                    try:
+                        process(slot, i1, min(n, i1 + self.chunk_size))
+                    finally:
+                        with lock:
+                            free.append(slot)
+                with ThreadPoolExecutor(slots) as pool:
+                    list(pool.map(work, range(0, n, self.chunk_size)))
+        return grid, aggs
+
+    def _agg(self, descs, binby=None, limits=None, shape=128, edges=False, reduce=None):
+        """Evaluate a list of descriptors in ONE pass; returns one ndarray per descriptor.  reduce: optional
+        callable(list of aggregator objects) run before the results are read (multi-GPU all-reduce hook)."""
+        specs = self._binner_specs(binby, limits, shape)
+        prims, index = [], {}
+        want = []
+        for d in descs:
+            ids = []
+            for p in d.prims():
+                k = p.key()
+                if k not in index:
+                    index[k] = len(prims)
+                    prims.append(p)
+                ids.append(index[k])
+            want.append(ids)
+        grid, aggs = self._run_pass(specs, prims)
+        if reduce is not None:
+            reduce(aggs)
+        raw = [np.array(a.get_result()) for a in aggs]
+        if not edges:  # vaex/agg.py:323-335
+            sl = tuple(slice(2, -1) if s["kind"] == "scalar" else slice(0, -2) for s in specs)
+            raw = [r[sl] for r in raw]
+        return [d.finish([raw[i] for i in ids]) for d, ids in zip(descs, want)]
+
+    # ------------------------------------------------------------------ the DataFrame-like methods
+    def _one(self, name, expression, binby, limits, shape, selection, edges):
+        desc = getattr(agg, name)(expression, selection=selection) if name != "count" else agg.count(expression, selection=selection)
+        return self._agg([desc], binby, limits, shape, edges)[0]
+
+    def count(self, expression=None, binby=None, limits=None, shape=128, selection=None, edges=False):
+        return self._one("count", expression, binby, limits, shape, selection, edges)
+
+    def sum(self, expression, binby=None, limits=None, shape=128, selection=None, edges=False):
+        return self._one("sum", expression, binby, limits, shape, selection, edges)
+
+    def mean(self, expression, binby=None, limits=None, shape=128, selection=None, edges=False):
+        return self._one("mean", expression, binby, limits, shape, selection, edges)
+
+    def var(self, expression, binby=None, limits=None, shape=128, selection=None, edges=False):
+        return self._one("var", expression, binby, limits, shape, selection, edges)
+
+    def std(self, expression, binby=None, limits=None, shape=128, selection=None, edges=False):
+        return self._one("std", expression, binby, limits, shape, selection, edges)
+
+    def min(self, expression, binby=None, limits=None, shape=128, selection=None, edges=False):
+        return self._one("min", expression, binby, limits, shape, selection, edges)
+
+    def max(self, expression, binby=None, limits=None, shape=128, selection=None, edges=False):
+        return self._one("max", expression, binby, limits, shape, selection, edges)
+
+    # ------------------------------------------------------------------ groupby
+    def groupby(self, by, agg_spec, reduce=None):
+        """df.groupby(by).agg({...}) for ONE integer key column.  Returns {by: keys (ascending), name: values}.
+
+        Pass 1 = distinct keys (ordered_set, vaex/hash.py:152-171); if they are dense
+        (range <= 4/3 * n_unique) the key column bins itself through BinnerOrdinal(min_value) — the
+        reference's simplification to BinnerInteger (vaex/groupby.py:263-272) — otherwise the keys are
+        mapped through the GPU hash map inside the binner (BinnerHash: one pass, no ordinal column)."""
+        sa = self.sa
+        key = self.columns[by]
+        if np.ma.isMaskedArray(key):
+            raise NotImplementedError("masked group keys")
+        pf = _class_postfix(key)
+        if pf.startswith("float") or pf.endswith("_non_native"):
+            raise NotImplementedError("groupby on float / non-native keys")
+        hm = getattr(sa, "ordered_set_" + pf)()
+        if _is_device(key):
+            hm.update(key)
+        else:
+            for i1 in range(0, self.n, 1 << 24):
+                hm.update(np.ascontiguousarray(key[i1:i1 + (1 << 24)]))
+        keys = np.array(hm.key_array())
+        if pf.startswith("uint"):
+            keys = keys.astype(np.uint64)
+        nuniq = len(keys)
+        descs, names = [], []
+        for name, d in agg_spec.items():
+            names.append(name)
+            descs.append(d)
+        if nuniq == 0:
+            return {by: keys, **{n: np.array([]) for n in names}}
+        kmin, kmax = int(keys.min()), int(keys.max())
+        if kmax - kmin + 1 <= 4 * nuniq // 3 + 1:
+            count = kmax - kmin + 1
+            res = self._agg(descs + [agg.count()], binby=[dict(column=by, count=count, min_value=kmin)], edges=True, reduce=reduce)
+            present = res[-1][:count] > 0
+            out_keys = (np.arange(count, dtype=np.int64) + kmin)[present]
+            vals = [r[:count][present] for r in res[:-1]]
+        else:
+            # sealed map with deterministic ordinals = rank of the key in ascending order (ordered_set::create)
+            out_keys = np.sort(keys)
+            sealed = getattr(sa, "ordered_set_" + pf)(len(out_keys))
+            sealed.set_keys(out_keys.astype(np.int64))
+            res = self._agg_hash(descs, by, pf, sealed, reduce)
+            vals = [r[1:1 + nuniq] for r in res]
+        return {by: out_keys.astype(keys.dtype), **dict(zip(names, vals))}
+
+    def _agg_hash(self, descs, by, pf, hm, reduce):
+        """Same fused pass with a BinnerHash on the key column (cells: [unknown, ordinal 0..N-1, null])."""
+        sa = self.sa
+        prims, index, want = [], {}, []
+        for d in descs:
+            ids = []
+            for p in d.prims():
+                k = p.key()
+                if k not in index:
+                    index[k] = len(prims)
+                    prims.append(p)
+                ids.append(index[k])
+            want.append(ids)
+        # build the pass by hand: one hash binner
+        key = self.columns[by]
+        device = _is_device(key)
+        slots = 1 if device and all(p.column is None or _is_device(self._col(p.column, p.as_float64)) for p in prims) else max(1, self.nthreads)
+        binner = getattr(sa, "BinnerHash_" + pf)(slots, by, hm)
+        grid = sa.Grid([binner])
+        aggs = []
+        for p in prims:
+            cpf = "int64" if p.column is None else _class_postfix(self._col(p.column, p.as_float64))
+            cls = getattr(sa, _KIND_CLASS[p.kind] + cpf)
+            aggs.append(cls(grid, slots, slots, p.moment) if p.kind == "summoment" else cls(grid, slots, slots))
+        step = self.n if slots == 1 and device else self.chunk_size
+        slot = 0
+        for i1 in range(0, self.n, max(1, step)):
+            i2 = min(self.n, i1 + step)
+            refs = []
+            k = key[i1:i2] if device else np.ascontiguousarray(key[i1:i2])
+            binner.set_data(slot, k); binner.clear_data_mask(slot); refs.append(k)
+            for a, p in zip(aggs, prims):
+                if p.column is not None:
+                    c = self._col(p.column, p.as_float64)
+                    d = c[i1:i2] if _is_device(c) else np.ascontiguousarray(c[i1:i2])
+                    a.set_data(slot, d, 0); refs.append(d)
+                sel = self._selection_mask(p.selection)
+                if sel is not None:
+                    m = _as_u8(sel[i1:i2]); a.set_data_mask(slot, m); refs.append(m)
+                else:
+                    a.clear_data_mask(slot)
+            grid.bin(slot, aggs, i2 - i1)
+            slot = (slot + 1) % slots
+        if reduce is not None:
+            reduce(aggs)
+        raw = [np.array(a.get_result()) for a in aggs]
+        return [d.finish([raw[i] for i in ids]) for d, ids in zip(descs, want)]
+
+
+_DT_CODE = {"float64": 0, "float32": 1, "int64": 2, "int32": 3, "int16": 4, "int8": 5, "uint64": 6, "uint32": 7, "uint16": 8, "uint8": 9, "bool": 10}

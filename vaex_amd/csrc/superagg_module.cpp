@@ -99,6 +99,9 @@ struct PyHashMap {
         }
         check(rc);
     }
+    void set_keys(py::array_t<int64_t, py::array::c_style | py::array::forcecast> keys) {
+        check(vxh_hashmap_set_keys(h, keys.data(), (uint64_t)keys.size()));
+    }
     int64_t count() {
         int64_t c;
         check(vxh_hashmap_count(h, &c));
@@ -472,6 +475,7 @@ PYBIND11_MODULE(superagg, m) {
     py::class_<PyHashMap> hashmap(m, "ordered_set");
     hashmap.def("update", &PyHashMap::update, py::arg("keys"), py::arg("mask") = py::none())
         .def("map_ordinal", &PyHashMap::map_ordinal)
+        .def("set_keys", &PyHashMap::set_keys)
         .def("key_array", &PyHashMap::key_array)
         .def("__len__", &PyHashMap::count)
         .def_property_readonly("null_index", &PyHashMap::null_index)

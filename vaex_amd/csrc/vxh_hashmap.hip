@@ -92,6 +92,23 @@ __global__ void __launch_bounds__(256) hm_lookup(const void *data, int dt, uint6
     }
 }
 
+// insert keys[i] with ordinal i (ordered_set::create — src/hash_primitives.hpp:486-537): keys must be distinct
+__global__ void __launch_bounds__(256) hm_insert_ordered(const long long *in_keys, uint64_t n, long long *keys, long long *vals, uint64_t hmask, unsigned long long *side) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        const long long key = in_keys[i];
+        if (key == EMPTY) { side[2] = 1; side[3] = i; continue; }
+        uint64_t p = splitmix64((uint64_t)key) & hmask;
+        for (;;) {
+            long long old = (long long)atomicCAS((unsigned long long *)&keys[p], (unsigned long long)EMPTY, (unsigned long long)key);
+            if (old == EMPTY) { vals[p] = (long long)i; break; }
+            if (old == key) break; // duplicate: first writer wins
+            p = (p + 1) & hmask;
+        }
+    }
+}
+
 // re-insert every occupied slot of the old table into the new one, keeping its ordinal
 __global__ void __launch_bounds__(256) hm_rehash(const long long *okeys, const long long *ovals, uint64_t ocap, long long *keys, long long *vals, uint64_t hmask) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -249,6 +266,25 @@ int vxh_hashmap_update(vxh_hashmap *m, const void *keys, const uint8_t *mask, ui
     }
     if (tmp_k) (void)hipFree(tmp_k);
     if (tmp_m) (void)hipFree(tmp_m);
+    HM_END
+}
+
+int vxh_hashmap_set_keys(vxh_hashmap *m, const int64_t *keys, uint64_t n) {
+    HM_BEGIN
+    std::lock_guard<std::mutex> lock(m->mutex);
+    if (m->host_side[0] != 0) throw std::runtime_error("hash map is not empty");
+    if (n == 0) return 0;
+    Slot &s = get_slot(0);
+    while (m->cap < 2 * n) hm_grow(m, m->cap * 2, s.stream);
+    long long *d = nullptr;
+    HIP_CHECK(hipMalloc(&d, n * 8));
+    HIP_CHECK(hipMemcpyAsync(d, keys, n * 8, hipMemcpyHostToDevice, s.stream));
+    hipLaunchKernelGGL(hm_insert_ordered, dim3(grid_for(n)), dim3(256), 0, s.stream, d, n, m->keys, m->vals, m->cap - 1, m->side);
+    HIP_CHECK(hipGetLastError());
+    unsigned long long cnt = n;
+    HIP_CHECK(hipMemcpyAsync(m->side, &cnt, 8, hipMemcpyHostToDevice, s.stream));
+    hm_refresh(m, s.stream);
+    (void)hipFree(d);
     HM_END
 }
 

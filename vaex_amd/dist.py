@@ -30,13 +30,17 @@ def _reduce_op(name):
 
 
 def allreduce_aggs(aggs, group=None):
-    """In-place all-reduce of the device grids of `aggs` across the process group (RCCL).
+    """In-place all-reduce of the grids of `aggs` across the process group.
 
-    After the call every rank's aggregators hold the global result (get_result() returns it)."""
+    "nccl" backend (RCCL): the device grids are reduced in place over xGMI.  Any other backend ("gloo" in
+    the CPU tests): the grids go through the aggregators' host buffers.  After the call every rank's
+    aggregators hold the global result (get_result() returns it)."""
     import torch
     import torch.distributed as dist
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return
+    if dist.get_backend(group) != "nccl" or not all(hasattr(a, "device_touch") for a in aggs):
+        return allreduce_aggs_host(aggs, group)
     works = []
     tensors = []
     for agg in aggs:
@@ -50,6 +54,28 @@ def allreduce_aggs(aggs, group=None):
     torch.cuda.synchronize()
     for agg in aggs:
         agg.device_touch()
+
+
+def allreduce_aggs_host(aggs, group=None):
+    """Same reduce through the (grids, *shapes) host buffers of the aggregators (buffer protocol of the
+    superagg surface, src/agg_base.hpp:106-125): grid 0 receives the global result, the others the identity."""
+    ops = [agg_reduce_op(a) for a in aggs]
+    local = [np.array(a.get_result()) for a in aggs]
+    reduced = allreduce_results(local, ops, group)
+    for a, r, op in zip(aggs, reduced, ops):
+        buf = np.asarray(a)
+        buf[0] = r
+        if buf.shape[0] > 1:
+            ident = 0
+            if op != "sum":
+                info = np.finfo(buf.dtype) if buf.dtype.kind == "f" else (np.iinfo(buf.dtype) if buf.dtype.kind in "iu" else None)
+                if buf.dtype.kind == "f":
+                    ident = np.inf if op == "min" else -np.inf
+                elif info is not None:
+                    ident = info.max if op == "min" else info.min
+                else:
+                    ident = op == "min"
+            buf[1:] = ident
 
 
 class _Wrap:
