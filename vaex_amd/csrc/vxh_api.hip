@@ -575,6 +575,7 @@ static void run_part_chunk(Slot &slot, const BinArgs &planned, const LaunchPlan 
         if (scatter_lds <= 78 * 1024 || R == 2) break;
     }
     P.rows_per_thread = R;
+    P.no_pipeline = c.cfg_no_pipeline ? 1 : 0;
     const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(4, kLdsMax / scatter_lds));
     const uint64_t tiles = (planned.n + 512ull * R - 1) / (512ull * R);
     const int scatter_blocks = (int)std::max<uint64_t>(1, std::min<uint64_t>(tiles, (uint64_t)c.cus * per_cu));
@@ -657,6 +658,7 @@ int vxh_config_set(const char *key, int64_t value) {
     else if (k == "parts") c.cfg_parts = value;
     else if (k == "part_lds") c.cfg_part_lds = value;
     else if (k == "part_rows") c.cfg_part_rows = value;
+    else if (k == "no_pipeline") c.cfg_no_pipeline = value;
     else if (k == "lds_replicas") c.cfg_lds_replicas = value;
     else throw std::runtime_error("unknown config key: " + k);
     VXH_API_END
@@ -676,6 +678,7 @@ int vxh_config_get(const char *key, int64_t *value) {
     else if (k == "parts") *value = c.cfg_parts;
     else if (k == "part_lds") *value = c.cfg_part_lds;
     else if (k == "part_rows") *value = c.cfg_part_rows;
+    else if (k == "no_pipeline") *value = c.cfg_no_pipeline;
     else if (k == "lds_replicas") *value = c.cfg_lds_replicas;
     else if (k == "cus") { ensure_device_ready(); *value = c.cus; }
     else throw std::runtime_error("unknown config key: " + k);

@@ -477,27 +477,105 @@ __device__ __forceinline__ void records_apply(const PartArgs &P, char *lds, cons
 }
 
 // pass 1: rows -> per-slab record queues.  512 threads, R rows per thread per tile.
+//
+// Per tile: [B] gather the tile's rows, compute cell -> (slab, local index), count the tile's records per slab
+// with returning LDS atomics (the return value is the record's position inside its bucket) | sync |
+// [C] S lanes: exclusive prefix of the bucket counts and ONE HBM atomic per slab reserving queue space — issued,
+// not yet consumed | sync | [D] every lane writes its records to the LDS staging area sorted by slab; the
+// reservation results are parked in LDS; bucket counters re-zeroed for the next tile | sync | [E] copy the
+// staging area out to the queues, consecutive lanes -> consecutive queue slots (coalesced).  Three barriers per
+// tile; nothing a later phase of the NEXT tile writes is still being read (see the hazard notes in DESIGN.md).
+struct ScatterLds {
+    uint32_t *s_cnt;              // [S]   records of this tile per slab
+    uint32_t *s_off;              // [S+1] exclusive prefix of s_cnt
+    unsigned long long *s_gbase;  // [S]   queue position reserved for the tile's records of slab s (or OVERFLOW)
+    uint64_t *st_val;             // [nvals][T]
+    uint32_t *st_idx;             // [T]
+    uint16_t *st_slab;            // [T]
+    uint8_t *st_flags;            // [T]
+};
+__device__ __forceinline__ ScatterLds scatter_carve(char *lds, uint32_t S, uint32_t T, int nvals) {
+    ScatterLds L;
+    L.s_cnt = (uint32_t *)lds;
+    L.s_off = L.s_cnt + S;
+    L.s_gbase = (unsigned long long *)(L.s_off + S + 4);
+    L.st_val = (uint64_t *)(L.s_gbase + S);
+    L.st_idx = (uint32_t *)(L.st_val + (size_t)nvals * T);
+    L.st_slab = (uint16_t *)(L.st_idx + T);
+    L.st_flags = (uint8_t *)(L.st_slab + T);
+    return L;
+}
+
+constexpr unsigned long long VXH_Q_OVERFLOW = ~0ull;
+
+// [C]: prefix + reservation issue (lanes < S)
+__device__ __forceinline__ void scatter_reserve(const PartArgs &P, const ScatterLds &L, uint32_t S, unsigned long long &my_gb, uint32_t &my_cnt) {
+    my_gb = 0;
+    my_cnt = 0;
+    if (threadIdx.x < S) {
+        const uint32_t s0 = threadIdx.x;
+        uint32_t off = 0;
+        for (uint32_t j = 0; j < s0; ++j) off += L.s_cnt[j];
+        L.s_off[s0] = off;
+        my_cnt = L.s_cnt[s0];
+        if (s0 == S - 1) L.s_off[S] = off + my_cnt;
+        if (my_cnt) my_gb = atomicAdd(&P.qcount[s0], (unsigned long long)my_cnt);
+    }
+}
+
+// [D] tail: consume the reservation, re-zero the bucket counter (lanes < S)
+__device__ __forceinline__ void scatter_commit(const PartArgs &P, const ScatterLds &L, uint32_t S, unsigned long long my_gb, uint32_t my_cnt) {
+    if (threadIdx.x < S) {
+        if (my_cnt && my_gb + my_cnt > P.cap) { // does not fit: remember where the valid prefix of the queue ends
+            atomicMin(&P.qlimit[threadIdx.x], my_gb);
+            my_gb = VXH_Q_OVERFLOW;
+        }
+        L.s_gbase[threadIdx.x] = my_gb;
+        L.s_cnt[threadIdx.x] = 0;
+    }
+}
+
+// [E]: staging -> queues
+__device__ __forceinline__ void scatter_copy_out(const PartArgs &P, const ScatterLds &L, uint32_t S, uint32_t T) {
+    const uint32_t total = L.s_off[S];
+    for (uint32_t j = threadIdx.x; j < total; j += 512) {
+        const uint32_t s = L.st_slab[j];
+        const unsigned long long gb = L.s_gbase[s];
+        if (gb != VXH_Q_OVERFLOW) {
+            const uint64_t dst = (uint64_t)s * P.cap + gb + (j - L.s_off[s]);
+            if (P.idx16) ((uint16_t *)P.qidx)[dst] = (uint16_t)L.st_idx[j];
+            else ((uint32_t *)P.qidx)[dst] = L.st_idx[j];
+            if (P.use_flags) P.qflags[dst] = L.st_flags[j];
+#pragma unroll
+            for (int k = 0; k < VXH_PART_MAX_VALS; ++k)
+                if (k < P.nvals) P.qval[k][dst] = L.st_val[(size_t)k * T + j];
+        } else {
+            // queue full (pathologically skewed data): scatter this record straight to HBM with atomics — into a
+            // replica of its own when pass 2 (which may be running concurrently for the previous chunk) flushes
+            // the others with plain read-modify-write
+            uint64_t gidx[1] = {((uint64_t)L.st_idx[j] << P.slab_log2) + s};
+            uint32_t f1[1] = {(uint32_t)L.st_flags[j]};
+            uint64_t v1[VXH_PART_MAX_VALS][1];
+#pragma unroll
+            for (int k = 0; k < VXH_PART_MAX_VALS; ++k) v1[k][0] = k < P.nvals ? L.st_val[(size_t)k * T + j] : 0;
+            records_apply<__HIP_MEMORY_SCOPE_AGENT, false, 1>(P, nullptr, gidx, f1, v1, 1u, P.A.flush_plain ? (uint64_t)P.parts : 0);
+        }
+    }
+}
+
+// generic version: any binner kind / dtype / byte order / masks
 template <bool FAST, int R>
 __global__ void __launch_bounds__(512) part_scatter(const PartArgs P) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    constexpr unsigned long long OVERFLOW = ~0ull;
     const uint32_t S = 1u << P.slab_log2;
     const uint32_t T = 512u * R;
-    // LDS carve (all offsets multiples of 8)
-    uint32_t *s_cnt = (uint32_t *)lds;                                   // [S]
-    uint32_t *s_off = s_cnt + S;                                         // [S+1] (+pad)
-    unsigned long long *s_gbase = (unsigned long long *)(s_off + S + 4); // [S]
-    uint64_t *st_val = (uint64_t *)(s_gbase + S);                        // [nvals][T]
-    uint32_t *st_idx = (uint32_t *)(st_val + (size_t)P.nvals * T);       // [T]
-    uint16_t *st_slab = (uint16_t *)(st_idx + T);                        // [T]
-    uint8_t *st_flags = (uint8_t *)(st_slab + T);                        // [T]
+    const ScatterLds L = scatter_carve(lds, S, T, P.nvals);
     const uint64_t n = P.A.n;
+    if (threadIdx.x < S) L.s_cnt[threadIdx.x] = 0;
+    __syncthreads();
 
     for (uint64_t tile = blockIdx.x; tile * T < n; tile += gridDim.x) {
         const uint64_t i0 = tile * T + threadIdx.x;
-        for (uint32_t s = threadIdx.x; s < S; s += 512) s_cnt[s] = 0;
-        __syncthreads();
-
         const Rows<R> rows = make_rows<R>(i0, 512, n);
         // aggregator masks -> one flag bit per distinct mask; rows no aggregator wants emit no record
         uint32_t fl[R];
@@ -534,68 +612,134 @@ __global__ void __launch_bounds__(512) part_scatter(const PartArgs P) {
             slab[r] = (uint32_t)idx[r] & (S - 1);
             loc[r] = (uint32_t)(idx[r] >> P.slab_log2);
             pos[r] = 0;
-            if ((keep >> r) & 1u) pos[r] = __hip_atomic_fetch_add(&s_cnt[slab[r]], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if ((keep >> r) & 1u) pos[r] = __hip_atomic_fetch_add(&L.s_cnt[slab[r]], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         __syncthreads();
-        // exclusive prefix over the S bucket counts; the reservation of queue space (one HBM atomic per slab per
-        // tile) is issued here but only consumed after the staging writes, which hides its round trip
-        unsigned long long my_gb = 0;
-        uint32_t my_cnt = 0;
-        if (threadIdx.x < S) {
-            const uint32_t s0 = threadIdx.x;
-            uint32_t off = 0;
-            for (uint32_t j = 0; j < s0; ++j) off += s_cnt[j];
-            s_off[s0] = off;
-            my_cnt = s_cnt[s0];
-            if (s0 == S - 1) s_off[S] = off + my_cnt;
-            if (my_cnt) my_gb = atomicAdd(&P.qcount[s0], (unsigned long long)my_cnt);
-        }
+        unsigned long long my_gb;
+        uint32_t my_cnt;
+        scatter_reserve(P, L, S, my_gb, my_cnt);
         __syncthreads();
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             if ((keep >> r) & 1u) {
-                const uint32_t j = s_off[slab[r]] + pos[r];
-                st_idx[j] = loc[r];
-                st_slab[j] = (uint16_t)slab[r];
-                st_flags[j] = (uint8_t)fl[r];
+                const uint32_t j = L.s_off[slab[r]] + pos[r];
+                L.st_idx[j] = loc[r];
+                L.st_slab[j] = (uint16_t)slab[r];
+                L.st_flags[j] = (uint8_t)fl[r];
 #pragma unroll
                 for (int k = 0; k < VXH_PART_MAX_VALS; ++k)
-                    if (k < P.nvals) st_val[(size_t)k * T + j] = val[k][r];
+                    if (k < P.nvals) L.st_val[(size_t)k * T + j] = val[k][r];
             }
         }
-        if (threadIdx.x < S) {
-            if (my_cnt && my_gb + my_cnt > P.cap) { // does not fit: remember where the valid prefix of the queue ends
-                atomicMin(&P.qlimit[threadIdx.x], my_gb);
-                my_gb = OVERFLOW;
+        scatter_commit(P, L, S, my_gb, my_cnt);
+        __syncthreads();
+        scatter_copy_out(P, L, S, T);
+    }
+}
+
+// software-pipelined version for the common case — NDIM (1..3) scalar float64 native unmasked binners, float64
+// native aggregator inputs, at most one aggregator mask: the raw columns of tile t+1 are requested right after
+// barrier 2 of tile t and land while phases D and E of tile t run.
+template <int NDIM, int NVAL, int R>
+__global__ void __launch_bounds__(512) part_scatter_f64(const PartArgs P) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const uint32_t S = 1u << P.slab_log2;
+    const uint32_t T = 512u * R;
+    const ScatterLds L = scatter_carve(lds, S, T, P.nvals);
+    const uint64_t n = P.A.n;
+    uint64_t tile = blockIdx.x;
+    if (tile * T >= n) return;
+    if (threadIdx.x < S) L.s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+
+    struct Raw {
+        double b[NDIM][R];
+        uint64_t v[NVAL > 0 ? NVAL : 1][R];
+        uint8_t m[R];
+        uint32_t valid;
+    };
+    auto request = [&](uint64_t t, Raw &raw) {
+        const Rows<R> rows = make_rows<R>(t * T + threadIdx.x, 512, n);
+        raw.valid = rows.valid;
+#pragma unroll
+        for (int d = 0; d < NDIM; ++d) {
+            const double *col = (const double *)P.A.b[d].data;
+#pragma unroll
+            for (int r = 0; r < R; ++r) raw.b[d][r] = col[rows.i[r]];
+        }
+#pragma unroll
+        for (int k = 0; k < NVAL; ++k) {
+            const uint64_t *col = (const uint64_t *)P.vdata[k];
+#pragma unroll
+            for (int r = 0; r < R; ++r) raw.v[k][r] = col[rows.i[r]];
+        }
+        if (P.nmasks) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) raw.m[r] = P.mdata[0][rows.i[r]];
+        }
+    };
+
+    Raw cur;
+    request(tile, cur);
+    for (;;) {
+        // [B]
+        uint32_t keep = cur.valid;
+        uint32_t fl[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) fl[r] = 0;
+        if (P.nmasks) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) fl[r] = cur.m[r] == 1 ? 1u : 0u;
+            if (P.all_masked) {
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+                    if (fl[r] == 0) keep &= ~(1u << r);
             }
-            s_gbase[threadIdx.x] = my_gb;
+        }
+        uint32_t slab[R], loc[R], pos[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            uint64_t idx = 0;
+#pragma unroll
+            for (int d = 0; d < NDIM; ++d) {
+                const BinnerDesc &b = P.A.b[d];
+                idx += scalar_sub_index(cur.b[d][r], false, b.vmin, b.scale, b.binsd, b.bins) * b.stride;
+            }
+            slab[r] = (uint32_t)idx & (S - 1);
+            loc[r] = (uint32_t)(idx >> P.slab_log2);
+            pos[r] = 0;
+            if ((keep >> r) & 1u) pos[r] = __hip_atomic_fetch_add(&L.s_cnt[slab[r]], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         __syncthreads();
-        const uint32_t total = s_off[S];
-        for (uint32_t j = threadIdx.x; j < total; j += 512) {
-            const uint32_t s = st_slab[j];
-            const unsigned long long gb = s_gbase[s];
-            if (gb != OVERFLOW) {
-                const uint64_t dst = (uint64_t)s * P.cap + gb + (j - s_off[s]);
-                if (P.idx16) ((uint16_t *)P.qidx)[dst] = (uint16_t)st_idx[j];
-                else ((uint32_t *)P.qidx)[dst] = st_idx[j];
-                if (P.use_flags) P.qflags[dst] = st_flags[j];
+        // [C]
+        unsigned long long my_gb;
+        uint32_t my_cnt;
+        scatter_reserve(P, L, S, my_gb, my_cnt);
+        __syncthreads();
+        // request the next tile's columns; they are not touched before the next [B]
+        const uint64_t next = tile + gridDim.x;
+        const bool has_next = next * T < n;
+        Raw nxt;
+        if (has_next) request(next, nxt);
+        // [D]
 #pragma unroll
-                for (int k = 0; k < VXH_PART_MAX_VALS; ++k)
-                    if (k < P.nvals) P.qval[k][dst] = st_val[(size_t)k * T + j];
-            } else {
-                // queue full (pathologically skewed data): scatter this record straight to HBM with atomics — into a
-                // replica of its own when pass 2 (which may be running concurrently for the previous chunk) flushes
-                // the others with plain read-modify-write
-                uint64_t gidx[1] = {((uint64_t)st_idx[j] << P.slab_log2) + s};
-                uint32_t f1[1] = {(uint32_t)st_flags[j]};
-                uint64_t v1[VXH_PART_MAX_VALS][1];
+        for (int r = 0; r < R; ++r) {
+            if ((keep >> r) & 1u) {
+                const uint32_t j = L.s_off[slab[r]] + pos[r];
+                L.st_idx[j] = loc[r];
+                L.st_slab[j] = (uint16_t)slab[r];
+                L.st_flags[j] = (uint8_t)fl[r];
 #pragma unroll
-                for (int k = 0; k < VXH_PART_MAX_VALS; ++k) v1[k][0] = k < P.nvals ? st_val[(size_t)k * T + j] : 0;
-                records_apply<__HIP_MEMORY_SCOPE_AGENT, false, 1>(P, nullptr, gidx, f1, v1, 1u, P.A.flush_plain ? (uint64_t)P.parts : 0);
+                for (int k = 0; k < NVAL; ++k) L.st_val[(size_t)k * T + j] = cur.v[k][r];
             }
         }
+        scatter_commit(P, L, S, my_gb, my_cnt);
         __syncthreads();
+        // [E]
+        scatter_copy_out(P, L, S, T);
+        if (!has_next) break;
+        cur = nxt;
+        tile = next;
     }
 }
 
@@ -733,15 +877,26 @@ size_t vxh_lds_cell_size(int kind, int cell) { return kind == VXH_AGG_COUNT ? 4 
 
 void vxh_launch_part_scatter(const PartArgs &args, bool fast_f64, int scatter_blocks, size_t scatter_lds, hipStream_t stream) {
     const int R = args.rows_per_thread;
-#define VXH_SC(F, RR)                                                                                                  \
+#define VXH_SC(KERNEL)                                                                                                 \
     do {                                                                                                               \
-        if (scatter_lds > 48 * 1024) (void)hipFuncSetAttribute((const void *)part_scatter<F, RR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)scatter_lds); \
-        hipLaunchKernelGGL((part_scatter<F, RR>), dim3(scatter_blocks), dim3(512), scatter_lds, stream, args);         \
+        if (scatter_lds > 48 * 1024) (void)hipFuncSetAttribute((const void *)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, (int)scatter_lds); \
+        hipLaunchKernelGGL(KERNEL, dim3(scatter_blocks), dim3(512), scatter_lds, stream, args);                        \
     } while (0)
-    if (fast_f64) {
-        if (R == 8) VXH_SC(true, 8); else if (R == 4) VXH_SC(true, 4); else VXH_SC(true, 2);
+    if (fast_f64 && R == 4 && args.A.ndim >= 1 && args.A.ndim <= 3 && args.nvals <= 2 && args.nmasks <= 1 && !args.no_pipeline) {
+#define VXH_SCN(ND)                                                                                                    \
+    do {                                                                                                               \
+        if (args.nvals == 0) VXH_SC((part_scatter_f64<ND, 0, 4>));                                                     \
+        else if (args.nvals == 1) VXH_SC((part_scatter_f64<ND, 1, 4>));                                                \
+        else VXH_SC((part_scatter_f64<ND, 2, 4>));                                                                     \
+    } while (0)
+        if (args.A.ndim == 1) VXH_SCN(1);
+        else if (args.A.ndim == 2) VXH_SCN(2);
+        else VXH_SCN(3);
+#undef VXH_SCN
+    } else if (fast_f64) {
+        if (R == 8) VXH_SC((part_scatter<true, 8>)); else if (R == 4) VXH_SC((part_scatter<true, 4>)); else VXH_SC((part_scatter<true, 2>));
     } else {
-        if (R == 8) VXH_SC(false, 8); else if (R == 4) VXH_SC(false, 4); else VXH_SC(false, 2);
+        if (R == 8) VXH_SC((part_scatter<false, 8>)); else if (R == 4) VXH_SC((part_scatter<false, 4>)); else VXH_SC((part_scatter<false, 2>));
     }
 #undef VXH_SC
 }
