@@ -575,18 +575,23 @@ static void run_part_chunk(Slot &slot, const BinArgs &planned, const LaunchPlan 
         if (scatter_lds <= 78 * 1024 || R == 2) break;
     }
     P.rows_per_thread = R;
-    P.no_pipeline = c.cfg_no_pipeline ? 1 : 0;
+    P.no_pipeline = (int32_t)c.cfg_no_pipeline; // bit 0: generic kernel; bit 1 (timing experiments only): skip the queue writes
     const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(4, kLdsMax / scatter_lds));
     const uint64_t tiles = (planned.n + 512ull * R - 1) / (512ull * R);
     const int scatter_blocks = (int)std::max<uint64_t>(1, std::min<uint64_t>(tiles, (uint64_t)c.cus * per_cu));
     vxh_launch_part_scatter(P, plan.fast_f64, scatter_blocks, scatter_lds, slot.stream);
     HIP_CHECK(hipGetLastError());
-    HIP_CHECK(hipEventRecord(pb.scattered, slot.stream));
-    HIP_CHECK(hipStreamWaitEvent(slot.stream2, pb.scattered, 0));
-    vxh_launch_part_reduce(P, plan, slot.stream2);
-    HIP_CHECK(hipGetLastError());
-    HIP_CHECK(hipEventRecord(pb.reduced, slot.stream2));
-    pb.busy = true;
+    if (c.cfg_part_overlap) {
+        HIP_CHECK(hipEventRecord(pb.scattered, slot.stream));
+        HIP_CHECK(hipStreamWaitEvent(slot.stream2, pb.scattered, 0));
+        vxh_launch_part_reduce(P, plan, slot.stream2);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipEventRecord(pb.reduced, slot.stream2));
+        pb.busy = true;
+    } else {
+        vxh_launch_part_reduce(P, plan, slot.stream);
+        HIP_CHECK(hipGetLastError());
+    }
 }
 
 // make slot.stream wait for every outstanding pass 2 (end of a vxh_grid_bin call)
@@ -659,6 +664,7 @@ int vxh_config_set(const char *key, int64_t value) {
     else if (k == "part_lds") c.cfg_part_lds = value;
     else if (k == "part_rows") c.cfg_part_rows = value;
     else if (k == "no_pipeline") c.cfg_no_pipeline = value;
+    else if (k == "part_overlap") c.cfg_part_overlap = value;
     else if (k == "lds_replicas") c.cfg_lds_replicas = value;
     else throw std::runtime_error("unknown config key: " + k);
     VXH_API_END
@@ -679,6 +685,7 @@ int vxh_config_get(const char *key, int64_t *value) {
     else if (k == "part_lds") *value = c.cfg_part_lds;
     else if (k == "part_rows") *value = c.cfg_part_rows;
     else if (k == "no_pipeline") *value = c.cfg_no_pipeline;
+    else if (k == "part_overlap") *value = c.cfg_part_overlap;
     else if (k == "lds_replicas") *value = c.cfg_lds_replicas;
     else if (k == "cus") { ensure_device_ready(); *value = c.cus; }
     else throw std::runtime_error("unknown config key: " + k);

@@ -736,7 +736,7 @@ __global__ void __launch_bounds__(512) part_scatter_f64(const PartArgs P) {
         scatter_commit(P, L, S, my_gb, my_cnt);
         __syncthreads();
         // [E]
-        scatter_copy_out(P, L, S, T);
+        if (!(P.no_pipeline & 2)) scatter_copy_out(P, L, S, T);
         if (!has_next) break;
         cur = nxt;
         tile = next;
@@ -882,7 +882,7 @@ void vxh_launch_part_scatter(const PartArgs &args, bool fast_f64, int scatter_bl
         if (scatter_lds > 48 * 1024) (void)hipFuncSetAttribute((const void *)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, (int)scatter_lds); \
         hipLaunchKernelGGL(KERNEL, dim3(scatter_blocks), dim3(512), scatter_lds, stream, args);                        \
     } while (0)
-    if (fast_f64 && R == 4 && args.A.ndim >= 1 && args.A.ndim <= 3 && args.nvals <= 2 && args.nmasks <= 1 && !args.no_pipeline) {
+    if (fast_f64 && R == 4 && args.A.ndim >= 1 && args.A.ndim <= 3 && args.nvals <= 2 && args.nmasks <= 1 && !(args.no_pipeline & 1)) {
 #define VXH_SCN(ND)                                                                                                    \
     do {                                                                                                               \
         if (args.nvals == 0) VXH_SC((part_scatter_f64<ND, 0, 4>));                                                     \
