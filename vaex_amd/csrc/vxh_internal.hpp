@@ -102,7 +102,7 @@ struct Context {
     int64_t cfg_part_chunk = 1 << 27; // rows per partition chunk
     int64_t cfg_parts = 0;        // pass-2 workgroups per slab (0 = auto)
     int64_t cfg_part_lds = 0;     // LDS bytes per pass-2 slab (0 = auto)
-    int64_t cfg_part_overlap = 1; // pass 2 of chunk i on a second stream, overlapping pass 1 of chunk i+1
+    int64_t cfg_part_overlap = 0; // pass 2 of chunk i on a second stream, overlapping pass 1 of chunk i+1
     int64_t cfg_no_pipeline = 0;  // 1: non-pipelined pass-1 kernel
     int64_t cfg_part_rows = 0;    // pass-1 rows per thread per tile: 8, 4 or 2 (0 = auto)
 };
