@@ -547,7 +547,7 @@ static void run_part_chunk(Slot &slot, const BinArgs &planned, const LaunchPlan 
     P.no_pipeline = (int32_t)c.cfg_no_pipeline; // bit 0: generic kernel; bit 1 (timing experiments only): skip the queue writes
     P.region_log2 = region_log2;
     const uint64_t tiles = (planned.n + 512ull * R - 1) / (512ull * R);
-    const int scatter_blocks = (int)std::max<uint64_t>(1, std::min<uint64_t>(tiles, (uint64_t)c.cus * 2));
+    const int scatter_blocks = (int)std::max<uint64_t>(1, std::min<uint64_t>(tiles, (uint64_t)c.cus * 3));
     // pool: every record of the chunk + a current and a spare region per (workgroup, slab)
     const uint64_t C = chunk_rows_max;
     const uint64_t max_regions = (C + G - 1) / G + (uint64_t)scatter_blocks * S * 2 + 64;
@@ -953,7 +953,7 @@ int vxh_grid_bin(vxh_grid *grid, int thread, vxh_agg *const *aggs, int n_aggs, u
         {
             BinArgs tmp;
             LaunchPlan whole = make_plan(A, tmp, length, bytes_per_row, exclusive);
-            if (whole.strategy == VXH_STRAT_PART) step = (uint64_t)std::max<int64_t>(1 << 20, ctx().cfg_part_chunk);
+            if (whole.strategy == VXH_STRAT_PART) step = (uint64_t)std::min<int64_t>(1ll << 30, std::max<int64_t>(1 << 20, ctx().cfg_part_chunk)); // pool offsets are 32-bit
         }
         for (uint64_t r0 = 0; r0 < length; r0 += step) {
             const uint64_t rn = std::min(step, length - r0);

@@ -655,19 +655,35 @@ __global__ void __launch_bounds__(512) part_scatter(const PartArgs P) {
     cursor_close(P, S, cursor);
 }
 
-// software-pipelined version for the common case — NDIM (1..3) scalar float64 native unmasked binners, NVAL (0..2)
-// float64 native aggregator inputs, at most one aggregator mask: the raw columns of tile t+1 are requested right
-// after barrier 2 of tile t and land while phases D and E of tile t run.
+// BinnerScalar sub-index in 32-bit integer arithmetic (grids < 2^32 cells) with two fp64 compares instead of
+// three: for scaled >= 0 the reference's  `scaled >= 1 ? bins+2 : (int)(scaled*bins)+2`  equals
+// min((int)(scaled*bins), bins) + 2 — when scaled < 1 the product never exceeds bins, when scaled >= 1 it is
+// >= bins (the conversion saturates) — so the overflow compare becomes an integer min.  NaN -> 0, negative -> 1.
+__device__ __forceinline__ uint32_t scalar_sub_index32(double v, double vmin, double scale, double binsd, uint32_t bins) {
+    const double scaled = (v - vmin) * scale;
+    const int t = (int)(scaled * binsd);
+    const uint32_t inside = (uint32_t)(t < (int)bins ? t : (int)bins) + 2u;
+    return scaled >= 0 ? inside : (scaled < 0 ? 1u : 0u);
+}
+
+// fast pass 1 for the common case — NDIM (1..3) scalar float64 native unmasked binners, NVAL (0..2) float64
+// native aggregator inputs, at most one aggregator mask.  Two differences from the generic kernel:
+//  * no LDS staging: after [C] every lane knows the slot of each of its records (current/spare region of the
+//    slab, fill + position from the returning LDS atomic) and stores them straight to the pool; the ~2 KB
+//    window a tile writes per slab is completed within the tile, so the partial lines merge in the XCD's L2;
+//  * software pipelining: the raw columns of tile t+1 are requested before the stores of tile t are issued.
+// Two barriers per tile.
 template <int NDIM, int NVAL, int R>
 __global__ void __launch_bounds__(512) part_scatter_f64(const PartArgs P) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const uint32_t S = 1u << P.slab_log2;
     const uint32_t T = 512u * R;
-    const ScatterLds L = scatter_carve(lds, S, T, P.nvals);
+    const uint32_t G = 1u << P.region_log2;
+    uint32_t *s_cnt = (uint32_t *)lds, *s_cur = s_cnt + S, *s_fill = s_cur + S, *s_spare = s_fill + S;
     const uint64_t n = P.A.n;
     uint64_t tile = blockIdx.x;
     if (tile * T >= n) return;
-    if (threadIdx.x < S) L.s_cnt[threadIdx.x] = 0;
+    if (threadIdx.x < S) s_cnt[threadIdx.x] = 0;
     RegionCursor cursor;
     cursor_init(P, S, cursor);
     __syncthreads();
@@ -702,7 +718,7 @@ __global__ void __launch_bounds__(512) part_scatter_f64(const PartArgs P) {
     Raw cur;
     request(tile, cur);
     for (;;) {
-        // [B]
+        // [B] cell -> (slab, local); position of the record inside the tile's bucket of that slab
         uint32_t keep = cur.valid;
         uint32_t fl[R];
 #pragma unroll
@@ -719,43 +735,60 @@ __global__ void __launch_bounds__(512) part_scatter_f64(const PartArgs P) {
         uint32_t slab[R], loc[R], pos[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            uint64_t idx = 0;
+            uint32_t idx = 0;
 #pragma unroll
             for (int d = 0; d < NDIM; ++d) {
                 const BinnerDesc &b = P.A.b[d];
-                idx += scalar_sub_index(cur.b[d][r], false, b.vmin, b.scale, b.binsd, b.bins) * b.stride;
+                idx += scalar_sub_index32(cur.b[d][r], b.vmin, b.scale, b.binsd, (uint32_t)b.bins) * (uint32_t)b.stride;
             }
-            slab[r] = (uint32_t)idx & (S - 1);
-            loc[r] = (uint32_t)(idx >> P.slab_log2);
+            slab[r] = idx & (S - 1);
+            loc[r] = idx >> P.slab_log2;
             pos[r] = 0;
-            if ((keep >> r) & 1u) pos[r] = __hip_atomic_fetch_add(&L.s_cnt[slab[r]], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if ((keep >> r) & 1u) pos[r] = __hip_atomic_fetch_add(&s_cnt[slab[r]], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         __syncthreads();
-        // [C]
-        scatter_place(P, L, S, cursor);
+        // [C] lanes < S: publish where bucket s goes, advance the cursor, re-zero the counter
+        if (threadIdx.x < S) {
+            const uint32_t s0 = threadIdx.x;
+            const uint32_t cnt = s_cnt[s0];
+            s_cnt[s0] = 0;
+            s_cur[s0] = cursor.cur;
+            s_fill[s0] = cursor.fill;
+            const uint32_t nf = cursor.fill + cnt;
+            if (nf >= G) {
+                s_spare[s0] = cursor.spare;
+                P.rslab[cursor.cur] = (uint16_t)s0;
+                P.rfill[cursor.cur] = G;
+                cursor.cur = cursor.spare;
+                cursor.fill = nf - G;
+                cursor.spare = region_alloc(P);
+            } else {
+                cursor.fill = nf;
+            }
+        }
         __syncthreads();
-        // request the next tile's columns (the last tile re-requests itself so that the number of loads in
-        // flight is static); they are not touched before the next [B]
+        // request the next tile's columns (the last tile re-requests itself: static number of loads in flight)
         const uint64_t next = tile + gridDim.x;
         const bool has_next = next * T < n;
         Raw nxt;
         request(has_next ? next : tile, nxt);
-        // [D]
+        // [D] store the records
+        if (!(P.no_pipeline & 2)) {
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            if ((keep >> r) & 1u) {
-                const uint32_t j = L.s_off[slab[r]] + pos[r];
-                L.st_idx[j] = loc[r];
-                L.st_slab[j] = (uint16_t)slab[r];
-                L.st_flags[j] = (uint8_t)fl[r];
+            for (int r = 0; r < R; ++r) {
+                if ((keep >> r) & 1u) {
+                    uint32_t q = s_fill[slab[r]] + pos[r];
+                    uint32_t id = s_cur[slab[r]];
+                    if (q >= G) { q -= G; id = s_spare[slab[r]]; }
+                    const uint32_t dst = (id << P.region_log2) + q; // max_regions * G < 2^32 (checked by the host)
+                    if (P.idx16) ((uint16_t *)P.qidx)[dst] = (uint16_t)loc[r];
+                    else ((uint32_t *)P.qidx)[dst] = loc[r];
+                    if (P.use_flags) P.qflags[dst] = (uint8_t)fl[r];
 #pragma unroll
-                for (int k = 0; k < NVAL; ++k) L.st_val[(size_t)k * T + j] = cur.v[k][r];
+                    for (int k = 0; k < NVAL; ++k) P.qval[k][dst] = cur.v[k][r];
+                }
             }
         }
-        if (threadIdx.x < S) L.s_cnt[threadIdx.x] = 0;
-        __syncthreads();
-        // [E]
-        if (!(P.no_pipeline & 2)) scatter_copy_out(P, L, S, T);
         if (!has_next) break;
         cur = nxt;
         tile = next;
@@ -819,12 +852,17 @@ __global__ void __launch_bounds__(1024) part_reduce(const PartArgs P) {
     __syncthreads();
     uint32_t nreg = *P.pool_next;
     if (nreg > P.max_regions) nreg = P.max_regions;
-    for (uint32_t base = 0; base < nreg; base += WINDOW) {
-        const uint32_t id = base + threadIdx.x;
-        if (threadIdx.x < WINDOW && id < nreg && P.rslab[id] == slab && id % (uint32_t)P.parts == part) {
-            const uint32_t k = atomicAdd(&w_n[0], 1u);
-            w_ids[k] = id;
-            w_fills[k] = P.rfill[id];
+    // candidates of this workgroup: ids congruent to `part` mod `parts`; WINDOW of them per scan
+    const uint32_t ncand = nreg > part ? (nreg - part + (uint32_t)P.parts - 1) / (uint32_t)P.parts : 0;
+    for (uint32_t base = 0; base < ncand; base += WINDOW) {
+        const uint32_t j = base + threadIdx.x;
+        if (threadIdx.x < WINDOW && j < ncand) {
+            const uint32_t id = part + j * (uint32_t)P.parts;
+            if (P.rslab[id] == slab) {
+                const uint32_t k = atomicAdd(&w_n[0], 1u);
+                w_ids[k] = id;
+                w_fills[k] = P.rfill[id];
+            }
         }
         __syncthreads();
         const uint32_t count = w_n[0];
@@ -913,6 +951,7 @@ void vxh_launch_part_scatter(const PartArgs &args, bool fast_f64, int scatter_bl
     if (fast_f64 && R == 4 && args.A.ndim >= 1 && args.A.ndim <= 3 && args.nvals <= 2 && args.nmasks <= 1 && !(args.no_pipeline & 1)) {
 #define VXH_SCN(ND)                                                                                                    \
     do {                                                                                                               \
+        scatter_lds = ((size_t)16 << args.slab_log2) + 64; /* the direct kernel only keeps 4 words per slab in LDS */ \
         if (args.nvals == 0) VXH_SC((part_scatter_f64<ND, 0, 4>));                                                     \
         else if (args.nvals == 1) VXH_SC((part_scatter_f64<ND, 1, 4>));                                                \
         else VXH_SC((part_scatter_f64<ND, 2, 4>));                                                                     \
