@@ -736,15 +736,21 @@ __global__ void __launch_bounds__(512) part_scatter_f64(const PartArgs P) {
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             uint32_t idx = 0;
+            if (P.no_pipeline & 8) { // timing experiment: no index arithmetic
 #pragma unroll
-            for (int d = 0; d < NDIM; ++d) {
-                const BinnerDesc &b = P.A.b[d];
-                idx += scalar_sub_index32(cur.b[d][r], b.vmin, b.scale, b.binsd, (uint32_t)b.bins) * (uint32_t)b.stride;
+                for (int d = 0; d < NDIM; ++d) idx += (uint32_t)__double_as_longlong(cur.b[d][r]) & 0xffffu;
+            } else {
+#pragma unroll
+                for (int d = 0; d < NDIM; ++d) {
+                    const BinnerDesc &b = P.A.b[d];
+                    idx += scalar_sub_index32(cur.b[d][r], b.vmin, b.scale, b.binsd, (uint32_t)b.bins) * (uint32_t)b.stride;
+                }
             }
             slab[r] = idx & (S - 1);
             loc[r] = idx >> P.slab_log2;
             pos[r] = 0;
-            if ((keep >> r) & 1u) pos[r] = __hip_atomic_fetch_add(&s_cnt[slab[r]], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (P.no_pipeline & 4) pos[r] = (threadIdx.x * R + r) & 63u; // timing experiment: no LDS atomics
+            else if ((keep >> r) & 1u) pos[r] = __hip_atomic_fetch_add(&s_cnt[slab[r]], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         __syncthreads();
         // [C] lanes < S: publish where bucket s goes, advance the cursor, re-zero the counter
@@ -852,17 +858,16 @@ __global__ void __launch_bounds__(1024) part_reduce(const PartArgs P) {
     __syncthreads();
     uint32_t nreg = *P.pool_next;
     if (nreg > P.max_regions) nreg = P.max_regions;
-    // candidates of this workgroup: ids congruent to `part` mod `parts`; WINDOW of them per scan
-    const uint32_t ncand = nreg > part ? (nreg - part + (uint32_t)P.parts - 1) / (uint32_t)P.parts : 0;
-    for (uint32_t base = 0; base < ncand; base += WINDOW) {
-        const uint32_t j = base + threadIdx.x;
-        if (threadIdx.x < WINDOW && j < ncand) {
-            const uint32_t id = part + j * (uint32_t)P.parts;
-            if (P.rslab[id] == slab) {
-                const uint32_t k = atomicAdd(&w_n[0], 1u);
-                w_ids[k] = id;
-                w_fills[k] = P.rfill[id];
-            }
+    // this workgroup's candidates: a contiguous range of region ids (ids are handed out in time order, every
+    // slab shows up uniformly in any range; a modular split would alias with the S-id groups the lanes of one
+    // pass-1 wave allocate together); WINDOW of them per scan
+    const uint32_t lo = (uint32_t)((uint64_t)nreg * part / (uint32_t)P.parts), hi = (uint32_t)((uint64_t)nreg * (part + 1) / (uint32_t)P.parts);
+    for (uint32_t base = lo; base < hi; base += WINDOW) {
+        const uint32_t id = base + threadIdx.x;
+        if (threadIdx.x < WINDOW && id < hi && P.rslab[id] == slab) {
+            const uint32_t k = atomicAdd(&w_n[0], 1u);
+            w_ids[k] = id;
+            w_fills[k] = P.rfill[id];
         }
         __syncthreads();
         const uint32_t count = w_n[0];
