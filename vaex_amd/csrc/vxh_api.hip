@@ -365,7 +365,6 @@ static size_t padded(size_t b) { return (b + 255) & ~(size_t)255; }
 static const double kIngestBytesPerSec = 6.0e12;
 static const double kHbmAtomicsPerSec = 22.0e9;
 static const size_t kLdsMax = 160 * 1024;
-static const size_t kPartWindowBytes = (2 * 1024 + 4) * 4; // part_reduce's region window in LDS
 
 static LaunchPlan make_plan(const BinArgs &A, BinArgs &out, uint64_t n, double bytes_per_row, bool exclusive) {
     Context &c = ctx();
@@ -396,7 +395,7 @@ static LaunchPlan make_plan(const BinArgs &A, BinArgs &out, uint64_t n, double b
     // partition strategy: any power-of-two number of slabs up to 256 (its cost does not grow with S)
     // fewest slabs that fit one CU's LDS: part_reduce is register-limited to one 1024-thread workgroup per CU
     // anyway, and fewer, longer-lived workgroups pay the LDS init + flush less often (profiles/r01_tune2*)
-    const size_t part_budget = (c.cfg_part_lds > 0 ? (size_t)c.cfg_part_lds : 150 * 1024) - kPartWindowBytes;
+    const size_t part_budget = c.cfg_part_lds > 0 ? (size_t)c.cfg_part_lds : 150 * 1024;
     int part_log2 = 0;
     while (part_log2 < 8 && ((A.cells + (1ull << part_log2) - 1) >> part_log2) * per_cell > part_budget) part_log2++;
     const uint64_t part_slab_cells = (A.cells + (1ull << part_log2) - 1) >> part_log2;
@@ -441,9 +440,9 @@ static LaunchPlan make_plan(const BinArgs &A, BinArgs &out, uint64_t n, double b
             out.a[k].lds_offset = (uint32_t)lds;
             lds += (part_slab_cells * vxh_lds_cell_size(A.a[k].kind, A.a[k].cell) + 15) & ~(size_t)15;
         }
-        p.lds_bytes = lds + kPartWindowBytes;
-        int per_cu = (int)std::max<size_t>(1, std::min<size_t>(2, kLdsMax / std::max<size_t>(p.lds_bytes, 1)));
-        p.block = 1024; // a region is 2 records per lane of a 1024-thread workgroup
+        p.lds_bytes = lds;
+        int per_cu = (int)std::max<size_t>(1, std::min<size_t>(2, kLdsMax / std::max<size_t>(lds, 1)));
+        p.block = c.cfg_block > 0 ? (int)c.cfg_block : 1024;
         per_cu = std::max(1, std::min(per_cu, 2048 / p.block));
         int parts = std::max(1, (int)((uint64_t)c.cus * per_cu / S));
         if (c.cfg_parts > 0) parts = (int)c.cfg_parts;
@@ -532,34 +531,18 @@ static void run_part_chunk(Slot &slot, const BinArgs &planned, const LaunchPlan 
     // the records store post-byte-swap values: pass 2 must not swap again
     for (int k = 0; k < planned.nagg; k++) P.A.a[k].flip = 0;
 
-    // pass-1 tile: 512 threads x R rows (R <= 4: a tile must fit one region), staged in LDS
-    const int region_log2 = 11; // G = 2048 records = 2 per lane of a 1024-thread pass-2 workgroup
-    const uint64_t G = 1ull << region_log2;
-    int R = c.cfg_part_rows > 0 ? (int)std::min<int64_t>(4, c.cfg_part_rows) : 4;
-    size_t scatter_lds = 0;
-    for (;; R >>= 1) {
-        const size_t T = 512 * (size_t)R;
-        scatter_lds = (size_t)S * 20 + 16 + T * (8 * (size_t)P.nvals + 4 + 2 + 1) + 64;
-        if (scatter_lds <= 78 * 1024 || R == 1) break;
-    }
-    if (R < 2) R = 2;
-    P.rows_per_thread = R;
-    P.no_pipeline = (int32_t)c.cfg_no_pipeline; // bit 0: generic kernel; bit 1 (timing experiments only): skip the queue writes
-    P.region_log2 = region_log2;
-    const uint64_t tiles = (planned.n + 512ull * R - 1) / (512ull * R);
-    const int scatter_blocks = (int)std::max<uint64_t>(1, std::min<uint64_t>(tiles, (uint64_t)c.cus * 3));
-    // pool: every record of the chunk + a current and a spare region per (workgroup, slab)
+    // queue capacity per slab: twice the expected share (interleaved slabs are balanced for any smooth
+    // distribution); whatever does not fit takes the HBM-atomic slow path inside part_scatter
     const uint64_t C = chunk_rows_max;
-    const uint64_t max_regions = (C + G - 1) / G + (uint64_t)scatter_blocks * S * 2 + 64;
-    P.max_regions = (uint32_t)max_regions;
+    P.cap = (S == 1 ? C : std::min<uint64_t>(C, 2 * (C / S) + 65536) + 7) & ~(uint64_t)7;
     const size_t idx_bytes = P.idx16 ? 2 : 4;
     size_t off = 0;
     auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
-    const size_t o_next = carve(256), o_rslab = carve(max_regions * 2), o_rfill = carve(max_regions * 4);
-    const size_t o_idx = carve(max_regions * G * idx_bytes);
-    const size_t o_flags = P.use_flags ? carve(max_regions * G) : 0;
+    const size_t o_count = carve((size_t)S * 8), o_limit = carve((size_t)S * 8);
+    const size_t o_idx = carve((size_t)S * P.cap * idx_bytes);
+    const size_t o_flags = P.use_flags ? carve((size_t)S * P.cap) : 0;
     size_t o_val[VXH_PART_MAX_VALS] = {0, 0, 0, 0};
-    for (int k = 0; k < P.nvals; k++) o_val[k] = carve(max_regions * G * 8);
+    for (int k = 0; k < P.nvals; k++) o_val[k] = carve((size_t)S * P.cap * 8);
     Slot::PartBuf &pb = slot.part[slot.part_next & 1];
     slot.part_next++;
     // the previous user of this buffer (pass 2 of chunk i-2, on stream2) must be done before pass 1 refills it
@@ -575,14 +558,27 @@ static void run_part_chunk(Slot &slot, const BinArgs &planned, const LaunchPlan 
         pb.cap = off;
     }
     char *sc = (char *)pb.scratch;
-    P.pool_next = (unsigned int *)(sc + o_next);
-    P.rslab = (uint16_t *)(sc + o_rslab);
-    P.rfill = (uint32_t *)(sc + o_rfill);
+    P.qcount = (unsigned long long *)(sc + o_count);
+    P.qlimit = (unsigned long long *)(sc + o_limit);
     P.qidx = sc + o_idx;
     P.qflags = P.use_flags ? (uint8_t *)(sc + o_flags) : nullptr;
     for (int k = 0; k < P.nvals; k++) P.qval[k] = (uint64_t *)(sc + o_val[k]);
-    HIP_CHECK(hipMemsetAsync(P.pool_next, 0, 256, slot.stream));
-    HIP_CHECK(hipMemsetAsync(P.rslab, 0xff, max_regions * 2, slot.stream));
+    HIP_CHECK(hipMemsetAsync(P.qcount, 0, (size_t)S * 8, slot.stream));
+    HIP_CHECK(hipMemsetAsync(P.qlimit, 0xff, (size_t)S * 8, slot.stream));
+
+    // pass-1 tile: 512 threads x R rows, staged in LDS
+    int R = c.cfg_part_rows > 0 ? (int)c.cfg_part_rows : 4;
+    size_t scatter_lds = 0;
+    for (;; R >>= 1) {
+        const size_t T = 512 * (size_t)R;
+        scatter_lds = (size_t)S * 4 + ((size_t)S + 4) * 4 + (size_t)S * 8 + T * (8 * (size_t)P.nvals + 4 + 2 + 1) + 64;
+        if (scatter_lds <= 78 * 1024 || R == 2) break;
+    }
+    P.rows_per_thread = R;
+    P.no_pipeline = (int32_t)c.cfg_no_pipeline; // bit 0: generic kernel; bit 1 (timing experiments only): skip the queue writes
+    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(4, kLdsMax / scatter_lds));
+    const uint64_t tiles = (planned.n + 512ull * R - 1) / (512ull * R);
+    const int scatter_blocks = (int)std::max<uint64_t>(1, std::min<uint64_t>(tiles, (uint64_t)c.cus * per_cu));
     vxh_launch_part_scatter(P, plan.fast_f64, scatter_blocks, scatter_lds, slot.stream);
     HIP_CHECK(hipGetLastError());
     if (c.cfg_part_overlap) {
@@ -953,7 +949,7 @@ int vxh_grid_bin(vxh_grid *grid, int thread, vxh_agg *const *aggs, int n_aggs, u
         {
             BinArgs tmp;
             LaunchPlan whole = make_plan(A, tmp, length, bytes_per_row, exclusive);
-            if (whole.strategy == VXH_STRAT_PART) step = (uint64_t)std::min<int64_t>(1ll << 30, std::max<int64_t>(1 << 20, ctx().cfg_part_chunk)); // pool offsets are 32-bit
+            if (whole.strategy == VXH_STRAT_PART) step = (uint64_t)std::max<int64_t>(1 << 20, ctx().cfg_part_chunk);
         }
         for (uint64_t r0 = 0; r0 < length; r0 += step) {
             const uint64_t rn = std::min(step, length - r0);

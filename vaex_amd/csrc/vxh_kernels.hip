@@ -476,106 +476,90 @@ __device__ __forceinline__ void records_apply(const PartArgs &P, char *lds, cons
     }
 }
 
-// pass 1: rows -> records in per-(workgroup, slab) regions.  512 threads, R rows per thread per tile.
+// pass 1: rows -> per-slab record queues.  512 threads, R rows per thread per tile.
 //
 // Per tile: [B] gather the tile's rows, compute cell -> (slab, local index), count the tile's records per slab
-// with returning LDS atomics (the return value is the record's position inside its bucket) | barrier |
-// [C] S lanes: exclusive prefix of the bucket counts; publish where bucket s goes (current region, fill, and
-// the spare region if the bucket crosses the end); advance the cursor, closing the region / requesting a new
-// spare when it fills up — that atomic's result is not needed before the NEXT region switch | barrier |
-// [D] every lane writes its records to the LDS staging area sorted by slab; bucket counters re-zeroed |
-// barrier | [E] copy the staging area out, consecutive lanes -> consecutive record slots (coalesced).
-// Three barriers per tile, no HBM round trip on the tile's critical path.
+// with returning LDS atomics (the return value is the record's position inside its bucket) | sync |
+// [C] S lanes: exclusive prefix of the bucket counts and ONE HBM atomic per slab reserving queue space — issued,
+// not yet consumed | sync | [D] every lane writes its records to the LDS staging area sorted by slab; the
+// reservation results are parked in LDS; bucket counters re-zeroed for the next tile | sync | [E] copy the
+// staging area out to the queues, consecutive lanes -> consecutive queue slots (coalesced).  Three barriers per
+// tile; nothing a later phase of the NEXT tile writes is still being read (see the hazard notes in DESIGN.md).
 struct ScatterLds {
-    uint32_t *s_cnt;    // [S]   records of this tile per slab
-    uint32_t *s_off;    // [S+1] exclusive prefix of s_cnt
-    uint32_t *s_cur;    // [S]   region receiving bucket s
-    uint32_t *s_fill;   // [S]   records already in it
-    uint32_t *s_spare;  // [S]   region receiving the part of bucket s beyond the end of s_cur (valid only then)
-    uint64_t *st_val;   // [nvals][T]
-    uint32_t *st_idx;   // [T]
-    uint16_t *st_slab;  // [T]
-    uint8_t *st_flags;  // [T]
+    uint32_t *s_cnt;              // [S]   records of this tile per slab
+    uint32_t *s_off;              // [S+1] exclusive prefix of s_cnt
+    unsigned long long *s_gbase;  // [S]   queue position reserved for the tile's records of slab s (or OVERFLOW)
+    uint64_t *st_val;             // [nvals][T]
+    uint32_t *st_idx;             // [T]
+    uint16_t *st_slab;            // [T]
+    uint8_t *st_flags;            // [T]
 };
 __device__ __forceinline__ ScatterLds scatter_carve(char *lds, uint32_t S, uint32_t T, int nvals) {
     ScatterLds L;
     L.s_cnt = (uint32_t *)lds;
     L.s_off = L.s_cnt + S;
-    L.s_cur = L.s_off + S + 2;
-    L.s_fill = L.s_cur + S;
-    L.s_spare = L.s_fill + S;
-    L.st_val = (uint64_t *)(((uintptr_t)(L.s_spare + S) + 7) & ~(uintptr_t)7);
+    L.s_gbase = (unsigned long long *)(L.s_off + S + 4);
+    L.st_val = (uint64_t *)(L.s_gbase + S);
     L.st_idx = (uint32_t *)(L.st_val + (size_t)nvals * T);
     L.st_slab = (uint16_t *)(L.st_idx + T);
     L.st_flags = (uint8_t *)(L.st_slab + T);
     return L;
 }
 
-struct RegionCursor {
-    uint32_t cur, fill, spare;
-};
+constexpr unsigned long long VXH_Q_OVERFLOW = ~0ull;
 
-__device__ __forceinline__ uint32_t region_alloc(const PartArgs &P) {
-    const uint32_t id = atomicAdd(P.pool_next, 1u);
-    return id < P.max_regions ? id : P.max_regions - 1; // the pool is sized so that this never clamps
-}
-
-__device__ __forceinline__ void cursor_init(const PartArgs &P, uint32_t S, RegionCursor &c) {
-    c.cur = c.spare = c.fill = 0;
+// [C]: prefix + reservation issue (lanes < S)
+__device__ __forceinline__ void scatter_reserve(const PartArgs &P, const ScatterLds &L, uint32_t S, unsigned long long &my_gb, uint32_t &my_cnt) {
+    my_gb = 0;
+    my_cnt = 0;
     if (threadIdx.x < S) {
-        c.cur = region_alloc(P);
-        c.spare = region_alloc(P);
-    }
-}
-
-// [C] (lanes < S)
-__device__ __forceinline__ void scatter_place(const PartArgs &P, const ScatterLds &L, uint32_t S, RegionCursor &c) {
-    if (threadIdx.x < S) {
-        const uint32_t s0 = threadIdx.x, G = 1u << P.region_log2;
+        const uint32_t s0 = threadIdx.x;
         uint32_t off = 0;
         for (uint32_t j = 0; j < s0; ++j) off += L.s_cnt[j];
         L.s_off[s0] = off;
-        const uint32_t cnt = L.s_cnt[s0];
-        if (s0 == S - 1) L.s_off[S] = off + cnt;
-        L.s_cur[s0] = c.cur;
-        L.s_fill[s0] = c.fill;
-        const uint32_t nf = c.fill + cnt;
-        if (nf >= G) { // the bucket reaches the end of the region: close it, continue in the spare, order a new spare
-            L.s_spare[s0] = c.spare;
-            P.rslab[c.cur] = (uint16_t)s0;
-            P.rfill[c.cur] = G;
-            c.cur = c.spare;
-            c.fill = nf - G;
-            c.spare = region_alloc(P);
-        } else {
-            c.fill = nf;
+        my_cnt = L.s_cnt[s0];
+        if (s0 == S - 1) L.s_off[S] = off + my_cnt;
+        if (my_cnt) my_gb = atomicAdd(&P.qcount[s0], (unsigned long long)my_cnt);
+    }
+}
+
+// [D] tail: consume the reservation, re-zero the bucket counter (lanes < S)
+__device__ __forceinline__ void scatter_commit(const PartArgs &P, const ScatterLds &L, uint32_t S, unsigned long long my_gb, uint32_t my_cnt) {
+    if (threadIdx.x < S) {
+        if (my_cnt && my_gb + my_cnt > P.cap) { // does not fit: remember where the valid prefix of the queue ends
+            atomicMin(&P.qlimit[threadIdx.x], my_gb);
+            my_gb = VXH_Q_OVERFLOW;
         }
+        L.s_gbase[threadIdx.x] = my_gb;
+        L.s_cnt[threadIdx.x] = 0;
     }
 }
 
-// end of kernel (lanes < S): close the partially filled current region
-__device__ __forceinline__ void cursor_close(const PartArgs &P, uint32_t S, const RegionCursor &c) {
-    if (threadIdx.x < S && c.fill) {
-        P.rslab[c.cur] = (uint16_t)threadIdx.x;
-        P.rfill[c.cur] = c.fill;
-    }
-}
-
-// [E]: staging -> regions
+// [E]: staging -> queues
 __device__ __forceinline__ void scatter_copy_out(const PartArgs &P, const ScatterLds &L, uint32_t S, uint32_t T) {
-    const uint32_t total = L.s_off[S], G = 1u << P.region_log2;
+    const uint32_t total = L.s_off[S];
     for (uint32_t j = threadIdx.x; j < total; j += 512) {
         const uint32_t s = L.st_slab[j];
-        uint32_t q = L.s_fill[s] + (j - L.s_off[s]);
-        uint32_t id = L.s_cur[s];
-        if (q >= G) { q -= G; id = L.s_spare[s]; }
-        const uint64_t dst = ((uint64_t)id << P.region_log2) + q;
-        if (P.idx16) ((uint16_t *)P.qidx)[dst] = (uint16_t)L.st_idx[j];
-        else ((uint32_t *)P.qidx)[dst] = L.st_idx[j];
-        if (P.use_flags) P.qflags[dst] = L.st_flags[j];
+        const unsigned long long gb = L.s_gbase[s];
+        if (gb != VXH_Q_OVERFLOW) {
+            const uint64_t dst = (uint64_t)s * P.cap + gb + (j - L.s_off[s]);
+            if (P.idx16) ((uint16_t *)P.qidx)[dst] = (uint16_t)L.st_idx[j];
+            else ((uint32_t *)P.qidx)[dst] = L.st_idx[j];
+            if (P.use_flags) P.qflags[dst] = L.st_flags[j];
 #pragma unroll
-        for (int k = 0; k < VXH_PART_MAX_VALS; ++k)
-            if (k < P.nvals) P.qval[k][dst] = L.st_val[(size_t)k * T + j];
+            for (int k = 0; k < VXH_PART_MAX_VALS; ++k)
+                if (k < P.nvals) P.qval[k][dst] = L.st_val[(size_t)k * T + j];
+        } else {
+            // queue full (pathologically skewed data): scatter this record straight to HBM with atomics — into a
+            // replica of its own when pass 2 (which may be running concurrently for the previous chunk) flushes
+            // the others with plain read-modify-write
+            uint64_t gidx[1] = {((uint64_t)L.st_idx[j] << P.slab_log2) + s};
+            uint32_t f1[1] = {(uint32_t)L.st_flags[j]};
+            uint64_t v1[VXH_PART_MAX_VALS][1];
+#pragma unroll
+            for (int k = 0; k < VXH_PART_MAX_VALS; ++k) v1[k][0] = k < P.nvals ? L.st_val[(size_t)k * T + j] : 0;
+            records_apply<__HIP_MEMORY_SCOPE_AGENT, false, 1>(P, nullptr, gidx, f1, v1, 1u, P.A.flush_plain ? (uint64_t)P.parts : 0);
+        }
     }
 }
 
@@ -587,10 +571,7 @@ __global__ void __launch_bounds__(512) part_scatter(const PartArgs P) {
     const uint32_t T = 512u * R;
     const ScatterLds L = scatter_carve(lds, S, T, P.nvals);
     const uint64_t n = P.A.n;
-    if ((uint64_t)blockIdx.x * T >= n) return;
     if (threadIdx.x < S) L.s_cnt[threadIdx.x] = 0;
-    RegionCursor cursor;
-    cursor_init(P, S, cursor);
     __syncthreads();
 
     for (uint64_t tile = blockIdx.x; tile * T < n; tile += gridDim.x) {
@@ -634,7 +615,9 @@ __global__ void __launch_bounds__(512) part_scatter(const PartArgs P) {
             if ((keep >> r) & 1u) pos[r] = __hip_atomic_fetch_add(&L.s_cnt[slab[r]], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         __syncthreads();
-        scatter_place(P, L, S, cursor);
+        unsigned long long my_gb;
+        uint32_t my_cnt;
+        scatter_reserve(P, L, S, my_gb, my_cnt);
         __syncthreads();
 #pragma unroll
         for (int r = 0; r < R; ++r) {
@@ -648,44 +631,25 @@ __global__ void __launch_bounds__(512) part_scatter(const PartArgs P) {
                     if (k < P.nvals) L.st_val[(size_t)k * T + j] = val[k][r];
             }
         }
-        if (threadIdx.x < S) L.s_cnt[threadIdx.x] = 0;
+        scatter_commit(P, L, S, my_gb, my_cnt);
         __syncthreads();
         scatter_copy_out(P, L, S, T);
     }
-    cursor_close(P, S, cursor);
 }
 
-// BinnerScalar sub-index in 32-bit integer arithmetic (grids < 2^32 cells) with two fp64 compares instead of
-// three: for scaled >= 0 the reference's  `scaled >= 1 ? bins+2 : (int)(scaled*bins)+2`  equals
-// min((int)(scaled*bins), bins) + 2 — when scaled < 1 the product never exceeds bins, when scaled >= 1 it is
-// >= bins (the conversion saturates) — so the overflow compare becomes an integer min.  NaN -> 0, negative -> 1.
-__device__ __forceinline__ uint32_t scalar_sub_index32(double v, double vmin, double scale, double binsd, uint32_t bins) {
-    const double scaled = (v - vmin) * scale;
-    const int t = (int)(scaled * binsd);
-    const uint32_t inside = (uint32_t)(t < (int)bins ? t : (int)bins) + 2u;
-    return scaled >= 0 ? inside : (scaled < 0 ? 1u : 0u);
-}
-
-// fast pass 1 for the common case — NDIM (1..3) scalar float64 native unmasked binners, NVAL (0..2) float64
-// native aggregator inputs, at most one aggregator mask.  Two differences from the generic kernel:
-//  * no LDS staging: after [C] every lane knows the slot of each of its records (current/spare region of the
-//    slab, fill + position from the returning LDS atomic) and stores them straight to the pool; the ~2 KB
-//    window a tile writes per slab is completed within the tile, so the partial lines merge in the XCD's L2;
-//  * software pipelining: the raw columns of tile t+1 are requested before the stores of tile t are issued.
-// Two barriers per tile.
+// software-pipelined version for the common case — NDIM (1..3) scalar float64 native unmasked binners, float64
+// native aggregator inputs, at most one aggregator mask: the raw columns of tile t+1 are requested right after
+// barrier 2 of tile t and land while phases D and E of tile t run.
 template <int NDIM, int NVAL, int R>
 __global__ void __launch_bounds__(512) part_scatter_f64(const PartArgs P) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const uint32_t S = 1u << P.slab_log2;
     const uint32_t T = 512u * R;
-    const uint32_t G = 1u << P.region_log2;
-    uint32_t *s_cnt = (uint32_t *)lds, *s_cur = s_cnt + S, *s_fill = s_cur + S, *s_spare = s_fill + S;
+    const ScatterLds L = scatter_carve(lds, S, T, P.nvals);
     const uint64_t n = P.A.n;
     uint64_t tile = blockIdx.x;
     if (tile * T >= n) return;
-    if (threadIdx.x < S) s_cnt[threadIdx.x] = 0;
-    RegionCursor cursor;
-    cursor_init(P, S, cursor);
+    if (threadIdx.x < S) L.s_cnt[threadIdx.x] = 0;
     __syncthreads();
 
     struct Raw {
@@ -718,7 +682,7 @@ __global__ void __launch_bounds__(512) part_scatter_f64(const PartArgs P) {
     Raw cur;
     request(tile, cur);
     for (;;) {
-        // [B] cell -> (slab, local); position of the record inside the tile's bucket of that slab
+        // [B]
         uint32_t keep = cur.valid;
         uint32_t fl[R];
 #pragma unroll
@@ -735,147 +699,112 @@ __global__ void __launch_bounds__(512) part_scatter_f64(const PartArgs P) {
         uint32_t slab[R], loc[R], pos[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            uint32_t idx = 0;
-            if (P.no_pipeline & 8) { // timing experiment: no index arithmetic
+            uint64_t idx = 0;
 #pragma unroll
-                for (int d = 0; d < NDIM; ++d) idx += (uint32_t)__double_as_longlong(cur.b[d][r]) & 0xffffu;
-            } else {
-#pragma unroll
-                for (int d = 0; d < NDIM; ++d) {
-                    const BinnerDesc &b = P.A.b[d];
-                    idx += scalar_sub_index32(cur.b[d][r], b.vmin, b.scale, b.binsd, (uint32_t)b.bins) * (uint32_t)b.stride;
-                }
+            for (int d = 0; d < NDIM; ++d) {
+                const BinnerDesc &b = P.A.b[d];
+                idx += scalar_sub_index(cur.b[d][r], false, b.vmin, b.scale, b.binsd, b.bins) * b.stride;
             }
-            slab[r] = idx & (S - 1);
-            loc[r] = idx >> P.slab_log2;
+            slab[r] = (uint32_t)idx & (S - 1);
+            loc[r] = (uint32_t)(idx >> P.slab_log2);
             pos[r] = 0;
-            if (P.no_pipeline & 4) pos[r] = (threadIdx.x * R + r) & 63u; // timing experiment: no LDS atomics
-            else if ((keep >> r) & 1u) pos[r] = __hip_atomic_fetch_add(&s_cnt[slab[r]], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if ((keep >> r) & 1u) pos[r] = __hip_atomic_fetch_add(&L.s_cnt[slab[r]], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         __syncthreads();
-        // [C] lanes < S: publish where bucket s goes, advance the cursor, re-zero the counter
-        if (threadIdx.x < S) {
-            const uint32_t s0 = threadIdx.x;
-            const uint32_t cnt = s_cnt[s0];
-            s_cnt[s0] = 0;
-            s_cur[s0] = cursor.cur;
-            s_fill[s0] = cursor.fill;
-            const uint32_t nf = cursor.fill + cnt;
-            if (nf >= G) {
-                s_spare[s0] = cursor.spare;
-                P.rslab[cursor.cur] = (uint16_t)s0;
-                P.rfill[cursor.cur] = G;
-                cursor.cur = cursor.spare;
-                cursor.fill = nf - G;
-                cursor.spare = region_alloc(P);
-            } else {
-                cursor.fill = nf;
-            }
-        }
+        // [C]
+        unsigned long long my_gb;
+        uint32_t my_cnt;
+        scatter_reserve(P, L, S, my_gb, my_cnt);
         __syncthreads();
-        // request the next tile's columns (the last tile re-requests itself: static number of loads in flight)
+        // request the next tile's columns; they are not touched before the next [B]
         const uint64_t next = tile + gridDim.x;
         const bool has_next = next * T < n;
         Raw nxt;
-        request(has_next ? next : tile, nxt);
-        // [D] store the records
-        if (!(P.no_pipeline & 2)) {
+        if (has_next) request(next, nxt);
+        // [D]
 #pragma unroll
-            for (int r = 0; r < R; ++r) {
-                if ((keep >> r) & 1u) {
-                    uint32_t q = s_fill[slab[r]] + pos[r];
-                    uint32_t id = s_cur[slab[r]];
-                    if (q >= G) { q -= G; id = s_spare[slab[r]]; }
-                    const uint32_t dst = (id << P.region_log2) + q; // max_regions * G < 2^32 (checked by the host)
-                    if (P.idx16) ((uint16_t *)P.qidx)[dst] = (uint16_t)loc[r];
-                    else ((uint32_t *)P.qidx)[dst] = loc[r];
-                    if (P.use_flags) P.qflags[dst] = (uint8_t)fl[r];
+        for (int r = 0; r < R; ++r) {
+            if ((keep >> r) & 1u) {
+                const uint32_t j = L.s_off[slab[r]] + pos[r];
+                L.st_idx[j] = loc[r];
+                L.st_slab[j] = (uint16_t)slab[r];
+                L.st_flags[j] = (uint8_t)fl[r];
 #pragma unroll
-                    for (int k = 0; k < NVAL; ++k) P.qval[k][dst] = cur.v[k][r];
-                }
+                for (int k = 0; k < NVAL; ++k) L.st_val[(size_t)k * T + j] = cur.v[k][r];
             }
         }
+        scatter_commit(P, L, S, my_gb, my_cnt);
+        __syncthreads();
+        // [E]
+        if (!(P.no_pipeline & 2)) scatter_copy_out(P, L, S, T);
         if (!has_next) break;
         cur = nxt;
         tile = next;
     }
-    cursor_close(P, S, cursor);
 }
 
-// pass 2: regions of one slab -> LDS-private slab -> HBM replica.  Region headers are scanned in windows; the
-// selected regions are streamed with 2 consecutive records per lane per region and NB regions per trip.
-template <int NB>
-__device__ __forceinline__ void reduce_regions(const PartArgs &P, char *lds, const uint32_t *ids, const uint32_t *fills, uint32_t first, uint32_t count) {
-    // this lane's records: 2*threadIdx.x, 2*threadIdx.x+1 of each of up to NB regions (G = 2 * blockDim.x)
-    constexpr int N = 2 * NB;
+// pass 2: slab queues -> LDS-private slab -> HBM replica.  Each lane streams 4 consecutive records per
+// vector load and keeps N4 such batches in flight.
+template <int N4>
+__device__ __forceinline__ void reduce_trip(const PartArgs &P, char *lds, uint64_t at, uint64_t step) {
+    constexpr int N = 4 * N4;
     uint32_t loc[N], flags[N];
     uint64_t vals[VXH_PART_MAX_VALS][N];
-    uint32_t valid = 0;
 #pragma unroll
-    for (int b = 0; b < NB; ++b) {
-        const bool have = first + b < count;
-        const uint32_t id = have ? ids[first + b] : ids[first];
-        const uint32_t fill = have ? fills[first + b] : 0;
-        const uint64_t q = ((uint64_t)id << P.region_log2) + 2u * threadIdx.x;
-        if (2u * threadIdx.x < fill) valid |= 1u << (2 * b);
-        if (2u * threadIdx.x + 1 < fill) valid |= 2u << (2 * b);
+    for (int b = 0; b < N4; ++b) {
+        const uint64_t q = at + (uint64_t)b * step;
         if (P.idx16) {
-            const ushort2 x = *(const ushort2 *)((const uint16_t *)P.qidx + q);
-            loc[2 * b] = x.x; loc[2 * b + 1] = x.y;
+            const ushort4 x = *(const ushort4 *)((const uint16_t *)P.qidx + q);
+            loc[4 * b] = x.x; loc[4 * b + 1] = x.y; loc[4 * b + 2] = x.z; loc[4 * b + 3] = x.w;
         } else {
-            const uint2 x = *(const uint2 *)((const uint32_t *)P.qidx + q);
-            loc[2 * b] = x.x; loc[2 * b + 1] = x.y;
+            const uint4 x = *(const uint4 *)((const uint32_t *)P.qidx + q);
+            loc[4 * b] = x.x; loc[4 * b + 1] = x.y; loc[4 * b + 2] = x.z; loc[4 * b + 3] = x.w;
         }
         if (P.use_flags) {
-            const uchar2 f = *(const uchar2 *)(P.qflags + q);
-            flags[2 * b] = f.x; flags[2 * b + 1] = f.y;
+            const uchar4 f = *(const uchar4 *)(P.qflags + q);
+            flags[4 * b] = f.x; flags[4 * b + 1] = f.y; flags[4 * b + 2] = f.z; flags[4 * b + 3] = f.w;
         } else {
-            flags[2 * b] = flags[2 * b + 1] = 0xffu;
+            flags[4 * b] = flags[4 * b + 1] = flags[4 * b + 2] = flags[4 * b + 3] = 0xffu;
         }
 #pragma unroll
         for (int k = 0; k < VXH_PART_MAX_VALS; ++k) {
             if (k < P.nvals) {
-                const ulonglong2 a = *(const ulonglong2 *)(P.qval[k] + q);
-                vals[k][2 * b] = a.x; vals[k][2 * b + 1] = a.y;
+                const ulonglong2 a = *(const ulonglong2 *)(P.qval[k] + q), c = *(const ulonglong2 *)(P.qval[k] + q + 2);
+                vals[k][4 * b] = a.x; vals[k][4 * b + 1] = a.y; vals[k][4 * b + 2] = c.x; vals[k][4 * b + 3] = c.y;
             }
         }
     }
-    records_apply<__HIP_MEMORY_SCOPE_WORKGROUP, true, N>(P, lds, loc, flags, vals, valid);
+    records_apply<__HIP_MEMORY_SCOPE_WORKGROUP, true, N>(P, lds, loc, flags, vals, (1u << N) - 1u);
 }
 
 __global__ void __launch_bounds__(1024) part_reduce(const PartArgs P) {
-    extern __shared__ __attribute__((aligned(16))) char lds_all[];
-    constexpr uint32_t WINDOW = 1024;
-    uint32_t *w_ids = (uint32_t *)lds_all;      // [WINDOW] regions of this workgroup found in the current window
-    uint32_t *w_fills = w_ids + WINDOW;          // [WINDOW]
-    uint32_t *w_n = w_fills + WINDOW;            // [4]
-    char *lds = lds_all + (2 * WINDOW + 4) * 4;  // slab grids (a.lds_offset is relative to here)
+    extern __shared__ __attribute__((aligned(16))) char lds[];
     const uint32_t S = 1u << P.slab_log2;
     const uint32_t slab = blockIdx.x % S, part = blockIdx.x / S;
     const uint64_t slab_cells = (P.A.cells + S - 1) >> P.slab_log2;
     lds_init(P.A, lds, slab_cells);
-    if (threadIdx.x == 0) w_n[0] = 0;
     __syncthreads();
-    uint32_t nreg = *P.pool_next;
-    if (nreg > P.max_regions) nreg = P.max_regions;
-    // this workgroup's candidates: a contiguous range of region ids (ids are handed out in time order, every
-    // slab shows up uniformly in any range; a modular split would alias with the S-id groups the lanes of one
-    // pass-1 wave allocate together); WINDOW of them per scan
-    const uint32_t lo = (uint32_t)((uint64_t)nreg * part / (uint32_t)P.parts), hi = (uint32_t)((uint64_t)nreg * (part + 1) / (uint32_t)P.parts);
-    for (uint32_t base = lo; base < hi; base += WINDOW) {
-        const uint32_t id = base + threadIdx.x;
-        if (threadIdx.x < WINDOW && id < hi && P.rslab[id] == slab) {
-            const uint32_t k = atomicAdd(&w_n[0], 1u);
-            w_ids[k] = id;
-            w_fills[k] = P.rfill[id];
-        }
-        __syncthreads();
-        const uint32_t count = w_n[0];
-        for (uint32_t r = 0; r < count; r += 4) reduce_regions<4>(P, lds, w_ids, w_fills, r, count);
-        __syncthreads();
-        if (threadIdx.x == 0) w_n[0] = 0;
-        __syncthreads();
+    unsigned long long len = P.qcount[slab];
+    const unsigned long long lim = P.qlimit[slab];
+    if (lim < len) len = lim;
+    // this workgroup's share, cut at multiples of 4 records so the vector loads stay aligned
+    const uint64_t quads = (len + 3) / 4;
+    const uint64_t lo = quads * part / P.parts * 4, hi = std::min<uint64_t>(len, quads * (part + 1) / P.parts * 4);
+    const uint64_t qb = (uint64_t)slab * P.cap;
+    const uint64_t hi4 = lo + ((hi - lo) & ~(uint64_t)3);
+    const uint64_t step = 4ull * blockDim.x;
+    uint64_t j = lo + 4ull * threadIdx.x;
+    for (; j + step < hi4; j += 2 * step) reduce_trip<2>(P, lds, qb + j, step);
+    for (; j < hi4; j += step) reduce_trip<1>(P, lds, qb + j, step);
+    for (uint64_t t = hi4 + threadIdx.x; t < hi; t += blockDim.x) { // tail (< 4 records)
+        uint32_t loc[1] = {P.idx16 ? (uint32_t)((const uint16_t *)P.qidx)[qb + t] : ((const uint32_t *)P.qidx)[qb + t]};
+        uint32_t fl[1] = {P.use_flags ? (uint32_t)P.qflags[qb + t] : 0xffu};
+        uint64_t v1[VXH_PART_MAX_VALS][1];
+#pragma unroll
+        for (int k = 0; k < VXH_PART_MAX_VALS; ++k) v1[k][0] = k < P.nvals ? P.qval[k][qb + t] : 0;
+        records_apply<__HIP_MEMORY_SCOPE_WORKGROUP, true, 1>(P, lds, loc, fl, v1, 1u);
     }
+    __syncthreads();
     const uint64_t replica = P.A.flush_plain ? part : part % (uint32_t)P.A.replicas;
     lds_flush(P.A, lds, slab_cells, P.slab_log2, slab, replica, P.A.flush_plain != 0);
 }
@@ -956,7 +885,6 @@ void vxh_launch_part_scatter(const PartArgs &args, bool fast_f64, int scatter_bl
     if (fast_f64 && R == 4 && args.A.ndim >= 1 && args.A.ndim <= 3 && args.nvals <= 2 && args.nmasks <= 1 && !(args.no_pipeline & 1)) {
 #define VXH_SCN(ND)                                                                                                    \
     do {                                                                                                               \
-        scatter_lds = ((size_t)16 << args.slab_log2) + 64; /* the direct kernel only keeps 4 words per slab in LDS */ \
         if (args.nvals == 0) VXH_SC((part_scatter_f64<ND, 0, 4>));                                                     \
         else if (args.nvals == 1) VXH_SC((part_scatter_f64<ND, 1, 4>));                                                \
         else VXH_SC((part_scatter_f64<ND, 2, 4>));                                                                     \

@@ -66,14 +66,11 @@ enum vxh_strategy : int {
 #define VXH_PART_MAX_VALS 4
 #define VXH_PART_MAX_MASKS 8
 
-// Partition strategy (grids too large for one workgroup's LDS).  Pass 1 (part_scatter*) reads the rows once,
+// Partition strategy (grids too large for one workgroup's LDS).  Pass 1 (part_scatter) reads the rows once,
 // computes the flat cell index, and appends a compact record {local index, [mask flags], aggregator inputs}
-// to a REGION owned by (workgroup, slab), slab = cell & (S-1), local = cell >> log2 S.  Regions are
-// fixed-size (G records) pieces of one pool handed out by a device counter; every workgroup keeps a current
-// and a pre-allocated spare region per slab, so the allocation atomic is never waited for on the per-tile path.
-// A region header {slab, fill} is written when the region is closed.  Pass 2 (part_reduce) gives every slab
-// to `parts` workgroups; each scans the headers, and aggregates the regions of its slab with id % parts ==
-// part into an LDS-private copy of the slab, then flushes it.
+// to the queue of the slab that owns the cell (slab = cell & (S-1), local = cell >> log2 S), bucketing each
+// tile in LDS so the queue writes are coalesced.  Pass 2 (part_reduce) gives every slab to `parts`
+// workgroups that aggregate their share of the queue into an LDS-private copy of the slab and flush it.
 struct PartArgs {
     BinArgs A;
     int32_t slab_log2;
@@ -84,21 +81,19 @@ struct PartArgs {
     int32_t idx16;      // local index stored as uint16
     int32_t parts;      // pass-2 workgroups per slab
     int32_t rows_per_thread;
-    int32_t no_pipeline; // bit 0: use the non-pipelined pass-1 kernel; bit 1 (timing experiments): skip the queue writes
-    int32_t region_log2; // G = 1 << region_log2 records per region (G >= rows per pass-1 tile)
-    uint32_t max_regions;
-    uint32_t reserved2_;
+    int32_t no_pipeline; // debugging knob: use the non-pipelined pass-1 kernel
+    int32_t reserved2_;
+    uint64_t cap;       // queue capacity per slab (records)
     const void *vdata[VXH_PART_MAX_VALS];
     const uint8_t *mdata[VXH_PART_MAX_MASKS];
     uint8_t vdtype[VXH_PART_MAX_VALS], vflip[VXH_PART_MAX_VALS];
     uint8_t agg_vslot[VXH_MAX_AGG]; // 0xff: no input column
     uint8_t agg_mbit[VXH_MAX_AGG];  // 0xff: no mask
-    unsigned int *pool_next;        // regions handed out so far
-    uint16_t *rslab;                // [max_regions] slab of a closed region (0xffff: never closed)
-    uint32_t *rfill;                // [max_regions] records in it
-    void *qidx;                     // [max_regions][G] uint16 / uint32
-    uint8_t *qflags;                // [max_regions][G]
-    uint64_t *qval[VXH_PART_MAX_VALS]; // [max_regions][G]
+    unsigned long long *qcount;     // [S] records reserved
+    unsigned long long *qlimit;     // [S] first reservation that did not fit (or ~0)
+    void *qidx;                     // [S][cap] uint16 / uint32
+    uint8_t *qflags;                // [S][cap]
+    uint64_t *qval[VXH_PART_MAX_VALS]; // [S][cap]
 };
 
 struct LaunchPlan {
