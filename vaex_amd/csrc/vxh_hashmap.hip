@@ -40,8 +40,10 @@ __device__ __forceinline__ long long load_key(const void *p, uint64_t i, int dt)
     }
 }
 
-// side words: [0] count  [1] null seen  [2] INT64_MIN key seen  [3] ordinal of INT64_MIN key
-__global__ void __launch_bounds__(256) hm_insert(const void *data, int dt, const uint8_t *mask, uint64_t n, long long *keys, long long *vals, uint64_t hmask, unsigned long long *side) {
+// side words: [0] count  [1] null seen  [2] INT64_MIN key seen  [3] ordinal of INT64_MIN key  [4] table got too full
+// Optimistic: rows are inserted until the table holds max_count keys; a row that would need a NEW slot beyond that
+// raises side[4] and is skipped — the host then grows the table and re-runs the same (idempotent) call.
+__global__ void __launch_bounds__(256) hm_insert(const void *data, int dt, const uint8_t *mask, uint64_t n, long long *keys, long long *vals, uint64_t hmask, unsigned long long *side, unsigned long long max_count) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (; i < n; i += stride) {
@@ -59,6 +61,11 @@ __global__ void __launch_bounds__(256) hm_insert(const void *data, int dt, const
             long long cur = keys[p]; // may be a stale EMPTY (L1); the CAS below then returns the true owner
             if (cur == key) break;
             if (cur == EMPTY) {
+                // agent-scope load: a plain load could be served from this CU's L1 forever (never refreshed by other CUs' atomics)
+                if (__hip_atomic_load(&side[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= max_count) {
+                    if (side[4] == 0) atomicExch(&side[4], 1ull);
+                    break;
+                }
                 long long old = (long long)atomicCAS((unsigned long long *)&keys[p], (unsigned long long)EMPTY, (unsigned long long)key);
                 if (old == EMPTY) {
                     vals[p] = (long long)atomicAdd(&side[0], 1ull);
@@ -152,8 +159,8 @@ struct vxh_hashmap {
     uint64_t cap = 0;
     long long *keys = nullptr;
     long long *vals = nullptr;
-    unsigned long long *side = nullptr; // 4 words on the device
-    unsigned long long host_side[4] = {0, 0, 0, 0};
+    unsigned long long *side = nullptr; // 8 words on the device
+    unsigned long long host_side[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     std::mutex mutex;
 };
 
@@ -165,7 +172,7 @@ static void hm_alloc_table(uint64_t cap, long long **keys, long long **vals, hip
 }
 
 static void hm_refresh(vxh_hashmap *m, hipStream_t st) {
-    HIP_CHECK(hipMemcpyAsync(m->host_side, m->side, 32, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipMemcpyAsync(m->host_side, m->side, 64, hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
 }
 
@@ -218,8 +225,8 @@ int vxh_hashmap_create(int dtype, uint64_t capacity_hint, vxh_hashmap **out) {
     while (cap < capacity_hint * 2) cap <<= 1;
     m->cap = cap;
     hm_alloc_table(cap, &m->keys, &m->vals, s.stream);
-    HIP_CHECK(hipMalloc(&m->side, 32));
-    HIP_CHECK(hipMemsetAsync(m->side, 0, 32, s.stream));
+    HIP_CHECK(hipMalloc(&m->side, 64));
+    HIP_CHECK(hipMemsetAsync(m->side, 0, 64, s.stream));
     HIP_CHECK(hipStreamSynchronize(s.stream));
     *out = m;
     HM_END
@@ -252,17 +259,16 @@ int vxh_hashmap_update(vxh_hashmap *m, const void *keys, const uint8_t *mask, ui
             dmask = (const uint8_t *)tmp_m;
         }
     }
-    uint64_t done = 0;
-    while (done < n) {
-        // the table can take cap*3/4 - count more distinct keys before its load passes 3/4
-        uint64_t count = m->host_side[0];
-        if (count * 4 > m->cap) hm_grow(m, m->cap * 4, s.stream);
-        uint64_t room = m->cap / 4 * 3 - count;
-        uint64_t batch = std::min<uint64_t>(n - done, room);
-        hipLaunchKernelGGL(hm_insert, dim3(grid_for(batch)), dim3(256), 0, s.stream, (const char *)dkeys + done * es, m->dtype, dmask ? dmask + done : nullptr, batch, m->keys, m->vals, m->cap - 1, m->side);
+    // whole array per launch; at most half full before, 3/4 full after; on overflow grow 4x and repeat (idempotent)
+    for (int attempt = 0; n && attempt < 40; ++attempt) {
+        if (m->host_side[0] * 2 > m->cap) hm_grow(m, m->cap * 4, s.stream);
+        const unsigned long long max_count = m->cap / 4 * 3;
+        HIP_CHECK(hipMemsetAsync(m->side + 4, 0, 8, s.stream));
+        hipLaunchKernelGGL(hm_insert, dim3(grid_for(n)), dim3(256), 0, s.stream, dkeys, m->dtype, dmask, n, m->keys, m->vals, m->cap - 1, m->side, max_count);
         HIP_CHECK(hipGetLastError());
         hm_refresh(m, s.stream);
-        done += batch;
+        if (!m->host_side[4]) break;
+        hm_grow(m, m->cap * 4, s.stream);
     }
     if (tmp_k) (void)hipFree(tmp_k);
     if (tmp_m) (void)hipFree(tmp_m);

@@ -518,14 +518,34 @@ constexpr unsigned long long VXH_Q_OVERFLOW = ~0ull;
 __device__ __forceinline__ void scatter_reserve(const PartArgs &P, const ScatterLds &L, uint32_t S, unsigned long long &my_gb, uint32_t &my_cnt) {
     my_gb = 0;
     my_cnt = 0;
+    // exclusive prefix of the S (<= 256) bucket counts by wave 0: up to 4 consecutive buckets per lane, then a
+    // shuffle scan over the lanes (a serial loop per bucket costs S dependent LDS reads on the last lane)
+    if (threadIdx.x < 64) {
+        const uint32_t lane = threadIdx.x, per = (S + 63) >> 6;
+        uint32_t e[4], sum = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < 4; ++j) {
+            const uint32_t b = lane * per + j;
+            e[j] = sum;
+            if (j < per && b < S) sum += L.s_cnt[b];
+        }
+        uint32_t inc = sum;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t t = (uint32_t)__shfl_up((int)inc, off, 64);
+            if ((int)lane >= off) inc += t;
+        }
+        const uint32_t base = inc - sum;
+#pragma unroll
+        for (uint32_t j = 0; j < 4; ++j) {
+            const uint32_t b = lane * per + j;
+            if (j < per && b < S) L.s_off[b] = base + e[j];
+        }
+        if (lane == 63) L.s_off[S] = inc;
+    }
     if (threadIdx.x < S) {
-        const uint32_t s0 = threadIdx.x;
-        uint32_t off = 0;
-        for (uint32_t j = 0; j < s0; ++j) off += L.s_cnt[j];
-        L.s_off[s0] = off;
-        my_cnt = L.s_cnt[s0];
-        if (s0 == S - 1) L.s_off[S] = off + my_cnt;
-        if (my_cnt) my_gb = atomicAdd(&P.qcount[s0], (unsigned long long)my_cnt);
+        my_cnt = L.s_cnt[threadIdx.x];
+        if (my_cnt) my_gb = atomicAdd(&P.qcount[threadIdx.x], (unsigned long long)my_cnt);
     }
 }
 
