@@ -179,6 +179,10 @@ int vxh_hashmap_keys(vxh_hashmap *map, int64_t *keys_out);
  * mask, rows whose mask byte is 1); {+inf, -inf} when empty.  Any dtype, computed in double. */
 int vxh_minmax(int dtype, int flip_endian, const void *data, const uint8_t *mask, uint64_t n, int mem, double *out2);
 
+/* exact int64 {min, max} of an integer column ({INT64_MAX, INT64_MIN} when empty): the range test of the
+ * groupby "simplify to BinnerInteger" rule, vaex/groupby.py:263-272 */
+int vxh_minmax_int(int dtype, int flip_endian, const void *data, const uint8_t *mask, uint64_t n, int mem, int64_t *out2);
+
 /* ---- profiling helpers ---------------------------------------------------------------- */
 /* HIP events on slot `thread`'s stream: record start/stop around vxh_grid_bin calls, read ms */
 int vxh_timer_start(int thread);

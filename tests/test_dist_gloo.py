@@ -32,12 +32,12 @@ def _worker(rank, world, port, q):
     try:
         rng = np.random.default_rng(3)
         n = 50_000
-        cols = dict(x=rng.normal(0, 1, n), y=rng.normal(0, 1, n), v=rng.normal(3, 2, n), k=rng.integers(0, 40, n))
+        cols = dict(x=rng.normal(0, 1, n), y=rng.normal(0, 1, n), v=rng.normal(3, 2, n), k=np.sort(rng.integers(0, 40, n)))  # sorted: ranks see different key ranges
         i1, i2 = vdist.shard_rows(n, rank, world)
         local = Frame({k: c[i1:i2] for k, c in cols.items()}, chunk_size=4096, nthreads=1, superagg=RefAdapter(oracle.ref_module("superagg")))  # 1 grid: the reference's own (grids, ...) buffer has a wrong grid stride for >1-d grids (agg_base.hpp:115)
         descs = [agg.count(), agg.mean("v"), agg.std("v"), agg.min("v"), agg.max("v")]
         res = local._agg(descs, binby=["x", "y"], limits=[[-4, 4], [-4, 4]], shape=32, reduce=vdist.allreduce_aggs)
-        g = local.groupby("k", {"s": agg.sum("v"), "c": agg.count()}, reduce=vdist.allreduce_aggs)
+        g = local.groupby("k", {"s": agg.sum("v"), "c": agg.count()}, reduce=vdist.allreduce_aggs, comm=vdist.Comm())
         q.put((rank, [np.asarray(r) for r in res], {k: np.asarray(v) for k, v in g.items()}))
     finally:
         dist.destroy_process_group()
@@ -59,7 +59,7 @@ def test_two_rank_allreduce_matches_single_process(ref):
         assert p.exitcode == 0
     rng = np.random.default_rng(3)
     n = 50_000
-    cols = dict(x=rng.normal(0, 1, n), y=rng.normal(0, 1, n), v=rng.normal(3, 2, n), k=rng.integers(0, 40, n))
+    cols = dict(x=rng.normal(0, 1, n), y=rng.normal(0, 1, n), v=rng.normal(3, 2, n), k=np.sort(rng.integers(0, 40, n)))
     whole = Frame(cols, chunk_size=4096, nthreads=2, superagg=RefAdapter(ref))
     want = whole._agg([agg.count(), agg.mean("v"), agg.std("v"), agg.min("v"), agg.max("v")], binby=["x", "y"], limits=[[-4, 4], [-4, 4]], shape=32)
     wantg = whole.groupby("k", {"s": agg.sum("v"), "c": agg.count()})

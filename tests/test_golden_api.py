@@ -37,6 +37,11 @@ class RefAdapter:
     def minmax(data, mask=None, dtype=0, flip=False):
         return oracle.minmax(data, mask)
 
+    @staticmethod
+    def minmax_int(data, mask=None, dtype=2, flip=False):
+        d = np.asarray(data)
+        return int(d.min()), int(d.max())
+
     class ordered_set_int64:
         def __init__(self, hint=0):
             self._keys = np.array([], dtype=np.int64)
@@ -124,3 +129,15 @@ def test_golden_api_frame_on_hip(sa, gpu_ready, device):
         cols = {k: (v if k in keep_host else torch.from_numpy(np.ascontiguousarray(v)).cuda()) for k, v in cols.items()}
     got = replay(lambda c: Frame(c, chunk_size=1000, nthreads=3), cols)
     compare(got, want)
+    # the same groupbys forced through the GPU hash map (ordered_set + BinnerHash)
+    from vaex_amd.binned import agg
+    df = Frame(cols, chunk_size=1000, nthreads=3)
+    df.direct_groupby_cells = 0
+    spec = {"c": agg.count(), "s": agg.sum("v"), "m": agg.mean("v"), "sd": agg.std("v"), "mn": agg.min("v"), "mx": agg.max("v")}
+    forced = {}
+    for name, key in (("dense", "k"), ("sparse", "ks")):
+        g = df.groupby(key, spec)
+        forced[f"groupby_{name}_keys"] = g[key]
+        for col in spec:
+            forced[f"groupby_{name}_{col}"] = g[col]
+    compare(forced, want)

@@ -141,6 +141,7 @@ class Frame:
             raise ValueError("columns differ in length")
         self.n = n.pop() if n else 0
         self._f64_cache = {}
+        self.direct_groupby_cells = 1 << 21  # widest key range binned without a hash map (fits the partition strategy)
 
     def __len__(self):
         return self.n
@@ -335,13 +336,14 @@ class Frame:
         return self._one("max", expression, binby, limits, shape, selection, edges)
 
     # ------------------------------------------------------------------ groupby
-    def groupby(self, by, agg_spec, reduce=None):
+    def groupby(self, by, agg_spec, reduce=None, comm=None):
         """df.groupby(by).agg({...}) for ONE integer key column.  Returns {by: keys (ascending), name: values}.
 
-        Pass 1 = distinct keys (ordered_set, vaex/hash.py:152-171); if they are dense
-        (range <= 4/3 * n_unique) the key column bins itself through BinnerOrdinal(min_value) — the
-        reference's simplification to BinnerInteger (vaex/groupby.py:263-272) — otherwise the keys are
-        mapped through the GPU hash map inside the binner (BinnerHash: one pass, no ordinal column)."""
+        The reference first collects the distinct keys (ordered_set, vaex/hash.py:152-171) and, when they are
+        dense (range <= 4/3 * n_unique), simplifies to BinnerInteger (vaex/groupby.py:263-272).  Here the range
+        is measured first (one streaming min/max pass): a range of up to `direct_groupby_cells` cells bins
+        directly through BinnerOrdinal(min_value) in a single pass; wider ranges go through the GPU hash map
+        inside the binner (BinnerHash).  reduce / comm: multi-GPU hooks (vaex_amd.dist)."""
         sa = self.sa
         key = self.columns[by]
         if np.ma.isMaskedArray(key):
@@ -349,6 +351,28 @@ class Frame:
         pf = _class_postfix(key)
         if pf.startswith("float") or pf.endswith("_non_native"):
             raise NotImplementedError("groupby on float / non-native keys")
+        descs, names = [], []
+        for name, d in agg_spec.items():
+            names.append(name)
+            descs.append(d)
+        if self.n == 0 and comm is None:
+            return {by: np.array([], dtype=np.int64), **{n: np.array([]) for n in names}}
+        # key range: one exact integer min/max pass (vxh_minmax_int); ranks agree on the global range
+        kmin, kmax = sa.minmax_int(key if _is_device(key) else np.ascontiguousarray(key), None, _DT_CODE[pf], False) if self.n else (2**63 - 1, -2**63)
+        if comm is not None:
+            kmin, kmax = comm.minmax(kmin, kmax)
+        count = kmax - kmin + 1
+        if 0 < count <= self.direct_groupby_cells:
+            # the key column bins itself (BinnerOrdinal with min_value): ONE pass, no hash map.  This is the
+            # reference's dense-key simplification; for sparse keys in a small range it gives the same result
+            # (empty cells are dropped below) without pass 1.
+            res = self._agg(descs + [agg.count()], binby=[dict(column=by, count=count, min_value=kmin)], edges=True, reduce=reduce)
+            present = res[-1][:count] > 0
+            out_keys = (np.arange(count, dtype=np.int64) + kmin)[present]
+            vals = [r[:count][present] for r in res[:-1]]
+            return {by: out_keys, **dict(zip(names, vals))}
+        # pass 1: distinct keys on the GPU (ordered_set.update), united over ranks, sorted -> sealed map whose
+        # ordinals are the rank of the key in ascending order (ordered_set::create): identical on every rank
         hm = getattr(sa, "ordered_set_" + pf)()
         if _is_device(key):
             hm.update(key)
@@ -356,30 +380,17 @@ class Frame:
             for i1 in range(0, self.n, 1 << 24):
                 hm.update(np.ascontiguousarray(key[i1:i1 + (1 << 24)]))
         keys = np.array(hm.key_array())
-        if pf.startswith("uint"):
-            keys = keys.astype(np.uint64)
-        nuniq = len(keys)
-        descs, names = [], []
-        for name, d in agg_spec.items():
-            names.append(name)
-            descs.append(d)
+        if comm is not None:
+            keys = comm.union_keys(keys)
+        out_keys = np.sort(keys)
+        nuniq = len(out_keys)
         if nuniq == 0:
-            return {by: keys, **{n: np.array([]) for n in names}}
-        kmin, kmax = int(keys.min()), int(keys.max())
-        if kmax - kmin + 1 <= 4 * nuniq // 3 + 1:
-            count = kmax - kmin + 1
-            res = self._agg(descs + [agg.count()], binby=[dict(column=by, count=count, min_value=kmin)], edges=True, reduce=reduce)
-            present = res[-1][:count] > 0
-            out_keys = (np.arange(count, dtype=np.int64) + kmin)[present]
-            vals = [r[:count][present] for r in res[:-1]]
-        else:
-            # sealed map with deterministic ordinals = rank of the key in ascending order (ordered_set::create)
-            out_keys = np.sort(keys)
-            sealed = getattr(sa, "ordered_set_" + pf)(len(out_keys))
-            sealed.set_keys(out_keys.astype(np.int64))
-            res = self._agg_hash(descs, by, pf, sealed, reduce)
-            vals = [r[1:1 + nuniq] for r in res]
-        return {by: out_keys.astype(keys.dtype), **dict(zip(names, vals))}
+            return {by: out_keys, **{n: np.array([]) for n in names}}
+        sealed = getattr(sa, "ordered_set_" + pf)(nuniq)
+        sealed.set_keys(out_keys.astype(np.int64))
+        res = self._agg_hash(descs, by, pf, sealed, reduce)
+        vals = [r[1:1 + nuniq] for r in res]
+        return {by: out_keys, **dict(zip(names, vals))}
 
     def _agg_hash(self, descs, by, pf, hm, reduce):
         """Same fused pass with a BinnerHash on the key column (cells: [unknown, ordinal 0..N-1, null])."""

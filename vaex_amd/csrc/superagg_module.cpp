@@ -432,6 +432,18 @@ PYBIND11_MODULE(superagg, m) {
         return py::make_tuple(out[0], out[1]);
     }, py::arg("data"), py::arg("mask") = py::none(), py::arg("dtype") = 0, py::arg("flip") = false);
 
+    m.def("minmax_int", [](const py::object &ar, const py::object &mask, int dtype, bool flip) {
+        ArrayRef a = resolve_array(ar);
+        if (a.itemsize != kTypeSizes[dtype]) throw std::runtime_error("Itemsize of data and dtype are not equal");
+        const uint8_t *mp = nullptr;
+        if (!mask.is_none()) { ArrayRef mk = resolve_array(mask); mp = (const uint8_t *)mk.ptr; }
+        int64_t out[2];
+        int rc;
+        { py::gil_scoped_release r; rc = vxh_minmax_int(dtype, flip, a.ptr, mp, a.n, a.mem, out); }
+        check(rc);
+        return py::make_tuple(out[0], out[1]);
+    }, py::arg("data"), py::arg("mask") = py::none(), py::arg("dtype") = 2, py::arg("flip") = false);
+
     py::class_<PyAgg> aggregator(m, "Aggregator", py::buffer_protocol());
     aggregator.def("merge", &PyAgg::merge)
         .def("get_result", &PyAgg::get_result)

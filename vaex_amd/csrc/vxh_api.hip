@@ -1171,6 +1171,38 @@ int vxh_minmax(int dtype, int flip_endian, const void *data, const uint8_t *mask
     VXH_API_END
 }
 
+int vxh_minmax_int(int dtype, int flip_endian, const void *data, const uint8_t *mask, uint64_t n, int mem, int64_t *out2) {
+    VXH_API_BEGIN
+    check_dtype(dtype);
+    if (dtype == VXH_F64 || dtype == VXH_F32) throw std::runtime_error("vxh_minmax_int: integer dtypes only");
+    ensure_device_ready();
+    Slot &slot = get_slot(0);
+    long long init[2] = {INT64_MAX, INT64_MIN};
+    long long *dev_out = nullptr;
+    HIP_CHECK(hipMalloc(&dev_out, 16));
+    HIP_CHECK(hipMemcpy(dev_out, init, 16, hipMemcpyHostToDevice));
+    const void *d = data;
+    const uint8_t *m = mask;
+    void *tmp_d = nullptr, *tmp_m = nullptr;
+    if (mem == VXH_MEM_HOST && n) {
+        HIP_CHECK(hipMalloc(&tmp_d, n * kDtypeSize[dtype]));
+        HIP_CHECK(hipMemcpy(tmp_d, data, n * kDtypeSize[dtype], hipMemcpyHostToDevice));
+        d = tmp_d;
+        if (mask) {
+            HIP_CHECK(hipMalloc(&tmp_m, n));
+            HIP_CHECK(hipMemcpy(tmp_m, mask, n, hipMemcpyHostToDevice));
+            m = (const uint8_t *)tmp_m;
+        }
+    }
+    if (n) vxh_launch_minmax_int(dtype, flip_endian ? 1 : 0, d, m, n, dev_out, slot.stream);
+    HIP_CHECK(hipStreamSynchronize(slot.stream));
+    HIP_CHECK(hipMemcpy(out2, dev_out, 16, hipMemcpyDeviceToHost));
+    (void)hipFree(dev_out);
+    if (tmp_d) (void)hipFree(tmp_d);
+    if (tmp_m) (void)hipFree(tmp_m);
+    VXH_API_END
+}
+
 int vxh_timer_start(int thread) {
     VXH_API_BEGIN
     ensure_device_ready();

@@ -221,7 +221,7 @@ int vxh_hashmap_create(int dtype, uint64_t capacity_hint, vxh_hashmap **out) {
     Slot &s = get_slot(0);
     vxh_hashmap *m = new vxh_hashmap();
     m->dtype = dtype;
-    uint64_t cap = 1ull << 20;
+    uint64_t cap = 1ull << 22; // 64 MiB of keys + ordinals: up to ~3 M distinct keys before the first growth
     while (cap < capacity_hint * 2) cap <<= 1;
     m->cap = cap;
     hm_alloc_table(cap, &m->keys, &m->vals, s.stream);

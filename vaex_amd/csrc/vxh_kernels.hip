@@ -865,6 +865,36 @@ __global__ void fold_kernel(T *grid, uint64_t cells, int replicas, T identity) {
 // ------------------------------------------------------------------------------------------
 // K5: min/max of one column (legacy statisticNd OP_MIN_MAX, 0-d grid): plain < / > so NaN never wins
 // ------------------------------------------------------------------------------------------
+// exact integer variant (group-key ranges: int64 keys do not survive a trip through double)
+__global__ void __launch_bounds__(256) minmax_int_kernel(int dtype, int flip, const void *data, const uint8_t *mask, uint64_t n, long long *out2) {
+    long long mn = 0x7fffffffffffffffll, mx = (long long)0x8000000000000000ull;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i0 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < n; i0 += 4 * stride) {
+        const Rows<4> rows = make_rows<4>(i0, stride, n);
+        uint32_t valid = rows.valid;
+        if (mask != nullptr) valid &= load_mask_bits<4>(mask, rows);
+        uint64_t c[4];
+        load_canon<4>(data, rows, dtype, flip, c);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if ((valid >> u) & 1u) {
+                const long long v = (long long)c[u];
+                mn = v < mn ? v : mn;
+                mx = v > mx ? v : mx;
+            }
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const long long omn = __shfl_down(mn, off, 64), omx = __shfl_down(mx, off, 64);
+        mn = omn < mn ? omn : mn;
+        mx = omx > mx ? omx : mx;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        at_min<__HIP_MEMORY_SCOPE_AGENT, long long>(out2, mn);
+        at_max<__HIP_MEMORY_SCOPE_AGENT, long long>(out2 + 1, mx);
+    }
+}
+
 __global__ void __launch_bounds__(256) minmax_kernel(int dtype, int flip, const void *data, const uint8_t *mask, uint64_t n, double *out2) {
     double mn = as_f64(0x7ff0000000000000ull), mx = as_f64(0xfff0000000000000ull);
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
@@ -979,6 +1009,13 @@ void vxh_launch_fold(void *grid, uint64_t cells, int replicas, int cell, int kin
     default: VXH_FOLD(unsigned) break;
     }
 #undef VXH_FOLD
+}
+
+void vxh_launch_minmax_int(int dtype, int flip, const void *data, const uint8_t *mask, uint64_t n, long long *out2_dev, hipStream_t stream) {
+    uint64_t blocks = (n + 1023) / 1024;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks == 0) blocks = 1;
+    hipLaunchKernelGGL(minmax_int_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, dtype, flip, data, mask, n, out2_dev);
 }
 
 void vxh_launch_minmax(int dtype, int flip, const void *data, const uint8_t *mask, uint64_t n, double *out2_dev, hipStream_t stream) {

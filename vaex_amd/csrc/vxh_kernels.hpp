@@ -113,6 +113,7 @@ void vxh_launch_bin(const BinArgs &args, const LaunchPlan &plan, hipStream_t str
 void vxh_launch_fill(void *dst, uint64_t ncells, int cell, const void *value8, hipStream_t stream);
 // dst[c] = fold(replica_0[c] .. replica_{R-1}[c]); replicas 1.. are reset to the identity
 void vxh_launch_fold(void *grid, uint64_t cells, int replicas, int cell, int kind, const void *identity8, hipStream_t stream);
+void vxh_launch_minmax_int(int dtype, int flip, const void *data, const uint8_t *mask, uint64_t n, long long *out2_dev, hipStream_t stream);
 void vxh_launch_minmax(int dtype, int flip, const void *data, const uint8_t *mask, uint64_t n, double *out2_dev, hipStream_t stream);
 size_t vxh_cell_size(int cell);
 size_t vxh_lds_cell_size(int kind, int cell);

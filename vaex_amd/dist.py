@@ -116,3 +116,36 @@ def shard_rows(n, rank, world):
     per = (n + world - 1) // world
     i1 = min(n, rank * per)
     return i1, min(n, i1 + per)
+
+
+class Comm:
+    """The two small exchanges a multi-rank groupby needs besides the grid all-reduce."""
+
+    def __init__(self, group=None):
+        self.group = group
+
+    def _device(self):
+        import torch.distributed as dist
+        return "cuda" if dist.get_backend(self.group) == "nccl" else "cpu"
+
+    def minmax(self, lo, hi):
+        """global (min, max) of per-rank integer ranges"""
+        import torch
+        import torch.distributed as dist
+        if not dist.is_initialized() or dist.get_world_size(self.group) == 1:
+            return lo, hi
+        t = torch.tensor([lo, -hi], dtype=torch.int64, device=self._device())
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
+        return int(t[0]), -int(t[1])
+
+    def union_keys(self, keys):
+        """sorted union of the ranks' distinct keys (<= 1e6 x 8 B per rank in the BASELINE config)"""
+        import torch.distributed as dist
+        if not dist.is_initialized() or dist.get_world_size(self.group) == 1:
+            return keys
+        parts = [None] * dist.get_world_size(self.group)
+        dist.all_gather_object(parts, np.asarray(keys), group=self.group)
+        return np.unique(np.concatenate(parts))
+
+    def allreduce(self, aggs):
+        allreduce_aggs(aggs, self.group)
