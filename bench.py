@@ -180,6 +180,12 @@ def main():
         value = total_rows * args.steps / elapsed
         k_ms = float(np.mean(kernel_ms))
         achieved = BYTES_PER_ROW * rows / (k_ms * 1e-3) / 1e9
+        # HBM bytes per launch from the PMC counters of the same command (separate rocprofv3 --pmc passes,
+        # FETCH_SIZE corrected x2 on gfx950): measured offline, kept under profiles/
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+        if os.path.exists(tpath) and sa.last_kernel(0).startswith("part_scatter") and shape == 256:
+            traffic = json.load(open(tpath))["hbm_bytes_per_row"] * rows
         out = {
             "metric": "rows/sec, 2-D count+mean on 256x256 grid (count(*), sum(v), count(v) fused), float64 x,y,v",
             "value": value, "unit": "rows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -188,7 +194,7 @@ def main():
             "config": {"workload": f"{rows:.3g}-row float64 x,y,v per GPU: count+sum+mean on {shape}x{shape} grid, HBM-resident (BASELINE configs[1])",
                        "rows_per_gpu": rows, "shape": shape, "kernel": sa.last_kernel(0), "parallelism": f"row-sharded x{world}, RCCL all-reduce of 3 grids"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "kernel_ms": k_ms, "bytes_per_row": BYTES_PER_ROW, "rows_per_launch": rows},
+                         "traffic": traffic, "kernel_ms": k_ms, "bytes_per_row": BYTES_PER_ROW, "rows_per_launch": rows},
         }
         if world == 1 and not args.no_cpu:
             cb, cpu_res, cpu_rows = cpu_baseline(x, y, v, shape, args.cpu_rows)
