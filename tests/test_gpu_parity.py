@@ -263,3 +263,37 @@ def test_full_size_properties(sa):
     assert np.max(np.abs(sg - sx)) <= 1e-12 * float(v.abs().sum()) / 1000
     inside = int(((x >= -4) & (x < 4) & (y >= -4) & (y < 4)).sum())
     assert cg[2:-1, 2:-1].sum() == inside
+
+
+def test_rccl_allreduce_path_single_rank(sa):
+    """The N>1 bench path on one GPU: a 1-rank RCCL group, all-reduce forced.  Exercises exactly what the
+    multi-GPU run does per rank — alias the library-owned device grid through __cuda_array_interface__,
+    dist.all_reduce (sum / min / max) in place, device_touch, get_result — and must leave the results unchanged."""
+    import os
+    import socket
+    import torch
+    import torch.distributed as dist
+    from vaex_amd import dist as vdist
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        case = cases.case_groupby(300_000, groups=500)
+        case["aggs"].append(dict(kind="count"))
+        keep = []
+        before = cases.run_superagg(sa, case, keep=keep, to_device=cases.torch_device_array)
+        aggs = keep[:-1]
+        vdist.allreduce_aggs(aggs, force=True)
+        after = [np.array(a.get_result()) for a in aggs]
+        for b, a in zip(before, after):
+            np.testing.assert_array_equal(a, b)
+        case2 = cases.case_2d_count_mean(2_000_000, shape=256)
+        keep2 = []
+        before2 = cases.run_superagg(sa, case2, keep=keep2, to_device=cases.torch_device_array)
+        vdist.allreduce_aggs(keep2[:-1], force=True)
+        for b, a in zip(before2, keep2[:-1]):
+            np.testing.assert_array_equal(np.array(a.get_result()), b)
+        assert vdist.Comm().minmax(3, 9) == (3, 9)
+    finally:
+        dist.destroy_process_group()

@@ -29,7 +29,7 @@ def _reduce_op(name):
     return {"sum": dist.ReduceOp.SUM, "min": dist.ReduceOp.MIN, "max": dist.ReduceOp.MAX}[name]
 
 
-def allreduce_aggs(aggs, group=None):
+def allreduce_aggs(aggs, group=None, force=False):
     """In-place all-reduce of the grids of `aggs` across the process group.
 
     "nccl" backend (RCCL): the device grids are reduced in place over xGMI.  Any other backend ("gloo" in
@@ -37,7 +37,7 @@ def allreduce_aggs(aggs, group=None):
     aggregators hold the global result (get_result() returns it)."""
     import torch
     import torch.distributed as dist
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not dist.is_initialized() or (dist.get_world_size(group) == 1 and not force):
         return
     if dist.get_backend(group) != "nccl" or not all(hasattr(a, "device_touch") for a in aggs):
         return allreduce_aggs_host(aggs, group)
