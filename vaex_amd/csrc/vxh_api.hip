@@ -52,10 +52,19 @@ Context &ctx() {
     return c;
 }
 
+// hipSetDevice is per host thread: every entry point that allocates or launches binds the calling thread to
+// the library's device first (thread-pool workers of a rank > 0 would otherwise land on device 0)
 static void ensure_device_ready() {
     Context &c = ctx();
     std::lock_guard<std::mutex> lock(c.mutex);
-    if (c.initialised) return;
+    if (c.initialised) {
+        static thread_local int bound = -1;
+        if (bound != c.device) {
+            HIP_CHECK(hipSetDevice(c.device));
+            bound = c.device;
+        }
+        return;
+    }
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
     if (e != hipSuccess || count == 0) {
@@ -274,6 +283,7 @@ static void agg_result_locked(vxh_agg *a, void *out) {
     const uint64_t cells = a->grid->length1d;
     const size_t hs = kDtypeSize[a->host_dtype];
     if (a->auth == AUTH_DEVICE) {
+        ensure_device_ready();
         agg_fold_device(a);
         const size_t cs = vxh_cell_size(a->cell);
         if (cs == hs) {

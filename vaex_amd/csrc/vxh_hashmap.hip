@@ -218,6 +218,7 @@ int vxh_hashmap_create(int dtype, uint64_t capacity_hint, vxh_hashmap **out) {
     if (dtype == VXH_F64 || dtype == VXH_F32 || dtype < 0 || dtype >= VXH_DTYPE_COUNT) throw std::runtime_error("hash map: only integer key dtypes are supported");
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n == 0) { (void)hipGetLastError(); throw std::runtime_error("vaex_hip: no HIP device available (libvaexhip has no CPU fallback)"); }
+    (void)hipSetDevice(ctx().device);
     Slot &s = get_slot(0);
     vxh_hashmap *m = new vxh_hashmap();
     m->dtype = dtype;
@@ -244,6 +245,7 @@ void vxh_hashmap_destroy(vxh_hashmap *m) {
 int vxh_hashmap_update(vxh_hashmap *m, const void *keys, const uint8_t *mask, uint64_t n, int mem) {
     HM_BEGIN
     std::lock_guard<std::mutex> lock(m->mutex);
+    (void)hipSetDevice(ctx().device);
     Slot &s = get_slot(0);
     const size_t es = (size_t)vxh_dtype_size(m->dtype);
     const void *dkeys = keys;
@@ -278,6 +280,7 @@ int vxh_hashmap_update(vxh_hashmap *m, const void *keys, const uint8_t *mask, ui
 int vxh_hashmap_set_keys(vxh_hashmap *m, const int64_t *keys, uint64_t n) {
     HM_BEGIN
     std::lock_guard<std::mutex> lock(m->mutex);
+    (void)hipSetDevice(ctx().device);
     if (m->host_side[0] != 0) throw std::runtime_error("hash map is not empty");
     if (n == 0) return 0;
     Slot &s = get_slot(0);
@@ -311,6 +314,7 @@ int vxh_hashmap_null_index(vxh_hashmap *m, int64_t *index_out) {
 int vxh_hashmap_map_ordinal(vxh_hashmap *m, const void *keys, uint64_t n, int mem, int64_t *out) {
     HM_BEGIN
     std::lock_guard<std::mutex> lock(m->mutex);
+    (void)hipSetDevice(ctx().device);
     if (n == 0) return 0;
     Slot &s = get_slot(0);
     const size_t es = (size_t)vxh_dtype_size(m->dtype);
@@ -338,6 +342,7 @@ int vxh_hashmap_map_ordinal(vxh_hashmap *m, const void *keys, uint64_t n, int me
 int vxh_hashmap_keys(vxh_hashmap *m, int64_t *keys_out) {
     HM_BEGIN
     std::lock_guard<std::mutex> lock(m->mutex);
+    (void)hipSetDevice(ctx().device);
     const uint64_t count = m->host_side[0];
     if (count == 0) return 0;
     Slot &s = get_slot(0);
