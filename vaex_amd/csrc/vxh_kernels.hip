@@ -556,7 +556,8 @@ __device__ __forceinline__ void scatter_commit(const PartArgs &P, const ScatterL
             atomicMin(&P.qlimit[threadIdx.x], my_gb);
             my_gb = VXH_Q_OVERFLOW;
         }
-        L.s_gbase[threadIdx.x] = my_gb;
+        // park "queue slot of staging position j, minus j" so that copy-out is one add per record
+        L.s_gbase[threadIdx.x] = my_gb == VXH_Q_OVERFLOW ? VXH_Q_OVERFLOW : (unsigned long long)threadIdx.x * P.cap + my_gb - L.s_off[threadIdx.x];
         L.s_cnt[threadIdx.x] = 0;
     }
 }
@@ -568,7 +569,7 @@ __device__ __forceinline__ void scatter_copy_out(const PartArgs &P, const Scatte
         const uint32_t s = L.st_slab[j];
         const unsigned long long gb = L.s_gbase[s];
         if (gb != VXH_Q_OVERFLOW) {
-            const uint64_t dst = (uint64_t)s * P.cap + gb + (j - L.s_off[s]);
+            const uint64_t dst = gb + j;
             if (P.idx16) ((uint16_t *)P.qidx)[dst] = (uint16_t)L.st_idx[j];
             else ((uint32_t *)P.qidx)[dst] = L.st_idx[j];
             if (P.use_flags) P.qflags[dst] = L.st_flags[j];
@@ -663,11 +664,22 @@ __global__ void __launch_bounds__(512) part_scatter(const PartArgs P) {
     }
 }
 
+// BinnerScalar sub-index in 32-bit integer arithmetic (grids < 2^31 cells) with two fp64 compares instead of
+// three: for scaled >= 0 the reference's  `scaled >= 1 ? bins+2 : (int)(scaled*bins)+2`  equals
+// min((int)(scaled*bins), bins) + 2 — when scaled < 1 the product never exceeds bins, when scaled >= 1 it is
+// >= bins (the conversion saturates) — so the overflow compare becomes an integer min.  NaN -> 0, negative -> 1.
+__device__ __forceinline__ uint32_t scalar_sub_index32(double v, double vmin, double scale, double binsd, uint32_t bins) {
+    const double scaled = (v - vmin) * scale;
+    const int t = (int)(scaled * binsd);
+    const uint32_t inside = (uint32_t)(t < (int)bins ? t : (int)bins) + 2u;
+    return scaled >= 0 ? inside : (scaled < 0 ? 1u : 0u);
+}
+
 // software-pipelined version for the common case — NDIM (1..3) scalar float64 native unmasked binners, float64
 // native aggregator inputs, at most one aggregator mask: the raw columns of tile t+1 are requested right after
 // barrier 2 of tile t and land while phases D and E of tile t run.
 template <int NDIM, int NVAL, int R>
-__global__ void __launch_bounds__(512) part_scatter_f64(const PartArgs P) {
+__global__ void __launch_bounds__(512) part_scatter_f64(const PartArgs P) { // (512, 6) = 3 workgroups/CU was measured: slower (spill)
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const uint32_t S = 1u << P.slab_log2;
     const uint32_t T = 512u * R;
@@ -725,14 +737,14 @@ __global__ void __launch_bounds__(512) part_scatter_f64(const PartArgs P) {
         uint32_t slab[R], loc[R], pos[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            uint64_t idx = 0;
+            uint32_t idx = 0; // the partition strategy is only planned for grids < 2^31 cells
 #pragma unroll
             for (int d = 0; d < NDIM; ++d) {
                 const BinnerDesc &b = P.A.b[d];
-                idx += scalar_sub_index(cur.b[d][r], false, b.vmin, b.scale, b.binsd, b.bins) * b.stride;
+                idx += scalar_sub_index32(cur.b[d][r], b.vmin, b.scale, b.binsd, (uint32_t)b.bins) * (uint32_t)b.stride;
             }
-            slab[r] = (uint32_t)idx & (S - 1);
-            loc[r] = (uint32_t)(idx >> P.slab_log2);
+            slab[r] = idx & (S - 1);
+            loc[r] = idx >> P.slab_log2;
             pos[r] = 0;
             if ((keep >> r) & 1u) pos[r] = __hip_atomic_fetch_add(&L.s_cnt[slab[r]], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
