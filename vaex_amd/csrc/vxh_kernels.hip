@@ -760,15 +760,17 @@ __global__ void __launch_bounds__(512) part_scatter_f64(const PartArgs P) { // (
         Raw nxt;
         if (has_next) request(next, nxt);
         // [D]
+        if (!(P.no_pipeline & 4)) { // (bit 2: timing experiments only)
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            if ((keep >> r) & 1u) {
-                const uint32_t j = L.s_off[slab[r]] + pos[r];
-                L.st_idx[j] = loc[r];
-                L.st_slab[j] = (uint16_t)slab[r];
-                L.st_flags[j] = (uint8_t)fl[r];
+            for (int r = 0; r < R; ++r) {
+                if ((keep >> r) & 1u) {
+                    const uint32_t j = L.s_off[slab[r]] + pos[r];
+                    L.st_idx[j] = loc[r];
+                    L.st_slab[j] = (uint16_t)slab[r];
+                    L.st_flags[j] = (uint8_t)fl[r];
 #pragma unroll
-                for (int k = 0; k < NVAL; ++k) L.st_val[(size_t)k * T + j] = cur.v[k][r];
+                    for (int k = 0; k < NVAL; ++k) L.st_val[(size_t)k * T + j] = cur.v[k][r];
+                }
             }
         }
         scatter_commit(P, L, S, my_gb, my_cnt);
@@ -837,6 +839,115 @@ __global__ void __launch_bounds__(1024) part_reduce(const PartArgs P) {
     for (uint64_t t = hi4 + threadIdx.x; t < hi; t += blockDim.x) { // tail (< 4 records)
         uint32_t loc[1] = {P.idx16 ? (uint32_t)((const uint16_t *)P.qidx)[qb + t] : ((const uint32_t *)P.qidx)[qb + t]};
         uint32_t fl[1] = {P.use_flags ? (uint32_t)P.qflags[qb + t] : 0xffu};
+        uint64_t v1[VXH_PART_MAX_VALS][1];
+#pragma unroll
+        for (int k = 0; k < VXH_PART_MAX_VALS; ++k) v1[k][0] = k < P.nvals ? P.qval[k][qb + t] : 0;
+        records_apply<__HIP_MEMORY_SCOPE_WORKGROUP, true, 1>(P, lds, loc, fl, v1, 1u);
+    }
+    __syncthreads();
+    const uint64_t replica = P.A.flush_plain ? part : part % (uint32_t)P.A.replicas;
+    lds_flush(P.A, lds, slab_cells, P.slab_log2, slab, replica, P.A.flush_plain != 0);
+}
+
+// pass 2, specialised: NAGG (1..4) aggregators, each count / sum / sum-moment on float64 inputs (or count(*)),
+// no masks in the records, uint16 local indices, at most two value columns.  Same data flow as part_reduce, but
+// the aggregator list is unrolled at compile time with its descriptors held in scalar registers, the NaN test is
+// one ballot per record (unpredicated LDS atomics unless some lane actually holds a NaN), and the LDS byte
+// offsets of a record are computed once for all aggregators.  (The generic kernel spends 366 scalar + 253 vector
+// instructions per 8 records per wave on dispatch and predication — profiles/r01_pmc_part_scatter_reduce_v1.txt.)
+template <int NAGG, int N4>
+__device__ __forceinline__ void reduce_trip_fast(const PartArgs &P, char *lds, uint64_t at, uint64_t step, const uint32_t (&off)[NAGG], const uint32_t (&kind)[NAGG],
+                                                 const uint32_t (&vs)[NAGG], const uint32_t (&mom)[NAGG]) {
+    constexpr int N = 4 * N4;
+    uint32_t loc[N];
+    uint64_t v0[N], v1[N];
+#pragma unroll
+    for (int b = 0; b < N4; ++b) {
+        const uint64_t q = at + (uint64_t)b * step;
+        const ushort4 x = *(const ushort4 *)((const uint16_t *)P.qidx + q);
+        loc[4 * b] = x.x; loc[4 * b + 1] = x.y; loc[4 * b + 2] = x.z; loc[4 * b + 3] = x.w;
+        if (P.nvals > 0) {
+            const ulonglong2 a = *(const ulonglong2 *)(P.qval[0] + q), c = *(const ulonglong2 *)(P.qval[0] + q + 2);
+            v0[4 * b] = a.x; v0[4 * b + 1] = a.y; v0[4 * b + 2] = c.x; v0[4 * b + 3] = c.y;
+        }
+        if (P.nvals > 1) {
+            const ulonglong2 a = *(const ulonglong2 *)(P.qval[1] + q), c = *(const ulonglong2 *)(P.qval[1] + q + 2);
+            v1[4 * b] = a.x; v1[4 * b + 1] = a.y; v1[4 * b + 2] = c.x; v1[4 * b + 3] = c.y;
+        }
+    }
+    // does any lane hold a NaN in value column 0 / 1 of this trip?
+    bool nan0 = false, nan1 = false;
+    if (P.nvals > 0) {
+        bool m = false;
+#pragma unroll
+        for (int u = 0; u < N; ++u) m |= as_f64(v0[u]) != as_f64(v0[u]);
+        nan0 = __ballot(m) != 0ull;
+    }
+    if (P.nvals > 1) {
+        bool m = false;
+#pragma unroll
+        for (int u = 0; u < N; ++u) m |= as_f64(v1[u]) != as_f64(v1[u]);
+        nan1 = __ballot(m) != 0ull;
+    }
+#pragma unroll
+    for (int k = 0; k < NAGG; ++k) {
+        char *base = lds + off[k];
+        const bool second = vs[k] == 1;
+        const bool has = vs[k] != 0xffu;
+        const bool any_nan = has && (second ? nan1 : nan0);
+        if (kind[k] == VXH_AGG_COUNT) {
+            if (!any_nan) {
+#pragma unroll
+                for (int u = 0; u < N; ++u) at_add<__HIP_MEMORY_SCOPE_WORKGROUP, uint32_t>((uint32_t *)base + loc[u], 1u);
+            } else {
+#pragma unroll
+                for (int u = 0; u < N; ++u) {
+                    const double d = as_f64(second ? v1[u] : v0[u]);
+                    if (d == d) at_add<__HIP_MEMORY_SCOPE_WORKGROUP, uint32_t>((uint32_t *)base + loc[u], 1u);
+                }
+            }
+        } else {
+            const bool sq = kind[k] == VXH_AGG_SUM_MOMENT;
+#pragma unroll
+            for (int u = 0; u < N; ++u) {
+                double d = as_f64(second ? v1[u] : v0[u]);
+                if (sq) d = pow_u(d, mom[k]);
+                if (!any_nan || d == d) at_add<__HIP_MEMORY_SCOPE_WORKGROUP, double>((double *)base + loc[u], d);
+            }
+        }
+    }
+}
+
+template <int NAGG>
+__global__ void __launch_bounds__(1024) part_reduce_fast(const PartArgs P) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const uint32_t S = 1u << P.slab_log2;
+    const uint32_t slab = blockIdx.x % S, part = blockIdx.x / S;
+    const uint64_t slab_cells = (P.A.cells + S - 1) >> P.slab_log2;
+    lds_init(P.A, lds, slab_cells);
+    uint32_t off[NAGG], kind[NAGG], vs[NAGG], mom[NAGG];
+#pragma unroll
+    for (int k = 0; k < NAGG; ++k) {
+        off[k] = P.A.a[k].lds_offset;
+        kind[k] = P.A.a[k].kind;
+        vs[k] = P.agg_vslot[k];
+        mom[k] = P.A.a[k].moment;
+    }
+    __syncthreads();
+    unsigned long long len = P.qcount[slab];
+    const unsigned long long lim = P.qlimit[slab];
+    if (lim < len) len = lim;
+    const uint64_t quads = (len + 3) / 4;
+    const uint64_t lo = quads * part / P.parts * 4, hi = std::min<uint64_t>(len, quads * (part + 1) / P.parts * 4);
+    const uint64_t qb = (uint64_t)slab * P.cap;
+    const uint64_t hi4 = lo + ((hi - lo) & ~(uint64_t)3);
+    const uint64_t step = 4ull * blockDim.x;
+    uint64_t j = lo + 4ull * threadIdx.x;
+    for (; j + step < hi4; j += 2 * step) reduce_trip_fast<NAGG, 2>(P, lds, qb + j, step, off, kind, vs, mom);
+    for (; j < hi4; j += step) reduce_trip_fast<NAGG, 1>(P, lds, qb + j, step, off, kind, vs, mom);
+    for (uint64_t t = hi4 + threadIdx.x; t < hi; t += blockDim.x) { // tail (< 4 records): generic path
+        uint32_t loc[1] = {(uint32_t)((const uint16_t *)P.qidx)[qb + t]};
+        uint32_t fl[1] = {0xffu};
         uint64_t v1[VXH_PART_MAX_VALS][1];
 #pragma unroll
         for (int k = 0; k < VXH_PART_MAX_VALS; ++k) v1[k][0] = k < P.nvals ? P.qval[k][qb + t] : 0;
@@ -970,8 +1081,25 @@ void vxh_launch_part_scatter(const PartArgs &args, bool fast_f64, int scatter_bl
 }
 
 void vxh_launch_part_reduce(const PartArgs &args, const LaunchPlan &plan, hipStream_t stream) {
-    if (plan.lds_bytes > 48 * 1024) (void)hipFuncSetAttribute((const void *)part_reduce, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds_bytes);
-    hipLaunchKernelGGL(part_reduce, dim3(plan.blocks), dim3(plan.block), plan.lds_bytes, stream, args);
+    // specialised kernel: count / sum / sum-moment over float64 inputs, no record flags, uint16 indices
+    bool fast = plan.fast_f64 && !args.use_flags && args.idx16 && args.nvals <= 2 && args.A.nagg >= 1 && args.A.nagg <= 4 && !(args.no_pipeline & 16);
+    for (int k = 0; fast && k < args.A.nagg; ++k) {
+        const AggDesc &a = args.A.a[k];
+        if (args.agg_mbit[k] != 0xff) fast = false;
+        if (a.kind == VXH_AGG_COUNT) continue;
+        if ((a.kind != VXH_AGG_SUM && a.kind != VXH_AGG_SUM_MOMENT) || a.cell != VXH_CELL_F64 || args.agg_vslot[k] == 0xff) fast = false;
+    }
+#define VXH_RD(KERNEL)                                                                                                 \
+    do {                                                                                                               \
+        if (plan.lds_bytes > 48 * 1024) (void)hipFuncSetAttribute((const void *)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds_bytes); \
+        hipLaunchKernelGGL(KERNEL, dim3(plan.blocks), dim3(plan.block), plan.lds_bytes, stream, args);                 \
+    } while (0)
+    if (!fast) VXH_RD(part_reduce);
+    else if (args.A.nagg == 1) VXH_RD(part_reduce_fast<1>);
+    else if (args.A.nagg == 2) VXH_RD(part_reduce_fast<2>);
+    else if (args.A.nagg == 3) VXH_RD(part_reduce_fast<3>);
+    else VXH_RD(part_reduce_fast<4>);
+#undef VXH_RD
 }
 
 void vxh_launch_bin(const BinArgs &args, const LaunchPlan &plan, hipStream_t stream) {
