@@ -541,18 +541,20 @@ static void run_part_chunk(Slot &slot, const BinArgs &planned, const LaunchPlan 
     // the records store post-byte-swap values: pass 2 must not swap again
     for (int k = 0; k < planned.nagg; k++) P.A.a[k].flip = 0;
 
-    // queue capacity per slab: twice the expected share (interleaved slabs are balanced for any smooth
-    // distribution); whatever does not fit takes the HBM-atomic slow path inside part_scatter
+    // every slab's queue is split into `parts` sub-queues (own counter each; pass 2's workgroup (slab, part) reads
+    // exactly one).  Capacity per sub-queue: twice the expected share (interleaved slabs and round-robin tiles
+    // balance any smooth distribution); whatever does not fit takes the HBM-atomic slow path inside part_scatter
     const uint64_t C = chunk_rows_max;
-    P.cap = (S == 1 ? C : std::min<uint64_t>(C, 2 * (C / S) + 65536) + 7) & ~(uint64_t)7;
+    const uint64_t nsub = (uint64_t)S * (uint64_t)P.parts;
+    P.cap = (nsub == 1 ? C : std::min<uint64_t>(C, 2 * (C / nsub) + 8192) + 7) & ~(uint64_t)7;
     const size_t idx_bytes = P.idx16 ? 2 : 4;
     size_t off = 0;
     auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
-    const size_t o_count = carve((size_t)S * 8), o_limit = carve((size_t)S * 8);
-    const size_t o_idx = carve((size_t)S * P.cap * idx_bytes);
-    const size_t o_flags = P.use_flags ? carve((size_t)S * P.cap) : 0;
+    const size_t o_count = carve((size_t)nsub * 8), o_limit = carve((size_t)nsub * 8);
+    const size_t o_idx = carve((size_t)nsub * P.cap * idx_bytes);
+    const size_t o_flags = P.use_flags ? carve((size_t)nsub * P.cap) : 0;
     size_t o_val[VXH_PART_MAX_VALS] = {0, 0, 0, 0};
-    for (int k = 0; k < P.nvals; k++) o_val[k] = carve((size_t)S * P.cap * 8);
+    for (int k = 0; k < P.nvals; k++) o_val[k] = carve((size_t)nsub * P.cap * 8);
     Slot::PartBuf &pb = slot.part[slot.part_next & 1];
     slot.part_next++;
     // the previous user of this buffer (pass 2 of chunk i-2, on stream2) must be done before pass 1 refills it
@@ -573,8 +575,8 @@ static void run_part_chunk(Slot &slot, const BinArgs &planned, const LaunchPlan 
     P.qidx = sc + o_idx;
     P.qflags = P.use_flags ? (uint8_t *)(sc + o_flags) : nullptr;
     for (int k = 0; k < P.nvals; k++) P.qval[k] = (uint64_t *)(sc + o_val[k]);
-    HIP_CHECK(hipMemsetAsync(P.qcount, 0, (size_t)S * 8, slot.stream));
-    HIP_CHECK(hipMemsetAsync(P.qlimit, 0xff, (size_t)S * 8, slot.stream));
+    HIP_CHECK(hipMemsetAsync(P.qcount, 0, (size_t)nsub * 8, slot.stream));
+    HIP_CHECK(hipMemsetAsync(P.qlimit, 0xff, (size_t)nsub * 8, slot.stream));
 
     // pass-1 tile: 512 threads x R rows, staged in LDS
     int R = c.cfg_part_rows > 0 ? (int)c.cfg_part_rows : 4;
@@ -585,6 +587,7 @@ static void run_part_chunk(Slot &slot, const BinArgs &planned, const LaunchPlan 
         if (scatter_lds <= 78 * 1024 || R == 2) break;
     }
     P.rows_per_thread = R;
+    P.scatter_lds_one = (int32_t)((scatter_lds + 15) & ~(size_t)15);
     P.no_pipeline = (int32_t)c.cfg_no_pipeline; // bit 0: generic kernel; bit 1 (timing experiments only): skip the queue writes
     const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(4, kLdsMax / scatter_lds));
     const uint64_t tiles = (planned.n + 512ull * R - 1) / (512ull * R);

@@ -543,22 +543,25 @@ __device__ __forceinline__ void scatter_reserve(const PartArgs &P, const Scatter
         }
         if (lane == 63) L.s_off[S] = inc;
     }
+    // reservation in sub-queue (slab, shard): every slab's queue is split into `parts` sub-queues with their own
+    // counters — a single counter per slab is a same-address HBM atomic per tile, ~12 ns each at the memory side,
+    // which alone costs ~800 us per 2^27-row chunk (profiles/r01_scatter_ablation.txt)
     if (threadIdx.x < S) {
         my_cnt = L.s_cnt[threadIdx.x];
-        if (my_cnt) my_gb = atomicAdd(&P.qcount[threadIdx.x], (unsigned long long)my_cnt);
+        if (my_cnt) my_gb = atomicAdd(&P.qcount[threadIdx.x * (uint32_t)P.parts + blockIdx.x % (uint32_t)P.parts], (unsigned long long)my_cnt);
     }
 }
 
 // [D] tail: consume the reservation, re-zero the bucket counter (lanes < S)
 __device__ __forceinline__ void scatter_commit(const PartArgs &P, const ScatterLds &L, uint32_t S, unsigned long long my_gb, uint32_t my_cnt) {
     if (threadIdx.x < S) {
-        if (my_cnt && my_gb + my_cnt > P.cap) { // does not fit: remember where the valid prefix of the queue ends
-            atomicMin(&P.qlimit[threadIdx.x], my_gb);
+        const uint32_t sub = threadIdx.x * (uint32_t)P.parts + blockIdx.x % (uint32_t)P.parts;
+        if (my_cnt && my_gb + my_cnt > P.cap) { // does not fit: remember where the valid prefix of the sub-queue ends
+            atomicMin(&P.qlimit[sub], my_gb);
             my_gb = VXH_Q_OVERFLOW;
         }
         // park "queue slot of staging position j, minus j" so that copy-out is one add per record
-        L.s_gbase[threadIdx.x] = my_gb == VXH_Q_OVERFLOW ? VXH_Q_OVERFLOW : (unsigned long long)threadIdx.x * P.cap + my_gb - L.s_off[threadIdx.x];
-        L.s_cnt[threadIdx.x] = 0;
+        L.s_gbase[threadIdx.x] = my_gb == VXH_Q_OVERFLOW ? VXH_Q_OVERFLOW : (unsigned long long)sub * P.cap + my_gb - L.s_off[threadIdx.x];
     }
 }
 
@@ -659,6 +662,7 @@ __global__ void __launch_bounds__(512) part_scatter(const PartArgs P) {
             }
         }
         scatter_commit(P, L, S, my_gb, my_cnt);
+        if (threadIdx.x < S) L.s_cnt[threadIdx.x] = 0;
         __syncthreads();
         scatter_copy_out(P, L, S, T);
     }
@@ -675,15 +679,21 @@ __device__ __forceinline__ uint32_t scalar_sub_index32(double v, double vmin, do
     return scaled >= 0 ? inside : (scaled < 0 ? 1u : 0u);
 }
 
-// software-pipelined version for the common case — NDIM (1..3) scalar float64 native unmasked binners, float64
-// native aggregator inputs, at most one aggregator mask: the raw columns of tile t+1 are requested right after
-// barrier 2 of tile t and land while phases D and E of tile t run.
+// software-pipelined version for the common case — NDIM (1..3) scalar float64 native unmasked binners, NVAL (0..2)
+// float64 native aggregator inputs, at most one aggregator mask.  Two things overlap with the next tile's work:
+//  * the raw columns of tile t+1 are requested right after barrier 2 of tile t;
+//  * the queue-space reservation of tile t (an HBM atomic: a multi-microsecond round trip) is only consumed in
+//    iteration t+1 — the staging area is double-buffered and tile t's records are copied out one iteration
+//    later, so no lane ever waits for that round trip (measured: ~300 us of a 950 us pass-1 launch otherwise).
 template <int NDIM, int NVAL, int R>
-__global__ void __launch_bounds__(512) part_scatter_f64(const PartArgs P) { // (512, 6) = 3 workgroups/CU was measured: slower (spill)
+__global__ void __launch_bounds__(512) part_scatter_f64(const PartArgs P) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const uint32_t S = 1u << P.slab_log2;
     const uint32_t T = 512u * R;
-    const ScatterLds L = scatter_carve(lds, S, T, P.nvals);
+    // two staging buffers, swapped by value every iteration (an array indexed by `it & 1` would live in scratch)
+    ScatterLds L = scatter_carve(lds, S, T, P.nvals);
+    ScatterLds Lp = scatter_carve(lds + P.scatter_lds_one, S, T, P.nvals);
+    Lp.s_cnt = L.s_cnt;
     const uint64_t n = P.A.n;
     uint64_t tile = blockIdx.x;
     if (tile * T >= n) return;
@@ -719,7 +729,10 @@ __global__ void __launch_bounds__(512) part_scatter_f64(const PartArgs P) { // (
 
     Raw cur;
     request(tile, cur);
-    for (;;) {
+    unsigned long long gb_prev = 0; // reservation of the previous tile (lanes < S), not yet consumed
+    uint32_t cnt_prev = 0;
+    uint32_t it = 0;
+    for (;; ++it) {
         // [B]
         uint32_t keep = cur.valid;
         uint32_t fl[R];
@@ -749,38 +762,48 @@ __global__ void __launch_bounds__(512) part_scatter_f64(const PartArgs P) { // (
             if ((keep >> r) & 1u) pos[r] = __hip_atomic_fetch_add(&L.s_cnt[slab[r]], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         __syncthreads();
-        // [C]
-        unsigned long long my_gb;
-        uint32_t my_cnt;
-        scatter_reserve(P, L, S, my_gb, my_cnt);
+        // [C] prefix of this tile's buckets + its reservation (issued only)
+        unsigned long long gb_new;
+        uint32_t cnt_new;
+        scatter_reserve(P, L, S, gb_new, cnt_new);
         __syncthreads();
         // request the next tile's columns; they are not touched before the next [B]
         const uint64_t next = tile + gridDim.x;
         const bool has_next = next * T < n;
         Raw nxt;
-        if (has_next) request(next, nxt);
-        // [D]
-        if (!(P.no_pipeline & 4)) { // (bit 2: timing experiments only)
+        request(has_next ? next : tile, nxt); // (the last tile re-requests itself: static number of loads in flight)
+        // [D] stage this tile; park the PREVIOUS tile's reservation
 #pragma unroll
-            for (int r = 0; r < R; ++r) {
-                if ((keep >> r) & 1u) {
-                    const uint32_t j = L.s_off[slab[r]] + pos[r];
-                    L.st_idx[j] = loc[r];
-                    L.st_slab[j] = (uint16_t)slab[r];
-                    L.st_flags[j] = (uint8_t)fl[r];
+        for (int r = 0; r < R; ++r) {
+            if ((keep >> r) & 1u) {
+                const uint32_t j = L.s_off[slab[r]] + pos[r];
+                L.st_idx[j] = loc[r];
+                L.st_slab[j] = (uint16_t)slab[r];
+                L.st_flags[j] = (uint8_t)fl[r];
 #pragma unroll
-                    for (int k = 0; k < NVAL; ++k) L.st_val[(size_t)k * T + j] = cur.v[k][r];
-                }
+                for (int k = 0; k < NVAL; ++k) L.st_val[(size_t)k * T + j] = cur.v[k][r];
             }
         }
-        scatter_commit(P, L, S, my_gb, my_cnt);
+        if (it > 0) scatter_commit(P, Lp, S, gb_prev, cnt_prev);
+        if (threadIdx.x < S) L.s_cnt[threadIdx.x] = 0;
         __syncthreads();
-        // [E]
-        if (!(P.no_pipeline & 2)) scatter_copy_out(P, L, S, T);
+        // [E] copy out the PREVIOUS tile
+        if (it > 0 && !(P.no_pipeline & 2)) scatter_copy_out(P, Lp, S, T);
+        gb_prev = gb_new;
+        cnt_prev = cnt_new;
+        {
+            const ScatterLds tmp = L;
+            L = Lp;
+            Lp = tmp;
+        }
         if (!has_next) break;
         cur = nxt;
         tile = next;
     }
+    // epilogue: the last tile's records (now in Lp)
+    scatter_commit(P, Lp, S, gb_prev, cnt_prev);
+    __syncthreads();
+    if (!(P.no_pipeline & 2)) scatter_copy_out(P, Lp, S, T);
 }
 
 // pass 2: slab queues -> LDS-private slab -> HBM replica.  Each lane streams 4 consecutive records per
@@ -824,13 +847,13 @@ __global__ void __launch_bounds__(1024) part_reduce(const PartArgs P) {
     const uint64_t slab_cells = (P.A.cells + S - 1) >> P.slab_log2;
     lds_init(P.A, lds, slab_cells);
     __syncthreads();
-    unsigned long long len = P.qcount[slab];
-    const unsigned long long lim = P.qlimit[slab];
+    // this workgroup's sub-queue (slab, part)
+    const uint32_t sub = slab * (uint32_t)P.parts + part;
+    unsigned long long len = P.qcount[sub];
+    const unsigned long long lim = P.qlimit[sub];
     if (lim < len) len = lim;
-    // this workgroup's share, cut at multiples of 4 records so the vector loads stay aligned
-    const uint64_t quads = (len + 3) / 4;
-    const uint64_t lo = quads * part / P.parts * 4, hi = std::min<uint64_t>(len, quads * (part + 1) / P.parts * 4);
-    const uint64_t qb = (uint64_t)slab * P.cap;
+    const uint64_t lo = 0, hi = len;
+    const uint64_t qb = (uint64_t)sub * P.cap;
     const uint64_t hi4 = lo + ((hi - lo) & ~(uint64_t)3);
     const uint64_t step = 4ull * blockDim.x;
     uint64_t j = lo + 4ull * threadIdx.x;
@@ -934,12 +957,13 @@ __global__ void __launch_bounds__(1024) part_reduce_fast(const PartArgs P) {
         mom[k] = P.A.a[k].moment;
     }
     __syncthreads();
-    unsigned long long len = P.qcount[slab];
-    const unsigned long long lim = P.qlimit[slab];
+    // this workgroup's sub-queue (slab, part)
+    const uint32_t sub = slab * (uint32_t)P.parts + part;
+    unsigned long long len = P.qcount[sub];
+    const unsigned long long lim = P.qlimit[sub];
     if (lim < len) len = lim;
-    const uint64_t quads = (len + 3) / 4;
-    const uint64_t lo = quads * part / P.parts * 4, hi = std::min<uint64_t>(len, quads * (part + 1) / P.parts * 4);
-    const uint64_t qb = (uint64_t)slab * P.cap;
+    const uint64_t lo = 0, hi = len;
+    const uint64_t qb = (uint64_t)sub * P.cap;
     const uint64_t hi4 = lo + ((hi - lo) & ~(uint64_t)3);
     const uint64_t step = 4ull * blockDim.x;
     uint64_t j = lo + 4ull * threadIdx.x;
@@ -1064,6 +1088,7 @@ void vxh_launch_part_scatter(const PartArgs &args, bool fast_f64, int scatter_bl
     if (fast_f64 && R == 4 && args.A.ndim >= 1 && args.A.ndim <= 3 && args.nvals <= 2 && args.nmasks <= 1 && !(args.no_pipeline & 1)) {
 #define VXH_SCN(ND)                                                                                                    \
     do {                                                                                                               \
+        scatter_lds = 2 * (size_t)args.scatter_lds_one; /* double-buffered staging */                                  \
         if (args.nvals == 0) VXH_SC((part_scatter_f64<ND, 0, 4>));                                                     \
         else if (args.nvals == 1) VXH_SC((part_scatter_f64<ND, 1, 4>));                                                \
         else VXH_SC((part_scatter_f64<ND, 2, 4>));                                                                     \

@@ -82,7 +82,7 @@ struct PartArgs {
     int32_t parts;      // pass-2 workgroups per slab
     int32_t rows_per_thread;
     int32_t no_pipeline; // debugging knob: use the non-pipelined pass-1 kernel
-    int32_t reserved2_;
+    int32_t scatter_lds_one; // bytes of ONE pass-1 LDS carve (the pipelined kernel uses two)
     uint64_t cap;       // queue capacity per slab (records)
     const void *vdata[VXH_PART_MAX_VALS];
     const uint8_t *mdata[VXH_PART_MAX_MASKS];
