@@ -52,7 +52,7 @@ def lib():
         L.vxo_set_update.argtypes = [vp, vp, u64]
         L.vxo_set_map_ordinal.argtypes = [vp, vp, u64, vp]
         L.vxo_set_keys.argtypes = [vp, vp]
-        L.vxo_statistic_nd.argtypes = [vp, i32, vp, u64, vp, vp, vp, vp, i32, i32, vp]
+        L.vxo_statistic_nd.argtypes = [vp, i32, vp, u64, vp, vp, vp, vp, i32, i32, i32, vp]
         _lib = L
     return _lib
 
@@ -207,6 +207,28 @@ def minmax(data, mask=None):
     if len(d) == 0:
         return np.inf, -np.inf
     return float(d.min()), float(d.max())
+
+
+STAT_FIELDS = {0: 1, 1: 1, 2: 2, 3: 2, 4: 3}
+
+
+def statistic_nd(blocks, weights, grid, minima, maxima, op, use_edges=0):
+    """vaexfast.statisticNd_f8 restated (vxo_statistic_nd): accumulates into the float64 `grid` of shape
+    sizes + (fields,), same argument order as vaexfast.cpp:1361-1370."""
+    blocks = [np.ascontiguousarray(b, dtype=np.float64) for b in blocks]
+    nd = len(blocks)
+    assert grid.dtype == np.float64 and grid.ndim == nd + 1 and grid.flags.c_contiguous
+    fields = grid.shape[-1]
+    w = None
+    if weights is not None:
+        w = np.ascontiguousarray(weights[0] if isinstance(weights, (list, tuple)) else weights, dtype=np.float64)
+    n = len(blocks[0]) if blocks else (len(w) if w is not None else 0)
+    ptrs = (ctypes.c_void_p * max(1, nd))(*[b.ctypes.data for b in blocks])
+    mins = np.asarray(minima, dtype=np.float64)
+    maxs = np.asarray(maxima, dtype=np.float64)
+    counts = np.asarray(grid.shape[:-1], dtype=np.int64)
+    strides = np.asarray([s // (8 * fields) for s in grid.strides[:-1]], dtype=np.int64)
+    lib().vxo_statistic_nd(ptrs, nd, _ptr(w), n, _ptr(mins), _ptr(maxs), _ptr(counts), _ptr(strides), op, fields, int(use_edges), _ptr(grid))
 
 
 # ------------------------------------------------------------------------------------------

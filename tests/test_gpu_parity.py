@@ -19,8 +19,9 @@ def _reset_config(sa, gpu_ready):
         sa.config_set("block", 0)
         sa.config_set("blocks", 0)
         sa.config_set("slab_log2", -1)
-        sa.config_set("part_chunk", 1 << 27)
+        sa.config_set("part_chunk", 0)
         sa.config_set("parts", 0)
+        sa.config_set("count16", 1)
     reset()
     yield
     reset()
@@ -297,3 +298,65 @@ def test_rccl_allreduce_path_single_rank(sa):
         assert vdist.Comm().minmax(3, 9) == (3, 9)
     finally:
         dist.destroy_process_group()
+
+
+# ---- packed 16-bit LDS counters (all-count passes whose grid fits LDS only as uint16 halves) -----------------
+def test_count16_2d_256(sa):
+    c = cases.gaussian_columns(1_500_000, seed=9)
+    sel = c["v"] > 3
+    nanv = c["v"].copy(); nanv[::7] = np.nan
+    bin2 = [dict(kind="scalar", data=c["x"], vmin=-4, vmax=4, bins=256), dict(kind="scalar", data=c["y"], vmin=-4, vmax=4, bins=256)]
+    for aggs in ([dict(kind="count")], [dict(kind="count", mask=sel)], [dict(kind="count", data=nanv)], [dict(kind="count", data=nanv, mask=sel)]):
+        check(sa, dict(n=1_500_000, binners=bin2, aggs=aggs))
+        assert sa.last_kernel(0).startswith(("bin_lds", "count_lds")), sa.last_kernel(0)
+    # non-float64 binner column: the generic (typed) instantiation of the same kernel
+    bin2f = [dict(kind="scalar", data=c["x"].astype("f4"), vmin=-4, vmax=4, bins=256), bin2[1]]
+    check(sa, dict(n=1_500_000, binners=bin2f, aggs=[dict(kind="count")]))
+    assert sa.last_kernel(0).startswith(("bin_lds", "count_lds"))
+    # switched off: same numbers through partition + reduce
+    sa.config_set("count16", 0)
+    try:
+        check(sa, dict(n=1_500_000, binners=bin2, aggs=[dict(kind="count")]))
+        assert sa.last_kernel(0).startswith("part_scatter")
+    finally:
+        sa.config_set("count16", 1)
+
+
+@pytest.mark.parametrize("pattern", ["one_even", "one_odd", "pair", "pair_skewed"])
+def test_count16_half_word_wraps(sa, pattern):
+    # 8 workgroups, ~2.4e5 rows each into one or two cells that share an LDS word: every half wraps 3+ times, the
+    # carries into (and back out of) the odd half included.  Counts must still be exact.
+    sa.config_set("blocks", 8)
+    n = 2_000_000
+    bins = 70_000  # 70 003 cells: 280 KB as uint32, 140 KB packed
+    width = 1.0 / bins
+    i = np.arange(n)
+    even, odd = 1000, 1001  # interior sub-indices; cells are +2 -> LDS word 501 holds cells 1002 (even) and 1003 (odd)
+    if pattern == "one_even":
+        sub = np.full(n, even)
+    elif pattern == "one_odd":
+        sub = np.full(n, odd)
+    elif pattern == "pair":
+        sub = np.where(i % 2 == 0, even, odd)
+    else:
+        sub = np.where(i % 5 == 0, even, odd)
+    x = (sub + 0.5) * width
+    x[::1000] = 0.123  # a few rows elsewhere
+    case = dict(n=n, binners=[dict(kind="scalar", data=x, vmin=0.0, vmax=1.0, bins=bins)], aggs=[dict(kind="count")])
+    got = check(sa, case)
+    assert sa.last_kernel(0).startswith(("bin_lds", "count_lds"))
+    assert got[0].sum() == n and got[0].max() > 8 * 65536
+
+
+def test_count16_partition_reduce_opt_in(sa):
+    sa.config_set("count16", 2)
+    sa.config_set("strategy", STRATEGIES["part"])
+    try:
+        case = cases.case_3d_selection(2_000_000, shape=64)
+        check(sa, case)
+        assert sa.last_kernel(0).startswith("part_scatter")
+        n = 3_000_000  # one hot cell: sub-queue overflow path + half-word wraps in pass 2
+        x = np.full(n, 0.5); y = np.full(n, -0.25)
+        check(sa, dict(n=n, binners=[dict(kind="scalar", data=x, vmin=-4, vmax=4, bins=512), dict(kind="scalar", data=y, vmin=-4, vmax=4, bins=512)], aggs=[dict(kind="count")]))
+    finally:
+        sa.config_set("count16", 1)

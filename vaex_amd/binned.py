@@ -303,7 +303,7 @@ class Frame:
         grid, aggs = self._run_pass(specs, prims)
         if reduce is not None:
             reduce(aggs)
-        raw = [np.array(a.get_result()) for a in aggs]
+        raw = [np.asarray(a.get_result()) for a in aggs]  # (get_result already returns a fresh array)
         if not edges:  # vaex/agg.py:323-335
             sl = tuple(slice(2, -1) if s["kind"] == "scalar" else slice(0, -2) for s in specs)
             raw = [r[sl] for r in raw]
@@ -437,7 +437,7 @@ class Frame:
             slot = (slot + 1) % slots
         if reduce is not None:
             reduce(aggs)
-        raw = [np.array(a.get_result()) for a in aggs]
+        raw = [np.asarray(a.get_result()) for a in aggs]  # (get_result already returns a fresh array)
         return [d.finish([raw[i] for i in ids]) for d, ids in zip(descs, want)]
 
 

@@ -262,8 +262,9 @@ static void agg_alloc_device(vxh_agg *a) {
 
 // fold replicas into replica 0 (device), after all slots' work has drained
 static void agg_fold_device(vxh_agg *a) {
-    if (!a->dev || a->folded) return;
-    HIP_CHECK(hipDeviceSynchronize());
+    if (!a->dev) return;
+    HIP_CHECK(hipDeviceSynchronize()); // every slot stream has drained — also when there is nothing to fold
+    if (a->folded) return;
     Slot &s0 = get_slot(0);
     vxh_launch_fold(a->dev, a->grid->length1d, a->used, a->cell, a->kind, &a->identity, s0.stream);
     HIP_CHECK(hipStreamSynchronize(s0.stream));
@@ -386,16 +387,27 @@ static LaunchPlan make_plan(const BinArgs &A, BinArgs &out, uint64_t n, double b
         const BinnerDesc &b = A.b[d];
         if (b.kind != VXH_BIN_SCALAR || b.dtype != VXH_F64 || b.flip || b.mask) fast = false;
     }
+    bool fast_vals = true;
     for (int k = 0; k < A.nagg; k++) {
         const AggDesc &a = A.a[k];
-        if (a.data && (a.dtype != VXH_F64 || a.flip)) fast = false;
+        if (a.data && (a.dtype != VXH_F64 || a.flip)) fast_vals = false;
     }
+    fast = fast && fast_vals;
     p.fast_f64 = fast;
+    p.fast_vals = fast_vals;
+    p.key_i64 = A.ndim == 1 && A.b[0].kind == VXH_BIN_ORDINAL && A.b[0].dtype == VXH_I64 && !A.b[0].flip && !A.b[0].mask;
 
     // LDS bytes per cell over all aggregators -> number of interleaved slabs S (power of two)
     size_t per_cell = 0;
     for (int k = 0; k < A.nagg; k++) per_cell += vxh_lds_cell_size(A.a[k].kind, A.a[k].cell);
     const size_t lds_budget = kLdsMax - 16 * (size_t)A.nagg - 64;
+    // all-count passes: packed 16-bit LDS counters when (and only when) that makes the whole grid fit one
+    // workgroup's LDS — a single LDS-private pass instead of interleaved slabs / partition + reduce
+    bool all_count = A.nagg > 0;
+    for (int k = 0; k < A.nagg; k++) all_count = all_count && A.a[k].kind == VXH_AGG_COUNT;
+    const bool c16_lds = all_count && c.cfg_count16 >= 1 && A.cells * per_cell > lds_budget && A.cells * (per_cell / 2) + 4 * (size_t)A.nagg <= lds_budget;
+    const bool c16_part = all_count && c.cfg_count16 >= 2;
+    if (c16_lds) per_cell /= 2;
     int slab_log2 = 0;
     while (slab_log2 < 5 && ((A.cells + (1ull << slab_log2) - 1) >> slab_log2) * per_cell > lds_budget) slab_log2++;
     const uint64_t slab_cells = (A.cells + (1ull << slab_log2) - 1) >> slab_log2;
@@ -406,8 +418,9 @@ static LaunchPlan make_plan(const BinArgs &A, BinArgs &out, uint64_t n, double b
     // fewest slabs that fit one CU's LDS: part_reduce is register-limited to one 1024-thread workgroup per CU
     // anyway, and fewer, longer-lived workgroups pay the LDS init + flush less often (profiles/r01_tune2*)
     const size_t part_budget = c.cfg_part_lds > 0 ? (size_t)c.cfg_part_lds : 150 * 1024;
+    const size_t part_per_cell = c16_part ? (size_t)2 * A.nagg : (c16_lds ? per_cell * 2 : per_cell);
     int part_log2 = 0;
-    while (part_log2 < 8 && ((A.cells + (1ull << part_log2) - 1) >> part_log2) * per_cell > part_budget) part_log2++;
+    while (part_log2 < 8 && ((A.cells + (1ull << part_log2) - 1) >> part_log2) * part_per_cell > part_budget) part_log2++;
     const uint64_t part_slab_cells = (A.cells + (1ull << part_log2) - 1) >> part_log2;
     int nvals = 0, nmasks = 0;
     {
@@ -417,7 +430,7 @@ static LaunchPlan make_plan(const BinArgs &A, BinArgs &out, uint64_t n, double b
             if (A.a[k].mask) { int j = 0; while (j < nmasks && seen_m[j] != A.a[k].mask) j++; if (j == nmasks) seen_m[nmasks++] = A.a[k].mask; }
         }
     }
-    const bool part_ok = part_slab_cells * per_cell <= lds_budget && A.cells < (1ull << 31) && nvals <= VXH_PART_MAX_VALS && nmasks <= VXH_PART_MAX_MASKS;
+    const bool part_ok = part_slab_cells * part_per_cell <= lds_budget && A.cells < (1ull << 31) && nvals <= VXH_PART_MAX_VALS && nmasks <= VXH_PART_MAX_MASKS;
     const double rec_bytes = (part_slab_cells <= 65536 ? 2.0 : 4.0) + (nmasks ? 1.0 : 0.0) + 8.0 * nvals;
 
     int strategy = (int)c.cfg_strategy;
@@ -448,8 +461,9 @@ static LaunchPlan make_plan(const BinArgs &A, BinArgs &out, uint64_t n, double b
         size_t lds = 0;
         for (int k = 0; k < A.nagg; k++) {
             out.a[k].lds_offset = (uint32_t)lds;
-            lds += (part_slab_cells * vxh_lds_cell_size(A.a[k].kind, A.a[k].cell) + 15) & ~(size_t)15;
+            lds += (part_slab_cells * vxh_lds_cell_size(A.a[k].kind, A.a[k].cell, c16_part) + 4 + 15) & ~(size_t)15;
         }
+        out.count16 = c16_part ? 1 : 0;
         p.lds_bytes = lds;
         int per_cu = (int)std::max<size_t>(1, std::min<size_t>(2, kLdsMax / std::max<size_t>(lds, 1)));
         p.block = c.cfg_block > 0 ? (int)c.cfg_block : 1024;
@@ -458,10 +472,11 @@ static LaunchPlan make_plan(const BinArgs &A, BinArgs &out, uint64_t n, double b
         if (c.cfg_parts > 0) parts = (int)c.cfg_parts;
         out.slab_log2 = part_log2;
         out.ngroups = parts; // pass-2 workgroups per slab
-        // plain flush: one replica per pass-2 part + one for the atomic overflow path of pass 1
-        out.flush_plain = (exclusive && A.replicas >= parts + 1) ? 1 : 0;
-        out.replicas = out.flush_plain ? parts + 1 : std::min(A.replicas, parts);
-        p.use_replicas = out.replicas;
+        // pass 2 flushes into the slot-private accumulators; only replica 0 of the grids is touched (part_merge,
+        // and device atomics from the rare slow paths)
+        out.flush_plain = exclusive ? 1 : 0; // part_merge: plain read-modify-write vs atomics
+        out.replicas = 1;
+        p.use_replicas = 1;
         p.blocks = parts * S;
         p.name = fast ? "part_scatter+part_reduce_f64" : "part_scatter+part_reduce_generic";
         return p;
@@ -472,13 +487,22 @@ static LaunchPlan make_plan(const BinArgs &A, BinArgs &out, uint64_t n, double b
         size_t lds = 0;
         for (int k = 0; k < A.nagg; k++) {
             out.a[k].lds_offset = (uint32_t)lds;
-            lds += (slab_cells * vxh_lds_cell_size(A.a[k].kind, A.a[k].cell) + 15) & ~(size_t)15;
+            lds += (slab_cells * vxh_lds_cell_size(A.a[k].kind, A.a[k].cell, c16_lds) + 4 + 15) & ~(size_t)15;
         }
+        out.count16 = c16_lds ? 1 : 0;
         p.lds_bytes = lds;
+        out.slab_log2 = slab_log2;
+        p.count_fast = vxh_count_fast(out, p) && c.cfg_count_fast;
         // workgroups per CU: as many as LDS allows, at most 2048 threads per CU
         int per_cu = (int)std::max<size_t>(1, std::min<size_t>(4, kLdsMax / std::max<size_t>(lds, 1)));
         p.block = c.cfg_block > 0 ? (int)c.cfg_block : (per_cu >= 2 ? 512 : 1024);
         per_cu = std::max(1, std::min(per_cu, 2048 / p.block));
+        if (p.count_fast) {
+            // K1d keeps 8 loads per lane in flight on its own: ONE 512-thread workgroup per CU is fastest (fewer
+            // concurrent streams into HBM; profiles/r01_count_tune.txt: 5.7-6.5 TB/s vs 5.3-6.0 with 2 x 512 / 1 x 1024)
+            if (c.cfg_block <= 0) p.block = 512;
+            per_cu = 1;
+        }
         // ngroups * S workgroups; ngroups a multiple of 8 (one group per XCD at least)
         uint64_t max_blocks = c.cfg_blocks > 0 ? (uint64_t)c.cfg_blocks : (uint64_t)c.cus * per_cu;
         uint64_t ngroups = std::max<uint64_t>(8, (max_blocks / S) / 8 * 8);
@@ -486,12 +510,12 @@ static LaunchPlan make_plan(const BinArgs &A, BinArgs &out, uint64_t n, double b
         want = std::max<uint64_t>(8, (want + 7) / 8 * 8);
         ngroups = std::min(ngroups, want);
         p.blocks = (int)(ngroups * S);
-        out.slab_log2 = slab_log2;
         out.ngroups = (int)ngroups;
         out.flush_plain = (exclusive && (uint64_t)A.replicas >= ngroups) ? 1 : 0;
         out.replicas = (int)std::min<uint64_t>((uint64_t)A.replicas, ngroups);
         p.use_replicas = out.replicas;
-        p.name = S > 1 ? (fast ? "bin_lds_slab_f64" : "bin_lds_slab_generic") : (fast ? "bin_lds_f64" : "bin_lds_generic");
+        p.name = S > 1 ? (fast ? "bin_lds_slab_f64" : "bin_lds_slab_generic") : (c16_lds ? (fast ? "bin_lds_count16_f64" : "bin_lds_count16_generic") : (fast ? "bin_lds_f64" : "bin_lds_generic"));
+        if (p.count_fast) p.name = c16_lds ? "count_lds16_f64" : "count_lds_f64";
     } else {
         p.lds_bytes = 0;
         p.block = c.cfg_block > 0 ? (int)c.cfg_block : 256;
@@ -502,6 +526,62 @@ static LaunchPlan make_plan(const BinArgs &A, BinArgs &out, uint64_t n, double b
         else p.name = fast ? "bin_global_f64" : "bin_global_generic";
     }
     return p;
+}
+
+// ------------------------------------------------------------------------------------------
+// partition accumulators: (re)allocate + identity-fill when the layout changes; merge at the end of a call
+// ------------------------------------------------------------------------------------------
+static void part_acc_prepare(Slot &slot, const BinArgs &planned) {
+    const uint64_t S = 1ull << planned.slab_log2;
+    const uint64_t slab_cells = (planned.cells + S - 1) >> planned.slab_log2;
+    const uint64_t plane = slab_cells * S, parts = (uint64_t)planned.ngroups;
+    uint64_t sig = 0xcbf29ce484222325ull;
+    auto mix = [&](uint64_t v) { sig = (sig ^ v) * 0x100000001b3ull; };
+    mix(planned.cells); mix(S); mix(parts); mix((uint64_t)planned.nagg);
+    size_t off = 0, offs[VXH_MAX_AGG];
+    for (int k = 0; k < planned.nagg; k++) {
+        mix(planned.a[k].kind); mix(planned.a[k].cell); mix(planned.a[k].dtype);
+        offs[k] = off;
+        off += (plane * parts * vxh_cell_size(planned.a[k].cell) + 255) & ~(size_t)255;
+    }
+    bool fill = sig != slot.acc_sig;
+    if (off > slot.acc_cap) {
+        HIP_CHECK(hipStreamSynchronize(slot.stream));
+        if (slot.acc) HIP_CHECK(hipFree(slot.acc));
+        slot.acc = nullptr;
+        HIP_CHECK(hipMalloc(&slot.acc, off));
+        slot.acc_cap = off;
+        fill = true;
+    }
+    for (int k = 0; k < planned.nagg; k++) slot.acc_ptr[k] = (char *)slot.acc + offs[k];
+    if (fill) {
+        for (int k = 0; k < planned.nagg; k++) {
+            const uint64_t ident = device_identity(planned.a[k].kind, planned.a[k].dtype, planned.a[k].cell);
+            vxh_launch_fill(slot.acc_ptr[k], plane * parts, planned.a[k].cell, &ident, slot.stream);
+        }
+        HIP_CHECK(hipGetLastError());
+        slot.acc_sig = sig;
+    }
+}
+
+static void part_acc_merge(Slot &slot, const BinArgs &planned) {
+    PartMergeArgs M{};
+    const uint64_t S = 1ull << planned.slab_log2;
+    M.cells = planned.cells;
+    M.slab_cells = (planned.cells + S - 1) >> planned.slab_log2;
+    M.slab_log2 = planned.slab_log2;
+    M.parts = planned.ngroups;
+    M.nagg = planned.nagg;
+    M.atomic = planned.flush_plain ? 0 : 1;
+    for (int k = 0; k < planned.nagg; k++) {
+        M.acc[k] = slot.acc_ptr[k];
+        M.grid[k] = planned.a[k].grid;
+        M.kind[k] = planned.a[k].kind;
+        M.cell[k] = planned.a[k].cell;
+        M.ident[k] = device_identity(planned.a[k].kind, planned.a[k].dtype, planned.a[k].cell);
+    }
+    vxh_launch_part_merge(M, slot.stream);
+    HIP_CHECK(hipGetLastError());
 }
 
 // ------------------------------------------------------------------------------------------
@@ -555,8 +635,8 @@ static void run_part_chunk(Slot &slot, const BinArgs &planned, const LaunchPlan 
     const size_t o_flags = P.use_flags ? carve((size_t)nsub * P.cap) : 0;
     size_t o_val[VXH_PART_MAX_VALS] = {0, 0, 0, 0};
     for (int k = 0; k < P.nvals; k++) o_val[k] = carve((size_t)nsub * P.cap * 8);
-    Slot::PartBuf &pb = slot.part[slot.part_next & 1];
-    slot.part_next++;
+    // (two scratch buffers only when pass 2 of chunk i overlaps pass 1 of chunk i+1)
+    Slot::PartBuf &pb = slot.part[c.cfg_part_overlap ? (slot.part_next++ & 1) : 0];
     // the previous user of this buffer (pass 2 of chunk i-2, on stream2) must be done before pass 1 refills it
     if (pb.busy) {
         HIP_CHECK(hipStreamWaitEvent(slot.stream, pb.reduced, 0));
@@ -579,7 +659,8 @@ static void run_part_chunk(Slot &slot, const BinArgs &planned, const LaunchPlan 
     HIP_CHECK(hipMemsetAsync(P.qlimit, 0xff, (size_t)nsub * 8, slot.stream));
 
     // pass-1 tile: 512 threads x R rows, staged in LDS
-    int R = c.cfg_part_rows > 0 ? (int)c.cfg_part_rows : 4;
+    // (many slabs: bigger tiles keep the per-bucket copy-out segments at >= 16 records)
+    int R = c.cfg_part_rows > 0 ? (int)c.cfg_part_rows : ((plan.key_i64 && plan.fast_vals && S >= 64) ? 8 : 4);
     size_t scatter_lds = 0;
     for (;; R >>= 1) {
         const size_t T = 512 * (size_t)R;
@@ -588,11 +669,13 @@ static void run_part_chunk(Slot &slot, const BinArgs &planned, const LaunchPlan 
     }
     P.rows_per_thread = R;
     P.scatter_lds_one = (int32_t)((scatter_lds + 15) & ~(size_t)15);
+    for (int k = 0; k < planned.nagg; k++) P.acc[k] = slot.acc_ptr[k];
     P.no_pipeline = (int32_t)c.cfg_no_pipeline; // bit 0: generic kernel; bit 1 (timing experiments only): skip the queue writes
-    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(4, kLdsMax / scatter_lds));
+    int per_cu = (int)std::max<size_t>(1, std::min<size_t>(4, kLdsMax / scatter_lds));
+    if (c.cfg_scatter_wgs > 0) per_cu = (int)c.cfg_scatter_wgs;
     const uint64_t tiles = (planned.n + 512ull * R - 1) / (512ull * R);
     const int scatter_blocks = (int)std::max<uint64_t>(1, std::min<uint64_t>(tiles, (uint64_t)c.cus * per_cu));
-    vxh_launch_part_scatter(P, plan.fast_f64, scatter_blocks, scatter_lds, slot.stream);
+    vxh_launch_part_scatter(P, plan, scatter_blocks, scatter_lds, slot.stream);
     HIP_CHECK(hipGetLastError());
     if (c.cfg_part_overlap) {
         HIP_CHECK(hipEventRecord(pb.scattered, slot.stream));
@@ -672,12 +755,15 @@ int vxh_config_set(const char *key, int64_t value) {
     else if (k == "blocks") c.cfg_blocks = value;
     else if (k == "stage_bytes") c.cfg_stage_bytes = value;
     else if (k == "slab_log2") c.cfg_slab_log2 = value;
-    else if (k == "part_chunk") c.cfg_part_chunk = value;
+    else if (k == "part_chunk") c.cfg_part_chunk = value > 0 ? value : (1ll << 28);
     else if (k == "parts") c.cfg_parts = value;
     else if (k == "part_lds") c.cfg_part_lds = value;
     else if (k == "part_rows") c.cfg_part_rows = value;
     else if (k == "no_pipeline") c.cfg_no_pipeline = value;
     else if (k == "part_overlap") c.cfg_part_overlap = value;
+    else if (k == "count16") c.cfg_count16 = value;
+    else if (k == "count_fast") c.cfg_count_fast = value;
+    else if (k == "scatter_wgs") c.cfg_scatter_wgs = value;
     else if (k == "lds_replicas") c.cfg_lds_replicas = value;
     else throw std::runtime_error("unknown config key: " + k);
     VXH_API_END
@@ -699,6 +785,9 @@ int vxh_config_get(const char *key, int64_t *value) {
     else if (k == "part_rows") *value = c.cfg_part_rows;
     else if (k == "no_pipeline") *value = c.cfg_no_pipeline;
     else if (k == "part_overlap") *value = c.cfg_part_overlap;
+    else if (k == "count16") *value = c.cfg_count16;
+    else if (k == "count_fast") *value = c.cfg_count_fast;
+    else if (k == "scatter_wgs") *value = c.cfg_scatter_wgs;
     else if (k == "lds_replicas") *value = c.cfg_lds_replicas;
     else if (k == "cus") { ensure_device_ready(); *value = c.cus; }
     else throw std::runtime_error("unknown config key: " + k);
@@ -959,10 +1048,11 @@ int vxh_grid_bin(vxh_grid *grid, int thread, vxh_agg *const *aggs, int n_aggs, u
         A.replicas = replicas;
         // plan once on the whole call: it fixes the strategy, hence the row step of the launches
         uint64_t step = kMaxRows;
-        {
-            BinArgs tmp;
-            LaunchPlan whole = make_plan(A, tmp, length, bytes_per_row, exclusive);
-            if (whole.strategy == VXH_STRAT_PART) step = (uint64_t)std::max<int64_t>(1 << 20, ctx().cfg_part_chunk);
+        BinArgs whole_args;
+        const LaunchPlan whole = make_plan(A, whole_args, length, bytes_per_row, exclusive);
+        if (whole.strategy == VXH_STRAT_PART) {
+            step = (uint64_t)std::max<int64_t>(1 << 20, ctx().cfg_part_chunk);
+            part_acc_prepare(slot, whole_args);
         }
         for (uint64_t r0 = 0; r0 < length; r0 += step) {
             const uint64_t rn = std::min(step, length - r0);
@@ -987,12 +1077,16 @@ int vxh_grid_bin(vxh_grid *grid, int thread, vxh_agg *const *aggs, int n_aggs, u
                 a->folded = a->used <= 1;
             }
             if (plan.strategy == VXH_STRAT_PART) {
-                run_part_chunk(slot, planned, plan, step);
+                run_part_chunk(slot, planned, plan, std::min<uint64_t>(step, length));
             } else {
                 vxh_launch_bin(planned, plan, slot.stream);
                 HIP_CHECK(hipGetLastError());
             }
             slot.last_kernel = plan.name;
+        }
+        if (whole.strategy == VXH_STRAT_PART) {
+            part_join(slot);
+            part_acc_merge(slot, whole_args);
         }
     }
     part_join(slot);

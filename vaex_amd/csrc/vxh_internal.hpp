@@ -81,6 +81,12 @@ struct Slot {
     } part[2];
     hipStream_t stream2 = nullptr;
     unsigned part_next = 0;
+    // partition accumulators (PartArgs::acc): identity-filled when the layout signature changes, put back to the
+    // identity by part_merge at the end of every vxh_grid_bin call
+    void *acc = nullptr;
+    size_t acc_cap = 0;
+    uint64_t acc_sig = 0;
+    void *acc_ptr[VXH_MAX_AGG] = {};
     const char *last_kernel = "";
 };
 
@@ -99,9 +105,12 @@ struct Context {
     int64_t cfg_stage_bytes = 64 << 20;
     int64_t cfg_slab_log2 = -1;   // -1 = auto
     int64_t cfg_lds_replicas = 0; // 0 = auto
-    int64_t cfg_part_chunk = 1 << 27; // rows per partition chunk
+    int64_t cfg_part_chunk = 1 << 28; // rows per partition chunk (scratch: ~2 x record bytes x this; larger chunks amortise the launches)
     int64_t cfg_parts = 0;        // pass-2 workgroups per slab (0 = auto)
     int64_t cfg_part_lds = 0;     // LDS bytes per pass-2 slab (0 = auto)
+    int64_t cfg_scatter_wgs = 0;  // pass-1 workgroups per CU (0 = as many as LDS allows, at most 4)
+    int64_t cfg_count_fast = 1;   // 0: keep count(*) passes on the generic bin_kernel (for A/B measurements)
+    int64_t cfg_count16 = 1;      // packed 16-bit LDS counters for all-count passes: 0 off, 1 LDS strategy, 2 also partition pass 2
     int64_t cfg_part_overlap = 0; // pass 2 of chunk i on a second stream, overlapping pass 1 of chunk i+1
     int64_t cfg_no_pipeline = 0;  // 1: non-pipelined pass-1 kernel
     int64_t cfg_part_rows = 0;    // pass-1 rows per thread per tile: 8, 4 or 2 (0 = auto)

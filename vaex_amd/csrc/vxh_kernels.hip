@@ -226,12 +226,80 @@ __device__ __forceinline__ double pow_u(double b, uint32_t m) {
 }
 
 __device__ __forceinline__ size_t cell_size_dev(int cell) { return cell >= VXH_CELL_F32 ? 4 : 8; }
-__device__ __forceinline__ size_t lds_cell_size_dev(int kind, int cell) { return kind == VXH_AGG_COUNT ? 4 : cell_size_dev(cell); }
+__device__ __forceinline__ size_t lds_cell_size_dev(int kind, int cell, int count16 = 0) { return kind == VXH_AGG_COUNT ? (count16 ? 2 : 4) : cell_size_dev(cell); }
+
+// Packed 16-bit LDS counters (BinArgs::count16): when every aggregator is a count, two cells share one LDS word,
+// which halves the LDS footprint again (a 259x259 count grid = 131 KB fits ONE workgroup's LDS: one pass over the
+// rows instead of partition + reduce).  A half that wraps is repaired through the value the LDS atomic returns:
+// all arithmetic on the word is mod 2^32 and commutative, so the final halves are exact mod 2^16, and every
+// wrap through 0xffff -> 0 (or back, when a carry is taken out again) is seen by exactly one lane, which books
+// +-65536 on the cell of the HBM replica this workgroup flushes into.  Rare by construction (a workgroup must
+// put 65536 rows into one cell), so the repair path costs nothing in the common case.
+struct C16 {
+    unsigned long long *grid; // HBM replica the workgroup flushes into (int64 count cells)
+    uint64_t cells;
+    uint32_t slab_log2, slab, on;
+};
+
+__device__ __forceinline__ void count16_book(const C16 &c, uint32_t local, long long delta) {
+    const uint64_t gc = ((uint64_t)local << c.slab_log2) + c.slab;
+    if (gc < c.cells) at_add<__HIP_MEMORY_SCOPE_AGENT, unsigned long long>(c.grid + gc, (unsigned long long)delta);
+}
+
+// N rows of one lane, in two halves so that a caller can put other work between them: issue() fires all N
+// returning LDS atomics, settle() looks at what they returned (one wait, not N; the repair is a single
+// rarely-taken branch).  bin_kernel settles a batch only after the NEXT batch's column loads have come back, so
+// the LDS round trip is hidden exactly as it is for the non-returning uint32 counters.
+template <int N, typename IDX>
+__device__ __forceinline__ void count16_issue(uint32_t *base, const IDX (&idx)[N], uint32_t keep, bool all_keep, uint32_t (&old)[N]) {
+#pragma unroll
+    for (int u = 0; u < N; ++u) {
+        const uint32_t sh = ((uint32_t)idx[u] & 1u) * 16u;
+        old[u] = 0; // rows not kept read as "no wrap"
+        if (all_keep || ((keep >> u) & 1u)) old[u] = __hip_atomic_fetch_add(base + ((uint32_t)idx[u] >> 1), 1u << sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+}
+
+template <int N, typename IDX>
+__device__ __forceinline__ void count16_settle(uint32_t *base, const IDX (&idx)[N], const uint32_t (&old)[N], const C16 &c) {
+    bool wrapped = false;
+#pragma unroll
+    for (int u = 0; u < N; ++u) {
+        const uint32_t sh = ((uint32_t)idx[u] & 1u) * 16u;
+        wrapped |= ((old[u] >> sh) & 0xffffu) == 0xffffu;
+    }
+    if (!wrapped) return;
+#pragma unroll
+    for (int u = 0; u < N; ++u) {
+        const uint32_t i = (uint32_t)idx[u];
+        if (i & 1u) {
+            if ((old[u] >> 16) == 0xffffu) count16_book(c, i, 65536);
+        } else if ((old[u] & 0xffffu) == 0xffffu) { // the low half wrapped and carried into the odd neighbour
+            count16_book(c, i, 65536);
+            if ((old[u] >> 16) == 0xffffu) count16_book(c, i | 1u, 65536); // ... which the carry wrapped upwards
+            const uint32_t old2 = __hip_atomic_fetch_sub(base + (i >> 1), 0x10000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if ((old2 >> 16) == 0u) count16_book(c, i | 1u, -65536);        // ... and taking it back wrapped downwards
+        }
+    }
+}
+
+// rows of a count aggregator that take part: NaN inputs are skipped (src/agg_count.cpp:56)
+template <int N>
+__device__ __forceinline__ uint32_t count_keep(const AggDesc &a, const uint64_t (&v)[N], uint32_t keep, bool has_data) {
+    if (has_data && dt_is_float(a.dtype)) {
+#pragma unroll
+        for (int u = 0; u < N; ++u) {
+            const double d = as_f64(v[u]);
+            if (d != d) keep &= ~(1u << u);
+        }
+    }
+    return keep;
+}
 
 // one aggregator, N rows.  v[] canonical values (ignored when the aggregator has no input), keep = rows that
 // take part.  LDS copies count in uint32 (a workgroup sees < 2^32 rows), HBM grids in the device cell type.
-template <int SCOPE, bool LDS, int N, typename IDX>
-__device__ __forceinline__ void agg_batch(const AggDesc &a, void *base, const IDX (&idx)[N], const uint64_t (&v)[N], uint32_t keep, bool has_data) {
+template <int SCOPE, bool LDS, int N, bool PACK16 = false, typename IDX>
+__device__ __forceinline__ void agg_batch(const AggDesc &a, void *base, const IDX (&idx)[N], const uint64_t (&v)[N], uint32_t keep, bool has_data, const C16 c16 = C16{}) {
     if (has_data && dt_is_float(a.dtype)) { // NaN rows are skipped (src/agg_sum.cpp:113, agg_count.cpp:56)
 #pragma unroll
         for (int u = 0; u < N; ++u) {
@@ -255,7 +323,12 @@ __device__ __forceinline__ void agg_batch(const AggDesc &a, void *base, const ID
     const bool mx = a.kind == VXH_AGG_MAX;
     switch (a.kind) {
     case VXH_AGG_COUNT:
-        if (LDS) VXH_EACH((at_add<SCOPE, uint32_t>((uint32_t *)base + idx[u], 1u)))
+        if (LDS && PACK16) {
+            uint32_t old[N];
+            count16_issue<N>((uint32_t *)base, idx, keep, all_keep, old);
+            count16_settle<N>((uint32_t *)base, idx, old, c16);
+        }
+        else if (LDS) VXH_EACH((at_add<SCOPE, uint32_t>((uint32_t *)base + idx[u], 1u)))
         else VXH_EACH((at_add<SCOPE, unsigned long long>((unsigned long long *)base + idx[u], 1ull)))
         break;
     case VXH_AGG_SUM:
@@ -317,7 +390,9 @@ __device__ __forceinline__ void lds_init(const BinArgs &A, char *lds, uint64_t s
         const AggDesc &a = A.a[k];
         char *base = lds + a.lds_offset;
         const uint64_t ident = identity_bits(a.kind, a.cell);
-        if (lds_cell_size_dev(a.kind, a.cell) == 4) for (uint64_t c = threadIdx.x; c < slab_cells; c += blockDim.x) ((uint32_t *)base)[c] = (uint32_t)ident;
+        const size_t cs = lds_cell_size_dev(a.kind, a.cell, A.count16);
+        if (cs == 2) for (uint64_t c = threadIdx.x; c < (slab_cells + 1) / 2; c += blockDim.x) ((uint32_t *)base)[c] = 0u;
+        else if (cs == 4) for (uint64_t c = threadIdx.x; c < slab_cells; c += blockDim.x) ((uint32_t *)base)[c] = (uint32_t)ident;
         else for (uint64_t c = threadIdx.x; c < slab_cells; c += blockDim.x) ((uint64_t *)base)[c] = ident;
     }
 }
@@ -336,18 +411,52 @@ __device__ __forceinline__ void flush_minmax(T *g, T v, bool mx, bool plain) {
 
 // flush the LDS-private slab of every aggregator into replica `replica` of its HBM grid: plain
 // read-modify-write when this workgroup is the replica's only writer, device-scope atomics otherwise
+// exclusive owner, count / sum grids: U cells per lane per trip — all U HBM reads are in flight together, then the
+// U writes.  (One cell per trip makes the flush a chain of dependent HBM round trips: ~36 x 2.5 us of a 376 us
+// part_reduce launch, profiles/r01_chunk_fit.txt.)
+template <typename G, typename L, int U = 4>
+__device__ __forceinline__ void flush_add_plain(G *g, const L *lds_cells, uint64_t slab_cells, uint32_t slab_log2, uint32_t slab, uint64_t cells) {
+    for (uint64_t c0 = threadIdx.x; c0 < slab_cells; c0 += (uint64_t)U * blockDim.x) {
+        G cur[U];
+        L v[U];
+        uint64_t gc[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint64_t c = c0 + (uint64_t)u * blockDim.x;
+            const bool ok = c < slab_cells && ((c << slab_log2) + slab) < cells;
+            gc[u] = ok ? (c << slab_log2) + slab : slab; // (cell `slab` always exists; its v is forced to 0)
+            v[u] = ok ? lds_cells[c] : (L)0;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) cur[u] = g[gc[u]];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (v[u] != (L)0) g[gc[u]] = cur[u] + (G)v[u];
+    }
+}
+
 __device__ __forceinline__ void lds_flush(const BinArgs &A, char *lds, uint64_t slab_cells, uint32_t slab_log2, uint32_t slab, uint64_t replica, bool plain) {
     for (int k = 0; k < A.nagg; ++k) {
         const AggDesc &a = A.a[k];
         char *base = lds + a.lds_offset;
         char *g = (char *)a.grid + replica * A.cells * cell_size_dev(a.cell);
         const bool mx = a.kind == VXH_AGG_MAX;
+        if (plain && a.kind == VXH_AGG_COUNT) {
+            if (A.count16) flush_add_plain<unsigned long long, uint16_t>((unsigned long long *)g, (const uint16_t *)base, slab_cells, slab_log2, slab, A.cells);
+            else flush_add_plain<unsigned long long, uint32_t>((unsigned long long *)g, (const uint32_t *)base, slab_cells, slab_log2, slab, A.cells);
+            continue;
+        }
+        if (plain && (a.kind == VXH_AGG_SUM || a.kind == VXH_AGG_SUM_MOMENT)) {
+            if (a.cell == VXH_CELL_F64) flush_add_plain<double, double>((double *)g, (const double *)base, slab_cells, slab_log2, slab, A.cells);
+            else flush_add_plain<unsigned long long, unsigned long long>((unsigned long long *)g, (const unsigned long long *)base, slab_cells, slab_log2, slab, A.cells);
+            continue;
+        }
         for (uint64_t c = threadIdx.x; c < slab_cells; c += blockDim.x) {
             const uint64_t gc = (c << slab_log2) + slab;
             if (gc >= A.cells) continue;
             switch (a.kind) {
             case VXH_AGG_COUNT: {
-                const uint32_t v = ((uint32_t *)base)[c];
+                const uint32_t v = A.count16 ? (uint32_t)((uint16_t *)base)[c] : ((uint32_t *)base)[c];
                 if (v) {
                     if (plain) ((unsigned long long *)g)[gc] += v;
                     else at_add<__HIP_MEMORY_SCOPE_AGENT, unsigned long long>((unsigned long long *)g + gc, (unsigned long long)v);
@@ -384,6 +493,36 @@ __device__ __forceinline__ void lds_flush(const BinArgs &A, char *lds, uint64_t 
     }
 }
 
+// pass 2 of the partition strategy: LDS slab -> this (slab, part)'s block of the slot-private accumulators
+// (PartArgs::acc).  Always the exclusive owner, always contiguous.
+__device__ __forceinline__ void lds_flush_acc(const PartArgs &P, char *lds, uint64_t slab_cells, uint32_t slab, uint32_t part) {
+    const uint64_t block = ((uint64_t)part << P.slab_log2) + slab;
+    for (int k = 0; k < P.A.nagg; ++k) {
+        const AggDesc &a = P.A.a[k];
+        char *base = lds + a.lds_offset;
+        char *g = (char *)P.acc[k] + block * slab_cells * cell_size_dev(a.cell);
+        if (a.kind == VXH_AGG_COUNT) {
+            if (P.A.count16) flush_add_plain<unsigned long long, uint16_t>((unsigned long long *)g, (const uint16_t *)base, slab_cells, 0, 0, slab_cells);
+            else flush_add_plain<unsigned long long, uint32_t>((unsigned long long *)g, (const uint32_t *)base, slab_cells, 0, 0, slab_cells);
+        } else if (a.kind == VXH_AGG_SUM || a.kind == VXH_AGG_SUM_MOMENT) {
+            if (a.cell == VXH_CELL_F64) flush_add_plain<double, double>((double *)g, (const double *)base, slab_cells, 0, 0, slab_cells);
+            else flush_add_plain<unsigned long long, unsigned long long>((unsigned long long *)g, (const unsigned long long *)base, slab_cells, 0, 0, slab_cells);
+        } else {
+            const bool mx = a.kind == VXH_AGG_MAX;
+            for (uint64_t c = threadIdx.x; c < slab_cells; c += blockDim.x) {
+                switch (a.cell) {
+                case VXH_CELL_F64: flush_minmax<double>((double *)g + c, ((double *)base)[c], mx, true); break;
+                case VXH_CELL_F32: flush_minmax<float>((float *)g + c, ((float *)base)[c], mx, true); break;
+                case VXH_CELL_I64: flush_minmax<long long>((long long *)g + c, ((long long *)base)[c], mx, true); break;
+                case VXH_CELL_U64: flush_minmax<unsigned long long>((unsigned long long *)g + c, ((unsigned long long *)base)[c], mx, true); break;
+                case VXH_CELL_I32: flush_minmax<int>((int *)g + c, ((int *)base)[c], mx, true); break;
+                default: flush_minmax<unsigned>((unsigned *)g + c, ((unsigned *)base)[c], mx, true); break;
+                }
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // K1
 // ------------------------------------------------------------------------------------------
@@ -392,7 +531,7 @@ __device__ __forceinline__ void lds_flush(const BinArgs &A, char *lds, uint64_t 
 //   xcd = b & 7, local = b >> 3, slab = local & (S-1), group = (local >> slab_log2) * 8 + xcd.
 // (S > 1 re-reads every row S times — measured: no L2 sharing between the owners, profiles/r01_microbench_v2*
 //  — so the planner prefers the partition strategy; S > 1 stays as a selectable variant.)
-template <int STRAT, bool FAST>
+template <int STRAT, bool FAST, bool PACK16 = false>
 __global__ void __launch_bounds__(1024) bin_kernel(const BinArgs A) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr bool LDS = STRAT == VXH_STRAT_LDS;
@@ -416,6 +555,13 @@ __global__ void __launch_bounds__(1024) bin_kernel(const BinArgs A) {
     } else {
         replica = blockIdx.x % A.replicas;
     }
+
+    // packed counters, one aggregator (df.count(binby=...)): the previous batch's atomics are settled after this
+    // batch's loads
+    const bool defer = PACK16 && A.nagg == 1;
+    uint32_t pend_old[N], pend_idx[N];
+#pragma unroll
+    for (int u = 0; u < N; ++u) pend_old[u] = pend_idx[u] = 0;
 
     const uint64_t stride = (uint64_t)ngroups * blockDim.x;
     for (uint64_t i0 = (uint64_t)group * blockDim.x + threadIdx.x; i0 < A.n; i0 += N * stride) {
@@ -448,11 +594,31 @@ __global__ void __launch_bounds__(1024) bin_kernel(const BinArgs A) {
                 for (int u = 0; u < N; ++u) v[u] = 0;
             }
             void *base = LDS ? (void *)(lds + a.lds_offset) : (void *)((char *)a.grid + replica * A.cells * cell_size_dev(a.cell));
-            agg_batch<SCOPE, LDS, N>(a, base, idx, v, keep, has_data);
+            if (PACK16) {
+                const C16 c16{(unsigned long long *)a.grid + replica * A.cells, A.cells, (uint32_t)A.slab_log2, slab, 1u};
+                if (defer) {
+                    keep = count_keep<N>(a, v, keep, has_data);
+                    const bool all_keep = __ballot(keep != (1u << N) - 1u) == 0ull;
+                    count16_settle<N>((uint32_t *)base, pend_idx, pend_old, c16);
+#pragma unroll
+                    for (int u = 0; u < N; ++u) pend_idx[u] = (uint32_t)idx[u];
+                    count16_issue<N>((uint32_t *)base, pend_idx, keep, all_keep, pend_old);
+                } else {
+                    agg_batch<SCOPE, LDS, N, true>(a, base, idx, v, keep, has_data, c16);
+                }
+            } else {
+                agg_batch<SCOPE, LDS, N>(a, base, idx, v, keep, has_data);
+            }
         }
     }
 
     if (LDS) {
+        if (defer) {
+            const AggDesc &a = A.a[0];
+            const C16 c16{(unsigned long long *)a.grid + replica * A.cells, A.cells, (uint32_t)A.slab_log2, slab, 1u};
+            count16_settle<N>((uint32_t *)(lds + a.lds_offset), pend_idx, pend_old, c16);
+        }
+        if (PACK16) __threadfence(); // wrap repairs (device atomics) land before the replica is flushed into
         __syncthreads();
         lds_flush(A, lds, slab_cells, A.slab_log2, slab, replica, A.flush_plain != 0);
     }
@@ -462,8 +628,8 @@ __global__ void __launch_bounds__(1024) bin_kernel(const BinArgs A) {
 // K1b / K1c — partition strategy (see PartArgs)
 // ------------------------------------------------------------------------------------------
 // all aggregators over N records whose mask flags and canonical inputs are in registers
-template <int SCOPE, bool LDS, int N, typename IDX>
-__device__ __forceinline__ void records_apply(const PartArgs &P, char *lds, const IDX (&idx)[N], const uint32_t (&flags)[N], const uint64_t (&vals)[VXH_PART_MAX_VALS][N], uint32_t valid, uint64_t replica = 0) {
+template <int SCOPE, bool LDS, int N, bool PACK16 = false, typename IDX>
+__device__ __forceinline__ void records_apply(const PartArgs &P, char *lds, const IDX (&idx)[N], const uint32_t (&flags)[N], const uint64_t (&vals)[VXH_PART_MAX_VALS][N], uint32_t valid, uint64_t replica = 0, uint32_t slab = 0) {
     for (int k = 0; k < P.A.nagg; ++k) {
         const AggDesc &a = P.A.a[k];
         uint32_t keep = valid;
@@ -478,7 +644,12 @@ __device__ __forceinline__ void records_apply(const PartArgs &P, char *lds, cons
 #pragma unroll
         for (int u = 0; u < N; ++u) v[u] = vs == 0 ? vals[0][u] : (vs == 1 ? vals[1][u] : (vs == 2 ? vals[2][u] : (vs == 3 ? vals[3][u] : 0)));
         void *base = LDS ? (void *)(lds + a.lds_offset) : (void *)((char *)a.grid + replica * P.A.cells * cell_size_dev(a.cell));
-        agg_batch<SCOPE, LDS, N>(a, base, idx, v, keep, vs != 0xffu);
+        if (PACK16) {
+            const C16 c16{(unsigned long long *)a.grid + replica * P.A.cells, P.A.cells, (uint32_t)P.slab_log2, slab, 1u};
+            agg_batch<SCOPE, LDS, N, true>(a, base, idx, v, keep, vs != 0xffu, c16);
+        } else {
+            agg_batch<SCOPE, LDS, N>(a, base, idx, v, keep, vs != 0xffu);
+        }
     }
 }
 
@@ -588,7 +759,7 @@ __device__ __forceinline__ void scatter_copy_out(const PartArgs &P, const Scatte
             uint64_t v1[VXH_PART_MAX_VALS][1];
 #pragma unroll
             for (int k = 0; k < VXH_PART_MAX_VALS; ++k) v1[k][0] = k < P.nvals ? L.st_val[(size_t)k * T + j] : 0;
-            records_apply<__HIP_MEMORY_SCOPE_AGENT, false, 1>(P, nullptr, gidx, f1, v1, 1u, P.A.flush_plain ? (uint64_t)P.parts : 0);
+            records_apply<__HIP_MEMORY_SCOPE_AGENT, false, 1>(P, nullptr, gidx, f1, v1, 1u, 0);
         }
     }
 }
@@ -679,13 +850,119 @@ __device__ __forceinline__ uint32_t scalar_sub_index32(double v, double vmin, do
     return scaled >= 0 ? inside : (scaled < 0 ? 1u : 0u);
 }
 
+// K1d — df.count(binby=<1..3 float64 columns>[, selection]) on a grid whose private copy fits one workgroup's LDS:
+// ONE aggregator, count(*), at most one mask.  Same LDS-private strategy and geometry as bin_kernel<LDS> with
+// S = 1, but everything is static: the columns of tile t+1 are requested (R loads per dimension per lane in
+// flight) before tile t is binned, the sub-index is the 32-bit form, and with PACK16 the previous tile's
+// returning atomics are settled a whole tile later.  bin_kernel spends 314 VALU + 77 scalar instructions per
+// 4 rows on this case (profiles/r01_pmc_count16.txt) and keeps only one dimension's loads in flight at a time.
+template <int NDIM, bool PACK16, bool MASKED>
+__global__ void __launch_bounds__(1024) count_lds_f64(const BinArgs A) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    constexpr int R = 4;
+    const uint64_t n = A.n;
+    const uint64_t T = (uint64_t)blockDim.x * R;
+    uint64_t tile = blockIdx.x;
+    if (tile * T >= n) return; // nothing to add: the replica keeps its identity
+    const uint64_t replica = A.flush_plain ? blockIdx.x : blockIdx.x % (uint32_t)A.replicas;
+    lds_init(A, lds, A.cells);
+    const AggDesc &a = A.a[0];
+    uint32_t *base = (uint32_t *)(lds + a.lds_offset);
+    const uint8_t *mask = a.mask;
+    const C16 c16{(unsigned long long *)a.grid + replica * A.cells, A.cells, 0u, 0u, 1u};
+    __syncthreads();
+
+    struct Raw {
+        double b[NDIM][R];
+        uint8_t m[R];
+        uint32_t valid;
+    };
+    auto request = [&](uint64_t t, Raw &raw) {
+        const Rows<R> rows = make_rows<R>(t * T + threadIdx.x, blockDim.x, n);
+        raw.valid = rows.valid;
+#pragma unroll
+        for (int d = 0; d < NDIM; ++d) {
+            const double *col = (const double *)A.b[d].data;
+#pragma unroll
+            for (int r = 0; r < R; ++r) raw.b[d][r] = col[rows.i[r]];
+        }
+        if (MASKED) { // (a template parameter: a conditional load makes the waitcnt pass give up on the loop)
+#pragma unroll
+            for (int r = 0; r < R; ++r) raw.m[r] = mask[rows.i[r]];
+        }
+    };
+
+    uint32_t pend_old[R], pend_idx[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) pend_old[r] = pend_idx[r] = 0;
+    auto process = [&](const Raw &cur) {
+        uint32_t keep = cur.valid;
+        if (MASKED) { // aggregator mask: 1 = keep (src/agg_count.cpp:50)
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                if (cur.m[r] != 1) keep &= ~(1u << r);
+        }
+        uint32_t idx[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            idx[r] = 0;
+#pragma unroll
+            for (int d = 0; d < NDIM; ++d) {
+                const BinnerDesc &b = A.b[d];
+                idx[r] += scalar_sub_index32(cur.b[d][r], b.vmin, b.scale, b.binsd, (uint32_t)b.bins) * (uint32_t)b.stride;
+            }
+        }
+        const bool all_keep = __ballot(keep != (1u << R) - 1u) == 0ull;
+        if (PACK16) {
+            count16_settle<R>(base, pend_idx, pend_old, c16);
+#pragma unroll
+            for (int r = 0; r < R; ++r) pend_idx[r] = idx[r];
+            count16_issue<R>(base, pend_idx, keep, all_keep, pend_old);
+        } else if (all_keep) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) at_add<__HIP_MEMORY_SCOPE_WORKGROUP, uint32_t>(base + idx[r], 1u);
+        } else {
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                if ((keep >> r) & 1u) at_add<__HIP_MEMORY_SCOPE_WORKGROUP, uint32_t>(base + idx[r], 1u);
+        }
+    };
+    // two register buffers in ping-pong, the loop unrolled by two so that neither is ever copied: a `cur = nxt`
+    // copy makes the register allocator wait for ALL loads in flight before it forms the next addresses
+    // (seen in the ISA: s_waitcnt vmcnt(0) ahead of the next tile's global_loads), i.e. no overlap at all
+    Raw bufA, bufB;
+    request(tile, bufA);
+    for (;;) {
+        uint64_t next = tile + gridDim.x;
+        bool has_next = next * T < n;
+        request(has_next ? next : tile, bufB); // (the last tile re-requests itself: static number of loads in flight)
+        process(bufA);
+        if (!has_next) break;
+        tile = next;
+        next = tile + gridDim.x;
+        has_next = next * T < n;
+        request(has_next ? next : tile, bufA);
+        process(bufB);
+        if (!has_next) break;
+        tile = next;
+    }
+    if (PACK16) {
+        count16_settle<R>(base, pend_idx, pend_old, c16);
+        __threadfence(); // wrap repairs (device atomics) land before the replica is flushed into
+    }
+    __syncthreads();
+    lds_flush(A, lds, A.cells, 0, 0, replica, A.flush_plain != 0);
+}
+
 // software-pipelined version for the common case — NDIM (1..3) scalar float64 native unmasked binners, NVAL (0..2)
 // float64 native aggregator inputs, at most one aggregator mask.  Two things overlap with the next tile's work:
 //  * the raw columns of tile t+1 are requested right after barrier 2 of tile t;
 //  * the queue-space reservation of tile t (an HBM atomic: a multi-microsecond round trip) is only consumed in
 //    iteration t+1 — the staging area is double-buffered and tile t's records are copied out one iteration
 //    later, so no lane ever waits for that round trip (measured: ~300 us of a 950 us pass-1 launch otherwise).
-template <int NDIM, int NVAL, int R>
+// KEY = 1: ONE ordinal binner over a native unmasked int64 column instead (df.groupby on an integer key): the
+// 8 bytes of a row are loaded the same way and only the sub-index expression differs.
+template <int NDIM, int NVAL, int R, int KEY = 0>
 __global__ void __launch_bounds__(512) part_scatter_f64(const PartArgs P) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const uint32_t S = 1u << P.slab_log2;
@@ -754,7 +1031,15 @@ __global__ void __launch_bounds__(512) part_scatter_f64(const PartArgs P) {
 #pragma unroll
             for (int d = 0; d < NDIM; ++d) {
                 const BinnerDesc &b = P.A.b[d];
-                idx += scalar_sub_index32(cur.b[d][r], b.vmin, b.scale, b.binsd, (uint32_t)b.bins) * (uint32_t)b.stride;
+                if (KEY == 1) { // src/binner_ordinal.cpp:138-175 without mask: out of range -> cell N (null / other)
+                    const int64_t value = (int64_t)((uint64_t)__double_as_longlong(cur.b[d][r]) - (uint64_t)b.min_value);
+                    const int64_t nord = (int64_t)b.bins;
+                    const bool oob = value < 0 || value >= nord;
+                    const uint32_t sub = oob ? (uint32_t)nord : (uint32_t)(b.invert ? nord - 1 - value : value);
+                    idx += sub * (uint32_t)b.stride;
+                } else {
+                    idx += scalar_sub_index32(cur.b[d][r], b.vmin, b.scale, b.binsd, (uint32_t)b.bins) * (uint32_t)b.stride;
+                }
             }
             slab[r] = idx & (S - 1);
             loc[r] = idx >> P.slab_log2;
@@ -808,8 +1093,8 @@ __global__ void __launch_bounds__(512) part_scatter_f64(const PartArgs P) {
 
 // pass 2: slab queues -> LDS-private slab -> HBM replica.  Each lane streams 4 consecutive records per
 // vector load and keeps N4 such batches in flight.
-template <int N4>
-__device__ __forceinline__ void reduce_trip(const PartArgs &P, char *lds, uint64_t at, uint64_t step) {
+template <int N4, bool PACK16>
+__device__ __forceinline__ void reduce_trip(const PartArgs &P, char *lds, uint64_t at, uint64_t step, uint64_t replica, uint32_t slab) {
     constexpr int N = 4 * N4;
     uint32_t loc[N], flags[N];
     uint64_t vals[VXH_PART_MAX_VALS][N];
@@ -837,9 +1122,10 @@ __device__ __forceinline__ void reduce_trip(const PartArgs &P, char *lds, uint64
             }
         }
     }
-    records_apply<__HIP_MEMORY_SCOPE_WORKGROUP, true, N>(P, lds, loc, flags, vals, (1u << N) - 1u);
+    records_apply<__HIP_MEMORY_SCOPE_WORKGROUP, true, N, PACK16>(P, lds, loc, flags, vals, (1u << N) - 1u, replica, slab);
 }
 
+template <bool PACK16>
 __global__ void __launch_bounds__(1024) part_reduce(const PartArgs P) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const uint32_t S = 1u << P.slab_log2;
@@ -856,20 +1142,21 @@ __global__ void __launch_bounds__(1024) part_reduce(const PartArgs P) {
     const uint64_t qb = (uint64_t)sub * P.cap;
     const uint64_t hi4 = lo + ((hi - lo) & ~(uint64_t)3);
     const uint64_t step = 4ull * blockDim.x;
+    const uint64_t replica = 0; // (HBM grid replica for the rare device-atomic repairs; the slab itself goes to P.acc)
     uint64_t j = lo + 4ull * threadIdx.x;
-    for (; j + step < hi4; j += 2 * step) reduce_trip<2>(P, lds, qb + j, step);
-    for (; j < hi4; j += step) reduce_trip<1>(P, lds, qb + j, step);
+    for (; j + step < hi4; j += 2 * step) reduce_trip<2, PACK16>(P, lds, qb + j, step, replica, slab);
+    for (; j < hi4; j += step) reduce_trip<1, PACK16>(P, lds, qb + j, step, replica, slab);
     for (uint64_t t = hi4 + threadIdx.x; t < hi; t += blockDim.x) { // tail (< 4 records)
         uint32_t loc[1] = {P.idx16 ? (uint32_t)((const uint16_t *)P.qidx)[qb + t] : ((const uint32_t *)P.qidx)[qb + t]};
         uint32_t fl[1] = {P.use_flags ? (uint32_t)P.qflags[qb + t] : 0xffu};
         uint64_t v1[VXH_PART_MAX_VALS][1];
 #pragma unroll
         for (int k = 0; k < VXH_PART_MAX_VALS; ++k) v1[k][0] = k < P.nvals ? P.qval[k][qb + t] : 0;
-        records_apply<__HIP_MEMORY_SCOPE_WORKGROUP, true, 1>(P, lds, loc, fl, v1, 1u);
+        records_apply<__HIP_MEMORY_SCOPE_WORKGROUP, true, 1, PACK16>(P, lds, loc, fl, v1, 1u, replica, slab);
     }
+    if (PACK16) __threadfence();
     __syncthreads();
-    const uint64_t replica = P.A.flush_plain ? part : part % (uint32_t)P.A.replicas;
-    lds_flush(P.A, lds, slab_cells, P.slab_log2, slab, replica, P.A.flush_plain != 0);
+    lds_flush_acc(P, lds, slab_cells, slab, part);
 }
 
 // pass 2, specialised: NAGG (1..4) aggregators, each count / sum / sum-moment on float64 inputs (or count(*)),
@@ -966,6 +1253,7 @@ __global__ void __launch_bounds__(1024) part_reduce_fast(const PartArgs P) {
     const uint64_t qb = (uint64_t)sub * P.cap;
     const uint64_t hi4 = lo + ((hi - lo) & ~(uint64_t)3);
     const uint64_t step = 4ull * blockDim.x;
+    const uint64_t replica = 0; // (HBM grid replica for the rare device-atomic repairs; the slab itself goes to P.acc)
     uint64_t j = lo + 4ull * threadIdx.x;
     for (; j + step < hi4; j += 2 * step) reduce_trip_fast<NAGG, 2>(P, lds, qb + j, step, off, kind, vs, mom);
     for (; j < hi4; j += step) reduce_trip_fast<NAGG, 1>(P, lds, qb + j, step, off, kind, vs, mom);
@@ -975,11 +1263,64 @@ __global__ void __launch_bounds__(1024) part_reduce_fast(const PartArgs P) {
         uint64_t v1[VXH_PART_MAX_VALS][1];
 #pragma unroll
         for (int k = 0; k < VXH_PART_MAX_VALS; ++k) v1[k][0] = k < P.nvals ? P.qval[k][qb + t] : 0;
-        records_apply<__HIP_MEMORY_SCOPE_WORKGROUP, true, 1>(P, lds, loc, fl, v1, 1u);
+        records_apply<__HIP_MEMORY_SCOPE_WORKGROUP, true, 1>(P, lds, loc, fl, v1, 1u, replica, slab);
     }
-    __syncthreads();
-    const uint64_t replica = P.A.flush_plain ? part : part % (uint32_t)P.A.replicas;
-    lds_flush(P.A, lds, slab_cells, P.slab_log2, slab, replica, P.A.flush_plain != 0);
+    __syncthreads(); // (never launched with count16: its LDS counts are uint32)
+    lds_flush_acc(P, lds, slab_cells, slab, part);
+}
+
+// K1e — once per vxh_grid_bin call on the partition strategy: fold the `parts` accumulator blocks of every
+// (aggregator, cell) into the aggregator's grid (replica 0) and put the identity back, so that the next call finds
+// clean accumulators.  Threads walk the accumulator layout (slab-major: coalesced reads of all parts); the write
+// into the grid is strided by S cells, once per cell.
+template <typename T, int OP>
+__device__ __forceinline__ void merge_cell(T *acc, uint64_t plane, int parts, T ident, T *out, bool live, bool atomic) {
+    T v = ident;
+    for (int p = 0; p < parts; ++p) {
+        const T x = acc[(uint64_t)p * plane];
+        acc[(uint64_t)p * plane] = ident;
+        v = OP == 0 ? (T)(v + x) : (OP == 1 ? (x < v ? x : v) : (x > v ? x : v));
+    }
+    if (!live || v == ident) return; // (a NaN sum is != ident and is written; min/max cells are never NaN)
+    if (atomic) {
+        if (OP == 0) at_add<__HIP_MEMORY_SCOPE_AGENT, T>(out, v);
+        else if (OP == 1) at_min<__HIP_MEMORY_SCOPE_AGENT, T>(out, v);
+        else at_max<__HIP_MEMORY_SCOPE_AGENT, T>(out, v);
+    } else {
+        const T cur = *out;
+        *out = OP == 0 ? (T)(cur + v) : (OP == 1 ? (v < cur ? v : cur) : (v > cur ? v : cur));
+    }
+}
+
+__global__ void __launch_bounds__(256) part_merge(const PartMergeArgs M) {
+    const uint64_t plane = M.slab_cells << M.slab_log2; // cells of one part
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < plane; t += stride) {
+        const uint64_t slab = t / M.slab_cells, local = t - slab * M.slab_cells;
+        const uint64_t c = (local << M.slab_log2) + slab;
+        const bool live = c < M.cells;
+        for (int k = 0; k < M.nagg; ++k) {
+            const int op = M.kind[k] == VXH_AGG_MIN ? 1 : (M.kind[k] == VXH_AGG_MAX ? 2 : 0);
+            const uint64_t cc = live ? c : 0;
+#define VXH_MERGE(T)                                                                                                   \
+    {                                                                                                                  \
+        T ident;                                                                                                       \
+        memcpy(&ident, &M.ident[k], sizeof(T));                                                                        \
+        if (op == 0) merge_cell<T, 0>((T *)M.acc[k] + t, plane, M.parts, ident, (T *)M.grid[k] + cc, live, M.atomic != 0); \
+        else if (op == 1) merge_cell<T, 1>((T *)M.acc[k] + t, plane, M.parts, ident, (T *)M.grid[k] + cc, live, M.atomic != 0); \
+        else merge_cell<T, 2>((T *)M.acc[k] + t, plane, M.parts, ident, (T *)M.grid[k] + cc, live, M.atomic != 0);  \
+    }
+            switch (M.cell[k]) {
+            case VXH_CELL_F64: VXH_MERGE(double) break;
+            case VXH_CELL_F32: VXH_MERGE(float) break;
+            case VXH_CELL_I64: VXH_MERGE(long long) break;
+            case VXH_CELL_U64: VXH_MERGE(unsigned long long) break;
+            case VXH_CELL_I32: VXH_MERGE(int) break;
+            default: VXH_MERGE(unsigned) break;
+            }
+#undef VXH_MERGE
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1076,10 +1417,11 @@ __global__ void __launch_bounds__(256) minmax_kernel(int dtype, int flip, const 
 } // namespace
 
 size_t vxh_cell_size(int cell) { return cell >= VXH_CELL_F32 ? 4 : 8; }
-size_t vxh_lds_cell_size(int kind, int cell) { return kind == VXH_AGG_COUNT ? 4 : vxh_cell_size(cell); }
+size_t vxh_lds_cell_size(int kind, int cell, int count16) { return kind == VXH_AGG_COUNT ? (count16 ? 2 : 4) : vxh_cell_size(cell); }
 
-void vxh_launch_part_scatter(const PartArgs &args, bool fast_f64, int scatter_blocks, size_t scatter_lds, hipStream_t stream) {
+void vxh_launch_part_scatter(const PartArgs &args, const LaunchPlan &plan, int scatter_blocks, size_t scatter_lds, hipStream_t stream) {
     const int R = args.rows_per_thread;
+    const bool fast_f64 = plan.fast_f64;
 #define VXH_SC(KERNEL)                                                                                                 \
     do {                                                                                                               \
         if (scatter_lds > 48 * 1024) (void)hipFuncSetAttribute((const void *)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, (int)scatter_lds); \
@@ -1097,6 +1439,16 @@ void vxh_launch_part_scatter(const PartArgs &args, bool fast_f64, int scatter_bl
         else if (args.A.ndim == 2) VXH_SCN(2);
         else VXH_SCN(3);
 #undef VXH_SCN
+    } else if (plan.key_i64 && plan.fast_vals && (R == 4 || R == 8) && args.nvals <= 2 && args.nmasks <= 1 && !(args.no_pipeline & 1)) {
+        scatter_lds = 2 * (size_t)args.scatter_lds_one;
+#define VXH_SCK(RR)                                                                                                    \
+    do {                                                                                                               \
+        if (args.nvals == 0) VXH_SC((part_scatter_f64<1, 0, RR, 1>));                                                  \
+        else if (args.nvals == 1) VXH_SC((part_scatter_f64<1, 1, RR, 1>));                                             \
+        else VXH_SC((part_scatter_f64<1, 2, RR, 1>));                                                                  \
+    } while (0)
+        if (R == 8) VXH_SCK(8); else VXH_SCK(4);
+#undef VXH_SCK
     } else if (fast_f64) {
         if (R == 8) VXH_SC((part_scatter<true, 8>)); else if (R == 4) VXH_SC((part_scatter<true, 4>)); else VXH_SC((part_scatter<true, 2>));
     } else {
@@ -1107,7 +1459,7 @@ void vxh_launch_part_scatter(const PartArgs &args, bool fast_f64, int scatter_bl
 
 void vxh_launch_part_reduce(const PartArgs &args, const LaunchPlan &plan, hipStream_t stream) {
     // specialised kernel: count / sum / sum-moment over float64 inputs, no record flags, uint16 indices
-    bool fast = plan.fast_f64 && !args.use_flags && args.idx16 && args.nvals <= 2 && args.A.nagg >= 1 && args.A.nagg <= 4 && !(args.no_pipeline & 16);
+    bool fast = plan.fast_vals && !args.use_flags && args.idx16 && args.nvals <= 2 && args.A.nagg >= 1 && args.A.nagg <= 4 && !(args.no_pipeline & 16) && !args.A.count16;
     for (int k = 0; fast && k < args.A.nagg; ++k) {
         const AggDesc &a = args.A.a[k];
         if (args.agg_mbit[k] != 0xff) fast = false;
@@ -1119,7 +1471,8 @@ void vxh_launch_part_reduce(const PartArgs &args, const LaunchPlan &plan, hipStr
         if (plan.lds_bytes > 48 * 1024) (void)hipFuncSetAttribute((const void *)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds_bytes); \
         hipLaunchKernelGGL(KERNEL, dim3(plan.blocks), dim3(plan.block), plan.lds_bytes, stream, args);                 \
     } while (0)
-    if (!fast) VXH_RD(part_reduce);
+    if (!fast && args.A.count16) VXH_RD(part_reduce<true>);
+    else if (!fast) VXH_RD(part_reduce<false>);
     else if (args.A.nagg == 1) VXH_RD(part_reduce_fast<1>);
     else if (args.A.nagg == 2) VXH_RD(part_reduce_fast<2>);
     else if (args.A.nagg == 3) VXH_RD(part_reduce_fast<3>);
@@ -1129,15 +1482,42 @@ void vxh_launch_part_reduce(const PartArgs &args, const LaunchPlan &plan, hipStr
 
 void vxh_launch_bin(const BinArgs &args, const LaunchPlan &plan, hipStream_t stream) {
     dim3 g(plan.blocks), b(plan.block);
-#define VXH_LAUNCH(S, F)                                                                                               \
+#define VXH_LAUNCH(...)                                                                                                \
     do {                                                                                                               \
-        if (plan.lds_bytes > 48 * 1024) (void)hipFuncSetAttribute((const void *)bin_kernel<S, F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds_bytes); \
-        hipLaunchKernelGGL((bin_kernel<S, F>), g, b, plan.lds_bytes, stream, args);                                    \
+        if (plan.lds_bytes > 48 * 1024) (void)hipFuncSetAttribute((const void *)bin_kernel<__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds_bytes); \
+        hipLaunchKernelGGL((bin_kernel<__VA_ARGS__>), g, b, plan.lds_bytes, stream, args);                             \
     } while (0)
-    if (plan.strategy == VXH_STRAT_LDS) { if (plan.fast_f64) VXH_LAUNCH(VXH_STRAT_LDS, true); else VXH_LAUNCH(VXH_STRAT_LDS, false); }
+    if (plan.count_fast) {
+#define VXH_CNT(ND)                                                                                                    \
+    do {                                                                                                               \
+        if (args.a[0].mask) {                                                                                          \
+            if (args.count16) VXH_LAUNCH_K((count_lds_f64<ND, true, true>)); else VXH_LAUNCH_K((count_lds_f64<ND, false, true>)); \
+        } else {                                                                                                       \
+            if (args.count16) VXH_LAUNCH_K((count_lds_f64<ND, true, false>)); else VXH_LAUNCH_K((count_lds_f64<ND, false, false>)); \
+        }                                                                                                              \
+    } while (0)
+#define VXH_LAUNCH_K(KERNEL)                                                                                           \
+    do {                                                                                                               \
+        if (plan.lds_bytes > 48 * 1024) (void)hipFuncSetAttribute((const void *)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds_bytes); \
+        hipLaunchKernelGGL(KERNEL, g, b, plan.lds_bytes, stream, args);                                                \
+    } while (0)
+        if (args.ndim == 1) VXH_CNT(1); else if (args.ndim == 2) VXH_CNT(2); else VXH_CNT(3);
+#undef VXH_LAUNCH_K
+#undef VXH_CNT
+    }
+    else if (plan.strategy == VXH_STRAT_LDS && args.count16) { if (plan.fast_f64) VXH_LAUNCH(VXH_STRAT_LDS, true, true); else VXH_LAUNCH(VXH_STRAT_LDS, false, true); }
+    else if (plan.strategy == VXH_STRAT_LDS) { if (plan.fast_f64) VXH_LAUNCH(VXH_STRAT_LDS, true); else VXH_LAUNCH(VXH_STRAT_LDS, false); }
     else if (plan.strategy == VXH_STRAT_XCC) { if (plan.fast_f64) VXH_LAUNCH(VXH_STRAT_XCC, true); else VXH_LAUNCH(VXH_STRAT_XCC, false); }
     else { if (plan.fast_f64) VXH_LAUNCH(VXH_STRAT_GLOBAL, true); else VXH_LAUNCH(VXH_STRAT_GLOBAL, false); }
 #undef VXH_LAUNCH
+}
+
+void vxh_launch_part_merge(const PartMergeArgs &args, hipStream_t stream) {
+    const uint64_t plane = args.slab_cells << args.slab_log2;
+    uint64_t blocks = (plane + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks == 0) blocks = 1;
+    hipLaunchKernelGGL(part_merge, dim3((unsigned)blocks), dim3(256), 0, stream, args);
 }
 
 void vxh_launch_fill(void *dst, uint64_t ncells, int cell, const void *value8, hipStream_t stream) {

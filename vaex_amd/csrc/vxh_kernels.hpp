@@ -50,7 +50,7 @@ struct BinArgs {
     int32_t slab_log2;       // LDS strategy: the grid is cut into S = 2^slab_log2 interleaved slabs (cell & (S-1))
     int32_t ngroups;         // LDS strategy: gridDim.x = ngroups * S; the S workgroups of a group read the same rows
     int32_t flush_plain;     // LDS strategy: flush with plain read-add-write into replica `group` (exclusive owner)
-    int32_t reserved_;
+    int32_t count16;         // LDS copies of count grids are packed 16-bit halves (every aggregator is a count)
     BinnerDesc b[VXH_MAX_DIM];
     AggDesc a[VXH_MAX_AGG];
 };
@@ -94,6 +94,21 @@ struct PartArgs {
     void *qidx;                     // [S][cap] uint16 / uint32
     uint8_t *qflags;                // [S][cap]
     uint64_t *qval[VXH_PART_MAX_VALS]; // [S][cap]
+    // slot-private partition accumulators, one per aggregator, laid out [part][slab][local] in the HBM cell type:
+    // pass 2 flushes its LDS slab into acc[k] + (part*S + slab)*slab_cells with contiguous, exclusive
+    // read-modify-writes; part_merge folds the parts into the aggregator's grid once per vxh_grid_bin call.
+    // (Flushing straight into grid replicas touches one 64-128 B line per 8 B cell — the slabs interleave — which
+    //  was ~130 us of every part_reduce launch: profiles/r01_chunk_fit.txt.)
+    void *acc[VXH_MAX_AGG];
+};
+
+struct PartMergeArgs {
+    uint64_t cells, slab_cells;
+    int32_t slab_log2, parts, nagg, atomic; // atomic: other slots may be adding into the same grids
+    void *acc[VXH_MAX_AGG];
+    void *grid[VXH_MAX_AGG];
+    uint64_t ident[VXH_MAX_AGG]; // identity bit pattern of the HBM cell
+    uint8_t kind[VXH_MAX_AGG], cell[VXH_MAX_AGG];
 };
 
 struct LaunchPlan {
@@ -102,18 +117,28 @@ struct LaunchPlan {
     int blocks;    // workgroups
     size_t lds_bytes;
     int use_replicas; // replicas [0, use_replicas) are written by this launch
+    bool fast_vals;  // every aggregator input is float64 native (or absent)
+    bool key_i64;    // ONE ordinal binner over a native unmasked int64 column (groupby on an integer key)
+    bool count_fast; // launch K1d (count_lds_f64) instead of bin_kernel<LDS>
     bool fast_f64; // all binners scalar f64 native unmasked, all aggregator inputs f64 native / absent
     const char *name;
 };
 
+// K1d (count_lds_f64) serves: LDS strategy, one slab, float64 fast path, 1..3 dims, ONE count(*) aggregator
+inline bool vxh_count_fast(const BinArgs &a, const LaunchPlan &p) {
+    return p.strategy == VXH_STRAT_LDS && p.fast_f64 && a.slab_log2 == 0 && a.ndim >= 1 && a.ndim <= 3 && a.nagg == 1 &&
+           a.a[0].kind == VXH_AGG_COUNT && a.a[0].data == nullptr;
+}
+
 // implemented in vxh_kernels.hip
-void vxh_launch_part_scatter(const PartArgs &args, bool fast_f64, int scatter_blocks, size_t scatter_lds, hipStream_t stream);
+void vxh_launch_part_scatter(const PartArgs &args, const LaunchPlan &plan, int scatter_blocks, size_t scatter_lds, hipStream_t stream);
 void vxh_launch_part_reduce(const PartArgs &args, const LaunchPlan &plan, hipStream_t stream);
 void vxh_launch_bin(const BinArgs &args, const LaunchPlan &plan, hipStream_t stream);
+void vxh_launch_part_merge(const PartMergeArgs &args, hipStream_t stream);
 void vxh_launch_fill(void *dst, uint64_t ncells, int cell, const void *value8, hipStream_t stream);
 // dst[c] = fold(replica_0[c] .. replica_{R-1}[c]); replicas 1.. are reset to the identity
 void vxh_launch_fold(void *grid, uint64_t cells, int replicas, int cell, int kind, const void *identity8, hipStream_t stream);
 void vxh_launch_minmax_int(int dtype, int flip, const void *data, const uint8_t *mask, uint64_t n, long long *out2_dev, hipStream_t stream);
 void vxh_launch_minmax(int dtype, int flip, const void *data, const uint8_t *mask, uint64_t n, double *out2_dev, hipStream_t stream);
 size_t vxh_cell_size(int cell);
-size_t vxh_lds_cell_size(int kind, int cell);
+size_t vxh_lds_cell_size(int kind, int cell, int count16 = 0);

@@ -1,0 +1,118 @@
+"""Legacy `vaex.vaexfast.statisticNd_f8` on the GPU.
+
+vaexfast.cpp:1361-1510 is the Python entry, :1168-1278 the row loop, :1062-1164 the per-cell ops.  The legacy task
+(vaex/cpu.py:510-610, TaskPartStatistic) calls
+    statisticNd_f8(blocks, weights, grid, minima, maxima, op_code, use_edges)
+once per chunk with `grid` a float64 array of shape (size_0, ..., size_{d-1}, fields) that it accumulates INTO.
+
+Nothing here computes on the host: every op is a fused pass of the same HIP kernels that serve vaex.superagg
+(BinnerScalar cells are a superset of statisticNd's: the interior cells use the identical expression
+`(int)(scaled * bins)`, vaexfast.cpp:1227-1229 vs agg.hpp BinnerScalar; use_edges=1 IS the BinnerScalar layout,
+vaexfast.cpp:1189-1209), followed by a cell-wise fold into the caller's grid:
+
+    OP_ADD1 (0)                 grid[...,0] += count(*)
+    OP_COUNT (1)                grid[...,0] += count(weights[0])            (NaN weights skipped, :1069-1075)
+    OP_MIN_MAX (2)              grid[...,0] = min(grid[...,0], min(w)); grid[...,1] = max(..)   (:1090-1101)
+    OP_ADD_WEIGHT_MOMENTS_01 (3)   count, sum
+    OP_ADD_WEIGHT_MOMENTS_012 (4)  count, sum, sum of squares
+OP_COV (5) and OP_FIRST (6) are not built (no caller on the binby/groupby path) and raise.
+float64 blocks only: the _f4 variant scales in float32 and is not offered rather than approximated."""
+import numpy as np
+
+from . import superagg as _sa
+
+OP_ADD1, OP_COUNT, OP_MIN_MAX, OP_ADD_WEIGHT_MOMENTS_01, OP_ADD_WEIGHT_MOMENTS_012, OP_COV, OP_FIRST = range(7)
+_FIELDS = {OP_ADD1: 1, OP_COUNT: 1, OP_MIN_MAX: 2, OP_ADD_WEIGHT_MOMENTS_01: 2, OP_ADD_WEIGHT_MOMENTS_012: 3}
+
+
+def _is_device(a):
+    return hasattr(a, "__cuda_array_interface__") and not isinstance(a, np.ndarray)
+
+
+def _f8(a, what):
+    if _is_device(a):
+        if a.__cuda_array_interface__["typestr"] not in ("<f8", ">f8"):
+            raise TypeError(f"statisticNd_f8: {what} must be float64")
+        return a
+    a = np.asarray(a)
+    if a.dtype.kind != "f" or a.dtype.itemsize != 8:
+        raise TypeError(f"statisticNd_f8: {what} must be float64, not {a.dtype}")
+    if a.ndim != 1:
+        raise ValueError(f"statisticNd_f8: {what} must be 1-dimensional")
+    return np.ascontiguousarray(a)
+
+
+def _postfix(a):
+    if _is_device(a):
+        return "float64" if a.__cuda_array_interface__["typestr"] == "<f8" else "float64_non_native"
+    return "float64" if a.dtype.isnative else "float64_non_native"
+
+
+def statisticNd_f8(blocks, weights, grid, minima, maxima, op_code, use_edges=0):
+    """Accumulates one chunk into `grid` (in place); returns None like the reference."""
+    if not isinstance(blocks, (list, tuple)):
+        raise ValueError("statisticNd_: blocklist (first argument) is not a list")
+    if op_code in (OP_COV, OP_FIRST):
+        raise NotImplementedError("statisticNd: OP_COV / OP_FIRST are outside the binned-statistics path built here")
+    if op_code not in _FIELDS:
+        raise ValueError(f"statisticNd_wrap_template_endian: unknown op code {op_code} for statistic")
+    blocks = [_f8(b, "block") for b in blocks]
+    nd = len(blocks)
+    if weights is None:
+        wlist = []
+    elif isinstance(weights, (list, tuple)):
+        wlist = [_f8(w, "weight") for w in weights]
+    else:
+        wlist = [_f8(weights, "weight")]
+    if op_code != OP_ADD1 and not wlist:
+        raise ValueError("statisticNd_: this op needs a weight array")
+    if not isinstance(grid, np.ndarray) or grid.dtype != np.float64:
+        raise TypeError("statisticNd_: grid must be a float64 ndarray")
+    if grid.ndim != nd + 1:
+        raise ValueError(f"statisticNd_: grid has {grid.ndim} dimensions, expected {nd + 1}")
+    if grid.strides[-1] != 8:
+        raise RuntimeError(f"last dimension in grid should have stride of 1, not {grid.strides[-1] // 8}")
+    fields = _FIELDS[op_code]
+    if grid.shape[-1] < fields:
+        raise ValueError(f"statisticNd_: op {op_code} writes {fields} values per cell, grid has {grid.shape[-1]}")
+    if len(minima) != nd or len(maxima) != nd:
+        raise ValueError("statisticNd_: minima/maxima must have one entry per block")
+    lengths = {len(b) if not _is_device(b) else b.__cuda_array_interface__["shape"][0] for b in blocks + wlist}
+    if len(lengths) > 1:
+        raise ValueError("statisticNd_: blocks and weights differ in length")
+    n = lengths.pop() if lengths else 0
+    sizes = grid.shape[:-1]
+    if use_edges and any(s < 4 for s in sizes):
+        raise ValueError("statisticNd_: with edges every grid dimension needs at least 4 cells")
+
+    binners = []
+    for d, b in enumerate(blocks):
+        bins = sizes[d] - 3 if use_edges else sizes[d]
+        binner = getattr(_sa, "BinnerScalar_" + _postfix(b))(1, f"block{d}", float(minima[d]), float(maxima[d]), int(bins))
+        binner.set_data(0, b)
+        binners.append(binner)
+    g = _sa.Grid(binners)
+    aggs = []
+    if op_code == OP_ADD1:
+        aggs.append(_sa.AggCount_int64(g, 1, 1))
+    else:
+        w = wlist[0]
+        pf = _postfix(w)
+        if op_code == OP_MIN_MAX:
+            kinds = [("AggMin_", None), ("AggMax_", None)]
+        else:
+            kinds = [("AggCount_", None), ("AggSum_", None), ("AggSumMoment_", 2)][:fields]
+        for cls, moment in kinds:
+            a = getattr(_sa, cls + pf)(g, 1, 1, moment) if moment is not None else getattr(_sa, cls + pf)(g, 1, 1)
+            a.set_data(0, w, 0)
+            aggs.append(a)
+    if n:
+        g.bin(0, aggs, n)
+    inner = tuple(slice(None) if use_edges else slice(2, -1) for _ in range(nd))
+    for f, a in enumerate(aggs):
+        part = np.asarray(a.get_result())[inner]
+        if op_code == OP_MIN_MAX:
+            np.minimum(grid[..., 0], part, out=grid[..., 0]) if f == 0 else np.maximum(grid[..., 1], part, out=grid[..., 1])
+        else:
+            grid[..., f] += part
+    return None
