@@ -360,3 +360,70 @@ def test_count16_partition_reduce_opt_in(sa):
         check(sa, dict(n=n, binners=[dict(kind="scalar", data=x, vmin=-4, vmax=4, bins=512), dict(kind="scalar", data=y, vmin=-4, vmax=4, bins=512)], aggs=[dict(kind="count")]))
     finally:
         sa.config_set("count16", 1)
+
+
+# ---- hot box: pass 1 of the partition strategy aggregates the densest rectangle of cells in LDS ---------------
+def _hot_reset(sa):
+    for k in ("hot_x0", "hot_y0", "hot_w", "hot_h"):
+        sa.config_set(k, 0)
+    sa.config_set("hot", 1)
+    sa.config_set("hot_min_rows", 0)
+    sa.config_set("hot_min_pct", 0)
+
+
+def _case_count_sum(n, seed=11, uniform=False, shape=256):
+    rng = np.random.default_rng(seed)
+    x = rng.uniform(-4, 4, n) if uniform else rng.normal(0.3, 1.0, n)
+    y = rng.uniform(-4, 4, n) if uniform else rng.normal(-0.5, 0.7, n)
+    v = rng.normal(3, 2, n)
+    v[::97] = np.nan
+    x[::1013] = np.nan
+    return dict(n=n, binners=[dict(kind="scalar", data=x, vmin=-4, vmax=4, bins=shape), dict(kind="scalar", data=y, vmin=-4, vmax=4, bins=shape)],
+                aggs=[dict(kind="count"), dict(kind="sum", data=v), dict(kind="count", data=v)])
+
+
+def test_hot_box_forced(sa):
+    sa.config_set("strategy", STRATEGIES["part"])
+    try:
+        for box in ((100, 110, 60, 50), (0, 0, 92, 92), (167, 167, 92, 92), (130, 1, 1, 200)):
+            for k, val in zip(("hot_x0", "hot_y0", "hot_w", "hot_h"), box):
+                sa.config_set(k, val)
+            check(sa, _case_count_sum(300_000))
+            assert (sa.config_get("hot_w"), sa.config_get("hot_h")) == box[2:], box
+        # several chunks share one box; count(*) + sum only; sum only
+        sa.config_set("part_chunk", 1 << 20)
+        case = _case_count_sum(2_500_000)
+        check(sa, case)
+        check(sa, dict(case, aggs=case["aggs"][:2]))
+        check(sa, dict(case, aggs=case["aggs"][1:2]))
+        # a signature the box does not serve (a selection mask) runs without it
+        m = case["binners"][0]["data"] > 0
+        check(sa, dict(case, aggs=[dict(a, mask=m) for a in case["aggs"]]))
+        assert sa.config_get("hot_w") == 0
+    finally:
+        _hot_reset(sa)
+
+
+def test_hot_box_from_sample(sa):
+    sa.config_set("strategy", STRATEGIES["part"])
+    try:
+        sa.config_set("hot_min_rows", 1)
+        sa.config_set("hot_min_pct", 35)
+        check(sa, _case_count_sum(3_000_000))
+        assert sa.config_get("hot_w") > 0 and sa.config_get("hot_fraction_ppm") > 600_000  # sigma 1.0 x 0.7: most rows in 92x92 cells
+        x0, y0, w, h = (sa.config_get(k) for k in ("hot_x0", "hot_y0", "hot_w", "hot_h"))
+        assert x0 < 2 + 256 * (0.3 + 4) / 8 < x0 + w and y0 < 2 + 256 * (-0.5 + 4) / 8 < y0 + h  # the box sits on the mode
+        # uniform data: no rectangle of 8.4 k cells holds 35 % of the rows -> the plain pass
+        check(sa, _case_count_sum(3_000_000, uniform=True))
+        assert sa.config_get("hot_w") == 0 and 0 < sa.config_get("hot_fraction_ppm") < 350_000
+        # device-resident columns (the bench's route)
+        # (run_superagg uploads every aggregator's input separately: two copies of v = two value columns = not the
+        #  box's signature; the result must still be right)
+        check(sa, _case_count_sum(3_000_000, seed=5), to_device=cases.torch_device_array)
+        case = _case_count_sum(3_000_000, seed=5)
+        check(sa, dict(case, aggs=case["aggs"][:2]), to_device=cases.torch_device_array)
+        assert sa.config_get("hot_w") > 0
+    finally:
+        _hot_reset(sa)
+        sa.config_set("hot_min_rows", 0)
+        sa.config_set("hot_min_pct", 0)

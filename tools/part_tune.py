@@ -36,14 +36,14 @@ def run(**cfg):
         sa.timer_start(0)
         grid.bin(0, aggs, rows)
         best = min(best, sa.timer_stop(0))
-    print(f"{str(cfg):<60} {best:.3f} ms = {rows/best/1e6:6.1f} Grows/s", flush=True)
+    hot = f"hot {sa.config_get('hot_w')}x{sa.config_get('hot_h')}@({sa.config_get('hot_x0')},{sa.config_get('hot_y0')}) {sa.config_get('hot_fraction_ppm')/1e4:.1f}%"
+    print(f"{str(cfg):<60} {best:.3f} ms = {rows/best/1e6:6.1f} Grows/s  [{hot}]", flush=True)
     for k in cfg:
-        sa.config_set(k, 0)
+        sa.config_set(k, {'hot': 1}.get(k, 0))
 
 
 run()
-for ch in (27, 28, 29, 30):
-    run(part_chunk=1 << ch)
-for ch in (27, 28):
-    run(part_chunk=1 << ch, part_overlap=1)
-run(part_chunk=1 << 28, block=512, part_lds=78000)
+run(hot=2)
+run(hot=0)
+run(part_chunk=1 << 29)
+run(part_chunk=1 << 29, hot=0)

@@ -528,6 +528,164 @@ static LaunchPlan make_plan(const BinArgs &A, BinArgs &out, uint64_t n, double b
     return p;
 }
 
+static size_t scatter_lds_bytes(size_t S, int R, int nvals) {
+    const size_t T = 512 * (size_t)R;
+    return S * 4 + (S + 4) * 4 + S * 8 + T * (8 * (size_t)nvals + 4 + 2 + 1) + 64;
+}
+
+// ------------------------------------------------------------------------------------------
+// hot box (PartArgs::hot): eligibility, choice of the box from a sample, accumulators, merge
+// ------------------------------------------------------------------------------------------
+// The signature pass 1's HOT instantiation serves: two scalar float64 binners, ONE float64 value column, no masks,
+// aggregators count(*) / count(v) / sum(v).
+static bool hot_eligible(const BinArgs &A, const LaunchPlan &plan) {
+    if (!plan.fast_f64 || A.ndim != 2 || A.nagg < 1 || A.cells >= (1ull << 31)) return false;
+    const void *v = nullptr;
+    for (int k = 0; k < A.nagg; k++) {
+        const AggDesc &a = A.a[k];
+        if (a.mask) return false;
+        if (a.kind == VXH_AGG_COUNT) { if (a.data) { if (v && v != a.data) return false; v = a.data; } }
+        else if (a.kind == VXH_AGG_SUM && a.cell == VXH_CELL_F64 && a.data) { if (v && v != a.data) return false; v = a.data; }
+        else return false;
+    }
+    return v != nullptr;
+}
+
+// densest w x h rectangle with w*h <= max_cells in a (sx, sy) count grid (dim 0 fastest): a dozen aspect ratios
+// around the square, every position, through 2-D prefix sums.  Returns the count inside the best box.
+static int64_t hot_search(const std::vector<int64_t> &g, uint32_t sx, uint32_t sy, uint64_t max_cells, uint32_t box[4]) {
+    std::vector<int64_t> pre((size_t)(sx + 1) * (sy + 1), 0);
+    auto P = [&](uint32_t x, uint32_t y) -> int64_t & { return pre[(size_t)y * (sx + 1) + x]; };
+    for (uint32_t y = 0; y < sy; y++)
+        for (uint32_t x = 0; x < sx; x++) P(x + 1, y + 1) = g[(size_t)y * sx + x] + P(x, y + 1) + P(x + 1, y) - P(x, y);
+    int64_t best = -1;
+    const double side = std::sqrt((double)max_cells);
+    for (int k = -8; k <= 8; k++) {
+        uint32_t h = (uint32_t)std::max(1.0, std::min((double)sy, std::floor(side * std::pow(2.0, k / 4.0))));
+        uint32_t w = (uint32_t)std::min<uint64_t>(sx, max_cells / h);
+        if (w == 0) continue;
+        h = (uint32_t)std::min<uint64_t>(sy, max_cells / w); // use what the clipped width leaves
+        for (uint32_t y0 = 0; y0 + h <= sy; y0++)
+            for (uint32_t x0 = 0; x0 + w <= sx; x0++) {
+                const int64_t in = P(x0 + w, y0 + h) - P(x0, y0 + h) - P(x0 + w, y0) + P(x0, y0);
+                if (in > best) { best = in; box[0] = x0; box[1] = y0; box[2] = w; box[3] = h; }
+            }
+    }
+    return best;
+}
+
+// decide slot.hot for this call.  A: the call's unplanned arguments (device pointers of the whole row range).
+static void hot_prepare(Slot &slot, const BinArgs &A, const BinArgs &planned, const LaunchPlan &plan, uint64_t length) {
+    Context &c = ctx();
+    Slot::Hot &H = slot.hot;
+    H.on = false;
+    H.last_on = false;
+    H.last_fraction = 0;
+    if (!c.cfg_hot || !hot_eligible(A, plan)) return;
+    const bool forced = c.cfg_hot_box[2] > 0 && c.cfg_hot_box[3] > 0;
+    if (!forced && length < (uint64_t)c.cfg_hot_min_rows) return;
+    const size_t S = (size_t)1 << planned.slab_log2;
+    const size_t one = (scatter_lds_bytes(S, 4, 1) + 15) & ~(size_t)15;
+    if (2 * one + 4096 > kLdsMax) return;
+    const uint64_t max_cells = (kLdsMax - 2 * one - 64) / 12;
+    const uint32_t sx = (uint32_t)(A.b[0].bins + 3), sy = (uint32_t)(A.b[1].bins + 3);
+    uint32_t box[4] = {0, 0, 0, 0};
+    if (forced) {
+        for (int i = 0; i < 4; i++) box[i] = (uint32_t)c.cfg_hot_box[i];
+        if (box[0] + box[2] > sx || box[1] + box[3] > sy || (uint64_t)box[2] * box[3] > max_cells) throw std::runtime_error("hot box override does not fit the grid / LDS");
+        H.last_fraction = 1;
+    } else {
+        const double lim[6] = {A.b[0].vmin, A.b[0].scale, A.b[0].binsd, A.b[1].vmin, A.b[1].scale, A.b[1].binsd};
+        const bool cached = H.key_fraction >= 0 && H.key_ptr[0] == A.b[0].data && H.key_ptr[1] == A.b[1].data && H.key_len == length &&
+                            H.key_cells == max_cells && memcmp(H.key_lim, lim, sizeof(lim)) == 0;
+        if (cached) {
+            memcpy(box, H.key_box, sizeof(box));
+            H.last_fraction = H.key_fraction;
+        } else {
+        // sample: 8 evenly spaced segments of 2^18 rows, counted with device atomics into a scratch grid
+            const size_t bytes = (size_t)A.cells * 8;
+            if (bytes > H.sample_cap) {
+                HIP_CHECK(hipStreamSynchronize(slot.stream));
+                if (H.sample) HIP_CHECK(hipFree(H.sample));
+                H.sample = nullptr;
+                HIP_CHECK(hipMalloc(&H.sample, bytes));
+                H.sample_cap = bytes;
+            }
+            HIP_CHECK(hipMemsetAsync(H.sample, 0, bytes, slot.stream));
+            const uint64_t seg = 1ull << 18, nseg = 8;
+            BinArgs Q = A;
+            Q.nagg = 1;
+            Q.a[0] = AggDesc{};
+            Q.a[0].grid = H.sample;
+            Q.a[0].kind = VXH_AGG_COUNT;
+            Q.a[0].dtype = VXH_I64;
+            Q.a[0].cell = VXH_CELL_I64;
+            Q.replicas = 1;
+            Q.replicas_per_xcc = 1;
+            LaunchPlan sp{};
+            sp.strategy = VXH_STRAT_GLOBAL;
+            sp.block = 256;
+            sp.fast_f64 = true;
+            sp.name = "hot_sample";
+            for (uint64_t j = 0; j < nseg; j++) {
+                const uint64_t r0 = (length / nseg) * j, rn = std::min(seg, length - r0);
+                BinArgs L = Q;
+                L.n = rn;
+                for (int d = 0; d < 2; d++) L.b[d].data = (const char *)A.b[d].data + r0 * 8;
+                sp.blocks = (int)std::max<uint64_t>(1, std::min<uint64_t>((rn + 1023) / 1024, (uint64_t)c.cus * 4));
+                vxh_launch_bin(L, sp, slot.stream);
+            }
+            HIP_CHECK(hipGetLastError());
+            std::vector<int64_t> g(A.cells);
+            HIP_CHECK(hipMemcpyAsync(g.data(), H.sample, bytes, hipMemcpyDeviceToHost, slot.stream));
+            HIP_CHECK(hipStreamSynchronize(slot.stream));
+            int64_t total = 0;
+            for (int64_t v : g) total += v;
+            const int64_t in = hot_search(g, sx, sy, max_cells, box);
+            H.last_fraction = total > 0 ? (double)in / (double)total : 0;
+            H.key_ptr[0] = A.b[0].data; H.key_ptr[1] = A.b[1].data;
+            memcpy(H.key_lim, lim, sizeof(lim));
+            H.key_len = length; H.key_cells = max_cells;
+            memcpy(H.key_box, box, sizeof(box));
+            H.key_fraction = H.last_fraction;
+        }
+        if (H.last_fraction * 100.0 < (double)c.cfg_hot_min_pct) return;
+    }
+    H.x0 = box[0]; H.y0 = box[1]; H.w = box[2]; H.h = box[3];
+    const uint64_t tiles = (std::min<uint64_t>(length, (uint64_t)std::max<int64_t>(1 << 20, c.cfg_part_chunk)) + 2047) / 2048;
+    H.blocks = (int)std::max<uint64_t>(1, std::min<uint64_t>(tiles, (uint64_t)c.cus)); // ONE workgroup per CU: the box takes the LDS
+    const size_t need = (size_t)H.blocks * H.w * H.h * 16;
+    if (need > H.acc_cap) {
+        HIP_CHECK(hipStreamSynchronize(slot.stream));
+        if (H.acc) HIP_CHECK(hipFree(H.acc));
+        H.acc = nullptr;
+        HIP_CHECK(hipMalloc(&H.acc, need));
+        H.acc_cap = need;
+    }
+    // (zeroed per call: the box geometry changes from call to call; part_hot_merge leaves zeros behind as well)
+    HIP_CHECK(hipMemsetAsync(H.acc, 0, need, slot.stream));
+    H.on = true;
+    H.last_on = true;
+}
+
+static void hot_merge(Slot &slot, const BinArgs &planned) {
+    const Slot::Hot &H = slot.hot;
+    HotMergeArgs M{};
+    M.x0 = H.x0; M.y0 = H.y0; M.w = H.w; M.h = H.h;
+    M.blocks = (uint32_t)H.blocks;
+    M.nagg = (uint32_t)planned.nagg;
+    M.stride_y = planned.b[1].stride;
+    M.atomic = planned.flush_plain ? 0 : 1;
+    M.sum_acc = (double *)H.acc;
+    M.cnt_acc = (unsigned long long *)((char *)H.acc + (size_t)H.blocks * H.w * H.h * 8);
+    for (int k = 0; k < planned.nagg; k++) {
+        M.grid[k] = planned.a[k].grid;
+        M.takes_sum[k] = planned.a[k].kind == VXH_AGG_SUM ? 1 : 0;
+    }
+    vxh_launch_hot_merge(M, slot.stream);
+    HIP_CHECK(hipGetLastError());
+}
+
 // ------------------------------------------------------------------------------------------
 // partition accumulators: (re)allocate + identity-fill when the layout changes; merge at the end of a call
 // ------------------------------------------------------------------------------------------
@@ -663,8 +821,7 @@ static void run_part_chunk(Slot &slot, const BinArgs &planned, const LaunchPlan 
     int R = c.cfg_part_rows > 0 ? (int)c.cfg_part_rows : ((plan.key_i64 && plan.fast_vals && S >= 64) ? 8 : 4);
     size_t scatter_lds = 0;
     for (;; R >>= 1) {
-        const size_t T = 512 * (size_t)R;
-        scatter_lds = (size_t)S * 4 + ((size_t)S + 4) * 4 + (size_t)S * 8 + T * (8 * (size_t)P.nvals + 4 + 2 + 1) + 64;
+        scatter_lds = scatter_lds_bytes(S, R, P.nvals);
         if (scatter_lds <= 78 * 1024 || R == 2) break;
     }
     P.rows_per_thread = R;
@@ -674,7 +831,17 @@ static void run_part_chunk(Slot &slot, const BinArgs &planned, const LaunchPlan 
     int per_cu = (int)std::max<size_t>(1, std::min<size_t>(4, kLdsMax / scatter_lds));
     if (c.cfg_scatter_wgs > 0) per_cu = (int)c.cfg_scatter_wgs;
     const uint64_t tiles = (planned.n + 512ull * R - 1) / (512ull * R);
-    const int scatter_blocks = (int)std::max<uint64_t>(1, std::min<uint64_t>(tiles, (uint64_t)c.cus * per_cu));
+    int scatter_blocks = (int)std::max<uint64_t>(1, std::min<uint64_t>(tiles, (uint64_t)c.cus * per_cu));
+    if (slot.hot.on && R == 4 && P.nvals == 1 && P.nmasks == 0) {
+        const Slot::Hot &H = slot.hot;
+        P.hot.on = 1;
+        if (c.cfg_hot != 2) P.rows_per_thread = 2; // 1024 threads x 2 rows (hot = 2: 512 x 4, for A/B runs)
+        P.hot.x0 = H.x0; P.hot.y0 = H.y0; P.hot.w = H.w; P.hot.h = H.h;
+        P.hot.lds_offset = (uint32_t)(2 * P.scatter_lds_one);
+        P.hot.sum_acc = (double *)H.acc;
+        P.hot.cnt_acc = (unsigned long long *)((char *)H.acc + (size_t)H.blocks * H.w * H.h * 8);
+        scatter_blocks = std::min(scatter_blocks, H.blocks); // accumulator blocks are indexed by blockIdx
+    }
     vxh_launch_part_scatter(P, plan, scatter_blocks, scatter_lds, slot.stream);
     HIP_CHECK(hipGetLastError());
     if (c.cfg_part_overlap) {
@@ -764,6 +931,13 @@ int vxh_config_set(const char *key, int64_t value) {
     else if (k == "count16") c.cfg_count16 = value;
     else if (k == "count_fast") c.cfg_count_fast = value;
     else if (k == "scatter_wgs") c.cfg_scatter_wgs = value;
+    else if (k == "hot") c.cfg_hot = value;
+    else if (k == "hot_min_rows") c.cfg_hot_min_rows = value > 0 ? value : (1 << 24);
+    else if (k == "hot_min_pct") c.cfg_hot_min_pct = value > 0 ? value : 35;
+    else if (k == "hot_x0") c.cfg_hot_box[0] = value;
+    else if (k == "hot_y0") c.cfg_hot_box[1] = value;
+    else if (k == "hot_w") c.cfg_hot_box[2] = value;
+    else if (k == "hot_h") c.cfg_hot_box[3] = value;
     else if (k == "lds_replicas") c.cfg_lds_replicas = value;
     else throw std::runtime_error("unknown config key: " + k);
     VXH_API_END
@@ -788,6 +962,14 @@ int vxh_config_get(const char *key, int64_t *value) {
     else if (k == "count16") *value = c.cfg_count16;
     else if (k == "count_fast") *value = c.cfg_count_fast;
     else if (k == "scatter_wgs") *value = c.cfg_scatter_wgs;
+    else if (k == "hot") *value = c.cfg_hot;
+    else if (k == "hot_min_rows") *value = c.cfg_hot_min_rows;
+    else if (k == "hot_min_pct") *value = c.cfg_hot_min_pct;
+    else if (k == "hot_fraction_ppm") *value = (int64_t)(get_slot(0).hot.last_fraction * 1e6);
+    else if (k == "hot_w") *value = get_slot(0).hot.last_on ? (int64_t)get_slot(0).hot.w : 0;
+    else if (k == "hot_h") *value = get_slot(0).hot.last_on ? (int64_t)get_slot(0).hot.h : 0;
+    else if (k == "hot_x0") *value = get_slot(0).hot.last_on ? (int64_t)get_slot(0).hot.x0 : 0;
+    else if (k == "hot_y0") *value = get_slot(0).hot.last_on ? (int64_t)get_slot(0).hot.y0 : 0;
     else if (k == "lds_replicas") *value = c.cfg_lds_replicas;
     else if (k == "cus") { ensure_device_ready(); *value = c.cus; }
     else throw std::runtime_error("unknown config key: " + k);
@@ -1053,6 +1235,9 @@ int vxh_grid_bin(vxh_grid *grid, int thread, vxh_agg *const *aggs, int n_aggs, u
         if (whole.strategy == VXH_STRAT_PART) {
             step = (uint64_t)std::max<int64_t>(1 << 20, ctx().cfg_part_chunk);
             part_acc_prepare(slot, whole_args);
+            hot_prepare(slot, A, whole_args, whole, length);
+        } else {
+            slot.hot.on = slot.hot.last_on = false;
         }
         for (uint64_t r0 = 0; r0 < length; r0 += step) {
             const uint64_t rn = std::min(step, length - r0);
@@ -1087,6 +1272,8 @@ int vxh_grid_bin(vxh_grid *grid, int thread, vxh_agg *const *aggs, int n_aggs, u
         if (whole.strategy == VXH_STRAT_PART) {
             part_join(slot);
             part_acc_merge(slot, whole_args);
+            if (slot.hot.on) hot_merge(slot, whole_args);
+            slot.hot.on = false;
         }
     }
     part_join(slot);

@@ -87,6 +87,23 @@ struct Slot {
     size_t acc_cap = 0;
     uint64_t acc_sig = 0;
     void *acc_ptr[VXH_MAX_AGG] = {};
+    // hot box of the current vxh_grid_bin call (PartArgs::hot) and its per-workgroup accumulators
+    struct Hot {
+        bool on = false, last_on = false; // last_on: the most recent call used the box (reporting)
+        uint32_t x0 = 0, y0 = 0, w = 0, h = 0;
+        int blocks = 0;          // pass-1 workgroups (= accumulator blocks)
+        void *acc = nullptr;     // [blocks][w*h] double sums, then [blocks][w*h] u64 counts
+        size_t acc_cap = 0;
+        void *sample = nullptr;  // cells x int64: count grid of the sample
+        size_t sample_cap = 0;
+        // the box of the previous sampled call, reused when the same columns are binned with the same limits again
+        const void *key_ptr[2] = {nullptr, nullptr};
+        double key_lim[6] = {0, 0, 0, 0, 0, 0};
+        uint64_t key_len = 0, key_cells = 0;
+        uint32_t key_box[4] = {0, 0, 0, 0};
+        double key_fraction = -1;
+        double last_fraction = 0; // share of the sample inside the box (vxh_config_get("hot_fraction_ppm"))
+    } hot;
     const char *last_kernel = "";
 };
 
@@ -108,6 +125,10 @@ struct Context {
     int64_t cfg_part_chunk = 1 << 28; // rows per partition chunk (scratch: ~2 x record bytes x this; larger chunks amortise the launches)
     int64_t cfg_parts = 0;        // pass-2 workgroups per slab (0 = auto)
     int64_t cfg_part_lds = 0;     // LDS bytes per pass-2 slab (0 = auto)
+    int64_t cfg_hot = 1;           // hot box in pass 1 of the partition strategy (0 off)
+    int64_t cfg_hot_min_rows = 1 << 24; // calls shorter than this do not pay for the sample
+    int64_t cfg_hot_min_pct = 35;  // use the box only when it catches at least this share of the sample
+    int64_t cfg_hot_box[4] = {0, 0, 0, 0}; // x0, y0, w, h override (w > 0) — tests / experiments
     int64_t cfg_scatter_wgs = 0;  // pass-1 workgroups per CU (0 = as many as LDS allows, at most 4)
     int64_t cfg_count_fast = 1;   // 0: keep count(*) passes on the generic bin_kernel (for A/B measurements)
     int64_t cfg_count16 = 1;      // packed 16-bit LDS counters for all-count passes: 0 off, 1 LDS strategy, 2 also partition pass 2

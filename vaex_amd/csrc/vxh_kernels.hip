@@ -739,7 +739,7 @@ __device__ __forceinline__ void scatter_commit(const PartArgs &P, const ScatterL
 // [E]: staging -> queues
 __device__ __forceinline__ void scatter_copy_out(const PartArgs &P, const ScatterLds &L, uint32_t S, uint32_t T) {
     const uint32_t total = L.s_off[S];
-    for (uint32_t j = threadIdx.x; j < total; j += 512) {
+    for (uint32_t j = threadIdx.x; j < total; j += blockDim.x) {
         const uint32_t s = L.st_slab[j];
         const unsigned long long gb = L.s_gbase[s];
         if (gb != VXH_Q_OVERFLOW) {
@@ -962,19 +962,28 @@ __global__ void __launch_bounds__(1024) count_lds_f64(const BinArgs A) {
 //    later, so no lane ever waits for that round trip (measured: ~300 us of a 950 us pass-1 launch otherwise).
 // KEY = 1: ONE ordinal binner over a native unmasked int64 column instead (df.groupby on an integer key): the
 // 8 bytes of a row are loaded the same way and only the sub-index expression differs.
-template <int NDIM, int NVAL, int R, int KEY = 0>
-__global__ void __launch_bounds__(512) part_scatter_f64(const PartArgs P) {
+// HOT (NDIM = 2, NVAL = 1, no masks; aggregators: count(*) / count(v) / sum(v)): rows that fall into the hot box
+// and carry a non-NaN value are added to the workgroup's LDS copy of the box and emit no record (PartArgs::hot).
+template <int NDIM, int NVAL, int R, int KEY = 0, bool HOT = false, int BLOCK = 512>
+__global__ void __launch_bounds__(BLOCK) part_scatter_f64(const PartArgs P) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const uint32_t S = 1u << P.slab_log2;
-    const uint32_t T = 512u * R;
+    const uint32_t T = (uint32_t)BLOCK * R;
     // two staging buffers, swapped by value every iteration (an array indexed by `it & 1` would live in scratch)
     ScatterLds L = scatter_carve(lds, S, T, P.nvals);
     ScatterLds Lp = scatter_carve(lds + P.scatter_lds_one, S, T, P.nvals);
-    Lp.s_cnt = L.s_cnt;
+    const bool few = S <= 8;
+    if (!few) Lp.s_cnt = L.s_cnt;
     const uint64_t n = P.A.n;
     uint64_t tile = blockIdx.x;
     if (tile * T >= n) return;
-    if (threadIdx.x < S) L.s_cnt[threadIdx.x] = 0;
+    if (threadIdx.x < S) { L.s_cnt[threadIdx.x] = 0; Lp.s_cnt[threadIdx.x] = 0; }
+    const uint32_t hot_cells = HOT ? P.hot.w * P.hot.h : 0u;
+    double *hot_sum = (double *)(lds + P.hot.lds_offset);
+    uint32_t *hot_cnt = (uint32_t *)(hot_sum + hot_cells);
+    if (HOT) {
+        for (uint32_t c = threadIdx.x; c < hot_cells; c += BLOCK) { hot_sum[c] = 0.0; hot_cnt[c] = 0u; }
+    }
     __syncthreads();
 
     struct Raw {
@@ -984,7 +993,7 @@ __global__ void __launch_bounds__(512) part_scatter_f64(const PartArgs P) {
         uint32_t valid;
     };
     auto request = [&](uint64_t t, Raw &raw) {
-        const Rows<R> rows = make_rows<R>(t * T + threadIdx.x, 512, n);
+        const Rows<R> rows = make_rows<R>(t * T + threadIdx.x, BLOCK, n);
         raw.valid = rows.valid;
 #pragma unroll
         for (int d = 0; d < NDIM; ++d) {
@@ -1004,12 +1013,11 @@ __global__ void __launch_bounds__(512) part_scatter_f64(const PartArgs P) {
         }
     };
 
-    Raw cur;
-    request(tile, cur);
     unsigned long long gb_prev = 0; // reservation of the previous tile (lanes < S), not yet consumed
     uint32_t cnt_prev = 0;
     uint32_t it = 0;
-    for (;; ++it) {
+    // one tile: bin `cur`; after barrier 2 request tile `req_tile` into `into` (a buffer nobody reads any more)
+    auto tile_body = [&](const Raw &cur, Raw &into, uint64_t req_tile) {
         // [B]
         uint32_t keep = cur.valid;
         uint32_t fl[R];
@@ -1028,6 +1036,20 @@ __global__ void __launch_bounds__(512) part_scatter_f64(const PartArgs P) {
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             uint32_t idx = 0; // the partition strategy is only planned for grids < 2^31 cells
+            if (HOT) {
+                const BinnerDesc &b0 = P.A.b[0], &b1 = P.A.b[NDIM > 1 ? 1 : 0];
+                const uint32_t ix = scalar_sub_index32(cur.b[0][r], b0.vmin, b0.scale, b0.binsd, (uint32_t)b0.bins);
+                const uint32_t iy = scalar_sub_index32(cur.b[NDIM > 1 ? 1 : 0][r], b1.vmin, b1.scale, b1.binsd, (uint32_t)b1.bins);
+                idx = ix * (uint32_t)b0.stride + iy * (uint32_t)b1.stride;
+                const uint32_t hx = ix - P.hot.x0, hy = iy - P.hot.y0; // (unsigned: below the box wraps to huge)
+                const double val = __longlong_as_double((long long)cur.v[0][r]);
+                if (hx < P.hot.w && hy < P.hot.h && val == val && ((keep >> r) & 1u)) {
+                    const uint32_t hc = hy * P.hot.w + hx;
+                    at_add<__HIP_MEMORY_SCOPE_WORKGROUP, double>(hot_sum + hc, val);
+                    at_add<__HIP_MEMORY_SCOPE_WORKGROUP, uint32_t>(hot_cnt + hc, 1u);
+                    keep &= ~(1u << r);
+                }
+            } else
 #pragma unroll
             for (int d = 0; d < NDIM; ++d) {
                 const BinnerDesc &b = P.A.b[d];
@@ -1051,17 +1073,28 @@ __global__ void __launch_bounds__(512) part_scatter_f64(const PartArgs P) {
         unsigned long long gb_new;
         uint32_t cnt_new;
         scatter_reserve(P, L, S, gb_new, cnt_new);
-        __syncthreads();
-        // request the next tile's columns; they are not touched before the next [B]
-        const uint64_t next = tile + gridDim.x;
-        const bool has_next = next * T < n;
-        Raw nxt;
-        request(has_next ? next : tile, nxt); // (the last tile re-requests itself: static number of loads in flight)
+        // few slabs: every lane forms the (<= 8-term) prefix it needs from the bucket counts itself, which saves the
+        // barrier between [C] and [D] (the two staging buffers then keep separate bucket counters)
+        uint32_t cn[8];
+        if (few) {
+#pragma unroll
+            for (uint32_t b = 0; b < 8; ++b) cn[b] = b < S ? L.s_cnt[b] : 0u;
+        } else {
+            __syncthreads();
+        }
+        // request a later tile's columns; they are not touched before that tile's [B]
+        request(req_tile, into);
         // [D] stage this tile; park the PREVIOUS tile's reservation
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             if ((keep >> r) & 1u) {
-                const uint32_t j = L.s_off[slab[r]] + pos[r];
+                uint32_t j = pos[r];
+                if (few) {
+#pragma unroll
+                    for (uint32_t b = 0; b < 8; ++b) j += b < slab[r] ? cn[b] : 0u;
+                } else {
+                    j += L.s_off[slab[r]];
+                }
                 L.st_idx[j] = loc[r];
                 L.st_slab[j] = (uint16_t)slab[r];
                 L.st_flags[j] = (uint8_t)fl[r];
@@ -1070,7 +1103,9 @@ __global__ void __launch_bounds__(512) part_scatter_f64(const PartArgs P) {
             }
         }
         if (it > 0) scatter_commit(P, Lp, S, gb_prev, cnt_prev);
-        if (threadIdx.x < S) L.s_cnt[threadIdx.x] = 0;
+        // re-zero bucket counters for the next tile: the shared ones (everybody is past reading them), or — few
+        // slabs — the OTHER buffer's (last read before the previous tile's final barrier; next written after this one's)
+        if (threadIdx.x < S) (few ? Lp.s_cnt : L.s_cnt)[threadIdx.x] = 0;
         __syncthreads();
         // [E] copy out the PREVIOUS tile
         if (it > 0 && !(P.no_pipeline & 2)) scatter_copy_out(P, Lp, S, T);
@@ -1081,14 +1116,47 @@ __global__ void __launch_bounds__(512) part_scatter_f64(const PartArgs P) {
             L = Lp;
             Lp = tmp;
         }
-        if (!has_next) break;
-        cur = nxt;
-        tile = next;
+        ++it;
+    };
+    const uint64_t G = gridDim.x;
+    auto clamp_tile = [&](uint64_t t) { return t * T < n ? t : tile; }; // (past the end: re-request a valid tile — static number of loads in flight)
+    if (HOT) {
+        // ONE workgroup per CU here (the box takes the LDS), so the loads of TWO tiles are kept in flight: three
+        // register buffers in rotation, the loop unrolled by three so that none is ever copied
+        Raw bufA, bufB, bufC;
+        request(tile, bufA);
+        request(clamp_tile(tile + G), bufB);
+        for (;;) {
+            tile_body(bufA, bufC, clamp_tile(tile + 2 * G));
+            if ((tile + G) * T >= n) break;
+            tile += G;
+            tile_body(bufB, bufA, clamp_tile(tile + 2 * G));
+            if ((tile + G) * T >= n) break;
+            tile += G;
+            tile_body(bufC, bufB, clamp_tile(tile + 2 * G));
+            if ((tile + G) * T >= n) break;
+            tile += G;
+        }
+    } else {
+        Raw cur, nxt;
+        request(tile, cur);
+        for (;;) {
+            tile_body(cur, nxt, clamp_tile(tile + G));
+            if ((tile + G) * T >= n) break;
+            cur = nxt;
+            tile += G;
+        }
     }
     // epilogue: the last tile's records (now in Lp)
     scatter_commit(P, Lp, S, gb_prev, cnt_prev);
     __syncthreads();
     if (!(P.no_pipeline & 2)) scatter_copy_out(P, Lp, S, T);
+    if (HOT) { // this workgroup's box -> its own block of the accumulators (exclusive, contiguous)
+        double *gs = P.hot.sum_acc + (uint64_t)blockIdx.x * hot_cells;
+        unsigned long long *gc = P.hot.cnt_acc + (uint64_t)blockIdx.x * hot_cells;
+        flush_add_plain<double, double>(gs, hot_sum, hot_cells, 0, 0, hot_cells);
+        flush_add_plain<unsigned long long, uint32_t>(gc, hot_cnt, hot_cells, 0, 0, hot_cells);
+    }
 }
 
 // pass 2: slab queues -> LDS-private slab -> HBM replica.  Each lane streams 4 consecutive records per
@@ -1323,6 +1391,45 @@ __global__ void __launch_bounds__(256) part_merge(const PartMergeArgs M) {
     }
 }
 
+// K1f — fold the pass-1 workgroups' hot boxes into the grids (once per vxh_grid_bin call) and zero them again
+__global__ void __launch_bounds__(256) part_hot_merge(const HotMergeArgs M) {
+    // 64 cells per workgroup; the 4 waves each fold a quarter of the pass-1 blocks (coalesced 512-byte reads),
+    // LDS combines the quarters
+    __shared__ double s_sum[4][64];
+    __shared__ unsigned long long s_cnt[4][64];
+    const uint32_t cells = M.w * M.h;
+    const uint32_t lane = threadIdx.x & 63u, q = threadIdx.x >> 6;
+    const uint32_t c = blockIdx.x * 64u + lane;
+    double s = 0.0;
+    unsigned long long k = 0;
+    if (c < cells) {
+        for (uint32_t b = q; b < M.blocks; b += 4) {
+            const uint64_t i = (uint64_t)b * cells + c;
+            s += M.sum_acc[i];
+            k += M.cnt_acc[i];
+            M.sum_acc[i] = 0.0;
+            M.cnt_acc[i] = 0ull;
+        }
+    }
+    s_sum[q][lane] = s;
+    s_cnt[q][lane] = k;
+    __syncthreads();
+    if (q != 0 || c >= cells) return;
+    s = (s_sum[0][lane] + s_sum[1][lane]) + (s_sum[2][lane] + s_sum[3][lane]);
+    k = s_cnt[0][lane] + s_cnt[1][lane] + s_cnt[2][lane] + s_cnt[3][lane];
+    if (k == 0) return;
+    const uint64_t cell = (uint64_t)(M.x0 + c % M.w) + (uint64_t)(M.y0 + c / M.w) * M.stride_y;
+    for (uint32_t a = 0; a < M.nagg; ++a) {
+        if (M.takes_sum[a]) {
+            double *g = (double *)M.grid[a] + cell;
+            if (M.atomic) at_add<__HIP_MEMORY_SCOPE_AGENT, double>(g, s); else *g += s;
+        } else {
+            unsigned long long *g = (unsigned long long *)M.grid[a] + cell;
+            if (M.atomic) at_add<__HIP_MEMORY_SCOPE_AGENT, unsigned long long>(g, k); else *g += k;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // fill / fold
 // ------------------------------------------------------------------------------------------
@@ -1422,12 +1529,18 @@ size_t vxh_lds_cell_size(int kind, int cell, int count16) { return kind == VXH_A
 void vxh_launch_part_scatter(const PartArgs &args, const LaunchPlan &plan, int scatter_blocks, size_t scatter_lds, hipStream_t stream) {
     const int R = args.rows_per_thread;
     const bool fast_f64 = plan.fast_f64;
+    int block = 512;
 #define VXH_SC(KERNEL)                                                                                                 \
     do {                                                                                                               \
         if (scatter_lds > 48 * 1024) (void)hipFuncSetAttribute((const void *)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, (int)scatter_lds); \
-        hipLaunchKernelGGL(KERNEL, dim3(scatter_blocks), dim3(512), scatter_lds, stream, args);                        \
+        hipLaunchKernelGGL(KERNEL, dim3(scatter_blocks), dim3(block), scatter_lds, stream, args);                      \
     } while (0)
-    if (fast_f64 && R == 4 && args.A.ndim >= 1 && args.A.ndim <= 3 && args.nvals <= 2 && args.nmasks <= 1 && !(args.no_pipeline & 1)) {
+    if (args.hot.on) { // (the host only switches it on for the signature the HOT instantiation serves)
+        // ONE workgroup per CU (the box takes the LDS): 1024 threads x 2 rows = the same 2048-row tile
+        scatter_lds = 2 * (size_t)args.scatter_lds_one + (size_t)args.hot.w * args.hot.h * 12 + 16;
+        if (R == 2) { block = 1024; VXH_SC((part_scatter_f64<2, 1, 2, 0, true, 1024>)); }
+        else VXH_SC((part_scatter_f64<2, 1, 4, 0, true>));
+    } else if (fast_f64 && R == 4 && args.A.ndim >= 1 && args.A.ndim <= 3 && args.nvals <= 2 && args.nmasks <= 1 && !(args.no_pipeline & 1)) {
 #define VXH_SCN(ND)                                                                                                    \
     do {                                                                                                               \
         scatter_lds = 2 * (size_t)args.scatter_lds_one; /* double-buffered staging */                                  \
@@ -1510,6 +1623,11 @@ void vxh_launch_bin(const BinArgs &args, const LaunchPlan &plan, hipStream_t str
     else if (plan.strategy == VXH_STRAT_XCC) { if (plan.fast_f64) VXH_LAUNCH(VXH_STRAT_XCC, true); else VXH_LAUNCH(VXH_STRAT_XCC, false); }
     else { if (plan.fast_f64) VXH_LAUNCH(VXH_STRAT_GLOBAL, true); else VXH_LAUNCH(VXH_STRAT_GLOBAL, false); }
 #undef VXH_LAUNCH
+}
+
+void vxh_launch_hot_merge(const HotMergeArgs &args, hipStream_t stream) {
+    const uint32_t cells = args.w * args.h;
+    hipLaunchKernelGGL(part_hot_merge, dim3((cells + 63) / 64), dim3(256), 0, stream, args);
 }
 
 void vxh_launch_part_merge(const PartMergeArgs &args, hipStream_t stream) {

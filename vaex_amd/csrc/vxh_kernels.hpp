@@ -100,6 +100,27 @@ struct PartArgs {
     // (Flushing straight into grid replicas touches one 64-128 B line per 8 B cell — the slabs interleave — which
     //  was ~130 us of every part_reduce launch: profiles/r01_chunk_fit.txt.)
     void *acc[VXH_MAX_AGG];
+    // "hot box" (part_scatter_f64<2,1,4,0,HOT=true>): a w x h rectangle of cells — chosen from a sample of the
+    // call's rows as the densest one that fits — is aggregated in LDS by pass 1 itself (fp64 sum + uint32 count per
+    // cell); only rows outside it (and rows whose value is NaN) are emitted as records.  Each pass-1 workgroup
+    // flushes its private box into hot_sum/hot_cnt[blockIdx][cell]; part_hot_merge folds them into the grids.
+    struct HotBox {
+        int32_t on;
+        uint32_t x0, y0, w, h;     // in sub-index units of dims 0 and 1 (edge cells included)
+        uint32_t lds_offset;       // of the box inside pass 1's dynamic LDS
+        double *sum_acc;           // [pass-1 workgroups][w*h]
+        unsigned long long *cnt_acc;
+    } hot;
+};
+
+struct HotMergeArgs {
+    uint32_t x0, y0, w, h, blocks, nagg;
+    uint64_t stride_y;             // cells per step of dim 1
+    int32_t atomic, reserved_;
+    double *sum_acc;
+    unsigned long long *cnt_acc;
+    void *grid[VXH_MAX_AGG];       // replica 0 of every aggregator
+    uint8_t takes_sum[VXH_MAX_AGG]; // 1: fp64 sum grid (+= box sum), 0: int64 count grid (+= box count)
 };
 
 struct PartMergeArgs {
@@ -135,6 +156,7 @@ void vxh_launch_part_scatter(const PartArgs &args, const LaunchPlan &plan, int s
 void vxh_launch_part_reduce(const PartArgs &args, const LaunchPlan &plan, hipStream_t stream);
 void vxh_launch_bin(const BinArgs &args, const LaunchPlan &plan, hipStream_t stream);
 void vxh_launch_part_merge(const PartMergeArgs &args, hipStream_t stream);
+void vxh_launch_hot_merge(const HotMergeArgs &args, hipStream_t stream);
 void vxh_launch_fill(void *dst, uint64_t ncells, int cell, const void *value8, hipStream_t stream);
 // dst[c] = fold(replica_0[c] .. replica_{R-1}[c]); replicas 1.. are reset to the identity
 void vxh_launch_fold(void *grid, uint64_t cells, int replicas, int cell, int kind, const void *identity8, hipStream_t stream);
