@@ -427,3 +427,26 @@ def test_hot_box_from_sample(sa):
         _hot_reset(sa)
         sa.config_set("hot_min_rows", 0)
         sa.config_set("hot_min_pct", 0)
+
+
+def test_hot_box_skewed_cold_rows(sa):
+    # every row outside the (forced) box and in ONE cell: a tile brings 4096 records into one bucket (more than a
+    # 1024-record queue block: the exact-reservation path), and with 1 Mi-row chunks the sub-queue overflows
+    # (device-atomic slow path).  Then the same with the rows inside the box (nothing is emitted at all).
+    sa.config_set("strategy", STRATEGIES["part"])
+    try:
+        for k, val in zip(("hot_x0", "hot_y0", "hot_w", "hot_h"), (100, 100, 60, 60)):
+            sa.config_set(k, val)
+        n = 3_000_000
+        v = np.arange(n, dtype="f8") % 7
+        v[::5] = np.nan
+        for xv, yv in ((3.5, -3.25), (0.5, 0.25)):
+            x = np.full(n, xv); y = np.full(n, yv)
+            case = dict(n=n, binners=[dict(kind="scalar", data=x, vmin=-4, vmax=4, bins=256), dict(kind="scalar", data=y, vmin=-4, vmax=4, bins=256)],
+                        aggs=[dict(kind="count"), dict(kind="sum", data=v), dict(kind="count", data=v)])
+            for chunk in (0, 1 << 20):
+                sa.config_set("part_chunk", chunk)
+                got = check(sa, case)
+                assert got[0].max() == n and sa.config_get("hot_w") == 60
+    finally:
+        _hot_reset(sa)

@@ -46,4 +46,3 @@ run()
 run(hot=2)
 run(hot=0)
 run(part_chunk=1 << 29)
-run(part_chunk=1 << 29, hot=0)

@@ -461,7 +461,7 @@ static LaunchPlan make_plan(const BinArgs &A, BinArgs &out, uint64_t n, double b
         size_t lds = 0;
         for (int k = 0; k < A.nagg; k++) {
             out.a[k].lds_offset = (uint32_t)lds;
-            lds += (part_slab_cells * vxh_lds_cell_size(A.a[k].kind, A.a[k].cell, c16_part) + 4 + 15) & ~(size_t)15;
+            lds += (part_slab_cells * vxh_lds_cell_size(A.a[k].kind, A.a[k].cell, c16_part) + 8 + 15) & ~(size_t)15; // (+ one dummy cell: null records of part_scatter_hot)
         }
         out.count16 = c16_part ? 1 : 0;
         p.lds_bytes = lds;
@@ -586,8 +586,14 @@ static void hot_prepare(Slot &slot, const BinArgs &A, const BinArgs &planned, co
     if (!forced && length < (uint64_t)c.cfg_hot_min_rows) return;
     const size_t S = (size_t)1 << planned.slab_log2;
     const size_t one = (scatter_lds_bytes(S, 4, 1) + 15) & ~(size_t)15;
-    if (2 * one + 4096 > kLdsMax) return;
-    const uint64_t max_cells = (kLdsMax - 2 * one - 64) / 12;
+    const uint64_t slab_cells = (planned.cells + S - 1) >> planned.slab_log2;
+    // cfg_hot = 1: part_scatter_hot (block-reserved queues, 4096-row tiles; needs S <= 8 and uint16 local indices
+    // with one value to spare for the null record); 2 / 3: the HOT instantiations of part_scatter_f64 (A/B runs)
+    const bool gen2 = c.cfg_hot == 1 && S <= 8 && slab_cells < 65535;
+    H.gen2 = gen2;
+    const size_t fixed = gen2 ? (size_t)VXH_HOT_FIXED_LDS : 2 * one;
+    if (fixed + 4096 > kLdsMax) return;
+    const uint64_t max_cells = (kLdsMax - fixed - 64) / 12;
     const uint32_t sx = (uint32_t)(A.b[0].bins + 3), sy = (uint32_t)(A.b[1].bins + 3);
     uint32_t box[4] = {0, 0, 0, 0};
     if (forced) {
@@ -652,7 +658,8 @@ static void hot_prepare(Slot &slot, const BinArgs &A, const BinArgs &planned, co
         if (H.last_fraction * 100.0 < (double)c.cfg_hot_min_pct) return;
     }
     H.x0 = box[0]; H.y0 = box[1]; H.w = box[2]; H.h = box[3];
-    const uint64_t tiles = (std::min<uint64_t>(length, (uint64_t)std::max<int64_t>(1 << 20, c.cfg_part_chunk)) + 2047) / 2048;
+    const uint64_t tile_rows = gen2 ? 4096 : 2048;
+    const uint64_t tiles = (std::min<uint64_t>(length, (uint64_t)std::max<int64_t>(1 << 20, c.cfg_part_chunk)) + tile_rows - 1) / tile_rows;
     H.blocks = (int)std::max<uint64_t>(1, std::min<uint64_t>(tiles, (uint64_t)c.cus)); // ONE workgroup per CU: the box takes the LDS
     const size_t need = (size_t)H.blocks * H.w * H.h * 16;
     if (need > H.acc_cap) {
@@ -834,10 +841,14 @@ static void run_part_chunk(Slot &slot, const BinArgs &planned, const LaunchPlan 
     int scatter_blocks = (int)std::max<uint64_t>(1, std::min<uint64_t>(tiles, (uint64_t)c.cus * per_cu));
     if (slot.hot.on && R == 4 && P.nvals == 1 && P.nmasks == 0) {
         const Slot::Hot &H = slot.hot;
-        P.hot.on = 1;
-        if (c.cfg_hot != 2) P.rows_per_thread = 2; // 1024 threads x 2 rows (hot = 2: 512 x 4, for A/B runs)
+        P.hot.on = H.gen2 ? 2 : 1;
+        if (c.cfg_hot != 3) P.rows_per_thread = 2; // 1024 threads x 2 rows (hot = 3: 512 x 4, for A/B runs)
         P.hot.x0 = H.x0; P.hot.y0 = H.y0; P.hot.w = H.w; P.hot.h = H.h;
-        P.hot.lds_offset = (uint32_t)(2 * P.scatter_lds_one);
+        P.hot.lds_offset = (uint32_t)(H.gen2 ? (size_t)VXH_HOT_FIXED_LDS : 2 * (size_t)P.scatter_lds_one);
+        if (H.gen2) {
+            scatter_lds = (size_t)VXH_HOT_FIXED_LDS + (size_t)H.w * H.h * 12 + 16;
+            scatter_blocks = (int)std::max<uint64_t>(1, (planned.n + 4095) / 4096);
+        }
         P.hot.sum_acc = (double *)H.acc;
         P.hot.cnt_acc = (unsigned long long *)((char *)H.acc + (size_t)H.blocks * H.w * H.h * 8);
         scatter_blocks = std::min(scatter_blocks, H.blocks); // accumulator blocks are indexed by blockIdx

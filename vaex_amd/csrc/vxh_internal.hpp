@@ -89,6 +89,7 @@ struct Slot {
     void *acc_ptr[VXH_MAX_AGG] = {};
     // hot box of the current vxh_grid_bin call (PartArgs::hot) and its per-workgroup accumulators
     struct Hot {
+        bool gen2 = false; // part_scatter_hot (vs the HOT instantiation of part_scatter_f64)
         bool on = false, last_on = false; // last_on: the most recent call used the box (reporting)
         uint32_t x0 = 0, y0 = 0, w = 0, h = 0;
         int blocks = 0;          // pass-1 workgroups (= accumulator blocks)

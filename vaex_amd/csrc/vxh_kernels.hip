@@ -1159,6 +1159,226 @@ __global__ void __launch_bounds__(BLOCK) part_scatter_f64(const PartArgs P) {
     }
 }
 
+// K1b' — pass 1 with a hot box, second generation (PartArgs::hot.on == 2).  ONE 1024-thread workgroup per CU,
+// 4096-row tiles, two barriers per tile:
+//   * rows inside the box (non-NaN value) are added to the workgroup's LDS copy of the box, nothing else happens to them;
+//   * the others are bucketed by slab exactly as in part_scatter_f64 ([B] returning ds_add = position in bucket |
+//     barrier | [D] stage sorted by slab; S <= 8, so every lane forms the prefix itself | barrier | [E] copy out),
+//     but the queue space comes from BLOCKS of 1024 records that lane b of wave 0 reserves for bucket b ahead of
+//     time: the HBM atomic that reserves block k+1 is issued when block k is opened and only looked at when block k
+//     is full, so no tile ever waits for it and the staging area needs no double buffering (which is what leaves
+//     room for 4096-row tiles next to a ~95 KB box).  A tile's segment may straddle two blocks (split point parked
+//     in LDS).  What is left of the open and of the pre-reserved block at the end is filled with null records
+//     (local index = slab_cells: a dummy LDS cell of pass 2, value 0).
+constexpr int VXH_HOT_BLOCK = 1024;   // threads
+constexpr int VXH_HOT_R = 4;          // rows per thread per tile
+constexpr uint32_t VXH_HOT_QBLK = 1024; // records per reserved queue block
+
+struct HotLds {
+    uint32_t *s_cnt;             // [2][8]
+    unsigned long long *base0;   // [8] queue slot of the bucket's record 0
+    unsigned long long *base1;   // [8] queue slot of its record `split` (second block), or OVERFLOW
+    uint32_t *split;             // [8]
+    unsigned long long *tail;    // [3][8] open block [cur,end) and pre-reserved block base, parked at the end
+    double *st_val;              // [T]
+    uint16_t *st_idx;            // [T]
+    uint8_t *st_slab;            // [T]
+    double *hot_sum;             // [w*h]
+    uint32_t *hot_cnt;           // [w*h]
+};
+
+__global__ void __launch_bounds__(VXH_HOT_BLOCK) part_scatter_hot(const PartArgs P) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    constexpr int R = VXH_HOT_R;
+    constexpr uint32_t T = VXH_HOT_BLOCK * R;
+    const uint32_t S = 1u << P.slab_log2; // <= 8
+    const uint32_t hot_cells = P.hot.w * P.hot.h;
+    HotLds L;
+    L.s_cnt = (uint32_t *)lds;
+    L.base0 = (unsigned long long *)(L.s_cnt + 16);
+    L.base1 = L.base0 + 8;
+    L.tail = L.base1 + 8;
+    L.split = (uint32_t *)(L.tail + 24);
+    L.st_val = (double *)(L.split + 8);
+    L.st_idx = (uint16_t *)(L.st_val + T);
+    L.st_slab = (uint8_t *)(L.st_idx + T);
+    L.hot_sum = (double *)(lds + P.hot.lds_offset);
+    L.hot_cnt = (uint32_t *)(L.hot_sum + hot_cells);
+    const uint64_t n = P.A.n;
+    uint64_t tile = blockIdx.x;
+    if (tile * T >= n) return;
+    if (threadIdx.x < 16) L.s_cnt[threadIdx.x] = 0;
+    for (uint32_t c = threadIdx.x; c < hot_cells; c += VXH_HOT_BLOCK) { L.hot_sum[c] = 0.0; L.hot_cnt[c] = 0u; }
+    // bucket b's queue blocks live in the registers of lane b (wave 0)
+    const uint32_t sub = (threadIdx.x < S ? threadIdx.x : 0u) * (uint32_t)P.parts + blockIdx.x % (uint32_t)P.parts;
+    unsigned long long q_cur = 0, q_end = 0, q_nxt = VXH_Q_OVERFLOW;
+    if (threadIdx.x < S) q_nxt = atomicAdd(&P.qcount[sub], (unsigned long long)VXH_HOT_QBLK);
+    __syncthreads();
+
+    struct Raw {
+        double x[R], y[R], v[R];
+        uint32_t valid;
+    };
+    const double *colx = (const double *)P.A.b[0].data, *coly = (const double *)P.A.b[1].data, *colv = (const double *)P.vdata[0];
+    auto request = [&](uint64_t t, Raw &raw) {
+        const Rows<R> rows = make_rows<R>(t * T + threadIdx.x, VXH_HOT_BLOCK, n);
+        raw.valid = rows.valid;
+#pragma unroll
+        for (int r = 0; r < R; ++r) raw.x[r] = colx[rows.i[r]];
+#pragma unroll
+        for (int r = 0; r < R; ++r) raw.y[r] = coly[rows.i[r]];
+#pragma unroll
+        for (int r = 0; r < R; ++r) raw.v[r] = colv[rows.i[r]];
+    };
+    // a reserved block that does not fit the sub-queue: remember where the valid prefix ends, use the slow path
+    auto checked = [&](unsigned long long base, unsigned long long size) -> unsigned long long {
+        if (base != VXH_Q_OVERFLOW && base + size > P.cap) { atomicMin(&P.qlimit[sub], base); return VXH_Q_OVERFLOW; }
+        return base;
+    };
+
+    uint32_t set = 0;
+    const BinnerDesc &b0 = P.A.b[0], &b1 = P.A.b[1];
+    auto tile_body = [&](const Raw &cur, Raw &into, uint64_t req_tile) {
+        uint32_t *cnt = L.s_cnt + set * 8;
+        // [B]
+        uint32_t keep = cur.valid;
+        uint32_t slab[R], loc[R], pos[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const uint32_t ix = scalar_sub_index32(cur.x[r], b0.vmin, b0.scale, b0.binsd, (uint32_t)b0.bins);
+            const uint32_t iy = scalar_sub_index32(cur.y[r], b1.vmin, b1.scale, b1.binsd, (uint32_t)b1.bins);
+            const uint32_t idx = ix * (uint32_t)b0.stride + iy * (uint32_t)b1.stride;
+            const uint32_t hx = ix - P.hot.x0, hy = iy - P.hot.y0; // (unsigned: below the box wraps to huge)
+            const double val = cur.v[r];
+            slab[r] = idx & (S - 1);
+            loc[r] = idx >> P.slab_log2;
+            pos[r] = 0;
+            if (hx < P.hot.w && hy < P.hot.h && val == val && ((keep >> r) & 1u)) {
+                const uint32_t hc = hy * P.hot.w + hx;
+                at_add<__HIP_MEMORY_SCOPE_WORKGROUP, double>(L.hot_sum + hc, val);
+                at_add<__HIP_MEMORY_SCOPE_WORKGROUP, uint32_t>(L.hot_cnt + hc, 1u);
+                keep &= ~(1u << r);
+            } else if ((keep >> r) & 1u) {
+                pos[r] = __hip_atomic_fetch_add(&cnt[slab[r]], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+        __syncthreads();
+        // [C] lane b: where bucket b's records of this tile go
+        if (threadIdx.x < S) {
+            const uint32_t c = cnt[threadIdx.x];
+            const unsigned long long room = q_end - q_cur;
+            unsigned long long a0 = q_cur, a1 = VXH_Q_OVERFLOW;
+            uint32_t sp = c;
+            if (c <= room) {
+                q_cur += c;
+            } else {
+                sp = (uint32_t)room;
+                const uint32_t rest = c - sp;
+                unsigned long long blk = checked(q_nxt, VXH_HOT_QBLK); // (first look at the value reserved a block ago)
+                if (blk == VXH_Q_OVERFLOW) {
+                    q_cur = q_end = 0; // sub-queue full: everything from here on takes the slow path
+                    q_nxt = VXH_Q_OVERFLOW;
+                } else if (rest <= VXH_HOT_QBLK) {
+                    a1 = blk;
+                    q_cur = blk + rest;
+                    q_end = blk + VXH_HOT_QBLK;
+                    q_nxt = atomicAdd(&P.qcount[sub], (unsigned long long)VXH_HOT_QBLK);
+                } else { // a tile that brings more than a block into one bucket: reserve exactly the rest, now
+                    a1 = checked(atomicAdd(&P.qcount[sub], (unsigned long long)rest), rest);
+                    q_cur = blk;
+                    q_end = blk + VXH_HOT_QBLK;
+                    q_nxt = atomicAdd(&P.qcount[sub], (unsigned long long)VXH_HOT_QBLK);
+                }
+            }
+            L.base0[threadIdx.x] = a0;
+            L.base1[threadIdx.x] = a1;
+            L.split[threadIdx.x] = sp;
+            (L.s_cnt + (set ^ 1u) * 8)[threadIdx.x] = 0; // next tile's counters (last read before the previous tile's final barrier)
+        }
+        uint32_t cn[8];
+#pragma unroll
+        for (uint32_t b = 0; b < 8; ++b) cn[b] = b < S ? cnt[b] : 0u;
+        request(req_tile, into);
+        // [D] stage, sorted by slab
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            if ((keep >> r) & 1u) {
+                uint32_t j = pos[r];
+#pragma unroll
+                for (uint32_t b = 0; b < 8; ++b) j += b < slab[r] ? cn[b] : 0u;
+                L.st_val[j] = cur.v[r];
+                L.st_idx[j] = (uint16_t)loc[r];
+                L.st_slab[j] = (uint8_t)slab[r];
+            }
+        }
+        __syncthreads();
+        // [E] copy out
+        uint32_t total = 0;
+#pragma unroll
+        for (uint32_t b = 0; b < 8; ++b) total += cn[b];
+        for (uint32_t j = threadIdx.x; j < total; j += VXH_HOT_BLOCK) {
+            const uint32_t s = L.st_slab[j];
+            uint32_t k = j;
+#pragma unroll
+            for (uint32_t b = 0; b < 8; ++b) k -= b < s ? cn[b] : 0u;
+            const uint32_t sp = L.split[s];
+            const unsigned long long base = k < sp ? L.base0[s] : L.base1[s];
+            if (base != VXH_Q_OVERFLOW) {
+                const uint64_t dst = (uint64_t)(s * (uint32_t)P.parts + blockIdx.x % (uint32_t)P.parts) * P.cap + base + (k < sp ? k : k - sp);
+                ((uint16_t *)P.qidx)[dst] = L.st_idx[j];
+                P.qval[0][dst] = (uint64_t)__double_as_longlong(L.st_val[j]);
+            } else { // sub-queue full (pathologically skewed data): device atomics straight into the grids
+                uint64_t gidx[1] = {((uint64_t)L.st_idx[j] << P.slab_log2) + s};
+                uint32_t f1[1] = {0xffu};
+                uint64_t v1[VXH_PART_MAX_VALS][1] = {{(uint64_t)__double_as_longlong(L.st_val[j])}, {0}, {0}, {0}};
+                records_apply<__HIP_MEMORY_SCOPE_AGENT, false, 1>(P, nullptr, gidx, f1, v1, 1u, 0);
+            }
+        }
+        set ^= 1u;
+    };
+
+    const uint64_t G = gridDim.x;
+    auto clamp_tile = [&](uint64_t t) { return t * T < n ? t : tile; };
+    Raw bufA, bufB; // ping-pong, the loop unrolled by two so that neither is copied
+    request(tile, bufA);
+    for (;;) {
+        tile_body(bufA, bufB, clamp_tile(tile + G));
+        if ((tile + G) * T >= n) break;
+        tile += G;
+        tile_body(bufB, bufA, clamp_tile(tile + G));
+        if ((tile + G) * T >= n) break;
+        tile += G;
+    }
+
+    // epilogue: null records into what is left of the open and of the pre-reserved block; flush the box
+    if (threadIdx.x < S) {
+        const unsigned long long blk = checked(q_nxt, VXH_HOT_QBLK);
+        L.tail[threadIdx.x] = q_cur;
+        L.tail[8 + threadIdx.x] = q_end;
+        L.tail[16 + threadIdx.x] = blk;
+    }
+    __syncthreads();
+    const uint64_t slab_cells = (P.A.cells + S - 1) >> P.slab_log2;
+    for (uint32_t s = 0; s < S; ++s) {
+        const uint64_t qb = (uint64_t)(s * (uint32_t)P.parts + blockIdx.x % (uint32_t)P.parts) * P.cap;
+        const unsigned long long c0 = L.tail[s], e0 = L.tail[8 + s], nb = L.tail[16 + s];
+        for (unsigned long long j = c0 + threadIdx.x; j < e0; j += VXH_HOT_BLOCK) {
+            ((uint16_t *)P.qidx)[qb + j] = (uint16_t)slab_cells;
+            P.qval[0][qb + j] = 0ull;
+        }
+        if (nb != VXH_Q_OVERFLOW) {
+            for (unsigned long long j = threadIdx.x; j < VXH_HOT_QBLK; j += VXH_HOT_BLOCK) {
+                ((uint16_t *)P.qidx)[qb + nb + j] = (uint16_t)slab_cells;
+                P.qval[0][qb + nb + j] = 0ull;
+            }
+        }
+    }
+    double *gs = P.hot.sum_acc + (uint64_t)blockIdx.x * hot_cells;
+    unsigned long long *gc = P.hot.cnt_acc + (uint64_t)blockIdx.x * hot_cells;
+    flush_add_plain<double, double>(gs, L.hot_sum, hot_cells, 0, 0, hot_cells);
+    flush_add_plain<unsigned long long, uint32_t>(gc, L.hot_cnt, hot_cells, 0, 0, hot_cells);
+}
+
 // pass 2: slab queues -> LDS-private slab -> HBM replica.  Each lane streams 4 consecutive records per
 // vector load and keeps N4 such batches in flight.
 template <int N4, bool PACK16>
@@ -1535,7 +1755,10 @@ void vxh_launch_part_scatter(const PartArgs &args, const LaunchPlan &plan, int s
         if (scatter_lds > 48 * 1024) (void)hipFuncSetAttribute((const void *)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, (int)scatter_lds); \
         hipLaunchKernelGGL(KERNEL, dim3(scatter_blocks), dim3(block), scatter_lds, stream, args);                      \
     } while (0)
-    if (args.hot.on) { // (the host only switches it on for the signature the HOT instantiation serves)
+    if (args.hot.on == 2) {
+        block = VXH_HOT_BLOCK;
+        VXH_SC(part_scatter_hot);
+    } else if (args.hot.on) { // (the host only switches it on for the signature the HOT instantiation serves)
         // ONE workgroup per CU (the box takes the LDS): 1024 threads x 2 rows = the same 2048-row tile
         scatter_lds = 2 * (size_t)args.scatter_lds_one + (size_t)args.hot.w * args.hot.h * 12 + 16;
         if (R == 2) { block = 1024; VXH_SC((part_scatter_f64<2, 1, 2, 0, true, 1024>)); }

@@ -113,6 +113,9 @@ struct PartArgs {
     } hot;
 };
 
+// LDS of part_scatter_hot ahead of the box: bucket counters, segment table, block tails, 4096-record staging
+#define VXH_HOT_FIXED_LDS (64 + 128 + 192 + 32 + 4096 * (8 + 2 + 1))
+
 struct HotMergeArgs {
     uint32_t x0, y0, w, h, blocks, nagg;
     uint64_t stride_y;             // cells per step of dim 1
