@@ -42,7 +42,9 @@ def run(**cfg):
         sa.config_set(k, {'hot': 1}.get(k, 0))
 
 
-run()
-run(hot=2)
-run(hot=0)
-run(part_chunk=1 << 29)
+for _ in range(2):
+    run()
+    run(no_pipeline=8)
+    run(no_pipeline=32)
+    run(no_pipeline=40)
+    run(hot=2)

@@ -1283,7 +1283,10 @@ int vxh_grid_bin(vxh_grid *grid, int thread, vxh_agg *const *aggs, int n_aggs, u
         if (whole.strategy == VXH_STRAT_PART) {
             part_join(slot);
             part_acc_merge(slot, whole_args);
-            if (slot.hot.on) hot_merge(slot, whole_args);
+            if (slot.hot.on) {
+                hot_merge(slot, whole_args);
+                slot.last_kernel = slot.hot.gen2 ? "part_scatter_hot+part_reduce_f64" : "part_scatter_f64(hot)+part_reduce_f64";
+            }
             slot.hot.on = false;
         }
     }

@@ -1221,6 +1221,17 @@ __global__ void __launch_bounds__(VXH_HOT_BLOCK) part_scatter_hot(const PartArgs
     };
     const double *colx = (const double *)P.A.b[0].data, *coly = (const double *)P.A.b[1].data, *colv = (const double *)P.vdata[0];
     auto request = [&](uint64_t t, Raw &raw) {
+        if ((t + 1) * T <= n && !(P.no_pipeline & 32)) { // whole tile inside the rows (wave-uniform): no per-row clamping
+            const uint64_t i0 = t * T + threadIdx.x;
+            raw.valid = (1u << R) - 1u;
+#pragma unroll
+            for (int r = 0; r < R; ++r) raw.x[r] = colx[i0 + (uint64_t)r * VXH_HOT_BLOCK];
+#pragma unroll
+            for (int r = 0; r < R; ++r) raw.y[r] = coly[i0 + (uint64_t)r * VXH_HOT_BLOCK];
+#pragma unroll
+            for (int r = 0; r < R; ++r) raw.v[r] = colv[i0 + (uint64_t)r * VXH_HOT_BLOCK];
+            return;
+        }
         const Rows<R> rows = make_rows<R>(t * T + threadIdx.x, VXH_HOT_BLOCK, n);
         raw.valid = rows.valid;
 #pragma unroll
@@ -1238,8 +1249,12 @@ __global__ void __launch_bounds__(VXH_HOT_BLOCK) part_scatter_hot(const PartArgs
 
     uint32_t set = 0;
     const BinnerDesc &b0 = P.A.b[0], &b1 = P.A.b[1];
+    const uint32_t stride1 = (uint32_t)b1.stride;
+    const uint32_t lane = threadIdx.x & 63u;
     auto tile_body = [&](const Raw &cur, Raw &into, uint64_t req_tile) {
         uint32_t *cnt = L.s_cnt + set * 8;
+        const bool late = (P.no_pipeline & 4) == 0; // default: after [C] (requesting at the top measured 1 % slower; knob bit 2)
+        if (!late) request(req_tile, into);
         // [B]
         uint32_t keep = cur.valid;
         uint32_t slab[R], loc[R], pos[R];
@@ -1247,14 +1262,14 @@ __global__ void __launch_bounds__(VXH_HOT_BLOCK) part_scatter_hot(const PartArgs
         for (int r = 0; r < R; ++r) {
             const uint32_t ix = scalar_sub_index32(cur.x[r], b0.vmin, b0.scale, b0.binsd, (uint32_t)b0.bins);
             const uint32_t iy = scalar_sub_index32(cur.y[r], b1.vmin, b1.scale, b1.binsd, (uint32_t)b1.bins);
-            const uint32_t idx = ix * (uint32_t)b0.stride + iy * (uint32_t)b1.stride;
+            const uint32_t idx = ix + __umul24(iy, stride1); // (dim 0 has stride 1; everything here is < 2^24)
             const uint32_t hx = ix - P.hot.x0, hy = iy - P.hot.y0; // (unsigned: below the box wraps to huge)
             const double val = cur.v[r];
             slab[r] = idx & (S - 1);
             loc[r] = idx >> P.slab_log2;
             pos[r] = 0;
             if (hx < P.hot.w && hy < P.hot.h && val == val && ((keep >> r) & 1u)) {
-                const uint32_t hc = hy * P.hot.w + hx;
+                const uint32_t hc = __umul24(hy, P.hot.w) + hx;
                 at_add<__HIP_MEMORY_SCOPE_WORKGROUP, double>(L.hot_sum + hc, val);
                 at_add<__HIP_MEMORY_SCOPE_WORKGROUP, uint32_t>(L.hot_cnt + hc, 1u);
                 keep &= ~(1u << r);
@@ -1295,32 +1310,45 @@ __global__ void __launch_bounds__(VXH_HOT_BLOCK) part_scatter_hot(const PartArgs
             L.split[threadIdx.x] = sp;
             (L.s_cnt + (set ^ 1u) * 8)[threadIdx.x] = 0; // next tile's counters (last read before the previous tile's final barrier)
         }
+        // lane l (< 8) of every wave forms the exclusive prefix of bucket l once per tile; a row then fetches the
+        // prefix of ITS bucket with one cross-lane read (ds_bpermute) instead of an 8-step compare/select chain
         uint32_t cn[8];
 #pragma unroll
         for (uint32_t b = 0; b < 8; ++b) cn[b] = b < S ? cnt[b] : 0u;
-        request(req_tile, into);
+        uint32_t my_off = 0, total = 0;
+#pragma unroll
+        for (uint32_t b = 0; b < 8; ++b) { my_off += b < lane ? cn[b] : 0u; total += cn[b]; }
+        uint32_t boff[R];
+        if (P.no_pipeline & 8) { // (A/B knob: the compare/select chain)
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                boff[r] = 0;
+#pragma unroll
+                for (uint32_t b = 0; b < 8; ++b) boff[r] += b < slab[r] ? cn[b] : 0u;
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < R; ++r) boff[r] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(slab[r] << 2), (int)my_off);
+        }
+        if (late) request(req_tile, into);
         // [D] stage, sorted by slab
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             if ((keep >> r) & 1u) {
-                uint32_t j = pos[r];
-#pragma unroll
-                for (uint32_t b = 0; b < 8; ++b) j += b < slab[r] ? cn[b] : 0u;
+                const uint32_t j = pos[r] + boff[r];
                 L.st_val[j] = cur.v[r];
                 L.st_idx[j] = (uint16_t)loc[r];
                 L.st_slab[j] = (uint8_t)slab[r];
             }
         }
         __syncthreads();
-        // [E] copy out
-        uint32_t total = 0;
-#pragma unroll
-        for (uint32_t b = 0; b < 8; ++b) total += cn[b];
-        for (uint32_t j = threadIdx.x; j < total; j += VXH_HOT_BLOCK) {
-            const uint32_t s = L.st_slab[j];
-            uint32_t k = j;
-#pragma unroll
-            for (uint32_t b = 0; b < 8; ++b) k -= b < s ? cn[b] : 0u;
+        // [E] copy out (the trip count is wave-uniform per wave: whole waves run the cross-lane read)
+        for (uint32_t j0 = threadIdx.x & ~63u; j0 < total; j0 += VXH_HOT_BLOCK) {
+            const uint32_t j = j0 + lane;
+            const bool live = j < total;
+            const uint32_t s = live ? (uint32_t)L.st_slab[j] : 0u;
+            const uint32_t k = j - (uint32_t)__builtin_amdgcn_ds_bpermute((int)(s << 2), (int)my_off);
+            if (!live) continue;
             const uint32_t sp = L.split[s];
             const unsigned long long base = k < sp ? L.base0[s] : L.base1[s];
             if (base != VXH_Q_OVERFLOW) {
