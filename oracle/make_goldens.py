@@ -72,6 +72,14 @@ def main():
     out["count_i32_binby"] = df.count(binby="i32", limits=[-1000, 1000], shape=10)
     out["sum_scalar"] = np.array(df.sum("v"))
     out["count_scalar"] = np.array(df.count())
+    # limits from the data — a min/max pass + a 1-d count pass + numpy (dataframe.py:1795-1840, :1632-1760)
+    out["limits_pct_y_90"] = df.limits_percentage("y", 90)
+    out["limits_pct_v_default"] = df.limits_percentage("v")
+    out["limits_pct_y_sel"] = df.limits_percentage("y", 95, selection="sel")
+    out["percentile_y_50"] = df.percentile_approx("y", 50)
+    out["percentile_y_multi"] = df.percentile_approx("y", [0, 10, 25, 50, 99, 100])
+    out["percentile_v_by_y"] = df.percentile_approx("v", 50, binby=["y"], limits=[[-3, 3]], shape=6)
+    out["median_y_sel"] = df.median_approx("y", selection="sel")
     out["mean_scalar"] = np.array(df.mean("v"))
 
     for name, key in (("dense", "k"), ("sparse", "ks")):

@@ -85,6 +85,13 @@ def replay(frame_factory, cols, dense_only=False):
     r["sum_scalar"] = df.sum("v")
     r["count_scalar"] = df.count()
     r["mean_scalar"] = df.mean("v")
+    r["limits_pct_y_90"] = df.limits_percentage("y", 90)
+    r["limits_pct_v_default"] = df.limits_percentage("v")
+    r["limits_pct_y_sel"] = df.limits_percentage("y", 95, selection="sel")
+    r["percentile_y_50"] = df.percentile_approx("y", 50)
+    r["percentile_y_multi"] = df.percentile_approx("y", [0, 10, 25, 50, 99, 100])
+    r["percentile_v_by_y"] = df.percentile_approx("v", 50, binby=["y"], limits=[[-3, 3]], shape=6)
+    r["median_y_sel"] = df.median_approx("y", selection="sel")
     spec = {"c": agg.count(), "s": agg.sum("v"), "m": agg.mean("v"), "sd": agg.std("v"), "mn": agg.min("v"), "mx": agg.max("v")}
     for name, key in (("dense", "k"),) + (() if dense_only else (("sparse", "ks"),)):
         g = df.groupby(key, spec)

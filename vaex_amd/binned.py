@@ -336,6 +336,100 @@ class Frame:
         return self._one("max", expression, binby, limits, shape, selection, edges)
 
     # ------------------------------------------------------------------ groupby
+    # ------------------------------------------------------------------ limits from the data
+    def limits_percentage(self, column, percentage=99.73, selection=None):
+        """df.limits_percentage (vaex/dataframe.py:1795-1840): the [lo, hi] range around the median that holds
+        `percentage` % of the rows — a min/max pass, a 16384-bin 1-d count pass (both on the GPU), then the
+        reference's numpy: cumulative counts, linear interpolation."""
+        vmin, vmax = self.minmax(column, selection=selection)
+        size = 1024 * 16
+        counts = self.count(binby=column, shape=size, limits=[vmin, vmax], selection=selection)
+        cumcounts = np.concatenate([[0], np.cumsum(counts)])
+        cumcounts = cumcounts / cumcounts.max()
+        f = (1 - percentage / 100.) / 2
+        x = np.linspace(vmin, vmax, size + 1)
+        return np.interp([f, 1 - f], cumcounts, x)
+
+    def percentile_approx(self, column, percentage=50., binby=(), limits=None, shape=128, percentile_shape=1024, percentile_limits="minmax", selection=None):
+        """df.percentile_approx (vaex/dataframe.py:1632-1760): the cumulative distribution of `column` on a grid of
+        percentile_shape cells (per binby cell), searched for the percentile and interpolated.  The count pass
+        (binby + [column], edges=True) runs on the GPU; the finish restates the reference's numpy and its
+        `vaexfast.grid_find_edges` (src/vaexfast.cpp:1680-1719) on the small result grid."""
+        binby = [binby] if isinstance(binby, str) else list(binby)
+        if isinstance(percentile_limits, str):
+            if percentile_limits != "minmax":
+                raise NotImplementedError("percentile_limits must be 'minmax' or [lo, hi]")
+            plim = self.minmax(column, selection=selection)
+        else:
+            plim = percentile_limits
+        nb = len(binby)
+        if not isinstance(shape, (list, tuple)):
+            shape = [shape] * nb
+        if nb:
+            if limits is not None and nb == 1 and np.ndim(limits) == 1:
+                limits = [limits]
+            blim = [self.minmax(b) if (limits is None or limits[i] is None) else limits[i] for i, b in enumerate(binby)]
+        else:
+            blim = []
+        counts = self.count(binby=binby + [column], shape=list(shape) + [percentile_shape], limits=list(blim) + [list(plim)], selection=selection, edges=True)
+        nonnans = tuple([slice(2, -1)] * nb + [slice(1, None)])  # drop the edge cells of the binby dims and the NaN cell of the last
+        counts_nonnans = counts[nonnans]
+        cumulative_grid = np.cumsum(counts_nonnans, -1).astype(np.float64)
+        totalcounts = np.sum(counts_nonnans, -1)
+        empty = totalcounts == 0
+        size = cumulative_grid.shape[-1]
+
+        def find_edges(values):  # per grid row: last edge left of `value`, first edge not left of it
+            edges = np.zeros(cumulative_grid.shape[:-1] + (2,), dtype=np.int64)
+            for i in np.ndindex(cumulative_grid.shape[:-1]):
+                row, value = cumulative_grid[i], values[i]
+                left = 0
+                while left < size - 1 and row[left + 1] < value:
+                    left += 1
+                right = left
+                while right < size - 1 and row[right] < value:
+                    right += 1
+                edges[i] = (left, right)
+            return edges
+
+        def index_choose(a, indices):
+            out = np.zeros(a.shape[:-1])
+            for i in np.ndindex(out.shape):
+                out[i] = a[i + (indices[i],)]
+            return out
+
+        lb, ub = plim
+        waslist = isinstance(percentage, (list, tuple, np.ndarray))
+        percentiles = []
+        for p in (percentage if waslist else [percentage]):
+            if p == 0:
+                percentiles.append(lb)
+                continue
+            if p == 100:
+                percentiles.append(ub)
+                continue
+            values = np.array((totalcounts + 1) * p / 100.)
+            values[empty] = 0
+            floor_values, ceil_values = np.array(np.floor(values)), np.array(np.ceil(values))
+
+            def calculate_x(edges, vals):
+                left, right = edges[..., 0], edges[..., 1]
+                left_value, right_value = index_choose(cumulative_grid, left), index_choose(cumulative_grid, right)
+                denom = np.array(right_value - left_value)
+                denom[denom == 0] = 1.0
+                u = np.array(vals - left_value) / denom
+                xleft = lb + (left - 0.5) * (ub - lb) / (size - 3)
+                xright = lb + (right - 0.5) * (ub - lb) / (size - 3)
+                return xleft + (xright - xleft) * u
+
+            x1 = calculate_x(find_edges(floor_values), floor_values)
+            x2 = calculate_x(find_edges(ceil_values), ceil_values)
+            percentiles.append(x1 + (x2 - x1) * (values - floor_values))
+        return np.array(percentiles) if waslist else np.array(percentiles[0])
+
+    def median_approx(self, column, binby=(), limits=None, shape=128, percentile_shape=256, percentile_limits="minmax", selection=None):
+        return self.percentile_approx(column, 50, binby=binby, limits=limits, shape=shape, percentile_shape=percentile_shape, percentile_limits=percentile_limits, selection=selection)
+
     def groupby(self, by, agg_spec, reduce=None, comm=None):
         """df.groupby(by).agg({...}) for ONE integer key column.  Returns {by: keys (ascending), name: values}.
 
