@@ -39,12 +39,10 @@ def run(**cfg):
     hot = f"hot {sa.config_get('hot_w')}x{sa.config_get('hot_h')}@({sa.config_get('hot_x0')},{sa.config_get('hot_y0')}) {sa.config_get('hot_fraction_ppm')/1e4:.1f}%"
     print(f"{str(cfg):<60} {best:.3f} ms = {rows/best/1e6:6.1f} Grows/s  [{hot}]", flush=True)
     for k in cfg:
-        sa.config_set(k, {'hot': 1}.get(k, 0))
+        sa.config_set(k, {'hot': 1, 'blk': 1}.get(k, 0))
 
 
-for _ in range(2):
-    run()
-    run(no_pipeline=8)
-    run(no_pipeline=32)
-    run(no_pipeline=40)
-    run(hot=2)
+run()
+run(hot=0)
+run(hot=0, blk=0)
+run(blk=0)

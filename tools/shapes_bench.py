@@ -53,7 +53,7 @@ def run(label, dims, shape, kinds, bytes_per_row, mask=False, cfg=()):
     total = int(aggs[0].get_result().sum())
     print(f"{label:<66} {best:8.3f} ms {rows/best/1e6:8.1f} Grows/s {rows*bytes_per_row/best/1e6:8.0f} GB/s  {sa.last_kernel(0)}  (sum {total})", flush=True)
     for k, _ in cfg:
-        sa.config_set(k, {"count16": 1}.get(k, 0))
+        sa.config_set(k, {"count16": 1, "blk": 1, "hot": 1}.get(k, 0))
 
 
 run("count only 256^2 (packed u16 LDS counters)", "xy", 256, ["count"], 16)
@@ -65,6 +65,10 @@ run("count+sum+countv 256^2 (the bench pass)", "xy", 256, ["count", "sum", "coun
 run("count+sum+countv 64^2 (LDS)", "xy", 64, ["count", "sum", "countv"], 24)
 run("count+sum+countv 1024^2", "xy", 1024, ["count", "sum", "countv"], 24)
 run("count 3-D 128^3 selection (25 B/row)", "xyz", 128, ["count"], 25, mask=True)
-run("count 3-D 128^3 selection, count16=2", "xyz", 128, ["count"], 25, mask=True, cfg=[("count16", 2)])
+run("count 3-D 128^3 selection, blk=0", "xyz", 128, ["count"], 25, mask=True, cfg=[("blk", 0)])
 run("count 3-D 64^3 (24 B/row)", "xyz", 64, ["count"], 24)
-run("count 3-D 64^3, count16=2", "xyz", 64, ["count"], 24, cfg=[("count16", 2)])
+run("count 3-D 64^3, blk=0", "xyz", 64, ["count"], 24, cfg=[("blk", 0)])
+run("count+sum+countv 1024^2, blk=0", "xy", 1024, ["count", "sum", "countv"], 24, cfg=[("blk", 0)])
+run("count only 512^2", "xy", 512, ["count"], 16)
+run("count only 512^2, hot=0", "xy", 512, ["count"], 16, cfg=[("hot", 0)])
+run("count only 512^2, blk=0", "xy", 512, ["count"], 16, cfg=[("blk", 0)])

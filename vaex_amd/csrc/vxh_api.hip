@@ -538,17 +538,17 @@ static size_t scatter_lds_bytes(size_t S, int R, int nvals) {
 // ------------------------------------------------------------------------------------------
 // The signature pass 1's HOT instantiation serves: two scalar float64 binners, ONE float64 value column, no masks,
 // aggregators count(*) / count(v) / sum(v).
-static bool hot_eligible(const BinArgs &A, const LaunchPlan &plan) {
-    if (!plan.fast_f64 || A.ndim != 2 || A.nagg < 1 || A.cells >= (1ull << 31)) return false;
+static int hot_eligible(const BinArgs &A, const LaunchPlan &plan) {
+    if (!plan.fast_f64 || A.ndim != 2 || A.nagg < 1 || A.cells >= (1ull << 31)) return -1;
     const void *v = nullptr;
     for (int k = 0; k < A.nagg; k++) {
         const AggDesc &a = A.a[k];
-        if (a.mask) return false;
-        if (a.kind == VXH_AGG_COUNT) { if (a.data) { if (v && v != a.data) return false; v = a.data; } }
-        else if (a.kind == VXH_AGG_SUM && a.cell == VXH_CELL_F64 && a.data) { if (v && v != a.data) return false; v = a.data; }
-        else return false;
+        if (a.mask) return -1;
+        if (a.kind == VXH_AGG_COUNT) { if (a.data) { if (v && v != a.data) return -1; v = a.data; } }
+        else if (a.kind == VXH_AGG_SUM && a.cell == VXH_CELL_F64 && a.data) { if (v && v != a.data) return -1; v = a.data; }
+        else return -1;
     }
-    return v != nullptr;
+    return v != nullptr ? 1 : 0; // 0: count(*) only — the box holds just counts
 }
 
 // densest w x h rectangle with w*h <= max_cells in a (sx, sy) count grid (dim 0 fastest): a dozen aspect ratios
@@ -581,7 +581,8 @@ static void hot_prepare(Slot &slot, const BinArgs &A, const BinArgs &planned, co
     H.on = false;
     H.last_on = false;
     H.last_fraction = 0;
-    if (!c.cfg_hot || !hot_eligible(A, plan)) return;
+    const int nval = c.cfg_hot ? hot_eligible(A, plan) : -1;
+    if (nval < 0) return;
     const bool forced = c.cfg_hot_box[2] > 0 && c.cfg_hot_box[3] > 0;
     if (!forced && length < (uint64_t)c.cfg_hot_min_rows) return;
     const size_t S = (size_t)1 << planned.slab_log2;
@@ -589,11 +590,14 @@ static void hot_prepare(Slot &slot, const BinArgs &A, const BinArgs &planned, co
     const uint64_t slab_cells = (planned.cells + S - 1) >> planned.slab_log2;
     // cfg_hot = 1: part_scatter_hot (block-reserved queues, 4096-row tiles; needs S <= 8 and uint16 local indices
     // with one value to spare for the null record); 2 / 3: the HOT instantiations of part_scatter_f64 (A/B runs)
-    const bool gen2 = c.cfg_hot == 1 && S <= 8 && slab_cells < 65535;
+    const bool gen2 = c.cfg_hot == 1 && c.cfg_blk && S <= 64 && slab_cells < 65535;
+    if (!gen2 && nval != 1) return; // the first-generation HOT instantiation needs the value column
     H.gen2 = gen2;
-    const size_t fixed = gen2 ? (size_t)VXH_HOT_FIXED_LDS : 2 * one;
+    H.nval = nval;
+    const size_t cell_bytes = nval ? 12 : 4;
+    const size_t fixed = gen2 ? (size_t)VXH_BLK_FIXED_LDS(nval) : 2 * one;
     if (fixed + 4096 > kLdsMax) return;
-    const uint64_t max_cells = (kLdsMax - fixed - 64) / 12;
+    const uint64_t max_cells = (kLdsMax - fixed - 64) / cell_bytes;
     const uint32_t sx = (uint32_t)(A.b[0].bins + 3), sy = (uint32_t)(A.b[1].bins + 3);
     uint32_t box[4] = {0, 0, 0, 0};
     if (forced) {
@@ -683,7 +687,7 @@ static void hot_merge(Slot &slot, const BinArgs &planned) {
     M.nagg = (uint32_t)planned.nagg;
     M.stride_y = planned.b[1].stride;
     M.atomic = planned.flush_plain ? 0 : 1;
-    M.sum_acc = (double *)H.acc;
+    M.sum_acc = H.nval ? (double *)H.acc : nullptr;
     M.cnt_acc = (unsigned long long *)((char *)H.acc + (size_t)H.blocks * H.w * H.h * 8);
     for (int k = 0; k < planned.nagg; k++) {
         M.grid[k] = planned.a[k].grid;
@@ -839,19 +843,30 @@ static void run_part_chunk(Slot &slot, const BinArgs &planned, const LaunchPlan 
     if (c.cfg_scatter_wgs > 0) per_cu = (int)c.cfg_scatter_wgs;
     const uint64_t tiles = (planned.n + 512ull * R - 1) / (512ull * R);
     int scatter_blocks = (int)std::max<uint64_t>(1, std::min<uint64_t>(tiles, (uint64_t)c.cus * per_cu));
-    if (slot.hot.on && R == 4 && P.nvals == 1 && P.nmasks == 0) {
+    // second-generation pass 1 (part_scatter_blk): float64 scalar binners, <= 1 float64 value column, <= 1 mask shared
+    // by every aggregator, uint16 local indices with one value to spare for the null record, <= 64 slabs
+    const bool blk = c.cfg_blk && plan.fast_f64 && !(c.cfg_no_pipeline & 1) && planned.ndim >= 1 && planned.ndim <= 3 && P.nvals <= 1 && !P.use_flags &&
+                     (P.nmasks == 0 || (P.nmasks == 1 && P.all_masked)) && P.idx16 && slab_cells < 65535 && S <= 64 && c.cfg_part_rows <= 0 &&
+                     (slot.hot.on || S > 8 || c.cfg_blk == 2); // (<= 8 slabs without a box: two 512-thread workgroups of part_scatter_f64 are 2 % faster)
+    const bool hot_here = slot.hot.on && P.nmasks == 0 && P.nvals == slot.hot.nval && (slot.hot.gen2 ? blk : (R == 4 && P.nvals == 1));
+    if (blk) {
+        P.blk = 1;
+        P.rows_per_thread = 4;
+        scatter_lds = (size_t)VXH_BLK_FIXED_LDS(P.nvals) + 16;
+        scatter_blocks = (int)std::max<uint64_t>(1, std::min<uint64_t>((planned.n + 4095) / 4096, (uint64_t)c.cus)); // ONE workgroup per CU
+    }
+    if (hot_here) {
         const Slot::Hot &H = slot.hot;
         P.hot.on = H.gen2 ? 2 : 1;
-        if (c.cfg_hot != 3) P.rows_per_thread = 2; // 1024 threads x 2 rows (hot = 3: 512 x 4, for A/B runs)
+        if (!H.gen2 && c.cfg_hot != 3) P.rows_per_thread = 2; // 1024 threads x 2 rows (hot = 3: 512 x 4, for A/B runs)
         P.hot.x0 = H.x0; P.hot.y0 = H.y0; P.hot.w = H.w; P.hot.h = H.h;
-        P.hot.lds_offset = (uint32_t)(H.gen2 ? (size_t)VXH_HOT_FIXED_LDS : 2 * (size_t)P.scatter_lds_one);
-        if (H.gen2) {
-            scatter_lds = (size_t)VXH_HOT_FIXED_LDS + (size_t)H.w * H.h * 12 + 16;
-            scatter_blocks = (int)std::max<uint64_t>(1, (planned.n + 4095) / 4096);
-        }
+        P.hot.lds_offset = (uint32_t)(H.gen2 ? (size_t)VXH_BLK_FIXED_LDS(P.nvals) : 2 * (size_t)P.scatter_lds_one);
+        if (H.gen2) scatter_lds = (size_t)VXH_BLK_FIXED_LDS(P.nvals) + (size_t)H.w * H.h * (P.nvals ? 12 : 4) + 16;
         P.hot.sum_acc = (double *)H.acc;
         P.hot.cnt_acc = (unsigned long long *)((char *)H.acc + (size_t)H.blocks * H.w * H.h * 8);
         scatter_blocks = std::min(scatter_blocks, H.blocks); // accumulator blocks are indexed by blockIdx
+    } else if (slot.hot.on) {
+        throw std::runtime_error("vaex_hip internal: hot box prepared for a signature pass 1 does not serve");
     }
     vxh_launch_part_scatter(P, plan, scatter_blocks, scatter_lds, slot.stream);
     HIP_CHECK(hipGetLastError());
@@ -943,6 +958,7 @@ int vxh_config_set(const char *key, int64_t value) {
     else if (k == "count_fast") c.cfg_count_fast = value;
     else if (k == "scatter_wgs") c.cfg_scatter_wgs = value;
     else if (k == "hot") c.cfg_hot = value;
+    else if (k == "blk") c.cfg_blk = value;
     else if (k == "hot_min_rows") c.cfg_hot_min_rows = value > 0 ? value : (1 << 24);
     else if (k == "hot_min_pct") c.cfg_hot_min_pct = value > 0 ? value : 35;
     else if (k == "hot_x0") c.cfg_hot_box[0] = value;
@@ -974,6 +990,7 @@ int vxh_config_get(const char *key, int64_t *value) {
     else if (k == "count_fast") *value = c.cfg_count_fast;
     else if (k == "scatter_wgs") *value = c.cfg_scatter_wgs;
     else if (k == "hot") *value = c.cfg_hot;
+    else if (k == "blk") *value = c.cfg_blk;
     else if (k == "hot_min_rows") *value = c.cfg_hot_min_rows;
     else if (k == "hot_min_pct") *value = c.cfg_hot_min_pct;
     else if (k == "hot_fraction_ppm") *value = (int64_t)(get_slot(0).hot.last_fraction * 1e6);

@@ -1159,56 +1159,52 @@ __global__ void __launch_bounds__(BLOCK) part_scatter_f64(const PartArgs P) {
     }
 }
 
-// K1b' — pass 1 with a hot box, second generation (PartArgs::hot.on == 2).  ONE 1024-thread workgroup per CU,
-// 4096-row tiles, two barriers per tile:
-//   * rows inside the box (non-NaN value) are added to the workgroup's LDS copy of the box, nothing else happens to them;
-//   * the others are bucketed by slab exactly as in part_scatter_f64 ([B] returning ds_add = position in bucket |
-//     barrier | [D] stage sorted by slab; S <= 8, so every lane forms the prefix itself | barrier | [E] copy out),
-//     but the queue space comes from BLOCKS of 1024 records that lane b of wave 0 reserves for bucket b ahead of
-//     time: the HBM atomic that reserves block k+1 is issued when block k is opened and only looked at when block k
-//     is full, so no tile ever waits for it and the staging area needs no double buffering (which is what leaves
-//     room for 4096-row tiles next to a ~95 KB box).  A tile's segment may straddle two blocks (split point parked
-//     in LDS).  What is left of the open and of the pre-reserved block at the end is filled with null records
-//     (local index = slab_cells: a dummy LDS cell of pass 2, value 0).
+// K1b' — pass 1, second generation (PartArgs::blk): 1..3 scalar float64 binners, at most one float64 value column,
+// at most one aggregator mask shared by every aggregator, uint16 local indices, S <= 64 slabs.  ONE 1024-thread
+// workgroup per CU, 4096-row tiles, two barriers per tile:
+//   * [B] rows are bucketed by slab (returning ds_add = position in bucket) | barrier | [D] staged sorted by slab —
+//     every wave forms the exclusive prefix of the bucket counts itself (one wave scan per tile, one ds_bpermute per
+//     row) | barrier | [E] copied out;
+//   * the queue space comes from BLOCKS of 1024 records that lane b of wave 0 reserves for bucket b ahead of time:
+//     the HBM atomic that reserves block k+1 is issued when block k is opened and only looked at when block k is
+//     full, so no tile ever waits for it and the staging area needs no double buffering (which is what leaves room
+//     for 4096-row tiles, and for the hot box).  A tile's segment may straddle two blocks (split point parked in LDS).
+//     What is left of the open and of the pre-reserved block at the end is filled with null records (local index =
+//     slab_cells: a dummy LDS cell of pass 2, value 0);
+//   * HOT (two binners, no mask; PartArgs::hot): rows inside the hot box (non-NaN value) are added to the
+//     workgroup's LDS copy of the box (fp64 sum + uint32 count per cell, or just the count) and emit no record.
 constexpr int VXH_HOT_BLOCK = 1024;   // threads
 constexpr int VXH_HOT_R = 4;          // rows per thread per tile
 constexpr uint32_t VXH_HOT_QBLK = 1024; // records per reserved queue block
 
-struct HotLds {
-    uint32_t *s_cnt;             // [2][8]
-    unsigned long long *base0;   // [8] queue slot of the bucket's record 0
-    unsigned long long *base1;   // [8] queue slot of its record `split` (second block), or OVERFLOW
-    uint32_t *split;             // [8]
-    unsigned long long *tail;    // [3][8] open block [cur,end) and pre-reserved block base, parked at the end
-    double *st_val;              // [T]
-    uint16_t *st_idx;            // [T]
-    uint8_t *st_slab;            // [T]
-    double *hot_sum;             // [w*h]
-    uint32_t *hot_cnt;           // [w*h]
-};
-
-__global__ void __launch_bounds__(VXH_HOT_BLOCK) part_scatter_hot(const PartArgs P) {
+template <int NDIM, int NVAL, bool MASKED, bool HOT>
+__global__ void __launch_bounds__(VXH_HOT_BLOCK) part_scatter_blk(const PartArgs P) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr int R = VXH_HOT_R;
     constexpr uint32_t T = VXH_HOT_BLOCK * R;
-    const uint32_t S = 1u << P.slab_log2; // <= 8
-    const uint32_t hot_cells = P.hot.w * P.hot.h;
-    HotLds L;
-    L.s_cnt = (uint32_t *)lds;
-    L.base0 = (unsigned long long *)(L.s_cnt + 16);
-    L.base1 = L.base0 + 8;
-    L.tail = L.base1 + 8;
-    L.split = (uint32_t *)(L.tail + 24);
-    L.st_val = (double *)(L.split + 8);
-    L.st_idx = (uint16_t *)(L.st_val + T);
-    L.st_slab = (uint8_t *)(L.st_idx + T);
-    L.hot_sum = (double *)(lds + P.hot.lds_offset);
-    L.hot_cnt = (uint32_t *)(L.hot_sum + hot_cells);
+    const uint32_t S = 1u << P.slab_log2; // <= 64
+    const uint32_t hot_cells = HOT ? P.hot.w * P.hot.h : 0u;
+    // LDS: [2][64] bucket counters | [64] base0 | [64] base1 | [3][64] block tails | [64] split | staging | box
+    uint32_t *const s_cnt = (uint32_t *)lds;
+    unsigned long long *const base0 = (unsigned long long *)(s_cnt + 128);
+    unsigned long long *const base1 = base0 + 64;
+    unsigned long long *const tail = base1 + 64;
+    uint32_t *const split = (uint32_t *)(tail + 192);
+    double *const st_val = (double *)(split + 64);
+    uint16_t *const st_idx = (uint16_t *)(st_val + (NVAL ? T : 0));
+    uint8_t *const st_slab = (uint8_t *)(st_idx + T);
+    double *const hot_sum = (double *)(lds + P.hot.lds_offset);
+    uint32_t *const hot_cnt = (uint32_t *)(hot_sum + (NVAL ? hot_cells : 0));
     const uint64_t n = P.A.n;
     uint64_t tile = blockIdx.x;
     if (tile * T >= n) return;
-    if (threadIdx.x < 16) L.s_cnt[threadIdx.x] = 0;
-    for (uint32_t c = threadIdx.x; c < hot_cells; c += VXH_HOT_BLOCK) { L.hot_sum[c] = 0.0; L.hot_cnt[c] = 0u; }
+    if (threadIdx.x < 128) s_cnt[threadIdx.x] = 0;
+    if (HOT) {
+        for (uint32_t c = threadIdx.x; c < hot_cells; c += VXH_HOT_BLOCK) {
+            if (NVAL) hot_sum[c] = 0.0;
+            hot_cnt[c] = 0u;
+        }
+    }
     // bucket b's queue blocks live in the registers of lane b (wave 0)
     const uint32_t sub = (threadIdx.x < S ? threadIdx.x : 0u) * (uint32_t)P.parts + blockIdx.x % (uint32_t)P.parts;
     unsigned long long q_cur = 0, q_end = 0, q_nxt = VXH_Q_OVERFLOW;
@@ -1216,30 +1212,39 @@ __global__ void __launch_bounds__(VXH_HOT_BLOCK) part_scatter_hot(const PartArgs
     __syncthreads();
 
     struct Raw {
-        double x[R], y[R], v[R];
+        double b[NDIM][R];
+        double v[NVAL ? R : 1];
+        uint8_t m[MASKED ? R : 1];
         uint32_t valid;
     };
-    const double *colx = (const double *)P.A.b[0].data, *coly = (const double *)P.A.b[1].data, *colv = (const double *)P.vdata[0];
+    const double *colv = NVAL ? (const double *)P.vdata[0] : nullptr;
+    const uint8_t *colm = MASKED ? P.mdata[0] : nullptr;
     auto request = [&](uint64_t t, Raw &raw) {
+        uint64_t i[R];
         if ((t + 1) * T <= n && !(P.no_pipeline & 32)) { // whole tile inside the rows (wave-uniform): no per-row clamping
-            const uint64_t i0 = t * T + threadIdx.x;
             raw.valid = (1u << R) - 1u;
 #pragma unroll
-            for (int r = 0; r < R; ++r) raw.x[r] = colx[i0 + (uint64_t)r * VXH_HOT_BLOCK];
+            for (int r = 0; r < R; ++r) i[r] = t * T + threadIdx.x + (uint64_t)r * VXH_HOT_BLOCK;
+        } else {
+            const Rows<R> rows = make_rows<R>(t * T + threadIdx.x, VXH_HOT_BLOCK, n);
+            raw.valid = rows.valid;
 #pragma unroll
-            for (int r = 0; r < R; ++r) raw.y[r] = coly[i0 + (uint64_t)r * VXH_HOT_BLOCK];
-#pragma unroll
-            for (int r = 0; r < R; ++r) raw.v[r] = colv[i0 + (uint64_t)r * VXH_HOT_BLOCK];
-            return;
+            for (int r = 0; r < R; ++r) i[r] = rows.i[r];
         }
-        const Rows<R> rows = make_rows<R>(t * T + threadIdx.x, VXH_HOT_BLOCK, n);
-        raw.valid = rows.valid;
 #pragma unroll
-        for (int r = 0; r < R; ++r) raw.x[r] = colx[rows.i[r]];
+        for (int d = 0; d < NDIM; ++d) {
+            const double *col = (const double *)P.A.b[d].data;
 #pragma unroll
-        for (int r = 0; r < R; ++r) raw.y[r] = coly[rows.i[r]];
+            for (int r = 0; r < R; ++r) raw.b[d][r] = col[i[r]];
+        }
+        if (NVAL) {
 #pragma unroll
-        for (int r = 0; r < R; ++r) raw.v[r] = colv[rows.i[r]];
+            for (int r = 0; r < R; ++r) raw.v[r] = colv[i[r]];
+        }
+        if (MASKED) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) raw.m[r] = colm[i[r]];
+        }
     };
     // a reserved block that does not fit the sub-queue: remember where the valid prefix ends, use the slow path
     auto checked = [&](unsigned long long base, unsigned long long size) -> unsigned long long {
@@ -1248,34 +1253,44 @@ __global__ void __launch_bounds__(VXH_HOT_BLOCK) part_scatter_hot(const PartArgs
     };
 
     uint32_t set = 0;
-    const BinnerDesc &b0 = P.A.b[0], &b1 = P.A.b[1];
-    const uint32_t stride1 = (uint32_t)b1.stride;
     const uint32_t lane = threadIdx.x & 63u;
     auto tile_body = [&](const Raw &cur, Raw &into, uint64_t req_tile) {
-        uint32_t *cnt = L.s_cnt + set * 8;
-        const bool late = (P.no_pipeline & 4) == 0; // default: after [C] (requesting at the top measured 1 % slower; knob bit 2)
-        if (!late) request(req_tile, into);
+        uint32_t *cnt = s_cnt + set * 64;
         // [B]
         uint32_t keep = cur.valid;
+        if (MASKED) { // aggregator mask: 1 = keep (src/agg_count.cpp:50); every aggregator carries this mask
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                if (cur.m[r] != 1) keep &= ~(1u << r);
+        }
         uint32_t slab[R], loc[R], pos[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            const uint32_t ix = scalar_sub_index32(cur.x[r], b0.vmin, b0.scale, b0.binsd, (uint32_t)b0.bins);
-            const uint32_t iy = scalar_sub_index32(cur.y[r], b1.vmin, b1.scale, b1.binsd, (uint32_t)b1.bins);
-            const uint32_t idx = ix + __umul24(iy, stride1); // (dim 0 has stride 1; everything here is < 2^24)
-            const uint32_t hx = ix - P.hot.x0, hy = iy - P.hot.y0; // (unsigned: below the box wraps to huge)
-            const double val = cur.v[r];
+            uint32_t sub_i[NDIM];
+#pragma unroll
+            for (int d = 0; d < NDIM; ++d) {
+                const BinnerDesc &b = P.A.b[d];
+                sub_i[d] = scalar_sub_index32(cur.b[d][r], b.vmin, b.scale, b.binsd, (uint32_t)b.bins);
+            }
+            uint32_t idx = sub_i[0]; // (dim 0 has stride 1; sub-indices and strides are < 2^24 here)
+#pragma unroll
+            for (int d = 1; d < NDIM; ++d) idx += __umul24(sub_i[d], (uint32_t)P.A.b[d].stride);
             slab[r] = idx & (S - 1);
             loc[r] = idx >> P.slab_log2;
             pos[r] = 0;
-            if (hx < P.hot.w && hy < P.hot.h && val == val && ((keep >> r) & 1u)) {
-                const uint32_t hc = __umul24(hy, P.hot.w) + hx;
-                at_add<__HIP_MEMORY_SCOPE_WORKGROUP, double>(L.hot_sum + hc, val);
-                at_add<__HIP_MEMORY_SCOPE_WORKGROUP, uint32_t>(L.hot_cnt + hc, 1u);
-                keep &= ~(1u << r);
-            } else if ((keep >> r) & 1u) {
-                pos[r] = __hip_atomic_fetch_add(&cnt[slab[r]], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            bool hot = false;
+            if (HOT) {
+                const uint32_t hx = sub_i[0] - P.hot.x0, hy = sub_i[NDIM > 1 ? 1 : 0] - P.hot.y0; // (unsigned: below the box wraps to huge)
+                hot = hx < P.hot.w && hy < P.hot.h && ((keep >> r) & 1u);
+                if (NVAL) hot = hot && cur.v[NVAL ? r : 0] == cur.v[NVAL ? r : 0];
+                if (hot) {
+                    const uint32_t hc = __umul24(hy, P.hot.w) + hx;
+                    if (NVAL) at_add<__HIP_MEMORY_SCOPE_WORKGROUP, double>(hot_sum + hc, cur.v[NVAL ? r : 0]);
+                    at_add<__HIP_MEMORY_SCOPE_WORKGROUP, uint32_t>(hot_cnt + hc, 1u);
+                    keep &= ~(1u << r);
+                }
             }
+            if (!hot && ((keep >> r) & 1u)) pos[r] = __hip_atomic_fetch_add(&cnt[slab[r]], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         __syncthreads();
         // [C] lane b: where bucket b's records of this tile go
@@ -1305,60 +1320,54 @@ __global__ void __launch_bounds__(VXH_HOT_BLOCK) part_scatter_hot(const PartArgs
                     q_nxt = atomicAdd(&P.qcount[sub], (unsigned long long)VXH_HOT_QBLK);
                 }
             }
-            L.base0[threadIdx.x] = a0;
-            L.base1[threadIdx.x] = a1;
-            L.split[threadIdx.x] = sp;
-            (L.s_cnt + (set ^ 1u) * 8)[threadIdx.x] = 0; // next tile's counters (last read before the previous tile's final barrier)
+            base0[threadIdx.x] = a0;
+            base1[threadIdx.x] = a1;
+            split[threadIdx.x] = sp;
+            (s_cnt + (set ^ 1u) * 64)[threadIdx.x] = 0; // next tile's counters (last read before the previous tile's final barrier)
         }
-        // lane l (< 8) of every wave forms the exclusive prefix of bucket l once per tile; a row then fetches the
-        // prefix of ITS bucket with one cross-lane read (ds_bpermute) instead of an 8-step compare/select chain
-        uint32_t cn[8];
+        // every wave: exclusive prefix of the bucket counts, bucket l in lane l (one scan per tile); a row then fetches
+        // the prefix of ITS bucket with one cross-lane read instead of a compare/select chain or an LDS table + barrier
+        const uint32_t c_l = lane < S ? cnt[lane] : 0u;
+        uint32_t inc = c_l;
 #pragma unroll
-        for (uint32_t b = 0; b < 8; ++b) cn[b] = b < S ? cnt[b] : 0u;
-        uint32_t my_off = 0, total = 0;
-#pragma unroll
-        for (uint32_t b = 0; b < 8; ++b) { my_off += b < lane ? cn[b] : 0u; total += cn[b]; }
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t t = (uint32_t)__shfl_up((int)inc, off, 64);
+            if ((int)lane >= off) inc += t;
+        }
+        const uint32_t my_off = inc - c_l;
+        const uint32_t total = (uint32_t)__shfl((int)inc, 63, 64);
         uint32_t boff[R];
-        if (P.no_pipeline & 8) { // (A/B knob: the compare/select chain)
 #pragma unroll
-            for (int r = 0; r < R; ++r) {
-                boff[r] = 0;
-#pragma unroll
-                for (uint32_t b = 0; b < 8; ++b) boff[r] += b < slab[r] ? cn[b] : 0u;
-            }
-        } else {
-#pragma unroll
-            for (int r = 0; r < R; ++r) boff[r] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(slab[r] << 2), (int)my_off);
-        }
-        if (late) request(req_tile, into);
+        for (int r = 0; r < R; ++r) boff[r] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(slab[r] << 2), (int)my_off);
+        request(req_tile, into); // the next tile's columns: in flight during [D], [E] and the barriers
         // [D] stage, sorted by slab
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             if ((keep >> r) & 1u) {
                 const uint32_t j = pos[r] + boff[r];
-                L.st_val[j] = cur.v[r];
-                L.st_idx[j] = (uint16_t)loc[r];
-                L.st_slab[j] = (uint8_t)slab[r];
+                if (NVAL) st_val[j] = cur.v[NVAL ? r : 0];
+                st_idx[j] = (uint16_t)loc[r];
+                st_slab[j] = (uint8_t)slab[r];
             }
         }
         __syncthreads();
-        // [E] copy out (the trip count is wave-uniform per wave: whole waves run the cross-lane read)
+        // [E] copy out (the trip count is uniform per wave: whole waves run the cross-lane read)
         for (uint32_t j0 = threadIdx.x & ~63u; j0 < total; j0 += VXH_HOT_BLOCK) {
             const uint32_t j = j0 + lane;
             const bool live = j < total;
-            const uint32_t s = live ? (uint32_t)L.st_slab[j] : 0u;
+            const uint32_t s = live ? (uint32_t)st_slab[j] : 0u;
             const uint32_t k = j - (uint32_t)__builtin_amdgcn_ds_bpermute((int)(s << 2), (int)my_off);
             if (!live) continue;
-            const uint32_t sp = L.split[s];
-            const unsigned long long base = k < sp ? L.base0[s] : L.base1[s];
+            const uint32_t sp = split[s];
+            const unsigned long long base = k < sp ? base0[s] : base1[s];
             if (base != VXH_Q_OVERFLOW) {
                 const uint64_t dst = (uint64_t)(s * (uint32_t)P.parts + blockIdx.x % (uint32_t)P.parts) * P.cap + base + (k < sp ? k : k - sp);
-                ((uint16_t *)P.qidx)[dst] = L.st_idx[j];
-                P.qval[0][dst] = (uint64_t)__double_as_longlong(L.st_val[j]);
+                ((uint16_t *)P.qidx)[dst] = st_idx[j];
+                if (NVAL) P.qval[0][dst] = (uint64_t)__double_as_longlong(st_val[j]);
             } else { // sub-queue full (pathologically skewed data): device atomics straight into the grids
-                uint64_t gidx[1] = {((uint64_t)L.st_idx[j] << P.slab_log2) + s};
+                uint64_t gidx[1] = {((uint64_t)st_idx[j] << P.slab_log2) + s};
                 uint32_t f1[1] = {0xffu};
-                uint64_t v1[VXH_PART_MAX_VALS][1] = {{(uint64_t)__double_as_longlong(L.st_val[j])}, {0}, {0}, {0}};
+                uint64_t v1[VXH_PART_MAX_VALS][1] = {{NVAL ? (uint64_t)__double_as_longlong(st_val[j]) : 0ull}, {0}, {0}, {0}};
                 records_apply<__HIP_MEMORY_SCOPE_AGENT, false, 1>(P, nullptr, gidx, f1, v1, 1u, 0);
             }
         }
@@ -1381,30 +1390,31 @@ __global__ void __launch_bounds__(VXH_HOT_BLOCK) part_scatter_hot(const PartArgs
     // epilogue: null records into what is left of the open and of the pre-reserved block; flush the box
     if (threadIdx.x < S) {
         const unsigned long long blk = checked(q_nxt, VXH_HOT_QBLK);
-        L.tail[threadIdx.x] = q_cur;
-        L.tail[8 + threadIdx.x] = q_end;
-        L.tail[16 + threadIdx.x] = blk;
+        tail[threadIdx.x] = q_cur;
+        tail[64 + threadIdx.x] = q_end;
+        tail[128 + threadIdx.x] = blk;
     }
     __syncthreads();
     const uint64_t slab_cells = (P.A.cells + S - 1) >> P.slab_log2;
     for (uint32_t s = 0; s < S; ++s) {
         const uint64_t qb = (uint64_t)(s * (uint32_t)P.parts + blockIdx.x % (uint32_t)P.parts) * P.cap;
-        const unsigned long long c0 = L.tail[s], e0 = L.tail[8 + s], nb = L.tail[16 + s];
+        const unsigned long long c0 = tail[s], e0 = tail[64 + s], nb = tail[128 + s];
         for (unsigned long long j = c0 + threadIdx.x; j < e0; j += VXH_HOT_BLOCK) {
             ((uint16_t *)P.qidx)[qb + j] = (uint16_t)slab_cells;
-            P.qval[0][qb + j] = 0ull;
+            if (NVAL) P.qval[0][qb + j] = 0ull;
         }
         if (nb != VXH_Q_OVERFLOW) {
             for (unsigned long long j = threadIdx.x; j < VXH_HOT_QBLK; j += VXH_HOT_BLOCK) {
                 ((uint16_t *)P.qidx)[qb + nb + j] = (uint16_t)slab_cells;
-                P.qval[0][qb + nb + j] = 0ull;
+                if (NVAL) P.qval[0][qb + nb + j] = 0ull;
             }
         }
     }
-    double *gs = P.hot.sum_acc + (uint64_t)blockIdx.x * hot_cells;
-    unsigned long long *gc = P.hot.cnt_acc + (uint64_t)blockIdx.x * hot_cells;
-    flush_add_plain<double, double>(gs, L.hot_sum, hot_cells, 0, 0, hot_cells);
-    flush_add_plain<unsigned long long, uint32_t>(gc, L.hot_cnt, hot_cells, 0, 0, hot_cells);
+    if (HOT) {
+        unsigned long long *gc = P.hot.cnt_acc + (uint64_t)blockIdx.x * hot_cells;
+        if (NVAL) flush_add_plain<double, double>(P.hot.sum_acc + (uint64_t)blockIdx.x * hot_cells, hot_sum, hot_cells, 0, 0, hot_cells);
+        flush_add_plain<unsigned long long, uint32_t>(gc, hot_cnt, hot_cells, 0, 0, hot_cells);
+    }
 }
 
 // pass 2: slab queues -> LDS-private slab -> HBM replica.  Each lane streams 4 consecutive records per
@@ -1653,9 +1663,8 @@ __global__ void __launch_bounds__(256) part_hot_merge(const HotMergeArgs M) {
     if (c < cells) {
         for (uint32_t b = q; b < M.blocks; b += 4) {
             const uint64_t i = (uint64_t)b * cells + c;
-            s += M.sum_acc[i];
+            if (M.sum_acc) { s += M.sum_acc[i]; M.sum_acc[i] = 0.0; }
             k += M.cnt_acc[i];
-            M.sum_acc[i] = 0.0;
             M.cnt_acc[i] = 0ull;
         }
     }
@@ -1783,9 +1792,19 @@ void vxh_launch_part_scatter(const PartArgs &args, const LaunchPlan &plan, int s
         if (scatter_lds > 48 * 1024) (void)hipFuncSetAttribute((const void *)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, (int)scatter_lds); \
         hipLaunchKernelGGL(KERNEL, dim3(scatter_blocks), dim3(block), scatter_lds, stream, args);                      \
     } while (0)
-    if (args.hot.on == 2) {
+    if (args.blk) { // second-generation pass 1 (the host checks the signature)
         block = VXH_HOT_BLOCK;
-        VXH_SC(part_scatter_hot);
+        const bool hot = args.hot.on == 2, masked = args.nmasks > 0;
+#define VXH_BLK(ND)                                                                                                    \
+    do {                                                                                                               \
+        if (args.nvals == 0) { if (masked) VXH_SC((part_scatter_blk<ND, 0, true, false>)); else VXH_SC((part_scatter_blk<ND, 0, false, false>)); } \
+        else { if (masked) VXH_SC((part_scatter_blk<ND, 1, true, false>)); else VXH_SC((part_scatter_blk<ND, 1, false, false>)); } \
+    } while (0)
+        if (hot) { if (args.nvals == 0) VXH_SC((part_scatter_blk<2, 0, false, true>)); else VXH_SC((part_scatter_blk<2, 1, false, true>)); }
+        else if (args.A.ndim == 1) VXH_BLK(1);
+        else if (args.A.ndim == 2) VXH_BLK(2);
+        else VXH_BLK(3);
+#undef VXH_BLK
     } else if (args.hot.on) { // (the host only switches it on for the signature the HOT instantiation serves)
         // ONE workgroup per CU (the box takes the LDS): 1024 threads x 2 rows = the same 2048-row tile
         scatter_lds = 2 * (size_t)args.scatter_lds_one + (size_t)args.hot.w * args.hot.h * 12 + 16;

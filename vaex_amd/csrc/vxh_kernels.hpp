@@ -100,6 +100,7 @@ struct PartArgs {
     // (Flushing straight into grid replicas touches one 64-128 B line per 8 B cell — the slabs interleave — which
     //  was ~130 us of every part_reduce launch: profiles/r01_chunk_fit.txt.)
     void *acc[VXH_MAX_AGG];
+    int32_t blk, reserved2_; // pass 1 = part_scatter_blk (block-reserved queues, 4096-row tiles)
     // "hot box" (part_scatter_f64<2,1,4,0,HOT=true>): a w x h rectangle of cells — chosen from a sample of the
     // call's rows as the densest one that fits — is aggregated in LDS by pass 1 itself (fp64 sum + uint32 count per
     // cell); only rows outside it (and rows whose value is NaN) are emitted as records.  Each pass-1 workgroup
@@ -113,8 +114,8 @@ struct PartArgs {
     } hot;
 };
 
-// LDS of part_scatter_hot ahead of the box: bucket counters, segment table, block tails, 4096-record staging
-#define VXH_HOT_FIXED_LDS (64 + 128 + 192 + 32 + 4096 * (8 + 2 + 1))
+// LDS of part_scatter_blk ahead of the box: bucket counters, segment table, block tails, 4096-record staging
+#define VXH_BLK_FIXED_LDS(NVAL) (512 + 512 + 512 + 1536 + 256 + 4096 * (8 * (NVAL) + 2 + 1))
 
 struct HotMergeArgs {
     uint32_t x0, y0, w, h, blocks, nagg;
