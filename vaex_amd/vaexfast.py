@@ -17,9 +17,15 @@ vaexfast.cpp:1189-1209), followed by a cell-wise fold into the caller's grid:
     OP_ADD_WEIGHT_MOMENTS_012 (4)  count, sum, sum of squares
 OP_COV (5) and OP_FIRST (6) are not built (no caller on the binby/groupby path) and raise.
 float64 blocks only: the _f4 variant scales in float32 and is not offered rather than approximated."""
+import threading
+
 import numpy as np
 
 from . import superagg as _sa
+
+# the entry has no thread-slot argument (the legacy task calls it from every pool thread with private grids): the
+# calls share slot 0 of the library, one at a time
+_LOCK = threading.Lock()
 
 OP_ADD1, OP_COUNT, OP_MIN_MAX, OP_ADD_WEIGHT_MOMENTS_01, OP_ADD_WEIGHT_MOMENTS_012, OP_COV, OP_FIRST = range(7)
 _FIELDS = {OP_ADD1: 1, OP_COUNT: 1, OP_MIN_MAX: 2, OP_ADD_WEIGHT_MOMENTS_01: 2, OP_ADD_WEIGHT_MOMENTS_012: 3}
@@ -50,6 +56,11 @@ def _postfix(a):
 
 def statisticNd_f8(blocks, weights, grid, minima, maxima, op_code, use_edges=0):
     """Accumulates one chunk into `grid` (in place); returns None like the reference."""
+    with _LOCK:
+        return _statistic_nd(blocks, weights, grid, minima, maxima, op_code, use_edges)
+
+
+def _statistic_nd(blocks, weights, grid, minima, maxima, op_code, use_edges):
     if not isinstance(blocks, (list, tuple)):
         raise ValueError("statisticNd_: blocklist (first argument) is not a list")
     if op_code in (OP_COV, OP_FIRST):
