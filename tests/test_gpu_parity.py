@@ -450,3 +450,32 @@ def test_hot_box_skewed_cold_rows(sa):
                 assert got[0].max() == n and sa.config_get("hot_w") == 60
     finally:
         _hot_reset(sa)
+
+
+def test_part_blk_signatures(sa):
+    # the second-generation pass 1 (part_scatter_blk) over its signature space: 1..3 dims, with / without a value
+    # column, with / without a shared mask, 16..64 slabs, ragged row counts; and the same cases with blk=0
+    c = cases.gaussian_columns(700_001, seed=21)
+    n = 700_001
+    m = c["v"] > 2.5
+    vn = c["v"].copy(); vn[::53] = np.nan
+
+    def bins(keys, shape):
+        return [dict(kind="scalar", data=c[k], vmin=-4, vmax=4, bins=shape) for k in keys]
+
+    todo = [
+        dict(n=n, binners=bins("x", 500_000), aggs=[dict(kind="count")]),                                            # 1-D, 500k cells: 16 slabs
+        dict(n=n, binners=bins("x", 500_000), aggs=[dict(kind="sum", data=vn, mask=m), dict(kind="count", mask=m)]),  # 1-D, value + mask
+        dict(n=n, binners=bins("xy", 700), aggs=[dict(kind="count"), dict(kind="max", data=vn), dict(kind="summoment", data=vn, moment=2)]),  # 2-D 703^2, min/max + moment on the records
+        dict(n=n, binners=bins("xyz", 96), aggs=[dict(kind="count", mask=m)]),                                        # 3-D 99^3 with a selection
+        dict(n=n, binners=bins("xyz", 96), aggs=[dict(kind="sum", data=vn)]),                                         # 3-D with a value column
+    ]
+    sa.config_set("strategy", STRATEGIES["part"])
+    for blk in (2, 0):
+        sa.config_set("blk", blk)
+        try:
+            for case in todo:
+                check(sa, case)
+                assert sa.last_kernel(0).startswith("part_scatter")
+        finally:
+            sa.config_set("blk", 1)
