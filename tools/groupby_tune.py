@@ -37,14 +37,10 @@ def run(**cfg):
     tot = int(aggs[1].get_result().sum())
     print(f"{str(cfg):<50} {best:8.3f} ms = {rows/best/1e6:6.1f} Grows/s {rows*16/best/1e6:6.0f} GB/s  {sa.last_kernel(0)} (count {tot})", flush=True)
     for key in cfg:
-        sa.config_set(key, 0)
+        sa.config_set(key, {'blk': 1}.get(key, 0))
 
 
 run()
-run(part_rows=4)
-run(part_rows=8)
-run(part_lds=78000)
-run(part_lds=78000, part_rows=8)
-run(part_lds=40000, part_rows=8)
-run(no_pipeline=1)        # generic pass-1 kernel
-run(no_pipeline=16)       # generic pass-2 kernel
+run(blk=0)
+run()
+run(blk=0)

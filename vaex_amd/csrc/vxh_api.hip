@@ -590,7 +590,7 @@ static void hot_prepare(Slot &slot, const BinArgs &A, const BinArgs &planned, co
     const uint64_t slab_cells = (planned.cells + S - 1) >> planned.slab_log2;
     // cfg_hot = 1: part_scatter_hot (block-reserved queues, 4096-row tiles; needs S <= 8 and uint16 local indices
     // with one value to spare for the null record); 2 / 3: the HOT instantiations of part_scatter_f64 (A/B runs)
-    const bool gen2 = c.cfg_hot == 1 && c.cfg_blk && S <= 64 && slab_cells < 65535;
+    const bool gen2 = c.cfg_hot == 1 && c.cfg_blk && S <= 256 && slab_cells < 65535;
     if (!gen2 && nval != 1) return; // the first-generation HOT instantiation needs the value column
     H.gen2 = gen2;
     H.nval = nval;
@@ -845,9 +845,10 @@ static void run_part_chunk(Slot &slot, const BinArgs &planned, const LaunchPlan 
     int scatter_blocks = (int)std::max<uint64_t>(1, std::min<uint64_t>(tiles, (uint64_t)c.cus * per_cu));
     // second-generation pass 1 (part_scatter_blk): float64 scalar binners, <= 1 float64 value column, <= 1 mask shared
     // by every aggregator, uint16 local indices with one value to spare for the null record, <= 64 slabs
-    const bool blk = c.cfg_blk && plan.fast_f64 && !(c.cfg_no_pipeline & 1) && planned.ndim >= 1 && planned.ndim <= 3 && P.nvals <= 1 && !P.use_flags &&
-                     (P.nmasks == 0 || (P.nmasks == 1 && P.all_masked)) && P.idx16 && slab_cells < 65535 && S <= 64 && c.cfg_part_rows <= 0 &&
-                     (slot.hot.on || S > 8 || c.cfg_blk == 2); // (<= 8 slabs without a box: two 512-thread workgroups of part_scatter_f64 are 2 % faster)
+    const bool blk = c.cfg_blk && (plan.fast_f64 || (plan.key_i64 && plan.fast_vals)) && !(c.cfg_no_pipeline & 1) && planned.ndim >= 1 && planned.ndim <= 3 && P.nvals <= 1 && !P.use_flags &&
+                     (P.nmasks == 0 || (P.nmasks == 1 && P.all_masked)) && P.idx16 && slab_cells < 65535 && S <= 256 && c.cfg_part_rows <= 0 &&
+                     (slot.hot.on || (S > 8 && S <= 64 && !plan.key_i64) || c.cfg_blk == 2); // measured (profiles/r01_other_shapes.txt, r01_groupby_tune.txt):
+                     // <= 8 slabs without a box: two 512-thread workgroups of part_scatter_f64 are 2 % faster; 128-256 slabs: +5 % (1024^2) / -35 % (1e6-key groupby)
     const bool hot_here = slot.hot.on && P.nmasks == 0 && P.nvals == slot.hot.nval && (slot.hot.gen2 ? blk : (R == 4 && P.nvals == 1));
     if (blk) {
         P.blk = 1;

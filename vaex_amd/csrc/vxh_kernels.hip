@@ -1177,20 +1177,22 @@ constexpr int VXH_HOT_BLOCK = 1024;   // threads
 constexpr int VXH_HOT_R = 4;          // rows per thread per tile
 constexpr uint32_t VXH_HOT_QBLK = 1024; // records per reserved queue block
 
-template <int NDIM, int NVAL, bool MASKED, bool HOT>
+template <int NDIM, int NVAL, bool MASKED, bool HOT, int KEY = 0>
 __global__ void __launch_bounds__(VXH_HOT_BLOCK) part_scatter_blk(const PartArgs P) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr int R = VXH_HOT_R;
     constexpr uint32_t T = VXH_HOT_BLOCK * R;
-    const uint32_t S = 1u << P.slab_log2; // <= 64
+    const uint32_t S = 1u << P.slab_log2; // <= 256
+    const bool few = S <= 64;             // one lane per bucket: prefix by wave scan + cross-lane reads, no LDS table
     const uint32_t hot_cells = HOT ? P.hot.w * P.hot.h : 0u;
-    // LDS: [2][64] bucket counters | [64] base0 | [64] base1 | [3][64] block tails | [64] split | staging | box
+    // LDS: [2][256] bucket counters | [256] base0 | [256] base1 | [3][256] block tails | [256] split | [260] prefix | staging | box
     uint32_t *const s_cnt = (uint32_t *)lds;
-    unsigned long long *const base0 = (unsigned long long *)(s_cnt + 128);
-    unsigned long long *const base1 = base0 + 64;
-    unsigned long long *const tail = base1 + 64;
-    uint32_t *const split = (uint32_t *)(tail + 192);
-    double *const st_val = (double *)(split + 64);
+    unsigned long long *const base0 = (unsigned long long *)(s_cnt + 512);
+    unsigned long long *const base1 = base0 + 256;
+    unsigned long long *const tail = base1 + 256;
+    uint32_t *const split = (uint32_t *)(tail + 768);
+    uint32_t *const s_off = split + 256;
+    double *const st_val = (double *)(s_off + 260);
     uint16_t *const st_idx = (uint16_t *)(st_val + (NVAL ? T : 0));
     uint8_t *const st_slab = (uint8_t *)(st_idx + T);
     double *const hot_sum = (double *)(lds + P.hot.lds_offset);
@@ -1198,7 +1200,7 @@ __global__ void __launch_bounds__(VXH_HOT_BLOCK) part_scatter_blk(const PartArgs
     const uint64_t n = P.A.n;
     uint64_t tile = blockIdx.x;
     if (tile * T >= n) return;
-    if (threadIdx.x < 128) s_cnt[threadIdx.x] = 0;
+    if (threadIdx.x < 512) s_cnt[threadIdx.x] = 0;
     if (HOT) {
         for (uint32_t c = threadIdx.x; c < hot_cells; c += VXH_HOT_BLOCK) {
             if (NVAL) hot_sum[c] = 0.0;
@@ -1255,7 +1257,7 @@ __global__ void __launch_bounds__(VXH_HOT_BLOCK) part_scatter_blk(const PartArgs
     uint32_t set = 0;
     const uint32_t lane = threadIdx.x & 63u;
     auto tile_body = [&](const Raw &cur, Raw &into, uint64_t req_tile) {
-        uint32_t *cnt = s_cnt + set * 64;
+        uint32_t *cnt = s_cnt + set * 256;
         // [B]
         uint32_t keep = cur.valid;
         if (MASKED) { // aggregator mask: 1 = keep (src/agg_count.cpp:50); every aggregator carries this mask
@@ -1270,7 +1272,13 @@ __global__ void __launch_bounds__(VXH_HOT_BLOCK) part_scatter_blk(const PartArgs
 #pragma unroll
             for (int d = 0; d < NDIM; ++d) {
                 const BinnerDesc &b = P.A.b[d];
-                sub_i[d] = scalar_sub_index32(cur.b[d][r], b.vmin, b.scale, b.binsd, (uint32_t)b.bins);
+                if (KEY == 1) { // ONE ordinal binner on a native int64 key (groupby): src/binner_ordinal.cpp:138-175 without mask
+                    const int64_t value = (int64_t)((uint64_t)__double_as_longlong(cur.b[d][r]) - (uint64_t)b.min_value);
+                    const int64_t nord = (int64_t)b.bins;
+                    sub_i[d] = (value < 0 || value >= nord) ? (uint32_t)nord : (uint32_t)(b.invert ? nord - 1 - value : value);
+                } else {
+                    sub_i[d] = scalar_sub_index32(cur.b[d][r], b.vmin, b.scale, b.binsd, (uint32_t)b.bins);
+                }
             }
             uint32_t idx = sub_i[0]; // (dim 0 has stride 1; sub-indices and strides are < 2^24 here)
 #pragma unroll
@@ -1323,22 +1331,48 @@ __global__ void __launch_bounds__(VXH_HOT_BLOCK) part_scatter_blk(const PartArgs
             base0[threadIdx.x] = a0;
             base1[threadIdx.x] = a1;
             split[threadIdx.x] = sp;
-            (s_cnt + (set ^ 1u) * 64)[threadIdx.x] = 0; // next tile's counters (last read before the previous tile's final barrier)
+            (s_cnt + (set ^ 1u) * 256)[threadIdx.x] = 0; // next tile's counters (last read before the previous tile's final barrier)
         }
-        // every wave: exclusive prefix of the bucket counts, bucket l in lane l (one scan per tile); a row then fetches
-        // the prefix of ITS bucket with one cross-lane read instead of a compare/select chain or an LDS table + barrier
-        const uint32_t c_l = lane < S ? cnt[lane] : 0u;
-        uint32_t inc = c_l;
+        // few buckets (<= 64): every wave forms the exclusive prefix itself, bucket l in lane l (one scan per tile); a
+        // row then fetches the prefix of ITS bucket with one cross-lane read instead of an LDS table + barrier.
+        // More buckets: wave 0 scans 4 buckets per lane into an LDS table, one more barrier.
+        uint32_t my_off = 0, total = 0;
+        if (few) {
+            const uint32_t c_l = lane < S ? cnt[lane] : 0u;
+            uint32_t inc = c_l;
 #pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t t = (uint32_t)__shfl_up((int)inc, off, 64);
-            if ((int)lane >= off) inc += t;
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t t = (uint32_t)__shfl_up((int)inc, off, 64);
+                if ((int)lane >= off) inc += t;
+            }
+            my_off = inc - c_l;
+            total = (uint32_t)__shfl((int)inc, 63, 64);
+        } else {
+            if (threadIdx.x < 64) {
+                const uint32_t per = S >> 6; // 2 or 4
+                uint32_t e[4], sum = 0;
+#pragma unroll
+                for (uint32_t j = 0; j < 4; ++j) {
+                    e[j] = sum;
+                    if (j < per) sum += cnt[lane * per + j];
+                }
+                uint32_t inc = sum;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const uint32_t t = (uint32_t)__shfl_up((int)inc, off, 64);
+                    if ((int)lane >= off) inc += t;
+                }
+#pragma unroll
+                for (uint32_t j = 0; j < 4; ++j)
+                    if (j < per) s_off[lane * per + j] = inc - sum + e[j];
+                if (lane == 63) s_off[S] = inc;
+            }
+            __syncthreads();
+            total = s_off[S];
         }
-        const uint32_t my_off = inc - c_l;
-        const uint32_t total = (uint32_t)__shfl((int)inc, 63, 64);
         uint32_t boff[R];
 #pragma unroll
-        for (int r = 0; r < R; ++r) boff[r] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(slab[r] << 2), (int)my_off);
+        for (int r = 0; r < R; ++r) boff[r] = few ? (uint32_t)__builtin_amdgcn_ds_bpermute((int)(slab[r] << 2), (int)my_off) : s_off[slab[r]];
         request(req_tile, into); // the next tile's columns: in flight during [D], [E] and the barriers
         // [D] stage, sorted by slab
 #pragma unroll
@@ -1356,7 +1390,7 @@ __global__ void __launch_bounds__(VXH_HOT_BLOCK) part_scatter_blk(const PartArgs
             const uint32_t j = j0 + lane;
             const bool live = j < total;
             const uint32_t s = live ? (uint32_t)st_slab[j] : 0u;
-            const uint32_t k = j - (uint32_t)__builtin_amdgcn_ds_bpermute((int)(s << 2), (int)my_off);
+            const uint32_t k = j - (few ? (uint32_t)__builtin_amdgcn_ds_bpermute((int)(s << 2), (int)my_off) : s_off[s]);
             if (!live) continue;
             const uint32_t sp = split[s];
             const unsigned long long base = k < sp ? base0[s] : base1[s];
@@ -1391,14 +1425,14 @@ __global__ void __launch_bounds__(VXH_HOT_BLOCK) part_scatter_blk(const PartArgs
     if (threadIdx.x < S) {
         const unsigned long long blk = checked(q_nxt, VXH_HOT_QBLK);
         tail[threadIdx.x] = q_cur;
-        tail[64 + threadIdx.x] = q_end;
-        tail[128 + threadIdx.x] = blk;
+        tail[256 + threadIdx.x] = q_end;
+        tail[512 + threadIdx.x] = blk;
     }
     __syncthreads();
     const uint64_t slab_cells = (P.A.cells + S - 1) >> P.slab_log2;
     for (uint32_t s = 0; s < S; ++s) {
         const uint64_t qb = (uint64_t)(s * (uint32_t)P.parts + blockIdx.x % (uint32_t)P.parts) * P.cap;
-        const unsigned long long c0 = tail[s], e0 = tail[64 + s], nb = tail[128 + s];
+        const unsigned long long c0 = tail[s], e0 = tail[256 + s], nb = tail[512 + s];
         for (unsigned long long j = c0 + threadIdx.x; j < e0; j += VXH_HOT_BLOCK) {
             ((uint16_t *)P.qidx)[qb + j] = (uint16_t)slab_cells;
             if (NVAL) P.qval[0][qb + j] = 0ull;
@@ -1800,7 +1834,11 @@ void vxh_launch_part_scatter(const PartArgs &args, const LaunchPlan &plan, int s
         if (args.nvals == 0) { if (masked) VXH_SC((part_scatter_blk<ND, 0, true, false>)); else VXH_SC((part_scatter_blk<ND, 0, false, false>)); } \
         else { if (masked) VXH_SC((part_scatter_blk<ND, 1, true, false>)); else VXH_SC((part_scatter_blk<ND, 1, false, false>)); } \
     } while (0)
-        if (hot) { if (args.nvals == 0) VXH_SC((part_scatter_blk<2, 0, false, true>)); else VXH_SC((part_scatter_blk<2, 1, false, true>)); }
+        if (plan.key_i64) { // groupby on an int64 key
+            if (args.nvals == 0) { if (masked) VXH_SC((part_scatter_blk<1, 0, true, false, 1>)); else VXH_SC((part_scatter_blk<1, 0, false, false, 1>)); }
+            else { if (masked) VXH_SC((part_scatter_blk<1, 1, true, false, 1>)); else VXH_SC((part_scatter_blk<1, 1, false, false, 1>)); }
+        }
+        else if (hot) { if (args.nvals == 0) VXH_SC((part_scatter_blk<2, 0, false, true>)); else VXH_SC((part_scatter_blk<2, 1, false, true>)); }
         else if (args.A.ndim == 1) VXH_BLK(1);
         else if (args.A.ndim == 2) VXH_BLK(2);
         else VXH_BLK(3);

@@ -115,7 +115,7 @@ struct PartArgs {
 };
 
 // LDS of part_scatter_blk ahead of the box: bucket counters, segment table, block tails, 4096-record staging
-#define VXH_BLK_FIXED_LDS(NVAL) (512 + 512 + 512 + 1536 + 256 + 4096 * (8 * (NVAL) + 2 + 1))
+#define VXH_BLK_FIXED_LDS(NVAL) (2048 + 2048 + 2048 + 6144 + 1024 + 1040 + 4096 * (8 * (NVAL) + 2 + 1))
 
 struct HotMergeArgs {
     uint32_t x0, y0, w, h, blocks, nagg;
