@@ -560,13 +560,15 @@ static int64_t hot_search(const std::vector<int64_t> &g, uint32_t sx, uint32_t s
         for (uint32_t x = 0; x < sx; x++) P(x + 1, y + 1) = g[(size_t)y * sx + x] + P(x, y + 1) + P(x + 1, y) - P(x, y);
     int64_t best = -1;
     const double side = std::sqrt((double)max_cells);
+    // big grids: candidate positions on a coarser lattice (<= ~256 per dim), so that the search stays ~1 ms
+    const uint32_t step = std::max<uint32_t>(1, (uint32_t)(std::max(sx, sy) / 256));
     for (int k = -8; k <= 8; k++) {
         uint32_t h = (uint32_t)std::max(1.0, std::min((double)sy, std::floor(side * std::pow(2.0, k / 4.0))));
         uint32_t w = (uint32_t)std::min<uint64_t>(sx, max_cells / h);
         if (w == 0) continue;
         h = (uint32_t)std::min<uint64_t>(sy, max_cells / w); // use what the clipped width leaves
-        for (uint32_t y0 = 0; y0 + h <= sy; y0++)
-            for (uint32_t x0 = 0; x0 + w <= sx; x0++) {
+        for (uint32_t y0 = 0; y0 + h <= sy; y0 += step)
+            for (uint32_t x0 = 0; x0 + w <= sx; x0 += step) {
                 const int64_t in = P(x0 + w, y0 + h) - P(x0, y0 + h) - P(x0 + w, y0) + P(x0, y0);
                 if (in > best) { best = in; box[0] = x0; box[1] = y0; box[2] = w; box[3] = h; }
             }
