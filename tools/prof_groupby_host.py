@@ -16,12 +16,14 @@ g = torch.Generator(device="cuda").manual_seed(7)
 v = torch.randn(rows, dtype=torch.float64, device="cuda", generator=g) * 2 + 3
 k = torch.randint(0, 1_000_000, (rows,), dtype=torch.int64, device="cuda", generator=g)
 torch.cuda.synchronize()
-df = Frame(dict(v=v, k=k))
+ks = (k * 2654435761) % (1 << 40)
+df = Frame(dict(v=v, k=k, ks=ks))
+KEY = os.environ.get("GROUP_KEY", "k")
 spec = {"s": agg.sum("v"), "m": agg.mean("v"), "sd": agg.std("v")}
-df.groupby("k", spec)
+df.groupby(KEY, spec)
 pr = cProfile.Profile()
 pr.enable()
 for _ in range(3):
-    df.groupby("k", spec)
+    df.groupby(KEY, spec)
 pr.disable()
 pstats.Stats(pr).sort_stats("cumulative").print_stats(22)

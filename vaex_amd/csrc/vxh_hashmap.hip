@@ -43,37 +43,59 @@ __device__ __forceinline__ long long load_key(const void *p, uint64_t i, int dt)
 // side words: [0] count  [1] null seen  [2] INT64_MIN key seen  [3] ordinal of INT64_MIN key  [4] table got too full
 // Optimistic: rows are inserted until the table holds max_count keys; a row that would need a NEW slot beyond that
 // raises side[4] and is skipped — the host then grows the table and re-runs the same (idempotent) call.
+// U keys per lane per trip: the U first probes (random 8-byte reads of a table that lives in Infinity Cache / HBM) are
+// in flight together; at load <= 1/4 most keys are settled by that probe and the rest finish in the sequential loop.
 __global__ void __launch_bounds__(256) hm_insert(const void *data, int dt, const uint8_t *mask, uint64_t n, long long *keys, long long *vals, uint64_t hmask, unsigned long long *side, unsigned long long max_count) {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    constexpr int U = 4;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (; i < n; i += stride) {
-        if (mask != nullptr && mask[i] == 1) {
-            if (side[1] == 0) atomicExch(&side[1], 1ull);
-            continue;
-        }
-        const long long key = load_key(data, i, dt);
-        if (key == EMPTY) {
-            if (side[2] == 0 && atomicCAS(&side[2], 0ull, 1ull) == 0ull) side[3] = atomicAdd(&side[0], 1ull);
-            continue;
-        }
-        uint64_t p = splitmix64((uint64_t)key) & hmask;
-        for (;;) {
-            long long cur = keys[p]; // may be a stale EMPTY (L1); the CAS below then returns the true owner
-            if (cur == key) break;
-            if (cur == EMPTY) {
-                // agent-scope load: a plain load could be served from this CU's L1 forever (never refreshed by other CUs' atomics)
-                if (__hip_atomic_load(&side[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= max_count) {
-                    if (side[4] == 0) atomicExch(&side[4], 1ull);
-                    break;
+    for (uint64_t i0 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < n; i0 += U * stride) {
+        long long key[U], first[U];
+        uint64_t p[U];
+        bool live[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint64_t i = i0 + (uint64_t)u * stride;
+            live[u] = i < n;
+            key[u] = EMPTY;
+            if (live[u]) {
+                if (mask != nullptr && mask[i] == 1) {
+                    if (side[1] == 0) atomicExch(&side[1], 1ull);
+                    live[u] = false;
+                } else {
+                    key[u] = load_key(data, i, dt);
+                    if (key[u] == EMPTY) {
+                        if (side[2] == 0 && atomicCAS(&side[2], 0ull, 1ull) == 0ull) side[3] = atomicAdd(&side[0], 1ull);
+                        live[u] = false;
+                    }
                 }
-                long long old = (long long)atomicCAS((unsigned long long *)&keys[p], (unsigned long long)EMPTY, (unsigned long long)key);
-                if (old == EMPTY) {
-                    vals[p] = (long long)atomicAdd(&side[0], 1ull);
-                    break;
-                }
-                if (old == key) break;
             }
-            p = (p + 1) & hmask;
+            p[u] = splitmix64((uint64_t)key[u]) & hmask;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) first[u] = keys[p[u]]; // (dead lanes read a valid slot and ignore it)
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (!live[u] || first[u] == key[u]) continue;
+            uint64_t q = p[u];
+            long long cur = first[u]; // may be a stale EMPTY (L1); the CAS below then returns the true owner
+            for (;;) {
+                if (cur == key[u]) break;
+                if (cur == EMPTY) {
+                    // agent-scope load: a plain load could be served from this CU's L1 forever (never refreshed by other CUs' atomics)
+                    if (__hip_atomic_load(&side[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= max_count) {
+                        if (side[4] == 0) atomicExch(&side[4], 1ull);
+                        break;
+                    }
+                    long long old = (long long)atomicCAS((unsigned long long *)&keys[q], (unsigned long long)EMPTY, (unsigned long long)key[u]);
+                    if (old == EMPTY) {
+                        vals[q] = (long long)atomicAdd(&side[0], 1ull);
+                        break;
+                    }
+                    if (old == key[u]) break;
+                }
+                q = (q + 1) & hmask;
+                cur = keys[q];
+            }
         }
     }
 }
@@ -161,8 +183,22 @@ struct vxh_hashmap {
     long long *vals = nullptr;
     unsigned long long *side = nullptr; // 8 words on the device
     unsigned long long host_side[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    // {key, ordinal} pairs, one 16-byte slot per table position: what a BinnerHash probes (ONE random line per probe
+    // instead of one in keys[] and one in vals[]); rebuilt lazily after the table changed
+    long long *packed = nullptr;
+    uint64_t packed_cap = 0;
+    bool packed_valid = false;
     std::mutex mutex;
 };
+
+__global__ void hm_pack(const long long *keys, const long long *vals, uint64_t cap, long long *packed) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (; i < cap; i += stride) {
+        packed[2 * i] = keys[i];
+        packed[2 * i + 1] = vals[i];
+    }
+}
 
 static void hm_alloc_table(uint64_t cap, long long **keys, long long **vals, hipStream_t st) {
     HIP_CHECK(hipMalloc(keys, cap * 8));
@@ -195,8 +231,21 @@ int64_t vxh_hashmap_size_for_binner(vxh_hashmap *m) {
 
 void vxh_hashmap_fill_binner_desc(vxh_hashmap *m, BinnerDesc *bd) {
     std::lock_guard<std::mutex> lock(m->mutex);
-    bd->hkeys = (const int64_t *)m->keys;
-    bd->hvals = (const int64_t *)m->vals;
+    if (!m->packed_valid) {
+        Slot &s = get_slot(0);
+        if (m->packed_cap != m->cap) {
+            HIP_CHECK(hipStreamSynchronize(s.stream));
+            if (m->packed) (void)hipFree(m->packed);
+            m->packed = nullptr;
+            HIP_CHECK(hipMalloc(&m->packed, m->cap * 16));
+            m->packed_cap = m->cap;
+        }
+        hipLaunchKernelGGL(hm_pack, dim3(grid_for(m->cap)), dim3(256), 0, s.stream, m->keys, m->vals, m->cap, m->packed);
+        HIP_CHECK(hipStreamSynchronize(s.stream)); // (the binner may be used from another slot's stream)
+        m->packed_valid = true;
+    }
+    bd->hkeys = (const int64_t *)m->packed; // packed {key, ordinal} slots: hvals == nullptr says so
+    bd->hvals = nullptr;
     bd->hmask = m->cap - 1;
     bd->bins = m->host_side[0];
     bd->null_bin = (int64_t)m->host_side[0] + 1;
@@ -238,6 +287,7 @@ void vxh_hashmap_destroy(vxh_hashmap *m) {
     (void)hipDeviceSynchronize();
     (void)hipFree(m->keys);
     (void)hipFree(m->vals);
+    if (m->packed) (void)hipFree(m->packed);
     (void)hipFree(m->side);
     delete m;
 }
@@ -266,6 +316,7 @@ int vxh_hashmap_update(vxh_hashmap *m, const void *keys, const uint8_t *mask, ui
         if (m->host_side[0] * 2 > m->cap) hm_grow(m, m->cap * 4, s.stream);
         const unsigned long long max_count = m->cap / 4 * 3;
         HIP_CHECK(hipMemsetAsync(m->side + 4, 0, 8, s.stream));
+        m->packed_valid = false;
         hipLaunchKernelGGL(hm_insert, dim3(grid_for(n)), dim3(256), 0, s.stream, dkeys, m->dtype, dmask, n, m->keys, m->vals, m->cap - 1, m->side, max_count);
         HIP_CHECK(hipGetLastError());
         hm_refresh(m, s.stream);
@@ -288,6 +339,7 @@ int vxh_hashmap_set_keys(vxh_hashmap *m, const int64_t *keys, uint64_t n) {
     long long *d = nullptr;
     HIP_CHECK(hipMalloc(&d, n * 8));
     HIP_CHECK(hipMemcpyAsync(d, keys, n * 8, hipMemcpyHostToDevice, s.stream));
+    m->packed_valid = false;
     hipLaunchKernelGGL(hm_insert_ordered, dim3(grid_for(n)), dim3(256), 0, s.stream, d, n, m->keys, m->vals, m->cap - 1, m->side);
     HIP_CHECK(hipGetLastError());
     unsigned long long cnt = n;

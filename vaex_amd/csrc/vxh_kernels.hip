@@ -182,8 +182,17 @@ __device__ __forceinline__ void flat_index_batch(const BinArgs &A, const Rows<N>
                 idx[u] += sub * b.stride;
             }
         } else {
-            // hash binner: cells [unknown, bin0..binN-1, null]
+            // hash binner: cells [unknown, bin0..binN-1, null].  The N first probes (random reads of a table in Infinity
+            // Cache / HBM) are issued together; keys not settled by them (collisions: load <= 3/4) finish one by one
             load_canon<N>(b.data, rows, b.dtype, b.flip, c);
+            // table slots are packed {key, ordinal} pairs (b.hkeys, 16 bytes each: one random line per probe)
+            const longlong2 *slots = (const longlong2 *)b.hkeys;
+            uint64_t p0[N];
+            int64_t k0[N], v0[N];
+#pragma unroll
+            for (int u = 0; u < N; ++u) p0[u] = splitmix64(c[u]) & b.hmask;
+#pragma unroll
+            for (int u = 0; u < N; ++u) { const longlong2 e = slots[p0[u]]; k0[u] = e.x; v0[u] = e.y; }
 #pragma unroll
             for (int u = 0; u < N; ++u) {
                 uint64_t sub = 0;
@@ -191,12 +200,15 @@ __device__ __forceinline__ void flat_index_batch(const BinArgs &A, const Rows<N>
                     sub = (uint64_t)b.null_bin;
                 } else {
                     const int64_t key = (int64_t)c[u];
-                    uint64_t p = splitmix64((uint64_t)key) & b.hmask;
+                    uint64_t p = p0[u];
+                    int64_t cur = k0[u], ord = v0[u];
                     for (;;) {
-                        const int64_t ord = b.hvals[p];
-                        if (ord < 0) break;
-                        if (b.hkeys[p] == key) { sub = (uint64_t)ord + 1; break; }
+                        if (ord < 0) break; // empty slot: unknown key
+                        if (cur == key) { sub = (uint64_t)ord + 1; break; }
                         p = (p + 1) & b.hmask;
+                        const longlong2 e = slots[p];
+                        cur = e.x;
+                        ord = e.y;
                     }
                 }
                 idx[u] += sub * b.stride;

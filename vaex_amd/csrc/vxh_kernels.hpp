@@ -24,8 +24,8 @@ struct BinnerDesc {
     uint64_t bins;       // scalar: bins; ordinal/hash: ordinal_count
     int64_t min_value;   // ordinal
     uint64_t stride;     // cells
-    const int64_t *hkeys; // hash: table keys
-    const int64_t *hvals; // hash: table ordinals (-1 = empty)
+    const int64_t *hkeys; // hash: table of packed {key, ordinal} slots (16 bytes each; ordinal -1 = empty)
+    const int64_t *hvals; // (unused: nullptr)
     uint64_t hmask;       // hash: capacity-1
     int64_t null_bin;     // hash: cell for masked rows
     uint8_t kind, dtype, flip, allow_other, invert;
