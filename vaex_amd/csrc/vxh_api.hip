@@ -1270,6 +1270,12 @@ int vxh_grid_bin(vxh_grid *grid, int thread, vxh_agg *const *aggs, int n_aggs, u
         } else {
             slot.hot.on = slot.hot.last_on = false;
         }
+        // a failure between prepare and merge would leave half-filled accumulators behind: make the next call refill them
+        struct PartGuard {
+            Slot &slot;
+            bool armed;
+            ~PartGuard() { if (armed) { slot.acc_sig = 0; slot.hot.on = false; } }
+        } part_guard{slot, whole.strategy == VXH_STRAT_PART};
         for (uint64_t r0 = 0; r0 < length; r0 += step) {
             const uint64_t rn = std::min(step, length - r0);
             BinArgs L = A;
@@ -1308,6 +1314,7 @@ int vxh_grid_bin(vxh_grid *grid, int thread, vxh_agg *const *aggs, int n_aggs, u
                 slot.last_kernel = slot.hot.gen2 ? "part_scatter_hot+part_reduce_f64" : "part_scatter_f64(hot)+part_reduce_f64";
             }
             slot.hot.on = false;
+            part_guard.armed = false;
         }
     }
     part_join(slot);
