@@ -1197,14 +1197,16 @@ __global__ void __launch_bounds__(VXH_HOT_BLOCK) part_scatter_blk(const PartArgs
     const uint32_t S = 1u << P.slab_log2; // <= 256
     const bool few = S <= 64;             // one lane per bucket: prefix by wave scan + cross-lane reads, no LDS table
     const uint32_t hot_cells = HOT ? P.hot.w * P.hot.h : 0u;
-    // LDS: [2][256] bucket counters | [256] base0 | [256] base1 | [3][256] block tails | [256] split | [260] prefix | staging | box
+    // LDS (SB = 64 or 256 bucket slots): [2][SB] bucket counters | [SB] base0 | [SB] base1 | [3][SB] block tails |
+    // [SB] split | [SB+4] prefix | staging | box          (VXH_BLK_FIXED_LDS on the host)
+    const uint32_t SB = few ? 64u : 256u;
     uint32_t *const s_cnt = (uint32_t *)lds;
-    unsigned long long *const base0 = (unsigned long long *)(s_cnt + 512);
-    unsigned long long *const base1 = base0 + 256;
-    unsigned long long *const tail = base1 + 256;
-    uint32_t *const split = (uint32_t *)(tail + 768);
-    uint32_t *const s_off = split + 256;
-    double *const st_val = (double *)(s_off + 260);
+    unsigned long long *const base0 = (unsigned long long *)(s_cnt + 2 * SB);
+    unsigned long long *const base1 = base0 + SB;
+    unsigned long long *const tail = base1 + SB;
+    uint32_t *const split = (uint32_t *)(tail + 3 * SB);
+    uint32_t *const s_off = split + SB;
+    double *const st_val = (double *)(s_off + SB + 4);
     uint16_t *const st_idx = (uint16_t *)(st_val + (NVAL ? T : 0));
     uint8_t *const st_slab = (uint8_t *)(st_idx + T);
     double *const hot_sum = (double *)(lds + P.hot.lds_offset);
@@ -1212,12 +1214,19 @@ __global__ void __launch_bounds__(VXH_HOT_BLOCK) part_scatter_blk(const PartArgs
     const uint64_t n = P.A.n;
     uint64_t tile = blockIdx.x;
     if (tile * T >= n) return;
-    if (threadIdx.x < 512) s_cnt[threadIdx.x] = 0;
+    if (threadIdx.x < 2 * SB) s_cnt[threadIdx.x] = 0;
+    // box counters: uint32, or two uint16 per word (P.hot.pack16: more cells fit; a half that wraps is repaired
+    // through the value the returning LDS atomic hands back — count16_issue / count16_settle, booked on this
+    // workgroup's block of the HBM accumulators)
+    const bool pack16 = HOT && P.hot.pack16 != 0;
+    const C16 hot_c16{HOT ? P.hot.cnt_acc + (uint64_t)blockIdx.x * hot_cells : nullptr, hot_cells, 0u, 0u, 1u};
     if (HOT) {
         for (uint32_t c = threadIdx.x; c < hot_cells; c += VXH_HOT_BLOCK) {
             if (NVAL) hot_sum[c] = 0.0;
-            hot_cnt[c] = 0u;
+            if (!pack16) hot_cnt[c] = 0u;
         }
+        if (pack16)
+            for (uint32_t c = threadIdx.x; c < (hot_cells + 1) / 2; c += VXH_HOT_BLOCK) hot_cnt[c] = 0u;
     }
     // bucket b's queue blocks live in the registers of lane b (wave 0)
     const uint32_t sub = (threadIdx.x < S ? threadIdx.x : 0u) * (uint32_t)P.parts + blockIdx.x % (uint32_t)P.parts;
@@ -1269,7 +1278,7 @@ __global__ void __launch_bounds__(VXH_HOT_BLOCK) part_scatter_blk(const PartArgs
     uint32_t set = 0;
     const uint32_t lane = threadIdx.x & 63u;
     auto tile_body = [&](const Raw &cur, Raw &into, uint64_t req_tile) {
-        uint32_t *cnt = s_cnt + set * 256;
+        uint32_t *cnt = s_cnt + set * SB;
         // [B]
         uint32_t keep = cur.valid;
         if (MASKED) { // aggregator mask: 1 = keep (src/agg_count.cpp:50); every aggregator carries this mask
@@ -1306,7 +1315,14 @@ __global__ void __launch_bounds__(VXH_HOT_BLOCK) part_scatter_blk(const PartArgs
                 if (hot) {
                     const uint32_t hc = __umul24(hy, P.hot.w) + hx;
                     if (NVAL) at_add<__HIP_MEMORY_SCOPE_WORKGROUP, double>(hot_sum + hc, cur.v[NVAL ? r : 0]);
-                    at_add<__HIP_MEMORY_SCOPE_WORKGROUP, uint32_t>(hot_cnt + hc, 1u);
+                    if (pack16) {
+                        const uint32_t one_idx[1] = {hc};
+                        uint32_t old1[1];
+                        count16_issue<1>(hot_cnt, one_idx, 1u, true, old1);
+                        count16_settle<1>(hot_cnt, one_idx, old1, hot_c16);
+                    } else {
+                        at_add<__HIP_MEMORY_SCOPE_WORKGROUP, uint32_t>(hot_cnt + hc, 1u);
+                    }
                     keep &= ~(1u << r);
                 }
             }
@@ -1343,7 +1359,7 @@ __global__ void __launch_bounds__(VXH_HOT_BLOCK) part_scatter_blk(const PartArgs
             base0[threadIdx.x] = a0;
             base1[threadIdx.x] = a1;
             split[threadIdx.x] = sp;
-            (s_cnt + (set ^ 1u) * 256)[threadIdx.x] = 0; // next tile's counters (last read before the previous tile's final barrier)
+            (s_cnt + (set ^ 1u) * SB)[threadIdx.x] = 0; // next tile's counters (last read before the previous tile's final barrier)
         }
         // few buckets (<= 64): every wave forms the exclusive prefix itself, bucket l in lane l (one scan per tile); a
         // row then fetches the prefix of ITS bucket with one cross-lane read instead of an LDS table + barrier.
@@ -1437,14 +1453,14 @@ __global__ void __launch_bounds__(VXH_HOT_BLOCK) part_scatter_blk(const PartArgs
     if (threadIdx.x < S) {
         const unsigned long long blk = checked(q_nxt, VXH_HOT_QBLK);
         tail[threadIdx.x] = q_cur;
-        tail[256 + threadIdx.x] = q_end;
-        tail[512 + threadIdx.x] = blk;
+        tail[SB + threadIdx.x] = q_end;
+        tail[2 * SB + threadIdx.x] = blk;
     }
     __syncthreads();
     const uint64_t slab_cells = (P.A.cells + S - 1) >> P.slab_log2;
     for (uint32_t s = 0; s < S; ++s) {
         const uint64_t qb = (uint64_t)(s * (uint32_t)P.parts + blockIdx.x % (uint32_t)P.parts) * P.cap;
-        const unsigned long long c0 = tail[s], e0 = tail[256 + s], nb = tail[512 + s];
+        const unsigned long long c0 = tail[s], e0 = tail[SB + s], nb = tail[2 * SB + s];
         for (unsigned long long j = c0 + threadIdx.x; j < e0; j += VXH_HOT_BLOCK) {
             ((uint16_t *)P.qidx)[qb + j] = (uint16_t)slab_cells;
             if (NVAL) P.qval[0][qb + j] = 0ull;
@@ -1459,7 +1475,13 @@ __global__ void __launch_bounds__(VXH_HOT_BLOCK) part_scatter_blk(const PartArgs
     if (HOT) {
         unsigned long long *gc = P.hot.cnt_acc + (uint64_t)blockIdx.x * hot_cells;
         if (NVAL) flush_add_plain<double, double>(P.hot.sum_acc + (uint64_t)blockIdx.x * hot_cells, hot_sum, hot_cells, 0, 0, hot_cells);
-        flush_add_plain<unsigned long long, uint32_t>(gc, hot_cnt, hot_cells, 0, 0, hot_cells);
+        if (pack16) {
+            __threadfence(); // the wrap repairs (device atomics on gc) of every wave land before the plain read-add-write
+            __syncthreads();
+            flush_add_plain<unsigned long long, uint16_t>(gc, (const uint16_t *)hot_cnt, hot_cells, 0, 0, hot_cells);
+        } else {
+            flush_add_plain<unsigned long long, uint32_t>(gc, hot_cnt, hot_cells, 0, 0, hot_cells);
+        }
     }
 }
 

@@ -109,13 +109,14 @@ struct PartArgs {
         int32_t on;
         uint32_t x0, y0, w, h;     // in sub-index units of dims 0 and 1 (edge cells included)
         uint32_t lds_offset;       // of the box inside pass 1's dynamic LDS
+        uint32_t pack16;           // box counters are two uint16 per LDS word (part_scatter_blk)
         double *sum_acc;           // [pass-1 workgroups][w*h]
         unsigned long long *cnt_acc;
     } hot;
 };
 
 // LDS of part_scatter_blk ahead of the box: bucket counters, segment table, block tails, 4096-record staging
-#define VXH_BLK_FIXED_LDS(NVAL) (2048 + 2048 + 2048 + 6144 + 1024 + 1040 + 4096 * (8 * (NVAL) + 2 + 1))
+#define VXH_BLK_FIXED_LDS(NVAL, S) (((S) <= 64 ? 64 : 256) * 56 + 16 + 4096 * (8 * (NVAL) + 2 + 1))
 
 struct HotMergeArgs {
     uint32_t x0, y0, w, h, blocks, nagg;
