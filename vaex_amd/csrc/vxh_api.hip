@@ -798,7 +798,11 @@ static void run_part_chunk(Slot &slot, const BinArgs &planned, const LaunchPlan 
     // balance any smooth distribution); whatever does not fit takes the HBM-atomic slow path inside part_scatter
     const uint64_t C = chunk_rows_max;
     const uint64_t nsub = (uint64_t)S * (uint64_t)P.parts;
-    P.cap = (nsub == 1 ? C : std::min<uint64_t>(C, 2 * (C / nsub) + 8192) + 7) & ~(uint64_t)7;
+    // With a hot box only the rows outside it are queued: the chunk is twice as long for the same scratch, and the
+    // capacity is three times the sampled outside share (+ 1/8) of a sub-queue's rows.
+    double share = 2.0;
+    if (slot.hot.on && slot.hot.gen2 && ctx().cfg_hot_box[2] <= 0 && slot.hot.last_fraction > 0 && slot.hot.last_fraction <= 1) share = std::min(2.0, 3.0 * (1.0 - slot.hot.last_fraction) + 0.125);
+    P.cap = (nsub == 1 ? C : std::min<uint64_t>(C, (uint64_t)(share * (double)(C / nsub)) + 8192 + 2 * 1024 * ((uint64_t)ctx().cus / std::max<uint64_t>(1, P.parts) + 1)) + 7) & ~(uint64_t)7;
     const size_t idx_bytes = P.idx16 ? 2 : 4;
     size_t off = 0;
     auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
@@ -1271,6 +1275,7 @@ int vxh_grid_bin(vxh_grid *grid, int thread, vxh_agg *const *aggs, int n_aggs, u
             step = (uint64_t)std::max<int64_t>(1 << 20, ctx().cfg_part_chunk);
             part_acc_prepare(slot, whole_args);
             hot_prepare(slot, A, whole_args, whole, length);
+            if (slot.hot.on && slot.hot.gen2 && ctx().cfg_hot_box[2] <= 0) step *= 2; // (see the capacity rule in run_part_chunk)
         } else {
             slot.hot.on = slot.hot.last_on = false;
         }
