@@ -8,7 +8,7 @@ from tests import cases
 
 pytestmark = pytest.mark.gpu
 
-KEYS = ("strategy", "blk", "hot", "hot_min_rows", "hot_min_pct", "hot_x0", "hot_y0", "hot_w", "hot_h", "part_chunk", "count16", "hot_pack16")
+KEYS = ("strategy", "blk", "hot", "hot_min_rows", "hot_min_pct", "hot_x0", "hot_y0", "hot_w", "hot_h", "part_chunk", "count16")
 
 
 def _reset(sa):
@@ -47,7 +47,7 @@ def test_fuzz_against_oracle(sa, gpu_ready, seed):
     try:
         sa.config_set("strategy", int(rng.choice([0, 0, 4, 4, 3])))
         sa.config_set("blk", int(rng.choice([1, 2, 0])))
-        sa.config_set("hot_pack16", int(rng.integers(0, 2)))
+        rng.integers(0, 2)  # (keeps the stream of the seeds stable)
         sa.config_set("count16", int(rng.choice([1, 2])))
         if rng.random() < 0.5:
             sa.config_set("part_chunk", 1 << 20)

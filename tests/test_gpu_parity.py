@@ -481,9 +481,8 @@ def test_part_blk_signatures(sa):
             sa.config_set("blk", 1)
 
 
-def test_hot_box_counter_wraps(sa):
-    # 4e7 rows into two neighbouring cells of the (forced) box: every workgroup adds ~78 k rows to each of two uint16
-    # box counters that share an LDS word -> both halves wrap, carries included.  Counts exact, sums within 1e-12.
+def test_hot_box_many_rows_per_cell(sa):
+    # 4e7 rows into two neighbouring cells of the (forced) box: ~78 k rows per workgroup and cell (uint32 box counters)
     sa.config_set("strategy", STRATEGIES["part"])
     try:
         for k, val in zip(("hot_x0", "hot_y0", "hot_w", "hot_h"), (100, 100, 60, 60)):
@@ -491,16 +490,13 @@ def test_hot_box_counter_wraps(sa):
         n = 40_000_000
         i = np.arange(n)
         width = 8.0 / 256
-        x = np.where(i % 2 == 0, 0.5 * width, 1.5 * width)  # sub-indices 130 and 131: box cells 30 and 31 of row 30 (even/odd pair)
+        x = np.where(i % 2 == 0, 0.5 * width, 1.5 * width)  # sub-indices 130 and 131: box cells 30 and 31 of row 30
         y = np.full(n, 0.5 * width)
         v = (i % 11).astype("f8")
         v[::1000] = np.nan
         case = dict(n=n, binners=[dict(kind="scalar", data=x, vmin=-4, vmax=4, bins=256), dict(kind="scalar", data=y, vmin=-4, vmax=4, bins=256)],
                     aggs=[dict(kind="count"), dict(kind="sum", data=v), dict(kind="count", data=v)])
-        for pack in (1, 0):
-            sa.config_set("hot_pack16", pack)
-            got = check(sa, case)
-            assert got[0].max() == n // 2 and sa.config_get("hot_w") == 60
+        got = check(sa, case)
+        assert got[0].max() == n // 2 and sa.config_get("hot_w") == 60
     finally:
-        sa.config_set("hot_pack16", 1)
         _hot_reset(sa)

@@ -596,8 +596,7 @@ static void hot_prepare(Slot &slot, const BinArgs &A, const BinArgs &planned, co
     if (!gen2 && nval != 1) return; // the first-generation HOT instantiation needs the value column
     H.gen2 = gen2;
     H.nval = nval;
-    H.pack16 = gen2 && c.cfg_hot_pack16;
-    const size_t cell_bytes = (nval ? 8 : 0) + (H.pack16 ? 2 : 4);
+    const size_t cell_bytes = nval ? 12 : 4;
     const size_t fixed = gen2 ? (size_t)VXH_BLK_FIXED_LDS(nval, S) : 2 * one;
     if (fixed + 4096 > kLdsMax) return;
     const uint64_t max_cells = (kLdsMax - fixed - 96) / cell_bytes;
@@ -869,8 +868,7 @@ static void run_part_chunk(Slot &slot, const BinArgs &planned, const LaunchPlan 
         if (!H.gen2 && c.cfg_hot != 3) P.rows_per_thread = 2; // 1024 threads x 2 rows (hot = 3: 512 x 4, for A/B runs)
         P.hot.x0 = H.x0; P.hot.y0 = H.y0; P.hot.w = H.w; P.hot.h = H.h;
         P.hot.lds_offset = (uint32_t)(H.gen2 ? (size_t)VXH_BLK_FIXED_LDS(P.nvals, S) : 2 * (size_t)P.scatter_lds_one);
-        P.hot.pack16 = H.pack16 ? 1 : 0;
-        if (H.gen2) scatter_lds = (size_t)VXH_BLK_FIXED_LDS(P.nvals, S) + (size_t)H.w * H.h * ((P.nvals ? 8 : 0) + (H.pack16 ? 2 : 4)) + 32;
+        if (H.gen2) scatter_lds = (size_t)VXH_BLK_FIXED_LDS(P.nvals, S) + (size_t)H.w * H.h * (P.nvals ? 12 : 4) + 32;
         P.hot.sum_acc = (double *)H.acc;
         P.hot.cnt_acc = (unsigned long long *)((char *)H.acc + (size_t)H.blocks * H.w * H.h * 8);
         scatter_blocks = std::min(scatter_blocks, H.blocks); // accumulator blocks are indexed by blockIdx
@@ -968,7 +966,6 @@ int vxh_config_set(const char *key, int64_t value) {
     else if (k == "scatter_wgs") c.cfg_scatter_wgs = value;
     else if (k == "hot") c.cfg_hot = value;
     else if (k == "blk") c.cfg_blk = value;
-    else if (k == "hot_pack16") c.cfg_hot_pack16 = value;
     else if (k == "hot_min_rows") c.cfg_hot_min_rows = value > 0 ? value : (1 << 24);
     else if (k == "hot_min_pct") c.cfg_hot_min_pct = value > 0 ? value : 35;
     else if (k == "hot_x0") c.cfg_hot_box[0] = value;
@@ -1001,7 +998,6 @@ int vxh_config_get(const char *key, int64_t *value) {
     else if (k == "scatter_wgs") *value = c.cfg_scatter_wgs;
     else if (k == "hot") *value = c.cfg_hot;
     else if (k == "blk") *value = c.cfg_blk;
-    else if (k == "hot_pack16") *value = c.cfg_hot_pack16;
     else if (k == "hot_min_rows") *value = c.cfg_hot_min_rows;
     else if (k == "hot_min_pct") *value = c.cfg_hot_min_pct;
     else if (k == "hot_fraction_ppm") *value = (int64_t)(get_slot(0).hot.last_fraction * 1e6);

@@ -90,7 +90,6 @@ struct Slot {
     // hot box of the current vxh_grid_bin call (PartArgs::hot) and its per-workgroup accumulators
     struct Hot {
         int nval = 1;      // value columns the box aggregates (1: fp64 sum + count per cell, 0: count only)
-        bool pack16 = false; // uint16 box counters
         bool gen2 = false; // part_scatter_hot (vs the HOT instantiation of part_scatter_f64)
         bool on = false, last_on = false; // last_on: the most recent call used the box (reporting)
         uint32_t x0 = 0, y0 = 0, w = 0, h = 0;
@@ -128,7 +127,6 @@ struct Context {
     int64_t cfg_part_chunk = 1 << 28; // rows per partition chunk (scratch: ~2 x record bytes x this; larger chunks amortise the launches)
     int64_t cfg_parts = 0;        // pass-2 workgroups per slab (0 = auto)
     int64_t cfg_part_lds = 0;     // LDS bytes per pass-2 slab (0 = auto)
-    int64_t cfg_hot_pack16 = 0;    // hot box counters: two uint16 per LDS word (measured slower than uint32: the returning atomics cost more than the ~4 % of traffic a 102x102 box saves over 98x98)
     int64_t cfg_blk = 1;           // second-generation pass 1 (part_scatter_blk) where its signature allows (0: part_scatter_f64)
     int64_t cfg_hot = 1;           // hot box in pass 1 of the partition strategy (0 off)
     int64_t cfg_hot_min_rows = 1 << 24; // calls shorter than this do not pay for the sample

@@ -1215,18 +1215,13 @@ __global__ void __launch_bounds__(VXH_HOT_BLOCK) part_scatter_blk(const PartArgs
     uint64_t tile = blockIdx.x;
     if (tile * T >= n) return;
     if (threadIdx.x < 2 * SB) s_cnt[threadIdx.x] = 0;
-    // box counters: uint32, or two uint16 per word (P.hot.pack16: more cells fit; a half that wraps is repaired
-    // through the value the returning LDS atomic hands back — count16_issue / count16_settle, booked on this
-    // workgroup's block of the HBM accumulators)
-    const bool pack16 = HOT && P.hot.pack16 != 0;
-    const C16 hot_c16{HOT ? P.hot.cnt_acc + (uint64_t)blockIdx.x * hot_cells : nullptr, hot_cells, 0u, 0u, 1u};
+    // (uint16 box counters — the K1d trick, 102x102 instead of 98x98 cells — were tried and dropped: the returning LDS
+    //  atomic + wrap check per hot row cost more than the 4 % of traffic the larger box saved: 141 vs 147-158 Grows/s)
     if (HOT) {
         for (uint32_t c = threadIdx.x; c < hot_cells; c += VXH_HOT_BLOCK) {
             if (NVAL) hot_sum[c] = 0.0;
-            if (!pack16) hot_cnt[c] = 0u;
+            hot_cnt[c] = 0u;
         }
-        if (pack16)
-            for (uint32_t c = threadIdx.x; c < (hot_cells + 1) / 2; c += VXH_HOT_BLOCK) hot_cnt[c] = 0u;
     }
     // bucket b's queue blocks live in the registers of lane b (wave 0)
     const uint32_t sub = (threadIdx.x < S ? threadIdx.x : 0u) * (uint32_t)P.parts + blockIdx.x % (uint32_t)P.parts;
@@ -1315,14 +1310,7 @@ __global__ void __launch_bounds__(VXH_HOT_BLOCK) part_scatter_blk(const PartArgs
                 if (hot) {
                     const uint32_t hc = __umul24(hy, P.hot.w) + hx;
                     if (NVAL) at_add<__HIP_MEMORY_SCOPE_WORKGROUP, double>(hot_sum + hc, cur.v[NVAL ? r : 0]);
-                    if (pack16) {
-                        const uint32_t one_idx[1] = {hc};
-                        uint32_t old1[1];
-                        count16_issue<1>(hot_cnt, one_idx, 1u, true, old1);
-                        count16_settle<1>(hot_cnt, one_idx, old1, hot_c16);
-                    } else {
-                        at_add<__HIP_MEMORY_SCOPE_WORKGROUP, uint32_t>(hot_cnt + hc, 1u);
-                    }
+                    at_add<__HIP_MEMORY_SCOPE_WORKGROUP, uint32_t>(hot_cnt + hc, 1u);
                     keep &= ~(1u << r);
                 }
             }
@@ -1475,13 +1463,7 @@ __global__ void __launch_bounds__(VXH_HOT_BLOCK) part_scatter_blk(const PartArgs
     if (HOT) {
         unsigned long long *gc = P.hot.cnt_acc + (uint64_t)blockIdx.x * hot_cells;
         if (NVAL) flush_add_plain<double, double>(P.hot.sum_acc + (uint64_t)blockIdx.x * hot_cells, hot_sum, hot_cells, 0, 0, hot_cells);
-        if (pack16) {
-            __threadfence(); // the wrap repairs (device atomics on gc) of every wave land before the plain read-add-write
-            __syncthreads();
-            flush_add_plain<unsigned long long, uint16_t>(gc, (const uint16_t *)hot_cnt, hot_cells, 0, 0, hot_cells);
-        } else {
-            flush_add_plain<unsigned long long, uint32_t>(gc, hot_cnt, hot_cells, 0, 0, hot_cells);
-        }
+        flush_add_plain<unsigned long long, uint32_t>(gc, hot_cnt, hot_cells, 0, 0, hot_cells);
     }
 }
 

@@ -109,7 +109,7 @@ struct PartArgs {
         int32_t on;
         uint32_t x0, y0, w, h;     // in sub-index units of dims 0 and 1 (edge cells included)
         uint32_t lds_offset;       // of the box inside pass 1's dynamic LDS
-        uint32_t pack16;           // box counters are two uint16 per LDS word (part_scatter_blk)
+        uint32_t reserved_;
         double *sum_acc;           // [pass-1 workgroups][w*h]
         unsigned long long *cnt_acc;
     } hot;
