@@ -45,4 +45,4 @@ def run(**cfg):
 run()
 run(hot=0)
 run(hot=0, blk=0)
-run(blk=0)
+run(part_chunk=1 << 29)

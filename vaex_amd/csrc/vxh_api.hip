@@ -588,16 +588,14 @@ static void hot_prepare(Slot &slot, const BinArgs &A, const BinArgs &planned, co
     const bool forced = c.cfg_hot_box[2] > 0 && c.cfg_hot_box[3] > 0;
     if (!forced && length < (uint64_t)c.cfg_hot_min_rows) return;
     const size_t S = (size_t)1 << planned.slab_log2;
-    const size_t one = (scatter_lds_bytes(S, 4, 1) + 15) & ~(size_t)15;
     const uint64_t slab_cells = (planned.cells + S - 1) >> planned.slab_log2;
-    // cfg_hot = 1: part_scatter_hot (block-reserved queues, 4096-row tiles; needs S <= 8 and uint16 local indices
-    // with one value to spare for the null record); 2 / 3: the HOT instantiations of part_scatter_f64 (A/B runs)
-    const bool gen2 = c.cfg_hot == 1 && c.cfg_blk && S <= 256 && slab_cells < 65535;
-    if (!gen2 && nval != 1) return; // the first-generation HOT instantiation needs the value column
-    H.gen2 = gen2;
+    // the box lives in part_scatter_blk: uint16 local indices with one value to spare for the null record
+    const bool gen2 = c.cfg_blk && S <= 256 && slab_cells < 65535 && !(c.cfg_no_pipeline & 1) && c.cfg_part_rows <= 0; // (= run_part_chunk's conditions for part_scatter_blk)
+    if (!gen2) return;
+    H.gen2 = true;
     H.nval = nval;
     const size_t cell_bytes = nval ? 12 : 4;
-    const size_t fixed = gen2 ? (size_t)VXH_BLK_FIXED_LDS(nval, S) : 2 * one;
+    const size_t fixed = (size_t)VXH_BLK_FIXED_LDS(nval, S);
     if (fixed + 4096 > kLdsMax) return;
     const uint64_t max_cells = (kLdsMax - fixed - 96) / cell_bytes;
     const uint32_t sx = (uint32_t)(A.b[0].bins + 3), sy = (uint32_t)(A.b[1].bins + 3);
@@ -664,7 +662,7 @@ static void hot_prepare(Slot &slot, const BinArgs &A, const BinArgs &planned, co
         if (H.last_fraction * 100.0 < (double)c.cfg_hot_min_pct) return;
     }
     H.x0 = box[0]; H.y0 = box[1]; H.w = box[2]; H.h = box[3];
-    const uint64_t tile_rows = gen2 ? 4096 : 2048;
+    const uint64_t tile_rows = 4096;
     const uint64_t tiles = (std::min<uint64_t>(length, (uint64_t)std::max<int64_t>(1 << 20, c.cfg_part_chunk)) + tile_rows - 1) / tile_rows;
     H.blocks = (int)std::max<uint64_t>(1, std::min<uint64_t>(tiles, (uint64_t)c.cus)); // ONE workgroup per CU: the box takes the LDS
     const size_t need = (size_t)H.blocks * H.w * H.h * 16;
@@ -855,7 +853,7 @@ static void run_part_chunk(Slot &slot, const BinArgs &planned, const LaunchPlan 
                      (P.nmasks == 0 || (P.nmasks == 1 && P.all_masked)) && P.idx16 && slab_cells < 65535 && S <= 256 && c.cfg_part_rows <= 0 &&
                      (slot.hot.on || (S > 8 && S <= 64 && !plan.key_i64) || c.cfg_blk == 2); // measured (profiles/r01_other_shapes.txt, r01_groupby_tune.txt):
                      // <= 8 slabs without a box: two 512-thread workgroups of part_scatter_f64 are 2 % faster; 128-256 slabs: +5 % (1024^2) / -35 % (1e6-key groupby)
-    const bool hot_here = slot.hot.on && P.nmasks == 0 && P.nvals == slot.hot.nval && (slot.hot.gen2 ? blk : (R == 4 && P.nvals == 1));
+    const bool hot_here = slot.hot.on && P.nmasks == 0 && P.nvals == slot.hot.nval && blk;
     if (blk) {
         P.blk = 1;
         P.rows_per_thread = 4;
@@ -864,11 +862,10 @@ static void run_part_chunk(Slot &slot, const BinArgs &planned, const LaunchPlan 
     }
     if (hot_here) {
         const Slot::Hot &H = slot.hot;
-        P.hot.on = H.gen2 ? 2 : 1;
-        if (!H.gen2 && c.cfg_hot != 3) P.rows_per_thread = 2; // 1024 threads x 2 rows (hot = 3: 512 x 4, for A/B runs)
+        P.hot.on = 2;
         P.hot.x0 = H.x0; P.hot.y0 = H.y0; P.hot.w = H.w; P.hot.h = H.h;
-        P.hot.lds_offset = (uint32_t)(H.gen2 ? (size_t)VXH_BLK_FIXED_LDS(P.nvals, S) : 2 * (size_t)P.scatter_lds_one);
-        if (H.gen2) scatter_lds = (size_t)VXH_BLK_FIXED_LDS(P.nvals, S) + (size_t)H.w * H.h * (P.nvals ? 12 : 4) + 32;
+        P.hot.lds_offset = (uint32_t)VXH_BLK_FIXED_LDS(P.nvals, S);
+        scatter_lds = (size_t)VXH_BLK_FIXED_LDS(P.nvals, S) + (size_t)H.w * H.h * (P.nvals ? 12 : 4) + 32;
         P.hot.sum_acc = (double *)H.acc;
         P.hot.cnt_acc = (unsigned long long *)((char *)H.acc + (size_t)H.blocks * H.w * H.h * 8);
         scatter_blocks = std::min(scatter_blocks, H.blocks); // accumulator blocks are indexed by blockIdx
@@ -1316,7 +1313,7 @@ int vxh_grid_bin(vxh_grid *grid, int thread, vxh_agg *const *aggs, int n_aggs, u
             part_acc_merge(slot, whole_args);
             if (slot.hot.on) {
                 hot_merge(slot, whole_args);
-                slot.last_kernel = slot.hot.gen2 ? "part_scatter_hot+part_reduce_f64" : "part_scatter_f64(hot)+part_reduce_f64";
+                slot.last_kernel = "part_scatter_hot+part_reduce_f64";
             }
             slot.hot.on = false;
             part_guard.armed = false;

@@ -974,10 +974,9 @@ __global__ void __launch_bounds__(1024) count_lds_f64(const BinArgs A) {
 //    later, so no lane ever waits for that round trip (measured: ~300 us of a 950 us pass-1 launch otherwise).
 // KEY = 1: ONE ordinal binner over a native unmasked int64 column instead (df.groupby on an integer key): the
 // 8 bytes of a row are loaded the same way and only the sub-index expression differs.
-// HOT (NDIM = 2, NVAL = 1, no masks; aggregators: count(*) / count(v) / sum(v)): rows that fall into the hot box
-// and carry a non-NaN value are added to the workgroup's LDS copy of the box and emit no record (PartArgs::hot).
-template <int NDIM, int NVAL, int R, int KEY = 0, bool HOT = false, int BLOCK = 512>
-__global__ void __launch_bounds__(BLOCK) part_scatter_f64(const PartArgs P) {
+template <int NDIM, int NVAL, int R, int KEY = 0>
+__global__ void __launch_bounds__(512) part_scatter_f64(const PartArgs P) {
+    constexpr int BLOCK = 512;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const uint32_t S = 1u << P.slab_log2;
     const uint32_t T = (uint32_t)BLOCK * R;
@@ -990,12 +989,6 @@ __global__ void __launch_bounds__(BLOCK) part_scatter_f64(const PartArgs P) {
     uint64_t tile = blockIdx.x;
     if (tile * T >= n) return;
     if (threadIdx.x < S) { L.s_cnt[threadIdx.x] = 0; Lp.s_cnt[threadIdx.x] = 0; }
-    const uint32_t hot_cells = HOT ? P.hot.w * P.hot.h : 0u;
-    double *hot_sum = (double *)(lds + P.hot.lds_offset);
-    uint32_t *hot_cnt = (uint32_t *)(hot_sum + hot_cells);
-    if (HOT) {
-        for (uint32_t c = threadIdx.x; c < hot_cells; c += BLOCK) { hot_sum[c] = 0.0; hot_cnt[c] = 0u; }
-    }
     __syncthreads();
 
     struct Raw {
@@ -1048,20 +1041,6 @@ __global__ void __launch_bounds__(BLOCK) part_scatter_f64(const PartArgs P) {
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             uint32_t idx = 0; // the partition strategy is only planned for grids < 2^31 cells
-            if (HOT) {
-                const BinnerDesc &b0 = P.A.b[0], &b1 = P.A.b[NDIM > 1 ? 1 : 0];
-                const uint32_t ix = scalar_sub_index32(cur.b[0][r], b0.vmin, b0.scale, b0.binsd, (uint32_t)b0.bins);
-                const uint32_t iy = scalar_sub_index32(cur.b[NDIM > 1 ? 1 : 0][r], b1.vmin, b1.scale, b1.binsd, (uint32_t)b1.bins);
-                idx = ix * (uint32_t)b0.stride + iy * (uint32_t)b1.stride;
-                const uint32_t hx = ix - P.hot.x0, hy = iy - P.hot.y0; // (unsigned: below the box wraps to huge)
-                const double val = __longlong_as_double((long long)cur.v[0][r]);
-                if (hx < P.hot.w && hy < P.hot.h && val == val && ((keep >> r) & 1u)) {
-                    const uint32_t hc = hy * P.hot.w + hx;
-                    at_add<__HIP_MEMORY_SCOPE_WORKGROUP, double>(hot_sum + hc, val);
-                    at_add<__HIP_MEMORY_SCOPE_WORKGROUP, uint32_t>(hot_cnt + hc, 1u);
-                    keep &= ~(1u << r);
-                }
-            } else
 #pragma unroll
             for (int d = 0; d < NDIM; ++d) {
                 const BinnerDesc &b = P.A.b[d];
@@ -1132,24 +1111,7 @@ __global__ void __launch_bounds__(BLOCK) part_scatter_f64(const PartArgs P) {
     };
     const uint64_t G = gridDim.x;
     auto clamp_tile = [&](uint64_t t) { return t * T < n ? t : tile; }; // (past the end: re-request a valid tile — static number of loads in flight)
-    if (HOT) {
-        // ONE workgroup per CU here (the box takes the LDS), so the loads of TWO tiles are kept in flight: three
-        // register buffers in rotation, the loop unrolled by three so that none is ever copied
-        Raw bufA, bufB, bufC;
-        request(tile, bufA);
-        request(clamp_tile(tile + G), bufB);
-        for (;;) {
-            tile_body(bufA, bufC, clamp_tile(tile + 2 * G));
-            if ((tile + G) * T >= n) break;
-            tile += G;
-            tile_body(bufB, bufA, clamp_tile(tile + 2 * G));
-            if ((tile + G) * T >= n) break;
-            tile += G;
-            tile_body(bufC, bufB, clamp_tile(tile + 2 * G));
-            if ((tile + G) * T >= n) break;
-            tile += G;
-        }
-    } else {
+    {
         Raw cur, nxt;
         request(tile, cur);
         for (;;) {
@@ -1163,12 +1125,6 @@ __global__ void __launch_bounds__(BLOCK) part_scatter_f64(const PartArgs P) {
     scatter_commit(P, Lp, S, gb_prev, cnt_prev);
     __syncthreads();
     if (!(P.no_pipeline & 2)) scatter_copy_out(P, Lp, S, T);
-    if (HOT) { // this workgroup's box -> its own block of the accumulators (exclusive, contiguous)
-        double *gs = P.hot.sum_acc + (uint64_t)blockIdx.x * hot_cells;
-        unsigned long long *gc = P.hot.cnt_acc + (uint64_t)blockIdx.x * hot_cells;
-        flush_add_plain<double, double>(gs, hot_sum, hot_cells, 0, 0, hot_cells);
-        flush_add_plain<unsigned long long, uint32_t>(gc, hot_cnt, hot_cells, 0, 0, hot_cells);
-    }
 }
 
 // K1b' — pass 1, second generation (PartArgs::blk): 1..3 scalar float64 binners, at most one float64 value column,
@@ -1859,11 +1815,6 @@ void vxh_launch_part_scatter(const PartArgs &args, const LaunchPlan &plan, int s
         else if (args.A.ndim == 2) VXH_BLK(2);
         else VXH_BLK(3);
 #undef VXH_BLK
-    } else if (args.hot.on) { // (the host only switches it on for the signature the HOT instantiation serves)
-        // ONE workgroup per CU (the box takes the LDS): 1024 threads x 2 rows = the same 2048-row tile
-        scatter_lds = 2 * (size_t)args.scatter_lds_one + (size_t)args.hot.w * args.hot.h * 12 + 16;
-        if (R == 2) { block = 1024; VXH_SC((part_scatter_f64<2, 1, 2, 0, true, 1024>)); }
-        else VXH_SC((part_scatter_f64<2, 1, 4, 0, true>));
     } else if (fast_f64 && R == 4 && args.A.ndim >= 1 && args.A.ndim <= 3 && args.nvals <= 2 && args.nmasks <= 1 && !(args.no_pipeline & 1)) {
 #define VXH_SCN(ND)                                                                                                    \
     do {                                                                                                               \
