@@ -249,6 +249,11 @@ static void agg_alloc_device(vxh_agg *a) {
         const uint64_t fit = (256ull << 20) / std::max<uint64_t>(1, cells * 8ull);
         if (fit >= 8) R = (int)std::min<uint64_t>(512, fit / 8 * 8);
         else R = cells * 8ull * 8ull <= (4ull << 30) ? 8 : 1;
+        // more than 64 replicas only serve the LDS strategy (one per workgroup group); a grid whose private copy can
+        // never fit a workgroup's LDS (counts: 2 B per cell when packed, everything else its cell size) takes the
+        // partition strategy (replica 0 only) or HBM atomics (<= 64 replicas)
+        const size_t lds_cell = a->kind == VXH_AGG_COUNT ? 2 : vxh_cell_size(a->cell);
+        if (cells * lds_cell > 160 * 1024) R = std::min(R, 64);
     }
     a->replicas = R;
     const size_t cs = vxh_cell_size(a->cell);
