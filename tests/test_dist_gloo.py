@@ -38,7 +38,11 @@ def _worker(rank, world, port, q):
         descs = [agg.count(), agg.mean("v"), agg.std("v"), agg.min("v"), agg.max("v")]
         res = local._agg(descs, binby=["x", "y"], limits=[[-4, 4], [-4, 4]], shape=32, reduce=vdist.allreduce_aggs)
         g = local.groupby("k", {"s": agg.sum("v"), "c": agg.count()}, reduce=vdist.allreduce_aggs, comm=vdist.Comm())
-        q.put((rank, [np.asarray(r) for r in res], {k: np.asarray(v) for k, v in g.items()}))
+        # a Frame that knows its communicator: limits from the data (global min/max), percentiles, groupby — no hooks passed
+        shard = Frame({k: c[i1:i2] for k, c in cols.items()}, chunk_size=4096, nthreads=1, superagg=RefAdapter(oracle.ref_module("superagg")), comm=vdist.Comm())
+        auto = dict(mm=shard.minmax("v"), cnt=shard.count(binby="v", shape=16), lp=shard.limits_percentage("x", 90), med=shard.median_approx("y"),
+                    gk=shard.groupby("k", {"c": agg.count()})["c"])
+        q.put((rank, [np.asarray(r) for r in res], {k: np.asarray(v) for k, v in g.items()}, {k: np.asarray(v) for k, v in auto.items()}))
     finally:
         dist.destroy_process_group()
 
@@ -63,7 +67,14 @@ def test_two_rank_allreduce_matches_single_process(ref):
     whole = Frame(cols, chunk_size=4096, nthreads=2, superagg=RefAdapter(ref))
     want = whole._agg([agg.count(), agg.mean("v"), agg.std("v"), agg.min("v"), agg.max("v")], binby=["x", "y"], limits=[[-4, 4], [-4, 4]], shape=32)
     wantg = whole.groupby("k", {"s": agg.sum("v"), "c": agg.count()})
-    for rank, res, g in got:
+    want_auto = dict(mm=whole.minmax("v"), cnt=whole.count(binby="v", shape=16), lp=whole.limits_percentage("x", 90), med=whole.median_approx("y"),
+                     gk=whole.groupby("k", {"c": agg.count()})["c"])
+    for rank, res, g, auto in got:
+        for name, w in want_auto.items():
+            if np.asarray(w).dtype.kind in "iu":
+                np.testing.assert_array_equal(auto[name], w, err_msg=name)
+            else:
+                np.testing.assert_allclose(auto[name], w, rtol=1e-12, err_msg=name)
         np.testing.assert_array_equal(res[0], want[0])
         for a, b in zip(res[1:], want[1:]):
             np.testing.assert_allclose(a, b, rtol=1e-9, atol=1e-12, equal_nan=True)

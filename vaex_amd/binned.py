@@ -130,9 +130,12 @@ _KIND_CLASS = {"count": "AggCount_", "sum": "AggSum_", "summoment": "AggSumMomen
 
 
 class Frame:
-    def __init__(self, columns=None, chunk_size=1 << 20, nthreads=4, superagg=None, **kw):
+    def __init__(self, columns=None, chunk_size=1 << 20, nthreads=4, superagg=None, comm=None, **kw):
+        """comm: a vaex_amd.dist.Comm when this Frame holds ONE RANK'S ROWS of a row-sharded table — every result is
+        then the result over all ranks' rows (grids all-reduced before the finishers, min/max and key sets agreed)."""
         self.columns = dict(columns or {})
         self.columns.update(kw)
+        self.comm = comm
         self.chunk_size = int(chunk_size)
         self.nthreads = int(nthreads)
         self.sa = superagg or _sa
@@ -175,13 +178,18 @@ class Frame:
         keep = None if sel is None else _as_u8(sel)
         if _is_device(c):
             pf = _class_postfix(c)
-            return np.array(self.sa.minmax(c, keep, _DT_CODE[pf.replace("_non_native", "")], pf.endswith("_non_native")))
+            return self._global_minmax(self.sa.minmax(c, keep, _DT_CODE[pf.replace("_non_native", "")], pf.endswith("_non_native")))
         data, miss = (np.ma.getdata(c), np.ma.getmaskarray(c)) if np.ma.isMaskedArray(c) else (c, None)
         if miss is not None:
             k = ~miss if keep is None else (keep.astype(bool) & ~miss)
             keep = _as_u8(k)
         pf = _class_postfix(data)
-        lo, hi = self.sa.minmax(np.ascontiguousarray(data), keep, _DT_CODE[pf.replace("_non_native", "")], pf.endswith("_non_native"))
+        return self._global_minmax(self.sa.minmax(np.ascontiguousarray(data), keep, _DT_CODE[pf.replace("_non_native", "")], pf.endswith("_non_native")))
+
+    def _global_minmax(self, lohi):
+        lo, hi = lohi
+        if self.comm is not None:
+            lo, hi = self.comm.minmax_float(float(lo), float(hi))
         return np.array([lo, hi])
 
     def _binner_specs(self, binby, limits, shape):
@@ -301,6 +309,8 @@ class Frame:
                 ids.append(index[k])
             want.append(ids)
         grid, aggs = self._run_pass(specs, prims)
+        if reduce is None and self.comm is not None:
+            reduce = self.comm.allreduce
         if reduce is not None:
             reduce(aggs)
         raw = [np.asarray(a.get_result()) for a in aggs]  # (get_result already returns a fresh array)
@@ -439,6 +449,10 @@ class Frame:
         directly through BinnerOrdinal(min_value) in a single pass; wider ranges go through the GPU hash map
         inside the binner (BinnerHash).  reduce / comm: multi-GPU hooks (vaex_amd.dist)."""
         sa = self.sa
+        if comm is None:
+            comm = self.comm
+        if reduce is None and comm is not None:
+            reduce = comm.allreduce
         key = self.columns[by]
         if np.ma.isMaskedArray(key):
             raise NotImplementedError("masked group keys")

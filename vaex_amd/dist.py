@@ -138,6 +138,17 @@ class Comm:
         dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
         return int(t[0]), -int(t[1])
 
+    def minmax_float(self, lo, hi):
+        """global (min, max) of per-rank float ranges (df.minmax / limits=None under row sharding); a rank without rows
+        contributes (+inf, -inf)"""
+        import torch
+        import torch.distributed as dist
+        if not dist.is_initialized() or dist.get_world_size(self.group) == 1:
+            return lo, hi
+        t = torch.tensor([lo, -hi], dtype=torch.float64, device=self._device())
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
+        return float(t[0]), -float(t[1])
+
     def union_keys(self, keys):
         """sorted union of the ranks' distinct keys (<= 1e6 x 8 B per rank in the BASELINE config)"""
         import torch.distributed as dist
