@@ -500,3 +500,17 @@ def test_hot_box_many_rows_per_cell(sa):
         assert got[0].max() == n // 2 and sa.config_get("hot_w") == 60
     finally:
         _hot_reset(sa)
+
+
+def test_hot_box_shared_aggregators_many_slots(sa):
+    # three slots (threads) feed the same aggregators chunk by chunk, every call with the (forced) box:
+    # slot-private accumulators and boxes, atomic merges into the shared grids
+    sa.config_set("strategy", STRATEGIES["part"])
+    try:
+        for k, val in zip(("hot_x0", "hot_y0", "hot_w", "hot_h"), (90, 95, 70, 66)):
+            sa.config_set(k, val)
+        case = _case_count_sum(2_200_000, seed=3)
+        check(sa, case, chunk=300_000, nthreads=3)
+        check(sa, case, chunk=1 << 20, nthreads=2, to_device=cases.torch_device_array)
+    finally:
+        _hot_reset(sa)
