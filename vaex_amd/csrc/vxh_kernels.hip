@@ -857,9 +857,13 @@ __global__ void __launch_bounds__(512) part_scatter(const PartArgs P) {
 // >= bins (the conversion saturates) — so the overflow compare becomes an integer min.  NaN -> 0, negative -> 1.
 __device__ __forceinline__ uint32_t scalar_sub_index32(double v, double vmin, double scale, double binsd, uint32_t bins) {
     const double scaled = (v - vmin) * scale;
-    const int t = (int)(scaled * binsd);
+    int t = (int)(scaled * binsd); // v_cvt_i32_f64 saturates and maps NaN to 0: safe for every input
+    // keep the conversion OUT of a branch: left alone, the compiler sinks it under `scaled >= 0` and builds a divergent
+    // region (5 exec-mask instructions + a branch per sub-index) where two selects do
+    asm volatile("" : "+v"(t));
     const uint32_t inside = (uint32_t)(t < (int)bins ? t : (int)bins) + 2u;
-    return scaled >= 0 ? inside : (scaled < 0 ? 1u : 0u);
+    const uint32_t outside = scaled < 0 ? 1u : 0u;
+    return scaled >= 0 ? inside : outside;
 }
 
 // K1d — df.count(binby=<1..3 float64 columns>[, selection]) on a grid whose private copy fits one workgroup's LDS:
@@ -1261,8 +1265,8 @@ __global__ void __launch_bounds__(VXH_HOT_BLOCK) part_scatter_blk(const PartArgs
             bool hot = false;
             if (HOT) {
                 const uint32_t hx = sub_i[0] - P.hot.x0, hy = sub_i[NDIM > 1 ? 1 : 0] - P.hot.y0; // (unsigned: below the box wraps to huge)
-                hot = hx < P.hot.w && hy < P.hot.h && ((keep >> r) & 1u);
-                if (NVAL) hot = hot && cur.v[NVAL ? r : 0] == cur.v[NVAL ? r : 0];
+                hot = (hx < P.hot.w) & (hy < P.hot.h) & (((keep >> r) & 1u) != 0u); // (& not &&: one condition, no nested branches)
+                if (NVAL) hot = hot & (cur.v[NVAL ? r : 0] == cur.v[NVAL ? r : 0]);
                 if (hot) {
                     const uint32_t hc = __umul24(hy, P.hot.w) + hx;
                     if (NVAL) at_add<__HIP_MEMORY_SCOPE_WORKGROUP, double>(hot_sum + hc, cur.v[NVAL ? r : 0]);
