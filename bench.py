@@ -9,6 +9,13 @@ fold of the replicas, (N>1) RCCL all-reduce of the three grids, D2H of the resul
 finish mean = sum/count.  Inputs are synthetic N(0,1)/N(3,2) columns generated on the device
 (there is no dataset on the box); limits [-4,4].
 
+`--gpus N` with N > 1 and no torchrun environment (WORLD_SIZE unset) makes this process spawn the N ranks itself
+(torch.multiprocessing, one process per GPU, RCCL); under `torch.distributed.run` the ranks come from the environment.
+
+Besides `value` (N(0,1) data, the hot box warm) the N=1 line carries the two unflattering numbers of the same pass:
+`value_uniform` (x,y ~ U(-4,4): no hot box, every row goes through the partition queues) and `value_cold` (the hot box
+sampled anew in every step, as a first call on fresh columns pays it).
+
 Prints ONE JSON line (rank 0) with `roofline` (HIP-event kernel time on the library's stream vs
 24 B/row of compulsory reads) and `cpu_baseline` (the reference's own C++ from oracle/_ref driven
 from a thread pool like vaex's executor, or the C port if that is absent) objects.
@@ -37,6 +44,7 @@ def parse():
     ap.add_argument("--shape", type=int, default=256)
     ap.add_argument("--cpu-rows", type=float, default=1e8, help="rows of the bounded CPU-baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip value_uniform / value_cold")
     return ap.parse_args()
 
 
@@ -100,8 +108,28 @@ def cpu_baseline(x, y, v, shape, rows):
                 sample=f"{rows:.3g} of the GPU's own rows (x,y,v float64), same 2-D {shape}x{shape} count+sum+count pass, best of {reps} passes, 1Mi-row chunks over a {nthreads}-thread pool"), res, rows
 
 
+def _spawned(local_rank, args, port):
+    os.environ.update(RANK=str(local_rank), LOCAL_RANK=str(local_rank), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    run(args)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # launched as plain `python bench.py --gpus N`: be the launcher (one rank per GPU of this node)
+        import socket
+        import torch.multiprocessing as mp
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        mp.spawn(_spawned, args=(args, port), nprocs=args.gpus, join=True)
+        return
+    run(args)
+
+
+def run(args):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -182,10 +210,13 @@ def main():
         achieved = BYTES_PER_ROW * rows / (k_ms * 1e-3) / 1e9
         # HBM bytes per launch from the PMC counters of the same command (separate rocprofv3 --pmc passes,
         # FETCH_SIZE corrected x2 on gfx950): measured offline, kept under profiles/
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
-        if os.path.exists(tpath) and sa.last_kernel(0).startswith("part_scatter") and shape == 256:
-            traffic = json.load(open(tpath))["hbm_bytes_per_row"] * rows
+        traffic = traffic_source = None
+        for tname in ("r02_traffic.json", "r01_traffic.json"):
+            tpath = os.path.join(ROOT, "profiles", tname)
+            if os.path.exists(tpath) and sa.last_kernel(0).startswith("part_scatter") and shape == 256:
+                traffic = json.load(open(tpath))["hbm_bytes_per_row"] * rows
+                traffic_source = "profiles/" + tname + " (rocprofv3 --pmc passes of this command, FETCH_SIZE x2 on gfx950; not a same-run counter)"
+                break
         out = {
             "metric": "rows/sec, 2-D count+mean on 256x256 grid (count(*), sum(v), count(v) fused), float64 x,y,v",
             "value": value, "unit": "rows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -194,10 +225,43 @@ def main():
             "config": {"workload": f"{rows:.3g}-row float64 x,y,v per GPU: count+sum+mean on {shape}x{shape} grid, HBM-resident (BASELINE configs[1])",
                        "rows_per_gpu": rows, "shape": shape, "kernel": sa.last_kernel(0), "parallelism": f"row-sharded x{world}, RCCL all-reduce of 3 grids"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel_ms": k_ms, "bytes_per_row": BYTES_PER_ROW, "rows_per_launch": rows},
+                         "traffic": traffic, "traffic_source": traffic_source, "kernel_ms": k_ms, "bytes_per_row": BYTES_PER_ROW, "rows_per_launch": rows},
         }
+        if world == 1 and not args.no_extra:
+            extra_steps = max(3, min(args.steps, 5))
+
+            def timed(nsteps):
+                kernel_ms.clear()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(nsteps):
+                    step()
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t1
+                return rows * nsteps / dt, float(np.mean(kernel_ms))
+            # (1) cold call: the hot box is sampled and searched again in every step (a first df.mean on fresh columns)
+            sa.config_set("hot_cache", 0)
+            step()
+            vc, kc = timed(extra_steps)
+            sa.config_set("hot_cache", 1)
+            out["value_cold"] = vc
+            out["roofline"]["frac_cold"] = BYTES_PER_ROW * rows / (kc * 1e-3) / 1e9 / HBM_PEAK_GBS
+            # (2) uniform x,y: no cell rectangle is hot, every row goes through the partition queues
+            gen_u = torch.Generator(device="cuda").manual_seed(4321)
+            xu = torch.rand(rows, dtype=torch.float64, device="cuda", generator=gen_u) * 8 - 4
+            yu = torch.rand(rows, dtype=torch.float64, device="cuda", generator=gen_u) * 8 - 4
+            bx.set_data(0, xu); by.set_data(0, yu)
+            step()
+            vu, ku = timed(extra_steps)
+            out["value_uniform"] = vu
+            out["roofline"]["frac_uniform"] = BYTES_PER_ROW * rows / (ku * 1e-3) / 1e9 / HBM_PEAK_GBS
+            out["config"]["kernel_uniform"] = sa.last_kernel(0)
+            assert int(count.get_result().sum()) == rows
+            bx.set_data(0, x); by.set_data(0, y)
+            del xu, yu
         if world == 1 and not args.no_cpu:
             cb, cpu_res, cpu_rows = cpu_baseline(x, y, v, shape, args.cpu_rows)
+            cb["driver"] = "Grid.bin of the reference's C++ over a bare thread pool (no vaex executor / expression layer on top: slightly favours the CPU)"
             out["cpu_baseline"] = cb
             # same-run parity on the CPU sample: counts bit-exact, sums to 1e-12 of sum|v|
             for a in aggs:

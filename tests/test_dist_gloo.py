@@ -83,6 +83,52 @@ def test_two_rank_allreduce_matches_single_process(ref):
         np.testing.assert_allclose(g["s"], wantg["s"], rtol=1e-12)
 
 
+def _worker_empty_shard(rank, world, port, q):
+    """rank 1 holds no rows at all: the key-range exchange of groupby must survive the (INT64_MAX, INT64_MIN) sentinel"""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    from oracle import oracle
+    from tests.test_golden_api import RefAdapter
+    from vaex_amd import dist as vdist
+    from vaex_amd.binned import Frame, agg
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        k = np.array([5, 7, 5, -3, 7, 7], dtype=np.int64)
+        v = np.arange(6, dtype=np.float64)
+        i1, i2 = (0, 6) if rank == 0 else (6, 6)
+        shard = Frame(dict(k=k[i1:i2], v=v[i1:i2]), chunk_size=4, nthreads=1, superagg=RefAdapter(oracle.ref_module("superagg")), comm=vdist.Comm())
+        mm = vdist.Comm().minmax(*((-3, 7) if rank == 0 else (2**63 - 1, -2**63)))  # the empty rank's sentinel pair must not overflow
+        g = shard.groupby("k", {"s": agg.sum("v"), "c": agg.count()})
+        q.put((rank, mm, {n: np.asarray(a) for n, a in g.items()}))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_groupby_with_an_empty_shard(ref):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_empty_shard, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, mm, g in got:
+        assert mm == (-3, 7)
+        if rank == 1:
+            # the reference's classes (the local compute of this CPU test) ignore values written into a grid they never
+            # aggregated into (grid_used, src/agg_base.hpp:40-43), so the empty rank cannot read the reduced grids back;
+            # what matters here is that it took part in every collective without raising
+            continue
+        np.testing.assert_array_equal(g["k"], [-3, 5, 7])
+        np.testing.assert_array_equal(g["c"], [1, 2, 3])
+        np.testing.assert_allclose(g["s"], [3.0, 2.0, 10.0])
+
+
 def test_shard_rows_cover_exactly():
     from vaex_amd.dist import shard_rows
     for n, w in ((10, 3), (0, 2), (7, 8), (1_000_003, 8)):

@@ -1,0 +1,444 @@
+"""-m gpu: parity at the REAL shapes of BASELINE.json's configs — configs[1] (2-D 256x256 count+mean), configs[2]
+(3-D 128^3 histogram with a uint8 selection) and configs[3] (groupby on a 1e6-cardinality int64 key, dense and
+scattered `k*2654435761 % 2**40`, agg sum/mean/std) — on >= 2e8 device-generated rows.  A >= 1e7-row slice of the same
+rows is compared with the reference's own C++ (oracle/_ref, the C restatement when that is absent) exactly the way
+bench.py's same-run check does: integer grids bit-exact, fp64 sums within 1e-12 * sum|v| of the cell.  The full
+size is tied to the slice through linearity: grid(all rows) == grid(slice) + grid(rest).
+
+Also here: the integer cases of the reference's hash-map tests (tests/internal/hash_test.py:81-153, :374-483;
+tests/hashmap_unique_test.py) against ordered_set_* / BinnerHash_* on the GPU, and sum-moments 3 and 4
+(vaex/agg.py:458-523 skew / kurtosis)."""
+import numpy as np
+import pytest
+
+from oracle import oracle
+from tests import cases
+
+pytestmark = pytest.mark.gpu
+
+N_FULL = 200_000_000
+N_SLICE = 10_000_000
+
+
+@pytest.fixture(autouse=True)
+def _ready(sa, gpu_ready):
+    for k in ("strategy", "block", "blocks", "parts", "part_chunk"):
+        sa.config_set(k, 0)
+    sa.config_set("slab_log2", -1)
+    yield
+
+
+def _ref_or_port_case(ref_mod, case):
+    """the case on the CPU: the reference's compiled C++ when it loads, else the C restatement"""
+    if ref_mod is not None:
+        return cases.run_superagg(ref_mod, case, chunk=1 << 20)
+    return oracle.run_case(case)
+
+
+def _ref_module():
+    return oracle.ref_module("superagg")
+
+
+def _sum_tolerance_ok(got, want, absv_sum_per_cell, rtol=1e-12):
+    return bool(np.all(np.abs(got - want) <= rtol * absv_sum_per_cell + 0.0))
+
+
+# ------------------------------------------------------------------------------------------------------------
+# configs[1] at full size: bench.py's parity_on_sample as a test
+# ------------------------------------------------------------------------------------------------------------
+def test_config1_2d_256_count_mean_full_size(sa):
+    import torch
+    g = torch.Generator(device="cuda").manual_seed(1234)
+    n = N_FULL
+    x = torch.randn(n, dtype=torch.float64, device="cuda", generator=g)
+    y = torch.randn(n, dtype=torch.float64, device="cuda", generator=g)
+    v = torch.randn(n, dtype=torch.float64, device="cuda", generator=g) * 2 + 3
+    v[::100_003] = float("nan")
+    torch.cuda.synchronize()
+
+    def run(lo, hi):
+        bx = sa.BinnerScalar_float64(1, "x", -4.0, 4.0, 256)
+        by = sa.BinnerScalar_float64(1, "y", -4.0, 4.0, 256)
+        grid = sa.Grid([bx, by])
+        aggs = [sa.AggCount_int64(grid, 1, 1), sa.AggSum_float64(grid, 1, 1), sa.AggCount_float64(grid, 1, 1)]
+        bx.set_data(0, x[lo:hi]); by.set_data(0, y[lo:hi])
+        aggs[1].set_data(0, v[lo:hi], 0); aggs[2].set_data(0, v[lo:hi], 0)
+        grid.bin(0, aggs, hi - lo)
+        return [np.array(a.get_result()) for a in aggs], sa.last_kernel(0)
+
+    full, kernel = run(0, n)
+    assert kernel.startswith("part_scatter"), kernel  # the bench's kernel pair
+    head, _ = run(0, N_SLICE)
+    rest, _ = run(N_SLICE, n)
+    # linearity over a split of the rows
+    np.testing.assert_array_equal(full[0], head[0] + rest[0])
+    np.testing.assert_array_equal(full[2], head[2] + rest[2])
+    vabs = float(torch.nan_to_num(v).abs().max().item())
+    assert _sum_tolerance_ok(full[1], head[1] + rest[1], vabs * np.maximum(full[2], 1))
+    assert int(full[0].sum()) == n
+    # the slice against the reference
+    xs, ys, vs = (t[:N_SLICE].cpu().numpy() for t in (x, y, v))
+    case = dict(n=N_SLICE, binners=[dict(kind="scalar", data=xs, vmin=-4, vmax=4, bins=256), dict(kind="scalar", data=ys, vmin=-4, vmax=4, bins=256)],
+                aggs=[dict(kind="count"), dict(kind="sum", data=vs), dict(kind="count", data=vs)])
+    want = _ref_or_port_case(_ref_module(), case)
+    np.testing.assert_array_equal(head[0], want[0])
+    np.testing.assert_array_equal(head[2], want[2])
+    cases.assert_case_equal(head, want, case)
+
+
+def test_config1_uniform_data_no_hot_box(sa):
+    """uniform x,y: the sampled hot box is off (catches < 35 % of the rows) — the plain partition pair must agree
+    with the reference as well"""
+    import torch
+    g = torch.Generator(device="cuda").manual_seed(99)
+    n = 60_000_000
+    x = torch.rand(n, dtype=torch.float64, device="cuda", generator=g) * 8.2 - 4.1
+    y = torch.rand(n, dtype=torch.float64, device="cuda", generator=g) * 8.2 - 4.1
+    v = torch.randn(n, dtype=torch.float64, device="cuda", generator=g) * 2 + 3
+    bx = sa.BinnerScalar_float64(1, "x", -4.0, 4.0, 256)
+    by = sa.BinnerScalar_float64(1, "y", -4.0, 4.0, 256)
+    grid = sa.Grid([bx, by])
+    aggs = [sa.AggCount_int64(grid, 1, 1), sa.AggSum_float64(grid, 1, 1), sa.AggCount_float64(grid, 1, 1)]
+    bx.set_data(0, x); by.set_data(0, y); aggs[1].set_data(0, v, 0); aggs[2].set_data(0, v, 0)
+    grid.bin(0, aggs, n)
+    got = [np.array(a.get_result()) for a in aggs]
+    assert sa.config_get("hot_w") == 0, "uniform data must not take the hot box"
+    m = N_SLICE
+    for a in aggs:
+        a.reset()
+    bx.set_data(0, x[:m]); by.set_data(0, y[:m]); aggs[1].set_data(0, v[:m], 0); aggs[2].set_data(0, v[:m], 0)
+    grid.bin(0, aggs, m)
+    head = [np.array(a.get_result()) for a in aggs]
+    xs, ys, vs = (t[:m].cpu().numpy() for t in (x, y, v))
+    case = dict(n=m, binners=[dict(kind="scalar", data=xs, vmin=-4, vmax=4, bins=256), dict(kind="scalar", data=ys, vmin=-4, vmax=4, bins=256)],
+                aggs=[dict(kind="count"), dict(kind="sum", data=vs), dict(kind="count", data=vs)])
+    want = _ref_or_port_case(_ref_module(), case)
+    cases.assert_case_equal(head, want, case)
+    assert int(got[0].sum()) == n
+
+
+# ------------------------------------------------------------------------------------------------------------
+# configs[2]: 3-D 128^3 + boolean selection
+# ------------------------------------------------------------------------------------------------------------
+def test_config2_3d_128_selection_full_size(sa):
+    import torch
+    g = torch.Generator(device="cuda").manual_seed(7)
+    n = N_FULL
+    x = torch.randn(n, dtype=torch.float64, device="cuda", generator=g)
+    y = torch.randn(n, dtype=torch.float64, device="cuda", generator=g)
+    z = torch.randn(n, dtype=torch.float64, device="cuda", generator=g)
+    v = torch.randn(n, dtype=torch.float64, device="cuda", generator=g) * 2 + 3
+    sel = (v > 3).to(torch.uint8)  # the selection vaex materialises as a byte mask (vaex/execution.py:530-549)
+    del v
+    x[:3] = torch.tensor([float("nan"), float("inf"), -float("inf")], dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+
+    def run(lo, hi):
+        bs = [sa.BinnerScalar_float64(1, nm, -4.0, 4.0, 128) for nm in "xyz"]
+        grid = sa.Grid(bs)
+        assert len(grid) == 131 ** 3
+        c = sa.AggCount_int64(grid, 1, 1)
+        for b, col in zip(bs, (x, y, z)):
+            b.set_data(0, col[lo:hi])
+        c.set_data_mask(0, sel[lo:hi])
+        grid.bin(0, [c], hi - lo)
+        return np.array(c.get_result()), sa.last_kernel(0)
+
+    full, kernel = run(0, n)
+    assert kernel.startswith("part_scatter"), kernel
+    head, _ = run(0, N_SLICE)
+    rest, _ = run(N_SLICE, n)
+    np.testing.assert_array_equal(full, head + rest)
+    assert int(full.sum()) == int(sel.sum().item())
+    xs, ys, zs = (t[:N_SLICE].cpu().numpy() for t in (x, y, z))
+    case = dict(n=N_SLICE, binners=[dict(kind="scalar", data=c, vmin=-4, vmax=4, bins=128) for c in (xs, ys, zs)],
+                aggs=[dict(kind="count", mask=sel[:N_SLICE].cpu().numpy())])
+    want = _ref_or_port_case(_ref_module(), case)
+    assert want[0].shape == (131, 131, 131)
+    np.testing.assert_array_equal(head, want[0])
+
+
+# ------------------------------------------------------------------------------------------------------------
+# configs[3]: groupby on 1e6 int64 keys, sum / mean / std
+# ------------------------------------------------------------------------------------------------------------
+def _groupby_want(keys, v):
+    """per-key count / sum / sum of squares with numpy in double (keys ascending), on a host slice"""
+    uniq, inv = np.unique(keys, return_inverse=True)
+    ok = v == v
+    cnt = np.bincount(inv[ok], minlength=len(uniq))
+    s1 = np.bincount(inv[ok], weights=v[ok], minlength=len(uniq))
+    s2 = np.bincount(inv[ok], weights=v[ok] * v[ok], minlength=len(uniq))
+    sabs = np.bincount(inv[ok], weights=np.abs(v[ok]), minlength=len(uniq))
+    return uniq, cnt, s1, s2, sabs
+
+
+@pytest.mark.parametrize("flavour", ["dense", "scattered"])
+def test_config3_groupby_1e6_keys_full_size(sa, flavour):
+    import torch
+    from vaex_amd.binned import Frame, agg
+    g = torch.Generator(device="cuda").manual_seed(11)
+    n = N_FULL
+    k = torch.randint(0, 1_000_000, (n,), dtype=torch.int64, device="cuda", generator=g)
+    if flavour == "scattered":
+        k = (k * 2654435761) % (1 << 40)  # forces the hash path
+    v = torch.randn(n, dtype=torch.float64, device="cuda", generator=g) * 2 + 3
+    v[::77_777] = float("nan")
+    torch.cuda.synchronize()
+    spec = {"c": agg.count("v"), "s": agg.sum("v"), "m": agg.mean("v"), "sd": agg.std("v")}
+
+    full = Frame(dict(k=k, v=v)).groupby("k", spec)
+    assert len(full["k"]) == 1_000_000
+    assert np.all(np.diff(full["k"]) > 0)
+    assert int(full["c"].sum()) == int((v == v).sum().item())
+    head = Frame(dict(k=k[:N_SLICE], v=v[:N_SLICE])).groupby("k", spec)
+    rest = Frame(dict(k=k[N_SLICE:], v=v[N_SLICE:])).groupby("k", spec)
+    # linearity of count / sum over a split of the rows (keys absent from one part contribute nothing)
+    pos_h = np.searchsorted(full["k"], head["k"]); pos_r = np.searchsorted(full["k"], rest["k"])
+    c = np.zeros(len(full["k"]), dtype=np.int64); s = np.zeros(len(full["k"]))
+    c[pos_h] += head["c"]; c[pos_r] += rest["c"]
+    s[pos_h] += head["s"]; s[pos_r] += rest["s"]
+    np.testing.assert_array_equal(full["c"], c)
+    assert np.all(np.abs(full["s"] - s) <= 1e-12 * 20.0 * np.maximum(full["c"], 1))
+    # the slice against numpy in double on the host (the reference path maps keys to ordinals and bins them:
+    # same per-key sums; ordinals differ, parity is per key)
+    ks, vs = k[:N_SLICE].cpu().numpy(), v[:N_SLICE].cpu().numpy()
+    uniq, cnt, s1, s2, sabs = _groupby_want(ks, vs)
+    np.testing.assert_array_equal(head["k"], uniq)
+    np.testing.assert_array_equal(head["c"], cnt)
+    assert np.all(np.abs(head["s"] - s1) <= 1e-12 * sabs)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        mean = s1 / cnt
+        var = s2 / cnt - mean ** 2
+    np.testing.assert_allclose(head["m"], mean, rtol=1e-12, equal_nan=True)
+    # std: sqrt(m2/n - mean^2) cancels; stated tolerance = 1e-12 of the magnitude that cancels (m2/n), per key
+    got_var = head["sd"] ** 2
+    okv = cnt > 0
+    assert np.all(np.abs(got_var[okv] - var[okv]) <= 4e-12 * (s2[okv] / cnt[okv]) + 1e-300)
+    # and against the reference's own C++ through the ordinal binner on codes (what vaex's groupby pass 2 runs)
+    ref = _ref_module()
+    if ref is not None:
+        codes = np.searchsorted(uniq, ks).astype(np.int64)
+        case = dict(n=N_SLICE, binners=[dict(kind="ordinal", data=codes, count=len(uniq), min_value=0)],
+                    aggs=[dict(kind="sum", data=vs), dict(kind="count", data=vs)])
+        want = cases.run_superagg(ref, case, chunk=1 << 20)
+        np.testing.assert_array_equal(head["c"], want[1][:len(uniq)])
+        assert np.all(np.abs(head["s"] - want[0][:len(uniq)]) <= 1e-12 * sabs)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# sum moments 3 and 4 (skew / kurtosis: vaex/agg.py:458-523) and integer inputs
+# ------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("moment", [1, 2, 3, 4])
+@pytest.mark.parametrize("strategy", [0, 3, 4])
+def test_sum_moments_float64(sa, moment, strategy):
+    sa.config_set("strategy", strategy)
+    c = cases.gaussian_columns(300_000, seed=5)
+    case = dict(n=300_000, binners=[dict(kind="scalar", data=c["x"], vmin=-4, vmax=4, bins=64), dict(kind="scalar", data=c["y"], vmin=-4, vmax=4, bins=64)],
+                aggs=[dict(kind="summoment", data=c["v"], moment=moment), dict(kind="count", data=c["v"])])
+    want = oracle.run_case(case)
+    got = cases.run_superagg(sa, case, to_device=cases.torch_device_array)
+    cases.assert_case_equal(got, want, case)
+    ref = _ref_module()
+    if ref is not None:  # libm pow in the reference vs repeated multiplication here: < 1 ulp per term
+        cases.assert_case_equal(got, cases.run_superagg(ref, case), case)
+    sa.config_set("strategy", 0)
+
+
+@pytest.mark.parametrize("dtype", ["int32", "int16", "uint8", "int64", "float32"])
+@pytest.mark.parametrize("moment", [2, 3, 4])
+def test_sum_moments_other_dtypes(sa, dtype, moment):
+    """integer inputs accumulate in int64 / uint64 here; the reference adds pow() to the accumulator in double
+    (src/agg_sum.cpp:159: `a += pow(b, moment)` with an integer `a`), so the two agree exactly while every partial
+    sum stays below 2^53 — the values below are sized for that (beyond it the reference itself drops low bits in an
+    order-dependent way, so there is no single right answer to match)."""
+    rng = np.random.default_rng(21)
+    n = 200_000
+    x = rng.normal(0, 1, n)
+    hi = {"int32": 2000, "int16": 300, "uint8": 200, "int64": 3000, "float32": 50}[dtype]
+    lo = 0 if dtype.startswith("u") else -hi
+    v = rng.integers(lo, hi, n).astype(dtype) if dtype != "float32" else rng.normal(0, 10, n).astype("f4")
+    case = dict(n=n, binners=[dict(kind="scalar", data=x, vmin=-4, vmax=4, bins=32)], aggs=[dict(kind="summoment", data=v, moment=moment), dict(kind="sum", data=v)])
+    want = oracle.run_case(case)
+    got = cases.run_superagg(sa, case)
+    cases.assert_case_equal(got, want, case)
+    ref = _ref_module()
+    if ref is not None:
+        cases.assert_case_equal(got, cases.run_superagg(ref, case), case)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# the GPU hash map: integer cases of tests/internal/hash_test.py and tests/hashmap_unique_test.py
+# ------------------------------------------------------------------------------------------------------------
+def _check_dense_ordinals(hm, expect_keys):
+    keys = np.array(hm.key_array())
+    assert len(hm) == len(expect_keys)
+    np.testing.assert_array_equal(np.sort(keys), np.sort(np.asarray(expect_keys, dtype=np.int64)))
+    ords = np.array(hm.map_ordinal(keys))
+    np.testing.assert_array_equal(ords, np.arange(len(keys)))  # key_array is ordered by ordinal; ordinals are dense
+    return keys
+
+
+def test_hashmap_unknown_keys_map_to_minus_one(sa):
+    # hash_test.py:391-404 (index_hash: unknown -> -1); ordered_set::map_ordinal src/hash_primitives.hpp:611-691
+    hm = sa.ordered_set_int64()
+    hm.update(np.array([0, 1, 2], dtype=np.int64))
+    np.testing.assert_array_equal(np.sort(hm.map_ordinal(np.array([0, 1, 2], dtype=np.int64))), [0, 1, 2])
+    got = hm.map_ordinal(np.array([1, 2, 3, -7, 2**62], dtype=np.int64))
+    assert got[2] == -1 and got[3] == -1 and got[4] == -1 and got[0] >= 0 and got[1] >= 0
+
+
+@pytest.mark.parametrize("dtype", ["int64", "int32", "int16", "int8", "uint64", "uint32", "uint16", "uint8", "bool"])
+def test_hashmap_every_integer_dtype(sa, dtype):
+    # hash_test.py:69-78 (ordered_set_bool) generalised over the integer key types
+    rng = np.random.default_rng(3)
+    if dtype == "bool":
+        keys = np.array([True, True, False, False, True])
+    else:
+        info = np.iinfo(dtype)
+        keys = rng.integers(max(info.min, -1000), min(info.max, 1000), 5000).astype(dtype)
+    hm = getattr(sa, "ordered_set_" + dtype)()
+    hm.update(keys)
+    uniq = np.unique(keys)
+    got = np.array(hm.key_array())
+    np.testing.assert_array_equal(np.sort(got), np.sort(uniq.astype(np.int64)))
+    ords = np.array(hm.map_ordinal(keys))
+    assert ords.min() == 0 and ords.max() == len(uniq) - 1
+    np.testing.assert_array_equal(got[ords], keys.astype(np.int64))
+
+
+def test_hashmap_null_ordinal_and_masked_rows(sa):
+    # hash_test.py:81-153 with `missing`: a masked row is the null key, counted once, with its own ordinal (= count)
+    keys = np.array([3, 2, 1, 0, 2, 9], dtype=np.int64)
+    mask = np.array([0, 0, 1, 0, 0, 1], dtype=np.uint8)
+    hm = sa.ordered_set_int64()
+    assert hm.null_index == -1 and not hm.has_null
+    hm.update(keys, mask)
+    assert hm.has_null
+    assert len(hm) == 3  # {3, 2, 0}: masked rows add no key
+    assert hm.null_index == 3
+    got = set(np.array(hm.key_array()).tolist())
+    assert got == {3, 2, 0}
+    assert hm.map_ordinal(np.array([1, 9], dtype=np.int64)).tolist() == [-1, -1]
+    # the null ordinal of the binner: cells [unknown, ordinal 0..N-1, null]
+    b = sa.BinnerHash_int64(1, "k", hm)
+    grid = sa.Grid([b])
+    assert len(grid) == 3 + 2
+    c = sa.AggCount_int64(grid, 1, 1)
+    probe = np.array([3, 2, 0, 2, 1, 7, 0], dtype=np.int64)
+    pmask = np.array([0, 0, 0, 0, 0, 1, 1], dtype=np.uint8)
+    b.set_data(0, probe); b.set_data_mask(0, pmask)
+    grid.bin(0, [c], len(probe))
+    r = np.array(c.get_result())
+    ords = hm.map_ordinal(np.array([3, 2, 0], dtype=np.int64))
+    assert r[0] == 1            # key 1 unknown (masked at insert time)
+    assert r[-1] == 2           # two masked rows -> null cell
+    assert r[1 + ords[0]] == 1 and r[1 + ords[1]] == 2 and r[1 + ords[2]] == 1
+
+
+def test_hashmap_int64_min_key(sa):
+    """INT64_MIN is the table's EMPTY sentinel: the key lives in the map's side words and must behave like any other key
+    in update / map_ordinal / key_array AND in the binner's probe"""
+    lo = np.iinfo(np.int64).min
+    keys = np.array([5, lo, 7, lo, 5, np.iinfo(np.int64).max], dtype=np.int64)
+    hm = sa.ordered_set_int64()
+    hm.update(keys)
+    assert len(hm) == 4
+    ka = _check_dense_ordinals(hm, [5, lo, 7, np.iinfo(np.int64).max])
+    o = hm.map_ordinal(np.array([lo, 6], dtype=np.int64))
+    assert o[0] >= 0 and ka[o[0]] == lo and o[1] == -1
+    b = sa.BinnerHash_int64(1, "k", hm)
+    grid = sa.Grid([b])
+    c = sa.AggCount_int64(grid, 1, 1)
+    rows = np.array([lo, lo, 5, 6, lo], dtype=np.int64)
+    b.set_data(0, rows); b.clear_data_mask(0)
+    grid.bin(0, [c], len(rows))
+    r = np.array(c.get_result())
+    assert r[0] == 1 and r[1 + o[0]] == 3 and r.sum() == 5
+    # a map WITHOUT that key: INT64_MIN rows are unknown
+    hm2 = sa.ordered_set_int64()
+    hm2.update(np.array([1, 2], dtype=np.int64))
+    b2 = sa.BinnerHash_int64(1, "k", hm2)
+    g2 = sa.Grid([b2])
+    c2 = sa.AggCount_int64(g2, 1, 1)
+    b2.set_data(0, rows); b2.clear_data_mask(0)
+    g2.bin(0, [c2], len(rows))
+    assert np.array(c2.get_result())[0] == 5
+
+
+def test_hashmap_growth_through_two_resizes(sa):
+    """the table starts at 2^22 slots; > 2^23 distinct keys take it through two 4x growths (the optimistic insert's
+    overflow flag + retry, and the load check before an update) — nothing may be lost or duplicated on the way"""
+    import torch
+    n = 9_500_000
+    base = torch.arange(n, dtype=torch.int64, device="cuda")
+    keys = (base * 2654435761) % (1 << 44) - (1 << 43)  # distinct (odd multiplier mod 2^44), scattered, both signs
+    assert int(torch.unique(keys).numel()) == n
+    hm = sa.ordered_set_int64()
+    step = 2_500_000
+    for i in range(0, n, step):
+        part = keys[i:i + step]
+        hm.update(torch.cat([part, part[: step // 3]]))  # duplicates inside the update as well
+        assert len(hm) == min(n, i + step)
+    hm.update(keys)  # everything again: idempotent
+    assert len(hm) == n
+    ka = np.array(hm.key_array())
+    np.testing.assert_array_equal(np.sort(ka), np.sort(keys.cpu().numpy()))
+    sample = keys[:: 9973].cpu().numpy()
+    ords = np.array(hm.map_ordinal(sample))
+    assert ords.min() >= 0 and ords.max() < n
+    np.testing.assert_array_equal(ka[ords], sample)
+    assert hm.map_ordinal(np.array([(1 << 50) + 1], dtype=np.int64))[0] == -1
+
+
+def test_hashmap_set_keys_1e6_and_binner(sa):
+    # ordered_set::create (src/hash_primitives.hpp:486-537): keys[i] gets ordinal i
+    rng = np.random.default_rng(8)
+    keys = np.unique(rng.integers(-2**60, 2**60, 1_100_000))[:1_000_000]
+    rng.shuffle(keys)
+    hm = sa.ordered_set_int64(len(keys))
+    hm.set_keys(keys)
+    assert len(hm) == 1_000_000
+    np.testing.assert_array_equal(np.array(hm.key_array()), keys)
+    probe = keys[rng.integers(0, len(keys), 200_000)]
+    np.testing.assert_array_equal(np.array(hm.map_ordinal(probe)), _positions(keys, probe))
+    with pytest.raises(RuntimeError, match="not empty"):
+        hm.set_keys(keys[:3])
+    # count rows per key through the binner, against numpy
+    rows = np.concatenate([probe, np.array([2**61, -2**61], dtype=np.int64)])
+    b = sa.BinnerHash_int64(1, "k", hm)
+    grid = sa.Grid([b])
+    c = sa.AggCount_int64(grid, 1, 1)
+    b.set_data(0, rows); b.clear_data_mask(0)
+    grid.bin(0, [c], len(rows))
+    r = np.array(c.get_result())
+    assert r[0] == 2 and r[-1] == 0
+    np.testing.assert_array_equal(r[1:-1], np.bincount(_positions(keys, probe), minlength=len(keys)))
+
+
+def _positions(keys, probe):
+    order = np.argsort(keys)
+    return order[np.searchsorted(keys[order], probe)]
+
+
+def test_hashmap_duplicate_heavy_concurrent_inserts(sa):
+    """1e7 rows over 100 distinct keys: every wave races for the same slots; ordinals must stay dense and unique"""
+    import torch
+    g = torch.Generator(device="cuda").manual_seed(5)
+    pool = (torch.arange(100, dtype=torch.int64, device="cuda") * 7919 - 333)
+    rows = pool[torch.randint(0, 100, (10_000_000,), device="cuda", generator=g)]
+    hm = sa.ordered_set_int64()
+    hm.update(rows)
+    _check_dense_ordinals(hm, pool.cpu().numpy())
+    hm.update(rows)
+    assert len(hm) == 100
+
+
+def test_hashmap_unique_matches_numpy_on_random_chunks(sa):
+    # tests/hashmap_unique_test.py: keys arrive in chunks (the executor's 1 Mi-row chunks); result = np.unique
+    rng = np.random.default_rng(17)
+    chunks = [rng.integers(-5000, 5000, 200_000) * 1_000_003 for _ in range(6)]
+    hm = sa.ordered_set_int64()
+    for ch in chunks:
+        hm.update(ch.astype(np.int64))
+    allk = np.unique(np.concatenate(chunks))
+    _check_dense_ordinals(hm, allk)

@@ -178,6 +178,11 @@ class Frame:
         keep = None if sel is None else _as_u8(sel)
         if _is_device(c):
             pf = _class_postfix(c)
+            if keep is not None and not _is_device(keep):  # the selection must live where the column lives
+                import torch
+                keep = torch.from_numpy(np.ascontiguousarray(keep)).cuda()
+            elif keep is not None and str(keep.dtype).endswith("bool"):
+                keep = keep.view(dtype=__import__("torch").uint8)
             return self._global_minmax(self.sa.minmax(c, keep, _DT_CODE[pf.replace("_non_native", "")], pf.endswith("_non_native")))
         data, miss = (np.ma.getdata(c), np.ma.getmaskarray(c)) if np.ma.isMaskedArray(c) else (c, None)
         if miss is not None:

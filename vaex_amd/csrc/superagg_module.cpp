@@ -73,6 +73,14 @@ ArrayRef resolve_array(const py::object &obj) {
     return r;
 }
 
+// a mask handed over next to `data` must live in the same memory space (a host pointer is not dereferenceable by a
+// kernel reading device data, and vice versa) and cover every row
+void check_mask(const ArrayRef &data, const ArrayRef &mask) {
+    if (mask.mem != data.mem) throw std::runtime_error("mask must live where the data lives (host with host, device with device)");
+    if (mask.n < data.n) throw std::runtime_error("mask is shorter than the data");
+    if (mask.itemsize != 1) throw std::runtime_error("mask must be a 1-byte (bool / uint8) array");
+}
+
 // ------------------------------------------------------------------------------------------
 // hash map
 // ------------------------------------------------------------------------------------------
@@ -424,7 +432,7 @@ PYBIND11_MODULE(superagg, m) {
         ArrayRef a = resolve_array(ar);
         if (a.itemsize != kTypeSizes[dtype]) throw std::runtime_error("Itemsize of data and dtype are not equal");
         const uint8_t *mp = nullptr;
-        if (!mask.is_none()) { ArrayRef mk = resolve_array(mask); mp = (const uint8_t *)mk.ptr; }
+        if (!mask.is_none()) { ArrayRef mk = resolve_array(mask); check_mask(a, mk); mp = (const uint8_t *)mk.ptr; }
         double out[2];
         int rc;
         { py::gil_scoped_release r; rc = vxh_minmax(dtype, flip, a.ptr, mp, a.n, a.mem, out); }
@@ -436,7 +444,7 @@ PYBIND11_MODULE(superagg, m) {
         ArrayRef a = resolve_array(ar);
         if (a.itemsize != kTypeSizes[dtype]) throw std::runtime_error("Itemsize of data and dtype are not equal");
         const uint8_t *mp = nullptr;
-        if (!mask.is_none()) { ArrayRef mk = resolve_array(mask); mp = (const uint8_t *)mk.ptr; }
+        if (!mask.is_none()) { ArrayRef mk = resolve_array(mask); check_mask(a, mk); mp = (const uint8_t *)mk.ptr; }
         int64_t out[2];
         int rc;
         { py::gil_scoped_release r; rc = vxh_minmax_int(dtype, flip, a.ptr, mp, a.n, a.mem, out); }

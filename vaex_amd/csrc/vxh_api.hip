@@ -538,6 +538,36 @@ static size_t scatter_lds_bytes(size_t S, int R, int nvals) {
     return S * 4 + (S + 4) * 4 + S * 8 + T * (8 * (size_t)nvals + 4 + 2 + 1) + 64;
 }
 
+// part_scatter_wv geometry: waves per workgroup and LDS per wave for S slabs and nvals value columns
+struct WvGeom {
+    bool ok = false;
+    int waves = 0;
+    size_t wave_bytes = 0;
+};
+static WvGeom wv_geometry(size_t S, int nvals) {
+    Context &c = ctx();
+    WvGeom g;
+    if (!c.cfg_wv || S > 64 || nvals > 1 || (c.cfg_no_pipeline & 1) || c.cfg_part_rows > 0) return g;
+    g.wave_bytes = VXH_WV_WAVE_LDS(nvals, S);
+    int waves = (int)std::min<int64_t>(16, std::max<int64_t>(1, c.cfg_wv_waves));
+    while (waves > 1 && (size_t)waves * g.wave_bytes > 150 * 1024) waves--;
+    if (waves < 4 || (size_t)waves * g.wave_bytes > 150 * 1024) return g; // too few waves to hide anything: not this kernel
+    g.waves = waves;
+    g.ok = true;
+    return g;
+}
+static bool aligned_to(const void *p, size_t a) { return ((uintptr_t)p & (a - 1)) == 0; }
+// part_scatter_wv reads two rows per 16-byte load (and two mask bytes per 2-byte load)
+static bool wv_aligned(const BinArgs &A) {
+    for (int d = 0; d < A.ndim; d++)
+        if (!aligned_to(A.b[d].data, 16)) return false;
+    for (int k = 0; k < A.nagg; k++) {
+        if (A.a[k].data && !aligned_to(A.a[k].data, 16)) return false;
+        if (A.a[k].mask && !aligned_to(A.a[k].mask, 2)) return false;
+    }
+    return true;
+}
+
 // ------------------------------------------------------------------------------------------
 // hot box (PartArgs::hot): eligibility, choice of the box from a sample, accumulators, merge
 // ------------------------------------------------------------------------------------------
@@ -596,11 +626,15 @@ static void hot_prepare(Slot &slot, const BinArgs &A, const BinArgs &planned, co
     const uint64_t slab_cells = (planned.cells + S - 1) >> planned.slab_log2;
     // the box lives in part_scatter_blk: uint16 local indices with one value to spare for the null record
     const bool gen2 = c.cfg_blk && S <= 256 && slab_cells < 65535 && !(c.cfg_no_pipeline & 1) && c.cfg_part_rows <= 0; // (= run_part_chunk's conditions for part_scatter_blk)
-    if (!gen2) return;
+    const WvGeom wg = wv_geometry(S, nval);
+    const bool wv = wg.ok && slab_cells < 65535 && wv_aligned(A); // (= run_part_chunk's conditions for part_scatter_wv)
+    if (!gen2 && !wv) return;
     H.gen2 = true;
+    H.wv = wv;
+    H.wv_waves = wv ? wg.waves : 0;
     H.nval = nval;
     const size_t cell_bytes = nval ? 12 : 4;
-    const size_t fixed = (size_t)VXH_BLK_FIXED_LDS(nval, S);
+    const size_t fixed = wv ? (size_t)wg.waves * wg.wave_bytes + 64 : (size_t)VXH_BLK_FIXED_LDS(nval, S);
     if (fixed + 4096 > kLdsMax) return;
     const uint64_t max_cells = (kLdsMax - fixed - 96) / cell_bytes;
     const uint32_t sx = (uint32_t)(A.b[0].bins + 3), sy = (uint32_t)(A.b[1].bins + 3);
@@ -611,7 +645,7 @@ static void hot_prepare(Slot &slot, const BinArgs &A, const BinArgs &planned, co
         H.last_fraction = 1;
     } else {
         const double lim[6] = {A.b[0].vmin, A.b[0].scale, A.b[0].binsd, A.b[1].vmin, A.b[1].scale, A.b[1].binsd};
-        const bool cached = H.key_fraction >= 0 && H.key_ptr[0] == A.b[0].data && H.key_ptr[1] == A.b[1].data && H.key_len == length &&
+        const bool cached = c.cfg_hot_cache && H.key_fraction >= 0 && H.key_ptr[0] == A.b[0].data && H.key_ptr[1] == A.b[1].data && H.key_len == length &&
                             H.key_cells == max_cells && memcmp(H.key_lim, lim, sizeof(lim)) == 0;
         if (cached) {
             memcpy(box, H.key_box, sizeof(box));
@@ -667,8 +701,8 @@ static void hot_prepare(Slot &slot, const BinArgs &A, const BinArgs &planned, co
         if (H.last_fraction * 100.0 < (double)c.cfg_hot_min_pct) return;
     }
     H.x0 = box[0]; H.y0 = box[1]; H.w = box[2]; H.h = box[3];
-    const uint64_t tile_rows = 4096;
-    const uint64_t tiles = (std::min<uint64_t>(length, (uint64_t)std::max<int64_t>(1 << 20, c.cfg_part_chunk)) + tile_rows - 1) / tile_rows;
+    const uint64_t tile_rows = H.wv ? 256ull * (uint64_t)H.wv_waves : 4096ull; // rows one workgroup takes per round
+    const uint64_t tiles = (std::min<uint64_t>(length, 2 * (uint64_t)std::max<int64_t>(1 << 20, c.cfg_part_chunk)) + tile_rows - 1) / tile_rows;
     H.blocks = (int)std::max<uint64_t>(1, std::min<uint64_t>(tiles, (uint64_t)c.cus)); // ONE workgroup per CU: the box takes the LDS
     const size_t need = (size_t)H.blocks * H.w * H.h * 16;
     if (need > H.acc_cap) {
@@ -804,7 +838,7 @@ static void run_part_chunk(Slot &slot, const BinArgs &planned, const LaunchPlan 
     // capacity is three times the sampled outside share (+ 1/8) of a sub-queue's rows.
     double share = 2.0;
     if (slot.hot.on && slot.hot.gen2 && ctx().cfg_hot_box[2] <= 0 && slot.hot.last_fraction > 0 && slot.hot.last_fraction <= 1) share = std::min(2.0, 3.0 * (1.0 - slot.hot.last_fraction) + 0.125);
-    P.cap = (nsub == 1 ? C : std::min<uint64_t>(C, (uint64_t)(share * (double)(C / nsub)) + 8192 + 2 * 1024 * ((uint64_t)ctx().cus / std::max<uint64_t>(1, P.parts) + 1)) + 7) & ~(uint64_t)7;
+    P.cap = (nsub == 1 ? C : std::min<uint64_t>(C, (uint64_t)(share * (double)(C / nsub)) + 8192 + 2 * 1024 * ((uint64_t)ctx().cus / std::max<uint64_t>(1, P.parts) + 1)) + 63) & ~(uint64_t)63; // (a multiple of part_scatter_wv's 64-record segments)
     const size_t idx_bytes = P.idx16 ? 2 : 4;
     size_t off = 0;
     auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
@@ -858,14 +892,36 @@ static void run_part_chunk(Slot &slot, const BinArgs &planned, const LaunchPlan 
                      (P.nmasks == 0 || (P.nmasks == 1 && P.all_masked)) && P.idx16 && slab_cells < 65535 && S <= 256 && c.cfg_part_rows <= 0 &&
                      (slot.hot.on || (S > 8 && S <= 64 && !plan.key_i64) || c.cfg_blk == 2); // measured (profiles/r01_other_shapes.txt, r01_groupby_tune.txt):
                      // <= 8 slabs without a box: two 512-thread workgroups of part_scatter_f64 are 2 % faster; 128-256 slabs: +5 % (1024^2) / -35 % (1e6-key groupby)
-    const bool hot_here = slot.hot.on && P.nmasks == 0 && P.nvals == slot.hot.nval && blk;
-    if (blk) {
+    // third-generation pass 1 (part_scatter_wv): the same signatures for <= 64 slabs, 16-byte aligned columns
+    const WvGeom wg = wv_geometry(S, P.nvals);
+    const bool wv = wg.ok && (plan.fast_f64 || (plan.key_i64 && plan.fast_vals)) && planned.ndim >= 1 && planned.ndim <= 3 && P.nvals <= 1 && !P.use_flags &&
+                    (P.nmasks == 0 || (P.nmasks == 1 && P.all_masked)) && P.idx16 && slab_cells < 65535 && wv_aligned(planned) && (!slot.hot.on || slot.hot.wv);
+    if (slot.hot.on && slot.hot.wv != wv) throw std::runtime_error("vaex_hip internal: hot box prepared for a different pass-1 kernel");
+    const bool hot_here = slot.hot.on && P.nmasks == 0 && P.nvals == slot.hot.nval && (blk || wv);
+    if (wv) {
+        P.wv = wg.waves;
+        P.wv_wave_bytes = (int32_t)wg.wave_bytes;
+        P.wv_base = 0;
+        P.rows_per_thread = 4;
+        scatter_lds = (size_t)wg.waves * wg.wave_bytes + 16;
+        scatter_blocks = (int)std::max<uint64_t>(1, std::min<uint64_t>((planned.n + 256ull * wg.waves - 1) / (256ull * wg.waves), (uint64_t)c.cus)); // ONE workgroup per CU
+    } else if (blk) {
         P.blk = 1;
         P.rows_per_thread = 4;
         scatter_lds = (size_t)VXH_BLK_FIXED_LDS(P.nvals, S) + 16;
         scatter_blocks = (int)std::max<uint64_t>(1, std::min<uint64_t>((planned.n + 4095) / 4096, (uint64_t)c.cus)); // ONE workgroup per CU
     }
-    if (hot_here) {
+    if (hot_here && wv) {
+        const Slot::Hot &H = slot.hot;
+        P.hot.on = 2;
+        P.hot.x0 = H.x0; P.hot.y0 = H.y0; P.hot.w = H.w; P.hot.h = H.h;
+        P.hot.lds_offset = 0; // the box first, the waves' rings behind it
+        P.wv_base = (int32_t)(((size_t)H.w * H.h * (P.nvals ? 12 : 4) + 15) & ~(size_t)15);
+        scatter_lds = (size_t)P.wv_base + (size_t)wg.waves * wg.wave_bytes + 16;
+        P.hot.sum_acc = (double *)H.acc;
+        P.hot.cnt_acc = (unsigned long long *)((char *)H.acc + (size_t)H.blocks * H.w * H.h * 8);
+        scatter_blocks = std::min(scatter_blocks, H.blocks); // accumulator blocks are indexed by blockIdx
+    } else if (hot_here) {
         const Slot::Hot &H = slot.hot;
         P.hot.on = 2;
         P.hot.x0 = H.x0; P.hot.y0 = H.y0; P.hot.w = H.w; P.hot.h = H.h;
@@ -877,6 +933,7 @@ static void run_part_chunk(Slot &slot, const BinArgs &planned, const LaunchPlan 
     } else if (slot.hot.on) {
         throw std::runtime_error("vaex_hip internal: hot box prepared for a signature pass 1 does not serve");
     }
+    slot.last_pass1 = wv ? 2 : (blk ? 1 : 0);
     vxh_launch_part_scatter(P, plan, scatter_blocks, scatter_lds, slot.stream);
     HIP_CHECK(hipGetLastError());
     if (c.cfg_part_overlap) {
@@ -900,6 +957,42 @@ static void part_join(Slot &slot) {
             pb.busy = false;
         }
     }
+}
+
+// RAII device scratch (freed on every exit path, exceptions included)
+struct DevBuf {
+    void *p = nullptr;
+    explicit DevBuf(size_t bytes) { if (bytes) HIP_CHECK(hipMalloc(&p, bytes)); }
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+};
+
+// shared driver of vxh_minmax / vxh_minmax_int: host inputs are streamed through a bounded device buffer
+// (cfg_stage_bytes per piece) instead of one allocation of the whole column
+template <typename OUT, typename LAUNCH>
+static void minmax_driver(int dtype, const void *data, const uint8_t *mask, uint64_t n, int mem, const OUT (&init)[2], OUT *out2, LAUNCH launch) {
+    Slot &slot = get_slot(0);
+    DevBuf dev_out(16);
+    HIP_CHECK(hipMemcpy(dev_out.p, init, 16, hipMemcpyHostToDevice));
+    const size_t es = (size_t)kDtypeSize[dtype];
+    if (n && mem == VXH_MEM_DEVICE) {
+        launch(data, mask, n, (OUT *)dev_out.p, slot.stream);
+    } else if (n) {
+        const uint64_t piece = std::max<uint64_t>(1 << 16, (uint64_t)ctx().cfg_stage_bytes / (es + 1));
+        const uint64_t rows = std::min(piece, n);
+        DevBuf tmp_d(rows * es), tmp_m(mask ? rows : 0);
+        for (uint64_t r0 = 0; r0 < n; r0 += rows) {
+            const uint64_t rn = std::min(rows, n - r0);
+            HIP_CHECK(hipMemcpyAsync(tmp_d.p, (const char *)data + r0 * es, rn * es, hipMemcpyHostToDevice, slot.stream));
+            if (mask) HIP_CHECK(hipMemcpyAsync(tmp_m.p, mask + r0, rn, hipMemcpyHostToDevice, slot.stream));
+            launch(tmp_d.p, mask ? (const uint8_t *)tmp_m.p : nullptr, rn, (OUT *)dev_out.p, slot.stream);
+            HIP_CHECK(hipGetLastError());
+            HIP_CHECK(hipStreamSynchronize(slot.stream)); // the piece buffer is reused
+        }
+    }
+    HIP_CHECK(hipStreamSynchronize(slot.stream));
+    HIP_CHECK(hipMemcpy(out2, dev_out.p, 16, hipMemcpyDeviceToHost));
 }
 
 // ------------------------------------------------------------------------------------------
@@ -968,8 +1061,11 @@ int vxh_config_set(const char *key, int64_t value) {
     else if (k == "scatter_wgs") c.cfg_scatter_wgs = value;
     else if (k == "hot") c.cfg_hot = value;
     else if (k == "blk") c.cfg_blk = value;
+    else if (k == "wv") c.cfg_wv = value;
+    else if (k == "wv_waves") c.cfg_wv_waves = value > 0 ? value : 8;
     else if (k == "hot_min_rows") c.cfg_hot_min_rows = value > 0 ? value : (1 << 24);
     else if (k == "hot_min_pct") c.cfg_hot_min_pct = value > 0 ? value : 35;
+    else if (k == "hot_cache") c.cfg_hot_cache = value;
     else if (k == "hot_x0") c.cfg_hot_box[0] = value;
     else if (k == "hot_y0") c.cfg_hot_box[1] = value;
     else if (k == "hot_w") c.cfg_hot_box[2] = value;
@@ -1000,8 +1096,11 @@ int vxh_config_get(const char *key, int64_t *value) {
     else if (k == "scatter_wgs") *value = c.cfg_scatter_wgs;
     else if (k == "hot") *value = c.cfg_hot;
     else if (k == "blk") *value = c.cfg_blk;
+    else if (k == "wv") *value = c.cfg_wv;
+    else if (k == "wv_waves") *value = c.cfg_wv_waves;
     else if (k == "hot_min_rows") *value = c.cfg_hot_min_rows;
     else if (k == "hot_min_pct") *value = c.cfg_hot_min_pct;
+    else if (k == "hot_cache") *value = c.cfg_hot_cache;
     else if (k == "hot_fraction_ppm") *value = (int64_t)(get_slot(0).hot.last_fraction * 1e6);
     else if (k == "hot_w") *value = get_slot(0).hot.last_on ? (int64_t)get_slot(0).hot.w : 0;
     else if (k == "hot_h") *value = get_slot(0).hot.last_on ? (int64_t)get_slot(0).hot.h : 0;
@@ -1316,9 +1415,10 @@ int vxh_grid_bin(vxh_grid *grid, int thread, vxh_agg *const *aggs, int n_aggs, u
         if (whole.strategy == VXH_STRAT_PART) {
             part_join(slot);
             part_acc_merge(slot, whole_args);
+            if (slot.last_pass1 == 2) slot.last_kernel = whole.fast_f64 ? "part_scatter_wv+part_reduce_f64" : "part_scatter_wv+part_reduce_generic";
             if (slot.hot.on) {
                 hot_merge(slot, whole_args);
-                slot.last_kernel = "part_scatter_hot+part_reduce_f64";
+                slot.last_kernel = slot.last_pass1 == 2 ? "part_scatter_wv_hot+part_reduce_f64" : "part_scatter_hot+part_reduce_f64";
             }
             slot.hot.on = false;
             part_guard.armed = false;
@@ -1486,30 +1586,10 @@ int vxh_minmax(int dtype, int flip_endian, const void *data, const uint8_t *mask
     VXH_API_BEGIN
     check_dtype(dtype);
     ensure_device_ready();
-    Slot &slot = get_slot(0);
-    double init[2] = {INFINITY, -INFINITY};
-    double *dev_out = nullptr;
-    HIP_CHECK(hipMalloc(&dev_out, 16));
-    HIP_CHECK(hipMemcpy(dev_out, init, 16, hipMemcpyHostToDevice));
-    const void *d = data;
-    const uint8_t *m = mask;
-    void *tmp_d = nullptr, *tmp_m = nullptr;
-    if (mem == VXH_MEM_HOST && n) {
-        HIP_CHECK(hipMalloc(&tmp_d, n * kDtypeSize[dtype]));
-        HIP_CHECK(hipMemcpy(tmp_d, data, n * kDtypeSize[dtype], hipMemcpyHostToDevice));
-        d = tmp_d;
-        if (mask) {
-            HIP_CHECK(hipMalloc(&tmp_m, n));
-            HIP_CHECK(hipMemcpy(tmp_m, mask, n, hipMemcpyHostToDevice));
-            m = (const uint8_t *)tmp_m;
-        }
-    }
-    if (n) vxh_launch_minmax(dtype, flip_endian ? 1 : 0, d, m, n, dev_out, slot.stream);
-    HIP_CHECK(hipStreamSynchronize(slot.stream));
-    HIP_CHECK(hipMemcpy(out2, dev_out, 16, hipMemcpyDeviceToHost));
-    (void)hipFree(dev_out);
-    if (tmp_d) (void)hipFree(tmp_d);
-    if (tmp_m) (void)hipFree(tmp_m);
+    const double init[2] = {INFINITY, -INFINITY};
+    minmax_driver<double>(dtype, data, mask, n, mem, init, out2, [&](const void *d, const uint8_t *m, uint64_t rn, double *o, hipStream_t st) {
+        vxh_launch_minmax(dtype, flip_endian ? 1 : 0, d, m, rn, o, st);
+    });
     VXH_API_END
 }
 
@@ -1518,30 +1598,10 @@ int vxh_minmax_int(int dtype, int flip_endian, const void *data, const uint8_t *
     check_dtype(dtype);
     if (dtype == VXH_F64 || dtype == VXH_F32) throw std::runtime_error("vxh_minmax_int: integer dtypes only");
     ensure_device_ready();
-    Slot &slot = get_slot(0);
-    long long init[2] = {INT64_MAX, INT64_MIN};
-    long long *dev_out = nullptr;
-    HIP_CHECK(hipMalloc(&dev_out, 16));
-    HIP_CHECK(hipMemcpy(dev_out, init, 16, hipMemcpyHostToDevice));
-    const void *d = data;
-    const uint8_t *m = mask;
-    void *tmp_d = nullptr, *tmp_m = nullptr;
-    if (mem == VXH_MEM_HOST && n) {
-        HIP_CHECK(hipMalloc(&tmp_d, n * kDtypeSize[dtype]));
-        HIP_CHECK(hipMemcpy(tmp_d, data, n * kDtypeSize[dtype], hipMemcpyHostToDevice));
-        d = tmp_d;
-        if (mask) {
-            HIP_CHECK(hipMalloc(&tmp_m, n));
-            HIP_CHECK(hipMemcpy(tmp_m, mask, n, hipMemcpyHostToDevice));
-            m = (const uint8_t *)tmp_m;
-        }
-    }
-    if (n) vxh_launch_minmax_int(dtype, flip_endian ? 1 : 0, d, m, n, dev_out, slot.stream);
-    HIP_CHECK(hipStreamSynchronize(slot.stream));
-    HIP_CHECK(hipMemcpy(out2, dev_out, 16, hipMemcpyDeviceToHost));
-    (void)hipFree(dev_out);
-    if (tmp_d) (void)hipFree(tmp_d);
-    if (tmp_m) (void)hipFree(tmp_m);
+    const long long init[2] = {INT64_MAX, INT64_MIN};
+    minmax_driver<long long>(dtype, data, mask, n, mem, init, (long long *)out2, [&](const void *d, const uint8_t *m, uint64_t rn, long long *o, hipStream_t st) {
+        vxh_launch_minmax_int(dtype, flip_endian ? 1 : 0, d, m, rn, o, st);
+    });
     VXH_API_END
 }
 

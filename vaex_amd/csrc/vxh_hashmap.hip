@@ -249,6 +249,7 @@ void vxh_hashmap_fill_binner_desc(vxh_hashmap *m, BinnerDesc *bd) {
     bd->hmask = m->cap - 1;
     bd->bins = m->host_side[0];
     bd->null_bin = (int64_t)m->host_side[0] + 1;
+    bd->hmin_ord = m->host_side[2] ? (int64_t)m->host_side[3] : -1;
 }
 
 extern "C" {

@@ -91,6 +91,8 @@ struct Slot {
     struct Hot {
         int nval = 1;      // value columns the box aggregates (1: fp64 sum + count per cell, 0: count only)
         bool gen2 = false; // part_scatter_hot (vs the HOT instantiation of part_scatter_f64)
+        bool wv = false;   // the box lives in part_scatter_wv
+        int wv_waves = 0;
         bool on = false, last_on = false; // last_on: the most recent call used the box (reporting)
         uint32_t x0 = 0, y0 = 0, w = 0, h = 0;
         int blocks = 0;          // pass-1 workgroups (= accumulator blocks)
@@ -107,6 +109,7 @@ struct Slot {
         double last_fraction = 0; // share of the sample inside the box (vxh_config_get("hot_fraction_ppm"))
     } hot;
     const char *last_kernel = "";
+    int last_pass1 = 0; // partition strategy, most recent chunk: 0 part_scatter / part_scatter_f64, 1 part_scatter_blk, 2 part_scatter_wv
 };
 
 struct Context {
@@ -128,8 +131,11 @@ struct Context {
     int64_t cfg_parts = 0;        // pass-2 workgroups per slab (0 = auto)
     int64_t cfg_part_lds = 0;     // LDS bytes per pass-2 slab (0 = auto)
     int64_t cfg_blk = 1;           // second-generation pass 1 (part_scatter_blk) where its signature allows (0: part_scatter_f64)
+    int64_t cfg_wv = 1;            // third-generation pass 1 (part_scatter_wv: barrier-free, wave-private rings) where its signature allows
+    int64_t cfg_wv_waves = 8;      // ... waves per workgroup (one workgroup per CU); fewer when the rings would not fit
     int64_t cfg_hot = 1;           // hot box in pass 1 of the partition strategy (0 off)
     int64_t cfg_hot_min_rows = 1 << 24; // calls shorter than this do not pay for the sample
+    int64_t cfg_hot_cache = 1;     // reuse the sampled box when the same columns are binned with the same limits again (0: sample every call)
     int64_t cfg_hot_min_pct = 35;  // use the box only when it catches at least this share of the sample
     int64_t cfg_hot_box[4] = {0, 0, 0, 0}; // x0, y0, w, h override (w > 0) — tests / experiments
     int64_t cfg_scatter_wgs = 0;  // pass-1 workgroups per CU (0 = as many as LDS allows, at most 4)

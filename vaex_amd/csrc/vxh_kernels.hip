@@ -202,6 +202,10 @@ __device__ __forceinline__ void flat_index_batch(const BinArgs &A, const Rows<N>
                     const int64_t key = (int64_t)c[u];
                     uint64_t p = p0[u];
                     int64_t cur = k0[u], ord = v0[u];
+                    if (key == INT64_MIN) { // the EMPTY sentinel as a key: never in the table (vxh_hashmap.hip side words)
+                        ord = -1;
+                        if (b.hmin_ord >= 0) sub = (uint64_t)b.hmin_ord + 1;
+                    }
                     for (;;) {
                         if (ord < 0) break; // empty slot: unknown key
                         if (cur == key) { sub = (uint64_t)ord + 1; break; }
@@ -1427,6 +1431,264 @@ __global__ void __launch_bounds__(VXH_HOT_BLOCK) part_scatter_blk(const PartArgs
     }
 }
 
+// K1w — pass 1, third generation (PartArgs::wv): BARRIER-FREE.  Same signatures as part_scatter_blk (1..3 scalar float64
+// binners or ONE int64 ordinal key, at most one float64 value column, at most one aggregator mask shared by every
+// aggregator, uint16 local indices) for S <= 64 slabs.  part_scatter_blk spends half of its wave-cycles parked at its
+// two workgroup barriers per tile (one 1024-thread workgroup per CU: nothing else runs meanwhile,
+// profiles/r01_pmc_hot_pass.txt); here nothing is shared between the waves of a workgroup except the hot box:
+//   * a wave owns 256-row tiles (two 16-byte loads per column per lane: rows 2l, 2l+1 and 128+2l, 129+2l), the next
+//     tile's columns requested before the current one is binned (ping-pong register buffers);
+//   * cold rows are bucketed by slab in a WAVE-PRIVATE LDS ring per slab (depth 128): the returning ds_add on the
+//     wave's own counter is the record's position, the record goes to ring[slab][position mod 128]; LDS operations
+//     of one wave execute in order, so no barrier is needed.  A lane whose position completes a 64-record granule
+//     flushes it (wave-uniform loop over the ballot of such lanes): 64 lanes copy the granule to the sub-queue in
+//     two fully coalesced stores (128 B of indices, 512 B of values);
+//   * queue space: segments of 64 records, one reserved AHEAD per (wave, slab) and kept in the registers of lane
+//     `slab` — the HBM atomic that reserves the next segment is issued when the current one is consumed and first
+//     looked at a whole granule later.  What is left in the rings at the end goes out as one last segment per slab,
+//     padded with null records (local index = slab_cells: a dummy LDS cell of pass 2);
+//   * rows are processed one per lane at a time within the tile (R = 4 sub-steps): at most 64 new records per slab
+//     per sub-step and every complete granule flushed before the next one is what makes depth 128 sufficient;
+//   * HOT (two binners, no mask): as in part_scatter_blk — the workgroup's LDS copy of the box takes what the rings
+//     leave of the 160 KiB; the only two barriers of the kernel are the ones around the box's lifetime.
+constexpr uint32_t VXH_WV_OVF = 0xffffffffu;
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// slow path of part_scatter_wv (sub-queue full: pathologically skewed data): ONE record straight into the grids with
+// device atomics.  Lean on purpose — it is inlined at every flush site: the kernel's signature guarantees float64
+// (or absent) aggregator inputs and no per-aggregator masks, so only the five kinds on double / int64 cells remain.
+__device__ __forceinline__ void wv_slow_record(const PartArgs &P, uint64_t cell, double v) {
+    const bool nan = v != v;
+    for (int k = 0; k < P.A.nagg; ++k) {
+        const AggDesc &a = P.A.a[k];
+        const bool has = P.agg_vslot[k] != 0xffu;
+        if (has && nan) continue; // NaN inputs are skipped by every aggregator that reads the column
+        if (a.kind == VXH_AGG_COUNT) at_add<__HIP_MEMORY_SCOPE_AGENT, unsigned long long>((unsigned long long *)a.grid + cell, 1ull);
+        else if (a.kind == VXH_AGG_SUM) at_add<__HIP_MEMORY_SCOPE_AGENT, double>((double *)a.grid + cell, v);
+        else if (a.kind == VXH_AGG_SUM_MOMENT) at_add<__HIP_MEMORY_SCOPE_AGENT, double>((double *)a.grid + cell, pow_u(v, a.moment));
+        else if (a.kind == VXH_AGG_MAX) at_max<__HIP_MEMORY_SCOPE_AGENT, double>((double *)a.grid + cell, v);
+        else at_min<__HIP_MEMORY_SCOPE_AGENT, double>((double *)a.grid + cell, v);
+    }
+}
+
+template <int NDIM, int NVAL, bool MASKED, bool HOT, int KEY = 0>
+__global__ void __launch_bounds__(1024) part_scatter_wv(const PartArgs P) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    constexpr int R = 4;
+    constexpr uint32_t TW = 64u * R; // rows per wave tile
+    constexpr uint32_t D = VXH_WV_D, G = VXH_WV_G;
+    const uint32_t S = 1u << P.slab_log2; // <= 64
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t nwave = blockDim.x >> 6;
+    const uint32_t hot_cells = HOT ? P.hot.w * P.hot.h : 0u;
+    double *const hot_sum = (double *)(lds + P.hot.lds_offset);
+    uint32_t *const hot_cnt = (uint32_t *)(hot_sum + (NVAL ? hot_cells : 0));
+    char *const wbase = lds + P.wv_base + wave * (uint32_t)P.wv_wave_bytes;
+    double *const ring_val = (double *)wbase;
+    uint16_t *const ring_idx = (uint16_t *)(wbase + (NVAL ? (size_t)S * D * 8 : 0));
+    uint32_t *const cnt = (uint32_t *)(ring_idx + (size_t)S * D);
+    const uint64_t n = P.A.n;
+    const uint64_t GW = (uint64_t)gridDim.x * nwave;
+    uint64_t tile = (uint64_t)blockIdx.x * nwave + wave;
+    const bool has_work = tile * TW < n; // (wave-uniform)
+
+    if (HOT) {
+        for (uint32_t c = threadIdx.x; c < hot_cells; c += blockDim.x) {
+            if (NVAL) hot_sum[c] = 0.0;
+            hot_cnt[c] = 0u;
+        }
+    }
+    if (lane < S) cnt[lane] = 0u;
+    // lane s keeps the queue segment reserved for slab s
+    const uint32_t part = blockIdx.x % (uint32_t)P.parts;
+    const uint32_t my_sub = (lane < S ? lane : 0u) * (uint32_t)P.parts + part;
+    auto reserve = [&]() -> uint32_t {
+        const unsigned long long b = atomicAdd(&P.qcount[my_sub], (unsigned long long)G);
+        if (b + G > P.cap) { // does not fit: remember where the valid prefix of the sub-queue ends; slow path from here on
+            atomicMin(&P.qlimit[my_sub], b);
+            return VXH_WV_OVF;
+        }
+        return (uint32_t)b;
+    };
+    uint32_t nxt = VXH_WV_OVF;
+    if (has_work && lane < S) nxt = reserve();
+    if (HOT) __syncthreads(); // the box is zero before any wave adds to it
+
+    // One tile = two 16-byte buffer loads per column per lane (rows 2l, 2l+1 and 128+2l, 129+2l of the tile).  Buffer
+    // loads: the descriptor (base of the tile, bytes the tile really has) is scalar, the per-lane offset a loop
+    // invariant, and the hardware bounds check returns zeros for rows past the end — the last, partial tile takes the
+    // same instructions as every other (a second, clamped code path made the register allocator copy freshly loaded
+    // values at the join, i.e. wait for the loads it had just issued).  `nt`: every row is read exactly once.
+    struct Raw {
+        u32x4 b[NDIM][2];
+        u32x4 v[2]; // (dead registers when NVAL == 0)
+        uint32_t m; // mask bytes of rows 0,1 (low half) and 2,3 (high half)
+        uint32_t rows; // rows the tile really has (wave-uniform)
+    };
+    const double *colv = NVAL ? (const double *)P.vdata[0] : nullptr;
+    const uint8_t *colm = MASKED ? P.mdata[0] : nullptr;
+    auto request = [&](uint64_t t, Raw &raw) {
+        const uint64_t r0 = t * TW;
+        const uint64_t left = n - r0;
+        const uint32_t rows_here = left < TW ? (uint32_t)left : TW;
+        raw.rows = rows_here;
+#pragma unroll
+        for (int d = 0; d < NDIM; ++d) {
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)((const double *)P.A.b[d].data + r0), 0, (int)(rows_here * 8u), 0x00020000);
+            raw.b[d][0] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(lane * 16u), 0, 2);
+            raw.b[d][1] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(lane * 16u), 1024, 2);
+        }
+        if (NVAL) {
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(colv + r0), 0, (int)(rows_here * 8u), 0x00020000);
+            raw.v[0] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(lane * 16u), 0, 2);
+            raw.v[1] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(lane * 16u), 1024, 2);
+        }
+        if (MASKED) {
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(colm + r0), 0, (int)rows_here, 0x00020000);
+            const uint32_t m0 = __builtin_amdgcn_raw_buffer_load_b16(rs, (int)(lane * 2u), 0, 2);
+            const uint32_t m1 = __builtin_amdgcn_raw_buffer_load_b16(rs, (int)(lane * 2u), 128, 2);
+            raw.m = (m0 & 0xffffu) | (m1 << 16);
+        }
+    };
+    // row r of the lane: bits of column value (d or the value column)
+    auto f64_of = [](const u32x4 (&q)[2], int r) -> double {
+        const u32x4 w = q[r >> 1];
+        const uint32_t lo = (r & 1) ? w[2] : w[0], hi = (r & 1) ? w[3] : w[1];
+        return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+    };
+
+    // copy the complete granule of slab s that starts at ring offset `off` (0 or 64) to the slab's reserved segment
+    // (count < 64: the final, partial granule — the rest of the segment is filled with null records)
+    const uint32_t null_idx = (uint32_t)((P.A.cells + S - 1) >> P.slab_log2); // = slab_cells: pass 2's dummy LDS cell
+    auto flush = [&](uint32_t s, uint32_t off, uint32_t count) {
+        __builtin_amdgcn_wave_barrier(); // (scheduling only: the ring writes above stay above)
+        const uint32_t j = s * D + off + lane;
+        const bool live = lane < count;
+        uint32_t ri = ring_idx[j];
+        double rv = NVAL ? ring_val[NVAL ? j : 0] : 0.0;
+        if (!live) { ri = null_idx; rv = 0.0; }
+        const uint32_t base = (uint32_t)__builtin_amdgcn_readlane((int)nxt, (int)s);
+        if (base != VXH_WV_OVF) {
+            const uint64_t dst = (uint64_t)(s * (uint32_t)P.parts + part) * P.cap + base + lane;
+            ((uint16_t *)P.qidx)[dst] = (uint16_t)ri;
+            if (NVAL) P.qval[0][dst] = (uint64_t)__double_as_longlong(rv);
+        } else if (live) { // sub-queue full (pathologically skewed data): device atomics straight into the grids
+            wv_slow_record(P, ((uint64_t)ri << P.slab_log2) + s, rv);
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
+
+    auto process = [&](const Raw &cur) {
+        uint32_t keep = (1u << R) - 1u;
+        if (cur.rows != TW) { // the last, partial tile (wave-uniform): rows past the end read as zeros and are dropped here
+            keep = 0;
+#pragma unroll
+            for (int r = 0; r < R; ++r) keep |= (((uint32_t)(r >> 1) * 128u + 2u * lane + (uint32_t)(r & 1)) < cur.rows ? 1u : 0u) << r;
+        }
+        if (MASKED) { // aggregator mask: 1 = keep (src/agg_count.cpp:50); every aggregator carries this mask
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                if (((cur.m >> (8 * r)) & 0xffu) != 1u) keep &= ~(1u << r);
+        }
+        double val[NVAL ? R : 1];
+        if (NVAL) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) val[NVAL ? r : 0] = f64_of(cur.v, r);
+        }
+        uint32_t slab[R], loc[R], pos[R], cold = 0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            uint32_t sub_i[NDIM];
+#pragma unroll
+            for (int d = 0; d < NDIM; ++d) {
+                const BinnerDesc &b = P.A.b[d];
+                if (KEY == 1) { // ONE ordinal binner on a native int64 key (groupby): src/binner_ordinal.cpp:138-175 without mask
+                    const int64_t value = (int64_t)((uint64_t)__double_as_longlong(f64_of(cur.b[d], r)) - (uint64_t)b.min_value);
+                    const int64_t nord = (int64_t)b.bins;
+                    sub_i[d] = (value < 0 || value >= nord) ? (uint32_t)nord : (uint32_t)(b.invert ? nord - 1 - value : value);
+                } else {
+                    sub_i[d] = scalar_sub_index32(f64_of(cur.b[d], r), b.vmin, b.scale, b.binsd, (uint32_t)b.bins);
+                }
+            }
+            uint32_t idx = sub_i[0]; // (dim 0 has stride 1; sub-indices and strides are < 2^24 here)
+#pragma unroll
+            for (int d = 1; d < NDIM; ++d) idx += __umul24(sub_i[d], (uint32_t)P.A.b[d].stride);
+            slab[r] = idx & (S - 1);
+            loc[r] = idx >> P.slab_log2;
+            bool is_cold = ((keep >> r) & 1u) != 0u;
+            if (HOT) {
+                const uint32_t hx = sub_i[0] - P.hot.x0, hy = sub_i[NDIM > 1 ? 1 : 0] - P.hot.y0; // (unsigned: below the box wraps to huge)
+                bool hot = (hx < P.hot.w) & (hy < P.hot.h) & is_cold;
+                if (NVAL) hot = hot & (val[NVAL ? r : 0] == val[NVAL ? r : 0]);
+                if (hot) {
+                    const uint32_t hc = __umul24(hy, P.hot.w) + hx;
+                    if (NVAL) at_add<__HIP_MEMORY_SCOPE_WORKGROUP, double>(hot_sum + hc, val[NVAL ? r : 0]);
+                    at_add<__HIP_MEMORY_SCOPE_WORKGROUP, uint32_t>(hot_cnt + hc, 1u);
+                }
+                is_cold = is_cold & !hot;
+            }
+            pos[r] = 0;
+            if (is_cold) {
+                pos[r] = __hip_atomic_fetch_add(&cnt[slab[r]], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                cold |= 1u << r;
+            }
+        }
+        // one sub-step per row of the lane: stage, then flush every granule this sub-step completed
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const bool c = ((cold >> r) & 1u) != 0u;
+            if (c) {
+                const uint32_t j = slab[r] * D + (pos[r] & (D - 1));
+                ring_idx[j] = (uint16_t)loc[r];
+                if (NVAL) ring_val[NVAL ? j : 0] = val[NVAL ? r : 0];
+            }
+            unsigned long long done = __ballot(c && (pos[r] & (G - 1)) == G - 1);
+            while (done) {
+                const int l = __builtin_ctzll(done);
+                done &= done - 1;
+                const uint32_t s = (uint32_t)__builtin_amdgcn_readlane((int)slab[r], l);
+                const uint32_t p = (uint32_t)__builtin_amdgcn_readlane((int)pos[r], l);
+                flush(s, (p + 1u - G) & (D - 1), G);
+                if (lane == s) nxt = reserve(); // (looked at when this slab's next granule is complete)
+            }
+        }
+    };
+
+    if (has_work) {
+        // ping-pong register buffers, the loop unrolled by two so that neither is ever copied (see count_lds_f64)
+        Raw bufA, bufB;
+        request(tile, bufA);
+        for (;;) {
+            uint64_t next = tile + GW;
+            bool has_next = next * TW < n;
+            request(has_next ? next : tile, bufB); // (the last tile re-requests itself: static number of loads in flight)
+            process(bufA);
+            if (!has_next) break;
+            tile = next;
+            next = tile + GW;
+            has_next = next * TW < n;
+            request(has_next ? next : tile, bufA);
+            process(bufB);
+            if (!has_next) break;
+            tile = next;
+        }
+        // what is left in the rings: one last segment per slab (the one reserved ahead), padded with null records
+        const uint32_t my_cnt = lane < S ? cnt[lane] : 0u;
+        for (uint32_t s = 0; s < S; ++s) {
+            const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)my_cnt, (int)s);
+            const uint32_t rem = c & (G - 1);
+            flush(s, (c - rem) & (D - 1), rem);
+        }
+    }
+    if (HOT) {
+        __syncthreads();
+        unsigned long long *gc = P.hot.cnt_acc + (uint64_t)blockIdx.x * hot_cells;
+        if (NVAL) flush_add_plain<double, double>(P.hot.sum_acc + (uint64_t)blockIdx.x * hot_cells, hot_sum, hot_cells, 0, 0, hot_cells);
+        flush_add_plain<unsigned long long, uint32_t>(gc, hot_cnt, hot_cells, 0, 0, hot_cells);
+    }
+}
+
 // pass 2: slab queues -> LDS-private slab -> HBM replica.  Each lane streams 4 consecutive records per
 // vector load and keeps N4 such batches in flight.
 template <int N4, bool PACK16>
@@ -1802,7 +2064,24 @@ void vxh_launch_part_scatter(const PartArgs &args, const LaunchPlan &plan, int s
         if (scatter_lds > 48 * 1024) (void)hipFuncSetAttribute((const void *)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, (int)scatter_lds); \
         hipLaunchKernelGGL(KERNEL, dim3(scatter_blocks), dim3(block), scatter_lds, stream, args);                      \
     } while (0)
-    if (args.blk) { // second-generation pass 1 (the host checks the signature)
+    if (args.wv) { // third-generation pass 1: barrier-free, wave-private rings (the host checks the signature)
+        block = args.wv * 64;
+        const bool hot = args.hot.on == 2, masked = args.nmasks > 0;
+#define VXH_WV(ND)                                                                                                     \
+    do {                                                                                                               \
+        if (args.nvals == 0) { if (masked) VXH_SC((part_scatter_wv<ND, 0, true, false>)); else VXH_SC((part_scatter_wv<ND, 0, false, false>)); } \
+        else { if (masked) VXH_SC((part_scatter_wv<ND, 1, true, false>)); else VXH_SC((part_scatter_wv<ND, 1, false, false>)); } \
+    } while (0)
+        if (plan.key_i64) { // groupby on an int64 key
+            if (args.nvals == 0) { if (masked) VXH_SC((part_scatter_wv<1, 0, true, false, 1>)); else VXH_SC((part_scatter_wv<1, 0, false, false, 1>)); }
+            else { if (masked) VXH_SC((part_scatter_wv<1, 1, true, false, 1>)); else VXH_SC((part_scatter_wv<1, 1, false, false, 1>)); }
+        }
+        else if (hot) { if (args.nvals == 0) VXH_SC((part_scatter_wv<2, 0, false, true>)); else VXH_SC((part_scatter_wv<2, 1, false, true>)); }
+        else if (args.A.ndim == 1) VXH_WV(1);
+        else if (args.A.ndim == 2) VXH_WV(2);
+        else VXH_WV(3);
+#undef VXH_WV
+    } else if (args.blk) { // second-generation pass 1 (the host checks the signature)
         block = VXH_HOT_BLOCK;
         const bool hot = args.hot.on == 2, masked = args.nmasks > 0;
 #define VXH_BLK(ND)                                                                                                    \

@@ -28,6 +28,7 @@ struct BinnerDesc {
     const int64_t *hvals; // (unused: nullptr)
     uint64_t hmask;       // hash: capacity-1
     int64_t null_bin;     // hash: cell for masked rows
+    int64_t hmin_ord;     // hash: ordinal of the key INT64_MIN (the table's EMPTY sentinel: kept in the map's side words), or -1
     uint8_t kind, dtype, flip, allow_other, invert;
 };
 
@@ -100,7 +101,10 @@ struct PartArgs {
     // (Flushing straight into grid replicas touches one 64-128 B line per 8 B cell — the slabs interleave — which
     //  was ~130 us of every part_reduce launch: profiles/r01_chunk_fit.txt.)
     void *acc[VXH_MAX_AGG];
-    int32_t blk, reserved2_; // pass 1 = part_scatter_blk (block-reserved queues, 4096-row tiles)
+    int32_t blk; // pass 1 = part_scatter_blk (block-reserved queues, 4096-row tiles)
+    // pass 1 = part_scatter_wv (barrier-free, wave-private staging rings): wv = waves per workgroup (0: not this
+    // kernel); each wave's LDS area of wv_wave_bytes starts at wv_base + wave * wv_wave_bytes
+    int32_t wv, wv_base, wv_wave_bytes;
     // "hot box" (part_scatter_f64<2,1,4,0,HOT=true>): a w x h rectangle of cells — chosen from a sample of the
     // call's rows as the densest one that fits — is aggregated in LDS by pass 1 itself (fp64 sum + uint32 count per
     // cell); only rows outside it (and rows whose value is NaN) are emitted as records.  Each pass-1 workgroup
@@ -117,6 +121,12 @@ struct PartArgs {
 
 // LDS of part_scatter_blk ahead of the box: bucket counters, segment table, block tails, 4096-record staging
 #define VXH_BLK_FIXED_LDS(NVAL, S) (((S) <= 64 ? 64 : 256) * 56 + 16 + 4096 * (8 * (NVAL) + 2 + 1))
+
+// part_scatter_wv: ring depth per (wave, slab) and the flush granule (= records per reserved queue segment)
+#define VXH_WV_D 128
+#define VXH_WV_G 64
+// LDS of ONE wave of part_scatter_wv: [value ring][index ring][S counters]
+#define VXH_WV_WAVE_LDS(NVAL, S) ((((size_t)(S) * VXH_WV_D * (2 + 8 * (size_t)(NVAL)) + (size_t)(S) * 4) + 15) & ~(size_t)15)
 
 struct HotMergeArgs {
     uint32_t x0, y0, w, h, blocks, nagg;

@@ -129,14 +129,17 @@ class Comm:
         return "cuda" if dist.get_backend(self.group) == "nccl" else "cpu"
 
     def minmax(self, lo, hi):
-        """global (min, max) of per-rank integer ranges"""
+        """global (min, max) of per-rank integer ranges.  A rank without rows passes (INT64_MAX, INT64_MIN): the two
+        ends are reduced separately (MIN of the lows, MAX of the highs) — negating INT64_MIN does not fit int64."""
         import torch
         import torch.distributed as dist
         if not dist.is_initialized() or dist.get_world_size(self.group) == 1:
             return lo, hi
-        t = torch.tensor([lo, -hi], dtype=torch.int64, device=self._device())
-        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
-        return int(t[0]), -int(t[1])
+        tlo = torch.tensor([lo], dtype=torch.int64, device=self._device())
+        thi = torch.tensor([hi], dtype=torch.int64, device=self._device())
+        dist.all_reduce(tlo, op=dist.ReduceOp.MIN, group=self.group)
+        dist.all_reduce(thi, op=dist.ReduceOp.MAX, group=self.group)
+        return int(tlo[0]), int(thi[0])
 
     def minmax_float(self, lo, hi):
         """global (min, max) of per-rank float ranges (df.minmax / limits=None under row sharding); a rank without rows
