@@ -471,14 +471,22 @@ def test_part_blk_signatures(sa):
         dict(n=n, binners=bins("xyz", 96), aggs=[dict(kind="sum", data=vn)]),                                         # 3-D with a value column
     ]
     sa.config_set("strategy", STRATEGIES["part"])
-    for blk in (2, 0):
+    for wv, blk in ((1, 1), (2, 1), (0, 2), (0, 0)):  # part_scatter_wv (sized / 64-record queue blocks) / part_scatter_blk / part_scatter_f64
+        sa.config_set("wv", 1 if wv else 0)
+        sa.config_set("wv_block", 64 if wv == 2 else 0)
         sa.config_set("blk", blk)
         try:
+            used = []
             for case in todo:
                 check(sa, case)
                 assert sa.last_kernel(0).startswith("part_scatter")
+                used.append(sa.last_kernel(0))
+            if wv:  # (more than 64 slabs — the 703^2 case with three aggregators — stay on the older kernels)
+                assert sum("part_scatter_wv" in k for k in used) >= 2, used
         finally:
             sa.config_set("blk", 1)
+            sa.config_set("wv", 1)
+            sa.config_set("wv_block", 0)
 
 
 def test_hot_box_many_rows_per_cell(sa):

@@ -60,22 +60,22 @@ print(f"rows={rows}")
 print("--- N(0,1) x,y: 2-D 256x256 count+sum+count")
 ms, k, box, ref = run_2d(x, y, wv=0)
 show("old: part_scatter_blk + box", ms, k, box)
-for waves in (4, 6, 8, 10, 12):
-    ms, k, box, r = run_2d(x, y, wv=1, wv_waves=waves)
+for waves in (6, 8, 10):
+    ms, k, box, r = run_2d(x, y, wv=2, wv_waves=waves)
     show(f"wv waves={waves} + box", ms, k, box + " " + same(r, ref))
 ms, k, box, r = run_2d(x, y, wv=0, hot=0)
 show("old, hot=0", ms, k, same(r, ref))
 for waves in (8, 12, 16):
-    ms, k, box, r = run_2d(x, y, wv=1, wv_waves=waves, hot=0)
+    ms, k, box, r = run_2d(x, y, wv=2, wv_waves=waves, hot=0)
     show(f"wv waves={waves}, hot=0", ms, k, same(r, ref))
 print("--- uniform x,y")
 ms, k, box, refu = run_2d(xu, yu, wv=0)
 show("old", ms, k, box)
 for waves in (8, 12, 16):
-    ms, k, box, r = run_2d(xu, yu, wv=1, wv_waves=waves)
+    ms, k, box, r = run_2d(xu, yu, wv=2, wv_waves=waves)
     show(f"wv waves={waves}", ms, k, box + " " + same(r, refu))
 for chunk in (1 << 26, 1 << 27):
-    ms, k, box, r = run_2d(xu, yu, wv=1, wv_waves=12, part_chunk=chunk)
+    ms, k, box, r = run_2d(xu, yu, wv=2, wv_waves=12, part_chunk=chunk)
     show(f"wv waves=12 chunk=2^{chunk.bit_length()-1}", ms, k, same(r, refu))
 sa.config_set("part_chunk", 0)
 
@@ -107,11 +107,11 @@ def run_3d(reps=2, masked=True, **cfg):
 ms, k, ref3 = run_3d(wv=0)
 show("old 3-D + selection", ms, k, bpr=25)
 for waves in (4, 6, 8):
-    ms, k, r = run_3d(wv=1, wv_waves=waves)
+    ms, k, r = run_3d(wv=2, wv_waves=waves)
     show(f"wv waves={waves} 3-D + selection", ms, k, "same" if np.array_equal(r, ref3) else "DIFFERENT RESULT", bpr=25)
 ms, k, ref3n = run_3d(wv=0, masked=False)
 show("old 3-D no selection", ms, k)
-ms, k, r = run_3d(wv=1, wv_waves=8, masked=False)
+ms, k, r = run_3d(wv=2, wv_waves=8, masked=False)
 show("wv waves=8 3-D no selection", ms, k, "same" if np.array_equal(r, ref3n) else "DIFFERENT RESULT")
 for k2, v2 in DEFAULTS.items():
     sa.config_set(k2, v2)

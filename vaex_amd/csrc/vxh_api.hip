@@ -90,6 +90,7 @@ Slot &get_slot(int thread) {
         HIP_CHECK(hipStreamCreateWithFlags(&s->own_stream, hipStreamNonBlocking));
         s->stream = s->own_stream;
         for (auto &st : s->stage) HIP_CHECK(hipEventCreateWithFlags(&st.done, hipEventDisableTiming));
+        HIP_CHECK(hipEventCreateWithFlags(&s->after_null, hipEventDisableTiming));
         HIP_CHECK(hipEventCreate(&s->t0));
         HIP_CHECK(hipEventCreate(&s->t1));
         HIP_CHECK(hipStreamCreateWithFlags(&s->stream2, hipStreamNonBlocking));
@@ -99,6 +100,12 @@ Slot &get_slot(int thread) {
         }
     }
     return *s;
+}
+
+void order_after_producers(Slot &slot) {
+    if (slot.stream != slot.own_stream) return; // a caller-owned stream: the caller orders its own work
+    HIP_CHECK(hipEventRecord(slot.after_null, nullptr)); // the legacy default stream: ordered after every blocking stream's work
+    HIP_CHECK(hipStreamWaitEvent(slot.stream, slot.after_null, 0));
 }
 
 // ------------------------------------------------------------------------------------------
@@ -557,13 +564,12 @@ static WvGeom wv_geometry(size_t S, int nvals) {
     return g;
 }
 static bool aligned_to(const void *p, size_t a) { return ((uintptr_t)p & (a - 1)) == 0; }
-// part_scatter_wv reads two rows per 16-byte load (and two mask bytes per 2-byte load)
+// part_scatter_wv reads two rows per 16-byte load
 static bool wv_aligned(const BinArgs &A) {
     for (int d = 0; d < A.ndim; d++)
         if (!aligned_to(A.b[d].data, 16)) return false;
     for (int k = 0; k < A.nagg; k++) {
         if (A.a[k].data && !aligned_to(A.a[k].data, 16)) return false;
-        if (A.a[k].mask && !aligned_to(A.a[k].mask, 2)) return false;
     }
     return true;
 }
@@ -627,7 +633,10 @@ static void hot_prepare(Slot &slot, const BinArgs &A, const BinArgs &planned, co
     // the box lives in part_scatter_blk: uint16 local indices with one value to spare for the null record
     const bool gen2 = c.cfg_blk && S <= 256 && slab_cells < 65535 && !(c.cfg_no_pipeline & 1) && c.cfg_part_rows <= 0; // (= run_part_chunk's conditions for part_scatter_blk)
     const WvGeom wg = wv_geometry(S, nval);
-    const bool wv = wg.ok && slab_cells < 65535 && wv_aligned(A); // (= run_part_chunk's conditions for part_scatter_wv)
+    bool wv = wg.ok && slab_cells < 65535 && wv_aligned(A); // (= run_part_chunk's conditions for part_scatter_wv)
+    if (wv && gen2 && c.cfg_wv == 1) wv = false; // next to a box part_scatter_blk is the (slightly) faster one: its staging leaves the box 111 KB, eight waves' rings 78 KB
+    // a forced box (tests / experiments) too big for what part_scatter_wv's rings leave of the LDS goes to part_scatter_blk
+    if (wv && forced && gen2 && (uint64_t)c.cfg_hot_box[2] * (uint64_t)c.cfg_hot_box[3] > (kLdsMax - ((size_t)wg.waves * wg.wave_bytes + 64) - 96) / (nval ? 12 : 4)) wv = false;
     if (!gen2 && !wv) return;
     H.gen2 = true;
     H.wv = wv;
@@ -829,6 +838,18 @@ static void run_part_chunk(Slot &slot, const BinArgs &planned, const LaunchPlan 
     // the records store post-byte-swap values: pass 2 must not swap again
     for (int k = 0; k < planned.nagg; k++) P.A.a[k].flip = 0;
 
+    // third-generation pass 1 (part_scatter_wv): 1..3 float64 scalar binners or one int64 key, <= 1 float64 value column,
+    // <= 1 mask shared by every aggregator, uint16 local indices, <= 64 slabs, 16-byte aligned columns
+    const WvGeom wg = wv_geometry(S, P.nvals);
+    const bool wv = wg.ok && (plan.fast_f64 || (plan.key_i64 && plan.fast_vals)) && planned.ndim >= 1 && planned.ndim <= 3 && P.nvals <= 1 && !P.use_flags &&
+                    (P.nmasks == 0 || (P.nmasks == 1 && P.all_masked)) && P.idx16 && slab_cells < 65535 && wv_aligned(planned) && (!slot.hot.on || slot.hot.wv);
+    if (slot.hot.on && slot.hot.wv != wv) throw std::runtime_error("vaex_hip internal: hot box prepared for a different pass-1 kernel");
+    int wv_blocks = 0;
+    if (wv) {
+        wv_blocks = (int)std::max<uint64_t>(1, std::min<uint64_t>((planned.n + 256ull * wg.waves - 1) / (256ull * wg.waves), (uint64_t)c.cus)); // ONE workgroup per CU
+        if (slot.hot.on) wv_blocks = std::min(wv_blocks, slot.hot.blocks); // (the box's accumulator blocks are indexed by blockIdx)
+    }
+
     // every slab's queue is split into `parts` sub-queues (own counter each; pass 2's workgroup (slab, part) reads
     // exactly one).  Capacity per sub-queue: twice the expected share (interleaved slabs and round-robin tiles
     // balance any smooth distribution); whatever does not fit takes the HBM-atomic slow path inside part_scatter
@@ -839,10 +860,26 @@ static void run_part_chunk(Slot &slot, const BinArgs &planned, const LaunchPlan 
     double share = 2.0;
     if (slot.hot.on && slot.hot.gen2 && ctx().cfg_hot_box[2] <= 0 && slot.hot.last_fraction > 0 && slot.hot.last_fraction <= 1) share = std::min(2.0, 3.0 * (1.0 - slot.hot.last_fraction) + 0.125);
     P.cap = (nsub == 1 ? C : std::min<uint64_t>(C, (uint64_t)(share * (double)(C / nsub)) + 8192 + 2 * 1024 * ((uint64_t)ctx().cus / std::max<uint64_t>(1, P.parts) + 1)) + 63) & ~(uint64_t)63; // (a multiple of part_scatter_wv's 64-record segments)
+    if (wv) {
+        // queue blocks of part_scatter_wv: ONE block per (wave, slab) sized for the wave's expected share of this launch's
+        // records (+ 1/8 + 3 granules); a second block is a rare, in-line reservation.  A wave's tiles are spread over
+        // the whole launch (stride = all waves), so its share of every slab is the launch's share of that slab.
+        const uint64_t waves_total = (uint64_t)wv_blocks * wg.waves;
+        const double cold = (slot.hot.on && ctx().cfg_hot_box[2] <= 0 && slot.hot.last_fraction > 0 && slot.hot.last_fraction <= 1) ? std::min(1.0, 1.25 * (1.0 - slot.hot.last_fraction) + 0.02) : 1.0;
+        const double expect = (double)planned.n * cold / (double)(waves_total * S);
+        uint64_t B = ((uint64_t)(expect * 1.125) + 192 + 63) & ~(uint64_t)63;
+        if (c.cfg_wv_block > 0) B = ((uint64_t)c.cfg_wv_block + 63) & ~(uint64_t)63;
+        const uint64_t waves_per_sub = ((uint64_t)wv_blocks + P.parts - 1) / P.parts * wg.waves; // waves writing to one sub-queue
+        P.qblk = (int32_t)B;
+        // room for every wave's first block, for second blocks of a quarter of them (at least 8), capped by the rows
+        P.cap = std::max<uint64_t>(P.cap, B * (waves_per_sub + std::max<uint64_t>(8, waves_per_sub / 4)));
+        P.qtab_stride = (int32_t)(P.cap / B + 2);
+    }
     const size_t idx_bytes = P.idx16 ? 2 : 4;
     size_t off = 0;
     auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
     const size_t o_count = carve((size_t)nsub * 8), o_limit = carve((size_t)nsub * 8);
+    const size_t o_tab = wv ? carve((size_t)nsub * (size_t)P.qtab_stride * 4) : 0;
     const size_t o_idx = carve((size_t)nsub * P.cap * idx_bytes);
     const size_t o_flags = P.use_flags ? carve((size_t)nsub * P.cap) : 0;
     size_t o_val[VXH_PART_MAX_VALS] = {0, 0, 0, 0};
@@ -869,6 +906,10 @@ static void run_part_chunk(Slot &slot, const BinArgs &planned, const LaunchPlan 
     for (int k = 0; k < P.nvals; k++) P.qval[k] = (uint64_t *)(sc + o_val[k]);
     HIP_CHECK(hipMemsetAsync(P.qcount, 0, (size_t)nsub * 8, slot.stream));
     HIP_CHECK(hipMemsetAsync(P.qlimit, 0xff, (size_t)nsub * 8, slot.stream));
+    if (wv) {
+        P.qtab = (uint32_t *)(sc + o_tab);
+        HIP_CHECK(hipMemsetAsync(P.qtab, 0, (size_t)nsub * (size_t)P.qtab_stride * 4, slot.stream));
+    }
 
     // pass-1 tile: 512 threads x R rows, staged in LDS
     // (many slabs: bigger tiles keep the per-bucket copy-out segments at >= 16 records)
@@ -892,11 +933,6 @@ static void run_part_chunk(Slot &slot, const BinArgs &planned, const LaunchPlan 
                      (P.nmasks == 0 || (P.nmasks == 1 && P.all_masked)) && P.idx16 && slab_cells < 65535 && S <= 256 && c.cfg_part_rows <= 0 &&
                      (slot.hot.on || (S > 8 && S <= 64 && !plan.key_i64) || c.cfg_blk == 2); // measured (profiles/r01_other_shapes.txt, r01_groupby_tune.txt):
                      // <= 8 slabs without a box: two 512-thread workgroups of part_scatter_f64 are 2 % faster; 128-256 slabs: +5 % (1024^2) / -35 % (1e6-key groupby)
-    // third-generation pass 1 (part_scatter_wv): the same signatures for <= 64 slabs, 16-byte aligned columns
-    const WvGeom wg = wv_geometry(S, P.nvals);
-    const bool wv = wg.ok && (plan.fast_f64 || (plan.key_i64 && plan.fast_vals)) && planned.ndim >= 1 && planned.ndim <= 3 && P.nvals <= 1 && !P.use_flags &&
-                    (P.nmasks == 0 || (P.nmasks == 1 && P.all_masked)) && P.idx16 && slab_cells < 65535 && wv_aligned(planned) && (!slot.hot.on || slot.hot.wv);
-    if (slot.hot.on && slot.hot.wv != wv) throw std::runtime_error("vaex_hip internal: hot box prepared for a different pass-1 kernel");
     const bool hot_here = slot.hot.on && P.nmasks == 0 && P.nvals == slot.hot.nval && (blk || wv);
     if (wv) {
         P.wv = wg.waves;
@@ -904,7 +940,7 @@ static void run_part_chunk(Slot &slot, const BinArgs &planned, const LaunchPlan 
         P.wv_base = 0;
         P.rows_per_thread = 4;
         scatter_lds = (size_t)wg.waves * wg.wave_bytes + 16;
-        scatter_blocks = (int)std::max<uint64_t>(1, std::min<uint64_t>((planned.n + 256ull * wg.waves - 1) / (256ull * wg.waves), (uint64_t)c.cus)); // ONE workgroup per CU
+        scatter_blocks = wv_blocks;
     } else if (blk) {
         P.blk = 1;
         P.rows_per_thread = 4;
@@ -977,6 +1013,7 @@ static void minmax_driver(int dtype, const void *data, const uint8_t *mask, uint
     HIP_CHECK(hipMemcpy(dev_out.p, init, 16, hipMemcpyHostToDevice));
     const size_t es = (size_t)kDtypeSize[dtype];
     if (n && mem == VXH_MEM_DEVICE) {
+        order_after_producers(slot);
         launch(data, mask, n, (OUT *)dev_out.p, slot.stream);
     } else if (n) {
         const uint64_t piece = std::max<uint64_t>(1 << 16, (uint64_t)ctx().cfg_stage_bytes / (es + 1));
@@ -1063,6 +1100,7 @@ int vxh_config_set(const char *key, int64_t value) {
     else if (k == "blk") c.cfg_blk = value;
     else if (k == "wv") c.cfg_wv = value;
     else if (k == "wv_waves") c.cfg_wv_waves = value > 0 ? value : 8;
+    else if (k == "wv_block") c.cfg_wv_block = value;
     else if (k == "hot_min_rows") c.cfg_hot_min_rows = value > 0 ? value : (1 << 24);
     else if (k == "hot_min_pct") c.cfg_hot_min_pct = value > 0 ? value : 35;
     else if (k == "hot_cache") c.cfg_hot_cache = value;
@@ -1098,6 +1136,7 @@ int vxh_config_get(const char *key, int64_t *value) {
     else if (k == "blk") *value = c.cfg_blk;
     else if (k == "wv") *value = c.cfg_wv;
     else if (k == "wv_waves") *value = c.cfg_wv_waves;
+    else if (k == "wv_block") *value = c.cfg_wv_block;
     else if (k == "hot_min_rows") *value = c.cfg_hot_min_rows;
     else if (k == "hot_min_pct") *value = c.cfg_hot_min_pct;
     else if (k == "hot_cache") *value = c.cfg_hot_cache;
@@ -1289,6 +1328,12 @@ int vxh_grid_bin(vxh_grid *grid, int thread, vxh_agg *const *aggs, int n_aggs, u
         agg_ensure_device_locked(a);
     }
 
+    {
+        bool any_device = false;
+        for (int d = 0; d < ndim; d++) any_device = any_device || grid->binners[d]->data[thread].mem == VXH_MEM_DEVICE || (grid->binners[d]->mask[thread].ptr && grid->binners[d]->mask[thread].mem == VXH_MEM_DEVICE);
+        for (int k = 0; k < n_aggs; k++) any_device = any_device || (aggs[k]->data[thread].ptr && aggs[k]->data[thread].mem == VXH_MEM_DEVICE) || (aggs[k]->mask[thread].ptr && aggs[k]->mask[thread].mem == VXH_MEM_DEVICE);
+        if (any_device) order_after_producers(slot);
+    }
     Stager stager(slot);
     if (stage_bytes) stager.reserve(stage_bytes);
     auto resolve = [&](const SlotData &sd, size_t elem) -> const void * {

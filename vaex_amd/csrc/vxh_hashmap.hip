@@ -302,6 +302,7 @@ int vxh_hashmap_update(vxh_hashmap *m, const void *keys, const uint8_t *mask, ui
     const void *dkeys = keys;
     const uint8_t *dmask = mask;
     void *tmp_k = nullptr, *tmp_m = nullptr;
+    if (mem == VXH_MEM_DEVICE) order_after_producers(s);
     if (mem == VXH_MEM_HOST && n) {
         HIP_CHECK(hipMalloc(&tmp_k, n * es));
         HIP_CHECK(hipMemcpyAsync(tmp_k, keys, n * es, hipMemcpyHostToDevice, s.stream));
@@ -374,6 +375,7 @@ int vxh_hashmap_map_ordinal(vxh_hashmap *m, const void *keys, uint64_t n, int me
     const void *dkeys = keys;
     long long *dout = (long long *)out;
     void *tmp_k = nullptr, *tmp_o = nullptr;
+    if (mem == VXH_MEM_DEVICE) order_after_producers(s);
     if (mem == VXH_MEM_HOST) {
         HIP_CHECK(hipMalloc(&tmp_k, n * es));
         HIP_CHECK(hipMalloc(&tmp_o, n * 8));

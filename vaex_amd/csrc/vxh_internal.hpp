@@ -72,6 +72,7 @@ struct Slot {
     } stage[2];
     int cur = 0;
     hipEvent_t t0 = nullptr, t1 = nullptr;
+    hipEvent_t after_null = nullptr; // order_after_producers()
     // partition strategy: two queue buffers so that pass 1 of chunk i+1 (on `stream`) overlaps pass 2 of chunk i (on `stream2`)
     struct PartBuf {
         void *scratch = nullptr;
@@ -131,7 +132,9 @@ struct Context {
     int64_t cfg_parts = 0;        // pass-2 workgroups per slab (0 = auto)
     int64_t cfg_part_lds = 0;     // LDS bytes per pass-2 slab (0 = auto)
     int64_t cfg_blk = 1;           // second-generation pass 1 (part_scatter_blk) where its signature allows (0: part_scatter_f64)
-    int64_t cfg_wv = 1;            // third-generation pass 1 (part_scatter_wv: barrier-free, wave-private rings) where its signature allows
+    int64_t cfg_wv = 1;            // third-generation pass 1 (part_scatter_wv: barrier-free, wave-private rings): 1 where its signature allows, except
+                                   // next to a hot box (part_scatter_blk leaves the box more LDS: profiles/r02_pass1_ab.txt); 2 = there too; 0 = never
+    int64_t cfg_wv_block = 0;      // ... records per queue block of a (wave, slab) (0 = sized from the expected share); tests force tiny blocks
     int64_t cfg_wv_waves = 8;      // ... waves per workgroup (one workgroup per CU); fewer when the rings would not fit
     int64_t cfg_hot = 1;           // hot box in pass 1 of the partition strategy (0 off)
     int64_t cfg_hot_min_rows = 1 << 24; // calls shorter than this do not pay for the sample
@@ -148,6 +151,11 @@ struct Context {
 
 Context &ctx();
 Slot &get_slot(int thread);
+// Device-resident inputs (VXH_MEM_DEVICE) are usually produced by the caller's framework on the legacy default stream
+// (torch's default stream on ROCm): make the slot's (non-blocking) stream wait for everything enqueued there so far, so
+// that a kernel of this library never reads a column whose producer kernel is still running.  Callers that produce
+// their columns on another stream hand that stream over with vxh_slot_set_stream.
+void order_after_producers(Slot &slot);
 
 // hash map hooks (vxh_hashmap.hip)
 int64_t vxh_hashmap_size_for_binner(vxh_hashmap *map);

@@ -1436,23 +1436,27 @@ __global__ void __launch_bounds__(VXH_HOT_BLOCK) part_scatter_blk(const PartArgs
 // aggregator, uint16 local indices) for S <= 64 slabs.  part_scatter_blk spends half of its wave-cycles parked at its
 // two workgroup barriers per tile (one 1024-thread workgroup per CU: nothing else runs meanwhile,
 // profiles/r01_pmc_hot_pass.txt); here nothing is shared between the waves of a workgroup except the hot box:
-//   * a wave owns 256-row tiles (two 16-byte loads per column per lane: rows 2l, 2l+1 and 128+2l, 129+2l), the next
-//     tile's columns requested before the current one is binned (ping-pong register buffers);
+//   * a wave owns 256-row tiles (two 16-byte buffer loads per column per lane: rows 2l, 2l+1 and 128+2l, 129+2l), the
+//     next tile's columns requested before the current one is binned (ping-pong register buffers);
 //   * cold rows are bucketed by slab in a WAVE-PRIVATE LDS ring per slab (depth 128): the returning ds_add on the
 //     wave's own counter is the record's position, the record goes to ring[slab][position mod 128]; LDS operations
 //     of one wave execute in order, so no barrier is needed.  A lane whose position completes a 64-record granule
-//     flushes it (wave-uniform loop over the ballot of such lanes): 64 lanes copy the granule to the sub-queue in
-//     two fully coalesced stores (128 B of indices, 512 B of values);
-//   * queue space: segments of 64 records, one reserved AHEAD per (wave, slab) and kept in the registers of lane
-//     `slab` — the HBM atomic that reserves the next segment is issued when the current one is consumed and first
-//     looked at a whole granule later.  What is left in the rings at the end goes out as one last segment per slab,
-//     padded with null records (local index = slab_cells: a dummy LDS cell of pass 2);
+//     flushes it (wave-uniform loop over the ballot of such lanes): 64 lanes copy the granule to the queue in two
+//     fully coalesced stores (128 B of indices, 512 B of values);
+//   * queue space: NO returning HBM atomic in the steady state.  Vector-memory results return in order, so a wave
+//     that looks at an atomic's result first waits for every load it has in flight — measured: a reservation per
+//     granule (even issued a tile ahead) parks the waves 53 % of the time (profiles/r02_pmc_wv_v1.txt).  Instead
+//     every (wave, slab) reserves ONE block of PartArgs::qblk records — the host sizes it for the wave's expected
+//     share of the chunk plus a margin — before its first load, keeps {next free record, end of block} in the
+//     registers of lane `slab`, and only reserves another block (in line, waiting for it) if that one fills up.  What
+//     each block really holds is written to PartArgs::qtab when the block is left; pass 2 walks the table, so nothing
+//     is padded;
 //   * rows are processed one per lane at a time within the tile (R = 4 sub-steps): at most 64 new records per slab
 //     per sub-step and every complete granule flushed before the next one is what makes depth 128 sufficient;
 //   * HOT (two binners, no mask): as in part_scatter_blk — the workgroup's LDS copy of the box takes what the rings
 //     leave of the 160 KiB; the only two barriers of the kernel are the ones around the box's lifetime.
-constexpr uint32_t VXH_WV_OVF = 0xffffffffu;
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr uint32_t VXH_WV_NONE = 0xffffffffu;
 
 // slow path of part_scatter_wv (sub-queue full: pathologically skewed data): ONE record straight into the grids with
 // device atomics.  Lean on purpose — it is inlined at every flush site: the kernel's signature guarantees float64
@@ -1489,9 +1493,12 @@ __global__ void __launch_bounds__(1024) part_scatter_wv(const PartArgs P) {
     uint16_t *const ring_idx = (uint16_t *)(wbase + (NVAL ? (size_t)S * D * 8 : 0));
     uint32_t *const cnt = (uint32_t *)(ring_idx + (size_t)S * D);
     const uint64_t n = P.A.n;
-    const uint64_t GW = (uint64_t)gridDim.x * nwave;
-    uint64_t tile = (uint64_t)blockIdx.x * nwave + wave;
-    const bool has_work = tile * TW < n; // (wave-uniform)
+    // tiles are counted in 32 bits (a launch never sees more than 2^31 rows): 64-bit `<` has no scalar form, and the
+    // vector compare the compiler falls back to borrows a register — waiting for every load in flight to get it
+    const uint32_t ntiles = (uint32_t)((n + TW - 1) / TW);
+    const uint32_t GW = gridDim.x * nwave;
+    uint32_t tile = blockIdx.x * nwave + wave;
+    const bool has_work = tile < ntiles; // (wave-uniform)
 
     if (HOT) {
         for (uint32_t c = threadIdx.x; c < hot_cells; c += blockDim.x) {
@@ -1503,16 +1510,23 @@ __global__ void __launch_bounds__(1024) part_scatter_wv(const PartArgs P) {
     // lane s keeps the queue segment reserved for slab s
     const uint32_t part = blockIdx.x % (uint32_t)P.parts;
     const uint32_t my_sub = (lane < S ? lane : 0u) * (uint32_t)P.parts + part;
-    auto reserve = [&]() -> uint32_t {
-        const unsigned long long b = atomicAdd(&P.qcount[my_sub], (unsigned long long)G);
-        if (b + G > P.cap) { // does not fit: remember where the valid prefix of the sub-queue ends; slow path from here on
+    // lane s: the block slab s's records are going to — [cur, end) are record offsets inside the sub-queue
+    const uint32_t B = (uint32_t)P.qblk;
+    uint32_t cur = VXH_WV_NONE, end = VXH_WV_NONE;
+    auto open_block = [&]() { // (one lane; the ONLY place that looks at an atomic's result: once per block)
+        const unsigned long long b = atomicAdd(&P.qcount[my_sub], (unsigned long long)B);
+        if (b + B > P.cap) { // does not fit: remember where the valid prefix of the sub-queue ends; slow path from here on
             atomicMin(&P.qlimit[my_sub], b);
-            return VXH_WV_OVF;
+            cur = end = VXH_WV_NONE;
+        } else {
+            cur = (uint32_t)b;
+            end = cur + B;
         }
-        return (uint32_t)b;
     };
-    uint32_t nxt = VXH_WV_OVF;
-    if (has_work && lane < S) nxt = reserve();
+    auto close_block = [&]() { // (one lane) records the block really holds
+        if (end != VXH_WV_NONE) P.qtab[(size_t)my_sub * (uint32_t)P.qtab_stride + (end - B) / B] = cur - (end - B);
+    };
+    if (has_work && lane < S) open_block();
     if (HOT) __syncthreads(); // the box is zero before any wave adds to it
 
     // One tile = two 16-byte buffer loads per column per lane (rows 2l, 2l+1 and 128+2l, 129+2l of the tile).  Buffer
@@ -1528,10 +1542,9 @@ __global__ void __launch_bounds__(1024) part_scatter_wv(const PartArgs P) {
     };
     const double *colv = NVAL ? (const double *)P.vdata[0] : nullptr;
     const uint8_t *colm = MASKED ? P.mdata[0] : nullptr;
-    auto request = [&](uint64_t t, Raw &raw) {
-        const uint64_t r0 = t * TW;
-        const uint64_t left = n - r0;
-        const uint32_t rows_here = left < TW ? (uint32_t)left : TW;
+    auto request = [&](uint32_t t, Raw &raw) {
+        const uint64_t r0 = (uint64_t)t * TW;
+        const uint32_t rows_here = t + 1u == ntiles ? (uint32_t)(n - r0) : TW;
         raw.rows = rows_here;
 #pragma unroll
         for (int d = 0; d < NDIM; ++d) {
@@ -1546,9 +1559,13 @@ __global__ void __launch_bounds__(1024) part_scatter_wv(const PartArgs P) {
         }
         if (MASKED) {
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(colm + r0), 0, (int)rows_here, 0x00020000);
-            const uint32_t m0 = __builtin_amdgcn_raw_buffer_load_b16(rs, (int)(lane * 2u), 0, 2);
-            const uint32_t m1 = __builtin_amdgcn_raw_buffer_load_b16(rs, (int)(lane * 2u), 128, 2);
-            raw.m = (m0 & 0xffffu) | (m1 << 16);
+            // (byte loads: a 2-byte load that straddles the end of the buffer reads as zero as a whole, which would drop
+            //  the last row of an odd-length tile; the 16-byte column loads are range-checked dword by dword)
+            const uint32_t m0 = __builtin_amdgcn_raw_buffer_load_b8(rs, (int)(lane * 2u), 0, 2);
+            const uint32_t m1 = __builtin_amdgcn_raw_buffer_load_b8(rs, (int)(lane * 2u), 1, 2);
+            const uint32_t m2 = __builtin_amdgcn_raw_buffer_load_b8(rs, (int)(lane * 2u), 128, 2);
+            const uint32_t m3 = __builtin_amdgcn_raw_buffer_load_b8(rs, (int)(lane * 2u), 129, 2);
+            raw.m = (m0 & 0xffu) | ((m1 & 0xffu) << 8) | ((m2 & 0xffu) << 16) | (m3 << 24);
         }
     };
     // row r of the lane: bits of column value (d or the value column)
@@ -1558,21 +1575,28 @@ __global__ void __launch_bounds__(1024) part_scatter_wv(const PartArgs P) {
         return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
     };
 
-    // copy the complete granule of slab s that starts at ring offset `off` (0 or 64) to the slab's reserved segment
-    // (count < 64: the final, partial granule — the rest of the segment is filled with null records)
-    const uint32_t null_idx = (uint32_t)((P.A.cells + S - 1) >> P.slab_log2); // = slab_cells: pass 2's dummy LDS cell
+    // copy `count` records of slab s (a complete granule, or what is left at the end) from ring offset `off` (0 or 64)
+    // to the slab's block
     auto flush = [&](uint32_t s, uint32_t off, uint32_t count) {
         __builtin_amdgcn_wave_barrier(); // (scheduling only: the ring writes above stay above)
         const uint32_t j = s * D + off + lane;
         const bool live = lane < count;
-        uint32_t ri = ring_idx[j];
-        double rv = NVAL ? ring_val[NVAL ? j : 0] : 0.0;
-        if (!live) { ri = null_idx; rv = 0.0; }
-        const uint32_t base = (uint32_t)__builtin_amdgcn_readlane((int)nxt, (int)s);
-        if (base != VXH_WV_OVF) {
-            const uint64_t dst = (uint64_t)(s * (uint32_t)P.parts + part) * P.cap + base + lane;
-            ((uint16_t *)P.qidx)[dst] = (uint16_t)ri;
-            if (NVAL) P.qval[0][dst] = (uint64_t)__double_as_longlong(rv);
+        const uint32_t ri = ring_idx[j];
+        const double rv = NVAL ? ring_val[NVAL ? j : 0] : 0.0;
+        if (__builtin_amdgcn_readlane((int)(cur == end), (int)s)) { // the slab's block is full (or there is none): the next one, now
+            if (lane == s) {
+                close_block();
+                open_block();
+            }
+        }
+        const uint32_t base = (uint32_t)__builtin_amdgcn_readlane((int)cur, (int)s);
+        if (base != VXH_WV_NONE) {
+            if (live) {
+                const uint64_t dst = (uint64_t)(s * (uint32_t)P.parts + part) * P.cap + base + lane;
+                ((uint16_t *)P.qidx)[dst] = (uint16_t)ri;
+                if (NVAL) P.qval[0][dst] = (uint64_t)__double_as_longlong(rv);
+            }
+            if (lane == s) cur += count;
         } else if (live) { // sub-queue full (pathologically skewed data): device atomics straight into the grids
             wv_slow_record(P, ((uint64_t)ri << P.slab_log2) + s, rv);
         }
@@ -1650,7 +1674,6 @@ __global__ void __launch_bounds__(1024) part_scatter_wv(const PartArgs P) {
                 const uint32_t s = (uint32_t)__builtin_amdgcn_readlane((int)slab[r], l);
                 const uint32_t p = (uint32_t)__builtin_amdgcn_readlane((int)pos[r], l);
                 flush(s, (p + 1u - G) & (D - 1), G);
-                if (lane == s) nxt = reserve(); // (looked at when this slab's next granule is complete)
             }
         }
     };
@@ -1660,26 +1683,27 @@ __global__ void __launch_bounds__(1024) part_scatter_wv(const PartArgs P) {
         Raw bufA, bufB;
         request(tile, bufA);
         for (;;) {
-            uint64_t next = tile + GW;
-            bool has_next = next * TW < n;
+            uint32_t next = tile + GW;
+            bool has_next = next < ntiles;
             request(has_next ? next : tile, bufB); // (the last tile re-requests itself: static number of loads in flight)
             process(bufA);
             if (!has_next) break;
             tile = next;
             next = tile + GW;
-            has_next = next * TW < n;
+            has_next = next < ntiles;
             request(has_next ? next : tile, bufA);
             process(bufB);
             if (!has_next) break;
             tile = next;
         }
-        // what is left in the rings: one last segment per slab (the one reserved ahead), padded with null records
+        // what is left in the rings (less than a granule per slab), then the fill of the blocks still open
         const uint32_t my_cnt = lane < S ? cnt[lane] : 0u;
         for (uint32_t s = 0; s < S; ++s) {
             const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)my_cnt, (int)s);
             const uint32_t rem = c & (G - 1);
-            flush(s, (c - rem) & (D - 1), rem);
+            if (rem) flush(s, (c - rem) & (D - 1), rem);
         }
+        if (lane < S) close_block();
     }
     if (HOT) {
         __syncthreads();
@@ -1736,21 +1760,36 @@ __global__ void __launch_bounds__(1024) part_reduce(const PartArgs P) {
     unsigned long long len = P.qcount[sub];
     const unsigned long long lim = P.qlimit[sub];
     if (lim < len) len = lim;
-    const uint64_t lo = 0, hi = len;
     const uint64_t qb = (uint64_t)sub * P.cap;
-    const uint64_t hi4 = lo + ((hi - lo) & ~(uint64_t)3);
-    const uint64_t step = 4ull * blockDim.x;
     const uint64_t replica = 0; // (HBM grid replica for the rare device-atomic repairs; the slab itself goes to P.acc)
-    uint64_t j = lo + 4ull * threadIdx.x;
-    for (; j + step < hi4; j += 2 * step) reduce_trip<2, PACK16>(P, lds, qb + j, step, replica, slab);
-    for (; j < hi4; j += step) reduce_trip<1, PACK16>(P, lds, qb + j, step, replica, slab);
-    for (uint64_t t = hi4 + threadIdx.x; t < hi; t += blockDim.x) { // tail (< 4 records)
-        uint32_t loc[1] = {P.idx16 ? (uint32_t)((const uint16_t *)P.qidx)[qb + t] : ((const uint32_t *)P.qidx)[qb + t]};
-        uint32_t fl[1] = {P.use_flags ? (uint32_t)P.qflags[qb + t] : 0xffu};
-        uint64_t v1[VXH_PART_MAX_VALS][1];
+    // records [lo, hi) of the sub-queue (lo a multiple of 4), walked by `width` consecutive threads starting at `first`
+    auto run = [&](uint64_t lo, uint64_t hi, uint32_t first, uint32_t width) {
+        const uint64_t step = 4ull * width;
+        const uint64_t hi4 = lo + ((hi - lo) & ~(uint64_t)3);
+        uint64_t j = lo + 4ull * (threadIdx.x - first);
+        for (; j + step < hi4; j += 2 * step) reduce_trip<2, PACK16>(P, lds, qb + j, step, replica, slab);
+        for (; j < hi4; j += step) reduce_trip<1, PACK16>(P, lds, qb + j, step, replica, slab);
+        for (uint64_t t = hi4 + (threadIdx.x - first); t < hi; t += width) { // tail (< 4 records)
+            uint32_t loc[1] = {P.idx16 ? (uint32_t)((const uint16_t *)P.qidx)[qb + t] : ((const uint32_t *)P.qidx)[qb + t]};
+            uint32_t fl[1] = {P.use_flags ? (uint32_t)P.qflags[qb + t] : 0xffu};
+            uint64_t v1[VXH_PART_MAX_VALS][1];
 #pragma unroll
-        for (int k = 0; k < VXH_PART_MAX_VALS; ++k) v1[k][0] = k < P.nvals ? P.qval[k][qb + t] : 0;
-        records_apply<__HIP_MEMORY_SCOPE_WORKGROUP, true, 1, PACK16>(P, lds, loc, fl, v1, 1u, replica, slab);
+            for (int k = 0; k < VXH_PART_MAX_VALS; ++k) v1[k][0] = k < P.nvals ? P.qval[k][qb + t] : 0;
+            records_apply<__HIP_MEMORY_SCOPE_WORKGROUP, true, 1, PACK16>(P, lds, loc, fl, v1, 1u, replica, slab);
+        }
+    };
+    if (P.qblk == 0) {
+        run(0, len, 0u, blockDim.x);
+    } else {
+        // part_scatter_wv's layout: blocks of qblk records, each with its own fill count.  Every WAVE takes whole blocks
+        // (block w, w + waves, ...): a block holds one pass-1 wave's records for this slab — a few hundred to a few
+        // thousand — which one 64-lane wave streams without leaving most of a 1024-thread trip idle.
+        const uint32_t nblk = (uint32_t)(len / (uint32_t)P.qblk);
+        const uint32_t wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
+        for (uint32_t b = wave; b < nblk; b += nwave) {
+            const uint32_t c = P.qtab[(size_t)sub * (uint32_t)P.qtab_stride + b];
+            if (c) run((uint64_t)b * (uint32_t)P.qblk, (uint64_t)b * (uint32_t)P.qblk + c, threadIdx.x & ~63u, 64u);
+        }
     }
     if (PACK16) __threadfence();
     __syncthreads();
@@ -1847,21 +1886,36 @@ __global__ void __launch_bounds__(1024) part_reduce_fast(const PartArgs P) {
     unsigned long long len = P.qcount[sub];
     const unsigned long long lim = P.qlimit[sub];
     if (lim < len) len = lim;
-    const uint64_t lo = 0, hi = len;
     const uint64_t qb = (uint64_t)sub * P.cap;
-    const uint64_t hi4 = lo + ((hi - lo) & ~(uint64_t)3);
-    const uint64_t step = 4ull * blockDim.x;
     const uint64_t replica = 0; // (HBM grid replica for the rare device-atomic repairs; the slab itself goes to P.acc)
-    uint64_t j = lo + 4ull * threadIdx.x;
-    for (; j + step < hi4; j += 2 * step) reduce_trip_fast<NAGG, 2>(P, lds, qb + j, step, off, kind, vs, mom);
-    for (; j < hi4; j += step) reduce_trip_fast<NAGG, 1>(P, lds, qb + j, step, off, kind, vs, mom);
-    for (uint64_t t = hi4 + threadIdx.x; t < hi; t += blockDim.x) { // tail (< 4 records): generic path
-        uint32_t loc[1] = {(uint32_t)((const uint16_t *)P.qidx)[qb + t]};
-        uint32_t fl[1] = {0xffu};
-        uint64_t v1[VXH_PART_MAX_VALS][1];
+    // records [lo, hi) of the sub-queue (lo a multiple of 4), walked by `width` consecutive threads starting at `first`
+    auto run = [&](uint64_t lo, uint64_t hi, uint32_t first, uint32_t width) {
+        const uint64_t step = 4ull * width;
+        const uint64_t hi4 = lo + ((hi - lo) & ~(uint64_t)3);
+        uint64_t j = lo + 4ull * (threadIdx.x - first);
+        for (; j + step < hi4; j += 2 * step) reduce_trip_fast<NAGG, 2>(P, lds, qb + j, step, off, kind, vs, mom);
+        for (; j < hi4; j += step) reduce_trip_fast<NAGG, 1>(P, lds, qb + j, step, off, kind, vs, mom);
+        for (uint64_t t = hi4 + (threadIdx.x - first); t < hi; t += width) { // tail (< 4 records): generic path
+            uint32_t loc[1] = {(uint32_t)((const uint16_t *)P.qidx)[qb + t]};
+            uint32_t fl[1] = {0xffu};
+            uint64_t v1[VXH_PART_MAX_VALS][1];
 #pragma unroll
-        for (int k = 0; k < VXH_PART_MAX_VALS; ++k) v1[k][0] = k < P.nvals ? P.qval[k][qb + t] : 0;
-        records_apply<__HIP_MEMORY_SCOPE_WORKGROUP, true, 1>(P, lds, loc, fl, v1, 1u, replica, slab);
+            for (int k = 0; k < VXH_PART_MAX_VALS; ++k) v1[k][0] = k < P.nvals ? P.qval[k][qb + t] : 0;
+            records_apply<__HIP_MEMORY_SCOPE_WORKGROUP, true, 1>(P, lds, loc, fl, v1, 1u, replica, slab);
+        }
+    };
+    if (P.qblk == 0) {
+        run(0, len, 0u, blockDim.x);
+    } else {
+        // part_scatter_wv's layout: blocks of qblk records, each with its own fill count.  Every WAVE takes whole blocks
+        // (block w, w + waves, ...): a block holds one pass-1 wave's records for this slab — a few hundred to a few
+        // thousand — which one 64-lane wave streams without leaving most of a 1024-thread trip idle.
+        const uint32_t nblk = (uint32_t)(len / (uint32_t)P.qblk);
+        const uint32_t wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
+        for (uint32_t b = wave; b < nblk; b += nwave) {
+            const uint32_t c = P.qtab[(size_t)sub * (uint32_t)P.qtab_stride + b];
+            if (c) run((uint64_t)b * (uint32_t)P.qblk, (uint64_t)b * (uint32_t)P.qblk + c, threadIdx.x & ~63u, 64u);
+        }
     }
     __syncthreads(); // (never launched with count16: its LDS counts are uint32)
     lds_flush_acc(P, lds, slab_cells, slab, part);

@@ -105,6 +105,12 @@ struct PartArgs {
     // pass 1 = part_scatter_wv (barrier-free, wave-private staging rings): wv = waves per workgroup (0: not this
     // kernel); each wave's LDS area of wv_wave_bytes starts at wv_base + wave * wv_wave_bytes
     int32_t wv, wv_base, wv_wave_bytes;
+    // part_scatter_wv's queue layout: every (wave, slab) fills BLOCKS of qblk records that it reserves from the
+    // sub-queue's counter one at a time (normally a single one per launch: qblk is sized for the wave's expected share),
+    // and writes how many records each block really holds into qtab[sub * qtab_stride + block].  Pass 2 walks the
+    // blocks of its sub-queue.  (qblk == 0: the older kernels' layout — one contiguous run of records per sub-queue.)
+    int32_t qblk, qtab_stride;
+    uint32_t *qtab;
     // "hot box" (part_scatter_f64<2,1,4,0,HOT=true>): a w x h rectangle of cells — chosen from a sample of the
     // call's rows as the densest one that fits — is aggregated in LDS by pass 1 itself (fp64 sum + uint32 count per
     // cell); only rows outside it (and rows whose value is NaN) are emitted as records.  Each pass-1 workgroup
