@@ -73,7 +73,8 @@ int vxh_set_device(int device);
 int vxh_synchronize(void);
 /* run slot `thread`'s work on a caller-owned hipStream_t (NULL = library-owned stream) */
 int vxh_slot_set_stream(int thread, void *hip_stream);
-/* tuning knobs ("strategy", "replicas", "block", "blocks_per_cu", "stage_bytes"); see DESIGN.md */
+/* tuning knobs for experiments and tests ("strategy", "part_chunk", "parts", "wv", "wv_waves", "blk", "hot", "hot_cache",
+ * "count16", "stage_bytes", ...: the full list is the if-chain of vxh_config_set in vaex_amd/csrc/vxh_api.hip) */
 int vxh_config_set(const char *key, int64_t value);
 int vxh_config_get(const char *key, int64_t *value);
 /* name of the kernel variant the last vxh_grid_bin on `thread` launched (for tests / bench) */
@@ -182,6 +183,62 @@ int vxh_minmax(int dtype, int flip_endian, const void *data, const uint8_t *mask
 /* exact int64 {min, max} of an integer column ({INT64_MAX, INT64_MIN} when empty): the range test of the
  * groupby "simplify to BinnerInteger" rule, vaex/groupby.py:263-272 */
 int vxh_minmax_int(int dtype, int flip_endian, const void *data, const uint8_t *mask, uint64_t n, int mem, int64_t *out2);
+
+/* ---- finishers on the device -------------------------------------------------------------- */
+/* What vaex computes with numpy on the result grids, on the device grids instead: vaex/agg.py:403-416 (mean =
+ * sum / count), :440-455 (variance = m2 / count - mean^2; std = sqrt), and the drop of empty groups of a groupby
+ * (vaex/groupby.py:955-972: rows of the result = cells whose count is > 0, in cell order). */
+typedef enum vxh_finish_op {
+    VXH_FIN_COPY = 0, /* in0's cell as it is: float cells as double, signed integer cells as int64, unsigned as uint64 */
+    VXH_FIN_MEAN = 1, /* in0 = sum, in1 = count */
+    VXH_FIN_VAR = 2,  /* in0 = sum of squares, in1 = sum, in2 = count */
+    VXH_FIN_STD = 3
+} vxh_finish_op;
+/* n_out result columns over the cells [first_cell, first_cell + n_cells) of 1-d... N-d grids taken flat:
+ * out[j][r] = op[j](in0[j], in1[j], in2[j]) at the r-th kept cell; `present` (a count aggregator, or NULL = keep every
+ * cell) selects the cells with present > 0, in cell order; index_out[r] (optional) = that cell's index relative to
+ * first_cell.  out[j] / index_out: host arrays of n_cells 8-byte elements (pinned memory from vxh_host_alloc makes
+ * the copy a plain DMA); *n_kept = rows written. */
+int vxh_finish(int n_out, const int *ops, vxh_agg *const *in0, vxh_agg *const *in1, vxh_agg *const *in2, vxh_agg *present,
+               uint64_t first_cell, uint64_t n_cells, void *const *out, int64_t *index_out, uint64_t *n_kept);
+/* page-locked host memory (result columns, staging) */
+int vxh_host_alloc(size_t bytes, void **out);
+void vxh_host_free(void *ptr);
+
+/* ---- hash groupby in one partitioned pass -------------------------------------------------- */
+/* df.groupby(<integer key>).agg({v: count / sum / mean / var / std}) — what vaex computes in two passes
+ * (ordered_set.update, vaex/hash.py:152-171 + src/hash_primitives.hpp:98-295; then map_ordinal :611-691 +
+ * BinnerOrdinal + AggCount / AggSum / AggSumMoment, vaex/cpu.py:678-786) — as ONE radix-partitioned aggregation whose
+ * hash table is probed in LDS (vaex_amd/csrc/vxh_groupby.hip).  Per distinct key: rows, and per value column the count,
+ * sum and sum of squares of its non-NaN values; groups come back ascending by key (vaex/groupby.py sorts them). */
+typedef struct vxh_groupby vxh_groupby;
+typedef enum vxh_groupby_column_kind {
+    VXH_GB_KEYS = 0,  /* int64 */
+    VXH_GB_ROWS = 1,  /* int64: rows of the group (agg.count()) */
+    VXH_GB_COUNT = 2, /* int64: non-NaN values (agg.count(v)) */
+    VXH_GB_SUM = 3,   /* float64 */
+    VXH_GB_SUM2 = 4,  /* float64: sum of squares (AggSumMoment, moment 2) */
+    VXH_GB_MEAN = 5,  /* float64: sum / count                     (vaex/agg.py:403-416) */
+    VXH_GB_VAR = 6,   /* float64: sum2 / count - mean^2           (vaex/agg.py:440-455) */
+    VXH_GB_STD = 7
+} vxh_groupby_column_kind;
+/* keys: n elements of an integer dtype; values: n_values (1 or 2) float64 columns; mem as everywhere.  groups_hint:
+ * expected number of distinct keys (0 = 2^20; only sizes the partition — a wrong hint costs a retry); max_groups: upper
+ * bound for the result (0 = min(n, 2^26)).  Fails (non-zero, message in vxh_last_error) when the keys are too many
+ * (> ~3.5e6) or too skewed for the LDS-partitioned path: the caller then takes ordered_set + BinnerHash. */
+int vxh_groupby_run(int key_dtype, const void *keys, int n_values, const void *const *values, uint64_t n, int mem,
+                    uint64_t groups_hint, uint64_t max_groups, vxh_groupby **out);
+/* the same aggregation over PARTIAL results (other chunks', other ranks'): host arrays of n partial groups */
+int vxh_groupby_merge(int n_values, const int64_t *keys, const int64_t *rows, const int64_t *const *counts,
+                      const double *const *sums, const double *const *sums2, uint64_t n, uint64_t groups_hint, vxh_groupby **out);
+void vxh_groupby_destroy(vxh_groupby *g);
+/* number of groups */
+uint64_t vxh_groupby_size(const vxh_groupby *g);
+/* one result column (vxh_groupby_column_kind; value_index selects the value column for COUNT..STD) into a host array of
+ * vxh_groupby_size elements of 8 bytes */
+int vxh_groupby_column(vxh_groupby *g, int value_index, int which, void *out_host);
+/* diagnostics: 0 buckets, 1 LDS slots per bucket, 2 retries, 3 / 4 / 5 = ms of the scatter / reduce / sort kernels */
+int vxh_groupby_info(const vxh_groupby *g, int what, double *value_out);
 
 /* ---- profiling helpers ---------------------------------------------------------------- */
 /* HIP events on slot `thread`'s stream: record start/stop around vxh_grid_bin calls, read ms */

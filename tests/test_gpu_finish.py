@@ -1,0 +1,70 @@
+"""-m gpu: the device finishers (vxh_finish) against the numpy vaex runs on the result grids (vaex/agg.py:403-416 mean,
+:440-455 var / std) and the drop of empty groups (vaex/groupby.py:955-972)."""
+import numpy as np
+import pytest
+
+from tests import cases
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(sa, n=400_000, groups=5000, dtype="float64"):
+    rng = np.random.default_rng(12)
+    k = rng.integers(0, groups, n).astype("int64")
+    k[k % 7 == 3] = 1  # leaves plenty of empty groups
+    v = rng.normal(3, 2, n).astype(dtype) if dtype.startswith("float") else rng.integers(-50, 50, n).astype(dtype)
+    if dtype.startswith("float"):
+        v[::97] = np.nan
+    vf = v.astype("f8")
+    case = dict(n=n, binners=[dict(kind="ordinal", data=k, count=groups, min_value=0)],
+                aggs=[dict(kind="sum", data=v), dict(kind="count", data=v), dict(kind="summoment", data=vf, moment=2), dict(kind="sum", data=vf),
+                      dict(kind="count", data=vf), dict(kind="min", data=v), dict(kind="max", data=v), dict(kind="count")])
+    keep = []
+    got = cases.run_superagg(sa, case, keep=keep)
+    return got, keep[:-1], groups
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32", "int32", "uint8"])
+def test_finish_matches_numpy(sa, gpu_ready, dtype):
+    got, aggs, groups = _run(sa, dtype=dtype)
+    s, c, m2, sf, cf, mn, mx, call = [g[:groups] for g in got]
+    a_s, a_c, a_m2, a_sf, a_cf, a_mn, a_mx, a_call = aggs
+    specs = [(sa.FIN_COPY, a_s, None, None), (sa.FIN_COPY, a_c, None, None), (sa.FIN_MEAN, a_s, a_c, None), (sa.FIN_VAR, a_m2, a_sf, a_cf),
+             (sa.FIN_STD, a_m2, a_sf, a_cf), (sa.FIN_COPY, a_mn, None, None), (sa.FIN_COPY, a_mx, None, None)]
+    # every cell
+    cols, index = sa.finish(specs, present=None, first=0, n=groups, want_index=True)
+    np.testing.assert_array_equal(np.asarray(index), np.arange(groups))
+    with np.errstate(divide="ignore", invalid="ignore"):
+        mean = s / c
+        meanf = sf / cf
+        var = m2 / cf - meanf ** 2
+    np.testing.assert_array_equal(np.asarray(cols[0]).astype(s.dtype), s)
+    np.testing.assert_array_equal(np.asarray(cols[1]), c)
+    np.testing.assert_array_equal(np.asarray(cols[2]), mean)          # same IEEE operations: bit-exact (NaN for empty groups)
+    np.testing.assert_array_equal(np.asarray(cols[3]), var)
+    np.testing.assert_array_equal(np.asarray(cols[4]), var ** 0.5)
+    np.testing.assert_array_equal(np.asarray(cols[5]).astype(mn.dtype), mn)
+    np.testing.assert_array_equal(np.asarray(cols[6]).astype(mx.dtype), mx)
+    assert np.asarray(cols[1]).dtype == np.int64 and np.asarray(cols[2]).dtype == np.float64
+    # only the groups that exist, in order
+    cols2, index2 = sa.finish(specs, present=a_call, first=0, n=groups)
+    present = np.nonzero(call > 0)[0]
+    assert 0 < len(present) < groups
+    np.testing.assert_array_equal(np.asarray(index2), present)
+    np.testing.assert_array_equal(np.asarray(cols2[2]), mean[present])
+    np.testing.assert_array_equal(np.asarray(cols2[4]), (var ** 0.5)[present])
+    # a sub-range of the cells
+    cols3, index3 = sa.finish(specs[:3], present=a_call, first=100, n=1000)
+    sub = present[(present >= 100) & (present < 1100)]
+    np.testing.assert_array_equal(np.asarray(index3), sub - 100)
+    np.testing.assert_array_equal(np.asarray(cols3[0]).astype(s.dtype), s[sub])
+
+
+def test_finish_errors(sa, gpu_ready):
+    got, aggs, groups = _run(sa, n=1000, groups=10)
+    with pytest.raises(RuntimeError, match="outside the grid"):
+        sa.finish([(sa.FIN_COPY, aggs[0], None, None)], first=5, n=100)
+    with pytest.raises(RuntimeError, match="count aggregator"):
+        sa.finish([(sa.FIN_COPY, aggs[0], None, None)], present=aggs[0], first=0, n=5)
+    with pytest.raises(RuntimeError, match="missing input"):
+        sa.finish([(sa.FIN_MEAN, aggs[0], None, None)], first=0, n=5)

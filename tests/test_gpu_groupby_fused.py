@@ -1,0 +1,136 @@
+"""-m gpu: the fused hash groupby (vxh_groupby_run: radix partition + LDS-probed aggregation) against numpy in double on
+the same rows — per key: rows, count / sum / sum of squares of the non-NaN values, mean, var, std — bit-exact for keys and
+counts, 1e-12 of sum|v| (sum|v^2|) per group for the float sums; plus the merge of partial results, the edge cases (few
+groups, one row, INT64_MIN as a key, every integer key dtype, two value columns) and the fallbacks."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+_DT = {"float64": 0, "float32": 1, "int64": 2, "int32": 3, "int16": 4, "int8": 5, "uint64": 6, "uint32": 7, "uint16": 8, "uint8": 9, "bool": 10}
+
+
+def _want(keys, cols):
+    uniq, inv = np.unique(keys.astype(np.int64) if keys.dtype != np.uint64 else keys.view(np.int64), return_inverse=True)
+    out = dict(k=uniq, rows=np.bincount(inv, minlength=len(uniq)), v=[])
+    for v in cols:
+        ok = v == v
+        out["v"].append(dict(cnt=np.bincount(inv[ok], minlength=len(uniq)), s=np.bincount(inv[ok], weights=v[ok], minlength=len(uniq)),
+                             s2=np.bincount(inv[ok], weights=v[ok] * v[ok], minlength=len(uniq)), sabs=np.bincount(inv[ok], weights=np.abs(v[ok]), minlength=len(uniq))))
+    return out
+
+
+def _check(sa, res, want):
+    assert len(res) == len(want["k"])
+    np.testing.assert_array_equal(np.asarray(res.column(sa.GB_KEYS)), want["k"])
+    np.testing.assert_array_equal(np.asarray(res.column(sa.GB_ROWS)), want["rows"])
+    for j, w in enumerate(want["v"]):
+        cnt, s, s2 = (np.asarray(res.column(c, j)) for c in (sa.GB_COUNT, sa.GB_SUM, sa.GB_SUM2))
+        np.testing.assert_array_equal(cnt, w["cnt"])
+        assert np.all(np.abs(s - w["s"]) <= 1e-12 * w["sabs"])
+        assert np.all(np.abs(s2 - w["s2"]) <= 1e-12 * w["s2"])
+        with np.errstate(divide="ignore", invalid="ignore"):
+            mean = s / cnt
+            var = s2 / cnt - mean ** 2
+        # the derived columns are the SAME IEEE operations on the device's own sums: bit-exact against numpy on them
+        np.testing.assert_array_equal(np.asarray(res.column(sa.GB_MEAN, j)), mean)
+        np.testing.assert_array_equal(np.asarray(res.column(sa.GB_VAR, j)), var)
+        np.testing.assert_array_equal(np.asarray(res.column(sa.GB_STD, j)), var ** 0.5)
+
+
+@pytest.mark.parametrize("n,groups", [(1, 1), (1000, 7), (300_000, 5_000), (3_000_000, 1_000_000), (2_000_000, 1_900_000)])
+def test_groupby_run_host_rows(sa, gpu_ready, n, groups):
+    rng = np.random.default_rng(n + groups)
+    k = (rng.integers(0, groups, n) * 2654435761) % (1 << 40) - (1 << 39)
+    v = rng.normal(3, 2, n)
+    v[rng.random(n) < 0.01] = np.nan
+    res = sa.groupby_run(k, [v], _DT["int64"])
+    _check(sa, res, _want(k, [v]))
+    info = res.info()
+    assert info["buckets"] >= 64 and info["slots"] in (2048, 4096)
+
+
+def test_groupby_run_device_rows_two_values(sa, gpu_ready):
+    import torch
+    g = torch.Generator(device="cuda").manual_seed(3)
+    n = 20_000_000
+    k = torch.randint(0, 400_000, (n,), dtype=torch.int64, device="cuda", generator=g) * 7919 - 10**9
+    v = torch.randn(n, dtype=torch.float64, device="cuda", generator=g) * 2 + 3
+    w = torch.randn(n, dtype=torch.float64, device="cuda", generator=g)
+    w[::1000] = float("nan")
+    res = sa.groupby_run(k, [v, w], _DT["int64"])  # (no synchronize: the library orders itself after the default stream)
+    _check(sa, res, _want(k.cpu().numpy(), [v.cpu().numpy(), w.cpu().numpy()]))
+    assert res.info()["slots"] == 2048
+
+
+@pytest.mark.parametrize("dtype", ["int64", "int32", "int16", "int8", "uint64", "uint32", "uint16", "uint8", "bool"])
+def test_groupby_run_key_dtypes(sa, gpu_ready, dtype):
+    rng = np.random.default_rng(5)
+    n = 100_000
+    if dtype == "bool":
+        k = rng.random(n) < 0.3
+    else:
+        info = np.iinfo(dtype)
+        k = rng.integers(max(info.min, -3000), min(info.max, 3000), n).astype(dtype)
+    v = rng.normal(0, 1, n)
+    res = sa.groupby_run(k, [v], _DT[dtype])
+    kk = k.astype(np.int64) if dtype != "uint64" else k.astype(np.int64)
+    _check(sa, res, _want(kk, [v]))
+
+
+def test_groupby_run_int64_min_key_and_empty(sa, gpu_ready):
+    lo = np.iinfo(np.int64).min
+    k = np.array([5, lo, 7, lo, 5, np.iinfo(np.int64).max, lo], dtype=np.int64)
+    v = np.array([1.0, 2.0, np.nan, 4.0, 5.0, 6.0, np.nan])
+    res = sa.groupby_run(k, [v], _DT["int64"])
+    _check(sa, res, _want(k, [v]))
+    assert np.asarray(res.column(sa.GB_KEYS))[0] == lo
+    empty = sa.groupby_run(np.array([], dtype=np.int64), [np.array([], dtype=np.float64)], _DT["int64"])
+    assert len(empty) == 0 and len(np.asarray(empty.column(sa.GB_KEYS))) == 0
+    with pytest.raises(RuntimeError, match="float64 value columns"):
+        sa.groupby_run(k, [v.astype("f4")], _DT["int64"])
+    with pytest.raises(RuntimeError, match="integer key"):
+        sa.groupby_run(v, [v], _DT["float64"])
+
+
+def test_groupby_merge_partials(sa, gpu_ready):
+    rng = np.random.default_rng(9)
+    n = 1_500_000
+    k = rng.integers(-200_000, 200_000, n) * 3
+    v = rng.normal(1, 3, n)
+    parts = [sa.groupby_run(k[i::3].copy(), [v[i::3].copy()], _DT["int64"]) for i in range(3)]
+    cat = lambda c, j=0: np.concatenate([np.asarray(p.column(c, j)) for p in parts])
+    merged = sa.groupby_merge(cat(sa.GB_KEYS), cat(sa.GB_ROWS), [cat(sa.GB_COUNT)], [cat(sa.GB_SUM)], [cat(sa.GB_SUM2)])
+    _check(sa, merged, _want(k, [v]))
+
+
+def test_frame_groupby_takes_the_fused_path_and_falls_back(sa, gpu_ready):
+    import torch
+    from vaex_amd.binned import Frame, agg
+    g = torch.Generator(device="cuda").manual_seed(4)
+    n = 6_000_000
+    k = (torch.randint(0, 300_000, (n,), dtype=torch.int64, device="cuda", generator=g) * 2654435761) % (1 << 40)
+    v = torch.randn(n, dtype=torch.float64, device="cuda", generator=g) * 2 + 3
+    v[::999] = float("nan")
+    spec = {"n": agg.count(), "c": agg.count("v"), "s": agg.sum("v"), "m": agg.mean("v"), "sd": agg.std("v")}
+    df = Frame(dict(k=k, v=v))
+    got = df.groupby("k", spec)
+    assert df.last_groupby_info["buckets"] >= 64  # the fused path ran
+    w = _want(k.cpu().numpy(), [v.cpu().numpy()])
+    np.testing.assert_array_equal(got["k"], w["k"])
+    np.testing.assert_array_equal(got["n"], w["rows"])
+    np.testing.assert_array_equal(got["c"], w["v"][0]["cnt"])
+    assert np.all(np.abs(got["s"] - w["v"][0]["s"]) <= 1e-12 * w["v"][0]["sabs"])
+    # a heavy hitter (half of the rows on one key): too skewed for the partitioned pass -> ordered_set + BinnerHash, same answer
+    k2 = k.clone()
+    k2[::2] = 12345678901
+    df2 = Frame(dict(k=k2, v=v))
+    df2.last_groupby_info = None
+    got2 = df2.groupby("k", spec)
+    w2 = _want(k2.cpu().numpy(), [v.cpu().numpy()])
+    np.testing.assert_array_equal(got2["k"], w2["k"])
+    np.testing.assert_array_equal(got2["c"], w2["v"][0]["cnt"])
+    assert np.all(np.abs(got2["s"] - w2["v"][0]["s"]) <= 1e-12 * w2["v"][0]["sabs"])
+    # min / max are outside the fused signature
+    got3 = df.groupby("k", {"lo": agg.min("v"), "s": agg.sum("v")})
+    np.testing.assert_array_equal(got3["k"], w["k"])

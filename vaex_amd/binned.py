@@ -86,6 +86,15 @@ class agg:
                 return [_Prim("summoment", c, s, 2, True), _Prim("sum", c, s, 0, True), _Prim("count", c, s, 0, True)]
             raise ValueError(n)
 
+        def finish_spec(self, sa, aggs):
+            """the same finish as a (op, agg0, agg1, agg2) tuple for the device finishers (superagg.finish)"""
+            n = self.name
+            if n in ("count", "sum", "min", "max"):
+                return (sa.FIN_COPY, aggs[0], None, None)
+            if n == "mean":
+                return (sa.FIN_MEAN, aggs[0], aggs[1], None)
+            return (sa.FIN_VAR if n == "var" else sa.FIN_STD, aggs[0], aggs[1], aggs[2])
+
         def finish(self, parts):
             n = self.name
             if n in ("count", "sum", "min", "max"):
@@ -298,9 +307,9 @@ class Frame:
                     list(pool.map(work, range(0, n, self.chunk_size)))
         return grid, aggs
 
-    def _agg(self, descs, binby=None, limits=None, shape=128, edges=False, reduce=None):
-        """Evaluate a list of descriptors in ONE pass; returns one ndarray per descriptor.  reduce: optional
-        callable(list of aggregator objects) run before the results are read (multi-GPU all-reduce hook)."""
+    def _pass(self, descs, binby=None, limits=None, shape=128, reduce=None):
+        """descriptors -> distinct primitive aggregations -> ONE fused pass (+ the cross-rank reduce); returns
+        (binner specs, grid, aggregator objects, per descriptor the indices of its primitives)"""
         specs = self._binner_specs(binby, limits, shape)
         prims, index = [], {}
         want = []
@@ -318,6 +327,12 @@ class Frame:
             reduce = self.comm.allreduce
         if reduce is not None:
             reduce(aggs)
+        return specs, grid, aggs, want
+
+    def _agg(self, descs, binby=None, limits=None, shape=128, edges=False, reduce=None):
+        """Evaluate a list of descriptors in ONE pass; returns one ndarray per descriptor.  reduce: optional
+        callable(list of aggregator objects) run before the results are read (multi-GPU all-reduce hook)."""
+        specs, grid, aggs, want = self._pass(descs, binby, limits, shape, reduce)
         raw = [np.asarray(a.get_result()) for a in aggs]  # (get_result already returns a fresh array)
         if not edges:  # vaex/agg.py:323-335
             sl = tuple(slice(2, -1) if s["kind"] == "scalar" else slice(0, -2) for s in specs)
@@ -349,6 +364,21 @@ class Frame:
 
     def max(self, expression, binby=None, limits=None, shape=128, selection=None, edges=False):
         return self._one("max", expression, binby, limits, shape, selection, edges)
+
+    def _result_dtype(self, desc):
+        """dtype of a descriptor's result column as the reference returns it (vaex/agg.py: count int64, sum upcast,
+        min/max the input's type, mean/var/std float64)"""
+        n = desc.name
+        if n == "count":
+            return np.dtype("int64")
+        if n in ("mean", "var", "std"):
+            return np.dtype("float64")
+        c = self.columns[desc.column]
+        name = str(c.dtype).replace("torch.", "")
+        dt = np.dtype("bool" if name == "bool" else name)
+        if n == "sum":
+            return np.dtype("float64") if dt.kind == "f" else (np.dtype("uint64") if dt.kind == "u" else np.dtype("int64"))
+        return dt.newbyteorder("=")
 
     # ------------------------------------------------------------------ groupby
     # ------------------------------------------------------------------ limits from the data (SURVEY §8 f.1)
@@ -479,11 +509,26 @@ class Frame:
             # the key column bins itself (BinnerOrdinal with min_value): ONE pass, no hash map.  This is the
             # reference's dense-key simplification; for sparse keys in a small range it gives the same result
             # (empty cells are dropped below) without pass 1.
-            res = self._agg(descs + [agg.count()], binby=[dict(column=by, count=count, min_value=kmin)], edges=True, reduce=reduce)
+            binby = [dict(column=by, count=count, min_value=kmin)]
+            if hasattr(sa, "finish"):
+                # finishers + the drop of empty groups on the device: only the finished columns of the groups that exist
+                # cross PCIe (vaex does this part with numpy on the full grids: vaex/agg.py:403-455, vaex/groupby.py:955-972)
+                specs, grid, aggs, want = self._pass(descs + [agg.count()], binby, reduce=reduce)
+                fin = [d.finish_spec(sa, [aggs[i] for i in ids]) for d, ids in zip(descs, want[:-1])]
+                cols, index = sa.finish(fin, present=aggs[want[-1][0]], first=0, n=count, want_index=True)
+                out_keys = np.asarray(index) + kmin
+                vals = [np.asarray(c).astype(self._result_dtype(d), copy=False) for c, d in zip(cols, descs)]
+                return {by: out_keys, **dict(zip(names, vals))}
+            res = self._agg(descs + [agg.count()], binby=binby, edges=True, reduce=reduce)
             present = res[-1][:count] > 0
             out_keys = (np.arange(count, dtype=np.int64) + kmin)[present]
             vals = [r[:count][present] for r in res[:-1]]
             return {by: out_keys, **dict(zip(names, vals))}
+        # scattered keys, plain count / sum / mean / var / std of float64 columns: ONE radix-partitioned pass with the hash
+        # table probed in LDS (vxh_groupby_run) instead of the reference's two passes over a global table
+        fused = self._groupby_fused(by, pf, descs, names, comm)
+        if fused is not None:
+            return fused
         # pass 1: distinct keys on the GPU (ordered_set.update), united over ranks, sorted -> sealed map whose
         # ordinals are the rank of the key in ascending order (ordered_set::create): identical on every rank
         hm = getattr(sa, "ordered_set_" + pf)()
@@ -501,11 +546,68 @@ class Frame:
             return {by: out_keys, **{n: np.array([]) for n in names}}
         sealed = getattr(sa, "ordered_set_" + pf)(nuniq)
         sealed.set_keys(out_keys.astype(np.int64))
-        res = self._agg_hash(descs, by, pf, sealed, reduce)
-        vals = [r[1:1 + nuniq] for r in res]
+        res = self._agg_hash(descs, by, pf, sealed, reduce, nuniq)
+        vals = [r[1:1 + nuniq] for r in res] if res[0].shape[0] != nuniq else res
         return {by: out_keys, **dict(zip(names, vals))}
 
-    def _agg_hash(self, descs, by, pf, hm, reduce):
+    def _groupby_fused(self, by, pf, descs, names, comm):
+        """the vxh_groupby_run path, or None when the call is outside its signature (then: ordered_set + BinnerHash)"""
+        sa = self.sa
+        if not hasattr(sa, "groupby_run") or self.n == 0 and comm is None:
+            return None
+        key = self.columns[by]
+        vcols = []
+        for d in descs:
+            if d.name not in ("count", "sum", "mean", "var", "std") or d.selection is not None:
+                return None
+            if d.column is not None and d.column not in vcols:
+                vcols.append(d.column)
+        if len(vcols) > 2:
+            return None
+        values = []
+        for c in vcols:
+            col = self.columns[c]
+            if np.ma.isMaskedArray(col) or str(col.dtype).replace("torch.", "") != "float64" or _is_device(col) != _is_device(key):
+                return None
+            values.append(col if _is_device(col) else np.ascontiguousarray(col))
+        if not values:  # only count(*): the pass still needs a payload column; let the general path do it
+            return None
+        try:
+            res = sa.groupby_run(key if _is_device(key) else np.ascontiguousarray(key), values, _DT_CODE[pf]) if self.n else None
+            if comm is not None:
+                res = self._groupby_fused_allranks(res, len(values), comm)
+        except RuntimeError as e:
+            if "partitioned path" not in str(e):
+                raise
+            return None  # too many / too skewed keys for the LDS-partitioned pass
+        which = {"sum": sa.GB_SUM, "mean": sa.GB_MEAN, "var": sa.GB_VAR, "std": sa.GB_STD}
+        out = {by: np.asarray(res.column(sa.GB_KEYS))}
+        for name, d in zip(names, descs):
+            if d.name == "count":
+                out[name] = np.asarray(res.column(sa.GB_ROWS) if d.column is None else res.column(sa.GB_COUNT, vcols.index(d.column)))
+            else:
+                out[name] = np.asarray(res.column(which[d.name], vcols.index(d.column)))
+        self.last_groupby_info = res.info()
+        return out
+
+    def _groupby_fused_allranks(self, res, nv, comm):
+        """every rank's partial groups -> the groups of all ranks' rows (the same kernels in MERGE mode)"""
+        import torch.distributed as dist
+        sa = self.sa
+        if not dist.is_initialized() or dist.get_world_size(comm.group) == 1:
+            return res
+        mine = None
+        if res is not None:
+            mine = dict(k=np.array(res.column(sa.GB_KEYS)), r=np.array(res.column(sa.GB_ROWS)), c=[np.array(res.column(sa.GB_COUNT, j)) for j in range(nv)],
+                        s=[np.array(res.column(sa.GB_SUM, j)) for j in range(nv)], s2=[np.array(res.column(sa.GB_SUM2, j)) for j in range(nv)])
+        parts = [None] * dist.get_world_size(comm.group)
+        dist.all_gather_object(parts, mine, group=comm.group)
+        parts = [p for p in parts if p is not None]
+        cat = lambda f: np.concatenate([f(p) for p in parts])
+        return sa.groupby_merge(cat(lambda p: p["k"]), cat(lambda p: p["r"]), [cat(lambda p, j=j: p["c"][j]) for j in range(nv)],
+                                [cat(lambda p, j=j: p["s"][j]) for j in range(nv)], [cat(lambda p, j=j: p["s2"][j]) for j in range(nv)])
+
+    def _agg_hash(self, descs, by, pf, hm, reduce, nuniq=None):
         """Same fused pass with a BinnerHash on the key column (cells: [unknown, ordinal 0..N-1, null])."""
         sa = self.sa
         prims, index, want = [], {}, []
@@ -550,6 +652,10 @@ class Frame:
             slot = (slot + 1) % slots
         if reduce is not None:
             reduce(aggs)
+        if hasattr(sa, "finish") and nuniq is not None:  # cells [unknown, ordinal 0..N-1, null]: finish the N group cells on the device
+            fin = [d.finish_spec(sa, [aggs[i] for i in ids]) for d, ids in zip(descs, want)]
+            cols, _ = sa.finish(fin, present=None, first=1, n=nuniq, want_index=False)
+            return [np.asarray(c).astype(self._result_dtype(d), copy=False) for c, d in zip(cols, descs)]
         raw = [np.asarray(a.get_result()) for a in aggs]  # (get_result already returns a fresh array)
         return [d.finish([raw[i] for i in ids]) for d, ids in zip(descs, want)]
 

@@ -17,6 +17,7 @@
 #include <pybind11/pybind11.h>
 #include <pybind11/stl.h>
 
+#include <algorithm>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -142,6 +143,46 @@ struct PyHashMap {
 template <int DT>
 struct THashMap : PyHashMap {
     explicit THashMap(uint64_t hint) : PyHashMap(DT, hint) {}
+};
+
+// ------------------------------------------------------------------------------------------
+// hash groupby in one partitioned pass (vxh_groupby_*)
+// ------------------------------------------------------------------------------------------
+py::array pinned_array(uint64_t elems, const std::string &fmt) { // 8-byte elements in page-locked memory owned by the array
+    void *p = nullptr;
+    check(vxh_host_alloc((size_t)std::max<uint64_t>(elems, 1) * 8, &p));
+    py::capsule owner(p, [](void *q) { vxh_host_free(q); });
+    return py::array(py::dtype(fmt), std::vector<ssize_t>{(ssize_t)elems}, std::vector<ssize_t>{8}, p, owner);
+}
+
+struct PyGroupBy {
+    vxh_groupby *h = nullptr;
+    int nv = 1;
+    ~PyGroupBy() { vxh_groupby_destroy(h); }
+    PyGroupBy() = default;
+    PyGroupBy(const PyGroupBy &) = delete;
+    uint64_t size() const { return vxh_groupby_size(h); }
+    py::array column(int which, int value_index) {
+        const bool integer = which == VXH_GB_KEYS || which == VXH_GB_ROWS || which == VXH_GB_COUNT;
+        py::array out = pinned_array(size(), integer ? "q" : "d");
+        int rc;
+        {
+            py::gil_scoped_release release;
+            rc = vxh_groupby_column(h, value_index, which, out.mutable_data());
+        }
+        check(rc);
+        return out;
+    }
+    py::dict info() const {
+        static const char *names[] = {"buckets", "slots", "retries", "ms_scatter", "ms_reduce", "ms_sort"};
+        py::dict d;
+        for (int i = 0; i < 6; i++) {
+            double v = 0;
+            check(vxh_groupby_info(h, i, &v));
+            d[names[i]] = v;
+        }
+        return d;
+    }
 };
 
 // ------------------------------------------------------------------------------------------
@@ -451,6 +492,123 @@ PYBIND11_MODULE(superagg, m) {
         check(rc);
         return py::make_tuple(out[0], out[1]);
     }, py::arg("data"), py::arg("mask") = py::none(), py::arg("dtype") = 2, py::arg("flip") = false);
+
+    // finishers on the device: finish([(op, agg0, agg1 | None, agg2 | None), ...], present=None, first=0, n=None)
+    // -> (list of 1-d ndarrays in pinned host memory, index ndarray | None)
+    m.def("finish", [](const std::vector<py::tuple> &specs, const py::object &present, uint64_t first, const py::object &n_obj, bool want_index) {
+        const int n_out = (int)specs.size();
+        if (n_out < 1) throw std::runtime_error("finish: no result columns");
+        std::vector<int> ops(n_out);
+        std::vector<vxh_agg *> a0(n_out, nullptr), a1(n_out, nullptr), a2(n_out, nullptr);
+        std::vector<std::string> fmt(n_out);
+        for (int j = 0; j < n_out; j++) {
+            const py::tuple &t = specs[j];
+            if (t.size() < 2) throw std::runtime_error("finish: (op, agg0[, agg1[, agg2]]) expected");
+            ops[j] = t[0].cast<int>();
+            a0[j] = t[1].cast<PyAgg &>().h;
+            if (t.size() > 2 && !t[2].is_none()) a1[j] = t[2].cast<PyAgg &>().h;
+            if (t.size() > 3 && !t[3].is_none()) a2[j] = t[3].cast<PyAgg &>().h;
+            fmt[j] = "d";
+            if (ops[j] == VXH_FIN_COPY) {
+                const int gdt = vxh_agg_grid_dtype(a0[j]);
+                fmt[j] = (gdt == VXH_F64 || gdt == VXH_F32) ? "d" : ((gdt == VXH_I64 || gdt == VXH_I32 || gdt == VXH_I16 || gdt == VXH_I8) ? "q" : "Q");
+            }
+        }
+        PyAgg &first_agg = specs[0][1].cast<PyAgg &>();
+        const uint64_t cells = vxh_grid_length1d(first_agg.grid->h);
+        const uint64_t n = n_obj.is_none() ? cells - first : n_obj.cast<uint64_t>();
+        vxh_agg *pres = present.is_none() ? nullptr : present.cast<PyAgg &>().h;
+        // result columns live in pinned host memory owned by the arrays (freed with them)
+        auto pinned = [](uint64_t elems, const std::string &f) { return pinned_array(elems, f); };
+        std::vector<py::array> cols;
+        std::vector<void *> outs(n_out);
+        for (int j = 0; j < n_out; j++) {
+            cols.push_back(pinned(n, fmt[j]));
+            outs[j] = cols.back().mutable_data();
+        }
+        py::object index = py::none();
+        int64_t *index_ptr = nullptr;
+        if (want_index) {
+            py::array ia = pinned(n, "q");
+            index_ptr = (int64_t *)ia.mutable_data();
+            index = ia;
+        }
+        uint64_t kept = 0;
+        int rc;
+        {
+            py::gil_scoped_release release;
+            rc = vxh_finish(n_out, ops.data(), a0.data(), a1.data(), a2.data(), pres, first, n, outs.data(), index_ptr, &kept);
+        }
+        check(rc);
+        py::list out;
+        py::slice sl(0, (ssize_t)kept, 1);
+        for (auto &c : cols) out.append(c[sl]);
+        if (want_index) index = index[sl];
+        return py::make_tuple(out, index);
+    }, py::arg("specs"), py::arg("present") = py::none(), py::arg("first") = 0, py::arg("n") = py::none(), py::arg("want_index") = true);
+    m.attr("FIN_COPY") = (int)VXH_FIN_COPY;
+    m.attr("FIN_MEAN") = (int)VXH_FIN_MEAN;
+    m.attr("FIN_VAR") = (int)VXH_FIN_VAR;
+    m.attr("FIN_STD") = (int)VXH_FIN_STD;
+
+    py::class_<PyGroupBy>(m, "GroupByResult")
+        .def("__len__", &PyGroupBy::size)
+        .def("column", &PyGroupBy::column, py::arg("which"), py::arg("value_index") = 0)
+        .def("info", &PyGroupBy::info);
+    m.attr("GB_KEYS") = (int)VXH_GB_KEYS;
+    m.attr("GB_ROWS") = (int)VXH_GB_ROWS;
+    m.attr("GB_COUNT") = (int)VXH_GB_COUNT;
+    m.attr("GB_SUM") = (int)VXH_GB_SUM;
+    m.attr("GB_SUM2") = (int)VXH_GB_SUM2;
+    m.attr("GB_MEAN") = (int)VXH_GB_MEAN;
+    m.attr("GB_VAR") = (int)VXH_GB_VAR;
+    m.attr("GB_STD") = (int)VXH_GB_STD;
+    // groupby_run(keys, [v0, v1], key_dtype, groups_hint=0, max_groups=0): keys any integer array (host or device), values
+    // float64 arrays living where the keys live
+    m.def("groupby_run", [](const py::object &keys, const std::vector<py::object> &values, int key_dtype, uint64_t hint, uint64_t max_groups) {
+        ArrayRef k = resolve_array(keys);
+        if (key_dtype < 0 || key_dtype >= VXH_DTYPE_COUNT || k.itemsize != kTypeSizes[key_dtype]) throw std::runtime_error("Itemsize of the keys and key dtype are not equal");
+        std::vector<const void *> vp;
+        for (const auto &v : values) {
+            ArrayRef a = resolve_array(v);
+            if (a.itemsize != 8) throw std::runtime_error("groupby: float64 value columns only");
+            if (a.mem != k.mem || a.n < k.n) throw std::runtime_error("groupby: value columns must live where the keys live and be as long");
+            vp.push_back(a.ptr);
+        }
+        auto res = std::make_unique<PyGroupBy>();
+        res->nv = (int)vp.size();
+        int rc;
+        {
+            py::gil_scoped_release release;
+            rc = vxh_groupby_run(key_dtype, k.ptr, (int)vp.size(), vp.data(), k.n, k.mem, hint, max_groups, &res->h);
+        }
+        check(rc);
+        return res;
+    }, py::arg("keys"), py::arg("values"), py::arg("key_dtype") = (int)VXH_I64, py::arg("groups_hint") = 0, py::arg("max_groups") = 0);
+    // groupby_merge(keys, rows, [count_j], [sum_j], [sum2_j]): partial results (host arrays) -> one result
+    m.def("groupby_merge", [](py::array_t<int64_t, py::array::c_style | py::array::forcecast> keys, py::array_t<int64_t, py::array::c_style | py::array::forcecast> rows,
+                              const std::vector<py::array_t<int64_t, py::array::c_style | py::array::forcecast>> &counts,
+                              const std::vector<py::array_t<double, py::array::c_style | py::array::forcecast>> &sums,
+                              const std::vector<py::array_t<double, py::array::c_style | py::array::forcecast>> &sums2, uint64_t hint) {
+        const uint64_t n = (uint64_t)keys.size();
+        const size_t nv = counts.size();
+        if (nv < 1 || sums.size() != nv || sums2.size() != nv || (uint64_t)rows.size() != n) throw std::runtime_error("groupby_merge: inconsistent arguments");
+        std::vector<const int64_t *> cp;
+        std::vector<const double *> sp, s2p;
+        for (size_t v = 0; v < nv; v++) {
+            if ((uint64_t)counts[v].size() != n || (uint64_t)sums[v].size() != n || (uint64_t)sums2[v].size() != n) throw std::runtime_error("groupby_merge: columns differ in length");
+            cp.push_back(counts[v].data()); sp.push_back(sums[v].data()); s2p.push_back(sums2[v].data());
+        }
+        auto res = std::make_unique<PyGroupBy>();
+        res->nv = (int)nv;
+        int rc;
+        {
+            py::gil_scoped_release release;
+            rc = vxh_groupby_merge((int)nv, keys.data(), rows.data(), cp.data(), sp.data(), s2p.data(), n, hint, &res->h);
+        }
+        check(rc);
+        return res;
+    }, py::arg("keys"), py::arg("rows"), py::arg("counts"), py::arg("sums"), py::arg("sums2"), py::arg("groups_hint") = 0);
 
     py::class_<PyAgg> aggregator(m, "Aggregator", py::buffer_protocol());
     aggregator.def("merge", &PyAgg::merge)

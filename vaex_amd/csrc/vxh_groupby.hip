@@ -1,0 +1,720 @@
+// K7 — hash groupby in one partitioned pass: df.groupby(<integer key>).agg({v: [count, sum, mean, var, std]}).
+//
+// vaex does this in two passes over the rows: pass 1 collects the distinct keys in an ordered_set (vaex/hash.py:152-171,
+// src/hash_primitives.hpp:98-295), pass 2 maps every key to its ordinal (map_ordinal :611-691 — one random probe of a
+// table of all keys per row) and bins the ordinals (BinnerOrdinal + AggCount / AggSum / AggSumMoment, vaex/cpu.py:678-786).
+// On the GPU a table of 1e6 keys lives in Infinity Cache / HBM and a probe per row costs a random 64-byte sector: the
+// round-1 path ran at 0.02-0.05 of the HBM roofline (profiles/r01_configs.txt).  This file restates the same result —
+// per key: rows, and per value column count / sum / sum of squares of the non-NaN values — as a radix-partitioned
+// aggregation whose hash table is probed in LDS:
+//
+//   gb_scatter   rows -> NB buckets by the TOP bits of splitmix64(key) (the reference's hash finaliser, src/hash.hpp:40-45).
+//                One 1024-thread workgroup per CU bucket-sorts 1024*R-row tiles in LDS (returning ds_add = position
+//                in bucket, workgroup scan = bucket offsets) and appends each bucket's segment to a block of the
+//                bucket's queue that only this workgroup writes to (contiguous appends: the L2 merges them into whole
+//                lines).  Blocks of `blk` records are reserved from the bucket's counter by the thread that owns the
+//                bucket (thread b <-> bucket b), normally ONE per launch; their fill goes to a table.  Records are
+//                SoA: key + W payload words (W = 1 per value column for rows; 4 for partial results being merged).
+//   gb_reduce    one workgroup per bucket: insert-or-get in an open-addressing table IN LDS (64-bit ds_cmpst on the key
+//                word, linear probing from lower hash bits), accumulators (rows, count, sum, sum of squares) next to
+//                the key in LDS (ds_add_u32 / ds_add_f64), every wave streaming whole queue blocks.  At the end the
+//                occupied slots are compacted (workgroup scan) into the result arrays behind ONE atomic per bucket.
+//   sort         rocPRIM radix sort of (key, position) + a gather: groups ascending by key, as vaex returns them.
+//
+// HBM traffic per row with one value column: 16 B read + 16 B written + 16 B read = 48 B (the two-pass scheme with a
+// global table: 8 + 16 B of streams plus two random probes).  No ordinals, no global table, no host in the loop.
+// Partial results (multi-chunk inputs, other ranks' results) are merged by the same two kernels in MERGE mode.
+#include "vxh_internal.hpp"
+
+#include <string.h> // (rocPRIM's texture_cache_iterator.hpp calls memset without including it)
+
+#include <rocprim/rocprim.hpp>
+
+#include <algorithm>
+#include <cstring>
+#include <memory>
+#include <stdexcept>
+#include <type_traits>
+#include <vector>
+
+namespace {
+
+constexpr long long GB_EMPTY = (long long)0x8000000000000000ull; // never stored as a key: the key INT64_MIN has its own slot
+constexpr int GB_MAX_NV = 2;
+constexpr int GB_MAX_W = 1 + 3 * GB_MAX_NV; // MERGE payload: rows, then (count, sum, sum2) per value column
+
+__device__ __forceinline__ uint64_t gb_mix(uint64_t x) { // splitmix64 finaliser (src/hash.hpp:40-45)
+    x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ULL;
+    x ^= x >> 27; x *= 0x94d049bb133111ebULL;
+    x ^= x >> 31;
+    return x;
+}
+
+__device__ __forceinline__ long long gb_load_key(const void *p, uint64_t i, int dt) {
+    switch (dt) {
+    case VXH_I64: case VXH_U64: return ((const long long *)p)[i];
+    case VXH_I32: return ((const int32_t *)p)[i];
+    case VXH_U32: return ((const uint32_t *)p)[i];
+    case VXH_I16: return ((const int16_t *)p)[i];
+    case VXH_U16: return ((const uint16_t *)p)[i];
+    case VXH_I8: return ((const int8_t *)p)[i];
+    case VXH_U8: return ((const uint8_t *)p)[i];
+    default: return ((const uint8_t *)p)[i] ? 1 : 0;
+    }
+}
+
+struct GbArgs {
+    // input rows
+    const void *keys;
+    int32_t key_dtype, nv, w, merge; // w payload words per record; merge: payload = partial results (rows, count, sum, sum2 ...)
+    const uint64_t *payload[GB_MAX_W]; // RAW: the value columns (float64 bits); MERGE: rows, count_0, sum_0, sum2_0, ...
+    uint64_t n;
+    // buckets
+    int32_t nb_log2, slots_log2;
+    uint32_t blk;        // records per queue block
+    uint32_t tab_stride; // table entries per bucket
+    uint64_t cap;        // records per bucket queue
+    unsigned long long *qcount; // [NB] records reserved
+    uint32_t *tab;              // [NB][tab_stride] records each block really holds
+    long long *qkey;            // [NB][cap]
+    uint64_t *qw[GB_MAX_W];     // [NB][cap] each
+    // results (unsorted)
+    unsigned long long *out_count; // groups written so far
+    unsigned int *overflow;        // a bucket's table got too full / a bucket's queue ran out of room
+    uint64_t out_cap;
+    long long *out_key;
+    uint64_t *out_w[GB_MAX_W]; // rows (int64), then per value column: count (int64), sum (f64), sum2 (f64)
+};
+
+// ------------------------------------------------------------------------------------------------------------------
+// gb_scatter
+// ------------------------------------------------------------------------------------------------------------------
+template <int W, int R>
+__global__ void __launch_bounds__(1024) gb_scatter(const GbArgs G) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    constexpr uint32_t T = 1024u * R;
+    const uint32_t NB = 1u << G.nb_log2; // <= 1024: thread b owns bucket b
+    uint64_t *const st_key = (uint64_t *)lds;
+    uint64_t *const st_w = st_key + T; // [W][T]
+    uint32_t *const cnt = (uint32_t *)(st_w + (size_t)W * T);
+    uint32_t *const off = cnt + NB;
+    uint32_t *const base0 = off + NB;
+    uint32_t *const base1 = base0 + NB;
+    uint32_t *const split = base1 + NB;
+    uint32_t *const s_wave = split + NB; // [16]
+    uint16_t *const st_b = (uint16_t *)(s_wave + 16);
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint64_t n = G.n;
+    if (tid < NB) cnt[tid] = 0u;
+    // thread b: the range of bucket b's queue this workgroup appends to: [cur, end), allocated from `start`
+    uint32_t start = 0, cur = 0, end = 0;
+    bool dead = false; // the bucket's queue is full: records are dropped and the overflow flag raised (the host retries)
+    const uint32_t B = G.blk;
+    auto close_range = [&]() { // fills of the blocks of [start, end)
+        for (uint32_t b0 = start; b0 < end; b0 += B) {
+            const uint32_t fill = cur <= b0 ? 0u : (cur - b0 < B ? cur - b0 : B);
+            G.tab[(size_t)tid * G.tab_stride + b0 / B] = fill;
+        }
+    };
+    auto open_range = [&](uint32_t need) { // room for `need` more records (whole blocks, contiguous)
+        const uint32_t nblk = (need + B - 1) / B;
+        const unsigned long long b = atomicAdd(&G.qcount[tid], (unsigned long long)nblk * B);
+        if (b + (unsigned long long)nblk * B > G.cap) {
+            atomicExch(G.overflow, 1u);
+            dead = true;
+            start = cur = end = 0;
+        } else {
+            start = cur = (uint32_t)b;
+            end = start + nblk * B;
+        }
+    };
+    __syncthreads();
+
+    for (uint64_t tile = blockIdx.x; tile * T < n; tile += gridDim.x) {
+        // [A] rows of the tile, bucket of every row, position inside the bucket
+        long long key[R];
+        uint64_t pay[W][R];
+        uint32_t bucket[R], pos[R];
+        bool ok[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const uint64_t i = tile * T + (uint64_t)r * 1024u + tid;
+            ok[r] = i < n;
+            const uint64_t ic = ok[r] ? i : n - 1;
+            key[r] = gb_load_key(G.keys, ic, G.key_dtype);
+#pragma unroll
+            for (int w = 0; w < W; ++w) pay[w][r] = G.payload[w][ic];
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            bucket[r] = (uint32_t)(gb_mix((uint64_t)key[r]) >> (64 - G.nb_log2));
+            pos[r] = 0;
+            if (ok[r]) pos[r] = __hip_atomic_fetch_add(&cnt[bucket[r]], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        __syncthreads();
+        // [B] thread b: where bucket b's records of this tile go; exclusive scan of the bucket counts
+        uint32_t c = 0;
+        if (tid < NB) {
+            c = cnt[tid];
+            cnt[tid] = 0u;
+            uint32_t a0 = cur, a1 = 0, sp = c;
+            if (dead) {
+                a0 = a1 = 0xffffffffu;
+            } else if (c <= end - cur) {
+                cur += c;
+            } else {
+                sp = end - cur;
+                cur = end;
+                close_range();
+                open_range(c - sp);
+                if (dead) {
+                    a1 = 0xffffffffu;
+                } else {
+                    a1 = cur;
+                    cur += c - sp;
+                }
+            }
+            base0[tid] = a0;
+            base1[tid] = a1;
+            split[tid] = sp;
+        }
+        uint32_t inc = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t t = (uint32_t)__shfl_up((int)inc, o, 64);
+            if ((int)lane >= o) inc += t;
+        }
+        if (lane == 63) s_wave[wave] = inc;
+        __syncthreads();
+        {
+            uint32_t before = 0;
+            for (uint32_t w2 = 0; w2 < wave; ++w2) before += s_wave[w2];
+            if (tid < NB) off[tid] = before + inc - c;
+        }
+        uint32_t total = 0;
+        for (uint32_t w2 = 0; w2 < 16; ++w2) total += s_wave[w2];
+        __syncthreads();
+        // [C] stage sorted by bucket
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            if (ok[r]) {
+                const uint32_t j = off[bucket[r]] + pos[r];
+                st_key[j] = (uint64_t)key[r];
+#pragma unroll
+                for (int w = 0; w < W; ++w) st_w[(size_t)w * T + j] = pay[w][r];
+                st_b[j] = (uint16_t)bucket[r];
+            }
+        }
+        __syncthreads();
+        // [D] copy out: consecutive threads -> consecutive records of a bucket's segment
+        for (uint32_t j = tid; j < total; j += 1024u) {
+            const uint32_t b = st_b[j];
+            const uint32_t k = j - off[b];
+            const uint32_t sp = split[b];
+            const uint32_t base = k < sp ? base0[b] : base1[b];
+            if (base == 0xffffffffu) continue; // (queue full: flagged, the host retries with more room)
+            const uint64_t dst = (uint64_t)b * G.cap + base + (k < sp ? k : k - sp);
+            G.qkey[dst] = (long long)st_key[j];
+#pragma unroll
+            for (int w = 0; w < W; ++w) G.qw[w][dst] = st_w[(size_t)w * T + j];
+        }
+        // (the next tile's [C] comes after two more barriers: nobody overwrites what [D] still reads)
+    }
+    if (tid < NB && !dead) close_range();
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// gb_reduce
+// ------------------------------------------------------------------------------------------------------------------
+// LDS table of one bucket: SLOTS + 1 entries (the last one belongs to the key INT64_MIN, which doubles as EMPTY)
+template <int NV, bool MERGE>
+__global__ void __launch_bounds__(1024) gb_reduce(const GbArgs G) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    // row counters: 32 bits while counting rows (a workgroup sees < 2^32 of them), 64 bits when merging partial counts
+    using CT = typename std::conditional<MERGE, unsigned long long, uint32_t>::type;
+    const uint32_t SLOTS = 1u << G.slots_log2, E = SLOTS + 1, EP = (E + 1) & ~1u; // (EP: even, keeps the 8-byte arrays aligned behind 4-byte ones)
+    unsigned long long *const t_key = (unsigned long long *)lds;    // [E]
+    double *const t_sum = (double *)(t_key + EP);                   // [NV][EP]
+    double *const t_sum2 = t_sum + (size_t)NV * EP;                 // [NV][EP]
+    CT *const t_rows = (CT *)(t_sum2 + (size_t)NV * EP);            // [EP]
+    CT *const t_cnt = t_rows + EP;                                  // [NV][EP]
+    uint32_t *const s_misc = (uint32_t *)(t_cnt + (size_t)NV * EP); // [0] claimed slots, [1] output base, [2..17] wave totals
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, nwave = blockDim.x >> 6;
+    const uint32_t bucket = blockIdx.x;
+    for (uint32_t s = tid; s < E; s += blockDim.x) {
+        t_key[s] = (unsigned long long)GB_EMPTY;
+        t_rows[s] = (CT)0;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) { t_sum[(size_t)v * EP + s] = 0.0; t_sum2[(size_t)v * EP + s] = 0.0; t_cnt[(size_t)v * EP + s] = (CT)0; }
+    }
+    if (tid < 18) s_misc[tid] = 0u;
+    __syncthreads();
+
+    const uint32_t limit = SLOTS - SLOTS / 8; // more distinct keys than this in one bucket: too slow / cannot terminate — flag and let the host retry
+    auto slot_of = [&](long long key) -> uint32_t { // insert-or-get; 0xffffffff when the table is full
+        if (key == GB_EMPTY) return SLOTS;
+        uint32_t s = (uint32_t)(gb_mix((uint64_t)key) >> 7) & (SLOTS - 1);
+        for (uint32_t probes = 0; probes < SLOTS; ++probes) {
+            const unsigned long long cur = t_key[s];
+            if (cur == (unsigned long long)key) return s;
+            if (cur == (unsigned long long)GB_EMPTY) {
+                if (s_misc[0] >= limit) return 0xffffffffu;
+                const unsigned long long old = atomicCAS(&t_key[s], (unsigned long long)GB_EMPTY, (unsigned long long)key);
+                if (old == (unsigned long long)GB_EMPTY) {
+                    __hip_atomic_fetch_add(&s_misc[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    return s;
+                }
+                if (old == (unsigned long long)key) return s;
+            }
+            s = (s + 1) & (SLOTS - 1);
+        }
+        return 0xffffffffu;
+    };
+    bool failed = false;
+    auto apply = [&](long long key, const uint64_t (&p)[MERGE ? 1 + 3 * NV : NV]) {
+        const uint32_t s = slot_of(key);
+        if (s == 0xffffffffu) { failed = true; return; }
+        if (MERGE) {
+            __hip_atomic_fetch_add(&t_rows[s], (CT)p[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                __hip_atomic_fetch_add(&t_cnt[(size_t)v * EP + s], (CT)p[1 + 3 * v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(&t_sum[(size_t)v * EP + s], __longlong_as_double((long long)p[2 + 3 * v]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(&t_sum2[(size_t)v * EP + s], __longlong_as_double((long long)p[3 + 3 * v]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        } else {
+            __hip_atomic_fetch_add(&t_rows[s], (CT)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                const double d = __longlong_as_double((long long)p[v]);
+                if (d == d) { // NaN values are skipped by count / sum / sum-moment alike (src/agg_sum.cpp:113, agg_count.cpp:56)
+                    __hip_atomic_fetch_add(&t_cnt[(size_t)v * EP + s], (CT)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(&t_sum[(size_t)v * EP + s], d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(&t_sum2[(size_t)v * EP + s], d * d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
+        }
+    };
+
+    // every wave streams whole queue blocks of this bucket (block w, w + waves, ...), two records per lane in flight
+    constexpr int PW = MERGE ? 1 + 3 * NV : NV;
+    unsigned long long reserved = G.qcount[bucket];
+    if (reserved > G.cap) reserved = G.cap; // (overflowed reservations hold nothing)
+    const uint32_t nblk = (uint32_t)(reserved / G.blk);
+    const uint64_t qb = (uint64_t)bucket * G.cap;
+    for (uint32_t b = wave; b < nblk; b += nwave) {
+        const uint32_t fill = G.tab[(size_t)bucket * G.tab_stride + b];
+        const uint64_t lo = qb + (uint64_t)b * G.blk;
+        for (uint32_t j0 = 0; j0 < fill; j0 += 128u) {
+            const uint32_t ja = j0 + lane, jb = j0 + 64u + lane;
+            const bool va = ja < fill, vb = jb < fill;
+            const long long ka = G.qkey[lo + (va ? ja : 0u)], kb = G.qkey[lo + (vb ? jb : 0u)];
+            uint64_t pa[PW], pb[PW];
+#pragma unroll
+            for (int w = 0; w < PW; ++w) { pa[w] = G.qw[w][lo + (va ? ja : 0u)]; pb[w] = G.qw[w][lo + (vb ? jb : 0u)]; }
+            if (va) apply(ka, pa);
+            if (vb) apply(kb, pb);
+        }
+    }
+    if (failed) atomicExch(G.overflow, 2u);
+    __syncthreads();
+
+    // compact the occupied slots into the result arrays: ONE device atomic per bucket reserves the range
+    uint32_t mine = 0;
+    for (uint32_t s = tid; s < E; s += blockDim.x) mine += t_rows[s] != (CT)0 ? 1u : 0u;
+    uint32_t inc = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = (uint32_t)__shfl_up((int)inc, o, 64);
+        if ((int)lane >= o) inc += t;
+    }
+    if (lane == 63) s_misc[2 + wave] = inc;
+    __syncthreads();
+    uint32_t before = 0, total = 0;
+    for (uint32_t w2 = 0; w2 < nwave; ++w2) {
+        if (w2 < wave) before += s_misc[2 + w2];
+        total += s_misc[2 + w2];
+    }
+    if (tid == 0) {
+        const unsigned long long base = atomicAdd(G.out_count, (unsigned long long)total);
+        if (base + total > G.out_cap) { atomicExch(G.overflow, 3u); s_misc[1] = 0xffffffffu; }
+        else s_misc[1] = (uint32_t)base;
+    }
+    __syncthreads();
+    if (s_misc[1] == 0xffffffffu) return;
+    uint64_t o = (uint64_t)s_misc[1] + before + inc - mine;
+    for (uint32_t s = tid; s < E; s += blockDim.x) {
+        if (t_rows[s] == (CT)0) continue;
+        G.out_key[o] = s == SLOTS ? GB_EMPTY : (long long)t_key[s];
+        G.out_w[0][o] = (uint64_t)t_rows[s];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            G.out_w[1 + 3 * v][o] = (uint64_t)t_cnt[(size_t)v * EP + s];
+            G.out_w[2 + 3 * v][o] = (uint64_t)__double_as_longlong(t_sum[(size_t)v * EP + s]);
+            G.out_w[3 + 3 * v][o] = (uint64_t)__double_as_longlong(t_sum2[(size_t)v * EP + s]);
+        }
+        ++o;
+    }
+}
+
+__global__ void gb_iota(unsigned int *p, uint64_t n) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) p[i] = (unsigned int)i;
+}
+
+__global__ void gb_gather(const uint64_t *src, const unsigned int *perm, uint64_t *dst, uint64_t n) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) dst[i] = src[perm[i]];
+}
+
+// derived columns on the sorted results: the finishers of vaex/agg.py:403-416, :440-455
+__global__ void gb_derive(const uint64_t *cnt, const uint64_t *sum, const uint64_t *sum2, int which, uint64_t *dst, uint64_t n) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        const double c = (double)(long long)cnt[i], s = __longlong_as_double((long long)sum[i]), s2 = __longlong_as_double((long long)sum2[i]);
+        const double mean = s / c;
+        const double raw2 = s2 / c;
+        const double var = raw2 - mean * mean;
+        const double r = which == VXH_GB_MEAN ? mean : (which == VXH_GB_VAR ? var : sqrt(var));
+        dst[i] = (uint64_t)__double_as_longlong(r);
+    }
+}
+
+unsigned gb_grid(uint64_t n) {
+    uint64_t b = (n + 255) / 256;
+    return (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(b, 4096));
+}
+
+struct Dev {
+    void *p = nullptr;
+    size_t cap = 0;
+    void need(size_t bytes) {
+        if (bytes <= cap) return;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        HIP_CHECK(hipMalloc(&p, bytes));
+        cap = bytes;
+    }
+    ~Dev() { if (p) (void)hipFree(p); }
+};
+
+} // namespace
+
+// result of one groupby: sorted by key, columns on the device until fetched
+struct vxh_groupby {
+    int nv = 1;
+    uint64_t n_groups = 0;
+    Dev cols; // [key | rows | (count, sum, sum2) x nv] x n_groups, 8-byte elements, sorted by key
+    Dev tmp;
+    uint64_t stride = 0; // elements between columns
+    int buckets = 0, slots = 0, retries = 0;
+    float ms_scatter = 0, ms_reduce = 0, ms_sort = 0;
+};
+
+namespace {
+
+// process-wide scratch of the pipeline (grow-only; one groupby at a time per process: guarded by the mutex)
+struct GbScratch {
+    std::mutex mutex;
+    Dev queues, small, out, sort_tmp, stage;
+};
+GbScratch &gb_scratch() {
+    static GbScratch *s = new GbScratch();
+    return *s;
+}
+
+template <int W, int R>
+void launch_scatter(const GbArgs &G, int blocks, hipStream_t st) {
+    const uint32_t NB = 1u << G.nb_log2;
+    const size_t T = 1024u * R;
+    const size_t lds = T * 8 * (1 + W) + (size_t)NB * 4 * 5 + 64 + T * 2 + 16;
+    (void)hipFuncSetAttribute((const void *)gb_scatter<W, R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((gb_scatter<W, R>), dim3(blocks), dim3(1024), lds, st, G);
+}
+
+template <int NV, bool MERGE>
+void launch_reduce(const GbArgs &G, hipStream_t st) {
+    const size_t EP = ((((size_t)1 << G.slots_log2) + 1) + 1) & ~(size_t)1;
+    const size_t ct = MERGE ? 8 : 4;
+    const size_t lds = EP * (8 + 16 * (size_t)NV + ct * (1 + (size_t)NV)) + 18 * 4 + 16;
+    (void)hipFuncSetAttribute((const void *)gb_reduce<NV, MERGE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((gb_reduce<NV, MERGE>), dim3(1u << G.nb_log2), dim3(1024), lds, st, G);
+}
+
+// one pipeline run over device-resident records; results appended (unsorted) to the arrays in G.out_*; returns the
+// overflow code (0 = fine)
+unsigned run_pipeline(GbArgs &G, int nv, bool merge, uint64_t n, uint64_t groups_hint, int cus, hipStream_t st, vxh_groupby *res) {
+    GbScratch &S = gb_scratch();
+    const int w = merge ? 1 + 3 * nv : nv;
+    const int R = w == 1 ? 8 : (w == 2 ? 4 : (w <= 4 ? 2 : 1));
+    const uint64_t T = 1024ull * R;
+    // LDS table of a bucket: 4096 slots x (key 8 + sum 8 + sum2 8 + rows 4 + count 4) = 128 KiB with one value column;
+    // 2048 slots with two, and when merging (64-bit counters)
+    const int slots_log2 = (nv == 1 && !merge) ? 12 : 11;
+    int nb_log2 = 6;
+    const uint64_t per_bucket = ((uint64_t)1 << slots_log2) / 2; // target load 0.5
+    while (nb_log2 < 10 && ((uint64_t)1 << nb_log2) * per_bucket < std::max<uint64_t>(groups_hint, 1)) nb_log2++;
+    hipEvent_t e0, e1, e2;
+    HIP_CHECK(hipEventCreate(&e0)); HIP_CHECK(hipEventCreate(&e1)); HIP_CHECK(hipEventCreate(&e2));
+    unsigned code = 0;
+    for (int attempt = 0; attempt < 6; ++attempt) {
+        const uint64_t NB = (uint64_t)1 << nb_log2;
+        const int blocks = (int)std::max<uint64_t>(1, std::min<uint64_t>((n + T - 1) / T, (uint64_t)cus));
+        // one block per (workgroup, bucket) sized for its expected share + 1/4 + a tile's worth; room for every
+        // workgroup's first block and 16 more
+        uint64_t B = (uint64_t)((double)n / (double)((uint64_t)blocks * NB) * 1.25) + 2 * (T / NB + 1) + 64;
+        B = (B + 3) & ~(uint64_t)3;
+        if (attempt >= 2) B *= 2; // (a skewed bucket ran out of queue: more slack)
+        const uint64_t cap = ((uint64_t)blocks + 16) * B;
+        if (cap >= (1ull << 32)) { code = 9; break; }
+        const uint64_t tab_stride = cap / B + 1;
+        G.nv = nv; G.w = w; G.merge = merge ? 1 : 0; G.n = n;
+        G.nb_log2 = nb_log2; G.slots_log2 = slots_log2;
+        G.blk = (uint32_t)B; G.cap = cap; G.tab_stride = (uint32_t)tab_stride;
+        S.queues.need(NB * cap * 8 * (size_t)(1 + w));
+        const size_t small_bytes = NB * 8 + NB * tab_stride * 4 + 64;
+        S.small.need(small_bytes);
+        char *q = (char *)S.queues.p;
+        G.qkey = (long long *)q;
+        for (int k = 0; k < w; k++) G.qw[k] = (uint64_t *)(q + NB * cap * 8 * (size_t)(1 + k));
+        G.qcount = (unsigned long long *)S.small.p;
+        G.tab = (uint32_t *)((char *)S.small.p + NB * 8);
+        G.overflow = (unsigned int *)((char *)S.small.p + NB * 8 + NB * tab_stride * 4);
+        G.out_count = (unsigned long long *)(G.overflow + 2);
+        HIP_CHECK(hipMemsetAsync(S.small.p, 0, small_bytes, st));
+        HIP_CHECK(hipEventRecord(e0, st));
+        if (w == 1) launch_scatter<1, 8>(G, blocks, st);
+        else if (w == 2) launch_scatter<2, 4>(G, blocks, st);
+        else if (w == 4) launch_scatter<4, 2>(G, blocks, st);
+        else launch_scatter<7, 1>(G, blocks, st);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipEventRecord(e1, st));
+        if (nv == 1) { if (merge) launch_reduce<1, true>(G, st); else launch_reduce<1, false>(G, st); }
+        else { if (merge) launch_reduce<2, true>(G, st); else launch_reduce<2, false>(G, st); }
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipEventRecord(e2, st));
+        unsigned int flags[4] = {0, 0, 0, 0};
+        HIP_CHECK(hipMemcpyAsync(flags, G.overflow, 16, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        code = flags[0];
+        if (res) {
+            (void)hipEventElapsedTime(&res->ms_scatter, e0, e1);
+            (void)hipEventElapsedTime(&res->ms_reduce, e1, e2);
+            res->buckets = (int)NB; res->slots = 1 << slots_log2; res->retries = attempt;
+        }
+        if (code == 0) {
+            unsigned long long cnt = 0;
+            memcpy(&cnt, &flags[2], 8);
+            if (res) res->n_groups = cnt;
+            break;
+        }
+        if (code == 2) { // a bucket holds too many distinct keys: more buckets
+            if (nb_log2 >= 10) { code = 8; break; }
+            nb_log2 = std::min(10, nb_log2 + 2);
+        } else if (code == 3) { // result arrays too small (the caller sized them from a hint): report
+            break;
+        }
+        // code 1: a bucket's queue was full — skewed keys: the retry doubles the block slack (attempt >= 2) after one plain retry
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e2);
+    return code;
+}
+
+} // namespace
+
+extern "C" {
+
+#define GB_BEGIN try {
+#define GB_END                                                                                                         \
+    }                                                                                                                  \
+    catch (const std::exception &e) {                                                                                  \
+        vxh_set_error(e.what());                                                                                       \
+        return 1;                                                                                                      \
+    }                                                                                                                  \
+    return 0;
+
+int vxh_groupby_run(int key_dtype, const void *keys, int n_values, const void *const *values, uint64_t n, int mem, uint64_t groups_hint, uint64_t max_groups, vxh_groupby **out) {
+    GB_BEGIN
+    if (key_dtype == VXH_F64 || key_dtype == VXH_F32 || key_dtype < 0 || key_dtype >= VXH_DTYPE_COUNT) throw std::runtime_error("groupby: integer key dtypes only");
+    if (n_values < 1 || n_values > GB_MAX_NV) throw std::runtime_error("groupby: 1 or 2 float64 value columns");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { (void)hipGetLastError(); throw std::runtime_error("vaex_hip: no HIP device available (libvaexhip has no CPU fallback)"); }
+    (void)hipSetDevice(ctx().device);
+    int64_t cus = 256;
+    (void)vxh_config_get("cus", &cus);
+    Slot &slot = get_slot(0);
+    GbScratch &S = gb_scratch();
+    std::lock_guard<std::mutex> lock(S.mutex);
+    std::unique_ptr<vxh_groupby> res(new vxh_groupby());
+    res->nv = n_values;
+    if (n == 0) { *out = res.release(); return 0; }
+    const size_t ks = (size_t)vxh_dtype_size(key_dtype);
+    GbArgs G{};
+    G.key_dtype = key_dtype;
+    if (mem == VXH_MEM_DEVICE) {
+        order_after_producers(slot);
+        G.keys = keys;
+        for (int v = 0; v < n_values; v++) G.payload[v] = (const uint64_t *)values[v];
+    } else {
+        S.stage.need(n * (ks + 8 * (size_t)n_values) + 256 * 3);
+        char *p = (char *)S.stage.p;
+        HIP_CHECK(hipMemcpyAsync(p, keys, n * ks, hipMemcpyHostToDevice, slot.stream));
+        G.keys = p;
+        p += (n * ks + 255) & ~(size_t)255;
+        for (int v = 0; v < n_values; v++) {
+            HIP_CHECK(hipMemcpyAsync(p, values[v], n * 8, hipMemcpyHostToDevice, slot.stream));
+            G.payload[v] = (const uint64_t *)p;
+            p += (n * 8 + 255) & ~(size_t)255;
+        }
+    }
+    if (max_groups == 0) max_groups = std::min<uint64_t>(n, 1ull << 26);
+    const uint64_t out_cap = std::min<uint64_t>(n, max_groups) + 1;
+    const int wout = 1 + 3 * n_values;
+    S.out.need(out_cap * 8 * (size_t)(1 + wout));
+    G.out_cap = out_cap;
+    G.out_key = (long long *)S.out.p;
+    for (int k = 0; k < wout; k++) G.out_w[k] = (uint64_t *)((char *)S.out.p + out_cap * 8 * (size_t)(1 + k));
+    const unsigned code = run_pipeline(G, n_values, false, n, groups_hint ? groups_hint : (1u << 20), (int)cus, slot.stream, res.get());
+    if (code == 3) throw std::runtime_error("groupby: more groups than max_groups");
+    if (code == 8 || code == 9) throw std::runtime_error("groupby: too many distinct keys for the LDS-partitioned path");
+    if (code != 0) throw std::runtime_error("groupby: the key distribution is too skewed for the partitioned path");
+    // sort by key: radix sort of (key, position), then gather every column
+    const uint64_t ng = res->n_groups;
+    hipEvent_t e0, e1;
+    HIP_CHECK(hipEventCreate(&e0)); HIP_CHECK(hipEventCreate(&e1));
+    HIP_CHECK(hipEventRecord(e0, slot.stream));
+    res->stride = (ng + 31) & ~(uint64_t)31;
+    res->cols.need(std::max<uint64_t>(res->stride, 32) * 8 * (size_t)(1 + wout));
+    if (ng) {
+        res->tmp.need(ng * 4 * 2 + ng * 8 + 256);
+        unsigned int *iota = (unsigned int *)res->tmp.p, *perm = iota + ng;
+        long long *keys_sorted = (long long *)res->cols.p;
+        hipLaunchKernelGGL(gb_iota, dim3(gb_grid(ng)), dim3(256), 0, slot.stream, iota, ng);
+        size_t tmp_bytes = 0;
+        HIP_CHECK(rocprim::radix_sort_pairs(nullptr, tmp_bytes, G.out_key, keys_sorted, iota, perm, ng, 0, 64, slot.stream));
+        S.sort_tmp.need(tmp_bytes + 16);
+        HIP_CHECK(rocprim::radix_sort_pairs(S.sort_tmp.p, tmp_bytes, G.out_key, keys_sorted, iota, perm, ng, 0, 64, slot.stream));
+        for (int k = 0; k < wout; k++)
+            hipLaunchKernelGGL(gb_gather, dim3(gb_grid(ng)), dim3(256), 0, slot.stream, G.out_w[k], perm, (uint64_t *)res->cols.p + res->stride * (size_t)(1 + k), ng);
+        HIP_CHECK(hipGetLastError());
+    }
+    HIP_CHECK(hipEventRecord(e1, slot.stream));
+    HIP_CHECK(hipStreamSynchronize(slot.stream));
+    (void)hipEventElapsedTime(&res->ms_sort, e0, e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    *out = res.release();
+    GB_END
+}
+
+int vxh_groupby_merge(int n_values, const int64_t *keys, const int64_t *rows, const int64_t *const *counts, const double *const *sums, const double *const *sums2, uint64_t n, uint64_t groups_hint, vxh_groupby **out) {
+    GB_BEGIN
+    if (n_values < 1 || n_values > GB_MAX_NV) throw std::runtime_error("groupby: 1 or 2 value columns");
+    (void)hipSetDevice(ctx().device);
+    int64_t cus = 256;
+    (void)vxh_config_get("cus", &cus);
+    Slot &slot = get_slot(0);
+    GbScratch &S = gb_scratch();
+    std::lock_guard<std::mutex> lock(S.mutex);
+    std::unique_ptr<vxh_groupby> res(new vxh_groupby());
+    res->nv = n_values;
+    if (n == 0) { *out = res.release(); return 0; }
+    const int w = 1 + 3 * n_values;
+    const size_t col = (n * 8 + 255) & ~(size_t)255;
+    S.stage.need(col * (size_t)(1 + w));
+    char *p = (char *)S.stage.p;
+    GbArgs G{};
+    G.key_dtype = VXH_I64;
+    HIP_CHECK(hipMemcpyAsync(p, keys, n * 8, hipMemcpyHostToDevice, slot.stream));
+    G.keys = p;
+    const void *src[GB_MAX_W];
+    src[0] = rows;
+    for (int v = 0; v < n_values; v++) { src[1 + 3 * v] = counts[v]; src[2 + 3 * v] = sums[v]; src[3 + 3 * v] = sums2[v]; }
+    for (int k = 0; k < w; k++) {
+        char *d = p + col * (size_t)(1 + k);
+        HIP_CHECK(hipMemcpyAsync(d, src[k], n * 8, hipMemcpyHostToDevice, slot.stream));
+        G.payload[k] = (const uint64_t *)d;
+    }
+    const uint64_t out_cap = n + 1;
+    S.out.need(out_cap * 8 * (size_t)(1 + w));
+    G.out_cap = out_cap;
+    G.out_key = (long long *)S.out.p;
+    for (int k = 0; k < w; k++) G.out_w[k] = (uint64_t *)((char *)S.out.p + out_cap * 8 * (size_t)(1 + k));
+    const unsigned code = run_pipeline(G, n_values, true, n, groups_hint ? groups_hint : n, (int)cus, slot.stream, res.get());
+    if (code != 0) throw std::runtime_error("groupby merge: too many distinct keys / too skewed for the LDS-partitioned path");
+    const uint64_t ng = res->n_groups;
+    res->stride = (ng + 31) & ~(uint64_t)31;
+    res->cols.need(std::max<uint64_t>(res->stride, 32) * 8 * (size_t)(1 + w));
+    if (ng) {
+        res->tmp.need(ng * 4 * 2 + ng * 8 + 256);
+        unsigned int *iota = (unsigned int *)res->tmp.p, *perm = iota + ng;
+        long long *keys_sorted = (long long *)res->cols.p;
+        hipLaunchKernelGGL(gb_iota, dim3(gb_grid(ng)), dim3(256), 0, slot.stream, iota, ng);
+        size_t tmp_bytes = 0;
+        HIP_CHECK(rocprim::radix_sort_pairs(nullptr, tmp_bytes, G.out_key, keys_sorted, iota, perm, ng, 0, 64, slot.stream));
+        S.sort_tmp.need(tmp_bytes + 16);
+        HIP_CHECK(rocprim::radix_sort_pairs(S.sort_tmp.p, tmp_bytes, G.out_key, keys_sorted, iota, perm, ng, 0, 64, slot.stream));
+        for (int k = 0; k < w; k++)
+            hipLaunchKernelGGL(gb_gather, dim3(gb_grid(ng)), dim3(256), 0, slot.stream, G.out_w[k], perm, (uint64_t *)res->cols.p + res->stride * (size_t)(1 + k), ng);
+        HIP_CHECK(hipGetLastError());
+    }
+    HIP_CHECK(hipStreamSynchronize(slot.stream));
+    *out = res.release();
+    GB_END
+}
+
+void vxh_groupby_destroy(vxh_groupby *g) {
+    if (!g) return;
+    (void)hipDeviceSynchronize();
+    delete g;
+}
+
+uint64_t vxh_groupby_size(const vxh_groupby *g) { return g->n_groups; }
+
+int vxh_groupby_info(const vxh_groupby *g, int what, double *value_out) {
+    GB_BEGIN
+    switch (what) {
+    case 0: *value_out = g->buckets; break;
+    case 1: *value_out = g->slots; break;
+    case 2: *value_out = g->retries; break;
+    case 3: *value_out = g->ms_scatter; break;
+    case 4: *value_out = g->ms_reduce; break;
+    case 5: *value_out = g->ms_sort; break;
+    default: throw std::runtime_error("groupby info: unknown item");
+    }
+    GB_END
+}
+
+int vxh_groupby_column(vxh_groupby *g, int value_index, int which, void *out_host) {
+    GB_BEGIN
+    (void)hipSetDevice(ctx().device);
+    if (g->n_groups == 0) return 0;
+    Slot &slot = get_slot(0);
+    const uint64_t ng = g->n_groups;
+    const uint64_t *base = (const uint64_t *)g->cols.p;
+    const uint64_t *col = nullptr;
+    if (which == VXH_GB_KEYS) col = base;
+    else if (which == VXH_GB_ROWS) col = base + g->stride;
+    else {
+        if (value_index < 0 || value_index >= g->nv) throw std::runtime_error("groupby column: value index out of range");
+        const uint64_t *cnt = base + g->stride * (size_t)(2 + 3 * value_index), *sum = cnt + g->stride, *sum2 = sum + g->stride;
+        if (which == VXH_GB_COUNT) col = cnt;
+        else if (which == VXH_GB_SUM) col = sum;
+        else if (which == VXH_GB_SUM2) col = sum2;
+        else if (which == VXH_GB_MEAN || which == VXH_GB_VAR || which == VXH_GB_STD) {
+            g->tmp.need(ng * 8 + ng * 8 + 256 + ng * 8);
+            uint64_t *dst = (uint64_t *)g->tmp.p;
+            hipLaunchKernelGGL(gb_derive, dim3(gb_grid(ng)), dim3(256), 0, slot.stream, cnt, sum, sum2, which, dst, ng);
+            HIP_CHECK(hipGetLastError());
+            col = dst;
+        } else throw std::runtime_error("groupby column: unknown column");
+    }
+    HIP_CHECK(hipMemcpyAsync(out_host, col, ng * 8, hipMemcpyDeviceToHost, slot.stream));
+    HIP_CHECK(hipStreamSynchronize(slot.stream));
+    GB_END
+}
+
+} // extern "C"

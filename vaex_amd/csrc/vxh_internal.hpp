@@ -109,6 +109,8 @@ struct Slot {
         double key_fraction = -1;
         double last_fraction = 0; // share of the sample inside the box (vxh_config_get("hot_fraction_ppm"))
     } hot;
+    void *fin_buf = nullptr; // vxh_finish scratch (grow-only)
+    size_t fin_cap = 0;
     const char *last_kernel = "";
     int last_pass1 = 0; // partition strategy, most recent chunk: 0 part_scatter / part_scatter_f64, 1 part_scatter_blk, 2 part_scatter_wv
 };
