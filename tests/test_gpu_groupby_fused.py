@@ -50,6 +50,18 @@ def test_groupby_run_host_rows(sa, gpu_ready, n, groups):
     assert info["buckets"] >= 64 and info["slots"] in (2048, 4096)
 
 
+def test_groupby_run_two_keys_only(sa, gpu_ready):
+    """two distinct keys: every row lands in one of two buckets — the queue slack grows on retry (small inputs), and the
+    result is still exact"""
+    rng = np.random.default_rng(2)
+    n = 200_000
+    k = np.where(rng.random(n) < 0.3, 7, -(1 << 50)).astype(np.int64)
+    v = rng.normal(0, 1, n)
+    res = sa.groupby_run(k, [v], _DT["int64"])
+    _check(sa, res, _want(k, [v]))
+    assert res.info()["retries"] >= 1
+
+
 def test_groupby_run_device_rows_two_values(sa, gpu_ready):
     import torch
     g = torch.Generator(device="cuda").manual_seed(3)

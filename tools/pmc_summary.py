@@ -11,7 +11,7 @@ for path in sys.argv[1:]:
     for f in glob.glob(path):
         for r in csv.DictReader(open(f)):
             name = r.get("Kernel_Name", "").replace("(anonymous namespace)::", "").replace("void ", "")[:40]
-            if not any(k in name for k in ("part_", "bin_kernel", "count_lds", "fold", "hm_")):
+            if not any(k in name for k in ("part_", "bin_kernel", "count_lds", "fold", "hm_", "gb_")):
                 continue
             acc[name][r["Counter_Name"]] += float(r["Counter_Value"])
             disp[(name, r["Counter_Name"])].add(r["Dispatch_Id"])

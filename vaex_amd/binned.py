@@ -316,6 +316,8 @@ class Frame:
         for d in descs:
             ids = []
             for p in d.prims():
+                if p.as_float64 and p.column is not None and str(self.columns[p.column].dtype).replace("torch.", "") == "float64":
+                    p.as_float64 = False  # astype('float64') of a float64 column is the column: std's sum / count are mean's
                 k = p.key()
                 if k not in index:
                     index[k] = len(prims)

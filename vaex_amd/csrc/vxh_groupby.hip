@@ -69,18 +69,23 @@ struct GbArgs {
     int32_t key_dtype, nv, w, merge; // w payload words per record; merge: payload = partial results (rows, count, sum, sum2 ...)
     const uint64_t *payload[GB_MAX_W]; // RAW: the value columns (float64 bits); MERGE: rows, count_0, sum_0, sum2_0, ...
     uint64_t n;
-    // buckets
+    // Queues.  A BLOCK holds up to `blk` records of ONE bucket written by ONE workgroup.  Block wg * NB + b is workgroup
+    // wg's primary block for bucket b — so everything a workgroup writes lies in one contiguous window of NB blocks
+    // (a bucket-major layout spreads a tile's 2 * NB segments over as many distant pages: the scatter pass then runs at a
+    // third of the speed, waiting on address translation) — and `pool` spare blocks behind the primaries are handed out
+    // through pool_used to (workgroup, bucket) pairs whose primary block fills up; pool_owner[] says whose they are.
     int32_t nb_log2, slots_log2;
-    uint32_t blk;        // records per queue block
-    uint32_t tab_stride; // table entries per bucket
-    uint64_t cap;        // records per bucket queue
-    unsigned long long *qcount; // [NB] records reserved
-    uint32_t *tab;              // [NB][tab_stride] records each block really holds
-    long long *qkey;            // [NB][cap]
-    uint64_t *qw[GB_MAX_W];     // [NB][cap] each
+    uint32_t blk;      // records per block
+    uint32_t scatter_wgs; // workgroups of gb_scatter (= primary blocks per bucket)
+    uint32_t pool;     // spare blocks
+    uint32_t *tab;     // [scatter_wgs * NB + pool] records each block holds
+    uint32_t *pool_used;  // spare blocks handed out
+    uint32_t *pool_owner; // [pool] bucket of a spare block
+    long long *qkey;        // [blocks][blk]
+    uint64_t *qw[GB_MAX_W]; // [blocks][blk] each
     // results (unsorted)
     unsigned long long *out_count; // groups written so far
-    unsigned int *overflow;        // a bucket's table got too full / a bucket's queue ran out of room
+    unsigned int *overflow;        // 1: out of spare blocks, 2: a bucket's LDS table too full, 3: result arrays too small
     uint64_t out_cap;
     long long *out_key;
     uint64_t *out_w[GB_MAX_W]; // rows (int64), then per value column: count (int64), sum (f64), sum2 (f64)
@@ -106,72 +111,65 @@ __global__ void __launch_bounds__(1024) gb_scatter(const GbArgs G) {
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint64_t n = G.n;
     if (tid < NB) cnt[tid] = 0u;
-    // thread b: the range of bucket b's queue this workgroup appends to: [cur, end), allocated from `start`
-    uint32_t start = 0, cur = 0, end = 0;
-    bool dead = false; // the bucket's queue is full: records are dropped and the overflow flag raised (the host retries)
+    // thread b: the block bucket b's records of this workgroup go to, and how full it is
     const uint32_t B = G.blk;
-    auto close_range = [&]() { // fills of the blocks of [start, end)
-        for (uint32_t b0 = start; b0 < end; b0 += B) {
-            const uint32_t fill = cur <= b0 ? 0u : (cur - b0 < B ? cur - b0 : B);
-            G.tab[(size_t)tid * G.tab_stride + b0 / B] = fill;
-        }
-    };
-    auto open_range = [&](uint32_t need) { // room for `need` more records (whole blocks, contiguous)
-        const uint32_t nblk = (need + B - 1) / B;
-        const unsigned long long b = atomicAdd(&G.qcount[tid], (unsigned long long)nblk * B);
-        if (b + (unsigned long long)nblk * B > G.cap) {
-            atomicExch(G.overflow, 1u);
-            dead = true;
-            start = cur = end = 0;
-        } else {
-            start = cur = (uint32_t)b;
-            end = start + nblk * B;
-        }
-    };
+    const uint32_t primaries = G.scatter_wgs * NB;
+    uint32_t block = blockIdx.x * NB + tid, fill = 0;
+    bool dead = false; // no spare block left for this bucket: records are dropped and the overflow flag raised (the host retries with more room)
     __syncthreads();
 
-    for (uint64_t tile = blockIdx.x; tile * T < n; tile += gridDim.x) {
-        // [A] rows of the tile, bucket of every row, position inside the bucket
-        long long key[R];
-        uint64_t pay[W][R];
-        uint32_t bucket[R], pos[R];
-        bool ok[R];
+    // the next tile's rows are requested while the current one is staged and copied out (two register sets; the copy
+    // at the end of the iteration is where their loads are waited for, a barrier and a copy-out later)
+    long long key[R], key_n[R];
+    uint64_t pay[W][R], pay_n[W][R];
+    bool ok[R], ok_n[R];
+    auto request = [&](uint64_t tile, long long (&k)[R], uint64_t (&p)[W][R], bool (&v)[R]) {
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const uint64_t i = tile * T + (uint64_t)r * 1024u + tid;
-            ok[r] = i < n;
-            const uint64_t ic = ok[r] ? i : n - 1;
-            key[r] = gb_load_key(G.keys, ic, G.key_dtype);
+            v[r] = i < n;
+            const uint64_t ic = v[r] ? i : n - 1;
+            k[r] = G.key_dtype == VXH_I64 ? ((const long long *)G.keys)[ic] : gb_load_key(G.keys, ic, G.key_dtype);
 #pragma unroll
-            for (int w = 0; w < W; ++w) pay[w][r] = G.payload[w][ic];
+            for (int w = 0; w < W; ++w) p[w][r] = G.payload[w][ic];
         }
+    };
+    if ((uint64_t)blockIdx.x * T < n) request(blockIdx.x, key, pay, ok);
+    for (uint64_t tile = blockIdx.x; tile * T < n; tile += gridDim.x) {
+        // [A] bucket of every row of the tile, position inside the bucket
+        uint32_t bucket[R], pos[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             bucket[r] = (uint32_t)(gb_mix((uint64_t)key[r]) >> (64 - G.nb_log2));
             pos[r] = 0;
             if (ok[r]) pos[r] = __hip_atomic_fetch_add(&cnt[bucket[r]], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
+        const uint64_t next = tile + gridDim.x;
+        const bool has_next = next * T < n;
+        if (has_next) request(next, key_n, pay_n, ok_n);
         __syncthreads();
         // [B] thread b: where bucket b's records of this tile go; exclusive scan of the bucket counts
         uint32_t c = 0;
         if (tid < NB) {
             c = cnt[tid];
             cnt[tid] = 0u;
-            uint32_t a0 = cur, a1 = 0, sp = c;
+            uint32_t a0 = block * B + fill, a1 = 0xffffffffu, sp = c;
             if (dead) {
-                a0 = a1 = 0xffffffffu;
-            } else if (c <= end - cur) {
-                cur += c;
-            } else {
-                sp = end - cur;
-                cur = end;
-                close_range();
-                open_range(c - sp);
-                if (dead) {
-                    a1 = 0xffffffffu;
+                a0 = 0xffffffffu;
+            } else if (c <= B - fill) {
+                fill += c;
+            } else { // the block fills up: the rest goes to a spare block (a tile never brings more than two blocks' worth: B >= the tile — else: retry)
+                sp = B - fill;
+                G.tab[block] = B;
+                const uint32_t spare = atomicAdd(G.pool_used, 1u);
+                if (spare >= G.pool || c - sp > B) {
+                    atomicExch(G.overflow, 1u);
+                    dead = true;
                 } else {
-                    a1 = cur;
-                    cur += c - sp;
+                    G.pool_owner[spare] = tid;
+                    block = primaries + spare;
+                    fill = c - sp;
+                    a1 = block * B;
                 }
             }
             base0[tid] = a0;
@@ -213,14 +211,23 @@ __global__ void __launch_bounds__(1024) gb_scatter(const GbArgs G) {
             const uint32_t sp = split[b];
             const uint32_t base = k < sp ? base0[b] : base1[b];
             if (base == 0xffffffffu) continue; // (queue full: flagged, the host retries with more room)
-            const uint64_t dst = (uint64_t)b * G.cap + base + (k < sp ? k : k - sp);
+            const uint64_t dst = (uint64_t)base + (k < sp ? k : k - sp);
             G.qkey[dst] = (long long)st_key[j];
 #pragma unroll
             for (int w = 0; w < W; ++w) G.qw[w][dst] = st_w[(size_t)w * T + j];
         }
         // (the next tile's [C] comes after two more barriers: nobody overwrites what [D] still reads)
+        if (has_next) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                key[r] = key_n[r];
+                ok[r] = ok_n[r];
+#pragma unroll
+                for (int w = 0; w < W; ++w) pay[w][r] = pay_n[w][r];
+            }
+        }
     }
-    if (tid < NB && !dead) close_range();
+    if (tid < NB && !dead) G.tab[block] = fill;
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -236,24 +243,62 @@ __global__ void __launch_bounds__(1024) gb_reduce(const GbArgs G) {
     unsigned long long *const t_key = (unsigned long long *)lds;    // [E]
     double *const t_sum = (double *)(t_key + EP);                   // [NV][EP]
     double *const t_sum2 = t_sum + (size_t)NV * EP;                 // [NV][EP]
-    CT *const t_rows = (CT *)(t_sum2 + (size_t)NV * EP);            // [EP]
-    CT *const t_cnt = t_rows + EP;                                  // [NV][EP]
-    uint32_t *const s_misc = (uint32_t *)(t_cnt + (size_t)NV * EP); // [0] claimed slots, [1] output base, [2..17] wave totals
+    // counting rows: {rows, count of value column 0} are the two halves of one 64-bit word per slot (t_rc), further
+    // columns' counts follow as 32-bit arrays; merging: 64-bit rows[] and counts[][]
+    unsigned long long *const t_rc = (unsigned long long *)(t_sum2 + (size_t)NV * EP);                           // RAW: [EP]
+    CT *const t_rows = (CT *)t_rc;                                                                                // MERGE: [EP]
+    CT *const t_cnt = MERGE ? t_rows + EP : (CT *)(t_rc + EP) - EP;                                               // MERGE: [NV][EP]; RAW: [v >= 1][EP] behind t_rc
+    uint32_t *const s_misc = (uint32_t *)((char *)t_rc + (MERGE ? (size_t)8 * EP * (1 + NV) : (size_t)8 * EP + (size_t)4 * EP * (NV - 1))); // [0] claimed slots, [1] output base, [2..17] wave totals
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, nwave = blockDim.x >> 6;
     const uint32_t bucket = blockIdx.x;
     for (uint32_t s = tid; s < E; s += blockDim.x) {
         t_key[s] = (unsigned long long)GB_EMPTY;
-        t_rows[s] = (CT)0;
+        if (MERGE) t_rows[s] = (CT)0; else t_rc[s] = 0ull;
 #pragma unroll
-        for (int v = 0; v < NV; ++v) { t_sum[(size_t)v * EP + s] = 0.0; t_sum2[(size_t)v * EP + s] = 0.0; t_cnt[(size_t)v * EP + s] = (CT)0; }
+        for (int v = 0; v < NV; ++v) {
+            t_sum[(size_t)v * EP + s] = 0.0;
+            t_sum2[(size_t)v * EP + s] = 0.0;
+            if (MERGE || v > 0) t_cnt[(size_t)v * EP + s] = (CT)0;
+        }
     }
     if (tid < 18) s_misc[tid] = 0u;
     __syncthreads();
 
     const uint32_t limit = SLOTS - SLOTS / 8; // more distinct keys than this in one bucket: too slow / cannot terminate — flag and let the host retry
+    constexpr int PW = MERGE ? 1 + 3 * NV : NV;
+    constexpr int U = 4; // records per lane per trip: their loads and their probe sequences run interleaved
+    bool failed = false;
+    auto accumulate = [&](uint32_t s, const uint64_t (&p)[PW]) {
+        if (MERGE) {
+            __hip_atomic_fetch_add(&t_rows[s], (CT)p[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                __hip_atomic_fetch_add(&t_cnt[(size_t)v * EP + s], (CT)p[1 + 3 * v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(&t_sum[(size_t)v * EP + s], __longlong_as_double((long long)p[2 + 3 * v]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(&t_sum2[(size_t)v * EP + s], __longlong_as_double((long long)p[3 + 3 * v]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        } else {
+            // rows (low half) and the count of value column 0 (high half) live in ONE 64-bit word: one LDS atomic for both
+            const double d0 = __longlong_as_double((long long)p[0]);
+            __hip_atomic_fetch_add(&t_rc[s], d0 == d0 ? 0x100000001ull : 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                const double d = __longlong_as_double((long long)p[v]);
+                if (d == d) { // NaN values are skipped by count / sum / sum-moment alike (src/agg_sum.cpp:113, agg_count.cpp:56)
+                    if (v > 0) __hip_atomic_fetch_add(&t_cnt[(size_t)v * EP + s], (CT)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(&t_sum[(size_t)v * EP + s], d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(&t_sum2[(size_t)v * EP + s], d * d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
+        }
+    };
+    // slot of a key inside the bucket's table: the top bits of a Fibonacci multiply — independent of the bucket (top
+    // bits of splitmix64) and a single 64-bit multiply (the pass is instruction-issue bound: ~150 instructions per 64
+    // records, a third of them the hash when splitmix64 is recomputed here)
+    auto home = [&](long long key) -> uint32_t { return (uint32_t)(((uint64_t)key * 0x9e3779b97f4a7c15ULL) >> (64 - G.slots_log2)); };
     auto slot_of = [&](long long key) -> uint32_t { // insert-or-get; 0xffffffff when the table is full
         if (key == GB_EMPTY) return SLOTS;
-        uint32_t s = (uint32_t)(gb_mix((uint64_t)key) >> 7) & (SLOTS - 1);
+        uint32_t s = home(key);
         for (uint32_t probes = 0; probes < SLOTS; ++probes) {
             const unsigned long long cur = t_key[s];
             if (cur == (unsigned long long)key) return s;
@@ -270,58 +315,54 @@ __global__ void __launch_bounds__(1024) gb_reduce(const GbArgs G) {
         }
         return 0xffffffffu;
     };
-    bool failed = false;
-    auto apply = [&](long long key, const uint64_t (&p)[MERGE ? 1 + 3 * NV : NV]) {
-        const uint32_t s = slot_of(key);
-        if (s == 0xffffffffu) { failed = true; return; }
-        if (MERGE) {
-            __hip_atomic_fetch_add(&t_rows[s], (CT)p[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    // `fill` records of one queue block starting at record `lo`, streamed by ONE wave, U records per lane per trip (their
+    // loads in flight together)
+    auto stream = [&](uint64_t lo, uint32_t fill) {
+        for (uint32_t j0 = 0; j0 < fill; j0 += 64u * U) {
+            long long kk[U];
+            uint64_t pp[U][PW];
+            bool todo[U];
 #pragma unroll
-            for (int v = 0; v < NV; ++v) {
-                __hip_atomic_fetch_add(&t_cnt[(size_t)v * EP + s], (CT)p[1 + 3 * v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                __hip_atomic_fetch_add(&t_sum[(size_t)v * EP + s], __longlong_as_double((long long)p[2 + 3 * v]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                __hip_atomic_fetch_add(&t_sum2[(size_t)v * EP + s], __longlong_as_double((long long)p[3 + 3 * v]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            for (int u = 0; u < U; ++u) {
+                const uint32_t j = j0 + 64u * u + lane;
+                todo[u] = j < fill;
+                kk[u] = G.qkey[lo + (todo[u] ? j : 0u)];
+#pragma unroll
+                for (int w = 0; w < PW; ++w) pp[u][w] = G.qw[w][lo + (todo[u] ? j : 0u)];
             }
-        } else {
-            __hip_atomic_fetch_add(&t_rows[s], (CT)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #pragma unroll
-            for (int v = 0; v < NV; ++v) {
-                const double d = __longlong_as_double((long long)p[v]);
-                if (d == d) { // NaN values are skipped by count / sum / sum-moment alike (src/agg_sum.cpp:113, agg_count.cpp:56)
-                    __hip_atomic_fetch_add(&t_cnt[(size_t)v * EP + s], (CT)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    __hip_atomic_fetch_add(&t_sum[(size_t)v * EP + s], d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    __hip_atomic_fetch_add(&t_sum2[(size_t)v * EP + s], d * d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                }
+            for (int u = 0; u < U; ++u) {
+                if (!todo[u]) continue;
+                const uint32_t sl = slot_of(kk[u]);
+                if (sl == 0xffffffffu) failed = true;
+                else accumulate(sl, pp[u]);
             }
         }
     };
 
-    // every wave streams whole queue blocks of this bucket (block w, w + waves, ...), two records per lane in flight
-    constexpr int PW = MERGE ? 1 + 3 * NV : NV;
-    unsigned long long reserved = G.qcount[bucket];
-    if (reserved > G.cap) reserved = G.cap; // (overflowed reservations hold nothing)
-    const uint32_t nblk = (uint32_t)(reserved / G.blk);
-    const uint64_t qb = (uint64_t)bucket * G.cap;
-    for (uint32_t b = wave; b < nblk; b += nwave) {
-        const uint32_t fill = G.tab[(size_t)bucket * G.tab_stride + b];
-        const uint64_t lo = qb + (uint64_t)b * G.blk;
-        for (uint32_t j0 = 0; j0 < fill; j0 += 128u) {
-            const uint32_t ja = j0 + lane, jb = j0 + 64u + lane;
-            const bool va = ja < fill, vb = jb < fill;
-            const long long ka = G.qkey[lo + (va ? ja : 0u)], kb = G.qkey[lo + (vb ? jb : 0u)];
-            uint64_t pa[PW], pb[PW];
-#pragma unroll
-            for (int w = 0; w < PW; ++w) { pa[w] = G.qw[w][lo + (va ? ja : 0u)]; pb[w] = G.qw[w][lo + (vb ? jb : 0u)]; }
-            if (va) apply(ka, pa);
-            if (vb) apply(kb, pb);
-        }
+    // every wave streams whole blocks of this bucket: the primary block of workgroup w, w + waves, ..., then the spare
+    // blocks this bucket owns
+    const uint32_t NB = 1u << G.nb_log2;
+    for (uint32_t g = wave; g < G.scatter_wgs; g += nwave) {
+        const uint32_t blk_id = g * NB + bucket;
+        const uint32_t fill = G.tab[blk_id];
+        if (fill) stream((uint64_t)blk_id * G.blk, fill);
+    }
+    const uint32_t used = min(*G.pool_used, G.pool);
+    for (uint32_t sp = wave; sp < used; sp += nwave) {
+        if (G.pool_owner[sp] != bucket) continue;
+        const uint32_t blk_id = G.scatter_wgs * NB + sp;
+        const uint32_t fill = G.tab[blk_id];
+        if (fill) stream((uint64_t)blk_id * G.blk, fill);
     }
     if (failed) atomicExch(G.overflow, 2u);
     __syncthreads();
 
     // compact the occupied slots into the result arrays: ONE device atomic per bucket reserves the range
     uint32_t mine = 0;
-    for (uint32_t s = tid; s < E; s += blockDim.x) mine += t_rows[s] != (CT)0 ? 1u : 0u;
+    auto rows_of = [&](uint32_t s) -> unsigned long long { return MERGE ? (unsigned long long)t_rows[s] : (t_rc[s] & 0xffffffffull); };
+    auto cnt_of = [&](int v, uint32_t s) -> unsigned long long { return (MERGE || v > 0) ? (unsigned long long)t_cnt[(size_t)v * EP + s] : (t_rc[s] >> 32); };
+    for (uint32_t s = tid; s < E; s += blockDim.x) mine += rows_of(s) != 0ull ? 1u : 0u;
     uint32_t inc = mine;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -344,12 +385,12 @@ __global__ void __launch_bounds__(1024) gb_reduce(const GbArgs G) {
     if (s_misc[1] == 0xffffffffu) return;
     uint64_t o = (uint64_t)s_misc[1] + before + inc - mine;
     for (uint32_t s = tid; s < E; s += blockDim.x) {
-        if (t_rows[s] == (CT)0) continue;
+        if (rows_of(s) == 0ull) continue;
         G.out_key[o] = s == SLOTS ? GB_EMPTY : (long long)t_key[s];
-        G.out_w[0][o] = (uint64_t)t_rows[s];
+        G.out_w[0][o] = (uint64_t)rows_of(s);
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
-            G.out_w[1 + 3 * v][o] = (uint64_t)t_cnt[(size_t)v * EP + s];
+            G.out_w[1 + 3 * v][o] = (uint64_t)cnt_of(v, s);
             G.out_w[2 + 3 * v][o] = (uint64_t)__double_as_longlong(t_sum[(size_t)v * EP + s]);
             G.out_w[3 + 3 * v][o] = (uint64_t)__double_as_longlong(t_sum2[(size_t)v * EP + s]);
         }
@@ -439,8 +480,8 @@ void launch_scatter(const GbArgs &G, int blocks, hipStream_t st) {
 template <int NV, bool MERGE>
 void launch_reduce(const GbArgs &G, hipStream_t st) {
     const size_t EP = ((((size_t)1 << G.slots_log2) + 1) + 1) & ~(size_t)1;
-    const size_t ct = MERGE ? 8 : 4;
-    const size_t lds = EP * (8 + 16 * (size_t)NV + ct * (1 + (size_t)NV)) + 18 * 4 + 16;
+    const size_t counters = MERGE ? (size_t)8 * (1 + NV) : (size_t)8 + (size_t)4 * (NV - 1);
+    const size_t lds = EP * (8 + 16 * (size_t)NV + counters) + 18 * 4 + 16;
     (void)hipFuncSetAttribute((const void *)gb_reduce<NV, MERGE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL((gb_reduce<NV, MERGE>), dim3(1u << G.nb_log2), dim3(1024), lds, st, G);
 }
@@ -450,8 +491,12 @@ void launch_reduce(const GbArgs &G, hipStream_t st) {
 unsigned run_pipeline(GbArgs &G, int nv, bool merge, uint64_t n, uint64_t groups_hint, int cus, hipStream_t st, vxh_groupby *res) {
     GbScratch &S = gb_scratch();
     const int w = merge ? 1 + 3 * nv : nv;
+    // rows per thread per tile.  One payload word: 8 (128 KiB of staging, one workgroup per CU).  Measured per 1e9 rows
+    // (profiles/r02_groupby.txt): 8 rows / 1 workgroup per CU 9.8 ms; 3 rows / 2 workgroups per CU 13.6 ms — the three
+    // barriers per tile cost more than the overlap of two workgroups' phases buys when a thread has only 3 rows between them.
     const int R = w == 1 ? 8 : (w == 2 ? 4 : (w <= 4 ? 2 : 1));
     const uint64_t T = 1024ull * R;
+    const int per_cu = 1;
     // LDS table of a bucket: 4096 slots x (key 8 + sum 8 + sum2 8 + rows 4 + count 4) = 128 KiB with one value column;
     // 2048 slots with two, and when merging (64-bit counters)
     const int slots_log2 = (nv == 1 && !merge) ? 12 : 11;
@@ -461,30 +506,33 @@ unsigned run_pipeline(GbArgs &G, int nv, bool merge, uint64_t n, uint64_t groups
     hipEvent_t e0, e1, e2;
     HIP_CHECK(hipEventCreate(&e0)); HIP_CHECK(hipEventCreate(&e1)); HIP_CHECK(hipEventCreate(&e2));
     unsigned code = 0;
+    uint64_t slack = 1;
     for (int attempt = 0; attempt < 6; ++attempt) {
         const uint64_t NB = (uint64_t)1 << nb_log2;
-        const int blocks = (int)std::max<uint64_t>(1, std::min<uint64_t>((n + T - 1) / T, (uint64_t)cus));
-        // one block per (workgroup, bucket) sized for its expected share + 1/4 + a tile's worth; room for every
-        // workgroup's first block and 16 more
-        uint64_t B = (uint64_t)((double)n / (double)((uint64_t)blocks * NB) * 1.25) + 2 * (T / NB + 1) + 64;
-        B = (B + 3) & ~(uint64_t)3;
-        if (attempt >= 2) B *= 2; // (a skewed bucket ran out of queue: more slack)
-        const uint64_t cap = ((uint64_t)blocks + 16) * B;
-        if (cap >= (1ull << 32)) { code = 9; break; }
-        const uint64_t tab_stride = cap / B + 1;
+        const int blocks = (int)std::max<uint64_t>(1, std::min<uint64_t>((n + T - 1) / T, (uint64_t)cus * per_cu));
+        // a (workgroup, bucket) block: the pair's expected share of the rows + 1/4, at least a few tiles' worth of one
+        // bucket; spare blocks for a quarter of the pairs (skew), more on retry
+        uint64_t B = (uint64_t)((double)n / (double)((uint64_t)blocks * NB) * 1.25) + 4 * (T / NB + 1) + 64;
+        B = ((B + 3) & ~(uint64_t)3) * slack;
+        B = std::min<uint64_t>(B, ((n + 3) & ~(uint64_t)3) + 64); // (a block never needs more room than every row)
+        const uint64_t primaries = (uint64_t)blocks * NB;
+        const uint64_t pool = std::max<uint64_t>(64, primaries / 4);
+        const uint64_t total_blocks = primaries + pool;
+        if (total_blocks * B >= (1ull << 32) || total_blocks * B * 8 * (uint64_t)(1 + w) > (96ull << 30)) { code = 9; break; }
         G.nv = nv; G.w = w; G.merge = merge ? 1 : 0; G.n = n;
         G.nb_log2 = nb_log2; G.slots_log2 = slots_log2;
-        G.blk = (uint32_t)B; G.cap = cap; G.tab_stride = (uint32_t)tab_stride;
-        S.queues.need(NB * cap * 8 * (size_t)(1 + w));
-        const size_t small_bytes = NB * 8 + NB * tab_stride * 4 + 64;
+        G.blk = (uint32_t)B; G.scatter_wgs = (uint32_t)blocks; G.pool = (uint32_t)pool;
+        S.queues.need(total_blocks * B * 8 * (size_t)(1 + w));
+        const size_t small_bytes = total_blocks * 4 + pool * 4 + 64;
         S.small.need(small_bytes);
         char *q = (char *)S.queues.p;
         G.qkey = (long long *)q;
-        for (int k = 0; k < w; k++) G.qw[k] = (uint64_t *)(q + NB * cap * 8 * (size_t)(1 + k));
-        G.qcount = (unsigned long long *)S.small.p;
-        G.tab = (uint32_t *)((char *)S.small.p + NB * 8);
-        G.overflow = (unsigned int *)((char *)S.small.p + NB * 8 + NB * tab_stride * 4);
-        G.out_count = (unsigned long long *)(G.overflow + 2);
+        for (int k = 0; k < w; k++) G.qw[k] = (uint64_t *)(q + total_blocks * B * 8 * (size_t)(1 + k));
+        G.tab = (uint32_t *)S.small.p;
+        G.pool_owner = G.tab + total_blocks;
+        G.overflow = G.pool_owner + pool;          // [0] code
+        G.pool_used = G.overflow + 1;              // [1]
+        G.out_count = (unsigned long long *)(G.overflow + 2); // [2..3]
         HIP_CHECK(hipMemsetAsync(S.small.p, 0, small_bytes, st));
         HIP_CHECK(hipEventRecord(e0, st));
         if (w == 1) launch_scatter<1, 8>(G, blocks, st);
@@ -518,7 +566,7 @@ unsigned run_pipeline(GbArgs &G, int nv, bool merge, uint64_t n, uint64_t groups
         } else if (code == 3) { // result arrays too small (the caller sized them from a hint): report
             break;
         }
-        // code 1: a bucket's queue was full — skewed keys: the retry doubles the block slack (attempt >= 2) after one plain retry
+        if (code == 1) slack *= 8; // out of spare blocks (few or skewed keys): eight times the room per block, as long as the scratch stays below 96 GiB
     }
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e2);
     return code;
