@@ -11,6 +11,7 @@
 #   oracle/_ref/superagg<ext>.so  superutils<ext>.so  vaexfast<ext>.so  superstrings<ext>.so
 #   oracle/_ref/overlay/          symlink overlay of the reference's pure-Python package
 #                                 (needed only HERE by oracle/make_goldens.py; gpurun-ignored)
+#   oracle/_ref/vaexpy/           the same package as plain files (travels to the GPU box: the drop-in test there)
 #
 # Usage: oracle/build_ref.sh [--minimal]   (--minimal: superagg only)
 set -euo pipefail
@@ -75,5 +76,14 @@ rich = vaex.progress:rich
 [vaex.dataframe.accessor]
 struct = vaex.struct:DataFrameAccessorStruct
 EOF
+    # The same package with the files themselves instead of symlinks (pure-Python modules only, no tests / images /
+    # datasets): what travels to the GPU box, where /root/reference does not exist, so that tests/test_vaex_dropin.py can
+    # drive the HIP classes through an UNMODIFIED vaex there.  Build output like the .so files above: under the
+    # git-ignored oracle/_ref/, never committed; test infrastructure, never imported by the product.
+    rm -rf $OUT/vaexpy
+    mkdir -p $OUT/vaexpy
+    (cd $REF && find vaex -name '*.py' -not -path 'vaex/test/*' -print0 | xargs -0 cp --parents -t $OUT/vaexpy)
+    for m in superagg superutils superstrings vaexfast; do ln -sf ../../$m$EXT $OUT/vaexpy/vaex/$m$EXT; done
+    cp -r $DI $OUT/vaexpy/
 fi
 echo "build_ref: done -> $OUT"

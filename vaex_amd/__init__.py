@@ -5,12 +5,14 @@ df.count/sum/mean/std(binby=...) and df.groupby().agg()), as hand-written HIP ke
 libvaexhip.so (C-ABI: include/vaex_hip.h) behind the reference's own class surface:
 
     vaex_amd.superagg      pybind11 shim with the classes of `vaex.superagg`
-    vaex_amd.install()     swap it into an (unmodified) vaex installation
+    vaex_amd.hashset       `vaex.superutils.ordered_set_<dtype>` on the GPU hash map
+    vaex_amd.install()     plug both into an (unmodified) vaex installation, task by task
     vaex_amd.vaexfast      the legacy `vaex.vaexfast.statisticNd_f8` entry on the same kernels
     vaex_amd.binned        host-side driver mirroring df.count/sum/mean/...(binby=, limits=, shape=)
     vaex_amd.dist          row-sharded multi-GPU reduce of the grids over RCCL
 
-There is no CPU fallback: without a GPU every compute call raises.
+There is no CPU fallback inside the library: without a GPU every compute call raises.  What install() falls
+back to for aggregations the HIP classes do not offer is vaex's OWN C++ — see `install`.
 """
 # torch (when present) must be imported BEFORE libvaexhip.so is loaded: torch ships its own
 # libamdhip64.so (SONAME libamdhip64.so.7); loading it first makes our library bind to the same
@@ -20,24 +22,146 @@ try:  # pragma: no cover - plumbing
 except Exception:  # torch is only needed for device tensors / torch.distributed
     _torch = None
 
+import threading as _threading
+
 from . import superagg  # noqa: E402  (fails loudly if the extension was not built)
 
-__all__ = ["superagg", "install"]
+__all__ = ["superagg", "install", "uninstall"]
+
+# names of the reference's vaex.superagg that the HIP module deliberately does not take over:
+#   BinnerHash_*   vaex's experimental hash binner (disabled by default, cells laid out differently, takes vaex's own
+#                  ordered_set): tasks that ask for it run on vaex's C++
+_HIDDEN_PREFIXES = ("BinnerHash_",)
+UNSUPPORTED = ("AggFirst_*", "AggList_*", "AggNUnique_*", "AggCount_string", "AggCount_object", "*_string / *_object aggregators", "BinnerCombined", "BinnerHash_*")
 
 
-def install(vaex_module=None, legacy=True):
-    """Make vaex use the HIP kernels: replaces the module attribute `vaex.superagg`, which vaex looks
-    classes up on by name at call time (vaex/utils.py:754-791, vaex/cpu.py:49-53, :646, vaex/agg.py:286-313).
-    legacy=True also points the legacy statistic task (df.minmax / limits=None: vaex/cpu.py:533-538) at
-    vaex_amd.vaexfast.statisticNd_f8; the float32 variant keeps the reference's CPU code (it scales in float32)."""
+class _Backend:
+    """What `vaex.superagg` is after install(): a per-thread switch between the HIP classes and vaex's own C++ module.
+
+    vaex looks classes up BY NAME on this object while it builds a task part (vaex/utils.py:754-791 from
+    vaex/cpu.py:44-65 and vaex/agg.py:278-321).  In "hip" mode a name the HIP module does not have raises AttributeError
+    — find_type_from_dtype turns that into its ValueError — and the task part is then rebuilt in "cpu" mode, i.e. entirely
+    from the reference's classes: a task is never a mix of the two (their grids are different objects)."""
+
+    def __init__(self, hip, cpu):
+        self.__dict__["_hip"] = hip
+        self.__dict__["_cpu"] = cpu
+        self.__dict__["_tls"] = _threading.local()
+        self.__dict__["__name__"] = "vaex.superagg"
+
+    def _mode(self):
+        return getattr(self._tls, "mode", "hip")
+
+    def use(self, mode):
+        backend = self
+
+        class _Ctx:
+            def __enter__(self_):
+                self_.prev = backend._mode()
+                backend._tls.mode = mode
+
+            def __exit__(self_, *exc):
+                backend._tls.mode = self_.prev
+                return False
+        return _Ctx()
+
+    def __getattr__(self, name):
+        if self._mode() == "cpu":
+            return getattr(self._cpu, name)
+        if name.startswith(_HIDDEN_PREFIXES):
+            raise AttributeError(name)
+        return getattr(self._hip, name)
+
+    def __dir__(self):
+        return dir(self._hip)
+
+
+_installed = {}
+
+
+def install(vaex_module=None, legacy=True, hash_sets=True):
+    """Plug the HIP kernels into an unmodified vaex.
+
+    * `vaex.superagg` becomes a `_Backend` and the task-part registry entry "aggregations" (vaex/cpu.py:629-631,
+      vaex/encoding.py:31-52) a subclass of vaex's TaskPartAggregation whose `decode` builds the task part from the HIP
+      classes and, when an aggregation or binner it needs is not among them (first / last / list / nunique, string and
+      object aggregators, BinnerCombined, BinnerHash: `vaex_amd.UNSUPPORTED`), builds it again from vaex's own C++ —
+      so everything that worked before install() still works, on the CPU, and everything on the hot path runs on the GPU.
+    * legacy=True points the legacy statistic task (df.minmax / limits=None: vaex/cpu.py:533-538) at
+      vaex_amd.vaexfast.statisticNd_f8 (the float32 variant keeps the reference's CPU code: it scales in float32).
+    * hash_sets=True replaces `vaex.hash.ordered_set_<dtype>` for the numeric dtypes (vaex/hash.py:49-52 looks them up
+      by name) with vaex_amd.hashset's GPU-backed classes: groupby's distinct-key pass and `_ordinal_values`."""
     import sys
     if vaex_module is None:
         import vaex as vaex_module
-    vaex_module.superagg = superagg
-    sys.modules["vaex.superagg"] = superagg
+    import vaex.cpu
+    if "backend" in _installed:
+        return _installed["backend"]
+    cpu_module = vaex_module.superagg
+    backend = _Backend(superagg, cpu_module)
+    _installed.update(backend=backend, cpu_module=cpu_module, vaex=vaex_module, task_cls=vaex.cpu.TaskPartAggregation)
+    vaex_module.superagg = backend
+    sys.modules["vaex.superagg"] = backend
+
+    base = vaex.cpu.TaskPartAggregation
+
+    class TaskPartAggregationHip(base):
+        snake_name = "aggregations"
+        backend_used = "hip"
+
+        @classmethod
+        def decode(cls, encoding, spec, df, nthreads):
+            with backend.use("hip"):
+                try:
+                    part = base.decode.__func__(cls, encoding, spec, df, nthreads)
+                    part.backend_used = "hip"
+                    return part
+                except (ValueError, TypeError, NotImplementedError) as e:
+                    if "Could not find a class" not in str(e) and not isinstance(e, NotImplementedError):
+                        raise
+            with backend.use("cpu"):
+                part = base.decode.__func__(cls, encoding, spec, df, nthreads)
+                part.backend_used = "cpu"
+                return part
+
+    vaex.cpu.register(TaskPartAggregationHip)
+    _installed["task_hip"] = TaskPartAggregationHip
     if legacy:
         from . import vaexfast as _vf
         legacy_mod = getattr(vaex_module, "vaexfast", None) or sys.modules.get("vaex.vaexfast")
         if legacy_mod is not None:
+            _installed["legacy"] = (legacy_mod, legacy_mod.statisticNd_f8)
             legacy_mod.statisticNd_f8 = _vf.statisticNd_f8
-    return superagg
+    if hash_sets:
+        import copyreg
+        import vaex.hash
+        from . import hashset
+        saved = {}
+        for name, cls in hashset.CLASSES.items():
+            attr = "ordered_set_" + name
+            if hasattr(vaex.hash, attr):
+                saved[attr] = getattr(vaex.hash, attr)
+                setattr(vaex.hash, attr, cls)
+                copyreg.pickle(cls, lambda x: x.__reduce__())
+        _installed["hash"] = saved
+        vaex.hash.ordered_set = tuple(vaex.hash.ordered_set) + tuple(hashset.CLASSES.values())
+    return backend
+
+
+def uninstall():
+    """undo install() (tests)"""
+    import sys
+    if "backend" not in _installed:
+        return
+    import vaex.cpu
+    import vaex.hash
+    vaex_module = _installed["vaex"]
+    vaex_module.superagg = _installed["cpu_module"]
+    sys.modules["vaex.superagg"] = _installed["cpu_module"]
+    vaex.cpu.register(_installed["task_cls"])
+    if "legacy" in _installed:
+        mod, fn = _installed["legacy"]
+        mod.statisticNd_f8 = fn
+    for attr, cls in _installed.get("hash", {}).items():
+        setattr(vaex.hash, attr, cls)
+    _installed.clear()
