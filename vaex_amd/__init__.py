@@ -126,6 +126,21 @@ def install(vaex_module=None, legacy=True, hash_sets=True):
 
     vaex.cpu.register(TaskPartAggregationHip)
     _installed["task_hip"] = TaskPartAggregationHip
+
+    base_h = vaex.cpu.TaskPartHashmapUniqueCreate
+
+    class TaskPartHashmapUniqueCreateHip(base_h):
+        """the distinct-key pass with a GPU-backed set: the executor compares the parts' memory_usage() with what its
+        tracker saw (vaex/execution.py:413-414) — sys.getsizeof of a Python object includes the GC header the
+        reference's pybind type does not have, so the bytes are asked from the set itself"""
+        snake_name = base_h.snake_name
+
+        def memory_usage(self):
+            internal = self.hash_map_unique._internal
+            return internal.bytes_used() if hasattr(internal, "bytes_used") else sys.getsizeof(internal)
+
+    _installed["hash_task_cls"] = base_h
+    vaex.cpu.register(TaskPartHashmapUniqueCreateHip)
     if legacy:
         from . import vaexfast as _vf
         legacy_mod = getattr(vaex_module, "vaexfast", None) or sys.modules.get("vaex.vaexfast")
@@ -159,6 +174,8 @@ def uninstall():
     vaex_module.superagg = _installed["cpu_module"]
     sys.modules["vaex.superagg"] = _installed["cpu_module"]
     vaex.cpu.register(_installed["task_cls"])
+    if "hash_task_cls" in _installed:
+        vaex.cpu.register(_installed["hash_task_cls"])
     if "legacy" in _installed:
         mod, fn = _installed["legacy"]
         mod.statisticNd_f8 = fn

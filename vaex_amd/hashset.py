@@ -253,8 +253,12 @@ class _OrderedSet:
         keys = self.key_array()
         return {k: i for i, k in enumerate(keys.tolist()) if i != self.null_index}
 
+    def bytes_used(self):
+        """bytes of the keys held (src/hash_primitives.hpp:64-71 counts (key, value) pairs the same way)"""
+        return int(len(self)) * 16
+
     def __sizeof__(self):
-        return int(len(self) * 16 * 2)  # {key, ordinal} slots at load <= 1/2 (bytes_used of the reference counts its buckets)
+        return self.bytes_used()
 
     def __reduce__(self):
         # vaex/hash.py:21-25 pickles sets as (type, (keys, null_index, nan_count, null_count, fingerprint))
