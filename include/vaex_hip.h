@@ -74,11 +74,36 @@ int vxh_synchronize(void);
 /* run slot `thread`'s work on a caller-owned hipStream_t (NULL = library-owned stream) */
 int vxh_slot_set_stream(int thread, void *hip_stream);
 /* tuning knobs for experiments and tests ("strategy", "part_chunk", "parts", "wv", "wv_waves", "blk", "hot", "hot_cache",
- * "count16", "stage_bytes", ...: the full list is the if-chain of vxh_config_set in vaex_amd/csrc/vxh_api.hip) */
+ * "count16", "stage_bytes", "feeder", "cache_bytes", ...: the full list is the if-chain of vxh_config_set in vaex_amd/csrc/vxh_api.hip) */
 int vxh_config_set(const char *key, int64_t value);
 int vxh_config_get(const char *key, int64_t *value);
 /* name of the kernel variant the last vxh_grid_bin on `thread` launched (for tests / bench) */
 const char *vxh_last_kernel(int thread);
+
+/* ---- chunk feeder and device column cache ---------------------------------------------- */
+/* vaex's executor hands the kernels one chunk (chunk_size rows, default 1 Mi) of every needed column at a time, from
+ * memory-mapped / numpy memory, once per pass and again on every later pass over the same columns
+ * (vaex/dataset.py:506-531 chunk_iterator; vaex/execution.py:283-292 one pass, :432-435 the pool's chunk loop).
+ * Host arrays handed to vxh_grid_bin (VXH_MEM_HOST) go through a per-slot feeder: a ring of 3 device arenas (knob
+ * "stage_bytes" each, grown on demand), the DMA on a copy stream of its own, event-chained to the slot's compute stream —
+ * the copy of chunk i+1 overlaps the kernels of chunk i, vxh_grid_bin never waits for kernels, and the caller's arrays are
+ * not read any more once it returns.  Knob "feeder": 1 (default) the engine reads the caller's memory; 2 the calling thread
+ * first copies into page-locked buffers of the ring, so the call returns before the DMA ran (a CPU pass per chunk: slower
+ * per thread, for callers whose threads must not wait for PCIe); 0 copies on the compute stream (no overlap inside a slot).
+ *
+ * vxh_cache_register declares [host, host+bytes) immutable until vxh_cache_unregister (a memory-mapped column, a numpy
+ * column of a DataFrame): chunks inside such ranges are kept in HBM, keyed by (pointer, bytes), least-recently-used within
+ * the knob "cache_bytes" (default 64 GiB of the 288), and the next pass over them runs at HBM speed.  With VXH_CACHE_PIN the
+ * range is also page-locked (hipHostRegister), so the DMA engine reads it in place without the CPU copy into the ring.
+ * *pinned (may be NULL) tells whether the range got page-locked. */
+enum { VXH_CACHE_PIN = 1 };
+int vxh_cache_register(const void *host, uint64_t bytes, int flags, int *pinned);
+/* forget the range and free its chunks (waits for device work that may be reading them) */
+int vxh_cache_unregister(const void *host);
+/* free every cached chunk, keep the registrations */
+int vxh_cache_clear(void);
+/* out = {bytes cached, chunks cached, hits, misses, evictions, registered ranges} */
+int vxh_cache_stats(uint64_t out[6]);
 
 /* ---- binners ------------------------------------------------------------------------- */
 /* BinnerScalar<T,…,FlipEndian>(threads, expression, vmin, vmax, bins) — src/binners.cpp:9-12, :97 */

@@ -26,7 +26,7 @@ import threading as _threading
 
 from . import superagg  # noqa: E402  (fails loudly if the extension was not built)
 
-__all__ = ["superagg", "install", "uninstall"]
+__all__ = ["superagg", "install", "uninstall", "cache_columns", "uncache_columns"]
 
 # names of the reference's vaex.superagg that the HIP module deliberately does not take over:
 #   BinnerHash_*   vaex's experimental hash binner (disabled by default, cells laid out differently, takes vaex's own
@@ -79,7 +79,7 @@ class _Backend:
 _installed = {}
 
 
-def install(vaex_module=None, legacy=True, hash_sets=True):
+def install(vaex_module=None, legacy=True, hash_sets=True, chunk_size=None):
     """Plug the HIP kernels into an unmodified vaex.
 
     * `vaex.superagg` becomes a `_Backend` and the task-part registry entry "aggregations" (vaex/cpu.py:629-631,
@@ -90,7 +90,10 @@ def install(vaex_module=None, legacy=True, hash_sets=True):
     * legacy=True points the legacy statistic task (df.minmax / limits=None: vaex/cpu.py:533-538) at
       vaex_amd.vaexfast.statisticNd_f8 (the float32 variant keeps the reference's CPU code: it scales in float32).
     * hash_sets=True replaces `vaex.hash.ordered_set_<dtype>` for the numeric dtypes (vaex/hash.py:49-52 looks them up
-      by name) with vaex_amd.hashset's GPU-backed classes: groupby's distinct-key pass and `_ordinal_values`."""
+      by name) with vaex_amd.hashset's GPU-backed classes: groupby's distinct-key pass and `_ordinal_values`.
+    * chunk_size=N sets vaex.settings.main.chunk.size (vaex/execution.py:283-292; default: rows / threads bracketed by
+      [size_min, size_max = 1 Mi]): the kernels reach their full rate on chunks of 16 Mi rows and more, a 1 Mi-row chunk
+      is bound by its fixed costs."""
     import sys
     if vaex_module is None:
         import vaex as vaex_module
@@ -147,6 +150,9 @@ def install(vaex_module=None, legacy=True, hash_sets=True):
         if legacy_mod is not None:
             _installed["legacy"] = (legacy_mod, legacy_mod.statisticNd_f8)
             legacy_mod.statisticNd_f8 = _vf.statisticNd_f8
+    if chunk_size is not None:
+        _installed["chunk_size"] = vaex_module.settings.main.chunk.size
+        vaex_module.settings.main.chunk.size = int(chunk_size)
     if hash_sets:
         import copyreg
         import vaex.hash
@@ -181,4 +187,63 @@ def uninstall():
         mod.statisticNd_f8 = fn
     for attr, cls in _installed.get("hash", {}).items():
         setattr(vaex.hash, attr, cls)
+    if "chunk_size" in _installed:
+        vaex_module.settings.main.chunk.size = _installed["chunk_size"]
     _installed.clear()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# device column cache (include/vaex_hip.h "chunk feeder and device column cache")
+# ---------------------------------------------------------------------------------------------------------------------
+_cached_arrays = {}
+
+
+def _host_arrays(obj, columns=None):
+    """the numpy arrays behind `obj`: a vaex DataFrame (df.columns: memory-mapped / numpy columns; virtual columns and
+    arrow columns are skipped), a dict of arrays, or one array"""
+    import numpy as np
+    if hasattr(obj, "columns") and hasattr(obj, "get_column_names"):
+        names = columns if columns is not None else list(obj.columns)
+        items = [(n, obj.columns[n]) for n in names if n in obj.columns]
+    elif isinstance(obj, dict):
+        items = [(n, a) for n, a in obj.items() if columns is None or n in columns]
+    else:
+        items = [("array", obj)]
+    out = []
+    for name, a in items:
+        if np.ma.isMaskedArray(a):
+            parts = [np.ma.getdata(a)] + ([np.ma.getmaskarray(a)] if a.mask is not np.ma.nomask else [])
+        elif isinstance(a, np.ndarray):
+            parts = [a]
+        else:
+            continue
+        for part in parts:
+            if part.ndim == 1 and part.flags.c_contiguous and part.dtype.kind in "iufb" and part.nbytes:
+                out.append(part)
+    return out
+
+
+def cache_columns(obj, columns=None, pin=True):
+    """Declare the columns' memory immutable and let their chunks stay in HBM between passes: the first
+    df.count/mean/...(binby=) over them streams the chunks across PCIe (straight from the page-locked columns when
+    `pin`), every later pass finds them on the device.  Returns the number of bytes registered.  The arrays are kept
+    alive until uncache_columns(); writing to them while registered gives stale results (vaex columns are immutable)."""
+    total = 0
+    for a in _host_arrays(obj, columns):
+        key = a.__array_interface__["data"][0]
+        if key in _cached_arrays:
+            continue
+        superagg.cache_register(a.view("u1") if a.dtype.kind == "b" else a, pin)
+        _cached_arrays[key] = a
+        total += a.nbytes
+    return total
+
+
+def uncache_columns(obj=None, columns=None):
+    """forget the columns registered by cache_columns (all of them when obj is None) and free their device chunks"""
+    arrays = list(_cached_arrays.values()) if obj is None else _host_arrays(obj, columns)
+    for a in arrays:
+        key = a.__array_interface__["data"][0]
+        if key in _cached_arrays:
+            superagg.cache_unregister(a.view("u1") if a.dtype.kind == "b" else a)
+            del _cached_arrays[key]

@@ -465,6 +465,30 @@ PYBIND11_MODULE(superagg, m) {
     m.def("synchronize", []() { py::gil_scoped_release r; check(vxh_synchronize()); });
     m.def("config_set", [](const std::string &k, int64_t v) { check(vxh_config_set(k.c_str(), v)); });
     m.def("config_get", [](const std::string &k) { int64_t v = 0; check(vxh_config_get(k.c_str(), &v)); return v; });
+    // device column cache (include/vaex_hip.h "chunk feeder and device column cache"): the array's memory is declared immutable
+    // until cache_unregister(array); returns whether it got page-locked
+    m.def("cache_register", [](const py::object &ar, bool pin) {
+        ArrayRef a = resolve_array(ar);
+        if (a.mem != VXH_MEM_HOST) throw std::runtime_error("cache_register: host arrays only");
+        int pinned = 0, rc;
+        { py::gil_scoped_release r; rc = vxh_cache_register(a.ptr, (uint64_t)a.n * a.itemsize, pin ? VXH_CACHE_PIN : 0, &pinned); }
+        check(rc);
+        return pinned != 0;
+    }, py::arg("array"), py::arg("pin") = true);
+    m.def("cache_unregister", [](const py::object &ar) {
+        ArrayRef a = resolve_array(ar);
+        int rc;
+        { py::gil_scoped_release r; rc = vxh_cache_unregister(a.ptr); }
+        check(rc);
+    });
+    m.def("cache_clear", []() { py::gil_scoped_release r; check(vxh_cache_clear()); });
+    m.def("cache_stats", []() {
+        uint64_t v[6];
+        check(vxh_cache_stats(v));
+        py::dict d;
+        d["bytes"] = v[0]; d["chunks"] = v[1]; d["hits"] = v[2]; d["misses"] = v[3]; d["evictions"] = v[4]; d["ranges"] = v[5];
+        return d;
+    });
     m.def("last_kernel", [](int thread) { return std::string(vxh_last_kernel(thread)); }, py::arg("thread") = 0);
     m.def("slot_set_stream", [](int thread, uintptr_t stream) { check(vxh_slot_set_stream(thread, (void *)stream)); });
     m.def("timer_start", [](int thread) { check(vxh_timer_start(thread)); }, py::arg("thread") = 0);

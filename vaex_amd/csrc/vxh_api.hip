@@ -89,7 +89,11 @@ Slot &get_slot(int thread) {
         HIP_CHECK(hipSetDevice(c.device));
         HIP_CHECK(hipStreamCreateWithFlags(&s->own_stream, hipStreamNonBlocking));
         s->stream = s->own_stream;
-        for (auto &st : s->stage) HIP_CHECK(hipEventCreateWithFlags(&st.done, hipEventDisableTiming));
+        for (auto &st : s->stage) {
+            HIP_CHECK(hipEventCreateWithFlags(&st.done, hipEventDisableTiming));
+            HIP_CHECK(hipEventCreateWithFlags(&st.copied, hipEventDisableTiming));
+        }
+        HIP_CHECK(hipStreamCreateWithFlags(&s->copy_stream, hipStreamNonBlocking));
         HIP_CHECK(hipEventCreateWithFlags(&s->after_null, hipEventDisableTiming));
         HIP_CHECK(hipEventCreate(&s->t0));
         HIP_CHECK(hipEventCreate(&s->t1));
@@ -340,39 +344,215 @@ static void agg_ensure_device_locked(vxh_agg *a) {
 }
 
 // ------------------------------------------------------------------------------------------
-// host-chunk staging
+// device column cache: chunks of host ranges the caller declared immutable stay in HBM between calls
+// ------------------------------------------------------------------------------------------
+// vaex aggregates the same memory-mapped columns over and over (every df.count / df.mean / selection change is a new
+// pass over the same 1 Mi-row chunks: vaex/execution.py:283-292, :432-435); with the columns registered here the
+// second pass finds its chunks in HBM and runs at HBM speed instead of PCIe speed.  Registration is explicit because
+// only the caller knows that a range is immutable (a memory-mapped column) — scratch arrays of evaluated expressions
+// re-use their addresses with different contents.  Entries are keyed by (host pointer, bytes): the executor's chunking
+// is deterministic, so a repeated pass asks for exactly the same pieces.  LRU within cfg_cache_bytes.
+struct ColumnCache {
+    struct Entry {
+        void *dev = nullptr;
+        size_t bytes = 0;
+        uint64_t last_use = 0;
+        int in_use = 0;             // calls that resolved it and have not enqueued their kernels yet: not evictable
+        hipEvent_t ready = nullptr; // the DMA that fills the entry
+    };
+    std::mutex mutex;
+    struct Range { size_t bytes; bool pinned; };
+    std::map<uintptr_t, Range> ranges; // start -> the registered (immutable) host ranges; pinned: page-locked with hipHostRegister
+    std::map<std::pair<const void *, size_t>, Entry> entries;
+    size_t used = 0;
+    uint64_t tick = 0, hits = 0, misses = 0, evictions = 0;
+
+    // 0: not inside a registered range, 1: inside one, 2: inside a page-locked one (the DMA engine can read it directly)
+    int covered(const void *p, size_t bytes) {
+        if (ranges.empty()) return 0;
+        auto it = ranges.upper_bound((uintptr_t)p);
+        if (it == ranges.begin()) return 0;
+        --it;
+        if ((uintptr_t)p < it->first || (uintptr_t)p + bytes > it->first + it->second.bytes) return 0;
+        return it->second.pinned ? 2 : 1;
+    }
+    void drop_locked(std::map<std::pair<const void *, size_t>, Entry>::iterator it) {
+        (void)hipFree(it->second.dev);
+        if (it->second.ready) (void)hipEventDestroy(it->second.ready);
+        used -= it->second.bytes;
+        entries.erase(it);
+    }
+    void drop_range_locked(uintptr_t start, size_t bytes) {
+        bool synced = false;
+        for (auto it = entries.begin(); it != entries.end();) {
+            const uintptr_t p = (uintptr_t)it->first.first;
+            if (p >= start && p < start + bytes) {
+                if (!synced) { (void)hipDeviceSynchronize(); synced = true; }
+                auto victim = it++;
+                drop_locked(victim);
+            } else {
+                ++it;
+            }
+        }
+    }
+};
+static ColumnCache &column_cache() {
+    static ColumnCache *c = new ColumnCache();
+    return *c;
+}
+
+// ------------------------------------------------------------------------------------------
+// host-chunk staging (the chunk feeder: see Slot::Stage)
 // ------------------------------------------------------------------------------------------
 struct Stager {
     Slot &slot;
     Slot::Stage &stage;
     size_t used = 0;
+    int feeder; // Context::cfg_feeder: 0 plain, 1 copy stream, 2 copy stream through the page-locked ring
+    bool copied_anything = false, wait_copied = false;
     std::map<std::pair<const void *, size_t>, const void *> seen;
-    Stager(Slot &s) : slot(s), stage(s.stage[s.cur]) {}
+    std::vector<std::pair<const void *, size_t>> held; // cache entries this call reads
+    Stager(Slot &s) : slot(s), stage(s.stage[s.cur]), feeder((int)ctx().cfg_feeder) {}
 
-    // total bytes are reserved up-front by the caller via reserve()
-    void reserve(size_t bytes) {
-        // the kernels of the previous use of this arena must have finished
+    // total bytes of the call's host arrays, stated up-front; the ring entry is only touched (waited for, grown) when an
+    // array really has to go through it — a call whose arrays are all in the column cache needs neither
+    size_t need = 0;
+    bool have = false;
+    void reserve(size_t bytes) { need = bytes; }
+    void ensure() {
+        if (have) return;
+        have = true;
+        // the kernels of the previous use of this ring entry must have finished (they read the arena) — with a ring of
+        // VXH_STAGE_RING entries that was VXH_STAGE_RING calls ago
         HIP_CHECK(hipEventSynchronize(stage.done));
-        if (bytes > stage.cap) {
+        if (need > stage.cap) {
             if (stage.dev) HIP_CHECK(hipFree(stage.dev));
-            size_t cap = std::max(bytes, (size_t)ctx().cfg_stage_bytes);
+            if (stage.pinned) HIP_CHECK(hipHostFree(stage.pinned));
+            stage.dev = stage.pinned = nullptr;
+            stage.cap = 0;
+            size_t cap = std::max(need, (size_t)ctx().cfg_stage_bytes);
             HIP_CHECK(hipMalloc(&stage.dev, cap));
             stage.cap = cap;
         }
     }
+    void ensure_pinned() {
+        ensure();
+        if (!stage.pinned) HIP_CHECK(hipHostMalloc(&stage.pinned, stage.cap, hipHostMallocDefault));
+    }
+    // host array -> device pointer the kernels of this call may read
     const void *put(const void *host, size_t bytes) {
         auto key = std::make_pair(host, bytes);
         auto it = seen.find(key);
         if (it != seen.end()) return it->second;
+        const void *dst = cached(host, bytes);
+        if (!dst) dst = stage_in(host, bytes);
+        seen[key] = dst;
+        return dst;
+    }
+    // DMA of `bytes` at `host` to `dst` (device).  `locked`: the source is page-locked and immutable (a registered range), the
+    // engine reads it in place; otherwise the bytes go through this call's pinned ring entry at `off`.
+    void dma(void *dst, const void *host, size_t bytes, size_t off, bool locked) {
+        if (locked || feeder == 1) {
+            // a pageable source is pinned / staged by the runtime and consumed when this returns; a page-locked one is read
+            // by the engine later: registered ranges are immutable, for anything else finish() waits for `copied`
+            HIP_CHECK(hipMemcpyAsync(dst, host, bytes, hipMemcpyHostToDevice, slot.copy_stream));
+            copied_anything = true;
+            if (!locked) wait_copied = true;
+        } else if (feeder == 2) {
+            ensure_pinned();
+            memcpy((char *)stage.pinned + off, host, bytes); // (the caller's memory is not read after this)
+            HIP_CHECK(hipMemcpyAsync(dst, (char *)stage.pinned + off, bytes, hipMemcpyHostToDevice, slot.copy_stream));
+            copied_anything = true;
+        } else {
+            HIP_CHECK(hipMemcpyAsync(dst, host, bytes, hipMemcpyHostToDevice, slot.stream));
+        }
+    }
+    const void *stage_in(const void *host, size_t bytes, bool locked = false) {
+        ensure();
         size_t off = (used + 255) & ~(size_t)255;
         if (off + bytes > stage.cap) throw std::runtime_error("internal: staging arena overflow");
         void *dst = (char *)stage.dev + off;
-        // pageable source: the runtime stages it through its own pinned buffers and returns once the
-        // source has been consumed, which is exactly the lifetime vaex guarantees (vaex/cpu.py:708-710)
-        HIP_CHECK(hipMemcpyAsync(dst, host, bytes, hipMemcpyHostToDevice, slot.stream));
+        dma(dst, host, bytes, off, locked);
         used = off + bytes;
-        seen[key] = dst;
         return dst;
+    }
+    // a chunk of a registered (immutable) host range: served from / entered into the device column cache
+    const void *cached(const void *host, size_t bytes) {
+        ColumnCache &cc = column_cache();
+        std::lock_guard<std::mutex> lock(cc.mutex);
+        const int cov = cc.covered(host, bytes);
+        if (!cov) return nullptr;
+        const bool locked = cov == 2;
+        auto key = std::make_pair(host, bytes);
+        auto it = cc.entries.find(key);
+        if (it != cc.entries.end()) {
+            cc.hits++;
+            it->second.last_use = ++cc.tick;
+            it->second.in_use++;
+            held.push_back(key);
+            HIP_CHECK(hipStreamWaitEvent(slot.stream, it->second.ready, 0)); // (another slot may still be filling it)
+            return it->second.dev;
+        }
+        cc.misses++;
+        const size_t budget = (size_t)std::max<int64_t>(0, ctx().cfg_cache_bytes);
+        if (bytes > budget) return locked ? stage_in(host, bytes, true) : nullptr;
+        while (cc.used + bytes > budget) { // evict the least recently used entries no call in progress holds
+            auto victim = cc.entries.end();
+            for (auto jt = cc.entries.begin(); jt != cc.entries.end(); ++jt)
+                if (jt->second.in_use == 0 && (victim == cc.entries.end() || jt->second.last_use < victim->second.last_use)) victim = jt;
+            if (victim == cc.entries.end()) return locked ? stage_in(host, bytes, true) : nullptr;
+            HIP_CHECK(hipDeviceSynchronize()); // (enqueued kernels of any slot may still be reading it)
+            cc.drop_locked(victim);
+            cc.evictions++;
+        }
+        ColumnCache::Entry e;
+        if (hipMalloc(&e.dev, bytes) != hipSuccess) { // HBM full: not cached
+            (void)hipGetLastError();
+            return locked ? stage_in(host, bytes, true) : nullptr;
+        }
+        e.bytes = bytes;
+        e.last_use = ++cc.tick;
+        e.in_use = 1;
+        held.push_back(key);
+        HIP_CHECK(hipEventCreateWithFlags(&e.ready, hipEventDisableTiming));
+        size_t off = (used + 255) & ~(size_t)255;
+        const bool through_ring = !locked && feeder == 2;
+        dma(e.dev, host, bytes, off, locked);
+        if (through_ring) used = off + bytes; // (the pinned bytes are in use until the DMA is done: `copied` / `done` cover them)
+        hipStream_t filled_on = (locked || feeder) ? slot.copy_stream : slot.stream;
+        HIP_CHECK(hipEventRecord(e.ready, filled_on));
+        if (filled_on != slot.stream) HIP_CHECK(hipStreamWaitEvent(slot.stream, e.ready, 0));
+        cc.used += bytes;
+        cc.entries[key] = e;
+        return e.dev;
+    }
+    // all arrays of the call are on their way: the kernels (about to be enqueued on slot.stream) wait for the DMA
+    void ready() {
+        if (copied_anything) {
+            HIP_CHECK(hipEventRecord(stage.copied, slot.copy_stream));
+            HIP_CHECK(hipStreamWaitEvent(slot.stream, stage.copied, 0));
+            copied_anything = false;
+        }
+    }
+    // the kernels are enqueued: `done` frees the ring entry; without the feeder the call must not return before the
+    // copies have consumed the caller's memory (true for pageable sources anyway; a page-locked source needs the wait)
+    void finish() {
+        if (!held.empty()) {
+            ColumnCache &cc = column_cache();
+            std::lock_guard<std::mutex> lock(cc.mutex);
+            for (auto &key : held) {
+                auto it = cc.entries.find(key);
+                if (it != cc.entries.end() && it->second.in_use > 0) it->second.in_use--;
+            }
+            held.clear();
+        }
+        HIP_CHECK(hipEventRecord(stage.done, slot.stream));
+        // (ensure() waits for `done` on the host before the entry is refilled, so the copy stream needs no wait of its own)
+        // the caller may overwrite its arrays as soon as this returns: plain copies of pageable memory have consumed them
+        // already, copies of page-locked memory the library does not know about have not
+        if (feeder == 0) HIP_CHECK(hipStreamSynchronize(slot.stream));
+        else if (wait_copied) HIP_CHECK(hipStreamSynchronize(slot.copy_stream));
+        slot.cur = (slot.cur + 1) % VXH_STAGE_RING;
     }
 };
 
@@ -1068,6 +1248,69 @@ int vxh_synchronize(void) {
     VXH_API_END
 }
 
+int vxh_cache_register(const void *host, uint64_t bytes, int flags, int *pinned_out) {
+    VXH_API_BEGIN
+    ensure_device_ready();
+    if (!host || !bytes) throw std::runtime_error("vxh_cache_register: empty range");
+    ColumnCache &cc = column_cache();
+    bool pinned = false;
+    if (flags & VXH_CACHE_PIN) {
+        // page-lock the caller's range (read-only mappings of files need the read-only flag; either way a failure is not an
+        // error: the range is then fed through the pinned ring like any other host array)
+        hipError_t e = hipHostRegister((void *)host, bytes, hipHostRegisterDefault);
+        if (e != hipSuccess) { (void)hipGetLastError(); e = hipHostRegister((void *)host, bytes, hipHostRegisterReadOnly); }
+        if (e != hipSuccess) (void)hipGetLastError();
+        pinned = e == hipSuccess;
+    }
+    std::lock_guard<std::mutex> lock(cc.mutex);
+    const uintptr_t a = (uintptr_t)host;
+    for (auto &kv : cc.ranges)
+        if (a < kv.first + kv.second.bytes && kv.first < a + bytes) {
+            if (pinned) (void)hipHostUnregister((void *)host);
+            throw std::runtime_error("vxh_cache_register: the range overlaps a registered one");
+        }
+    cc.ranges[a] = ColumnCache::Range{(size_t)bytes, pinned};
+    if (pinned_out) *pinned_out = pinned ? 1 : 0;
+    VXH_API_END
+}
+
+int vxh_cache_unregister(const void *host) {
+    VXH_API_BEGIN
+    ColumnCache &cc = column_cache();
+    std::lock_guard<std::mutex> lock(cc.mutex);
+    auto it = cc.ranges.find((uintptr_t)host);
+    if (it == cc.ranges.end()) throw std::runtime_error("vxh_cache_unregister: not a registered range");
+    cc.drop_range_locked(it->first, it->second.bytes); // (waits for the device: copies and kernels may be reading it)
+    if (it->second.pinned) {
+        HIP_CHECK(hipDeviceSynchronize());
+        (void)hipHostUnregister((void *)host);
+    }
+    cc.ranges.erase(it);
+    VXH_API_END
+}
+
+int vxh_cache_clear(void) {
+    VXH_API_BEGIN
+    ColumnCache &cc = column_cache();
+    std::lock_guard<std::mutex> lock(cc.mutex);
+    if (!cc.entries.empty()) HIP_CHECK(hipDeviceSynchronize());
+    while (!cc.entries.empty()) cc.drop_locked(cc.entries.begin());
+    VXH_API_END
+}
+
+int vxh_cache_stats(uint64_t out[6]) {
+    VXH_API_BEGIN
+    ColumnCache &cc = column_cache();
+    std::lock_guard<std::mutex> lock(cc.mutex);
+    out[0] = cc.used;
+    out[1] = cc.entries.size();
+    out[2] = cc.hits;
+    out[3] = cc.misses;
+    out[4] = cc.evictions;
+    out[5] = cc.ranges.size();
+    VXH_API_END
+}
+
 int vxh_slot_set_stream(int thread, void *hip_stream) {
     VXH_API_BEGIN
     ensure_device_ready();
@@ -1086,6 +1329,8 @@ int vxh_config_set(const char *key, int64_t value) {
     else if (k == "block") c.cfg_block = value;
     else if (k == "blocks") c.cfg_blocks = value;
     else if (k == "stage_bytes") c.cfg_stage_bytes = value;
+    else if (k == "feeder") c.cfg_feeder = value;
+    else if (k == "cache_bytes") c.cfg_cache_bytes = value;
     else if (k == "slab_log2") c.cfg_slab_log2 = value;
     else if (k == "part_chunk") c.cfg_part_chunk = value > 0 ? value : (1ll << 28);
     else if (k == "parts") c.cfg_parts = value;
@@ -1122,6 +1367,8 @@ int vxh_config_get(const char *key, int64_t *value) {
     else if (k == "block") *value = c.cfg_block;
     else if (k == "blocks") *value = c.cfg_blocks;
     else if (k == "stage_bytes") *value = c.cfg_stage_bytes;
+    else if (k == "feeder") *value = c.cfg_feeder;
+    else if (k == "cache_bytes") *value = c.cfg_cache_bytes;
     else if (k == "slab_log2") *value = c.cfg_slab_log2;
     else if (k == "part_chunk") *value = c.cfg_part_chunk;
     else if (k == "parts") *value = c.cfg_parts;
@@ -1341,6 +1588,11 @@ int vxh_grid_bin(vxh_grid *grid, int thread, vxh_agg *const *aggs, int n_aggs, u
         if (sd.mem == VXH_MEM_DEVICE) return sd.ptr;
         return stager.put(sd.ptr, length * elem);
     };
+    struct StageGuard { // (a failing call must still release the ring entry)
+        Stager &st;
+        bool active, done = false;
+        ~StageGuard() { if (active && !done) { try { st.finish(); } catch (...) {} } }
+    } stage_guard{stager, stage_bytes != 0};
 
     // distinct bytes streamed per row (an array registered twice, e.g. count(x) binby x, is read once)
     double bytes_per_row = 0;
@@ -1409,6 +1661,7 @@ int vxh_grid_bin(vxh_grid *grid, int thread, vxh_agg *const *aggs, int n_aggs, u
             replicas = std::min(replicas, a->replicas);
         }
         A.replicas = replicas;
+        stager.ready(); // the kernels below wait for the DMA of the arrays resolved so far
         // plan once on the whole call: it fixes the strategy, hence the row step of the launches
         uint64_t step = kMaxRows;
         BinArgs whole_args;
@@ -1471,8 +1724,8 @@ int vxh_grid_bin(vxh_grid *grid, int thread, vxh_agg *const *aggs, int n_aggs, u
     }
     part_join(slot);
     if (stage_bytes) {
-        HIP_CHECK(hipEventRecord(stager.stage.done, slot.stream));
-        slot.cur ^= 1;
+        stager.finish();
+        stage_guard.done = true;
     }
     VXH_API_END
 }

@@ -9,6 +9,7 @@
 #include "vxh_kernels.hpp"
 
 #define VXH_MAX_SLOTS 256
+#define VXH_STAGE_RING 3
 
 void vxh_hip_check(hipError_t e, const char *what, const char *file, int line);
 #define HIP_CHECK(expr) vxh_hip_check((expr), #expr, __FILE__, __LINE__)
@@ -65,11 +66,21 @@ struct vxh_agg {
 struct Slot {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
+    // Chunk feeder (host chunks of a vxh_grid_bin call): a ring of VXH_STAGE_RING device arenas per slot.  The DMA into
+    // the arena runs on `copy_stream`, the kernels on `stream` wait for the `copied` event, and `done` (recorded behind the
+    // kernels) frees the entry for re-use — so the copy of chunk i+1 overlaps the binning of chunk i within ONE slot and
+    // vxh_grid_bin never waits for kernels.  cfg_feeder 1: the engine reads the caller's memory (pageable: pinned / staged
+    // by the runtime, consumed when the copy call returns; page-locked: vxh_grid_bin waits for the copies before it
+    // returns).  cfg_feeder 2: the calling thread copies the arrays into the entry's page-locked buffer first, so the call
+    // returns before the DMA has run — for callers whose threads must not wait for PCIe (costs a CPU pass over the chunk).
     struct Stage {
         void *dev = nullptr;
+        void *pinned = nullptr;
         size_t cap = 0;
-        hipEvent_t done = nullptr;
-    } stage[2];
+        hipEvent_t done = nullptr;   // the kernels that read the arena have finished
+        hipEvent_t copied = nullptr; // the DMA into the arena has finished
+    } stage[VXH_STAGE_RING];
+    hipStream_t copy_stream = nullptr;
     int cur = 0;
     hipEvent_t t0 = nullptr, t1 = nullptr;
     hipEvent_t after_null = nullptr; // order_after_producers()
@@ -128,6 +139,8 @@ struct Context {
     int64_t cfg_block = 0;
     int64_t cfg_blocks = 0;
     int64_t cfg_stage_bytes = 64 << 20;
+    int64_t cfg_feeder = 1;       // host chunks: 1 copy stream + arena ring, 2 the same through page-locked buffers (see Slot::Stage), 0 copies on the compute stream
+    int64_t cfg_cache_bytes = 64ll << 30; // device column cache budget (only ranges registered with vxh_cache_register are cached)
     int64_t cfg_slab_log2 = -1;   // -1 = auto
     int64_t cfg_lds_replicas = 0; // 0 = auto
     int64_t cfg_part_chunk = 1 << 28; // rows per partition chunk (scratch: ~2 x record bytes x this; larger chunks amortise the launches)
