@@ -60,6 +60,7 @@ typedef struct vxh_binner vxh_binner;
 typedef struct vxh_grid vxh_grid;
 typedef struct vxh_agg vxh_agg;
 typedef struct vxh_hashmap vxh_hashmap;
+typedef struct vxh_selection vxh_selection;
 
 /* ---- library ------------------------------------------------------------------------- */
 int vxh_abi_version(void);
@@ -155,6 +156,32 @@ int vxh_agg_set_data(vxh_agg *agg, int thread, const void *data, uint64_t n, int
 int vxh_agg_set_data_mask(vxh_agg *agg, int thread, const uint8_t *mask, uint64_t n, int mem);
 /* clear_data_mask(thread) — src/agg_base.hpp:148-151 */
 int vxh_agg_clear_data_mask(vxh_agg *agg, int thread);
+
+/* ---- device-side selections -------------------------------------------------------------- */
+/* The reference evaluates a selection ("(x > 0) & (v < 3.5)") with numpy on every chunk (vaex/execution.py:530-549,
+ * vaex/scopes.py:138-177) and hands the boolean array to the aggregators as their data mask (vaex/cpu.py:740-784).
+ * A vxh_selection carries the predicate instead: up to 4 terms `column <op> constant` over up to 4 columns, and a truth
+ * table — bit b of `truth` says whether a row is kept when the terms' outcomes, term t in bit t, spell b (so any
+ * combination of & | ~ of the terms is one 16-bit number).  The library evaluates it on the GPU into the keep-mask the
+ * kernels read: no host pass over the chunk and no mask bytes over PCIe.  Comparisons follow numpy: NaN makes every
+ * comparison false except !=; an integer column is compared exactly with an integer constant (is_int, ivalue) and as
+ * float64 with a float constant.  Columns are native-endian. */
+typedef enum vxh_cmp { VXH_CMP_LT = 0, VXH_CMP_LE = 1, VXH_CMP_GT = 2, VXH_CMP_GE = 3, VXH_CMP_EQ = 4, VXH_CMP_NE = 5 } vxh_cmp;
+typedef struct vxh_sel_term {
+    int32_t column; /* index into the selection's columns */
+    int32_t op;     /* vxh_cmp */
+    int32_t is_int; /* the constant is an integer: use ivalue for integer columns */
+    int32_t reserved;
+    double value;
+    int64_t ivalue;
+} vxh_sel_term;
+int vxh_selection_create(int threads, int n_columns, const int *dtypes, int n_terms, const vxh_sel_term *terms, uint32_t truth, vxh_selection **out);
+void vxh_selection_destroy(vxh_selection *selection);
+/* the chunk of column `column` slot `thread` works on (borrowed like the aggregators' data: set_data, src/agg_base.hpp:166-179) */
+int vxh_selection_set_data(vxh_selection *selection, int thread, int column, const void *data, uint64_t n, int mem);
+/* attach (NULL: detach) a selection to an aggregator: rows are kept where the predicate holds AND the data mask, if one is
+ * set, is non-zero.  The selection is borrowed and must outlive its use in vxh_grid_bin. */
+int vxh_agg_set_selection(vxh_agg *agg, vxh_selection *selection);
 /* bytes_used() = sizeof(grid_type) * grids * length1d — src/agg_base.hpp:29 (vaex/agg.py:311-318 checks it) */
 size_t vxh_agg_bytes_used(const vxh_agg *agg);
 /* dtype of one grid cell as exposed to the host (int64 for count, upcast<T> for sums, T for min/max) */

@@ -1,0 +1,130 @@
+"""Device-side selections (include/vaex_hip.h "device-side selections", vaex_amd/csrc/vxh_select.hip): a
+selection handed over as a predicate and evaluated on the GPU must keep exactly the rows numpy keeps when it evaluates the
+same expression on the host (what vaex does per chunk: vaex/execution.py:530-549) — compared through the same aggregation
+fed with the numpy-built mask, and against plain numpy for the counts."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+sa = pytest.importorskip("vaex_amd.superagg")
+from vaex_amd import predicate as P  # noqa: E402
+from vaex_amd.binned import Frame  # noqa: E402
+
+LIM = [[-4, 4], [-4, 4]]
+
+
+def _columns(n, seed=0):
+    rng = np.random.default_rng(seed)
+    x = rng.normal(0, 1, n)
+    x[::501] = np.nan
+    cols = dict(
+        x=x, y=rng.normal(0, 1, n), v=rng.normal(3, 2, n),
+        f=rng.normal(0, 1, n).astype("f4"),
+        i=rng.integers(-(1 << 62), 1 << 62, n),
+        j=rng.integers(-100, 100, n).astype("i4"), h=rng.integers(-100, 100, n).astype("i2"), b=rng.integers(-100, 100, n).astype("i1"),
+        U=rng.integers(0, 1 << 63, n).astype("u8") * 2, u=rng.integers(0, 1 << 32, n).astype("u4"), w=rng.integers(0, 1 << 16, n).astype("u2"),
+        c=rng.integers(0, 256, n).astype("u1"), t=rng.random(n) < 0.5,
+    )
+    cols["v"][::333] = np.nan
+    return cols
+
+
+EXPRS = [
+    "v > 3", "(x > 0) & (v < 3.5)", "~(x > 0) | (y >= 1)", "-1 < y <= 1", "x != 0.25", "f < 0.5", "(f >= -1) & (f <= 1) & (j != 0) & (h > -50)",
+    "i > 0", "i >= 4611686018427387000", "i > 0.5", "U >= 9223372036854775807", "U > -1", "U < -1", "(u < 2147483648) | (w == 17)", "b <= -3",
+    "c != 255", "t == 1", "(t != 0) & (c > 10)", "j > 2.5",
+]
+
+
+def _want_mask(expr, cols):
+    p = P.compile_selection(expr, cols)
+    return p.numpy_mask(cols)
+
+
+@pytest.mark.parametrize("n,chunk,threads", [(200_003, 50_000, 3), (3_000_000, 1 << 20, 4)])
+def test_predicates_keep_the_rows_numpy_keeps(n, chunk, threads):
+    cols = _columns(n, 1)
+    f = Frame(cols, chunk_size=chunk, nthreads=threads)
+    for expr in EXPRS:
+        keep = _want_mask(expr, cols)
+        got = f.count(binby=["x", "y"], limits=LIM, shape=64, selection=expr, edges=True)
+        want = f.count(binby=["x", "y"], limits=LIM, shape=64, selection=keep, edges=True)
+        assert np.array_equal(got, want), expr
+        assert int(got.sum()) == int(keep.sum()), expr
+
+
+def test_python_and_numpy_agree_on_the_expressions_used_here():
+    cols = _columns(10_000, 2)
+    with np.errstate(invalid="ignore"):
+        for expr in EXPRS:
+            py = expr.replace("-1 < y <= 1", "(-1 < y) & (y <= 1)")
+            want = eval(py, {}, dict(cols))
+            assert np.array_equal(_want_mask(expr, cols), want), expr
+
+
+def test_sums_and_moments_with_a_predicate_and_missing_values():
+    n = 1_500_000
+    cols = _columns(n, 3)
+    miss = np.random.default_rng(4).random(n) < 0.1
+    cols["m"] = np.ma.array(cols["y"] * 10, mask=miss)
+    f = Frame(cols, chunk_size=1 << 19, nthreads=2)
+    expr = "(x > -1) & (v < 6)"
+    keep = _want_mask(expr, cols)
+    for method in ("sum", "mean", "std", "min", "max"):
+        got = getattr(f, method)("m", binby=["x", "y"], limits=LIM, shape=32, selection=expr)
+        want = getattr(f, method)("m", binby=["x", "y"], limits=LIM, shape=32, selection=keep)
+        assert np.array_equal(got, want, equal_nan=True), method  # same kernels, same row set, same order: identical
+
+
+def test_device_resident_columns_and_several_selections_in_one_pass():
+    import torch
+    from vaex_amd import binned
+    n = 4_000_000
+    cols = _columns(n, 5)
+    host = {k: cols[k] for k in ("x", "y", "v", "j")}
+    dev = {k: torch.from_numpy(a).cuda() for k, a in host.items()}
+    torch.cuda.synchronize()
+    f = Frame(dev)
+    descs = [binned.agg.count(selection="v > 3"), binned.agg.mean("v", selection="v > 3"), binned.agg.count(selection="(j >= 0) & (x < 0.5)"), binned.agg.sum("v")]
+    got = f._agg(descs, ["x", "y"], LIM, 256)
+    k1, k2 = _want_mask("v > 3", host), _want_mask("(j >= 0) & (x < 0.5)", host)
+    fh = Frame(host, nthreads=2)
+    want = fh._agg([binned.agg.count(selection=k1), binned.agg.mean("v", selection=k1), binned.agg.count(selection=k2), binned.agg.sum("v")], ["x", "y"], LIM, 256)
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[2], want[2])
+    assert np.allclose(got[1], want[1], rtol=1e-12, atol=0, equal_nan=True) and np.allclose(got[3], want[3], rtol=1e-12, atol=0, equal_nan=True)
+    assert int(got[0].sum()) == int((k1 & (np.abs(host["x"]) < 4) & (np.abs(host["y"]) < 4)).sum())
+    # a 3-D pass with the selection over a binned column (the partition strategy's masked path)
+    z = torch.from_numpy(cols["f"].astype("f8")).cuda()
+    f3 = Frame(dict(dev, z=z))
+    lim3 = LIM + [[-4, 4]]
+    g = f3.count(binby=["x", "y", "z"], limits=lim3, shape=64, selection="x > 0.125")
+    w = Frame(dict(host, z=cols["f"].astype("f8")), nthreads=2).count(binby=["x", "y", "z"], limits=lim3, shape=64, selection=_want_mask("x > 0.125", host))
+    assert np.array_equal(g, w)
+
+
+def test_c_abi_argument_checks():
+    with pytest.raises(RuntimeError, match="1 to 4 terms"):
+        sa.Selection(1, [0], [], 0)
+    with pytest.raises(RuntimeError, match="column that does not exist"):
+        sa.Selection(1, [0], [(1, sa.CMP_GT, 0.0)], 2)
+    sel = sa.Selection(1, [0], [(0, sa.CMP_GT, 0.0)], 2)
+    with pytest.raises(RuntimeError, match="Itemsize"):
+        sel.set_data(0, 0, np.zeros(4, dtype="f4"))
+    b = sa.BinnerScalar_float64(1, "x", 0.0, 1.0, 4)
+    g = sa.Grid([b])
+    a = sa.AggCount_float64(g, 1, 1)
+    x = np.linspace(-1, 2, 100)
+    b.set_data(0, x); a.set_data(0, x, 0); a.set_selection(sel)
+    with pytest.raises(RuntimeError, match="selection data not set"):
+        g.bin(0, [a], len(x))
+    sel.set_data(0, 0, x[:50])
+    with pytest.raises(RuntimeError, match="selection data is shorter"):
+        g.bin(0, [a], len(x))
+    sel.set_data(0, 0, x)
+    g.bin(0, [a], len(x))
+    r = np.asarray(a.get_result())
+    assert r[2:-1].sum() == ((x > 0) & (x >= 0) & (x < 1)).sum()
+    a.set_selection(None)
+    g.bin(0, [a], len(x))
+    assert np.asarray(a.get_result())[2:-1].sum() == ((x > 0) & (x < 1)).sum() + ((x >= 0) & (x < 1)).sum()

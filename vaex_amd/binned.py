@@ -22,6 +22,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 
+from . import predicate as _predicate
 from . import superagg as _sa
 
 _DTYPE_NAMES = {"float64", "float32", "int64", "int32", "int16", "int8", "uint64", "uint32", "uint16", "uint8", "bool"}
@@ -153,6 +154,7 @@ class Frame:
             raise ValueError("columns differ in length")
         self.n = n.pop() if n else 0
         self._f64_cache = {}
+        self._predicates = {}
         self.direct_groupby_cells = 1 << 21  # widest key range binned without a hash map (fits the partition strategy)
 
     def __len__(self):
@@ -173,17 +175,39 @@ class Frame:
         return self._f64_cache[name]
 
     def _selection_mask(self, selection):
+        """None, a mask array (host / device; 1 = keep), or a predicate.Predicate the GPU evaluates itself: a selection
+        given as an expression string ("(x > 0) & (v < 3.5)"; a bare column name is that boolean column)"""
         if selection is None or selection is False:
             return None
         if isinstance(selection, str):
-            selection = self.columns[selection]
+            if selection in self.columns:
+                return self.columns[selection]
+            if selection not in self._predicates:
+                self._predicates[selection] = _predicate.compile_selection(selection, self.columns)
+            return self._predicates[selection]
         return selection
+
+    def _mask_array(self, selection):
+        """the selection as a keep-mask array (the passes that have no device-side predicate: minmax, hashed groupby)"""
+        sel = self._selection_mask(selection)
+        if isinstance(sel, _predicate.Predicate):
+            cols = {n: self.columns[n] for n in sel.columns}
+            if any(_is_device(c) for c in cols.values()):
+                import torch
+                ops = {0: torch.lt, 1: torch.le, 2: torch.gt, 3: torch.ge, 4: torch.eq, 5: torch.ne}
+                bits = None
+                for t, (c, op, v) in enumerate(sel.terms):
+                    o = ops[op](cols[sel.columns[c]], v).to(torch.int32) << t
+                    bits = o if bits is None else bits | o
+                return ((sel.truth >> bits) & 1).to(torch.uint8)
+            return sel.numpy_mask(cols)
+        return sel
 
     # ------------------------------------------------------------------ binners
     def minmax(self, column, selection=None):
         """df.minmax: the legacy statisticNd OP_MIN_MAX pass (vaex/dataframe.py:1520, vaexfast.cpp:1090-1101)."""
         c = self.columns[column]
-        sel = self._selection_mask(selection)
+        sel = self._mask_array(selection)
         keep = None if sel is None else _as_u8(sel)
         if _is_device(c):
             pf = _class_postfix(c)
@@ -239,6 +263,18 @@ class Frame:
 
         bcols = [column(s["column"]) for s in specs]
         all_device = all(_is_device(c) for c in bcols) and all(p.column is None or _is_device(column(p.column, p.as_float64)) for p in prims)
+        # selections given as expressions: one device-side Selection per distinct predicate (vaex_amd/predicate.py)
+        sels = [self._selection_mask(p.selection) for p in prims]
+        preds = {}
+        for sel in sels:
+            if isinstance(sel, _predicate.Predicate) and sel.key() not in preds:
+                pcols = [column(n) for n in sel.columns]
+                if any(np.ma.isMaskedArray(c) for c in pcols):
+                    raise ValueError("selection over a column with missing values: pass the mask array instead")
+                all_device = all_device and all(_is_device(c) for c in pcols)
+                preds[sel.key()] = [None, pcols, [_predicate.dtype_code(c.dtype) for c in pcols], sel]
+            elif sel is not None and not isinstance(sel, _predicate.Predicate):
+                all_device = all_device and _is_device(sel)
         slots = 1 if all_device else nthreads
         binners = []
         for s, c in zip(specs, bcols):
@@ -248,6 +284,8 @@ class Frame:
                 binners.append(getattr(sa, "BinnerScalar_" + pf)(slots, s["column"], s["vmin"], s["vmax"], s["bins"]))
             else:
                 binners.append(getattr(sa, "BinnerOrdinal_" + pf)(slots, s["column"], s["count"], s["min_value"], False, s["invert"]))
+        for entry in preds.values():
+            entry[0] = sa.Selection(slots, entry[2], [(c, op, v) for c, op, v in entry[3].terms], entry[3].truth)
         grid = sa.Grid(binners)
         aggs = []
         for p in prims:
@@ -268,8 +306,14 @@ class Frame:
                 else:
                     d = c[i1:i2] if _is_device(c) else np.ascontiguousarray(c[i1:i2])
                     b.set_data(slot, d); b.clear_data_mask(slot); refs.append(d)
-            for a, p in zip(aggs, prims):
-                sel = self._selection_mask(p.selection)
+            for entry in preds.values():
+                for ci, c in enumerate(entry[1]):
+                    d = c[i1:i2] if _is_device(c) else np.ascontiguousarray(c[i1:i2])
+                    entry[0].set_data(slot, ci, d.view("u1") if (not _is_device(d) and d.dtype == np.bool_) else d); refs.append(d)
+            for a, p, sel in zip(aggs, prims, sels):
+                if isinstance(sel, _predicate.Predicate):
+                    a.set_selection(preds[sel.key()][0])
+                    sel = None
                 mask = None if sel is None else sel[i1:i2]
                 if p.column is not None:
                     c = column(p.column, p.as_float64)
@@ -645,7 +689,7 @@ class Frame:
                     c = self._col(p.column, p.as_float64)
                     d = c[i1:i2] if _is_device(c) else np.ascontiguousarray(c[i1:i2])
                     a.set_data(slot, d, 0); refs.append(d)
-                sel = self._selection_mask(p.selection)
+                sel = self._mask_array(p.selection)
                 if sel is not None:
                     m = _as_u8(sel[i1:i2]); a.set_data_mask(slot, m); refs.append(m)
                 else:

@@ -286,10 +286,44 @@ struct PyGrid {
 // ------------------------------------------------------------------------------------------
 // aggregators
 // ------------------------------------------------------------------------------------------
+// device-side selection (include/vaex_hip.h "device-side selections"): built by vaex_amd.predicate from an expression string
+struct PySelection {
+    vxh_selection *h = nullptr;
+    std::vector<int> dtypes;
+    PySelection(int threads, const std::vector<int> &dtypes_, const std::vector<std::tuple<int, int, py::object>> &terms, uint32_t truth) : dtypes(dtypes_) {
+        std::vector<vxh_sel_term> ts;
+        for (auto &t : terms) {
+            vxh_sel_term v{};
+            v.column = std::get<0>(t);
+            v.op = std::get<1>(t);
+            const py::object &c = std::get<2>(t);
+            if (py::isinstance<py::int_>(c) && !py::isinstance<py::bool_>(c)) {
+                v.is_int = 1;
+                v.ivalue = c.cast<int64_t>();
+                v.value = (double)v.ivalue;
+            } else {
+                v.value = c.cast<double>();
+                v.ivalue = (int64_t)v.value;
+            }
+            ts.push_back(v);
+        }
+        check(vxh_selection_create(threads, (int)dtypes.size(), dtypes.data(), (int)ts.size(), ts.data(), truth, &h));
+    }
+    ~PySelection() { vxh_selection_destroy(h); }
+    PySelection(const PySelection &) = delete;
+    void set_data(int thread, int column, const py::object &ar) {
+        ArrayRef a = resolve_array(ar);
+        if (column < 0 || column >= (int)dtypes.size()) throw std::runtime_error("no such selection column");
+        if (a.itemsize != kTypeSizes[dtypes[column]]) throw std::runtime_error("Itemsize of data and selection column are not equal");
+        check(vxh_selection_set_data(h, thread, column, a.ptr, a.n, a.mem));
+    }
+};
+
 struct PyAgg {
     vxh_agg *h = nullptr;
     PyGrid *grid;
     int kind, dtype;
+    py::object selection_ref; // keeps the attached selection alive
     PyAgg(int kind, int dtype, bool flip, PyGrid *grid, int grids, int threads, uint32_t moment) : grid(grid), kind(kind), dtype(dtype) {
         check(vxh_agg_create(kind, dtype, flip, grid->h, grids, threads, moment, &h));
     }
@@ -306,6 +340,15 @@ struct PyAgg {
         check(vxh_agg_set_data_mask(h, thread, (const uint8_t *)a.ptr, a.n, a.mem));
     }
     void clear_data_mask(int thread) { check(vxh_agg_clear_data_mask(h, thread)); }
+    void set_selection(const py::object &sel) {
+        if (sel.is_none()) {
+            check(vxh_agg_set_selection(h, nullptr));
+            selection_ref = py::none();
+        } else {
+            check(vxh_agg_set_selection(h, sel.cast<PySelection *>()->h));
+            selection_ref = sel;
+        }
+    }
     size_t bytes_used() const { return vxh_agg_bytes_used(h); }
 
     void merge(const std::vector<PyAgg *> &others) {
@@ -634,6 +677,11 @@ PYBIND11_MODULE(superagg, m) {
         return res;
     }, py::arg("keys"), py::arg("rows"), py::arg("counts"), py::arg("sums"), py::arg("sums2"), py::arg("groups_hint") = 0);
 
+    py::class_<PySelection>(m, "Selection")
+        .def(py::init<int, const std::vector<int> &, const std::vector<std::tuple<int, int, py::object>> &, uint32_t>(), py::arg("threads"), py::arg("dtypes"), py::arg("terms"), py::arg("truth"))
+        .def("set_data", &PySelection::set_data);
+    m.attr("CMP_LT") = (int)VXH_CMP_LT; m.attr("CMP_LE") = (int)VXH_CMP_LE; m.attr("CMP_GT") = (int)VXH_CMP_GT;
+    m.attr("CMP_GE") = (int)VXH_CMP_GE; m.attr("CMP_EQ") = (int)VXH_CMP_EQ; m.attr("CMP_NE") = (int)VXH_CMP_NE;
     py::class_<PyAgg> aggregator(m, "Aggregator", py::buffer_protocol());
     aggregator.def("merge", &PyAgg::merge)
         .def("get_result", &PyAgg::get_result)
@@ -641,6 +689,7 @@ PYBIND11_MODULE(superagg, m) {
         .def("set_data", &PyAgg::set_data, py::arg("thread"), py::arg("ar"), py::arg("index") = 0)
         .def("clear_data_mask", &PyAgg::clear_data_mask)
         .def("set_data_mask", &PyAgg::set_data_mask)
+        .def("set_selection", &PyAgg::set_selection)
         .def("device_touch", &PyAgg::device_touch)
         .def("reset", &PyAgg::reset)
         .def_property_readonly("__cuda_array_interface__", &PyAgg::device_grid_interface)

@@ -9,6 +9,7 @@
 #include <cstring>
 #include <limits>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <stdexcept>
 #include <string>
@@ -1537,7 +1538,7 @@ int vxh_grid_bin(vxh_grid *grid, int thread, vxh_agg *const *aggs, int n_aggs, u
     const int ndim = (int)grid->binners.size();
 
     // validate slots and sizes (the reference reads out of bounds instead; we refuse)
-    size_t stage_bytes = 0;
+    size_t stage_bytes = 0, sel_bytes = 0;
     for (int d = 0; d < ndim; d++) {
         vxh_binner *b = grid->binners[d];
         check_slot(thread, b->data.size(), "data_ptr");
@@ -1566,6 +1567,17 @@ int vxh_grid_bin(vxh_grid *grid, int thread, vxh_agg *const *aggs, int n_aggs, u
             if (sm.n < length) throw std::runtime_error("aggregator data mask is shorter than the requested length");
             if (sm.mem == VXH_MEM_HOST) stage_bytes += padded(length);
         }
+        if (a->selection) {
+            const vxh_selection *sel = a->selection;
+            check_slot(thread, (size_t)sel->threads, "selection data");
+            for (int c = 0; c < sel->n_columns; c++) {
+                const SlotData &sc = sel->data[c][thread];
+                if (!sc.ptr) throw std::runtime_error("selection data not set");
+                if (sc.n < length) throw std::runtime_error("selection data is shorter than the requested length");
+                if (sc.mem == VXH_MEM_HOST) stage_bytes += padded(length * kDtypeSize[sel->dtype[c]]);
+            }
+            sel_bytes += padded(length);
+        }
     }
 
     // device grids must own the truth before we scatter into them
@@ -1579,6 +1591,9 @@ int vxh_grid_bin(vxh_grid *grid, int thread, vxh_agg *const *aggs, int n_aggs, u
         bool any_device = false;
         for (int d = 0; d < ndim; d++) any_device = any_device || grid->binners[d]->data[thread].mem == VXH_MEM_DEVICE || (grid->binners[d]->mask[thread].ptr && grid->binners[d]->mask[thread].mem == VXH_MEM_DEVICE);
         for (int k = 0; k < n_aggs; k++) any_device = any_device || (aggs[k]->data[thread].ptr && aggs[k]->data[thread].mem == VXH_MEM_DEVICE) || (aggs[k]->mask[thread].ptr && aggs[k]->mask[thread].mem == VXH_MEM_DEVICE);
+        for (int k = 0; k < n_aggs; k++)
+            if (aggs[k]->selection)
+                for (int c = 0; c < aggs[k]->selection->n_columns; c++) any_device = any_device || aggs[k]->selection->data[c][thread].mem == VXH_MEM_DEVICE;
         if (any_device) order_after_producers(slot);
     }
     Stager stager(slot);
@@ -1594,6 +1609,51 @@ int vxh_grid_bin(vxh_grid *grid, int thread, vxh_agg *const *aggs, int n_aggs, u
         ~StageGuard() { if (active && !done) { try { st.finish(); } catch (...) {} } }
     } stage_guard{stager, stage_bytes != 0};
 
+    // device-side selections: one keep-mask per distinct (selection, data mask) pair, evaluated on the slot's stream in front
+    // of the binning kernels (vxh_select.hip); the aggregators below read it as their data mask
+    std::map<std::pair<const vxh_selection *, const void *>, const uint8_t *> sel_masks;
+    if (sel_bytes) {
+        if (sel_bytes > slot.sel_cap) {
+            HIP_CHECK(hipStreamSynchronize(slot.stream));
+            if (slot.sel_buf) HIP_CHECK(hipFree(slot.sel_buf));
+            slot.sel_buf = nullptr;
+            slot.sel_cap = 0;
+            HIP_CHECK(hipMalloc(&slot.sel_buf, sel_bytes));
+            slot.sel_cap = sel_bytes;
+        }
+        size_t off = 0;
+        for (int k = 0; k < n_aggs; k++) {
+            vxh_agg *a = aggs[k];
+            if (!a->selection) continue;
+            const vxh_selection *sel = a->selection;
+            auto key = std::make_pair(sel, a->mask[thread].ptr);
+            if (sel_masks.count(key)) continue;
+            SelArgs S{};
+            for (int c = 0; c < sel->n_columns; c++) {
+                S.col[c] = resolve(sel->data[c][thread], kDtypeSize[sel->dtype[c]]);
+                S.dtype[c] = (uint8_t)sel->dtype[c];
+            }
+            S.nterms = sel->n_terms;
+            S.truth = sel->truth;
+            for (int t = 0; t < sel->n_terms; t++) {
+                S.t[t].column = sel->term[t].column; S.t[t].op = sel->term[t].op; S.t[t].is_int = sel->term[t].is_int;
+                S.t[t].value = sel->term[t].value; S.t[t].ivalue = sel->term[t].ivalue;
+            }
+            S.and_mask = (const uint8_t *)resolve(a->mask[thread], 1);
+            S.out = (uint8_t *)slot.sel_buf + off;
+            S.n = length;
+            off += padded(length);
+            stager.ready();
+            vxh_launch_sel_eval(S, slot.stream);
+            HIP_CHECK(hipGetLastError());
+            sel_masks[key] = S.out;
+        }
+    }
+    auto agg_mask = [&](vxh_agg *a) -> const uint8_t * {
+        if (a->selection) return sel_masks.at(std::make_pair((const vxh_selection *)a->selection, a->mask[thread].ptr));
+        return (const uint8_t *)resolve(a->mask[thread], 1);
+    };
+
     // distinct bytes streamed per row (an array registered twice, e.g. count(x) binby x, is read once)
     double bytes_per_row = 0;
     {
@@ -1605,7 +1665,8 @@ int vxh_grid_bin(vxh_grid *grid, int thread, vxh_agg *const *aggs, int n_aggs, u
         }
         for (int k = 0; k < n_aggs; k++) {
             if (aggs[k]->data[thread].ptr) uniq[aggs[k]->data[thread].ptr] = kDtypeSize[aggs[k]->dtype];
-            if (aggs[k]->mask[thread].ptr) uniq[aggs[k]->mask[thread].ptr] = 1;
+            if (aggs[k]->selection) uniq[agg_mask(aggs[k])] = 1;
+            else if (aggs[k]->mask[thread].ptr) uniq[aggs[k]->mask[thread].ptr] = 1;
         }
         for (auto &kv : uniq) bytes_per_row += (double)kv.second;
     }
@@ -1651,7 +1712,7 @@ int vxh_grid_bin(vxh_grid *grid, int thread, vxh_agg *const *aggs, int n_aggs, u
             vxh_agg *a = aggs[k0 + k];
             AggDesc &ad = A.a[k];
             ad.data = resolve(a->data[thread], kDtypeSize[a->dtype]);
-            ad.mask = (const uint8_t *)resolve(a->mask[thread], 1);
+            ad.mask = agg_mask(a);
             ad.grid = a->dev;
             ad.moment = a->moment;
             ad.kind = (uint8_t)a->kind;
@@ -1780,6 +1841,44 @@ int vxh_agg_clear_data_mask(vxh_agg *a, int thread) {
     VXH_API_BEGIN
     check_slot(thread, a->mask.size(), "data_mask_ptr");
     a->mask[thread] = SlotData{nullptr, 0, VXH_MEM_HOST};
+    VXH_API_END
+}
+
+int vxh_selection_create(int threads, int n_columns, const int *dtypes, int n_terms, const vxh_sel_term *terms, uint32_t truth, vxh_selection **out) {
+    VXH_API_BEGIN
+    if (threads < 1 || threads > VXH_MAX_SLOTS) throw std::runtime_error("vxh_selection_create: bad number of threads");
+    if (n_columns < 1 || n_columns > VXH_SEL_MAX_COLUMNS) throw std::runtime_error("vxh_selection_create: 1 to 4 columns");
+    if (n_terms < 1 || n_terms > VXH_SEL_MAX_TERMS) throw std::runtime_error("vxh_selection_create: 1 to 4 terms");
+    std::unique_ptr<vxh_selection> sel(new vxh_selection());
+    sel->threads = threads;
+    sel->n_columns = n_columns;
+    sel->n_terms = n_terms;
+    sel->truth = truth & ((n_terms == 4) ? 0xffffu : ((1u << (1u << n_terms)) - 1u));
+    for (int c = 0; c < n_columns; c++) {
+        if (dtypes[c] < 0 || dtypes[c] >= VXH_DTYPE_COUNT) throw std::runtime_error("vxh_selection_create: bad dtype");
+        sel->dtype[c] = dtypes[c];
+        sel->data[c].resize(threads);
+    }
+    for (int t = 0; t < n_terms; t++) {
+        if (terms[t].column < 0 || terms[t].column >= n_columns) throw std::runtime_error("vxh_selection_create: term refers to a column that does not exist");
+        if (terms[t].op < VXH_CMP_LT || terms[t].op > VXH_CMP_NE) throw std::runtime_error("vxh_selection_create: bad comparison");
+        sel->term[t] = {terms[t].column, terms[t].op, terms[t].is_int ? 1 : 0, terms[t].value, terms[t].ivalue};
+    }
+    *out = sel.release();
+    VXH_API_END
+}
+void vxh_selection_destroy(vxh_selection *selection) { delete selection; }
+int vxh_selection_set_data(vxh_selection *sel, int thread, int column, const void *data, uint64_t n, int mem) {
+    VXH_API_BEGIN
+    if (column < 0 || column >= sel->n_columns) throw std::runtime_error("vxh_selection_set_data: no such column");
+    check_slot(thread, sel->data[column].size(), "selection data");
+    sel->data[column][thread] = SlotData{data, n, mem};
+    VXH_API_END
+}
+int vxh_agg_set_selection(vxh_agg *a, vxh_selection *selection) {
+    VXH_API_BEGIN
+    if (selection && selection->threads < a->threads) throw std::runtime_error("vxh_agg_set_selection: the selection has fewer thread slots than the aggregator");
+    a->selection = selection;
     VXH_API_END
 }
 

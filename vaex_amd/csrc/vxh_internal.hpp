@@ -44,7 +44,16 @@ struct vxh_grid {
 
 enum { AUTH_NONE = 0, AUTH_DEVICE = 1, AUTH_HOST = 2 };
 
+struct vxh_selection {
+    int threads = 1, n_columns = 0, n_terms = 0;
+    int dtype[4] = {0, 0, 0, 0};
+    struct Term { int column, op, is_int; double value; int64_t ivalue; } term[4];
+    uint32_t truth = 0;
+    std::vector<SlotData> data[4]; // per column, per thread slot
+};
+
 struct vxh_agg {
+    vxh_selection *selection = nullptr; // borrowed: vxh_agg_set_selection
     int kind = 0, dtype = 0, flip = 0;
     uint32_t moment = 0;
     vxh_grid *grid = nullptr;
@@ -121,6 +130,8 @@ struct Slot {
         double last_fraction = 0; // share of the sample inside the box (vxh_config_get("hot_fraction_ppm"))
     } hot;
     void *fin_buf = nullptr; // vxh_finish scratch (grow-only)
+    void *sel_buf = nullptr; // keep-masks of device-side selections (grow-only; stream-ordered re-use)
+    size_t sel_cap = 0;
     size_t fin_cap = 0;
     const char *last_kernel = "";
     int last_pass1 = 0; // partition strategy, most recent chunk: 0 part_scatter / part_scatter_f64, 1 part_scatter_blk, 2 part_scatter_wv

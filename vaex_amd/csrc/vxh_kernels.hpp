@@ -173,6 +173,27 @@ inline bool vxh_count_fast(const BinArgs &a, const LaunchPlan &p) {
 }
 
 // implemented in vxh_kernels.hip
+// device-side selections (vxh_select.hip): terms `column <op> constant`, keep = bit (outcomes of the terms) of `truth`
+#define VXH_SEL_MAX_TERMS 4
+#define VXH_SEL_MAX_COLUMNS 4
+struct SelTerm {
+    int32_t column, op; // vxh_cmp
+    int32_t is_int, pad;
+    double value;
+    int64_t ivalue;
+};
+struct SelArgs {
+    const void *col[VXH_SEL_MAX_COLUMNS];
+    uint8_t dtype[VXH_SEL_MAX_COLUMNS];
+    int32_t nterms;
+    uint32_t truth;
+    SelTerm t[VXH_SEL_MAX_TERMS];
+    const uint8_t *and_mask; // optional: keep only where this is non-zero too (missing values: vaex/cpu.py:770-784)
+    uint8_t *out;
+    uint64_t n;
+};
+void vxh_launch_sel_eval(const SelArgs &args, hipStream_t stream);
+
 void vxh_launch_part_scatter(const PartArgs &args, const LaunchPlan &plan, int scatter_blocks, size_t scatter_lds, hipStream_t stream);
 void vxh_launch_part_reduce(const PartArgs &args, const LaunchPlan &plan, hipStream_t stream);
 void vxh_launch_bin(const BinArgs &args, const LaunchPlan &plan, hipStream_t stream);

@@ -1,0 +1,92 @@
+// Device-side selections: a predicate over up to four columns evaluated on the GPU into the aggregators' keep-mask.
+//
+// The reference evaluates a selection like "(x > 0) & (v < 3.5)" with numpy on the host, once per chunk, into a boolean
+// array (vaex/execution.py:530-549 via vaex/scopes.py:138-177) that TaskPartAggregation.process hands to every aggregator
+// as its data mask (vaex/cpu.py:740-784; polarity 1 = keep: src/agg_count.cpp:50, src/agg_sum.cpp:108).  Here the predicate
+// itself crosses the C-ABI (include/vaex_hip.h "device-side selections") as comparison terms `column <op> constant` plus a
+// truth table over the terms' outcomes; this kernel turns it into the same byte mask in HBM — no numpy pass over the chunk,
+// no mask bytes over PCIe.  Comparisons follow numpy: every comparison with NaN is false except !=; an integer column is
+// compared exactly with an integer constant and as float64 with a float constant.
+#include "vxh_internal.hpp"
+#include "vxh_kernels.hpp"
+
+namespace {
+
+__device__ __forceinline__ bool cmp_f64(double x, int op, double c) {
+    switch (op) {
+    case VXH_CMP_LT: return x < c;
+    case VXH_CMP_LE: return x <= c;
+    case VXH_CMP_GT: return x > c;
+    case VXH_CMP_GE: return x >= c;
+    case VXH_CMP_EQ: return x == c;
+    default: return x != c;
+    }
+}
+template <typename I>
+__device__ __forceinline__ bool cmp_int(I x, int op, I c) {
+    switch (op) {
+    case VXH_CMP_LT: return x < c;
+    case VXH_CMP_LE: return x <= c;
+    case VXH_CMP_GT: return x > c;
+    case VXH_CMP_GE: return x >= c;
+    case VXH_CMP_EQ: return x == c;
+    default: return x != c;
+    }
+}
+
+__device__ __forceinline__ bool term_at(const SelArgs &A, int t, uint64_t i) {
+    const SelTerm &T = A.t[t];
+    const void *p = A.col[T.column];
+    const int op = T.op;
+    switch (A.dtype[T.column]) {
+    case VXH_F64: return cmp_f64(((const double *)p)[i], op, T.value);
+    case VXH_F32: return cmp_f64((double)((const float *)p)[i], op, T.value);
+    case VXH_I64: {
+        const int64_t x = ((const int64_t *)p)[i];
+        return T.is_int ? cmp_int<int64_t>(x, op, T.ivalue) : cmp_f64((double)x, op, T.value);
+    }
+    case VXH_U64: {
+        const uint64_t x = ((const uint64_t *)p)[i];
+        if (!T.is_int) return cmp_f64((double)x, op, T.value);
+        if (T.ivalue < 0) return op == VXH_CMP_GT || op == VXH_CMP_GE || op == VXH_CMP_NE; // every uint64 is above a negative constant
+        return cmp_int<uint64_t>(x, op, (uint64_t)T.ivalue);
+    }
+    case VXH_I32: { const int64_t x = ((const int32_t *)p)[i]; return T.is_int ? cmp_int<int64_t>(x, op, T.ivalue) : cmp_f64((double)x, op, T.value); }
+    case VXH_I16: { const int64_t x = ((const int16_t *)p)[i]; return T.is_int ? cmp_int<int64_t>(x, op, T.ivalue) : cmp_f64((double)x, op, T.value); }
+    case VXH_I8: { const int64_t x = ((const int8_t *)p)[i]; return T.is_int ? cmp_int<int64_t>(x, op, T.ivalue) : cmp_f64((double)x, op, T.value); }
+    case VXH_U32: { const int64_t x = ((const uint32_t *)p)[i]; return T.is_int ? cmp_int<int64_t>(x, op, T.ivalue) : cmp_f64((double)x, op, T.value); }
+    case VXH_U16: { const int64_t x = ((const uint16_t *)p)[i]; return T.is_int ? cmp_int<int64_t>(x, op, T.ivalue) : cmp_f64((double)x, op, T.value); }
+    default: { const int64_t x = ((const uint8_t *)p)[i]; return T.is_int ? cmp_int<int64_t>(x, op, T.ivalue) : cmp_f64((double)x, op, T.value); } // U8 / BOOL
+    }
+}
+
+// four consecutive rows per thread: one 32-bit store of four mask bytes (the tail rows one by one)
+__global__ __launch_bounds__(256) void sel_eval(SelArgs A) {
+    const uint64_t quads = (A.n + 3) / 4;
+    for (uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; q < quads; q += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t i0 = q * 4;
+        uint32_t packed = 0;
+        const int rows = (int)(A.n - i0 < 4 ? A.n - i0 : 4);
+        for (int r = 0; r < rows; r++) {
+            uint32_t bits = 0;
+            for (int t = 0; t < A.nterms; t++) bits |= (term_at(A, t, i0 + r) ? 1u : 0u) << t;
+            uint32_t keep = (A.truth >> bits) & 1u;
+            if (A.and_mask) keep &= A.and_mask[i0 + r] != 0 ? 1u : 0u;
+            packed |= keep << (8 * r);
+        }
+        if (rows == 4) {
+            *(uint32_t *)(A.out + i0) = packed; // (out is 256-byte aligned scratch)
+        } else {
+            for (int r = 0; r < rows; r++) A.out[i0 + r] = (uint8_t)(packed >> (8 * r));
+        }
+    }
+}
+
+} // namespace
+
+void vxh_launch_sel_eval(const SelArgs &A, hipStream_t stream) {
+    if (!A.n) return;
+    const uint64_t quads = (A.n + 3) / 4;
+    const int blocks = (int)std::min<uint64_t>((quads + 255) / 256, 256 * 16);
+    hipLaunchKernelGGL(sel_eval, dim3(blocks), dim3(256), 0, stream, A);
+}
