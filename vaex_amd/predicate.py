@@ -44,7 +44,8 @@ class Predicate:
         return (tuple(self.columns), tuple(self.terms), self.truth)
 
     def numpy_mask(self, arrays):
-        """the same predicate with numpy (tests, and the oracle of the device evaluation)"""
+        """the same predicate evaluated with numpy on host columns: what vaex itself does per chunk; used by the passes that take
+        a ready-made mask (minmax, hashed groupby) and by the tests as the expected row set"""
         outcomes = []
         for c, op, value in self.terms:
             with np.errstate(invalid="ignore"):
