@@ -182,6 +182,35 @@ int vxh_selection_set_data(vxh_selection *selection, int thread, int column, con
 /* attach (NULL: detach) a selection to an aggregator: rows are kept where the predicate holds AND the data mask, if one is
  * set, is non-zero.  The selection is borrowed and must outlive its use in vxh_grid_bin. */
 int vxh_agg_set_selection(vxh_agg *agg, vxh_selection *selection);
+
+/* ---- AggFirst ------------------------------------------------------------------------------ */
+/* AggFirst_<T>_<T2>(grid, grids, threads, invert) — src/agg_first.cpp:7-163: per cell the value of the row whose order
+ * value is smallest (invert: largest — vaex.agg.last), rows with a NaN value or order skipped, ties kept by the earlier
+ * row.  set_data index 0 is the value column (dtype), index 1 the order column (dtype_order); without an order column a
+ * row's order is its index inside the call (:136).  flip_endian applies to both.  merge() does not exist (the reference
+ * throws, :42).  vxh_first_bin bins slot `thread` of the grid's binners like vxh_grid_bin.  vxh_first_result: values_out
+ * (cells of dtype, empty cells read 99 like the reference's fill :22-28), masked_out (1 = empty cell), order_out (cells of
+ * dtype_order; may be NULL). */
+typedef struct vxh_first vxh_first;
+int vxh_first_create(int dtype, int dtype_order, int flip_endian, vxh_grid *grid, int grids, int threads, int invert, vxh_first **out);
+void vxh_first_destroy(vxh_first *first);
+int vxh_first_set_data(vxh_first *first, int thread, int index, const void *data, uint64_t n, int mem);
+int vxh_first_set_data_mask(vxh_first *first, int thread, const uint8_t *mask, uint64_t n, int mem); /* NULL clears */
+int vxh_first_bin(vxh_first *first, int thread, uint64_t length);
+int vxh_first_result(vxh_first *first, void *values_out, uint8_t *masked_out, void *order_out);
+/* dtype size * grids * cells: what vaex's memory check expects of the reference class (vaex/agg.py:300-318) */
+size_t vxh_first_bytes_used(const vxh_first *first);
+
+/* ---- row-wise helpers ---------------------------------------------------------------------- */
+/* device memory for the helpers' results (a plain hipMalloc / hipFree) */
+int vxh_device_alloc(size_t bytes, void **out);
+void vxh_device_free(void *p);
+/* packed key of a multi-key groupby: out[i] = sum_k (column_k[i] - min_value_k) * multiplier_k, int64 — what vaex's
+ * GrouperCombined evaluates with numpy from its parents' ordinals (vaex/groupby.py:526-584 `_combine`: multipliers are the
+ * cumulative products of the parents' group counts).  Integer columns (host or device), result on the device. */
+int vxh_pack_keys(int n_keys, const void *const *columns, const int *dtypes, const int *mems, const int64_t *min_values, const int64_t *multipliers, uint64_t n, int64_t *out_device);
+/* out[i] = a[i] * b[i] (NaN where either is NaN): the pair columns of the legacy OP_COV statistic (src/vaexfast.cpp:1117-1153) */
+int vxh_product_f64(const double *a, int mem_a, const double *b, int mem_b, uint64_t n, double *out_device);
 /* bytes_used() = sizeof(grid_type) * grids * length1d — src/agg_base.hpp:29 (vaex/agg.py:311-318 checks it) */
 size_t vxh_agg_bytes_used(const vxh_agg *agg);
 /* dtype of one grid cell as exposed to the host (int64 for count, upcast<T> for sums, T for min/max) */

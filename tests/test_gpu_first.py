@@ -1,0 +1,164 @@
+"""AggFirst_<T>_<T2> (src/agg_first.cpp; vaex.agg.first / last) on the GPU against the reference's own compiled class
+(oracle/_ref/superagg): the same call sequence vaex's TaskPartAggregation.process makes (set_data index 0 = value, 1 = order,
+set_data_mask, Grid.bin), several chunks, one thread slot — values and masks must be identical, ties go to the earlier row."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = {"float64": "f8", "float32": "f4", "int64": "i8", "int32": "i4", "int16": "i2", "int8": "i1", "uint64": "u8", "uint32": "u4", "uint16": "u2", "uint8": "u1", "bool": "?"}
+
+
+def _column(rng, name, n):
+    k = DTYPES[name]
+    if k in ("f8", "f4"):
+        a = rng.normal(0, 100, n).astype(k)
+        a[rng.random(n) < 0.03] = np.nan
+        return a
+    if k == "?":
+        return rng.random(n) < 0.5
+    info = np.iinfo(k)
+    return rng.integers(info.min, info.max, n, dtype=k, endpoint=True)
+
+
+def _run(mod, x, y, value, order, keep, vt, ot, invert, chunks, shape=(6, 5)):
+    bx = mod.BinnerScalar_float64(1, "x", -2.0, 2.0, shape[0])
+    by = mod.BinnerScalar_float64(1, "y", -2.0, 2.0, shape[1])
+    g = mod.Grid([bx, by])
+    a = getattr(mod, f"AggFirst_{vt}_{ot}")(g, 1, 1, invert)
+    refs = []
+    for i1, i2 in chunks:
+        host = isinstance(value, np.ndarray)
+        cx, cy, cv = x[i1:i2], y[i1:i2], (np.ascontiguousarray(value[i1:i2]) if host else value[i1:i2])
+        cv = cv.view("u1") if host and cv.dtype == np.bool_ else cv
+        bx.set_data(0, cx); by.set_data(0, cy); a.set_data(0, cv, 0)
+        refs += [cx, cy, cv]
+        if order is not None:
+            co = np.ascontiguousarray(order[i1:i2]) if host else order[i1:i2]
+            co = co.view("u1") if host and co.dtype == np.bool_ else co
+            a.set_data(0, co, 1); refs.append(co)
+        if keep is not None:
+            ck = np.ascontiguousarray(keep[i1:i2]).view("u1")
+            a.set_data_mask(0, ck); refs.append(ck)
+        else:
+            a.clear_data_mask(0)
+        g.bin(0, [a], i2 - i1)
+    r = a.get_result()
+    return np.ma.getdata(r), np.ma.getmaskarray(r), a
+
+
+PAIRS = [("float64", "float64"), ("float64", "int64"), ("float32", "float32"), ("int64", "float64"), ("int32", "int16"), ("int8", "uint8"), ("uint64", "uint64"),
+         ("uint32", "int64"), ("uint16", "float32"), ("int16", "uint32"), ("bool", "int8"), ("float64", "bool")]
+
+
+@pytest.mark.parametrize("vt,ot", PAIRS)
+@pytest.mark.parametrize("invert", [False, True])
+def test_first_and_last_equal_the_reference_class(sa, ref, gpu_ready, vt, ot, invert):
+    rng = np.random.default_rng(hash((vt, ot, invert)) % (1 << 31))
+    n = 40_000
+    x, y = rng.normal(0, 1.2, n), rng.normal(0, 1.2, n)
+    x[rng.random(n) < 0.01] = np.nan
+    value, order = _column(rng, vt, n), _column(rng, ot, n)  # narrow order types: many ties
+    keep = rng.random(n) < 0.8
+    chunks = [(0, 15_000), (15_000, 15_001), (15_001, n)]
+    for use_keep in (None, keep):
+        want_v, want_m, wa = _run(ref, x, y, value, order, use_keep, vt, ot, invert, chunks)
+        got_v, got_m, ga = _run(sa, x, y, value, order, use_keep, vt, ot, invert, chunks)
+        assert np.array_equal(got_m, want_m)
+        assert np.array_equal(got_v[~got_m], want_v[~want_m])
+        assert got_v.dtype == want_v.dtype and got_v.shape == want_v.shape
+        assert ga.__sizeof__() == wa.__sizeof__()
+    assert (~want_m).sum() > 20
+
+
+def test_without_an_order_column_the_row_index_orders(sa, ref, gpu_ready):
+    rng = np.random.default_rng(11)
+    n = 30_000
+    x, y = rng.normal(0, 1.2, n), rng.normal(0, 1.2, n)
+    value = rng.normal(0, 1, n)
+    value[::7] = np.nan  # NaN values never win (src/agg_first.cpp:139)
+    for invert in (False, True):
+        for chunks in ([(0, n)], [(0, 10_000), (10_000, n)]):
+            want_v, want_m, _ = _run(ref, x, y, value, None, None, "float64", "int64", invert, chunks)
+            got_v, got_m, _ = _run(sa, x, y, value, None, None, "float64", "int64", invert, chunks)
+            assert np.array_equal(got_m, want_m)
+            assert np.array_equal(got_v[~got_m], want_v[~want_m])
+
+
+def test_big_grid_many_rows_and_device_columns(sa, ref, gpu_ready):
+    import torch
+    rng = np.random.default_rng(12)
+    n = 2_000_000
+    x, y = rng.normal(0, 1, n), rng.normal(0, 1, n)
+    value, order = rng.normal(0, 1, n), rng.permutation(n).astype("i8")
+    want_v, want_m, _ = _run(ref, x, y, value, order, None, "float64", "int64", False, [(0, n)], shape=(200, 100))
+    got_v, got_m, _ = _run(sa, x, y, value, order, None, "float64", "int64", False, [(0, 700_000), (700_000, n)], shape=(200, 100))
+    assert np.array_equal(got_m, want_m) and np.array_equal(got_v[~got_m], want_v[~want_m])
+    dev = [torch.from_numpy(a).cuda() for a in (x, y, value, order)]
+    torch.cuda.synchronize()
+    got_v, got_m, _ = _run(sa, dev[0], dev[1], dev[2], dev[3], None, "float64", "int64", False, [(0, n)], shape=(200, 100))
+    assert np.array_equal(got_m, want_m) and np.array_equal(got_v[~got_m], want_v[~want_m])
+
+
+def test_merge_is_not_offered_like_the_reference(sa, gpu_ready):
+    b = sa.BinnerScalar_float64(1, "x", 0.0, 1.0, 4)
+    g = sa.Grid([b])
+    a = sa.AggFirst_float64_float64(g, 1, 1, False)
+    with pytest.raises(RuntimeError, match="merge: not implemented"):
+        a.merge([a])
+    r = a.get_result()  # nothing binned: every cell masked, values read 99 (src/agg_first.cpp:22-28)
+    assert np.ma.getmaskarray(r).all() and (np.ma.getdata(r) == 99).all()
+
+
+def test_frame_first_last_against_numpy(sa, gpu_ready):
+    from vaex_amd.binned import Frame
+    rng = np.random.default_rng(21)
+    n = 500_000
+    x, v, t = rng.uniform(0, 10, n), rng.normal(0, 1, n), rng.permutation(n).astype("f8")
+    f = Frame(x=x, v=v, t=t, chunk_size=1 << 17)
+    cell = np.floor(x).astype(int)
+    for method, pick in (("first", np.argmin), ("last", np.argmax)):
+        got = getattr(f, method)("v", "t", binby="x", limits=[0, 10], shape=10)
+        want = np.array([v[cell == c][pick(t[cell == c])] for c in range(10)])
+        assert not np.ma.getmaskarray(got).any() and np.array_equal(np.ma.getdata(got), want)
+    keep = v > 0
+    got = f.first("v", "t", binby="x", limits=[0, 20], shape=20, selection=keep)
+    assert np.ma.getmaskarray(got)[10:].all() and not np.ma.getmaskarray(got)[:10].any()
+    want = np.array([v[(cell == c) & keep][np.argmin(t[(cell == c) & keep])] for c in range(10)])
+    assert np.array_equal(np.ma.getdata(got)[:10], want)
+
+
+def test_groupby_on_several_keys_packs_them_on_the_device(sa, gpu_ready):
+    """GrouperCombined (vaex/groupby.py:526-584): sum_i ordinal_i * multiplier_i as ONE int64 key — here packed by
+    vxh_pack_keys and grouped by the single-key path; against pandas."""
+    import pandas as pd
+    from vaex_amd import binned
+    rng = np.random.default_rng(22)
+    n = 1_000_000
+    a = rng.integers(-5, 40, n).astype("i4")
+    b = rng.integers(1000, 1300, n)
+    c = rng.integers(0, 3, n).astype("u1")
+    v = rng.normal(3, 2, n)
+    v[::101] = np.nan
+    f = binned.Frame(a=a, b=b, c=c, v=v)
+    spec = {"n": binned.agg.count(), "s": binned.agg.sum("v"), "m": binned.agg.mean("v"), "sd": binned.agg.std("v")}
+    for keys in (["a", "b"], ["c", "a", "b"]):
+        got = f.groupby(keys, spec)
+        df = pd.DataFrame(dict(a=a, b=b, c=c, v=v))
+        g = df.groupby(keys, sort=True)["v"]
+        want = pd.DataFrame({"n": df.groupby(keys, sort=True).size(), "s": g.sum(), "m": g.mean(), "sd": g.std(ddof=0)}).reset_index()
+        assert len(got[keys[0]]) == len(want)
+        for k in keys:
+            assert np.array_equal(got[k], want[k].to_numpy()) and got[k].dtype == want[k].to_numpy().dtype
+        assert np.array_equal(got["n"], want["n"].to_numpy())
+        assert np.allclose(got["s"], want["s"].to_numpy(), rtol=1e-12, atol=1e-9)
+        assert np.allclose(got["m"], want["m"].to_numpy(), rtol=1e-12, atol=1e-12)
+        assert np.allclose(got["sd"], want["sd"].to_numpy(), rtol=1e-9, atol=1e-12)
+    # a wide second key: the packed key takes the hashed (fused) path
+    w = (rng.integers(0, 50_000, n) * 2654435761) % (1 << 40)
+    f2 = binned.Frame(a=a, w=w, v=v)
+    got = f2.groupby(["a", "w"], {"n": binned.agg.count(), "s": binned.agg.sum("v")})
+    df = pd.DataFrame(dict(a=a, w=w, v=v))
+    want = pd.DataFrame({"n": df.groupby(["a", "w"]).size(), "s": df.groupby(["a", "w"])["v"].sum()}).reset_index()
+    assert np.array_equal(got["a"], want["a"].to_numpy()) and np.array_equal(got["w"], want["w"].to_numpy())
+    assert np.array_equal(got["n"], want["n"].to_numpy()) and np.allclose(got["s"], want["s"].to_numpy(), rtol=1e-12, atol=1e-9)

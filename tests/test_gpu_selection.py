@@ -74,7 +74,11 @@ def test_sums_and_moments_with_a_predicate_and_missing_values():
     for method in ("sum", "mean", "std", "min", "max"):
         got = getattr(f, method)("m", binby=["x", "y"], limits=LIM, shape=32, selection=expr)
         want = getattr(f, method)("m", binby=["x", "y"], limits=LIM, shape=32, selection=keep)
-        assert np.array_equal(got, want, equal_nan=True), method  # same kernels, same row set, same order: identical
+        if method in ("min", "max"):
+            assert np.array_equal(got, want, equal_nan=True), method
+        else:  # fp64 sums in a different order (chunks land on different slots): 1e-12 of the summed magnitude
+            scale = np.nanmax(np.abs(want)) if method == "sum" else 1.0
+            assert np.allclose(got, want, rtol=1e-9 if method == "std" else 1e-12, atol=1e-12 * scale, equal_nan=True), method
 
 
 def test_device_resident_columns_and_several_selections_in_one_pass():

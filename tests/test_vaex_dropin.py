@@ -28,7 +28,7 @@ backend = vaex_amd.install()
 hip = vaex_amd.superagg
 assert vaex.superagg is backend and sys.modules["vaex.superagg"] is backend
 assert vaex.superagg.Grid is hip.Grid and vaex.superagg.AggSum_float64 is hip.AggSum_float64
-assert not hasattr(vaex.superagg, "AggFirst_float64_int64") and not hasattr(vaex.superagg, "BinnerHash_int64")
+assert not hasattr(vaex.superagg, "AggNUnique_float64") and not hasattr(vaex.superagg, "BinnerHash_int64") and hasattr(vaex.superagg, "AggFirst_float64_int64")
 assert vaex.hash.ordered_set_int64.__module__ == "vaex_amd.hashset"
 rng = np.random.default_rng(1)
 n = %(n)d
@@ -37,6 +37,10 @@ kf = rng.integers(0, 50, n).astype("f8"); kf[::777] = np.nan
 df = vaex.from_arrays(x=x, y=rng.normal(0, 1, n), v=rng.normal(3, 2, n), k=rng.integers(0, 9, n), kb=rng.integers(-10**12, 10**12, n) // 10**9 * 10**9,
                       kf=kf, i=rng.integers(-100, 100, n).astype("i4"))
 lim2 = [[-4, 4], [-4, 4]]
+def two_keys(d):
+    k, i = d["k"].to_numpy(), d["i"].to_numpy()
+    o = np.lexsort((i, k))
+    return [np.asarray(d[c].to_numpy(), dtype="f8")[o] for c in ["k", "i", "c", "s"]]
 def by_key(d, key, cols):
     d = d.sort(key)
     return [np.asarray(d[c].to_numpy(), dtype="f8") for c in [key] + cols]
@@ -52,9 +56,10 @@ hot = {
   "groupby_small": lambda d: by_key(d.groupby("k", agg={"s": vaex.agg.sum("v"), "c": vaex.agg.count(), "m": vaex.agg.mean("v"), "sd": vaex.agg.std("v")}), "k", ["s", "c", "m", "sd"]),
   "groupby_sparse": lambda d: by_key(d.groupby("kb", agg={"s": vaex.agg.sum("v"), "c": vaex.agg.count()}), "kb", ["s", "c"]),
   "groupby_float_nan": lambda d: by_key(d.groupby("kf", agg={"c": vaex.agg.count()}), "kf", ["c"]),
+  "first_last": lambda d: np.stack([d.first("v", "y", binby="x", limits=[-4, 4], shape=8), d.last("v", "y", binby="x", limits=[-4, 4], shape=8)]),  # AggFirst_float64_float64
+  "groupby_two_keys": lambda d: two_keys(d.groupby(["k", "i"], agg={"c": vaex.agg.count(), "s": vaex.agg.sum("v")})),  # GrouperCombined: vaex/groupby.py:526-584
 }
 fallback = {   # not offered by the HIP classes: must run on vaex's own C++ after install(), GPU or not
-  "first": lambda d: d.first("v", "x", binby="y", limits=[-4, 4], shape=4),
   "nunique": lambda d: d._compute_agg("nunique", "i", binby="y", limits=[-4, 4], shape=4),
 }
 has_gpu = hip.device_count() > 0
@@ -143,14 +148,14 @@ def test_unmodified_vaex_without_a_gpu_fails_loudly_and_falls_back():
     if vaex_amd.superagg.device_count() > 0:
         pytest.skip("a GPU is visible: see the -m gpu test")
     out = _run(20000, 0, 300)
-    assert out.count("ok-loud-failure") == 11 and out.count("ok-fallback") == 2, out
+    assert out.count("ok-loud-failure") == 13 and out.count("ok-fallback") == 1, out
 
 
 @pytest.mark.gpu
 @pytest.mark.skipif(not os.path.isdir(os.path.join(PKG, "vaex")), reason="real vaex package not built (oracle/build_ref.sh needs /root/reference)")
 def test_unmodified_vaex_drives_the_hip_classes_on_the_gpu():
     out = _run(300_000, int(os.environ.get("VAEX_DROPIN_TIMING_ROWS", "100000000")), 900)
-    assert out.count("ok-parity") == 11 and out.count("ok-fallback") == 3, out
+    assert out.count("ok-parity") == 13 and out.count("ok-fallback") == 2, out
     line = [l for l in out.splitlines() if l.startswith("TIMING")]
     assert line, out
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)

@@ -521,8 +521,110 @@ class Frame:
     def median_approx(self, column, binby=(), limits=None, shape=128, percentile_shape=256, percentile_limits="minmax", selection=None):
         return self.percentile_approx(column, 50, binby=binby, limits=limits, shape=shape, percentile_shape=percentile_shape, percentile_limits=percentile_limits, selection=selection)
 
+    # ------------------------------------------------------------------ first / last
+    def _first_last(self, invert, expression, order_expression, binby, limits, shape, selection, edges):
+        """df.first / df.last (vaex/dataframe.py:976-1011 -> AggFirst, vaex/agg.py:556-576): per cell the value of the row
+        with the smallest (last: largest) order value; a masked array (cells without rows masked)."""
+        sa = self.sa
+        specs = self._binner_specs(binby, limits, shape)
+        value = self.columns[expression]
+        order = None if order_expression is None else self.columns[order_expression]
+        cols = [self.columns[s["column"]] for s in specs] + [value] + ([order] if order is not None else [])
+        if any(np.ma.isMaskedArray(c) for c in cols):
+            raise NotImplementedError("first/last over columns with missing values")
+        sel = self._mask_array(selection)
+        device = all(_is_device(c) for c in cols) and (sel is None or _is_device(sel))
+        binners = []
+        for s, c in zip(specs, cols):
+            pf = _class_postfix(c)
+            if s["kind"] == "scalar":
+                binners.append(getattr(sa, "BinnerScalar_" + pf)(1, s["column"], s["vmin"], s["vmax"], s["bins"]))
+            else:
+                binners.append(getattr(sa, "BinnerOrdinal_" + pf)(1, s["column"], s["count"], s["min_value"], False, s["invert"]))
+        grid = sa.Grid(binners)
+        opf = "int64" if order is None else _class_postfix(order)  # vaex/agg.py:280-283: "rows use int64"
+        a = getattr(sa, "AggFirst_" + _class_postfix(value).replace("_non_native", "") + "_" + opf.replace("_non_native", "") + ("_non_native" if _class_postfix(value).endswith("_non_native") else ""))(grid, 1, 1, invert)
+        step = self.n if device else self.chunk_size
+        if order is None and step < self.n:
+            raise NotImplementedError("first/last without an order column over several chunks: the order would be the row's index inside its chunk (src/agg_first.cpp:136)")
+        for i1 in range(0, self.n, max(1, step)):
+            i2 = min(self.n, i1 + step)
+            refs = []
+            pick = (lambda c: c[i1:i2]) if device else (lambda c: (lambda d: d.view("u1") if d.dtype == np.bool_ else d)(np.ascontiguousarray(c[i1:i2])))
+            for b, c in zip(binners, cols):
+                d = pick(c); b.set_data(0, d); b.clear_data_mask(0); refs.append(d)
+            d = pick(value); a.set_data(0, d, 0); refs.append(d)
+            if order is not None:
+                d = pick(order); a.set_data(0, d, 1); refs.append(d)
+            if sel is not None:
+                m = _as_u8(sel[i1:i2]); a.set_data_mask(0, m); refs.append(m)
+            else:
+                a.clear_data_mask(0)
+            grid.bin(0, [a], i2 - i1)
+        r = a.get_result()
+        if not edges:
+            r = r[tuple(slice(2, -1) if s["kind"] == "scalar" else slice(0, -2) for s in specs)]
+        return r
+
+    def first(self, expression, order_expression=None, binby=None, limits=None, shape=128, selection=None, edges=False):
+        return self._first_last(False, expression, order_expression, binby, limits, shape, selection, edges)
+
+    def last(self, expression, order_expression=None, binby=None, limits=None, shape=128, selection=None, edges=False):
+        return self._first_last(True, expression, order_expression, binby, limits, shape, selection, edges)
+
+    # ------------------------------------------------------------------ groupby
+    def _groupby_combined(self, by, agg_spec, reduce, comm):
+        """df.groupby([k1, k2, ...]): the keys' ordinals packed into ONE int64 key on the device (vxh_pack_keys — the
+        expression vaex's GrouperCombined evaluates with numpy, vaex/groupby.py:526-584), the single-key machinery on the
+        packed column, the packed group keys unpacked again.  Groups come out in ascending (k1, k2, ...) order."""
+        import torch
+        sa = self.sa
+        if comm is not None:
+            raise NotImplementedError("multi-key groupby across ranks")
+        cols, dtypes, mins, counts = [], [], [], []
+        for k in by:
+            c = self.columns[k]
+            if np.ma.isMaskedArray(c):
+                raise NotImplementedError("masked group keys")
+            pf = _class_postfix(c)
+            if pf.startswith("float") or pf.endswith("_non_native"):
+                raise NotImplementedError("groupby on float / non-native keys")
+            data = c if _is_device(c) else np.ascontiguousarray(c.view("u1") if c.dtype == np.bool_ else c)
+            kmin, kmax = sa.minmax_int(data, None, _DT_CODE[pf], False) if self.n else (0, 0)
+            cols.append(data); dtypes.append(_DT_CODE[pf]); mins.append(int(kmin)); counts.append(int(kmax) - int(kmin) + 1)
+        total = 1
+        for n in counts:
+            total *= n
+        if total >= 2**63 - 1:  # vaex/groupby.py:541-549 combines in stages through a hash map there; not built here
+            raise NotImplementedError("the key ranges' product overflows 64 bits")
+        mults = [1] * len(by)
+        for i in range(len(by) - 2, -1, -1):
+            mults[i] = mults[i + 1] * counts[i + 1]
+        packed = sa.pack_keys(cols, dtypes, mins, mults)
+        sub = {"__packed__": torch.as_tensor(packed, device="cuda")}
+        for d in agg_spec.values():
+            if d.column is not None and d.column not in sub:
+                c = self.columns[d.column]
+                if np.ma.isMaskedArray(c):
+                    raise NotImplementedError("multi-key groupby over columns with missing values")
+                sub[d.column] = c if _is_device(c) else torch.from_numpy(np.ascontiguousarray(c)).cuda()
+            if d.selection is not None:
+                raise NotImplementedError("multi-key groupby with a selection")
+        f = Frame(sub, chunk_size=self.chunk_size, nthreads=self.nthreads, superagg=sa)
+        f.direct_groupby_cells = self.direct_groupby_cells
+        res = f.groupby("__packed__", agg_spec, reduce=reduce)
+        self.last_groupby_info = getattr(f, "last_groupby_info", None)
+        pk = np.asarray(res.pop("__packed__")).astype(np.int64)
+        out = {}
+        for k, mult, n, kmin in zip(by, mults, counts, mins):
+            out[k] = ((pk // mult) % n + kmin).astype(np.asarray(self.columns[k][:0].cpu() if _is_device(self.columns[k]) else self.columns[k][:0]).dtype)
+        out.update(res)
+        del packed
+        return out
+
     def groupby(self, by, agg_spec, reduce=None, comm=None):
-        """df.groupby(by).agg({...}) for ONE integer key column.  Returns {by: keys (ascending), name: values}.
+        """df.groupby(by).agg({...}) for ONE integer key column (a list of key columns: see _groupby_combined).
+        Returns {by: keys (ascending), name: values}.
 
         The reference first collects the distinct keys (ordered_set, vaex/hash.py:152-171) and, when they are
         dense (range <= 4/3 * n_unique), simplifies to BinnerInteger (vaex/groupby.py:263-272).  Here the range
@@ -532,6 +634,10 @@ class Frame:
         sa = self.sa
         if comm is None:
             comm = self.comm
+        if isinstance(by, (list, tuple)):
+            if len(by) > 1:
+                return self._groupby_combined(list(by), agg_spec, reduce, comm)
+            by = by[0]
         if reduce is None and comm is not None:
             reduce = comm.allreduce
         key = self.columns[by]

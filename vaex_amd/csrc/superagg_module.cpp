@@ -134,6 +134,19 @@ struct PyHashMap {
         check(rc);
         return out;
     }
+    // device-resident keys -> device-resident ordinals (one lookup kernel; -1 = unknown key)
+    void map_ordinal_device(const py::object &keys, uintptr_t out_ptr, uint64_t out_n) {
+        ArrayRef k = resolve_array(keys);
+        if (k.mem != VXH_MEM_DEVICE) throw std::runtime_error("map_ordinal_device: device arrays only");
+        if (k.itemsize != kTypeSizes[dtype]) throw std::runtime_error("Itemsize of data and hash map are not equal");
+        if (out_n < k.n) throw std::runtime_error("map_ordinal_device: output too short");
+        int rc;
+        {
+            py::gil_scoped_release release;
+            rc = vxh_hashmap_map_ordinal(h, k.ptr, k.n, VXH_MEM_DEVICE, (int64_t *)out_ptr);
+        }
+        check(rc);
+    }
     py::array_t<int64_t> key_array() {
         py::array_t<int64_t> out((ssize_t)count());
         check(vxh_hashmap_keys(h, out.mutable_data()));
@@ -143,6 +156,28 @@ struct PyHashMap {
 template <int DT>
 struct THashMap : PyHashMap {
     explicit THashMap(uint64_t hint) : PyHashMap(DT, hint) {}
+};
+
+// ------------------------------------------------------------------------------------------
+// results of the row-wise helpers: a device array any consumer of __cuda_array_interface__ (set_data, torch) can read
+// ------------------------------------------------------------------------------------------
+struct PyDeviceArray {
+    void *p = nullptr;
+    uint64_t n = 0;
+    int dtype = VXH_F64;
+    PyDeviceArray(uint64_t n, int dtype) : n(n), dtype(dtype) { check(vxh_device_alloc((size_t)n * kTypeSizes[dtype], &p)); }
+    ~PyDeviceArray() { vxh_device_free(p); }
+    PyDeviceArray(const PyDeviceArray &) = delete;
+    py::dict interface() const {
+        static const char *typestr[VXH_DTYPE_COUNT] = {"<f8", "<f4", "<i8", "<i4", "<i2", "|i1", "<u8", "<u4", "<u2", "|u1", "|b1"};
+        py::dict d;
+        d["shape"] = py::make_tuple(n);
+        d["typestr"] = typestr[dtype];
+        d["data"] = py::make_tuple((uintptr_t)p, false);
+        d["version"] = 3;
+        d["strides"] = py::none();
+        return d;
+    }
 };
 
 // ------------------------------------------------------------------------------------------
@@ -429,6 +464,52 @@ void PyGrid::bin(int thread, const std::vector<PyAgg *> &aggs, uint64_t length) 
     check(rc);
 }
 
+// AggFirst_<T>_<T2>[_non_native](grid, grids, threads, invert) — src/agg_first.cpp:165-178.  ONE class here; the 11 x 11 x 2
+// names of the reference are made on demand by the module's __getattr__ (vaex looks them up by name: vaex/agg.py:279-285)
+struct PyAggFirst {
+    vxh_first *h = nullptr;
+    PyGrid *grid;
+    int dtype, dtype_order;
+    PyAggFirst(PyGrid *grid, int grids, int threads, bool invert, int dtype, int dtype_order, bool flip) : grid(grid), dtype(dtype), dtype_order(dtype_order) {
+        check(vxh_first_create(dtype, dtype_order, flip, grid->h, grids, threads, invert, &h));
+    }
+    ~PyAggFirst() { vxh_first_destroy(h); }
+    PyAggFirst(const PyAggFirst &) = delete;
+    void set_data(int thread, const py::object &ar, size_t index) {
+        ArrayRef a = resolve_array(ar);
+        if (a.itemsize != kTypeSizes[index == 1 ? dtype_order : dtype]) throw std::runtime_error("Itemsize of data and aggregator are not equal");
+        check(vxh_first_set_data(h, thread, (int)index, a.ptr, a.n, a.mem));
+    }
+    void set_data_mask(int thread, const py::object &ar) {
+        ArrayRef a = resolve_array(ar);
+        check(vxh_first_set_data_mask(h, thread, (const uint8_t *)a.ptr, a.n, a.mem));
+    }
+    void clear_data_mask(int thread) { check(vxh_first_set_data_mask(h, thread, nullptr, 0, VXH_MEM_HOST)); }
+    size_t bytes_used() const { return vxh_first_bytes_used(h); }
+    // (values, masked, order) as arrays of `shapes`, dim 0 fastest
+    py::tuple raw_result() {
+        std::vector<uint64_t> shp = grid->shapes(), str = grid->strides();
+        auto make = [&](int dt) {
+            std::vector<ssize_t> shape(shp.begin(), shp.end()), strides;
+            for (auto v : str) strides.push_back((ssize_t)v * kTypeSizes[dt]);
+            return py::array(py::dtype(std::string(kNumpyFormats[dt])), shape, strides);
+        };
+        py::array values = make(dtype), masked = make(VXH_BOOL), order = make(dtype_order);
+        int rc;
+        {
+            py::gil_scoped_release release;
+            rc = vxh_first_result(h, values.mutable_data(), (uint8_t *)masked.mutable_data(), order.mutable_data());
+        }
+        check(rc);
+        return py::make_tuple(values, masked, order);
+    }
+    // numpy.ma array like the reference (src/agg_first.cpp:60-117)
+    py::object get_result() {
+        py::tuple r = raw_result();
+        return py::module::import("numpy.ma").attr("array")(r[0], py::arg("mask") = r[1]);
+    }
+};
+
 template <int KIND, int DT, bool FLIP>
 struct TAgg : PyAgg {
     TAgg(PyGrid *grid, int grids, int threads) : PyAgg(KIND, DT, FLIP, grid, grids, threads, 0) {}
@@ -677,6 +758,48 @@ PYBIND11_MODULE(superagg, m) {
         return res;
     }, py::arg("keys"), py::arg("rows"), py::arg("counts"), py::arg("sums"), py::arg("sums2"), py::arg("groups_hint") = 0);
 
+    py::class_<PyDeviceArray>(m, "DeviceArray")
+        .def("__len__", [](const PyDeviceArray &a) { return a.n; })
+        .def_property_readonly("__cuda_array_interface__", &PyDeviceArray::interface)
+        .def_property_readonly("dtype", [](const PyDeviceArray &a) { return py::dtype(kNumpyFormats[a.dtype]); });
+    // packed multi-key group key (vxh_pack_keys): integer columns, host or device -> int64 device array
+    m.def("pack_keys", [](const std::vector<py::object> &columns, const std::vector<int> &dtypes, const std::vector<int64_t> &mins, const std::vector<int64_t> &mults) {
+        const size_t nk = columns.size();
+        if (!nk || dtypes.size() != nk || mins.size() != nk || mults.size() != nk) throw std::runtime_error("pack_keys: one dtype, minimum and multiplier per column");
+        std::vector<const void *> ptrs;
+        std::vector<int> mems;
+        uint64_t n = 0;
+        for (size_t k = 0; k < nk; k++) {
+            ArrayRef a = resolve_array(columns[k]);
+            if (a.itemsize != kTypeSizes[dtypes[k]]) throw std::runtime_error("pack_keys: itemsize of a column and its dtype differ");
+            if (k && a.n != n) throw std::runtime_error("pack_keys: columns differ in length");
+            n = a.n;
+            ptrs.push_back(a.ptr);
+            mems.push_back(a.mem);
+        }
+        auto out = std::make_unique<PyDeviceArray>(n, VXH_I64);
+        int rc;
+        {
+            py::gil_scoped_release release;
+            rc = vxh_pack_keys((int)nk, ptrs.data(), dtypes.data(), mems.data(), mins.data(), mults.data(), n, (int64_t *)out->p);
+        }
+        check(rc);
+        return out;
+    });
+    // row-wise product of two float64 columns (vxh_product_f64) -> float64 device array
+    m.def("product", [](const py::object &a, const py::object &b) {
+        ArrayRef x = resolve_array(a), y = resolve_array(b);
+        if (x.itemsize != 8 || y.itemsize != 8) throw std::runtime_error("product: float64 columns");
+        if (x.n != y.n) throw std::runtime_error("product: columns differ in length");
+        auto out = std::make_unique<PyDeviceArray>(x.n, VXH_F64);
+        int rc;
+        {
+            py::gil_scoped_release release;
+            rc = vxh_product_f64((const double *)x.ptr, x.mem, (const double *)y.ptr, y.mem, x.n, (double *)out->p);
+        }
+        check(rc);
+        return out;
+    });
     py::class_<PySelection>(m, "Selection")
         .def(py::init<int, const std::vector<int> &, const std::vector<std::tuple<int, int, py::object>> &, uint32_t>(), py::arg("threads"), py::arg("dtypes"), py::arg("terms"), py::arg("truth"))
         .def("set_data", &PySelection::set_data);
@@ -716,16 +839,77 @@ PYBIND11_MODULE(superagg, m) {
 
     py::class_<PyGrid>(m, "Grid")
         .def(py::init<std::vector<PyBinner *>>(), py::keep_alive<1, 2>())
-        .def("bin", &PyGrid::bin)
-        .def("bin", &PyGrid::bin_all)
+        .def("bin", [](PyGrid &g, int thread, const py::list &aggs, py::object length) {
+            // AggFirst aggregators take their own passes (vxh_first_bin), everything else ONE fused vxh_grid_bin
+            std::vector<PyAgg *> plain;
+            std::vector<PyAggFirst *> firsts;
+            for (const py::handle &a : aggs) {
+                if (py::isinstance<PyAggFirst>(a)) firsts.push_back(a.cast<PyAggFirst *>());
+                else plain.push_back(a.cast<PyAgg *>());
+            }
+            uint64_t n;
+            if (length.is_none()) {
+                if (g.binners.empty()) throw std::runtime_error("no binners set and no length given"); // src/agg.hpp:78
+                n = vxh_binner_data_length(g.binners[0]->h, thread);
+            } else {
+                n = length.cast<uint64_t>();
+            }
+            if (!plain.empty()) g.bin(thread, plain, n);
+            for (PyAggFirst *f : firsts) {
+                int rc;
+                {
+                    py::gil_scoped_release release;
+                    rc = vxh_first_bin(f->h, thread, n);
+                }
+                check(rc);
+            }
+        }, py::arg("thread"), py::arg("aggregators"), py::arg("length") = py::none())
         .def("__len__", [](const PyGrid &g) { return vxh_grid_length1d(g.h); })
         .def_property_readonly("binners", [](const PyGrid &g) { return g.binners; }, py::return_value_policy::reference)
         .def_property_readonly("shapes", &PyGrid::shapes)
         .def_property_readonly("strides", &PyGrid::strides);
 
+    py::class_<PyAggFirst>(m, "AggFirst")
+        .def(py::init<PyGrid *, int, int, bool, int, int, bool>(), py::keep_alive<1, 2>(), py::arg("grid"), py::arg("grids"), py::arg("threads"), py::arg("invert"),
+             py::arg("dtype"), py::arg("dtype_order"), py::arg("flip") = false)
+        .def("set_data", &PyAggFirst::set_data, py::arg("thread"), py::arg("ar"), py::arg("index") = 0)
+        .def("set_data_mask", &PyAggFirst::set_data_mask)
+        .def("clear_data_mask", &PyAggFirst::clear_data_mask)
+        .def("get_result", &PyAggFirst::get_result)
+        .def("raw_result", &PyAggFirst::raw_result)
+        .def("merge", [](PyAggFirst &, const py::object &) { throw std::runtime_error("merge: not implemented"); }) // src/agg_first.cpp:42
+        .def("__sizeof__", &PyAggFirst::bytes_used)
+        .def_property_readonly("grid", [](const PyAggFirst &a) { return a.grid; }, py::return_value_policy::reference);
+    // AggFirst_<T>_<T2>[_non_native] -> a constructor with the reference's signature (grid, grids, threads, invert)
+    m.def("__getattr__", [m](const std::string &name) -> py::object {
+        const std::string prefix = "AggFirst_";
+        if (name.compare(0, prefix.size(), prefix) == 0) {
+            std::string rest = name.substr(prefix.size());
+            bool flip = false;
+            const std::string nn = "_non_native";
+            if (rest.size() > nn.size() && rest.compare(rest.size() - nn.size(), nn.size(), nn) == 0) {
+                flip = true;
+                rest = rest.substr(0, rest.size() - nn.size());
+            }
+            for (int a = 0; a < VXH_DTYPE_COUNT; a++)
+                for (int b = 0; b < VXH_DTYPE_COUNT; b++)
+                    if (rest == std::string(kTypeNames[a]) + "_" + kTypeNames[b]) {
+                        py::object cls = m.attr("AggFirst");
+                        return py::module::import("functools").attr("partial")(cls, py::arg("dtype") = a, py::arg("dtype_order") = b, py::arg("flip") = flip);
+                    }
+        }
+        throw py::attribute_error("module 'vaex_amd.superagg' has no attribute '" + name + "'");
+    });
+
     py::class_<PyHashMap> hashmap(m, "ordered_set");
     hashmap.def("update", &PyHashMap::update, py::arg("keys"), py::arg("mask") = py::none())
         .def("map_ordinal", &PyHashMap::map_ordinal)
+        .def("map_ordinal_device", [](PyHashMap &h, const py::object &keys) {
+            ArrayRef k = resolve_array(keys);
+            auto out = std::make_unique<PyDeviceArray>(k.n, VXH_I64);
+            h.map_ordinal_device(keys, (uintptr_t)out->p, out->n);
+            return out;
+        })
         .def("set_keys", &PyHashMap::set_keys)
         .def("key_array", &PyHashMap::key_array)
         .def("__len__", &PyHashMap::count)

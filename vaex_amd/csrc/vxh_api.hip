@@ -1185,6 +1185,37 @@ struct DevBuf {
     DevBuf &operator=(const DevBuf &) = delete;
 };
 
+// the binners of `grid` as the kernels see them; resolve(SlotData, element size) -> device pointer of slot `thread`'s array
+template <typename RESOLVE>
+static void fill_binner_descs(vxh_grid *grid, int thread, BinArgs &base, RESOLVE &&resolve) {
+    const int ndim = (int)grid->binners.size();
+    base.cells = grid->length1d;
+    base.ndim = ndim;
+    for (int d = 0; d < ndim; d++) {
+        vxh_binner *b = grid->binners[d];
+        BinnerDesc &bd = base.b[d];
+        bd.data = resolve(b->data[thread], kDtypeSize[b->dtype]);
+        bd.mask = (const uint8_t *)resolve(b->mask[thread], 1);
+        bd.kind = (uint8_t)b->kind;
+        bd.dtype = (uint8_t)b->dtype;
+        bd.flip = (uint8_t)b->flip;
+        bd.stride = grid->strides[d];
+        if (b->kind == VXH_BIN_SCALAR) {
+            bd.vmin = b->vmin;
+            bd.scale = 1. / (b->vmax - b->vmin); // src/binners.cpp:16
+            bd.binsd = (double)b->bins;
+            bd.bins = b->bins;
+        } else if (b->kind == VXH_BIN_ORDINAL) {
+            bd.bins = (uint64_t)b->ordinal_count;
+            bd.min_value = b->min_value;
+            bd.allow_other = b->allow_other;
+            bd.invert = b->invert;
+        } else {
+            vxh_hashmap_fill_binner_desc(b->map, &bd);
+        }
+    }
+}
+
 // shared driver of vxh_minmax / vxh_minmax_int: host inputs are streamed through a bounded device buffer
 // (cfg_stage_bytes per piece) instead of one allocation of the whole column
 template <typename OUT, typename LAUNCH>
@@ -1676,31 +1707,7 @@ int vxh_grid_bin(vxh_grid *grid, int thread, vxh_agg *const *aggs, int n_aggs, u
 
     BinArgs base{};
     base.n = length;
-    base.cells = grid->length1d;
-    base.ndim = ndim;
-    for (int d = 0; d < ndim; d++) {
-        vxh_binner *b = grid->binners[d];
-        BinnerDesc &bd = base.b[d];
-        bd.data = resolve(b->data[thread], kDtypeSize[b->dtype]);
-        bd.mask = (const uint8_t *)resolve(b->mask[thread], 1);
-        bd.kind = (uint8_t)b->kind;
-        bd.dtype = (uint8_t)b->dtype;
-        bd.flip = (uint8_t)b->flip;
-        bd.stride = grid->strides[d];
-        if (b->kind == VXH_BIN_SCALAR) {
-            bd.vmin = b->vmin;
-            bd.scale = 1. / (b->vmax - b->vmin); // src/binners.cpp:16
-            bd.binsd = (double)b->bins;
-            bd.bins = b->bins;
-        } else if (b->kind == VXH_BIN_ORDINAL) {
-            bd.bins = (uint64_t)b->ordinal_count;
-            bd.min_value = b->min_value;
-            bd.allow_other = b->allow_other;
-            bd.invert = b->invert;
-        } else {
-            vxh_hashmap_fill_binner_desc(b->map, &bd);
-        }
-    }
+    fill_binner_descs(grid, thread, base, resolve);
 
     const uint64_t kMaxRows = 1ull << 31; // LDS count cells are u32: a workgroup never sees more rows than this
     for (int k0 = 0; k0 < n_aggs; k0 += VXH_MAX_AGG) {
@@ -1879,6 +1886,206 @@ int vxh_agg_set_selection(vxh_agg *a, vxh_selection *selection) {
     VXH_API_BEGIN
     if (selection && selection->threads < a->threads) throw std::runtime_error("vxh_agg_set_selection: the selection has fewer thread slots than the aggregator");
     a->selection = selection;
+    VXH_API_END
+}
+
+static const void *on_device(Slot &slot, const void *p, size_t bytes, int mem, std::unique_ptr<DevBuf> &tmp);
+
+// ------------------------------------------------------------------------------------------
+// AggFirst
+// ------------------------------------------------------------------------------------------
+static void canon_to_host(uint64_t c, int dt, void *out, uint64_t i) {
+    switch (dt) {
+    case VXH_F64: ((uint64_t *)out)[i] = c; break;
+    case VXH_F32: { double d; memcpy(&d, &c, 8); ((float *)out)[i] = (float)d; break; }
+    case VXH_I64: case VXH_U64: ((uint64_t *)out)[i] = c; break;
+    case VXH_I32: case VXH_U32: ((uint32_t *)out)[i] = (uint32_t)c; break;
+    case VXH_I16: case VXH_U16: ((uint16_t *)out)[i] = (uint16_t)c; break;
+    default: ((uint8_t *)out)[i] = (uint8_t)c; break;
+    }
+}
+static uint64_t key_to_canon(uint64_t k, int dt, bool invert) {
+    if (invert) k = ~k;
+    if (dt == VXH_F64 || dt == VXH_F32) return (k >> 63) ? (k ^ (1ull << 63)) : ~k;
+    if (dt >= VXH_U64) return k;
+    return k ^ (1ull << 63);
+}
+
+int vxh_first_create(int dtype, int dtype_order, int flip_endian, vxh_grid *grid, int grids, int threads, int invert, vxh_first **out) {
+    VXH_API_BEGIN
+    check_dtype(dtype);
+    check_dtype(dtype_order);
+    if (!grid) throw std::runtime_error("grid is null");
+    if (grids < 1 || threads < 1) throw std::runtime_error("grids and threads must be >= 1");
+    std::unique_ptr<vxh_first> f(new vxh_first());
+    f->dtype = dtype;
+    f->dtype_order = dtype_order;
+    f->flip = flip_endian ? 1 : 0;
+    f->invert = invert ? 1 : 0;
+    f->grid = grid;
+    f->grids = grids;
+    f->threads = threads;
+    f->data.resize(threads);
+    f->order.resize(threads);
+    f->mask.resize(threads);
+    *out = f.release();
+    VXH_API_END
+}
+void vxh_first_destroy(vxh_first *f) {
+    if (!f) return;
+    if (f->state) {
+        (void)hipDeviceSynchronize();
+        (void)hipFree(f->state);
+    }
+    delete f;
+}
+int vxh_first_set_data(vxh_first *f, int thread, int index, const void *data, uint64_t n, int mem) {
+    VXH_API_BEGIN
+    check_slot(thread, f->data.size(), "data_ptr");
+    if (index == 1) f->order[thread] = SlotData{data, n, mem}; // src/agg_first.cpp:34-40
+    else f->data[thread] = SlotData{data, n, mem};
+    VXH_API_END
+}
+int vxh_first_set_data_mask(vxh_first *f, int thread, const uint8_t *mask, uint64_t n, int mem) {
+    VXH_API_BEGIN
+    check_slot(thread, f->mask.size(), "data_mask_ptr");
+    f->mask[thread] = SlotData{mask, n, mem};
+    VXH_API_END
+}
+size_t vxh_first_bytes_used(const vxh_first *f) { return (size_t)kDtypeSize[f->dtype] * (size_t)f->grids * f->grid->length1d; }
+
+int vxh_first_bin(vxh_first *f, int thread, uint64_t length) {
+    VXH_API_BEGIN
+    ensure_device_ready();
+    if (!length) return 0;
+    vxh_grid *grid = f->grid;
+    check_slot(thread, f->data.size(), "data_ptr");
+    const SlotData &sv = f->data[thread], &so = f->order[thread], &sm = f->mask[thread];
+    if (!sv.ptr) throw std::runtime_error("data not set");
+    if (sv.n < length) throw std::runtime_error("aggregator data is shorter than the requested length");
+    if (so.ptr && so.n < length) throw std::runtime_error("aggregator order data is shorter than the requested length");
+    if (sm.ptr && sm.n < length) throw std::runtime_error("aggregator data mask is shorter than the requested length");
+    for (vxh_binner *b : grid->binners) {
+        check_slot(thread, b->data.size(), "data_ptr");
+        if (!b->data[thread].ptr) throw std::runtime_error("data not set");
+        if (b->data[thread].n < length) throw std::runtime_error("binner data is shorter than the requested length");
+        if (b->mask[thread].ptr && b->mask[thread].n < length) throw std::runtime_error("binner data mask is shorter than the requested length");
+    }
+    std::lock_guard<std::mutex> lock(f->mutex);
+    Slot &slot = get_slot(thread);
+    order_after_producers(slot);
+    const uint64_t cells = grid->length1d;
+    if (!f->state) {
+        HIP_CHECK(hipMalloc(&f->state, cells * 8 * 5));
+        HIP_CHECK(hipMemsetAsync(f->state, 0xff, cells * 8 * 3, slot.stream)); // empty cells: row stamp ~0 (key and value never read)
+    }
+    HIP_CHECK(hipMemsetAsync(f->state + cells * 3, 0xff, cells * 8 * 2, slot.stream));
+    std::vector<std::unique_ptr<DevBuf>> tmps;
+    auto resolve = [&](const SlotData &sd, size_t elem) -> const void * {
+        if (!sd.ptr) return nullptr;
+        tmps.emplace_back();
+        return on_device(slot, sd.ptr, (size_t)length * elem, sd.mem, tmps.back());
+    };
+    FirstArgs F{};
+    F.A.n = length;
+    fill_binner_descs(grid, thread, F.A, resolve);
+    F.val = resolve(sv, kDtypeSize[f->dtype]);
+    F.ord = resolve(so, kDtypeSize[f->dtype_order]);
+    F.mask = (const uint8_t *)resolve(sm, 1);
+    F.val_dtype = (uint8_t)f->dtype;
+    F.ord_dtype = (uint8_t)f->dtype_order;
+    F.flip = (uint8_t)f->flip;
+    F.invert = (uint8_t)f->invert;
+    F.stamp0 = f->stamp;
+    f->stamp += length;
+    F.key = f->state;
+    F.row = f->state + cells;
+    F.value = f->state + 2 * cells;
+    F.tmp_key = f->state + 3 * cells;
+    F.tmp_row = f->state + 4 * cells;
+    vxh_launch_first(F, slot.stream);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipStreamSynchronize(slot.stream)); // (the next call, maybe from another slot's stream, reads this state)
+    VXH_API_END
+}
+
+int vxh_first_result(vxh_first *f, void *values_out, uint8_t *masked_out, void *order_out) {
+    VXH_API_BEGIN
+    std::lock_guard<std::mutex> lock(f->mutex);
+    const uint64_t cells = f->grid->length1d;
+    std::vector<uint64_t> host(f->state ? cells * 3 : 0);
+    if (f->state) HIP_CHECK(hipMemcpy(host.data(), f->state, cells * 8 * 3, hipMemcpyDeviceToHost));
+    for (uint64_t c = 0; c < cells; c++) {
+        const bool empty = !f->state || host[cells + c] == ~0ull;
+        masked_out[c] = empty ? 1 : 0;
+        // an empty cell reads 99, the reference's fill (src/agg_first.cpp:22-28), under the mask
+        uint64_t v = empty ? 0 : host[2 * cells + c];
+        if (empty) {
+            const double d99 = 99.0;
+            if (f->dtype == VXH_F64 || f->dtype == VXH_F32) memcpy(&v, &d99, 8);
+            else v = f->dtype == VXH_BOOL ? 1 : 99;
+        }
+        canon_to_host(v, f->dtype, values_out, c);
+        if (order_out) canon_to_host(empty ? 0 : key_to_canon(host[c], f->dtype_order, f->invert), f->dtype_order, order_out, c);
+    }
+    VXH_API_END
+}
+
+// a column where the helper kernels below can read it: device pointers as they are, host arrays copied into `tmp`
+static const void *on_device(Slot &slot, const void *p, size_t bytes, int mem, std::unique_ptr<DevBuf> &tmp) {
+    if (mem == VXH_MEM_DEVICE || !bytes) return p;
+    tmp.reset(new DevBuf(bytes));
+    HIP_CHECK(hipMemcpyAsync(tmp->p, p, bytes, hipMemcpyHostToDevice, slot.stream));
+    return tmp->p;
+}
+
+int vxh_device_alloc(size_t bytes, void **out) {
+    VXH_API_BEGIN
+    ensure_device_ready();
+    *out = nullptr;
+    HIP_CHECK(hipMalloc(out, std::max<size_t>(bytes, 8)));
+    VXH_API_END
+}
+void vxh_device_free(void *p) {
+    if (p) (void)hipFree(p);
+}
+
+int vxh_pack_keys(int n_keys, const void *const *columns, const int *dtypes, const int *mems, const int64_t *min_values, const int64_t *multipliers, uint64_t n, int64_t *out_device) {
+    VXH_API_BEGIN
+    ensure_device_ready();
+    if (n_keys < 1 || n_keys > VXH_PACK_MAX_KEYS) throw std::runtime_error("vxh_pack_keys: 1 to 8 key columns");
+    Slot &slot = get_slot(0);
+    order_after_producers(slot);
+    std::unique_ptr<DevBuf> tmp[VXH_PACK_MAX_KEYS];
+    PackArgs A{};
+    A.nkeys = n_keys;
+    A.n = n;
+    A.out = out_device;
+    for (int k = 0; k < n_keys; k++) {
+        const int dt = dtypes[k];
+        if (dt < VXH_I64 || dt >= VXH_DTYPE_COUNT) throw std::runtime_error("vxh_pack_keys: integer key columns only");
+        A.col[k] = on_device(slot, columns[k], (size_t)n * kDtypeSize[dt], mems[k], tmp[k]);
+        A.dtype[k] = (uint8_t)dt;
+        A.min_value[k] = min_values[k];
+        A.multiplier[k] = multipliers[k];
+    }
+    vxh_launch_pack_keys(A, slot.stream);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipStreamSynchronize(slot.stream)); // (the temporaries go away; the result may be read on any stream)
+    VXH_API_END
+}
+
+int vxh_product_f64(const double *a, int mem_a, const double *b, int mem_b, uint64_t n, double *out_device) {
+    VXH_API_BEGIN
+    ensure_device_ready();
+    Slot &slot = get_slot(0);
+    order_after_producers(slot);
+    std::unique_ptr<DevBuf> ta, tb;
+    const double *da = (const double *)on_device(slot, a, (size_t)n * 8, mem_a, ta);
+    const double *db = (const double *)on_device(slot, b, (size_t)n * 8, mem_b, tb);
+    vxh_launch_product_f64(da, db, out_device, n, slot.stream);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipStreamSynchronize(slot.stream));
     VXH_API_END
 }
 

@@ -188,8 +188,24 @@ struct vxh_hashmap {
     long long *packed = nullptr;
     uint64_t packed_cap = 0;
     bool packed_valid = false;
+    // staging of host key / mask / ordinal chunks: grow-only, re-used by every update / map_ordinal / set_keys / keys call of
+    // this map (all of them hold `mutex` and end with a wait on the stream, so one buffer is enough)
+    void *scratch = nullptr;
+    size_t scratch_cap = 0;
     std::mutex mutex;
 };
+
+static char *hm_scratch(vxh_hashmap *m, size_t bytes) {
+    if (bytes > m->scratch_cap) {
+        if (m->scratch) (void)hipFree(m->scratch);
+        m->scratch = nullptr;
+        m->scratch_cap = 0;
+        const size_t cap = std::max<size_t>(bytes + bytes / 4, 1 << 20);
+        HIP_CHECK(hipMalloc(&m->scratch, cap));
+        m->scratch_cap = cap;
+    }
+    return (char *)m->scratch;
+}
 
 __global__ void hm_pack(const long long *keys, const long long *vals, uint64_t cap, long long *packed) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -289,6 +305,7 @@ void vxh_hashmap_destroy(vxh_hashmap *m) {
     (void)hipFree(m->keys);
     (void)hipFree(m->vals);
     if (m->packed) (void)hipFree(m->packed);
+    if (m->scratch) (void)hipFree(m->scratch);
     (void)hipFree(m->side);
     delete m;
 }
@@ -301,16 +318,15 @@ int vxh_hashmap_update(vxh_hashmap *m, const void *keys, const uint8_t *mask, ui
     const size_t es = (size_t)vxh_dtype_size(m->dtype);
     const void *dkeys = keys;
     const uint8_t *dmask = mask;
-    void *tmp_k = nullptr, *tmp_m = nullptr;
     if (mem == VXH_MEM_DEVICE) order_after_producers(s);
     if (mem == VXH_MEM_HOST && n) {
-        HIP_CHECK(hipMalloc(&tmp_k, n * es));
-        HIP_CHECK(hipMemcpyAsync(tmp_k, keys, n * es, hipMemcpyHostToDevice, s.stream));
-        dkeys = tmp_k;
+        const size_t kbytes = (n * es + 255) & ~(size_t)255;
+        char *tmp = hm_scratch(m, kbytes + (mask ? n : 0));
+        HIP_CHECK(hipMemcpyAsync(tmp, keys, n * es, hipMemcpyHostToDevice, s.stream));
+        dkeys = tmp;
         if (mask) {
-            HIP_CHECK(hipMalloc(&tmp_m, n));
-            HIP_CHECK(hipMemcpyAsync(tmp_m, mask, n, hipMemcpyHostToDevice, s.stream));
-            dmask = (const uint8_t *)tmp_m;
+            HIP_CHECK(hipMemcpyAsync(tmp + kbytes, mask, n, hipMemcpyHostToDevice, s.stream));
+            dmask = (const uint8_t *)(tmp + kbytes);
         }
     }
     // whole array per launch; at most half full before, 3/4 full after; on overflow grow 4x and repeat (idempotent)
@@ -325,8 +341,6 @@ int vxh_hashmap_update(vxh_hashmap *m, const void *keys, const uint8_t *mask, ui
         if (!m->host_side[4]) break;
         hm_grow(m, m->cap * 4, s.stream);
     }
-    if (tmp_k) (void)hipFree(tmp_k);
-    if (tmp_m) (void)hipFree(tmp_m);
     HM_END
 }
 
@@ -338,8 +352,7 @@ int vxh_hashmap_set_keys(vxh_hashmap *m, const int64_t *keys, uint64_t n) {
     if (n == 0) return 0;
     Slot &s = get_slot(0);
     while (m->cap < 2 * n) hm_grow(m, m->cap * 2, s.stream);
-    long long *d = nullptr;
-    HIP_CHECK(hipMalloc(&d, n * 8));
+    long long *d = (long long *)hm_scratch(m, n * 8);
     HIP_CHECK(hipMemcpyAsync(d, keys, n * 8, hipMemcpyHostToDevice, s.stream));
     m->packed_valid = false;
     hipLaunchKernelGGL(hm_insert_ordered, dim3(grid_for(n)), dim3(256), 0, s.stream, d, n, m->keys, m->vals, m->cap - 1, m->side);
@@ -347,7 +360,6 @@ int vxh_hashmap_set_keys(vxh_hashmap *m, const int64_t *keys, uint64_t n) {
     unsigned long long cnt = n;
     HIP_CHECK(hipMemcpyAsync(m->side, &cnt, 8, hipMemcpyHostToDevice, s.stream));
     hm_refresh(m, s.stream);
-    (void)hipFree(d);
     HM_END
 }
 
@@ -374,22 +386,19 @@ int vxh_hashmap_map_ordinal(vxh_hashmap *m, const void *keys, uint64_t n, int me
     const size_t es = (size_t)vxh_dtype_size(m->dtype);
     const void *dkeys = keys;
     long long *dout = (long long *)out;
-    void *tmp_k = nullptr, *tmp_o = nullptr;
     if (mem == VXH_MEM_DEVICE) order_after_producers(s);
     if (mem == VXH_MEM_HOST) {
-        HIP_CHECK(hipMalloc(&tmp_k, n * es));
-        HIP_CHECK(hipMalloc(&tmp_o, n * 8));
-        HIP_CHECK(hipMemcpyAsync(tmp_k, keys, n * es, hipMemcpyHostToDevice, s.stream));
-        dkeys = tmp_k;
-        dout = (long long *)tmp_o;
+        const size_t kbytes = (n * es + 255) & ~(size_t)255;
+        char *tmp = hm_scratch(m, kbytes + n * 8);
+        HIP_CHECK(hipMemcpyAsync(tmp, keys, n * es, hipMemcpyHostToDevice, s.stream));
+        dkeys = tmp;
+        dout = (long long *)(tmp + kbytes);
     }
     hipLaunchKernelGGL(hm_lookup, dim3(grid_for(n)), dim3(256), 0, s.stream, dkeys, m->dtype, n, m->keys, m->vals, m->cap - 1, m->side, dout);
     HIP_CHECK(hipGetLastError());
     if (mem == VXH_MEM_HOST) {
-        HIP_CHECK(hipMemcpyAsync(out, tmp_o, n * 8, hipMemcpyDeviceToHost, s.stream));
+        HIP_CHECK(hipMemcpyAsync(out, dout, n * 8, hipMemcpyDeviceToHost, s.stream));
         HIP_CHECK(hipStreamSynchronize(s.stream));
-        (void)hipFree(tmp_k);
-        (void)hipFree(tmp_o);
     }
     HM_END
 }
@@ -401,13 +410,11 @@ int vxh_hashmap_keys(vxh_hashmap *m, int64_t *keys_out) {
     const uint64_t count = m->host_side[0];
     if (count == 0) return 0;
     Slot &s = get_slot(0);
-    long long *d = nullptr;
-    HIP_CHECK(hipMalloc(&d, count * 8));
+    long long *d = (long long *)hm_scratch(m, count * 8);
     hipLaunchKernelGGL(hm_collect, dim3(grid_for(m->cap)), dim3(256), 0, s.stream, m->keys, m->vals, m->cap, d);
     HIP_CHECK(hipMemcpyAsync(keys_out, d, count * 8, hipMemcpyDeviceToHost, s.stream));
     HIP_CHECK(hipStreamSynchronize(s.stream));
     if (m->host_side[2]) keys_out[m->host_side[3]] = (int64_t)EMPTY; // the INT64_MIN key lives in the side words
-    (void)hipFree(d);
     HM_END
 }
 

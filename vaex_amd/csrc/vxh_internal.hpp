@@ -72,6 +72,18 @@ struct vxh_agg {
     std::vector<SlotData> data, mask;
 };
 
+// AggFirst / "last" (src/agg_first.cpp): ONE device state for all thread slots — calls are serialised (`mutex`, and every
+// call ends with a wait on its stream), so the `grids` of the reference only set the size vaex's memory check expects
+struct vxh_first {
+    int dtype = 0, dtype_order = 0, flip = 0, invert = 0;
+    vxh_grid *grid = nullptr;
+    int grids = 1, threads = 1;
+    uint64_t *state = nullptr; // 5 planes of length1d words: key, row, value, tmp_key, tmp_row
+    uint64_t stamp = 0;
+    std::mutex mutex;
+    std::vector<SlotData> data, order, mask;
+};
+
 struct Slot {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;

@@ -222,6 +222,65 @@ __device__ __forceinline__ void flat_index_batch(const BinArgs &A, const Rows<N>
 }
 
 // ------------------------------------------------------------------------------------------
+// AggFirst: per cell the value of the row with the smallest (invert: largest) order — src/agg_first.cpp:119-163.
+// No 128-bit atomic exists for (order, row), so a call runs three passes over its rows, all with the generic bin index:
+//   1  tmp_key[cell] = min sortable key of the call's rows      (64-bit atomic min)
+//   2  tmp_row[cell] = min stamp among the rows with that key    (ties inside a call: the earliest row, as the reference)
+//   3  the one winner row per cell replaces the cell's state when the cell is empty or its key is strictly smaller
+//      (`value_order < grid_data_order[i]`; equal keys keep the earlier call's row)
+// Rows with a NaN value or a NaN order never take part (:139).  Calls on one aggregator are serialised by the host.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t sortable_key(uint64_t canon, int dt, bool invert) {
+    uint64_t k;
+    if (dt_is_float(dt)) k = (canon >> 63) ? ~canon : (canon ^ (1ull << 63));
+    else if (dt_is_unsigned(dt)) k = canon;
+    else k = canon ^ (1ull << 63);
+    return invert ? ~k : k;
+}
+__device__ __forceinline__ bool canon_is_nan(uint64_t canon, int dt) {
+    const double d = as_f64(canon);
+    return dt_is_float(dt) && d != d;
+}
+
+template <int PASS>
+__global__ void __launch_bounds__(256) first_pass(const FirstArgs F) {
+    constexpr int N = 2;
+    const uint64_t total = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t base = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; base < F.A.n; base += N * total) {
+        const Rows<N> rows = make_rows<N>(base, total, F.A.n);
+        uint64_t idx[N], v[N], o[N];
+        flat_index_batch<false, N>(F.A, rows, idx);
+        uint32_t keep = rows.valid;
+        if (F.mask) keep &= load_mask_bits<N>(F.mask, rows);
+        load_canon<N>(F.val, rows, F.val_dtype, F.flip, v);
+        if (F.ord) {
+            load_canon<N>(F.ord, rows, F.ord_dtype, F.flip, o);
+        } else {
+#pragma unroll
+            for (int u = 0; u < N; ++u) o[u] = dt_is_float(F.ord_dtype) ? f64_bits((double)rows.i[u]) : rows.i[u];
+        }
+#pragma unroll
+        for (int u = 0; u < N; ++u) {
+            if (!((keep >> u) & 1u) || canon_is_nan(v[u], F.val_dtype) || canon_is_nan(o[u], F.ord_dtype)) continue;
+            const uint64_t k = sortable_key(o[u], F.ord_dtype, F.invert);
+            const uint64_t stamp = F.stamp0 + rows.i[u];
+            const uint64_t c = idx[u];
+            if (PASS == 1) {
+                (void)__hip_atomic_fetch_min((unsigned long long *)F.tmp_key + c, (unsigned long long)k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else if (PASS == 2) {
+                if (F.tmp_key[c] == k) (void)__hip_atomic_fetch_min((unsigned long long *)F.tmp_row + c, (unsigned long long)stamp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                if (F.tmp_key[c] == k && F.tmp_row[c] == stamp && (F.row[c] == ~0ull || k < F.key[c])) {
+                    F.key[c] = k;
+                    F.row[c] = stamp;
+                    F.value[c] = v[u];
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // scatter ops.  SCOPE: __HIP_MEMORY_SCOPE_AGENT (device) or __HIP_MEMORY_SCOPE_WORKGROUP (LDS)
 // ------------------------------------------------------------------------------------------
 template <int SCOPE, typename T>
@@ -2248,6 +2307,14 @@ void vxh_launch_part_merge(const PartMergeArgs &args, hipStream_t stream) {
     if (blocks > 2048) blocks = 2048;
     if (blocks == 0) blocks = 1;
     hipLaunchKernelGGL(part_merge, dim3((unsigned)blocks), dim3(256), 0, stream, args);
+}
+
+void vxh_launch_first(const FirstArgs &F, hipStream_t stream) {
+    if (!F.A.n) return;
+    const int blocks = (int)std::min<uint64_t>((F.A.n + 511) / 512, 256 * 8);
+    hipLaunchKernelGGL(first_pass<1>, dim3(blocks), dim3(256), 0, stream, F);
+    hipLaunchKernelGGL(first_pass<2>, dim3(blocks), dim3(256), 0, stream, F);
+    hipLaunchKernelGGL(first_pass<3>, dim3(blocks), dim3(256), 0, stream, F);
 }
 
 void vxh_launch_fill(void *dst, uint64_t ncells, int cell, const void *value8, hipStream_t stream) {

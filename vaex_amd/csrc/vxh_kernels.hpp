@@ -192,7 +192,29 @@ struct SelArgs {
     uint8_t *out;
     uint64_t n;
 };
+// AggFirst (first / last value per cell by an order column): vxh_kernels.hip first_pass<1..3>
+struct FirstArgs {
+    BinArgs A; // binners + n (the aggregator descriptors are unused)
+    const void *val, *ord; // ord == nullptr: the row's index inside the call is its order (src/agg_first.cpp:136)
+    const uint8_t *mask;   // keep-mask (1 = keep) or nullptr
+    uint8_t val_dtype, ord_dtype, flip, invert;
+    uint64_t stamp0;       // stamp of row 0: rows of earlier calls win ties
+    uint64_t *key, *row, *value;   // per cell: sortable order key of the winner, its stamp (~0 = empty cell), its value (canonical bits)
+    uint64_t *tmp_key, *tmp_row;   // per cell, this call only
+};
+void vxh_launch_first(const FirstArgs &args, hipStream_t stream);
 void vxh_launch_sel_eval(const SelArgs &args, hipStream_t stream);
+#define VXH_PACK_MAX_KEYS 8
+struct PackArgs {
+    const void *col[VXH_PACK_MAX_KEYS];
+    uint8_t dtype[VXH_PACK_MAX_KEYS];
+    int32_t nkeys;
+    int64_t min_value[VXH_PACK_MAX_KEYS], multiplier[VXH_PACK_MAX_KEYS];
+    int64_t *out;
+    uint64_t n;
+};
+void vxh_launch_pack_keys(const PackArgs &args, hipStream_t stream);
+void vxh_launch_product_f64(const double *a, const double *b, double *out, uint64_t n, hipStream_t stream);
 
 void vxh_launch_part_scatter(const PartArgs &args, const LaunchPlan &plan, int scatter_blocks, size_t scatter_lds, hipStream_t stream);
 void vxh_launch_part_reduce(const PartArgs &args, const LaunchPlan &plan, hipStream_t stream);

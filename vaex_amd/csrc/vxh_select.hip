@@ -1,3 +1,5 @@
+// Row-wise helper kernels: device-side selections, packed multi-key group keys, column products.
+//
 // Device-side selections: a predicate over up to four columns evaluated on the GPU into the aggregators' keep-mask.
 //
 // The reference evaluates a selection like "(x > 0) & (v < 3.5)" with numpy on the host, once per chunk, into a boolean
@@ -82,7 +84,44 @@ __global__ __launch_bounds__(256) void sel_eval(SelArgs A) {
     }
 }
 
+// packed group key of a multi-key groupby: sum_i (key_i - min_i) * multiplier_i as int64 — the expression vaex's
+// GrouperCombined builds out of its parents' ordinals (vaex/groupby.py:526-584 `_combine`)
+__device__ __forceinline__ int64_t load_i64(const void *p, int dtype, uint64_t i) {
+    switch (dtype) {
+    case VXH_I64: case VXH_U64: return ((const int64_t *)p)[i];
+    case VXH_I32: return ((const int32_t *)p)[i];
+    case VXH_I16: return ((const int16_t *)p)[i];
+    case VXH_I8: return ((const int8_t *)p)[i];
+    case VXH_U32: return ((const uint32_t *)p)[i];
+    case VXH_U16: return ((const uint16_t *)p)[i];
+    default: return ((const uint8_t *)p)[i];
+    }
+}
+__global__ __launch_bounds__(256) void pack_keys(PackArgs A) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < A.n; i += (uint64_t)gridDim.x * blockDim.x) {
+        int64_t packed = 0;
+        for (int k = 0; k < A.nkeys; k++) packed += (int64_t)((uint64_t)(load_i64(A.col[k], A.dtype[k], i) - A.min_value[k]) * (uint64_t)A.multiplier[k]);
+        A.out[i] = packed;
+    }
+}
+
+// row-wise product of two float64 columns (NaN where either is NaN): the off-diagonal inputs of OP_COV (src/vaexfast.cpp:1117-1153)
+__global__ __launch_bounds__(256) void product_f64(const double *a, const double *b, double *out, uint64_t n) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) out[i] = a[i] * b[i];
+}
+
 } // namespace
+
+void vxh_launch_pack_keys(const PackArgs &A, hipStream_t stream) {
+    if (!A.n) return;
+    const int blocks = (int)std::min<uint64_t>((A.n + 255) / 256, 256 * 16);
+    hipLaunchKernelGGL(pack_keys, dim3(blocks), dim3(256), 0, stream, A);
+}
+void vxh_launch_product_f64(const double *a, const double *b, double *out, uint64_t n, hipStream_t stream) {
+    if (!n) return;
+    const int blocks = (int)std::min<uint64_t>((n + 255) / 256, 256 * 16);
+    hipLaunchKernelGGL(product_f64, dim3(blocks), dim3(256), 0, stream, a, b, out, n);
+}
 
 void vxh_launch_sel_eval(const SelArgs &A, hipStream_t stream) {
     if (!A.n) return;

@@ -15,7 +15,14 @@ vaexfast.cpp:1189-1209), followed by a cell-wise fold into the caller's grid:
     OP_MIN_MAX (2)              grid[...,0] = min(grid[...,0], min(w)); grid[...,1] = max(..)   (:1090-1101)
     OP_ADD_WEIGHT_MOMENTS_01 (3)   count, sum
     OP_ADD_WEIGHT_MOMENTS_012 (4)  count, sum, sum of squares
-OP_COV (5) and OP_FIRST (6) are not built (no caller on the binby/groupby path) and raise.
+    OP_COV (5)                  per cell [count_c (N), sum_c (N), pair counts (N x N), pair sums of products (N x N)] of the N
+                                weight columns, a pair counted where both are not NaN (:1117-1153; df.cov, vaex/dataframe.py:1456):
+                                count / sum / sum-of-squares aggregators per column, count / sum aggregators over the
+                                row-wise product column (vxh_product_f64) per pair.  One deviation, stated: a pair inf x 0
+                                (product NaN, neither input NaN) is skipped where the reference adds NaN to the cell.
+    OP_FIRST (6)                grid[...,0] = weights[0] of the row with the smallest weights[1] seen so far, grid[...,1] that
+                                order value (:1155-1166; vaex/dataframe.py:975): the AggFirst passes (vxh_first_*), folded into
+                                the caller's grid with the same `order < grid[...,1]` rule.
 float64 blocks only: the _f4 variant scales in float32 and is not offered rather than approximated."""
 import threading
 
@@ -28,7 +35,7 @@ from . import superagg as _sa
 _LOCK = threading.Lock()
 
 OP_ADD1, OP_COUNT, OP_MIN_MAX, OP_ADD_WEIGHT_MOMENTS_01, OP_ADD_WEIGHT_MOMENTS_012, OP_COV, OP_FIRST = range(7)
-_FIELDS = {OP_ADD1: 1, OP_COUNT: 1, OP_MIN_MAX: 2, OP_ADD_WEIGHT_MOMENTS_01: 2, OP_ADD_WEIGHT_MOMENTS_012: 3}
+_FIELDS = {OP_ADD1: 1, OP_COUNT: 1, OP_MIN_MAX: 2, OP_ADD_WEIGHT_MOMENTS_01: 2, OP_ADD_WEIGHT_MOMENTS_012: 3, OP_FIRST: 2}
 
 
 def _is_device(a):
@@ -63,9 +70,7 @@ def statisticNd_f8(blocks, weights, grid, minima, maxima, op_code, use_edges=0):
 def _statistic_nd(blocks, weights, grid, minima, maxima, op_code, use_edges):
     if not isinstance(blocks, (list, tuple)):
         raise ValueError("statisticNd_: blocklist (first argument) is not a list")
-    if op_code in (OP_COV, OP_FIRST):
-        raise NotImplementedError("statisticNd: OP_COV / OP_FIRST are outside the binned-statistics path built here")
-    if op_code not in _FIELDS:
+    if op_code not in _FIELDS and op_code != OP_COV:
         raise ValueError(f"statisticNd_wrap_template_endian: unknown op code {op_code} for statistic")
     blocks = [_f8(b, "block") for b in blocks]
     nd = len(blocks)
@@ -83,7 +88,10 @@ def _statistic_nd(blocks, weights, grid, minima, maxima, op_code, use_edges):
         raise ValueError(f"statisticNd_: grid has {grid.ndim} dimensions, expected {nd + 1}")
     if grid.strides[-1] != 8:
         raise RuntimeError(f"last dimension in grid should have stride of 1, not {grid.strides[-1] // 8}")
-    fields = _FIELDS[op_code]
+    ncol = len(wlist)
+    fields = 2 * ncol + 2 * ncol * ncol if op_code == OP_COV else _FIELDS[op_code]
+    if op_code == OP_FIRST and ncol < 2:
+        raise ValueError("statisticNd_: OP_FIRST needs a value and an order weight")
     if grid.shape[-1] < fields:
         raise ValueError(f"statisticNd_: op {op_code} writes {fields} values per cell, grid has {grid.shape[-1]}")
     if len(minima) != nd or len(maxima) != nd:
@@ -103,6 +111,60 @@ def _statistic_nd(blocks, weights, grid, minima, maxima, op_code, use_edges):
         binner.set_data(0, b)
         binners.append(binner)
     g = _sa.Grid(binners)
+    inner = tuple(slice(None) if use_edges else slice(2, -1) for _ in range(nd))
+    if op_code == OP_FIRST:
+        w, order = wlist[0], wlist[1]
+        if _postfix(w) != _postfix(order):
+            raise NotImplementedError("statisticNd: OP_FIRST with weights of different byte order")
+        a = getattr(_sa, "AggFirst_float64_" + _postfix(order))(g, 1, 1, False)
+        a.set_data(0, w, 0)
+        a.set_data(0, order, 1)
+        if n:
+            g.bin(0, [a], n)
+        values, masked, orders = (np.asarray(r)[inner] for r in a.raw_result())
+        take = ~masked & (orders < grid[..., 1])  # src/vaexfast.cpp:1160-1163
+        grid[..., 0][take] = values[take]
+        grid[..., 1][take] = orders[take]
+        return None
+    if op_code == OP_COV:
+        if any(_postfix(w) != "float64" for w in wlist):
+            raise NotImplementedError("statisticNd: OP_COV on non-native weights")
+        N = ncol
+        per_col, per_pair = [], {}
+        aggs = []
+        for w in wlist:
+            trio = [_sa.AggCount_float64(g, 1, 1), _sa.AggSum_float64(g, 1, 1), _sa.AggSumMoment_float64(g, 1, 1, 2)]
+            for a in trio:
+                a.set_data(0, w, 0)
+            per_col.append(trio)
+            aggs += trio
+        keep = []
+        for col in range(N):
+            for row in range(col + 1, N):
+                prod = _sa.product(wlist[col], wlist[row])
+                duo = [_sa.AggCount_float64(g, 1, 1), _sa.AggSum_float64(g, 1, 1)]
+                for a in duo:
+                    a.set_data(0, prod, 0)
+                per_pair[(col, row)] = duo
+                aggs += duo
+                keep.append(prod)
+        if n:
+            g.bin(0, aggs, n)
+        res = lambda a: np.asarray(a.get_result())[inner]
+        for col in range(N):
+            cnt, sm, sq = (res(a) for a in per_col[col])
+            grid[..., col] += cnt
+            grid[..., col + N] += sm
+            grid[..., 2 * N + col + col * N] += cnt
+            grid[..., 2 * N + N * N + col + col * N] += sq
+            for row in range(col + 1, N):
+                pc, ps = (res(a) for a in per_pair[(col, row)])
+                ia, ib = row + col * N, col + row * N
+                grid[..., 2 * N + ia] += pc
+                grid[..., 2 * N + ib] = grid[..., 2 * N + ia]
+                grid[..., 2 * N + N * N + ia] += ps
+                grid[..., 2 * N + N * N + ib] = grid[..., 2 * N + N * N + ia]
+        return None
     aggs = []
     if op_code == OP_ADD1:
         aggs.append(_sa.AggCount_int64(g, 1, 1))
@@ -119,7 +181,6 @@ def _statistic_nd(blocks, weights, grid, minima, maxima, op_code, use_edges):
             aggs.append(a)
     if n:
         g.bin(0, aggs, n)
-    inner = tuple(slice(None) if use_edges else slice(2, -1) for _ in range(nd))
     for f, a in enumerate(aggs):
         part = np.asarray(a.get_result())[inner]
         if op_code == OP_MIN_MAX:
