@@ -190,7 +190,11 @@ int vxh_agg_set_selection(vxh_agg *agg, vxh_selection *selection);
  * row's order is its index inside the call (:136).  flip_endian applies to both.  merge() does not exist (the reference
  * throws, :42).  vxh_first_bin bins slot `thread` of the grid's binners like vxh_grid_bin.  vxh_first_result: values_out
  * (cells of dtype, empty cells read 99 like the reference's fill :22-28), masked_out (1 = empty cell), order_out (cells of
- * dtype_order; may be NULL). */
+ * dtype_order; may be NULL).
+ * Deliberate difference: the keep-mask (1 = keep) is read at the row's index, mask[row].  The reference reads
+ * `data_mask_ptr[j]` with j counted inside the current 1024-row block of Grid::bin_ (src/agg_first.cpp:131 — every other
+ * aggregator reads `[j + offset]`), so it agrees only for calls of <= 1024 rows; vxh_config_set("first_mask_block", 1024)
+ * reproduces the reference's indexing bit for bit (tests/test_gpu_first.py pins both). */
 typedef struct vxh_first vxh_first;
 int vxh_first_create(int dtype, int dtype_order, int flip_endian, vxh_grid *grid, int grids, int threads, int invert, vxh_first **out);
 void vxh_first_destroy(vxh_first *first);

@@ -1386,6 +1386,7 @@ int vxh_config_set(const char *key, int64_t value) {
     else if (k == "hot_w") c.cfg_hot_box[2] = value;
     else if (k == "hot_h") c.cfg_hot_box[3] = value;
     else if (k == "lds_replicas") c.cfg_lds_replicas = value;
+    else if (k == "first_mask_block") c.cfg_first_mask_block = value > 0 ? value : 0;
     else throw std::runtime_error("unknown config key: " + k);
     VXH_API_END
 }
@@ -1996,6 +1997,7 @@ int vxh_first_bin(vxh_first *f, int thread, uint64_t length) {
     F.ord_dtype = (uint8_t)f->dtype_order;
     F.flip = (uint8_t)f->flip;
     F.invert = (uint8_t)f->invert;
+    F.mask_block = (uint32_t)ctx().cfg_first_mask_block;
     F.stamp0 = f->stamp;
     f->stamp += length;
     F.key = f->state;

@@ -166,6 +166,7 @@ struct Context {
     int64_t cfg_cache_bytes = 64ll << 30; // device column cache budget (only ranges registered with vxh_cache_register are cached)
     int64_t cfg_slab_log2 = -1;   // -1 = auto
     int64_t cfg_lds_replicas = 0; // 0 = auto
+    int64_t cfg_first_mask_block = 0; // AggFirst keep-mask index: 0 = mask[row] (what the reference means); 1024 = mask[row % 1024] (what src/agg_first.cpp:131 does)
     int64_t cfg_part_chunk = 1 << 28; // rows per partition chunk (scratch: ~2 x record bytes x this; larger chunks amortise the launches)
     int64_t cfg_parts = 0;        // pass-2 workgroups per slab (0 = auto)
     int64_t cfg_part_lds = 0;     // LDS bytes per pass-2 slab (0 = auto)

@@ -251,7 +251,16 @@ __global__ void __launch_bounds__(256) first_pass(const FirstArgs F) {
         uint64_t idx[N], v[N], o[N];
         flat_index_batch<false, N>(F.A, rows, idx);
         uint32_t keep = rows.valid;
-        if (F.mask) keep &= load_mask_bits<N>(F.mask, rows);
+        if (F.mask) {
+            if (F.mask_block) { // the reference's indexing: mask[j] with j counted inside the 1024-row block (src/agg_first.cpp:131)
+                Rows<N> mrows = rows;
+#pragma unroll
+                for (int u = 0; u < N; ++u) mrows.i[u] = rows.i[u] % F.mask_block;
+                keep &= load_mask_bits<N>(F.mask, mrows);
+            } else {
+                keep &= load_mask_bits<N>(F.mask, rows);
+            }
+        }
         load_canon<N>(F.val, rows, F.val_dtype, F.flip, v);
         if (F.ord) {
             load_canon<N>(F.ord, rows, F.ord_dtype, F.flip, o);

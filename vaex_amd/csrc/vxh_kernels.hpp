@@ -198,6 +198,7 @@ struct FirstArgs {
     const void *val, *ord; // ord == nullptr: the row's index inside the call is its order (src/agg_first.cpp:136)
     const uint8_t *mask;   // keep-mask (1 = keep) or nullptr
     uint8_t val_dtype, ord_dtype, flip, invert;
+    uint32_t mask_block;   // 0: mask[row]; 1024: mask[row % 1024], the reference's block-local mask index ("first_mask_block" knob)
     uint64_t stamp0;       // stamp of row 0: rows of earlier calls win ties
     uint64_t *key, *row, *value;   // per cell: sortable order key of the winner, its stamp (~0 = empty cell), its value (canonical bits)
     uint64_t *tmp_key, *tmp_row;   // per cell, this call only
