@@ -8,12 +8,13 @@ from tests import cases
 
 pytestmark = pytest.mark.gpu
 
-KEYS = ("strategy", "wv", "wv_waves", "wv_block", "blk", "hot", "hot_min_rows", "hot_min_pct", "hot_x0", "hot_y0", "hot_w", "hot_h", "part_chunk", "count16")
+WV_DEFAULT = 3  # pass 1 next to a hot box: part_scatter_wv without rings
+KEYS = ("strategy", "wv", "wv_waves", "wv_waves_direct", "wv_block", "blk", "hot", "hot_min_rows", "hot_min_pct", "hot_x0", "hot_y0", "hot_w", "hot_h", "part_chunk", "count16")
 
 
 def _reset(sa):
     for k in KEYS:
-        sa.config_set(k, {"blk": 1, "hot": 1, "count16": 1, "wv": 1, "wv_waves": 8}.get(k, 0))
+        sa.config_set(k, {"blk": 1, "hot": 1, "count16": 1, "wv": WV_DEFAULT, "wv_waves": 8, "wv_waves_direct": 16}.get(k, 0))
 
 
 @pytest.mark.parametrize("seed", range(160))
@@ -47,8 +48,11 @@ def test_fuzz_against_oracle(sa, gpu_ready, seed):
     try:
         sa.config_set("strategy", int(rng.choice([0, 0, 4, 4, 3])))
         sa.config_set("blk", int(rng.choice([1, 2, 0])))
-        wv = int(rng.integers(0, 2)) * (1 + seed % 2)  # third-generation pass 1 (part_scatter_wv): off / auto / also next to a hot box
+        # third-generation pass 1 (part_scatter_wv): off / auto / also next to a hot box / there without rings, one record
+        # stream per (wave, slab) / per (workgroup, slab)
+        wv = int(rng.integers(0, 2)) * (1 + seed % 4)
         sa.config_set("wv", wv)
+        sa.config_set("wv_waves_direct", [16, 8, 4, 12][seed % 4])
         sa.config_set("wv_waves", [4, 6, 8, 12, 16][seed % 5])
         sa.config_set("wv_block", [0, 64, 320][seed % 3])  # tiny queue blocks: many blocks per (wave, slab), in-line reservations
         sa.config_set("count16", int(rng.choice([1, 2])))

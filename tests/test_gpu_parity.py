@@ -363,6 +363,19 @@ def test_count16_partition_reduce_opt_in(sa):
 
 
 # ---- hot box: pass 1 of the partition strategy aggregates the densest rectangle of cells in LDS ---------------
+WV_DEFAULT = 3  # pass 1 next to a hot box: part_scatter_wv without rings, one record stream per (wave, slab)
+
+
+@pytest.fixture(params=[1, 2, 3, 4], ids=["blk", "wv_rings", "direct", "shared"])
+def hot_pass1(request, sa):
+    """The hot-box tests run with every pass-1 kernel that can sit next to a box: part_scatter_blk ("wv" 1),
+    part_scatter_wv with rings (2), without rings and one record stream per (wave, slab) (3) / per (workgroup, slab) (4)."""
+    sa.config_set("wv", request.param)
+    yield request.param
+    sa.config_set("wv", WV_DEFAULT)
+    sa.config_set("wv_block", 0)
+
+
 def _hot_reset(sa):
     for k in ("hot_x0", "hot_y0", "hot_w", "hot_h"):
         sa.config_set(k, 0)
@@ -382,7 +395,7 @@ def _case_count_sum(n, seed=11, uniform=False, shape=256):
                 aggs=[dict(kind="count"), dict(kind="sum", data=v), dict(kind="count", data=v)])
 
 
-def test_hot_box_forced(sa):
+def test_hot_box_forced(sa, hot_pass1):
     sa.config_set("strategy", STRATEGIES["part"])
     try:
         for box in ((100, 110, 60, 50), (0, 0, 92, 92), (167, 167, 92, 92), (130, 1, 1, 200)):
@@ -404,7 +417,7 @@ def test_hot_box_forced(sa):
         _hot_reset(sa)
 
 
-def test_hot_box_from_sample(sa):
+def test_hot_box_from_sample(sa, hot_pass1):
     sa.config_set("strategy", STRATEGIES["part"])
     try:
         sa.config_set("hot_min_rows", 1)
@@ -429,7 +442,7 @@ def test_hot_box_from_sample(sa):
         sa.config_set("hot_min_pct", 0)
 
 
-def test_hot_box_skewed_cold_rows(sa):
+def test_hot_box_skewed_cold_rows(sa, hot_pass1):
     # every row outside the (forced) box and in ONE cell: a tile brings 4096 records into one bucket (more than a
     # 1024-record queue block: the exact-reservation path), and with 1 Mi-row chunks the sub-queue overflows
     # (device-atomic slow path).  Then the same with the rows inside the box (nothing is emitted at all).
@@ -485,11 +498,11 @@ def test_part_blk_signatures(sa):
                 assert sum("part_scatter_wv" in k for k in used) >= 2, used
         finally:
             sa.config_set("blk", 1)
-            sa.config_set("wv", 1)
+            sa.config_set("wv", WV_DEFAULT)
             sa.config_set("wv_block", 0)
 
 
-def test_hot_box_many_rows_per_cell(sa):
+def test_hot_box_many_rows_per_cell(sa, hot_pass1):
     # 4e7 rows into two neighbouring cells of the (forced) box: ~78 k rows per workgroup and cell (uint32 box counters)
     sa.config_set("strategy", STRATEGIES["part"])
     try:
@@ -510,7 +523,7 @@ def test_hot_box_many_rows_per_cell(sa):
         _hot_reset(sa)
 
 
-def test_hot_box_shared_aggregators_many_slots(sa):
+def test_hot_box_shared_aggregators_many_slots(sa, hot_pass1):
     # three slots (threads) feed the same aggregators chunk by chunk, every call with the (forced) box:
     # slot-private accumulators and boxes, atomic merges into the shared grids
     sa.config_set("strategy", STRATEGIES["part"])

@@ -729,15 +729,18 @@ static size_t scatter_lds_bytes(size_t S, int R, int nvals) {
 // part_scatter_wv geometry: waves per workgroup and LDS per wave for S slabs and nvals value columns
 struct WvGeom {
     bool ok = false;
+    int direct = 0; // no rings, cold records go straight from the registers to the queue blocks (next to a hot box): 1 = one record stream per (wave, slab) ("wv" = 3), 2 = per (workgroup, slab) ("wv" = 4)
     int waves = 0;
     size_t wave_bytes = 0;
 };
-static WvGeom wv_geometry(size_t S, int nvals) {
+static WvGeom wv_geometry(size_t S, int nvals, bool with_box) {
     Context &c = ctx();
     WvGeom g;
     if (!c.cfg_wv || S > 64 || nvals > 1 || (c.cfg_no_pipeline & 1) || c.cfg_part_rows > 0) return g;
-    g.wave_bytes = VXH_WV_WAVE_LDS(nvals, S);
-    int waves = (int)std::min<int64_t>(16, std::max<int64_t>(1, c.cfg_wv_waves));
+    g.direct = with_box ? (c.cfg_wv == 3 ? 1 : (c.cfg_wv == 4 && S <= 16 ? 2 : 0)) : 0;
+    int waves = (int)std::min<int64_t>(16, std::max<int64_t>(1, g.direct ? c.cfg_wv_waves_direct : c.cfg_wv_waves));
+    // (shared streams: the kernel's LDS is one area for the workgroup; expressed per wave for the bookkeeping below)
+    g.wave_bytes = g.direct == 2 ? ((VXH_WV_SHARED_LDS(S) + waves - 1) / waves + 15) & ~(size_t)15 : (g.direct ? VXH_WV_WAVE_LDS_DIRECT(S) : VXH_WV_WAVE_LDS(nvals, S));
     while (waves > 1 && (size_t)waves * g.wave_bytes > 150 * 1024) waves--;
     if (waves < 4 || (size_t)waves * g.wave_bytes > 150 * 1024) return g; // too few waves to hide anything: not this kernel
     g.waves = waves;
@@ -813,7 +816,7 @@ static void hot_prepare(Slot &slot, const BinArgs &A, const BinArgs &planned, co
     const uint64_t slab_cells = (planned.cells + S - 1) >> planned.slab_log2;
     // the box lives in part_scatter_blk: uint16 local indices with one value to spare for the null record
     const bool gen2 = c.cfg_blk && S <= 256 && slab_cells < 65535 && !(c.cfg_no_pipeline & 1) && c.cfg_part_rows <= 0; // (= run_part_chunk's conditions for part_scatter_blk)
-    const WvGeom wg = wv_geometry(S, nval);
+    const WvGeom wg = wv_geometry(S, nval, true);
     bool wv = wg.ok && slab_cells < 65535 && wv_aligned(A); // (= run_part_chunk's conditions for part_scatter_wv)
     if (wv && gen2 && c.cfg_wv == 1) wv = false; // next to a box part_scatter_blk is the (slightly) faster one: its staging leaves the box 111 KB, eight waves' rings 78 KB
     // a forced box (tests / experiments) too big for what part_scatter_wv's rings leave of the LDS goes to part_scatter_blk
@@ -1021,7 +1024,7 @@ static void run_part_chunk(Slot &slot, const BinArgs &planned, const LaunchPlan 
 
     // third-generation pass 1 (part_scatter_wv): 1..3 float64 scalar binners or one int64 key, <= 1 float64 value column,
     // <= 1 mask shared by every aggregator, uint16 local indices, <= 64 slabs, 16-byte aligned columns
-    const WvGeom wg = wv_geometry(S, P.nvals);
+    const WvGeom wg = wv_geometry(S, P.nvals, slot.hot.on);
     const bool wv = wg.ok && (plan.fast_f64 || (plan.key_i64 && plan.fast_vals)) && planned.ndim >= 1 && planned.ndim <= 3 && P.nvals <= 1 && !P.use_flags &&
                     (P.nmasks == 0 || (P.nmasks == 1 && P.all_masked)) && P.idx16 && slab_cells < 65535 && wv_aligned(planned) && (!slot.hot.on || slot.hot.wv);
     if (slot.hot.on && slot.hot.wv != wv) throw std::runtime_error("vaex_hip internal: hot box prepared for a different pass-1 kernel");
@@ -1055,16 +1058,46 @@ static void run_part_chunk(Slot &slot, const BinArgs &planned, const LaunchPlan 
         // room for every wave's first block, for second blocks of a quarter of them (at least 8), capped by the rows
         P.cap = std::max<uint64_t>(P.cap, B * (waves_per_sub + std::max<uint64_t>(8, waves_per_sub / 4)));
         P.qtab_stride = (int32_t)(P.cap / B + 2);
+        if (wg.direct == 2) { // one stream per (workgroup, slab): blocks of VXH_WV_SHARED_QB records, reserved half a block ahead
+            uint64_t QB = VXH_WV_SHARED_QB;
+            if (c.cfg_wv_block > 0) { QB = 64; while (QB < (uint64_t)c.cfg_wv_block && QB < 65536) QB <<= 1; } // (tests: tiny blocks)
+            const uint64_t wgs_per_sub = ((uint64_t)wv_blocks + P.parts - 1) / P.parts;
+            const double per_sub = (double)planned.n * cold / (double)nsub;
+            P.qblk = (int32_t)QB;
+            // expected records + 1/8, and per writing workgroup a partly filled and a reserved-ahead block
+            P.cap = ((uint64_t)(per_sub * 1.125) + QB * (2 * wgs_per_sub + 8) + QB - 1) & ~(QB - 1);
+            P.qtab_stride = (int32_t)(P.cap / QB + 2);
+            P.qbtab_stride = P.qtab_stride;
+            const size_t need = (size_t)wv_blocks * S * (size_t)P.qbtab_stride * 16;
+            if (need > slot.qbtab_cap) {
+                HIP_CHECK(hipStreamSynchronize(slot.stream));
+                HIP_CHECK(hipStreamSynchronize(slot.stream2));
+                if (slot.qbtab) HIP_CHECK(hipFree(slot.qbtab));
+                slot.qbtab = nullptr;
+                HIP_CHECK(hipMalloc(&slot.qbtab, need));
+                slot.qbtab_cap = need;
+                HIP_CHECK(hipMemsetAsync(slot.qbtab, 0, need, slot.stream)); // (epoch 0 is never used)
+            }
+            P.qbtab = (unsigned long long *)slot.qbtab;
+            slot.epoch = slot.epoch >= 0x7ffffff0 ? 1 : slot.epoch + 1;
+            if (slot.epoch == 1 && slot.qbtab) HIP_CHECK(hipMemsetAsync(slot.qbtab, 0, slot.qbtab_cap, slot.stream));
+            P.epoch = slot.epoch;
+        }
     }
-    const size_t idx_bytes = P.idx16 ? 2 : 4;
+    const bool rec12 = wv && wg.direct && P.nvals == 1;
+    P.qrec12 = rec12 ? 1 : 0;
+    const size_t idx_bytes = rec12 ? 12 : (P.idx16 ? 2 : 4);
     size_t off = 0;
     auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
     const size_t o_count = carve((size_t)nsub * 8), o_limit = carve((size_t)nsub * 8);
     const size_t o_tab = wv ? carve((size_t)nsub * (size_t)P.qtab_stride * 4) : 0;
-    const size_t o_idx = carve((size_t)nsub * P.cap * idx_bytes);
+    // (ring-less part_scatter_wv: one sink record per wave behind the sub-queues, 16 records apart)
+    const size_t n_sink = (wv && wg.direct) ? (size_t)wv_blocks * wg.waves * 16 : 0;
+    P.qsink = (uint64_t)nsub * P.cap;
+    const size_t o_idx = carve(((size_t)nsub * P.cap + n_sink) * idx_bytes);
     const size_t o_flags = P.use_flags ? carve((size_t)nsub * P.cap) : 0;
     size_t o_val[VXH_PART_MAX_VALS] = {0, 0, 0, 0};
-    for (int k = 0; k < P.nvals; k++) o_val[k] = carve((size_t)nsub * P.cap * 8);
+    for (int k = 0; k < P.nvals && !rec12; k++) o_val[k] = carve((size_t)nsub * P.cap * 8);
     // (two scratch buffers only when pass 2 of chunk i overlaps pass 1 of chunk i+1)
     Slot::PartBuf &pb = slot.part[c.cfg_part_overlap ? (slot.part_next++ & 1) : 0];
     // the previous user of this buffer (pass 2 of chunk i-2, on stream2) must be done before pass 1 refills it
@@ -1084,7 +1117,7 @@ static void run_part_chunk(Slot &slot, const BinArgs &planned, const LaunchPlan 
     P.qlimit = (unsigned long long *)(sc + o_limit);
     P.qidx = sc + o_idx;
     P.qflags = P.use_flags ? (uint8_t *)(sc + o_flags) : nullptr;
-    for (int k = 0; k < P.nvals; k++) P.qval[k] = (uint64_t *)(sc + o_val[k]);
+    for (int k = 0; k < P.nvals && !rec12; k++) P.qval[k] = (uint64_t *)(sc + o_val[k]);
     HIP_CHECK(hipMemsetAsync(P.qcount, 0, (size_t)nsub * 8, slot.stream));
     HIP_CHECK(hipMemsetAsync(P.qlimit, 0xff, (size_t)nsub * 8, slot.stream));
     if (wv) {
@@ -1117,6 +1150,7 @@ static void run_part_chunk(Slot &slot, const BinArgs &planned, const LaunchPlan 
     const bool hot_here = slot.hot.on && P.nmasks == 0 && P.nvals == slot.hot.nval && (blk || wv);
     if (wv) {
         P.wv = wg.waves;
+        P.wv_direct = wg.direct;
         P.wv_wave_bytes = (int32_t)wg.wave_bytes;
         P.wv_base = 0;
         P.rows_per_thread = 4;
@@ -1150,7 +1184,7 @@ static void run_part_chunk(Slot &slot, const BinArgs &planned, const LaunchPlan 
     } else if (slot.hot.on) {
         throw std::runtime_error("vaex_hip internal: hot box prepared for a signature pass 1 does not serve");
     }
-    slot.last_pass1 = wv ? 2 : (blk ? 1 : 0);
+    slot.last_pass1 = wv ? (P.wv_direct ? 2 + P.wv_direct : 2) : (blk ? 1 : 0);
     vxh_launch_part_scatter(P, plan, scatter_blocks, scatter_lds, slot.stream);
     HIP_CHECK(hipGetLastError());
     if (c.cfg_part_overlap) {
@@ -1377,6 +1411,7 @@ int vxh_config_set(const char *key, int64_t value) {
     else if (k == "blk") c.cfg_blk = value;
     else if (k == "wv") c.cfg_wv = value;
     else if (k == "wv_waves") c.cfg_wv_waves = value > 0 ? value : 8;
+    else if (k == "wv_waves_direct") c.cfg_wv_waves_direct = value > 0 ? value : 16;
     else if (k == "wv_block") c.cfg_wv_block = value;
     else if (k == "hot_min_rows") c.cfg_hot_min_rows = value > 0 ? value : (1 << 24);
     else if (k == "hot_min_pct") c.cfg_hot_min_pct = value > 0 ? value : 35;
@@ -1782,10 +1817,10 @@ int vxh_grid_bin(vxh_grid *grid, int thread, vxh_agg *const *aggs, int n_aggs, u
         if (whole.strategy == VXH_STRAT_PART) {
             part_join(slot);
             part_acc_merge(slot, whole_args);
-            if (slot.last_pass1 == 2) slot.last_kernel = whole.fast_f64 ? "part_scatter_wv+part_reduce_f64" : "part_scatter_wv+part_reduce_generic";
+            if (slot.last_pass1 >= 2) slot.last_kernel = whole.fast_f64 ? "part_scatter_wv+part_reduce_f64" : "part_scatter_wv+part_reduce_generic";
             if (slot.hot.on) {
                 hot_merge(slot, whole_args);
-                slot.last_kernel = slot.last_pass1 == 2 ? "part_scatter_wv_hot+part_reduce_f64" : "part_scatter_hot+part_reduce_f64";
+                slot.last_kernel = slot.last_pass1 == 4 ? "part_scatter_shared_hot+part_reduce_f64" : slot.last_pass1 == 3 ? "part_scatter_direct_hot+part_reduce_f64" : (slot.last_pass1 == 2 ? "part_scatter_wv_hot+part_reduce_f64" : "part_scatter_hot+part_reduce_f64");
             }
             slot.hot.on = false;
             part_guard.armed = false;

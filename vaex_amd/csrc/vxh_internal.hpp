@@ -114,6 +114,9 @@ struct Slot {
     } part[2];
     hipStream_t stream2 = nullptr;
     unsigned part_next = 0;
+    void *qbtab = nullptr; // PartArgs::qbtab (shared-stream pass 1): entries are tagged with the launch's epoch, never cleared
+    size_t qbtab_cap = 0;
+    int32_t epoch = 0;
     // partition accumulators (PartArgs::acc): identity-filled when the layout signature changes, put back to the
     // identity by part_merge at the end of every vxh_grid_bin call
     void *acc = nullptr;
@@ -146,7 +149,7 @@ struct Slot {
     size_t sel_cap = 0;
     size_t fin_cap = 0;
     const char *last_kernel = "";
-    int last_pass1 = 0; // partition strategy, most recent chunk: 0 part_scatter / part_scatter_f64, 1 part_scatter_blk, 2 part_scatter_wv
+    int last_pass1 = 0; // partition strategy, most recent chunk: 0 part_scatter / part_scatter_f64, 1 part_scatter_blk, 2 part_scatter_wv, 3 its ring-less variant
 };
 
 struct Context {
@@ -171,9 +174,12 @@ struct Context {
     int64_t cfg_parts = 0;        // pass-2 workgroups per slab (0 = auto)
     int64_t cfg_part_lds = 0;     // LDS bytes per pass-2 slab (0 = auto)
     int64_t cfg_blk = 1;           // second-generation pass 1 (part_scatter_blk) where its signature allows (0: part_scatter_f64)
-    int64_t cfg_wv = 1;            // third-generation pass 1 (part_scatter_wv: barrier-free, wave-private rings): 1 where its signature allows, except
-                                   // next to a hot box (part_scatter_blk leaves the box more LDS: profiles/r02_pass1_ab.txt); 2 = there too; 0 = never
+    int64_t cfg_wv = 3;            // third-generation pass 1 (part_scatter_wv: barrier-free): 0 = never; >= 1: with wave-private rings wherever its
+                                   // signature allows and no hot box is on.  Next to a hot box: 1 = part_scatter_blk, 2 = the rings, 3 = no rings, cold records
+                                   // straight from the registers into per-(wave, slab) queue blocks, 4 = into per-(workgroup, slab) blocks (<= 16 slabs)
+                                   // (profiles/r02_direct_ab.txt: 158 / 157 / 177 / 177 Grows/s on the bench pass)
     int64_t cfg_wv_block = 0;      // ... records per queue block of a (wave, slab) (0 = sized from the expected share); tests force tiny blocks
+    int64_t cfg_wv_waves_direct = 16; // ... waves per workgroup of the ring-less variant ("wv" = 3, next to a hot box)
     int64_t cfg_wv_waves = 8;      // ... waves per workgroup (one workgroup per CU); fewer when the rings would not fit
     int64_t cfg_hot = 1;           // hot box in pass 1 of the partition strategy (0 off)
     int64_t cfg_hot_min_rows = 1 << 24; // calls shorter than this do not pay for the sample

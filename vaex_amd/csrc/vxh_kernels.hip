@@ -1341,11 +1341,14 @@ __global__ void __launch_bounds__(VXH_HOT_BLOCK) part_scatter_blk(const PartArgs
                 if (NVAL) hot = hot & (cur.v[NVAL ? r : 0] == cur.v[NVAL ? r : 0]);
                 if (hot) {
                     const uint32_t hc = __umul24(hy, P.hot.w) + hx;
-                    if (NVAL) at_add<__HIP_MEMORY_SCOPE_WORKGROUP, double>(hot_sum + hc, cur.v[NVAL ? r : 0]);
-                    at_add<__HIP_MEMORY_SCOPE_WORKGROUP, uint32_t>(hot_cnt + hc, 1u);
+                    if (!(P.no_pipeline & 128)) { // (timing experiments: bit 7 drops the box updates)
+                        if (NVAL) at_add<__HIP_MEMORY_SCOPE_WORKGROUP, double>(hot_sum + hc, cur.v[NVAL ? r : 0]);
+                        at_add<__HIP_MEMORY_SCOPE_WORKGROUP, uint32_t>(hot_cnt + hc, 1u);
+                    }
                     keep &= ~(1u << r);
                 }
             }
+            if (P.no_pipeline & 64) keep = 0; // (timing experiments: bit 6 drops the cold rows)
             if (!hot && ((keep >> r) & 1u)) pos[r] = __hip_atomic_fetch_add(&cnt[slab[r]], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         __syncthreads();
@@ -1524,6 +1527,8 @@ __global__ void __launch_bounds__(VXH_HOT_BLOCK) part_scatter_blk(const PartArgs
 //   * HOT (two binners, no mask): as in part_scatter_blk — the workgroup's LDS copy of the box takes what the rings
 //     leave of the 160 KiB; the only two barriers of the kernel are the ones around the box's lifetime.
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x3 __attribute__((ext_vector_type(3)));
+typedef u32x3 u32x3_a4 __attribute__((aligned(4)));
 constexpr uint32_t VXH_WV_NONE = 0xffffffffu;
 
 // slow path of part_scatter_wv (sub-queue full: pathologically skewed data): ONE record straight into the grids with
@@ -1543,12 +1548,12 @@ __device__ __forceinline__ void wv_slow_record(const PartArgs &P, uint64_t cell,
     }
 }
 
-template <int NDIM, int NVAL, bool MASKED, bool HOT, int KEY = 0>
+template <int NDIM, int NVAL, bool MASKED, bool HOT, int KEY = 0, int DIRECT = 0>
 __global__ void __launch_bounds__(1024) part_scatter_wv(const PartArgs P) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr int R = 4;
     constexpr uint32_t TW = 64u * R; // rows per wave tile
-    constexpr uint32_t D = VXH_WV_D, G = VXH_WV_G;
+    constexpr uint32_t D = DIRECT ? 0u : VXH_WV_D, G = VXH_WV_G;
     const uint32_t S = 1u << P.slab_log2; // <= 64
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -1559,7 +1564,17 @@ __global__ void __launch_bounds__(1024) part_scatter_wv(const PartArgs P) {
     char *const wbase = lds + P.wv_base + wave * (uint32_t)P.wv_wave_bytes;
     double *const ring_val = (double *)wbase;
     uint16_t *const ring_idx = (uint16_t *)(wbase + (NVAL ? (size_t)S * D * 8 : 0));
-    uint32_t *const cnt = (uint32_t *)(ring_idx + (size_t)S * D);
+    // DIRECT: no rings — [S] x {record index base (64 bit), limit, slow flag} | [S] counters   (VXH_WV_WAVE_LDS_DIRECT)
+    u32x4 *const tab = (u32x4 *)wbase;
+    uint32_t *const cnt = DIRECT ? (uint32_t *)(tab + S) : (uint32_t *)(ring_idx + (size_t)S * D);
+    // DIRECT == 2: the WORKGROUP's waves share one record stream per slab (16x fewer streams than one per wave: a
+    // stream's 128-byte lines fill before the L2 evicts them half written — the cost of the scattered stores grows with
+    // the number of streams, profiles/r02_direct_streams.txt).  LDS at wv_base: [S] record counters | [S][NB] block
+    // entries {record index base (64 bit), block number, epoch | slow << 31}; blocks of QB records.
+    constexpr uint32_t NB = VXH_WV_SHARED_NB;
+    const uint32_t QB = (uint32_t)P.qblk, QSH = (uint32_t)__builtin_ctz(QB); // (a power of two: VXH_WV_SHARED_QB unless a test asks for tiny blocks)
+    uint32_t *const scnt = (uint32_t *)(lds + P.wv_base);
+    u32x4 *const stab = (u32x4 *)(lds + P.wv_base + ((S * 4u + 15u) & ~15u));
     const uint64_t n = P.A.n;
     // tiles are counted in 32 bits (a launch never sees more than 2^31 rows): 64-bit `<` has no scalar form, and the
     // vector compare the compiler falls back to borrows a register — waiting for every load in flight to get it
@@ -1594,7 +1609,71 @@ __global__ void __launch_bounds__(1024) part_scatter_wv(const PartArgs P) {
     auto close_block = [&]() { // (one lane) records the block really holds
         if (end != VXH_WV_NONE) P.qtab[(size_t)my_sub * (uint32_t)P.qtab_stride + (end - B) / B] = cur - (end - B);
     };
-    if (has_work && lane < S) open_block();
+    if (DIRECT != 2 && has_work && lane < S) open_block();
+    // DIRECT == 2: block j of (workgroup, slab s) holds the slab's records [j * QB, (j + 1) * QB) of this workgroup; it is
+    // reserved by the lane that draws position (j - 1) * QB + QB / 2 (block 0: here), which publishes its entry in the
+    // LDS ring and in the HBM block table (PartArgs::qbtab — for a lane that finds its ring entry not yet written or,
+    // in theory, already overwritten).  The fill table gets QB for every reserved block; the last two are corrected
+    // at the end.
+    auto shared_alloc = [&](uint32_t sl, uint32_t j) {
+        const uint32_t sub = sl * (uint32_t)P.parts + part;
+        const unsigned long long b = atomicAdd(&P.qcount[sub], (unsigned long long)QB);
+        u32x4 e;
+        if (b + QB > P.cap) { // does not fit: remember where the valid prefix of the sub-queue ends; slow path for this block
+            atomicMin(&P.qlimit[sub], b);
+            e = u32x4{0u, 0u, j, (uint32_t)P.epoch | 0x80000000u};
+        } else {
+            const uint64_t base = (uint64_t)sub * P.cap + b;
+            P.qtab[(size_t)sub * (uint32_t)P.qtab_stride + (uint32_t)(b >> QSH)] = QB;
+            e = u32x4{(uint32_t)base, (uint32_t)(base >> 32), j, (uint32_t)P.epoch};
+        }
+        stab[sl * NB + (j & (NB - 1))] = e;
+        if (j < (uint32_t)P.qbtab_stride) {
+            unsigned long long *t = P.qbtab + ((size_t)(blockIdx.x * S + sl) * (uint32_t)P.qbtab_stride + j) * 2;
+            // two relaxed stores, no release fence (at device scope that is a write-back of the L2 — of every half-filled
+            // queue line in it): the reader accepts the pair when the tag in the base word's top bits matches too
+            const unsigned long long tag = (unsigned long long)(((uint32_t)P.epoch * 2654435761u + j) & 0xffffffu) << 40;
+            __hip_atomic_store(t, ((((unsigned long long)e[1] << 32) | e[0]) & 0xffffffffffull) | tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(t + 1, ((unsigned long long)e[3] << 32) | e[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
+    // the entry of block j of slab sl from the HBM block table, waiting for it if need be (its reservation never waits for anything)
+    auto shared_wait = [&](uint32_t sl, uint32_t j) -> u32x4 {
+        if (j >= (uint32_t)P.qbtab_stride) return u32x4{0u, 0u, j, 0x80000000u}; // (beyond the table: slow path)
+        unsigned long long *t = P.qbtab + ((size_t)(blockIdx.x * S + sl) * (uint32_t)P.qbtab_stride + j) * 2;
+        for (;;) {
+            const unsigned long long je = __hip_atomic_load(t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long bt = __hip_atomic_load(t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((uint32_t)je == j && ((uint32_t)(je >> 32) & 0x7fffffffu) == (uint32_t)P.epoch && (bt >> 40) == (((uint32_t)P.epoch * 2654435761u + j) & 0xffffffu)) {
+                const unsigned long long base = bt & 0xffffffffffull;
+                return u32x4{(uint32_t)base, (uint32_t)(base >> 32), j, (uint32_t)(je >> 32)};
+            }
+            __builtin_amdgcn_s_sleep(8);
+        }
+    };
+    if (DIRECT == 2) {
+        if (threadIdx.x < S) {
+            scnt[threadIdx.x] = 0u;
+            for (uint32_t k = 1; k < NB; ++k) stab[threadIdx.x * NB + k] = u32x4{0u, 0u, 0xffffffffu, 0u};
+            shared_alloc(threadIdx.x, 0u);
+        }
+        __syncthreads();
+    }
+    // DIRECT: record p of slab s (p = the wave's running count of the slab's records, from the returning ds_add) goes to
+    // record index tab[s].base + p of the queue arrays as long as p < tab[s].limit; lane s keeps the count at which its
+    // block was opened
+    uint32_t open_count = 0;
+    auto publish_block = [&]() { // (lane s) after open_block
+        u32x4 t;
+        if (cur == VXH_WV_NONE) {
+            t = u32x4{0u, 0u, 0u, 1u}; // no room in the sub-queue: every further record of this slab takes the slow path
+        } else {
+            const uint64_t base = (uint64_t)my_sub * P.cap + cur - open_count;
+            t = u32x4{(uint32_t)base, (uint32_t)(base >> 32), open_count + B, 0u};
+        }
+        tab[lane] = t;
+    };
+    if (DIRECT == 1 && lane < S) publish_block();
     if (HOT) __syncthreads(); // the box is zero before any wave adds to it
 
     // One tile = two 16-byte buffer loads per column per lane (rows 2l, 2l+1 and 128+2l, 129+2l of the tile).  Buffer
@@ -1671,6 +1750,19 @@ __global__ void __launch_bounds__(1024) part_scatter_wv(const PartArgs P) {
         __builtin_amdgcn_wave_barrier();
     };
 
+    // DIRECT: ONE store per record — with a value column the record is 12 bytes {value, local index} (PartArgs::qrec12;
+    // two scattered stores per cold row, 2 + 8 bytes, were a quarter of the kernel's time: each lane's store is its own
+    // request to the L2), without one just the uint16 index
+    auto store_record = [&](uint64_t dst, uint32_t local, double value) {
+        if (NVAL) {
+            const uint64_t bits = (uint64_t)__double_as_longlong(value);
+            if (P.no_pipeline & 256) __builtin_nontemporal_store(u32x3_a4{(uint32_t)bits, (uint32_t)(bits >> 32), local}, (u32x3_a4 *)((uint32_t *)P.qidx + dst * 3)); // (experiment)
+            else *(u32x3_a4 *)((uint32_t *)P.qidx + dst * 3) = u32x3_a4{(uint32_t)bits, (uint32_t)(bits >> 32), local};
+        } else {
+            ((uint16_t *)P.qidx)[dst] = (uint16_t)local;
+        }
+    };
+    const uint64_t sink = P.qsink + (uint64_t)(blockIdx.x * nwave + wave) * 16u; // (record index: 16 records apart, behind the sub-queues)
     auto process = [&](const Raw &cur) {
         uint32_t keep = (1u << R) - 1u;
         if (cur.rows != TW) { // the last, partial tile (wave-uniform): rows past the end read as zeros and are dropped here
@@ -1689,6 +1781,7 @@ __global__ void __launch_bounds__(1024) part_scatter_wv(const PartArgs P) {
             for (int r = 0; r < R; ++r) val[NVAL ? r : 0] = f64_of(cur.v, r);
         }
         uint32_t slab[R], loc[R], pos[R], cold = 0;
+        u32x4 where[DIRECT ? R : 1];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             uint32_t sub_i[NDIM];
@@ -1721,10 +1814,84 @@ __global__ void __launch_bounds__(1024) part_scatter_wv(const PartArgs P) {
                 is_cold = is_cold & !hot;
             }
             pos[r] = 0;
+            if (DIRECT && (P.no_pipeline & 64)) is_cold = false; // (timing experiments: bit 6 drops the cold rows)
             if (is_cold) {
-                pos[r] = __hip_atomic_fetch_add(&cnt[slab[r]], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                pos[r] = __hip_atomic_fetch_add(DIRECT == 2 ? &scnt[slab[r]] : &cnt[slab[r]], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (DIRECT == 1) where[r] = tab[slab[r]];
                 cold |= 1u << r;
             }
+        }
+        if (DIRECT == 2) {
+            // reservations first (they wait for nothing), then the entries, then the stores
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                if (((cold >> r) & 1u) && (pos[r] & (QB - 1)) == QB / 2) shared_alloc(slab[r], (pos[r] >> QSH) + 1u);
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                if ((cold >> r) & 1u) where[r] = stab[slab[r] * NB + ((pos[r] >> QSH) & (NB - 1))];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                bool c = ((cold >> r) & 1u) != 0u;
+                const uint32_t j = pos[r] >> QSH;
+                // (every lane stores, the others to the wave's sink record: see DIRECT == 1 below)
+                bool fits = c && where[r][2] == j && where[r][3] == (uint32_t)P.epoch;
+                if (P.no_pipeline & 2) { fits = false; c = false; } // (timing experiments: bit 1 sends every record to the sink)
+                if (P.no_pipeline & 512) fits = fits && slab[r] == 0; // (timing experiments: bit 9 keeps one slab's records)
+                if (P.no_pipeline & 512) c = c && slab[r] == 0;
+                store_record(fits ? ((((uint64_t)where[r][1] << 32) | where[r][0]) + (pos[r] & (QB - 1))) : sink, loc[r], NVAL ? val[NVAL ? r : 0] : 0.0);
+                c = c && !fits;
+                if (__ballot(c)) { // rare: slow path (sub-queue full), or the ring entry is not the block's (yet, or any more)
+                    if (c) {
+                        u32x4 e = where[r];
+                        if (e[2] != j || (e[3] & 0x7fffffffu) != (uint32_t)P.epoch) e = shared_wait(slab[r], j);
+                        if (e[3] >> 31) wv_slow_record(P, ((uint64_t)loc[r] << P.slab_log2) + slab[r], NVAL ? val[NVAL ? r : 0] : 0.0);
+                        else store_record((((uint64_t)e[1] << 32) | e[0]) + (pos[r] & (QB - 1)), loc[r], NVAL ? val[NVAL ? r : 0] : 0.0);
+                    }
+                }
+            }
+            return;
+        }
+        if (DIRECT) {
+            // straight from the registers to the queue: two scattered stores per cold row, nothing staged, nothing copied
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                bool c = ((cold >> r) & 1u) != 0u;
+                // The store is issued by EVERY lane, unconditionally (the others write the wave's sink record): vector
+                // memory operations complete in issue order, so a store inside a branch — a number of operations the
+                // compiler cannot count — makes the wait for the next tile's columns (requested before, i.e. older) a
+                // wait for every store's acknowledgement too: 1.3 us per tile, a quarter of the kernel's time.
+                const bool fits = c && pos[r] < where[r][2];
+                store_record(fits ? (((uint64_t)where[r][1] << 32) | where[r][0]) + pos[r] : sink, loc[r], NVAL ? val[NVAL ? r : 0] : 0.0);
+                c = c && !fits;
+                // rare: the slab's block is full (the next one, now) or the sub-queue is (slow path).  `where` may be
+                // stale (a block opened while an earlier row of this tile was stored): look at the table again first
+                unsigned long long left = __ballot(c);
+                while (left) {
+                    const uint32_t sl = (uint32_t)__builtin_amdgcn_readlane((int)slab[r], __builtin_ctzll(left));
+                    const bool mine = c && slab[r] == sl;
+                    if (mine) {
+                        const u32x4 t = tab[sl];
+                        if (t[3]) {
+                            wv_slow_record(P, ((uint64_t)loc[r] << P.slab_log2) + sl, NVAL ? val[NVAL ? r : 0] : 0.0);
+                            c = false;
+                        } else if (pos[r] < t[2]) {
+                            store_record((((uint64_t)t[1] << 32) | t[0]) + pos[r], loc[r], NVAL ? val[NVAL ? r : 0] : 0.0);
+                            c = false;
+                        }
+                    }
+                    if (__ballot(mine && c)) { // records beyond the slab's current block: every position of that block is taken
+                        if (lane == sl) {
+                            P.qtab[(size_t)my_sub * (uint32_t)P.qtab_stride + (end - B) / B] = B;
+                            open_count += B;
+                            open_block();
+                            publish_block();
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                    left = __ballot(c);
+                }
+            }
+            return;
         }
         // one sub-step per row of the lane: stage, then flush every granule this sub-step completed
 #pragma unroll
@@ -1765,16 +1932,36 @@ __global__ void __launch_bounds__(1024) part_scatter_wv(const PartArgs P) {
             tile = next;
         }
         // what is left in the rings (less than a granule per slab), then the fill of the blocks still open
-        const uint32_t my_cnt = lane < S ? cnt[lane] : 0u;
-        for (uint32_t s = 0; s < S; ++s) {
-            const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)my_cnt, (int)s);
-            const uint32_t rem = c & (G - 1);
-            if (rem) flush(s, (c - rem) & (D - 1), rem);
+        const uint32_t my_cnt = (DIRECT != 2 && lane < S) ? cnt[lane] : 0u;
+        if (DIRECT == 2) {
+        } else if (DIRECT) {
+            if (lane < S && end != VXH_WV_NONE) P.qtab[(size_t)my_sub * (uint32_t)P.qtab_stride + (end - B) / B] = my_cnt - open_count;
+        } else {
+            for (uint32_t s = 0; s < S; ++s) {
+                const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)my_cnt, (int)s);
+                const uint32_t rem = c & (G - 1);
+                if (rem) flush(s, (c - rem) & (D - 1), rem);
+            }
+            if (lane < S) close_block();
         }
-        if (lane < S) close_block();
+    }
+    if (HOT || DIRECT == 2) __syncthreads();
+    if (DIRECT == 2 && threadIdx.x < S) {
+        // the fill table says QB for every reserved block: correct the block the last record went to and the one
+        // reserved ahead of it (both still in the ring)
+        const uint32_t sl = threadIdx.x, total = scnt[sl];
+        const uint32_t jlast = total ? (total - 1u) >> QSH : 0u;
+        const uint32_t jmax = total > QB / 2 ? ((total - QB / 2 - 1u) >> QSH) + 1u : 0u; // blocks 0..jmax were reserved
+        const uint32_t sub = sl * (uint32_t)P.parts + part;
+        for (uint32_t j = jlast; j <= jmax; ++j) {
+            const u32x4 e = stab[sl * NB + (j & (NB - 1))];
+            if (e[2] == j && !(e[3] >> 31)) {
+                const uint64_t b = ((((uint64_t)e[1] << 32) | e[0])) - (uint64_t)sub * P.cap;
+                P.qtab[(size_t)sub * (uint32_t)P.qtab_stride + (uint32_t)(b >> QSH)] = j == jlast ? total - jlast * QB : 0u;
+            }
+        }
     }
     if (HOT) {
-        __syncthreads();
         unsigned long long *gc = P.hot.cnt_acc + (uint64_t)blockIdx.x * hot_cells;
         if (NVAL) flush_add_plain<double, double>(P.hot.sum_acc + (uint64_t)blockIdx.x * hot_cells, hot_sum, hot_cells, 0, 0, hot_cells);
         flush_add_plain<unsigned long long, uint32_t>(gc, hot_cnt, hot_cells, 0, 0, hot_cells);
@@ -1879,6 +2066,15 @@ __device__ __forceinline__ void reduce_trip_fast(const PartArgs &P, char *lds, u
 #pragma unroll
     for (int b = 0; b < N4; ++b) {
         const uint64_t q = at + (uint64_t)b * step;
+        if (P.qrec12) { // 12-byte records {value, local index}: four of them are three 16-byte loads
+            const u32x4 *src = (const u32x4 *)((const uint32_t *)P.qidx + q * 3);
+            const u32x4 w0 = src[0], w1 = src[1], w2 = src[2];
+            v0[4 * b] = ((uint64_t)w0[1] << 32) | w0[0];     loc[4 * b] = w0[2];
+            v0[4 * b + 1] = ((uint64_t)w1[0] << 32) | w0[3]; loc[4 * b + 1] = w1[1];
+            v0[4 * b + 2] = ((uint64_t)w1[3] << 32) | w1[2]; loc[4 * b + 2] = w2[0];
+            v0[4 * b + 3] = ((uint64_t)w2[2] << 32) | w2[1]; loc[4 * b + 3] = w2[3];
+            continue;
+        }
         const ushort4 x = *(const ushort4 *)((const uint16_t *)P.qidx + q);
         loc[4 * b] = x.x; loc[4 * b + 1] = x.y; loc[4 * b + 2] = x.z; loc[4 * b + 3] = x.w;
         if (P.nvals > 0) {
@@ -1968,7 +2164,12 @@ __global__ void __launch_bounds__(1024) part_reduce_fast(const PartArgs P) {
             uint32_t fl[1] = {0xffu};
             uint64_t v1[VXH_PART_MAX_VALS][1];
 #pragma unroll
-            for (int k = 0; k < VXH_PART_MAX_VALS; ++k) v1[k][0] = k < P.nvals ? P.qval[k][qb + t] : 0;
+            for (int k = 0; k < VXH_PART_MAX_VALS; ++k) v1[k][0] = (k < P.nvals && !P.qrec12) ? P.qval[k][qb + t] : 0;
+            if (P.qrec12) {
+                const uint32_t *rec = (const uint32_t *)P.qidx + (qb + t) * 3;
+                v1[0][0] = ((uint64_t)rec[1] << 32) | rec[0];
+                loc[0] = rec[2];
+            }
             records_apply<__HIP_MEMORY_SCOPE_WORKGROUP, true, 1>(P, lds, loc, fl, v1, 1u, replica, slab);
         }
     };
@@ -2198,6 +2399,8 @@ void vxh_launch_part_scatter(const PartArgs &args, const LaunchPlan &plan, int s
             if (args.nvals == 0) { if (masked) VXH_SC((part_scatter_wv<1, 0, true, false, 1>)); else VXH_SC((part_scatter_wv<1, 0, false, false, 1>)); }
             else { if (masked) VXH_SC((part_scatter_wv<1, 1, true, false, 1>)); else VXH_SC((part_scatter_wv<1, 1, false, false, 1>)); }
         }
+        else if (hot && args.wv_direct == 2) { if (args.nvals == 0) VXH_SC((part_scatter_wv<2, 0, false, true, 0, 2>)); else VXH_SC((part_scatter_wv<2, 1, false, true, 0, 2>)); }
+        else if (hot && args.wv_direct) { if (args.nvals == 0) VXH_SC((part_scatter_wv<2, 0, false, true, 0, 1>)); else VXH_SC((part_scatter_wv<2, 1, false, true, 0, 1>)); }
         else if (hot) { if (args.nvals == 0) VXH_SC((part_scatter_wv<2, 0, false, true>)); else VXH_SC((part_scatter_wv<2, 1, false, true>)); }
         else if (args.A.ndim == 1) VXH_WV(1);
         else if (args.A.ndim == 2) VXH_WV(2);
@@ -2264,6 +2467,7 @@ void vxh_launch_part_reduce(const PartArgs &args, const LaunchPlan &plan, hipStr
         if (plan.lds_bytes > 48 * 1024) (void)hipFuncSetAttribute((const void *)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds_bytes); \
         hipLaunchKernelGGL(KERNEL, dim3(plan.blocks), dim3(plan.block), plan.lds_bytes, stream, args);                 \
     } while (0)
+    if (args.qrec12 && !fast) throw std::runtime_error("vaex_hip internal: 12-byte queue records need part_reduce_fast");
     if (!fast && args.A.count16) VXH_RD(part_reduce<true>);
     else if (!fast) VXH_RD(part_reduce<false>);
     else if (args.A.nagg == 1) VXH_RD(part_reduce_fast<1>);

@@ -105,6 +105,13 @@ struct PartArgs {
     // pass 1 = part_scatter_wv (barrier-free, wave-private staging rings): wv = waves per workgroup (0: not this
     // kernel); each wave's LDS area of wv_wave_bytes starts at wv_base + wave * wv_wave_bytes
     int32_t wv, wv_base, wv_wave_bytes;
+    int32_t qrec12;    // the queue holds 12-byte records {value bits, local index} in qidx (ring-less variant with one value column); qval unused
+    uint64_t qsink;    // ring-less variant: record index of the first sink record (one per wave, 16 records apart) behind the sub-queues
+    // wv_direct == 2 (one record stream per (workgroup, slab)): HBM copy of the block entries, [workgroup][slab][qbtab_stride] x 16 bytes
+    // {record index base, block number | (epoch | slow << 31) << 32}; entries of earlier launches carry another epoch
+    unsigned long long *qbtab;
+    int32_t qbtab_stride, epoch;
+    int32_t wv_direct; // part_scatter_wv without rings: cold records go from the registers straight to the queue blocks
     // part_scatter_wv's queue layout: every (wave, slab) fills BLOCKS of qblk records that it reserves from the
     // sub-queue's counter one at a time (normally a single one per launch: qblk is sized for the wave's expected share),
     // and writes how many records each block really holds into qtab[sub * qtab_stride + block].  Pass 2 walks the
@@ -132,6 +139,10 @@ struct PartArgs {
 #define VXH_WV_D 128
 #define VXH_WV_G 64
 // LDS of ONE wave of part_scatter_wv: [value ring][index ring][S counters]
+#define VXH_WV_SHARED_QB 1024u
+#define VXH_WV_SHARED_NB 16u
+#define VXH_WV_SHARED_LDS(S) ((((size_t)(S) * 4 + 15) & ~(size_t)15) + (size_t)(S) * VXH_WV_SHARED_NB * 16)
+#define VXH_WV_WAVE_LDS_DIRECT(S) ((((size_t)(S) * 20) + 15) & ~(size_t)15)
 #define VXH_WV_WAVE_LDS(NVAL, S) ((((size_t)(S) * VXH_WV_D * (2 + 8 * (size_t)(NVAL)) + (size_t)(S) * 4) + 15) & ~(size_t)15)
 
 struct HotMergeArgs {
