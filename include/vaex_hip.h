@@ -205,6 +205,34 @@ int vxh_first_result(vxh_first *first, void *values_out, uint8_t *masked_out, vo
 /* dtype size * grids * cells: what vaex's memory check expects of the reference class (vaex/agg.py:300-318) */
 size_t vxh_first_bytes_used(const vxh_first *first);
 
+/* ---- AggNUnique / AggList -------------------------------------------------------------------- */
+/* One collector object behind both: every vxh_collect_bin call appends its rows' {value, flat cell} pairs to a device array
+ * (sorted and, for nunique, reduced to the distinct pairs whenever it has doubled, and when a result is asked for).
+ *   mode 0 = AggNUnique_<T>(grid, grids, threads, dropmissing, dropnan) — src/agg_nunique.cpp:7-95: per cell the number of
+ *     distinct values (+1 if a missing value was seen, +1 if a NaN was seen, unless dropped).  data mask: 0 = missing value;
+ *     selection mask: 0 = the row is skipped (:70-73).  drop_a = dropmissing, drop_b = dropnan.
+ *     Deliberate difference: dropmissing / dropnan take ONE entry away from a cell that saw such rows; the reference
+ *     subtracts the number of those ROWS (`count -= counter->null_count`, :31-34), right only for cells with at most one —
+ *     vxh_config_set("nunique_row_counts", 1) reproduces it.  Values are told apart by their bits (-0.0 and +0.0 are two, as
+ *     for the reference's hash of the bits).
+ *   mode 1 = AggList_<T>_<T2>(grid, grids, threads, dropnan, dropnull) — src/agg_list.cpp:7-128: per cell the values in row
+ *     order, then its NaNs, then one slot per counted missing value (the reference leaves those slots uninitialised; here
+ *     they read 0).  data mask: 1 = value present, 0 = missing (other bytes: the row is ignored, :103,:116).
+ *     drop_a = dropnan, drop_b = dropnull.  Deliberate difference: the mask is read at the row's index (the reference reads
+ *     `data_mask_ptr[j]` inside its 1024-row block, :103, like AggFirst).
+ * grids must be 1 (the reference's own restriction).  merge() is not offered (the reference's are empty / throw). */
+typedef struct vxh_collect vxh_collect;
+int vxh_collect_create(int mode, int dtype, int flip_endian, vxh_grid *grid, int grids, int threads, int drop_a, int drop_b, vxh_collect **out);
+void vxh_collect_destroy(vxh_collect *collect);
+int vxh_collect_set_data(vxh_collect *collect, int thread, const void *data, uint64_t n, int mem);
+int vxh_collect_set_data_mask(vxh_collect *collect, int thread, const uint8_t *mask, uint64_t n, int mem);      /* NULL clears */
+int vxh_collect_set_selection_mask(vxh_collect *collect, int thread, const uint8_t *mask, uint64_t n, int mem); /* NULL clears */
+int vxh_collect_bin(vxh_collect *collect, int thread, uint64_t length);
+/* int64 per cell, dim 0 fastest (get_result, src/agg_nunique.cpp:17-45) */
+int vxh_collect_nunique_result(vxh_collect *collect, int64_t *out_cells);
+/* offsets_out[cells + 1]; values_out NULL: only the offsets and *flat_length_out; else flat_length elements of dtype */
+int vxh_collect_list_result(vxh_collect *collect, int64_t *offsets_out, void *values_out, uint64_t *flat_length_out);
+
 /* ---- row-wise helpers ---------------------------------------------------------------------- */
 /* device memory for the helpers' results (a plain hipMalloc / hipFree) */
 int vxh_device_alloc(size_t bytes, void **out);

@@ -41,6 +41,12 @@ def run(**cfg):
 
 
 run()
-run(blk=0)
+run(part_lds=160000)
+run(part_lds=160000, part_rows=4)
+run(part_lds=160000, blk=2)
+run(part_lds=160000, scatter_wgs=1)
+run(part_lds=160000, scatter_wgs=3)
+run(part_lds=160000, part_chunk=1 << 27)
+run(part_lds=160000, part_chunk=1 << 29)
+run(blk=2)
 run()
-run(blk=0)

@@ -32,7 +32,7 @@ __all__ = ["superagg", "install", "uninstall", "cache_columns", "uncache_columns
 #   BinnerHash_*   vaex's experimental hash binner (disabled by default, cells laid out differently, takes vaex's own
 #                  ordered_set): tasks that ask for it run on vaex's C++
 _HIDDEN_PREFIXES = ("BinnerHash_",)
-UNSUPPORTED = ("AggList_*", "AggNUnique_*", "AggCount_string", "AggCount_object", "*_string / *_object aggregators", "BinnerCombined", "BinnerHash_*")
+UNSUPPORTED = ("AggCount_string", "AggCount_object", "*_string / *_object aggregators", "BinnerCombined", "BinnerHash_*")
 
 
 class _Backend:
@@ -84,7 +84,7 @@ def install(vaex_module=None, legacy=True, hash_sets=True, chunk_size=None):
 
     * `vaex.superagg` becomes a `_Backend` and the task-part registry entry "aggregations" (vaex/cpu.py:629-631,
       vaex/encoding.py:31-52) a subclass of vaex's TaskPartAggregation whose `decode` builds the task part from the HIP
-      classes and, when an aggregation or binner it needs is not among them (list / nunique, string and
+      classes and, when an aggregation or binner it needs is not among them (string and
       object aggregators, BinnerCombined, BinnerHash: `vaex_amd.UNSUPPORTED`), builds it again from vaex's own C++ —
       so everything that worked before install() still works, on the CPU, and everything on the hot path runs on the GPU.
     * legacy=True points the legacy statistic task (df.minmax / limits=None: vaex/cpu.py:533-538) at

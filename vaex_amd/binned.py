@@ -572,6 +572,96 @@ class Frame:
     def last(self, expression, order_expression=None, binby=None, limits=None, shape=128, selection=None, edges=False):
         return self._first_last(True, expression, order_expression, binby, limits, shape, selection, edges)
 
+    def nunique(self, expression, binby=None, limits=None, shape=128, selection=None, dropna=False, dropnan=False, dropmissing=False, edges=False):
+        """df.nunique (vaex/dataframe.py:1057-1089 -> vaex.agg.nunique, vaex/agg.py:600-612 -> AggNUnique_<T>): per cell the
+        number of distinct values of `expression`; NaN and the missing value count as one value each unless dropped
+        (dropna = both).  The rows' {value, cell} pairs are sorted and reduced on the device (vxh_collect_*)."""
+        sa = self.sa
+        specs = self._binner_specs(binby or [], limits, shape)
+        value = self.columns[expression]
+        missing = None
+        if np.ma.isMaskedArray(value):
+            missing = np.ma.getmaskarray(value)
+            value = np.ma.getdata(value)
+        cols = [self.columns[s["column"]] for s in specs]
+        if any(np.ma.isMaskedArray(c) for c in cols):
+            raise NotImplementedError("nunique binned by columns with missing values")
+        sel = self._mask_array(selection)
+        device = all(_is_device(c) for c in cols + [value]) and (sel is None or _is_device(sel))
+        binners = []
+        for s_, c in zip(specs, cols):
+            pf = _class_postfix(c)
+            if s_["kind"] == "scalar":
+                binners.append(getattr(sa, "BinnerScalar_" + pf)(1, s_["column"], s_["vmin"], s_["vmax"], s_["bins"]))
+            else:
+                binners.append(getattr(sa, "BinnerOrdinal_" + pf)(1, s_["column"], s_["count"], s_["min_value"], False, s_["invert"]))
+        grid = sa.Grid(binners)
+        a = getattr(sa, "AggNUnique_" + _class_postfix(value))(grid, 1, 1, bool(dropmissing or dropna), bool(dropnan or dropna))
+        step = self.n if device else self.chunk_size
+        for i1 in range(0, self.n, max(1, step)):
+            i2 = min(self.n, i1 + step)
+            refs = []
+            pick = (lambda c: c[i1:i2]) if device else (lambda c: (lambda d: d.view("u1") if d.dtype == np.bool_ else d)(np.ascontiguousarray(c[i1:i2])))
+            for b, c in zip(binners, cols):
+                d = pick(c); b.set_data(0, d); b.clear_data_mask(0); refs.append(d)
+            d = pick(value); a.set_data(0, d, 0); refs.append(d)
+            # vaex/cpu.py:733-770: the selection goes in as selection mask, selection & ~missing as data mask
+            if sel is not None:
+                m = _as_u8(sel[i1:i2]); a.set_selection_mask(0, m); refs.append(m)
+            else:
+                a.clear_selection_mask(0)
+            if missing is not None:
+                m = _as_u8(~missing[i1:i2] if sel is None else (np.asarray(sel[i1:i2]).astype(bool) & ~missing[i1:i2])); a.set_data_mask(0, m); refs.append(m)
+            elif sel is not None:
+                a.set_data_mask(0, refs[-1])
+            else:
+                a.clear_data_mask(0)
+            grid.bin(0, [a], i2 - i1)
+        r = np.asarray(a.get_result())
+        if not specs:
+            return int(r.reshape(-1)[0])
+        if not edges:
+            r = r[tuple(slice(2, -1) if s_["kind"] == "scalar" else slice(0, -2) for s_ in specs)]
+        return r
+
+    def value_counts(self, expression, dropna=False, dropnan=False, dropmissing=False, ascending=False):
+        """df[expression].value_counts() (vaex/expression.py:1029-1130 -> TaskPartValueCounts, vaex/cpu.py:141-283: a
+        `counter_<T>` hash map per thread, merged) for an integer or float column: (values, counts) sorted by count
+        (descending unless `ascending`; ties by value).  = the groupby count of the column on itself: the dense-range
+        ordinal pass or the fused hash aggregation on the device; float values are counted by their bits (NaN one value)."""
+        col = self.columns[expression]
+        missing = 0
+        if np.ma.isMaskedArray(col):
+            m = np.ma.getmaskarray(col)
+            missing = int(m.sum())
+            col = np.ma.getdata(col)[~m]
+        kind = str(col.dtype).replace("torch.", "")
+        nans = 0
+        if kind.startswith("float"):
+            import torch
+            dev = _is_device(col)
+            t = col if dev else torch.from_numpy(np.ascontiguousarray(col))
+            isnan = torch.isnan(t)
+            nans = int(isnan.sum())
+            t = t[~isnan].to(torch.float64)
+            t = torch.where(t == 0, torch.zeros_like(t), t)  # -0.0 counts as 0.0 (one key, as for the hash sets)
+            keys = t.view(torch.int64)
+            keys = keys if dev else keys.numpy()
+        else:
+            keys = col
+        sub = Frame({"k": keys}, chunk_size=self.chunk_size, superagg=self.sa)
+        out = sub.groupby("k", {"n": agg.count()}) if len(keys) else {"k": np.array([], dtype="i8"), "n": np.array([], dtype="i8")}
+        values, counts = np.asarray(out["k"]), np.asarray(out["n"]).astype(np.int64)
+        if kind.startswith("float"):
+            values = values.astype(np.int64).view(np.float64).astype(kind)
+            if nans and not (dropnan or dropna):
+                values = np.concatenate([values, [np.nan]]); counts = np.concatenate([counts, [nans]])
+        values = np.ma.array(values, mask=np.zeros(len(values), bool)) if missing and not (dropmissing or dropna) else values
+        if missing and not (dropmissing or dropna):
+            values = np.ma.concatenate([values, np.ma.masked_all(1, dtype=values.dtype)]); counts = np.concatenate([counts, [missing]])
+        order = np.lexsort((np.arange(len(counts)), counts if ascending else -counts))
+        return values[order], counts[order]
+
     # ------------------------------------------------------------------ groupby
     def _groupby_combined(self, by, agg_spec, reduce, comm):
         """df.groupby([k1, k2, ...]): the keys' ordinals packed into ONE int64 key on the device (vxh_pack_keys — the
@@ -622,6 +712,20 @@ class Frame:
         del packed
         return out
 
+    def _key_range(self, by, key, pf):
+        """exact integer (min, max) of this rank's rows of a key column: one streaming pass (vxh_minmax_int), remembered per
+        column — a frame's columns do not change under it, which is the contract vaex's own per-dataframe caches rest on
+        (vaex/dataframe.py:1795-1840 `limits`, vaex/cache.py)."""
+        if not self.n:
+            return 2**63 - 1, -2**63
+        cache = self.__dict__.setdefault("_key_range_cache", {})
+        hit = cache.get(by)
+        if hit is not None and hit[0] is key:
+            return hit[1]
+        r = self.sa.minmax_int(key if _is_device(key) else np.ascontiguousarray(key), None, _DT_CODE[pf], False)
+        cache[by] = (key, r)
+        return r
+
     def groupby(self, by, agg_spec, reduce=None, comm=None):
         """df.groupby(by).agg({...}) for ONE integer key column (a list of key columns: see _groupby_combined).
         Returns {by: keys (ascending), name: values}.
@@ -653,7 +757,7 @@ class Frame:
         if self.n == 0 and comm is None:
             return {by: np.array([], dtype=np.int64), **{n: np.array([]) for n in names}}
         # key range: one exact integer min/max pass (vxh_minmax_int); ranks agree on the global range
-        kmin, kmax = sa.minmax_int(key if _is_device(key) else np.ascontiguousarray(key), None, _DT_CODE[pf], False) if self.n else (2**63 - 1, -2**63)
+        kmin, kmax = self._key_range(by, key, pf)
         if comm is not None:
             kmin, kmax = comm.minmax(kmin, kmax)
         count = kmax - kmin + 1

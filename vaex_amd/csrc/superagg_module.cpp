@@ -510,6 +510,79 @@ struct PyAggFirst {
     }
 };
 
+// AggNUnique_<T>[_non_native](grid, grids, threads, dropmissing, dropnan) — src/agg_nunique.cpp:226-235 — and
+// AggList_<T>_<T2>[_non_native](grid, grids, threads, dropnan, dropnull) — src/agg_list.cpp:223-233: ONE class each here, the
+// reference's names come from the module's __getattr__
+struct PyCollect {
+    vxh_collect *h = nullptr;
+    PyGrid *grid;
+    int mode, dtype;
+    PyCollect(PyGrid *grid, int grids, int threads, bool a, bool b, int mode, int dtype, bool flip) : grid(grid), mode(mode), dtype(dtype) {
+        check(vxh_collect_create(mode, dtype, flip, grid->h, grids, threads, a, b, &h));
+    }
+    ~PyCollect() { vxh_collect_destroy(h); }
+    PyCollect(const PyCollect &) = delete;
+    void set_data(int thread, const py::object &ar, size_t index) {
+        if (index != 0) return; // (AggList's second column is registered and never read: src/agg_list.cpp:91)
+        ArrayRef a = resolve_array(ar);
+        if (a.itemsize != kTypeSizes[dtype]) throw std::runtime_error("Itemsize of data and aggregator are not equal");
+        check(vxh_collect_set_data(h, thread, a.ptr, a.n, a.mem));
+    }
+    void set_data_mask(int thread, const py::object &ar) {
+        ArrayRef a = resolve_array(ar);
+        check(vxh_collect_set_data_mask(h, thread, (const uint8_t *)a.ptr, a.n, a.mem));
+    }
+    void clear_data_mask(int thread) { check(vxh_collect_set_data_mask(h, thread, nullptr, 0, VXH_MEM_HOST)); }
+    void set_selection_mask(int thread, const py::object &ar) {
+        ArrayRef a = resolve_array(ar);
+        check(vxh_collect_set_selection_mask(h, thread, (const uint8_t *)a.ptr, a.n, a.mem));
+    }
+    void clear_selection_mask(int thread) { check(vxh_collect_set_selection_mask(h, thread, nullptr, 0, VXH_MEM_HOST)); }
+    void bin(int thread, uint64_t length) {
+        int rc;
+        {
+            py::gil_scoped_release release;
+            rc = vxh_collect_bin(h, thread, length);
+        }
+        check(rc);
+    }
+    // nunique: int64 array of the grid's shape, transposed like the reference's (src/agg_nunique.cpp:40-44)
+    py::object nunique_result() {
+        std::vector<uint64_t> shp = grid->shapes(), str = grid->strides();
+        std::vector<ssize_t> shape(shp.begin(), shp.end()), strides;
+        for (auto v : str) strides.push_back((ssize_t)v * 8);
+        py::array out(py::dtype("int64"), shape, strides);
+        int rc;
+        {
+            py::gil_scoped_release release;
+            rc = vxh_collect_nunique_result(h, (int64_t *)out.mutable_data());
+        }
+        check(rc);
+        return out;
+    }
+    // list: (offsets int64[cells + 1], values[flat]) — what the reference hands to vaex.arrow.convert.list_from_arrays
+    py::tuple list_arrays() {
+        uint64_t cells = 1;
+        for (auto v : grid->shapes()) cells *= v;
+        py::array_t<int64_t> offsets((ssize_t)cells + 1);
+        uint64_t flat = 0;
+        check(vxh_collect_list_result(h, offsets.mutable_data(), nullptr, &flat));
+        py::array values(py::dtype(std::string(kNumpyFormats[dtype])), std::vector<ssize_t>{(ssize_t)flat});
+        int rc;
+        {
+            py::gil_scoped_release release;
+            rc = vxh_collect_list_result(h, offsets.mutable_data(), values.mutable_data(), &flat);
+        }
+        check(rc);
+        return py::make_tuple(offsets, values);
+    }
+    py::object get_result() {
+        if (mode == 0) return nunique_result();
+        py::tuple r = list_arrays();
+        return py::module::import("vaex.arrow.convert").attr("list_from_arrays")(r[0], r[1]); // src/agg_list.cpp:81-83
+    }
+};
+
 template <int KIND, int DT, bool FLIP>
 struct TAgg : PyAgg {
     TAgg(PyGrid *grid, int grids, int threads) : PyAgg(KIND, DT, FLIP, grid, grids, threads, 0) {}
@@ -843,8 +916,10 @@ PYBIND11_MODULE(superagg, m) {
             // AggFirst aggregators take their own passes (vxh_first_bin), everything else ONE fused vxh_grid_bin
             std::vector<PyAgg *> plain;
             std::vector<PyAggFirst *> firsts;
+            std::vector<PyCollect *> collects;
             for (const py::handle &a : aggs) {
                 if (py::isinstance<PyAggFirst>(a)) firsts.push_back(a.cast<PyAggFirst *>());
+                else if (py::isinstance<PyCollect>(a)) collects.push_back(a.cast<PyCollect *>());
                 else plain.push_back(a.cast<PyAgg *>());
             }
             uint64_t n;
@@ -863,6 +938,7 @@ PYBIND11_MODULE(superagg, m) {
                 }
                 check(rc);
             }
+            for (PyCollect *c : collects) c->bin(thread, n);
         }, py::arg("thread"), py::arg("aggregators"), py::arg("length") = py::none())
         .def("__len__", [](const PyGrid &g) { return vxh_grid_length1d(g.h); })
         .def_property_readonly("binners", [](const PyGrid &g) { return g.binners; }, py::return_value_policy::reference)
@@ -880,8 +956,45 @@ PYBIND11_MODULE(superagg, m) {
         .def("merge", [](PyAggFirst &, const py::object &) { throw std::runtime_error("merge: not implemented"); }) // src/agg_first.cpp:42
         .def("__sizeof__", &PyAggFirst::bytes_used)
         .def_property_readonly("grid", [](const PyAggFirst &a) { return a.grid; }, py::return_value_policy::reference);
+    py::class_<PyCollect>(m, "AggCollect")
+        .def(py::init<PyGrid *, int, int, bool, bool, int, int, bool>(), py::keep_alive<1, 2>(), py::arg("grid"), py::arg("grids"), py::arg("threads"), py::arg("a"), py::arg("b"),
+             py::arg("mode"), py::arg("dtype"), py::arg("flip") = false)
+        .def("set_data", &PyCollect::set_data, py::arg("thread"), py::arg("ar"), py::arg("index") = 0)
+        .def("set_data_mask", &PyCollect::set_data_mask)
+        .def("clear_data_mask", &PyCollect::clear_data_mask)
+        .def("set_selection_mask", &PyCollect::set_selection_mask)
+        .def("clear_selection_mask", &PyCollect::clear_selection_mask)
+        .def("bin", &PyCollect::bin)
+        .def("get_result", &PyCollect::get_result)
+        .def("list_arrays", &PyCollect::list_arrays)
+        .def("merge", [](PyCollect &c, const py::object &others) {
+            if (c.mode == 0 && py::len(others) > 0) throw std::runtime_error("merge not implemented"); // src/agg_nunique.cpp:46-49 (AggList: a no-op, src/agg_list.cpp:49)
+        })
+        // (vaex predicts nunique's footprint as sizeof(the class on a grid of one cell) x cells and insists on equality:
+        //  vaex/agg.py:354-368 — any per-cell constant does; the pairs live on the device)
+        .def("__sizeof__", [](const PyCollect &c) { return (size_t)8 * (size_t)vxh_grid_length1d(c.grid->h); })
+        .def_property_readonly("grid", [](const PyCollect &a) { return a.grid; }, py::return_value_policy::reference);
     // AggFirst_<T>_<T2>[_non_native] -> a constructor with the reference's signature (grid, grids, threads, invert)
     m.def("__getattr__", [m](const std::string &name) -> py::object {
+        for (int mode = 0; mode < 2; mode++) {
+            const std::string prefix = mode ? "AggList_" : "AggNUnique_";
+            if (name.compare(0, prefix.size(), prefix) != 0) continue;
+            std::string rest = name.substr(prefix.size());
+            bool flip = false;
+            const std::string nn = "_non_native";
+            if (rest.size() > nn.size() && rest.compare(rest.size() - nn.size(), nn.size(), nn) == 0) {
+                flip = true;
+                rest = rest.substr(0, rest.size() - nn.size());
+            }
+            for (int a = 0; a < VXH_DTYPE_COUNT; a++) {
+                bool hit = rest == kTypeNames[a];
+                if (mode) { // AggList_<T>_<T2>: the second type is registered and never used
+                    hit = false;
+                    for (int b = 0; b < VXH_DTYPE_COUNT; b++) hit = hit || rest == std::string(kTypeNames[a]) + "_" + kTypeNames[b];
+                }
+                if (hit) return py::module::import("functools").attr("partial")(m.attr("AggCollect"), py::arg("mode") = mode, py::arg("dtype") = a, py::arg("flip") = flip);
+            }
+        }
         const std::string prefix = "AggFirst_";
         if (name.compare(0, prefix.size(), prefix) == 0) {
             std::string rest = name.substr(prefix.size());

@@ -14,6 +14,8 @@
 #include <stdexcept>
 #include <string>
 #include <vector>
+#include <string.h>
+#include <rocprim/rocprim.hpp>
 
 #include "vxh_internal.hpp"
 
@@ -614,6 +616,14 @@ static LaunchPlan make_plan(const BinArgs &A, BinArgs &out, uint64_t n, double b
     const size_t part_per_cell = c16_part ? (size_t)2 * A.nagg : (c16_lds ? per_cell * 2 : per_cell);
     int part_log2 = 0;
     while (part_log2 < 8 && ((A.cells + (1ull << part_log2) - 1) >> part_log2) * part_per_cell > part_budget) part_log2++;
+    // ... but when ALL of the LDS holds a slab twice as big, half as many slabs are worth it: pass 1's per-slab segments
+    // double (1e6-group sum/count/sum2: 256 -> 128 slabs, 10.8 -> 9.3 ms per 1e9 rows, profiles/r02_groupby_tune.txt)
+    if (c.cfg_part_lds <= 0 && part_log2 >= 6) {
+        const uint64_t cells2 = (A.cells + (1ull << (part_log2 - 1)) - 1) >> (part_log2 - 1);
+        size_t lds2 = 0;
+        for (int k = 0; k < A.nagg; k++) lds2 += (cells2 * vxh_lds_cell_size(A.a[k].kind, A.a[k].cell, c16_part) + 8 + 15) & ~(size_t)15;
+        if (lds2 + 256 <= kLdsMax) part_log2--;
+    }
     const uint64_t part_slab_cells = (A.cells + (1ull << part_log2) - 1) >> part_log2;
     int nvals = 0, nmasks = 0;
     {
@@ -1422,6 +1432,7 @@ int vxh_config_set(const char *key, int64_t value) {
     else if (k == "hot_h") c.cfg_hot_box[3] = value;
     else if (k == "lds_replicas") c.cfg_lds_replicas = value;
     else if (k == "first_mask_block") c.cfg_first_mask_block = value > 0 ? value : 0;
+    else if (k == "nunique_row_counts") c.cfg_nunique_row_counts = value;
     else throw std::runtime_error("unknown config key: " + k);
     VXH_API_END
 }
@@ -2065,6 +2076,237 @@ int vxh_first_result(vxh_first *f, void *values_out, uint8_t *masked_out, void *
         canon_to_host(v, f->dtype, values_out, c);
         if (order_out) canon_to_host(empty ? 0 : key_to_canon(host[c], f->dtype_order, f->invert), f->dtype_order, order_out, c);
     }
+    VXH_API_END
+}
+
+// ------------------------------------------------------------------------------------------
+// AggNUnique / AggList (src/agg_nunique.cpp, src/agg_list.cpp): the reference keeps a hash counter / a std::vector per
+// cell.  Here every call appends its rows' {value bits, flat cell} pairs to ONE device array; two stable radix sorts
+// (value, then cell) put equal pairs next to each other, a flag + select pass keeps one of each (nunique) or all live
+// ones in row order per cell (list).  The array is compacted when it has doubled since the last time, so a stream of
+// 1 Mi-row calls costs O(rows log) sorts in total, and the footprint stays <= 2 x the distinct pairs + one call.
+// ------------------------------------------------------------------------------------------
+static void collect_compact(vxh_collect *c, Slot &slot) {
+    if (c->n == c->compact) return;
+    const uint64_t n = c->n;
+    DevBuf val2(n * 8), cell2(n * 4), flags(n), count_d(8);
+    size_t t1 = 0, t2 = 0, t3 = 0, t4 = 0;
+    uint64_t *v0 = c->val, *v1 = (uint64_t *)val2.p;
+    uint32_t *c0 = c->cell, *c1 = (uint32_t *)cell2.p;
+    if (c->mode == 0) HIP_CHECK(rocprim::radix_sort_pairs(nullptr, t1, v0, v1, c0, c1, n, 0, 64, slot.stream));
+    HIP_CHECK(rocprim::radix_sort_pairs(nullptr, t2, c1, c0, v1, v0, n, 0, 32, slot.stream));
+    HIP_CHECK(rocprim::select(nullptr, t3, v0, (uint8_t *)flags.p, v1, (uint64_t *)count_d.p, n, slot.stream));
+    HIP_CHECK(rocprim::select(nullptr, t4, c0, (uint8_t *)flags.p, c1, (uint64_t *)count_d.p, n, slot.stream));
+    DevBuf tmp(std::max(std::max(t1, t2), std::max(t3, t4)) + 16);
+    if (c->mode == 0) { // by value, then (stable) by cell: equal pairs adjacent, cells ascending
+        HIP_CHECK(rocprim::radix_sort_pairs(tmp.p, t1, v0, v1, c0, c1, n, 0, 64, slot.stream));
+        HIP_CHECK(rocprim::radix_sort_pairs(tmp.p, t2, c1, c0, v1, v0, n, 0, 32, slot.stream));
+    } else { // list: (stable) by cell only — rows keep their order inside a cell
+        HIP_CHECK(rocprim::radix_sort_pairs(tmp.p, t2, c0, c1, v0, v1, n, 0, 32, slot.stream));
+        HIP_CHECK(hipMemcpyAsync(c0, c1, n * 4, hipMemcpyDeviceToDevice, slot.stream));
+        HIP_CHECK(hipMemcpyAsync(v0, v1, n * 8, hipMemcpyDeviceToDevice, slot.stream));
+    }
+    vxh_launch_pair_flags(v0, c0, (uint8_t *)flags.p, n, c->mode == 0 ? 1 : 0, slot.stream);
+    HIP_CHECK(rocprim::select(tmp.p, t3, v0, (uint8_t *)flags.p, v1, (uint64_t *)count_d.p, n, slot.stream));
+    HIP_CHECK(rocprim::select(tmp.p, t4, c0, (uint8_t *)flags.p, c1, (uint64_t *)count_d.p, n, slot.stream));
+    uint64_t kept = 0;
+    HIP_CHECK(hipMemcpyAsync(&kept, count_d.p, 8, hipMemcpyDeviceToHost, slot.stream));
+    HIP_CHECK(hipMemcpyAsync(v0, v1, n * 8, hipMemcpyDeviceToDevice, slot.stream));
+    HIP_CHECK(hipMemcpyAsync(c0, c1, n * 4, hipMemcpyDeviceToDevice, slot.stream));
+    HIP_CHECK(hipStreamSynchronize(slot.stream));
+    c->n = c->compact = kept;
+}
+
+int vxh_collect_create(int mode, int dtype, int flip_endian, vxh_grid *grid, int grids, int threads, int drop_a, int drop_b, vxh_collect **out) {
+    VXH_API_BEGIN
+    if (mode != 0 && mode != 1) throw std::runtime_error("vxh_collect_create: mode 0 (nunique) or 1 (list)");
+    if (dtype < 0 || dtype >= VXH_DTYPE_COUNT) throw std::runtime_error("unknown dtype");
+    if (grids != 1) throw std::runtime_error(mode ? "list aggregation only accepts 1 grid" : "Expected 1 grid"); // src/agg_list.cpp:18, src/agg_nunique.cpp:20
+    if (grid->length1d >= 0xffffffffull) throw std::runtime_error("vxh_collect: grids of 2^32 cells and more are not supported");
+    std::unique_ptr<vxh_collect> c(new vxh_collect());
+    c->mode = mode; c->dtype = dtype; c->flip = flip_endian ? 1 : 0; c->drop_a = drop_a ? 1 : 0; c->drop_b = drop_b ? 1 : 0;
+    c->grid = grid; c->threads = threads;
+    c->data.resize(threads); c->mask.resize(threads); c->selection.resize(threads);
+    *out = c.release();
+    VXH_API_END
+}
+void vxh_collect_destroy(vxh_collect *c) {
+    if (!c) return;
+    if (c->val || c->null_rows) (void)hipDeviceSynchronize();
+    (void)hipFree(c->val); (void)hipFree(c->cell); (void)hipFree(c->null_rows); (void)hipFree(c->nan_rows);
+    delete c;
+}
+int vxh_collect_set_data(vxh_collect *c, int thread, const void *data, uint64_t n, int mem) {
+    VXH_API_BEGIN
+    check_slot(thread, c->data.size(), "data_ptr");
+    c->data[thread] = SlotData{data, n, mem};
+    VXH_API_END
+}
+int vxh_collect_set_data_mask(vxh_collect *c, int thread, const uint8_t *mask, uint64_t n, int mem) {
+    VXH_API_BEGIN
+    check_slot(thread, c->mask.size(), "data_mask_ptr");
+    c->mask[thread] = SlotData{mask, n, mem};
+    VXH_API_END
+}
+int vxh_collect_set_selection_mask(vxh_collect *c, int thread, const uint8_t *mask, uint64_t n, int mem) {
+    VXH_API_BEGIN
+    check_slot(thread, c->selection.size(), "selection_mask_ptr");
+    c->selection[thread] = SlotData{mask, n, mem};
+    VXH_API_END
+}
+
+int vxh_collect_bin(vxh_collect *c, int thread, uint64_t length) {
+    VXH_API_BEGIN
+    ensure_device_ready();
+    if (!length) return 0;
+    vxh_grid *grid = c->grid;
+    check_slot(thread, c->data.size(), "data_ptr");
+    const SlotData &sv = c->data[thread], &sm = c->mask[thread], &ss = c->selection[thread];
+    if (!sv.ptr) throw std::runtime_error("data not set");
+    if (sv.n < length) throw std::runtime_error("aggregator data is shorter than the requested length");
+    if (sm.ptr && sm.n < length) throw std::runtime_error("aggregator data mask is shorter than the requested length");
+    if (ss.ptr && ss.n < length) throw std::runtime_error("aggregator selection mask is shorter than the requested length");
+    for (vxh_binner *b : grid->binners) {
+        check_slot(thread, b->data.size(), "data_ptr");
+        if (!b->data[thread].ptr) throw std::runtime_error("data not set");
+        if (b->data[thread].n < length) throw std::runtime_error("binner data is shorter than the requested length");
+        if (b->mask[thread].ptr && b->mask[thread].n < length) throw std::runtime_error("binner data mask is shorter than the requested length");
+    }
+    std::lock_guard<std::mutex> lock(c->mutex);
+    Slot &slot = get_slot(thread);
+    order_after_producers(slot);
+    const uint64_t cells = grid->length1d;
+    if (!c->null_rows) {
+        HIP_CHECK(hipMalloc(&c->null_rows, cells * 8));
+        HIP_CHECK(hipMalloc(&c->nan_rows, cells * 8));
+        HIP_CHECK(hipMemsetAsync(c->null_rows, 0, cells * 8, slot.stream));
+        HIP_CHECK(hipMemsetAsync(c->nan_rows, 0, cells * 8, slot.stream));
+    }
+    if (c->n + length > c->cap) {
+        // compact first when that is worth it (the array has at least doubled since the last time), then grow
+        if (c->n > 2 * c->compact + (1u << 22)) collect_compact(c, slot);
+        if (c->n + length > c->cap) {
+            const uint64_t cap = std::max<uint64_t>(c->n + length, c->cap + c->cap / 2);
+            uint64_t *nv = nullptr; uint32_t *nc = nullptr;
+            HIP_CHECK(hipMalloc(&nv, cap * 8));
+            HIP_CHECK(hipMalloc(&nc, cap * 4));
+            if (c->n) {
+                HIP_CHECK(hipMemcpyAsync(nv, c->val, c->n * 8, hipMemcpyDeviceToDevice, slot.stream));
+                HIP_CHECK(hipMemcpyAsync(nc, c->cell, c->n * 4, hipMemcpyDeviceToDevice, slot.stream));
+            }
+            HIP_CHECK(hipStreamSynchronize(slot.stream));
+            (void)hipFree(c->val); (void)hipFree(c->cell);
+            c->val = nv; c->cell = nc; c->cap = cap;
+        }
+    }
+    std::vector<std::unique_ptr<DevBuf>> tmps;
+    auto resolve = [&](const SlotData &sd, size_t elem) -> const void * {
+        if (!sd.ptr) return nullptr;
+        tmps.emplace_back();
+        return on_device(slot, sd.ptr, (size_t)length * elem, sd.mem, tmps.back());
+    };
+    CollectArgs C{};
+    C.A.n = length;
+    fill_binner_descs(grid, thread, C.A, resolve);
+    C.val = resolve(sv, kDtypeSize[c->dtype]);
+    C.data_mask = (const uint8_t *)resolve(sm, 1);
+    C.selection_mask = (const uint8_t *)resolve(ss, 1);
+    C.val_dtype = (uint8_t)c->dtype;
+    C.flip = (uint8_t)c->flip;
+    C.mode = (uint8_t)c->mode;
+    C.drop_nan = (uint8_t)(c->mode ? c->drop_a : 0);
+    C.drop_null = (uint8_t)(c->mode ? c->drop_b : 0);
+    C.out_val = c->val + c->n;
+    C.out_cell = c->cell + c->n;
+    C.null_rows = c->null_rows;
+    C.nan_rows = c->nan_rows;
+    vxh_launch_collect(C, slot.stream);
+    HIP_CHECK(hipGetLastError());
+    c->n += length;
+    HIP_CHECK(hipStreamSynchronize(slot.stream)); // (the temporaries go away; the next call may come from another slot's stream)
+    VXH_API_END
+}
+
+// nunique per cell: distinct non-NaN values + 1 if the cell saw a missing value + 1 if it saw a NaN, minus what
+// dropmissing / dropnan take away (src/agg_nunique.cpp:17-45)
+int vxh_collect_nunique_result(vxh_collect *c, int64_t *out_cells) {
+    VXH_API_BEGIN
+    if (c->mode != 0) throw std::runtime_error("vxh_collect_nunique_result: not an nunique collector");
+    std::lock_guard<std::mutex> lock(c->mutex);
+    const uint64_t cells = c->grid->length1d;
+    std::vector<unsigned long long> distinct(cells, 0), nulls(cells, 0), nans(cells, 0);
+    if (c->null_rows) {
+        ensure_device_ready();
+        Slot &slot = get_slot(0);
+        order_after_producers(slot);
+        collect_compact(c, slot);
+        DevBuf counts(cells * 8);
+        HIP_CHECK(hipMemsetAsync(counts.p, 0, cells * 8, slot.stream));
+        vxh_launch_cell_counts(c->cell, c->n, (unsigned long long *)counts.p, slot.stream);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipMemcpyAsync(distinct.data(), counts.p, cells * 8, hipMemcpyDeviceToHost, slot.stream));
+        HIP_CHECK(hipMemcpyAsync(nulls.data(), c->null_rows, cells * 8, hipMemcpyDeviceToHost, slot.stream));
+        HIP_CHECK(hipMemcpyAsync(nans.data(), c->nan_rows, cells * 8, hipMemcpyDeviceToHost, slot.stream));
+        HIP_CHECK(hipStreamSynchronize(slot.stream));
+    }
+    // the reference subtracts the NUMBER of missing / NaN rows (`count -= counter->null_count`, :31-34), which is only right
+    // for cells with at most one such row; "nunique_row_counts" = 1 reproduces that
+    const bool quirk = ctx().cfg_nunique_row_counts != 0;
+    for (uint64_t j = 0; j < cells; j++) {
+        int64_t count = (int64_t)distinct[j] + (nulls[j] ? 1 : 0) + (nans[j] ? 1 : 0);
+        if (c->drop_a) count -= quirk ? (int64_t)nulls[j] : (nulls[j] ? 1 : 0);
+        if (c->drop_b) count -= quirk ? (int64_t)nans[j] : (nans[j] ? 1 : 0);
+        out_cells[j] = count;
+    }
+    VXH_API_END
+}
+
+// list per cell (src/agg_list.cpp:52-84): offsets_out[cells + 1]; *flat_length_out = offsets_out[cells].  Call once with
+// values_out == NULL for the length, then with a buffer of flat_length elements of the aggregator's dtype: per cell the
+// kept values in row order, then its NaNs, then one (zero) slot per counted missing value.
+int vxh_collect_list_result(vxh_collect *c, int64_t *offsets_out, void *values_out, uint64_t *flat_length_out) {
+    VXH_API_BEGIN
+    if (c->mode != 1) throw std::runtime_error("vxh_collect_list_result: not a list collector");
+    std::lock_guard<std::mutex> lock(c->mutex);
+    const uint64_t cells = c->grid->length1d;
+    std::vector<unsigned long long> kept(cells, 0), nulls(cells, 0), nans(cells, 0);
+    std::vector<uint64_t> vals;
+    if (c->null_rows) {
+        ensure_device_ready();
+        Slot &slot = get_slot(0);
+        order_after_producers(slot);
+        collect_compact(c, slot);
+        DevBuf counts(cells * 8);
+        HIP_CHECK(hipMemsetAsync(counts.p, 0, cells * 8, slot.stream));
+        vxh_launch_cell_counts(c->cell, c->n, (unsigned long long *)counts.p, slot.stream);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipMemcpyAsync(kept.data(), counts.p, cells * 8, hipMemcpyDeviceToHost, slot.stream));
+        HIP_CHECK(hipMemcpyAsync(nulls.data(), c->null_rows, cells * 8, hipMemcpyDeviceToHost, slot.stream));
+        HIP_CHECK(hipMemcpyAsync(nans.data(), c->nan_rows, cells * 8, hipMemcpyDeviceToHost, slot.stream));
+        if (values_out && c->n) {
+            vals.resize(c->n);
+            HIP_CHECK(hipMemcpyAsync(vals.data(), c->val, c->n * 8, hipMemcpyDeviceToHost, slot.stream));
+        }
+        HIP_CHECK(hipStreamSynchronize(slot.stream));
+    }
+    int64_t off = 0;
+    uint64_t src = 0;
+    offsets_out[0] = 0;
+    for (uint64_t j = 0; j < cells; j++) {
+        if (values_out) {
+            for (uint64_t k = 0; k < kept[j]; k++) canon_to_host(vals[src + k], c->dtype, values_out, (uint64_t)off + k);
+            uint64_t nanbits;
+            const double qnan = std::numeric_limits<double>::quiet_NaN();
+            memcpy(&nanbits, &qnan, 8);
+            const bool is_float = c->dtype == VXH_F64 || c->dtype == VXH_F32;
+            for (uint64_t k = 0; k < nans[j]; k++) canon_to_host(is_float ? nanbits : 0, c->dtype, values_out, (uint64_t)off + kept[j] + k);
+            for (uint64_t k = 0; k < nulls[j]; k++) canon_to_host(0, c->dtype, values_out, (uint64_t)off + kept[j] + nans[j] + k);
+        }
+        src += kept[j];
+        off += (int64_t)(kept[j] + nans[j] + nulls[j]);
+        offsets_out[j + 1] = off;
+    }
+    *flat_length_out = (uint64_t)off;
     VXH_API_END
 }
 

@@ -84,6 +84,21 @@ struct vxh_first {
     std::vector<SlotData> data, order, mask;
 };
 
+// AggNUnique / AggList: the rows' {value, cell} pairs, kept on the device
+struct vxh_collect {
+    int mode = 0; // 0 nunique, 1 list
+    int dtype = 0, flip = 0, drop_a = 0, drop_b = 0; // nunique: dropmissing, dropnan; list: dropnan, dropnull
+    vxh_grid *grid = nullptr;
+    int threads = 1;
+    uint64_t *val = nullptr;   // [cap]
+    uint32_t *cell = nullptr;  // [cap]
+    uint64_t n = 0, cap = 0;   // pairs held / capacity
+    uint64_t compact = 0;      // pairs [0, compact) are sorted by (cell, value) and, for nunique, distinct
+    unsigned long long *null_rows = nullptr, *nan_rows = nullptr; // per cell
+    std::mutex mutex;
+    std::vector<SlotData> data, mask, selection;
+};
+
 struct Slot {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
@@ -169,6 +184,7 @@ struct Context {
     int64_t cfg_cache_bytes = 64ll << 30; // device column cache budget (only ranges registered with vxh_cache_register are cached)
     int64_t cfg_slab_log2 = -1;   // -1 = auto
     int64_t cfg_lds_replicas = 0; // 0 = auto
+    int64_t cfg_nunique_row_counts = 0; // AggNUnique dropmissing / dropnan: 0 = one entry less for a cell that saw missing values / NaNs; 1 = the reference's `count -= null_count` (rows)
     int64_t cfg_first_mask_block = 0; // AggFirst keep-mask index: 0 = mask[row] (what the reference means); 1024 = mask[row % 1024] (what src/agg_first.cpp:131 does)
     int64_t cfg_part_chunk = 1 << 28; // rows per partition chunk (scratch: ~2 x record bytes x this; larger chunks amortise the launches)
     int64_t cfg_parts = 0;        // pass-2 workgroups per slab (0 = auto)

@@ -289,6 +289,63 @@ __global__ void __launch_bounds__(256) first_pass(const FirstArgs F) {
     }
 }
 
+// AggNUnique / AggList: one pair {canonical value bits, flat cell} per row; what happens to the pairs (sort, unique, count)
+// is rocPRIM's business on the host side (vxh_api.hip).
+__global__ void __launch_bounds__(256) collect_pass(const CollectArgs C) {
+    constexpr int N = 2;
+    const uint64_t total = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t base = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; base < C.A.n; base += N * total) {
+        const Rows<N> rows = make_rows<N>(base, total, C.A.n);
+        uint64_t idx[N], v[N];
+        flat_index_batch<false, N>(C.A, rows, idx);
+        load_canon<N>(C.val, rows, C.val_dtype, C.flip, v);
+        uint8_t dm[N], sm[N];
+#pragma unroll
+        for (int u = 0; u < N; ++u) {
+            dm[u] = C.data_mask ? C.data_mask[rows.i[u]] : (uint8_t)1;
+            sm[u] = C.selection_mask ? C.selection_mask[rows.i[u]] : (uint8_t)1;
+        }
+#pragma unroll
+        for (int u = 0; u < N; ++u) {
+            if (!((rows.valid >> u) & 1u)) continue;
+            const uint64_t row = rows.i[u];
+            uint32_t cell = 0xffffffffu;
+            const bool nan = canon_is_nan(v[u], C.val_dtype);
+            if (C.mode == 0) { // src/agg_nunique.cpp:66-88
+                if (sm[u] != 0) {
+                    if (dm[u] == 0) (void)atomicAdd(C.null_rows + idx[u], 1ull);
+                    else if (nan) (void)atomicAdd(C.nan_rows + idx[u], 1ull);
+                    else cell = (uint32_t)idx[u];
+                }
+            } else { // src/agg_list.cpp:98-118
+                if (!C.data_mask || dm[u] == 1) {
+                    if (!nan) cell = (uint32_t)idx[u];
+                    else if (!C.drop_nan) (void)atomicAdd(C.nan_rows + idx[u], 1ull);
+                } else if (dm[u] == 0 && !C.drop_null) {
+                    (void)atomicAdd(C.null_rows + idx[u], 1ull);
+                }
+            }
+            C.out_val[row] = v[u]; // (bit patterns: -0.0 and +0.0 are two values, as for the reference's hash of the bits)
+            C.out_cell[row] = cell;
+        }
+    }
+}
+// flags[i] = the pair starts a new run (distinct: of equal {cell, value}; else every live pair) and takes part (cell != ~0)
+__global__ void __launch_bounds__(256) pair_flags(const uint64_t *val, const uint32_t *cell, uint8_t *flags, uint64_t n, int distinct) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t c = cell[i];
+        bool f = c != 0xffffffffu;
+        if (f && distinct && i > 0) f = cell[i - 1] != c || val[i - 1] != val[i];
+        flags[i] = f ? 1 : 0;
+    }
+}
+__global__ void __launch_bounds__(256) cell_counts(const uint32_t *cell, uint64_t n, unsigned long long *counts) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t c = cell[i];
+        if (c != 0xffffffffu) (void)atomicAdd(counts + c, 1ull);
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // scatter ops.  SCOPE: __HIP_MEMORY_SCOPE_AGENT (device) or __HIP_MEMORY_SCOPE_WORKGROUP (LDS)
 // ------------------------------------------------------------------------------------------
@@ -2528,6 +2585,18 @@ void vxh_launch_first(const FirstArgs &F, hipStream_t stream) {
     hipLaunchKernelGGL(first_pass<1>, dim3(blocks), dim3(256), 0, stream, F);
     hipLaunchKernelGGL(first_pass<2>, dim3(blocks), dim3(256), 0, stream, F);
     hipLaunchKernelGGL(first_pass<3>, dim3(blocks), dim3(256), 0, stream, F);
+}
+
+static unsigned grid_for(uint64_t n) { return (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n + 255) / 256, 256 * 16)); }
+void vxh_launch_collect(const CollectArgs &C, hipStream_t stream) {
+    if (!C.A.n) return;
+    hipLaunchKernelGGL(collect_pass, dim3((unsigned)std::min<uint64_t>((C.A.n + 511) / 512, 256 * 8)), dim3(256), 0, stream, C);
+}
+void vxh_launch_pair_flags(const uint64_t *val, const uint32_t *cell, uint8_t *flags, uint64_t n, int distinct, hipStream_t stream) {
+    if (n) hipLaunchKernelGGL(pair_flags, dim3(grid_for(n)), dim3(256), 0, stream, val, cell, flags, n, distinct);
+}
+void vxh_launch_cell_counts(const uint32_t *cell, uint64_t n, unsigned long long *counts, hipStream_t stream) {
+    if (n) hipLaunchKernelGGL(cell_counts, dim3(grid_for(n)), dim3(256), 0, stream, cell, n, counts);
 }
 
 void vxh_launch_fill(void *dst, uint64_t ncells, int cell, const void *value8, hipStream_t stream) {

@@ -215,6 +215,23 @@ struct FirstArgs {
     uint64_t *tmp_key, *tmp_row;   // per cell, this call only
 };
 void vxh_launch_first(const FirstArgs &args, hipStream_t stream);
+// AggNUnique / AggList (vxh_api.hip: vxh_collect_*): every row of a call becomes a pair {canonical value bits, flat cell
+// index}; rows that do not take part get cell 0xffffffff (sorted behind everything else and dropped)
+struct CollectArgs {
+    BinArgs A;               // binners + n
+    const void *val;
+    const uint8_t *data_mask;      // nullptr or per row: 0 = missing value (src/agg_nunique.cpp:72)  [list: != 1 ... see mode]
+    const uint8_t *selection_mask; // nullptr or per row: 0 = the row is not looked at at all (:70)
+    uint8_t val_dtype, flip;
+    uint8_t mode;            // 0 nunique: NaN / missing rows only counted per cell; 1 list: keep-mask semantics of src/agg_list.cpp:98-118
+    uint8_t drop_nan, drop_null; // list: NaN / missing rows are not even counted
+    uint64_t *out_val;       // [n]
+    uint32_t *out_cell;      // [n]
+    unsigned long long *null_rows, *nan_rows; // per cell
+};
+void vxh_launch_collect(const CollectArgs &args, hipStream_t stream);
+void vxh_launch_pair_flags(const uint64_t *val, const uint32_t *cell, uint8_t *flags, uint64_t n, int distinct, hipStream_t stream);
+void vxh_launch_cell_counts(const uint32_t *cell, uint64_t n, unsigned long long *counts, hipStream_t stream);
 void vxh_launch_sel_eval(const SelArgs &args, hipStream_t stream);
 #define VXH_PACK_MAX_KEYS 8
 struct PackArgs {
