@@ -24,7 +24,8 @@ def step(n):
     return [a.get_result() for a in aggs]
 vmax = float(torch.nan_to_num(v[:cpu_rows]).abs().max().item())
 full = None
-for it in range(30):
+for it in range(40):
+    sa.config_set('hot_cache', it % 2)
     setd(x[:cpu_rows], y[:cpu_rows], v[:cpu_rows])
     g = step(cpu_rows)
     d0 = (g[0] != cpu_res[0]); d2 = (g[2] != cpu_res[2])
