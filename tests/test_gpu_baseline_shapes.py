@@ -86,9 +86,11 @@ def test_config1_2d_256_count_mean_full_size(sa):
     cases.assert_case_equal(head, want, case)
 
 
-def test_config1_uniform_data_no_hot_box(sa):
-    """uniform x,y: the sampled hot box is off (catches < 35 % of the rows) — the plain partition pair must agree
-    with the reference as well"""
+@pytest.mark.parametrize("box", [True, False])
+def test_config1_uniform_data(sa, box):
+    """uniform x,y: the densest box holds only ~15 % of the rows — it is still taken (next to part_scatter_blk: staged
+    records; the ring-less pass 1 needs ~62 %), and with the box switched off the plain partition pair runs: both must
+    agree with the reference"""
     import torch
     g = torch.Generator(device="cuda").manual_seed(99)
     n = 60_000_000
@@ -100,15 +102,22 @@ def test_config1_uniform_data_no_hot_box(sa):
     grid = sa.Grid([bx, by])
     aggs = [sa.AggCount_int64(grid, 1, 1), sa.AggSum_float64(grid, 1, 1), sa.AggCount_float64(grid, 1, 1)]
     bx.set_data(0, x); by.set_data(0, y); aggs[1].set_data(0, v, 0); aggs[2].set_data(0, v, 0)
-    grid.bin(0, aggs, n)
-    got = [np.array(a.get_result()) for a in aggs]
-    assert sa.config_get("hot_w") == 0, "uniform data must not take the hot box"
-    m = N_SLICE
-    for a in aggs:
-        a.reset()
-    bx.set_data(0, x[:m]); by.set_data(0, y[:m]); aggs[1].set_data(0, v[:m], 0); aggs[2].set_data(0, v[:m], 0)
-    grid.bin(0, aggs, m)
-    head = [np.array(a.get_result()) for a in aggs]
+    sa.config_set("hot", 1 if box else 0)
+    try:
+        grid.bin(0, aggs, n)
+        got = [np.array(a.get_result()) for a in aggs]
+        if box:
+            assert sa.config_get("hot_w") > 0 and 100_000 < sa.config_get("hot_fraction_ppm") < 350_000 and sa.last_kernel(0).startswith("part_scatter_hot")
+        else:
+            assert sa.config_get("hot_w") == 0
+        m = N_SLICE
+        for a in aggs:
+            a.reset()
+        bx.set_data(0, x[:m]); by.set_data(0, y[:m]); aggs[1].set_data(0, v[:m], 0); aggs[2].set_data(0, v[:m], 0)
+        grid.bin(0, aggs, m)
+        head = [np.array(a.get_result()) for a in aggs]
+    finally:
+        sa.config_set("hot", 1)
     xs, ys, vs = (t[:m].cpu().numpy() for t in (x, y, v))
     case = dict(n=m, binners=[dict(kind="scalar", data=xs, vmin=-4, vmax=4, bins=256), dict(kind="scalar", data=ys, vmin=-4, vmax=4, bins=256)],
                 aggs=[dict(kind="count"), dict(kind="sum", data=vs), dict(kind="count", data=vs)])

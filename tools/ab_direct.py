@@ -8,8 +8,12 @@ sa = vaex_amd.superagg
 rows = int(float(sys.argv[1])) if len(sys.argv) > 1 else 1_000_000_000
 variants = sys.argv[2:] or ["wv=0", "wv=3", "wv=3,wv_waves_direct=12", "wv=3,wv_waves_direct=8", "wv=2"]
 g = torch.Generator(device="cuda").manual_seed(1234)
-x = torch.randn(rows, dtype=torch.float64, device="cuda", generator=g)
-y = torch.randn(rows, dtype=torch.float64, device="cuda", generator=g)
+sigma = float(os.environ.get("AB_SIGMA", "1.0"))  # wider columns: a smaller share of the rows inside the hot box
+x = torch.randn(rows, dtype=torch.float64, device="cuda", generator=g) * sigma
+y = torch.randn(rows, dtype=torch.float64, device="cuda", generator=g) * sigma
+if os.environ.get("AB_UNIFORM"):
+    x = torch.rand(rows, dtype=torch.float64, device="cuda", generator=g) * 8 - 4
+    y = torch.rand(rows, dtype=torch.float64, device="cuda", generator=g) * 8 - 4
 v = torch.randn(rows, dtype=torch.float64, device="cuda", generator=g) * 2 + 3
 v[::1001] = float("nan")
 ref = None
@@ -28,4 +32,4 @@ for var in variants:
     if ref is None: ref = res
     ok = np.array_equal(res[0], ref[0]) and np.array_equal(res[2], ref[2]) and bool(np.all(np.abs(res[1] - ref[1]) <= 1e-12 * 20.0 * np.maximum(res[0], 1)))
     print(f"{var:<34} {best:7.3f} ms {rows/best/1e6:6.1f} Grows/s {rows*24/best/1e6/8000:5.3f}  {sa.last_kernel(0)} box {sa.config_get('hot_w')}x{sa.config_get('hot_h')} {sa.config_get('hot_fraction_ppm')/1e4:.1f}% {'same' if ok else 'DIFFERENT'} n={int(res[0].sum())}", flush=True)
-    for k in cfg: sa.config_set(k, {"wv": 1, "wv_waves_direct": 16, "wv_waves": 8}.get(k, 0))
+    for k in cfg: sa.config_set(k, {"wv": 3, "wv_waves_direct": 16, "wv_waves": 8, "hot_min_pct": 35, "hot": 1}.get(k, 0))

@@ -833,27 +833,25 @@ static void hot_prepare(Slot &slot, const BinArgs &A, const BinArgs &planned, co
     if (wv && forced && gen2 && (uint64_t)c.cfg_hot_box[2] * (uint64_t)c.cfg_hot_box[3] > (kLdsMax - ((size_t)wg.waves * wg.wave_bytes + 64) - 96) / (nval ? 12 : 4)) wv = false;
     if (!gen2 && !wv) return;
     H.gen2 = true;
-    H.wv = wv;
-    H.wv_waves = wv ? wg.waves : 0;
     H.nval = nval;
     const size_t cell_bytes = nval ? 12 : 4;
-    const size_t fixed = wv ? (size_t)wg.waves * wg.wave_bytes + 64 : (size_t)VXH_BLK_FIXED_LDS(nval, S);
-    if (fixed + 4096 > kLdsMax) return;
-    const uint64_t max_cells = (kLdsMax - fixed - 96) / cell_bytes;
+    auto room = [&](bool with_wv) -> uint64_t { // cells the box may have next to this pass-1 kernel's own LDS (0: does not fit)
+        const size_t fixed = with_wv ? (size_t)wg.waves * wg.wave_bytes + 64 : (size_t)VXH_BLK_FIXED_LDS(nval, S);
+        return fixed + 4096 > kLdsMax ? 0 : (kLdsMax - fixed - 96) / cell_bytes;
+    };
     const uint32_t sx = (uint32_t)(A.b[0].bins + 3), sy = (uint32_t)(A.b[1].bins + 3);
     uint32_t box[4] = {0, 0, 0, 0};
     if (forced) {
+        const uint64_t max_cells = room(wv);
+        if (!max_cells) return;
         for (int i = 0; i < 4; i++) box[i] = (uint32_t)c.cfg_hot_box[i];
         if (box[0] + box[2] > sx || box[1] + box[3] > sy || (uint64_t)box[2] * box[3] > max_cells) throw std::runtime_error("hot box override does not fit the grid / LDS");
         H.last_fraction = 1;
     } else {
         const double lim[6] = {A.b[0].vmin, A.b[0].scale, A.b[0].binsd, A.b[1].vmin, A.b[1].scale, A.b[1].binsd};
         const bool cached = c.cfg_hot_cache && H.key_fraction >= 0 && H.key_ptr[0] == A.b[0].data && H.key_ptr[1] == A.b[1].data && H.key_len == length &&
-                            H.key_cells == max_cells && memcmp(H.key_lim, lim, sizeof(lim)) == 0;
-        if (cached) {
-            memcpy(box, H.key_box, sizeof(box));
-            H.last_fraction = H.key_fraction;
-        } else {
+                            H.key_grid.size() == A.cells && memcmp(H.key_lim, lim, sizeof(lim)) == 0;
+        if (!cached) {
         // sample: 8 evenly spaced segments of 2^18 rows, counted with device atomics into a scratch grid
             const size_t bytes = (size_t)A.cells * 8;
             if (bytes > H.sample_cap) {
@@ -888,21 +886,49 @@ static void hot_prepare(Slot &slot, const BinArgs &A, const BinArgs &planned, co
                 vxh_launch_bin(L, sp, slot.stream);
             }
             HIP_CHECK(hipGetLastError());
-            std::vector<int64_t> g(A.cells);
-            HIP_CHECK(hipMemcpyAsync(g.data(), H.sample, bytes, hipMemcpyDeviceToHost, slot.stream));
+            H.key_fraction = -1;
+            H.key_grid.resize(A.cells);
+            HIP_CHECK(hipMemcpyAsync(H.key_grid.data(), H.sample, bytes, hipMemcpyDeviceToHost, slot.stream));
             HIP_CHECK(hipStreamSynchronize(slot.stream));
-            int64_t total = 0;
-            for (int64_t v : g) total += v;
-            const int64_t in = hot_search(g, sx, sy, max_cells, box);
-            H.last_fraction = total > 0 ? (double)in / (double)total : 0;
+            H.key_total = 0;
+            for (int64_t v : H.key_grid) H.key_total += v;
             H.key_ptr[0] = A.b[0].data; H.key_ptr[1] = A.b[1].data;
             memcpy(H.key_lim, lim, sizeof(lim));
-            H.key_len = length; H.key_cells = max_cells;
-            memcpy(H.key_box, box, sizeof(box));
-            H.key_fraction = H.last_fraction;
+            H.key_len = length;
+            H.key_cells[0] = H.key_cells[1] = 0;
+            H.key_fraction = 0;
         }
+        // the densest box for a budget of `max_cells` cells (searched once per sample and budget)
+        auto searched = [&](uint64_t max_cells, uint32_t (&out)[4]) -> double {
+            int e = H.key_cells[0] == max_cells ? 0 : (H.key_cells[1] == max_cells ? 1 : -1);
+            if (e < 0) {
+                e = H.key_cells[0] == 0 ? 0 : 1;
+                const int64_t in = hot_search(H.key_grid, sx, sy, max_cells, H.key_box[e]);
+                H.key_cells[e] = max_cells;
+                H.key_box_fraction[e] = H.key_total > 0 ? (double)in / (double)H.key_total : 0;
+            }
+            memcpy(out, H.key_box[e], sizeof(out));
+            return H.key_box_fraction[e];
+        };
+        // Which pass 1 sits next to the box (profiles/r02_box_share.txt): the ring-less part_scatter_wv leaves the box the most
+        // room, but its scattered record stores cost in proportion to the cold rows — from ~62 % of the rows inside the
+        // box on it wins; below that part_scatter_blk (staged records, smaller box), which still pays off down to ~15 %.
+        bool chosen = false;
+        if (wv && wg.direct && gen2 && room(true)) {
+            const double f = searched(room(true), box);
+            if (f * 100.0 >= (double)c.cfg_hot_direct_pct) { H.last_fraction = f; chosen = true; }
+            else wv = false;
+        }
+        if (!chosen) {
+            const uint64_t max_cells = room(wv);
+            if (!max_cells) return;
+            H.last_fraction = searched(max_cells, box);
+        }
+        H.key_fraction = H.last_fraction;
         if (H.last_fraction * 100.0 < (double)c.cfg_hot_min_pct) return;
     }
+    H.wv = wv;
+    H.wv_waves = wv ? wg.waves : 0;
     H.x0 = box[0]; H.y0 = box[1]; H.w = box[2]; H.h = box[3];
     const uint64_t tile_rows = H.wv ? 256ull * (uint64_t)H.wv_waves : 4096ull; // rows one workgroup takes per round
     const uint64_t tiles = (std::min<uint64_t>(length, 2 * (uint64_t)std::max<int64_t>(1 << 20, c.cfg_part_chunk)) + tile_rows - 1) / tile_rows;
@@ -1424,7 +1450,8 @@ int vxh_config_set(const char *key, int64_t value) {
     else if (k == "wv_waves_direct") c.cfg_wv_waves_direct = value > 0 ? value : 16;
     else if (k == "wv_block") c.cfg_wv_block = value;
     else if (k == "hot_min_rows") c.cfg_hot_min_rows = value > 0 ? value : (1 << 24);
-    else if (k == "hot_min_pct") c.cfg_hot_min_pct = value > 0 ? value : 35;
+    else if (k == "hot_min_pct") c.cfg_hot_min_pct = value > 0 ? value : 10;
+    else if (k == "hot_direct_pct") c.cfg_hot_direct_pct = value > 0 ? value : 62;
     else if (k == "hot_cache") c.cfg_hot_cache = value;
     else if (k == "hot_x0") c.cfg_hot_box[0] = value;
     else if (k == "hot_y0") c.cfg_hot_box[1] = value;

@@ -154,8 +154,13 @@ struct Slot {
         // the box of the previous sampled call, reused when the same columns are binned with the same limits again
         const void *key_ptr[2] = {nullptr, nullptr};
         double key_lim[6] = {0, 0, 0, 0, 0, 0};
-        uint64_t key_len = 0, key_cells = 0;
-        uint32_t key_box[4] = {0, 0, 0, 0};
+        uint64_t key_len = 0;
+        std::vector<int64_t> key_grid; // the sample's counts per cell (valid while key_fraction >= 0)
+        int64_t key_total = 0;
+        // searched boxes for up to two LDS budgets (the ring-less pass 1 and part_scatter_blk leave the box different room)
+        uint64_t key_cells[2] = {0, 0};
+        uint32_t key_box[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+        double key_box_fraction[2] = {-1, -1};
         double key_fraction = -1;
         double last_fraction = 0; // share of the sample inside the box (vxh_config_get("hot_fraction_ppm"))
     } hot;
@@ -200,7 +205,8 @@ struct Context {
     int64_t cfg_hot = 1;           // hot box in pass 1 of the partition strategy (0 off)
     int64_t cfg_hot_min_rows = 1 << 24; // calls shorter than this do not pay for the sample
     int64_t cfg_hot_cache = 1;     // reuse the sampled box when the same columns are binned with the same limits again (0: sample every call)
-    int64_t cfg_hot_min_pct = 35;  // use the box only when it catches at least this share of the sample
+    int64_t cfg_hot_min_pct = 10;  // use the box only when it catches at least this share of the sample (profiles/r02_box_share.txt: worth it from ~15 %)
+    int64_t cfg_hot_direct_pct = 62; // ... and the ring-less pass 1 (scattered record stores) only from this share on; below it part_scatter_blk stages the records
     int64_t cfg_hot_box[4] = {0, 0, 0, 0}; // x0, y0, w, h override (w > 0) — tests / experiments
     int64_t cfg_scatter_wgs = 0;  // pass-1 workgroups per CU (0 = as many as LDS allows, at most 4)
     int64_t cfg_count_fast = 1;   // 0: keep count(*) passes on the generic bin_kernel (for A/B measurements)
