@@ -409,9 +409,19 @@ def test_hot_box_forced(sa, hot_pass1):
         check(sa, case)
         check(sa, dict(case, aggs=case["aggs"][:2]))
         check(sa, dict(case, aggs=case["aggs"][1:2]))
-        # a signature the box does not serve (a selection mask) runs without it
+        # ONE selection mask shared by every aggregator: the box stays (next to part_scatter_blk, whatever pass 1 was asked for)
         m = case["binners"][0]["data"] > 0
         check(sa, dict(case, aggs=[dict(a, mask=m) for a in case["aggs"]]))
+        assert sa.config_get("hot_w") == 1 and sa.last_kernel(0).startswith("part_scatter_hot")
+        for box in ((100, 110, 60, 50), (0, 0, 92, 92)):
+            for k, val in zip(("hot_x0", "hot_y0", "hot_w", "hot_h"), box):
+                sa.config_set(k, val)
+            check(sa, dict(case, aggs=[dict(a, mask=m) for a in case["aggs"]]))
+            check(sa, dict(case, aggs=[dict(kind="count", mask=m)]))
+            assert sa.config_get("hot_w") == box[2]
+        # a signature the box does not serve (aggregators with different masks) runs without it
+        m2 = case["binners"][1]["data"] > 0
+        check(sa, dict(case, aggs=[dict(case["aggs"][0], mask=m), dict(case["aggs"][1], mask=m2)]))
         assert sa.config_get("hot_w") == 0
     finally:
         _hot_reset(sa)

@@ -771,14 +771,15 @@ static bool wv_aligned(const BinArgs &A) {
 // ------------------------------------------------------------------------------------------
 // hot box (PartArgs::hot): eligibility, choice of the box from a sample, accumulators, merge
 // ------------------------------------------------------------------------------------------
-// The signature pass 1's HOT instantiation serves: two scalar float64 binners, ONE float64 value column, no masks,
-// aggregators count(*) / count(v) / sum(v).
-static int hot_eligible(const BinArgs &A, const LaunchPlan &plan) {
+// The signature pass 1's HOT instantiation serves: two scalar float64 binners, ONE float64 value column, no masks or
+// ONE mask shared by every aggregator (a selection: part_scatter_blk only), aggregators count(*) / count(v) / sum(v).
+static int hot_eligible(const BinArgs &A, const LaunchPlan &plan, bool *masked = nullptr) {
     if (!plan.fast_f64 || A.ndim != 2 || A.nagg < 1 || A.cells >= (1ull << 31)) return -1;
     const void *v = nullptr;
+    if (masked) *masked = A.a[0].mask != nullptr;
     for (int k = 0; k < A.nagg; k++) {
         const AggDesc &a = A.a[k];
-        if (a.mask) return -1;
+        if (a.mask != A.a[0].mask) return -1;
         if (a.kind == VXH_AGG_COUNT) { if (a.data) { if (v && v != a.data) return -1; v = a.data; } }
         else if (a.kind == VXH_AGG_SUM && a.cell == VXH_CELL_F64 && a.data) { if (v && v != a.data) return -1; v = a.data; }
         else return -1;
@@ -818,7 +819,8 @@ static void hot_prepare(Slot &slot, const BinArgs &A, const BinArgs &planned, co
     H.on = false;
     H.last_on = false;
     H.last_fraction = 0;
-    const int nval = c.cfg_hot ? hot_eligible(A, plan) : -1;
+    bool masked = false;
+    const int nval = c.cfg_hot ? hot_eligible(A, plan, &masked) : -1;
     if (nval < 0) return;
     const bool forced = c.cfg_hot_box[2] > 0 && c.cfg_hot_box[3] > 0;
     if (!forced && length < (uint64_t)c.cfg_hot_min_rows) return;
@@ -828,6 +830,10 @@ static void hot_prepare(Slot &slot, const BinArgs &A, const BinArgs &planned, co
     const bool gen2 = c.cfg_blk && S <= 256 && slab_cells < 65535 && !(c.cfg_no_pipeline & 1) && c.cfg_part_rows <= 0; // (= run_part_chunk's conditions for part_scatter_blk)
     const WvGeom wg = wv_geometry(S, nval, true);
     bool wv = wg.ok && slab_cells < 65535 && wv_aligned(A); // (= run_part_chunk's conditions for part_scatter_wv)
+    if (masked) { // (the box next to a selection mask: part_scatter_blk's instantiation only)
+        if (!gen2) return;
+        wv = false;
+    }
     if (wv && gen2 && c.cfg_wv == 1) wv = false; // next to a box part_scatter_blk is the (slightly) faster one: its staging leaves the box 111 KB, eight waves' rings 78 KB
     // a forced box (tests / experiments) too big for what part_scatter_wv's rings leave of the LDS goes to part_scatter_blk
     if (wv && forced && gen2 && (uint64_t)c.cfg_hot_box[2] * (uint64_t)c.cfg_hot_box[3] > (kLdsMax - ((size_t)wg.waves * wg.wave_bytes + 64) - 96) / (nval ? 12 : 4)) wv = false;
@@ -1183,7 +1189,7 @@ static void run_part_chunk(Slot &slot, const BinArgs &planned, const LaunchPlan 
                      (P.nmasks == 0 || (P.nmasks == 1 && P.all_masked)) && P.idx16 && slab_cells < 65535 && S <= 256 && c.cfg_part_rows <= 0 &&
                      (slot.hot.on || (S > 8 && S <= 64 && !plan.key_i64) || c.cfg_blk == 2); // measured (profiles/r01_other_shapes.txt, r01_groupby_tune.txt):
                      // <= 8 slabs without a box: two 512-thread workgroups of part_scatter_f64 are 2 % faster; 128-256 slabs: +5 % (1024^2) / -35 % (1e6-key groupby)
-    const bool hot_here = slot.hot.on && P.nmasks == 0 && P.nvals == slot.hot.nval && (blk || wv);
+    const bool hot_here = slot.hot.on && (P.nmasks == 0 || (P.nmasks == 1 && P.all_masked && blk && !wv)) && P.nvals == slot.hot.nval && (blk || wv);
     if (wv) {
         P.wv = wg.waves;
         P.wv_direct = wg.direct;

@@ -1272,7 +1272,7 @@ __global__ void __launch_bounds__(512) part_scatter_f64(const PartArgs P) {
 //     for 4096-row tiles, and for the hot box).  A tile's segment may straddle two blocks (split point parked in LDS).
 //     What is left of the open and of the pre-reserved block at the end is filled with null records (local index =
 //     slab_cells: a dummy LDS cell of pass 2, value 0);
-//   * HOT (two binners, no mask; PartArgs::hot): rows inside the hot box (non-NaN value) are added to the
+//   * HOT (two binners; PartArgs::hot): rows inside the hot box (kept by the mask, non-NaN value) are added to the
 //     workgroup's LDS copy of the box (fp64 sum + uint32 count per cell, or just the count) and emit no record.
 constexpr int VXH_HOT_BLOCK = 1024;   // threads
 constexpr int VXH_HOT_R = 4;          // rows per thread per tile
@@ -2475,6 +2475,7 @@ void vxh_launch_part_scatter(const PartArgs &args, const LaunchPlan &plan, int s
             if (args.nvals == 0) { if (masked) VXH_SC((part_scatter_blk<1, 0, true, false, 1>)); else VXH_SC((part_scatter_blk<1, 0, false, false, 1>)); }
             else { if (masked) VXH_SC((part_scatter_blk<1, 1, true, false, 1>)); else VXH_SC((part_scatter_blk<1, 1, false, false, 1>)); }
         }
+        else if (hot && masked) { if (args.nvals == 0) VXH_SC((part_scatter_blk<2, 0, true, true>)); else VXH_SC((part_scatter_blk<2, 1, true, true>)); }
         else if (hot) { if (args.nvals == 0) VXH_SC((part_scatter_blk<2, 0, false, true>)); else VXH_SC((part_scatter_blk<2, 1, false, true>)); }
         else if (args.A.ndim == 1) VXH_BLK(1);
         else if (args.A.ndim == 2) VXH_BLK(2);
