@@ -409,6 +409,19 @@ def test_hot_box_forced(sa, hot_pass1):
         check(sa, case)
         check(sa, dict(case, aggs=case["aggs"][:2]))
         check(sa, dict(case, aggs=case["aggs"][1:2]))
+        # var / std: the sum of squares (AggSumMoment, moment 2) has a plane of its own in the box; moment 3 is not the box's business
+        v = case["aggs"][1]["data"]
+        std_aggs = [dict(kind="count", data=v), dict(kind="sum", data=v), dict(kind="summoment", data=v, moment=2)]
+        for box in ((100, 110, 60, 50), (0, 0, 70, 70)):
+            for k, val in zip(("hot_x0", "hot_y0", "hot_w", "hot_h"), box):
+                sa.config_set(k, val)
+            check(sa, dict(case, aggs=std_aggs))
+            assert sa.config_get("hot_w") == box[2]
+            check(sa, dict(case, aggs=std_aggs[2:]))
+            assert sa.config_get("hot_w") == box[2]
+        check(sa, dict(case, aggs=std_aggs[:2] + [dict(kind="summoment", data=v, moment=3)]))
+        assert sa.config_get("hot_w") == 0
+        sa.config_set("hot_x0", 130); sa.config_set("hot_y0", 1); sa.config_set("hot_w", 1); sa.config_set("hot_h", 200)
         # ONE selection mask shared by every aggregator: the box stays (next to part_scatter_blk, whatever pass 1 was asked for)
         m = case["binners"][0]["data"] > 0
         check(sa, dict(case, aggs=[dict(a, mask=m) for a in case["aggs"]]))

@@ -773,15 +773,17 @@ static bool wv_aligned(const BinArgs &A) {
 // ------------------------------------------------------------------------------------------
 // The signature pass 1's HOT instantiation serves: two scalar float64 binners, ONE float64 value column, no masks or
 // ONE mask shared by every aggregator (a selection: part_scatter_blk only), aggregators count(*) / count(v) / sum(v).
-static int hot_eligible(const BinArgs &A, const LaunchPlan &plan, bool *masked = nullptr) {
+static int hot_eligible(const BinArgs &A, const LaunchPlan &plan, bool *masked = nullptr, bool *mom2 = nullptr) {
     if (!plan.fast_f64 || A.ndim != 2 || A.nagg < 1 || A.cells >= (1ull << 31)) return -1;
     const void *v = nullptr;
     if (masked) *masked = A.a[0].mask != nullptr;
+    if (mom2) *mom2 = false;
     for (int k = 0; k < A.nagg; k++) {
         const AggDesc &a = A.a[k];
         if (a.mask != A.a[0].mask) return -1;
         if (a.kind == VXH_AGG_COUNT) { if (a.data) { if (v && v != a.data) return -1; v = a.data; } }
         else if (a.kind == VXH_AGG_SUM && a.cell == VXH_CELL_F64 && a.data) { if (v && v != a.data) return -1; v = a.data; }
+        else if (a.kind == VXH_AGG_SUM_MOMENT && a.moment == 2 && a.cell == VXH_CELL_F64 && a.data && mom2) { if (v && v != a.data) return -1; v = a.data; *mom2 = true; } // var / std
         else return -1;
     }
     return v != nullptr ? 1 : 0; // 0: count(*) only — the box holds just counts
@@ -819,9 +821,10 @@ static void hot_prepare(Slot &slot, const BinArgs &A, const BinArgs &planned, co
     H.on = false;
     H.last_on = false;
     H.last_fraction = 0;
-    bool masked = false;
-    const int nval = c.cfg_hot ? hot_eligible(A, plan, &masked) : -1;
+    bool masked = false, mom2 = false;
+    const int nval = c.cfg_hot ? hot_eligible(A, plan, &masked, &mom2) : -1;
     if (nval < 0) return;
+    H.mom2 = mom2;
     const bool forced = c.cfg_hot_box[2] > 0 && c.cfg_hot_box[3] > 0;
     if (!forced && length < (uint64_t)c.cfg_hot_min_rows) return;
     const size_t S = (size_t)1 << planned.slab_log2;
@@ -836,11 +839,11 @@ static void hot_prepare(Slot &slot, const BinArgs &A, const BinArgs &planned, co
     }
     if (wv && gen2 && c.cfg_wv == 1) wv = false; // next to a box part_scatter_blk is the (slightly) faster one: its staging leaves the box 111 KB, eight waves' rings 78 KB
     // a forced box (tests / experiments) too big for what part_scatter_wv's rings leave of the LDS goes to part_scatter_blk
-    if (wv && forced && gen2 && (uint64_t)c.cfg_hot_box[2] * (uint64_t)c.cfg_hot_box[3] > (kLdsMax - ((size_t)wg.waves * wg.wave_bytes + 64) - 96) / (nval ? 12 : 4)) wv = false;
+    if (wv && forced && gen2 && (uint64_t)c.cfg_hot_box[2] * (uint64_t)c.cfg_hot_box[3] > (kLdsMax - ((size_t)wg.waves * wg.wave_bytes + 64) - 96) / (nval ? (mom2 ? 20 : 12) : 4)) wv = false;
     if (!gen2 && !wv) return;
     H.gen2 = true;
     H.nval = nval;
-    const size_t cell_bytes = nval ? 12 : 4;
+    const size_t cell_bytes = nval ? (mom2 ? 20 : 12) : 4;
     auto room = [&](bool with_wv) -> uint64_t { // cells the box may have next to this pass-1 kernel's own LDS (0: does not fit)
         const size_t fixed = with_wv ? (size_t)wg.waves * wg.wave_bytes + 64 : (size_t)VXH_BLK_FIXED_LDS(nval, S);
         return fixed + 4096 > kLdsMax ? 0 : (kLdsMax - fixed - 96) / cell_bytes;
@@ -939,7 +942,7 @@ static void hot_prepare(Slot &slot, const BinArgs &A, const BinArgs &planned, co
     const uint64_t tile_rows = H.wv ? 256ull * (uint64_t)H.wv_waves : 4096ull; // rows one workgroup takes per round
     const uint64_t tiles = (std::min<uint64_t>(length, 2 * (uint64_t)std::max<int64_t>(1 << 20, c.cfg_part_chunk)) + tile_rows - 1) / tile_rows;
     H.blocks = (int)std::max<uint64_t>(1, std::min<uint64_t>(tiles, (uint64_t)c.cus)); // ONE workgroup per CU: the box takes the LDS
-    const size_t need = (size_t)H.blocks * H.w * H.h * 16;
+    const size_t need = (size_t)H.blocks * H.w * H.h * (H.mom2 ? 24 : 16);
     if (need > H.acc_cap) {
         HIP_CHECK(hipStreamSynchronize(slot.stream));
         if (H.acc) HIP_CHECK(hipFree(H.acc));
@@ -961,11 +964,13 @@ static void hot_merge(Slot &slot, const BinArgs &planned) {
     M.nagg = (uint32_t)planned.nagg;
     M.stride_y = planned.b[1].stride;
     M.atomic = planned.flush_plain ? 0 : 1;
+    const size_t plane = (size_t)H.blocks * H.w * H.h * 8;
     M.sum_acc = H.nval ? (double *)H.acc : nullptr;
-    M.cnt_acc = (unsigned long long *)((char *)H.acc + (size_t)H.blocks * H.w * H.h * 8);
+    M.sum2_acc = H.mom2 ? (double *)((char *)H.acc + plane) : nullptr;
+    M.cnt_acc = (unsigned long long *)((char *)H.acc + plane * (H.mom2 ? 2 : 1));
     for (int k = 0; k < planned.nagg; k++) {
         M.grid[k] = planned.a[k].grid;
-        M.takes_sum[k] = planned.a[k].kind == VXH_AGG_SUM ? 1 : 0;
+        M.takes_sum[k] = planned.a[k].kind == VXH_AGG_SUM ? 1 : (planned.a[k].kind == VXH_AGG_SUM_MOMENT ? 2 : 0);
     }
     vxh_launch_hot_merge(M, slot.stream);
     HIP_CHECK(hipGetLastError());
@@ -1209,19 +1214,23 @@ static void run_part_chunk(Slot &slot, const BinArgs &planned, const LaunchPlan 
         P.hot.on = 2;
         P.hot.x0 = H.x0; P.hot.y0 = H.y0; P.hot.w = H.w; P.hot.h = H.h;
         P.hot.lds_offset = 0; // the box first, the waves' rings behind it
-        P.wv_base = (int32_t)(((size_t)H.w * H.h * (P.nvals ? 12 : 4) + 15) & ~(size_t)15);
+        P.wv_base = (int32_t)(((size_t)H.w * H.h * (P.nvals ? (H.mom2 ? 20 : 12) : 4) + 15) & ~(size_t)15);
         scatter_lds = (size_t)P.wv_base + (size_t)wg.waves * wg.wave_bytes + 16;
+        P.hot.mom2 = H.mom2 ? 1u : 0u;
         P.hot.sum_acc = (double *)H.acc;
-        P.hot.cnt_acc = (unsigned long long *)((char *)H.acc + (size_t)H.blocks * H.w * H.h * 8);
+        P.hot.sum2_acc = (double *)((char *)H.acc + (size_t)H.blocks * H.w * H.h * 8);
+        P.hot.cnt_acc = (unsigned long long *)((char *)H.acc + (size_t)H.blocks * H.w * H.h * 8 * (H.mom2 ? 2 : 1));
         scatter_blocks = std::min(scatter_blocks, H.blocks); // accumulator blocks are indexed by blockIdx
     } else if (hot_here) {
         const Slot::Hot &H = slot.hot;
         P.hot.on = 2;
         P.hot.x0 = H.x0; P.hot.y0 = H.y0; P.hot.w = H.w; P.hot.h = H.h;
         P.hot.lds_offset = (uint32_t)VXH_BLK_FIXED_LDS(P.nvals, S);
-        scatter_lds = (size_t)VXH_BLK_FIXED_LDS(P.nvals, S) + (size_t)H.w * H.h * (P.nvals ? 12 : 4) + 32;
+        scatter_lds = (size_t)VXH_BLK_FIXED_LDS(P.nvals, S) + (size_t)H.w * H.h * (P.nvals ? (H.mom2 ? 20 : 12) : 4) + 32;
+        P.hot.mom2 = H.mom2 ? 1u : 0u;
         P.hot.sum_acc = (double *)H.acc;
-        P.hot.cnt_acc = (unsigned long long *)((char *)H.acc + (size_t)H.blocks * H.w * H.h * 8);
+        P.hot.sum2_acc = (double *)((char *)H.acc + (size_t)H.blocks * H.w * H.h * 8);
+        P.hot.cnt_acc = (unsigned long long *)((char *)H.acc + (size_t)H.blocks * H.w * H.h * 8 * (H.mom2 ? 2 : 1));
         scatter_blocks = std::min(scatter_blocks, H.blocks); // accumulator blocks are indexed by blockIdx
     } else if (slot.hot.on) {
         throw std::runtime_error("vaex_hip internal: hot box prepared for a signature pass 1 does not serve");

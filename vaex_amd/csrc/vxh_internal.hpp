@@ -141,6 +141,7 @@ struct Slot {
     // hot box of the current vxh_grid_bin call (PartArgs::hot) and its per-workgroup accumulators
     struct Hot {
         int nval = 1;      // value columns the box aggregates (1: fp64 sum + count per cell, 0: count only)
+        bool mom2 = false; // ... and the fp64 sum of squares (an AggSumMoment with moment 2 among the aggregators: 20-byte cells)
         bool gen2 = false; // part_scatter_hot (vs the HOT instantiation of part_scatter_f64)
         bool wv = false;   // the box lives in part_scatter_wv
         int wv_waves = 0;

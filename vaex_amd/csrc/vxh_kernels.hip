@@ -1299,7 +1299,9 @@ __global__ void __launch_bounds__(VXH_HOT_BLOCK) part_scatter_blk(const PartArgs
     uint16_t *const st_idx = (uint16_t *)(st_val + (NVAL ? T : 0));
     uint8_t *const st_slab = (uint8_t *)(st_idx + T);
     double *const hot_sum = (double *)(lds + P.hot.lds_offset);
-    uint32_t *const hot_cnt = (uint32_t *)(hot_sum + (NVAL ? hot_cells : 0));
+    const bool hot_mom2 = HOT && NVAL && P.hot.mom2 != 0u; // (wave-uniform) the box also keeps the sum of squares
+    double *const hot_sum2 = hot_sum + hot_cells;
+    uint32_t *const hot_cnt = (uint32_t *)(hot_sum + (NVAL ? (hot_mom2 ? 2u : 1u) * hot_cells : 0u));
     const uint64_t n = P.A.n;
     uint64_t tile = blockIdx.x;
     if (tile * T >= n) return;
@@ -1309,6 +1311,7 @@ __global__ void __launch_bounds__(VXH_HOT_BLOCK) part_scatter_blk(const PartArgs
     if (HOT) {
         for (uint32_t c = threadIdx.x; c < hot_cells; c += VXH_HOT_BLOCK) {
             if (NVAL) hot_sum[c] = 0.0;
+            if (hot_mom2) hot_sum2[c] = 0.0;
             hot_cnt[c] = 0u;
         }
     }
@@ -1400,6 +1403,7 @@ __global__ void __launch_bounds__(VXH_HOT_BLOCK) part_scatter_blk(const PartArgs
                     const uint32_t hc = __umul24(hy, P.hot.w) + hx;
                     if (!(P.no_pipeline & 128)) { // (timing experiments: bit 7 drops the box updates)
                         if (NVAL) at_add<__HIP_MEMORY_SCOPE_WORKGROUP, double>(hot_sum + hc, cur.v[NVAL ? r : 0]);
+                        if (hot_mom2) at_add<__HIP_MEMORY_SCOPE_WORKGROUP, double>(hot_sum2 + hc, cur.v[NVAL ? r : 0] * cur.v[NVAL ? r : 0]); // (= pow_u(v, 2))
                         at_add<__HIP_MEMORY_SCOPE_WORKGROUP, uint32_t>(hot_cnt + hc, 1u);
                     }
                     keep &= ~(1u << r);
@@ -1555,6 +1559,7 @@ __global__ void __launch_bounds__(VXH_HOT_BLOCK) part_scatter_blk(const PartArgs
     if (HOT) {
         unsigned long long *gc = P.hot.cnt_acc + (uint64_t)blockIdx.x * hot_cells;
         if (NVAL) flush_add_plain<double, double>(P.hot.sum_acc + (uint64_t)blockIdx.x * hot_cells, hot_sum, hot_cells, 0, 0, hot_cells);
+        if (hot_mom2) flush_add_plain<double, double>(P.hot.sum2_acc + (uint64_t)blockIdx.x * hot_cells, hot_sum2, hot_cells, 0, 0, hot_cells);
         flush_add_plain<unsigned long long, uint32_t>(gc, hot_cnt, hot_cells, 0, 0, hot_cells);
     }
 }
@@ -1617,7 +1622,9 @@ __global__ void __launch_bounds__(1024) part_scatter_wv(const PartArgs P) {
     const uint32_t nwave = blockDim.x >> 6;
     const uint32_t hot_cells = HOT ? P.hot.w * P.hot.h : 0u;
     double *const hot_sum = (double *)(lds + P.hot.lds_offset);
-    uint32_t *const hot_cnt = (uint32_t *)(hot_sum + (NVAL ? hot_cells : 0));
+    const bool hot_mom2 = HOT && NVAL && P.hot.mom2 != 0u; // (wave-uniform) the box also keeps the sum of squares
+    double *const hot_sum2 = hot_sum + hot_cells;
+    uint32_t *const hot_cnt = (uint32_t *)(hot_sum + (NVAL ? (hot_mom2 ? 2u : 1u) * hot_cells : 0u));
     char *const wbase = lds + P.wv_base + wave * (uint32_t)P.wv_wave_bytes;
     double *const ring_val = (double *)wbase;
     uint16_t *const ring_idx = (uint16_t *)(wbase + (NVAL ? (size_t)S * D * 8 : 0));
@@ -1643,6 +1650,7 @@ __global__ void __launch_bounds__(1024) part_scatter_wv(const PartArgs P) {
     if (HOT) {
         for (uint32_t c = threadIdx.x; c < hot_cells; c += blockDim.x) {
             if (NVAL) hot_sum[c] = 0.0;
+            if (hot_mom2) hot_sum2[c] = 0.0;
             hot_cnt[c] = 0u;
         }
     }
@@ -1866,6 +1874,7 @@ __global__ void __launch_bounds__(1024) part_scatter_wv(const PartArgs P) {
                 if (hot) {
                     const uint32_t hc = __umul24(hy, P.hot.w) + hx;
                     if (NVAL) at_add<__HIP_MEMORY_SCOPE_WORKGROUP, double>(hot_sum + hc, val[NVAL ? r : 0]);
+                    if (hot_mom2) at_add<__HIP_MEMORY_SCOPE_WORKGROUP, double>(hot_sum2 + hc, val[NVAL ? r : 0] * val[NVAL ? r : 0]); // (= pow_u(v, 2))
                     at_add<__HIP_MEMORY_SCOPE_WORKGROUP, uint32_t>(hot_cnt + hc, 1u);
                 }
                 is_cold = is_cold & !hot;
@@ -2021,6 +2030,7 @@ __global__ void __launch_bounds__(1024) part_scatter_wv(const PartArgs P) {
     if (HOT) {
         unsigned long long *gc = P.hot.cnt_acc + (uint64_t)blockIdx.x * hot_cells;
         if (NVAL) flush_add_plain<double, double>(P.hot.sum_acc + (uint64_t)blockIdx.x * hot_cells, hot_sum, hot_cells, 0, 0, hot_cells);
+        if (hot_mom2) flush_add_plain<double, double>(P.hot.sum2_acc + (uint64_t)blockIdx.x * hot_cells, hot_sum2, hot_cells, 0, 0, hot_cells);
         flush_add_plain<unsigned long long, uint32_t>(gc, hot_cnt, hot_cells, 0, 0, hot_cells);
     }
 }
@@ -2305,33 +2315,37 @@ __global__ void __launch_bounds__(256) part_merge(const PartMergeArgs M) {
 __global__ void __launch_bounds__(256) part_hot_merge(const HotMergeArgs M) {
     // 64 cells per workgroup; the 4 waves each fold a quarter of the pass-1 blocks (coalesced 512-byte reads),
     // LDS combines the quarters
-    __shared__ double s_sum[4][64];
+    __shared__ double s_sum[4][64], s_sum2[4][64];
     __shared__ unsigned long long s_cnt[4][64];
     const uint32_t cells = M.w * M.h;
     const uint32_t lane = threadIdx.x & 63u, q = threadIdx.x >> 6;
     const uint32_t c = blockIdx.x * 64u + lane;
-    double s = 0.0;
+    double s = 0.0, s2 = 0.0;
     unsigned long long k = 0;
     if (c < cells) {
         for (uint32_t b = q; b < M.blocks; b += 4) {
             const uint64_t i = (uint64_t)b * cells + c;
             if (M.sum_acc) { s += M.sum_acc[i]; M.sum_acc[i] = 0.0; }
+            if (M.sum2_acc) { s2 += M.sum2_acc[i]; M.sum2_acc[i] = 0.0; }
             k += M.cnt_acc[i];
             M.cnt_acc[i] = 0ull;
         }
     }
     s_sum[q][lane] = s;
+    s_sum2[q][lane] = s2;
     s_cnt[q][lane] = k;
     __syncthreads();
     if (q != 0 || c >= cells) return;
     s = (s_sum[0][lane] + s_sum[1][lane]) + (s_sum[2][lane] + s_sum[3][lane]);
+    s2 = (s_sum2[0][lane] + s_sum2[1][lane]) + (s_sum2[2][lane] + s_sum2[3][lane]);
     k = s_cnt[0][lane] + s_cnt[1][lane] + s_cnt[2][lane] + s_cnt[3][lane];
     if (k == 0) return;
     const uint64_t cell = (uint64_t)(M.x0 + c % M.w) + (uint64_t)(M.y0 + c / M.w) * M.stride_y;
     for (uint32_t a = 0; a < M.nagg; ++a) {
         if (M.takes_sum[a]) {
             double *g = (double *)M.grid[a] + cell;
-            if (M.atomic) at_add<__HIP_MEMORY_SCOPE_AGENT, double>(g, s); else *g += s;
+            const double add = M.takes_sum[a] == 2 ? s2 : s;
+            if (M.atomic) at_add<__HIP_MEMORY_SCOPE_AGENT, double>(g, add); else *g += add;
         } else {
             unsigned long long *g = (unsigned long long *)M.grid[a] + cell;
             if (M.atomic) at_add<__HIP_MEMORY_SCOPE_AGENT, unsigned long long>(g, k); else *g += k;

@@ -126,8 +126,9 @@ struct PartArgs {
         int32_t on;
         uint32_t x0, y0, w, h;     // in sub-index units of dims 0 and 1 (edge cells included)
         uint32_t lds_offset;       // of the box inside pass 1's dynamic LDS
-        uint32_t reserved_;
+        uint32_t mom2;             // the box also keeps the sum of squares (AggSumMoment with moment 2: var / std), LDS order: sum | sum2 | count
         double *sum_acc;           // [pass-1 workgroups][w*h]
+        double *sum2_acc;          // ... (mom2)
         unsigned long long *cnt_acc;
     } hot;
 };
@@ -149,10 +150,10 @@ struct HotMergeArgs {
     uint32_t x0, y0, w, h, blocks, nagg;
     uint64_t stride_y;             // cells per step of dim 1
     int32_t atomic, reserved_;
-    double *sum_acc;
+    double *sum_acc, *sum2_acc;
     unsigned long long *cnt_acc;
     void *grid[VXH_MAX_AGG];       // replica 0 of every aggregator
-    uint8_t takes_sum[VXH_MAX_AGG]; // 1: fp64 sum grid (+= box sum), 0: int64 count grid (+= box count)
+    uint8_t takes_sum[VXH_MAX_AGG]; // 1: fp64 sum grid (+= box sum), 2: fp64 sum-of-squares grid (+= box sum2), 0: int64 count grid (+= box count)
 };
 
 struct PartMergeArgs {
