@@ -34,6 +34,34 @@ def test_class_surface_names(sa):
                 assert hasattr(sa, prefix + dt + nn), prefix + dt + nn
     for name in ("Grid", "Binner", "Aggregator"):
         assert hasattr(sa, name)
+    # the rest of the aggregator family resolves on demand (module __getattr__): src/agg_first.cpp:165-178, agg_nunique.cpp:226-235, agg_list.cpp:223-233
+    for dt in DTYPES:
+        for nn in ("", "_non_native"):
+            assert callable(getattr(sa, "AggNUnique_" + dt + nn))
+            assert callable(getattr(sa, "AggList_" + dt + "_int64" + nn))
+            assert callable(getattr(sa, "AggFirst_" + dt + "_float64" + nn))
+    for missing in ("AggCount_string", "AggNUnique_string", "BinnerCombined"):
+        assert not hasattr(sa, missing)
+
+
+def test_collector_surface_without_a_gpu(sa):
+    import sys
+    g0 = sa.Grid([])
+    b = sa.BinnerScalar_float64(4, "x", 0.0, 1.0, 10)
+    g = sa.Grid([b])
+    # vaex predicts nunique's footprint as sizeof(class on an empty grid) x cells and insists on equality (vaex/agg.py:354-368)
+    one = sys.getsizeof(sa.AggNUnique_float64(g0, 1, 4, False, True))
+    assert sys.getsizeof(sa.AggNUnique_float64(g, 1, 4, False, True)) == one * len(g)
+    with pytest.raises(RuntimeError, match="Expected 1 grid"):       # src/agg_nunique.cpp:20
+        sa.AggNUnique_int32(g, 2, 4, False, False)
+    with pytest.raises(RuntimeError, match="only accepts 1 grid"):   # src/agg_list.cpp:18
+        sa.AggList_float64_int64(g, 2, 4, False, False)
+    a = sa.AggNUnique_int32(g, 1, 4, True, False)
+    with pytest.raises(RuntimeError, match="Itemsize"):
+        a.set_data(0, __import__("numpy").zeros(4, dtype="f8"), 0)
+    with pytest.raises(RuntimeError, match="merge not implemented"):  # src/agg_nunique.cpp:46-49
+        a.merge([a])
+    sa.AggList_float64_int64(g, 1, 4, False, False).merge([])         # (a no-op in the reference: src/agg_list.cpp:49)
 
 
 def test_binner_scalar_surface(sa):
