@@ -798,17 +798,45 @@ static int64_t hot_search(const std::vector<int64_t> &g, uint32_t sx, uint32_t s
         for (uint32_t x = 0; x < sx; x++) P(x + 1, y + 1) = g[(size_t)y * sx + x] + P(x, y + 1) + P(x + 1, y) - P(x, y);
     int64_t best = -1;
     const double side = std::sqrt((double)max_cells);
-    // big grids: candidate positions on a coarser lattice (<= ~256 per dim), so that the search stays ~1 ms
-    const uint32_t step = std::max<uint32_t>(1, (uint32_t)(std::max(sx, sy) / 256));
-    for (int k = -8; k <= 8; k++) {
-        uint32_t h = (uint32_t)std::max(1.0, std::min((double)sy, std::floor(side * std::pow(2.0, k / 4.0))));
-        uint32_t w = (uint32_t)std::min<uint64_t>(sx, max_cells / h);
-        if (w == 0) continue;
+    auto inside = [&](uint32_t x0, uint32_t y0, uint32_t w, uint32_t h) { return P(x0 + w, y0 + h) - P(x0, y0 + h) - P(x0 + w, y0) + P(x0, y0); };
+    auto shape_of = [&](int k, uint32_t &w, uint32_t &h) {
+        h = (uint32_t)std::max(1.0, std::min((double)sy, std::floor(side * std::pow(2.0, k / 4.0))));
+        w = (uint32_t)std::min<uint64_t>(sx, max_cells / h);
+        if (w == 0) return false;
         h = (uint32_t)std::min<uint64_t>(sy, max_cells / w); // use what the clipped width leaves
-        for (uint32_t y0 = 0; y0 + h <= sy; y0 += step)
-            for (uint32_t x0 = 0; x0 + w <= sx; x0 += step) {
-                const int64_t in = P(x0 + w, y0 + h) - P(x0, y0 + h) - P(x0 + w, y0) + P(x0, y0);
-                if (in > best) { best = in; box[0] = x0; box[1] = y0; box[2] = w; box[3] = h; }
+        return true;
+    };
+    // coarse to fine: every aspect ratio on a lattice of ~64 positions per dimension (the whole search is on the calling
+    // thread's critical path of a first call: ~0.1 ms instead of 1-2), then every position within one lattice step
+    // of the best candidate of each of the three best-scoring ratios
+    const uint32_t step = std::max<uint32_t>(1, (uint32_t)(std::max(sx, sy) / 64));
+    struct Cand { int64_t in; uint32_t x0, y0, w, h; };
+    std::vector<Cand> cands;
+    for (int k = -8; k <= 8; k++) {
+        uint32_t w, h;
+        if (!shape_of(k, w, h)) continue;
+        Cand c{-1, 0, 0, w, h};
+        for (uint32_t y0 = 0;; y0 += step) {
+            if (y0 + h > sy) y0 = sy - h; // (the last lattice row / column sits against the edge)
+            for (uint32_t x0 = 0;; x0 += step) {
+                if (x0 + w > sx) x0 = sx - w;
+                const int64_t in = inside(x0, y0, w, h);
+                if (in > c.in) { c.in = in; c.x0 = x0; c.y0 = y0; }
+                if (x0 + w >= sx) break;
+            }
+            if (y0 + h >= sy) break;
+        }
+        cands.push_back(c);
+    }
+    std::sort(cands.begin(), cands.end(), [](const Cand &a, const Cand &b) { return a.in > b.in; });
+    for (size_t i = 0; i < cands.size() && i < 3; i++) {
+        const Cand &c = cands[i];
+        const uint32_t ya = c.y0 > step ? c.y0 - step : 0, yb = std::min(sy - c.h, c.y0 + step);
+        const uint32_t xa = c.x0 > step ? c.x0 - step : 0, xb = std::min(sx - c.w, c.x0 + step);
+        for (uint32_t y0 = ya; y0 <= yb; y0++)
+            for (uint32_t x0 = xa; x0 <= xb; x0++) {
+                const int64_t in = inside(x0, y0, c.w, c.h);
+                if (in > best) { best = in; box[0] = x0; box[1] = y0; box[2] = c.w; box[3] = c.h; }
             }
     }
     return best;
