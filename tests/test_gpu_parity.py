@@ -440,6 +440,44 @@ def test_hot_box_forced(sa, hot_pass1):
         _hot_reset(sa)
 
 
+def test_float32_columns_take_the_block_kernel(sa):
+    """every binner column and the value column float32: part_scatter_blk's float instantiation (widening on use, like
+    BinnerScalar<float> / AggSum<float>), with and without a box, with a shared selection, 1-3 dims"""
+    sa.config_set("strategy", STRATEGIES["part"])
+    try:
+        rng = np.random.default_rng(77)
+        n = 1_300_001
+        x, y, z = (rng.normal(0.2, 1.0, n).astype("f4") for _ in range(3))
+        v = rng.normal(3, 2, n).astype("f4")
+        v[::89] = np.nan
+        x[::997] = np.nan
+        m = v > 2.5
+        b2 = [dict(kind="scalar", data=c, vmin=-4, vmax=4, bins=256) for c in (x, y)]
+        aggs = [dict(kind="count"), dict(kind="sum", data=v), dict(kind="count", data=v)]
+        check(sa, dict(n=n, binners=b2, aggs=aggs))
+        assert sa.last_kernel(0).startswith("part_scatter") and sa.config_get("hot_w") == 0  # (below hot_min_rows: no box)
+        for box in ((100, 110, 60, 50), (0, 0, 92, 92)):
+            for k, val in zip(("hot_x0", "hot_y0", "hot_w", "hot_h"), box):
+                sa.config_set(k, val)
+            check(sa, dict(n=n, binners=b2, aggs=aggs))
+            assert sa.config_get("hot_w") == box[2] and sa.last_kernel(0).startswith("part_scatter_hot")
+            check(sa, dict(n=n, binners=b2, aggs=[dict(a, mask=m) for a in aggs]))
+            if box[2] * box[3] * 20 < 100_000:  # (20-byte cells with the sum of squares)
+                check(sa, dict(n=n, binners=b2, aggs=[dict(kind="count", data=v), dict(kind="sum", data=v), dict(kind="summoment", data=v, moment=2)]))
+                assert sa.config_get("hot_w") == box[2]
+        _hot_reset(sa)
+        sa.config_set("hot_min_rows", 1)
+        check(sa, dict(n=n, binners=b2, aggs=aggs))          # the box from the sample (float32 sample pass)
+        assert sa.config_get("hot_w") > 0 and sa.config_get("hot_fraction_ppm") > 500_000
+        _hot_reset(sa)
+        check(sa, dict(n=n, binners=[dict(kind="scalar", data=x, vmin=-4, vmax=4, bins=400_000)], aggs=[dict(kind="count"), dict(kind="sum", data=v)]))
+        check(sa, dict(n=n, binners=[dict(kind="scalar", data=c, vmin=-4, vmax=4, bins=96) for c in (x, y, z)], aggs=[dict(kind="count", mask=m)]))
+        # a float64 value column next to float32 binners is not this signature: the generic kernels
+        check(sa, dict(n=n, binners=b2, aggs=[dict(kind="sum", data=v.astype("f8"))]))
+    finally:
+        _hot_reset(sa)
+
+
 def test_hot_box_from_sample(sa, hot_pass1):
     sa.config_set("strategy", STRATEGIES["part"])
     try:

@@ -590,6 +590,16 @@ static LaunchPlan make_plan(const BinArgs &A, BinArgs &out, uint64_t n, double b
     fast = fast && fast_vals;
     p.fast_f64 = fast;
     p.fast_vals = fast_vals;
+    bool f32 = A.ndim >= 1;
+    for (int d = 0; d < A.ndim; d++) {
+        const BinnerDesc &b = A.b[d];
+        if (b.kind != VXH_BIN_SCALAR || b.dtype != VXH_F32 || b.flip || b.mask) f32 = false;
+    }
+    for (int k = 0; k < A.nagg; k++) {
+        const AggDesc &a = A.a[k];
+        if (a.data && (a.dtype != VXH_F32 || a.flip)) f32 = false;
+    }
+    p.fast_f32 = f32;
     p.key_i64 = A.ndim == 1 && A.b[0].kind == VXH_BIN_ORDINAL && A.b[0].dtype == VXH_I64 && !A.b[0].flip && !A.b[0].mask;
 
     // LDS bytes per cell over all aggregators -> number of interleaved slabs S (power of two)
@@ -774,7 +784,7 @@ static bool wv_aligned(const BinArgs &A) {
 // The signature pass 1's HOT instantiation serves: two scalar float64 binners, ONE float64 value column, no masks or
 // ONE mask shared by every aggregator (a selection: part_scatter_blk only), aggregators count(*) / count(v) / sum(v).
 static int hot_eligible(const BinArgs &A, const LaunchPlan &plan, bool *masked = nullptr, bool *mom2 = nullptr) {
-    if (!plan.fast_f64 || A.ndim != 2 || A.nagg < 1 || A.cells >= (1ull << 31)) return -1;
+    if ((!plan.fast_f64 && !plan.fast_f32) || A.ndim != 2 || A.nagg < 1 || A.cells >= (1ull << 31)) return -1;
     const void *v = nullptr;
     if (masked) *masked = A.a[0].mask != nullptr;
     if (mom2) *mom2 = false;
@@ -861,7 +871,7 @@ static void hot_prepare(Slot &slot, const BinArgs &A, const BinArgs &planned, co
     const bool gen2 = c.cfg_blk && S <= 256 && slab_cells < 65535 && !(c.cfg_no_pipeline & 1) && c.cfg_part_rows <= 0; // (= run_part_chunk's conditions for part_scatter_blk)
     const WvGeom wg = wv_geometry(S, nval, true);
     bool wv = wg.ok && slab_cells < 65535 && wv_aligned(A); // (= run_part_chunk's conditions for part_scatter_wv)
-    if (masked) { // (the box next to a selection mask: part_scatter_blk's instantiation only)
+    if (masked || plan.fast_f32) { // (the box next to a selection mask / on float32 columns: part_scatter_blk's instantiations only)
         if (!gen2) return;
         wv = false;
     }
@@ -912,13 +922,13 @@ static void hot_prepare(Slot &slot, const BinArgs &A, const BinArgs &planned, co
             LaunchPlan sp{};
             sp.strategy = VXH_STRAT_GLOBAL;
             sp.block = 256;
-            sp.fast_f64 = true;
+            sp.fast_f64 = !plan.fast_f32;
             sp.name = "hot_sample";
             for (uint64_t j = 0; j < nseg; j++) {
                 const uint64_t r0 = (length / nseg) * j, rn = std::min(seg, length - r0);
                 BinArgs L = Q;
                 L.n = rn;
-                for (int d = 0; d < 2; d++) L.b[d].data = (const char *)A.b[d].data + r0 * 8;
+                for (int d = 0; d < 2; d++) L.b[d].data = (const char *)A.b[d].data + r0 * (plan.fast_f32 ? 4 : 8);
                 sp.blocks = (int)std::max<uint64_t>(1, std::min<uint64_t>((rn + 1023) / 1024, (uint64_t)c.cus * 4));
                 vxh_launch_bin(L, sp, slot.stream);
             }
@@ -1218,9 +1228,9 @@ static void run_part_chunk(Slot &slot, const BinArgs &planned, const LaunchPlan 
     int scatter_blocks = (int)std::max<uint64_t>(1, std::min<uint64_t>(tiles, (uint64_t)c.cus * per_cu));
     // second-generation pass 1 (part_scatter_blk): float64 scalar binners, <= 1 float64 value column, <= 1 mask shared
     // by every aggregator, uint16 local indices with one value to spare for the null record, <= 64 slabs
-    const bool blk = c.cfg_blk && (plan.fast_f64 || (plan.key_i64 && plan.fast_vals)) && !(c.cfg_no_pipeline & 1) && planned.ndim >= 1 && planned.ndim <= 3 && P.nvals <= 1 && !P.use_flags &&
+    const bool blk = c.cfg_blk && (plan.fast_f64 || plan.fast_f32 || (plan.key_i64 && plan.fast_vals)) && !(c.cfg_no_pipeline & 1) && planned.ndim >= 1 && planned.ndim <= 3 && P.nvals <= 1 && !P.use_flags &&
                      (P.nmasks == 0 || (P.nmasks == 1 && P.all_masked)) && P.idx16 && slab_cells < 65535 && S <= 256 && c.cfg_part_rows <= 0 &&
-                     (slot.hot.on || (S > 8 && S <= 64 && !plan.key_i64) || c.cfg_blk == 2); // measured (profiles/r01_other_shapes.txt, r01_groupby_tune.txt):
+                     (slot.hot.on || (S > 8 && S <= 64 && !plan.key_i64) || (plan.fast_f32 && S <= 64) || c.cfg_blk == 2); // measured (profiles/r01_other_shapes.txt, r01_groupby_tune.txt):
                      // <= 8 slabs without a box: two 512-thread workgroups of part_scatter_f64 are 2 % faster; 128-256 slabs: +5 % (1024^2) / -35 % (1e6-key groupby)
     const bool hot_here = slot.hot.on && (P.nmasks == 0 || (P.nmasks == 1 && P.all_masked && blk && !wv)) && P.nvals == slot.hot.nval && (blk || wv);
     if (wv) {
@@ -1233,6 +1243,7 @@ static void run_part_chunk(Slot &slot, const BinArgs &planned, const LaunchPlan 
         scatter_blocks = wv_blocks;
     } else if (blk) {
         P.blk = 1;
+        P.f32 = plan.fast_f32 ? 1 : 0;
         P.rows_per_thread = 4;
         scatter_lds = (size_t)VXH_BLK_FIXED_LDS(P.nvals, S) + 16;
         scatter_blocks = (int)std::max<uint64_t>(1, std::min<uint64_t>((planned.n + 4095) / 4096, (uint64_t)c.cus)); // ONE workgroup per CU

@@ -1278,7 +1278,9 @@ constexpr int VXH_HOT_BLOCK = 1024;   // threads
 constexpr int VXH_HOT_R = 4;          // rows per thread per tile
 constexpr uint32_t VXH_HOT_QBLK = 1024; // records per reserved queue block
 
-template <int NDIM, int NVAL, bool MASKED, bool HOT, int KEY = 0>
+// CT: the columns' element type — double, or float (every binner and the value column float32: widened on use, exactly
+// what BinnerScalar<float> / AggSum<float> do: src/binners.cpp:16-35, src/agg_sum.cpp:98-127)
+template <int NDIM, int NVAL, bool MASKED, bool HOT, int KEY = 0, typename CT = double>
 __global__ void __launch_bounds__(VXH_HOT_BLOCK) part_scatter_blk(const PartArgs P) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr int R = VXH_HOT_R;
@@ -1322,12 +1324,12 @@ __global__ void __launch_bounds__(VXH_HOT_BLOCK) part_scatter_blk(const PartArgs
     __syncthreads();
 
     struct Raw {
-        double b[NDIM][R];
-        double v[NVAL ? R : 1];
+        CT b[NDIM][R];
+        CT v[NVAL ? R : 1];
         uint8_t m[MASKED ? R : 1];
         uint32_t valid;
     };
-    const double *colv = NVAL ? (const double *)P.vdata[0] : nullptr;
+    const CT *colv = NVAL ? (const CT *)P.vdata[0] : nullptr;
     const uint8_t *colm = MASKED ? P.mdata[0] : nullptr;
     auto request = [&](uint64_t t, Raw &raw) {
         uint64_t i[R];
@@ -1343,7 +1345,7 @@ __global__ void __launch_bounds__(VXH_HOT_BLOCK) part_scatter_blk(const PartArgs
         }
 #pragma unroll
         for (int d = 0; d < NDIM; ++d) {
-            const double *col = (const double *)P.A.b[d].data;
+            const CT *col = (const CT *)P.A.b[d].data;
 #pragma unroll
             for (int r = 0; r < R; ++r) raw.b[d][r] = col[i[r]];
         }
@@ -1381,7 +1383,7 @@ __global__ void __launch_bounds__(VXH_HOT_BLOCK) part_scatter_blk(const PartArgs
             for (int d = 0; d < NDIM; ++d) {
                 const BinnerDesc &b = P.A.b[d];
                 if (KEY == 1) { // ONE ordinal binner on a native int64 key (groupby): src/binner_ordinal.cpp:138-175 without mask
-                    const int64_t value = (int64_t)((uint64_t)__double_as_longlong(cur.b[d][r]) - (uint64_t)b.min_value);
+                    const int64_t value = (int64_t)((uint64_t)__double_as_longlong((double)cur.b[d][r]) - (uint64_t)b.min_value);
                     const int64_t nord = (int64_t)b.bins;
                     sub_i[d] = (value < 0 || value >= nord) ? (uint32_t)nord : (uint32_t)(b.invert ? nord - 1 - value : value);
                 } else {
@@ -1403,7 +1405,7 @@ __global__ void __launch_bounds__(VXH_HOT_BLOCK) part_scatter_blk(const PartArgs
                     const uint32_t hc = __umul24(hy, P.hot.w) + hx;
                     if (!(P.no_pipeline & 128)) { // (timing experiments: bit 7 drops the box updates)
                         if (NVAL) at_add<__HIP_MEMORY_SCOPE_WORKGROUP, double>(hot_sum + hc, cur.v[NVAL ? r : 0]);
-                        if (hot_mom2) at_add<__HIP_MEMORY_SCOPE_WORKGROUP, double>(hot_sum2 + hc, cur.v[NVAL ? r : 0] * cur.v[NVAL ? r : 0]); // (= pow_u(v, 2))
+                        if (hot_mom2) at_add<__HIP_MEMORY_SCOPE_WORKGROUP, double>(hot_sum2 + hc, (double)cur.v[NVAL ? r : 0] * (double)cur.v[NVAL ? r : 0]); // (= pow_u(v, 2))
                         at_add<__HIP_MEMORY_SCOPE_WORKGROUP, uint32_t>(hot_cnt + hc, 1u);
                     }
                     keep &= ~(1u << r);
@@ -2489,6 +2491,18 @@ void vxh_launch_part_scatter(const PartArgs &args, const LaunchPlan &plan, int s
             if (args.nvals == 0) { if (masked) VXH_SC((part_scatter_blk<1, 0, true, false, 1>)); else VXH_SC((part_scatter_blk<1, 0, false, false, 1>)); }
             else { if (masked) VXH_SC((part_scatter_blk<1, 1, true, false, 1>)); else VXH_SC((part_scatter_blk<1, 1, false, false, 1>)); }
         }
+        else if (args.f32) { // every binner column and the value column float32
+#define VXH_BLKF(ND, HT)                                                                                               \
+    do {                                                                                                               \
+        if (args.nvals == 0) { if (masked) VXH_SC((part_scatter_blk<ND, 0, true, HT, 0, float>)); else VXH_SC((part_scatter_blk<ND, 0, false, HT, 0, float>)); } \
+        else { if (masked) VXH_SC((part_scatter_blk<ND, 1, true, HT, 0, float>)); else VXH_SC((part_scatter_blk<ND, 1, false, HT, 0, float>)); } \
+    } while (0)
+            if (hot) VXH_BLKF(2, true);
+            else if (args.A.ndim == 1) VXH_BLKF(1, false);
+            else if (args.A.ndim == 2) VXH_BLKF(2, false);
+            else VXH_BLKF(3, false);
+#undef VXH_BLKF
+        }
         else if (hot && masked) { if (args.nvals == 0) VXH_SC((part_scatter_blk<2, 0, true, true>)); else VXH_SC((part_scatter_blk<2, 1, true, true>)); }
         else if (hot) { if (args.nvals == 0) VXH_SC((part_scatter_blk<2, 0, false, true>)); else VXH_SC((part_scatter_blk<2, 1, false, true>)); }
         else if (args.A.ndim == 1) VXH_BLK(1);
@@ -2527,7 +2541,7 @@ void vxh_launch_part_scatter(const PartArgs &args, const LaunchPlan &plan, int s
 
 void vxh_launch_part_reduce(const PartArgs &args, const LaunchPlan &plan, hipStream_t stream) {
     // specialised kernel: count / sum / sum-moment over float64 inputs, no record flags, uint16 indices
-    bool fast = plan.fast_vals && !args.use_flags && args.idx16 && args.nvals <= 2 && args.A.nagg >= 1 && args.A.nagg <= 4 && !(args.no_pipeline & 16) && !args.A.count16;
+    bool fast = (plan.fast_vals || args.f32) && !args.use_flags && args.idx16 && args.nvals <= 2 && args.A.nagg >= 1 && args.A.nagg <= 4 && !(args.no_pipeline & 16) && !args.A.count16;
     for (int k = 0; fast && k < args.A.nagg; ++k) {
         const AggDesc &a = args.A.a[k];
         if (args.agg_mbit[k] != 0xff) fast = false;

@@ -102,6 +102,7 @@ struct PartArgs {
     //  was ~130 us of every part_reduce launch: profiles/r01_chunk_fit.txt.)
     void *acc[VXH_MAX_AGG];
     int32_t blk; // pass 1 = part_scatter_blk (block-reserved queues, 4096-row tiles)
+    int32_t f32; // ... its float instantiation: every binner column and the value column float32 (the records carry float64 all the same)
     // pass 1 = part_scatter_wv (barrier-free, wave-private staging rings): wv = waves per workgroup (0: not this
     // kernel); each wave's LDS area of wv_wave_bytes starts at wv_base + wave * wv_wave_bytes
     int32_t wv, wv_base, wv_wave_bytes;
@@ -175,6 +176,7 @@ struct LaunchPlan {
     bool key_i64;    // ONE ordinal binner over a native unmasked int64 column (groupby on an integer key)
     bool count_fast; // launch K1d (count_lds_f64) instead of bin_kernel<LDS>
     bool fast_f64; // all binners scalar f64 native unmasked, all aggregator inputs f64 native / absent
+    bool fast_f32; // the same with float32 everywhere (part_scatter_blk<..., float>)
     const char *name;
 };
 
