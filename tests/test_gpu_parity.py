@@ -472,9 +472,20 @@ def test_float32_columns_take_the_block_kernel(sa):
         _hot_reset(sa)
         check(sa, dict(n=n, binners=[dict(kind="scalar", data=x, vmin=-4, vmax=4, bins=400_000)], aggs=[dict(kind="count"), dict(kind="sum", data=v)]))
         check(sa, dict(n=n, binners=[dict(kind="scalar", data=c, vmin=-4, vmax=4, bins=96) for c in (x, y, z)], aggs=[dict(kind="count", mask=m)]))
+        # count(*) on float32 columns whose grid fits LDS: the float instantiation of the count kernel (plain / packed uint16 / with a selection)
+        sa.config_set("strategy", 0)
+        for shape, name in ((128, "count_lds_f32"), (256, "count_lds16_f32")):
+            bb = [dict(kind="scalar", data=c, vmin=-4, vmax=4, bins=shape) for c in (x, y)]
+            check(sa, dict(n=n, binners=bb, aggs=[dict(kind="count")]))
+            assert sa.last_kernel(0) == name, sa.last_kernel(0)
+            check(sa, dict(n=n, binners=bb, aggs=[dict(kind="count", mask=m)]))
+        check(sa, dict(n=n, binners=[dict(kind="scalar", data=c, vmin=-4, vmax=4, bins=30) for c in (x, y, z)], aggs=[dict(kind="count")]))
+        assert sa.last_kernel(0) == "count_lds_f32"
+        sa.config_set("strategy", STRATEGIES["part"])
         # a float64 value column next to float32 binners is not this signature: the generic kernels
         check(sa, dict(n=n, binners=b2, aggs=[dict(kind="sum", data=v.astype("f8"))]))
     finally:
+        sa.config_set("strategy", 0)
         _hot_reset(sa)
 
 

@@ -728,7 +728,7 @@ static LaunchPlan make_plan(const BinArgs &A, BinArgs &out, uint64_t n, double b
         out.replicas = (int)std::min<uint64_t>((uint64_t)A.replicas, ngroups);
         p.use_replicas = out.replicas;
         p.name = S > 1 ? (fast ? "bin_lds_slab_f64" : "bin_lds_slab_generic") : (c16_lds ? (fast ? "bin_lds_count16_f64" : "bin_lds_count16_generic") : (fast ? "bin_lds_f64" : "bin_lds_generic"));
-        if (p.count_fast) p.name = c16_lds ? "count_lds16_f64" : "count_lds_f64";
+        if (p.count_fast) p.name = p.fast_f32 ? (c16_lds ? "count_lds16_f32" : "count_lds_f32") : (c16_lds ? "count_lds16_f64" : "count_lds_f64");
     } else {
         p.lds_bytes = 0;
         p.block = c.cfg_block > 0 ? (int)c.cfg_block : 256;

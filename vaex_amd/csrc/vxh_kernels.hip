@@ -1001,7 +1001,7 @@ __device__ __forceinline__ uint32_t scalar_sub_index32(double v, double vmin, do
 // flight) before tile t is binned, the sub-index is the 32-bit form, and with PACK16 the previous tile's
 // returning atomics are settled a whole tile later.  bin_kernel spends 314 VALU + 77 scalar instructions per
 // 4 rows on this case (profiles/r01_pmc_count16.txt) and keeps only one dimension's loads in flight at a time.
-template <int NDIM, bool PACK16, bool MASKED>
+template <int NDIM, bool PACK16, bool MASKED, typename CT = double> // (CT float: every binner column float32, widened on use)
 __global__ void __launch_bounds__(1024) count_lds_f64(const BinArgs A) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr int R = 4;
@@ -1018,7 +1018,7 @@ __global__ void __launch_bounds__(1024) count_lds_f64(const BinArgs A) {
     __syncthreads();
 
     struct Raw {
-        double b[NDIM][R];
+        CT b[NDIM][R];
         uint8_t m[R];
         uint32_t valid;
     };
@@ -1027,7 +1027,7 @@ __global__ void __launch_bounds__(1024) count_lds_f64(const BinArgs A) {
         raw.valid = rows.valid;
 #pragma unroll
         for (int d = 0; d < NDIM; ++d) {
-            const double *col = (const double *)A.b[d].data;
+            const CT *col = (const CT *)A.b[d].data;
 #pragma unroll
             for (int r = 0; r < R; ++r) raw.b[d][r] = col[rows.i[r]];
         }
@@ -2571,14 +2571,15 @@ void vxh_launch_bin(const BinArgs &args, const LaunchPlan &plan, hipStream_t str
         hipLaunchKernelGGL((bin_kernel<__VA_ARGS__>), g, b, plan.lds_bytes, stream, args);                             \
     } while (0)
     if (plan.count_fast) {
-#define VXH_CNT(ND)                                                                                                    \
+#define VXH_CNT_T(ND, T)                                                                                               \
     do {                                                                                                               \
         if (args.a[0].mask) {                                                                                          \
-            if (args.count16) VXH_LAUNCH_K((count_lds_f64<ND, true, true>)); else VXH_LAUNCH_K((count_lds_f64<ND, false, true>)); \
+            if (args.count16) VXH_LAUNCH_K((count_lds_f64<ND, true, true, T>)); else VXH_LAUNCH_K((count_lds_f64<ND, false, true, T>)); \
         } else {                                                                                                       \
-            if (args.count16) VXH_LAUNCH_K((count_lds_f64<ND, true, false>)); else VXH_LAUNCH_K((count_lds_f64<ND, false, false>)); \
+            if (args.count16) VXH_LAUNCH_K((count_lds_f64<ND, true, false, T>)); else VXH_LAUNCH_K((count_lds_f64<ND, false, false, T>)); \
         }                                                                                                              \
     } while (0)
+#define VXH_CNT(ND) do { if (plan.fast_f32) VXH_CNT_T(ND, float); else VXH_CNT_T(ND, double); } while (0)
 #define VXH_LAUNCH_K(KERNEL)                                                                                           \
     do {                                                                                                               \
         if (plan.lds_bytes > 48 * 1024) (void)hipFuncSetAttribute((const void *)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds_bytes); \
@@ -2587,6 +2588,7 @@ void vxh_launch_bin(const BinArgs &args, const LaunchPlan &plan, hipStream_t str
         if (args.ndim == 1) VXH_CNT(1); else if (args.ndim == 2) VXH_CNT(2); else VXH_CNT(3);
 #undef VXH_LAUNCH_K
 #undef VXH_CNT
+#undef VXH_CNT_T
     }
     else if (plan.strategy == VXH_STRAT_LDS && args.count16) { if (plan.fast_f64) VXH_LAUNCH(VXH_STRAT_LDS, true, true); else VXH_LAUNCH(VXH_STRAT_LDS, false, true); }
     else if (plan.strategy == VXH_STRAT_LDS) { if (plan.fast_f64) VXH_LAUNCH(VXH_STRAT_LDS, true); else VXH_LAUNCH(VXH_STRAT_LDS, false); }

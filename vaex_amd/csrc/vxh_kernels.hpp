@@ -182,7 +182,7 @@ struct LaunchPlan {
 
 // K1d (count_lds_f64) serves: LDS strategy, one slab, float64 fast path, 1..3 dims, ONE count(*) aggregator
 inline bool vxh_count_fast(const BinArgs &a, const LaunchPlan &p) {
-    return p.strategy == VXH_STRAT_LDS && p.fast_f64 && a.slab_log2 == 0 && a.ndim >= 1 && a.ndim <= 3 && a.nagg == 1 &&
+    return p.strategy == VXH_STRAT_LDS && (p.fast_f64 || p.fast_f32) && a.slab_log2 == 0 && a.ndim >= 1 && a.ndim <= 3 && a.nagg == 1 &&
            a.a[0].kind == VXH_AGG_COUNT && a.a[0].data == nullptr;
 }
 
