@@ -240,3 +240,26 @@ def test_frame_nunique_and_value_counts_against_pandas(sa, gpu_ready):
     assert got_map == {("nan" if np.isnan(a) else a): c for a, c in want.to_dict().items()}
     vals, counts = f.value_counts("v", dropnan=True, ascending=True)
     assert not np.isnan(vals).any() and np.array_equal(np.sort(counts), counts) and counts.sum() == int((~np.isnan(v)).sum())
+
+
+def test_frame_list_against_numpy(sa, gpu_ready):
+    from vaex_amd.binned import Frame
+    rng = np.random.default_rng(41)
+    n = 200_000
+    x = rng.uniform(0, 10, n)
+    v = rng.normal(0, 1, n)
+    v[rng.random(n) < 0.02] = np.nan
+    f = Frame(x=x, v=v, chunk_size=1 << 16)
+    cell = np.floor(x).astype(int)
+    got = f.list("v", binby="x", limits=[0, 10], shape=10)
+    assert got.shape == (10,)
+    for c in range(10):
+        mine = v[cell == c]
+        want = np.concatenate([mine[~np.isnan(mine)], mine[np.isnan(mine)]])  # values in row order, the NaNs behind them
+        assert np.array_equal(got[c], want, equal_nan=True)
+    keep = v > 0
+    got = f.list("v", binby="x", limits=[0, 10], shape=10, selection=keep, dropnan=True)
+    for c in range(10):
+        assert np.array_equal(got[c], v[(cell == c) & keep])
+    whole = f.list("v", dropnan=True)
+    assert np.array_equal(whole, v[~np.isnan(v)])

@@ -624,6 +624,67 @@ class Frame:
             r = r[tuple(slice(2, -1) if s_["kind"] == "scalar" else slice(0, -2) for s_ in specs)]
         return r
 
+    def list(self, expression, binby=None, limits=None, shape=128, selection=None, dropna=False, dropnan=False, dropmissing=False, edges=False):
+        """vaex.agg.list (vaex/agg.py:655-670 -> AggList_<T>_<T2>): per cell the values of `expression` in row order, then one NaN
+        per NaN row, then one (zero) slot per missing value (unless dropped).  Returns an object array of the grid's shape whose
+        elements are the cells' value arrays (vaex wraps the same (offsets, values) pair into an arrow list array)."""
+        sa = self.sa
+        specs = self._binner_specs(binby or [], limits, shape)
+        value = self.columns[expression]
+        missing = None
+        if np.ma.isMaskedArray(value):
+            missing = np.ma.getmaskarray(value)
+            value = np.ma.getdata(value)
+        cols = [self.columns[s_["column"]] for s_ in specs]
+        if any(np.ma.isMaskedArray(c) for c in cols):
+            raise NotImplementedError("list binned by columns with missing values")
+        sel = self._mask_array(selection)
+        device = all(_is_device(c) for c in cols + [value]) and (sel is None or _is_device(sel))
+        binners = []
+        for s_, c in zip(specs, cols):
+            pf = _class_postfix(c)
+            if s_["kind"] == "scalar":
+                binners.append(getattr(sa, "BinnerScalar_" + pf)(1, s_["column"], s_["vmin"], s_["vmax"], s_["bins"]))
+            else:
+                binners.append(getattr(sa, "BinnerOrdinal_" + pf)(1, s_["column"], s_["count"], s_["min_value"], False, s_["invert"]))
+        grid = sa.Grid(binners)
+        pf = _class_postfix(value)
+        a = getattr(sa, "AggList_" + pf.replace("_non_native", "") + "_int64" + ("_non_native" if pf.endswith("_non_native") else ""))(grid, 1, 1, bool(dropnan or dropna), bool(dropmissing or dropna))
+        step = self.n if device else self.chunk_size
+        for i1 in range(0, self.n, max(1, step)):
+            i2 = min(self.n, i1 + step)
+            refs = []
+            pick = (lambda c: c[i1:i2]) if device else (lambda c: (lambda d: d.view("u1") if d.dtype == np.bool_ else d)(np.ascontiguousarray(c[i1:i2])))
+            for b, c in zip(binners, cols):
+                d = pick(c); b.set_data(0, d); b.clear_data_mask(0); refs.append(d)
+            d = pick(value); a.set_data(0, d, 0); refs.append(d)
+            # data mask: 1 = value present (and selected), 0 = missing; rows outside the selection carry 2: neither kept nor counted
+            # (vaex hands selection & ~missing as data mask, which turns unselected rows into missing ones: vaex/cpu.py:733-770)
+            if sel is not None or missing is not None:
+                m = np.ones(i2 - i1, dtype="u1")
+                if missing is not None:
+                    m[missing[i1:i2]] = 0
+                if sel is not None:
+                    m[~np.asarray(sel[i1:i2].cpu() if _is_device(sel) else sel[i1:i2]).astype(bool)] = 2
+                if device:
+                    import torch
+                    m = torch.from_numpy(m).to(value.device)
+                a.set_data_mask(0, m); refs.append(m)
+            else:
+                a.clear_data_mask(0)
+            grid.bin(0, [a], i2 - i1)
+        offsets, values = a.list_arrays()
+        offsets, values = np.asarray(offsets), np.asarray(values)
+        cells = np.empty(len(offsets) - 1, dtype=object)
+        for j in range(len(cells)):
+            cells[j] = values[offsets[j]:offsets[j + 1]]
+        if not specs:
+            return cells[0]
+        r = cells.reshape([len(b) for b in binners][::-1]).T  # (dim 0 fastest)
+        if not edges:
+            r = r[tuple(slice(2, -1) if s_["kind"] == "scalar" else slice(0, -2) for s_ in specs)]
+        return r
+
     def value_counts(self, expression, dropna=False, dropnan=False, dropmissing=False, ascending=False):
         """df[expression].value_counts() (vaex/expression.py:1029-1130 -> TaskPartValueCounts, vaex/cpu.py:141-283: a
         `counter_<T>` hash map per thread, merged) for an integer or float column: (values, counts) sorted by count
