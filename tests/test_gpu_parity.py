@@ -489,6 +489,27 @@ def test_float32_columns_take_the_block_kernel(sa):
         _hot_reset(sa)
 
 
+@pytest.mark.parametrize("dt,tag", [("i4", "i32"), ("i8", "i64")])
+def test_integer_columns_take_the_count_kernel(sa, dt, tag):
+    """count(*) binned by integer columns whose grid fits LDS: the integer instantiations of the count kernel
+    (BinnerScalar<int32_t / int64_t>: the element is converted to double before the subtraction, src/binners.cpp:16-35)"""
+    rng = np.random.default_rng(78)
+    n = 1_100_003
+    info = np.iinfo(dt)
+    x = np.clip(rng.normal(0, 900, n), -5000, 5000).astype(dt)
+    y = np.clip(rng.normal(100, 700, n), -5000, 5000).astype(dt)
+    x[:4] = [info.min, info.max, -4000, 4000]  # far outside, and the limits themselves
+    m = rng.random(n) < 0.6
+    for shape, name in ((128, f"count_lds_{tag}"), (256, f"count_lds16_{tag}")):
+        bb = [dict(kind="scalar", data=c, vmin=-4000, vmax=4000, bins=shape) for c in (x, y)]
+        check(sa, dict(n=n, binners=bb, aggs=[dict(kind="count")]))
+        assert sa.last_kernel(0) == name, sa.last_kernel(0)
+        check(sa, dict(n=n, binners=bb, aggs=[dict(kind="count", mask=m)]))
+        assert sa.last_kernel(0) == name
+    check(sa, dict(n=n, binners=[dict(kind="scalar", data=x, vmin=-4000.5, vmax=3999.5, bins=8000)], aggs=[dict(kind="count")]))
+    assert sa.last_kernel(0) == f"count_lds_{tag}"
+
+
 def test_hot_box_from_sample(sa, hot_pass1):
     sa.config_set("strategy", STRATEGIES["part"])
     try:

@@ -600,6 +600,16 @@ static LaunchPlan make_plan(const BinArgs &A, BinArgs &out, uint64_t n, double b
         if (a.data && (a.dtype != VXH_F32 || a.flip)) f32 = false;
     }
     p.fast_f32 = f32;
+    p.count_ct = -1;
+    if (A.ndim >= 1) {
+        const int dt = A.b[0].dtype;
+        bool same = dt == VXH_F64 || dt == VXH_F32 || dt == VXH_I64 || dt == VXH_I32;
+        for (int d = 0; d < A.ndim; d++) {
+            const BinnerDesc &b = A.b[d];
+            if (b.kind != VXH_BIN_SCALAR || b.dtype != dt || b.flip || b.mask) same = false;
+        }
+        if (same) p.count_ct = dt;
+    }
     p.key_i64 = A.ndim == 1 && A.b[0].kind == VXH_BIN_ORDINAL && A.b[0].dtype == VXH_I64 && !A.b[0].flip && !A.b[0].mask;
 
     // LDS bytes per cell over all aggregators -> number of interleaved slabs S (power of two)
@@ -728,7 +738,10 @@ static LaunchPlan make_plan(const BinArgs &A, BinArgs &out, uint64_t n, double b
         out.replicas = (int)std::min<uint64_t>((uint64_t)A.replicas, ngroups);
         p.use_replicas = out.replicas;
         p.name = S > 1 ? (fast ? "bin_lds_slab_f64" : "bin_lds_slab_generic") : (c16_lds ? (fast ? "bin_lds_count16_f64" : "bin_lds_count16_generic") : (fast ? "bin_lds_f64" : "bin_lds_generic"));
-        if (p.count_fast) p.name = p.fast_f32 ? (c16_lds ? "count_lds16_f32" : "count_lds_f32") : (c16_lds ? "count_lds16_f64" : "count_lds_f64");
+        if (p.count_fast) {
+            static const char *const names[2][4] = {{"count_lds_f64", "count_lds_f32", "count_lds_i64", "count_lds_i32"}, {"count_lds16_f64", "count_lds16_f32", "count_lds16_i64", "count_lds16_i32"}};
+            p.name = names[c16_lds ? 1 : 0][p.count_ct == VXH_F64 ? 0 : (p.count_ct == VXH_F32 ? 1 : (p.count_ct == VXH_I64 ? 2 : 3))];
+        }
     } else {
         p.lds_bytes = 0;
         p.block = c.cfg_block > 0 ? (int)c.cfg_block : 256;

@@ -1001,7 +1001,7 @@ __device__ __forceinline__ uint32_t scalar_sub_index32(double v, double vmin, do
 // flight) before tile t is binned, the sub-index is the 32-bit form, and with PACK16 the previous tile's
 // returning atomics are settled a whole tile later.  bin_kernel spends 314 VALU + 77 scalar instructions per
 // 4 rows on this case (profiles/r01_pmc_count16.txt) and keeps only one dimension's loads in flight at a time.
-template <int NDIM, bool PACK16, bool MASKED, typename CT = double> // (CT float: every binner column float32, widened on use)
+template <int NDIM, bool PACK16, bool MASKED, typename CT = double> // (CT float / long long / int: every binner column of that type, converted to double on use like BinnerScalar<T>)
 __global__ void __launch_bounds__(1024) count_lds_f64(const BinArgs A) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr int R = 4;
@@ -2579,7 +2579,7 @@ void vxh_launch_bin(const BinArgs &args, const LaunchPlan &plan, hipStream_t str
             if (args.count16) VXH_LAUNCH_K((count_lds_f64<ND, true, false, T>)); else VXH_LAUNCH_K((count_lds_f64<ND, false, false, T>)); \
         }                                                                                                              \
     } while (0)
-#define VXH_CNT(ND) do { if (plan.fast_f32) VXH_CNT_T(ND, float); else VXH_CNT_T(ND, double); } while (0)
+#define VXH_CNT(ND) do { if (plan.count_ct == VXH_F32) VXH_CNT_T(ND, float); else if (plan.count_ct == VXH_I64) VXH_CNT_T(ND, long long); else if (plan.count_ct == VXH_I32) VXH_CNT_T(ND, int); else VXH_CNT_T(ND, double); } while (0)
 #define VXH_LAUNCH_K(KERNEL)                                                                                           \
     do {                                                                                                               \
         if (plan.lds_bytes > 48 * 1024) (void)hipFuncSetAttribute((const void *)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds_bytes); \

@@ -177,12 +177,13 @@ struct LaunchPlan {
     bool count_fast; // launch K1d (count_lds_f64) instead of bin_kernel<LDS>
     bool fast_f64; // all binners scalar f64 native unmasked, all aggregator inputs f64 native / absent
     bool fast_f32; // the same with float32 everywhere (part_scatter_blk<..., float>)
+    int count_ct;  // dtype every (scalar, native, unmasked) binner column has, when that is one the count kernel K1d is instantiated for (VXH_F64 / F32 / I64 / I32), else -1
     const char *name;
 };
 
 // K1d (count_lds_f64) serves: LDS strategy, one slab, float64 fast path, 1..3 dims, ONE count(*) aggregator
 inline bool vxh_count_fast(const BinArgs &a, const LaunchPlan &p) {
-    return p.strategy == VXH_STRAT_LDS && (p.fast_f64 || p.fast_f32) && a.slab_log2 == 0 && a.ndim >= 1 && a.ndim <= 3 && a.nagg == 1 &&
+    return p.strategy == VXH_STRAT_LDS && p.count_ct >= 0 && a.slab_log2 == 0 && a.ndim >= 1 && a.ndim <= 3 && a.nagg == 1 &&
            a.a[0].kind == VXH_AGG_COUNT && a.a[0].data == nullptr;
 }
 
