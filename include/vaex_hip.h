@@ -74,8 +74,10 @@ int vxh_set_device(int device);
 int vxh_synchronize(void);
 /* run slot `thread`'s work on a caller-owned hipStream_t (NULL = library-owned stream) */
 int vxh_slot_set_stream(int thread, void *hip_stream);
-/* tuning knobs for experiments and tests ("strategy", "part_chunk", "parts", "wv", "wv_waves", "blk", "hot", "hot_cache",
- * "count16", "stage_bytes", "feeder", "cache_bytes", ...: the full list is the if-chain of vxh_config_set in vaex_amd/csrc/vxh_api.hip) */
+/* tuning knobs for experiments and tests ("strategy", "part_chunk", "parts", "wv", "wv_waves", "wv_waves_direct", "blk", "hot",
+ * "hot_cache", "hot_min_pct", "hot_direct_pct", "count16", "stage_bytes", "feeder", "cache_bytes", ...) and the two switches that
+ * reproduce reference quirks ("first_mask_block", "nunique_row_counts": see AggFirst / AggNUnique below): the full list is the
+ * if-chain of vxh_config_set in vaex_amd/csrc/vxh_api.hip; DESIGN.md §3 */
 int vxh_config_set(const char *key, int64_t value);
 int vxh_config_get(const char *key, int64_t *value);
 /* name of the kernel variant the last vxh_grid_bin on `thread` launched (for tests / bench) */
