@@ -797,7 +797,9 @@ static bool wv_aligned(const BinArgs &A) {
 // The signature pass 1's HOT instantiation serves: two scalar float64 binners, ONE float64 value column, no masks or
 // ONE mask shared by every aggregator (a selection: part_scatter_blk only), aggregators count(*) / count(v) / sum(v).
 static int hot_eligible(const BinArgs &A, const LaunchPlan &plan, bool *masked = nullptr, bool *mom2 = nullptr) {
-    if ((!plan.fast_f64 && !plan.fast_f32) || A.ndim != 2 || A.nagg < 1 || A.cells >= (1ull << 31)) return -1;
+    // (grids beyond 2^21 cells: the box could hold well under 1 % of the area, and the sample's count grid — copied to the host —
+    //  would be tens of megabytes)
+    if ((!plan.fast_f64 && !plan.fast_f32) || A.ndim != 2 || A.nagg < 1 || A.cells > (1ull << 21)) return -1;
     const void *v = nullptr;
     if (masked) *masked = A.a[0].mask != nullptr;
     if (mom2) *mom2 = false;
