@@ -51,3 +51,4 @@ for dt in (torch.float64, torch.float32, torch.int32):
     run(f"{NAMES[dt]} count+sum+count 256^2", dt, 256, True)
     run(f"{NAMES[dt]} count 256^2", dt, 256, False)
     run(f"{NAMES[dt]} count 128^2", dt, 128, False)
+    run(f"{NAMES[dt]} count+sum+count 64^2 (LDS)", dt, 64, True)
