@@ -2283,16 +2283,15 @@ int vxh_collect_bin(vxh_collect *c, int thread, uint64_t length) {
         if (c->n > 2 * c->compact + (1u << 22)) collect_compact(c, slot);
         if (c->n + length > c->cap) {
             const uint64_t cap = std::max<uint64_t>(c->n + length, c->cap + c->cap / 2);
-            uint64_t *nv = nullptr; uint32_t *nc = nullptr;
-            HIP_CHECK(hipMalloc(&nv, cap * 8));
-            HIP_CHECK(hipMalloc(&nc, cap * 4));
+            DevBuf nv(cap * 8), nc(cap * 4); // (freed again if anything below throws)
             if (c->n) {
-                HIP_CHECK(hipMemcpyAsync(nv, c->val, c->n * 8, hipMemcpyDeviceToDevice, slot.stream));
-                HIP_CHECK(hipMemcpyAsync(nc, c->cell, c->n * 4, hipMemcpyDeviceToDevice, slot.stream));
+                HIP_CHECK(hipMemcpyAsync(nv.p, c->val, c->n * 8, hipMemcpyDeviceToDevice, slot.stream));
+                HIP_CHECK(hipMemcpyAsync(nc.p, c->cell, c->n * 4, hipMemcpyDeviceToDevice, slot.stream));
             }
             HIP_CHECK(hipStreamSynchronize(slot.stream));
             (void)hipFree(c->val); (void)hipFree(c->cell);
-            c->val = nv; c->cell = nc; c->cap = cap;
+            c->val = (uint64_t *)nv.p; c->cell = (uint32_t *)nc.p; c->cap = cap;
+            nv.p = nc.p = nullptr; // (owned by the collector now)
         }
     }
     std::vector<std::unique_ptr<DevBuf>> tmps;
