@@ -525,6 +525,8 @@ class Frame:
     def _first_last(self, invert, expression, order_expression, binby, limits, shape, selection, edges):
         """df.first / df.last (vaex/dataframe.py:976-1011 -> AggFirst, vaex/agg.py:556-576): per cell the value of the row
         with the smallest (last: largest) order value; a masked array (cells without rows masked)."""
+        if self.comm is not None:
+            raise NotImplementedError("first / last over a row-sharded Frame (the aggregator has no merge, like the reference's: src/agg_first.cpp:42)")
         sa = self.sa
         specs = self._binner_specs(binby, limits, shape)
         value = self.columns[expression]
@@ -576,6 +578,8 @@ class Frame:
         """df.nunique (vaex/dataframe.py:1057-1089 -> vaex.agg.nunique, vaex/agg.py:600-612 -> AggNUnique_<T>): per cell the
         number of distinct values of `expression`; NaN and the missing value count as one value each unless dropped
         (dropna = both).  The rows' {value, cell} pairs are sorted and reduced on the device (vxh_collect_*)."""
+        if self.comm is not None:
+            raise NotImplementedError("nunique / list over a row-sharded Frame (the aggregators have no merge, like the reference's)")
         sa = self.sa
         specs = self._binner_specs(binby or [], limits, shape)
         value = self.columns[expression]
@@ -628,6 +632,8 @@ class Frame:
         """vaex.agg.list (vaex/agg.py:655-670 -> AggList_<T>_<T2>): per cell the values of `expression` in row order, then one NaN
         per NaN row, then one (zero) slot per missing value (unless dropped).  Returns an object array of the grid's shape whose
         elements are the cells' value arrays (vaex wraps the same (offsets, values) pair into an arrow list array)."""
+        if self.comm is not None:
+            raise NotImplementedError("nunique / list over a row-sharded Frame (the aggregators have no merge, like the reference's)")
         sa = self.sa
         specs = self._binner_specs(binby or [], limits, shape)
         value = self.columns[expression]
@@ -690,6 +696,8 @@ class Frame:
         `counter_<T>` hash map per thread, merged) for an integer or float column: (values, counts) sorted by count
         (descending unless `ascending`; ties by value).  = the groupby count of the column on itself: the dense-range
         ordinal pass or the fused hash aggregation on the device; float values are counted by their bits (NaN one value)."""
+        if self.comm is not None:
+            raise NotImplementedError("value_counts over a row-sharded Frame")
         col = self.columns[expression]
         missing = 0
         if np.ma.isMaskedArray(col):
