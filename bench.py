@@ -117,7 +117,18 @@ def cpu_baseline(x, y, v, shape, rows):
         res, dt = one_pass()
         best = min(best, dt)
         reps += 1
-    return dict(value=rows / best, unit="rows/s", cores=nthreads, kind=kind,
+    single = None
+    if ref is not None:
+        # the raw single-thread Grid.bin rate of the reference on 2e7 of the rows (SURVEY §8d asks for it beside the pool's)
+        m = min(rows, 20_000_000)
+        bx = ref.BinnerScalar_float64(1, "x", -4.0, 4.0, shape); by = ref.BinnerScalar_float64(1, "y", -4.0, 4.0, shape)
+        g1 = ref.Grid([bx, by])
+        a1 = [ref.AggCount_int64(g1, 1, 1), ref.AggSum_float64(g1, 1, 1), ref.AggCount_float64(g1, 1, 1)]
+        bx.set_data(0, xs[:m]); by.set_data(0, ys[:m]); a1[1].set_data(0, vs[:m], 0); a1[2].set_data(0, vs[:m], 0)
+        t1 = time.perf_counter()
+        g1.bin(0, a1, m)
+        single = m / (time.perf_counter() - t1)
+    return dict(value=rows / best, unit="rows/s", cores=nthreads, kind=kind, single_thread_value=single,
                 sample=f"{rows:.3g} of the GPU's own rows (x,y,v float64), same 2-D {shape}x{shape} count+sum+count pass, best of {reps} passes, 1Mi-row chunks over a {nthreads}-thread pool"), res, rows
 
 
@@ -238,6 +249,7 @@ def run(args):
             "config": {"workload": f"{rows:.3g}-row float64 x,y,v per GPU: count+sum+mean on {shape}x{shape} grid, HBM-resident (BASELINE configs[1])",
                        "rows_per_gpu": rows, "shape": shape, "kernel": sa.last_kernel(0), "parallelism": f"row-sharded x{world}, RCCL all-reduce of 3 grids"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "frac_of_measured_copy_rate": achieved / 6290.0,  # (6.29 TB/s float4 copy: MI355X_MICROARCH.md)
                          "traffic": traffic, "traffic_source": traffic_source, "kernel_ms": k_ms, "bytes_per_row": BYTES_PER_ROW, "rows_per_launch": rows},
         }
         if world == 1 and not args.no_extra:
