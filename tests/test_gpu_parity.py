@@ -422,10 +422,10 @@ def test_hot_box_forced(sa, hot_pass1):
         check(sa, dict(case, aggs=std_aggs[:2] + [dict(kind="summoment", data=v, moment=3)]))
         assert sa.config_get("hot_w") == 0
         sa.config_set("hot_x0", 130); sa.config_set("hot_y0", 1); sa.config_set("hot_w", 1); sa.config_set("hot_h", 200)
-        # ONE selection mask shared by every aggregator: the box stays (next to part_scatter_blk, whatever pass 1 was asked for)
+        # ONE selection mask shared by every aggregator: the box stays (next to the ring-less pass 1 if that was asked for, else part_scatter_blk)
         m = case["binners"][0]["data"] > 0
         check(sa, dict(case, aggs=[dict(a, mask=m) for a in case["aggs"]]))
-        assert sa.config_get("hot_w") == 1 and sa.last_kernel(0).startswith("part_scatter_hot")
+        assert sa.config_get("hot_w") == 1 and sa.last_kernel(0).startswith("part_scatter_direct_hot" if hot_pass1 == 3 else "part_scatter_hot")
         for box in ((100, 110, 60, 50), (0, 0, 92, 92)):
             for k, val in zip(("hot_x0", "hot_y0", "hot_w", "hot_h"), box):
                 sa.config_set(k, val)

@@ -886,7 +886,7 @@ static void hot_prepare(Slot &slot, const BinArgs &A, const BinArgs &planned, co
     const bool gen2 = c.cfg_blk && S <= 256 && slab_cells < 65535 && !(c.cfg_no_pipeline & 1) && c.cfg_part_rows <= 0; // (= run_part_chunk's conditions for part_scatter_blk)
     const WvGeom wg = wv_geometry(S, nval, true);
     bool wv = wg.ok && slab_cells < 65535 && wv_aligned(A); // (= run_part_chunk's conditions for part_scatter_wv)
-    if (masked || plan.fast_f32) { // (the box next to a selection mask / on float32 columns: part_scatter_blk's instantiations only)
+    if ((masked && !(wv && wg.direct == 1)) || plan.fast_f32) { // (the box next to a selection mask: part_scatter_blk's or the ring-less part_scatter_wv's instantiations; on float32 columns: part_scatter_blk's only)
         if (!gen2) return;
         wv = false;
     }
@@ -1247,7 +1247,7 @@ static void run_part_chunk(Slot &slot, const BinArgs &planned, const LaunchPlan 
                      (P.nmasks == 0 || (P.nmasks == 1 && P.all_masked)) && P.idx16 && slab_cells < 65535 && S <= 256 && c.cfg_part_rows <= 0 &&
                      (slot.hot.on || (S > 8 && S <= 64 && !plan.key_i64) || (plan.fast_f32 && S <= 64) || c.cfg_blk == 2); // measured (profiles/r01_other_shapes.txt, r01_groupby_tune.txt):
                      // <= 8 slabs without a box: two 512-thread workgroups of part_scatter_f64 are 2 % faster; 128-256 slabs: +5 % (1024^2) / -35 % (1e6-key groupby)
-    const bool hot_here = slot.hot.on && (P.nmasks == 0 || (P.nmasks == 1 && P.all_masked && blk && !wv)) && P.nvals == slot.hot.nval && (blk || wv);
+    const bool hot_here = slot.hot.on && (P.nmasks == 0 || (P.nmasks == 1 && P.all_masked && ((blk && !wv) || (wv && wg.direct == 1)))) && P.nvals == slot.hot.nval && (blk || wv);
     if (wv) {
         P.wv = wg.waves;
         P.wv_direct = wg.direct;

@@ -2473,6 +2473,7 @@ void vxh_launch_part_scatter(const PartArgs &args, const LaunchPlan &plan, int s
             else { if (masked) VXH_SC((part_scatter_wv<1, 1, true, false, 1>)); else VXH_SC((part_scatter_wv<1, 1, false, false, 1>)); }
         }
         else if (hot && args.wv_direct == 2) { if (args.nvals == 0) VXH_SC((part_scatter_wv<2, 0, false, true, 0, 2>)); else VXH_SC((part_scatter_wv<2, 1, false, true, 0, 2>)); }
+        else if (hot && args.wv_direct && masked) { if (args.nvals == 0) VXH_SC((part_scatter_wv<2, 0, true, true, 0, 1>)); else VXH_SC((part_scatter_wv<2, 1, true, true, 0, 1>)); }
         else if (hot && args.wv_direct) { if (args.nvals == 0) VXH_SC((part_scatter_wv<2, 0, false, true, 0, 1>)); else VXH_SC((part_scatter_wv<2, 1, false, true, 0, 1>)); }
         else if (hot) { if (args.nvals == 0) VXH_SC((part_scatter_wv<2, 0, false, true>)); else VXH_SC((part_scatter_wv<2, 1, false, true>)); }
         else if (args.A.ndim == 1) VXH_WV(1);
@@ -2544,7 +2545,7 @@ void vxh_launch_part_reduce(const PartArgs &args, const LaunchPlan &plan, hipStr
     bool fast = (plan.fast_vals || args.f32) && !args.use_flags && args.idx16 && args.nvals <= 2 && args.A.nagg >= 1 && args.A.nagg <= 4 && !(args.no_pipeline & 16) && !args.A.count16;
     for (int k = 0; fast && k < args.A.nagg; ++k) {
         const AggDesc &a = args.A.a[k];
-        if (args.agg_mbit[k] != 0xff) fast = false;
+        if (args.agg_mbit[k] != 0xff && args.use_flags) fast = false; // (one mask shared by every aggregator: pass 1 dropped the masked rows, the records carry no flags)
         if (a.kind == VXH_AGG_COUNT) continue;
         if ((a.kind != VXH_AGG_SUM && a.kind != VXH_AGG_SUM_MOMENT) || a.cell != VXH_CELL_F64 || args.agg_vslot[k] == 0xff) fast = false;
     }
