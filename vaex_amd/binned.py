@@ -795,6 +795,27 @@ class Frame:
         cache[by] = (key, r)
         return r
 
+    def _may_hold_nan(self, name):
+        """False when column `name` certainly holds no NaN / missing value: integer columns, and float columns scanned once
+        (remembered per column object, like the key range)."""
+        col = self.columns[name]
+        if np.ma.isMaskedArray(col):
+            return True
+        kind = str(col.dtype).replace("torch.", "")
+        if not kind.startswith("float"):
+            return False
+        cache = self.__dict__.setdefault("_nan_cache", {})
+        hit = cache.get(name)
+        if hit is not None and hit[0] is col:
+            return hit[1]
+        if _is_device(col):
+            import torch
+            r = bool(torch.isnan(col).any())
+        else:
+            r = bool(np.isnan(col).any())
+        cache[name] = (col, r)
+        return r
+
     def groupby(self, by, agg_spec, reduce=None, comm=None):
         """df.groupby(by).agg({...}) for ONE integer key column (a list of key columns: see _groupby_combined).
         Returns {by: keys (ascending), name: values}.
@@ -838,7 +859,16 @@ class Frame:
             if hasattr(sa, "finish"):
                 # finishers + the drop of empty groups on the device: only the finished columns of the groups that exist
                 # cross PCIe (vaex does this part with numpy on the full grids: vaex/agg.py:403-455, vaex/groupby.py:955-972)
-                specs, grid, aggs, want = self._pass(descs + [agg.count()], binby, reduce=reduce)
+                # which groups exist: count(*) > 0 — or the count of a value column the pass computes anyway, when that column
+                # is known to hold no NaN (then the two counts are the same grid and the pass has one aggregator less: for
+                # sum/mean/std of one column over 1e6 groups that is 128 instead of 256 slabs)
+                present_desc = agg.count()
+                if comm is None:
+                    for d in descs:
+                        if d.column is not None and d.selection is None and d.name in ("mean", "var", "std", "count") and not self._may_hold_nan(d.column):
+                            present_desc = agg.count(d.column)
+                            break
+                specs, grid, aggs, want = self._pass(descs + [present_desc], binby, reduce=reduce)
                 fin = [d.finish_spec(sa, [aggs[i] for i in ids]) for d, ids in zip(descs, want[:-1])]
                 cols, index = sa.finish(fin, present=aggs[want[-1][0]], first=0, n=count, want_index=True)
                 out_keys = np.asarray(index) + kmin
