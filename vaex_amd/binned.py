@@ -871,7 +871,9 @@ class Frame:
                 specs, grid, aggs, want = self._pass(descs + [present_desc], binby, reduce=reduce)
                 fin = [d.finish_spec(sa, [aggs[i] for i in ids]) for d, ids in zip(descs, want[:-1])]
                 cols, index = sa.finish(fin, present=aggs[want[-1][0]], first=0, n=count, want_index=True)
-                out_keys = np.asarray(index) + kmin
+                out_keys = np.asarray(index)
+                if kmin:
+                    out_keys += kmin  # (in place: the array is this call's own pinned buffer)
                 vals = [np.asarray(c).astype(self._result_dtype(d), copy=False) for c, d in zip(cols, descs)]
                 return {by: out_keys, **dict(zip(names, vals))}
             res = self._agg(descs + [agg.count()], binby=binby, edges=True, reduce=reduce)
