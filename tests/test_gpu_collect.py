@@ -235,8 +235,11 @@ def test_frame_nunique_and_value_counts_against_pandas(sa, gpu_ready):
     want = df["k"].value_counts()
     assert np.array_equal(np.sort(counts)[::-1], counts) and dict(zip(vals.tolist(), counts.tolist())) == want.to_dict()
     vals, counts = f.value_counts("v")
-    want = df["v"].value_counts(dropna=False)
-    got_map = {("nan" if np.isnan(a) else a): c for a, c in zip(vals.tolist(), counts.tolist())}
+    want = df["v"].value_counts(dropna=False)   # (pandas folds -0.0 onto 0.0; value_counts here keeps them apart like the reference)
+    got_map = {}
+    for a, c in zip(vals.tolist(), counts.tolist()):
+        key = "nan" if np.isnan(a) else a + 0.0
+        got_map[key] = got_map.get(key, 0) + c
     assert got_map == {("nan" if np.isnan(a) else a): c for a, c in want.to_dict().items()}
     vals, counts = f.value_counts("v", dropnan=True, ascending=True)
     assert not np.isnan(vals).any() and np.array_equal(np.sort(counts), counts) and counts.sum() == int((~np.isnan(v)).sum())

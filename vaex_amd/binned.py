@@ -695,7 +695,8 @@ class Frame:
         """df[expression].value_counts() (vaex/expression.py:1029-1130 -> TaskPartValueCounts, vaex/cpu.py:141-283: a
         `counter_<T>` hash map per thread, merged) for an integer or float column: (values, counts) sorted by count
         (descending unless `ascending`; ties by value).  = the groupby count of the column on itself: the dense-range
-        ordinal pass or the fused hash aggregation on the device; float values are counted by their bits (NaN one value)."""
+        ordinal pass or the fused hash aggregation on the device; float values are counted by their bits (-0.0 and +0.0 apart,
+        NaN one value)."""
         if self.comm is not None:
             raise NotImplementedError("value_counts over a row-sharded Frame")
         col = self.columns[expression]
@@ -713,8 +714,7 @@ class Frame:
             isnan = torch.isnan(t)
             nans = int(isnan.sum())
             t = t[~isnan].to(torch.float64)
-            t = torch.where(t == 0, torch.zeros_like(t), t)  # -0.0 counts as 0.0 (one key, as for the hash sets)
-            keys = t.view(torch.int64)
+            keys = t.view(torch.int64)  # (by bit pattern: -0.0 and +0.0 are two values, as for the reference's counter)
             keys = keys if dev else keys.numpy()
         else:
             keys = col
