@@ -52,6 +52,29 @@ def _cases(make, gpu):
     # tests/agg_test.py:150-158 (1-d count golden: also pinned at the class level in tests/test_gpu_parity.py)
     xa = np.array([-1, -2, 0.5, 1.5, 4.5, 5], dtype="f8")
     assert make(x=xa).count(binby="x", limits=[0, 5], shape=5, edges=True).tolist() == [0, 2, 1, 1, 0, 0, 1, 1]
+    # tests/agg_test.py:108-132 test_count_basics (fixture: x = arange(10), y = x**2)
+    x = np.arange(10.0)
+    y = x ** 2
+    f = make(x=x, y=y)
+    counts = f.count(binby="x", limits=[0, 10], shape=10)
+    assert len(counts) == 10 and all(counts == 1)
+    assert all(f.sum("y", binby="x", limits=[0, 10], shape=10) == y)
+    mask = x < 5
+    counts = f.count("x", binby="x", limits=[0, 10], shape=10, selection=mask)
+    assert all(counts == mask * 1)
+    assert all(f.sum("y", binby="x", limits=[0, 10], shape=10, selection=mask) == np.where(mask, y, 0))
+    # tests/agg_test.py:8-48 test_sum, the binned half: x with a NaN in row 0, selection x < 5
+    xn = x.copy()
+    xn[0] = np.nan
+    f = make(x=xn, y=y)
+    sel5 = np.arange(10) < 5
+    A = np.testing.assert_array_almost_equal
+    A(f.sum("x", binby=["y"], limits=[0, 9 ** 2 + 1], shape=1), [np.nansum(xn)])
+    A(f.sum("x", binby=["y"], limits=[0, 9 ** 2 + 1], shape=1, selection=sel5), [np.nansum(xn[:5])])
+    A(f.sum("x", binby=["y"], limits=[0, 9 ** 2 + 1], shape=2), [np.nansum(xn[:7]), np.nansum(xn[7:])])
+    A(f.sum("x", binby=["y"], limits=[0, 9 ** 2 + 1], shape=2, selection=sel5), [np.nansum(xn[:5]), 0])
+    A(f.sum("y", binby=["x"], limits=[0, 10], shape=2), [np.nansum(y[1:5]), np.nansum(y[5:])])   # (row 0: x is NaN — the NaN cell)
+    A(f.sum("y", binby=["x"], limits=[0, 10], shape=2, selection=sel5), [np.nansum(y[1:5]), 0])
     if gpu:
         # tests/agg_test.py:294-316 test_nunique, float half (AggNUnique on the HIP path)
         mapping = {"aap": 1.2, "noot": 2.5, "mies": 3.7, "kees": 4.8, None: np.nan}
