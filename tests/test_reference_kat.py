@@ -75,6 +75,28 @@ def _cases(make, gpu):
     A(f.sum("x", binby=["y"], limits=[0, 9 ** 2 + 1], shape=2, selection=sel5), [np.nansum(xn[:5]), 0])
     A(f.sum("y", binby=["x"], limits=[0, 10], shape=2), [np.nansum(y[1:5]), np.nansum(y[5:])])   # (row 0: x is NaN — the NaN cell)
     A(f.sum("y", binby=["x"], limits=[0, 10], shape=2, selection=sel5), [np.nansum(y[1:5]), 0])
+    # tests/agg_test.py:171-180 test_count_1d_ordinal: ordinal binner of 5, count(edges=True)
+    xo = np.array([-1, -2, 0, 1, 4, 5], dtype="i8")
+    assert make(x=xo).count(binby=[dict(column="x", count=5)], edges=True).tolist() == [1, 1, 0, 0, 1, 3, 0]
+    # tests/agg_test.py:184-192 test_mean_basics (x = arange(10), y = x**2)
+    f = make(x=x, y=y)
+    assert float(f.mean("x")) == 4.5 and float(f.mean("y")) == 28.5
+    assert float(f.mean("x", selection=x < 3)) == 1 and float(f.mean("y", selection=x < 3)) == 5 / 3
+    # tests/agg_test.py:257-262 test_big_endian_binning, :265-273 non-contiguous big-endian, :276-282 test_strides
+    xb = np.arange(10, dtype=">f8")
+    yb = np.zeros(10, dtype=">f8")
+    counts = make(x=xb, y=yb).count(binby=["x", "y"], limits=[[-0.5, 9.5], [-0.5, 0.5]], shape=[10, 1])
+    assert counts.ravel().tolist() == np.ones(10).tolist()
+    xs = np.arange(20, dtype=">f8")[::2]
+    xs[:] = np.arange(10, dtype=">f8")
+    ys = np.arange(20, dtype=">f8")[::2]
+    ys[:] = np.arange(10, dtype=">f8")
+    counts = make(x=xs, y=ys).count(binby=["x", "y"], limits=[[-0.5, 9.5], [-0.5, 9.5]], shape=[10, 10])
+    assert np.diagonal(counts).tolist() == np.ones(10).tolist()
+    ar = np.zeros((10, 2)).reshape(20)
+    xst = ar[::2]
+    xst[:] = np.arange(10)
+    assert make(x=xst).count(binby="x", limits=[-0.5, 9.5], shape=10).tolist() == np.ones(10).tolist()
     if gpu:
         # tests/agg_test.py:294-316 test_nunique, float half (AggNUnique on the HIP path)
         mapping = {"aap": 1.2, "noot": 2.5, "mies": 3.7, "kees": 4.8, None: np.nan}
