@@ -65,6 +65,7 @@ hot = {
 }
 hot["nunique"] = lambda d: d._compute_agg("nunique", "i", binby="y", limits=[-4, 4], shape=4)   # AggNUnique_int32
 hot["groupby_nunique"] = lambda d: by_key(d.groupby("k", agg={"u": vaex.agg.nunique("i"), "uv": vaex.agg.nunique("kf", dropnan=True)}), "k", ["u", "uv"])
+hot["groupby_list"] = lambda d: (lambda g: [sorted(c) for c in g["l"].tolist()])(d.groupby("k", agg={"l": vaex.agg.list("i")}).sort("k"))   # AggList_int32_int64
 fallback = {   # not offered by the HIP classes: must run on vaex's own C++ after install(), GPU or not
   "count_string": lambda d: d.count("s", binby="y", limits=[-4, 4], shape=4),   # AggCount_string
 }
@@ -152,14 +153,14 @@ def test_unmodified_vaex_without_a_gpu_fails_loudly_and_falls_back():
     if vaex_amd.superagg.device_count() > 0:
         pytest.skip("a GPU is visible: see the -m gpu test")
     out = _run(20000, 0, 300)
-    assert out.count("ok-loud-failure") == 15 and out.count("ok-fallback") == 1, out
+    assert out.count("ok-loud-failure") == 16 and out.count("ok-fallback") == 1, out
 
 
 @pytest.mark.gpu
 @pytest.mark.skipif(not os.path.isdir(os.path.join(PKG, "vaex")), reason="real vaex package not built (oracle/build_ref.sh needs /root/reference)")
 def test_unmodified_vaex_drives_the_hip_classes_on_the_gpu():
     out = _run(300_000, int(os.environ.get("VAEX_DROPIN_TIMING_ROWS", "100000000")), 900)
-    assert out.count("ok-parity") == 15 and out.count("ok-fallback") == 1, out
+    assert out.count("ok-parity") == 16 and out.count("ok-fallback") == 1, out
     line = [l for l in out.splitlines() if l.startswith("TIMING")]
     assert line, out
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
