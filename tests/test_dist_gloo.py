@@ -42,6 +42,8 @@ def _worker(rank, world, port, q):
         shard = Frame({k: c[i1:i2] for k, c in cols.items()}, chunk_size=4096, nthreads=1, superagg=RefAdapter(oracle.ref_module("superagg")), comm=vdist.Comm())
         auto = dict(mm=shard.minmax("v"), cnt=shard.count(binby="v", shape=16), lp=shard.limits_percentage("x", 90), med=shard.median_approx("y"),
                     gk=shard.groupby("k", {"c": agg.count()})["c"])
+        vals, counts = shard.value_counts("k")
+        auto["vc_values"], auto["vc_counts"] = vals, counts
         q.put((rank, [np.asarray(r) for r in res], {k: np.asarray(v) for k, v in g.items()}, {k: np.asarray(v) for k, v in auto.items()}))
     finally:
         dist.destroy_process_group()
@@ -69,6 +71,7 @@ def test_two_rank_allreduce_matches_single_process(ref):
     wantg = whole.groupby("k", {"s": agg.sum("v"), "c": agg.count()})
     want_auto = dict(mm=whole.minmax("v"), cnt=whole.count(binby="v", shape=16), lp=whole.limits_percentage("x", 90), med=whole.median_approx("y"),
                      gk=whole.groupby("k", {"c": agg.count()})["c"])
+    want_auto["vc_values"], want_auto["vc_counts"] = whole.value_counts("k")
     for rank, res, g, auto in got:
         for name, w in want_auto.items():
             if np.asarray(w).dtype.kind in "iu":

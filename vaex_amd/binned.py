@@ -697,8 +697,6 @@ class Frame:
         (descending unless `ascending`; ties by value).  = the groupby count of the column on itself: the dense-range
         ordinal pass or the fused hash aggregation on the device; float values are counted by their bits (-0.0 and +0.0 apart,
         NaN one value)."""
-        if self.comm is not None:
-            raise NotImplementedError("value_counts over a row-sharded Frame")
         col = self.columns[expression]
         missing = 0
         if np.ma.isMaskedArray(col):
@@ -718,8 +716,12 @@ class Frame:
             keys = keys if dev else keys.numpy()
         else:
             keys = col
-        sub = Frame({"k": keys}, chunk_size=self.chunk_size, superagg=self.sa)
-        out = sub.groupby("k", {"n": agg.count()}) if len(keys) else {"k": np.array([], dtype="i8"), "n": np.array([], dtype="i8")}
+        # (a row-sharded frame: the groupby on the sub-frame agrees on the keys and all-reduces the counts; the NaN / missing
+        #  row counts are summed over the ranks)
+        sub = Frame({"k": keys}, chunk_size=self.chunk_size, nthreads=self.nthreads, superagg=self.sa, comm=self.comm)
+        if self.comm is not None:
+            nans, missing = self.comm.sum_ints([nans, missing])
+        out = sub.groupby("k", {"n": agg.count()}) if (len(keys) or self.comm is not None) else {"k": np.array([], dtype="i8"), "n": np.array([], dtype="i8")}
         values, counts = np.asarray(out["k"]), np.asarray(out["n"]).astype(np.int64)
         if kind.startswith("float"):
             values = values.astype(np.int64).view(np.float64).astype(kind)

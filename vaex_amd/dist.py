@@ -141,6 +141,16 @@ class Comm:
         dist.all_reduce(thi, op=dist.ReduceOp.MAX, group=self.group)
         return int(tlo[0]), int(thi[0])
 
+    def sum_ints(self, values):
+        """element-wise sum over the ranks of a short list of Python ints (row counts of NaN / missing values)"""
+        import torch
+        import torch.distributed as dist
+        if not dist.is_initialized() or dist.get_world_size(self.group) == 1:
+            return [int(v) for v in values]
+        t = torch.tensor([int(v) for v in values], dtype=torch.int64, device=self._device())
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return [int(v) for v in t.cpu().tolist()]
+
     def minmax_float(self, lo, hi):
         """global (min, max) of per-rank float ranges (df.minmax / limits=None under row sharding); a rank without rows
         contributes (+inf, -inf)"""
