@@ -1,4 +1,8 @@
-import os, sys; sys.path.insert(0, '.')
+#!/usr/bin/env python3
+"""The bench pass with ONE selection mask shared by every aggregator, and with the sum of squares (std), with and without the hot box.
+GPU box."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import vaex_amd
 sa = vaex_amd.superagg
