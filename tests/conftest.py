@@ -34,3 +34,18 @@ def gpu_ready(sa):
     if sa.device_count() == 0:
         pytest.fail("no HIP device visible: -m gpu tests need the GPU box")
     return True
+
+
+import contextlib
+
+
+@contextlib.contextmanager
+def knob(sa, key, value):
+    """vxh_config_set(key, value) for the duration of the block, then the value it had before (the library's defaults are the
+    reference's behaviour: first_mask_block = 1024, nunique_row_counts = 1)"""
+    before = sa.config_get(key)
+    sa.config_set(key, value)
+    try:
+        yield
+    finally:
+        sa.config_set(key, before)

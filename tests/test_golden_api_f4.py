@@ -8,6 +8,7 @@ import os
 import numpy as np
 import pytest
 
+from tests.conftest import knob
 from tests.test_golden_api import RefAdapter
 
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "vaex_api_f4.npz")
@@ -80,12 +81,12 @@ def test_f4_goldens_frame_on_hip(sa, gpu_ready, device):
         cols = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in cols.items()}
     df = Frame(cols, chunk_size=1000, nthreads=3)
     _first_last_and_nunique(df, out, masks)
-    _first_with_selection(df, out, masks, cols, False)  # the product's default: mask[row]
-    sa.config_set("first_mask_block", 1024)             # the reference's indexing, one call of all rows: the fixture
-    try:
-        _first_with_selection(Frame(cols, chunk_size=len(cols["x"]), nthreads=1), out, masks, cols, True)
-    finally:
-        sa.config_set("first_mask_block", 0)
+    _first_with_selection(df, out, masks, cols, False)  # calls of <= 1024 rows: the reference's mask index is the row's
+    # one call of all rows with the library's default (the reference's block-local indexing): the fixture
+    assert sa.config_get("first_mask_block") == 1024
+    _first_with_selection(Frame(cols, chunk_size=len(cols["x"]), nthreads=1), out, masks, cols, True)
+    with knob(sa, "first_mask_block", 0):               # mask[row]: what the call means, whatever the chunking
+        _first_with_selection(Frame(cols, chunk_size=len(cols["x"]), nthreads=1), out, masks, cols, False)
     # groupby on two keys (GrouperCombined, vaex/groupby.py:526-584), sorted by (k2, k3) like the fixture
     g = df.groupby(["k2", "k3"], {"c": agg.count(), "s": agg.sum("v"), "m": agg.mean("v")})
     assert np.array_equal(g["k2"], out["groupby2_k2"]) and np.array_equal(g["k3"], out["groupby2_k3"])

@@ -6,6 +6,8 @@ import zlib
 import numpy as np
 import pytest
 
+from tests.conftest import knob
+
 pytestmark = pytest.mark.gpu
 
 DTYPES = {"float64": "f8", "float32": "f4", "int64": "i8", "int32": "i4", "int16": "i2", "int8": "i1", "uint64": "u8", "uint32": "u4", "uint16": "u2", "uint8": "u1", "bool": "?"}
@@ -104,22 +106,22 @@ def test_nunique_equals_the_reference_class(sa, ref, gpu_ready, name, flip):
     assert want.max() > 20 or name == "bool"
 
 
-def test_nunique_drop_counts_rows_like_the_reference_behind_the_knob(sa, ref, gpu_ready):
+def test_nunique_drop_counts_rows_like_the_reference_by_default(sa, ref, gpu_ready):
     rng = np.random.default_rng(5)
     n = 30_000
     x, y = rng.normal(0, 1.2, n), rng.normal(0, 1.2, n)
     value = _column(rng, "float64", n)          # several NaN rows per cell
     dm = rng.random(n) < 0.97                  # several missing rows per cell
     chunks = [(0, 10_000), (10_000, n)]
+    # the default is the reference's arithmetic: `count -= null_count` takes the NUMBER of missing / NaN rows away
+    # (src/agg_nunique.cpp:31-34), not the one entry they occupy
+    assert sa.config_get("nunique_row_counts") == 1
     want = _run(ref, "AggNUnique_float64", (True, True), x, y, value, dm, None, chunks).get_result()
-    sa.config_set("nunique_row_counts", 1)
-    try:
-        got = _run(sa, "AggNUnique_float64", (True, True), x, y, value, dm, None, chunks).get_result()
-    finally:
-        sa.config_set("nunique_row_counts", 0)
-    assert np.array_equal(got, want)
-    # what the product returns by default: distinct non-NaN values of the cell's present rows
     got = _run(sa, "AggNUnique_float64", (True, True), x, y, value, dm, None, chunks).get_result()
+    assert np.array_equal(got, want)
+    # behind the knob: distinct non-NaN values of the cell's present rows
+    with knob(sa, "nunique_row_counts", 0):
+        got = _run(sa, "AggNUnique_float64", (True, True), x, y, value, dm, None, chunks).get_result()
     assert (got > want).any()  # (the reference took the number of missing / NaN ROWS away)
     cx = np.clip(np.floor((x + 2) / 4 * 6), -1, 6).astype(int) + 2
     cy = np.clip(np.floor((y + 2) / 4 * 5), -1, 5).astype(int) + 2
@@ -159,33 +161,41 @@ def test_list_equals_the_reference_class(sa, ref, gpu_ready, name):
     value = _column(rng, name, n)
     cls = f"AggList_{name}_int64"
     present = rng.random(n) < 0.9
-    # the reference reads the data mask at the row's position inside its 1024-row block (src/agg_list.cpp:103): calls of
-    # <= 1024 rows are where it means what it says
+    # the reference reads the data mask at the row's position inside its 1024-row block of the call (src/agg_list.cpp:103,
+    # `data_mask_ptr[j]`), and so does the product by default; "first_mask_block" = 0 reads mask[row].  The reference's result
+    # goes through vaex.arrow.convert, so both are compared with a direct restatement of src/agg_list.cpp:52-118: offsets =
+    # cumulative (kept + nan + null) per cell, values in row order — `pres` = the mask byte each row actually looked at
+    calls = [(0, 7_000), (7_000, n)]
     chunks = [(i, min(i + 1000, n)) for i in range(0, n, 1000)]
-    for dropnan, dropnull, dm in ((False, False, None), (True, False, None), (False, False, present), (True, True, present), (False, True, present)):
-        wa = _run(ref, cls, (dropnan, dropnull), x, y, value, dm, None, chunks)
-        ga = _run(sa, cls, (dropnan, dropnull), x, y, value, dm, None, [(0, 7_000), (7_000, n)])
-        off, vals = ga.list_arrays()
-        # the reference's result goes through vaex.arrow.convert; compare with a direct restatement of src/agg_list.cpp:52-84
-        # on the reference's own per-cell state instead: offsets = cumulative (kept + nan + null) per cell, values in row order
-        bx = np.clip(np.floor((x + 2) / 4 * 6), -1, 6); by = np.clip(np.floor((y + 2) / 4 * 5), -1, 5)
-        cx = np.where(np.isnan(x), 0, np.where((x + 2) / 4 < 0, 1, np.where((x + 2) / 4 >= 1, 8, bx + 2))).astype(int)
-        cy = np.where(np.isnan(y), 0, np.where((y + 2) / 4 < 0, 1, np.where((y + 2) / 4 >= 1, 7, by + 2))).astype(int)
-        cell = cx + 9 * cy
-        isnan = np.isnan(value) if value.dtype.kind == "f" else np.zeros(n, bool)
-        pres = np.ones(n, bool) if dm is None else dm
-        want_off = [0]
-        want_vals = []
-        for c in range(72):
-            m = cell == c
-            kept = value[m & pres & ~isnan]
-            nn = 0 if dropnan else int((m & pres & isnan).sum())
-            nu = 0 if dropnull else int((m & ~pres).sum())
-            want_vals.append(np.concatenate([kept, np.full(nn, np.nan, dtype=value.dtype) if nn else kept[:0], np.zeros(nu, dtype=value.dtype)]))
-            want_off.append(want_off[-1] + len(want_vals[-1]))
-        assert np.array_equal(off, np.array(want_off))
-        assert np.array_equal(vals, np.concatenate(want_vals), equal_nan=True)
-        assert vals.dtype == value.dtype
+    bx = np.clip(np.floor((x + 2) / 4 * 6), -1, 6); by = np.clip(np.floor((y + 2) / 4 * 5), -1, 5)
+    cx = np.where(np.isnan(x), 0, np.where((x + 2) / 4 < 0, 1, np.where((x + 2) / 4 >= 1, 8, bx + 2))).astype(int)
+    cy = np.where(np.isnan(y), 0, np.where((y + 2) / 4 < 0, 1, np.where((y + 2) / 4 >= 1, 7, by + 2))).astype(int)
+    cell = cx + 9 * cy
+    isnan = np.isnan(value) if value.dtype.kind == "f" else np.zeros(n, bool)
+    for block in (1024, 0):
+        for dropnan, dropnull, dm in ((False, False, None), (True, False, None), (False, False, present), (True, True, present), (False, True, present)):
+            wa = _run(ref, cls, (dropnan, dropnull), x, y, value, dm, None, chunks)
+            with knob(sa, "first_mask_block", block):
+                ga = _run(sa, cls, (dropnan, dropnull), x, y, value, dm, None, calls)
+            off, vals = ga.list_arrays()
+            if dm is None:
+                pres = np.ones(n, bool)
+            elif block:  # row r of the call [i1, i2) looked at mask byte (r - i1) % 1024 of the call's mask
+                pres = np.concatenate([dm[i1:i2][(np.arange(i2 - i1) % block)] for i1, i2 in calls])
+            else:
+                pres = dm
+            want_off = [0]
+            want_vals = []
+            for c in range(72):
+                m = cell == c
+                kept = value[m & pres & ~isnan]
+                nn = 0 if dropnan else int((m & pres & isnan).sum())
+                nu = 0 if dropnull else int((m & ~pres).sum())
+                want_vals.append(np.concatenate([kept, np.full(nn, np.nan, dtype=value.dtype) if nn else kept[:0], np.zeros(nu, dtype=value.dtype)]))
+                want_off.append(want_off[-1] + len(want_vals[-1]))
+            assert np.array_equal(off, np.array(want_off)), (block, dropnan, dropnull)
+            assert np.array_equal(vals, np.concatenate(want_vals), equal_nan=True)
+            assert vals.dtype == value.dtype
     assert wa is not None  # (the reference class constructs and bins the same calls without complaint)
 
 
@@ -196,9 +206,8 @@ def test_nunique_golden_of_the_reference_tests(sa, gpu_ready):
     mapping = {"aap": 1.2, "noot": 2.5, "mies": 3.7, "kees": 4.8, None: np.nan}
     s = np.array([mapping[k] for k in ["aap", "aap", "noot", "mies", None, "mies", "kees", "mies", "aap"]], dtype="f8")
     x = np.array([0, 0, 0, 0, 0, 1, 1, 1, 2], dtype="i8")
-    for knob in (0, 1):
-        sa.config_set("nunique_row_counts", knob)
-        try:
+    for setting in (0, 1):
+        with knob(sa, "nunique_row_counts", setting):
             for dropnan, want in ((False, [4, 2, 1]), (True, [3, 2, 1])):
                 b = sa.BinnerOrdinal_int64(1, "x", 3, 0, False, False)
                 g = sa.Grid([b])
@@ -206,8 +215,6 @@ def test_nunique_golden_of_the_reference_tests(sa, gpu_ready):
                 b.set_data(0, x); a.set_data(0, s, 0)
                 g.bin(0, [a], len(x))
                 assert np.asarray(a.get_result())[:3].tolist() == want
-        finally:
-            sa.config_set("nunique_row_counts", 0)
 
 
 def test_frame_nunique_and_value_counts_against_pandas(sa, gpu_ready):
@@ -224,8 +231,12 @@ def test_frame_nunique_and_value_counts_against_pandas(sa, gpu_ready):
     df = pd.DataFrame(dict(cell=cell, k=k, v=v))
     got = f.nunique("v", binby="x", limits=[0, 10], shape=10)
     assert np.array_equal(got, df.groupby("cell")["v"].nunique(dropna=False).to_numpy())
-    got = f.nunique("v", binby="x", limits=[0, 10], shape=10, dropnan=True)
+    with knob(sa, "nunique_row_counts", 0):  # pandas' meaning of dropna (the default is the reference's: NaN ROWS taken away)
+        got = f.nunique("v", binby="x", limits=[0, 10], shape=10, dropnan=True)
     assert np.array_equal(got, df.groupby("cell")["v"].nunique(dropna=True).to_numpy())
+    nan_rows = df[df["v"].isna()].groupby("cell").size().reindex(range(10), fill_value=0).to_numpy()
+    got = f.nunique("v", binby="x", limits=[0, 10], shape=10, dropnan=True)   # default: src/agg_nunique.cpp:31-34
+    assert np.array_equal(got, df.groupby("cell")["v"].nunique(dropna=False).to_numpy() - nan_rows)
     keep = v > 20
     got = f.nunique("v", binby=[dict(column="k", count=40)], selection=keep)
     assert np.array_equal(got, df[keep].groupby("k")["v"].nunique().reindex(range(40), fill_value=0).to_numpy())
@@ -261,7 +272,8 @@ def test_frame_list_against_numpy(sa, gpu_ready):
         want = np.concatenate([mine[~np.isnan(mine)], mine[np.isnan(mine)]])  # values in row order, the NaNs behind them
         assert np.array_equal(got[c], want, equal_nan=True)
     keep = v > 0
-    got = f.list("v", binby="x", limits=[0, 10], shape=10, selection=keep, dropnan=True)
+    with knob(sa, "first_mask_block", 0):  # mask[row]; the default reads the call's mask block-locally like src/agg_list.cpp:103
+        got = f.list("v", binby="x", limits=[0, 10], shape=10, selection=keep, dropnan=True)
     for c in range(10):
         assert np.array_equal(got[c], v[(cell == c) & keep])
     whole = f.list("v", dropnan=True)

@@ -1,8 +1,12 @@
 """AggFirst_<T>_<T2> (src/agg_first.cpp; vaex.agg.first / last) on the GPU against the reference's own compiled class
 (oracle/_ref/superagg): the same call sequence vaex's TaskPartAggregation.process makes (set_data index 0 = value, 1 = order,
 set_data_mask, Grid.bin), several chunks, one thread slot — values and masks must be identical, ties go to the earlier row."""
+import contextlib
+
 import numpy as np
 import pytest
+
+from tests.conftest import knob
 
 pytestmark = pytest.mark.gpu
 
@@ -64,18 +68,16 @@ def test_first_and_last_equal_the_reference_class(sa, ref, gpu_ready, vt, ot, in
     chunks = [(0, 15_000), (15_000, 15_001), (15_001, n)]
     # The reference indexes the keep-mask with the row's position inside the current 1024-row block of Grid::bin_
     # (`data_mask_ptr[j]`, src/agg_first.cpp:131 — every other aggregator reads `[j + offset]`), i.e. it only means
-    # what it says for calls of <= 1024 rows.  The product reads mask[row] (documented in include/vaex_hip.h); the
-    # "first_mask_block" knob reproduces the reference's indexing.  Both are pinned here:
-    #   knob off  == the reference fed the same rows in <= 1024-row calls (where its indexing is right),
-    #   knob 1024 == the reference fed the same chunks.
+    # what it says for calls of <= 1024 rows.  The product does the same by default (results identical to the reference's on
+    # the same calls); "first_mask_block" = 0 reads mask[row].  Both are pinned here:
+    #   default (1024) == the reference fed the same chunks,
+    #   knob 0         == the reference fed the same rows in <= 1024-row calls (where its indexing is right).
     small = [(i, min(i + 1024, n)) for i in range(0, n, 1024)]
-    for use_keep, ref_chunks, knob in ((None, chunks, 0), (keep, small, 0), (keep, chunks, 1024)):
-        sa.config_set("first_mask_block", knob)
-        try:
+    assert sa.config_get("first_mask_block") == 1024
+    for use_keep, ref_chunks, setting in ((None, chunks, None), (keep, chunks, None), (keep, small, 0), (keep, chunks, 1024)):
+        with (knob(sa, "first_mask_block", setting) if setting is not None else contextlib.nullcontext()):
             want_v, want_m, wa = _run(ref, x, y, value, order, use_keep, vt, ot, invert, ref_chunks)
             got_v, got_m, ga = _run(sa, x, y, value, order, use_keep, vt, ot, invert, chunks)
-        finally:
-            sa.config_set("first_mask_block", 0)
         assert np.array_equal(got_m, want_m)
         assert np.array_equal(got_v[~got_m], want_v[~want_m])
         assert got_v.dtype == want_v.dtype and got_v.shape == want_v.shape
@@ -134,7 +136,8 @@ def test_frame_first_last_against_numpy(sa, gpu_ready):
         want = np.array([v[cell == c][pick(t[cell == c])] for c in range(10)])
         assert not np.ma.getmaskarray(got).any() and np.array_equal(np.ma.getdata(got), want)
     keep = v > 0
-    got = f.first("v", "t", binby="x", limits=[0, 20], shape=20, selection=keep)
+    with knob(sa, "first_mask_block", 0):  # mask[row]: what the call means (the default reproduces src/agg_first.cpp:131)
+        got = f.first("v", "t", binby="x", limits=[0, 20], shape=20, selection=keep)
     assert np.ma.getmaskarray(got)[10:].all() and not np.ma.getmaskarray(got)[:10].any()
     want = np.array([v[(cell == c) & keep][np.argmin(t[(cell == c) & keep])] for c in range(10)])
     assert np.array_equal(np.ma.getdata(got)[:10], want)

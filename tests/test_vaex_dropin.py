@@ -26,9 +26,24 @@ import vaex, vaex.hash, vaex_amd
 cpu = vaex.superagg
 backend = vaex_amd.install()
 hip = vaex_amd.superagg
-# nunique(dropnan=True) below sees several NaN rows per group: the reference takes the number of those ROWS away (src/agg_nunique.cpp:31-34),
-# the HIP class one entry unless asked to do the same (include/vaex_hip.h) — this test compares with the reference
-hip.config_set("nunique_row_counts", 1)
+# (no knob is touched: the library's defaults are the reference's behaviour, incl. AggFirst / AggList's block-local keep-mask index,
+# src/agg_first.cpp:131, and AggNUnique's `count -= null_count` ROWS, src/agg_nunique.cpp:31-34 — both exercised below)
+# which backend every task really ran on: each decode of the registered "aggregations" task part is recorded
+import vaex_amd.vaexfast as _vf
+used = []
+_task = vaex_amd._installed["task_hip"]
+_decode = _task.decode.__func__
+def _recording_decode(cls, *a, **k):
+    part = _decode(cls, *a, **k)
+    used.append(("agg", part.backend_used, [type(ag).__module__ for d in part.aggregations for ag in d[2]]))
+    return part
+_task.decode = classmethod(_recording_decode)
+_legacy = vaex.vaexfast.statisticNd_f8
+assert _legacy is _vf.statisticNd_f8
+def _recording_legacy(*a, **k):
+    used.append(("legacy", "hip", []))
+    return _legacy(*a, **k)
+vaex.vaexfast.statisticNd_f8 = _recording_legacy
 assert vaex.superagg is backend and sys.modules["vaex.superagg"] is backend
 assert vaex.superagg.Grid is hip.Grid and vaex.superagg.AggSum_float64 is hip.AggSum_float64
 assert hasattr(vaex.superagg, "AggNUnique_float64") and not hasattr(vaex.superagg, "BinnerHash_int64") and hasattr(vaex.superagg, "AggFirst_float64_int64")
@@ -38,8 +53,9 @@ rng = np.random.default_rng(1)
 n = %(n)d
 x = rng.normal(0, 1, n); x[::1000] = np.nan
 kf = rng.integers(0, 50, n).astype("f8"); kf[::777] = np.nan
+im = np.ma.array(rng.integers(0, 500, n).astype("i4"), mask=rng.random(n) < 0.03)   # thousands of missing rows per group
 df = vaex.from_arrays(x=x, y=rng.normal(0, 1, n), v=rng.normal(3, 2, n), k=rng.integers(0, 9, n), kb=rng.integers(-10**12, 10**12, n) // 10**9 * 10**9,
-                      kf=kf, i=rng.integers(-100, 100, n).astype("i4"), s=np.array(["a", "bb", None, "dddd"], dtype=object)[rng.integers(0, 4, n)])
+                      kf=kf, i=rng.integers(-100, 100, n).astype("i4"), im=im, s=np.array(["a", "bb", None, "dddd"], dtype=object)[rng.integers(0, 4, n)])
 lim2 = [[-4, 4], [-4, 4]]
 def two_keys(d):
     k, i = d["k"].to_numpy(), d["i"].to_numpy()
@@ -66,6 +82,13 @@ hot = {
 hot["nunique"] = lambda d: d._compute_agg("nunique", "i", binby="y", limits=[-4, 4], shape=4)   # AggNUnique_int32
 hot["groupby_nunique"] = lambda d: by_key(d.groupby("k", agg={"u": vaex.agg.nunique("i"), "uv": vaex.agg.nunique("kf", dropnan=True)}), "k", ["u", "uv"])
 hot["groupby_list"] = lambda d: (lambda g: [sorted(c) for c in g["l"].tolist()])(d.groupby("k", agg={"l": vaex.agg.list("i")}).sort("k"))   # AggList_int32_int64
+# the reference's quirks, reproduced by default: the selection reaches AggFirst as a keep-mask it reads block-locally
+# (src/agg_first.cpp:131); dropmissing / dropnan take the number of missing / NaN ROWS away (src/agg_nunique.cpp:31-34)
+hot["first_sel"] = lambda d: np.stack([np.ma.filled(d.first("v", "y", binby="x", limits=[-4, 4], shape=8, selection="v > 3"), -1e300),
+                                        np.ma.filled(d.last("v", "y", binby="x", limits=[-4, 4], shape=8, selection="y < 0"), -1e300)])
+hot["groupby_nunique_drop"] = lambda d: by_key(d.groupby("k", agg={"um": vaex.agg.nunique("im", dropmissing=True), "ua": vaex.agg.nunique("kf", dropna=True),
+                                                                    "u0": vaex.agg.nunique("im")}), "k", ["um", "ua", "u0"])
+hot["groupby_list_sel"] = lambda d: (lambda g: [sorted(c) for c in g["l"].tolist()])(d.groupby("k", agg={"l": vaex.agg.list("i", selection="v > 5")}).sort("k"))
 fallback = {   # not offered by the HIP classes: must run on vaex's own C++ after install(), GPU or not
   "count_string": lambda d: d.count("s", binby="y", limits=[-4, 4], shape=4),   # AggCount_string
 }
@@ -82,9 +105,18 @@ if not has_gpu:
             raise SystemExit("computed without a GPU: " + name)
 else:
     for name, fn in hot.items():
+        del used[:]
         got[name] = fn(df)
+        # every task of a hot call ran on the HIP classes (and there was at least one: an aggregation task part or the legacy statistic)
+        assert used and all(u[1] == "hip" for u in used), (name, used)
+        assert all(m == "vaex_amd.superagg" for u in used for m in u[2]), (name, used)
+        print("ok-backend hip", name, len(used))
 for name, fn in fallback.items():
+    del used[:]
     got[name] = fn(df)
+    assert used and all(u[1] == "cpu" for u in used) and all(m != "vaex_amd.superagg" for u in used for m in u[2]), (name, used)
+    print("ok-backend cpu", name)
+vaex.vaexfast.statisticNd_f8 = _legacy
 vaex_amd.uninstall()
 assert vaex.superagg is cpu and vaex.hash.ordered_set_int64.__module__ != "vaex_amd.hashset"
 df2 = vaex.from_arrays(**{c: df[c].to_numpy() for c in df.get_column_names()})
@@ -153,14 +185,15 @@ def test_unmodified_vaex_without_a_gpu_fails_loudly_and_falls_back():
     if vaex_amd.superagg.device_count() > 0:
         pytest.skip("a GPU is visible: see the -m gpu test")
     out = _run(20000, 0, 300)
-    assert out.count("ok-loud-failure") == 16 and out.count("ok-fallback") == 1, out
+    assert out.count("ok-loud-failure") == 19 and out.count("ok-fallback") == 1, out
 
 
 @pytest.mark.gpu
 @pytest.mark.skipif(not os.path.isdir(os.path.join(PKG, "vaex")), reason="real vaex package not built (oracle/build_ref.sh needs /root/reference)")
 def test_unmodified_vaex_drives_the_hip_classes_on_the_gpu():
     out = _run(300_000, int(os.environ.get("VAEX_DROPIN_TIMING_ROWS", "100000000")), 900)
-    assert out.count("ok-parity") == 16 and out.count("ok-fallback") == 1, out
+    assert out.count("ok-parity") == 19 and out.count("ok-fallback") == 1, out
+    assert out.count("ok-backend hip") == 19 and out.count("ok-backend cpu") == 1, out
     line = [l for l in out.splitlines() if l.startswith("TIMING")]
     assert line, out
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)

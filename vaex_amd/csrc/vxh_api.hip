@@ -1568,6 +1568,8 @@ int vxh_config_get(const char *key, int64_t *value) {
     else if (k == "hot_x0") *value = get_slot(0).hot.last_on ? (int64_t)get_slot(0).hot.x0 : 0;
     else if (k == "hot_y0") *value = get_slot(0).hot.last_on ? (int64_t)get_slot(0).hot.y0 : 0;
     else if (k == "lds_replicas") *value = c.cfg_lds_replicas;
+    else if (k == "first_mask_block") *value = c.cfg_first_mask_block;
+    else if (k == "nunique_row_counts") *value = c.cfg_nunique_row_counts;
     else if (k == "cus") { ensure_device_ready(); *value = c.cus; }
     else throw std::runtime_error("unknown config key: " + k);
     VXH_API_END
@@ -2312,6 +2314,7 @@ int vxh_collect_bin(vxh_collect *c, int thread, uint64_t length) {
     C.mode = (uint8_t)c->mode;
     C.drop_nan = (uint8_t)(c->mode ? c->drop_a : 0);
     C.drop_null = (uint8_t)(c->mode ? c->drop_b : 0);
+    C.mask_block = (uint32_t)ctx().cfg_first_mask_block;
     C.out_val = c->val + c->n;
     C.out_cell = c->cell + c->n;
     C.null_rows = c->null_rows;

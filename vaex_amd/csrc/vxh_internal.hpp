@@ -190,8 +190,8 @@ struct Context {
     int64_t cfg_cache_bytes = 64ll << 30; // device column cache budget (only ranges registered with vxh_cache_register are cached)
     int64_t cfg_slab_log2 = -1;   // -1 = auto
     int64_t cfg_lds_replicas = 0; // 0 = auto
-    int64_t cfg_nunique_row_counts = 0; // AggNUnique dropmissing / dropnan: 0 = one entry less for a cell that saw missing values / NaNs; 1 = the reference's `count -= null_count` (rows)
-    int64_t cfg_first_mask_block = 0; // AggFirst keep-mask index: 0 = mask[row] (what the reference means); 1024 = mask[row % 1024] (what src/agg_first.cpp:131 does)
+    int64_t cfg_nunique_row_counts = 1; // AggNUnique dropmissing / dropnan: 1 (default) = the reference's `count -= null_count` (rows, src/agg_nunique.cpp:31-34); 0 = one entry less for a cell that saw missing values / NaNs
+    int64_t cfg_first_mask_block = 1024; // AggFirst / AggList keep-mask index: 1024 (default) = mask[row % 1024], what src/agg_first.cpp:131 / agg_list.cpp:103 do; 0 = mask[row] (what they mean)
     int64_t cfg_part_chunk = 1 << 28; // rows per partition chunk (scratch: ~2 x record bytes x this; larger chunks amortise the launches)
     int64_t cfg_parts = 0;        // pass-2 workgroups per slab (0 = auto)
     int64_t cfg_part_lds = 0;     // LDS bytes per pass-2 slab (0 = auto)

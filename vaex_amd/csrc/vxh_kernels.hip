@@ -302,7 +302,7 @@ __global__ void __launch_bounds__(256) collect_pass(const CollectArgs C) {
         uint8_t dm[N], sm[N];
 #pragma unroll
         for (int u = 0; u < N; ++u) {
-            dm[u] = C.data_mask ? C.data_mask[rows.i[u]] : (uint8_t)1;
+            dm[u] = C.data_mask ? C.data_mask[(C.mode == 1 && C.mask_block) ? rows.i[u] % C.mask_block : rows.i[u]] : (uint8_t)1;
             sm[u] = C.selection_mask ? C.selection_mask[rows.i[u]] : (uint8_t)1;
         }
 #pragma unroll

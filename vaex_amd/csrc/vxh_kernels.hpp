@@ -229,6 +229,7 @@ struct CollectArgs {
     uint8_t val_dtype, flip;
     uint8_t mode;            // 0 nunique: NaN / missing rows only counted per cell; 1 list: keep-mask semantics of src/agg_list.cpp:98-118
     uint8_t drop_nan, drop_null; // list: NaN / missing rows are not even counted
+    uint32_t mask_block;     // list only: 0 = data_mask[row]; 1024 = data_mask[row % 1024] (src/agg_list.cpp:103, the "first_mask_block" knob)
     uint64_t *out_val;       // [n]
     uint32_t *out_cell;      // [n]
     unsigned long long *null_rows, *nan_rows; // per cell

@@ -10,12 +10,16 @@ HashMapUnique, vaex/cpu.py:285-404 TaskPartHashmapUniqueCreate):
 
 Keys live in ONE open-addressing table in HBM (vaex_amd/csrc/vxh_hashmap.hip, the `ordered_set` of the pybind shim);
 this module adds, in numpy on the host, what that table does not know about: float keys (a float64 / float32 key goes in
-as its bit pattern with -0.0 folded onto +0.0; NaN has its own ordinal, like the reference's nan_value), the ordinal of
+as its bit pattern — -0.0 and +0.0 are two keys, as for the reference's hash of the bits, src/hash.hpp:138-150;
+NaN has its own ordinal, like the reference's nan_value), the ordinal of
 the null key, ordinals fixed by the caller (the `create` constructor: vaex seals and re-creates its sets from sorted key
 arrays, vaex/hash.py:260-283), and map_ordinal's narrowest-integer result type (:611-626).
 
-Ordinals of a set that is still being filled are dense 0..n-1 in claim order on the device (the reference: shard offset
-+ insertion order) with the null key and NaN behind the keys; parity with the reference is per key, never per ordinal.
+Ordinals of a set that is still being filled are dense in claim order on the device (the reference: shard offset +
+insertion order); the null key and NaN take the next free ordinal when they are first seen and keep it, like the
+reference's add_null / add_nan (:455-470) — so the ordinals update(return_values=True) hands back stay valid while the set
+grows.  Parity with the reference is per key, never per ordinal (except for sets made by `create`, whose ordinals are the
+positions in the key array on both sides).
 """
 import numpy as np
 
@@ -45,7 +49,7 @@ class _OrderedSet:
         self.fingerprint = ""
         self.null_count = 0
         self.nan_count = 0
-        self._null_seen = False
+        self._specials = []     # [(keys on the device when first seen, "null" | "nan")]: ordinal = that count + position in this list
         self._fixed = None      # (key array incl. placeholders, null_index, nan_index) of a set made by `create`
         self._perm = None       # create: position in the key array of the device map's ordinal
         self.sealed = False
@@ -67,7 +71,6 @@ class _OrderedSet:
         if self._is_float:
             a = np.ascontiguousarray(ar, dtype=self._np)
             nan = a != a
-            a = np.where(a == 0, self._np.type(0), a)  # -0.0 == +0.0: one key
             bits = a.view(np.int64 if self._np.itemsize == 8 else np.int32).astype(np.int64)
             return bits, (nan if nan.any() else None)
         return np.ascontiguousarray(ar).astype(np.int64, copy=False) if ar.dtype != np.uint64 else np.ascontiguousarray(ar).view(np.int64), None
@@ -91,7 +94,7 @@ class _OrderedSet:
         self.null_count = int(null_count)
         self.nan_count = int(nan_count)
         null_index = int(np.asarray(null_index).ravel()[0]) if np.ndim(null_index) else int(null_index)
-        self._null_seen = self.null_count > 0 and null_index >= 0
+        null_seen = self.null_count > 0 and null_index >= 0
         n = len(keys)
         real = np.ones(n, dtype=bool)
         nan_index = -1
@@ -100,7 +103,9 @@ class _OrderedSet:
             if len(where):
                 nan_index = int(where[0])
                 real[where] = False
-        if self._null_seen:
+        if self._is_float and (self.nan_count > 0) != bool((keys != keys).any()):  # src/hash_primitives.hpp:505-513
+            raise RuntimeError("no NaN found in data, while claiming there should be" if self.nan_count > 0 else "NaN found in data, while claiming there should be none")
+        if null_seen:
             real[null_index] = False
         pos = np.nonzero(real)[0]
         bits, _ = self._bits(keys[pos])
@@ -108,62 +113,86 @@ class _OrderedSet:
         if len(bits):
             self._map.set_keys(bits)  # ordinal i <-> bits[i] <-> position pos[i] of the key array
         self._perm = pos if len(pos) != n else None
-        self._fixed = (keys, null_index if self._null_seen else -1, nan_index)
+        self._fixed = (keys, null_index if null_seen else -1, nan_index)
         self.sealed = True
 
     # ---------------------------------------------------------------- filling
     def update(self, values, *args, **kwargs):
-        """update(values[, masks], start_index, chunk_size, bucket_size, return_values)"""
-        if self.sealed:
-            raise RuntimeError("hashmap is sealed, cannot update")
+        """update(values[, masks], start_index, chunk_size, bucket_size, return_values) — src/hash_primitives.hpp:98-295.
+        return_values=True hands back (ordinal of every row, map index of every row = 0: one table): masked rows get the null
+        key's ordinal, NaNs the NaN's."""
+        if self._fixed is not None:  # (the reference checks `sealed` in merge only, :694-696; a set made by `create` holds its
+            raise RuntimeError("hashmap is sealed, cannot update")  # keys' positions and cannot take new ones here)
         masks = None
         rest = list(args)
-        if rest and isinstance(rest[0], np.ndarray):
+        if rest and isinstance(rest[0], (np.ndarray, list, tuple)):
             masks = rest.pop(0)
         masks = kwargs.get("masks", masks)
-        return_values = kwargs.get("return_values", rest[3] if len(rest) > 3 else False)
-        if return_values:
-            raise NotImplementedError("ordered_set.update(return_values=True) (materialized groupers) is not offered on the GPU map")
+        return_values = bool(kwargs.get("return_values", rest[3] if len(rest) > 3 else False))
+        if return_values and self._limit is not None and self._limit >= 0:
+            raise RuntimeError("Cannot combine limit with return_inverse")
         data = np.ma.getdata(values) if np.ma.isMaskedArray(values) else np.asarray(values)
         if np.ma.isMaskedArray(values) and masks is None:
             masks = np.ma.getmaskarray(values)
         bits, nan = self._bits(data)
-        mask = None
+        null = None
         if masks is not None:
-            mask = np.ascontiguousarray(masks).view(np.uint8) if np.asarray(masks).dtype == np.bool_ else np.ascontiguousarray(masks, dtype=np.uint8)
-            k = int(mask.sum())
-            self.null_count += k
-            self._null_seen = self._null_seen or k > 0
-        if nan is not None:  # NaN keys: counted here, never inserted (their own ordinal: src/hash_primitives.hpp:144-160)
-            live = ~nan if mask is None else (~nan & (mask == 0))
-            self.nan_count += int((nan if mask is None else (nan & (mask == 0))).sum())
-            bits = np.ascontiguousarray(bits[live])
-            mask = None
-        if len(bits):
-            if mask is not None:
-                self._map.update(bits, mask)
-            else:
-                self._map.update(bits)
-        if self._limit is not None and self._limit >= 0 and len(self) > self._limit:
-            pass  # the caller (vaex/cpu.py:370-376) checks len() against its limit itself
+            null = np.ascontiguousarray(masks).astype(bool, copy=False)
+            if not null.any():
+                null = None
+        if nan is not None and null is not None:
+            nan = nan & ~null
+            if not nan.any():
+                nan = None
+        special = null if nan is None else (nan if null is None else (null | nan))
+        live_bits = bits if special is None else np.ascontiguousarray(bits[~special])
+        if len(live_bits):
+            self._map.update(live_bits)
+        # the null key and NaN take the next free ordinal at first sight, nulls before NaNs (:262-277), behind the call's keys
+        if null is not None:
+            if not self.null_count:
+                self._specials.append((self._n_keys(), "null"))
+            self.null_count += int(null.sum())
+        if nan is not None:
+            if not self.nan_count:
+                self._specials.append((self._n_keys(), "nan"))
+            self.nan_count += int(nan.sum())
+        if not return_values:
+            return None
+        out = np.empty(len(bits), dtype=np.int64)
+        if special is None:
+            out[...] = self._public(np.asarray(self._map.map_ordinal(live_bits))) if len(live_bits) else 0
+        else:
+            if len(live_bits):
+                out[~special] = self._public(np.asarray(self._map.map_ordinal(live_bits)))
+            if null is not None:
+                out[null] = self.null_index
+            if nan is not None:
+                out[nan] = self.nan_index
+        return out, np.zeros(len(bits), dtype=np.int16)
 
     def merge(self, others):
         if self.sealed:
             raise RuntimeError("hashmap is sealed, cannot merge")
         for other in others:
             other = getattr(other, "_internal", other)  # a HashMapUnique wrapper or the set itself
-            keys = other.key_array()
+            keys = np.asarray(other.key_array())
             live = np.ones(len(keys), dtype=bool)
             if other.has_null:
                 live[other.null_index] = False
-                self._null_seen = True
             if other.has_nan:
                 live[other.nan_index] = False
-            self.null_count += other.null_count
-            self.nan_count += other.nan_count
-            bits, _ = self._bits(np.asarray(keys)[live])
+            bits, _ = self._bits(keys[live])
             if len(bits):
                 self._map.update(bits)
+            if other.null_count:
+                if not self.null_count:
+                    self._specials.append((self._n_keys(), "null"))
+                self.null_count += other.null_count
+            if other.nan_count:
+                if not self.nan_count:
+                    self._specials.append((self._n_keys(), "nan"))
+                self.nan_count += other.nan_count
 
     def seal(self):
         self.sealed = True
@@ -172,10 +201,26 @@ class _OrderedSet:
     def _n_keys(self):
         return len(self._map)
 
+    def _public(self, ords):
+        """device ordinals (dense over the real keys) -> the set's ordinals (the null key and NaN sit among them)"""
+        ords = np.asarray(ords, dtype=np.int64)
+        if not self._specials:
+            return ords
+        out = ords.copy()
+        for t, _ in self._specials:
+            out += (ords >= t)
+        return np.where(ords >= 0, out, -1)
+
+    def _special_index(self, kind):
+        for i, (t, k) in enumerate(self._specials):
+            if k == kind:
+                return t + i
+        return -1
+
     def __len__(self):
         if self._fixed is not None:
             return len(self._fixed[0])
-        return self._n_keys() + (1 if self._null_seen else 0) + (1 if self.nan_count > 0 else 0)
+        return self._n_keys() + len(self._specials)
 
     @property
     def count(self):
@@ -183,7 +228,7 @@ class _OrderedSet:
 
     @property
     def has_null(self):
-        return self._null_seen
+        return self.null_index >= 0 if self._fixed is not None else self.null_count > 0
 
     @property
     def has_nan(self):
@@ -193,29 +238,26 @@ class _OrderedSet:
     def null_index(self):
         if self._fixed is not None:
             return self._fixed[1]
-        return self._n_keys() if self._null_seen else -1
+        return self._special_index("null")
 
     @property
     def nan_index(self):
         if self._fixed is not None:
             return self._fixed[2]
-        if self.nan_count <= 0:
-            return -1
-        return self._n_keys() + (1 if self._null_seen else 0)
+        return self._special_index("nan")
 
     def key_array(self):
         """keys ordered by ordinal; the null key's slot holds a placeholder, NaN's slot NaN (src/hash_primitives.hpp:303-328)"""
         if self._fixed is not None:
             return self._fixed[0].copy()
         keys = self._unbits(np.asarray(self._map.key_array()))
-        extra = []
-        if self._null_seen:
-            extra.append(self._np.type(0))
-        if self.nan_count > 0:
-            extra.append(self._np.type(np.nan))
-        if extra:
-            keys = np.concatenate([keys, np.array(extra, dtype=self._np)])
-        return keys
+        if not self._specials:
+            return keys
+        out = np.zeros(len(keys) + len(self._specials), dtype=self._np)
+        out[self._public(np.arange(len(keys)))] = keys
+        if self.nan_count > 0 and self._is_float:
+            out[self.nan_index] = np.nan
+        return out
 
     def keys(self):
         out = self.key_array().tolist()
@@ -231,12 +273,15 @@ class _OrderedSet:
         ords = np.asarray(self._map.map_ordinal(bits)) if len(bits) else np.zeros(0, dtype=np.int64)
         if self._perm is not None:
             ords = np.where(ords >= 0, self._perm[np.maximum(ords, 0)], -1)
+        elif self._fixed is None:
+            ords = self._public(ords)
         if nan is not None:
             ords = np.where(nan, self.nan_index if self.nan_count > 0 else -1, ords)
         return ords.astype(_narrowest(len(self)))
 
     def isin(self, values):
-        return np.asarray(self.map_ordinal(values)) >= 0
+        # src/hash_primitives.hpp:539-565: a NaN is in the set when the set saw one
+        return np.asarray(self.map_ordinal(values)).astype(np.int64) >= 0
 
     def flatten_values(self, values, map_index, out):
         out[...] = values  # one table: local ordinals are global ordinals (src/hash_primitives.hpp:540-565 adds shard offsets)
