@@ -176,8 +176,7 @@ def test_op_first_vs_reference_vaexfast(sa, gpu_ready, nd, use_edges):
         bs, wc = [b[i1:i2] for b in blocks], [ws[0][i1:i2], order[i1:i2]]
         vf.statisticNd_f8(bs, wc, want, minima, maxima, 6, use_edges)
         vaexfast.statisticNd_f8(bs, wc, got, minima, maxima, vaexfast.OP_FIRST, use_edges)
-    # the reference lets a NaN VALUE win (only the order is compared, :1160); so do the AggFirst passes not — state the rows
-    # where that matters and compare the rest
-    nan_first = np.isnan(want[..., 0])
-    np.testing.assert_array_equal(got[..., 1][~nan_first], want[..., 1][~nan_first])
-    np.testing.assert_array_equal(got[..., 0][~nan_first], want[..., 0][~nan_first])
+    # the reference lets a NaN VALUE win (only the order is compared, :1160): the value column goes through the AggFirst passes
+    # as its bit pattern, so the same rows win here
+    np.testing.assert_array_equal(got[..., 1], want[..., 1])
+    np.testing.assert_array_equal(got[..., 0], want[..., 0])

@@ -165,6 +165,7 @@ def install(vaex_module=None, legacy=True, hash_sets=True, chunk_size=None):
                 setattr(vaex.hash, attr, cls)
                 copyreg.pickle(cls, lambda x: x.__reduce__())
         _installed["hash"] = saved
+        _installed["hash_tuple"] = vaex.hash.ordered_set
         vaex.hash.ordered_set = tuple(vaex.hash.ordered_set) + tuple(hashset.CLASSES.values())
     return backend
 
@@ -187,6 +188,8 @@ def uninstall():
         mod.statisticNd_f8 = fn
     for attr, cls in _installed.get("hash", {}).items():
         setattr(vaex.hash, attr, cls)
+    if "hash_tuple" in _installed:
+        vaex.hash.ordered_set = _installed["hash_tuple"]
     if "chunk_size" in _installed:
         vaex_module.settings.main.chunk.size = _installed["chunk_size"]
     _installed.clear()

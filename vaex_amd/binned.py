@@ -197,7 +197,10 @@ class Frame:
                 ops = {0: torch.lt, 1: torch.le, 2: torch.gt, 3: torch.ge, 4: torch.eq, 5: torch.ne}
                 bits = None
                 for t, (c, op, v) in enumerate(sel.terms):
-                    o = ops[op](cols[sel.columns[c]], v).to(torch.int32) << t
+                    col = cols[sel.columns[c]]
+                    if isinstance(v, float) and not col.dtype.is_floating_point:
+                        col = col.to(torch.float64)  # numpy compares an integer column with a float constant in float64 (torch would pick float32)
+                    o = ops[op](col, v).to(torch.int32) << t
                     bits = o if bits is None else bits | o
                 return ((sel.truth >> bits) & 1).to(torch.uint8)
             return sel.numpy_mask(cols)

@@ -8,7 +8,8 @@
 // itself crosses the C-ABI (include/vaex_hip.h "device-side selections") as comparison terms `column <op> constant` plus a
 // truth table over the terms' outcomes; this kernel turns it into the same byte mask in HBM — no numpy pass over the chunk,
 // no mask bytes over PCIe.  Comparisons follow numpy: every comparison with NaN is false except !=; an integer column is
-// compared exactly with an integer constant and as float64 with a float constant.
+// compared exactly with an integer constant and as float64 with a float constant; a float32 column is compared in float32
+// (the constant is rounded first: `f4 <= 0.3` holds for float32(0.3), as in numpy).
 #include "vxh_internal.hpp"
 #include "vxh_kernels.hpp"
 
@@ -42,7 +43,7 @@ __device__ __forceinline__ bool term_at(const SelArgs &A, int t, uint64_t i) {
     const int op = T.op;
     switch (A.dtype[T.column]) {
     case VXH_F64: return cmp_f64(((const double *)p)[i], op, T.value);
-    case VXH_F32: return cmp_f64((double)((const float *)p)[i], op, T.value);
+    case VXH_F32: return cmp_f64((double)((const float *)p)[i], op, (double)(float)T.value); // numpy compares a float32 column with the constant ROUNDED to float32
     case VXH_I64: {
         const int64_t x = ((const int64_t *)p)[i];
         return T.is_int ? cmp_int<int64_t>(x, op, T.ivalue) : cmp_f64((double)x, op, T.value);

@@ -21,8 +21,9 @@ vaexfast.cpp:1189-1209), followed by a cell-wise fold into the caller's grid:
                                 row-wise product column (vxh_product_f64) per pair.  One deviation, stated: a pair inf x 0
                                 (product NaN, neither input NaN) is skipped where the reference adds NaN to the cell.
     OP_FIRST (6)                grid[...,0] = weights[0] of the row with the smallest weights[1] seen so far, grid[...,1] that
-                                order value (:1155-1166; vaex/dataframe.py:975): the AggFirst passes (vxh_first_*), folded into
-                                the caller's grid with the same `order < grid[...,1]` rule.
+                                order value (:1155-1166; vaex/dataframe.py:975): the AggFirst passes (vxh_first_*) over the value
+                                column's BIT PATTERN (op_first compares the order only: a NaN value can win, which AggFirst
+                                would skip), folded into the caller's grid with the same `order < grid[...,1]` rule.
 float64 blocks only: the _f4 variant scales in float32 and is not offered rather than approximated."""
 import threading
 
@@ -116,12 +117,20 @@ def _statistic_nd(blocks, weights, grid, minima, maxima, op_code, use_edges):
         w, order = wlist[0], wlist[1]
         if _postfix(w) != _postfix(order):
             raise NotImplementedError("statisticNd: OP_FIRST with weights of different byte order")
-        a = getattr(_sa, "AggFirst_float64_" + _postfix(order))(g, 1, 1, False)
-        a.set_data(0, w, 0)
+        # op_first looks at the ORDER only (:1160: a row whose value is NaN can win), AggFirst also skips NaN values
+        # (src/agg_first.cpp:139): the value column goes in as its int64 bit pattern, which has no NaN
+        if _is_device(w):
+            import torch
+            wbits = torch.as_tensor(w).view(torch.int64)
+        else:
+            wbits = w.view(w.dtype.byteorder.replace("=", "<").replace("|", "<") + "i8") if not w.dtype.isnative else w.view("i8")
+        a = getattr(_sa, "AggFirst_int64_" + _postfix(order))(g, 1, 1, False)
+        a.set_data(0, wbits, 0)
         a.set_data(0, order, 1)
         if n:
             g.bin(0, [a], n)
         values, masked, orders = (np.asarray(r)[inner] for r in a.raw_result())
+        values = np.ascontiguousarray(values).view("f8")
         take = ~masked & (orders < grid[..., 1])  # src/vaexfast.cpp:1160-1163
         grid[..., 0][take] = values[take]
         grid[..., 1][take] = orders[take]
