@@ -263,6 +263,33 @@ def test_merge_per_key(hs, refu, name, specials):
             assert (ours.map_ordinal(ar[live]) >= 0).all()
 
 
+def test_concurrent_updates_of_one_set(hs):
+    """vaex's pool threads call update() on ONE set at the same time (TaskPartHashmapUniqueCreate.process, vaex/cpu.py:340-361):
+    the null key and NaN must get ONE ordinal each and every count must add up"""
+    import threading
+    s = hs.ordered_set_float64(1)
+    rng = np.random.default_rng(8)
+    parts = []
+    for i in range(16):
+        ar = rng.integers(0, 50, 5000).astype("f8")
+        ar[::97] = np.nan
+        parts.append((ar, rng.random(5000) < 0.02))
+    start = threading.Barrier(8)
+
+    def work(j):
+        start.wait()
+        for ar, mask in parts[j::8]:
+            s.update(ar, mask, -1, chunk_size=1 << 20, bucket_size=1 << 22)
+    threads = [threading.Thread(target=work, args=(j,)) for j in range(8)]
+    [t.start() for t in threads]
+    [t.join() for t in threads]
+    assert len(s) == 52 and s.has_null and s.has_nan and s.null_index != s.nan_index
+    assert s.null_count == sum(int(m.sum()) for _, m in parts)
+    assert s.nan_count == sum(int((np.isnan(a) & ~m).sum()) for a, m in parts)
+    keys = s.key_array()
+    assert np.isnan(keys[s.nan_index]) and sorted(np.delete(keys, [s.null_index, s.nan_index]).tolist()) == list(range(50))
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # the reference's own tests (tests/internal/hash_test.py)
 # ---------------------------------------------------------------------------------------------------------------------

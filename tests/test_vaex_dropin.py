@@ -88,7 +88,8 @@ hot["first_sel"] = lambda d: np.stack([np.ma.filled(d.first("v", "y", binby="x",
                                         np.ma.filled(d.last("v", "y", binby="x", limits=[-4, 4], shape=8, selection="y < 0"), -1e300)])
 hot["groupby_nunique_drop"] = lambda d: by_key(d.groupby("k", agg={"um": vaex.agg.nunique("im", dropmissing=True), "ua": vaex.agg.nunique("kf", dropna=True),
                                                                     "u0": vaex.agg.nunique("im")}), "k", ["um", "ua", "u0"])
-hot["groupby_list_sel"] = lambda d: (lambda g: [sorted(c) for c in g["l"].tolist()])(d.groupby("k", agg={"l": vaex.agg.list("i", selection="v > 5")}).sort("k"))
+# (dropmissing: the slots the reference appends per unselected row are uninitialised memory, src/agg_list.cpp:68-71)
+hot["groupby_list_sel"] = lambda d: (lambda g: [sorted(c) for c in g["l"].tolist()])(d.groupby("k", agg={"l": vaex.agg.list("i", selection="v > 5", dropmissing=True)}).sort("k"))
 fallback = {   # not offered by the HIP classes: must run on vaex's own C++ after install(), GPU or not
   "count_string": lambda d: d.count("s", binby="y", limits=[-4, 4], shape=4),   # AggCount_string
 }

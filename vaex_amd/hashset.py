@@ -21,6 +21,8 @@ reference's add_null / add_nan (:455-470) — so the ordinals update(return_valu
 grows.  Parity with the reference is per key, never per ordinal (except for sets made by `create`, whose ordinals are the
 positions in the key array on both sides).
 """
+import threading
+
 import numpy as np
 
 from . import superagg as _sa
@@ -56,6 +58,7 @@ class _OrderedSet:
         self._np = np.dtype(self.dtype_name)
         self._is_float = self.dtype_name in _FLOAT
         self._limit = -1
+        self._lock = threading.Lock()   # vaex's pool threads update ONE set concurrently (vaex/cpu.py:340-361; the reference: a mutex per map)
         if args and not isinstance(args[0], (int, np.integer)):
             self._create(*args, **kwargs)
         else:
@@ -146,17 +149,18 @@ class _OrderedSet:
                 nan = None
         special = null if nan is None else (nan if null is None else (null | nan))
         live_bits = bits if special is None else np.ascontiguousarray(bits[~special])
-        if len(live_bits):
-            self._map.update(live_bits)
-        # the null key and NaN take the next free ordinal at first sight, nulls before NaNs (:262-277), behind the call's keys
-        if null is not None:
-            if not self.null_count:
-                self._specials.append((self._n_keys(), "null"))
-            self.null_count += int(null.sum())
-        if nan is not None:
-            if not self.nan_count:
-                self._specials.append((self._n_keys(), "nan"))
-            self.nan_count += int(nan.sum())
+        with self._lock:
+            if len(live_bits):
+                self._map.update(live_bits)
+            # the null key and NaN take the next free ordinal at first sight, nulls before NaNs (:262-277), behind the call's keys
+            if null is not None:
+                if not self.null_count:
+                    self._specials.append((self._n_keys(), "null"))
+                self.null_count += int(null.sum())
+            if nan is not None:
+                if not self.nan_count:
+                    self._specials.append((self._n_keys(), "nan"))
+                self.nan_count += int(nan.sum())
         if not return_values:
             return None
         out = np.empty(len(bits), dtype=np.int64)
@@ -176,6 +180,8 @@ class _OrderedSet:
             raise RuntimeError("hashmap is sealed, cannot merge")
         for other in others:
             other = getattr(other, "_internal", other)  # a HashMapUnique wrapper or the set itself
+            if other is self:
+                continue
             keys = np.asarray(other.key_array())
             live = np.ones(len(keys), dtype=bool)
             if other.has_null:

@@ -130,7 +130,7 @@ def _statistic_nd(blocks, weights, grid, minima, maxima, op_code, use_edges):
         if n:
             g.bin(0, [a], n)
         values, masked, orders = (np.asarray(r)[inner] for r in a.raw_result())
-        values = np.ascontiguousarray(values).view("f8")
+        values = values.view("f8")  # (same item size: fine for the strided and the 0-d result alike)
         take = ~masked & (orders < grid[..., 1])  # src/vaexfast.cpp:1160-1163
         grid[..., 0][take] = values[take]
         grid[..., 1][take] = orders[take]
