@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--cpu-rows", type=float, default=1e8, help="rows of the bounded CPU-baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip value_uniform / value_cold")
+    ap.add_argument("--no-configs", action="store_true", help="skip the `configs` section (BASELINE configs[2] / configs[3] on the same clock)")
     return ap.parse_args()
 
 
@@ -130,6 +131,109 @@ def cpu_baseline(x, y, v, shape, rows):
         single = m / (time.perf_counter() - t1)
     return dict(value=rows / best, unit="rows/s", cores=nthreads, kind=kind, single_thread_value=single,
                 sample=f"{rows:.3g} of the GPU's own rows (x,y,v float64), same 2-D {shape}x{shape} count+sum+count pass, best of {reps} passes, 1Mi-row chunks over a {nthreads}-thread pool"), res, rows
+
+
+def other_configs(sa, torch, rows, sample_rows):
+    """BASELINE configs[2] (3-D 128^3 histogram with a boolean selection) and configs[3] (groupby on a 1e6-cardinality int64
+    key, sum / mean / std — dense keys and scattered keys) at `rows` rows through vaex_amd.binned.Frame, each with its wall
+    rate, the HIP-event time of its kernels on the library's stream, a roofline object (SURVEY §8d bytes per row) and a
+    same-run parity check of a `sample_rows` slice against the reference's own C++ (oracle/_ref)."""
+    from oracle import oracle
+    from vaex_amd.binned import Frame, agg
+    ref = oracle.ref_module("superagg")
+    out = []
+    g = torch.Generator(device="cuda").manual_seed(7)
+
+    def timed(fn, reps=3):
+        fn()
+        best, best_k = float("inf"), float("inf")
+        for _ in range(reps):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            sa.timer_start(0)
+            res = fn()
+            k_ms = sa.timer_stop(0)
+            dt = time.perf_counter() - t0
+            best, best_k = min(best, dt), min(best_k, k_ms)
+        return res, best, best_k
+
+    def line(config, what, bytes_per_row, wall, k_ms, kernel, parity):
+        gbs = bytes_per_row * rows / (k_ms * 1e-3) / 1e9
+        return {"config": config, "what": what, "rows": rows, "rows_per_s": rows / wall, "ms": wall * 1e3, "kernel_ms": k_ms, "kernel": kernel,
+                "roofline": {"bound": "hbm", "bytes_per_row": bytes_per_row, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS},
+                "parity_on_sample": parity}
+
+    m = int(min(sample_rows, rows))
+    # ---- configs[2]: 3-D 128^3 count with the selection v > 3 handed over as a byte mask (what vaex materialises) ----
+    x = torch.randn(rows, dtype=torch.float64, device="cuda", generator=g)
+    y = torch.randn(rows, dtype=torch.float64, device="cuda", generator=g)
+    z = torch.randn(rows, dtype=torch.float64, device="cuda", generator=g)
+    v = torch.randn(rows, dtype=torch.float64, device="cuda", generator=g) * 2 + 3
+    sel = (v > 3).to(torch.uint8)
+    torch.cuda.synchronize()
+    df = Frame(dict(x=x, y=y, z=z, sel=sel))
+    lim3 = [[-4, 4]] * 3
+    c3, wall, k_ms = timed(lambda: df.count(binby=["x", "y", "z"], limits=lim3, shape=128, selection="sel", edges=True))
+    kernel = sa.last_kernel(0)
+    parity = None
+    if ref is not None:
+        head = Frame(dict(x=x[:m], y=y[:m], z=z[:m], sel=sel[:m])).count(binby=["x", "y", "z"], limits=lim3, shape=128, selection="sel", edges=True)
+        cols = [t[:m].cpu().numpy() for t in (x, y, z)]
+        keep = sel[:m].cpu().numpy()
+        bs = [ref.BinnerScalar_float64(1, nm, -4.0, 4.0, 128) for nm in "xyz"]
+        grid = ref.Grid(bs)
+        c = ref.AggCount_int64(grid, 1, 1)
+        for b, col in zip(bs, cols):
+            b.set_data(0, col); b.clear_data_mask(0)
+        c.set_data_mask(0, keep)
+        grid.bin(0, [c], m)
+        want = np.asarray(c.get_result())
+        parity = {"ok": bool(np.array_equal(np.asarray(head), want)), "sample_rows": m, "cells_differ": int((np.asarray(head) != want).sum()),
+                  "rows_counted": [int(np.asarray(c3).sum()), int(sel.sum().item())]}
+        parity["ok"] = parity["ok"] and parity["rows_counted"][0] == parity["rows_counted"][1]
+    out.append(line("configs[2]", "3-D 128^3 count(*) of float64 x,y,z with a boolean selection mask", 25, wall, k_ms, kernel, parity))
+    del df, x, y, z, sel, c3
+    # ---- configs[3]: groupby on 1e6 int64 keys, agg sum / mean / std of v ----
+    k = torch.randint(0, 1_000_000, (rows,), dtype=torch.int64, device="cuda", generator=g)
+    spec = {"c": agg.count("v"), "s": agg.sum("v"), "m": agg.mean("v"), "sd": agg.std("v")}
+    for flavour in ("dense", "scattered"):
+        keys = k if flavour == "dense" else (k * 2654435761) % (1 << 40)
+        torch.cuda.synchronize()
+        df = Frame(dict(k=keys, v=v))
+        res, wall, k_ms = timed(lambda: df.groupby("k", spec))
+        kernel = sa.last_kernel(0) if flavour == "dense" else "gb_scatter+gb_reduce"
+        info = getattr(df, "last_groupby_info", None) or {}
+        parity = None
+        if ref is not None:
+            head = Frame(dict(k=keys[:m], v=v[:m])).groupby("k", spec)
+            ks, vs = keys[:m].cpu().numpy(), v[:m].cpu().numpy()
+            uniq, codes = np.unique(ks, return_inverse=True)
+            # the reference's pass 2: BinnerOrdinal over the keys' ordinals + AggSum / AggCount / AggSumMoment (vaex/cpu.py:678-786)
+            b = ref.BinnerOrdinal_int64(1, "k", len(uniq), 0, False, False)
+            grid = ref.Grid([b])
+            aggs = [ref.AggSum_float64(grid, 1, 1), ref.AggCount_float64(grid, 1, 1), ref.AggSumMoment_float64(grid, 1, 1, 2)]
+            codes = np.ascontiguousarray(codes.astype(np.int64))
+            b.set_data(0, codes); b.clear_data_mask(0)
+            for a in aggs:
+                a.set_data(0, vs, 0); a.clear_data_mask(0)
+            grid.bin(0, aggs, m)
+            s1, cnt, s2 = (np.asarray(a.get_result())[:len(uniq)] for a in aggs)
+            sabs = np.bincount(codes[vs == vs], weights=np.abs(vs[vs == vs]), minlength=len(uniq))
+            with np.errstate(divide="ignore", invalid="ignore"):
+                var = s2 / cnt - (s1 / cnt) ** 2
+            okv = cnt > 0
+            detail = {"keys_equal": bool(np.array_equal(head["k"], uniq)), "count_groups_differ": int((head["c"] != cnt).sum()) if len(head["c"]) == len(cnt) else -1,
+                      "sum_groups_over_tol": int((np.abs(head["s"] - s1) > 1e-12 * sabs).sum()) if len(head["s"]) == len(s1) else -1,
+                      "var_groups_over_tol": int((np.abs(head["sd"][okv] ** 2 - var[okv]) > 4e-12 * (s2[okv] / cnt[okv]) + 1e-300).sum()) if len(head["sd"]) == len(cnt) else -1,
+                      "groups": [int(len(res["k"])), 1_000_000], "rows_counted": [int(res["c"].sum()), rows], "sample_rows": m}
+            detail["ok"] = detail["keys_equal"] and not (detail["count_groups_differ"] or detail["sum_groups_over_tol"] or detail["var_groups_over_tol"]) and detail["rows_counted"][0] == rows
+            parity = detail
+        ln = line("configs[3]" if flavour == "dense" else "configs[3]'", f"groupby on 1e6 {flavour} int64 keys: count / sum / mean / std of float64 v", 16, wall, k_ms, kernel, parity)
+        if info:
+            ln["groupby_kernels_ms"] = {kk: info[kk] for kk in ("ms_scatter", "ms_reduce", "ms_sort") if kk in info}
+        out.append(ln)
+        del df, res
+    return out
 
 
 def _spawned(local_rank, args, port):
@@ -247,7 +351,7 @@ def run(args):
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic (device-generated N(0,1) x,y; N(3,2) v; limits [-4,4])",
             "config": {"workload": f"{rows:.3g}-row float64 x,y,v per GPU: count+sum+mean on {shape}x{shape} grid, HBM-resident (BASELINE configs[1])",
-                       "rows_per_gpu": rows, "shape": shape, "kernel": sa.last_kernel(0), "parallelism": f"row-sharded x{world}, RCCL all-reduce of 3 grids"},
+                       "rows_per_gpu": rows, "shape": shape, "kernel": sa.last_kernel(0), "parallelism": f"row-sharded x{world}, RCCL all-reduce of 3 grids" if world > 1 else "one GPU: nothing to reduce"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "frac_of_measured_copy_rate": achieved / 6290.0,  # (6.29 TB/s float4 copy: MI355X_MICROARCH.md)
                          "traffic": traffic, "traffic_source": traffic_source, "kernel_ms": k_ms, "bytes_per_row": BYTES_PER_ROW, "rows_per_launch": rows},
@@ -300,6 +404,10 @@ def run(args):
                       "sum_cells_over_tol": int(bad_sum.sum()), "rows_counted": [int(g[0].sum()), int(cpu_res[0].sum())]}
             out["cpu_baseline"]["parity_on_sample"] = not any(detail[k] for k in ("count_cells_differ", "countv_cells_differ", "sum_cells_over_tol"))
             out["cpu_baseline"]["parity_detail"] = detail
+        if world == 1 and not args.no_configs:
+            del x, y, v
+            torch.cuda.empty_cache()
+            out["configs"] = other_configs(sa, torch, rows, 1e7)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
