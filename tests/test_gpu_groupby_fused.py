@@ -47,7 +47,7 @@ def test_groupby_run_host_rows(sa, gpu_ready, n, groups):
     res = sa.groupby_run(k, [v], _DT["int64"])
     _check(sa, res, _want(k, [v]))
     info = res.info()
-    assert info["buckets"] >= 64 and info["slots"] in (2048, 4096)
+    assert info["buckets"] >= 64 and info["slots"] >= 2048 and info["slots"] % 4 == 0  # (4-key lines, as many as the LDS holds)
 
 
 def test_groupby_run_two_keys_only(sa, gpu_ready):
@@ -72,7 +72,7 @@ def test_groupby_run_device_rows_two_values(sa, gpu_ready):
     w[::1000] = float("nan")
     res = sa.groupby_run(k, [v, w], _DT["int64"])  # (no synchronize: the library orders itself after the default stream)
     _check(sa, res, _want(k.cpu().numpy(), [v.cpu().numpy(), w.cpu().numpy()]))
-    assert res.info()["slots"] == 2048
+    assert 2048 <= res.info()["slots"] < 4096  # (two value columns: 40-byte slots)
 
 
 @pytest.mark.parametrize("dtype", ["int64", "int32", "int16", "int8", "uint64", "uint32", "uint16", "uint8", "bool"])
@@ -146,3 +146,28 @@ def test_frame_groupby_takes_the_fused_path_and_falls_back(sa, gpu_ready):
     # min / max are outside the fused signature
     got3 = df.groupby("k", {"lo": agg.min("v"), "s": agg.sum("v")})
     np.testing.assert_array_equal(got3["k"], w["k"])
+
+
+@pytest.mark.parametrize("groups", [3_400_000, 4_700_000])
+def test_frame_groupby_millions_of_scattered_keys(sa, gpu_ready, groups):
+    """more distinct keys than the default plan's 512 LDS tables hold: 3.4e6 -> the pass retries with 1024 buckets (whose
+    bookkeeping leaves room for 4096-row tiles only); 4.7e6 -> beyond 1024 tables of ~4000 keys: the pass reports it and
+    Frame.groupby answers through ordered_set + BinnerHash.  Either way the groups equal numpy's."""
+    import torch
+    from vaex_amd.binned import Frame, agg
+    g = torch.Generator(device="cuda").manual_seed(groups)
+    n = 3 * groups
+    k = (torch.randint(0, groups, (n,), dtype=torch.int64, device="cuda", generator=g) * 2654435761) % (1 << 42)
+    v = torch.randn(n, dtype=torch.float64, device="cuda", generator=g)
+    df = Frame(dict(k=k, v=v))
+    df.last_groupby_info = None
+    got = df.groupby("k", {"c": agg.count("v"), "s": agg.sum("v")})
+    w = _want(k.cpu().numpy(), [v.cpu().numpy()])
+    assert len(w["k"]) > 0.9 * groups
+    np.testing.assert_array_equal(got["k"], w["k"])
+    np.testing.assert_array_equal(got["c"], w["v"][0]["cnt"])
+    assert np.all(np.abs(got["s"] - w["v"][0]["s"]) <= 1e-12 * w["v"][0]["sabs"])
+    if groups < 4_000_000:
+        assert df.last_groupby_info is not None and df.last_groupby_info["buckets"] == 1024 and df.last_groupby_info["retries"] >= 1
+    else:
+        assert df.last_groupby_info is None  # (the partitioned pass declined)

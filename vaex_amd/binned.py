@@ -939,9 +939,9 @@ class Frame:
             if comm is not None:
                 res = self._groupby_fused_allranks(res, len(values), comm)
         except RuntimeError as e:
-            if "partitioned path" not in str(e):
+            if not str(e).startswith("groupby"):   # (anything the pass itself reports: too many / too skewed keys, no room for its queues)
                 raise
-            return None  # too many / too skewed keys for the LDS-partitioned pass
+            return None  # -> ordered_set + BinnerHash
         which = {"sum": sa.GB_SUM, "mean": sa.GB_MEAN, "var": sa.GB_VAR, "std": sa.GB_STD}
         out = {by: np.asarray(res.column(sa.GB_KEYS))}
         for name, d in zip(names, descs):

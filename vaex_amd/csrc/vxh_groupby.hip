@@ -15,10 +15,14 @@
 //                lines).  Blocks of `blk` records are reserved from the bucket's counter by the thread that owns the
 //                bucket (thread b <-> bucket b), normally ONE per launch; their fill goes to a table.  Records are
 //                SoA: key + W payload words (W = 1 per value column for rows; 4 for partial results being merged).
-//   gb_reduce    one workgroup per bucket: insert-or-get in an open-addressing table IN LDS (64-bit ds_cmpst on the key
-//                word, linear probing from lower hash bits), accumulators (rows, count, sum, sum of squares) next to
-//                the key in LDS (ds_add_u32 / ds_add_f64), every wave streaming whole queue blocks.  At the end the
-//                occupied slots are compacted (workgroup scan) into the result arrays behind ONE atomic per bucket.
+//   gb_reduce    one workgroup per bucket: insert-or-get in an open-addressing table IN LDS — round 3: BUCKETISED, four keys
+//                per 32-byte line read with two ds_read_b128 and compared at once, a key lives in its home line or (when
+//                that is full) in the next ones; 64-bit ds_cmpst claims an empty word.  A probe is one trip for ~99 % of the
+//                records (round 2's one-key-per-trip linear probing kept every wave in a divergent, scalar-issue-bound
+//                loop: 1.22e9 SALU vs 0.69e9 VALU wave-instructions per 1e9 records, profiles/r02_pmc_groupby_fused.txt).
+//                Accumulators (rows, count, sum, sum of squares) sit in LDS arrays indexed by the slot (ds_add_u64 /
+//                ds_add_f64), every wave streams whole queue blocks.  At the end the occupied slots are compacted
+//                (workgroup scan) into the result arrays behind ONE atomic per bucket.
 //   sort         rocPRIM radix sort of (key, position) + a gather: groups ascending by key, as vaex returns them.
 //
 // HBM traffic per row with one value column: 16 B read + 16 B written + 16 B read = 48 B (the two-pass scheme with a
@@ -83,6 +87,8 @@ struct GbArgs {
     uint32_t *pool_owner; // [pool] bucket of a spare block
     long long *qkey;        // [blocks][blk]
     uint64_t *qw[GB_MAX_W]; // [blocks][blk] each
+    uint4 *qrec;            // W == 1: the queues hold 16-byte records {key, payload} instead (one store / one load per record)
+    uint32_t lines;         // gb_reduce: 4-key lines of the LDS table (slots = 4 * lines; any count, not a power of two)
     // results (unsorted)
     unsigned long long *out_count; // groups written so far
     unsigned int *overflow;        // 1: out of spare blocks, 2: a bucket's LDS table too full, 3: result arrays too small
@@ -212,9 +218,14 @@ __global__ void __launch_bounds__(1024) gb_scatter(const GbArgs G) {
             const uint32_t base = k < sp ? base0[b] : base1[b];
             if (base == 0xffffffffu) continue; // (queue full: flagged, the host retries with more room)
             const uint64_t dst = (uint64_t)base + (k < sp ? k : k - sp);
-            G.qkey[dst] = (long long)st_key[j];
+            if (W == 1) { // one 16-byte record {key, payload}: a tile's segment of a bucket is 16 B x its records, contiguous
+                const uint64_t a = st_key[j], c2 = st_w[j];
+                G.qrec[dst] = make_uint4((uint32_t)a, (uint32_t)(a >> 32), (uint32_t)c2, (uint32_t)(c2 >> 32));
+            } else {
+                G.qkey[dst] = (long long)st_key[j];
 #pragma unroll
-            for (int w = 0; w < W; ++w) G.qw[w][dst] = st_w[(size_t)w * T + j];
+                for (int w = 0; w < W; ++w) G.qw[w][dst] = st_w[(size_t)w * T + j];
+            }
         }
         // (the next tile's [C] comes after two more barriers: nobody overwrites what [D] still reads)
         if (has_next) {
@@ -233,14 +244,14 @@ __global__ void __launch_bounds__(1024) gb_scatter(const GbArgs G) {
 // ------------------------------------------------------------------------------------------------------------------
 // gb_reduce
 // ------------------------------------------------------------------------------------------------------------------
-// LDS table of one bucket: SLOTS + 1 entries (the last one belongs to the key INT64_MIN, which doubles as EMPTY)
+// LDS table of one bucket: `lines` lines of four keys (SLOTS = 4 * lines) + one entry for the key INT64_MIN, which doubles as EMPTY
 template <int NV, bool MERGE>
 __global__ void __launch_bounds__(1024) gb_reduce(const GbArgs G) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     // row counters: 32 bits while counting rows (a workgroup sees < 2^32 of them), 64 bits when merging partial counts
     using CT = typename std::conditional<MERGE, unsigned long long, uint32_t>::type;
-    const uint32_t SLOTS = 1u << G.slots_log2, E = SLOTS + 1, EP = (E + 1) & ~1u; // (EP: even, keeps the 8-byte arrays aligned behind 4-byte ones)
-    unsigned long long *const t_key = (unsigned long long *)lds;    // [E]
+    const uint32_t LINES = G.lines, SLOTS = 4u * LINES, E = SLOTS + 1, EP = (E + 3) & ~3u; // (EP: keeps the arrays 16-byte aligned)
+    unsigned long long *const t_key = (unsigned long long *)lds;    // [EP]: line l = t_key[4 l .. 4 l + 3]
     double *const t_sum = (double *)(t_key + EP);                   // [NV][EP]
     double *const t_sum2 = t_sum + (size_t)NV * EP;                 // [NV][EP]
     // counting rows: {rows, count of value column 0} are the two halves of one 64-bit word per slot (t_rc), further
@@ -251,7 +262,7 @@ __global__ void __launch_bounds__(1024) gb_reduce(const GbArgs G) {
     uint32_t *const s_misc = (uint32_t *)((char *)t_rc + (MERGE ? (size_t)8 * EP * (1 + NV) : (size_t)8 * EP + (size_t)4 * EP * (NV - 1))); // [0] claimed slots, [1] output base, [2..17] wave totals
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, nwave = blockDim.x >> 6;
     const uint32_t bucket = blockIdx.x;
-    for (uint32_t s = tid; s < E; s += blockDim.x) {
+    for (uint32_t s = tid; s < EP; s += blockDim.x) {
         t_key[s] = (unsigned long long)GB_EMPTY;
         if (MERGE) t_rows[s] = (CT)0; else t_rc[s] = 0ull;
 #pragma unroll
@@ -264,9 +275,9 @@ __global__ void __launch_bounds__(1024) gb_reduce(const GbArgs G) {
     if (tid < 18) s_misc[tid] = 0u;
     __syncthreads();
 
-    const uint32_t limit = SLOTS - SLOTS / 8; // more distinct keys than this in one bucket: too slow / cannot terminate — flag and let the host retry
+    const uint32_t limit = SLOTS - SLOTS / 5; // more distinct keys than this in one bucket: the overflow chains get long — flag and let the host retry with more buckets
     constexpr int PW = MERGE ? 1 + 3 * NV : NV;
-    constexpr int U = 4; // records per lane per trip: their loads and their probe sequences run interleaved
+    constexpr int U = 4; // records per lane per trip: their loads run interleaved
     bool failed = false;
     auto accumulate = [&](uint32_t s, const uint64_t (&p)[PW]) {
         if (MERGE) {
@@ -292,26 +303,30 @@ __global__ void __launch_bounds__(1024) gb_reduce(const GbArgs G) {
             }
         }
     };
-    // slot of a key inside the bucket's table: the top bits of a Fibonacci multiply — independent of the bucket (top
-    // bits of splitmix64) and a single 64-bit multiply (the pass is instruction-issue bound: ~150 instructions per 64
-    // records, a third of them the hash when splitmix64 is recomputed here)
-    auto home = [&](long long key) -> uint32_t { return (uint32_t)(((uint64_t)key * 0x9e3779b97f4a7c15ULL) >> (64 - G.slots_log2)); };
-    auto slot_of = [&](long long key) -> uint32_t { // insert-or-get; 0xffffffff when the table is full
+    // home line of a key inside the bucket's table: the high word of a Fibonacci multiply, range-reduced by a multiply-high —
+    // independent of the bucket (top bits of splitmix64)
+    auto home = [&](long long key) -> uint32_t { return __umulhi((uint32_t)(((uint64_t)key * 0x9e3779b97f4a7c15ULL) >> 32), LINES); };
+    // insert-or-get: the four keys of a line are read and compared at once; 0xffffffff when the table is too full
+    auto slot_of = [&](long long key) -> uint32_t {
         if (key == GB_EMPTY) return SLOTS;
-        uint32_t s = home(key);
-        for (uint32_t probes = 0; probes < SLOTS; ++probes) {
-            const unsigned long long cur = t_key[s];
-            if (cur == (unsigned long long)key) return s;
-            if (cur == (unsigned long long)GB_EMPTY) {
-                if (s_misc[0] >= limit) return 0xffffffffu;
-                const unsigned long long old = atomicCAS(&t_key[s], (unsigned long long)GB_EMPTY, (unsigned long long)key);
-                if (old == (unsigned long long)GB_EMPTY) {
-                    __hip_atomic_fetch_add(&s_misc[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    return s;
-                }
-                if (old == (unsigned long long)key) return s;
+        uint32_t l = home(key);
+        const unsigned long long k = (unsigned long long)key, empty = (unsigned long long)GB_EMPTY;
+        for (uint32_t trips = 0; trips < 2u * LINES; ++trips) {
+            const ulonglong2 a = *(const ulonglong2 *)(t_key + 4u * l), b = *(const ulonglong2 *)(t_key + 4u * l + 2);
+            if (a.x == k) return 4u * l;
+            if (a.y == k) return 4u * l + 1;
+            if (b.x == k) return 4u * l + 2;
+            if (b.y == k) return 4u * l + 3;
+            const int e = a.x == empty ? 0 : (a.y == empty ? 1 : (b.x == empty ? 2 : (b.y == empty ? 3 : -1)));
+            if (e < 0) { l = l + 1 == LINES ? 0u : l + 1; continue; } // a full line without the key: it can only be further on
+            if (s_misc[0] >= limit) return 0xffffffffu;
+            const unsigned long long old = atomicCAS(&t_key[4u * l + e], empty, k);
+            if (old == empty) {
+                __hip_atomic_fetch_add(&s_misc[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                return 4u * l + e;
             }
-            s = (s + 1) & (SLOTS - 1);
+            if (old == k) return 4u * l + e;
+            // somebody else's key took the word: look at the same line again
         }
         return 0xffffffffu;
     };
@@ -326,9 +341,16 @@ __global__ void __launch_bounds__(1024) gb_reduce(const GbArgs G) {
             for (int u = 0; u < U; ++u) {
                 const uint32_t j = j0 + 64u * u + lane;
                 todo[u] = j < fill;
-                kk[u] = G.qkey[lo + (todo[u] ? j : 0u)];
+                const uint64_t at = lo + (todo[u] ? j : 0u);
+                if (PW == 1) {
+                    const uint4 r = G.qrec[at];
+                    kk[u] = (long long)((uint64_t)r.x | ((uint64_t)r.y << 32));
+                    pp[u][0] = (uint64_t)r.z | ((uint64_t)r.w << 32);
+                } else {
+                    kk[u] = G.qkey[at];
 #pragma unroll
-                for (int w = 0; w < PW; ++w) pp[u][w] = G.qw[w][lo + (todo[u] ? j : 0u)];
+                    for (int w = 0; w < PW; ++w) pp[u][w] = G.qw[w][at];
+                }
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -468,21 +490,31 @@ GbScratch &gb_scratch() {
     return *s;
 }
 
+constexpr size_t GB_LDS_MAX = 160 * 1024;
+
+template <int W, int R>
+size_t scatter_lds(int nb_log2) {
+    const size_t T = 1024u * R;
+    return T * 8 * (1 + W) + ((size_t)1 << nb_log2) * 4 * 5 + 64 + T * 2 + 16;
+}
 template <int W, int R>
 void launch_scatter(const GbArgs &G, int blocks, hipStream_t st) {
-    const uint32_t NB = 1u << G.nb_log2;
-    const size_t T = 1024u * R;
-    const size_t lds = T * 8 * (1 + W) + (size_t)NB * 4 * 5 + 64 + T * 2 + 16;
-    (void)hipFuncSetAttribute((const void *)gb_scatter<W, R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const size_t lds = scatter_lds<W, R>(G.nb_log2);
+    if (lds > GB_LDS_MAX) throw std::runtime_error("groupby: internal: gb_scatter staging exceeds the LDS");
+    HIP_CHECK(hipFuncSetAttribute((const void *)gb_scatter<W, R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL((gb_scatter<W, R>), dim3(blocks), dim3(1024), lds, st, G);
 }
 
+// bytes of LDS per table slot, and the number of 4-key lines that fit
+inline size_t reduce_slot_bytes(int nv, bool merge) { return 8 + 16 * (size_t)nv + (merge ? (size_t)8 * (1 + nv) : (size_t)8 + (size_t)4 * (nv - 1)); }
+inline uint32_t reduce_lines(int nv, bool merge) { return (uint32_t)((GB_LDS_MAX - 18 * 4 - 64) / reduce_slot_bytes(nv, merge) / 4 - 1); }
+
 template <int NV, bool MERGE>
 void launch_reduce(const GbArgs &G, hipStream_t st) {
-    const size_t EP = ((((size_t)1 << G.slots_log2) + 1) + 1) & ~(size_t)1;
-    const size_t counters = MERGE ? (size_t)8 * (1 + NV) : (size_t)8 + (size_t)4 * (NV - 1);
-    const size_t lds = EP * (8 + 16 * (size_t)NV + counters) + 18 * 4 + 16;
-    (void)hipFuncSetAttribute((const void *)gb_reduce<NV, MERGE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const size_t EP = (4 * (size_t)G.lines + 1 + 3) & ~(size_t)3;
+    const size_t lds = EP * reduce_slot_bytes(NV, MERGE) + 18 * 4 + 16;
+    if (lds > GB_LDS_MAX) throw std::runtime_error("groupby: internal: gb_reduce table exceeds the LDS");
+    HIP_CHECK(hipFuncSetAttribute((const void *)gb_reduce<NV, MERGE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL((gb_reduce<NV, MERGE>), dim3(1u << G.nb_log2), dim3(1024), lds, st, G);
 }
 
@@ -497,14 +529,20 @@ unsigned run_pipeline(GbArgs &G, int nv, bool merge, uint64_t n, uint64_t groups
     const int R = w == 1 ? 8 : (w == 2 ? 4 : (w <= 4 ? 2 : 1));
     const uint64_t T = 1024ull * R;
     const int per_cu = 1;
-    // LDS table of a bucket: 4096 slots x (key 8 + sum 8 + sum2 8 + rows 4 + count 4) = 128 KiB with one value column;
-    // 2048 slots with two, and when merging (64-bit counters)
-    const int slots_log2 = (nv == 1 && !merge) ? 12 : 11;
+    // LDS table of a bucket: as many 4-key lines as the 160 KiB hold — 5112 slots x (key 8 + sum 8 + sum2 8 + rows 4 + count 4)
+    // with one value column, 2916 with two, 4092 / 2556 when merging (64-bit counters)
+    const uint32_t lines = reduce_lines(nv, merge);
+    // one payload word: 8 rows per thread per tile (128 KiB of staging) as long as the bucket tables fit beside it
+    const int nb_max = 10;
     int nb_log2 = 6;
-    const uint64_t per_bucket = ((uint64_t)1 << slots_log2) / 2; // target load 0.5
-    while (nb_log2 < 10 && ((uint64_t)1 << nb_log2) * per_bucket < std::max<uint64_t>(groups_hint, 1)) nb_log2++;
-    hipEvent_t e0, e1, e2;
-    HIP_CHECK(hipEventCreate(&e0)); HIP_CHECK(hipEventCreate(&e1)); HIP_CHECK(hipEventCreate(&e2));
+    const uint64_t per_bucket = (uint64_t)lines * 4 / 2; // target load 0.5
+    while (nb_log2 < nb_max && ((uint64_t)1 << nb_log2) * per_bucket < std::max<uint64_t>(groups_hint, 1)) nb_log2++;
+    struct Events { // (destroyed on every way out, a throwing launch included)
+        hipEvent_t e[3] = {nullptr, nullptr, nullptr};
+        Events() { for (auto &x : e) HIP_CHECK(hipEventCreate(&x)); }
+        ~Events() { for (auto &x : e) if (x) (void)hipEventDestroy(x); }
+    } ev;
+    hipEvent_t e0 = ev.e[0], e1 = ev.e[1], e2 = ev.e[2];
     unsigned code = 0;
     uint64_t slack = 1;
     for (int attempt = 0; attempt < 6; ++attempt) {
@@ -520,13 +558,14 @@ unsigned run_pipeline(GbArgs &G, int nv, bool merge, uint64_t n, uint64_t groups
         const uint64_t total_blocks = primaries + pool;
         if (total_blocks * B >= (1ull << 32) || total_blocks * B * 8 * (uint64_t)(1 + w) > (96ull << 30)) { code = 9; break; }
         G.nv = nv; G.w = w; G.merge = merge ? 1 : 0; G.n = n;
-        G.nb_log2 = nb_log2; G.slots_log2 = slots_log2;
+        G.nb_log2 = nb_log2; G.slots_log2 = 0; G.lines = lines;
         G.blk = (uint32_t)B; G.scatter_wgs = (uint32_t)blocks; G.pool = (uint32_t)pool;
         S.queues.need(total_blocks * B * 8 * (size_t)(1 + w));
         const size_t small_bytes = total_blocks * 4 + pool * 4 + 64;
         S.small.need(small_bytes);
         char *q = (char *)S.queues.p;
         G.qkey = (long long *)q;
+        G.qrec = (uint4 *)q; // (w == 1: 16-byte records in the same space)
         for (int k = 0; k < w; k++) G.qw[k] = (uint64_t *)(q + total_blocks * B * 8 * (size_t)(1 + k));
         G.tab = (uint32_t *)S.small.p;
         G.pool_owner = G.tab + total_blocks;
@@ -535,7 +574,8 @@ unsigned run_pipeline(GbArgs &G, int nv, bool merge, uint64_t n, uint64_t groups
         G.out_count = (unsigned long long *)(G.overflow + 2); // [2..3]
         HIP_CHECK(hipMemsetAsync(S.small.p, 0, small_bytes, st));
         HIP_CHECK(hipEventRecord(e0, st));
-        if (w == 1) launch_scatter<1, 8>(G, blocks, st);
+        if (w == 1 && scatter_lds<1, 8>(nb_log2) <= GB_LDS_MAX) launch_scatter<1, 8>(G, blocks, st);
+        else if (w == 1) launch_scatter<1, 4>(G, blocks, st); // (1024 buckets: their tables leave room for 4096-row tiles)
         else if (w == 2) launch_scatter<2, 4>(G, blocks, st);
         else if (w == 4) launch_scatter<4, 2>(G, blocks, st);
         else launch_scatter<7, 1>(G, blocks, st);
@@ -552,7 +592,7 @@ unsigned run_pipeline(GbArgs &G, int nv, bool merge, uint64_t n, uint64_t groups
         if (res) {
             (void)hipEventElapsedTime(&res->ms_scatter, e0, e1);
             (void)hipEventElapsedTime(&res->ms_reduce, e1, e2);
-            res->buckets = (int)NB; res->slots = 1 << slots_log2; res->retries = attempt;
+            res->buckets = (int)NB; res->slots = (int)(4 * lines); res->retries = attempt;
         }
         if (code == 0) {
             unsigned long long cnt = 0;
@@ -568,7 +608,6 @@ unsigned run_pipeline(GbArgs &G, int nv, bool merge, uint64_t n, uint64_t groups
         }
         if (code == 1) slack *= 8; // out of spare blocks (few or skewed keys): eight times the room per block, as long as the scratch stays below 96 GiB
     }
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e2);
     return code;
 }
 
