@@ -105,13 +105,20 @@ if not has_gpu:
         else:
             raise SystemExit("computed without a GPU: " + name)
 else:
+    from vaex_amd import vaex_groupby as vg
     for name, fn in hot.items():
         del used[:]
+        vg.last.clear()
         got[name] = fn(df)
         # every task of a hot call ran on the HIP classes (and there was at least one: an aggregation task part or the legacy statistic)
-        assert used and all(u[1] == "hip" for u in used), (name, used)
+        # — or the call was a groupby answered by the device groupby as a whole (vaex_amd/vaex_groupby.py: no vaex task at all)
+        whole = vg.last.get("path") == "device"
+        assert (used or whole) and all(u[1] == "hip" for u in used), (name, used, vg.last)
         assert all(m == "vaex_amd.superagg" for u in used for m in u[2]), (name, used)
-        print("ok-backend hip", name, len(used))
+        assert whole == (name in ("groupby_small", "groupby_sparse", "groupby_two_keys")), (name, vg.last)
+        if whole:
+            assert ("gb_scatter" in vg.last["kernel"]) == (name == "groupby_sparse") and ("part_scatter" in vg.last["kernel"] or "bin_" in vg.last["kernel"] or name == "groupby_sparse"), (name, vg.last)
+        print("ok-backend hip", name, len(used), vg.last.get("kernel", ""))
 for name, fn in fallback.items():
     del used[:]
     got[name] = fn(df)
@@ -147,7 +154,7 @@ if has_gpu and %(timing)d:
         c = big.count(binby=["x", "y"], limits=lim2, shape=256)
         return time.perf_counter() - t0, c
     cpu_t = min(run()[0] for _ in range(2))
-    vaex_amd.install()
+    vaex_amd.install(chunk_size=None)   # vaex's own chunk bracket (1 Mi rows)
     run()
     hip_t, c = min((run() for _ in range(3)), key=lambda r: r[0])
     assert int(c.sum()) <= m
@@ -163,11 +170,45 @@ if has_gpu and %(timing)d:
     print("TIMING   same call, columns registered (vaex_amd.cache_columns): first pass %%.1f ms, later passes %%.1f ms = %%.2f Grows/s (chunks of %%d rows served from HBM)"
           %% (first * 1e3, again * 1e3, m / again / 1e9, vaex.settings.main.chunk.size_max))
     vaex_amd.uninstall()
-    vaex_amd.install(chunk_size=1 << 24)
+    vaex_amd.install()   # the default: chunk_size="auto" raises vaex's upper chunk bracket to 64 Mi rows (one chunk per pool thread)
+    assert vaex.settings.main.chunk.size_max == vaex_amd.AUTO_CHUNK_ROWS_MAX
     run()
     big_t, c3 = min((run() for _ in range(3)), key=lambda r: r[0])
     assert np.array_equal(c, c3)
-    print("TIMING   with install(chunk_size=16 Mi rows): cached passes %%.1f ms = %%.2f Grows/s" %% (big_t * 1e3, m / big_t / 1e9))
+    print("TIMING   with plain install() (chunk bracket raised to %%d rows): cached passes %%.1f ms = %%.2f Grows/s" %% (vaex.settings.main.chunk.size_max, big_t * 1e3, m / big_t / 1e9))
+    vaex_amd.uncache_columns()
+    vaex_amd.uninstall()
+    assert vaex.settings.main.chunk.size_max == 1024 ** 2
+    vaex_amd.install()
+    host_t2, c4 = min((run() for _ in range(3)), key=lambda r: r[0])
+    assert np.array_equal(c, c4)
+    print("TIMING   host-streamed with plain install(): %%.1f ms = %%.2f Grows/s (%%.1f GB/s over PCIe)" %% (host_t2 * 1e3, m / host_t2 / 1e9, m * 16 / host_t2 / 1e9))
+    vaex_amd.uncache_columns()
+    vaex_amd.uninstall()
+    # df.groupby(k).agg(sum / mean / std) of an unmodified vaex: its own two passes on the CPU (2e7-row slice), the device groupby
+    # behind the same call on all rows — host columns (every call crosses PCIe), then registered columns (HBM-resident copies)
+    from vaex_amd import vaex_groupby as vg
+    big["k"] = rng.integers(0, 1_000_000, m)
+    big["v"] = rng.normal(3, 2, m)
+    spec = {"s": vaex.agg.sum("v"), "m": vaex.agg.mean("v"), "sd": vaex.agg.std("v")}
+    small = big[:20_000_000].extract()
+    t0 = time.perf_counter(); g_cpu = small.groupby("k", agg=spec); cpu_t = time.perf_counter() - t0
+    vaex_amd.install()
+    def run_g(d):
+        t0 = time.perf_counter()
+        g = d.groupby("k", agg=spec)
+        return time.perf_counter() - t0, g
+    run_g(big)
+    host_t, g = min((run_g(big) for _ in range(2)), key=lambda r: r[0])
+    assert vg.last["path"] == "device" and len(g) == 1_000_000
+    g_small = small.groupby("k", agg=spec)
+    a, b = g_small.sort("k"), g_cpu.sort("k")
+    assert np.array_equal(np.ma.getdata(a["k"].to_numpy()), np.ma.getdata(b["k"].to_numpy())) and np.allclose(a["s"].to_numpy(), b["s"].to_numpy(), rtol=1e-12, atol=1e-9) and np.allclose(a["sd"].to_numpy(), b["sd"].to_numpy(), rtol=1e-9, atol=1e-9)
+    vaex_amd.cache_columns(big, ["k", "v"])
+    run_g(big)
+    dev_t, g2 = min((run_g(big) for _ in range(3)), key=lambda r: r[0])
+    print("TIMING vaex df.groupby(k, agg=sum/mean/std), 1e6 int64 keys: cpu (reference, %%d threads) %%.0f ms on %%d rows = %%.3f Grows/s; device groupby on %%d host rows %%.1f ms = %%.2f Grows/s (%%s); columns registered: %%.1f ms = %%.2f Grows/s"
+          %% (vaex.settings.main.thread_count, cpu_t * 1e3, len(small), len(small) / cpu_t / 1e9, m, host_t * 1e3, m / host_t / 1e9, vg.last["kernel"], dev_t * 1e3, m / dev_t / 1e9))
     vaex_amd.uncache_columns()
     vaex_amd.uninstall()
 '''

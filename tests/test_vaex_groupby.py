@@ -1,0 +1,137 @@
+"""vaex_amd.vaex_groupby: DataFrame.groupby(by, agg=...) of the REAL vaex package answered by the device groupby — here, without
+a GPU, its host logic (which calls are taken, the output column names for every form of `agg` GroupByBase._agg accepts,
+the group order, how the key column is typed, the construction of the result DataFrame) with vaex_amd.binned.Frame driving the
+reference's C++ (RefAdapter: dense key ranges only), compared call by call with vaex's own groupby in the same process.
+The -m gpu run of the same script drives the HIP path (dense, scattered and packed keys)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+VAEXPY = os.path.join(ROOT, "oracle", "_ref", "vaexpy")
+OVERLAY = os.path.join(ROOT, "oracle", "_ref", "overlay")
+FAKE = os.path.join(ROOT, "oracle", "fake")
+PKG = VAEXPY if os.path.isdir(os.path.join(VAEXPY, "vaex")) else OVERLAY
+
+SCRIPT = r'''
+import sys, numpy as np
+sys.path[:0] = [%(pkg)r, %(fake)r, %(root)r]
+import vaex, vaex_amd
+from vaex_amd import vaex_groupby as vg, binned
+gpu = %(gpu)d
+if gpu:
+    assert vaex_amd.superagg.device_count() > 0
+    vaex_amd.install()
+    original = vaex.dataframe.DataFrameLocal.groupby.__wrapped__
+else:
+    from tests.test_golden_api import RefAdapter
+    ref = RefAdapter(vaex.superagg)   # (the reference's own compiled module, as this vaex imported it)
+    vg._frame_for = lambda df, columns: binned.Frame(dict(columns), chunk_size=50_000, nthreads=2, superagg=ref)
+    state = {}
+    vg.install(vaex, state)
+    original = state["groupby"][1]
+rng = np.random.default_rng(3)
+n = 200_000
+v = rng.normal(3, 2, n); v[::97] = np.nan
+df = vaex.from_arrays(k=rng.integers(-5, 40, n), k32=rng.integers(100, 130, n).astype("i4"), ku=rng.integers(0, 9, n).astype("u2"),
+                      kgap=rng.integers(0, 50, n) * 3, ks=(rng.integers(0, 3000, n) * 2654435761) %% (1 << 40), kf=rng.integers(0, 5, n).astype("f8"),
+                      k8=rng.integers(0, 5, n).astype("i1"),
+                      v=v, w=rng.normal(0, 1, n).astype("f4"), i=rng.integers(-100, 100, n).astype("i4"))
+df["virt"] = df.k + 1
+
+def frame(d, sort_by):
+    d = d.sort(sort_by)
+    out = {}
+    for c in d.get_column_names():
+        a = d[c].to_numpy() if not hasattr(d[c], "values") or True else None
+        out[c] = a
+    return out
+
+def same(a, b, what):
+    assert list(a) == list(b), (what, list(a), list(b))           # same columns, same order
+    for c in a:
+        x, y = a[c], b[c]
+        assert len(x) == len(y), (what, c, len(x), len(y))
+        assert np.ma.isMaskedArray(x) == np.ma.isMaskedArray(y), (what, c, type(x), type(y))
+        x, y = np.ma.getdata(x), np.ma.getdata(y)
+        assert x.dtype == y.dtype, (what, c, x.dtype, y.dtype)
+        if x.dtype.kind in "iub":
+            assert np.array_equal(x, y), (what, c)
+        else:
+            assert np.allclose(x, y, rtol=1e-9, atol=1e-12, equal_nan=True), (what, c, np.nanmax(np.abs(x - y)))
+
+A = vaex.agg
+taken = [
+  ("k", {"s": A.sum("v"), "c": A.count(), "m": A.mean("v"), "sd": A.std("v"), "va": A.var("v"), "cv": A.count("v")}, {}),
+  ("k", [A.sum("v"), A.count("v"), A.mean("w")], {}),
+  ("k", "count", {}),
+  ("k", {"v": ["sum", "mean"], "i": "sum"}, {}),
+  ("k32", {"n": "count", "si": A.sum("i"), "mw": A.mean("w")}, dict(sort=True, ascending=False)),
+  ("ku", A.mean("v"), dict(sort=True)),   # (descending on an unsigned key trips vaex's own BinnerInteger: vmin - 2 wraps, vaex/groupby.py:162-166)
+  ("kgap", {"s": A.sum("v"), "c": A.count()}, {}),                 # range 148 > 4/3 * 50 keys: vaex keeps its Grouper (narrowed key dtype)
+]
+if gpu:   # (several keys are packed on the device, scattered keys need the hash aggregation: no CPU stand-in)
+    taken += [(["k", "k32"], {"c": A.count(), "s": A.sum("v")}, {}),
+              (["ku", "k", "k32"], {"m": A.mean("v")}, dict(sort=True)),
+              ("ks", {"s": A.sum("v"), "c": A.count(), "m": A.mean("v"), "sd": A.std("v")}, {}),
+              (["ks", "ku"], {"c": A.count("v")}, {})]
+declined = [
+  ("kf", {"c": A.count()}, "dtype float64"),
+  ("k8", {"c": A.count()}, "dtype int8"),
+  ("virt", {"c": A.count()}, "not a real column"),
+  ("k", {"u": A.nunique("i")}, "AggNUnique"),
+  ("k", {"lo": A.min("v")}, "AggMin"),
+  ("k", {"c": A.count(selection="v > 3")}, "selection"),
+  ("k", {"sd": A.std("i")}, "var / std of an integer column"),
+]
+for by, agg, kw in taken:
+    vg.last.clear()
+    got = df.groupby(by, agg=agg, **kw)
+    assert vg.last.get("path") == "device", (by, agg, vg.last)
+    want = original(df, by, agg=agg, **kw)
+    keys = [by] if isinstance(by, str) else by
+    same(frame(got, keys[::-1][0] if len(keys) == 1 else keys[0]) if len(keys) == 1 else {c: got.sort(keys)[c].to_numpy() for c in got.get_column_names()},
+         frame(want, keys[0]) if len(keys) == 1 else {c: want.sort(keys)[c].to_numpy() for c in want.get_column_names()}, (by, agg))
+    if kw.get("sort"):   # with sort=True the row order itself is specified
+        g, w = got[keys[0]].to_numpy(), want[keys[0]].to_numpy()
+        assert np.array_equal(np.ma.getdata(g), np.ma.getdata(w)), (by, kw)
+    print("ok-device", by, list(got.get_column_names()), vg.last.get("kernel"))
+for by, agg, why in declined:
+    vg.last.clear()
+    got = df.groupby(by, agg=agg)
+    assert vg.last.get("path") == "vaex" and why in vg.last.get("why", ""), (by, vg.last)
+    print("ok-declined", by, vg.last["why"])
+# a filtered frame and a row limit are vaex's business
+vg.last.clear(); df[df.k > 3].groupby("k", agg="count"); assert vg.last.get("path") == "vaex" and "filtered" in vg.last["why"]
+# without agg the GroupBy object comes from vaex
+assert type(df.groupby("k")).__name__ == "GroupBy"
+# a slice of the frame (active range)
+part = df[1000:150_000]
+vg.last.clear()
+same(frame(part.groupby("k", agg={"s": A.sum("v"), "c": A.count()}), "k"), frame(original(part, "k", agg={"s": A.sum("v"), "c": A.count()}), "k"), "slice")
+print("ok-slice", vg.last.get("path"))
+print("DONE")
+'''
+
+
+def _run(gpu, timeout):
+    env = dict(os.environ, VAEX_NUM_THREADS=os.environ.get("VAEX_NUM_THREADS", "4"))
+    out = subprocess.run([sys.executable, "-c", SCRIPT % dict(pkg=PKG, fake=FAKE, root=ROOT, gpu=gpu)], cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-6000:]
+    return out.stdout
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(PKG, "vaex")), reason="real vaex package not built (oracle/build_ref.sh needs /root/reference)")
+def test_groupby_host_logic_against_vaex_on_the_reference_cpp():
+    out = _run(0, 600)
+    assert "DONE" in out and out.count("ok-device") == 7 and out.count("ok-declined") == 7, out
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.isdir(os.path.join(PKG, "vaex")), reason="real vaex package not built (oracle/build_ref.sh needs /root/reference)")
+def test_groupby_of_real_vaex_runs_on_the_device_groupby():
+    out = _run(1, 900)
+    assert "DONE" in out and out.count("ok-device") == 11 and out.count("ok-declined") == 7, out
+    assert "gb_scatter+gb_reduce" in out and "bin_lds" in out, out   # (the fused hash aggregation, and — few groups — the LDS-resident grid)

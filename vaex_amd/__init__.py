@@ -79,7 +79,10 @@ class _Backend:
 _installed = {}
 
 
-def install(vaex_module=None, legacy=True, hash_sets=True, chunk_size=None):
+AUTO_CHUNK_ROWS_MAX = 1 << 26   # install(chunk_size="auto"): upper bracket of vaex's automatic chunk size (rows)
+
+
+def install(vaex_module=None, legacy=True, hash_sets=True, chunk_size="auto", groupby=True):
     """Plug the HIP kernels into an unmodified vaex.
 
     * `vaex.superagg` becomes a `_Backend` and the task-part registry entry "aggregations" (vaex/cpu.py:629-631,
@@ -91,9 +94,14 @@ def install(vaex_module=None, legacy=True, hash_sets=True, chunk_size=None):
       vaex_amd.vaexfast.statisticNd_f8 (the float32 variant keeps the reference's CPU code: it scales in float32).
     * hash_sets=True replaces `vaex.hash.ordered_set_<dtype>` for the numeric dtypes (vaex/hash.py:49-52 looks them up
       by name) with vaex_amd.hashset's GPU-backed classes: groupby's distinct-key pass and `_ordinal_values`.
-    * chunk_size=N sets vaex.settings.main.chunk.size (vaex/execution.py:283-292; default: rows / threads bracketed by
-      [size_min, size_max = 1 Mi]): the kernels reach their full rate on chunks of 16 Mi rows and more, a 1 Mi-row chunk
-      is bound by its fixed costs."""
+    * chunk_size: vaex's executor cuts a pass into chunks of `rows / threads` rows bracketed by [chunk.size_min, chunk.size_max
+      = 1 Mi] (vaex/execution.py:283-292) — a bracket chosen for CPU caches: at 1 Mi rows a chunk is bound by its fixed costs
+      here (the Python of TaskPartAggregation.process, one launch: profiles/r02_vaex_dropin_timing.txt, 8 Grows/s from HBM).
+      "auto" (default) raises the UPPER bracket, vaex.settings.main.chunk.size_max, to AUTO_CHUNK_ROWS_MAX = 64 Mi rows unless
+      the user changed it, so that every pool thread gets one chunk of rows / threads rows up to that size and nobody has to
+      pass anything; an integer sets vaex.settings.main.chunk.size itself; None leaves vaex's chunking alone.
+    * groupby=True: df.groupby(<integer key columns>, agg=count / sum / mean / var / std ...) is answered by the device
+      groupby (vaex_amd/vaex_groupby.py) instead of vaex's two passes; everything else falls through to vaex's own code."""
     import sys
     if vaex_module is None:
         import vaex as vaex_module
@@ -150,9 +158,16 @@ def install(vaex_module=None, legacy=True, hash_sets=True, chunk_size=None):
         if legacy_mod is not None:
             _installed["legacy"] = (legacy_mod, legacy_mod.statisticNd_f8)
             legacy_mod.statisticNd_f8 = _vf.statisticNd_f8
-    if chunk_size is not None:
+    if chunk_size == "auto":
+        if vaex_module.settings.main.chunk.size_max == 1024 ** 2:  # (vaex's default: the user has not chosen one)
+            _installed["chunk_size_max"] = vaex_module.settings.main.chunk.size_max
+            vaex_module.settings.main.chunk.size_max = AUTO_CHUNK_ROWS_MAX
+    elif chunk_size is not None:
         _installed["chunk_size"] = vaex_module.settings.main.chunk.size
         vaex_module.settings.main.chunk.size = int(chunk_size)
+    if groupby:
+        from . import vaex_groupby
+        vaex_groupby.install(vaex_module, _installed)
     if hash_sets:
         import copyreg
         import vaex.hash
@@ -192,6 +207,11 @@ def uninstall():
         vaex.hash.ordered_set = _installed["hash_tuple"]
     if "chunk_size" in _installed:
         vaex_module.settings.main.chunk.size = _installed["chunk_size"]
+    if "chunk_size_max" in _installed:
+        vaex_module.settings.main.chunk.size_max = _installed["chunk_size_max"]
+    if "groupby" in _installed:
+        from . import vaex_groupby
+        vaex_groupby.uninstall(vaex_module, _installed)
     _installed.clear()
 
 

@@ -1,0 +1,277 @@
+"""df.groupby(<integer key columns>, agg=...) of an unmodified vaex on the device groupby.
+
+vaex answers a groupby in two passes over the rows plus numpy finishers (vaex/groupby.py:602-1017): the distinct keys go
+through `ordered_set` (vaex/hash.py:152-214, vaex/cpu.py:285-404), every chunk's keys are mapped to ordinals on the host
+(`_ordinal_values`, vaex/groupby.py:303-317), the ordinals are binned by BinnerOrdinal with one aggregator per primitive,
+and mean / var / std are finished with numpy over the full grids (vaex/agg.py:386-455).  vaex_amd.install() swaps the HIP
+classes under that machinery already; this module goes one step further for the calls the device groupby of
+vaex_amd.binned.Frame covers — it answers `DataFrame.groupby(by, agg=...)` itself:
+
+    keys   1..8 real integer columns (int16 .. int64, uint16 .. uint32; numpy / memory-mapped, no missing values)
+    agg    count(*) / count(x) / sum(x) / mean(x) / var(x) / std(x) on real numeric columns without missing values, no
+           selection — given as vaex.agg objects, names ('count', 'mean', ...), lists or {name: ...} dicts, i.e. every
+           form GroupByBase._agg accepts (vaex/groupby.py:688-745; the output column names follow its rules)
+    frame  not filtered, row_limit=None
+
+and builds the resulting DataFrame the way GroupBy.agg does (vaex/groupby.py:955-983): one row per group that exists, the key
+columns first.  Dense key ranges bin themselves in ONE partitioned pass (BinnerOrdinal(min_value) + vxh_finish: what vaex
+reaches after its distinct-key pass through the BinnerInteger simplification, vaex/groupby.py:263-272), scattered keys go
+through the fused radix-partitioned hash aggregation (vxh_groupby_run), several keys are packed into one on the device
+(vxh_pack_keys: vaex's GrouperCombined, vaex/groupby.py:526-584).  Anything outside that signature — and any failure the
+device path reports — falls through to vaex's own groupby, which then still runs on the HIP classes task by task.
+
+Group order: ascending by key(s) (descending with sort=True, ascending=False).  vaex's own order without `sort` is its hash
+set's insertion order — unspecified; with sort=True it is this one.  The key column comes back the way vaex types it: a
+masked int64 array without masked entries when vaex would have simplified to BinnerInteger (key range <= 4/3 of the distinct
+keys), else the narrowest signed integer type that holds the key range (vaex/groupby.py:263-277).
+"""
+import collections.abc
+
+import numpy as np
+
+from . import binned
+
+#: what the most recent DataFrame.groupby(..., agg=...) ran on: {"path": "device" | "vaex", "kernel": ..., "why": ...}
+last = {}
+
+_KEY_KINDS = ("int16", "int32", "int64", "uint16", "uint32")
+_VALUE_KINDS = ("float64", "float32", "int64", "int32", "int16", "int8", "uint32", "uint16", "uint8")
+_AGG_NAMES = {"AggCount": "count", "AggSum": "sum"}
+
+
+class _Decline(Exception):
+    """the call is outside the device groupby's signature: vaex's own code answers it"""
+
+
+def _real_column(df, expression, kinds, what):
+    """the numpy array behind `expression` when it names a real, unmasked column of one of `kinds` (active range applied)"""
+    name = str(expression)
+    if name not in df.columns:
+        label = getattr(df[name], "_label", name) if name in getattr(df, "virtual_columns", {}) else name
+        raise _Decline(f"{what} {label!r} is not a real column")
+    ar = df.columns[name]
+    if np.ma.isMaskedArray(ar) or not isinstance(ar, np.ndarray):
+        raise _Decline(f"{what} {name!r} is not a plain numpy column")
+    if ar.dtype.name not in kinds or not ar.dtype.isnative or ar.ndim != 1:
+        raise _Decline(f"{what} {name!r} has dtype {ar.dtype}")
+    i1, i2 = df._index_start, df._index_end
+    if i2 is None:
+        i2 = len(ar)
+    if i1 != 0 or i2 != len(ar):
+        ar = ar[i1:i2]
+    return name, ar
+
+
+def _normalise_actions(df, keys, actions):
+    """[(output column name, vaex aggregator descriptor)] — the iteration of GroupByBase._agg (vaex/groupby.py:688-745)"""
+    import vaex.agg
+    out = []
+    if isinstance(actions, collections.abc.Mapping):
+        actions = list(actions.items())
+    elif not isinstance(actions, collections.abc.Iterable) or isinstance(actions, str):
+        actions = [actions]
+
+    def add(aggregate, column_name=None, override_name=None):
+        if column_name is None or override_name is not None:
+            column_name = aggregate.pretty_name(override_name, df)
+        out.append((column_name, aggregate))
+
+    for item in actions:
+        override_name = None
+        if isinstance(item, tuple):
+            name, aggregates = item
+        else:
+            aggregates = item
+            name = None
+        if not isinstance(aggregates, collections.abc.Iterable) or isinstance(aggregates, str):
+            aggregates = [aggregates]
+        elif name is not None:
+            override_name = name
+        for aggregate in aggregates:
+            if isinstance(aggregate, str) and aggregate == "count":
+                add(vaex.agg.count(), "count" if name is None else name)
+                continue
+            if isinstance(aggregate, str):
+                if aggregate not in vaex.agg.aggregates:
+                    raise _Decline(f"unknown aggregate {aggregate!r}")
+                aggregate = vaex.agg.aggregates[aggregate]
+            if callable(aggregate) and not isinstance(aggregate, vaex.agg.AggregatorDescriptor):
+                if name is None:
+                    for column_name in df.get_column_names():
+                        if column_name not in keys:
+                            add(aggregate(column_name), override_name=override_name)
+                else:
+                    add(aggregate(name), name, override_name=override_name)
+            else:
+                add(aggregate, name, override_name=override_name)
+    return out
+
+
+def _translate(df, aggregate, columns):
+    """vaex aggregator descriptor -> binned.agg descriptor; the value column is entered into `columns`"""
+    import vaex.agg
+    if getattr(aggregate, "selection", None) is not None:
+        raise _Decline("aggregation with a selection")
+    if isinstance(aggregate, vaex.agg.AggregatorDescriptorBasic):
+        kind = _AGG_NAMES.get(aggregate.name)
+        if kind is None or aggregate.agg_args:
+            raise _Decline(f"aggregator {aggregate.name}")
+    elif type(aggregate) is vaex.agg.AggregatorDescriptorMean:
+        kind = "mean"
+    elif type(aggregate) in (vaex.agg.AggregatorDescriptorVar, vaex.agg.AggregatorDescriptorStd):
+        kind = "std" if isinstance(aggregate, vaex.agg.AggregatorDescriptorStd) else "var"  # (ddof never enters vaex's formula: vaex/agg.py:440-455)
+    else:
+        raise _Decline(f"aggregator {type(aggregate).__name__}")
+    expressions = list(aggregate.expressions)
+    if kind == "count" and not expressions:
+        return binned.agg.count()
+    if len(expressions) != 1:
+        raise _Decline("aggregator over several expressions")
+    name, ar = _real_column(df, expressions[0], _VALUE_KINDS, "aggregated expression")
+    if kind in ("var", "std") and ar.dtype.kind != "f":
+        raise _Decline("var / std of an integer column")  # (vaex casts to float64 first: vaex/agg.py:427)
+    columns[name] = ar
+    return getattr(binned.agg, kind)(name)
+
+
+def _key_column_like_vaex(values):
+    """a key column of the result typed the way vaex's groupers hand it back (vaex/groupby.py:147-205, :263-277) — decided per key
+    from its distinct values: BinnerInteger (range <= 4/3 of the distinct keys) -> int64 with an (empty) mask; else Grouper -> the
+    narrowest signed integer type that holds the range"""
+    k = np.asarray(values)
+    if len(k) == 0:
+        return k
+    vmin, vmax = int(k.min()), int(k.max())
+    distinct = len(k) if np.all(k[1:] > k[:-1]) or np.all(k[1:] < k[:-1]) else len(np.unique(k))
+    if vmax - vmin + 1 <= distinct * 4 / 3:
+        return np.ma.array(k.astype(np.int64), mask=np.zeros(len(k), dtype=bool), shrink=False)
+    for dt in (np.int8, np.int16, np.int32, np.int64):
+        if vmin >= np.iinfo(dt).min and vmax <= np.iinfo(dt).max:
+            return k.astype(dt)
+    return k
+
+
+def fast_groupby(df, by, agg, sort=False, ascending=True, row_limit=None):
+    """the grouped DataFrame, or _Decline"""
+    import vaex
+    import vaex.dataset
+    import vaex.groupby
+    if row_limit is not None:
+        raise _Decline("row_limit")
+    if df.filtered:
+        raise _Decline("filtered DataFrame")
+    if by is None:
+        raise _Decline("no key")
+    by_list = [by] if isinstance(by, str) or not isinstance(by, collections.abc.Iterable) else list(by)
+    if not 1 <= len(by_list) <= 8:
+        raise _Decline(f"{len(by_list)} keys")
+    for b in by_list:
+        if isinstance(b, vaex.groupby.BinnerBase):
+            raise _Decline("binner object as key")
+    asc = list(ascending) if isinstance(ascending, (list, tuple)) else [ascending] * len(by_list)
+    srt = list(sort) if isinstance(sort, (list, tuple)) else [sort] * len(by_list)
+    if len(set(zip(srt, asc))) > 1:
+        raise _Decline("keys sorted in different directions")
+    columns, key_names = {}, []
+    for b in by_list:
+        name, ar = _real_column(df, vaex.utils._ensure_string_from_expression(b), _KEY_KINDS, "group key")
+        if name in columns:
+            raise _Decline("the same key twice")
+        columns[name] = ar
+        key_names.append(name)
+    actions = _normalise_actions(df, key_names, agg)
+    if not actions:
+        raise _Decline("no aggregation")
+    spec = {}
+    for out_name, aggregate in actions:
+        if out_name in spec or out_name in key_names:
+            raise _Decline("duplicate output column")
+        spec[out_name] = _translate(df, aggregate, columns)
+    frame = _frame_for(df, columns)
+    frame.last_groupby_info = None
+    try:
+        res = frame.groupby(key_names if len(key_names) > 1 else key_names[0], spec)
+    except NotImplementedError as e:
+        raise _Decline(str(e))
+    descending = bool(srt[0]) and not asc[0]
+    out = {}
+    typed = {name: _key_column_like_vaex(np.asarray(res[name])) for name in key_names}
+    # several keys: vaex packs them into one grouper when the cartesian product of the key sets is sparsely occupied (< 10 rows
+    # per cell, combine='auto': vaex/groupby.py:660-672); the key columns then come back through arrow, as plain arrays
+    cells = 1
+    for name in key_names:
+        cells *= max(1, len(np.unique(np.ma.getdata(typed[name]))))
+    combined = len(key_names) >= 2 and frame.n / cells < 10
+    for name in key_names:
+        k = np.ma.getdata(typed[name]) if combined else typed[name]
+        k = k[::-1] if descending else k
+        out[df[name]._label] = k
+    for out_name, _ in actions:
+        v = np.asarray(res[out_name])
+        out[out_name] = v[::-1] if descending else v
+    last.clear()
+    kernel = "gb_scatter+gb_reduce" if frame.last_groupby_info else (frame.sa.last_kernel(0) if hasattr(frame.sa, "last_kernel") else "")
+    last.update(path="device", kernel=kernel, info=frame.last_groupby_info, groups=len(next(iter(out.values()))))
+    dataset_arrays = vaex.dataset.DatasetArrays(out)
+    dataset = vaex.groupby.DatasetGroupby(dataset_arrays, df, by, agg, combine=combined, expand=True, sort=sort)
+    return vaex.from_dataset(dataset)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# device-resident copies of registered columns: a column handed to vaex_amd.cache_columns() is immutable by contract, so a
+# groupby over it may keep its bytes in HBM between calls (the same promise the C-level chunk cache rests on)
+# ---------------------------------------------------------------------------------------------------------------------
+_device_copies = {}
+
+
+def _frame_for(df, columns):
+    from . import _cached_arrays
+    cols = {}
+    for name, ar in columns.items():
+        key = ar.__array_interface__["data"][0]
+        base = _cached_arrays.get(key)
+        if base is not None and base.nbytes == ar.nbytes:
+            hit = _device_copies.get(key)
+            if hit is None or hit[0] is not base:
+                import torch
+                hit = (base, torch.from_numpy(np.ascontiguousarray(base)).cuda())
+                _device_copies[key] = hit
+            cols[name] = hit[1]
+        else:
+            cols[name] = ar
+    if len({binned._is_device(c) for c in cols.values()}) > 1:  # (the fused pass wants keys and values in one place)
+        cols = dict(columns)
+    return binned.Frame(cols)
+
+
+def drop_device_copies():
+    _device_copies.clear()
+
+
+def install(vaex_module, state):
+    import vaex.dataframe
+    import vaex.promise
+    cls = vaex.dataframe.DataFrameLocal   # (vaex/dataframe.py:7133: groupby is defined on the local frame)
+    original = cls.groupby
+
+    def groupby(self, by=None, agg=None, sort=False, ascending=True, assume_sparse="auto", row_limit=None, copy=True, progress=None, delay=False):
+        if agg is not None:
+            try:
+                result = fast_groupby(self, by, agg, sort=sort, ascending=ascending, row_limit=row_limit)
+            except _Decline as e:
+                last.clear()
+                last.update(path="vaex", why=str(e))
+            else:
+                return self._delay(delay, vaex.promise.Promise.fulfilled(result))
+        return original(self, by=by, agg=agg, sort=sort, ascending=ascending, assume_sparse=assume_sparse, row_limit=row_limit, copy=copy, progress=progress, delay=delay)
+
+    groupby.__doc__ = original.__doc__
+    groupby.__wrapped__ = original
+    cls.groupby = groupby
+    state["groupby"] = (cls, original)
+
+
+def uninstall(vaex_module, state):
+    cls, original = state["groupby"]
+    cls.groupby = original
+    drop_device_copies()
