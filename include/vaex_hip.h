@@ -76,7 +76,8 @@ int vxh_synchronize(void);
 int vxh_slot_set_stream(int thread, void *hip_stream);
 /* tuning knobs for experiments and tests ("strategy", "part_chunk", "parts", "wv", "wv_waves", "wv_waves_direct", "blk", "hot",
  * "hot_cache", "hot_min_pct", "hot_direct_pct", "count16", "stage_bytes", "feeder", "cache_bytes", ...) and the two switches that
- * reproduce reference quirks ("first_mask_block", "nunique_row_counts": see AggFirst / AggNUnique below): the full list is the
+ * switch two reference quirks OFF ("first_mask_block", "nunique_row_counts": see AggFirst / AggNUnique below; the defaults are
+ * the reference's behaviour): the full list is the
  * if-chain of vxh_config_set in vaex_amd/csrc/vxh_api.hip; DESIGN.md §3 */
 int vxh_config_set(const char *key, int64_t value);
 int vxh_config_get(const char *key, int64_t *value);
@@ -193,10 +194,10 @@ int vxh_agg_set_selection(vxh_agg *agg, vxh_selection *selection);
  * throws, :42).  vxh_first_bin bins slot `thread` of the grid's binners like vxh_grid_bin.  vxh_first_result: values_out
  * (cells of dtype, empty cells read 99 like the reference's fill :22-28), masked_out (1 = empty cell), order_out (cells of
  * dtype_order; may be NULL).
- * Deliberate difference: the keep-mask (1 = keep) is read at the row's index, mask[row].  The reference reads
- * `data_mask_ptr[j]` with j counted inside the current 1024-row block of Grid::bin_ (src/agg_first.cpp:131 — every other
- * aggregator reads `[j + offset]`), so it agrees only for calls of <= 1024 rows; vxh_config_set("first_mask_block", 1024)
- * reproduces the reference's indexing bit for bit (tests/test_gpu_first.py pins both). */
+ * Reference quirk, reproduced by default: the keep-mask (1 = keep) is read at `data_mask_ptr[j]` with j counted inside the
+ * current 1024-row block of Grid::bin_ (src/agg_first.cpp:131 — every other aggregator reads `[j + offset]`), i.e. at
+ * mask[row % 1024] of the call's mask: what the call means only for calls of <= 1024 rows.  vxh_config_set("first_mask_block",
+ * 0) reads mask[row] instead (tests/test_gpu_first.py pins both against the reference's compiled class). */
 typedef struct vxh_first vxh_first;
 int vxh_first_create(int dtype, int dtype_order, int flip_endian, vxh_grid *grid, int grids, int threads, int invert, vxh_first **out);
 void vxh_first_destroy(vxh_first *first);
@@ -213,16 +214,17 @@ size_t vxh_first_bytes_used(const vxh_first *first);
  *   mode 0 = AggNUnique_<T>(grid, grids, threads, dropmissing, dropnan) — src/agg_nunique.cpp:7-95: per cell the number of
  *     distinct values (+1 if a missing value was seen, +1 if a NaN was seen, unless dropped).  data mask: 0 = missing value;
  *     selection mask: 0 = the row is skipped (:70-73).  drop_a = dropmissing, drop_b = dropnan.
- *     Deliberate difference: dropmissing / dropnan take ONE entry away from a cell that saw such rows; the reference
- *     subtracts the number of those ROWS (`count -= counter->null_count`, :31-34), right only for cells with at most one —
- *     vxh_config_set("nunique_row_counts", 1) reproduces it.  Values are told apart by their bits (-0.0 and +0.0 are two, as
- *     for the reference's hash of the bits).
+ *     Reference quirk, reproduced by default: dropmissing / dropnan subtract the number of missing / NaN ROWS of a cell
+ *     (`count -= counter->null_count`, :31-34) — right only for cells with at most one such row;
+ *     vxh_config_set("nunique_row_counts", 0) takes the ONE entry they occupy away instead.  Values are told apart by their
+ *     bits (-0.0 and +0.0 are two, as for the reference's hash of the bits).
  *   mode 1 = AggList_<T>_<T2>(grid, grids, threads, dropnan, dropnull) — src/agg_list.cpp:7-128: per cell the values in row
  *     order, then its NaNs, then one slot per counted missing value (the reference leaves those slots uninitialised; here
  *     they read 0).  data mask: 1 = value present, 0 = missing (other bytes: the row is ignored, :103,:116).
- *     drop_a = dropnan, drop_b = dropnull.  Deliberate difference: the mask is read at the row's index (the reference reads
- *     `data_mask_ptr[j]` inside its 1024-row block, :103, like AggFirst).
- * grids must be 1 (the reference's own restriction).  merge() is not offered (the reference's are empty / throw). */
+ *     drop_a = dropnan, drop_b = dropnull.  The mask is read like AggFirst's: `data_mask_ptr[j]` inside the 1024-row block
+ *     (:103) by default, mask[row] with "first_mask_block" = 0.
+ * grids must be 1 (the reference's own restriction).  merge() is not offered on the class surface (the reference's are empty /
+ * throw); ranks exchange their state through vxh_collect_pairs / vxh_collect_merge_pairs. */
 typedef struct vxh_collect vxh_collect;
 int vxh_collect_create(int mode, int dtype, int flip_endian, vxh_grid *grid, int grids, int threads, int drop_a, int drop_b, vxh_collect **out);
 void vxh_collect_destroy(vxh_collect *collect);
@@ -234,6 +236,14 @@ int vxh_collect_bin(vxh_collect *collect, int thread, uint64_t length);
 int vxh_collect_nunique_result(vxh_collect *collect, int64_t *out_cells);
 /* offsets_out[cells + 1]; values_out NULL: only the offsets and *flat_length_out; else flat_length elements of dtype */
 int vxh_collect_list_result(vxh_collect *collect, int64_t *offsets_out, void *values_out, uint64_t *flat_length_out);
+/* The collector's state for an exchange between ranks (the cross-rank form of TaskPartAggregation.reduce, vaex/cpu.py:788-796 —
+ * the reference's own merge of these two aggregators is empty / throws, src/agg_nunique.cpp:46-59, src/agg_list.cpp:45): the
+ * compacted {canonical value bits, flat cell} pairs — nunique: the distinct ones; list: every kept value, cells ascending, row
+ * order inside a cell — and the per-cell counts of missing / NaN rows (cells int64 each).  Call with values_out == NULL for *n_out. */
+int vxh_collect_pairs(vxh_collect *collect, uint64_t *n_out, uint64_t *values_out, uint32_t *cells_out, int64_t *null_rows_out, int64_t *nan_rows_out);
+/* appends pairs exported by a collector over the same grid (host arrays) and adds its missing / NaN row counts; list: the
+ * appended values come BEHIND the present ones in every cell (merge in rank order = row order) */
+int vxh_collect_merge_pairs(vxh_collect *collect, uint64_t n, const uint64_t *values, const uint32_t *cells, const int64_t *null_rows, const int64_t *nan_rows);
 
 /* ---- row-wise helpers ---------------------------------------------------------------------- */
 /* device memory for the helpers' results (a plain hipMalloc / hipFree) */

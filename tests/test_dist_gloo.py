@@ -138,3 +138,68 @@ def test_shard_rows_cover_exactly():
         parts = [shard_rows(n, r, w) for r in range(w)]
         assert parts[0][0] == 0 and parts[-1][1] == n
         assert all(a[1] == b[0] for a, b in zip(parts, parts[1:]))
+
+
+def _worker_first_last(rank, world, port, q):
+    """first / last over a row-sharded Frame (order column: the generic route with a second AggFirst for the order grid),
+    and the two exchange helpers: all_gather_arrays (padded tensor all_gather) and all_agree"""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    from oracle import oracle
+    from tests.test_golden_api import RefAdapter
+    from vaex_amd import dist as vdist
+    from vaex_amd.binned import Frame
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rng = np.random.default_rng(17)
+        n = 30_000
+        cols = dict(x=rng.uniform(0, 10, n), v=rng.normal(0, 1, n), t=rng.permutation(n).astype("f8"), ti=rng.integers(0, 500, n).astype("i4"),  # ti: many ties across the ranks
+                    i=rng.integers(-1000, 1000, n).astype("i2"))
+        cols["v"][::53] = np.nan   # NaN values never win
+        i1, i2 = (0, 11_000) if rank == 0 else (11_000, n)   # uneven shards
+        comm = vdist.Comm()
+        shard = Frame({k: c[i1:i2] for k, c in cols.items()}, chunk_size=1000, nthreads=1, superagg=RefAdapter(oracle.ref_module("superagg")), comm=comm)
+        out = {}
+        for name, call in (("first_t", lambda f: f.first("v", "t", binby="x", limits=[0, 12], shape=12)), ("last_t", lambda f: f.last("v", "t", binby="x", limits=[0, 12], shape=12)),
+                           ("first_ties", lambda f: f.first("i", "ti", binby="x", limits=[0, 10], shape=5)), ("last_ties", lambda f: f.last("i", "ti", binby="x", limits=[0, 10], shape=5))):
+            r = call(shard)
+            out[name] = (np.asarray(np.ma.getdata(r)), np.asarray(np.ma.getmaskarray(r)))
+        parts = comm.all_gather_arrays([np.arange(rank * 3 + 2, dtype=np.int64), np.array([], dtype=np.float64) if rank else np.array([1.5, 2.5]), np.array([rank], dtype=np.uint8)])
+        out["gathered"] = [[p.tolist() for p in per_rank] for per_rank in parts]
+        out["agree"] = [comm.all_agree(True), comm.all_agree(rank == 0), comm.all_agree(False)]
+        q.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_first_last_over_two_ranks(ref):
+    import torch.multiprocessing as mp
+    from tests.test_golden_api import RefAdapter
+    from vaex_amd.binned import Frame
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_first_last, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    rng = np.random.default_rng(17)
+    n = 30_000
+    cols = dict(x=rng.uniform(0, 10, n), v=rng.normal(0, 1, n), t=rng.permutation(n).astype("f8"), ti=rng.integers(0, 500, n).astype("i4"), i=rng.integers(-1000, 1000, n).astype("i2"))
+    cols["v"][::53] = np.nan
+    whole = Frame(cols, chunk_size=1000, nthreads=1, superagg=RefAdapter(ref))
+    want = {"first_t": whole.first("v", "t", binby="x", limits=[0, 12], shape=12), "last_t": whole.last("v", "t", binby="x", limits=[0, 12], shape=12),
+            "first_ties": whole.first("i", "ti", binby="x", limits=[0, 10], shape=5), "last_ties": whole.last("i", "ti", binby="x", limits=[0, 10], shape=5)}
+    for rank, out in got:
+        for name, w in want.items():
+            v, m = out[name]
+            np.testing.assert_array_equal(m, np.ma.getmaskarray(w), err_msg=name)
+            np.testing.assert_array_equal(v[~m], np.ma.getdata(w)[~m], err_msg=name)
+            assert v.dtype == np.ma.getdata(w).dtype
+        assert out["first_t"][1].any() and not out["first_t"][1].all()   # (cells beyond x = 10 are empty on every rank)
+        assert out["gathered"] == [[[0, 1], [1.5, 2.5], [0]], [[0, 1, 2, 3, 4], [], [1]]]
+        assert out["agree"] == [True, False, False]

@@ -1,0 +1,202 @@
+"""-m gpu: the cross-rank forms of the f.4 family on the PRODUCT path.  torch.distributed cannot put two RCCL ranks on one GPU,
+so two "ranks" here are two threads of this process, each with its own row shard, its own Frame over device columns and a
+communicator whose collectives (the interface of vaex_amd.dist.Comm) meet at a thread barrier — every kernel, every
+vxh_collect_pairs / merge_pairs / groupby_merge call is the real one; only the transport is a Python list instead of RCCL
+(tests/test_dist_gloo.py runs the transport itself: gloo, two processes).  Each result must equal ONE Frame over all rows."""
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+class ThreadComm:
+    """vaex_amd.dist.Comm for `world` threads of one process"""
+
+    class Shared:
+        def __init__(self, world):
+            self.world = world
+            self.slots = [None] * world
+            self.barrier = threading.Barrier(world)
+
+    def __init__(self, shared, rank):
+        self.s, self._rank, self.group = shared, rank, None
+
+    def world(self):
+        return self.s.world
+
+    def rank(self):
+        return self._rank
+
+    def _exchange(self, obj):
+        self.s.slots[self._rank] = obj
+        self.s.barrier.wait()
+        out = list(self.s.slots)
+        self.s.barrier.wait()
+        return out
+
+    def minmax(self, lo, hi):
+        parts = self._exchange((lo, hi))
+        return min(p[0] for p in parts), max(p[1] for p in parts)
+
+    minmax_float = minmax
+
+    def sum_ints(self, values):
+        parts = self._exchange([int(v) for v in values])
+        return [sum(p[i] for p in parts) for i in range(len(values))]
+
+    def all_gather_arrays(self, arrays):
+        return [[np.array(a) for a in p] for p in self._exchange([np.ascontiguousarray(a) for a in arrays])]
+
+    def all_agree(self, ok):
+        return all(self._exchange(bool(ok)))
+
+    def union_keys(self, keys):
+        return np.unique(np.concatenate([p[0] for p in self.all_gather_arrays([np.asarray(keys)])]))
+
+    def allreduce_arrays(self, arrays, ops):
+        parts = self._exchange([np.array(a) for a in arrays])
+        fn = {"sum": np.add, "min": np.minimum, "max": np.maximum}
+        out = []
+        for i, op in enumerate(ops):
+            acc = parts[0][i].copy()
+            for p in parts[1:]:
+                acc = fn[op](acc, p[i])
+            out.append(acc)
+        return out
+
+    def allreduce(self, aggs):
+        from vaex_amd import dist as vdist
+        vdist.allreduce_aggs_host(aggs, reduce_arrays=self.allreduce_arrays)
+
+
+def _run_ranks(cols, cut, fn, world=2):
+    """fn(frame) on every rank's shard (threads), returns the per-rank results; exceptions are re-raised"""
+    import torch
+    from vaex_amd.binned import Frame
+    shared = ThreadComm.Shared(world)
+    bounds = [0] + list(cut) + [len(next(iter(cols.values())))]
+    out, errs = [None] * world, [None] * world
+
+    def work(r):
+        try:
+            torch.cuda.set_device(0)
+            f = Frame({k: c[bounds[r]:bounds[r + 1]] for k, c in cols.items()}, comm=ThreadComm(shared, r))
+            out[r] = fn(f, r)
+        except BaseException as e:  # noqa
+            errs[r] = e
+            shared.barrier.abort()
+    ts = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    [t.start() for t in ts]
+    [t.join(300) for t in ts]
+    for e in errs:
+        if e is not None and not isinstance(e, threading.BrokenBarrierError):
+            raise e
+    for e in errs:
+        if e is not None:
+            raise e
+    return out
+
+
+@pytest.fixture(scope="module")
+def table():
+    import torch
+    rng = np.random.default_rng(77)
+    n = 400_000
+    v = rng.normal(0, 1, n); v[::41] = np.nan
+    host = dict(x=rng.uniform(0, 10, n), v=v, t=rng.permutation(n).astype("f8"), ti=rng.integers(0, 300, n).astype("i4"),
+                q=(rng.integers(0, 200, n) / 4.0), k=rng.integers(-5, 60, n), k2=rng.integers(1000, 1040, n).astype("i4"),
+                ks=(rng.integers(0, 20_000, n) * 2654435761) % (1 << 40))
+    host["q"][rng.random(n) < 0.02] = np.nan
+    dev = {k: torch.from_numpy(a).cuda() for k, a in host.items()}
+    return host, dev
+
+
+def test_first_last_two_ranks(sa, gpu_ready, table):
+    from vaex_amd.binned import Frame
+    host, dev = table
+    whole = Frame(dev)
+    calls = {"first_t": lambda f: f.first("v", "t", binby="x", limits=[0, 12], shape=12), "last_t": lambda f: f.last("v", "t", binby="x", limits=[0, 12], shape=12),
+             "first_ties": lambda f: f.first("k2", "ti", binby="x", limits=[0, 10], shape=7), "last_ties": lambda f: f.last("k2", "ti", binby="x", limits=[0, 10], shape=7),
+             "first_row": lambda f: f.first("q", None, binby="x", limits=[0, 10], shape=7), "last_row": lambda f: f.last("q", None, binby="x", limits=[0, 10], shape=7)}
+    got = _run_ranks(dev, [150_001], lambda f, r: {n: c(f) for n, c in calls.items()})
+    for name, c in calls.items():
+        w = c(whole)
+        for r in range(2):
+            g = got[r][name]
+            np.testing.assert_array_equal(np.ma.getmaskarray(g), np.ma.getmaskarray(w), err_msg=name)
+            np.testing.assert_array_equal(np.ma.getdata(g)[~np.ma.getmaskarray(g)], np.ma.getdata(w)[~np.ma.getmaskarray(w)], err_msg=name)
+
+
+def test_nunique_and_list_two_ranks(sa, gpu_ready, table):
+    from vaex_amd.binned import Frame
+    host, dev = table
+    whole = Frame(dev)
+    keep = dev["v"] > 0
+    dev2 = dict(dev, keep=keep)
+    whole = Frame(dev2)
+    calls = {"nunique": lambda f: f.nunique("q", binby="x", limits=[0, 10], shape=9), "nunique_dropnan": lambda f: f.nunique("q", binby="x", limits=[0, 10], shape=9, dropnan=True),
+             "nunique_sel_by_key": lambda f: f.nunique("ti", binby=[dict(column="k2", count=40, min_value=1000)], selection="keep"), "nunique_scalar": lambda f: f.nunique("ti")}
+    got = _run_ranks(dev2, [99_999], lambda f, r: {n: c(f) for n, c in calls.items()})
+    for name, c in calls.items():
+        w = c(whole)
+        for r in range(2):
+            np.testing.assert_array_equal(np.asarray(got[r][name]), np.asarray(w), err_msg=name)
+    lst = lambda f: f.list("q", binby="x", limits=[0, 10], shape=5)
+    got = _run_ranks(dev2, [250_000], lambda f, r: lst(f))
+    w = lst(whole)
+    for r in range(2):
+        for c in range(5):
+            np.testing.assert_array_equal(got[r][c], w[c])   # values in global row order, then the cell's NaNs
+
+
+def test_groupbys_two_ranks(sa, gpu_ready, table):
+    from vaex_amd.binned import Frame, agg
+    host, dev = table
+    whole = Frame(dev)
+    spec = {"c": agg.count(), "cv": agg.count("v"), "s": agg.sum("v"), "m": agg.mean("v"), "sd": agg.std("v")}
+
+    def check(g, w, keys):
+        for k in keys:
+            np.testing.assert_array_equal(g[k], w[k])
+        np.testing.assert_array_equal(g["c"], w["c"]); np.testing.assert_array_equal(g["cv"], w["cv"])
+        assert np.all(np.abs(g["s"] - w["s"]) <= 1e-12 * 6 * np.maximum(w["cv"], 1))
+        np.testing.assert_allclose(g["m"], w["m"], rtol=1e-9, atol=1e-12); np.testing.assert_allclose(g["sd"], w["sd"], rtol=1e-7, atol=1e-9)
+    for keys in (["k"], ["ks"], ["k", "k2"], ["k2", "ks"]):
+        by = keys if len(keys) > 1 else keys[0]
+        got = _run_ranks(dev, [123_457], lambda f, r: f.groupby(by, spec))
+        w = whole.groupby(by, spec)
+        for r in range(2):
+            check(got[r], w, keys)
+
+
+def test_one_rank_declines_the_fused_pass_and_all_take_the_fallback(sa, gpu_ready, table):
+    """the fused hash aggregation fails on ONE rank only (here: forced): every rank must leave it together (all_agree) and
+    answer through ordered_set + BinnerHash — a rank going on alone would sit in a collective nobody else enters"""
+    from vaex_amd.binned import Frame, agg
+    host, dev = table
+    spec = {"c": agg.count("v"), "s": agg.sum("v")}
+    w = Frame(dev).groupby("ks", spec)
+
+    class Failing:
+        def __init__(self, sa):
+            self._sa = sa
+
+        def __getattr__(self, name):
+            return getattr(self._sa, name)
+
+        def groupby_run(self, *a, **k):
+            raise RuntimeError("groupby: the key distribution is too skewed for the partitioned path")
+
+    def run(f, r):
+        if r == 1:
+            f.sa = Failing(f.sa)
+        f.last_groupby_info = None
+        g = f.groupby("ks", spec)
+        return g, f.last_groupby_info
+    got = _run_ranks(dev, [200_000], run)
+    for g, info in got:
+        assert info is None   # nobody reports the fused pass
+        np.testing.assert_array_equal(g["ks"], w["ks"]); np.testing.assert_array_equal(g["c"], w["c"])
+        assert np.all(np.abs(g["s"] - w["s"]) <= 1e-12 * 6 * np.maximum(w["c"], 1))

@@ -528,8 +528,7 @@ class Frame:
     def _first_last(self, invert, expression, order_expression, binby, limits, shape, selection, edges):
         """df.first / df.last (vaex/dataframe.py:976-1011 -> AggFirst, vaex/agg.py:556-576): per cell the value of the row
         with the smallest (last: largest) order value; a masked array (cells without rows masked)."""
-        if self.comm is not None:
-            raise NotImplementedError("first / last over a row-sharded Frame (the aggregator has no merge, like the reference's: src/agg_first.cpp:42)")
+        comm = self.comm
         sa = self.sa
         specs = self._binner_specs(binby, limits, shape)
         value = self.columns[expression]
@@ -548,7 +547,15 @@ class Frame:
                 binners.append(getattr(sa, "BinnerOrdinal_" + pf)(1, s["column"], s["count"], s["min_value"], False, s["invert"]))
         grid = sa.Grid(binners)
         opf = "int64" if order is None else _class_postfix(order)  # vaex/agg.py:280-283: "rows use int64"
-        a = getattr(sa, "AggFirst_" + _class_postfix(value).replace("_non_native", "") + "_" + opf.replace("_non_native", "") + ("_non_native" if _class_postfix(value).endswith("_non_native") else ""))(grid, 1, 1, invert)
+        nn = "_non_native" if _class_postfix(value).endswith("_non_native") else ""
+        a = getattr(sa, "AggFirst_" + _class_postfix(value).replace("_non_native", "") + "_" + opf.replace("_non_native", "") + nn)(grid, 1, 1, invert)
+        # a row-sharded frame also needs every cell's winning ORDER value: the product hands it out (raw_result); classes without
+        # that accessor (the reference's) get a second AggFirst whose value column is the order column itself
+        a2 = None
+        if comm is not None and not hasattr(a, "raw_result"):
+            if order is None:
+                raise NotImplementedError("first / last without an order column over a row-sharded Frame needs the aggregator's raw_result()")
+            a2 = getattr(sa, "AggFirst_" + opf.replace("_non_native", "") + "_" + opf.replace("_non_native", "") + nn)(grid, 1, 1, invert)
         step = self.n if device else self.chunk_size
         if order is None and step < self.n:
             raise NotImplementedError("first/last without an order column over several chunks: the order would be the row's index inside its chunk (src/agg_first.cpp:136)")
@@ -561,15 +568,66 @@ class Frame:
             d = pick(value); a.set_data(0, d, 0); refs.append(d)
             if order is not None:
                 d = pick(order); a.set_data(0, d, 1); refs.append(d)
+            if a2 is not None:
+                d = pick(order); a2.set_data(0, d, 0); a2.set_data(0, d, 1); refs.append(d)
             if sel is not None:
-                m = _as_u8(sel[i1:i2]); a.set_data_mask(0, m); refs.append(m)
+                m = _as_u8(sel[i1:i2]); refs.append(m)
+                for x in (a, a2):
+                    if x is not None:
+                        x.set_data_mask(0, m)
             else:
-                a.clear_data_mask(0)
-            grid.bin(0, [a], i2 - i1)
-        r = a.get_result()
+                for x in (a, a2):
+                    if x is not None:
+                        x.clear_data_mask(0)
+            grid.bin(0, [a] if a2 is None else [a, a2], i2 - i1)
+        r = a.get_result() if comm is None else self._first_last_allranks(a, a2, order is None, invert, comm)
         if not edges:
             r = r[tuple(slice(2, -1) if s["kind"] == "scalar" else slice(0, -2) for s in specs)]
         return r
+
+    def _first_last_allranks(self, a, a2, by_row_index, invert, comm):
+        """per cell the winner over ALL ranks' rows (the cross-rank form of the merge the reference's AggFirst does not have,
+        src/agg_first.cpp:42): MIN (last: MAX) all-reduce of the ranks' winning order values, MIN all-reduce of the rank that holds
+        it (equal orders: the earlier rows win, as `value_order < grid_data_order[i]` keeps the first one seen), and the
+        winner's value as the only non-zero term of a SUM all-reduce of bit patterns.  Three grid-sized all-reduces."""
+        if a2 is None:
+            values, masked, order = (np.array(x) for x in a.raw_result())
+        else:
+            r1, r2 = a.get_result(), a2.get_result()
+            values, masked, order = np.array(np.ma.getdata(r1)), np.array(np.ma.getmaskarray(r1)), np.array(np.ma.getdata(r2))
+        masked = masked.astype(bool)
+        rank, world = comm.rank(), comm.world()
+        if order.dtype == np.uint64:
+            raise NotImplementedError("first / last ordered by a uint64 column over a row-sharded Frame")
+        if by_row_index:  # the order is the row's index: make it global (rows are sharded in rank order)
+            counts = [int(p[0][0]) for p in comm.all_gather_arrays([np.array([self.n], dtype=np.int64)])]
+            order = order.astype(np.int64) + sum(counts[:rank])
+        is_float = order.dtype.kind == "f"
+        o = order.astype(np.float64 if is_float else np.int64)
+        worst = (np.inf if is_float else np.iinfo(np.int64).max) if not invert else (-np.inf if is_float else np.iinfo(np.int64).min)
+        o = np.where(masked, worst, o)
+        best = comm.allreduce_arrays([o], ["max" if invert else "min"])[0]
+        cand = np.where(~masked & (o == best), rank, world).astype(np.int64)
+        winner = comm.allreduce_arrays([cand], ["min"])[0]
+        mine = winner == rank
+        v = np.ascontiguousarray(values)
+        if v.dtype.itemsize == 8:
+            bits = v.view(np.int64)
+        elif v.dtype.kind == "f":
+            bits = v.view(np.int32).astype(np.int64)
+        else:
+            bits = v.astype(np.int64)
+        bits = comm.allreduce_arrays([np.where(mine, bits, 0)], ["sum"])[0]
+        if v.dtype.itemsize == 8:
+            out = bits.view(v.dtype)
+        elif v.dtype.kind == "f":
+            out = bits.astype(np.int32).view(np.float32)
+        else:
+            out = bits.astype(v.dtype)
+        empty = winner == world
+        out = np.array(out)
+        out[empty] = True if out.dtype == np.bool_ else 99  # (what the reference's empty cells read under the mask, src/agg_first.cpp:22-28)
+        return np.ma.array(out, mask=empty)
 
     def first(self, expression, order_expression=None, binby=None, limits=None, shape=128, selection=None, edges=False):
         return self._first_last(False, expression, order_expression, binby, limits, shape, selection, edges)
@@ -581,8 +639,6 @@ class Frame:
         """df.nunique (vaex/dataframe.py:1057-1089 -> vaex.agg.nunique, vaex/agg.py:600-612 -> AggNUnique_<T>): per cell the
         number of distinct values of `expression`; NaN and the missing value count as one value each unless dropped
         (dropna = both).  The rows' {value, cell} pairs are sorted and reduced on the device (vxh_collect_*)."""
-        if self.comm is not None:
-            raise NotImplementedError("nunique / list over a row-sharded Frame (the aggregators have no merge, like the reference's)")
         sa = self.sa
         specs = self._binner_specs(binby or [], limits, shape)
         value = self.columns[expression]
@@ -603,7 +659,8 @@ class Frame:
             else:
                 binners.append(getattr(sa, "BinnerOrdinal_" + pf)(1, s_["column"], s_["count"], s_["min_value"], False, s_["invert"]))
         grid = sa.Grid(binners)
-        a = getattr(sa, "AggNUnique_" + _class_postfix(value))(grid, 1, 1, bool(dropmissing or dropna), bool(dropnan or dropna))
+        make = lambda: getattr(sa, "AggNUnique_" + _class_postfix(value))(grid, 1, 1, bool(dropmissing or dropna), bool(dropnan or dropna))
+        a = make()
         step = self.n if device else self.chunk_size
         for i1 in range(0, self.n, max(1, step)):
             i2 = min(self.n, i1 + step)
@@ -624,6 +681,8 @@ class Frame:
             else:
                 a.clear_data_mask(0)
             grid.bin(0, [a], i2 - i1)
+        if self.comm is not None:
+            a = self._collect_allranks(a, make, self.comm)
         r = np.asarray(a.get_result())
         if not specs:
             return int(r.reshape(-1)[0])
@@ -635,8 +694,6 @@ class Frame:
         """vaex.agg.list (vaex/agg.py:655-670 -> AggList_<T>_<T2>): per cell the values of `expression` in row order, then one NaN
         per NaN row, then one (zero) slot per missing value (unless dropped).  Returns an object array of the grid's shape whose
         elements are the cells' value arrays (vaex wraps the same (offsets, values) pair into an arrow list array)."""
-        if self.comm is not None:
-            raise NotImplementedError("nunique / list over a row-sharded Frame (the aggregators have no merge, like the reference's)")
         sa = self.sa
         specs = self._binner_specs(binby or [], limits, shape)
         value = self.columns[expression]
@@ -658,7 +715,8 @@ class Frame:
                 binners.append(getattr(sa, "BinnerOrdinal_" + pf)(1, s_["column"], s_["count"], s_["min_value"], False, s_["invert"]))
         grid = sa.Grid(binners)
         pf = _class_postfix(value)
-        a = getattr(sa, "AggList_" + pf.replace("_non_native", "") + "_int64" + ("_non_native" if pf.endswith("_non_native") else ""))(grid, 1, 1, bool(dropnan or dropna), bool(dropmissing or dropna))
+        make = lambda: getattr(sa, "AggList_" + pf.replace("_non_native", "") + "_int64" + ("_non_native" if pf.endswith("_non_native") else ""))(grid, 1, 1, bool(dropnan or dropna), bool(dropmissing or dropna))
+        a = make()
         step = self.n if device else self.chunk_size
         for i1 in range(0, self.n, max(1, step)):
             i2 = min(self.n, i1 + step)
@@ -682,6 +740,8 @@ class Frame:
             else:
                 a.clear_data_mask(0)
             grid.bin(0, [a], i2 - i1)
+        if self.comm is not None:
+            a = self._collect_allranks(a, make, self.comm)
         offsets, values = a.list_arrays()
         offsets, values = np.asarray(offsets), np.asarray(values)
         cells = np.empty(len(offsets) - 1, dtype=object)
@@ -693,6 +753,20 @@ class Frame:
         if not edges:
             r = r[tuple(slice(2, -1) if s_["kind"] == "scalar" else slice(0, -2) for s_ in specs)]
         return r
+
+    def _collect_allranks(self, a, make, comm):
+        """AggNUnique / AggList over ALL ranks' rows: every rank's collector state — its {value bits, cell} pairs (nunique: the
+        distinct ones) and the per-cell missing / NaN row counts (vxh_collect_pairs) — is all-gathered as device tensors and
+        merged, in rank order (= row order: what AggList's per-cell sequences need), into a fresh collector on every rank
+        (vxh_collect_merge_pairs).  The cross-rank form of TaskPartAggregation.reduce (vaex/cpu.py:788-796); the reference's own
+        merge of these aggregators is empty / throws."""
+        if not hasattr(a, "pairs"):
+            raise NotImplementedError("nunique / list over a row-sharded Frame need the collector's pairs() / merge_pairs()")
+        parts = comm.all_gather_arrays([np.asarray(x) for x in a.pairs()])
+        merged = make()
+        for p in parts:
+            merged.merge_pairs(*p)
+        return merged
 
     def value_counts(self, expression, dropna=False, dropnan=False, dropmissing=False, ascending=False):
         """df[expression].value_counts() (vaex/expression.py:1029-1130 -> TaskPartValueCounts, vaex/cpu.py:141-283: a
@@ -743,8 +817,6 @@ class Frame:
         packed column, the packed group keys unpacked again.  Groups come out in ascending (k1, k2, ...) order."""
         import torch
         sa = self.sa
-        if comm is not None:
-            raise NotImplementedError("multi-key groupby across ranks")
         cols, dtypes, mins, counts = [], [], [], []
         for k in by:
             c = self.columns[k]
@@ -754,7 +826,11 @@ class Frame:
             if pf.startswith("float") or pf.endswith("_non_native"):
                 raise NotImplementedError("groupby on float / non-native keys")
             data = c if _is_device(c) else np.ascontiguousarray(c.view("u1") if c.dtype == np.bool_ else c)
-            kmin, kmax = sa.minmax_int(data, None, _DT_CODE[pf], False) if self.n else (0, 0)
+            kmin, kmax = sa.minmax_int(data, None, _DT_CODE[pf], False) if self.n else ((0, 0) if comm is None else (2**63 - 1, -2**63))
+            if comm is not None:   # ranks pack with the SAME minima and multipliers: the global key ranges
+                kmin, kmax = comm.minmax(int(kmin), int(kmax))
+                if kmin > kmax:
+                    kmin, kmax = 0, 0
             cols.append(data); dtypes.append(_DT_CODE[pf]); mins.append(int(kmin)); counts.append(int(kmax) - int(kmin) + 1)
         total = 1
         for n in counts:
@@ -774,9 +850,9 @@ class Frame:
                 sub[d.column] = c if _is_device(c) else torch.from_numpy(np.ascontiguousarray(c)).cuda()
             if d.selection is not None:
                 raise NotImplementedError("multi-key groupby with a selection")
-        f = Frame(sub, chunk_size=self.chunk_size, nthreads=self.nthreads, superagg=sa)
+        f = Frame(sub, chunk_size=self.chunk_size, nthreads=self.nthreads, superagg=sa, comm=comm)
         f.direct_groupby_cells = self.direct_groupby_cells
-        res = f.groupby("__packed__", agg_spec, reduce=reduce)
+        res = f.groupby("__packed__", agg_spec, reduce=reduce, comm=comm)
         self.last_groupby_info = getattr(f, "last_groupby_info", None)
         pk = np.asarray(res.pop("__packed__")).astype(np.int64)
         out = {}
@@ -934,14 +1010,30 @@ class Frame:
             values.append(col if _is_device(col) else np.ascontiguousarray(col))
         if not values:  # only count(*): the pass still needs a payload column; let the general path do it
             return None
+        res, failed = None, None
         try:
             res = sa.groupby_run(key if _is_device(key) else np.ascontiguousarray(key), values, _DT_CODE[pf]) if self.n else None
-            if comm is not None:
-                res = self._groupby_fused_allranks(res, len(values), comm)
         except RuntimeError as e:
             if not str(e).startswith("groupby"):   # (anything the pass itself reports: too many / too skewed keys, no room for its queues)
                 raise
+            failed = e
+        if comm is not None:
+            # every rank takes the same branch: one rank's shard may be too skewed for the partitioned pass while the others'
+            # are fine — then ALL of them answer through ordered_set + BinnerHash (whose collectives must match up)
+            if not comm.all_agree(failed is None):
+                return None
+            try:
+                res = self._groupby_fused_allranks(res, len(values), comm)
+            except RuntimeError as e:
+                if not str(e).startswith("groupby"):
+                    raise
+                failed = e
+            if not comm.all_agree(failed is None):
+                return None
+        elif failed is not None:
             return None  # -> ordered_set + BinnerHash
+        if res is None:   # (no rank holds a row)
+            return {by: np.array([], dtype=np.int64), **{n: np.array([]) for n in names}}
         which = {"sum": sa.GB_SUM, "mean": sa.GB_MEAN, "var": sa.GB_VAR, "std": sa.GB_STD}
         out = {by: np.asarray(res.column(sa.GB_KEYS))}
         for name, d in zip(names, descs):
@@ -953,21 +1045,23 @@ class Frame:
         return out
 
     def _groupby_fused_allranks(self, res, nv, comm):
-        """every rank's partial groups -> the groups of all ranks' rows (the same kernels in MERGE mode)"""
-        import torch.distributed as dist
+        """every rank's partial groups -> the groups of all ranks' rows: the partial columns {key, rows, count_j, sum_j, sum2_j}
+        are all-gathered as tensors of the backend's device (dist.Comm.all_gather_arrays: RCCL over xGMI on GPUs) and merged
+        by the same two kernels in MERGE mode on every rank (the cross-rank form of the reference's per-thread merge,
+        vaex/cpu.py:788-796).  A rank without rows contributes empty columns."""
         sa = self.sa
-        if not dist.is_initialized() or dist.get_world_size(comm.group) == 1:
+        if comm.world() == 1:
             return res
-        mine = None
-        if res is not None:
-            mine = dict(k=np.array(res.column(sa.GB_KEYS)), r=np.array(res.column(sa.GB_ROWS)), c=[np.array(res.column(sa.GB_COUNT, j)) for j in range(nv)],
-                        s=[np.array(res.column(sa.GB_SUM, j)) for j in range(nv)], s2=[np.array(res.column(sa.GB_SUM2, j)) for j in range(nv)])
-        parts = [None] * dist.get_world_size(comm.group)
-        dist.all_gather_object(parts, mine, group=comm.group)
-        parts = [p for p in parts if p is not None]
-        cat = lambda f: np.concatenate([f(p) for p in parts])
-        return sa.groupby_merge(cat(lambda p: p["k"]), cat(lambda p: p["r"]), [cat(lambda p, j=j: p["c"][j]) for j in range(nv)],
-                                [cat(lambda p, j=j: p["s"][j]) for j in range(nv)], [cat(lambda p, j=j: p["s2"][j]) for j in range(nv)])
+        i8, f8 = np.zeros(0, dtype=np.int64), np.zeros(0, dtype=np.float64)
+        mine = [np.asarray(res.column(sa.GB_KEYS)) if res is not None else i8, np.asarray(res.column(sa.GB_ROWS)) if res is not None else i8]
+        for j in range(nv):
+            mine += [np.asarray(res.column(c, j)) if res is not None else (i8 if c == sa.GB_COUNT else f8) for c in (sa.GB_COUNT, sa.GB_SUM, sa.GB_SUM2)]
+        parts = comm.all_gather_arrays(mine)
+        cat = lambda i: np.concatenate([p[i] for p in parts])
+        keys = cat(0)
+        if len(keys) == 0:
+            return None
+        return sa.groupby_merge(keys, cat(1), [cat(2 + 3 * j) for j in range(nv)], [cat(3 + 3 * j) for j in range(nv)], [cat(4 + 3 * j) for j in range(nv)])
 
     def _agg_hash(self, descs, by, pf, hm, reduce, nuniq=None):
         """Same fused pass with a BinnerHash on the key column (cells: [unknown, ordinal 0..N-1, null])."""

@@ -576,6 +576,36 @@ struct PyCollect {
         check(rc);
         return py::make_tuple(offsets, values);
     }
+    // (values as uint64 canonical bits, cells uint32, missing rows per cell int64, NaN rows per cell int64): vxh_collect_pairs
+    py::tuple pairs() {
+        uint64_t cells = 1;
+        for (auto v : grid->shapes()) cells *= v;
+        uint64_t n = 0;
+        py::array_t<int64_t> nulls((ssize_t)cells), nans((ssize_t)cells);
+        check(vxh_collect_pairs(h, &n, nullptr, nullptr, nulls.mutable_data(), nans.mutable_data()));
+        py::array_t<uint64_t> values((ssize_t)n);
+        py::array_t<uint32_t> cell((ssize_t)n);
+        int rc;
+        {
+            py::gil_scoped_release release;
+            rc = vxh_collect_pairs(h, &n, values.mutable_data(), cell.mutable_data(), nulls.mutable_data(), nans.mutable_data());
+        }
+        check(rc);
+        if ((uint64_t)values.size() != n) throw std::runtime_error("collector changed while its pairs were read");
+        return py::make_tuple(values, cell, nulls, nans);
+    }
+    void merge_pairs(py::array_t<uint64_t, py::array::c_style | py::array::forcecast> values, py::array_t<uint32_t, py::array::c_style | py::array::forcecast> cell,
+                     py::array_t<int64_t, py::array::c_style | py::array::forcecast> nulls, py::array_t<int64_t, py::array::c_style | py::array::forcecast> nans) {
+        uint64_t cells = 1;
+        for (auto v : grid->shapes()) cells *= v;
+        if (values.size() != cell.size() || (uint64_t)nulls.size() != cells || (uint64_t)nans.size() != cells) throw std::runtime_error("merge_pairs: inconsistent arguments");
+        int rc;
+        {
+            py::gil_scoped_release release;
+            rc = vxh_collect_merge_pairs(h, (uint64_t)values.size(), values.data(), cell.data(), nulls.data(), nans.data());
+        }
+        check(rc);
+    }
     py::object get_result() {
         if (mode == 0) return nunique_result();
         py::tuple r = list_arrays();
@@ -959,6 +989,8 @@ PYBIND11_MODULE(superagg, m) {
     py::class_<PyCollect>(m, "AggCollect")
         .def(py::init<PyGrid *, int, int, bool, bool, int, int, bool>(), py::keep_alive<1, 2>(), py::arg("grid"), py::arg("grids"), py::arg("threads"), py::arg("a"), py::arg("b"),
              py::arg("mode"), py::arg("dtype"), py::arg("flip") = false)
+        .def("pairs", &PyCollect::pairs)
+        .def("merge_pairs", &PyCollect::merge_pairs)
         .def("set_data", &PyCollect::set_data, py::arg("thread"), py::arg("ar"), py::arg("index") = 0)
         .def("set_data_mask", &PyCollect::set_data_mask)
         .def("clear_data_mask", &PyCollect::clear_data_mask)

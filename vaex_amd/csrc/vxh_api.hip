@@ -2409,6 +2409,81 @@ int vxh_collect_list_result(vxh_collect *c, int64_t *offsets_out, void *values_o
     VXH_API_END
 }
 
+// the collector's state for an exchange between ranks: the compacted pairs and the per-cell missing / NaN row counts
+int vxh_collect_pairs(vxh_collect *c, uint64_t *n_out, uint64_t *values_out, uint32_t *cells_out, int64_t *null_rows_out, int64_t *nan_rows_out) {
+    VXH_API_BEGIN
+    std::lock_guard<std::mutex> lock(c->mutex);
+    const uint64_t cells = c->grid->length1d;
+    if (!c->null_rows) { // nothing binned yet
+        *n_out = 0;
+        if (null_rows_out) std::fill(null_rows_out, null_rows_out + cells, (int64_t)0);
+        if (nan_rows_out) std::fill(nan_rows_out, nan_rows_out + cells, (int64_t)0);
+        return 0;
+    }
+    ensure_device_ready();
+    Slot &slot = get_slot(0);
+    order_after_producers(slot);
+    collect_compact(c, slot);
+    // (nunique: dead pairs — rows outside the selection, NaN / missing rows — carry cell ~0 and sort behind the live ones;
+    //  the flag + select pass of collect_compact has dropped them)
+    *n_out = c->n;
+    if (values_out && c->n) HIP_CHECK(hipMemcpyAsync(values_out, c->val, c->n * 8, hipMemcpyDeviceToHost, slot.stream));
+    if (cells_out && c->n) HIP_CHECK(hipMemcpyAsync(cells_out, c->cell, c->n * 4, hipMemcpyDeviceToHost, slot.stream));
+    if (null_rows_out) HIP_CHECK(hipMemcpyAsync(null_rows_out, c->null_rows, cells * 8, hipMemcpyDeviceToHost, slot.stream));
+    if (nan_rows_out) HIP_CHECK(hipMemcpyAsync(nan_rows_out, c->nan_rows, cells * 8, hipMemcpyDeviceToHost, slot.stream));
+    HIP_CHECK(hipStreamSynchronize(slot.stream));
+    VXH_API_END
+}
+
+// pairs exported by another collector over the same grid: appended (list: behind the present rows of every cell — the
+// compaction's sort by cell is stable), their missing / NaN row counts added
+int vxh_collect_merge_pairs(vxh_collect *c, uint64_t n, const uint64_t *values, const uint32_t *cells_in, const int64_t *null_rows, const int64_t *nan_rows) {
+    VXH_API_BEGIN
+    std::lock_guard<std::mutex> lock(c->mutex);
+    ensure_device_ready();
+    Slot &slot = get_slot(0);
+    order_after_producers(slot);
+    const uint64_t cells = c->grid->length1d;
+    for (uint64_t i = 0; i < n; i++)
+        if (cells_in[i] >= cells) throw std::runtime_error("vxh_collect_merge_pairs: cell index outside the grid");
+    if (!c->null_rows) {
+        HIP_CHECK(hipMalloc(&c->null_rows, cells * 8));
+        HIP_CHECK(hipMalloc(&c->nan_rows, cells * 8));
+        HIP_CHECK(hipMemsetAsync(c->null_rows, 0, cells * 8, slot.stream));
+        HIP_CHECK(hipMemsetAsync(c->nan_rows, 0, cells * 8, slot.stream));
+    }
+    if (c->n + n > c->cap) {
+        const uint64_t cap = std::max<uint64_t>(c->n + n, c->cap + c->cap / 2);
+        DevBuf nv(cap * 8), nc(cap * 4);
+        if (c->n) {
+            HIP_CHECK(hipMemcpyAsync(nv.p, c->val, c->n * 8, hipMemcpyDeviceToDevice, slot.stream));
+            HIP_CHECK(hipMemcpyAsync(nc.p, c->cell, c->n * 4, hipMemcpyDeviceToDevice, slot.stream));
+        }
+        HIP_CHECK(hipStreamSynchronize(slot.stream));
+        (void)hipFree(c->val); (void)hipFree(c->cell);
+        c->val = (uint64_t *)nv.p; c->cell = (uint32_t *)nc.p; c->cap = cap;
+        nv.p = nc.p = nullptr;
+    }
+    if (n) {
+        HIP_CHECK(hipMemcpyAsync(c->val + c->n, values, n * 8, hipMemcpyHostToDevice, slot.stream));
+        HIP_CHECK(hipMemcpyAsync(c->cell + c->n, cells_in, n * 4, hipMemcpyHostToDevice, slot.stream));
+        c->n += n;
+    }
+    // the row counts: host add (cells x 8 B, once per merged rank)
+    std::vector<unsigned long long> a(cells), b(cells);
+    HIP_CHECK(hipMemcpyAsync(a.data(), c->null_rows, cells * 8, hipMemcpyDeviceToHost, slot.stream));
+    HIP_CHECK(hipMemcpyAsync(b.data(), c->nan_rows, cells * 8, hipMemcpyDeviceToHost, slot.stream));
+    HIP_CHECK(hipStreamSynchronize(slot.stream));
+    for (uint64_t j = 0; j < cells; j++) {
+        if (null_rows) a[j] += (unsigned long long)null_rows[j];
+        if (nan_rows) b[j] += (unsigned long long)nan_rows[j];
+    }
+    HIP_CHECK(hipMemcpyAsync(c->null_rows, a.data(), cells * 8, hipMemcpyHostToDevice, slot.stream));
+    HIP_CHECK(hipMemcpyAsync(c->nan_rows, b.data(), cells * 8, hipMemcpyHostToDevice, slot.stream));
+    HIP_CHECK(hipStreamSynchronize(slot.stream));
+    VXH_API_END
+}
+
 // a column where the helper kernels below can read it: device pointers as they are, host arrays copied into `tmp`
 static const void *on_device(Slot &slot, const void *p, size_t bytes, int mem, std::unique_ptr<DevBuf> &tmp) {
     if (mem == VXH_MEM_DEVICE || !bytes) return p;

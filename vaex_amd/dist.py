@@ -34,7 +34,14 @@ def allreduce_aggs(aggs, group=None, force=False):
 
     "nccl" backend (RCCL): the device grids are reduced in place over xGMI.  Any other backend ("gloo" in
     the CPU tests): the grids go through the aggregators' host buffers.  After the call every rank's
-    aggregators hold the global result (get_result() returns it)."""
+    aggregators hold the global result (get_result() returns it).
+
+    Stream hand-off (the grids belong to the library's streams, RCCL runs on torch's): asking an aggregator for its
+    `__cuda_array_interface__` is vxh_agg_device_grid — it DRAINS the device (hipDeviceSynchronize), folds the replicas on
+    the library's stream and waits for that fold before it returns (vxh_api.hip agg_fold_device), so the pointer RCCL gets
+    is final and nothing of the library is in flight.  On the way back every all-reduce is waited for and the device
+    synchronised before `device_touch()` hands the grid back to the library.  Both hand-offs are host-side full stops; the
+    grids are 0.5 - 18 MB, once per pass."""
     import torch
     import torch.distributed as dist
     if not dist.is_initialized() or (dist.get_world_size(group) == 1 and not force):
@@ -56,12 +63,13 @@ def allreduce_aggs(aggs, group=None, force=False):
         agg.device_touch()
 
 
-def allreduce_aggs_host(aggs, group=None):
+def allreduce_aggs_host(aggs, group=None, reduce_arrays=None):
     """Same reduce through the (grids, *shapes) host buffers of the aggregators (buffer protocol of the
-    superagg surface, src/agg_base.hpp:106-125): grid 0 receives the global result, the others the identity."""
+    superagg surface, src/agg_base.hpp:106-125): grid 0 receives the global result, the others the identity.
+    reduce_arrays(arrays, ops) -> arrays: the exchange itself (default: allreduce_results over `group`)."""
     ops = [agg_reduce_op(a) for a in aggs]
     local = [np.array(a.get_result()) for a in aggs]
-    reduced = allreduce_results(local, ops, group)
+    reduced = reduce_arrays(local, ops) if reduce_arrays is not None else allreduce_results(local, ops, group)
     for a, r, op in zip(aggs, reduced, ops):
         buf = np.asarray(a)
         buf[0] = r
@@ -162,14 +170,61 @@ class Comm:
         dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
         return float(t[0]), -float(t[1])
 
+    def world(self):
+        import torch.distributed as dist
+        return dist.get_world_size(self.group) if dist.is_initialized() else 1
+
+    def rank(self):
+        import torch.distributed as dist
+        return dist.get_rank(self.group) if dist.is_initialized() else 0
+
+    def all_gather_arrays(self, arrays):
+        """every rank's list of 1-d numpy arrays (same dtypes on every rank, any lengths) -> [rank][array].  The bytes travel as
+        tensors of the backend's device (RCCL over xGMI on GPUs: one all_gather of the lengths, one padded all_gather per
+        array) — no pickling, no host round trip of the collective itself."""
+        import torch
+        import torch.distributed as dist
+        arrays = [np.ascontiguousarray(a) for a in arrays]
+        world = self.world()
+        if world == 1:
+            return [arrays]
+        dev = self._device()
+        lens = torch.tensor([a.nbytes for a in arrays], dtype=torch.int64, device=dev)
+        all_lens = [torch.empty_like(lens) for _ in range(world)]
+        dist.all_gather(all_lens, lens, group=self.group)
+        all_lens = [t.cpu().tolist() for t in all_lens]
+        out = [[] for _ in range(world)]
+        for j, a in enumerate(arrays):
+            longest = max(l[j] for l in all_lens)
+            buf = torch.zeros(max(longest, 1), dtype=torch.uint8, device=dev)
+            if a.nbytes:
+                buf[:a.nbytes] = torch.from_numpy(a.reshape(-1).view(np.uint8)).to(dev)
+            parts = [torch.empty_like(buf) for _ in range(world)]
+            dist.all_gather(parts, buf, group=self.group)
+            for r in range(world):
+                out[r].append(parts[r][:all_lens[r][j]].cpu().numpy().view(a.dtype).copy())
+        return out
+
+    def all_agree(self, ok):
+        """True when `ok` holds on EVERY rank (one MIN all-reduce): ranks must take the same branch before a collective"""
+        import torch
+        import torch.distributed as dist
+        if self.world() == 1:
+            return bool(ok)
+        t = torch.tensor([1 if ok else 0], dtype=torch.int64, device=self._device())
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
+        return bool(int(t[0]))
+
     def union_keys(self, keys):
         """sorted union of the ranks' distinct keys (<= 1e6 x 8 B per rank in the BASELINE config)"""
-        import torch.distributed as dist
-        if not dist.is_initialized() or dist.get_world_size(self.group) == 1:
+        if self.world() == 1:
             return keys
-        parts = [None] * dist.get_world_size(self.group)
-        dist.all_gather_object(parts, np.asarray(keys), group=self.group)
-        return np.unique(np.concatenate(parts))
+        parts = self.all_gather_arrays([np.asarray(keys)])
+        return np.unique(np.concatenate([p[0] for p in parts]))
 
     def allreduce(self, aggs):
         allreduce_aggs(aggs, self.group)
+
+    def allreduce_arrays(self, arrays, ops):
+        """element-wise 'sum' / 'min' / 'max' of host arrays over the ranks (tensors of the backend's device underneath)"""
+        return allreduce_results(arrays, ops, self.group)
