@@ -55,7 +55,7 @@ x = rng.normal(0, 1, n); x[::1000] = np.nan
 kf = rng.integers(0, 50, n).astype("f8"); kf[::777] = np.nan
 im = np.ma.array(rng.integers(0, 500, n).astype("i4"), mask=rng.random(n) < 0.03)   # thousands of missing rows per group
 df = vaex.from_arrays(x=x, y=rng.normal(0, 1, n), v=rng.normal(3, 2, n), k=rng.integers(0, 9, n), kb=rng.integers(-10**12, 10**12, n) // 10**9 * 10**9,
-                      kf=kf, i=rng.integers(-100, 100, n).astype("i4"), im=im, s=np.array(["a", "bb", None, "dddd"], dtype=object)[rng.integers(0, 4, n)])
+                      kf=kf, i=rng.integers(-100, 100, n).astype("i4"), im=im, f4=rng.choice(np.array([0.1, 0.3, 0.30000001, 0.5, 0.7], dtype="f4"), n), s=np.array(["a", "bb", None, "dddd"], dtype=object)[rng.integers(0, 4, n)])
 lim2 = [[-4, 4], [-4, 4]]
 def two_keys(d):
     k, i = d["k"].to_numpy(), d["i"].to_numpy()
@@ -90,8 +90,17 @@ hot["groupby_nunique_drop"] = lambda d: by_key(d.groupby("k", agg={"um": vaex.ag
                                                                     "u0": vaex.agg.nunique("im")}), "k", ["um", "ua", "u0"])
 # (dropmissing: the slots the reference appends per unselected row are uninitialised memory, src/agg_list.cpp:68-71)
 hot["groupby_list_sel"] = lambda d: (lambda g: [sorted(c) for c in g["l"].tolist()])(d.groupby("k", agg={"l": vaex.agg.list("i", selection="v > 5", dropmissing=True)}).sort("k"))
+# selections: comparison expressions run as device predicates (vaex_amd/vaex_selection.py); a named selection keeps vaex's host mask
+hot["count_sel2"] = lambda d: d.count(binby=["x", "y"], limits=lim2, shape=16, selection="(x > 0) & (v < 3.5)")
+hot["sum_sel_int"] = lambda d: d.sum("v", binby="y", limits=[-4, 4], shape=8, selection="~(i >= 3) | (x < -1)")
+hot["f32_boundary"] = lambda d: d.count(binby="y", limits=[-4, 4], shape=4, selection="f4 <= 0.3")   # numpy compares in float32: float32(0.3) <= 0.3
+def _named(d):
+    d.select("v > 4")
+    return d.count(binby="x", limits=[-4, 4], shape=8, selection=True)
+hot["named_sel"] = _named
 fallback = {   # not offered by the HIP classes: must run on vaex's own C++ after install(), GPU or not
   "count_string": lambda d: d.count("s", binby="y", limits=[-4, 4], shape=4),   # AggCount_string
+  "count_string_sel": lambda d: d.count("s", binby="y", limits=[-4, 4], shape=4, selection="v > 3"),   # ... with a planned predicate: numpy inside process
 }
 has_gpu = hip.device_count() > 0
 got = {}
@@ -105,7 +114,8 @@ if not has_gpu:
         else:
             raise SystemExit("computed without a GPU: " + name)
 else:
-    from vaex_amd import vaex_groupby as vg
+    from vaex_amd import vaex_groupby as vg, vaex_selection as vsel
+    seen_device = 0
     for name, fn in hot.items():
         del used[:]
         vg.last.clear()
@@ -119,6 +129,11 @@ else:
         if whole:
             assert ("gb_scatter" in vg.last["kernel"]) == (name == "groupby_sparse") and ("part_scatter" in vg.last["kernel"] or "bin_" in vg.last["kernel"] or name == "groupby_sparse"), (name, vg.last)
         print("ok-backend hip", name, len(used), vg.last.get("kernel", ""))
+        if name in ("mean_sel", "count_sel2", "sum_sel_int", "f32_boundary"):
+            assert vsel.stats["device_chunks"] > seen_device, (name, vsel.stats)   # the predicate ran on the device
+        elif name in ("named_sel", "first_sel", "groupby_list_sel"):   # (a named selection; aggregators that read host masks only)
+            assert vsel.stats["device_chunks"] == seen_device, (name, vsel.stats)  # vaex's own mask
+        seen_device = vsel.stats["device_chunks"]
 for name, fn in fallback.items():
     del used[:]
     got[name] = fn(df)
@@ -227,15 +242,15 @@ def test_unmodified_vaex_without_a_gpu_fails_loudly_and_falls_back():
     if vaex_amd.superagg.device_count() > 0:
         pytest.skip("a GPU is visible: see the -m gpu test")
     out = _run(20000, 0, 300)
-    assert out.count("ok-loud-failure") == 19 and out.count("ok-fallback") == 1, out
+    assert out.count("ok-loud-failure") == 23 and out.count("ok-fallback") == 2, out
 
 
 @pytest.mark.gpu
 @pytest.mark.skipif(not os.path.isdir(os.path.join(PKG, "vaex")), reason="real vaex package not built (oracle/build_ref.sh needs /root/reference)")
 def test_unmodified_vaex_drives_the_hip_classes_on_the_gpu():
     out = _run(300_000, int(os.environ.get("VAEX_DROPIN_TIMING_ROWS", "100000000")), 900)
-    assert out.count("ok-parity") == 19 and out.count("ok-fallback") == 1, out
-    assert out.count("ok-backend hip") == 19 and out.count("ok-backend cpu") == 1, out
+    assert out.count("ok-parity") == 23 and out.count("ok-fallback") == 2, out
+    assert out.count("ok-backend hip") == 23 and out.count("ok-backend cpu") == 2, out
     line = [l for l in out.splitlines() if l.startswith("TIMING")]
     assert line, out
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)

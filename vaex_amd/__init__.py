@@ -82,7 +82,7 @@ _installed = {}
 AUTO_CHUNK_ROWS_MAX = 1 << 26   # install(chunk_size="auto"): upper bracket of vaex's automatic chunk size (rows)
 
 
-def install(vaex_module=None, legacy=True, hash_sets=True, chunk_size="auto", groupby=True):
+def install(vaex_module=None, legacy=True, hash_sets=True, chunk_size="auto", groupby=True, selections=True):
     """Plug the HIP kernels into an unmodified vaex.
 
     * `vaex.superagg` becomes a `_Backend` and the task-part registry entry "aggregations" (vaex/cpu.py:629-631,
@@ -100,6 +100,8 @@ def install(vaex_module=None, legacy=True, hash_sets=True, chunk_size="auto", gr
       "auto" (default) raises the UPPER bracket, vaex.settings.main.chunk.size_max, to AUTO_CHUNK_ROWS_MAX = 64 Mi rows unless
       the user changed it, so that every pool thread gets one chunk of rows / threads rows up to that size and nobody has to
       pass anything; an integer sets vaex.settings.main.chunk.size itself; None leaves vaex's chunking alone.
+    * selections=True: selection expressions of the comparison subset (`column <op> number` joined by & | ~, <= 4 terms) are
+      evaluated on the device instead of numpy (vaex_amd/vaex_selection.py); everything else keeps vaex's host masks.
     * groupby=True: df.groupby(<integer key columns>, agg=count / sum / mean / var / std ...) is answered by the device
       groupby (vaex_amd/vaex_groupby.py) instead of vaex's two passes; everything else falls through to vaex's own code."""
     import sys
@@ -122,10 +124,12 @@ def install(vaex_module=None, legacy=True, hash_sets=True, chunk_size="auto", gr
 
         @classmethod
         def decode(cls, encoding, spec, df, nthreads):
+            from . import vaex_selection
             with backend.use("hip"):
                 try:
                     part = base.decode.__func__(cls, encoding, spec, df, nthreads)
                     part.backend_used = "hip"
+                    vaex_selection.attach(part, "hip", superagg, nthreads)
                     return part
                 except (ValueError, TypeError, NotImplementedError) as e:
                     if "Could not find a class" not in str(e) and not isinstance(e, NotImplementedError):
@@ -133,7 +137,14 @@ def install(vaex_module=None, legacy=True, hash_sets=True, chunk_size="auto", gr
             with backend.use("cpu"):
                 part = base.decode.__func__(cls, encoding, spec, df, nthreads)
                 part.backend_used = "cpu"
+                vaex_selection.attach(part, "cpu", superagg, nthreads)
                 return part
+
+        def process(self, thread_index, i1, i2, filter_mask, selection_masks, blocks):
+            # selections planned for the device (vaex_amd/vaex_selection.py): their columns' chunks ride behind the blocks
+            from . import vaex_selection
+            selection_masks, blocks = vaex_selection.before_process(self, thread_index, selection_masks, blocks)
+            return base.process(self, thread_index, i1, i2, filter_mask, selection_masks, blocks)
 
     vaex.cpu.register(TaskPartAggregationHip)
     _installed["task_hip"] = TaskPartAggregationHip
@@ -168,6 +179,9 @@ def install(vaex_module=None, legacy=True, hash_sets=True, chunk_size="auto", gr
     if groupby:
         from . import vaex_groupby
         vaex_groupby.install(vaex_module, _installed)
+    if selections:
+        from . import vaex_selection
+        vaex_selection.install(vaex_module, _installed)
     if hash_sets:
         import copyreg
         import vaex.hash
@@ -212,6 +226,9 @@ def uninstall():
     if "groupby" in _installed:
         from . import vaex_groupby
         vaex_groupby.uninstall(vaex_module, _installed)
+    if "selection" in _installed:
+        from . import vaex_selection
+        vaex_selection.uninstall(vaex_module, _installed)
     _installed.clear()
 
 

@@ -1,0 +1,155 @@
+"""Selections of an unmodified vaex evaluated on the device (SURVEY §8 f.2 through the reference's own API).
+
+vaex evaluates `df.count(..., selection="(x > 0) & (v < 3.5)")` per chunk with numpy on the pool threads
+(vaex/execution.py:530-549 `selections = [... selection_scope.evaluate(s) for s in task.selections]`, vaex/scopes.py:138-177)
+and hands TaskPartAggregation.process one boolean array per aggregation, which becomes the aggregator's keep-mask
+(vaex/cpu.py:735-784).  With vaex_amd.install() the comparison subset of vaex_amd.predicate (<= 4 terms `column <op> number`
+joined by & | ~) never becomes a host array:
+
+  * TaskAggregations.add_aggregation_operation (vaex/tasks.py:516-541) is wrapped: when an aggregation's selection is such an
+    expression over real numeric columns, its entry in `task.selections` becomes None — the executor then evaluates nothing
+    for it — and the predicate's columns join the TAIL of `task.expressions_all`, so that the executor loads their chunks
+    like any other column the task reads and hands them to the task part behind the blocks it already expects;
+  * the registered task part (TaskPartAggregationHip, vaex_amd/__init__.py) finds the same predicates from the encoded
+    aggregations, attaches ONE device Selection per distinct predicate to the aggregators concerned (vxh_agg_set_selection:
+    rows are kept where the predicate holds AND the data mask, if any, is set) and registers the predicate columns' chunks
+    per thread slot in `process`;
+  * a task that ends up on vaex's own C++ (an aggregator the HIP classes do not offer) evaluates the same predicate with numpy
+    in `process` and passes the mask on — nothing is lost, only not accelerated.
+
+Named selections (df.select(...), selection=True / 'default'), selections with missing-value columns, and expressions outside
+the subset keep vaex's host evaluation untouched."""
+import numpy as np
+
+from . import predicate as _predicate
+
+#: counters for tests: predicates planned at task-build time, chunks whose predicate ran on the device / on the host fallback
+stats = {"planned": 0, "device_chunks": 0, "host_chunks": 0}
+
+_WITH_DEVICE_SELECTION = ("AggCount", "AggSum", "AggSumMoment", "AggMin", "AggMax")   # (vxh_agg_set_selection)
+_NUMERIC = ("float64", "float32", "int64", "int32", "int16", "int8", "uint64", "uint32", "uint16", "uint8", "bool")
+
+
+def plan_for(df, descriptor):
+    """the Predicate an aggregation's selection compiles to, or None (then vaex evaluates the selection itself)"""
+    sel = getattr(descriptor, "selection", None)
+    if sel is None or sel is False or sel is True or isinstance(sel, (list, tuple)):
+        return None
+    if getattr(descriptor, "name", None) not in _WITH_DEVICE_SELECTION:   # AggFirst / AggList / AggNUnique read host masks only
+        return None
+    sel = str(sel)
+    if df.has_selection(sel):   # a named selection (history, modes): vaex's business
+        return None
+    known = {}
+    for name, ar in df.columns.items():
+        if isinstance(ar, np.ndarray) and not np.ma.isMaskedArray(ar) and ar.ndim == 1 and ar.dtype.isnative and ar.dtype.name in _NUMERIC:
+            known[name] = ar
+    try:
+        pred = _predicate.compile_selection(sel, known)
+    except _predicate.Unsupported:
+        return None
+    return pred
+
+
+def extras_of(df, descriptors):
+    """[(aggregation index, Predicate)], and the predicate columns in first-seen order (= the tail of task.expressions_all)"""
+    plans, extras = [], []
+    for i, d in enumerate(descriptors):
+        p = plan_for(df, d)
+        if p is not None:
+            plans.append((i, p))
+            for c in p.columns:
+                if c not in extras:
+                    extras.append(c)
+    return plans, extras
+
+
+def install(vaex_module, state):
+    import vaex.tasks
+    cls = vaex.tasks.TaskAggregations
+    original = cls.add_aggregation_operation
+
+    def add_aggregation_operation(self, aggregator_descriptor):
+        extras = self.__dict__.get("_hip_extras", [])
+        if extras:   # (they sit at the tail: take them off while vaex appends this aggregation's own expressions)
+            del self.expressions_all[len(self.expressions_all) - len(extras):]
+        task = original(self, aggregator_descriptor)
+        pred = plan_for(self.df, aggregator_descriptor)
+        if pred is not None:
+            self.selections[-1] = None   # the executor evaluates nothing for this aggregation (vaex/execution.py:549)
+            stats["planned"] += 1
+            for c in pred.columns:
+                if c not in extras:
+                    extras.append(c)
+        self.__dict__["_hip_extras"] = extras
+        if extras:
+            self.expressions_all.extend(extras)
+            self.dtypes = {expr: self.df.data_type(expr).index_type for expr in self.expressions_all}
+        return task
+
+    cls.add_aggregation_operation = add_aggregation_operation
+    state["selection"] = (cls, original)
+
+
+def uninstall(vaex_module, state):
+    cls, original = state["selection"]
+    cls.add_aggregation_operation = original
+
+
+def attach(part, backend_used, superagg, nthreads):
+    """called by the task part's decode: remember the predicates, and (HIP classes) hand them to the aggregators"""
+    plans, extras = extras_of(part.df, part.aggregation_descriptions)
+    part._hip_plans, part._hip_extras, part._hip_selections = plans, extras, []
+    if not plans:
+        return
+    objs = {}
+    # global index of an aggregation's (single) selection in the executor's `selections` list: one entry per aggregation
+    # without a list of selections (vaex/tasks.py:528-535); lists of selections never get a plan
+    position = 0
+    positions = []
+    for desc, selections, aggs, waslist in part.aggregations:
+        positions.append(position)
+        position += len(selections)
+    for i, pred in plans:
+        desc, selections, aggs, waslist = part.aggregations[i]
+        entry = dict(index=positions[i], pred=pred, sel=None)
+        if backend_used == "hip":
+            key = pred.key()
+            if key not in objs:
+                dtypes = [_predicate.dtype_code(part.df.columns[c].dtype) for c in pred.columns]
+                objs[key] = superagg.Selection(nthreads, dtypes, [(c, op, v) for c, op, v in pred.terms], pred.truth)
+            entry["sel"] = objs[key]
+            for a in aggs:
+                a.set_selection(objs[key])
+            # the aggregation is "unselected" for the base class from here on: no host mask is expected for it
+            part.aggregations[i] = (desc, [None] * len(selections), aggs, waslist)
+        part._hip_selections.append(entry)
+
+
+def before_process(part, thread_index, selection_masks, blocks):
+    """-> (selection_masks, blocks) for the base class's process: the predicate columns' chunks go to the device selections
+    (or, on vaex's own C++, become numpy masks); the blocks lose their tail"""
+    extras = part._hip_extras
+    if not extras:
+        return selection_masks, blocks
+    nbase = len(blocks) - len(extras)
+    tail = dict(zip(extras, blocks[nbase:]))
+    seen = set()
+    for entry in part._hip_selections:
+        pred, idx = entry["pred"], entry["index"]
+        if selection_masks[idx] is not None:   # (the executor evaluated it after all: use its mask)
+            continue
+        if entry["sel"] is not None:
+            if id(entry["sel"]) not in seen:
+                seen.add(id(entry["sel"]))
+                for ci, c in enumerate(pred.columns):
+                    d = np.ascontiguousarray(np.asarray(tail[c]))
+                    entry["sel"].set_data(thread_index, ci, d.view("u1") if d.dtype == np.bool_ else d)
+                    part._hip_refs = getattr(part, "_hip_refs", {})
+                    part._hip_refs[(thread_index, id(entry["sel"]), ci)] = d   # (borrowed until the slot's next chunk)
+                stats["device_chunks"] += 1
+        else:
+            selection_masks = list(selection_masks)
+            selection_masks[idx] = pred.numpy_mask({c: np.asarray(tail[c]) for c in pred.columns})
+            stats["host_chunks"] += 1
+    return selection_masks, blocks[:nbase]
