@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""One BASELINE config, a few passes on device-resident columns — for rocprofv3 (kernel stats / --pmc FETCH_SIZE, WRITE_SIZE).
+Usage: python tools/r03_config_one.py c2|c3d|c3s [rows] [passes]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import vaex_amd
+from vaex_amd.binned import Frame, agg
+sa = vaex_amd.superagg
+which = sys.argv[1]
+rows = int(float(sys.argv[2])) if len(sys.argv) > 2 else 1_000_000_000
+passes = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+g = torch.Generator(device="cuda").manual_seed(7)
+if which == "c2":
+    x, y, z, v = (torch.randn(rows, dtype=torch.float64, device="cuda", generator=g) for _ in range(4))
+    sel = (v * 2 + 3 > 3).to(torch.uint8)
+    del v
+    df = Frame(dict(x=x, y=y, z=z, sel=sel))
+    run = lambda: df.count(binby=["x", "y", "z"], limits=[[-4, 4]] * 3, shape=128, selection="sel", edges=True)
+else:
+    v = torch.randn(rows, dtype=torch.float64, device="cuda", generator=g) * 2 + 3
+    k = torch.randint(0, 1_000_000, (rows,), dtype=torch.int64, device="cuda", generator=g)
+    if which == "c3s":
+        k = (k * 2654435761) % (1 << 40)
+    df = Frame(dict(k=k, v=v))
+    spec = {"c": agg.count("v"), "s": agg.sum("v"), "m": agg.mean("v"), "sd": agg.std("v")}
+    run = lambda: df.groupby("k", spec)
+torch.cuda.synchronize()
+for i in range(passes):
+    t0 = time.perf_counter(); sa.timer_start(0); r = run(); k_ms = sa.timer_stop(0); dt = time.perf_counter() - t0
+    print(f"{which} pass {i}: {dt*1e3:.3f} ms wall, {k_ms:.3f} ms on the stream = {rows/dt/1e9:.1f} Grows/s  {sa.last_kernel(0)}", flush=True)
