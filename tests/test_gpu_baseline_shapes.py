@@ -453,3 +453,47 @@ def test_hashmap_unique_matches_numpy_on_random_chunks(sa):
         hm.update(ch.astype(np.int64))
     allk = np.unique(np.concatenate(chunks))
     _check_dense_ordinals(hm, allk)
+
+
+def test_hot_box_uint16_counters_are_exact(sa):
+    """round 3: the hot box next to the ring-less pass 1 keeps uint16 counters (10-byte cells: 128x127 instead of 116x115 cells on
+    the bench pass).  Exactness: every workgroup compares the sum of its counters with the hot rows it counted; rows piled onto ONE
+    cell (> 65535 per workgroup) wrap a counter -> the call runs again with uint32 counters.  Both ways: the result is the oracle's."""
+    import torch
+    g = torch.Generator(device="cuda").manual_seed(5)
+    n = 1 << 25
+    for piled in (False, True):
+        x = torch.randn(n, dtype=torch.float64, device="cuda", generator=g)
+        y = torch.randn(n, dtype=torch.float64, device="cuda", generator=g)
+        v = torch.randn(n, dtype=torch.float64, device="cuda", generator=g) * 2 + 3
+        if piled:
+            x[: n - n // 8] = 0.25; y[: n - n // 8] = -0.5   # 7/8 of the rows in one cell: 114688 per workgroup
+        bx = sa.BinnerScalar_float64(1, "x", -4.0, 4.0, 256); by = sa.BinnerScalar_float64(1, "y", -4.0, 4.0, 256)
+        grid = sa.Grid([bx, by])
+        aggs = [sa.AggCount_int64(grid, 1, 1), sa.AggSum_float64(grid, 1, 1), sa.AggCount_float64(grid, 1, 1)]
+        bx.set_data(0, x); by.set_data(0, y); aggs[1].set_data(0, v, 0); aggs[2].set_data(0, v, 0)
+        grid.bin(0, aggs, n)
+        got = [np.array(a.get_result()) for a in aggs]
+        assert sa.last_kernel(0).startswith("part_scatter_direct_hot"), sa.last_kernel(0)
+        assert sa.config_get("hot_cnt16_used") == (0 if piled else 1)   # (the piled call ended on uint32 counters)
+        sa.config_set("hot_cnt16", 0)
+        try:
+            for a in aggs:
+                a.reset()
+            grid.bin(0, aggs, n)
+            want = [np.array(a.get_result()) for a in aggs]
+        finally:
+            sa.config_set("hot_cnt16", 1)
+        np.testing.assert_array_equal(got[0], want[0]); np.testing.assert_array_equal(got[2], want[2])
+        assert int(got[0].sum()) == n
+        assert np.all(np.abs(got[1] - want[1]) <= 1e-12 * 20.0 * np.maximum(want[0], 1))
+        m = N_SLICE
+        xs, ys, vs = (t[:m].cpu().numpy() for t in (x, y, v))
+        for a in aggs:
+            a.reset()
+        bx.set_data(0, x[:m]); by.set_data(0, y[:m]); aggs[1].set_data(0, v[:m], 0); aggs[2].set_data(0, v[:m], 0)
+        grid.bin(0, aggs, m)
+        head = [np.array(a.get_result()) for a in aggs]
+        case = dict(n=m, binners=[dict(kind="scalar", data=xs, vmin=-4, vmax=4, bins=256), dict(kind="scalar", data=ys, vmin=-4, vmax=4, bins=256)],
+                    aggs=[dict(kind="count"), dict(kind="sum", data=vs), dict(kind="count", data=vs)])
+        cases.assert_case_equal(head, _ref_or_port_case(_ref_module(), case), case)

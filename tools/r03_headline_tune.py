@@ -10,6 +10,9 @@ rows = int(float(sys.argv[1])) if len(sys.argv) > 1 else 1_000_000_000
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 settings = [dict()]
 for kv in sys.argv[3:]:
+    if "+" in kv:   # one setting of several knobs: a=1+b=2
+        settings.append({p.split("=")[0]: int(p.split("=")[1]) for p in kv.split("+")})
+        continue
     k, vs = kv.split("=")
     settings += [{k: int(v)} for v in vs.split(",")]
 g = torch.Generator(device="cuda").manual_seed(1234)
@@ -35,6 +38,8 @@ for r in range(reps + 1):
         ms = sa.timer_stop(0)
         if r:
             best[i] = min(best[i], ms)
+        else:
+            print(cfg, "box", sa.config_get("hot_w"), "x", sa.config_get("hot_h"), "fraction", sa.config_get("hot_fraction_ppm") / 1e4, "%", sa.last_kernel(0), flush=True)
         res = [np.array(a.get_result()) for a in aggs]
         if ref is None:
             ref = res

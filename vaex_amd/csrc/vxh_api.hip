@@ -892,14 +892,18 @@ static void hot_prepare(Slot &slot, const BinArgs &A, const BinArgs &planned, co
     }
     if (wv && gen2 && c.cfg_wv == 1) wv = false; // next to a box part_scatter_blk is the (slightly) faster one: its staging leaves the box 111 KB, eight waves' rings 78 KB
     // a forced box (tests / experiments) too big for what part_scatter_wv's rings leave of the LDS goes to part_scatter_blk
-    if (wv && forced && gen2 && (uint64_t)c.cfg_hot_box[2] * (uint64_t)c.cfg_hot_box[3] > (kLdsMax - ((size_t)wg.waves * wg.wave_bytes + 64) - 96) / (nval ? (mom2 ? 20 : 12) : 4)) wv = false;
+    // uint16 counters (two per LDS word) next to the ring-less pass 1 with one value column: 10-byte cells instead of 12
+    const bool c16 = c.cfg_hot_cnt16 && !H.no_cnt16 && nval == 1 && !mom2 && wg.ok && wg.direct == 1;
+    H.cnt16 = false;
+    if (wv && forced && gen2 && (uint64_t)c.cfg_hot_box[2] * (uint64_t)c.cfg_hot_box[3] > (kLdsMax - ((size_t)wg.waves * wg.wave_bytes + 64) - 96 - (c16 ? 16 : 0)) / (c16 ? 10 : (nval ? (mom2 ? 20 : 12) : 4))) wv = false;
     if (!gen2 && !wv) return;
     H.gen2 = true;
     H.nval = nval;
     const size_t cell_bytes = nval ? (mom2 ? 20 : 12) : 4;
     auto room = [&](bool with_wv) -> uint64_t { // cells the box may have next to this pass-1 kernel's own LDS (0: does not fit)
         const size_t fixed = with_wv ? (size_t)wg.waves * wg.wave_bytes + 64 : (size_t)VXH_BLK_FIXED_LDS(nval, S);
-        return fixed + 4096 > kLdsMax ? 0 : (kLdsMax - fixed - 96) / cell_bytes;
+        if (fixed + 4096 > kLdsMax) return 0;
+        return with_wv && c16 ? (kLdsMax - fixed - 96 - 16) / 10 : (kLdsMax - fixed - 96) / cell_bytes;
     };
     const uint32_t sx = (uint32_t)(A.b[0].bins + 3), sy = (uint32_t)(A.b[1].bins + 3);
     uint32_t box[4] = {0, 0, 0, 0};
@@ -990,6 +994,11 @@ static void hot_prepare(Slot &slot, const BinArgs &A, const BinArgs &planned, co
         if (H.last_fraction * 100.0 < (double)c.cfg_hot_min_pct) return;
     }
     H.wv = wv;
+    H.cnt16 = wv && c16;
+    if (H.cnt16) {
+        if (!H.flag) HIP_CHECK(hipMalloc((void **)&H.flag, 64));
+        HIP_CHECK(hipMemsetAsync(H.flag, 0, 64, slot.stream));
+    }
     H.wv_waves = wv ? wg.waves : 0;
     H.x0 = box[0]; H.y0 = box[1]; H.w = box[2]; H.h = box[3];
     const uint64_t tile_rows = H.wv ? 256ull * (uint64_t)H.wv_waves : 4096ull; // rows one workgroup takes per round
@@ -1268,7 +1277,11 @@ static void run_part_chunk(Slot &slot, const BinArgs &planned, const LaunchPlan 
         P.hot.on = 2;
         P.hot.x0 = H.x0; P.hot.y0 = H.y0; P.hot.w = H.w; P.hot.h = H.h;
         P.hot.lds_offset = 0; // the box first, the waves' rings behind it
-        P.wv_base = (int32_t)(((size_t)H.w * H.h * (P.nvals ? (H.mom2 ? 20 : 12) : 4) + 15) & ~(size_t)15);
+        P.hot.cnt16 = H.cnt16 ? 1u : 0u;
+        P.hot.overflow = H.flag;
+        const size_t box_cells = (size_t)H.w * H.h;
+        // (uint16 counters: two per word, then two words: the hot rows the workgroup saw, and the sum of its counters)
+        P.wv_base = (int32_t)(((H.cnt16 ? box_cells * 8 + ((box_cells + 1) / 2) * 4 + 8 : box_cells * (P.nvals ? (H.mom2 ? 20 : 12) : 4)) + 15) & ~(size_t)15);
         scatter_lds = (size_t)P.wv_base + (size_t)wg.waves * wg.wave_bytes + 16;
         P.hot.mom2 = H.mom2 ? 1u : 0u;
         P.hot.sum_acc = (double *)H.acc;
@@ -1513,6 +1526,7 @@ int vxh_config_set(const char *key, int64_t value) {
     else if (k == "count_fast") c.cfg_count_fast = value;
     else if (k == "scatter_wgs") c.cfg_scatter_wgs = value;
     else if (k == "hot") c.cfg_hot = value;
+    else if (k == "hot_cnt16") c.cfg_hot_cnt16 = value;
     else if (k == "blk") c.cfg_blk = value;
     else if (k == "wv") c.cfg_wv = value;
     else if (k == "wv_waves") c.cfg_wv_waves = value > 0 ? value : 8;
@@ -1555,9 +1569,13 @@ int vxh_config_get(const char *key, int64_t *value) {
     else if (k == "count_fast") *value = c.cfg_count_fast;
     else if (k == "scatter_wgs") *value = c.cfg_scatter_wgs;
     else if (k == "hot") *value = c.cfg_hot;
+    else if (k == "hot_cnt16") *value = c.cfg_hot_cnt16;
+    else if (k == "hot_cnt16_used") *value = get_slot(0).hot.cnt16 ? 1 : 0;
     else if (k == "blk") *value = c.cfg_blk;
     else if (k == "wv") *value = c.cfg_wv;
     else if (k == "wv_waves") *value = c.cfg_wv_waves;
+    else if (k == "wv_waves_direct") *value = c.cfg_wv_waves_direct;
+    else if (k == "hot_direct_pct") *value = c.cfg_hot_direct_pct;
     else if (k == "wv_block") *value = c.cfg_wv_block;
     else if (k == "hot_min_rows") *value = c.cfg_hot_min_rows;
     else if (k == "hot_min_pct") *value = c.cfg_hot_min_pct;
@@ -1894,6 +1912,7 @@ int vxh_grid_bin(vxh_grid *grid, int thread, vxh_agg *const *aggs, int n_aggs, u
             bool armed;
             ~PartGuard() { if (armed) { slot.acc_sig = 0; slot.hot.on = false; } }
         } part_guard{slot, whole.strategy == VXH_STRAT_PART};
+        for (int attempt = 0; attempt < 2; ++attempt) {
         for (uint64_t r0 = 0; r0 < length; r0 += step) {
             const uint64_t rn = std::min(step, length - r0);
             BinArgs L = A;
@@ -1923,6 +1942,25 @@ int vxh_grid_bin(vxh_grid *grid, int thread, vxh_agg *const *aggs, int n_aggs, u
                 HIP_CHECK(hipGetLastError());
             }
             slot.last_kernel = plan.name;
+        }
+        if (attempt == 0 && whole.strategy == VXH_STRAT_PART && slot.hot.on && slot.hot.cnt16) {
+            // uint16 box counters: every workgroup compared the sum of its counters with the hot rows it saw.  One that wrapped
+            // (> 65535 rows of ONE workgroup in ONE cell: very skewed data) raised the flag: nothing of this call has reached the
+            // grids yet (the accumulators are merged below) — put the accumulators back and run the call again with uint32 counters.
+            part_join(slot);
+            unsigned int wrapped = 0;
+            HIP_CHECK(hipMemcpyAsync(&wrapped, slot.hot.flag, 4, hipMemcpyDeviceToHost, slot.stream));
+            HIP_CHECK(hipStreamSynchronize(slot.stream));
+            if (wrapped) {
+                slot.acc_sig = 0;
+                part_acc_prepare(slot, whole_args);
+                slot.hot.no_cnt16 = true;
+                hot_prepare(slot, A, whole_args, whole, length);
+                slot.hot.no_cnt16 = false;
+                continue;
+            }
+        }
+        break;
         }
         if (whole.strategy == VXH_STRAT_PART) {
             part_join(slot);

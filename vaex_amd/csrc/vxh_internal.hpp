@@ -141,6 +141,9 @@ struct Slot {
     // hot box of the current vxh_grid_bin call (PartArgs::hot) and its per-workgroup accumulators
     struct Hot {
         int nval = 1;      // value columns the box aggregates (1: fp64 sum + count per cell, 0: count only)
+        bool cnt16 = false;    // uint16 box counters this call (10-byte cells; exact: checked per workgroup, the call is redone with uint32 ones if one wrapped)
+        bool no_cnt16 = false; // ... not for this call (the redo)
+        unsigned int *flag = nullptr; // device word the workgroups raise
         bool mom2 = false; // ... and the fp64 sum of squares (an AggSumMoment with moment 2 among the aggregators: 20-byte cells)
         bool gen2 = false; // part_scatter_hot (vs the HOT instantiation of part_scatter_f64)
         bool wv = false;   // the box lives in part_scatter_wv
@@ -204,6 +207,7 @@ struct Context {
     int64_t cfg_wv_waves_direct = 16; // ... waves per workgroup of the ring-less variant ("wv" = 3, next to a hot box)
     int64_t cfg_wv_waves = 8;      // ... waves per workgroup (one workgroup per CU); fewer when the rings would not fit
     int64_t cfg_hot = 1;           // hot box in pass 1 of the partition strategy (0 off)
+    int64_t cfg_hot_cnt16 = 1;     // uint16 counters in the box next to the ring-less pass 1 (one value column): 20 % more cells
     int64_t cfg_hot_min_rows = 1 << 24; // calls shorter than this do not pay for the sample
     int64_t cfg_hot_cache = 1;     // reuse the sampled box when the same columns are binned with the same limits again (0: sample every call)
     int64_t cfg_hot_min_pct = 10;  // use the box only when it catches at least this share of the sample (profiles/r02_box_share.txt: worth it from ~15 %)

@@ -1627,6 +1627,12 @@ __global__ void __launch_bounds__(1024) part_scatter_wv(const PartArgs P) {
     const bool hot_mom2 = HOT && NVAL && P.hot.mom2 != 0u; // (wave-uniform) the box also keeps the sum of squares
     double *const hot_sum2 = hot_sum + hot_cells;
     uint32_t *const hot_cnt = (uint32_t *)(hot_sum + (NVAL ? (hot_mom2 ? 2u : 1u) * hot_cells : 0u));
+    // uint16 counters, two per word (PartArgs::hot.cnt16): 10-byte cells make the box 20 % larger.  Exact: a wave counts the hot
+    // rows it adds (s_bcnt1 of the ballot), the workgroup compares their total with the sum of its counters before the flush — a
+    // counter that wrapped (> 65535 rows of this workgroup in one cell) makes them differ, and the host runs the call again.
+    const bool c16 = HOT && DIRECT == 1 && NVAL == 1 && P.hot.cnt16 != 0u; // (wave-uniform)
+    const uint32_t cnt_words = c16 ? (hot_cells + 1u) / 2u : hot_cells;      // [cnt_words] hot rows seen, [cnt_words + 1] sum of the counters
+    uint32_t nhot = 0;
     char *const wbase = lds + P.wv_base + wave * (uint32_t)P.wv_wave_bytes;
     double *const ring_val = (double *)wbase;
     uint16_t *const ring_idx = (uint16_t *)(wbase + (NVAL ? (size_t)S * D * 8 : 0));
@@ -1653,8 +1659,10 @@ __global__ void __launch_bounds__(1024) part_scatter_wv(const PartArgs P) {
         for (uint32_t c = threadIdx.x; c < hot_cells; c += blockDim.x) {
             if (NVAL) hot_sum[c] = 0.0;
             if (hot_mom2) hot_sum2[c] = 0.0;
-            hot_cnt[c] = 0u;
+            if (!c16) hot_cnt[c] = 0u;
         }
+        if (c16)
+            for (uint32_t c = threadIdx.x; c < cnt_words + 2u; c += blockDim.x) hot_cnt[c] = 0u;
     }
     if (lane < S) cnt[lane] = 0u;
     // lane s keeps the queue segment reserved for slab s
@@ -1877,8 +1885,9 @@ __global__ void __launch_bounds__(1024) part_scatter_wv(const PartArgs P) {
                     const uint32_t hc = __umul24(hy, P.hot.w) + hx;
                     if (NVAL) at_add<__HIP_MEMORY_SCOPE_WORKGROUP, double>(hot_sum + hc, val[NVAL ? r : 0]);
                     if (hot_mom2) at_add<__HIP_MEMORY_SCOPE_WORKGROUP, double>(hot_sum2 + hc, val[NVAL ? r : 0] * val[NVAL ? r : 0]); // (= pow_u(v, 2))
-                    at_add<__HIP_MEMORY_SCOPE_WORKGROUP, uint32_t>(hot_cnt + hc, 1u);
+                    at_add<__HIP_MEMORY_SCOPE_WORKGROUP, uint32_t>(hot_cnt + (c16 ? hc >> 1 : hc), c16 ? 1u << ((hc & 1u) << 4) : 1u);
                 }
+                if (c16) nhot += (uint32_t)__builtin_popcountll(__ballot(hot));
                 is_cold = is_cold & !hot;
             }
             pos[r] = 0;
@@ -2013,6 +2022,7 @@ __global__ void __launch_bounds__(1024) part_scatter_wv(const PartArgs P) {
             if (lane < S) close_block();
         }
     }
+    if (c16 && lane == 0 && nhot) at_add<__HIP_MEMORY_SCOPE_WORKGROUP, uint32_t>(hot_cnt + cnt_words, nhot);
     if (HOT || DIRECT == 2) __syncthreads();
     if (DIRECT == 2 && threadIdx.x < S) {
         // the fill table says QB for every reserved block: correct the block the last record went to and the one
@@ -2033,7 +2043,21 @@ __global__ void __launch_bounds__(1024) part_scatter_wv(const PartArgs P) {
         unsigned long long *gc = P.hot.cnt_acc + (uint64_t)blockIdx.x * hot_cells;
         if (NVAL) flush_add_plain<double, double>(P.hot.sum_acc + (uint64_t)blockIdx.x * hot_cells, hot_sum, hot_cells, 0, 0, hot_cells);
         if (hot_mom2) flush_add_plain<double, double>(P.hot.sum2_acc + (uint64_t)blockIdx.x * hot_cells, hot_sum2, hot_cells, 0, 0, hot_cells);
-        flush_add_plain<unsigned long long, uint32_t>(gc, hot_cnt, hot_cells, 0, 0, hot_cells);
+        if (!c16) {
+            flush_add_plain<unsigned long long, uint32_t>(gc, hot_cnt, hot_cells, 0, 0, hot_cells);
+        } else {
+            uint32_t mine = 0;
+            for (uint32_t c = threadIdx.x; c < hot_cells; c += blockDim.x) {
+                const uint32_t v = (hot_cnt[c >> 1] >> ((c & 1u) << 4)) & 0xffffu;
+                if (v) gc[c] += v;
+                mine += v;
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) mine += (uint32_t)__shfl_down((int)mine, o, 64);
+            if (lane == 0 && mine) at_add<__HIP_MEMORY_SCOPE_WORKGROUP, uint32_t>(hot_cnt + cnt_words + 1u, mine);
+            __syncthreads();
+            if (threadIdx.x == 0 && hot_cnt[cnt_words] != hot_cnt[cnt_words + 1u]) atomicExch(P.hot.overflow, 1u);
+        }
     }
 }
 

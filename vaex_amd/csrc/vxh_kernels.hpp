@@ -131,6 +131,9 @@ struct PartArgs {
         double *sum_acc;           // [pass-1 workgroups][w*h]
         double *sum2_acc;          // ... (mom2)
         unsigned long long *cnt_acc;
+        uint32_t cnt16;            // the box's counters are uint16, two per LDS word (part_scatter_wv DIRECT = 1, one value column): 10-byte
+                                   // cells; a workgroup checks sum(counters) == hot rows it saw before it flushes and raises *overflow otherwise
+        unsigned int *overflow;
     } hot;
 };
 
