@@ -112,6 +112,10 @@ int vxh_cache_stats(uint64_t out[6]);
 /* ---- binners ------------------------------------------------------------------------- */
 /* BinnerScalar<T,…,FlipEndian>(threads, expression, vmin, vmax, bins) — src/binners.cpp:9-12, :97 */
 int vxh_binner_scalar_create(int threads, int dtype, int flip_endian, double vmin, double vmax, uint64_t bins, vxh_binner **out);
+/* the arithmetic of the legacy statisticNd<float> instead of BinnerScalar's (src/vaexfast.cpp:1185-1262: `T scales[]`, `(value -
+ * minima[d]) * scales[d]` in float32): mode 1 = the product with the bin count in double (its 1-, 3+-dimensional and use_edges loops),
+ * mode 2 = in float32 (its two-dimensional loop, `T scaled`, :1240-1246), 0 = off.  Used by vaex_amd.vaexfast.statisticNd_f4. */
+int vxh_binner_scalar_set_f32_scaling(vxh_binner *binner, int mode);
 /* BinnerOrdinal<T,…>(threads, expression, ordinal_count, min_value, allow_other, invert) — src/binner_ordinal.cpp:15-17, :217 */
 int vxh_binner_ordinal_create(int threads, int dtype, int flip_endian, int64_t ordinal_count, int64_t min_value, int allow_other, int invert, vxh_binner **out);
 /* BinnerHash<T>(threads, expression, hash_map) — src/binner_hash.cpp:13-20, :152.  Cells

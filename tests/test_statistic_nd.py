@@ -180,3 +180,72 @@ def test_op_first_vs_reference_vaexfast(sa, gpu_ready, nd, use_edges):
     # as its bit pattern, so the same rows win here
     np.testing.assert_array_equal(got[..., 1], want[..., 1])
     np.testing.assert_array_equal(got[..., 0], want[..., 0])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nd,op,use_edges", CASES)
+def test_statistic_nd_f4_hip_vs_reference_vaexfast(sa, gpu_ready, nd, op, use_edges):
+    """statisticNd_f4: float32 blocks / weights with the reference's float32 scaling arithmetic ((value - min) * scale in float32;
+    the product with the bin count in float32 in the two-dimensional loop, in double elsewhere: src/vaexfast.cpp:1185-1262) —
+    against the reference's own compiled entry.  Half of the rows sit exactly on a 1/64 lattice, i.e. on and next to bin edges,
+    where a double-precision scaling puts rows into other cells than the reference does."""
+    vf = oracle.ref_module("vaexfast")
+    if vf is None:
+        pytest.skip("oracle/_ref/vaexfast not built (reference sources absent)")
+    from vaex_amd import vaexfast
+    n = 40000
+    rng = np.random.default_rng(500 + nd * 10 + op)
+    sizes = [7, 5, 4, 6][:nd]
+    blocks = []
+    for d in range(nd):
+        b = rng.normal(0.0, 1.5, n).astype("f4")
+        b[: n // 2] = (rng.integers(-200, 200, n // 2) / 64.0).astype("f4")
+        b[rng.random(n) < 0.02] = np.nan
+        blocks.append(b)
+    w = rng.normal(1.0, 3.0, n).astype("f4")
+    w[rng.random(n) < 0.05] = np.nan
+    minima = [-2.0 - 0.3 * d for d in range(nd)]     # (-2.3, -2.6: not float32 numbers — the reference rounds them first)
+    maxima = [2.5 + 0.7 * d for d in range(nd)]
+    grid = np.zeros(tuple(sizes) + (oracle.STAT_FIELDS[op],), dtype=np.float64)
+    if op == 2:
+        grid[..., 0] = np.inf
+        grid[..., 1] = -np.inf
+    weights = None if op == 0 else [w]
+    want, got = grid.copy(), grid.copy()
+    for i1, i2 in ((0, 15000), (15000, n)):
+        bs = [b[i1:i2] for b in blocks]
+        ws = None if weights is None else [x[i1:i2] for x in weights]
+        vf.statisticNd_f4(bs, ws, want, minima, maxima, op, use_edges)
+        assert vaexfast.statisticNd_f4(bs, ws, got, minima, maxima, op, use_edges) is None
+    compare(got, want, op)
+    if nd and op == 0:
+        assert want.sum() > 0
+    with pytest.raises(TypeError, match="float32"):
+        vaexfast.statisticNd_f4([b.astype("f8") for b in blocks] or [np.zeros(3)], None, np.zeros(tuple(sizes or [4]) + (1,)), minima or [0.0], maxima or [1.0], 0, 0)
+
+
+@pytest.mark.gpu
+def test_statistic_nd_f4_first_and_float32_scaling_differs_from_float64(sa, gpu_ready):
+    vf = oracle.ref_module("vaexfast")
+    if vf is None:
+        pytest.skip("oracle/_ref/vaexfast not built (reference sources absent)")
+    from vaex_amd import vaexfast
+    rng = np.random.default_rng(9)
+    n = 30000
+    x = (rng.integers(-300, 300, n) / 100.0).astype("f4")
+    y = (rng.integers(-300, 300, n) / 100.0).astype("f4")
+    v = rng.normal(0, 1, n).astype("f4"); v[::37] = np.nan
+    order = rng.permutation(n).astype("f4")
+    want = np.zeros((10, 2)); want[..., 1] = np.inf
+    got = want.copy()
+    vf.statisticNd_f4([x], [v, order], want, [-3.0], [3.0], 6, 0)
+    vaexfast.statisticNd_f4([x], [v, order], got, [-3.0], [3.0], 6, 0)
+    np.testing.assert_array_equal(got, want)
+    # the float32 arithmetic matters: the same rows binned with the float64 entry land in other cells
+    a, b = np.zeros((30, 30, 1)), np.zeros((30, 30, 1))
+    vaexfast.statisticNd_f4([x, y], None, a, [-3.0, -3.0], [3.0, 3.0], 0, 0)
+    vf.statisticNd_f4([x, y], None, b, [-3.0, -3.0], [3.0, 3.0], 0, 0)
+    np.testing.assert_array_equal(a, b)
+    c = np.zeros((30, 30, 1))
+    vaexfast.statisticNd_f8([x.astype("f8"), y.astype("f8")], None, c, [-3.0, -3.0], [3.0, 3.0], 0, 0)
+    assert (a != c).any()

@@ -91,7 +91,7 @@ def install(vaex_module=None, legacy=True, hash_sets=True, chunk_size="auto", gr
       object aggregators, BinnerCombined, BinnerHash: `vaex_amd.UNSUPPORTED`), builds it again from vaex's own C++ —
       so everything that worked before install() still works, on the CPU, and everything on the hot path runs on the GPU.
     * legacy=True points the legacy statistic task (df.minmax / limits=None: vaex/cpu.py:533-538) at
-      vaex_amd.vaexfast.statisticNd_f8 (the float32 variant keeps the reference's CPU code: it scales in float32).
+      vaex_amd.vaexfast.statisticNd_f8 / statisticNd_f4 (the float32 entry with the reference's float32 scaling arithmetic).
     * hash_sets=True replaces `vaex.hash.ordered_set_<dtype>` for the numeric dtypes (vaex/hash.py:49-52 looks them up
       by name) with vaex_amd.hashset's GPU-backed classes: groupby's distinct-key pass and `_ordinal_values`.
     * chunk_size: vaex's executor cuts a pass into chunks of `rows / threads` rows bracketed by [chunk.size_min, chunk.size_max
@@ -169,6 +169,16 @@ def install(vaex_module=None, legacy=True, hash_sets=True, chunk_size="auto", gr
         if legacy_mod is not None:
             _installed["legacy"] = (legacy_mod, legacy_mod.statisticNd_f8)
             legacy_mod.statisticNd_f8 = _vf.statisticNd_f8
+            if hasattr(legacy_mod, "statisticNd_f4"):
+                original_f4 = legacy_mod.statisticNd_f4
+                _installed["legacy_f4"] = original_f4
+
+                def statisticNd_f4(*args, **kwargs):   # (OP_COV over float32 weights stays with the reference's function)
+                    try:
+                        return _vf.statisticNd_f4(*args, **kwargs)
+                    except NotImplementedError:
+                        return original_f4(*args, **kwargs)
+                legacy_mod.statisticNd_f4 = statisticNd_f4
     if chunk_size == "auto":
         if vaex_module.settings.main.chunk.size_max == 1024 ** 2:  # (vaex's default: the user has not chosen one)
             _installed["chunk_size_max"] = vaex_module.settings.main.chunk.size_max
@@ -215,6 +225,8 @@ def uninstall():
     if "legacy" in _installed:
         mod, fn = _installed["legacy"]
         mod.statisticNd_f8 = fn
+        if "legacy_f4" in _installed:
+            mod.statisticNd_f4 = _installed["legacy_f4"]
     for attr, cls in _installed.get("hash", {}).items():
         setattr(vaex.hash, attr, cls)
     if "hash_tuple" in _installed:

@@ -931,7 +931,8 @@ PYBIND11_MODULE(superagg, m) {
     py::class_<PyBinnerScalar, PyBinner> scalar_base(m, "BinnerScalar");
     scalar_base.def_property_readonly("bins", [](const PyBinnerScalar &b) { return b.bins; })
         .def_property_readonly("vmin", [](const PyBinnerScalar &b) { return b.vmin; })
-        .def_property_readonly("vmax", [](const PyBinnerScalar &b) { return b.vmax; });
+        .def_property_readonly("vmax", [](const PyBinnerScalar &b) { return b.vmax; })
+        .def("set_float32_scaling", [](PyBinnerScalar &b, int mode) { check(vxh_binner_scalar_set_f32_scaling(b.h, mode)); }); // (the legacy statisticNd_f4 arithmetic)
     py::class_<PyBinnerOrdinal, PyBinner> ordinal_base(m, "BinnerOrdinal");
     ordinal_base.def_property_readonly("ordinal_count", [](const PyBinnerOrdinal &b) { return b.ordinal_count; })
         .def_property_readonly("min_value", [](const PyBinnerOrdinal &b) { return b.min_value; })

@@ -580,7 +580,7 @@ static LaunchPlan make_plan(const BinArgs &A, BinArgs &out, uint64_t n, double b
     bool fast = true;
     for (int d = 0; d < A.ndim; d++) {
         const BinnerDesc &b = A.b[d];
-        if (b.kind != VXH_BIN_SCALAR || b.dtype != VXH_F64 || b.flip || b.mask) fast = false;
+        if (b.kind != VXH_BIN_SCALAR || b.dtype != VXH_F64 || b.flip || b.mask || b.f32mode) fast = false;
     }
     bool fast_vals = true;
     for (int k = 0; k < A.nagg; k++) {
@@ -593,7 +593,7 @@ static LaunchPlan make_plan(const BinArgs &A, BinArgs &out, uint64_t n, double b
     bool f32 = A.ndim >= 1;
     for (int d = 0; d < A.ndim; d++) {
         const BinnerDesc &b = A.b[d];
-        if (b.kind != VXH_BIN_SCALAR || b.dtype != VXH_F32 || b.flip || b.mask) f32 = false;
+        if (b.kind != VXH_BIN_SCALAR || b.dtype != VXH_F32 || b.flip || b.mask || b.f32mode) f32 = false; // (the typed kernels widen first)
     }
     for (int k = 0; k < A.nagg; k++) {
         const AggDesc &a = A.a[k];
@@ -606,7 +606,7 @@ static LaunchPlan make_plan(const BinArgs &A, BinArgs &out, uint64_t n, double b
         bool same = dt == VXH_F64 || dt == VXH_F32 || dt == VXH_I64 || dt == VXH_I32;
         for (int d = 0; d < A.ndim; d++) {
             const BinnerDesc &b = A.b[d];
-            if (b.kind != VXH_BIN_SCALAR || b.dtype != dt || b.flip || b.mask) same = false;
+            if (b.kind != VXH_BIN_SCALAR || b.dtype != dt || b.flip || b.mask || b.f32mode) same = false;
         }
         if (same) p.count_ct = dt;
     }
@@ -1357,6 +1357,9 @@ static void fill_binner_descs(vxh_grid *grid, int thread, BinArgs &base, RESOLVE
             bd.scale = 1. / (b->vmax - b->vmin); // src/binners.cpp:16
             bd.binsd = (double)b->bins;
             bd.bins = b->bins;
+            bd.f32mode = (uint8_t)b->f32mode;
+            bd.vmin_f = (float)b->vmin;
+            bd.scale_f = 1 / ((float)b->vmax - (float)b->vmin); // src/vaexfast.cpp:1187: `T scales[d] = 1 / (maxima[d] - minima[d])`
         } else if (b->kind == VXH_BIN_ORDINAL) {
             bd.bins = (uint64_t)b->ordinal_count;
             bd.min_value = b->min_value;
@@ -1623,6 +1626,14 @@ int vxh_binner_scalar_create(int threads, int dtype, int flip_endian, double vmi
     b->vmax = vmax;
     b->bins = bins;
     *out = b;
+    VXH_API_END
+}
+
+int vxh_binner_scalar_set_f32_scaling(vxh_binner *b, int mode) {
+    VXH_API_BEGIN
+    if (b->kind != VXH_BIN_SCALAR) throw std::runtime_error("vxh_binner_scalar_set_f32_scaling: not a scalar binner");
+    if (mode < 0 || mode > 2) throw std::runtime_error("vxh_binner_scalar_set_f32_scaling: mode 0, 1 or 2");
+    b->f32mode = mode;
     VXH_API_END
 }
 

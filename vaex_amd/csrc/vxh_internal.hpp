@@ -28,6 +28,7 @@ struct vxh_binner {
     // scalar
     double vmin = 0, vmax = 1;
     uint64_t bins = 0;
+    int f32mode = 0; // vxh_binner_scalar_set_f32_scaling
     // ordinal
     int64_t ordinal_count = 0, min_value = 0;
     bool allow_other = false, invert = false;

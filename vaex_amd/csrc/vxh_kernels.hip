@@ -133,6 +133,18 @@ __device__ __forceinline__ uint64_t scalar_sub_index(double v, bool masked, doub
     return index;
 }
 
+// the legacy statisticNd<float> flavour (src/vaexfast.cpp:1185-1262): `T scales[]`, `(value - minima[d]) * scales[d]` are float32
+// operations; the product with the bin count is a double one except in the two-dimensional loop (`T scaled`, :1240-1246)
+__device__ __forceinline__ uint64_t scalar_sub_index_f32(float v, bool masked, float vmin, float scale, double binsd, uint64_t bins, bool float_product) {
+    const float scaled = (v - vmin) * scale;
+    const int bin = (float_product ? (int)(scaled * (float)(int)bins) : (int)((double)scaled * binsd)) + 2;
+    uint64_t index = (uint64_t)(int64_t)bin;
+    index = scaled >= 1 ? bins + 2 : index;
+    index = scaled < 0 ? 1 : index;
+    index = (scaled != scaled || masked) ? 0 : index;
+    return index;
+}
+
 // flat cell index of N rows: sum over dims of sub_index * stride (src/agg.hpp:63-73, :106-137)
 template <bool FAST, int N>
 __device__ __forceinline__ void flat_index_batch(const BinArgs &A, const Rows<N> &rows, uint64_t (&idx)[N]) {
@@ -156,7 +168,8 @@ __device__ __forceinline__ void flat_index_batch(const BinArgs &A, const Rows<N>
 #pragma unroll
             for (int u = 0; u < N; ++u) {
                 const double v = cls == 0 ? as_f64(c[u]) : (cls == 1 ? (double)(int64_t)c[u] : (double)c[u]);
-                idx[u] += scalar_sub_index(v, (masked >> u) & 1u, b.vmin, b.scale, b.binsd, b.bins) * b.stride;
+                if (b.f32mode) idx[u] += scalar_sub_index_f32((float)v, (masked >> u) & 1u, b.vmin_f, b.scale_f, b.binsd, b.bins, b.f32mode == 2) * b.stride;
+                else idx[u] += scalar_sub_index(v, (masked >> u) & 1u, b.vmin, b.scale, b.binsd, b.bins) * b.stride;
             }
         } else if (b.kind == VXH_BIN_ORDINAL) {
             // src/binner_ordinal.cpp:138-175 (+ the invert / allow_other variants :22-137).  The element is NOT

@@ -30,6 +30,9 @@ struct BinnerDesc {
     int64_t null_bin;     // hash: cell for masked rows
     int64_t hmin_ord;     // hash: ordinal of the key INT64_MIN (the table's EMPTY sentinel: kept in the map's side words), or -1
     uint8_t kind, dtype, flip, allow_other, invert;
+    uint8_t f32mode;      // scalar: the legacy statisticNd<float> arithmetic (src/vaexfast.cpp:1185-1262): (value - min) * scale in float32;
+                          // 1: the product with the bin count in double, 2: in float32 (its two-dimensional loop)
+    float vmin_f, scale_f;
 };
 
 struct AggDesc {

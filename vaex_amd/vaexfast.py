@@ -24,7 +24,12 @@ vaexfast.cpp:1189-1209), followed by a cell-wise fold into the caller's grid:
                                 order value (:1155-1166; vaex/dataframe.py:975): the AggFirst passes (vxh_first_*) over the value
                                 column's BIT PATTERN (op_first compares the order only: a NaN value can win, which AggFirst
                                 would skip), folded into the caller's grid with the same `order < grid[...,1]` rule.
-float64 blocks only: the _f4 variant scales in float32 and is not offered rather than approximated."""
+`statisticNd_f4` (round 3) is the same over float32 blocks / weights with the reference's float32 ARITHMETIC: `T scales[d] = 1 /
+(maxima[d] - minima[d])` and `(value - minima[d]) * scales[d]` are float32 operations (vaexfast.cpp:1185-1190), the product with the
+bin count is a double one — except in the two-dimensional loop, whose `T scaled` keeps it in float32 (:1240-1246).  The scalar
+binner takes that arithmetic through vxh_binner_scalar_set_f32_scaling (mode 2 for two dimensions without edges, else 1); the ops
+accumulate in double exactly like the float64 entry.  OP_COV over float32 weights is not offered (NotImplementedError: install()
+keeps the reference's function for it)."""
 import threading
 
 import numpy as np
@@ -43,23 +48,25 @@ def _is_device(a):
     return hasattr(a, "__cuda_array_interface__") and not isinstance(a, np.ndarray)
 
 
-def _f8(a, what):
+def _f8(a, what, size=8):
+    name = f"statisticNd_f{size}"
     if _is_device(a):
-        if a.__cuda_array_interface__["typestr"] not in ("<f8", ">f8"):
-            raise TypeError(f"statisticNd_f8: {what} must be float64")
+        if a.__cuda_array_interface__["typestr"] not in (f"<f{size}", f">f{size}"):
+            raise TypeError(f"{name}: {what} must be float{size * 8}")
         return a
     a = np.asarray(a)
-    if a.dtype.kind != "f" or a.dtype.itemsize != 8:
-        raise TypeError(f"statisticNd_f8: {what} must be float64, not {a.dtype}")
+    if a.dtype.kind != "f" or a.dtype.itemsize != size:
+        raise TypeError(f"{name}: {what} must be float{size * 8}, not {a.dtype}")
     if a.ndim != 1:
-        raise ValueError(f"statisticNd_f8: {what} must be 1-dimensional")
+        raise ValueError(f"{name}: {what} must be 1-dimensional")
     return np.ascontiguousarray(a)
 
 
 def _postfix(a):
     if _is_device(a):
-        return "float64" if a.__cuda_array_interface__["typestr"] == "<f8" else "float64_non_native"
-    return "float64" if a.dtype.isnative else "float64_non_native"
+        t = a.__cuda_array_interface__["typestr"]
+        return ("float64" if t[1:] == "f8" else "float32") + ("" if t[0] == "<" else "_non_native")
+    return ("float64" if a.dtype.itemsize == 8 else "float32") + ("" if a.dtype.isnative else "_non_native")
 
 
 def statisticNd_f8(blocks, weights, grid, minima, maxima, op_code, use_edges=0):
@@ -68,19 +75,26 @@ def statisticNd_f8(blocks, weights, grid, minima, maxima, op_code, use_edges=0):
         return _statistic_nd(blocks, weights, grid, minima, maxima, op_code, use_edges)
 
 
-def _statistic_nd(blocks, weights, grid, minima, maxima, op_code, use_edges):
+def statisticNd_f4(blocks, weights, grid, minima, maxima, op_code, use_edges=0):
+    """The float32 entry (vaexfast.cpp:1361-1510 with T = float): float32 blocks and weights, the float32 scaling arithmetic of the
+    reference's loops, a float64 grid."""
+    with _LOCK:
+        return _statistic_nd(blocks, weights, grid, minima, maxima, op_code, use_edges, size=4)
+
+
+def _statistic_nd(blocks, weights, grid, minima, maxima, op_code, use_edges, size=8):
     if not isinstance(blocks, (list, tuple)):
         raise ValueError("statisticNd_: blocklist (first argument) is not a list")
     if op_code not in _FIELDS and op_code != OP_COV:
         raise ValueError(f"statisticNd_wrap_template_endian: unknown op code {op_code} for statistic")
-    blocks = [_f8(b, "block") for b in blocks]
+    blocks = [_f8(b, "block", size) for b in blocks]
     nd = len(blocks)
     if weights is None:
         wlist = []
     elif isinstance(weights, (list, tuple)):
-        wlist = [_f8(w, "weight") for w in weights]
+        wlist = [_f8(w, "weight", size) for w in weights]
     else:
-        wlist = [_f8(weights, "weight")]
+        wlist = [_f8(weights, "weight", size)]
     if op_code != OP_ADD1 and not wlist:
         raise ValueError("statisticNd_: this op needs a weight array")
     if not isinstance(grid, np.ndarray) or grid.dtype != np.float64:
@@ -109,6 +123,8 @@ def _statistic_nd(blocks, weights, grid, minima, maxima, op_code, use_edges):
     for d, b in enumerate(blocks):
         bins = sizes[d] - 3 if use_edges else sizes[d]
         binner = getattr(_sa, "BinnerScalar_" + _postfix(b))(1, f"block{d}", float(minima[d]), float(maxima[d]), int(bins))
+        if size == 4:
+            binner.set_float32_scaling(2 if (nd == 2 and not use_edges) else 1)
         binner.set_data(0, b)
         binners.append(binner)
     g = _sa.Grid(binners)
@@ -121,21 +137,23 @@ def _statistic_nd(blocks, weights, grid, minima, maxima, op_code, use_edges):
         # (src/agg_first.cpp:139): the value column goes in as its int64 bit pattern, which has no NaN
         if _is_device(w):
             import torch
-            wbits = torch.as_tensor(w).view(torch.int64)
+            wbits = torch.as_tensor(w).view(torch.int64 if size == 8 else torch.int32)
         else:
-            wbits = w.view(w.dtype.byteorder.replace("=", "<").replace("|", "<") + "i8") if not w.dtype.isnative else w.view("i8")
-        a = getattr(_sa, "AggFirst_int64_" + _postfix(order))(g, 1, 1, False)
+            wbits = w.view(w.dtype.byteorder.replace("=", "<").replace("|", "<") + f"i{size}") if not w.dtype.isnative else w.view(f"i{size}")
+        a = getattr(_sa, ("AggFirst_int64_" if size == 8 else "AggFirst_int32_") + _postfix(order))(g, 1, 1, False)
         a.set_data(0, wbits, 0)
         a.set_data(0, order, 1)
         if n:
             g.bin(0, [a], n)
         values, masked, orders = (np.asarray(r)[inner] for r in a.raw_result())
-        values = values.view("f8")  # (same item size: fine for the strided and the 0-d result alike)
+        values = values.view(f"f{size}")  # (same item size: fine for the strided and the 0-d result alike)
         take = ~masked & (orders < grid[..., 1])  # src/vaexfast.cpp:1160-1163
         grid[..., 0][take] = values[take]
         grid[..., 1][take] = orders[take]
         return None
     if op_code == OP_COV:
+        if size != 8:
+            raise NotImplementedError("statisticNd_f4: OP_COV")
         if any(_postfix(w) != "float64" for w in wlist):
             raise NotImplementedError("statisticNd: OP_COV on non-native weights")
         N = ncol
