@@ -132,3 +132,22 @@ def test_c_abi_argument_checks():
     a.set_selection(None)
     g.bin(0, [a], len(x))
     assert np.asarray(a.get_result())[2:-1].sum() == ((x > 0) & (x < 1)).sum() + ((x >= 0) & (x < 1)).sum()
+
+
+def test_float32_columns_are_compared_in_float32_like_numpy():
+    """numpy compares a float32 column with a Python float in float32: `f4 <= 0.3` holds for float32(0.3) (0.30000001192...), and
+    `f4 == 0.1` for float32(0.1).  The device predicate rounds the constant to float32 first (round-2 ADVICE: comparing the widened
+    column with the double constant dropped / added exactly the rows that sit on the constant — decimal data stored as float32)."""
+    rng = np.random.default_rng(8)
+    n = 400_000
+    pool = np.array([0.1, 0.3, 0.30000001, 0.29999998, 0.5, 0.7, np.nan, -0.1], dtype="f4")
+    cols = dict(x=rng.normal(0, 1, n), y=rng.normal(0, 1, n), f=rng.choice(pool, n), g=rng.choice(pool, n).astype("f8"))
+    f = Frame(cols, chunk_size=100_000, nthreads=2)
+    with np.errstate(invalid="ignore"):
+        for expr, keep in (("f <= 0.3", cols["f"] <= 0.3), ("f == 0.1", cols["f"] == 0.1), ("f > 0.1", cols["f"] > 0.1), ("f != 0.3", cols["f"] != 0.3),
+                           ("f < 0.3", cols["f"] < 0.3), ("(f >= 0.3) & (g >= 0.3)", (cols["f"] >= 0.3) & (cols["g"] >= 0.3))):
+            got = f.count(binby=["x", "y"], limits=LIM, shape=16, selection=expr, edges=True)
+            assert int(got.sum()) == int(keep.sum()), (expr, int(got.sum()), int(keep.sum()))
+            assert np.array_equal(_want_mask(expr, cols), keep), expr
+    # the rows ON the constant are what the rounding decides
+    assert int((cols["f"] == np.float32(0.3)).sum()) > 10_000 and int((cols["f"].astype("f8") <= 0.3).sum()) != int((cols["f"] <= 0.3).sum())
