@@ -2004,6 +2004,7 @@ __global__ void __launch_bounds__(1024) part_scatter_wv(const PartArgs P) {
     };
 
     if (has_work) {
+        if (!(P.no_pipeline & 1024)) {
         // ping-pong register buffers, the loop unrolled by two so that neither is ever copied (see count_lds_f64)
         Raw bufA, bufB;
         request(tile, bufA);
@@ -2020,6 +2021,34 @@ __global__ void __launch_bounds__(1024) part_scatter_wv(const PartArgs P) {
             process(bufB);
             if (!has_next) break;
             tile = next;
+        }
+        } else {
+        // experiment of round 3 (no_pipeline bit 10; measured: no difference, 4.93 vs 4.93 ms in one process): THREE register
+        // buffers — two tiles requested ahead of the one being binned (196 KB in flight per CU instead of 98 KB); unrolled by three so that no buffer is ever copied; a tile index past the end re-requests
+        // the wave's first tile (a static number of loads in flight)
+        Raw bufA, bufB, bufC;
+        const uint32_t first = tile;
+        bool vb = tile + GW < ntiles, vc, va;
+        request(first, bufA);
+        request(vb ? tile + GW : first, bufB);
+        uint32_t rq = tile + 2u * GW; // the next tile to request
+        for (;;) {
+            vc = vb && rq < ntiles;
+            request(vc ? rq : first, bufC);
+            rq += GW;
+            process(bufA);
+            if (!vb) break;
+            va = vc && rq < ntiles;
+            request(va ? rq : first, bufA);
+            rq += GW;
+            process(bufB);
+            if (!vc) break;
+            vb = va && rq < ntiles;
+            request(vb ? rq : first, bufB);
+            rq += GW;
+            process(bufC);
+            if (!va) break;
+        }
         }
         // what is left in the rings (less than a granule per slab), then the fill of the blocks still open
         const uint32_t my_cnt = (DIRECT != 2 && lane < S) ? cnt[lane] : 0u;
