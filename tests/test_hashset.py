@@ -2,6 +2,8 @@
 method by method and key by key: update(return_values=True) incl. masked rows / NaN / -0.0 and +0.0, merge, create
 (-> map_ordinal's dtype and ordinals), isin, null_index / nan_index, key_array / keys, flatten_values, pickling — plus the
 cases of the reference's own tests/internal/hash_test.py:69-153 (test_set_bool, test_set_float over nan x missing x nmaps).
+(hash_test.py:374-483 test `index_hash_<T>` — the row-index map behind df.join, vaex/join.py — which is not on the groupby path:
+SURVEY §8 row a9 is `ordered_set<T>`; joins are §2 out of scope.)
 
 Two backends run the same checks:
   * `-m gpu`: the product — the device hash map of libvaexhip.so behind the host logic of vaex_amd/hashset.py;
