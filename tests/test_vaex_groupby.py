@@ -70,7 +70,8 @@ taken = [
   ("k", {"v": ["sum", "mean"], "i": "sum"}, {}),
   ("k32", {"n": "count", "si": A.sum("i"), "mw": A.mean("w")}, dict(sort=True, ascending=False)),
   ("ku", A.mean("v"), dict(sort=True)),   # (descending on an unsigned key trips vaex's own BinnerInteger: vmin - 2 wraps, vaex/groupby.py:162-166)
-  ("kgap", {"s": A.sum("v"), "c": A.count()}, {}),                 # range 148 > 4/3 * 50 keys: vaex keeps its Grouper (narrowed key dtype)
+  ("kgap", {"s": A.sum("v"), "c": A.count()}, {}),
+  ("k", {"lo": A.min("v"), "hi": A.max("v"), "ilo": A.min("i"), "s": A.sum("v")}, {}),                 # range 148 > 4/3 * 50 keys: vaex keeps its Grouper (narrowed key dtype)
 ]
 if gpu:   # (several keys are packed on the device, scattered keys need the hash aggregation: no CPU stand-in)
     taken += [(["k", "k32"], {"c": A.count(), "s": A.sum("v")}, {}),
@@ -82,7 +83,7 @@ declined = [
   ("k8", {"c": A.count()}, "dtype int8"),
   ("virt", {"c": A.count()}, "not a real column"),
   ("k", {"u": A.nunique("i")}, "AggNUnique"),
-  ("k", {"lo": A.min("v")}, "AggMin"),
+  ("k", {"lo": A.first("v", "i")}, "AggFirst"),
   ("k", {"c": A.count(selection="v > 3")}, "selection"),
   ("k", {"sd": A.std("i")}, "var / std of an integer column"),
 ]
@@ -126,12 +127,12 @@ def _run(gpu, timeout):
 @pytest.mark.skipif(not os.path.isdir(os.path.join(PKG, "vaex")), reason="real vaex package not built (oracle/build_ref.sh needs /root/reference)")
 def test_groupby_host_logic_against_vaex_on_the_reference_cpp():
     out = _run(0, 600)
-    assert "DONE" in out and out.count("ok-device") == 7 and out.count("ok-declined") == 7, out
+    assert "DONE" in out and out.count("ok-device") == 8 and out.count("ok-declined") == 7, out
 
 
 @pytest.mark.gpu
 @pytest.mark.skipif(not os.path.isdir(os.path.join(PKG, "vaex")), reason="real vaex package not built (oracle/build_ref.sh needs /root/reference)")
 def test_groupby_of_real_vaex_runs_on_the_device_groupby():
     out = _run(1, 900)
-    assert "DONE" in out and out.count("ok-device") == 11 and out.count("ok-declined") == 7, out
+    assert "DONE" in out and out.count("ok-device") == 12 and out.count("ok-declined") == 7, out
     assert "gb_scatter+gb_reduce" in out and "bin_lds" in out, out   # (the fused hash aggregation, and — few groups — the LDS-resident grid)

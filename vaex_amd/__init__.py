@@ -299,3 +299,7 @@ def uncache_columns(obj=None, columns=None):
         if key in _cached_arrays:
             superagg.cache_unregister(a.view("u1") if a.dtype.kind == "b" else a)
             del _cached_arrays[key]
+            import sys
+            vg = sys.modules.get(__name__ + ".vaex_groupby")
+            if vg is not None:   # (the wrapped df.groupby keeps device copies of registered columns)
+                vg._device_copies.pop(key, None)

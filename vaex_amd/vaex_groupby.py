@@ -8,7 +8,7 @@ classes under that machinery already; this module goes one step further for the 
 vaex_amd.binned.Frame covers — it answers `DataFrame.groupby(by, agg=...)` itself:
 
     keys   1..8 real integer columns (int16 .. int64, uint16 .. uint32; numpy / memory-mapped, no missing values)
-    agg    count(*) / count(x) / sum(x) / mean(x) / var(x) / std(x) on real numeric columns without missing values, no
+    agg    count(*) / count(x) / sum(x) / mean(x) / var(x) / std(x) / min(x) / max(x) on real numeric columns without missing values, no
            selection — given as vaex.agg objects, names ('count', 'mean', ...), lists or {name: ...} dicts, i.e. every
            form GroupByBase._agg accepts (vaex/groupby.py:688-745; the output column names follow its rules)
     frame  not filtered, row_limit=None
@@ -36,7 +36,7 @@ last = {}
 
 _KEY_KINDS = ("int16", "int32", "int64", "uint16", "uint32")
 _VALUE_KINDS = ("float64", "float32", "int64", "int32", "int16", "int8", "uint32", "uint16", "uint8")
-_AGG_NAMES = {"AggCount": "count", "AggSum": "sum"}
+_AGG_NAMES = {"AggCount": "count", "AggSum": "sum", "AggMin": "min", "AggMax": "max"}
 
 
 class _Decline(Exception):
