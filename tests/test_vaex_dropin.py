@@ -98,6 +98,16 @@ def _named(d):
     d.select("v > 4")
     return d.count(binby="x", limits=[-4, 4], shape=8, selection=True)
 hot["named_sel"] = _named
+def _mixed(d):   # ONE task, four aggregations: a device predicate, a named selection (host mask), none, a list of selections (host masks)
+    d.select("v > 4")
+    a = d.count(binby="x", limits=[-4, 4], shape=8, selection="(v > 3) & (y < 1)", delay=True)
+    b = d.sum("v", binby="x", limits=[-4, 4], shape=8, selection=True, delay=True)
+    c = d.mean("v", binby="x", limits=[-4, 4], shape=8, delay=True)
+    e = d.count(binby="x", limits=[-4, 4], shape=8, selection=["v > 3", "i < 0"], delay=True)
+    f = d.max("i", binby="x", limits=[-4, 4], shape=8, selection="i < 50", delay=True)
+    d.execute()
+    return [np.asarray(a.get()), np.asarray(b.get()), np.asarray(c.get()), np.asarray(e.get()), np.asarray(f.get())]
+hot["mixed_selections"] = _mixed
 fallback = {   # not offered by the HIP classes: must run on vaex's own C++ after install(), GPU or not
   "count_string": lambda d: d.count("s", binby="y", limits=[-4, 4], shape=4),   # AggCount_string
   "count_string_sel": lambda d: d.count("s", binby="y", limits=[-4, 4], shape=4, selection="v > 3"),   # ... with a planned predicate: numpy inside process
@@ -129,7 +139,7 @@ else:
         if whole:
             assert ("gb_scatter" in vg.last["kernel"]) == (name == "groupby_sparse") and ("part_scatter" in vg.last["kernel"] or "bin_" in vg.last["kernel"] or name == "groupby_sparse"), (name, vg.last)
         print("ok-backend hip", name, len(used), vg.last.get("kernel", ""))
-        if name in ("mean_sel", "count_sel2", "sum_sel_int", "f32_boundary"):
+        if name in ("mean_sel", "count_sel2", "sum_sel_int", "f32_boundary", "mixed_selections"):
             assert vsel.stats["device_chunks"] > seen_device, (name, vsel.stats)   # the predicate ran on the device
         elif name in ("named_sel", "first_sel", "groupby_list_sel"):   # (a named selection; aggregators that read host masks only)
             assert vsel.stats["device_chunks"] == seen_device, (name, vsel.stats)  # vaex's own mask
@@ -242,15 +252,15 @@ def test_unmodified_vaex_without_a_gpu_fails_loudly_and_falls_back():
     if vaex_amd.superagg.device_count() > 0:
         pytest.skip("a GPU is visible: see the -m gpu test")
     out = _run(20000, 0, 300)
-    assert out.count("ok-loud-failure") == 23 and out.count("ok-fallback") == 2, out
+    assert out.count("ok-loud-failure") == 24 and out.count("ok-fallback") == 2, out
 
 
 @pytest.mark.gpu
 @pytest.mark.skipif(not os.path.isdir(os.path.join(PKG, "vaex")), reason="real vaex package not built (oracle/build_ref.sh needs /root/reference)")
 def test_unmodified_vaex_drives_the_hip_classes_on_the_gpu():
     out = _run(300_000, int(os.environ.get("VAEX_DROPIN_TIMING_ROWS", "100000000")), 900)
-    assert out.count("ok-parity") == 23 and out.count("ok-fallback") == 2, out
-    assert out.count("ok-backend hip") == 23 and out.count("ok-backend cpu") == 2, out
+    assert out.count("ok-parity") == 24 and out.count("ok-fallback") == 2, out
+    assert out.count("ok-backend hip") == 24 and out.count("ok-backend cpu") == 2, out
     line = [l for l in out.splitlines() if l.startswith("TIMING")]
     assert line, out
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)

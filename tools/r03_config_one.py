@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One BASELINE config, a few passes on device-resident columns — for rocprofv3 (kernel stats / --pmc FETCH_SIZE, WRITE_SIZE).
-Usage: python tools/r03_config_one.py c2|c3d|c3s [rows] [passes]"""
+Usage: python tools/r03_config_one.py c2|c3d|c3s [rows] [passes] [knob=value ...]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -10,6 +10,8 @@ sa = vaex_amd.superagg
 which = sys.argv[1]
 rows = int(float(sys.argv[2])) if len(sys.argv) > 2 else 1_000_000_000
 passes = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+for kv in sys.argv[4:]:   # knobs: key=value
+    sa.config_set(kv.split("=")[0], int(kv.split("=")[1]))
 g = torch.Generator(device="cuda").manual_seed(7)
 if which == "c2":
     x, y, z, v = (torch.randn(rows, dtype=torch.float64, device="cuda", generator=g) for _ in range(4))
