@@ -258,7 +258,7 @@ def test_unmodified_vaex_without_a_gpu_fails_loudly_and_falls_back():
 @pytest.mark.gpu
 @pytest.mark.skipif(not os.path.isdir(os.path.join(PKG, "vaex")), reason="real vaex package not built (oracle/build_ref.sh needs /root/reference)")
 def test_unmodified_vaex_drives_the_hip_classes_on_the_gpu():
-    out = _run(300_000, int(os.environ.get("VAEX_DROPIN_TIMING_ROWS", "100000000")), 900)
+    out = _run(300_000, int(os.environ.get("VAEX_DROPIN_TIMING_ROWS", "400000000")), 900)
     assert out.count("ok-parity") == 24 and out.count("ok-fallback") == 2, out
     assert out.count("ok-backend hip") == 24 and out.count("ok-backend cpu") == 2, out
     line = [l for l in out.splitlines() if l.startswith("TIMING")]
