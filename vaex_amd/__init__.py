@@ -125,6 +125,11 @@ def install(vaex_module=None, legacy=True, hash_sets=True, chunk_size="auto", gr
         @classmethod
         def decode(cls, encoding, spec, df, nthreads):
             from . import vaex_selection
+            import vaex.memory
+            # the executor checks the parts' memory_usage() against what its tracker saw (vaex/execution.py:413-414): aggregators a
+            # failed HIP attempt built before it hit an unsupported one must not stay on the tracker's books
+            tracker = getattr(vaex.memory.local, "agg", None)
+            booked = getattr(tracker, "used", None)
             with backend.use("hip"):
                 try:
                     part = base.decode.__func__(cls, encoding, spec, df, nthreads)
@@ -134,6 +139,8 @@ def install(vaex_module=None, legacy=True, hash_sets=True, chunk_size="auto", gr
                 except (ValueError, TypeError, NotImplementedError) as e:
                     if "Could not find a class" not in str(e) and not isinstance(e, NotImplementedError):
                         raise
+            if booked is not None:
+                tracker.used = booked
             with backend.use("cpu"):
                 part = base.decode.__func__(cls, encoding, spec, df, nthreads)
                 part.backend_used = "cpu"
