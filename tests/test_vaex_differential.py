@@ -87,14 +87,40 @@ calls = {
   "groupby_two": lambda d: (lambda g: [g[c].to_numpy() for c in g.get_column_names()])(d.groupby(["k", "i"], agg={"c": "count", "s": vaex.agg.sum("v")}).sort(["k", "i"])),
   "first_last": lambda d: [np.ma.filled(d.first("v", "z", binby="x", limits=L1, shape=8), -9), np.ma.filled(d.last("i", "v", binby="y", limits=L1, shape=8), -9)],
   "nunique": lambda d: [d._compute_agg("nunique", "i", binby="x", limits=L1, shape=4), d.k.nunique(), d._compute_agg("nunique", "u1", binby="y", limits=L1, shape=4)],
+  "binby_int_cols": lambda d: [d.count(binby="i", limits=[-50, 50], shape=100), d.count(binby="u1", limits=[0, 200], shape=20), d.count(binby="f4", limits=L1, shape=16), d.mean("v", binby=["i", "f4"], limits=[[-50, 50], [-3, 3]], shape=[10, 6])],
+  "binby_int_edges_sel": lambda d: d.count(binby=["i", "x"], limits=[[-20, 20], [-3, 3]], shape=[40, 8], selection="x > 0", edges=True),
+  "big_shape_1d": lambda d: d.count(binby="v", limits=[-5, 11], shape=100_000),
+  "sliced": lambda d: [d[1000:200_001].count(binby="x", limits=L1, shape=16), d[123:200_001].mean("v", binby="y", limits=L1, shape=8, selection="x > 0"), np.ma.filled(d[777:9999].first("v", "z", binby="x", limits=L1, shape=8), -9)],
+  "active_range": lambda d: (lambda e: (e.set_active_range(10, 200_000), e.sum("v", binby="x", limits=L1, shape=8))[1])(d.copy()),
+  "concat": lambda d: (lambda e: [e.count(binby="x", limits=L1, shape=16), e.mean("v", binby="y", limits=L1, shape=8, selection="(i > 0) & (x < 1)"), e.min("i", binby="y", limits=L1, shape=4)])(vaex.concat([d, d[5:1000], d])),
+  "take_sort": lambda d: [d.take(np.arange(0, n, 3)).count(binby="x", limits=L1, shape=16), d.sort("x").sum("v", binby="y", limits=L1, shape=8)],
+  "categorical": lambda d: (lambda e: [e.count(binby="k"), e.mean("v", binby=["k", "x"], limits=[None, [-3, 3]], shape=[None, 4]) if False else 0, e.sum("v", binby="k")])((lambda e: (e.categorize("k", min_value=0, max_value=29, inplace=True), e)[1])(d.copy())),
+  # (which code a value gets is the hash map's iteration order — unspecified, thread-count dependent in vaex itself: compare per LABEL)
+  "ordinal_encode": lambda d: (lambda e: (lambda o: [np.asarray(e.category_labels("ks"))[o], e.count(binby="ks")[o], e.sum("v", binby="ks", selection="v > 3")[o]])(np.argsort(e.category_labels("ks"))))(d.ordinal_encode("ks")),
+  "value_counts_unique": lambda d: [d.k.value_counts().sort_index().values, np.sort(d.ks.unique()), np.sort(np.asarray(d.i.unique(), dtype="f8")), d.x.value_counts(dropnan=True).sort_index().values[:50]],
+  "groupby_sparse": lambda d: (lambda g: [g[c].to_numpy() for c in g.get_column_names()])(d.groupby(["k", "b"], agg={"c": "count", "s": vaex.agg.sum("v")}, assume_sparse=True).sort(["k", "b"])),
+  "groupby_agg_dict": lambda d: (lambda g: [g[c].to_numpy() for c in sorted(g.get_column_names())])(d.groupby("k").agg({"v": ["sum", "mean"], "i": "max"}).sort("k")),
+  "groupby_minmax_var": lambda d: (lambda g: [g[c].to_numpy() for c in g.get_column_names()])(d.groupby("i", agg={"lo": vaex.agg.min("v"), "hi": vaex.agg.max("f4"), "va": vaex.agg.var("v"), "me": vaex.agg.mean("x")}).sort("i")),
+  "groupby_f4_key": lambda d: (lambda g: [g[c].to_numpy() for c in g.get_column_names()])(d.groupby(d.i.astype("float32"), agg={"c": "count"}).sort("i")) if False else 0,
+  "groupby_list": lambda d: (lambda g: [g["k"].to_numpy(), np.array([np.sort(np.asarray(l)).sum() for l in g["l"].tolist()]), np.array([len(l) for l in g["l"].tolist()])])(d[:5000].groupby("k", agg={"l": vaex.agg.list("i")}).sort("k")),
+  "groupby_first": lambda d: (lambda g: [g[c].to_numpy() for c in g.get_column_names()])(d.groupby("k", agg={"f": vaex.agg.first("v", "z"), "l": vaex.agg.last("v", "z")}).sort("k")),
+  "groupby_nunique": lambda d: (lambda g: [g[c].to_numpy() for c in g.get_column_names()])(d.groupby("k", agg={"u": vaex.agg.nunique("i"), "w": vaex.agg.nunique("u1")}).sort("k")),
+  "groupby_binner_objs": lambda d: [(lambda g: [np.ma.filled(g[c].to_numpy().astype("f8") if g[c].to_numpy().dtype.kind in "iufM" else g[c].to_numpy(), -1) for c in g.get_column_names()])(d.groupby(by, agg={"c": "count", "s": vaex.agg.sum("v")}))
+                                    for by in (vaex.groupby.Binner(d.x, -3, 3, 8), vaex.groupby.BinnerInteger(d.i, min_value=-50, max_value=49), vaex.groupby.BinnerInteger(d.u1), vaex.groupby.BinnerTime(d.t, "M"), vaex.groupby.GrouperLimited(d.k, values=[1, 2, 3], keep_other=True, other_value=-1))],
+  "means_with_nan_values": lambda d: [d.mean("x"), d.sum("x"), d.std("x"), d.count("x", binby="y", limits=L1, shape=4), d.mean("x", binby="y", limits=L1, shape=4)],
+  "describe_bits": lambda d: [d.mean(["x", "y", "v"]), d.std(["x", "y"]), d.minmax("i"), d.minmax("u1")],
   "correlation_cov": lambda d: [d.correlation("x", "y"), d.cov("x", "v"), d.mutual_information("x", "y", mi_limits=L2, mi_shape=16) if hasattr(d, "mutual_information") else 0],
 }
+where = {}
 def run_all(tag):
     df = make()
     out = {}
     for name, fn in calls.items():
+        before = dict(hip=vaex_amd.task_stats["hip"], cpu=vaex_amd.task_stats["cpu"], gb=vg.stats["device"]) if tag == "hip" else None
         try:
             out[name] = fn(df)
+            if before:
+                where[name] = (vaex_amd.task_stats["hip"] - before["hip"], vaex_amd.task_stats["cpu"] - before["cpu"], "device groupby" if vg.stats["device"] > before["gb"] else "")
         except Exception as e:
             out[name] = ("EXC", type(e).__name__, str(e)[:200])
     return out
@@ -109,6 +135,7 @@ def flat(v):
     return [np.ma.filled(np.ma.asarray(v).astype("f8") if np.ma.asarray(v).dtype.kind in "iubfM" or np.ma.asarray(v).dtype.kind == "m" else np.asarray(v), np.nan)]
 if gpu:
     import vaex_amd
+    from vaex_amd import vaex_selection as vsel, vaex_groupby as vg
     assert vaex_amd.superagg.device_count() > 0
     vaex_amd.install()
 first = run_all("hip" if gpu else "cpu-1")
@@ -135,8 +162,12 @@ for name in calls:
             bad.append((name, "values", float(np.nanmax(np.abs(p - q)))))
     exc = [x for x in a if isinstance(x, tuple)]
     assert not exc, (name, first[name], second[name])   # (every call of this list works on the reference)
-    print("ok", name)
+    print("ok", name, "tasks on hip / on vaex's C++:", where.get(name))
 assert not bad, bad
+if gpu:
+    print("task parts built on the HIP classes:", vaex_amd.task_stats["hip"], " on vaex's C++:", vaex_amd.task_stats["cpu"], vaex_amd.task_stats["cpu_reasons"])
+    print("df.groupby calls on the device groupby:", vg.stats["device"], " on vaex's two passes:", vg.stats["vaex"], vg.stats["why"])
+    assert vaex_amd.task_stats["hip"] > 3 * vaex_amd.task_stats["cpu"] and vg.stats["device"] >= 4
 print("DONE")
 '''
 

@@ -79,6 +79,10 @@ class _Backend:
 _installed = {}
 
 
+#: where the aggregation task parts of an installed vaex were built (one per task and pool decode): on the HIP classes, or on vaex's own
+#: C++ because an aggregator class / dtype is not offered here — with the reason, so that "drop-in" can be audited per workload
+task_stats = {"hip": 0, "cpu": 0, "cpu_reasons": {}}
+
 AUTO_CHUNK_ROWS_MAX = 1 << 26   # install(chunk_size="auto"): upper bracket of vaex's automatic chunk size (rows)
 
 
@@ -135,16 +139,19 @@ def install(vaex_module=None, legacy=True, hash_sets=True, chunk_size="auto", gr
                     part = base.decode.__func__(cls, encoding, spec, df, nthreads)
                     part.backend_used = "hip"
                     vaex_selection.attach(part, "hip", superagg, nthreads)
+                    task_stats["hip"] += 1
                     return part
                 except (ValueError, TypeError, NotImplementedError) as e:
                     if "Could not find a class" not in str(e) and not isinstance(e, NotImplementedError):
                         raise
+                    task_stats["cpu_reasons"][str(e)[:120]] = task_stats["cpu_reasons"].get(str(e)[:120], 0) + 1
             if booked is not None:
                 tracker.used = booked
             with backend.use("cpu"):
                 part = base.decode.__func__(cls, encoding, spec, df, nthreads)
                 part.backend_used = "cpu"
                 vaex_selection.attach(part, "cpu", superagg, nthreads)
+                task_stats["cpu"] += 1
                 return part
 
         def process(self, thread_index, i1, i2, filter_mask, selection_masks, blocks):

@@ -33,6 +33,8 @@ from . import binned
 
 #: what the most recent DataFrame.groupby(..., agg=...) ran on: {"path": "device" | "vaex", "kernel": ..., "why": ...}
 last = {}
+#: df.groupby calls answered by the device groupby / handed on to vaex's own two passes (with the reasons)
+stats = {"device": 0, "vaex": 0, "why": {}}
 
 _KEY_KINDS = ("int16", "int32", "int64", "uint16", "uint32")
 _VALUE_KINDS = ("float64", "float32", "int64", "int32", "int16", "int8", "uint32", "uint16", "uint8")
@@ -261,7 +263,10 @@ def install(vaex_module, state):
             except _Decline as e:
                 last.clear()
                 last.update(path="vaex", why=str(e))
+                stats["vaex"] += 1
+                stats["why"][str(e)[:100]] = stats["why"].get(str(e)[:100], 0) + 1
             else:
+                stats["device"] += 1
                 return self._delay(delay, vaex.promise.Promise.fulfilled(result))
         return original(self, by=by, agg=agg, sort=sort, ascending=ascending, assume_sparse=assume_sparse, row_limit=row_limit, copy=copy, progress=progress, delay=delay)
 
