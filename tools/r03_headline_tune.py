@@ -43,7 +43,7 @@ for r in range(reps + 1):
         res = [np.array(a.get_result()) for a in aggs]
         if ref is None:
             ref = res
-        else:
+        elif "no_pipeline" not in cfg:   # (ablation bits drop work on purpose)
             assert np.array_equal(res[0], ref[0]) and np.array_equal(res[2], ref[2]) and np.all(np.abs(res[1] - ref[1]) <= 1e-12 * 20 * np.maximum(ref[0], 1)), cfg
         for k, val in saved.items():
             sa.config_set(k, val)

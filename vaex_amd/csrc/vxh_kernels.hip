@@ -1950,8 +1950,9 @@ __global__ void __launch_bounds__(1024) part_scatter_wv(const PartArgs P) {
                 // memory operations complete in issue order, so a store inside a branch — a number of operations the
                 // compiler cannot count — makes the wait for the next tile's columns (requested before, i.e. older) a
                 // wait for every store's acknowledgement too: 1.3 us per tile, a quarter of the kernel's time.
-                const bool fits = c && pos[r] < where[r][2];
-                store_record(fits ? (((uint64_t)where[r][1] << 32) | where[r][0]) + pos[r] : sink, loc[r], NVAL ? val[NVAL ? r : 0] : 0.0);
+                bool fits = c && pos[r] < where[r][2];
+                if (P.no_pipeline & 2) { fits = false; c = false; } // (timing experiments: bit 1 sends every record to the sink; bit 11 keeps every stream inside 32 records — its lines never leave the L2)
+                store_record(fits ? (((uint64_t)where[r][1] << 32) | where[r][0]) + ((P.no_pipeline & 2048) ? (pos[r] & 31u) : pos[r]) : sink, loc[r], NVAL ? val[NVAL ? r : 0] : 0.0);
                 c = c && !fits;
                 // rare: the slab's block is full (the next one, now) or the sub-queue is (slow path).  `where` may be
                 // stale (a block opened while an earlier row of this tile was stored): look at the table again first
