@@ -497,3 +497,80 @@ def test_hot_box_uint16_counters_are_exact(sa):
         case = dict(n=m, binners=[dict(kind="scalar", data=xs, vmin=-4, vmax=4, bins=256), dict(kind="scalar", data=ys, vmin=-4, vmax=4, bins=256)],
                     aggs=[dict(kind="count"), dict(kind="sum", data=vs), dict(kind="count", data=vs)])
         cases.assert_case_equal(head, _ref_or_port_case(_ref_module(), case), case)
+
+
+@pytest.mark.parametrize("shape", ["bench_2d", "selection_2d", "uniform_2d", "three_d", "groupby_key"])
+def test_int64_value_columns_ride_the_fast_kernels_with_integer_sums(sa, shape):
+    """round 3: an int64 value column (ids, counts, datetimes: AggSum_int64 / AggCount_int64 into int64 cells) takes
+    part_scatter_wv + the box + part_reduce_fast with two's-complement adds in LDS instead of the generic kernels.  Sums wrap like the
+    reference's `grid[i] += value` on int64 (src/agg_sum.cpp:98-127): values up to +-2^62 are in the data.  Bit-exact against the
+    reference's C++ on a slice, and linear over a split of the rows at the full size."""
+    import torch
+    g = torch.Generator(device="cuda").manual_seed(77)
+    n = 1 << 26
+    v = torch.randint(-(1 << 40), 1 << 40, (n,), dtype=torch.int64, device="cuda", generator=g)
+    v[::1001] = (1 << 62) + 12345
+    v[1::1001] = -(1 << 62) - 999
+    v[2::5003] = 0x7FF8000000000001   # (the bit pattern of a float64 NaN: an integer like any other)
+    if shape == "uniform_2d":
+        x = torch.rand(n, dtype=torch.float64, device="cuda", generator=g) * 8 - 4
+        y = torch.rand(n, dtype=torch.float64, device="cuda", generator=g) * 8 - 4
+    else:
+        x = torch.randn(n, dtype=torch.float64, device="cuda", generator=g)
+        y = torch.randn(n, dtype=torch.float64, device="cuda", generator=g)
+    z = torch.randn(n, dtype=torch.float64, device="cuda", generator=g)
+    key = torch.randint(0, 200_000, (n,), dtype=torch.int64, device="cuda", generator=g) + 1000
+    keep = (torch.rand(n, device="cuda", generator=g) < 0.6).to(torch.uint8)
+    torch.cuda.synchronize()
+
+    def run(lo, hi):
+        if shape == "groupby_key":
+            binners = [sa.BinnerOrdinal_int64(1, "k", 200_000, 1000, False, False)]
+            binners[0].set_data(0, key[lo:hi])
+        elif shape == "three_d":
+            binners = [sa.BinnerScalar_float64(1, c, -4.0, 4.0, 64) for c in "xyz"]
+            for b, col in zip(binners, (x, y, z)):
+                b.set_data(0, col[lo:hi])
+        else:
+            binners = [sa.BinnerScalar_float64(1, c, -4.0, 4.0, 256) for c in "xy"]
+            for b, col in zip(binners, (x, y)):
+                b.set_data(0, col[lo:hi])
+        grid = sa.Grid(binners)
+        aggs = [sa.AggCount_int64(grid, 1, 1), sa.AggSum_int64(grid, 1, 1), sa.AggCount_int64(grid, 1, 1)]
+        aggs[1].set_data(0, v[lo:hi], 0); aggs[2].set_data(0, v[lo:hi], 0)
+        if shape == "selection_2d":
+            for a in aggs:
+                a.set_data_mask(0, keep[lo:hi])
+        grid.bin(0, aggs, hi - lo)
+        return [np.array(a.get_result()) for a in aggs], sa.last_kernel(0)
+
+    full, kernel = run(0, n)
+    assert kernel.startswith("part_scatter") and ("i64" in kernel or "hot" in kernel), kernel   # (not the generic pair)
+    if shape == "bench_2d":
+        assert kernel.startswith("part_scatter_direct_hot"), kernel
+    m = 4_000_000
+    head, _ = run(0, m)
+    rest, _ = run(m, n)
+    for k in range(3):
+        with np.errstate(over="ignore"):
+            np.testing.assert_array_equal(full[k], head[k] + rest[k])
+    assert full[1].dtype == np.int64
+    kept = int(keep.sum().item()) if shape == "selection_2d" else n
+    assert int(full[0].sum()) == kept and int(full[2].sum()) == kept
+    cols = dict(x=x, y=y, z=z)
+    if shape == "groupby_key":
+        bs = [dict(kind="ordinal", data=key[:m].cpu().numpy(), count=200_000, min_value=1000)]
+    elif shape == "three_d":
+        bs = [dict(kind="scalar", data=cols[c][:m].cpu().numpy(), vmin=-4, vmax=4, bins=64) for c in "xyz"]
+    else:
+        bs = [dict(kind="scalar", data=cols[c][:m].cpu().numpy(), vmin=-4, vmax=4, bins=256) for c in "xy"]
+    vs = v[:m].cpu().numpy()
+    aggs = [dict(kind="count"), dict(kind="sum", data=vs), dict(kind="count", data=vs)]
+    if shape == "selection_2d":
+        ks = keep[:m].cpu().numpy()
+        for a in aggs:
+            a["mask"] = ks
+    case = dict(n=m, binners=bs, aggs=aggs)
+    want = _ref_or_port_case(_ref_module(), case)
+    for k in range(3):
+        np.testing.assert_array_equal(head[k], want[k])

@@ -106,8 +106,25 @@ for by, agg, why in declined:
     print("ok-declined", by, vg.last["why"])
 # a filtered frame and a row limit are vaex's business
 vg.last.clear(); df[df.k > 3].groupby("k", agg="count"); assert vg.last.get("path") == "vaex" and "filtered" in vg.last["why"]
-# without agg the GroupBy object comes from vaex
-assert type(df.groupby("k")).__name__ == "GroupBy"
+# without agg: a GroupBy whose groupers are only built when something other than a device-servable .agg() is asked of it
+g = df.groupby("k", sort=True)
+assert isinstance(g, vaex.groupby.GroupBy) and "_lazy" in g.__dict__
+vg.last.clear()
+got = g.agg({"v": ["sum", "mean"], "i": "max"})
+assert vg.last.get("path") == "device" and "_lazy" in g.__dict__, vg.last
+want = original(df, "k", sort=True).agg({"v": ["sum", "mean"], "i": "max"})
+assert got.get_column_names() == want.get_column_names()
+same({c: got[c].to_numpy() for c in got.get_column_names()}, {c: want[c].to_numpy() for c in want.get_column_names()}, "lazy agg")
+got = g.agg({"c": A.count(selection="v > 3")})     # outside the signature: becomes the real object, answers as vaex does
+assert "_lazy" not in g.__dict__ and vg.last.get("path") == "vaex"
+want = original(df, "k", sort=True).agg({"c": A.count(selection="v > 3")})
+same({c: got[c].to_numpy() for c in got.get_column_names()}, {c: want[c].to_numpy() for c in want.get_column_names()}, "lazy agg declined")
+g = df.groupby("k")
+assert "_lazy" in g.__dict__ and len(list(g.groups)) == len(np.unique(df.k.to_numpy())) and "_lazy" not in g.__dict__   # (any other attribute: the real one)
+assert same({c: g.get_group(3)[c].to_numpy() for c in ["k", "v"]}, {c: original(df, "k").get_group(3)[c].to_numpy() for c in ["k", "v"]}, "get_group") is None
+assert type(df.groupby("kf")).__name__ == "GroupBy" and type(df.groupby(df.k + 1)).__name__ == "GroupBy"   # (keys the device groupby does not take)
+assert type(df.groupby("k", row_limit=100)).__name__ == "GroupBy"
+print("ok-lazy")
 # a slice of the frame (active range)
 part = df[1000:150_000]
 vg.last.clear()

@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Round 3: the bench pass (2-D 256x256, count + sum + count(v), 1e9 N(0,1) rows) with other value dtypes — which kernels run, how fast.
+Usage: python tools/r03_dtype_paths.py [rows] [reps]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import vaex_amd
+sa = vaex_amd.superagg
+rows = int(float(sys.argv[1])) if len(sys.argv) > 1 else 1_000_000_000
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+g = torch.Generator(device="cuda").manual_seed(1234)
+x = torch.randn(rows, dtype=torch.float64, device="cuda", generator=g)
+y = torch.randn(rows, dtype=torch.float64, device="cuda", generator=g)
+vals = {
+    "float64": torch.randn(rows, dtype=torch.float64, device="cuda", generator=g) * 2 + 3,
+    "int64": torch.randint(-1000, 1000, (rows,), dtype=torch.int64, device="cuda", generator=g),
+    "int32": torch.randint(-1000, 1000, (rows,), dtype=torch.int32, device="cuda", generator=g),
+    "float32": torch.randn(rows, dtype=torch.float32, device="cuda", generator=g),
+}
+torch.cuda.synchronize()
+for name, v in vals.items():
+    bx = sa.BinnerScalar_float64(1, "x", -4.0, 4.0, 256); by = sa.BinnerScalar_float64(1, "y", -4.0, 4.0, 256)
+    grid = sa.Grid([bx, by])
+    aggs = [sa.AggCount_int64(grid, 1, 1), getattr(sa, "AggSum_" + name)(grid, 1, 1), getattr(sa, "AggCount_" + name)(grid, 1, 1)]
+    bx.set_data(0, x); by.set_data(0, y); aggs[1].set_data(0, v, 0); aggs[2].set_data(0, v, 0)
+    best = 1e9
+    for r in range(reps + 1):
+        for a in aggs:
+            a.reset()
+        sa.timer_start(0)
+        grid.bin(0, aggs, rows)
+        ms = sa.timer_stop(0)
+        if r:
+            best = min(best, ms)
+    total = int(np.array(aggs[0].get_result()).sum())
+    assert total == rows
+    bytes_per_row = 16 + v.element_size()
+    print(f"value {name:<8} {best:8.3f} ms {rows/best/1e6:7.1f} Grows/s  {rows*bytes_per_row/best/1e6/8000:6.3f} of 8 TB/s on {bytes_per_row} B/row   {sa.last_kernel(0)}", flush=True)

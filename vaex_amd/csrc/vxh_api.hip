@@ -587,9 +587,23 @@ static LaunchPlan make_plan(const BinArgs &A, BinArgs &out, uint64_t n, double b
         const AggDesc &a = A.a[k];
         if (a.data && (a.dtype != VXH_F64 || a.flip)) fast_vals = false;
     }
+    p.bin_f64 = fast;
     fast = fast && fast_vals;
     p.fast_f64 = fast;
     p.fast_vals = fast_vals;
+    // integer value columns (sums of counts, ids, datetimes): int64 inputs counted / summed into int64 cells ride the float64
+    // kernels' 8-byte payloads with integer adds (PartArgs::val_i64)
+    bool vals_i64 = false;
+    for (int k = 0; k < A.nagg; k++) {
+        const AggDesc &a = A.a[k];
+        if (a.data) vals_i64 = true;
+    }
+    for (int k = 0; k < A.nagg; k++) {
+        const AggDesc &a = A.a[k];
+        if (a.data && (a.dtype != VXH_I64 || a.flip)) vals_i64 = false;
+        if (a.kind == VXH_AGG_SUM ? a.cell != VXH_CELL_I64 : a.kind != VXH_AGG_COUNT) vals_i64 = false;
+    }
+    p.vals_i64 = vals_i64;
     bool f32 = A.ndim >= 1;
     for (int d = 0; d < A.ndim; d++) {
         const BinnerDesc &b = A.b[d];
@@ -701,7 +715,7 @@ static LaunchPlan make_plan(const BinArgs &A, BinArgs &out, uint64_t n, double b
         out.replicas = 1;
         p.use_replicas = 1;
         p.blocks = parts * S;
-        p.name = fast ? "part_scatter+part_reduce_f64" : "part_scatter+part_reduce_generic";
+        p.name = fast ? "part_scatter+part_reduce_f64" : ((p.vals_i64 && (p.bin_f64 || p.key_i64)) ? "part_scatter+part_reduce_i64" : "part_scatter+part_reduce_generic");
         return p;
     }
 
@@ -799,7 +813,8 @@ static bool wv_aligned(const BinArgs &A) {
 static int hot_eligible(const BinArgs &A, const LaunchPlan &plan, bool *masked = nullptr, bool *mom2 = nullptr) {
     // (grids beyond 2^21 cells: the box could hold well under 1 % of the area, and the sample's count grid — copied to the host —
     //  would be tens of megabytes)
-    if ((!plan.fast_f64 && !plan.fast_f32) || A.ndim != 2 || A.nagg < 1 || A.cells > (1ull << 21)) return -1;
+    const bool ints = plan.bin_f64 && plan.vals_i64; // (int64 sums: the ring-less part_scatter_wv only, see hot_prepare)
+    if ((!plan.fast_f64 && !plan.fast_f32 && !ints) || A.ndim != 2 || A.nagg < 1 || A.cells > (1ull << 21)) return -1;
     const void *v = nullptr;
     if (masked) *masked = A.a[0].mask != nullptr;
     if (mom2) *mom2 = false;
@@ -807,7 +822,7 @@ static int hot_eligible(const BinArgs &A, const LaunchPlan &plan, bool *masked =
         const AggDesc &a = A.a[k];
         if (a.mask != A.a[0].mask) return -1;
         if (a.kind == VXH_AGG_COUNT) { if (a.data) { if (v && v != a.data) return -1; v = a.data; } }
-        else if (a.kind == VXH_AGG_SUM && a.cell == VXH_CELL_F64 && a.data) { if (v && v != a.data) return -1; v = a.data; }
+        else if (a.kind == VXH_AGG_SUM && a.cell == (ints ? VXH_CELL_I64 : VXH_CELL_F64) && a.data) { if (v && v != a.data) return -1; v = a.data; }
         else if (a.kind == VXH_AGG_SUM_MOMENT && a.moment == 2 && a.cell == VXH_CELL_F64 && a.data && mom2) { if (v && v != a.data) return -1; v = a.data; *mom2 = true; } // var / std
         else return -1;
     }
@@ -886,8 +901,9 @@ static void hot_prepare(Slot &slot, const BinArgs &A, const BinArgs &planned, co
     const bool gen2 = c.cfg_blk && S <= 256 && slab_cells < 65535 && !(c.cfg_no_pipeline & 1) && c.cfg_part_rows <= 0; // (= run_part_chunk's conditions for part_scatter_blk)
     const WvGeom wg = wv_geometry(S, nval, true);
     bool wv = wg.ok && slab_cells < 65535 && wv_aligned(A); // (= run_part_chunk's conditions for part_scatter_wv)
+    const bool ints = plan.bin_f64 && plan.vals_i64; // int64 sums: part_scatter_wv's instantiations only
     if ((masked && !(wv && wg.direct == 1)) || plan.fast_f32) { // (the box next to a selection mask: part_scatter_blk's or the ring-less part_scatter_wv's instantiations; on float32 columns: part_scatter_blk's only)
-        if (!gen2) return;
+        if (!gen2 || ints) return;
         wv = false;
     }
     if (wv && gen2 && c.cfg_wv == 1) wv = false; // next to a box part_scatter_blk is the (slightly) faster one: its staging leaves the box 111 KB, eight waves' rings 78 KB
@@ -897,6 +913,7 @@ static void hot_prepare(Slot &slot, const BinArgs &A, const BinArgs &planned, co
     H.cnt16 = false;
     if (wv && forced && gen2 && (uint64_t)c.cfg_hot_box[2] * (uint64_t)c.cfg_hot_box[3] > (kLdsMax - ((size_t)wg.waves * wg.wave_bytes + 64) - 96 - (c16 ? 16 : 0)) / (c16 ? 10 : (nval ? (mom2 ? 20 : 12) : 4))) wv = false;
     if (!gen2 && !wv) return;
+    if (ints && !wv) return;
     H.gen2 = true;
     H.nval = nval;
     const size_t cell_bytes = nval ? (mom2 ? 20 : 12) : 4;
@@ -983,6 +1000,7 @@ static void hot_prepare(Slot &slot, const BinArgs &A, const BinArgs &planned, co
         if (wv && wg.direct && gen2 && room(true)) {
             const double f = searched(room(true), box);
             if (f * 100.0 >= (double)c.cfg_hot_direct_pct) { H.last_fraction = f; chosen = true; }
+            else if (ints) return; // (int64 sums: the box lives in part_scatter_wv only)
             else wv = false;
         }
         if (!chosen) {
@@ -1033,6 +1051,7 @@ static void hot_merge(Slot &slot, const BinArgs &planned) {
     for (int k = 0; k < planned.nagg; k++) {
         M.grid[k] = planned.a[k].grid;
         M.takes_sum[k] = planned.a[k].kind == VXH_AGG_SUM ? 1 : (planned.a[k].kind == VXH_AGG_SUM_MOMENT ? 2 : 0);
+        if (planned.a[k].kind == VXH_AGG_SUM && planned.a[k].cell == VXH_CELL_I64) M.val_i64 = 1; // (hot_eligible: then every sum is one)
     }
     vxh_launch_hot_merge(M, slot.stream);
     HIP_CHECK(hipGetLastError());
@@ -1134,7 +1153,8 @@ static void run_part_chunk(Slot &slot, const BinArgs &planned, const LaunchPlan 
     // third-generation pass 1 (part_scatter_wv): 1..3 float64 scalar binners or one int64 key, <= 1 float64 value column,
     // <= 1 mask shared by every aggregator, uint16 local indices, <= 64 slabs, 16-byte aligned columns
     const WvGeom wg = wv_geometry(S, P.nvals, slot.hot.on);
-    const bool wv = wg.ok && (plan.fast_f64 || (plan.key_i64 && plan.fast_vals)) && planned.ndim >= 1 && planned.ndim <= 3 && P.nvals <= 1 && !P.use_flags &&
+    P.val_i64 = plan.vals_i64 ? 1 : 0;
+    const bool wv = wg.ok && (plan.fast_f64 || (plan.bin_f64 && plan.vals_i64) || (plan.key_i64 && (plan.fast_vals || plan.vals_i64))) && planned.ndim >= 1 && planned.ndim <= 3 && P.nvals <= 1 && !P.use_flags &&
                     (P.nmasks == 0 || (P.nmasks == 1 && P.all_masked)) && P.idx16 && slab_cells < 65535 && wv_aligned(planned) && (!slot.hot.on || slot.hot.wv);
     if (slot.hot.on && slot.hot.wv != wv) throw std::runtime_error("vaex_hip internal: hot box prepared for a different pass-1 kernel");
     int wv_blocks = 0;
@@ -1236,7 +1256,7 @@ static void run_part_chunk(Slot &slot, const BinArgs &planned, const LaunchPlan 
 
     // pass-1 tile: 512 threads x R rows, staged in LDS
     // (many slabs: bigger tiles keep the per-bucket copy-out segments at >= 16 records)
-    int R = c.cfg_part_rows > 0 ? (int)c.cfg_part_rows : ((plan.key_i64 && plan.fast_vals && S >= 64) ? 8 : 4);
+    int R = c.cfg_part_rows > 0 ? (int)c.cfg_part_rows : ((plan.key_i64 && (plan.fast_vals || plan.vals_i64) && S >= 64) ? 8 : 4);
     size_t scatter_lds = 0;
     for (;; R >>= 1) {
         scatter_lds = scatter_lds_bytes(S, R, P.nvals);
@@ -1252,7 +1272,8 @@ static void run_part_chunk(Slot &slot, const BinArgs &planned, const LaunchPlan 
     int scatter_blocks = (int)std::max<uint64_t>(1, std::min<uint64_t>(tiles, (uint64_t)c.cus * per_cu));
     // second-generation pass 1 (part_scatter_blk): float64 scalar binners, <= 1 float64 value column, <= 1 mask shared
     // by every aggregator, uint16 local indices with one value to spare for the null record, <= 64 slabs
-    const bool blk = c.cfg_blk && (plan.fast_f64 || plan.fast_f32 || (plan.key_i64 && plan.fast_vals)) && !(c.cfg_no_pipeline & 1) && planned.ndim >= 1 && planned.ndim <= 3 && P.nvals <= 1 && !P.use_flags &&
+    // (int64 value columns: payloads pass through the box-less instantiations unchanged)
+    const bool blk = c.cfg_blk && (plan.fast_f64 || plan.fast_f32 || (plan.key_i64 && (plan.fast_vals || plan.vals_i64)) || (plan.bin_f64 && plan.vals_i64 && !slot.hot.on)) && !(c.cfg_no_pipeline & 1) && planned.ndim >= 1 && planned.ndim <= 3 && P.nvals <= 1 && !P.use_flags &&
                      (P.nmasks == 0 || (P.nmasks == 1 && P.all_masked)) && P.idx16 && slab_cells < 65535 && S <= 256 && c.cfg_part_rows <= 0 &&
                      (slot.hot.on || (S > 8 && S <= 64 && !plan.key_i64) || (plan.fast_f32 && S <= 64) || c.cfg_blk == 2); // measured (profiles/r01_other_shapes.txt, r01_groupby_tune.txt):
                      // <= 8 slabs without a box: two 512-thread workgroups of part_scatter_f64 are 2 % faster; 128-256 slabs: +5 % (1024^2) / -35 % (1e6-key groupby)
@@ -1913,7 +1934,7 @@ int vxh_grid_bin(vxh_grid *grid, int thread, vxh_agg *const *aggs, int n_aggs, u
             part_acc_prepare(slot, whole_args);
             hot_prepare(slot, A, whole_args, whole, length);
             if (slot.hot.on && slot.hot.gen2 && ctx().cfg_hot_box[2] <= 0) step *= 2; // (see the capacity rule in run_part_chunk)
-            else if (whole.key_i64 && whole.fast_vals && ctx().cfg_part_chunk == (1 << 28)) step *= 2; // groupby on an integer key: 16-byte rows, twice the rows for the same input bytes (8.95 -> 8.66 ms per 1e9 rows, profiles/r02_groupby_tune.txt)
+            else if (whole.key_i64 && (whole.fast_vals || whole.vals_i64) && ctx().cfg_part_chunk == (1 << 28)) step *= 2; // groupby on an integer key: 16-byte rows, twice the rows for the same input bytes (8.95 -> 8.66 ms per 1e9 rows, profiles/r02_groupby_tune.txt)
         } else {
             slot.hot.on = slot.hot.last_on = false;
         }
@@ -1976,10 +1997,10 @@ int vxh_grid_bin(vxh_grid *grid, int thread, vxh_agg *const *aggs, int n_aggs, u
         if (whole.strategy == VXH_STRAT_PART) {
             part_join(slot);
             part_acc_merge(slot, whole_args);
-            if (slot.last_pass1 >= 2) slot.last_kernel = whole.fast_f64 ? "part_scatter_wv+part_reduce_f64" : "part_scatter_wv+part_reduce_generic";
+            if (slot.last_pass1 >= 2) slot.last_kernel = whole.fast_f64 ? "part_scatter_wv+part_reduce_f64" : (whole.vals_i64 ? "part_scatter_wv+part_reduce_i64" : "part_scatter_wv+part_reduce_generic");
             if (slot.hot.on) {
                 hot_merge(slot, whole_args);
-                slot.last_kernel = slot.last_pass1 == 4 ? "part_scatter_shared_hot+part_reduce_f64" : slot.last_pass1 == 3 ? "part_scatter_direct_hot+part_reduce_f64" : (slot.last_pass1 == 2 ? "part_scatter_wv_hot+part_reduce_f64" : "part_scatter_hot+part_reduce_f64");
+                slot.last_kernel = slot.last_pass1 == 4 ? "part_scatter_shared_hot+part_reduce_f64" : slot.last_pass1 == 3 ? (whole.vals_i64 ? "part_scatter_direct_hot+part_reduce_i64" : "part_scatter_direct_hot+part_reduce_f64") : (slot.last_pass1 == 2 ? "part_scatter_wv_hot+part_reduce_f64" : "part_scatter_hot+part_reduce_f64");
             }
             slot.hot.on = false;
             part_guard.armed = false;

@@ -1612,6 +1612,14 @@ constexpr uint32_t VXH_WV_NONE = 0xffffffffu;
 // device atomics.  Lean on purpose — it is inlined at every flush site: the kernel's signature guarantees float64
 // (or absent) aggregator inputs and no per-aggregator masks, so only the five kinds on double / int64 cells remain.
 __device__ __forceinline__ void wv_slow_record(const PartArgs &P, uint64_t cell, double v) {
+    if (P.val_i64) { // int64 value column: counts and int64 sums only (make_plan), `v` carries the integer's bits
+        for (int k = 0; k < P.A.nagg; ++k) {
+            const AggDesc &a = P.A.a[k];
+            if (a.kind == VXH_AGG_COUNT) at_add<__HIP_MEMORY_SCOPE_AGENT, unsigned long long>((unsigned long long *)a.grid + cell, 1ull);
+            else at_add<__HIP_MEMORY_SCOPE_AGENT, unsigned long long>((unsigned long long *)a.grid + cell, (unsigned long long)__double_as_longlong(v));
+        }
+        return;
+    }
     const bool nan = v != v;
     for (int k = 0; k < P.A.nagg; ++k) {
         const AggDesc &a = P.A.a[k];
@@ -1638,6 +1646,7 @@ __global__ void __launch_bounds__(1024) part_scatter_wv(const PartArgs P) {
     const uint32_t hot_cells = HOT ? P.hot.w * P.hot.h : 0u;
     double *const hot_sum = (double *)(lds + P.hot.lds_offset);
     const bool hot_mom2 = HOT && NVAL && P.hot.mom2 != 0u; // (wave-uniform) the box also keeps the sum of squares
+    const bool vint = NVAL && P.val_i64 != 0;               // (wave-uniform) int64 value column: integer adds, no NaN
     double *const hot_sum2 = hot_sum + hot_cells;
     uint32_t *const hot_cnt = (uint32_t *)(hot_sum + (NVAL ? (hot_mom2 ? 2u : 1u) * hot_cells : 0u));
     // uint16 counters, two per word (PartArgs::hot.cnt16): 10-byte cells make the box 20 % larger.  Exact: a wave counts the hot
@@ -1893,10 +1902,11 @@ __global__ void __launch_bounds__(1024) part_scatter_wv(const PartArgs P) {
             if (HOT) {
                 const uint32_t hx = sub_i[0] - P.hot.x0, hy = sub_i[NDIM > 1 ? 1 : 0] - P.hot.y0; // (unsigned: below the box wraps to huge)
                 bool hot = (hx < P.hot.w) & (hy < P.hot.h) & is_cold;
-                if (NVAL) hot = hot & (val[NVAL ? r : 0] == val[NVAL ? r : 0]);
+                if (NVAL && !vint) hot = hot & (val[NVAL ? r : 0] == val[NVAL ? r : 0]);
                 if (hot) {
                     const uint32_t hc = __umul24(hy, P.hot.w) + hx;
-                    if (NVAL) at_add<__HIP_MEMORY_SCOPE_WORKGROUP, double>(hot_sum + hc, val[NVAL ? r : 0]);
+                    if (NVAL && vint) at_add<__HIP_MEMORY_SCOPE_WORKGROUP, unsigned long long>((unsigned long long *)hot_sum + hc, (unsigned long long)__double_as_longlong(val[NVAL ? r : 0]));
+                    else if (NVAL) at_add<__HIP_MEMORY_SCOPE_WORKGROUP, double>(hot_sum + hc, val[NVAL ? r : 0]);
                     if (hot_mom2) at_add<__HIP_MEMORY_SCOPE_WORKGROUP, double>(hot_sum2 + hc, val[NVAL ? r : 0] * val[NVAL ? r : 0]); // (= pow_u(v, 2))
                     at_add<__HIP_MEMORY_SCOPE_WORKGROUP, uint32_t>(hot_cnt + (c16 ? hc >> 1 : hc), c16 ? 1u << ((hc & 1u) << 4) : 1u);
                 }
@@ -2084,7 +2094,8 @@ __global__ void __launch_bounds__(1024) part_scatter_wv(const PartArgs P) {
     }
     if (HOT) {
         unsigned long long *gc = P.hot.cnt_acc + (uint64_t)blockIdx.x * hot_cells;
-        if (NVAL) flush_add_plain<double, double>(P.hot.sum_acc + (uint64_t)blockIdx.x * hot_cells, hot_sum, hot_cells, 0, 0, hot_cells);
+        if (NVAL && vint) flush_add_plain<unsigned long long, unsigned long long>((unsigned long long *)P.hot.sum_acc + (uint64_t)blockIdx.x * hot_cells, (const unsigned long long *)hot_sum, hot_cells, 0, 0, hot_cells);
+        else if (NVAL) flush_add_plain<double, double>(P.hot.sum_acc + (uint64_t)blockIdx.x * hot_cells, hot_sum, hot_cells, 0, 0, hot_cells);
         if (hot_mom2) flush_add_plain<double, double>(P.hot.sum2_acc + (uint64_t)blockIdx.x * hot_cells, hot_sum2, hot_cells, 0, 0, hot_cells);
         if (!c16) {
             flush_add_plain<unsigned long long, uint32_t>(gc, hot_cnt, hot_cells, 0, 0, hot_cells);
@@ -2224,13 +2235,14 @@ __device__ __forceinline__ void reduce_trip_fast(const PartArgs &P, char *lds, u
     }
     // does any lane hold a NaN in value column 0 / 1 of this trip?
     bool nan0 = false, nan1 = false;
-    if (P.nvals > 0) {
+    const bool vint = P.val_i64 != 0; // int64 payloads: integer sums, nothing is NaN
+    if (P.nvals > 0 && !vint) {
         bool m = false;
 #pragma unroll
         for (int u = 0; u < N; ++u) m |= as_f64(v0[u]) != as_f64(v0[u]);
         nan0 = __ballot(m) != 0ull;
     }
-    if (P.nvals > 1) {
+    if (P.nvals > 1 && !vint) {
         bool m = false;
 #pragma unroll
         for (int u = 0; u < N; ++u) m |= as_f64(v1[u]) != as_f64(v1[u]);
@@ -2253,6 +2265,9 @@ __device__ __forceinline__ void reduce_trip_fast(const PartArgs &P, char *lds, u
                     if (d == d) at_add<__HIP_MEMORY_SCOPE_WORKGROUP, uint32_t>((uint32_t *)base + loc[u], 1u);
                 }
             }
+        } else if (vint) {
+#pragma unroll
+            for (int u = 0; u < N; ++u) at_add<__HIP_MEMORY_SCOPE_WORKGROUP, unsigned long long>((unsigned long long *)base + loc[u], (unsigned long long)(second ? v1[u] : v0[u]));
         } else {
             const bool sq = kind[k] == VXH_AGG_SUM_MOMENT;
 #pragma unroll
@@ -2390,28 +2405,33 @@ __global__ void __launch_bounds__(256) part_hot_merge(const HotMergeArgs M) {
     const uint32_t lane = threadIdx.x & 63u, q = threadIdx.x >> 6;
     const uint32_t c = blockIdx.x * 64u + lane;
     double s = 0.0, s2 = 0.0;
-    unsigned long long k = 0;
+    unsigned long long k = 0, si = 0; // (si: the box sums of an int64 value column)
     if (c < cells) {
         for (uint32_t b = q; b < M.blocks; b += 4) {
             const uint64_t i = (uint64_t)b * cells + c;
-            if (M.sum_acc) { s += M.sum_acc[i]; M.sum_acc[i] = 0.0; }
+            if (M.sum_acc && M.val_i64) { si += ((unsigned long long *)M.sum_acc)[i]; M.sum_acc[i] = 0.0; }
+            else if (M.sum_acc) { s += M.sum_acc[i]; M.sum_acc[i] = 0.0; }
             if (M.sum2_acc) { s2 += M.sum2_acc[i]; M.sum2_acc[i] = 0.0; }
             k += M.cnt_acc[i];
             M.cnt_acc[i] = 0ull;
         }
     }
-    s_sum[q][lane] = s;
+    s_sum[q][lane] = M.val_i64 ? __longlong_as_double((long long)si) : s;
     s_sum2[q][lane] = s2;
     s_cnt[q][lane] = k;
     __syncthreads();
     if (q != 0 || c >= cells) return;
     s = (s_sum[0][lane] + s_sum[1][lane]) + (s_sum[2][lane] + s_sum[3][lane]);
+    if (M.val_i64) si = (unsigned long long)__double_as_longlong(s_sum[0][lane]) + (unsigned long long)__double_as_longlong(s_sum[1][lane]) + (unsigned long long)__double_as_longlong(s_sum[2][lane]) + (unsigned long long)__double_as_longlong(s_sum[3][lane]);
     s2 = (s_sum2[0][lane] + s_sum2[1][lane]) + (s_sum2[2][lane] + s_sum2[3][lane]);
     k = s_cnt[0][lane] + s_cnt[1][lane] + s_cnt[2][lane] + s_cnt[3][lane];
     if (k == 0) return;
     const uint64_t cell = (uint64_t)(M.x0 + c % M.w) + (uint64_t)(M.y0 + c / M.w) * M.stride_y;
     for (uint32_t a = 0; a < M.nagg; ++a) {
-        if (M.takes_sum[a]) {
+        if (M.takes_sum[a] && M.val_i64) {
+            unsigned long long *g = (unsigned long long *)M.grid[a] + cell;
+            if (M.atomic) at_add<__HIP_MEMORY_SCOPE_AGENT, unsigned long long>(g, si); else *g += si;
+        } else if (M.takes_sum[a]) {
             double *g = (double *)M.grid[a] + cell;
             const double add = M.takes_sum[a] == 2 ? s2 : s;
             if (M.atomic) at_add<__HIP_MEMORY_SCOPE_AGENT, double>(g, add); else *g += add;
@@ -2577,7 +2597,7 @@ void vxh_launch_part_scatter(const PartArgs &args, const LaunchPlan &plan, int s
         else if (args.A.ndim == 2) VXH_BLK(2);
         else VXH_BLK(3);
 #undef VXH_BLK
-    } else if (fast_f64 && R == 4 && args.A.ndim >= 1 && args.A.ndim <= 3 && args.nvals <= 2 && args.nmasks <= 1 && !(args.no_pipeline & 1)) {
+    } else if ((fast_f64 || (plan.bin_f64 && plan.vals_i64)) && R == 4 && args.A.ndim >= 1 && args.A.ndim <= 3 && args.nvals <= 2 && args.nmasks <= 1 && !(args.no_pipeline & 1)) {
 #define VXH_SCN(ND)                                                                                                    \
     do {                                                                                                               \
         scatter_lds = 2 * (size_t)args.scatter_lds_one; /* double-buffered staging */                                  \
@@ -2589,7 +2609,7 @@ void vxh_launch_part_scatter(const PartArgs &args, const LaunchPlan &plan, int s
         else if (args.A.ndim == 2) VXH_SCN(2);
         else VXH_SCN(3);
 #undef VXH_SCN
-    } else if (plan.key_i64 && plan.fast_vals && (R == 4 || R == 8) && args.nvals <= 2 && args.nmasks <= 1 && !(args.no_pipeline & 1)) {
+    } else if (plan.key_i64 && (plan.fast_vals || plan.vals_i64) && (R == 4 || R == 8) && args.nvals <= 2 && args.nmasks <= 1 && !(args.no_pipeline & 1)) {
         scatter_lds = 2 * (size_t)args.scatter_lds_one;
 #define VXH_SCK(RR)                                                                                                    \
     do {                                                                                                               \
@@ -2609,12 +2629,13 @@ void vxh_launch_part_scatter(const PartArgs &args, const LaunchPlan &plan, int s
 
 void vxh_launch_part_reduce(const PartArgs &args, const LaunchPlan &plan, hipStream_t stream) {
     // specialised kernel: count / sum / sum-moment over float64 inputs, no record flags, uint16 indices
-    bool fast = (plan.fast_vals || args.f32) && !args.use_flags && args.idx16 && args.nvals <= 2 && args.A.nagg >= 1 && args.A.nagg <= 4 && !(args.no_pipeline & 16) && !args.A.count16;
+    bool fast = (plan.fast_vals || args.f32 || args.val_i64) && !args.use_flags && args.idx16 && args.nvals <= 2 && args.A.nagg >= 1 && args.A.nagg <= 4 && !(args.no_pipeline & 16) && !args.A.count16;
     for (int k = 0; fast && k < args.A.nagg; ++k) {
         const AggDesc &a = args.A.a[k];
         if (args.agg_mbit[k] != 0xff && args.use_flags) fast = false; // (one mask shared by every aggregator: pass 1 dropped the masked rows, the records carry no flags)
         if (a.kind == VXH_AGG_COUNT) continue;
-        if ((a.kind != VXH_AGG_SUM && a.kind != VXH_AGG_SUM_MOMENT) || a.cell != VXH_CELL_F64 || args.agg_vslot[k] == 0xff) fast = false;
+        if (args.val_i64 ? (a.kind != VXH_AGG_SUM || a.cell != VXH_CELL_I64 || args.agg_vslot[k] == 0xff)
+                         : ((a.kind != VXH_AGG_SUM && a.kind != VXH_AGG_SUM_MOMENT) || a.cell != VXH_CELL_F64 || args.agg_vslot[k] == 0xff)) fast = false;
     }
 #define VXH_RD(KERNEL)                                                                                                 \
     do {                                                                                                               \

@@ -104,6 +104,8 @@ struct PartArgs {
     // (Flushing straight into grid replicas touches one 64-128 B line per 8 B cell — the slabs interleave — which
     //  was ~130 us of every part_reduce launch: profiles/r01_chunk_fit.txt.)
     void *acc[VXH_MAX_AGG];
+    int32_t val_i64; // the value column(s) are int64 and every aggregator counts or sums them into int64 cells: the records' payloads, the
+                     // box's and pass 2's LDS sums are two's-complement integers (part_scatter_wv, part_reduce_fast, part_hot_merge)
     int32_t blk; // pass 1 = part_scatter_blk (block-reserved queues, 4096-row tiles)
     int32_t f32; // ... its float instantiation: every binner column and the value column float32 (the records carry float64 all the same)
     // pass 1 = part_scatter_wv (barrier-free, wave-private staging rings): wv = waves per workgroup (0: not this
@@ -156,7 +158,7 @@ struct PartArgs {
 struct HotMergeArgs {
     uint32_t x0, y0, w, h, blocks, nagg;
     uint64_t stride_y;             // cells per step of dim 1
-    int32_t atomic, reserved_;
+    int32_t atomic, val_i64; // val_i64: the box sums are int64 (PartArgs::val_i64)
     double *sum_acc, *sum2_acc;
     unsigned long long *cnt_acc;
     void *grid[VXH_MAX_AGG];       // replica 0 of every aggregator
@@ -179,6 +181,8 @@ struct LaunchPlan {
     size_t lds_bytes;
     int use_replicas; // replicas [0, use_replicas) are written by this launch
     bool fast_vals;  // every aggregator input is float64 native (or absent)
+    bool vals_i64;   // every aggregator input is int64 native (or absent; at least one), aggregators count / sum into int64 cells
+    bool bin_f64;    // all binners scalar f64 native unmasked
     bool key_i64;    // ONE ordinal binner over a native unmasked int64 column (groupby on an integer key)
     bool count_fast; // launch K1d (count_lds_f64) instead of bin_kernel<LDS>
     bool fast_f64; // all binners scalar f64 native unmasked, all aggregator inputs f64 native / absent

@@ -250,24 +250,81 @@ def drop_device_copies():
     _device_copies.clear()
 
 
+def _could_be_served(df, by, row_limit):
+    """cheap look at a groupby WITHOUT aggregation: only integer key columns the device groupby takes make the lazy object worth it"""
+    import vaex
+    import vaex.groupby
+    if row_limit is not None or df.filtered or by is None:
+        return False
+    by_list = [by] if isinstance(by, str) or not isinstance(by, collections.abc.Iterable) else list(by)
+    if not 1 <= len(by_list) <= 8 or any(isinstance(b, vaex.groupby.BinnerBase) for b in by_list):
+        return False
+    try:
+        for b in by_list:
+            _real_column(df, vaex.utils._ensure_string_from_expression(b), _KEY_KINDS, "group key")
+    except (_Decline, Exception):
+        return False
+    return True
+
+
 def install(vaex_module, state):
     import vaex.dataframe
+    import vaex.groupby
     import vaex.promise
     cls = vaex.dataframe.DataFrameLocal   # (vaex/dataframe.py:7133: groupby is defined on the local frame)
     original = cls.groupby
+
+    def declined(e):
+        last.clear()
+        last.update(path="vaex", why=str(e))
+        stats["vaex"] += 1
+        stats["why"][str(e)[:100]] = stats["why"].get(str(e)[:100], 0) + 1
+
+    class LazyGroupBy(vaex.groupby.GroupBy):
+        """df.groupby(by) WITHOUT agg: vaex builds the groupers — the distinct-key pass over the key columns — in GroupBy.__init__
+        (vaex/groupby.py:602-668), before it knows the aggregation.  This object postpones that: `.agg(...)` of a signature the device
+        groupby takes is answered by it (one fused pass, no groupers at all); anything else — another method, an attribute, an
+        aggregation outside the signature — first becomes the real GroupBy (same arguments, vaex's own constructor) and carries on as
+        that."""
+
+        def __init__(self, df, kwargs):
+            self.__dict__["_lazy"] = (df, kwargs)
+
+        def _materialise(self):
+            df, kw = self.__dict__.pop("_lazy")
+            real = original(df, agg=None, delay=False, **kw)
+            self.__dict__.update(real.__dict__)
+
+        def __getattr__(self, name):   # (only reached when the attribute is not there: everything GroupByBase.__init__ sets)
+            if "_lazy" in self.__dict__ and not (name.startswith("__") and name.endswith("__")):
+                self._materialise()
+                return getattr(self, name)
+            raise AttributeError(name)
+
+        def agg(self, actions, delay=False, progress=None):
+            if "_lazy" in self.__dict__:
+                df, kw = self.__dict__["_lazy"]
+                try:
+                    result = fast_groupby(df, kw["by"], actions, sort=kw["sort"], ascending=kw["ascending"], row_limit=kw["row_limit"])
+                except _Decline as e:
+                    declined(e)
+                    self._materialise()
+                else:
+                    stats["device"] += 1
+                    return df._delay(delay, vaex.promise.Promise.fulfilled(result))
+            return vaex.groupby.GroupBy.agg(self, actions, delay=delay, progress=progress)
 
     def groupby(self, by=None, agg=None, sort=False, ascending=True, assume_sparse="auto", row_limit=None, copy=True, progress=None, delay=False):
         if agg is not None:
             try:
                 result = fast_groupby(self, by, agg, sort=sort, ascending=ascending, row_limit=row_limit)
             except _Decline as e:
-                last.clear()
-                last.update(path="vaex", why=str(e))
-                stats["vaex"] += 1
-                stats["why"][str(e)[:100]] = stats["why"].get(str(e)[:100], 0) + 1
+                declined(e)
             else:
                 stats["device"] += 1
                 return self._delay(delay, vaex.promise.Promise.fulfilled(result))
+        elif not delay and _could_be_served(self, by, row_limit):
+            return LazyGroupBy(self, dict(by=by, sort=sort, ascending=ascending, assume_sparse=assume_sparse, row_limit=row_limit, copy=copy, progress=progress))
         return original(self, by=by, agg=agg, sort=sort, ascending=ascending, assume_sparse=assume_sparse, row_limit=row_limit, copy=copy, progress=progress, delay=delay)
 
     groupby.__doc__ = original.__doc__
