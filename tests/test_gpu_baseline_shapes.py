@@ -499,19 +499,31 @@ def test_hot_box_uint16_counters_are_exact(sa):
         cases.assert_case_equal(head, _ref_or_port_case(_ref_module(), case), case)
 
 
+@pytest.mark.parametrize("vdtype", ["int64", "int32", "float32"])
 @pytest.mark.parametrize("shape", ["bench_2d", "selection_2d", "uniform_2d", "three_d", "groupby_key"])
-def test_int64_value_columns_ride_the_fast_kernels_with_integer_sums(sa, shape):
-    """round 3: an int64 value column (ids, counts, datetimes: AggSum_int64 / AggCount_int64 into int64 cells) takes
-    part_scatter_wv + the box + part_reduce_fast with two's-complement adds in LDS instead of the generic kernels.  Sums wrap like the
-    reference's `grid[i] += value` on int64 (src/agg_sum.cpp:98-127): values up to +-2^62 are in the data.  Bit-exact against the
-    reference's C++ on a slice, and linear over a split of the rows at the full size."""
+def test_other_value_dtypes_ride_the_fast_kernels(sa, shape, vdtype):
+    """round 3: value columns that are not float64 next to float64 binners / an int64 key.
+    int64 (ids, counts, datetimes: AggSum_int64 / AggCount_int64 into int64 cells) takes part_scatter_wv + the box + part_reduce_fast
+    with two's-complement adds in LDS; int32 and float32 columns are converted by part_scatter_wv as it loads them (two 8-byte loads
+    per lane) and are int64 / float64 payloads from there on.  Integer sums wrap like the reference's `grid[i] += value` on int64
+    (src/agg_sum.cpp:98-127): values up to +-2^62 are in the int64 data.  Integers bit-exact, float32 sums within 1e-12 x sum|v| against
+    the reference's C++ on a slice; linear over a split of the rows at the full size."""
     import torch
     g = torch.Generator(device="cuda").manual_seed(77)
     n = 1 << 26
-    v = torch.randint(-(1 << 40), 1 << 40, (n,), dtype=torch.int64, device="cuda", generator=g)
-    v[::1001] = (1 << 62) + 12345
-    v[1::1001] = -(1 << 62) - 999
-    v[2::5003] = 0x7FF8000000000001   # (the bit pattern of a float64 NaN: an integer like any other)
+    if vdtype == "int64":
+        v = torch.randint(-(1 << 40), 1 << 40, (n,), dtype=torch.int64, device="cuda", generator=g)
+        v[::1001] = (1 << 62) + 12345
+        v[1::1001] = -(1 << 62) - 999
+        v[2::5003] = 0x7FF8000000000001   # (the bit pattern of a float64 NaN: an integer like any other)
+    elif vdtype == "int32":
+        v = torch.randint(-(1 << 31), (1 << 31) - 1, (n,), dtype=torch.int64, device="cuda", generator=g).to(torch.int32)
+        v[::1001] = -(1 << 31)
+        v[2::5003] = 0x7FC00001           # (the bit pattern of a float32 NaN)
+    else:
+        v = (torch.randn(n, dtype=torch.float32, device="cuda", generator=g) * 100).contiguous()
+        v[::1009] = float("nan")
+        v[2::5003] = 1e-42                # (a float32 denormal: widening is exact)
     if shape == "uniform_2d":
         x = torch.rand(n, dtype=torch.float64, device="cuda", generator=g) * 8 - 4
         y = torch.rand(n, dtype=torch.float64, device="cuda", generator=g) * 8 - 4
@@ -522,6 +534,7 @@ def test_int64_value_columns_ride_the_fast_kernels_with_integer_sums(sa, shape):
     key = torch.randint(0, 200_000, (n,), dtype=torch.int64, device="cuda", generator=g) + 1000
     keep = (torch.rand(n, device="cuda", generator=g) < 0.6).to(torch.uint8)
     torch.cuda.synchronize()
+    Sum, Count = getattr(sa, "AggSum_" + vdtype), getattr(sa, "AggCount_" + vdtype)
 
     def run(lo, hi):
         if shape == "groupby_key":
@@ -536,7 +549,7 @@ def test_int64_value_columns_ride_the_fast_kernels_with_integer_sums(sa, shape):
             for b, col in zip(binners, (x, y)):
                 b.set_data(0, col[lo:hi])
         grid = sa.Grid(binners)
-        aggs = [sa.AggCount_int64(grid, 1, 1), sa.AggSum_int64(grid, 1, 1), sa.AggCount_int64(grid, 1, 1)]
+        aggs = [sa.AggCount_int64(grid, 1, 1), Sum(grid, 1, 1), Count(grid, 1, 1)]
         aggs[1].set_data(0, v[lo:hi], 0); aggs[2].set_data(0, v[lo:hi], 0)
         if shape == "selection_2d":
             for a in aggs:
@@ -545,18 +558,27 @@ def test_int64_value_columns_ride_the_fast_kernels_with_integer_sums(sa, shape):
         return [np.array(a.get_result()) for a in aggs], sa.last_kernel(0)
 
     full, kernel = run(0, n)
-    assert kernel.startswith("part_scatter") and ("i64" in kernel or "hot" in kernel), kernel   # (not the generic pair)
+    narrow = vdtype != "int64"
+    # (not the generic pair; a 4-byte column is only converted by part_scatter_wv: where that kernel does not run — 3-d with its 64 slabs,
+    #  the 200 000-key groupby — the generic kernels still do)
+    if not (narrow and shape in ("three_d", "groupby_key")):
+        assert kernel.startswith("part_scatter") and kernel.endswith("_f64" if vdtype == "float32" else "_i64"), kernel
     if shape == "bench_2d":
         assert kernel.startswith("part_scatter_direct_hot"), kernel
     m = 4_000_000
     head, _ = run(0, m)
     rest, _ = run(m, n)
-    for k in range(3):
+    for k in (0, 2) if vdtype == "float32" else (0, 1, 2):
         with np.errstate(over="ignore"):
             np.testing.assert_array_equal(full[k], head[k] + rest[k])
-    assert full[1].dtype == np.int64
+    assert full[1].dtype == (np.float64 if vdtype == "float32" else np.int64)
     kept = int(keep.sum().item()) if shape == "selection_2d" else n
-    assert int(full[0].sum()) == kept and int(full[2].sum()) == kept
+    assert int(full[0].sum()) == kept
+    if vdtype == "float32":
+        assert int(full[2].sum()) == int((~torch.isnan(v) & ((keep == 1) if shape == "selection_2d" else True)).sum().item())
+        assert np.all(np.abs(full[1] - (head[1] + rest[1])) <= 1e-12 * 600.0 * np.maximum(full[2], 1))
+    else:
+        assert int(full[2].sum()) == kept
     cols = dict(x=x, y=y, z=z)
     if shape == "groupby_key":
         bs = [dict(kind="ordinal", data=key[:m].cpu().numpy(), count=200_000, min_value=1000)]
@@ -572,5 +594,9 @@ def test_int64_value_columns_ride_the_fast_kernels_with_integer_sums(sa, shape):
             a["mask"] = ks
     case = dict(n=m, binners=bs, aggs=aggs)
     want = _ref_or_port_case(_ref_module(), case)
-    for k in range(3):
-        np.testing.assert_array_equal(head[k], want[k])
+    if vdtype == "float32":
+        np.testing.assert_array_equal(head[0], want[0]); np.testing.assert_array_equal(head[2], want[2])
+        cases.assert_case_equal(head, want, case)
+    else:
+        for k in range(3):
+            np.testing.assert_array_equal(head[k], want[k])

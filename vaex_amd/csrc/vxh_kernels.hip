@@ -1605,6 +1605,7 @@ __global__ void __launch_bounds__(VXH_HOT_BLOCK) part_scatter_blk(const PartArgs
 //     leave of the 160 KiB; the only two barriers of the kernel are the ones around the box's lifetime.
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x3 __attribute__((ext_vector_type(3)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef u32x3 u32x3_a4 __attribute__((aligned(4)));
 constexpr uint32_t VXH_WV_NONE = 0xffffffffu;
 
@@ -1633,7 +1634,9 @@ __device__ __forceinline__ void wv_slow_record(const PartArgs &P, uint64_t cell,
     }
 }
 
-template <int NDIM, int NVAL, bool MASKED, bool HOT, int KEY = 0, int DIRECT = 0>
+// VT: element type of the value column — 0: 8 bytes, taken as they are (float64; int64 with PartArgs::val_i64), 1: float32, widened
+// to float64 when loaded, 2: int32, sign-extended to int64 (PartArgs::val_ct; two 8-byte loads per lane instead of two 16-byte ones)
+template <int NDIM, int NVAL, bool MASKED, bool HOT, int KEY = 0, int DIRECT = 0, int VT = 0>
 __global__ void __launch_bounds__(1024) part_scatter_wv(const PartArgs P) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr int R = 4;
@@ -1796,10 +1799,16 @@ __global__ void __launch_bounds__(1024) part_scatter_wv(const PartArgs P) {
             raw.b[d][0] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(lane * 16u), 0, 2);
             raw.b[d][1] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(lane * 16u), 1024, 2);
         }
-        if (NVAL) {
+        if (NVAL && VT == 0) {
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(colv + r0), 0, (int)(rows_here * 8u), 0x00020000);
             raw.v[0] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(lane * 16u), 0, 2);
             raw.v[1] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(lane * 16u), 1024, 2);
+        } else if (NVAL) { // 4-byte elements: the lane's rows 2l, 2l+1 and 128+2l, 129+2l are two 8-byte loads
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)((const uint32_t *)colv + r0), 0, (int)(rows_here * 4u), 0x00020000);
+            const u32x2 a = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)(lane * 8u), 0, 2);
+            const u32x2 b = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)(lane * 8u), 512, 2);
+            raw.v[0] = u32x4{a[0], a[1], 0u, 0u};
+            raw.v[1] = u32x4{b[0], b[1], 0u, 0u};
         }
         if (MASKED) {
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(colm + r0), 0, (int)rows_here, 0x00020000);
@@ -1875,7 +1884,14 @@ __global__ void __launch_bounds__(1024) part_scatter_wv(const PartArgs P) {
         double val[NVAL ? R : 1];
         if (NVAL) {
 #pragma unroll
-            for (int r = 0; r < R; ++r) val[NVAL ? r : 0] = f64_of(cur.v, r);
+            for (int r = 0; r < R; ++r) {
+                if (VT == 0) {
+                    val[NVAL ? r : 0] = f64_of(cur.v, r);
+                } else {
+                    const uint32_t w = cur.v[r >> 1][r & 1];
+                    val[NVAL ? r : 0] = VT == 1 ? (double)__uint_as_float(w) : __longlong_as_double((long long)(int32_t)w);
+                }
+            }
         }
         uint32_t slab[R], loc[R], pos[R], cold = 0;
         u32x4 where[DIRECT ? R : 1];
@@ -2555,7 +2571,20 @@ void vxh_launch_part_scatter(const PartArgs &args, const LaunchPlan &plan, int s
         if (args.nvals == 0) { if (masked) VXH_SC((part_scatter_wv<ND, 0, true, false>)); else VXH_SC((part_scatter_wv<ND, 0, false, false>)); } \
         else { if (masked) VXH_SC((part_scatter_wv<ND, 1, true, false>)); else VXH_SC((part_scatter_wv<ND, 1, false, false>)); } \
     } while (0)
-        if (plan.key_i64) { // groupby on an int64 key
+        if (args.val_ct && args.nvals == 1) { // a 4-byte value column, converted on load (the host checks: next to a box only the ring-less variant)
+#define VXH_WVT(VT)                                                                                                    \
+    do {                                                                                                               \
+        if (plan.key_i64) { if (masked) VXH_SC((part_scatter_wv<1, 1, true, false, 1, 0, VT>)); else VXH_SC((part_scatter_wv<1, 1, false, false, 1, 0, VT>)); } \
+        else if (hot) { if (masked) VXH_SC((part_scatter_wv<2, 1, true, true, 0, 1, VT>)); else VXH_SC((part_scatter_wv<2, 1, false, true, 0, 1, VT>)); } \
+        else if (args.A.ndim == 1) { if (masked) VXH_SC((part_scatter_wv<1, 1, true, false, 0, 0, VT>)); else VXH_SC((part_scatter_wv<1, 1, false, false, 0, 0, VT>)); } \
+        else if (args.A.ndim == 2) { if (masked) VXH_SC((part_scatter_wv<2, 1, true, false, 0, 0, VT>)); else VXH_SC((part_scatter_wv<2, 1, false, false, 0, 0, VT>)); } \
+        else { if (masked) VXH_SC((part_scatter_wv<3, 1, true, false, 0, 0, VT>)); else VXH_SC((part_scatter_wv<3, 1, false, false, 0, 0, VT>)); } \
+    } while (0)
+            if (hot && args.wv_direct != 1) throw std::runtime_error("vaex_hip internal: 4-byte value column next to a box needs the ring-less pass 1");
+            if (args.val_ct == 1) VXH_WVT(1); else VXH_WVT(2);
+#undef VXH_WVT
+        }
+        else if (plan.key_i64) { // groupby on an int64 key
             if (args.nvals == 0) { if (masked) VXH_SC((part_scatter_wv<1, 0, true, false, 1>)); else VXH_SC((part_scatter_wv<1, 0, false, false, 1>)); }
             else { if (masked) VXH_SC((part_scatter_wv<1, 1, true, false, 1>)); else VXH_SC((part_scatter_wv<1, 1, false, false, 1>)); }
         }
@@ -2629,7 +2658,7 @@ void vxh_launch_part_scatter(const PartArgs &args, const LaunchPlan &plan, int s
 
 void vxh_launch_part_reduce(const PartArgs &args, const LaunchPlan &plan, hipStream_t stream) {
     // specialised kernel: count / sum / sum-moment over float64 inputs, no record flags, uint16 indices
-    bool fast = (plan.fast_vals || args.f32 || args.val_i64) && !args.use_flags && args.idx16 && args.nvals <= 2 && args.A.nagg >= 1 && args.A.nagg <= 4 && !(args.no_pipeline & 16) && !args.A.count16;
+    bool fast = (plan.fast_vals || args.f32 || args.val_i64 || args.val_ct) && !args.use_flags && args.idx16 && args.nvals <= 2 && args.A.nagg >= 1 && args.A.nagg <= 4 && !(args.no_pipeline & 16) && !args.A.count16;
     for (int k = 0; fast && k < args.A.nagg; ++k) {
         const AggDesc &a = args.A.a[k];
         if (args.agg_mbit[k] != 0xff && args.use_flags) fast = false; // (one mask shared by every aggregator: pass 1 dropped the masked rows, the records carry no flags)
