@@ -499,7 +499,7 @@ def test_hot_box_uint16_counters_are_exact(sa):
         cases.assert_case_equal(head, _ref_or_port_case(_ref_module(), case), case)
 
 
-@pytest.mark.parametrize("vdtype", ["int64", "int32", "float32"])
+@pytest.mark.parametrize("vdtype", ["int64", "int32", "float32", "f32bin+float64", "f32bin+int64", "f32bin+float32"])
 @pytest.mark.parametrize("shape", ["bench_2d", "selection_2d", "uniform_2d", "three_d", "groupby_key"])
 def test_other_value_dtypes_ride_the_fast_kernels(sa, shape, vdtype):
     """round 3: value columns that are not float64 next to float64 binners / an int64 key.
@@ -509,9 +509,16 @@ def test_other_value_dtypes_ride_the_fast_kernels(sa, shape, vdtype):
     (src/agg_sum.cpp:98-127): values up to +-2^62 are in the int64 data.  Integers bit-exact, float32 sums within 1e-12 x sum|v| against
     the reference's C++ on a slice; linear over a split of the rows at the full size."""
     import torch
+    f32bin = vdtype.startswith("f32bin+")   # float32 binner columns next to an 8-byte value column: converted on load as well
+    vdtype = vdtype.replace("f32bin+", "")
+    if f32bin and shape == "groupby_key":
+        pytest.skip("an integer key has no float32 form")
     g = torch.Generator(device="cuda").manual_seed(77)
     n = 1 << 26
-    if vdtype == "int64":
+    if vdtype == "float64":
+        v = torch.randn(n, dtype=torch.float64, device="cuda", generator=g) * 2 + 3
+        v[::1009] = float("nan")
+    elif vdtype == "int64":
         v = torch.randint(-(1 << 40), 1 << 40, (n,), dtype=torch.int64, device="cuda", generator=g)
         v[::1001] = (1 << 62) + 12345
         v[1::1001] = -(1 << 62) - 999
@@ -531,21 +538,25 @@ def test_other_value_dtypes_ride_the_fast_kernels(sa, shape, vdtype):
         x = torch.randn(n, dtype=torch.float64, device="cuda", generator=g)
         y = torch.randn(n, dtype=torch.float64, device="cuda", generator=g)
     z = torch.randn(n, dtype=torch.float64, device="cuda", generator=g)
+    if f32bin:
+        x, y, z = (t.to(torch.float32) for t in (x, y, z))
+    Scalar = sa.BinnerScalar_float32 if f32bin else sa.BinnerScalar_float64
     key = torch.randint(0, 200_000, (n,), dtype=torch.int64, device="cuda", generator=g) + 1000
     keep = (torch.rand(n, device="cuda", generator=g) < 0.6).to(torch.uint8)
     torch.cuda.synchronize()
     Sum, Count = getattr(sa, "AggSum_" + vdtype), getattr(sa, "AggCount_" + vdtype)
+    floats = vdtype in ("float32", "float64")
 
     def run(lo, hi):
         if shape == "groupby_key":
             binners = [sa.BinnerOrdinal_int64(1, "k", 200_000, 1000, False, False)]
             binners[0].set_data(0, key[lo:hi])
         elif shape == "three_d":
-            binners = [sa.BinnerScalar_float64(1, c, -4.0, 4.0, 64) for c in "xyz"]
+            binners = [Scalar(1, c, -4.0, 4.0, 64) for c in "xyz"]
             for b, col in zip(binners, (x, y, z)):
                 b.set_data(0, col[lo:hi])
         else:
-            binners = [sa.BinnerScalar_float64(1, c, -4.0, 4.0, 256) for c in "xy"]
+            binners = [Scalar(1, c, -4.0, 4.0, 256) for c in "xy"]
             for b, col in zip(binners, (x, y)):
                 b.set_data(0, col[lo:hi])
         grid = sa.Grid(binners)
@@ -558,23 +569,23 @@ def test_other_value_dtypes_ride_the_fast_kernels(sa, shape, vdtype):
         return [np.array(a.get_result()) for a in aggs], sa.last_kernel(0)
 
     full, kernel = run(0, n)
-    narrow = vdtype != "int64"
+    narrow = vdtype in ("int32", "float32") or f32bin
     # (not the generic pair; a 4-byte column is only converted by part_scatter_wv: where that kernel does not run — 3-d with its 64 slabs,
     #  the 200 000-key groupby — the generic kernels still do)
     if not (narrow and shape in ("three_d", "groupby_key")):
-        assert kernel.startswith("part_scatter") and kernel.endswith("_f64" if vdtype == "float32" else "_i64"), kernel
+        assert kernel.startswith("part_scatter") and kernel.endswith("_f64" if floats else "_i64"), kernel
     if shape == "bench_2d":
         assert kernel.startswith("part_scatter_direct_hot"), kernel
     m = 4_000_000
     head, _ = run(0, m)
     rest, _ = run(m, n)
-    for k in (0, 2) if vdtype == "float32" else (0, 1, 2):
+    for k in (0, 2) if floats else (0, 1, 2):
         with np.errstate(over="ignore"):
             np.testing.assert_array_equal(full[k], head[k] + rest[k])
-    assert full[1].dtype == (np.float64 if vdtype == "float32" else np.int64)
+    assert full[1].dtype == (np.float64 if floats else np.int64)
     kept = int(keep.sum().item()) if shape == "selection_2d" else n
     assert int(full[0].sum()) == kept
-    if vdtype == "float32":
+    if floats:
         assert int(full[2].sum()) == int((~torch.isnan(v) & ((keep == 1) if shape == "selection_2d" else True)).sum().item())
         assert np.all(np.abs(full[1] - (head[1] + rest[1])) <= 1e-12 * 600.0 * np.maximum(full[2], 1))
     else:
@@ -594,7 +605,7 @@ def test_other_value_dtypes_ride_the_fast_kernels(sa, shape, vdtype):
             a["mask"] = ks
     case = dict(n=m, binners=bs, aggs=aggs)
     want = _ref_or_port_case(_ref_module(), case)
-    if vdtype == "float32":
+    if floats:
         np.testing.assert_array_equal(head[0], want[0]); np.testing.assert_array_equal(head[2], want[2])
         cases.assert_case_equal(head, want, case)
     else:

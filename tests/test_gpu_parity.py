@@ -440,9 +440,10 @@ def test_hot_box_forced(sa, hot_pass1):
         _hot_reset(sa)
 
 
-def test_float32_columns_take_the_block_kernel(sa):
-    """every binner column and the value column float32: part_scatter_blk's float instantiation (widening on use, like
-    BinnerScalar<float> / AggSum<float>), with and without a box, with a shared selection, 1-3 dims"""
+def test_float32_columns_take_the_typed_kernels(sa):
+    """every binner column and the value column float32 (widening on use, like BinnerScalar<float> / AggSum<float>): part_scatter_wv's
+    instantiations that convert on load (round 3) or part_scatter_blk's float instantiation (no value column, the sum of squares, a
+    small box), with and without a box, with a shared selection, 1-3 dims"""
     sa.config_set("strategy", STRATEGIES["part"])
     try:
         rng = np.random.default_rng(77)
@@ -460,7 +461,7 @@ def test_float32_columns_take_the_block_kernel(sa):
             for k, val in zip(("hot_x0", "hot_y0", "hot_w", "hot_h"), box):
                 sa.config_set(k, val)
             check(sa, dict(n=n, binners=b2, aggs=aggs))
-            assert sa.config_get("hot_w") == box[2] and sa.last_kernel(0).startswith("part_scatter_hot")
+            assert sa.config_get("hot_w") == box[2] and sa.last_kernel(0).startswith(("part_scatter_hot", "part_scatter_direct_hot")), sa.last_kernel(0)
             check(sa, dict(n=n, binners=b2, aggs=[dict(a, mask=m) for a in aggs]))
             if box[2] * box[3] * 20 < 100_000:  # (20-byte cells with the sum of squares)
                 check(sa, dict(n=n, binners=b2, aggs=[dict(kind="count", data=v), dict(kind="sum", data=v), dict(kind="summoment", data=v, moment=2)]))

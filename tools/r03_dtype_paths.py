@@ -18,11 +18,15 @@ vals = {
     "float32": torch.randn(rows, dtype=torch.float32, device="cuda", generator=g),
 }
 torch.cuda.synchronize()
-for name, v in vals.items():
-    bx = sa.BinnerScalar_float64(1, "x", -4.0, 4.0, 256); by = sa.BinnerScalar_float64(1, "y", -4.0, 4.0, 256)
+x32, y32 = x.to(torch.float32), y.to(torch.float32)
+for name, v in list(vals.items()) + [("f32bin+float64", vals["float64"]), ("f32bin+int64", vals["int64"]), ("f32bin+float32", vals["float32"])]:
+    f32bin = name.startswith("f32bin+")
+    name = name.replace("f32bin+", "")
+    B = sa.BinnerScalar_float32 if f32bin else sa.BinnerScalar_float64
+    bx = B(1, "x", -4.0, 4.0, 256); by = B(1, "y", -4.0, 4.0, 256)
     grid = sa.Grid([bx, by])
     aggs = [sa.AggCount_int64(grid, 1, 1), getattr(sa, "AggSum_" + name)(grid, 1, 1), getattr(sa, "AggCount_" + name)(grid, 1, 1)]
-    bx.set_data(0, x); by.set_data(0, y); aggs[1].set_data(0, v, 0); aggs[2].set_data(0, v, 0)
+    bx.set_data(0, x32 if f32bin else x); by.set_data(0, y32 if f32bin else y); aggs[1].set_data(0, v, 0); aggs[2].set_data(0, v, 0)
     best = 1e9
     for r in range(reps + 1):
         for a in aggs:
@@ -34,5 +38,5 @@ for name, v in vals.items():
             best = min(best, ms)
     total = int(np.array(aggs[0].get_result()).sum())
     assert total == rows
-    bytes_per_row = 16 + v.element_size()
-    print(f"value {name:<8} {best:8.3f} ms {rows/best/1e6:7.1f} Grows/s  {rows*bytes_per_row/best/1e6/8000:6.3f} of 8 TB/s on {bytes_per_row} B/row   {sa.last_kernel(0)}", flush=True)
+    bytes_per_row = (8 if f32bin else 16) + v.element_size()
+    print(f"binners {'float32' if f32bin else 'float64'} value {name:<8} {best:8.3f} ms {rows/best/1e6:7.1f} Grows/s  {rows*bytes_per_row/best/1e6/8000:6.3f} of 8 TB/s on {bytes_per_row} B/row   {sa.last_kernel(0)}", flush=True)

@@ -628,6 +628,11 @@ static LaunchPlan make_plan(const BinArgs &A, BinArgs &out, uint64_t n, double b
         if (a.data && (a.dtype != VXH_F32 || a.flip)) f32 = false;
     }
     p.fast_f32 = f32;
+    p.bin_f32 = A.ndim >= 1;
+    for (int d = 0; d < A.ndim; d++) {
+        const BinnerDesc &b = A.b[d];
+        if (b.kind != VXH_BIN_SCALAR || b.dtype != VXH_F32 || b.flip || b.mask || b.f32mode) p.bin_f32 = false;
+    }
     p.count_ct = -1;
     if (A.ndim >= 1) {
         const int dt = A.b[0].dtype;
@@ -829,7 +834,8 @@ static int hot_eligible(const BinArgs &A, const LaunchPlan &plan, bool *masked =
     //  would be tens of megabytes)
     const bool ints = plan.bin_f64 && (plan.vals_i64 || plan.vals_i32); // (integer sums: the ring-less part_scatter_wv only, see hot_prepare)
     const bool f32v = plan.bin_f64 && plan.vals_f32;                     // (float32 value column next to float64 binners: the same)
-    if ((!plan.fast_f64 && !plan.fast_f32 && !ints && !f32v) || A.ndim != 2 || A.nagg < 1 || A.cells > (1ull << 21)) return -1;
+    const bool f32b = plan.bin_f32 && !plan.fast_f32 && (plan.fast_vals || plan.vals_i64); // (float32 binners, 8-byte value column: the same)
+    if ((!plan.fast_f64 && !plan.fast_f32 && !ints && !f32v && !f32b) || A.ndim != 2 || A.nagg < 1 || A.cells > (1ull << 21)) return -1;
     const void *v = nullptr;
     if (masked) *masked = A.a[0].mask != nullptr;
     if (mom2) *mom2 = false;
@@ -837,7 +843,7 @@ static int hot_eligible(const BinArgs &A, const LaunchPlan &plan, bool *masked =
         const AggDesc &a = A.a[k];
         if (a.mask != A.a[0].mask) return -1;
         if (a.kind == VXH_AGG_COUNT) { if (a.data) { if (v && v != a.data) return -1; v = a.data; } }
-        else if (a.kind == VXH_AGG_SUM && a.cell == (ints ? VXH_CELL_I64 : VXH_CELL_F64) && a.data) { if (v && v != a.data) return -1; v = a.data; }
+        else if (a.kind == VXH_AGG_SUM && a.cell == ((ints || (f32b && plan.vals_i64)) ? VXH_CELL_I64 : VXH_CELL_F64) && a.data) { if (v && v != a.data) return -1; v = a.data; }
         else if (a.kind == VXH_AGG_SUM_MOMENT && a.moment == 2 && a.cell == VXH_CELL_F64 && a.data && mom2) { if (v && v != a.data) return -1; v = a.data; *mom2 = true; } // var / std
         else return -1;
     }
@@ -916,8 +922,11 @@ static void hot_prepare(Slot &slot, const BinArgs &A, const BinArgs &planned, co
     const bool gen2 = c.cfg_blk && S <= 256 && slab_cells < 65535 && !(c.cfg_no_pipeline & 1) && c.cfg_part_rows <= 0; // (= run_part_chunk's conditions for part_scatter_blk)
     const WvGeom wg = wv_geometry(S, nval, true);
     bool wv = wg.ok && slab_cells < 65535 && wv_aligned(A); // (= run_part_chunk's conditions for part_scatter_wv)
-    const bool ints = plan.bin_f64 && (plan.vals_i64 || plan.vals_i32 || plan.vals_f32); // integer sums / 4-byte value columns: part_scatter_wv's instantiations only
-    if ((masked && !(wv && wg.direct == 1)) || plan.fast_f32) { // (the box next to a selection mask: part_scatter_blk's or the ring-less part_scatter_wv's instantiations; on float32 columns: part_scatter_blk's only)
+    const bool f32b = plan.bin_f32 && !plan.fast_f32 && (plan.fast_vals || plan.vals_i64); // float32 binners next to an 8-byte value column
+    const bool ints = (plan.bin_f64 && (plan.vals_i64 || plan.vals_i32 || plan.vals_f32)) || f32b; // integer sums / 4-byte columns converted on load: part_scatter_wv's instantiations only
+    const bool f32all = plan.fast_f32 && nval == 1; // float32 binners AND value column: the ring-less part_scatter_wv converts both on load; otherwise part_scatter_blk's float instantiation
+    if (f32all && wg.direct != 1) wv = false;
+    if ((masked && !(wv && wg.direct == 1)) || (plan.fast_f32 && !f32all)) { // (the box next to a selection mask: part_scatter_blk's or the ring-less part_scatter_wv's instantiations; float32 columns without a value column: part_scatter_blk's only)
         if (!gen2 || ints) return;
         wv = false;
     }
@@ -929,7 +938,7 @@ static void hot_prepare(Slot &slot, const BinArgs &A, const BinArgs &planned, co
     if (wv && forced && gen2 && (uint64_t)c.cfg_hot_box[2] * (uint64_t)c.cfg_hot_box[3] > (kLdsMax - ((size_t)wg.waves * wg.wave_bytes + 64) - 96 - (c16 ? 16 : 0)) / (c16 ? 10 : (nval ? (mom2 ? 20 : 12) : 4))) wv = false;
     if (!gen2 && !wv) return;
     if (ints && !wv) return;
-    if ((plan.vals_f32 || plan.vals_i32) && wg.direct != 1) return; // (4-byte value columns: only the ring-less variant is instantiated for them)
+    if (ints && wg.direct != 1) return; // (4-byte columns: only the ring-less variant is instantiated for them)
     H.gen2 = true;
     H.nval = nval;
     const size_t cell_bytes = nval ? (mom2 ? 20 : 12) : 4;
@@ -974,13 +983,13 @@ static void hot_prepare(Slot &slot, const BinArgs &A, const BinArgs &planned, co
             LaunchPlan sp{};
             sp.strategy = VXH_STRAT_GLOBAL;
             sp.block = 256;
-            sp.fast_f64 = !plan.fast_f32;
+            sp.fast_f64 = !plan.bin_f32; // (float32 binner columns: the generic kernel reads them through their dtype)
             sp.name = "hot_sample";
             for (uint64_t j = 0; j < nseg; j++) {
                 const uint64_t r0 = (length / nseg) * j, rn = std::min(seg, length - r0);
                 BinArgs L = Q;
                 L.n = rn;
-                for (int d = 0; d < 2; d++) L.b[d].data = (const char *)A.b[d].data + r0 * (plan.fast_f32 ? 4 : 8);
+                for (int d = 0; d < 2; d++) L.b[d].data = (const char *)A.b[d].data + r0 * (plan.bin_f32 ? 4 : 8);
                 sp.blocks = (int)std::max<uint64_t>(1, std::min<uint64_t>((rn + 1023) / 1024, (uint64_t)c.cus * 4));
                 vxh_launch_bin(L, sp, slot.stream);
             }
@@ -1171,7 +1180,9 @@ static void run_part_chunk(Slot &slot, const BinArgs &planned, const LaunchPlan 
     const WvGeom wg = wv_geometry(S, P.nvals, slot.hot.on);
     P.val_i64 = plan.vals_i64 ? 1 : 0;
     const bool narrow = plan.vals_f32 || plan.vals_i32; // (a 4-byte value column: part_scatter_wv converts it on load — nobody else does)
-    const bool wv = wg.ok && (plan.fast_f64 || (plan.bin_f64 && (plan.vals_i64 || narrow)) || (plan.key_i64 && (plan.fast_vals || plan.vals_i64 || narrow))) && (!narrow || !slot.hot.on || wg.direct == 1) && planned.ndim >= 1 && planned.ndim <= 3 && P.nvals <= 1 && !P.use_flags &&
+    const bool f32b = plan.bin_f32 && !plan.fast_f32 && (plan.fast_vals || plan.vals_i64) && P.nvals == 1; // (float32 binners next to an 8-byte value column: the same)
+    const bool f32all = plan.fast_f32 && P.nvals == 1; // (float32 binners and value column: both converted on load)
+    const bool wv = wg.ok && (plan.fast_f64 || (plan.bin_f64 && (plan.vals_i64 || narrow)) || f32b || f32all || (plan.key_i64 && (plan.fast_vals || plan.vals_i64 || narrow))) && (!(narrow || f32b || f32all) || !slot.hot.on || wg.direct == 1) && planned.ndim >= 1 && planned.ndim <= 3 && P.nvals <= 1 && !P.use_flags &&
                     (P.nmasks == 0 || (P.nmasks == 1 && P.all_masked)) && P.idx16 && slab_cells < 65535 && wv_aligned(planned) && (!slot.hot.on || slot.hot.wv);
     if (slot.hot.on && slot.hot.wv != wv) throw std::runtime_error("vaex_hip internal: hot box prepared for a different pass-1 kernel");
     int wv_blocks = 0;
@@ -1295,13 +1306,14 @@ static void run_part_chunk(Slot &slot, const BinArgs &planned, const LaunchPlan 
                      (slot.hot.on || (S > 8 && S <= 64 && !plan.key_i64) || (plan.fast_f32 && S <= 64) || c.cfg_blk == 2); // measured (profiles/r01_other_shapes.txt, r01_groupby_tune.txt):
                      // <= 8 slabs without a box: two 512-thread workgroups of part_scatter_f64 are 2 % faster; 128-256 slabs: +5 % (1024^2) / -35 % (1e6-key groupby)
     const bool hot_here = slot.hot.on && (P.nmasks == 0 || (P.nmasks == 1 && P.all_masked && ((blk && !wv) || (wv && wg.direct == 1)))) && P.nvals == slot.hot.nval && (blk || wv);
-    if (wv && narrow) { // from here on the value column is what part_scatter_wv makes of it
-        P.val_ct = plan.vals_f32 ? 1 : 2;
-        P.val_i64 = plan.vals_i32 ? 1 : 0;
+    if (wv && (f32b || f32all)) P.bin_ct = 1;
+    if (wv && (narrow || f32all)) { // from here on the value column is what part_scatter_wv makes of it
+        P.val_ct = (plan.vals_f32 || f32all) ? 1 : 2;
+        P.val_i64 = (plan.vals_i32 && !f32all) ? 1 : 0;
         // (the records carry the widened values: whoever reads a payload through the aggregator's dtype — pass 2's tail, the slow paths —
         //  must see that type)
         for (int k = 0; k < planned.nagg; k++)
-            if (P.A.a[k].data) P.A.a[k].dtype = plan.vals_f32 ? VXH_F64 : VXH_I64;
+            if (P.A.a[k].data) P.A.a[k].dtype = P.val_ct == 1 ? VXH_F64 : VXH_I64;
     }
     if (wv) {
         P.wv = wg.waves;
@@ -2022,7 +2034,7 @@ int vxh_grid_bin(vxh_grid *grid, int thread, vxh_agg *const *aggs, int n_aggs, u
         if (whole.strategy == VXH_STRAT_PART) {
             part_join(slot);
             part_acc_merge(slot, whole_args);
-            if (slot.last_pass1 >= 2) slot.last_kernel = (whole.fast_f64 || whole.vals_f32) ? "part_scatter_wv+part_reduce_f64" : ((whole.vals_i64 || whole.vals_i32) ? "part_scatter_wv+part_reduce_i64" : "part_scatter_wv+part_reduce_generic");
+            if (slot.last_pass1 >= 2) slot.last_kernel = (whole.fast_f64 || whole.fast_f32 || whole.vals_f32 || (whole.bin_f32 && whole.fast_vals)) ? "part_scatter_wv+part_reduce_f64" : ((whole.vals_i64 || whole.vals_i32) ? "part_scatter_wv+part_reduce_i64" : "part_scatter_wv+part_reduce_generic");
             if (slot.hot.on) {
                 hot_merge(slot, whole_args);
                 slot.last_kernel = slot.last_pass1 == 4 ? "part_scatter_shared_hot+part_reduce_f64" : slot.last_pass1 == 3 ? ((whole.vals_i64 || whole.vals_i32) ? "part_scatter_direct_hot+part_reduce_i64" : "part_scatter_direct_hot+part_reduce_f64") : (slot.last_pass1 == 2 ? "part_scatter_wv_hot+part_reduce_f64" : "part_scatter_hot+part_reduce_f64");

@@ -1636,7 +1636,8 @@ __device__ __forceinline__ void wv_slow_record(const PartArgs &P, uint64_t cell,
 
 // VT: element type of the value column — 0: 8 bytes, taken as they are (float64; int64 with PartArgs::val_i64), 1: float32, widened
 // to float64 when loaded, 2: int32, sign-extended to int64 (PartArgs::val_ct; two 8-byte loads per lane instead of two 16-byte ones)
-template <int NDIM, int NVAL, bool MASKED, bool HOT, int KEY = 0, int DIRECT = 0, int VT = 0>
+// BT: 1 = the binner columns are float32 (PartArgs::bin_ct), loaded and widened the same way
+template <int NDIM, int NVAL, bool MASKED, bool HOT, int KEY = 0, int DIRECT = 0, int VT = 0, int BT = 0>
 __global__ void __launch_bounds__(1024) part_scatter_wv(const PartArgs P) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr int R = 4;
@@ -1795,9 +1796,17 @@ __global__ void __launch_bounds__(1024) part_scatter_wv(const PartArgs P) {
         raw.rows = rows_here;
 #pragma unroll
         for (int d = 0; d < NDIM; ++d) {
-            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)((const double *)P.A.b[d].data + r0), 0, (int)(rows_here * 8u), 0x00020000);
-            raw.b[d][0] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(lane * 16u), 0, 2);
-            raw.b[d][1] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(lane * 16u), 1024, 2);
+            if (BT == 0) {
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)((const double *)P.A.b[d].data + r0), 0, (int)(rows_here * 8u), 0x00020000);
+                raw.b[d][0] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(lane * 16u), 0, 2);
+                raw.b[d][1] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(lane * 16u), 1024, 2);
+            } else {
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)((const float *)P.A.b[d].data + r0), 0, (int)(rows_here * 4u), 0x00020000);
+                const u32x2 a = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)(lane * 8u), 0, 2);
+                const u32x2 b = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)(lane * 8u), 512, 2);
+                raw.b[d][0] = u32x4{a[0], a[1], 0u, 0u};
+                raw.b[d][1] = u32x4{b[0], b[1], 0u, 0u};
+            }
         }
         if (NVAL && VT == 0) {
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(colv + r0), 0, (int)(rows_here * 8u), 0x00020000);
@@ -1906,7 +1915,7 @@ __global__ void __launch_bounds__(1024) part_scatter_wv(const PartArgs P) {
                     const int64_t nord = (int64_t)b.bins;
                     sub_i[d] = (value < 0 || value >= nord) ? (uint32_t)nord : (uint32_t)(b.invert ? nord - 1 - value : value);
                 } else {
-                    sub_i[d] = scalar_sub_index32(f64_of(cur.b[d], r), b.vmin, b.scale, b.binsd, (uint32_t)b.bins);
+                    sub_i[d] = scalar_sub_index32(BT == 0 ? f64_of(cur.b[d], r) : (double)__uint_as_float(cur.b[d][r >> 1][r & 1]), b.vmin, b.scale, b.binsd, (uint32_t)b.bins);
                 }
             }
             uint32_t idx = sub_i[0]; // (dim 0 has stride 1; sub-indices and strides are < 2^24 here)
@@ -2571,7 +2580,14 @@ void vxh_launch_part_scatter(const PartArgs &args, const LaunchPlan &plan, int s
         if (args.nvals == 0) { if (masked) VXH_SC((part_scatter_wv<ND, 0, true, false>)); else VXH_SC((part_scatter_wv<ND, 0, false, false>)); } \
         else { if (masked) VXH_SC((part_scatter_wv<ND, 1, true, false>)); else VXH_SC((part_scatter_wv<ND, 1, false, false>)); } \
     } while (0)
-        if (args.val_ct && args.nvals == 1) { // a 4-byte value column, converted on load (the host checks: next to a box only the ring-less variant)
+        if (args.val_ct == 1 && args.bin_ct && args.nvals == 1) { // float32 binners AND value column
+            if (hot && args.wv_direct != 1) throw std::runtime_error("vaex_hip internal: float32 columns next to a box need the ring-less pass 1");
+            if (hot) { if (masked) VXH_SC((part_scatter_wv<2, 1, true, true, 0, 1, 1, 1>)); else VXH_SC((part_scatter_wv<2, 1, false, true, 0, 1, 1, 1>)); }
+            else if (args.A.ndim == 1) { if (masked) VXH_SC((part_scatter_wv<1, 1, true, false, 0, 0, 1, 1>)); else VXH_SC((part_scatter_wv<1, 1, false, false, 0, 0, 1, 1>)); }
+            else if (args.A.ndim == 2) { if (masked) VXH_SC((part_scatter_wv<2, 1, true, false, 0, 0, 1, 1>)); else VXH_SC((part_scatter_wv<2, 1, false, false, 0, 0, 1, 1>)); }
+            else { if (masked) VXH_SC((part_scatter_wv<3, 1, true, false, 0, 0, 1, 1>)); else VXH_SC((part_scatter_wv<3, 1, false, false, 0, 0, 1, 1>)); }
+        }
+        else if (args.val_ct && args.nvals == 1) { // a 4-byte value column, converted on load (the host checks: next to a box only the ring-less variant)
 #define VXH_WVT(VT)                                                                                                    \
     do {                                                                                                               \
         if (plan.key_i64) { if (masked) VXH_SC((part_scatter_wv<1, 1, true, false, 1, 0, VT>)); else VXH_SC((part_scatter_wv<1, 1, false, false, 1, 0, VT>)); } \
@@ -2583,6 +2599,13 @@ void vxh_launch_part_scatter(const PartArgs &args, const LaunchPlan &plan, int s
             if (hot && args.wv_direct != 1) throw std::runtime_error("vaex_hip internal: 4-byte value column next to a box needs the ring-less pass 1");
             if (args.val_ct == 1) VXH_WVT(1); else VXH_WVT(2);
 #undef VXH_WVT
+        }
+        else if (args.bin_ct && args.nvals == 1) { // float32 binner columns next to an 8-byte value column
+            if (hot && args.wv_direct != 1) throw std::runtime_error("vaex_hip internal: float32 binners next to a box need the ring-less pass 1");
+            if (hot) { if (masked) VXH_SC((part_scatter_wv<2, 1, true, true, 0, 1, 0, 1>)); else VXH_SC((part_scatter_wv<2, 1, false, true, 0, 1, 0, 1>)); }
+            else if (args.A.ndim == 1) { if (masked) VXH_SC((part_scatter_wv<1, 1, true, false, 0, 0, 0, 1>)); else VXH_SC((part_scatter_wv<1, 1, false, false, 0, 0, 0, 1>)); }
+            else if (args.A.ndim == 2) { if (masked) VXH_SC((part_scatter_wv<2, 1, true, false, 0, 0, 0, 1>)); else VXH_SC((part_scatter_wv<2, 1, false, false, 0, 0, 0, 1>)); }
+            else { if (masked) VXH_SC((part_scatter_wv<3, 1, true, false, 0, 0, 0, 1>)); else VXH_SC((part_scatter_wv<3, 1, false, false, 0, 0, 0, 1>)); }
         }
         else if (plan.key_i64) { // groupby on an int64 key
             if (args.nvals == 0) { if (masked) VXH_SC((part_scatter_wv<1, 0, true, false, 1>)); else VXH_SC((part_scatter_wv<1, 0, false, false, 1>)); }
