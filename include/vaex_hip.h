@@ -121,6 +121,15 @@ int vxh_binner_ordinal_create(int threads, int dtype, int flip_endian, int64_t o
 /* BinnerHash<T>(threads, expression, hash_map) — src/binner_hash.cpp:13-20, :152.  Cells
  * [unknown key, bin0..binN-1, null]; the map must stay alive as long as the binner. */
 int vxh_binner_hash_create(int threads, int dtype, vxh_hashmap *map, vxh_binner **out);
+/* BinnerHash<T, ..., FlipEndian> with the reference's cells — src/binner_hash.cpp:13-20 (constructor: hash_bins = hashmap->size(),
+ * missing_bin = null_index() + 1, nan_bin = nan_index() + 1), :23-69 (to_bins), :71 (shape() = hash_bins + 2); map_many:
+ * src/hash_primitives.hpp:567-590.  Cells [invalid, ordinal 0 .. ordinal size-1, (never written)]: `size` counts the null key and NaN
+ * (they are ordinals of the set), a masked row goes to null_index + 1 (cell 0 when the set holds no null), a NaN to nan_index + 1 when
+ * the set saw one.  Keys the set does not hold (and NaN next to a set without one) go to cell 0 — the reference reads their -1 through
+ * its unsigned index type and writes one cell past the grid (:36-40, :56-60); that is the one deliberate difference.  dtype: the 11
+ * numeric dtypes (float keys are looked up by bit pattern, the way vaex_amd.hashset stores them); the map's ordinals are the public
+ * ones (vxh_hashmap_set_public_ordinals). */
+int vxh_binner_hash_create_ref(int threads, int dtype, int flip_endian, vxh_hashmap *map, uint64_t size, int64_t null_index, int64_t nan_index, vxh_binner **out);
 /* BinnerScalar::copy / BinnerOrdinal::copy — src/binners.cpp:11, binner_ordinal.cpp:18 */
 int vxh_binner_copy(const vxh_binner *binner, vxh_binner **out);
 void vxh_binner_destroy(vxh_binner *binner);
@@ -302,6 +311,10 @@ int vxh_hashmap_null_index(vxh_hashmap *map, int64_t *index_out);
 int vxh_hashmap_map_ordinal(vxh_hashmap *map, const void *keys, uint64_t n, int mem, int64_t *out);
 /* key_array(): the distinct keys ordered by ordinal, as int64, into host memory */
 int vxh_hashmap_keys(vxh_hashmap *map, int64_t *keys_out);
+/* the ordinals a BinnerHash on this map sees: public[i] (host, n entries) replaces the table's ordinal i; n = 0: the table's own.
+ * The reference's ordered_set keeps the null key and NaN among its ordinals (add_null / add_nan, src/hash_primitives.hpp:455-470)
+ * and fixes the ordinals of a set made by `create` (:486-537); vaex_amd.hashset keeps those on the host and hands them over here. */
+int vxh_hashmap_set_public_ordinals(vxh_hashmap *map, const int64_t *public_ordinals, uint64_t n);
 
 /* ---- legacy fused statistic (vaexfast.statisticNd) ------------------------------------ */
 /* OP_MIN_MAX on a 0-d grid — src/vaexfast.cpp:1090-1101, :1198-1203 (used by df.minmax /

@@ -46,7 +46,7 @@ def _recording_legacy(*a, **k):
 vaex.vaexfast.statisticNd_f8 = _recording_legacy
 assert vaex.superagg is backend and sys.modules["vaex.superagg"] is backend
 assert vaex.superagg.Grid is hip.Grid and vaex.superagg.AggSum_float64 is hip.AggSum_float64
-assert hasattr(vaex.superagg, "AggNUnique_float64") and not hasattr(vaex.superagg, "BinnerHash_int64") and hasattr(vaex.superagg, "AggFirst_float64_int64")
+assert hasattr(vaex.superagg, "AggNUnique_float64") and hasattr(vaex.superagg, "BinnerHash_int64") and hasattr(vaex.superagg, "AggFirst_float64_int64")
 assert not hasattr(vaex.superagg, "AggCount_string")
 assert vaex.hash.ordered_set_int64.__module__ == "vaex_amd.hashset"
 rng = np.random.default_rng(1)

@@ -28,11 +28,11 @@ from . import superagg  # noqa: E402  (fails loudly if the extension was not bui
 
 __all__ = ["superagg", "install", "uninstall", "cache_columns", "uncache_columns"]
 
-# names of the reference's vaex.superagg that the HIP module deliberately does not take over:
-#   BinnerHash_*   vaex's experimental hash binner (disabled by default, cells laid out differently, takes vaex's own
-#                  ordered_set): tasks that ask for it run on vaex's C++
-_HIDDEN_PREFIXES = ("BinnerHash_",)
-UNSUPPORTED = ("AggCount_string", "AggCount_object", "*_string / *_object aggregators", "BinnerCombined", "BinnerHash_*")
+# names of the reference's vaex.superagg that the HIP module deliberately does not take over (none of the binner / numeric aggregator
+# classes any more: BinnerHash_<T>[_non_native] takes the reference's constructor and cells since round 3, vaex_amd/hashset.py +
+# vxh_binner_hash_create_ref; vaex itself cannot build one — vaex/cpu.py:63 calls the three-argument constructor with two)
+_HIDDEN_PREFIXES = ()
+UNSUPPORTED = ("AggCount_string", "AggCount_object", "*_string / *_object aggregators", "BinnerCombined", "BinnerHash_string")
 
 
 class _Backend:
@@ -68,7 +68,7 @@ class _Backend:
     def __getattr__(self, name):
         if self._mode() == "cpu":
             return getattr(self._cpu, name)
-        if name.startswith(_HIDDEN_PREFIXES):
+        if _HIDDEN_PREFIXES and name.startswith(_HIDDEN_PREFIXES):
             raise AttributeError(name)
         return getattr(self._hip, name)
 
@@ -92,7 +92,7 @@ def install(vaex_module=None, legacy=True, hash_sets=True, chunk_size="auto", gr
     * `vaex.superagg` becomes a `_Backend` and the task-part registry entry "aggregations" (vaex/cpu.py:629-631,
       vaex/encoding.py:31-52) a subclass of vaex's TaskPartAggregation whose `decode` builds the task part from the HIP
       classes and, when an aggregation or binner it needs is not among them (string and
-      object aggregators, BinnerCombined, BinnerHash: `vaex_amd.UNSUPPORTED`), builds it again from vaex's own C++ —
+      object aggregators, BinnerCombined: `vaex_amd.UNSUPPORTED`), builds it again from vaex's own C++ —
       so everything that worked before install() still works, on the CPU, and everything on the hot path runs on the GPU.
     * legacy=True points the legacy statistic task (df.minmax / limits=None: vaex/cpu.py:533-538) at
       vaex_amd.vaexfast.statisticNd_f8 / statisticNd_f4 (the float32 entry with the reference's float32 scaling arithmetic).

@@ -5,7 +5,7 @@
 // Python (vaex/cpu.py:44-65, :630-845; vaex/agg.py:278-335) can drive the HIP kernels:
 //
 //     Grid, Binner, Aggregator,
-//     BinnerScalar_<T>[_non_native], BinnerOrdinal_<T>[_non_native], BinnerHash_<T>,
+//     BinnerScalar_<T>[_non_native], BinnerOrdinal_<T>[_non_native], BinnerHash_<T>[_non_native],
 //     AggCount_<T>, AggSum_<T>, AggSumMoment_<T>, AggMin_<T>, AggMax_<T>   [_non_native]
 //     ordered_set_<T>  (the subset of vaex.superutils the groupby path uses)
 //
@@ -274,17 +274,37 @@ struct TBinnerOrdinal : PyBinnerOrdinal {
         : PyBinnerOrdinal(DT, FLIP, threads, std::move(expr), ordinal_count, min_value, allow_other, invert) {}
 };
 
+// BinnerHash_<T>[_non_native](threads, expression, hashmap) — src/binner_hash.cpp:13-20, :148-171.  `hashmap` is
+//   * a vaex_amd.hashset.ordered_set_<T> (what vaex.hash holds after install(); anything with `_binner_view()`): the reference's
+//     cells [invalid, ordinal 0 .. ordinal len(set)-1, unused] with the null key / NaN among the ordinals (vxh_binner_hash_create_ref), or
+//   * a bare device table (this module's ordered_set_<T>, used by vaex_amd.binned): cells [unknown, ordinal 0..N-1, null].
 struct PyBinnerHash : PyBinner {
     py::object map_ref; // keeps the map alive
-    PyBinnerHash(int dt, int threads_, std::string expr, py::object map) : map_ref(std::move(map)) {
-        dtype = dt; threads = threads_; expression = std::move(expr);
-        PyHashMap &m = map_ref.cast<PyHashMap &>();
-        check(vxh_binner_hash_create(threads, dt, m.h, &h));
+    PyBinnerHash(int dt, bool fl, int threads_, std::string expr, py::object map) : map_ref(std::move(map)) {
+        dtype = dt; flip = fl; threads = threads_; expression = std::move(expr);
+        if (py::isinstance<PyHashMap>(map_ref)) {
+            if (fl) throw std::runtime_error("BinnerHash: byte-swapped keys need a vaex_amd.hashset set");
+            PyHashMap &m = map_ref.cast<PyHashMap &>();
+            check(vxh_binner_hash_create(threads, dt, m.h, &h));
+            return;
+        }
+        if (!py::hasattr(map_ref, "_binner_view")) throw py::type_error("BinnerHash: expected a vaex_amd.hashset.ordered_set_<dtype> (or this module's ordered_set_<dtype>)");
+        // (device table, public ordinal of every device ordinal or None, len(set), null_index, nan_index when the set saw a NaN else -1)
+        py::tuple view = map_ref.attr("_binner_view")();
+        PyHashMap &m = view[0].cast<PyHashMap &>();
+        if (view[1].is_none()) {
+            check(vxh_hashmap_set_public_ordinals(m.h, nullptr, 0));
+        } else {
+            auto perm = py::array_t<int64_t, py::array::c_style | py::array::forcecast>::ensure(view[1]);
+            if (!perm) throw std::runtime_error("BinnerHash: the set's ordinals are not an int64 array");
+            check(vxh_hashmap_set_public_ordinals(m.h, perm.data(), (uint64_t)perm.size()));
+        }
+        check(vxh_binner_hash_create_ref(threads, dt, fl ? 1 : 0, m.h, view[2].cast<uint64_t>(), view[3].cast<int64_t>(), view[4].cast<int64_t>(), &h));
     }
 };
-template <int DT>
+template <int DT, bool FLIP>
 struct TBinnerHash : PyBinnerHash {
-    TBinnerHash(int threads, std::string expr, py::object map) : PyBinnerHash(DT, threads, std::move(expr), std::move(map)) {}
+    TBinnerHash(int threads, std::string expr, py::object map) : PyBinnerHash(DT, FLIP, threads, std::move(expr), std::move(map)) {}
 };
 
 // ------------------------------------------------------------------------------------------
@@ -668,9 +688,21 @@ void add_aggs(py::module &m, py::class_<PyAgg> &base) {
 }
 
 template <int DT>
-void add_hash(py::module &m, py::class_<PyHashMap> &map_base, py::class_<PyBinnerHash, PyBinner> &binner_base) {
+void add_hash(py::module &m, py::class_<PyHashMap> &map_base) {
     py::class_<THashMap<DT>, PyHashMap>(m, (std::string("ordered_set_") + kTypeNames[DT]).c_str()).def(py::init<uint64_t>(), py::arg("capacity_hint") = 0);
-    py::class_<TBinnerHash<DT>, PyBinnerHash>(m, (std::string("BinnerHash_") + kTypeNames[DT]).c_str()).def(py::init<int, std::string, py::object>());
+}
+
+template <int DT, bool FLIP>
+void add_binner_hash(py::module &m, py::class_<PyBinnerHash, PyBinner> &binner_base) {
+    typedef TBinnerHash<DT, FLIP> Type;
+    py::class_<Type, PyBinnerHash>(m, (std::string("BinnerHash_") + kTypeNames[DT] + (FLIP ? "_non_native" : "")).c_str())
+        .def(py::init<int, std::string, py::object>())
+        .def("copy", [](const Type &b) { return new Type(b); })
+        .def(py::pickle([](const Type &b) { return py::make_tuple(b.threads, b.expression, b.map_ref); }, // src/binner_hash.cpp:159-170
+                        [](py::tuple t) {
+                            if (t.size() != 3) throw std::runtime_error("Invalid state!");
+                            return new Type(t[0].cast<int>(), t[1].cast<std::string>(), t[2]);
+                        }));
 }
 
 template <int DT>
@@ -1074,13 +1106,35 @@ PYBIND11_MODULE(superagg, m) {
     add_type<VXH_U8>(m, scalar_base, ordinal_base, aggregator);
     add_type<VXH_BOOL>(m, scalar_base, ordinal_base, aggregator);
 
-    add_hash<VXH_I64>(m, hashmap, hash_base);
-    add_hash<VXH_I32>(m, hashmap, hash_base);
-    add_hash<VXH_I16>(m, hashmap, hash_base);
-    add_hash<VXH_I8>(m, hashmap, hash_base);
-    add_hash<VXH_U64>(m, hashmap, hash_base);
-    add_hash<VXH_U32>(m, hashmap, hash_base);
-    add_hash<VXH_U16>(m, hashmap, hash_base);
-    add_hash<VXH_U8>(m, hashmap, hash_base);
-    add_hash<VXH_BOOL>(m, hashmap, hash_base);
+    add_binner_hash<VXH_F64, false>(m, hash_base);
+    add_binner_hash<VXH_F64, true>(m, hash_base);
+    add_binner_hash<VXH_F32, false>(m, hash_base);
+    add_binner_hash<VXH_F32, true>(m, hash_base);
+    add_binner_hash<VXH_I64, false>(m, hash_base);
+    add_binner_hash<VXH_I64, true>(m, hash_base);
+    add_binner_hash<VXH_I32, false>(m, hash_base);
+    add_binner_hash<VXH_I32, true>(m, hash_base);
+    add_binner_hash<VXH_I16, false>(m, hash_base);
+    add_binner_hash<VXH_I16, true>(m, hash_base);
+    add_binner_hash<VXH_I8, false>(m, hash_base);
+    add_binner_hash<VXH_I8, true>(m, hash_base);
+    add_binner_hash<VXH_U64, false>(m, hash_base);
+    add_binner_hash<VXH_U64, true>(m, hash_base);
+    add_binner_hash<VXH_U32, false>(m, hash_base);
+    add_binner_hash<VXH_U32, true>(m, hash_base);
+    add_binner_hash<VXH_U16, false>(m, hash_base);
+    add_binner_hash<VXH_U16, true>(m, hash_base);
+    add_binner_hash<VXH_U8, false>(m, hash_base);
+    add_binner_hash<VXH_U8, true>(m, hash_base);
+    add_binner_hash<VXH_BOOL, false>(m, hash_base);
+    add_binner_hash<VXH_BOOL, true>(m, hash_base);
+    add_hash<VXH_I64>(m, hashmap);
+    add_hash<VXH_I32>(m, hashmap);
+    add_hash<VXH_I16>(m, hashmap);
+    add_hash<VXH_I8>(m, hashmap);
+    add_hash<VXH_U64>(m, hashmap);
+    add_hash<VXH_U32>(m, hashmap);
+    add_hash<VXH_U16>(m, hashmap);
+    add_hash<VXH_U8>(m, hashmap);
+    add_hash<VXH_BOOL>(m, hashmap);
 }

@@ -1425,6 +1425,12 @@ static void fill_binner_descs(vxh_grid *grid, int thread, BinArgs &base, RESOLVE
             bd.invert = b->invert;
         } else {
             vxh_hashmap_fill_binner_desc(b->map, &bd);
+            bd.min_value = 0; // (hash: the cell of a NaN key)
+            if (b->ref_cells) {
+                bd.bins = b->ref_size;
+                bd.null_bin = b->ref_null_bin;
+                bd.min_value = b->ref_nan_bin;
+            }
         }
     }
 }
@@ -1716,6 +1722,19 @@ int vxh_binner_hash_create(int threads, int dtype, vxh_hashmap *map, vxh_binner 
     VXH_API_END
 }
 
+int vxh_binner_hash_create_ref(int threads, int dtype, int flip_endian, vxh_hashmap *map, uint64_t size, int64_t null_index, int64_t nan_index, vxh_binner **out) {
+    VXH_API_BEGIN
+    if (!map) throw std::runtime_error("hash map is null");
+    vxh_binner *b = new_binner(threads, VXH_BIN_HASH, dtype, flip_endian);
+    b->map = map;
+    b->ref_cells = true;
+    b->ref_size = size;
+    b->ref_null_bin = null_index + 1; // src/binner_hash.cpp:16: missing_bin(hashmap->null_index() + 1) — 0 without a null
+    b->ref_nan_bin = nan_index + 1;   // map_many hands nan_value back when the set saw a NaN, -1 otherwise (src/hash_primitives.hpp:573-578)
+    *out = b;
+    VXH_API_END
+}
+
 int vxh_binner_copy(const vxh_binner *binner, vxh_binner **out) {
     VXH_API_BEGIN
     *out = new vxh_binner(*binner); // copies the slot pointers too, like `new BinnerScalar(*this)`
@@ -1728,7 +1747,7 @@ uint64_t vxh_binner_shape(const vxh_binner *b) {
     switch (b->kind) {
     case VXH_BIN_SCALAR: return b->bins + 3;
     case VXH_BIN_ORDINAL: return (uint64_t)b->ordinal_count + (b->allow_other ? 3 : 2);
-    default: return (uint64_t)vxh_hashmap_size_for_binner(b->map) + 2;
+    default: return (b->ref_cells ? b->ref_size : (uint64_t)vxh_hashmap_size_for_binner(b->map)) + 2;
     }
 }
 

@@ -15,6 +15,7 @@
 #include "vxh_internal.hpp"
 
 #include <stdexcept>
+#include <vector>
 
 namespace {
 
@@ -188,6 +189,10 @@ struct vxh_hashmap {
     long long *packed = nullptr;
     uint64_t packed_cap = 0;
     bool packed_valid = false;
+    // device ordinal -> the ordinal the owner of the map hands out (vxh_hashmap_set_public_ordinals: vaex_amd.hashset puts the null key
+    // and NaN among the keys and fixes the ordinals of sets made by `create`); applied when the slots are packed.  Empty: identity
+    long long *perm = nullptr;
+    std::vector<int64_t> perm_host;
     // staging of host key / mask / ordinal chunks: grow-only, re-used by every update / map_ordinal / set_keys / keys call of
     // this map (all of them hold `mutex` and end with a wait on the stream, so one buffer is enough)
     void *scratch = nullptr;
@@ -207,12 +212,13 @@ static char *hm_scratch(vxh_hashmap *m, size_t bytes) {
     return (char *)m->scratch;
 }
 
-__global__ void hm_pack(const long long *keys, const long long *vals, uint64_t cap, long long *packed) {
+__global__ void hm_pack(const long long *keys, const long long *vals, uint64_t cap, long long *packed, const long long *perm, uint64_t perm_n) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (; i < cap; i += stride) {
+        const long long v = vals[i];
         packed[2 * i] = keys[i];
-        packed[2 * i + 1] = vals[i];
+        packed[2 * i + 1] = (perm && v >= 0 && (uint64_t)v < perm_n) ? perm[v] : v;
     }
 }
 
@@ -256,7 +262,7 @@ void vxh_hashmap_fill_binner_desc(vxh_hashmap *m, BinnerDesc *bd) {
             HIP_CHECK(hipMalloc(&m->packed, m->cap * 16));
             m->packed_cap = m->cap;
         }
-        hipLaunchKernelGGL(hm_pack, dim3(grid_for(m->cap)), dim3(256), 0, s.stream, m->keys, m->vals, m->cap, m->packed);
+        hipLaunchKernelGGL(hm_pack, dim3(grid_for(m->cap)), dim3(256), 0, s.stream, m->keys, m->vals, m->cap, m->packed, m->perm, (uint64_t)m->perm_host.size());
         HIP_CHECK(hipStreamSynchronize(s.stream)); // (the binner may be used from another slot's stream)
         m->packed_valid = true;
     }
@@ -266,6 +272,7 @@ void vxh_hashmap_fill_binner_desc(vxh_hashmap *m, BinnerDesc *bd) {
     bd->bins = m->host_side[0];
     bd->null_bin = (int64_t)m->host_side[0] + 1;
     bd->hmin_ord = m->host_side[2] ? (int64_t)m->host_side[3] : -1;
+    if (bd->hmin_ord >= 0 && (uint64_t)bd->hmin_ord < m->perm_host.size()) bd->hmin_ord = m->perm_host[(size_t)bd->hmin_ord];
 }
 
 extern "C" {
@@ -305,6 +312,7 @@ void vxh_hashmap_destroy(vxh_hashmap *m) {
     (void)hipFree(m->keys);
     (void)hipFree(m->vals);
     if (m->packed) (void)hipFree(m->packed);
+    if (m->perm) (void)hipFree(m->perm);
     if (m->scratch) (void)hipFree(m->scratch);
     (void)hipFree(m->side);
     delete m;
@@ -360,6 +368,24 @@ int vxh_hashmap_set_keys(vxh_hashmap *m, const int64_t *keys, uint64_t n) {
     unsigned long long cnt = n;
     HIP_CHECK(hipMemcpyAsync(m->side, &cnt, 8, hipMemcpyHostToDevice, s.stream));
     hm_refresh(m, s.stream);
+    HM_END
+}
+
+int vxh_hashmap_set_public_ordinals(vxh_hashmap *m, const int64_t *perm, uint64_t n) {
+    HM_BEGIN
+    std::lock_guard<std::mutex> lock(m->mutex);
+    (void)hipSetDevice(ctx().device);
+    Slot &s = get_slot(0);
+    HIP_CHECK(hipStreamSynchronize(s.stream));
+    if (m->perm) (void)hipFree(m->perm);
+    m->perm = nullptr;
+    m->perm_host.assign(perm, perm + (perm ? n : 0));
+    if (!m->perm_host.empty()) {
+        HIP_CHECK(hipMalloc(&m->perm, n * 8));
+        HIP_CHECK(hipMemcpyAsync(m->perm, m->perm_host.data(), n * 8, hipMemcpyHostToDevice, s.stream));
+        HIP_CHECK(hipStreamSynchronize(s.stream));
+    }
+    m->packed_valid = false;
     HM_END
 }
 

@@ -34,6 +34,9 @@ struct vxh_binner {
     bool allow_other = false, invert = false;
     // hash
     vxh_hashmap *map = nullptr;
+    bool ref_cells = false;   // vxh_binner_hash_create_ref: the reference's cell layout
+    uint64_t ref_size = 0;    // ... hashmap->size(): keys incl. the null key and NaN
+    int64_t ref_null_bin = 0, ref_nan_bin = 0;
     std::vector<SlotData> data, mask;
 };
 

@@ -195,11 +195,23 @@ __device__ __forceinline__ void flat_index_batch(const BinArgs &A, const Rows<N>
                 idx[u] += sub * b.stride;
             }
         } else {
-            // hash binner: cells [unknown, bin0..binN-1, null].  The N first probes (random reads of a table in Infinity
+            // hash binner: cells [unknown, bin0..binN-1, null], or the reference's (vxh_binner_hash_create_ref: null_bin / the NaN cell
+            // come from the set).  The N first probes (random reads of a table in Infinity
             // Cache / HBM) are issued together; keys not settled by them (collisions: load <= 3/4) finish one by one
             load_canon<N>(b.data, rows, b.dtype, b.flip, c);
             // table slots are packed {key, ordinal} pairs (b.hkeys, 16 bytes each: one random line per probe)
             const longlong2 *slots = (const longlong2 *)b.hkeys;
+            // float keys are looked up by bit pattern, the way vaex_amd.hashset stores them: float64 as it is, float32 as its sign-extended
+            // 32 bits (load_canon widened it to float64); a NaN never reaches the probe
+            uint32_t nans = 0;
+            if (b.dtype == VXH_F64 || b.dtype == VXH_F32) {
+#pragma unroll
+                for (int u = 0; u < N; ++u) {
+                    const double dv = __longlong_as_double((long long)c[u]);
+                    nans |= (dv != dv ? 1u : 0u) << u;
+                    if (b.dtype == VXH_F32) c[u] = (uint64_t)(int64_t)(int32_t)__float_as_uint((float)dv);
+                }
+            }
             uint64_t p0[N];
             int64_t k0[N], v0[N];
 #pragma unroll
@@ -211,6 +223,8 @@ __device__ __forceinline__ void flat_index_batch(const BinArgs &A, const Rows<N>
                 uint64_t sub = 0;
                 if ((masked >> u) & 1u) {
                     sub = (uint64_t)b.null_bin;
+                } else if ((nans >> u) & 1u) {
+                    sub = (uint64_t)b.min_value; // a NaN: the set's NaN ordinal + 1, or the invalid cell (src/hash_primitives.hpp:573-578)
                 } else {
                     const int64_t key = (int64_t)c[u];
                     uint64_t p = p0[u];

@@ -252,6 +252,19 @@ class _OrderedSet:
             return self._fixed[2]
         return self._special_index("nan")
 
+    def _binner_view(self):
+        """what BinnerHash_<T>(threads, expression, this set) needs (src/binner_hash.cpp:13-20 reads hashmap->size(), null_index(),
+        nan_index()): (device table, the set's ordinal of every device ordinal — None when they are the same —, len(self),
+        null_index, nan_index when a NaN was seen else -1)"""
+        with self._lock:
+            if self._perm is not None:
+                public = np.ascontiguousarray(self._perm, dtype=np.int64)
+            elif self._fixed is None and self._specials:
+                public = np.ascontiguousarray(self._public(np.arange(self._n_keys(), dtype=np.int64)))
+            else:
+                public = None
+            return self._map, public, len(self), int(self.null_index), int(self.nan_index) if self.nan_count > 0 else -1
+
     def key_array(self):
         """keys ordered by ordinal; the null key's slot holds a placeholder, NaN's slot NaN (src/hash_primitives.hpp:303-328)"""
         if self._fixed is not None:
