@@ -86,7 +86,7 @@ task_stats = {"hip": 0, "cpu": 0, "cpu_reasons": {}}
 AUTO_CHUNK_ROWS_MAX = 1 << 26   # install(chunk_size="auto"): upper bracket of vaex's automatic chunk size (rows)
 
 
-def install(vaex_module=None, legacy=True, hash_sets=True, chunk_size="auto", groupby=True, selections=True):
+def install(vaex_module=None, legacy=True, hash_sets=True, chunk_size="auto", groupby=True, selections=True, filters=True):
     """Plug the HIP kernels into an unmodified vaex.
 
     * `vaex.superagg` becomes a `_Backend` and the task-part registry entry "aggregations" (vaex/cpu.py:629-631,
@@ -106,6 +106,9 @@ def install(vaex_module=None, legacy=True, hash_sets=True, chunk_size="auto", gr
       pass anything; an integer sets vaex.settings.main.chunk.size itself; None leaves vaex's chunking alone.
     * selections=True: selection expressions of the comparison subset (`column <op> number` joined by & | ~, <= 4 terms) are
       evaluated on the device instead of numpy (vaex_amd/vaex_selection.py); everything else keeps vaex's host masks.
+    * filters=True (needs selections=True): binned aggregations over a FILTERED frame (df[df.x > 0]) get their chunks uncompacted and
+      take the filter as a keep-mask — a device predicate where it compiles — instead of vaex copying every column through a boolean
+      index per chunk (vaex_amd/vaex_filter.py); the device column cache then serves filtered frames too.
     * groupby=True: df.groupby(<integer key columns>, agg=count / sum / mean / var / std ...) is answered by the device
       groupby (vaex_amd/vaex_groupby.py) instead of vaex's two passes; everything else falls through to vaex's own code."""
     import sys
@@ -128,8 +131,9 @@ def install(vaex_module=None, legacy=True, hash_sets=True, chunk_size="auto", gr
 
         @classmethod
         def decode(cls, encoding, spec, df, nthreads):
-            from . import vaex_selection
+            from . import vaex_selection, vaex_filter
             import vaex.memory
+            as_mask = bool(spec.get(vaex_filter.SPEC_KEY, False))   # a filtered frame's blocks arrive uncompacted (vaex_amd/vaex_filter.py)
             # the executor checks the parts' memory_usage() against what its tracker saw (vaex/execution.py:413-414): aggregators a
             # failed HIP attempt built before it hit an unsupported one must not stay on the tracker's books
             tracker = getattr(vaex.memory.local, "agg", None)
@@ -138,7 +142,7 @@ def install(vaex_module=None, legacy=True, hash_sets=True, chunk_size="auto", gr
                 try:
                     part = base.decode.__func__(cls, encoding, spec, df, nthreads)
                     part.backend_used = "hip"
-                    vaex_selection.attach(part, "hip", superagg, nthreads)
+                    vaex_selection.attach(part, "hip", superagg, nthreads, filter_as_mask=as_mask)
                     task_stats["hip"] += 1
                     return part
                 except (ValueError, TypeError, NotImplementedError) as e:
@@ -150,14 +154,16 @@ def install(vaex_module=None, legacy=True, hash_sets=True, chunk_size="auto", gr
             with backend.use("cpu"):
                 part = base.decode.__func__(cls, encoding, spec, df, nthreads)
                 part.backend_used = "cpu"
-                vaex_selection.attach(part, "cpu", superagg, nthreads)
+                vaex_selection.attach(part, "cpu", superagg, nthreads, filter_as_mask=as_mask)
                 task_stats["cpu"] += 1
                 return part
 
         def process(self, thread_index, i1, i2, filter_mask, selection_masks, blocks):
             # selections planned for the device (vaex_amd/vaex_selection.py): their columns' chunks ride behind the blocks
-            from . import vaex_selection
+            from . import vaex_selection, vaex_filter
             selection_masks, blocks = vaex_selection.before_process(self, thread_index, selection_masks, blocks)
+            if getattr(self, "_hip_filter_as_mask", False) and filter_mask is not None:
+                return vaex_filter.process(self, base, thread_index, i1, i2, filter_mask, selection_masks, blocks)
             return base.process(self, thread_index, i1, i2, filter_mask, selection_masks, blocks)
 
     vaex.cpu.register(TaskPartAggregationHip)
@@ -206,6 +212,9 @@ def install(vaex_module=None, legacy=True, hash_sets=True, chunk_size="auto", gr
     if selections:
         from . import vaex_selection
         vaex_selection.install(vaex_module, _installed)
+        if filters:
+            from . import vaex_filter
+            vaex_filter.install(vaex_module, _installed)
     if hash_sets:
         import copyreg
         import vaex.hash
@@ -252,6 +261,9 @@ def uninstall():
     if "groupby" in _installed:
         from . import vaex_groupby
         vaex_groupby.uninstall(vaex_module, _installed)
+    if "filter" in _installed:
+        from . import vaex_filter
+        vaex_filter.uninstall(vaex_module, _installed)
     if "selection" in _installed:
         from . import vaex_selection
         vaex_selection.uninstall(vaex_module, _installed)

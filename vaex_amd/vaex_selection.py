@@ -51,8 +51,19 @@ def plan_for(df, descriptor):
     return pred
 
 
+def _filter_columns(df, descriptors):
+    """columns of the frame's filter when it compiles to a device predicate and the task could run with the filter as a keep-mask
+    (vaex_amd/vaex_filter.py): they ride behind the selection predicates' columns"""
+    from . import vaex_filter
+    if not df.filtered or not all(getattr(d, "name", None) in vaex_filter._KEEP_MASK_AGGS for d in descriptors):
+        return []
+    pred = vaex_filter.filter_plan(df)
+    return list(pred.columns) if pred is not None else []
+
+
 def extras_of(df, descriptors):
-    """[(aggregation index, Predicate)], and the predicate columns in first-seen order (= the tail of task.expressions_all)"""
+    """[(aggregation index, Predicate)], and the predicate columns in first-seen order, the filter's last (= the tail of
+    task.expressions_all)"""
     plans, extras = [], []
     for i, d in enumerate(descriptors):
         p = plan_for(df, d)
@@ -61,6 +72,9 @@ def extras_of(df, descriptors):
             for c in p.columns:
                 if c not in extras:
                     extras.append(c)
+    for c in _filter_columns(df, descriptors):
+        if c not in extras:
+            extras.append(c)
     return plans, extras
 
 
@@ -70,20 +84,17 @@ def install(vaex_module, state):
     original = cls.add_aggregation_operation
 
     def add_aggregation_operation(self, aggregator_descriptor):
-        extras = self.__dict__.get("_hip_extras", [])
-        if extras:   # (they sit at the tail: take them off while vaex appends this aggregation's own expressions)
-            del self.expressions_all[len(self.expressions_all) - len(extras):]
+        tail = self.__dict__.get("_hip_extras", [])
+        if tail:   # (they sit at the tail: take them off while vaex appends this aggregation's own expressions)
+            del self.expressions_all[len(self.expressions_all) - len(tail):]
         task = original(self, aggregator_descriptor)
-        pred = plan_for(self.df, aggregator_descriptor)
-        if pred is not None:
+        if plan_for(self.df, aggregator_descriptor) is not None:
             self.selections[-1] = None   # the executor evaluates nothing for this aggregation (vaex/execution.py:549)
             stats["planned"] += 1
-            for c in pred.columns:
-                if c not in extras:
-                    extras.append(c)
-        self.__dict__["_hip_extras"] = extras
-        if extras:
-            self.expressions_all.extend(extras)
+        _, tail = extras_of(self.df, self.aggregation_descriptions)   # (the same call the task part's decode makes)
+        self.__dict__["_hip_extras"] = tail
+        if tail:
+            self.expressions_all.extend(tail)
             self.dtypes = {expr: self.df.data_type(expr).index_type for expr in self.expressions_all}
         return task
 
@@ -96,13 +107,32 @@ def uninstall(vaex_module, state):
     cls.add_aggregation_operation = original
 
 
-def attach(part, backend_used, superagg, nthreads):
-    """called by the task part's decode: remember the predicates, and (HIP classes) hand them to the aggregators"""
+def attach(part, backend_used, superagg, nthreads, filter_as_mask=False):
+    """called by the task part's decode: remember the predicates, and (HIP classes) hand them to the aggregators.
+    filter_as_mask: the run hands this part uncompacted blocks of a filtered frame (vaex_amd/vaex_filter.py) — where the filter is a
+    device predicate it joins the aggregators' Selection here (alone or AND-ed with the aggregation's own predicate)"""
+    from . import vaex_filter
     plans, extras = extras_of(part.df, part.aggregation_descriptions)
     part._hip_plans, part._hip_extras, part._hip_selections = plans, extras, []
-    if not plans:
-        return
+    part._hip_filter_as_mask = bool(filter_as_mask)
+    part._hip_filter_on_device = set()
+    fpred = vaex_filter.filter_plan(part.df) if (filter_as_mask and backend_used == "hip") else None
+    if plans or fpred is not None:
+        _attach_predicates(part, backend_used, superagg, nthreads, plans, extras, fpred)
+    if filter_as_mask:
+        vaex_filter.mark(part)
+
+
+def _attach_predicates(part, backend_used, superagg, nthreads, plans, extras, fpred):
+    from . import vaex_filter
     objs = {}
+
+    def selection_object(pred):
+        key = pred.key()
+        if key not in objs:
+            dtypes = [_predicate.dtype_code(part.df.columns[c].dtype) for c in pred.columns]
+            objs[key] = superagg.Selection(nthreads, dtypes, [(c, op, v) for c, op, v in pred.terms], pred.truth)
+        return objs[key]
     # global index of an aggregation's (single) selection in the executor's `selections` list: one entry per aggregation
     # without a list of selections (vaex/tasks.py:528-535); lists of selections never get a plan
     position = 0
@@ -110,17 +140,21 @@ def attach(part, backend_used, superagg, nthreads):
     for desc, selections, aggs, waslist in part.aggregations:
         positions.append(position)
         position += len(selections)
-    for i, pred in plans:
-        desc, selections, aggs, waslist = part.aggregations[i]
+    planned = dict(plans)
+    for i, (desc, selections, aggs, waslist) in enumerate(part.aggregations):
+        pred = planned.get(i)
+        if pred is None and not (fpred is not None and len(selections) == 1 and (selections[0] is None or selections[0] is False)):
+            continue   # (a host-evaluated selection / a list of selections: the filter, if any, joins as a host mask in process)
         entry = dict(index=positions[i], pred=pred, sel=None)
         if backend_used == "hip":
-            key = pred.key()
-            if key not in objs:
-                dtypes = [_predicate.dtype_code(part.df.columns[c].dtype) for c in pred.columns]
-                objs[key] = superagg.Selection(nthreads, dtypes, [(c, op, v) for c, op, v in pred.terms], pred.truth)
-            entry["sel"] = objs[key]
+            if fpred is not None:
+                both = fpred if pred is None else vaex_filter.combined_plan(part.df, str(desc.selection))
+                if both is not None and all(c in extras for c in both.columns):
+                    pred = entry["pred"] = both
+                    part._hip_filter_on_device.add(i)
+            entry["sel"] = selection_object(pred)
             for a in aggs:
-                a.set_selection(objs[key])
+                a.set_selection(entry["sel"])
             # the aggregation is "unselected" for the base class from here on: no host mask is expected for it
             part.aggregations[i] = (desc, [None] * len(selections), aggs, waslist)
         part._hip_selections.append(entry)
