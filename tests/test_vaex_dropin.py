@@ -210,6 +210,30 @@ if has_gpu and %(timing)d:
     print("TIMING   host-streamed with plain install(): %%.1f ms = %%.2f Grows/s (%%.1f GB/s over PCIe)" %% (host_t2 * 1e3, m / host_t2 / 1e9, m * 16 / host_t2 / 1e9))
     vaex_amd.uncache_columns()
     vaex_amd.uninstall()
+    # a FILTERED frame, big[big.x > 0]: vaex copies every column of every chunk through a boolean index before a task part sees a row
+    # (vaex/execution.py:515-523) — fresh temporaries, so the device column cache never hits; with install() the chunks stay uncompacted
+    # and the filter is a device predicate in the aggregators' keep-mask (vaex_amd/vaex_filter.py)
+    flt = big[big.x > 0]
+    def run_f():
+        t0 = time.perf_counter()
+        c = flt.count(binby=["x", "y"], limits=lim2, shape=256)
+        return time.perf_counter() - t0, c
+    cpu_f, cf = min((run_f() for _ in range(2)), key=lambda r: r[0])
+    vaex_amd.install(filters=False)
+    vaex_amd.cache_columns(big, ["x", "y"])
+    run_f()
+    old_f, c5 = min((run_f() for _ in range(2)), key=lambda r: r[0])
+    vaex_amd.uncache_columns()
+    vaex_amd.uninstall()
+    vaex_amd.install()
+    vaex_amd.cache_columns(big, ["x", "y"])
+    run_f()
+    new_f, c6 = min((run_f() for _ in range(3)), key=lambda r: r[0])
+    assert np.array_equal(cf, c5) and np.array_equal(cf, c6) and int(cf.sum()) > m // 3
+    print("TIMING vaex filtered frame big[big.x > 0].count(binby=[x,y], shape=256) on %%d host rows, columns registered: cpu (reference, %%d threads) %%.1f ms; install(filters=False) = vaex's numpy compaction per chunk %%.1f ms = %%.2f Grows/s; install() = filter as a device predicate over uncompacted chunks %%.1f ms = %%.2f Grows/s"
+          %% (m, vaex.settings.main.thread_count, cpu_f * 1e3, old_f * 1e3, m / old_f / 1e9, new_f * 1e3, m / new_f / 1e9))
+    vaex_amd.uncache_columns()
+    vaex_amd.uninstall()
     # df.groupby(k).agg(sum / mean / std) of an unmodified vaex: its own two passes on the CPU (2e7-row slice), the device groupby
     # behind the same call on all rows — host columns (every call crosses PCIe), then registered columns (HBM-resident copies)
     from vaex_amd import vaex_groupby as vg
