@@ -28,7 +28,16 @@ if gpu:
 else:
     from tests.test_golden_api import RefAdapter
     ref = RefAdapter(vaex.superagg)   # (the reference's own compiled module, as this vaex imported it)
-    vg._frame_for = lambda df, columns: binned.Frame(dict(columns), chunk_size=50_000, nthreads=2, superagg=ref)
+    class HostMaskFrame(binned.Frame):   # (the reference's module has no device Selection: predicates become host keep-masks here)
+        def _selection_mask(self, selection):
+            sel = super()._selection_mask(selection)
+            if isinstance(sel, binned._predicate.Predicate):
+                key = ("mask", sel.key())
+                if key not in self._predicates:
+                    self._predicates[key] = sel.numpy_mask({c: self.columns[c] for c in sel.columns})
+                return self._predicates[key]
+            return sel
+    vg._frame_for = lambda df, columns: HostMaskFrame(dict(columns), chunk_size=50_000, nthreads=2, superagg=ref)
     state = {}
     vg.install(vaex, state)
     original = state["groupby"][1]
@@ -104,8 +113,29 @@ for by, agg, why in declined:
     got = df.groupby(by, agg=agg)
     assert vg.last.get("path") == "vaex" and why in vg.last.get("why", ""), (by, vg.last)
     print("ok-declined", by, vg.last["why"])
-# a filtered frame and a row limit are vaex's business
-vg.last.clear(); df[df.k > 3].groupby("k", agg="count"); assert vg.last.get("path") == "vaex" and "filtered" in vg.last["why"]
+# filtered frames: the filter is a keep-mask over the whole call when it is in the predicate subset (groups without a row inside it do
+# not exist, the key column is typed from the keys that are left); any other filter — and a row limit — is vaex's business
+filtered = [
+  (df[df.k > 3], "k", {"c": A.count(), "s": A.sum("v"), "m": A.mean("v"), "sd": A.std("v")}, {}),
+  (df[df.v > 3.5], "k32", {"n": "count", "mw": A.mean("w"), "lo": A.min("i")}, dict(sort=True, ascending=False)),      # the filter column is not otherwise read
+  (df[df.w < 0][df.k >= 10], "kgap", {"c": A.count("v"), "s": A.sum("i")}, {}),                                          # a chain: (w < 0) & (k >= 10)
+  (df[(df.k == 7) | (df.k == 30)], "k", "count", {}),                                                                    # two groups left of 45
+]
+if gpu:
+    filtered += [(df[df.v > 2], ["k", "k32"], {"c": A.count(), "s": A.sum("v")}, {}),
+                 (df[df.i > 0], "ks", {"s": A.sum("v"), "c": A.count(), "m": A.mean("v")}, {})]                          # scattered keys: the hash binner + presence count
+for d, by, agg, kw in filtered:
+    vg.last.clear()
+    got = d.groupby(by, agg=agg, **kw)
+    assert vg.last.get("path") == "device", (by, agg, vg.last)
+    want = original(d, by, agg=agg, **kw)
+    keys = [by] if isinstance(by, str) else by
+    same({c: got.sort(keys)[c].to_numpy() for c in got.get_column_names()}, {c: want.sort(keys)[c].to_numpy() for c in want.get_column_names()}, ("filtered", by, agg))
+    if kw.get("sort"):
+        assert np.array_equal(np.ma.getdata(got[keys[0]].to_numpy()), np.ma.getdata(want[keys[0]].to_numpy())), (by, kw)
+    print("ok-device-filtered", by, len(got), vg.last.get("kernel"))
+vg.last.clear(); df[(df.k * 2) > 3].groupby("k", agg="count"); assert vg.last.get("path") == "vaex" and "filter outside" in vg.last["why"], vg.last
+vg.last.clear(); df.dropnan(column_names=["v"]).groupby("k", agg="count"); assert vg.last.get("path") == "vaex" and "filter outside" in vg.last["why"], vg.last
 # without agg: a GroupBy whose groupers are only built when something other than a device-servable .agg() is asked of it
 g = df.groupby("k", sort=True)
 assert isinstance(g, vaex.groupby.GroupBy) and "_lazy" in g.__dict__
@@ -144,12 +174,12 @@ def _run(gpu, timeout):
 @pytest.mark.skipif(not os.path.isdir(os.path.join(PKG, "vaex")), reason="real vaex package not built (oracle/build_ref.sh needs /root/reference)")
 def test_groupby_host_logic_against_vaex_on_the_reference_cpp():
     out = _run(0, 600)
-    assert "DONE" in out and out.count("ok-device") == 8 and out.count("ok-declined") == 7, out
+    assert "DONE" in out and out.count("ok-device ") == 8 and out.count("ok-device-filtered") == 4 and out.count("ok-declined") == 7, out
 
 
 @pytest.mark.gpu
 @pytest.mark.skipif(not os.path.isdir(os.path.join(PKG, "vaex")), reason="real vaex package not built (oracle/build_ref.sh needs /root/reference)")
 def test_groupby_of_real_vaex_runs_on_the_device_groupby():
     out = _run(1, 900)
-    assert "DONE" in out and out.count("ok-device") == 12 and out.count("ok-declined") == 7, out
+    assert "DONE" in out and out.count("ok-device ") == 12 and out.count("ok-device-filtered") == 6 and out.count("ok-declined") == 7, out
     assert "gb_scatter+gb_reduce" in out and "bin_lds" in out, out   # (the fused hash aggregation, and — few groups — the LDS-resident grid)

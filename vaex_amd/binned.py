@@ -811,7 +811,7 @@ class Frame:
         return values[order], counts[order]
 
     # ------------------------------------------------------------------ groupby
-    def _groupby_combined(self, by, agg_spec, reduce, comm):
+    def _groupby_combined(self, by, agg_spec, reduce, comm, selection=None):
         """df.groupby([k1, k2, ...]): the keys' ordinals packed into ONE int64 key on the device (vxh_pack_keys — the
         expression vaex's GrouperCombined evaluates with numpy, vaex/groupby.py:526-584), the single-key machinery on the
         packed column, the packed group keys unpacked again.  Groups come out in ascending (k1, k2, ...) order."""
@@ -850,9 +850,21 @@ class Frame:
                 sub[d.column] = c if _is_device(c) else torch.from_numpy(np.ascontiguousarray(c)).cuda()
             if d.selection is not None:
                 raise NotImplementedError("multi-key groupby with a selection")
+        if selection is not None:   # a filter over the call: its predicate's columns (or its mask) go along
+            sel = self._selection_mask(selection)
+            if isinstance(sel, _predicate.Predicate):
+                for c in sel.columns:
+                    if c not in sub:
+                        col = self.columns[c]
+                        if np.ma.isMaskedArray(col):
+                            raise NotImplementedError("filter over a column with missing values")
+                        sub[c] = col if _is_device(col) else torch.from_numpy(np.ascontiguousarray(col)).cuda()
+            else:
+                sub["__keep__"] = sel if _is_device(sel) else torch.from_numpy(np.ascontiguousarray(_as_u8(sel))).cuda()
+                selection = "__keep__"
         f = Frame(sub, chunk_size=self.chunk_size, nthreads=self.nthreads, superagg=sa, comm=comm)
         f.direct_groupby_cells = self.direct_groupby_cells
-        res = f.groupby("__packed__", agg_spec, reduce=reduce, comm=comm)
+        res = f.groupby("__packed__", agg_spec, reduce=reduce, comm=comm, selection=selection)
         self.last_groupby_info = getattr(f, "last_groupby_info", None)
         pk = np.asarray(res.pop("__packed__")).astype(np.int64)
         out = {}
@@ -899,9 +911,11 @@ class Frame:
         cache[name] = (col, r)
         return r
 
-    def groupby(self, by, agg_spec, reduce=None, comm=None):
+    def groupby(self, by, agg_spec, reduce=None, comm=None, selection=None):
         """df.groupby(by).agg({...}) for ONE integer key column (a list of key columns: see _groupby_combined).
-        Returns {by: keys (ascending), name: values}.
+        Returns {by: keys (ascending), name: values}.  selection: a keep-filter over the whole call (an expression of
+        vaex_amd.predicate's subset or a mask array) — what a filtered vaex frame is, `df[df.x > 0].groupby(...)`: rows outside it
+        reach no aggregator and groups without a row inside it do not exist.
 
         The reference first collects the distinct keys (ordered_set, vaex/hash.py:152-171) and, when they are
         dense (range <= 4/3 * n_unique), simplifies to BinnerInteger (vaex/groupby.py:263-272).  Here the range
@@ -913,7 +927,7 @@ class Frame:
             comm = self.comm
         if isinstance(by, (list, tuple)):
             if len(by) > 1:
-                return self._groupby_combined(list(by), agg_spec, reduce, comm)
+                return self._groupby_combined(list(by), agg_spec, reduce, comm, selection)
             by = by[0]
         if reduce is None and comm is not None:
             reduce = comm.allreduce
@@ -926,6 +940,10 @@ class Frame:
         descs, names = [], []
         for name, d in agg_spec.items():
             names.append(name)
+            if selection is not None:
+                if d.selection is not None:
+                    raise NotImplementedError("groupby: an aggregation with its own selection next to a filter")
+                d = agg._Desc(d.name, d.column, selection)
             descs.append(d)
         if self.n == 0 and comm is None:
             return {by: np.array([], dtype=np.int64), **{n: np.array([]) for n in names}}
@@ -945,11 +963,11 @@ class Frame:
                 # which groups exist: count(*) > 0 — or the count of a value column the pass computes anyway, when that column
                 # is known to hold no NaN (then the two counts are the same grid and the pass has one aggregator less: for
                 # sum/mean/std of one column over 1e6 groups that is 128 instead of 256 slabs)
-                present_desc = agg.count()
+                present_desc = agg.count(selection=selection)
                 if comm is None:
                     for d in descs:
-                        if d.column is not None and d.selection is None and d.name in ("mean", "var", "std", "count") and not self._may_hold_nan(d.column):
-                            present_desc = agg.count(d.column)
+                        if d.column is not None and d.selection is selection and d.name in ("mean", "var", "std", "count") and not self._may_hold_nan(d.column):
+                            present_desc = agg.count(d.column, selection=selection)
                             break
                 specs, grid, aggs, want = self._pass(descs + [present_desc], binby, reduce=reduce)
                 fin = [d.finish_spec(sa, [aggs[i] for i in ids]) for d, ids in zip(descs, want[:-1])]
@@ -959,7 +977,7 @@ class Frame:
                     out_keys += kmin  # (in place: the array is this call's own pinned buffer)
                 vals = [np.asarray(c).astype(self._result_dtype(d), copy=False) for c, d in zip(cols, descs)]
                 return {by: out_keys, **dict(zip(names, vals))}
-            res = self._agg(descs + [agg.count()], binby=binby, edges=True, reduce=reduce)
+            res = self._agg(descs + [agg.count(selection=selection)], binby=binby, edges=True, reduce=reduce)
             present = res[-1][:count] > 0
             out_keys = (np.arange(count, dtype=np.int64) + kmin)[present]
             vals = [r[:count][present] for r in res[:-1]]
@@ -986,8 +1004,11 @@ class Frame:
             return {by: out_keys, **{n: np.array([]) for n in names}}
         sealed = getattr(sa, "ordered_set_" + pf)(nuniq)
         sealed.set_keys(out_keys.astype(np.int64))
-        res = self._agg_hash(descs, by, pf, sealed, reduce, nuniq)
+        res = self._agg_hash(descs + ([agg.count(selection=selection)] if selection is not None else []), by, pf, sealed, reduce, nuniq)
         vals = [r[1:1 + nuniq] for r in res] if res[0].shape[0] != nuniq else res
+        if selection is not None:   # (the key set came from every row: groups without a row inside the filter do not exist)
+            present = np.asarray(vals[-1]) > 0
+            out_keys, vals = out_keys[present], [np.asarray(v)[present] for v in vals[:-1]]
         return {by: out_keys, **dict(zip(names, vals))}
 
     def _groupby_fused(self, by, pf, descs, names, comm):

@@ -11,7 +11,8 @@ vaex_amd.binned.Frame covers — it answers `DataFrame.groupby(by, agg=...)` its
     agg    count(*) / count(x) / sum(x) / mean(x) / var(x) / std(x) / min(x) / max(x) on real numeric columns without missing values, no
            selection — given as vaex.agg objects, names ('count', 'mean', ...), lists or {name: ...} dicts, i.e. every
            form GroupByBase._agg accepts (vaex/groupby.py:688-745; the output column names follow its rules)
-    frame  not filtered, row_limit=None
+    frame  unfiltered, or filtered by comparison expressions over real numeric columns (vaex_amd.predicate's subset: the filter
+           becomes a device predicate); row_limit=None
 
 and builds the resulting DataFrame the way GroupBy.agg does (vaex/groupby.py:955-983): one row per group that exists, the key
 columns first.  Dense key ranges bin themselves in ONE partitioned pass (BinnerOrdinal(min_value) + vxh_finish: what vaex
@@ -160,8 +161,6 @@ def fast_groupby(df, by, agg, sort=False, ascending=True, row_limit=None):
     import vaex.groupby
     if row_limit is not None:
         raise _Decline("row_limit")
-    if df.filtered:
-        raise _Decline("filtered DataFrame")
     if by is None:
         raise _Decline("no key")
     by_list = [by] if isinstance(by, str) or not isinstance(by, collections.abc.Iterable) else list(by)
@@ -189,11 +188,24 @@ def fast_groupby(df, by, agg, sort=False, ascending=True, row_limit=None):
         if out_name in spec or out_name in key_names:
             raise _Decline("duplicate output column")
         spec[out_name] = _translate(df, aggregate, columns)
+    # a filtered frame (df[df.x > 0].groupby(...)): vaex compacts every chunk of every column with numpy before its two passes see a row
+    # (vaex/execution.py:515-523); here the filter is a device predicate in every aggregator's keep-mask (vaex_amd/vaex_filter.py) and
+    # groups without a row inside it are dropped — when it is in the predicate subset over real numeric columns; else vaex's own code
+    selection = None
+    if df.filtered:
+        from . import vaex_filter
+        pred = vaex_filter.filter_plan(df)
+        if pred is None:
+            raise _Decline("filtered DataFrame (filter outside the device predicate subset)")
+        selection = vaex_filter.filter_expression(df)
+        for c in pred.columns:
+            if c not in columns:
+                columns[c] = _real_column(df, c, tuple(k for k in vaex_filter._NUMERIC if k != "bool"), "filter column")[1]
     frame = _frame_for(df, columns)
     frame.last_groupby_info = None
     try:
-        res = frame.groupby(key_names if len(key_names) > 1 else key_names[0], spec)
-    except NotImplementedError as e:
+        res = frame.groupby(key_names if len(key_names) > 1 else key_names[0], spec, selection=selection)
+    except (NotImplementedError, ValueError) as e:
         raise _Decline(str(e))
     descending = bool(srt[0]) and not asc[0]
     out = {}
@@ -254,8 +266,12 @@ def _could_be_served(df, by, row_limit):
     """cheap look at a groupby WITHOUT aggregation: only integer key columns the device groupby takes make the lazy object worth it"""
     import vaex
     import vaex.groupby
-    if row_limit is not None or df.filtered or by is None:
+    if row_limit is not None or by is None:
         return False
+    if df.filtered:
+        from . import vaex_filter
+        if vaex_filter.filter_plan(df) is None:
+            return False
     by_list = [by] if isinstance(by, str) or not isinstance(by, collections.abc.Iterable) else list(by)
     if not 1 <= len(by_list) <= 8 or any(isinstance(b, vaex.groupby.BinnerBase) for b in by_list):
         return False
