@@ -455,35 +455,61 @@ def test_hashmap_unique_matches_numpy_on_random_chunks(sa):
     _check_dense_ordinals(hm, allk)
 
 
-def test_hot_box_uint16_counters_are_exact(sa):
-    """round 3: the hot box next to the ring-less pass 1 keeps uint16 counters (10-byte cells: 128x127 instead of 116x115 cells on
-    the bench pass).  Exactness: every workgroup compares the sum of its counters with the hot rows it counted; rows piled onto ONE
-    cell (> 65535 per workgroup) wrap a counter -> the call runs again with uint32 counters.  Both ways: the result is the oracle's."""
+@pytest.mark.parametrize("scenario", ["normal", "piled", "hidden_pile", "forced_flush"])
+def test_hot_box_packed_counters_are_exact(sa, scenario):
+    """round 3: the hot box next to the ring-less pass 1 keeps packed counters — uint16 (10-byte cells: 128x127 instead of 116x115 cells on
+    the bench pass) or, where the sampled share of the fullest cell allows, uint8 (9-byte cells: 135x134) that the workgroup flushes
+    every few hundred tiles.  Exactness: whenever a workgroup flushes its counters it compares their sum with the hot rows it counted; a
+    wrapped counter makes them differ and the call runs again with the next wider counters.
+      normal        N(0,1): uint8 counters
+      piled         7/8 of the rows in ONE cell, the sample sees it: uint16 straight away, which wraps (114688 rows per workgroup) -> uint32
+      hidden_pile   1/8 of the rows in one cell, all of them BETWEEN the sampled segments: uint8 chosen, wraps -> uint16 holds
+      forced_flush  a forced box with a flush every 2 trips of the tile loop (the periodic flush itself; a launch of this size would
+                    otherwise end before the first one)
+    Every way the result is the uint32 box's and the oracle's."""
     import torch
     g = torch.Generator(device="cuda").manual_seed(5)
     n = 1 << 25
-    for piled in (False, True):
+    if True:
+        piled = scenario == "piled"
         x = torch.randn(n, dtype=torch.float64, device="cuda", generator=g)
         y = torch.randn(n, dtype=torch.float64, device="cuda", generator=g)
         v = torch.randn(n, dtype=torch.float64, device="cuda", generator=g) * 2 + 3
         if piled:
             x[: n - n // 8] = 0.25; y[: n - n // 8] = -0.5   # 7/8 of the rows in one cell: 114688 per workgroup
+        if scenario == "hidden_pile":   # (the sample: 8 segments of 2^18 rows starting at multiples of n / 8)
+            i = torch.arange(n, device="cuda") % (n // 8)
+            hidden = (i >= (1 << 20)) & (i < (1 << 20) + (1 << 19))
+            x[hidden] = 0.25; y[hidden] = -0.5              # 1/8 of the rows: 16384 per workgroup in one cell
         bx = sa.BinnerScalar_float64(1, "x", -4.0, 4.0, 256); by = sa.BinnerScalar_float64(1, "y", -4.0, 4.0, 256)
         grid = sa.Grid([bx, by])
         aggs = [sa.AggCount_int64(grid, 1, 1), sa.AggSum_float64(grid, 1, 1), sa.AggCount_float64(grid, 1, 1)]
         bx.set_data(0, x); by.set_data(0, y); aggs[1].set_data(0, v, 0); aggs[2].set_data(0, v, 0)
-        grid.bin(0, aggs, n)
+        forced = dict(hot_x0=66, hot_y0=67, hot_w=126, hot_h=125, hot_flush_trips=2) if scenario == "forced_flush" else {}
+        for k, val in forced.items():
+            sa.config_set(k, val)
+        try:
+            grid.bin(0, aggs, n)
+            used, trips = sa.config_get("hot_cnt16_used"), sa.config_get("hot_flush_trips_used")
+        finally:
+            for k in forced:
+                sa.config_set(k, 0)
         got = [np.array(a.get_result()) for a in aggs]
         assert sa.last_kernel(0).startswith("part_scatter_direct_hot"), sa.last_kernel(0)
-        assert sa.config_get("hot_cnt16_used") == (0 if piled else 1)   # (the piled call ended on uint32 counters)
+        assert used == dict(normal=2, piled=0, hidden_pile=1, forced_flush=2)[scenario], used   # (what the call ENDED on)
+        if scenario == "forced_flush":
+            assert trips == 2
+        elif scenario == "normal":
+            assert trips >= 8
         sa.config_set("hot_cnt16", 0)
         try:
             for a in aggs:
                 a.reset()
             grid.bin(0, aggs, n)
             want = [np.array(a.get_result()) for a in aggs]
+            assert sa.config_get("hot_cnt16_used") == 0
         finally:
-            sa.config_set("hot_cnt16", 1)
+            sa.config_set("hot_cnt16", 2)
         np.testing.assert_array_equal(got[0], want[0]); np.testing.assert_array_equal(got[2], want[2])
         assert int(got[0].sum()) == n
         assert np.all(np.abs(got[1] - want[1]) <= 1e-12 * 20.0 * np.maximum(want[0], 1))

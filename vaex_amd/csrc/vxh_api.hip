@@ -933,8 +933,13 @@ static void hot_prepare(Slot &slot, const BinArgs &A, const BinArgs &planned, co
     if (wv && gen2 && c.cfg_wv == 1) wv = false; // next to a box part_scatter_blk is the (slightly) faster one: its staging leaves the box 111 KB, eight waves' rings 78 KB
     // a forced box (tests / experiments) too big for what part_scatter_wv's rings leave of the LDS goes to part_scatter_blk
     // uint16 counters (two per LDS word) next to the ring-less pass 1 with one value column: 10-byte cells instead of 12
-    const bool c16 = c.cfg_hot_cnt16 && !H.no_cnt16 && nval == 1 && !mom2 && wg.ok && wg.direct == 1;
+    // ... uint8 counters (four per word, 9-byte cells) where the fullest cell fills slowly enough for a flush every few hundred tiles
+    const int shift_max = (nval == 1 && !mom2 && wg.ok && wg.direct == 1) ? (int)std::max<int64_t>(0, std::min<int64_t>(std::min<int64_t>(c.cfg_hot_cnt16, H.max_shift), (c.cfg_no_pipeline & 1024) ? 1 : 2)) : 0;
+    const bool c16 = shift_max >= 1;
+    int shift = c16 ? 1 : 0; // (uint8 is decided below, from the sample)
     H.cnt16 = false;
+    H.cnt_shift = 0;
+    H.flush_trips = 0;
     if (wv && forced && gen2 && (uint64_t)c.cfg_hot_box[2] * (uint64_t)c.cfg_hot_box[3] > (kLdsMax - ((size_t)wg.waves * wg.wave_bytes + 64) - 96 - (c16 ? 16 : 0)) / (c16 ? 10 : (nval ? (mom2 ? 20 : 12) : 4))) wv = false;
     if (!gen2 && !wv) return;
     if (ints && !wv) return;
@@ -942,10 +947,11 @@ static void hot_prepare(Slot &slot, const BinArgs &A, const BinArgs &planned, co
     H.gen2 = true;
     H.nval = nval;
     const size_t cell_bytes = nval ? (mom2 ? 20 : 12) : 4;
-    auto room = [&](bool with_wv) -> uint64_t { // cells the box may have next to this pass-1 kernel's own LDS (0: does not fit)
+    auto room = [&](bool with_wv, int sh = -1) -> uint64_t { // cells the box may have next to this pass-1 kernel's own LDS (0: does not fit)
         const size_t fixed = with_wv ? (size_t)wg.waves * wg.wave_bytes + 64 : (size_t)VXH_BLK_FIXED_LDS(nval, S);
         if (fixed + 4096 > kLdsMax) return 0;
-        return with_wv && c16 ? (kLdsMax - fixed - 96 - 16) / 10 : (kLdsMax - fixed - 96) / cell_bytes;
+        if (sh < 0) sh = shift;
+        return with_wv && sh ? (kLdsMax - fixed - 96 - 16) / (size_t)(8 + (4 >> sh)) : (kLdsMax - fixed - 96) / cell_bytes;
     };
     const uint32_t sx = (uint32_t)(A.b[0].bins + 3), sy = (uint32_t)(A.b[1].bins + 3);
     uint32_t box[4] = {0, 0, 0, 0};
@@ -1003,14 +1009,17 @@ static void hot_prepare(Slot &slot, const BinArgs &A, const BinArgs &planned, co
             H.key_ptr[0] = A.b[0].data; H.key_ptr[1] = A.b[1].data;
             memcpy(H.key_lim, lim, sizeof(lim));
             H.key_len = length;
-            H.key_cells[0] = H.key_cells[1] = 0;
+            H.key_cells[0] = H.key_cells[1] = H.key_cells[2] = 0;
+            H.key_next = 0;
+            H.key_max_shift = 2;
             H.key_fraction = 0;
         }
         // the densest box for a budget of `max_cells` cells (searched once per sample and budget)
         auto searched = [&](uint64_t max_cells, uint32_t (&out)[4]) -> double {
-            int e = H.key_cells[0] == max_cells ? 0 : (H.key_cells[1] == max_cells ? 1 : -1);
+            int e = H.key_cells[0] == max_cells ? 0 : (H.key_cells[1] == max_cells ? 1 : (H.key_cells[2] == max_cells ? 2 : -1));
             if (e < 0) {
-                e = H.key_cells[0] == 0 ? 0 : 1;
+                e = H.key_next;
+                H.key_next = (H.key_next + 1) % 3;
                 const int64_t in = hot_search(H.key_grid, sx, sy, max_cells, H.key_box[e]);
                 H.key_cells[e] = max_cells;
                 H.key_box_fraction[e] = H.key_total > 0 ? (double)in / (double)H.key_total : 0;
@@ -1022,6 +1031,21 @@ static void hot_prepare(Slot &slot, const BinArgs &A, const BinArgs &planned, co
         // room, but its scattered record stores cost in proportion to the cold rows — from ~62 % of the rows inside the
         // box on it wins; below that part_scatter_blk (staged records, smaller box), which still pays off down to ~15 %.
         bool chosen = false;
+        // uint8 counters: the bigger box, if the fullest cell inside it takes long enough to reach 256 rows of ONE workgroup — the
+        // workgroup flushes its counters when ~128 rows are expected there (a trip of its waves' loop is 2 x waves x 256 rows)
+        if (wv && wg.direct && gen2 && std::min(shift_max, H.key_max_shift) >= 2 && room(true, 2) && H.key_total > 0) {
+            uint32_t b8[4];
+            const double f = searched(room(true, 2), b8);
+            int64_t peak = 0;
+            for (uint32_t yy = b8[1]; yy < b8[1] + b8[3]; yy++)
+                for (uint32_t xx = b8[0]; xx < b8[0] + b8[2]; xx++) peak = std::max(peak, H.key_grid[(size_t)yy * sx + xx]);
+            const double rows_between = peak > 0 ? 128.0 * (double)H.key_total / (double)peak : 1e18;
+            const double trips = rows_between / (2.0 * (double)wg.waves * 256.0);
+            if (f * 100.0 >= (double)c.cfg_hot_direct_pct && trips >= 8.0) {
+                shift = 2;
+                H.flush_trips = (uint32_t)std::min<double>(trips, 1 << 20);
+            }
+        }
         if (wv && wg.direct && gen2 && room(true)) {
             const double f = searched(room(true), box);
             if (f * 100.0 >= (double)c.cfg_hot_direct_pct) { H.last_fraction = f; chosen = true; }
@@ -1038,6 +1062,12 @@ static void hot_prepare(Slot &slot, const BinArgs &A, const BinArgs &planned, co
     }
     H.wv = wv;
     H.cnt16 = wv && c16;
+    H.cnt_shift = H.cnt16 ? shift : 0;
+    if (forced && H.cnt16 && shift_max >= 2 && c.cfg_hot_flush_trips > 0 && (uint64_t)box[2] * box[3] <= room(true, 2)) { // (tests: a forced box with uint8 counters and a given interval)
+        H.cnt_shift = 2;
+        H.flush_trips = (uint32_t)c.cfg_hot_flush_trips;
+    }
+    if (H.cnt_shift != 2) H.flush_trips = 0;
     if (H.cnt16) {
         if (!H.flag) HIP_CHECK(hipMalloc((void **)&H.flag, 64));
         HIP_CHECK(hipMemsetAsync(H.flag, 0, 64, slot.stream));
@@ -1335,11 +1365,12 @@ static void run_part_chunk(Slot &slot, const BinArgs &planned, const LaunchPlan 
         P.hot.on = 2;
         P.hot.x0 = H.x0; P.hot.y0 = H.y0; P.hot.w = H.w; P.hot.h = H.h;
         P.hot.lds_offset = 0; // the box first, the waves' rings behind it
-        P.hot.cnt16 = H.cnt16 ? 1u : 0u;
+        P.hot.cnt16 = H.cnt16 ? (uint32_t)H.cnt_shift : 0u;
+        P.hot.flush_trips = H.flush_trips;
         P.hot.overflow = H.flag;
         const size_t box_cells = (size_t)H.w * H.h;
-        // (uint16 counters: two per word, then two words: the hot rows the workgroup saw, and the sum of its counters)
-        P.wv_base = (int32_t)(((H.cnt16 ? box_cells * 8 + ((box_cells + 1) / 2) * 4 + 8 : box_cells * (P.nvals ? (H.mom2 ? 20 : 12) : 4)) + 15) & ~(size_t)15);
+        // (packed counters: 2 or 4 per word, then two words: the hot rows the workgroup saw, and the sum of its counters)
+        P.wv_base = (int32_t)(((H.cnt16 ? box_cells * 8 + ((box_cells + ((size_t)1 << H.cnt_shift) - 1) >> H.cnt_shift) * 4 + 8 : box_cells * (P.nvals ? (H.mom2 ? 20 : 12) : 4)) + 15) & ~(size_t)15);
         scatter_lds = (size_t)P.wv_base + (size_t)wg.waves * wg.wave_bytes + 16;
         P.hot.mom2 = H.mom2 ? 1u : 0u;
         P.hot.sum_acc = (double *)H.acc;
@@ -1594,6 +1625,7 @@ int vxh_config_set(const char *key, int64_t value) {
     else if (k == "scatter_wgs") c.cfg_scatter_wgs = value;
     else if (k == "hot") c.cfg_hot = value;
     else if (k == "hot_cnt16") c.cfg_hot_cnt16 = value;
+    else if (k == "hot_flush_trips") c.cfg_hot_flush_trips = value;
     else if (k == "blk") c.cfg_blk = value;
     else if (k == "wv") c.cfg_wv = value;
     else if (k == "wv_waves") c.cfg_wv_waves = value > 0 ? value : 8;
@@ -1637,7 +1669,9 @@ int vxh_config_get(const char *key, int64_t *value) {
     else if (k == "scatter_wgs") *value = c.cfg_scatter_wgs;
     else if (k == "hot") *value = c.cfg_hot;
     else if (k == "hot_cnt16") *value = c.cfg_hot_cnt16;
-    else if (k == "hot_cnt16_used") *value = get_slot(0).hot.cnt16 ? 1 : 0;
+    else if (k == "hot_cnt16_used") *value = get_slot(0).hot.cnt16 ? get_slot(0).hot.cnt_shift : 0;
+    else if (k == "hot_flush_trips") *value = c.cfg_hot_flush_trips;
+    else if (k == "hot_flush_trips_used") *value = get_slot(0).hot.flush_trips;
     else if (k == "blk") *value = c.cfg_blk;
     else if (k == "wv") *value = c.cfg_wv;
     else if (k == "wv_waves") *value = c.cfg_wv_waves;
@@ -2000,7 +2034,7 @@ int vxh_grid_bin(vxh_grid *grid, int thread, vxh_agg *const *aggs, int n_aggs, u
             bool armed;
             ~PartGuard() { if (armed) { slot.acc_sig = 0; slot.hot.on = false; } }
         } part_guard{slot, whole.strategy == VXH_STRAT_PART};
-        for (int attempt = 0; attempt < 2; ++attempt) {
+        for (int attempt = 0; attempt < 3; ++attempt) {
         for (uint64_t r0 = 0; r0 < length; r0 += step) {
             const uint64_t rn = std::min(step, length - r0);
             BinArgs L = A;
@@ -2031,10 +2065,10 @@ int vxh_grid_bin(vxh_grid *grid, int thread, vxh_agg *const *aggs, int n_aggs, u
             }
             slot.last_kernel = plan.name;
         }
-        if (attempt == 0 && whole.strategy == VXH_STRAT_PART && slot.hot.on && slot.hot.cnt16) {
-            // uint16 box counters: every workgroup compared the sum of its counters with the hot rows it saw.  One that wrapped
-            // (> 65535 rows of ONE workgroup in ONE cell: very skewed data) raised the flag: nothing of this call has reached the
-            // grids yet (the accumulators are merged below) — put the accumulators back and run the call again with uint32 counters.
+        if (attempt < 2 && whole.strategy == VXH_STRAT_PART && slot.hot.on && slot.hot.cnt16) {
+            // packed box counters: every workgroup compared the sum of its counters with the hot rows it saw.  One that wrapped
+            // (uint16: > 65535 rows of ONE workgroup in ONE cell; uint8: > 255 between two flushes — data far from what the sample said) raised the flag: nothing of this call has reached the
+            // grids yet (the accumulators are merged below) — put the accumulators back and run the call again with the next wider counters.
             part_join(slot);
             unsigned int wrapped = 0;
             HIP_CHECK(hipMemcpyAsync(&wrapped, slot.hot.flag, 4, hipMemcpyDeviceToHost, slot.stream));
@@ -2042,9 +2076,10 @@ int vxh_grid_bin(vxh_grid *grid, int thread, vxh_agg *const *aggs, int n_aggs, u
             if (wrapped) {
                 slot.acc_sig = 0;
                 part_acc_prepare(slot, whole_args);
-                slot.hot.no_cnt16 = true;
+                slot.hot.max_shift = slot.hot.cnt_shift - 1; // uint8 -> uint16 -> uint32
+                slot.hot.key_max_shift = std::min(slot.hot.key_max_shift, slot.hot.max_shift);
                 hot_prepare(slot, A, whole_args, whole, length);
-                slot.hot.no_cnt16 = false;
+                slot.hot.max_shift = 2;
                 continue;
             }
         }

@@ -145,8 +145,11 @@ struct Slot {
     // hot box of the current vxh_grid_bin call (PartArgs::hot) and its per-workgroup accumulators
     struct Hot {
         int nval = 1;      // value columns the box aggregates (1: fp64 sum + count per cell, 0: count only)
-        bool cnt16 = false;    // uint16 box counters this call (10-byte cells; exact: checked per workgroup, the call is redone with uint32 ones if one wrapped)
-        bool no_cnt16 = false; // ... not for this call (the redo)
+        bool cnt16 = false;    // packed box counters this call (exact: checked per workgroup, the call is redone with wider ones if one wrapped)
+        int cnt_shift = 0;     // ... log2(counters per LDS word): 1 = uint16 (10-byte cells), 2 = uint8 (9-byte cells, flushed every flush_trips trips)
+        uint32_t flush_trips = 0;
+        int max_shift = 2;     // widest packing allowed for this call (the redo after a wrap lowers it)
+        int key_max_shift = 2; // ... remembered with the sample (key_*): columns whose counters wrapped once do not try again
         unsigned int *flag = nullptr; // device word the workgroups raise
         bool mom2 = false; // ... and the fp64 sum of squares (an AggSumMoment with moment 2 among the aggregators: 20-byte cells)
         bool gen2 = false; // part_scatter_hot (vs the HOT instantiation of part_scatter_f64)
@@ -166,9 +169,10 @@ struct Slot {
         std::vector<int64_t> key_grid; // the sample's counts per cell (valid while key_fraction >= 0)
         int64_t key_total = 0;
         // searched boxes for up to two LDS budgets (the ring-less pass 1 and part_scatter_blk leave the box different room)
-        uint64_t key_cells[2] = {0, 0};
-        uint32_t key_box[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
-        double key_box_fraction[2] = {-1, -1};
+        uint64_t key_cells[3] = {0, 0, 0};   // the box searches of this sample, by cell budget (uint8 / uint16 counters next to part_scatter_wv, part_scatter_blk)
+        uint32_t key_box[3][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+        double key_box_fraction[3] = {-1, -1, -1};
+        int key_next = 0;
         double key_fraction = -1;
         double last_fraction = 0; // share of the sample inside the box (vxh_config_get("hot_fraction_ppm"))
     } hot;
@@ -211,7 +215,9 @@ struct Context {
     int64_t cfg_wv_waves_direct = 16; // ... waves per workgroup of the ring-less variant ("wv" = 3, next to a hot box)
     int64_t cfg_wv_waves = 8;      // ... waves per workgroup (one workgroup per CU); fewer when the rings would not fit
     int64_t cfg_hot = 1;           // hot box in pass 1 of the partition strategy (0 off)
-    int64_t cfg_hot_cnt16 = 1;     // uint16 counters in the box next to the ring-less pass 1 (one value column): 20 % more cells
+    int64_t cfg_hot_flush_trips = 0; // tests: uint8 counters with this flush interval next to a FORCED box
+    int64_t cfg_hot_cnt16 = 2;     // packed counters in the box next to the ring-less pass 1 (one value column): 1 = uint16 (20 % more cells than uint32),
+                                   // 2 = uint8 where the sampled share of the fullest cell allows (33 % more), 0 = uint32
     int64_t cfg_hot_min_rows = 1 << 24; // calls shorter than this do not pay for the sample
     int64_t cfg_hot_cache = 1;     // reuse the sampled box when the same columns are binned with the same limits again (0: sample every call)
     int64_t cfg_hot_min_pct = 10;  // use the box only when it catches at least this share of the sample (profiles/r02_box_share.txt: worth it from ~15 %)

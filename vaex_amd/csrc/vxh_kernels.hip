@@ -1670,9 +1670,13 @@ __global__ void __launch_bounds__(1024) part_scatter_wv(const PartArgs P) {
     // uint16 counters, two per word (PartArgs::hot.cnt16): 10-byte cells make the box 20 % larger.  Exact: a wave counts the hot
     // rows it adds (s_bcnt1 of the ballot), the workgroup compares their total with the sum of its counters before the flush — a
     // counter that wrapped (> 65535 rows of this workgroup in one cell) makes them differ, and the host runs the call again.
+    // uint8 counters, four per word (cnt16 == 2): 9-byte cells.  The workgroup flushes and clears them every P.hot.flush_trips trips
+    // of the tile loop (the host picks the interval from the sampled share of the fullest cell: ~128 rows expected there), with the
+    // same check at every flush — a wrapped byte carries into its neighbour, the sum of the counters comes out 255 short.
     const bool c16 = HOT && DIRECT == 1 && NVAL == 1 && P.hot.cnt16 != 0u; // (wave-uniform)
-    const uint32_t cnt_words = c16 ? (hot_cells + 1u) / 2u : hot_cells;      // [cnt_words] hot rows seen, [cnt_words + 1] sum of the counters
-    uint32_t nhot = 0;
+    const uint32_t csh = c16 ? P.hot.cnt16 : 0u;                            // log2(counters per word): 1 or 2
+    const uint32_t cnt_words = c16 ? (hot_cells + (1u << csh) - 1u) >> csh : hot_cells; // [cnt_words] hot rows seen, [cnt_words + 1] sum of the counters
+    uint32_t nhot = 0, flushed = 0; // (per wave / per thread)
     char *const wbase = lds + P.wv_base + wave * (uint32_t)P.wv_wave_bytes;
     double *const ring_val = (double *)wbase;
     uint16_t *const ring_idx = (uint16_t *)(wbase + (NVAL ? (size_t)S * D * 8 : 0));
@@ -1947,7 +1951,7 @@ __global__ void __launch_bounds__(1024) part_scatter_wv(const PartArgs P) {
                     if (NVAL && vint) at_add<__HIP_MEMORY_SCOPE_WORKGROUP, unsigned long long>((unsigned long long *)hot_sum + hc, (unsigned long long)__double_as_longlong(val[NVAL ? r : 0]));
                     else if (NVAL) at_add<__HIP_MEMORY_SCOPE_WORKGROUP, double>(hot_sum + hc, val[NVAL ? r : 0]);
                     if (hot_mom2) at_add<__HIP_MEMORY_SCOPE_WORKGROUP, double>(hot_sum2 + hc, val[NVAL ? r : 0] * val[NVAL ? r : 0]); // (= pow_u(v, 2))
-                    at_add<__HIP_MEMORY_SCOPE_WORKGROUP, uint32_t>(hot_cnt + (c16 ? hc >> 1 : hc), c16 ? 1u << ((hc & 1u) << 4) : 1u);
+                    at_add<__HIP_MEMORY_SCOPE_WORKGROUP, uint32_t>(hot_cnt + (hc >> csh), 1u << ((hc & ((1u << csh) - 1u)) << (5u - csh))); // (csh = 0: word hc, +1)
                 }
                 if (c16) nhot += (uint32_t)__builtin_popcountll(__ballot(hot));
                 is_cold = is_cold & !hot;
@@ -2053,12 +2057,40 @@ __global__ void __launch_bounds__(1024) part_scatter_wv(const PartArgs P) {
         }
     };
 
+    // packed counters -> the workgroup's HBM copy of the box (its own cells: plain adds); returns this thread's share of their sum
+    auto hot_flush_counts = [&]() -> uint32_t {
+        unsigned long long *gc = P.hot.cnt_acc + (uint64_t)blockIdx.x * hot_cells;
+        uint32_t mine = 0;
+        __syncthreads(); // (every wave's adds so far have landed: the barrier waits for the LDS queue)
+        for (uint32_t c = threadIdx.x; c < hot_cells; c += blockDim.x) {
+            const uint32_t v = (hot_cnt[c >> csh] >> ((c & ((1u << csh) - 1u)) << (5u - csh))) & (0xffffffffu >> (32u - (32u >> csh)));
+            if (v) gc[c] += v;
+            mine += v;
+        }
+        __syncthreads();
+        for (uint32_t w = threadIdx.x; w < cnt_words; w += blockDim.x) hot_cnt[w] = 0u;
+        __syncthreads();
+        return mine;
+    };
+
     if (has_work) {
         if (!(P.no_pipeline & 1024)) {
         // ping-pong register buffers, the loop unrolled by two so that neither is ever copied (see count_lds_f64)
         Raw bufA, bufB;
         request(tile, bufA);
+        // uint8 counters: every wave of the workgroup comes by here once per trip, and trip t exists for ALL of them as long as the
+        // workgroup's last wave has a tile 2 t GW further on — the condition is the same for the whole workgroup, so the barriers
+        // of a flush are met by every wave (a wave that leaves the loop earlier has seen every flush there was)
+        const uint32_t wg_last = blockIdx.x * nwave + (nwave - 1u);
+        uint32_t trip = 0, until_flush = P.hot.flush_trips;
         for (;;) {
+            if (HOT && DIRECT == 1 && NVAL == 1 && csh == 2u) {
+                if (trip && --until_flush == 0u) {
+                    until_flush = P.hot.flush_trips;
+                    if ((uint64_t)wg_last + 2ull * trip * GW < ntiles) flushed += hot_flush_counts();
+                }
+                ++trip;
+            }
             uint32_t next = tile + GW;
             bool has_next = next < ntiles;
             request(has_next ? next : tile, bufB); // (the last tile re-requests itself: static number of loads in flight)
@@ -2139,9 +2171,9 @@ __global__ void __launch_bounds__(1024) part_scatter_wv(const PartArgs P) {
         if (!c16) {
             flush_add_plain<unsigned long long, uint32_t>(gc, hot_cnt, hot_cells, 0, 0, hot_cells);
         } else {
-            uint32_t mine = 0;
+            uint32_t mine = flushed; // (what this thread moved in the flushes on the way, uint8 counters)
             for (uint32_t c = threadIdx.x; c < hot_cells; c += blockDim.x) {
-                const uint32_t v = (hot_cnt[c >> 1] >> ((c & 1u) << 4)) & 0xffffu;
+                const uint32_t v = (hot_cnt[c >> csh] >> ((c & ((1u << csh) - 1u)) << (5u - csh))) & (0xffffffffu >> (32u - (32u >> csh)));
                 if (v) gc[c] += v;
                 mine += v;
             }

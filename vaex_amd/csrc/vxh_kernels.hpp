@@ -139,8 +139,11 @@ struct PartArgs {
         double *sum_acc;           // [pass-1 workgroups][w*h]
         double *sum2_acc;          // ... (mom2)
         unsigned long long *cnt_acc;
-        uint32_t cnt16;            // the box's counters are uint16, two per LDS word (part_scatter_wv DIRECT = 1, one value column): 10-byte
-                                   // cells; a workgroup checks sum(counters) == hot rows it saw before it flushes and raises *overflow otherwise
+        uint32_t cnt16;            // packed box counters (part_scatter_wv DIRECT = 1, one value column): 1 = uint16, two per LDS word (10-byte
+                                   // cells), 2 = uint8, four per word (9-byte cells); a workgroup checks sum(counters) == hot rows it saw
+                                   // whenever it flushes them and raises *overflow otherwise
+        uint32_t flush_trips;      // uint8 counters: the workgroup flushes and clears them every `flush_trips` trips of its waves' tile loop
+                                   // (2 tiles per wave and trip), so that no cell sees 256 rows in between
         unsigned int *overflow;
     } hot;
 };
