@@ -18,6 +18,10 @@
 //   MODE 13 as 10, the wave's stream only 64 records long (rewritten in place: the lines can stay in the L2)
 //   MODE 14 as 10, the wave's stream wraps after 1536 records: 63 MB of queue in all (would fit the 256 MB Infinity Cache)
 //   MODE 15 as 10, wraps after 384 records: 16 MB in all (would fit the L2s: 4 MB per XCD, 2 MB of queue per XCD)
+//   MODE 16 as 10, but TIME-PHASED: a wave holds its flushes back (here: counts them — the records are synthetic) and issues them all
+//           when bit 11 of the 100 MHz wall clock (s_memrealtime) flips, i.e. every wave of the chip writes in the same ~1 us window
+//           every 20 us and only reads in between: does the memory side like its writes in bursts?
+//   MODE 17 as 16 with an 82 us period (bit 13); MODE 18 as 17 with non-temporal stores; MODE 19 as 16 with a 328 us period (bit 15)
 // Lanes that have no record store to the sink (every lane executes every store, as in the production kernel).
 // Build: hipcc --offload-arch=gfx950 -O3 -o tools/microbench6 tools/microbench6.hip ; run: tools/microbench6 [rows]
 #include <hip/hip_runtime.h>
@@ -62,7 +66,8 @@ __global__ void __launch_bounds__(1024) pass(const Args A) {
     const uint64_t sbase = (uint64_t)gwave * S * A.cap;              // first record of the wave's stream 0
     const uint64_t sink = (uint64_t)GW * S * A.cap + (uint64_t)gwave * 16u;
     uint32_t filled = 0;   // records per stream so far (the same for every stream of the wave: 3 per tile)
-    uint32_t phase = 0, flushes = 0;
+    uint32_t phase = 0, flushes = 0, pending = 0;
+    uint64_t epoch = 0;
     double acc = 0;
     auto store12 = [&](uint64_t dst, uint32_t local, uint64_t bits) {
         *(u32x3_a4 *)(A.q12 + dst * 3) = u32x3_a4{(uint32_t)bits, (uint32_t)(bits >> 32), local};
@@ -85,6 +90,26 @@ __global__ void __launch_bounds__(1024) pass(const Args A) {
                 store12(dst, local, bits);
             }
             filled += 3;
+            return;
+        }
+        if (MODE >= 16) {
+            if (++phase == 3u) { phase = 0; ++pending; }
+            const uint64_t now = __builtin_amdgcn_s_memrealtime() >> (MODE == 16 ? 11 : (MODE == 19 ? 15 : 13));
+            if (now != epoch) {
+                epoch = now;
+                while (pending) {
+                    const uint64_t dst = sbase + filled + lane;
+                    if (MODE == 18) {
+                        __builtin_nontemporal_store(bits, A.qv + dst);
+                        __builtin_nontemporal_store((uint16_t)local, A.qi + dst);
+                    } else {
+                        A.qv[dst] = bits;
+                        A.qi[dst] = (uint16_t)local;
+                    }
+                    filled += 64u;
+                    --pending;
+                }
+            }
             return;
         }
         // MODE 4/5/6: every third tile a flush of 64 records (the 72 of three tiles, minus 8 to keep it simple)
@@ -123,6 +148,12 @@ __global__ void __launch_bounds__(1024) pass(const Args A) {
         if (!has_next) break;
         tile = next;
     }
+    if (MODE >= 16)
+        while (pending) { // (what the last period left)
+            A.qv[sbase + filled + lane] = (uint64_t)__double_as_longlong(acc);
+            filled += 64u;
+            --pending;
+        }
     if (acc == 1.2345e-300) A.out[0] = acc;
 }
 
@@ -150,11 +181,12 @@ int main(int argc, char **argv) {
     printf("rows %.3g, %u workgroups x 16 waves, %.2f GB of 12-byte records per pass (9.4 %% of the rows)\n", (double)n, wgs, (double)n * 24 / 256 * 12 / 1e9);
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    const char *names[16] = {"read loop alone", "scattered dwordx3 (production)", "sorted by stream, runs of 3, dwordx3", "sorted, runs of 3, SoA 8+2 bytes",
+    const char *names[20] = {"read loop alone", "scattered dwordx3 (production)", "sorted by stream, runs of 3, dwordx3", "sorted, runs of 3, SoA 8+2 bytes",
                             "staged: 64 per flush, runs of 8, dwordx3", "staged: 64 per flush, runs of 8, SoA", "staged: 64 per flush, one stream, SoA", "every lane to the sink",
-                            "one stream per flush, half the records", "one stream per flush, aligned whole lines", "aligned, ONE stream per wave", "... non-temporal stores", "... ordinary loads", "... stream rewritten in place (64 records)", "... stream wraps: 63 MB of queue in all", "... stream wraps: 16 MB of queue in all"};
+                            "one stream per flush, half the records", "one stream per flush, aligned whole lines", "aligned, ONE stream per wave", "... non-temporal stores", "... ordinary loads", "... stream rewritten in place (64 records)", "... stream wraps: 63 MB of queue in all", "... stream wraps: 16 MB of queue in all",
+                            "time-phased: all waves flush every 20 us", "time-phased: every 82 us", "time-phased: every 82 us, non-temporal", "time-phased: every 328 us"};
     for (int rep = 0; rep < 2; ++rep)
-        for (int mode = 0; mode < 16; ++mode) {
+        for (int mode = 0; mode < 20; ++mode) {
             float best = 1e9f;
             for (int it = 0; it < 4; ++it) {
                 CK(hipEventRecord(e0));
@@ -174,7 +206,11 @@ int main(int argc, char **argv) {
                 case 12: hipLaunchKernelGGL(pass<12>, dim3(wgs), dim3(1024), 0, 0, A); break;
                 case 13: hipLaunchKernelGGL(pass<13>, dim3(wgs), dim3(1024), 0, 0, A); break;
                 case 14: hipLaunchKernelGGL(pass<14>, dim3(wgs), dim3(1024), 0, 0, A); break;
-                default: hipLaunchKernelGGL(pass<15>, dim3(wgs), dim3(1024), 0, 0, A); break;
+                case 15: hipLaunchKernelGGL(pass<15>, dim3(wgs), dim3(1024), 0, 0, A); break;
+                case 16: hipLaunchKernelGGL(pass<16>, dim3(wgs), dim3(1024), 0, 0, A); break;
+                case 17: hipLaunchKernelGGL(pass<17>, dim3(wgs), dim3(1024), 0, 0, A); break;
+                case 18: hipLaunchKernelGGL(pass<18>, dim3(wgs), dim3(1024), 0, 0, A); break;
+                default: hipLaunchKernelGGL(pass<19>, dim3(wgs), dim3(1024), 0, 0, A); break;
                 }
                 CK(hipEventRecord(e1));
                 CK(hipEventSynchronize(e1));
