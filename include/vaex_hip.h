@@ -370,6 +370,11 @@ typedef enum vxh_groupby_column_kind {
  * (> ~3.5e6) or too skewed for the LDS-partitioned path: the caller then takes ordered_set + BinnerHash. */
 int vxh_groupby_run(int key_dtype, const void *keys, int n_values, const void *const *values, uint64_t n, int mem,
                     uint64_t groups_hint, uint64_t max_groups, vxh_groupby **out);
+/* the same with a keep-mask over the call (one byte per row where the keys live, 1 = the row takes part; null = every row): a filtered
+ * frame / a selection shared by every aggregation — vaex compacts the chunks of a filtered frame before its passes see them
+ * (vaex/execution.py:515-523); here rows outside the mask leave no record and groups without a row inside it do not exist. */
+int vxh_groupby_run_kept(int key_dtype, const void *keys, int n_values, const void *const *values, const uint8_t *keep, uint64_t n, int mem,
+                         uint64_t groups_hint, uint64_t max_groups, vxh_groupby **out);
 /* the same aggregation over PARTIAL results (other chunks', other ranks'): host arrays of n partial groups */
 int vxh_groupby_merge(int n_values, const int64_t *keys, const int64_t *rows, const int64_t *const *counts,
                       const double *const *sums, const double *const *sums2, uint64_t n, uint64_t groups_hint, vxh_groupby **out);

@@ -171,3 +171,51 @@ def test_frame_groupby_millions_of_scattered_keys(sa, gpu_ready, groups):
         assert df.last_groupby_info is not None and df.last_groupby_info["buckets"] == 1024 and df.last_groupby_info["retries"] >= 1
     else:
         assert df.last_groupby_info is None  # (the partitioned pass declined)
+
+
+@pytest.mark.parametrize("where", ["host", "device"])
+def test_groupby_run_with_a_keep_mask(sa, gpu_ready, where):
+    """vxh_groupby_run_kept: rows outside the mask leave no record (a filtered frame / a selection over the whole call) — the result
+    is that of the kept rows alone, groups without a kept row do not exist; mask values other than 1 do not keep"""
+    import torch
+    rng = np.random.default_rng(8)
+    n = 2_000_000
+    k = (rng.integers(0, 300_000, n) * 2654435761) % (1 << 40) - (1 << 39)
+    v = rng.normal(3, 2, n); v[rng.random(n) < 0.01] = np.nan
+    w = rng.normal(0, 1, n)
+    keep = (rng.random(n) < 0.3).astype(np.uint8)
+    keep[::1000] = 2   # (not 1: dropped, like Aggregator masks, src/agg_count.cpp:50)
+    kept = keep == 1
+    args = (k, [v, w], keep) if where == "host" else (torch.from_numpy(k).cuda(), [torch.from_numpy(v).cuda(), torch.from_numpy(w).cuda()], torch.from_numpy(keep).cuda())
+    res = sa.groupby_run(args[0], args[1], _DT["int64"], keep=args[2])
+    want = _want(k[kept], [v[kept], w[kept]])
+    assert len(want["k"]) < len(np.unique(k))   # (some groups have no kept row)
+    _check(sa, res, want)
+    none = sa.groupby_run(args[0], args[1], _DT["int64"], keep=(np.zeros(n, dtype=np.uint8) if where == "host" else torch.zeros(n, dtype=torch.uint8, device="cuda")))
+    assert len(none) == 0
+
+
+def test_frame_groupby_with_a_selection_takes_the_fused_path(sa, gpu_ready):
+    """Frame.groupby(selection=): one selection shared by the whole call rides the fused pass as its keep-mask (device and host rows)"""
+    import torch
+    from vaex_amd import binned
+    rng = np.random.default_rng(9)
+    n = 1_500_000
+    k = (rng.integers(0, 200_000, n) * 2654435761) % (1 << 40)
+    v = rng.normal(3, 2, n); v[::313] = np.nan
+    x = rng.normal(0, 1, n)
+    for device in (False, True):
+        cols = dict(k=k, v=v, x=x)
+        if device:
+            cols = {c: torch.from_numpy(a).cuda() for c, a in cols.items()}
+        f = binned.Frame(cols, superagg=sa)
+        f.last_groupby_info = None
+        got = f.groupby("k", {"c": binned.agg.count(), "cv": binned.agg.count("v"), "s": binned.agg.sum("v"), "m": binned.agg.mean("v"), "sd": binned.agg.std("v")}, selection="(x > 0.25) & (x < 2)")
+        assert f.last_groupby_info is not None, "the fused pass did not run"
+        kept = (x > 0.25) & (x < 2)
+        want = _want(k[kept], [v[kept]])
+        np.testing.assert_array_equal(got["k"], want["k"]); np.testing.assert_array_equal(got["c"], want["rows"]); np.testing.assert_array_equal(got["cv"], want["v"][0]["cnt"])
+        assert np.all(np.abs(got["s"] - want["v"][0]["s"]) <= 1e-12 * want["v"][0]["sabs"])
+        with np.errstate(divide="ignore", invalid="ignore"):
+            mean = want["v"][0]["s"] / want["v"][0]["cnt"]
+        assert np.allclose(got["m"], mean, rtol=1e-11, atol=0, equal_nan=True)

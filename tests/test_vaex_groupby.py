@@ -134,6 +134,7 @@ for d, by, agg, kw in filtered:
     if kw.get("sort"):
         assert np.array_equal(np.ma.getdata(got[keys[0]].to_numpy()), np.ma.getdata(want[keys[0]].to_numpy())), (by, kw)
     print("ok-device-filtered", by, len(got), vg.last.get("kernel"))
+    assert by != "ks" or vg.last.get("kernel") == "gb_scatter+gb_reduce", vg.last   # (scattered keys: the fused hash aggregation with the filter as its keep-mask)
 vg.last.clear(); df[(df.k * 2) > 3].groupby("k", agg="count"); assert vg.last.get("path") == "vaex" and "filter outside" in vg.last["why"], vg.last
 vg.last.clear(); df.dropnan(column_names=["v"]).groupby("k", agg="count"); assert vg.last.get("path") == "vaex" and "filter outside" in vg.last["why"], vg.last
 # without agg: a GroupBy whose groupers are only built when something other than a device-servable .agg() is asked of it

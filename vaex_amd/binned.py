@@ -1018,8 +1018,9 @@ class Frame:
             return None
         key = self.columns[by]
         vcols = []
+        shared = descs[0].selection if descs else None   # ONE selection over the whole call (a filter): a keep-mask of the pass
         for d in descs:
-            if d.name not in ("count", "sum", "mean", "var", "std") or d.selection is not None:
+            if d.name not in ("count", "sum", "mean", "var", "std") or d.selection is not shared:
                 return None
             if d.column is not None and d.column not in vcols:
                 vcols.append(d.column)
@@ -1033,9 +1034,16 @@ class Frame:
             values.append(col if _is_device(col) else np.ascontiguousarray(col))
         if not values:  # only count(*): the pass still needs a payload column; let the general path do it
             return None
+        keep = None
+        if shared is not None:
+            keep = self._mask_array(shared)
+            if _is_device(keep) != _is_device(key):
+                return None
+            keep = keep if _is_device(keep) else np.ascontiguousarray(_as_u8(keep))
         res, failed = None, None
         try:
-            res = sa.groupby_run(key if _is_device(key) else np.ascontiguousarray(key), values, _DT_CODE[pf]) if self.n else None
+            res = (sa.groupby_run(key if _is_device(key) else np.ascontiguousarray(key), values, _DT_CODE[pf], keep=keep) if keep is not None else
+                   sa.groupby_run(key if _is_device(key) else np.ascontiguousarray(key), values, _DT_CODE[pf])) if self.n else None
         except RuntimeError as e:
             if not str(e).startswith("groupby"):   # (anything the pass itself reports: too many / too skewed keys, no room for its queues)
                 raise

@@ -848,8 +848,14 @@ PYBIND11_MODULE(superagg, m) {
     m.attr("GB_STD") = (int)VXH_GB_STD;
     // groupby_run(keys, [v0, v1], key_dtype, groups_hint=0, max_groups=0): keys any integer array (host or device), values
     // float64 arrays living where the keys live
-    m.def("groupby_run", [](const py::object &keys, const std::vector<py::object> &values, int key_dtype, uint64_t hint, uint64_t max_groups) {
+    m.def("groupby_run", [](const py::object &keys, const std::vector<py::object> &values, int key_dtype, uint64_t hint, uint64_t max_groups, const py::object &keep) {
         ArrayRef k = resolve_array(keys);
+        const uint8_t *keep_ptr = nullptr;
+        if (!keep.is_none()) { // uint8 keep-mask where the keys live (vxh_groupby_run_kept)
+            ArrayRef km = resolve_array(keep);
+            if (km.itemsize != 1 || km.mem != k.mem || km.n < k.n) throw std::runtime_error("groupby: the keep-mask must be one byte per row and live where the keys live");
+            keep_ptr = (const uint8_t *)km.ptr;
+        }
         if (key_dtype < 0 || key_dtype >= VXH_DTYPE_COUNT || k.itemsize != kTypeSizes[key_dtype]) throw std::runtime_error("Itemsize of the keys and key dtype are not equal");
         std::vector<const void *> vp;
         for (const auto &v : values) {
@@ -863,11 +869,11 @@ PYBIND11_MODULE(superagg, m) {
         int rc;
         {
             py::gil_scoped_release release;
-            rc = vxh_groupby_run(key_dtype, k.ptr, (int)vp.size(), vp.data(), k.n, k.mem, hint, max_groups, &res->h);
+            rc = vxh_groupby_run_kept(key_dtype, k.ptr, (int)vp.size(), vp.data(), keep_ptr, k.n, k.mem, hint, max_groups, &res->h);
         }
         check(rc);
         return res;
-    }, py::arg("keys"), py::arg("values"), py::arg("key_dtype") = (int)VXH_I64, py::arg("groups_hint") = 0, py::arg("max_groups") = 0);
+    }, py::arg("keys"), py::arg("values"), py::arg("key_dtype") = (int)VXH_I64, py::arg("groups_hint") = 0, py::arg("max_groups") = 0, py::arg("keep") = py::none());
     // groupby_merge(keys, rows, [count_j], [sum_j], [sum2_j]): partial results (host arrays) -> one result
     m.def("groupby_merge", [](py::array_t<int64_t, py::array::c_style | py::array::forcecast> keys, py::array_t<int64_t, py::array::c_style | py::array::forcecast> rows,
                               const std::vector<py::array_t<int64_t, py::array::c_style | py::array::forcecast>> &counts,

@@ -72,6 +72,7 @@ struct GbArgs {
     const void *keys;
     int32_t key_dtype, nv, w, merge; // w payload words per record; merge: payload = partial results (rows, count, sum, sum2 ...)
     const uint64_t *payload[GB_MAX_W]; // RAW: the value columns (float64 bits); MERGE: rows, count_0, sum_0, sum2_0, ...
+    const uint8_t *keep;               // RAW: one byte per row, 1 = the row takes part (a filter / selection over the whole call), or null
     uint64_t n;
     // Queues.  A BLOCK holds up to `blk` records of ONE bucket written by ONE workgroup.  Block wg * NB + b is workgroup
     // wg's primary block for bucket b — so everything a workgroup writes lies in one contiguous window of NB blocks
@@ -135,6 +136,7 @@ __global__ void __launch_bounds__(1024) gb_scatter(const GbArgs G) {
             const uint64_t i = tile * T + (uint64_t)r * 1024u + tid;
             v[r] = i < n;
             const uint64_t ic = v[r] ? i : n - 1;
+            if (G.keep) v[r] = v[r] && G.keep[ic] == 1; // (a row outside the filter leaves no record: a group without a row inside does not exist)
             k[r] = G.key_dtype == VXH_I64 ? ((const long long *)G.keys)[ic] : gb_load_key(G.keys, ic, G.key_dtype);
 #pragma unroll
             for (int w = 0; w < W; ++w) p[w][r] = G.payload[w][ic];
@@ -625,6 +627,10 @@ extern "C" {
     return 0;
 
 int vxh_groupby_run(int key_dtype, const void *keys, int n_values, const void *const *values, uint64_t n, int mem, uint64_t groups_hint, uint64_t max_groups, vxh_groupby **out) {
+    return vxh_groupby_run_kept(key_dtype, keys, n_values, values, nullptr, n, mem, groups_hint, max_groups, out);
+}
+
+int vxh_groupby_run_kept(int key_dtype, const void *keys, int n_values, const void *const *values, const uint8_t *keep, uint64_t n, int mem, uint64_t groups_hint, uint64_t max_groups, vxh_groupby **out) {
     GB_BEGIN
     if (key_dtype == VXH_F64 || key_dtype == VXH_F32 || key_dtype < 0 || key_dtype >= VXH_DTYPE_COUNT) throw std::runtime_error("groupby: integer key dtypes only");
     if (n_values < 1 || n_values > GB_MAX_NV) throw std::runtime_error("groupby: 1 or 2 float64 value columns");
@@ -645,9 +651,10 @@ int vxh_groupby_run(int key_dtype, const void *keys, int n_values, const void *c
     if (mem == VXH_MEM_DEVICE) {
         order_after_producers(slot);
         G.keys = keys;
+        G.keep = keep;
         for (int v = 0; v < n_values; v++) G.payload[v] = (const uint64_t *)values[v];
     } else {
-        S.stage.need(n * (ks + 8 * (size_t)n_values) + 256 * 3);
+        S.stage.need(n * (ks + 8 * (size_t)n_values + (keep ? 1 : 0)) + 256 * 4);
         char *p = (char *)S.stage.p;
         HIP_CHECK(hipMemcpyAsync(p, keys, n * ks, hipMemcpyHostToDevice, slot.stream));
         G.keys = p;
@@ -656,6 +663,10 @@ int vxh_groupby_run(int key_dtype, const void *keys, int n_values, const void *c
             HIP_CHECK(hipMemcpyAsync(p, values[v], n * 8, hipMemcpyHostToDevice, slot.stream));
             G.payload[v] = (const uint64_t *)p;
             p += (n * 8 + 255) & ~(size_t)255;
+        }
+        if (keep) {
+            HIP_CHECK(hipMemcpyAsync(p, keep, n, hipMemcpyHostToDevice, slot.stream));
+            G.keep = (const uint8_t *)p;
         }
     }
     if (max_groups == 0) max_groups = std::min<uint64_t>(n, 1ull << 26);
