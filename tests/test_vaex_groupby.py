@@ -161,6 +161,18 @@ part = df[1000:150_000]
 vg.last.clear()
 same(frame(part.groupby("k", agg={"s": A.sum("v"), "c": A.count()}), "k"), frame(original(part, "k", agg={"s": A.sum("v"), "c": A.count()}), "k"), "slice")
 print("ok-slice", vg.last.get("path"))
+# a failure the device path reports (HBM exhausted, a HIP error) does not kill the call: vaex's own groupby answers
+keep_frame_for = vg._frame_for
+def broken(df_, columns):
+    raise RuntimeError("HIP error 2 (out of memory) at vxh_api.hip:0")
+vg._frame_for = broken
+vg.last.clear()
+got = df.groupby("k", agg={"s": A.sum("v"), "c": A.count()}, sort=True)
+vg._frame_for = keep_frame_for
+assert vg.last.get("path") == "vaex" and "device groupby failed" in vg.last.get("why", ""), vg.last
+want = original(df, "k", agg={"s": A.sum("v"), "c": A.count()}, sort=True)
+same({c: got[c].to_numpy() for c in got.get_column_names()}, {c: want[c].to_numpy() for c in want.get_column_names()}, "device failure falls back")
+print("ok-device-failure-falls-back")
 print("DONE")
 '''
 
@@ -176,6 +188,7 @@ def _run(gpu, timeout):
 def test_groupby_host_logic_against_vaex_on_the_reference_cpp():
     out = _run(0, 600)
     assert "DONE" in out and out.count("ok-device ") == 8 and out.count("ok-device-filtered") == 4 and out.count("ok-declined") == 7, out
+    assert "ok-device-failure-falls-back" in out, out
 
 
 @pytest.mark.gpu

@@ -2467,18 +2467,20 @@ __global__ void __launch_bounds__(256) part_merge(const PartMergeArgs M) {
 }
 
 // K1f — fold the pass-1 workgroups' hot boxes into the grids (once per vxh_grid_bin call) and zero them again
-__global__ void __launch_bounds__(256) part_hot_merge(const HotMergeArgs M) {
-    // 64 cells per workgroup; the 4 waves each fold a quarter of the pass-1 blocks (coalesced 512-byte reads),
-    // LDS combines the quarters
-    __shared__ double s_sum[4][64], s_sum2[4][64];
-    __shared__ unsigned long long s_cnt[4][64];
+constexpr uint32_t kHotMergeWaves = 16;
+__global__ void __launch_bounds__(64 * kHotMergeWaves) part_hot_merge(const HotMergeArgs M) {
+    // 64 cells per workgroup; the 16 waves each fold a sixteenth of the pass-1 blocks (coalesced 512-byte reads: 256 blocks are
+    // 16 dependent trips per wave instead of 64 with four waves — the kernel moved its 146 MB at 1.8 TB/s), LDS combines the parts
+    constexpr uint32_t W = kHotMergeWaves;
+    __shared__ double s_sum[W][64], s_sum2[W][64];
+    __shared__ unsigned long long s_cnt[W][64];
     const uint32_t cells = M.w * M.h;
     const uint32_t lane = threadIdx.x & 63u, q = threadIdx.x >> 6;
     const uint32_t c = blockIdx.x * 64u + lane;
     double s = 0.0, s2 = 0.0;
     unsigned long long k = 0, si = 0; // (si: the box sums of an int64 value column)
     if (c < cells) {
-        for (uint32_t b = q; b < M.blocks; b += 4) {
+        for (uint32_t b = q; b < M.blocks; b += W) {
             const uint64_t i = (uint64_t)b * cells + c;
             if (M.sum_acc && M.val_i64) { si += ((unsigned long long *)M.sum_acc)[i]; M.sum_acc[i] = 0.0; }
             else if (M.sum_acc) { s += M.sum_acc[i]; M.sum_acc[i] = 0.0; }
@@ -2492,10 +2494,14 @@ __global__ void __launch_bounds__(256) part_hot_merge(const HotMergeArgs M) {
     s_cnt[q][lane] = k;
     __syncthreads();
     if (q != 0 || c >= cells) return;
-    s = (s_sum[0][lane] + s_sum[1][lane]) + (s_sum[2][lane] + s_sum[3][lane]);
-    if (M.val_i64) si = (unsigned long long)__double_as_longlong(s_sum[0][lane]) + (unsigned long long)__double_as_longlong(s_sum[1][lane]) + (unsigned long long)__double_as_longlong(s_sum[2][lane]) + (unsigned long long)__double_as_longlong(s_sum[3][lane]);
-    s2 = (s_sum2[0][lane] + s_sum2[1][lane]) + (s_sum2[2][lane] + s_sum2[3][lane]);
-    k = s_cnt[0][lane] + s_cnt[1][lane] + s_cnt[2][lane] + s_cnt[3][lane];
+    s = 0.0; s2 = 0.0; si = 0; k = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < W; ++w) {
+        s += s_sum[w][lane];
+        si += (unsigned long long)__double_as_longlong(s_sum[w][lane]); // (only read when val_i64: the parts are bit patterns then)
+        s2 += s_sum2[w][lane];
+        k += s_cnt[w][lane];
+    }
     if (k == 0) return;
     const uint64_t cell = (uint64_t)(M.x0 + c % M.w) + (uint64_t)(M.y0 + c / M.w) * M.stride_y;
     for (uint32_t a = 0; a < M.nagg; ++a) {
@@ -2786,7 +2792,7 @@ void vxh_launch_bin(const BinArgs &args, const LaunchPlan &plan, hipStream_t str
 
 void vxh_launch_hot_merge(const HotMergeArgs &args, hipStream_t stream) {
     const uint32_t cells = args.w * args.h;
-    hipLaunchKernelGGL(part_hot_merge, dim3((cells + 63) / 64), dim3(256), 0, stream, args);
+    hipLaunchKernelGGL(part_hot_merge, dim3((cells + 63) / 64), dim3(64 * kHotMergeWaves), 0, stream, args);
 }
 
 void vxh_launch_part_merge(const PartMergeArgs &args, hipStream_t stream) {

@@ -201,12 +201,17 @@ def fast_groupby(df, by, agg, sort=False, ascending=True, row_limit=None):
         for c in pred.columns:
             if c not in columns:
                 columns[c] = _real_column(df, c, tuple(k for k in vaex_filter._NUMERIC if k != "bool"), "filter column")[1]
-    frame = _frame_for(df, columns)
-    frame.last_groupby_info = None
     try:
+        frame = _frame_for(df, columns)
+        frame.last_groupby_info = None
         res = frame.groupby(key_names if len(key_names) > 1 else key_names[0], spec, selection=selection)
     except (NotImplementedError, ValueError) as e:
         raise _Decline(str(e))
+    except (RuntimeError, MemoryError) as e:
+        # a failure the device path reports (HBM exhausted by the device copies or the partition queues, a HIP error): vaex's own two
+        # passes answer — chunk by chunk, on the HIP classes where those still work — instead of the call dying here
+        drop_device_copies()
+        raise _Decline(f"device groupby failed: {type(e).__name__}: {str(e)[:200]}")
     descending = bool(srt[0]) and not asc[0]
     out = {}
     typed = {name: _key_column_like_vaex(np.asarray(res[name])) for name in key_names}
