@@ -176,6 +176,10 @@ def _run(gpu, timeout):
     env = dict(os.environ, VAEX_NUM_THREADS=os.environ.get("VAEX_NUM_THREADS", "4"))
     out = subprocess.run([sys.executable, "-c", SCRIPT % dict(pkg=PKG, fake=FAKE, root=ROOT, gpu=gpu)], cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout)
     assert out.returncode == 0, out.stdout[-4000:] + out.stderr[-6000:]
+    report = os.environ.get("VAEX_AMD_REPORT_DIR")   # (tools/r03b_check.sh: where every call's task parts ran, kept under profiles/)
+    if report and gpu:
+        with open(os.path.join(report, "differential_report.txt"), "w") as f:
+            f.write(out.stdout)
     return out.stdout
 
 

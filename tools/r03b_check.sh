@@ -4,8 +4,7 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/r03b; rm -rf $O; mkdir -p $O
 cd $R
-timeout 420 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 > $O/gpu_pytest_tail.txt
-timeout 200 python -m pytest tests/test_vaex_differential.py -m gpu -q -s 2>&1 | tail -150 > $O/differential.txt
+VAEX_AMD_REPORT_DIR=$O timeout 420 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 > $O/gpu_pytest_tail.txt
 cd /tmp; export TMPDIR=/tmp
 timeout 300 python $R/bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err
 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks -- python $R/bench.py --no-cpu --no-extra --no-configs > $O/bench_prof.json 2> $O/ks.log

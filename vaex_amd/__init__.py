@@ -134,6 +134,7 @@ def install(vaex_module=None, legacy=True, hash_sets=True, chunk_size="auto", gr
             from . import vaex_selection, vaex_filter
             import vaex.memory
             as_mask = bool(spec.get(vaex_filter.SPEC_KEY, False))   # a filtered frame's blocks arrive uncompacted (vaex_amd/vaex_filter.py)
+            named = spec.get(vaex_selection.SPEC_KEY)                # what the task's named selections stood for when scheduled
             # the executor checks the parts' memory_usage() against what its tracker saw (vaex/execution.py:413-414): aggregators a
             # failed HIP attempt built before it hit an unsupported one must not stay on the tracker's books
             tracker = getattr(vaex.memory.local, "agg", None)
@@ -142,7 +143,7 @@ def install(vaex_module=None, legacy=True, hash_sets=True, chunk_size="auto", gr
                 try:
                     part = base.decode.__func__(cls, encoding, spec, df, nthreads)
                     part.backend_used = "hip"
-                    vaex_selection.attach(part, "hip", superagg, nthreads, filter_as_mask=as_mask)
+                    vaex_selection.attach(part, "hip", superagg, nthreads, filter_as_mask=as_mask, named=named)
                     task_stats["hip"] += 1
                     return part
                 except (ValueError, TypeError, NotImplementedError) as e:
@@ -154,7 +155,7 @@ def install(vaex_module=None, legacy=True, hash_sets=True, chunk_size="auto", gr
             with backend.use("cpu"):
                 part = base.decode.__func__(cls, encoding, spec, df, nthreads)
                 part.backend_used = "cpu"
-                vaex_selection.attach(part, "cpu", superagg, nthreads, filter_as_mask=as_mask)
+                vaex_selection.attach(part, "cpu", superagg, nthreads, filter_as_mask=as_mask, named=named)
                 task_stats["cpu"] += 1
                 return part
 

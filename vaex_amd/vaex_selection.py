@@ -17,8 +17,17 @@ joined by & | ~) never becomes a host array:
   * a task that ends up on vaex's own C++ (an aggregator the HIP classes do not offer) evaluates the same predicate with numpy
     in `process` and passes the mask on — nothing is lost, only not accelerated.
 
-Named selections (df.select(...), selection=True / 'default'), selections with missing-value columns, and expressions outside
-the subset keep vaex's host evaluation untouched."""
+NAMED selections (df.select("x > 0"); df.count(selection=True) — vaex/dataframe.py:5041, the history of SelectionExpression /
+SelectionInvert objects per name, vaex/selections.py:40-160) are resolved to ONE boolean expression when the aggregation is
+scheduled — `replace` drops the history, `and` / `or` / `subtract` combine with the previous one, select_inverse negates — and
+take the same road when that expression is in the subset.  vaex looks a name up when the run starts; so does this: delayed
+aggregations enter their TaskAggregations in the executor's merge at the start of the run (vaex/execution.py:_merge ->
+add_aggregation_operation), which is where the name is resolved.  The resolved expression travels with the task (SPEC_KEY in
+its encoding) and the task part checks it against the frame once more when it is built — should the name mean something else by
+then, it raises instead of aggregating rows that are neither definition's.
+
+Selections with missing-value columns, lasso / dropna selections, `xor` histories and expressions outside the subset keep vaex's
+host evaluation untouched."""
 import numpy as np
 
 from . import predicate as _predicate
@@ -30,25 +39,75 @@ _WITH_DEVICE_SELECTION = ("AggCount", "AggSum", "AggSumMoment", "AggMin", "AggMa
 _NUMERIC = ("float64", "float32", "int64", "int32", "int16", "int8", "uint64", "uint32", "uint16", "uint8", "bool")
 
 
-def plan_for(df, descriptor):
-    """the Predicate an aggregation's selection compiles to, or None (then vaex evaluates the selection itself)"""
-    sel = getattr(descriptor, "selection", None)
-    if sel is None or sel is False or sel is True or isinstance(sel, (list, tuple)):
+SPEC_KEY = "hip-named-selections"   # {str(aggregation index): the expression its named selection stood for when scheduled}
+
+
+def _selection_as_expression(sel):
+    """a selection object's history as one boolean expression string, or None (vaex/selections.py:_select_functions)"""
+    if sel is None:
         return None
-    if getattr(descriptor, "name", None) not in _WITH_DEVICE_SELECTION:   # AggFirst / AggList / AggNUnique read host masks only
+    kind = type(sel).__name__
+    if kind == "SelectionInvert":
+        prev = _selection_as_expression(sel.previous_selection)
+        return None if prev is None else f"~({prev})"
+    if kind != "SelectionExpression":
         return None
-    sel = str(sel)
-    if df.has_selection(sel):   # a named selection (history, modes): vaex's business
+    cur = f"({sel.boolean_expression})"
+    if sel.previous_selection is None:   # (mode "replace" drops it in Selection.__init__; the first selection of a name has none)
+        return cur
+    prev = _selection_as_expression(sel.previous_selection)
+    if prev is None:
         return None
+    if sel.mode == "and":
+        return f"({prev}) & {cur}"
+    if sel.mode == "or":
+        return f"({prev}) | {cur}"
+    if sel.mode == "subtract":
+        return f"({prev}) & ~{cur}"
+    return None
+
+
+def named_expression(df, name):
+    """the boolean expression the named selection `name` stands for right now, or None"""
+    if not df.has_selection(name):
+        return None
+    return _selection_as_expression(df.get_selection(name))
+
+
+def _known_columns(df):
     known = {}
     for name, ar in df.columns.items():
         if isinstance(ar, np.ndarray) and not np.ma.isMaskedArray(ar) and ar.ndim == 1 and ar.dtype.isnative and ar.dtype.name in _NUMERIC:
             known[name] = ar
+    return known
+
+
+def plan_for(df, descriptor, resolved=None):
+    """the Predicate an aggregation's selection compiles to, or None (then vaex evaluates the selection itself).
+    resolved: for a NAMED selection the expression it stood for when the aggregation was scheduled ("" = it was not planned then);
+    None = resolve the name now"""
+    sel = getattr(descriptor, "selection", None)
+    if sel is None or sel is False or isinstance(sel, (list, tuple)):
+        return None
+    if getattr(descriptor, "name", None) not in _WITH_DEVICE_SELECTION:   # AggFirst / AggList / AggNUnique read host masks only
+        return None
+    sel = "default" if sel is True else str(sel)
+    if df.has_selection(sel):   # a named selection: its history as one expression
+        sel = named_expression(df, sel) if resolved is None else resolved
+        if not sel:
+            return None
     try:
-        pred = _predicate.compile_selection(sel, known)
+        pred = _predicate.compile_selection(sel, _known_columns(df))
     except _predicate.Unsupported:
         return None
     return pred
+
+
+def _is_named(df, descriptor):
+    sel = getattr(descriptor, "selection", None)
+    if sel is None or sel is False or isinstance(sel, (list, tuple)):
+        return False
+    return df.has_selection("default" if sel is True else str(sel))
 
 
 def _filter_columns(df, descriptors):
@@ -61,12 +120,13 @@ def _filter_columns(df, descriptors):
     return list(pred.columns) if pred is not None else []
 
 
-def extras_of(df, descriptors):
+def extras_of(df, descriptors, named):
     """[(aggregation index, Predicate)], and the predicate columns in first-seen order, the filter's last (= the tail of
-    task.expressions_all)"""
+    task.expressions_all).  named: {str(index): expression} of the aggregations whose NAMED selection was planned when they were
+    scheduled — a named selection outside it is never planned here, whatever the name means by now"""
     plans, extras = [], []
     for i, d in enumerate(descriptors):
-        p = plan_for(df, d)
+        p = plan_for(df, d, named.get(str(i), "") if _is_named(df, d) else None)
         if p is not None:
             plans.append((i, p))
             for c in p.columns:
@@ -88,10 +148,14 @@ def install(vaex_module, state):
         if tail:   # (they sit at the tail: take them off while vaex appends this aggregation's own expressions)
             del self.expressions_all[len(self.expressions_all) - len(tail):]
         task = original(self, aggregator_descriptor)
-        if plan_for(self.df, aggregator_descriptor) is not None:
+        named = self.__dict__.setdefault("_hip_named", {})
+        pred = plan_for(self.df, aggregator_descriptor)
+        if pred is not None:
             self.selections[-1] = None   # the executor evaluates nothing for this aggregation (vaex/execution.py:549)
             stats["planned"] += 1
-        _, tail = extras_of(self.df, self.aggregation_descriptions)   # (the same call the task part's decode makes)
+            if _is_named(self.df, aggregator_descriptor):
+                named[str(len(self.aggregation_descriptions) - 1)] = pred.expression
+        _, tail = extras_of(self.df, self.aggregation_descriptions, named)   # (the same call the task part's decode makes)
         self.__dict__["_hip_extras"] = tail
         if tail:
             self.expressions_all.extend(tail)
@@ -99,20 +163,38 @@ def install(vaex_module, state):
         return task
 
     cls.add_aggregation_operation = add_aggregation_operation
-    state["selection"] = (cls, original)
+    original_encode = cls.encode
+
+    def encode(self, encoding):
+        spec = original_encode(self, encoding)
+        if self.__dict__.get("_hip_named"):
+            spec[SPEC_KEY] = dict(self.__dict__["_hip_named"])
+        return spec
+
+    cls.encode = encode
+    state["selection"] = (cls, original, original_encode)
 
 
 def uninstall(vaex_module, state):
-    cls, original = state["selection"]
+    cls, original, original_encode = state["selection"]
     cls.add_aggregation_operation = original
+    cls.encode = original_encode
 
 
-def attach(part, backend_used, superagg, nthreads, filter_as_mask=False):
+def attach(part, backend_used, superagg, nthreads, filter_as_mask=False, named=None):
     """called by the task part's decode: remember the predicates, and (HIP classes) hand them to the aggregators.
     filter_as_mask: the run hands this part uncompacted blocks of a filtered frame (vaex_amd/vaex_filter.py) — where the filter is a
-    device predicate it joins the aggregators' Selection here (alone or AND-ed with the aggregation's own predicate)"""
+    device predicate it joins the aggregators' Selection here (alone or AND-ed with the aggregation's own predicate).
+    named: the task's SPEC_KEY entry — what its named selections stood for when they were scheduled"""
     from . import vaex_filter
-    plans, extras = extras_of(part.df, part.aggregation_descriptions)
+    named = dict(named or {})
+    for i, expr in named.items():
+        name = part.aggregation_descriptions[int(i)].selection
+        name = "default" if name is True else str(name)
+        if named_expression(part.df, name) != expr:
+            raise RuntimeError(f"selection {name!r} was re-defined after an aggregation over it was scheduled (it stood for {expr!r}): "
+                               "vaex_amd planned that definition for the device; execute delayed aggregations before changing a selection they use")
+    plans, extras = extras_of(part.df, part.aggregation_descriptions, named)
     part._hip_plans, part._hip_extras, part._hip_selections = plans, extras, []
     part._hip_filter_as_mask = bool(filter_as_mask)
     part._hip_filter_on_device = set()
@@ -148,7 +230,7 @@ def _attach_predicates(part, backend_used, superagg, nthreads, plans, extras, fp
         entry = dict(index=positions[i], pred=pred, sel=None)
         if backend_used == "hip":
             if fpred is not None:
-                both = fpred if pred is None else vaex_filter.combined_plan(part.df, str(desc.selection))
+                both = fpred if pred is None else vaex_filter.combined_plan(part.df, pred.expression)
                 if both is not None and all(c in extras for c in both.columns):
                     pred = entry["pred"] = both
                     part._hip_filter_on_device.add(i)
