@@ -90,7 +90,8 @@ hot["groupby_nunique_drop"] = lambda d: by_key(d.groupby("k", agg={"um": vaex.ag
                                                                     "u0": vaex.agg.nunique("im")}), "k", ["um", "ua", "u0"])
 # (dropmissing: the slots the reference appends per unselected row are uninitialised memory, src/agg_list.cpp:68-71)
 hot["groupby_list_sel"] = lambda d: (lambda g: [sorted(c) for c in g["l"].tolist()])(d.groupby("k", agg={"l": vaex.agg.list("i", selection="v > 5", dropmissing=True)}).sort("k"))
-# selections: comparison expressions run as device predicates (vaex_amd/vaex_selection.py); a named selection keeps vaex's host mask
+# selections: comparison expressions run as device predicates (vaex_amd/vaex_selection.py); so does a named selection whose history
+# resolves to one (tests/test_vaex_named_selection.py)
 hot["count_sel2"] = lambda d: d.count(binby=["x", "y"], limits=lim2, shape=16, selection="(x > 0) & (v < 3.5)")
 hot["sum_sel_int"] = lambda d: d.sum("v", binby="y", limits=[-4, 4], shape=8, selection="~(i >= 3) | (x < -1)")
 hot["f32_boundary"] = lambda d: d.count(binby="y", limits=[-4, 4], shape=4, selection="f4 <= 0.3")   # numpy compares in float32: float32(0.3) <= 0.3
@@ -98,7 +99,7 @@ def _named(d):
     d.select("v > 4")
     return d.count(binby="x", limits=[-4, 4], shape=8, selection=True)
 hot["named_sel"] = _named
-def _mixed(d):   # ONE task, four aggregations: a device predicate, a named selection (host mask), none, a list of selections (host masks)
+def _mixed(d):   # ONE task, five aggregations: a device predicate, a named selection (resolved: device too), none, a list of selections (host masks)
     d.select("v > 4")
     a = d.count(binby="x", limits=[-4, 4], shape=8, selection="(v > 3) & (y < 1)", delay=True)
     b = d.sum("v", binby="x", limits=[-4, 4], shape=8, selection=True, delay=True)
@@ -139,9 +140,9 @@ else:
         if whole:
             assert ("gb_scatter" in vg.last["kernel"]) == (name == "groupby_sparse") and ("part_scatter" in vg.last["kernel"] or "bin_" in vg.last["kernel"] or name == "groupby_sparse"), (name, vg.last)
         print("ok-backend hip", name, len(used), vg.last.get("kernel", ""))
-        if name in ("mean_sel", "count_sel2", "sum_sel_int", "f32_boundary", "mixed_selections"):
+        if name in ("mean_sel", "count_sel2", "sum_sel_int", "f32_boundary", "mixed_selections", "named_sel"):
             assert vsel.stats["device_chunks"] > seen_device, (name, vsel.stats)   # the predicate ran on the device
-        elif name in ("named_sel", "first_sel", "groupby_list_sel"):   # (a named selection; aggregators that read host masks only)
+        elif name in ("first_sel", "groupby_list_sel"):   # (aggregators that read host masks only)
             assert vsel.stats["device_chunks"] == seen_device, (name, vsel.stats)  # vaex's own mask
         seen_device = vsel.stats["device_chunks"]
 for name, fn in fallback.items():

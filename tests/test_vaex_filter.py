@@ -59,7 +59,7 @@ def calls(d):
     out["ordinal"] = d.count(binby=[d.k], limits=[-0.5, 8.5], shape=9)
     out["minmax_limits"] = d.mean(d.v, binby=[d.x], limits="minmax", shape=8)    # a minmax run (left pre-filtered) before the aggregation run
     d.select("v > 3.5")
-    out["named_selection"] = d.count(binby=[d.y], limits=[-4, 4], shape=16, selection=True)          # vaex's own (cached) selection mask
+    out["named_selection"] = d.count(binby=[d.y], limits=[-4, 4], shape=16, selection=True)          # a named selection: resolved to its expression, a device predicate next to the filter
     d.select_nothing()
     out["first"] = d.first(d.v, d.y, binby=[d.k], limits=[-0.5, 8.5], shape=9)   # AggFirst: the run stays pre-filtered
     g = d.groupby("k", agg={"c": "count", "s": vaex.agg.sum("v")}, sort=True)    # vaex's two passes (the distinct-key pass is pre-filtered)
