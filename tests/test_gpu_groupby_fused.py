@@ -133,16 +133,27 @@ def test_frame_groupby_takes_the_fused_path_and_falls_back(sa, gpu_ready):
     np.testing.assert_array_equal(got["n"], w["rows"])
     np.testing.assert_array_equal(got["c"], w["v"][0]["cnt"])
     assert np.all(np.abs(got["s"] - w["v"][0]["s"]) <= 1e-12 * w["v"][0]["sabs"])
-    # a heavy hitter (half of the rows on one key): too skewed for the partitioned pass -> ordered_set + BinnerHash, same answer
+    # a heavy hitter (half of the rows on one key): too skewed for the partitioned pass by itself — the key is found in a sample and
+    # peeled off (Frame._groupby_peeled), the rest takes the fused pass
     k2 = k.clone()
     k2[::2] = 12345678901
     df2 = Frame(dict(k=k2, v=v))
     df2.last_groupby_info = None
     got2 = df2.groupby("k", spec)
+    assert df2.last_groupby_info is not None and df2.last_groupby_info.get("heavy_keys") == 1 and df2.last_groupby_info["retries"] == 0, df2.last_groupby_info
     w2 = _want(k2.cpu().numpy(), [v.cpu().numpy()])
     np.testing.assert_array_equal(got2["k"], w2["k"])
+    np.testing.assert_array_equal(got2["n"], w2["rows"])
     np.testing.assert_array_equal(got2["c"], w2["v"][0]["cnt"])
     assert np.all(np.abs(got2["s"] - w2["v"][0]["s"]) <= 1e-12 * w2["v"][0]["sabs"])
+    # ... without the sample (host rows are not sampled; here: switched off) the skewed call still answers: ordered_set + BinnerHash
+    df3 = Frame(dict(k=k2, v=v))
+    df3.heavy_key_rows = 1 << 62
+    df3.last_groupby_info = None
+    got3 = df3.groupby("k", spec)
+    np.testing.assert_array_equal(got3["k"], w2["k"])
+    np.testing.assert_array_equal(got3["c"], w2["v"][0]["cnt"])
+    assert np.all(np.abs(got3["s"] - w2["v"][0]["s"]) <= 1e-12 * w2["v"][0]["sabs"])
     # min / max are outside the fused signature
     got3 = df.groupby("k", {"lo": agg.min("v"), "s": agg.sum("v")})
     np.testing.assert_array_equal(got3["k"], w["k"])
@@ -219,3 +230,50 @@ def test_frame_groupby_with_a_selection_takes_the_fused_path(sa, gpu_ready):
         with np.errstate(divide="ignore", invalid="ignore"):
             mean = want["v"][0]["s"] / want["v"][0]["cnt"]
         assert np.allclose(got["m"], mean, rtol=1e-11, atol=0, equal_nan=True)
+
+
+@pytest.mark.parametrize("flavour", ["zipf", "three_keys", "zipf_int32_selection"])
+def test_frame_groupby_peels_heavy_keys(sa, gpu_ready, flavour):
+    """skewed key columns (the head of a Zipf law, a handful of scattered keys, a default value) on the device: the heavy keys are found
+    in a sample and aggregated as a dense groupby over their ordinals, the rest takes the fused pass with those rows masked out — same
+    groups, counts bit-exact, sums to 1e-12 of sum|v|; with a selection whose mask holds values other than 1 (they do not keep)"""
+    import torch
+    from vaex_amd.binned import Frame, agg
+    rng = np.random.default_rng(21)
+    n = 5_000_000
+    if flavour == "three_keys":
+        k = rng.choice(np.array([-(1 << 45), 17, (1 << 50) + 3]), n, p=[0.6, 0.3, 0.1])
+    else:
+        z = rng.zipf(1.3, n)
+        k = (np.minimum(z, 400_000) * 2654435761) % (1 << 40)
+        if flavour == "zipf_int32_selection":
+            k = (k % (1 << 31)).astype(np.int32)
+    v = rng.normal(3, 2, n); v[::777] = np.nan
+    keep = None
+    if flavour == "zipf_int32_selection":
+        keep = (rng.random(n) < 0.6).astype(np.uint8)
+        keep[::500] = 3   # (not 1: the row is dropped)
+    cols = dict(k=torch.from_numpy(np.ascontiguousarray(k)).cuda(), v=torch.from_numpy(v).cuda())
+    if keep is not None:
+        cols["sel"] = torch.from_numpy(keep).cuda()
+    df = Frame(cols, superagg=sa)
+    df.last_groupby_info = None
+    spec = {"n": agg.count(), "c": agg.count("v"), "s": agg.sum("v"), "m": agg.mean("v"), "sd": agg.std("v")}
+    got = df.groupby("k", spec, selection="sel" if keep is not None else None)
+    info = df.last_groupby_info
+    assert info is not None and info.get("heavy_keys", 0) >= (3 if flavour == "three_keys" else 2) and info["retries"] == 0, info
+    kept = np.ones(n, dtype=bool) if keep is None else keep == 1
+    w = _want(k[kept], [v[kept]])
+    np.testing.assert_array_equal(np.asarray(got["k"]).astype(np.int64), w["k"])
+    np.testing.assert_array_equal(got["n"], w["rows"])
+    np.testing.assert_array_equal(got["c"], w["v"][0]["cnt"])
+    assert np.all(np.abs(got["s"] - w["v"][0]["s"]) <= 1e-12 * w["v"][0]["sabs"])
+    with np.errstate(divide="ignore", invalid="ignore"):
+        mean = w["v"][0]["s"] / w["v"][0]["cnt"]
+        var = w["v"][0]["s2"] / w["v"][0]["cnt"] - mean ** 2
+    assert np.allclose(got["m"], mean, rtol=1e-11, atol=0, equal_nan=True)
+    big = w["v"][0]["cnt"] > 100
+    assert np.allclose(np.asarray(got["sd"])[big] ** 2, var[big], rtol=1e-8, atol=0)
+    # the same call again: the heavy keys are remembered per column object
+    again = df.groupby("k", spec, selection="sel" if keep is not None else None)
+    np.testing.assert_array_equal(again["n"], got["n"])

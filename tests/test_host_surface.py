@@ -153,3 +153,26 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".cpp", ".hpp", ".h")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in src.replace("no CPU fallback", ""), os.path.join(dirpath, f)
+
+
+def test_heavy_key_sample_finds_the_head_of_a_zipf_law_and_nothing_in_uniform_keys():
+    """Frame._heavy_keys (host logic of the groupby's heavy-hitter peel): keys with >= 1/128 of a strided sample, ascending, remembered
+    per column object; uniform keys give None"""
+    import numpy as np
+    from vaex_amd.binned import Frame
+    rng = np.random.default_rng(1)
+    n = 3_000_000
+    z = rng.zipf(1.3, n)
+    k = (np.minimum(z, 400_000) * 2654435761) % (1 << 40)
+    f = Frame.__new__(Frame)
+    f.n = n
+    heavy = f._heavy_keys("k", k)
+    share = {key: float((k == key).mean()) for key in heavy}
+    assert heavy is not None and 8 <= len(heavy) <= 128 and np.all(np.diff(heavy) > 0)
+    assert all(s > 0.004 for s in share.values()), share                       # nothing light is called heavy
+    top = [(c * 2654435761) % (1 << 40) for c in (1, 2, 3, 400_000)]            # the head of the law, and the clipped "default" value
+    assert all(t in set(heavy.tolist()) for t in top)
+    assert f._heavy_keys("k", k) is heavy                                      # remembered per column object
+    g = Frame.__new__(Frame)
+    g.n = n
+    assert g._heavy_keys("k", (rng.integers(0, 1_000_000, n) * 2654435761) % (1 << 40)) is None

@@ -1040,6 +1040,26 @@ class Frame:
             if _is_device(keep) != _is_device(key):
                 return None
             keep = keep if _is_device(keep) else np.ascontiguousarray(_as_u8(keep))
+        # heavy hitters (a default / missing-value key, the head of a Zipf law): every row of ONE key lands in ONE bucket of the
+        # partitioned pass — the bucket's queue overflows its spare blocks from a ~25 % share on, and long before that its single
+        # reduce workgroup is the whole pass (a 1 % key of 1e9 rows: 7 ms on one CU).  A sample of the keys finds them; they are
+        # peeled off (`_groupby_peeled`): everything else takes the fused pass with the heavy rows masked out, the few heavy
+        # keys are a dense groupby over their ordinals.
+        if comm is None and self.n >= self.heavy_key_rows and pf in ("int64", "int32", "uint32", "int16", "uint16", "int8", "uint8"):
+            heavy = self._heavy_keys(by, key)
+            try:
+                import torch
+            except ImportError:   # (the peel keeps its row-wise intermediates in torch tensors)
+                heavy = None
+            if heavy is not None:
+                try:
+                    # (host rows: the pass would copy them to the device anyway — here once, for both parts)
+                    dev = lambda a: a if _is_device(a) else torch.from_numpy(np.ascontiguousarray(a)).cuda()
+                    peeled = self._groupby_peeled(by, pf, descs, names, vcols, dev(key), [dev(v) for v in values], None if keep is None else dev(keep), heavy)
+                except torch.cuda.OutOfMemoryError:   # (the ordinals are 8 more bytes per row: no room — the plain attempt below)
+                    peeled = None
+                if peeled is not None:
+                    return peeled
         res, failed = None, None
         try:
             res = (sa.groupby_run(key if _is_device(key) else np.ascontiguousarray(key), values, _DT_CODE[pf], keep=keep) if keep is not None else
@@ -1074,6 +1094,95 @@ class Frame:
                 out[name] = np.asarray(res.column(which[d.name], vcols.index(d.column)))
         self.last_groupby_info = res.info()
         return out
+
+    #: rows from which a device-resident key column is sampled for heavy hitters before the fused hash groupby
+    heavy_key_rows = 1 << 22
+    #: sampled share from which a key counts as heavy (1/128: at most 128 of them)
+    heavy_key_share = 1.0 / 128
+
+    def _heavy_keys(self, by, key):
+        """keys holding >= heavy_key_share of a strided sample of 2^17 rows of the key column (ascending int64 array), or None.
+        A heuristic: correctness never rests on it (a missed heavy key only costs time, a false one a little).  Remembered per
+        column object like the key range."""
+        cache = self.__dict__.setdefault("_heavy_cache", {})
+        hit = cache.get(by)
+        if hit is not None and hit[0] is key:
+            return hit[1]
+        m = 1 << 17
+        step = max(1, self.n // m)
+        if isinstance(key, np.ndarray):
+            uniq, cnt = np.unique(np.asarray(key[::step][:m]), return_counts=True)
+            hv = uniq[cnt >= max(8, int(min(m, len(key[::step])) * self.heavy_key_share))]
+        else:
+            try:
+                import torch
+            except ImportError:
+                return None
+            if not isinstance(key, torch.Tensor):
+                return None
+            sample = key[::step][:m]
+            uniq, cnt = torch.unique(sample, return_counts=True)
+            hv = uniq[cnt >= max(8, int(len(sample) * self.heavy_key_share))].cpu().numpy()
+        heavy = np.sort(hv.astype(np.int64)) if len(hv) else None
+        cache[by] = (key, heavy)
+        return heavy
+
+    def _groupby_peeled(self, by, pf, descs, names, vcols, key, values, keep, heavy):
+        """the fused hash groupby with the rows of the `heavy` keys taken out of it: a sealed device set of the heavy keys maps
+        every row to the key's ordinal or -1 (vxh_hashmap_map_ordinal: a table of <= 128 keys stays in the caches); rows with -1
+        take the partitioned pass (keep-mask), the others a dense groupby over the ordinals — <= 128 groups, LDS-resident, at the
+        rate of a binned count.  The two group sets are disjoint; the result is their union in ascending key order.
+        None: the light part is still too much for the partitioned pass (-> ordered_set + BinnerHash)."""
+        import torch
+        sa = self.sa
+        sealed = getattr(sa, "ordered_set_" + pf)(len(heavy))
+        sealed.set_keys(heavy)
+        ords_dev = sealed.map_ordinal_device(key)
+        ords = torch.as_tensor(ords_dev, device="cuda")          # int64: rank of the row's key among the heavy ones, -1 = not heavy
+        light = ords < 0
+        if keep is not None:   # (1 = keep, anything else drops the row: src/agg_count.cpp:50)
+            if not isinstance(keep, torch.Tensor):
+                keep = torch.as_tensor(keep, device="cuda")
+            light = light & ((keep.view(torch.uint8) if keep.dtype == torch.bool else keep) == 1)
+        light = light.to(torch.uint8)
+        try:
+            res = sa.groupby_run(key, values, _DT_CODE[pf], keep=light)
+        except RuntimeError as e:
+            if not str(e).startswith("groupby"):
+                raise
+            return None
+        which = {"sum": sa.GB_SUM, "mean": sa.GB_MEAN, "var": sa.GB_VAR, "std": sa.GB_STD}
+        out = {by: np.asarray(res.column(sa.GB_KEYS))}
+        for name, d in zip(names, descs):
+            if d.name == "count":
+                out[name] = np.asarray(res.column(sa.GB_ROWS) if d.column is None else res.column(sa.GB_COUNT, vcols.index(d.column)))
+            else:
+                out[name] = np.asarray(res.column(which[d.name], vcols.index(d.column)))
+        info = dict(res.info())
+        # the heavy keys: their ordinals are a dense key column
+        sub = {"__heavy__": ords}
+        for c, col in zip(vcols, values):
+            sub[c] = col
+        selection = None
+        if keep is not None:
+            sub["__keep__"] = keep
+            selection = "__keep__"
+        f = Frame(sub, chunk_size=self.chunk_size, nthreads=self.nthreads, superagg=sa)
+        f.heavy_key_rows = 1 << 62
+        hres = f.groupby("__heavy__", {n: agg._Desc(d.name, d.column, None) for n, d in zip(names, descs)}, selection=selection)
+        hk = np.asarray(hres.pop("__heavy__")).astype(np.int64)
+        inside = hk >= 0                                          # (the group of ordinal -1 is every light row: not a group)
+        hkeys = heavy[hk[inside]]
+        keys = np.concatenate([np.asarray(out[by]).astype(np.int64), hkeys])
+        order = np.argsort(keys, kind="stable")
+        merged = {by: keys[order].astype(np.asarray(out[by]).dtype, copy=False)}
+        for n in names:
+            a, b = np.asarray(out[n]), np.asarray(hres[n])[inside]
+            merged[n] = np.concatenate([a, b.astype(a.dtype, copy=False)])[order]
+        info.update(heavy_keys=int(len(heavy)), heavy_groups=int(inside.sum()))
+        self.last_groupby_info = info
+        del ords, ords_dev
+        return merged
 
     def _groupby_fused_allranks(self, res, nv, comm):
         """every rank's partial groups -> the groups of all ranks' rows: the partial columns {key, rows, count_j, sum_j, sum2_j}

@@ -425,6 +425,8 @@ int vxh_hashmap_map_ordinal(vxh_hashmap *m, const void *keys, uint64_t n, int me
     if (mem == VXH_MEM_HOST) {
         HIP_CHECK(hipMemcpyAsync(out, dout, n * 8, hipMemcpyDeviceToHost, s.stream));
         HIP_CHECK(hipStreamSynchronize(s.stream));
+    } else {
+        HIP_CHECK(hipStreamSynchronize(s.stream)); // (device ordinals: the caller may read them on any stream — torch's, another slot's)
     }
     HM_END
 }
