@@ -277,3 +277,37 @@ def test_frame_groupby_peels_heavy_keys(sa, gpu_ready, flavour):
     # the same call again: the heavy keys are remembered per column object
     again = df.groupby("k", spec, selection="sel" if keep is not None else None)
     np.testing.assert_array_equal(again["n"], got["n"])
+
+
+@pytest.mark.parametrize("where", ["device", "host"])
+def test_frame_groupby_peels_heavy_keys_of_a_dense_range(sa, gpu_ready, where):
+    """a dense key range too wide for one workgroup's LDS (the slab-partitioned pass) with a Zipf head and a default value: the heavy keys
+    are peeled off here too (Frame._groupby_dense_peeled) — min / max and an int32 value column included, with a predicate selection"""
+    import torch
+    from vaex_amd.binned import Frame, agg
+    rng = np.random.default_rng(22)
+    n = 4_500_000
+    k = np.minimum(rng.zipf(1.25, n), 300_000).astype(np.int64) - 1000
+    v = rng.normal(3, 2, n); v[::555] = np.nan
+    i = rng.integers(-1000, 1000, n).astype(np.int32)
+    x = rng.normal(0, 1, n)
+    cols = dict(k=k, v=v, i=i, x=x)
+    if where == "device":
+        cols = {c: torch.from_numpy(a).cuda() for c, a in cols.items()}
+    spec = {"n": agg.count(), "c": agg.count("v"), "s": agg.sum("v"), "m": agg.mean("v"), "sd": agg.std("v"), "lo": agg.min("v"), "hi": agg.max("i"), "si": agg.sum("i")}
+    for selection in (None, "x > -0.5"):
+        df = Frame(cols, superagg=sa)
+        df.last_groupby_info = None
+        got = df.groupby("k", spec, selection=selection)
+        assert df.last_groupby_info is not None and df.last_groupby_info.get("dense") == 1 and df.last_groupby_info["heavy_keys"] >= 2, df.last_groupby_info
+        plain = Frame(cols, superagg=sa)
+        plain.heavy_key_rows = 1 << 62
+        want = plain.groupby("k", spec, selection=selection)          # the same call without the peel
+        kept = np.ones(n, dtype=bool) if selection is None else x > -0.5
+        w = _want(k[kept], [v[kept]])
+        np.testing.assert_array_equal(got["k"], w["k"]); np.testing.assert_array_equal(got["n"], w["rows"]); np.testing.assert_array_equal(got["c"], w["v"][0]["cnt"])
+        assert np.all(np.abs(got["s"] - w["v"][0]["s"]) <= 1e-12 * w["v"][0]["sabs"])
+        for name in ("k", "n", "c", "lo", "hi", "si"):
+            np.testing.assert_array_equal(np.asarray(got[name]), np.asarray(want[name]), err_msg=name)
+            assert np.asarray(got[name]).dtype == np.asarray(want[name]).dtype, name
+        assert np.allclose(got["m"], want["m"], rtol=1e-11, atol=0, equal_nan=True) and np.allclose(got["sd"], want["sd"], rtol=1e-7, atol=1e-9, equal_nan=True)

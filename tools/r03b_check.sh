@@ -10,4 +10,5 @@ timeout 300 python $R/bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench
 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks -- python $R/bench.py --no-cpu --no-extra --no-configs > $O/bench_prof.json 2> $O/ks.log
 f=$(find $O/ks -name "*kernel_stats.csv" | head -1); python $R/tools/kstats.py "$f" 14 | grep -v "at::native\|rocclr" > $O/bench_kernel_stats.txt
 rm -rf $O/ks
-cat $O/gpu_pytest_tail.txt; cat $O/bench_kernel_stats.txt; cut -c1-600 $O/bench.json
+timeout 120 python $R/tools/r03_skew_groupby.py 2e8 2> /dev/null > $O/skew_groupby.txt
+cat $O/gpu_pytest_tail.txt; cat $O/bench_kernel_stats.txt; cat $O/skew_groupby.txt; cut -c1-600 $O/bench.json

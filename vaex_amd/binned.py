@@ -953,6 +953,13 @@ class Frame:
             kmin, kmax = comm.minmax(kmin, kmax)
         count = kmax - kmin + 1
         if 0 < count <= self.direct_groupby_cells:
+            if count > self.dense_peel_cells and comm is None and self.n >= self.heavy_key_rows and hasattr(sa, "groupby_run"):
+                # a key range wider than one CU's LDS bins through the slab-partitioned pass: every row of one key goes to one slab's
+                # queue — a heavy key overflows it (rows beyond its capacity are same-address device atomics) and is one workgroup's
+                # work in pass 2.  Same remedy as in front of the fused hash pass: the heavy keys are peeled off.
+                peeled = self._groupby_dense_peeled(by, pf, key, descs, names, (kmin, kmax))
+                if peeled is not None:
+                    return peeled
             # the key column bins itself (BinnerOrdinal with min_value): ONE pass, no hash map.  This is the
             # reference's dense-key simplification; for sparse keys in a small range it gives the same result
             # (empty cells are dropped below) without pass 1.
@@ -1100,6 +1107,40 @@ class Frame:
     #: sampled share from which a key counts as heavy (1/128: at most 128 of them)
     heavy_key_share = 1.0 / 128
 
+    #: dense key ranges wider than this many cells are checked for heavy keys too (narrower ones live in one workgroup's LDS)
+    dense_peel_cells = 1 << 14
+
+    def _groupby_dense_peeled(self, by, pf, key, descs, names, key_range):
+        """the dense (BinnerOrdinal) groupby with the heavy keys peeled off, or None (no heavy key, or a call outside the peel's
+        signature: aggregations other than count / sum / mean / var / std / min / max over plain columns, selections that differ)"""
+        if pf not in ("int64", "int32", "uint32", "int16", "uint16", "int8", "uint8") or not descs:
+            return None
+        shared = descs[0].selection
+        cols = []
+        for d in descs:
+            if d.name not in ("count", "sum", "mean", "var", "std", "min", "max") or d.selection is not shared:
+                return None
+            if d.column is not None and d.column not in cols:
+                if np.ma.isMaskedArray(self.columns[d.column]) or "_non_native" in _class_postfix(self.columns[d.column]):
+                    return None
+                cols.append(d.column)
+        heavy = self._heavy_keys(by, key)
+        if heavy is None:
+            return None
+        try:
+            import torch
+        except ImportError:
+            return None
+        try:
+            dev = lambda a: a if _is_device(a) else torch.from_numpy(np.ascontiguousarray(a)).cuda()
+            keep = None
+            if shared is not None:
+                keep = self._mask_array(shared)
+                keep = dev(keep if _is_device(keep) else _as_u8(keep))
+            return self._groupby_peeled(by, pf, descs, names, cols, dev(key), [dev(self.columns[c]) for c in cols], keep, heavy, dense_range=key_range)
+        except torch.cuda.OutOfMemoryError:
+            return None
+
     def _heavy_keys(self, by, key):
         """keys holding >= heavy_key_share of a strided sample of 2^17 rows of the key column (ascending int64 array), or None.
         A heuristic: correctness never rests on it (a missed heavy key only costs time, a false one a little).  Remembered per
@@ -1127,7 +1168,7 @@ class Frame:
         cache[by] = (key, heavy)
         return heavy
 
-    def _groupby_peeled(self, by, pf, descs, names, vcols, key, values, keep, heavy):
+    def _groupby_peeled(self, by, pf, descs, names, vcols, key, values, keep, heavy, dense_range=None):
         """the fused hash groupby with the rows of the `heavy` keys taken out of it: a sealed device set of the heavy keys maps
         every row to the key's ordinal or -1 (vxh_hashmap_map_ordinal: a table of <= 128 keys stays in the caches); rows with -1
         take the partitioned pass (keep-mask), the others a dense groupby over the ordinals — <= 128 groups, LDS-resident, at the
@@ -1145,20 +1186,30 @@ class Frame:
                 keep = torch.as_tensor(keep, device="cuda")
             light = light & ((keep.view(torch.uint8) if keep.dtype == torch.bool else keep) == 1)
         light = light.to(torch.uint8)
-        try:
-            res = sa.groupby_run(key, values, _DT_CODE[pf], keep=light)
-        except RuntimeError as e:
-            if not str(e).startswith("groupby"):
-                raise
-            return None
-        which = {"sum": sa.GB_SUM, "mean": sa.GB_MEAN, "var": sa.GB_VAR, "std": sa.GB_STD}
-        out = {by: np.asarray(res.column(sa.GB_KEYS))}
-        for name, d in zip(names, descs):
-            if d.name == "count":
-                out[name] = np.asarray(res.column(sa.GB_ROWS) if d.column is None else res.column(sa.GB_COUNT, vcols.index(d.column)))
-            else:
-                out[name] = np.asarray(res.column(which[d.name], vcols.index(d.column)))
-        info = dict(res.info())
+        plain = {n: agg._Desc(d.name, d.column, None) for n, d in zip(names, descs)}
+        if dense_range is not None:
+            # the light rows of a dense key range: the same dense groupby with the heavy rows masked out
+            fl = Frame({by: key, **dict(zip(vcols, values)), "__light__": light}, chunk_size=self.chunk_size, nthreads=self.nthreads, superagg=sa)
+            fl.heavy_key_rows = 1 << 62
+            fl.direct_groupby_cells = self.direct_groupby_cells
+            fl.__dict__["_key_range_cache"] = {by: (key, dense_range)}
+            out = fl.groupby(by, plain, selection="__light__")
+            info = {"dense": 1}
+        else:
+            try:
+                res = sa.groupby_run(key, values, _DT_CODE[pf], keep=light)
+            except RuntimeError as e:
+                if not str(e).startswith("groupby"):
+                    raise
+                return None
+            which = {"sum": sa.GB_SUM, "mean": sa.GB_MEAN, "var": sa.GB_VAR, "std": sa.GB_STD}
+            out = {by: np.asarray(res.column(sa.GB_KEYS))}
+            for name, d in zip(names, descs):
+                if d.name == "count":
+                    out[name] = np.asarray(res.column(sa.GB_ROWS) if d.column is None else res.column(sa.GB_COUNT, vcols.index(d.column)))
+                else:
+                    out[name] = np.asarray(res.column(which[d.name], vcols.index(d.column)))
+            info = dict(res.info())
         # the heavy keys: their ordinals are a dense key column
         sub = {"__heavy__": ords}
         for c, col in zip(vcols, values):
@@ -1169,7 +1220,16 @@ class Frame:
             selection = "__keep__"
         f = Frame(sub, chunk_size=self.chunk_size, nthreads=self.nthreads, superagg=sa)
         f.heavy_key_rows = 1 << 62
-        hres = f.groupby("__heavy__", {n: agg._Desc(d.name, d.column, None) for n, d in zip(names, descs)}, selection=selection)
+        # what the sub-frame would scan the rows for is known: the ordinals' range, and whether a value column holds NaN (as far as
+        # this frame has looked: the columns are the same objects)
+        f.__dict__["_key_range_cache"] = {"__heavy__": (ords, (-1, len(heavy) - 1))}
+        nan_seen = self.__dict__.get("_nan_cache", {})
+        f.__dict__["_nan_cache"] = {c: (col, nan_seen[c][1]) for c, col in zip(vcols, values) if c in nan_seen and nan_seen[c][0] is col}
+        hres = f.groupby("__heavy__", plain, selection=selection)
+        for c, col in zip(vcols, values):   # (what the sub-frame learnt about NaN in a column of this frame is this frame's to keep)
+            hit = f.__dict__.get("_nan_cache", {}).get(c)
+            if hit is not None and self.columns.get(c) is col:
+                self.__dict__.setdefault("_nan_cache", {})[c] = hit
         hk = np.asarray(hres.pop("__heavy__")).astype(np.int64)
         inside = hk >= 0                                          # (the group of ordinal -1 is every light row: not a group)
         hkeys = heavy[hk[inside]]

@@ -229,7 +229,8 @@ def fast_groupby(df, by, agg, sort=False, ascending=True, row_limit=None):
         v = np.asarray(res[out_name])
         out[out_name] = v[::-1] if descending else v
     last.clear()
-    kernel = "gb_scatter+gb_reduce" if frame.last_groupby_info else (frame.sa.last_kernel(0) if hasattr(frame.sa, "last_kernel") else "")
+    fused = frame.last_groupby_info and not frame.last_groupby_info.get("dense")   # (a dense range with its heavy keys peeled off leaves an info too)
+    kernel = "gb_scatter+gb_reduce" if fused else (frame.sa.last_kernel(0) if hasattr(frame.sa, "last_kernel") else "")
     last.update(path="device", kernel=kernel, info=frame.last_groupby_info, groups=len(next(iter(out.values()))))
     dataset_arrays = vaex.dataset.DatasetArrays(out)
     dataset = vaex.groupby.DatasetGroupby(dataset_arrays, df, by, agg, combine=combined, expand=True, sort=sort)
