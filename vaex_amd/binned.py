@@ -139,6 +139,10 @@ class agg:
 _KIND_CLASS = {"count": "AggCount_", "sum": "AggSum_", "summoment": "AggSumMoment_", "min": "AggMin_", "max": "AggMax_"}
 
 
+#: key dtypes the groupby's heavy-hitter peel handles (its row-wise intermediates are torch tensors: the dtypes torch computes with)
+_PEEL_KEY_KINDS = ("int64", "int32", "int16", "int8", "uint8")
+
+
 class Frame:
     def __init__(self, columns=None, chunk_size=1 << 20, nthreads=4, superagg=None, comm=None, **kw):
         """comm: a vaex_amd.dist.Comm when this Frame holds ONE RANK'S ROWS of a row-sharded table — every result is
@@ -1052,7 +1056,7 @@ class Frame:
         # reduce workgroup is the whole pass (a 1 % key of 1e9 rows: 7 ms on one CU).  A sample of the keys finds them; they are
         # peeled off (`_groupby_peeled`): everything else takes the fused pass with the heavy rows masked out, the few heavy
         # keys are a dense groupby over their ordinals.
-        if comm is None and self.n >= self.heavy_key_rows and pf in ("int64", "int32", "uint32", "int16", "uint16", "int8", "uint8"):
+        if comm is None and self.n >= self.heavy_key_rows and pf in _PEEL_KEY_KINDS:
             heavy = self._heavy_keys(by, key)
             try:
                 import torch
@@ -1113,7 +1117,7 @@ class Frame:
     def _groupby_dense_peeled(self, by, pf, key, descs, names, key_range):
         """the dense (BinnerOrdinal) groupby with the heavy keys peeled off, or None (no heavy key, or a call outside the peel's
         signature: aggregations other than count / sum / mean / var / std / min / max over plain columns, selections that differ)"""
-        if pf not in ("int64", "int32", "uint32", "int16", "uint16", "int8", "uint8") or not descs:
+        if pf not in _PEEL_KEY_KINDS or not descs:
             return None
         shared = descs[0].selection
         cols = []
@@ -1162,7 +1166,11 @@ class Frame:
             if not isinstance(key, torch.Tensor):
                 return None
             sample = key[::step][:m]
-            uniq, cnt = torch.unique(sample, return_counts=True)
+            try:
+                uniq, cnt = torch.unique(sample, return_counts=True)
+            except RuntimeError:   # (a dtype torch does not sort)
+                cache[by] = (key, None)
+                return None
             hv = uniq[cnt >= max(8, int(len(sample) * self.heavy_key_share))].cpu().numpy()
         heavy = np.sort(hv.astype(np.int64)) if len(hv) else None
         cache[by] = (key, heavy)
