@@ -1069,6 +1069,8 @@ class Frame:
                     peeled = self._groupby_peeled(by, pf, descs, names, vcols, dev(key), [dev(v) for v in values], None if keep is None else dev(keep), heavy)
                 except torch.cuda.OutOfMemoryError:   # (the ordinals are 8 more bytes per row: no room — the plain attempt below)
                     peeled = None
+                if not _is_device(key) or peeled is None:
+                    torch.cuda.empty_cache()   # (whole columns went through torch's allocator: the library's own hipMallocs need the room back)
                 if peeled is not None:
                     return peeled
         res, failed = None, None
@@ -1144,6 +1146,9 @@ class Frame:
             return self._groupby_peeled(by, pf, descs, names, cols, dev(key), [dev(self.columns[c]) for c in cols], keep, heavy, dense_range=key_range)
         except torch.cuda.OutOfMemoryError:
             return None
+        finally:
+            if not _is_device(key):
+                torch.cuda.empty_cache()   # (whole columns went through torch's allocator: the library's own hipMallocs need the room back)
 
     def _heavy_keys(self, by, key):
         """keys holding >= heavy_key_share of a strided sample of 2^17 rows of the key column (ascending int64 array), or None.
