@@ -311,3 +311,36 @@ def test_frame_groupby_peels_heavy_keys_of_a_dense_range(sa, gpu_ready, where):
             np.testing.assert_array_equal(np.asarray(got[name]), np.asarray(want[name]), err_msg=name)
             assert np.asarray(got[name]).dtype == np.asarray(want[name]).dtype, name
         assert np.allclose(got["m"], want["m"], rtol=1e-11, atol=0, equal_nan=True) and np.allclose(got["sd"], want["sd"], rtol=1e-7, atol=1e-9, equal_nan=True)
+
+
+def test_count_only_groupby_and_value_counts_take_the_fused_pass(sa, gpu_ready):
+    """`n: count` over scattered int64 keys (and value_counts of a float column: its bit patterns are such keys) has no value column
+    to carry through the partitioned pass: the key column lends its own 8 bytes as payload, only the row counts are read"""
+    import torch
+    from vaex_amd.binned import Frame, agg
+    rng = np.random.default_rng(31)
+    n = 3_000_000
+    k = (rng.integers(0, 400_000, n) * 2654435761) % (1 << 42) - (1 << 41)
+    x = rng.normal(0, 1, n).round(2); x[::501] = np.nan; x[::777] = -0.0
+    for device in (True, False):
+        cols = dict(k=k, x=x)
+        if device:
+            cols = {c: torch.from_numpy(a).cuda() for c, a in cols.items()}
+        df = Frame(cols, superagg=sa)
+        df.last_groupby_info = None
+        got = df.groupby("k", {"n": agg.count()})
+        assert df.last_groupby_info is not None, "the fused pass did not run"
+        uniq, cnt = np.unique(k, return_counts=True)
+        np.testing.assert_array_equal(got["k"], uniq); np.testing.assert_array_equal(got["n"], cnt)
+        sel = df.groupby("k", {"n": agg.count()}, selection="x > 0.5")
+        kept = x > 0.5
+        uniq2, cnt2 = np.unique(k[kept], return_counts=True)
+        np.testing.assert_array_equal(sel["k"], uniq2); np.testing.assert_array_equal(sel["n"], cnt2)
+        vals, counts = df.value_counts("x")
+        ok = x == x
+        bits, c3 = np.unique(x[ok].view(np.int64), return_counts=True)
+        want = dict(zip(bits.tolist(), c3.tolist()))
+        got_pairs = {int(np.float64(v).view(np.int64)): int(c) for v, c in zip(vals, counts) if v == v}
+        assert got_pairs == want
+        assert int(counts[[i for i, v in enumerate(vals) if v != v][0]]) == int((~ok).sum())
+        assert np.all(np.diff(counts) <= 0)

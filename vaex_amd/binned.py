@@ -1043,8 +1043,13 @@ class Frame:
             if np.ma.isMaskedArray(col) or str(col.dtype).replace("torch.", "") != "float64" or _is_device(col) != _is_device(key):
                 return None
             values.append(col if _is_device(col) else np.ascontiguousarray(col))
-        if not values:  # only count(*): the pass still needs a payload column; let the general path do it
-            return None
+        if not values:
+            # only count(*) (value_counts, `n: count`): the pass needs a payload word per record — an int64 key column lends its own
+            # 8 bytes (the pass's count / sum / sum2 of them are never read, only the row counts); other key widths: the general path
+            if pf != "int64":
+                return None
+            vcols = ["__payload__"]
+            values = [key if _is_device(key) else np.ascontiguousarray(key)]
         keep = None
         if shared is not None:
             keep = self._mask_array(shared)
