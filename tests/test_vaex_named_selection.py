@@ -98,6 +98,48 @@ assert vsel.named_expression(d, "default") is None
 d.select_nothing()
 assert vsel.named_expression(d, "default") is None
 
+# ... and against vaex's own evaluation of the name, over random histories (modes, inversions, undo / redo; <= 4 distinct comparisons so
+# that most of them stay inside the device subset): the rows the resolved predicate keeps are the rows vaex's host mask keeps
+from vaex_amd import predicate as vpred
+d = make()
+host = {c: d[c].to_numpy() for c in ("x", "y", "v", "i")}
+known = {c: host[c] for c in host}
+rng = np.random.default_rng(77)
+terms = ["x > 0.3", "y <= -0.2", "v >= 3.5", "i != 4", "x < 1.5", "i < 0"]
+checked = unsupported = 0
+for trial in range(60):
+    d.select_nothing()
+    pool = list(rng.choice(terms, 3, replace=False))
+    for step in range(int(rng.integers(1, 6))):
+        what = rng.random()
+        if what < 0.12 and d.has_selection():
+            d.select_inverse()
+        elif what < 0.2 and d.has_selection() and d.selection_can_undo():
+            d.selection_undo()
+        elif what < 0.25 and d.selection_can_redo():
+            d.selection_redo()
+        else:
+            e = str(rng.choice(pool))
+            if rng.random() < 0.3:
+                e = f"({e}) & ({rng.choice(pool)})"
+            d.select(e, mode=str(rng.choice(["replace", "and", "or", "subtract", "and", "or", "xor"])))
+    expr = vsel.named_expression(d, "default")
+    if expr is None:
+        unsupported += 1
+        continue
+    try:
+        pred = vpred.compile_selection(expr, known)
+    except vpred.Unsupported:
+        unsupported += 1
+        continue
+    mine = pred.numpy_mask(host)
+    theirs = d.count(binby="x", limits=L, shape=64, selection=True)
+    xs = host["x"][mine]
+    assert np.array_equal(theirs, np.histogram(xs[xs == xs], bins=64, range=L)[0]), (trial, expr)
+    checked += 1
+assert checked >= 30, (checked, unsupported)
+print("ok fuzz", checked, "histories resolved and equal to vaex's masks,", unsupported, "left to vaex", flush=True)
+
 if GPU:
     backend = vaex_amd.install()
 else:
