@@ -1,0 +1,79 @@
+"""Arrow-backed frames of the REAL vaex (what `vaex.open` gives for arrow / parquet files: pyarrow ChunkedArray columns,
+vaex/arrow/dataset.py) under vaex_amd.install(): aggregations run through the same task parts (vaex hands their chunks over as arrays),
+and since late round 3 a comparison over an arrow column WITHOUT nulls is planned as a device predicate like one over a numpy column
+(vaex_amd.predicate.plain_numeric_dtype) — selections, named selections and filters; columns with nulls keep vaex's host masks, the
+device groupby declines arrow key columns.  Here (no GPU) the HIP classes are switched off: every task part falls back to vaex's C++
+and the planned predicates are evaluated with numpy on the arrow chunks — the host logic, compared with plain vaex in the same process."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+VAEXPY = os.path.join(ROOT, "oracle", "_ref", "vaexpy")
+OVERLAY = os.path.join(ROOT, "oracle", "_ref", "overlay")
+FAKE = os.path.join(ROOT, "oracle", "fake")
+PKG = VAEXPY if os.path.isdir(os.path.join(VAEXPY, "vaex")) else OVERLAY
+
+SCRIPT = r'''
+import sys, numpy as np
+sys.path[:0] = [%(pkg)r, %(fake)r, %(root)r]
+import vaex, vaex_amd, pyarrow as pa
+from vaex_amd import vaex_selection as vsel, vaex_groupby as vg, vaex_filter as vf, predicate
+rng = np.random.default_rng(5)
+n = 150_000
+x = rng.normal(0, 1, n); v = rng.normal(3, 2, n); k = rng.integers(0, 20, n)
+tbl = pa.table({"x": pa.array(x), "v": pa.array(v, mask=rng.random(n) < 0.1), "k": pa.array(k), "b": pa.array(rng.random(n) < 0.4),
+                "f4": pa.array(rng.choice(np.array([0.1, 0.3, 0.5], dtype="f4"), n)), "i2": pa.array(rng.integers(-9, 9, n).astype("i2"))})
+# a table of several record batches: the executor's chunks cross batch borders
+tbl = pa.concat_tables([tbl.slice(0, 40_000), tbl.slice(40_000, 70_001), tbl.slice(110_001)])
+L = [-3, 3]
+def calls(d):
+    out = {}
+    out["count"] = d.count(binby="x", limits=L, shape=8)
+    out["mean_nulls"] = d.mean("v", binby="x", limits=L, shape=8)
+    out["sel"] = d.count(binby="x", limits=L, shape=8, selection="(x > 0) & (i2 != 3)")
+    out["sel_bool_f4"] = d.sum("x", binby="x", limits=L, shape=8, selection="(b == 1) & (f4 <= 0.3)")
+    out["sel_nulls"] = d.count(binby="x", limits=L, shape=8, selection="v > 3")            # a column with nulls: vaex's host mask
+    d.select("x < 0.5"); d.select("k >= 5", mode="and")
+    out["named"] = d.count(binby="x", limits=L, shape=8, selection=True)
+    d.select_nothing()
+    f = d[d.x > -1]
+    out["filt"] = f.sum("x", binby="x", limits=L, shape=8)
+    out["filt_sel"] = f.count(binby="x", limits=L, shape=8, selection="k < 10")
+    out["filt_nulls"] = d[d.v > 2].count(binby="x", limits=L, shape=8)                    # filter over a column with nulls: host mask
+    g = d.groupby("k", agg={"c": "count", "m": vaex.agg.mean("x")}, sort=True)
+    out["gb"] = np.array([g.k.to_numpy(), g.c.to_numpy(), g.m.to_numpy()], dtype="f8")
+    return out
+assert predicate.plain_numeric_dtype(tbl.column("x")) == np.dtype("f8") and predicate.plain_numeric_dtype(tbl.column("v")) is None
+assert predicate.plain_numeric_dtype(tbl.column("b")) == np.dtype("bool") and predicate.plain_numeric_dtype(tbl.column("i2")) == np.dtype("i2")
+assert predicate.plain_numeric_dtype(pa.chunked_array([pa.array(["a", "b"])])) is None and predicate.plain_numeric_dtype([1, 2]) is None
+want = calls(vaex.from_arrow_table(tbl))
+backend = vaex_amd.install(hash_sets=False, legacy=False)
+class _NoHip:
+    def __getattr__(self, name):
+        raise NotImplementedError("test: HIP classes switched off")
+backend.__dict__["_hip"] = _NoHip()
+got = calls(vaex.from_arrow_table(tbl))
+for key in want:
+    w, g = np.asarray(want[key], dtype="f8"), np.asarray(got[key], dtype="f8")
+    assert w.shape == g.shape and np.allclose(w, g, equal_nan=True, rtol=1e-12, atol=1e-9), key
+    if key not in ("mean_nulls", "sel_bool_f4", "filt", "gb"):
+        assert np.array_equal(w, g), key
+# the comparisons over null-free arrow columns were planned (selection x 2, the named one, the one next to the filter), the ones over `v` not
+assert vsel.stats["planned"] == 4 and vsel.stats["host_chunks"] > 0, vsel.stats
+assert vf.stats["runs_switched"] >= 3, vf.stats
+assert vg.stats["device"] == 0 and any("not a plain numpy column" in why for why in vg.stats["why"]), vg.stats
+print("ARROW OK", vsel.stats, vf.stats, vg.stats)
+'''
+
+
+def test_arrow_backed_frames_host_logic_on_vaex_cpp():
+    if not os.path.isdir(os.path.join(PKG, "vaex")):
+        pytest.skip("oracle/_ref/vaexpy not built (run __graft_entry__.build() where /root/reference exists)")
+    pytest.importorskip("pyarrow")
+    env = dict(os.environ, VAEX_NUM_THREADS=os.environ.get("VAEX_NUM_THREADS", "4"))
+    env.setdefault("VAEX_HOME", "/tmp/vaex_home_arrow")
+    r = subprocess.run([sys.executable, "-c", SCRIPT % dict(pkg=PKG, fake=FAKE, root=ROOT)], cwd="/tmp", capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0 and "ARROW OK" in r.stdout, (r.stdout[-3000:], r.stderr[-4000:])

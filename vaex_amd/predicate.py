@@ -39,6 +39,30 @@ def dtype_code(dtype):
     return _DTYPES.index(name)
 
 
+def plain_numeric_dtype(ar):
+    """numpy dtype of a column OBJECT when it is a real numeric column without missing values — a numpy array (1-d, native byte order,
+    not masked) or a pyarrow Array / ChunkedArray of a primitive numeric / bool type with null_count == 0 (what vaex holds for
+    arrow / parquet files: vaex/arrow/dataset.py) — else None.  Such a column's chunks reach the task part as arrays numpy views
+    without a copy (bool: unpacked), so a comparison over it can run as a device predicate."""
+    if isinstance(ar, np.ndarray):
+        if np.ma.isMaskedArray(ar) or ar.ndim != 1 or not ar.dtype.isnative or ar.dtype.name not in _DTYPES:
+            return None
+        return ar.dtype
+    if getattr(ar, "type", None) is None or not hasattr(ar, "null_count"):
+        return None
+    try:
+        import pyarrow as pa
+    except ImportError:
+        return None
+    if not isinstance(ar, (pa.Array, pa.ChunkedArray)) or ar.null_count != 0:
+        return None
+    try:
+        dt = np.dtype(ar.type.to_pandas_dtype())
+    except (TypeError, NotImplementedError, ValueError):
+        return None
+    return dt if dt.name in _DTYPES else None
+
+
 class Predicate:
     """columns: names; terms: (column index, op code, python int/float constant); truth: bit b = keep when term outcomes spell b"""
 

@@ -54,11 +54,7 @@ def filter_expression(df):
 
 
 def _known_columns(df):
-    known = {}
-    for name, ar in df.columns.items():
-        if isinstance(ar, np.ndarray) and not np.ma.isMaskedArray(ar) and ar.ndim == 1 and ar.dtype.isnative and ar.dtype.name in _NUMERIC:
-            known[name] = ar
-    return known
+    return {name: ar for name, ar in df.columns.items() if _predicate.plain_numeric_dtype(ar) is not None}
 
 
 def filter_plan(df):

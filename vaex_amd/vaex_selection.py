@@ -75,11 +75,8 @@ def named_expression(df, name):
 
 
 def _known_columns(df):
-    known = {}
-    for name, ar in df.columns.items():
-        if isinstance(ar, np.ndarray) and not np.ma.isMaskedArray(ar) and ar.ndim == 1 and ar.dtype.isnative and ar.dtype.name in _NUMERIC:
-            known[name] = ar
-    return known
+    """the frame's real numeric columns without missing values (numpy, or arrow without nulls): what a device predicate may compare"""
+    return {name: ar for name, ar in df.columns.items() if _predicate.plain_numeric_dtype(ar) is not None}
 
 
 def plan_for(df, descriptor, resolved=None):
@@ -212,7 +209,7 @@ def _attach_predicates(part, backend_used, superagg, nthreads, plans, extras, fp
     def selection_object(pred):
         key = pred.key()
         if key not in objs:
-            dtypes = [_predicate.dtype_code(part.df.columns[c].dtype) for c in pred.columns]
+            dtypes = [_predicate.dtype_code(_predicate.plain_numeric_dtype(part.df.columns[c])) for c in pred.columns]
             objs[key] = superagg.Selection(nthreads, dtypes, [(c, op, v) for c, op, v in pred.terms], pred.truth)
         return objs[key]
     # global index of an aggregation's (single) selection in the executor's `selections` list: one entry per aggregation
@@ -242,6 +239,18 @@ def _attach_predicates(part, backend_used, superagg, nthreads, plans, extras, fp
         part._hip_selections.append(entry)
 
 
+def _as_numpy(block):
+    """a predicate column's chunk as numpy: numpy chunks as they are, arrow chunks (no nulls: plain_numeric_dtype) through vaex's own
+    converter — a view of the arrow buffer for the primitive types, an unpacked copy for bool"""
+    if isinstance(block, np.ndarray):
+        return block
+    try:
+        import vaex.array_types
+        return np.asarray(vaex.array_types.to_numpy(block))
+    except ImportError:
+        return np.asarray(block)
+
+
 def before_process(part, thread_index, selection_masks, blocks):
     """-> (selection_masks, blocks) for the base class's process: the predicate columns' chunks go to the device selections
     (or, on vaex's own C++, become numpy masks); the blocks lose their tail"""
@@ -259,13 +268,13 @@ def before_process(part, thread_index, selection_masks, blocks):
             if id(entry["sel"]) not in seen:
                 seen.add(id(entry["sel"]))
                 for ci, c in enumerate(pred.columns):
-                    d = np.ascontiguousarray(np.asarray(tail[c]))
+                    d = np.ascontiguousarray(_as_numpy(tail[c]))
                     entry["sel"].set_data(thread_index, ci, d.view("u1") if d.dtype == np.bool_ else d)
                     part._hip_refs = getattr(part, "_hip_refs", {})
                     part._hip_refs[(thread_index, id(entry["sel"]), ci)] = d   # (borrowed until the slot's next chunk)
                 stats["device_chunks"] += 1
         else:
             selection_masks = list(selection_masks)
-            selection_masks[idx] = pred.numpy_mask({c: np.asarray(tail[c]) for c in pred.columns})
+            selection_masks[idx] = pred.numpy_mask({c: _as_numpy(tail[c]) for c in pred.columns})
             stats["host_chunks"] += 1
     return selection_masks, blocks[:nbase]
