@@ -105,7 +105,9 @@ def install(vaex_module=None, legacy=True, hash_sets=True, chunk_size="auto", gr
       the user changed it, so that every pool thread gets one chunk of rows / threads rows up to that size and nobody has to
       pass anything; an integer sets vaex.settings.main.chunk.size itself; None leaves vaex's chunking alone.
     * selections=True: selection expressions of the comparison subset (`column <op> number` joined by & | ~, <= 4 terms) are
-      evaluated on the device instead of numpy (vaex_amd/vaex_selection.py); everything else keeps vaex's host masks.
+      evaluated on the device instead of numpy (vaex_amd/vaex_selection.py) — given as an expression or as a NAMED selection whose
+      history (df.select modes, select_inverse, undo / redo) resolves to one, over numpy columns or arrow columns without nulls;
+      everything else keeps vaex's host masks.
     * filters=True (needs selections=True): binned aggregations over a FILTERED frame (df[df.x > 0]) get their chunks uncompacted and
       take the filter as a keep-mask — a device predicate where it compiles — instead of vaex copying every column through a boolean
       index per chunk (vaex_amd/vaex_filter.py); the device column cache then serves filtered frames too.
