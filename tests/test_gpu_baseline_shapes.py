@@ -455,7 +455,7 @@ def test_hashmap_unique_matches_numpy_on_random_chunks(sa):
     _check_dense_ordinals(hm, allk)
 
 
-@pytest.mark.parametrize("scenario", ["normal", "piled", "hidden_pile", "forced_flush"])
+@pytest.mark.parametrize("scenario", ["normal", "piled", "hidden_pile", "forced_flush", "queue_overflow", "pile_and_queue_overflow"])
 def test_hot_box_packed_counters_are_exact(sa, scenario):
     """round 3: the hot box next to the ring-less pass 1 keeps packed counters — uint16 (10-byte cells: 128x127 instead of 116x115 cells on
     the bench pass) or, where the sampled share of the fullest cell allows, uint8 (9-byte cells: 135x134) that the workgroup flushes
@@ -466,6 +466,11 @@ def test_hot_box_packed_counters_are_exact(sa, scenario):
       hidden_pile   1/8 of the rows in one cell, all of them BETWEEN the sampled segments: uint8 chosen, wraps -> uint16 holds
       forced_flush  a forced box with a flush every 2 trips of the tile loop (the periodic flush itself; a launch of this size would
                     otherwise end before the first one)
+      queue_overflow           (round 4) sub-queues forced tiny (`part_cap`): cold records that find their queue full take
+                    the slow path — device atomics straight into the grids, which a rerun could not take back.  Next to packed
+                    counters that path adds nothing and raises a flag; the call runs again with uint32 counters (one redo)
+      pile_and_queue_overflow  the hidden pile (uint8 wraps) AND tiny queues in one call: whichever flag comes first, no row is
+                    counted twice
     Every way the result is the uint32 box's and the oracle's."""
     import torch
     g = torch.Generator(device="cuda").manual_seed(5)
@@ -477,7 +482,7 @@ def test_hot_box_packed_counters_are_exact(sa, scenario):
         v = torch.randn(n, dtype=torch.float64, device="cuda", generator=g) * 2 + 3
         if piled:
             x[: n - n // 8] = 0.25; y[: n - n // 8] = -0.5   # 7/8 of the rows in one cell: 114688 per workgroup
-        if scenario == "hidden_pile":   # (the sample: 8 segments of 2^18 rows starting at multiples of n / 8)
+        if scenario in ("hidden_pile", "pile_and_queue_overflow"):   # (the sample: 8 segments of 2^18 rows starting at multiples of n / 8)
             i = torch.arange(n, device="cuda") % (n // 8)
             hidden = (i >= (1 << 20)) & (i < (1 << 20) + (1 << 19))
             x[hidden] = 0.25; y[hidden] = -0.5              # 1/8 of the rows: 16384 per workgroup in one cell
@@ -486,6 +491,9 @@ def test_hot_box_packed_counters_are_exact(sa, scenario):
         aggs = [sa.AggCount_int64(grid, 1, 1), sa.AggSum_float64(grid, 1, 1), sa.AggCount_float64(grid, 1, 1)]
         bx.set_data(0, x); by.set_data(0, y); aggs[1].set_data(0, v, 0); aggs[2].set_data(0, v, 0)
         forced = dict(hot_x0=66, hot_y0=67, hot_w=126, hot_h=125, hot_flush_trips=2) if scenario == "forced_flush" else {}
+        if "queue_overflow" in scenario:
+            forced = dict(part_cap=2048)   # records per sub-queue: a handful of the 4096 waves' first blocks fit
+        redo0 = sa.config_get("redo_count")
         for k, val in forced.items():
             sa.config_set(k, val)
         try:
@@ -494,9 +502,13 @@ def test_hot_box_packed_counters_are_exact(sa, scenario):
         finally:
             for k in forced:
                 sa.config_set(k, 0)
+        redone = sa.config_get("redo_count") - redo0
         got = [np.array(a.get_result()) for a in aggs]
         assert sa.last_kernel(0).startswith("part_scatter_direct_hot"), sa.last_kernel(0)
-        assert used == dict(normal=2, piled=0, hidden_pile=1, forced_flush=2)[scenario], used   # (what the call ENDED on)
+        assert used == dict(normal=2, piled=0, hidden_pile=1, forced_flush=2, queue_overflow=0, pile_and_queue_overflow=0)[scenario], used   # (what the call ENDED on)
+        assert redone == dict(normal=0, piled=1, hidden_pile=1, forced_flush=0, queue_overflow=1).get(scenario, redone), redone
+        if scenario == "pile_and_queue_overflow":
+            assert redone in (1, 2)
         if scenario == "forced_flush":
             assert trips == 2
         elif scenario == "normal":

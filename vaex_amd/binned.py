@@ -53,6 +53,19 @@ def _as_u8(mask):
     return m.view(np.uint8) if m.dtype == np.bool_ else m.astype(np.uint8)
 
 
+
+def _same_selection(a, b):
+    """two selection arguments name the same rows: None / False are 'no selection', strings compare by value (an equal but distinct
+    expression string must not drop a call to the slow path), anything else by identity"""
+    a = None if a is False else a
+    b = None if b is False else b
+    if a is None or b is None:
+        return a is None and b is None
+    if isinstance(a, str) and isinstance(b, str):
+        return a == b
+    return a is b
+
+
 class _Prim:
     """One native aggregation: (kind, column, selection, moment) — what AggregatorDescriptorBasic is to vaex."""
 
@@ -977,7 +990,7 @@ class Frame:
                 present_desc = agg.count(selection=selection)
                 if comm is None:
                     for d in descs:
-                        if d.column is not None and d.selection is selection and d.name in ("mean", "var", "std", "count") and not self._may_hold_nan(d.column):
+                        if d.column is not None and _same_selection(d.selection, selection) and d.name in ("mean", "var", "std", "count") and not self._may_hold_nan(d.column):
                             present_desc = agg.count(d.column, selection=selection)
                             break
                 specs, grid, aggs, want = self._pass(descs + [present_desc], binby, reduce=reduce)
@@ -1031,7 +1044,7 @@ class Frame:
         vcols = []
         shared = descs[0].selection if descs else None   # ONE selection over the whole call (a filter): a keep-mask of the pass
         for d in descs:
-            if d.name not in ("count", "sum", "mean", "var", "std") or d.selection is not shared:
+            if d.name not in ("count", "sum", "mean", "var", "std") or not _same_selection(d.selection, shared):
                 return None
             if d.column is not None and d.column not in vcols:
                 vcols.append(d.column)
@@ -1129,7 +1142,7 @@ class Frame:
         shared = descs[0].selection
         cols = []
         for d in descs:
-            if d.name not in ("count", "sum", "mean", "var", "std", "min", "max") or d.selection is not shared:
+            if d.name not in ("count", "sum", "mean", "var", "std", "min", "max") or not _same_selection(d.selection, shared):
                 return None
             if d.column is not None and d.column not in cols:
                 if np.ma.isMaskedArray(self.columns[d.column]) or "_non_native" in _class_postfix(self.columns[d.column]):

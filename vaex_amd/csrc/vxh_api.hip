@@ -1244,6 +1244,7 @@ static void run_part_chunk(Slot &slot, const BinArgs &planned, const LaunchPlan 
         P.qblk = (int32_t)B;
         // room for every wave's first block, for second blocks of a quarter of them (at least 8), capped by the rows
         P.cap = std::max<uint64_t>(P.cap, B * (waves_per_sub + std::max<uint64_t>(8, waves_per_sub / 4)));
+        if (c.cfg_part_cap > 0) P.cap = ((uint64_t)c.cfg_part_cap + B - 1) / B * B; // (tests: a queue that overflows)
         P.qtab_stride = (int32_t)(P.cap / B + 2);
         if (wg.direct == 2) { // one stream per (workgroup, slab): blocks of VXH_WV_SHARED_QB records, reserved half a block ahead
             uint64_t QB = VXH_WV_SHARED_QB;
@@ -1631,6 +1632,7 @@ int vxh_config_set(const char *key, int64_t value) {
     else if (k == "wv_waves") c.cfg_wv_waves = value > 0 ? value : 8;
     else if (k == "wv_waves_direct") c.cfg_wv_waves_direct = value > 0 ? value : 16;
     else if (k == "wv_block") c.cfg_wv_block = value;
+    else if (k == "part_cap") c.cfg_part_cap = value;
     else if (k == "hot_min_rows") c.cfg_hot_min_rows = value > 0 ? value : (1 << 24);
     else if (k == "hot_min_pct") c.cfg_hot_min_pct = value > 0 ? value : 10;
     else if (k == "hot_direct_pct") c.cfg_hot_direct_pct = value > 0 ? value : 62;
@@ -1678,6 +1680,8 @@ int vxh_config_get(const char *key, int64_t *value) {
     else if (k == "wv_waves_direct") *value = c.cfg_wv_waves_direct;
     else if (k == "hot_direct_pct") *value = c.cfg_hot_direct_pct;
     else if (k == "wv_block") *value = c.cfg_wv_block;
+    else if (k == "part_cap") *value = c.cfg_part_cap;
+    else if (k == "redo_count") *value = get_slot(0).redo_count;
     else if (k == "hot_min_rows") *value = c.cfg_hot_min_rows;
     else if (k == "hot_min_pct") *value = c.cfg_hot_min_pct;
     else if (k == "hot_cache") *value = c.cfg_hot_cache;
@@ -2069,14 +2073,18 @@ int vxh_grid_bin(vxh_grid *grid, int thread, vxh_agg *const *aggs, int n_aggs, u
             // packed box counters: every workgroup compared the sum of its counters with the hot rows it saw.  One that wrapped
             // (uint16: > 65535 rows of ONE workgroup in ONE cell; uint8: > 255 between two flushes — data far from what the sample said) raised the flag: nothing of this call has reached the
             // grids yet (the accumulators are merged below) — put the accumulators back and run the call again with the next wider counters.
+            // Records that found their sub-queue full next to packed counters were NOT added to the grids (wv_slow_record: what
+            // that path adds cannot be undone by a rerun) — they raised the second flag word, and the call runs again with uint32
+            // counters, where that path is allowed and nothing is rerun afterwards.
             part_join(slot);
-            unsigned int wrapped = 0;
-            HIP_CHECK(hipMemcpyAsync(&wrapped, slot.hot.flag, 4, hipMemcpyDeviceToHost, slot.stream));
+            unsigned int flags[2] = {0, 0}; // {a counter wrapped, a record needed the slow path}
+            HIP_CHECK(hipMemcpyAsync(flags, slot.hot.flag, 8, hipMemcpyDeviceToHost, slot.stream));
             HIP_CHECK(hipStreamSynchronize(slot.stream));
-            if (wrapped) {
+            if (flags[0] || flags[1]) {
                 slot.acc_sig = 0;
                 part_acc_prepare(slot, whole_args);
-                slot.hot.max_shift = slot.hot.cnt_shift - 1; // uint8 -> uint16 -> uint32
+                slot.hot.max_shift = flags[1] ? 0 : slot.hot.cnt_shift - 1; // uint8 -> uint16 -> uint32; slow path: uint32 at once
+                slot.redo_count++;
                 slot.hot.key_max_shift = std::min(slot.hot.key_max_shift, slot.hot.max_shift);
                 hot_prepare(slot, A, whole_args, whole, length);
                 slot.hot.max_shift = 2;

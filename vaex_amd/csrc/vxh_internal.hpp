@@ -133,6 +133,7 @@ struct Slot {
     } part[2];
     hipStream_t stream2 = nullptr;
     unsigned part_next = 0;
+    unsigned redo_count = 0; // vxh_grid_bin attempts that were thrown away and run again (packed box counters: a wrap, or a record that needed the slow path)
     void *qbtab = nullptr; // PartArgs::qbtab (shared-stream pass 1): entries are tagged with the launch's epoch, never cleared
     size_t qbtab_cap = 0;
     int32_t epoch = 0;
@@ -212,6 +213,7 @@ struct Context {
                                    // straight from the registers into per-(wave, slab) queue blocks, 4 = into per-(workgroup, slab) blocks (<= 16 slabs)
                                    // (profiles/r02_direct_ab.txt: 158 / 157 / 177 / 177 Grows/s on the bench pass)
     int64_t cfg_wv_block = 0;      // ... records per queue block of a (wave, slab) (0 = sized from the expected share); tests force tiny blocks
+    int64_t cfg_part_cap = 0;      // ... records per sub-queue (0 = sized from the expected share); tests force tiny queues to reach the slow path
     int64_t cfg_wv_waves_direct = 16; // ... waves per workgroup of the ring-less variant ("wv" = 3, next to a hot box)
     int64_t cfg_wv_waves = 8;      // ... waves per workgroup (one workgroup per CU); fewer when the rings would not fit
     int64_t cfg_hot = 1;           // hot box in pass 1 of the partition strategy (0 off)

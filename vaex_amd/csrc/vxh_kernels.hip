@@ -1627,6 +1627,13 @@ constexpr uint32_t VXH_WV_NONE = 0xffffffffu;
 // device atomics.  Lean on purpose — it is inlined at every flush site: the kernel's signature guarantees float64
 // (or absent) aggregator inputs and no per-aggregator masks, so only the five kinds on double / int64 cells remain.
 __device__ __forceinline__ void wv_slow_record(const PartArgs &P, uint64_t cell, double v) {
+    // Packed box counters (PartArgs::hot.cnt16): the host may run the whole call again when a counter wrapped, and what this path
+    // adds to the grids cannot be taken back.  So next to packed counters it adds nothing: it raises the second flag word and the
+    // host repeats the call with uint32 counters, where this path is allowed (vxh_grid_bin's attempt loop).
+    if (P.hot.on && P.hot.cnt16) {
+        __hip_atomic_store(P.hot.overflow + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
     if (P.val_i64) { // int64 value column: counts and int64 sums only (make_plan), `v` carries the integer's bits
         for (int k = 0; k < P.A.nagg; ++k) {
             const AggDesc &a = P.A.a[k];

@@ -193,6 +193,7 @@ def attach(part, backend_used, superagg, nthreads, filter_as_mask=False, named=N
                                "vaex_amd planned that definition for the device; execute delayed aggregations before changing a selection they use")
     plans, extras = extras_of(part.df, part.aggregation_descriptions, named)
     part._hip_plans, part._hip_extras, part._hip_selections = plans, extras, []
+    part._hip_refs = {}   # created ONCE, here: pool threads call process() of one part concurrently and must never rebind it
     part._hip_filter_as_mask = bool(filter_as_mask)
     part._hip_filter_on_device = set()
     fpred = vaex_filter.filter_plan(part.df) if (filter_as_mask and backend_used == "hip") else None
@@ -262,7 +263,11 @@ def before_process(part, thread_index, selection_masks, blocks):
     seen = set()
     for entry in part._hip_selections:
         pred, idx = entry["pred"], entry["index"]
-        if selection_masks[idx] is not None:   # (the executor evaluated it after all: use its mask)
+        if selection_masks[idx] is not None and entry["sel"] is not None:
+            # the task and this part disagree about the plan (the executor evaluated a selection the part handed to the device): the
+            # base class ignores host masks of this aggregation by now and the device Selection would read stale slot pointers
+            raise RuntimeError("vaex_amd: a host mask arrived for an aggregation whose selection was attached to the device")
+        if selection_masks[idx] is not None:   # (vaex's own C++: the executor evaluated it after all, use its mask)
             continue
         if entry["sel"] is not None:
             if id(entry["sel"]) not in seen:
@@ -270,8 +275,7 @@ def before_process(part, thread_index, selection_masks, blocks):
                 for ci, c in enumerate(pred.columns):
                     d = np.ascontiguousarray(_as_numpy(tail[c]))
                     entry["sel"].set_data(thread_index, ci, d.view("u1") if d.dtype == np.bool_ else d)
-                    part._hip_refs = getattr(part, "_hip_refs", {})
-                    part._hip_refs[(thread_index, id(entry["sel"]), ci)] = d   # (borrowed until the slot's next chunk)
+                    part._hip_refs[(thread_index, id(entry["sel"]), ci)] = d   # (borrowed until the slot's next chunk; distinct keys per thread)
                 stats["device_chunks"] += 1
         else:
             selection_masks = list(selection_masks)
