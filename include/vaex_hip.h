@@ -391,6 +391,10 @@ int vxh_groupby_info(const vxh_groupby *g, int what, double *value_out);
 /* HIP events on slot `thread`'s stream: record start/stop around vxh_grid_bin calls, read ms */
 int vxh_timer_start(int thread);
 int vxh_timer_stop(int thread, float *elapsed_ms_out);
+/* Stream time from vxh_timer_start to the end of the last KERNEL the calls in between enqueued on the slot's stream; what follows
+ * on the stream (result columns crossing PCIe) is in vxh_timer_stop's figure only.  Call after vxh_timer_stop.  (Measurement only:
+ * bench.py's `kernel_ms`; no counterpart in the reference.) */
+int vxh_timer_kernels_ms(int thread, float *elapsed_ms_out);
 
 #ifdef __cplusplus
 }

@@ -752,6 +752,7 @@ PYBIND11_MODULE(superagg, m) {
     m.def("slot_set_stream", [](int thread, uintptr_t stream) { check(vxh_slot_set_stream(thread, (void *)stream)); });
     m.def("timer_start", [](int thread) { check(vxh_timer_start(thread)); }, py::arg("thread") = 0);
     m.def("timer_stop", [](int thread) { float ms = 0; { py::gil_scoped_release r; check(vxh_timer_stop(thread, &ms)); } return ms; }, py::arg("thread") = 0);
+    m.def("timer_kernels_ms", [](int thread) { float ms = 0; { py::gil_scoped_release r; check(vxh_timer_kernels_ms(thread, &ms)); } return ms; }, py::arg("thread") = 0);
     m.def("minmax", [](const py::object &ar, const py::object &mask, int dtype, bool flip) {
         ArrayRef a = resolve_array(ar);
         if (a.itemsize != kTypeSizes[dtype]) throw std::runtime_error("Itemsize of data and dtype are not equal");

@@ -266,6 +266,7 @@ int vxh_finish(int n_out, const int *ops, vxh_agg *const *in0, vxh_agg *const *i
         }
         hipLaunchKernelGGL(fin_emit, dim3(nb), dim3(FIN_BLOCK), 0, slot.stream, F);
         HIP_CHECK(hipGetLastError());
+        vxh_timer_lap(slot);
         if (F.has_present) {
             unsigned int total = 0;
             HIP_CHECK(hipMemcpyAsync(&total, F.block_offset + nb, 4, hipMemcpyDeviceToHost, slot.stream));

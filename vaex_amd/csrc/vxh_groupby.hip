@@ -456,15 +456,17 @@ unsigned gb_grid(uint64_t n) {
 struct Dev {
     void *p = nullptr;
     size_t cap = 0;
+    // (from the library's block pool: a groupby result's columns are 40 MB per 1e6 groups, allocated per call — hipMalloc /
+    //  hipFree there were host-blocking gaps in the middle of the pipeline)
     void need(size_t bytes) {
         if (bytes <= cap) return;
-        if (p) (void)hipFree(p);
+        if (p) vxh_pool_free(p);
         p = nullptr;
         cap = 0;
-        HIP_CHECK(hipMalloc(&p, bytes));
+        p = vxh_pool_alloc(bytes);
         cap = bytes;
     }
-    ~Dev() { if (p) (void)hipFree(p); }
+    ~Dev() { if (p) vxh_pool_free(p); }
 };
 
 } // namespace
@@ -701,6 +703,7 @@ int vxh_groupby_run_kept(int key_dtype, const void *keys, int n_values, const vo
         HIP_CHECK(hipGetLastError());
     }
     HIP_CHECK(hipEventRecord(e1, slot.stream));
+    vxh_timer_lap(slot);
     HIP_CHECK(hipStreamSynchronize(slot.stream));
     (void)hipEventElapsedTime(&res->ms_sort, e0, e1);
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
@@ -807,7 +810,7 @@ int vxh_groupby_column(vxh_groupby *g, int value_index, int which, void *out_hos
             uint64_t *dst = (uint64_t *)g->tmp.p;
             hipLaunchKernelGGL(gb_derive, dim3(gb_grid(ng)), dim3(256), 0, slot.stream, cnt, sum, sum2, which, dst, ng);
             HIP_CHECK(hipGetLastError());
-            col = dst;
+            col = dst; // (no vxh_timer_lap: a few microseconds of kernel between result columns that are already crossing PCIe)
         } else throw std::runtime_error("groupby column: unknown column");
     }
     HIP_CHECK(hipMemcpyAsync(out_host, col, ng * 8, hipMemcpyDeviceToHost, slot.stream));

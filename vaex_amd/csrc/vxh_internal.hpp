@@ -70,6 +70,7 @@ struct vxh_agg {
     int replicas = 1;    // allocated
     int used = 1;        // replicas [0, used) may hold data; the rest are identity
     bool folded = true; // replicas 1.. hold only the identity
+    int init = 0;        // replicas [0, init) have been filled with the identity (the rest: on first use, vxh_grid_bin)
     int auth = AUTH_NONE;
     std::vector<unsigned char> mirror; // lazily allocated (grids, *shapes) host buffer
     std::mutex mutex;
@@ -123,6 +124,8 @@ struct Slot {
     hipStream_t copy_stream = nullptr;
     int cur = 0;
     hipEvent_t t0 = nullptr, t1 = nullptr;
+    hipEvent_t t_lap = nullptr; // recorded behind the last KERNEL of a call (before its results cross PCIe): vxh_timer_kernels_ms
+    bool lap_set = false;
     hipEvent_t after_null = nullptr; // order_after_producers()
     // partition strategy: two queue buffers so that pass 1 of chunk i+1 (on `stream`) overlaps pass 2 of chunk i (on `stream2`)
     struct PartBuf {
@@ -235,6 +238,15 @@ struct Context {
 
 Context &ctx();
 Slot &get_slot(int thread);
+// Device scratch that outlives a call's objects: aggregator grids, groupby results.  hipMalloc / hipFree are host-blocking
+// and cost 0.1-0.4 ms for the 100-256 MB a 1e6-cell aggregator used to ask for on EVERY df.groupby / df.count call (the
+// stream sat idle meanwhile: 1.2-1.6 ms per 1e9-row call); freed blocks are kept in size classes (bounded)
+// and handed out again.  The caller guarantees that nothing in flight still touches a block it frees.
+void *vxh_pool_alloc(size_t bytes);
+void vxh_pool_free(void *p);
+void vxh_pool_trim(void);
+// marks "the kernels of this call are all enqueued": what follows on the stream is result traffic (D2H)
+void vxh_timer_lap(Slot &slot);
 // Device-resident inputs (VXH_MEM_DEVICE) are usually produced by the caller's framework on the legacy default stream
 // (torch's default stream on ROCm): make the slot's (non-blocking) stream wait for everything enqueued there so far, so
 // that a kernel of this library never reads a column whose producer kernel is still running.  Callers that produce
