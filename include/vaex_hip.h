@@ -387,6 +387,25 @@ int vxh_groupby_column(vxh_groupby *g, int value_index, int which, void *out_hos
 /* diagnostics: 0 buckets, 1 LDS slots per bucket, 2 retries, 3 / 4 / 5 = ms of the scatter / reduce / sort kernels */
 int vxh_groupby_info(const vxh_groupby *g, int what, double *value_out);
 
+/* ---- multi-GPU reduce ------------------------------------------------------------------ */
+/* One process per GPU; rows are sharded, every rank bins its rows into private grids, and the ranks' grids are combined with
+ * ONE RCCL all-reduce per grid over xGMI (ncclSum on int64 / uint64 / fp64 cells, ncclMin / ncclMax for AggMin / AggMax) —
+ * the cross-rank form of Aggregator::merge (src/agg_count.cpp:15-23, agg_sum.cpp:72-79, agg_minmax.cpp:19-26), which the
+ * reference drives over its thread grids in TaskPartAggregation.reduce (vaex/cpu.py:788-796); SURVEY section 8b's
+ * `vxh_allreduce(aggs[], comm)`.  The host distributes rank 0's id by its own means (MPI, a socket, torch.distributed's store):
+ *   rank 0: vxh_comm_unique_id(id); everybody: vxh_comm_init(n_ranks, rank, id, &comm) after vxh_set_device(local GPU).
+ * vxh_allreduce folds the replicas and runs the collective on the library's slot-0 stream: stream-ordered with the binning
+ * before it and with everything enqueued after it, no host-side stop; afterwards every rank's aggregators hold the global grids
+ * (vxh_agg_result / get_result returns them). */
+typedef struct vxh_comm vxh_comm;
+#define VXH_COMM_ID_BYTES 128
+int vxh_comm_unique_id(char *id_out /* [VXH_COMM_ID_BYTES] */);
+int vxh_comm_init(int n_ranks, int rank, const char *id /* [VXH_COMM_ID_BYTES] */, vxh_comm **out);
+void vxh_comm_destroy(vxh_comm *comm);
+int vxh_comm_size(const vxh_comm *comm);
+int vxh_comm_rank(const vxh_comm *comm);
+int vxh_allreduce(vxh_agg *const *aggs, int n_aggs, vxh_comm *comm);
+
 /* ---- profiling helpers ---------------------------------------------------------------- */
 /* HIP events on slot `thread`'s stream: record start/stop around vxh_grid_bin calls, read ms */
 int vxh_timer_start(int thread);

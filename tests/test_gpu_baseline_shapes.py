@@ -506,8 +506,8 @@ def test_hot_box_packed_counters_are_exact(sa, scenario):
         got = [np.array(a.get_result()) for a in aggs]
         assert sa.last_kernel(0).startswith("part_scatter_direct_hot"), sa.last_kernel(0)
         assert used == dict(normal=2, piled=0, hidden_pile=1, forced_flush=2, queue_overflow=0, pile_and_queue_overflow=0)[scenario], used   # (what the call ENDED on)
-        assert redone == dict(normal=0, piled=1, hidden_pile=1, forced_flush=0, queue_overflow=1).get(scenario, redone), redone
-        if scenario == "pile_and_queue_overflow":
+        assert redone == dict(normal=0, hidden_pile=1, forced_flush=0, queue_overflow=1).get(scenario, redone), redone
+        if scenario in ("piled", "pile_and_queue_overflow"):   # (piled: uint8 -> uint16 -> uint32 when the sample lets uint8 start)
             assert redone in (1, 2)
         if scenario == "forced_flush":
             assert trips == 2

@@ -297,6 +297,50 @@ def test_rccl_allreduce_path_single_rank(sa):
             np.testing.assert_array_equal(np.array(a.get_result()), b)
         assert vdist.Comm().minmax(3, 9) == (3, 9)
     finally:
+        vdist._NATIVE.clear()
+        dist.destroy_process_group()
+
+
+def test_vxh_allreduce_native_world1(sa, monkeypatch):
+    """round 4: the C-ABI's own collective (vxh_comm_unique_id / vxh_comm_init / vxh_allreduce on RCCL directly) with one
+    rank: replicas folded and all-reduced in place on the library's stream — count / sum / moment (ncclSum on int64 / fp64),
+    min / max (ncclMin / ncclMax, float32 cells included), twice in a row, with binning in between (stream order, no host stop);
+    results unchanged.  No torch.distributed anywhere."""
+    comm = sa.Comm(1, 0, sa.comm_unique_id())
+    assert (comm.size, comm.rank) == (1, 0)
+    c = cases.gaussian_columns(400_000, seed=21)
+    v32 = c["v"].astype("f4")
+    case = dict(n=400_000, binners=[dict(kind="scalar", data=c["x"], vmin=-4, vmax=4, bins=64), dict(kind="scalar", data=c["y"], vmin=-4, vmax=4, bins=64)],
+                aggs=[dict(kind="count"), dict(kind="sum", data=c["v"]), dict(kind="summoment", data=c["v"], moment=2), dict(kind="min", data=c["v"]),
+                      dict(kind="max", data=v32), dict(kind="count", data=c["v"])])
+    keep = []
+    before = cases.run_superagg(sa, case, keep=keep, to_device=cases.torch_device_array)
+    aggs = keep[:-1]
+    comm.allreduce(aggs)
+    comm.allreduce(aggs[:2])
+    for b, a in zip(before, aggs):
+        np.testing.assert_array_equal(np.array(a.get_result()), b)
+    # the torch path (round 3) still answers the same when asked for
+    import os
+    import socket
+    import torch
+    import torch.distributed as dist
+    from vaex_amd import dist as vdist
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        monkeypatch.setenv("VAEX_AMD_TORCH_ALLREDUCE", "1")
+        assert vdist.native_comm() is None
+        vdist.allreduce_aggs(aggs[:3], force=True)
+        monkeypatch.delenv("VAEX_AMD_TORCH_ALLREDUCE")
+        assert vdist.native_comm() is not None
+        vdist.allreduce_aggs(aggs[:3], force=True)
+        for b, a in zip(before[:3], aggs[:3]):
+            np.testing.assert_array_equal(np.array(a.get_result()), b)
+    finally:
+        vdist._NATIVE.clear()
         dist.destroy_process_group()
 
 

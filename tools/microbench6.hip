@@ -22,6 +22,9 @@
 //           when bit 11 of the 100 MHz wall clock (s_memrealtime) flips, i.e. every wave of the chip writes in the same ~1 us window
 //           every 20 us and only reads in between: does the memory side like its writes in bursts?
 //   MODE 17 as 16 with an 82 us period (bit 13); MODE 18 as 17 with non-temporal stores; MODE 19 as 16 with a 328 us period (bit 15)
+//   MODE 20 (round 4) compacted: four times per tile lanes 0..5 store six NEIGHBOURING 12-byte records of the wave's ONE stream
+//           straight from the registers (positions from a ballot / mbcnt, no LDS ring, no flush); MODE 21 with non-temporal stores;
+//           MODE 22 once per tile lanes 0..23 store 24 neighbouring records
 // Lanes that have no record store to the sink (every lane executes every store, as in the production kernel).
 // Build: hipcc --offload-arch=gfx950 -O3 -o tools/microbench6 tools/microbench6.hip ; run: tools/microbench6 [rows]
 #include <hip/hip_runtime.h>
@@ -78,6 +81,19 @@ __global__ void __launch_bounds__(1024) pass(const Args A) {
         const uint32_t local = (raw.b[0][0][0] ^ t) & 0x1fffu;
         if (MODE == 0) return;
         if (MODE == 7) { store12(sink, local, bits); return; }
+        if (MODE >= 20 && MODE <= 22) {
+            // round 4: COMPACTED records straight from the registers into ONE stream per wave — what a ballot / mbcnt position
+            // gives: a row-step's cold rows (6 of 64 lanes) are neighbouring records of the wave's stream, no LDS ring, no flush
+            constexpr uint32_t steps = MODE == 22 ? 1u : 4u, per = 24u / steps;
+#pragma unroll
+            for (uint32_t r = 0; r < steps; ++r) {
+                const uint64_t dst = lane < per ? sbase + filled + lane : sink;
+                if (MODE == 21) __builtin_nontemporal_store(u32x3_a4{(uint32_t)bits, (uint32_t)(bits >> 32), local + r}, (u32x3_a4 *)(A.q12 + dst * 3));
+                else store12(dst, local + r, bits);
+                filled += per;
+            }
+            return;
+        }
         if (MODE == 1 || MODE == 2 || MODE == 3) {
             const bool live = lane < 24u;
             // MODE 1: lane -> stream lane % 8, record (lane / 8) of the tile's three; MODE 2/3: stream lane / 3, record lane % 3
@@ -159,13 +175,14 @@ __global__ void __launch_bounds__(1024) pass(const Args A) {
 
 int main(int argc, char **argv) {
     const uint64_t n = argc > 1 ? (uint64_t)atof(argv[1]) : 1000000000ull;
+    const bool only_new = argc > 2; // a second argument: the round-4 modes next to their references (0, 1, 7, 10, 11)
     int dev_cus = 256;
     hipDeviceProp_t prop;
     CK(hipGetDeviceProperties(&prop, 0));
     dev_cus = prop.multiProcessorCount;
     const uint32_t wgs = dev_cus, waves = wgs * 16;
     const uint64_t tiles_per_wave = (n / 256 + waves - 1) / waves + 2;
-    const uint64_t cap = (tiles_per_wave * 3 + 128 + 63) / 64 * 64 * (argc > 2 ? 1 : 1);   // records per (wave, stream); MODE 10+: the wave's eight regions are used as one
+    const uint64_t cap = (tiles_per_wave * 3 + 128 + 63) / 64 * 64 * 1;   // records per (wave, stream); MODE 10+: the wave's eight regions are used as one
     const uint64_t recs = (uint64_t)waves * 8 * cap + (uint64_t)waves * 16 + 64;
     Args A{};
     A.n = n;
@@ -181,12 +198,14 @@ int main(int argc, char **argv) {
     printf("rows %.3g, %u workgroups x 16 waves, %.2f GB of 12-byte records per pass (9.4 %% of the rows)\n", (double)n, wgs, (double)n * 24 / 256 * 12 / 1e9);
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    const char *names[20] = {"read loop alone", "scattered dwordx3 (production)", "sorted by stream, runs of 3, dwordx3", "sorted, runs of 3, SoA 8+2 bytes",
+    const char *names[23] = {"read loop alone", "scattered dwordx3 (production)", "sorted by stream, runs of 3, dwordx3", "sorted, runs of 3, SoA 8+2 bytes",
                             "staged: 64 per flush, runs of 8, dwordx3", "staged: 64 per flush, runs of 8, SoA", "staged: 64 per flush, one stream, SoA", "every lane to the sink",
                             "one stream per flush, half the records", "one stream per flush, aligned whole lines", "aligned, ONE stream per wave", "... non-temporal stores", "... ordinary loads", "... stream rewritten in place (64 records)", "... stream wraps: 63 MB of queue in all", "... stream wraps: 16 MB of queue in all",
-                            "time-phased: all waves flush every 20 us", "time-phased: every 82 us", "time-phased: every 82 us, non-temporal", "time-phased: every 328 us"};
+                            "time-phased: all waves flush every 20 us", "time-phased: every 82 us", "time-phased: every 82 us, non-temporal", "time-phased: every 328 us",
+                            "compacted from registers, one stream, 4 x 6 records", "... non-temporal", "... 1 x 24 records per tile"};
     for (int rep = 0; rep < 2; ++rep)
-        for (int mode = 0; mode < 20; ++mode) {
+        for (int mode = 0; mode < 23; ++mode) {
+            if (only_new && !(mode == 0 || mode == 1 || mode == 7 || mode == 10 || mode == 11 || mode >= 20)) continue;
             float best = 1e9f;
             for (int it = 0; it < 4; ++it) {
                 CK(hipEventRecord(e0));
@@ -210,7 +229,10 @@ int main(int argc, char **argv) {
                 case 16: hipLaunchKernelGGL(pass<16>, dim3(wgs), dim3(1024), 0, 0, A); break;
                 case 17: hipLaunchKernelGGL(pass<17>, dim3(wgs), dim3(1024), 0, 0, A); break;
                 case 18: hipLaunchKernelGGL(pass<18>, dim3(wgs), dim3(1024), 0, 0, A); break;
-                default: hipLaunchKernelGGL(pass<19>, dim3(wgs), dim3(1024), 0, 0, A); break;
+                case 19: hipLaunchKernelGGL(pass<19>, dim3(wgs), dim3(1024), 0, 0, A); break;
+                case 20: hipLaunchKernelGGL(pass<20>, dim3(wgs), dim3(1024), 0, 0, A); break;
+                case 21: hipLaunchKernelGGL(pass<21>, dim3(wgs), dim3(1024), 0, 0, A); break;
+                default: hipLaunchKernelGGL(pass<22>, dim3(wgs), dim3(1024), 0, 0, A); break;
                 }
                 CK(hipEventRecord(e1));
                 CK(hipEventSynchronize(e1));

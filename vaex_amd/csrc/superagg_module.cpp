@@ -426,7 +426,19 @@ struct PyAgg {
         for (auto s : str) strides.push_back((ssize_t)s * isz);
         const std::string fmt = kNumpyFormats[gdt];
         py::dtype np_dtype{fmt};
-        py::array out(np_dtype, shape, strides);
+        // Page-locked memory from the library's host block cache for anything beyond a few pages: a device-to-host copy into
+        // pageable memory is staged by the runtime (18 MB of a 128^3 count grid: 1.17 ms against 0.33 ms; the 0.5 MB grids of the
+        // bench pass: ~60 us against ~15 us each).  The array owns the block and gives it back to the cache when it dies.
+        const size_t bytes = (size_t)vxh_grid_length1d(grid->h) * (size_t)isz;
+        py::array out;
+        if (bytes >= (64u << 10)) {
+            void *p = nullptr;
+            check(vxh_host_alloc(bytes, &p));
+            py::capsule owner(p, [](void *q) { vxh_host_free(q); });
+            out = py::array(np_dtype, shape, strides, p, owner);
+        } else {
+            out = py::array(np_dtype, shape, strides);
+        }
         int rc;
         {
             py::gil_scoped_release release;
@@ -948,6 +960,41 @@ PYBIND11_MODULE(superagg, m) {
     m.attr("CMP_LT") = (int)VXH_CMP_LT; m.attr("CMP_LE") = (int)VXH_CMP_LE; m.attr("CMP_GT") = (int)VXH_CMP_GT;
     m.attr("CMP_GE") = (int)VXH_CMP_GE; m.attr("CMP_EQ") = (int)VXH_CMP_EQ; m.attr("CMP_NE") = (int)VXH_CMP_NE;
     py::class_<PyAgg> aggregator(m, "Aggregator", py::buffer_protocol());
+    // multi-GPU reduce on RCCL directly (vxh_comm_*, vxh_allreduce): Comm(n_ranks, rank, id) with rank 0's comm_unique_id()
+    struct PyComm {
+        vxh_comm *h = nullptr;
+        ~PyComm() { vxh_comm_destroy(h); }
+    };
+    m.def("comm_unique_id", []() {
+        char id[VXH_COMM_ID_BYTES];
+        check(vxh_comm_unique_id(id));
+        return py::bytes(id, VXH_COMM_ID_BYTES);
+    });
+    py::class_<PyComm>(m, "Comm")
+        .def(py::init([](int n_ranks, int rank, const py::bytes &id) {
+            const std::string raw = id;
+            if (raw.size() != VXH_COMM_ID_BYTES) throw std::runtime_error("Comm: the id is comm_unique_id()'s 128 bytes");
+            auto c = std::make_unique<PyComm>();
+            int rc;
+            {
+                py::gil_scoped_release release; // (blocks until every rank has called it)
+                rc = vxh_comm_init(n_ranks, rank, raw.data(), &c->h);
+            }
+            check(rc);
+            return c;
+        }), py::arg("n_ranks"), py::arg("rank"), py::arg("id"))
+        .def_property_readonly("size", [](const PyComm &c) { return vxh_comm_size(c.h); })
+        .def_property_readonly("rank", [](const PyComm &c) { return vxh_comm_rank(c.h); })
+        .def("allreduce", [](PyComm &c, const std::vector<PyAgg *> &aggs) {
+            std::vector<vxh_agg *> hs;
+            for (auto *a : aggs) hs.push_back(a->h);
+            int rc;
+            {
+                py::gil_scoped_release release;
+                rc = vxh_allreduce(hs.data(), (int)hs.size(), c.h);
+            }
+            check(rc);
+        });
     aggregator.def("merge", &PyAgg::merge)
         .def("get_result", &PyAgg::get_result)
         .def("__sizeof__", &PyAgg::bytes_used)

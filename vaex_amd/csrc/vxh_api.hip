@@ -16,6 +16,7 @@
 #include <vector>
 #include <string.h>
 #include <rocprim/rocprim.hpp>
+#include <rccl/rccl.h>
 
 #include "vxh_internal.hpp"
 
@@ -1957,6 +1958,7 @@ int vxh_grid_bin(vxh_grid *grid, int thread, vxh_agg *const *aggs, int n_aggs, u
     if (n_aggs <= 0 || length == 0) return 0;
     Slot &slot = get_slot(thread);
     const int ndim = (int)grid->binners.size();
+    if (thread != 0 && ctx().reduced_set) HIP_CHECK(hipStreamWaitEvent(slot.stream, ctx().reduced, 0)); // (vxh_allreduce runs on slot 0's stream)
 
     // validate slots and sizes (the reference reads out of bounds instead; we refuse)
     size_t stage_bytes = 0, sel_bytes = 0;
@@ -2931,6 +2933,105 @@ int vxh_minmax_int(int dtype, int flip_endian, const void *data, const uint8_t *
     minmax_driver<long long>(dtype, data, mask, n, mem, init, (long long *)out2, [&](const void *d, const uint8_t *m, uint64_t rn, long long *o, hipStream_t st) {
         vxh_launch_minmax_int(dtype, flip_endian ? 1 : 0, d, m, rn, o, st);
     });
+    VXH_API_END
+}
+
+// ------------------------------------------------------------------------------------------
+// multi-GPU: the cross-rank form of Aggregator::merge (src/agg_count.cpp:15-23, agg_sum.cpp:72-79, agg_minmax.cpp:19-26;
+// driven by TaskPartAggregation.reduce, vaex/cpu.py:788-796) — ONE RCCL all-reduce per grid over xGMI, on the library's own
+// stream: fold of the replicas, collective and whatever the ranks enqueue next are stream-ordered, nothing waits on the host
+// ------------------------------------------------------------------------------------------
+struct vxh_comm {
+    ncclComm_t comm = nullptr;
+    int n = 1, rank = 0;
+};
+#define NCCL_CHECKED(call)                                                                                             \
+    do {                                                                                                               \
+        ncclResult_t r_ = (call);                                                                                      \
+        if (r_ != ncclSuccess) throw std::runtime_error(std::string("RCCL: ") + ncclGetErrorString(r_) + " in " #call); \
+    } while (0)
+
+int vxh_comm_unique_id(char *id_out) {
+    VXH_API_BEGIN
+    ncclUniqueId id;
+    NCCL_CHECKED(ncclGetUniqueId(&id));
+    static_assert(sizeof(id.internal) == VXH_COMM_ID_BYTES, "RCCL unique id size");
+    memcpy(id_out, id.internal, VXH_COMM_ID_BYTES);
+    VXH_API_END
+}
+
+int vxh_comm_init(int n_ranks, int rank, const char *id, vxh_comm **out) {
+    VXH_API_BEGIN
+    if (n_ranks < 1 || rank < 0 || rank >= n_ranks) throw std::runtime_error("vxh_comm_init: rank outside [0, n_ranks)");
+    ensure_device_ready();
+    std::unique_ptr<vxh_comm> c(new vxh_comm());
+    c->n = n_ranks;
+    c->rank = rank;
+    ncclUniqueId u;
+    memcpy(u.internal, id, VXH_COMM_ID_BYTES);
+    NCCL_CHECKED(ncclCommInitRank(&c->comm, n_ranks, u, rank)); // (on the device vxh_set_device chose: one process per GPU)
+    *out = c.release();
+    VXH_API_END
+}
+
+void vxh_comm_destroy(vxh_comm *c) {
+    if (!c) return;
+    (void)hipDeviceSynchronize();
+    if (c->comm) (void)ncclCommDestroy(c->comm);
+    delete c;
+}
+int vxh_comm_size(const vxh_comm *c) { return c->n; }
+int vxh_comm_rank(const vxh_comm *c) { return c->rank; }
+
+int vxh_allreduce(vxh_agg *const *aggs, int n_aggs, vxh_comm *comm) {
+    VXH_API_BEGIN
+    if (!comm || !comm->comm) throw std::runtime_error("vxh_allreduce: no communicator");
+    if (n_aggs <= 0) return 0;
+    ensure_device_ready();
+    Context &c = ctx();
+    Slot &s0 = get_slot(0);
+    // every slot's stream has produced its share of the grids before the fold: slot 0's stream waits for the others (events, no host stop)
+    for (int t = 1; t < VXH_MAX_SLOTS; t++) {
+        Slot *s = nullptr;
+        {
+            std::lock_guard<std::mutex> lock(c.mutex);
+            s = c.slots[t];
+        }
+        if (!s) continue;
+        HIP_CHECK(hipEventRecord(s->after_null, s->stream));
+        HIP_CHECK(hipStreamWaitEvent(s0.stream, s->after_null, 0));
+    }
+    for (int k = 0; k < n_aggs; k++) {
+        vxh_agg *a = aggs[k];
+        std::lock_guard<std::mutex> lock(a->mutex);
+        agg_ensure_device_locked(a);
+        if (!a->folded) {
+            vxh_launch_fold(a->dev, a->grid->length1d, a->used, a->cell, a->kind, &a->identity, s0.stream);
+            HIP_CHECK(hipGetLastError());
+            a->folded = true;
+            a->used = 1;
+        }
+    }
+    NCCL_CHECKED(ncclGroupStart());
+    for (int k = 0; k < n_aggs; k++) {
+        vxh_agg *a = aggs[k];
+        static const ncclDataType_t cell2nccl[] = {ncclInt64, ncclFloat64, ncclUint64, ncclFloat32, ncclInt32, ncclUint32};
+        const ncclRedOp_t op = a->kind == VXH_AGG_MIN ? ncclMin : (a->kind == VXH_AGG_MAX ? ncclMax : ncclSum);
+        NCCL_CHECKED(ncclAllReduce(a->dev, a->dev, (size_t)a->grid->length1d, cell2nccl[a->cell], op, comm->comm, s0.stream));
+    }
+    NCCL_CHECKED(ncclGroupEnd());
+    for (int k = 0; k < n_aggs; k++) {
+        std::lock_guard<std::mutex> lock(aggs[k]->mutex);
+        aggs[k]->auth = AUTH_DEVICE;
+    }
+    // whoever bins into these grids next from another slot's stream waits for the collective (vxh_grid_bin)
+    {
+        std::lock_guard<std::mutex> lock(c.mutex);
+        if (!c.reduced) HIP_CHECK(hipEventCreateWithFlags(&c.reduced, hipEventDisableTiming));
+    }
+    HIP_CHECK(hipEventRecord(c.reduced, s0.stream));
+    c.reduced_set = true;
+    vxh_timer_lap(s0);
     VXH_API_END
 }
 

@@ -195,6 +195,8 @@ struct Context {
     int cus = 256;
     size_t max_lds = 65536;
     Slot *slots[VXH_MAX_SLOTS] = {};
+    hipEvent_t reduced = nullptr; // recorded on slot 0's stream behind the latest vxh_allreduce
+    bool reduced_set = false;
     // tuning knobs (vxh_config_set)
     int64_t cfg_strategy = VXH_STRAT_AUTO;
     int64_t cfg_replicas = 0; // 0 = auto

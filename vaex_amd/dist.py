@@ -36,7 +36,9 @@ def allreduce_aggs(aggs, group=None, force=False):
     the CPU tests): the grids go through the aggregators' host buffers.  After the call every rank's
     aggregators hold the global result (get_result() returns it).
 
-    Stream hand-off (the grids belong to the library's streams, RCCL runs on torch's): asking an aggregator for its
+    Default on GPUs: the library's own RCCL communicator (`native_comm`, vxh_allreduce) — everything below about streams
+    describes the torch path that VAEX_AMD_TORCH_ALLREDUCE=1 selects.
+    Stream hand-off there (the grids belong to the library's streams, RCCL runs on torch's): asking an aggregator for its
     `__cuda_array_interface__` is vxh_agg_device_grid — it DRAINS the device (hipDeviceSynchronize), folds the replicas on
     the library's stream and waits for that fold before it returns (vxh_api.hip agg_fold_device), so the pointer RCCL gets
     is final and nothing of the library is in flight.  On the way back every all-reduce is waited for and the device
@@ -48,6 +50,12 @@ def allreduce_aggs(aggs, group=None, force=False):
         return
     if dist.get_backend(group) != "nccl" or not all(hasattr(a, "device_touch") for a in aggs):
         return allreduce_aggs_host(aggs, group)
+    native = native_comm(group)
+    if native is not None:
+        # the library's own collective (vxh_allreduce, RCCL directly): fold + all-reduce on ITS stream, stream-ordered with the
+        # binning before and whatever follows — no hand-off to torch's stream, no host-side stop
+        native.allreduce(list(aggs))
+        return
     works = []
     tensors = []
     for agg in aggs:
@@ -61,6 +69,31 @@ def allreduce_aggs(aggs, group=None, force=False):
     torch.cuda.synchronize()
     for agg in aggs:
         agg.device_touch()
+
+
+_NATIVE = {}
+
+
+def native_comm(group=None):
+    """the library's RCCL communicator (vaex_amd.superagg.Comm = vxh_comm_init) over the ranks of `group`, created on first
+    use: rank 0's unique id travels through torch.distributed's object broadcast (any transport would do — a non-Python host
+    of libvaexhip.so uses its own).  None when the extension has no Comm or VAEX_AMD_TORCH_ALLREDUCE=1 asks for torch's
+    collectives (the round-3 path, kept for A/B runs)."""
+    import os
+    import torch.distributed as dist
+    if os.environ.get("VAEX_AMD_TORCH_ALLREDUCE") == "1":
+        return None
+    from . import superagg as sa
+    if not hasattr(sa, "Comm"):
+        return None
+    key = id(group) if group is not None else 0
+    if key not in _NATIVE:
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        box = [sa.comm_unique_id() if rank == 0 else None]
+        if world > 1:
+            dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        _NATIVE[key] = sa.Comm(world, rank, box[0])
+    return _NATIVE[key]
 
 
 def allreduce_aggs_host(aggs, group=None, reduce_arrays=None):
