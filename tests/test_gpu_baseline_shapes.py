@@ -496,10 +496,12 @@ def test_hot_box_packed_counters_are_exact(sa, scenario):
         redo0 = sa.config_get("redo_count")
         for k, val in forced.items():
             sa.config_set(k, val)
+        sa.config_set("hot_cache", 0)   # a fresh sample: torch hands the next scenario the previous one's addresses, and the remembered box (and its widest safe counters) with them
         try:
             grid.bin(0, aggs, n)
             used, trips = sa.config_get("hot_cnt16_used"), sa.config_get("hot_flush_trips_used")
         finally:
+            sa.config_set("hot_cache", 1)
             for k in forced:
                 sa.config_set(k, 0)
         redone = sa.config_get("redo_count") - redo0
@@ -507,7 +509,7 @@ def test_hot_box_packed_counters_are_exact(sa, scenario):
         assert sa.last_kernel(0).startswith("part_scatter_direct_hot"), sa.last_kernel(0)
         assert used == dict(normal=2, piled=0, hidden_pile=1, forced_flush=2, queue_overflow=0, pile_and_queue_overflow=0)[scenario], used   # (what the call ENDED on)
         assert redone == dict(normal=0, hidden_pile=1, forced_flush=0, queue_overflow=1).get(scenario, redone), redone
-        if scenario in ("piled", "pile_and_queue_overflow"):   # (piled: uint8 -> uint16 -> uint32 when the sample lets uint8 start)
+        if scenario in ("piled", "pile_and_queue_overflow"):   # (uint16 -> uint32, or uint8 -> uint16 -> uint32; both flags at once: uint32 at once)
             assert redone in (1, 2)
         if scenario == "forced_flush":
             assert trips == 2
@@ -649,3 +651,101 @@ def test_other_value_dtypes_ride_the_fast_kernels(sa, shape, vdtype):
     else:
         for k in range(3):
             np.testing.assert_array_equal(head[k], want[k])
+
+
+# ------------------------------------------------------------------------------------------------------------
+# round 4: the GROUPED pass 1 ("wv" = 5: cold records compacted into a wave-private ring, slab-sorted 64-record groups in one
+# stream per wave, pass 2 = part_reduce_grp) against the ring-less one ("wv" = 3) and the reference's C++
+# ------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("variant", ["bench", "masked", "count_only", "std", "int64_values", "tiny_blocks", "region_overflow", "nan_values", "sigma2"])
+def test_grouped_pass1(sa, variant):
+    """Every variant bins the same rows with wv = 5 and wv = 3: integer grids bit-exact, fp64 sums within 1e-12 x sum|v| of the cell, and
+    a 1e7-row slice equals the reference's C++ (restatement when absent).
+      bench            256x256 count(*) + sum(v) + count(v), N(0,1) x,y, an odd row count (partial tile, partial last group)
+      masked           ... one keep-mask shared by the three aggregators
+      count_only       count(*) alone (records without a value)
+      std              + the sum of squares (three-plane box, uint32 counters)
+      int64_values     integer sums (payload bits pass through)
+      tiny_blocks      one group per reserved block: every flush reserves (the in-line reservation path)
+      region_overflow  regions forced tiny: the slow path next to packed counters -> rerun with uint32 counters
+      nan_values       1 % NaN in v: cold by definition (the box takes non-NaN values only)
+      sigma2           x,y ~ N(0, 2): ~40 % of the rows cold, many groups per wave"""
+    import torch
+    g = torch.Generator(device="cuda").manual_seed(31)
+    n = (1 << 25) + 12_345
+    scale = 2.0 if variant == "sigma2" else 1.0
+    x = torch.randn(n, dtype=torch.float64, device="cuda", generator=g) * scale
+    y = torch.randn(n, dtype=torch.float64, device="cuda", generator=g) * scale
+    v = torch.randn(n, dtype=torch.float64, device="cuda", generator=g) * 2 + 3
+    if variant == "nan_values":
+        v[torch.rand(n, device="cuda", generator=g) < 0.01] = float("nan")
+    if variant == "int64_values":
+        v = (v * 1000).to(torch.int64)
+    keep = (torch.rand(n, device="cuda", generator=g) < 0.6).to(torch.uint8) if variant == "masked" else None
+    bx = sa.BinnerScalar_float64(1, "x", -4.0, 4.0, 256); by = sa.BinnerScalar_float64(1, "y", -4.0, 4.0, 256)
+    grid = sa.Grid([bx, by])
+    if variant == "count_only":
+        aggs = [sa.AggCount_int64(grid, 1, 1)]
+    elif variant == "int64_values":
+        aggs = [sa.AggCount_int64(grid, 1, 1), sa.AggSum_int64(grid, 1, 1), sa.AggCount_int64(grid, 1, 1)]
+    else:
+        aggs = [sa.AggCount_int64(grid, 1, 1), sa.AggSum_float64(grid, 1, 1), sa.AggCount_float64(grid, 1, 1)]
+        if variant == "std":
+            aggs.append(sa.AggSumMoment_float64(grid, 1, 1, 2))
+
+    def run(rows, wv, **knobs):
+        for a in aggs:
+            a.reset()
+        bx.set_data(0, x[:rows]); by.set_data(0, y[:rows])
+        for a in aggs[1:]:
+            a.set_data(0, v[:rows], 0)
+        for a in aggs:
+            if keep is not None:
+                a.set_data_mask(0, keep[:rows])
+            else:
+                a.clear_data_mask(0)
+        sa.config_set("wv", wv)
+        sa.config_set("hot_cache", 0)
+        for k, val in knobs.items():
+            sa.config_set(k, val)
+        try:
+            grid.bin(0, aggs, rows)
+            kernel = sa.last_kernel(0)
+        finally:
+            sa.config_set("wv", 3); sa.config_set("hot_cache", 1)
+            for k in knobs:
+                sa.config_set(k, 0)
+        return [np.array(a.get_result()) for a in aggs], kernel
+
+    knobs = dict(tiny_blocks=dict(wv_block=64), region_overflow=dict(part_cap=4096)).get(variant, {})
+    redo0 = sa.config_get("redo_count")
+    got, kernel = run(n, 5, **knobs)
+    redone = sa.config_get("redo_count") - redo0
+    assert kernel.startswith("part_scatter_grouped_hot"), kernel
+    if variant == "region_overflow":
+        assert redone >= 1 or sa.config_get("hot_cnt16_used") == 0
+    want, kernel3 = run(n, 3)
+    assert kernel3.startswith("part_scatter_direct_hot"), kernel3
+    vabs = torch.nan_to_num(v.to(torch.float64)).abs().max().item()
+    for k, (a, b) in enumerate(zip(got, want)):
+        if a.dtype.kind in "iu":
+            np.testing.assert_array_equal(a, b, err_msg=f"{variant}: aggregator {k}")
+        else:
+            scale_k = vabs ** 2 if k == 3 else vabs
+            assert np.all(np.abs(a - b) <= 1e-12 * scale_k * np.maximum(got[0], 1)), f"{variant}: aggregator {k}"
+    expect_rows = int(keep.sum().item()) if keep is not None else n
+    assert int(got[0].sum()) == expect_rows
+    m = N_SLICE
+    head, _ = run(m, 5, **knobs)
+    xs, ys = x[:m].cpu().numpy(), y[:m].cpu().numpy()
+    vs = v[:m].cpu().numpy()
+    ks = None if keep is None else keep[:m].cpu().numpy().astype(bool)
+    mk = lambda d: dict(d, mask=ks) if ks is not None else d
+    if variant == "count_only":
+        ca = [mk(dict(kind="count"))]
+    else:
+        ca = [mk(dict(kind="count")), mk(dict(kind="sum", data=vs)), mk(dict(kind="count", data=vs))]
+        if variant == "std":
+            ca.append(mk(dict(kind="summoment", data=vs, moment=2)))
+    case = dict(n=m, binners=[dict(kind="scalar", data=xs, vmin=-4, vmax=4, bins=256), dict(kind="scalar", data=ys, vmin=-4, vmax=4, bins=256)], aggs=ca)
+    cases.assert_case_equal(head, _ref_or_port_case(_ref_module(), case), case)

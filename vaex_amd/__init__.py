@@ -280,8 +280,8 @@ _cached_arrays = {}
 
 
 def _host_arrays(obj, columns=None):
-    """the numpy arrays behind `obj`: a vaex DataFrame (df.columns: memory-mapped / numpy columns; virtual columns and
-    arrow columns are skipped), a dict of arrays, or one array"""
+    """the numpy arrays behind `obj`: a vaex DataFrame (df.columns: memory-mapped / numpy columns, the value buffers of null-free
+    arrow columns; virtual columns are skipped), a dict of arrays, or one array"""
     import numpy as np
     if hasattr(obj, "columns") and hasattr(obj, "get_column_names"):
         names = columns if columns is not None else list(obj.columns)
@@ -297,10 +297,37 @@ def _host_arrays(obj, columns=None):
         elif isinstance(a, np.ndarray):
             parts = [a]
         else:
-            continue
+            # arrow-backed columns (pyarrow.ChunkedArray: what vaex holds for arrow / parquet files, vaex/arrow/dataset.py:164-200):
+            # the value buffers of null-free chunks of a fixed-width numeric type, as zero-copy numpy views (bool is bit-packed
+            # and chunks with nulls carry a validity bitmap: those keep streaming)
+            parts = _arrow_value_buffers(a)
         for part in parts:
             if part.ndim == 1 and part.flags.c_contiguous and part.dtype.kind in "iufb" and part.nbytes:
                 out.append(part)
+    return out
+
+
+def _arrow_value_buffers(column):
+    try:
+        import pyarrow as pa
+    except ImportError:
+        return []
+    import numpy as np
+    if isinstance(column, pa.Array):
+        chunks = [column]
+    elif isinstance(column, pa.ChunkedArray):
+        chunks = column.chunks
+    else:
+        return []
+    out = []
+    for chunk in chunks:
+        t = chunk.type
+        if chunk.null_count or not (pa.types.is_integer(t) or pa.types.is_floating(t)) or len(chunk) == 0:
+            continue
+        try:
+            out.append(chunk.to_numpy(zero_copy_only=True))   # (a view: keeps the arrow buffer alive)
+        except (pa.ArrowInvalid, ValueError):
+            continue
     return out
 
 

@@ -901,14 +901,17 @@ struct WvGeom {
     int waves = 0;
     size_t wave_bytes = 0;
 };
-static WvGeom wv_geometry(size_t S, int nvals, bool with_box) {
+// converted: the call's columns are converted on load (4-byte value column / float32 binners): only the ring-less variant 1 is instantiated for them
+static WvGeom wv_geometry(size_t S, int nvals, bool with_box, bool converted = false) {
     Context &c = ctx();
     WvGeom g;
     if (!c.cfg_wv || S > 64 || nvals > 1 || (c.cfg_no_pipeline & 1) || c.cfg_part_rows > 0) return g;
-    g.direct = with_box ? (c.cfg_wv == 3 ? 1 : (c.cfg_wv == 4 && S <= 16 ? 2 : 0)) : 0;
-    int waves = (int)std::min<int64_t>(16, std::max<int64_t>(1, g.direct ? c.cfg_wv_waves_direct : c.cfg_wv_waves));
+    // next to a box: "wv" = 3 -> 1 (records straight from the registers, one stream per (wave, slab)), 4 -> 2 (per (workgroup, slab)),
+    // 5 -> 3 (round 4: compacted into a wave-private ring, slab-sorted 64-record groups in ONE stream per wave; <= 8 slabs)
+    g.direct = with_box ? ((c.cfg_wv == 3 || (c.cfg_wv == 5 && (converted || S > 8))) ? 1 : (c.cfg_wv == 5 ? 3 : (c.cfg_wv == 4 && S <= 16 ? 2 : 0))) : 0;
+    int waves = (int)std::min<int64_t>(16, std::max<int64_t>(1, g.direct == 3 ? c.cfg_wv_waves_grouped : (g.direct ? c.cfg_wv_waves_direct : c.cfg_wv_waves)));
     // (shared streams: the kernel's LDS is one area for the workgroup; expressed per wave for the bookkeeping below)
-    g.wave_bytes = g.direct == 2 ? ((VXH_WV_SHARED_LDS(S) + waves - 1) / waves + 15) & ~(size_t)15 : (g.direct ? VXH_WV_WAVE_LDS_DIRECT(S) : VXH_WV_WAVE_LDS(nvals, S));
+    g.wave_bytes = g.direct == 3 ? VXH_WV_WAVE_LDS_GROUPED : (g.direct == 2 ? ((VXH_WV_SHARED_LDS(S) + waves - 1) / waves + 15) & ~(size_t)15 : (g.direct ? VXH_WV_WAVE_LDS_DIRECT(S) : VXH_WV_WAVE_LDS(nvals, S)));
     while (waves > 1 && (size_t)waves * g.wave_bytes > 150 * 1024) waves--;
     if (waves < 4 || (size_t)waves * g.wave_bytes > 150 * 1024) return g; // too few waves to hide anything: not this kernel
     g.waves = waves;
@@ -1022,13 +1025,13 @@ static void hot_prepare(Slot &slot, const BinArgs &A, const BinArgs &planned, co
     const uint64_t slab_cells = (planned.cells + S - 1) >> planned.slab_log2;
     // the box lives in part_scatter_blk: uint16 local indices with one value to spare for the null record
     const bool gen2 = c.cfg_blk && S <= 256 && slab_cells < 65535 && !(c.cfg_no_pipeline & 1) && c.cfg_part_rows <= 0; // (= run_part_chunk's conditions for part_scatter_blk)
-    const WvGeom wg = wv_geometry(S, nval, true);
-    bool wv = wg.ok && slab_cells < 65535 && wv_aligned(A); // (= run_part_chunk's conditions for part_scatter_wv)
     const bool f32b = plan.bin_f32 && !plan.fast_f32 && (plan.fast_vals || plan.vals_i64); // float32 binners next to an 8-byte value column
     const bool ints = (plan.bin_f64 && (plan.vals_i64 || plan.vals_i32 || plan.vals_f32)) || f32b; // integer sums / 4-byte columns converted on load: part_scatter_wv's instantiations only
     const bool f32all = plan.fast_f32 && nval == 1; // float32 binners AND value column: the ring-less part_scatter_wv converts both on load; otherwise part_scatter_blk's float instantiation
+    const WvGeom wg = wv_geometry(S, nval, true, plan.vals_i32 || plan.vals_f32 || f32b || f32all);
+    bool wv = wg.ok && slab_cells < 65535 && wv_aligned(A); // (= run_part_chunk's conditions for part_scatter_wv)
     if (f32all && wg.direct != 1) wv = false;
-    if ((masked && !(wv && wg.direct == 1)) || (plan.fast_f32 && !f32all)) { // (the box next to a selection mask: part_scatter_blk's or the ring-less part_scatter_wv's instantiations; float32 columns without a value column: part_scatter_blk's only)
+    if ((masked && !(wv && (wg.direct == 1 || wg.direct == 3))) || (plan.fast_f32 && !f32all)) { // (the box next to a selection mask: part_scatter_blk's or the ring-less part_scatter_wv's instantiations; float32 columns without a value column: part_scatter_blk's only)
         if (!gen2 || ints) return;
         wv = false;
     }
@@ -1036,7 +1039,7 @@ static void hot_prepare(Slot &slot, const BinArgs &A, const BinArgs &planned, co
     // a forced box (tests / experiments) too big for what part_scatter_wv's rings leave of the LDS goes to part_scatter_blk
     // uint16 counters (two per LDS word) next to the ring-less pass 1 with one value column: 10-byte cells instead of 12
     // ... uint8 counters (four per word, 9-byte cells) where the fullest cell fills slowly enough for a flush every few hundred tiles
-    const int shift_max = (nval == 1 && !mom2 && wg.ok && wg.direct == 1) ? (int)std::max<int64_t>(0, std::min<int64_t>(std::min<int64_t>(c.cfg_hot_cnt16, H.max_shift), (c.cfg_no_pipeline & 1024) ? 1 : 2)) : 0;
+    const int shift_max = (nval == 1 && !mom2 && wg.ok && (wg.direct == 1 || wg.direct == 3)) ? (int)std::max<int64_t>(0, std::min<int64_t>(std::min<int64_t>(c.cfg_hot_cnt16, H.max_shift), (c.cfg_no_pipeline & 1024) ? 1 : 2)) : 0;
     const bool c16 = shift_max >= 1;
     int shift = c16 ? 1 : 0; // (uint8 is decided below, from the sample)
     H.cnt16 = false;
@@ -1045,7 +1048,7 @@ static void hot_prepare(Slot &slot, const BinArgs &A, const BinArgs &planned, co
     if (wv && forced && gen2 && (uint64_t)c.cfg_hot_box[2] * (uint64_t)c.cfg_hot_box[3] > (kLdsMax - ((size_t)wg.waves * wg.wave_bytes + 64) - 96 - (c16 ? 16 : 0)) / (c16 ? 10 : (nval ? (mom2 ? 20 : 12) : 4))) wv = false;
     if (!gen2 && !wv) return;
     if (ints && !wv) return;
-    if (ints && wg.direct != 1) return; // (4-byte columns: only the ring-less variant is instantiated for them)
+    if (ints && !(wg.direct == 1 || wg.direct == 3)) return; // (4-byte columns: only the ring-less variant is instantiated for them — wv_geometry never answers 3 for those; int64 sums ride either)
     H.gen2 = true;
     H.nval = nval;
     const size_t cell_bytes = nval ? (mom2 ? 20 : 12) : 4;
@@ -1309,11 +1312,11 @@ static void run_part_chunk(Slot &slot, const BinArgs &planned, const LaunchPlan 
 
     // third-generation pass 1 (part_scatter_wv): 1..3 float64 scalar binners or one int64 key, <= 1 float64 value column,
     // <= 1 mask shared by every aggregator, uint16 local indices, <= 64 slabs, 16-byte aligned columns
-    const WvGeom wg = wv_geometry(S, P.nvals, slot.hot.on);
     P.val_i64 = plan.vals_i64 ? 1 : 0;
     const bool narrow = plan.vals_f32 || plan.vals_i32; // (a 4-byte value column: part_scatter_wv converts it on load — nobody else does)
     const bool f32b = plan.bin_f32 && !plan.fast_f32 && (plan.fast_vals || plan.vals_i64) && P.nvals == 1; // (float32 binners next to an 8-byte value column: the same)
     const bool f32all = plan.fast_f32 && P.nvals == 1; // (float32 binners and value column: both converted on load)
+    const WvGeom wg = wv_geometry(S, P.nvals, slot.hot.on, narrow || f32b || f32all);
     const bool wv = wg.ok && (plan.fast_f64 || (plan.bin_f64 && (plan.vals_i64 || narrow)) || f32b || f32all || (plan.key_i64 && (plan.fast_vals || plan.vals_i64 || narrow))) && (!(narrow || f32b || f32all) || !slot.hot.on || wg.direct == 1) && planned.ndim >= 1 && planned.ndim <= 3 && P.nvals <= 1 && !P.use_flags &&
                     (P.nmasks == 0 || (P.nmasks == 1 && P.all_masked)) && P.idx16 && slab_cells < 65535 && wv_aligned(planned) && (!slot.hot.on || slot.hot.wv);
     if (slot.hot.on && slot.hot.wv != wv) throw std::runtime_error("vaex_hip internal: hot box prepared for a different pass-1 kernel");
@@ -1333,7 +1336,23 @@ static void run_part_chunk(Slot &slot, const BinArgs &planned, const LaunchPlan 
     double share = 2.0;
     if (slot.hot.on && slot.hot.gen2 && ctx().cfg_hot_box[2] <= 0 && slot.hot.last_fraction > 0 && slot.hot.last_fraction <= 1) share = std::min(2.0, 3.0 * (1.0 - slot.hot.last_fraction) + 0.125);
     P.cap = (nsub == 1 ? C : std::min<uint64_t>(C, (uint64_t)(share * (double)(C / nsub)) + 8192 + 2 * 1024 * ((uint64_t)ctx().cus / std::max<uint64_t>(1, P.parts) + 1)) + 63) & ~(uint64_t)63; // (a multiple of part_scatter_wv's 64-record segments)
-    if (wv) {
+    const bool grouped = wv && wg.direct == 3;
+    if (grouped) {
+        // grouped layout: `parts` regions of 64-record groups; ONE block of GB groups per wave sized for the wave's expected cold
+        // records (+ 1/8 + 3 groups), a second block is a rare in-line reservation
+        const uint64_t waves_total = (uint64_t)wv_blocks * wg.waves;
+        const double cold = (slot.hot.on && ctx().cfg_hot_box[2] <= 0 && slot.hot.last_fraction > 0 && slot.hot.last_fraction <= 1) ? std::min(1.0, 1.25 * (1.0 - slot.hot.last_fraction) + 0.02) : 1.0;
+        const double expect = (double)planned.n * cold / (double)waves_total / (double)VXH_WV_GROUP;
+        uint64_t GB = (uint64_t)(expect * 1.125) + 3;
+        if (c.cfg_wv_block > 0) GB = std::max<uint64_t>(1, (uint64_t)c.cfg_wv_block / VXH_WV_GROUP);
+        const uint64_t waves_per_region = ((uint64_t)wv_blocks + P.parts - 1) / P.parts * wg.waves;
+        uint64_t capG = GB * (waves_per_region + std::max<uint64_t>(8, waves_per_region / 4));
+        if (c.cfg_part_cap > 0) capG = std::max<uint64_t>(1, ((uint64_t)c.cfg_part_cap / VXH_WV_GROUP + GB - 1) / GB) * GB; // (tests: a region that overflows)
+        P.qblk = (int32_t)GB;
+        P.cap = capG * VXH_WV_GROUP;
+        if (P.cap >= (1ull << 32)) throw std::runtime_error("vaex_hip internal: grouped queue region beyond 2^32 records");
+        P.qtab_stride = (int32_t)(capG / GB + 2);
+    } else if (wv) {
         // queue blocks of part_scatter_wv: ONE block per (wave, slab) sized for the wave's expected share of this launch's
         // records (+ 1/8 + 3 granules); a second block is a rare, in-line reservation.  A wave's tiles are spread over
         // the whole launch (stride = all waves), so its share of every slab is the launch's share of that slab.
@@ -1374,20 +1393,22 @@ static void run_part_chunk(Slot &slot, const BinArgs &planned, const LaunchPlan 
             P.epoch = slot.epoch;
         }
     }
-    const bool rec12 = wv && wg.direct && P.nvals == 1;
+    const bool rec12 = wv && (wg.direct == 1 || wg.direct == 2) && P.nvals == 1;
     P.qrec12 = rec12 ? 1 : 0;
     const size_t idx_bytes = rec12 ? 12 : (P.idx16 ? 2 : 4);
     size_t off = 0;
     auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
-    const size_t o_count = carve((size_t)nsub * 8), o_limit = carve((size_t)nsub * 8);
-    const size_t o_tab = wv ? carve((size_t)nsub * (size_t)P.qtab_stride * 4) : 0;
+    const uint64_t nq = grouped ? (uint64_t)P.parts : nsub; // queues with their own counter: regions (grouped) or (slab, part) sub-queues
+    const size_t o_count = carve((size_t)nq * 8), o_limit = carve((size_t)nq * 8);
+    const size_t o_tab = wv ? carve((size_t)nq * (size_t)P.qtab_stride * 4) : 0;
+    const size_t o_hdr = grouped ? carve((size_t)nq * (size_t)(P.cap / VXH_WV_GROUP) * 8) : 0;
     // (ring-less part_scatter_wv: one sink record per wave behind the sub-queues, 16 records apart)
-    const size_t n_sink = (wv && wg.direct) ? (size_t)wv_blocks * wg.waves * 16 : 0;
-    P.qsink = (uint64_t)nsub * P.cap;
-    const size_t o_idx = carve(((size_t)nsub * P.cap + n_sink) * idx_bytes);
-    const size_t o_flags = P.use_flags ? carve((size_t)nsub * P.cap) : 0;
+    const size_t n_sink = (wv && (wg.direct == 1 || wg.direct == 2)) ? (size_t)wv_blocks * wg.waves * 16 : 0;
+    P.qsink = (uint64_t)nq * P.cap;
+    const size_t o_idx = carve(((size_t)nq * P.cap + n_sink) * idx_bytes);
+    const size_t o_flags = P.use_flags ? carve((size_t)nq * P.cap) : 0;
     size_t o_val[VXH_PART_MAX_VALS] = {0, 0, 0, 0};
-    for (int k = 0; k < P.nvals && !rec12; k++) o_val[k] = carve((size_t)nsub * P.cap * 8);
+    for (int k = 0; k < P.nvals && !rec12; k++) o_val[k] = carve((size_t)nq * P.cap * 8);
     // (two scratch buffers only when pass 2 of chunk i overlaps pass 1 of chunk i+1)
     Slot::PartBuf &pb = slot.part[c.cfg_part_overlap ? (slot.part_next++ & 1) : 0];
     // the previous user of this buffer (pass 2 of chunk i-2, on stream2) must be done before pass 1 refills it
@@ -1408,12 +1429,13 @@ static void run_part_chunk(Slot &slot, const BinArgs &planned, const LaunchPlan 
     P.qidx = sc + o_idx;
     P.qflags = P.use_flags ? (uint8_t *)(sc + o_flags) : nullptr;
     for (int k = 0; k < P.nvals && !rec12; k++) P.qval[k] = (uint64_t *)(sc + o_val[k]);
-    HIP_CHECK(hipMemsetAsync(P.qcount, 0, (size_t)nsub * 8, slot.stream));
-    HIP_CHECK(hipMemsetAsync(P.qlimit, 0xff, (size_t)nsub * 8, slot.stream));
+    HIP_CHECK(hipMemsetAsync(P.qcount, 0, (size_t)nq * 8, slot.stream));
+    HIP_CHECK(hipMemsetAsync(P.qlimit, 0xff, (size_t)nq * 8, slot.stream));
     if (wv) {
         P.qtab = (uint32_t *)(sc + o_tab);
-        HIP_CHECK(hipMemsetAsync(P.qtab, 0, (size_t)nsub * (size_t)P.qtab_stride * 4, slot.stream));
+        HIP_CHECK(hipMemsetAsync(P.qtab, 0, (size_t)nq * (size_t)P.qtab_stride * 4, slot.stream));
     }
+    if (grouped) P.qhdr = (unsigned long long *)(sc + o_hdr);
 
     // pass-1 tile: 512 threads x R rows, staged in LDS
     // (many slabs: bigger tiles keep the per-bucket copy-out segments at >= 16 records)
@@ -1438,7 +1460,7 @@ static void run_part_chunk(Slot &slot, const BinArgs &planned, const LaunchPlan 
                      (P.nmasks == 0 || (P.nmasks == 1 && P.all_masked)) && P.idx16 && slab_cells < 65535 && S <= 256 && c.cfg_part_rows <= 0 &&
                      (slot.hot.on || (S > 8 && S <= 64 && !plan.key_i64) || (plan.fast_f32 && S <= 64) || c.cfg_blk == 2); // measured (profiles/r01_other_shapes.txt, r01_groupby_tune.txt):
                      // <= 8 slabs without a box: two 512-thread workgroups of part_scatter_f64 are 2 % faster; 128-256 slabs: +5 % (1024^2) / -35 % (1e6-key groupby)
-    const bool hot_here = slot.hot.on && (P.nmasks == 0 || (P.nmasks == 1 && P.all_masked && ((blk && !wv) || (wv && wg.direct == 1)))) && P.nvals == slot.hot.nval && (blk || wv);
+    const bool hot_here = slot.hot.on && (P.nmasks == 0 || (P.nmasks == 1 && P.all_masked && ((blk && !wv) || (wv && (wg.direct == 1 || wg.direct == 3))))) && P.nvals == slot.hot.nval && (blk || wv);
     if (wv && (f32b || f32all)) P.bin_ct = 1;
     if (wv && (narrow || f32all)) { // from here on the value column is what part_scatter_wv makes of it
         P.val_ct = (plan.vals_f32 || f32all) ? 1 : 2;
@@ -1733,6 +1755,7 @@ int vxh_config_set(const char *key, int64_t value) {
     else if (k == "wv") c.cfg_wv = value;
     else if (k == "wv_waves") c.cfg_wv_waves = value > 0 ? value : 8;
     else if (k == "wv_waves_direct") c.cfg_wv_waves_direct = value > 0 ? value : 16;
+    else if (k == "wv_waves_grouped") c.cfg_wv_waves_grouped = value > 0 ? value : 8;
     else if (k == "wv_block") c.cfg_wv_block = value;
     else if (k == "part_cap") c.cfg_part_cap = value;
     else if (k == "hot_min_rows") c.cfg_hot_min_rows = value > 0 ? value : (1 << 24);
@@ -1780,6 +1803,7 @@ int vxh_config_get(const char *key, int64_t *value) {
     else if (k == "wv") *value = c.cfg_wv;
     else if (k == "wv_waves") *value = c.cfg_wv_waves;
     else if (k == "wv_waves_direct") *value = c.cfg_wv_waves_direct;
+    else if (k == "wv_waves_grouped") *value = c.cfg_wv_waves_grouped;
     else if (k == "hot_direct_pct") *value = c.cfg_hot_direct_pct;
     else if (k == "wv_block") *value = c.cfg_wv_block;
     else if (k == "part_cap") *value = c.cfg_part_cap;
@@ -2203,7 +2227,7 @@ int vxh_grid_bin(vxh_grid *grid, int thread, vxh_agg *const *aggs, int n_aggs, u
             if (slot.last_pass1 >= 2) slot.last_kernel = (whole.fast_f64 || whole.fast_f32 || whole.vals_f32 || (whole.bin_f32 && whole.fast_vals)) ? "part_scatter_wv+part_reduce_f64" : ((whole.vals_i64 || whole.vals_i32) ? "part_scatter_wv+part_reduce_i64" : "part_scatter_wv+part_reduce_generic");
             if (slot.hot.on) {
                 hot_merge(slot, whole_args);
-                slot.last_kernel = slot.last_pass1 == 4 ? "part_scatter_shared_hot+part_reduce_f64" : slot.last_pass1 == 3 ? ((whole.vals_i64 || whole.vals_i32) ? "part_scatter_direct_hot+part_reduce_i64" : "part_scatter_direct_hot+part_reduce_f64") : (slot.last_pass1 == 2 ? "part_scatter_wv_hot+part_reduce_f64" : "part_scatter_hot+part_reduce_f64");
+                slot.last_kernel = slot.last_pass1 == 5 ? ((whole.vals_i64 || whole.vals_i32) ? "part_scatter_grouped_hot+part_reduce_grp_i64" : "part_scatter_grouped_hot+part_reduce_grp_f64") : slot.last_pass1 == 4 ? "part_scatter_shared_hot+part_reduce_f64" : slot.last_pass1 == 3 ? ((whole.vals_i64 || whole.vals_i32) ? "part_scatter_direct_hot+part_reduce_i64" : "part_scatter_direct_hot+part_reduce_f64") : (slot.last_pass1 == 2 ? "part_scatter_wv_hot+part_reduce_f64" : "part_scatter_hot+part_reduce_f64");
             }
             slot.hot.on = false;
             part_guard.armed = false;

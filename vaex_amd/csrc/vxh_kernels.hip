@@ -1680,7 +1680,7 @@ __global__ void __launch_bounds__(1024) part_scatter_wv(const PartArgs P) {
     // uint8 counters, four per word (cnt16 == 2): 9-byte cells.  The workgroup flushes and clears them every P.hot.flush_trips trips
     // of the tile loop (the host picks the interval from the sampled share of the fullest cell: ~128 rows expected there), with the
     // same check at every flush — a wrapped byte carries into its neighbour, the sum of the counters comes out 255 short.
-    const bool c16 = HOT && DIRECT == 1 && NVAL == 1 && P.hot.cnt16 != 0u; // (wave-uniform)
+    const bool c16 = HOT && (DIRECT == 1 || DIRECT == 3) && NVAL == 1 && P.hot.cnt16 != 0u; // (wave-uniform)
     const uint32_t csh = c16 ? P.hot.cnt16 : 0u;                            // log2(counters per word): 1 or 2
     const uint32_t cnt_words = c16 ? (hot_cells + (1u << csh) - 1u) >> csh : hot_cells; // [cnt_words] hot rows seen, [cnt_words + 1] sum of the counters
     uint32_t nhot = 0, flushed = 0; // (per wave / per thread)
@@ -1690,6 +1690,12 @@ __global__ void __launch_bounds__(1024) part_scatter_wv(const PartArgs P) {
     // DIRECT: no rings — [S] x {record index base (64 bit), limit, slow flag} | [S] counters   (VXH_WV_WAVE_LDS_DIRECT)
     u32x4 *const tab = (u32x4 *)wbase;
     uint32_t *const cnt = DIRECT ? (uint32_t *)(tab + S) : (uint32_t *)(ring_idx + (size_t)S * D);
+    // DIRECT == 3 (grouped): the wave's ring of 2 x 64 records — [128] value bits | [128] flat cell index (VXH_WV_WAVE_LDS_GROUPED)
+    constexpr uint32_t GR = VXH_WV_GROUP;
+    uint64_t *const g_val = (uint64_t *)wbase;
+    uint32_t *const g_idx = (uint32_t *)(wbase + 2u * GR * 8u);
+    uint32_t wcount = 0, wflushed = 0; // (wave-uniform) records staged / flushed so far
+    uint32_t gcur = VXH_WV_NONE, gend = VXH_WV_NONE; // (wave-uniform) next group of the wave's block, end of the block — group indices inside the region
     // DIRECT == 2: the WORKGROUP's waves share one record stream per slab (16x fewer streams than one per wave: a
     // stream's 128-byte lines fill before the L2 evicts them half written — the cost of the scattered stores grows with
     // the number of streams, profiles/r02_direct_streams.txt).  LDS at wv_base: [S] record counters | [S][NB] block
@@ -1715,7 +1721,7 @@ __global__ void __launch_bounds__(1024) part_scatter_wv(const PartArgs P) {
         if (c16)
             for (uint32_t c = threadIdx.x; c < cnt_words + 2u; c += blockDim.x) hot_cnt[c] = 0u;
     }
-    if (lane < S) cnt[lane] = 0u;
+    if (DIRECT != 3 && lane < S) cnt[lane] = 0u;
     // lane s keeps the queue segment reserved for slab s
     const uint32_t part = blockIdx.x % (uint32_t)P.parts;
     const uint32_t my_sub = (lane < S ? lane : 0u) * (uint32_t)P.parts + part;
@@ -1735,7 +1741,24 @@ __global__ void __launch_bounds__(1024) part_scatter_wv(const PartArgs P) {
     auto close_block = [&]() { // (one lane) records the block really holds
         if (end != VXH_WV_NONE) P.qtab[(size_t)my_sub * (uint32_t)P.qtab_stride + (end - B) / B] = cur - (end - B);
     };
-    if (DIRECT != 2 && has_work && lane < S) open_block();
+    if (DIRECT != 2 && DIRECT != 3 && has_work && lane < S) open_block();
+    // DIRECT == 3: the wave's block of qblk groups in region `part` (one returning atomic per block: once per launch as a rule)
+    auto open_group_block = [&]() {
+        unsigned long long b = 0;
+        if (lane == 0) b = atomicAdd(&P.qcount[part], (unsigned long long)B);
+        b = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(b >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b);
+        if ((b + B) * GR > P.cap) { // the region is full: remember where its valid prefix ends; slow path from here on
+            if (lane == 0) atomicMin(&P.qlimit[part], b);
+            gcur = gend = VXH_WV_NONE;
+        } else {
+            gcur = (uint32_t)b;
+            gend = gcur + B;
+        }
+    };
+    auto close_group_block = [&]() { // groups the block really holds
+        if (gend != VXH_WV_NONE && lane == 0) P.qtab[(size_t)part * (uint32_t)P.qtab_stride + (gend - B) / B] = gcur - (gend - B);
+    };
+    if (DIRECT == 3 && has_work) open_group_block();
     // DIRECT == 2: block j of (workgroup, slab s) holds the slab's records [j * QB, (j + 1) * QB) of this workgroup; it is
     // reserved by the lane that draws position (j - 1) * QB + QB / 2 (block 0: here), which publishes its entry in the
     // LDS ring and in the HBM block table (PartArgs::qbtab — for a lane that finds its ring entry not yet written or,
@@ -1902,6 +1925,47 @@ __global__ void __launch_bounds__(1024) part_scatter_wv(const PartArgs P) {
             ((uint16_t *)P.qidx)[dst] = (uint16_t)local;
         }
     };
+    // DIRECT == 3: the oldest `count` staged records (64, or what is left at the end) leave as one group: read, ranked by slab
+    // (eight ballots: this runs once per 64 COLD rows with every lane on, not once per row-step with a handful of them), put back
+    // sorted into the same ring granule, read back in order and stored as whole lines — 512 B of values, 128 B of local indices,
+    // non-temporal — plus the header of the slabs' end offsets.
+    auto flush_group = [&](uint32_t count) {
+        const uint32_t g0 = wflushed & (2u * GR - 1u); // 0 or 64
+        const bool live = lane < count;
+        const uint64_t vb = NVAL ? g_val[g0 + lane] : 0ull;
+        const uint32_t ix = g_idx[g0 + lane];
+        const uint32_t sl = live ? (ix & (S - 1u)) : 0xffu;
+        uint32_t start = 0, rank = 0;
+        uint64_t hdr = 0;
+#pragma unroll
+        for (uint32_t s8 = 0; s8 < 8u; ++s8) {
+            const unsigned long long bmask = __ballot(sl == s8);
+            const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(bmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bmask, 0u));
+            if (sl == s8) rank = start + below;
+            start += (uint32_t)__builtin_popcountll(bmask);
+            hdr |= (uint64_t)start << (8u * s8);
+        }
+        if (live) { // (LDS operations of one wave execute in order: every lane's read above is ahead of these writes)
+            if (NVAL) g_val[g0 + rank] = vb;
+            g_idx[g0 + rank] = ix >> P.slab_log2;
+        }
+        const uint64_t v2 = NVAL ? g_val[g0 + lane] : 0ull;
+        const uint32_t l2 = g_idx[g0 + lane];
+        if (gcur == gend) { // the block is full (or there is none): the next one, now
+            close_group_block();
+            open_group_block();
+        }
+        if (gcur != VXH_WV_NONE) {
+            const uint64_t rec = ((uint64_t)part * P.cap) + (uint64_t)gcur * GR + lane;
+            if (NVAL) __builtin_nontemporal_store(v2, P.qval[0] + rec);
+            __builtin_nontemporal_store((uint16_t)l2, (uint16_t *)P.qidx + rec);
+            if (lane == 0) P.qhdr[(uint64_t)part * (P.cap / GR) + gcur] = hdr;
+            ++gcur;
+        } else if (live) { // region full (pathologically skewed data): device atomics straight into the grids
+            wv_slow_record(P, (uint64_t)ix, NVAL ? __longlong_as_double((long long)vb) : 0.0);
+        }
+        wflushed += count;
+    };
     const uint64_t sink = P.qsink + (uint64_t)(blockIdx.x * nwave + wave) * 16u; // (record index: 16 records apart, behind the sub-queues)
     auto process = [&](const Raw &cur) {
         uint32_t keep = (1u << R) - 1u;
@@ -1965,12 +2029,28 @@ __global__ void __launch_bounds__(1024) part_scatter_wv(const PartArgs P) {
             }
             pos[r] = 0;
             if (DIRECT && (P.no_pipeline & 64)) is_cold = false; // (timing experiments: bit 6 drops the cold rows)
+            if (DIRECT == 3) {
+                // compaction: the row-step's cold rows become neighbouring entries of the wave's ring — positions from the ballot,
+                // the running count is a scalar; no returning LDS atomic, no table, no store from a handful of lanes
+                const unsigned long long cm = __ballot(is_cold);
+                if (cm) {
+                    if (is_cold) {
+                        const uint32_t at = (wcount + __builtin_amdgcn_mbcnt_hi((uint32_t)(cm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cm, 0u))) & (2u * GR - 1u);
+                        if (NVAL) g_val[at] = (uint64_t)__double_as_longlong(val[NVAL ? r : 0]);
+                        g_idx[at] = idx;
+                    }
+                    wcount += (uint32_t)__builtin_popcountll(cm);
+                    if (wcount - wflushed >= GR) flush_group(GR); // (a row-step adds at most 64: never more than 127 staged)
+                }
+                continue;
+            }
             if (is_cold) {
                 pos[r] = __hip_atomic_fetch_add(DIRECT == 2 ? &scnt[slab[r]] : &cnt[slab[r]], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 if (DIRECT == 1) where[r] = tab[slab[r]];
                 cold |= 1u << r;
             }
         }
+        if (DIRECT == 3) return;
         if (DIRECT == 2) {
             // reservations first (they wait for nothing), then the entries, then the stores
 #pragma unroll
@@ -2091,7 +2171,7 @@ __global__ void __launch_bounds__(1024) part_scatter_wv(const PartArgs P) {
         const uint32_t wg_last = blockIdx.x * nwave + (nwave - 1u);
         uint32_t trip = 0, until_flush = P.hot.flush_trips;
         for (;;) {
-            if (HOT && DIRECT == 1 && NVAL == 1 && csh == 2u) {
+            if (HOT && (DIRECT == 1 || DIRECT == 3) && NVAL == 1 && csh == 2u) {
                 if (trip && --until_flush == 0u) {
                     until_flush = P.hot.flush_trips;
                     if ((uint64_t)wg_last + 2ull * trip * GW < ntiles) flushed += hot_flush_counts();
@@ -2140,8 +2220,11 @@ __global__ void __launch_bounds__(1024) part_scatter_wv(const PartArgs P) {
         }
         }
         // what is left in the rings (less than a granule per slab), then the fill of the blocks still open
-        const uint32_t my_cnt = (DIRECT != 2 && lane < S) ? cnt[lane] : 0u;
-        if (DIRECT == 2) {
+        const uint32_t my_cnt = (DIRECT != 2 && DIRECT != 3 && lane < S) ? cnt[lane] : 0u;
+        if (DIRECT == 3) {
+            if (wcount != wflushed) flush_group(wcount - wflushed); // (< 64 records: the header says how many)
+            close_group_block();
+        } else if (DIRECT == 2) {
         } else if (DIRECT) {
             if (lane < S && end != VXH_WV_NONE) P.qtab[(size_t)my_sub * (uint32_t)P.qtab_stride + (end - B) / B] = my_cnt - open_count;
         } else {
@@ -2419,6 +2502,114 @@ __global__ void __launch_bounds__(1024) part_reduce_fast(const PartArgs P) {
     lds_flush_acc(P, lds, slab_cells, slab, part);
 }
 
+// pass 2 of the GROUPED queue layout (part_scatter_wv<..., DIRECT = 3>): the queue is `parts` regions of 64-record groups, every
+// group sorted by slab with a header of the slabs' end offsets.  Workgroup (slab, part) walks region `part` and reads, of every
+// group, its own slab's segment (8 records on average with 8 slabs): a wave fetches 64 headers with one coalesced load, then 16
+// lanes take one group each trip — four groups per trip, four trips' record loads in flight.  The workgroups that read the same
+// region are `parts` apart in blockIdx, i.e. on the same XCD (blocks are dealt to the XCDs round robin) and start together: the
+// lines of a group one of them fetches are L2 hits for the other slabs' workgroups.
+template <int NAGG>
+__device__ __forceinline__ void grp_apply(const PartArgs &P, char *lds, uint32_t loc, uint64_t vbits, bool valid, const uint32_t (&off)[NAGG], const uint32_t (&kind)[NAGG],
+                                          const uint32_t (&vs)[NAGG], const uint32_t (&mom)[NAGG]) {
+    const bool vint = P.val_i64 != 0;
+    const double d = as_f64(vbits);
+    const bool nan = !vint && d != d;
+#pragma unroll
+    for (int k = 0; k < NAGG; ++k) {
+        char *base = lds + off[k];
+        const bool has = vs[k] != 0xffu;
+        if (kind[k] == VXH_AGG_COUNT) {
+            if (valid && !(has && nan)) at_add<__HIP_MEMORY_SCOPE_WORKGROUP, uint32_t>((uint32_t *)base + loc, 1u);
+        } else if (vint) {
+            if (valid) at_add<__HIP_MEMORY_SCOPE_WORKGROUP, unsigned long long>((unsigned long long *)base + loc, (unsigned long long)vbits);
+        } else {
+            const double x = kind[k] == VXH_AGG_SUM_MOMENT ? pow_u(d, mom[k]) : d;
+            if (valid && !nan) at_add<__HIP_MEMORY_SCOPE_WORKGROUP, double>((double *)base + loc, x);
+        }
+    }
+}
+
+template <int NAGG>
+__global__ void __launch_bounds__(1024) part_reduce_grp(const PartArgs P) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    constexpr uint32_t GR = VXH_WV_GROUP;
+    const uint32_t S = 1u << P.slab_log2;
+    const uint32_t part = blockIdx.x % (uint32_t)P.parts, slab = blockIdx.x / (uint32_t)P.parts; // (the slabs of one region: same XCD)
+    const uint64_t slab_cells = (P.A.cells + S - 1) >> P.slab_log2;
+    lds_init(P.A, lds, slab_cells);
+    uint32_t off[NAGG], kind[NAGG], vs[NAGG], mom[NAGG];
+#pragma unroll
+    for (int k = 0; k < NAGG; ++k) {
+        off[k] = P.A.a[k].lds_offset;
+        kind[k] = P.A.a[k].kind;
+        vs[k] = P.agg_vslot[k];
+        mom[k] = P.A.a[k].moment;
+    }
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
+    unsigned long long len = P.qcount[part]; // groups reserved in the region
+    const unsigned long long lim = P.qlimit[part];
+    if (lim < len) len = lim;
+    const uint32_t GB = (uint32_t)P.qblk;
+    const uint32_t nblk = (uint32_t)(len / GB);
+    const uint64_t groups_per_region = P.cap / GR;
+    const unsigned long long *const hdrs = P.qhdr + (uint64_t)part * groups_per_region;
+    const uint64_t *const vals = P.nvals ? P.qval[0] + (uint64_t)part * P.cap : nullptr;
+    const uint16_t *const locs = (const uint16_t *)P.qidx + (uint64_t)part * P.cap;
+    const uint32_t sh0 = slab ? 8u * (slab - 1u) : 0u, sh1 = 8u * slab;
+    const uint32_t sub = lane & 15u, quad = lane >> 4; // 16 lanes per group, 4 groups per trip
+    for (uint32_t b = wave; b < nblk; b += nwave) {
+        const uint32_t ng = P.qtab[(size_t)part * (uint32_t)P.qtab_stride + b];
+        const uint32_t G0 = b * GB;
+        for (uint32_t c0 = 0; c0 < ng; c0 += 64u) {
+            const uint32_t here = ng - c0 < 64u ? ng - c0 : 64u; // groups of this chunk
+            const unsigned long long h_mine = lane < here ? hdrs[G0 + c0 + lane] : 0ull;
+            for (uint32_t t0 = 0; t0 < here; t0 += 16u) { // four trips of four groups: their loads in flight together
+                uint32_t loc[4], end[4], at[4];
+                uint64_t vb[4];
+                bool ok[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const uint32_t gi = t0 + 4u * (uint32_t)u + quad; // (< 64: the header of a group beyond `here` is 0 — an empty segment)
+                    const uint32_t hlo = (uint32_t)__shfl((int)(uint32_t)h_mine, (int)gi, 64), hhi = (uint32_t)__shfl((int)(uint32_t)(h_mine >> 32), (int)gi, 64);
+                    const unsigned long long h = ((unsigned long long)hhi << 32) | hlo;
+                    const uint32_t s0 = slab ? (uint32_t)(h >> sh0) & 0xffu : 0u;
+                    end[u] = (uint32_t)(h >> sh1) & 0xffu;
+                    at[u] = (G0 + c0 + gi) * GR + s0 + sub; // record index inside the region
+                    ok[u] = s0 + sub < end[u];
+                    end[u] = (G0 + c0 + gi) * GR + end[u];
+                    vb[u] = 0ull;
+                    loc[u] = 0u;
+                    if (ok[u]) {
+                        loc[u] = locs[at[u]];
+                        if (P.nvals) vb[u] = vals[at[u]];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) grp_apply<NAGG>(P, lds, loc[u], vb[u], ok[u], off, kind, vs, mom);
+                // segments longer than 16 records (one in five hundred with eight slabs): the rest, 16 at a time
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    uint32_t r = at[u] + 16u;
+                    while (__ballot(r < end[u])) {
+                        const bool more = r < end[u];
+                        uint32_t l = 0;
+                        uint64_t v = 0;
+                        if (more) {
+                            l = locs[r];
+                            if (P.nvals) v = vals[r];
+                        }
+                        grp_apply<NAGG>(P, lds, l, v, more, off, kind, vs, mom);
+                        r += 16u;
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    lds_flush_acc(P, lds, slab_cells, slab, part);
+}
+
 // K1e — once per vxh_grid_bin call on the partition strategy: fold the `parts` accumulator blocks of every
 // (aggregator, cell) into the aggregator's grid (replica 0) and put the identity back, so that the next call finds
 // clean accumulators.  Threads walk the accumulator layout (slab-major: coalesced reads of all parts); the write
@@ -2670,6 +2861,8 @@ void vxh_launch_part_scatter(const PartArgs &args, const LaunchPlan &plan, int s
             if (args.nvals == 0) { if (masked) VXH_SC((part_scatter_wv<1, 0, true, false, 1>)); else VXH_SC((part_scatter_wv<1, 0, false, false, 1>)); }
             else { if (masked) VXH_SC((part_scatter_wv<1, 1, true, false, 1>)); else VXH_SC((part_scatter_wv<1, 1, false, false, 1>)); }
         }
+        else if (hot && args.wv_direct == 3 && masked) { if (args.nvals == 0) VXH_SC((part_scatter_wv<2, 0, true, true, 0, 3>)); else VXH_SC((part_scatter_wv<2, 1, true, true, 0, 3>)); }
+        else if (hot && args.wv_direct == 3) { if (args.nvals == 0) VXH_SC((part_scatter_wv<2, 0, false, true, 0, 3>)); else VXH_SC((part_scatter_wv<2, 1, false, true, 0, 3>)); }
         else if (hot && args.wv_direct == 2) { if (args.nvals == 0) VXH_SC((part_scatter_wv<2, 0, false, true, 0, 2>)); else VXH_SC((part_scatter_wv<2, 1, false, true, 0, 2>)); }
         else if (hot && args.wv_direct && masked) { if (args.nvals == 0) VXH_SC((part_scatter_wv<2, 0, true, true, 0, 1>)); else VXH_SC((part_scatter_wv<2, 1, true, true, 0, 1>)); }
         else if (hot && args.wv_direct) { if (args.nvals == 0) VXH_SC((part_scatter_wv<2, 0, false, true, 0, 1>)); else VXH_SC((part_scatter_wv<2, 1, false, true, 0, 1>)); }
@@ -2753,6 +2946,14 @@ void vxh_launch_part_reduce(const PartArgs &args, const LaunchPlan &plan, hipStr
         if (plan.lds_bytes > 48 * 1024) (void)hipFuncSetAttribute((const void *)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds_bytes); \
         hipLaunchKernelGGL(KERNEL, dim3(plan.blocks), dim3(plan.block), plan.lds_bytes, stream, args);                 \
     } while (0)
+    if (args.wv_direct == 3) { // grouped queue layout (the host checks the signature: what part_reduce_fast serves)
+        if (!fast) throw std::runtime_error("vaex_hip internal: the grouped queue layout needs part_reduce_grp's signature");
+        if (args.A.nagg == 1) VXH_RD(part_reduce_grp<1>);
+        else if (args.A.nagg == 2) VXH_RD(part_reduce_grp<2>);
+        else if (args.A.nagg == 3) VXH_RD(part_reduce_grp<3>);
+        else VXH_RD(part_reduce_grp<4>);
+        return;
+    }
     if (args.qrec12 && !fast) throw std::runtime_error("vaex_hip internal: 12-byte queue records need part_reduce_fast");
     if (!fast && args.A.count16) VXH_RD(part_reduce<true>);
     else if (!fast) VXH_RD(part_reduce<false>);

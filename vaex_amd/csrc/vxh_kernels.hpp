@@ -127,6 +127,11 @@ struct PartArgs {
     // blocks of its sub-queue.  (qblk == 0: the older kernels' layout — one contiguous run of records per sub-queue.)
     int32_t qblk, qtab_stride;
     uint32_t *qtab;
+    // wv_direct == 3: the queue is `parts` REGIONS of cap records (= cap / 64 groups) in qidx (uint16 local indices) and qval[0];
+    // a pass-1 wave of workgroup b reserves blocks of qblk GROUPS from qcount[b % parts] (counted in groups), writes the groups a
+    // block really holds to qtab[region * qtab_stride + block] and every group's header — byte s = records of slabs 0..s, byte
+    // S - 1 = records of the group — to qhdr[region * (cap / 64) + group]
+    unsigned long long *qhdr;
     // "hot box" (part_scatter_f64<2,1,4,0,HOT=true>): a w x h rectangle of cells — chosen from a sample of the
     // call's rows as the densest one that fits — is aggregated in LDS by pass 1 itself (fp64 sum + uint32 count per
     // cell); only rows outside it (and rows whose value is NaN) are emitted as records.  Each pass-1 workgroup
@@ -159,6 +164,12 @@ struct PartArgs {
 #define VXH_WV_SHARED_NB 16u
 #define VXH_WV_SHARED_LDS(S) ((((size_t)(S) * 4 + 15) & ~(size_t)15) + (size_t)(S) * VXH_WV_SHARED_NB * 16)
 #define VXH_WV_WAVE_LDS_DIRECT(S) ((((size_t)(S) * 20) + 15) & ~(size_t)15)
+// wv_direct == 3 (round 4, "grouped"): ONE record stream per wave.  Cold records are compacted (ballot / mbcnt) into a wave-private
+// LDS ring of 2 x 64 records {value 8 B | flat cell index 4 B}; every 64 of them leave as one GROUP: sorted by slab inside the
+// group, written as whole aligned lines (512 B of values + 128 B of uint16 local indices, non-temporal) plus an 8-byte header of
+// the slabs' end offsets.  Pass 2 (part_reduce_grp) reads, of every group, the segment of its own slab.
+#define VXH_WV_GROUP 64u
+#define VXH_WV_WAVE_LDS_GROUPED ((size_t)(2 * VXH_WV_GROUP) * 12)
 #define VXH_WV_WAVE_LDS(NVAL, S) ((((size_t)(S) * VXH_WV_D * (2 + 8 * (size_t)(NVAL)) + (size_t)(S) * 4) + 15) & ~(size_t)15)
 
 struct HotMergeArgs {
