@@ -66,10 +66,14 @@ def same(a, b, what):
         assert np.ma.isMaskedArray(x) == np.ma.isMaskedArray(y), (what, c, type(x), type(y))
         x, y = np.ma.getdata(x), np.ma.getdata(y)
         assert x.dtype == y.dtype, (what, c, x.dtype, y.dtype)
-        if x.dtype.kind in "iub":
+        if x.dtype.kind in "iub":   # keys, counts, integer sums / extrema: exact
             assert np.array_equal(x, y), (what, c)
-        else:
+        elif set(c.lower().split("_")) & {"sd", "va", "std", "var"}:   # variances / standard deviations: the cancellation bound (tests/cases.py)
             assert np.allclose(x, y, rtol=1e-9, atol=1e-12, equal_nan=True), (what, c, np.nanmax(np.abs(x - y)))
+        else:   # fp64 sums / means / extrema: 1e-12 of the value or of the column's largest magnitude (<= sum|v| of that group)
+            fin = np.abs(y[np.isfinite(y)])
+            scale = max(float(fin.max()) if fin.size else 0.0, 1.0)
+            assert np.allclose(x, y, rtol=1e-12, atol=1e-12 * scale, equal_nan=True), (what, c, np.nanmax(np.abs(x - y)))
 
 A = vaex.agg
 taken = [

@@ -1517,6 +1517,7 @@ static void run_part_chunk(Slot &slot, const BinArgs &planned, const LaunchPlan 
         throw std::runtime_error("vaex_hip internal: hot box prepared for a signature pass 1 does not serve");
     }
     slot.last_pass1 = wv ? (P.wv_direct ? 2 + P.wv_direct : 2) : (blk ? 1 : 0);
+    slot.last_slabs = (int)S;
     vxh_launch_part_scatter(P, plan, scatter_blocks, scatter_lds, slot.stream);
     HIP_CHECK(hipGetLastError());
     if (c.cfg_part_overlap) {
@@ -1808,6 +1809,7 @@ int vxh_config_get(const char *key, int64_t *value) {
     else if (k == "wv_block") *value = c.cfg_wv_block;
     else if (k == "part_cap") *value = c.cfg_part_cap;
     else if (k == "redo_count") *value = get_slot(0).redo_count;
+    else if (k == "last_slabs") *value = get_slot(0).last_slabs;
     else if (k == "hot_min_rows") *value = c.cfg_hot_min_rows;
     else if (k == "hot_min_pct") *value = c.cfg_hot_min_pct;
     else if (k == "hot_cache") *value = c.cfg_hot_cache;

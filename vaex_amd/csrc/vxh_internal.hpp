@@ -185,6 +185,7 @@ struct Slot {
     size_t sel_cap = 0;
     size_t fin_cap = 0;
     const char *last_kernel = "";
+    int last_slabs = 0; // partition strategy, most recent chunk: slabs of pass 2
     int last_pass1 = 0; // partition strategy, most recent chunk: 0 part_scatter / part_scatter_f64, 1 part_scatter_blk, 2 part_scatter_wv, 3 its ring-less variant
 };
 

@@ -1957,8 +1957,14 @@ __global__ void __launch_bounds__(1024) part_scatter_wv(const PartArgs P) {
         }
         if (gcur != VXH_WV_NONE) {
             const uint64_t rec = ((uint64_t)part * P.cap) + (uint64_t)gcur * GR + lane;
-            if (NVAL) __builtin_nontemporal_store(v2, P.qval[0] + rec);
-            __builtin_nontemporal_store((uint16_t)l2, (uint16_t *)P.qidx + rec);
+            if (P.no_pipeline & 2) { // (timing experiments: bit 1 keeps the groups out of HBM — results wrong on purpose)
+            } else if (P.no_pipeline & 256) { // (timing experiments: bit 8 = ordinary stores)
+                if (NVAL) P.qval[0][rec] = v2;
+                ((uint16_t *)P.qidx)[rec] = (uint16_t)l2;
+            } else {
+                if (NVAL) __builtin_nontemporal_store(v2, P.qval[0] + rec);
+                __builtin_nontemporal_store((uint16_t)l2, (uint16_t *)P.qidx + rec);
+            }
             if (lane == 0) P.qhdr[(uint64_t)part * (P.cap / GR) + gcur] = hdr;
             ++gcur;
         } else if (live) { // region full (pathologically skewed data): device atomics straight into the grids
@@ -2558,46 +2564,59 @@ __global__ void __launch_bounds__(1024) part_reduce_grp(const PartArgs P) {
     const uint16_t *const locs = (const uint16_t *)P.qidx + (uint64_t)part * P.cap;
     const uint32_t sh0 = slab ? 8u * (slab - 1u) : 0u, sh1 = 8u * slab;
     const uint32_t sub = lane & 15u, quad = lane >> 4; // 16 lanes per group, 4 groups per trip
+    // segment [s0, s1) of this workgroup's slab inside group `gi` of the 64 whose headers the lanes hold
+    auto segment = [&](unsigned long long h_mine, uint32_t gi, uint32_t &s0, uint32_t &s1) {
+        const uint32_t hlo = (uint32_t)__shfl((int)(uint32_t)h_mine, (int)gi, 64), hhi = (uint32_t)__shfl((int)(uint32_t)(h_mine >> 32), (int)gi, 64);
+        const unsigned long long h = ((unsigned long long)hhi << 32) | hlo;
+        s0 = slab ? (uint32_t)(h >> sh0) & 0xffu : 0u;
+        s1 = (uint32_t)(h >> sh1) & 0xffu;
+    };
     for (uint32_t b = wave; b < nblk; b += nwave) {
         const uint32_t ng = P.qtab[(size_t)part * (uint32_t)P.qtab_stride + b];
         const uint32_t G0 = b * GB;
+        // the headers of the NEXT 64 groups are requested before this chunk's records: one dependent round trip per chunk, not two
+        unsigned long long h_next = lane < ng ? hdrs[G0 + lane] : 0ull;
         for (uint32_t c0 = 0; c0 < ng; c0 += 64u) {
-            const uint32_t here = ng - c0 < 64u ? ng - c0 : 64u; // groups of this chunk
-            const unsigned long long h_mine = lane < here ? hdrs[G0 + c0 + lane] : 0ull;
-            for (uint32_t t0 = 0; t0 < here; t0 += 16u) { // four trips of four groups: their loads in flight together
-                uint32_t loc[4], end[4], at[4];
-                uint64_t vb[4];
-                bool ok[4];
+            const unsigned long long h_mine = h_next;
+            h_next = c0 + 64u + lane < ng ? hdrs[G0 + c0 + 64u + lane] : 0ull; // (beyond the block: 0 = empty segments)
+            // all sixteen trips' record loads in flight together (4 groups per trip, 16 lanes per group)
+            uint32_t loc[16];
+            uint64_t vb[16];
+            uint32_t okmask = 0, longmask = 0;
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const uint32_t gi = t0 + 4u * (uint32_t)u + quad; // (< 64: the header of a group beyond `here` is 0 — an empty segment)
-                    const uint32_t hlo = (uint32_t)__shfl((int)(uint32_t)h_mine, (int)gi, 64), hhi = (uint32_t)__shfl((int)(uint32_t)(h_mine >> 32), (int)gi, 64);
-                    const unsigned long long h = ((unsigned long long)hhi << 32) | hlo;
-                    const uint32_t s0 = slab ? (uint32_t)(h >> sh0) & 0xffu : 0u;
-                    end[u] = (uint32_t)(h >> sh1) & 0xffu;
-                    at[u] = (G0 + c0 + gi) * GR + s0 + sub; // record index inside the region
-                    ok[u] = s0 + sub < end[u];
-                    end[u] = (G0 + c0 + gi) * GR + end[u];
-                    vb[u] = 0ull;
-                    loc[u] = 0u;
-                    if (ok[u]) {
-                        loc[u] = locs[at[u]];
-                        if (P.nvals) vb[u] = vals[at[u]];
-                    }
+            for (int u = 0; u < 16; ++u) {
+                const uint32_t gi = 4u * (uint32_t)u + quad;
+                uint32_t s0, s1;
+                segment(h_mine, gi, s0, s1);
+                const uint32_t at = (G0 + c0 + gi) * GR + s0 + sub; // record index inside the region
+                const bool ok = s0 + sub < s1;
+                okmask |= (ok ? 1u : 0u) << u;
+                longmask |= (s1 - s0 > 16u ? 1u : 0u) << u;
+                loc[u] = 0u;
+                vb[u] = 0ull;
+                if (ok) {
+                    loc[u] = locs[at];
+                    if (P.nvals) vb[u] = vals[at];
                 }
+            }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) grp_apply<NAGG>(P, lds, loc[u], vb[u], ok[u], off, kind, vs, mom);
-                // segments longer than 16 records (one in five hundred with eight slabs): the rest, 16 at a time
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    uint32_t r = at[u] + 16u;
-                    while (__ballot(r < end[u])) {
-                        const bool more = r < end[u];
+            for (int u = 0; u < 16; ++u) grp_apply<NAGG>(P, lds, loc[u], vb[u], ((okmask >> u) & 1u) != 0u, off, kind, vs, mom);
+            // segments longer than 16 records (one in five hundred with eight slabs): the rest, 16 at a time
+            if (__ballot(longmask != 0u)) {
+                for (uint32_t u = 0; u < 16u; ++u) {
+                    if (!__ballot(((longmask >> u) & 1u) != 0u)) continue;
+                    const uint32_t gi = 4u * u + quad;
+                    uint32_t s0, s1;
+                    segment(h_mine, gi, s0, s1);
+                    uint32_t r = s0 + sub + 16u;
+                    while (__ballot(r < s1)) {
+                        const bool more = r < s1;
+                        const uint32_t at = (G0 + c0 + gi) * GR + r;
                         uint32_t l = 0;
                         uint64_t v = 0;
                         if (more) {
-                            l = locs[r];
-                            if (P.nvals) v = vals[r];
+                            l = locs[at];
+                            if (P.nvals) v = vals[at];
                         }
                         grp_apply<NAGG>(P, lds, l, v, more, off, kind, vs, mom);
                         r += 16u;
