@@ -717,7 +717,7 @@ def test_grouped_pass1(sa, variant):
                 sa.config_set(k, 62 if k == "hot_direct_pct" else 0)
         return [np.array(a.get_result()) for a in aggs], kernel
 
-    knobs = dict(tiny_blocks=dict(wv_block=64), region_overflow=dict(part_cap=4096), sigma2=dict(hot_direct_pct=20)).get(variant, {})   # (sigma2: the ring-less family down to a 20 % box, where the default hands over to part_scatter_blk at 62 %)
+    knobs = dict(tiny_blocks=dict(wv_block=64), region_overflow=dict(part_cap=4096), sigma2=dict(hot_direct_pct=20), count_only=dict(strategy=4)).get(variant, {})   # (sigma2: the ring-less family down to a 20 % box, where the default hands over to part_scatter_blk at 62 %)
     redo0 = sa.config_get("redo_count")
     got, kernel = run(n, 5, **knobs)
     redone = sa.config_get("redo_count") - redo0
@@ -727,7 +727,7 @@ def test_grouped_pass1(sa, variant):
     assert kernel.startswith("part_scatter_grouped_hot"), kernel
     if variant == "region_overflow":
         assert redone >= 1 or sa.config_get("hot_cnt16_used") == 0
-    want, kernel3 = run(n, 3, **{k: val for k, val in knobs.items() if k == "hot_direct_pct"})
+    want, kernel3 = run(n, 3, **{k: val for k, val in knobs.items() if k in ("hot_direct_pct", "strategy")})
     assert kernel3.startswith("part_scatter_direct_hot"), kernel3
     vabs = torch.nan_to_num(v.to(torch.float64)).abs().max().item()
     for k, (a, b) in enumerate(zip(got, want)):

@@ -89,7 +89,7 @@ def test_two_hip_processes_reduce_over_gloo(sa):
     ref = oracle.ref_module("superagg")
     want = _calls(Frame(dict(cols, sel=(cols["v"] > 3).astype(np.uint8)), chunk_size=1 << 18, nthreads=1, superagg=RefAdapter(ref)), agg, selection="sel") if ref is not None else whole
     for rank, res in sorted(got):
-        assert res["kernel_binned"] == whole["kernel_binned"] and not res["kernel_binned"].startswith("ref"), res["kernel_binned"]   # (the HIP kernels ran in the rank)
+        assert res["kernel_binned"] and not res["kernel_binned"].startswith("ref"), res["kernel_binned"]   # (a HIP kernel's name: the rank computed on the device; half the rows may take another strategy than the whole table)
         for name, w in want.items():
             if isinstance(w, str):
                 continue

@@ -1196,7 +1196,7 @@ static void hot_prepare(Slot &slot, const BinArgs &A, const BinArgs &planned, co
     H.last_on = true;
 }
 
-static void hot_merge(Slot &slot, const BinArgs &planned) {
+static HotMergeArgs hot_merge_args(Slot &slot, const BinArgs &planned) {
     const Slot::Hot &H = slot.hot;
     HotMergeArgs M{};
     M.x0 = H.x0; M.y0 = H.y0; M.w = H.w; M.h = H.h;
@@ -1213,7 +1213,10 @@ static void hot_merge(Slot &slot, const BinArgs &planned) {
         M.takes_sum[k] = planned.a[k].kind == VXH_AGG_SUM ? 1 : (planned.a[k].kind == VXH_AGG_SUM_MOMENT ? 2 : 0);
         if (planned.a[k].kind == VXH_AGG_SUM && planned.a[k].cell == VXH_CELL_I64) M.val_i64 = 1; // (hot_eligible: then every sum is one)
     }
-    vxh_launch_hot_merge(M, slot.stream);
+    return M;
+}
+static void hot_merge(Slot &slot, const BinArgs &planned) {
+    vxh_launch_hot_merge(hot_merge_args(slot, planned), slot.stream);
     HIP_CHECK(hipGetLastError());
 }
 
@@ -1253,7 +1256,7 @@ static void part_acc_prepare(Slot &slot, const BinArgs &planned) {
     }
 }
 
-static void part_acc_merge(Slot &slot, const BinArgs &planned) {
+static PartMergeArgs part_merge_args(Slot &slot, const BinArgs &planned) {
     PartMergeArgs M{};
     const uint64_t S = 1ull << planned.slab_log2;
     M.cells = planned.cells;
@@ -1269,7 +1272,10 @@ static void part_acc_merge(Slot &slot, const BinArgs &planned) {
         M.cell[k] = planned.a[k].cell;
         M.ident[k] = device_identity(planned.a[k].kind, planned.a[k].dtype, planned.a[k].cell);
     }
-    vxh_launch_part_merge(M, slot.stream);
+    return M;
+}
+static void part_acc_merge(Slot &slot, const BinArgs &planned) {
+    vxh_launch_part_merge(part_merge_args(slot, planned), slot.stream);
     HIP_CHECK(hipGetLastError());
 }
 
@@ -1759,6 +1765,7 @@ int vxh_config_set(const char *key, int64_t value) {
     else if (k == "wv_waves_grouped") c.cfg_wv_waves_grouped = value > 0 ? value : 8;
     else if (k == "wv_block") c.cfg_wv_block = value;
     else if (k == "part_cap") c.cfg_part_cap = value;
+    else if (k == "merge_fused") c.cfg_merge_fused = value;
     else if (k == "hot_min_rows") c.cfg_hot_min_rows = value > 0 ? value : (1 << 24);
     else if (k == "hot_min_pct") c.cfg_hot_min_pct = value > 0 ? value : 10;
     else if (k == "hot_direct_pct") c.cfg_hot_direct_pct = value > 0 ? value : 62;
@@ -1808,6 +1815,7 @@ int vxh_config_get(const char *key, int64_t *value) {
     else if (k == "hot_direct_pct") *value = c.cfg_hot_direct_pct;
     else if (k == "wv_block") *value = c.cfg_wv_block;
     else if (k == "part_cap") *value = c.cfg_part_cap;
+    else if (k == "merge_fused") *value = c.cfg_merge_fused;
     else if (k == "redo_count") *value = get_slot(0).redo_count;
     else if (k == "last_slabs") *value = get_slot(0).last_slabs;
     else if (k == "hot_min_rows") *value = c.cfg_hot_min_rows;
@@ -2225,10 +2233,17 @@ int vxh_grid_bin(vxh_grid *grid, int thread, vxh_agg *const *aggs, int n_aggs, u
         }
         if (whole.strategy == VXH_STRAT_PART) {
             part_join(slot);
-            part_acc_merge(slot, whole_args);
+            const bool fused_merge = slot.hot.on && ctx().cfg_merge_fused != 0; // both merges in one launch ("merge_fused" = 0: the two kernels of rounds 1-3)
+            if (fused_merge) {
+                const HotMergeArgs hm = hot_merge_args(slot, whole_args);
+                vxh_launch_merge_fused(part_merge_args(slot, whole_args), &hm, slot.stream);
+                HIP_CHECK(hipGetLastError());
+            } else {
+                part_acc_merge(slot, whole_args);
+            }
             if (slot.last_pass1 >= 2) slot.last_kernel = (whole.fast_f64 || whole.fast_f32 || whole.vals_f32 || (whole.bin_f32 && whole.fast_vals)) ? "part_scatter_wv+part_reduce_f64" : ((whole.vals_i64 || whole.vals_i32) ? "part_scatter_wv+part_reduce_i64" : "part_scatter_wv+part_reduce_generic");
             if (slot.hot.on) {
-                hot_merge(slot, whole_args);
+                if (!fused_merge) hot_merge(slot, whole_args);
                 slot.last_kernel = slot.last_pass1 == 5 ? ((whole.vals_i64 || whole.vals_i32) ? "part_scatter_grouped_hot+part_reduce_grp_i64" : "part_scatter_grouped_hot+part_reduce_grp_f64") : slot.last_pass1 == 4 ? "part_scatter_shared_hot+part_reduce_f64" : slot.last_pass1 == 3 ? ((whole.vals_i64 || whole.vals_i32) ? "part_scatter_direct_hot+part_reduce_i64" : "part_scatter_direct_hot+part_reduce_f64") : (slot.last_pass1 == 2 ? "part_scatter_wv_hot+part_reduce_f64" : "part_scatter_hot+part_reduce_f64");
             }
             slot.hot.on = false;

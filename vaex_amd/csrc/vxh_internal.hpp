@@ -219,6 +219,7 @@ struct Context {
                                    // straight from the registers into per-(wave, slab) queue blocks, 4 = into per-(workgroup, slab) blocks (<= 16 slabs)
                                    // (profiles/r02_direct_ab.txt: 158 / 157 / 177 / 177 Grows/s on the bench pass)
     int64_t cfg_wv_block = 0;      // ... records per queue block of a (wave, slab) (0 = sized from the expected share); tests force tiny blocks
+    int64_t cfg_merge_fused = 1;   // the box merge and the partition-accumulator merge in ONE launch (0: part_merge + part_hot_merge)
     int64_t cfg_part_cap = 0;      // ... records per sub-queue (0 = sized from the expected share); tests force tiny queues to reach the slow path
     int64_t cfg_wv_waves_grouped = 8; // ... waves per workgroup of the grouped variant ("wv" = 5): 1.5 KB of ring each
     int64_t cfg_wv_waves_direct = 16; // ... waves per workgroup of the ring-less variant ("wv" = 3, next to a hot box)
