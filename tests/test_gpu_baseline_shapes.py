@@ -506,7 +506,7 @@ def test_hot_box_packed_counters_are_exact(sa, scenario):
                 sa.config_set(k, 0)
         redone = sa.config_get("redo_count") - redo0
         got = [np.array(a.get_result()) for a in aggs]
-        assert sa.last_kernel(0).startswith("part_scatter_direct_hot"), sa.last_kernel(0)
+        assert sa.last_kernel(0).startswith(("part_scatter_direct_hot", "part_scatter_grouped_hot")), sa.last_kernel(0)
         assert used == dict(normal=2, piled=0, hidden_pile=1, forced_flush=2, queue_overflow=0, pile_and_queue_overflow=0)[scenario], used   # (what the call ENDED on)
         assert redone == dict(normal=0, hidden_pile=1, forced_flush=0, queue_overflow=1).get(scenario, redone), redone
         if scenario in ("piled", "pile_and_queue_overflow"):   # (uint16 -> uint32, or uint8 -> uint16 -> uint32; both flags at once: uint32 at once)
@@ -615,7 +615,7 @@ def test_other_value_dtypes_ride_the_fast_kernels(sa, shape, vdtype):
     if not (narrow and shape in ("three_d", "groupby_key")):
         assert kernel.startswith("part_scatter") and kernel.endswith("_f64" if floats else "_i64"), kernel
     if shape == "bench_2d":
-        assert kernel.startswith("part_scatter_direct_hot"), kernel
+        assert kernel.startswith(("part_scatter_direct_hot", "part_scatter_grouped_hot")), kernel
     m = 4_000_000
     head, _ = run(0, m)
     rest, _ = run(m, n)

@@ -173,3 +173,37 @@ def test_frame_results_with_cached_columns_and_selection():
         got = f.mean("v", binby=["x", "y"], limits=[[-4, 4], [-4, 4]], shape=32, selection="s")
         assert np.allclose(got, ref, rtol=1e-12, atol=0, equal_nan=True)
     assert sa.cache_stats()["hits"] > 0
+
+
+@pytest.mark.parametrize("mode", ["r", "c", "r+"])
+def test_memory_mapped_files_stream_and_cache(tmp_path, mode):
+    """north_star: "column chunks streamed from memory-mapped HDF5 / Arrow into pinned host buffers".  What vaex hands the aggregators
+    for an opened file is a numpy view of a memory MAPPING (vaex/dataset.py:506-531 over np.memmap / mmap'ed HDF5 datasets): the columns
+    here are real files mapped read-only ("r": PROT_READ pages, the way vaex.open maps them — page-locking them takes
+    hipHostRegisterReadOnly), copy-on-write ("c") and read-write ("r+").  Streamed chunk by chunk, then registered with the device
+    column cache (pin=True: the mapping itself is page-locked) and served from HBM on the second pass."""
+    import vaex_amd
+    x, v, sel = _data(1_500_001, 7)
+    want = _expected(x, v, -4, 4, 64)
+    fx, fv = tmp_path / "x.f8", tmp_path / "v.f8"
+    x.tofile(fx); v.tofile(fv)
+    mx = np.memmap(fx, dtype="f8", mode=mode, shape=(len(x),))
+    mv = np.memmap(fv, dtype="f8", mode=mode, shape=(len(v),))
+    assert isinstance(mx, np.memmap) and (mode != "r" or not mx.flags.writeable)
+    for feeder in (1, 2):
+        sa.config_set("feeder", feeder)
+        c, s = _stream(mx, mv, 1 << 17, slots=2)
+        assert np.array_equal(c, want[0]) and np.array_equal(s, want[1]), (mode, feeder)
+    sa.config_set("feeder", 1)
+    assert vaex_amd.cache_columns({"x": mx, "v": mv}, pin=True) == x.nbytes + v.nbytes
+    st0 = sa.cache_stats()
+    c, s = _stream(mx, mv, 1 << 18, slots=2)
+    st1 = sa.cache_stats()
+    assert np.array_equal(c, want[0]) and np.array_equal(s, want[1])
+    assert st1["misses"] > st0["misses"]
+    c, s = _stream(mx, mv, 1 << 18, slots=2)
+    st2 = sa.cache_stats()
+    assert np.array_equal(c, want[0]) and np.array_equal(s, want[1])
+    assert st2["hits"] - st1["hits"] == 2 * -(-len(x) // (1 << 18)) and st2["misses"] == st1["misses"]
+    vaex_amd.uncache_columns()
+    del mx, mv

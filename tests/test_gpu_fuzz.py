@@ -8,7 +8,7 @@ from tests import cases
 
 pytestmark = pytest.mark.gpu
 
-WV_DEFAULT = 3  # pass 1 next to a hot box: part_scatter_wv without rings
+WV_DEFAULT = 5  # pass 1 next to a hot box: part_scatter_wv, cold records in slab-sorted groups (3: without rings, one record stream per (wave, slab))
 KEYS = ("strategy", "wv", "wv_waves", "wv_waves_direct", "wv_block", "blk", "hot", "hot_min_rows", "hot_min_pct", "hot_x0", "hot_y0", "hot_w", "hot_h", "part_chunk", "count16")
 
 
@@ -49,8 +49,8 @@ def test_fuzz_against_oracle(sa, gpu_ready, seed):
         sa.config_set("strategy", int(rng.choice([0, 0, 4, 4, 3])))
         sa.config_set("blk", int(rng.choice([1, 2, 0])))
         # third-generation pass 1 (part_scatter_wv): off / auto / also next to a hot box / there without rings, one record
-        # stream per (wave, slab) / per (workgroup, slab)
-        wv = int(rng.integers(0, 2)) * (1 + seed % 4)
+        # stream per (wave, slab) / per (workgroup, slab) / slab-sorted groups in one stream per wave
+        wv = int(rng.integers(0, 2)) * (1 + seed % 5)
         sa.config_set("wv", wv)
         sa.config_set("wv_waves_direct", [16, 8, 4, 12][seed % 4])
         sa.config_set("wv_waves", [4, 6, 8, 12, 16][seed % 5])

@@ -369,6 +369,17 @@ static void agg_alloc_device(vxh_agg *a) {
     a->used = 1;
 }
 
+// "the grids were rewritten on slot 0's stream" (vxh_allreduce, vxh_agg_reset): later vxh_grid_bin calls on OTHER slots' streams wait for this event
+static void grids_event_record(Slot &s0) {
+    Context &c = ctx();
+    {
+        std::lock_guard<std::mutex> lock(c.mutex);
+        if (!c.reduced) HIP_CHECK(hipEventCreateWithFlags(&c.reduced, hipEventDisableTiming));
+    }
+    HIP_CHECK(hipEventRecord(c.reduced, s0.stream));
+    c.reduced_set = true;
+}
+
 // replicas [0, upto) hold the identity or data (caller holds a->mutex); a rare, one-off event per aggregator, hence the wait:
 // launches of other slots' streams may use the new replicas next
 static void agg_init_replicas(vxh_agg *a, int upto) {
@@ -1766,6 +1777,7 @@ int vxh_config_set(const char *key, int64_t value) {
     else if (k == "wv_block") c.cfg_wv_block = value;
     else if (k == "part_cap") c.cfg_part_cap = value;
     else if (k == "merge_fused") c.cfg_merge_fused = value;
+    else if (k == "hot_chunk_factor") c.cfg_hot_chunk_factor = value > 0 ? value : 4;
     else if (k == "hot_min_rows") c.cfg_hot_min_rows = value > 0 ? value : (1 << 24);
     else if (k == "hot_min_pct") c.cfg_hot_min_pct = value > 0 ? value : 10;
     else if (k == "hot_direct_pct") c.cfg_hot_direct_pct = value > 0 ? value : 62;
@@ -1816,6 +1828,7 @@ int vxh_config_get(const char *key, int64_t *value) {
     else if (k == "wv_block") *value = c.cfg_wv_block;
     else if (k == "part_cap") *value = c.cfg_part_cap;
     else if (k == "merge_fused") *value = c.cfg_merge_fused;
+    else if (k == "hot_chunk_factor") *value = c.cfg_hot_chunk_factor;
     else if (k == "redo_count") *value = get_slot(0).redo_count;
     else if (k == "last_slabs") *value = get_slot(0).last_slabs;
     else if (k == "hot_min_rows") *value = c.cfg_hot_min_rows;
@@ -2164,7 +2177,11 @@ int vxh_grid_bin(vxh_grid *grid, int thread, vxh_agg *const *aggs, int n_aggs, u
             step = (uint64_t)std::max<int64_t>(1 << 20, ctx().cfg_part_chunk);
             part_acc_prepare(slot, whole_args);
             hot_prepare(slot, A, whole_args, whole, length);
-            if (slot.hot.on && slot.hot.gen2 && ctx().cfg_hot_box[2] <= 0) step *= 2; // (see the capacity rule in run_part_chunk)
+            // (see the capacity rule in run_part_chunk: only the cold rows are queued, the same scratch serves a longer chunk.  Round 4: four times,
+            //  i.e. ONE chunk per 2^30 rows — the bench pass 5.20 -> 5.09 ms with the ring-less pass 1, 5.07 -> 4.98 with the grouped one,
+            //  profiles/r04_headline_ab.txt: a second launch pair costs its tails and pass 2's fixed LDS init / flush)
+            //  (a box that holds less than half of the rows leaves queues as long as without it: twice, as before)
+            if (slot.hot.on && slot.hot.gen2 && ctx().cfg_hot_box[2] <= 0) step *= slot.hot.last_fraction >= 0.5 ? (uint64_t)std::max<int64_t>(1, ctx().cfg_hot_chunk_factor) : 2;
             else if (whole.key_i64 && (whole.fast_vals || whole.vals_i64) && ctx().cfg_part_chunk == (1 << 28)) step *= 2; // groupby on an integer key: 16-byte rows, twice the rows for the same input bytes (8.95 -> 8.66 ms per 1e9 rows, profiles/r02_groupby_tune.txt)
         } else {
             slot.hot.on = slot.hot.last_on = false;
@@ -2937,10 +2954,12 @@ int vxh_agg_reset(vxh_agg *a) {
     VXH_API_BEGIN
     std::lock_guard<std::mutex> lock(a->mutex);
     if (a->dev) {
-        HIP_CHECK(hipDeviceSynchronize());
+        HIP_CHECK(hipDeviceSynchronize()); // nothing in flight touches the grids
         Slot &s0 = get_slot(0);
         vxh_launch_fill(a->dev, (uint64_t)a->used * a->grid->length1d, a->cell, &a->identity, s0.stream);
-        HIP_CHECK(hipStreamSynchronize(s0.stream));
+        // No wait for the fill: slot 0's later work is behind it on the same stream, the other slots' streams wait for the event
+        // (vxh_grid_bin), readers of the grid drain the device first (agg_fold_device).  A df.count pass resets three grids: 3 x ~15 us.
+        grids_event_record(s0);
         a->folded = true;
         a->used = 1;
         a->auth = AUTH_DEVICE;
@@ -3066,12 +3085,7 @@ int vxh_allreduce(vxh_agg *const *aggs, int n_aggs, vxh_comm *comm) {
         aggs[k]->auth = AUTH_DEVICE;
     }
     // whoever bins into these grids next from another slot's stream waits for the collective (vxh_grid_bin)
-    {
-        std::lock_guard<std::mutex> lock(c.mutex);
-        if (!c.reduced) HIP_CHECK(hipEventCreateWithFlags(&c.reduced, hipEventDisableTiming));
-    }
-    HIP_CHECK(hipEventRecord(c.reduced, s0.stream));
-    c.reduced_set = true;
+    grids_event_record(s0);
     vxh_timer_lap(s0);
     VXH_API_END
 }

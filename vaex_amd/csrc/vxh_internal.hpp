@@ -214,12 +214,14 @@ struct Context {
     int64_t cfg_parts = 0;        // pass-2 workgroups per slab (0 = auto)
     int64_t cfg_part_lds = 0;     // LDS bytes per pass-2 slab (0 = auto)
     int64_t cfg_blk = 1;           // second-generation pass 1 (part_scatter_blk) where its signature allows (0: part_scatter_f64)
-    int64_t cfg_wv = 3;            // third-generation pass 1 (part_scatter_wv: barrier-free): 0 = never; >= 1: with wave-private rings wherever its
+    int64_t cfg_wv = 5;            // third-generation pass 1 (part_scatter_wv: barrier-free): 0 = never; >= 1: with wave-private rings wherever its
                                    // signature allows and no hot box is on.  Next to a hot box: 1 = part_scatter_blk, 2 = the rings, 3 = no rings, cold records
                                    // straight from the registers into per-(wave, slab) queue blocks, 4 = into per-(workgroup, slab) blocks (<= 16 slabs)
-                                   // (profiles/r02_direct_ab.txt: 158 / 157 / 177 / 177 Grows/s on the bench pass)
+                                   // (profiles/r02_direct_ab.txt: 158 / 157 / 177 / 177 Grows/s on the bench pass); 5 (round 4, default) = compacted into a wave-private ring,
+                                   // slab-sorted 64-record groups in ONE stream per wave + part_reduce_grp (<= 8 slabs, 8-byte columns; otherwise as 3)
     int64_t cfg_wv_block = 0;      // ... records per queue block of a (wave, slab) (0 = sized from the expected share); tests force tiny blocks
-    int64_t cfg_merge_fused = 1;   // the box merge and the partition-accumulator merge in ONE launch (0: part_merge + part_hot_merge)
+    int64_t cfg_merge_fused = 0;   // 1: the box merge and the partition-accumulator merge in ONE launch (measured: 5.204 vs 5.174 ms for the two launches — its grid adds are all atomics; kept as a knob)
+    int64_t cfg_hot_chunk_factor = 4; // rows per partition chunk next to a hot box = this x part_chunk
     int64_t cfg_part_cap = 0;      // ... records per sub-queue (0 = sized from the expected share); tests force tiny queues to reach the slow path
     int64_t cfg_wv_waves_grouped = 8; // ... waves per workgroup of the grouped variant ("wv" = 5): 1.5 KB of ring each
     int64_t cfg_wv_waves_direct = 16; // ... waves per workgroup of the ring-less variant ("wv" = 3, next to a hot box)
