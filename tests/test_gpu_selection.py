@@ -150,3 +150,54 @@ def test_float32_columns_are_compared_in_float32_like_numpy():
             assert np.array_equal(_want_mask(expr, cols), keep), expr
     # the rows ON the constant are what the rounding decides
     assert int((cols["f"] == np.float32(0.3)).sum()) > 10_000 and int((cols["f"].astype("f8") <= 0.3).sum()) != int((cols["f"] <= 0.3).sum())
+
+
+# ------------------------------------------------------------------------------------------------------------
+# round 4: the selection FUSED into the binning kernels (BinArgs::pred) — one selection shared by every aggregator, its terms over
+# one float64 column: no sel_eval pass, no mask byte.  Each shape is binned three ways — fused, through sel_eval's mask
+# ("fuse_selection" = 0) and with a numpy-built mask: the three must agree bit for bit on integer grids (the same rows are kept).
+# ------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape", ["three_d_128", "bench_2d_box", "count_2d_lds", "one_d_big", "two_terms_nan", "std_box", "not_fusable_int", "not_fusable_two_columns"])
+def test_selection_fused_into_the_binning_kernels(shape):
+    import torch
+    g = torch.Generator(device="cuda").manual_seed(77)
+    n = (1 << 25) + 4_321
+    x, y, z = (torch.randn(n, dtype=torch.float64, device="cuda", generator=g) for _ in range(3))
+    v = torch.randn(n, dtype=torch.float64, device="cuda", generator=g) * 2 + 3
+    v[::1000] = float("nan")
+    j = torch.randint(-100, 100, (n,), dtype=torch.int32, device="cuda", generator=g)
+    f = Frame(dict(x=x, y=y, z=z, v=v, j=j))
+    spec = {
+        "three_d_128": ("count", None, ["x", "y", "z"], [[-4, 4]] * 3, 128, "v > 3", "part_scatter_wv", True),
+        "bench_2d_box": ("mean", "v", ["x", "y"], LIM, 256, "v > 3", "part_scatter_", True),               # the selection's column IS the value column
+        "count_2d_lds": ("count", None, ["x", "y"], LIM, 256, "z <= 0.5", "count_lds", True),
+        "one_d_big": ("sum", "v", ["x"], [[-4, 4]], 100_000, "y != 0.25", "part_scatter", True),
+        "two_terms_nan": ("count", None, ["x", "y", "z"], [[-4, 4]] * 3, 128, "~(v >= 1) | (v == 3.5)", "part_scatter_wv", True),   # NaN rows: kept by ~(v >= 1)
+        "std_box": ("std", "v", ["x", "y"], LIM, 256, "(z > -1) & (z < 2)", "part_scatter_", True),
+        "not_fusable_int": ("count", None, ["x", "y", "z"], [[-4, 4]] * 3, 128, "j > 3", "part_scatter_wv", False),
+        "not_fusable_two_columns": ("count", None, ["x", "y", "z"], [[-4, 4]] * 3, 128, "(v > 3) & (x < 1)", "part_scatter_wv", False),
+    }[shape]
+    what, col, binby, lim, shp, expr, kernel_prefix, fusable = spec
+    call = lambda sel: (getattr(f, what)(binby=binby, limits=lim, shape=shp, selection=sel, edges=True) if col is None else getattr(f, what)(col, binby=binby, limits=lim, shape=shp, selection=sel, edges=True))
+    f0, m0 = sa.config_get("pred_fused"), sa.config_get("pred_materialized")
+    fused = np.asarray(call(expr))
+    kernel = sa.last_kernel(0)
+    df, dm = sa.config_get("pred_fused") - f0, sa.config_get("pred_materialized") - m0
+    assert kernel.startswith(kernel_prefix), kernel
+    assert (df > 0 and dm == 0) if fusable else (df == 0), (shape, df, dm, kernel)
+    sa.config_set("fuse_selection", 0)
+    try:
+        through_mask = np.asarray(call(expr))
+    finally:
+        sa.config_set("fuse_selection", 1)
+    cols = dict(x=x, y=y, z=z, v=v, j=j)
+    keep = _want_mask(expr, {k: t.cpu().numpy() for k, t in cols.items() if k in expr})
+    numpy_mask = np.asarray(call(torch.from_numpy(keep.astype(np.uint8)).cuda()))
+    if fused.dtype.kind in "iu":
+        assert np.array_equal(fused, through_mask) and np.array_equal(fused, numpy_mask), shape
+        assert int(fused.sum()) == int(keep.sum())
+    else:   # mean / sum / std of the same kept rows: the kernels differ in their order of addition only
+        for other in (through_mask, numpy_mask):
+            assert np.array_equal(np.isnan(fused), np.isnan(other)), shape
+            tol = 1e-6 if what == "std" else 1e-11
+            assert np.allclose(fused, other, rtol=tol, atol=tol * 20, equal_nan=True), (shape, float(np.nanmax(np.abs(fused - other))))

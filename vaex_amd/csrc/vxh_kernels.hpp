@@ -44,7 +44,22 @@ struct AggDesc {
     uint8_t kind, dtype, flip, cell;
 };
 
+// Fused selection (round 4): every aggregator of the launch shares ONE device-side selection whose terms all read the same float64
+// column; the fast kernels evaluate it on the rows they bin instead of reading a keep-mask that a separate pass (sel_eval) wrote.
+// A term `x <op> c` holds iff bit (relation of x to c: 0 less, 1 equal, 2 greater, 3 unordered = NaN) of `code` is set — numpy's rules:
+// every comparison with NaN is false except != (vxh_select.hip cmp_f64).  keep = bit (outcomes of the terms) of `truth`.
+struct PredDesc {
+    const void *col;   // float64, one element per row of the launch
+    int32_t on;        // 0: no fused selection (aggregator masks, if any, are byte masks)
+    int32_t nterms;    // 1..4
+    uint32_t truth;
+    uint32_t code[4];
+    int32_t op[4];     // the terms as they came (vxh_cmp): what sel_eval needs when a launch cannot take the fused form
+    double c[4];
+};
+
 struct BinArgs {
+    PredDesc pred;
     uint64_t n;     // rows in this launch
     uint64_t cells; // length1d
     int32_t ndim;
