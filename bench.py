@@ -221,7 +221,19 @@ def other_configs(sa, torch, rows, sample_rows):
                   "rows_counted": [int(np.asarray(c3).sum()), int(sel.sum().item())]}
         parity["ok"] = parity["ok"] and parity["rows_counted"][0] == parity["rows_counted"][1]
     out.append(line("configs[2]", "3-D 128^3 count(*) of float64 x,y,z with a boolean selection mask", 25, wall, k_ms, kernel, parity))
-    del df, x, y, z, sel, c3
+    # ---- configs[2]': the same histogram with the selection as an EXPRESSION over a fourth column — evaluated inside the binning
+    # kernel (no mask bytes: x, y, z, v = 32 B/row; through a separate predicate pass it was 8 + 1 + 24 + 1 = 34) ----
+    dfe = Frame(dict(x=x, y=y, z=z, v=v))
+    c3e, wall, k_ms = timed(lambda: dfe.count(binby=["x", "y", "z"], limits=lim3, shape=128, selection="v > 3", edges=True))
+    kernel = sa.last_kernel(0)
+    parity = None
+    if ref is not None:
+        heade = Frame(dict(x=x[:m], y=y[:m], z=z[:m], v=v[:m])).count(binby=["x", "y", "z"], limits=lim3, shape=128, selection="v > 3", edges=True)
+        parity = {"ok": bool(np.array_equal(np.asarray(heade), want)) and bool(np.array_equal(np.asarray(c3e), np.asarray(c3))), "sample_rows": m,
+                  "cells_differ": int((np.asarray(heade) != want).sum()), "equals_the_mask_form_on_all_rows": bool(np.array_equal(np.asarray(c3e), np.asarray(c3))),
+                  "selection_fused_in_kernel": bool(sa.config_get("pred_fused") > 0)}
+    out.append(line("configs[2]'", "3-D 128^3 count(*) of float64 x,y,z, selection = the expression \"v > 3\" over a fourth float64 column (evaluated in the binning kernel)", 32, wall, k_ms, kernel, parity))
+    del df, dfe, x, y, z, sel, c3, c3e
     # ---- configs[3]: groupby on 1e6 int64 keys, agg sum / mean / std of v ----
     k = torch.randint(0, 1_000_000, (rows,), dtype=torch.int64, device="cuda", generator=g)
     spec = {"c": agg.count("v"), "s": agg.sum("v"), "m": agg.mean("v"), "sd": agg.std("v")}

@@ -490,7 +490,7 @@ def test_hot_box_packed_counters_are_exact(sa, scenario):
         grid = sa.Grid([bx, by])
         aggs = [sa.AggCount_int64(grid, 1, 1), sa.AggSum_float64(grid, 1, 1), sa.AggCount_float64(grid, 1, 1)]
         bx.set_data(0, x); by.set_data(0, y); aggs[1].set_data(0, v, 0); aggs[2].set_data(0, v, 0)
-        forced = dict(hot_x0=66, hot_y0=67, hot_w=126, hot_h=125, hot_flush_trips=2) if scenario == "forced_flush" else {}
+        forced = dict(hot_x0=69, hot_y0=70, hot_w=120, hot_h=120, hot_flush_trips=2) if scenario == "forced_flush" else {}   # (fits next to either pass 1's LDS with uint16 sizing)
         if "queue_overflow" in scenario:
             forced = dict(part_cap=2048)   # records per sub-queue: a handful of the 4096 waves' first blocks fit
         redo0 = sa.config_get("redo_count")

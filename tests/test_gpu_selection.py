@@ -180,24 +180,36 @@ def test_selection_fused_into_the_binning_kernels(shape):
     what, col, binby, lim, shp, expr, kernel_prefix, fusable = spec
     call = lambda sel: (getattr(f, what)(binby=binby, limits=lim, shape=shp, selection=sel, edges=True) if col is None else getattr(f, what)(col, binby=binby, limits=lim, shape=shp, selection=sel, edges=True))
     f0, m0 = sa.config_get("pred_fused"), sa.config_get("pred_materialized")
-    fused = np.asarray(call(expr))
-    kernel = sa.last_kernel(0)
-    df, dm = sa.config_get("pred_fused") - f0, sa.config_get("pred_materialized") - m0
-    assert kernel.startswith(kernel_prefix), kernel
-    assert (df > 0 and dm == 0) if fusable else (df == 0), (shape, df, dm, kernel)
-    sa.config_set("fuse_selection", 0)
+    if len(binby) == 3:
+        sa.config_set("strategy", 4)   # (33 M rows into 2.2 M cells: the planner would take device atomics; BASELINE configs[2]'s 1e9 rows take the partition)
     try:
-        through_mask = np.asarray(call(expr))
+        fused = np.asarray(call(expr))
+        kernel = sa.last_kernel(0)
+        df, dm = sa.config_get("pred_fused") - f0, sa.config_get("pred_materialized") - m0
+        assert kernel.startswith(kernel_prefix), kernel
+        assert (df > 0 and dm == 0) if fusable else (df == 0), (shape, df, dm, kernel)
+        sa.config_set("fuse_selection", 0)
+        try:
+            through_mask = np.asarray(call(expr))
+        finally:
+            sa.config_set("fuse_selection", 1)
+        cols = dict(x=x, y=y, z=z, v=v, j=j)
+        keep = _want_mask(expr, {k: t.cpu().numpy() for k, t in cols.items() if k in expr})
+        numpy_mask = np.asarray(call(torch.from_numpy(keep.astype(np.uint8)).cuda()))
     finally:
-        sa.config_set("fuse_selection", 1)
-    cols = dict(x=x, y=y, z=z, v=v, j=j)
-    keep = _want_mask(expr, {k: t.cpu().numpy() for k, t in cols.items() if k in expr})
-    numpy_mask = np.asarray(call(torch.from_numpy(keep.astype(np.uint8)).cuda()))
+        sa.config_set("strategy", 0)
+    _compare_three(shape, what, fused, through_mask, numpy_mask, keep)
+
+
+def _compare_three(shape, what, fused, through_mask, numpy_mask, keep):
     if fused.dtype.kind in "iu":
         assert np.array_equal(fused, through_mask) and np.array_equal(fused, numpy_mask), shape
         assert int(fused.sum()) == int(keep.sum())
     else:   # mean / sum / std of the same kept rows: the kernels differ in their order of addition only
         for other in (through_mask, numpy_mask):
-            assert np.array_equal(np.isnan(fused), np.isnan(other)), shape
-            tol = 1e-6 if what == "std" else 1e-11
-            assert np.allclose(fused, other, rtol=tol, atol=tol * 20, equal_nan=True), (shape, float(np.nanmax(np.abs(fused - other))))
+            if what == "std":   # (a cell with one kept row: s2/n - mean^2 is rounding noise around zero, its root NaN or 1e-8)
+                a, b = np.nan_to_num(fused, nan=0.0), np.nan_to_num(other, nan=0.0)
+                assert np.allclose(a, b, rtol=1e-6, atol=1e-5), (shape, float(np.max(np.abs(a - b))))
+            else:
+                assert np.array_equal(np.isnan(fused), np.isnan(other)), shape
+                assert np.allclose(fused, other, rtol=1e-11, atol=2e-10, equal_nan=True), (shape, float(np.nanmax(np.abs(fused - other))))

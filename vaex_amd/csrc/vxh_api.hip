@@ -1818,6 +1818,7 @@ int vxh_config_set(const char *key, int64_t value) {
     else if (k == "wv_block") c.cfg_wv_block = value;
     else if (k == "part_cap") c.cfg_part_cap = value;
     else if (k == "merge_fused") c.cfg_merge_fused = value;
+    else if (k == "gb_load_pct") c.cfg_gb_load_pct = value > 0 ? value : 50;
     else if (k == "fuse_selection") c.cfg_fuse_selection = value;
     else if (k == "hot_chunk_factor") c.cfg_hot_chunk_factor = value > 0 ? value : 4;
     else if (k == "hot_min_rows") c.cfg_hot_min_rows = value > 0 ? value : (1 << 24);
@@ -1870,6 +1871,7 @@ int vxh_config_get(const char *key, int64_t *value) {
     else if (k == "wv_block") *value = c.cfg_wv_block;
     else if (k == "part_cap") *value = c.cfg_part_cap;
     else if (k == "merge_fused") *value = c.cfg_merge_fused;
+    else if (k == "gb_load_pct") *value = c.cfg_gb_load_pct;
     else if (k == "fuse_selection") *value = c.cfg_fuse_selection;
     else if (k == "pred_fused") *value = get_slot(0).pred_fused;
     else if (k == "pred_materialized") *value = get_slot(0).pred_materialized;
@@ -2137,7 +2139,7 @@ int vxh_grid_bin(vxh_grid *grid, int thread, vxh_agg *const *aggs, int n_aggs, u
             else fsel = a->selection;
         }
         ok = ok && fsel && fsel->n_columns == 1 && fsel->dtype[0] == VXH_F64 && fsel->n_terms >= 1 && fsel->n_terms <= 4;
-        for (int t = 0; ok && t < fsel->n_terms; t++) ok = fsel->term[t].is_int == 0 && fsel->term[t].column == 0;
+        for (int t = 0; ok && t < fsel->n_terms; t++) ok = fsel->term[t].column == 0; // (an integer constant next to a float64 column is compared as float64: vxh_select.hip term_at)
         if (!ok) fsel = nullptr;
     }
     PredDesc call_pred{};

@@ -539,7 +539,9 @@ unsigned run_pipeline(GbArgs &G, int nv, bool merge, uint64_t n, uint64_t groups
     // one payload word: 8 rows per thread per tile (128 KiB of staging) as long as the bucket tables fit beside it
     const int nb_max = 10;
     int nb_log2 = 6;
-    const uint64_t per_bucket = (uint64_t)lines * 4 / 2; // target load 0.5
+    // target load of a bucket's table ("gb_load_pct", default 50 %): 80 % halves the buckets for 2^20 expected groups (512 -> 256
+    // queues to scatter into) at longer probe chains; a bucket that overflows anyway costs a retry with four times the buckets
+    const uint64_t per_bucket = std::max<uint64_t>(64, (uint64_t)lines * 4 * (uint64_t)std::min<int64_t>(95, std::max<int64_t>(10, ctx().cfg_gb_load_pct)) / 100);
     while (nb_log2 < nb_max && ((uint64_t)1 << nb_log2) * per_bucket < std::max<uint64_t>(groups_hint, 1)) nb_log2++;
     struct Events { // (destroyed on every way out, a throwing launch included)
         hipEvent_t e[3] = {nullptr, nullptr, nullptr};
