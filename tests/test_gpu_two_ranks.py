@@ -200,3 +200,46 @@ def test_one_rank_declines_the_fused_pass_and_all_take_the_fallback(sa, gpu_read
         assert info is None   # nobody reports the fused pass
         np.testing.assert_array_equal(g["ks"], w["ks"]); np.testing.assert_array_equal(g["c"], w["c"])
         assert np.all(np.abs(g["s"] - w["s"]) <= 1e-12 * 6 * np.maximum(w["c"], 1))
+
+
+@pytest.mark.parametrize("flavour", ["scattered", "dense"])
+def test_heavy_keys_are_peeled_on_row_sharded_frames(flavour):
+    """round 4 (missing #7): Zipf keys on two ranks.  One key holding a large share of the rows sent a rank to the
+    1 Grows/s fallback and — ranks must agree on their branch — every rank with it.  Now the ranks agree on the UNION of the heavy
+    keys their samples found (`union_keys`), every rank peels that set (the heavy rows: a dense groupby over their ordinals whose grids
+    are all-reduced; the rest: the partitioned pass, partial groups merged across the ranks), and every rank returns the whole table's
+    groups.  Rank 1's shard holds a heavy key rank 0's does not: the union matters."""
+    import torch
+    from vaex_amd.binned import Frame, agg
+    rng = np.random.default_rng(5)
+    n = 6_000_000
+    base = rng.zipf(1.3, n).astype(np.int64)
+    base[base > 300_000] = rng.integers(1, 300_000, int((base > 300_000).sum()))
+    k = base if flavour == "dense" else (base * 2654435761) % (1 << 40)
+    extra = 777_777 if flavour == "dense" else int((424_242 * 2654435761) % (1 << 40))
+    half = n // 2
+    k[half:][rng.random(n - half) < 0.2] = extra    # heavy in rank 1's rows only
+    v = rng.normal(3, 2, n)
+    cols = dict(k=torch.from_numpy(k).cuda(), v=torch.from_numpy(v).cuda())
+    spec = {"c": agg.count(), "s": agg.sum("v"), "m": agg.mean("v"), "cv": agg.count("v")}
+
+    def run(f, rank):
+        f.heavy_key_rows = 1 << 20
+        f.dense_peel_cells = 1 << 12
+        r = f.groupby("k", spec)
+        info = dict(getattr(f, "last_groupby_info", None) or {})
+        return {n_: np.asarray(a) for n_, a in r.items()}, info
+
+    got = _run_ranks(cols, [half], run)
+    whole = Frame(cols)
+    whole.heavy_key_rows = 1 << 62   # (the plain path as the expectation)
+    want = whole.groupby("k", spec)
+    uniq, codes = np.unique(k, return_inverse=True)
+    sabs = np.bincount(codes, weights=np.abs(v), minlength=len(uniq))
+    for rank, (res, info) in enumerate(got):
+        assert info.get("heavy_keys", 0) >= 2, (rank, info)        # the peel ran on every rank, with rank 1's key among the set
+        assert np.array_equal(res["k"], np.asarray(want["k"])) and np.array_equal(res["k"], uniq), rank
+        assert np.array_equal(res["c"], np.asarray(want["c"])) and np.array_equal(res["cv"], np.asarray(want["cv"])), rank
+        assert int(res["c"].sum()) == n
+        assert np.all(np.abs(res["s"] - np.bincount(codes, weights=v, minlength=len(uniq))) <= 1e-12 * sabs), rank
+        assert np.allclose(res["m"], np.asarray(want["m"]), rtol=1e-11, atol=1e-12), rank

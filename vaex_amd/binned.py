@@ -970,11 +970,11 @@ class Frame:
             kmin, kmax = comm.minmax(kmin, kmax)
         count = kmax - kmin + 1
         if 0 < count <= self.direct_groupby_cells:
-            if count > self.dense_peel_cells and comm is None and self.n >= self.heavy_key_rows and hasattr(sa, "groupby_run"):
+            if count > self.dense_peel_cells and (comm is not None or self.n >= self.heavy_key_rows) and hasattr(sa, "groupby_run"):
                 # a key range wider than one CU's LDS bins through the slab-partitioned pass: every row of one key goes to one slab's
                 # queue — a heavy key overflows it (rows beyond its capacity are same-address device atomics) and is one workgroup's
                 # work in pass 2.  Same remedy as in front of the fused hash pass: the heavy keys are peeled off.
-                peeled = self._groupby_dense_peeled(by, pf, key, descs, names, (kmin, kmax))
+                peeled = self._groupby_dense_peeled(by, pf, key, descs, names, (kmin, kmax), comm)
                 if peeled is not None:
                     return peeled
             # the key column bins itself (BinnerOrdinal with min_value): ONE pass, no hash map.  This is the
@@ -1074,17 +1074,17 @@ class Frame:
         # reduce workgroup is the whole pass (a 1 % key of 1e9 rows: 7 ms on one CU).  A sample of the keys finds them; they are
         # peeled off (`_groupby_peeled`): everything else takes the fused pass with the heavy rows masked out, the few heavy
         # keys are a dense groupby over their ordinals.
-        if comm is None and self.n >= self.heavy_key_rows and pf in _PEEL_KEY_KINDS:
-            heavy = self._heavy_keys(by, key)
+        if (comm is not None or self.n >= self.heavy_key_rows) and pf in _PEEL_KEY_KINDS:
             try:
                 import torch
-            except ImportError:   # (the peel keeps its row-wise intermediates in torch tensors)
-                heavy = None
+            except ImportError:   # (the peel keeps its row-wise intermediates in torch tensors: no rank has it then)
+                torch = None
+            heavy = self._heavy_keys_all_ranks(by, key, comm) if torch is not None else None
             if heavy is not None:
                 try:
                     # (host rows: the pass would copy them to the device anyway — here once, for both parts)
                     dev = lambda a: a if _is_device(a) else torch.from_numpy(np.ascontiguousarray(a)).cuda()
-                    peeled = self._groupby_peeled(by, pf, descs, names, vcols, dev(key), [dev(v) for v in values], None if keep is None else dev(keep), heavy)
+                    peeled = self._groupby_peeled(by, pf, descs, names, vcols, dev(key), [dev(v) for v in values], None if keep is None else dev(keep), heavy, comm=comm)
                 except torch.cuda.OutOfMemoryError:   # (the ordinals are 8 more bytes per row: no room — the plain attempt below)
                     peeled = None
                 if not _is_device(key) or peeled is None:
@@ -1092,9 +1092,15 @@ class Frame:
                 if peeled is not None:
                     return peeled
         res, failed = None, None
+        # the number of groups of an earlier call over the same key column (remembered like the key range): the pass sizes its
+        # bucket tables for a known count at 80 % load instead of a guessed 2^20 at 50 % — half the buckets for 1e6 keys
+        seen = self.__dict__.setdefault("_group_count_cache", {}).get(by)
+        hint = int(seen[1]) if seen is not None and seen[0] is key and keep is None else 0
         try:
             res = (sa.groupby_run(key if _is_device(key) else np.ascontiguousarray(key), values, _DT_CODE[pf], keep=keep) if keep is not None else
-                   sa.groupby_run(key if _is_device(key) else np.ascontiguousarray(key), values, _DT_CODE[pf])) if self.n else None
+                   sa.groupby_run(key if _is_device(key) else np.ascontiguousarray(key), values, _DT_CODE[pf], hint)) if self.n else None
+            if res is not None and keep is None:
+                self.__dict__["_group_count_cache"][by] = (key, len(res))
         except RuntimeError as e:
             if not str(e).startswith("groupby"):   # (anything the pass itself reports: too many / too skewed keys, no room for its queues)
                 raise
@@ -1134,7 +1140,7 @@ class Frame:
     #: dense key ranges wider than this many cells are checked for heavy keys too (narrower ones live in one workgroup's LDS)
     dense_peel_cells = 1 << 14
 
-    def _groupby_dense_peeled(self, by, pf, key, descs, names, key_range):
+    def _groupby_dense_peeled(self, by, pf, key, descs, names, key_range, comm=None):
         """the dense (BinnerOrdinal) groupby with the heavy keys peeled off, or None (no heavy key, or a call outside the peel's
         signature: aggregations other than count / sum / mean / var / std / min / max over plain columns, selections that differ)"""
         if pf not in _PEEL_KEY_KINDS or not descs:
@@ -1148,12 +1154,12 @@ class Frame:
                 if np.ma.isMaskedArray(self.columns[d.column]) or "_non_native" in _class_postfix(self.columns[d.column]):
                     return None
                 cols.append(d.column)
-        heavy = self._heavy_keys(by, key)
-        if heavy is None:
-            return None
         try:
             import torch
         except ImportError:
+            return None
+        heavy = self._heavy_keys_all_ranks(by, key, comm)   # (the signature checks above come out the same on every rank: a collective from here on)
+        if heavy is None:
             return None
         try:
             dev = lambda a: a if _is_device(a) else torch.from_numpy(np.ascontiguousarray(a)).cuda()
@@ -1161,12 +1167,22 @@ class Frame:
             if shared is not None:
                 keep = self._mask_array(shared)
                 keep = dev(keep if _is_device(keep) else _as_u8(keep))
-            return self._groupby_peeled(by, pf, descs, names, cols, dev(key), [dev(self.columns[c]) for c in cols], keep, heavy, dense_range=key_range)
+            return self._groupby_peeled(by, pf, descs, names, cols, dev(key), [dev(self.columns[c]) for c in cols], keep, heavy, dense_range=key_range, comm=comm)
         except torch.cuda.OutOfMemoryError:
             return None
         finally:
             if not _is_device(key):
                 torch.cuda.empty_cache()   # (whole columns went through torch's allocator: the library's own hipMallocs need the room back)
+
+    def _heavy_keys_all_ranks(self, by, key, comm):
+        """the heavy keys of this rank's sample, or — row-sharded frames — the sorted union over the ranks (one `union_keys`
+        exchange of <= 128 keys per rank: every rank peels the same set, whether or not a key is heavy in its own shard; round 4).
+        None when no rank found one.  Every rank must call this (it is a collective under `comm`)."""
+        mine = self._heavy_keys(by, key) if self.n >= self.heavy_key_rows else None
+        if comm is None or comm.world() == 1:
+            return mine
+        allk = np.asarray(comm.union_keys(np.zeros(0, dtype=np.int64) if mine is None else np.asarray(mine, dtype=np.int64)), dtype=np.int64)
+        return allk if len(allk) else None
 
     def _heavy_keys(self, by, key):
         """keys holding >= heavy_key_share of a strided sample of 2^17 rows of the key column (ascending int64 array), or None.
@@ -1199,12 +1215,15 @@ class Frame:
         cache[by] = (key, heavy)
         return heavy
 
-    def _groupby_peeled(self, by, pf, descs, names, vcols, key, values, keep, heavy, dense_range=None):
+    def _groupby_peeled(self, by, pf, descs, names, vcols, key, values, keep, heavy, dense_range=None, comm=None):
         """the fused hash groupby with the rows of the `heavy` keys taken out of it: a sealed device set of the heavy keys maps
         every row to the key's ordinal or -1 (vxh_hashmap_map_ordinal: a table of <= 128 keys stays in the caches); rows with -1
         take the partitioned pass (keep-mask), the others a dense groupby over the ordinals — <= 128 groups, LDS-resident, at the
         rate of a binned count.  The two group sets are disjoint; the result is their union in ascending key order.
-        None: the light part is still too much for the partitioned pass (-> ordered_set + BinnerHash)."""
+        None: the light part is still too much for the partitioned pass (-> ordered_set + BinnerHash).
+        comm (round 4): row-sharded frames — `heavy` is the set all ranks agreed on; the light part's partial groups are merged across
+        the ranks like the fused pass's (all-gather + MERGE kernels), the heavy part is a dense groupby whose grids are all-reduced;
+        every rank returns the whole table's groups."""
         import torch
         sa = self.sa
         sealed = getattr(sa, "ordered_set_" + pf)(len(heavy))
@@ -1220,27 +1239,45 @@ class Frame:
         plain = {n: agg._Desc(d.name, d.column, None) for n, d in zip(names, descs)}
         if dense_range is not None:
             # the light rows of a dense key range: the same dense groupby with the heavy rows masked out
-            fl = Frame({by: key, **dict(zip(vcols, values)), "__light__": light}, chunk_size=self.chunk_size, nthreads=self.nthreads, superagg=sa)
+            fl = Frame({by: key, **dict(zip(vcols, values)), "__light__": light}, chunk_size=self.chunk_size, nthreads=self.nthreads, superagg=sa, comm=comm)
             fl.heavy_key_rows = 1 << 62
             fl.direct_groupby_cells = self.direct_groupby_cells
             fl.__dict__["_key_range_cache"] = {by: (key, dense_range)}
             out = fl.groupby(by, plain, selection="__light__")
             info = {"dense": 1}
         else:
+            res, failed = None, False
             try:
-                res = sa.groupby_run(key, values, _DT_CODE[pf], keep=light)
+                res = sa.groupby_run(key, values, _DT_CODE[pf], keep=light) if len(key) else None
             except RuntimeError as e:
                 if not str(e).startswith("groupby"):
                     raise
+                failed = True
+            if comm is not None and comm.world() > 1:
+                if not comm.all_agree(not failed):   # (every rank leaves the peel together)
+                    return None
+                try:
+                    res = self._groupby_fused_allranks(res, len(values), comm)
+                except RuntimeError as e:
+                    if not str(e).startswith("groupby"):
+                        raise
+                    failed = True
+                if not comm.all_agree(not failed):
+                    return None
+            elif failed:
                 return None
             which = {"sum": sa.GB_SUM, "mean": sa.GB_MEAN, "var": sa.GB_VAR, "std": sa.GB_STD}
-            out = {by: np.asarray(res.column(sa.GB_KEYS))}
-            for name, d in zip(names, descs):
-                if d.name == "count":
-                    out[name] = np.asarray(res.column(sa.GB_ROWS) if d.column is None else res.column(sa.GB_COUNT, vcols.index(d.column)))
-                else:
-                    out[name] = np.asarray(res.column(which[d.name], vcols.index(d.column)))
-            info = dict(res.info())
+            if res is None:   # (no rank holds a light row)
+                out = {by: np.zeros(0, dtype=np.int64), **{n: np.zeros(0, dtype=np.int64 if d.name == "count" else np.float64) for n, d in zip(names, descs)}}
+                info = {}
+            else:
+                out = {by: np.asarray(res.column(sa.GB_KEYS))}
+                for name, d in zip(names, descs):
+                    if d.name == "count":
+                        out[name] = np.asarray(res.column(sa.GB_ROWS) if d.column is None else res.column(sa.GB_COUNT, vcols.index(d.column)))
+                    else:
+                        out[name] = np.asarray(res.column(which[d.name], vcols.index(d.column)))
+                info = dict(res.info())
         # the heavy keys: their ordinals are a dense key column
         sub = {"__heavy__": ords}
         for c, col in zip(vcols, values):
@@ -1249,7 +1286,7 @@ class Frame:
         if keep is not None:
             sub["__keep__"] = keep
             selection = "__keep__"
-        f = Frame(sub, chunk_size=self.chunk_size, nthreads=self.nthreads, superagg=sa)
+        f = Frame(sub, chunk_size=self.chunk_size, nthreads=self.nthreads, superagg=sa, comm=comm)
         f.heavy_key_rows = 1 << 62
         # what the sub-frame would scan the rows for is known: the ordinals' range, and whether a value column holds NaN (as far as
         # this frame has looked: the columns are the same objects)

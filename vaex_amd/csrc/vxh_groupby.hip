@@ -524,7 +524,7 @@ void launch_reduce(const GbArgs &G, hipStream_t st) {
 
 // one pipeline run over device-resident records; results appended (unsorted) to the arrays in G.out_*; returns the
 // overflow code (0 = fine)
-unsigned run_pipeline(GbArgs &G, int nv, bool merge, uint64_t n, uint64_t groups_hint, int cus, hipStream_t st, vxh_groupby *res) {
+unsigned run_pipeline(GbArgs &G, int nv, bool merge, uint64_t n, uint64_t groups_hint, int cus, hipStream_t st, vxh_groupby *res, bool hint_is_a_count = false) {
     GbScratch &S = gb_scratch();
     const int w = merge ? 1 + 3 * nv : nv;
     // rows per thread per tile.  One payload word: 8 (128 KiB of staging, one workgroup per CU).  Measured per 1e9 rows
@@ -541,7 +541,10 @@ unsigned run_pipeline(GbArgs &G, int nv, bool merge, uint64_t n, uint64_t groups
     int nb_log2 = 6;
     // target load of a bucket's table ("gb_load_pct", default 50 %): 80 % halves the buckets for 2^20 expected groups (512 -> 256
     // queues to scatter into) at longer probe chains; a bucket that overflows anyway costs a retry with four times the buckets
-    const uint64_t per_bucket = std::max<uint64_t>(64, (uint64_t)lines * 4 * (uint64_t)std::min<int64_t>(95, std::max<int64_t>(10, ctx().cfg_gb_load_pct)) / 100);
+    // When the caller KNOWS the number of groups (a repeated groupby over the same key column: vaex_amd.binned remembers it) the tables
+    // may run at 80 %: 1e6 keys take 256 buckets instead of 512 (14.6 -> 13.85 ms per 1e9 rows, profiles/r04_groupby_load.txt); a guess keeps 50 %.
+    const int64_t load_pct = hint_is_a_count ? std::max<int64_t>(80, ctx().cfg_gb_load_pct) : ctx().cfg_gb_load_pct;
+    const uint64_t per_bucket = std::max<uint64_t>(64, (uint64_t)lines * 4 * (uint64_t)std::min<int64_t>(95, std::max<int64_t>(10, load_pct)) / 100);
     while (nb_log2 < nb_max && ((uint64_t)1 << nb_log2) * per_bucket < std::max<uint64_t>(groups_hint, 1)) nb_log2++;
     struct Events { // (destroyed on every way out, a throwing launch included)
         hipEvent_t e[3] = {nullptr, nullptr, nullptr};
@@ -680,7 +683,7 @@ int vxh_groupby_run_kept(int key_dtype, const void *keys, int n_values, const vo
     G.out_cap = out_cap;
     G.out_key = (long long *)S.out.p;
     for (int k = 0; k < wout; k++) G.out_w[k] = (uint64_t *)((char *)S.out.p + out_cap * 8 * (size_t)(1 + k));
-    const unsigned code = run_pipeline(G, n_values, false, n, groups_hint ? groups_hint : (1u << 20), (int)cus, slot.stream, res.get());
+    const unsigned code = run_pipeline(G, n_values, false, n, groups_hint ? groups_hint : (1u << 20), (int)cus, slot.stream, res.get(), groups_hint != 0);
     if (code == 3) throw std::runtime_error("groupby: more groups than max_groups");
     if (code == 8 || code == 9) throw std::runtime_error("groupby: too many distinct keys for the LDS-partitioned path");
     if (code != 0) throw std::runtime_error("groupby: the key distribution is too skewed for the partitioned path");
