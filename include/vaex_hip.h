@@ -375,6 +375,11 @@ int vxh_groupby_run(int key_dtype, const void *keys, int n_values, const void *c
  * (vaex/execution.py:515-523); here rows outside the mask leave no record and groups without a row inside it do not exist. */
 int vxh_groupby_run_kept(int key_dtype, const void *keys, int n_values, const void *const *values, const uint8_t *keep, uint64_t n, int mem,
                          uint64_t groups_hint, uint64_t max_groups, vxh_groupby **out);
+/* ... with the key RANGE the caller measured (vxh_minmax_int; key_min > key_max: unknown = vxh_groupby_run_kept): when key_max - key_min
+ * leaves, below the bucket bits of an invertible mix, a remainder of at most 32 bits, the pass moves 12-byte records {remainder,
+ * value} instead of 16-byte {key, value} ones — a quarter off what it writes and reads back.  Keys outside the range: undefined groups. */
+int vxh_groupby_run_ranged(int key_dtype, const void *keys, int n_values, const void *const *values, const uint8_t *keep, uint64_t n, int mem,
+                           uint64_t groups_hint, uint64_t max_groups, int64_t key_min, int64_t key_max, vxh_groupby **out);
 /* the same aggregation over PARTIAL results (other chunks', other ranks'): host arrays of n partial groups */
 int vxh_groupby_merge(int n_values, const int64_t *keys, const int64_t *rows, const int64_t *const *counts,
                       const double *const *sums, const double *const *sums2, uint64_t n, uint64_t groups_hint, vxh_groupby **out);
@@ -384,7 +389,7 @@ uint64_t vxh_groupby_size(const vxh_groupby *g);
 /* one result column (vxh_groupby_column_kind; value_index selects the value column for COUNT..STD) into a host array of
  * vxh_groupby_size elements of 8 bytes */
 int vxh_groupby_column(vxh_groupby *g, int value_index, int which, void *out_host);
-/* diagnostics: 0 buckets, 1 LDS slots per bucket, 2 retries, 3 / 4 / 5 = ms of the scatter / reduce / sort kernels */
+/* diagnostics: 0 buckets, 1 LDS slots per bucket, 2 retries, 3 / 4 / 5 = ms of the scatter / reduce / sort kernels, 6 = 1 when the pass moved 12-byte records */
 int vxh_groupby_info(const vxh_groupby *g, int what, double *value_out);
 
 /* ---- multi-GPU reduce ------------------------------------------------------------------ */

@@ -344,3 +344,54 @@ def test_count_only_groupby_and_value_counts_take_the_fused_pass(sa, gpu_ready):
         assert got_pairs == want
         assert int(counts[[i for i, v in enumerate(vals) if v != v][0]]) == int((~ok).sum())
         assert np.all(np.diff(counts) <= 0)
+
+
+@pytest.mark.parametrize("case", ["bench_2e40", "negative_min", "exactly_32_bits", "too_wide", "int32_keys", "with_keep", "few_groups"])
+def test_groupby_run_compact_records(sa, gpu_ready, case):
+    """round 4: with the key RANGE known (vxh_groupby_run_ranged) the pass moves 12-byte records {remainder, value}: key - min is mixed
+    by an invertible map whose top bits are the bucket, only the <= 32 bits below travel; gb_reduce mixes every group's key back.
+    Same groups, counts bit-exact and sums within 1e-12 x sum|v| as with 16-byte records and as numpy — for ranges that fit, one that
+    leaves exactly 32 bits, a negative minimum, narrow key dtypes, a keep-mask; a range too wide keeps the 16-byte records."""
+    rng = np.random.default_rng(17)
+    n = 3_000_000
+    groups = 200_000
+    base = rng.integers(0, groups, n)
+    dtype = np.int64
+    if case == "bench_2e40":
+        keys = (base * 2654435761) % (1 << 40)
+    elif case == "negative_min":
+        keys = (base * 2654435761) % (1 << 38) - (1 << 37) - 12345
+    elif case == "exactly_32_bits":   # 2^20 expected groups at 50 % load: 512 buckets = 9 bits; a 41-bit range leaves 32
+        keys = (base * 2654435761) % (1 << 41)
+        keys[0], keys[1] = 0, (1 << 41) - 1
+    elif case == "too_wide":
+        keys = (base * 11400714819323198485) % (1 << 62)
+    elif case == "int32_keys":
+        keys = ((base * 2654435761) % (1 << 31) - (1 << 30)).astype(np.int32)
+        dtype = np.int32
+    elif case == "with_keep":
+        keys = (base * 2654435761) % (1 << 40)
+    else:
+        keys = rng.choice(np.array([5, 1 << 35, -(1 << 33), 77], dtype=np.int64), n)
+    keys = np.ascontiguousarray(keys.astype(dtype))
+    v = rng.normal(3, 2, n)
+    v[::97] = np.nan
+    keep = (rng.random(n) < 0.5).astype(np.uint8) if case == "with_keep" else None
+    kr = (int(keys.min()), int(keys.max()))
+    dt = _DT[np.dtype(dtype).name]
+    res = sa.groupby_run(keys, [v], dt, keep=keep, key_range=kr)
+    assert res.info()["compact_records"] == (0 if case == "too_wide" else 1), (case, res.info())
+    sa.config_set("gb_compact", 0)
+    try:
+        plain = sa.groupby_run(keys, [v], dt, keep=keep, key_range=kr)
+        assert plain.info()["compact_records"] == 0
+    finally:
+        sa.config_set("gb_compact", 1)
+    sel = slice(None) if keep is None else keep == 1
+    want = _want(keys[sel], [v[sel]])
+    _check(sa, res, want)
+    _check(sa, plain, want)
+    # on device-resident rows too
+    import torch
+    dev = sa.groupby_run(torch.from_numpy(keys).cuda(), [torch.from_numpy(v).cuda()], dt, keep=None if keep is None else torch.from_numpy(keep).cuda(), key_range=kr)
+    _check(sa, dev, want)

@@ -1008,7 +1008,7 @@ class Frame:
             return {by: out_keys, **dict(zip(names, vals))}
         # scattered keys, plain count / sum / mean / var / std of float64 columns: ONE radix-partitioned pass with the hash
         # table probed in LDS (vxh_groupby_run) instead of the reference's two passes over a global table
-        fused = self._groupby_fused(by, pf, descs, names, comm)
+        fused = self._groupby_fused(by, pf, descs, names, comm, key_range=(kmin, kmax) if self.n or comm is not None else None)
         if fused is not None:
             return fused
         # pass 1: distinct keys on the GPU (ordered_set.update), united over ranks, sorted -> sealed map whose
@@ -1035,7 +1035,7 @@ class Frame:
             out_keys, vals = out_keys[present], [np.asarray(v)[present] for v in vals[:-1]]
         return {by: out_keys, **dict(zip(names, vals))}
 
-    def _groupby_fused(self, by, pf, descs, names, comm):
+    def _groupby_fused(self, by, pf, descs, names, comm, key_range=None):
         """the vxh_groupby_run path, or None when the call is outside its signature (then: ordered_set + BinnerHash)"""
         sa = self.sa
         if not hasattr(sa, "groupby_run") or self.n == 0 and comm is None:
@@ -1097,8 +1097,10 @@ class Frame:
         seen = self.__dict__.setdefault("_group_count_cache", {}).get(by)
         hint = int(seen[1]) if seen is not None and seen[0] is key and keep is None else 0
         try:
-            res = (sa.groupby_run(key if _is_device(key) else np.ascontiguousarray(key), values, _DT_CODE[pf], keep=keep) if keep is not None else
-                   sa.groupby_run(key if _is_device(key) else np.ascontiguousarray(key), values, _DT_CODE[pf], hint)) if self.n else None
+            # (the measured key range: where it leaves a remainder of <= 32 bits below the bucket bits, the pass moves 12-byte records)
+            kr = None if key_range is None or key_range[0] > key_range[1] else (int(key_range[0]), int(key_range[1]))
+            res = (sa.groupby_run(key if _is_device(key) else np.ascontiguousarray(key), values, _DT_CODE[pf], keep=keep, key_range=kr) if keep is not None else
+                   sa.groupby_run(key if _is_device(key) else np.ascontiguousarray(key), values, _DT_CODE[pf], hint, key_range=kr)) if self.n else None
             if res is not None and keep is None:
                 self.__dict__["_group_count_cache"][by] = (key, len(res))
         except RuntimeError as e:

@@ -1818,6 +1818,7 @@ int vxh_config_set(const char *key, int64_t value) {
     else if (k == "wv_block") c.cfg_wv_block = value;
     else if (k == "part_cap") c.cfg_part_cap = value;
     else if (k == "merge_fused") c.cfg_merge_fused = value;
+    else if (k == "gb_compact") c.cfg_gb_compact = value;
     else if (k == "gb_load_pct") c.cfg_gb_load_pct = value > 0 ? value : 50;
     else if (k == "fuse_selection") c.cfg_fuse_selection = value;
     else if (k == "hot_chunk_factor") c.cfg_hot_chunk_factor = value > 0 ? value : 4;
@@ -1871,6 +1872,7 @@ int vxh_config_get(const char *key, int64_t *value) {
     else if (k == "wv_block") *value = c.cfg_wv_block;
     else if (k == "part_cap") *value = c.cfg_part_cap;
     else if (k == "merge_fused") *value = c.cfg_merge_fused;
+    else if (k == "gb_compact") *value = c.cfg_gb_compact;
     else if (k == "gb_load_pct") *value = c.cfg_gb_load_pct;
     else if (k == "fuse_selection") *value = c.cfg_fuse_selection;
     else if (k == "pred_fused") *value = get_slot(0).pred_fused;

@@ -90,6 +90,13 @@ struct GbArgs {
     uint64_t *qw[GB_MAX_W]; // [blocks][blk] each
     uint4 *qrec;            // W == 1: the queues hold 16-byte records {key, payload} instead (one store / one load per record)
     uint32_t lines;         // gb_reduce: 4-key lines of the LDS table (slots = 4 * lines; any count, not a power of two)
+    // Compact records (round 4; W == 1, counting rows, the key RANGE known): key - kc_min is a kc_bits-bit number; an invertible
+    // mix of it (multiply / xor-shift / multiply modulo 2^kc_bits) gives the bucket in its top nb_log2 bits and a remainder of
+    // <= 32 bits below — what the bucket implies is not stored: records are 12 bytes {remainder, payload} instead of 16, in the
+    // scatter's writes and the reduce's reads alike.  gb_reduce rebuilds the key of every GROUP (bucket | remainder, mixed back).
+    int32_t kc_bits;        // 0: 16-byte records {key, payload}
+    long long kc_min;
+    uint64_t kc_a_inv, kc_b_inv; // inverses of the two multipliers modulo 2^64
     // results (unsorted)
     unsigned long long *out_count; // groups written so far
     unsigned int *overflow;        // 1: out of spare blocks, 2: a bucket's LDS table too full, 3: result arrays too small
@@ -101,6 +108,22 @@ struct GbArgs {
 // ------------------------------------------------------------------------------------------------------------------
 // gb_scatter
 // ------------------------------------------------------------------------------------------------------------------
+constexpr uint64_t GB_KC_A = 0x9e3779b97f4a7c15ULL, GB_KC_B = 0xbf58476d1ce4e5b9ULL; // (odd: invertible modulo any power of two)
+__device__ __forceinline__ uint64_t gb_kc_mix(uint64_t x, int bits) { // a bijection of [0, 2^bits)
+    const uint64_t mask = bits >= 64 ? ~0ull : ((1ull << bits) - 1ull);
+    x = (x * GB_KC_A) & mask;
+    x ^= x >> ((bits + 1) >> 1);
+    return (x * GB_KC_B) & mask;
+}
+__device__ __forceinline__ uint64_t gb_kc_unmix(uint64_t m, int bits, uint64_t a_inv, uint64_t b_inv) {
+    const uint64_t mask = bits >= 64 ? ~0ull : ((1ull << bits) - 1ull);
+    uint64_t x = (m * b_inv) & mask;
+    x ^= x >> ((bits + 1) >> 1); // (the shift is at least half the width: one application undoes itself)
+    return (x * a_inv) & mask;
+}
+typedef unsigned int gb_u32x3 __attribute__((ext_vector_type(3)));
+typedef gb_u32x3 gb_u32x3_a4 __attribute__((aligned(4)));
+
 template <int W, int R>
 __global__ void __launch_bounds__(1024) gb_scatter(const GbArgs G) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -148,7 +171,13 @@ __global__ void __launch_bounds__(1024) gb_scatter(const GbArgs G) {
         uint32_t bucket[R], pos[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            bucket[r] = (uint32_t)(gb_mix((uint64_t)key[r]) >> (64 - G.nb_log2));
+            if (W == 1 && G.kc_bits) { // compact records: the key becomes its remainder, the bucket what the mix puts on top of it
+                const uint64_t m = gb_kc_mix((uint64_t)key[r] - (uint64_t)G.kc_min, G.kc_bits);
+                bucket[r] = (uint32_t)(m >> (G.kc_bits - G.nb_log2));
+                key[r] = (long long)(m & ((1ull << (G.kc_bits - G.nb_log2)) - 1ull));
+            } else {
+                bucket[r] = (uint32_t)(gb_mix((uint64_t)key[r]) >> (64 - G.nb_log2));
+            }
             pos[r] = 0;
             if (ok[r]) pos[r] = __hip_atomic_fetch_add(&cnt[bucket[r]], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
@@ -220,7 +249,10 @@ __global__ void __launch_bounds__(1024) gb_scatter(const GbArgs G) {
             const uint32_t base = k < sp ? base0[b] : base1[b];
             if (base == 0xffffffffu) continue; // (queue full: flagged, the host retries with more room)
             const uint64_t dst = (uint64_t)base + (k < sp ? k : k - sp);
-            if (W == 1) { // one 16-byte record {key, payload}: a tile's segment of a bucket is 16 B x its records, contiguous
+            if (W == 1 && G.kc_bits) { // 12-byte record {remainder, payload}
+                const uint64_t c2 = st_w[j];
+                *(gb_u32x3_a4 *)((uint32_t *)G.qrec + dst * 3) = gb_u32x3_a4{(uint32_t)st_key[j], (uint32_t)c2, (uint32_t)(c2 >> 32)};
+            } else if (W == 1) { // one 16-byte record {key, payload}: a tile's segment of a bucket is 16 B x its records, contiguous
                 const uint64_t a = st_key[j], c2 = st_w[j];
                 G.qrec[dst] = make_uint4((uint32_t)a, (uint32_t)(a >> 32), (uint32_t)c2, (uint32_t)(c2 >> 32));
             } else {
@@ -344,7 +376,11 @@ __global__ void __launch_bounds__(1024) gb_reduce(const GbArgs G) {
                 const uint32_t j = j0 + 64u * u + lane;
                 todo[u] = j < fill;
                 const uint64_t at = lo + (todo[u] ? j : 0u);
-                if (PW == 1) {
+                if (PW == 1 && G.kc_bits) { // (wave-uniform) 12-byte records {remainder, payload}: the table is keyed by the remainder
+                    const gb_u32x3_a4 r = *(const gb_u32x3_a4 *)((const uint32_t *)G.qrec + at * 3);
+                    kk[u] = (long long)(uint64_t)r[0];
+                    pp[u][0] = (uint64_t)r[1] | ((uint64_t)r[2] << 32);
+                } else if (PW == 1) {
                     const uint4 r = G.qrec[at];
                     kk[u] = (long long)((uint64_t)r.x | ((uint64_t)r.y << 32));
                     pp[u][0] = (uint64_t)r.z | ((uint64_t)r.w << 32);
@@ -410,7 +446,10 @@ __global__ void __launch_bounds__(1024) gb_reduce(const GbArgs G) {
     uint64_t o = (uint64_t)s_misc[1] + before + inc - mine;
     for (uint32_t s = tid; s < E; s += blockDim.x) {
         if (rows_of(s) == 0ull) continue;
-        G.out_key[o] = s == SLOTS ? GB_EMPTY : (long long)t_key[s];
+        if (!MERGE && NV == 1 && G.kc_bits) // the group's key from its bucket and remainder, mixed back
+            G.out_key[o] = (long long)(gb_kc_unmix(((uint64_t)bucket << (G.kc_bits - G.nb_log2)) | (uint64_t)t_key[s], G.kc_bits, G.kc_a_inv, G.kc_b_inv) + (uint64_t)G.kc_min);
+        else
+            G.out_key[o] = s == SLOTS ? GB_EMPTY : (long long)t_key[s];
         G.out_w[0][o] = (uint64_t)rows_of(s);
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
@@ -478,7 +517,7 @@ struct vxh_groupby {
     Dev cols; // [key | rows | (count, sum, sum2) x nv] x n_groups, 8-byte elements, sorted by key
     Dev tmp;
     uint64_t stride = 0; // elements between columns
-    int buckets = 0, slots = 0, retries = 0;
+    int buckets = 0, slots = 0, retries = 0, compact = 0;
     float ms_scatter = 0, ms_reduce = 0, ms_sort = 0;
 };
 
@@ -524,7 +563,16 @@ void launch_reduce(const GbArgs &G, hipStream_t st) {
 
 // one pipeline run over device-resident records; results appended (unsorted) to the arrays in G.out_*; returns the
 // overflow code (0 = fine)
-unsigned run_pipeline(GbArgs &G, int nv, bool merge, uint64_t n, uint64_t groups_hint, int cus, hipStream_t st, vxh_groupby *res, bool hint_is_a_count = false) {
+uint64_t inverse_mod_2_64(uint64_t a) { // Newton: every step doubles the correct low bits (a odd)
+    uint64_t x = a;
+    for (int i = 0; i < 6; i++) x *= 2 - a * x;
+    return x;
+}
+
+// key_bits > 0: every key lies in [key_min, key_min + 2^key_bits) (the caller measured the range): compact 12-byte records where the
+// remainder below the bucket bits fits 32 bits (GbArgs::kc_*)
+unsigned run_pipeline(GbArgs &G, int nv, bool merge, uint64_t n, uint64_t groups_hint, int cus, hipStream_t st, vxh_groupby *res, bool hint_is_a_count = false,
+                      long long key_min = 0, int key_bits = 0) {
     GbScratch &S = gb_scratch();
     const int w = merge ? 1 + 3 * nv : nv;
     // rows per thread per tile.  One payload word: 8 (128 KiB of staging, one workgroup per CU).  Measured per 1e9 rows
@@ -568,6 +616,12 @@ unsigned run_pipeline(GbArgs &G, int nv, bool merge, uint64_t n, uint64_t groups
         if (total_blocks * B >= (1ull << 32) || total_blocks * B * 8 * (uint64_t)(1 + w) > (96ull << 30)) { code = 9; break; }
         G.nv = nv; G.w = w; G.merge = merge ? 1 : 0; G.n = n;
         G.nb_log2 = nb_log2; G.slots_log2 = 0; G.lines = lines;
+        const bool compact = ctx().cfg_gb_compact && w == 1 && !merge && key_bits > nb_log2 && key_bits - nb_log2 <= 32;
+        G.kc_bits = compact ? key_bits : 0;
+        G.kc_min = key_min;
+        G.kc_a_inv = inverse_mod_2_64(GB_KC_A);
+        G.kc_b_inv = inverse_mod_2_64(GB_KC_B);
+        if (res) res->compact = compact ? 1 : 0;
         G.blk = (uint32_t)B; G.scatter_wgs = (uint32_t)blocks; G.pool = (uint32_t)pool;
         S.queues.need(total_blocks * B * 8 * (size_t)(1 + w));
         const size_t small_bytes = total_blocks * 4 + pool * 4 + 64;
@@ -638,7 +692,18 @@ int vxh_groupby_run(int key_dtype, const void *keys, int n_values, const void *c
 }
 
 int vxh_groupby_run_kept(int key_dtype, const void *keys, int n_values, const void *const *values, const uint8_t *keep, uint64_t n, int mem, uint64_t groups_hint, uint64_t max_groups, vxh_groupby **out) {
+    return vxh_groupby_run_ranged(key_dtype, keys, n_values, values, keep, n, mem, groups_hint, max_groups, 1, 0, out);
+}
+
+int vxh_groupby_run_ranged(int key_dtype, const void *keys, int n_values, const void *const *values, const uint8_t *keep, uint64_t n, int mem, uint64_t groups_hint, uint64_t max_groups,
+                           int64_t key_min, int64_t key_max, vxh_groupby **out) {
     GB_BEGIN
+    int key_bits = 0; // bits of key_max - key_min (0: range unknown)
+    if (key_min <= key_max) {
+        const uint64_t span = (uint64_t)key_max - (uint64_t)key_min;
+        key_bits = 1;
+        while (key_bits < 64 && (span >> key_bits)) key_bits++;
+    }
     if (key_dtype == VXH_F64 || key_dtype == VXH_F32 || key_dtype < 0 || key_dtype >= VXH_DTYPE_COUNT) throw std::runtime_error("groupby: integer key dtypes only");
     if (n_values < 1 || n_values > GB_MAX_NV) throw std::runtime_error("groupby: 1 or 2 float64 value columns");
     int ndev = 0;
@@ -683,7 +748,7 @@ int vxh_groupby_run_kept(int key_dtype, const void *keys, int n_values, const vo
     G.out_cap = out_cap;
     G.out_key = (long long *)S.out.p;
     for (int k = 0; k < wout; k++) G.out_w[k] = (uint64_t *)((char *)S.out.p + out_cap * 8 * (size_t)(1 + k));
-    const unsigned code = run_pipeline(G, n_values, false, n, groups_hint ? groups_hint : (1u << 20), (int)cus, slot.stream, res.get(), groups_hint != 0);
+    const unsigned code = run_pipeline(G, n_values, false, n, groups_hint ? groups_hint : (1u << 20), (int)cus, slot.stream, res.get(), groups_hint != 0, (long long)key_min, key_bits);
     if (code == 3) throw std::runtime_error("groupby: more groups than max_groups");
     if (code == 8 || code == 9) throw std::runtime_error("groupby: too many distinct keys for the LDS-partitioned path");
     if (code != 0) throw std::runtime_error("groupby: the key distribution is too skewed for the partitioned path");
@@ -789,6 +854,7 @@ int vxh_groupby_info(const vxh_groupby *g, int what, double *value_out) {
     case 3: *value_out = g->ms_scatter; break;
     case 4: *value_out = g->ms_reduce; break;
     case 5: *value_out = g->ms_sort; break;
+    case 6: *value_out = g->compact; break;
     default: throw std::runtime_error("groupby info: unknown item");
     }
     GB_END
