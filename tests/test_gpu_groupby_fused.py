@@ -365,7 +365,7 @@ def test_groupby_run_compact_records(sa, gpu_ready, case):
         keys = (base * 2654435761) % (1 << 41)
         keys[0], keys[1] = 0, (1 << 41) - 1
     elif case == "too_wide":
-        keys = (base * 11400714819323198485) % (1 << 62)
+        keys = ((base.astype(np.uint64) * np.uint64(11400714819323198485)) % np.uint64(1 << 62)).astype(np.int64)
     elif case == "int32_keys":
         keys = ((base * 2654435761) % (1 << 31) - (1 << 30)).astype(np.int32)
         dtype = np.int32
