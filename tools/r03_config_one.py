@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One BASELINE config, a few passes on device-resident columns — for rocprofv3 (kernel stats / --pmc FETCH_SIZE, WRITE_SIZE).
-Usage: python tools/r03_config_one.py c2|c3d|c3s [rows] [passes] [knob=value ...]"""
+Usage: python tools/r03_config_one.py c2|c2e|count2d|c3d|c3s [rows] [passes] [knob=value ...]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -19,6 +19,15 @@ if which == "c2":
     del v
     df = Frame(dict(x=x, y=y, z=z, sel=sel))
     run = lambda: df.count(binby=["x", "y", "z"], limits=[[-4, 4]] * 3, shape=128, selection="sel", edges=True)
+elif which == "c2e":   # (round 4) the selection as an expression over a fourth float64 column: evaluated inside the binning kernel
+    x, y, z, v = (torch.randn(rows, dtype=torch.float64, device="cuda", generator=g) for _ in range(4))
+    v = v * 2 + 3
+    df = Frame(dict(x=x, y=y, z=z, v=v))
+    run = lambda: df.count(binby=["x", "y", "z"], limits=[[-4, 4]] * 3, shape=128, selection="v > 3", edges=True)
+elif which == "count2d":   # (round 4) north_star's target sentence: 2-D count(*) on a 256 x 256 grid
+    x, y = (torch.randn(rows, dtype=torch.float64, device="cuda", generator=g) for _ in range(2))
+    df = Frame(dict(x=x, y=y))
+    run = lambda: df.count(binby=["x", "y"], limits=[[-4, 4]] * 2, shape=256, edges=True)
 else:
     v = torch.randn(rows, dtype=torch.float64, device="cuda", generator=g) * 2 + 3
     k = torch.randint(0, 1_000_000, (rows,), dtype=torch.int64, device="cuda", generator=g)
@@ -30,4 +39,4 @@ else:
 torch.cuda.synchronize()
 for i in range(passes):
     t0 = time.perf_counter(); sa.timer_start(0); r = run(); k_ms = sa.timer_stop(0); dt = time.perf_counter() - t0
-    print(f"{which} pass {i}: {dt*1e3:.3f} ms wall, {k_ms:.3f} ms on the stream = {rows/dt/1e9:.1f} Grows/s  {sa.last_kernel(0)}", flush=True)
+    print(f"{which} pass {i}: {dt*1e3:.3f} ms wall, {k_ms:.3f} ms on the stream = {rows/dt/1e9:.1f} Grows/s  {sa.last_kernel(0)} {getattr(df, 'last_groupby_info', '') if which == 'c3s' else ''}", flush=True)

@@ -589,9 +589,10 @@ unsigned run_pipeline(GbArgs &G, int nv, bool merge, uint64_t n, uint64_t groups
     int nb_log2 = 6;
     // target load of a bucket's table ("gb_load_pct", default 50 %): 80 % halves the buckets for 2^20 expected groups (512 -> 256
     // queues to scatter into) at longer probe chains; a bucket that overflows anyway costs a retry with four times the buckets
-    // When the caller KNOWS the number of groups (a repeated groupby over the same key column: vaex_amd.binned remembers it) the tables
-    // may run at 80 %: 1e6 keys take 256 buckets instead of 512 (14.6 -> 13.85 ms per 1e9 rows, profiles/r04_groupby_load.txt); a guess keeps 50 %.
-    const int64_t load_pct = hint_is_a_count ? std::max<int64_t>(80, ctx().cfg_gb_load_pct) : ctx().cfg_gb_load_pct;
+    // (Round 4 tried 256 buckets for 1e6 KNOWN groups, i.e. tables at 76 % load: the fullest buckets pass gb_reduce's 80 % limit, the
+    //  retry with four times the buckets costs a whole second pass: 14.4 -> 24.5 ms.  The load stays a knob; a known count only replaces the 2^20 guess.)
+    (void)hint_is_a_count;
+    const int64_t load_pct = ctx().cfg_gb_load_pct;
     const uint64_t per_bucket = std::max<uint64_t>(64, (uint64_t)lines * 4 * (uint64_t)std::min<int64_t>(95, std::max<int64_t>(10, load_pct)) / 100);
     while (nb_log2 < nb_max && ((uint64_t)1 << nb_log2) * per_bucket < std::max<uint64_t>(groups_hint, 1)) nb_log2++;
     struct Events { // (destroyed on every way out, a throwing launch included)

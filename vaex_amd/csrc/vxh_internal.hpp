@@ -164,6 +164,7 @@ struct Slot {
         int blocks = 0;          // pass-1 workgroups (= accumulator blocks)
         void *acc = nullptr;     // [blocks][w*h] double sums, then [blocks][w*h] u64 counts
         size_t acc_cap = 0;
+        uint64_t acc_zero_sig = 0, acc_layout_sig = 0; // layout the accumulators are known to be all-zero for (0: not known) / layout of the current call
         void *sample = nullptr;  // cells x int64: count grid of the sample
         size_t sample_cap = 0;
         // the box of the previous sampled call, reused when the same columns are binned with the same limits again
