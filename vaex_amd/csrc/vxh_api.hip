@@ -1407,6 +1407,7 @@ static void run_part_chunk(Slot &slot, const BinArgs &planned, const LaunchPlan 
         const double expect = (double)planned.n * cold / (double)waves_total / (double)VXH_WV_GROUP;
         uint64_t GB = (uint64_t)(expect * 1.125) + 3;
         if (c.cfg_wv_block > 0) GB = std::max<uint64_t>(1, (uint64_t)c.cfg_wv_block / VXH_WV_GROUP);
+        GB = (GB + 15) & ~(uint64_t)15; // (a block's group headers leave in whole 128-byte lines of 16)
         const uint64_t waves_per_region = ((uint64_t)wv_blocks + P.parts - 1) / P.parts * wg.waves;
         uint64_t capG = GB * (waves_per_region + std::max<uint64_t>(8, waves_per_region / 4));
         if (c.cfg_part_cap > 0) capG = std::max<uint64_t>(1, ((uint64_t)c.cfg_part_cap / VXH_WV_GROUP + GB - 1) / GB) * GB; // (tests: a region that overflows)

@@ -1721,6 +1721,7 @@ __global__ void __launch_bounds__(1024) part_scatter_wv(const PartArgs P) {
     constexpr uint32_t GR = VXH_WV_GROUP;
     uint64_t *const g_val = (uint64_t *)wbase;
     uint32_t *const g_idx = (uint32_t *)(wbase + 2u * GR * 8u);
+    unsigned long long *const g_hdr = (unsigned long long *)(wbase + 2u * GR * 12u); // [16] headers of the groups since the last whole line of them
     uint32_t wcount = 0, wflushed = 0; // (wave-uniform) records staged / flushed so far
     uint32_t gcur = VXH_WV_NONE, gend = VXH_WV_NONE; // (wave-uniform) next group of the wave's block, end of the block — group indices inside the region
     // DIRECT == 2: the WORKGROUP's waves share one record stream per slab (16x fewer streams than one per wave: a
@@ -1782,8 +1783,16 @@ __global__ void __launch_bounds__(1024) part_scatter_wv(const PartArgs P) {
             gend = gcur + B;
         }
     };
+    // group headers leave 16 at a time — one whole 128-byte line (blocks start at multiples of 16 groups): a lone 8-byte store per group
+    // left 16 partial writes per line, minutes apart in cache terms
+    auto flush_headers = [&](uint32_t upto) { // headers of groups [upto & ~15, upto) of the region
+        const uint32_t first = (upto - 1u) & ~15u, count = upto - first;
+        if (lane < count) P.qhdr[(uint64_t)part * (P.cap / GR) + first + lane] = g_hdr[lane];
+    };
     auto close_group_block = [&]() { // groups the block really holds
-        if (gend != VXH_WV_NONE && lane == 0) P.qtab[(size_t)part * (uint32_t)P.qtab_stride + (gend - B) / B] = gcur - (gend - B);
+        if (gend == VXH_WV_NONE) return;
+        if (gcur & 15u) flush_headers(gcur);
+        if (lane == 0) P.qtab[(size_t)part * (uint32_t)P.qtab_stride + (gend - B) / B] = gcur - (gend - B);
     };
     if (DIRECT == 3 && has_work) open_group_block();
     // DIRECT == 2: block j of (workgroup, slab s) holds the slab's records [j * QB, (j + 1) * QB) of this workgroup; it is
@@ -1998,8 +2007,9 @@ __global__ void __launch_bounds__(1024) part_scatter_wv(const PartArgs P) {
                 if (NVAL) __builtin_nontemporal_store(v2, P.qval[0] + rec);
                 __builtin_nontemporal_store((uint16_t)l2, (uint16_t *)P.qidx + rec);
             }
-            if (lane == 0) P.qhdr[(uint64_t)part * (P.cap / GR) + gcur] = hdr;
+            if (lane == 0) g_hdr[gcur & 15u] = hdr;
             ++gcur;
+            if ((gcur & 15u) == 0u) flush_headers(gcur);
         } else if (live) { // region full (pathologically skewed data): device atomics straight into the grids
             wv_slow_record(P, (uint64_t)ix, NVAL ? __longlong_as_double((long long)vb) : 0.0);
         }
@@ -2558,6 +2568,10 @@ __device__ __forceinline__ void grp_apply(const PartArgs &P, char *lds, uint32_t
     const bool vint = P.val_i64 != 0;
     const double d = as_f64(vbits);
     const bool nan = !vint && d != d;
+    if (P.no_pipeline & 8192) { // (timing experiments: bit 13 drops the LDS atomics of pass 2 — what is left is its loads and bookkeeping)
+        if (valid && loc == 0xffffffffu) at_add<__HIP_MEMORY_SCOPE_WORKGROUP, uint32_t>((uint32_t *)lds, (uint32_t)vbits);
+        return;
+    }
 #pragma unroll
     for (int k = 0; k < NAGG; ++k) {
         char *base = lds + off[k];

@@ -184,7 +184,7 @@ struct PartArgs {
 // group, written as whole aligned lines (512 B of values + 128 B of uint16 local indices, non-temporal) plus an 8-byte header of
 // the slabs' end offsets.  Pass 2 (part_reduce_grp) reads, of every group, the segment of its own slab.
 #define VXH_WV_GROUP 64u
-#define VXH_WV_WAVE_LDS_GROUPED ((size_t)(2 * VXH_WV_GROUP) * 12)
+#define VXH_WV_WAVE_LDS_GROUPED ((size_t)(2 * VXH_WV_GROUP) * 12 + 128) /* ring of 128 records + 16 group headers waiting for their line */
 #define VXH_WV_WAVE_LDS(NVAL, S) ((((size_t)(S) * VXH_WV_D * (2 + 8 * (size_t)(NVAL)) + (size_t)(S) * 4) + 15) & ~(size_t)15)
 
 struct HotMergeArgs {
