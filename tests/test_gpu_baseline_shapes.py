@@ -752,3 +752,37 @@ def test_grouped_pass1(sa, variant):
             ca.append(mk(dict(kind="summoment", data=vs, moment=2)))
     case = dict(n=m, binners=[dict(kind="scalar", data=xs, vmin=-4, vmax=4, bins=256), dict(kind="scalar", data=ys, vmin=-4, vmax=4, bins=256)], aggs=ca)
     cases.assert_case_equal(head, _ref_or_port_case(_ref_module(), case), case)
+
+
+def test_pass1_form_is_chosen_by_a_timed_trial(sa):
+    """round 4: with "wv_auto" on (the library's default; any explicit "wv" switches it off) the first two sampled calls over the same
+    columns run the grouped and the ring-less pass 1 once each under HIP events, the faster one serves from the third call on — the
+    results are the same grids either way."""
+    import torch
+    g = torch.Generator(device="cuda").manual_seed(3)
+    n = (1 << 26) + 999
+    x = torch.randn(n, dtype=torch.float64, device="cuda", generator=g)
+    y = torch.randn(n, dtype=torch.float64, device="cuda", generator=g)
+    v = torch.randn(n, dtype=torch.float64, device="cuda", generator=g) * 2 + 3
+    bx = sa.BinnerScalar_float64(1, "x", -4.0, 4.0, 256); by = sa.BinnerScalar_float64(1, "y", -4.0, 4.0, 256)
+    grid = sa.Grid([bx, by])
+    aggs = [sa.AggCount_int64(grid, 1, 1), sa.AggSum_float64(grid, 1, 1), sa.AggCount_float64(grid, 1, 1)]
+    bx.set_data(0, x); by.set_data(0, y); aggs[1].set_data(0, v, 0); aggs[2].set_data(0, v, 0)
+    sa.config_set("wv_auto", 1)
+    try:
+        kernels, results = [], []
+        for _ in range(4):
+            for a in aggs:
+                a.reset()
+            grid.bin(0, aggs, n)
+            kernels.append(sa.last_kernel(0))
+            results.append([np.array(a.get_result()) for a in aggs])
+        choice = sa.config_get("wv_auto_choice")
+    finally:
+        sa.config_set("wv", 5)   # (explicit from here on: the other tests get the kernel they name)
+    assert kernels[0].startswith("part_scatter_grouped_hot") and kernels[1].startswith("part_scatter_direct_hot"), kernels
+    assert choice in (3, 5) and kernels[2] == kernels[3] and kernels[2].startswith("part_scatter_grouped_hot" if choice == 5 else "part_scatter_direct_hot"), (choice, kernels)
+    for r in results[1:]:
+        assert np.array_equal(r[0], results[0][0]) and np.array_equal(r[2], results[0][2])
+        assert np.all(np.abs(r[1] - results[0][1]) <= 1e-12 * 20.0 * np.maximum(results[0][0], 1))
+    assert int(results[0][0].sum()) == n

@@ -102,6 +102,8 @@ Slot &get_slot(int thread) {
         HIP_CHECK(hipEventCreate(&s->t0));
         HIP_CHECK(hipEventCreate(&s->t1));
         HIP_CHECK(hipEventCreate(&s->t_lap));
+        HIP_CHECK(hipEventCreate(&s->t_trial0));
+        HIP_CHECK(hipEventCreate(&s->t_trial1));
         HIP_CHECK(hipStreamCreateWithFlags(&s->stream2, hipStreamNonBlocking));
         for (auto &pb : s->part) {
             HIP_CHECK(hipEventCreateWithFlags(&pb.scattered, hipEventDisableTiming));
@@ -913,13 +915,15 @@ struct WvGeom {
     size_t wave_bytes = 0;
 };
 // converted: the call's columns are converted on load (4-byte value column / float32 binners): only the ring-less variant 1 is instantiated for them
-static WvGeom wv_geometry(size_t S, int nvals, bool with_box, bool converted = false) {
+// mode: the "wv" knob, or what the per-box trial picked for this call (Slot::Hot::wv_mode)
+static WvGeom wv_geometry(size_t S, int nvals, bool with_box, bool converted = false, int64_t mode = -1) {
     Context &c = ctx();
     WvGeom g;
+    if (mode < 0) mode = c.cfg_wv;
     if (!c.cfg_wv || S > 64 || nvals > 1 || (c.cfg_no_pipeline & 1) || c.cfg_part_rows > 0) return g;
     // next to a box: "wv" = 3 -> 1 (records straight from the registers, one stream per (wave, slab)), 4 -> 2 (per (workgroup, slab)),
     // 5 -> 3 (round 4: compacted into a wave-private ring, slab-sorted 64-record groups in ONE stream per wave; <= 8 slabs)
-    g.direct = with_box ? ((c.cfg_wv == 3 || (c.cfg_wv == 5 && (converted || S > 8))) ? 1 : (c.cfg_wv == 5 ? 3 : (c.cfg_wv == 4 && S <= 16 ? 2 : 0))) : 0;
+    g.direct = with_box ? ((mode == 3 || (mode == 5 && (converted || S > 8))) ? 1 : (mode == 5 ? 3 : (mode == 4 && S <= 16 ? 2 : 0))) : 0;
     int waves = (int)std::min<int64_t>(16, std::max<int64_t>(1, g.direct == 3 ? c.cfg_wv_waves_grouped : (g.direct ? c.cfg_wv_waves_direct : c.cfg_wv_waves)));
     // (shared streams: the kernel's LDS is one area for the workgroup; expressed per wave for the bookkeeping below)
     g.wave_bytes = g.direct == 3 ? VXH_WV_WAVE_LDS_GROUPED : (g.direct == 2 ? ((VXH_WV_SHARED_LDS(S) + waves - 1) / waves + 15) & ~(size_t)15 : (g.direct ? VXH_WV_WAVE_LDS_DIRECT(S) : VXH_WV_WAVE_LDS(nvals, S)));
@@ -1039,7 +1043,25 @@ static void hot_prepare(Slot &slot, const BinArgs &A, const BinArgs &planned, co
     const bool f32b = plan.bin_f32 && !plan.fast_f32 && (plan.fast_vals || plan.vals_i64); // float32 binners next to an 8-byte value column
     const bool ints = (plan.bin_f64 && (plan.vals_i64 || plan.vals_i32 || plan.vals_f32)) || f32b; // integer sums / 4-byte columns converted on load: part_scatter_wv's instantiations only
     const bool f32all = plan.fast_f32 && nval == 1; // float32 binners AND value column: the ring-less part_scatter_wv converts both on load; otherwise part_scatter_blk's float instantiation
-    const WvGeom wg = wv_geometry(S, nval, true, plan.vals_i32 || plan.vals_f32 || f32b || f32all);
+    // Grouped (5) or ring-less (3) pass 1?  The two are within 2 % of each other and WHICH one is ahead depends on the box the process
+    // landed on (profiles/r04_headline_ab.txt: 4.98 vs 5.09 ms on one, 5.13 vs 5.02 on another — how its memory side takes 1 GB of
+    // queue writes under 24 GB of reads).  So with "wv" = 5 and "wv_auto" on, the first two sampled calls over the same columns time one
+    // each (HIP events around the passes) and the faster one serves from then on; calls whose sample is not remembered take the
+    // process's last decision.
+    {
+        const double lim0[6] = {A.b[0].vmin, A.b[0].scale, A.b[0].binsd, A.b[1].vmin, A.b[1].scale, A.b[1].binsd};
+        const bool same_key = c.cfg_hot_cache && H.key_fraction >= 0 && H.key_ptr[0] == A.b[0].data && H.key_ptr[1] == A.b[1].data && H.key_len == length &&
+                              H.key_grid.size() == A.cells && memcmp(H.key_lim, lim0, sizeof(lim0)) == 0;
+        if (!same_key) H.auto_state = 0;
+        H.wv_trial = -1;
+        H.wv_mode = c.cfg_wv;
+        if (c.cfg_wv == 5 && c.cfg_wv_auto && !c.cfg_wv_user_set && !forced) { // (a caller that SET "wv" gets exactly that kernel)
+            if (H.auto_state >= 2) H.wv_mode = H.auto_choice;
+            else if (!same_key && c.wv_auto_last) H.wv_mode = c.wv_auto_last;                 // (the first call over new columns: the process's last decision; its sample is taken now)
+            else if (length >= (1ull << 26)) { H.wv_trial = H.auto_state; H.wv_mode = H.auto_state == 0 ? 5 : 3; }
+        }
+    }
+    const WvGeom wg = wv_geometry(S, nval, true, plan.vals_i32 || plan.vals_f32 || f32b || f32all, H.wv_mode);
     bool wv = wg.ok && slab_cells < 65535 && wv_aligned(A); // (= run_part_chunk's conditions for part_scatter_wv)
     if (f32all && wg.direct != 1) wv = false;
     if ((masked && !(wv && (wg.direct == 1 || wg.direct == 3))) || (plan.fast_f32 && !f32all)) { // (the box next to a selection mask: part_scatter_blk's or the ring-less part_scatter_wv's instantiations; float32 columns without a value column: part_scatter_blk's only)
@@ -1366,7 +1388,7 @@ static void run_part_chunk(Slot &slot, const BinArgs &planned, const LaunchPlan 
     const bool narrow = plan.vals_f32 || plan.vals_i32; // (a 4-byte value column: part_scatter_wv converts it on load — nobody else does)
     const bool f32b = plan.bin_f32 && !plan.fast_f32 && (plan.fast_vals || plan.vals_i64) && P.nvals == 1; // (float32 binners next to an 8-byte value column: the same)
     const bool f32all = plan.fast_f32 && P.nvals == 1; // (float32 binners and value column: both converted on load)
-    const WvGeom wg = wv_geometry(S, P.nvals, slot.hot.on, narrow || f32b || f32all);
+    const WvGeom wg = wv_geometry(S, P.nvals, slot.hot.on, narrow || f32b || f32all, slot.hot.on ? slot.hot.wv_mode : -1);
     const bool wv = wg.ok && (plan.fast_f64 || (plan.bin_f64 && (plan.vals_i64 || narrow)) || f32b || f32all || (plan.key_i64 && (plan.fast_vals || plan.vals_i64 || narrow))) && (!(narrow || f32b || f32all) || !slot.hot.on || wg.direct == 1) && planned.ndim >= 1 && planned.ndim <= 3 && P.nvals <= 1 && !P.use_flags &&
                     (P.nmasks == 0 || (P.nmasks == 1 && P.all_masked)) && P.idx16 && slab_cells < 65535 && wv_aligned(planned) && (!slot.hot.on || slot.hot.wv);
     if (slot.hot.on && slot.hot.wv != wv) throw std::runtime_error("vaex_hip internal: hot box prepared for a different pass-1 kernel");
@@ -1816,13 +1838,14 @@ int vxh_config_set(const char *key, int64_t value) {
     else if (k == "hot_cnt16") c.cfg_hot_cnt16 = value;
     else if (k == "hot_flush_trips") c.cfg_hot_flush_trips = value;
     else if (k == "blk") c.cfg_blk = value;
-    else if (k == "wv") c.cfg_wv = value;
+    else if (k == "wv") { c.cfg_wv = value; c.cfg_wv_user_set = true; }
     else if (k == "wv_waves") c.cfg_wv_waves = value > 0 ? value : 8;
     else if (k == "wv_waves_direct") c.cfg_wv_waves_direct = value > 0 ? value : 16;
     else if (k == "wv_waves_grouped") c.cfg_wv_waves_grouped = value > 0 ? value : 8;
     else if (k == "wv_block") c.cfg_wv_block = value;
     else if (k == "part_cap") c.cfg_part_cap = value;
     else if (k == "merge_fused") c.cfg_merge_fused = value;
+    else if (k == "wv_auto") { c.cfg_wv_auto = value; c.wv_auto_last = 0; if (value) { c.cfg_wv = 5; c.cfg_wv_user_set = false; } }
     else if (k == "gb_compact") c.cfg_gb_compact = value;
     else if (k == "gb_load_pct") c.cfg_gb_load_pct = value > 0 ? value : 50;
     else if (k == "fuse_selection") c.cfg_fuse_selection = value;
@@ -1877,6 +1900,8 @@ int vxh_config_get(const char *key, int64_t *value) {
     else if (k == "wv_block") *value = c.cfg_wv_block;
     else if (k == "part_cap") *value = c.cfg_part_cap;
     else if (k == "merge_fused") *value = c.cfg_merge_fused;
+    else if (k == "wv_auto") *value = c.cfg_wv_auto;
+    else if (k == "wv_auto_choice") *value = get_slot(0).hot.auto_state >= 2 ? get_slot(0).hot.auto_choice : 0;
     else if (k == "gb_compact") *value = c.cfg_gb_compact;
     else if (k == "gb_load_pct") *value = c.cfg_gb_load_pct;
     else if (k == "fuse_selection") *value = c.cfg_fuse_selection;
@@ -2281,6 +2306,9 @@ int vxh_grid_bin(vxh_grid *grid, int thread, vxh_agg *const *aggs, int n_aggs, u
             bool armed;
             ~PartGuard() { if (armed) { slot.acc_sig = 0; slot.hot.on = false; } }
         } part_guard{slot, whole.strategy == VXH_STRAT_PART};
+        const bool trial = whole.strategy == VXH_STRAT_PART && slot.hot.on && slot.hot.wv_trial >= 0 && slot.hot.wv && slot.t_trial0;
+        const unsigned redo_before = slot.redo_count;
+        if (trial) HIP_CHECK(hipEventRecord(slot.t_trial0, slot.stream));
         for (int attempt = 0; attempt < 3; ++attempt) {
         for (uint64_t r0 = 0; r0 < length; r0 += step) {
             const uint64_t rn = std::min(step, length - r0);
@@ -2363,6 +2391,24 @@ int vxh_grid_bin(vxh_grid *grid, int thread, vxh_agg *const *aggs, int n_aggs, u
                 if (!fused_merge) hot_merge(slot, whole_args);
                 slot.hot.acc_zero_sig = slot.hot.acc_layout_sig; // (the merge zeroes what it folds)
                 slot.last_kernel = slot.last_pass1 == 5 ? ((whole.vals_i64 || whole.vals_i32) ? "part_scatter_grouped_hot+part_reduce_grp_i64" : "part_scatter_grouped_hot+part_reduce_grp_f64") : slot.last_pass1 == 4 ? "part_scatter_shared_hot+part_reduce_f64" : slot.last_pass1 == 3 ? ((whole.vals_i64 || whole.vals_i32) ? "part_scatter_direct_hot+part_reduce_i64" : "part_scatter_direct_hot+part_reduce_f64") : (slot.last_pass1 == 2 ? "part_scatter_wv_hot+part_reduce_f64" : "part_scatter_hot+part_reduce_f64");
+            }
+            if (trial) { // one of the two timed calls of the grouped / ring-less decision (hot_prepare)
+                HIP_CHECK(hipEventRecord(slot.t_trial1, slot.stream));
+                HIP_CHECK(hipEventSynchronize(slot.t_trial1));
+                float ms = 0;
+                HIP_CHECK(hipEventElapsedTime(&ms, slot.t_trial0, slot.t_trial1));
+                Slot::Hot &H = slot.hot;
+                const bool was_that_kernel = (H.wv_trial == 0) == (slot.last_pass1 == 5);
+                if (slot.redo_count == redo_before && was_that_kernel && H.auto_state == H.wv_trial) { // (a rerun's time says nothing; neither does a call that fell to another pass 1)
+                    H.auto_t[H.auto_state] = (double)ms / (double)length;
+                    if (++H.auto_state == 2) {
+                        H.auto_choice = H.auto_t[0] <= H.auto_t[1] ? 5 : 3;
+                        ctx().wv_auto_last = H.auto_choice;
+                    }
+                } else if (!was_that_kernel) { // the grouped form does not serve this signature (> 8 slabs, converted columns): nothing to decide
+                    H.auto_state = 2;
+                    H.auto_choice = 5;
+                }
             }
             slot.hot.on = false;
             part_guard.armed = false;

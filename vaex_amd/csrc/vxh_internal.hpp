@@ -124,6 +124,7 @@ struct Slot {
     hipStream_t copy_stream = nullptr;
     int cur = 0;
     hipEvent_t t0 = nullptr, t1 = nullptr;
+    hipEvent_t t_trial0 = nullptr, t_trial1 = nullptr; // around the passes of a call that times one of the two pass-1 forms (Hot::wv_trial)
     hipEvent_t t_lap = nullptr; // recorded behind the last KERNEL of a call (before its results cross PCIe): vxh_timer_kernels_ms
     bool lap_set = false;
     hipEvent_t after_null = nullptr; // order_after_producers()
@@ -164,6 +165,12 @@ struct Slot {
         int blocks = 0;          // pass-1 workgroups (= accumulator blocks)
         void *acc = nullptr;     // [blocks][w*h] double sums, then [blocks][w*h] u64 counts
         size_t acc_cap = 0;
+        // grouped (5) vs ring-less (3) pass 1, decided per sampled columns by timing one call of each ("wv_auto")
+        int auto_state = 0;        // calls timed so far (0: none, 1: the grouped one, 2: decided)
+        int auto_choice = 5;
+        double auto_t[2] = {0, 0}; // ms per row: grouped, ring-less
+        int wv_trial = -1;         // this call is trial number ... (-1: not a trial)
+        int64_t wv_mode = 5;       // the "wv" mode of this call
         uint64_t acc_zero_sig = 0, acc_layout_sig = 0; // layout the accumulators are known to be all-zero for (0: not known) / layout of the current call
         void *sample = nullptr;  // cells x int64: count grid of the sample
         size_t sample_cap = 0;
@@ -198,6 +205,9 @@ struct Context {
     int cus = 256;
     size_t max_lds = 65536;
     Slot *slots[VXH_MAX_SLOTS] = {};
+    int64_t cfg_wv_auto = 1;  // "wv" = 5: time the grouped and the ring-less pass 1 once each per sampled columns, keep the faster (0: always grouped)
+    bool cfg_wv_user_set = false; // vxh_config_set("wv", ...) was called: no trials, the caller's kernel
+    int wv_auto_last = 0;     // the most recent decision of this process (0: none yet): what calls without a remembered sample take
     hipEvent_t reduced = nullptr; // recorded on slot 0's stream behind the latest vxh_allreduce
     bool reduced_set = false;
     // tuning knobs (vxh_config_set)
