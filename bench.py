@@ -401,6 +401,8 @@ def run(args):
                          "frac_of_measured_copy_rate": achieved / 6290.0,  # (6.29 TB/s float4 copy: MI355X_MICROARCH.md)
                          "traffic": traffic, "traffic_source": traffic_source, "kernel_ms": k_ms, "bytes_per_row": BYTES_PER_ROW, "rows_per_launch": rows},
         }
+        if os.environ.get("VAEX_AMD_BENCH_STEPS_DEBUG"):
+            out["kernel_ms_per_step"] = [round(float(k), 3) for k in kernel_ms]
         if world > 1:
             # rank 0's kernel time above excludes the reduce; this one is the whole step on the slowest rank against all GPUs' peak
             out["roofline"]["frac_incl_allreduce"] = BYTES_PER_ROW * rows * world / (elapsed / args.steps) / 1e9 / (world * HBM_PEAK_GBS)
