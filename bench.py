@@ -359,6 +359,13 @@ def run(args):
             dist.barrier()
         torch.cuda.synchronize()
 
+    settle_s = float(os.environ.get("VAEX_AMD_BENCH_SETTLE_S", "0"))   # (experiments: the pass repeated for this long before the warm-up)
+    settle_trace = []
+    if settle_s > 0:
+        t_s = time.perf_counter()
+        while time.perf_counter() - t_s < settle_s:
+            step()
+            settle_trace.append((round(time.perf_counter() - t_s, 3), round(float(kernel_ms[-1]), 3)))
     for _ in range(args.warmup):
         step()
     kernel_ms.clear()
@@ -403,6 +410,8 @@ def run(args):
         }
         if os.environ.get("VAEX_AMD_BENCH_STEPS_DEBUG"):
             out["kernel_ms_per_step"] = [round(float(k), 3) for k in kernel_ms]
+            if settle_trace:
+                out["settle_trace"] = settle_trace[::max(1, len(settle_trace) // 60)]
         if world > 1:
             # rank 0's kernel time above excludes the reduce; this one is the whole step on the slowest rank against all GPUs' peak
             out["roofline"]["frac_incl_allreduce"] = BYTES_PER_ROW * rows * world / (elapsed / args.steps) / 1e9 / (world * HBM_PEAK_GBS)

@@ -1559,6 +1559,7 @@ static void run_part_chunk(Slot &slot, const BinArgs &planned, const LaunchPlan 
         P.wv = wg.waves;
         P.wv_direct = wg.direct;
         P.wv_wave_bytes = (int32_t)wg.wave_bytes;
+        P.wv_span = (int32_t)std::max<int64_t>(1, std::min<int64_t>(c.cfg_wv_span, 1 << 20));
         P.wv_base = 0;
         P.rows_per_thread = 4;
         scatter_lds = (size_t)wg.waves * wg.wave_bytes + 16;
@@ -1600,6 +1601,11 @@ static void run_part_chunk(Slot &slot, const BinArgs &planned, const LaunchPlan 
         scatter_blocks = std::min(scatter_blocks, H.blocks); // accumulator blocks are indexed by blockIdx
     } else if (slot.hot.on) {
         throw std::runtime_error("vaex_hip internal: hot box prepared for a signature pass 1 does not serve");
+    }
+    if (wv) { // no super-block deeper than a workgroup's share of the launch (and the tile arithmetic stays inside 32 bits)
+        const uint64_t tiles = (P.A.n + 255) / 256, per_wg = (tiles + (uint64_t)scatter_blocks * P.wv - 1) / ((uint64_t)scatter_blocks * P.wv);
+        P.wv_span = (int32_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)P.wv_span, per_wg));
+        if (c.cfg_no_pipeline & 1024) P.wv_span = 1; // (the three-buffer experiment deals tiles one by one)
     }
     slot.last_pass1 = wv ? (P.wv_direct ? 2 + P.wv_direct : 2) : (blk ? 1 : 0);
     slot.last_slabs = (int)S;
@@ -1842,6 +1848,7 @@ int vxh_config_set(const char *key, int64_t value) {
     else if (k == "wv_waves") c.cfg_wv_waves = value > 0 ? value : 8;
     else if (k == "wv_waves_direct") c.cfg_wv_waves_direct = value > 0 ? value : 16;
     else if (k == "wv_waves_grouped") c.cfg_wv_waves_grouped = value > 0 ? value : 8;
+    else if (k == "wv_span") c.cfg_wv_span = value > 0 ? value : 1;
     else if (k == "wv_block") c.cfg_wv_block = value;
     else if (k == "part_cap") c.cfg_part_cap = value;
     else if (k == "merge_fused") c.cfg_merge_fused = value;
@@ -1896,6 +1903,7 @@ int vxh_config_get(const char *key, int64_t *value) {
     else if (k == "wv_waves") *value = c.cfg_wv_waves;
     else if (k == "wv_waves_direct") *value = c.cfg_wv_waves_direct;
     else if (k == "wv_waves_grouped") *value = c.cfg_wv_waves_grouped;
+    else if (k == "wv_span") *value = c.cfg_wv_span;
     else if (k == "hot_direct_pct") *value = c.cfg_hot_direct_pct;
     else if (k == "wv_block") *value = c.cfg_wv_block;
     else if (k == "part_cap") *value = c.cfg_part_cap;

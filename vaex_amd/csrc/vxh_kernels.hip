@@ -1684,7 +1684,8 @@ __device__ __forceinline__ void wv_slow_record(const PartArgs &P, uint64_t cell,
 // to float64 when loaded, 2: int32, sign-extended to int64 (PartArgs::val_ct; two 8-byte loads per lane instead of two 16-byte ones)
 // BT: 1 = the binner columns are float32 (PartArgs::bin_ct), loaded and widened the same way
 // MASKED: 1 = one byte keep-mask shared by every aggregator, 2 (round 4) = the shared selection itself (P.A.pred: terms over one float64
-// column, loaded like a value column and evaluated on the rows as they are binned — no sel_eval pass, no mask bytes)
+// column, loaded like a value column and evaluated on the rows as they are binned — no sel_eval pass, no mask bytes), 3 = the same when
+// that column IS the value column (VT == 0)
 template <int NDIM, int NVAL, int MASKED, bool HOT, int KEY = 0, int DIRECT = 0, int VT = 0, int BT = 0>
 __global__ void __launch_bounds__(1024) part_scatter_wv(const PartArgs P) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -1737,7 +1738,15 @@ __global__ void __launch_bounds__(1024) part_scatter_wv(const PartArgs P) {
     // vector compare the compiler falls back to borrows a register — waiting for every load in flight to get it
     const uint32_t ntiles = (uint32_t)((n + TW - 1) / TW);
     const uint32_t GW = gridDim.x * nwave;
-    uint32_t tile = blockIdx.x * nwave + wave;
+    // tiles are dealt in super-blocks of nwave x SPAN consecutive ones per workgroup (PartArgs::wv_span; SPAN = 1: one by one)
+    const uint32_t SPAN = (uint32_t)P.wv_span, JUMP = nwave + (gridDim.x - 1u) * nwave * SPAN;
+    uint32_t in_span = 0; // (wave-uniform) trips taken inside the current super-block
+    auto tile_after = [&](uint32_t t) -> uint32_t { // the wave's tile after `t`; saturates instead of wrapping (a launch has < 2^31 rows, not < 2^32 / 256 tiles x any jump)
+        uint32_t step = nwave;
+        if (++in_span == SPAN) { in_span = 0; step = JUMP; }
+        return t > 0xffffffffu - step ? 0xffffffffu : t + step;
+    };
+    uint32_t tile = blockIdx.x * nwave * SPAN + wave;
     const bool has_work = tile < ntiles; // (wave-uniform)
 
     if (HOT) {
@@ -2033,6 +2042,11 @@ __global__ void __launch_bounds__(1024) part_scatter_wv(const PartArgs P) {
             for (int r = 0; r < R; ++r)
                 if (!pred_keep(P.A.pred, f64_of(cur.p, r))) keep &= ~(1u << r);
         }
+        if (MASKED == 3 && NVAL) { // ... over the VALUE column itself (df.mean(v, selection="v > 3")): nothing more to load
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                if (!pred_keep(P.A.pred, f64_of(cur.v, r))) keep &= ~(1u << r);
+        }
         double val[NVAL ? R : 1];
         if (NVAL) {
 #pragma unroll
@@ -2222,23 +2236,24 @@ __global__ void __launch_bounds__(1024) part_scatter_wv(const PartArgs P) {
         // uint8 counters: every wave of the workgroup comes by here once per trip, and trip t exists for ALL of them as long as the
         // workgroup's last wave has a tile 2 t GW further on — the condition is the same for the whole workgroup, so the barriers
         // of a flush are met by every wave (a wave that leaves the loop earlier has seen every flush there was)
-        const uint32_t wg_last = blockIdx.x * nwave + (nwave - 1u);
+        // (the workgroup's last wave is nwave - 1 - wave tiles ahead of this one at every trip, and tiles only grow: if ITS tile of this
+        //  trip exists, every wave of the workgroup is here)
         uint32_t trip = 0, until_flush = P.hot.flush_trips;
         for (;;) {
             if (HOT && (DIRECT == 1 || DIRECT == 3) && NVAL == 1 && csh == 2u) {
                 if (trip && --until_flush == 0u) {
                     until_flush = P.hot.flush_trips;
-                    if ((uint64_t)wg_last + 2ull * trip * GW < ntiles) flushed += hot_flush_counts();
+                    if ((uint64_t)tile - wave + (nwave - 1u) < ntiles) flushed += hot_flush_counts();
                 }
                 ++trip;
             }
-            uint32_t next = tile + GW;
+            uint32_t next = tile_after(tile);
             bool has_next = next < ntiles;
             request(has_next ? next : tile, bufB); // (the last tile re-requests itself: static number of loads in flight)
             process(bufA);
             if (!has_next) break;
             tile = next;
-            next = tile + GW;
+            next = tile_after(tile);
             has_next = next < ntiles;
             request(has_next ? next : tile, bufA);
             process(bufB);
@@ -3030,9 +3045,11 @@ void vxh_launch_part_scatter(const PartArgs &args, const LaunchPlan &plan, int s
         const bool hot = args.hot.on == 2, masked = args.nmasks > 0;
         const bool pred = args.A.pred.on != 0; // the shared selection evaluated in the kernel (the host checks: float64 columns only, no conversions)
         if (pred && (args.val_ct || args.bin_ct || plan.key_i64 || (hot && args.wv_direct != 1 && args.wv_direct != 3))) throw std::runtime_error("vaex_hip internal: fused selection next to a pass 1 that is not instantiated for it");
+        const bool pred_v = pred && args.nvals == 1 && args.A.pred.col == args.vdata[0] && !args.val_i64; // the selection reads the value column
 #define VXH_WV(ND)                                                                                                     \
     do {                                                                                                               \
-        if (pred) { if (args.nvals == 0) VXH_SC((part_scatter_wv<ND, 0, 2, false>)); else VXH_SC((part_scatter_wv<ND, 1, 2, false>)); } \
+        if (pred_v) VXH_SC((part_scatter_wv<ND, 1, 3, false>));                                                        \
+        else if (pred) { if (args.nvals == 0) VXH_SC((part_scatter_wv<ND, 0, 2, false>)); else VXH_SC((part_scatter_wv<ND, 1, 2, false>)); } \
         else if (args.nvals == 0) { if (masked) VXH_SC((part_scatter_wv<ND, 0, true, false>)); else VXH_SC((part_scatter_wv<ND, 0, false, false>)); } \
         else { if (masked) VXH_SC((part_scatter_wv<ND, 1, true, false>)); else VXH_SC((part_scatter_wv<ND, 1, false, false>)); } \
     } while (0)
@@ -3067,6 +3084,8 @@ void vxh_launch_part_scatter(const PartArgs &args, const LaunchPlan &plan, int s
             if (args.nvals == 0) { if (masked) VXH_SC((part_scatter_wv<1, 0, true, false, 1>)); else VXH_SC((part_scatter_wv<1, 0, false, false, 1>)); }
             else { if (masked) VXH_SC((part_scatter_wv<1, 1, true, false, 1>)); else VXH_SC((part_scatter_wv<1, 1, false, false, 1>)); }
         }
+        else if (hot && args.wv_direct == 3 && pred_v) VXH_SC((part_scatter_wv<2, 1, 3, true, 0, 3>));
+        else if (hot && args.wv_direct == 1 && pred_v) VXH_SC((part_scatter_wv<2, 1, 3, true, 0, 1>));
         else if (hot && args.wv_direct == 3 && pred) { if (args.nvals == 0) VXH_SC((part_scatter_wv<2, 0, 2, true, 0, 3>)); else VXH_SC((part_scatter_wv<2, 1, 2, true, 0, 3>)); }
         else if (hot && args.wv_direct == 1 && pred) { if (args.nvals == 0) VXH_SC((part_scatter_wv<2, 0, 2, true, 0, 1>)); else VXH_SC((part_scatter_wv<2, 1, 2, true, 0, 1>)); }
         else if (hot && args.wv_direct == 3 && masked) { if (args.nvals == 0) VXH_SC((part_scatter_wv<2, 0, true, true, 0, 3>)); else VXH_SC((part_scatter_wv<2, 1, true, true, 0, 3>)); }

@@ -129,6 +129,10 @@ struct PartArgs {
     // pass 1 = part_scatter_wv (barrier-free, wave-private staging rings): wv = waves per workgroup (0: not this
     // kernel); each wave's LDS area of wv_wave_bytes starts at wv_base + wave * wv_wave_bytes
     int32_t wv, wv_base, wv_wave_bytes;
+    // ... how its tiles are dealt: a workgroup takes SUPER-BLOCKS of wv x wv_span consecutive tiles (its waves side by side, wv_span trips
+    // deep), the super-blocks go round robin over the workgroups.  1 = tiles dealt one by one over the whole launch (every trip of a wave is
+    // 8 MiB further on in every column: a page the CU has not touched before); large = every workgroup walks its own contiguous range
+    int32_t wv_span;
     int32_t qrec12;    // the queue holds 12-byte records {value bits, local index} in qidx (ring-less variant with one value column); qval unused
     uint64_t qsink;    // ring-less variant: record index of the first sink record (one per wave, 16 records apart) behind the sub-queues
     // wv_direct == 2 (one record stream per (workgroup, slab)): HBM copy of the block entries, [workgroup][slab][qbtab_stride] x 16 bytes
