@@ -46,7 +46,7 @@ n = 200_000
 v = rng.normal(3, 2, n); v[::97] = np.nan
 df = vaex.from_arrays(k=rng.integers(-5, 40, n), k32=rng.integers(100, 130, n).astype("i4"), ku=rng.integers(0, 9, n).astype("u2"),
                       kgap=rng.integers(0, 50, n) * 3, ks=(rng.integers(0, 3000, n) * 2654435761) %% (1 << 40), kf=rng.integers(0, 5, n).astype("f8"),
-                      k8=rng.integers(0, 5, n).astype("i1"),
+                      k8=rng.integers(-3, 5, n).astype("i1"), ku8=rng.integers(0, 7, n).astype("u1"), kb=rng.integers(0, 2, n).astype(bool),
                       v=v, w=rng.normal(0, 1, n).astype("f4"), i=rng.integers(-100, 100, n).astype("i4"))
 df["virt"] = df.k + 1
 
@@ -85,6 +85,14 @@ taken = [
   ("ku", A.mean("v"), dict(sort=True)),   # (descending on an unsigned key trips vaex's own BinnerInteger: vmin - 2 wraps, vaex/groupby.py:162-166)
   ("kgap", {"s": A.sum("v"), "c": A.count()}, {}),
   ("k", {"lo": A.min("v"), "hi": A.max("v"), "ilo": A.min("i"), "s": A.sum("v")}, {}),                 # range 148 > 4/3 * 50 keys: vaex keeps its Grouper (narrowed key dtype)
+  # round 4: bool / int8 / uint8 keys (vaex: BinnerInteger from the start), aggregations with a selection, var / std of an integer column
+  ("k8", {"c": A.count(), "m": A.mean("v")}, {}),
+  ("ku8", {"c": A.count("v"), "s": A.sum("i")}, dict(sort=True, ascending=False)),
+  ("kb", {"c": A.count(), "s": A.sum("v"), "sd": A.std("v")}, {}),
+  ("k", {"c": A.count(selection="v > 3"), "s": A.sum("v", selection="i < 0"), "n": A.count()}, {}),
+  ("k", {"m": A.mean("v", selection="(v > 3) & (i < 50)"), "sd": A.std("v", selection="v > 3")}, {}),
+  ("kgap", {"c": A.count(selection="w >= 0")}, {}),                                                      # (no count(*) among the actions: the groups still come from all rows)
+  ("k", {"sd": A.std("i"), "va": A.var("i"), "m": A.mean("i")}, {}),
 ]
 if gpu:   # (several keys are packed on the device, scattered keys need the hash aggregation: no CPU stand-in)
     taken += [(["k", "k32"], {"c": A.count(), "s": A.sum("v")}, {}),
@@ -93,12 +101,12 @@ if gpu:   # (several keys are packed on the device, scattered keys need the hash
               (["ks", "ku"], {"c": A.count("v")}, {})]
 declined = [
   ("kf", {"c": A.count()}, "dtype float64"),
-  ("k8", {"c": A.count()}, "dtype int8"),
+  (["k8", "k"], {"c": A.count()}, "int8 key next to other keys"),
   ("virt", {"c": A.count()}, "not a real column"),
   ("k", {"u": A.nunique("i")}, "AggNUnique"),
   ("k", {"lo": A.first("v", "i")}, "AggFirst"),
-  ("k", {"c": A.count(selection="v > 3")}, "selection"),
-  ("k", {"sd": A.std("i")}, "var / std of an integer column"),
+  ("k", {"c": A.count(selection="sin(v) > 0")}, "selection outside the device predicate subset"),
+  ("k", {"lo": A.min("v", selection="v > 3")}, "min / max with a selection"),
 ]
 for by, agg, kw in taken:
     vg.last.clear()
@@ -150,9 +158,13 @@ assert vg.last.get("path") == "device" and "_lazy" in g.__dict__, vg.last
 want = original(df, "k", sort=True).agg({"v": ["sum", "mean"], "i": "max"})
 assert got.get_column_names() == want.get_column_names()
 same({c: got[c].to_numpy() for c in got.get_column_names()}, {c: want[c].to_numpy() for c in want.get_column_names()}, "lazy agg")
-got = g.agg({"c": A.count(selection="v > 3")})     # outside the signature: becomes the real object, answers as vaex does
-assert "_lazy" not in g.__dict__ and vg.last.get("path") == "vaex"
+got = g.agg({"c": A.count(selection="v > 3")})     # (round 4: inside the signature too)
+assert vg.last.get("path") == "device" and "_lazy" in g.__dict__, vg.last
 want = original(df, "k", sort=True).agg({"c": A.count(selection="v > 3")})
+same({c: got[c].to_numpy() for c in got.get_column_names()}, {c: want[c].to_numpy() for c in want.get_column_names()}, "lazy agg with a selection")
+got = g.agg({"c": A.count(selection="sin(v) > 0")})     # outside the signature: becomes the real object, answers as vaex does
+assert "_lazy" not in g.__dict__ and vg.last.get("path") == "vaex"
+want = original(df, "k", sort=True).agg({"c": A.count(selection="sin(v) > 0")})
 same({c: got[c].to_numpy() for c in got.get_column_names()}, {c: want[c].to_numpy() for c in want.get_column_names()}, "lazy agg declined")
 g = df.groupby("k")
 assert "_lazy" in g.__dict__ and len(list(g.groups)) == len(np.unique(df.k.to_numpy())) and "_lazy" not in g.__dict__   # (any other attribute: the real one)
@@ -160,6 +172,17 @@ assert same({c: g.get_group(3)[c].to_numpy() for c in ["k", "v"]}, {c: original(
 assert type(df.groupby("kf")).__name__ == "GroupBy" and type(df.groupby(df.k + 1)).__name__ == "GroupBy"   # (keys the device groupby does not take)
 assert type(df.groupby("k", row_limit=100)).__name__ == "GroupBy"
 print("ok-lazy")
+# progress= reaches the device groupby too: the callable sees 0 before the pass and 1 after it, a False before the pass cancels (vaex's UserAbort)
+seen = []
+vg.last.clear()
+got = df.groupby("k", agg={"c": A.count()}, progress=lambda f: seen.append(f) or True)
+assert vg.last.get("path") == "device" and seen and seen[0] == 0.0 and seen[-1] == 1.0, (vg.last, seen)
+try:
+    df.groupby("k", agg={"c": A.count()}, progress=lambda f: False)
+    raise SystemExit("a progress callback returning False did not cancel")
+except vaex.execution.UserAbort:
+    pass
+print("ok-progress")
 # a slice of the frame (active range)
 part = df[1000:150_000]
 vg.last.clear()
@@ -191,7 +214,7 @@ def _run(gpu, timeout):
 @pytest.mark.skipif(not os.path.isdir(os.path.join(PKG, "vaex")), reason="real vaex package not built (oracle/build_ref.sh needs /root/reference)")
 def test_groupby_host_logic_against_vaex_on_the_reference_cpp():
     out = _run(0, 600)
-    assert "DONE" in out and out.count("ok-device ") == 8 and out.count("ok-device-filtered") == 4 and out.count("ok-declined") == 7, out
+    assert "DONE" in out and out.count("ok-device ") == 15 and out.count("ok-device-filtered") == 4 and out.count("ok-declined") == 7, out
     assert "ok-device-failure-falls-back" in out, out
 
 
@@ -199,5 +222,5 @@ def test_groupby_host_logic_against_vaex_on_the_reference_cpp():
 @pytest.mark.skipif(not os.path.isdir(os.path.join(PKG, "vaex")), reason="real vaex package not built (oracle/build_ref.sh needs /root/reference)")
 def test_groupby_of_real_vaex_runs_on_the_device_groupby():
     out = _run(1, 900)
-    assert "DONE" in out and out.count("ok-device ") == 12 and out.count("ok-device-filtered") == 6 and out.count("ok-declined") == 7, out
+    assert "DONE" in out and out.count("ok-device ") == 19 and out.count("ok-device-filtered") == 6 and out.count("ok-declined") == 7, out
     assert "gb_scatter+gb_reduce" in out and "bin_lds" in out, out   # (the fused hash aggregation, and — few groups — the LDS-resident grid)

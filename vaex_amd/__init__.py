@@ -86,7 +86,7 @@ task_stats = {"hip": 0, "cpu": 0, "cpu_reasons": {}}
 AUTO_CHUNK_ROWS_MAX = 1 << 26   # install(chunk_size="auto"): upper bracket of vaex's automatic chunk size (rows)
 
 
-def install(vaex_module=None, legacy=True, hash_sets=True, chunk_size="auto", groupby=True, selections=True, filters=True):
+def install(vaex_module=None, legacy=True, hash_sets=True, chunk_size="auto", groupby=True, selections=True, filters=True, distributed=False, group=None):
     """Plug the HIP kernels into an unmodified vaex.
 
     * `vaex.superagg` becomes a `_Backend` and the task-part registry entry "aggregations" (vaex/cpu.py:629-631,
@@ -112,7 +112,10 @@ def install(vaex_module=None, legacy=True, hash_sets=True, chunk_size="auto", gr
       take the filter as a keep-mask — a device predicate where it compiles — instead of vaex copying every column through a boolean
       index per chunk (vaex_amd/vaex_filter.py); the device column cache then serves filtered frames too.
     * groupby=True: df.groupby(<integer key columns>, agg=count / sum / mean / var / std ...) is answered by the device
-      groupby (vaex_amd/vaex_groupby.py) instead of vaex's two passes; everything else falls through to vaex's own code."""
+      groupby (vaex_amd/vaex_groupby.py) instead of vaex's two passes; everything else falls through to vaex's own code.
+    * distributed=True (torch.distributed initialised, one process per GPU; `group`: the ranks that share the table): every rank
+      runs the same vaex program on its shard (`vaex_amd.shard(df)`), and the task parts' reduce() — where vaex merges its threads
+      (vaex/cpu.py:788-796) — also merges across the ranks: one RCCL all-reduce per aggregator grid (vaex_amd/vaex_dist.py)."""
     import sys
     if vaex_module is None:
         import vaex as vaex_module
@@ -185,7 +188,11 @@ def install(vaex_module=None, legacy=True, hash_sets=True, chunk_size="auto", gr
             return internal.bytes_used() if hasattr(internal, "bytes_used") else sys.getsizeof(internal)
 
     _installed["hash_task_cls"] = base_h
+    _installed["hash_task_hip"] = TaskPartHashmapUniqueCreateHip
     vaex.cpu.register(TaskPartHashmapUniqueCreateHip)
+    if distributed:
+        from . import vaex_dist
+        vaex_dist.install(vaex_module, _installed, base_agg=TaskPartAggregationHip, group=group)
     if legacy:
         from . import vaexfast as _vf
         legacy_mod = getattr(vaex_module, "vaexfast", None) or sys.modules.get("vaex.vaexfast")
@@ -235,6 +242,12 @@ def install(vaex_module=None, legacy=True, hash_sets=True, chunk_size="auto", gr
     return backend
 
 
+def shard(df, group=None):
+    """this rank's contiguous row range of a vaex DataFrame (install(distributed=True): vaex_amd/vaex_dist.py)"""
+    from . import vaex_dist
+    return vaex_dist.shard(df, group)
+
+
 def uninstall():
     """undo install() (tests)"""
     import sys
@@ -245,6 +258,9 @@ def uninstall():
     vaex_module = _installed["vaex"]
     vaex_module.superagg = _installed["cpu_module"]
     sys.modules["vaex.superagg"] = _installed["cpu_module"]
+    if "dist" in _installed:
+        from . import vaex_dist
+        vaex_dist.uninstall(vaex_module, _installed)
     vaex.cpu.register(_installed["task_cls"])
     if "hash_task_cls" in _installed:
         vaex.cpu.register(_installed["hash_task_cls"])

@@ -7,10 +7,12 @@ and mean / var / std are finished with numpy over the full grids (vaex/agg.py:38
 classes under that machinery already; this module goes one step further for the calls the device groupby of
 vaex_amd.binned.Frame covers — it answers `DataFrame.groupby(by, agg=...)` itself:
 
-    keys   1..8 real integer columns (int16 .. int64, uint16 .. uint32; numpy / memory-mapped, no missing values)
-    agg    count(*) / count(x) / sum(x) / mean(x) / var(x) / std(x) / min(x) / max(x) on real numeric columns without missing values, no
-           selection — given as vaex.agg objects, names ('count', 'mean', ...), lists or {name: ...} dicts, i.e. every
-           form GroupByBase._agg accepts (vaex/groupby.py:688-745; the output column names follow its rules)
+    keys   1..8 real integer columns (bool, int8 .. int64, uint8 .. uint32; numpy / memory-mapped, no missing values)
+    agg    count(*) / count(x) / sum(x) / mean(x) / var(x) / std(x) / min(x) / max(x) on real numeric columns without missing values,
+           each with or without a selection of vaex_amd.predicate's subset (an expression or a named selection: the groups are those of
+           ALL rows, an aggregation sees the rows its selection keeps — vaex/groupby.py:884-899) — given as vaex.agg objects, names
+           ('count', 'mean', ...), lists or {name: ...} dicts, i.e. every form GroupByBase._agg accepts: the actions are walked by
+           vaex's OWN loop (vaex/groupby.py:688-745) over a frame that records the aggregations instead of running them
     frame  unfiltered, or filtered by comparison expressions over real numeric columns (vaex_amd.predicate's subset: the filter
            becomes a device predicate); row_limit=None
 
@@ -37,7 +39,8 @@ last = {}
 #: df.groupby calls answered by the device groupby / handed on to vaex's own two passes (with the reasons)
 stats = {"device": 0, "vaex": 0, "why": {}}
 
-_KEY_KINDS = ("int16", "int32", "int64", "uint16", "uint32")
+_KEY_KINDS = ("bool", "int8", "int16", "int32", "int64", "uint8", "uint16", "uint32")
+_TINY_KEYS = ("bool", "int8", "uint8")   # vaex bins these with BinnerInteger straight away (vaex/groupby.py:593-595): no combined grouper, own key typing
 _VALUE_KINDS = ("float64", "float32", "int64", "int32", "int16", "int8", "uint32", "uint16", "uint8")
 _AGG_NAMES = {"AggCount": "count", "AggSum": "sum", "AggMin": "min", "AggMax": "max"}
 
@@ -65,56 +68,55 @@ def _real_column(df, expression, kinds, what):
     return name, ar
 
 
+class _RecordingFrame:
+    """the DataFrame as GroupByBase._agg sees it: `_agg` records the aggregation instead of scheduling it, the rest is the real frame"""
+
+    def __init__(self, df):
+        self.__dict__["_df"] = df
+        self.__dict__["recorded"] = []
+
+    def _agg(self, aggregate, binners=(), delay=False, progress=None, **kw):
+        self.recorded.append(aggregate)
+        return None
+
+    def __getattr__(self, name):
+        return getattr(self._df, name)
+
+    def __getitem__(self, item):
+        return self._df[item]
+
+
 def _normalise_actions(df, keys, actions):
-    """[(output column name, vaex aggregator descriptor)] — the iteration of GroupByBase._agg (vaex/groupby.py:688-745)"""
+    """[(output column name, vaex aggregator descriptor)] in vaex's order, by running vaex's own action loop — GroupByBase._agg
+    (vaex/groupby.py:688-745: lists, dicts, names, callables over all columns, override names) — on a bare GroupByBase whose
+    frame records what it is asked to aggregate"""
     import vaex.agg
-    out = []
-    if isinstance(actions, collections.abc.Mapping):
-        actions = list(actions.items())
-    elif not isinstance(actions, collections.abc.Iterable) or isinstance(actions, str):
-        actions = [actions]
-
-    def add(aggregate, column_name=None, override_name=None):
-        if column_name is None or override_name is not None:
-            column_name = aggregate.pretty_name(override_name, df)
-        out.append((column_name, aggregate))
-
-    for item in actions:
-        override_name = None
-        if isinstance(item, tuple):
-            name, aggregates = item
-        else:
-            aggregates = item
-            name = None
-        if not isinstance(aggregates, collections.abc.Iterable) or isinstance(aggregates, str):
-            aggregates = [aggregates]
-        elif name is not None:
-            override_name = name
-        for aggregate in aggregates:
-            if isinstance(aggregate, str) and aggregate == "count":
-                add(vaex.agg.count(), "count" if name is None else name)
-                continue
-            if isinstance(aggregate, str):
-                if aggregate not in vaex.agg.aggregates:
-                    raise _Decline(f"unknown aggregate {aggregate!r}")
-                aggregate = vaex.agg.aggregates[aggregate]
-            if callable(aggregate) and not isinstance(aggregate, vaex.agg.AggregatorDescriptor):
-                if name is None:
-                    for column_name in df.get_column_names():
-                        if column_name not in keys:
-                            add(aggregate(column_name), override_name=override_name)
-                else:
-                    add(aggregate(name), name, override_name=override_name)
-            else:
-                add(aggregate, name, override_name=override_name)
-    return out
+    import vaex.groupby
+    rec = _RecordingFrame(df)
+    shell = object.__new__(vaex.groupby.GroupByBase)
+    shell.df = rec
+    shell.binners = ()
+    shell.groupby_expression = list(keys)
+    for a in ([actions] if isinstance(actions, (str, vaex.agg.AggregatorDescriptor)) or not isinstance(actions, collections.abc.Iterable) else
+              (actions.values() if isinstance(actions, collections.abc.Mapping) else actions)):
+        for one in (a if isinstance(a, (list, tuple)) else [a]):
+            if isinstance(one, str) and one != "count" and one not in vaex.agg.aggregates:
+                raise _Decline(f"unknown aggregate {one!r}")
+    try:
+        grids = vaex.groupby.GroupByBase._agg(shell, actions, None)
+    except (KeyError, TypeError, ValueError, AttributeError) as e:
+        raise _Decline(f"actions vaex does not take: {type(e).__name__}: {e}")
+    if len(grids) != len(rec.recorded):
+        raise _Decline("duplicate output column")
+    for a in rec.recorded:   # (vaex's loop sets it on every aggregation it schedules; these objects are the caller's and may be reused)
+        a.edges = False
+    return list(zip(grids.keys(), rec.recorded))
 
 
 def _translate(df, aggregate, columns):
     """vaex aggregator descriptor -> binned.agg descriptor; the value column is entered into `columns`"""
     import vaex.agg
-    if getattr(aggregate, "selection", None) is not None:
-        raise _Decline("aggregation with a selection")
+    selection = _selection_of(df, aggregate, columns)
     if isinstance(aggregate, vaex.agg.AggregatorDescriptorBasic):
         kind = _AGG_NAMES.get(aggregate.name)
         if kind is None or aggregate.agg_args:
@@ -127,21 +129,51 @@ def _translate(df, aggregate, columns):
         raise _Decline(f"aggregator {type(aggregate).__name__}")
     expressions = list(aggregate.expressions)
     if kind == "count" and not expressions:
-        return binned.agg.count()
+        return binned.agg.count(selection=selection)
     if len(expressions) != 1:
         raise _Decline("aggregator over several expressions")
     name, ar = _real_column(df, expressions[0], _VALUE_KINDS, "aggregated expression")
-    if kind in ("var", "std") and ar.dtype.kind != "f":
-        raise _Decline("var / std of an integer column")  # (vaex casts to float64 first: vaex/agg.py:427)
-    columns[name] = ar
-    return getattr(binned.agg, kind)(name)
+    if selection is not None and kind in ("min", "max"):
+        raise _Decline("min / max with a selection")   # (a group without a selected row: vaex hands back the dtype's extreme, masked or not by dtype)
+    columns[name] = ar   # (var / std of an integer column: the primitives run on astype(float64), as vaex/agg.py:427 does)
+    return getattr(binned.agg, kind)(name, selection=selection)
 
 
-def _key_column_like_vaex(values):
+def _selection_of(df, aggregate, columns):
+    """the aggregation's selection as an expression of the device predicate subset (its columns entered into `columns`), or None"""
+    sel = getattr(aggregate, "selection", None)
+    if sel is None or sel is False:
+        return None
+    if isinstance(sel, (list, tuple)):
+        raise _Decline("aggregation with several selections")
+    if df.filtered:
+        raise _Decline("aggregation with a selection on a filtered frame")
+    from . import vaex_selection, predicate
+    sel = "default" if sel is True else str(sel)
+    if df.has_selection(sel):   # a named selection: its history as one expression
+        sel = vaex_selection.named_expression(df, sel)
+        if not sel:
+            raise _Decline("named selection outside the device predicate subset")
+    try:
+        pred = predicate.compile_selection(sel, vaex_selection._known_columns(df))
+    except predicate.Unsupported as e:
+        raise _Decline(f"selection outside the device predicate subset ({e})")
+    for c in pred.columns:
+        if c not in columns:
+            columns[c] = _real_column(df, c, tuple(k for k in vaex_selection._NUMERIC), "selection column")[1]
+    return sel
+
+
+def _key_column_like_vaex(values, source_kind=None):
     """a key column of the result typed the way vaex's groupers hand it back (vaex/groupby.py:147-205, :263-277) — decided per key
     from its distinct values: BinnerInteger (range <= 4/3 of the distinct keys) -> int64 with an (empty) mask; else Grouper -> the
-    narrowest signed integer type that holds the range"""
+    narrowest signed integer type that holds the range.  bool / int8 / uint8 keys are BinnerInteger from the start (vaex/groupby.py:
+    593-595): bin_values [False, True, null] resp. arange + null as a masked int64 array (:166-187)"""
     k = np.asarray(values)
+    if source_kind == "bool":
+        return np.ma.array(k.astype(bool), mask=np.zeros(len(k), dtype=bool), shrink=False)
+    if source_kind in ("int8", "uint8"):
+        return np.ma.array(k.astype(np.int64), mask=np.zeros(len(k), dtype=bool), shrink=False)
     if len(k) == 0:
         return k
     vmin, vmax = int(k.min()), int(k.max())
@@ -178,6 +210,8 @@ def fast_groupby(df, by, agg, sort=False, ascending=True, row_limit=None):
         name, ar = _real_column(df, vaex.utils._ensure_string_from_expression(b), _KEY_KINDS, "group key")
         if name in columns:
             raise _Decline("the same key twice")
+        if ar.dtype.name in _TINY_KEYS and len(by_list) > 1:
+            raise _Decline(f"{ar.dtype.name} key next to other keys")   # (BinnerInteger's N is the dtype's range, not the distinct keys: vaex's combine decision differs)
         columns[name] = ar
         key_names.append(name)
     actions = _normalise_actions(df, key_names, agg)
@@ -214,7 +248,7 @@ def fast_groupby(df, by, agg, sort=False, ascending=True, row_limit=None):
         raise _Decline(f"device groupby failed: {type(e).__name__}: {str(e)[:200]}")
     descending = bool(srt[0]) and not asc[0]
     out = {}
-    typed = {name: _key_column_like_vaex(np.asarray(res[name])) for name in key_names}
+    typed = {name: _key_column_like_vaex(np.asarray(res[name]), columns[name].dtype.name) for name in key_names}
     # several keys: vaex packs them into one grouper when the cartesian product of the key sets is sparsely occupied (< 10 rows
     # per cell, combine='auto': vaex/groupby.py:660-672); the key columns then come back through arrow, as plain arrays
     cells = 1
@@ -261,7 +295,8 @@ def _frame_for(df, columns):
             cols[name] = ar
     if len({binned._is_device(c) for c in cols.values()}) > 1:  # (the fused pass wants keys and values in one place)
         cols = dict(columns)
-    return binned.Frame(cols)
+    from . import vaex_dist
+    return binned.Frame(cols, comm=vaex_dist.comm())   # (install(distributed=True): the ranks agree on key ranges / unions and merge their partial groups)
 
 
 def drop_device_copies():
@@ -287,6 +322,25 @@ def _could_be_served(df, by, row_limit):
     except (_Decline, Exception):
         return False
     return True
+
+
+def _served(progress, fn):
+    """fn() under vaex's progress protocol (vaex/progress.py: a bool, a name or a callable f(fraction) whose False cancels): the device
+    groupby is ONE uninterruptible pass, so the callback is asked before it starts — a False there is vaex's UserAbort
+    (vaex/execution.py:UserAbort) — and told 1.0 when the result exists"""
+    if progress is None or progress is False:
+        return fn()
+    import vaex.execution
+    import vaex.utils
+    bar = vaex.utils.progressbars(progress, title="groupby")
+    if bar(0.0) is False:
+        raise vaex.execution.UserAbort("cancelled")
+    try:
+        result = fn()
+    except _Decline:
+        raise
+    bar(1.0)
+    return result
 
 
 def install(vaex_module, state):
@@ -327,7 +381,8 @@ def install(vaex_module, state):
             if "_lazy" in self.__dict__:
                 df, kw = self.__dict__["_lazy"]
                 try:
-                    result = fast_groupby(df, kw["by"], actions, sort=kw["sort"], ascending=kw["ascending"], row_limit=kw["row_limit"])
+                    result = _served(progress if progress is not None else kw.get("progress"),
+                                     lambda: fast_groupby(df, kw["by"], actions, sort=kw["sort"], ascending=kw["ascending"], row_limit=kw["row_limit"]))
                 except _Decline as e:
                     declined(e)
                     self._materialise()
@@ -339,7 +394,7 @@ def install(vaex_module, state):
     def groupby(self, by=None, agg=None, sort=False, ascending=True, assume_sparse="auto", row_limit=None, copy=True, progress=None, delay=False):
         if agg is not None:
             try:
-                result = fast_groupby(self, by, agg, sort=sort, ascending=ascending, row_limit=row_limit)
+                result = _served(progress, lambda: fast_groupby(self, by, agg, sort=sort, ascending=ascending, row_limit=row_limit))
             except _Decline as e:
                 declined(e)
             else:
