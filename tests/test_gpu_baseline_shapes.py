@@ -653,6 +653,90 @@ def test_other_value_dtypes_ride_the_fast_kernels(sa, shape, vdtype):
             np.testing.assert_array_equal(head[k], want[k])
 
 
+@pytest.mark.parametrize("bdtype", ["int64", "int32"])
+@pytest.mark.parametrize("shape", ["hours_2d_sum", "ids_1d_count", "three_d_masked", "wide_2d_int64_values"])
+def test_integer_binner_columns_ride_the_fast_kernels(sa, shape, bdtype):
+    """round 4: int64 / int32 BINNER columns (df.count(binby=[hour, weekday]), ids, datetimes as integers) on grids larger
+    than one CU's LDS.  BinnerScalar<T> converts the element to double before `(value - vmin) * scale` (src/binners.cpp:16-35);
+    part_scatter_wv does that as it loads the column (PartArgs::bin_ct 2 / 3) instead of the generic pair reading every element through
+    its dtype.  Cells bit-exact against the reference's C++ on a slice (integers that sit exactly ON bin edges included), linear over
+    a split of the rows at the full size."""
+    import torch
+    g = torch.Generator(device="cuda").manual_seed(99)
+    n = 1 << 26
+    tdt = torch.int64 if bdtype == "int64" else torch.int32
+    # integer columns whose values land on bin edges of [0, 1024) in 512 bins (every even value IS an edge), below and above the limits
+    a = torch.randint(-40, 1100, (n,), dtype=torch.int64, device="cuda", generator=g).to(tdt)
+    b = torch.randint(-5, 1030, (n,), dtype=torch.int64, device="cuda", generator=g).to(tdt)
+    c = torch.randint(0, 1024, (n,), dtype=torch.int64, device="cuda", generator=g).to(tdt)
+    if bdtype == "int64":
+        a[::100_003] = (1 << 62)          # (far outside: the overflow cell; exactly representable as a double)
+        a[1::100_003] = -(1 << 62)
+    v = torch.randn(n, dtype=torch.float64, device="cuda", generator=g) * 2 + 3
+    v[::1013] = float("nan")
+    iv = torch.randint(-(1 << 40), 1 << 40, (n,), dtype=torch.int64, device="cuda", generator=g)
+    keep = (torch.rand(n, device="cuda", generator=g) < 0.5).to(torch.uint8)
+    torch.cuda.synchronize()
+    Scalar = getattr(sa, "BinnerScalar_" + bdtype)
+    cols = dict(a=a, b=b, c=c)
+    # (grids of <= 16 slabs: the box-less part_scatter_wv keeps a ring per (wave, slab) — beyond that its rings do not fit the LDS and the
+    #  generic pair still serves integer binner columns)
+    spec = {"hours_2d_sum": (["a", "b"], 256, "f64"), "ids_1d_count": (["a"], 1 << 17, None), "three_d_masked": (["a", "b", "c"], 32, "f64"),
+            "wide_2d_int64_values": (["b", "c"], 384, "i64")}[shape]
+    names, bins, vkind = spec
+    lim = (0.0, float(1 << 17)) if shape == "ids_1d_count" else (0.0, 1024.0)
+
+    def run(lo, hi):
+        binners = [Scalar(1, nm, lim[0], lim[1], bins) for nm in names]
+        for bn, nm in zip(binners, names):
+            bn.set_data(0, cols[nm][lo:hi])
+        grid = sa.Grid(binners)
+        if vkind == "f64":
+            aggs = [sa.AggCount_int64(grid, 1, 1), sa.AggSum_float64(grid, 1, 1), sa.AggCount_float64(grid, 1, 1)]
+            aggs[1].set_data(0, v[lo:hi], 0); aggs[2].set_data(0, v[lo:hi], 0)
+        elif vkind == "i64":
+            aggs = [sa.AggCount_int64(grid, 1, 1), sa.AggSum_int64(grid, 1, 1)]
+            aggs[1].set_data(0, iv[lo:hi], 0)
+        else:
+            aggs = [sa.AggCount_int64(grid, 1, 1)]
+        if shape == "three_d_masked":
+            for ag in aggs:
+                ag.set_data_mask(0, keep[lo:hi])
+        grid.bin(0, aggs, hi - lo)
+        return [np.array(ag.get_result()) for ag in aggs], sa.last_kernel(0)
+
+    full, kernel = run(0, n)
+    assert kernel.startswith("part_scatter_wv") and "generic" not in kernel, kernel
+    m = 4_000_000
+    head, _ = run(0, m)
+    rest, _ = run(m, n)
+    np.testing.assert_array_equal(full[0], head[0] + rest[0])
+    assert int(full[0].sum()) == (int(keep.sum().item()) if shape == "three_d_masked" else n)
+    if vkind == "i64":
+        with np.errstate(over="ignore"):
+            np.testing.assert_array_equal(full[1], head[1] + rest[1])
+    bs = [dict(kind="scalar", data=cols[nm][:m].cpu().numpy(), vmin=lim[0], vmax=lim[1], bins=bins) for nm in names]
+    if vkind == "f64":
+        vs = v[:m].cpu().numpy()
+        aggs = [dict(kind="count"), dict(kind="sum", data=vs), dict(kind="count", data=vs)]
+    elif vkind == "i64":
+        aggs = [dict(kind="count"), dict(kind="sum", data=iv[:m].cpu().numpy())]
+    else:
+        aggs = [dict(kind="count")]
+    if shape == "three_d_masked":
+        ks = keep[:m].cpu().numpy()
+        for ag in aggs:
+            ag["mask"] = ks
+    case = dict(n=m, binners=bs, aggs=aggs)
+    want = _ref_or_port_case(_ref_module(), case)
+    np.testing.assert_array_equal(head[0], want[0])
+    if vkind == "i64":
+        np.testing.assert_array_equal(head[1], want[1])
+    elif vkind == "f64":
+        np.testing.assert_array_equal(head[2], want[2])
+        cases.assert_case_equal(head, want, case)
+
+
 # ------------------------------------------------------------------------------------------------------------
 # round 4: the GROUPED pass 1 ("wv" = 5: cold records compacted into a wave-private ring, slab-sorted 64-record groups in one
 # stream per wave, pass 2 = part_reduce_grp) against the ring-less one ("wv" = 3) and the reference's C++

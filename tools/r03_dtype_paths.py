@@ -40,3 +40,30 @@ for name, v in list(vals.items()) + [("f32bin+float64", vals["float64"]), ("f32b
     assert total == rows
     bytes_per_row = (8 if f32bin else 16) + v.element_size()
     print(f"binners {'float32' if f32bin else 'float64'} value {name:<8} {best:8.3f} ms {rows/best/1e6:7.1f} Grows/s  {rows*bytes_per_row/best/1e6/8000:6.3f} of 8 TB/s on {bytes_per_row} B/row   {sa.last_kernel(0)}", flush=True)
+
+# round 4: integer BINNER columns (converted on load by part_scatter_wv: PartArgs::bin_ct 2 / 3), 256 x 256 cells: 8 slabs
+for bname, tdt in (("int64", torch.int64), ("int32", torch.int32)):
+    xi = torch.randint(0, 1024, (rows,), dtype=torch.int64, device="cuda", generator=g).to(tdt)
+    yi = torch.randint(0, 1024, (rows,), dtype=torch.int64, device="cuda", generator=g).to(tdt)
+    B = getattr(sa, "BinnerScalar_" + bname)
+    for knob in (1, 0):   # 0: what ran before (the generic pair)
+        sa.config_set("wv", 5 if knob else 0); sa.config_set("blk", 1 if knob else 0)
+        bx = B(1, "x", 0.0, 1024.0, 256); by = B(1, "y", 0.0, 1024.0, 256)
+        grid = sa.Grid([bx, by])
+        v = vals["float64"]
+        aggs = [sa.AggCount_int64(grid, 1, 1), sa.AggSum_float64(grid, 1, 1), sa.AggCount_float64(grid, 1, 1)]
+        bx.set_data(0, xi); by.set_data(0, yi); aggs[1].set_data(0, v, 0); aggs[2].set_data(0, v, 0)
+        best = 1e9
+        for r in range(reps + 1):
+            for a in aggs:
+                a.reset()
+            sa.timer_start(0)
+            grid.bin(0, aggs, rows)
+            ms = sa.timer_stop(0)
+            if r:
+                best = min(best, ms)
+        assert int(np.array(aggs[0].get_result()).sum()) == rows
+        bpr = 2 * xi.element_size() + 8
+        print(f"binners {bname:<7} value float64 (256x256 uniform) {best:8.3f} ms {rows/best/1e6:7.1f} Grows/s  {rows*bpr/best/1e6/8000:6.3f} of 8 TB/s on {bpr} B/row   {sa.last_kernel(0)}", flush=True)
+    sa.config_set("wv", 5); sa.config_set("blk", 1)
+    del xi, yi

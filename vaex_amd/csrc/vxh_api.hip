@@ -748,6 +748,13 @@ static LaunchPlan make_plan(const BinArgs &A, BinArgs &out, uint64_t n, double b
         const BinnerDesc &b = A.b[d];
         if (b.kind != VXH_BIN_SCALAR || b.dtype != VXH_F32 || b.flip || b.mask || b.f32mode) p.bin_f32 = false;
     }
+    p.bin_i64 = p.bin_i32 = A.ndim >= 1;
+    for (int d = 0; d < A.ndim; d++) {
+        const BinnerDesc &b = A.b[d];
+        const bool plain = b.kind == VXH_BIN_SCALAR && !b.flip && !b.mask && !b.f32mode;
+        if (!plain || b.dtype != VXH_I64) p.bin_i64 = false;
+        if (!plain || b.dtype != VXH_I32) p.bin_i32 = false;
+    }
     p.count_ct = -1;
     if (A.ndim >= 1) {
         const int dt = A.b[0].dtype;
@@ -1388,13 +1395,14 @@ static void run_part_chunk(Slot &slot, const BinArgs &planned, const LaunchPlan 
     const bool narrow = plan.vals_f32 || plan.vals_i32; // (a 4-byte value column: part_scatter_wv converts it on load — nobody else does)
     const bool f32b = plan.bin_f32 && !plan.fast_f32 && (plan.fast_vals || plan.vals_i64) && P.nvals == 1; // (float32 binners next to an 8-byte value column: the same)
     const bool f32all = plan.fast_f32 && P.nvals == 1; // (float32 binners and value column: both converted on load)
+    const bool intb = (plan.bin_i64 || plan.bin_i32) && (plan.fast_vals || plan.vals_i64) && !slot.hot.on; // (int64 / int32 binner columns, an 8-byte value column or none: converted on load, box-less)
     const WvGeom wg = wv_geometry(S, P.nvals, slot.hot.on, narrow || f32b || f32all, slot.hot.on ? slot.hot.wv_mode : -1);
-    const bool wv = wg.ok && (plan.fast_f64 || (plan.bin_f64 && (plan.vals_i64 || narrow)) || f32b || f32all || (plan.key_i64 && (plan.fast_vals || plan.vals_i64 || narrow))) && (!(narrow || f32b || f32all) || !slot.hot.on || wg.direct == 1) && planned.ndim >= 1 && planned.ndim <= 3 && P.nvals <= 1 && !P.use_flags &&
+    const bool wv = wg.ok && (plan.fast_f64 || (plan.bin_f64 && (plan.vals_i64 || narrow)) || f32b || f32all || intb || (plan.key_i64 && (plan.fast_vals || plan.vals_i64 || narrow))) && (!(narrow || f32b || f32all) || !slot.hot.on || wg.direct == 1) && planned.ndim >= 1 && planned.ndim <= 3 && P.nvals <= 1 && !P.use_flags &&
                     (P.nmasks == 0 || (P.nmasks == 1 && P.all_masked)) && P.idx16 && slab_cells < 65535 && wv_aligned(planned) && (!slot.hot.on || slot.hot.wv);
     if (slot.hot.on && slot.hot.wv != wv) throw std::runtime_error("vaex_hip internal: hot box prepared for a different pass-1 kernel");
     if (P.A.pred.on) {
         // the fused selection rides part_scatter_wv's float64 instantiations (box-less, or next to a box without rings / grouped); every other pass 1 reads a byte mask
-        const bool fusable = wv && !(narrow || f32b || f32all) && !plan.key_i64 && (!slot.hot.on || wg.direct == 1 || wg.direct == 3) && aligned_to(P.A.pred.col, 16);
+        const bool fusable = wv && !(narrow || f32b || f32all || intb) && !plan.key_i64 && (!slot.hot.on || wg.direct == 1 || wg.direct == 3) && aligned_to(P.A.pred.col, 16);
         if (!fusable) {
             const uint8_t *m = materialize_pred(slot, P.A.pred, planned.n);
             for (int k = 0; k < planned.nagg; k++) P.A.a[k].mask = m;
@@ -1547,6 +1555,7 @@ static void run_part_chunk(Slot &slot, const BinArgs &planned, const LaunchPlan 
                      // <= 8 slabs without a box: two 512-thread workgroups of part_scatter_f64 are 2 % faster; 128-256 slabs: +5 % (1024^2) / -35 % (1e6-key groupby)
     const bool hot_here = slot.hot.on && (P.nmasks == 0 || (P.nmasks == 1 && P.all_masked && ((blk && !wv) || (wv && (wg.direct == 1 || wg.direct == 3))))) && P.nvals == slot.hot.nval && (blk || wv);
     if (wv && (f32b || f32all)) P.bin_ct = 1;
+    else if (wv && intb) P.bin_ct = plan.bin_i64 ? 2 : 3;
     if (wv && (narrow || f32all)) { // from here on the value column is what part_scatter_wv makes of it
         P.val_ct = (plan.vals_f32 || f32all) ? 1 : 2;
         P.val_i64 = (plan.vals_i32 && !f32all) ? 1 : 0;
@@ -2394,7 +2403,7 @@ int vxh_grid_bin(vxh_grid *grid, int thread, vxh_agg *const *aggs, int n_aggs, u
             } else {
                 part_acc_merge(slot, whole_args);
             }
-            if (slot.last_pass1 >= 2) slot.last_kernel = (whole.fast_f64 || whole.fast_f32 || whole.vals_f32 || (whole.bin_f32 && whole.fast_vals)) ? "part_scatter_wv+part_reduce_f64" : ((whole.vals_i64 || whole.vals_i32) ? "part_scatter_wv+part_reduce_i64" : "part_scatter_wv+part_reduce_generic");
+            if (slot.last_pass1 >= 2) slot.last_kernel = (whole.fast_f64 || whole.fast_f32 || whole.vals_f32 || ((whole.bin_f32 || whole.bin_i64 || whole.bin_i32) && whole.fast_vals)) ? "part_scatter_wv+part_reduce_f64" : ((whole.vals_i64 || whole.vals_i32) ? "part_scatter_wv+part_reduce_i64" : "part_scatter_wv+part_reduce_generic");
             if (slot.hot.on) {
                 if (!fused_merge) hot_merge(slot, whole_args);
                 slot.hot.acc_zero_sig = slot.hot.acc_layout_sig; // (the merge zeroes what it folds)

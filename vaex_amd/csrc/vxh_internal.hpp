@@ -239,7 +239,7 @@ struct Context {
     int64_t cfg_hot_chunk_factor = 4; // rows per partition chunk next to a hot box = this x part_chunk
     int64_t cfg_part_cap = 0;      // ... records per sub-queue (0 = sized from the expected share); tests force tiny queues to reach the slow path
     int64_t cfg_wv_waves_grouped = 8; // ... waves per workgroup of the grouped variant ("wv" = 5): 1.5 KB of ring each
-    int64_t cfg_wv_span = 1;       // ... consecutive trips a workgroup's waves take before the workgroup jumps to its next super-block (PartArgs::wv_span)
+    int64_t cfg_wv_span = 16;      // ... consecutive trips a workgroup's waves take before the workgroup jumps to its next super-block (PartArgs::wv_span; 16: -1.1 ... -1.4 % on the bench pass, profiles/r04_headline_ab.txt)
     int64_t cfg_wv_waves_direct = 16; // ... waves per workgroup of the ring-less variant ("wv" = 3, next to a hot box)
     int64_t cfg_wv_waves = 8;      // ... waves per workgroup (one workgroup per CU); fewer when the rings would not fit
     int64_t cfg_hot = 1;           // hot box in pass 1 of the partition strategy (0 off)

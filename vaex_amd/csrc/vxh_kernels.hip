@@ -1682,7 +1682,9 @@ __device__ __forceinline__ void wv_slow_record(const PartArgs &P, uint64_t cell,
 
 // VT: element type of the value column — 0: 8 bytes, taken as they are (float64; int64 with PartArgs::val_i64), 1: float32, widened
 // to float64 when loaded, 2: int32, sign-extended to int64 (PartArgs::val_ct; two 8-byte loads per lane instead of two 16-byte ones)
-// BT: 1 = the binner columns are float32 (PartArgs::bin_ct), loaded and widened the same way
+// BT: 1 = the binner columns are float32 (PartArgs::bin_ct), loaded and widened the same way; round 4: 2 = int64, 3 = int32 binner columns
+// (df.count(binby=[hour, weekday]), ids, datetimes as integers): the element converted to double before the subtraction, as
+// BinnerScalar<T> does (src/binners.cpp:16-35) — box-less instantiations only
 // MASKED: 1 = one byte keep-mask shared by every aggregator, 2 (round 4) = the shared selection itself (P.A.pred: terms over one float64
 // column, loaded like a value column and evaluated on the rows as they are binned — no sel_eval pass, no mask bytes), 3 = the same when
 // that column IS the value column (VT == 0)
@@ -1890,7 +1892,7 @@ __global__ void __launch_bounds__(1024) part_scatter_wv(const PartArgs P) {
         raw.rows = rows_here;
 #pragma unroll
         for (int d = 0; d < NDIM; ++d) {
-            if (BT == 0) {
+            if (BT == 0 || BT == 2) {
                 const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)((const double *)P.A.b[d].data + r0), 0, (int)(rows_here * 8u), 0x00020000);
                 raw.b[d][0] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(lane * 16u), 0, 2);
                 raw.b[d][1] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(lane * 16u), 1024, 2);
@@ -2072,7 +2074,12 @@ __global__ void __launch_bounds__(1024) part_scatter_wv(const PartArgs P) {
                     const int64_t nord = (int64_t)b.bins;
                     sub_i[d] = (value < 0 || value >= nord) ? (uint32_t)nord : (uint32_t)(b.invert ? nord - 1 - value : value);
                 } else {
-                    sub_i[d] = scalar_sub_index32(BT == 0 ? f64_of(cur.b[d], r) : (double)__uint_as_float(cur.b[d][r >> 1][r & 1]), b.vmin, b.scale, b.binsd, (uint32_t)b.bins);
+                    double bv;
+                    if (BT == 0) bv = f64_of(cur.b[d], r);
+                    else if (BT == 1) bv = (double)__uint_as_float(cur.b[d][r >> 1][r & 1]);
+                    else if (BT == 2) bv = (double)__double_as_longlong(f64_of(cur.b[d], r));
+                    else bv = (double)(int32_t)cur.b[d][r >> 1][r & 1];
+                    sub_i[d] = scalar_sub_index32(bv, b.vmin, b.scale, b.binsd, (uint32_t)b.bins);
                 }
             }
             uint32_t idx = sub_i[0]; // (dim 0 has stride 1; sub-indices and strides are < 2^24 here)
@@ -3072,6 +3079,17 @@ void vxh_launch_part_scatter(const PartArgs &args, const LaunchPlan &plan, int s
             if (hot && args.wv_direct != 1) throw std::runtime_error("vaex_hip internal: 4-byte value column next to a box needs the ring-less pass 1");
             if (args.val_ct == 1) VXH_WVT(1); else VXH_WVT(2);
 #undef VXH_WVT
+        }
+        else if (args.bin_ct >= 2) { // int64 / int32 binner columns, an 8-byte value column or none (the host checks: no box, no fused selection)
+            if (hot) throw std::runtime_error("vaex_hip internal: integer binner columns next to a box");
+#define VXH_WVB(ND, BTV)                                                                                               \
+    do {                                                                                                               \
+        if (args.nvals == 0) { if (masked) VXH_SC((part_scatter_wv<ND, 0, true, false, 0, 0, 0, BTV>)); else VXH_SC((part_scatter_wv<ND, 0, false, false, 0, 0, 0, BTV>)); } \
+        else { if (masked) VXH_SC((part_scatter_wv<ND, 1, true, false, 0, 0, 0, BTV>)); else VXH_SC((part_scatter_wv<ND, 1, false, false, 0, 0, 0, BTV>)); } \
+    } while (0)
+            if (args.bin_ct == 2) { if (args.A.ndim == 1) VXH_WVB(1, 2); else if (args.A.ndim == 2) VXH_WVB(2, 2); else VXH_WVB(3, 2); }
+            else { if (args.A.ndim == 1) VXH_WVB(1, 3); else if (args.A.ndim == 2) VXH_WVB(2, 3); else VXH_WVB(3, 3); }
+#undef VXH_WVB
         }
         else if (args.bin_ct && args.nvals == 1) { // float32 binner columns next to an 8-byte value column
             if (hot && args.wv_direct != 1) throw std::runtime_error("vaex_hip internal: float32 binners next to a box need the ring-less pass 1");

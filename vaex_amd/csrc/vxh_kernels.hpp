@@ -123,7 +123,7 @@ struct PartArgs {
                      // box's and pass 2's LDS sums are two's-complement integers (part_scatter_wv, part_reduce_fast, part_hot_merge)
     int32_t val_ct;  // part_scatter_wv: element type of the value column — 0: 8 bytes (float64, or int64 with val_i64), 1: float32 (widened to
                      // float64 on load: the records carry doubles), 2: int32 (sign-extended to int64 on load; val_i64 is set)
-    int32_t bin_ct;  // part_scatter_wv: element type of the binner columns — 0: float64, 1: float32 (every one of them; widened on load like BinnerScalar<float>)
+    int32_t bin_ct;  // part_scatter_wv: element type of the binner columns — 0: float64, 1: float32 (every one of them; widened on load like BinnerScalar<float>), 2: int64, 3: int32
     int32_t blk; // pass 1 = part_scatter_blk (block-reserved queues, 4096-row tiles)
     int32_t f32; // ... its float instantiation: every binner column and the value column float32 (the records carry float64 all the same)
     // pass 1 = part_scatter_wv (barrier-free, wave-private staging rings): wv = waves per workgroup (0: not this
@@ -220,6 +220,7 @@ struct LaunchPlan {
     bool vals_i64;   // every aggregator input is int64 native (or absent; at least one), aggregators count / sum into int64 cells
     bool bin_f64;    // all binners scalar f64 native unmasked
     bool bin_f32;    // all binners scalar f32 native unmasked (and not in float32-scaling mode)
+    bool bin_i64, bin_i32; // all binners scalar int64 / int32 native unmasked (part_scatter_wv converts them on load: PartArgs::bin_ct 2 / 3)
     bool vals_f32;   // every aggregator input is float32 native (or absent; at least one), aggregators count / sum / sum-moment into float64 cells
     bool vals_i32;   // every aggregator input is int32 native (or absent; at least one), aggregators count / sum into int64 cells
     bool key_i64;    // ONE ordinal binner over a native unmasked int64 column (groupby on an integer key)
