@@ -493,7 +493,13 @@ def test_hot_box_packed_counters_are_exact(sa, scenario):
         forced = dict(hot_x0=69, hot_y0=70, hot_w=120, hot_h=120, hot_flush_trips=2) if scenario == "forced_flush" else {}   # (fits next to either pass 1's LDS with uint16 sizing)
         if "queue_overflow" in scenario:
             forced = dict(part_cap=2048)   # records per sub-queue: a handful of the 4096 waves' first blocks fit
+        if scenario == "hidden_pile":
+            # tiles dealt one by one: every workgroup sees 1/256 of the pile (16384 rows: uint8 wraps, uint16 holds).  With the default
+            # super-blocks (wv_span = 16: 32768 consecutive rows per workgroup at a time) the pile's 8 segments land on 32 workgroups,
+            # 131072 rows each, and the chain rightly goes on to uint32 — the scenario above (`piled`) already covers that end
+            forced = dict(wv_span=1)
         redo0 = sa.config_get("redo_count")
+        before = {k: (sa.config_get(k) if k == "wv_span" else 0) for k in forced}   # (config_get of the hot_* keys reports the LAST box, not the forced one: those go back to 0 = not forced)
         for k, val in forced.items():
             sa.config_set(k, val)
         sa.config_set("hot_cache", 0)   # a fresh sample: torch hands the next scenario the previous one's addresses, and the remembered box (and its widest safe counters) with them
@@ -503,7 +509,7 @@ def test_hot_box_packed_counters_are_exact(sa, scenario):
         finally:
             sa.config_set("hot_cache", 1)
             for k in forced:
-                sa.config_set(k, 0)
+                sa.config_set(k, before[k])
         redone = sa.config_get("redo_count") - redo0
         got = [np.array(a.get_result()) for a in aggs]
         assert sa.last_kernel(0).startswith(("part_scatter_direct_hot", "part_scatter_grouped_hot")), sa.last_kernel(0)

@@ -66,6 +66,17 @@ __device__ __forceinline__ long long gb_load_key(const void *p, uint64_t i, int 
     default: return ((const uint8_t *)p)[i] ? 1 : 0;
     }
 }
+// a key as its load returned it (zero-extended) -> the int64 the reference's ordered_set<T> holds (sign extension, bool != 0).
+// Kept apart from the load: arithmetic on a loaded value next to the load makes the wave wait for it before the next load leaves.
+__device__ __forceinline__ long long gb_fix_key(long long raw, int dt) {
+    switch (dt) {
+    case VXH_I32: return (long long)(int32_t)(uint32_t)raw;
+    case VXH_I16: return (long long)(int16_t)(uint16_t)raw;
+    case VXH_I8: return (long long)(int8_t)(uint8_t)raw;
+    case VXH_I64: case VXH_U64: case VXH_U32: case VXH_U16: case VXH_U8: return raw;
+    default: return raw ? 1 : 0;
+    }
+}
 
 struct GbArgs {
     // input rows
@@ -124,7 +135,14 @@ __device__ __forceinline__ uint64_t gb_kc_unmix(uint64_t m, int bits, uint64_t a
 typedef unsigned int gb_u32x3 __attribute__((ext_vector_type(3)));
 typedef gb_u32x3 gb_u32x3_a4 __attribute__((aligned(4)));
 
-template <int W, int R>
+// K64: 8-byte keys (int64 / uint64: loaded as they are); KEEP: G.keep != null.  Both were run-time branches around every row's loads
+// until round 4 — the compiler then waits for each load behind its branch (vmcnt(0) after every global_load in the ISA): the 16-24 loads
+// of a thread's tile left one after the other, a memory latency each, and "the next tile requested under the current one" did not exist:
+// 8.9 ms per 1e9 rows with the HBM idle most of the time.  Now the loads of a tile are issued back to back and nothing touches what
+// they return before the next tile's turn.
+// EARLY: the next tile's registers are taken over between staging [C] and copy-out [D] (the wait for its loads then is not also a wait
+// for [D]'s stores, which count in the same vmcnt on gfx9) instead of behind [D].
+template <int W, int R, bool K64, bool KEEP, bool EARLY>
 __global__ void __launch_bounds__(1024) gb_scatter(const GbArgs G) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr uint32_t T = 1024u * R;
@@ -153,20 +171,76 @@ __global__ void __launch_bounds__(1024) gb_scatter(const GbArgs G) {
     long long key[R], key_n[R];
     uint64_t pay[W][R], pay_n[W][R];
     bool ok[R], ok_n[R];
-    auto request = [&](uint64_t tile, long long (&k)[R], uint64_t (&p)[W][R], bool (&v)[R]) {
+    uint32_t kb[R], kb_n[R]; // KEEP: the rows' keep bytes as loaded
+    auto request = [&](uint64_t tile, long long (&k)[R], uint64_t (&p)[W][R], bool (&v)[R], uint32_t (&b)[R]) {
+        uint64_t ic[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const uint64_t i = tile * T + (uint64_t)r * 1024u + tid;
             v[r] = i < n;
-            const uint64_t ic = v[r] ? i : n - 1;
-            if (G.keep) v[r] = v[r] && G.keep[ic] == 1; // (a row outside the filter leaves no record: a group without a row inside does not exist)
-            k[r] = G.key_dtype == VXH_I64 ? ((const long long *)G.keys)[ic] : gb_load_key(G.keys, ic, G.key_dtype);
+            ic[r] = v[r] ? i : n - 1;
+            b[r] = 1u;
+        }
+        if (KEEP) {
 #pragma unroll
-            for (int w = 0; w < W; ++w) p[w][r] = G.payload[w][ic];
+            for (int r = 0; r < R; ++r) b[r] = G.keep[ic[r]]; // (a row outside the filter leaves no record: a group without a row inside does not exist)
+        }
+        if (K64) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) k[r] = ((const long long *)G.keys)[ic[r]];
+        } else { // (wave-uniform switch around the R loads of a case, not inside every row)
+            switch (G.key_dtype) {
+            case VXH_I32: case VXH_U32:
+#pragma unroll
+                for (int r = 0; r < R; ++r) k[r] = (long long)(uint64_t)((const uint32_t *)G.keys)[ic[r]];
+                break;
+            case VXH_I16: case VXH_U16:
+#pragma unroll
+                for (int r = 0; r < R; ++r) k[r] = (long long)(uint64_t)((const uint16_t *)G.keys)[ic[r]];
+                break;
+            case VXH_I64: case VXH_U64:
+#pragma unroll
+                for (int r = 0; r < R; ++r) k[r] = ((const long long *)G.keys)[ic[r]];
+                break;
+            default:
+#pragma unroll
+                for (int r = 0; r < R; ++r) k[r] = (long long)(uint64_t)((const uint8_t *)G.keys)[ic[r]];
+                break;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+#pragma unroll
+            for (int w = 0; w < W; ++w) p[w][r] = G.payload[w][ic[r]];
         }
     };
-    if ((uint64_t)blockIdx.x * T < n) request(blockIdx.x, key, pay, ok);
+    // what the loads returned -> the tile's keys and validity (run at the tile's turn, not at the request)
+    auto settle = [&]() {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            if (!K64) key[r] = gb_fix_key(key[r], G.key_dtype);
+            if (KEEP) ok[r] = ok[r] && kb[r] == 1u;
+        }
+    };
+    auto take_over = [&]() {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            key[r] = key_n[r];
+            ok[r] = ok_n[r];
+            kb[r] = kb_n[r];
+#pragma unroll
+            for (int w = 0; w < W; ++w) pay[w][r] = pay_n[w][r];
+        }
+    };
+    // (the first tile goes through the same two steps as every other one — requested into the `_n` set, taken over: loaded straight into
+    //  `key` it left [A] with two histories of outstanding loads, and the compiler's wait counts in [A] then waited for the NEXT tile's keys)
+    if ((uint64_t)blockIdx.x * T < n) { request(blockIdx.x, key_n, pay_n, ok_n, kb_n); take_over(); }
     for (uint64_t tile = blockIdx.x; tile * T < n; tile += gridDim.x) {
+        // the next tile's rows are requested first: their loads fly under [A] .. [C] (and [D] unless EARLY)
+        const uint64_t next = tile + gridDim.x;
+        const bool has_next = next * T < n;
+        if (has_next) request(next, key_n, pay_n, ok_n, kb_n);
+        settle();
         // [A] bucket of every row of the tile, position inside the bucket
         uint32_t bucket[R], pos[R];
 #pragma unroll
@@ -181,9 +255,6 @@ __global__ void __launch_bounds__(1024) gb_scatter(const GbArgs G) {
             pos[r] = 0;
             if (ok[r]) pos[r] = __hip_atomic_fetch_add(&cnt[bucket[r]], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
-        const uint64_t next = tile + gridDim.x;
-        const bool has_next = next * T < n;
-        if (has_next) request(next, key_n, pay_n, ok_n);
         __syncthreads();
         // [B] thread b: where bucket b's records of this tile go; exclusive scan of the bucket counts
         uint32_t c = 0;
@@ -240,6 +311,7 @@ __global__ void __launch_bounds__(1024) gb_scatter(const GbArgs G) {
                 st_b[j] = (uint16_t)bucket[r];
             }
         }
+        if (EARLY && has_next) take_over();
         __syncthreads();
         // [D] copy out: consecutive threads -> consecutive records of a bucket's segment
         for (uint32_t j = tid; j < total; j += 1024u) {
@@ -262,15 +334,7 @@ __global__ void __launch_bounds__(1024) gb_scatter(const GbArgs G) {
             }
         }
         // (the next tile's [C] comes after two more barriers: nobody overwrites what [D] still reads)
-        if (has_next) {
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                key[r] = key_n[r];
-                ok[r] = ok_n[r];
-#pragma unroll
-                for (int w = 0; w < W; ++w) pay[w][r] = pay_n[w][r];
-            }
-        }
+        if (!EARLY && has_next) take_over();
     }
     if (tid < NB && !dead) G.tab[block] = fill;
 }
@@ -279,7 +343,9 @@ __global__ void __launch_bounds__(1024) gb_scatter(const GbArgs G) {
 // gb_reduce
 // ------------------------------------------------------------------------------------------------------------------
 // LDS table of one bucket: `lines` lines of four keys (SLOTS = 4 * lines) + one entry for the key INT64_MIN, which doubles as EMPTY
-template <int NV, bool MERGE>
+// KC: the queues hold compact 12-byte records (GbArgs::kc_bits != 0) — a compile-time switch: as a run-time branch around every
+// record load it made the compiler wait for each load on its own (vmcnt(0) behind every global_load: 4.0 -> 5.2 ms per 1e9 records)
+template <int NV, bool MERGE, bool KC = false>
 __global__ void __launch_bounds__(1024) gb_reduce(const GbArgs G) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     // row counters: 32 bits while counting rows (a workgroup sees < 2^32 of them), 64 bits when merging partial counts
@@ -294,7 +360,8 @@ __global__ void __launch_bounds__(1024) gb_reduce(const GbArgs G) {
     CT *const t_rows = (CT *)t_rc;                                                                                // MERGE: [EP]
     CT *const t_cnt = MERGE ? t_rows + EP : (CT *)(t_rc + EP) - EP;                                               // MERGE: [NV][EP]; RAW: [v >= 1][EP] behind t_rc
     uint32_t *const s_misc = (uint32_t *)((char *)t_rc + (MERGE ? (size_t)8 * EP * (1 + NV) : (size_t)8 * EP + (size_t)4 * EP * (NV - 1))); // [0] claimed slots, [1] output base, [2..17] wave totals
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, nwave = blockDim.x >> 6;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, nwave = blockDim.x >> 6;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6)); // (scalar: the block iterator's table loads are s_loads)
     const uint32_t bucket = blockIdx.x;
     for (uint32_t s = tid; s < EP; s += blockDim.x) {
         t_key[s] = (unsigned long long)GB_EMPTY;
@@ -311,7 +378,7 @@ __global__ void __launch_bounds__(1024) gb_reduce(const GbArgs G) {
 
     const uint32_t limit = SLOTS - SLOTS / 5; // more distinct keys than this in one bucket: the overflow chains get long — flag and let the host retry with more buckets
     constexpr int PW = MERGE ? 1 + 3 * NV : NV;
-    constexpr int U = 4; // records per lane per trip: their loads run interleaved
+    constexpr int U = PW >= 7 ? 1 : (PW >= 4 ? 2 : 4); // records per lane per trip (their loads run interleaved), two trips in registers: <= 128 VGPRs at 16 waves
     bool failed = false;
     auto accumulate = [&](uint32_t s, const uint64_t (&p)[PW]) {
         if (MERGE) {
@@ -364,56 +431,101 @@ __global__ void __launch_bounds__(1024) gb_reduce(const GbArgs G) {
         }
         return 0xffffffffu;
     };
-    // `fill` records of one queue block starting at record `lo`, streamed by ONE wave, U records per lane per trip (their
-    // loads in flight together)
-    auto stream = [&](uint64_t lo, uint32_t fill) {
-        for (uint32_t j0 = 0; j0 < fill; j0 += 64u * U) {
-            long long kk[U];
-            uint64_t pp[U][PW];
-            bool todo[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const uint32_t j = j0 + 64u * u + lane;
-                todo[u] = j < fill;
-                const uint64_t at = lo + (todo[u] ? j : 0u);
-                if (PW == 1 && G.kc_bits) { // (wave-uniform) 12-byte records {remainder, payload}: the table is keyed by the remainder
-                    const gb_u32x3_a4 r = *(const gb_u32x3_a4 *)((const uint32_t *)G.qrec + at * 3);
-                    kk[u] = (long long)(uint64_t)r[0];
-                    pp[u][0] = (uint64_t)r[1] | ((uint64_t)r[2] << 32);
-                } else if (PW == 1) {
-                    const uint4 r = G.qrec[at];
-                    kk[u] = (long long)((uint64_t)r.x | ((uint64_t)r.y << 32));
-                    pp[u][0] = (uint64_t)r.z | ((uint64_t)r.w << 32);
-                } else {
-                    kk[u] = G.qkey[at];
-#pragma unroll
-                    for (int w = 0; w < PW; ++w) pp[u][w] = G.qw[w][at];
-                }
+    // A wave streams whole blocks of this bucket — the primary block of scatter workgroup w, w + waves, ..., then the spare blocks
+    // this bucket owns — U records per lane per trip.  Round 4: the trips are software-pipelined ACROSS the blocks: the next trip's
+    // records (of this block or of the wave's next non-empty one) are requested before the current trip's are probed and added, so a
+    // wave's loads are in flight under its own LDS work (before: load, wait, work — 12-16 GB read at 2.3-3 TB/s with the LDS idle
+    // during the waits).
+    const uint32_t NB = 1u << G.nb_log2;
+    const uint32_t used = min(*G.pool_used, G.pool);
+    uint32_t it_g = wave, it_phase = 0; // iterator over the wave's blocks (wave-uniform)
+    uint64_t cur_lo = 0;
+    uint32_t cur_fill = 0;
+    auto next_block = [&]() -> bool {
+        for (;;) {
+            uint32_t blk_id;
+            if (it_phase == 0) {
+                if (it_g >= G.scatter_wgs) { it_phase = 1; it_g = wave; continue; }
+                blk_id = it_g * NB + bucket;
+                it_g += nwave;
+            } else {
+                if (it_g >= used) return false;
+                const uint32_t sp = it_g;
+                it_g += nwave;
+                if (G.pool_owner[sp] != bucket) continue;
+                blk_id = G.scatter_wgs * NB + sp;
             }
+            const uint32_t fill = G.tab[blk_id];
+            if (!fill) continue;
+            cur_lo = (uint64_t)blk_id * G.blk;
+            cur_fill = fill;
+            return true;
+        }
+    };
+    struct Trip { // what a trip's loads return, untouched: any arithmetic on it here would make the wave wait for the loads at once
+        gb_u32x3 c[U];        // compact 12-byte records
+        uint4 q[U];           // 16-byte records
+        long long kk[U];      // separate arrays (several payload words)
+        uint64_t pp[U][PW];
+        uint32_t fill, j0;
+    };
+    auto request = [&](Trip &t, uint64_t lo, uint32_t fill, uint32_t j0) {
+        t.fill = fill;
+        t.j0 = j0;
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                if (!todo[u]) continue;
-                const uint32_t sl = slot_of(kk[u]);
-                if (sl == 0xffffffffu) failed = true;
-                else accumulate(sl, pp[u]);
+        for (int u = 0; u < U; ++u) {
+            const uint32_t j = j0 + 64u * u + lane;
+            const uint64_t at = lo + (j < fill ? j : 0u);
+            if (PW == 1 && KC) t.c[u] = *(const gb_u32x3_a4 *)((const uint32_t *)G.qrec + at * 3);
+            else if (PW == 1) t.q[u] = G.qrec[at];
+            else {
+                t.kk[u] = G.qkey[at];
+#pragma unroll
+                for (int w = 0; w < PW; ++w) t.pp[u][w] = G.qw[w][at];
             }
         }
     };
-
-    // every wave streams whole blocks of this bucket: the primary block of workgroup w, w + waves, ..., then the spare
-    // blocks this bucket owns
-    const uint32_t NB = 1u << G.nb_log2;
-    for (uint32_t g = wave; g < G.scatter_wgs; g += nwave) {
-        const uint32_t blk_id = g * NB + bucket;
-        const uint32_t fill = G.tab[blk_id];
-        if (fill) stream((uint64_t)blk_id * G.blk, fill);
-    }
-    const uint32_t used = min(*G.pool_used, G.pool);
-    for (uint32_t sp = wave; sp < used; sp += nwave) {
-        if (G.pool_owner[sp] != bucket) continue;
-        const uint32_t blk_id = G.scatter_wgs * NB + sp;
-        const uint32_t fill = G.tab[blk_id];
-        if (fill) stream((uint64_t)blk_id * G.blk, fill);
+    auto work = [&](const Trip &t) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (t.j0 + 64u * u + lane >= t.fill) continue;
+            long long key;
+            uint64_t p[PW];
+            if (PW == 1 && KC) { // {remainder, payload}: the table is keyed by the remainder
+                key = (long long)(uint64_t)t.c[u][0];
+                p[0] = (uint64_t)t.c[u][1] | ((uint64_t)t.c[u][2] << 32);
+            } else if (PW == 1) {
+                key = (long long)((uint64_t)t.q[u].x | ((uint64_t)t.q[u].y << 32));
+                p[0] = (uint64_t)t.q[u].z | ((uint64_t)t.q[u].w << 32);
+            } else {
+                key = t.kk[u];
+#pragma unroll
+                for (int w = 0; w < PW; ++w) p[w] = t.pp[u][w];
+            }
+            const uint32_t sl = slot_of(key);
+            if (sl == 0xffffffffu) failed = true;
+            else accumulate(sl, p);
+        }
+    };
+    { // (the request behind the last trip is issued all the same, with fill = 0 at a valid address: a conditional request would leave
+      //  two paths with different numbers of loads outstanding in front of work(), and the compiler's wait-count pass then waits for
+      //  the NEW trip's loads too — seen in the ISA as vmcnt(3..0) instead of vmcnt(7..4))
+        Trip a, b;
+        bool have = next_block();
+        uint32_t j0 = 0;
+        request(a, cur_lo, have ? cur_fill : 0u, 0u);
+        while (have) {
+            j0 += 64u * U;
+            bool more = true;
+            if (j0 >= cur_fill) { more = next_block(); j0 = 0; }
+            request(b, cur_lo, more ? cur_fill : 0u, j0);
+            work(a);
+            if (!more) break;
+            j0 += 64u * U;
+            if (j0 >= cur_fill) { have = next_block(); j0 = 0; }
+            request(a, cur_lo, have ? cur_fill : 0u, j0);
+            work(b);
+        }
     }
     if (failed) atomicExch(G.overflow, 2u);
     __syncthreads();
@@ -446,7 +558,7 @@ __global__ void __launch_bounds__(1024) gb_reduce(const GbArgs G) {
     uint64_t o = (uint64_t)s_misc[1] + before + inc - mine;
     for (uint32_t s = tid; s < E; s += blockDim.x) {
         if (rows_of(s) == 0ull) continue;
-        if (!MERGE && NV == 1 && G.kc_bits) // the group's key from its bucket and remainder, mixed back
+        if (!MERGE && NV == 1 && KC) // the group's key from its bucket and remainder, mixed back
             G.out_key[o] = (long long)(gb_kc_unmix(((uint64_t)bucket << (G.kc_bits - G.nb_log2)) | (uint64_t)t_key[s], G.kc_bits, G.kc_a_inv, G.kc_b_inv) + (uint64_t)G.kc_min);
         else
             G.out_key[o] = s == SLOTS ? GB_EMPTY : (long long)t_key[s];
@@ -540,12 +652,24 @@ size_t scatter_lds(int nb_log2) {
     const size_t T = 1024u * R;
     return T * 8 * (1 + W) + ((size_t)1 << nb_log2) * 4 * 5 + 64 + T * 2 + 16;
 }
+template <int W, int R, bool K64, bool KEEP, bool EARLY>
+void launch_scatter_as(const GbArgs &G, int blocks, size_t lds, hipStream_t st) {
+    HIP_CHECK(hipFuncSetAttribute((const void *)gb_scatter<W, R, K64, KEEP, EARLY>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((gb_scatter<W, R, K64, KEEP, EARLY>), dim3(blocks), dim3(1024), lds, st, G);
+}
 template <int W, int R>
 void launch_scatter(const GbArgs &G, int blocks, hipStream_t st) {
     const size_t lds = scatter_lds<W, R>(G.nb_log2);
     if (lds > GB_LDS_MAX) throw std::runtime_error("groupby: internal: gb_scatter staging exceeds the LDS");
-    HIP_CHECK(hipFuncSetAttribute((const void *)gb_scatter<W, R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((gb_scatter<W, R>), dim3(blocks), dim3(1024), lds, st, G);
+    const bool k64 = G.key_dtype == VXH_I64 || G.key_dtype == VXH_U64, keep = G.keep != nullptr;
+    const bool early = W == 1 && ctx().cfg_gb_early != 0; // ("gb_early": the one-payload-word forms only)
+    if (W == 1 && early) {
+        if (k64) { if (keep) launch_scatter_as<W, R, true, true, W == 1>(G, blocks, lds, st); else launch_scatter_as<W, R, true, false, W == 1>(G, blocks, lds, st); }
+        else { if (keep) launch_scatter_as<W, R, false, true, W == 1>(G, blocks, lds, st); else launch_scatter_as<W, R, false, false, W == 1>(G, blocks, lds, st); }
+        return;
+    }
+    if (k64) { if (keep) launch_scatter_as<W, R, true, true, false>(G, blocks, lds, st); else launch_scatter_as<W, R, true, false, false>(G, blocks, lds, st); }
+    else { if (keep) launch_scatter_as<W, R, false, true, false>(G, blocks, lds, st); else launch_scatter_as<W, R, false, false, false>(G, blocks, lds, st); }
 }
 
 // bytes of LDS per table slot, and the number of 4-key lines that fit
@@ -557,6 +681,11 @@ void launch_reduce(const GbArgs &G, hipStream_t st) {
     const size_t EP = (4 * (size_t)G.lines + 1 + 3) & ~(size_t)3;
     const size_t lds = EP * reduce_slot_bytes(NV, MERGE) + 18 * 4 + 16;
     if (lds > GB_LDS_MAX) throw std::runtime_error("groupby: internal: gb_reduce table exceeds the LDS");
+    if (NV == 1 && !MERGE && G.kc_bits) { // compact records (run_pipeline sets kc_bits for this form only)
+        HIP_CHECK(hipFuncSetAttribute((const void *)gb_reduce<1, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((gb_reduce<1, false, true>), dim3(1u << G.nb_log2), dim3(1024), lds, st, G);
+        return;
+    }
     HIP_CHECK(hipFuncSetAttribute((const void *)gb_reduce<NV, MERGE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL((gb_reduce<NV, MERGE>), dim3(1u << G.nb_log2), dim3(1024), lds, st, G);
 }

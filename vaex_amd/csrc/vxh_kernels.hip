@@ -1769,13 +1769,13 @@ __global__ void __launch_bounds__(1024) part_scatter_wv(const PartArgs P) {
     uint32_t cur = VXH_WV_NONE, end = VXH_WV_NONE;
     auto open_block = [&]() { // (one lane; the ONLY place that looks at an atomic's result: once per block)
         const unsigned long long b = atomicAdd(&P.qcount[my_sub], (unsigned long long)B);
-        if (b + B > P.cap) { // does not fit: remember where the valid prefix of the sub-queue ends; slow path from here on
-            atomicMin(&P.qlimit[my_sub], b);
-            cur = end = VXH_WV_NONE;
-        } else {
-            cur = (uint32_t)b;
-            end = cur + B;
-        }
+        const bool full = b + B > P.cap; // does not fit: remember where the valid prefix of the sub-queue ends; slow path from here on
+        if (full) atomicMin(&P.qlimit[my_sub], b);
+        // (selects, not assignments under the branch: the compiler merged those into ONE store through a selected ADDRESS, which kept
+        //  `cur` / `end` in scratch memory — and every scratch load in the tile loop is a vmcnt(0), i.e. a wait for all the tile loads
+        //  requested ahead; seen in the ISA of round 4 as scratch_load_dword + s_waitcnt vmcnt(0) in front of every flush)
+        cur = full ? VXH_WV_NONE : (uint32_t)b;
+        end = full ? VXH_WV_NONE : (uint32_t)b + B;
     };
     auto close_block = [&]() { // (one lane) records the block really holds
         if (end != VXH_WV_NONE) P.qtab[(size_t)my_sub * (uint32_t)P.qtab_stride + (end - B) / B] = cur - (end - B);
@@ -1786,13 +1786,10 @@ __global__ void __launch_bounds__(1024) part_scatter_wv(const PartArgs P) {
         unsigned long long b = 0;
         if (lane == 0) b = atomicAdd(&P.qcount[part], (unsigned long long)B);
         b = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(b >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b);
-        if ((b + B) * GR > P.cap) { // the region is full: remember where its valid prefix ends; slow path from here on
-            if (lane == 0) atomicMin(&P.qlimit[part], b);
-            gcur = gend = VXH_WV_NONE;
-        } else {
-            gcur = (uint32_t)b;
-            gend = gcur + B;
-        }
+        const bool full = (b + B) * GR > P.cap; // the region is full: remember where its valid prefix ends; slow path from here on
+        if (full && lane == 0) atomicMin(&P.qlimit[part], b);
+        gcur = full ? VXH_WV_NONE : (uint32_t)b; // (selects: see open_block)
+        gend = full ? VXH_WV_NONE : (uint32_t)b + B;
     };
     // group headers leave 16 at a time — one whole 128-byte line (blocks start at multiples of 16 groups): a lone 8-byte store per group
     // left 16 partial writes per line, minutes apart in cache terms
