@@ -16,8 +16,12 @@ for kv in sys.argv[3:]:
     k, vs = kv.split("=")
     settings += [{k: int(v)} for v in vs.split(",")]
 g = torch.Generator(device="cuda").manual_seed(1234)
-x = torch.randn(rows, dtype=torch.float64, device="cuda", generator=g)
-y = torch.randn(rows, dtype=torch.float64, device="cuda", generator=g)
+if os.environ.get("VAEX_TUNE_DIST") == "uniform":   # (round 4) bench.py's value_uniform data: x, y ~ U(-4, 4)
+    x = torch.rand(rows, dtype=torch.float64, device="cuda", generator=g) * 8 - 4
+    y = torch.rand(rows, dtype=torch.float64, device="cuda", generator=g) * 8 - 4
+else:
+    x = torch.randn(rows, dtype=torch.float64, device="cuda", generator=g)
+    y = torch.randn(rows, dtype=torch.float64, device="cuda", generator=g)
 v = torch.randn(rows, dtype=torch.float64, device="cuda", generator=g) * 2 + 3
 torch.cuda.synchronize()
 bx = sa.BinnerScalar_float64(1, "x", -4.0, 4.0, 256); by = sa.BinnerScalar_float64(1, "y", -4.0, 4.0, 256)

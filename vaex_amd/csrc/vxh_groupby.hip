@@ -35,6 +35,7 @@
 #include <rocprim/rocprim.hpp>
 
 #include <algorithm>
+#include <cmath>
 #include <cstring>
 #include <memory>
 #include <stdexcept>
@@ -376,7 +377,7 @@ __global__ void __launch_bounds__(1024) gb_reduce(const GbArgs G) {
     if (tid < 18) s_misc[tid] = 0u;
     __syncthreads();
 
-    const uint32_t limit = SLOTS - SLOTS / 5; // more distinct keys than this in one bucket: the overflow chains get long — flag and let the host retry with more buckets
+    const uint32_t limit = SLOTS - SLOTS / 5; // more distinct keys than this in one bucket (80 % of the slots): the overflow chains get long (a wave pays for the longest of its 64) — flag and let the host retry with more buckets
     constexpr int PW = MERGE ? 1 + 3 * NV : NV;
     constexpr int U = PW >= 7 ? 1 : (PW >= 4 ? 2 : 4); // records per lane per trip (their loads run interleaved), two trips in registers: <= 128 VGPRs at 16 waves
     bool failed = false;
@@ -716,14 +717,25 @@ unsigned run_pipeline(GbArgs &G, int nv, bool merge, uint64_t n, uint64_t groups
     // one payload word: 8 rows per thread per tile (128 KiB of staging) as long as the bucket tables fit beside it
     const int nb_max = 10;
     int nb_log2 = 6;
-    // target load of a bucket's table ("gb_load_pct", default 50 %): 80 % halves the buckets for 2^20 expected groups (512 -> 256
-    // queues to scatter into) at longer probe chains; a bucket that overflows anyway costs a retry with four times the buckets
-    // (Round 4 tried 256 buckets for 1e6 KNOWN groups, i.e. tables at 76 % load: the fullest buckets pass gb_reduce's 80 % limit, the
-    //  retry with four times the buckets costs a whole second pass: 14.4 -> 24.5 ms.  The load stays a knob; a known count only replaces the 2^20 guess.)
-    (void)hint_is_a_count;
+    // target load of a bucket's table ("gb_load_pct", default 50 % of the slots: 512 buckets for the 2^20 guess or for 1e6 known groups);
+    // a bucket that overflows anyway (80 % of its slots taken) costs a retry with four times the buckets
     const int64_t load_pct = ctx().cfg_gb_load_pct;
     const uint64_t per_bucket = std::max<uint64_t>(64, (uint64_t)lines * 4 * (uint64_t)std::min<int64_t>(95, std::max<int64_t>(10, load_pct)) / 100);
     while (nb_log2 < nb_max && ((uint64_t)1 << nb_log2) * per_bucket < std::max<uint64_t>(groups_hint, 1)) nb_log2++;
+    // "gb_known_count" (off): a KNOWN number of groups (the count an earlier call over the same key column returned) sizes the buckets
+    // at mean + 4 sigma under gb_reduce's table limit — 256 buckets at 76 % mean load for 1e6 groups instead of 512 at 38 %.  Measured
+    // (round 4, profiles/r04_groupby_compact.txt): the scatter gains what microbench5 promised (8.25 -> 7.2 ms per 1e9 rows), but
+    // gb_reduce goes from 3.8 to 20 ms — a wave's probe costs what its LONGEST chain of 64 costs, and linear probing over lines at
+    // 76 % load has a long tail.  Tables stay at <= 50 % of their slots.
+    if (hint_is_a_count && ctx().cfg_gb_known_count) {
+        const double cap = 0.86 * (double)lines * 4.0;
+        int nb = 6;
+        for (; nb < nb_max; ++nb) {
+            const double mean = (double)groups_hint / (double)((uint64_t)1 << nb);
+            if (mean + 4.0 * std::sqrt(mean) + 8.0 <= cap) break;
+        }
+        nb_log2 = std::min(nb_log2, nb);
+    }
     struct Events { // (destroyed on every way out, a throwing launch included)
         hipEvent_t e[3] = {nullptr, nullptr, nullptr};
         Events() { for (auto &x : e) HIP_CHECK(hipEventCreate(&x)); }
