@@ -2438,45 +2438,78 @@ __global__ void __launch_bounds__(1024) part_reduce(const PartArgs P) {
 // one ballot per record (unpredicated LDS atomics unless some lane actually holds a NaN), and the LDS byte
 // offsets of a record are computed once for all aggregators.  (The generic kernel spends 366 scalar + 253 vector
 // instructions per 8 records per wave on dispatch and predication — profiles/r01_pmc_part_scatter_reduce_v1.txt.)
-template <int NAGG, int N4>
-__device__ __forceinline__ void reduce_trip_fast(const PartArgs &P, char *lds, uint64_t at, uint64_t step, const uint32_t (&off)[NAGG], const uint32_t (&kind)[NAGG],
-                                                 const uint32_t (&vs)[NAGG], const uint32_t (&mom)[NAGG]) {
+// Round 4 (after the ISA audit): the record FORM is a template parameter — 0 / 1 / 2: SoA queues with uint16 local
+// indices and that many value columns, 3: 12-byte records {value, local index} — because `if (P.qrec12)` / `if (P.nvals > 0)` around the
+// loads made the compiler wait for every group of loads behind its branch; a trip's loads are issued back to back into RAW registers
+// (nothing looks at them before the trip's turn), and the trips are software-pipelined across the wave's queue blocks: the next trip
+// (of this block or of the wave's next non-empty one) is requested before the current one is added to the slab.
+template <int FORM, int N4>
+struct ReduceTrip {
+    u32x4 w[N4][3];            // FORM 3: four 12-byte records = three 16-byte loads
+    ushort4 x[N4];             // FORM 0..2: four local indices
+    ulonglong2 a0[N4], c0[N4]; // FORM 1..2: four values of column 0
+    ulonglong2 a1[N4], c1[N4]; // FORM 2: ... of column 1
+    uint32_t valid;            // bit b: batch b holds records of this lane
+};
+
+template <int FORM, int N4>
+__device__ __forceinline__ void reduce_trip_request(const PartArgs &P, ReduceTrip<FORM, N4> &t, uint64_t base, uint64_t nb4, uint64_t first_batch, uint32_t width, bool live) {
+    t.valid = 0u;
+#pragma unroll
+    for (int b = 0; b < N4; ++b) {
+        const uint64_t bi = first_batch + (uint64_t)b * width;
+        const bool ok = live && bi < nb4;
+        t.valid |= (ok ? 1u : 0u) << b;
+        const uint64_t q = base + 4ull * (ok ? bi : 0ull); // (a batch past the end re-reads batch 0: the load count of a trip never varies)
+        if (FORM == 3) {
+            const u32x4 *src = (const u32x4 *)((const uint32_t *)P.qidx + q * 3);
+            t.w[b][0] = src[0]; t.w[b][1] = src[1]; t.w[b][2] = src[2];
+        } else {
+            t.x[b] = *(const ushort4 *)((const uint16_t *)P.qidx + q);
+            if (FORM >= 1) { t.a0[b] = *(const ulonglong2 *)(P.qval[0] + q); t.c0[b] = *(const ulonglong2 *)(P.qval[0] + q + 2); }
+            if (FORM >= 2) { t.a1[b] = *(const ulonglong2 *)(P.qval[1] + q); t.c1[b] = *(const ulonglong2 *)(P.qval[1] + q + 2); }
+        }
+    }
+}
+
+template <int NAGG, int FORM, int N4>
+__device__ __forceinline__ void reduce_trip_apply(const PartArgs &P, char *lds, const ReduceTrip<FORM, N4> &t, const uint32_t (&off)[NAGG], const uint32_t (&kind)[NAGG],
+                                                  const uint32_t (&vs)[NAGG], const uint32_t (&mom)[NAGG]) {
     constexpr int N = 4 * N4;
     uint32_t loc[N];
     uint64_t v0[N], v1[N];
+    bool ok[N];
 #pragma unroll
     for (int b = 0; b < N4; ++b) {
-        const uint64_t q = at + (uint64_t)b * step;
-        if (P.qrec12) { // 12-byte records {value, local index}: four of them are three 16-byte loads
-            const u32x4 *src = (const u32x4 *)((const uint32_t *)P.qidx + q * 3);
-            const u32x4 w0 = src[0], w1 = src[1], w2 = src[2];
+        const bool live = ((t.valid >> b) & 1u) != 0u;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { ok[4 * b + u] = live; v0[4 * b + u] = 0ull; v1[4 * b + u] = 0ull; }
+        if (FORM == 3) {
+            const u32x4 w0 = t.w[b][0], w1 = t.w[b][1], w2 = t.w[b][2];
             v0[4 * b] = ((uint64_t)w0[1] << 32) | w0[0];     loc[4 * b] = w0[2];
             v0[4 * b + 1] = ((uint64_t)w1[0] << 32) | w0[3]; loc[4 * b + 1] = w1[1];
             v0[4 * b + 2] = ((uint64_t)w1[3] << 32) | w1[2]; loc[4 * b + 2] = w2[0];
             v0[4 * b + 3] = ((uint64_t)w2[2] << 32) | w2[1]; loc[4 * b + 3] = w2[3];
-            continue;
+        } else {
+            loc[4 * b] = t.x[b].x; loc[4 * b + 1] = t.x[b].y; loc[4 * b + 2] = t.x[b].z; loc[4 * b + 3] = t.x[b].w;
+            if (FORM >= 1) { v0[4 * b] = t.a0[b].x; v0[4 * b + 1] = t.a0[b].y; v0[4 * b + 2] = t.c0[b].x; v0[4 * b + 3] = t.c0[b].y; }
+            if (FORM >= 2) { v1[4 * b] = t.a1[b].x; v1[4 * b + 1] = t.a1[b].y; v1[4 * b + 2] = t.c1[b].x; v1[4 * b + 3] = t.c1[b].y; }
         }
-        const ushort4 x = *(const ushort4 *)((const uint16_t *)P.qidx + q);
-        loc[4 * b] = x.x; loc[4 * b + 1] = x.y; loc[4 * b + 2] = x.z; loc[4 * b + 3] = x.w;
-        if (P.nvals > 0) {
-            const ulonglong2 a = *(const ulonglong2 *)(P.qval[0] + q), c = *(const ulonglong2 *)(P.qval[0] + q + 2);
-            v0[4 * b] = a.x; v0[4 * b + 1] = a.y; v0[4 * b + 2] = c.x; v0[4 * b + 3] = c.y;
-        }
-        if (P.nvals > 1) {
-            const ulonglong2 a = *(const ulonglong2 *)(P.qval[1] + q), c = *(const ulonglong2 *)(P.qval[1] + q + 2);
-            v1[4 * b] = a.x; v1[4 * b + 1] = a.y; v1[4 * b + 2] = c.x; v1[4 * b + 3] = c.y;
+        if (!live) { // (re-read records of batch 0: they take no part, and must not raise the NaN flags)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { v0[4 * b + u] = 0ull; v1[4 * b + u] = 0ull; }
         }
     }
     // does any lane hold a NaN in value column 0 / 1 of this trip?
     bool nan0 = false, nan1 = false;
     const bool vint = P.val_i64 != 0; // int64 payloads: integer sums, nothing is NaN
-    if (P.nvals > 0 && !vint) {
+    if (FORM >= 1 && !vint) {
         bool m = false;
 #pragma unroll
         for (int u = 0; u < N; ++u) m |= as_f64(v0[u]) != as_f64(v0[u]);
         nan0 = __ballot(m) != 0ull;
     }
-    if (P.nvals > 1 && !vint) {
+    if (FORM == 2 && !vint) {
         bool m = false;
 #pragma unroll
         for (int u = 0; u < N; ++u) m |= as_f64(v1[u]) != as_f64(v1[u]);
@@ -2485,36 +2518,53 @@ __device__ __forceinline__ void reduce_trip_fast(const PartArgs &P, char *lds, u
 #pragma unroll
     for (int k = 0; k < NAGG; ++k) {
         char *base = lds + off[k];
-        const bool second = vs[k] == 1;
+        const bool second = FORM == 2 && vs[k] == 1;
         const bool has = vs[k] != 0xffu;
         const bool any_nan = has && (second ? nan1 : nan0);
         if (kind[k] == VXH_AGG_COUNT) {
             if (!any_nan) {
 #pragma unroll
-                for (int u = 0; u < N; ++u) at_add<__HIP_MEMORY_SCOPE_WORKGROUP, uint32_t>((uint32_t *)base + loc[u], 1u);
+                for (int u = 0; u < N; ++u)
+                    if (ok[u]) at_add<__HIP_MEMORY_SCOPE_WORKGROUP, uint32_t>((uint32_t *)base + loc[u], 1u);
             } else {
 #pragma unroll
                 for (int u = 0; u < N; ++u) {
                     const double d = as_f64(second ? v1[u] : v0[u]);
-                    if (d == d) at_add<__HIP_MEMORY_SCOPE_WORKGROUP, uint32_t>((uint32_t *)base + loc[u], 1u);
+                    if (ok[u] && d == d) at_add<__HIP_MEMORY_SCOPE_WORKGROUP, uint32_t>((uint32_t *)base + loc[u], 1u);
                 }
             }
         } else if (vint) {
 #pragma unroll
-            for (int u = 0; u < N; ++u) at_add<__HIP_MEMORY_SCOPE_WORKGROUP, unsigned long long>((unsigned long long *)base + loc[u], (unsigned long long)(second ? v1[u] : v0[u]));
+            for (int u = 0; u < N; ++u)
+                if (ok[u]) at_add<__HIP_MEMORY_SCOPE_WORKGROUP, unsigned long long>((unsigned long long *)base + loc[u], (unsigned long long)(second ? v1[u] : v0[u]));
         } else {
-            const bool sq = kind[k] == VXH_AGG_SUM_MOMENT;
+            // (the power is chosen once per aggregator, not inside every record's step: pow_u's branches on the exponent are uniform,
+            //  but eight copies of them per aggregator and trip were a dozen scalar instructions per record)
+            const uint32_t m = kind[k] == VXH_AGG_SUM_MOMENT ? mom[k] : 1u;
+            if (m == 1u) {
 #pragma unroll
-            for (int u = 0; u < N; ++u) {
-                double d = as_f64(second ? v1[u] : v0[u]);
-                if (sq) d = pow_u(d, mom[k]);
-                if (!any_nan || d == d) at_add<__HIP_MEMORY_SCOPE_WORKGROUP, double>((double *)base + loc[u], d);
+                for (int u = 0; u < N; ++u) {
+                    const double d = as_f64(second ? v1[u] : v0[u]);
+                    if (ok[u] && (!any_nan || d == d)) at_add<__HIP_MEMORY_SCOPE_WORKGROUP, double>((double *)base + loc[u], d);
+                }
+            } else if (m == 2u) {
+#pragma unroll
+                for (int u = 0; u < N; ++u) {
+                    const double x = as_f64(second ? v1[u] : v0[u]), d = x * x;
+                    if (ok[u] && (!any_nan || d == d)) at_add<__HIP_MEMORY_SCOPE_WORKGROUP, double>((double *)base + loc[u], d);
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < N; ++u) {
+                    const double d = pow_u(as_f64(second ? v1[u] : v0[u]), m);
+                    if (ok[u] && (!any_nan || d == d)) at_add<__HIP_MEMORY_SCOPE_WORKGROUP, double>((double *)base + loc[u], d);
+                }
             }
         }
     }
 }
 
-template <int NAGG>
+template <int NAGG, int FORM>
 __global__ void __launch_bounds__(1024) part_reduce_fast(const PartArgs P) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const uint32_t S = 1u << P.slab_log2;
@@ -2537,38 +2587,86 @@ __global__ void __launch_bounds__(1024) part_reduce_fast(const PartArgs P) {
     if (lim < len) len = lim;
     const uint64_t qb = (uint64_t)sub * P.cap;
     const uint64_t replica = 0; // (HBM grid replica for the rare device-atomic repairs; the slab itself goes to P.acc)
-    // records [lo, hi) of the sub-queue (lo a multiple of 4), walked by `width` consecutive threads starting at `first`
-    auto run = [&](uint64_t lo, uint64_t hi, uint32_t first, uint32_t width) {
-        const uint64_t step = 4ull * width;
-        const uint64_t hi4 = lo + ((hi - lo) & ~(uint64_t)3);
-        uint64_t j = lo + 4ull * (threadIdx.x - first);
-        for (; j + step < hi4; j += 2 * step) reduce_trip_fast<NAGG, 2>(P, lds, qb + j, step, off, kind, vs, mom);
-        for (; j < hi4; j += step) reduce_trip_fast<NAGG, 1>(P, lds, qb + j, step, off, kind, vs, mom);
-        for (uint64_t t = hi4 + (threadIdx.x - first); t < hi; t += width) { // tail (< 4 records): generic path
-            uint32_t loc[1] = {(uint32_t)((const uint16_t *)P.qidx)[qb + t]};
-            uint32_t fl[1] = {0xffu};
-            uint64_t v1[VXH_PART_MAX_VALS][1];
-#pragma unroll
-            for (int k = 0; k < VXH_PART_MAX_VALS; ++k) v1[k][0] = (k < P.nvals && !P.qrec12) ? P.qval[k][qb + t] : 0;
-            if (P.qrec12) {
-                const uint32_t *rec = (const uint32_t *)P.qidx + (qb + t) * 3;
-                v1[0][0] = ((uint64_t)rec[1] << 32) | rec[0];
-                loc[0] = rec[2];
+    constexpr int N4 = FORM == 2 ? 1 : 2; // batches of four records per lane per trip (two trips live in registers)
+    // SEGMENTS of the sub-queue.  qblk == 0: the whole sub-queue, walked by all the workgroup's threads.  Otherwise part_scatter_wv's
+    // layout: blocks of qblk records, each with its own fill count; every WAVE takes whole blocks (block w, w + waves, ...) — a block
+    // holds one pass-1 wave's records for this slab, a few hundred to a few thousand, which one 64-lane wave streams without leaving
+    // most of a 1024-thread trip idle.
+    const bool blocks = P.qblk != 0;
+    const uint32_t lane = threadIdx.x & 63u, nwave = blockDim.x >> 6;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t width = blocks ? 64u : blockDim.x, me = blocks ? lane : threadIdx.x; // (blockDim.x: a power of two — vxh_launch_part_reduce)
+    const uint32_t wsh = (uint32_t)__builtin_ctz(width);
+    const uint32_t QB = (uint32_t)P.qblk;
+    const uint32_t nblk = blocks ? (uint32_t)(len / QB) : 0u;
+    const uint32_t *const fills = P.qtab + (size_t)sub * (uint32_t)P.qtab_stride;
+    uint32_t it_b = wave;
+    bool it_done = false;
+    uint64_t seg_lo = 0, seg_nb4 = 0; // the segment's first record (inside the sub-queue), its whole batches of four
+    uint32_t seg_trips = 0, seg_t = 0;
+    auto next_segment = [&]() -> bool {
+        if (!blocks) {
+            if (it_done) return false;
+            it_done = true;
+            seg_lo = 0;
+            seg_nb4 = len >> 2;
+            if (seg_nb4 == 0) return false;
+        } else {
+            for (;;) {
+                if (it_b >= nblk) return false;
+                const uint32_t b = it_b;
+                it_b += nwave;
+                const uint32_t c = fills[b];
+                if (c < 4u) continue; // (its records are the tail loop's)
+                seg_lo = (uint64_t)b * QB;
+                seg_nb4 = c >> 2;
+                break;
             }
-            records_apply<__HIP_MEMORY_SCOPE_WORKGROUP, true, 1>(P, lds, loc, fl, v1, 1u, replica, slab);
         }
+        seg_trips = (uint32_t)((((width & (width - 1u)) == 0u ? (seg_nb4 + width - 1) >> wsh : (seg_nb4 + width - 1) / width) + N4 - 1) / N4); // (a shift: a 64-bit division here is a dozen vector instructions per segment, in registers the trips' loads are flying into)
+        seg_t = 0;
+        return true;
     };
-    if (P.qblk == 0) {
-        run(0, len, 0u, blockDim.x);
+    auto advance = [&]() -> bool { return ++seg_t < seg_trips ? true : next_segment(); };
+    auto request = [&](ReduceTrip<FORM, N4> &t, bool live) {
+        reduce_trip_request<FORM, N4>(P, t, qb + seg_lo, seg_nb4, (uint64_t)me + (uint64_t)seg_t * N4 * width, width, live);
+    };
+    if (next_segment()) {
+        // (every request is issued whether or not a trip is left — a conditional one would leave two load histories in front of the
+        //  apply, and the compiler's wait counts would then wait for the NEW trip's loads too)
+        ReduceTrip<FORM, N4> ta, tb;
+        request(ta, true);
+        for (;;) {
+            bool more = advance();
+            request(tb, more);
+            reduce_trip_apply<NAGG, FORM, N4>(P, lds, ta, off, kind, vs, mom);
+            if (!more) break;
+            more = advance();
+            request(ta, more);
+            reduce_trip_apply<NAGG, FORM, N4>(P, lds, tb, off, kind, vs, mom);
+            if (!more) break;
+        }
+    }
+    // tails (< 4 records behind a segment's whole batches): generic path
+    auto tail = [&](uint64_t t) {
+        uint32_t loc[1] = {FORM == 3 ? 0u : (uint32_t)((const uint16_t *)P.qidx)[qb + t]};
+        uint32_t fl[1] = {0xffu};
+        uint64_t v1[VXH_PART_MAX_VALS][1];
+#pragma unroll
+        for (int k = 0; k < VXH_PART_MAX_VALS; ++k) v1[k][0] = (FORM != 3 && k < FORM) ? P.qval[k < 2 ? k : 0][qb + t] : 0;
+        if (FORM == 3) {
+            const uint32_t *rec = (const uint32_t *)P.qidx + (qb + t) * 3;
+            v1[0][0] = ((uint64_t)rec[1] << 32) | rec[0];
+            loc[0] = rec[2];
+        }
+        records_apply<__HIP_MEMORY_SCOPE_WORKGROUP, true, 1>(P, lds, loc, fl, v1, 1u, replica, slab);
+    };
+    if (!blocks) {
+        for (uint64_t t = (len & ~3ull) + threadIdx.x; t < len; t += blockDim.x) tail(t);
     } else {
-        // part_scatter_wv's layout: blocks of qblk records, each with its own fill count.  Every WAVE takes whole blocks
-        // (block w, w + waves, ...): a block holds one pass-1 wave's records for this slab — a few hundred to a few
-        // thousand — which one 64-lane wave streams without leaving most of a 1024-thread trip idle.
-        const uint32_t nblk = (uint32_t)(len / (uint32_t)P.qblk);
-        const uint32_t wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
         for (uint32_t b = wave; b < nblk; b += nwave) {
-            const uint32_t c = P.qtab[(size_t)sub * (uint32_t)P.qtab_stride + b];
-            if (c) run((uint64_t)b * (uint32_t)P.qblk, (uint64_t)b * (uint32_t)P.qblk + c, threadIdx.x & ~63u, 64u);
+            const uint32_t c = fills[b];
+            for (uint32_t t = (c & ~3u) + lane; t < c; t += 64u) tail((uint64_t)b * QB + t);
         }
     }
     __syncthreads(); // (never launched with count16: its LDS counts are uint32)
@@ -3199,10 +3297,21 @@ void vxh_launch_part_reduce(const PartArgs &args, const LaunchPlan &plan, hipStr
     if (args.qrec12 && !fast) throw std::runtime_error("vaex_hip internal: 12-byte queue records need part_reduce_fast");
     if (!fast && args.A.count16) VXH_RD(part_reduce<true>);
     else if (!fast) VXH_RD(part_reduce<false>);
-    else if (args.A.nagg == 1) VXH_RD(part_reduce_fast<1>);
-    else if (args.A.nagg == 2) VXH_RD(part_reduce_fast<2>);
-    else if (args.A.nagg == 3) VXH_RD(part_reduce_fast<3>);
-    else VXH_RD(part_reduce_fast<4>);
+    else {
+        const int form = args.qrec12 ? 3 : args.nvals; // (fast: nvals <= 2)
+#define VXH_RDF(NA)                                                                                                    \
+    do {                                                                                                               \
+        if (form == 3) VXH_RD((part_reduce_fast<NA, 3>));                                                              \
+        else if (form == 2) VXH_RD((part_reduce_fast<NA, 2>));                                                         \
+        else if (form == 1) VXH_RD((part_reduce_fast<NA, 1>));                                                         \
+        else VXH_RD((part_reduce_fast<NA, 0>));                                                                        \
+    } while (0)
+        if (args.A.nagg == 1) VXH_RDF(1);
+        else if (args.A.nagg == 2) VXH_RDF(2);
+        else if (args.A.nagg == 3) VXH_RDF(3);
+        else VXH_RDF(4);
+#undef VXH_RDF
+    }
 #undef VXH_RD
 }
 
