@@ -380,6 +380,17 @@ int vxh_groupby_run_kept(int key_dtype, const void *keys, int n_values, const vo
  * value} instead of 16-byte {key, value} ones — a quarter off what it writes and reads back.  Keys outside the range: undefined groups. */
 int vxh_groupby_run_ranged(int key_dtype, const void *keys, int n_values, const void *const *values, const uint8_t *keep, uint64_t n, int mem,
                            uint64_t groups_hint, uint64_t max_groups, int64_t key_min, int64_t key_max, vxh_groupby **out);
+/* ... with HEAVY keys named by the caller (n_heavy <= 128 distinct int64 values — the head of a Zipf law, a default / missing-value
+ * key — found in a sample of the column; host array): every row of ONE key lands in ONE bucket of the partitioned pass, so a key with
+ * a few per cent of the rows overflows its queue, and long before that its single reduce workgroup is the whole pass.  The reference
+ * has no such cliff — ordered_set<T>::update keeps every key in its map (src/hash_primitives.hpp:471-479) and BinnerOrdinal adds a
+ * heavy key's rows to one cell like any other (src/binner_ordinal.cpp:138-175) — so the listed keys are peeled off INSIDE the pass:
+ * gb_scatter looks every row's key up in an LDS copy of the list, adds heavy rows to per-workgroup partials in LDS and leaves no
+ * record for them; their totals join the result as ordinary groups.  A key that is listed but absent yields no group; a heavy key
+ * that is not listed only costs time.  n_heavy = 0: vxh_groupby_run_ranged. */
+int vxh_groupby_run_peeled(int key_dtype, const void *keys, int n_values, const void *const *values, const uint8_t *keep, uint64_t n, int mem,
+                           uint64_t groups_hint, uint64_t max_groups, int64_t key_min, int64_t key_max, const int64_t *heavy_keys, int n_heavy,
+                           vxh_groupby **out);
 /* the same aggregation over PARTIAL results (other chunks', other ranks'): host arrays of n partial groups */
 int vxh_groupby_merge(int n_values, const int64_t *keys, const int64_t *rows, const int64_t *const *counts,
                       const double *const *sums, const double *const *sums2, uint64_t n, uint64_t groups_hint, vxh_groupby **out);
@@ -389,7 +400,7 @@ uint64_t vxh_groupby_size(const vxh_groupby *g);
 /* one result column (vxh_groupby_column_kind; value_index selects the value column for COUNT..STD) into a host array of
  * vxh_groupby_size elements of 8 bytes */
 int vxh_groupby_column(vxh_groupby *g, int value_index, int which, void *out_host);
-/* diagnostics: 0 buckets, 1 LDS slots per bucket, 2 retries, 3 / 4 / 5 = ms of the scatter / reduce / sort kernels, 6 = 1 when the pass moved 12-byte records */
+/* diagnostics: 0 buckets, 1 LDS slots per bucket, 2 retries, 3 / 4 / 5 = ms of the scatter / reduce / sort kernels, 6 = 1 when the pass moved 12-byte records, 7 = heavy keys peeled inside the pass */
 int vxh_groupby_info(const vxh_groupby *g, int what, double *value_out);
 
 /* ---- multi-GPU reduce ------------------------------------------------------------------ */

@@ -313,6 +313,42 @@ def test_frame_groupby_peels_heavy_keys_of_a_dense_range(sa, gpu_ready, where):
         assert np.allclose(got["m"], want["m"], rtol=1e-11, atol=0, equal_nan=True) and np.allclose(got["sd"], want["sd"], rtol=1e-7, atol=1e-9, equal_nan=True)
 
 
+def test_skewed_dense_key_range_takes_the_fused_pass_with_the_peel_inside(sa, gpu_ready):
+    """round 4: heavy keys are peeled INSIDE the fused pass (vxh_groupby_run_peeled: gb_scatter looks every key up in an LDS copy of the
+    heavy list, adds such rows to per-workgroup partials and leaves no record).  A dense key range wider than one workgroup's LDS whose
+    sample shows heavy keys takes that pass too when the call is count / sum / mean / var / std of float64 columns; heavy keys listed
+    but absent, a listed key with rows only outside the keep-mask, and NaN values of heavy rows are covered at the C-ABI level"""
+    import torch
+    from vaex_amd.binned import Frame, agg
+    rng = np.random.default_rng(23)
+    n = 4_500_000
+    k = np.minimum(rng.zipf(1.25, n), 300_000).astype(np.int64) - 1000
+    v = rng.normal(3, 2, n); v[::555] = np.nan
+    cols = {c: torch.from_numpy(a).cuda() for c, a in dict(k=k, v=v).items()}
+    spec = {"n": agg.count(), "c": agg.count("v"), "s": agg.sum("v"), "m": agg.mean("v"), "sd": agg.std("v")}
+    df = Frame(cols, superagg=sa)
+    df.last_groupby_info = None
+    got = df.groupby("k", spec)
+    info = df.last_groupby_info
+    assert info is not None and info.get("dense_range_through_fused_pass") == 1 and info["heavy_keys"] >= 2 and info["retries"] == 0, info
+    w = _want(k, [v])
+    np.testing.assert_array_equal(got["k"], w["k"]); np.testing.assert_array_equal(got["n"], w["rows"]); np.testing.assert_array_equal(got["c"], w["v"][0]["cnt"])
+    assert np.all(np.abs(got["s"] - w["v"][0]["s"]) <= 1e-12 * w["v"][0]["sabs"])
+    # the C-ABI entry itself: two value columns, a keep-mask, a listed key that does not occur, one whose rows are all masked out
+    m = 3_000_000
+    kk = (rng.integers(0, 50_000, m).astype(np.int64) * 2654435761) % (1 << 40)
+    hot, cold, masked_out = int(kk[0]), 12345678901234, int(kk[1])
+    kk[rng.random(m) < 0.3] = hot
+    v0 = rng.normal(1, 1, m); v1 = rng.normal(-2, 3, m); v0[::97] = np.nan
+    keep = (rng.random(m) < 0.7).astype(np.uint8); keep[kk == masked_out] = 0
+    res = sa.groupby_run(torch.from_numpy(kk).cuda(), [torch.from_numpy(v0).cuda(), torch.from_numpy(v1).cuda()], 2,   # (2 = VXH_I64)
+                         keep=torch.from_numpy(keep).cuda(), heavy=np.array([hot, cold, masked_out, hot], dtype=np.int64))
+    assert res.info()["heavy_keys_in_pass"] == 3 and res.info()["retries"] == 0, res.info()
+    sel = keep == 1
+    w2 = _want(kk[sel], [v0[sel], v1[sel]])
+    _check(sa, res, w2)
+
+
 def test_count_only_groupby_and_value_counts_take_the_fused_pass(sa, gpu_ready):
     """`n: count` over scattered int64 keys (and value_counts of a float column: its bit patterns are such keys) has no value column
     to carry through the partitioned pass: the key column lends its own 8 bytes as payload, only the row counts are read"""

@@ -18,11 +18,13 @@ spec = {"c": agg.count("v"), "s": agg.sum("v"), "m": agg.mean("v"), "sd": agg.st
 uni = (torch.randint(0, 1_000_000, (len(k),), dtype=torch.int64, device="cuda") * 2654435761) % (1 << 40)
 kd = torch.from_numpy(np.minimum(z, 1_000_000)).cuda().repeat(8)       # the same law on a DENSE key range (1e6 cells: the slab-partitioned pass)
 kd = kd[torch.randperm(len(kd), device="cuda")] if rows <= 400_000_000 else kd
-for label, keys, peel in (("zipf keys, peeled", k, True), ("zipf keys, no peel", k, False), ("uniform 1e6 keys", uni, True),
+for label, keys, peel in (("zipf keys, peeled", k, True), ("zipf, 3-pass peel (r3)", k, 3), ("zipf keys, no peel", k, False), ("uniform 1e6 keys", uni, True),
                           ("dense zipf, peeled", kd, True), ("dense zipf, no peel", kd, False), ("dense uniform 1e6", uni // 2654435761 % 1_000_000 if False else torch.randint(0, 1_000_000, (len(k),), dtype=torch.int64, device="cuda"), True)):
     df = Frame(dict(k=keys, v=v))
     if not peel:
         df.heavy_key_rows = 1 << 62
+    if peel == 3:   # (round 3's peel: ordinals + keep-mask + a dense groupby of the heavy rows; round 4 peels inside the fused pass)
+        df.one_kernel_peel = False
     best = 1e9
     for rep in range(3):
         df.last_groupby_info = None
@@ -30,4 +32,4 @@ for label, keys, peel in (("zipf keys, peeled", k, True), ("zipf keys, no peel",
         res = df.groupby("k", spec)
         torch.cuda.synchronize(); best = min(best, time.perf_counter() - t0)
     info = df.last_groupby_info or {}
-    print(f"{label:<22} {len(keys):.3g} rows  {best*1e3:9.2f} ms  {len(keys)/best/1e9:7.2f} Grows/s  groups {len(res['k'])}  rows counted {int(res['c'].sum())}  info {({k_: info[k_] for k_ in ('buckets','retries','heavy_keys','heavy_groups','dense') if k_ in info})}", flush=True)
+    print(f"{label:<22} {len(keys):.3g} rows  {best*1e3:9.2f} ms  {len(keys)/best/1e9:7.2f} Grows/s  groups {len(res['k'])}  rows counted {int(res['c'].sum())}  info {({k_: info[k_] for k_ in ('buckets','retries','heavy_keys','heavy_groups','dense','ms_scatter','ms_reduce','ms_sort') if k_ in info})}", flush=True)

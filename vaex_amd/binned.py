@@ -974,6 +974,18 @@ class Frame:
                 # a key range wider than one CU's LDS bins through the slab-partitioned pass: every row of one key goes to one slab's
                 # queue — a heavy key overflows it (rows beyond its capacity are same-address device atomics) and is one workgroup's
                 # work in pass 2.  Same remedy as in front of the fused hash pass: the heavy keys are peeled off.
+                # Round 4: such a column goes through the FUSED hash pass with the heavy keys peeled inside it (one pass, ~1x the
+                # uniform-key pass; the dense three-pass peel of round 3 costs ~4x) — when its sample shows heavy keys, on every rank
+                # (the ranks must take the same branch: one MIN all-reduce), and the call is inside the fused pass's signature.
+                if self.one_kernel_peel:
+                    mine = self.n >= self.heavy_key_rows and self._heavy_keys(by, key, share=self.heavy_key_share_in_pass) is not None
+                    skewed = mine if comm is None else not comm.all_agree(not mine)   # (any rank's sample: one MIN all-reduce)
+                    if skewed:
+                        fused = self._groupby_fused(by, pf, descs, names, comm, key_range=(kmin, kmax))
+                        if fused is not None:
+                            self.last_groupby_info = dict(self.last_groupby_info or {}, dense_range_through_fused_pass=1)
+                            return fused
+                # (outside the fused pass's signature — min / max, integer value columns, several selections: round 3's three passes)
                 peeled = self._groupby_dense_peeled(by, pf, key, descs, names, (kmin, kmax), comm)
                 if peeled is not None:
                     return peeled
@@ -1074,35 +1086,46 @@ class Frame:
         # reduce workgroup is the whole pass (a 1 % key of 1e9 rows: 7 ms on one CU).  A sample of the keys finds them; they are
         # peeled off (`_groupby_peeled`): everything else takes the fused pass with the heavy rows masked out, the few heavy
         # keys are a dense groupby over their ordinals.
-        if (comm is not None or self.n >= self.heavy_key_rows) and pf in _PEEL_KEY_KINDS:
+        # Round 4: the peel happens INSIDE the pass (vxh_groupby_run_peeled: gb_scatter looks every key up in an LDS copy of the heavy
+        # list and adds such rows to per-workgroup partials instead of emitting a record) — no ordinal column, no keep-mask, no second
+        # groupby over the heavy rows.  Row-sharded frames: every rank peels what is heavy in ITS shard; the partial groups of a heavy
+        # key are ordinary partial groups in the cross-rank merge (a handful per key: nothing skewed about them).
+        heavy = None
+        if self.n >= self.heavy_key_rows and self.one_kernel_peel:
+            heavy = self._heavy_keys(by, key, share=self.heavy_key_share_in_pass)
+        elif (comm is not None or self.n >= self.heavy_key_rows) and pf in _PEEL_KEY_KINDS and not self.one_kernel_peel:
+            # (the three-pass peel of round 3, kept behind the knob for the timing comparison: tools/r03_skew_groupby.py)
             try:
                 import torch
             except ImportError:   # (the peel keeps its row-wise intermediates in torch tensors: no rank has it then)
                 torch = None
-            heavy = self._heavy_keys_all_ranks(by, key, comm) if torch is not None else None
-            if heavy is not None:
+            heavy3 = self._heavy_keys_all_ranks(by, key, comm) if torch is not None else None
+            if heavy3 is not None:
                 try:
                     # (host rows: the pass would copy them to the device anyway — here once, for both parts)
                     dev = lambda a: a if _is_device(a) else torch.from_numpy(np.ascontiguousarray(a)).cuda()
-                    peeled = self._groupby_peeled(by, pf, descs, names, vcols, dev(key), [dev(v) for v in values], None if keep is None else dev(keep), heavy, comm=comm)
+                    peeled = self._groupby_peeled(by, pf, descs, names, vcols, dev(key), [dev(v) for v in values], None if keep is None else dev(keep), heavy3, comm=comm)
                 except torch.cuda.OutOfMemoryError:   # (the ordinals are 8 more bytes per row: no room — the plain attempt below)
                     peeled = None
                 if not _is_device(key) or peeled is None:
                     torch.cuda.empty_cache()   # (whole columns went through torch's allocator: the library's own hipMallocs need the room back)
                 if peeled is not None:
                     return peeled
-        res, failed = None, None
+        res, failed, peeled_here = None, None, 0
         # the number of groups of an earlier call over the same key column (remembered like the key range): the pass sizes its
         # bucket tables for a known count at 80 % load instead of a guessed 2^20 at 50 % — half the buckets for 1e6 keys
         seen = self.__dict__.setdefault("_group_count_cache", {}).get(by)
         hint = int(seen[1]) if seen is not None and seen[0] is key and keep is None else 0
+        if heavy is not None:
+            hint = 0   # (skewed keys: as many buckets as the default gives — the light keys are still uneven, and a bucket is one workgroup's work)
         try:
             # (the measured key range: where it leaves a remainder of <= 32 bits below the bucket bits, the pass moves 12-byte records)
             kr = None if key_range is None or key_range[0] > key_range[1] else (int(key_range[0]), int(key_range[1]))
-            res = (sa.groupby_run(key if _is_device(key) else np.ascontiguousarray(key), values, _DT_CODE[pf], keep=keep, key_range=kr) if keep is not None else
-                   sa.groupby_run(key if _is_device(key) else np.ascontiguousarray(key), values, _DT_CODE[pf], hint, key_range=kr)) if self.n else None
+            res = (sa.groupby_run(key if _is_device(key) else np.ascontiguousarray(key), values, _DT_CODE[pf], keep=keep, key_range=kr, heavy=heavy) if keep is not None else
+                   sa.groupby_run(key if _is_device(key) else np.ascontiguousarray(key), values, _DT_CODE[pf], hint, key_range=kr, heavy=heavy)) if self.n else None
             if res is not None and keep is None:
                 self.__dict__["_group_count_cache"][by] = (key, len(res))
+            peeled_here = int(res.info().get("heavy_keys_in_pass", 0)) if res is not None else 0
         except RuntimeError as e:
             if not str(e).startswith("groupby"):   # (anything the pass itself reports: too many / too skewed keys, no room for its queues)
                 raise
@@ -1132,12 +1155,19 @@ class Frame:
             else:
                 out[name] = np.asarray(res.column(which[d.name], vcols.index(d.column)))
         self.last_groupby_info = res.info()
+        if heavy is not None:
+            self.last_groupby_info.update(heavy_keys=peeled_here)   # (of THIS rank's pass; a cross-rank merge has none)
         return out
 
+    #: heavy keys are peeled inside the fused pass (round 4); False: round 3's three passes (ordinals, keep-mask, a dense groupby of the heavy rows)
+    one_kernel_peel = True
     #: rows from which a device-resident key column is sampled for heavy hitters before the fused hash groupby
     heavy_key_rows = 1 << 22
     #: sampled share from which a key counts as heavy (1/128: at most 128 of them)
     heavy_key_share = 1.0 / 128
+    #: ... for the peel inside the fused pass: 1/1024 (128 sampled rows of 2^17; the 128 most frequent such keys) — a bucket is ONE reduce
+    #: workgroup's work, and a key with 0.5 % of the rows still triples its bucket's share of a 512-bucket pass
+    heavy_key_share_in_pass = 1.0 / 1024
 
     #: dense key ranges wider than this many cells are checked for heavy keys too (narrower ones live in one workgroup's LDS)
     dense_peel_cells = 1 << 14
@@ -1186,19 +1216,22 @@ class Frame:
         allk = np.asarray(comm.union_keys(np.zeros(0, dtype=np.int64) if mine is None else np.asarray(mine, dtype=np.int64)), dtype=np.int64)
         return allk if len(allk) else None
 
-    def _heavy_keys(self, by, key):
-        """keys holding >= heavy_key_share of a strided sample of 2^17 rows of the key column (ascending int64 array), or None.
-        A heuristic: correctness never rests on it (a missed heavy key only costs time, a false one a little).  Remembered per
-        column object like the key range."""
+    def _heavy_keys(self, by, key, share=None):
+        """keys holding >= `share` (default heavy_key_share) of a strided sample of 2^17 rows of the key column — the 128 most frequent
+        of them at most (ascending int64 array) — or None.  A heuristic: correctness never rests on it (a missed heavy key only costs
+        time, a false one a little).  Remembered per column object like the key range."""
+        share = self.heavy_key_share if share is None else share
         cache = self.__dict__.setdefault("_heavy_cache", {})
-        hit = cache.get(by)
+        hit = cache.get((by, share))
         if hit is not None and hit[0] is key:
             return hit[1]
         m = 1 << 17
         step = max(1, self.n // m)
         if isinstance(key, np.ndarray):
             uniq, cnt = np.unique(np.asarray(key[::step][:m]), return_counts=True)
-            hv = uniq[cnt >= max(8, int(min(m, len(key[::step])) * self.heavy_key_share))]
+            sel = cnt >= max(8, int(min(m, len(key[::step])) * share))
+            uniq, cnt = uniq[sel], cnt[sel]
+            hv = uniq[np.argsort(-cnt, kind="stable")[:128]]
         else:
             try:
                 import torch
@@ -1210,11 +1243,13 @@ class Frame:
             try:
                 uniq, cnt = torch.unique(sample, return_counts=True)
             except RuntimeError:   # (a dtype torch does not sort)
-                cache[by] = (key, None)
+                cache[(by, share)] = (key, None)
                 return None
-            hv = uniq[cnt >= max(8, int(len(sample) * self.heavy_key_share))].cpu().numpy()
+            sel = cnt >= max(8, int(len(sample) * share))
+            uniq, cnt = uniq[sel].cpu().numpy(), cnt[sel].cpu().numpy()
+            hv = uniq[np.argsort(-cnt, kind="stable")[:128]]
         heavy = np.sort(hv.astype(np.int64)) if len(hv) else None
-        cache[by] = (key, heavy)
+        cache[(by, share)] = (key, heavy)
         return heavy
 
     def _groupby_peeled(self, by, pf, descs, names, vcols, key, values, keep, heavy, dense_range=None, comm=None):

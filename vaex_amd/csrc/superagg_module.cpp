@@ -209,9 +209,9 @@ struct PyGroupBy {
         return out;
     }
     py::dict info() const {
-        static const char *names[] = {"buckets", "slots", "retries", "ms_scatter", "ms_reduce", "ms_sort", "compact_records"};
+        static const char *names[] = {"buckets", "slots", "retries", "ms_scatter", "ms_reduce", "ms_sort", "compact_records", "heavy_keys_in_pass"};
         py::dict d;
-        for (int i = 0; i < 7; i++) {
+        for (int i = 0; i < 8; i++) {
             double v = 0;
             check(vxh_groupby_info(h, i, &v));
             d[names[i]] = v;
@@ -861,7 +861,9 @@ PYBIND11_MODULE(superagg, m) {
     m.attr("GB_STD") = (int)VXH_GB_STD;
     // groupby_run(keys, [v0, v1], key_dtype, groups_hint=0, max_groups=0): keys any integer array (host or device), values
     // float64 arrays living where the keys live
-    m.def("groupby_run", [](const py::object &keys, const std::vector<py::object> &values, int key_dtype, uint64_t hint, uint64_t max_groups, const py::object &keep, const py::object &key_range) {
+    m.def("groupby_run", [](const py::object &keys, const std::vector<py::object> &values, int key_dtype, uint64_t hint, uint64_t max_groups, const py::object &keep, const py::object &key_range, const py::object &heavy) {
+        std::vector<int64_t> hv; // heavy keys peeled inside the pass (vxh_groupby_run_peeled)
+        if (!heavy.is_none()) for (auto item : py::array_t<int64_t, py::array::c_style | py::array::forcecast>::ensure(heavy).cast<std::vector<int64_t>>()) hv.push_back(item);
         int64_t key_min = 1, key_max = 0; // (unknown)
         if (!key_range.is_none()) {
             auto kr = key_range.cast<std::pair<int64_t, int64_t>>();
@@ -887,11 +889,11 @@ PYBIND11_MODULE(superagg, m) {
         int rc;
         {
             py::gil_scoped_release release;
-            rc = vxh_groupby_run_ranged(key_dtype, k.ptr, (int)vp.size(), vp.data(), keep_ptr, k.n, k.mem, hint, max_groups, key_min, key_max, &res->h);
+            rc = vxh_groupby_run_peeled(key_dtype, k.ptr, (int)vp.size(), vp.data(), keep_ptr, k.n, k.mem, hint, max_groups, key_min, key_max, hv.data(), (int)hv.size(), &res->h);
         }
         check(rc);
         return res;
-    }, py::arg("keys"), py::arg("values"), py::arg("key_dtype") = (int)VXH_I64, py::arg("groups_hint") = 0, py::arg("max_groups") = 0, py::arg("keep") = py::none(), py::arg("key_range") = py::none());
+    }, py::arg("keys"), py::arg("values"), py::arg("key_dtype") = (int)VXH_I64, py::arg("groups_hint") = 0, py::arg("max_groups") = 0, py::arg("keep") = py::none(), py::arg("key_range") = py::none(), py::arg("heavy") = py::none());
     // groupby_merge(keys, rows, [count_j], [sum_j], [sum2_j]): partial results (host arrays) -> one result
     m.def("groupby_merge", [](py::array_t<int64_t, py::array::c_style | py::array::forcecast> keys, py::array_t<int64_t, py::array::c_style | py::array::forcecast> rows,
                               const std::vector<py::array_t<int64_t, py::array::c_style | py::array::forcecast>> &counts,

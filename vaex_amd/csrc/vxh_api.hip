@@ -1863,7 +1863,7 @@ int vxh_config_set(const char *key, int64_t value) {
     else if (k == "merge_fused") c.cfg_merge_fused = value;
     else if (k == "wv_auto") { c.cfg_wv_auto = value; c.wv_auto_last = 0; if (value) { c.cfg_wv = 5; c.cfg_wv_user_set = false; } }
     else if (k == "gb_compact") c.cfg_gb_compact = value;
-    else if (k == "gb_early") c.cfg_gb_early = value;
+    else if (k == "gb_abl") c.cfg_gb_abl = value;
     else if (k == "gb_known_count") c.cfg_gb_known_count = value;
     else if (k == "gb_load_pct") c.cfg_gb_load_pct = value > 0 ? value : 50;
     else if (k == "fuse_selection") c.cfg_fuse_selection = value;
@@ -1922,7 +1922,7 @@ int vxh_config_get(const char *key, int64_t *value) {
     else if (k == "wv_auto") *value = c.cfg_wv_auto;
     else if (k == "wv_auto_choice") *value = get_slot(0).hot.auto_state >= 2 ? get_slot(0).hot.auto_choice : 0;
     else if (k == "gb_compact") *value = c.cfg_gb_compact;
-    else if (k == "gb_early") *value = c.cfg_gb_early;
+    else if (k == "gb_abl") *value = c.cfg_gb_abl;
     else if (k == "gb_known_count") *value = c.cfg_gb_known_count;
     else if (k == "gb_load_pct") *value = c.cfg_gb_load_pct;
     else if (k == "fuse_selection") *value = c.cfg_fuse_selection;

@@ -107,6 +107,15 @@ struct GbArgs {
     // <= 32 bits below — what the bucket implies is not stored: records are 12 bytes {remainder, payload} instead of 16, in the
     // scatter's writes and the reduce's reads alike.  gb_reduce rebuilds the key of every GROUP (bucket | remainder, mixed back).
     int32_t kc_bits;        // 0: 16-byte records {key, payload}
+    // Heavy keys (round 4, the one-kernel peel): rows whose key is one of `n_heavy` <= 128 listed keys leave NO record — gb_scatter looks
+    // every key up in an LDS copy of the list, adds such rows to per-workgroup partials in LDS {rows | count, sum, sum2 ...} and folds those
+    // into heavy_acc at its end; gb_append_heavy turns the accumulators into ordinary groups in front of the sort.  (Every row of ONE key
+    // lands in ONE bucket: a key with a few per cent of the rows overflows its queue, and long before that its single reduce workgroup is
+    // the whole pass — src/hash_primitives.hpp:471-479 keeps such keys in one map like any other; the partitioned pass cannot.)
+    const long long *heavy_keys;   // [n_heavy] distinct, none of them INT64_MIN
+    int32_t n_heavy;
+    unsigned long long *heavy_acc; // [n_heavy][1 + 3 nv]: rows, then per value column count, sum bits, sum2 bits
+    int32_t abl;            // timing experiments ("gb_abl"; results wrong on purpose): 1 = gb_scatter's copy-out computes but does not store, 2 = no copy-out, 4 = no staging and no copy-out
     long long kc_min;
     uint64_t kc_a_inv, kc_b_inv; // inverses of the two multipliers modulo 2^64
     // results (unsorted)
@@ -141,9 +150,12 @@ typedef gb_u32x3 gb_u32x3_a4 __attribute__((aligned(4)));
 // of a thread's tile left one after the other, a memory latency each, and "the next tile requested under the current one" did not exist:
 // 8.9 ms per 1e9 rows with the HBM idle most of the time.  Now the loads of a tile are issued back to back and nothing touches what
 // they return before the next tile's turn.
-// EARLY: the next tile's registers are taken over between staging [C] and copy-out [D] (the wait for its loads then is not also a wait
-// for [D]'s stores, which count in the same vmcnt on gfx9) instead of behind [D].
-template <int W, int R, bool K64, bool KEEP, bool EARLY>
+// (Tried and removed: taking the next tile's registers over between staging [C] and copy-out [D], so that the wait for its loads is
+//  not also a wait for [D]'s stores — 8.30 vs 8.33 ms per 1e9 rows; non-temporal copy-out stores: 8.28 vs 8.31.)
+// HEAVY: G.n_heavy > 0 (RAW records only: W = value columns).
+constexpr uint32_t GB_HEAVY_MAX = 128, GB_HEAVY_SLOTS = 256;
+constexpr size_t gb_heavy_lds(int w) { return (size_t)GB_HEAVY_SLOTS * 8 + GB_HEAVY_SLOTS + (size_t)GB_HEAVY_MAX * 8 + (size_t)w * GB_HEAVY_MAX * 16 + (size_t)(w > 1 ? w - 1 : 0) * GB_HEAVY_MAX * 4 + 16; }
+template <int W, int R, bool K64, bool KEEP, bool HEAVY>
 __global__ void __launch_bounds__(1024) gb_scatter(const GbArgs G) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr uint32_t T = 1024u * R;
@@ -157,9 +169,32 @@ __global__ void __launch_bounds__(1024) gb_scatter(const GbArgs G) {
     uint32_t *const split = base1 + NB;
     uint32_t *const s_wave = split + NB; // [16]
     uint16_t *const st_b = (uint16_t *)(s_wave + 16);
+    // HEAVY: the heavy keys' table (open addressing, <= half full) and this workgroup's partials, behind the staging area
+    unsigned long long *const hk_key = (unsigned long long *)(((uintptr_t)(st_b + T) + 15) & ~(uintptr_t)15); // [GB_HEAVY_SLOTS]
+    unsigned long long *const h_rc = hk_key + GB_HEAVY_SLOTS;                                                   // [GB_HEAVY_MAX] rows (low half) | count of value column 0 (high half)
+    double *const h_sum = (double *)(h_rc + GB_HEAVY_MAX);                                                      // [W][GB_HEAVY_MAX]
+    double *const h_sum2 = h_sum + (size_t)W * GB_HEAVY_MAX;                                                    // [W][GB_HEAVY_MAX]
+    uint32_t *const h_cnt = (uint32_t *)(h_sum2 + (size_t)W * GB_HEAVY_MAX);                                    // [W - 1][GB_HEAVY_MAX] counts of value columns >= 1
+    uint8_t *const hk_ord = (uint8_t *)(h_cnt + (size_t)(W > 1 ? W - 1 : 0) * GB_HEAVY_MAX);                    // [GB_HEAVY_SLOTS] position of the slot's key in G.heavy_keys
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint64_t n = G.n;
     if (tid < NB) cnt[tid] = 0u;
+    auto heavy_home = [](unsigned long long k) -> uint32_t { return (uint32_t)((k * 0x9e3779b97f4a7c15ULL) >> 56) & (GB_HEAVY_SLOTS - 1u); };
+    if (HEAVY) {
+        if (tid < GB_HEAVY_SLOTS) hk_key[tid] = (unsigned long long)GB_EMPTY;
+        if (tid < GB_HEAVY_MAX) {
+            h_rc[tid] = 0ull;
+#pragma unroll
+            for (int w = 0; w < W; ++w) { h_sum[(size_t)w * GB_HEAVY_MAX + tid] = 0.0; h_sum2[(size_t)w * GB_HEAVY_MAX + tid] = 0.0; if (w > 0) h_cnt[(size_t)(w - 1) * GB_HEAVY_MAX + tid] = 0u; }
+        }
+        __syncthreads();
+        if (tid < (uint32_t)G.n_heavy) { // (distinct keys, a table twice their number: every insert finds a free slot)
+            const unsigned long long k = (unsigned long long)G.heavy_keys[tid];
+            for (uint32_t sl = heavy_home(k);; sl = (sl + 1u) & (GB_HEAVY_SLOTS - 1u)) {
+                if (atomicCAS(&hk_key[sl], (unsigned long long)GB_EMPTY, k) == (unsigned long long)GB_EMPTY) { hk_ord[sl] = (uint8_t)tid; break; }
+            }
+        }
+    }
     // thread b: the block bucket b's records of this workgroup go to, and how full it is
     const uint32_t B = G.blk;
     const uint32_t primaries = G.scatter_wgs * NB;
@@ -221,6 +256,30 @@ __global__ void __launch_bounds__(1024) gb_scatter(const GbArgs G) {
         for (int r = 0; r < R; ++r) {
             if (!K64) key[r] = gb_fix_key(key[r], G.key_dtype);
             if (KEEP) ok[r] = ok[r] && kb[r] == 1u;
+            if (HEAVY) { // a heavy key's row goes to the workgroup's partials and leaves no record
+                const unsigned long long k = (unsigned long long)key[r];
+                uint32_t sl = heavy_home(k), h = 0xffffffffu;
+                for (;;) {
+                    const unsigned long long t = hk_key[sl];
+                    if (t == k) { h = hk_ord[sl]; break; }
+                    if (t == (unsigned long long)GB_EMPTY) break;
+                    sl = (sl + 1u) & (GB_HEAVY_SLOTS - 1u);
+                }
+                if (ok[r] && h != 0xffffffffu && key[r] != GB_EMPTY) {
+                    const double d0 = __longlong_as_double((long long)pay[0][r]);
+                    __hip_atomic_fetch_add(&h_rc[h], d0 == d0 ? 0x100000001ull : 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+                    for (int w = 0; w < W; ++w) {
+                        const double d = __longlong_as_double((long long)pay[w][r]);
+                        if (d == d) { // NaN values are skipped by count / sum / sum-moment alike (src/agg_sum.cpp:113, agg_count.cpp:56)
+                            if (w > 0) __hip_atomic_fetch_add(&h_cnt[(size_t)(w - 1) * GB_HEAVY_MAX + h], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            __hip_atomic_fetch_add(&h_sum[(size_t)w * GB_HEAVY_MAX + h], d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            __hip_atomic_fetch_add(&h_sum2[(size_t)w * GB_HEAVY_MAX + h], d * d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        }
+                    }
+                    ok[r] = false;
+                }
+            }
         }
     };
     auto take_over = [&]() {
@@ -237,7 +296,7 @@ __global__ void __launch_bounds__(1024) gb_scatter(const GbArgs G) {
     //  `key` it left [A] with two histories of outstanding loads, and the compiler's wait counts in [A] then waited for the NEXT tile's keys)
     if ((uint64_t)blockIdx.x * T < n) { request(blockIdx.x, key_n, pay_n, ok_n, kb_n); take_over(); }
     for (uint64_t tile = blockIdx.x; tile * T < n; tile += gridDim.x) {
-        // the next tile's rows are requested first: their loads fly under [A] .. [C] (and [D] unless EARLY)
+        // the next tile's rows are requested first: their loads fly under [A] .. [D]
         const uint64_t next = tile + gridDim.x;
         const bool has_next = next * T < n;
         if (has_next) request(next, key_n, pay_n, ok_n, kb_n);
@@ -304,7 +363,7 @@ __global__ void __launch_bounds__(1024) gb_scatter(const GbArgs G) {
         // [C] stage sorted by bucket
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            if (ok[r]) {
+            if (ok[r] && !(G.abl & 4)) {
                 const uint32_t j = off[bucket[r]] + pos[r];
                 st_key[j] = (uint64_t)key[r];
 #pragma unroll
@@ -312,19 +371,21 @@ __global__ void __launch_bounds__(1024) gb_scatter(const GbArgs G) {
                 st_b[j] = (uint16_t)bucket[r];
             }
         }
-        if (EARLY && has_next) take_over();
         __syncthreads();
         // [D] copy out: consecutive threads -> consecutive records of a bucket's segment
-        for (uint32_t j = tid; j < total; j += 1024u) {
+        for (uint32_t j = tid; j < ((G.abl & 6) ? 0u : total); j += 1024u) {
             const uint32_t b = st_b[j];
             const uint32_t k = j - off[b];
             const uint32_t sp = split[b];
             const uint32_t base = k < sp ? base0[b] : base1[b];
             if (base == 0xffffffffu) continue; // (queue full: flagged, the host retries with more room)
-            const uint64_t dst = (uint64_t)base + (k < sp ? k : k - sp);
+            uint64_t dst = (uint64_t)base + (k < sp ? k : k - sp);
+            if (G.abl & 1) { if (st_key[j] != 0x123456789abcdefull) continue; dst = 0; } // (the staged words are read, nothing is stored)
             if (W == 1 && G.kc_bits) { // 12-byte record {remainder, payload}
                 const uint64_t c2 = st_w[j];
-                *(gb_u32x3_a4 *)((uint32_t *)G.qrec + dst * 3) = gb_u32x3_a4{(uint32_t)st_key[j], (uint32_t)c2, (uint32_t)(c2 >> 32)};
+                const gb_u32x3_a4 rec = gb_u32x3_a4{(uint32_t)st_key[j], (uint32_t)c2, (uint32_t)(c2 >> 32)};
+                if (G.abl & 8) __builtin_nontemporal_store(rec, (gb_u32x3_a4 *)((uint32_t *)G.qrec + dst * 3)); // (experiment: non-temporal)
+                else *(gb_u32x3_a4 *)((uint32_t *)G.qrec + dst * 3) = rec;
             } else if (W == 1) { // one 16-byte record {key, payload}: a tile's segment of a bucket is 16 B x its records, contiguous
                 const uint64_t a = st_key[j], c2 = st_w[j];
                 G.qrec[dst] = make_uint4((uint32_t)a, (uint32_t)(a >> 32), (uint32_t)c2, (uint32_t)(c2 >> 32));
@@ -335,9 +396,41 @@ __global__ void __launch_bounds__(1024) gb_scatter(const GbArgs G) {
             }
         }
         // (the next tile's [C] comes after two more barriers: nobody overwrites what [D] still reads)
-        if (!EARLY && has_next) take_over();
+        if (has_next) take_over();
     }
     if (tid < NB && !dead) G.tab[block] = fill;
+    if (HEAVY) { // this workgroup's partials into the call's accumulators (a few hundred device atomics per workgroup)
+        __syncthreads();
+        if (tid < (uint32_t)G.n_heavy) {
+            const unsigned long long rc = h_rc[tid];
+            if (rc & 0xffffffffull) {
+                unsigned long long *acc = G.heavy_acc + (size_t)tid * (1 + 3 * W);
+                atomicAdd(&acc[0], rc & 0xffffffffull);
+#pragma unroll
+                for (int w = 0; w < W; ++w) {
+                    const unsigned long long c = w == 0 ? rc >> 32 : (unsigned long long)h_cnt[(size_t)(w - 1) * GB_HEAVY_MAX + tid];
+                    if (c) {
+                        atomicAdd(&acc[1 + 3 * w], c);
+                        atomicAdd((double *)&acc[2 + 3 * w], h_sum[(size_t)w * GB_HEAVY_MAX + tid]);
+                        atomicAdd((double *)&acc[3 + 3 * w], h_sum2[(size_t)w * GB_HEAVY_MAX + tid]);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// heavy_acc -> groups: one thread per heavy key with at least one row (behind gb_reduce, in front of the sort)
+__global__ void gb_append_heavy(const GbArgs G) {
+    const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
+    if (h >= (uint32_t)G.n_heavy) return;
+    const int wout = 1 + 3 * G.nv;
+    const unsigned long long *acc = G.heavy_acc + (size_t)h * wout;
+    if (acc[0] == 0ull) return;
+    const unsigned long long o = atomicAdd(G.out_count, 1ull);
+    if (o >= G.out_cap) { atomicExch(G.overflow, 3u); return; }
+    G.out_key[o] = G.heavy_keys[h];
+    for (int k = 0; k < wout; ++k) G.out_w[k][o] = acc[k];
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -630,7 +723,7 @@ struct vxh_groupby {
     Dev cols; // [key | rows | (count, sum, sum2) x nv] x n_groups, 8-byte elements, sorted by key
     Dev tmp;
     uint64_t stride = 0; // elements between columns
-    int buckets = 0, slots = 0, retries = 0, compact = 0;
+    int buckets = 0, slots = 0, retries = 0, compact = 0, heavy = 0;
     float ms_scatter = 0, ms_reduce = 0, ms_sort = 0;
 };
 
@@ -653,20 +746,21 @@ size_t scatter_lds(int nb_log2) {
     const size_t T = 1024u * R;
     return T * 8 * (1 + W) + ((size_t)1 << nb_log2) * 4 * 5 + 64 + T * 2 + 16;
 }
-template <int W, int R, bool K64, bool KEEP, bool EARLY>
+template <int W, int R, bool K64, bool KEEP, bool HEAVY>
 void launch_scatter_as(const GbArgs &G, int blocks, size_t lds, hipStream_t st) {
-    HIP_CHECK(hipFuncSetAttribute((const void *)gb_scatter<W, R, K64, KEEP, EARLY>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((gb_scatter<W, R, K64, KEEP, EARLY>), dim3(blocks), dim3(1024), lds, st, G);
+    HIP_CHECK(hipFuncSetAttribute((const void *)gb_scatter<W, R, K64, KEEP, HEAVY>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((gb_scatter<W, R, K64, KEEP, HEAVY>), dim3(blocks), dim3(1024), lds, st, G);
 }
 template <int W, int R>
 void launch_scatter(const GbArgs &G, int blocks, hipStream_t st) {
-    const size_t lds = scatter_lds<W, R>(G.nb_log2);
+    constexpr bool CAN_PEEL = W <= 2; // (RAW records of one or two value columns; merges carry partial results, not rows)
+    const bool heavy = CAN_PEEL && G.n_heavy > 0 && !G.merge;
+    const size_t lds = scatter_lds<W, R>(G.nb_log2) + (heavy ? gb_heavy_lds(W) : 0);
     if (lds > GB_LDS_MAX) throw std::runtime_error("groupby: internal: gb_scatter staging exceeds the LDS");
     const bool k64 = G.key_dtype == VXH_I64 || G.key_dtype == VXH_U64, keep = G.keep != nullptr;
-    const bool early = W == 1 && ctx().cfg_gb_early != 0; // ("gb_early": the one-payload-word forms only)
-    if (W == 1 && early) {
-        if (k64) { if (keep) launch_scatter_as<W, R, true, true, W == 1>(G, blocks, lds, st); else launch_scatter_as<W, R, true, false, W == 1>(G, blocks, lds, st); }
-        else { if (keep) launch_scatter_as<W, R, false, true, W == 1>(G, blocks, lds, st); else launch_scatter_as<W, R, false, false, W == 1>(G, blocks, lds, st); }
+    if (heavy) {
+        if (k64) { if (keep) launch_scatter_as<W, R, true, true, CAN_PEEL>(G, blocks, lds, st); else launch_scatter_as<W, R, true, false, CAN_PEEL>(G, blocks, lds, st); }
+        else { if (keep) launch_scatter_as<W, R, false, true, CAN_PEEL>(G, blocks, lds, st); else launch_scatter_as<W, R, false, false, CAN_PEEL>(G, blocks, lds, st); }
         return;
     }
     if (k64) { if (keep) launch_scatter_as<W, R, true, true, false>(G, blocks, lds, st); else launch_scatter_as<W, R, true, false, false>(G, blocks, lds, st); }
@@ -702,7 +796,7 @@ uint64_t inverse_mod_2_64(uint64_t a) { // Newton: every step doubles the correc
 // key_bits > 0: every key lies in [key_min, key_min + 2^key_bits) (the caller measured the range): compact 12-byte records where the
 // remainder below the bucket bits fits 32 bits (GbArgs::kc_*)
 unsigned run_pipeline(GbArgs &G, int nv, bool merge, uint64_t n, uint64_t groups_hint, int cus, hipStream_t st, vxh_groupby *res, bool hint_is_a_count = false,
-                      long long key_min = 0, int key_bits = 0) {
+                      long long key_min = 0, int key_bits = 0, const long long *heavy_host = nullptr, int n_heavy = 0) {
     GbScratch &S = gb_scratch();
     const int w = merge ? 1 + 3 * nv : nv;
     // rows per thread per tile.  One payload word: 8 (128 KiB of staging, one workgroup per CU).  Measured per 1e9 rows
@@ -760,13 +854,17 @@ unsigned run_pipeline(GbArgs &G, int nv, bool merge, uint64_t n, uint64_t groups
         G.nb_log2 = nb_log2; G.slots_log2 = 0; G.lines = lines;
         const bool compact = ctx().cfg_gb_compact && w == 1 && !merge && key_bits > nb_log2 && key_bits - nb_log2 <= 32;
         G.kc_bits = compact ? key_bits : 0;
+        G.abl = (int32_t)ctx().cfg_gb_abl;
         G.kc_min = key_min;
         G.kc_a_inv = inverse_mod_2_64(GB_KC_A);
         G.kc_b_inv = inverse_mod_2_64(GB_KC_B);
         if (res) res->compact = compact ? 1 : 0;
         G.blk = (uint32_t)B; G.scatter_wgs = (uint32_t)blocks; G.pool = (uint32_t)pool;
         S.queues.need(total_blocks * B * 8 * (size_t)(1 + w));
-        const size_t small_bytes = total_blocks * 4 + pool * 4 + 64;
+        const size_t tabs_bytes = (total_blocks * 4 + pool * 4 + 64 + 15) & ~(size_t)15;
+        const bool peel = n_heavy > 0 && !merge && nv <= 2;
+        const size_t heavy_bytes = peel ? (size_t)n_heavy * 8 * (size_t)(1 + 1 + 3 * nv) : 0; // keys | accumulators
+        const size_t small_bytes = tabs_bytes + heavy_bytes;
         S.small.need(small_bytes);
         char *q = (char *)S.queues.p;
         G.qkey = (long long *)q;
@@ -778,6 +876,13 @@ unsigned run_pipeline(GbArgs &G, int nv, bool merge, uint64_t n, uint64_t groups
         G.pool_used = G.overflow + 1;              // [1]
         G.out_count = (unsigned long long *)(G.overflow + 2); // [2..3]
         HIP_CHECK(hipMemsetAsync(S.small.p, 0, small_bytes, st));
+        G.n_heavy = 0; G.heavy_keys = nullptr; G.heavy_acc = nullptr;
+        if (peel) {
+            G.n_heavy = n_heavy;
+            G.heavy_keys = (const long long *)((char *)S.small.p + tabs_bytes);
+            G.heavy_acc = (unsigned long long *)((char *)S.small.p + tabs_bytes + (size_t)n_heavy * 8);
+            HIP_CHECK(hipMemcpyAsync((void *)G.heavy_keys, heavy_host, (size_t)n_heavy * 8, hipMemcpyHostToDevice, st)); // (the caller's array outlives the call's stream wait)
+        }
         HIP_CHECK(hipEventRecord(e0, st));
         if (w == 1 && scatter_lds<1, 8>(nb_log2) <= GB_LDS_MAX) launch_scatter<1, 8>(G, blocks, st);
         else if (w == 1) launch_scatter<1, 4>(G, blocks, st); // (1024 buckets: their tables leave room for 4096-row tiles)
@@ -789,6 +894,10 @@ unsigned run_pipeline(GbArgs &G, int nv, bool merge, uint64_t n, uint64_t groups
         if (nv == 1) { if (merge) launch_reduce<1, true>(G, st); else launch_reduce<1, false>(G, st); }
         else { if (merge) launch_reduce<2, true>(G, st); else launch_reduce<2, false>(G, st); }
         HIP_CHECK(hipGetLastError());
+        if (peel) { // the heavy keys' accumulators become groups like any other
+            hipLaunchKernelGGL(gb_append_heavy, dim3(1), dim3(GB_HEAVY_MAX), 0, st, G);
+            HIP_CHECK(hipGetLastError());
+        }
         HIP_CHECK(hipEventRecord(e2, st));
         unsigned int flags[4] = {0, 0, 0, 0};
         HIP_CHECK(hipMemcpyAsync(flags, G.overflow, 16, hipMemcpyDeviceToHost, st));
@@ -839,7 +948,19 @@ int vxh_groupby_run_kept(int key_dtype, const void *keys, int n_values, const vo
 
 int vxh_groupby_run_ranged(int key_dtype, const void *keys, int n_values, const void *const *values, const uint8_t *keep, uint64_t n, int mem, uint64_t groups_hint, uint64_t max_groups,
                            int64_t key_min, int64_t key_max, vxh_groupby **out) {
+    return vxh_groupby_run_peeled(key_dtype, keys, n_values, values, keep, n, mem, groups_hint, max_groups, key_min, key_max, nullptr, 0, out);
+}
+
+int vxh_groupby_run_peeled(int key_dtype, const void *keys, int n_values, const void *const *values, const uint8_t *keep, uint64_t n, int mem, uint64_t groups_hint, uint64_t max_groups,
+                           int64_t key_min, int64_t key_max, const int64_t *heavy_keys, int n_heavy, vxh_groupby **out) {
     GB_BEGIN
+    // the heavy keys as the pass wants them: distinct, none the table's EMPTY marker, at most GB_HEAVY_MAX (more: the first ones — a
+    // heavy key that is not peeled only costs time)
+    std::vector<long long> heavy;
+    for (int i = 0; i < n_heavy && heavy.size() < GB_HEAVY_MAX; i++) {
+        const long long k = (long long)heavy_keys[i];
+        if (k != GB_EMPTY && std::find(heavy.begin(), heavy.end(), k) == heavy.end()) heavy.push_back(k);
+    }
     int key_bits = 0; // bits of key_max - key_min (0: range unknown)
     if (key_min <= key_max) {
         const uint64_t span = (uint64_t)key_max - (uint64_t)key_min;
@@ -884,13 +1005,14 @@ int vxh_groupby_run_ranged(int key_dtype, const void *keys, int n_values, const 
         }
     }
     if (max_groups == 0) max_groups = std::min<uint64_t>(n, 1ull << 26);
-    const uint64_t out_cap = std::min<uint64_t>(n, max_groups) + 1;
+    const uint64_t out_cap = std::min<uint64_t>(n, max_groups) + 1 + heavy.size();
     const int wout = 1 + 3 * n_values;
     S.out.need(out_cap * 8 * (size_t)(1 + wout));
     G.out_cap = out_cap;
     G.out_key = (long long *)S.out.p;
     for (int k = 0; k < wout; k++) G.out_w[k] = (uint64_t *)((char *)S.out.p + out_cap * 8 * (size_t)(1 + k));
-    const unsigned code = run_pipeline(G, n_values, false, n, groups_hint ? groups_hint : (1u << 20), (int)cus, slot.stream, res.get(), groups_hint != 0, (long long)key_min, key_bits);
+    const unsigned code = run_pipeline(G, n_values, false, n, groups_hint ? groups_hint : (1u << 20), (int)cus, slot.stream, res.get(), groups_hint != 0, (long long)key_min, key_bits, heavy.data(), (int)heavy.size());
+    res->heavy = (int)heavy.size();
     if (code == 3) throw std::runtime_error("groupby: more groups than max_groups");
     if (code == 8 || code == 9) throw std::runtime_error("groupby: too many distinct keys for the LDS-partitioned path");
     if (code != 0) throw std::runtime_error("groupby: the key distribution is too skewed for the partitioned path");
@@ -997,6 +1119,7 @@ int vxh_groupby_info(const vxh_groupby *g, int what, double *value_out) {
     case 4: *value_out = g->ms_reduce; break;
     case 5: *value_out = g->ms_sort; break;
     case 6: *value_out = g->compact; break;
+    case 7: *value_out = g->heavy; break;
     default: throw std::runtime_error("groupby info: unknown item");
     }
     GB_END

@@ -1878,7 +1878,7 @@ __global__ void __launch_bounds__(1024) part_scatter_wv(const PartArgs P) {
         u32x4 b[NDIM][2];
         u32x4 v[2]; // (dead registers when NVAL == 0)
         u32x4 p[2]; // the selection's column (dead unless MASKED == 2)
-        uint32_t m; // mask bytes of rows 0,1 (low half) and 2,3 (high half)
+        uint32_t m[4]; // mask bytes of rows 0..3, each as its byte load returned it (packing them at the request made the wave wait for the NEWEST tile's loads every trip — vmcnt(0) at the bottom of the loop in round 4's ISA)
         uint32_t rows; // rows the tile really has (wave-uniform)
     };
     const double *colv = NVAL ? (const double *)P.vdata[0] : nullptr;
@@ -1921,11 +1921,10 @@ __global__ void __launch_bounds__(1024) part_scatter_wv(const PartArgs P) {
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(colm + r0), 0, (int)rows_here, 0x00020000);
             // (byte loads: a 2-byte load that straddles the end of the buffer reads as zero as a whole, which would drop
             //  the last row of an odd-length tile; the 16-byte column loads are range-checked dword by dword)
-            const uint32_t m0 = __builtin_amdgcn_raw_buffer_load_b8(rs, (int)(lane * 2u), 0, 2);
-            const uint32_t m1 = __builtin_amdgcn_raw_buffer_load_b8(rs, (int)(lane * 2u), 1, 2);
-            const uint32_t m2 = __builtin_amdgcn_raw_buffer_load_b8(rs, (int)(lane * 2u), 128, 2);
-            const uint32_t m3 = __builtin_amdgcn_raw_buffer_load_b8(rs, (int)(lane * 2u), 129, 2);
-            raw.m = (m0 & 0xffu) | ((m1 & 0xffu) << 8) | ((m2 & 0xffu) << 16) | (m3 << 24);
+            raw.m[0] = __builtin_amdgcn_raw_buffer_load_b8(rs, (int)(lane * 2u), 0, 2);
+            raw.m[1] = __builtin_amdgcn_raw_buffer_load_b8(rs, (int)(lane * 2u), 1, 2);
+            raw.m[2] = __builtin_amdgcn_raw_buffer_load_b8(rs, (int)(lane * 2u), 128, 2);
+            raw.m[3] = __builtin_amdgcn_raw_buffer_load_b8(rs, (int)(lane * 2u), 129, 2);
         }
     };
     // row r of the lane: bits of column value (d or the value column)
@@ -2034,7 +2033,7 @@ __global__ void __launch_bounds__(1024) part_scatter_wv(const PartArgs P) {
         if (MASKED == 1) { // aggregator mask: 1 = keep (src/agg_count.cpp:50); every aggregator carries this mask
 #pragma unroll
             for (int r = 0; r < R; ++r)
-                if (((cur.m >> (8 * r)) & 0xffu) != 1u) keep &= ~(1u << r);
+                if ((cur.m[r] & 0xffu) != 1u) keep &= ~(1u << r);
         }
         if (MASKED == 2) { // the shared selection, evaluated here
 #pragma unroll
