@@ -50,10 +50,13 @@ print("ok test_agg_selections")
 # the same without the string aggregator: every task on the HIP classes, the selections as device predicates
 if gpu:
     before = vsel.stats["device_chunks"]
+    vg.last.clear()
 g2 = df.groupby(df.x).agg({'count': vaex.agg.count(selection='y<=3'), 'zs': vaex.agg.sum(expression=df.z, selection='y<=3'), 'zm': vaex.agg.mean(expression=df.z, selection=df.y <= 3)}).sort('x')
 assert g2['count'].tolist() == [2, 1, 2] and g2['zs'].tolist() == [2, 4, 13] and g2['zm'].tolist() == [1, 4, 6.5]
 if gpu:
-    assert vsel.stats["device_chunks"] > before, vsel.stats
+    # (round 4: aggregations with their own selection are inside the device groupby's signature — the call is answered as a whole, its
+    #  selections device predicates of the Frame behind it; before that it ran as vaex's tasks with the predicates attached per task part)
+    assert vg.last.get("path") == "device" or vsel.stats["device_chunks"] > before, (vg.last, vsel.stats)
 print("ok test_agg_selections (numeric)")
 
 # ---- agg_test.py:364-377
