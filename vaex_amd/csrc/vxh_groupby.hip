@@ -151,7 +151,8 @@ typedef gb_u32x3 gb_u32x3_a4 __attribute__((aligned(4)));
 // 8.9 ms per 1e9 rows with the HBM idle most of the time.  Now the loads of a tile are issued back to back and nothing touches what
 // they return before the next tile's turn.
 // (Tried and removed: taking the next tile's registers over between staging [C] and copy-out [D], so that the wait for its loads is
-//  not also a wait for [D]'s stores — 8.30 vs 8.33 ms per 1e9 rows; non-temporal copy-out stores: 8.28 vs 8.31.)
+//  not also a wait for [D]'s stores — 8.30 vs 8.33 ms per 1e9 rows; non-temporal copy-out stores ("gb_abl" bit 3): 8.28 vs 8.31;
+//  the rows read with non-temporal loads, so that half-written queue lines might live longer in the L2: 8.74 vs 8.19.)
 // HEAVY: G.n_heavy > 0 (RAW records only: W = value columns).
 constexpr uint32_t GB_HEAVY_MAX = 128, GB_HEAVY_SLOTS = 256;
 constexpr size_t gb_heavy_lds(int w) { return (size_t)GB_HEAVY_SLOTS * 8 + GB_HEAVY_SLOTS + (size_t)GB_HEAVY_MAX * 8 + (size_t)w * GB_HEAVY_MAX * 16 + (size_t)(w > 1 ? w - 1 : 0) * GB_HEAVY_MAX * 4 + 16; }
