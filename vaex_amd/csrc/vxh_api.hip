@@ -1864,6 +1864,7 @@ int vxh_config_set(const char *key, int64_t value) {
     else if (k == "wv_auto") { c.cfg_wv_auto = value; c.wv_auto_last = 0; if (value) { c.cfg_wv = 5; c.cfg_wv_user_set = false; } }
     else if (k == "gb_compact") c.cfg_gb_compact = value;
     else if (k == "gb_abl") c.cfg_gb_abl = value;
+    else if (k == "gb_sets") c.cfg_gb_sets = value > 0 ? value : 8;
     else if (k == "gb_known_count") c.cfg_gb_known_count = value;
     else if (k == "gb_load_pct") c.cfg_gb_load_pct = value > 0 ? value : 50;
     else if (k == "fuse_selection") c.cfg_fuse_selection = value;
@@ -1923,6 +1924,7 @@ int vxh_config_get(const char *key, int64_t *value) {
     else if (k == "wv_auto_choice") *value = get_slot(0).hot.auto_state >= 2 ? get_slot(0).hot.auto_choice : 0;
     else if (k == "gb_compact") *value = c.cfg_gb_compact;
     else if (k == "gb_abl") *value = c.cfg_gb_abl;
+    else if (k == "gb_sets") *value = c.cfg_gb_sets;
     else if (k == "gb_known_count") *value = c.cfg_gb_known_count;
     else if (k == "gb_load_pct") *value = c.cfg_gb_load_pct;
     else if (k == "fuse_selection") *value = c.cfg_fuse_selection;

@@ -10,18 +10,21 @@
 //
 //   gb_scatter   rows -> NB buckets by the TOP bits of splitmix64(key) (the reference's hash finaliser, src/hash.hpp:40-45).
 //                One 1024-thread workgroup per CU bucket-sorts 1024*R-row tiles in LDS (returning ds_add = position
-//                in bucket, workgroup scan = bucket offsets) and appends each bucket's segment to a block of the
-//                bucket's queue that only this workgroup writes to (contiguous appends: the L2 merges them into whole
-//                lines).  Blocks of `blk` records are reserved from the bucket's counter by the thread that owns the
-//                bucket (thread b <-> bucket b), normally ONE per launch; their fill goes to a table.  Records are
-//                SoA: key + W payload words (W = 1 per value column for rows; 4 for partial results being merged).
+//                in bucket, workgroup scan = bucket offsets) and appends each bucket's segment to the bucket's record STREAM of
+//                the workgroup's SET — round 4: the 32 workgroups of an XCD share one set of NB streams, a tile's segment is
+//                reserved with one returning device atomic on the stream's counter by the thread that owns the bucket
+//                (thread b <-> bucket b), so a stream grows by neighbouring segments written within a microsecond of each
+//                other (rounds 2-3: every (workgroup, bucket) pair had a private block — 131072 streams growing 192 bytes a
+//                tile, which the memory side absorbed at ~3 TB/s).  Records: 16 bytes {key, payload} or 12 {remainder,
+//                payload} with one payload word, SoA key + W words otherwise (W = 1 per value column for rows; 4 / 7 for
+//                partial results being merged).  Heavy keys named by the host are aggregated in LDS partials instead.
 //   gb_reduce    one workgroup per bucket: insert-or-get in an open-addressing table IN LDS — round 3: BUCKETISED, four keys
 //                per 32-byte line read with two ds_read_b128 and compared at once, a key lives in its home line or (when
 //                that is full) in the next ones; 64-bit ds_cmpst claims an empty word.  A probe is one trip for ~99 % of the
 //                records (round 2's one-key-per-trip linear probing kept every wave in a divergent, scalar-issue-bound
 //                loop: 1.22e9 SALU vs 0.69e9 VALU wave-instructions per 1e9 records, profiles/r02_pmc_groupby_fused.txt).
 //                Accumulators (rows, count, sum, sum of squares) sit in LDS arrays indexed by the slot (ds_add_u64 /
-//                ds_add_f64), every wave streams whole queue blocks.  At the end the occupied slots are compacted
+//                ds_add_f64), the waves walk the bucket's stream of every set in blocks of 2048 records, software-pipelined.  At the end the occupied slots are compacted
 //                (workgroup scan) into the result arrays behind ONE atomic per bucket.
 //   sort         rocPRIM radix sort of (key, position) + a gather: groups ascending by key, as vaex returns them.
 //
@@ -86,20 +89,20 @@ struct GbArgs {
     const uint64_t *payload[GB_MAX_W]; // RAW: the value columns (float64 bits); MERGE: rows, count_0, sum_0, sum2_0, ...
     const uint8_t *keep;               // RAW: one byte per row, 1 = the row takes part (a filter / selection over the whole call), or null
     uint64_t n;
-    // Queues.  A BLOCK holds up to `blk` records of ONE bucket written by ONE workgroup.  Block wg * NB + b is workgroup
-    // wg's primary block for bucket b — so everything a workgroup writes lies in one contiguous window of NB blocks
-    // (a bucket-major layout spreads a tile's 2 * NB segments over as many distant pages: the scatter pass then runs at a
-    // third of the speed, waiting on address translation) — and `pool` spare blocks behind the primaries are handed out
-    // through pool_used to (workgroup, bucket) pairs whose primary block fills up; pool_owner[] says whose they are.
+    // Queues (round 4, late): `ng` SETS of NB record streams; workgroup w appends to the streams of set w % ng — blocks are dealt to
+    // the 8 XCDs round robin, so with ng = 8 the 32 workgroups of ONE XCD share a set.  Every tile's segment of a stream is reserved
+    // with one returning device atomic on the stream's counter: neighbouring segments of a stream are written by the XCD's
+    // workgroups within a microsecond of each other, the chip has 4096 streams growing line after line instead of 131072 private
+    // ones growing 192 bytes a tile — which is what the memory side was slow at (tools/microbench8.hip: 4.8 -> 3.46 ms per 5.4e8
+    // 16-byte records; 4 or 1 sets: 4.15 / 4.47; 32 sets: 3.76).  Stream (set, b) owns records [(set NB + b) cap, ... + cap).
     int32_t nb_log2, slots_log2;
-    uint32_t blk;      // records per block
-    uint32_t scatter_wgs; // workgroups of gb_scatter (= primary blocks per bucket)
-    uint32_t pool;     // spare blocks
-    uint32_t *tab;     // [scatter_wgs * NB + pool] records each block holds
-    uint32_t *pool_used;  // spare blocks handed out
-    uint32_t *pool_owner; // [pool] bucket of a spare block
-    long long *qkey;        // [blocks][blk]
-    uint64_t *qw[GB_MAX_W]; // [blocks][blk] each
+    uint32_t ng;       // sets of streams
+    uint64_t cap;      // records per stream
+    const unsigned long long *gstart; // null: stream s owns records [s cap, (s + 1) cap); else [gstart[s], gstart[s + 1]) — the second attempt of a call
+                                      // whose first found a stream too small lays the streams out from the counts that attempt measured
+    unsigned long long *gcount; // [ng][NB] records reserved so far (may pass `cap`: the segments beyond it are dropped, flag 1, the host retries with more room)
+    long long *qkey;        // [streams][cap]
+    uint64_t *qw[GB_MAX_W]; // [streams][cap] each
     uint4 *qrec;            // W == 1: the queues hold 16-byte records {key, payload} instead (one store / one load per record)
     uint32_t lines;         // gb_reduce: 4-key lines of the LDS table (slots = 4 * lines; any count, not a power of two)
     // Compact records (round 4; W == 1, counting rows, the key RANGE known): key - kc_min is a kc_bits-bit number; an invertible
@@ -165,10 +168,8 @@ __global__ void __launch_bounds__(1024) gb_scatter(const GbArgs G) {
     uint64_t *const st_w = st_key + T; // [W][T]
     uint32_t *const cnt = (uint32_t *)(st_w + (size_t)W * T);
     uint32_t *const off = cnt + NB;
-    uint32_t *const base0 = off + NB;
-    uint32_t *const base1 = base0 + NB;
-    uint32_t *const split = base1 + NB;
-    uint32_t *const s_wave = split + NB; // [16]
+    unsigned long long *const gbase = (unsigned long long *)(off + NB); // [NB] first record of this tile's segment of stream b (8-byte aligned: NB is even)
+    uint32_t *const s_wave = (uint32_t *)(gbase + NB) + NB; // [16] (behind one spare word per bucket: the layout's size is scatter_lds')
     uint16_t *const st_b = (uint16_t *)(s_wave + 16);
     // HEAVY: the heavy keys' table (open addressing, <= half full) and this workgroup's partials, behind the staging area
     unsigned long long *const hk_key = (unsigned long long *)(((uintptr_t)(st_b + T) + 15) & ~(uintptr_t)15); // [GB_HEAVY_SLOTS]
@@ -196,11 +197,14 @@ __global__ void __launch_bounds__(1024) gb_scatter(const GbArgs G) {
             }
         }
     }
-    // thread b: the block bucket b's records of this workgroup go to, and how full it is
-    const uint32_t B = G.blk;
-    const uint32_t primaries = G.scatter_wgs * NB;
-    uint32_t block = blockIdx.x * NB + tid, fill = 0;
-    bool dead = false; // no spare block left for this bucket: records are dropped and the overflow flag raised (the host retries with more room)
+    const uint32_t set = blockIdx.x % G.ng; // this workgroup's set of streams
+    // thread b: where stream (set, b) starts and how many records it has room for
+    unsigned long long s_first = 0ull, s_room = 0ull;
+    if (tid < NB) {
+        const size_t sid = (size_t)set * NB + tid;
+        s_first = G.gstart ? G.gstart[sid] : (unsigned long long)sid * G.cap;
+        s_room = G.gstart ? G.gstart[sid + 1] - s_first : G.cap;
+    }
     __syncthreads();
 
     // the next tile's rows are requested while the current one is staged and copied out (two register sets; the copy
@@ -322,28 +326,13 @@ __global__ void __launch_bounds__(1024) gb_scatter(const GbArgs G) {
         if (tid < NB) {
             c = cnt[tid];
             cnt[tid] = 0u;
-            uint32_t a0 = block * B + fill, a1 = 0xffffffffu, sp = c;
-            if (dead) {
-                a0 = 0xffffffffu;
-            } else if (c <= B - fill) {
-                fill += c;
-            } else { // the block fills up: the rest goes to a spare block (a tile never brings more than two blocks' worth: B >= the tile — else: retry)
-                sp = B - fill;
-                G.tab[block] = B;
-                const uint32_t spare = atomicAdd(G.pool_used, 1u);
-                if (spare >= G.pool || c - sp > B) {
-                    atomicExch(G.overflow, 1u);
-                    dead = true;
-                } else {
-                    G.pool_owner[spare] = tid;
-                    block = primaries + spare;
-                    fill = c - sp;
-                    a1 = block * B;
-                }
-            }
-            base0[tid] = a0;
-            base1[tid] = a1;
-            split[tid] = sp;
+            // this tile's segment of stream (set, b): ONE returning device atomic (a stream that passes its capacity drops the segment
+            // and raises the flag: the host retries with more room)
+            unsigned long long at = 0ull;
+            if (c) at = atomicAdd(&G.gcount[(size_t)set * NB + tid], (unsigned long long)c);
+            const bool fits = at + c <= s_room;
+            if (c && !fits) atomicExch(G.overflow, 1u);
+            gbase[tid] = fits ? s_first + at : ~0ull;
         }
         uint32_t inc = c;
 #pragma unroll
@@ -376,11 +365,9 @@ __global__ void __launch_bounds__(1024) gb_scatter(const GbArgs G) {
         // [D] copy out: consecutive threads -> consecutive records of a bucket's segment
         for (uint32_t j = tid; j < ((G.abl & 6) ? 0u : total); j += 1024u) {
             const uint32_t b = st_b[j];
-            const uint32_t k = j - off[b];
-            const uint32_t sp = split[b];
-            const uint32_t base = k < sp ? base0[b] : base1[b];
-            if (base == 0xffffffffu) continue; // (queue full: flagged, the host retries with more room)
-            uint64_t dst = (uint64_t)base + (k < sp ? k : k - sp);
+            const unsigned long long base = gbase[b];
+            if (base == ~0ull) continue; // (stream full: flagged, the host retries with more room)
+            uint64_t dst = base + (j - off[b]);
             if (G.abl & 1) { if (st_key[j] != 0x123456789abcdefull) continue; dst = 0; } // (the staged words are read, nothing is stored)
             if (W == 1 && G.kc_bits) { // 12-byte record {remainder, payload}
                 const uint64_t c2 = st_w[j];
@@ -399,7 +386,6 @@ __global__ void __launch_bounds__(1024) gb_scatter(const GbArgs G) {
         // (the next tile's [C] comes after two more barriers: nobody overwrites what [D] still reads)
         if (has_next) take_over();
     }
-    if (tid < NB && !dead) G.tab[block] = fill;
     if (HEAVY) { // this workgroup's partials into the call's accumulators (a few hundred device atomics per workgroup)
         __syncthreads();
         if (tid < (uint32_t)G.n_heavy) {
@@ -458,6 +444,9 @@ __global__ void __launch_bounds__(1024) gb_reduce(const GbArgs G) {
     const uint32_t tid = threadIdx.x, lane = tid & 63u, nwave = blockDim.x >> 6;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6)); // (scalar: the block iterator's table loads are s_loads)
     const uint32_t bucket = blockIdx.x;
+    // a stream passed its room in gb_scatter (segments were dropped, the counters point at records nobody wrote): nothing to reduce —
+    // the host lays the streams out from the counters and runs the pass again
+    if (__hip_atomic_load(G.overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1u) return;
     for (uint32_t s = tid; s < EP; s += blockDim.x) {
         t_key[s] = (unsigned long long)GB_EMPTY;
         if (MERGE) t_rows[s] = (CT)0; else t_rc[s] = 0ull;
@@ -532,29 +521,31 @@ __global__ void __launch_bounds__(1024) gb_reduce(const GbArgs G) {
     // wave's loads are in flight under its own LDS work (before: load, wait, work — 12-16 GB read at 2.3-3 TB/s with the LDS idle
     // during the waits).
     const uint32_t NB = 1u << G.nb_log2;
-    const uint32_t used = min(*G.pool_used, G.pool);
-    uint32_t it_g = wave, it_phase = 0; // iterator over the wave's blocks (wave-uniform)
+    // the bucket's records: its stream of every set, walked in blocks of RB records dealt to the waves round robin (wave w: block w,
+    // w + waves, ... of the concatenated streams)
+    constexpr uint32_t RB_LOG2 = 11, RB = 1u << RB_LOG2;
+    uint32_t it_s = 0;      // (wave-uniform) stream = set the iterator is in
+    uint64_t it_k = wave;   // ... and the wave's next block, counted from the start of that stream
     uint64_t cur_lo = 0;
     uint32_t cur_fill = 0;
     auto next_block = [&]() -> bool {
         for (;;) {
-            uint32_t blk_id;
-            if (it_phase == 0) {
-                if (it_g >= G.scatter_wgs) { it_phase = 1; it_g = wave; continue; }
-                blk_id = it_g * NB + bucket;
-                it_g += nwave;
-            } else {
-                if (it_g >= used) return false;
-                const uint32_t sp = it_g;
-                it_g += nwave;
-                if (G.pool_owner[sp] != bucket) continue;
-                blk_id = G.scatter_wgs * NB + sp;
+            if (it_s >= G.ng) return false;
+            const size_t sid = (size_t)it_s * NB + bucket;
+            const unsigned long long reserved = G.gcount[sid];
+            const unsigned long long s_first = G.gstart ? G.gstart[sid] : (unsigned long long)sid * G.cap;
+            const unsigned long long s_room = G.gstart ? G.gstart[sid + 1] - s_first : G.cap;
+            const uint64_t fill = reserved < s_room ? reserved : s_room;
+            const uint64_t nblk = (fill + RB - 1) >> RB_LOG2;
+            if (it_k < nblk) {
+                const uint64_t first = it_k << RB_LOG2;
+                cur_lo = s_first + first;
+                cur_fill = (uint32_t)(fill - first < RB ? fill - first : RB);
+                it_k += nwave;
+                return true;
             }
-            const uint32_t fill = G.tab[blk_id];
-            if (!fill) continue;
-            cur_lo = (uint64_t)blk_id * G.blk;
-            cur_fill = fill;
-            return true;
+            it_k -= nblk; // (the wave's stride carries over into the next stream)
+            ++it_s;
         }
     };
     struct Trip { // what a trip's loads return, untouched: any arithmetic on it here would make the wave wait for the loads at once
@@ -839,18 +830,17 @@ unsigned run_pipeline(GbArgs &G, int nv, bool merge, uint64_t n, uint64_t groups
     hipEvent_t e0 = ev.e[0], e1 = ev.e[1], e2 = ev.e[2];
     unsigned code = 0;
     uint64_t slack = 1;
+    std::vector<unsigned long long> exact; // stream starts measured by a first attempt that found a stream too small (then: one exact second attempt)
     for (int attempt = 0; attempt < 6; ++attempt) {
         const uint64_t NB = (uint64_t)1 << nb_log2;
         const int blocks = (int)std::max<uint64_t>(1, std::min<uint64_t>((n + T - 1) / T, (uint64_t)cus * per_cu));
-        // a (workgroup, bucket) block: the pair's expected share of the rows + 1/4, at least a few tiles' worth of one
-        // bucket; spare blocks for a quarter of the pairs (skew), more on retry
-        uint64_t B = (uint64_t)((double)n / (double)((uint64_t)blocks * NB) * 1.25) + 4 * (T / NB + 1) + 64;
-        B = ((B + 3) & ~(uint64_t)3) * slack;
-        B = std::min<uint64_t>(B, ((n + 3) & ~(uint64_t)3) + 64); // (a block never needs more room than every row)
-        const uint64_t primaries = (uint64_t)blocks * NB;
-        const uint64_t pool = std::max<uint64_t>(64, primaries / 4);
-        const uint64_t total_blocks = primaries + pool;
-        if (total_blocks * B >= (1ull << 32) || total_blocks * B * 8 * (uint64_t)(1 + w) > (96ull << 30)) { code = 9; break; }
+        // sets of streams: one per XCD ("gb_sets", 8: blockIdx % 8 is the XCD a workgroup lands on), fewer when the launch has fewer
+        // workgroups.  A stream's room: its expected share of the rows + 1/4 + a few tiles' worth; four times as much on retry
+        const uint64_t NG = std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)std::max<int64_t>(1, ctx().cfg_gb_sets), (uint64_t)blocks));
+        uint64_t cap = (uint64_t)((double)n / (double)(NG * NB) * 1.25) + 8 * (T / NB + 1) + 1024;
+        cap = std::min<uint64_t>(((cap + 3) & ~(uint64_t)3) * slack, ((n + 3) & ~(uint64_t)3) + 64); // (a stream never needs more room than every row)
+        const uint64_t total_records = exact.empty() ? NG * NB * cap : (uint64_t)exact.back();
+        if (total_records * 8 * (uint64_t)(1 + w) > (96ull << 30)) { code = 9; break; }
         G.nv = nv; G.w = w; G.merge = merge ? 1 : 0; G.n = n;
         G.nb_log2 = nb_log2; G.slots_log2 = 0; G.lines = lines;
         const bool compact = ctx().cfg_gb_compact && w == 1 && !merge && key_bits > nb_log2 && key_bits - nb_log2 <= 32;
@@ -860,23 +850,27 @@ unsigned run_pipeline(GbArgs &G, int nv, bool merge, uint64_t n, uint64_t groups
         G.kc_a_inv = inverse_mod_2_64(GB_KC_A);
         G.kc_b_inv = inverse_mod_2_64(GB_KC_B);
         if (res) res->compact = compact ? 1 : 0;
-        G.blk = (uint32_t)B; G.scatter_wgs = (uint32_t)blocks; G.pool = (uint32_t)pool;
-        S.queues.need(total_blocks * B * 8 * (size_t)(1 + w));
-        const size_t tabs_bytes = (total_blocks * 4 + pool * 4 + 64 + 15) & ~(size_t)15;
+        G.ng = (uint32_t)NG; G.cap = cap;
+        S.queues.need(total_records * 8 * (size_t)(1 + w));
+        const size_t starts_bytes = (NG * NB + 1) * 8;
+        const size_t tabs_bytes = (NG * NB * 8 + 64 + starts_bytes + 15) & ~(size_t)15; // stream counters | flags | stream starts (exact layout)
         const bool peel = n_heavy > 0 && !merge && nv <= 2;
         const size_t heavy_bytes = peel ? (size_t)n_heavy * 8 * (size_t)(1 + 1 + 3 * nv) : 0; // keys | accumulators
         const size_t small_bytes = tabs_bytes + heavy_bytes;
         S.small.need(small_bytes);
         char *q = (char *)S.queues.p;
         G.qkey = (long long *)q;
-        G.qrec = (uint4 *)q; // (w == 1: 16-byte records in the same space)
-        for (int k = 0; k < w; k++) G.qw[k] = (uint64_t *)(q + total_blocks * B * 8 * (size_t)(1 + k));
-        G.tab = (uint32_t *)S.small.p;
-        G.pool_owner = G.tab + total_blocks;
-        G.overflow = G.pool_owner + pool;          // [0] code
-        G.pool_used = G.overflow + 1;              // [1]
+        G.qrec = (uint4 *)q; // (w == 1: 16-byte / 12-byte records in the same space)
+        for (int k = 0; k < w; k++) G.qw[k] = (uint64_t *)(q + total_records * 8 * (size_t)(1 + k));
+        G.gcount = (unsigned long long *)S.small.p;
+        G.overflow = (unsigned int *)(G.gcount + NG * NB); // [0] code
         G.out_count = (unsigned long long *)(G.overflow + 2); // [2..3]
         HIP_CHECK(hipMemsetAsync(S.small.p, 0, small_bytes, st));
+        G.gstart = nullptr;
+        if (!exact.empty()) {
+            G.gstart = (const unsigned long long *)((char *)S.small.p + NG * NB * 8 + 64);
+            HIP_CHECK(hipMemcpyAsync((void *)G.gstart, exact.data(), exact.size() * 8, hipMemcpyHostToDevice, st));
+        }
         G.n_heavy = 0; G.heavy_keys = nullptr; G.heavy_acc = nullptr;
         if (peel) {
             G.n_heavy = n_heavy;
@@ -918,10 +912,20 @@ unsigned run_pipeline(GbArgs &G, int nv, bool merge, uint64_t n, uint64_t groups
         if (code == 2) { // a bucket holds too many distinct keys: more buckets
             if (nb_log2 >= 10) { code = 8; break; }
             nb_log2 = std::min(10, nb_log2 + 2);
+            exact.clear(); // (measured for the old bucket count)
         } else if (code == 3) { // result arrays too small (the caller sized them from a hint): report
             break;
         }
-        if (code == 1) slack *= 8; // out of spare blocks (few or skewed keys): eight times the room per block, as long as the scratch stays below 96 GiB
+        if (code == 1) {
+            // a stream passed its room (few or skewed keys).  The counters kept counting: they hold every stream's exact length, and
+            // the second attempt deals the same tiles to the same workgroups — lay the streams out from them (4-record aligned)
+            if (!exact.empty()) { code = 7; break; } // (cannot happen: the layout is exact)
+            std::vector<unsigned long long> counts(NG * NB);
+            HIP_CHECK(hipMemcpy(counts.data(), G.gcount, counts.size() * 8, hipMemcpyDeviceToHost));
+            exact.assign(counts.size() + 1, 0ull);
+            for (size_t i = 0; i < counts.size(); i++) exact[i + 1] = exact[i] + ((counts[i] + 3) & ~3ull);
+            (void)slack;
+        }
     }
     return code;
 }
