@@ -847,6 +847,11 @@ static LaunchPlan make_plan(const BinArgs &A, BinArgs &out, uint64_t n, double b
         p.block = c.cfg_block > 0 ? (int)c.cfg_block : 1024;
         per_cu = std::max(1, std::min(per_cu, 2048 / p.block));
         int parts = std::max(1, (int)((uint64_t)c.cus * per_cu / S));
+        // 128 slabs and more (a groupby's key range): at least 8 sub-queues per slab — workgroup w appends to sub-queue w % parts, blocks are
+        // dealt to the 8 XCDs round robin, so with 8 the 32 workgroups of ONE XCD share a sub-queue and a slab's stream grows by
+        // neighbouring tile segments; with the 2 that 256 CUs / 128 slabs gives, 128 workgroups of 4 XCDs do (1e6-key dense groupby,
+        // same box: 10.39 -> 10.00 ms per 1e9 rows with 8, 10.15 with 4, 10.2 with 16; tools/microbench8.hip has the same optimum)
+        if (S >= 128) parts = std::max(parts, 8); // (64 slabs — 3-D 128^3 — are better off with their 4: 5.43 vs 5.55 ms)
         if (c.cfg_parts > 0) parts = (int)c.cfg_parts;
         out.slab_log2 = part_log2;
         out.ngroups = parts; // pass-2 workgroups per slab
@@ -1440,6 +1445,10 @@ static void run_part_chunk(Slot &slot, const BinArgs &planned, const LaunchPlan 
         GB = (GB + 15) & ~(uint64_t)15; // (a block's group headers leave in whole 128-byte lines of 16)
         const uint64_t waves_per_region = ((uint64_t)wv_blocks + P.parts - 1) / P.parts * wg.waves;
         uint64_t capG = GB * (waves_per_region + std::max<uint64_t>(8, waves_per_region / 4));
+        if (c.cfg_wv_block > 0) { // (small blocks: a wave takes many of them — room for the region's expected groups + 1/4, and a partly filled block per wave)
+            const uint64_t need = (uint64_t)(expect * (double)waves_per_region * 1.25) + GB * (waves_per_region + 8);
+            capG = std::max(capG, (need + GB - 1) / GB * GB);
+        }
         if (c.cfg_part_cap > 0) capG = std::max<uint64_t>(1, ((uint64_t)c.cfg_part_cap / VXH_WV_GROUP + GB - 1) / GB) * GB; // (tests: a region that overflows)
         P.qblk = (int32_t)GB;
         P.cap = capG * VXH_WV_GROUP;
