@@ -426,6 +426,11 @@ __global__ void gb_append_heavy(const GbArgs G) {
 // LDS table of one bucket: `lines` lines of four keys (SLOTS = 4 * lines) + one entry for the key INT64_MIN, which doubles as EMPTY
 // KC: the queues hold compact 12-byte records (GbArgs::kc_bits != 0) — a compile-time switch: as a run-time branch around every
 // record load it made the compiler wait for each load on its own (vmcnt(0) behind every global_load: 4.0 -> 5.2 ms per 1e9 records)
+// (records per lane per trip with one payload word: 8 instead of 4 — twice the loads in flight — changes nothing, 4.03 vs 4.03 ms per 1e9
+//  records in two libraries on one box: after the software pipeline the kernel is bound by its LDS work, ~2 ms of atomics + probes per CU)
+#ifndef GB_REDUCE_U
+#define GB_REDUCE_U 4
+#endif
 template <int NV, bool MERGE, bool KC = false>
 __global__ void __launch_bounds__(1024) gb_reduce(const GbArgs G) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -462,7 +467,7 @@ __global__ void __launch_bounds__(1024) gb_reduce(const GbArgs G) {
 
     const uint32_t limit = SLOTS - SLOTS / 5; // more distinct keys than this in one bucket (80 % of the slots): the overflow chains get long (a wave pays for the longest of its 64) — flag and let the host retry with more buckets
     constexpr int PW = MERGE ? 1 + 3 * NV : NV;
-    constexpr int U = PW >= 7 ? 1 : (PW >= 4 ? 2 : 4); // records per lane per trip (their loads run interleaved), two trips in registers: <= 128 VGPRs at 16 waves
+    constexpr int U = PW >= 7 ? 1 : (PW >= 4 ? 2 : (PW == 1 ? GB_REDUCE_U : 4)); // records per lane per trip (their loads run interleaved), two trips in registers: <= 128 VGPRs at 16 waves
     bool failed = false;
     auto accumulate = [&](uint32_t s, const uint64_t (&p)[PW]) {
         if (MERGE) {
