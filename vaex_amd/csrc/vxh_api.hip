@@ -1495,7 +1495,11 @@ static void run_part_chunk(Slot &slot, const BinArgs &planned, const LaunchPlan 
             P.epoch = slot.epoch;
         }
     }
-    const bool rec12 = wv && (wg.direct == 1 || wg.direct == 2) && P.nvals == 1;
+    // 12-byte records {value, local index}: the ring-less pass 1 next to a box (one store per cold row), and — round 4, "f64_rec12" —
+    // the staged pass 1 of calls with >= 128 slabs and one value column (a groupby's key range): ONE record stream per sub-queue
+    // instead of a value stream and an index stream, i.e. half as many streams growing (what the memory side is sensitive to)
+    const bool rec12_f64 = c.cfg_f64_rec12 && !(c.cfg_no_pipeline & 17) && !wv && S >= 128 && !slot.hot.on && c.cfg_blk != 2 && P.nvals == 1 && !P.use_flags && P.idx16 && vxh_part_reduce_is_fast(P, plan);
+    const bool rec12 = (wv && (wg.direct == 1 || wg.direct == 2) && P.nvals == 1) || rec12_f64;
     P.qrec12 = rec12 ? 1 : 0;
     const size_t idx_bytes = rec12 ? 12 : (P.idx16 ? 2 : 4);
     size_t off = 0;
@@ -1873,6 +1877,7 @@ int vxh_config_set(const char *key, int64_t value) {
     else if (k == "wv_auto") { c.cfg_wv_auto = value; c.wv_auto_last = 0; if (value) { c.cfg_wv = 5; c.cfg_wv_user_set = false; } }
     else if (k == "gb_compact") c.cfg_gb_compact = value;
     else if (k == "gb_abl") c.cfg_gb_abl = value;
+    else if (k == "f64_rec12") c.cfg_f64_rec12 = value;
     else if (k == "gb_sets") c.cfg_gb_sets = value > 0 ? value : 8;
     else if (k == "gb_known_count") c.cfg_gb_known_count = value;
     else if (k == "gb_load_pct") c.cfg_gb_load_pct = value > 0 ? value : 50;
@@ -1933,6 +1938,7 @@ int vxh_config_get(const char *key, int64_t *value) {
     else if (k == "wv_auto_choice") *value = get_slot(0).hot.auto_state >= 2 ? get_slot(0).hot.auto_choice : 0;
     else if (k == "gb_compact") *value = c.cfg_gb_compact;
     else if (k == "gb_abl") *value = c.cfg_gb_abl;
+    else if (k == "f64_rec12") *value = c.cfg_f64_rec12;
     else if (k == "gb_sets") *value = c.cfg_gb_sets;
     else if (k == "gb_known_count") *value = c.cfg_gb_known_count;
     else if (k == "gb_load_pct") *value = c.cfg_gb_load_pct;

@@ -235,6 +235,7 @@ struct Context {
     int64_t cfg_fuse_selection = 1; // a selection shared by every aggregator of a call, over one float64 column, is evaluated inside the binning kernels (0: always through sel_eval's byte mask)
     int64_t cfg_gb_compact = 1;    // fused hash groupby: 12-byte records when the measured key range allows (vxh_groupby_run_ranged)
     int64_t cfg_gb_known_count = 0; // fused hash groupby: a remembered group count sizes the buckets at mean + 4 sigma under the table limit (measured: a loss — see run_pipeline)
+    int64_t cfg_f64_rec12 = 0;     // staged pass 1 with >= 128 slabs: 12-byte AoS queue records instead of a value stream + an index stream
     int64_t cfg_gb_sets = 8;       // fused hash groupby: sets of record streams shared by the workgroups w % sets (8: one per XCD)
     int64_t cfg_gb_abl = 0;        // fused hash groupby, timing experiments only (GbArgs::abl)
     int64_t cfg_gb_load_pct = 50;  // fused hash groupby: target load of a bucket's LDS table when the bucket count is chosen

@@ -844,6 +844,8 @@ __device__ __forceinline__ void records_apply(const PartArgs &P, char *lds, cons
 // reservation results are parked in LDS; bucket counters re-zeroed for the next tile | sync | [E] copy the
 // staging area out to the queues, consecutive lanes -> consecutive queue slots (coalesced).  Three barriers per
 // tile; nothing a later phase of the NEXT tile writes is still being read (see the hazard notes in DESIGN.md).
+typedef unsigned int u32x3 __attribute__((ext_vector_type(3)));
+typedef u32x3 u32x3_a4 __attribute__((aligned(4))); // (a 12-byte queue record: 4-byte aligned)
 struct ScatterLds {
     uint32_t *s_cnt;              // [S]   records of this tile per slab
     uint32_t *s_off;              // [S+1] exclusive prefix of s_cnt
@@ -926,6 +928,11 @@ __device__ __forceinline__ void scatter_copy_out(const PartArgs &P, const Scatte
         const unsigned long long gb = L.s_gbase[s];
         if (gb != VXH_Q_OVERFLOW) {
             const uint64_t dst = gb + j;
+            if (P.qrec12) { // one 12-byte record {value, local index} (one value column, no flags): ONE stream per sub-queue instead of two
+                const uint64_t bits = L.st_val[j];
+                *(u32x3_a4 *)((uint32_t *)P.qidx + dst * 3) = u32x3_a4{(uint32_t)bits, (uint32_t)(bits >> 32), L.st_idx[j]};
+                continue;
+            }
             if (P.idx16) ((uint16_t *)P.qidx)[dst] = (uint16_t)L.st_idx[j];
             else ((uint32_t *)P.qidx)[dst] = L.st_idx[j];
             if (P.use_flags) P.qflags[dst] = L.st_flags[j];
@@ -1643,9 +1650,7 @@ __global__ void __launch_bounds__(VXH_HOT_BLOCK) part_scatter_blk(const PartArgs
 //   * HOT (two binners, no mask): as in part_scatter_blk — the workgroup's LDS copy of the box takes what the rings
 //     leave of the 160 KiB; the only two barriers of the kernel are the ones around the box's lifetime.
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned int u32x3 __attribute__((ext_vector_type(3)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-typedef u32x3 u32x3_a4 __attribute__((aligned(4)));
 constexpr uint32_t VXH_WV_NONE = 0xffffffffu;
 
 // slow path of part_scatter_wv (sub-queue full: pathologically skewed data): ONE record straight into the grids with
@@ -3270,8 +3275,8 @@ void vxh_launch_part_scatter(const PartArgs &args, const LaunchPlan &plan, int s
 #undef VXH_SC
 }
 
-void vxh_launch_part_reduce(const PartArgs &args, const LaunchPlan &plan, hipStream_t stream) {
-    // specialised kernel: count / sum / sum-moment over float64 inputs, no record flags, uint16 indices
+// does pass 2 of this call take the specialised kernel (count / sum / sum-moment over float64 or int64 inputs, no record flags, uint16 indices)?
+bool vxh_part_reduce_is_fast(const PartArgs &args, const LaunchPlan &plan) {
     bool fast = (plan.fast_vals || args.f32 || args.val_i64 || args.val_ct) && !args.use_flags && args.idx16 && args.nvals <= 2 && args.A.nagg >= 1 && args.A.nagg <= 4 && !(args.no_pipeline & 16) && !args.A.count16;
     for (int k = 0; fast && k < args.A.nagg; ++k) {
         const AggDesc &a = args.A.a[k];
@@ -3280,6 +3285,11 @@ void vxh_launch_part_reduce(const PartArgs &args, const LaunchPlan &plan, hipStr
         if (args.val_i64 ? (a.kind != VXH_AGG_SUM || a.cell != VXH_CELL_I64 || args.agg_vslot[k] == 0xff)
                          : ((a.kind != VXH_AGG_SUM && a.kind != VXH_AGG_SUM_MOMENT) || a.cell != VXH_CELL_F64 || args.agg_vslot[k] == 0xff)) fast = false;
     }
+    return fast;
+}
+
+void vxh_launch_part_reduce(const PartArgs &args, const LaunchPlan &plan, hipStream_t stream) {
+    const bool fast = vxh_part_reduce_is_fast(args, plan);
 #define VXH_RD(KERNEL)                                                                                                 \
     do {                                                                                                               \
         if (plan.lds_bytes > 48 * 1024) (void)hipFuncSetAttribute((const void *)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds_bytes); \

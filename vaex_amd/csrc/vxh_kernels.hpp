@@ -302,6 +302,7 @@ void vxh_launch_product_f64(const double *a, const double *b, double *out, uint6
 
 void vxh_launch_part_scatter(const PartArgs &args, const LaunchPlan &plan, int scatter_blocks, size_t scatter_lds, hipStream_t stream);
 void vxh_launch_part_reduce(const PartArgs &args, const LaunchPlan &plan, hipStream_t stream);
+bool vxh_part_reduce_is_fast(const PartArgs &args, const LaunchPlan &plan);
 void vxh_launch_bin(const BinArgs &args, const LaunchPlan &plan, hipStream_t stream);
 void vxh_launch_part_merge(const PartMergeArgs &args, hipStream_t stream);
 void vxh_launch_hot_merge(const HotMergeArgs &args, hipStream_t stream);
