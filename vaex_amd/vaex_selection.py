@@ -74,9 +74,23 @@ def named_expression(df, name):
     return _selection_as_expression(df.get_selection(name))
 
 
+_known_cache = {}   # id(df.columns dict) -> (fingerprint, names); one entry per live frame, a handful of frames per process
+
+
 def _known_columns(df):
-    """the frame's real numeric columns without missing values (numpy, or arrow without nulls): what a device predicate may compare"""
-    return {name: ar for name, ar in df.columns.items() if _predicate.plain_numeric_dtype(ar) is not None}
+    """the frame's real numeric columns without missing values (numpy, or arrow without nulls): what a device predicate may compare.
+    Remembered per frame while its column set stays the same objects (every scheduled aggregation — and every task part's
+    decode — asked again, a scan of all columns and of the arrow null counts each time: O(aggregations^2 x columns) on wide frames)"""
+    cols = df.columns
+    fp = tuple((name, id(ar)) for name, ar in cols.items())
+    hit = _known_cache.get(id(cols))
+    if hit is not None and hit[0] == fp:
+        return {name: cols[name] for name in hit[1]}   # (names only are remembered: no array is kept alive by the cache)
+    known = {name: ar for name, ar in cols.items() if _predicate.plain_numeric_dtype(ar) is not None}
+    if len(_known_cache) > 64:
+        _known_cache.clear()
+    _known_cache[id(cols)] = (fp, tuple(known))
+    return known
 
 
 def plan_for(df, descriptor, resolved=None):
