@@ -345,6 +345,11 @@ int vxh_finish(int n_out, const int *ops, vxh_agg *const *in0, vxh_agg *const *i
                uint64_t first_cell, uint64_t n_cells, void *const *out, int64_t *index_out, uint64_t *n_kept);
 /* page-locked host memory (result columns, staging) */
 int vxh_host_alloc(size_t bytes, void **out);
+/* a whole pageable host array to device memory the caller owns, pushed by `threads` host threads (0 = 8) on streams of their own;
+ * returns when the bytes are there.  For hosts that hold a whole column and want it in HBM for one call (the wrapped df.groupby,
+ * vaex/dataframe.py:7133-7205, over plain numpy columns): the chunk passes of vaex/cpu.py:678-786 get their PCIe rate from the pool
+ * threads copying chunks side by side, a single hipMemcpy of a pageable column does not.  No counterpart in the reference. */
+int vxh_upload(const void *host, void *device, uint64_t bytes, int threads);
 void vxh_host_free(void *ptr);
 
 /* ---- hash groupby in one partitioned pass -------------------------------------------------- */

@@ -738,6 +738,15 @@ PYBIND11_MODULE(superagg, m) {
     m.def("config_get", [](const std::string &k) { int64_t v = 0; check(vxh_config_get(k.c_str(), &v)); return v; });
     // device column cache (include/vaex_hip.h "chunk feeder and device column cache"): the array's memory is declared immutable
     // until cache_unregister(array); returns whether it got page-locked
+    // upload(host_array, device_array, threads=0): the host array's bytes into the device array (same byte length), several copy threads
+    m.def("upload", [](const py::object &src, const py::object &dst, int threads) {
+        ArrayRef a = resolve_array(src), d = resolve_array(dst);
+        if (a.mem != VXH_MEM_HOST || d.mem != VXH_MEM_DEVICE) throw std::runtime_error("upload: (host array, device array)");
+        if ((uint64_t)a.n * a.itemsize != (uint64_t)d.n * d.itemsize) throw std::runtime_error("upload: the arrays differ in byte length");
+        int rc;
+        { py::gil_scoped_release r; rc = vxh_upload(a.ptr, (void *)d.ptr, (uint64_t)a.n * a.itemsize, threads); }
+        check(rc);
+    }, py::arg("src"), py::arg("dst"), py::arg("threads") = 0);
     m.def("cache_register", [](const py::object &ar, bool pin) {
         ArrayRef a = resolve_array(ar);
         if (a.mem != VXH_MEM_HOST) throw std::runtime_error("cache_register: host arrays only");

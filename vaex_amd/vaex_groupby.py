@@ -276,6 +276,8 @@ def fast_groupby(df, by, agg, sort=False, ascending=True, row_limit=None):
 # groupby over it may keep its bytes in HBM between calls (the same promise the C-level chunk cache rests on)
 # ---------------------------------------------------------------------------------------------------------------------
 _device_copies = {}
+#: plain host columns smaller than this (bytes, all of a call's columns together) are not worth an upload of their own
+upload_min_bytes = 256 << 20
 
 
 def _frame_for(df, columns):
@@ -293,6 +295,33 @@ def _frame_for(df, columns):
             cols[name] = hit[1]
         else:
             cols[name] = ar
+    # Plain (unregistered) host columns: the groupby reads the key column twice (its exact range, then the aggregation) and every
+    # pass over a whole pageable column from ONE thread crosses PCIe at a third of what the bus gives.  Round 4: such a call uploads
+    # each column once, with several copy threads (vxh_upload), into device memory that lives for this call only, and runs on the
+    # device copies — 4e8 rows x {int64 key, float64 value}: 216 -> 151 ms (profiles/r04_vaex_dropin_timing.txt).  (Registered columns keep their copies between calls, above.)
+    host = [name for name, c in cols.items() if not binned._is_device(c)]
+    if host:
+        try:
+            import torch
+            import vaex_amd
+            sa = vaex_amd.superagg
+            total = sum(cols[name].nbytes for name in host)
+            free, _ = torch.cuda.mem_get_info()
+            kinds = {"int8": torch.int8, "int16": torch.int16, "int32": torch.int32, "int64": torch.int64, "uint8": torch.uint8, "bool": torch.uint8,
+                     "float32": torch.float32, "float64": torch.float64}
+            plain = all(isinstance(cols[name], np.ndarray) and not np.ma.isMaskedArray(cols[name]) and cols[name].dtype.name in kinds and cols[name].dtype.isnative for name in host)
+            if plain and total >= upload_min_bytes and total * 4 < free:
+                up = {}
+                for name in host:
+                    a = np.ascontiguousarray(cols[name])
+                    t = torch.empty(a.shape, dtype=kinds[a.dtype.name], device="cuda")
+                    sa.upload(a.view("u1") if a.dtype == np.bool_ else a, t)
+                    up[name] = t
+                if all(cols[name].dtype.name != "bool" for name in host):   # (a bool key is told from a uint8 one by its numpy dtype: leave those on the host path)
+                    cols.update(up)
+                    stats["uploaded"] = stats.get("uploaded", 0) + 1
+        except (ImportError, RuntimeError, MemoryError):
+            pass   # (no room, no torch: the host columns go through the chunk passes as before)
     if len({binned._is_device(c) for c in cols.values()}) > 1:  # (the fused pass wants keys and values in one place)
         cols = dict(columns)
     from . import vaex_dist
