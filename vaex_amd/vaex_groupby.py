@@ -312,11 +312,18 @@ def _frame_for(df, columns):
             plain = all(isinstance(cols[name], np.ndarray) and not np.ma.isMaskedArray(cols[name]) and cols[name].dtype.name in kinds and cols[name].dtype.isnative for name in host)
             if plain and total >= upload_min_bytes and total * 4 < free:
                 up = {}
+                jobs = []
                 for name in host:
                     a = np.ascontiguousarray(cols[name])
                     t = torch.empty(a.shape, dtype=kinds[a.dtype.name], device="cuda")
-                    sa.upload(a.view("u1") if a.dtype == np.bool_ else a, t)
+                    jobs.append((a.view("u1") if a.dtype == np.bool_ else a, t))
                     up[name] = t
+                if len(jobs) > 1:   # (the columns cross PCIe side by side: upload() releases the GIL)
+                    from concurrent.futures import ThreadPoolExecutor
+                    with ThreadPoolExecutor(len(jobs)) as pool:
+                        list(pool.map(lambda j: sa.upload(j[0], j[1], 6), jobs))
+                else:
+                    sa.upload(jobs[0][0], jobs[0][1])
                 if all(cols[name].dtype.name != "bool" for name in host):   # (a bool key is told from a uint8 one by its numpy dtype: leave those on the host path)
                     cols.update(up)
                     stats["uploaded"] = stats.get("uploaded", 0) + 1
