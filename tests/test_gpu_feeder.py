@@ -207,3 +207,21 @@ def test_memory_mapped_files_stream_and_cache(tmp_path, mode):
     assert st2["hits"] - st1["hits"] == 2 * -(-len(x) // (1 << 18)) and st2["misses"] == st1["misses"]
     vaex_amd.uncache_columns()
     del mx, mv
+
+
+@pytest.mark.parametrize("threads", [0, 1, 3, 16])
+def test_upload_moves_a_whole_pageable_column(threads):
+    """round 4: vxh_upload — a whole host array into device memory the caller owns, pushed by several copy threads (what the wrapped
+    df.groupby does with plain numpy columns, once per call).  Sizes that are no multiple of the slices or of the 32 MiB pieces, a
+    one-byte dtype, a length-mismatch and a host destination"""
+    import torch
+    rng = np.random.default_rng(threads)
+    for n, dt in ((70_000_001, np.int64), (33_554_433, np.uint8), (5, np.float64)):
+        a = rng.integers(0, 250, n).astype(dt)
+        t = torch.zeros(n, dtype={np.int64: torch.int64, np.uint8: torch.uint8, np.float64: torch.float64}[dt], device="cuda")
+        sa.upload(a, t, threads)
+        assert np.array_equal(t.cpu().numpy(), a)
+    with pytest.raises(RuntimeError, match="byte length"):
+        sa.upload(np.zeros(8, dtype=np.int64), torch.zeros(7, dtype=torch.int64, device="cuda"))
+    with pytest.raises(RuntimeError, match="host array, device array"):
+        sa.upload(np.zeros(8, dtype=np.int64), np.zeros(8, dtype=np.int64))

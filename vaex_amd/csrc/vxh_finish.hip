@@ -175,6 +175,9 @@ int vxh_upload(const void *host, void *device, uint64_t bytes, int threads) {
         if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { (void)hipGetLastError(); throw std::runtime_error("vaex_hip: no HIP device available (libvaexhip has no CPU fallback)"); }
         int dev = 0;
         (void)hipGetDevice(&dev);
+        // whatever the caller enqueued on its own streams for the destination (an allocator's fill, an earlier reader) comes first: the
+        // copy threads' streams know nothing of them
+        if (hipDeviceSynchronize() != hipSuccess) throw std::runtime_error("vxh_upload: the device reports an earlier error");
         const int nt = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)(threads > 0 ? std::min(threads, 16) : 8), (bytes + (64u << 20) - 1) / (64u << 20)));
         const uint64_t slice = ((bytes + (uint64_t)nt - 1) / (uint64_t)nt + 4095) & ~(uint64_t)4095;
         std::vector<std::string> errors((size_t)nt);
