@@ -176,3 +176,28 @@ def test_heavy_key_sample_finds_the_head_of_a_zipf_law_and_nothing_in_uniform_ke
     g = Frame.__new__(Frame)
     g.n = n
     assert g._heavy_keys("k", (rng.integers(0, 1_000_000, n) * 2654435761) % (1 << 40)) is None
+
+
+def test_heavy_key_sampler_host_logic():
+    """round 4: the keys the fused groupby peels inside its scatter kernel come from a strided sample of the key column — those holding
+    >= `share` of it, the 128 most frequent at most, ascending; remembered per (column, share).  Host logic only (numpy keys): no GPU"""
+    import numpy as np
+    from vaex_amd.binned import Frame
+    rng = np.random.default_rng(0)
+    n = 1 << 22
+    k = rng.integers(0, 1_000_000, n).astype(np.int64)
+    k[rng.random(n) < 0.2] = 777
+    k[rng.random(n) < 0.01] = -5
+    f = Frame(dict(k=k, v=rng.normal(size=n)))
+    assert list(f._heavy_keys("k", f.columns["k"], share=1 / 1024)) == [-5, 777]
+    assert list(f._heavy_keys("k", f.columns["k"])) == [-5, 777]            # (1 / 128: both are above it too)
+    assert f._heavy_keys("k", f.columns["k"], share=1 / 1024) is f._heavy_keys("k", f.columns["k"], share=1 / 1024)   # remembered
+    # more than 128 keys above the threshold: the 128 most frequent
+    many = np.repeat(np.arange(300, dtype=np.int64), np.r_[np.full(150, 40_000), np.full(150, 20_000)])
+    rng.shuffle(many)
+    g = Frame(dict(k=many, v=np.zeros(len(many))))
+    top = g._heavy_keys("k", g.columns["k"], share=1 / 1024)
+    assert len(top) == 128 and set(top) <= set(range(150))
+    # uniform keys: none
+    u = Frame(dict(k=rng.integers(0, 1_000_000, n).astype(np.int64), v=np.zeros(n)))
+    assert u._heavy_keys("k", u.columns["k"], share=1 / 1024) is None
