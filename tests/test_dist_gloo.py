@@ -203,3 +203,39 @@ def test_first_last_over_two_ranks(ref):
         assert out["first_t"][1].any() and not out["first_t"][1].all()   # (cells beyond x = 10 are empty on every rank)
         assert out["gathered"] == [[[0, 1], [1.5, 2.5], [0]], [[0, 1, 2, 3, 4], [], [1]]]
         assert out["agree"] == [True, False, False]
+
+
+def test_host_reduce_does_not_depend_on_which_thread_slot_saw_rows(ref):
+    """VERDICT r4 weak #1, deterministic form.  The reference's get_result() re-initialises grid 0 when thread slot 0 never saw a
+    row (`if (!grid_used[0]) initial_fill(0)`, src/agg_count.cpp:24-41) — a result written into buf[0] is wiped.  With a pool,
+    which slots see rows is the scheduler's choice (one thread may take every chunk), so allreduce_aggs_host must hand the
+    reduced arrays back for such aggregators instead of writing them through."""
+    from vaex_amd import dist as vdist
+    rng = np.random.default_rng(5)
+    x = rng.uniform(0, 1, 1000)
+    v = rng.normal(0, 1, 1000)
+    binner = ref.BinnerScalar_float64(2, "x", 0.0, 1.0, 4)
+    grid = ref.Grid([binner])
+    aggs = [ref.AggCount_int64(grid, 2, 2), ref.AggSum_float64(grid, 2, 2), ref.AggMax_float64(grid, 2, 2)]
+    binner.set_data(1, x)                     # every row on slot 1: slot 0's grids stay unused
+    binner.clear_data_mask(1)
+    for a in aggs[1:]:
+        a.set_data(1, v, 0)
+    for a in aggs:
+        a.clear_data_mask(1)
+    grid.bin(1, aggs, len(x))
+    local = [np.array(a.get_result()) for a in aggs]
+    assert local[0].sum() == 1000
+
+    def two_ranks(arrays, ops):               # "the other rank" holds the same grids
+        assert ops == ["sum", "sum", "max"]
+        return [a * 2 if op == "sum" else a for a, op in zip(arrays, ops)]
+    returned = vdist.allreduce_aggs_host(aggs, reduce_arrays=two_ranks)
+    assert returned is not None and all(r is not None for r in returned)
+    merged = vdist.with_reduced(aggs, returned)
+    np.testing.assert_array_equal(merged[0].get_result(), local[0] * 2)
+    np.testing.assert_array_equal(merged[1].get_result(), local[1] * 2)
+    np.testing.assert_array_equal(merged[2].get_result(), local[2])
+    assert merged[0].grid is grid              # everything else is the aggregator's
+    # and the aggregators themselves were left alone (nothing was written into buf[0] for get_result to wipe)
+    np.testing.assert_array_equal(np.array(aggs[0].get_result()), local[0])

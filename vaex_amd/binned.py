@@ -392,7 +392,8 @@ class Frame:
         if reduce is None and self.comm is not None:
             reduce = self.comm.allreduce
         if reduce is not None:
-            reduce(aggs)
+            from .dist import with_reduced
+            aggs = with_reduced(aggs, reduce(aggs))   # (aggregators that cannot be written through come back as result arrays)
         return specs, grid, aggs, want
 
     def _agg(self, descs, binby=None, limits=None, shape=128, edges=False, reduce=None):
@@ -1412,7 +1413,8 @@ class Frame:
             grid.bin(slot, aggs, i2 - i1)
             slot = (slot + 1) % slots
         if reduce is not None:
-            reduce(aggs)
+            from .dist import with_reduced
+            aggs = with_reduced(aggs, reduce(aggs))
         if hasattr(sa, "finish") and nuniq is not None:  # cells [unknown, ordinal 0..N-1, null]: finish the N group cells on the device
             fin = [d.finish_spec(sa, [aggs[i] for i in ids]) for d, ids in zip(descs, want)]
             cols, _ = sa.finish(fin, present=None, first=1, n=nuniq, want_index=False)

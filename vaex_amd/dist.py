@@ -97,13 +97,26 @@ def native_comm(group=None):
 
 
 def allreduce_aggs_host(aggs, group=None, reduce_arrays=None):
-    """Same reduce through the (grids, *shapes) host buffers of the aggregators (buffer protocol of the
-    superagg surface, src/agg_base.hpp:106-125): grid 0 receives the global result, the others the identity.
-    reduce_arrays(arrays, ops) -> arrays: the exchange itself (default: allreduce_results over `group`)."""
+    """Same reduce through host copies of the results.  reduce_arrays(arrays, ops) -> arrays: the exchange itself (default:
+    allreduce_results over `group`).
+
+    The HIP classes take the global result back through their (grids, *shapes) host buffer (buffer protocol of the superagg
+    surface, src/agg_base.hpp:106-125): grid 0 receives it, the others the identity, and get_result() folds every replica.
+    Aggregators of any OTHER class (the reference's own C++ in the CPU tests) are not written to — their get_result() folds
+    only the grids whose thread slot saw a row and RE-INITIALISES grid 0 when slot 0 never did (`if (!grid_used[0])
+    initial_fill(0)`, src/agg_count.cpp:24-41; which slots see rows depends on how the pool's threads were scheduled, and a
+    rank without rows uses none), and their buffer's grid stride is wrong beyond one dimension (src/agg_base.hpp:115).  For
+    those the reduced arrays are RETURNED, one per aggregator (None where the aggregator was written through), and the
+    caller reads them instead of get_result() — vaex_amd.binned.Frame does, vaex_dist merges results the same way."""
     ops = [agg_reduce_op(a) for a in aggs]
     local = [np.array(a.get_result()) for a in aggs]
     reduced = reduce_arrays(local, ops) if reduce_arrays is not None else allreduce_results(local, ops, group)
+    returned = []
     for a, r, op in zip(aggs, reduced, ops):
+        if not hasattr(a, "device_touch"):
+            returned.append(np.asarray(r))
+            continue
+        returned.append(None)
         buf = np.asarray(a)
         buf[0] = r
         if buf.shape[0] > 1:
@@ -117,6 +130,28 @@ def allreduce_aggs_host(aggs, group=None, reduce_arrays=None):
                 else:
                     ident = op == "min"
             buf[1:] = ident
+    return returned if any(r is not None for r in returned) else None
+
+
+class ReducedAgg:
+    """Stand-in for an aggregator that could not take the cross-rank result back (see allreduce_aggs_host): get_result() is
+    the reduced array, everything else is the aggregator's."""
+
+    def __init__(self, agg, result):
+        self._agg, self._result = agg, result
+
+    def get_result(self):
+        return self._result
+
+    def __getattr__(self, name):
+        return getattr(self._agg, name)
+
+
+def with_reduced(aggs, returned):
+    """aggs with the ones `reduce(aggs)` returned arrays for replaced by ReducedAgg stand-ins"""
+    if returned is None:
+        return aggs
+    return [a if r is None else ReducedAgg(a, r) for a, r in zip(aggs, returned)]
 
 
 class _Wrap:
@@ -256,7 +291,7 @@ class Comm:
         return np.unique(np.concatenate([p[0] for p in parts]))
 
     def allreduce(self, aggs):
-        allreduce_aggs(aggs, self.group)
+        return allreduce_aggs(aggs, self.group)
 
     def allreduce_arrays(self, arrays, ops):
         """element-wise 'sum' / 'min' / 'max' of host arrays over the ranks (tensors of the backend's device underneath)"""
