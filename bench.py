@@ -302,6 +302,12 @@ def run(args):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # stdout carries ONE line, the JSON: librccl prints a version banner on stdout from C stdio when its first communicator comes up
+    # (flushed whenever — seen BEHIND the JSON line), so file descriptor 1 is pointed at stderr for the run and the line goes to a
+    # private duplicate of the real stdout at the end
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
     import vaex_amd
@@ -450,6 +456,30 @@ def run(args):
             assert int(count.get_result().sum()) == rows
             bx.set_data(0, x); by.set_data(0, y)
             del xu, yu
+        if world == 1:
+            # The driver's 1-GPU run never reaches the collective of the N > 1 step, and no multi-GPU node has run this repo
+            # (no scaling curve has been measured in any round).  So the same C-ABI call — vxh_comm_init + vxh_allreduce, RCCL on
+            # the library's stream — runs here on a ONE-rank communicator over the three grids of the last step, outside every
+            # timed region: the code path is exercised on the box the bench runs on, its cost at world 1 is on the line, and the
+            # grids must come back unchanged.  (The cross-rank merge it stands for: vaex/cpu.py:788-796, src/agg_count.cpp:15-23.)
+            try:
+                before = [np.array(a.get_result()) for a in aggs]
+                comm1 = sa.Comm(1, 0, sa.comm_unique_id())
+                comm1.allreduce(aggs)                  # (first call: communicator warm-up)
+                torch.cuda.synchronize()
+                ar = []
+                for _ in range(5):
+                    sa.timer_start(0)
+                    comm1.allreduce(aggs)
+                    ar.append(sa.timer_stop(0))
+                same = all(np.array_equal(b, np.array(a.get_result()), equal_nan=True) for b, a in zip(before, aggs))
+                out["allreduce_world1_ms"] = float(np.median(ar))
+                out["allreduce_world1"] = {"ranks": comm1.size, "grids": len(aggs), "bytes_per_grid": int(before[0].nbytes), "grids_unchanged": bool(same),
+                                           "note": "vxh_allreduce (RCCL) on a one-rank communicator, HIP events on the library's stream, outside the timed value; "
+                                                   "N > 1 has never run on hardware for this repo: no scaling curve measured"}
+                del comm1
+            except Exception as e:   # (the bench line must not depend on it)
+                out["allreduce_world1"] = {"error": repr(e)}
         if not args.no_cpu:
             # (at N > 1 too: rank 0's own shard is the sample — the other ranks wait at the end of the job, outside every timed region)
             cb, cpu_res, cpu_rows, sabs = cpu_baseline(x, y, v, shape, args.cpu_rows if world == 1 else min(args.cpu_rows, 5e7))
@@ -476,7 +506,8 @@ def run(args):
             del x, y, v
             torch.cuda.empty_cache()
             out["configs"] = other_configs(sa, torch, rows, 1e7)
-        print(json.dumps(out), flush=True)
+        json_out.write(json.dumps(out) + "\n")
+        json_out.flush()
     if world > 1:
         dist.destroy_process_group()
 

@@ -232,6 +232,58 @@ def test_frame_groupby_with_a_selection_takes_the_fused_path(sa, gpu_ready):
         assert np.allclose(got["m"], mean, rtol=1e-11, atol=0, equal_nan=True)
 
 
+@pytest.mark.parametrize("keys", ["scattered", "dense_skewed"])
+def test_aggregations_with_their_own_selection_keep_the_groups_of_all_rows(sa, gpu_ready, keys):
+    """vaex.agg.count(selection=...) is NOT a filter — the groups are those of ALL rows, a group without a selected
+    row reports count 0 / sum 0 / mean NaN (vaex/groupby.py:884-899).  The fused pass used to take such a selection as its keep-mask
+    and the groups without a kept row vanished.  Scattered keys (the fused hash pass, run twice and joined) and a skewed dense range
+    wider than one workgroup's LDS (the fused pass with the peel inside / the dense peel): half the groups have NO selected row."""
+    import torch
+    from vaex_amd import binned
+    rng = np.random.default_rng(21)
+    n = 5_000_000 if keys == "dense_skewed" else 1_200_000
+    if keys == "scattered":
+        base = rng.integers(0, 60_000, n)
+        k = (base * 2654435761) % (1 << 40)
+    else:
+        base = np.where(rng.random(n) < 0.5, rng.integers(0, 8, n) * 3001, rng.integers(0, 40_000, n))   # eight heavy keys in a 40 000-cell range
+        k = base + 17
+    v = rng.normal(3, 2, n); v[::211] = np.nan
+    x = rng.normal(0, 1, n)
+    x[base % 2 == 1] = -1.0              # odd groups: no row passes "x > 0"
+    for device in (True, False):
+        cols = dict(k=k, v=v, x=x)
+        if device:
+            cols = {c: torch.from_numpy(a).cuda() for c, a in cols.items()}
+        f = binned.Frame(cols, superagg=sa)
+        A = binned.agg
+        got = f.groupby("k", {"c": A.count(selection="x > 0"), "cv": A.count("v", selection="x > 0"), "s": A.sum("v", selection="x > 0"),
+                              "m": A.mean("v", selection="x > 0"), "sd": A.std("v", selection="x > 0")})
+        uniq, inv = np.unique(k, return_inverse=True)
+        kept = x > 0
+        ok = kept & (v == v)
+        rows = np.bincount(inv[kept], minlength=len(uniq))
+        cnt = np.bincount(inv[ok], minlength=len(uniq))
+        s = np.bincount(inv[ok], weights=v[ok], minlength=len(uniq))
+        sabs = np.bincount(inv[ok], weights=np.abs(v[ok]), minlength=len(uniq))
+        np.testing.assert_array_equal(got["k"], uniq)                       # every group of ALL rows is there
+        assert (rows == 0).sum() > len(uniq) // 3                          # ... and many of them have no selected row
+        np.testing.assert_array_equal(got["c"], rows)
+        np.testing.assert_array_equal(got["cv"], cnt)
+        assert np.all(np.abs(got["s"] - s) <= 1e-12 * sabs)
+        assert np.all(got["s"][cnt == 0] == 0)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            mean = s / cnt
+        assert np.allclose(got["m"], mean, rtol=1e-11, atol=0, equal_nan=True)
+        assert np.isnan(got["m"][cnt == 0]).all() and np.isnan(got["sd"][cnt == 0]).all()
+        # the same selection as the CALL's filter is the other thing: groups without a kept row do not exist
+        flt = f.groupby("k", {"c": A.count()}, selection="x > 0")
+        np.testing.assert_array_equal(flt["k"], uniq[rows > 0])
+        np.testing.assert_array_equal(flt["c"], rows[rows > 0])
+        if keys == "scattered":
+            assert (f.last_groupby_info or {}).get("groups") is not None or f.last_groupby_info is not None
+
+
 @pytest.mark.parametrize("flavour", ["zipf", "three_keys", "zipf_int32_selection"])
 def test_frame_groupby_peels_heavy_keys(sa, gpu_ready, flavour):
     """skewed key columns (the head of a Zipf law, a handful of scattered keys, a default value) on the device: the heavy keys are found

@@ -98,6 +98,9 @@ if gpu:   # (several keys are packed on the device, scattered keys need the hash
     taken += [(["k", "k32"], {"c": A.count(), "s": A.sum("v")}, {}),
               (["ku", "k", "k32"], {"m": A.mean("v")}, dict(sort=True)),
               ("ks", {"s": A.sum("v"), "c": A.count(), "m": A.mean("v"), "sd": A.std("v")}, {}),
+              # ADVICE r4: an aggregation's OWN selection on scattered keys — groups without a selected row stay (count 0 / mean NaN)
+              ("ks", {"c": A.count(selection="i < -98"), "s": A.sum("v", selection="i < -98"), "m": A.mean("v", selection="i < -98")}, {}),   # about one row in a hundred: half of the 3000 groups have none
+              ("ks", {"c": A.count(selection="v > 100")}, {}),                                                 # NO row selected at all: every group, all zeros
               (["ks", "ku"], {"c": A.count("v")}, {})]
 declined = [
   ("kf", {"c": A.count()}, "dtype float64"),
@@ -222,5 +225,5 @@ def test_groupby_host_logic_against_vaex_on_the_reference_cpp():
 @pytest.mark.skipif(not os.path.isdir(os.path.join(PKG, "vaex")), reason="real vaex package not built (oracle/build_ref.sh needs /root/reference)")
 def test_groupby_of_real_vaex_runs_on_the_device_groupby():
     out = _run(1, 900)
-    assert "DONE" in out and out.count("ok-device ") == 19 and out.count("ok-device-filtered") == 6 and out.count("ok-declined") == 7, out
+    assert "DONE" in out and out.count("ok-device ") == 21 and out.count("ok-device-filtered") == 6 and out.count("ok-declined") == 7, out
     assert "gb_scatter+gb_reduce" in out and "bin_lds" in out, out   # (the fused hash aggregation, and — few groups — the LDS-resident grid)

@@ -982,12 +982,12 @@ class Frame:
                     mine = self.n >= self.heavy_key_rows and self._heavy_keys(by, key, share=self.heavy_key_share_in_pass) is not None
                     skewed = mine if comm is None else not comm.all_agree(not mine)   # (any rank's sample: one MIN all-reduce)
                     if skewed:
-                        fused = self._groupby_fused(by, pf, descs, names, comm, key_range=(kmin, kmax))
+                        fused = self._groupby_fused(by, pf, descs, names, comm, key_range=(kmin, kmax), filter_sel=selection)
                         if fused is not None:
                             self.last_groupby_info = dict(self.last_groupby_info or {}, dense_range_through_fused_pass=1)
                             return fused
                 # (outside the fused pass's signature — min / max, integer value columns, several selections: round 3's three passes)
-                peeled = self._groupby_dense_peeled(by, pf, key, descs, names, (kmin, kmax), comm)
+                peeled = self._groupby_dense_peeled(by, pf, key, descs, names, (kmin, kmax), comm, filter_sel=selection)
                 if peeled is not None:
                     return peeled
             # the key column bins itself (BinnerOrdinal with min_value): ONE pass, no hash map.  This is the
@@ -1021,7 +1021,7 @@ class Frame:
             return {by: out_keys, **dict(zip(names, vals))}
         # scattered keys, plain count / sum / mean / var / std of float64 columns: ONE radix-partitioned pass with the hash
         # table probed in LDS (vxh_groupby_run) instead of the reference's two passes over a global table
-        fused = self._groupby_fused(by, pf, descs, names, comm, key_range=(kmin, kmax) if self.n or comm is not None else None)
+        fused = self._groupby_fused(by, pf, descs, names, comm, key_range=(kmin, kmax) if self.n or comm is not None else None, filter_sel=selection)
         if fused is not None:
             return fused
         # pass 1: distinct keys on the GPU (ordered_set.update), united over ranks, sorted -> sealed map whose
@@ -1048,14 +1048,21 @@ class Frame:
             out_keys, vals = out_keys[present], [np.asarray(v)[present] for v in vals[:-1]]
         return {by: out_keys, **dict(zip(names, vals))}
 
-    def _groupby_fused(self, by, pf, descs, names, comm, key_range=None):
-        """the vxh_groupby_run path, or None when the call is outside its signature (then: ordered_set + BinnerHash)"""
+    def _groupby_fused(self, by, pf, descs, names, comm, key_range=None, filter_sel=None):
+        """the vxh_groupby_run path, or None when the call is outside its signature (then: ordered_set + BinnerHash).
+
+        filter_sel: the CALL's filter (groupby(selection=), a filtered vaex frame) — rows outside it reach nothing and groups without
+        a row inside it do not exist: it is the pass's keep-mask.  A selection of the AGGREGATIONS' own (vaex.agg.count(selection=...);
+        filter_sel None) is something else — the groups are those of ALL rows, and a group without a selected row reports count 0 /
+        sum 0 / mean NaN (vaex/groupby.py:884-899) — so it must not become the keep-mask of the one pass (groups vanished).
+        One selection shared by every aggregation runs the pass TWICE: all rows for the group keys, the kept rows for the values,
+        left-joined on the sorted keys."""
         sa = self.sa
         if not hasattr(sa, "groupby_run") or self.n == 0 and comm is None:
             return None
         key = self.columns[by]
         vcols = []
-        shared = descs[0].selection if descs else None   # ONE selection over the whole call (a filter): a keep-mask of the pass
+        shared = descs[0].selection if descs else None   # ONE selection over the whole call: a keep-mask of the pass
         for d in descs:
             if d.name not in ("count", "sum", "mean", "var", "std") or not _same_selection(d.selection, shared):
                 return None
@@ -1063,6 +1070,10 @@ class Frame:
                 vcols.append(d.column)
         if len(vcols) > 2:
             return None
+        if shared is not None and not _same_selection(shared, filter_sel):
+            if filter_sel is not None or pf != "int64":   # (an own selection next to a filter is refused in groupby(); the key pass lends the int64 key as payload)
+                return None
+            return self._groupby_fused_own_selection(by, pf, descs, names, comm, key_range, shared)
         values = []
         for c in vcols:
             col = self.columns[c]
@@ -1079,7 +1090,10 @@ class Frame:
         keep = None
         if shared is not None:
             keep = self._mask_array(shared)
-            if _is_device(keep) != _is_device(key):
+            usable = keep is not None and _is_device(keep) == _is_device(key)
+            # (what a rank's mask turns out to be is rank-local; leaving alone here would strand the other ranks in the pass's
+            #  collectives below — ADVICE r4: every rank-local exit is agreed on first)
+            if not (usable if comm is None else comm.all_agree(usable)):
                 return None
             keep = keep if _is_device(keep) else np.ascontiguousarray(_as_u8(keep))
         # heavy hitters (a default / missing-value key, the head of a Zipf law): every row of ONE key lands in ONE bucket of the
@@ -1102,12 +1116,17 @@ class Frame:
                 torch = None
             heavy3 = self._heavy_keys_all_ranks(by, key, comm) if torch is not None else None
             if heavy3 is not None:
+                peeled = dk = dv = dkeep = None
                 try:
                     # (host rows: the pass would copy them to the device anyway — here once, for both parts)
                     dev = lambda a: a if _is_device(a) else torch.from_numpy(np.ascontiguousarray(a)).cuda()
-                    peeled = self._groupby_peeled(by, pf, descs, names, vcols, dev(key), [dev(v) for v in values], None if keep is None else dev(keep), heavy3, comm=comm)
-                except torch.cuda.OutOfMemoryError:   # (the ordinals are 8 more bytes per row: no room — the plain attempt below)
-                    peeled = None
+                    dk, dv, dkeep = dev(key), [dev(v) for v in values], None if keep is None else dev(keep)
+                    ready = True
+                except torch.cuda.OutOfMemoryError:   # (no room for the copies — the plain attempt below; every rank goes there together)
+                    ready = False
+                if ready if comm is None else comm.all_agree(ready):
+                    peeled = self._groupby_peeled(by, pf, descs, names, vcols, dk, dv, dkeep, heavy3, comm=comm)
+                dk = dv = dkeep = None
                 if not _is_device(key) or peeled is None:
                     torch.cuda.empty_cache()   # (whole columns went through torch's allocator: the library's own hipMallocs need the room back)
                 if peeled is not None:
@@ -1160,6 +1179,41 @@ class Frame:
             self.last_groupby_info.update(heavy_keys=peeled_here)   # (of THIS rank's pass; a cross-rank merge has none)
         return out
 
+    def _groupby_fused_own_selection(self, by, pf, descs, names, comm, key_range, shared):
+        """aggregations sharing ONE selection of their own: the groups are those of all rows (pass 1: count(*) per key, no keep-mask),
+        the values those of the kept rows (pass 2: the same call with the selection as its filter); groups pass 2 does not know get
+        count 0 / sum 0 / mean, var, std NaN — what vaex's numpy finishers make of empty cells (vaex/agg.py:403-455).  Both passes are
+        collectives under `comm`, entered by every rank in the same order (the branch depends on the call's signature only)."""
+        keys_only = self._groupby_fused(by, pf, [agg.count()], ["__rows__"], comm, key_range=key_range, filter_sel=None)
+        ok = keys_only is not None
+        if comm is not None and not comm.all_agree(ok):
+            return None
+        if not ok:
+            return None
+        info_keys = dict(self.last_groupby_info or {})
+        kept = self._groupby_fused(by, pf, descs, names, comm, key_range=key_range, filter_sel=shared)
+        ok = kept is not None
+        if comm is not None and not comm.all_agree(ok):
+            return None
+        if not ok:
+            return None
+        all_keys = np.asarray(keys_only[by])
+        pos = np.searchsorted(all_keys, np.asarray(kept[by]))   # (both ascending; the kept groups are a subset)
+        out = {by: all_keys}
+        for name, d in zip(names, descs):
+            col = np.asarray(kept[name])
+            if d.name == "count":
+                full = np.zeros(len(all_keys), dtype=col.dtype if len(col) else np.int64)
+            elif d.name == "sum":
+                full = np.zeros(len(all_keys), dtype=col.dtype if len(col) else np.float64)
+            else:
+                full = np.full(len(all_keys), np.nan, dtype=np.float64)
+            full[pos] = col
+            out[name] = full
+        self.last_groupby_info = dict(self.last_groupby_info or {}, own_selection_two_passes=1, groups_of_all_rows=int(len(all_keys)),
+                                      groups_with_a_kept_row=int(len(pos)), ms_keys_pass=info_keys.get("ms_scatter", 0) + info_keys.get("ms_reduce", 0))
+        return out
+
     #: heavy keys are peeled inside the fused pass (round 4); False: round 3's three passes (ordinals, keep-mask, a dense groupby of the heavy rows)
     one_kernel_peel = True
     #: rows from which a device-resident key column is sampled for heavy hitters before the fused hash groupby
@@ -1173,12 +1227,14 @@ class Frame:
     #: dense key ranges wider than this many cells are checked for heavy keys too (narrower ones live in one workgroup's LDS)
     dense_peel_cells = 1 << 14
 
-    def _groupby_dense_peeled(self, by, pf, key, descs, names, key_range, comm=None):
+    def _groupby_dense_peeled(self, by, pf, key, descs, names, key_range, comm=None, filter_sel=None):
         """the dense (BinnerOrdinal) groupby with the heavy keys peeled off, or None (no heavy key, or a call outside the peel's
         signature: aggregations other than count / sum / mean / var / std / min / max over plain columns, selections that differ)"""
         if pf not in _PEEL_KEY_KINDS or not descs:
             return None
         shared = descs[0].selection
+        if not _same_selection(shared, filter_sel):
+            return None   # (the aggregations' own selection is not a filter: the peel's keep-mask would drop the groups without a kept row — the plain dense pass keeps them)
         cols = []
         for d in descs:
             if d.name not in ("count", "sum", "mean", "var", "std", "min", "max") or not _same_selection(d.selection, shared):
@@ -1195,15 +1251,23 @@ class Frame:
         if heavy is None:
             return None
         try:
-            dev = lambda a: a if _is_device(a) else torch.from_numpy(np.ascontiguousarray(a)).cuda()
-            keep = None
-            if shared is not None:
-                keep = self._mask_array(shared)
-                keep = dev(keep if _is_device(keep) else _as_u8(keep))
-            return self._groupby_peeled(by, pf, descs, names, cols, dev(key), [dev(self.columns[c]) for c in cols], keep, heavy, dense_range=key_range, comm=comm)
-        except torch.cuda.OutOfMemoryError:
-            return None
+            # rank-local preparation (uploads: a rank may run out of memory alone) — then ALL ranks decide together whether the peel
+            # goes ahead: its sub-frames' groupbys and the heavy part's all-reduce are collectives
+            dkey = keep = dvals = None
+            try:
+                dev = lambda a: a if _is_device(a) else torch.from_numpy(np.ascontiguousarray(a)).cuda()
+                if shared is not None:
+                    keep = self._mask_array(shared)
+                    keep = dev(keep if _is_device(keep) else _as_u8(keep))
+                dkey, dvals = dev(key), [dev(self.columns[c]) for c in cols]
+                ready = True
+            except torch.cuda.OutOfMemoryError:
+                ready = False
+            if not (ready if comm is None else comm.all_agree(ready)):
+                return None
+            return self._groupby_peeled(by, pf, descs, names, cols, dkey, dvals, keep, heavy, dense_range=key_range, comm=comm)
         finally:
+            dkey = keep = dvals = None
             if not _is_device(key):
                 torch.cuda.empty_cache()   # (whole columns went through torch's allocator: the library's own hipMallocs need the room back)
 
@@ -1264,16 +1328,27 @@ class Frame:
         every rank returns the whole table's groups."""
         import torch
         sa = self.sa
-        sealed = getattr(sa, "ordered_set_" + pf)(len(heavy))
-        sealed.set_keys(heavy)
-        ords_dev = sealed.map_ordinal_device(key)
-        ords = torch.as_tensor(ords_dev, device="cuda")          # int64: rank of the row's key among the heavy ones, -1 = not heavy
-        light = ords < 0
-        if keep is not None:   # (1 = keep, anything else drops the row: src/agg_count.cpp:50)
-            if not isinstance(keep, torch.Tensor):
-                keep = torch.as_tensor(keep, device="cuda")
-            light = light & ((keep.view(torch.uint8) if keep.dtype == torch.bool else keep) == 1)
-        light = light.to(torch.uint8)
+        ords = ords_dev = light = None
+        try:   # (rank-local: 9 more bytes per row — a rank short of memory takes EVERY rank out of the peel, before its first collective)
+            sealed = getattr(sa, "ordered_set_" + pf)(len(heavy))
+            sealed.set_keys(heavy)
+            ords_dev = sealed.map_ordinal_device(key)
+            ords = torch.as_tensor(ords_dev, device="cuda")          # int64: rank of the row's key among the heavy ones, -1 = not heavy
+            light = ords < 0
+            if keep is not None:   # (1 = keep, anything else drops the row: src/agg_count.cpp:50)
+                if not isinstance(keep, torch.Tensor):
+                    keep = torch.as_tensor(keep, device="cuda")
+                light = light & ((keep.view(torch.uint8) if keep.dtype == torch.bool else keep) == 1)
+            light = light.to(torch.uint8)
+            ready = True
+        except (torch.cuda.OutOfMemoryError, MemoryError):
+            ready = False
+        except RuntimeError as e:
+            if "memory" not in str(e).lower():
+                raise
+            ready = False
+        if not (ready if comm is None or comm.world() == 1 else comm.all_agree(ready)):
+            return None
         plain = {n: agg._Desc(d.name, d.column, None) for n, d in zip(names, descs)}
         if dense_range is not None:
             # the light rows of a dense key range: the same dense groupby with the heavy rows masked out
