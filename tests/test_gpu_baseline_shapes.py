@@ -747,9 +747,13 @@ def test_integer_binner_columns_ride_the_fast_kernels(sa, shape, bdtype):
 # round 4: the GROUPED pass 1 ("wv" = 5: cold records compacted into a wave-private ring, slab-sorted 64-record groups in one
 # stream per wave, pass 2 = part_reduce_grp) against the ring-less one ("wv" = 3) and the reference's C++
 # ------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("form", [5, 6])
 @pytest.mark.parametrize("variant", ["bench", "masked", "count_only", "std", "int64_values", "tiny_blocks", "region_overflow", "nan_values", "sigma2"])
-def test_grouped_pass1(sa, variant):
-    """Every variant bins the same rows with wv = 5 and wv = 3: integer grids bit-exact, fp64 sums within 1e-12 x sum|v| of the cell, and
+def test_grouped_pass1(sa, variant, form):
+    """form 5: the grouped pass 1; form 6 (round 5): the same with the groups' record stores held back in a register queue and issued in
+    chip-wide bursts on the flips of a wall-clock bit ("wv" = 6, part_scatter_wv<..., DIRECT = 4>; sigma2 fills the queue between two
+    flips, tiny_blocks leaves a block with groups still held, region_overflow meets the slow path with groups held).
+    Every variant bins the same rows with wv = 5 / 6 and wv = 3: integer grids bit-exact, fp64 sums within 1e-12 x sum|v| of the cell, and
     a 1e7-row slice equals the reference's C++ (restatement when absent).
       bench            256x256 count(*) + sum(v) + count(v), N(0,1) x,y, an odd row count (partial tile, partial last group)
       masked           ... one keep-mask shared by the three aggregators
@@ -804,17 +808,21 @@ def test_grouped_pass1(sa, variant):
         finally:
             sa.config_set("wv", 3); sa.config_set("hot_cache", 1)
             for k in knobs:
-                sa.config_set(k, 62 if k == "hot_direct_pct" else 0)
+                sa.config_set(k, 62 if k == "hot_direct_pct" else (13 if k == "wv_phase" else 0))
         return [np.array(a.get_result()) for a in aggs], kernel
 
     knobs = dict(tiny_blocks=dict(wv_block=64), region_overflow=dict(part_cap=4096), sigma2=dict(hot_direct_pct=20), count_only=dict(strategy=4)).get(variant, {})   # (sigma2: the ring-less family down to a 20 % box, where the default hands over to part_scatter_blk at 62 %)
     redo0 = sa.config_get("redo_count")
-    got, kernel = run(n, 5, **knobs)
+    got, kernel = run(n, form, **knobs)
     redone = sa.config_get("redo_count") - redo0
     if sa.config_get("last_slabs") > 8:   # (the groups' header holds eight slabs: wider signatures keep the per-(wave, slab) streams)
         assert kernel.startswith("part_scatter_direct_hot"), kernel
         pytest.skip(f"{variant}: {sa.config_get('last_slabs')} slabs, the grouped layout serves <= 8")
-    assert kernel.startswith("part_scatter_grouped_hot"), kernel
+    assert kernel.startswith("part_scatter_grouped_hot" if form == 5 else "part_scatter_phased_hot"), kernel
+    if form == 6 and variant in ("bench", "masked"):   # the other end of the phase knob: a flip every 160 ns — every tile ends in a burst
+        again, _ = run(n, form, wv_phase=4, **knobs)
+        for a, b in zip(again, got):
+            assert np.array_equal(a, b) if a.dtype.kind in "iu" else np.all(np.abs(a - b) <= 1e-12 * 20.0 * np.maximum(got[0], 1)), variant
     if variant == "region_overflow":
         assert redone >= 1 or sa.config_get("hot_cnt16_used") == 0
     want, kernel3 = run(n, 3, **{k: val for k, val in knobs.items() if k in ("hot_direct_pct", "strategy")})
@@ -829,7 +837,7 @@ def test_grouped_pass1(sa, variant):
     expect_rows = int(keep.sum().item()) if keep is not None else n
     assert int(got[0].sum()) == expect_rows
     m = N_SLICE
-    head, _ = run(m, 5, **knobs)
+    head, _ = run(m, form, **knobs)
     xs, ys = x[:m].cpu().numpy(), y[:m].cpu().numpy()
     vs = v[:m].cpu().numpy()
     ks = None if keep is None else keep[:m].cpu().numpy().astype(bool)

@@ -935,10 +935,13 @@ static WvGeom wv_geometry(size_t S, int nvals, bool with_box, bool converted = f
     if (!c.cfg_wv || S > 64 || nvals > 1 || (c.cfg_no_pipeline & 1) || c.cfg_part_rows > 0) return g;
     // next to a box: "wv" = 3 -> 1 (records straight from the registers, one stream per (wave, slab)), 4 -> 2 (per (workgroup, slab)),
     // 5 -> 3 (round 4: compacted into a wave-private ring, slab-sorted 64-record groups in ONE stream per wave; <= 8 slabs)
-    g.direct = with_box ? ((mode == 3 || (mode == 5 && (converted || S > 8))) ? 1 : (mode == 5 ? 3 : (mode == 4 && S <= 16 ? 2 : 0))) : 0;
-    int waves = (int)std::min<int64_t>(16, std::max<int64_t>(1, g.direct == 3 ? c.cfg_wv_waves_grouped : (g.direct ? c.cfg_wv_waves_direct : c.cfg_wv_waves)));
+    // 6 -> 4 (round 5: the grouped form with the groups' stores held back in registers and issued in chip-wide bursts; at most 8 waves — the register queue)
+    const bool grp_mode = mode == 5 || mode == 6;
+    g.direct = with_box ? ((mode == 3 || (grp_mode && (converted || S > 8))) ? 1 : (grp_mode ? (mode == 6 ? 4 : 3) : (mode == 4 && S <= 16 ? 2 : 0))) : 0;
+    int waves = (int)std::min<int64_t>(16, std::max<int64_t>(1, g.direct >= 3 ? c.cfg_wv_waves_grouped : (g.direct ? c.cfg_wv_waves_direct : c.cfg_wv_waves)));
+    if (g.direct == 4) waves = std::min(waves, 8);
     // (shared streams: the kernel's LDS is one area for the workgroup; expressed per wave for the bookkeeping below)
-    g.wave_bytes = g.direct == 3 ? VXH_WV_WAVE_LDS_GROUPED : (g.direct == 2 ? ((VXH_WV_SHARED_LDS(S) + waves - 1) / waves + 15) & ~(size_t)15 : (g.direct ? VXH_WV_WAVE_LDS_DIRECT(S) : VXH_WV_WAVE_LDS(nvals, S)));
+    g.wave_bytes = g.direct >= 3 ? VXH_WV_WAVE_LDS_GROUPED : (g.direct == 2 ? ((VXH_WV_SHARED_LDS(S) + waves - 1) / waves + 15) & ~(size_t)15 : (g.direct ? VXH_WV_WAVE_LDS_DIRECT(S) : VXH_WV_WAVE_LDS(nvals, S)));
     while (waves > 1 && (size_t)waves * g.wave_bytes > 150 * 1024) waves--;
     if (waves < 4 || (size_t)waves * g.wave_bytes > 150 * 1024) return g; // too few waves to hide anything: not this kernel
     g.waves = waves;
@@ -1076,7 +1079,7 @@ static void hot_prepare(Slot &slot, const BinArgs &A, const BinArgs &planned, co
     const WvGeom wg = wv_geometry(S, nval, true, plan.vals_i32 || plan.vals_f32 || f32b || f32all, H.wv_mode);
     bool wv = wg.ok && slab_cells < 65535 && wv_aligned(A); // (= run_part_chunk's conditions for part_scatter_wv)
     if (f32all && wg.direct != 1) wv = false;
-    if ((masked && !(wv && (wg.direct == 1 || wg.direct == 3))) || (plan.fast_f32 && !f32all)) { // (the box next to a selection mask: part_scatter_blk's or the ring-less part_scatter_wv's instantiations; float32 columns without a value column: part_scatter_blk's only)
+    if ((masked && !(wv && (wg.direct == 1 || wg.direct >= 3))) || (plan.fast_f32 && !f32all)) { // (the box next to a selection mask: part_scatter_blk's or the ring-less part_scatter_wv's instantiations; float32 columns without a value column: part_scatter_blk's only)
         if (!gen2 || ints) return;
         wv = false;
     }
@@ -1084,7 +1087,7 @@ static void hot_prepare(Slot &slot, const BinArgs &A, const BinArgs &planned, co
     // a forced box (tests / experiments) too big for what part_scatter_wv's rings leave of the LDS goes to part_scatter_blk
     // uint16 counters (two per LDS word) next to the ring-less pass 1 with one value column: 10-byte cells instead of 12
     // ... uint8 counters (four per word, 9-byte cells) where the fullest cell fills slowly enough for a flush every few hundred tiles
-    const int shift_max = (nval == 1 && !mom2 && wg.ok && (wg.direct == 1 || wg.direct == 3)) ? (int)std::max<int64_t>(0, std::min<int64_t>(std::min<int64_t>(c.cfg_hot_cnt16, H.max_shift), (c.cfg_no_pipeline & 1024) ? 1 : 2)) : 0;
+    const int shift_max = (nval == 1 && !mom2 && wg.ok && (wg.direct == 1 || wg.direct >= 3)) ? (int)std::max<int64_t>(0, std::min<int64_t>(std::min<int64_t>(c.cfg_hot_cnt16, H.max_shift), (c.cfg_no_pipeline & 1024) ? 1 : 2)) : 0;
     const bool c16 = shift_max >= 1;
     int shift = c16 ? 1 : 0; // (uint8 is decided below, from the sample)
     H.cnt16 = false;
@@ -1093,7 +1096,7 @@ static void hot_prepare(Slot &slot, const BinArgs &A, const BinArgs &planned, co
     if (wv && forced && gen2 && (uint64_t)c.cfg_hot_box[2] * (uint64_t)c.cfg_hot_box[3] > (kLdsMax - ((size_t)wg.waves * wg.wave_bytes + 64) - 96 - (c16 ? 16 : 0)) / (c16 ? 10 : (nval ? (mom2 ? 20 : 12) : 4))) wv = false;
     if (!gen2 && !wv) return;
     if (ints && !wv) return;
-    if (ints && !(wg.direct == 1 || wg.direct == 3)) return; // (4-byte columns: only the ring-less variant is instantiated for them — wv_geometry never answers 3 for those; int64 sums ride either)
+    if (ints && !(wg.direct == 1 || wg.direct >= 3)) return; // (4-byte columns: only the ring-less variant is instantiated for them — wv_geometry never answers 3 for those; int64 sums ride either)
     H.gen2 = true;
     H.nval = nval;
     const size_t cell_bytes = nval ? (mom2 ? 20 : 12) : 4;
@@ -1407,7 +1410,7 @@ static void run_part_chunk(Slot &slot, const BinArgs &planned, const LaunchPlan 
     if (slot.hot.on && slot.hot.wv != wv) throw std::runtime_error("vaex_hip internal: hot box prepared for a different pass-1 kernel");
     if (P.A.pred.on) {
         // the fused selection rides part_scatter_wv's float64 instantiations (box-less, or next to a box without rings / grouped); every other pass 1 reads a byte mask
-        const bool fusable = wv && !(narrow || f32b || f32all || intb) && !plan.key_i64 && (!slot.hot.on || wg.direct == 1 || wg.direct == 3) && aligned_to(P.A.pred.col, 16);
+        const bool fusable = wv && !(narrow || f32b || f32all || intb) && !plan.key_i64 && (!slot.hot.on || wg.direct == 1 || wg.direct >= 3) && aligned_to(P.A.pred.col, 16);
         if (!fusable) {
             const uint8_t *m = materialize_pred(slot, P.A.pred, planned.n);
             for (int k = 0; k < planned.nagg; k++) P.A.a[k].mask = m;
@@ -1420,6 +1423,7 @@ static void run_part_chunk(Slot &slot, const BinArgs &planned, const LaunchPlan 
     int wv_blocks = 0;
     if (wv) {
         wv_blocks = (int)std::max<uint64_t>(1, std::min<uint64_t>((planned.n + 256ull * wg.waves - 1) / (256ull * wg.waves), (uint64_t)c.cus)); // ONE workgroup per CU
+        if (c.cfg_wv_blocks > 0) wv_blocks = (int)std::min<int64_t>(wv_blocks, c.cfg_wv_blocks); // ("wv_blocks": fewer workgroups than CUs — how much of the read rate hangs on the CU count)
         if (slot.hot.on) wv_blocks = std::min(wv_blocks, slot.hot.blocks); // (the box's accumulator blocks are indexed by blockIdx)
     }
 
@@ -1433,7 +1437,7 @@ static void run_part_chunk(Slot &slot, const BinArgs &planned, const LaunchPlan 
     double share = 2.0;
     if (slot.hot.on && slot.hot.gen2 && ctx().cfg_hot_box[2] <= 0 && slot.hot.last_fraction > 0 && slot.hot.last_fraction <= 1) share = std::min(2.0, 3.0 * (1.0 - slot.hot.last_fraction) + 0.125);
     P.cap = (nsub == 1 ? C : std::min<uint64_t>(C, (uint64_t)(share * (double)(C / nsub)) + 8192 + 2 * 1024 * ((uint64_t)ctx().cus / std::max<uint64_t>(1, P.parts) + 1)) + 63) & ~(uint64_t)63; // (a multiple of part_scatter_wv's 64-record segments)
-    const bool grouped = wv && wg.direct == 3;
+    const bool grouped = wv && wg.direct >= 3;
     if (grouped) {
         // grouped layout: `parts` regions of 64-record groups; ONE block of GB groups per wave sized for the wave's expected cold
         // records (+ 1/8 + 3 groups), a second block is a rare in-line reservation
@@ -1566,7 +1570,7 @@ static void run_part_chunk(Slot &slot, const BinArgs &planned, const LaunchPlan 
                      (P.nmasks == 0 || (P.nmasks == 1 && P.all_masked)) && P.idx16 && slab_cells < 65535 && S <= 256 && c.cfg_part_rows <= 0 &&
                      (slot.hot.on || (S > 8 && S <= 64 && !plan.key_i64) || (plan.fast_f32 && S <= 64) || c.cfg_blk == 2); // measured (profiles/r01_other_shapes.txt, r01_groupby_tune.txt):
                      // <= 8 slabs without a box: two 512-thread workgroups of part_scatter_f64 are 2 % faster; 128-256 slabs: +5 % (1024^2) / -35 % (1e6-key groupby)
-    const bool hot_here = slot.hot.on && (P.nmasks == 0 || (P.nmasks == 1 && P.all_masked && ((blk && !wv) || (wv && (wg.direct == 1 || wg.direct == 3))))) && P.nvals == slot.hot.nval && (blk || wv);
+    const bool hot_here = slot.hot.on && (P.nmasks == 0 || (P.nmasks == 1 && P.all_masked && ((blk && !wv) || (wv && (wg.direct == 1 || wg.direct >= 3))))) && P.nvals == slot.hot.nval && (blk || wv);
     if (wv && (f32b || f32all)) P.bin_ct = 1;
     else if (wv && intb) P.bin_ct = plan.bin_i64 ? 2 : 3;
     if (wv && (narrow || f32all)) { // from here on the value column is what part_scatter_wv makes of it
@@ -1580,6 +1584,7 @@ static void run_part_chunk(Slot &slot, const BinArgs &planned, const LaunchPlan 
     if (wv) {
         P.wv = wg.waves;
         P.wv_direct = wg.direct;
+        P.wv_phase = (int32_t)std::max<int64_t>(4, std::min<int64_t>(c.cfg_wv_phase, 30));
         P.wv_wave_bytes = (int32_t)wg.wave_bytes;
         P.wv_span = (int32_t)std::max<int64_t>(1, std::min<int64_t>(c.cfg_wv_span, 1 << 20));
         P.wv_base = 0;
@@ -1849,6 +1854,8 @@ int vxh_config_set(const char *key, int64_t value) {
     else if (k == "replicas") c.cfg_replicas = value;
     else if (k == "block") c.cfg_block = value;
     else if (k == "blocks") c.cfg_blocks = value;
+    else if (k == "wv_blocks") c.cfg_wv_blocks = value;
+    else if (k == "wv_phase") c.cfg_wv_phase = value;
     else if (k == "stage_bytes") c.cfg_stage_bytes = value;
     else if (k == "feeder") c.cfg_feeder = value;
     else if (k == "cache_bytes") c.cfg_cache_bytes = value;
@@ -1906,6 +1913,8 @@ int vxh_config_get(const char *key, int64_t *value) {
     else if (k == "replicas") *value = c.cfg_replicas;
     else if (k == "block") *value = c.cfg_block;
     else if (k == "blocks") *value = c.cfg_blocks;
+    else if (k == "wv_blocks") *value = c.cfg_wv_blocks;
+    else if (k == "wv_phase") *value = c.cfg_wv_phase;
     else if (k == "stage_bytes") *value = c.cfg_stage_bytes;
     else if (k == "feeder") *value = c.cfg_feeder;
     else if (k == "cache_bytes") *value = c.cfg_cache_bytes;
@@ -2428,7 +2437,7 @@ int vxh_grid_bin(vxh_grid *grid, int thread, vxh_agg *const *aggs, int n_aggs, u
             if (slot.hot.on) {
                 if (!fused_merge) hot_merge(slot, whole_args);
                 slot.hot.acc_zero_sig = slot.hot.acc_layout_sig; // (the merge zeroes what it folds)
-                slot.last_kernel = slot.last_pass1 == 5 ? ((whole.vals_i64 || whole.vals_i32) ? "part_scatter_grouped_hot+part_reduce_grp_i64" : "part_scatter_grouped_hot+part_reduce_grp_f64") : slot.last_pass1 == 4 ? "part_scatter_shared_hot+part_reduce_f64" : slot.last_pass1 == 3 ? ((whole.vals_i64 || whole.vals_i32) ? "part_scatter_direct_hot+part_reduce_i64" : "part_scatter_direct_hot+part_reduce_f64") : (slot.last_pass1 == 2 ? "part_scatter_wv_hot+part_reduce_f64" : "part_scatter_hot+part_reduce_f64");
+                slot.last_kernel = slot.last_pass1 == 6 ? ((whole.vals_i64 || whole.vals_i32) ? "part_scatter_phased_hot+part_reduce_grp_i64" : "part_scatter_phased_hot+part_reduce_grp_f64") : slot.last_pass1 == 5 ? ((whole.vals_i64 || whole.vals_i32) ? "part_scatter_grouped_hot+part_reduce_grp_i64" : "part_scatter_grouped_hot+part_reduce_grp_f64") : slot.last_pass1 == 4 ? "part_scatter_shared_hot+part_reduce_f64" : slot.last_pass1 == 3 ? ((whole.vals_i64 || whole.vals_i32) ? "part_scatter_direct_hot+part_reduce_i64" : "part_scatter_direct_hot+part_reduce_f64") : (slot.last_pass1 == 2 ? "part_scatter_wv_hot+part_reduce_f64" : "part_scatter_hot+part_reduce_f64");
             }
             if (trial) { // one of the two timed calls of the grouped / ring-less decision (hot_prepare)
                 HIP_CHECK(hipEventRecord(slot.t_trial1, slot.stream));

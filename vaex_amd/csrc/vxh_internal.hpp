@@ -215,6 +215,8 @@ struct Context {
     int64_t cfg_replicas = 0; // 0 = auto
     int64_t cfg_block = 0;
     int64_t cfg_blocks = 0;
+    int64_t cfg_wv_blocks = 0;    // part_scatter_wv: workgroups of the launch (0 = one per CU)
+    int64_t cfg_wv_phase = 13;    // "wv" = 6: bit of the 100 MHz wall clock whose flips are the chip's write bursts (13: every 82 us)
     int64_t cfg_stage_bytes = 64 << 20;
     int64_t cfg_feeder = 1;       // host chunks: 1 copy stream + arena ring, 2 the same through page-locked buffers (see Slot::Stage), 0 copies on the compute stream
     int64_t cfg_cache_bytes = 64ll << 30; // device column cache budget (only ranges registered with vxh_cache_register are cached)

@@ -1291,7 +1291,7 @@ __global__ void __launch_bounds__(512) part_scatter_f64(const PartArgs P) {
         if (threadIdx.x < S) (few ? Lp.s_cnt : L.s_cnt)[threadIdx.x] = 0;
         __syncthreads();
         // [E] copy out the PREVIOUS tile
-        if (it > 0 && !(P.no_pipeline & 2)) scatter_copy_out(P, Lp, S, T);
+        if (it > 0 && !VXH_ABL(P, 2)) scatter_copy_out(P, Lp, S, T);
         gb_prev = gb_new;
         cnt_prev = cnt_new;
         {
@@ -1316,7 +1316,7 @@ __global__ void __launch_bounds__(512) part_scatter_f64(const PartArgs P) {
     // epilogue: the last tile's records (now in Lp)
     scatter_commit(P, Lp, S, gb_prev, cnt_prev);
     __syncthreads();
-    if (!(P.no_pipeline & 2)) scatter_copy_out(P, Lp, S, T);
+    if (!VXH_ABL(P, 2)) scatter_copy_out(P, Lp, S, T);
 }
 
 // K1b' — pass 1, second generation (PartArgs::blk): 1..3 scalar float64 binners, at most one float64 value column,
@@ -1392,7 +1392,7 @@ __global__ void __launch_bounds__(VXH_HOT_BLOCK) part_scatter_blk(const PartArgs
     const uint8_t *colm = MASKED == 1 ? P.mdata[0] : nullptr;
     auto request = [&](uint64_t t, Raw &raw) {
         uint64_t i[R];
-        if ((t + 1) * T <= n && !(P.no_pipeline & 32)) { // whole tile inside the rows (wave-uniform): no per-row clamping
+        if ((t + 1) * T <= n && !VXH_ABL(P, 32)) { // whole tile inside the rows (wave-uniform): no per-row clamping
             raw.valid = (1u << R) - 1u;
 #pragma unroll
             for (int r = 0; r < R; ++r) i[r] = t * T + threadIdx.x + (uint64_t)r * VXH_HOT_BLOCK;
@@ -1462,7 +1462,7 @@ __global__ void __launch_bounds__(VXH_HOT_BLOCK) part_scatter_blk(const PartArgs
                 if (NVAL) hot = hot & (cur.v[NVAL ? r : 0] == cur.v[NVAL ? r : 0]);
                 if (hot) {
                     const uint32_t hc = __umul24(hy, P.hot.w) + hx;
-                    if (!(P.no_pipeline & 128)) { // (timing experiments: bit 7 drops the box updates)
+                    if (!VXH_ABL(P, 128)) { // (timing experiments: bit 7 drops the box updates)
                         if (NVAL) at_add<__HIP_MEMORY_SCOPE_WORKGROUP, double>(hot_sum + hc, cur.v[NVAL ? r : 0]);
                         if (hot_mom2) at_add<__HIP_MEMORY_SCOPE_WORKGROUP, double>(hot_sum2 + hc, (double)cur.v[NVAL ? r : 0] * (double)cur.v[NVAL ? r : 0]); // (= pow_u(v, 2))
                         at_add<__HIP_MEMORY_SCOPE_WORKGROUP, uint32_t>(hot_cnt + hc, 1u);
@@ -1470,7 +1470,7 @@ __global__ void __launch_bounds__(VXH_HOT_BLOCK) part_scatter_blk(const PartArgs
                     keep &= ~(1u << r);
                 }
             }
-            if (P.no_pipeline & 64) keep = 0; // (timing experiments: bit 6 drops the cold rows)
+            if (VXH_ABL(P, 64)) keep = 0; // (timing experiments: bit 6 drops the cold rows)
             if (!hot && ((keep >> r) & 1u)) pos[r] = __hip_atomic_fetch_add(&cnt[slab[r]], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         __syncthreads();
@@ -1693,10 +1693,17 @@ __device__ __forceinline__ void wv_slow_record(const PartArgs &P, uint64_t cell,
 // MASKED: 1 = one byte keep-mask shared by every aggregator, 2 (round 4) = the shared selection itself (P.A.pred: terms over one float64
 // column, loaded like a value column and evaluated on the rows as they are binned — no sel_eval pass, no mask bytes), 3 = the same when
 // that column IS the value column (VT == 0)
+// DIRECT == 4 (round 5): the grouped form (3) with the groups' RECORD STORES held back in registers and issued in chip-wide bursts.  What
+// 1 GB of cold records costs next to 24 GB of streaming reads is the presence of write traffic in the read stream (DRAM read / write
+// turnarounds), not the stores themselves (profiles/r03_microbench6_cold_stores.txt, run 4: the same 64-record groups written as they
+// come +0.45 ms, written by every wave in the same short window of the 100 MHz wall clock +0.27).  A sorted group is 3 VGPRs across the
+// wave (value lo / hi, local index); up to VXH_WV_HELD groups wait in a register queue — eight waves per CU leave 256 VGPRs per wave,
+// the kernel needs ~100 — and leave when bit PartArgs::wv_phase of s_memrealtime flips (looked at once per tile) or the queue is full.
 template <int NDIM, int NVAL, int MASKED, bool HOT, int KEY = 0, int DIRECT = 0, int VT = 0, int BT = 0>
-__global__ void __launch_bounds__(1024) part_scatter_wv(const PartArgs P) {
+__global__ void __launch_bounds__(DIRECT == 4 ? 512 : 1024) part_scatter_wv(const PartArgs P) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr int R = 4;
+    constexpr bool GRP = DIRECT == 3 || DIRECT == 4; // cold records leave as slab-sorted 64-record groups in ONE stream per wave
     constexpr uint32_t TW = 64u * R; // rows per wave tile
     constexpr uint32_t D = DIRECT ? 0u : VXH_WV_D, G = VXH_WV_G;
     const uint32_t S = 1u << P.slab_log2; // <= 64
@@ -1715,7 +1722,7 @@ __global__ void __launch_bounds__(1024) part_scatter_wv(const PartArgs P) {
     // uint8 counters, four per word (cnt16 == 2): 9-byte cells.  The workgroup flushes and clears them every P.hot.flush_trips trips
     // of the tile loop (the host picks the interval from the sampled share of the fullest cell: ~128 rows expected there), with the
     // same check at every flush — a wrapped byte carries into its neighbour, the sum of the counters comes out 255 short.
-    const bool c16 = HOT && (DIRECT == 1 || DIRECT == 3) && NVAL == 1 && P.hot.cnt16 != 0u; // (wave-uniform)
+    const bool c16 = HOT && (DIRECT == 1 || GRP) && NVAL == 1 && P.hot.cnt16 != 0u; // (wave-uniform)
     const uint32_t csh = c16 ? P.hot.cnt16 : 0u;                            // log2(counters per word): 1 or 2
     const uint32_t cnt_words = c16 ? (hot_cells + (1u << csh) - 1u) >> csh : hot_cells; // [cnt_words] hot rows seen, [cnt_words + 1] sum of the counters
     uint32_t nhot = 0, flushed = 0; // (per wave / per thread)
@@ -1765,7 +1772,7 @@ __global__ void __launch_bounds__(1024) part_scatter_wv(const PartArgs P) {
         if (c16)
             for (uint32_t c = threadIdx.x; c < cnt_words + 2u; c += blockDim.x) hot_cnt[c] = 0u;
     }
-    if (DIRECT != 3 && lane < S) cnt[lane] = 0u;
+    if (!GRP && lane < S) cnt[lane] = 0u;
     // lane s keeps the queue segment reserved for slab s
     const uint32_t part = blockIdx.x % (uint32_t)P.parts;
     const uint32_t my_sub = (lane < S ? lane : 0u) * (uint32_t)P.parts + part;
@@ -1785,9 +1792,9 @@ __global__ void __launch_bounds__(1024) part_scatter_wv(const PartArgs P) {
     auto close_block = [&]() { // (one lane) records the block really holds
         if (end != VXH_WV_NONE) P.qtab[(size_t)my_sub * (uint32_t)P.qtab_stride + (end - B) / B] = cur - (end - B);
     };
-    if (DIRECT != 2 && DIRECT != 3 && has_work && lane < S) open_block();
+    if (DIRECT != 2 && !GRP && has_work && lane < S) open_block();
     // DIRECT == 3: the wave's block of qblk groups in region `part` (one returning atomic per block: once per launch as a rule)
-    auto open_group_block = [&]() {
+    auto open_group_block = [&]() __attribute__((always_inline)) {
         unsigned long long b = 0;
         if (lane == 0) b = atomicAdd(&P.qcount[part], (unsigned long long)B);
         b = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(b >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b);
@@ -1798,16 +1805,16 @@ __global__ void __launch_bounds__(1024) part_scatter_wv(const PartArgs P) {
     };
     // group headers leave 16 at a time — one whole 128-byte line (blocks start at multiples of 16 groups): a lone 8-byte store per group
     // left 16 partial writes per line, minutes apart in cache terms
-    auto flush_headers = [&](uint32_t upto) { // headers of groups [upto & ~15, upto) of the region
+    auto flush_headers = [&](uint32_t upto) __attribute__((always_inline)) { // headers of groups [upto & ~15, upto) of the region
         const uint32_t first = (upto - 1u) & ~15u, count = upto - first;
         if (lane < count) P.qhdr[(uint64_t)part * (P.cap / GR) + first + lane] = g_hdr[lane];
     };
-    auto close_group_block = [&]() { // groups the block really holds
+    auto close_group_block = [&]() __attribute__((always_inline)) { // groups the block really holds
         if (gend == VXH_WV_NONE) return;
         if (gcur & 15u) flush_headers(gcur);
         if (lane == 0) P.qtab[(size_t)part * (uint32_t)P.qtab_stride + (gend - B) / B] = gcur - (gend - B);
     };
-    if (DIRECT == 3 && has_work) open_group_block();
+    if (GRP && has_work) open_group_block();
     // DIRECT == 2: block j of (workgroup, slab s) holds the slab's records [j * QB, (j + 1) * QB) of this workgroup; it is
     // reserved by the lane that draws position (j - 1) * QB + QB / 2 (block 0: here), which publishes its entry in the
     // LDS ring and in the HBM block table (PartArgs::qbtab — for a lane that finds its ring entry not yet written or,
@@ -1973,7 +1980,7 @@ __global__ void __launch_bounds__(1024) part_scatter_wv(const PartArgs P) {
     auto store_record = [&](uint64_t dst, uint32_t local, double value) {
         if (NVAL) {
             const uint64_t bits = (uint64_t)__double_as_longlong(value);
-            if (P.no_pipeline & 256) __builtin_nontemporal_store(u32x3_a4{(uint32_t)bits, (uint32_t)(bits >> 32), local}, (u32x3_a4 *)((uint32_t *)P.qidx + dst * 3)); // (experiment)
+            if (VXH_ABL(P, 256)) __builtin_nontemporal_store(u32x3_a4{(uint32_t)bits, (uint32_t)(bits >> 32), local}, (u32x3_a4 *)((uint32_t *)P.qidx + dst * 3)); // (experiment)
             else *(u32x3_a4 *)((uint32_t *)P.qidx + dst * 3) = u32x3_a4{(uint32_t)bits, (uint32_t)(bits >> 32), local};
         } else {
             ((uint16_t *)P.qidx)[dst] = (uint16_t)local;
@@ -1983,7 +1990,25 @@ __global__ void __launch_bounds__(1024) part_scatter_wv(const PartArgs P) {
     // (eight ballots: this runs once per 64 COLD rows with every lane on, not once per row-step with a handful of them), put back
     // sorted into the same ring granule, read back in order and stored as whole lines — 512 B of values, 128 B of local indices,
     // non-temporal — plus the header of the slabs' end offsets.
-    auto flush_group = [&](uint32_t count) {
+    // DIRECT == 4: groups waiting for the next burst — the records of group held_first + k of the wave's block are in registers
+    constexpr int HELD = DIRECT == 4 ? (int)VXH_WV_HELD : 1;
+    uint32_t hq_lo[HELD], hq_hi[HELD], hq_ix[HELD];
+    uint32_t held = 0, held_first = 0, last_phase = 0; // (wave-uniform)
+#pragma unroll
+    for (int k = 0; k < HELD; ++k) hq_lo[k] = hq_hi[k] = hq_ix[k] = 0u;
+    auto burst = [&]() __attribute__((always_inline)) {
+        const uint64_t rec0 = ((uint64_t)part * P.cap) + (uint64_t)held_first * GR + lane;
+#pragma unroll
+        for (int k = 0; k < HELD; ++k) {
+            if ((uint32_t)k < held) { // (wave-uniform)
+                const uint64_t rec = rec0 + (uint64_t)k * GR;
+                if (NVAL) __builtin_nontemporal_store(((uint64_t)hq_hi[k] << 32) | hq_lo[k], P.qval[0] + rec);
+                __builtin_nontemporal_store((uint16_t)hq_ix[k], (uint16_t *)P.qidx + rec);
+            }
+        }
+        held = 0;
+    };
+    auto flush_group = [&](uint32_t count) __attribute__((always_inline)) {
         const uint32_t g0 = wflushed & (2u * GR - 1u); // 0 or 64
         const bool live = lane < count;
         const uint64_t vb = NVAL ? g_val[g0 + lane] : 0ull;
@@ -2006,13 +2031,24 @@ __global__ void __launch_bounds__(1024) part_scatter_wv(const PartArgs P) {
         const uint64_t v2 = NVAL ? g_val[g0 + lane] : 0ull;
         const uint32_t l2 = g_idx[g0 + lane];
         if (gcur == gend) { // the block is full (or there is none): the next one, now
+            if (DIRECT == 4 && held) burst(); // (the held groups belong to the block that is left)
             close_group_block();
             open_group_block();
         }
         if (gcur != VXH_WV_NONE) {
             const uint64_t rec = ((uint64_t)part * P.cap) + (uint64_t)gcur * GR + lane;
-            if (P.no_pipeline & 2) { // (timing experiments: bit 1 keeps the groups out of HBM — results wrong on purpose)
-            } else if (P.no_pipeline & 256) { // (timing experiments: bit 8 = ordinary stores)
+            if (DIRECT == 4) { // into the register queue (a dynamic index, wave-uniform: selects over the HELD entries)
+                if (held == 0u) held_first = gcur;
+#pragma unroll
+                for (int k = 0; k < HELD; ++k) {
+                    const bool here = held == (uint32_t)k;
+                    hq_lo[k] = here ? (uint32_t)v2 : hq_lo[k];
+                    hq_hi[k] = here ? (uint32_t)(v2 >> 32) : hq_hi[k];
+                    hq_ix[k] = here ? l2 : hq_ix[k];
+                }
+                ++held;
+            } else if (VXH_ABL(P, 2)) { // (timing experiments: bit 1 keeps the groups out of HBM)
+            } else if (VXH_ABL(P, 256)) { // (bit 8 = ordinary stores instead of non-temporal ones)
                 if (NVAL) P.qval[0][rec] = v2;
                 ((uint16_t *)P.qidx)[rec] = (uint16_t)l2;
             } else {
@@ -2022,6 +2058,7 @@ __global__ void __launch_bounds__(1024) part_scatter_wv(const PartArgs P) {
             if (lane == 0) g_hdr[gcur & 15u] = hdr;
             ++gcur;
             if ((gcur & 15u) == 0u) flush_headers(gcur);
+            if (DIRECT == 4 && held == (uint32_t)HELD) burst(); // (the queue is full: out of phase, for once)
         } else if (live) { // region full (pathologically skewed data): device atomics straight into the grids
             wv_slow_record(P, (uint64_t)ix, NVAL ? __longlong_as_double((long long)vb) : 0.0);
         }
@@ -2104,8 +2141,8 @@ __global__ void __launch_bounds__(1024) part_scatter_wv(const PartArgs P) {
                 is_cold = is_cold & !hot;
             }
             pos[r] = 0;
-            if (DIRECT && (P.no_pipeline & 64)) is_cold = false; // (timing experiments: bit 6 drops the cold rows)
-            if (DIRECT == 3) {
+            if (DIRECT && VXH_ABL(P, 64)) is_cold = false; // (timing experiments: bit 6 drops the cold rows)
+            if (GRP) {
                 // compaction: the row-step's cold rows become neighbouring entries of the wave's ring — positions from the ballot,
                 // the running count is a scalar; no returning LDS atomic, no table, no store from a handful of lanes
                 const unsigned long long cm = __ballot(is_cold);
@@ -2126,7 +2163,7 @@ __global__ void __launch_bounds__(1024) part_scatter_wv(const PartArgs P) {
                 cold |= 1u << r;
             }
         }
-        if (DIRECT == 3) return;
+        if (GRP) return;
         if (DIRECT == 2) {
             // reservations first (they wait for nothing), then the entries, then the stores
 #pragma unroll
@@ -2141,9 +2178,9 @@ __global__ void __launch_bounds__(1024) part_scatter_wv(const PartArgs P) {
                 const uint32_t j = pos[r] >> QSH;
                 // (every lane stores, the others to the wave's sink record: see DIRECT == 1 below)
                 bool fits = c && where[r][2] == j && where[r][3] == (uint32_t)P.epoch;
-                if (P.no_pipeline & 2) { fits = false; c = false; } // (timing experiments: bit 1 sends every record to the sink)
-                if (P.no_pipeline & 512) fits = fits && slab[r] == 0; // (timing experiments: bit 9 keeps one slab's records)
-                if (P.no_pipeline & 512) c = c && slab[r] == 0;
+                if (VXH_ABL(P, 2)) { fits = false; c = false; } // (timing experiments: bit 1 sends every record to the sink)
+                if (VXH_ABL(P, 512)) fits = fits && slab[r] == 0; // (timing experiments: bit 9 keeps one slab's records)
+                if (VXH_ABL(P, 512)) c = c && slab[r] == 0;
                 store_record(fits ? ((((uint64_t)where[r][1] << 32) | where[r][0]) + (pos[r] & (QB - 1))) : sink, loc[r], NVAL ? val[NVAL ? r : 0] : 0.0);
                 c = c && !fits;
                 if (__ballot(c)) { // rare: slow path (sub-queue full), or the ring entry is not the block's (yet, or any more)
@@ -2167,8 +2204,8 @@ __global__ void __launch_bounds__(1024) part_scatter_wv(const PartArgs P) {
                 // compiler cannot count — makes the wait for the next tile's columns (requested before, i.e. older) a
                 // wait for every store's acknowledgement too: 1.3 us per tile, a quarter of the kernel's time.
                 bool fits = c && pos[r] < where[r][2];
-                if (P.no_pipeline & 2) { fits = false; c = false; } // (timing experiments: bit 1 sends every record to the sink; bit 11 keeps every stream inside 32 records — its lines never leave the L2)
-                store_record(fits ? (((uint64_t)where[r][1] << 32) | where[r][0]) + ((P.no_pipeline & 2048) ? (pos[r] & 31u) : pos[r]) : sink, loc[r], NVAL ? val[NVAL ? r : 0] : 0.0);
+                if (VXH_ABL(P, 2)) { fits = false; c = false; } // (timing experiments: bit 1 sends every record to the sink; bit 11 keeps every stream inside 32 records — its lines never leave the L2)
+                store_record(fits ? (((uint64_t)where[r][1] << 32) | where[r][0]) + (VXH_ABL(P, 2048) ? (pos[r] & 31u) : pos[r]) : sink, loc[r], NVAL ? val[NVAL ? r : 0] : 0.0);
                 c = c && !fits;
                 // rare: the slab's block is full (the next one, now) or the sub-queue is (slow path).  `where` may be
                 // stale (a block opened while an earlier row of this tile was stored): look at the table again first
@@ -2220,6 +2257,15 @@ __global__ void __launch_bounds__(1024) part_scatter_wv(const PartArgs P) {
         }
     };
 
+    // DIRECT == 4: once per tile — has the wall clock's phase bit flipped?  Then every wave of the chip is writing now.
+    auto phase_check = [&]() __attribute__((always_inline)) {
+        if (DIRECT != 4) return;
+        const uint32_t ph = (uint32_t)(__builtin_amdgcn_s_memrealtime() >> (uint32_t)P.wv_phase) & 1u;
+        if (ph != last_phase) {
+            last_phase = ph;
+            if (held) burst();
+        }
+    };
     // packed counters -> the workgroup's HBM copy of the box (its own cells: plain adds); returns this thread's share of their sum
     auto hot_flush_counts = [&]() -> uint32_t {
         unsigned long long *gc = P.hot.cnt_acc + (uint64_t)blockIdx.x * hot_cells;
@@ -2237,7 +2283,6 @@ __global__ void __launch_bounds__(1024) part_scatter_wv(const PartArgs P) {
     };
 
     if (has_work) {
-        if (!(P.no_pipeline & 1024)) {
         // ping-pong register buffers, the loop unrolled by two so that neither is ever copied (see count_lds_f64)
         Raw bufA, bufB;
         request(tile, bufA);
@@ -2248,7 +2293,7 @@ __global__ void __launch_bounds__(1024) part_scatter_wv(const PartArgs P) {
         //  trip exists, every wave of the workgroup is here)
         uint32_t trip = 0, until_flush = P.hot.flush_trips;
         for (;;) {
-            if (HOT && (DIRECT == 1 || DIRECT == 3) && NVAL == 1 && csh == 2u) {
+            if (HOT && (DIRECT == 1 || GRP) && NVAL == 1 && csh == 2u) {
                 if (trip && --until_flush == 0u) {
                     until_flush = P.hot.flush_trips;
                     if ((uint64_t)tile - wave + (nwave - 1u) < ntiles) flushed += hot_flush_counts();
@@ -2259,47 +2304,22 @@ __global__ void __launch_bounds__(1024) part_scatter_wv(const PartArgs P) {
             bool has_next = next < ntiles;
             request(has_next ? next : tile, bufB); // (the last tile re-requests itself: static number of loads in flight)
             process(bufA);
+            phase_check();
             if (!has_next) break;
             tile = next;
             next = tile_after(tile);
             has_next = next < ntiles;
             request(has_next ? next : tile, bufA);
             process(bufB);
+            phase_check();
             if (!has_next) break;
             tile = next;
         }
-        } else {
-        // experiment of round 3 (no_pipeline bit 10; measured: no difference, 4.93 vs 4.93 ms in one process): THREE register
-        // buffers — two tiles requested ahead of the one being binned (196 KB in flight per CU instead of 98 KB); unrolled by three so that no buffer is ever copied; a tile index past the end re-requests
-        // the wave's first tile (a static number of loads in flight)
-        Raw bufA, bufB, bufC;
-        const uint32_t first = tile;
-        bool vb = tile + GW < ntiles, vc, va;
-        request(first, bufA);
-        request(vb ? tile + GW : first, bufB);
-        uint32_t rq = tile + 2u * GW; // the next tile to request
-        for (;;) {
-            vc = vb && rq < ntiles;
-            request(vc ? rq : first, bufC);
-            rq += GW;
-            process(bufA);
-            if (!vb) break;
-            va = vc && rq < ntiles;
-            request(va ? rq : first, bufA);
-            rq += GW;
-            process(bufB);
-            if (!vc) break;
-            vb = va && rq < ntiles;
-            request(vb ? rq : first, bufB);
-            rq += GW;
-            process(bufC);
-            if (!va) break;
-        }
-        }
         // what is left in the rings (less than a granule per slab), then the fill of the blocks still open
-        const uint32_t my_cnt = (DIRECT != 2 && DIRECT != 3 && lane < S) ? cnt[lane] : 0u;
-        if (DIRECT == 3) {
+        const uint32_t my_cnt = (DIRECT != 2 && !GRP && lane < S) ? cnt[lane] : 0u;
+        if (GRP) {
             if (wcount != wflushed) flush_group(wcount - wflushed); // (< 64 records: the header says how many)
+            if (DIRECT == 4) burst();
             close_group_block();
         } else if (DIRECT == 2) {
         } else if (DIRECT) {
@@ -2689,7 +2709,7 @@ __device__ __forceinline__ void grp_apply(const PartArgs &P, char *lds, uint32_t
     const bool vint = P.val_i64 != 0;
     const double d = as_f64(vbits);
     const bool nan = !vint && d != d;
-    if (P.no_pipeline & 8192) { // (timing experiments: bit 13 drops the LDS atomics of pass 2 — what is left is its loads and bookkeeping)
+    if (VXH_ABL(P, 8192)) { // (timing experiments: bit 13 drops the LDS atomics of pass 2 — what is left is its loads and bookkeeping)
         if (valid && loc == 0xffffffffu) at_add<__HIP_MEMORY_SCOPE_WORKGROUP, uint32_t>((uint32_t *)lds, (uint32_t)vbits);
         return;
     }
@@ -3153,7 +3173,7 @@ void vxh_launch_part_scatter(const PartArgs &args, const LaunchPlan &plan, int s
         block = args.wv * 64;
         const bool hot = args.hot.on == 2, masked = args.nmasks > 0;
         const bool pred = args.A.pred.on != 0; // the shared selection evaluated in the kernel (the host checks: float64 columns only, no conversions)
-        if (pred && (args.val_ct || args.bin_ct || plan.key_i64 || (hot && args.wv_direct != 1 && args.wv_direct != 3))) throw std::runtime_error("vaex_hip internal: fused selection next to a pass 1 that is not instantiated for it");
+        if (pred && (args.val_ct || args.bin_ct || plan.key_i64 || (hot && args.wv_direct != 1 && args.wv_direct != 3 && args.wv_direct != 4))) throw std::runtime_error("vaex_hip internal: fused selection next to a pass 1 that is not instantiated for it");
         const bool pred_v = pred && args.nvals == 1 && args.A.pred.col == args.vdata[0] && !args.val_i64; // the selection reads the value column
 #define VXH_WV(ND)                                                                                                     \
     do {                                                                                                               \
@@ -3203,6 +3223,13 @@ void vxh_launch_part_scatter(const PartArgs &args, const LaunchPlan &plan, int s
         else if (plan.key_i64) { // groupby on an int64 key
             if (args.nvals == 0) { if (masked) VXH_SC((part_scatter_wv<1, 0, true, false, 1>)); else VXH_SC((part_scatter_wv<1, 0, false, false, 1>)); }
             else { if (masked) VXH_SC((part_scatter_wv<1, 1, true, false, 1>)); else VXH_SC((part_scatter_wv<1, 1, false, false, 1>)); }
+        }
+        else if (hot && args.wv_direct == 4) { // the grouped form with register-held groups and chip-wide write bursts: 8 waves
+            if (block > 512) throw std::runtime_error("vaex_hip internal: the phased grouped pass 1 runs with at most 8 waves");
+            if (pred_v) VXH_SC((part_scatter_wv<2, 1, 3, true, 0, 4>));
+            else if (pred) { if (args.nvals == 0) VXH_SC((part_scatter_wv<2, 0, 2, true, 0, 4>)); else VXH_SC((part_scatter_wv<2, 1, 2, true, 0, 4>)); }
+            else if (masked) { if (args.nvals == 0) VXH_SC((part_scatter_wv<2, 0, true, true, 0, 4>)); else VXH_SC((part_scatter_wv<2, 1, true, true, 0, 4>)); }
+            else { if (args.nvals == 0) VXH_SC((part_scatter_wv<2, 0, false, true, 0, 4>)); else VXH_SC((part_scatter_wv<2, 1, false, true, 0, 4>)); }
         }
         else if (hot && args.wv_direct == 3 && pred_v) VXH_SC((part_scatter_wv<2, 1, 3, true, 0, 3>));
         else if (hot && args.wv_direct == 1 && pred_v) VXH_SC((part_scatter_wv<2, 1, 3, true, 0, 1>));
@@ -3298,7 +3325,7 @@ void vxh_launch_part_reduce(const PartArgs &args, const LaunchPlan &plan, hipStr
         if (plan.lds_bytes > 48 * 1024) (void)hipFuncSetAttribute((const void *)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds_bytes); \
         hipLaunchKernelGGL(KERNEL, dim3(plan.blocks), dim3(plan.block), plan.lds_bytes, stream, args);                 \
     } while (0)
-    if (args.wv_direct == 3) { // grouped queue layout (the host checks the signature: what part_reduce_fast serves)
+    if (args.wv_direct == 3 || args.wv_direct == 4) { // grouped queue layout (the host checks the signature: what part_reduce_fast serves)
         if (!fast) throw std::runtime_error("vaex_hip internal: the grouped queue layout needs part_reduce_grp's signature");
         if (args.A.nagg == 1) VXH_RD(part_reduce_grp<1>);
         else if (args.A.nagg == 2) VXH_RD(part_reduce_grp<2>);

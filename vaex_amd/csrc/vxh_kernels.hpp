@@ -82,6 +82,14 @@ enum vxh_strategy : int {
     VXH_STRAT_PART = 4,   // two passes: partition rows into per-slab record queues, then aggregate each slab in LDS
 };
 
+// Timing experiments that make results WRONG on purpose (cold rows dropped, records kept out of HBM, ...) exist only in the ablation build
+// (`make ablate`: -DVXH_ABLATE, a second library under tools/); in the product library the tests below are compile-time zeros.
+#ifdef VXH_ABLATE
+#define VXH_ABL(P, mask) ((P).no_pipeline & (mask))
+#else
+#define VXH_ABL(P, mask) 0
+#endif
+
 #define VXH_PART_MAX_VALS 4
 #define VXH_PART_MAX_MASKS 8
 
@@ -140,6 +148,7 @@ struct PartArgs {
     unsigned long long *qbtab;
     int32_t qbtab_stride, epoch;
     int32_t wv_direct; // part_scatter_wv without rings: cold records go from the registers straight to the queue blocks
+    int32_t wv_phase;  // wv_direct == 4: the bit of the 100 MHz wall clock (s_memrealtime) whose flips are the chip's write bursts (13: every 82 us)
     // part_scatter_wv's queue layout: every (wave, slab) fills BLOCKS of qblk records that it reserves from the
     // sub-queue's counter one at a time (normally a single one per launch: qblk is sized for the wave's expected share),
     // and writes how many records each block really holds into qtab[sub * qtab_stride + block].  Pass 2 walks the
@@ -188,6 +197,7 @@ struct PartArgs {
 // group, written as whole aligned lines (512 B of values + 128 B of uint16 local indices, non-temporal) plus an 8-byte header of
 // the slabs' end offsets.  Pass 2 (part_reduce_grp) reads, of every group, the segment of its own slab.
 #define VXH_WV_GROUP 64u
+#define VXH_WV_HELD 16 /* wv_direct == 4: groups (of 64 records = 3 VGPRs) a wave may hold back between two write bursts */
 #define VXH_WV_WAVE_LDS_GROUPED ((size_t)(2 * VXH_WV_GROUP) * 12 + 128) /* ring of 128 records + 16 group headers waiting for their line */
 #define VXH_WV_WAVE_LDS(NVAL, S) ((((size_t)(S) * VXH_WV_D * (2 + 8 * (size_t)(NVAL)) + (size_t)(S) * 4) + 15) & ~(size_t)15)
 
