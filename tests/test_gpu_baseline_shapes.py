@@ -512,7 +512,7 @@ def test_hot_box_packed_counters_are_exact(sa, scenario):
                 sa.config_set(k, before[k])
         redone = sa.config_get("redo_count") - redo0
         got = [np.array(a.get_result()) for a in aggs]
-        assert sa.last_kernel(0).startswith(("part_scatter_direct_hot", "part_scatter_grouped_hot")), sa.last_kernel(0)
+        assert sa.last_kernel(0).startswith(("part_scatter_direct_hot", "part_scatter_grouped_hot", "part_scatter_phased_hot")), sa.last_kernel(0)
         assert used == dict(normal=2, piled=0, hidden_pile=1, forced_flush=2, queue_overflow=0, pile_and_queue_overflow=0)[scenario], used   # (what the call ENDED on)
         assert redone == dict(normal=0, hidden_pile=1, forced_flush=0, queue_overflow=1).get(scenario, redone), redone
         if scenario in ("piled", "pile_and_queue_overflow"):   # (uint16 -> uint32, or uint8 -> uint16 -> uint32; both flags at once: uint32 at once)
@@ -621,7 +621,7 @@ def test_other_value_dtypes_ride_the_fast_kernels(sa, shape, vdtype):
     if not (narrow and shape in ("three_d", "groupby_key")):
         assert kernel.startswith("part_scatter") and kernel.endswith("_f64" if floats else "_i64"), kernel
     if shape == "bench_2d":
-        assert kernel.startswith(("part_scatter_direct_hot", "part_scatter_grouped_hot")), kernel
+        assert kernel.startswith(("part_scatter_direct_hot", "part_scatter_grouped_hot", "part_scatter_phased_hot")), kernel
     m = 4_000_000
     head, _ = run(0, m)
     rest, _ = run(m, n)
@@ -806,9 +806,9 @@ def test_grouped_pass1(sa, variant, form):
             grid.bin(0, aggs, rows)
             kernel = sa.last_kernel(0)
         finally:
-            sa.config_set("wv", 3); sa.config_set("hot_cache", 1)
+            sa.config_set("wv", 6); sa.config_set("hot_cache", 1)   # (the library's default)
             for k in knobs:
-                sa.config_set(k, 62 if k == "hot_direct_pct" else (13 if k == "wv_phase" else 0))
+                sa.config_set(k, 62 if k == "hot_direct_pct" else (12 if k == "wv_phase" else 0))
         return [np.array(a.get_result()) for a in aggs], kernel
 
     knobs = dict(tiny_blocks=dict(wv_block=64), region_overflow=dict(part_cap=4096), sigma2=dict(hot_direct_pct=20), count_only=dict(strategy=4)).get(variant, {})   # (sigma2: the ring-less family down to a 20 % box, where the default hands over to part_scatter_blk at 62 %)
@@ -852,10 +852,10 @@ def test_grouped_pass1(sa, variant, form):
     cases.assert_case_equal(head, _ref_or_port_case(_ref_module(), case), case)
 
 
-def test_pass1_form_is_chosen_by_a_timed_trial(sa):
-    """round 4: with "wv_auto" on (the library's default; any explicit "wv" switches it off) the first two sampled calls over the same
-    columns run the grouped and the ring-less pass 1 once each under HIP events, the faster one serves from the third call on — the
-    results are the same grids either way."""
+def test_default_pass1_next_to_a_box_is_the_phased_grouped_form(sa):
+    """round 5: without any knob the bench signature runs part_scatter_wv<..., DIRECT = 4> (cold records in slab-sorted groups, held in
+    registers, written in chip-wide bursts) + part_reduce_grp; the timed trial between the grouped and the ring-less form of round 4 is
+    gone (the phased form is ahead of both on every box: profiles/r05_headline_ab.txt).  Same grids as the ring-less form."""
     import torch
     g = torch.Generator(device="cuda").manual_seed(3)
     n = (1 << 26) + 999
@@ -866,20 +866,19 @@ def test_pass1_form_is_chosen_by_a_timed_trial(sa):
     grid = sa.Grid([bx, by])
     aggs = [sa.AggCount_int64(grid, 1, 1), sa.AggSum_float64(grid, 1, 1), sa.AggCount_float64(grid, 1, 1)]
     bx.set_data(0, x); by.set_data(0, y); aggs[1].set_data(0, v, 0); aggs[2].set_data(0, v, 0)
-    sa.config_set("wv_auto", 1)
+    assert sa.config_get("wv") == 6 and sa.config_get("wv_phase") == 12
+    kernels, results = [], []
     try:
-        kernels, results = [], []
-        for _ in range(4):
+        for wv in (6, 6, 3):
+            sa.config_set("wv", wv)
             for a in aggs:
                 a.reset()
             grid.bin(0, aggs, n)
             kernels.append(sa.last_kernel(0))
             results.append([np.array(a.get_result()) for a in aggs])
-        choice = sa.config_get("wv_auto_choice")
     finally:
-        sa.config_set("wv", 5)   # (explicit from here on: the other tests get the kernel they name)
-    assert kernels[0].startswith("part_scatter_grouped_hot") and kernels[1].startswith("part_scatter_direct_hot"), kernels
-    assert choice in (3, 5) and kernels[2] == kernels[3] and kernels[2].startswith("part_scatter_grouped_hot" if choice == 5 else "part_scatter_direct_hot"), (choice, kernels)
+        sa.config_set("wv", 6)
+    assert kernels[0] == kernels[1] == "part_scatter_phased_hot+part_reduce_grp_f64" and kernels[2].startswith("part_scatter_direct_hot"), kernels
     for r in results[1:]:
         assert np.array_equal(r[0], results[0][0]) and np.array_equal(r[2], results[0][2])
         assert np.all(np.abs(r[1] - results[0][1]) <= 1e-12 * 20.0 * np.maximum(results[0][0], 1))

@@ -8,13 +8,13 @@ from tests import cases
 
 pytestmark = pytest.mark.gpu
 
-WV_DEFAULT = 5  # pass 1 next to a hot box: part_scatter_wv, cold records in slab-sorted groups (3: without rings, one record stream per (wave, slab))
-KEYS = ("strategy", "wv", "wv_waves", "wv_waves_direct", "wv_block", "blk", "hot", "hot_min_rows", "hot_min_pct", "hot_x0", "hot_y0", "hot_w", "hot_h", "part_chunk", "count16")
+WV_DEFAULT = 6  # pass 1 next to a hot box: part_scatter_wv, cold records in slab-sorted groups written in chip-wide bursts (5: as they come; 3: without rings, one record stream per (wave, slab))
+KEYS = ("strategy", "wv", "wv_waves", "wv_waves_direct", "wv_block", "blk", "hot", "hot_min_rows", "hot_min_pct", "hot_x0", "hot_y0", "hot_w", "hot_h", "part_chunk", "count16", "wv_phase")
 
 
 def _reset(sa):
     for k in KEYS:
-        sa.config_set(k, {"blk": 1, "hot": 1, "count16": 1, "wv": WV_DEFAULT, "wv_waves": 8, "wv_waves_direct": 16}.get(k, 0))
+        sa.config_set(k, {"blk": 1, "hot": 1, "count16": 1, "wv": WV_DEFAULT, "wv_waves": 8, "wv_waves_direct": 16, "wv_phase": 12}.get(k, 0))
 
 
 @pytest.mark.parametrize("seed", range(160))
@@ -49,11 +49,12 @@ def test_fuzz_against_oracle(sa, gpu_ready, seed):
         sa.config_set("strategy", int(rng.choice([0, 0, 4, 4, 3])))
         sa.config_set("blk", int(rng.choice([1, 2, 0])))
         # third-generation pass 1 (part_scatter_wv): off / auto / also next to a hot box / there without rings, one record
-        # stream per (wave, slab) / per (workgroup, slab) / slab-sorted groups in one stream per wave
-        wv = int(rng.integers(0, 2)) * (1 + seed % 5)
+        # stream per (wave, slab) / per (workgroup, slab) / slab-sorted groups in one stream per wave / ... held back for chip-wide bursts
+        wv = int(rng.integers(0, 2)) * (1 + seed % 6)
         sa.config_set("wv", wv)
         sa.config_set("wv_waves_direct", [16, 8, 4, 12][seed % 4])
         sa.config_set("wv_waves", [4, 6, 8, 12, 16][seed % 5])
+        sa.config_set("wv_phase", [13, 4, 9, 12][seed % 4])   # (the write bursts' wall-clock bit: 4 = a flip every 160 ns)
         sa.config_set("wv_block", [0, 64, 320][seed % 3])  # tiny queue blocks: many blocks per (wave, slab), in-line reservations
         sa.config_set("count16", int(rng.choice([1, 2])))
         if rng.random() < 0.5:

@@ -407,14 +407,15 @@ def test_count16_partition_reduce_opt_in(sa):
 
 
 # ---- hot box: pass 1 of the partition strategy aggregates the densest rectangle of cells in LDS ---------------
-WV_DEFAULT = 5  # pass 1 next to a hot box: part_scatter_wv, cold records in slab-sorted groups, one stream per wave (3: without rings, one record stream per (wave, slab))
+WV_DEFAULT = 6  # pass 1 next to a hot box: part_scatter_wv, cold records in slab-sorted groups held in registers and written in chip-wide bursts (5: written as they come; 3: without rings, one record stream per (wave, slab))
 
 
-@pytest.fixture(params=[1, 2, 3, 4, 5], ids=["blk", "wv_rings", "direct", "shared", "grouped"])
+@pytest.fixture(params=[1, 2, 3, 4, 5, 6], ids=["blk", "wv_rings", "direct", "shared", "grouped", "phased"])
 def hot_pass1(request, sa):
     """The hot-box tests run with every pass-1 kernel that can sit next to a box: part_scatter_blk ("wv" 1),
     part_scatter_wv with rings (2), without rings and one record stream per (wave, slab) (3) / per (workgroup, slab) (4), with slab-sorted
-    groups in one stream per wave (5: <= 8 slabs, otherwise it is 3)."""
+    groups in one stream per wave (5: <= 8 slabs, otherwise it is 3), the same with the groups held in registers between chip-wide write
+    bursts (6, round 5: the default)."""
     sa.config_set("wv", request.param)
     yield request.param
     sa.config_set("wv", WV_DEFAULT)
@@ -470,7 +471,7 @@ def test_hot_box_forced(sa, hot_pass1):
         # ONE selection mask shared by every aggregator: the box stays (next to the ring-less pass 1 if that was asked for, else part_scatter_blk)
         m = case["binners"][0]["data"] > 0
         check(sa, dict(case, aggs=[dict(a, mask=m) for a in case["aggs"]]))
-        assert sa.config_get("hot_w") == 1 and sa.last_kernel(0).startswith(("part_scatter_direct_hot", "part_scatter_grouped_hot") if hot_pass1 in (3, 5) else "part_scatter_hot")
+        assert sa.config_get("hot_w") == 1 and sa.last_kernel(0).startswith(("part_scatter_direct_hot", "part_scatter_grouped_hot", "part_scatter_phased_hot") if hot_pass1 in (3, 5, 6) else "part_scatter_hot")
         for box in ((100, 110, 60, 50), (0, 0, 92, 92)):
             for k, val in zip(("hot_x0", "hot_y0", "hot_w", "hot_h"), box):
                 sa.config_set(k, val)
@@ -506,7 +507,7 @@ def test_float32_columns_take_the_typed_kernels(sa):
             for k, val in zip(("hot_x0", "hot_y0", "hot_w", "hot_h"), box):
                 sa.config_set(k, val)
             check(sa, dict(n=n, binners=b2, aggs=aggs))
-            assert sa.config_get("hot_w") == box[2] and sa.last_kernel(0).startswith(("part_scatter_hot", "part_scatter_direct_hot", "part_scatter_grouped_hot")), sa.last_kernel(0)
+            assert sa.config_get("hot_w") == box[2] and sa.last_kernel(0).startswith(("part_scatter_hot", "part_scatter_direct_hot", "part_scatter_grouped_hot", "part_scatter_phased_hot")), sa.last_kernel(0)
             check(sa, dict(n=n, binners=b2, aggs=[dict(a, mask=m) for a in aggs]))
             if box[2] * box[3] * 20 < 100_000:  # (20-byte cells with the sum of squares)
                 check(sa, dict(n=n, binners=b2, aggs=[dict(kind="count", data=v), dict(kind="sum", data=v), dict(kind="summoment", data=v, moment=2)]))

@@ -201,3 +201,35 @@ def test_heavy_key_sampler_host_logic():
     # uniform keys: none
     u = Frame(dict(k=rng.integers(0, 1_000_000, n).astype(np.int64), v=np.zeros(n)))
     assert u._heavy_keys("k", u.columns["k"], share=1 / 1024) is None
+
+
+def test_the_product_library_ships_no_ablation_switches():
+    """timing experiments that make results wrong on purpose are not reachable through the product's C-ABI.
+    vxh_config_set takes `no_pipeline` bits 1 / 16 only (A/B switches to the generic kernels, results unchanged), refuses every other
+    bit and `gb_abl` by name, and the knobs that lost their A/B are gone; the sources keep such branches behind VXH_ABL / VXH_GB_ABL,
+    compile-time zeros unless the ablation build (`make ablate` -> tools/ablate/) defines VXH_ABLATE.  No device needed."""
+    import re
+    import pytest
+    import vaex_amd
+    sa = vaex_amd.superagg
+    for ok in (0, 1, 16, 17, 0):
+        sa.config_set("no_pipeline", ok)
+        assert sa.config_get("no_pipeline") == ok
+    for bits in (2, 64, 128, 256, 512, 1024, 2048, 8192, 64 | 1):
+        with pytest.raises(RuntimeError, match="ablation build"):
+            sa.config_set("no_pipeline", bits)
+    assert sa.config_get("no_pipeline") == 0
+    with pytest.raises(RuntimeError, match="ablation build"):
+        sa.config_set("gb_abl", 1)
+    for gone in ("merge_fused", "gb_known_count", "f64_rec12"):
+        with pytest.raises(RuntimeError, match="unknown config key"):
+            sa.config_set(gone, 1)
+    csrc = os.path.join(ROOT, "vaex_amd", "csrc")
+    for f in os.listdir(csrc):
+        if f.endswith((".hip", ".hpp", ".cpp")):
+            src = open(os.path.join(csrc, f)).read()
+            assert "wrong on purpose" not in src, f
+            # a kernel may look at the experiment bits only through the macros (bits 1 and 16 are the launchers' strategy switches)
+            for m in re.finditer(r"no_pipeline & (\d+)", src):
+                assert int(m.group(1)) in (1, 16, 17), (f, m.group(0))
+            assert not re.search(r"[GP]\.abl &", src), f

@@ -47,7 +47,7 @@ for bname, tdt in (("int64", torch.int64), ("int32", torch.int32)):
     yi = torch.randint(0, 1024, (rows,), dtype=torch.int64, device="cuda", generator=g).to(tdt)
     B = getattr(sa, "BinnerScalar_" + bname)
     for knob in (1, 0):   # 0: what ran before (the generic pair)
-        sa.config_set("wv", 5 if knob else 0); sa.config_set("blk", 1 if knob else 0)
+        sa.config_set("wv", 6 if knob else 0); sa.config_set("blk", 1 if knob else 0)
         bx = B(1, "x", 0.0, 1024.0, 256); by = B(1, "y", 0.0, 1024.0, 256)
         grid = sa.Grid([bx, by])
         v = vals["float64"]
@@ -65,5 +65,5 @@ for bname, tdt in (("int64", torch.int64), ("int32", torch.int32)):
         assert int(np.array(aggs[0].get_result()).sum()) == rows
         bpr = 2 * xi.element_size() + 8
         print(f"binners {bname:<7} value float64 (256x256 uniform) {best:8.3f} ms {rows/best/1e6:7.1f} Grows/s  {rows*bpr/best/1e6/8000:6.3f} of 8 TB/s on {bpr} B/row   {sa.last_kernel(0)}", flush=True)
-    sa.config_set("wv", 5); sa.config_set("blk", 1)
+    sa.config_set("wv", 6); sa.config_set("blk", 1)
     del xi, yi

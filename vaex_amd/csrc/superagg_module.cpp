@@ -14,6 +14,7 @@
 // the reference: set_data / set_data_mask also accept objects exposing __cuda_array_interface__
 // (e.g. torch tensors on the GPU) — HBM-resident columns are then used in place.
 #include <pybind11/numpy.h>
+#include <atomic>
 #include <pybind11/pybind11.h>
 #include <pybind11/stl.h>
 
@@ -310,6 +311,10 @@ struct TBinnerHash : PyBinnerHash {
 // ------------------------------------------------------------------------------------------
 // grid
 // ------------------------------------------------------------------------------------------
+// page-locked bytes currently owned by result arrays (get_result): capped, see there
+static std::atomic<size_t> g_pinned_result_bytes{0};
+static constexpr size_t kPinnedResultBudget = (size_t)1 << 30;
+
 struct PyAgg;
 struct PyGrid {
     vxh_grid *h = nullptr;
@@ -429,12 +434,20 @@ struct PyAgg {
         // Page-locked memory from the library's host block cache for anything beyond a few pages: a device-to-host copy into
         // pageable memory is staged by the runtime (18 MB of a 128^3 count grid: 1.17 ms against 0.33 ms; the 0.5 MB grids of the
         // bench pass: ~60 us against ~15 us each).  The array owns the block and gives it back to the cache when it dies.
+        //  Bounded: results a caller keeps alive hold at most kPinnedResultBudget of page-locked memory between them — beyond
+        // that, and whenever the pinned allocation fails, the result is an ordinary pageable array (slower copy, never an error).
         const size_t bytes = (size_t)vxh_grid_length1d(grid->h) * (size_t)isz;
         py::array out;
-        if (bytes >= (64u << 10)) {
-            void *p = nullptr;
-            check(vxh_host_alloc(bytes, &p));
-            py::capsule owner(p, [](void *q) { vxh_host_free(q); });
+        void *p = nullptr;
+        if (bytes >= (64u << 10) && g_pinned_result_bytes.load() + bytes <= kPinnedResultBudget && vxh_host_alloc(bytes, &p) == 0 && p) {
+            g_pinned_result_bytes += bytes;
+            struct Block { void *p; size_t bytes; };
+            py::capsule owner(new Block{p, bytes}, [](void *q) {
+                Block *b = (Block *)q;
+                vxh_host_free(b->p); // (back to the library's host block cache — an object that is never destroyed, so this is safe during interpreter shutdown)
+                g_pinned_result_bytes -= b->bytes;
+                delete b;
+            });
             out = py::array(np_dtype, shape, strides, p, owner);
         } else {
             out = py::array(np_dtype, shape, strides);

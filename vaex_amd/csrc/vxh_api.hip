@@ -102,8 +102,6 @@ Slot &get_slot(int thread) {
         HIP_CHECK(hipEventCreate(&s->t0));
         HIP_CHECK(hipEventCreate(&s->t1));
         HIP_CHECK(hipEventCreate(&s->t_lap));
-        HIP_CHECK(hipEventCreate(&s->t_trial0));
-        HIP_CHECK(hipEventCreate(&s->t_trial1));
         HIP_CHECK(hipStreamCreateWithFlags(&s->stream2, hipStreamNonBlocking));
         for (auto &pb : s->part) {
             HIP_CHECK(hipEventCreateWithFlags(&pb.scattered, hipEventDisableTiming));
@@ -1058,24 +1056,10 @@ static void hot_prepare(Slot &slot, const BinArgs &A, const BinArgs &planned, co
     const bool f32b = plan.bin_f32 && !plan.fast_f32 && (plan.fast_vals || plan.vals_i64); // float32 binners next to an 8-byte value column
     const bool ints = (plan.bin_f64 && (plan.vals_i64 || plan.vals_i32 || plan.vals_f32)) || f32b; // integer sums / 4-byte columns converted on load: part_scatter_wv's instantiations only
     const bool f32all = plan.fast_f32 && nval == 1; // float32 binners AND value column: the ring-less part_scatter_wv converts both on load; otherwise part_scatter_blk's float instantiation
-    // Grouped (5) or ring-less (3) pass 1?  The two are within 2 % of each other and WHICH one is ahead depends on the box the process
-    // landed on (profiles/r04_headline_ab.txt: 4.98 vs 5.09 ms on one, 5.13 vs 5.02 on another — how its memory side takes 1 GB of
-    // queue writes under 24 GB of reads).  So with "wv" = 5 and "wv_auto" on, the first two sampled calls over the same columns time one
-    // each (HIP events around the passes) and the faster one serves from then on; calls whose sample is not remembered take the
-    // process's last decision.
-    {
-        const double lim0[6] = {A.b[0].vmin, A.b[0].scale, A.b[0].binsd, A.b[1].vmin, A.b[1].scale, A.b[1].binsd};
-        const bool same_key = c.cfg_hot_cache && H.key_fraction >= 0 && H.key_ptr[0] == A.b[0].data && H.key_ptr[1] == A.b[1].data && H.key_len == length &&
-                              H.key_grid.size() == A.cells && memcmp(H.key_lim, lim0, sizeof(lim0)) == 0;
-        if (!same_key) H.auto_state = 0;
-        H.wv_trial = -1;
-        H.wv_mode = c.cfg_wv;
-        if (c.cfg_wv == 5 && c.cfg_wv_auto && !c.cfg_wv_user_set && !forced) { // (a caller that SET "wv" gets exactly that kernel)
-            if (H.auto_state >= 2) H.wv_mode = H.auto_choice;
-            else if (!same_key && c.wv_auto_last) H.wv_mode = c.wv_auto_last;                 // (the first call over new columns: the process's last decision; its sample is taken now)
-            else if (length >= (1ull << 26)) { H.wv_trial = H.auto_state; H.wv_mode = H.auto_state == 0 ? 5 : 3; }
-        }
-    }
+    // (Round 4 let the first two sampled calls over new columns time the grouped and the ring-less pass 1 once each and kept the faster:
+    //  the two were within 2 % of each other, box by box.  Round 5's phased form is 5-7 % ahead of the grouped one and ~10 % ahead of
+    //  the ring-less one on every box measured — profiles/r05_headline_ab.txt — so the trial and its knobs are gone.)
+    H.wv_mode = c.cfg_wv;
     const WvGeom wg = wv_geometry(S, nval, true, plan.vals_i32 || plan.vals_f32 || f32b || f32all, H.wv_mode);
     bool wv = wg.ok && slab_cells < 65535 && wv_aligned(A); // (= run_part_chunk's conditions for part_scatter_wv)
     if (f32all && wg.direct != 1) wv = false;
@@ -1087,7 +1071,7 @@ static void hot_prepare(Slot &slot, const BinArgs &A, const BinArgs &planned, co
     // a forced box (tests / experiments) too big for what part_scatter_wv's rings leave of the LDS goes to part_scatter_blk
     // uint16 counters (two per LDS word) next to the ring-less pass 1 with one value column: 10-byte cells instead of 12
     // ... uint8 counters (four per word, 9-byte cells) where the fullest cell fills slowly enough for a flush every few hundred tiles
-    const int shift_max = (nval == 1 && !mom2 && wg.ok && (wg.direct == 1 || wg.direct >= 3)) ? (int)std::max<int64_t>(0, std::min<int64_t>(std::min<int64_t>(c.cfg_hot_cnt16, H.max_shift), (c.cfg_no_pipeline & 1024) ? 1 : 2)) : 0;
+    const int shift_max = (nval == 1 && !mom2 && wg.ok && (wg.direct == 1 || wg.direct >= 3)) ? (int)std::max<int64_t>(0, std::min<int64_t>(std::min<int64_t>(c.cfg_hot_cnt16, H.max_shift), 2)) : 0;
     const bool c16 = shift_max >= 1;
     int shift = c16 ? 1 : 0; // (uint8 is decided below, from the sample)
     H.cnt16 = false;
@@ -1499,11 +1483,9 @@ static void run_part_chunk(Slot &slot, const BinArgs &planned, const LaunchPlan 
             P.epoch = slot.epoch;
         }
     }
-    // 12-byte records {value, local index}: the ring-less pass 1 next to a box (one store per cold row), and — round 4, "f64_rec12" —
-    // the staged pass 1 of calls with >= 128 slabs and one value column (a groupby's key range): ONE record stream per sub-queue
-    // instead of a value stream and an index stream, i.e. half as many streams growing (what the memory side is sensitive to)
-    const bool rec12_f64 = c.cfg_f64_rec12 && !(c.cfg_no_pipeline & 17) && !wv && S >= 128 && !slot.hot.on && c.cfg_blk != 2 && P.nvals == 1 && !P.use_flags && P.idx16 && vxh_part_reduce_is_fast(P, plan);
-    const bool rec12 = (wv && (wg.direct == 1 || wg.direct == 2) && P.nvals == 1) || rec12_f64;
+    // 12-byte records {value, local index}: the ring-less pass 1 next to a box (one store per cold row).  (Round 4 also tried them for
+    // the staged pass 1 of a groupby's key range — one stream per sub-queue instead of two: 9.69-9.78 vs 9.75-9.83 ms, removed.)
+    const bool rec12 = wv && (wg.direct == 1 || wg.direct == 2) && P.nvals == 1;
     P.qrec12 = rec12 ? 1 : 0;
     const size_t idx_bytes = rec12 ? 12 : (P.idx16 ? 2 : 4);
     size_t off = 0;
@@ -1632,7 +1614,6 @@ static void run_part_chunk(Slot &slot, const BinArgs &planned, const LaunchPlan 
     if (wv) { // no super-block deeper than a workgroup's share of the launch (and the tile arithmetic stays inside 32 bits)
         const uint64_t tiles = (P.A.n + 255) / 256, per_wg = (tiles + (uint64_t)scatter_blocks * P.wv - 1) / ((uint64_t)scatter_blocks * P.wv);
         P.wv_span = (int32_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)P.wv_span, per_wg));
-        if (c.cfg_no_pipeline & 1024) P.wv_span = 1; // (the three-buffer experiment deals tiles one by one)
     }
     slot.last_pass1 = wv ? (P.wv_direct ? 2 + P.wv_direct : 2) : (blk ? 1 : 0);
     slot.last_slabs = (int)S;
@@ -1864,7 +1845,14 @@ int vxh_config_set(const char *key, int64_t value) {
     else if (k == "parts") c.cfg_parts = value;
     else if (k == "part_lds") c.cfg_part_lds = value;
     else if (k == "part_rows") c.cfg_part_rows = value;
-    else if (k == "no_pipeline") c.cfg_no_pipeline = value;
+    else if (k == "no_pipeline") {
+        // bit 0: the generic pass-1 kernel, bit 4: the generic pass 2 (A/B switches with correct results).  Every other bit is a timing
+        // experiment of the ablation build (`make ablate`, tools/ablate/): cold rows dropped, records kept out of HBM, ... — not in this library
+#ifndef VXH_ABLATE
+        if (value & ~(int64_t)17) throw std::runtime_error("no_pipeline: bits other than 1 and 16 are timing experiments of the ablation build (make -C vaex_amd/csrc ablate)");
+#endif
+        c.cfg_no_pipeline = value;
+    }
     else if (k == "part_overlap") c.cfg_part_overlap = value;
     else if (k == "count16") c.cfg_count16 = value;
     else if (k == "count_fast") c.cfg_count_fast = value;
@@ -1873,20 +1861,21 @@ int vxh_config_set(const char *key, int64_t value) {
     else if (k == "hot_cnt16") c.cfg_hot_cnt16 = value;
     else if (k == "hot_flush_trips") c.cfg_hot_flush_trips = value;
     else if (k == "blk") c.cfg_blk = value;
-    else if (k == "wv") { c.cfg_wv = value; c.cfg_wv_user_set = true; }
+    else if (k == "wv") c.cfg_wv = value;
     else if (k == "wv_waves") c.cfg_wv_waves = value > 0 ? value : 8;
     else if (k == "wv_waves_direct") c.cfg_wv_waves_direct = value > 0 ? value : 16;
     else if (k == "wv_waves_grouped") c.cfg_wv_waves_grouped = value > 0 ? value : 8;
     else if (k == "wv_span") c.cfg_wv_span = value > 0 ? value : 1;
     else if (k == "wv_block") c.cfg_wv_block = value;
     else if (k == "part_cap") c.cfg_part_cap = value;
-    else if (k == "merge_fused") c.cfg_merge_fused = value;
-    else if (k == "wv_auto") { c.cfg_wv_auto = value; c.wv_auto_last = 0; if (value) { c.cfg_wv = 5; c.cfg_wv_user_set = false; } }
     else if (k == "gb_compact") c.cfg_gb_compact = value;
-    else if (k == "gb_abl") c.cfg_gb_abl = value;
-    else if (k == "f64_rec12") c.cfg_f64_rec12 = value;
+    else if (k == "gb_abl") {
+#ifndef VXH_ABLATE
+        throw std::runtime_error("gb_abl: a timing experiment of the ablation build (make -C vaex_amd/csrc ablate)");
+#endif
+        c.cfg_gb_abl = value;
+    }
     else if (k == "gb_sets") c.cfg_gb_sets = value > 0 ? value : 8;
-    else if (k == "gb_known_count") c.cfg_gb_known_count = value;
     else if (k == "gb_load_pct") c.cfg_gb_load_pct = value > 0 ? value : 50;
     else if (k == "fuse_selection") c.cfg_fuse_selection = value;
     else if (k == "hot_chunk_factor") c.cfg_hot_chunk_factor = value > 0 ? value : 4;
@@ -1942,14 +1931,9 @@ int vxh_config_get(const char *key, int64_t *value) {
     else if (k == "hot_direct_pct") *value = c.cfg_hot_direct_pct;
     else if (k == "wv_block") *value = c.cfg_wv_block;
     else if (k == "part_cap") *value = c.cfg_part_cap;
-    else if (k == "merge_fused") *value = c.cfg_merge_fused;
-    else if (k == "wv_auto") *value = c.cfg_wv_auto;
-    else if (k == "wv_auto_choice") *value = get_slot(0).hot.auto_state >= 2 ? get_slot(0).hot.auto_choice : 0;
     else if (k == "gb_compact") *value = c.cfg_gb_compact;
     else if (k == "gb_abl") *value = c.cfg_gb_abl;
-    else if (k == "f64_rec12") *value = c.cfg_f64_rec12;
     else if (k == "gb_sets") *value = c.cfg_gb_sets;
-    else if (k == "gb_known_count") *value = c.cfg_gb_known_count;
     else if (k == "gb_load_pct") *value = c.cfg_gb_load_pct;
     else if (k == "fuse_selection") *value = c.cfg_fuse_selection;
     else if (k == "pred_fused") *value = get_slot(0).pred_fused;
@@ -1969,6 +1953,7 @@ int vxh_config_get(const char *key, int64_t *value) {
     else if (k == "first_mask_block") *value = c.cfg_first_mask_block;
     else if (k == "nunique_row_counts") *value = c.cfg_nunique_row_counts;
     else if (k == "cus") { ensure_device_ready(); *value = c.cus; }
+    else if (k == "device") *value = c.device; // (the device vxh_set_device chose: whoever asks another runtime about free memory asks about THIS one)
     else throw std::runtime_error("unknown config key: " + k);
     VXH_API_END
 }
@@ -2353,9 +2338,6 @@ int vxh_grid_bin(vxh_grid *grid, int thread, vxh_agg *const *aggs, int n_aggs, u
             bool armed;
             ~PartGuard() { if (armed) { slot.acc_sig = 0; slot.hot.on = false; } }
         } part_guard{slot, whole.strategy == VXH_STRAT_PART};
-        const bool trial = whole.strategy == VXH_STRAT_PART && slot.hot.on && slot.hot.wv_trial >= 0 && slot.hot.wv && slot.t_trial0;
-        const unsigned redo_before = slot.redo_count;
-        if (trial) HIP_CHECK(hipEventRecord(slot.t_trial0, slot.stream));
         for (int attempt = 0; attempt < 3; ++attempt) {
         for (uint64_t r0 = 0; r0 < length; r0 += step) {
             const uint64_t rn = std::min(step, length - r0);
@@ -2425,37 +2407,12 @@ int vxh_grid_bin(vxh_grid *grid, int thread, vxh_agg *const *aggs, int n_aggs, u
         }
         if (whole.strategy == VXH_STRAT_PART) {
             part_join(slot);
-            const bool fused_merge = slot.hot.on && ctx().cfg_merge_fused != 0; // both merges in one launch ("merge_fused" = 0: the two kernels of rounds 1-3)
-            if (fused_merge) {
-                const HotMergeArgs hm = hot_merge_args(slot, whole_args);
-                vxh_launch_merge_fused(part_merge_args(slot, whole_args), &hm, slot.stream);
-                HIP_CHECK(hipGetLastError());
-            } else {
-                part_acc_merge(slot, whole_args);
-            }
+            part_acc_merge(slot, whole_args); // (one fused launch of both merges was 5.204 vs 5.174 ms in round 4 — its grid adds are all atomics; removed)
             if (slot.last_pass1 >= 2) slot.last_kernel = (whole.fast_f64 || whole.fast_f32 || whole.vals_f32 || ((whole.bin_f32 || whole.bin_i64 || whole.bin_i32) && whole.fast_vals)) ? "part_scatter_wv+part_reduce_f64" : ((whole.vals_i64 || whole.vals_i32) ? "part_scatter_wv+part_reduce_i64" : "part_scatter_wv+part_reduce_generic");
             if (slot.hot.on) {
-                if (!fused_merge) hot_merge(slot, whole_args);
+                hot_merge(slot, whole_args);
                 slot.hot.acc_zero_sig = slot.hot.acc_layout_sig; // (the merge zeroes what it folds)
                 slot.last_kernel = slot.last_pass1 == 6 ? ((whole.vals_i64 || whole.vals_i32) ? "part_scatter_phased_hot+part_reduce_grp_i64" : "part_scatter_phased_hot+part_reduce_grp_f64") : slot.last_pass1 == 5 ? ((whole.vals_i64 || whole.vals_i32) ? "part_scatter_grouped_hot+part_reduce_grp_i64" : "part_scatter_grouped_hot+part_reduce_grp_f64") : slot.last_pass1 == 4 ? "part_scatter_shared_hot+part_reduce_f64" : slot.last_pass1 == 3 ? ((whole.vals_i64 || whole.vals_i32) ? "part_scatter_direct_hot+part_reduce_i64" : "part_scatter_direct_hot+part_reduce_f64") : (slot.last_pass1 == 2 ? "part_scatter_wv_hot+part_reduce_f64" : "part_scatter_hot+part_reduce_f64");
-            }
-            if (trial) { // one of the two timed calls of the grouped / ring-less decision (hot_prepare)
-                HIP_CHECK(hipEventRecord(slot.t_trial1, slot.stream));
-                HIP_CHECK(hipEventSynchronize(slot.t_trial1));
-                float ms = 0;
-                HIP_CHECK(hipEventElapsedTime(&ms, slot.t_trial0, slot.t_trial1));
-                Slot::Hot &H = slot.hot;
-                const bool was_that_kernel = (H.wv_trial == 0) == (slot.last_pass1 == 5);
-                if (slot.redo_count == redo_before && was_that_kernel && H.auto_state == H.wv_trial) { // (a rerun's time says nothing; neither does a call that fell to another pass 1)
-                    H.auto_t[H.auto_state] = (double)ms / (double)length;
-                    if (++H.auto_state == 2) {
-                        H.auto_choice = H.auto_t[0] <= H.auto_t[1] ? 5 : 3;
-                        ctx().wv_auto_last = H.auto_choice;
-                    }
-                } else if (!was_that_kernel) { // the grouped form does not serve this signature (> 8 slabs, converted columns): nothing to decide
-                    H.auto_state = 2;
-                    H.auto_choice = 5;
-                }
             }
             slot.hot.on = false;
             part_guard.armed = false;

@@ -33,6 +33,12 @@
 // Partial results (multi-chunk inputs, other ranks' results) are merged by the same two kernels in MERGE mode.
 #include "vxh_internal.hpp"
 
+#ifdef VXH_ABLATE
+#define VXH_GB_ABL(G, mask) ((G).abl & (mask))
+#else
+#define VXH_GB_ABL(G, mask) 0
+#endif
+
 #include <string.h> // (rocPRIM's texture_cache_iterator.hpp calls memset without including it)
 
 #include <rocprim/rocprim.hpp>
@@ -118,7 +124,7 @@ struct GbArgs {
     const long long *heavy_keys;   // [n_heavy] distinct, none of them INT64_MIN
     int32_t n_heavy;
     unsigned long long *heavy_acc; // [n_heavy][1 + 3 nv]: rows, then per value column count, sum bits, sum2 bits
-    int32_t abl;            // timing experiments ("gb_abl"; results wrong on purpose): 1 = gb_scatter's copy-out computes but does not store, 2 = no copy-out, 4 = no staging and no copy-out
+    int32_t abl;            // timing experiments ("gb_abl", the ablation build only — VXH_GB_ABL is a compile-time zero in the product library): 1 = gb_scatter's copy-out computes but does not store, 2 = no copy-out, 4 = no staging and no copy-out
     long long kc_min;
     uint64_t kc_a_inv, kc_b_inv; // inverses of the two multipliers modulo 2^64
     // results (unsorted)
@@ -353,7 +359,7 @@ __global__ void __launch_bounds__(1024) gb_scatter(const GbArgs G) {
         // [C] stage sorted by bucket
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            if (ok[r] && !(G.abl & 4)) {
+            if (ok[r] && !VXH_GB_ABL(G, 4)) {
                 const uint32_t j = off[bucket[r]] + pos[r];
                 st_key[j] = (uint64_t)key[r];
 #pragma unroll
@@ -363,16 +369,16 @@ __global__ void __launch_bounds__(1024) gb_scatter(const GbArgs G) {
         }
         __syncthreads();
         // [D] copy out: consecutive threads -> consecutive records of a bucket's segment
-        for (uint32_t j = tid; j < ((G.abl & 6) ? 0u : total); j += 1024u) {
+        for (uint32_t j = tid; j < (VXH_GB_ABL(G, 6) ? 0u : total); j += 1024u) {
             const uint32_t b = st_b[j];
             const unsigned long long base = gbase[b];
             if (base == ~0ull) continue; // (stream full: flagged, the host retries with more room)
             uint64_t dst = base + (j - off[b]);
-            if (G.abl & 1) { if (st_key[j] != 0x123456789abcdefull) continue; dst = 0; } // (the staged words are read, nothing is stored)
+            if (VXH_GB_ABL(G, 1)) { if (st_key[j] != 0x123456789abcdefull) continue; dst = 0; } // (the staged words are read, nothing is stored)
             if (W == 1 && G.kc_bits) { // 12-byte record {remainder, payload}
                 const uint64_t c2 = st_w[j];
                 const gb_u32x3_a4 rec = gb_u32x3_a4{(uint32_t)st_key[j], (uint32_t)c2, (uint32_t)(c2 >> 32)};
-                if (G.abl & 8) __builtin_nontemporal_store(rec, (gb_u32x3_a4 *)((uint32_t *)G.qrec + dst * 3)); // (experiment: non-temporal)
+                if (VXH_GB_ABL(G, 8)) __builtin_nontemporal_store(rec, (gb_u32x3_a4 *)((uint32_t *)G.qrec + dst * 3)); // (experiment: non-temporal)
                 else *(gb_u32x3_a4 *)((uint32_t *)G.qrec + dst * 3) = rec;
             } else if (W == 1) { // one 16-byte record {key, payload}: a tile's segment of a bucket is 16 B x its records, contiguous
                 const uint64_t a = st_key[j], c2 = st_w[j];
@@ -813,20 +819,9 @@ unsigned run_pipeline(GbArgs &G, int nv, bool merge, uint64_t n, uint64_t groups
     const int64_t load_pct = ctx().cfg_gb_load_pct;
     const uint64_t per_bucket = std::max<uint64_t>(64, (uint64_t)lines * 4 * (uint64_t)std::min<int64_t>(95, std::max<int64_t>(10, load_pct)) / 100);
     while (nb_log2 < nb_max && ((uint64_t)1 << nb_log2) * per_bucket < std::max<uint64_t>(groups_hint, 1)) nb_log2++;
-    // "gb_known_count" (off): a KNOWN number of groups (the count an earlier call over the same key column returned) sizes the buckets
-    // at mean + 4 sigma under gb_reduce's table limit — 256 buckets at 76 % mean load for 1e6 groups instead of 512 at 38 %.  Measured
-    // (round 4, profiles/r04_groupby_compact.txt): the scatter gains what microbench5 promised (8.25 -> 7.2 ms per 1e9 rows), but
-    // gb_reduce goes from 3.8 to 20 ms — a wave's probe costs what its LONGEST chain of 64 costs, and linear probing over lines at
-    // 76 % load has a long tail.  Tables stay at <= 50 % of their slots.
-    if (hint_is_a_count && ctx().cfg_gb_known_count) {
-        const double cap = 0.86 * (double)lines * 4.0;
-        int nb = 6;
-        for (; nb < nb_max; ++nb) {
-            const double mean = (double)groups_hint / (double)((uint64_t)1 << nb);
-            if (mean + 4.0 * std::sqrt(mean) + 8.0 <= cap) break;
-        }
-        nb_log2 = std::min(nb_log2, nb);
-    }
+    // (Round 4 sized the buckets for a KNOWN group count at 76 % mean load — 256 buckets instead of 512 for 1e6 groups: the scatter gained
+    //  what microbench5 promised, 8.25 -> 7.2 ms per 1e9 rows, gb_reduce went from 3.8 to 20 ms — a wave's probe costs what its LONGEST
+    //  chain of 64 costs.  profiles/r04_groupby_compact.txt; removed in round 5: tables stay at <= 50 % of their slots.)
     struct Events { // (destroyed on every way out, a throwing launch included)
         hipEvent_t e[3] = {nullptr, nullptr, nullptr};
         Events() { for (auto &x : e) HIP_CHECK(hipEventCreate(&x)); }
@@ -850,7 +845,9 @@ unsigned run_pipeline(GbArgs &G, int nv, bool merge, uint64_t n, uint64_t groups
         G.nb_log2 = nb_log2; G.slots_log2 = 0; G.lines = lines;
         const bool compact = ctx().cfg_gb_compact && w == 1 && !merge && key_bits > nb_log2 && key_bits - nb_log2 <= 32;
         G.kc_bits = compact ? key_bits : 0;
+#ifdef VXH_ABLATE
         G.abl = (int32_t)ctx().cfg_gb_abl;
+#endif
         G.kc_min = key_min;
         G.kc_a_inv = inverse_mod_2_64(GB_KC_A);
         G.kc_b_inv = inverse_mod_2_64(GB_KC_B);

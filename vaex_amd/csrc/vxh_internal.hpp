@@ -124,7 +124,6 @@ struct Slot {
     hipStream_t copy_stream = nullptr;
     int cur = 0;
     hipEvent_t t0 = nullptr, t1 = nullptr;
-    hipEvent_t t_trial0 = nullptr, t_trial1 = nullptr; // around the passes of a call that times one of the two pass-1 forms (Hot::wv_trial)
     hipEvent_t t_lap = nullptr; // recorded behind the last KERNEL of a call (before its results cross PCIe): vxh_timer_kernels_ms
     bool lap_set = false;
     hipEvent_t after_null = nullptr; // order_after_producers()
@@ -165,11 +164,6 @@ struct Slot {
         int blocks = 0;          // pass-1 workgroups (= accumulator blocks)
         void *acc = nullptr;     // [blocks][w*h] double sums, then [blocks][w*h] u64 counts
         size_t acc_cap = 0;
-        // grouped (5) vs ring-less (3) pass 1, decided per sampled columns by timing one call of each ("wv_auto")
-        int auto_state = 0;        // calls timed so far (0: none, 1: the grouped one, 2: decided)
-        int auto_choice = 5;
-        double auto_t[2] = {0, 0}; // ms per row: grouped, ring-less
-        int wv_trial = -1;         // this call is trial number ... (-1: not a trial)
         int64_t wv_mode = 5;       // the "wv" mode of this call
         uint64_t acc_zero_sig = 0, acc_layout_sig = 0; // layout the accumulators are known to be all-zero for (0: not known) / layout of the current call
         void *sample = nullptr;  // cells x int64: count grid of the sample
@@ -205,9 +199,6 @@ struct Context {
     int cus = 256;
     size_t max_lds = 65536;
     Slot *slots[VXH_MAX_SLOTS] = {};
-    int64_t cfg_wv_auto = 1;  // "wv" = 5: time the grouped and the ring-less pass 1 once each per sampled columns, keep the faster (0: always grouped)
-    bool cfg_wv_user_set = false; // vxh_config_set("wv", ...) was called: no trials, the caller's kernel
-    int wv_auto_last = 0;     // the most recent decision of this process (0: none yet): what calls without a remembered sample take
     hipEvent_t reduced = nullptr; // recorded on slot 0's stream behind the latest vxh_allreduce
     bool reduced_set = false;
     // tuning knobs (vxh_config_set)
@@ -216,7 +207,7 @@ struct Context {
     int64_t cfg_block = 0;
     int64_t cfg_blocks = 0;
     int64_t cfg_wv_blocks = 0;    // part_scatter_wv: workgroups of the launch (0 = one per CU)
-    int64_t cfg_wv_phase = 13;    // "wv" = 6: bit of the 100 MHz wall clock whose flips are the chip's write bursts (13: every 82 us)
+    int64_t cfg_wv_phase = 12;    // "wv" = 6: bit of the 100 MHz wall clock whose flips are the chip's write bursts (12: every 41 us — 11 / 12 / 13 / 14: 4.64 / 4.58 / 4.60 / 4.68 ms on the bench pass)
     int64_t cfg_stage_bytes = 64 << 20;
     int64_t cfg_feeder = 1;       // host chunks: 1 copy stream + arena ring, 2 the same through page-locked buffers (see Slot::Stage), 0 copies on the compute stream
     int64_t cfg_cache_bytes = 64ll << 30; // device column cache budget (only ranges registered with vxh_cache_register are cached)
@@ -228,20 +219,19 @@ struct Context {
     int64_t cfg_parts = 0;        // pass-2 workgroups per slab (0 = auto)
     int64_t cfg_part_lds = 0;     // LDS bytes per pass-2 slab (0 = auto)
     int64_t cfg_blk = 1;           // second-generation pass 1 (part_scatter_blk) where its signature allows (0: part_scatter_f64)
-    int64_t cfg_wv = 5;            // third-generation pass 1 (part_scatter_wv: barrier-free): 0 = never; >= 1: with wave-private rings wherever its
+    int64_t cfg_wv = 6;            // third-generation pass 1 (part_scatter_wv: barrier-free): 0 = never; >= 1: with wave-private rings wherever its
                                    // signature allows and no hot box is on.  Next to a hot box: 1 = part_scatter_blk, 2 = the rings, 3 = no rings, cold records
                                    // straight from the registers into per-(wave, slab) queue blocks, 4 = into per-(workgroup, slab) blocks (<= 16 slabs)
                                    // (profiles/r02_direct_ab.txt: 158 / 157 / 177 / 177 Grows/s on the bench pass); 5 (round 4, default) = compacted into a wave-private ring,
-                                   // slab-sorted 64-record groups in ONE stream per wave + part_reduce_grp (<= 8 slabs, 8-byte columns; otherwise as 3)
+                                   // slab-sorted 64-record groups in ONE stream per wave + part_reduce_grp (<= 8 slabs, 8-byte columns; otherwise as 3);
+                                   // 6 (round 5, default) = 5 with the groups' record stores held back in registers and issued in chip-wide bursts
+                                   // on the flips of a wall-clock bit ("wv_phase"): 4.96 -> 4.60 ms on the bench pass
     int64_t cfg_wv_block = 0;      // ... records per queue block of a (wave, slab) (0 = sized from the expected share); tests force tiny blocks
     int64_t cfg_fuse_selection = 1; // a selection shared by every aggregator of a call, over one float64 column, is evaluated inside the binning kernels (0: always through sel_eval's byte mask)
     int64_t cfg_gb_compact = 1;    // fused hash groupby: 12-byte records when the measured key range allows (vxh_groupby_run_ranged)
-    int64_t cfg_gb_known_count = 0; // fused hash groupby: a remembered group count sizes the buckets at mean + 4 sigma under the table limit (measured: a loss — see run_pipeline)
-    int64_t cfg_f64_rec12 = 0;     // staged pass 1 with >= 128 slabs: 12-byte AoS queue records instead of a value stream + an index stream
     int64_t cfg_gb_sets = 8;       // fused hash groupby: sets of record streams shared by the workgroups w % sets (8: one per XCD)
     int64_t cfg_gb_abl = 0;        // fused hash groupby, timing experiments only (GbArgs::abl)
     int64_t cfg_gb_load_pct = 50;  // fused hash groupby: target load of a bucket's LDS table when the bucket count is chosen
-    int64_t cfg_merge_fused = 0;   // 1: the box merge and the partition-accumulator merge in ONE launch (measured: 5.204 vs 5.174 ms for the two launches — its grid adds are all atomics; kept as a knob)
     int64_t cfg_hot_chunk_factor = 4; // rows per partition chunk next to a hot box = this x part_chunk
     int64_t cfg_part_cap = 0;      // ... records per sub-queue (0 = sized from the expected share); tests force tiny queues to reach the slow path
     int64_t cfg_wv_waves_grouped = 8; // ... waves per workgroup of the grouped variant ("wv" = 5): 1.5 KB of ring each

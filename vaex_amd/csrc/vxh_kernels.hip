@@ -2957,113 +2957,6 @@ __global__ void __launch_bounds__(64 * kHotMergeWaves) part_hot_merge(const HotM
     }
 }
 
-// K1g (round 4) — both merges of a vxh_grid_bin call in ONE launch: workgroups [0, hot_blocks) fold the pass-1 workgroups' boxes
-// (part_hot_merge's role), the rest fold the partition accumulators, 64 cells per workgroup with the 16 waves each taking a sixteenth
-// of the `parts` (part_merge's one-thread-per-cell loop over 32 parts was a dependent chain: 52 us for 51 MB).  The two roles may
-// add into the same grid cell (a NaN-valued row inside the box's rectangle is a cold record), so every add into a grid is a device
-// atomic here — 2.5e5 of them per call.
-template <typename T, int OP>
-__device__ __forceinline__ void merge_cell16(T *acc, uint64_t plane, int parts, T ident, T *out, bool in_plane, bool live, uint32_t q, uint32_t lane, unsigned long long (*sh)[64]) {
-    T v = ident;
-    if (in_plane)
-        for (int p = (int)q; p < parts; p += (int)kHotMergeWaves) {
-            const T x = acc[(uint64_t)p * plane];
-            acc[(uint64_t)p * plane] = ident;
-            v = OP == 0 ? (T)(v + x) : (OP == 1 ? (x < v ? x : v) : (x > v ? x : v));
-        }
-    unsigned long long bits = 0;
-    memcpy(&bits, &v, sizeof(T));
-    sh[q][lane] = bits;
-    __syncthreads();
-    if (q == 0) {
-        v = ident;
-#pragma unroll
-        for (uint32_t w = 0; w < kHotMergeWaves; ++w) {
-            T x;
-            memcpy(&x, &sh[w][lane], sizeof(T));
-            v = OP == 0 ? (T)(v + x) : (OP == 1 ? (x < v ? x : v) : (x > v ? x : v));
-        }
-        if (live && !(v == ident)) { // (a NaN sum is != ident and is written; min / max cells are never NaN)
-            if (OP == 0) at_add<__HIP_MEMORY_SCOPE_AGENT, T>(out, v);
-            else if (OP == 1) at_min<__HIP_MEMORY_SCOPE_AGENT, T>(out, v);
-            else at_max<__HIP_MEMORY_SCOPE_AGENT, T>(out, v);
-        }
-    }
-    __syncthreads();
-}
-
-__global__ void __launch_bounds__(64 * kHotMergeWaves) part_merge_fused(const PartMergeArgs M, const HotMergeArgs H, const uint32_t hot_blocks) {
-    __shared__ unsigned long long sh[3][kHotMergeWaves][64];
-    const uint32_t lane = threadIdx.x & 63u, q = threadIdx.x >> 6;
-    if (blockIdx.x < hot_blocks) {
-        // ---- the boxes (part_hot_merge with atomic adds) ----
-        const uint32_t cells = H.w * H.h;
-        const uint32_t c = blockIdx.x * 64u + lane;
-        double s = 0.0, s2 = 0.0;
-        unsigned long long k = 0, si = 0;
-        if (c < cells) {
-            for (uint32_t b = q; b < H.blocks; b += kHotMergeWaves) {
-                const uint64_t i = (uint64_t)b * cells + c;
-                if (H.sum_acc && H.val_i64) { si += ((unsigned long long *)H.sum_acc)[i]; H.sum_acc[i] = 0.0; }
-                else if (H.sum_acc) { s += H.sum_acc[i]; H.sum_acc[i] = 0.0; }
-                if (H.sum2_acc) { s2 += H.sum2_acc[i]; H.sum2_acc[i] = 0.0; }
-                k += H.cnt_acc[i];
-                H.cnt_acc[i] = 0ull;
-            }
-        }
-        sh[0][q][lane] = H.val_i64 ? si : (unsigned long long)__double_as_longlong(s);
-        sh[1][q][lane] = (unsigned long long)__double_as_longlong(s2);
-        sh[2][q][lane] = k;
-        __syncthreads();
-        if (q != 0 || c >= cells) return;
-        s = 0.0; s2 = 0.0; si = 0; k = 0;
-#pragma unroll
-        for (uint32_t w = 0; w < kHotMergeWaves; ++w) {
-            s += __longlong_as_double((long long)sh[0][w][lane]);
-            si += sh[0][w][lane];
-            s2 += __longlong_as_double((long long)sh[1][w][lane]);
-            k += sh[2][w][lane];
-        }
-        if (k == 0) return;
-        const uint64_t cell = (uint64_t)(H.x0 + c % H.w) + (uint64_t)(H.y0 + c / H.w) * H.stride_y;
-        for (uint32_t a = 0; a < H.nagg; ++a) {
-            if (H.takes_sum[a] && H.val_i64) at_add<__HIP_MEMORY_SCOPE_AGENT, unsigned long long>((unsigned long long *)H.grid[a] + cell, si);
-            else if (H.takes_sum[a]) at_add<__HIP_MEMORY_SCOPE_AGENT, double>((double *)H.grid[a] + cell, H.takes_sum[a] == 2 ? s2 : s);
-            else at_add<__HIP_MEMORY_SCOPE_AGENT, unsigned long long>((unsigned long long *)H.grid[a] + cell, k);
-        }
-        return;
-    }
-    // ---- the partition accumulators ----
-    const uint64_t plane = M.slab_cells << M.slab_log2; // cells of one part
-    const uint64_t t = (uint64_t)(blockIdx.x - hot_blocks) * 64u + lane;
-    const bool in_plane = t < plane;
-    const uint64_t tt = in_plane ? t : 0;
-    const uint64_t slab = tt / M.slab_cells, local = tt - slab * M.slab_cells;
-    const uint64_t c = (local << M.slab_log2) + slab;
-    const bool live = in_plane && c < M.cells;
-    const uint64_t cc = live ? c : 0;
-    for (int k = 0; k < M.nagg; ++k) {
-        const int op = M.kind[k] == VXH_AGG_MIN ? 1 : (M.kind[k] == VXH_AGG_MAX ? 2 : 0);
-#define VXH_MERGE16(T)                                                                                                 \
-    {                                                                                                                  \
-        T ident;                                                                                                       \
-        memcpy(&ident, &M.ident[k], sizeof(T));                                                                        \
-        if (op == 0) merge_cell16<T, 0>((T *)M.acc[k] + tt, plane, M.parts, ident, (T *)M.grid[k] + cc, in_plane, live, q, lane, sh[0]); \
-        else if (op == 1) merge_cell16<T, 1>((T *)M.acc[k] + tt, plane, M.parts, ident, (T *)M.grid[k] + cc, in_plane, live, q, lane, sh[0]); \
-        else merge_cell16<T, 2>((T *)M.acc[k] + tt, plane, M.parts, ident, (T *)M.grid[k] + cc, in_plane, live, q, lane, sh[0]); \
-    }
-        switch (M.cell[k]) {
-        case VXH_CELL_F64: VXH_MERGE16(double) break;
-        case VXH_CELL_F32: VXH_MERGE16(float) break;
-        case VXH_CELL_I64: VXH_MERGE16(long long) break;
-        case VXH_CELL_U64: VXH_MERGE16(unsigned long long) break;
-        case VXH_CELL_I32: VXH_MERGE16(int) break;
-        default: VXH_MERGE16(unsigned) break;
-        }
-#undef VXH_MERGE16
-    }
-}
-
 // ------------------------------------------------------------------------------------------
 // fill / fold
 // ------------------------------------------------------------------------------------------
@@ -3393,14 +3286,6 @@ void vxh_launch_bin(const BinArgs &args, const LaunchPlan &plan, hipStream_t str
 void vxh_launch_hot_merge(const HotMergeArgs &args, hipStream_t stream) {
     const uint32_t cells = args.w * args.h;
     hipLaunchKernelGGL(part_hot_merge, dim3((cells + 63) / 64), dim3(64 * kHotMergeWaves), 0, stream, args);
-}
-
-void vxh_launch_merge_fused(const PartMergeArgs &M, const HotMergeArgs *H, hipStream_t stream) {
-    const uint64_t plane = M.slab_cells << M.slab_log2;
-    const uint32_t hot_blocks = H ? (H->w * H->h + 63u) / 64u : 0u;
-    const uint32_t part_blocks = (uint32_t)((plane + 63) / 64);
-    HotMergeArgs none{};
-    hipLaunchKernelGGL(part_merge_fused, dim3(hot_blocks + part_blocks), dim3(64 * kHotMergeWaves), 0, stream, M, H ? *H : none, hot_blocks);
 }
 
 void vxh_launch_part_merge(const PartMergeArgs &args, hipStream_t stream) {

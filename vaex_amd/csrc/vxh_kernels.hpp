@@ -316,8 +316,6 @@ bool vxh_part_reduce_is_fast(const PartArgs &args, const LaunchPlan &plan);
 void vxh_launch_bin(const BinArgs &args, const LaunchPlan &plan, hipStream_t stream);
 void vxh_launch_part_merge(const PartMergeArgs &args, hipStream_t stream);
 void vxh_launch_hot_merge(const HotMergeArgs &args, hipStream_t stream);
-// both merges in one launch (hot == nullptr: the partition accumulators alone); every add into a grid is a device atomic
-void vxh_launch_merge_fused(const PartMergeArgs &args, const HotMergeArgs *hot, hipStream_t stream);
 void vxh_launch_fill(void *dst, uint64_t ncells, int cell, const void *value8, hipStream_t stream);
 // dst[c] = fold(replica_0[c] .. replica_{R-1}[c]); replicas 1.. are reset to the identity
 void vxh_launch_fold(void *grid, uint64_t cells, int replicas, int cell, int kind, const void *identity8, hipStream_t stream);

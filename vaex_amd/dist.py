@@ -189,9 +189,11 @@ def allreduce_results(results, ops, group=None):
 
 def shard_rows(n, rank, world):
     """Contiguous row range [i1, i2) of `rank` (rows are independent: SURVEY §8e)."""
-    per = (n + world - 1) // world
-    i1 = min(n, rank * per)
-    return i1, min(n, i1 + per)
+    # balanced: the first n % world ranks take one row more — no rank is empty while n >= world (the ceil(n / world) split of rounds 2-4
+    # left the last ranks without rows for small n; a rank without rows never reaches vaex's reduce: vaex_dist.shard)
+    base, rem = divmod(n, world)
+    i1 = rank * base + min(rank, rem)
+    return i1, i1 + base + (1 if rank < rem else 0)
 
 
 class Comm:

@@ -52,7 +52,11 @@ def shard(df, group=None):
     import torch.distributed as dist
     if not dist.is_initialized():
         return df
-    i1, i2 = vdist.shard_rows(len(df), dist.get_rank(group), dist.get_world_size(group))
+    world = dist.get_world_size(group)
+    if len(df) < world:
+        # (a rank holding df[i:i] schedules no task part, never reaches reduce(), and the others wait in the all-reduce for ever)
+        raise ValueError(f"vaex_amd.shard: {len(df)} rows over {world} ranks — every rank needs at least one row (a rank without rows would never reach the cross-rank merge)")
+    i1, i2 = vdist.shard_rows(len(df), dist.get_rank(group), world)
     return df[i1:i2]
 
 

@@ -306,8 +306,10 @@ def _frame_for(df, columns):
             import vaex_amd
             sa = vaex_amd.superagg
             total = sum(cols[name].nbytes for name in host)
-            free, _ = torch.cuda.mem_get_info()
-            kinds = {"int8": torch.int8, "int16": torch.int16, "int32": torch.int32, "int64": torch.int64, "uint8": torch.uint8, "bool": torch.uint8,
+            free, _ = torch.cuda.mem_get_info(int(sa.config_get("device")))   # (the LIBRARY's device, vxh_set_device: not necessarily torch's current one)
+            # (no "bool": a bool key is told from a uint8 one by its numpy dtype, so such frames stay on the host path — decided HERE,
+            #  before anything crosses PCIe; ADVICE r4: the check used to come after the upload)
+            kinds = {"int8": torch.int8, "int16": torch.int16, "int32": torch.int32, "int64": torch.int64, "uint8": torch.uint8,
                      "float32": torch.float32, "float64": torch.float64}
             plain = all(isinstance(cols[name], np.ndarray) and not np.ma.isMaskedArray(cols[name]) and cols[name].dtype.name in kinds and cols[name].dtype.isnative for name in host)
             if plain and total >= upload_min_bytes and total * 4 < free:
@@ -316,7 +318,7 @@ def _frame_for(df, columns):
                 for name in host:
                     a = np.ascontiguousarray(cols[name])
                     t = torch.empty(a.shape, dtype=kinds[a.dtype.name], device="cuda")
-                    jobs.append((a.view("u1") if a.dtype == np.bool_ else a, t))
+                    jobs.append((a, t))
                     up[name] = t
                 if len(jobs) > 1:   # (the columns cross PCIe side by side: upload() releases the GIL)
                     from concurrent.futures import ThreadPoolExecutor
@@ -324,9 +326,8 @@ def _frame_for(df, columns):
                         list(pool.map(lambda j: sa.upload(j[0], j[1], 6), jobs))
                 else:
                     sa.upload(jobs[0][0], jobs[0][1])
-                if all(cols[name].dtype.name != "bool" for name in host):   # (a bool key is told from a uint8 one by its numpy dtype: leave those on the host path)
-                    cols.update(up)
-                    stats["uploaded"] = stats.get("uploaded", 0) + 1
+                cols.update(up)
+                stats["uploaded"] = stats.get("uploaded", 0) + 1
         except (ImportError, RuntimeError, MemoryError):
             pass   # (no room, no torch: the host columns go through the chunk passes as before)
     if len({binned._is_device(c) for c in cols.values()}) > 1:  # (the fused pass wants keys and values in one place)

@@ -82,7 +82,9 @@ def _known_columns(df):
     Remembered per frame while its column set stays the same objects (every scheduled aggregation — and every task part's
     decode — asked again, a scan of all columns and of the arrow null counts each time: O(aggregations^2 x columns) on wide frames)"""
     cols = df.columns
-    fp = tuple((name, id(ar)) for name, ar in cols.items())
+    # (ids alone can be reused after a collection by a column of another type under the same name — ADVICE r4: a stale "plain numeric"
+    #  verdict would let a predicate compile over strings or nulls — so the fingerprint carries each column's type and dtype as well)
+    fp = tuple((name, id(ar), type(ar).__name__, str(getattr(ar, "dtype", getattr(ar, "type", "")))) for name, ar in cols.items())
     hit = _known_cache.get(id(cols))
     if hit is not None and hit[0] == fp:
         return {name: cols[name] for name in hit[1]}   # (names only are remembered: no array is kept alive by the cache)
