@@ -883,3 +883,4 @@ def test_default_pass1_next_to_a_box_is_the_phased_grouped_form(sa):
         assert np.array_equal(r[0], results[0][0]) and np.array_equal(r[2], results[0][2])
         assert np.all(np.abs(r[1] - results[0][1]) <= 1e-12 * 20.0 * np.maximum(results[0][0], 1))
     assert int(results[0][0].sum()) == n
+
