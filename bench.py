@@ -94,7 +94,7 @@ def vaex_cpu_pass(xs, ys, vs, shape, cores):
         if out.returncode != 0:
             return {"error": (out.stderr or out.stdout)[-400:]}
         r = json.loads(out.stdout.strip().splitlines()[-1])
-        return {"value": r["rows"] / r["s"], "unit": "rows/s", "threads": r["threads"], "rows_counted": [r["counted"], r["rows"]],
+        return {"value": r["rows"] / r["s"], "unit": "rows/s", "threads": r["threads"], "rows_inside_the_limits": [r["counted"], r["rows"]],
                 "call": "df.count(binby=[x,y], delay=True) + df.mean(v, binby=[x,y], delay=True) + df.execute(): one executor pass, best of 3 after a warm-up"}
     except Exception as e:   # (the bench line must not depend on it)
         return {"error": repr(e)}
@@ -114,8 +114,10 @@ def cpu_baseline(x, y, v, shape, rows):
     if ref is not None:
         nthreads = cores
         chunk = 1 << 20  # vaex's chunk size cap (vaex/settings.py:83-87)
+        pool_threads = [cores]   # (a list: picked below — every core, or fewer where that is faster)
 
         def one_pass(vals=None):
+            nthreads = pool_threads[0]
             vv = vs if vals is None else vals
             bx = ref.BinnerScalar_float64(nthreads, "x", -4.0, 4.0, shape)
             by = ref.BinnerScalar_float64(nthreads, "y", -4.0, 4.0, shape)
@@ -165,6 +167,16 @@ def cpu_baseline(x, y, v, shape, rows):
             res = oracle.run_case(case)
             return res, time.perf_counter() - t0
         kind = "port"
+    tried = {}
+    if ref is not None and cores > 32:
+        # the fairest CPU number: a pool of every host core, or of 64 / 32 of them where hundreds of threads over 100 1-Mi-row chunks
+        # get in each other's way (vaex's own executor: 3.0e9 rows/s at 32 threads against 3.8e7 at 256 on the round-5 box)
+        for t in (cores, 64, 32):
+            pool_threads[0] = t
+            one_pass()
+            tried[t] = min(one_pass()[1] for _ in range(2))
+        pool_threads[0] = min(tried, key=tried.get)
+        nthreads = pool_threads[0]
     best = float("inf")
     res = None
     t_start = time.perf_counter()
@@ -188,8 +200,14 @@ def cpu_baseline(x, y, v, shape, rows):
         t1 = time.perf_counter()
         g1.bin(0, a1, m)
         single = m / (time.perf_counter() - t1)
-    through_vaex = vaex_cpu_pass(xs, ys, vs, shape, cores) if ref is not None else None
-    return dict(value=rows / best, unit="rows/s", cores=nthreads, kind=kind, single_thread_value=single, through_vaex=through_vaex,
+    through_vaex = None
+    if ref is not None:
+        # vaex's executor at VAEX_NUM_THREADS = every host core (north_star's wording) and, where that is more than 32, at 32 as well —
+        # its thread pool and per-chunk Python do not scale to hundreds of threads; both are reported, `value` is the better one
+        runs = [vaex_cpu_pass(xs, ys, vs, shape, t) for t in sorted({cores, min(cores, 32)}, reverse=True)]
+        good = [r for r in runs if r and "value" in r]
+        through_vaex = dict(max(good, key=lambda r: r["value"]), runs=[{k: r.get(k) for k in ("value", "threads", "error") if k in r} for r in runs if r]) if good else (runs[0] if runs else None)
+    return dict(value=rows / best, unit="rows/s", cores=nthreads, host_cores=cores, pool_sizes_tried={str(t): rows / dt for t, dt in tried.items()} or None, kind=kind, single_thread_value=single, through_vaex=through_vaex,
                 sample=f"{rows:.3g} of the GPU's own rows (x,y,v float64), same 2-D {shape}x{shape} count+sum+count pass, best of {reps} passes, 1Mi-row chunks over a {nthreads}-thread pool"), res, rows, sabs
 
 
@@ -207,8 +225,21 @@ def other_configs(sa, torch, rows, sample_rows):
     stream_ms = [0.0]
 
     first_call = [0.0, 0.0]
+    process_first = [None]
 
-    def timed(fn, reps=3):
+    def timed(fn, reps=3, prime=None):
+        # `prime`: the same call over COPIES of the columns (other column objects) first, so that what a PROCESS pays once at this size —
+        # code objects loaded on first launch, gigabytes of queue scratch and the pinned result buffers allocated (0.5-0.7 s for a
+        # 1e9-row groupby: `ms_first_call_in_process`) — is not booked on the columns: `ms_first_call` is what a later call over FRESH
+        # columns pays (their key range / NaN scan, their hot-box sample)
+        process_first[0] = None
+        if prime is not None:
+            torch.cuda.synchronize()
+            tp = time.perf_counter()
+            prime()
+            torch.cuda.synchronize()
+            process_first[0] = (time.perf_counter() - tp) * 1e3
+            torch.cuda.empty_cache()
         # the FIRST call over fresh columns is timed too: it pays what the later ones find remembered per column
         # object — the groupby's exact key-range pass (vxh_minmax_int, 8 B/row) and NaN scan of the value column, the hot-box sample —
         # and goes on the line as `ms_first_call` / `kernel_ms_first_call`; `ms` / `kernel_ms` are the best of the warm calls after it
@@ -236,7 +267,7 @@ def other_configs(sa, torch, rows, sample_rows):
     def line(config, what, bytes_per_row, wall, k_ms, kernel, parity):
         gbs = bytes_per_row * rows / (k_ms * 1e-3) / 1e9
         return {"config": config, "what": what, "rows": rows, "rows_per_s": rows / wall, "ms": wall * 1e3, "kernel_ms": k_ms, "stream_ms": stream_ms[0], "kernel": kernel,
-                "ms_first_call": first_call[0], "kernel_ms_first_call": first_call[1],
+                "ms_first_call": first_call[0], "kernel_ms_first_call": first_call[1], "ms_first_call_in_process": process_first[0],
                 "roofline": {"bound": "hbm", "bytes_per_row": bytes_per_row, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS},
                 "parity_on_sample": parity}
 
@@ -251,7 +282,8 @@ def other_configs(sa, torch, rows, sample_rows):
     df = Frame(dict(x=x, y=y, z=z, sel=sel))
     lim3 = [[-4, 4]] * 3
     # ---- north_star's target sentence: 2-D count(*) on a 256x256 grid (16 B/row; src/agg_count.cpp:43-67) ----
-    c2d, wall, k_ms = timed(lambda: df.count(binby=["x", "y"], limits=lim3[:2], shape=256, edges=True))
+    c2d, wall, k_ms = timed(lambda: df.count(binby=["x", "y"], limits=lim3[:2], shape=256, edges=True),
+                            prime=lambda: Frame(dict(x=x.clone(), y=y.clone())).count(binby=["x", "y"], limits=lim3[:2], shape=256, edges=True))
     kernel = sa.last_kernel(0)
     parity = None
     if ref is not None:
@@ -269,7 +301,8 @@ def other_configs(sa, torch, rows, sample_rows):
                   "cells_differ": int((np.asarray(head) != want).sum()), "rows_counted": [int(np.asarray(c2d).sum()), rows]}
     out.append(line("count2d", "2-D count(*) of float64 x,y on a 256x256 grid (north_star's target sentence)", 16, wall, k_ms, kernel, parity))
     del c2d
-    c3, wall, k_ms = timed(lambda: df.count(binby=["x", "y", "z"], limits=lim3, shape=128, selection="sel", edges=True))
+    c3, wall, k_ms = timed(lambda: df.count(binby=["x", "y", "z"], limits=lim3, shape=128, selection="sel", edges=True),
+                           prime=lambda: Frame(dict(x=x.clone(), y=y.clone(), z=z.clone(), sel=sel.clone())).count(binby=["x", "y", "z"], limits=lim3, shape=128, selection="sel", edges=True))
     kernel = sa.last_kernel(0)
     parity = None
     if ref is not None:
@@ -291,7 +324,8 @@ def other_configs(sa, torch, rows, sample_rows):
     # ---- configs[2]': the same histogram with the selection as an EXPRESSION over a fourth column — evaluated inside the binning
     # kernel (no mask bytes: x, y, z, v = 32 B/row; through a separate predicate pass it was 8 + 1 + 24 + 1 = 34) ----
     dfe = Frame(dict(x=x, y=y, z=z, v=v))
-    c3e, wall, k_ms = timed(lambda: dfe.count(binby=["x", "y", "z"], limits=lim3, shape=128, selection="v > 3", edges=True))
+    c3e, wall, k_ms = timed(lambda: dfe.count(binby=["x", "y", "z"], limits=lim3, shape=128, selection="v > 3", edges=True),
+                            prime=lambda: Frame(dict(x=x.clone(), y=y.clone(), z=z.clone(), v=v.clone())).count(binby=["x", "y", "z"], limits=lim3, shape=128, selection="v > 3", edges=True))
     kernel = sa.last_kernel(0)
     parity = None
     if ref is not None:
@@ -308,7 +342,7 @@ def other_configs(sa, torch, rows, sample_rows):
         keys = k if flavour == "dense" else (k * 2654435761) % (1 << 40)
         torch.cuda.synchronize()
         df = Frame(dict(k=keys, v=v))
-        res, wall, k_ms = timed(lambda: df.groupby("k", spec))
+        res, wall, k_ms = timed(lambda: df.groupby("k", spec), prime=lambda: Frame(dict(k=keys.clone(), v=v.clone())).groupby("k", spec))
         kernel = sa.last_kernel(0) if flavour == "dense" else "gb_scatter+gb_reduce"
         info = getattr(df, "last_groupby_info", None) or {}
         parity = None

@@ -326,6 +326,12 @@ int vxh_minmax(int dtype, int flip_endian, const void *data, const uint8_t *mask
  * groupby "simplify to BinnerInteger" rule, vaex/groupby.py:263-272 */
 int vxh_minmax_int(int dtype, int flip_endian, const void *data, const uint8_t *mask, uint64_t n, int mem, int64_t *out2);
 
+/* the two scans a FIRST df.groupby(key).agg(value) over fresh device columns pays, in one pass over the 16 bytes of a row: the exact
+ * {min, max} of an int64 key column (vxh_minmax_int: the "simplify to BinnerInteger" test, vaex/groupby.py:263-272) and the number of
+ * NaN values of a float64 value column (whether count(value) can stand in for a group's presence, vaex/groupby.py:955-972).
+ * Both columns in device memory, 16-byte aligned.  out3 = {key min, key max, NaN values}; {INT64_MAX, INT64_MIN, 0} when empty. */
+int vxh_scan_key_value(const int64_t *keys, const double *values, uint64_t n, int64_t *out3);
+
 /* ---- finishers on the device -------------------------------------------------------------- */
 /* What vaex computes with numpy on the result grids, on the device grids instead: vaex/agg.py:403-416 (mean =
  * sum / count), :440-455 (variance = m2 / count - mean^2; std = sqrt), and the drop of empty groups of a groupby

@@ -68,3 +68,38 @@ def test_finish_errors(sa, gpu_ready):
         sa.finish([(sa.FIN_COPY, aggs[0], None, None)], present=aggs[0], first=0, n=5)
     with pytest.raises(RuntimeError, match="missing input"):
         sa.finish([(sa.FIN_MEAN, aggs[0], None, None)], first=0, n=5)
+
+
+def test_scan_key_value_is_both_prescans_in_one_pass(sa, gpu_ready):
+    """round 5: vxh_scan_key_value = the exact int64 key range (vxh_minmax_int) and the NaN count of a float64 value column in ONE pass
+    over the 16 bytes of a row; Frame.groupby fills both per-column memories from it on a first call over fresh device columns."""
+    import torch
+    from vaex_amd import binned
+    g = torch.Generator(device="cuda").manual_seed(5)
+    for n in (0, 1, 2, 7, 1_000_003, 4_000_000):
+        k = torch.randint(-(1 << 40), 1 << 41, (n,), dtype=torch.int64, device="cuda", generator=g)
+        v = torch.randn(n, dtype=torch.float64, device="cuda", generator=g)
+        if n > 5:
+            v[3] = float("nan"); v[n - 1] = float("nan"); k[n - 1] = -(1 << 50); k[0] = 1 << 52
+        kmin, kmax, nans = sa.scan_key_value(k, v)
+        if n == 0:
+            assert (kmin, kmax, nans) == (2**63 - 1, -2**63, 0)
+        else:
+            assert (kmin, kmax) == (int(k.min()), int(k.max())) == tuple(sa.minmax_int(k, None, 2, False))
+            assert nans == int(torch.isnan(v).sum())
+    n = 3_000_000
+    k = torch.randint(0, 5000, (n,), dtype=torch.int64, device="cuda", generator=g)
+    v = torch.randn(n, dtype=torch.float64, device="cuda", generator=g)
+    for with_nan in (False, True):
+        if with_nan:
+            v = v.clone(); v[::1000] = float("nan")
+        f = binned.Frame(dict(k=k, v=v), superagg=sa)
+        got = f.groupby("k", {"c": binned.agg.count("v"), "m": binned.agg.mean("v"), "n": binned.agg.count()})
+        assert f.__dict__["_key_range_cache"]["k"][1] == (int(k.min()), int(k.max()))
+        assert f.__dict__["_nan_cache"]["v"][1] is with_nan
+        kk, vv = k.cpu().numpy(), v.cpu().numpy()
+        ok = vv == vv
+        np.testing.assert_array_equal(got["k"], np.unique(kk))
+        np.testing.assert_array_equal(got["n"], np.bincount(kk, minlength=5000))
+        np.testing.assert_array_equal(got["c"], np.bincount(kk[ok], minlength=5000))
+        assert np.allclose(got["m"], np.bincount(kk[ok], weights=vv[ok], minlength=5000) / np.bincount(kk[ok], minlength=5000), rtol=1e-11)

@@ -15,7 +15,7 @@ for c in d.get("configs") or []:
           c.get("ms_first_call"), (c.get("parity_on_sample") or {}).get("ok"), c.get("groupby_kernels_ms", "")))
 cb = d.get("cpu_baseline") or {}
 if cb:
-    print("  cpu %.4g rows/s on %s cores (%s) parity %s  vaex: %s" % (cb.get("value", 0), cb.get("cores"), cb.get("kind"), cb.get("parity_on_sample"), cb.get("through_vaex")))
+    print("  cpu %.4g rows/s on %s cores (%s) parity %s  vaex: %s" % (cb.get("value", 0), cb.get("cores"), cb.get("kind"), cb.get("parity_on_sample"), ({k: cb["through_vaex"].get(k) for k in ("value", "threads", "runs", "error")} if cb.get("through_vaex") else None)))
 if len(sys.argv) > 2:
     tot, steps = 0.0, d["steps"] + d["warmup"]
     for line in open(sys.argv[2]):

@@ -906,6 +906,36 @@ class Frame:
         cache[by] = (key, r)
         return r
 
+    def _prescan(self, by, key, pf, descs):
+        """A FIRST groupby over fresh device columns needs the key's exact range and whether a float64 value column holds NaN; both are
+        remembered per column object, and both used to be a pass of their own (vxh_minmax_int 8 B/row; torch.isnan + any: 8 B/row read,
+        1 B/row written and read back).  An int64 key and a float64 value column that are both unknown are scanned in ONE pass over
+        the 16 bytes of a row (vxh_scan_key_value), which fills both memories."""
+        if pf != "int64" or not self.n or not _is_device(key) or not hasattr(self.sa, "scan_key_value"):
+            return
+        kr = self.__dict__.setdefault("_key_range_cache", {})
+        hit = kr.get(by)
+        if hit is not None and hit[0] is key:
+            return
+        nc = self.__dict__.setdefault("_nan_cache", {})
+        for d in descs:
+            c = d.column
+            if c is None:
+                continue
+            col = self.columns[c]
+            if np.ma.isMaskedArray(col) or not _is_device(col) or str(col.dtype).replace("torch.", "") != "float64" or len(col) != len(key):
+                continue
+            seen = nc.get(c)
+            if seen is not None and seen[0] is col:
+                continue
+            try:
+                kmin, kmax, nans = self.sa.scan_key_value(key, col)
+            except RuntimeError:   # (unaligned views: the two separate passes)
+                return
+            kr[by] = (key, (int(kmin), int(kmax)))
+            nc[c] = (col, bool(nans))
+            return
+
     def _may_hold_nan(self, name):
         """False when column `name` certainly holds no NaN / missing value: integer columns, and float columns scanned once
         (remembered per column object, like the key range)."""
@@ -966,6 +996,7 @@ class Frame:
         if self.n == 0 and comm is None:
             return {by: np.array([], dtype=np.int64), **{n: np.array([]) for n in names}}
         # key range: one exact integer min/max pass (vxh_minmax_int); ranks agree on the global range
+        self._prescan(by, key, pf, descs)
         kmin, kmax = self._key_range(by, key, pf)
         if comm is not None:
             kmin, kmax = comm.minmax(kmin, kmax)

@@ -811,6 +811,17 @@ PYBIND11_MODULE(superagg, m) {
         return py::make_tuple(out[0], out[1]);
     }, py::arg("data"), py::arg("mask") = py::none(), py::arg("dtype") = 2, py::arg("flip") = false);
 
+    // one pass over an int64 key column and a float64 value column on the device: (key min, key max, NaN values)
+    m.def("scan_key_value", [](const py::object &keys, const py::object &values) {
+        ArrayRef k = resolve_array(keys), v = resolve_array(values);
+        if (k.mem != VXH_MEM_DEVICE || v.mem != VXH_MEM_DEVICE || k.itemsize != 8 || v.itemsize != 8 || k.n != v.n) throw std::runtime_error("scan_key_value: two device columns of 8-byte elements and equal length");
+        int64_t out[3];
+        int rc;
+        { py::gil_scoped_release r; rc = vxh_scan_key_value((const int64_t *)k.ptr, (const double *)v.ptr, k.n, out); }
+        check(rc);
+        return py::make_tuple(out[0], out[1], out[2]);
+    }, py::arg("keys"), py::arg("values"));
+
     // finishers on the device: finish([(op, agg0, agg1 | None, agg2 | None), ...], present=None, first=0, n=None)
     // -> (list of 1-d ndarrays in pinned host memory, index ndarray | None)
     m.def("finish", [](const std::vector<py::tuple> &specs, const py::object &present, uint64_t first, const py::object &n_obj, bool want_index) {

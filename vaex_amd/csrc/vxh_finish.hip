@@ -147,6 +147,40 @@ __global__ void __launch_bounds__(FIN_BLOCK) fin_emit(const FinArgs F) {
     }
 }
 
+// the two scans a first df.groupby(k).agg(v) over fresh device columns needs — the exact range of the int64 key (dense or scattered?
+// vaex/groupby.py:263-272) and whether the float64 value column holds a NaN (then count(v) cannot stand in for the groups' presence) —
+// in ONE pass over the 16 bytes of a row: 16-byte loads (two rows per lane and trip), wave reduction, three device atomics per wave
+__global__ void __launch_bounds__(256) scan_key_value_kernel(const long long *keys, const double *vals, uint64_t n, long long *out3) {
+    long long mn = 0x7fffffffffffffffll, mx = (long long)0x8000000000000000ull;
+    unsigned long long nan = 0;
+    const uint64_t pairs = n >> 1, stride = (uint64_t)gridDim.x * blockDim.x;
+    typedef long long ll2 __attribute__((ext_vector_type(2)));
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < pairs; i += stride) {
+        const ll2 k = __builtin_nontemporal_load((const ll2 *)keys + i);
+        const d2 v = __builtin_nontemporal_load((const d2 *)vals + i);
+        mn = k[0] < mn ? k[0] : mn; mx = k[0] > mx ? k[0] : mx;
+        mn = k[1] < mn ? k[1] : mn; mx = k[1] > mx ? k[1] : mx;
+        nan += (v[0] != v[0]) + (v[1] != v[1]);
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+        const long long k = keys[n - 1];
+        mn = k < mn ? k : mn; mx = k > mx ? k : mx;
+        nan += vals[n - 1] != vals[n - 1];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const long long a = __shfl_down(mn, o, 64), b = __shfl_down(mx, o, 64);
+        mn = a < mn ? a : mn; mx = b > mx ? b : mx;
+        nan += __shfl_down(nan, o, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMin(out3, mn);
+        atomicMax(out3 + 1, mx);
+        if (nan) atomicAdd((unsigned long long *)(out3 + 2), nan);
+    }
+}
+
 struct HostCache {
     std::mutex mutex;
     std::multimap<size_t, void *> free_blocks; // by block size
@@ -200,6 +234,32 @@ int vxh_upload(const void *host, void *device, uint64_t bytes, int threads) {
         }
         for (auto &th : pool) th.join();
         for (auto &er : errors) if (!er.empty()) throw std::runtime_error("vxh_upload: " + er);
+    } catch (const std::exception &e) {
+        vxh_set_error(e.what());
+        return 1;
+    }
+    return 0;
+}
+
+int vxh_scan_key_value(const int64_t *keys, const double *values, uint64_t n, int64_t *out3) {
+    try {
+        (void)hipSetDevice(ctx().device);
+        if (((uintptr_t)keys | (uintptr_t)values) & 15) throw std::runtime_error("vxh_scan_key_value: columns must be 16-byte aligned device arrays");
+        Slot &slot = get_slot(0);
+        order_after_producers(slot);
+        long long init[3] = {INT64_MAX, INT64_MIN, 0};
+        long long *dev = (long long *)vxh_pool_alloc(64);
+        HIP_CHECK(hipMemcpyAsync(dev, init, sizeof(init), hipMemcpyHostToDevice, slot.stream));
+        if (n) {
+            const unsigned blocks = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n / 2 + 255) / 256, (uint64_t)ctx().cus * 16));
+            hipLaunchKernelGGL(scan_key_value_kernel, dim3(blocks), dim3(256), 0, slot.stream, (const long long *)keys, values, n, dev);
+            HIP_CHECK(hipGetLastError());
+        }
+        vxh_timer_lap(slot);
+        HIP_CHECK(hipMemcpyAsync(init, dev, sizeof(init), hipMemcpyDeviceToHost, slot.stream));
+        HIP_CHECK(hipStreamSynchronize(slot.stream));
+        vxh_pool_free(dev);
+        out3[0] = init[0]; out3[1] = init[1]; out3[2] = init[2];
     } catch (const std::exception &e) {
         vxh_set_error(e.what());
         return 1;
