@@ -334,7 +334,29 @@ def other_configs(sa, torch, rows, sample_rows):
                   "cells_differ": int((np.asarray(heade) != want).sum()), "equals_the_mask_form_on_all_rows": bool(np.array_equal(np.asarray(c3e), np.asarray(c3))),
                   "selection_fused_in_kernel": bool(sa.config_get("pred_fused") > 0)}
     out.append(line("configs[2]'", "3-D 128^3 count(*) of float64 x,y,z, selection = the expression \"v > 3\" over a fourth float64 column (evaluated in the binning kernel)", 32, wall, k_ms, kernel, parity))
-    del df, dfe, x, y, z, sel, c3, c3e
+    # ---- configs[2]'': a TWO-term selection over two further float64 columns, "(v > 3) & (w < 1)" — both read by the binning kernel
+    # (round 5: PredDesc::col2; x, y, z, v, w = 40 B/row; through the predicate pass it was 16 + 1 + 24 + 1 = 42) ----
+    w = torch.randn(rows, dtype=torch.float64, device="cuda", generator=g)
+    sel2 = ((v > 3) & (w < 1)).to(torch.uint8)
+    dfe2 = Frame(dict(x=x, y=y, z=z, v=v, w=w))
+    f_before = sa.config_get("pred_fused")
+    c3t, wall, k_ms = timed(lambda: dfe2.count(binby=["x", "y", "z"], limits=lim3, shape=128, selection="(v > 3) & (w < 1)", edges=True))
+    kernel = sa.last_kernel(0)
+    parity = None
+    if ref is not None:
+        headt = Frame(dict(x=x[:m], y=y[:m], z=z[:m], v=v[:m], w=w[:m])).count(binby=["x", "y", "z"], limits=lim3, shape=128, selection="(v > 3) & (w < 1)", edges=True)
+        c2 = ref.AggCount_int64(grid, 1, 1)
+        keep2 = sel2[:m].cpu().numpy()   # (kept alive: the reference borrows the pointer)
+        c2.set_data_mask(0, keep2)
+        grid.bin(0, [c2], m)
+        want2 = np.asarray(c2.get_result())
+        via_mask = Frame(dict(x=x, y=y, z=z, sel2=sel2)).count(binby=["x", "y", "z"], limits=lim3, shape=128, selection="sel2", edges=True)
+        parity = {"ok": bool(np.array_equal(np.asarray(headt), want2)) and bool(np.array_equal(np.asarray(c3t), np.asarray(via_mask))), "sample_rows": m,
+                  "cells_differ": int((np.asarray(headt) != want2).sum()), "equals_the_mask_form_on_all_rows": bool(np.array_equal(np.asarray(c3t), np.asarray(via_mask))),
+                  "rows_counted": [int(np.asarray(c3t).sum()), int(sel2.sum().item())], "selection_fused_in_kernel": bool(sa.config_get("pred_fused") > f_before)}
+        del via_mask
+    out.append(line("configs[2]''", "3-D 128^3 count(*) of float64 x,y,z, selection = \"(v > 3) & (w < 1)\" over two further float64 columns (both evaluated in the binning kernel)", 40, wall, k_ms, kernel, parity))
+    del df, dfe, dfe2, x, y, z, w, sel, sel2, c3, c3e, c3t
     # ---- configs[3]: groupby on 1e6 int64 keys, agg sum / mean / std of v ----
     k = torch.randint(0, 1_000_000, (rows,), dtype=torch.int64, device="cuda", generator=g)
     spec = {"c": agg.count("v"), "s": agg.sum("v"), "m": agg.mean("v"), "sd": agg.std("v")}

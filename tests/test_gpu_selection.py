@@ -157,7 +157,7 @@ def test_float32_columns_are_compared_in_float32_like_numpy():
 # one float64 column: no sel_eval pass, no mask byte.  Each shape is binned three ways — fused, through sel_eval's mask
 # ("fuse_selection" = 0) and with a numpy-built mask: the three must agree bit for bit on integer grids (the same rows are kept).
 # ------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("shape", ["three_d_128", "bench_2d_box", "count_2d_lds", "one_d_big", "two_terms_nan", "std_box", "not_fusable_int", "not_fusable_two_columns"])
+@pytest.mark.parametrize("shape", ["three_d_128", "bench_2d_box", "count_2d_lds", "one_d_big", "two_terms_nan", "std_box", "not_fusable_int", "two_columns_3d", "two_columns_or_nan_3d", "two_columns_box", "two_columns_count_lds", "two_columns_1d", "not_fusable_three_columns"])
 def test_selection_fused_into_the_binning_kernels(shape):
     import torch
     g = torch.Generator(device="cuda").manual_seed(77)
@@ -175,7 +175,13 @@ def test_selection_fused_into_the_binning_kernels(shape):
         "two_terms_nan": ("count", None, ["x", "y", "z"], [[-4, 4]] * 3, 128, "~(v >= 1) | (v == 3.5)", "part_scatter_wv", True),   # NaN rows: kept by ~(v >= 1)
         "std_box": ("std", "v", ["x", "y"], LIM, 256, "(z > -1) & (z < 2)", "part_scatter_", True),
         "not_fusable_int": ("count", None, ["x", "y", "z"], [[-4, 4]] * 3, 128, "j > 3", "part_scatter_wv", False),
-        "not_fusable_two_columns": ("count", None, ["x", "y", "z"], [[-4, 4]] * 3, 128, "(v > 3) & (x < 1)", "part_scatter_wv", False),
+        # round 5: terms over TWO float64 columns are evaluated in the kernels too (PredDesc::col2; MASKED = 4)
+        "two_columns_3d": ("count", None, ["x", "y", "z"], [[-4, 4]] * 3, 128, "(v > 3) & (x < 1)", "part_scatter_wv", True),
+        "two_columns_or_nan_3d": ("count", None, ["x", "y", "z"], [[-4, 4]] * 3, 128, "~(v >= 1) | (y > 0.5)", "part_scatter_wv", True),
+        "two_columns_box": ("mean", "v", ["x", "y"], LIM, 256, "(z > -1) & (v < 5)", "part_scatter_phased_hot", True),   # next to the hot box (the phased grouped form)
+        "two_columns_count_lds": ("count", None, ["x", "y"], LIM, 256, "(z <= 0.5) | (v > 4)", "count_lds", True),
+        "two_columns_1d": ("sum", "v", ["x"], [[-4, 4]], 100_000, "(y != 0.25) & (z < 1)", "part_scatter", True),
+        "not_fusable_three_columns": ("count", None, ["x", "y", "z"], [[-4, 4]] * 3, 128, "(v > 3) & (x < 1) & (y > -1)", "part_scatter_wv", False),
     }[shape]
     what, col, binby, lim, shp, expr, kernel_prefix, fusable = spec
     call = lambda sel: (getattr(f, what)(binby=binby, limits=lim, shape=shp, selection=sel, edges=True) if col is None else getattr(f, what)(col, binby=binby, limits=lim, shape=shp, selection=sel, edges=True))

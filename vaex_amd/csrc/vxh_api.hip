@@ -1330,10 +1330,12 @@ static const uint8_t *materialize_pred(Slot &slot, const PredDesc &Q, uint64_t r
     SelArgs S{};
     S.col[0] = Q.col;
     S.dtype[0] = (uint8_t)VXH_F64;
+    S.col[1] = Q.col2;
+    S.dtype[1] = (uint8_t)VXH_F64;
     S.nterms = Q.nterms;
     S.truth = Q.truth;
     for (int t = 0; t < Q.nterms; t++) {
-        S.t[t].column = 0; S.t[t].op = Q.op[t]; S.t[t].is_int = 0; S.t[t].value = Q.c[t]; S.t[t].ivalue = 0;
+        S.t[t].column = Q.col2 ? Q.tcol[t] : 0; S.t[t].op = Q.op[t]; S.t[t].is_int = 0; S.t[t].value = Q.c[t]; S.t[t].ivalue = 0;
     }
     S.and_mask = nullptr;
     S.out = (uint8_t *)slot.sel_buf;
@@ -1394,7 +1396,10 @@ static void run_part_chunk(Slot &slot, const BinArgs &planned, const LaunchPlan 
     if (slot.hot.on && slot.hot.wv != wv) throw std::runtime_error("vaex_hip internal: hot box prepared for a different pass-1 kernel");
     if (P.A.pred.on) {
         // the fused selection rides part_scatter_wv's float64 instantiations (box-less, or next to a box without rings / grouped); every other pass 1 reads a byte mask
-        const bool fusable = wv && !(narrow || f32b || f32all || intb) && !plan.key_i64 && (!slot.hot.on || wg.direct == 1 || wg.direct >= 3) && aligned_to(P.A.pred.col, 16);
+        // (two-column predicates: the box-less instantiations and, next to a box, the phased grouped form — the default — only)
+        const bool two = P.A.pred.col2 != nullptr;
+        const bool fusable = wv && !(narrow || f32b || f32all || intb) && !plan.key_i64 && (!slot.hot.on || (two ? wg.direct == 4 : (wg.direct == 1 || wg.direct >= 3))) && aligned_to(P.A.pred.col, 16) &&
+                             (!two || aligned_to(P.A.pred.col2, 16));
         if (!fusable) {
             const uint8_t *m = materialize_pred(slot, P.A.pred, planned.n);
             for (int k = 0; k < planned.nagg; k++) P.A.a[k].mask = m;
@@ -2202,14 +2207,17 @@ int vxh_grid_bin(vxh_grid *grid, int thread, vxh_agg *const *aggs, int n_aggs, u
             if (!a->selection || a->mask[thread].ptr || (fsel && fsel != a->selection)) ok = false;
             else fsel = a->selection;
         }
-        ok = ok && fsel && fsel->n_columns == 1 && fsel->dtype[0] == VXH_F64 && fsel->n_terms >= 1 && fsel->n_terms <= 4;
-        for (int t = 0; ok && t < fsel->n_terms; t++) ok = fsel->term[t].column == 0; // (an integer constant next to a float64 column is compared as float64: vxh_select.hip term_at)
+        // (round 5: the terms may read TWO float64 columns — "(v > 3) & (w < 1)" — PredDesc::col2 / tcol)
+        ok = ok && fsel && (fsel->n_columns == 1 || fsel->n_columns == 2) && fsel->n_terms >= 1 && fsel->n_terms <= 4;
+        for (int cidx = 0; ok && cidx < fsel->n_columns; cidx++) ok = fsel->dtype[cidx] == VXH_F64;
+        for (int t = 0; ok && t < fsel->n_terms; t++) ok = fsel->term[t].column >= 0 && fsel->term[t].column < fsel->n_columns; // (an integer constant next to a float64 column is compared as float64: vxh_select.hip term_at)
         if (!ok) fsel = nullptr;
     }
     PredDesc call_pred{};
     static const uint8_t *const kPredSentinel = (const uint8_t *)(uintptr_t)0x1000; // "a mask shared by every aggregator" for the planner; never read
     if (fsel) {
         call_pred.col = resolve(fsel->data[0][thread], 8);
+        call_pred.col2 = fsel->n_columns == 2 ? resolve(fsel->data[1][thread], 8) : nullptr;
         call_pred.on = 1;
         call_pred.nterms = fsel->n_terms;
         call_pred.truth = fsel->truth;
@@ -2220,6 +2228,7 @@ int vxh_grid_bin(vxh_grid *grid, int thread, vxh_agg *const *aggs, int n_aggs, u
             call_pred.code[t] = rel_code[op - VXH_CMP_LT];
             call_pred.op[t] = op;
             call_pred.c[t] = fsel->term[t].value;
+            call_pred.tcol[t] = (uint8_t)fsel->term[t].column;
         }
     }
     // device-side selections: one keep-mask per distinct (selection, data mask) pair, evaluated on the slot's stream in front
@@ -2279,7 +2288,7 @@ int vxh_grid_bin(vxh_grid *grid, int thread, vxh_agg *const *aggs, int n_aggs, u
         }
         for (int k = 0; k < n_aggs; k++) {
             if (aggs[k]->data[thread].ptr) uniq[aggs[k]->data[thread].ptr] = kDtypeSize[aggs[k]->dtype];
-            if (fsel) uniq[call_pred.col] = 8;
+            if (fsel) { uniq[call_pred.col] = 8; if (call_pred.col2) uniq[call_pred.col2] = 8; }
             else if (aggs[k]->selection) uniq[agg_mask(aggs[k])] = 1;
             else if (aggs[k]->mask[thread].ptr) uniq[aggs[k]->mask[thread].ptr] = 1;
         }
@@ -2353,6 +2362,7 @@ int vxh_grid_bin(vxh_grid *grid, int thread, vxh_agg *const *aggs, int n_aggs, u
                     if (L.a[k].mask && !L.pred.on) L.a[k].mask += r0;
                 }
                 if (L.pred.on) L.pred.col = (const char *)L.pred.col + r0 * 8;
+                if (L.pred.on && L.pred.col2) L.pred.col2 = (const char *)L.pred.col2 + r0 * 8;
             }
             BinArgs planned;
             LaunchPlan plan = make_plan(L, planned, step == kMaxRows ? rn : length, bytes_per_row, exclusive);

@@ -69,6 +69,20 @@ __device__ __forceinline__ bool pred_keep(const PredDesc &Q, double x) {
     return ((Q.truth >> bits) & 1u) != 0u;
 }
 
+// ... with terms over two columns (PredDesc::col2, tcol): x0 / x1 are the row's values of `col` / `col2`
+__device__ __forceinline__ bool pred_keep2(const PredDesc &Q, double x0, double x1) {
+    uint32_t bits = 0;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        if (t < Q.nterms) {
+            const double c = Q.c[t], x = Q.tcol[t] ? x1 : x0;
+            const uint32_t rel = x < c ? 0u : (x == c ? 1u : (x > c ? 2u : 3u));
+            bits |= ((Q.code[t] >> rel) & 1u) << t;
+        }
+    }
+    return ((Q.truth >> bits) & 1u) != 0u;
+}
+
 template <int N>
 struct Rows {
     uint64_t i[N];
@@ -1068,10 +1082,11 @@ __global__ void __launch_bounds__(1024) count_lds_f64(const BinArgs A) {
     struct Raw {
         CT b[NDIM][R];
         uint8_t m[R];
-        double p[MASKED == 2 ? R : 1];
+        double p[(MASKED == 2 || MASKED == 4) ? R : 1];
+        double p2[MASKED == 4 ? R : 1];
         uint32_t valid;
     };
-    const double *pcol = (const double *)A.pred.col;
+    const double *pcol = (const double *)A.pred.col, *pcol2 = (const double *)A.pred.col2;
     auto request = [&](uint64_t t, Raw &raw) {
         const Rows<R> rows = make_rows<R>(t * T + threadIdx.x, blockDim.x, n);
         raw.valid = rows.valid;
@@ -1085,9 +1100,13 @@ __global__ void __launch_bounds__(1024) count_lds_f64(const BinArgs A) {
 #pragma unroll
             for (int r = 0; r < R; ++r) raw.m[r] = mask[rows.i[r]];
         }
-        if (MASKED == 2) {
+        if (MASKED == 2 || MASKED == 4) {
 #pragma unroll
-            for (int r = 0; r < R; ++r) raw.p[MASKED == 2 ? r : 0] = pcol[rows.i[r]];
+            for (int r = 0; r < R; ++r) raw.p[(MASKED == 2 || MASKED == 4) ? r : 0] = pcol[rows.i[r]];
+        }
+        if (MASKED == 4) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) raw.p2[MASKED == 4 ? r : 0] = pcol2[rows.i[r]];
         }
     };
 
@@ -1105,6 +1124,11 @@ __global__ void __launch_bounds__(1024) count_lds_f64(const BinArgs A) {
 #pragma unroll
             for (int r = 0; r < R; ++r)
                 if (!pred_keep(A.pred, cur.p[MASKED == 2 ? r : 0])) keep &= ~(1u << r);
+        }
+        if (MASKED == 4) { // ... its terms over two columns
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                if (!pred_keep2(A.pred, cur.p[MASKED == 4 ? r : 0], cur.p2[MASKED == 4 ? r : 0])) keep &= ~(1u << r);
         }
         uint32_t idx[R];
 #pragma unroll
@@ -1889,7 +1913,8 @@ __global__ void __launch_bounds__(DIRECT == 4 ? 512 : 1024) part_scatter_wv(cons
     struct Raw {
         u32x4 b[NDIM][2];
         u32x4 v[2]; // (dead registers when NVAL == 0)
-        u32x4 p[2]; // the selection's column (dead unless MASKED == 2)
+        u32x4 p[2]; // the selection's column (dead unless MASKED == 2 / 4)
+        u32x4 p2[2]; // ... its second column (MASKED == 4)
         uint32_t m[4]; // mask bytes of rows 0..3, each as its byte load returned it (packing them at the request made the wave wait for the NEWEST tile's loads every trip — vmcnt(0) at the bottom of the loop in round 4's ISA)
         uint32_t rows; // rows the tile really has (wave-uniform)
     };
@@ -1924,10 +1949,15 @@ __global__ void __launch_bounds__(DIRECT == 4 ? 512 : 1024) part_scatter_wv(cons
             raw.v[0] = u32x4{a[0], a[1], 0u, 0u};
             raw.v[1] = u32x4{b[0], b[1], 0u, 0u};
         }
-        if (MASKED == 2) {
+        if (MASKED == 2 || MASKED == 4) {
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)((const double *)P.A.pred.col + r0), 0, (int)(rows_here * 8u), 0x00020000);
             raw.p[0] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(lane * 16u), 0, 2);
             raw.p[1] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(lane * 16u), 1024, 2);
+        }
+        if (MASKED == 4) {
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)((const double *)P.A.pred.col2 + r0), 0, (int)(rows_here * 8u), 0x00020000);
+            raw.p2[0] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(lane * 16u), 0, 2);
+            raw.p2[1] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(lane * 16u), 1024, 2);
         }
         if (MASKED == 1) {
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(colm + r0), 0, (int)rows_here, 0x00020000);
@@ -2081,6 +2111,11 @@ __global__ void __launch_bounds__(DIRECT == 4 ? 512 : 1024) part_scatter_wv(cons
 #pragma unroll
             for (int r = 0; r < R; ++r)
                 if (!pred_keep(P.A.pred, f64_of(cur.p, r))) keep &= ~(1u << r);
+        }
+        if (MASKED == 4) { // ... its terms over two columns ("(v > 3) & (w < 1)")
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                if (!pred_keep2(P.A.pred, f64_of(cur.p, r), f64_of(cur.p2, r))) keep &= ~(1u << r);
         }
         if (MASKED == 3 && NVAL) { // ... over the VALUE column itself (df.mean(v, selection="v > 3")): nothing more to load
 #pragma unroll
@@ -3067,10 +3102,12 @@ void vxh_launch_part_scatter(const PartArgs &args, const LaunchPlan &plan, int s
         const bool hot = args.hot.on == 2, masked = args.nmasks > 0;
         const bool pred = args.A.pred.on != 0; // the shared selection evaluated in the kernel (the host checks: float64 columns only, no conversions)
         if (pred && (args.val_ct || args.bin_ct || plan.key_i64 || (hot && args.wv_direct != 1 && args.wv_direct != 3 && args.wv_direct != 4))) throw std::runtime_error("vaex_hip internal: fused selection next to a pass 1 that is not instantiated for it");
-        const bool pred_v = pred && args.nvals == 1 && args.A.pred.col == args.vdata[0] && !args.val_i64; // the selection reads the value column
+        const bool pred2 = pred && args.A.pred.col2 != nullptr;                                            // its terms read two columns
+        const bool pred_v = pred && !pred2 && args.nvals == 1 && args.A.pred.col == args.vdata[0] && !args.val_i64; // the selection reads the value column
 #define VXH_WV(ND)                                                                                                     \
     do {                                                                                                               \
         if (pred_v) VXH_SC((part_scatter_wv<ND, 1, 3, false>));                                                        \
+        else if (pred2) { if (args.nvals == 0) VXH_SC((part_scatter_wv<ND, 0, 4, false>)); else VXH_SC((part_scatter_wv<ND, 1, 4, false>)); } \
         else if (pred) { if (args.nvals == 0) VXH_SC((part_scatter_wv<ND, 0, 2, false>)); else VXH_SC((part_scatter_wv<ND, 1, 2, false>)); } \
         else if (args.nvals == 0) { if (masked) VXH_SC((part_scatter_wv<ND, 0, true, false>)); else VXH_SC((part_scatter_wv<ND, 0, false, false>)); } \
         else { if (masked) VXH_SC((part_scatter_wv<ND, 1, true, false>)); else VXH_SC((part_scatter_wv<ND, 1, false, false>)); } \
@@ -3119,7 +3156,8 @@ void vxh_launch_part_scatter(const PartArgs &args, const LaunchPlan &plan, int s
         }
         else if (hot && args.wv_direct == 4) { // the grouped form with register-held groups and chip-wide write bursts: 8 waves
             if (block > 512) throw std::runtime_error("vaex_hip internal: the phased grouped pass 1 runs with at most 8 waves");
-            if (pred_v) VXH_SC((part_scatter_wv<2, 1, 3, true, 0, 4>));
+            if (pred2) { if (args.nvals == 0) VXH_SC((part_scatter_wv<2, 0, 4, true, 0, 4>)); else VXH_SC((part_scatter_wv<2, 1, 4, true, 0, 4>)); }
+            else if (pred_v) VXH_SC((part_scatter_wv<2, 1, 3, true, 0, 4>));
             else if (pred) { if (args.nvals == 0) VXH_SC((part_scatter_wv<2, 0, 2, true, 0, 4>)); else VXH_SC((part_scatter_wv<2, 1, 2, true, 0, 4>)); }
             else if (masked) { if (args.nvals == 0) VXH_SC((part_scatter_wv<2, 0, true, true, 0, 4>)); else VXH_SC((part_scatter_wv<2, 1, true, true, 0, 4>)); }
             else { if (args.nvals == 0) VXH_SC((part_scatter_wv<2, 0, false, true, 0, 4>)); else VXH_SC((part_scatter_wv<2, 1, false, true, 0, 4>)); }
@@ -3257,7 +3295,9 @@ void vxh_launch_bin(const BinArgs &args, const LaunchPlan &plan, hipStream_t str
     if (plan.count_fast) {
 #define VXH_CNT_T(ND, T)                                                                                               \
     do {                                                                                                               \
-        if (args.pred.on) { /* (the host checks: float64 binner columns) */                                            \
+        if (args.pred.on && args.pred.col2) {                                                                          \
+            if (args.count16) VXH_LAUNCH_K((count_lds_f64<ND, true, 4, double>)); else VXH_LAUNCH_K((count_lds_f64<ND, false, 4, double>)); \
+        } else if (args.pred.on) { /* (the host checks: float64 binner columns) */                                     \
             if (args.count16) VXH_LAUNCH_K((count_lds_f64<ND, true, 2, double>)); else VXH_LAUNCH_K((count_lds_f64<ND, false, 2, double>)); \
         } else if (args.a[0].mask) {                                                                                   \
             if (args.count16) VXH_LAUNCH_K((count_lds_f64<ND, true, true, T>)); else VXH_LAUNCH_K((count_lds_f64<ND, false, true, T>)); \

@@ -50,6 +50,8 @@ struct AggDesc {
 // every comparison with NaN is false except != (vxh_select.hip cmp_f64).  keep = bit (outcomes of the terms) of `truth`.
 struct PredDesc {
     const void *col;   // float64, one element per row of the launch
+    const void *col2;  // round 5: a SECOND float64 column (null: every term reads `col`) — "(v > 3) & (w < 1)"; tcol[t] says which one term t reads
+    uint8_t tcol[4];
     int32_t on;        // 0: no fused selection (aggregator masks, if any, are byte masks)
     int32_t nterms;    // 1..4
     uint32_t truth;
