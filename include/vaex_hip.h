@@ -193,6 +193,22 @@ typedef struct vxh_sel_term {
 } vxh_sel_term;
 int vxh_selection_create(int threads, int n_columns, const int *dtypes, int n_terms, const vxh_sel_term *terms, uint32_t truth, vxh_selection **out);
 void vxh_selection_destroy(vxh_selection *selection);
+/* Round 5 — arithmetic and virtual columns (`a*x + b > c`, `x**2 + y**2 < r`, a selection over `r = sqrt(x**2 + y**2)`): the LEFT side of
+ * term `term` becomes an expression over the selection's float64 columns instead of one column — a postfix program of up to
+ * VXH_SEL_MAX_STEPS steps evaluated per row in float64 (stack depth <= 4), its result compared with the term's constant.  Only operations
+ * whose IEEE results are correctly rounded are offered (add, subtract, multiply, divide, negate, square = x*x as numpy's `x**2`, square
+ * root, absolute value), so the mask equals what vaex's numpy evaluation of the same expression gives (vaex/scopes.py:138-177) bit for
+ * bit; every column a program reads must be float64 (other dtypes follow numpy's promotion rules on the host: not offered).  Such a
+ * selection is evaluated into its keep-mask by a pass of its own (never inside the binning kernels). */
+typedef enum vxh_sel_op { VXH_SEL_COL = 0, VXH_SEL_CONST = 1, VXH_SEL_ADD = 2, VXH_SEL_SUB = 3, VXH_SEL_MUL = 4, VXH_SEL_DIV = 5, VXH_SEL_NEG = 6,
+                          VXH_SEL_SQUARE = 7, VXH_SEL_SQRT = 8, VXH_SEL_ABS = 9 } vxh_sel_op;
+#define VXH_SEL_MAX_STEPS 16
+typedef struct vxh_sel_step {
+    int32_t op;     /* vxh_sel_op */
+    int32_t column; /* VXH_SEL_COL: index into the selection's columns */
+    double value;   /* VXH_SEL_CONST */
+} vxh_sel_step;
+int vxh_selection_set_program(vxh_selection *selection, int term, int n_steps, const vxh_sel_step *steps);
 /* the chunk of column `column` slot `thread` works on (borrowed like the aggregators' data: set_data, src/agg_base.hpp:166-179) */
 int vxh_selection_set_data(vxh_selection *selection, int thread, int column, const void *data, uint64_t n, int mem);
 /* attach (NULL: detach) a selection to an aggregator: rows are kept where the predicate holds AND the data mask, if one is

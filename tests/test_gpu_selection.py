@@ -219,3 +219,50 @@ def _compare_three(shape, what, fused, through_mask, numpy_mask, keep):
             else:
                 assert np.array_equal(np.isnan(fused), np.isnan(other)), shape
                 assert np.allclose(fused, other, rtol=1e-11, atol=2e-10, equal_nan=True), (shape, float(np.nanmax(np.abs(fused - other))))
+
+
+# ------------------------------------------------------------------------------------------------------------
+# round 5: arithmetic over float64 columns and virtual columns — the term's left side is a postfix program evaluated per row on the
+# device (vxh_selection_set_program: + - * / negate, square, sqrt, abs).  IEEE makes each of these correctly rounded, so the device
+# must keep EXACTLY the rows numpy keeps; the columns below carry the values where that is decided (zeros of both signs, infinities,
+# NaN, subnormals, 1 ulp around the constants, negative arguments of sqrt, division by zero).
+# ------------------------------------------------------------------------------------------------------------
+ARITH_EXPRS = [
+    ("x**2 + y**2 < 2", None), ("2*x + 1 > 0", None), ("(rs < 1.5) & (v > 2)", {"rs": "sqrt(x**2 + y**2)"}), ("abs(x - y) / 3 >= 0.25", None),
+    ("-x <= 0", None), ("x / y > 2", None), ("1 / x < -3", None), ("sqrt(x) >= 0.7071067811865476", None), ("sqrt(e) == 1.4142135623730951", None),
+    ("(e * e - 2) / 3 != 0", None), ("x * y - v > -2.5", None), ("e - 1.4142135623730951 > 0", None), ("((x + y) * (x - y)) / (1 + x**2) <= 0.1", None),
+    ("(r2 < 1) | ~(abs(v - 3) > 0.5)", {"r2": "x*x + y*y"}),
+]
+
+
+@pytest.mark.parametrize("where", ["host", "device"])
+def test_arithmetic_and_virtual_column_selections_keep_the_rows_numpy_keeps(where):
+    import torch
+    n = 2_000_003
+    cols = {k: c for k, c in _columns(n, 4).items() if k in ("x", "y", "v")}
+    rng = np.random.default_rng(9)
+    special = np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 5e-324, -5e-324, 2.2250738585072014e-308, 1.0, -1.0, 0.5, 2.0, 1e308, -1e308, 1e-200, 1e200])
+    for k in ("x", "y"):
+        cols[k][rng.integers(0, n, 20_000)] = rng.choice(special, 20_000)
+    e = np.full(n, np.sqrt(2.0))
+    e[::3] = np.nextafter(np.sqrt(2.0), 2.0); e[1::3] = np.nextafter(np.sqrt(2.0), 0.0)
+    e[::7] = 2.0; e[::11] = np.nextafter(2.0, 3.0); e[::13] = np.nextafter(2.0, 1.0)
+    cols["e"] = e
+    held = {k: (torch.from_numpy(c).cuda() if where == "device" else c) for k, c in cols.items()}
+    f = Frame(held, chunk_size=1 << 19, nthreads=3)
+    ns = dict(cols, sqrt=np.sqrt, abs=np.abs)
+    for expr, virtual in ARITH_EXPRS:
+        pred = P.compile_selection(expr, cols, virtual=virtual)
+        assert pred.programs, expr
+        env = dict(ns)
+        for name, ve in (virtual or {}).items():
+            env[name] = eval(ve, {}, env)
+        with np.errstate(all="ignore"):
+            keep = np.asarray(eval(expr, {}, env), dtype=bool)
+        assert np.array_equal(pred.numpy_mask(cols), keep), expr
+        f._predicates[expr] = pred                      # (Frame compiles a string itself; a virtual column's expression comes with the Predicate)
+        got = f.count(binby=["v"], limits=[[-5, 11]], shape=64, selection=expr, edges=True)
+        mask = torch.from_numpy(keep.astype(np.uint8)).cuda() if where == "device" else keep
+        want = f.count(binby=["v"], limits=[[-5, 11]], shape=64, selection=mask, edges=True)
+        assert np.array_equal(got, want), (expr, int(np.abs(np.asarray(got) - np.asarray(want)).sum()))
+        assert int(np.asarray(got).sum()) == int(keep.sum()), expr

@@ -97,12 +97,20 @@ def test_two_hip_processes_reduce_over_gloo(sa):
             assert r.shape == w.shape, name
             if w.dtype.kind in "iub" or name in ("min", "max", "minmax"):   # integers, keys, extrema: exact
                 np.testing.assert_array_equal(r, w, err_msg=f"rank {rank}: {name}")
-            elif name in ("std", "scat_sd"):   # variance from moments: the cancellation bound of tests/cases.py, not the sums' 1e-12
-                # (a cell with ONE row: s2/n - mean^2 is rounding noise around zero, its root NaN on one side and 1e-8 on the other)
+            elif name in ("std", "scat_sd"):
+                # variance from moments, s2/n - mean^2: both sums are exact to 1e-12 of their sum of magnitudes, so the VARIANCE is within
+                # 4e-12 x mean(v^2) of the reference's (bench.py's bound; VERDICT r4 weak #11: rtol 1e-7 / atol 1e-6 on the root was two
+                # orders looser than tests/cases.py's per-cell bound).  mean(v^2) = var + mean^2 from the expected columns.
+                # (a cell with ONE row: the variance is rounding noise around zero, its root NaN on one side and 1e-8 on the other)
                 r0, w0 = np.nan_to_num(r, nan=0.0), np.nan_to_num(w, nan=0.0)
-                empty = want["count"] == 0 if name == "std" else np.zeros(w.shape, dtype=bool)
+                cnt = want["count"] if name == "std" else want["scat_c"]
+                sm = want["sum"] if name == "std" else want["scat_s"]
+                empty = cnt == 0
                 assert np.array_equal(np.isnan(r) & empty, np.isnan(w) & empty), f"rank {rank}: {name}"
-                np.testing.assert_allclose(r0, w0, rtol=1e-7, atol=1e-6, err_msg=f"rank {rank}: {name}")
+                with np.errstate(divide="ignore", invalid="ignore"):
+                    mean_sq = w0 ** 2 + np.nan_to_num(sm / cnt, nan=0.0) ** 2
+                bad = np.abs(r0 ** 2 - w0 ** 2) > 4e-12 * mean_sq + 1e-300
+                assert not bad.any(), (f"rank {rank}: {name}", int(bad.sum()), float(np.max(np.abs(r0 ** 2 - w0 ** 2) / np.maximum(mean_sq, 1e-300))))
             else:   # fp64 sums: |gpu - cpu| <= 1e-12 x sum|v| of the cell / group (north_star's bound)
                 scale = want[{"sum": "sum_abs", "sum_abs": "sum_abs", "dense_s": "dense_s_abs", "dense_s_abs": "dense_s_abs", "scat_s": "scat_s_abs", "scat_s_abs": "scat_s_abs"}[name]]
                 assert np.all(np.abs(r - w) <= 1e-12 * scale), f"rank {rank}: {name}"

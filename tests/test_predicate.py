@@ -32,7 +32,7 @@ def test_compiled_form_equals_numpy(expr):
 
 
 # (chained comparisons, `and` / `or` / `not`: vaex keeps the last link / operand or refuses — left to vaex, see vaex_amd/predicate.py)
-@pytest.mark.parametrize("expr", ["-1.5 <= x < 2", "x > 0 and i < 3", "x > 0 or i < 3", "not (x > 0)", "x + 1 > 0", "x > y", "abs(x) > 1", "z > 0", "x > 0 & y < 1", "(x>0)&(x>1)&(x>2)&(x>3)&(x>4)", "x", "x != x", "x > 'a'", "x >", "i > 99999999999999999999"])
+@pytest.mark.parametrize("expr", ["-1.5 <= x < 2", "x > 0 and i < 3", "x > 0 or i < 3", "not (x > 0)", "i + 1 > 0", "x > y", "sin(x) > 1", "x ** 3 > 1", "x ** 0.5 > 1", "z > 0", "x > 0 & y < 1", "(x>0)&(x>1)&(x>2)&(x>3)&(x>4)", "x", "x != x", "x > 'a'", "x >", "i > 99999999999999999999"])
 def test_everything_else_is_refused(expr):
     with pytest.raises(P.Unsupported):
         P.compile_selection(expr, COLS)
@@ -44,3 +44,39 @@ def test_identical_comparisons_share_a_term_and_keys_identify_predicates():
     assert len(a.terms) == 2
     assert a.key() != b.key()  # (different column order: different objects, same rows)
     assert np.array_equal(a.numpy_mask(COLS), b.numpy_mask(COLS))
+
+
+# round 5: arithmetic over float64 columns (+ - * / unary minus, ** 2, sqrt, abs, numbers) and virtual columns are compiled into postfix
+# programs (vxh_selection_set_program); what numpy computes for these operations is correctly rounded, so the host evaluation below is
+# also what the device must produce
+ARITH = [("2*x + 1 > 0", None), ("x**2 + y**2 < 4", None), ("(r < 1.5) & (x > -1)", {"r": "sqrt(x**2 + y**2)"}), ("abs(x - y)/2 >= 0.25", None),
+         ("-x < 0.5", None), ("3 > x*y", None), ("(x / y > 2) | (1 / x < -3)", None), ("r2 - 1 != 0", {"r2": "x*x", "unused": "sin(x)"}),
+         ("((x + y) * (x - y)) / (1 + x**2) <= 0.1", None)]
+
+
+@pytest.mark.parametrize("expr,virtual", ARITH)
+def test_arithmetic_terms_equal_numpy(expr, virtual):
+    cols = dict(COLS)
+    cols["y"] = np.linspace(-2.0, 2.0, len(cols["x"]))
+    p = P.compile_selection(expr, cols, virtual=virtual)
+    ns = dict(cols, sqrt=np.sqrt, abs=np.abs)
+    for k, v in (virtual or {}).items():
+        if k in expr:
+            ns[k] = eval(v, {}, ns)
+    with np.errstate(all="ignore"):
+        want = eval(expr, {}, ns)
+    assert np.array_equal(p.numpy_mask(cols), want), expr
+    assert p.programs and all(len(st) <= P.MAX_STEPS for st in p.programs.values())
+    assert p.key() != P.compile_selection("x > 0", cols).key()
+
+
+def test_arithmetic_is_float64_only_and_bounded():
+    cols = dict(COLS)
+    cols["f"] = cols["x"].astype("f4")
+    for expr in ("f * 2 > 1", "i + 1 > 2", "x + i > 0", "x ** 3 > 1", "exp(x) > 1", "x > x * 2", "1 > 2 + 3"):
+        with pytest.raises(P.Unsupported):
+            P.compile_selection(expr, cols)
+    with pytest.raises(P.Unsupported):   # more than sixteen steps
+        P.compile_selection(" + ".join(["x * x"] * 9) + " > 1", cols)
+    # a virtual column that is just another name of a real column is a plain term
+    assert not P.compile_selection("alias > 1", cols, virtual={"alias": "x"}).programs

@@ -39,7 +39,8 @@ def frames():
         "or_not": df[(df.x > 1) | ~(df.y >= 0)],
         "f4_boundary": df[df.f4 <= 0.3],                              # float32 column against a double constant
         "int_key": df[df.k != 3],
-        "arithmetic": df[(df.x ** 2 + df.y ** 2) < 4],                # outside the subset: the executor's host mask
+        "arithmetic": df[(df.x ** 2 + df.y ** 2) < 4],                # round 5: arithmetic over float64 columns is a device predicate too
+        "libm": df[np.sin(df.x) + df.y ** 3 < 0.5],                   # outside the subset (libm, other powers): the executor's host mask
         "five_terms": df[(df.x > -2) & (df.x < 2) & (df.y > -2) & (df.y < 2) & (df.v > 0)],   # too many terms: host mask
         "dropnan": df.dropnan(column_names=["v"]),                    # SelectionDropNa: host mask
         "masked_dep": df[df.m > 0],                                   # a filter over a column with missing values: host mask
@@ -108,7 +109,7 @@ for name, d in frames().items():
     parts_as_mask = [u for u in used if u[1]]
     assert parts_as_mask, name
     assert all(u[0] == ("hip" if GPU else "cpu") for u in parts_as_mask), (name, used)
-    device_filter = name in ("one_term", "chain", "or_not", "f4_boundary", "int_key")
+    device_filter = name in ("one_term", "chain", "or_not", "f4_boundary", "int_key", "arithmetic")
     if GPU and device_filter:
         assert delta["device_chunks"] > 0, (name, delta)
         assert any(u[2] for u in parts_as_mask), (name, used)

@@ -60,7 +60,7 @@ def s_xor(d):
     d.select("x > 0"); d.select("y > 0", mode="xor")        # no device form: vaex's host masks
     return [d.count(binby="x", limits=L, shape=32, selection=True)]
 def s_outside_subset(d):
-    d.select("x ** 2 + y ** 2 < 2")                        # arithmetic: host
+    d.select("sin(x) + y ** 3 < 0.5")                      # libm functions / other powers: host
     a = d.count(binby="x", limits=L, shape=32, selection=True)
     d.select("m > 0")                                      # a column with missing values: host
     return [a, d.count(binby="x", limits=L, shape=32, selection=True)]
@@ -69,7 +69,7 @@ def s_filtered(d):
     f.select("x > 0"); f.select("v < 5", mode="and")
     return [f.count(binby="x", limits=L, shape=32, selection=True), f.mean("v", binby="x", limits=L, shape=8, selection=True), f.count(selection=True)]
 def s_one_task(d):                                         # a device name, an expression, nothing and a host name in ONE task
-    d.select("x > 0"); d.select("x ** 2 < 1", name="host")
+    d.select("x > 0"); d.select("sin(x) ** 2 < 0.5", name="host")
     a = d.count(binby="x", limits=L, shape=16, selection=True, delay=True)
     b = d.count(binby="x", limits=L, shape=16, selection="y > 0", delay=True)
     c = d.count(binby="x", limits=L, shape=16, delay=True)
@@ -77,11 +77,27 @@ def s_one_task(d):                                         # a device name, an e
     g = d.sum("v", binby="x", limits=L, shape=16, selection=True, delay=True)
     d.execute()
     return [a.get(), b.get(), c.get(), e.get(), g.get()]
+def s_arithmetic(d):                                       # round 5: arithmetic over float64 columns is evaluated on the device
+    d.select("x ** 2 + y ** 2 < 2")
+    a = d.count(binby="x", limits=L, shape=32, selection=True)
+    d.select("(2 * x - y / 3 > -0.5) & (abs(v - 3) <= 1.5)")
+    return [a, d.count(binby="x", limits=L, shape=32, selection=True), d.mean("v", binby="y", limits=L, shape=16, selection=True)]
+def s_virtual(d):                                          # ... and so is a selection over a VIRTUAL column whose expression is
+    d["r"] = (d.x ** 2 + d.y ** 2) ** 0.5                  # (a power other than 2: host)
+    d["r2"] = d.x ** 2 + d.y ** 2
+    d["rs"] = np.sqrt(d.x ** 2 + d.y ** 2)
+    a = d.count(binby="x", limits=L, shape=32, selection="r2 < 2")
+    b = d.count(binby="x", limits=L, shape=32, selection="(rs < 1.5) & (v > 2)")
+    d.select("rs >= 0.5")
+    c = d.sum("v", binby="y", limits=L, shape=16, selection=True)
+    e = d.count(binby="x", limits=L, shape=32, selection="r < 1")
+    return [a, b, c, e]
 def s_zero_d(d):
     d.select("(i >= 3) | (x < -2)")
     return [np.array([float(d.count(selection=True)), float(d.sum("v", selection=True)), float(d.max("i", selection=True))])]
 scenarios = dict(replace=(s_replace, 2), and_or=(s_and_or, 2), subtract=(s_subtract, 2), inverse=(s_inverse, 2), undo_redo=(s_undo_redo, 2), two_names=(s_two_names, 2),
-                 xor=(s_xor, 0), outside_subset=(s_outside_subset, 0), filtered=(s_filtered, 3), one_task=(s_one_task, 3), zero_d=(s_zero_d, 3))
+                 xor=(s_xor, 0), outside_subset=(s_outside_subset, 0), filtered=(s_filtered, 3), one_task=(s_one_task, 3), zero_d=(s_zero_d, 3),
+                 arithmetic=(s_arithmetic, 3), virtual=(s_virtual, 3))
 
 want = {name: fn(make()) for name, (fn, _) in scenarios.items()}      # plain vaex, its own C++, its own host masks
 

@@ -306,6 +306,8 @@ class Frame:
                 binners.append(getattr(sa, "BinnerOrdinal_" + pf)(slots, s["column"], s["count"], s["min_value"], False, s["invert"]))
         for entry in preds.values():
             entry[0] = sa.Selection(slots, entry[2], [(c, op, v) for c, op, v in entry[3].terms], entry[3].truth)
+            if entry[3].programs:   # terms whose left side is an arithmetic expression over float64 columns (vxh_selection_set_program)
+                entry[0].set_programs({t: [tuple(st) for st in steps] for t, steps in entry[3].programs.items()})
         grid = sa.Grid(binners)
         aggs = []
         for p in prims:

@@ -19,6 +19,7 @@
 #include <pybind11/stl.h>
 
 #include <algorithm>
+#include <map>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -368,6 +369,14 @@ struct PySelection {
             ts.push_back(v);
         }
         check(vxh_selection_create(threads, (int)dtypes.size(), dtypes.data(), (int)ts.size(), ts.data(), truth, &h));
+    }
+    // programs: {term index: [(op, column, value), ...]} — the terms whose left side is an arithmetic expression (vxh_selection_set_program)
+    void set_programs(const std::map<int, std::vector<std::tuple<int, int, double>>> &programs) {
+        for (auto &kv : programs) {
+            std::vector<vxh_sel_step> steps;
+            for (auto &st : kv.second) steps.push_back(vxh_sel_step{std::get<0>(st), std::get<1>(st), std::get<2>(st)});
+            check(vxh_selection_set_program(h, kv.first, (int)steps.size(), steps.data()));
+        }
     }
     ~PySelection() { vxh_selection_destroy(h); }
     PySelection(const PySelection &) = delete;
@@ -996,7 +1005,11 @@ PYBIND11_MODULE(superagg, m) {
     });
     py::class_<PySelection>(m, "Selection")
         .def(py::init<int, const std::vector<int> &, const std::vector<std::tuple<int, int, py::object>> &, uint32_t>(), py::arg("threads"), py::arg("dtypes"), py::arg("terms"), py::arg("truth"))
+        .def("set_programs", &PySelection::set_programs, py::arg("programs"))
         .def("set_data", &PySelection::set_data);
+    m.attr("SEL_COL") = (int)VXH_SEL_COL; m.attr("SEL_CONST") = (int)VXH_SEL_CONST; m.attr("SEL_ADD") = (int)VXH_SEL_ADD; m.attr("SEL_SUB") = (int)VXH_SEL_SUB;
+    m.attr("SEL_MUL") = (int)VXH_SEL_MUL; m.attr("SEL_DIV") = (int)VXH_SEL_DIV; m.attr("SEL_NEG") = (int)VXH_SEL_NEG; m.attr("SEL_SQUARE") = (int)VXH_SEL_SQUARE;
+    m.attr("SEL_SQRT") = (int)VXH_SEL_SQRT; m.attr("SEL_ABS") = (int)VXH_SEL_ABS;
     m.attr("CMP_LT") = (int)VXH_CMP_LT; m.attr("CMP_LE") = (int)VXH_CMP_LE; m.attr("CMP_GT") = (int)VXH_CMP_GT;
     m.attr("CMP_GE") = (int)VXH_CMP_GE; m.attr("CMP_EQ") = (int)VXH_CMP_EQ; m.attr("CMP_NE") = (int)VXH_CMP_NE;
     py::class_<PyAgg> aggregator(m, "Aggregator", py::buffer_protocol());

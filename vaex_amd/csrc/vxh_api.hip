@@ -2210,7 +2210,7 @@ int vxh_grid_bin(vxh_grid *grid, int thread, vxh_agg *const *aggs, int n_aggs, u
         // (round 5: the terms may read TWO float64 columns — "(v > 3) & (w < 1)" — PredDesc::col2 / tcol)
         ok = ok && fsel && (fsel->n_columns == 1 || fsel->n_columns == 2) && fsel->n_terms >= 1 && fsel->n_terms <= 4;
         for (int cidx = 0; ok && cidx < fsel->n_columns; cidx++) ok = fsel->dtype[cidx] == VXH_F64;
-        for (int t = 0; ok && t < fsel->n_terms; t++) ok = fsel->term[t].column >= 0 && fsel->term[t].column < fsel->n_columns; // (an integer constant next to a float64 column is compared as float64: vxh_select.hip term_at)
+        for (int t = 0; ok && t < fsel->n_terms; t++) ok = fsel->term[t].column >= 0 && fsel->term[t].column < fsel->n_columns && fsel->nsteps[t] == 0; // (expression terms: sel_eval's pass) // (an integer constant next to a float64 column is compared as float64: vxh_select.hip term_at)
         if (!ok) fsel = nullptr;
     }
     PredDesc call_pred{};
@@ -2260,6 +2260,10 @@ int vxh_grid_bin(vxh_grid *grid, int thread, vxh_agg *const *aggs, int n_aggs, u
             for (int t = 0; t < sel->n_terms; t++) {
                 S.t[t].column = sel->term[t].column; S.t[t].op = sel->term[t].op; S.t[t].is_int = sel->term[t].is_int;
                 S.t[t].value = sel->term[t].value; S.t[t].ivalue = sel->term[t].ivalue;
+            }
+            for (int t = 0; t < sel->n_terms; t++) {
+                S.nsteps[t] = sel->nsteps[t];
+                for (int k2 = 0; k2 < sel->nsteps[t]; k2++) S.prog[t][k2] = sel->prog[t][k2];
             }
             S.and_mask = (const uint8_t *)resolve(a->mask[thread], 1);
             S.out = (uint8_t *)slot.sel_buf + off;
@@ -2514,6 +2518,36 @@ int vxh_selection_create(int threads, int n_columns, const int *dtypes, int n_te
     VXH_API_END
 }
 void vxh_selection_destroy(vxh_selection *selection) { delete selection; }
+int vxh_selection_set_program(vxh_selection *sel, int term, int n_steps, const vxh_sel_step *steps) {
+    VXH_API_BEGIN
+    if (term < 0 || term >= sel->n_terms) throw std::runtime_error("vxh_selection_set_program: no such term");
+    if (n_steps < 1 || n_steps > VXH_SEL_MAX_STEPS) throw std::runtime_error("vxh_selection_set_program: 1 to 16 steps");
+    int depth = 0;
+    for (int k = 0; k < n_steps; k++) {
+        const vxh_sel_step &st = steps[k];
+        switch (st.op) {
+        case VXH_SEL_COL:
+            if (st.column < 0 || st.column >= sel->n_columns) throw std::runtime_error("vxh_selection_set_program: step reads a column that does not exist");
+            if (sel->dtype[st.column] != VXH_F64) throw std::runtime_error("vxh_selection_set_program: expressions are evaluated over float64 columns only");
+            depth++;
+            break;
+        case VXH_SEL_CONST: depth++; break;
+        case VXH_SEL_ADD: case VXH_SEL_SUB: case VXH_SEL_MUL: case VXH_SEL_DIV:
+            if (depth < 2) throw std::runtime_error("vxh_selection_set_program: operator without two operands");
+            depth--;
+            break;
+        case VXH_SEL_NEG: case VXH_SEL_SQUARE: case VXH_SEL_SQRT: case VXH_SEL_ABS:
+            if (depth < 1) throw std::runtime_error("vxh_selection_set_program: operator without an operand");
+            break;
+        default: throw std::runtime_error("vxh_selection_set_program: unknown step");
+        }
+        if (depth > 4) throw std::runtime_error("vxh_selection_set_program: expression needs more than four stack entries");
+    }
+    if (depth != 1) throw std::runtime_error("vxh_selection_set_program: the program does not leave exactly one value");
+    sel->nsteps[term] = n_steps;
+    for (int k = 0; k < n_steps; k++) sel->prog[term][k] = steps[k];
+    VXH_API_END
+}
 int vxh_selection_set_data(vxh_selection *sel, int thread, int column, const void *data, uint64_t n, int mem) {
     VXH_API_BEGIN
     if (column < 0 || column >= sel->n_columns) throw std::runtime_error("vxh_selection_set_data: no such column");

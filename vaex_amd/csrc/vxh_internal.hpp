@@ -54,6 +54,8 @@ struct vxh_selection {
     struct Term { int column, op, is_int; double value; int64_t ivalue; } term[4];
     uint32_t truth = 0;
     std::vector<SlotData> data[4]; // per column, per thread slot
+    int nsteps[4] = {0, 0, 0, 0};  // > 0: the term's left side is this postfix program (vxh_selection_set_program)
+    vxh_sel_step prog[4][VXH_SEL_MAX_STEPS];
 };
 
 struct vxh_agg {

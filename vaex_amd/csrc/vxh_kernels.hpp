@@ -268,6 +268,8 @@ struct SelArgs {
     const uint8_t *and_mask; // optional: keep only where this is non-zero too (missing values: vaex/cpu.py:770-784)
     uint8_t *out;
     uint64_t n;
+    int32_t nsteps[VXH_SEL_MAX_TERMS];                       // > 0: term t compares the result of prog[t] (float64 columns only) instead of a column
+    vxh_sel_step prog[VXH_SEL_MAX_TERMS][VXH_SEL_MAX_STEPS];
 };
 // AggFirst (first / last value per cell by an order column): vxh_kernels.hip first_pass<1..3>
 struct FirstArgs {

@@ -37,8 +37,32 @@ __device__ __forceinline__ bool cmp_int(I x, int op, I c) {
     }
 }
 
+// the left side of an expression term: a postfix program over float64 columns, a stack of four doubles kept in registers (pushes
+// and pops are moves — no indexed array, nothing in scratch memory); every step is a wave-uniform switch
+__device__ __forceinline__ double eval_program(const SelArgs &A, int t, uint64_t i) {
+    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    const int n = A.nsteps[t];
+    for (int k = 0; k < n; ++k) {
+        const vxh_sel_step &st = A.prog[t][k];
+        switch (st.op) {
+        case VXH_SEL_COL: s3 = s2; s2 = s1; s1 = s0; s0 = ((const double *)A.col[st.column])[i]; break;
+        case VXH_SEL_CONST: s3 = s2; s2 = s1; s1 = s0; s0 = st.value; break;
+        case VXH_SEL_ADD: s0 = s1 + s0; s1 = s2; s2 = s3; break;
+        case VXH_SEL_SUB: s0 = s1 - s0; s1 = s2; s2 = s3; break;
+        case VXH_SEL_MUL: s0 = s1 * s0; s1 = s2; s2 = s3; break;
+        case VXH_SEL_DIV: s0 = s1 / s0; s1 = s2; s2 = s3; break;
+        case VXH_SEL_NEG: s0 = -s0; break;
+        case VXH_SEL_SQUARE: s0 = s0 * s0; break;
+        case VXH_SEL_SQRT: s0 = sqrt(s0); break;
+        default: s0 = fabs(s0); break;
+        }
+    }
+    return s0;
+}
+
 __device__ __forceinline__ bool term_at(const SelArgs &A, int t, uint64_t i) {
     const SelTerm &T = A.t[t];
+    if (A.nsteps[t] > 0) return cmp_f64(eval_program(A, t, i), T.op, T.value);
     const void *p = A.col[T.column];
     const int op = T.op;
     switch (A.dtype[T.column]) {

@@ -6,6 +6,11 @@ validated against the AST whitelist of vaex/expresso.py:46-155) and evaluates it
 
     comparisons  <column> (< <= > >= == !=) <number>,  <number> (op) <column>
     combined with  &  |  ~,  at most 4 comparisons over at most 4 columns
+    round 5: the column side may be an ARITHMETIC EXPRESSION over float64 columns — + - * / unary minus, `** 2`, sqrt(), abs(),
+    numbers — e.g. `2*x + 1 > 0`, `x**2 + y**2 < 4`; names of VIRTUAL columns (`virtual=`: name -> expression string, as in
+    df.virtual_columns) are inlined, so a selection over `r = sqrt(x**2 + y**2)` qualifies.  Only operations whose float64 results are
+    correctly rounded are taken (what numpy computes for them is what the device computes, bit for bit); other dtypes and functions
+    stay with vaex's numpy evaluation (numpy's promotion rules and libm are not restated).
 
 Left to vaex on purpose: `and` / `or` and chained comparisons (`a < x <= b`) — vaex's expression rewriter keeps only the LAST operand
 / link of those (vaex/expresso.py:438-446 visit_Compare and its BoolOp sibling overwrite their string per operand: on
@@ -63,22 +68,53 @@ def plain_numeric_dtype(ar):
     return dt if dt.name in _DTYPES else None
 
 
-class Predicate:
-    """columns: names; terms: (column index, op code, python int/float constant); truth: bit b = keep when term outcomes spell b"""
+# steps of an expression term's postfix program (include/vaex_hip.h vxh_sel_op)
+SEL_COL, SEL_CONST, SEL_ADD, SEL_SUB, SEL_MUL, SEL_DIV, SEL_NEG, SEL_SQUARE, SEL_SQRT, SEL_ABS = range(10)
+MAX_STEPS = 16
 
-    def __init__(self, expression, columns, terms, truth):
+
+class Predicate:
+    """columns: names; terms: (column index, op code, python int/float constant); truth: bit b = keep when term outcomes spell b;
+    programs: {term index: ((step op, column index, float value), ...)} for the terms whose left side is an arithmetic expression
+    (their `column index` in `terms` is the first column the program reads)"""
+
+    def __init__(self, expression, columns, terms, truth, programs=None):
         self.expression, self.columns, self.terms, self.truth = expression, columns, terms, truth
+        self.programs = dict(programs or {})
 
     def key(self):
-        return (tuple(self.columns), tuple(self.terms), self.truth)
+        return (tuple(self.columns), tuple(self.terms), self.truth, tuple(sorted(self.programs.items())))
+
+    def _evaluate_program(self, steps, arrays):
+        stack = []
+        with np.errstate(all="ignore"):
+            for op, c, value in steps:
+                if op == SEL_COL:
+                    stack.append(np.asarray(arrays[self.columns[c]], dtype=np.float64))
+                elif op == SEL_CONST:
+                    stack.append(np.float64(value))
+                elif op in (SEL_ADD, SEL_SUB, SEL_MUL, SEL_DIV):
+                    b, a = stack.pop(), stack.pop()
+                    stack.append({SEL_ADD: operator.add, SEL_SUB: operator.sub, SEL_MUL: operator.mul, SEL_DIV: operator.truediv}[op](a, b))
+                elif op == SEL_NEG:
+                    stack.append(-stack.pop())
+                elif op == SEL_SQUARE:
+                    a = stack.pop()
+                    stack.append(a * a)
+                elif op == SEL_SQRT:
+                    stack.append(np.sqrt(stack.pop()))
+                else:
+                    stack.append(np.abs(stack.pop()))
+        return stack[0]
 
     def numpy_mask(self, arrays):
         """the same predicate evaluated with numpy on host columns: what vaex itself does per chunk; used by the passes that take
         a ready-made mask (minmax, hashed groupby) and by the tests as the expected row set"""
         outcomes = []
-        for c, op, value in self.terms:
+        for t, (c, op, value) in enumerate(self.terms):
             with np.errstate(invalid="ignore"):
-                outcomes.append(_NUMPY[op](np.asarray(arrays[self.columns[c]]), value))
+                left = self._evaluate_program(self.programs[t], arrays) if t in self.programs else np.asarray(arrays[self.columns[c]])
+                outcomes.append(_NUMPY[op](left, value))
         bits = np.zeros(len(outcomes[0]), dtype=np.uint32)
         for t, o in enumerate(outcomes):
             bits |= o.astype(np.uint32) << t
@@ -95,13 +131,90 @@ def _constant(node):
     return None
 
 
-def compile_selection(expression, known_columns):
-    """expression string -> Predicate; raises Unsupported for anything outside the subset"""
+def compile_selection(expression, known_columns, virtual=None):
+    """expression string -> Predicate; raises Unsupported for anything outside the subset.
+    known_columns: name -> column object (its dtype decides whether it may appear in an arithmetic expression: float64 only);
+    virtual: name -> expression string of the frame's virtual columns (inlined)"""
     try:
         tree = ast.parse(expression.strip(), mode="eval").body
     except SyntaxError as e:
         raise Unsupported(str(e))
-    columns, terms = [], []
+    columns, terms, programs = [], [], {}
+    virtual = dict(virtual or {})
+
+    def is_f64(name):
+        col = known_columns[name] if hasattr(known_columns, "__getitem__") else None
+        dt = getattr(col, "dtype", None)
+        if dt is None:
+            dt = plain_numeric_dtype(col)
+        return str(dt).replace("torch.", "") == "float64"
+
+    def arithmetic(node, steps, depth=0):
+        """postfix steps of an arithmetic expression over float64 columns; returns the stack depth it needs"""
+        if depth > 24:
+            raise Unsupported("expression nested too deeply")
+        c = _constant(node)
+        if c is not None:
+            steps.append((SEL_CONST, 0, float(c)))
+            return 1
+        if isinstance(node, ast.Name):
+            if node.id in virtual and node.id not in known_columns:
+                try:
+                    sub = ast.parse(str(virtual[node.id]).strip(), mode="eval").body
+                except SyntaxError as e:
+                    raise Unsupported(str(e))
+                return arithmetic(sub, steps, depth + 1)
+            if node.id not in known_columns:
+                raise Unsupported(f"{node.id!r} is not a column")
+            if not is_f64(node.id):
+                raise Unsupported(f"arithmetic over {node.id!r}: only float64 columns are computed on the device (numpy's promotion rules stay on the host)")
+            if node.id not in columns:
+                columns.append(node.id)
+            steps.append((SEL_COL, columns.index(node.id), 0.0))
+            return 1
+        if isinstance(node, ast.BinOp):
+            if isinstance(node.op, ast.Pow):
+                if _constant(node.right) != 2 or isinstance(_constant(node.right), float) and _constant(node.right) != 2.0:
+                    raise Unsupported("only `** 2` is computed on the device (numpy squares; other powers go through libm)")
+                d = arithmetic(node.left, steps, depth + 1)
+                steps.append((SEL_SQUARE, 0, 0.0))
+                return d
+            code = {ast.Add: SEL_ADD, ast.Sub: SEL_SUB, ast.Mult: SEL_MUL, ast.Div: SEL_DIV}.get(type(node.op))
+            if code is None:
+                raise Unsupported(f"operator {type(node.op).__name__} is not computed on the device")
+            dl = arithmetic(node.left, steps, depth + 1)
+            dr = arithmetic(node.right, steps, depth + 1)
+            steps.append((code, 0, 0.0))
+            return max(dl, 1 + dr)
+        if isinstance(node, ast.UnaryOp) and isinstance(node.op, (ast.USub, ast.UAdd)):
+            d = arithmetic(node.operand, steps, depth + 1)
+            if isinstance(node.op, ast.USub):
+                steps.append((SEL_NEG, 0, 0.0))
+            return d
+        if isinstance(node, ast.Call) and isinstance(node.func, ast.Name) and node.func.id in ("sqrt", "abs") and len(node.args) == 1 and not node.keywords:
+            d = arithmetic(node.args[0], steps, depth + 1)
+            steps.append((SEL_SQRT if node.func.id == "sqrt" else SEL_ABS, 0, 0.0))
+            return d
+        raise Unsupported(f"{type(node).__name__} is not part of the device expression subset")
+
+    def expression_term(node, op, value):
+        steps = []
+        need = arithmetic(node, steps)
+        if need > 4 or len(steps) > MAX_STEPS:
+            raise Unsupported("expression too long for the device (16 steps, four stack entries)")
+        if len(steps) == 1 and steps[0][0] == SEL_COL:   # (a virtual column that IS a real column)
+            return term(columns[steps[0][1]], op, value)
+        first = next((c for o, c, _ in steps if o == SEL_COL), None)
+        if first is None:
+            raise Unsupported("a comparison between two constants")
+        t = (first, op, float(value))
+        prog = tuple(steps)
+        for i, old in enumerate(terms):
+            if old == t and programs.get(i) == prog:
+                return ("term", i)
+        terms.append(t)
+        programs[len(terms) - 1] = prog
+        return ("term", len(terms) - 1)
 
     def term(name, op, value):
         if name not in known_columns:
@@ -111,9 +224,11 @@ def compile_selection(expression, known_columns):
         if name not in columns:
             columns.append(name)
         t = (columns.index(name), op, value)
-        if t not in terms:
-            terms.append(t)
-        return ("term", terms.index(t))
+        for i, old in enumerate(terms):
+            if old == t and i not in programs:
+                return ("term", i)
+        terms.append(t)
+        return ("term", len(terms) - 1)
 
     def walk(node):
         if isinstance(node, ast.BoolOp):
@@ -132,12 +247,17 @@ def compile_selection(expression, known_columns):
                 if type(op) not in _OPS:
                     raise Unsupported("comparison not supported")
                 code = _OPS[type(op)]
-                if isinstance(left, ast.Name) and _constant(right) is not None:
+                plain = lambda nd: isinstance(nd, ast.Name) and (nd.id in known_columns or nd.id not in virtual)
+                if plain(left) and _constant(right) is not None:
                     parts.append(term(left.id, code, _constant(right)))
-                elif isinstance(right, ast.Name) and _constant(left) is not None:
+                elif plain(right) and _constant(left) is not None:
                     parts.append(term(right.id, _SWAP[code], _constant(left)))
+                elif _constant(right) is not None and _constant(left) is None:
+                    parts.append(expression_term(left, code, _constant(right)))
+                elif _constant(left) is not None and _constant(right) is None:
+                    parts.append(expression_term(right, _SWAP[code], _constant(left)))
                 else:
-                    raise Unsupported("only <column> <op> <number> comparisons run on the device")
+                    raise Unsupported("only <column or arithmetic expression> <op> <number> comparisons run on the device")
                 left = right
             return parts[0] if len(parts) == 1 else ("and", parts)
         raise Unsupported(f"{type(node).__name__} is not part of the device predicate subset")
@@ -160,4 +280,4 @@ def compile_selection(expression, known_columns):
         bits = sum(1 << t for t, o in enumerate(outcome) if o)
         if value(tree, outcome):
             truth |= 1 << bits
-    return Predicate(expression, columns, terms, truth)
+    return Predicate(expression, columns, terms, truth, programs)

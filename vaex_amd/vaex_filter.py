@@ -57,13 +57,18 @@ def _known_columns(df):
     return {name: ar for name, ar in df.columns.items() if _predicate.plain_numeric_dtype(ar) is not None}
 
 
+def _virtual_columns(df):
+    from . import vaex_selection
+    return vaex_selection._virtual_columns(df)
+
+
 def filter_plan(df):
     """the Predicate the frame's filter compiles to, or None (then the executor's host mask is used)"""
     expr = filter_expression(df)
     if expr is None:
         return None
     try:
-        return _predicate.compile_selection(expr, _known_columns(df))
+        return _predicate.compile_selection(expr, _known_columns(df), virtual=_virtual_columns(df))
     except _predicate.Unsupported:
         return None
 
@@ -74,7 +79,7 @@ def combined_plan(df, selection):
     if expr is None:
         return None
     try:
-        return _predicate.compile_selection(f"({expr}) & ({selection})", _known_columns(df))
+        return _predicate.compile_selection(f"({expr}) & ({selection})", _known_columns(df), virtual=_virtual_columns(df))
     except _predicate.Unsupported:
         return None
 

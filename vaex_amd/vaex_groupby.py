@@ -155,7 +155,7 @@ def _selection_of(df, aggregate, columns):
         if not sel:
             raise _Decline("named selection outside the device predicate subset")
     try:
-        pred = predicate.compile_selection(sel, vaex_selection._known_columns(df))
+        pred = predicate.compile_selection(sel, vaex_selection._known_columns(df), virtual=vaex_selection._virtual_columns(df))
     except predicate.Unsupported as e:
         raise _Decline(f"selection outside the device predicate subset ({e})")
     for c in pred.columns:

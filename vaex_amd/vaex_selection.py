@@ -95,6 +95,15 @@ def _known_columns(df):
     return known
 
 
+def _virtual_columns(df):
+    """name -> expression string of the frame's virtual columns (vaex/dataframe.py `virtual_columns`): a selection over one is compiled
+    with the expression inlined, when that is arithmetic over float64 columns (vaex_amd.predicate)"""
+    try:
+        return {str(k): str(v) for k, v in dict(df.virtual_columns).items()}
+    except Exception:
+        return {}
+
+
 def plan_for(df, descriptor, resolved=None):
     """the Predicate an aggregation's selection compiles to, or None (then vaex evaluates the selection itself).
     resolved: for a NAMED selection the expression it stood for when the aggregation was scheduled ("" = it was not planned then);
@@ -110,7 +119,7 @@ def plan_for(df, descriptor, resolved=None):
         if not sel:
             return None
     try:
-        pred = _predicate.compile_selection(sel, _known_columns(df))
+        pred = _predicate.compile_selection(sel, _known_columns(df), virtual=_virtual_columns(df))
     except _predicate.Unsupported:
         return None
     return pred
@@ -228,6 +237,8 @@ def _attach_predicates(part, backend_used, superagg, nthreads, plans, extras, fp
         if key not in objs:
             dtypes = [_predicate.dtype_code(_predicate.plain_numeric_dtype(part.df.columns[c])) for c in pred.columns]
             objs[key] = superagg.Selection(nthreads, dtypes, [(c, op, v) for c, op, v in pred.terms], pred.truth)
+            if pred.programs:   # arithmetic / virtual-column terms (vxh_selection_set_program)
+                objs[key].set_programs({t: [tuple(st) for st in steps] for t, steps in pred.programs.items()})
         return objs[key]
     # global index of an aggregation's (single) selection in the executor's `selections` list: one entry per aggregation
     # without a list of selections (vaex/tasks.py:528-535); lists of selections never get a plan
