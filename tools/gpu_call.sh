@@ -8,6 +8,7 @@
 #   kstats[:<bench.py args>]   rocprofv3 --kernel-trace --stats of bench.py --no-cpu --no-extra --no-configs <args> -> kernel_stats.txt
 #                              and the bench line of THAT SAME process -> bench_profiled.json
 #   pmc[:<set>;<set>...]       one rocprofv3 --pmc pass per counter set (',' inside a set; kernel-trace only, never with other traces) of a short bench command -> pmc_<n>.txt
+#   cfgprof[:<configs>]        kernel stats + FETCH_SIZE / WRITE_SIZE passes of every BASELINE config alone -> configs_kernel_stats.txt, configs_pmc_traffic.txt
 #   tune:<args>                python tools/r03_headline_tune.py <args>
 #   py:<script>[:<args>]       python <script> <args>
 #   sh:<command>               bash -c <command>
@@ -39,6 +40,17 @@ for step in "$@"; do
               (cd /tmp && timeout 600 rocprofv3 --pmc ${ctr//,/ } --kernel-trace --output-format csv -d /tmp/pmc_${n}_$i -- python $R/bench.py --no-cpu --no-extra --no-configs --steps 2 --warmup 1 > /dev/null 2> $O/pmc_${n}_$i.err)
             done
             python tools/pmc_summary.py "/tmp/pmc_${n}_*/*/*counter_collection.csv" > $O/pmc_$n.txt 2>&1; head -60 $O/pmc_$n.txt ;;
+    cfgprof) # per-config kernel stats + HBM traffic counters (tools/r03_config_one.py <config> 1e9): configs_kernel_stats.txt, configs_pmc_traffic.txt
+            for c in ${args:-count2d c2 c2e c3d c3s}; do
+              rm -rf /tmp/ks_$c; (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks_$c -- python $R/tools/r03_config_one.py $c 1e9 3 > $O/${c}_run.txt 2> $O/ks_$c.err)
+              f=$(find /tmp/ks_$c -name "*kernel_stats.csv" | head -1)
+              (echo "=== $c: $(tail -1 $O/${c}_run.txt)"; python tools/kstats.py "$f" 12 | grep -v "at::native\|rocclr\|fill_kernel") >> $O/configs_kernel_stats.txt
+              for ctr in FETCH_SIZE WRITE_SIZE; do
+                rm -rf /tmp/pmc_${c}_$ctr; (cd /tmp && timeout 300 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d /tmp/pmc_${c}_$ctr -- python $R/tools/r03_config_one.py $c 1e9 2 > /dev/null 2> $O/pmc_${c}_$ctr.err)
+              done
+              (echo "=== $c (per dispatch; 2 passes of 1e9 rows)"; python tools/pmc_summary.py "/tmp/pmc_${c}_*/*/*counter_collection.csv") >> $O/configs_pmc_traffic.txt
+            done
+            cat $O/configs_kernel_stats.txt | head -60 ;;
     tune)   timeout 1200 python tools/r03_headline_tune.py $args 2>&1 | filter | tee $O/tune_$n.txt | tail -30 ;;
     py)     script=${rest%%:*}; a=""; [[ "$rest" == *:* ]] && a=${rest#*:}; timeout 1500 python $script ${a//,/ } 2>&1 | filter | tee $O/py_$n.txt | tail -40 ;;
     sh)     timeout 1500 bash -c "$rest" 2>&1 | filter | tee $O/sh_$n.txt | tail -40 ;;

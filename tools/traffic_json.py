@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
-"""profiles/r04_traffic.json from the PMC summaries of tools/r04_round_profile.sh (pmc_bench_traffic.txt, configs_pmc_traffic.txt):
+"""profiles/r<NN>_traffic.json from the PMC summaries of a profiling call (the bench pass's: pmc_bench_traffic.txt or pmc_<n>.txt; the configs': configs_pmc_traffic.txt):
 HBM bytes per row = sum over the kernels of a pass of (FETCH_SIZE x 2 + WRITE_SIZE) KiB per dispatch x dispatches per pass / rows.
 FETCH_SIZE x 2: gfx950 counts 128-byte requests as 64 B (MI355X_MICROARCH.md, HBM section; the check printed with every config:
 the dominant kernel's read bytes per row against the columns it must read).
-Usage: python tools/r04_traffic_json.py <dir with the two txt files> > profiles/r04_traffic.json"""
+Usage: python tools/traffic_json.py <bench pmc summary> <configs pmc summary> [round label] > profiles/r05_traffic.json"""
 import json, re, sys, os
 
 def parse(path):
@@ -22,9 +22,9 @@ def parse(path):
             out[sect][cur][m.group(1)] = (float(m.group(2)), int(m.group(3)))
     return out
 
-d = sys.argv[1]
-bench = parse(os.path.join(d, "pmc_bench_traffic.txt")).get("bench", {})
-cfgs = parse(os.path.join(d, "configs_pmc_traffic.txt"))
+bench = parse(sys.argv[1]).get("bench", {})
+cfgs = parse(sys.argv[2]) if len(sys.argv) > 2 and os.path.exists(sys.argv[2]) else {}
+label = sys.argv[3] if len(sys.argv) > 3 else "5"
 ROWS = 1_000_000_000
 # kernels of one pass: (name prefix, dispatches per pass)
 SPEC = {
@@ -50,7 +50,7 @@ def per_row(kernels, spec):
         total += b
     return round(total, 2), parts
 
-out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) of bench.py and of tools/r03_config_one.py <config> 1e9 2 on the final tree of round 4 (tools/r04_round_profile.sh; summaries: profiles/r04_pmc_bench_traffic.txt, r04_configs_pmc_traffic.txt)",
+out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) of bench.py and of tools/r03_config_one.py <config> 1e9 2 on the final tree of round " + label + " (tools/gpu_call.sh steps `pmc` and `cfgprof`; summaries: profiles/r0" + label + "_pmc_bench.txt, r0" + label + "_configs_pmc_traffic.txt)",
        "correction": "FETCH_SIZE x2 (gfx950 counts 128-B requests as 64 B: MI355X_MICROARCH.md HBM section)", "rows_per_pass": ROWS}
 t, parts = per_row(bench, SPEC["bench"][0])
 out["hbm_bytes_per_row"] = t
