@@ -884,3 +884,49 @@ def test_default_pass1_next_to_a_box_is_the_phased_grouped_form(sa):
         assert np.all(np.abs(r[1] - results[0][1]) <= 1e-12 * 20.0 * np.maximum(results[0][0], 1))
     assert int(results[0][0].sum()) == n
 
+
+
+def test_count_256x256_takes_the_box_when_the_sample_says_so(sa):
+    """round 5: count(*) on 256 x 256 (north_star's target sentence) fits one workgroup's LDS only with packed uint16 counters, i.e. a
+    returning LDS atomic per row.  Where a sample of the columns says the hot box of the partition strategy (194 x 194 uint32 counters)
+    holds >= 90 % of the rows, the call takes that road (phased pass 1 + part_reduce_grp); spread-out data and the knob set to 0 keep
+    count_lds_f64<PACK16>.  Same grid either way, every row counted, with and without a keep-mask."""
+    import torch
+    g = torch.Generator(device="cuda").manual_seed(19)
+    n = (1 << 26) + 777
+    x = torch.randn(n, dtype=torch.float64, device="cuda", generator=g)
+    y = torch.randn(n, dtype=torch.float64, device="cuda", generator=g)
+    xu = torch.rand(n, dtype=torch.float64, device="cuda", generator=g) * 8 - 4
+    keep = (torch.rand(n, device="cuda", generator=g) < 0.5).to(torch.uint8)
+
+    def count(cx, cy, mask=None, **knobs):
+        bx = sa.BinnerScalar_float64(1, "x", -4.0, 4.0, 256); by = sa.BinnerScalar_float64(1, "y", -4.0, 4.0, 256)
+        grid = sa.Grid([bx, by])
+        c = sa.AggCount_int64(grid, 1, 1)
+        bx.set_data(0, cx); by.set_data(0, cy)
+        if mask is not None:
+            c.set_data_mask(0, mask)
+        for k, val in knobs.items():
+            sa.config_set(k, val)
+        try:
+            grid.bin(0, [c], n)
+            return np.array(c.get_result()), sa.last_kernel(0)
+        finally:
+            for k in knobs:
+                sa.config_set(k, 90 if k == "count_box_pct" else 0)
+
+    via_box, k_box = count(x, y)
+    packed, k_packed = count(x, y, count_box_pct=0)
+    assert k_box.startswith("part_scatter_phased_hot") and k_packed.startswith(("count_lds16", "bin_lds_count16")), (k_box, k_packed)
+    np.testing.assert_array_equal(via_box, packed)
+    assert int(via_box.sum()) == n
+    yu = torch.rand(n, dtype=torch.float64, device="cuda", generator=g) * 8 - 4
+    wide, k_wide = count(xu, y)                           # uniform x, N(0,1) y: the box search turns the box into a 259 x 145 band — still > 90 %
+    assert k_wide.startswith("part_scatter_phased_hot") and int(wide.sum()) == n, k_wide
+    spread, k_spread = count(xu, yu)                      # uniform x AND y: no box holds more than ~57 % of the sample — the packed kernel stays
+    assert k_spread.startswith(("count_lds16", "bin_lds_count16")), k_spread
+    assert int(spread.sum()) == n
+    m_box, k_mbox = count(x, y, keep)
+    m_packed, _ = count(x, y, keep, count_box_pct=0)
+    np.testing.assert_array_equal(m_box, m_packed)
+    assert int(m_box.sum()) == int(keep.sum().item())

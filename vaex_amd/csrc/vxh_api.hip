@@ -685,6 +685,10 @@ static const double kIngestBytesPerSec = 6.0e12;
 static const double kHbmAtomicsPerSec = 22.0e9;
 static const size_t kLdsMax = 160 * 1024;
 
+// set for the duration of a vxh_grid_bin call that takes a count(*) pass through the partition strategy's hot box instead of the
+// packed-counter LDS kernel (see there): every make_plan of that call plans without the uint16 LDS form
+static thread_local bool tl_no_count16 = false;
+
 static LaunchPlan make_plan(const BinArgs &A, BinArgs &out, uint64_t n, double bytes_per_row, bool exclusive) {
     Context &c = ctx();
     LaunchPlan p{};
@@ -773,7 +777,7 @@ static LaunchPlan make_plan(const BinArgs &A, BinArgs &out, uint64_t n, double b
     // workgroup's LDS — a single LDS-private pass instead of interleaved slabs / partition + reduce
     bool all_count = A.nagg > 0;
     for (int k = 0; k < A.nagg; k++) all_count = all_count && A.a[k].kind == VXH_AGG_COUNT;
-    const bool c16_lds = all_count && c.cfg_count16 >= 1 && A.cells * per_cell > lds_budget && A.cells * (per_cell / 2) + 4 * (size_t)A.nagg <= lds_budget;
+    const bool c16_lds = all_count && c.cfg_count16 >= 1 && !tl_no_count16 && A.cells * per_cell > lds_budget && A.cells * (per_cell / 2) + 4 * (size_t)A.nagg <= lds_budget;
     const bool c16_part = all_count && c.cfg_count16 >= 2;
     if (c16_lds) per_cell /= 2;
     int slab_log2 = 0;
@@ -1842,6 +1846,7 @@ int vxh_config_set(const char *key, int64_t value) {
     else if (k == "blocks") c.cfg_blocks = value;
     else if (k == "wv_blocks") c.cfg_wv_blocks = value;
     else if (k == "wv_phase") c.cfg_wv_phase = value;
+    else if (k == "count_box_pct") c.cfg_count_box_pct = value;
     else if (k == "stage_bytes") c.cfg_stage_bytes = value;
     else if (k == "feeder") c.cfg_feeder = value;
     else if (k == "cache_bytes") c.cfg_cache_bytes = value;
@@ -1909,6 +1914,7 @@ int vxh_config_get(const char *key, int64_t *value) {
     else if (k == "blocks") *value = c.cfg_blocks;
     else if (k == "wv_blocks") *value = c.cfg_wv_blocks;
     else if (k == "wv_phase") *value = c.cfg_wv_phase;
+    else if (k == "count_box_pct") *value = c.cfg_count_box_pct;
     else if (k == "stage_bytes") *value = c.cfg_stage_bytes;
     else if (k == "feeder") *value = c.cfg_feeder;
     else if (k == "cache_bytes") *value = c.cfg_cache_bytes;
@@ -2331,8 +2337,31 @@ int vxh_grid_bin(vxh_grid *grid, int thread, vxh_agg *const *aggs, int n_aggs, u
         // plan once on the whole call: it fixes the strategy, hence the row step of the launches
         uint64_t step = kMaxRows;
         BinArgs whole_args;
-        const LaunchPlan whole = make_plan(A, whole_args, length, bytes_per_row, exclusive);
-        if (whole.strategy == VXH_STRAT_PART) {
+        LaunchPlan whole = make_plan(A, whole_args, length, bytes_per_row, exclusive);
+        // Round 5: count(*) on a 2-D grid that fits one workgroup's LDS only with packed uint16 counters (256 x 256: north_star's own target
+        // sentence).  Those need a RETURNING LDS atomic per row (count_lds_f64<PACK16>: 5.25 TB/s); the partition strategy's hot box holds
+        // 194 x 194 uint32 counters — 99.5 % of N(0,1)^2 inside [-4, 4]^2 — next to the phased pass 1 and runs at 5.9 TB/s
+        // (profiles/r05_other_shapes.txt: 1.455 vs 1.636 ms per 5.4e8 rows).  So such a call is planned a second time without the packed
+        // form, its columns are sampled, and where the box holds >= "count_box_pct" of the sample (90) the call takes that road; anything
+        // else — a spread-out distribution, a short call — keeps the packed-counter kernel.
+        struct NoCount16 { bool on = false; ~NoCount16() { if (on) tl_no_count16 = false; } } no_count16;
+        if (whole.strategy == VXH_STRAT_LDS && whole_args.count16 && A.ndim == 2 && A.nagg == 1 && A.a[0].kind == VXH_AGG_COUNT && !A.a[0].data && whole.count_ct == VXH_F64 &&
+            ctx().cfg_strategy == VXH_STRAT_AUTO && ctx().cfg_hot && ctx().cfg_wv == 6 && ctx().cfg_count_box_pct > 0 && ctx().cfg_hot_box[2] <= 0 && length >= (uint64_t)ctx().cfg_hot_min_rows) {
+            tl_no_count16 = no_count16.on = true;
+            BinArgs alt_args;
+            const LaunchPlan alt = make_plan(A, alt_args, length, bytes_per_row, exclusive);
+            bool take = false;
+            if (alt.strategy == VXH_STRAT_PART) {
+                part_acc_prepare(slot, alt_args);
+                hot_prepare(slot, A, alt_args, alt, length);
+                take = slot.hot.on && slot.hot.wv && slot.hot.last_fraction * 100.0 >= (double)ctx().cfg_count_box_pct;
+            }
+            if (take) { whole = alt; whole_args = alt_args; }
+            else { tl_no_count16 = no_count16.on = false; slot.hot.on = slot.hot.last_on = false; }
+        }
+        if (whole.strategy == VXH_STRAT_PART && no_count16.on) {
+            step = (uint64_t)std::max<int64_t>(1 << 20, ctx().cfg_part_chunk) * (uint64_t)std::max<int64_t>(1, ctx().cfg_hot_chunk_factor); // (prepared above)
+        } else if (whole.strategy == VXH_STRAT_PART) {
             step = (uint64_t)std::max<int64_t>(1 << 20, ctx().cfg_part_chunk);
             part_acc_prepare(slot, whole_args);
             hot_prepare(slot, A, whole_args, whole, length);

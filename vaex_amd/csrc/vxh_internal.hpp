@@ -209,6 +209,8 @@ struct Context {
     int64_t cfg_block = 0;
     int64_t cfg_blocks = 0;
     int64_t cfg_wv_blocks = 0;    // part_scatter_wv: workgroups of the launch (0 = one per CU)
+    int64_t cfg_count_box_pct = 90; // count(*) on a 2-D grid that needs packed uint16 LDS counters goes through the partition strategy's hot box instead when the box holds
+                                    // at least this share of the sampled rows (0: never; vxh_grid_bin)
     int64_t cfg_wv_phase = 12;    // "wv" = 6: bit of the 100 MHz wall clock whose flips are the chip's write bursts (12: every 41 us — 11 / 12 / 13 / 14: 4.64 / 4.58 / 4.60 / 4.68 ms on the bench pass)
     int64_t cfg_stage_bytes = 64 << 20;
     int64_t cfg_feeder = 1;       // host chunks: 1 copy stream + arena ring, 2 the same through page-locked buffers (see Slot::Stage), 0 copies on the compute stream
