@@ -157,7 +157,7 @@ def test_float32_columns_are_compared_in_float32_like_numpy():
 # one float64 column: no sel_eval pass, no mask byte.  Each shape is binned three ways — fused, through sel_eval's mask
 # ("fuse_selection" = 0) and with a numpy-built mask: the three must agree bit for bit on integer grids (the same rows are kept).
 # ------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("shape", ["three_d_128", "bench_2d_box", "count_2d_lds", "one_d_big", "two_terms_nan", "std_box", "not_fusable_int", "two_columns_3d", "two_columns_or_nan_3d", "two_columns_box", "two_columns_count_lds", "two_columns_1d", "not_fusable_three_columns"])
+@pytest.mark.parametrize("shape", ["three_d_128", "bench_2d_box", "count_2d_lds", "count_2d_box", "two_columns_count_box", "one_d_big", "two_terms_nan", "std_box", "not_fusable_int", "two_columns_3d", "two_columns_or_nan_3d", "two_columns_box", "two_columns_count_lds", "two_columns_1d", "not_fusable_three_columns"])
 def test_selection_fused_into_the_binning_kernels(shape):
     import torch
     g = torch.Generator(device="cuda").manual_seed(77)
@@ -170,7 +170,9 @@ def test_selection_fused_into_the_binning_kernels(shape):
     spec = {
         "three_d_128": ("count", None, ["x", "y", "z"], [[-4, 4]] * 3, 128, "v > 3", "part_scatter_wv", True),
         "bench_2d_box": ("mean", "v", ["x", "y"], LIM, 256, "v > 3", "part_scatter_", True),               # the selection's column IS the value column
-        "count_2d_lds": ("count", None, ["x", "y"], LIM, 256, "z <= 0.5", "count_lds", True),
+        "count_2d_lds": ("count", None, ["x", "y"], LIM, 256, "z <= 0.5", "count_lds", True),             # (count_box_pct = 0: the packed-counter LDS kernel)
+        "count_2d_box": ("count", None, ["x", "y"], LIM, 256, "z <= 0.5", "part_scatter_phased_hot", True),   # round 5: the same call's default road, through the hot box
+        "two_columns_count_box": ("count", None, ["x", "y"], LIM, 256, "(z <= 0.5) | (v > 4)", "part_scatter_phased_hot", True),
         "one_d_big": ("sum", "v", ["x"], [[-4, 4]], 100_000, "y != 0.25", "part_scatter", True),
         "two_terms_nan": ("count", None, ["x", "y", "z"], [[-4, 4]] * 3, 128, "~(v >= 1) | (v == 3.5)", "part_scatter_wv", True),   # NaN rows: kept by ~(v >= 1)
         "std_box": ("std", "v", ["x", "y"], LIM, 256, "(z > -1) & (z < 2)", "part_scatter_", True),
@@ -188,6 +190,8 @@ def test_selection_fused_into_the_binning_kernels(shape):
     f0, m0 = sa.config_get("pred_fused"), sa.config_get("pred_materialized")
     if len(binby) == 3:
         sa.config_set("strategy", 4)   # (33 M rows into 2.2 M cells: the planner would take device atomics; BASELINE configs[2]'s 1e9 rows take the partition)
+    if shape.endswith("count_lds") or shape == "count_2d_lds":
+        sa.config_set("count_box_pct", 0)   # (keep the call on count_lds_f64: its fused instantiations are what these two shapes test)
     try:
         fused = np.asarray(call(expr))
         kernel = sa.last_kernel(0)
@@ -204,6 +208,7 @@ def test_selection_fused_into_the_binning_kernels(shape):
         numpy_mask = np.asarray(call(torch.from_numpy(keep.astype(np.uint8)).cuda()))
     finally:
         sa.config_set("strategy", 0)
+        sa.config_set("count_box_pct", 90)
     _compare_three(shape, what, fused, through_mask, numpy_mask, keep)
 
 

@@ -29,7 +29,7 @@ ROWS = 1_000_000_000
 # kernels of one pass: (name prefix, dispatches per pass)
 SPEC = {
     "bench": ([("part_scatter_wv", 1), ("part_reduce_", 1), ("part_merge", 1), ("part_hot_merge", 1)], 24),
-    "count2d": ([("count_lds_f64", 1), ("fold_kernel", 1)], 16),
+    "count2d": ([("part_scatter_wv", 1), ("part_reduce_", 1), ("part_merge", 1), ("part_hot_merge", 1)], 16),   # (round 5: through the hot box; rounds 3-4: count_lds_f64 + fold_kernel)
     "c2": ([("part_scatter_wv", 4), ("part_reduce_fast", 4), ("part_merge", 1)], 25),
     "c2e": ([("part_scatter_wv", 4), ("part_reduce_fast", 4), ("part_merge", 1)], 32),
     "c3d": ([("part_scatter_f64", 2), ("part_reduce_fast", 2), ("part_merge", 1)], 16),
