@@ -930,3 +930,70 @@ def test_count_256x256_takes_the_box_when_the_sample_says_so(sa):
     m_packed, _ = count(x, y, keep, count_box_pct=0)
     np.testing.assert_array_equal(m_box, m_packed)
     assert int(m_box.sum()) == int(keep.sum().item())
+
+
+# ------------------------------------------------------------------------------------------------------------
+# round 5: scalar binner columns of dtypes the fast kernels do not read — int8 / int16 / unsigned / bool,
+# byte-swapped, or with a missing-value mask — are converted to float64 by a pass of their own ("convert_binners": calls of >= 2^22
+# device rows) and then ride the float64 fast paths; BinnerScalar<T> converts to double first anyway (src/binners.cpp:16-35) and a
+# masked row lands where a NaN lands (cell 0), so the grids must be the reference's bit for bit.
+# ------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("kind", ["int8", "int16", "uint8", "uint16", "uint32", "uint64", "bool", "float64_be", "int32_be", "float32_be",
+                                  "float64_masked", "int16_masked", "int64_be_masked"])
+def test_other_binner_dtypes_are_converted_for_the_fast_kernels(sa, kind):
+    rng = np.random.default_rng(abs(hash(kind)) % 1000)
+    n = (1 << 23) + 1_001
+    base = kind.split("_")[0]
+    be, masked = "_be" in kind, "masked" in kind
+    if base == "bool":
+        a, b, lim = rng.random(n) < 0.3, rng.random(n) < 0.6, (0.0, 2.0)
+    elif base.startswith("float"):
+        a, b, lim = rng.normal(0, 1, n).astype(base), rng.normal(0, 1, n).astype(base), (-4.0, 4.0)
+        a[::977] = np.nan
+    else:
+        info = np.iinfo(base)
+        lo, hi = max(info.min, -120), min(int(info.max), 1000)
+        a, b = rng.integers(lo, hi, n).astype(base), rng.integers(lo, hi, n).astype(base)
+        if base in ("uint64", "int64"):
+            a[::50_021] = info.max            # (beyond 2^53: double(value) rounds, as BinnerScalar<T> does)
+        lim = (float(lo) + 0.5, float(hi) * 0.75)
+    if be:
+        a, b = a.astype(a.dtype.newbyteorder(">")), b.astype(b.dtype.newbyteorder(">"))
+    ma = (rng.random(n) < 0.1) if masked else None
+    v = rng.normal(3, 2, n); v[::1013] = np.nan
+    shape = 64 if base == "bool" else 256
+    case = dict(n=n, binners=[dict(kind="scalar", data=a, vmin=lim[0], vmax=lim[1], bins=shape, mask=ma), dict(kind="scalar", data=b, vmin=lim[0], vmax=lim[1], bins=shape)],
+                aggs=[dict(kind="count"), dict(kind="sum", data=v), dict(kind="count", data=v)])
+    c0 = sa.config_get("converted_calls")
+    got = cases.run_superagg(sa, case, to_device=cases.torch_device_array)
+    kernel = sa.last_kernel(0)
+    assert sa.config_get("converted_calls") == c0 + 1, kind
+    assert "generic" not in kernel, kernel
+    sa.config_set("convert_binners", 0)
+    try:
+        generic = cases.run_superagg(sa, case, to_device=cases.torch_device_array)
+        assert sa.config_get("converted_calls") == c0 + 1
+    finally:
+        sa.config_set("convert_binners", 1 << 22)
+    np.testing.assert_array_equal(got[0], generic[0]); np.testing.assert_array_equal(got[2], generic[2])
+    assert int(got[0].sum()) == n
+    m = 2_000_000
+    head_case = dict(n=m, binners=[dict(bd, data=bd["data"][:m], mask=None if bd.get("mask") is None else bd["mask"][:m]) for bd in case["binners"]],
+                     aggs=[dict(ad, data=None if ad.get("data") is None else ad["data"][:m]) for ad in case["aggs"]])
+    # (a slice below the conversion threshold: the generic kernels — pinned against the reference's C++ elsewhere — and the converted
+    #  full-size call must agree with the reference on it through linearity: head + rest = whole)
+    want = _ref_or_port_case(_ref_module(), head_case)
+    sa.config_set("convert_binners", 1)
+    try:
+        head = cases.run_superagg(sa, head_case, to_device=cases.torch_device_array)
+    finally:
+        sa.config_set("convert_binners", 1 << 22)
+    cases.assert_case_equal(head, want, head_case)
+    cases.assert_case_equal(got, generic, case)
+    # ONE value column (the harness above uploads v once per aggregator = two): 8- / 16-bit integers, bool and float32 columns are
+    # converted to FLOAT32 (exact for them, half the bytes) and ride the float32-binner fast paths
+    one = dict(case, aggs=case["aggs"][:2])
+    got1 = cases.run_superagg(sa, one, to_device=cases.torch_device_array)
+    assert "generic" not in sa.last_kernel(0), sa.last_kernel(0)
+    np.testing.assert_array_equal(got1[0], got[0])
+    cases.assert_case_equal(got1, generic[:2], one)

@@ -1847,6 +1847,7 @@ int vxh_config_set(const char *key, int64_t value) {
     else if (k == "wv_blocks") c.cfg_wv_blocks = value;
     else if (k == "wv_phase") c.cfg_wv_phase = value;
     else if (k == "count_box_pct") c.cfg_count_box_pct = value;
+    else if (k == "convert_binners") c.cfg_convert_binners = value;
     else if (k == "stage_bytes") c.cfg_stage_bytes = value;
     else if (k == "feeder") c.cfg_feeder = value;
     else if (k == "cache_bytes") c.cfg_cache_bytes = value;
@@ -1915,6 +1916,8 @@ int vxh_config_get(const char *key, int64_t *value) {
     else if (k == "wv_blocks") *value = c.cfg_wv_blocks;
     else if (k == "wv_phase") *value = c.cfg_wv_phase;
     else if (k == "count_box_pct") *value = c.cfg_count_box_pct;
+    else if (k == "convert_binners") *value = c.cfg_convert_binners;
+    else if (k == "converted_calls") *value = (int64_t)get_slot(0).conv_calls;
     else if (k == "stage_bytes") *value = c.cfg_stage_bytes;
     else if (k == "feeder") *value = c.cfg_feeder;
     else if (k == "cache_bytes") *value = c.cfg_cache_bytes;
@@ -2312,6 +2315,61 @@ int vxh_grid_bin(vxh_grid *grid, int thread, vxh_agg *const *aggs, int n_aggs, u
     base.n = length;
     base.pred = call_pred;
     fill_binner_descs(grid, thread, base, resolve);
+    // Round 5: the fast kernels read float64 / float32 / int64 / int32 binner columns; every other scalar binner column — int8, int16,
+    // unsigned, bool, byte-swapped (`_non_native`), or with a missing-value mask — took the generic pair (69-102 Grows/s on the bench
+    // shape against 200+).  BinnerScalar<T> converts its element to double before anything else and sends a masked row where a NaN goes
+    // (src/binners.cpp:16-35), so such a column is turned into that float64 column ONCE per call by a pass of its own (1-8 B/row read,
+    // 4 or 8 written) and the call plans as if it had been handed float32 / float64 columns: 1-3 scalar dimensions, large calls only.
+    if (ctx().cfg_convert_binners > 0 && length >= (uint64_t)ctx().cfg_convert_binners && ndim >= 1 && ndim <= 3) {
+        bool scalar_only = true, any = false;
+        for (int d = 0; d < ndim; d++) {
+            const BinnerDesc &bd = base.b[d];
+            scalar_only = scalar_only && bd.kind == VXH_BIN_SCALAR && !bd.f32mode;
+            const bool fast_dt = (bd.dtype == VXH_F64 || bd.dtype == VXH_F32 || bd.dtype == VXH_I64 || bd.dtype == VXH_I32) && !bd.flip && !bd.mask;
+            any = any || !fast_dt;
+        }
+        if (scalar_only && any) {
+            // the target type: float32 when EVERY column is one float32 holds exactly (8- / 16-bit integers, bool, float32 itself) — half the
+            // bytes written and read back, and the float32 fast paths convert `double(value)` to the same double — else float64 for all
+            // (the typed fast paths want one type for every binner column)
+            bool all_f32 = true;
+            {   // (the float32-binner fast paths carry at most ONE value column: with two, float64 it is — part_scatter_f64 takes two)
+                std::map<const void *, int> distinct;
+                for (int k = 0; k < n_aggs; k++)
+                    if (aggs[k]->data[thread].ptr) distinct[aggs[k]->data[thread].ptr] = 1;
+                if (distinct.size() > 1) all_f32 = false;
+                if (grid->length1d <= 16384) all_f32 = false; // (grids that live in one workgroup's LDS: bin_kernel's fast form reads float64 binners)
+            }
+            for (int d = 0; d < ndim; d++) {
+                const int dt = base.b[d].dtype;
+                all_f32 = all_f32 && (dt == VXH_F32 || dt == VXH_I16 || dt == VXH_U16 || dt == VXH_I8 || dt == VXH_U8 || dt == VXH_BOOL);
+            }
+            const int target = all_f32 ? VXH_F32 : VXH_F64;
+            const size_t osz = all_f32 ? 4 : 8;
+            for (int d = 0; d < ndim; d++) {
+                BinnerDesc &bd = base.b[d];
+                if (bd.dtype == target && !bd.flip && !bd.mask) continue;
+                const size_t need = (((size_t)length * osz) + 255) & ~(size_t)255;
+                if (need > slot.conv_cap[d]) {
+                    HIP_CHECK(hipStreamSynchronize(slot.stream));
+                    if (slot.conv_buf[d]) HIP_CHECK(hipFree(slot.conv_buf[d]));
+                    slot.conv_buf[d] = nullptr;
+                    slot.conv_cap[d] = 0;
+                    HIP_CHECK(hipMalloc(&slot.conv_buf[d], need));
+                    slot.conv_cap[d] = need;
+                }
+                stager.ready();
+                vxh_launch_column_convert(bd.data, bd.mask, bd.dtype, bd.flip, length, slot.conv_buf[d], all_f32 ? 1 : 0, slot.stream);
+                HIP_CHECK(hipGetLastError());
+                bd.data = slot.conv_buf[d];
+                bd.mask = nullptr;
+                bd.dtype = (uint8_t)target;
+                bd.flip = 0;
+            }
+            slot.conv_calls++;
+            slot.hot.key_fraction = -1; // (the hot-box sample is remembered per column POINTER: the conversion buffers are the same pointers for other data)
+        }
+    }
 
     const uint64_t kMaxRows = 1ull << 31; // LDS count cells are u32: a workgroup never sees more rows than this
     for (int k0 = 0; k0 < n_aggs; k0 += VXH_MAX_AGG) {

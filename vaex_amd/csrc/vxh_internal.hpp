@@ -109,6 +109,10 @@ struct vxh_collect {
 struct Slot {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
+    // binner columns converted to float64 for the fast kernels (vxh_grid_bin, "convert_binners"): one grow-only buffer per dimension
+    void *conv_buf[3] = {nullptr, nullptr, nullptr};
+    size_t conv_cap[3] = {0, 0, 0};
+    uint64_t conv_calls = 0; // calls that converted at least one column
     // Chunk feeder (host chunks of a vxh_grid_bin call): a ring of VXH_STAGE_RING device arenas per slot.  The DMA into
     // the arena runs on `copy_stream`, the kernels on `stream` wait for the `copied` event, and `done` (recorded behind the
     // kernels) frees the entry for re-use — so the copy of chunk i+1 overlaps the binning of chunk i within ONE slot and
@@ -211,6 +215,8 @@ struct Context {
     int64_t cfg_wv_blocks = 0;    // part_scatter_wv: workgroups of the launch (0 = one per CU)
     int64_t cfg_count_box_pct = 90; // count(*) on a 2-D grid that needs packed uint16 LDS counters goes through the partition strategy's hot box instead when the box holds
                                     // at least this share of the sampled rows (0: never; vxh_grid_bin)
+    int64_t cfg_convert_binners = 1 << 22; // scalar binner columns of dtypes the fast kernels do not read (int8 / int16 / unsigned / byte-swapped / masked ...) are converted
+                                           // to float64 in a pass of their own for calls of at least this many device rows (0: never; they then take the generic kernels)
     int64_t cfg_wv_phase = 12;    // "wv" = 6: bit of the 100 MHz wall clock whose flips are the chip's write bursts (12: every 41 us — 11 / 12 / 13 / 14: 4.64 / 4.58 / 4.60 / 4.68 ms on the bench pass)
     int64_t cfg_stage_bytes = 64 << 20;
     int64_t cfg_feeder = 1;       // host chunks: 1 copy stream + arena ring, 2 the same through page-locked buffers (see Slot::Stage), 0 copies on the compute stream

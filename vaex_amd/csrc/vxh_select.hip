@@ -135,7 +135,84 @@ __global__ __launch_bounds__(256) void product_f64(const double *a, const double
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) out[i] = a[i] * b[i];
 }
 
+// A scalar binner column of ANY dtype / byte order / with a missing-value mask as the float64 column the fast kernels read:
+// BinnerScalar<T>::to_bins converts the element to double before anything else (src/binners.cpp:16-35; byte-swapped first for
+// `_non_native`, src/agg.hpp:18-26), and a masked row lands in cell 0 like a NaN does (:26-29) — so double(value), NaN where masked, is
+// the same column to every binning kernel.  Two rows per thread and trip.
+__device__ __forceinline__ double element_as_f64(const void *p, int dtype, int flip, uint64_t i) {
+    switch (dtype) {
+    case VXH_F64: { uint64_t x = ((const uint64_t *)p)[i]; if (flip) x = __builtin_bswap64(x); return __longlong_as_double((long long)x); }
+    case VXH_F32: { uint32_t x = ((const uint32_t *)p)[i]; if (flip) x = __builtin_bswap32(x); return (double)__uint_as_float(x); }
+    case VXH_I64: { uint64_t x = ((const uint64_t *)p)[i]; if (flip) x = __builtin_bswap64(x); return (double)(int64_t)x; }
+    case VXH_U64: { uint64_t x = ((const uint64_t *)p)[i]; if (flip) x = __builtin_bswap64(x); return (double)x; }
+    case VXH_I32: { uint32_t x = ((const uint32_t *)p)[i]; if (flip) x = __builtin_bswap32(x); return (double)(int32_t)x; }
+    case VXH_U32: { uint32_t x = ((const uint32_t *)p)[i]; if (flip) x = __builtin_bswap32(x); return (double)x; }
+    case VXH_I16: { uint16_t x = ((const uint16_t *)p)[i]; if (flip) x = __builtin_bswap16(x); return (double)(int16_t)x; }
+    case VXH_U16: { uint16_t x = ((const uint16_t *)p)[i]; if (flip) x = __builtin_bswap16(x); return (double)x; }
+    case VXH_I8: return (double)((const int8_t *)p)[i];
+    case VXH_U8: return (double)((const uint8_t *)p)[i];
+    default: return ((const uint8_t *)p)[i] ? 1.0 : 0.0; // bool
+    }
+}
+// OUT = double, or float for the dtypes float32 holds exactly (8- / 16-bit integers, bool, float32 itself): half the bytes written and
+// read back, and BinnerScalar<float>'s `double(value)` of the converted column is the same double.  Four consecutive rows per thread:
+// ONE load of 4 x itemsize bytes, one or two 16-byte stores (VEC: the column is 16-byte aligned; otherwise element by element).
+template <typename OUT, bool VEC>
+__global__ __launch_bounds__(256) void column_convert(const void *data, const uint8_t *mask, int dtype, int flip, uint64_t n, OUT *out) {
+    const OUT nan = (OUT)__longlong_as_double(0x7ff8000000000000ll);
+    const uint64_t quads = n >> 2;
+    for (uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; q < quads; q += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t i0 = q * 4;
+        OUT r[4];
+        if (VEC) {
+            // the four elements' bytes in registers, then converted one by one from there
+            union { uint4 v[2]; uint8_t b[32]; } raw;
+            const int isz = dtype == VXH_F64 || dtype == VXH_I64 || dtype == VXH_U64 ? 8 : (dtype == VXH_F32 || dtype == VXH_I32 || dtype == VXH_U32 ? 4 : (dtype == VXH_I16 || dtype == VXH_U16 ? 2 : 1));
+            const char *p = (const char *)data + i0 * (uint64_t)isz;
+            if (isz == 8) { raw.v[0] = ((const uint4 *)p)[0]; raw.v[1] = ((const uint4 *)p)[1]; }
+            else if (isz == 4) raw.v[0] = *(const uint4 *)p;
+            else if (isz == 2) *(uint2 *)raw.b = *(const uint2 *)p;
+            else *(uint32_t *)raw.b = *(const uint32_t *)p;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) r[k] = (OUT)element_as_f64(raw.b, dtype, flip, (uint64_t)k);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) r[k] = (OUT)element_as_f64(data, dtype, flip, i0 + (uint64_t)k);
+        }
+        if (mask) {
+            const uint32_t m = VEC ? *(const uint32_t *)(mask + i0) : ((uint32_t)mask[i0] | ((uint32_t)mask[i0 + 1] << 8) | ((uint32_t)mask[i0 + 2] << 16) | ((uint32_t)mask[i0 + 3] << 24));
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (((m >> (8 * k)) & 0xffu) == 1u) r[k] = nan; // (binner masks: 1 = masked, src/binners.cpp:26)
+        }
+        if (sizeof(OUT) == 4) {
+            *(float4 *)(out + i0) = make_float4((float)r[0], (float)r[1], (float)r[2], (float)r[3]);
+        } else {
+            ((double2 *)(out + i0))[0] = make_double2((double)r[0], (double)r[1]);
+            ((double2 *)(out + i0))[1] = make_double2((double)r[2], (double)r[3]);
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) { // the last 1-3 rows
+        const uint64_t i = (n & ~(uint64_t)3) + threadIdx.x;
+        const OUT v = (OUT)element_as_f64(data, dtype, flip, i);
+        out[i] = (mask && mask[i] == 1) ? nan : v;
+    }
+}
+
 } // namespace
+
+void vxh_launch_column_convert(const void *data, const uint8_t *mask, int dtype, int flip, uint64_t n, void *out, int out_f32, hipStream_t stream) {
+    if (!n) return;
+    const int blocks = (int)std::min<uint64_t>((n / 4 + 255) / 256 + 1, 256 * 32);
+    const bool vec = (((uintptr_t)data | (uintptr_t)mask) & 15) == 0;
+    if (out_f32) {
+        if (vec) hipLaunchKernelGGL((column_convert<float, true>), dim3(blocks), dim3(256), 0, stream, data, mask, dtype, flip, n, (float *)out);
+        else hipLaunchKernelGGL((column_convert<float, false>), dim3(blocks), dim3(256), 0, stream, data, mask, dtype, flip, n, (float *)out);
+    } else {
+        if (vec) hipLaunchKernelGGL((column_convert<double, true>), dim3(blocks), dim3(256), 0, stream, data, mask, dtype, flip, n, (double *)out);
+        else hipLaunchKernelGGL((column_convert<double, false>), dim3(blocks), dim3(256), 0, stream, data, mask, dtype, flip, n, (double *)out);
+    }
+}
 
 void vxh_launch_pack_keys(const PackArgs &A, hipStream_t stream) {
     if (!A.n) return;
