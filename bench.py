@@ -559,6 +559,10 @@ def run(args):
                 torch.cuda.synchronize()
                 dt = time.perf_counter() - t1
                 return rows * nsteps / dt, float(np.mean(kernel_ms))
+            # (0) the same step 200 more times in a row (~1 s of device time): the timed region above is 0.1 s at the driver's 20 steps —
+            # too short for an outside utilisation sampler to see — and a steady second says whether the rate holds
+            vs, ks = timed(200)
+            out["sustained"] = {"steps": 200, "value": vs, "kernel_ms": ks, "frac": BYTES_PER_ROW * rows / (ks * 1e-3) / 1e9 / HBM_PEAK_GBS}
             # (1) cold call: the hot box is sampled and searched again in every step (a first df.mean on fresh columns)
             sa.config_set("hot_cache", 0)
             step()

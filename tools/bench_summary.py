@@ -5,9 +5,9 @@ import re
 import sys
 d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
 r = d["roofline"]
-print("headline %.4g rows/s  ms/step %.3f  kernel_ms %.3f  frac %.4f  cold %s  uniform %s  %s" % (
+print("headline %.4g rows/s  ms/step %.3f  kernel_ms %.3f  frac %.4f  cold %s  uniform %s  sustained %s  %s" % (
     d["value"], d["ms_per_step"], r["kernel_ms"], r["frac"], ("%.3f" % r["frac_cold"]) if "frac_cold" in r else "-",
-    ("%.3f" % r["frac_uniform"]) if "frac_uniform" in r else "-", d["config"]["kernel"]))
+    ("%.3f" % r["frac_uniform"]) if "frac_uniform" in r else "-", ("%.3f" % d["sustained"]["frac"]) if "sustained" in d else "-", d["config"]["kernel"]))
 if "allreduce_world1_ms" in d or "allreduce_world1" in d:
     print("  allreduce_world1_ms", d.get("allreduce_world1_ms"), d.get("allreduce_world1"))
 for c in d.get("configs") or []:
