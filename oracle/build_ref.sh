@@ -12,6 +12,7 @@
 #   oracle/_ref/overlay/          symlink overlay of the reference's pure-Python package
 #                                 (needed only HERE by oracle/make_goldens.py; gpurun-ignored)
 #   oracle/_ref/vaexpy/           the same package as plain files (travels to the GPU box: the drop-in test there)
+#   oracle/_ref/reftests/         the reference's own test files of this path (travel too: tests/test_vaex_reference_suite.py)
 #
 # Usage: oracle/build_ref.sh [--minimal]   (--minimal: superagg only)
 set -euo pipefail
@@ -75,6 +76,12 @@ rich = vaex.progress:rich
 
 [vaex.dataframe.accessor]
 struct = vaex.struct:DataFrameAccessorStruct
+
+[vaex.dataset.opener]
+csv = vaex.csv:DatasetCsvLazy
+arrow = vaex.arrow.opener:ArrowOpener
+parquet = vaex.arrow.opener:ParquetOpener
+feather = vaex.arrow.opener:FeatherOpener
 EOF
     # The same package with the files themselves instead of symlinks (pure-Python modules only, no tests / images /
     # datasets): what travels to the GPU box, where /root/reference does not exist, so that tests/test_vaex_dropin.py can
@@ -85,5 +92,17 @@ EOF
     (cd $REF && find vaex -name '*.py' -not -path 'vaex/test/*' -print0 | xargs -0 cp --parents -t $OUT/vaexpy)
     for m in superagg superutils superstrings vaexfast; do ln -sf ../../$m$EXT $OUT/vaexpy/vaex/$m$EXT; done
     cp -r $DI $OUT/vaexpy/
+    # The reference's OWN test files of this path (aggregations, binby, groupby, selections, limits, percentiles, unique /
+    # value_counts), as they are, for tests/test_vaex_reference_suite.py: run there against vaex's C++ (the baseline) and, on the
+    # GPU box, under vaex_amd.install() — what passes on the reference's classes must pass on the HIP classes.  Build output like
+    # vaexpy above: git-ignored, never committed, never imported by the product.  (They are RUN from this copy, never in place:
+    # the fixtures write a parquet file next to themselves.)
+    rm -rf $OUT/reftests
+    mkdir -p $OUT/reftests/data
+    for t in common.py conftest.py agg_test.py count_test.py groupby_test.py selection_test.py limits_test.py percentile_approx_test.py \
+             grid_test.py first_test.py correlation_test.py mutual_information_test.py filter_test.py describe_test.py countna_test.py \
+             masked_values_filters_test.py unique_test.py value_counts_test.py hashmap_unique_test.py concat_test.py slice_test.py; do
+        cp /root/reference/tests/$t $OUT/reftests/
+    done
 fi
 echo "build_ref: done -> $OUT"

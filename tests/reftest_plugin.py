@@ -1,0 +1,68 @@
+"""pytest plugin of the subprocess tests/test_vaex_reference_suite.py starts over the reference's own test files (TEST
+INFRASTRUCTURE; loaded with `-p reftest_plugin`, never by the product).
+
+* the reference's tests/common.py imports vaex-server and pytest-asyncio for its remote fixtures, which exist in neither this image
+  nor the oracle build of the reference: empty stand-ins are registered (VAEX_TEST_SKIP_REMOTE=1 keeps those fixtures out of the
+  parametrisations, tests/common.py:225-236);
+* VAEX_AMD_REFTEST_INSTALL=1: vaex_amd.install() before the first test — from there on every aggregation task part, statistic,
+  selection, filter and groupby of the reference's tests runs on the HIP classes (or on the per-task fallback install() decides);
+* every test's outcome goes to the JSON file VAEX_AMD_REFTEST_REPORT names, with install()'s counters."""
+import json
+import os
+import sys
+import types
+
+import pytest
+
+import vaex
+
+for _name in ("vaex.server", "vaex.server.service", "vaex.server.tornado_server", "vaex.server.dummy", "vaex.server.fastapi"):
+    sys.modules[_name] = types.ModuleType(_name)
+vaex.server = sys.modules["vaex.server"]
+for _sub in ("service", "tornado_server", "dummy", "fastapi"):
+    setattr(vaex.server, _sub, sys.modules["vaex.server." + _sub])
+_asyncio = types.ModuleType("pytest_asyncio")
+_asyncio.fixture = pytest.fixture
+sys.modules.setdefault("pytest_asyncio", _asyncio)
+
+INSTALL = os.environ.get("VAEX_AMD_REFTEST_INSTALL") == "1"
+_outcomes = {}
+_why = {}
+
+if INSTALL:
+    import vaex_amd
+    assert vaex_amd.superagg.device_count() > 0, "vaex_amd.install() needs a HIP device"
+    vaex_amd.install()
+
+
+def pytest_runtest_logreport(report):
+    # one outcome per test: a failing setup / teardown counts as "error", a skip in any phase as "skipped"
+    prev = _outcomes.get(report.nodeid)
+    if report.when == "call":
+        out = report.outcome if not hasattr(report, "wasxfail") else "xfail"
+    elif report.failed:
+        out = "error"
+    elif report.skipped:
+        out = "skipped" if not hasattr(report, "wasxfail") else "xfail"
+    else:
+        return
+    if prev in ("failed", "error"):
+        return
+    _outcomes[report.nodeid] = out
+    if out in ("failed", "error"):
+        _why[report.nodeid] = str(report.longrepr)[-1500:]
+
+
+def pytest_sessionfinish(session, exitstatus):
+    path = os.environ.get("VAEX_AMD_REFTEST_REPORT")
+    if not path:
+        return
+    doc = {"install": INSTALL, "outcomes": _outcomes, "why": _why}
+    if INSTALL:
+        from vaex_amd import vaex_groupby, vaex_selection, vaex_filter
+        doc["task_stats"] = {k: v for k, v in vaex_amd.task_stats.items() if isinstance(v, (int, float, str, dict))}
+        doc["groupby"] = {"device": vaex_groupby.stats.get("device", 0), "vaex": vaex_groupby.stats.get("vaex", 0), "why": vaex_groupby.stats.get("why", {})}
+        doc["selection"] = dict(vaex_selection.stats)
+        doc["filter"] = dict(vaex_filter.stats)
+    with open(path, "w") as f:
+        json.dump(doc, f, default=str)

@@ -1,0 +1,92 @@
+"""The reference's OWN test files of this path, unmodified, as the parity test ("the golden vectors, known-answer tests
+and fixtures the reference's own tests hold for this path").
+
+oracle/build_ref.sh copies twenty of /root/reference/tests/*_test.py (aggregations, count, groupby, selections, limits, percentiles,
+grid, first, correlation, mutual information, filters, describe, countna, masked values, unique / value_counts / hashmap, concat,
+slice) with their common.py / conftest.py into the git-ignored oracle/_ref/reftests/ — a build product like oracle/_ref/vaexpy, which is
+the reference's unmodified Python package.  They run in a subprocess (tests/reftest_plugin.py stands in for vaex-server / pytest-asyncio,
+which only the remote fixtures need):
+
+  * here (no GPU) on vaex's C++ classes (oracle/_ref/*.so): the harness works, and most of each file passes — what does not is the
+    oracle build's stubbed string classes, `vaex.example()` (a download) and xarray;
+  * -m gpu: once on vaex's C++ (the baseline of THAT box) and once under vaex_amd.install(): every test that passes on the reference's
+    classes must pass on the HIP classes — same assertions, same fixtures (big-endian and masked columns, filtered / sliced /
+    concatenated / Arrow / parquet frames, 3-row chunks through `buffer_size`).  The report (gpurun_out/.../reference_suite.json when
+    VAEX_AMD_REPORT_DIR is set) says how many task parts, selections, filters and groupbys ran on the device meanwhile."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REFTESTS = os.path.join(ROOT, "oracle", "_ref", "reftests")
+VAEXPY = os.path.join(ROOT, "oracle", "_ref", "vaexpy")
+OVERLAY = os.path.join(ROOT, "oracle", "_ref", "overlay")
+FAKE = os.path.join(ROOT, "oracle", "fake")
+PKG = VAEXPY if os.path.isdir(os.path.join(VAEXPY, "vaex")) else OVERLAY
+
+FILES = ["agg_test.py", "count_test.py", "groupby_test.py", "selection_test.py", "limits_test.py", "percentile_approx_test.py", "grid_test.py",
+         "first_test.py", "correlation_test.py", "mutual_information_test.py", "filter_test.py", "describe_test.py", "countna_test.py",
+         "masked_values_filters_test.py", "unique_test.py", "value_counts_test.py", "hashmap_unique_test.py", "concat_test.py", "slice_test.py"]
+
+pytestmark = pytest.mark.skipif(not (os.path.isfile(os.path.join(REFTESTS, "agg_test.py")) and os.path.isdir(os.path.join(PKG, "vaex"))),
+                                reason="oracle/_ref/reftests or the reference's Python package not built (oracle/build_ref.sh needs /root/reference)")
+
+#: tests that pass on vaex's C++ and are NOT expected to pass under install(), with the reason (none: the list is the claim)
+EXPECTED_DIFFERENT = {}
+
+
+def run_files(install, tmp_path, files=FILES, threads=4):
+    report = str(tmp_path / ("report_hip.json" if install else "report_cpp.json"))
+    env = dict(os.environ)
+    env.update(PYTHONPATH=os.pathsep.join([os.path.join(ROOT, "tests"), PKG, FAKE, ROOT]), PYTHONDONTWRITEBYTECODE="1", VAEX_TEST_SKIP_REMOTE="1",
+               VAEX_NUM_THREADS=str(threads), VAEX_AMD_REFTEST_INSTALL="1" if install else "0", VAEX_AMD_REFTEST_REPORT=report,
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("VAEX_AMD_REPORT_DIR", None)
+    cmd = [sys.executable, "-m", "pytest", "-p", "reftest_plugin", "-q", "-p", "no:cacheprovider", "--tb=short", "--rootdir", REFTESTS] + list(files)
+    p = subprocess.run(cmd, cwd=REFTESTS, env=env, capture_output=True, text=True, timeout=3000)
+    assert os.path.exists(report), (p.stdout[-3000:], p.stderr[-3000:])
+    doc = json.load(open(report))
+    doc["tail"] = p.stdout[-600:]
+    return doc
+
+
+def counts(doc):
+    c = {}
+    for o in doc["outcomes"].values():
+        c[o] = c.get(o, 0) + 1
+    return c
+
+
+def test_reference_files_run_against_the_reference_classes(tmp_path):
+    doc = run_files(False, tmp_path)
+    c = counts(doc)
+    # (this image: 470 pass; the rest need the string hash classes the oracle build of the reference stubs out, or vaex.example(): a download)
+    assert c.get("passed", 0) >= 440, (c, doc["tail"])
+    per_file = {}
+    for node, o in doc["outcomes"].items():
+        per_file.setdefault(node.split("::")[0], {}).setdefault(o, 0)
+        per_file[node.split("::")[0]][o] += 1
+    for f in ("selection_test.py", "limits_test.py", "grid_test.py", "first_test.py", "filter_test.py", "describe_test.py", "countna_test.py", "concat_test.py"):
+        assert per_file[f].get("failed", 0) + per_file[f].get("error", 0) == 0, (f, per_file[f])
+
+
+@pytest.mark.gpu
+def test_what_passes_on_the_reference_classes_passes_on_the_hip_classes(tmp_path):
+    base = run_files(False, tmp_path)
+    hip = run_files(True, tmp_path)
+    passed = [n for n, o in base["outcomes"].items() if o == "passed"]
+    assert len(passed) >= 440, counts(base)
+    regressions = {n: hip["why"].get(n, hip["outcomes"].get(n, "not run"))[-700:] for n in passed if hip["outcomes"].get(n) != "passed" and n not in EXPECTED_DIFFERENT}
+    fixed = [n for n, o in hip["outcomes"].items() if o == "passed" and base["outcomes"].get(n) in ("failed", "error")]
+    summary = {"reference_classes": counts(base), "hip_classes": counts(hip), "pass_on_both": len(passed) - len(regressions), "regressions": regressions,
+               "pass_only_under_install": fixed, "expected_different": EXPECTED_DIFFERENT,
+               "task_parts": hip.get("task_stats"), "groupby": hip.get("groupby"), "selection": hip.get("selection"), "filter": hip.get("filter")}
+    out_dir = os.environ.get("VAEX_AMD_REPORT_DIR")
+    if out_dir:
+        with open(os.path.join(out_dir, "reference_suite.json"), "w") as f:
+            json.dump(summary, f, indent=1)
+    assert hip["task_stats"]["hip"] > 500, hip["task_stats"]       # the tests DID run on the HIP classes
+    assert not regressions, (len(regressions), dict(list(regressions.items())[:8]))

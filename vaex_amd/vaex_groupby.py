@@ -415,6 +415,11 @@ def install(vaex_module, state):
             raise AttributeError(name)
 
         def agg(self, actions, delay=False, progress=None):
+            if "_lazy" in self.__dict__ and delay:
+                # (delay=True is a request to batch this aggregation with the caller's other tasks into one pass of the executor —
+                #  vaex/groupby.py:975-1017 — which the device groupby, one call outside the executor, cannot honour: vaex's own tasks)
+                declined(_Decline("delay=True: scheduled as vaex's own tasks"))
+                self._materialise()
             if "_lazy" in self.__dict__:
                 df, kw = self.__dict__["_lazy"]
                 try:
@@ -429,7 +434,11 @@ def install(vaex_module, state):
             return vaex.groupby.GroupBy.agg(self, actions, delay=delay, progress=progress)
 
     def groupby(self, by=None, agg=None, sort=False, ascending=True, assume_sparse="auto", row_limit=None, copy=True, progress=None, delay=False):
-        if agg is not None:
+        if agg is not None and delay:
+            # (see LazyGroupBy.agg: a delayed groupby shares the pass of df.execute() with the caller's other tasks — vaex's task parts,
+            #  on the HIP classes; the reference's tests count the passes: tests/groupby_test.py:598-606)
+            declined(_Decline("delay=True: scheduled as vaex's own tasks"))
+        elif agg is not None:
             try:
                 result = _served(progress, lambda: fast_groupby(self, by, agg, sort=sort, ascending=ascending, row_limit=row_limit))
             except _Decline as e:
