@@ -101,8 +101,13 @@ EOF
     mkdir -p $OUT/reftests/data
     for t in common.py conftest.py agg_test.py count_test.py groupby_test.py selection_test.py limits_test.py percentile_approx_test.py \
              grid_test.py first_test.py correlation_test.py mutual_information_test.py filter_test.py describe_test.py countna_test.py \
-             masked_values_filters_test.py unique_test.py value_counts_test.py hashmap_unique_test.py concat_test.py slice_test.py; do
+             masked_values_filters_test.py unique_test.py value_counts_test.py hashmap_unique_test.py concat_test.py slice_test.py \
+             execution_test.py progress_test.py cache_test.py category_test.py datetime_test.py timedelta_test.py isin_test.py join_test.py \
+             dtypes_test.py nop_test.py trim_test.py dropna_test.py sort_test.py stack_test.py materialize_test.py map_test.py sparse_test.py \
+             fingerprint_test.py cornercases_test.py shape_test.py values_test.py; do
         cp /root/reference/tests/$t $OUT/reftests/
     done
+    mkdir -p $OUT/reftests/internal
+    for t in __init__.py groupby_test.py hash_test.py; do cp /root/reference/tests/internal/$t $OUT/reftests/internal/; done
 fi
 echo "build_ref: done -> $OUT"

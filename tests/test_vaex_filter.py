@@ -116,6 +116,18 @@ for name, d in frames().items():
     else:
         assert delta["device_chunks"] == 0 and delta["host_chunks"] > 0, (name, delta)
     print(name, delta, flush=True)
+# a frame with functions of its own: the filter may be what protects the function from rows it cannot take — the reference's own test,
+# /root/reference/tests/agg_test.py:405-416 and tests/selection_test.py:167-177 — so such frames keep vaex's compaction
+def custom_func(x):
+    assert 4 not in x; return x**2
+dfu = vaex.from_arrays(x=np.arange(10))
+dff = dfu[dfu.x != 4]
+dff.add_function('custom_function', custom_func)
+dff['y'] = dff.func.custom_function(dff.x)
+before = dict(vaex_filter.stats)
+assert dff.count(dff.y) == 9 and dff.count(dff.y, selection='y > 0') == 8
+assert vaex_filter.stats["runs_switched"] == before["runs_switched"], (before, vaex_filter.stats)
+print("user-function frame keeps the compaction", flush=True)
 # an unfiltered frame is nobody's business here
 before = dict(vaex_filter.stats)
 calls(df)

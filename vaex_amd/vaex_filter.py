@@ -13,7 +13,8 @@ A binned aggregation does not need compacted rows; a keep-mask says the same.  S
     AggNUnique, whose masks the reference indexes block-locally, src/agg_first.cpp:131), those tasks run with pre_filter = False:
     the executor then evaluates the filter exactly as before (cached per chunk in df._selection_mask_caches) but hands the task part
     the UNCOMPACTED blocks plus the full-length filter mask (vaex/execution.py:535-536, :573).  A run that mixes such tasks with
-    others (df.minmax, the distinct-key pass of a groupby, ...) is left alone — vaex refuses mixed runs (:62-66);
+    others (df.minmax, the distinct-key pass of a groupby, ...) is left alone — vaex refuses mixed runs (:62-66) — and so is every run of a
+    frame that carries functions of its own (add_function / apply): such a function may rely on never seeing a filtered-out row;
   * the registered task part (TaskPartAggregationHip) makes the filter part of every aggregator's keep-mask: as a DEVICE predicate
     when the filter is in the comparison subset of vaex_amd.predicate (alone, or `(filter) & (selection)` in one predicate when the
     aggregation's selection is on the device too and both fit its four terms) — then no mask byte crosses PCIe — otherwise by AND-ing
@@ -103,7 +104,9 @@ def install(vaex_module, state):
         for df, ts in per_df.items():
             if not df.filtered:
                 continue
-            if all(_qualifies(t) for t in ts):
+            # (a frame with functions of its own — df.add_function, apply: the filter may be what keeps rows such a function cannot take away
+            #  from it, and only compacted blocks do that: tests/agg_test.py:405-416 `assert 4 not in x` — stays with vaex's compaction)
+            if all(_qualifies(t) for t in ts) and not df.functions:
                 for t in ts:
                     t.pre_filter = False
                     t.__dict__["_hip_filter_as_mask"] = True
