@@ -104,10 +104,17 @@ EOF
              masked_values_filters_test.py unique_test.py value_counts_test.py hashmap_unique_test.py concat_test.py slice_test.py \
              execution_test.py progress_test.py cache_test.py category_test.py datetime_test.py timedelta_test.py isin_test.py join_test.py \
              dtypes_test.py nop_test.py trim_test.py dropna_test.py sort_test.py stack_test.py materialize_test.py map_test.py sparse_test.py \
-             fingerprint_test.py cornercases_test.py shape_test.py values_test.py; do
+             fingerprint_test.py cornercases_test.py shape_test.py values_test.py \
+             apply_test.py astype_test.py cast_to_array_test.py compute_test.py copy_test.py dataset_test.py derivative_test.py dot_product_test.py \
+             drop_test.py dropinf_test.py expression_variables_test.py extract_test.py fillna_test.py getattr_test.py indexing_test.py isna_test.py \
+             propagate_uncertainty_test.py rename_test.py rolling_test.py row_test.py split_test.py struct_test.py to_test.py utils_test.py \
+             variables_test.py evaluate_test.py column_test.py; do
         cp /root/reference/tests/$t $OUT/reftests/
     done
-    mkdir -p $OUT/reftests/internal
+    mkdir -p $OUT/reftests/internal $OUT/reftests/arrow
     for t in __init__.py groupby_test.py hash_test.py; do cp /root/reference/tests/internal/$t $OUT/reftests/internal/; done
+    for t in __init__.py assumptions_test.py compute_test.py conversion_test.py convert_test.py dataset_test.py dict_test.py io_test.py to_arrow_table_test.py; do
+        cp /root/reference/tests/arrow/$t $OUT/reftests/arrow/
+    done
 fi
 echo "build_ref: done -> $OUT"
