@@ -92,9 +92,16 @@ def test_what_passes_on_the_reference_classes_passes_on_the_hip_classes(tmp_path
     passed = [n for n, o in base["outcomes"].items() if o == "passed"]
     assert len(passed) >= 1600, counts(base)
     regressions = {n: hip["why"].get(n, hip["outcomes"].get(n, "not run"))[-700:] for n in passed if hip["outcomes"].get(n) != "passed" and n not in EXPECTED_DIFFERENT}
+    retried = {}
+    if regressions and len(regressions) <= 40:
+        # a few of the reference's tests are nondeterministic on its own classes (execution_test.py::test_thread_safe enters the executor from
+        # four threads while the chunk size is being changed): what failed runs once more, alone, and only a second failure counts
+        again = run_files(True, tmp_path, files=sorted(regressions))
+        retried = {n: again["outcomes"].get(n, "not run") for n in regressions}
+        regressions = {n: w for n, w in regressions.items() if retried[n] != "passed"}
     fixed = [n for n, o in hip["outcomes"].items() if o == "passed" and base["outcomes"].get(n) in ("failed", "error")]
     summary = {"reference_classes": counts(base), "hip_classes": counts(hip), "pass_on_both": len(passed) - len(regressions), "regressions": regressions,
-               "pass_only_under_install": fixed, "expected_different": EXPECTED_DIFFERENT,
+               "pass_only_under_install": fixed, "expected_different": EXPECTED_DIFFERENT, "second_runs": retried,
                "task_parts": hip.get("task_stats"), "groupby": hip.get("groupby"), "selection": hip.get("selection"), "filter": hip.get("filter")}
     out_dir = os.environ.get("VAEX_AMD_REPORT_DIR")
     if out_dir:
