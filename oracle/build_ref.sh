@@ -111,7 +111,8 @@ EOF
              variables_test.py evaluate_test.py column_test.py; do
         cp /root/reference/tests/$t $OUT/reftests/
     done
-    mkdir -p $OUT/reftests/internal $OUT/reftests/arrow
+    mkdir -p $OUT/reftests/internal $OUT/reftests/arrow $OUT/reftests/legacy
+    cp $REF/vaex/test/cmodule.py $OUT/reftests/legacy/   # the unittest of vaexfast.statisticNd_f8: add / weights / moments / edges
     for t in __init__.py groupby_test.py hash_test.py; do cp /root/reference/tests/internal/$t $OUT/reftests/internal/; done
     for t in __init__.py assumptions_test.py compute_test.py conversion_test.py convert_test.py dataset_test.py dict_test.py io_test.py to_arrow_table_test.py; do
         cp /root/reference/tests/arrow/$t $OUT/reftests/arrow/

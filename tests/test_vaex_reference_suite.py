@@ -1,7 +1,7 @@
 """The reference's OWN test files of this path, unmodified, as the parity test ("the golden vectors, known-answer tests
 and fixtures the reference's own tests hold for this path").
 
-oracle/build_ref.sh copies seventy-seven of /root/reference/tests/*_test.py (aggregations, count, groupby, selections, limits, percentiles,
+oracle/build_ref.sh copies seventy-seven of /root/reference/tests/*_test.py and vaex/test/cmodule.py (aggregations, count, groupby, selections, limits, percentiles,
 grid, first, correlation, mutual information, filters, describe, countna, masked values, unique / value_counts / hashmap, concat,
 slice; the executor, its progress and task cache; categories, datetimes, isin, join, map, sort; the rest of the frame API; arrow/) with their common.py / conftest.py into the git-ignored oracle/_ref/reftests/ — a build product like oracle/_ref/vaexpy, which is
 the reference's unmodified Python package.  They run in a subprocess (tests/reftest_plugin.py stands in for vaex-server / pytest-asyncio,
@@ -41,7 +41,8 @@ FILES = ["agg_test.py", "count_test.py", "groupby_test.py", "selection_test.py",
          "propagate_uncertainty_test.py", "rename_test.py", "rolling_test.py", "row_test.py", "split_test.py", "struct_test.py", "to_test.py", "utils_test.py",
          "variables_test.py", "evaluate_test.py", "column_test.py",
          "arrow/assumptions_test.py", "arrow/compute_test.py", "arrow/conversion_test.py", "arrow/convert_test.py", "arrow/dataset_test.py", "arrow/dict_test.py",
-         "arrow/io_test.py", "arrow/to_arrow_table_test.py"]
+         "arrow/io_test.py", "arrow/to_arrow_table_test.py",
+         "legacy/cmodule.py"]   # packages/vaex-core/vaex/test/cmodule.py: the unittest of vaexfast.statisticNd_f8 (install() puts the HIP entry there)
 
 pytestmark = pytest.mark.skipif(not (os.path.isfile(os.path.join(REFTESTS, "agg_test.py")) and os.path.isdir(os.path.join(PKG, "vaex"))),
                                 reason="oracle/_ref/reftests or the reference's Python package not built (oracle/build_ref.sh needs /root/reference)")
