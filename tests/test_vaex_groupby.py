@@ -38,6 +38,18 @@ else:
                 return self._predicates[key]
             return sel
     vg._frame_for = lambda df, columns: HostMaskFrame(dict(columns), chunk_size=50_000, nthreads=2, superagg=ref)
+    import threading
+    class HostCollector:   # (the delayed groupby's columns, assembled on the host instead of in HBM)
+        def __init__(self, plan, capacity):
+            self.parts, self.lock, self.rows, self.capacity = [], threading.Lock(), 0, capacity
+        def append(self, chunks):
+            with self.lock:
+                self.parts.append({k: np.array(v) for k, v in chunks.items()})
+                self.rows += len(next(iter(chunks.values())))
+                assert self.rows <= self.capacity
+        def frame(self):
+            return HostMaskFrame({k: np.concatenate([p[k] for p in self.parts]) for k in self.parts[0]}, chunk_size=50_000, nthreads=2, superagg=ref)
+    vg._collector_for = lambda plan, capacity: HostCollector(plan, capacity)
     state = {}
     vg.install(vaex, state)
     original = state["groupby"][1]
@@ -128,6 +140,14 @@ for by, agg, why in declined:
     got = df.groupby(by, agg=agg)
     assert vg.last.get("path") == "vaex" and why in vg.last.get("why", ""), (by, vg.last)
     print("ok-declined", by, vg.last["why"])
+# a categorical key comes back as its LABELS, one group per category (vaex's GrouperCategory): vaex's business
+dcat = vaex.from_arrays(c=np.array([0, 1, 1, 2, 1]), v=np.arange(5.0))
+dcat.categorize("c", labels=["a", "b", "c"], inplace=True)
+vg.last.clear()
+gc = dcat.groupby("c", agg="count", sort=True)
+assert vg.last.get("path") == "vaex" and "categorical" in vg.last["why"], vg.last
+assert gc["c"].tolist() == ["a", "b", "c"] and gc["count"].tolist() == [1, 3, 1], gc
+print("ok-declined categorical", vg.last["why"])
 # filtered frames: the filter is a keep-mask over the whole call when it is in the predicate subset (groups without a row inside it do
 # not exist, the key column is typed from the keys that are left); any other filter — and a row limit — is vaex's business
 filtered = [
@@ -135,6 +155,7 @@ filtered = [
   (df[df.v > 3.5], "k32", {"n": "count", "mw": A.mean("w"), "lo": A.min("i")}, dict(sort=True, ascending=False)),      # the filter column is not otherwise read
   (df[df.w < 0][df.k >= 10], "kgap", {"c": A.count("v"), "s": A.sum("i")}, {}),                                          # a chain: (w < 0) & (k >= 10)
   (df[(df.k == 7) | (df.k == 30)], "k", "count", {}),                                                                    # two groups left of 45
+  (df[df.k > 1000], "k", {"c": A.count(), "s": A.sum("v")}, {}),                                                          # NO row left: no group
 ]
 if gpu:
     filtered += [(df[df.v > 2], ["k", "k32"], {"c": A.count(), "s": A.sum("v")}, {}),
@@ -191,6 +212,69 @@ part = df[1000:150_000]
 vg.last.clear()
 same(frame(part.groupby("k", agg={"s": A.sum("v"), "c": A.count()}), "k"), frame(original(part, "k", agg={"s": A.sum("v"), "c": A.count()}), "k"), "slice")
 print("ok-slice", vg.last.get("path"))
+# delay=True: the device groupby as a TASK of the executor's pass (round 5) — scheduled next to the caller's other delayed work, fulfilled
+# by df.execute() in ONE pass over the data (vaex's own delayed groupby takes two: the distinct keys, then the aggregation)
+def grouped(d, keys):
+    return {c: d.sort(keys)[c].to_numpy() for c in d.get_column_names()}
+passes = df.executor.passes
+tasks_before = vg.stats["task"]
+p1 = df.groupby("k", agg={"s": A.sum("v"), "c": A.count(), "m": A.mean("v")}, delay=True)
+p2 = df.groupby("k32", agg={"n": "count", "mw": A.mean("w")}, sort=True, ascending=False, delay=True)
+pm = df.mean("v", delay=True)                                  # somebody else's task in the same pass
+p3 = df.groupby("k").agg({"c": A.count(selection="v > 3")}, delay=True)   # the lazy object's agg
+assert df.executor.passes == passes and not p1.isFulfilled
+df.execute()
+assert df.executor.passes == passes + 1, (df.executor.passes, passes)
+assert vg.stats["task"] == tasks_before + 3, vg.stats
+same(grouped(p1.get(), ["k"]), grouped(original(df, "k", agg={"s": A.sum("v"), "c": A.count(), "m": A.mean("v")}), ["k"]), "delayed")
+w2 = original(df, "k32", agg={"n": "count", "mw": A.mean("w")}, sort=True, ascending=False)
+same({c: p2.get()[c].to_numpy() for c in p2.get().get_column_names()}, {c: w2[c].to_numpy() for c in w2.get_column_names()}, "delayed, sorted descending")
+same(grouped(p3.get(), ["k"]), grouped(original(df, "k").agg({"c": A.count(selection="v > 3")}), ["k"]), "delayed lazy agg")
+assert abs(pm.get() - np.nanmean(v)) < 1e-9
+print("ok-task one pass for three groupbys and a mean")
+# a filtered frame: the executor compacts the chunks for the task like for every other task — ANY filter, also one outside the predicate subset
+dflt = df[np.sin(df.v) > 0]
+vg.last.clear()
+pf = dflt.groupby("k", agg={"c": A.count(), "s": A.sum("v")}, delay=True)
+pc = dflt.count(delay=True)
+dflt.execute()
+assert vg.last.get("path") == "device", vg.last
+same(grouped(pf.get(), ["k"]), grouped(original(dflt, "k", agg={"c": A.count(), "s": A.sum("v")}), ["k"]), "delayed, filtered")
+assert int(pc.get()) == int((np.sin(v) > 0).sum())
+print("ok-task filtered")
+# a slice, and a frame that is a slice of a filtered one
+part = df[5000:120_000]
+pp = part.groupby("kgap", agg={"c": A.count("v"), "s": A.sum("i")}, delay=True)
+part.execute()
+same(grouped(pp.get(), ["kgap"]), grouped(original(part, "kgap", agg={"c": A.count("v"), "s": A.sum("i")}), ["kgap"]), "delayed, sliced")
+print("ok-task slice")
+# outside the signature: vaex's own delayed tasks (two passes), as before
+passes = df.executor.passes
+vg.last.clear()
+pd_ = df.groupby("kf", agg={"c": A.count()}, delay=True)
+assert vg.last.get("path") == "vaex", vg.last
+df.execute()
+assert len(pd_.get()) == 5
+print("ok-task declined at scheduling")
+# the data turns out to be outside the device groupby when the pass is over: vaex's own groupby answers from get_result
+keep_run = vg._run
+def refusing(plan, frame_):
+    raise vg._Decline("test: refused after the pass")
+vg._run = refusing
+vg.last.clear()
+pr = df.groupby("k", agg={"c": A.count(), "s": A.sum("v")}, delay=True)
+df.execute()
+vg._run = keep_run
+assert vg.last.get("path") == "vaex" and "refused after the pass" in vg.last.get("why", ""), vg.last
+same(grouped(pr.get(), ["k"]), grouped(original(df, "k", agg={"c": A.count(), "s": A.sum("v")}), ["k"]), "delayed, answered by vaex after the pass")
+print("ok-task fallback after the pass")
+# a progress callable sees the executor's fractions; returning False cancels the task (vaex's UserAbort at .get())
+seen = []
+pg = df.groupby("k", agg={"c": A.count()}, delay=True)
+pg.signal_progress.connect(lambda f: seen.append(f) or True)
+df.execute()
+assert seen and seen[0] == 0 and seen[-1] == 1 and len(pg.get()) == len(np.unique(df.k.to_numpy())), seen
+print("ok-task progress")
 # a failure the device path reports (HBM exhausted, a HIP error) does not kill the call: vaex's own groupby answers
 keep_frame_for = vg._frame_for
 def broken(df_, columns):
@@ -217,13 +301,13 @@ def _run(gpu, timeout):
 @pytest.mark.skipif(not os.path.isdir(os.path.join(PKG, "vaex")), reason="real vaex package not built (oracle/build_ref.sh needs /root/reference)")
 def test_groupby_host_logic_against_vaex_on_the_reference_cpp():
     out = _run(0, 600)
-    assert "DONE" in out and out.count("ok-device ") == 15 and out.count("ok-device-filtered") == 4 and out.count("ok-declined") == 7, out
-    assert "ok-device-failure-falls-back" in out, out
+    assert "DONE" in out and out.count("ok-device ") == 15 and out.count("ok-device-filtered") == 5 and out.count("ok-declined") == 8, out
+    assert "ok-device-failure-falls-back" in out and out.count("ok-task") == 6, out
 
 
 @pytest.mark.gpu
 @pytest.mark.skipif(not os.path.isdir(os.path.join(PKG, "vaex")), reason="real vaex package not built (oracle/build_ref.sh needs /root/reference)")
 def test_groupby_of_real_vaex_runs_on_the_device_groupby():
     out = _run(1, 900)
-    assert "DONE" in out and out.count("ok-device ") == 21 and out.count("ok-device-filtered") == 6 and out.count("ok-declined") == 7, out
+    assert "DONE" in out and out.count("ok-device ") == 21 and out.count("ok-device-filtered") == 7 and out.count("ok-declined") == 8 and out.count("ok-task") == 6, out
     assert "gb_scatter+gb_reduce" in out and "bin_lds" in out, out   # (the fused hash aggregation, and — few groups — the LDS-resident grid)

@@ -29,6 +29,8 @@ masked int64 array without masked entries when vaex would have simplified to Bin
 keys), else the narrowest signed integer type that holds the key range (vaex/groupby.py:263-277).
 """
 import collections.abc
+import itertools
+import threading
 
 import numpy as np
 
@@ -37,7 +39,7 @@ from . import binned
 #: what the most recent DataFrame.groupby(..., agg=...) ran on: {"path": "device" | "vaex", "kernel": ..., "why": ...}
 last = {}
 #: df.groupby calls answered by the device groupby / handed on to vaex's own two passes (with the reasons)
-stats = {"device": 0, "vaex": 0, "why": {}}
+stats = {"device": 0, "task": 0, "vaex": 0, "why": {}}
 
 _KEY_KINDS = ("bool", "int8", "int16", "int32", "int64", "uint8", "uint16", "uint32")
 _TINY_KEYS = ("bool", "int8", "uint8")   # vaex bins these with BinnerInteger straight away (vaex/groupby.py:593-595): no combined grouper, own key typing
@@ -186,10 +188,15 @@ def _key_column_like_vaex(values, source_kind=None):
     return k
 
 
-def fast_groupby(df, by, agg, sort=False, ascending=True, row_limit=None):
-    """the grouped DataFrame, or _Decline"""
+class _Plan:
+    """what a df.groupby(by, agg) call needs from the device groupby, decided before a row is read"""
+    __slots__ = ("by", "agg", "sort", "srt", "asc", "columns", "key_names", "actions", "spec", "selection", "rows")
+
+
+def _plan(df, by, agg, sort=False, ascending=True, row_limit=None, for_task=False):
+    """the call's _Plan, or _Decline.  for_task: the rows will come from the executor's chunks (already compacted by the frame's filter:
+    the task is pre-filtered like every other task of a filtered frame), so the filter is not planned as a device predicate"""
     import vaex
-    import vaex.dataset
     import vaex.groupby
     if row_limit is not None:
         raise _Decline("row_limit")
@@ -210,6 +217,8 @@ def fast_groupby(df, by, agg, sort=False, ascending=True, row_limit=None):
         name, ar = _real_column(df, vaex.utils._ensure_string_from_expression(b), _KEY_KINDS, "group key")
         if name in columns:
             raise _Decline("the same key twice")
+        if df.is_category(name):
+            raise _Decline(f"group key {name!r} is categorical")   # (vaex's GrouperCategory hands back the LABELS, and a group per category: vaex/groupby.py:384-442)
         if ar.dtype.name in _TINY_KEYS and len(by_list) > 1:
             raise _Decline(f"{ar.dtype.name} key next to other keys")   # (BinnerInteger's N is the dtype's range, not the distinct keys: vaex's combine decision differs)
         columns[name] = ar
@@ -226,7 +235,7 @@ def fast_groupby(df, by, agg, sort=False, ascending=True, row_limit=None):
     # (vaex/execution.py:515-523); here the filter is a device predicate in every aggregator's keep-mask (vaex_amd/vaex_filter.py) and
     # groups without a row inside it are dropped — when it is in the predicate subset over real numeric columns; else vaex's own code
     selection = None
-    if df.filtered:
+    if df.filtered and not for_task:
         from . import vaex_filter
         pred = vaex_filter.filter_plan(df)
         if pred is None:
@@ -235,10 +244,19 @@ def fast_groupby(df, by, agg, sort=False, ascending=True, row_limit=None):
         for c in pred.columns:
             if c not in columns:
                 columns[c] = _real_column(df, c, tuple(k for k in vaex_filter._NUMERIC if k != "bool"), "filter column")[1]
+    plan = _Plan()
+    plan.by, plan.agg, plan.sort, plan.srt, plan.asc = by, agg, sort, srt, asc
+    plan.columns, plan.key_names, plan.actions, plan.spec, plan.selection = columns, key_names, actions, spec, selection
+    plan.rows = len(next(iter(columns.values())))
+    return plan
+
+
+def _run(plan, frame):
+    """the groups of `frame` (a binned.Frame over the plan's columns): {column: array}, or _Decline"""
+    key_names = plan.key_names
     try:
-        frame = _frame_for(df, columns)
         frame.last_groupby_info = None
-        res = frame.groupby(key_names if len(key_names) > 1 else key_names[0], spec, selection=selection)
+        return frame.groupby(key_names if len(key_names) > 1 else key_names[0], plan.spec, selection=plan.selection)
     except (NotImplementedError, ValueError) as e:
         raise _Decline(str(e))
     except (RuntimeError, MemoryError) as e:
@@ -246,7 +264,15 @@ def fast_groupby(df, by, agg, sort=False, ascending=True, row_limit=None):
         # passes answer — chunk by chunk, on the HIP classes where those still work — instead of the call dying here
         drop_device_copies()
         raise _Decline(f"device groupby failed: {type(e).__name__}: {str(e)[:200]}")
-    descending = bool(srt[0]) and not asc[0]
+
+
+def _finish(df, plan, frame, res):
+    """the grouped DataFrame the way GroupBy.agg builds it (vaex/groupby.py:955-983)"""
+    import vaex
+    import vaex.dataset
+    import vaex.groupby
+    key_names, columns, actions = plan.key_names, plan.columns, plan.actions
+    descending = bool(plan.srt[0]) and not plan.asc[0]
     out = {}
     typed = {name: _key_column_like_vaex(np.asarray(res[name]), columns[name].dtype.name) for name in key_names}
     # several keys: vaex packs them into one grouper when the cartesian product of the key sets is sparsely occupied (< 10 rows
@@ -254,7 +280,7 @@ def fast_groupby(df, by, agg, sort=False, ascending=True, row_limit=None):
     cells = 1
     for name in key_names:
         cells *= max(1, len(np.unique(np.ma.getdata(typed[name]))))
-    combined = len(key_names) >= 2 and frame.n / cells < 10
+    combined = len(key_names) >= 2 and plan.rows / cells < 10
     for name in key_names:
         k = np.ma.getdata(typed[name]) if combined else typed[name]
         k = k[::-1] if descending else k
@@ -267,8 +293,22 @@ def fast_groupby(df, by, agg, sort=False, ascending=True, row_limit=None):
     kernel = "gb_scatter+gb_reduce" if fused else (frame.sa.last_kernel(0) if hasattr(frame.sa, "last_kernel") else "")
     last.update(path="device", kernel=kernel, info=frame.last_groupby_info, groups=len(next(iter(out.values()))))
     dataset_arrays = vaex.dataset.DatasetArrays(out)
-    dataset = vaex.groupby.DatasetGroupby(dataset_arrays, df, by, agg, combine=combined, expand=True, sort=sort)
+    dataset = vaex.groupby.DatasetGroupby(dataset_arrays, df, plan.by, plan.agg, combine=combined, expand=True, sort=plan.sort)
     return vaex.from_dataset(dataset)
+
+
+def fast_groupby(df, by, agg, sort=False, ascending=True, row_limit=None):
+    """the grouped DataFrame, or _Decline"""
+    plan = _plan(df, by, agg, sort=sort, ascending=ascending, row_limit=row_limit)
+    try:
+        frame = _frame_for(df, plan.columns)
+    except (NotImplementedError, ValueError) as e:
+        raise _Decline(str(e))
+    except (RuntimeError, MemoryError) as e:   # (see _run)
+        drop_device_copies()
+        raise _Decline(f"device groupby failed: {type(e).__name__}: {str(e)[:200]}")
+    res = _run(plan, frame)
+    return _finish(df, plan, frame, res)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -340,6 +380,68 @@ def drop_device_copies():
     _device_copies.clear()
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# df.groupby(..., delay=True): the device groupby as a TASK of vaex's executor (vaex/tasks.py, vaex/cpu.py, vaex/execution.py:343-470).
+# A delayed call asks for its work to share ONE pass over the data with whatever else the caller has scheduled (df.mean(delay=True), other
+# groupbys, ...) and to be fulfilled by df.execute().  The task names the plan's columns as its expressions; the executor evaluates and —
+# for a filtered frame — compacts them chunk by chunk like it does for every task, hands each chunk to the task part from its pool threads,
+# and the part appends the chunk to the plan's columns IN HBM (vxh_upload, outside the lock that hands out row offsets: the order of the
+# rows does not matter to a groupby).  When the pass is over, `get_result` runs the same device groupby the eager path runs, on the
+# assembled columns.  Progress, cancellation and the pass count are the executor's.
+# ---------------------------------------------------------------------------------------------------------------------
+_PLANS = {}
+_tokens = itertools.count(1)
+_TORCH_KINDS = ("int8", "int16", "int32", "int64", "uint8", "float32", "float64")
+
+
+class DeviceCollector:
+    """the plan's columns, assembled in HBM from the chunks the executor hands over"""
+
+    def __init__(self, plan, capacity):
+        import torch
+        import vaex_amd
+        self.sa = vaex_amd.superagg
+        for name, ar in plan.columns.items():
+            if ar.dtype.name not in _TORCH_KINDS:
+                raise _Decline(f"delayed groupby: column {name!r} has dtype {ar.dtype} (no device column of that type)")
+        total = sum(ar.dtype.itemsize for ar in plan.columns.values()) * capacity
+        free, _ = torch.cuda.mem_get_info(int(self.sa.config_get("device")))
+        if total * 4 >= free:
+            raise _Decline("delayed groupby: the columns do not fit the device next to the partition queues")
+        self.capacity = capacity
+        self.dtypes = {name: ar.dtype for name, ar in plan.columns.items()}
+        self.cols = {name: torch.empty(capacity, dtype=getattr(torch, ar.dtype.name), device="cuda") for name, ar in plan.columns.items()}
+        self.rows = 0
+        self.lock = threading.Lock()
+
+    def append(self, chunks):
+        n = len(next(iter(chunks.values())))
+        if n == 0:
+            return
+        with self.lock:
+            at = self.rows
+            self.rows += n
+        if at + n > self.capacity:
+            raise RuntimeError("delayed groupby: more rows than the frame has")
+        for name, block in chunks.items():
+            a = np.ascontiguousarray(np.asarray(block), dtype=self.dtypes[name])
+            self.sa.upload(a, self.cols[name][at:at + n], 2)
+
+    def frame(self):
+        from . import vaex_dist
+        return binned.Frame({name: t[:self.rows] for name, t in self.cols.items()}, comm=vaex_dist.comm())
+
+
+def _collector_for(plan, capacity):
+    return DeviceCollector(plan, capacity)
+
+
+def _block_as_numpy(block):
+    if isinstance(block, np.ndarray) and not np.ma.isMaskedArray(block):
+        return block
+    raise RuntimeError(f"delayed groupby: a chunk of type {type(block).__name__} (the plan saw plain numpy columns)")
+
+
 def _could_be_served(df, by, row_limit):
     """cheap look at a groupby WITHOUT aggregation: only integer key columns the device groupby takes make the lazy object worth it"""
     import vaex
@@ -393,6 +495,90 @@ def install(vaex_module, state):
         stats["vaex"] += 1
         stats["why"][str(e)[:100]] = stats["why"].get(str(e)[:100], 0) + 1
 
+    import vaex.cpu
+    import vaex.tasks
+
+    class TaskGroupbyHip(vaex.tasks.Task):
+        """df.groupby(by, agg, delay=True) as one task of the executor's pass (see above); fulfilled with the grouped DataFrame"""
+        snake_name = "groupby_hip"
+        see_all = True        # ONE task part, shown every chunk (vaex/execution.py:404-406, :553-556)
+        cacheable = False
+
+        def __init__(self, df, plan, token):
+            super().__init__(df=df, expressions=list(plan.columns), pre_filter=df.filtered, name=self.snake_name)
+            self.selections = []
+            self.plan, self.token = plan, token
+
+        def get_bin_count(self):
+            return 0
+
+        def encode(self, encoding):
+            return {"token": self.token}
+
+        def __repr__(self):
+            return f"task-{self.snake_name}: by={self.plan.key_names!r}"
+
+    class TaskPartGroupbyHip(vaex.cpu.TaskPart):
+        snake_name = "groupby_hip"
+
+        def __init__(self, df, token):
+            plan, collector, fallback = _PLANS[token]
+            super().__init__(df, list(plan.columns), self.snake_name, df.filtered)
+            self.token, self.plan, self.collector, self.fallback = token, plan, collector, fallback
+
+        @classmethod
+        def decode(cls, encoding, spec, df, nthreads):
+            return cls(df, spec["token"])
+
+        def ideal_splits(self, nthreads):
+            return 1
+
+        def memory_usage(self):
+            return 0
+
+        def process(self, thread_index, i1, i2, filter_mask, selection_masks, blocks):
+            # (called from the pool's threads, several at a time: the collector hands out row ranges under its lock)
+            self.collector.append({name: _block_as_numpy(b) for name, b in zip(self.plan.columns, blocks)})
+
+        def reduce(self, others):
+            pass
+
+        def get_result(self):
+            _PLANS.pop(self.token, None)
+            try:
+                frame = self.collector.frame()
+                res = _run(self.plan, frame)
+                result = _finish(self.df, self.plan, frame, res)
+            except _Decline as e:
+                # the data turned out to be outside the device groupby (key ranges whose product overflows, a device failure, ...): the pass
+                # is over and the executor idle (vaex/execution.py:436-441) — vaex's own groupby answers, now
+                declined(e)
+                result = self.fallback()
+            else:
+                stats["task"] += 1
+            finally:
+                self.collector = None
+            return result
+
+    vaex.tasks.register(TaskGroupbyHip)
+    vaex.cpu.register(TaskPartGroupbyHip)
+
+    def schedule_task(df, by, agg, sort, ascending, row_limit, kwargs):
+        """the scheduled TaskGroupbyHip (a promise of the grouped DataFrame), or _Decline"""
+        from . import vaex_dist
+        if vaex_dist.active():
+            raise _Decline("delayed groupby on a row-sharded frame")
+        plan = _plan(df, by, agg, sort=sort, ascending=ascending, row_limit=row_limit, for_task=True)
+        if plan.rows == 0:
+            raise _Decline("empty frame")
+        try:
+            collector = _collector_for(plan, plan.rows)
+        except (RuntimeError, MemoryError, ImportError) as e:
+            raise _Decline(f"device groupby failed: {type(e).__name__}: {str(e)[:200]}")
+        token = next(_tokens)
+        _PLANS[token] = (plan, collector, lambda: original(df, by=by, agg=agg, delay=False, **kwargs))
+        return df.executor.schedule(TaskGroupbyHip(df, plan, token))
+
     class LazyGroupBy(vaex.groupby.GroupBy):
         """df.groupby(by) WITHOUT agg: vaex builds the groupers — the distinct-key pass over the key columns — in GroupBy.__init__
         (vaex/groupby.py:602-668), before it knows the aggregation.  This object postpones that: `.agg(...)` of a signature the device
@@ -417,9 +603,14 @@ def install(vaex_module, state):
         def agg(self, actions, delay=False, progress=None):
             if "_lazy" in self.__dict__ and delay:
                 # (delay=True is a request to batch this aggregation with the caller's other tasks into one pass of the executor —
-                #  vaex/groupby.py:975-1017 — which the device groupby, one call outside the executor, cannot honour: vaex's own tasks)
-                declined(_Decline("delay=True: scheduled as vaex's own tasks"))
-                self._materialise()
+                #  vaex/groupby.py:975-1017: the device groupby joins that pass as a task)
+                df, kw = self.__dict__["_lazy"]
+                try:
+                    return schedule_task(df, kw["by"], actions, kw["sort"], kw["ascending"], kw["row_limit"],
+                                         dict(sort=kw["sort"], ascending=kw["ascending"], assume_sparse=kw["assume_sparse"], row_limit=kw["row_limit"], copy=kw["copy"], progress=progress if progress is not None else kw.get("progress")))
+                except _Decline as e:
+                    declined(e)
+                    self._materialise()
             if "_lazy" in self.__dict__:
                 df, kw = self.__dict__["_lazy"]
                 try:
@@ -435,9 +626,14 @@ def install(vaex_module, state):
 
     def groupby(self, by=None, agg=None, sort=False, ascending=True, assume_sparse="auto", row_limit=None, copy=True, progress=None, delay=False):
         if agg is not None and delay:
-            # (see LazyGroupBy.agg: a delayed groupby shares the pass of df.execute() with the caller's other tasks — vaex's task parts,
-            #  on the HIP classes; the reference's tests count the passes: tests/groupby_test.py:598-606)
-            declined(_Decline("delay=True: scheduled as vaex's own tasks"))
+            # (a delayed groupby shares the pass of df.execute() with the caller's other tasks: the device groupby as a task of that pass —
+            #  or, outside its signature, vaex's own delayed tasks on the HIP classes; the reference's tests count the passes:
+            #  tests/groupby_test.py:598-606)
+            try:
+                return schedule_task(self, by, agg, sort, ascending, row_limit,
+                                     dict(sort=sort, ascending=ascending, assume_sparse=assume_sparse, row_limit=row_limit, copy=copy, progress=progress))
+            except _Decline as e:
+                declined(e)
         elif agg is not None:
             try:
                 result = _served(progress, lambda: fast_groupby(self, by, agg, sort=sort, ascending=ascending, row_limit=row_limit))
@@ -454,6 +650,7 @@ def install(vaex_module, state):
     groupby.__wrapped__ = original
     cls.groupby = groupby
     state["groupby"] = (cls, original)
+    state["groupby_task"] = (TaskGroupbyHip, TaskPartGroupbyHip)
 
 
 def uninstall(vaex_module, state):
