@@ -99,6 +99,16 @@ def _statistic_nd(blocks, weights, grid, minima, maxima, op_code, use_edges, siz
         raise ValueError("statisticNd_: this op needs a weight array")
     if not isinstance(grid, np.ndarray) or grid.dtype != np.float64:
         raise TypeError("statisticNd_: grid must be a float64 ndarray")
+    if grid.ndim > nd + 1:
+        # The reference never compares the grid's rank with the blocks': it takes the first `nd` sizes / strides as the binned dimensions and
+        # writes field f of a cell at the cell's offset + f (vaexfast.cpp:197-213, :1485-1493) — i.e. everything behind the binned dimensions is
+        # ONE run of values per cell (the reference's own unittest hands a (10, 2) grid to a call without blocks: vaex/test/cmodule.py:26-35)
+        flat = grid.view()
+        try:
+            flat.shape = grid.shape[:nd] + (-1,)
+        except AttributeError:
+            raise ValueError("statisticNd_: the grid's trailing dimensions are not contiguous")
+        grid = flat
     if grid.ndim != nd + 1:
         raise ValueError(f"statisticNd_: grid has {grid.ndim} dimensions, expected {nd + 1}")
     if grid.strides[-1] != 8:
