@@ -61,7 +61,7 @@ def pytest_sessionfinish(session, exitstatus):
     if INSTALL:
         from vaex_amd import vaex_groupby, vaex_selection, vaex_filter
         doc["task_stats"] = {k: v for k, v in vaex_amd.task_stats.items() if isinstance(v, (int, float, str, dict))}
-        doc["groupby"] = {"device": vaex_groupby.stats.get("device", 0), "vaex": vaex_groupby.stats.get("vaex", 0), "why": vaex_groupby.stats.get("why", {})}
+        doc["groupby"] = {"device": vaex_groupby.stats.get("device", 0), "task": vaex_groupby.stats.get("task", 0), "vaex": vaex_groupby.stats.get("vaex", 0), "why": vaex_groupby.stats.get("why", {})}
         doc["selection"] = dict(vaex_selection.stats)
         doc["filter"] = dict(vaex_filter.stats)
     with open(path, "w") as f:

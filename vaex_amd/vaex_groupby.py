@@ -23,6 +23,9 @@ through the fused radix-partitioned hash aggregation (vxh_groupby_run), several 
 (vxh_pack_keys: vaex's GrouperCombined, vaex/groupby.py:526-584).  Anything outside that signature — and any failure the
 device path reports — falls through to vaex's own groupby, which then still runs on the HIP classes task by task.
 
+`delay=True` (round 5): the same signature as a TASK of the executor's pass — TaskGroupbyHip below: the executor's chunks are appended to the
+plan's columns in HBM, the fused groupby runs when the pass is over; one pass for any number of delayed groupbys and the caller's other tasks.
+
 Group order: ascending by key(s) (descending with sort=True, ascending=False).  vaex's own order without `sort` is its hash
 set's insertion order — unspecified; with sort=True it is this one.  The key column comes back the way vaex types it: a
 masked int64 array without masked entries when vaex would have simplified to BinnerInteger (key range <= 4/3 of the distinct
