@@ -148,6 +148,25 @@ gc = dcat.groupby("c", agg="count", sort=True)
 assert vg.last.get("path") == "vaex" and "categorical" in vg.last["why"], vg.last
 assert gc["c"].tolist() == ["a", "b", "c"] and gc["count"].tolist() == [1, 3, 1], gc
 print("ok-declined categorical", vg.last["why"])
+# three defects of the reference's own groupby where the device groupby answers what the data says (INTEGRATION.md "Differences"): pinned
+# BOTH ways, so that a change on either side shows
+db = vaex.from_arrays(k=np.array([True, True, True, False]), v=np.arange(4.0))
+w, g = original(db, "k", agg="count", sort=True, ascending=False), db.groupby("k", agg="count", sort=True, ascending=False)
+assert w["k"].tolist() == [False, True] and w["count"].tolist() == [3, 1], w      # vaex: the counts are reversed, the labels are not (vaex/groupby.py:174-178)
+assert g["k"].tolist() == [True, False] and g["count"].tolist() == [3, 1], g
+de = vaex.from_arrays(k=np.array([-32768, -32767, 0, 32766, 32767, 0], dtype="i2"), v=np.arange(6.0))
+assert len(original(de, "k", agg="count")) == 0                                    # vaex: vmax - vmin + 1 wraps in the key's own dtype: no group at all
+g = de.groupby("k", agg="count", sort=True)
+assert g["k"].tolist() == [-32768, -32767, 0, 32766, 32767] and g["count"].tolist() == [1, 1, 2, 1, 1], g
+d1 = vaex.from_arrays(k=np.array([7], dtype="u2"), v=np.arange(1.0))
+try:
+    original(d1, "k", agg="count", sort=True, ascending=False)                     # vaex: IndexError (vmin - 2 wraps for an unsigned key, vaex/groupby.py:163-166)
+    raise SystemExit("the reference no longer raises here")
+except IndexError:
+    pass
+g = d1.groupby("k", agg="count", sort=True, ascending=False)
+assert g["k"].tolist() == [7] and g["count"].tolist() == [1], g
+print("ok-reference-defects")
 # filtered frames: the filter is a keep-mask over the whole call when it is in the predicate subset (groups without a row inside it do
 # not exist, the key column is typed from the keys that are left); any other filter — and a row limit — is vaex's business
 filtered = [
@@ -302,7 +321,7 @@ def _run(gpu, timeout):
 def test_groupby_host_logic_against_vaex_on_the_reference_cpp():
     out = _run(0, 600)
     assert "DONE" in out and out.count("ok-device ") == 15 and out.count("ok-device-filtered") == 5 and out.count("ok-declined") == 8, out
-    assert "ok-device-failure-falls-back" in out and out.count("ok-task") == 6, out
+    assert "ok-device-failure-falls-back" in out and out.count("ok-task") == 6 and "ok-reference-defects" in out, out
 
 
 @pytest.mark.gpu
