@@ -271,3 +271,29 @@ def test_arithmetic_and_virtual_column_selections_keep_the_rows_numpy_keeps(wher
         want = f.count(binby=["v"], limits=[[-5, 11]], shape=64, selection=mask, edges=True)
         assert np.array_equal(got, want), (expr, int(np.abs(np.asarray(got) - np.asarray(want)).sum()))
         assert int(np.asarray(got).sum()) == int(keep.sum()), expr
+
+
+def test_random_predicates_keep_the_rows_numpy_keeps():
+    """the differential fuzz of tests/test_predicate.py on the device: random expressions (comparisons of every column type with integer / float
+    / huge / float32-boundary constants on either side, arithmetic over float64 columns, & | ~ three levels deep) as device predicates — in the
+    kernels where the call's shape allows, through sel_eval otherwise — against the same call with numpy's keep-mask"""
+    from tests.predicate_fuzz import random_expression
+    cols = _columns(150_001, 9)
+    cols["x"][5], cols["x"][6], cols["x"][7] = np.inf, -np.inf, -0.0
+    cols["f"][::17] = np.nan
+    names = [k for k in cols if k != "t"] + ["t"]
+    f = Frame(cols, chunk_size=40_000, nthreads=2)
+    inside = 0
+    for seed in range(260):
+        expr = random_expression(np.random.default_rng(1000 + seed), names, ["x", "y", "v"])
+        try:
+            keep = _want_mask(expr, cols)
+        except P.Unsupported:
+            continue
+        inside += 1
+        shape = 64 if seed % 3 else 300                      # (LDS-resident count kernels / the partition pass)
+        got = f.count(binby=["y", "v"], limits=[[-4, 4], [-3, 9]], shape=shape, selection=expr, edges=True)
+        want = f.count(binby=["y", "v"], limits=[[-4, 4], [-3, 9]], shape=shape, selection=keep, edges=True)
+        assert np.array_equal(got, want), expr
+        assert int(got.sum()) == int(keep.sum()), expr
+    assert inside > 150, inside

@@ -80,3 +80,30 @@ def test_arithmetic_is_float64_only_and_bounded():
         P.compile_selection(" + ".join(["x * x"] * 9) + " > 1", cols)
     # a virtual column that is just another name of a real column is a plain term
     assert not P.compile_selection("alias > 1", cols, virtual={"alias": "x"}).programs
+
+
+def test_random_expressions_keep_the_rows_numpy_keeps():
+    """a differential fuzz of the subset's host evaluation (Predicate.numpy_mask — the specification the device kernels are tested against,
+    tests/test_gpu_selection.py) against plain numpy on the same expression string — which is what vaex evaluates (vaex/scopes.py:138-177; 3000
+    such expressions were also run against the real package's df.evaluate while this test was written: 0 differences)"""
+    from tests.predicate_fuzz import random_expression
+    rng0 = np.random.default_rng(5)
+    n = 3000
+    x = rng0.normal(0, 2, n); x[::13] = np.nan; x[5] = np.inf; x[6] = -np.inf; x[7] = -0.0
+    f = rng0.choice(np.array([0.1, 0.3, 0.30000001, 0.5, -0.7, 1e-8], dtype="f4"), n); f[::17] = np.nan
+    i = rng0.integers(-5, 6, n).astype("i8"); i[3] = 2**62; i[4] = -2**62
+    cols = dict(x=x, y=rng0.normal(1, 1, n), f=f, i=i, i4=rng0.integers(-100, 100, n).astype("i4"), h=rng0.integers(-300, 300, n).astype("i2"),
+                u1=rng0.integers(0, 255, n).astype("u1"), u4=rng0.integers(0, 2**32 - 1, n, dtype="u8").astype("u4"), b=rng0.integers(0, 2, n).astype(bool))
+    scope = dict(cols, sqrt=np.sqrt, abs=np.abs)
+    inside = 0
+    for seed in range(600):
+        expr = random_expression(np.random.default_rng(seed), list(cols), ["x", "y"])
+        try:
+            pred = P.compile_selection(expr, cols)
+        except P.Unsupported:
+            continue
+        inside += 1
+        with np.errstate(all="ignore"):
+            want = np.asarray(eval(expr, {}, scope)).astype(bool)
+        assert np.array_equal(pred.numpy_mask(cols), want), expr
+    assert inside > 400, inside
