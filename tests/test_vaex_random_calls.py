@@ -1,0 +1,190 @@
+"""Randomised differential test through the REAL vaex API (the fixed list of calls is tests/test_vaex_differential.py): 220 calls drawn from
+a grammar — statistic x expression (plain / float32 / integer / bool / big-endian / masked / virtual / arithmetic) x 0-3 binby dimensions
+(float, integer, virtual, big-endian, masked columns; fixed or data-derived limits; random shapes) x selection (none / a random expression of
+the predicate grammar / a list / a named selection) x frame (plain / filtered inside and outside the device-predicate subset / sliced /
+both) x immediate or delayed in batches — run once under vaex_amd.install() and once on vaex's own C++ after uninstall(), compared call by
+call: integers exactly, fp64 sums / means to 1e-12 of the result's magnitude, variances to the cancellation bound, and an exception on one
+side must be the same exception on the other.  Without a GPU both halves run on vaex's C++ (checks the script and its determinism)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+VAEXPY = os.path.join(ROOT, "oracle", "_ref", "vaexpy")
+OVERLAY = os.path.join(ROOT, "oracle", "_ref", "overlay")
+FAKE = os.path.join(ROOT, "oracle", "fake")
+PKG = VAEXPY if os.path.isdir(os.path.join(VAEXPY, "vaex")) else OVERLAY
+
+SCRIPT = r'''
+import sys, numpy as np
+sys.path[:0] = [%(pkg)r, %(fake)r, %(root)r]
+import vaex
+from tests.predicate_fuzz import random_expression
+gpu = %(gpu)d
+ncalls = %(ncalls)d
+n = 120_000
+def make():
+    r = np.random.default_rng(21)
+    x = r.normal(0, 1, n); x[::997] = np.nan
+    v = r.normal(3, 2, n); v[::501] = np.nan
+    cols = dict(x=x, y=r.normal(0, 1, n), z=r.normal(0, 2, n), v=v, f4=r.normal(0, 1, n).astype("f4"),
+                i=r.integers(-50, 50, n).astype("i4"), h=r.integers(-300, 300, n).astype("i2"), u1=r.integers(0, 200, n).astype("u1"), b=r.random(n) < 0.3,
+                k=r.integers(0, 30, n), be=r.normal(0, 1, n).astype(">f8"), m=np.ma.array(r.normal(0, 1, n), mask=r.random(n) < 0.05))
+    df = vaex.from_arrays(**cols)
+    df["r"] = np.sqrt(df.x ** 2 + df.y ** 2)
+    df["vi"] = df.v * df.i
+    return df
+LIMITS = dict(x=[-3, 3], y=[-3, 3], z=[-5, 5], f4=[-2.5, 2.5], i=[-50.5, 49.5], h=[-100, 100], u1=[0, 256], k=[-0.5, 29.5], be=[-3, 3], m=[-2, 2], r=[0, 4], v=[-3, 9])
+VALUES = ["x", "y", "v", "f4", "i", "h", "u1", "be", "m", "r", "vi", "x*2+y", "b"]
+STATS = ["count", "count", "sum", "mean", "mean", "std", "var", "min", "max", "minmax", "count_star"]
+SEL_COLS = ["x", "y", "v", "f4", "i", "h", "u1", "b"]
+def frames(df):
+    return {"plain": df, "filtered": df[df.x > -0.5], "filtered_libm": df[np.sin(df.y * 3) > -0.5], "sliced": df[3000:110_000], "both": df[df.v < 5][1000:90_000]}
+def draw(seed):
+    r = np.random.default_rng(5000 + seed)
+    c = dict(frame=str(r.choice(["plain", "plain", "filtered", "filtered_libm", "sliced", "both"])), stat=str(r.choice(STATS)), value=str(r.choice(VALUES)))
+    nd = int(r.choice([0, 1, 1, 2, 2, 3]))
+    c["binby"] = [str(b) for b in r.choice(list(LIMITS), size=nd, replace=False)]
+    c["shape"] = [int(r.integers(1, 70 if nd < 3 else 20)) for _ in range(nd)]
+    c["limits"] = "minmax" if (nd and r.random() < 0.12 and not set(c["binby"]) & {"m"}) else [LIMITS[b] for b in c["binby"]]
+    s = r.random()
+    def sel():
+        for t in range(20):
+            e = random_expression(np.random.default_rng(int(r.integers(1 << 30))), SEL_COLS, ["x", "y", "v"])
+            if len(e) < 160:
+                return e
+        return "x > 0"
+    c["selection"] = None if s < 0.4 else (sel() if s < 0.75 else ([None, sel()] if s < 0.87 else "named"))
+    c["named"] = sel() if c["selection"] == "named" else None
+    c["delayed"] = bool(r.random() < 0.25)
+    if c["stat"] in ("min", "max", "minmax") and c["value"] == "b":
+        c["value"] = "u1"
+    if c["stat"] == "minmax":
+        c["binby"], c["shape"], c["limits"] = [], [], []
+    return c
+def call(d, c, delay=False):
+    kw = {}
+    if c["binby"]:
+        kw.update(binby=c["binby"], limits=c["limits"], shape=c["shape"])
+    sel = c["selection"]
+    if sel == "named":
+        d.select(c["named"], name="fuzz")
+        sel = "fuzz"
+    if sel is not None:
+        kw["selection"] = sel
+    if delay:
+        kw["delay"] = True
+    if c["stat"] == "count_star":
+        return d.count(**kw)
+    return getattr(d, c["stat"])(c["value"], **kw)
+def run_all(tag):
+    df = make()
+    fr = frames(df)
+    out, pending = {}, []
+    def flush():
+        if pending:
+            try:
+                fr["plain"].execute()
+            except Exception as e:
+                pass
+            for i, p in pending:
+                try:
+                    out[i] = p.get()
+                except Exception as e:
+                    out[i] = ("EXC", type(e).__name__, str(e)[:160])
+            del pending[:]
+    for i in range(ncalls):
+        c = draw(i)
+        d = fr[c["frame"]]
+        try:
+            if c["delayed"]:
+                pending.append((i, call(d, c, delay=True)))
+                if len(pending) >= 3:
+                    flush()
+            else:
+                flush()
+                out[i] = call(d, c)
+        except Exception as e:
+            flush()
+            out[i] = ("EXC", type(e).__name__, str(e)[:160])
+    flush()
+    return out
+def flat(v):
+    if isinstance(v, tuple) and v and v[0] == "EXC":
+        return [("EXC", v[1])]
+    if isinstance(v, (list, tuple)):
+        r = []
+        for p in v:
+            r += flat(p)
+        return r
+    a = np.ma.asarray(v)
+    return [np.ma.filled(a.astype("f8"), np.nan)]
+if gpu:
+    import vaex_amd
+    from vaex_amd import vaex_selection as vsel, vaex_filter as vflt
+    assert vaex_amd.superagg.device_count() > 0
+    vaex_amd.install()
+first = run_all("hip" if gpu else "cpu-1")
+if gpu:
+    print("task parts on the HIP classes:", vaex_amd.task_stats["hip"], "on vaex's C++:", vaex_amd.task_stats["cpu"], vaex_amd.task_stats["cpu_reasons"])
+    print("selections as device predicates (chunks):", vsel.stats["device_chunks"], "host masks:", vsel.stats["host_chunks"], "| filtered runs in the keep-mask form:", vflt.stats["runs_switched"], "left pre-filtered:", vflt.stats["runs_mixed"])
+    assert vaex_amd.task_stats["hip"] > 10 * max(1, vaex_amd.task_stats["cpu"]) and vsel.stats["device_chunks"] > 20
+    vaex_amd.uninstall()
+second = run_all("cpu")
+bad, excs = [], 0
+for i in range(ncalls):
+    c = draw(i)
+    a, b = flat(first[i]), flat(second[i])
+    if len(a) != len(b):
+        bad.append((i, c, "different structure")); continue
+    for p, q in zip(a, b):
+        if isinstance(p, tuple) or isinstance(q, tuple):
+            excs += 1
+            if p != q:
+                bad.append((i, c, "exception on one side only / another exception", first[i] if isinstance(p, tuple) else "result", second[i] if isinstance(q, tuple) else "result"))
+            continue
+        if p.shape != q.shape:
+            bad.append((i, c, "shape", p.shape, q.shape)); continue
+        if not np.array_equal(np.isnan(p), np.isnan(q)):
+            bad.append((i, c, "NaN pattern", int((np.isnan(p) != np.isnan(q)).sum()))); continue
+        if c["stat"] in ("std", "var"):
+            ok = np.allclose(p, q, rtol=1e-7, atol=1e-9, equal_nan=True)
+        elif c["stat"] in ("count", "count_star", "min", "max", "minmax"):
+            ok = np.array_equal(p, q, equal_nan=True)
+        else:
+            fin = np.abs(q[np.isfinite(q)])
+            scale = max(float(fin.max()) if fin.size else 0.0, 1.0) * (n if c["stat"] == "sum" and False else 1.0)
+            ok = np.allclose(p, q, rtol=1e-11, atol=1e-11 * scale, equal_nan=True)
+        if not ok:
+            with np.errstate(invalid="ignore"):
+                bad.append((i, c, "values", float(np.nanmax(np.abs(p - q)))))
+print("calls", ncalls, "of which raised on both sides alike:", excs, "different:", len(bad))
+for bline in bad[:12]:
+    print("BAD", bline)
+assert not bad
+print("DONE")
+'''
+
+
+def _run(gpu, ncalls, timeout):
+    env = dict(os.environ, VAEX_NUM_THREADS=os.environ.get("VAEX_NUM_THREADS", "4"))
+    out = subprocess.run([sys.executable, "-c", SCRIPT % dict(pkg=PKG, fake=FAKE, root=ROOT, gpu=gpu, ncalls=ncalls)], cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout)
+    assert out.returncode == 0 and "DONE" in out.stdout, out.stdout[-5000:] + out.stderr[-5000:]
+    report = os.environ.get("VAEX_AMD_REPORT_DIR")
+    if report and gpu:
+        with open(os.path.join(report, "random_calls_report.txt"), "w") as f:
+            f.write("\n".join(line for line in out.stdout.splitlines() if not line.startswith("BAD")))
+    return out.stdout
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(PKG, "vaex")), reason="real vaex package not built (oracle/build_ref.sh needs /root/reference)")
+def test_the_random_calls_are_deterministic_on_the_reference_alone():
+    _run(0, 80, 900)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.isdir(os.path.join(PKG, "vaex")), reason="real vaex package not built (oracle/build_ref.sh needs /root/reference)")
+def test_random_calls_agree_with_the_reference():
+    _run(1, 220, 1500)
