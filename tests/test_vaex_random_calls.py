@@ -113,7 +113,7 @@ def run_all(tag):
     return out
 def flat(v):
     if isinstance(v, tuple) and v and v[0] == "EXC":
-        return [("EXC", v[1])]
+        return [("EXC", v[1], v[2])]
     if isinstance(v, (list, tuple)):
         r = []
         for p in v:
@@ -131,9 +131,22 @@ if gpu:
     print("task parts on the HIP classes:", vaex_amd.task_stats["hip"], "on vaex's C++:", vaex_amd.task_stats["cpu"], vaex_amd.task_stats["cpu_reasons"])
     print("selections as device predicates (chunks):", vsel.stats["device_chunks"], "host masks:", vsel.stats["host_chunks"], "| filtered runs in the keep-mask form:", vflt.stats["runs_switched"], "left pre-filtered:", vflt.stats["runs_mixed"])
     assert vaex_amd.task_stats["hip"] > 10 * max(1, vaex_amd.task_stats["cpu"]) and vsel.stats["device_chunks"] > 20
+    # what the HIP entry answers where the reference raises (KNOWN_DEFECT below): the extrema of the rows the selection keeps
+    dfp = make()
+    keep = (dfp.x.to_numpy() > 2.5) & (dfp.y.to_numpy() > 2.5)          # a handful of rows: most chunks have none
+    assert 0 < keep.sum() < 40, keep.sum()
+    got = dfp.minmax("v", selection="(x > 2.5) & (y > 2.5)")
+    vs = dfp.v.to_numpy()[keep]
+    assert np.array_equal(np.asarray(got), np.array([np.nanmin(vs), np.nanmax(vs)])), (got, vs)
+    print("minmax(v, selection keeping", int(keep.sum()), "rows) under install():", np.asarray(got), "| of a selection keeping none:", np.asarray(dfp.minmax("v", selection="x > 100")))
     vaex_amd.uninstall()
 second = run_all("cpu")
-bad, excs = [], 0
+# A defect of the reference this test keeps finding: its legacy statistic task (df.minmax, limits="minmax": vaex/cpu.py:488-623) hands
+# vaexfast.statisticNd the selected rows of every chunk, and a chunk in which the selection keeps NO row is an empty array whose stride the C
+# wrapper refuses (src/vaexfast.cpp:160-195) — `df.minmax("y", selection="x == 4")` raises ValueError in plain vaex.  The HIP entry takes the
+# empty chunk for what it is.  Such calls are counted, not compared.
+KNOWN_DEFECT = "object_to_numpy1d_nocopy_endian: stride is not equal to 1"
+bad, excs, known = [], 0, 0
 for i in range(ncalls):
     c = draw(i)
     a, b = flat(first[i]), flat(second[i])
@@ -142,7 +155,10 @@ for i in range(ncalls):
     for p, q in zip(a, b):
         if isinstance(p, tuple) or isinstance(q, tuple):
             excs += 1
-            if not (isinstance(p, tuple) and isinstance(q, tuple) and p == q):
+            if isinstance(q, tuple) and not isinstance(p, tuple) and KNOWN_DEFECT in q[2]:
+                known += 1      # (the reference raises, the HIP entry answers: see KNOWN_DEFECT)
+                continue
+            if not (isinstance(p, tuple) and isinstance(q, tuple) and p[:2] == q[:2]):
                 bad.append((i, c, "exception on one side only / another exception", first[i] if isinstance(p, tuple) else "result", second[i] if isinstance(q, tuple) else "result"))
             continue
         if p.shape != q.shape:
@@ -160,7 +176,7 @@ for i in range(ncalls):
         if not ok:
             with np.errstate(invalid="ignore"):
                 bad.append((i, c, "values", float(np.nanmax(np.abs(p - q)))))
-print("calls", ncalls, "of which raised on both sides alike:", excs, "different:", len(bad))
+print("calls", ncalls, "of which raised on both sides alike:", excs - known, "| the reference raised on an empty selected chunk, the HIP entry answered:", known, "| different:", len(bad))
 for bline in bad[:12]:
     print("BAD", bline)
 assert not bad
