@@ -1,4 +1,4 @@
-"""Randomised differential test through the REAL vaex API (the fixed list of calls is tests/test_vaex_differential.py): 220 calls drawn from
+"""Randomised differential test through the REAL vaex API (the fixed list of calls is tests/test_vaex_differential.py): 1200 calls drawn from
 a grammar — statistic x expression (plain / float32 / integer / bool / big-endian / masked / virtual / arithmetic) x 0-3 binby dimensions
 (float, integer, virtual, big-endian, masked columns; fixed or data-derived limits; random shapes) x selection (none / a random expression of
 the predicate grammar / a list / a named selection) x frame (plain / filtered inside and outside the device-predicate subset / sliced /
@@ -203,4 +203,4 @@ def test_the_random_calls_are_deterministic_on_the_reference_alone():
 @pytest.mark.gpu
 @pytest.mark.skipif(not os.path.isdir(os.path.join(PKG, "vaex")), reason="real vaex package not built (oracle/build_ref.sh needs /root/reference)")
 def test_random_calls_agree_with_the_reference():
-    _run(1, 220, 1500)
+    _run(1, 1200, 1500)
