@@ -155,7 +155,7 @@ for i in range(ncalls):
     for p, q in zip(a, b):
         if isinstance(p, tuple) or isinstance(q, tuple):
             excs += 1
-            if isinstance(q, tuple) and not isinstance(p, tuple) and KNOWN_DEFECT in q[2]:
+            if isinstance(q, tuple) and KNOWN_DEFECT in q[2]:   # (whatever the HIP side then ran into further on)
                 known += 1      # (the reference raises, the HIP entry answers: see KNOWN_DEFECT)
                 continue
             if not (isinstance(p, tuple) and isinstance(q, tuple) and p[:2] == q[:2]):
@@ -163,6 +163,15 @@ for i in range(ncalls):
             continue
         if p.shape != q.shape:
             bad.append((i, c, "shape", p.shape, q.shape)); continue
+        if c["stat"] in ("std", "var"):
+            # a cell with ONE row (or equal rows) has variance 0 +- an ulp of x^2: the reference sums pow(x, 2) (glibc: within an ulp of x * x, not
+            # always equal to it — src/agg_sum.cpp:159) and subtracts numpy's mean * mean, so its variance of such a cell is now and then
+            # -1e-17 and its std NaN, where x * x on the device gives 0 exactly.  Noise-level values count as equal to a NaN of that origin.
+            noise = np.isnan(p) != np.isnan(q)
+            tiny = 1e-7 if c["stat"] == "std" else 1e-14
+            if not np.all(np.abs(np.where(np.isnan(p), q, p)[noise]) <= tiny * max(1.0, float(np.nanmax(np.abs(q))) if np.isfinite(q).any() else 1.0)):
+                bad.append((i, c, "NaN pattern beyond rounding noise", int(noise.sum()))); continue
+            p, q = np.where(noise, 0.0, p), np.where(noise, 0.0, q)
         if not np.array_equal(np.isnan(p), np.isnan(q)):
             bad.append((i, c, "NaN pattern", int((np.isnan(p) != np.isnan(q)).sum()))); continue
         if c["stat"] in ("std", "var"):
