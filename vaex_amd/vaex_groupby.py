@@ -549,6 +549,8 @@ def install(vaex_module, state):
         def get_result(self):
             _PLANS.pop(self.token, None)
             try:
+                if self.collector.rows == 0:
+                    raise _Decline("delayed groupby: the filter left no row")   # (vaex's own answer: no group, its own column types)
                 frame = self.collector.frame()
                 res = _run(self.plan, frame)
                 result = _finish(self.df, self.plan, frame, res)
