@@ -24,7 +24,8 @@ import vaex
 from tests.predicate_fuzz import random_expression
 gpu = %(gpu)d
 ncalls = %(ncalls)d
-n = 120_000
+big = %(big)d     # 1: millions of rows and grids beyond one workgroup's LDS — the partition passes, the hot box, the selections evaluated inside them
+n = 4_000_000 if big else 120_000
 def make():
     r = np.random.default_rng(21)
     x = r.normal(0, 1, n); x[::997] = np.nan
@@ -41,13 +42,15 @@ VALUES = ["x", "y", "v", "f4", "i", "h", "u1", "be", "m", "r", "vi", "x*2+y", "b
 STATS = ["count", "count", "sum", "mean", "mean", "std", "var", "min", "max", "minmax", "count_star"]
 SEL_COLS = ["x", "y", "v", "f4", "i", "h", "u1", "b"]
 def frames(df):
-    return {"plain": df, "filtered": df[df.x > -0.5], "filtered_libm": df[np.sin(df.y * 3) > -0.5], "sliced": df[3000:110_000], "both": df[df.v < 5][1000:90_000]}
+    return {"plain": df, "filtered": df[df.x > -0.5], "filtered_libm": df[np.sin(df.y * 3) > -0.5], "sliced": df[3000:n - 10_000], "both": df[df.v < 5][1000:n - 30_000]}
 def draw(seed):
     r = np.random.default_rng(5000 + seed)
     c = dict(frame=str(r.choice(["plain", "plain", "filtered", "filtered_libm", "sliced", "both"])), stat=str(r.choice(STATS)), value=str(r.choice(VALUES)))
     nd = int(r.choice([0, 1, 1, 2, 2, 3]))
     c["binby"] = [str(b) for b in r.choice(list(LIMITS), size=nd, replace=False)]
     c["shape"] = [int(r.integers(1, 70 if nd < 3 else 20)) for _ in range(nd)]
+    if big and nd:
+        c["shape"] = [int(r.choice([128, 256, 300, 512])) for _ in range(nd)] if nd < 3 else [int(r.choice([48, 64, 128])) for _ in range(nd)]
     c["limits"] = "minmax" if (nd and r.random() < 0.12 and not set(c["binby"]) & {"m"}) else [LIMITS[b] for b in c["binby"]]
     s = r.random()
     def sel():
@@ -134,7 +137,7 @@ if gpu:
     # what the HIP entry answers where the reference raises (KNOWN_DEFECT below): the extrema of the rows the selection keeps
     dfp = make()
     keep = (dfp.x.to_numpy() > 2.5) & (dfp.y.to_numpy() > 2.5)          # a handful of rows: most chunks have none
-    assert 0 < keep.sum() < 40, keep.sum()
+    assert 0 < keep.sum() < 1500, keep.sum()
     got = dfp.minmax("v", selection="(x > 2.5) & (y > 2.5)")
     vs = dfp.v.to_numpy()[keep]
     assert np.array_equal(np.asarray(got), np.array([np.nanmin(vs), np.nanmax(vs)])), (got, vs)
@@ -193,13 +196,13 @@ print("DONE")
 '''
 
 
-def _run(gpu, ncalls, timeout):
+def _run(gpu, ncalls, timeout, big=0):
     env = dict(os.environ, VAEX_NUM_THREADS=os.environ.get("VAEX_NUM_THREADS", "4"))
-    out = subprocess.run([sys.executable, "-c", SCRIPT % dict(pkg=PKG, fake=FAKE, root=ROOT, gpu=gpu, ncalls=ncalls)], cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout)
+    out = subprocess.run([sys.executable, "-c", SCRIPT % dict(pkg=PKG, fake=FAKE, root=ROOT, gpu=gpu, ncalls=ncalls, big=big)], cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout)
     assert out.returncode == 0 and "DONE" in out.stdout, out.stdout[-5000:] + out.stderr[-5000:]
     report = os.environ.get("VAEX_AMD_REPORT_DIR")
     if report and gpu:
-        with open(os.path.join(report, "random_calls_report.txt"), "w") as f:
+        with open(os.path.join(report, "random_calls_big_report.txt" if big else "random_calls_report.txt"), "w") as f:
             f.write("\n".join(line for line in out.stdout.splitlines() if not line.startswith("BAD")))
     return out.stdout
 
@@ -213,3 +216,9 @@ def test_the_random_calls_are_deterministic_on_the_reference_alone():
 @pytest.mark.skipif(not os.path.isdir(os.path.join(PKG, "vaex")), reason="real vaex package not built (oracle/build_ref.sh needs /root/reference)")
 def test_random_calls_agree_with_the_reference():
     _run(1, 1200, 1500)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.isdir(os.path.join(PKG, "vaex")), reason="real vaex package not built (oracle/build_ref.sh needs /root/reference)")
+def test_random_calls_on_millions_of_rows_and_large_grids_agree_with_the_reference():
+    _run(1, 90, 2400, big=1)
