@@ -1,5 +1,7 @@
 """-m gpu: seeded random cases over the signature space of the partition / LDS kernels (dims, shapes, value columns,
 masks, NaNs, ragged row counts, strategies, second-generation pass 1 on/off, forced hot boxes) against the oracle."""
+import os
+
 import numpy as np
 import pytest
 
@@ -17,7 +19,8 @@ def _reset(sa):
         sa.config_set(k, {"blk": 1, "hot": 1, "count16": 1, "wv": WV_DEFAULT, "wv_waves": 8, "wv_waves_direct": 16, "wv_phase": 12}.get(k, 0))
 
 
-@pytest.mark.parametrize("seed", range(160))
+#: 160 seeds in the suite; a soak run sets VAEX_AMD_FUZZ_SEEDS (profiles/r05_fuzz_soak.txt: 3000 seeds)
+@pytest.mark.parametrize("seed", range(int(os.environ.get("VAEX_AMD_FUZZ_SEEDS", "160"))))
 def test_fuzz_against_oracle(sa, gpu_ready, seed):
     rng = np.random.default_rng(1000 + seed)
     ndim = int(rng.integers(1, 4))
