@@ -1064,6 +1064,9 @@ static void hot_prepare(Slot &slot, const BinArgs &A, const BinArgs &planned, co
     //  the two were within 2 % of each other, box by box.  Round 5's phased form is 5-7 % ahead of the grouped one and ~10 % ahead of
     //  the ring-less one on every box measured — profiles/r05_headline_ab.txt — so the trial and its knobs are gone.)
     H.wv_mode = c.cfg_wv;
+    // (packed uint16 counters in pass 2's slabs — the "count16" = 2 test knob — are part_reduce's, not part_reduce_grp's: such a call takes the
+    //  ring-less pass 1 and the block queues next to its box; found by the fuzz's soak run, seed 623)
+    if (planned.count16 && (H.wv_mode == 5 || H.wv_mode == 6)) H.wv_mode = 3;
     const WvGeom wg = wv_geometry(S, nval, true, plan.vals_i32 || plan.vals_f32 || f32b || f32all, H.wv_mode);
     bool wv = wg.ok && slab_cells < 65535 && wv_aligned(A); // (= run_part_chunk's conditions for part_scatter_wv)
     if (f32all && wg.direct != 1) wv = false;
