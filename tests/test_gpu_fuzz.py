@@ -19,8 +19,8 @@ def _reset(sa):
         sa.config_set(k, {"blk": 1, "hot": 1, "count16": 1, "wv": WV_DEFAULT, "wv_waves": 8, "wv_waves_direct": 16, "wv_phase": 12}.get(k, 0))
 
 
-#: 160 seeds in the suite; a soak run sets VAEX_AMD_FUZZ_SEEDS (profiles/r05_fuzz_soak.txt: 3000 seeds)
-@pytest.mark.parametrize("seed", range(int(os.environ.get("VAEX_AMD_FUZZ_SEEDS", "160"))))
+#: 400 seeds in the suite (160 until round 5); a soak run sets VAEX_AMD_FUZZ_SEEDS (profiles/r05_fuzz_soak.txt: 3000 seeds)
+@pytest.mark.parametrize("seed", range(int(os.environ.get("VAEX_AMD_FUZZ_SEEDS", "400"))))
 def test_fuzz_against_oracle(sa, gpu_ready, seed):
     rng = np.random.default_rng(1000 + seed)
     ndim = int(rng.integers(1, 4))

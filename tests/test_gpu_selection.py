@@ -297,3 +297,75 @@ def test_random_predicates_keep_the_rows_numpy_keeps():
         assert np.array_equal(got, want), expr
         assert int(got.sum()) == int(keep.sum()), expr
     assert inside > 150, inside
+
+
+KNOBS = ("strategy", "wv", "hot_min_rows", "hot_min_pct", "convert_binners", "count_box_pct", "part_chunk")
+
+
+@pytest.mark.parametrize("block", range(6))
+def test_random_calls_with_predicates_over_every_column_kind_and_kernel_form(block):
+    """the same differential fuzz over what round 5 added to the kernels: 1-3 binner columns of any kind (float64 / float32 / int32 / int16 /
+    uint8 — converted on load or by the pre-pass), count / sum / mean / min of a float64 or float32 column, up to 1.2e6 rows with the
+    thresholds pulled down so that the partition passes, the hot box (grouped, phased and ring-less forms) and the conversion pre-pass all run —
+    each call once with its random selection as a device predicate (inside the binning kernels where the shape allows) and once with numpy's
+    keep-mask of the same expression"""
+    import vaex_amd
+    from tests.predicate_fuzz import random_expression
+    sa = vaex_amd.superagg
+    defaults = {k: sa.config_get(k) for k in KNOBS}
+    limits = dict(x=[-4, 4], y=[-4, 4], v=[-3, 9], f=[-3, 3], j=[-100, 100], h=[-100, 100], c=[0, 256])
+    frames = {}
+    try:
+        for seed in range(block * 14, block * 14 + 14):
+            rng = np.random.default_rng(7000 + seed)
+            n = int(rng.choice([5_000, 150_001, 1_200_003]))
+            if n not in frames:
+                cols = _columns(n, 11)
+                cols["v"][::333] = np.nan
+                frames[n] = (cols, Frame(cols, chunk_size=1 << 22, nthreads=2))
+            cols, f = frames[n]
+            nd = int(rng.choice([1, 2, 2, 3]))
+            binby = [str(b) for b in rng.choice(list(limits), size=nd, replace=False)]
+            shape = int(rng.choice([16, 64, 300, 700])) if nd < 3 else int(rng.choice([16, 64, 128]))
+            expr = None
+            for t in range(30):
+                e = random_expression(np.random.default_rng(int(rng.integers(1 << 30))), [k for k in cols if k != "U"], ["x", "y", "v"])
+                try:
+                    keep = _want_mask(e, cols)
+                    expr = e
+                    break
+                except P.Unsupported:
+                    continue
+            assert expr is not None
+            sa.config_set("strategy", int(rng.choice([0, 0, 4])))
+            sa.config_set("wv", int(rng.choice([6, 6, 5, 3, 0])))
+            if rng.random() < 0.6:
+                sa.config_set("hot_min_rows", 1)
+                sa.config_set("hot_min_pct", 5)
+            if rng.random() < 0.5:
+                sa.config_set("convert_binners", 1000)
+            if rng.random() < 0.3:
+                sa.config_set("count_box_pct", 0)
+            if rng.random() < 0.3:
+                sa.config_set("part_chunk", 1 << 20)
+            stat = str(rng.choice(["count", "count", "sum", "mean", "min", "sumf"]))
+            kw = dict(binby=binby, limits=[limits[b] for b in binby], shape=shape, edges=True)
+            if stat == "count":
+                got, want = f.count(selection=expr, **kw), f.count(selection=keep, **kw)
+            elif stat == "sumf":
+                got, want = f.sum("f", selection=expr, **kw), f.sum("f", selection=keep, **kw)
+            else:
+                got, want = getattr(f, stat)("v", selection=expr, **kw), getattr(f, stat)("v", selection=keep, **kw)
+            what = (seed, n, binby, shape, stat, expr, {k: sa.config_get(k) for k in KNOBS})
+            if stat in ("count", "min"):
+                assert np.array_equal(got, want, equal_nan=True), what
+            else:
+                fin = np.abs(want[np.isfinite(want)])
+                assert np.allclose(got, want, rtol=1e-12, atol=1e-12 * max(1.0, float(fin.max()) if fin.size else 1.0), equal_nan=True), what
+            if stat == "count":
+                assert int(got.sum()) == int(keep.sum()), what
+            for k, val in defaults.items():
+                sa.config_set(k, val)
+    finally:
+        for k, val in defaults.items():
+            sa.config_set(k, val)
