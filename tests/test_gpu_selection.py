@@ -302,7 +302,7 @@ def test_random_predicates_keep_the_rows_numpy_keeps():
 KNOBS = ("strategy", "wv", "hot_min_rows", "hot_min_pct", "convert_binners", "count_box_pct", "part_chunk")
 
 
-@pytest.mark.parametrize("block", range(6))
+@pytest.mark.parametrize("block", range(int(__import__("os").environ.get("VAEX_AMD_FUZZ_BLOCKS", "6"))))   # (14 calls a block; a soak run raises it)
 def test_random_calls_with_predicates_over_every_column_kind_and_kernel_form(block):
     """the same differential fuzz over what round 5 added to the kernels: 1-3 binner columns of any kind (float64 / float32 / int32 / int16 /
     uint8 — converted on load or by the pre-pass), count / sum / mean / min of a float64 or float32 column, up to 1.2e6 rows with the
