@@ -98,7 +98,11 @@ for seed in range(ncalls):
     data = {f"k{j}": key_column(rng, n, kinds[j], styles[j]) for j in range(nkeys)}
     v = rng.normal(0, 3, n)
     if rng.random() < 0.5: v[rng.random(n) < 0.2] = np.nan
-    data.update(v=v, vi=rng.integers(-1000, 1000, n).astype(str(rng.choice(["i1", "i2", "i4", "i8", "u1", "u2", "u4"]))), vf=rng.normal(0, 1, n).astype("f4"))
+    vdt = str(rng.choice(["i1", "i2", "i4", "i8", "u1", "u2", "u4"]))
+    # (values that fit the type: a negative number wrapped into uint32 is ~4e9, its variance a difference of two ~2e19 moments — rounding noise on
+    #  either side, not a result to compare)
+    vi = rng.integers(0, 200, n) if vdt.startswith("u") else rng.integers(-100 if vdt == "i1" else -1000, 100 if vdt == "i1" else 1000, n)
+    data.update(v=v, vi=vi.astype(vdt), vf=rng.normal(0, 1, n).astype("f4"))
     df = vaex.from_arrays(**data)
     aggs = {"c": A.count(), "cv": A.count("v"), "s": A.sum("v"), "m": A.mean("v"), "sd": A.std("v"), "va": A.var("vi"), "lo": A.min("v"), "hi": A.max("vi"),
             "si": A.sum("vi"), "mf": A.mean("vf"), "sf": A.sum("vf"), "lof": A.min("vf"), "cs": A.count(selection="v > 0"), "ms": A.mean("vi", selection="vf < 0")}

@@ -179,8 +179,8 @@ def _key_column_like_vaex(values, source_kind=None):
         return np.ma.array(k.astype(bool), mask=np.zeros(len(k), dtype=bool), shrink=False)
     if source_kind in ("int8", "uint8"):
         return np.ma.array(k.astype(np.int64), mask=np.zeros(len(k), dtype=bool), shrink=False)
-    if len(k) == 0:
-        return k
+    if len(k) == 0:   # (no group: vaex hands back an empty column of the key's own type)
+        return k.astype(source_kind) if source_kind else k
     vmin, vmax = int(k.min()), int(k.max())
     distinct = len(k) if np.all(k[1:] > k[:-1]) or np.all(k[1:] < k[:-1]) else len(np.unique(k))
     if vmax - vmin + 1 <= distinct * 4 / 3:
