@@ -17,6 +17,10 @@
  *     available from vxh_last_error() on the calling thread.
  *   - `thread` is the reference's per-thread slot index (agg_base.hpp:97-98): distinct slots
  *     may be driven concurrently from different host threads; each slot owns a HIP stream.
+ *     ONE host thread at a time per slot.  Slots 0 .. VXH_AUX_SLOT - 1 are the indices of the host's
+ *     worker pool (vaex: the executor's thread_index); VXH_AUX_SLOT .. VXH_AUX_SLOT + 7 are auxiliary
+ *     slots for callers that run NEXT to that pool (the legacy statisticNd entry, called from pool
+ *     threads in the same pass as aggregation task parts, serialises itself on the first of them).
  *   - Data pointers are BORROWED for the duration of vxh_grid_bin (src/agg_base.hpp:166-179:
  *     raw pointer, no incref).  `mem` says where the pointer lives:
  *       VXH_MEM_HOST   - host memory (numpy chunk).  vxh_grid_bin stages it through pinned
@@ -38,6 +42,7 @@
 extern "C" {
 #endif
 
+#define VXH_AUX_SLOT 256 /* first auxiliary thread slot (see `thread` above) */
 #define VXH_ABI_VERSION 1
 
 /* element types, in the order of src/create_alltypes.hpp; names as src/utils.hpp:32-90 */

@@ -142,7 +142,21 @@ if gpu:
     vs = dfp.v.to_numpy()[keep]
     assert np.array_equal(np.asarray(got), np.array([np.nanmin(vs), np.nanmax(vs)])), (got, vs)
     print("minmax(v, selection keeping", int(keep.sum()), "rows) under install():", np.asarray(got), "| of a selection keeping none:", np.asarray(dfp.minmax("v", selection="x > 100")))
+    # a delayed minmax (the legacy statistic task: vaexfast.statisticNd from the pool's threads) in the SAME pass as a binned aggregation: the
+    # two must not share a thread slot of the library (round 5: the legacy entry moved to an auxiliary slot; before, one of the two results
+    # was corrupted in ~1 %% of such passes — this test's soak run)
+    mixed = []
+    for rep in range(250):
+        a = dfp.count(binby="x", limits=[-3, 3], shape=32, delay=True)
+        b = dfp.minmax("v", delay=True)
+        c3 = dfp.sum("y", binby=["x", "z"], limits=[[-3, 3], [-5, 5]], shape=[9, 7], delay=True)
+        dfp.execute()
+        mixed.append((np.asarray(a.get()), np.asarray(b.get()), np.asarray(c3.get())))
     vaex_amd.uninstall()
+    a, b, c3 = dfp.count(binby="x", limits=[-3, 3], shape=32), dfp.minmax("v"), dfp.sum("y", binby=["x", "z"], limits=[[-3, 3], [-5, 5]], shape=[9, 7])
+    wrong = [rep for rep, (pa, pb, pc) in enumerate(mixed) if not (np.array_equal(pa, a) and np.array_equal(pb, b) and np.allclose(pc, c3, rtol=1e-12, atol=1e-9))]
+    assert not wrong, ("a delayed minmax and binned aggregations in one pass", wrong[:10], len(wrong))
+    print("250 passes holding a delayed minmax next to two binned aggregations: all equal to the reference")
 second = run_all("cpu")
 # A defect of the reference this test keeps finding: its legacy statistic task (df.minmax, limits="minmax": vaex/cpu.py:488-623) hands
 # vaexfast.statisticNd the selected rows of every chunk, and a chunk in which the selection keeps NO row is an empty array whose stride the C

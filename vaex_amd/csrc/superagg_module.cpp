@@ -753,6 +753,7 @@ PYBIND11_MODULE(superagg, m) {
     m.doc() = "MI355X (HIP) implementation of the vaex.superagg class surface: binned statistics / groupby aggregation";
     m.attr("__hip__") = true;
     m.def("abi_version", &vxh_abi_version);
+    m.attr("AUX_SLOT") = (int)VXH_AUX_SLOT; // first thread slot outside the host pool's indices (include/vaex_hip.h)
     m.def("device_count", []() { int n = 0; check(vxh_device_count(&n)); return n; });
     m.def("set_device", [](int d) { check(vxh_set_device(d)); });
     m.def("synchronize", []() { py::gil_scoped_release r; check(vxh_synchronize()); });

@@ -8,7 +8,7 @@
 
 #include "vxh_kernels.hpp"
 
-#define VXH_MAX_SLOTS 256
+#define VXH_MAX_SLOTS (VXH_AUX_SLOT + 8) // 0 .. VXH_AUX_SLOT - 1: the host pool's thread indices; the rest: auxiliary slots (include/vaex_hip.h)
 #define VXH_STAGE_RING 3
 
 void vxh_hip_check(hipError_t e, const char *what, const char *file, int line);

@@ -69,6 +69,16 @@ def _postfix(a):
     return ("float64" if a.dtype.itemsize == 8 else "float32") + ("" if a.dtype.isnative else "_non_native")
 
 
+#: The thread slot every call of this module bins on.  vaex calls statisticNd from its pool threads DURING a pass (TaskPartStatistic.process,
+#: vaex/cpu.py:600-611) — possibly the same pass in which the aggregation task parts of other delayed calls bin on the pool's own slots
+#: 0 .. nthreads-1 (df.minmax(delay=True) next to df.count(binby=..., delay=True)).  A slot must only be driven by one host thread at a time
+#: (include/vaex_hip.h), so this entry stays off the pool's slots: it serialises itself (_LOCK) on the first of the library's auxiliary slots.
+#: (Until round 5 it used slot 0: a delayed minmax in the same pass as a binned aggregation corrupted one of the two now and then — found by
+#: tests/test_vaex_random_calls.py's soak run, 7 of 8000 calls.)
+_SLOT = int(_sa.AUX_SLOT)
+_T = _SLOT + 1
+
+
 def statisticNd_f8(blocks, weights, grid, minima, maxima, op_code, use_edges=0):
     """Accumulates one chunk into `grid` (in place); returns None like the reference."""
     with _LOCK:
@@ -132,10 +142,10 @@ def _statistic_nd(blocks, weights, grid, minima, maxima, op_code, use_edges, siz
     binners = []
     for d, b in enumerate(blocks):
         bins = sizes[d] - 3 if use_edges else sizes[d]
-        binner = getattr(_sa, "BinnerScalar_" + _postfix(b))(1, f"block{d}", float(minima[d]), float(maxima[d]), int(bins))
+        binner = getattr(_sa, "BinnerScalar_" + _postfix(b))(_T, f"block{d}", float(minima[d]), float(maxima[d]), int(bins))
         if size == 4:
             binner.set_float32_scaling(2 if (nd == 2 and not use_edges) else 1)
-        binner.set_data(0, b)
+        binner.set_data(_SLOT, b)
         binners.append(binner)
     g = _sa.Grid(binners)
     inner = tuple(slice(None) if use_edges else slice(2, -1) for _ in range(nd))
@@ -150,11 +160,11 @@ def _statistic_nd(blocks, weights, grid, minima, maxima, op_code, use_edges, siz
             wbits = torch.as_tensor(w).view(torch.int64 if size == 8 else torch.int32)
         else:
             wbits = w.view(w.dtype.byteorder.replace("=", "<").replace("|", "<") + f"i{size}") if not w.dtype.isnative else w.view(f"i{size}")
-        a = getattr(_sa, ("AggFirst_int64_" if size == 8 else "AggFirst_int32_") + _postfix(order))(g, 1, 1, False)
-        a.set_data(0, wbits, 0)
-        a.set_data(0, order, 1)
+        a = getattr(_sa, ("AggFirst_int64_" if size == 8 else "AggFirst_int32_") + _postfix(order))(g, 1, _T, False)
+        a.set_data(_SLOT, wbits, 0)
+        a.set_data(_SLOT, order, 1)
         if n:
-            g.bin(0, [a], n)
+            g.bin(_SLOT, [a], n)
         values, masked, orders = (np.asarray(r)[inner] for r in a.raw_result())
         values = values.view(f"f{size}")  # (same item size: fine for the strided and the 0-d result alike)
         take = ~masked & (orders < grid[..., 1])  # src/vaexfast.cpp:1160-1163
@@ -170,23 +180,23 @@ def _statistic_nd(blocks, weights, grid, minima, maxima, op_code, use_edges, siz
         per_col, per_pair = [], {}
         aggs = []
         for w in wlist:
-            trio = [_sa.AggCount_float64(g, 1, 1), _sa.AggSum_float64(g, 1, 1), _sa.AggSumMoment_float64(g, 1, 1, 2)]
+            trio = [_sa.AggCount_float64(g, 1, _T), _sa.AggSum_float64(g, 1, _T), _sa.AggSumMoment_float64(g, 1, _T, 2)]
             for a in trio:
-                a.set_data(0, w, 0)
+                a.set_data(_SLOT, w, 0)
             per_col.append(trio)
             aggs += trio
         keep = []
         for col in range(N):
             for row in range(col + 1, N):
                 prod = _sa.product(wlist[col], wlist[row])
-                duo = [_sa.AggCount_float64(g, 1, 1), _sa.AggSum_float64(g, 1, 1)]
+                duo = [_sa.AggCount_float64(g, 1, _T), _sa.AggSum_float64(g, 1, _T)]
                 for a in duo:
-                    a.set_data(0, prod, 0)
+                    a.set_data(_SLOT, prod, 0)
                 per_pair[(col, row)] = duo
                 aggs += duo
                 keep.append(prod)
         if n:
-            g.bin(0, aggs, n)
+            g.bin(_SLOT, aggs, n)
         res = lambda a: np.asarray(a.get_result())[inner]
         for col in range(N):
             cnt, sm, sq = (res(a) for a in per_col[col])
@@ -204,7 +214,7 @@ def _statistic_nd(blocks, weights, grid, minima, maxima, op_code, use_edges, siz
         return None
     aggs = []
     if op_code == OP_ADD1:
-        aggs.append(_sa.AggCount_int64(g, 1, 1))
+        aggs.append(_sa.AggCount_int64(g, 1, _T))
     else:
         w = wlist[0]
         pf = _postfix(w)
@@ -213,11 +223,11 @@ def _statistic_nd(blocks, weights, grid, minima, maxima, op_code, use_edges, siz
         else:
             kinds = [("AggCount_", None), ("AggSum_", None), ("AggSumMoment_", 2)][:fields]
         for cls, moment in kinds:
-            a = getattr(_sa, cls + pf)(g, 1, 1, moment) if moment is not None else getattr(_sa, cls + pf)(g, 1, 1)
-            a.set_data(0, w, 0)
+            a = getattr(_sa, cls + pf)(g, 1, _T, moment) if moment is not None else getattr(_sa, cls + pf)(g, 1, _T)
+            a.set_data(_SLOT, w, 0)
             aggs.append(a)
     if n:
-        g.bin(0, aggs, n)
+        g.bin(_SLOT, aggs, n)
     for f, a in enumerate(aggs):
         part = np.asarray(a.get_result())[inner]
         if op_code == OP_MIN_MAX:
