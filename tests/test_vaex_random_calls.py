@@ -39,6 +39,7 @@ def make():
     return df
 LIMITS = dict(x=[-3, 3], y=[-3, 3], z=[-5, 5], f4=[-2.5, 2.5], i=[-50.5, 49.5], h=[-100, 100], u1=[0, 256], k=[-0.5, 29.5], be=[-3, 3], m=[-2, 2], r=[0, 4], v=[-3, 9])
 VALUES = ["x", "y", "v", "f4", "i", "h", "u1", "be", "m", "r", "vi", "x*2+y", "b"]
+SCALE = {"x": 5, "y": 5, "v": 12, "f4": 5, "i": 50, "h": 300, "u1": 200, "be": 5, "m": 5, "r": 7, "vi": 600, "x*2+y": 15, "b": 1}   # largest magnitudes of the values
 STATS = ["count", "count", "sum", "mean", "mean", "std", "var", "min", "max", "minmax", "count_star"]
 SEL_COLS = ["x", "y", "v", "f4", "i", "h", "u1", "b"]
 def frames(df):
@@ -185,7 +186,7 @@ for i in range(ncalls):
             # always equal to it — src/agg_sum.cpp:159) and subtracts numpy's mean * mean, so its variance of such a cell is now and then
             # -1e-17 and its std NaN, where x * x on the device gives 0 exactly.  Noise-level values count as equal to a NaN of that origin.
             noise = np.isnan(p) != np.isnan(q)
-            tiny = 1e-7 if c["stat"] == "std" else 1e-14
+            tiny = 1e-7 * SCALE[c["value"]] if c["stat"] == "std" else 1e-13 * SCALE[c["value"]] ** 2
             if not np.all(np.abs(np.where(np.isnan(p), q, p)[noise]) <= tiny * max(1.0, float(np.nanmax(np.abs(q))) if np.isfinite(q).any() else 1.0)):
                 bad.append((i, c, "NaN pattern beyond rounding noise", int(noise.sum()))); continue
             p, q = np.where(noise, 0.0, p), np.where(noise, 0.0, q)
@@ -194,7 +195,8 @@ for i in range(ncalls):
         if c["stat"] in ("std", "var"):
             # (a variance is a difference of two moments of size mean^2: +- 1e-16 x mean^2 of rounding noise, whose square root — up to 1e-7 for the
             #  values of these columns — is what the std of a cell with one row, or equal rows, comes out as on either side)
-            ok = np.allclose(p, q, rtol=1e-7, atol=1e-6 if c["stat"] == "std" else 1e-11, equal_nan=True)
+            mag = SCALE[c["value"]]     # (noise of the variance: ~1e-16 x the second moment; of the std: its square root)
+            ok = np.allclose(p, q, rtol=1e-7, atol=1e-7 * mag if c["stat"] == "std" else 1e-13 * mag * mag, equal_nan=True)
         elif c["stat"] in ("count", "count_star", "min", "max", "minmax"):
             ok = np.array_equal(p, q, equal_nan=True)
         else:
