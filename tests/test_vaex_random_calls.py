@@ -40,7 +40,7 @@ def make():
 LIMITS = dict(x=[-3, 3], y=[-3, 3], z=[-5, 5], f4=[-2.5, 2.5], i=[-50.5, 49.5], h=[-100, 100], u1=[0, 256], k=[-0.5, 29.5], be=[-3, 3], m=[-2, 2], r=[0, 4], v=[-3, 9])
 VALUES = ["x", "y", "v", "f4", "i", "h", "u1", "be", "m", "r", "vi", "x*2+y", "b"]
 SCALE = {"x": 5, "y": 5, "v": 12, "f4": 5, "i": 50, "h": 300, "u1": 200, "be": 5, "m": 5, "r": 7, "vi": 600, "x*2+y": 15, "b": 1}   # largest magnitudes of the values
-STATS = ["count", "count", "sum", "mean", "mean", "std", "var", "min", "max", "minmax", "count_star"]
+STATS = ["count", "count", "sum", "mean", "mean", "std", "var", "min", "max", "minmax", "count_star", "nunique"]   # (nunique: the distinct-key task on the device hash set, also batched with the others)
 SEL_COLS = ["x", "y", "v", "f4", "i", "h", "u1", "b"]
 def frames(df):
     return {"plain": df, "filtered": df[df.x > -0.5], "filtered_libm": df[np.sin(df.y * 3) > -0.5], "sliced": df[3000:n - 10_000], "both": df[df.v < 5][1000:n - 30_000]}
@@ -67,6 +67,11 @@ def draw(seed):
         c["value"] = "u1"
     if c["stat"] == "minmax":
         c["binby"], c["shape"], c["limits"] = [], [], []
+    if c["stat"] == "nunique":
+        c["binby"], c["shape"], c["limits"] = [], [], []
+        c["value"] = str(r.choice(["i", "h", "u1", "k", "f4", "b"]))
+        if isinstance(c["selection"], list):
+            c["selection"] = c["selection"][1]
     return c
 def call(d, c, delay=False):
     kw = {}
@@ -197,7 +202,7 @@ for i in range(ncalls):
             #  values of these columns — is what the std of a cell with one row, or equal rows, comes out as on either side)
             mag = SCALE[c["value"]]     # (noise of the variance: ~1e-16 x the second moment; of the std: its square root)
             ok = np.allclose(p, q, rtol=1e-7, atol=1e-7 * mag if c["stat"] == "std" else 1e-13 * mag * mag, equal_nan=True)
-        elif c["stat"] in ("count", "count_star", "min", "max", "minmax"):
+        elif c["stat"] in ("count", "count_star", "min", "max", "minmax", "nunique"):
             ok = np.array_equal(p, q, equal_nan=True)
         else:
             fin = np.abs(q[np.isfinite(q)])
