@@ -87,6 +87,8 @@ def call(d, c, delay=False):
         kw["delay"] = True
     if c["stat"] == "count_star":
         return d.count(**kw)
+    if c["stat"] == "nunique":
+        return d[c["value"]].nunique(**kw)
     return getattr(d, c["stat"])(c["value"], **kw)
 def run_all(tag):
     df = make()
