@@ -354,16 +354,19 @@ class Frame:
             return refs
 
         n = self.n
+        self.last_slots = [0]   # the thread slots the most recent pass binned on (sa.last_kernel(slot) says what ran there)
         if n:
             if all_device:
                 process(0, 0, n)
             else:
                 free = list(range(slots))
                 lock = threading.Lock()
+                used = set()
 
                 def work(i1):
                     with lock:
                         slot = free.pop()
+                        used.add(slot)
                     try:
                         process(slot, i1, min(n, i1 + self.chunk_size))
                     finally:
@@ -371,6 +374,7 @@ class Frame:
                             free.append(slot)
                 with ThreadPoolExecutor(slots) as pool:
                     list(pool.map(work, range(0, n, self.chunk_size)))
+                self.last_slots = sorted(used) or [0]
         return grid, aggs
 
     def _pass(self, descs, binby=None, limits=None, shape=128, reduce=None):

@@ -293,7 +293,9 @@ def _finish(df, plan, frame, res):
         out[out_name] = v[::-1] if descending else v
     last.clear()
     fused = frame.last_groupby_info and not frame.last_groupby_info.get("dense")   # (a dense range with its heavy keys peeled off leaves an info too)
-    kernel = "gb_scatter+gb_reduce" if fused else (frame.sa.last_kernel(0) if hasattr(frame.sa, "last_kernel") else "")
+    # (a frame over host columns hands its chunks to whichever of its thread slots is free: the kernel names are those of the slots the last pass used)
+    ran = sorted({frame.sa.last_kernel(t) for t in getattr(frame, "last_slots", [0])} - {""}) if hasattr(frame.sa, "last_kernel") else []
+    kernel = "gb_scatter+gb_reduce" if fused else "+".join(ran)
     last.update(path="device", kernel=kernel, info=frame.last_groupby_info, groups=len(next(iter(out.values()))))
     dataset_arrays = vaex.dataset.DatasetArrays(out)
     dataset = vaex.groupby.DatasetGroupby(dataset_arrays, df, plan.by, plan.agg, combine=combined, expand=True, sort=plan.sort)
