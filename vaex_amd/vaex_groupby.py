@@ -34,6 +34,7 @@ keys), else the narrowest signed integer type that holds the key range (vaex/gro
 import collections.abc
 import itertools
 import threading
+import weakref
 
 import numpy as np
 
@@ -415,7 +416,7 @@ class DeviceCollector:
             raise _Decline("delayed groupby: the columns do not fit the device next to the partition queues")
         self.capacity = capacity
         self.dtypes = {name: ar.dtype for name, ar in plan.columns.items()}
-        self.cols = {name: torch.empty(capacity, dtype=getattr(torch, ar.dtype.name), device="cuda") for name, ar in plan.columns.items()}
+        self.cols = None   # (allocated when the first chunk arrives: a scheduled call that never runs holds no HBM)
         self.rows = 0
         self.lock = threading.Lock()
 
@@ -424,6 +425,9 @@ class DeviceCollector:
         if n == 0:
             return
         with self.lock:
+            if self.cols is None:
+                import torch
+                self.cols = {name: torch.empty(self.capacity, dtype=getattr(torch, dt.name), device="cuda") for name, dt in self.dtypes.items()}
             at = self.rows
             self.rows += n
         if at + n > self.capacity:
@@ -530,6 +534,7 @@ def install(vaex_module, state):
             plan, collector, fallback = _PLANS[token]
             super().__init__(df, list(plan.columns), self.snake_name, df.filtered)
             self.token, self.plan, self.collector, self.fallback = token, plan, collector, fallback
+            self.failed = None
 
         @classmethod
         def decode(cls, encoding, spec, df, nthreads):
@@ -543,7 +548,14 @@ def install(vaex_module, state):
 
         def process(self, thread_index, i1, i2, filter_mask, selection_masks, blocks):
             # (called from the pool's threads, several at a time: the collector hands out row ranges under its lock)
-            self.collector.append({name: _block_as_numpy(b) for name, b in zip(self.plan.columns, blocks)})
+            if self.failed is not None:
+                return
+            try:
+                self.collector.append({name: _block_as_numpy(b) for name, b in zip(self.plan.columns, blocks)})
+            except (RuntimeError, MemoryError) as e:
+                # (HBM exhausted, a HIP error, a chunk the plan did not expect: the pass goes on for the caller's other tasks; this task is
+                #  answered by vaex's own groupby when the pass is over)
+                self.failed = e
 
         def reduce(self, others):
             pass
@@ -551,6 +563,9 @@ def install(vaex_module, state):
         def get_result(self):
             _PLANS.pop(self.token, None)
             try:
+                if self.failed is not None:
+                    drop_device_copies()
+                    raise _Decline(f"device groupby failed: {type(self.failed).__name__}: {str(self.failed)[:200]}")
                 if self.collector.rows == 0:
                     raise _Decline("delayed groupby: the filter left no row")   # (vaex's own answer: no group, its own column types)
                 frame = self.collector.frame()
@@ -584,7 +599,9 @@ def install(vaex_module, state):
             raise _Decline(f"device groupby failed: {type(e).__name__}: {str(e)[:200]}")
         token = next(_tokens)
         _PLANS[token] = (plan, collector, lambda: original(df, by=by, agg=agg, delay=False, **kwargs))
-        return df.executor.schedule(TaskGroupbyHip(df, plan, token))
+        task = TaskGroupbyHip(df, plan, token)
+        weakref.finalize(task, _PLANS.pop, token, None)   # (a task that is dropped, cancelled or rejected before its part is built)
+        return df.executor.schedule(task)
 
     class LazyGroupBy(vaex.groupby.GroupBy):
         """df.groupby(by) WITHOUT agg: vaex builds the groupers — the distinct-key pass over the key columns — in GroupBy.__init__
