@@ -416,7 +416,9 @@ class DeviceCollector:
             raise _Decline("delayed groupby: the columns do not fit the device next to the partition queues")
         self.capacity = capacity
         self.dtypes = {name: ar.dtype for name, ar in plan.columns.items()}
-        self.cols = None   # (allocated when the first chunk arrives: a scheduled call that never runs holds no HBM)
+        # (allocated here, on the scheduling thread, and held until the task has run or is dropped: an allocation from inside the pass — the
+        #  pool's threads — ended in a GPU memory fault on the one box it was tried on)
+        self.cols = {name: torch.empty(capacity, dtype=getattr(torch, ar.dtype.name), device="cuda") for name, ar in plan.columns.items()}
         self.rows = 0
         self.lock = threading.Lock()
 
@@ -425,9 +427,6 @@ class DeviceCollector:
         if n == 0:
             return
         with self.lock:
-            if self.cols is None:
-                import torch
-                self.cols = {name: torch.empty(self.capacity, dtype=getattr(torch, dt.name), device="cuda") for name, dt in self.dtypes.items()}
             at = self.rows
             self.rows += n
         if at + n > self.capacity:
