@@ -244,3 +244,52 @@ def test_named_selections_host_logic_on_vaex_cpp():
 def test_named_selections_on_the_device():
     out = _run(1, 2_000_000)
     assert out.count("\nok") + out.startswith("ok") >= 12, out
+
+
+HISTORY_FUZZ = r"""
+import sys, warnings, numpy as np
+warnings.simplefilter("ignore")
+sys.path[:0] = [%(pkg)r, %(fake)r, %(root)r]
+import vaex
+from vaex_amd import vaex_selection as vs
+n = 4000
+r0 = np.random.default_rng(1)
+df = vaex.from_arrays(x=r0.normal(0, 1, n), y=r0.normal(0, 1, n), i=r0.integers(-5, 5, n), idx=np.arange(n))
+exprs = ["x > 0", "y < 0.5", "i != 2", "x + y > 1", "(x > -1) & (y > -1)", "i >= 0"]
+expressible = 0
+for seed in range(400):
+    rng = np.random.default_rng(seed)
+    d = df.copy()
+    name = str(rng.choice(["default", "other"]))
+    steps = []
+    for k in range(int(rng.integers(1, 7))):
+        op = str(rng.choice(["select", "select", "select", "inverse", "nothing", "undo", "redo"]))
+        if op == "select":
+            e, mode = str(rng.choice(exprs)), str(rng.choice(["replace", "and", "or", "subtract", "xor"]))
+            d.select(e, mode=mode, name=name); steps.append((e, mode))
+        elif op == "inverse":
+            d.select_inverse(name=name); steps.append(op)
+        elif op == "nothing":
+            d.select_nothing(name=name); steps.append(op)
+        elif op == "undo" and d.selection_can_undo(name):
+            d.selection_undo(name); steps.append(op)
+        elif op == "redo" and d.selection_can_redo(name):
+            d.selection_redo(name); steps.append(op)
+    expr = vs.named_expression(d, name)
+    if expr is None:        # (xor in the history, or nothing selected: vaex's own masks)
+        continue
+    expressible += 1
+    want = np.isin(np.arange(n), d.evaluate("idx", selection=name))      # the rows vaex's selection machinery keeps
+    got = np.asarray(d.evaluate(expr)).astype(bool)
+    assert np.array_equal(got, want), (seed, steps, expr, int(got.sum()), int(want.sum()))
+assert expressible > 150, expressible
+print("HISTORIES OK", expressible)
+"""
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(PKG, "vaex")), reason="real vaex package not built (oracle/build_ref.sh needs /root/reference)")
+def test_random_selection_histories_resolve_to_the_rows_vaex_keeps():
+    """a named selection's history (select with every mode, inverse, nothing, undo, redo, in random order) as ONE expression — what the device
+    predicate of `selection=True` / `selection="name"` is compiled from — keeps exactly the rows vaex's own selection machinery keeps"""
+    r = subprocess.run([sys.executable, "-c", HISTORY_FUZZ % dict(pkg=PKG, fake=FAKE, root=ROOT)], capture_output=True, text=True, timeout=600, cwd="/tmp")
+    assert r.returncode == 0 and "HISTORIES OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
