@@ -157,3 +157,49 @@ def test_filtered_frames_host_logic_on_vaex_cpp():
 @pytest.mark.gpu
 def test_filtered_frames_on_the_device():
     _run(1, 3_000_000)
+
+
+CHAIN_FUZZ = r"""
+import sys, warnings, numpy as np
+warnings.simplefilter("ignore")
+sys.path[:0] = [%(pkg)r, %(fake)r, %(root)r]
+import vaex
+from vaex_amd import vaex_filter as vf
+n = 4000
+r0 = np.random.default_rng(1)
+df = vaex.from_arrays(x=r0.normal(0, 1, n), y=r0.normal(0, 1, n), i=r0.integers(-5, 5, n), idx=np.arange(n))
+exprs = ["x > 0", "y < 0.5", "i != 2", "x + y > 1", "(x > -1) & (y > -1)", "i >= 0"]
+expressible = 0
+for seed in range(500):
+    rng = np.random.default_rng(seed)
+    d, steps = df, []
+    for k in range(int(rng.integers(1, 5))):
+        op = str(rng.choice(["getitem", "getitem", "filter_and", "filter_or", "filter_replace", "drop"]))
+        e = str(rng.choice(exprs))
+        if op == "getitem":
+            d = d[d._expr(e)]; steps.append(("[]", e))
+        elif op == "drop":
+            d = d.drop_filter(); steps.append("drop")
+        else:
+            d = d.filter(e, mode=op.split("_")[1]); steps.append((op, e))
+    expr = vf.filter_expression(d)
+    if not d.filtered:
+        assert expr is None, (steps, expr)
+        continue
+    if expr is None:     # (an "or" / "replace" link in the chain: the executor's host mask)
+        continue
+    expressible += 1
+    kept = np.isin(np.arange(n), d.idx.to_numpy())
+    assert np.array_equal(np.asarray(df.evaluate(expr)).astype(bool), kept), (seed, steps, expr)
+assert expressible > 200, expressible
+print("CHAINS OK", expressible)
+"""
+
+
+def test_random_filter_chains_resolve_to_the_rows_vaex_keeps():
+    """df[a][b], df.filter(..., mode=and / or / replace), drop_filter in random order: the ONE expression a filtered frame's filter is compiled
+    from (the device predicate in every aggregator's keep-mask) keeps exactly the rows vaex's own filter keeps — or is declared not expressible"""
+    if not os.path.isdir(os.path.join(PKG, "vaex")):
+        pytest.skip("oracle/_ref/vaexpy not built (run __graft_entry__.build() where /root/reference exists)")
+    r = subprocess.run([sys.executable, "-c", CHAIN_FUZZ % dict(pkg=PKG, fake=FAKE, root=ROOT)], capture_output=True, text=True, timeout=600, cwd="/tmp")
+    assert r.returncode == 0 and "CHAINS OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
