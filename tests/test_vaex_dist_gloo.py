@@ -42,6 +42,41 @@ calls = {
   "count_scalar": lambda d: d.count("v"),
   "pct": lambda d: d.percentile_approx("x", 50),
 }
+# ... and random ones (round 5): statistic x column x 0-2 binby dimensions x random shapes x selection (none / expression / list), some of them
+# delayed in pairs — every rank draws the same calls, in the same order
+LIM = dict(x=[-3, 3], y=[-3, 3], v=[-3, 9], f4=[-2.5, 2.5], i=[-100.5, 99.5], k=[-3.5, 39.5])
+def draw(seed):
+    r = np.random.default_rng(900 + seed)
+    stat = str(r.choice(["count", "sum", "mean", "std", "min", "max", "minmax", "count_star"]))
+    value = str(r.choice(["x", "y", "v", "i", "f4"]))
+    nd = 0 if stat == "minmax" else int(r.choice([0, 1, 1, 2]))
+    binby = [str(b) for b in r.choice(list(LIM), size=nd, replace=False)]
+    kw = dict(binby=binby, limits=[LIM[b] for b in binby], shape=[int(r.integers(1, 40)) for _ in binby]) if nd else {}
+    s = r.random()
+    sel = None if s < 0.45 else (str(r.choice(["y > 0", "(v > 2) & (x < 1)", "i != 3", "f4 <= 0.3", "x + y > 0.5"])) if s < 0.85 else [None, "y < 0.25"])
+    if sel is not None:
+        kw["selection"] = sel
+    return stat, value, kw, bool(r.random() < 0.3)
+def random_calls(d):
+    out, pending = [], []
+    def flush():
+        if pending:
+            d.execute()
+            out.extend(p.get() for p in pending)
+            del pending[:]
+    for seed in range(%(nrandom)d):
+        stat, value, kw, delayed = draw(seed)
+        fn = (lambda **k: d.count(**k)) if stat == "count_star" else (lambda **k: getattr(d, stat)(value, **k))
+        if delayed:
+            pending.append(fn(delay=True, **kw))
+            if len(pending) == 2:
+                flush()
+        else:
+            flush()
+            out.append(fn(**kw))
+    flush()
+    return out
+want_random = random_calls(whole)
 want = {name: fn(whole) for name, fn in calls.items()}                       # before anything is installed: plain vaex, the whole table
 want_g = whole.groupby("k", agg={"s": A.sum("v"), "c": A.count(), "m": A.mean("v")}, sort=True)
 want_g = {c: want_g[c].to_numpy() for c in want_g.get_column_names()}
@@ -72,6 +107,18 @@ for name, fn in calls.items():
     else:
         close(got, want[name], name)
     print("ok", name, flush=True)
+got_random = random_calls(df)
+assert len(got_random) == len(want_random) == %(nrandom)d
+for seed, (g_, w_) in enumerate(zip(got_random, want_random)):
+    stat = draw(seed)[0]
+    a_, b_ = np.ma.filled(np.ma.asarray(g_).astype("f8"), np.nan), np.ma.filled(np.ma.asarray(w_).astype("f8"), np.nan)
+    assert a_.shape == b_.shape, (seed, draw(seed))
+    if stat in ("count", "count_star", "min", "max", "minmax"):
+        assert np.array_equal(a_, b_, equal_nan=True), (seed, draw(seed))
+    else:
+        fin = np.abs(b_[np.isfinite(b_)])
+        assert np.allclose(a_, b_, rtol=1e-7 if stat == "std" else 1e-11, atol=(1e-6 if stat == "std" else 1e-11) * max(1.0, float(fin.max()) if fin.size else 1.0), equal_nan=True), (seed, draw(seed))
+print("ok random", len(got_random), flush=True)
 vg.last.clear()
 g = df.groupby("k", agg={"s": A.sum("v"), "c": A.count(), "m": A.mean("v")}, sort=True)
 assert vg.last.get("path") == "device", vg.last
@@ -104,7 +151,7 @@ def _run(gpu, timeout):
     port = _free_port()
     env = dict(os.environ, VAEX_NUM_THREADS="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.setdefault("VAEX_HOME", "/tmp/vaex_home_dist")
-    procs = [subprocess.Popen([sys.executable, "-c", SCRIPT % dict(pkg=PKG, fake=FAKE, root=ROOT, gpu=gpu), str(r), "2", str(port)], cwd="/tmp", env=env,
+    procs = [subprocess.Popen([sys.executable, "-c", SCRIPT % dict(pkg=PKG, fake=FAKE, root=ROOT, gpu=gpu, nrandom=60), str(r), "2", str(port)], cwd="/tmp", env=env,
                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
     outs = []
     for p in procs:
@@ -117,7 +164,7 @@ def _run(gpu, timeout):
         outs.append((p.returncode, o, e))
     for rc, o, e in outs:
         assert rc == 0 and "DONE" in o, o[-2000:] + e[-5000:]
-        assert o.count("ok refused") == 3 and "ok groupby" in o, o
+        assert o.count("ok refused") == 3 and "ok groupby" in o and "ok random 60" in o, o
     return outs
 
 
