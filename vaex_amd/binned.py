@@ -478,6 +478,10 @@ class Frame:
             if percentile_limits != "minmax":
                 raise NotImplementedError("percentile_limits must be 'minmax' or [lo, hi]")
             plim = self.minmax(column, selection=selection)
+            if str(self.columns[column].dtype).replace("torch.", "") == "float32":
+                # (vaex's minmax comes back in the column's own type — vaex/dataframe.py:1528 — so for a float32 column `ub - lb` below is a
+                #  float32 subtraction there: mirrored, or the interpolated percentile differs in the 7th digit)
+                plim = np.asarray(plim).astype(np.float32)
         else:
             plim = percentile_limits
         nb = len(binby)
