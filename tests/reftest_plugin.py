@@ -26,6 +26,7 @@ _asyncio.fixture = pytest.fixture
 sys.modules.setdefault("pytest_asyncio", _asyncio)
 
 INSTALL = os.environ.get("VAEX_AMD_REFTEST_INSTALL") == "1"
+HOST_LOGIC = os.environ.get("VAEX_AMD_REFTEST_INSTALL") == "host"   # install()'s host logic alone over vaex's own classes (no GPU needed)
 _outcomes = {}
 _why = {}
 
@@ -33,6 +34,14 @@ if INSTALL:
     import vaex_amd
     assert vaex_amd.superagg.device_count() > 0, "vaex_amd.install() needs a HIP device"
     vaex_amd.install()
+elif HOST_LOGIC:
+    import vaex_amd
+    _backend = vaex_amd.install(hash_sets=False, legacy=False, groupby=False)
+
+    class _NoHip:
+        def __getattr__(self, name):
+            raise NotImplementedError("reftest: HIP classes switched off")
+    _backend.__dict__["_hip"] = _NoHip()
 
 
 def pytest_runtest_logreport(report):
@@ -57,8 +66,8 @@ def pytest_sessionfinish(session, exitstatus):
     path = os.environ.get("VAEX_AMD_REFTEST_REPORT")
     if not path:
         return
-    doc = {"install": INSTALL, "outcomes": _outcomes, "why": _why}
-    if INSTALL:
+    doc = {"install": INSTALL or HOST_LOGIC, "outcomes": _outcomes, "why": _why}
+    if INSTALL or HOST_LOGIC:
         from vaex_amd import vaex_groupby, vaex_selection, vaex_filter
         doc["task_stats"] = {k: v for k, v in vaex_amd.task_stats.items() if isinstance(v, (int, float, str, dict))}
         doc["groupby"] = {"device": vaex_groupby.stats.get("device", 0), "task": vaex_groupby.stats.get("task", 0), "vaex": vaex_groupby.stats.get("vaex", 0), "why": vaex_groupby.stats.get("why", {})}
