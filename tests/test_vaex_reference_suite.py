@@ -58,8 +58,14 @@ def run_files(install, tmp_path, files=FILES, threads=4):
                VAEX_NUM_THREADS=str(threads), VAEX_AMD_REFTEST_INSTALL=install if isinstance(install, str) else ("1" if install else "0"), VAEX_AMD_REFTEST_REPORT=report,
                HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.pop("VAEX_AMD_REPORT_DIR", None)
-    cmd = [sys.executable, "-m", "pytest", "-p", "reftest_plugin", "-q", "-p", "no:cacheprovider", "--tb=short", "--rootdir", REFTESTS] + list(files)
-    p = subprocess.run(cmd, cwd=REFTESTS, env=env, capture_output=True, text=True, timeout=3000)
+    # (a copy of its own per run: the reference's parquet fixture writes data/unittest.parquet next to the tests, and two runs go side by side)
+    import shutil
+    import uuid
+    work = str(tmp_path / ("reftests_" + uuid.uuid4().hex[:8]))
+    shutil.copytree(REFTESTS, work)
+    cmd = [sys.executable, "-m", "pytest", "-p", "reftest_plugin", "-q", "-p", "no:cacheprovider", "--tb=short", "--rootdir", work] + list(files)
+    p = subprocess.run(cmd, cwd=work, env=env, capture_output=True, text=True, timeout=3000)
+    shutil.rmtree(work, ignore_errors=True)
     assert os.path.exists(report), (p.stdout[-3000:], p.stderr[-3000:])
     doc = json.load(open(report))
     doc["tail"] = p.stdout[-600:]
@@ -70,9 +76,17 @@ _cache = {}
 
 
 def cached_run(install, tmp_path):
-    """one run per mode and pytest process (a run is ~2 minutes)"""
+    """one run per mode and pytest process (a run is ~2 minutes; without a GPU the two modes of this file's tests run side by side)"""
     if install not in _cache:
-        _cache[install] = run_files(install, tmp_path)
+        import torch
+        if not torch.cuda.is_available() and not _cache:
+            from concurrent.futures import ThreadPoolExecutor
+            with ThreadPoolExecutor(2) as pool:
+                both = {mode: pool.submit(run_files, mode, tmp_path) for mode in (False, "host")}
+                for mode, f in both.items():
+                    _cache[mode] = f.result()
+        else:
+            _cache[install] = run_files(install, tmp_path)
     return _cache[install]
 
 
