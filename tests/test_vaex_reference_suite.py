@@ -44,6 +44,10 @@ FILES = ["agg_test.py", "count_test.py", "groupby_test.py", "selection_test.py",
          "arrow/io_test.py", "arrow/to_arrow_table_test.py",
          "legacy/cmodule.py"]   # packages/vaex-core/vaex/test/cmodule.py: the unittest of vaexfast.statisticNd_f8 (install() puts the HIP entry there)
 
+_SUBSET = [f for f in os.environ.get("VAEX_AMD_REFTEST_FILES", "").split(",") if f]   # (a quick check of the harness itself: a few files, no thresholds)
+if _SUBSET:
+    FILES = _SUBSET
+
 pytestmark = pytest.mark.skipif(not (os.path.isfile(os.path.join(REFTESTS, "agg_test.py")) and os.path.isdir(os.path.join(PKG, "vaex"))),
                                 reason="oracle/_ref/reftests or the reference's Python package not built (oracle/build_ref.sh needs /root/reference)")
 
@@ -129,7 +133,7 @@ def test_what_passes_on_the_reference_classes_passes_on_the_hip_classes(tmp_path
     base = cached_run(False, tmp_path)
     hip = run_files(True, tmp_path)
     passed = [n for n, o in base["outcomes"].items() if o == "passed"]
-    assert len(passed) >= 1600, counts(base)
+    assert len(passed) >= 1600 or _SUBSET, counts(base)
     regressions = {n: hip["why"].get(n, hip["outcomes"].get(n, "not run"))[-700:] for n in passed if hip["outcomes"].get(n) != "passed" and n not in EXPECTED_DIFFERENT}
     retried = {}
     if regressions and len(regressions) <= 40:
@@ -146,5 +150,5 @@ def test_what_passes_on_the_reference_classes_passes_on_the_hip_classes(tmp_path
     if out_dir:
         with open(os.path.join(out_dir, "reference_suite.json"), "w") as f:
             json.dump(summary, f, indent=1)
-    assert hip["task_stats"]["hip"] > 500, hip["task_stats"]       # the tests DID run on the HIP classes
+    assert hip["task_stats"]["hip"] > (20 if _SUBSET else 500), hip["task_stats"]       # the tests DID run on the HIP classes
     assert not regressions, (len(regressions), dict(list(regressions.items())[:8]))
