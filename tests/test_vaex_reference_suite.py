@@ -131,7 +131,16 @@ def test_what_passes_on_the_reference_classes_passes_through_the_host_logic_of_i
 @pytest.mark.gpu
 def test_what_passes_on_the_reference_classes_passes_on_the_hip_classes(tmp_path):
     base = cached_run(False, tmp_path)
-    hip = run_files(True, tmp_path)
+    first_attempt = None
+    try:
+        hip = run_files(True, tmp_path)
+    except AssertionError as e:          # (the subprocess died before it wrote its report)
+        hip, first_attempt = {"outcomes": {}}, str(e)[-1500:]
+    if len(hip["outcomes"]) < len(base["outcomes"]) // 2:
+        # One of three quick runs of this test on a fresh box ended within seconds (round 5, not understood, not reproduced in the two runs after
+        # it; the seven whole runs before it never did): a run that lost most of its tests is repeated ONCE, and the report says so.
+        first_attempt = first_attempt or hip.get("tail", "")
+        hip = run_files(True, tmp_path)
     passed = [n for n, o in base["outcomes"].items() if o == "passed"]
     assert len(passed) >= 1600 or _SUBSET, counts(base)
     regressions = {n: hip["why"].get(n, hip["outcomes"].get(n, "not run"))[-700:] for n in passed if hip["outcomes"].get(n) != "passed" and n not in EXPECTED_DIFFERENT}
@@ -144,7 +153,7 @@ def test_what_passes_on_the_reference_classes_passes_on_the_hip_classes(tmp_path
         regressions = {n: w for n, w in regressions.items() if retried[n] != "passed"}
     fixed = [n for n, o in hip["outcomes"].items() if o == "passed" and base["outcomes"].get(n) in ("failed", "error")]
     summary = {"reference_classes": counts(base), "hip_classes": counts(hip), "pass_on_both": len(passed) - len(regressions), "regressions": regressions,
-               "pass_only_under_install": fixed, "expected_different": EXPECTED_DIFFERENT, "second_runs": retried,
+               "pass_only_under_install": fixed, "expected_different": EXPECTED_DIFFERENT, "second_runs": retried, "first_attempt_lost": first_attempt,
                "task_parts": hip.get("task_stats"), "groupby": hip.get("groupby"), "selection": hip.get("selection"), "filter": hip.get("filter")}
     out_dir = os.environ.get("VAEX_AMD_REPORT_DIR")
     if out_dir:
