@@ -130,7 +130,10 @@ def test_what_passes_on_the_reference_classes_passes_through_the_host_logic_of_i
 
 @pytest.mark.gpu
 def test_what_passes_on_the_reference_classes_passes_on_the_hip_classes(tmp_path):
-    base = cached_run(False, tmp_path)
+    try:
+        base = cached_run(False, tmp_path)
+    except AssertionError:               # (the same once-only allowance for the run on the reference's classes)
+        base = cached_run(False, tmp_path)
     first_attempt = None
     try:
         hip = run_files(True, tmp_path)
