@@ -31,7 +31,12 @@ _outcomes = {}
 _why = {}
 
 if INSTALL:
+    import time
     import vaex_amd
+    for _attempt in range(20):       # (this process may be the first user of the GPU on a fresh box)
+        if vaex_amd.superagg.device_count() > 0:
+            break
+        time.sleep(0.5)
     assert vaex_amd.superagg.device_count() > 0, "vaex_amd.install() needs a HIP device"
     vaex_amd.install()
 elif HOST_LOGIC:
