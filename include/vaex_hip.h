@@ -21,13 +21,28 @@
  *     worker pool (vaex: the executor's thread_index); VXH_AUX_SLOT .. VXH_AUX_SLOT + 7 are auxiliary
  *     slots for callers that run NEXT to that pool (the legacy statisticNd entry, called from pool
  *     threads in the same pass as aggregation task parts, serialises itself on the first of them).
- *   - Data pointers are BORROWED for the duration of vxh_grid_bin (src/agg_base.hpp:166-179:
- *     raw pointer, no incref).  `mem` says where the pointer lives:
+ *   - Data pointers are BORROWED (src/agg_base.hpp:166-179: raw pointer, no incref).  `mem` says
+ *     where the pointer lives, and that decides for how long it is borrowed:
  *       VXH_MEM_HOST   - host memory (numpy chunk).  vxh_grid_bin stages it through pinned
  *                        buffers + hipMemcpyAsync on the slot's stream; the host pointer is no
- *                        longer read once vxh_grid_bin returns.
- *       VXH_MEM_DEVICE - HBM-resident column (device pointer); used in place, nothing copied,
- *                        vxh_grid_bin returns as soon as the kernels are enqueued.
+ *                        longer read once vxh_grid_bin returns (the reference's contract: the
+ *                        caller keeps the array alive for the duration of the call, vaex/cpu.py:708-710).
+ *       VXH_MEM_DEVICE - HBM-resident column (device pointer); used in place, nothing copied.
+ *                        vxh_grid_bin returns as soon as its kernels are ENQUEUED on the slot's
+ *                        stream, so the column is read AFTER the call has returned: it must stay
+ *                        allocated and unmodified until the slot has drained — vxh_slot_wait(thread),
+ *                        vxh_synchronize(), or a call that hands a result to the host (vxh_agg_result /
+ *                        vxh_agg_host_view) has returned; vxh_slot_busy(thread) polls.  Handing the
+ *                        block back to a stream-ordered caching allocator before that is a use
+ *                        after free.  (The pybind11 shim does this bookkeeping for Python callers:
+ *                        it keeps a reference to every device array it was given until the slot
+ *                        that read it is idle.)
+ *                        Ordering against the PRODUCER of a device column: the slot's work is
+ *                        ordered after everything enqueued on the legacy default stream before the
+ *                        call (and after every blocking stream through it).  A column written on a
+ *                        NON-BLOCKING stream is ordered by the caller: vxh_slot_wait_stream(thread,
+ *                        producer) before vxh_grid_bin, or vxh_slot_set_stream to run the slot on
+ *                        that stream.
  *   - Grid cell layout: dim 0 fastest (src/agg.hpp:63-73); scalar binner = bins+3 cells
  *     [nan/masked, underflow, bin0..binN-1, overflow] (src/binners.cpp:13-59); ordinal binner
  *     = N+2 (+1) cells [0..N-1, (other), null, nan] (src/binner_ordinal.cpp:11-13, :178).
@@ -79,6 +94,14 @@ int vxh_set_device(int device);
 int vxh_synchronize(void);
 /* run slot `thread`'s work on a caller-owned hipStream_t (NULL = library-owned stream) */
 int vxh_slot_set_stream(int thread, void *hip_stream);
+/* lifetime of VXH_MEM_DEVICE pointers (see "Data pointers" above; the reference has no counterpart — its bin() is synchronous,
+ * src/agg.hpp:84-137): *busy = 1 while work enqueued for slot `thread` may still read the caller's device columns */
+int vxh_slot_busy(int thread, int *busy);
+/* block until slot `thread` has drained: from here on the device columns it was given may be freed or overwritten */
+int vxh_slot_wait(int thread);
+/* order slot `thread`'s next work after everything enqueued so far on `producer_stream` (a hipStream_t: the stream that writes the
+ * caller's device columns; only needed for non-blocking streams — the legacy default stream is ordered implicitly) */
+int vxh_slot_wait_stream(int thread, void *producer_stream);
 /* tuning knobs for experiments and tests ("strategy", "part_chunk", "parts", "wv", "wv_waves", "wv_waves_direct", "blk", "hot",
  * "hot_cache", "hot_min_pct", "hot_direct_pct", "count16", "stage_bytes", "feeder", "cache_bytes", ...) and the two switches that
  * switch two reference quirks OFF ("first_mask_block", "nunique_row_counts": see AggFirst / AggNUnique below; the defaults are

@@ -273,6 +273,47 @@ def test_arithmetic_and_virtual_column_selections_keep_the_rows_numpy_keeps(wher
         assert int(np.asarray(got).sum()) == int(keep.sum()), expr
 
 
+def test_arithmetic_selections_through_the_ready_made_mask_passes_on_device_columns():
+    """the passes that take a ready-made keep-mask — minmax, the percentile / limits passes, the fused hash groupby —
+    built it for DEVICE columns from (first column, op, constant) of every term and dropped the term's arithmetic program: `2*x + 1 > 0`
+    became `x > 0`.  Device columns against the same calls over host columns and against numpy."""
+    import torch
+    from vaex_amd.binned import agg
+    n = 1_500_007
+    rng = np.random.default_rng(21)
+    x, y, v = rng.normal(0, 1, n), rng.normal(0, 1, n), rng.normal(3, 2, n)
+    x[::701] = np.nan
+    k = (rng.integers(0, 5000, n) * 2654435761) % (1 << 40)      # scattered keys: the fused hash pass
+    kd = rng.integers(0, 300, n)                                 # a dense range: the ordinal pass
+    host = dict(x=x, y=y, v=v, k=k, kd=kd)
+    dev = {c: torch.from_numpy(a).cuda() for c, a in host.items()}
+    fh, fd = Frame(host, chunk_size=1 << 19, nthreads=3), Frame(dev)
+    for expr in ("2*x + 1 > 0", "x**2 + y**2 < 4", "(abs(x - y)/2 >= 0.25) & (v > 3)", "sqrt(x*x + 1) - y < 1.5"):
+        pred = P.compile_selection(expr, host)
+        assert pred.programs, expr
+        with np.errstate(all="ignore"):
+            keep = np.asarray(eval(expr, {}, dict(host, sqrt=np.sqrt, abs=np.abs)), dtype=bool)
+        plain = P.Predicate(expr, pred.columns, pred.terms, pred.truth).numpy_mask(host)   # (the programs dropped: what the bug computed)
+        assert not np.array_equal(plain, keep), expr
+        assert np.array_equal(fd._mask_array(expr).cpu().numpy().astype(bool), keep), expr
+        # minmax
+        want = np.array([np.nanmin(v[keep]), np.nanmax(v[keep])])
+        assert np.array_equal(fd.minmax("v", selection=expr), want) and np.array_equal(fh.minmax("v", selection=expr), want), expr
+        # groupby: scattered keys (gb_scatter + gb_reduce with the mask as keep), and a dense range
+        for key in ("k", "kd"):
+            spec = {"c": agg.count("v"), "s": agg.sum("v"), "n": agg.count()}
+            rd, rh = fd.groupby(key, spec, selection=expr), fh.groupby(key, spec, selection=expr)
+            uniq, inv = np.unique(host[key][keep], return_inverse=True)
+            assert np.array_equal(rd[key], uniq) and np.array_equal(rh[key], uniq), (expr, key)
+            assert np.array_equal(rd["n"], np.bincount(inv)) and np.array_equal(rd["c"], rh["c"]), (expr, key)
+            ssum = np.bincount(inv, weights=v[keep])
+            assert np.allclose(rd["s"], ssum, rtol=1e-12, atol=1e-9) and np.allclose(rh["s"], ssum, rtol=1e-12, atol=1e-9), (expr, key)
+        # the aggregations' OWN selection (groups of all rows, values of the kept rows): the fused pass run twice
+        own = fd.groupby("k", {"c": agg.count(selection=expr), "s": agg.sum("v", selection=expr)})
+        uniq_all, inv_all = np.unique(k, return_inverse=True)
+        assert np.array_equal(own["k"], uniq_all) and np.array_equal(own["c"], np.bincount(inv_all, weights=keep, minlength=len(uniq_all)).astype(np.int64)), expr
+
+
 def test_random_predicates_keep_the_rows_numpy_keeps():
     """the differential fuzz of tests/test_predicate.py on the device: random expressions (comparisons of every column type with integer / float
     / huge / float32-boundary constants on either side, arithmetic over float64 columns, & | ~ three levels deep) as device predicates — in the

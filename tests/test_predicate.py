@@ -107,3 +107,42 @@ def test_random_expressions_keep_the_rows_numpy_keeps():
             want = np.asarray(eval(expr, {}, scope)).astype(bool)
         assert np.array_equal(pred.numpy_mask(cols), want), expr
     assert inside > 400, inside
+
+
+def test_constant_subtrees_are_folded_with_python_semantics():
+    """vaex evaluates a selection with Python's eval(): a subexpression made of numbers only is folded in exact integer arithmetic before
+    anything becomes a float64 — `(2**53 + 1 + 1) * x` multiplies by ...994, the step-by-step float64 folding the device used to do gives
+    ...992."""
+    cols = {"x": np.array([1.0, 1.0000000000000002, 0.9999999999999999, -1.0, np.nan])}
+    p = P.compile_selection("(9007199254740992 + 1 + 1) * x > 9007199254740994", cols)
+    consts = [v for op, _, v in p.programs[0] if op == P.SEL_CONST]
+    assert consts == [9007199254740994.0]
+    with np.errstate(invalid="ignore"):
+        want = eval("(9007199254740992 + 1 + 1) * x > 9007199254740994", {}, dict(cols))
+    assert np.array_equal(p.numpy_mask(cols), want) and want.tolist() == [False, True, False, False, False]
+    # the constant side of a comparison is folded too, and stays an int where Python's is one
+    q = P.compile_selection("x > 2 * 3 - 5", cols)
+    assert not q.programs and q.terms == [(0, 2, 1)] and isinstance(q.terms[0][2], int)
+    r = P.compile_selection("x * (1 / 3) >= 1 / 3", cols)
+    assert [v for op, _, v in r.programs[0] if op == P.SEL_CONST] == [1 / 3] and r.terms[0][2] == 1 / 3
+    assert P.compile_selection("x < 2 ** -1", cols).terms == [(0, 0, 0.5)]
+    for expr in ("x > 1 / 0", "x * 10 ** 400 > 1", "x > 2 ** 1000 ** 1000", "x > (-8) ** 0.5"):
+        with pytest.raises(P.Unsupported):
+            P.compile_selection(expr, cols)
+
+
+@pytest.mark.parametrize("expr,virtual", [(e, None) for e in CASES] + ARITH)
+def test_torch_mask_equals_numpy_mask(expr, virtual):
+    """Predicate.torch_mask — what Frame's ready-made keep-masks over DEVICE columns are built with (minmax, percentiles, the hashed
+    groupby) — keeps numpy_mask's rows, arithmetic programs included (the programs used to be dropped on that road).  Here on
+    CPU tensors; tests/test_gpu_selection.py runs the same on the GPU."""
+    torch = pytest.importorskip("torch")
+    cols = dict(COLS)
+    if virtual is not None or expr in [a for a, _ in ARITH]:
+        cols["y"] = np.linspace(-2.0, 2.0, len(cols["x"]))
+    p = P.compile_selection(expr, cols, virtual=virtual)
+    tensors = {c: torch.from_numpy(np.ascontiguousarray(cols[c])) for c in p.columns}
+    with np.errstate(all="ignore"):
+        want = p.numpy_mask({c: cols[c] for c in p.columns})
+    got = p.torch_mask(tensors)
+    assert got.dtype == torch.uint8 and np.array_equal(got.numpy().astype(bool), want), expr

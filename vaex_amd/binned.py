@@ -210,16 +210,7 @@ class Frame:
         if isinstance(sel, _predicate.Predicate):
             cols = {n: self.columns[n] for n in sel.columns}
             if any(_is_device(c) for c in cols.values()):
-                import torch
-                ops = {0: torch.lt, 1: torch.le, 2: torch.gt, 3: torch.ge, 4: torch.eq, 5: torch.ne}
-                bits = None
-                for t, (c, op, v) in enumerate(sel.terms):
-                    col = cols[sel.columns[c]]
-                    if isinstance(v, float) and not col.dtype.is_floating_point:
-                        col = col.to(torch.float64)  # numpy compares an integer column with a float constant in float64 (torch would pick float32)
-                    o = ops[op](col, v).to(torch.int32) << t
-                    bits = o if bits is None else bits | o
-                return ((sel.truth >> bits) & 1).to(torch.uint8)
+                return sel.torch_mask(cols)   # (terms AND their arithmetic programs: ADVICE r5 — the programs used to be dropped here)
             return sel.numpy_mask(cols)
         return sel
 

@@ -85,6 +85,79 @@ void check_mask(const ArrayRef &data, const ArrayRef &mask) {
 }
 
 // ------------------------------------------------------------------------------------------
+// lifetime of device arrays (include/vaex_hip.h "Data pointers": VXH_MEM_DEVICE)
+// ------------------------------------------------------------------------------------------
+// Grid.bin over device columns returns with its kernels ENQUEUED on the slot's stream: the columns are read after the call has
+// returned.  The reference's contract — the caller keeps its arrays alive for the duration of bin() (vaex/cpu.py:708-710) — is all a
+// Python caller knows, so the bookkeeping is done here: every object that was handed a device array keeps a reference to it per thread
+// slot; a reference that is replaced (the next chunk's set_data), cleared or orphaned by its holder's destruction is RETIRED to its
+// slot's list and dropped only once that slot is idle (vxh_slot_busy).  A torch tensor freed by the caller right after bin() therefore
+// does not go back to torch's caching allocator — which would hand the block to the next torch.empty on ANOTHER stream — while a
+// kernel of this library still reads it.  (All of this runs under the GIL; the lists are never destroyed: no decref at interpreter exit.)
+std::map<int, std::vector<py::object>> &retired_refs() {
+    static auto *m = new std::map<int, std::vector<py::object>>();
+    return *m;
+}
+constexpr size_t kMaxRetiredPerSlot = 128; // (beyond this the slot is waited for: the list must not grow with the number of chunks)
+
+void collect_retired(int thread) {
+    auto &all = retired_refs();
+    auto it = all.find(thread);
+    if (it == all.end() || it->second.empty()) return;
+    int busy = 1;
+    if (vxh_slot_busy(thread, &busy) != 0) return; // (a failing query keeps the references: leaking is the safe side)
+    if (busy && it->second.size() >= kMaxRetiredPerSlot) {
+        int rc;
+        {
+            py::gil_scoped_release release;
+            rc = vxh_slot_wait(thread);
+        }
+        busy = rc != 0;
+        it = all.find(thread); // (the GIL was released: another thread may have touched the map)
+        if (it == all.end()) return;
+    }
+    if (!busy) {
+        std::vector<py::object> drop;
+        drop.swap(it->second); // (decrefs may run arbitrary Python: after the list is empty)
+    }
+}
+
+void retire_ref(int thread, py::object &&o) {
+    if (!o || o.is_none()) return;
+    int busy = 1;
+    if (vxh_slot_busy(thread, &busy) == 0 && !busy) return; // (nothing in flight on that slot: dropped here)
+    retired_refs()[thread].push_back(std::move(o));
+}
+
+void collect_all_retired() { // after vxh_synchronize: nothing is in flight anywhere
+    std::vector<py::object> drop;
+    for (auto &kv : retired_refs()) {
+        for (auto &o : kv.second) drop.push_back(std::move(o));
+        kv.second.clear();
+    }
+}
+
+// the device arrays one binner / aggregator / selection currently points at: (thread slot, index) -> reference
+struct HeldArrays {
+    std::map<std::pair<int, int>, py::object> refs;
+    void hold(int thread, int index, const py::object &obj, const ArrayRef &a) {
+        collect_retired(thread);
+        release(thread, index);
+        if (a.mem == VXH_MEM_DEVICE) refs[{thread, index}] = obj;
+    }
+    void release(int thread, int index) {
+        auto it = refs.find({thread, index});
+        if (it == refs.end()) return;
+        py::object o = std::move(it->second);
+        refs.erase(it);
+        retire_ref(thread, std::move(o));
+    }
+    ~HeldArrays() {
+        for (auto &kv : refs) retire_ref(kv.first.first, std::move(kv.second));
+    }
+};
+
+// ------------------------------------------------------------------------------------------
 // hash map
 // ------------------------------------------------------------------------------------------
 struct PyHashMap {
@@ -231,20 +304,29 @@ struct PyBinner {
     bool flip = false;
     int threads = 1;
     std::string expression;
+    HeldArrays held; // index 0: data, 1: mask
     virtual ~PyBinner() { vxh_binner_destroy(h); }
     PyBinner() = default;
-    PyBinner(const PyBinner &o) : dtype(o.dtype), flip(o.flip), threads(o.threads), expression(o.expression) { check(vxh_binner_copy(o.h, &h)); }
+    PyBinner(const PyBinner &o) : dtype(o.dtype), flip(o.flip), threads(o.threads), expression(o.expression) {
+        check(vxh_binner_copy(o.h, &h));
+        held.refs = o.held.refs; // (whatever pointers the copy inherited stay alive with it)
+    }
 
     void set_data(int thread, const py::object &ar) {
         ArrayRef a = resolve_array(ar);
         if (a.itemsize != kTypeSizes[dtype]) throw std::runtime_error("Itemsize of data and binner are not equal");
         check(vxh_binner_set_data(h, thread, a.ptr, a.n, a.mem));
+        held.hold(thread, 0, ar, a);
     }
     void set_data_mask(int thread, const py::object &ar) {
         ArrayRef a = resolve_array(ar);
         check(vxh_binner_set_data_mask(h, thread, (const uint8_t *)a.ptr, a.n, a.mem));
+        held.hold(thread, 1, ar, a);
     }
-    void clear_data_mask(int thread) { check(vxh_binner_clear_data_mask(h, thread)); }
+    void clear_data_mask(int thread) {
+        check(vxh_binner_clear_data_mask(h, thread));
+        held.release(thread, 1);
+    }
     uint64_t shape() const { return vxh_binner_shape(h); }
 };
 
@@ -378,6 +460,7 @@ struct PySelection {
             check(vxh_selection_set_program(h, kv.first, (int)steps.size(), steps.data()));
         }
     }
+    HeldArrays held; // index = column
     ~PySelection() { vxh_selection_destroy(h); }
     PySelection(const PySelection &) = delete;
     void set_data(int thread, int column, const py::object &ar) {
@@ -385,6 +468,7 @@ struct PySelection {
         if (column < 0 || column >= (int)dtypes.size()) throw std::runtime_error("no such selection column");
         if (a.itemsize != kTypeSizes[dtypes[column]]) throw std::runtime_error("Itemsize of data and selection column are not equal");
         check(vxh_selection_set_data(h, thread, column, a.ptr, a.n, a.mem));
+        held.hold(thread, column, ar, a);
     }
 };
 
@@ -393,6 +477,7 @@ struct PyAgg {
     PyGrid *grid;
     int kind, dtype;
     py::object selection_ref; // keeps the attached selection alive
+    HeldArrays held;          // index 0: data, 1: mask
     PyAgg(int kind, int dtype, bool flip, PyGrid *grid, int grids, int threads, uint32_t moment) : grid(grid), kind(kind), dtype(dtype) {
         check(vxh_agg_create(kind, dtype, flip, grid->h, grids, threads, moment, &h));
     }
@@ -403,12 +488,17 @@ struct PyAgg {
         ArrayRef a = resolve_array(ar);
         if (a.itemsize != kTypeSizes[dtype]) throw std::runtime_error("Itemsize of data and aggregator are not equal");
         check(vxh_agg_set_data(h, thread, a.ptr, a.n, a.mem));
+        held.hold(thread, 0, ar, a);
     }
     void set_data_mask(int thread, const py::object &ar) {
         ArrayRef a = resolve_array(ar);
         check(vxh_agg_set_data_mask(h, thread, (const uint8_t *)a.ptr, a.n, a.mem));
+        held.hold(thread, 1, ar, a);
     }
-    void clear_data_mask(int thread) { check(vxh_agg_clear_data_mask(h, thread)); }
+    void clear_data_mask(int thread) {
+        check(vxh_agg_clear_data_mask(h, thread));
+        held.release(thread, 1);
+    }
     void set_selection(const py::object &sel) {
         if (sel.is_none()) {
             check(vxh_agg_set_selection(h, nullptr));
@@ -508,6 +598,7 @@ struct PyAgg {
 };
 
 void PyGrid::bin(int thread, const std::vector<PyAgg *> &aggs, uint64_t length) {
+    collect_retired(thread);
     std::vector<vxh_agg *> hs;
     for (auto *a : aggs) hs.push_back(a->h);
     int rc;
@@ -527,18 +618,24 @@ struct PyAggFirst {
     PyAggFirst(PyGrid *grid, int grids, int threads, bool invert, int dtype, int dtype_order, bool flip) : grid(grid), dtype(dtype), dtype_order(dtype_order) {
         check(vxh_first_create(dtype, dtype_order, flip, grid->h, grids, threads, invert, &h));
     }
+    HeldArrays held; // index 0 / 1: value / order column, 2: mask
     ~PyAggFirst() { vxh_first_destroy(h); }
     PyAggFirst(const PyAggFirst &) = delete;
     void set_data(int thread, const py::object &ar, size_t index) {
         ArrayRef a = resolve_array(ar);
         if (a.itemsize != kTypeSizes[index == 1 ? dtype_order : dtype]) throw std::runtime_error("Itemsize of data and aggregator are not equal");
         check(vxh_first_set_data(h, thread, (int)index, a.ptr, a.n, a.mem));
+        held.hold(thread, index == 1 ? 1 : 0, ar, a);
     }
     void set_data_mask(int thread, const py::object &ar) {
         ArrayRef a = resolve_array(ar);
         check(vxh_first_set_data_mask(h, thread, (const uint8_t *)a.ptr, a.n, a.mem));
+        held.hold(thread, 2, ar, a);
     }
-    void clear_data_mask(int thread) { check(vxh_first_set_data_mask(h, thread, nullptr, 0, VXH_MEM_HOST)); }
+    void clear_data_mask(int thread) {
+        check(vxh_first_set_data_mask(h, thread, nullptr, 0, VXH_MEM_HOST));
+        held.release(thread, 2);
+    }
     size_t bytes_used() const { return vxh_first_bytes_used(h); }
     // (values, masked, order) as arrays of `shapes`, dim 0 fastest
     py::tuple raw_result() {
@@ -574,6 +671,7 @@ struct PyCollect {
     PyCollect(PyGrid *grid, int grids, int threads, bool a, bool b, int mode, int dtype, bool flip) : grid(grid), mode(mode), dtype(dtype) {
         check(vxh_collect_create(mode, dtype, flip, grid->h, grids, threads, a, b, &h));
     }
+    HeldArrays held; // index 0: data, 1: mask, 2: selection mask
     ~PyCollect() { vxh_collect_destroy(h); }
     PyCollect(const PyCollect &) = delete;
     void set_data(int thread, const py::object &ar, size_t index) {
@@ -581,17 +679,26 @@ struct PyCollect {
         ArrayRef a = resolve_array(ar);
         if (a.itemsize != kTypeSizes[dtype]) throw std::runtime_error("Itemsize of data and aggregator are not equal");
         check(vxh_collect_set_data(h, thread, a.ptr, a.n, a.mem));
+        held.hold(thread, 0, ar, a);
     }
     void set_data_mask(int thread, const py::object &ar) {
         ArrayRef a = resolve_array(ar);
         check(vxh_collect_set_data_mask(h, thread, (const uint8_t *)a.ptr, a.n, a.mem));
+        held.hold(thread, 1, ar, a);
     }
-    void clear_data_mask(int thread) { check(vxh_collect_set_data_mask(h, thread, nullptr, 0, VXH_MEM_HOST)); }
+    void clear_data_mask(int thread) {
+        check(vxh_collect_set_data_mask(h, thread, nullptr, 0, VXH_MEM_HOST));
+        held.release(thread, 1);
+    }
     void set_selection_mask(int thread, const py::object &ar) {
         ArrayRef a = resolve_array(ar);
         check(vxh_collect_set_selection_mask(h, thread, (const uint8_t *)a.ptr, a.n, a.mem));
+        held.hold(thread, 2, ar, a);
     }
-    void clear_selection_mask(int thread) { check(vxh_collect_set_selection_mask(h, thread, nullptr, 0, VXH_MEM_HOST)); }
+    void clear_selection_mask(int thread) {
+        check(vxh_collect_set_selection_mask(h, thread, nullptr, 0, VXH_MEM_HOST));
+        held.release(thread, 2);
+    }
     void bin(int thread, uint64_t length) {
         int rc;
         {
@@ -756,7 +863,20 @@ PYBIND11_MODULE(superagg, m) {
     m.attr("AUX_SLOT") = (int)VXH_AUX_SLOT; // first thread slot outside the host pool's indices (include/vaex_hip.h)
     m.def("device_count", []() { int n = 0; check(vxh_device_count(&n)); return n; });
     m.def("set_device", [](int d) { check(vxh_set_device(d)); });
-    m.def("synchronize", []() { py::gil_scoped_release r; check(vxh_synchronize()); });
+    m.def("synchronize", []() {
+        { py::gil_scoped_release r; check(vxh_synchronize()); }
+        collect_all_retired();
+    });
+    // lifetime of device columns (include/vaex_hip.h "Data pointers"): the slot's streams may still read them after Grid.bin returned
+    m.def("slot_busy", [](int thread) { int busy = 0; check(vxh_slot_busy(thread, &busy)); return busy != 0; }, py::arg("thread") = 0);
+    m.def("slot_wait", [](int thread) {
+        { py::gil_scoped_release r; check(vxh_slot_wait(thread)); }
+        collect_retired(thread);
+    }, py::arg("thread") = 0);
+    m.def("wait_stream", [](int thread, uintptr_t stream) { check(vxh_slot_wait_stream(thread, (void *)stream)); }, py::arg("thread"), py::arg("stream"),
+          "order slot `thread`'s next work after everything enqueued so far on the hipStream_t `stream` (e.g. torch.cuda.current_stream().cuda_stream)");
+    m.def("retired_device_arrays", [](int thread) { auto &all = retired_refs(); auto it = all.find(thread); return it == all.end() ? (size_t)0 : it->second.size(); }, py::arg("thread") = 0,
+          "device arrays the shim still holds for slot `thread` although their holders have let go of them (their kernels may still be running)");
     m.def("config_set", [](const std::string &k, int64_t v) { check(vxh_config_set(k.c_str(), v)); });
     m.def("config_get", [](const std::string &k) { int64_t v = 0; check(vxh_config_get(k.c_str(), &v)); return v; });
     // device column cache (include/vaex_hip.h "chunk feeder and device column cache"): the array's memory is declared immutable

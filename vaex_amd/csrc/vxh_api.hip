@@ -1839,6 +1839,59 @@ int vxh_slot_set_stream(int thread, void *hip_stream) {
     VXH_API_END
 }
 
+// ---- lifetime of VXH_MEM_DEVICE pointers (include/vaex_hip.h "Data pointers") -----------------------------------------------
+// vxh_grid_bin over device columns returns with its kernels enqueued: the columns are read until the slot's streams have drained.
+int vxh_slot_busy(int thread, int *busy) {
+    VXH_API_BEGIN
+    *busy = 0;
+    Context &c = ctx();
+    Slot *s = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(c.mutex);
+        if (thread < 0 || thread >= VXH_MAX_SLOTS) throw std::runtime_error("thread slot out of range");
+        s = c.slots[thread];
+    }
+    if (!s) return 0; // (a slot nobody has used has nothing in flight)
+    for (hipStream_t st : {s->stream, s->stream2}) {
+        const hipError_t e = hipStreamQuery(st);
+        if (e == hipErrorNotReady) { (void)hipGetLastError(); *busy = 1; break; }
+        HIP_CHECK(e);
+    }
+    VXH_API_END
+}
+
+int vxh_slot_wait(int thread) {
+    VXH_API_BEGIN
+    Context &c = ctx();
+    Slot *s = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(c.mutex);
+        if (thread < 0 || thread >= VXH_MAX_SLOTS) throw std::runtime_error("thread slot out of range");
+        s = c.slots[thread];
+    }
+    if (!s) return 0;
+    HIP_CHECK(hipStreamSynchronize(s->stream));
+    HIP_CHECK(hipStreamSynchronize(s->stream2));
+    VXH_API_END
+}
+
+// the slot's NEXT work starts after everything enqueued so far on `producer_stream` (the stream that writes the caller's device columns).
+// Without this call the slot is ordered after the legacy default stream only (order_after_producers): a column produced on a
+// non-blocking side stream is not ordered against the slot's kernels at all.
+int vxh_slot_wait_stream(int thread, void *producer_stream) {
+    VXH_API_BEGIN
+    ensure_device_ready();
+    Slot &s = get_slot(thread);
+    if ((hipStream_t)producer_stream == s.stream) return 0; // (the slot runs ON that stream: vxh_slot_set_stream)
+    hipEvent_t ev = nullptr;
+    HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    hipError_t e = hipEventRecord(ev, (hipStream_t)producer_stream);
+    if (e == hipSuccess) e = hipStreamWaitEvent(s.stream, ev, 0);
+    (void)hipEventDestroy(ev); // (released by the runtime once the wait has been satisfied)
+    HIP_CHECK(e);
+    VXH_API_END
+}
+
 int vxh_config_set(const char *key, int64_t value) {
     VXH_API_BEGIN
     Context &c = ctx();

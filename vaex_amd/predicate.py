@@ -107,6 +107,43 @@ class Predicate:
                     stack.append(np.abs(stack.pop()))
         return stack[0]
 
+    def torch_mask(self, tensors):
+        """the same predicate over DEVICE columns (torch tensors), one elementwise float64 operation per program step — each of them
+        (+ - * / negate, square as a * a, sqrt, abs) is correctly rounded on the device as in numpy, and no two are fused, so the rows
+        kept are numpy_mask's.  For the passes that take a ready-made keep-mask over device columns (minmax, percentiles, hashed groupby)."""
+        import torch
+        ops = {0: torch.lt, 1: torch.le, 2: torch.gt, 3: torch.ge, 4: torch.eq, 5: torch.ne}
+        bits = None
+        for t, (c, op, value) in enumerate(self.terms):
+            if t in self.programs:
+                stack = []
+                for step, sc, sv in self.programs[t]:
+                    if step == SEL_COL:
+                        stack.append(tensors[self.columns[sc]].to(torch.float64))
+                    elif step == SEL_CONST:
+                        first = next(iter(tensors.values()))
+                        stack.append(torch.tensor(float(sv), dtype=torch.float64, device=first.device))
+                    elif step in (SEL_ADD, SEL_SUB, SEL_MUL, SEL_DIV):
+                        b, a = stack.pop(), stack.pop()
+                        stack.append({SEL_ADD: torch.add, SEL_SUB: torch.sub, SEL_MUL: torch.mul, SEL_DIV: torch.true_divide}[step](a, b))
+                    elif step == SEL_NEG:
+                        stack.append(torch.neg(stack.pop()))
+                    elif step == SEL_SQUARE:
+                        a = stack.pop()
+                        stack.append(torch.mul(a, a))
+                    elif step == SEL_SQRT:
+                        stack.append(torch.sqrt(stack.pop()))
+                    else:
+                        stack.append(torch.abs(stack.pop()))
+                col = stack[0]
+            else:
+                col = tensors[self.columns[c]]
+            if isinstance(value, float) and not col.dtype.is_floating_point:
+                col = col.to(torch.float64)  # numpy compares an integer column with a float constant in float64 (torch would pick float32)
+            o = ops[op](col, value).to(torch.int32) << t
+            bits = o if bits is None else bits | o
+        return ((self.truth >> bits) & 1).to(torch.uint8)
+
     def numpy_mask(self, arrays):
         """the same predicate evaluated with numpy on host columns: what vaex itself does per chunk; used by the passes that take
         a ready-made mask (minmax, hashed groupby) and by the tests as the expected row set"""
@@ -121,13 +158,35 @@ class Predicate:
         return ((self.truth >> bits) & 1).astype(bool)
 
 
-def _constant(node):
+def _constant(node, depth=0):
+    """the value of a subtree made of numbers only, folded the way vaex's eval() folds it — Python semantics: integers stay exact
+    integers (`9007199254740992 + 1 + 1` is ...994, not the ...992 step-by-step float64 folding gives), `/` is true division — or None.
+    Function calls are never folded (vaex's sqrt / abs are numpy's)."""
+    if depth > 24:
+        return None
     if isinstance(node, ast.Constant) and isinstance(node.value, (int, float)) and not isinstance(node.value, bool):
         return node.value
     if isinstance(node, ast.UnaryOp) and isinstance(node.op, (ast.USub, ast.UAdd)):
-        v = _constant(node.operand)
+        v = _constant(node.operand, depth + 1)
         if v is not None:
             return -v if isinstance(node.op, ast.USub) else v
+    if isinstance(node, ast.BinOp) and isinstance(node.op, (ast.Add, ast.Sub, ast.Mult, ast.Div, ast.Pow)):
+        a = _constant(node.left, depth + 1)
+        b = _constant(node.right, depth + 1) if a is not None else None
+        if b is None:
+            return None
+        try:
+            if isinstance(node.op, ast.Pow):
+                if not -64 <= b <= 64 or isinstance(a, int) and abs(a) > 1 << 64:   # (an exact integer power can take forever)
+                    return None
+                v = a ** b
+            else:
+                v = {ast.Add: operator.add, ast.Sub: operator.sub, ast.Mult: operator.mul, ast.Div: operator.truediv}[type(node.op)](a, b)
+        except (ZeroDivisionError, OverflowError, ValueError):
+            return None   # (vaex's eval raises on these: not a selection the device takes)
+        if isinstance(v, complex) or isinstance(v, int) and v.bit_length() > 4096:
+            return None
+        return v
     return None
 
 
@@ -155,7 +214,10 @@ def compile_selection(expression, known_columns, virtual=None):
             raise Unsupported("expression nested too deeply")
         c = _constant(node)
         if c is not None:
-            steps.append((SEL_CONST, 0, float(c)))
+            try:
+                steps.append((SEL_CONST, 0, float(c)))   # (ONE rounding of the exactly folded constant, like numpy's conversion of a Python int)
+            except OverflowError:
+                raise Unsupported("integer constant too large for float64")
             return 1
         if isinstance(node, ast.Name):
             if node.id in virtual and node.id not in known_columns:
@@ -207,7 +269,10 @@ def compile_selection(expression, known_columns, virtual=None):
         first = next((c for o, c, _ in steps if o == SEL_COL), None)
         if first is None:
             raise Unsupported("a comparison between two constants")
-        t = (first, op, float(value))
+        try:
+            t = (first, op, float(value))
+        except OverflowError:
+            raise Unsupported("integer constant too large for float64")
         prog = tuple(steps)
         for i, old in enumerate(terms):
             if old == t and programs.get(i) == prog:

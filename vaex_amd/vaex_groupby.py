@@ -119,10 +119,10 @@ def _normalise_actions(df, keys, actions):
     return list(zip(grids.keys(), rec.recorded))
 
 
-def _translate(df, aggregate, columns):
-    """vaex aggregator descriptor -> binned.agg descriptor; the value column is entered into `columns`"""
+def _translate(df, aggregate, columns, predicates):
+    """vaex aggregator descriptor -> binned.agg descriptor; the value column is entered into `columns`, the compiled selection into `predicates`"""
     import vaex.agg
-    selection = _selection_of(df, aggregate, columns)
+    selection = _selection_of(df, aggregate, columns, predicates)
     if isinstance(aggregate, vaex.agg.AggregatorDescriptorBasic):
         kind = _AGG_NAMES.get(aggregate.name)
         if kind is None or aggregate.agg_args:
@@ -145,8 +145,11 @@ def _translate(df, aggregate, columns):
     return getattr(binned.agg, kind)(name, selection=selection)
 
 
-def _selection_of(df, aggregate, columns):
-    """the aggregation's selection as an expression of the device predicate subset (its columns entered into `columns`), or None"""
+def _selection_of(df, aggregate, columns, predicates):
+    """the aggregation's selection as an expression of the device predicate subset (its columns entered into `columns`), or None.
+    The Predicate compiled HERE — against the frame's real and virtual columns — is entered into `predicates` under the expression: the
+    binned.Frame that runs the call is seeded with it (_run), since it knows the plan's real columns only and could not inline `r < 1`
+    over a virtual column `r` by itself."""
     sel = getattr(aggregate, "selection", None)
     if sel is None or sel is False:
         return None
@@ -167,6 +170,7 @@ def _selection_of(df, aggregate, columns):
     for c in pred.columns:
         if c not in columns:
             columns[c] = _real_column(df, c, tuple(k for k in vaex_selection._NUMERIC), "selection column")[1]
+    predicates[sel] = pred
     return sel
 
 
@@ -194,7 +198,7 @@ def _key_column_like_vaex(values, source_kind=None):
 
 class _Plan:
     """what a df.groupby(by, agg) call needs from the device groupby, decided before a row is read"""
-    __slots__ = ("by", "agg", "sort", "srt", "asc", "columns", "key_names", "actions", "spec", "selection", "rows")
+    __slots__ = ("by", "agg", "sort", "srt", "asc", "columns", "key_names", "actions", "spec", "selection", "rows", "predicates")
 
 
 def _plan(df, by, agg, sort=False, ascending=True, row_limit=None, for_task=False):
@@ -230,11 +234,11 @@ def _plan(df, by, agg, sort=False, ascending=True, row_limit=None, for_task=Fals
     actions = _normalise_actions(df, key_names, agg)
     if not actions:
         raise _Decline("no aggregation")
-    spec = {}
+    spec, predicates = {}, {}
     for out_name, aggregate in actions:
         if out_name in spec or out_name in key_names:
             raise _Decline("duplicate output column")
-        spec[out_name] = _translate(df, aggregate, columns)
+        spec[out_name] = _translate(df, aggregate, columns, predicates)
     # a filtered frame (df[df.x > 0].groupby(...)): vaex compacts every chunk of every column with numpy before its two passes see a row
     # (vaex/execution.py:515-523); here the filter is a device predicate in every aggregator's keep-mask (vaex_amd/vaex_filter.py) and
     # groups without a row inside it are dropped — when it is in the predicate subset over real numeric columns; else vaex's own code
@@ -245,6 +249,7 @@ def _plan(df, by, agg, sort=False, ascending=True, row_limit=None, for_task=Fals
         if pred is None:
             raise _Decline("filtered DataFrame (filter outside the device predicate subset)")
         selection = vaex_filter.filter_expression(df)
+        predicates[selection] = pred
         for c in pred.columns:
             if c not in columns:
                 columns[c] = _real_column(df, c, tuple(k for k in vaex_filter._NUMERIC if k != "bool"), "filter column")[1]
@@ -252,6 +257,7 @@ def _plan(df, by, agg, sort=False, ascending=True, row_limit=None, for_task=Fals
     plan.by, plan.agg, plan.sort, plan.srt, plan.asc = by, agg, sort, srt, asc
     plan.columns, plan.key_names, plan.actions, plan.spec, plan.selection = columns, key_names, actions, spec, selection
     plan.rows = len(next(iter(columns.values())))
+    plan.predicates = predicates
     return plan
 
 
@@ -260,6 +266,7 @@ def _run(plan, frame):
     key_names = plan.key_names
     try:
         frame.last_groupby_info = None
+        frame._predicates.update(plan.predicates)   # (compiled against the DataFrame: virtual columns are inlined there)
         return frame.groupby(key_names if len(key_names) > 1 else key_names[0], plan.spec, selection=plan.selection)
     except (NotImplementedError, ValueError) as e:
         raise _Decline(str(e))
@@ -336,7 +343,8 @@ def _frame_for(df, columns):
             hit = _device_copies.get(key)
             if hit is None or hit[0] is not base:
                 import torch
-                hit = (base, torch.from_numpy(np.ascontiguousarray(base)).cuda())
+                import vaex_amd
+                hit = (base, torch.from_numpy(np.ascontiguousarray(base)).to(f"cuda:{int(vaex_amd.superagg.config_get('device'))}"))
                 _device_copies[key] = hit
             cols[name] = hit[1]
         else:
@@ -352,7 +360,8 @@ def _frame_for(df, columns):
             import vaex_amd
             sa = vaex_amd.superagg
             total = sum(cols[name].nbytes for name in host)
-            free, _ = torch.cuda.mem_get_info(int(sa.config_get("device")))   # (the LIBRARY's device, vxh_set_device: not necessarily torch's current one)
+            device = int(sa.config_get("device"))   # (the LIBRARY's device, vxh_set_device: not necessarily torch's current one)
+            free, _ = torch.cuda.mem_get_info(device)
             # (no "bool": a bool key is told from a uint8 one by its numpy dtype, so such frames stay on the host path — decided HERE,
             #  before anything crosses PCIe; ADVICE r4: the check used to come after the upload)
             kinds = {"int8": torch.int8, "int16": torch.int16, "int32": torch.int32, "int64": torch.int64, "uint8": torch.uint8,
@@ -363,7 +372,7 @@ def _frame_for(df, columns):
                 jobs = []
                 for name in host:
                     a = np.ascontiguousarray(cols[name])
-                    t = torch.empty(a.shape, dtype=kinds[a.dtype.name], device="cuda")
+                    t = torch.empty(a.shape, dtype=kinds[a.dtype.name], device=f"cuda:{device}")
                     jobs.append((a, t))
                     up[name] = t
                 if len(jobs) > 1:   # (the columns cross PCIe side by side: upload() releases the GIL)
@@ -411,14 +420,15 @@ class DeviceCollector:
             if ar.dtype.name not in _TORCH_KINDS:
                 raise _Decline(f"delayed groupby: column {name!r} has dtype {ar.dtype} (no device column of that type)")
         total = sum(ar.dtype.itemsize for ar in plan.columns.values()) * capacity
-        free, _ = torch.cuda.mem_get_info(int(self.sa.config_get("device")))
+        device = int(self.sa.config_get("device"))   # (the LIBRARY's device, vxh_set_device: the kernels run there, so the columns live there)
+        free, _ = torch.cuda.mem_get_info(device)
         if total * 4 >= free:
             raise _Decline("delayed groupby: the columns do not fit the device next to the partition queues")
         self.capacity = capacity
         self.dtypes = {name: ar.dtype for name, ar in plan.columns.items()}
         # (allocated here, on the scheduling thread, and held until the task has run or is dropped: an allocation from inside the pass — the
         #  pool's threads — ended in a GPU memory fault on the one box it was tried on)
-        self.cols = {name: torch.empty(capacity, dtype=getattr(torch, ar.dtype.name), device="cuda") for name, ar in plan.columns.items()}
+        self.cols = {name: torch.empty(capacity, dtype=getattr(torch, ar.dtype.name), device=f"cuda:{device}") for name, ar in plan.columns.items()}
         self.rows = 0
         self.lock = threading.Lock()
 
@@ -551,9 +561,10 @@ def install(vaex_module, state):
                 return
             try:
                 self.collector.append({name: _block_as_numpy(b) for name, b in zip(self.plan.columns, blocks)})
-            except (RuntimeError, MemoryError) as e:
-                # (HBM exhausted, a HIP error, a chunk the plan did not expect: the pass goes on for the caller's other tasks; this task is
-                #  answered by vaex's own groupby when the pass is over)
+            except Exception as e:
+                # (HBM exhausted, a HIP error, a chunk the plan did not expect — a TypeError / ValueError from its conversion included: the
+                #  pass goes on for the caller's other tasks; this task is answered by vaex's own groupby when the pass is over.  An exception
+                #  leaving process() would cancel EVERY task of the pass: vaex/execution.py:567-570)
                 self.failed = e
 
         def reduce(self, others):
