@@ -11,6 +11,11 @@ finish mean = sum/count.  Inputs are synthetic N(0,1)/N(3,2) columns generated o
 
 `--gpus N` with N > 1 and no torchrun environment (WORLD_SIZE unset) makes this process spawn the N ranks itself
 (torch.multiprocessing, one process per GPU, RCCL); under `torch.distributed.run` the ranks come from the environment.
+Rows per GPU (weak scaling): 1e9 at N = 1 — BASELINE configs[1], the BENCH line — and 1.25e9 at N > 1, the shard of configs[4]
+(1e10 rows row-sharded over 8 GPUs: `--gpus 8` runs exactly that config; 2 and 4 GPUs the same shard).  `--total-rows T` splits ONE
+table over the ranks instead (strong scaling).  At N > 1 the line also carries north_star's target sentence (2-D count(*), 16 B/row)
+on the same shards as `configs[0]`.  `--backend gloo` sends the grids through host buffers, so the ranks may share a GPU: the dry run
+of launcher, sharding, reduce and JSON on a one-GPU box (tests/test_bench_contract.py).
 
 Besides `value` (N(0,1) data, the hot box warm) the N=1 line carries the two unflattering numbers of the same pass:
 `value_uniform` (x,y ~ U(-4,4): the densest box holds only ~15 % of the rows, the rest goes through the partition queues) and `value_cold` (the hot box
@@ -40,7 +45,11 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--rows", type=float, default=1e9, help="rows per GPU (weak scaling)")
+    ap.add_argument("--rows", type=float, default=None, help="rows per GPU (weak scaling).  Default: 1e9 at N = 1 (BASELINE configs[1]); 1.25e9 at N > 1 — the "
+                    "shard of configs[4] (1e10 rows row-sharded over 8 GPUs: N = 8 runs exactly that config, N = 2 / 4 the same shard on fewer GPUs)")
+    ap.add_argument("--total-rows", type=float, default=None, help="rows of the WHOLE job, split evenly over the ranks (strong scaling; overrides --rows)")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="torch.distributed backend at N > 1: nccl (= RCCL over xGMI, one GPU per rank) or gloo "
+                    "(the grids cross through host buffers; the ranks may then SHARE a GPU — the N = 2 dry run of launcher, sharding, reduce and JSON on a one-GPU box)")
     ap.add_argument("--shape", type=int, default=256)
     ap.add_argument("--cpu-rows", type=float, default=1e8, help="rows of the bounded CPU-baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
@@ -405,6 +414,27 @@ def _spawned(local_rank, args, port):
     run(args)
 
 
+ROWS_CONFIG1 = 1_000_000_000      # BASELINE configs[1]: 1e9 rows on one GPU
+ROWS_CONFIG4_SHARD = 1_250_000_000  # BASELINE configs[4]: 1e10 rows over 8 GPUs
+
+
+def rows_of_rank(args, rank, world):
+    """(rows of this rank, scaling, workload name).  Weak scaling by default: every rank bins the same number of rows — configs[1]'s 1e9 at N = 1 (the
+    BENCH line), configs[4]'s 1.25e9-row shard at N > 1 (N = 8: the config itself).  --total-rows: one table split over the ranks (strong)."""
+    if args.total_rows is not None:
+        from vaex_amd.dist import shard_rows
+        total = int(args.total_rows)
+        i1, i2 = shard_rows(total, rank, world)
+        return i2 - i1, "strong", f"{total:.4g}-row float64 x,y,v table row-sharded over {world} GPU(s) (--total-rows; strong scaling)"
+    if args.rows is not None:
+        rows = int(args.rows)
+        return rows, "weak", f"{rows:.4g}-row float64 x,y,v per GPU (--rows)"
+    if world == 1:
+        return ROWS_CONFIG1, "weak", "1e9-row float64 x,y,v (BASELINE configs[1])"
+    what = "BASELINE configs[4]: 1e10 rows row-sharded over 8 GPUs" if world == 8 else f"the 1.25e9-row shard of BASELINE configs[4] on {world} GPUs ({world * 1.25:.4g}e9 rows)"
+    return ROWS_CONFIG4_SHARD, "weak", f"1.25e9-row float64 x,y,v per GPU ({what})"
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -438,12 +468,18 @@ def run(args):
     sa = vaex_amd.superagg
     if not torch.cuda.is_available() or sa.device_count() == 0:
         raise SystemExit("bench.py needs a GPU (no CPU fallback in the product path)")
-    torch.cuda.set_device(local_rank)
-    sa.set_device(local_rank)
+    # one GPU per rank; under gloo the ranks may outnumber the GPUs (the dry run of the N > 1 path on a one-GPU box) and share them
+    device = local_rank if args.backend == "nccl" else local_rank % sa.device_count()
+    torch.cuda.set_device(device)
+    sa.set_device(device)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    rows = int(args.rows)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group("gloo")
+    rows, scaling, workload = rows_of_rank(args, rank, world)
     shape = args.shape
+    reduce_dev = "cuda" if args.backend == "nccl" else "cpu"   # where the small timing / row-count reductions live
 
     gen = torch.Generator(device="cuda").manual_seed(1234 + rank)
     x = torch.randn(rows, dtype=torch.float64, device="cuda", generator=gen)
@@ -505,12 +541,51 @@ def run(args):
         c, mean = step()
     barrier()
     elapsed = time.perf_counter() - t0
+    total_rows = rows
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=reduce_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    total_rows = rows * world
+        tr = torch.tensor([rows], dtype=torch.int64, device=reduce_dev)
+        dist.all_reduce(tr, op=dist.ReduceOp.SUM)
+        total_rows = int(tr.item())
     assert int(count.get_result().sum()) == total_rows, "count conservation violated"
+    main_kernel = sa.last_kernel(0)
+
+    # ---- N > 1: north_star's target sentence (2-D count(*) on 256x256, 16 B/row) on the same shards, the same clock and the same reduce ----
+    count2d = None
+    if world > 1 and not args.no_configs:
+        c2 = sa.AggCount_int64(grid, 1, 1)
+        c2.clear_data_mask(0)
+        k2 = []
+
+        def step2():
+            c2.reset()
+            sa.timer_start(0)
+            grid.bin(0, [c2], rows)
+            k2.append(sa.timer_stop(0))
+            vdist.allreduce_aggs([c2])
+            return c2.get_result()
+        for _ in range(max(1, args.warmup)):
+            step2()
+        k2.clear()
+        barrier()
+        t2 = time.perf_counter()
+        for _ in range(args.steps):
+            r2 = step2()
+        barrier()
+        el2 = time.perf_counter() - t2
+        t = torch.tensor([el2], dtype=torch.float64, device=reduce_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el2 = float(t.item())
+        assert int(r2.sum()) == total_rows, "count conservation violated (count2d)"
+        k2_ms = float(np.mean(k2))
+        count2d = {"config": "count2d", "what": f"2-D count(*) of float64 x,y on a {shape}x{shape} grid (north_star's target sentence), row-sharded x{world}, one all-reduce of the grid per step",
+                   "rows": total_rows, "rows_per_s": total_rows * args.steps / el2, "ms": el2 / args.steps * 1e3, "kernel_ms": k2_ms, "kernel": sa.last_kernel(0),
+                   "roofline": {"bound": "hbm", "bytes_per_row": 16, "achieved": 16 * rows / (k2_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                "frac": 16 * rows / (k2_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "frac_incl_allreduce": 16 * total_rows / (el2 / args.steps) / 1e9 / (world * HBM_PEAK_GBS),
+                                "note": "frac: rank 0's kernels against one GPU's peak; frac_incl_allreduce: the whole step on the slowest rank against all GPUs' peak"}}
+        del c2
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -522,17 +597,18 @@ def run(args):
         traffic = traffic_source = None
         for tname in ("r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
             tpath = os.path.join(ROOT, "profiles", tname)
-            if os.path.exists(tpath) and sa.last_kernel(0).startswith("part_scatter") and shape == 256:
+            if os.path.exists(tpath) and main_kernel.startswith("part_scatter") and shape == 256:
                 traffic = json.load(open(tpath))["hbm_bytes_per_row"] * rows
                 traffic_source = "profiles/" + tname + " (rocprofv3 --pmc passes of this command, FETCH_SIZE x2 on gfx950; not a same-run counter)"
                 break
         out = {
             "metric": "rows/sec, 2-D count+mean on 256x256 grid (count(*), sum(v), count(v) fused), float64 x,y,v",
             "value": value, "unit": "rows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic (device-generated N(0,1) x,y; N(3,2) v; limits [-4,4])",
-            "config": {"workload": f"{rows:.3g}-row float64 x,y,v per GPU: count+sum+mean on {shape}x{shape} grid, HBM-resident (BASELINE configs[1])",
-                       "rows_per_gpu": rows, "shape": shape, "kernel": sa.last_kernel(0), "parallelism": f"row-sharded x{world}, RCCL all-reduce of 3 grids" if world > 1 else "one GPU: nothing to reduce"},
+            "config": {"workload": f"{workload}: count+sum+mean on {shape}x{shape} grid, HBM-resident",
+                       "rows_per_gpu": rows, "total_rows": total_rows, "shape": shape, "kernel": main_kernel, "backend": args.backend if world > 1 else None,
+                       "parallelism": (f"row-sharded x{world}, " + ("RCCL all-reduce of 3 grids (vxh_allreduce)" if args.backend == "nccl" else "gloo all-reduce of 3 grids through host buffers (dry run: ranks may share a GPU)")) if world > 1 else "one GPU: nothing to reduce"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "frac_of_measured_copy_rate": achieved / 6290.0,  # (6.29 TB/s float4 copy: MI355X_MICROARCH.md)
                          "traffic": traffic, "traffic_source": traffic_source, "kernel_ms": k_ms, "bytes_per_row": BYTES_PER_ROW, "rows_per_launch": rows},
@@ -543,10 +619,10 @@ def run(args):
                 out["settle_trace"] = settle_trace[::max(1, len(settle_trace) // 60)]
         if world > 1:
             # rank 0's kernel time above excludes the reduce; this one is the whole step on the slowest rank against all GPUs' peak
-            out["roofline"]["frac_incl_allreduce"] = BYTES_PER_ROW * rows * world / (elapsed / args.steps) / 1e9 / (world * HBM_PEAK_GBS)
+            out["roofline"]["frac_incl_allreduce"] = BYTES_PER_ROW * total_rows / (elapsed / args.steps) / 1e9 / (world * HBM_PEAK_GBS)
             out["roofline"]["allreduce_ms"] = float(np.mean(allreduce_ms))
             out["rccl_ranks"] = dist.get_world_size()
-            out["scaling_note"] = "weak scaling: every rank bins its own rows_per_gpu rows; one RCCL all-reduce per grid and step"
+            out["scaling_note"] = ("weak scaling: every rank bins its own rows_per_gpu rows" if scaling == "weak" else "strong scaling: one table split over the ranks") + "; one all-reduce per grid and step"
         if world == 1 and not args.no_extra:
             extra_steps = max(3, min(args.steps, 5))
 
@@ -629,6 +705,8 @@ def run(args):
                       "sum_cells_over_tol": int(bad_sum.sum()), "rows_counted": [int(g[0].sum()), int(cpu_res[0].sum())]}
             out["cpu_baseline"]["parity_on_sample"] = not any(detail[k] for k in ("count_cells_differ", "countv_cells_differ", "sum_cells_over_tol"))
             out["cpu_baseline"]["parity_detail"] = detail
+        if count2d is not None:
+            out["configs"] = [count2d]
         if world == 1 and not args.no_configs:
             del x, y, v
             torch.cuda.empty_cache()
