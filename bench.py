@@ -234,9 +234,10 @@ def other_configs(sa, torch, rows, sample_rows):
     stream_ms = [0.0]
 
     first_call = [0.0, 0.0]
+    first_detail = [None]
     process_first = [None]
 
-    def timed(fn, reps=3, prime=None):
+    def timed(fn, reps=3, prime=None, info=None):
         # `prime`: the same call over COPIES of the columns (other column objects) first, so that what a PROCESS pays once at this size —
         # code objects loaded on first launch, gigabytes of queue scratch and the pinned result buffers allocated (0.5-0.7 s for a
         # 1e9-row groupby: `ms_first_call_in_process`) — is not booked on the columns: `ms_first_call` is what a later call over FRESH
@@ -252,13 +253,44 @@ def other_configs(sa, torch, rows, sample_rows):
         # the FIRST call over fresh columns is timed too: it pays what the later ones find remembered per column
         # object — the groupby's exact key-range pass (vxh_minmax_int, 8 B/row) and NaN scan of the value column, the hot-box sample —
         # and goes on the line as `ms_first_call` / `kernel_ms_first_call`; `ms` / `kernel_ms` are the best of the warm calls after it
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        sa.timer_start(0)
-        fn()
-        sa.timer_stop(0)
-        first_call[1] = sa.timer_kernels_ms(0)
-        first_call[0] = (time.perf_counter() - t0) * 1e3
+        def first(label):
+            # the first call with a host clock around every library call it makes and the block pool's hipMalloc / hipFree counters around
+            # it: a first call far above the warm ones (the driver's round-5 line: 464 ms against 11) then says on the line itself where the
+            # time went — a library call's host time, the runtime's allocator, or neither (the device queue itself stalled)
+            names = [nm for nm in ("groupby_run", "scan_key_value", "minmax_int", "minmax", "finish") if hasattr(sa, nm)]
+            saved, log = {nm: getattr(sa, nm) for nm in names}, []
+
+            def wrap(nm, f):
+                def g_(*a, **kw):
+                    tw = time.perf_counter()
+                    try:
+                        return f(*a, **kw)
+                    finally:
+                        log.append([nm, round((time.perf_counter() - tw) * 1e3, 3)])
+                return g_
+            pool0 = {k_: sa.config_get(k_) for k_ in ("pool_mallocs", "pool_malloc_bytes", "pool_malloc_us", "pool_frees", "pool_free_us")}
+            free0 = torch.cuda.mem_get_info()[0]
+            for nm in names:
+                setattr(sa, nm, wrap(nm, saved[nm]))
+            try:
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                sa.timer_start(0)
+                r_ = fn()
+                sa.timer_stop(0)
+                k_first = sa.timer_kernels_ms(0)
+                ms_first = (time.perf_counter() - t0) * 1e3
+            finally:
+                for nm in names:
+                    setattr(sa, nm, saved[nm])
+            detail = {"label": label, "ms": round(ms_first, 3), "kernel_ms": round(k_first, 3), "library_calls_ms": log,
+                      "pool": {k_: sa.config_get(k_) - v_ for k_, v_ in pool0.items()}, "pool_cached_gb": round(sa.config_get("pool_cached_bytes") / 2**30, 2),
+                      "hbm_free_gb_before": round(free0 / 2**30, 1)}
+            if info is not None:   # (the groupby's own account of THIS call: retries, buckets, kernel times)
+                detail["groupby_info"] = {k_: (round(v_, 3) if isinstance(v_, float) else v_) for k_, v_ in (info() or {}).items()}
+            del r_
+            return ms_first, k_first, detail
+        first_call[0], first_call[1], first_detail[0] = first("first call over fresh columns")
         best, best_k = float("inf"), float("inf")
         for _ in range(reps):
             torch.cuda.synchronize()
@@ -276,7 +308,7 @@ def other_configs(sa, torch, rows, sample_rows):
     def line(config, what, bytes_per_row, wall, k_ms, kernel, parity):
         gbs = bytes_per_row * rows / (k_ms * 1e-3) / 1e9
         return {"config": config, "what": what, "rows": rows, "rows_per_s": rows / wall, "ms": wall * 1e3, "kernel_ms": k_ms, "stream_ms": stream_ms[0], "kernel": kernel,
-                "ms_first_call": first_call[0], "kernel_ms_first_call": first_call[1], "ms_first_call_in_process": process_first[0],
+                "ms_first_call": first_call[0], "kernel_ms_first_call": first_call[1], "ms_first_call_in_process": process_first[0], "first_call": first_detail[0],
                 "roofline": {"bound": "hbm", "bytes_per_row": bytes_per_row, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS},
                 "parity_on_sample": parity}
 
@@ -373,7 +405,8 @@ def other_configs(sa, torch, rows, sample_rows):
         keys = k if flavour == "dense" else (k * 2654435761) % (1 << 40)
         torch.cuda.synchronize()
         df = Frame(dict(k=keys, v=v))
-        res, wall, k_ms = timed(lambda: df.groupby("k", spec), prime=lambda: Frame(dict(k=keys.clone(), v=v.clone())).groupby("k", spec))
+        res, wall, k_ms = timed(lambda: df.groupby("k", spec), prime=lambda: Frame(dict(k=keys.clone(), v=v.clone())).groupby("k", spec),
+                                info=lambda: getattr(df, "last_groupby_info", None))
         kernel = sa.last_kernel(0) if flavour == "dense" else "gb_scatter+gb_reduce"
         info = getattr(df, "last_groupby_info", None) or {}
         parity = None

@@ -92,6 +92,9 @@ int vxh_device_count(int *count);
 int vxh_set_device(int device);
 /* block until all work enqueued by this library has finished */
 int vxh_synchronize(void);
+/* load the library's code objects and create thread slot 0 now instead of inside the first compute call (the reference has no
+ * counterpart: a host that imports vaex.superagg has its machine code mapped by the dynamic loader) */
+int vxh_warmup(void);
 /* run slot `thread`'s work on a caller-owned hipStream_t (NULL = library-owned stream) */
 int vxh_slot_set_stream(int thread, void *hip_stream);
 /* lifetime of VXH_MEM_DEVICE pointers (see "Data pointers" above; the reference has no counterpart — its bin() is synchronous,

@@ -123,6 +123,13 @@ def install(vaex_module=None, legacy=True, hash_sets=True, chunk_size="auto", gr
     if "backend" in _installed:
         return _installed["backend"]
     cpu_module = vaex_module.superagg
+    # the kernels' code objects and thread slot 0 now, not inside the user's first df.count / df.groupby (a fresh process paid 0.2-0.6 s
+    # there: profiles/r06_process_first.txt); without a device install() still succeeds — every compute call then raises, as before
+    try:
+        if superagg.device_count() > 0:
+            superagg.warmup()
+    except RuntimeError:
+        pass
     backend = _Backend(superagg, cpu_module)
     _installed.update(backend=backend, cpu_module=cpu_module, vaex=vaex_module, task_cls=vaex.cpu.TaskPartAggregation)
     vaex_module.superagg = backend

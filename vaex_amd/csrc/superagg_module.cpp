@@ -863,6 +863,7 @@ PYBIND11_MODULE(superagg, m) {
     m.attr("AUX_SLOT") = (int)VXH_AUX_SLOT; // first thread slot outside the host pool's indices (include/vaex_hip.h)
     m.def("device_count", []() { int n = 0; check(vxh_device_count(&n)); return n; });
     m.def("set_device", [](int d) { check(vxh_set_device(d)); });
+    m.def("warmup", []() { py::gil_scoped_release r; check(vxh_warmup()); }, "load the kernels' code objects and create thread slot 0 now (vaex_amd.install() does)");
     m.def("synchronize", []() {
         { py::gil_scoped_release r; check(vxh_synchronize()); }
         collect_all_retired();

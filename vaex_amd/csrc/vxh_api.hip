@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -119,6 +121,9 @@ struct DevPool {
     std::map<void *, size_t> size_of;          // every block this pool handed out
     size_t cached = 0;
     static constexpr size_t kMaxCached = 24ull << 30; // of 288 GB
+    // what the runtime was asked for behind the pool (vxh_config_get "pool_*"): a call whose host clock is far above its kernels' time
+    // can be told apart — hipMalloc / hipFree of gigabytes block the host for tens to hundreds of milliseconds
+    std::atomic<uint64_t> mallocs{0}, malloc_bytes{0}, malloc_us{0}, frees{0}, free_us{0};
 };
 DevPool &dev_pool() {
     static DevPool *p = new DevPool(); // (never destroyed: blocks may come back during interpreter shutdown)
@@ -150,12 +155,15 @@ void *vxh_pool_alloc(size_t bytes) {
         }
     }
     void *p = nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
     hipError_t e = hipMalloc(&p, cls);
     if (e != hipSuccess) { // out of memory: give the cached blocks back and try once more
         (void)hipGetLastError();
         vxh_pool_trim();
         HIP_CHECK(hipMalloc(&p, cls));
     }
+    P.mallocs++; P.malloc_bytes += cls;
+    P.malloc_us += (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
     std::lock_guard<std::mutex> lock(P.mutex);
     P.size_of[p] = cls;
     return p;
@@ -174,7 +182,10 @@ void vxh_pool_free(void *p) {
         }
         if (it != P.size_of.end()) P.size_of.erase(it);
     }
+    const auto t0 = std::chrono::steady_clock::now();
     (void)hipFree(p);
+    P.frees++;
+    P.free_us += (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
 }
 
 void vxh_pool_trim(void) {
@@ -186,7 +197,22 @@ void vxh_pool_trim(void) {
         P.free_blocks.clear();
         P.cached = 0;
     }
+    const auto t0 = std::chrono::steady_clock::now();
     for (void *p : drop) (void)hipFree(p);
+    P.frees += drop.size();
+    P.free_us += (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
+}
+
+int64_t vxh_pool_stat(int what) {
+    DevPool &P = dev_pool();
+    switch (what) {
+    case 0: return (int64_t)P.mallocs.load();
+    case 1: return (int64_t)P.malloc_bytes.load();
+    case 2: return (int64_t)P.malloc_us.load();
+    case 3: return (int64_t)P.frees.load();
+    case 4: return (int64_t)P.free_us.load();
+    default: { std::lock_guard<std::mutex> lock(P.mutex); return (int64_t)P.cached; }
+    }
 }
 
 void vxh_timer_lap(Slot &slot) {
@@ -1839,6 +1865,21 @@ int vxh_slot_set_stream(int thread, void *hip_stream) {
     VXH_API_END
 }
 
+// What a process otherwise pays inside its FIRST call (a first 1e9-row groupby took 0.6-1.0 s, its tenth 10 ms): the
+// runtime loads a translation unit's code object when the first of its kernels is launched (tens of milliseconds each for the big ones),
+// and thread slot 0's streams / events are created on first use.  vaex_amd.install() calls this once, before the first task exists.
+int vxh_warmup(void) {
+    VXH_API_BEGIN
+    ensure_device_ready();
+    (void)get_slot(0);
+    vxh_preload_kernels();
+    vxh_preload_groupby();
+    vxh_preload_finish();
+    vxh_preload_select();
+    vxh_preload_hashmap();
+    VXH_API_END
+}
+
 // ---- lifetime of VXH_MEM_DEVICE pointers (include/vaex_hip.h "Data pointers") -----------------------------------------------
 // vxh_grid_bin over device columns returns with its kernels enqueued: the columns are read until the slot's streams have drained.
 int vxh_slot_busy(int thread, int *busy) {
@@ -1975,6 +2016,12 @@ int vxh_config_get(const char *key, int64_t *value) {
     else if (k == "convert_binners") *value = c.cfg_convert_binners;
     else if (k == "converted_calls") *value = (int64_t)get_slot(0).conv_calls;
     else if (k == "stage_bytes") *value = c.cfg_stage_bytes;
+    else if (k == "pool_mallocs") *value = vxh_pool_stat(0);
+    else if (k == "pool_malloc_bytes") *value = vxh_pool_stat(1);
+    else if (k == "pool_malloc_us") *value = vxh_pool_stat(2);
+    else if (k == "pool_frees") *value = vxh_pool_stat(3);
+    else if (k == "pool_free_us") *value = vxh_pool_stat(4);
+    else if (k == "pool_cached_bytes") *value = vxh_pool_stat(5);
     else if (k == "feeder") *value = c.cfg_feeder;
     else if (k == "cache_bytes") *value = c.cfg_cache_bytes;
     else if (k == "slab_log2") *value = c.cfg_slab_log2;

@@ -393,3 +393,9 @@ int vxh_finish(int n_out, const int *ops, vxh_agg *const *in0, vxh_agg *const *i
 }
 
 } // extern "C"
+
+void vxh_preload_finish(void) {
+    hipFuncAttributes a;
+    (void)hipFuncGetAttributes(&a, (const void *)scan_key_value_kernel);
+    (void)hipGetLastError();
+}

@@ -1162,3 +1162,9 @@ int vxh_groupby_column(vxh_groupby *g, int value_index, int which, void *out_hos
 }
 
 } // extern "C"
+
+void vxh_preload_groupby(void) {
+    hipFuncAttributes a;
+    (void)hipFuncGetAttributes(&a, (const void *)gb_append_heavy);
+    (void)hipGetLastError();
+}

@@ -447,3 +447,9 @@ int vxh_hashmap_keys(vxh_hashmap *m, int64_t *keys_out) {
 }
 
 } // extern "C"
+
+void vxh_preload_hashmap(void) {
+    hipFuncAttributes a;
+    (void)hipFuncGetAttributes(&a, (const void *)hm_fill);
+    (void)hipGetLastError();
+}

@@ -282,6 +282,13 @@ void vxh_timer_lap(Slot &slot);
 // their columns on another stream hand that stream over with vxh_slot_set_stream.
 void order_after_producers(Slot &slot);
 
+// code-object preload hooks, one per translation unit (vxh_warmup)
+void vxh_preload_kernels(void);
+void vxh_preload_hashmap(void);
+void vxh_preload_select(void);
+void vxh_preload_finish(void);
+void vxh_preload_groupby(void);
+
 // hash map hooks (vxh_hashmap.hip)
 int64_t vxh_hashmap_size_for_binner(vxh_hashmap *map);
 void vxh_hashmap_fill_binner_desc(vxh_hashmap *map, BinnerDesc *bd);

@@ -231,3 +231,9 @@ void vxh_launch_sel_eval(const SelArgs &A, hipStream_t stream) {
     const int blocks = (int)std::min<uint64_t>((quads + 255) / 256, 256 * 16);
     hipLaunchKernelGGL(sel_eval, dim3(blocks), dim3(256), 0, stream, A);
 }
+
+void vxh_preload_select(void) {
+    hipFuncAttributes a;
+    (void)hipFuncGetAttributes(&a, (const void *)product_f64);
+    (void)hipGetLastError();
+}
