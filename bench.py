@@ -407,8 +407,9 @@ def other_configs(sa, torch, rows, sample_rows):
         df = Frame(dict(k=keys, v=v))
         res, wall, k_ms = timed(lambda: df.groupby("k", spec), prime=lambda: Frame(dict(k=keys.clone(), v=v.clone())).groupby("k", spec),
                                 info=lambda: getattr(df, "last_groupby_info", None))
-        kernel = sa.last_kernel(0) if flavour == "dense" else "gb_scatter+gb_reduce"
         info = getattr(df, "last_groupby_info", None) or {}
+        # (round 6: the dense range takes the fused pass too — with a direct LDS table; `info` is that pass's own account, absent for the slab-partitioned pair)
+        kernel = ("gb_scatter+gb_reduce" + ("_direct" if info.get("direct_table") else "")) if "ms_scatter" in info else sa.last_kernel(0)
         parity = None
         if ref is not None:
             head = Frame(dict(k=keys[:m], v=v[:m])).groupby("k", spec)

@@ -458,7 +458,8 @@ uint64_t vxh_groupby_size(const vxh_groupby *g);
 /* one result column (vxh_groupby_column_kind; value_index selects the value column for COUNT..STD) into a host array of
  * vxh_groupby_size elements of 8 bytes */
 int vxh_groupby_column(vxh_groupby *g, int value_index, int which, void *out_host);
-/* diagnostics: 0 buckets, 1 LDS slots per bucket, 2 retries, 3 / 4 / 5 = ms of the scatter / reduce / sort kernels, 6 = 1 when the pass moved 12-byte records, 7 = heavy keys peeled inside the pass */
+/* diagnostics: 0 buckets, 1 LDS slots per bucket, 2 retries, 3 / 4 / 5 = ms of the scatter / reduce / sort kernels, 6 = 1 when the pass moved 12-byte records, 7 = heavy keys peeled inside the pass,
+ * 8 = 1 when gb_reduce indexed its LDS table with the record's remainder (key ranges of <= 2^22 cells: no keys in the table, no probe) */
 int vxh_groupby_info(const vxh_groupby *g, int what, double *value_out);
 
 /* ---- multi-GPU reduce ------------------------------------------------------------------ */

@@ -483,3 +483,102 @@ def test_groupby_run_compact_records(sa, gpu_ready, case):
     import torch
     dev = sa.groupby_run(torch.from_numpy(keys).cuda(), [torch.from_numpy(v).cuda()], dt, keep=None if keep is None else torch.from_numpy(keep).cuda(), key_range=kr)
     _check(sa, dev, want)
+
+
+@pytest.mark.parametrize("cells,kmin,dtype,keep_some", [(1_000_000, 0, "int64", False), (300_000, -777, "int64", True), (1 << 22, 5, "int64", False),
+                                                          ((1 << 22) + 1, 0, "int64", False), (70_000, -35_000, "int32", True), (20_001, 1 << 40, "int64", False)])
+def test_narrow_key_ranges_index_the_lds_table_directly(sa, gpu_ready, cells, kmin, dtype, keep_some):
+    """round 6: with the key range known and <= 2^22 cells, gb_reduce's table is indexed by the compact record's remainder — the mix is a
+    bijection of the range, so (bucket, remainder) is a perfect hash: no keys in the table, no probe, no overflow (`direct_table`).  Same
+    results as numpy and as the probing table on the same rows; one cell beyond 2^22 the probing table takes over by itself."""
+    rng = np.random.default_rng(cells % 9973)
+    n = 2_500_000
+    k = (rng.integers(0, cells, n) + kmin).astype(dtype)
+    k[:2] = [kmin, kmin + cells - 1]                     # the range's two ends exist
+    k[100:50_000] = kmin + cells // 3                    # a key with 2 % of the rows (not peeled: the caller names no heavy key)
+    v = rng.normal(3, 2, n)
+    v[rng.random(n) < 0.01] = np.nan
+    keep = None
+    if keep_some:
+        keep = (rng.random(n) < 0.7).astype(np.uint8)
+        keep[::333] = 2                                   # (not 1: dropped)
+    kr = (int(kmin), int(kmin + cells - 1))
+    res = sa.groupby_run(k, [v], _DT[dtype], keep=keep, key_range=kr)
+    kept = np.ones(n, dtype=bool) if keep is None else keep == 1
+    want = _want(k[kept], [v[kept]])
+    _check(sa, res, want)
+    info = res.info()
+    assert info["compact_records"] == 1 and info["retries"] == 0, info
+    assert info["direct_table"] == (1 if cells <= (1 << 22) else 0), info
+    sa.config_set("gb_direct", 0)
+    try:
+        probing = sa.groupby_run(k, [v], _DT[dtype], keep=keep, key_range=kr)
+    finally:
+        sa.config_set("gb_direct", 1)
+    assert probing.info()["direct_table"] == 0
+    _check(sa, probing, want)
+    np.testing.assert_array_equal(np.asarray(res.column(sa.GB_KEYS)), np.asarray(probing.column(sa.GB_KEYS)))
+    np.testing.assert_array_equal(np.asarray(res.column(sa.GB_COUNT, 0)), np.asarray(probing.column(sa.GB_COUNT, 0)))
+
+
+def test_dense_ranges_take_the_fused_pass_with_the_direct_table(sa, gpu_ready):
+    """Frame.groupby over a dense 1e6-key range (BASELINE configs[3]) on device columns: the fused pass with the direct table answers (one value
+    column), the slab-partitioned BinnerOrdinal pass still answers what is outside it (two value columns, min / max) — same groups either way"""
+    import torch
+    from vaex_amd.binned import Frame, agg
+    rng = np.random.default_rng(77)
+    n = 6_000_000
+    k = rng.integers(0, 1_000_000, n)
+    v = rng.normal(3, 2, n); v[::999] = np.nan
+    w = rng.normal(0, 1, n)
+    df = Frame(dict(k=torch.from_numpy(k).cuda(), v=torch.from_numpy(v).cuda(), w=torch.from_numpy(w).cuda()), superagg=sa)
+    spec = {"c": agg.count("v"), "s": agg.sum("v"), "m": agg.mean("v"), "sd": agg.std("v"), "n": agg.count()}
+    df.last_groupby_info = None
+    got = df.groupby("k", spec)
+    info = df.last_groupby_info
+    assert info and info.get("direct_table") == 1 and info.get("dense_range_through_fused_pass") == 1, info
+    want = _want(k, [v])
+    np.testing.assert_array_equal(got["k"], want["k"]); np.testing.assert_array_equal(got["n"], want["rows"]); np.testing.assert_array_equal(got["c"], want["v"][0]["cnt"])
+    assert np.all(np.abs(got["s"] - want["v"][0]["s"]) <= 1e-12 * want["v"][0]["sabs"])
+    df.dense_through_fused = False                      # the slab-partitioned pair on the same rows
+    df.last_groupby_info = None
+    slab = df.groupby("k", spec)
+    assert not (df.last_groupby_info or {}).get("direct_table")
+    for name in ("k", "n", "c"):
+        np.testing.assert_array_equal(slab[name], got[name])
+    assert np.all(np.abs(slab["s"] - got["s"]) <= 2e-12 * want["v"][0]["sabs"])
+    ok = want["v"][0]["cnt"] > 0
+    assert np.allclose(np.asarray(slab["m"])[ok], np.asarray(got["m"])[ok], rtol=1e-11, atol=0)
+    df.dense_through_fused = True
+    df.last_groupby_info = None
+    two = df.groupby("k", {"sv": agg.sum("v"), "sw": agg.sum("w"), "hi": agg.max("w")})   # outside the direct form: the dense pass
+    assert not (df.last_groupby_info or {}).get("direct_table")
+    np.testing.assert_array_equal(two["k"], want["k"])
+    assert np.allclose(two["sw"], np.bincount(k, weights=w, minlength=1_000_000)[np.bincount(k, minlength=1_000_000) > 0], rtol=1e-11, atol=1e-9)
+
+
+def test_a_column_overwritten_in_place_is_scanned_again(sa, gpu_ready):
+    """the per-column memos (key range, NaN verdict, group count, heavy keys) were keyed on object identity alone — a torch
+    tensor overwritten IN PLACE kept them.  They now carry the tensor's version counter."""
+    import torch
+    from vaex_amd.binned import Frame, agg
+    rng = np.random.default_rng(5)
+    n = 5_000_000
+    k = rng.integers(0, 40_000, n)
+    v = rng.normal(0, 1, n)
+    kd, vd = torch.from_numpy(k).cuda(), torch.from_numpy(v).cuda()
+    df = Frame(dict(k=kd, v=vd), superagg=sa)
+    spec = {"c": agg.count("v"), "s": agg.sum("v"), "n": agg.count()}
+    first = df.groupby("k", spec)
+    np.testing.assert_array_equal(first["k"], np.unique(k))
+    kd.mul_(977).add_(-5)                      # another range (dense -> scattered), same object
+    vd[::3] = float("nan")                     # NaNs appear in a column that was NaN-free
+    torch.cuda.synchronize()
+    k2, v2 = k * 977 - 5, v.copy()
+    v2[::3] = np.nan
+    second = df.groupby("k", spec)
+    w = _want(k2, [v2])
+    np.testing.assert_array_equal(second["k"], w["k"])
+    np.testing.assert_array_equal(second["n"], w["rows"])
+    np.testing.assert_array_equal(second["c"], w["v"][0]["cnt"])
+    assert np.all(np.abs(second["s"] - w["v"][0]["s"]) <= 1e-12 * w["v"][0]["sabs"])

@@ -116,6 +116,8 @@ struct GbArgs {
     // <= 32 bits below — what the bucket implies is not stored: records are 12 bytes {remainder, payload} instead of 16, in the
     // scatter's writes and the reduce's reads alike.  gb_reduce rebuilds the key of every GROUP (bucket | remainder, mixed back).
     int32_t kc_bits;        // 0: 16-byte records {key, payload}
+    int32_t key32;          // compact records with a remainder of < 32 bits: gb_reduce keeps 32-bit keys in its table
+    int32_t direct;         // compact records AND 2^(kc_bits - nb_log2) <= GB_DIRECT_SLOTS: gb_reduce indexes its table with the remainder (no keys, no probe)
     // Heavy keys (round 4, the one-kernel peel): rows whose key is one of `n_heavy` <= 128 listed keys leave NO record — gb_scatter looks
     // every key up in an LDS copy of the list, adds such rows to per-workgroup partials in LDS {rows | count, sum, sum2 ...} and folds those
     // into heavy_acc at its end; gb_append_heavy turns the accumulators into ordinary groups in front of the sort.  (Every row of ONE key
@@ -437,14 +439,25 @@ __global__ void gb_append_heavy(const GbArgs G) {
 #ifndef GB_REDUCE_U
 #define GB_REDUCE_U 4
 #endif
-template <int NV, bool MERGE, bool KC = false>
+// DIRECT (round 6; KC records only): the remainder of a compact record IS the slot — when the key range is narrow enough for
+// 2^(kc_bits - nb_log2) accumulators to fit the LDS (<= 4096: every key range the dense BinnerOrdinal path takes), the bijective mix
+// makes (bucket, remainder) a PERFECT hash: no keys in the table, no probe, no claim, no overflow — a record costs its three atomics.
+// This is what the slab-partitioned dense groupby (part_scatter_f64 + part_reduce_fast) does behind a pass 1 that moves 27 GB per 1e9
+// rows at 4.0 TB/s; here it sits behind gb_scatter's shared streams (28 GB at 5.0 TB/s).
+// K32 (round 6; KC records whose remainder has < 32 bits): the table's keys are 32-bit words — a line of four keys is ONE ds_read_b128
+// instead of two, the claim a 32-bit ds_cmpst (the probe's LDS reads were ~40 % of the kernel's LDS time: DESIGN section 3).
+template <int NV, bool MERGE, bool KC = false, bool DIRECT = false, bool K32 = false>
 __global__ void __launch_bounds__(1024) gb_reduce(const GbArgs G) {
+    static_assert(!DIRECT || (KC && !MERGE), "a direct table needs compact records");
+    static_assert(!K32 || (KC && !MERGE && !DIRECT), "32-bit table keys need compact records");
+    using KT = typename std::conditional<K32, uint32_t, unsigned long long>::type;
+    constexpr KT KEMPTY = K32 ? (KT)0xffffffffu : (KT)GB_EMPTY; // (a remainder of < 32 bits is never all ones)
     extern __shared__ __attribute__((aligned(16))) char lds[];
     // row counters: 32 bits while counting rows (a workgroup sees < 2^32 of them), 64 bits when merging partial counts
     using CT = typename std::conditional<MERGE, unsigned long long, uint32_t>::type;
-    const uint32_t LINES = G.lines, SLOTS = 4u * LINES, E = SLOTS + 1, EP = (E + 3) & ~3u; // (EP: keeps the arrays 16-byte aligned)
-    unsigned long long *const t_key = (unsigned long long *)lds;    // [EP]: line l = t_key[4 l .. 4 l + 3]
-    double *const t_sum = (double *)(t_key + EP);                   // [NV][EP]
+    const uint32_t LINES = G.lines, SLOTS = DIRECT ? 1u << (G.kc_bits - G.nb_log2) : 4u * LINES, E = DIRECT ? SLOTS : SLOTS + 1, EP = (E + 3) & ~3u; // (EP: keeps the arrays 16-byte aligned)
+    KT *const t_key = (KT *)lds;                                    // [EP]: line l = t_key[4 l .. 4 l + 3]
+    double *const t_sum = (double *)(t_key + EP);                   // [NV][EP] (EP is a multiple of 4: 16-byte aligned behind 32-bit keys too)
     double *const t_sum2 = t_sum + (size_t)NV * EP;                 // [NV][EP]
     // counting rows: {rows, count of value column 0} are the two halves of one 64-bit word per slot (t_rc), further
     // columns' counts follow as 32-bit arrays; merging: 64-bit rows[] and counts[][]
@@ -459,7 +472,7 @@ __global__ void __launch_bounds__(1024) gb_reduce(const GbArgs G) {
     // the host lays the streams out from the counters and runs the pass again
     if (__hip_atomic_load(G.overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1u) return;
     for (uint32_t s = tid; s < EP; s += blockDim.x) {
-        t_key[s] = (unsigned long long)GB_EMPTY;
+        if (!DIRECT) t_key[s] = KEMPTY;
         if (MERGE) t_rows[s] = (CT)0; else t_rc[s] = 0ull;
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
@@ -504,19 +517,27 @@ __global__ void __launch_bounds__(1024) gb_reduce(const GbArgs G) {
     auto home = [&](long long key) -> uint32_t { return __umulhi((uint32_t)(((uint64_t)key * 0x9e3779b97f4a7c15ULL) >> 32), LINES); };
     // insert-or-get: the four keys of a line are read and compared at once; 0xffffffff when the table is too full
     auto slot_of = [&](long long key) -> uint32_t {
+        if (DIRECT) return (uint32_t)key; // (the remainder: < 2^(kc_bits - nb_log2) = SLOTS by construction)
         if (key == GB_EMPTY) return SLOTS;
         uint32_t l = home(key);
-        const unsigned long long k = (unsigned long long)key, empty = (unsigned long long)GB_EMPTY;
+        const KT k = (KT)key, empty = KEMPTY;
         for (uint32_t trips = 0; trips < 2u * LINES; ++trips) {
-            const ulonglong2 a = *(const ulonglong2 *)(t_key + 4u * l), b = *(const ulonglong2 *)(t_key + 4u * l + 2);
-            if (a.x == k) return 4u * l;
-            if (a.y == k) return 4u * l + 1;
-            if (b.x == k) return 4u * l + 2;
-            if (b.y == k) return 4u * l + 3;
-            const int e = a.x == empty ? 0 : (a.y == empty ? 1 : (b.x == empty ? 2 : (b.y == empty ? 3 : -1)));
+            KT k0, k1, k2, k3;
+            if (K32) {
+                const uint4 a = *(const uint4 *)(t_key + 4u * l);
+                k0 = (KT)a.x; k1 = (KT)a.y; k2 = (KT)a.z; k3 = (KT)a.w;
+            } else {
+                const ulonglong2 a = *(const ulonglong2 *)(t_key + 4u * l), b = *(const ulonglong2 *)(t_key + 4u * l + 2);
+                k0 = (KT)a.x; k1 = (KT)a.y; k2 = (KT)b.x; k3 = (KT)b.y;
+            }
+            if (k0 == k) return 4u * l;
+            if (k1 == k) return 4u * l + 1;
+            if (k2 == k) return 4u * l + 2;
+            if (k3 == k) return 4u * l + 3;
+            const int e = k0 == empty ? 0 : (k1 == empty ? 1 : (k2 == empty ? 2 : (k3 == empty ? 3 : -1)));
             if (e < 0) { l = l + 1 == LINES ? 0u : l + 1; continue; } // a full line without the key: it can only be further on
             if (s_misc[0] >= limit) return 0xffffffffu;
-            const unsigned long long old = atomicCAS(&t_key[4u * l + e], empty, k);
+            const KT old = atomicCAS(&t_key[4u * l + e], empty, k);
             if (old == empty) {
                 __hip_atomic_fetch_add(&s_misc[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 return 4u * l + e;
@@ -656,7 +677,7 @@ __global__ void __launch_bounds__(1024) gb_reduce(const GbArgs G) {
     for (uint32_t s = tid; s < E; s += blockDim.x) {
         if (rows_of(s) == 0ull) continue;
         if (!MERGE && NV == 1 && KC) // the group's key from its bucket and remainder, mixed back
-            G.out_key[o] = (long long)(gb_kc_unmix(((uint64_t)bucket << (G.kc_bits - G.nb_log2)) | (uint64_t)t_key[s], G.kc_bits, G.kc_a_inv, G.kc_b_inv) + (uint64_t)G.kc_min);
+            G.out_key[o] = (long long)(gb_kc_unmix(((uint64_t)bucket << (G.kc_bits - G.nb_log2)) | (DIRECT ? (uint64_t)s : (uint64_t)t_key[s]), G.kc_bits, G.kc_a_inv, G.kc_b_inv) + (uint64_t)G.kc_min);
         else
             G.out_key[o] = s == SLOTS ? GB_EMPTY : (long long)t_key[s];
         G.out_w[0][o] = (uint64_t)rows_of(s);
@@ -726,7 +747,7 @@ struct vxh_groupby {
     Dev cols; // [key | rows | (count, sum, sum2) x nv] x n_groups, 8-byte elements, sorted by key
     Dev tmp;
     uint64_t stride = 0; // elements between columns
-    int buckets = 0, slots = 0, retries = 0, compact = 0, heavy = 0;
+    int buckets = 0, slots = 0, retries = 0, compact = 0, heavy = 0, direct = 0;
     float ms_scatter = 0, ms_reduce = 0, ms_sort = 0;
 };
 
@@ -743,6 +764,7 @@ GbScratch &gb_scratch() {
 }
 
 constexpr size_t GB_LDS_MAX = 160 * 1024;
+constexpr int GB_DIRECT_BITS = 12; // direct tables: 4096 slots x (rc 8 + sum 8 + sum2 8 + the unused key word 8) = 128 KiB
 
 template <int W, int R>
 size_t scatter_lds(int nb_log2) {
@@ -779,6 +801,20 @@ void launch_reduce(const GbArgs &G, hipStream_t st) {
     const size_t EP = (4 * (size_t)G.lines + 1 + 3) & ~(size_t)3;
     const size_t lds = EP * reduce_slot_bytes(NV, MERGE) + 18 * 4 + 16;
     if (lds > GB_LDS_MAX) throw std::runtime_error("groupby: internal: gb_reduce table exceeds the LDS");
+    if (NV == 1 && !MERGE && G.kc_bits && G.direct) { // compact records whose remainder indexes the table (run_pipeline decides)
+        const size_t slots = (size_t)1 << (G.kc_bits - G.nb_log2), ep = (slots + 3) & ~(size_t)3;
+        const size_t dlds = ep * reduce_slot_bytes(1, false) + 18 * 4 + 16;
+        if (dlds > GB_LDS_MAX) throw std::runtime_error("groupby: internal: gb_reduce direct table exceeds the LDS");
+        HIP_CHECK(hipFuncSetAttribute((const void *)gb_reduce<1, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dlds));
+        hipLaunchKernelGGL((gb_reduce<1, false, true, true>), dim3(1u << G.nb_log2), dim3(1024), dlds, st, G);
+        return;
+    }
+    if (NV == 1 && !MERGE && G.kc_bits && G.key32) { // compact records with a remainder of < 32 bits: 32-bit table keys (4 bytes less per slot)
+        const size_t klds = EP * (reduce_slot_bytes(1, false) - 4) + 18 * 4 + 16;
+        HIP_CHECK(hipFuncSetAttribute((const void *)gb_reduce<1, false, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)klds));
+        hipLaunchKernelGGL((gb_reduce<1, false, true, false, true>), dim3(1u << G.nb_log2), dim3(1024), klds, st, G);
+        return;
+    }
     if (NV == 1 && !MERGE && G.kc_bits) { // compact records (run_pipeline sets kc_bits for this form only)
         HIP_CHECK(hipFuncSetAttribute((const void *)gb_reduce<1, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL((gb_reduce<1, false, true>), dim3(1u << G.nb_log2), dim3(1024), lds, st, G);
@@ -843,15 +879,20 @@ unsigned run_pipeline(GbArgs &G, int nv, bool merge, uint64_t n, uint64_t groups
         if (total_records * 8 * (uint64_t)(1 + w) > (96ull << 30)) { code = 9; break; }
         G.nv = nv; G.w = w; G.merge = merge ? 1 : 0; G.n = n;
         G.nb_log2 = nb_log2; G.slots_log2 = 0; G.lines = lines;
+        // a key range of at most 2^(10 + GB_DIRECT_BITS) cells: as many buckets as leave a remainder the LDS can index directly ("gb_direct", default on)
+        if (ctx().cfg_gb_compact && ctx().cfg_gb_direct && w == 1 && !merge && key_bits > 6 && key_bits <= nb_max + GB_DIRECT_BITS)
+            nb_log2 = std::max(nb_log2, std::min(nb_max, key_bits - GB_DIRECT_BITS));
         const bool compact = ctx().cfg_gb_compact && w == 1 && !merge && key_bits > nb_log2 && key_bits - nb_log2 <= 32;
         G.kc_bits = compact ? key_bits : 0;
+        G.direct = compact && ctx().cfg_gb_direct && key_bits - nb_log2 <= GB_DIRECT_BITS ? 1 : 0;
+        G.key32 = compact && !G.direct && ctx().cfg_gb_key32 && key_bits - nb_log2 < 32 ? 1 : 0;
 #ifdef VXH_ABLATE
         G.abl = (int32_t)ctx().cfg_gb_abl;
 #endif
         G.kc_min = key_min;
         G.kc_a_inv = inverse_mod_2_64(GB_KC_A);
         G.kc_b_inv = inverse_mod_2_64(GB_KC_B);
-        if (res) res->compact = compact ? 1 : 0;
+        if (res) { res->compact = compact ? 1 : 0; res->direct = G.direct; }
         G.ng = (uint32_t)NG; G.cap = cap;
         S.queues.need(total_records * 8 * (size_t)(1 + w));
         const size_t starts_bytes = (NG * NB + 1) * 8;
@@ -1127,6 +1168,7 @@ int vxh_groupby_info(const vxh_groupby *g, int what, double *value_out) {
     case 5: *value_out = g->ms_sort; break;
     case 6: *value_out = g->compact; break;
     case 7: *value_out = g->heavy; break;
+    case 8: *value_out = g->direct; break;
     default: throw std::runtime_error("groupby info: unknown item");
     }
     GB_END

@@ -239,6 +239,8 @@ struct Context {
     int64_t cfg_wv_block = 0;      // ... records per queue block of a (wave, slab) (0 = sized from the expected share); tests force tiny blocks
     int64_t cfg_fuse_selection = 1; // a selection shared by every aggregator of a call, over one float64 column, is evaluated inside the binning kernels (0: always through sel_eval's byte mask)
     int64_t cfg_gb_compact = 1;    // fused hash groupby: 12-byte records when the measured key range allows (vxh_groupby_run_ranged)
+    int64_t cfg_gb_key32 = 1;     // fused groupby: 32-bit keys in gb_reduce's probing table when the compact record's remainder has < 32 bits (0: 64-bit keys, for A/B runs)
+    int64_t cfg_gb_direct = 1;    // fused groupby: key ranges of <= 2^22 cells index gb_reduce's LDS table with the record's remainder (0: the probing table, for A/B runs)
     int64_t cfg_gb_sets = 8;       // fused hash groupby: sets of record streams shared by the workgroups w % sets (8: one per XCD)
     int64_t cfg_gb_abl = 0;        // fused hash groupby, timing experiments only (GbArgs::abl)
     int64_t cfg_gb_load_pct = 50;  // fused hash groupby: target load of a bucket's LDS table when the bucket count is chosen
