@@ -508,7 +508,7 @@ def test_narrow_key_ranges_index_the_lds_table_directly(sa, gpu_ready, cells, km
     want = _want(k[kept], [v[kept]])
     _check(sa, res, want)
     info = res.info()
-    assert info["compact_records"] == 1 and info["retries"] == 0, info
+    assert info["compact_records"] == 1 and info["retries"] <= 1, info   # (the 2 % key's stream passes its room: ONE exact second attempt; a table never overflows)
     assert info["direct_table"] == (1 if cells <= (1 << 22) else 0), info
     sa.config_set("gb_direct", 0)
     try:

@@ -39,4 +39,4 @@ else:
 torch.cuda.synchronize()
 for i in range(passes):
     t0 = time.perf_counter(); sa.timer_start(0); r = run(); k_ms = sa.timer_stop(0); dt = time.perf_counter() - t0
-    print(f"{which} pass {i}: {dt*1e3:.3f} ms wall, {k_ms:.3f} ms on the stream = {rows/dt/1e9:.1f} Grows/s  {sa.last_kernel(0)} {getattr(df, 'last_groupby_info', '') if which == 'c3s' else ''}", flush=True)
+    print(f"{which} pass {i}: {dt*1e3:.3f} ms wall, {k_ms:.3f} ms on the stream = {rows/dt/1e9:.1f} Grows/s  {sa.last_kernel(0)} {getattr(df, 'last_groupby_info', '') if which in ('c3s', 'c3') else ''}", flush=True)

@@ -128,7 +128,6 @@ struct GbArgs {
     unsigned long long *heavy_acc; // [n_heavy][1 + 3 nv]: rows, then per value column count, sum bits, sum2 bits
     int32_t abl;            // timing experiments ("gb_abl", the ablation build only — VXH_GB_ABL is a compile-time zero in the product library): 1 = gb_scatter's copy-out computes but does not store, 2 = no copy-out, 4 = no staging and no copy-out
     long long kc_min;
-    uint64_t kc_a_inv, kc_b_inv; // inverses of the two multipliers modulo 2^64
     // results (unsorted)
     unsigned long long *out_count; // groups written so far
     unsigned int *overflow;        // 1: out of spare blocks, 2: a bucket's LDS table too full, 3: result arrays too small
@@ -140,18 +139,29 @@ struct GbArgs {
 // ------------------------------------------------------------------------------------------------------------------
 // gb_scatter
 // ------------------------------------------------------------------------------------------------------------------
-constexpr uint64_t GB_KC_A = 0x9e3779b97f4a7c15ULL, GB_KC_B = 0xbf58476d1ce4e5b9ULL; // (odd: invertible modulo any power of two)
-__device__ __forceinline__ uint64_t gb_kc_mix(uint64_t x, int bits) { // a bijection of [0, 2^bits)
-    const uint64_t mask = bits >= 64 ? ~0ull : ((1ull << bits) - 1ull);
-    x = (x * GB_KC_A) & mask;
-    x ^= x >> ((bits + 1) >> 1);
-    return (x * GB_KC_B) & mask;
+// The compact records' mix: a BIJECTION of [0, 2^bits) whose top bits name the bucket.  Round 6: three Feistel rounds over the two halves
+// of the number (low bits / 2 bits and the rest; each at most 32 bits wide), every round ONE 32-bit multiply — the top bits of v * C depend
+// on every bit of v, so after the rounds the bucket depends on all of the key.  (Rounds 4-5 mixed with two 64-bit multiplies modulo
+// 2^bits: ~8 quarter-rate 32-bit multiplies per row — the ablation build showed gb_scatter spending ~2 ms per 1e9 rows in its ALU phases
+// with every load, atomic and store taken out, profiles/r06_gb_scatter_ablation.txt.)  Any round function gives a bijection: the inverse
+// runs the rounds backwards.
+constexpr uint32_t GB_KC_C1 = 0x9e3779b1u, GB_KC_C2 = 0x85ebca77u, GB_KC_C3 = 0xc2b2ae3du;
+__device__ __forceinline__ uint32_t gb_kc_f(uint32_t v, uint32_t c, int w) { return (v * c) >> (32 - w); } // the top w bits of the product (1 <= w <= 32)
+__device__ __forceinline__ uint64_t gb_kc_mix(uint64_t x, int bits) {
+    const int wr = bits >> 1, wl = bits - wr;
+    uint32_t r = (uint32_t)(x & ((1ull << wr) - 1ull)), l = (uint32_t)(x >> wr);
+    l ^= gb_kc_f(r, GB_KC_C1, wl);
+    r ^= gb_kc_f(l, GB_KC_C2, wr);
+    l ^= gb_kc_f(r, GB_KC_C3, wl);
+    return ((uint64_t)l << wr) | (uint64_t)r;
 }
-__device__ __forceinline__ uint64_t gb_kc_unmix(uint64_t m, int bits, uint64_t a_inv, uint64_t b_inv) {
-    const uint64_t mask = bits >= 64 ? ~0ull : ((1ull << bits) - 1ull);
-    uint64_t x = (m * b_inv) & mask;
-    x ^= x >> ((bits + 1) >> 1); // (the shift is at least half the width: one application undoes itself)
-    return (x * a_inv) & mask;
+__device__ __forceinline__ uint64_t gb_kc_unmix(uint64_t m, int bits) {
+    const int wr = bits >> 1, wl = bits - wr;
+    uint32_t r = (uint32_t)(m & ((1ull << wr) - 1ull)), l = (uint32_t)(m >> wr);
+    l ^= gb_kc_f(r, GB_KC_C3, wl);
+    r ^= gb_kc_f(l, GB_KC_C2, wr);
+    l ^= gb_kc_f(r, GB_KC_C1, wl);
+    return ((uint64_t)l << wr) | (uint64_t)r;
 }
 typedef unsigned int gb_u32x3 __attribute__((ext_vector_type(3)));
 typedef gb_u32x3 gb_u32x3_a4 __attribute__((aligned(4)));
@@ -167,8 +177,11 @@ typedef gb_u32x3 gb_u32x3_a4 __attribute__((aligned(4)));
 // HEAVY: G.n_heavy > 0 (RAW records only: W = value columns).
 constexpr uint32_t GB_HEAVY_MAX = 128, GB_HEAVY_SLOTS = 256;
 constexpr size_t gb_heavy_lds(int w) { return (size_t)GB_HEAVY_SLOTS * 8 + GB_HEAVY_SLOTS + (size_t)GB_HEAVY_MAX * 8 + (size_t)w * GB_HEAVY_MAX * 16 + (size_t)(w > 1 ? w - 1 : 0) * GB_HEAVY_MAX * 4 + 16; }
-template <int W, int R, bool K64, bool KEEP, bool HEAVY>
+// KC (round 6): compact 12-byte records (G.kc_bits != 0; W == 1) as a compile-time switch like gb_reduce's — the staged key is then the
+// 32-bit remainder (half the LDS bytes of the key staging), and the per-row `if (G.kc_bits)` is gone from [A] and [D].
+template <int W, int R, bool K64, bool KEEP, bool HEAVY, bool KC = false>
 __global__ void __launch_bounds__(1024) gb_scatter(const GbArgs G) {
+    static_assert(!KC || W == 1, "compact records carry one payload word");
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr uint32_t T = 1024u * R;
     const uint32_t NB = 1u << G.nb_log2; // <= 1024: thread b owns bucket b
@@ -229,6 +242,15 @@ __global__ void __launch_bounds__(1024) gb_scatter(const GbArgs G) {
             v[r] = i < n;
             ic[r] = v[r] ? i : n - 1;
             b[r] = 1u;
+        }
+        if (VXH_GB_ABL(G, 32)) { // (timing: no row loads at all — synthetic keys and payloads)
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                k[r] = (long long)(gb_mix(ic[r]) & ((1ull << 40) - 1ull));
+#pragma unroll
+                for (int w = 0; w < W; ++w) p[w][r] = ic[r];
+            }
+            return;
         }
         if (KEEP) {
 #pragma unroll
@@ -318,7 +340,7 @@ __global__ void __launch_bounds__(1024) gb_scatter(const GbArgs G) {
         uint32_t bucket[R], pos[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            if (W == 1 && G.kc_bits) { // compact records: the key becomes its remainder, the bucket what the mix puts on top of it
+            if (KC) { // compact records: the key becomes its remainder, the bucket what the mix puts on top of it
                 const uint64_t m = gb_kc_mix((uint64_t)key[r] - (uint64_t)G.kc_min, G.kc_bits);
                 bucket[r] = (uint32_t)(m >> (G.kc_bits - G.nb_log2));
                 key[r] = (long long)(m & ((1ull << (G.kc_bits - G.nb_log2)) - 1ull));
@@ -326,7 +348,7 @@ __global__ void __launch_bounds__(1024) gb_scatter(const GbArgs G) {
                 bucket[r] = (uint32_t)(gb_mix((uint64_t)key[r]) >> (64 - G.nb_log2));
             }
             pos[r] = 0;
-            if (ok[r]) pos[r] = __hip_atomic_fetch_add(&cnt[bucket[r]], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (ok[r] && !VXH_GB_ABL(G, 16)) pos[r] = __hip_atomic_fetch_add(&cnt[bucket[r]], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); // (bit 16, timing: no position atomics — the counts stay 0, nothing is staged or copied out)
         }
         __syncthreads();
         // [B] thread b: where bucket b's records of this tile go; exclusive scan of the bucket counts
@@ -353,7 +375,13 @@ __global__ void __launch_bounds__(1024) gb_scatter(const GbArgs G) {
         {
             uint32_t before = 0;
             for (uint32_t w2 = 0; w2 < wave; ++w2) before += s_wave[w2];
-            if (tid < NB) off[tid] = before + inc - c;
+            if (tid < NB) {
+                const uint32_t o = before + inc - c;
+                off[tid] = o;
+                // [D] wants `segment start - offset of the bucket inside the staged tile`: folded here, once per bucket (a segment starts at
+                // >= one stream's room past 0 for every bucket but the first, whose offset is 0: the difference never wraps, never is ~0)
+                if (gbase[tid] != ~0ull) gbase[tid] -= o;
+            }
         }
         uint32_t total = 0;
         for (uint32_t w2 = 0; w2 < 16; ++w2) total += s_wave[w2];
@@ -363,7 +391,7 @@ __global__ void __launch_bounds__(1024) gb_scatter(const GbArgs G) {
         for (int r = 0; r < R; ++r) {
             if (ok[r] && !VXH_GB_ABL(G, 4)) {
                 const uint32_t j = off[bucket[r]] + pos[r];
-                st_key[j] = (uint64_t)key[r];
+                if (KC) ((uint32_t *)st_key)[j] = (uint32_t)key[r]; else st_key[j] = (uint64_t)key[r];
 #pragma unroll
                 for (int w = 0; w < W; ++w) st_w[(size_t)w * T + j] = pay[w][r];
                 st_b[j] = (uint16_t)bucket[r];
@@ -373,13 +401,13 @@ __global__ void __launch_bounds__(1024) gb_scatter(const GbArgs G) {
         // [D] copy out: consecutive threads -> consecutive records of a bucket's segment
         for (uint32_t j = tid; j < (VXH_GB_ABL(G, 6) ? 0u : total); j += 1024u) {
             const uint32_t b = st_b[j];
-            const unsigned long long base = gbase[b];
+            const unsigned long long base = gbase[b]; // (segment start - the bucket's offset in the staged tile)
             if (base == ~0ull) continue; // (stream full: flagged, the host retries with more room)
-            uint64_t dst = base + (j - off[b]);
-            if (VXH_GB_ABL(G, 1)) { if (st_key[j] != 0x123456789abcdefull) continue; dst = 0; } // (the staged words are read, nothing is stored)
-            if (W == 1 && G.kc_bits) { // 12-byte record {remainder, payload}
+            uint64_t dst = base + j;
+            if (VXH_GB_ABL(G, 1)) { if ((KC ? (uint64_t)((uint32_t *)st_key)[j] : st_key[j]) + st_w[j] != 0x123456789abcdefull) continue; dst = 0; } // (the staged words are read, nothing is stored)
+            if (KC) { // 12-byte record {remainder, payload}
                 const uint64_t c2 = st_w[j];
-                const gb_u32x3_a4 rec = gb_u32x3_a4{(uint32_t)st_key[j], (uint32_t)c2, (uint32_t)(c2 >> 32)};
+                const gb_u32x3_a4 rec = gb_u32x3_a4{((uint32_t *)st_key)[j], (uint32_t)c2, (uint32_t)(c2 >> 32)};
                 if (VXH_GB_ABL(G, 8)) __builtin_nontemporal_store(rec, (gb_u32x3_a4 *)((uint32_t *)G.qrec + dst * 3)); // (experiment: non-temporal)
                 else *(gb_u32x3_a4 *)((uint32_t *)G.qrec + dst * 3) = rec;
             } else if (W == 1) { // one 16-byte record {key, payload}: a tile's segment of a bucket is 16 B x its records, contiguous
@@ -514,7 +542,10 @@ __global__ void __launch_bounds__(1024) gb_reduce(const GbArgs G) {
     };
     // home line of a key inside the bucket's table: the high word of a Fibonacci multiply, range-reduced by a multiply-high —
     // independent of the bucket (top bits of splitmix64)
-    auto home = [&](long long key) -> uint32_t { return __umulhi((uint32_t)(((uint64_t)key * 0x9e3779b97f4a7c15ULL) >> 32), LINES); };
+    auto home = [&](long long key) -> uint32_t {
+        if (K32) return __umulhi((uint32_t)key * 0x9e3779b1u, LINES); // (a 32-bit remainder: one 32-bit multiply instead of a 64-bit one)
+        return __umulhi((uint32_t)(((uint64_t)key * 0x9e3779b97f4a7c15ULL) >> 32), LINES);
+    };
     // insert-or-get: the four keys of a line are read and compared at once; 0xffffffff when the table is too full
     auto slot_of = [&](long long key) -> uint32_t {
         if (DIRECT) return (uint32_t)key; // (the remainder: < 2^(kc_bits - nb_log2) = SLOTS by construction)
@@ -677,7 +708,7 @@ __global__ void __launch_bounds__(1024) gb_reduce(const GbArgs G) {
     for (uint32_t s = tid; s < E; s += blockDim.x) {
         if (rows_of(s) == 0ull) continue;
         if (!MERGE && NV == 1 && KC) // the group's key from its bucket and remainder, mixed back
-            G.out_key[o] = (long long)(gb_kc_unmix(((uint64_t)bucket << (G.kc_bits - G.nb_log2)) | (DIRECT ? (uint64_t)s : (uint64_t)t_key[s]), G.kc_bits, G.kc_a_inv, G.kc_b_inv) + (uint64_t)G.kc_min);
+            G.out_key[o] = (long long)(gb_kc_unmix(((uint64_t)bucket << (G.kc_bits - G.nb_log2)) | (DIRECT ? (uint64_t)s : (uint64_t)t_key[s]), G.kc_bits) + (uint64_t)G.kc_min);
         else
             G.out_key[o] = s == SLOTS ? GB_EMPTY : (long long)t_key[s];
         G.out_w[0][o] = (uint64_t)rows_of(s);
@@ -773,6 +804,12 @@ size_t scatter_lds(int nb_log2) {
 }
 template <int W, int R, bool K64, bool KEEP, bool HEAVY>
 void launch_scatter_as(const GbArgs &G, int blocks, size_t lds, hipStream_t st) {
+    if (W == 1 && G.kc_bits) { // compact records: the KC instantiation (constexpr-guarded: the template only exists for W == 1)
+        constexpr bool KC = W == 1;
+        HIP_CHECK(hipFuncSetAttribute((const void *)gb_scatter<W, R, K64, KEEP, HEAVY, KC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((gb_scatter<W, R, K64, KEEP, HEAVY, KC>), dim3(blocks), dim3(1024), lds, st, G);
+        return;
+    }
     HIP_CHECK(hipFuncSetAttribute((const void *)gb_scatter<W, R, K64, KEEP, HEAVY>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL((gb_scatter<W, R, K64, KEEP, HEAVY>), dim3(blocks), dim3(1024), lds, st, G);
 }
@@ -826,11 +863,6 @@ void launch_reduce(const GbArgs &G, hipStream_t st) {
 
 // one pipeline run over device-resident records; results appended (unsorted) to the arrays in G.out_*; returns the
 // overflow code (0 = fine)
-uint64_t inverse_mod_2_64(uint64_t a) { // Newton: every step doubles the correct low bits (a odd)
-    uint64_t x = a;
-    for (int i = 0; i < 6; i++) x *= 2 - a * x;
-    return x;
-}
 
 // key_bits > 0: every key lies in [key_min, key_min + 2^key_bits) (the caller measured the range): compact 12-byte records where the
 // remainder below the bucket bits fits 32 bits (GbArgs::kc_*)
@@ -890,8 +922,6 @@ unsigned run_pipeline(GbArgs &G, int nv, bool merge, uint64_t n, uint64_t groups
         G.abl = (int32_t)ctx().cfg_gb_abl;
 #endif
         G.kc_min = key_min;
-        G.kc_a_inv = inverse_mod_2_64(GB_KC_A);
-        G.kc_b_inv = inverse_mod_2_64(GB_KC_B);
         if (res) { res->compact = compact ? 1 : 0; res->direct = G.direct; }
         G.ng = (uint32_t)NG; G.cap = cap;
         S.queues.need(total_records * 8 * (size_t)(1 + w));
