@@ -270,8 +270,15 @@ def other_configs(sa, torch, rows, sample_rows):
                 return g_
             pool0 = {k_: sa.config_get(k_) for k_ in ("pool_mallocs", "pool_malloc_bytes", "pool_malloc_us", "pool_frees", "pool_free_us")}
             free0 = torch.cuda.mem_get_info()[0]
+            # ... and around the Frame's own steps between those calls (the heavy-key sample is torch.unique over 2^17 keys: torch's allocator and
+            # kernels, not this library's), with the number of blocks torch's caching allocator had to ask the runtime for meanwhile
+            fnames = [nm for nm in ("_heavy_keys", "_prescan", "_key_range", "_may_hold_nan") if hasattr(Frame, nm)]
+            fsaved = {nm: getattr(Frame, nm) for nm in fnames}
+            tstats0 = torch.cuda.memory_stats()
             for nm in names:
                 setattr(sa, nm, wrap(nm, saved[nm]))
+            for nm in fnames:
+                setattr(Frame, nm, wrap("Frame." + nm, fsaved[nm]))
             try:
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
@@ -283,9 +290,13 @@ def other_configs(sa, torch, rows, sample_rows):
             finally:
                 for nm in names:
                     setattr(sa, nm, saved[nm])
+                for nm in fnames:
+                    setattr(Frame, nm, fsaved[nm])
+            tstats1 = torch.cuda.memory_stats()
             detail = {"label": label, "ms": round(ms_first, 3), "kernel_ms": round(k_first, 3), "library_calls_ms": log,
                       "pool": {k_: sa.config_get(k_) - v_ for k_, v_ in pool0.items()}, "pool_cached_gb": round(sa.config_get("pool_cached_bytes") / 2**30, 2),
-                      "hbm_free_gb_before": round(free0 / 2**30, 1)}
+                      "hbm_free_gb_before": round(free0 / 2**30, 1),
+                      "torch_allocator": {k_: int(tstats1.get(k_, 0)) - int(tstats0.get(k_, 0)) for k_ in ("num_device_alloc", "num_device_free", "num_alloc_retries")}}
             if info is not None:   # (the groupby's own account of THIS call: retries, buckets, kernel times)
                 detail["groupby_info"] = {k_: (round(v_, 3) if isinstance(v_, float) else v_) for k_, v_ in (info() or {}).items()}
             del r_

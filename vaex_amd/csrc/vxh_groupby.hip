@@ -900,6 +900,9 @@ unsigned run_pipeline(GbArgs &G, int nv, bool merge, uint64_t n, uint64_t groups
     uint64_t slack = 1;
     std::vector<unsigned long long> exact; // stream starts measured by a first attempt that found a stream too small (then: one exact second attempt)
     for (int attempt = 0; attempt < 6; ++attempt) {
+        // a key range of at most 2^(10 + GB_DIRECT_BITS) cells: as many buckets as leave a remainder the LDS can index directly ("gb_direct", default on)
+        if (ctx().cfg_gb_compact && ctx().cfg_gb_direct && w == 1 && !merge && key_bits > 6 && key_bits <= nb_max + GB_DIRECT_BITS)
+            nb_log2 = std::max(nb_log2, std::min(nb_max, key_bits - GB_DIRECT_BITS));
         const uint64_t NB = (uint64_t)1 << nb_log2;
         const int blocks = (int)std::max<uint64_t>(1, std::min<uint64_t>((n + T - 1) / T, (uint64_t)cus * per_cu));
         // sets of streams: one per XCD ("gb_sets", 8: blockIdx % 8 is the XCD a workgroup lands on), fewer when the launch has fewer
@@ -911,9 +914,6 @@ unsigned run_pipeline(GbArgs &G, int nv, bool merge, uint64_t n, uint64_t groups
         if (total_records * 8 * (uint64_t)(1 + w) > (96ull << 30)) { code = 9; break; }
         G.nv = nv; G.w = w; G.merge = merge ? 1 : 0; G.n = n;
         G.nb_log2 = nb_log2; G.slots_log2 = 0; G.lines = lines;
-        // a key range of at most 2^(10 + GB_DIRECT_BITS) cells: as many buckets as leave a remainder the LDS can index directly ("gb_direct", default on)
-        if (ctx().cfg_gb_compact && ctx().cfg_gb_direct && w == 1 && !merge && key_bits > 6 && key_bits <= nb_max + GB_DIRECT_BITS)
-            nb_log2 = std::max(nb_log2, std::min(nb_max, key_bits - GB_DIRECT_BITS));
         const bool compact = ctx().cfg_gb_compact && w == 1 && !merge && key_bits > nb_log2 && key_bits - nb_log2 <= 32;
         G.kc_bits = compact ? key_bits : 0;
         G.direct = compact && ctx().cfg_gb_direct && key_bits - nb_log2 <= GB_DIRECT_BITS ? 1 : 0;
