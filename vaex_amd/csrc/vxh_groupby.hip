@@ -179,9 +179,12 @@ constexpr uint32_t GB_HEAVY_MAX = 128, GB_HEAVY_SLOTS = 256;
 constexpr size_t gb_heavy_lds(int w) { return (size_t)GB_HEAVY_SLOTS * 8 + GB_HEAVY_SLOTS + (size_t)GB_HEAVY_MAX * 8 + (size_t)w * GB_HEAVY_MAX * 16 + (size_t)(w > 1 ? w - 1 : 0) * GB_HEAVY_MAX * 4 + 16; }
 // KC (round 6): compact 12-byte records (G.kc_bits != 0; W == 1) as a compile-time switch like gb_reduce's — the staged key is then the
 // 32-bit remainder (half the LDS bytes of the key staging), and the per-row `if (G.kc_bits)` is gone from [A] and [D].
-template <int W, int R, bool K64, bool KEEP, bool HEAVY, bool KC = false>
+// D16 (round 6; with a direct table in gb_reduce the remainder has <= 12 bits): the record is split over two streams of the same positions —
+// the value's 8 bytes and the remainder's 2 — 10 bytes written and read back per row instead of 12.
+template <int W, int R, bool K64, bool KEEP, bool HEAVY, bool KC = false, bool D16 = false>
 __global__ void __launch_bounds__(1024) gb_scatter(const GbArgs G) {
     static_assert(!KC || W == 1, "compact records carry one payload word");
+    static_assert(!D16 || KC, "the split record is a compact record");
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr uint32_t T = 1024u * R;
     const uint32_t NB = 1u << G.nb_log2; // <= 1024: thread b owns bucket b
@@ -405,7 +408,10 @@ __global__ void __launch_bounds__(1024) gb_scatter(const GbArgs G) {
             if (base == ~0ull) continue; // (stream full: flagged, the host retries with more room)
             uint64_t dst = base + j;
             if (VXH_GB_ABL(G, 1)) { if ((KC ? (uint64_t)((uint32_t *)st_key)[j] : st_key[j]) + st_w[j] != 0x123456789abcdefull) continue; dst = 0; } // (the staged words are read, nothing is stored)
-            if (KC) { // 12-byte record {remainder, payload}
+            if (D16) { // 10 bytes: the value into the stream's 8-byte half, the remainder into its 2-byte half, same position
+                ((uint64_t *)G.qkey)[dst] = st_w[j];
+                ((uint16_t *)G.qw[0])[dst] = (uint16_t)((uint32_t *)st_key)[j];
+            } else if (KC) { // 12-byte record {remainder, payload}
                 const uint64_t c2 = st_w[j];
                 const gb_u32x3_a4 rec = gb_u32x3_a4{((uint32_t *)st_key)[j], (uint32_t)c2, (uint32_t)(c2 >> 32)};
                 if (VXH_GB_ABL(G, 8)) __builtin_nontemporal_store(rec, (gb_u32x3_a4 *)((uint32_t *)G.qrec + dst * 3)); // (experiment: non-temporal)
@@ -612,6 +618,8 @@ __global__ void __launch_bounds__(1024) gb_reduce(const GbArgs G) {
         }
     };
     struct Trip { // what a trip's loads return, untouched: any arithmetic on it here would make the wave wait for the loads at once
+        uint64_t dv[U];       // split records behind a direct table: the value ...
+        uint16_t di[U];       // ... and the remainder
         gb_u32x3 c[U];        // compact 12-byte records
         uint4 q[U];           // 16-byte records
         long long kk[U];      // separate arrays (several payload words)
@@ -625,7 +633,8 @@ __global__ void __launch_bounds__(1024) gb_reduce(const GbArgs G) {
         for (int u = 0; u < U; ++u) {
             const uint32_t j = j0 + 64u * u + lane;
             const uint64_t at = lo + (j < fill ? j : 0u);
-            if (PW == 1 && KC) t.c[u] = *(const gb_u32x3_a4 *)((const uint32_t *)G.qrec + at * 3);
+            if (DIRECT) { t.dv[u] = ((const uint64_t *)G.qkey)[at]; t.di[u] = ((const uint16_t *)G.qw[0])[at]; }
+            else if (PW == 1 && KC) t.c[u] = *(const gb_u32x3_a4 *)((const uint32_t *)G.qrec + at * 3);
             else if (PW == 1) t.q[u] = G.qrec[at];
             else {
                 t.kk[u] = G.qkey[at];
@@ -640,7 +649,10 @@ __global__ void __launch_bounds__(1024) gb_reduce(const GbArgs G) {
             if (t.j0 + 64u * u + lane >= t.fill) continue;
             long long key;
             uint64_t p[PW];
-            if (PW == 1 && KC) { // {remainder, payload}: the table is keyed by the remainder
+            if (DIRECT) {
+                key = (long long)t.di[u];
+                p[0] = t.dv[u];
+            } else if (PW == 1 && KC) { // {remainder, payload}: the table is keyed by the remainder
                 key = (long long)(uint64_t)t.c[u][0];
                 p[0] = (uint64_t)t.c[u][1] | ((uint64_t)t.c[u][2] << 32);
             } else if (PW == 1) {
@@ -804,6 +816,12 @@ size_t scatter_lds(int nb_log2) {
 }
 template <int W, int R, bool K64, bool KEEP, bool HEAVY>
 void launch_scatter_as(const GbArgs &G, int blocks, size_t lds, hipStream_t st) {
+    if (W == 1 && G.kc_bits && G.direct) { // compact records behind a direct table: 8 + 2 bytes in two streams
+        constexpr bool KC = W == 1;
+        HIP_CHECK(hipFuncSetAttribute((const void *)gb_scatter<W, R, K64, KEEP, HEAVY, KC, KC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((gb_scatter<W, R, K64, KEEP, HEAVY, KC, KC>), dim3(blocks), dim3(1024), lds, st, G);
+        return;
+    }
     if (W == 1 && G.kc_bits) { // compact records: the KC instantiation (constexpr-guarded: the template only exists for W == 1)
         constexpr bool KC = W == 1;
         HIP_CHECK(hipFuncSetAttribute((const void *)gb_scatter<W, R, K64, KEEP, HEAVY, KC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
