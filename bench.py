@@ -458,6 +458,14 @@ def other_configs(sa, torch, rows, sample_rows):
         ln = line("configs[3]" if flavour == "dense" else "configs[3]'", f"groupby on 1e6 {flavour} int64 keys: count / sum / mean / std of float64 v", 16, wall, k_ms, kernel, parity)
         if info:
             ln["groupby_kernels_ms"] = {kk: info[kk] for kk in ("ms_scatter", "ms_reduce", "ms_sort") if kk in info}
+            ln["groupby_pass"] = {kk: info[kk] for kk in ("buckets", "retries", "compact_records", "direct_table", "heavy_keys_in_pass", "dense_range_through_fused_pass") if kk in info}
+            # what a two-pass partition can reach at all: every row crosses the fabric three times — read (16 B), written as a
+            # record, read back as a record — and mixed read / write traffic moves at the chip's copy rate (6.29 TB/s measured, MI355X_MICROARCH.md),
+            # not at the 8 TB/s read peak `frac` is quoted against: floor_frac = 16 / structural bytes x 6.29 / 8
+            rec = 10 if info.get("direct_table") else (12 if info.get("compact_records") else 16)
+            ln["roofline"]["floor"] = {"structural_bytes_per_row": 16 + 2 * rec, "record_bytes": rec, "mixed_traffic_rate_GBs": 6290.0,
+                                        "floor_frac": 16.0 / (16 + 2 * rec) * 6290.0 / HBM_PEAK_GBS,
+                                        "note": "two-pass partition: 16 B read + record written + record read back per row, at the measured copy rate"}
         out.append(ln)
         del df, res
     return out

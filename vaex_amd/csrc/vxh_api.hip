@@ -1978,6 +1978,7 @@ int vxh_config_set(const char *key, int64_t value) {
     else if (k == "part_cap") c.cfg_part_cap = value;
     else if (k == "gb_compact") c.cfg_gb_compact = value;
     else if (k == "gb_direct") c.cfg_gb_direct = value;
+    else if (k == "gb_direct_nb") c.cfg_gb_direct_nb = value;
     else if (k == "gb_key32") c.cfg_gb_key32 = value;
     else if (k == "gb_abl") {
 #ifndef VXH_ABLATE
@@ -2052,6 +2053,7 @@ int vxh_config_get(const char *key, int64_t *value) {
     else if (k == "part_cap") *value = c.cfg_part_cap;
     else if (k == "gb_compact") *value = c.cfg_gb_compact;
     else if (k == "gb_direct") *value = c.cfg_gb_direct;
+    else if (k == "gb_direct_nb") *value = c.cfg_gb_direct_nb;
     else if (k == "gb_key32") *value = c.cfg_gb_key32;
     else if (k == "gb_abl") *value = c.cfg_gb_abl;
     else if (k == "gb_sets") *value = c.cfg_gb_sets;

@@ -643,6 +643,10 @@ __global__ void __launch_bounds__(1024) gb_reduce(const GbArgs G) {
             }
         }
     };
+    // (Round 6, tried and removed: the U records of a trip probed TOGETHER — all home lines read first, then compared, then accumulated, the
+    //  rare miss through slot_of — so that a lane's probe reads do not queue behind the previous record's atomics: 3.62 -> 4.07 ms per 1e9
+    //  records.  The kernel is bound by the LDS's throughput, not its latency: three 64-bit atomics per record are ~1.6 ms per CU at the
+    //  rates of profiles/r01_microbench_v3_lds_atomics.txt — the direct table's 1.9 ms — and the probe's 16-byte read and compares about as much again.)
     auto work = [&](const Trip &t) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -919,8 +923,13 @@ unsigned run_pipeline(GbArgs &G, int nv, bool merge, uint64_t n, uint64_t groups
     std::vector<unsigned long long> exact; // stream starts measured by a first attempt that found a stream too small (then: one exact second attempt)
     for (int attempt = 0; attempt < 6; ++attempt) {
         // a key range of at most 2^(10 + GB_DIRECT_BITS) cells: as many buckets as leave a remainder the LDS can index directly ("gb_direct", default on)
-        if (ctx().cfg_gb_compact && ctx().cfg_gb_direct && w == 1 && !merge && key_bits > 6 && key_bits <= nb_max + GB_DIRECT_BITS)
+        // (a direct table has no load factor: the bucket count follows from the range alone — "gb_direct_nb" buckets at least, as few as the
+        //  4096-slot tables allow: fewer streams grow longer segments per tile in gb_scatter)
+        if (ctx().cfg_gb_compact && ctx().cfg_gb_direct && w == 1 && !merge && key_bits > 6 && key_bits <= nb_max + GB_DIRECT_BITS) {
+            const int floor_nb = (int)std::min<int64_t>(nb_max, std::max<int64_t>(6, ctx().cfg_gb_direct_nb));
+            nb_log2 = std::min(std::max(floor_nb, key_bits - GB_DIRECT_BITS), key_bits - 1);
             nb_log2 = std::max(nb_log2, std::min(nb_max, key_bits - GB_DIRECT_BITS));
+        }
         const uint64_t NB = (uint64_t)1 << nb_log2;
         const int blocks = (int)std::max<uint64_t>(1, std::min<uint64_t>((n + T - 1) / T, (uint64_t)cus * per_cu));
         // sets of streams: one per XCD ("gb_sets", 8: blockIdx % 8 is the XCD a workgroup lands on), fewer when the launch has fewer
