@@ -453,6 +453,11 @@ int vxh_groupby_run_peeled(int key_dtype, const void *keys, int n_values, const 
 int vxh_groupby_merge(int n_values, const int64_t *keys, const int64_t *rows, const int64_t *const *counts,
                       const double *const *sums, const double *const *sums2, uint64_t n, uint64_t groups_hint, vxh_groupby **out);
 void vxh_groupby_destroy(vxh_groupby *g);
+/* the heavy hitters of a device-resident integer key column, from a strided sample of `sample` rows (every (n / sample)-th row): the keys
+ * holding at least `min_count` sampled rows, at most `max_keys` of them (the most frequent; ties by key), ascending, as int64 (a uint64
+ * key by its bit pattern) — the list vxh_groupby_run_peeled takes.  The reference has no counterpart: its hash map keeps a heavy key like
+ * any other (src/hash_primitives.hpp:471-479); the partitioned pass must know them beforehand.  out_keys: room for max_keys entries. */
+int vxh_sample_heavy_keys(int key_dtype, const void *keys, uint64_t n, uint32_t sample, uint32_t min_count, int max_keys, int64_t *out_keys, int *n_out);
 /* number of groups */
 uint64_t vxh_groupby_size(const vxh_groupby *g);
 /* one result column (vxh_groupby_column_kind; value_index selects the value column for COUNT..STD) into a host array of

@@ -582,3 +582,31 @@ def test_a_column_overwritten_in_place_is_scanned_again(sa, gpu_ready):
     np.testing.assert_array_equal(second["n"], w["rows"])
     np.testing.assert_array_equal(second["c"], w["v"][0]["cnt"])
     assert np.all(np.abs(second["s"] - w["v"][0]["s"]) <= 1e-12 * w["v"][0]["sabs"])
+
+
+@pytest.mark.parametrize("dtype,n", [("int64", 5_000_000), ("int32", 3_000_001), ("int16", 400_000), ("uint8", 1_000_000), ("int64", 1000), ("uint32", 2_000_000)])
+def test_the_librarys_heavy_key_sample_is_numpys(sa, gpu_ready, dtype, n):
+    """vxh_sample_heavy_keys (round 6: the heavy-hitter sample without torch.unique) against numpy on the same strided sample: the keys holding
+    >= min_count of 2^17 sampled rows, the 128 most frequent (ties: the smaller key), ascending"""
+    import torch
+    rng = np.random.default_rng(n % 1000 + len(dtype))
+    info = np.iinfo(dtype)
+    z = np.minimum(rng.zipf(1.2, n), 50_000)
+    k = ((z * 2654435761) % (int(info.max) - int(info.min) + 1) + int(info.min)).astype(dtype) if dtype not in ("uint8", "int16") else (z % 200 + (0 if dtype == "uint8" else -100)).astype(dtype)
+    tdt = {"uint32": None}.get(dtype, dtype)
+    if tdt is None:   # (torch has no uint32 tensors: the same bytes as int32, the library is told the real dtype)
+        kd = torch.from_numpy(k.view(np.int32)).cuda()
+    else:
+        kd = torch.from_numpy(k).cuda()
+    m = 1 << 17
+    step = max(1, n // m)
+    sample = k[::step][:m]
+    for share in (1.0 / 1024, 1.0 / 128, 0.5):
+        thr = max(8, int(len(sample) * share))
+        uniq, cnt = np.unique(sample.astype(np.int64), return_counts=True)
+        sel = cnt >= thr
+        uniq, cnt = uniq[sel], cnt[sel]
+        want = np.sort(uniq[np.argsort(-cnt, kind="stable")[:128]])
+        got = np.asarray(sa.sample_heavy_keys(kd, _DT[dtype], m, thr, 128))
+        np.testing.assert_array_equal(got, want)
+    assert len(np.asarray(sa.sample_heavy_keys(kd, _DT[dtype], m, len(sample) + 1, 128))) == 0

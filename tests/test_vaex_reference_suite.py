@@ -121,44 +121,47 @@ def test_what_passes_on_the_reference_classes_passes_through_the_host_logic_of_i
     host = cached_run("host", tmp_path)
     passed = [n for n, o in base["outcomes"].items() if o == "passed"]
     regressions = {n: host["why"].get(n, host["outcomes"].get(n, "not run"))[-700:] for n in passed if host["outcomes"].get(n) != "passed"}
-    if regressions and len(regressions) <= 40:   # (see the GPU test: the reference's nondeterministic tests get a second run)
-        again = run_files("host", tmp_path, files=sorted(regressions))
+    allowed = sorted(n for n in regressions if any(a in n for a in SECOND_RUN_ALLOWED))   # (see the GPU test: only the reference's known nondeterministic tests get a second run)
+    if allowed:
+        again = run_files("host", tmp_path, files=allowed)
         regressions = {n: w for n, w in regressions.items() if again["outcomes"].get(n) != "passed"}
     assert host["filter"]["runs_switched"] > 500 and host["task_stats"]["cpu"] > 1000, (host.get("filter"), host.get("task_stats"))
     assert not regressions, (len(regressions), dict(list(regressions.items())[:8]))
 
 
+#: tests of the reference that are nondeterministic ON THE REFERENCE'S OWN CLASSES and may take a second run alone (the list is the claim: anything
+#: else that needs one fails the test — ADVICE r5: a blanket second run would hide an intermittent fault of install()).
+#: execution_test.py::test_thread_safe enters the executor from four threads while the chunk size is being changed.
+SECOND_RUN_ALLOWED = ("execution_test.py::test_thread_safe",)
+
+
 @pytest.mark.gpu
 def test_what_passes_on_the_reference_classes_passes_on_the_hip_classes(tmp_path):
+    """ONE run on the reference's classes, ONE under install(): no run is repeated (round 5 repeated a run that died early and re-ran every
+    regression once; round 6 looped install() as the first GPU user of 360 fresh processes without a failure — profiles/r06_first_user.txt —
+    and took the allowances out).  A subprocess that dies leaves its whole output in the report directory."""
+    out_dir = os.environ.get("VAEX_AMD_REPORT_DIR")
     try:
         base = cached_run(False, tmp_path)
-    except AssertionError:               # (the same once-only allowance for the run on the reference's classes)
-        base = cached_run(False, tmp_path)
-    first_attempt = None
-    try:
         hip = run_files(True, tmp_path)
-    except AssertionError as e:          # (the subprocess died before it wrote its report)
-        hip, first_attempt = {"outcomes": {}}, str(e)[-1500:]
-    if len(hip["outcomes"]) < len(base["outcomes"]) // 2:
-        # One of three quick runs of this test on a fresh box ended within seconds (round 5, not understood, not reproduced in the two runs after
-        # it; the seven whole runs before it never did): a run that lost most of its tests is repeated ONCE, and the report says so.
-        first_attempt = first_attempt or hip.get("tail", "")
-        hip = run_files(True, tmp_path)
+    except AssertionError as e:          # (the subprocess died before it wrote its report: keep everything it said)
+        if out_dir:
+            with open(os.path.join(out_dir, "reference_suite_lost_run.txt"), "w") as f:
+                f.write(str(e))
+        raise
     passed = [n for n, o in base["outcomes"].items() if o == "passed"]
     assert len(passed) >= 1600 or _SUBSET, counts(base)
     regressions = {n: hip["why"].get(n, hip["outcomes"].get(n, "not run"))[-700:] for n in passed if hip["outcomes"].get(n) != "passed" and n not in EXPECTED_DIFFERENT}
     retried = {}
-    if regressions and len(regressions) <= 40:
-        # a few of the reference's tests are nondeterministic on its own classes (execution_test.py::test_thread_safe enters the executor from
-        # four threads while the chunk size is being changed): what failed runs once more, alone, and only a second failure counts
-        again = run_files(True, tmp_path, files=sorted(regressions))
-        retried = {n: again["outcomes"].get(n, "not run") for n in regressions}
-        regressions = {n: w for n, w in regressions.items() if retried[n] != "passed"}
+    allowed = sorted(n for n in regressions if any(a in n for a in SECOND_RUN_ALLOWED))
+    if allowed:
+        again = run_files(True, tmp_path, files=allowed)
+        retried = {n: again["outcomes"].get(n, "not run") for n in allowed}
+        regressions = {n: w for n, w in regressions.items() if retried.get(n) != "passed"}
     fixed = [n for n, o in hip["outcomes"].items() if o == "passed" and base["outcomes"].get(n) in ("failed", "error")]
     summary = {"reference_classes": counts(base), "hip_classes": counts(hip), "pass_on_both": len(passed) - len(regressions), "regressions": regressions,
-               "pass_only_under_install": fixed, "expected_different": EXPECTED_DIFFERENT, "second_runs": retried, "first_attempt_lost": first_attempt,
+               "pass_only_under_install": fixed, "expected_different": EXPECTED_DIFFERENT, "second_runs": retried, "second_run_allowed": list(SECOND_RUN_ALLOWED),
                "task_parts": hip.get("task_stats"), "groupby": hip.get("groupby"), "selection": hip.get("selection"), "filter": hip.get("filter")}
-    out_dir = os.environ.get("VAEX_AMD_REPORT_DIR")
     if out_dir:
         with open(os.path.join(out_dir, "reference_suite.json"), "w") as f:
             json.dump(summary, f, indent=1)

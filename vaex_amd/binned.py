@@ -1352,6 +1352,14 @@ class Frame:
             sel = cnt >= max(8, int(min(m, len(key[::step])) * share))
             uniq, cnt = uniq[sel], cnt[sel]
             hv = uniq[np.argsort(-cnt, kind="stable")[:128]]
+        elif hasattr(self.sa, "sample_heavy_keys") and _is_device(key) and _class_postfix(key) in _DT_CODE and not _class_postfix(key).startswith("float"):
+            # the library's own sampler (round 6: gather + rocPRIM sort + run-length encode; until then torch.unique — whose kernels torch loads
+            # on first use, ~100 ms of a process's first groupby)
+            m_eff = min(m, -(-self.n // step))
+            hv = np.asarray(self.sa.sample_heavy_keys(key, _DT_CODE[_class_postfix(key)], m, max(8, int(m_eff * share)), 128))
+            heavy = hv.astype(np.int64) if len(hv) else None
+            cache[(by, share)] = _memo(key, heavy)
+            return heavy
         else:
             try:
                 import torch

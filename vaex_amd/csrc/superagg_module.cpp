@@ -1025,6 +1025,18 @@ PYBIND11_MODULE(superagg, m) {
     m.attr("GB_STD") = (int)VXH_GB_STD;
     // groupby_run(keys, [v0, v1], key_dtype, groups_hint=0, max_groups=0): keys any integer array (host or device), values
     // float64 arrays living where the keys live
+    m.def("sample_heavy_keys", [](const py::object &keys, int key_dtype, uint32_t sample, uint32_t min_count, int max_keys) {
+        ArrayRef k = resolve_array(keys);
+        if (k.mem != VXH_MEM_DEVICE) throw std::runtime_error("sample_heavy_keys: a device-resident key column");
+        if (k.itemsize != kTypeSizes[key_dtype]) throw std::runtime_error("Itemsize of keys and key dtype are not equal");
+        py::array_t<int64_t> out((size_t)std::max(max_keys, 0));
+        int n_out = 0, rc;
+        { py::gil_scoped_release r; rc = vxh_sample_heavy_keys(key_dtype, k.ptr, k.n, sample, min_count, max_keys, out.mutable_data(), &n_out); }
+        check(rc);
+        out.resize({(size_t)n_out});
+        return out;
+    }, py::arg("keys"), py::arg("key_dtype") = (int)VXH_I64, py::arg("sample") = 1u << 17, py::arg("min_count") = 8, py::arg("max_keys") = 128,
+       "heavy hitters of a device-resident integer key column from a strided sample (vxh_sample_heavy_keys)");
     m.def("groupby_run", [](const py::object &keys, const std::vector<py::object> &values, int key_dtype, uint64_t hint, uint64_t max_groups, const py::object &keep, const py::object &key_range, const py::object &heavy) {
         std::vector<int64_t> hv; // heavy keys peeled inside the pass (vxh_groupby_run_peeled)
         if (!heavy.is_none()) for (auto item : py::array_t<int64_t, py::array::c_style | py::array::forcecast>::ensure(heavy).cast<std::vector<int64_t>>()) hv.push_back(item);

@@ -738,6 +738,12 @@ __global__ void __launch_bounds__(1024) gb_reduce(const GbArgs G) {
     }
 }
 
+// every `step`-th key of the column as the int64 the reference's ordered_set<T> would hold (vxh_sample_heavy_keys)
+__global__ void gb_sample_keys(const void *keys, int dt, uint64_t step, uint32_t m, long long *out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < m) out[i] = gb_fix_key(gb_load_key(keys, (uint64_t)i * step, dt), dt);
+}
+
 __global__ void gb_iota(unsigned int *p, uint64_t n) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
@@ -1147,6 +1153,64 @@ int vxh_groupby_run_peeled(int key_dtype, const void *keys, int n_values, const 
     (void)hipEventElapsedTime(&res->ms_sort, e0, e1);
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     *out = res.release();
+    GB_END
+}
+
+// The heavy hitters of a key column from a strided sample (Frame._heavy_keys: every key holding >= min_count of `sample` rows taken every
+// n / sample rows — the `max_keys` most frequent of them, ties by key, ascending in the output): gather + rocPRIM radix sort + run-length encode on
+// the device, the few runs that reach the threshold picked on the host.  (Until round 6 this was torch.unique over the same sample: torch's sort
+// kernels are loaded on first use, ~100 ms of a process's first groupby, profiles/r06_process_first.txt — and the one step of a groupby that
+// ran outside this library.)
+int vxh_sample_heavy_keys(int key_dtype, const void *keys, uint64_t n, uint32_t sample, uint32_t min_count, int max_keys, int64_t *out_keys, int *n_out) {
+    GB_BEGIN
+    *n_out = 0;
+    if (key_dtype == VXH_F64 || key_dtype == VXH_F32 || key_dtype < 0 || key_dtype >= VXH_DTYPE_COUNT) throw std::runtime_error("groupby: integer key dtypes only");
+    if (!n || !sample || max_keys <= 0) return 0;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { (void)hipGetLastError(); throw std::runtime_error("vaex_hip: no HIP device available (libvaexhip has no CPU fallback)"); }
+    (void)hipSetDevice(ctx().device);
+    Slot &slot = get_slot(0);
+    GbScratch &S = gb_scratch();
+    std::lock_guard<std::mutex> lock(S.mutex);
+    order_after_producers(slot);
+    const uint64_t step = std::max<uint64_t>(1, n / sample);
+    const uint32_t m = (uint32_t)std::min<uint64_t>(sample, (n + step - 1) / step); // = len(key[::step][:sample])
+    size_t sort_bytes = 0, rle_bytes = 0;
+    long long *raw = nullptr, *sorted = nullptr, *uniq = nullptr;
+    unsigned int *counts = nullptr, *runs = nullptr;
+    HIP_CHECK(rocprim::radix_sort_keys(nullptr, sort_bytes, raw, sorted, m, 0, 64, slot.stream));
+    HIP_CHECK(rocprim::run_length_encode(nullptr, rle_bytes, sorted, m, uniq, counts, runs, slot.stream));
+    const size_t tmp_bytes = (std::max(sort_bytes, rle_bytes) + 255) & ~(size_t)255;
+    S.small.need((size_t)m * (8 * 3 + 4) + 256 + tmp_bytes + 256);
+    char *p = (char *)S.small.p;
+    raw = (long long *)p; p += (size_t)m * 8;
+    sorted = (long long *)p; p += (size_t)m * 8;
+    uniq = (long long *)p; p += (size_t)m * 8;
+    counts = (unsigned int *)p; p += ((size_t)m * 4 + 255) & ~(size_t)255;
+    runs = (unsigned int *)p; p += 256;
+    void *tmp = p;
+    hipLaunchKernelGGL(gb_sample_keys, dim3((m + 255) / 256), dim3(256), 0, slot.stream, keys, key_dtype, step, m, raw);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(rocprim::radix_sort_keys(tmp, sort_bytes, raw, sorted, m, 0, 64, slot.stream));
+    HIP_CHECK(rocprim::run_length_encode(tmp, rle_bytes, sorted, m, uniq, counts, runs, slot.stream));
+    unsigned int n_runs = 0;
+    HIP_CHECK(hipMemcpyAsync(&n_runs, runs, 4, hipMemcpyDeviceToHost, slot.stream));
+    HIP_CHECK(hipStreamSynchronize(slot.stream));
+    std::vector<long long> hk(n_runs);
+    std::vector<unsigned int> hc(n_runs);
+    if (n_runs) {
+        HIP_CHECK(hipMemcpyAsync(hk.data(), uniq, (size_t)n_runs * 8, hipMemcpyDeviceToHost, slot.stream));
+        HIP_CHECK(hipMemcpyAsync(hc.data(), counts, (size_t)n_runs * 4, hipMemcpyDeviceToHost, slot.stream));
+        HIP_CHECK(hipStreamSynchronize(slot.stream));
+    }
+    // (rocPRIM sorts int64 as signed: the runs come in ascending key order — the order of numpy.unique / torch.unique)
+    std::vector<uint32_t> pick;
+    for (uint32_t i = 0; i < n_runs; i++) if (hc[i] >= min_count) pick.push_back(i);
+    std::stable_sort(pick.begin(), pick.end(), [&](uint32_t a, uint32_t b) { return hc[a] > hc[b]; }); // the most frequent first, ties by key
+    if (pick.size() > (size_t)max_keys) pick.resize((size_t)max_keys);
+    std::sort(pick.begin(), pick.end());
+    for (size_t i = 0; i < pick.size(); i++) out_keys[i] = (int64_t)hk[pick[i]];
+    *n_out = (int)pick.size();
     GB_END
 }
 
