@@ -534,6 +534,7 @@ def run(args):
     device = local_rank if args.backend == "nccl" else local_rank % sa.device_count()
     torch.cuda.set_device(device)
     sa.set_device(device)
+    sa.warmup()   # (what vaex_amd.install() does once: the kernels' code objects and thread slot 0 now, not inside the first call — `ms_first_call_in_process` is measured behind it)
     if world > 1:
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", device))
