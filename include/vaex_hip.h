@@ -242,6 +242,11 @@ typedef struct vxh_sel_step {
 int vxh_selection_set_program(vxh_selection *selection, int term, int n_steps, const vxh_sel_step *steps);
 /* the chunk of column `column` slot `thread` works on (borrowed like the aggregators' data: set_data, src/agg_base.hpp:166-179) */
 int vxh_selection_set_data(vxh_selection *selection, int thread, int column, const void *data, uint64_t n, int mem);
+/* the selection's keep-mask (1 = keep) of slot `thread`'s first n rows as bytes in caller-owned DEVICE memory (4-byte aligned, n bytes
+ * rounded up to 4): one pass on the slot's stream over device-resident columns, enqueued — not waited for; what the slot is given
+ * afterwards runs behind it.  For the passes that take a ready-made mask (vxh_groupby_run_kept, vxh_minmax): what vaex's numpy evaluation
+ * hands them per chunk (vaex/execution.py:530-549) */
+int vxh_selection_evaluate(vxh_selection *selection, int thread, uint64_t n, uint8_t *out_device);
 /* attach (NULL: detach) a selection to an aggregator: rows are kept where the predicate holds AND the data mask, if one is
  * set, is non-zero.  The selection is borrowed and must outlive its use in vxh_grid_bin. */
 int vxh_agg_set_selection(vxh_agg *agg, vxh_selection *selection);

@@ -222,9 +222,41 @@ class Frame:
         if isinstance(sel, _predicate.Predicate):
             cols = {n: self.columns[n] for n in sel.columns}
             if any(_is_device(c) for c in cols.values()):
-                return sel.torch_mask(cols)   # (terms AND their arithmetic programs: ADVICE r5 — the programs used to be dropped here)
+                mask = self._device_mask(sel, cols)
+                return mask if mask is not None else sel.torch_mask(cols)   # (terms AND their arithmetic programs: ADVICE r5 — the programs used to be dropped here)
             return sel.numpy_mask(cols)
         return sel
+
+    def _device_mask(self, pred, cols):
+        """the predicate's keep bytes over device columns from ONE pass of the library's sel_eval (vxh_selection_evaluate; round 6) — the
+        kernel the binned passes' device selections run through, so the rows kept are the same by construction — or None when the shim has no
+        such entry or a column's dtype has no device comparison (then: Predicate.torch_mask)"""
+        if not hasattr(getattr(self.sa, "Selection", None), "evaluate") or not all(_is_device(c) for c in cols.values()):
+            return None
+        try:
+            import torch
+            dtypes = [_predicate.dtype_code(cols[c].dtype) for c in pred.columns]
+        except (ImportError, _predicate.Unsupported):
+            return None
+        first = cols[pred.columns[0]]
+        n = len(first)
+        cache = self.__dict__.setdefault("_device_masks", {})
+        key = pred.key()
+        hit = cache.get(key)
+        if hit is not None and all(_memo_hit(m, cols[c]) for m, c in zip(hit[0], pred.columns)):
+            return hit[1]
+        sel = self.sa.Selection(1, dtypes, [(c, op, v) for c, op, v in pred.terms], pred.truth)
+        if pred.programs:
+            sel.set_programs({t: [tuple(st) for st in steps] for t, steps in pred.programs.items()})
+        for i, c in enumerate(pred.columns):
+            sel.set_data(0, i, cols[c])
+        out = torch.empty((n + 3) & ~3, dtype=torch.uint8, device=first.device)
+        sel.evaluate(0, n, out)
+        self.sa.slot_wait(0)   # (the mask is also read by torch kernels on torch's stream — the peel's intermediates — which the slot's stream does not order)
+        mask = out[:n]
+        cache.clear()   # (one mask per frame at a time: n bytes of HBM each)
+        cache[key] = ([_memo(cols[c], None) for c in pred.columns], mask)
+        return mask
 
     # ------------------------------------------------------------------ binners
     def minmax(self, column, selection=None):

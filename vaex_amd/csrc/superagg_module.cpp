@@ -470,6 +470,13 @@ struct PySelection {
         check(vxh_selection_set_data(h, thread, column, a.ptr, a.n, a.mem));
         held.hold(thread, column, ar, a);
     }
+    // keep-mask of the slot's first n rows into `out` (a device uint8 array of >= n bytes, e.g. a torch tensor): vxh_selection_evaluate
+    void evaluate(int thread, uint64_t n, const py::object &out) {
+        ArrayRef o = resolve_array(out);
+        if (o.mem != VXH_MEM_DEVICE || o.itemsize != 1 || o.n < ((n + 3) & ~(uint64_t)3)) throw std::runtime_error("Selection.evaluate: a device uint8 array of n bytes rounded up to 4");
+        check(vxh_selection_evaluate(h, thread, n, (uint8_t *)o.ptr));
+        held.hold(thread, 100, out, o); // (written by a kernel that may still be running when this returns)
+    }
 };
 
 struct PyAgg {
@@ -1140,7 +1147,8 @@ PYBIND11_MODULE(superagg, m) {
     py::class_<PySelection>(m, "Selection")
         .def(py::init<int, const std::vector<int> &, const std::vector<std::tuple<int, int, py::object>> &, uint32_t>(), py::arg("threads"), py::arg("dtypes"), py::arg("terms"), py::arg("truth"))
         .def("set_programs", &PySelection::set_programs, py::arg("programs"))
-        .def("set_data", &PySelection::set_data);
+        .def("set_data", &PySelection::set_data)
+        .def("evaluate", &PySelection::evaluate, py::arg("thread"), py::arg("n"), py::arg("out"));
     m.attr("SEL_COL") = (int)VXH_SEL_COL; m.attr("SEL_CONST") = (int)VXH_SEL_CONST; m.attr("SEL_ADD") = (int)VXH_SEL_ADD; m.attr("SEL_SUB") = (int)VXH_SEL_SUB;
     m.attr("SEL_MUL") = (int)VXH_SEL_MUL; m.attr("SEL_DIV") = (int)VXH_SEL_DIV; m.attr("SEL_NEG") = (int)VXH_SEL_NEG; m.attr("SEL_SQUARE") = (int)VXH_SEL_SQUARE;
     m.attr("SEL_SQRT") = (int)VXH_SEL_SQRT; m.attr("SEL_ABS") = (int)VXH_SEL_ABS;

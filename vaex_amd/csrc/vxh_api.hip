@@ -1865,6 +1865,44 @@ int vxh_slot_set_stream(int thread, void *hip_stream) {
     VXH_API_END
 }
 
+// The selection's keep-mask over its thread slot's DEVICE columns as bytes in caller-owned device memory (the passes that take a ready-made
+// mask — the fused groupby's keep bytes, minmax — get it from ONE sel_eval pass on the slot's stream instead of a chain of host-framework
+// elementwise kernels): enqueued, not waited for — work enqueued on the same slot afterwards is ordered behind it.
+int vxh_selection_evaluate(vxh_selection *sel, int thread, uint64_t n, uint8_t *out_device) {
+    VXH_API_BEGIN
+    ensure_device_ready();
+    if (!sel || !out_device) throw std::runtime_error("vxh_selection_evaluate: null argument");
+    if (thread < 0 || thread >= sel->threads) throw std::runtime_error("thread out of bound for data_ptr");
+    if (((uintptr_t)out_device & 3) != 0) throw std::runtime_error("vxh_selection_evaluate: the mask must be 4-byte aligned");
+    Slot &slot = get_slot(thread);
+    SelArgs S{};
+    for (int c = 0; c < sel->n_columns; c++) {
+        const SlotData &d = sel->data[c][(size_t)thread];
+        if (!d.ptr) throw std::runtime_error("data not set");
+        if (d.mem != VXH_MEM_DEVICE) throw std::runtime_error("vxh_selection_evaluate: device-resident columns only");
+        if (d.n < n) throw std::runtime_error("vxh_selection_evaluate: a column is shorter than the rows asked for");
+        S.col[c] = d.ptr;
+        S.dtype[c] = (uint8_t)sel->dtype[c];
+    }
+    S.nterms = sel->n_terms;
+    S.truth = sel->truth;
+    for (int t = 0; t < sel->n_terms; t++) {
+        S.t[t].column = sel->term[t].column; S.t[t].op = sel->term[t].op; S.t[t].is_int = sel->term[t].is_int;
+        S.t[t].value = sel->term[t].value; S.t[t].ivalue = sel->term[t].ivalue;
+        S.nsteps[t] = sel->nsteps[t];
+        for (int k2 = 0; k2 < sel->nsteps[t]; k2++) S.prog[t][k2] = sel->prog[t][k2];
+    }
+    S.and_mask = nullptr;
+    S.out = out_device;
+    S.n = n;
+    if (n) {
+        order_after_producers(slot);
+        vxh_launch_sel_eval(S, slot.stream);
+        HIP_CHECK(hipGetLastError());
+    }
+    VXH_API_END
+}
+
 // What a process otherwise pays inside its FIRST call (a first 1e9-row groupby took 0.6-1.0 s, its tenth 10 ms): the
 // runtime loads a translation unit's code object when the first of its kernels is launched (tens of milliseconds each for the big ones),
 // and thread slot 0's streams / events are created on first use.  vaex_amd.install() calls this once, before the first task exists.
