@@ -244,11 +244,13 @@ def other_configs(sa, torch, rows, sample_rows):
         # columns pays (their key range / NaN scan, their hot-box sample)
         process_first[0] = None
         if prime is not None:
+            run_primed = prime()   # (the copies are made HERE, outside the clock: torch's allocator asking the runtime for 8 GB blocks was 0.3-0.6 s of round 5's `ms_first_call_in_process`)
             torch.cuda.synchronize()
             tp = time.perf_counter()
-            prime()
+            run_primed()
             torch.cuda.synchronize()
             process_first[0] = (time.perf_counter() - tp) * 1e3
+            del run_primed
             torch.cuda.empty_cache()
         # the FIRST call over fresh columns is timed too: it pays what the later ones find remembered per column
         # object — the groupby's exact key-range pass (vxh_minmax_int, 8 B/row) and NaN scan of the value column, the hot-box sample —
@@ -339,7 +341,7 @@ def other_configs(sa, torch, rows, sample_rows):
     lim3 = [[-4, 4]] * 3
     # ---- north_star's target sentence: 2-D count(*) on a 256x256 grid (16 B/row; src/agg_count.cpp:43-67) ----
     c2d, wall, k_ms = timed(lambda: df.count(binby=["x", "y"], limits=lim3[:2], shape=256, edges=True),
-                            prime=lambda: Frame(dict(x=x.clone(), y=y.clone())).count(binby=["x", "y"], limits=lim3[:2], shape=256, edges=True))
+                            prime=lambda: (lambda f: lambda: f.count(binby=["x", "y"], limits=lim3[:2], shape=256, edges=True))(Frame(dict(x=x.clone(), y=y.clone()))))
     kernel = sa.last_kernel(0)
     parity = None
     if ref is not None:
@@ -358,7 +360,7 @@ def other_configs(sa, torch, rows, sample_rows):
     out.append(line("count2d", "2-D count(*) of float64 x,y on a 256x256 grid (north_star's target sentence)", 16, wall, k_ms, kernel, parity))
     del c2d
     c3, wall, k_ms = timed(lambda: df.count(binby=["x", "y", "z"], limits=lim3, shape=128, selection="sel", edges=True),
-                           prime=lambda: Frame(dict(x=x.clone(), y=y.clone(), z=z.clone(), sel=sel.clone())).count(binby=["x", "y", "z"], limits=lim3, shape=128, selection="sel", edges=True))
+                           prime=lambda: (lambda f: lambda: f.count(binby=["x", "y", "z"], limits=lim3, shape=128, selection="sel", edges=True))(Frame(dict(x=x.clone(), y=y.clone(), z=z.clone(), sel=sel.clone()))))
     kernel = sa.last_kernel(0)
     parity = None
     if ref is not None:
@@ -381,7 +383,7 @@ def other_configs(sa, torch, rows, sample_rows):
     # kernel (no mask bytes: x, y, z, v = 32 B/row; through a separate predicate pass it was 8 + 1 + 24 + 1 = 34) ----
     dfe = Frame(dict(x=x, y=y, z=z, v=v))
     c3e, wall, k_ms = timed(lambda: dfe.count(binby=["x", "y", "z"], limits=lim3, shape=128, selection="v > 3", edges=True),
-                            prime=lambda: Frame(dict(x=x.clone(), y=y.clone(), z=z.clone(), v=v.clone())).count(binby=["x", "y", "z"], limits=lim3, shape=128, selection="v > 3", edges=True))
+                            prime=lambda: (lambda f: lambda: f.count(binby=["x", "y", "z"], limits=lim3, shape=128, selection="v > 3", edges=True))(Frame(dict(x=x.clone(), y=y.clone(), z=z.clone(), v=v.clone()))))
     kernel = sa.last_kernel(0)
     parity = None
     if ref is not None:
@@ -424,7 +426,7 @@ def other_configs(sa, torch, rows, sample_rows):
             nonlocal_df[0] = Frame(dict(k=keys.clone(), v=v.clone()))
             return first_fn("the same first call again, over fresh clones")[2]
         nonlocal_df = [None]
-        res, wall, k_ms = timed(lambda: (nonlocal_df[0] or df).groupby("k", spec), prime=lambda: Frame(dict(k=keys.clone(), v=v.clone())).groupby("k", spec),
+        res, wall, k_ms = timed(lambda: (nonlocal_df[0] or df).groupby("k", spec), prime=lambda: (lambda f: lambda: f.groupby("k", spec))(Frame(dict(k=keys.clone(), v=v.clone()))),
                                 info=lambda: getattr(nonlocal_df[0] or df, "last_groupby_info", None), again=once_more)
         nonlocal_df[0] = None
         info = getattr(df, "last_groupby_info", None) or {}

@@ -592,7 +592,12 @@ def test_the_librarys_heavy_key_sample_is_numpys(sa, gpu_ready, dtype, n):
     rng = np.random.default_rng(n % 1000 + len(dtype))
     info = np.iinfo(dtype)
     z = np.minimum(rng.zipf(1.2, n), 50_000)
-    k = ((z * 2654435761) % (int(info.max) - int(info.min) + 1) + int(info.min)).astype(dtype) if dtype not in ("uint8", "int16") else (z % 200 + (0 if dtype == "uint8" else -100)).astype(dtype)
+    if dtype in ("uint8", "int16"):
+        k = (z % 200 + (0 if dtype == "uint8" else -100)).astype(dtype)
+    elif dtype == "int64":
+        k = (z * 2654435761) % (1 << 40) - (1 << 39)
+    else:
+        k = ((z * 2654435761) % (int(info.max) - int(info.min) + 1) + int(info.min)).astype(dtype)
     tdt = {"uint32": None}.get(dtype, dtype)
     if tdt is None:   # (torch has no uint32 tensors: the same bytes as int32, the library is told the real dtype)
         kd = torch.from_numpy(k.view(np.int32)).cuda()
