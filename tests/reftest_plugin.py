@@ -26,7 +26,8 @@ _asyncio.fixture = pytest.fixture
 sys.modules.setdefault("pytest_asyncio", _asyncio)
 
 INSTALL = os.environ.get("VAEX_AMD_REFTEST_INSTALL") == "1"
-HOST_LOGIC = os.environ.get("VAEX_AMD_REFTEST_INSTALL") == "host"   # install()'s host logic alone over vaex's own classes (no GPU needed)
+HOST_LOGIC = os.environ.get("VAEX_AMD_REFTEST_INSTALL") in ("host", "hostgb")   # install()'s host logic alone over vaex's own classes (no GPU needed)
+HOST_GROUPBY = os.environ.get("VAEX_AMD_REFTEST_INSTALL") == "hostgb"                # ... with the groupby wrapper's PLANNING on (which calls would the device groupby take?): without a device every planned call then declines with "device groupby failed" and vaex answers
 _outcomes = {}
 _why = {}
 
@@ -41,12 +42,48 @@ if INSTALL:
     vaex_amd.install()
 elif HOST_LOGIC:
     import vaex_amd
-    _backend = vaex_amd.install(hash_sets=False, legacy=False, groupby=False)
+    _backend = vaex_amd.install(hash_sets=False, legacy=False, groupby=HOST_GROUPBY)
 
     class _NoHip:
         def __getattr__(self, name):
             raise NotImplementedError("reftest: HIP classes switched off")
     _backend.__dict__["_hip"] = _NoHip()
+    if HOST_GROUPBY:
+        # the device groupby's stand-in without a GPU (as in tests/test_vaex_groupby.py): vaex_amd.binned.Frame driving the reference's own C++
+        # (dense key ranges; predicates as host masks) — so that which calls the wrapper TAKES, and what it hands back for them, can be checked here
+        import threading
+        import numpy as _np
+        from vaex_amd import binned as _binned, vaex_groupby as _vg
+        from tests.test_golden_api import RefAdapter
+        _ref = RefAdapter(vaex_amd._installed["cpu_module"])
+
+        def _no_pack(*a, **kw):   # (several keys are packed on the device: no CPU stand-in — such calls decline here)
+            raise NotImplementedError("reftest: multi-key packing needs the device")
+        _ref.pack_keys = _no_pack
+
+        class HostMaskFrame(_binned.Frame):
+            def _selection_mask(self, selection):
+                sel = super()._selection_mask(selection)
+                if isinstance(sel, _binned._predicate.Predicate):
+                    key = ("mask", sel.key())
+                    if key not in self._predicates:
+                        self._predicates[key] = sel.numpy_mask({c: self.columns[c] for c in sel.columns})
+                    return self._predicates[key]
+                return sel
+
+        class HostCollector:
+            def __init__(self, plan, capacity):
+                self.parts, self.lock, self.rows, self.capacity = [], threading.Lock(), 0, capacity
+
+            def append(self, chunks):
+                with self.lock:
+                    self.parts.append({k: _np.array(v) for k, v in chunks.items()})   # (process() has turned the blocks into plain numpy: _block_as_numpy)
+                    self.rows += len(next(iter(chunks.values())))
+
+            def frame(self):
+                return HostMaskFrame({k: _np.concatenate([p[k] for p in self.parts]) for k in self.parts[0]}, chunk_size=50_000, nthreads=2, superagg=_ref)
+        _vg._frame_for = lambda df, columns: HostMaskFrame(dict(columns), chunk_size=50_000, nthreads=2, superagg=_ref)
+        _vg._collector_for = lambda plan, capacity: HostCollector(plan, capacity)
 
 
 def pytest_runtest_logreport(report):
@@ -75,7 +112,7 @@ def pytest_sessionfinish(session, exitstatus):
     if INSTALL or HOST_LOGIC:
         from vaex_amd import vaex_groupby, vaex_selection, vaex_filter
         doc["task_stats"] = {k: v for k, v in vaex_amd.task_stats.items() if isinstance(v, (int, float, str, dict))}
-        doc["groupby"] = {"device": vaex_groupby.stats.get("device", 0), "task": vaex_groupby.stats.get("task", 0), "vaex": vaex_groupby.stats.get("vaex", 0), "why": vaex_groupby.stats.get("why", {})}
+        doc["groupby"] = {"device": vaex_groupby.stats.get("device", 0), "task": vaex_groupby.stats.get("task", 0), "vaex": vaex_groupby.stats.get("vaex", 0), "why": vaex_groupby.stats.get("why", {}), "by_test": vaex_groupby.stats.get("by_test", {})}
         doc["selection"] = dict(vaex_selection.stats)
         doc["filter"] = dict(vaex_filter.stats)
     with open(path, "w") as f:

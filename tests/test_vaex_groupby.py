@@ -334,6 +334,38 @@ assert vg.last.get("path") == "vaex" and "device groupby failed" in vg.last.get(
 want = original(df, "k", agg={"s": A.sum("v"), "c": A.count()}, sort=True)
 same({c: got[c].to_numpy() for c in got.get_column_names()}, {c: want[c].to_numpy() for c in want.get_column_names()}, "device failure falls back")
 print("ok-device-failure-falls-back")
+# round 6: columns that are not ONE numpy array — arrow arrays / chunked arrays without nulls, a concatenated frame's ColumnProxy — are streamed to the
+# device groupby through one pass of the executor (the groupby task collects the chunks); nulls decline at the plan (arrow) or after the pass (proxy)
+import pyarrow as pa
+na = 60_000
+ra = np.random.default_rng(9)
+ka, va, ia = ra.integers(-7, 300, na), ra.normal(1, 2, na), ra.integers(0, 50, na).astype("i4")
+va[::41] = np.nan
+dfa = vaex.from_arrays(k=pa.array(ka), v=pa.chunked_array([pa.array(va[:25_000]), pa.array(va[25_000:])]), i=pa.array(ia), kn=pa.array(ka, mask=ra.random(na) < 0.01), plain=ka * 2)
+agg_a = {"s": A.sum("v"), "c": A.count(), "m": A.mean("v"), "si": A.sum("i")}
+for by_a, what in (("k", "arrow key and values"), ("plain", "numpy key, arrow values"), ("i", "arrow int32 key")):
+    vg.last.clear()
+    got = dfa.groupby(by_a, agg=agg_a)
+    assert vg.last.get("path") == "device", (what, vg.last)
+    same(grouped(got, [by_a]), grouped(original(dfa, by_a, agg=agg_a), [by_a]), what)
+    print("ok-streamed " + what)
+vg.last.clear()
+got = dfa[dfa.i > 10].groupby("k", agg={"c": A.count(), "s": A.sum("v")})        # a filter: the executor compacts the chunks of the pass
+assert vg.last.get("path") == "device", vg.last
+same(grouped(got, ["k"]), grouped(original(dfa[dfa.i > 10], "k", agg={"c": A.count(), "s": A.sum("v")}), ["k"]), "streamed, filtered")
+print("ok-streamed filtered")
+vg.last.clear()
+got = dfa.groupby("kn", agg={"c": A.count()})                                  # nulls in the key: vaex's own groupby (a missing-value group exists there)
+assert vg.last.get("path") == "vaex" and "not a plain numpy column" in vg.last.get("why", ""), vg.last
+same(grouped(got, ["kn"]), grouped(original(dfa, "kn", agg={"c": A.count()}), ["kn"]), "arrow key with nulls")
+print("ok-streamed nulls decline")
+dfc = vaex.concat([vaex.from_arrays(k=ka[:20_000], v=va[:20_000]), vaex.from_arrays(k=ka[20_000:], v=va[20_000:])])
+vg.last.clear()
+got = dfc.groupby("k", agg={"c": A.count(), "s": A.sum("v"), "sd": A.std("v")}, sort=True)
+assert vg.last.get("path") == "device", vg.last
+want = original(dfc, "k", agg={"c": A.count(), "s": A.sum("v"), "sd": A.std("v")}, sort=True)
+same({c: got[c].to_numpy() for c in got.get_column_names()}, {c: want[c].to_numpy() for c in want.get_column_names()}, "concatenated frame (ColumnProxy)")
+print("ok-streamed concat")
 print("DONE")
 '''
 
@@ -349,7 +381,7 @@ def _run(gpu, timeout):
 def test_groupby_host_logic_against_vaex_on_the_reference_cpp():
     out = _run(0, 600)
     assert "DONE" in out and out.count("ok-device ") == 15 and out.count("ok-device-filtered") == 5 and out.count("ok-declined") == 8, out
-    assert "ok-device-failure-falls-back" in out and out.count("ok-task") == 8 and "ok-reference-defects" in out, out
+    assert "ok-device-failure-falls-back" in out and out.count("ok-task") == 8 and "ok-reference-defects" in out and out.count("ok-streamed") == 6, out
 
 
 @pytest.mark.gpu
@@ -357,4 +389,4 @@ def test_groupby_host_logic_against_vaex_on_the_reference_cpp():
 def test_groupby_of_real_vaex_runs_on_the_device_groupby():
     out = _run(1, 900)
     assert "DONE" in out and out.count("ok-device ") == 21 and out.count("ok-device-filtered") == 7 and out.count("ok-declined") == 8 and out.count("ok-task") == 8, out
-    assert "gb_scatter+gb_reduce" in out and "bin_lds" in out, out   # (the fused hash aggregation, and — few groups — the LDS-resident grid)
+    assert "gb_scatter+gb_reduce" in out and "bin_lds" in out and out.count("ok-streamed") == 6, out   # (the fused hash aggregation, and — few groups — the LDS-resident grid)

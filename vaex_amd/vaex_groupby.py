@@ -32,6 +32,7 @@ masked int64 array without masked entries when vaex would have simplified to Bin
 keys), else the narrowest signed integer type that holds the key range (vaex/groupby.py:263-277).
 """
 import collections.abc
+import os
 import itertools
 import threading
 import weakref
@@ -55,18 +56,55 @@ class _Decline(Exception):
     """the call is outside the device groupby's signature: vaex's own code answers it"""
 
 
+class _Streamed:
+    """a real numeric column that is not one numpy array — a pyarrow Array / ChunkedArray without nulls (arrow / parquet files,
+    vaex/arrow/dataset.py), a dataset's ColumnProxy (sliced / concatenated / renamed datasets, vaex/dataset.py:575-611): the plan knows its
+    dtype and length, the rows come chunk by chunk through the executor (the groupby TASK: TaskGroupbyHip) — round 6"""
+
+    def __init__(self, dtype, n, source):
+        self.dtype, self.n, self.source = np.dtype(dtype), int(n), source
+
+    def __len__(self):
+        return self.n
+
+
+def _streamed_dtype(df, name, ar):
+    """numpy dtype of a column object whose rows can be streamed to the device groupby as plain numeric chunks, else None"""
+    from . import predicate
+    dt = predicate.plain_numeric_dtype(ar)          # arrow without nulls (and plain numpy)
+    if dt is not None:
+        return dt
+    if type(ar).__name__ == "ColumnProxy" and hasattr(ar, "ds"):
+        try:
+            dt = df.data_type(name)
+            if dt.is_numeric or dt == bool:         # (missing values show when the chunks arrive: the task then leaves the pass to vaex)
+                dt = np.dtype(dt.numpy)
+                return dt if dt.isnative else None
+        except Exception:   # noqa: BLE001  (a column type vaex itself cannot describe as numpy)
+            return None
+    return None
+
+
 def _real_column(df, expression, kinds, what):
-    """the numpy array behind `expression` when it names a real, unmasked column of one of `kinds` (active range applied)"""
+    """the numpy array behind `expression` when it names a real, unmasked column of one of `kinds` (active range applied) — or a _Streamed
+    stand-in for a real numeric column held in another container (its rows then reach the device through the executor's chunks)"""
     name = str(expression)
     if name not in df.columns:
         label = getattr(df[name], "_label", name) if name in getattr(df, "virtual_columns", {}) else name
         raise _Decline(f"{what} {label!r} is not a real column")
     ar = df.columns[name]
+    i1, i2 = df._index_start, df._index_end
     if np.ma.isMaskedArray(ar) or not isinstance(ar, np.ndarray):
-        raise _Decline(f"{what} {name!r} is not a plain numpy column")
+        kind = "masked numpy" if np.ma.isMaskedArray(ar) else f"{type(ar).__module__.split('.')[0]}.{type(ar).__name__}" + (f"[{ar.type}]" if hasattr(ar, "type") and hasattr(ar, "null_count") else "")
+        dt = None if np.ma.isMaskedArray(ar) else _streamed_dtype(df, name, ar)
+        if dt is None:
+            raise _Decline(f"{what} {name!r} is not a plain numpy column ({kind})")
+        if dt.name not in kinds:
+            raise _Decline(f"{what} {name!r} has dtype {dt}")
+        n = len(ar)
+        return name, _Streamed(dt, (n if i2 is None else i2) - i1, ar)
     if ar.dtype.name not in kinds or not ar.dtype.isnative or ar.ndim != 1:
         raise _Decline(f"{what} {name!r} has dtype {ar.dtype}")
-    i1, i2 = df._index_start, df._index_end
     if i2 is None:
         i2 = len(ar)
     if i1 != 0 or i2 != len(ar):
@@ -196,9 +234,13 @@ def _key_column_like_vaex(values, source_kind=None):
     return k
 
 
+class _NeedsTask(Exception):
+    """the call is inside the device groupby's signature, but a column is not one numpy array: answer it as a task of an executor pass"""
+
+
 class _Plan:
     """what a df.groupby(by, agg) call needs from the device groupby, decided before a row is read"""
-    __slots__ = ("by", "agg", "sort", "srt", "asc", "columns", "key_names", "actions", "spec", "selection", "rows", "predicates")
+    __slots__ = ("by", "agg", "sort", "srt", "asc", "columns", "key_names", "actions", "spec", "selection", "rows", "predicates", "streamed")
 
 
 def _plan(df, by, agg, sort=False, ascending=True, row_limit=None, for_task=False):
@@ -215,7 +257,7 @@ def _plan(df, by, agg, sort=False, ascending=True, row_limit=None, for_task=Fals
         raise _Decline(f"{len(by_list)} keys")
     for b in by_list:
         if isinstance(b, vaex.groupby.BinnerBase):
-            raise _Decline("binner object as key")
+            raise _Decline(f"binner object as key ({type(b).__name__})")
     asc = list(ascending) if isinstance(ascending, (list, tuple)) else [ascending] * len(by_list)
     srt = list(sort) if isinstance(sort, (list, tuple)) else [sort] * len(by_list)
     if len(set(zip(srt, asc))) > 1:
@@ -258,6 +300,7 @@ def _plan(df, by, agg, sort=False, ascending=True, row_limit=None, for_task=Fals
     plan.columns, plan.key_names, plan.actions, plan.spec, plan.selection = columns, key_names, actions, spec, selection
     plan.rows = len(next(iter(columns.values())))
     plan.predicates = predicates
+    plan.streamed = any(isinstance(c, _Streamed) for c in columns.values())
     return plan
 
 
@@ -313,6 +356,8 @@ def _finish(df, plan, frame, res):
 def fast_groupby(df, by, agg, sort=False, ascending=True, row_limit=None):
     """the grouped DataFrame, or _Decline"""
     plan = _plan(df, by, agg, sort=sort, ascending=ascending, row_limit=row_limit)
+    if plan.streamed:
+        raise _NeedsTask()   # (arrow / proxy columns: their chunks come through the executor — the caller schedules the groupby task and runs the pass)
     try:
         frame = _frame_for(df, plan.columns)
     except (NotImplementedError, ValueError) as e:
@@ -455,9 +500,20 @@ def _collector_for(plan, capacity):
 
 
 def _block_as_numpy(block):
-    if isinstance(block, np.ndarray) and not np.ma.isMaskedArray(block):
+    """a chunk as the executor hands it over -> a plain numpy array; missing values are outside the device groupby (RuntimeError: the task
+    then leaves the pass to the others and vaex's own groupby answers afterwards)"""
+    if isinstance(block, np.ndarray):
+        if np.ma.isMaskedArray(block):
+            if np.ma.getmaskarray(block).any():
+                raise RuntimeError("delayed groupby: a chunk with masked values")
+            return np.ma.getdata(block)
         return block
-    raise RuntimeError(f"delayed groupby: a chunk of type {type(block).__name__} (the plan saw plain numpy columns)")
+    if hasattr(block, "null_count") and hasattr(block, "type"):   # a pyarrow Array / ChunkedArray (arrow-backed frames)
+        if block.null_count:
+            raise RuntimeError("delayed groupby: a chunk with missing values")
+        import vaex.array_types
+        return np.asarray(vaex.array_types.to_numpy(block))
+    raise RuntimeError(f"delayed groupby: a chunk of type {type(block).__name__} (the plan saw plain numeric columns)")
 
 
 def _could_be_served(df, by, row_limit):
@@ -512,6 +568,8 @@ def install(vaex_module, state):
         last.update(path="vaex", why=str(e))
         stats["vaex"] += 1
         stats["why"][str(e)[:100]] = stats["why"].get(str(e)[:100], 0) + 1
+        if os.environ.get("VAEX_AMD_GROUPBY_TRACE"):   # (which caller: the reference's test id when its suite runs under install())
+            stats.setdefault("by_test", {}).setdefault(os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0], []).append(str(e)[:70])
 
     import vaex.cpu
     import vaex.tasks
@@ -613,6 +671,28 @@ def install(vaex_module, state):
         weakref.finalize(task, _PLANS.pop, token, None)   # (a task that is dropped, cancelled or rejected before its part is built)
         return df.executor.schedule(task)
 
+    def eager(df, by, actions, sort, ascending, row_limit, kwargs, progress):
+        """the grouped DataFrame of an eager call, or _Decline: one fused pass over whole numpy columns — or, where a column is held in another
+        container (arrow, a dataset's proxy: round 6), the same device groupby fed by ONE pass of the executor, the groupby task collecting the
+        chunks in HBM (vaex's own groupby takes two passes); what else the caller has scheduled rides that pass, as with vaex's own"""
+        try:
+            result = _served(progress, lambda: fast_groupby(df, by, actions, sort=sort, ascending=ascending, row_limit=row_limit))
+        except _NeedsTask:
+            promise = schedule_task(df, by, actions, sort, ascending, row_limit, kwargs)
+            before = stats["task"]
+            df.execute()
+            result = promise.get()
+            if stats["task"] == before:   # (the task handed the call back to vaex after the pass — a chunk with missing values, ...: booked as declined there)
+                raise _Answered(result)
+            stats["task"] -= 1            # (an eager call: the caller books it under "device")
+        return result
+
+    class _Answered(Exception):
+        """vaex's own groupby answered inside the task (and the decline is booked): nothing left to do but hand the result on"""
+
+        def __init__(self, result):
+            self.result = result
+
     class LazyGroupBy(vaex.groupby.GroupBy):
         """df.groupby(by) WITHOUT agg: vaex builds the groupers — the distinct-key pass over the key columns — in GroupBy.__init__
         (vaex/groupby.py:602-668), before it knows the aggregation.  This object postpones that: `.agg(...)` of a signature the device
@@ -648,8 +728,11 @@ def install(vaex_module, state):
             if "_lazy" in self.__dict__:
                 df, kw = self.__dict__["_lazy"]
                 try:
-                    result = _served(progress if progress is not None else kw.get("progress"),
-                                     lambda: fast_groupby(df, kw["by"], actions, sort=kw["sort"], ascending=kw["ascending"], row_limit=kw["row_limit"]))
+                    result = eager(df, kw["by"], actions, kw["sort"], kw["ascending"], kw["row_limit"],
+                                   dict(sort=kw["sort"], ascending=kw["ascending"], assume_sparse=kw["assume_sparse"], row_limit=kw["row_limit"], copy=kw["copy"], progress=progress if progress is not None else kw.get("progress")),
+                                   progress if progress is not None else kw.get("progress"))
+                except _Answered as a:
+                    return df._delay(delay, vaex.promise.Promise.fulfilled(a.result))
                 except _Decline as e:
                     declined(e)
                     self._materialise()
@@ -670,7 +753,10 @@ def install(vaex_module, state):
                 declined(e)
         elif agg is not None:
             try:
-                result = _served(progress, lambda: fast_groupby(self, by, agg, sort=sort, ascending=ascending, row_limit=row_limit))
+                result = eager(self, by, agg, sort, ascending, row_limit,
+                               dict(sort=sort, ascending=ascending, assume_sparse=assume_sparse, row_limit=row_limit, copy=copy, progress=progress), progress)
+            except _Answered as a:
+                return self._delay(delay, vaex.promise.Promise.fulfilled(a.result))
             except _Decline as e:
                 declined(e)
             else:
