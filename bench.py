@@ -660,7 +660,7 @@ def run(args):
         # HBM bytes per launch from the PMC counters of the same command (separate rocprofv3 --pmc passes,
         # FETCH_SIZE corrected x2 on gfx950): measured offline, kept under profiles/
         traffic = traffic_source = None
-        for tname in ("r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
+        for tname in ("r06_traffic.json", "r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
             tpath = os.path.join(ROOT, "profiles", tname)
             if os.path.exists(tpath) and main_kernel.startswith("part_scatter") and shape == 256:
                 traffic = json.load(open(tpath))["hbm_bytes_per_row"] * rows

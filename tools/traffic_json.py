@@ -24,7 +24,7 @@ def parse(path):
 
 bench = parse(sys.argv[1]).get("bench", {})
 cfgs = parse(sys.argv[2]) if len(sys.argv) > 2 and os.path.exists(sys.argv[2]) else {}
-label = sys.argv[3] if len(sys.argv) > 3 else "5"
+label = sys.argv[3] if len(sys.argv) > 3 else "6"
 ROWS = 1_000_000_000
 # kernels of one pass: (name prefix, dispatches per pass)
 SPEC = {
@@ -32,7 +32,7 @@ SPEC = {
     "count2d": ([("part_scatter_wv", 1), ("part_reduce_", 1), ("part_merge", 1), ("part_hot_merge", 1)], 16),   # (round 5: through the hot box; rounds 3-4: count_lds_f64 + fold_kernel)
     "c2": ([("part_scatter_wv", 4), ("part_reduce_fast", 4), ("part_merge", 1)], 25),
     "c2e": ([("part_scatter_wv", 4), ("part_reduce_fast", 4), ("part_merge", 1)], 32),
-    "c3d": ([("part_scatter_f64", 2), ("part_reduce_fast", 2), ("part_merge", 1)], 16),
+    "c3d": ([("gb_scatter", 1), ("gb_reduce", 1)], 16),   # (round 6: the dense range through the fused pass with a direct table; rounds 3-5: part_scatter_f64 x2 + part_reduce_fast x2 + part_merge)
     "c3s": ([("gb_scatter", 1), ("gb_reduce", 1)], 16),
 }
 
