@@ -310,11 +310,32 @@ import gc
 before_plans = len(vg._PLANS)
 pz = df.groupby("k", agg={"c": A.count()}, delay=True)
 assert len(vg._PLANS) == before_plans + 1
-df.executor.tasks.remove(pz)
-del pz
+tz = [t for t in df.executor.tasks if type(t).__name__ == "TaskGroupbyHip"][-1]   # (the promise handed out is the task's .then(): round 6)
+df.executor.tasks.remove(tz)
+del pz, tz
 gc.collect()
 assert len(vg._PLANS) == before_plans, (before_plans, len(vg._PLANS))
 print("ok-task dropped before it ran")
+# round 6: the groupby task is cacheable like the reference's tasks (vaex/execution.py:227-237): with vaex.cache on, the same delayed call again is
+# fulfilled when it is scheduled — no pass — and equal calls waiting for the same pass are ONE task
+import vaex.cache
+with vaex.cache.memory_infinite(clear=True):
+    passes0 = df.executor.passes if hasattr(df.executor, "passes") else None
+    pc1 = df.groupby("k", agg={"c": A.count(), "s": A.sum("v")}, delay=True)
+    pc1b = df.groupby("k", agg={"c": A.count(), "s": A.sum("v")}, delay=True)      # an equal call before the pass: the same task
+    assert sum(type(t).__name__ == "TaskGroupbyHip" for t in df.executor.tasks) == 1, df.executor.tasks
+    df.execute()
+    cached0 = vg.stats.get("cached", 0)
+    pc2 = df.groupby("k", agg={"c": A.count(), "s": A.sum("v")}, delay=True)        # after it: from the cache, nothing scheduled
+    assert vg.stats.get("cached", 0) == cached0 + 1 and not any(type(t).__name__ == "TaskGroupbyHip" for t in df.executor.tasks), (vg.stats, df.executor.tasks)
+    pc3 = df.groupby("k", agg={"c": A.count(), "s": A.sum("w")}, delay=True)        # another aggregation: another fingerprint
+    assert any(type(t).__name__ == "TaskGroupbyHip" for t in df.executor.tasks)
+    df.execute()
+    want_c = grouped(original(df, "k", agg={"c": A.count(), "s": A.sum("v")}), ["k"])
+    for pc in (pc1, pc1b, pc2):
+        same(grouped(pc.get(), ["k"]), want_c, "cached delayed groupby")
+    same(grouped(pc3.get(), ["k"]), grouped(original(df, "k", agg={"c": A.count(), "s": A.sum("w")}), ["k"]), "another aggregation is another cache entry")
+print("ok-task cache")
 # a progress callable sees the executor's fractions; returning False cancels the task (vaex's UserAbort at .get())
 seen = []
 pg = df.groupby("k", agg={"c": A.count()}, delay=True)
@@ -381,12 +402,12 @@ def _run(gpu, timeout):
 def test_groupby_host_logic_against_vaex_on_the_reference_cpp():
     out = _run(0, 600)
     assert "DONE" in out and out.count("ok-device ") == 15 and out.count("ok-device-filtered") == 5 and out.count("ok-declined") == 8, out
-    assert "ok-device-failure-falls-back" in out and out.count("ok-task") == 8 and "ok-reference-defects" in out and out.count("ok-streamed") == 6, out
+    assert "ok-device-failure-falls-back" in out and out.count("ok-task") == 9 and "ok-reference-defects" in out and out.count("ok-streamed") == 6, out
 
 
 @pytest.mark.gpu
 @pytest.mark.skipif(not os.path.isdir(os.path.join(PKG, "vaex")), reason="real vaex package not built (oracle/build_ref.sh needs /root/reference)")
 def test_groupby_of_real_vaex_runs_on_the_device_groupby():
     out = _run(1, 900)
-    assert "DONE" in out and out.count("ok-device ") == 21 and out.count("ok-device-filtered") == 7 and out.count("ok-declined") == 8 and out.count("ok-task") == 8, out
+    assert "DONE" in out and out.count("ok-device ") == 21 and out.count("ok-device-filtered") == 7 and out.count("ok-declined") == 8 and out.count("ok-task") == 9, out
     assert "gb_scatter+gb_reduce" in out and "bin_lds" in out and out.count("ok-streamed") == 6, out   # (the fused hash aggregation, and — few groups — the LDS-resident grid)

@@ -322,9 +322,21 @@ def _run(plan, frame):
 
 def _finish(df, plan, frame, res):
     """the grouped DataFrame the way GroupBy.agg builds it (vaex/groupby.py:955-983)"""
+    return _frame_from(df, plan, _finish_arrays(df, plan, frame, res))
+
+
+def _frame_from(df, plan, finished):
+    """finished = {"arrays": {column: array}, "combined": bool} (what the groupby task's result is, and what vaex's task cache keeps) -> the DataFrame"""
     import vaex
     import vaex.dataset
     import vaex.groupby
+    dataset_arrays = vaex.dataset.DatasetArrays(dict(finished["arrays"]))
+    dataset = vaex.groupby.DatasetGroupby(dataset_arrays, df, plan.by, plan.agg, combine=finished["combined"], expand=True, sort=plan.sort)
+    return vaex.from_dataset(dataset)
+
+
+def _finish_arrays(df, plan, frame, res):
+    """the result columns typed and ordered the way GroupBy.agg hands them back, as plain arrays"""
     key_names, columns, actions = plan.key_names, plan.columns, plan.actions
     descending = bool(plan.srt[0]) and not plan.asc[0]
     out = {}
@@ -348,9 +360,7 @@ def _finish(df, plan, frame, res):
     ran = sorted({frame.sa.last_kernel(t) for t in getattr(frame, "last_slots", [0])} - {""}) if hasattr(frame.sa, "last_kernel") else []
     kernel = "gb_scatter+gb_reduce" if fused else "+".join(ran)
     last.update(path="device", kernel=kernel, info=frame.last_groupby_info, groups=len(next(iter(out.values()))))
-    dataset_arrays = vaex.dataset.DatasetArrays(out)
-    dataset = vaex.groupby.DatasetGroupby(dataset_arrays, df, plan.by, plan.agg, combine=combined, expand=True, sort=plan.sort)
-    return vaex.from_dataset(dataset)
+    return {"arrays": out, "combined": bool(combined)}
 
 
 def fast_groupby(df, by, agg, sort=False, ascending=True, row_limit=None):
@@ -578,12 +588,27 @@ def install(vaex_module, state):
         """df.groupby(by, agg, delay=True) as one task of the executor's pass (see above); fulfilled with the grouped DataFrame"""
         snake_name = "groupby_hip"
         see_all = True        # ONE task part, shown every chunk (vaex/execution.py:404-406, :553-556)
-        cacheable = False
+        # Round 6: like every task of the reference (vaex/execution.py:227-237, :457-474) — with vaex.cache on, a groupby whose frame, keys and
+        # aggregations were seen before is fulfilled from the cache when it is scheduled, without a pass.  The task's result is the finished
+        # columns as plain arrays (what the cache keeps: any backend can pickle them); the caller's promise turns them into the DataFrame.
+        cacheable = True
 
         def __init__(self, df, plan, token):
             super().__init__(df=df, expressions=list(plan.columns), pre_filter=df.filtered, name=self.snake_name)
             self.selections = []
             self.plan, self.token = plan, token
+
+        def fingerprint(self):
+            # (the reference hashes the task's ENCODING, vaex/tasks.py:108-114 — here a per-call token that finds the plan again, so the call
+            #  itself is hashed: keys, output columns and their aggregations / selections, the filter, the order)
+            if self._fingerprint is None:
+                import vaex.cache
+                plan = self.plan
+                call = [list(plan.key_names), [[name, d.name, d.column, None if d.selection is None else str(d.selection)] for name, d in plan.spec.items()],
+                        None if plan.selection is None else str(plan.selection), [bool(x) for x in plan.srt], [bool(x) for x in plan.asc]]
+                df_fp = self.df.fingerprint(dependencies=self.dependencies())
+                self._fingerprint = f"task-{self.name}-{vaex.cache.fingerprint(call)}-{df_fp}"
+            return self._fingerprint
 
         def get_bin_count(self):
             return 0
@@ -598,9 +623,9 @@ def install(vaex_module, state):
         snake_name = "groupby_hip"
 
         def __init__(self, df, token):
-            plan, collector, fallback = _PLANS[token]
+            plan, collector, fallback, task = _PLANS[token]
             super().__init__(df, list(plan.columns), self.snake_name, df.filtered)
-            self.token, self.plan, self.collector, self.fallback = token, plan, collector, fallback
+            self.token, self.plan, self.collector, self.fallback, self.task = token, plan, collector, fallback, task
             self.failed = None
 
         @classmethod
@@ -638,12 +663,15 @@ def install(vaex_module, state):
                     raise _Decline("delayed groupby: the filter left no row")   # (vaex's own answer: no group, its own column types)
                 frame = self.collector.frame()
                 res = _run(self.plan, frame)
-                result = _finish(self.df, self.plan, frame, res)
+                result = _finish_arrays(self.df, self.plan, frame, res)
             except _Decline as e:
                 # the data turned out to be outside the device groupby (key ranges whose product overflows, a device failure, ...): the pass
                 # is over and the executor idle (vaex/execution.py:436-441) — vaex's own groupby answers, now
                 declined(e)
-                result = self.fallback()
+                task = self.task() if self.task is not None else None
+                if task is not None:
+                    task.cacheable = False      # (a DataFrame of vaex's own making is not what this task's cache entries are)
+                result = {"frame": self.fallback()}
             else:
                 stats["task"] += 1
             finally:
@@ -666,10 +694,15 @@ def install(vaex_module, state):
         except (RuntimeError, MemoryError, ImportError) as e:
             raise _Decline(f"device groupby failed: {type(e).__name__}: {str(e)[:200]}")
         token = next(_tokens)
-        _PLANS[token] = (plan, collector, lambda: original(df, by=by, agg=agg, delay=False, **kwargs))
         task = TaskGroupbyHip(df, plan, token)
+        _PLANS[token] = (plan, collector, lambda: original(df, by=by, agg=agg, delay=False, **kwargs), weakref.ref(task))
         weakref.finalize(task, _PLANS.pop, token, None)   # (a task that is dropped, cancelled or rejected before its part is built)
-        return df.executor.schedule(task)
+        scheduled = df.executor.schedule(task)            # (the task itself, an equal one already waiting, or — vaex.cache on — this one, fulfilled from the cache)
+        if scheduled is not task or scheduled.isFulfilled:
+            _PLANS.pop(token, None)                       # (no part will be built for this token: its collector's HBM goes now)
+            if scheduled.isFulfilled:
+                stats["cached"] = stats.get("cached", 0) + 1
+        return scheduled.then(lambda finished: finished["frame"] if "frame" in finished else _frame_from(df, plan, finished))
 
     def eager(df, by, actions, sort, ascending, row_limit, kwargs, progress):
         """the grouped DataFrame of an eager call, or _Decline: one fused pass over whole numpy columns — or, where a column is held in another
