@@ -113,6 +113,9 @@ struct Slot {
     void *conv_buf[3] = {nullptr, nullptr, nullptr};
     size_t conv_cap[3] = {0, 0, 0};
     uint64_t conv_calls = 0; // calls that converted at least one column
+    void *vconv_buf[2] = {nullptr, nullptr}; // VALUE columns converted to int64 / float64 for the fast paths (round 6)
+    size_t vconv_cap[2] = {0, 0};
+    uint64_t vconv_calls = 0;
     // Chunk feeder (host chunks of a vxh_grid_bin call): a ring of VXH_STAGE_RING device arenas per slot.  The DMA into
     // the arena runs on `copy_stream`, the kernels on `stream` wait for the `copied` event, and `done` (recorded behind the
     // kernels) frees the entry for re-use — so the copy of chunk i+1 overlaps the binning of chunk i within ONE slot and

@@ -3243,7 +3243,7 @@ bool vxh_part_reduce_is_fast(const PartArgs &args, const LaunchPlan &plan) {
         const AggDesc &a = args.A.a[k];
         if (args.agg_mbit[k] != 0xff && args.use_flags) fast = false; // (one mask shared by every aggregator: pass 1 dropped the masked rows, the records carry no flags)
         if (a.kind == VXH_AGG_COUNT) continue;
-        if (args.val_i64 ? (a.kind != VXH_AGG_SUM || a.cell != VXH_CELL_I64 || args.agg_vslot[k] == 0xff)
+        if (args.val_i64 ? (a.kind != VXH_AGG_SUM || (a.cell != VXH_CELL_I64 && a.cell != VXH_CELL_U64) || args.agg_vslot[k] == 0xff)
                          : ((a.kind != VXH_AGG_SUM && a.kind != VXH_AGG_SUM_MOMENT) || a.cell != VXH_CELL_F64 || args.agg_vslot[k] == 0xff)) fast = false;
     }
     return fast;

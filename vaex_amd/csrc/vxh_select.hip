@@ -199,7 +199,45 @@ __global__ __launch_bounds__(256) void column_convert(const void *data, const ui
     }
 }
 
+// An integer VALUE column of any width / byte order as int64 (round 6): count / sum over int8 / int16 / unsigned / byte-swapped columns ride the
+// int64 fast paths (upcast<T> of src/agg_sum.cpp:6-62 gives them the int64 / uint64 grids those paths fill; an unsigned value zero-extends, and a
+// uint64 sum is the same 64 bits as the int64 sum of its bit patterns).  Four rows per thread and trip like column_convert.
+__device__ __forceinline__ long long element_as_i64(const void *p, int dtype, int flip, uint64_t i) {
+    switch (dtype) {
+    case VXH_I64: case VXH_U64: { uint64_t x = ((const uint64_t *)p)[i]; if (flip) x = __builtin_bswap64(x); return (long long)x; }
+    case VXH_I32: { uint32_t x = ((const uint32_t *)p)[i]; if (flip) x = __builtin_bswap32(x); return (long long)(int32_t)x; }
+    case VXH_U32: { uint32_t x = ((const uint32_t *)p)[i]; if (flip) x = __builtin_bswap32(x); return (long long)x; }
+    case VXH_I16: { uint16_t x = ((const uint16_t *)p)[i]; if (flip) x = __builtin_bswap16(x); return (long long)(int16_t)x; }
+    case VXH_U16: { uint16_t x = ((const uint16_t *)p)[i]; if (flip) x = __builtin_bswap16(x); return (long long)x; }
+    case VXH_I8: return (long long)((const int8_t *)p)[i];
+    case VXH_U8: return (long long)((const uint8_t *)p)[i];
+    default: return ((const uint8_t *)p)[i] ? 1ll : 0ll; // bool
+    }
+}
+__global__ __launch_bounds__(256) void column_convert_i64(const void *data, int dtype, int flip, uint64_t n, long long *out) {
+    const uint64_t quads = n >> 2;
+    for (uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; q < quads; q += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t i0 = q * 4;
+        long long r[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) r[k] = element_as_i64(data, dtype, flip, i0 + (uint64_t)k);
+        typedef long long ll2 __attribute__((ext_vector_type(2)));
+        ((ll2 *)(out + i0))[0] = ll2{r[0], r[1]};
+        ((ll2 *)(out + i0))[1] = ll2{r[2], r[3]};
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const uint64_t i = (n & ~(uint64_t)3) + threadIdx.x;
+        out[i] = element_as_i64(data, dtype, flip, i);
+    }
+}
+
 } // namespace
+
+void vxh_launch_column_convert_i64(const void *data, int dtype, int flip, uint64_t n, void *out, hipStream_t stream) {
+    if (!n) return;
+    const int blocks = (int)std::min<uint64_t>((n / 4 + 255) / 256 + 1, 256 * 32);
+    hipLaunchKernelGGL(column_convert_i64, dim3(blocks), dim3(256), 0, stream, data, dtype, flip, n, (long long *)out);
+}
 
 void vxh_launch_column_convert(const void *data, const uint8_t *mask, int dtype, int flip, uint64_t n, void *out, int out_f32, hipStream_t stream) {
     if (!n) return;
