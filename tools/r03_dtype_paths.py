@@ -97,3 +97,28 @@ for bname, tdt, scale in (("int16", torch.int16, 1000.0), ("int8", torch.int8, 3
         print(f"binners {bname:<7} value float64 {'converted to float64 first' if conv else 'generic kernels         '} {best:8.3f} ms {rows/best/1e6:7.1f} Grows/s  {rows*bpr/best/1e6/8000:6.3f} of 8 TB/s on {bpr} B/row   {sa.last_kernel(0)}", flush=True)
     sa.config_set("convert_binners", 1 << 22)
     del xi, yi
+
+# round 6: VALUE columns of the dtypes the typed paths do not load — converted to int64 by a pass of their own — float64 binners, bench shape,
+# against the generic pair (convert_binners=0)
+for vname, tdt in (("int16", torch.int16), ("int8", torch.int8), ("uint8", torch.uint8)):
+    vv = torch.randint(0, 100, (rows,), dtype=torch.int64, device="cuda", generator=g).to(tdt)
+    for conv in (1 << 22, 0):
+        sa.config_set("convert_binners", conv)
+        bx = sa.BinnerScalar_float64(1, "x", -4.0, 4.0, 256); by = sa.BinnerScalar_float64(1, "y", -4.0, 4.0, 256)
+        grid = sa.Grid([bx, by])
+        aggs = [sa.AggCount_int64(grid, 1, 1), getattr(sa, "AggSum_" + vname)(grid, 1, 1), getattr(sa, "AggCount_" + vname)(grid, 1, 1)]
+        bx.set_data(0, x); by.set_data(0, y); aggs[1].set_data(0, vv, 0); aggs[2].set_data(0, vv, 0)
+        best = 1e9
+        for r in range(reps + 1):
+            for a in aggs:
+                a.reset()
+            sa.timer_start(0)
+            grid.bin(0, aggs, rows)
+            ms = sa.timer_stop(0)
+            if r:
+                best = min(best, ms)
+        assert int(np.array(aggs[0].get_result()).sum()) == rows
+        bpr = 16 + vv.element_size()
+        print(f"binners float64 value {vname:<7} {'converted to int64 first' if conv else 'generic kernels        '} {best:8.3f} ms {rows/best/1e6:7.1f} Grows/s  {rows*bpr/best/1e6/8000:6.3f} of 8 TB/s on {bpr} B/row   {sa.last_kernel(0)}", flush=True)
+    sa.config_set("convert_binners", 1 << 22)
+    del vv

@@ -1134,8 +1134,36 @@ static void hot_prepare(Slot &slot, const BinArgs &A, const BinArgs &planned, co
     } else {
         const double lim[6] = {A.b[0].vmin, A.b[0].scale, A.b[0].binsd, A.b[1].vmin, A.b[1].scale, A.b[1].binsd};
         const bool cached = c.cfg_hot_cache && H.key_fraction >= 0 && H.key_ptr[0] == A.b[0].data && H.key_ptr[1] == A.b[1].data && H.key_len == length &&
-                            H.key_grid.size() == A.cells && memcmp(H.key_lim, lim, sizeof(lim)) == 0;
-        if (!cached) {
+                            H.key_fine_cells == A.cells && memcmp(H.key_lim, lim, sizeof(lim)) == 0;
+        // Round 6: two plain float64 binner columns on a grid of >= 64 x 64 cells are sampled into 4 x 4 blocks of cells, privatised in LDS, by ONE
+        // launch (hot_sample_coarse) — the box is searched on the blocks and scaled back; anything else keeps the per-cell sample below
+        const bool coarse = c.cfg_hot_coarse && !plan.bin_f32 && A.b[0].dtype == VXH_F64 && A.b[1].dtype == VXH_F64 && !A.b[0].mask && !A.b[1].mask && !A.b[0].flip && !A.b[1].flip &&
+                            !A.b[0].f32mode && !A.b[1].f32mode && A.b[0].kind == VXH_BIN_SCALAR && A.b[1].kind == VXH_BIN_SCALAR && sx >= 64 && sy >= 64;
+        if (!cached && coarse) {
+            const uint32_t cf = 2, csx = (sx + 3) >> 2, csy = (sy + 3) >> 2;
+            const size_t bytes = (size_t)csx * csy * 8;
+            if (bytes > H.sample_cap) {
+                HIP_CHECK(hipStreamSynchronize(slot.stream));
+                if (H.sample) HIP_CHECK(hipFree(H.sample));
+                H.sample = nullptr;
+                HIP_CHECK(hipMalloc(&H.sample, bytes));
+                H.sample_cap = bytes;
+            }
+            HIP_CHECK(hipMemsetAsync(H.sample, 0, bytes, slot.stream));
+            HotSampleArgs Q{};
+            Q.x = (const double *)A.b[0].data; Q.y = (const double *)A.b[1].data;
+            for (int d = 0; d < 2; d++) { Q.vmin[d] = A.b[d].vmin; Q.scale[d] = A.b[d].scale; Q.binsd[d] = A.b[d].binsd; Q.bins[d] = A.b[d].bins; }
+            Q.length = length; Q.seg_rows = 1ull << 18; Q.nseg = 8; Q.wgs_per_seg = 32;
+            Q.csx = csx; Q.csy = csy; Q.cf = cf;
+            Q.out = (unsigned long long *)H.sample;
+            vxh_launch_hot_sample(Q, slot.stream);
+            HIP_CHECK(hipGetLastError());
+            H.key_fraction = -1;
+            H.key_grid.resize((size_t)csx * csy);
+            HIP_CHECK(hipMemcpyAsync(H.key_grid.data(), H.sample, bytes, hipMemcpyDeviceToHost, slot.stream));
+            HIP_CHECK(hipStreamSynchronize(slot.stream));
+            H.key_cf = cf; H.key_csx = csx; H.key_csy = csy;
+        } else if (!cached) {
         // sample: 8 evenly spaced segments of 2^18 rows, counted with device atomics into a scratch grid
             const size_t bytes = (size_t)A.cells * 8;
             if (bytes > H.sample_cap) {
@@ -1174,6 +1202,10 @@ static void hot_prepare(Slot &slot, const BinArgs &A, const BinArgs &planned, co
             H.key_grid.resize(A.cells);
             HIP_CHECK(hipMemcpyAsync(H.key_grid.data(), H.sample, bytes, hipMemcpyDeviceToHost, slot.stream));
             HIP_CHECK(hipStreamSynchronize(slot.stream));
+            H.key_cf = 0; H.key_csx = sx; H.key_csy = sy;
+        }
+        if (!cached) {
+            H.key_fine_cells = A.cells;
             H.key_total = 0;
             for (int64_t v : H.key_grid) H.key_total += v;
             H.key_ptr[0] = A.b[0].data; H.key_ptr[1] = A.b[1].data;
@@ -1190,7 +1222,14 @@ static void hot_prepare(Slot &slot, const BinArgs &A, const BinArgs &planned, co
             if (e < 0) {
                 e = H.key_next;
                 H.key_next = (H.key_next + 1) % 3;
-                const int64_t in = hot_search(H.key_grid, sx, sy, max_cells, H.key_box[e]);
+                const uint32_t cf = H.key_cf;
+                const int64_t in = hot_search(H.key_grid, H.key_csx, H.key_csy, max_cells >> (2 * cf), H.key_box[e]);
+                if (cf) { // blocks -> cells; the last block of a dimension may stick out of the grid
+                    uint32_t *b = H.key_box[e];
+                    b[0] <<= cf; b[1] <<= cf;
+                    b[2] = std::min<uint32_t>(b[2] << cf, sx - b[0]);
+                    b[3] = std::min<uint32_t>(b[3] << cf, sy - b[1]);
+                }
                 H.key_cells[e] = max_cells;
                 H.key_box_fraction[e] = H.key_total > 0 ? (double)in / (double)H.key_total : 0;
             }
@@ -1207,8 +1246,12 @@ static void hot_prepare(Slot &slot, const BinArgs &A, const BinArgs &planned, co
             uint32_t b8[4];
             const double f = searched(room(true, 2), b8);
             int64_t peak = 0;
-            for (uint32_t yy = b8[1]; yy < b8[1] + b8[3]; yy++)
-                for (uint32_t xx = b8[0]; xx < b8[0] + b8[2]; xx++) peak = std::max(peak, H.key_grid[(size_t)yy * sx + xx]);
+            {   // the fullest cell of the box (a block's fullest cell is taken to hold a block's share: the density is flat across 4 cells where it peaks)
+                const uint32_t cf = H.key_cf;
+                for (uint32_t yy = b8[1] >> cf; yy <= (b8[1] + b8[3] - 1) >> cf; yy++)
+                    for (uint32_t xx = b8[0] >> cf; xx <= (b8[0] + b8[2] - 1) >> cf; xx++) peak = std::max(peak, H.key_grid[(size_t)yy * H.key_csx + xx]);
+                peak = (peak + (1ll << (2 * cf)) - 1) >> (2 * cf);
+            }
             const double rows_between = peak > 0 ? 128.0 * (double)H.key_total / (double)peak : 1e18;
             const double trips = rows_between / (2.0 * (double)wg.waves * 256.0);
             if (f * 100.0 >= (double)c.cfg_hot_direct_pct && trips >= 8.0) {
@@ -2032,6 +2075,7 @@ int vxh_config_set(const char *key, int64_t value) {
     else if (k == "hot_min_pct") c.cfg_hot_min_pct = value > 0 ? value : 10;
     else if (k == "hot_direct_pct") c.cfg_hot_direct_pct = value > 0 ? value : 62;
     else if (k == "hot_cache") c.cfg_hot_cache = value;
+    else if (k == "hot_coarse") c.cfg_hot_coarse = value;
     else if (k == "hot_x0") c.cfg_hot_box[0] = value;
     else if (k == "hot_y0") c.cfg_hot_box[1] = value;
     else if (k == "hot_w") c.cfg_hot_box[2] = value;
@@ -2106,6 +2150,7 @@ int vxh_config_get(const char *key, int64_t *value) {
     else if (k == "hot_min_rows") *value = c.cfg_hot_min_rows;
     else if (k == "hot_min_pct") *value = c.cfg_hot_min_pct;
     else if (k == "hot_cache") *value = c.cfg_hot_cache;
+    else if (k == "hot_coarse") *value = c.cfg_hot_coarse;
     else if (k == "hot_fraction_ppm") *value = (int64_t)(get_slot(0).hot.last_fraction * 1e6);
     else if (k == "hot_w") *value = get_slot(0).hot.last_on ? (int64_t)get_slot(0).hot.w : 0;
     else if (k == "hot_h") *value = get_slot(0).hot.last_on ? (int64_t)get_slot(0).hot.h : 0;

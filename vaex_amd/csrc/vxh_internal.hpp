@@ -181,7 +181,9 @@ struct Slot {
         const void *key_ptr[2] = {nullptr, nullptr};
         double key_lim[6] = {0, 0, 0, 0, 0, 0};
         uint64_t key_len = 0;
-        std::vector<int64_t> key_grid; // the sample's counts per cell (valid while key_fraction >= 0)
+        std::vector<int64_t> key_grid; // the sample's counts per cell — per 2^key_cf x 2^key_cf block of cells, [key_csy][key_csx] (valid while key_fraction >= 0)
+        uint32_t key_cf = 0, key_csx = 0, key_csy = 0;
+        uint64_t key_fine_cells = 0;   // cells of the grid the sample was taken for
         int64_t key_total = 0;
         // searched boxes for up to two LDS budgets (the ring-less pass 1 and part_scatter_blk leave the box different room)
         uint64_t key_cells[3] = {0, 0, 0};   // the box searches of this sample, by cell budget (uint8 / uint16 counters next to part_scatter_wv, part_scatter_blk)
@@ -259,6 +261,7 @@ struct Context {
     int64_t cfg_hot_cnt16 = 2;     // packed counters in the box next to the ring-less pass 1 (one value column): 1 = uint16 (20 % more cells than uint32),
                                    // 2 = uint8 where the sampled share of the fullest cell allows (33 % more), 0 = uint32
     int64_t cfg_hot_min_rows = 1 << 24; // calls shorter than this do not pay for the sample
+    int64_t cfg_hot_coarse = 1;    // sample the hot box on 4 x 4 blocks of cells, privatised in LDS, one launch (0: the per-cell sample with device atomics, eight launches)
     int64_t cfg_hot_cache = 1;     // reuse the sampled box when the same columns are binned with the same limits again (0: sample every call)
     int64_t cfg_hot_min_pct = 10;  // use the box only when it catches at least this share of the sample (profiles/r02_box_share.txt: worth it from ~15 %)
     int64_t cfg_hot_direct_pct = 62; // ... and the ring-less pass 1 (scattered record stores) only from this share on; below it part_scatter_blk stages the records

@@ -203,6 +203,18 @@ struct PartArgs {
 #define VXH_WV_WAVE_LDS_GROUPED ((size_t)(2 * VXH_WV_GROUP) * 12 + 128) /* ring of 128 records + 16 group headers waiting for their line */
 #define VXH_WV_WAVE_LDS(NVAL, S) ((((size_t)(S) * VXH_WV_D * (2 + 8 * (size_t)(NVAL)) + (size_t)(S) * 4) + 15) & ~(size_t)15)
 
+// hot-box sample over COARSE cells (round 6): nseg evenly spaced segments of seg_rows rows of two float64 binner columns, counted into
+// 2^cf x 2^cf blocks of grid cells — few enough to privatise in LDS (65 x 65 counters for a 259 x 259 grid)
+struct HotSampleArgs {
+    const double *x, *y;
+    double vmin[2], scale[2], binsd[2];
+    uint64_t bins[2];
+    uint64_t length, seg_rows;
+    uint32_t nseg, wgs_per_seg, csx, csy, cf;
+    unsigned long long *out; // [csy][csx]
+};
+void vxh_launch_hot_sample(const HotSampleArgs &args, hipStream_t stream);
+
 struct HotMergeArgs {
     uint32_t x0, y0, w, h, blocks, nagg;
     uint64_t stride_y;             // cells per step of dim 1

@@ -214,13 +214,26 @@ __device__ __forceinline__ long long element_as_i64(const void *p, int dtype, in
     default: return ((const uint8_t *)p)[i] ? 1ll : 0ll; // bool
     }
 }
+template <bool VEC>
 __global__ __launch_bounds__(256) void column_convert_i64(const void *data, int dtype, int flip, uint64_t n, long long *out) {
     const uint64_t quads = n >> 2;
     for (uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; q < quads; q += (uint64_t)gridDim.x * blockDim.x) {
         const uint64_t i0 = q * 4;
         long long r[4];
+        if (VEC) { // ONE load of the four elements' bytes (the column is 16-byte aligned), converted from registers
+            union { uint4 v[2]; uint8_t b[32]; } raw;
+            const int isz = dtype == VXH_I64 || dtype == VXH_U64 ? 8 : (dtype == VXH_I32 || dtype == VXH_U32 ? 4 : (dtype == VXH_I16 || dtype == VXH_U16 ? 2 : 1));
+            const char *p = (const char *)data + i0 * (uint64_t)isz;
+            if (isz == 8) { raw.v[0] = ((const uint4 *)p)[0]; raw.v[1] = ((const uint4 *)p)[1]; }
+            else if (isz == 4) raw.v[0] = *(const uint4 *)p;
+            else if (isz == 2) *(uint2 *)raw.b = *(const uint2 *)p;
+            else *(uint32_t *)raw.b = *(const uint32_t *)p;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) r[k] = element_as_i64(data, dtype, flip, i0 + (uint64_t)k);
+            for (int k = 0; k < 4; ++k) r[k] = element_as_i64(raw.b, dtype, flip, (uint64_t)k);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) r[k] = element_as_i64(data, dtype, flip, i0 + (uint64_t)k);
+        }
         typedef long long ll2 __attribute__((ext_vector_type(2)));
         ((ll2 *)(out + i0))[0] = ll2{r[0], r[1]};
         ((ll2 *)(out + i0))[1] = ll2{r[2], r[3]};
@@ -236,7 +249,8 @@ __global__ __launch_bounds__(256) void column_convert_i64(const void *data, int 
 void vxh_launch_column_convert_i64(const void *data, int dtype, int flip, uint64_t n, void *out, hipStream_t stream) {
     if (!n) return;
     const int blocks = (int)std::min<uint64_t>((n / 4 + 255) / 256 + 1, 256 * 32);
-    hipLaunchKernelGGL(column_convert_i64, dim3(blocks), dim3(256), 0, stream, data, dtype, flip, n, (long long *)out);
+    if (((uintptr_t)data & 15) == 0) hipLaunchKernelGGL(column_convert_i64<true>, dim3(blocks), dim3(256), 0, stream, data, dtype, flip, n, (long long *)out);
+    else hipLaunchKernelGGL(column_convert_i64<false>, dim3(blocks), dim3(256), 0, stream, data, dtype, flip, n, (long long *)out);
 }
 
 void vxh_launch_column_convert(const void *data, const uint8_t *mask, int dtype, int flip, uint64_t n, void *out, int out_f32, hipStream_t stream) {
