@@ -469,7 +469,8 @@ uint64_t vxh_groupby_size(const vxh_groupby *g);
  * vxh_groupby_size elements of 8 bytes */
 int vxh_groupby_column(vxh_groupby *g, int value_index, int which, void *out_host);
 /* diagnostics: 0 buckets, 1 LDS slots per bucket, 2 retries, 3 / 4 / 5 = ms of the scatter / reduce / sort kernels, 6 = 1 when the pass moved 12-byte records, 7 = heavy keys peeled inside the pass,
- * 8 = 1 when gb_reduce indexed its LDS table with the record's remainder (key ranges of <= 2^22 cells: no keys in the table, no probe) */
+ * 8 = 1 when gb_reduce indexed its LDS table with the record's remainder (key ranges of <= 2^22 cells: no keys in the table, no probe),
+ * 9 = 1 when gb_reduce probed its tag table (compact records with a remainder of < 32 bits: lines of four {tag, group id} entries, straight-line probe) */
 int vxh_groupby_info(const vxh_groupby *g, int what, double *value_out);
 
 /* ---- multi-GPU reduce ------------------------------------------------------------------ */

@@ -284,9 +284,9 @@ struct PyGroupBy {
         return out;
     }
     py::dict info() const {
-        static const char *names[] = {"buckets", "slots", "retries", "ms_scatter", "ms_reduce", "ms_sort", "compact_records", "heavy_keys_in_pass", "direct_table"};
+        static const char *names[] = {"buckets", "slots", "retries", "ms_scatter", "ms_reduce", "ms_sort", "compact_records", "heavy_keys_in_pass", "direct_table", "tag_table"};
         py::dict d;
-        for (int i = 0; i < 9; i++) {
+        for (int i = 0; i < 10; i++) {
             double v = 0;
             check(vxh_groupby_info(h, i, &v));
             d[names[i]] = v;

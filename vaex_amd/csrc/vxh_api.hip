@@ -2061,6 +2061,7 @@ int vxh_config_set(const char *key, int64_t value) {
     else if (k == "gb_direct") c.cfg_gb_direct = value;
     else if (k == "gb_direct_nb") c.cfg_gb_direct_nb = value;
     else if (k == "gb_key32") c.cfg_gb_key32 = value;
+    else if (k == "gb_tag") c.cfg_gb_tag = value;
     else if (k == "gb_abl") {
 #ifndef VXH_ABLATE
         throw std::runtime_error("gb_abl: a timing experiment of the ablation build (make -C vaex_amd/csrc ablate)");
@@ -2138,6 +2139,7 @@ int vxh_config_get(const char *key, int64_t *value) {
     else if (k == "gb_direct") *value = c.cfg_gb_direct;
     else if (k == "gb_direct_nb") *value = c.cfg_gb_direct_nb;
     else if (k == "gb_key32") *value = c.cfg_gb_key32;
+    else if (k == "gb_tag") *value = c.cfg_gb_tag;
     else if (k == "gb_abl") *value = c.cfg_gb_abl;
     else if (k == "gb_sets") *value = c.cfg_gb_sets;
     else if (k == "gb_load_pct") *value = c.cfg_gb_load_pct;

@@ -118,6 +118,9 @@ struct GbArgs {
     int32_t kc_bits;        // 0: 16-byte records {key, payload}
     int32_t key32;          // compact records with a remainder of < 32 bits: gb_reduce keeps 32-bit keys in its table
     int32_t direct;         // compact records AND 2^(kc_bits - nb_log2) <= GB_DIRECT_SLOTS: gb_reduce indexes its table with the remainder (no keys, no probe)
+    int32_t tag;            // compact records with a remainder of < 32 bits (no direct table): gb_reduce's TAG table (lines of four 4-byte entries indexed by the remainder's top bits, accumulators by group id)
+    int32_t tag_idx_bits;   // ... log2 of its LINES of four entries (<= 12)
+    uint32_t ids;           // ... group ids (accumulator sets) a bucket has room for (a multiple of 4, < 4095)
     // Heavy keys (round 4, the one-kernel peel): rows whose key is one of `n_heavy` <= 128 listed keys leave NO record — gb_scatter looks
     // every key up in an LDS copy of the list, adds such rows to per-workgroup partials in LDS {rows | count, sum, sum2 ...} and folds those
     // into heavy_acc at its end; gb_append_heavy turns the accumulators into ordinary groups in front of the sort.  (Every row of ONE key
@@ -480,23 +483,36 @@ __global__ void gb_append_heavy(const GbArgs G) {
 // rows at 4.0 TB/s; here it sits behind gb_scatter's shared streams (28 GB at 5.0 TB/s).
 // K32 (round 6; KC records whose remainder has < 32 bits): the table's keys are 32-bit words — a line of four keys is ONE ds_read_b128
 // instead of two, the claim a 32-bit ds_cmpst (the probe's LDS reads were ~40 % of the kernel's LDS time: DESIGN section 3).
-template <int NV, bool MERGE, bool KC = false, bool DIRECT = false, bool K32 = false>
+// TAG (round 6, late; KC records whose remainder has < 32 bits and no direct table — the scattered 1e6-key groupby): the probe as
+// STRAIGHT-LINE code.  The counters of the 4-key-line table (profiles/r06_gb_reduce_pmc.txt) showed gb_reduce bound by instruction issue,
+// not by the LDS: 67 scalar + 62 vector instructions per 64 records (the divergent insert-or-get loop: exec-mask bookkeeping, and ~85 % of
+// the waves took a second trip for the one lane in 64 whose key lived in an overflow line) against 8 + 17 behind a direct table.  Here the
+// bijective mix's remainder supplies the hash: its top 12 bits name a LINE of four 4-byte entries {tag = the remainder's other bits (<= 19),
+// group id (12 bits)} — 4096 lines = 64 KiB at ~12 % load — and the accumulators are dense arrays indexed by the group id, handed out in
+// order of first appearance.  A record: one ds_read_b128, four xors and a min3/min — an entry of the same tag xors to its id (< 4094), anything
+// else to >= 4096 — and the three atomics under `hit`.  Records that miss (the first of a key; ~0.03 % of the keys live in an overflow list
+// because their line was full) are collected in a per-lane mask and settled in ONE slow pass per trip of 4 x 64 records.
+template <int NV, bool MERGE, bool KC = false, bool DIRECT = false, bool K32 = false, bool TAG = false>
 __global__ void __launch_bounds__(1024) gb_reduce(const GbArgs G) {
     static_assert(!DIRECT || (KC && !MERGE), "a direct table needs compact records");
     static_assert(!K32 || (KC && !MERGE && !DIRECT), "32-bit table keys need compact records");
+    static_assert(!TAG || (K32 && NV == 1), "the tag table holds 32-bit entries of compact records");
     using KT = typename std::conditional<K32, uint32_t, unsigned long long>::type;
-    constexpr KT KEMPTY = K32 ? (KT)0xffffffffu : (KT)GB_EMPTY; // (a remainder of < 32 bits is never all ones)
+    constexpr KT KEMPTY = K32 ? (KT)0xffffffffu : (KT)GB_EMPTY; // (a remainder of < 32 bits is never all ones; a tag entry has its top two bits clear)
     extern __shared__ __attribute__((aligned(16))) char lds[];
     // row counters: 32 bits while counting rows (a workgroup sees < 2^32 of them), 64 bits when merging partial counts
     using CT = typename std::conditional<MERGE, unsigned long long, uint32_t>::type;
-    const uint32_t LINES = G.lines, SLOTS = DIRECT ? 1u << (G.kc_bits - G.nb_log2) : 4u * LINES, E = DIRECT ? SLOTS : SLOTS + 1, EP = (E + 3) & ~3u; // (EP: keeps the arrays 16-byte aligned)
-    KT *const t_key = (KT *)lds;                                    // [EP]: line l = t_key[4 l .. 4 l + 3]
-    double *const t_sum = (double *)(t_key + EP);                   // [NV][EP] (EP is a multiple of 4: 16-byte aligned behind 32-bit keys too)
+    const uint32_t LINES = G.lines, SLOTS = TAG ? G.ids : (DIRECT ? 1u << (G.kc_bits - G.nb_log2) : 4u * LINES), E = DIRECT ? SLOTS : SLOTS + 1, EP = (E + 3) & ~3u; // (TAG: entry SLOTS is the spare accumulator set of the lanes without a hit) // (EP: keeps the arrays 16-byte aligned)
+    const uint32_t TS = TAG ? 4u << G.tag_idx_bits : 0u;           // TAG: entries of the tag table (four per line)
+    KT *const t_key = (KT *)lds;                                    // [EP]: line l = t_key[4 l .. 4 l + 3]; TAG: [TS] entries
+    double *const t_sum = (double *)(t_key + (TAG ? TS : EP));      // [NV][EP] (EP is a multiple of 4: 16-byte aligned behind 32-bit keys too)
     double *const t_sum2 = t_sum + (size_t)NV * EP;                 // [NV][EP]
-    // counting rows: {rows, count of value column 0} are the two halves of one 64-bit word per slot (t_rc), further
-    // columns' counts follow as 32-bit arrays; merging: 64-bit rows[] and counts[][]
-    unsigned long long *const t_rc = (unsigned long long *)(t_sum2 + (size_t)NV * EP);                           // RAW: [EP]
+    // counting rows: rows[] and the NaN values of column 0 nan0[] as two dense 32-bit arrays (count of column 0 = rows - nan0: ONE 4-byte
+    // atomic per record instead of an 8-byte one, a second only for a NaN), further columns' counts follow as 32-bit arrays;
+    // merging: 64-bit rows[] and counts[][]
+    unsigned long long *const t_rc = (unsigned long long *)(t_sum2 + (size_t)NV * EP);                           // RAW: [EP] x 8 bytes = rows32[EP] | nan32[EP]
     CT *const t_rows = (CT *)t_rc;                                                                                // MERGE: [EP]
+    uint32_t *const t_rows32 = (uint32_t *)t_rc, *const t_nan32 = t_rows32 + EP;                                  // RAW
     CT *const t_cnt = MERGE ? t_rows + EP : (CT *)(t_rc + EP) - EP;                                               // MERGE: [NV][EP]; RAW: [v >= 1][EP] behind t_rc
     uint32_t *const s_misc = (uint32_t *)((char *)t_rc + (MERGE ? (size_t)8 * EP * (1 + NV) : (size_t)8 * EP + (size_t)4 * EP * (NV - 1))); // [0] claimed slots, [1] output base, [2..17] wave totals
     const uint32_t tid = threadIdx.x, lane = tid & 63u, nwave = blockDim.x >> 6;
@@ -505,8 +521,9 @@ __global__ void __launch_bounds__(1024) gb_reduce(const GbArgs G) {
     // a stream passed its room in gb_scatter (segments were dropped, the counters point at records nobody wrote): nothing to reduce —
     // the host lays the streams out from the counters and runs the pass again
     if (__hip_atomic_load(G.overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1u) return;
+    if (TAG) for (uint32_t s = tid; s < TS; s += blockDim.x) t_key[s] = KEMPTY;
     for (uint32_t s = tid; s < EP; s += blockDim.x) {
-        if (!DIRECT) t_key[s] = KEMPTY;
+        if (!DIRECT && !TAG) t_key[s] = KEMPTY;
         if (MERGE) t_rows[s] = (CT)0; else t_rc[s] = 0ull;
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
@@ -515,7 +532,7 @@ __global__ void __launch_bounds__(1024) gb_reduce(const GbArgs G) {
             if (MERGE || v > 0) t_cnt[(size_t)v * EP + s] = (CT)0;
         }
     }
-    if (tid < 18) s_misc[tid] = 0u;
+    if (tid < 18 + (TAG ? 2 : 0)) s_misc[tid] = 0u; // (TAG: the overflow list's count and lock sit right behind)
     __syncthreads();
 
     const uint32_t limit = SLOTS - SLOTS / 5; // more distinct keys than this in one bucket (80 % of the slots): the overflow chains get long (a wave pays for the longest of its 64) — flag and let the host retry with more buckets
@@ -532,9 +549,10 @@ __global__ void __launch_bounds__(1024) gb_reduce(const GbArgs G) {
                 __hip_atomic_fetch_add(&t_sum2[(size_t)v * EP + s], __longlong_as_double((long long)p[3 + 3 * v]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         } else {
-            // rows (low half) and the count of value column 0 (high half) live in ONE 64-bit word: one LDS atomic for both
+            // rows: one 4-byte atomic; the count of value column 0 is rows minus its NaNs, counted apart (rare)
             const double d0 = __longlong_as_double((long long)p[0]);
-            __hip_atomic_fetch_add(&t_rc[s], d0 == d0 ? 0x100000001ull : 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(&t_rows32[s], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (d0 != d0) __hip_atomic_fetch_add(&t_nan32[s], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
                 const double d = __longlong_as_double((long long)p[v]);
@@ -553,6 +571,56 @@ __global__ void __launch_bounds__(1024) gb_reduce(const GbArgs G) {
         return __umulhi((uint32_t)(((uint64_t)key * 0x9e3779b97f4a7c15ULL) >> 32), LINES);
     };
     // insert-or-get: the four keys of a line are read and compared at once; 0xffffffff when the table is too full
+    const int tag_bits = TAG ? G.kc_bits - G.nb_log2 - G.tag_idx_bits : 0; // (tag_idx_bits: log2 of the table's lines)
+    const uint32_t tag_mask = (1u << tag_bits) - 1u;
+    constexpr uint32_t TAG_PENDING = 0xffeu, TAG_OV = 256u; // ids <= 0xffd; an empty entry is all ones (a valid one has bit 31 clear)
+    uint32_t *const s_ov = s_misc + 18; // TAG: [0] keys in the overflow list, [1] its lock, [2 .. 2 + TAG_OV) their remainders, then their ids
+    // the slow road of a record whose line did not show its key: look again (atomically), claim an empty entry of the line, or — line
+    // full of other keys — find / append the key in the overflow list.  0xffffffff: out of accumulator sets or of list entries.
+    auto slot_of_tag = [&](uint32_t rem) -> uint32_t {
+        uint32_t *const line = (uint32_t *)t_key + 4u * (rem >> tag_bits);
+        const uint32_t want = (rem & tag_mask) << 12;
+        auto new_id = [&]() -> uint32_t {
+            const uint32_t id = __hip_atomic_fetch_add(&s_misc[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            return id >= SLOTS ? 0xffffffffu : id;
+        };
+        for (;;) {
+            int empty = -1;
+            bool pending = false;
+#pragma unroll
+            for (int j = 3; j >= 0; --j) {
+                const uint32_t e = __hip_atomic_load(line + j, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const uint32_t y = e ^ want;
+                if (y < TAG_PENDING) return y;
+                if (y == TAG_PENDING) pending = true; // its owner publishes the id within its own trip
+                if (e == 0xffffffffu) empty = j;
+            }
+            if (pending) continue;
+            if (empty >= 0) {
+                if (atomicCAS(line + empty, 0xffffffffu, want | TAG_PENDING) != 0xffffffffu) continue; // somebody took the entry: look again
+                const uint32_t id = new_id(); // (out of ids: the entry is published all the same — nobody spins on it — and the call retried with more buckets)
+                __hip_atomic_store(line + empty, want | (id == 0xffffffffu ? 0u : id), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                return id;
+            }
+            // the line is full of other keys: the overflow list (append-only; read without the lock, appended under it)
+            uint32_t n = __hip_atomic_load(&s_ov[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            for (uint32_t i = 0; i < n; ++i) if (__hip_atomic_load(&s_ov[2 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == rem) return __hip_atomic_load(&s_ov[2 + TAG_OV + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (atomicCAS(&s_ov[1], 0u, 1u) != 0u) continue; // (the holder finishes inside its own trip of this loop)
+            uint32_t id = 0xffffffffu;
+            const uint32_t n2 = __hip_atomic_load(&s_ov[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            for (uint32_t i = n; i < n2; ++i) if (__hip_atomic_load(&s_ov[2 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == rem) id = __hip_atomic_load(&s_ov[2 + TAG_OV + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (id == 0xffffffffu && n2 < TAG_OV) {
+                id = new_id();
+                if (id != 0xffffffffu) {
+                    __hip_atomic_store(&s_ov[2 + n2], rem, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_store(&s_ov[2 + TAG_OV + n2], id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_store(&s_ov[0], n2 + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
+            __hip_atomic_store(&s_ov[1], 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            return id;
+        }
+    };
     auto slot_of = [&](long long key) -> uint32_t {
         if (DIRECT) return (uint32_t)key; // (the remainder: < 2^(kc_bits - nb_log2) = SLOTS by construction)
         if (key == GB_EMPTY) return SLOTS;
@@ -648,6 +716,44 @@ __global__ void __launch_bounds__(1024) gb_reduce(const GbArgs G) {
     //  records.  The kernel is bound by the LDS's throughput, not its latency: three 64-bit atomics per record are ~1.6 ms per CU at the
     //  rates of profiles/r01_microbench_v3_lds_atomics.txt — the direct table's 1.9 ms — and the probe's 16-byte read and compares about as much again.)
     auto work = [&](const Trip &t) {
+        if (TAG) { // straight-line probes; the misses of the trip settled together afterwards
+            uint32_t miss = 0u;
+            uint4 ee[U]; // the U lines are read up front: a read behind the previous record's atomics would wait for them (one lgkm counter, in order)
+#pragma unroll
+            for (int u = 0; u < U; ++u) ee[u] = *(const uint4 *)((const uint32_t *)t_key + 4u * (t.c[u][0] >> tag_bits));
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t rem = t.c[u][0];
+                const uint64_t p0 = (uint64_t)t.c[u][1] | ((uint64_t)t.c[u][2] << 32);
+                const uint32_t want = (rem & tag_mask) << 12;
+                const uint4 e = ee[u];
+                const uint32_t a = e.x ^ want, b = e.y ^ want, c = e.z ^ want, d = e.w ^ want;
+                const uint32_t m = min(min(a, b), min(c, d)); // the key's entry xors to its id, every other one (and an empty one) to >= 2^12
+                const bool valid = t.j0 + 64u * u + lane < t.fill;
+                const double v = __longlong_as_double((long long)p0);
+                // the three atomics are issued by every lane, branch-free (the compiler then counts them: the next record's line is waited
+                // for with lgkmcnt(5), not behind these) — a lane without a hit adds nothing to a spare accumulator set.  A NaN value takes
+                // the slow road too (its row counts, its value does not).
+                const bool hit = valid && m < TAG_PENDING && v == v;
+                const uint32_t id = hit ? m : SLOTS;
+                __hip_atomic_fetch_add(&t_rows32[id], hit ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(&t_sum[id], hit ? v : -0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); // (-0.0: x + -0.0 == x for every x)
+                __hip_atomic_fetch_add(&t_sum2[id], hit ? v * v : -0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                miss |= (valid && !hit ? 1u : 0u) << u;
+            }
+            while (miss) {
+                const int u = __builtin_ctz(miss);
+                miss &= miss - 1u;
+                uint32_t rem = 0u;
+                uint64_t p[PW];
+#pragma unroll
+                for (int q = 0; q < U; ++q) if (q == u) { rem = t.c[q][0]; p[0] = (uint64_t)t.c[q][1] | ((uint64_t)t.c[q][2] << 32); }
+                const uint32_t sl = slot_of_tag(rem);
+                if (sl == 0xffffffffu) failed = true;
+                else accumulate(sl, p);
+            }
+            return;
+        }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if (t.j0 + 64u * u + lane >= t.fill) continue;
@@ -697,9 +803,20 @@ __global__ void __launch_bounds__(1024) gb_reduce(const GbArgs G) {
 
     // compact the occupied slots into the result arrays: ONE device atomic per bucket reserves the range
     uint32_t mine = 0;
-    auto rows_of = [&](uint32_t s) -> unsigned long long { return MERGE ? (unsigned long long)t_rows[s] : (t_rc[s] & 0xffffffffull); };
-    auto cnt_of = [&](int v, uint32_t s) -> unsigned long long { return (MERGE || v > 0) ? (unsigned long long)t_cnt[(size_t)v * EP + s] : (t_rc[s] >> 32); };
-    for (uint32_t s = tid; s < E; s += blockDim.x) mine += rows_of(s) != 0ull ? 1u : 0u;
+    auto rows_of = [&](uint32_t s) -> unsigned long long { return MERGE ? (unsigned long long)t_rows[s] : (unsigned long long)t_rows32[s]; };
+    auto cnt_of = [&](int v, uint32_t s) -> unsigned long long { return (MERGE || v > 0) ? (unsigned long long)t_cnt[(size_t)v * EP + s] : (unsigned long long)(t_rows32[s] - t_nan32[s]); };
+    // TAG: the groups are the table's entries and the overflow list's (an entry's place and tag are its key's remainder, its id the accumulators)
+    const uint32_t EO = TAG ? TS + s_ov[0] : E;
+    auto tag_entry = [&](uint32_t s, uint32_t &rem) -> uint32_t { // -> id, or 0xffffffff for an empty entry
+        if (s >= TS) { rem = s_ov[2 + (s - TS)]; return s_ov[2 + TAG_OV + (s - TS)]; }
+        const uint32_t e = ((const uint32_t *)t_key)[s];
+        rem = ((s >> 2) << tag_bits) | (e >> 12);
+        return e == 0xffffffffu ? 0xffffffffu : (e & 0xfffu);
+    };
+    for (uint32_t s = tid; s < EO; s += blockDim.x) {
+        if (TAG) { uint32_t rem; mine += tag_entry(s, rem) != 0xffffffffu ? 1u : 0u; }
+        else mine += rows_of(s) != 0ull ? 1u : 0u;
+    }
     uint32_t inc = mine;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -721,10 +838,12 @@ __global__ void __launch_bounds__(1024) gb_reduce(const GbArgs G) {
     __syncthreads();
     if (s_misc[1] == 0xffffffffu) return;
     uint64_t o = (uint64_t)s_misc[1] + before + inc - mine;
-    for (uint32_t s = tid; s < E; s += blockDim.x) {
-        if (rows_of(s) == 0ull) continue;
+    for (uint32_t s0 = tid; s0 < EO; s0 += blockDim.x) {
+        uint32_t s = s0, rem = 0u;
+        if (TAG) { s = tag_entry(s0, rem); if (s == 0xffffffffu) continue; }
+        else if (rows_of(s) == 0ull) continue;
         if (!MERGE && NV == 1 && KC) // the group's key from its bucket and remainder, mixed back
-            G.out_key[o] = (long long)(gb_kc_unmix(((uint64_t)bucket << (G.kc_bits - G.nb_log2)) | (DIRECT ? (uint64_t)s : (uint64_t)t_key[s]), G.kc_bits) + (uint64_t)G.kc_min);
+            G.out_key[o] = (long long)(gb_kc_unmix(((uint64_t)bucket << (G.kc_bits - G.nb_log2)) | (DIRECT ? (uint64_t)s : (TAG ? (uint64_t)rem : (uint64_t)t_key[s])), G.kc_bits) + (uint64_t)G.kc_min);
         else
             G.out_key[o] = s == SLOTS ? GB_EMPTY : (long long)t_key[s];
         G.out_w[0][o] = (uint64_t)rows_of(s);
@@ -800,7 +919,7 @@ struct vxh_groupby {
     Dev cols; // [key | rows | (count, sum, sum2) x nv] x n_groups, 8-byte elements, sorted by key
     Dev tmp;
     uint64_t stride = 0; // elements between columns
-    int buckets = 0, slots = 0, retries = 0, compact = 0, heavy = 0, direct = 0;
+    int buckets = 0, slots = 0, retries = 0, compact = 0, heavy = 0, direct = 0, tag = 0;
     float ms_scatter = 0, ms_reduce = 0, ms_sort = 0;
 };
 
@@ -872,6 +991,13 @@ void launch_reduce(const GbArgs &G, hipStream_t st) {
         if (dlds > GB_LDS_MAX) throw std::runtime_error("groupby: internal: gb_reduce direct table exceeds the LDS");
         HIP_CHECK(hipFuncSetAttribute((const void *)gb_reduce<1, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dlds));
         hipLaunchKernelGGL((gb_reduce<1, false, true, true>), dim3(1u << G.nb_log2), dim3(1024), dlds, st, G);
+        return;
+    }
+    if (NV == 1 && !MERGE && G.kc_bits && G.tag) { // compact records with a remainder of < 32 bits: the tag table (straight-line probe of one 16-byte line)
+        const size_t tlds = ((size_t)16 << G.tag_idx_bits) + ((size_t)G.ids + 4) * 24 + (18 + 2 + 2 * 256) * 4 + 16;
+        if (tlds > GB_LDS_MAX) throw std::runtime_error("groupby: internal: gb_reduce tag table exceeds the LDS");
+        HIP_CHECK(hipFuncSetAttribute((const void *)gb_reduce<1, false, true, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tlds));
+        hipLaunchKernelGGL((gb_reduce<1, false, true, false, true, true>), dim3(1u << G.nb_log2), dim3(1024), tlds, st, G);
         return;
     }
     if (NV == 1 && !MERGE && G.kc_bits && G.key32) { // compact records with a remainder of < 32 bits: 32-bit table keys (4 bytes less per slot)
@@ -951,6 +1077,11 @@ unsigned run_pipeline(GbArgs &G, int nv, bool merge, uint64_t n, uint64_t groups
         G.kc_bits = compact ? key_bits : 0;
         G.direct = compact && ctx().cfg_gb_direct && key_bits - nb_log2 <= GB_DIRECT_BITS ? 1 : 0;
         G.key32 = compact && !G.direct && ctx().cfg_gb_key32 && key_bits - nb_log2 < 32 ? 1 : 0;
+        // the tag table ("gb_tag", default on): 2^12 lines of four entries (fewer when the remainder is shorter), a 256-key overflow list, and as
+        // many accumulator sets (24 bytes) as the rest of the LDS holds (4000 behind 2^12 lines: a bucket is sized for <= 2554 distinct keys)
+        G.tag = G.key32 && ctx().cfg_gb_tag ? 1 : 0;
+        G.tag_idx_bits = std::min(12, key_bits - nb_log2);
+        G.ids = (uint32_t)std::min<size_t>(4092, (((GB_LDS_MAX - (18 + 2 + 2 * 256) * 4 - 64 - ((size_t)16 << G.tag_idx_bits)) / 24) & ~(size_t)3) - 4);
 #ifdef VXH_ABLATE
         G.abl = (int32_t)ctx().cfg_gb_abl;
 #endif
@@ -1007,7 +1138,7 @@ unsigned run_pipeline(GbArgs &G, int nv, bool merge, uint64_t n, uint64_t groups
         if (res) {
             (void)hipEventElapsedTime(&res->ms_scatter, e0, e1);
             (void)hipEventElapsedTime(&res->ms_reduce, e1, e2);
-            res->buckets = (int)NB; res->slots = (int)(4 * lines); res->retries = attempt;
+            res->buckets = (int)NB; res->slots = G.tag ? (int)G.ids : (int)(4 * lines); res->retries = attempt; res->tag = G.tag;
         }
         if (code == 0) {
             unsigned long long cnt = 0;
@@ -1290,6 +1421,7 @@ int vxh_groupby_info(const vxh_groupby *g, int what, double *value_out) {
     case 6: *value_out = g->compact; break;
     case 7: *value_out = g->heavy; break;
     case 8: *value_out = g->direct; break;
+    case 9: *value_out = g->tag; break;
     default: throw std::runtime_error("groupby info: unknown item");
     }
     GB_END

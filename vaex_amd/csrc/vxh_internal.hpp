@@ -244,6 +244,7 @@ struct Context {
     int64_t cfg_wv_block = 0;      // ... records per queue block of a (wave, slab) (0 = sized from the expected share); tests force tiny blocks
     int64_t cfg_fuse_selection = 1; // a selection shared by every aggregator of a call, over one float64 column, is evaluated inside the binning kernels (0: always through sel_eval's byte mask)
     int64_t cfg_gb_compact = 1;    // fused hash groupby: 12-byte records when the measured key range allows (vxh_groupby_run_ranged)
+    int64_t cfg_gb_tag = 1;       // fused groupby: gb_reduce's tag table for compact records whose remainder has < 32 bits (0: the 4-key-line probing table, for A/B runs)
     int64_t cfg_gb_key32 = 1;     // fused groupby: 32-bit keys in gb_reduce's probing table when the compact record's remainder has < 32 bits (0: 64-bit keys, for A/B runs)
     int64_t cfg_gb_direct_nb = 8; // ... log2 of the fewest buckets a direct-table pass takes (6 .. 10; 256 buckets: gb_scatter 5.4 -> 5.1 ms per 1e9 rows against 512, profiles/r06_groupby.txt)
     int64_t cfg_gb_direct = 1;    // fused groupby: key ranges of <= 2^22 cells index gb_reduce's LDS table with the record's remainder (0: the probing table, for A/B runs)
