@@ -61,6 +61,7 @@ df = vaex.from_arrays(k=rng.integers(-5, 40, n), k32=rng.integers(100, 130, n).a
                       k8=rng.integers(-3, 5, n).astype("i1"), ku8=rng.integers(0, 7, n).astype("u1"), kb=rng.integers(0, 2, n).astype(bool),
                       v=v, w=rng.normal(0, 1, n).astype("f4"), i=rng.integers(-100, 100, n).astype("i4"))
 df["virt"] = df.k + 1
+df["alias"] = df.v
 
 def frame(d, sort_by):
     d = d.sort(sort_by)
@@ -105,6 +106,12 @@ taken = [
   ("k", {"m": A.mean("v", selection="(v > 3) & (i < 50)"), "sd": A.std("v", selection="v > 3")}, {}),
   ("kgap", {"c": A.count(selection="w >= 0")}, {}),                                                      # (no count(*) among the actions: the groups still come from all rows)
   ("k", {"sd": A.std("i"), "va": A.var("i"), "m": A.mean("i")}, {}),
+  # round 6: a virtual column as key (materialised once on the host by vaex's own evaluate) or as value (an alias of a real column is that column),
+  # arithmetic over aggregators (vaex/agg.py:77-189: the leaves are aggregations of the same pass)
+  ("virt", {"c": A.count(), "s": A.sum("v")}, {}),
+  ("k", {"m": A.mean("alias"), "s": A.sum(df.alias)}, {}),
+  ("k", {"r": A.sum("v") / A.count(), "neg": -A.mean("v"), "x2": A.sum("i") * 2, "c": A.count()}, {}),
+  ("kgap", {"d": A.max("v") - A.min("v"), "off": 1 + A.mean("w")}, dict(sort=True)),
 ]
 if gpu:   # (several keys are packed on the device, scattered keys need the hash aggregation: no CPU stand-in)
     taken += [(["k", "k32"], {"c": A.count(), "s": A.sum("v")}, {}),
@@ -117,7 +124,7 @@ if gpu:   # (several keys are packed on the device, scattered keys need the hash
 declined = [
   ("kf", {"c": A.count()}, "dtype float64"),
   (["k8", "k"], {"c": A.count()}, "int8 key next to other keys"),
-  ("virt", {"c": A.count()}, "not a real column"),
+  ("virt * kf", {"c": A.count()}, "dtype float64"),
   ("k", {"u": A.nunique("i")}, "AggNUnique"),
   ("k", {"lo": A.first("v", "i")}, "AggFirst"),
   ("k", {"c": A.count(selection="sin(v) > 0")}, "selection outside the device predicate subset"),
@@ -140,6 +147,30 @@ for by, agg, why in declined:
     got = df.groupby(by, agg=agg)
     assert vg.last.get("path") == "vaex" and why in vg.last.get("why", ""), (by, vg.last)
     print("ok-declined", by, vg.last["why"])
+# round 6: binner OBJECTS as the key — vaex.groupby.Grouper over an integer column (the groups are the object's bins in the object's order, typed the
+# narrowest signed integer: vaex/groupby.py:226-330) and vaex.groupby.BinnerInteger over bool / int8 / uint8 (:147-205)
+G = vaex.groupby
+for make, ordered in [(lambda: G.Grouper(df.kgap, sort=True), True), (lambda: G.Grouper(df.kgap, sort=True, ascending=False), True), (lambda: G.Grouper(df.k32), False),
+                      (lambda: G.Grouper(df.ku, sort=True, pre_sort=False), True), (lambda: G.BinnerInteger(df.k8), True), (lambda: G.BinnerInteger(df.ku8, sort=True, ascending=False), True),
+                      (lambda: G.BinnerInteger(df.kb), True)]:
+    obj = make()
+    key = str(obj.expression)
+    vg.last.clear()
+    got = df.groupby(obj, agg={"c": A.count(), "m": A.mean("v"), "hi": A.max("i")})
+    assert vg.last.get("path") == "device", (key, vg.last)
+    want = original(df, make(), agg={"c": A.count(), "m": A.mean("v"), "hi": A.max("i")})
+    same(frame(got, key), frame(want, key), ("binner object", key))
+    if ordered:   # (an unsorted Grouper's order is its hash map's: unspecified between two objects)
+        assert np.array_equal(np.ma.getdata(got[key].to_numpy()), np.ma.getdata(want[key].to_numpy())), key
+    print("ok-device binner object", type(obj).__name__, key, ordered)
+for obj, why in [(G.Grouper(df.kf), "Grouper over float64"), (G.Binner(df.v, 0, 6, bins=3), "(Binner)")]:
+    vg.last.clear()
+    df.groupby(obj, agg="count")
+    assert vg.last.get("path") == "vaex" and why in vg.last.get("why", ""), vg.last
+vg.last.clear()
+df.groupby([G.Grouper(df.k), G.Grouper(df.k32)], agg="count")
+assert vg.last.get("path") == "vaex" and "next to other keys" in vg.last.get("why", ""), vg.last
+print("ok-declined binner objects")
 # a categorical key comes back as its LABELS, one group per category (vaex's GrouperCategory): vaex's business
 dcat = vaex.from_arrays(c=np.array([0, 1, 1, 2, 1]), v=np.arange(5.0))
 dcat.categorize("c", labels=["a", "b", "c"], inplace=True)
@@ -401,7 +432,7 @@ def _run(gpu, timeout):
 @pytest.mark.skipif(not os.path.isdir(os.path.join(PKG, "vaex")), reason="real vaex package not built (oracle/build_ref.sh needs /root/reference)")
 def test_groupby_host_logic_against_vaex_on_the_reference_cpp():
     out = _run(0, 600)
-    assert "DONE" in out and out.count("ok-device ") == 15 and out.count("ok-device-filtered") == 5 and out.count("ok-declined") == 8, out
+    assert "DONE" in out and out.count("ok-device ") == 26 and out.count("ok-device-filtered") == 5 and out.count("ok-declined") == 9, out
     assert "ok-device-failure-falls-back" in out and out.count("ok-task") == 9 and "ok-reference-defects" in out and out.count("ok-streamed") == 6, out
 
 
@@ -409,5 +440,5 @@ def test_groupby_host_logic_against_vaex_on_the_reference_cpp():
 @pytest.mark.skipif(not os.path.isdir(os.path.join(PKG, "vaex")), reason="real vaex package not built (oracle/build_ref.sh needs /root/reference)")
 def test_groupby_of_real_vaex_runs_on_the_device_groupby():
     out = _run(1, 900)
-    assert "DONE" in out and out.count("ok-device ") == 21 and out.count("ok-device-filtered") == 7 and out.count("ok-declined") == 8 and out.count("ok-task") == 9, out
+    assert "DONE" in out and out.count("ok-device ") == 32 and out.count("ok-device-filtered") == 7 and out.count("ok-declined") == 9 and out.count("ok-task") == 9, out
     assert "gb_scatter+gb_reduce" in out and "bin_lds" in out and out.count("ok-streamed") == 6, out   # (the fused hash aggregation, and — few groups — the LDS-resident grid)

@@ -104,8 +104,12 @@ for seed in range(ncalls):
     vi = rng.integers(0, 200, n) if vdt.startswith("u") else rng.integers(-100 if vdt == "i1" else -1000, 100 if vdt == "i1" else 1000, n)
     data.update(v=v, vi=vi.astype(vdt), vf=rng.normal(0, 1, n).astype("f4"))
     df = vaex.from_arrays(**data)
+    df["virt"] = df.vf * 2 + 1      # (round 6: a virtual column as a value — materialised once by vaex's own evaluate)
+    df["alias"] = df.v              # (... and an alias of a real column)
     aggs = {"c": A.count(), "cv": A.count("v"), "s": A.sum("v"), "m": A.mean("v"), "sd": A.std("v"), "va": A.var("vi"), "lo": A.min("v"), "hi": A.max("vi"),
-            "si": A.sum("vi"), "mf": A.mean("vf"), "sf": A.sum("vf"), "lof": A.min("vf"), "cs": A.count(selection="v > 0"), "ms": A.mean("vi", selection="vf < 0")}
+            "si": A.sum("vi"), "mf": A.mean("vf"), "sf": A.sum("vf"), "lof": A.min("vf"), "cs": A.count(selection="v > 0"), "ms": A.mean("vi", selection="vf < 0"),
+            # round 6: arithmetic over aggregators, virtual columns
+            "r": A.sum("v") / A.count(), "dd": A.max("vi") - A.min("vi"), "ng": -A.mean("vf"), "x3": 3 * A.sum("vi"), "svt": A.sum("virt"), "mal": A.mean("alias")}
     pick = [str(p) for p in rng.choice(list(aggs), size=int(rng.integers(1, 5)), replace=False)]
     agg = {p: aggs[p] for p in pick}
     kw = dict(sort=True, ascending=bool(rng.random() < 0.5)) if rng.random() < 0.4 else {}
@@ -115,9 +119,20 @@ for seed in range(ncalls):
     delayed = bool(rng.random() < 0.25)
     keys = list(data)[:nkeys]
     by = keys if nkeys > 1 else keys[0]
-    what = (seed, n, kinds, styles, pick, kw, "filtered" if d.filtered else "", "delayed" if delayed else "")
+    make_by = lambda: by
+    # round 6: the key as a binner OBJECT (vaex.groupby.Grouper / BinnerInteger): the order is the object's, not the call's
+    use_object = nkeys == 1 and not delayed and rng.random() < 0.2
+    if use_object:
+        okw = dict(sort=bool(rng.random() < 0.7), ascending=bool(rng.random() < 0.5))
+        cls = vaex.groupby.BinnerInteger if kinds[0] in ("i1", "u1", "bool") else vaex.groupby.Grouper
+        make_by = lambda: cls(d[keys[0]], **okw)
+        kw, kwc = {}, (okw if okw["sort"] or cls is vaex.groupby.BinnerInteger else {})
+        if cls is vaex.groupby.BinnerInteger: kwc = dict(sort=True, ascending=not (okw["sort"] and not okw["ascending"]))
+    else:
+        kwc = kw
+    what = (seed, n, kinds, styles, pick, kw, "filtered" if d.filtered else "", "delayed" if delayed else "", ("object", okw) if use_object else "")
     try:
-        want = original(d, by, agg=agg, **kw)
+        want = original(d, make_by(), agg=agg, **kw)
     except Exception as e:
         want = e
     try:
@@ -127,9 +142,10 @@ for seed in range(ncalls):
             d.execute()
             got = p.get()
         else:
-            got = d.groupby(by, agg=agg, **kw)
+            got = d.groupby(make_by(), agg=agg, **kw)
     except Exception as e:
         got = e
+    kw = kwc
     paths[vg.last.get("path")] = paths.get(vg.last.get("path"), 0) + 1
     if isinstance(want, Exception):
         if isinstance(got, Exception) and type(got) is type(want):

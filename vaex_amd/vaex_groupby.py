@@ -85,13 +85,12 @@ def _streamed_dtype(df, name, ar):
     return None
 
 
-def _real_column(df, expression, kinds, what):
+def _real_column(df, expression, kinds, what, materialise=True):
     """the numpy array behind `expression` when it names a real, unmasked column of one of `kinds` (active range applied) — or a _Streamed
     stand-in for a real numeric column held in another container (its rows then reach the device through the executor's chunks)"""
     name = str(expression)
     if name not in df.columns:
-        label = getattr(df[name], "_label", name) if name in getattr(df, "virtual_columns", {}) else name
-        raise _Decline(f"{what} {label!r} is not a real column")
+        return _virtual_column(df, name, kinds, what, materialise)
     ar = df.columns[name]
     i1, i2 = df._index_start, df._index_end
     if np.ma.isMaskedArray(ar) or not isinstance(ar, np.ndarray):
@@ -110,6 +109,71 @@ def _real_column(df, expression, kinds, what):
     if i1 != 0 or i2 != len(ar):
         ar = ar[i1:i2]
     return name, ar
+
+
+#: a virtual column / expression is materialised on the host for the device groupby up to this many rows (one numpy array of the frame's length)
+materialise_max_rows = 1 << 27
+
+
+def _virtual_column(df, name, kinds, what, materialise=True):
+    """`name` is a virtual column or an expression (round 6).  An alias of a real column (df['long_name'] = df.x: vaex/dataframe.py:3596-3640 stores
+    the expression 'x') is that column; anything else is evaluated ONCE on the host by vaex itself (df.evaluate over the active range,
+    unfiltered: the frame's filter is applied by the groupby) when the frame is small enough for one array — vaex's own passes evaluate it too,
+    chunk by chunk, twice for a key.  Masked results, strings and other dtypes decline."""
+    virtual = getattr(df, "virtual_columns", {})
+    label = getattr(df[name], "_label", name) if name in virtual else name
+    seen = set()
+    target = name
+    while target in virtual and target not in seen:   # an alias chain ends at a real column
+        seen.add(target)
+        target = str(virtual[target]).strip()
+    if target in df.columns and target != name:
+        return name, _real_column(df, target, kinds, what)[1]
+    if not materialise or len(df) > materialise_max_rows or df.length_original() > materialise_max_rows:
+        raise _Decline(f"{what} {label!r} is not a real column")
+    try:
+        ar = df.evaluate(name, filtered=False, parallel=False)
+    except Exception as e:   # noqa: BLE001  (an expression vaex cannot evaluate to an array: its own groupby says so)
+        raise _Decline(f"{what} {label!r} is not a real column ({type(e).__name__})")
+    if np.ma.isMaskedArray(ar) or not isinstance(ar, np.ndarray) or ar.ndim != 1:
+        raise _Decline(f"{what} {label!r} is not a real column (evaluates to {type(ar).__name__})")
+    if ar.dtype.name not in kinds or not ar.dtype.isnative:
+        raise _Decline(f"{what} {label!r} has dtype {ar.dtype}")
+    return name, np.ascontiguousarray(ar)
+
+
+def _binner_object_key(df, b, n_keys, run_pending=True):
+    """a binner OBJECT passed as a key (round 6) -> (key column expression, what the result must look like), or _Decline.
+    vaex.groupby.Grouper(expression, sort=, ascending=) over an integer column (vaex/groupby.py:226-330): the object has run its distinct-key
+    pass already when it was made; the groups are its bin_values IN ITS ORDER (sorted either way, or the hash map's own), typed the narrowest
+    signed integer that holds them (no BinnerInteger simplification: allow_simplify is the wrapper's own, :599).
+    vaex.groupby.BinnerInteger(expression) over bool / int8 / uint8 (:147-205): what df.groupby(<such a column>) makes itself (:593-596)."""
+    import vaex.array_types
+    import vaex.groupby
+    kind = type(b).__name__
+    if n_keys != 1:
+        raise _Decline(f"binner object as key ({kind} next to other keys)")   # (several binner objects: the combine decision and the cell order are the objects' own)
+    if type(b) is vaex.groupby.Grouper:
+        if not hasattr(b, "hashmap_unique") and run_pending and getattr(getattr(b, "_promise", None), "isPending", False):
+            # the object's distinct-key pass is scheduled, not run (vaex/groupby.py:298: delay=True; GroupBy.__init__ would run it now, :1021)
+            b.df.execute()
+        if getattr(b, "simpler", None) is not None or not hasattr(b, "bin_values") or not hasattr(b, "hashmap_unique"):
+            raise _Decline(f"binner object as key ({kind} that has not run its distinct-key pass)")
+        if b.df.dataset != df.dataset:
+            raise _Decline(f"binner object as key ({kind} of another dataset)")
+        bv = b.bin_values
+        if hasattr(bv, "null_count"):   # (an arrow array: the sorted forms come back through pyarrow)
+            if bv.null_count:
+                raise _Decline(f"binner object as key ({kind} with a missing-value group)")
+            bv = vaex.array_types.to_numpy(bv)
+        if np.ma.isMaskedArray(bv) or not isinstance(bv, np.ndarray) or bv.dtype.kind not in "iu" or getattr(b.hashmap_unique, "has_null", False) or getattr(b.hashmap_unique, "has_nan", False):
+            raise _Decline(f"binner object as key ({kind} over {getattr(bv, 'dtype', type(bv).__name__)})")
+        return str(b.expression), {"kind": "grouper", "bin_values": bv}
+    if type(b) is vaex.groupby.BinnerInteger:
+        if b.dtype.numpy.name not in _TINY_KEYS or getattr(b, "dropmissing", False) or b.df.dataset != df.dataset:
+            raise _Decline(f"binner object as key ({kind})")
+        return str(b.expression), {"kind": "integer", "invert": bool(b.invert)}
+    raise _Decline(f"binner object as key ({kind})")
 
 
 class _RecordingFrame:
@@ -155,6 +219,32 @@ def _normalise_actions(df, keys, actions):
     for a in rec.recorded:   # (vaex's loop sets it on every aggregation it schedules; these objects are the caller's and may be reused)
         a.edges = False
     return list(zip(grids.keys(), rec.recorded))
+
+
+def _expression_types():
+    import vaex.agg
+    return (vaex.agg.AggregatorExpressionUnary, vaex.agg.AggregatorExpressionBinary, vaex.agg.AggregatorExpressionBinaryScalar)
+
+
+def _translate_tree(df, aggregate, columns, predicates, spec):
+    """an aggregator expression -> a tree of ("leaf", hidden output name) / ("op", callable, children...); the leaves are entered into `spec`"""
+    import vaex.agg
+    if isinstance(aggregate, vaex.agg.AggregatorExpressionUnary):
+        return ("op", aggregate.finish, _translate_tree(df, aggregate.agg, columns, predicates, spec))
+    if isinstance(aggregate, vaex.agg.AggregatorExpressionBinary):
+        return ("op", aggregate.finish, _translate_tree(df, aggregate.agg1, columns, predicates, spec), _translate_tree(df, aggregate.agg2, columns, predicates, spec))
+    if isinstance(aggregate, vaex.agg.AggregatorExpressionBinaryScalar):
+        return ("op", aggregate.finish, _translate_tree(df, aggregate.agg, columns, predicates, spec))
+    name = f"__leaf_{len(spec)}"
+    spec[name] = _translate(df, aggregate, columns, predicates)
+    return ("leaf", name)
+
+
+def _finish_tree(tree, res):
+    if tree[0] == "leaf":
+        return np.asarray(res[tree[1]])
+    with np.errstate(all="ignore"):
+        return np.asarray(tree[1](*[_finish_tree(t, res) for t in tree[2:]]))
 
 
 def _translate(df, aggregate, columns, predicates):
@@ -240,7 +330,7 @@ class _NeedsTask(Exception):
 
 class _Plan:
     """what a df.groupby(by, agg) call needs from the device groupby, decided before a row is read"""
-    __slots__ = ("by", "agg", "sort", "srt", "asc", "columns", "key_names", "actions", "spec", "selection", "rows", "predicates", "streamed")
+    __slots__ = ("by", "agg", "sort", "srt", "asc", "columns", "key_names", "actions", "spec", "selection", "rows", "predicates", "streamed", "key_object", "finishers")
 
 
 def _plan(df, by, agg, sort=False, ascending=True, row_limit=None, for_task=False):
@@ -255,11 +345,14 @@ def _plan(df, by, agg, sort=False, ascending=True, row_limit=None, for_task=Fals
     by_list = [by] if isinstance(by, str) or not isinstance(by, collections.abc.Iterable) else list(by)
     if not 1 <= len(by_list) <= 8:
         raise _Decline(f"{len(by_list)} keys")
-    for b in by_list:
+    key_object = None
+    for i, b in enumerate(by_list):
         if isinstance(b, vaex.groupby.BinnerBase):
-            raise _Decline(f"binner object as key ({type(b).__name__})")
+            by_list[i], key_object = _binner_object_key(df, b, len(by_list), run_pending=not for_task)
     asc = list(ascending) if isinstance(ascending, (list, tuple)) else [ascending] * len(by_list)
     srt = list(sort) if isinstance(sort, (list, tuple)) else [sort] * len(by_list)
+    if key_object is not None:   # (the object's own order, not the call's: vaex/groupby.py:632-636 passes sort / ascending to the groupers IT makes)
+        srt, asc = ([True], [not key_object["invert"]]) if key_object["kind"] == "integer" else ([False], [True])
     if len(set(zip(srt, asc))) > 1:
         raise _Decline("keys sorted in different directions")
     columns, key_names = {}, []
@@ -267,8 +360,10 @@ def _plan(df, by, agg, sort=False, ascending=True, row_limit=None, for_task=Fals
         name, ar = _real_column(df, vaex.utils._ensure_string_from_expression(b), _KEY_KINDS, "group key")
         if name in columns:
             raise _Decline("the same key twice")
-        if df.is_category(name):
+        if df.is_category(name) and not (key_object is not None and key_object["kind"] == "grouper"):   # (a Grouper OBJECT groups the codes like any integer column)
             raise _Decline(f"group key {name!r} is categorical")   # (vaex's GrouperCategory hands back the LABELS, and a group per category: vaex/groupby.py:384-442)
+        if key_object is not None and key_object["kind"] == "integer" and ar.dtype.name not in _TINY_KEYS:
+            raise _Decline("binner object as key (BinnerInteger)")
         if ar.dtype.name in _TINY_KEYS and len(by_list) > 1:
             raise _Decline(f"{ar.dtype.name} key next to other keys")   # (BinnerInteger's N is the dtype's range, not the distinct keys: vaex's combine decision differs)
         columns[name] = ar
@@ -276,11 +371,16 @@ def _plan(df, by, agg, sort=False, ascending=True, row_limit=None, for_task=Fals
     actions = _normalise_actions(df, key_names, agg)
     if not actions:
         raise _Decline("no aggregation")
-    spec, predicates = {}, {}
+    spec, predicates, finishers = {}, {}, {}
     for out_name, aggregate in actions:
-        if out_name in spec or out_name in key_names:
+        if out_name in spec or out_name in finishers or out_name in key_names:
             raise _Decline("duplicate output column")
-        spec[out_name] = _translate(df, aggregate, columns, predicates)
+        if isinstance(aggregate, _expression_types()):
+            # arithmetic over aggregators (vaex.agg.sum('x') / vaex.agg.count(), -vaex.agg.mean('y'), ...: vaex/agg.py:77-189): the leaves are
+            # aggregations of the same pass under hidden names, the operators run over their per-group columns when the groups exist
+            finishers[out_name] = _translate_tree(df, aggregate, columns, predicates, spec)
+        else:
+            spec[out_name] = _translate(df, aggregate, columns, predicates)
     # a filtered frame (df[df.x > 0].groupby(...)): vaex compacts every chunk of every column with numpy before its two passes see a row
     # (vaex/execution.py:515-523); here the filter is a device predicate in every aggregator's keep-mask (vaex_amd/vaex_filter.py) and
     # groups without a row inside it are dropped — when it is in the predicate subset over real numeric columns; else vaex's own code
@@ -301,6 +401,8 @@ def _plan(df, by, agg, sort=False, ascending=True, row_limit=None, for_task=Fals
     plan.rows = len(next(iter(columns.values())))
     plan.predicates = predicates
     plan.streamed = any(isinstance(c, _Streamed) for c in columns.values())
+    plan.key_object = key_object
+    plan.finishers = finishers
     return plan
 
 
@@ -347,13 +449,24 @@ def _finish_arrays(df, plan, frame, res):
     for name in key_names:
         cells *= max(1, len(np.unique(np.ma.getdata(typed[name]))))
     combined = len(key_names) >= 2 and plan.rows / cells < 10
+    order = None
+    if plan.key_object is not None and plan.key_object["kind"] == "grouper":
+        # a Grouper object's groups are its bin_values in ITS order (a single Grouper is `dense`: every bin is a row of the result,
+        # vaex/groupby.py:949-953) — the device's groups, ascending, are looked up bin by bin; a bin without a row (the object was made over
+        # other rows than the frame has now) is vaex's own business
+        bins = plan.key_object["bin_values"]
+        mine = np.asarray(res[key_names[0]]).astype(np.int64)
+        order = np.searchsorted(mine, bins.astype(np.int64))
+        if len(bins) != len(mine) or (len(mine) and (order.max() >= len(mine) or not np.array_equal(mine[order], bins.astype(np.int64)))):
+            raise _Decline("binner object as key (Grouper whose bins are not the frame's groups)")
+        typed[key_names[0]] = bins
     for name in key_names:
         k = np.ma.getdata(typed[name]) if combined else typed[name]
         k = k[::-1] if descending else k
         out[df[name]._label] = k
     for out_name, _ in actions:
-        v = np.asarray(res[out_name])
-        out[out_name] = v[::-1] if descending else v
+        v = _finish_tree(plan.finishers[out_name], res) if out_name in plan.finishers else np.asarray(res[out_name])
+        out[out_name] = v[order] if order is not None else (v[::-1] if descending else v)
     last.clear()
     fused = frame.last_groupby_info and not frame.last_groupby_info.get("dense")   # (a dense range with its heavy keys peeled off leaves an info too)
     # (a frame over host columns hands its chunks to whichever of its thread slots is free: the kernel names are those of the slots the last pass used)
@@ -541,7 +654,7 @@ def _could_be_served(df, by, row_limit):
         return False
     try:
         for b in by_list:
-            _real_column(df, vaex.utils._ensure_string_from_expression(b), _KEY_KINDS, "group key")
+            _real_column(df, vaex.utils._ensure_string_from_expression(b), _KEY_KINDS, "group key", materialise=False)   # (a cheap look: nothing is evaluated here)
     except (_Decline, Exception):
         return False
     return True
@@ -605,7 +718,9 @@ def install(vaex_module, state):
                 import vaex.cache
                 plan = self.plan
                 call = [list(plan.key_names), [[name, d.name, d.column, None if d.selection is None else str(d.selection)] for name, d in plan.spec.items()],
-                        None if plan.selection is None else str(plan.selection), [bool(x) for x in plan.srt], [bool(x) for x in plan.asc]]
+                        None if plan.selection is None else str(plan.selection), [bool(x) for x in plan.srt], [bool(x) for x in plan.asc],
+                        None if plan.key_object is None else [plan.key_object["kind"], vaex.cache.fingerprint(plan.key_object.get("bin_values"))],
+                        [[name, repr(a)] for name, a in plan.actions if name in plan.finishers]]
                 df_fp = self.df.fingerprint(dependencies=self.dependencies())
                 self._fingerprint = f"task-{self.name}-{vaex.cache.fingerprint(call)}-{df_fp}"
             return self._fingerprint
