@@ -232,7 +232,9 @@ void vxh_selection_destroy(vxh_selection *selection);
  * bit; every column a program reads must be float64 (other dtypes follow numpy's promotion rules on the host: not offered).  Such a
  * selection is evaluated into its keep-mask by a pass of its own (never inside the binning kernels). */
 typedef enum vxh_sel_op { VXH_SEL_COL = 0, VXH_SEL_CONST = 1, VXH_SEL_ADD = 2, VXH_SEL_SUB = 3, VXH_SEL_MUL = 4, VXH_SEL_DIV = 5, VXH_SEL_NEG = 6,
-                          VXH_SEL_SQUARE = 7, VXH_SEL_SQRT = 8, VXH_SEL_ABS = 9 } vxh_sel_op;
+                          VXH_SEL_SQUARE = 7, VXH_SEL_SQRT = 8, VXH_SEL_ABS = 9,
+                          /* round 6: comparisons of the two top entries (1.0 / 0.0): `x > y`, `x + y <= 2 * z` as `<program> != 0` */
+                          VXH_SEL_LT = 10, VXH_SEL_LE = 11, VXH_SEL_GT = 12, VXH_SEL_GE = 13, VXH_SEL_EQ = 14, VXH_SEL_NE = 15 } vxh_sel_op;
 #define VXH_SEL_MAX_STEPS 16
 typedef struct vxh_sel_step {
     int32_t op;     /* vxh_sel_op */

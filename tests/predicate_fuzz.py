@@ -27,6 +27,9 @@ def _term(rng, names, f64):
         a, b = str(rng.choice(f64)), str(rng.choice(f64))
         e = str(rng.choice([f"{a} + {b}", f"{a} * 2 - {b}", f"{a}**2", f"abs({a})", f"sqrt({b}**2)", f"-{a}", f"{a}/{b}", f"({a} - {b})/2 + 1"]))
         return f"({e} {rng.choice(OPS)} {c})"
+    if rng.random() < 0.15 and len(f64) >= 2:   # round 6: column / expression against column / expression
+        a, b = str(rng.choice(f64)), str(rng.choice(f64))
+        return str(rng.choice([f"({a} {rng.choice(OPS)} {b})", f"({a} + 1 {rng.choice(OPS)} {b} * 2)", f"(abs({a}) {rng.choice(OPS)} {b}**2)", f"({a} - {b} {rng.choice(OPS)} {b} / {a})"]))
     return f"({name} {rng.choice(OPS)} {c})"
 
 

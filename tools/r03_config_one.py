@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One BASELINE config, a few passes on device-resident columns — for rocprofv3 (kernel stats / --pmc FETCH_SIZE, WRITE_SIZE).
-Usage: python tools/r03_config_one.py c2|c2e|count2d|c3d|c3s [rows] [passes] [knob=value ...]"""
+Usage: python tools/r03_config_one.py c2|c2e|count2d|uni|bench|c3d|c3s [rows] [passes] [knob=value ...]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -24,6 +24,12 @@ elif which == "c2e":   # (round 4) the selection as an expression over a fourth 
     v = v * 2 + 3
     df = Frame(dict(x=x, y=y, z=z, v=v))
     run = lambda: df.count(binby=["x", "y", "z"], limits=[[-4, 4]] * 3, shape=128, selection="v > 3", edges=True)
+elif which in ("uni", "bench"):   # (round 6) the bench pass — count(*), sum(v), count(v) on 256 x 256 — over UNIFORM x, y (no dense box) / over N(0,1)
+    mk = (lambda: torch.rand(rows, dtype=torch.float64, device="cuda", generator=g) * 8 - 4) if which == "uni" else (lambda: torch.randn(rows, dtype=torch.float64, device="cuda", generator=g))
+    x, y = mk(), mk()
+    v = torch.randn(rows, dtype=torch.float64, device="cuda", generator=g) * 2 + 3
+    df = Frame(dict(x=x, y=y, v=v))
+    run = lambda: df._agg([agg.count(), agg.mean("v")], binby=["x", "y"], limits=[[-4, 4]] * 2, shape=256, edges=True)
 elif which == "count2d":   # (round 4) north_star's target sentence: 2-D count(*) on a 256 x 256 grid
     x, y = (torch.randn(rows, dtype=torch.float64, device="cuda", generator=g) for _ in range(2))
     df = Frame(dict(x=x, y=y))

@@ -1152,6 +1152,7 @@ PYBIND11_MODULE(superagg, m) {
     m.attr("SEL_COL") = (int)VXH_SEL_COL; m.attr("SEL_CONST") = (int)VXH_SEL_CONST; m.attr("SEL_ADD") = (int)VXH_SEL_ADD; m.attr("SEL_SUB") = (int)VXH_SEL_SUB;
     m.attr("SEL_MUL") = (int)VXH_SEL_MUL; m.attr("SEL_DIV") = (int)VXH_SEL_DIV; m.attr("SEL_NEG") = (int)VXH_SEL_NEG; m.attr("SEL_SQUARE") = (int)VXH_SEL_SQUARE;
     m.attr("SEL_SQRT") = (int)VXH_SEL_SQRT; m.attr("SEL_ABS") = (int)VXH_SEL_ABS;
+    m.attr("SEL_LT") = (int)VXH_SEL_LT; m.attr("SEL_LE") = (int)VXH_SEL_LE; m.attr("SEL_GT") = (int)VXH_SEL_GT; m.attr("SEL_GE") = (int)VXH_SEL_GE; m.attr("SEL_EQ") = (int)VXH_SEL_EQ; m.attr("SEL_NE") = (int)VXH_SEL_NE;
     m.attr("CMP_LT") = (int)VXH_CMP_LT; m.attr("CMP_LE") = (int)VXH_CMP_LE; m.attr("CMP_GT") = (int)VXH_CMP_GT;
     m.attr("CMP_GE") = (int)VXH_CMP_GE; m.attr("CMP_EQ") = (int)VXH_CMP_EQ; m.attr("CMP_NE") = (int)VXH_CMP_NE;
     py::class_<PyAgg> aggregator(m, "Aggregator", py::buffer_protocol());

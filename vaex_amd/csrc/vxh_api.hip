@@ -2866,6 +2866,7 @@ int vxh_selection_set_program(vxh_selection *sel, int term, int n_steps, const v
             break;
         case VXH_SEL_CONST: depth++; break;
         case VXH_SEL_ADD: case VXH_SEL_SUB: case VXH_SEL_MUL: case VXH_SEL_DIV:
+        case VXH_SEL_LT: case VXH_SEL_LE: case VXH_SEL_GT: case VXH_SEL_GE: case VXH_SEL_EQ: case VXH_SEL_NE:
             if (depth < 2) throw std::runtime_error("vxh_selection_set_program: operator without two operands");
             depth--;
             break;

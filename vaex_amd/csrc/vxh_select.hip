@@ -54,6 +54,12 @@ __device__ __forceinline__ double eval_program(const SelArgs &A, int t, uint64_t
         case VXH_SEL_NEG: s0 = -s0; break;
         case VXH_SEL_SQUARE: s0 = s0 * s0; break;
         case VXH_SEL_SQRT: s0 = sqrt(s0); break;
+        case VXH_SEL_LT: s0 = s1 < s0 ? 1.0 : 0.0; s1 = s2; s2 = s3; break;   // (IEEE comparisons: false next to a NaN, != true — numpy's)
+        case VXH_SEL_LE: s0 = s1 <= s0 ? 1.0 : 0.0; s1 = s2; s2 = s3; break;
+        case VXH_SEL_GT: s0 = s1 > s0 ? 1.0 : 0.0; s1 = s2; s2 = s3; break;
+        case VXH_SEL_GE: s0 = s1 >= s0 ? 1.0 : 0.0; s1 = s2; s2 = s3; break;
+        case VXH_SEL_EQ: s0 = s1 == s0 ? 1.0 : 0.0; s1 = s2; s2 = s3; break;
+        case VXH_SEL_NE: s0 = s1 != s0 ? 1.0 : 0.0; s1 = s2; s2 = s3; break;
         default: s0 = fabs(s0); break;
         }
     }

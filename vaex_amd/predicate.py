@@ -5,6 +5,7 @@ validated against the AST whitelist of vaex/expresso.py:46-155) and evaluates it
 (vaex/execution.py:530-549).  `compile_selection` accepts the subset the GPU evaluates itself:
 
     comparisons  <column> (< <= > >= == !=) <number>,  <number> (op) <column>
+    round 6: <expression> (op) <expression> over float64 columns (`x > y`, `x + y <= 2 * z`): both sides and the comparison in one program
     combined with  &  |  ~,  at most 4 comparisons over at most 4 columns
     round 5: the column side may be an ARITHMETIC EXPRESSION over float64 columns — + - * / unary minus, `** 2`, sqrt(), abs(),
     numbers — e.g. `2*x + 1 > 0`, `x**2 + y**2 < 4`; names of VIRTUAL columns (`virtual=`: name -> expression string, as in
@@ -70,6 +71,7 @@ def plain_numeric_dtype(ar):
 
 # steps of an expression term's postfix program (include/vaex_hip.h vxh_sel_op)
 SEL_COL, SEL_CONST, SEL_ADD, SEL_SUB, SEL_MUL, SEL_DIV, SEL_NEG, SEL_SQUARE, SEL_SQRT, SEL_ABS = range(10)
+SEL_CMP = 10   # round 6: SEL_CMP + comparison code (0 .. 5: < <= > >= == !=) compares the two top entries -> 1.0 / 0.0
 MAX_STEPS = 16
 
 
@@ -96,6 +98,9 @@ class Predicate:
                 elif op in (SEL_ADD, SEL_SUB, SEL_MUL, SEL_DIV):
                     b, a = stack.pop(), stack.pop()
                     stack.append({SEL_ADD: operator.add, SEL_SUB: operator.sub, SEL_MUL: operator.mul, SEL_DIV: operator.truediv}[op](a, b))
+                elif op >= SEL_CMP:
+                    b, a = stack.pop(), stack.pop()
+                    stack.append(np.asarray(_NUMPY[op - SEL_CMP](a, b), dtype=np.float64))
                 elif op == SEL_NEG:
                     stack.append(-stack.pop())
                 elif op == SEL_SQUARE:
@@ -126,6 +131,9 @@ class Predicate:
                     elif step in (SEL_ADD, SEL_SUB, SEL_MUL, SEL_DIV):
                         b, a = stack.pop(), stack.pop()
                         stack.append({SEL_ADD: torch.add, SEL_SUB: torch.sub, SEL_MUL: torch.mul, SEL_DIV: torch.true_divide}[step](a, b))
+                    elif step >= SEL_CMP:
+                        b, a = stack.pop(), stack.pop()
+                        stack.append(ops[step - SEL_CMP](a, b).to(torch.float64))
                     elif step == SEL_NEG:
                         stack.append(torch.neg(stack.pop()))
                     elif step == SEL_SQUARE:
@@ -219,6 +227,10 @@ def compile_selection(expression, known_columns, virtual=None):
             except OverflowError:
                 raise Unsupported("integer constant too large for float64")
             return 1
+        if not any(isinstance(n, ast.Name) for n in ast.walk(node)):
+            # numbers only, and _constant did not fold them: `1 / 0`, `10 ** 400 * 1.0`, ... — vaex's eval() raises on these, the device would
+            # quietly compute inf
+            raise Unsupported("a constant subexpression Python does not evaluate")
         if isinstance(node, ast.Name):
             if node.id in virtual and node.id not in known_columns:
                 try:
@@ -281,6 +293,24 @@ def compile_selection(expression, known_columns, virtual=None):
         programs[len(terms) - 1] = prog
         return ("term", len(terms) - 1)
 
+    def comparison_term(left, op, right):
+        steps = []
+        dl = arithmetic(left, steps)
+        dr = arithmetic(right, steps)
+        steps.append((SEL_CMP + op, 0, 0.0))
+        if max(dl, 1 + dr) > 4 or len(steps) > MAX_STEPS:
+            raise Unsupported("expression too long for the device (16 steps, four stack entries)")
+        first = next((c for o, c, _ in steps if o == SEL_COL), None)
+        if first is None:
+            raise Unsupported("a comparison between two constants")
+        t, prog = (first, 5, 0.0), tuple(steps)
+        for i, old in enumerate(terms):
+            if old == t and programs.get(i) == prog:
+                return ("term", i)
+        terms.append(t)
+        programs[len(terms) - 1] = prog
+        return ("term", len(terms) - 1)
+
     def term(name, op, value):
         if name not in known_columns:
             raise Unsupported(f"{name!r} is not a column")
@@ -321,8 +351,12 @@ def compile_selection(expression, known_columns, virtual=None):
                     parts.append(expression_term(left, code, _constant(right)))
                 elif _constant(left) is not None and _constant(right) is None:
                     parts.append(expression_term(right, _SWAP[code], _constant(left)))
+                elif _constant(left) is None and _constant(right) is None:
+                    # round 6: <expression> <op> <expression> over float64 columns (`x > y`, `x + y <= 2 * z`): both sides and the comparison
+                    # in ONE program that leaves 1.0 / 0.0 — the term is `<program> != 0`
+                    parts.append(comparison_term(left, code, right))
                 else:
-                    raise Unsupported("only <column or arithmetic expression> <op> <number> comparisons run on the device")
+                    raise Unsupported("only <column or arithmetic expression> <op> <number or expression> comparisons run on the device")
                 left = right
             return parts[0] if len(parts) == 1 else ("and", parts)
         raise Unsupported(f"{type(node).__name__} is not part of the device predicate subset")
