@@ -523,7 +523,7 @@ def test_narrow_key_ranges_index_the_lds_table_directly(sa, gpu_ready, cells, km
 
 def test_dense_ranges_take_the_fused_pass_with_the_direct_table(sa, gpu_ready):
     """Frame.groupby over a dense 1e6-key range (BASELINE configs[3]) on device columns: the fused pass with the direct table answers (one value
-    column), the slab-partitioned BinnerOrdinal pass still answers what is outside it (two value columns, min / max) — same groups either way"""
+    column; several: one such pass per column), the slab-partitioned BinnerOrdinal pass still answers what is outside it (min / max) — same groups either way"""
     import torch
     from vaex_amd.binned import Frame, agg
     rng = np.random.default_rng(77)
@@ -555,6 +555,49 @@ def test_dense_ranges_take_the_fused_pass_with_the_direct_table(sa, gpu_ready):
     assert not (df.last_groupby_info or {}).get("direct_table")
     np.testing.assert_array_equal(two["k"], want["k"])
     assert np.allclose(two["sw"], np.bincount(k, weights=w, minlength=1_000_000)[np.bincount(k, minlength=1_000_000) > 0], rtol=1e-11, atol=1e-9)
+
+
+@pytest.mark.parametrize("keys", ["dense", "scattered", "wide"])
+def test_several_value_columns_are_one_fused_pass_per_column(sa, gpu_ready, keys):
+    """round 6: the fused pass's fast forms carry one payload word per record — a call over several value columns is one pass per column where
+    the key range leaves compact records (dense: the direct table; scattered: the tag table), one pass per PAIR of columns over wider keys
+    (three columns did not ride the fused pass at all before); the passes agree on the groups"""
+    import torch
+    from vaex_amd.binned import Frame, agg
+    rng = np.random.default_rng({"dense": 1, "scattered": 2, "wide": 3}[keys])
+    n = 5_000_000
+    k = rng.integers(0, 300_000, n)
+    if keys == "scattered":
+        k = (k * 2654435761) % (1 << 36)
+    elif keys == "wide":
+        k = (k.astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15)).astype(np.int64)
+    cols = {c: rng.normal(i, 1 + i, n) for i, c in enumerate("abc")}
+    cols["a"][::777] = np.nan
+    df = Frame(dict(k=torch.from_numpy(k).cuda(), **{c: torch.from_numpy(x).cuda() for c, x in cols.items()}), superagg=sa)
+    spec = {"n": agg.count(), "ca": agg.count("a"), "ma": agg.mean("a"), "sb": agg.sum("b"), "sdb": agg.std("b"), "sc": agg.sum("c"), "mc": agg.mean("c")}
+    df.last_groupby_info = None
+    got = df.groupby("k", spec)
+    info = df.last_groupby_info
+    assert info and info.get("passes") == (3 if keys != "wide" else 2) and info.get("value_columns_per_pass") == (1 if keys != "wide" else 2), info
+    if keys == "dense":
+        assert info.get("direct_table") == 1, info
+    want = _want(k, [cols["a"], cols["b"], cols["c"]])
+    np.testing.assert_array_equal(got["k"], want["k"]); np.testing.assert_array_equal(got["n"], want["rows"]); np.testing.assert_array_equal(got["ca"], want["v"][0]["cnt"])
+    for name, j in (("sb", 1), ("sc", 2)):
+        assert np.all(np.abs(got[name] - want["v"][j]["s"]) <= 1e-12 * want["v"][j]["sabs"] + 1e-300), name
+    ok = want["v"][0]["cnt"] > 0
+    assert np.allclose(np.asarray(got["ma"])[ok], (want["v"][0]["s"] / want["v"][0]["cnt"])[ok], rtol=1e-11, atol=1e-12)
+    assert np.allclose(got["mc"], want["v"][2]["s"] / want["v"][2]["cnt"], rtol=1e-11, atol=1e-12)
+    # two columns over compact keys: two passes, same numbers as the one 24-byte-record pass they replace
+    if keys == "scattered":
+        two = df.groupby("k", {"sb": agg.sum("b"), "sc": agg.sum("c")})
+        assert df.last_groupby_info.get("passes") == 2
+        df.compact_key_bits = 0
+        one = df.groupby("k", {"sb": agg.sum("b"), "sc": agg.sum("c")})
+        assert not df.last_groupby_info.get("passes")
+        np.testing.assert_array_equal(one["k"], two["k"])
+        for name, j in (("sb", 1), ("sc", 2)):
+            assert np.all(np.abs(one[name] - two[name]) <= 2e-12 * want["v"][j]["sabs"] + 1e-300), name
 
 
 def test_a_column_overwritten_in_place_is_scanned_again(sa, gpu_ready):

@@ -37,12 +37,17 @@ elif which == "count2d":   # (round 4) north_star's target sentence: 2-D count(*
 else:
     v = torch.randn(rows, dtype=torch.float64, device="cuda", generator=g) * 2 + 3
     k = torch.randint(0, 1_000_000, (rows,), dtype=torch.int64, device="cuda", generator=g)
-    if which == "c3s":
+    if which in ("c3s", "c3s2"):
         k = (k * 2654435761) % (1 << 40)
+    if which in ("c3w", "c3w2"):   # (round 6) 1e6 distinct keys spread over the whole int64 range (hashed ids): no compact records
+        k = k * 0x9E3779B97F4A7C15 + 12345
     df = Frame(dict(k=k, v=v))
     spec = {"c": agg.count("v"), "s": agg.sum("v"), "m": agg.mean("v"), "sd": agg.std("v")}
+    if which in ("c3s2", "c3w2", "c3d2"):   # (round 6) two value columns
+        df = Frame(dict(k=k, v=v, w=torch.randn(rows, dtype=torch.float64, device="cuda", generator=g)))
+        spec = {"c": agg.count("v"), "m": agg.mean("v"), "sw": agg.sum("w"), "sdw": agg.std("w")}
     run = lambda: df.groupby("k", spec)
 torch.cuda.synchronize()
 for i in range(passes):
     t0 = time.perf_counter(); sa.timer_start(0); r = run(); k_ms = sa.timer_stop(0); dt = time.perf_counter() - t0
-    print(f"{which} pass {i}: {dt*1e3:.3f} ms wall, {k_ms:.3f} ms on the stream = {rows/dt/1e9:.1f} Grows/s  {sa.last_kernel(0)} {getattr(df, 'last_groupby_info', '') if which in ('c3s', 'c3') else ''}", flush=True)
+    print(f"{which} pass {i}: {dt*1e3:.3f} ms wall, {k_ms:.3f} ms on the stream = {rows/dt/1e9:.1f} Grows/s  {sa.last_kernel(0)} {getattr(df, 'last_groupby_info', '') if which.startswith('c3') else ''}", flush=True)

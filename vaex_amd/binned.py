@@ -1070,7 +1070,7 @@ class Frame:
             # table — the record's remainder indexes gb_reduce's LDS accumulators, no keys, no probe (vxh_groupby.hip) — behind gb_scatter's
             # shared streams, instead of the slab-partitioned pair (part_scatter_f64 4.0 TB/s -> gb_scatter 5.0 TB/s of the same traffic)
             if (self.dense_through_fused and comm is None and count > self.dense_peel_cells and self.n >= self.heavy_key_rows and hasattr(sa, "groupby_run")
-                    and len({d.column for d in descs if d.column is not None}) <= 1 and sa.config_get("gb_direct") and sa.config_get("gb_compact")):
+                    and sa.config_get("gb_direct") and sa.config_get("gb_compact")):   # (several value columns: one pass per column, _groupby_fused_split)
                 fused = self._groupby_fused(by, pf, descs, names, comm, key_range=(kmin, kmax), filter_sel=selection)
                 if fused is not None:
                     self.last_groupby_info = dict(self.last_groupby_info or {}, dense_range_through_fused_pass=1)
@@ -1153,8 +1153,15 @@ class Frame:
                 return None
             if d.column is not None and d.column not in vcols:
                 vcols.append(d.column)
-        if len(vcols) > 2:
-            return None
+        # Round 6: several value columns.  The pass's fast forms carry ONE payload word per record (compact 10 / 12-byte records, the direct and
+        # the tag table: 7.2 / 8.2 ms per 1e9 rows); two value columns ride 24-byte SoA records through the generic table (19.5 ms), three
+        # or more did not ride at all.  Where the key range allows compact records the call is ONE PASS PER VALUE COLUMN (two columns: 14.4 /
+        # 16.4 ms), elsewhere one pass per PAIR of columns; the passes see the same rows, so their sorted group keys are the same array.
+        if len(vcols) >= 2:
+            bits = 64 if key_range is None or key_range[0] > key_range[1] else (int(key_range[1]) - int(key_range[0])).bit_length()
+            per_pass = 1 if bits <= self.compact_key_bits and sa.config_get("gb_compact") else 2
+            if len(vcols) > per_pass:
+                return self._groupby_fused_split(by, pf, descs, names, comm, key_range, filter_sel, vcols, per_pass)
         if shared is not None and not _same_selection(shared, filter_sel):
             if filter_sel is not None or pf != "int64":   # (an own selection next to a filter is refused in groupby(); the key pass lends the int64 key as payload)
                 return None
@@ -1264,6 +1271,30 @@ class Frame:
             self.last_groupby_info.update(heavy_keys=peeled_here)   # (of THIS rank's pass; a cross-rank merge has none)
         return out
 
+    def _groupby_fused_split(self, by, pf, descs, names, comm, key_range, filter_sel, vcols, per_pass):
+        """_groupby_fused over more value columns than one pass carries: the aggregations are dealt to passes by their value column
+        (`per_pass` columns each; count(*) rides the first), every pass is the whole fused groupby over the same rows and the same keep-mask,
+        so the passes agree on the groups.  Collective under `comm`: the passes are entered by every rank in the same order (the split
+        depends on the call's signature and the agreed key range only)."""
+        groups = [vcols[i:i + per_pass] for i in range(0, len(vcols), per_pass)]
+        out, infos = None, []
+        for g, cols in enumerate(groups):
+            picked = [(n, d) for n, d in zip(names, descs) if (d.column in cols) or (d.column is None and g == 0)]
+            part = self._groupby_fused(by, pf, [d for _, d in picked], [n for n, _ in picked], comm, key_range=key_range, filter_sel=filter_sel)
+            ok = part is not None and (out is None or np.array_equal(np.asarray(part[by]), np.asarray(out[by])))
+            if not (ok if comm is None else comm.all_agree(ok)):
+                return None
+            infos.append(dict(self.last_groupby_info or {}))
+            if out is None:
+                out = {by: part[by]}
+            out.update({n: part[n] for n, _ in picked})
+        info = dict(infos[0])
+        for k in ("ms_scatter", "ms_reduce", "ms_sort", "retries"):
+            info[k] = sum(float(i.get(k, 0)) for i in infos)
+        info.update(passes=len(groups), value_columns_per_pass=per_pass)
+        self.last_groupby_info = info
+        return {by: out[by], **{n: out[n] for n in names}}
+
     def _groupby_fused_own_selection(self, by, pf, descs, names, comm, key_range, shared):
         """aggregations sharing ONE selection of their own: the groups are those of all rows (pass 1: count(*) per key, no keep-mask),
         the values those of the kept rows (pass 2: the same call with the selection as its filter); groups pass 2 does not know get
@@ -1299,8 +1330,11 @@ class Frame:
                                       groups_with_a_kept_row=int(len(pos)), ms_keys_pass=info_keys.get("ms_scatter", 0) + info_keys.get("ms_reduce", 0))
         return out
 
-    #: dense key ranges of 2^14 .. 2^21 cells with at most one value column take the fused pass with a direct LDS table (round 6); False: the slab-partitioned BinnerOrdinal pass
+    #: dense key ranges of 2^14 .. 2^21 cells take the fused pass with a direct LDS table (round 6; several value columns: one pass per column); False: the slab-partitioned BinnerOrdinal pass
     dense_through_fused = True
+    #: key ranges of up to this many bits leave compact records in the fused pass whatever its bucket count (remainder <= 32 bits below the >= 8 bucket bits of a pass over an unknown or large number of groups): a call with
+    #: several value columns is then one pass per column (_groupby_fused_split)
+    compact_key_bits = 40
     #: heavy keys are peeled inside the fused pass (round 4); False: round 3's three passes (ordinals, keep-mask, a dense groupby of the heavy rows)
     one_kernel_peel = True
     #: rows from which a device-resident key column is sampled for heavy hitters before the fused hash groupby
