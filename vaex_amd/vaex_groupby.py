@@ -47,6 +47,7 @@ last = {}
 stats = {"device": 0, "task": 0, "vaex": 0, "why": {}}
 
 _KEY_KINDS = ("bool", "int8", "int16", "int32", "int64", "uint8", "uint16", "uint32")
+_FLOAT_KEYS = ("float64", "float32")   # round 6: grouped by their bit patterns (_coded_key)
 _TINY_KEYS = ("bool", "int8", "uint8")   # vaex bins these with BinnerInteger straight away (vaex/groupby.py:593-595): no combined grouper, own key typing
 _VALUE_KINDS = ("float64", "float32", "int64", "int32", "int16", "int8", "uint32", "uint16", "uint8")
 _AGG_NAMES = {"AggCount": "count", "AggSum": "sum", "AggMin": "min", "AggMax": "max"}
@@ -74,9 +75,16 @@ def _streamed_dtype(df, name, ar):
     dt = predicate.plain_numeric_dtype(ar)          # arrow without nulls (and plain numpy)
     if dt is not None:
         return dt
+    if hasattr(ar, "null_count") and hasattr(ar, "type"):   # an arrow dictionary column (a categorical key: its indices are the codes)
+        import pyarrow as pa
+        if pa.types.is_dictionary(ar.type) and not ar.null_count and pa.types.is_integer(ar.type.index_type):
+            return np.dtype(ar.type.index_type.to_pandas_dtype())
+        return None
     if type(ar).__name__ == "ColumnProxy" and hasattr(ar, "ds"):
         try:
             dt = df.data_type(name)
+            if dt.is_encoded:                       # (a categorical column of a _future() frame shows as a dictionary: the chunks are indices into the labels)
+                dt = dt.index_type
             if dt.is_numeric or dt == bool:         # (missing values show when the chunks arrive: the task then leaves the pass to vaex)
                 dt = np.dtype(dt.numpy)
                 return dt if dt.isnative else None
@@ -85,29 +93,71 @@ def _streamed_dtype(df, name, ar):
     return None
 
 
-def _real_column(df, expression, kinds, what, materialise=True):
+class _Nullable:
+    """a numeric / bool column with missing values, split on the host (round 6): `data` (a missing entry holds whatever the container held) and `mask`"""
+
+    def __init__(self, data, mask):
+        self.data, self.mask, self.dtype = data, mask, data.dtype
+
+    def __len__(self):
+        return len(self.data)
+
+
+def _split_nullable(ar, i1=0, i2=None):
+    """a masked numpy array / a pyarrow Array or ChunkedArray of a primitive numeric or bool type WITH nulls -> _Nullable, else None"""
+    if isinstance(ar, np.ndarray):
+        if not np.ma.isMaskedArray(ar) or ar.ndim != 1 or not ar.dtype.isnative or ar.dtype.kind not in "biuf":
+            return None
+        i2 = len(ar) if i2 is None else i2
+        return _Nullable(np.ascontiguousarray(np.ma.getdata(ar)[i1:i2]), np.ascontiguousarray(np.ma.getmaskarray(ar)[i1:i2]))
+    if getattr(ar, "type", None) is None or not hasattr(ar, "null_count"):
+        return None
+    import pyarrow as pa
+    if not isinstance(ar, (pa.Array, pa.ChunkedArray)) or not (pa.types.is_integer(ar.type) or pa.types.is_floating(ar.type) or pa.types.is_boolean(ar.type)):
+        return None
+    i2 = len(ar) if i2 is None else i2
+    ar = ar.slice(i1, i2 - i1)
+    if isinstance(ar, pa.ChunkedArray):
+        ar = ar.combine_chunks() if ar.num_chunks else pa.array([], type=ar.type)
+        ar = pa.concat_arrays(ar.chunks) if isinstance(ar, pa.ChunkedArray) else ar
+    mask = np.asarray(ar.is_null().to_numpy(zero_copy_only=False))
+    data = np.asarray(ar.fill_null(False if pa.types.is_boolean(ar.type) else 0).to_numpy(zero_copy_only=False))
+    return _Nullable(np.ascontiguousarray(data), np.ascontiguousarray(mask))
+
+
+def _real_column(df, expression, kinds, what, materialise=True, nullable=False):
     """the numpy array behind `expression` when it names a real, unmasked column of one of `kinds` (active range applied) — or a _Streamed
     stand-in for a real numeric column held in another container (its rows then reach the device through the executor's chunks)"""
     name = str(expression)
     if name not in df.columns:
-        return _virtual_column(df, name, kinds, what, materialise)
+        return _virtual_column(df, name, kinds, what, materialise, nullable)
     ar = df.columns[name]
     i1, i2 = df._index_start, df._index_end
     if np.ma.isMaskedArray(ar) or not isinstance(ar, np.ndarray):
         kind = "masked numpy" if np.ma.isMaskedArray(ar) else f"{type(ar).__module__.split('.')[0]}.{type(ar).__name__}" + (f"[{ar.type}]" if hasattr(ar, "type") and hasattr(ar, "null_count") else "")
         dt = None if np.ma.isMaskedArray(ar) else _streamed_dtype(df, name, ar)
+        if dt is None and nullable and len(ar) <= materialise_max_rows:
+            # round 6: missing values (a numpy mask / arrow nulls) — the column is split on the host into data and mask; a key's missing rows
+            # become a code of their own (_nullable_key), a value column's become NaN (_nullable_values)
+            split = _split_nullable(ar, i1, i2)
+            if split is not None:
+                if split.dtype.name not in kinds:
+                    raise _Decline(f"{what} {name!r} has dtype {split.dtype}")
+                return name, (split if split.mask.any() else split.data)
         if dt is None:
             raise _Decline(f"{what} {name!r} is not a plain numpy column ({kind})")
         if dt.name not in kinds:
             raise _Decline(f"{what} {name!r} has dtype {dt}")
         n = len(ar)
         return name, _Streamed(dt, (n if i2 is None else i2) - i1, ar)
-    if ar.dtype.name not in kinds or not ar.dtype.isnative or ar.ndim != 1:
+    if ar.dtype.name not in kinds or ar.ndim != 1 or (not ar.dtype.isnative and (not nullable or len(ar) > materialise_max_rows)):
         raise _Decline(f"{what} {name!r} has dtype {ar.dtype}")
     if i2 is None:
         i2 = len(ar)
     if i1 != 0 or i2 != len(ar):
         ar = ar[i1:i2]
+    if not ar.dtype.isnative:   # (round 6: a byte-swapped column — FITS / big-endian HDF5 — is converted once on the host)
+        ar = ar.astype(ar.dtype.newbyteorder("="))
     return name, ar
 
 
@@ -115,7 +165,7 @@ def _real_column(df, expression, kinds, what, materialise=True):
 materialise_max_rows = 1 << 27
 
 
-def _virtual_column(df, name, kinds, what, materialise=True):
+def _virtual_column(df, name, kinds, what, materialise=True, nullable=False):
     """`name` is a virtual column or an expression (round 6).  An alias of a real column (df['long_name'] = df.x: vaex/dataframe.py:3596-3640 stores
     the expression 'x') is that column; anything else is evaluated ONCE on the host by vaex itself (df.evaluate over the active range,
     unfiltered: the frame's filter is applied by the groupby) when the frame is small enough for one array — vaex's own passes evaluate it too,
@@ -128,13 +178,27 @@ def _virtual_column(df, name, kinds, what, materialise=True):
         seen.add(target)
         target = str(virtual[target]).strip()
     if target in df.columns and target != name:
-        return name, _real_column(df, target, kinds, what)[1]
+        return name, _real_column(df, target, kinds, what, nullable=nullable)[1]
     if not materialise or len(df) > materialise_max_rows or df.length_original() > materialise_max_rows:
         raise _Decline(f"{what} {label!r} is not a real column")
     try:
         ar = df.evaluate(name, filtered=False, parallel=False)
     except Exception as e:   # noqa: BLE001  (an expression vaex cannot evaluate to an array: its own groupby says so)
         raise _Decline(f"{what} {label!r} is not a real column ({type(e).__name__})")
+    if nullable and (np.ma.isMaskedArray(ar) or not isinstance(ar, np.ndarray)):
+        split = _split_nullable(ar)
+        if split is None and not np.ma.isMaskedArray(ar):   # (an arrow result without nulls)
+            dt = __import__("vaex_amd").predicate.plain_numeric_dtype(ar)
+            if dt is not None:
+                import vaex.array_types
+                ar = np.asarray(vaex.array_types.to_numpy(ar))
+        if split is not None:
+            if not split.mask.any():
+                ar = split.data
+            elif split.dtype.name in kinds:
+                return name, split
+            else:
+                raise _Decline(f"{what} {label!r} has dtype {split.dtype}")
     if np.ma.isMaskedArray(ar) or not isinstance(ar, np.ndarray) or ar.ndim != 1:
         raise _Decline(f"{what} {label!r} is not a real column (evaluates to {type(ar).__name__})")
     if ar.dtype.name not in kinds or not ar.dtype.isnative:
@@ -145,14 +209,19 @@ def _virtual_column(df, name, kinds, what, materialise=True):
 def _binner_object_key(df, b, n_keys, run_pending=True):
     """a binner OBJECT passed as a key (round 6) -> (key column expression, what the result must look like), or _Decline.
     vaex.groupby.Grouper(expression, sort=, ascending=) over an integer column (vaex/groupby.py:226-330): the object has run its distinct-key
-    pass already when it was made; the groups are its bin_values IN ITS ORDER (sorted either way, or the hash map's own), typed the narrowest
-    signed integer that holds them (no BinnerInteger simplification: allow_simplify is the wrapper's own, :599).
-    vaex.groupby.BinnerInteger(expression) over bool / int8 / uint8 (:147-205): what df.groupby(<such a column>) makes itself (:593-596)."""
+    pass already when it was made; the groups are its bin_values IN ITS ORDER (sorted either way, or the hash map's own; a missing-value
+    group among them), typed the narrowest signed integer that holds them (no BinnerInteger simplification: allow_simplify is the wrapper's own, :599).
+    vaex.groupby.BinnerInteger(expression[, min_value, max_value, dropmissing]) (:147-205): what df.groupby(<bool / int8 / uint8 column>) makes itself (:593-596).
+    vaex.groupby.GrouperCategory(expression) (:384-442): the categories of a categorical column."""
     import vaex.array_types
     import vaex.groupby
     kind = type(b).__name__
-    if n_keys != 1:
-        raise _Decline(f"binner object as key ({kind} next to other keys)")   # (several binner objects: the combine decision and the cell order are the objects' own)
+    if type(b) is vaex.groupby.GrouperCategory:
+        # the object's bins are the column's categories in the order IT settled on (natural, or sorted by label either way — pre_sort or not, its
+        # bin_values are already in that order); alone it is `dense`: every category is a row of the result
+        if b.df.dataset != df.dataset or getattr(b, "row_limit", None) is not None:
+            raise _Decline(f"binner object as key ({kind} of another dataset / with a row limit)")
+        return str(b.expression_original), {"kind": "category", "bin_values": b.bin_values}
     if type(b) is vaex.groupby.Grouper:
         if not hasattr(b, "hashmap_unique") and run_pending and getattr(getattr(b, "_promise", None), "isPending", False):
             # the object's distinct-key pass is scheduled, not run (vaex/groupby.py:298: delay=True; GroupBy.__init__ would run it now, :1021)
@@ -161,19 +230,165 @@ def _binner_object_key(df, b, n_keys, run_pending=True):
             raise _Decline(f"binner object as key ({kind} that has not run its distinct-key pass)")
         if b.df.dataset != df.dataset:
             raise _Decline(f"binner object as key ({kind} of another dataset)")
-        bv = b.bin_values
+        bv, null_at = b.bin_values, None
         if hasattr(bv, "null_count"):   # (an arrow array: the sorted forms come back through pyarrow)
-            if bv.null_count:
-                raise _Decline(f"binner object as key ({kind} with a missing-value group)")
-            bv = vaex.array_types.to_numpy(bv)
-        if np.ma.isMaskedArray(bv) or not isinstance(bv, np.ndarray) or bv.dtype.kind not in "iu" or getattr(b.hashmap_unique, "has_null", False) or getattr(b.hashmap_unique, "has_nan", False):
+            if not (__import__("pyarrow").types.is_integer(bv.type)):
+                raise _Decline(f"binner object as key ({kind} over {bv.type})")
+            split = _split_nullable(bv) if bv.null_count else None
+            bv = vaex.array_types.to_numpy(bv) if split is None else np.ma.array(split.data, mask=split.mask)
+        if not isinstance(bv, np.ndarray) or bv.dtype.kind not in "iu" or getattr(b.hashmap_unique, "has_nan", False):
             raise _Decline(f"binner object as key ({kind} over {getattr(bv, 'dtype', type(bv).__name__)})")
-        return str(b.expression), {"kind": "grouper", "bin_values": bv}
+        if np.ma.isMaskedArray(bv):
+            at = np.flatnonzero(np.ma.getmaskarray(bv))
+            if len(at) > 1:
+                raise _Decline(f"binner object as key ({kind} with several missing-value groups)")
+            null_at = int(at[0]) if len(at) else None
+            bv = np.ma.getdata(bv) if null_at is None else bv
+        if null_at is None and n_keys == 1 and not getattr(b.hashmap_unique, "has_null", False):
+            return str(b.expression), {"kind": "grouper", "bin_values": np.asarray(bv)}   # (the plain road: _finish_arrays)
+        return str(b.expression), {"kind": "bins", "values": np.ma.getdata(bv).astype(np.int64), "null_at": null_at, "bin_values": b.bin_values, "dense": True, "what": kind}
     if type(b) is vaex.groupby.BinnerInteger:
-        if b.dtype.numpy.name not in _TINY_KEYS or getattr(b, "dropmissing", False) or b.df.dataset != df.dataset:
-            raise _Decline(f"binner object as key ({kind})")
-        return str(b.expression), {"kind": "integer", "invert": bool(b.invert)}
+        if b.df.dataset != df.dataset:
+            raise _Decline(f"binner object as key ({kind} of another dataset)")
+        tiny = b.dtype.numpy.name in _TINY_KEYS
+        if tiny and not getattr(b, "dropmissing", False) and n_keys == 1:
+            return str(b.expression), {"kind": "integer", "invert": bool(b.invert)}   # (the plain road; a column with missing values leaves it in _plan)
+        if b.dtype.numpy.kind not in "iu" or (b.invert and b.dtype.numpy.name == "bool"):
+            raise _Decline(f"binner object as key ({kind} over {b.dtype})")
+        values = np.arange(b.min_value, b.min_value + b.N, dtype=np.int64)
+        values = values[::-1] if b.invert else values
+        bv = b.bin_values
+        if len(bv) != len(values) + (0 if b.dropmissing else 1):
+            raise _Decline(f"binner object as key ({kind} whose bins are not min_value .. max_value)")
+        # (BinnerOrdinal counts a row outside min_value .. max_value into the MISSING-VALUE bin — src/binner_ordinal.cpp:70-72, "negative values are
+        #  interpreted as null, as well as out of bound" — which a BinnerInteger keeps unless dropmissing: "outside" tells _coded_key to do the same)
+        return str(b.expression), {"kind": "bins", "values": values, "null_at": None if b.dropmissing else len(values), "bin_values": bv, "dense": bool(b.dense), "what": kind,
+                                   "outside": (int(b.min_value), int(b.min_value) + int(b.N) - 1)}
+    if type(b) is vaex.groupby.BinnerTime:
+        # vaex.BinnerTime(expression, resolution, every) (vaex/groupby.py:63-144): bin = (t in the resolution's units - tmin in those units) // every over
+        # N bins from the column's own minmax; not dense — only bins with a row are rows of the result, labelled with the bin's first instant
+        if b.df.dataset != df.dataset:
+            raise _Decline(f"binner object as key ({kind} of another dataset)")
+        unit, every, t0, count = b.resolution_type, int(b.every), b.tmin, int(b.N)
+        if len(b.bin_values) != count:
+            raise _Decline(f"binner object as key ({kind} whose bins are not tmin .. tmax)")
+
+        def codes_of(t):
+            steps = (t.astype(unit) - t0.astype(unit)).astype(np.int64)
+            steps[np.isnat(t)] = -1
+            return np.floor_divide(steps, every)
+        return str(b.expression), {"kind": "bins", "values": np.arange(count, dtype=np.int64), "null_at": None, "bin_values": b.bin_values, "dense": False, "what": kind, "codes_of": codes_of}
     raise _Decline(f"binner object as key ({kind})")
+
+
+def _materialised(df, name, what):
+    """the whole real column `name` (held as arrow / behind a dataset proxy) as ONE numpy array over the active range — for keys whose codes are
+    made on the host (float keys); frames up to materialise_max_rows rows"""
+    if len(df) > materialise_max_rows or df.length_original() > materialise_max_rows:
+        raise _Decline(f"{what} {name!r} is not one array")
+    try:
+        import vaex.array_types
+        ar = df.evaluate(name, filtered=False, parallel=False)
+        ar = ar if isinstance(ar, np.ndarray) else np.asarray(vaex.array_types.to_numpy(ar))
+    except Exception as e:   # noqa: BLE001
+        raise _Decline(f"{what} {name!r} is not one array ({type(e).__name__})")
+    if np.ma.isMaskedArray(ar) or ar.ndim != 1:
+        raise _Decline(f"{what} {name!r} is not one array")
+    return np.ascontiguousarray(ar if ar.dtype.isnative else ar.astype(ar.dtype.newbyteorder("=")))
+
+
+def _datetime_column(df, name, what):
+    """the numpy datetime64 array behind the real column `name` (active range applied), or _Decline"""
+    ar = df.columns.get(name)
+    if not isinstance(ar, np.ndarray) or np.ma.isMaskedArray(ar) or ar.dtype.kind != "M" or ar.ndim != 1 or not ar.dtype.isnative or len(ar) > materialise_max_rows:
+        raise _Decline(f"{what} {name!r} is not a plain numpy datetime column")
+    i1, i2 = df._index_start, df._index_end
+    return ar[i1:len(ar) if i2 is None else i2]
+
+
+def _category_key(df, name, sort, ascending, bin_values=None):
+    """a categorical key column (df.categorize / ordinal_encode: integer codes min_value .. min_value + N - 1 with N labels; vaex's GrouperCategory,
+    vaex/groupby.py:384-442) -> how the device's groups — the CODES that occur, ascending — become the rows vaex hands back: the labels in
+    natural order or sorted by label (`order[p]` = label index of bin p), codes outside the categories dropped (BinnerOrdinal's overflow bin,
+    extract_center), and — a single key is `dense` — a row for every category, with or without rows"""
+    import pyarrow as pa
+    import vaex.array_types
+    try:
+        labels = df.category_labels(name, aslist=False)
+        count, offset = int(df.category_count(name)), int(df.category_offset(name))
+    except Exception as e:   # noqa: BLE001
+        raise _Decline(f"group key {name!r} is categorical ({type(e).__name__})")
+    labels = pa.array(labels) if isinstance(labels, list) else labels
+    if len(labels) != count:
+        raise _Decline(f"group key {name!r} is categorical (labels and count disagree)")
+    natural = np.arange(count, dtype=np.int64)
+    if bin_values is not None:   # a GrouperCategory OBJECT: which of the three orders did it take?
+        mine = vaex.array_types.to_arrow(bin_values)
+        mine = pa.concat_arrays(mine.chunks) if isinstance(mine, pa.ChunkedArray) else mine
+        ref = vaex.array_types.to_arrow(labels)
+        ref = pa.concat_arrays(ref.chunks) if isinstance(ref, pa.ChunkedArray) else ref
+        for order in (natural, None, False):
+            if order is not natural:
+                order = vaex.array_types.to_numpy(pa.compute.sort_indices(ref, sort_keys=[("x", "ascending" if order is None else "descending")])).astype(np.int64)
+            if mine.equals(ref.take(pa.array(order))):
+                break
+        else:
+            raise _Decline("binner object as key (GrouperCategory whose bins are not the column's categories)")
+        bins = bin_values
+    elif sort:
+        order = vaex.array_types.to_numpy(pa.compute.sort_indices(labels, sort_keys=[("x", "ascending" if ascending else "descending")])).astype(np.int64)
+        bins = pa.compute.take(labels, pa.array(order))
+    else:
+        order, bins = natural, labels
+    rank = np.empty(count, dtype=np.int64)
+    rank[order] = natural
+    return {"kind": "category", "offset": offset, "count": count, "bins": bins, "rank": rank}
+
+
+def _coded_key(name, ar, obj, key_object, sort, ascending):
+    """(int64 codes the device groups, the key's meta for _finish_general) of a key column with missing values (`ar` a _Nullable) and / or under a
+    binner object with enumerated bins (`obj`, kind "bins").  The missing rows' code is one past the largest value of the column and of the bins."""
+    if isinstance(ar, _Nullable):
+        data, mask = ar.data, ar.mask
+    else:
+        data, mask = np.asarray(ar), None
+    source = data.dtype.name
+    if data.dtype.kind == "f":
+        # a float key (vaex's Grouper over ordered_set<double>: one group per value, one for NaN, one for the missing values, vaex/groupby.py:226-330):
+        # the device groups the BIT PATTERNS of the float64 values (+ 0.0 first: -0.0 and 0.0 are one key); every NaN becomes one NaN pattern,
+        # a missing value another — patterns no value has
+        v = data.astype(np.float64) + 0.0
+        codes = v.view(np.int64).copy()
+        nan_code, null_code = 0x7ff8000000000000, 0x7ff8000000000001
+        codes[np.isnan(v)] = nan_code
+        if mask is not None:
+            codes[mask] = null_code
+        return codes, {"kind": "coded", "float": True, "null_code": null_code, "nan_code": nan_code, "source": source, "sort": bool(sort), "ascending": bool(ascending)}
+    if data.dtype.kind not in "biu":
+        raise _Decline(f"group key {name!r} has dtype {data.dtype}")
+    codes = data.astype(np.int64)
+    top = int(codes[~mask].max()) if mask is not None and not mask.all() else (int(codes.max()) if mask is None and len(codes) else 0)
+    if obj is not None and len(obj["values"]):
+        top = max(top, int(obj["values"].max()))
+    if top >= np.iinfo(np.int64).max:
+        raise _Decline(f"group key {name!r}: no code left for the missing values")
+    null_code = top + 1
+    if mask is not None:
+        codes[mask] = null_code
+    if obj is not None and obj.get("outside") is not None:
+        codes[(codes < obj["outside"][0]) | (codes > obj["outside"][1])] = null_code
+    meta = {"kind": "coded", "null_code": null_code, "source": source}
+    if obj is not None:   # enumerated bins, in the object's order
+        in_order = obj["values"].copy()
+        if obj["null_at"] is not None:
+            in_order = in_order if obj["null_at"] < len(in_order) else np.append(in_order, 0)
+            in_order[obj["null_at"]] = null_code
+        meta.update(in_order=in_order, bins=obj["bin_values"], dense=bool(obj["dense"]), what=obj["what"])
+    elif key_object is not None and key_object["kind"] == "integer":   # BinnerInteger over bool / int8 / uint8: ascending or inverted, the missing values last
+        meta.update(sort=True, ascending=not key_object["invert"], tiny=True)
+    else:
+        meta.update(sort=bool(sort), ascending=bool(ascending), tiny=source in _TINY_KEYS)
+    return codes, meta
 
 
 class _RecordingFrame:
@@ -266,11 +481,50 @@ def _translate(df, aggregate, columns, predicates):
         return binned.agg.count(selection=selection)
     if len(expressions) != 1:
         raise _Decline("aggregator over several expressions")
-    name, ar = _real_column(df, expressions[0], _VALUE_KINDS, "aggregated expression")
+    name, ar = _real_column(df, expressions[0], _VALUE_KINDS, "aggregated expression", nullable=True)
+    if isinstance(ar, _Nullable):
+        ar = _nullable_values(name, ar, kind, columns)
     if selection is not None and kind in ("min", "max"):
         raise _Decline("min / max with a selection")   # (a group without a selected row: vaex hands back the dtype's extreme, masked or not by dtype)
     columns[name] = ar   # (var / std of an integer column: the primitives run on astype(float64), as vaex/agg.py:427 does)
     return getattr(binned.agg, kind)(name, selection=selection)
+
+
+class _Columns(dict):
+    """the plan's columns; `int_nullable`: integer value columns with missing values that ride the pass as float64 with NaN (their sums are integers again)"""
+
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        self.int_nullable = set()
+        self.host_made = set()   # columns whose rows were MADE on the host for this call (codes of a key, NaN for missing values): not what the executor's chunks hold
+
+
+def _nullable_values(name, ar, kind, columns):
+    """a value column with missing values (round 6) -> float64 with NaN where a value is missing: count / sum / the moments skip NaN exactly as they skip
+    a missing value (src/agg_count.cpp:56, agg_sum.cpp:113).  An integer column only while every partial sum stays exact in float64 (rows x largest
+    magnitude < 2^53); its sums are handed back as int64.  min / max keep their dtype and mask in vaex: not taken."""
+    if kind in ("min", "max"):
+        raise _Decline(f"min / max of {name!r}, a column with missing values")
+    if name in columns and not isinstance(columns[name], np.ndarray):
+        raise _Decline(f"aggregated expression {name!r} is also a key with missing values")
+    if name in columns:
+        return columns[name]   # (converted for another aggregation of this call)
+    data, mask = ar.data, ar.mask
+    if data.dtype.kind in "iu":
+        live = data[~mask]
+        if len(live) and float(np.abs(live.astype(np.float64)).max()) * len(data) >= 2.0 ** 53:
+            raise _Decline(f"aggregated expression {name!r}: integer column with missing values too large for exact float64 sums")
+        if hasattr(columns, "int_nullable"):
+            columns.int_nullable.add(name)
+        else:
+            raise _Decline(f"aggregated expression {name!r} is an integer column with missing values")
+    elif data.dtype.kind != "f":
+        raise _Decline(f"aggregated expression {name!r} has dtype {data.dtype}")
+    out = data.astype(np.float64)
+    out[mask] = np.nan
+    if hasattr(columns, "host_made"):
+        columns.host_made.add(name)
+    return out
 
 
 def _selection_of(df, aggregate, columns, predicates):
@@ -330,7 +584,7 @@ class _NeedsTask(Exception):
 
 class _Plan:
     """what a df.groupby(by, agg) call needs from the device groupby, decided before a row is read"""
-    __slots__ = ("by", "agg", "sort", "srt", "asc", "columns", "key_names", "actions", "spec", "selection", "rows", "predicates", "streamed", "key_object", "finishers")
+    __slots__ = ("by", "agg", "sort", "srt", "asc", "columns", "key_names", "actions", "spec", "selection", "rows", "predicates", "streamed", "key_object", "finishers", "key_meta", "key_label")
 
 
 def _plan(df, by, agg, sort=False, ascending=True, row_limit=None, for_task=False):
@@ -345,35 +599,69 @@ def _plan(df, by, agg, sort=False, ascending=True, row_limit=None, for_task=Fals
     by_list = [by] if isinstance(by, str) or not isinstance(by, collections.abc.Iterable) else list(by)
     if not 1 <= len(by_list) <= 8:
         raise _Decline(f"{len(by_list)} keys")
-    key_object = None
+    key_object, objects = None, {}
     for i, b in enumerate(by_list):
         if isinstance(b, vaex.groupby.BinnerBase):
-            by_list[i], key_object = _binner_object_key(df, b, len(by_list), run_pending=not for_task)
+            by_list[i], obj = _binner_object_key(df, b, len(by_list), run_pending=not for_task)
+            if obj["kind"] in ("category", "bins"):
+                objects[i] = obj
+            else:
+                key_object = obj
     asc = list(ascending) if isinstance(ascending, (list, tuple)) else [ascending] * len(by_list)
     srt = list(sort) if isinstance(sort, (list, tuple)) else [sort] * len(by_list)
+    if len(asc) != len(by_list) or len(srt) != len(by_list):
+        raise _Decline("sort / ascending lists of another length than the keys")
     if key_object is not None:   # (the object's own order, not the call's: vaex/groupby.py:632-636 passes sort / ascending to the groupers IT makes)
         srt, asc = ([True], [not key_object["invert"]]) if key_object["kind"] == "integer" else ([False], [True])
-    if len(set(zip(srt, asc))) > 1:
-        raise _Decline("keys sorted in different directions")
-    columns, key_names = {}, []
-    for b in by_list:
-        name, ar = _real_column(df, vaex.utils._ensure_string_from_expression(b), _KEY_KINDS, "group key")
-        if name in columns:
+    columns, key_names, key_meta, key_originals, key_label = _Columns(), [], {}, [], {}
+    for i, b in enumerate(by_list):
+        obj = objects.get(i)
+        if obj is not None and "codes_of" in obj:   # (BinnerTime: the bin index of every row, computed once on the host from the datetime column)
+            name = str(vaex.utils._ensure_string_from_expression(b))
+            ar = obj["codes_of"](_datetime_column(df, name, "group key"))
+        else:
+            name, ar = _real_column(df, vaex.utils._ensure_string_from_expression(b), _KEY_KINDS + _FLOAT_KEYS, "group key", nullable=True)
+        if name in columns or name in key_originals:
             raise _Decline("the same key twice")
-        if df.is_category(name) and not (key_object is not None and key_object["kind"] == "grouper"):   # (a Grouper OBJECT groups the codes like any integer column)
-            raise _Decline(f"group key {name!r} is categorical")   # (vaex's GrouperCategory hands back the LABELS, and a group per category: vaex/groupby.py:384-442)
+        if ar.dtype.name in _FLOAT_KEYS and (obj is not None or key_object is not None):
+            raise _Decline(f"group key {name!r} has dtype {ar.dtype} under a binner object")
+        if ar.dtype.name in _FLOAT_KEYS and isinstance(ar, _Streamed):
+            ar = _materialised(df, name, "group key")   # (the codes are made from the whole column: arrow without nulls is a view, a proxied column one evaluate)
+        if ((obj is not None and obj["kind"] == "category") or (obj is None and df.is_category(name))) and not (key_object is not None and key_object["kind"] == "grouper"):   # (a Grouper OBJECT groups the codes like any integer column)
+            # round 6: vaex's GrouperCategory (vaex/groupby.py:384-442; chosen before the dtype is looked at, :587-589) — the device groups the
+            # codes, _finish_general turns them into the labels, in the grouper's order, one row per category when the key stands alone
+            if isinstance(ar, _Nullable):
+                raise _Decline(f"group key {name!r} is categorical with missing codes")
+            key_meta[name] = _category_key(df, name, srt[i], asc[i], bin_values=None if obj is None else obj["bin_values"])
         if key_object is not None and key_object["kind"] == "integer" and ar.dtype.name not in _TINY_KEYS:
             raise _Decline("binner object as key (BinnerInteger)")
-        if ar.dtype.name in _TINY_KEYS and len(by_list) > 1:
+        if ar.dtype.name in _TINY_KEYS and len(by_list) > 1 and name not in key_meta and obj is None:
             raise _Decline(f"{ar.dtype.name} key next to other keys")   # (BinnerInteger's N is the dtype's range, not the distinct keys: vaex's combine decision differs)
+        if isinstance(ar, _Nullable) or (obj is not None and obj["kind"] == "bins") or ar.dtype.name in _FLOAT_KEYS:
+            # round 6: a key with missing values, and / or a binner object whose bins are an enumeration (a Grouper with a missing-value group or
+            # next to other keys, a BinnerInteger over a range): the device groups int64 CODES — the values, the missing rows under a code of their own
+            if key_object is not None and key_object["kind"] == "grouper":
+                raise _Decline("binner object as key (Grouper over a column with missing values that it does not list)")
+            ar, meta = _coded_key(name, ar, obj, key_object, srt[i], asc[i])
+            key_originals.append(name)
+            key_label["__codes_of_" + name] = name   # (the codes live beside the column itself: a filter or an aggregation may read that too)
+            name = "__codes_of_" + name
+            key_meta[name] = meta
+            columns.host_made.add(name)
+            if key_object is not None:   # (a tiny BinnerInteger over a column with missing values: the general road orders and types it)
+                key_object = None
+        else:
+            key_originals.append(name)
         columns[name] = ar
         key_names.append(name)
-    actions = _normalise_actions(df, key_names, agg)
+    if not key_meta and len(set(zip(srt, asc))) > 1:
+        raise _Decline("keys sorted in different directions")   # (_finish_general orders key by key; the plain road reverses the whole result)
+    actions = _normalise_actions(df, key_originals, agg)
     if not actions:
         raise _Decline("no aggregation")
     spec, predicates, finishers = {}, {}, {}
     for out_name, aggregate in actions:
-        if out_name in spec or out_name in finishers or out_name in key_names:
+        if out_name in spec or out_name in finishers or out_name in key_originals:
             raise _Decline("duplicate output column")
         if isinstance(aggregate, _expression_types()):
             # arithmetic over aggregators (vaex.agg.sum('x') / vaex.agg.count(), -vaex.agg.mean('y'), ...: vaex/agg.py:77-189): the leaves are
@@ -388,13 +676,35 @@ def _plan(df, by, agg, sort=False, ascending=True, row_limit=None, for_task=Fals
     if df.filtered and not for_task:
         from . import vaex_filter
         pred = vaex_filter.filter_plan(df)
+        if pred is None and vaex_filter.filter_expression(df) is not None:
+            # (round 6: a filter over byte-swapped numeric columns — the executor's chunk predicates want native columns; this call converts such a
+            #  column once on the host, _real_column — compiled against stand-ins of the native dtype)
+            from . import predicate, vaex_selection
+            known = dict(vaex_selection._known_columns(df))
+            for cname, car in df.columns.items():
+                if cname not in known and isinstance(car, np.ndarray) and not np.ma.isMaskedArray(car) and car.ndim == 1 and not car.dtype.isnative and car.dtype.kind in "iuf":
+                    known[cname] = np.empty(0, dtype=car.dtype.newbyteorder("="))
+            try:
+                pred = predicate.compile_selection(vaex_filter.filter_expression(df), known, virtual=vaex_selection._virtual_columns(df))
+            except predicate.Unsupported:
+                pred = None
         if pred is None:
             raise _Decline("filtered DataFrame (filter outside the device predicate subset)")
         selection = vaex_filter.filter_expression(df)
         predicates[selection] = pred
         for c in pred.columns:
             if c not in columns:
-                columns[c] = _real_column(df, c, tuple(k for k in vaex_filter._NUMERIC if k != "bool"), "filter column")[1]
+                columns[c] = _real_column(df, c, tuple(k for k in vaex_filter._NUMERIC if k != "bool"), "filter column", nullable=True)[1]
+            if not isinstance(columns[c], (np.ndarray, _Streamed)):
+                raise _Decline(f"filter column {c!r} has missing values")
+    if columns.host_made:
+        # (a column made on the host is not what the executor would evaluate chunk by chunk: such a call is eager over whole arrays — its other
+        #  columns held in arrow / behind a proxy are evaluated once — and not a task of a delayed pass)
+        if for_task:
+            raise _Decline("delayed groupby over a key or value column made on the host (missing values, float keys, binner objects)")
+        for cname in list(columns):
+            if isinstance(columns[cname], _Streamed):
+                columns[cname] = _materialised(df, cname, "column")
     plan = _Plan()
     plan.by, plan.agg, plan.sort, plan.srt, plan.asc = by, agg, sort, srt, asc
     plan.columns, plan.key_names, plan.actions, plan.spec, plan.selection = columns, key_names, actions, spec, selection
@@ -403,6 +713,14 @@ def _plan(df, by, agg, sort=False, ascending=True, row_limit=None, for_task=Fals
     plan.streamed = any(isinstance(c, _Streamed) for c in columns.values())
     plan.key_object = key_object
     plan.finishers = finishers
+    plan.key_meta = key_meta
+    plan.key_label = key_label
+    if key_meta and len(key_names) == 1:   # a dense key: a bin without a row is a row of the result — count 0, sum 0, mean / var / std NaN; min / max: vaex's own
+        m0 = key_meta[key_names[0]]
+        for d in spec.values():
+            if d.name in ("min", "max") and (m0["kind"] == "category" or m0.get("dense", False)):
+                raise _Decline("min / max over a dense enumerated key")
+
     return plan
 
 
@@ -440,6 +758,14 @@ def _frame_from(df, plan, finished):
 def _finish_arrays(df, plan, frame, res):
     """the result columns typed and ordered the way GroupBy.agg hands them back, as plain arrays"""
     key_names, columns, actions = plan.key_names, plan.columns, plan.actions
+    if getattr(columns, "int_nullable", None):
+        # (an integer column with missing values rode the pass as float64 with NaN, _nullable_values: its sums are integers again)
+        res = dict(res)
+        for name, d in plan.spec.items():
+            if d.name == "sum" and d.column in columns.int_nullable:
+                res[name] = np.rint(np.asarray(res[name])).astype(np.int64)
+    if plan.key_meta:
+        return _finish_general(df, plan, frame, res)
     descending = bool(plan.srt[0]) and not plan.asc[0]
     out = {}
     typed = {name: _key_column_like_vaex(np.asarray(res[name]), columns[name].dtype.name) for name in key_names}
@@ -473,6 +799,121 @@ def _finish_arrays(df, plan, frame, res):
     ran = sorted({frame.sa.last_kernel(t) for t in getattr(frame, "last_slots", [0])} - {""}) if hasattr(frame.sa, "last_kernel") else []
     kernel = "gb_scatter+gb_reduce" if fused else "+".join(ran)
     last.update(path="device", kernel=kernel, info=frame.last_groupby_info, groups=len(next(iter(out.values()))))
+    return {"arrays": out, "combined": bool(combined)}
+
+
+def _finish_general(df, plan, frame, res):
+    """_finish_arrays where a key is not handed back as the integers the device grouped (round 6: categorical keys, keys with missing values,
+    binner objects with enumerated bins).  The device's groups — one row per combination of key CODES that occurs — are filtered (codes outside
+    a key's bins: BinnerOrdinal's overflow bin, vaex/groupby.py extract_center), ordered key by key (first key slowest, each in ITS grouper's bin
+    order: vaex's grid order, vaex/groupby.py:941-948; missing values last, as arrow sorts them), a single dense key gets a row for every bin
+    (count 0, sum 0, mean / var / std NaN: what vaex's finishers make of an empty cell), and the keys are decoded (labels, masked arrays)."""
+    import pyarrow as pa
+    key_names, columns, actions, metas = plan.key_names, plan.columns, plan.actions, plan.key_meta
+    codes = {name: np.asarray(res[name]).astype(np.int64) for name in key_names}
+    n = len(codes[key_names[0]])
+    keep = np.ones(n, dtype=bool)
+    at = {}
+    for name in key_names:
+        m, c = metas.get(name), codes[name]
+        if m is None:
+            continue
+        if m["kind"] == "category":
+            keep &= (c >= m["offset"]) & (c < m["offset"] + m["count"])
+        elif "in_order" in m:
+            o = np.argsort(m["in_order"], kind="stable")
+            sc = m["in_order"][o]
+            pos = np.minimum(np.searchsorted(sc, c), max(len(sc) - 1, 0))
+            found = (sc[pos] == c) if len(sc) else np.zeros(n, dtype=bool)
+            keep &= found
+            at[name] = o[pos] if len(sc) else np.zeros(n, dtype=np.int64)
+    ranks, cells, sizes = [], 1, []
+    for i, name in enumerate(key_names):
+        m = metas.get(name)
+        c = codes[name][keep]
+        if m is not None and m["kind"] == "category":
+            ranks.append(m["rank"][c - m["offset"]])
+            sizes.append(m["count"])
+        elif m is not None and "in_order" in m:
+            ranks.append(at[name][keep])
+            sizes.append(len(m["in_order"]))
+        else:
+            down = (m["sort"] and not m["ascending"]) if m is not None else (plan.srt[i] and not plan.asc[i])
+            if m is not None and m.get("float"):   # by value; NaN behind the numbers, the missing values last (arrow's order either way)
+                v = c.view(np.float64).copy()
+                cls = np.where(c == m["null_code"], 2, np.where(c == m["nan_code"], 1, 0))
+                v[cls > 0] = 0.0
+                ranks.append(cls)
+                ranks.append(-v if down else v)
+            else:
+                r = -c if down else c.copy()
+                if m is not None:
+                    cls = (c == m["null_code"]).astype(np.int64)
+                    r[cls > 0] = 0
+                    ranks.append(cls)
+                ranks.append(r)
+            sizes.append(len(np.unique(c)))
+        cells *= max(1, sizes[-1])
+    order = np.lexsort(ranks[::-1]) if n else np.arange(0)
+    rank_of = {}   # (key index -> its position among `ranks`: enumerated keys contribute one array)
+    j = 0
+    for i, name in enumerate(key_names):
+        m = metas.get(name)
+        enumerated = m is not None and (m["kind"] == "category" or "in_order" in m)
+        rank_of[i] = j
+        j += 1 if (enumerated or m is None) else 2
+    pick = np.flatnonzero(keep)[order]
+    m0 = metas.get(key_names[0])
+    dense = len(key_names) == 1 and m0 is not None and (m0["kind"] == "category" or m0.get("dense", False))
+    combined = len(key_names) >= 2 and plan.rows / cells < 10
+    values = {}
+    for name, d in plan.spec.items():
+        col = np.asarray(res[name])[pick]
+        if dense:
+            if d.name == "count":
+                full = np.zeros(sizes[0], dtype=col.dtype if len(col) else np.int64)
+            elif d.name == "sum":
+                full = np.zeros(sizes[0], dtype=col.dtype if len(col) else np.float64)
+            else:
+                full = np.full(sizes[0], np.nan, dtype=np.float64)
+            full[ranks[rank_of[0]][order]] = col
+            col = full
+        values[name] = col
+    out = {}
+    for i, name in enumerate(key_names):
+        m = metas.get(name)
+        if m is not None and (m["kind"] == "category" or "in_order" in m):
+            bins = m["bins"]
+            if dense:
+                k = bins
+            else:
+                idx = ranks[rank_of[i]][order]
+                k = bins.take(pa.array(idx)) if hasattr(bins, "null_count") else (bins[idx] if isinstance(bins, np.ndarray) else np.asarray(bins)[idx])
+        elif m is not None and m.get("float"):
+            c = codes[name][pick]
+            k = c.view(np.float64).astype(m["source"])
+            if (c == m["null_code"]).any():
+                k = np.ma.array(k, mask=c == m["null_code"], shrink=False)
+        elif m is not None:
+            c = codes[name][pick]
+            real = c != m["null_code"]
+            typed = _key_column_like_vaex(c[real], m["source"])
+            if real.all():
+                k = np.ma.getdata(typed) if combined else typed
+            else:
+                data = np.zeros(len(c), dtype=np.ma.getdata(typed).dtype)
+                data[real] = np.ma.getdata(typed)
+                k = np.ma.array(data, mask=~real, shrink=False)
+        else:
+            k = _key_column_like_vaex(codes[name][pick], columns[name].dtype.name)
+            k = np.ma.getdata(k) if combined else k
+        out[df[plan.key_label.get(name, name)]._label] = k
+    for out_name, _ in actions:
+        out[out_name] = _finish_tree(plan.finishers[out_name], values) if out_name in plan.finishers else values[out_name]
+    last.clear()
+    fused = frame.last_groupby_info and not frame.last_groupby_info.get("dense")
+    ran = sorted({frame.sa.last_kernel(t) for t in getattr(frame, "last_slots", [0])} - {""}) if hasattr(frame.sa, "last_kernel") else []
+    last.update(path="device", kernel="gb_scatter+gb_reduce" if fused else "+".join(ran), info=frame.last_groupby_info, groups=len(next(iter(out.values()))))
     return {"arrays": out, "combined": bool(combined)}
 
 
@@ -622,9 +1063,17 @@ def _collector_for(plan, capacity):
     return DeviceCollector(plan, capacity)
 
 
-def _block_as_numpy(block):
+def _block_as_numpy(block, offset=0):
     """a chunk as the executor hands it over -> a plain numpy array; missing values are outside the device groupby (RuntimeError: the task
-    then leaves the pass to the others and vaex's own groupby answers afterwards)"""
+    then leaves the pass to the others and vaex's own groupby answers afterwards).  A dictionary-encoded chunk (a categorical key of a
+    _future() frame or an arrow dictionary column: vaex/dataframe.py:5835-5854) becomes its codes: the indices + the category offset."""
+    if hasattr(block, "null_count") and hasattr(block, "type"):
+        import pyarrow as pa
+        if pa.types.is_dictionary(block.type):
+            if block.null_count:
+                raise RuntimeError("delayed groupby: a chunk with missing values")
+            block = pa.concat_arrays([c.indices for c in block.chunks]) if isinstance(block, pa.ChunkedArray) else block.indices
+            return np.asarray(block.to_numpy(zero_copy_only=False)) + offset if offset else np.asarray(block.to_numpy(zero_copy_only=False))
     if isinstance(block, np.ndarray):
         if np.ma.isMaskedArray(block):
             if np.ma.getmaskarray(block).any():
@@ -720,7 +1169,11 @@ def install(vaex_module, state):
                 call = [list(plan.key_names), [[name, d.name, d.column, None if d.selection is None else str(d.selection)] for name, d in plan.spec.items()],
                         None if plan.selection is None else str(plan.selection), [bool(x) for x in plan.srt], [bool(x) for x in plan.asc],
                         None if plan.key_object is None else [plan.key_object["kind"], vaex.cache.fingerprint(plan.key_object.get("bin_values"))],
-                        [[name, repr(a)] for name, a in plan.actions if name in plan.finishers]]
+                        [[name, repr(a)] for name, a in plan.actions if name in plan.finishers],
+                        # (round 6: how every key's codes were made and are decoded — two BinnerTime objects over one column differ only here)
+                        [[name, m.get("kind"), m.get("what"), m.get("sort"), m.get("ascending"), m.get("dense"), m.get("null_code"),
+                          vaex.cache.fingerprint(np.asarray(m["in_order"]).tolist() if "in_order" in m else None), vaex.cache.fingerprint(np.asarray(m["rank"]).tolist() if "rank" in m else None),
+                          str(m.get("bins"))] for name, m in plan.key_meta.items()]]
                 df_fp = self.df.fingerprint(dependencies=self.dependencies())
                 self._fingerprint = f"task-{self.name}-{vaex.cache.fingerprint(call)}-{df_fp}"
             return self._fingerprint
@@ -758,7 +1211,8 @@ def install(vaex_module, state):
             if self.failed is not None:
                 return
             try:
-                self.collector.append({name: _block_as_numpy(b) for name, b in zip(self.plan.columns, blocks)})
+                metas = self.plan.key_meta
+                self.collector.append({name: _block_as_numpy(b, metas[name].get("offset", 0) if name in metas else 0) for name, b in zip(self.plan.columns, blocks)})
             except Exception as e:
                 # (HBM exhausted, a HIP error, a chunk the plan did not expect — a TypeError / ValueError from its conversion included: the
                 #  pass goes on for the caller's other tasks; this task is answered by vaex's own groupby when the pass is over.  An exception
