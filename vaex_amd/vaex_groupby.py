@@ -355,9 +355,9 @@ def _coded_key(name, ar, obj, key_object, sort, ascending):
     source = data.dtype.name
     if data.dtype.kind == "f":
         # a float key (vaex's Grouper over ordered_set<double>: one group per value, one for NaN, one for the missing values, vaex/groupby.py:226-330):
-        # the device groups the BIT PATTERNS of the float64 values (+ 0.0 first: -0.0 and 0.0 are one key); every NaN becomes one NaN pattern,
-        # a missing value another — patterns no value has
-        v = data.astype(np.float64) + 0.0
+        # the device groups the BIT PATTERNS of the float64 values (-0.0 and 0.0 are two keys, as in the reference's hash map: src/hash_primitives.hpp
+        # compares what it hashes); every NaN becomes one NaN pattern, a missing value another — patterns no value has
+        v = data.astype(np.float64)
         codes = v.view(np.int64).copy()
         nan_code, null_code = 0x7ff8000000000000, 0x7ff8000000000001
         codes[np.isnan(v)] = nan_code
@@ -451,7 +451,10 @@ def _translate_tree(df, aggregate, columns, predicates, spec):
     if isinstance(aggregate, vaex.agg.AggregatorExpressionBinaryScalar):
         return ("op", aggregate.finish, _translate_tree(df, aggregate.agg, columns, predicates, spec))
     name = f"__leaf_{len(spec)}"
-    spec[name] = _translate(df, aggregate, columns, predicates)
+    leaf = _translate(df, aggregate, columns, predicates)
+    if isinstance(leaf, dict):
+        raise _Decline("nunique inside an aggregator expression")
+    spec[name] = leaf
     return ("leaf", name)
 
 
@@ -466,6 +469,24 @@ def _translate(df, aggregate, columns, predicates):
     """vaex aggregator descriptor -> binned.agg descriptor; the value column is entered into `columns`, the compiled selection into `predicates`"""
     import vaex.agg
     selection = _selection_of(df, aggregate, columns, predicates)
+    if isinstance(aggregate, vaex.agg.AggregatorDescriptorBasic) and aggregate.name == "AggNUnique" and selection is None and len(aggregate.expressions) == 1 and isinstance(columns, _Columns):
+        # round 6: nunique(x) per group = the number of distinct (keys, x) combinations per group — a second device groupby over the keys and x
+        # (_nunique_pass); integer / bool x, missing values a value of their own unless dropmissing (src/agg_nunique.cpp)
+        name, ar = _real_column(df, aggregate.expressions[0], _KEY_KINDS, "nunique expression", nullable=True)
+        nu = {"nunique": True, "dropmissing": bool(aggregate.dropmissing), "null_code": None}
+        if isinstance(ar, _Nullable):
+            if aggregate.dropmissing:
+                raise _Decline("nunique(dropmissing=True) of a column with missing values")   # (the reference's own answer there is not a count: INTEGRATION.md "Differences")
+            alias = "__codes_of_" + name
+            if alias not in columns:
+                columns[alias], meta = _coded_key(name, ar, None, None, False, True)
+                columns.host_made.add(alias)
+                columns.null_codes[alias] = meta["null_code"]
+            nu.update(column=alias, null_code=columns.null_codes.get(alias))
+        else:
+            columns.setdefault(name, ar)
+            nu.update(column=name)
+        return nu
     if isinstance(aggregate, vaex.agg.AggregatorDescriptorBasic):
         kind = _AGG_NAMES.get(aggregate.name)
         if kind is None or aggregate.agg_args:
@@ -496,6 +517,7 @@ class _Columns(dict):
     def __init__(self, *a, **kw):
         super().__init__(*a, **kw)
         self.int_nullable = set()
+        self.null_codes = {}     # coded column -> the code of its missing values
         self.host_made = set()   # columns whose rows were MADE on the host for this call (codes of a key, NaN for missing values): not what the executor's chunks hold
 
 
@@ -584,7 +606,7 @@ class _NeedsTask(Exception):
 
 class _Plan:
     """what a df.groupby(by, agg) call needs from the device groupby, decided before a row is read"""
-    __slots__ = ("by", "agg", "sort", "srt", "asc", "columns", "key_names", "actions", "spec", "selection", "rows", "predicates", "streamed", "key_object", "finishers", "key_meta", "key_label")
+    __slots__ = ("by", "agg", "sort", "srt", "asc", "columns", "key_names", "actions", "spec", "selection", "rows", "predicates", "streamed", "key_object", "finishers", "key_meta", "key_label", "nunique")
 
 
 def _plan(df, by, agg, sort=False, ascending=True, row_limit=None, for_task=False):
@@ -659,16 +681,22 @@ def _plan(df, by, agg, sort=False, ascending=True, row_limit=None, for_task=Fals
     actions = _normalise_actions(df, key_originals, agg)
     if not actions:
         raise _Decline("no aggregation")
-    spec, predicates, finishers = {}, {}, {}
+    spec, predicates, finishers, nunique = {}, {}, {}, {}
     for out_name, aggregate in actions:
-        if out_name in spec or out_name in finishers or out_name in key_originals:
+        if out_name in spec or out_name in finishers or out_name in key_originals or out_name in nunique:
             raise _Decline("duplicate output column")
         if isinstance(aggregate, _expression_types()):
             # arithmetic over aggregators (vaex.agg.sum('x') / vaex.agg.count(), -vaex.agg.mean('y'), ...: vaex/agg.py:77-189): the leaves are
             # aggregations of the same pass under hidden names, the operators run over their per-group columns when the groups exist
             finishers[out_name] = _translate_tree(df, aggregate, columns, predicates, spec)
         else:
-            spec[out_name] = _translate(df, aggregate, columns, predicates)
+            one = _translate(df, aggregate, columns, predicates)
+            if isinstance(one, dict):
+                if one["column"] in key_names:
+                    raise _Decline("nunique of a key")
+                nunique[out_name] = one
+            else:
+                spec[out_name] = one
     # a filtered frame (df[df.x > 0].groupby(...)): vaex compacts every chunk of every column with numpy before its two passes see a row
     # (vaex/execution.py:515-523); here the filter is a device predicate in every aggregator's keep-mask (vaex_amd/vaex_filter.py) and
     # groups without a row inside it are dropped — when it is in the predicate subset over real numeric columns; else vaex's own code
@@ -715,6 +743,7 @@ def _plan(df, by, agg, sort=False, ascending=True, row_limit=None, for_task=Fals
     plan.finishers = finishers
     plan.key_meta = key_meta
     plan.key_label = key_label
+    plan.nunique = nunique
     if key_meta and len(key_names) == 1:   # a dense key: a bin without a row is a row of the result — count 0, sum 0, mean / var / std NaN; min / max: vaex's own
         m0 = key_meta[key_names[0]]
         for d in spec.values():
@@ -730,7 +759,15 @@ def _run(plan, frame):
     try:
         frame.last_groupby_info = None
         frame._predicates.update(plan.predicates)   # (compiled against the DataFrame: virtual columns are inlined there)
-        return frame.groupby(key_names if len(key_names) > 1 else key_names[0], plan.spec, selection=plan.selection)
+        spec = dict(plan.spec) if plan.spec or not plan.nunique else {"__rows__": binned.agg.count()}
+        res = frame.groupby(key_names if len(key_names) > 1 else key_names[0], spec, selection=plan.selection)
+        if plan.nunique:
+            info = frame.last_groupby_info
+            res = dict(res)
+            for out_name, nu in plan.nunique.items():
+                res[out_name] = _nunique_pass(plan, frame, res, nu)
+            frame.last_groupby_info = dict(info or {}, nunique_passes=len(plan.nunique))
+        return res
     except (NotImplementedError, ValueError) as e:
         raise _Decline(str(e))
     except (RuntimeError, MemoryError) as e:
@@ -738,6 +775,35 @@ def _run(plan, frame):
         # passes answer — chunk by chunk, on the HIP classes where those still work — instead of the call dying here
         drop_device_copies()
         raise _Decline(f"device groupby failed: {type(e).__name__}: {str(e)[:200]}")
+
+
+def _nunique_pass(plan, frame, res, nu):
+    """nunique(x) per group of `res` (the main pass's groups, ascending by the keys): ONE more device groupby over (keys..., x) — its groups are the
+    distinct combinations — and a run-length count per key combination on the host (as many entries as there are distinct combinations)"""
+    key_names = plan.key_names
+    pairs = frame.groupby(list(key_names) + [nu["column"]], {"__pairs__": binned.agg.count()}, selection=plan.selection)
+    x = np.asarray(pairs[nu["column"]]).astype(np.int64)
+    keys = [np.asarray(pairs[k]).astype(np.int64) for k in key_names]
+    if nu["dropmissing"] and nu["null_code"] is not None:
+        live = x != nu["null_code"]
+        keys = [k[live] for k in keys]
+    stacked = np.stack(keys, axis=1) if len(keys[0]) else np.zeros((0, len(keys)), dtype=np.int64)
+    main = np.stack([np.asarray(res[k]).astype(np.int64) for k in key_names], axis=1)
+    out = np.zeros(len(main), dtype=np.int64)
+    if len(stacked):
+        start = np.ones(len(stacked), dtype=bool)
+        start[1:] = np.any(stacked[1:] != stacked[:-1], axis=1)
+        at = np.flatnonzero(start)
+        counts = np.diff(np.append(at, len(stacked)))
+        both, inverse = np.unique(np.concatenate([main, stacked[at]]), axis=0, return_inverse=True)
+        inverse = inverse.reshape(-1)
+        where = np.full(len(both), -1, dtype=np.int64)
+        where[inverse[:len(main)]] = np.arange(len(main))
+        pos = where[inverse[len(main):]]
+        if (pos < 0).any():
+            raise _Decline("nunique: the pair pass found a group the main pass did not")
+        out[pos] = counts
+    return out
 
 
 def _finish(df, plan, frame, res):
@@ -845,6 +911,7 @@ def _finish_general(df, plan, frame, res):
                 v[cls > 0] = 0.0
                 ranks.append(cls)
                 ranks.append(-v if down else v)
+                ranks.append(c)   # (-0.0 and 0.0 compare equal: the bit pattern settles their order)
             else:
                 r = -c if down else c.copy()
                 if m is not None:
@@ -861,13 +928,13 @@ def _finish_general(df, plan, frame, res):
         m = metas.get(name)
         enumerated = m is not None and (m["kind"] == "category" or "in_order" in m)
         rank_of[i] = j
-        j += 1 if (enumerated or m is None) else 2
+        j += 1 if (enumerated or m is None) else (3 if m.get("float") else 2)
     pick = np.flatnonzero(keep)[order]
     m0 = metas.get(key_names[0])
     dense = len(key_names) == 1 and m0 is not None and (m0["kind"] == "category" or m0.get("dense", False))
     combined = len(key_names) >= 2 and plan.rows / cells < 10
     values = {}
-    for name, d in plan.spec.items():
+    for name, d in list(plan.spec.items()) + [(name, binned.agg.count()) for name in plan.nunique]:
         col = np.asarray(res[name])[pick]
         if dense:
             if d.name == "count":
@@ -1099,11 +1166,28 @@ def _could_be_served(df, by, row_limit):
         if vaex_filter.filter_plan(df) is None:
             return False
     by_list = [by] if isinstance(by, str) or not isinstance(by, collections.abc.Iterable) else list(by)
-    if not 1 <= len(by_list) <= 8 or any(isinstance(b, vaex.groupby.BinnerBase) for b in by_list):
+    if not 1 <= len(by_list) <= 8:
         return False
     try:
         for b in by_list:
-            _real_column(df, vaex.utils._ensure_string_from_expression(b), _KEY_KINDS, "group key", materialise=False)   # (a cheap look: nothing is evaluated here)
+            if isinstance(b, vaex.groupby.BinnerBase):   # (round 6: the object kinds _binner_object_key takes; the plan looks closer when the aggregation is known)
+                if type(b) not in (vaex.groupby.Grouper, vaex.groupby.BinnerInteger, vaex.groupby.GrouperCategory, vaex.groupby.BinnerTime):
+                    return False
+                continue
+            name = str(vaex.utils._ensure_string_from_expression(b))
+            ar = df.columns.get(name)
+            if ar is not None and (np.ma.isMaskedArray(ar) or (hasattr(ar, "null_count") and hasattr(ar, "type"))):
+                # (a column with missing values / an arrow column: split or streamed when the aggregation is known — a cheap look at the type only)
+                import pyarrow as pa
+                if np.ma.isMaskedArray(ar):
+                    ok = ar.dtype.kind in "biuf"
+                else:
+                    t = ar.type.index_type if pa.types.is_dictionary(ar.type) else ar.type
+                    ok = pa.types.is_integer(t) or pa.types.is_floating(t) or pa.types.is_boolean(t)
+                if not ok:
+                    return False
+                continue
+            _real_column(df, name, _KEY_KINDS + _FLOAT_KEYS, "group key", materialise=False)   # (a cheap look: nothing is evaluated here)
     except (_Decline, Exception):
         return False
     return True
@@ -1169,7 +1253,7 @@ def install(vaex_module, state):
                 call = [list(plan.key_names), [[name, d.name, d.column, None if d.selection is None else str(d.selection)] for name, d in plan.spec.items()],
                         None if plan.selection is None else str(plan.selection), [bool(x) for x in plan.srt], [bool(x) for x in plan.asc],
                         None if plan.key_object is None else [plan.key_object["kind"], vaex.cache.fingerprint(plan.key_object.get("bin_values"))],
-                        [[name, repr(a)] for name, a in plan.actions if name in plan.finishers],
+                        [[name, repr(a)] for name, a in plan.actions if name in plan.finishers], [[name, nu["column"], nu["dropmissing"]] for name, nu in plan.nunique.items()],
                         # (round 6: how every key's codes were made and are decoded — two BinnerTime objects over one column differ only here)
                         [[name, m.get("kind"), m.get("what"), m.get("sort"), m.get("ascending"), m.get("dense"), m.get("null_code"),
                           vaex.cache.fingerprint(np.asarray(m["in_order"]).tolist() if "in_order" in m else None), vaex.cache.fingerprint(np.asarray(m["rank"]).tolist() if "rank" in m else None),
