@@ -67,9 +67,16 @@ def same(a, b):
         x, y = a[c], b[c]
         assert len(x) == len(y), ("groups", c, len(x), len(y))
         assert np.ma.isMaskedArray(x) == np.ma.isMaskedArray(y), ("masked-ness", c, type(x), type(y))
+        if np.ma.isMaskedArray(x):   # (the same entries are missing; what the arrays hold UNDER the mask is nobody's result)
+            mx, my = np.ma.getmaskarray(x), np.ma.getmaskarray(y)
+            assert np.array_equal(mx, my), ("mask", c, mx[:10], my[:10])
+            x, y = np.ma.getdata(x).copy(), np.ma.getdata(y).copy()
+            x[mx] = 0; y[my] = 0
         x, y = np.ma.getdata(x), np.ma.getdata(y)
         assert x.dtype == y.dtype, ("dtype", c, x.dtype, y.dtype)
-        if x.dtype.kind in "iub":
+        if x.dtype.kind in "OUS":   # (labels of a categorical key)
+            assert x.tolist() == y.tolist(), (c, x[:10], y[:10])
+        elif x.dtype.kind in "iub":
             assert np.array_equal(x, y), (c, x[:10], y[:10])
         else:
             assert np.allclose(x, y, rtol=1e-9, atol=1e-9, equal_nan=True), (c, x[:10], y[:10])
@@ -87,7 +94,9 @@ def key_column(rng, n, kdt, style):
     else: k = rng.choice(np.array([info.min, info.min + 1, 0, info.max - 1, info.max], dtype="u8" if kdt == "u8" else "i8"), n)
     return np.asarray(k).astype(kdt)
 bad, known, paths = [], {}, {}
-for seed in range(ncalls):
+import os
+only = [int(q) for q in os.environ.get("VAEX_AMD_RANDOM_SEEDS", "").split(",") if q]   # (a diagnosis run: these seeds only, both results printed)
+for seed in (only or range(ncalls)):
     rng = np.random.default_rng(seed)
     n = int(rng.choice([1, 2, 3, 10, 100, 5000, 20000]))
     nkeys = int(rng.choice([1, 1, 1, 2, 3])) if gpu else 1
@@ -96,6 +105,19 @@ for seed in range(ncalls):
     if not gpu and styles[0] in ("wide", "extreme") and kinds[0] not in ("i1", "u1", "i2", "u2", "bool"):
         continue      # (scattered keys need the hash aggregation: no stand-in without a GPU)
     data = {f"k{j}": key_column(rng, n, kinds[j], styles[j]) for j in range(nkeys)}
+    # round 6 (late): keys that are not handed back as the integers the device grouped — missing values in a key (a numpy mask), a categorical key
+    # (dense, non-negative codes), a float key with NaN (scattered bit patterns: the device only) — _finish_general
+    special = ["plain"] * nkeys
+    for j in range(nkeys):
+        q = rng.random()
+        if q < 0.15 and n > 1:
+            data[f"k{j}"] = np.ma.array(data[f"k{j}"], mask=rng.random(n) < 0.15); special[j] = "masked"
+        elif q < 0.25 and styles[j] in ("dense", "gappy", "single") and kinds[j] != "bool":
+            special[j] = "categorical"
+        elif q < 0.32 and gpu and nkeys == 1:
+            f = rng.integers(-3, 4, n) * 0.25
+            if rng.random() < 0.5: f[rng.random(n) < 0.1] = np.nan
+            data[f"k{j}"] = f; special[j] = "float"; kinds[j] = "f8"
     v = rng.normal(0, 3, n)
     if rng.random() < 0.5: v[rng.random(n) < 0.2] = np.nan
     vdt = str(rng.choice(["i1", "i2", "i4", "i8", "u1", "u2", "u4"]))
@@ -103,13 +125,25 @@ for seed in range(ncalls):
     #  either side, not a result to compare)
     vi = rng.integers(0, 200, n) if vdt.startswith("u") else rng.integers(-100 if vdt == "i1" else -1000, 100 if vdt == "i1" else 1000, n)
     data.update(v=v, vi=vi.astype(vdt), vf=rng.normal(0, 1, n).astype("f4"))
+    data.update(vm=np.ma.array(rng.normal(1, 2, n), mask=rng.random(n) < 0.2), vim=np.ma.array(rng.integers(-50, 50, n), mask=rng.random(n) < 0.2))   # (values with missing entries)
     df = vaex.from_arrays(**data)
+    for j in range(nkeys):
+        if special[j] == "categorical":
+            if rng.random() < 0.5:
+                df.categorize(f"k{j}", inplace=True)
+            else:   # labels of its own, one more than the codes need (a category without a row)
+                top = int(np.max(data[f"k{j}"])) if n else 0
+                df.categorize(f"k{j}", labels=[f"L{q:03d}" for q in rng.permutation(top + 2)], min_value=0, inplace=True) if int(np.min(data[f"k{j}"])) == 0 else df.categorize(f"k{j}", inplace=True)
     df["virt"] = df.vf * 2 + 1      # (round 6: a virtual column as a value — materialised once by vaex's own evaluate)
     df["alias"] = df.v              # (... and an alias of a real column)
     aggs = {"c": A.count(), "cv": A.count("v"), "s": A.sum("v"), "m": A.mean("v"), "sd": A.std("v"), "va": A.var("vi"), "lo": A.min("v"), "hi": A.max("vi"),
             "si": A.sum("vi"), "mf": A.mean("vf"), "sf": A.sum("vf"), "lof": A.min("vf"), "cs": A.count(selection="v > 0"), "ms": A.mean("vi", selection="vf < 0"),
             # round 6: arithmetic over aggregators, virtual columns
-            "r": A.sum("v") / A.count(), "dd": A.max("vi") - A.min("vi"), "ng": -A.mean("vf"), "x3": 3 * A.sum("vi"), "svt": A.sum("virt"), "mal": A.mean("alias")}
+            "r": A.sum("v") / A.count(), "dd": A.max("vi") - A.min("vi"), "ng": -A.mean("vf"), "x3": 3 * A.sum("vi"), "svt": A.sum("virt"), "mal": A.mean("alias"),
+            # round 6 (late): values with missing entries, nunique (a second device groupby)
+            "svm": A.sum("vm"), "mvm": A.mean("vm"), "cvm": A.count("vm"), "svim": A.sum("vim"), "mvim": A.mean("vim"), "sdvm": A.std("vm")}
+    if gpu:
+        aggs.update(nu=A.nunique("vi"), nuk=A.nunique("vim"))
     pick = [str(p) for p in rng.choice(list(aggs), size=int(rng.integers(1, 5)), replace=False)]
     agg = {p: aggs[p] for p in pick}
     kw = dict(sort=True, ascending=bool(rng.random() < 0.5)) if rng.random() < 0.4 else {}
@@ -121,7 +155,7 @@ for seed in range(ncalls):
     by = keys if nkeys > 1 else keys[0]
     make_by = lambda: by
     # round 6: the key as a binner OBJECT (vaex.groupby.Grouper / BinnerInteger): the order is the object's, not the call's
-    use_object = nkeys == 1 and not delayed and rng.random() < 0.2
+    use_object = nkeys == 1 and not delayed and rng.random() < 0.2 and special[0] in ("plain", "masked")
     if use_object:
         okw = dict(sort=bool(rng.random() < 0.7), ascending=bool(rng.random() < 0.5))
         cls = vaex.groupby.BinnerInteger if kinds[0] in ("i1", "u1", "bool") else vaex.groupby.Grouper
@@ -130,7 +164,7 @@ for seed in range(ncalls):
         if cls is vaex.groupby.BinnerInteger: kwc = dict(sort=True, ascending=not (okw["sort"] and not okw["ascending"]))
     else:
         kwc = kw
-    what = (seed, n, kinds, styles, pick, kw, "filtered" if d.filtered else "", "delayed" if delayed else "", ("object", okw) if use_object else "")
+    what = (seed, n, kinds, styles, special, pick, kw, "filtered" if d.filtered else "", "delayed" if delayed else "", ("object", okw) if use_object else "")
     try:
         want = original(d, make_by(), agg=agg, **kw)
     except Exception as e:
@@ -157,8 +191,23 @@ for seed in range(ncalls):
         continue
     if isinstance(got, Exception):
         bad.append((what, "raises here only", type(got).__name__, str(got)[:300])); continue
-    if len(want) == 0 and len(d) > 0 and len(got) > 0 and vg.last.get("path") == "device":
+    wraps = any(st == "extreme" and kd in ("i2", "i4", "u2", "u4") for st, kd in zip(styles, kinds))
+    if (len(want) == 0 or (wraps and "masked" in special and len(want) < len(got))) and len(d) > 0 and len(got) > 0 and vg.last.get("path") == "device":   # (with a missing-value group the reference keeps that one)
         known["reference: no group at all (key range wraps in the key's dtype)"] = known.get("reference: no group at all (key range wraps in the key's dtype)", 0) + 1
+        continue
+    if nkeys >= 2 and "masked" in special:
+        # several keys, one with missing values: where the reference COMBINES its groupers (rows / cells < 10) the missing rows of a key it simplified to
+        # BinnerInteger(min_value != 0) get the code N - min_value (vaex/groupby.py:203: fillmissing(N), :525 subtracts min_value) — they fall into OTHER
+        # cells, and its answer varies from run to run (1697 / 1699 groups over the same 5000 rows: tools/r07_masked_combined.py).  The device's groups are
+        # checked against the rows themselves instead
+        label = "reference: combined groupers over a key with missing values (not deterministic there)"
+        if vg.last.get("path") == "device":
+            from collections import Counter
+            truth = Counter(zip(*[d[k].to_numpy().tolist() for k in keys]))
+            mine = list(zip(*[got[k].tolist() for k in keys]))
+            if set(mine) != set(truth) or len(mine) != len(truth) or ("c" in pick and dict(zip(mine, got["c"].tolist())) != dict(truth)):
+                bad.append((what, "device groups are not the rows' key combinations", len(mine), len(truth)))
+        known[label] = known.get(label, 0) + 1
         continue
     if "bool" in kinds and kw.get("sort") and not kw.get("ascending") and vg.last.get("path") == "device":
         known["reference: bool key descending, labels not reversed"] = known.get("reference: bool key descending, labels not reversed", 0) + 1
@@ -170,6 +219,10 @@ for seed in range(ncalls):
             same(cols(got, keys), cols(want, keys))
     except AssertionError as e:
         bad.append((what, vg.last.get("path"), vg.last.get("kernel"), str(e)[:300]))
+        if only:
+            print("why", vg.last)
+            for label, t in (("got", got), ("want", want)):
+                print(label, {c: t.sort(keys)[c].tolist()[:40] for c in t.get_column_names()})
 print("calls", ncalls, "| answered by:", paths, "| groupby stats:", {k: vg.stats[k] for k in ("device", "task", "vaex")})
 print("recognised reference defects / alike exceptions:", known)
 for b in bad[:15]:

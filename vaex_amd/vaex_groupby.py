@@ -940,7 +940,9 @@ def _finish_general(df, plan, frame, res):
             if d.name == "count":
                 full = np.zeros(sizes[0], dtype=col.dtype if len(col) else np.int64)
             elif d.name == "sum":
-                full = np.zeros(sizes[0], dtype=col.dtype if len(col) else np.float64)
+                src = columns[d.column].dtype.kind if d.column in columns else "f"   # (no group at all: the sum's type follows the column's, upcast<>: src/agg_sum.cpp:6-62)
+                empty = np.int64 if (src in "ib" or d.column in getattr(columns, "int_nullable", ())) else (np.uint64 if src == "u" else np.float64)
+                full = np.zeros(sizes[0], dtype=col.dtype if len(col) else empty)
             else:
                 full = np.full(sizes[0], np.nan, dtype=np.float64)
             full[ranks[rank_of[0]][order]] = col
