@@ -357,17 +357,19 @@ def _coded_key(name, ar, obj, key_object, sort, ascending):
         # a float key (vaex's Grouper over ordered_set<double>: one group per value, one for NaN, one for the missing values, vaex/groupby.py:226-330):
         # the device groups the BIT PATTERNS of the float64 values (-0.0 and 0.0 are two keys, as in the reference's hash map: src/hash_primitives.hpp
         # compares what it hashes); every NaN becomes one NaN pattern, a missing value another — patterns no value has
-        v = data.astype(np.float64)
-        codes = v.view(np.int64).copy()
+        v = data.astype(np.float64)   # (a copy of the call's own: its bits become the codes in place)
+        codes = v.view(np.int64)
         nan_code, null_code = 0x7ff8000000000000, 0x7ff8000000000001
-        codes[np.isnan(v)] = nan_code
+        nan = np.isnan(v)
+        if nan.any():
+            codes[nan] = nan_code
         if mask is not None:
             codes[mask] = null_code
         return codes, {"kind": "coded", "float": True, "null_code": null_code, "nan_code": nan_code, "source": source, "sort": bool(sort), "ascending": bool(ascending)}
     if data.dtype.kind not in "biu":
         raise _Decline(f"group key {name!r} has dtype {data.dtype}")
     codes = data.astype(np.int64)
-    top = int(codes[~mask].max()) if mask is not None and not mask.all() else (int(codes.max()) if mask is None and len(codes) else 0)
+    top = int(np.max(codes, where=~mask, initial=np.iinfo(np.int64).min)) if mask is not None and not mask.all() else (int(codes.max()) if mask is None and len(codes) else 0)
     if obj is not None and len(obj["values"]):
         top = max(top, int(obj["values"].max()))
     if top >= np.iinfo(np.int64).max:
