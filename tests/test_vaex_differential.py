@@ -175,6 +175,24 @@ for name in calls:
     exc = [x for x in a if isinstance(x, tuple)]
     assert not exc, (name, first[name], second[name])   # (every call of this list works on the reference)
     print("ok", name, "tasks on hip / on vaex's C++:", where.get(name))
+if bad and gpu:
+    # which side moved?  Every differing call once more on both sides (round 6: the reference's own answer over the masked column is now and then
+    # another one on its first run — its per-thread grids race, profiles/r06_reference_moved.txt).  A call whose two HIP runs agree with each
+    # other and with the reference's second run is counted, not failed.
+    def same(u, w, name):
+        return len(u) == len(w) and all((not isinstance(p, tuple)) and (not isinstance(q, tuple)) and p.shape == q.shape and close(p, q, name, j) for j, (p, q) in enumerate(zip(u, w)))
+    names = sorted({b[0] for b in bad})
+    df3 = make()
+    again_ref = {name: flat(calls[name](df3)) for name in names}
+    vaex_amd.install()
+    again_hip = {name: flat(calls[name](df3)) for name in names}
+    vaex_amd.uninstall()
+    for name in names:
+        hip_stable, ref_stable, agree_now = same(flat(first[name]), again_hip[name], name), same(flat(second[name]), again_ref[name], name), same(again_hip[name], again_ref[name], name)
+        print("AGAIN", name, "| first HIP run == HIP again:", hip_stable, "| reference == reference again:", ref_stable, "| HIP again == reference again:", agree_now)
+        if hip_stable and agree_now and not ref_stable:
+            bad = [b for b in bad if b[0] != name]
+            print("the reference's own answer moved between two runs (the HIP answer did not):", name)
 assert not bad, bad
 if gpu:
     print("task parts built on the HIP classes:", vaex_amd.task_stats["hip"], " on vaex's C++:", vaex_amd.task_stats["cpu"], vaex_amd.task_stats["cpu_reasons"])

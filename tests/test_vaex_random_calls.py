@@ -225,6 +225,28 @@ for i in range(ncalls):
         if not ok:
             with np.errstate(invalid="ignore"):
                 bad.append((i, c, "values", float(np.nanmax(np.abs(p - q)))))
+if bad and gpu:
+    # which side moved?  Every differing call once more on both sides, alone (round 6: one intermittent difference per ~3 full-suite runs — a variance of
+    # the masked column with a selection on a filtered frame — that no repeat of the call alone reproduces: tools/r07_var_masked_stress.py)
+    fr2 = frames(make())
+    again_ref = {b[0]: flat(call(fr2[draw(b[0])["frame"]], draw(b[0]))) for b in bad if not draw(b[0])["delayed"]}
+    vaex_amd.install()
+    again_hip = {i: flat(call(fr2[draw(i)["frame"]], draw(i))) for i in again_ref}
+    vaex_amd.uninstall()
+    moved = 0
+    for i in again_ref:
+        eq = lambda u, w: all(isinstance(p, np.ndarray) and isinstance(q, np.ndarray) and p.shape == q.shape and np.allclose(p, q, rtol=1e-9, atol=1e-12, equal_nan=True) for p, q in zip(u, w))
+        hip_stable, ref_stable, agree_now = eq(flat(first[i]), again_hip[i]), eq(flat(second[i]), again_ref[i]), eq(again_hip[i], again_ref[i])
+        print("AGAIN", i, "| first HIP run == reference:", eq(flat(first[i]), flat(second[i])), "| HIP again == reference again:", agree_now,
+              "| first HIP run == HIP again:", hip_stable, "| reference == reference again:", ref_stable)
+        if hip_stable and agree_now and not ref_stable:
+            # the REFERENCE's first answer was the outlier: its second run, alone, equals both HIP runs.  Caught on the GPU box (profiles/r06_reference_moved.txt:
+            # call 946, a mean of the masked column — the reference's per-thread grids race, INTEGRATION.md "Differences": grid_used is a vector<bool>
+            # written by concurrent threads).  Counted, not compared.
+            moved += 1
+            bad = [b for b in bad if b[0] != i]
+    if moved:
+        print("the reference's own answer moved between two runs (the HIP answer did not):", moved)
 print("calls", ncalls, "of which raised on both sides alike:", excs - known, "| the reference raised on an empty selected chunk, the HIP entry answered:", known, "| different:", len(bad))
 for bline in bad[:12]:
     print("BAD", bline)
