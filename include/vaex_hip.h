@@ -320,6 +320,15 @@ void vxh_device_free(void *p);
  * GrouperCombined evaluates with numpy from its parents' ordinals (vaex/groupby.py:526-584 `_combine`: multipliers are the
  * cumulative products of the parents' group counts).  Integer columns (host or device), result on the device. */
 int vxh_pack_keys(int n_keys, const void *const *columns, const int *dtypes, const int *mems, const int64_t *min_values, const int64_t *multipliers, uint64_t n, int64_t *out_device);
+/* the column a groupby reads INSTEAD of a key with missing values / a float key / a value column with missing entries (round 6):
+ *   VXH_CODE_KEY    out int64:   `null_code` where mask[i] == 1 (numpy's convention), else the value — integers sign- / zero-extended, bool 0 / 1,
+ *                                float kinds: the bit pattern of the value as a double, `nan_code` for every NaN.  What the reference keeps in
+ *                                ordered_set<T>'s null / NaN slots (src/hash_primitives.hpp:455-470, vaex/hash.py:179-190) becomes ordinary keys.
+ *   VXH_CODE_VALUE  out float64: NaN where mask[i] == 1, else (double) value — count / sum / the moments skip NaN exactly as they skip a
+ *                                masked row (src/agg_count.cpp:50-56, agg_sum.cpp:108-115).
+ * data / mask: host or device (mask may be null); flip: byte-swapped elements; out: device, n elements. */
+enum vxh_code_mode { VXH_CODE_KEY = 0, VXH_CODE_VALUE = 1 };
+int vxh_code_column(int mode, int dtype, const void *data, int mem_data, const uint8_t *mask, int mem_mask, int flip, uint64_t n, int64_t null_code, int64_t nan_code, void *out_device);
 /* out[i] = a[i] * b[i] (NaN where either is NaN): the pair columns of the legacy OP_COV statistic (src/vaexfast.cpp:1117-1153) */
 int vxh_product_f64(const double *a, int mem_a, const double *b, int mem_b, uint64_t n, double *out_device);
 /* bytes_used() = sizeof(grid_type) * grids * length1d — src/agg_base.hpp:29 (vaex/agg.py:311-318 checks it) */

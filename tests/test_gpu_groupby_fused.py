@@ -658,3 +658,46 @@ def test_the_librarys_heavy_key_sample_is_numpys(sa, gpu_ready, dtype, n):
         got = np.asarray(sa.sample_heavy_keys(kd, _DT[dtype], m, thr, 128))
         np.testing.assert_array_equal(got, want)
     assert len(np.asarray(sa.sample_heavy_keys(kd, _DT[dtype], m, len(sample) + 1, 128))) == 0
+
+
+@pytest.mark.parametrize("kind", ["f8", "f4", "i8", "i4", "i2", "i1", "u4", "u2", "u1", "bool"])
+def test_code_column_makes_key_codes_and_nan_filled_values(sa, gpu_ready, kind):
+    """round 6 (late): vxh_code_column — the int64 codes of a group key with missing values / of a float key (the missing rows under `null_code`, every NaN
+    under `nan_code`, float values as the bit patterns of their doubles) and a value column as float64 with NaN where an entry is missing; host and device inputs"""
+    import torch
+    from vaex_amd.binned import _DT_CODE
+    rng = np.random.default_rng(5)
+    n = 100_003
+    if kind == "bool":
+        data = rng.random(n) < 0.4
+    elif kind.startswith("f"):
+        data = (rng.integers(-40, 40, n) * 0.25).astype(kind)
+        data[::17] = np.nan
+        data[1::17] = -0.0
+    else:
+        info = np.iinfo(kind)
+        data = rng.integers(info.min, info.max, n, dtype="i8" if kind != "u8" else "u8", endpoint=True).astype(kind)
+    mask = rng.random(n) < 0.2
+    dt = _DT_CODE[np.dtype(kind).name]
+    null_code, nan_code = (1 << 62) + 12345, 0x7ff8000000000000
+    want = data.astype("f8").view("i8").copy() if kind.startswith("f") else data.astype("i8")
+    if kind.startswith("f"):
+        want[np.isnan(data)] = nan_code
+    want[mask] = null_code
+    wantv = data.astype("f8")
+    wantv[mask] = np.nan
+    for where in ("host", "device"):
+        d = data.view("u1") if kind == "bool" else data
+        m = mask.view("u1")
+        if where == "device":
+            d, m = torch.from_numpy(np.ascontiguousarray(d)).cuda(), torch.from_numpy(np.ascontiguousarray(m)).cuda()
+        got = torch.as_tensor(sa.code_column(d, m, dt if kind != "bool" else _DT_CODE["uint8"], 0, null_code, nan_code), device="cuda").cpu().numpy()
+        np.testing.assert_array_equal(got, want)
+        gotv = torch.as_tensor(sa.code_column(d, m, dt if kind != "bool" else _DT_CODE["uint8"], 1), device="cuda").cpu().numpy()
+        np.testing.assert_array_equal(gotv.view("i8")[~np.isnan(wantv)], wantv.view("i8")[~np.isnan(wantv)])
+        assert np.array_equal(np.isnan(gotv), np.isnan(wantv))
+        nomask = torch.as_tensor(sa.code_column(d, None, dt if kind != "bool" else _DT_CODE["uint8"], 0, null_code, nan_code), device="cuda").cpu().numpy()
+        unmasked = data.astype("f8").view("i8").copy() if kind.startswith("f") else data.astype("i8")
+        if kind.startswith("f"):
+            unmasked[np.isnan(data)] = nan_code
+        np.testing.assert_array_equal(nomask, unmasked)

@@ -265,6 +265,21 @@ assert vg.last.get("path") == "vaex", vg.last
 check(d2, ["c", "k"], {"u": A.nunique("g8")}, nkeys=2, device=bool(gpu), sort=True)
 check(d2[d2.x > 3.5], "k", A.nunique("gm"), device=bool(gpu), sort=True)
 print("ok-general packed and float keys")
+if gpu:
+    # the same calls with the columns MADE ON THE DEVICE (vxh_code_column behind the uploads: what frames of device_coding_min_rows rows and more take)
+    vg.device_coding_min_rows, before = 1000, vg.stats.get("coded_on_device", 0)
+    for key in ("gm", "g8", "gb", "ga"):
+        check(d2, key, aggs, sort=True)
+        check(d2[d2.x > 2.5], key, {"n": A.count()}, sort=True, ascending=False) if key != "gb" else None
+    check(d2, "k", {"n": A.count(), "cx": A.count("xm"), "s": A.sum("xm"), "m": A.mean("xm"), "si": A.sum("im"), "mi": A.mean("im"), "ci": A.count("im")}, sort=True)
+    check(d2, "gm", {"s": A.sum("xm"), "si": A.sum("im"), "sd": A.std("xm")}, sort=True)
+    for kw in (dict(sort=True), dict(sort=True, ascending=False)):
+        check(d2, "fk", aggs, ordered=False, **kw)
+    check(d2, "gm", {"u": A.nunique("im"), "n": A.count()}, sort=True)
+    check(d2, ["gm", "k"], aggs, nkeys=2, sort=True)
+    assert vg.stats.get("coded_on_device", 0) >= before + 14 and not vg.stats.get("coded_on_host"), vg.stats
+    vg.device_coding_min_rows = 2_000_000
+    print("ok-general coded on the device", vg.stats.get("coded_on_device", 0) - before)
 # three defects of the reference's own groupby where the device groupby answers what the data says (INTEGRATION.md "Differences"): pinned
 # BOTH ways, so that a change on either side shows
 db = vaex.from_arrays(k=np.array([True, True, True, False]), v=np.arange(4.0))
@@ -527,5 +542,5 @@ def test_groupby_host_logic_against_vaex_on_the_reference_cpp():
 def test_groupby_of_real_vaex_runs_on_the_device_groupby():
     out = _run(1, 900)
     assert "DONE" in out and out.count("ok-device ") == 34 and out.count("ok-device-filtered") == 7 and out.count("ok-declined") == 8 and out.count("ok-task") == 9, out
-    assert out.count("ok-general") == 4 and "declined here" not in out, out   # (round 6, late: categorical / missing-value / float keys, binner objects — all on the device)
+    assert out.count("ok-general") == 5 and "declined here" not in out, out   # (round 6, late: categorical / missing-value / float keys, binner objects — all on the device)
     assert "gb_scatter+gb_reduce" in out and "bin_lds" in out and out.count("ok-streamed") == 6, out   # (the fused hash aggregation, and — few groups — the LDS-resident grid)

@@ -1130,6 +1130,25 @@ PYBIND11_MODULE(superagg, m) {
         check(rc);
         return out;
     });
+    // codes of a key with missing values / a float key (mode 0 -> int64), or a value column with NaN where missing (mode 1 -> float64): vxh_code_column
+    m.def("code_column", [](const py::object &data, const py::object &mask, int dtype, int mode, int64_t null_code, int64_t nan_code, bool flip) {
+        ArrayRef d = resolve_array(data);
+        if (d.itemsize != kTypeSizes[dtype]) throw std::runtime_error("code_column: itemsize of the column and its dtype differ");
+        ArrayRef k{};
+        const bool has_mask = !mask.is_none();
+        if (has_mask) {
+            k = resolve_array(mask);
+            if (k.itemsize != 1 || k.n != d.n) throw std::runtime_error("code_column: the mask is one byte per row of the column");
+        }
+        auto out = std::make_unique<PyDeviceArray>(d.n, mode == VXH_CODE_KEY ? VXH_I64 : VXH_F64);
+        int rc;
+        {
+            py::gil_scoped_release release;
+            rc = vxh_code_column(mode, dtype, d.ptr, d.mem, has_mask ? (const uint8_t *)k.ptr : nullptr, has_mask ? k.mem : VXH_MEM_HOST, flip ? 1 : 0, d.n, null_code, nan_code, out->p);
+        }
+        check(rc);
+        return out;
+    }, py::arg("data"), py::arg("mask"), py::arg("dtype"), py::arg("mode"), py::arg("null_code") = 0, py::arg("nan_code") = 0, py::arg("flip") = false);
     // row-wise product of two float64 columns (vxh_product_f64) -> float64 device array
     m.def("product", [](const py::object &a, const py::object &b) {
         ArrayRef x = resolve_array(a), y = resolve_array(b);

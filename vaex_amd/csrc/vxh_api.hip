@@ -3389,6 +3389,23 @@ int vxh_pack_keys(int n_keys, const void *const *columns, const int *dtypes, con
     VXH_API_END
 }
 
+int vxh_code_column(int mode, int dtype, const void *data, int mem_data, const uint8_t *mask, int mem_mask, int flip, uint64_t n, int64_t null_code, int64_t nan_code, void *out_device) {
+    VXH_API_BEGIN
+    ensure_device_ready();
+    if (dtype < 0 || dtype >= VXH_DTYPE_COUNT) throw std::runtime_error("vxh_code_column: unknown dtype");
+    if (mode != VXH_CODE_KEY && mode != VXH_CODE_VALUE) throw std::runtime_error("vxh_code_column: mode is VXH_CODE_KEY or VXH_CODE_VALUE");
+    Slot &slot = get_slot(0);
+    order_after_producers(slot);
+    std::unique_ptr<DevBuf> td, tm;
+    const void *dd = on_device(slot, data, (size_t)n * kDtypeSize[dtype], mem_data, td);
+    const uint8_t *dm = mask ? (const uint8_t *)on_device(slot, mask, (size_t)n, mem_mask, tm) : nullptr;
+    if (mode == VXH_CODE_KEY) vxh_launch_key_codes(dd, dm, dtype, flip ? 1 : 0, n, (long long)null_code, (long long)nan_code, (long long *)out_device, slot.stream);
+    else vxh_launch_column_convert(dd, dm, dtype, flip ? 1 : 0, n, out_device, 0, slot.stream);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipStreamSynchronize(slot.stream)); // (the temporaries go away; the result may be read on any stream)
+    VXH_API_END
+}
+
 int vxh_product_f64(const double *a, int mem_a, const double *b, int mem_b, uint64_t n, double *out_device) {
     VXH_API_BEGIN
     ensure_device_ready();

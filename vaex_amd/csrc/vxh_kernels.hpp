@@ -328,6 +328,8 @@ void vxh_launch_pack_keys(const PackArgs &args, hipStream_t stream);
 // integers, bool, float32: exactly representable) — NaN where masked
 void vxh_launch_column_convert(const void *data, const uint8_t *mask, int dtype, int flip, uint64_t n, void *out, int out_f32, hipStream_t stream);
 void vxh_launch_column_convert_i64(const void *data, int dtype, int flip, uint64_t n, void *out, hipStream_t stream);
+// int64 codes of a group key with missing values / of a float key (vxh_code_column)
+void vxh_launch_key_codes(const void *data, const uint8_t *mask, int dtype, int flip, uint64_t n, long long null_code, long long nan_code, long long *out, hipStream_t stream);
 void vxh_launch_product_f64(const double *a, const double *b, double *out, uint64_t n, hipStream_t stream);
 
 void vxh_launch_part_scatter(const PartArgs &args, const LaunchPlan &plan, int scatter_blocks, size_t scatter_lds, hipStream_t stream);

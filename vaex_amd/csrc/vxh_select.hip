@@ -250,7 +250,32 @@ __global__ __launch_bounds__(256) void column_convert_i64(const void *data, int 
     }
 }
 
+// Codes of a group key (round 6, late): what the fused groupby groups instead of the column itself when the key has missing values or is a float —
+// the value as int64 (integers sign- / zero-extended, bool 0 / 1; float kinds: the bit pattern of the value as a double, every NaN under `nan_code`),
+// `null_code` where the mask says missing (numpy's convention: 1).  vaex groups such keys through ordered_set<T>'s null / NaN slots
+// (src/hash_primitives.hpp:455-470); here they are ordinary keys of the partitioned pass.  One pass, 8 + 8 (+ 1) bytes per row.
+__global__ __launch_bounds__(256) void key_codes(const void *data, const uint8_t *mask, int dtype, int flip, uint64_t n, long long null_code, long long nan_code, long long *out) {
+    const bool is_float = dtype == VXH_F64 || dtype == VXH_F32;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        long long c;
+        if (is_float) {
+            const double x = element_as_f64(data, dtype, flip, i);
+            c = x != x ? nan_code : __double_as_longlong(x);
+        } else {
+            c = element_as_i64(data, dtype, flip, i);
+        }
+        if (mask && mask[i] == 1) c = null_code;
+        out[i] = c;
+    }
+}
+
 } // namespace
+
+void vxh_launch_key_codes(const void *data, const uint8_t *mask, int dtype, int flip, uint64_t n, long long null_code, long long nan_code, long long *out, hipStream_t stream) {
+    if (!n) return;
+    const int blocks = (int)std::min<uint64_t>((n + 255) / 256, 256 * 32);
+    hipLaunchKernelGGL(key_codes, dim3(blocks), dim3(256), 0, stream, data, mask, dtype, flip, n, null_code, nan_code, out);
+}
 
 void vxh_launch_column_convert_i64(const void *data, int dtype, int flip, uint64_t n, void *out, hipStream_t stream) {
     if (!n) return;

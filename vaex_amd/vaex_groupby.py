@@ -345,6 +345,84 @@ def _category_key(df, name, sort, ascending, bin_values=None):
     return {"kind": "category", "offset": offset, "count": count, "bins": bins, "rank": rank}
 
 
+#: from this many rows on, the codes of a key with missing values / of a float key, and the NaN-filled form of a value column with missing entries, are made
+#: ON THE DEVICE (vxh_code_column behind a multi-threaded upload of data and mask) instead of by numpy passes over the host column — on the GPU box's
+#: host one numpy thread codes 1e8 int64 keys in ~0.35 s, more than vaex's own two passes take on 256 threads (profiles/r06_keykinds_timing.txt)
+device_coding_min_rows = 2_000_000
+_FLOAT_NAN_CODE, _FLOAT_NULL_CODE = 0x7ff8000000000000, 0x7ff8000000000001   # NaN bit patterns no value has once every NaN is the first of them
+
+
+class _Lazy:
+    """a column of the plan that is MADE from host arrays — the int64 codes of a key (`mode` "key"; `meta` is the key's entry of plan.key_meta and gets its
+    null_code when the codes exist), or float64 values with NaN where an entry is missing ("value") — and not made yet.  The real _frame_for makes it on
+    the device (device()); host() is the numpy road (small columns never become a _Lazy: device_coding_min_rows)."""
+
+    def __init__(self, mode, name, data, mask, meta=None, exact_sums=False):
+        self.mode, self.name, self.data, self.mask, self.meta, self.exact_sums = mode, name, data, mask, meta, exact_sums
+        self.dtype = np.dtype(np.int64 if mode == "key" else np.float64)
+
+    def __len__(self):
+        return len(self.data)
+
+    def host(self):
+        if self.mode == "value":
+            return _nan_filled_host(self.name, self.data, self.mask, self.exact_sums)
+        return _codes_host(self.name, self.data, self.mask, self.meta)
+
+    def device(self, sa, torch, data, mask):
+        """`data` / `mask`: the host arrays' device copies (torch tensors; bool as uint8) -> (torch tensor of the made column, its owner)"""
+        kind = "uint8" if self.data.dtype.kind == "b" else self.data.dtype.name
+        dt = binned._DT_CODE[kind]
+        n = len(self.data)
+        if self.mode == "value":
+            if self.exact_sums and n:
+                lo, hi = sa.minmax_int(data, None, dt, False)
+                if float(max(abs(int(lo)), abs(int(hi)))) * n >= 2.0 ** 53:
+                    raise _Decline(f"aggregated expression {self.name!r}: integer column with missing values too large for exact float64 sums")
+            out = sa.code_column(data, mask, dt, 1)
+        elif self.data.dtype.kind == "f":
+            out = sa.code_column(data, mask, dt, 0, _FLOAT_NULL_CODE, _FLOAT_NAN_CODE)
+        else:
+            # (the missing rows' code: one past the largest element — what the column holds UNDER its mask counts too: a code no value has, which is all it must be)
+            lo, hi = sa.minmax_int(data, None, dt, False) if n else (0, 0)
+            if int(hi) >= np.iinfo(np.int64).max:
+                raise _Decline(f"group key {self.name!r}: no code left for the missing values")
+            self.meta["null_code"] = int(hi) + 1
+            out = sa.code_column(data, mask, dt, 0, int(hi) + 1, 0)
+        return torch.as_tensor(out, device=data.device), out
+
+
+def _codes_host(name, data, mask, meta):
+    """int64 codes of a by-name key with numpy (see _coded_key); sets meta["null_code"]"""
+    if data.dtype.kind == "f":
+        v = data.astype(np.float64)   # (a copy of the call's own: its bits become the codes in place)
+        codes = v.view(np.int64)
+        nan = np.isnan(v)
+        if nan.any():
+            codes[nan] = _FLOAT_NAN_CODE
+        if mask is not None:
+            codes[mask] = _FLOAT_NULL_CODE
+        return codes
+    codes = data.astype(np.int64)
+    top = int(np.max(codes, where=~mask, initial=np.iinfo(np.int64).min)) if mask is not None and not mask.all() else (int(codes.max()) if mask is None and len(codes) else 0)
+    if top >= np.iinfo(np.int64).max:
+        raise _Decline(f"group key {name!r}: no code left for the missing values")
+    meta["null_code"] = top + 1
+    if mask is not None:
+        codes[mask] = top + 1
+    return codes
+
+
+def _nan_filled_host(name, data, mask, exact_sums):
+    if exact_sums:
+        live = data[~mask]
+        if len(live) and float(np.abs(live.astype(np.float64)).max()) * len(data) >= 2.0 ** 53:
+            raise _Decline(f"aggregated expression {name!r}: integer column with missing values too large for exact float64 sums")
+    out = data.astype(np.float64)
+    out[mask] = np.nan
+    return out
+
+
 def _coded_key(name, ar, obj, key_object, sort, ascending):
     """(int64 codes the device groups, the key's meta for _finish_general) of a key column with missing values (`ar` a _Nullable) and / or under a
     binner object with enumerated bins (`obj`, kind "bins").  The missing rows' code is one past the largest value of the column and of the bins."""
@@ -353,21 +431,22 @@ def _coded_key(name, ar, obj, key_object, sort, ascending):
     else:
         data, mask = np.asarray(ar), None
     source = data.dtype.name
+    lazy = len(data) >= device_coding_min_rows and obj is None
     if data.dtype.kind == "f":
         # a float key (vaex's Grouper over ordered_set<double>: one group per value, one for NaN, one for the missing values, vaex/groupby.py:226-330):
         # the device groups the BIT PATTERNS of the float64 values (-0.0 and 0.0 are two keys, as in the reference's hash map: src/hash_primitives.hpp
         # compares what it hashes); every NaN becomes one NaN pattern, a missing value another — patterns no value has
-        v = data.astype(np.float64)   # (a copy of the call's own: its bits become the codes in place)
-        codes = v.view(np.int64)
-        nan_code, null_code = 0x7ff8000000000000, 0x7ff8000000000001
-        nan = np.isnan(v)
-        if nan.any():
-            codes[nan] = nan_code
-        if mask is not None:
-            codes[mask] = null_code
-        return codes, {"kind": "coded", "float": True, "null_code": null_code, "nan_code": nan_code, "source": source, "sort": bool(sort), "ascending": bool(ascending)}
+        meta = {"kind": "coded", "float": True, "null_code": _FLOAT_NULL_CODE, "nan_code": _FLOAT_NAN_CODE, "source": source, "sort": bool(sort), "ascending": bool(ascending)}
+        return (_Lazy("key", name, data, mask, meta) if lazy else _codes_host(name, data, mask, meta)), meta
     if data.dtype.kind not in "biu":
         raise _Decline(f"group key {name!r} has dtype {data.dtype}")
+    if obj is None:   # a key by name (or a tiny BinnerInteger over a column with missing values): ordered and typed by _finish_general
+        meta = {"kind": "coded", "null_code": None, "source": source}
+        if key_object is not None and key_object["kind"] == "integer":   # BinnerInteger over bool / int8 / uint8: ascending or inverted, the missing values last
+            meta.update(sort=True, ascending=not key_object["invert"], tiny=True)
+        else:
+            meta.update(sort=bool(sort), ascending=bool(ascending), tiny=source in _TINY_KEYS)
+        return (_Lazy("key", name, data, mask, meta) if lazy else _codes_host(name, data, mask, meta)), meta
     codes = data.astype(np.int64)
     top = int(np.max(codes, where=~mask, initial=np.iinfo(np.int64).min)) if mask is not None and not mask.all() else (int(codes.max()) if mask is None and len(codes) else 0)
     if obj is not None and len(obj["values"]):
@@ -475,7 +554,7 @@ def _translate(df, aggregate, columns, predicates):
         # round 6: nunique(x) per group = the number of distinct (keys, x) combinations per group — a second device groupby over the keys and x
         # (_nunique_pass); integer / bool x, missing values a value of their own unless dropmissing (src/agg_nunique.cpp)
         name, ar = _real_column(df, aggregate.expressions[0], _KEY_KINDS, "nunique expression", nullable=True)
-        nu = {"nunique": True, "dropmissing": bool(aggregate.dropmissing), "null_code": None}
+        nu = {"nunique": True, "dropmissing": bool(aggregate.dropmissing), "meta": None}
         if isinstance(ar, _Nullable):
             if aggregate.dropmissing:
                 raise _Decline("nunique(dropmissing=True) of a column with missing values")   # (the reference's own answer there is not a count: INTEGRATION.md "Differences")
@@ -483,8 +562,8 @@ def _translate(df, aggregate, columns, predicates):
             if alias not in columns:
                 columns[alias], meta = _coded_key(name, ar, None, None, False, True)
                 columns.host_made.add(alias)
-                columns.null_codes[alias] = meta["null_code"]
-            nu.update(column=alias, null_code=columns.null_codes.get(alias))
+                columns.null_codes[alias] = meta   # (its "null_code" is known when the codes are made: _Lazy)
+            nu.update(column=alias, meta=columns.null_codes.get(alias))
         else:
             columns.setdefault(name, ar)
             nu.update(column=name)
@@ -529,26 +608,23 @@ def _nullable_values(name, ar, kind, columns):
     magnitude < 2^53); its sums are handed back as int64.  min / max keep their dtype and mask in vaex: not taken."""
     if kind in ("min", "max"):
         raise _Decline(f"min / max of {name!r}, a column with missing values")
-    if name in columns and not isinstance(columns[name], np.ndarray):
+    if name in columns and not isinstance(columns[name], (np.ndarray, _Lazy)):
         raise _Decline(f"aggregated expression {name!r} is also a key with missing values")
     if name in columns:
         return columns[name]   # (converted for another aggregation of this call)
     data, mask = ar.data, ar.mask
-    if data.dtype.kind in "iu":
-        live = data[~mask]
-        if len(live) and float(np.abs(live.astype(np.float64)).max()) * len(data) >= 2.0 ** 53:
-            raise _Decline(f"aggregated expression {name!r}: integer column with missing values too large for exact float64 sums")
-        if hasattr(columns, "int_nullable"):
-            columns.int_nullable.add(name)
-        else:
+    exact_sums = data.dtype.kind in "iu"
+    if exact_sums:
+        if not hasattr(columns, "int_nullable"):
             raise _Decline(f"aggregated expression {name!r} is an integer column with missing values")
+        columns.int_nullable.add(name)
     elif data.dtype.kind != "f":
         raise _Decline(f"aggregated expression {name!r} has dtype {data.dtype}")
-    out = data.astype(np.float64)
-    out[mask] = np.nan
     if hasattr(columns, "host_made"):
         columns.host_made.add(name)
-    return out
+    if len(data) >= device_coding_min_rows:
+        return _Lazy("value", name, data, mask, exact_sums=exact_sums)
+    return _nan_filled_host(name, data, mask, exact_sums)
 
 
 def _selection_of(df, aggregate, columns, predicates):
@@ -786,8 +862,9 @@ def _nunique_pass(plan, frame, res, nu):
     pairs = frame.groupby(list(key_names) + [nu["column"]], {"__pairs__": binned.agg.count()}, selection=plan.selection)
     x = np.asarray(pairs[nu["column"]]).astype(np.int64)
     keys = [np.asarray(pairs[k]).astype(np.int64) for k in key_names]
-    if nu["dropmissing"] and nu["null_code"] is not None:
-        live = x != nu["null_code"]
+    null_code = (nu.get("meta") or {}).get("null_code")
+    if nu["dropmissing"] and null_code is not None:
+        live = x != null_code
         keys = [k[live] for k in keys]
     stacked = np.stack(keys, axis=1) if len(keys[0]) else np.zeros((0, len(keys)), dtype=np.int64)
     main = np.stack([np.asarray(res[k]).astype(np.int64) for k in key_names], axis=1)
@@ -1013,8 +1090,62 @@ _device_copies = {}
 upload_min_bytes = 256 << 20
 
 
+def _made_columns(columns):
+    """the plan's columns with every _Lazy MADE: on the device — every column of the call uploaded with several copy threads, the lazy ones coded there by
+    vxh_code_column — when the call's columns are plain numeric arrays and fit; else with numpy on the host.  -> (columns, owners of device arrays)"""
+    lazies = [name for name, c in columns.items() if isinstance(c, _Lazy)]
+    if not lazies:
+        return columns, []
+    try:
+        import torch
+        import vaex_amd
+        sa = vaex_amd.superagg
+        if not hasattr(sa, "code_column"):
+            raise KeyError("no device coding in this library")
+        kinds = {"int8": torch.int8, "int16": torch.int16, "int32": torch.int32, "int64": torch.int64, "uint8": torch.uint8, "float32": torch.float32, "float64": torch.float64}
+        device = int(sa.config_get("device"))
+        free, _ = torch.cuda.mem_get_info(device)
+        total = 0
+        for name, c in columns.items():
+            arrays = [c.data, c.mask] if isinstance(c, _Lazy) else [c]
+            for a in arrays:
+                if a is None:
+                    continue
+                if not isinstance(a, np.ndarray) or np.ma.isMaskedArray(a) or not a.dtype.isnative or (a.dtype.name not in kinds and not (isinstance(c, _Lazy) and a.dtype.kind == "b")):
+                    raise KeyError(f"column {name!r} does not upload as it is")
+                total += a.nbytes + (8 * len(a) if isinstance(c, _Lazy) and a is c.data else 0)
+        if total * 3 >= free:
+            raise MemoryError("the call's columns do not fit the device next to the partition queues")
+
+        def upload(a):
+            a = np.ascontiguousarray(a.view("u1") if a.dtype.kind == "b" else a)
+            t = torch.empty(a.shape, dtype=kinds[a.dtype.name], device=f"cuda:{device}")
+            sa.upload(a, t, 6)
+            return t
+        made, owners = {}, []
+        for name, c in columns.items():
+            if isinstance(c, _Lazy):
+                d, m = upload(c.data), (None if c.mask is None else upload(c.mask))
+                made[name], owner = c.device(sa, torch, d, m)
+                owners.append(owner)
+                del d, m
+            else:
+                made[name] = upload(c)
+        stats["coded_on_device"] = stats.get("coded_on_device", 0) + len(lazies)
+        return made, owners
+    except (ImportError, KeyError, RuntimeError, MemoryError):
+        stats["coded_on_host"] = stats.get("coded_on_host", 0) + len(lazies)
+        return {name: (c.host() if isinstance(c, _Lazy) else c) for name, c in columns.items()}, []
+
+
 def _frame_for(df, columns):
     from . import _cached_arrays
+    columns, owners = _made_columns(columns)
+    if owners:   # (everything sits in HBM already)
+        from . import vaex_dist
+        frame = binned.Frame(dict(columns), comm=vaex_dist.comm())
+        frame._device_owners = owners
+        return frame
     cols = {}
     for name, ar in columns.items():
         key = ar.__array_interface__["data"][0]
