@@ -473,6 +473,58 @@ def other_configs(sa, torch, rows, sample_rows):
     return out
 
 
+def measured_traffic(rows, shape, timeout=240):
+    """HBM bytes per launch of the bench pass from the PMC counters of THIS command on THIS box (the line used to carry a constant
+    read from profiles/): two rocprofv3 passes over a short run of this script — `--pmc FETCH_SIZE`, then `--pmc WRITE_SIZE`, each with --kernel-trace
+    only, as MI355X_MICROARCH.md's HBM section prescribes — FETCH_SIZE counted twice (gfx950 books a 128-byte request as 64), both in KiB.  Per kernel of the
+    pass the average per dispatch.  -> (bytes per launch, per-kernel breakdown) or (None, why)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    per = {}
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="vxh_pmc_", dir="/tmp")
+        try:
+            cmd = [exe, "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__), "--steps", "2", "--warmup", "1",
+                   "--no-cpu", "--no-extra", "--no-configs", "--rows", str(int(rows)), "--shape", str(int(shape))]
+            p = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=timeout)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if p.returncode != 0 or not files:
+                return None, f"rocprofv3 --pmc {ctr}: rc {p.returncode}, {len(files)} counter files"
+            acc = {}
+            for f in files:
+                with open(f, newline="") as fh:
+                    for r in csv.DictReader(fh):
+                        if r.get("Counter_Name") != ctr:
+                            continue
+                        name = r.get("Kernel_Name", "").replace("(anonymous namespace)::", "").replace("void ", "")
+                        a = acc.setdefault(name, [0.0, set()])
+                        a[0] += float(r["Counter_Value"])
+                        a[1].add(r["Dispatch_Id"])
+            per[ctr] = {k: (v[0] / len(v[1]), len(v[1])) for k, v in acc.items()}
+        except Exception as e:   # noqa: BLE001  (a profiler that is not there, times out or writes another format: the line says so and keeps the offline figure)
+            return None, f"rocprofv3 --pmc {ctr}: {type(e).__name__}: {str(e)[:120]}"
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    total, parts = 0.0, {}
+    for prefix in ("part_scatter_wv", "part_reduce_", "part_merge", "part_hot_merge"):   # the kernels of one pass (one dispatch each per launch)
+        cands = [(n, k, avg) for k, (avg, n) in per["FETCH_SIZE"].items() if k.startswith(prefix)]
+        if not cands:
+            continue
+        n, k, f = max(cands)   # (the instantiation with the most dispatches: a first call's timed trial launches the other form once)
+        w = per["WRITE_SIZE"].get(k, (0.0, 0))[0]
+        total += (2.0 * f + w) * 1024.0
+        parts[k[:48]] = {"read_bytes": 2.0 * f * 1024.0, "written_bytes": w * 1024.0, "dispatches": n}
+    if not parts:
+        return None, "no kernel of the pass among the profiled dispatches"
+    return total, parts
+
+
 def _spawned(local_rank, args, port):
     os.environ.update(RANK=str(local_rank), LOCAL_RANK=str(local_rank), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     run(args)
@@ -666,6 +718,17 @@ def run(args):
                 traffic = json.load(open(tpath))["hbm_bytes_per_row"] * rows
                 traffic_source = "profiles/" + tname + " (rocprofv3 --pmc passes of this command, FETCH_SIZE x2 on gfx950; not a same-run counter)"
                 break
+        traffic_parts = None
+        if world == 1 and not args.no_extra and traffic is not None and not os.environ.get("VAEX_AMD_BENCH_NO_PMC"):
+            # the counters of THIS command on THIS box (two short profiled runs of this script, ~20 s each), when rocprofv3 is there
+            t0 = time.perf_counter()
+            live, parts = measured_traffic(rows, shape)
+            if live is not None:
+                traffic, traffic_parts = live, parts
+                traffic_source = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes (--kernel-trace only) of `bench.py --steps 2 --warmup 1` run by this process on this box, "
+                                  f"FETCH_SIZE x2 on gfx950, per-dispatch averages of the pass's kernels ({time.perf_counter() - t0:.0f} s)")
+            else:
+                traffic_source += f"; a same-run measurement was tried: {parts}"
         out = {
             "metric": "rows/sec, 2-D count+mean on 256x256 grid (count(*), sum(v), count(v) fused), float64 x,y,v",
             "value": value, "unit": "rows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -678,6 +741,10 @@ def run(args):
                          "frac_of_measured_copy_rate": achieved / 6290.0,  # (6.29 TB/s float4 copy: MI355X_MICROARCH.md)
                          "traffic": traffic, "traffic_source": traffic_source, "kernel_ms": k_ms, "bytes_per_row": BYTES_PER_ROW, "rows_per_launch": rows},
         }
+        if traffic is not None:
+            out["roofline"]["traffic_bytes_per_row"] = traffic / rows
+        if traffic_parts:
+            out["roofline"]["traffic_kernels"] = traffic_parts
         if os.environ.get("VAEX_AMD_BENCH_STEPS_DEBUG"):
             out["kernel_ms_per_step"] = [round(float(k), 3) for k in kernel_ms]
             if settle_trace:

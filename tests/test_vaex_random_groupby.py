@@ -98,6 +98,7 @@ import os
 only = [int(q) for q in os.environ.get("VAEX_AMD_RANDOM_SEEDS", "").split(",") if q]   # (a diagnosis run: these seeds only, both results printed)
 for seed in (only or range(ncalls)):
     rng = np.random.default_rng(seed)
+    vg.device_coding_min_rows = 1000 if (gpu and seed %% 2) else 2_000_000   # (every other call: keys / values with missing entries and float keys are coded on the device, vxh_code_column)
     n = int(rng.choice([1, 2, 3, 10, 100, 5000, 20000]))
     nkeys = int(rng.choice([1, 1, 1, 2, 3])) if gpu else 1
     kinds = [str(rng.choice(["i1", "i2", "i4", "i8", "u1", "u2", "u4", "bool"])) for _ in range(nkeys)]
@@ -225,6 +226,7 @@ for seed in (only or range(ncalls)):
                 print(label, {c: t.sort(keys)[c].tolist()[:40] for c in t.get_column_names()})
 print("calls", ncalls, "| answered by:", paths, "| groupby stats:", {k: vg.stats[k] for k in ("device", "task", "vaex")})
 print("recognised reference defects / alike exceptions:", known)
+print("columns coded on the device:", vg.stats.get("coded_on_device", 0), "on the host for want of room / a plain dtype:", vg.stats.get("coded_on_host", 0))
 for b in bad[:15]:
     print("BAD", b)
 assert not bad, len(bad)
@@ -239,7 +241,7 @@ def _run(gpu, ncalls, timeout):
     report = os.environ.get("VAEX_AMD_REPORT_DIR")
     if report and gpu:
         with open(os.path.join(report, "random_groupby_report.txt"), "w") as f:
-            f.write("\n".join(line for line in out.stdout.splitlines() if line.startswith(("calls", "recognised", "DONE"))))
+            f.write("\n".join(line for line in out.stdout.splitlines() if line.startswith(("calls", "recognised", "columns coded", "DONE"))))
     return out.stdout
 
 

@@ -49,7 +49,7 @@ stats = {"device": 0, "task": 0, "vaex": 0, "why": {}}
 _KEY_KINDS = ("bool", "int8", "int16", "int32", "int64", "uint8", "uint16", "uint32")
 _FLOAT_KEYS = ("float64", "float32")   # round 6: grouped by their bit patterns (_coded_key)
 _TINY_KEYS = ("bool", "int8", "uint8")   # vaex bins these with BinnerInteger straight away (vaex/groupby.py:593-595): no combined grouper, own key typing
-_VALUE_KINDS = ("float64", "float32", "int64", "int32", "int16", "int8", "uint32", "uint16", "uint8")
+_VALUE_KINDS = ("float64", "float32", "int64", "int32", "int16", "int8", "uint32", "uint16", "uint8", "bool")
 _AGG_NAMES = {"AggCount": "count", "AggSum": "sum", "AggMin": "min", "AggMax": "max"}
 
 
@@ -742,6 +742,8 @@ def _plan(df, by, agg, sort=False, ascending=True, row_limit=None, for_task=Fals
             # next to other keys, a BinnerInteger over a range): the device groups int64 CODES — the values, the missing rows under a code of their own
             if key_object is not None and key_object["kind"] == "grouper":
                 raise _Decline("binner object as key (Grouper over a column with missing values that it does not list)")
+            if isinstance(ar, _Streamed):
+                ar = _materialised(df, name, "group key")   # (the codes are made from the whole column: arrow without nulls is a view, a proxied column one evaluate)
             ar, meta = _coded_key(name, ar, obj, key_object, srt[i], asc[i])
             key_originals.append(name)
             key_label["__codes_of_" + name] = name   # (the codes live beside the column itself: a filter or an aggregation may read that too)
@@ -1103,6 +1105,7 @@ def _made_columns(columns):
         if not hasattr(sa, "code_column"):
             raise KeyError("no device coding in this library")
         kinds = {"int8": torch.int8, "int16": torch.int16, "int32": torch.int32, "int64": torch.int64, "uint8": torch.uint8, "float32": torch.float32, "float64": torch.float64}
+        kinds.update({name: getattr(torch, name) for name in ("uint16", "uint32") if hasattr(torch, name)})   # (storage only: the library reads the bytes)
         device = int(sa.config_get("device"))
         free, _ = torch.cuda.mem_get_info(device)
         total = 0
