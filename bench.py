@@ -236,6 +236,7 @@ def other_configs(sa, torch, rows, sample_rows):
     first_call = [0.0, 0.0]
     first_detail = [None]
     process_first = [None]
+    process_first_detail = [None]
 
     def timed(fn, reps=3, prime=None, info=None, again=None):
         # `prime`: the same call over COPIES of the columns (other column objects) first, so that what a PROCESS pays once at this size —
@@ -243,19 +244,11 @@ def other_configs(sa, torch, rows, sample_rows):
         # 1e9-row groupby: `ms_first_call_in_process`) — is not booked on the columns: `ms_first_call` is what a later call over FRESH
         # columns pays (their key range / NaN scan, their hot-box sample)
         process_first[0] = None
-        if prime is not None:
-            run_primed = prime()   # (the copies are made HERE, outside the clock: torch's allocator asking the runtime for 8 GB blocks was 0.3-0.6 s of round 5's `ms_first_call_in_process`)
-            torch.cuda.synchronize()
-            tp = time.perf_counter()
-            run_primed()
-            torch.cuda.synchronize()
-            process_first[0] = (time.perf_counter() - tp) * 1e3
-            del run_primed
-            torch.cuda.empty_cache()
+        process_first_detail[0] = None
         # the FIRST call over fresh columns is timed too: it pays what the later ones find remembered per column
         # object — the groupby's exact key-range pass (vxh_minmax_int, 8 B/row) and NaN scan of the value column, the hot-box sample —
         # and goes on the line as `ms_first_call` / `kernel_ms_first_call`; `ms` / `kernel_ms` are the best of the warm calls after it
-        def first(label):
+        def first(label, fn=fn):
             # the first call with a host clock around every library call it makes and the block pool's hipMalloc / hipFree counters around
             # it: a first call far above the warm ones (the driver's round-5 line: 464 ms against 11) then says on the line itself where the
             # time went — a library call's host time, the runtime's allocator, or neither (the device queue itself stalled)
@@ -303,6 +296,13 @@ def other_configs(sa, torch, rows, sample_rows):
                 detail["groupby_info"] = {k_: (round(v_, 3) if isinstance(v_, float) else v_) for k_, v_ in (info() or {}).items()}
             del r_
             return ms_first, k_first, detail
+        if prime is not None:
+            run_primed = prime()   # (the copies are made HERE, outside the clock: torch's allocator asking the runtime for 8 GB blocks was 0.3-0.6 s of round 5's `ms_first_call_in_process`)
+            # the same account as the first call's: library calls on the host clock, the block pool's hipMalloc / hipFree counters, torch's allocator — a slow process-first
+            # call (the dense groupby: the first call that needs the 24 GB of record streams) then says on the line where its time went
+            process_first[0], _, process_first_detail[0] = first("first call of this kind in the process, over copies of the columns", run_primed)
+            del run_primed
+            torch.cuda.empty_cache()
         first_call[0], first_call[1], first_detail[0] = first("first call over fresh columns")
         best, best_k = float("inf"), float("inf")
         for _ in range(reps):
@@ -325,7 +325,7 @@ def other_configs(sa, torch, rows, sample_rows):
     def line(config, what, bytes_per_row, wall, k_ms, kernel, parity):
         gbs = bytes_per_row * rows / (k_ms * 1e-3) / 1e9
         return {"config": config, "what": what, "rows": rows, "rows_per_s": rows / wall, "ms": wall * 1e3, "kernel_ms": k_ms, "stream_ms": stream_ms[0], "kernel": kernel,
-                "ms_first_call": first_call[0], "kernel_ms_first_call": first_call[1], "ms_first_call_in_process": process_first[0], "first_call": first_detail[0],
+                "ms_first_call": first_call[0], "kernel_ms_first_call": first_call[1], "ms_first_call_in_process": process_first[0], "first_call": first_detail[0], "first_call_in_process": process_first_detail[0],
                 "roofline": {"bound": "hbm", "bytes_per_row": bytes_per_row, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS},
                 "parity_on_sample": parity}
 
