@@ -656,11 +656,12 @@ def _selection_of(df, aggregate, columns, predicates):
     return sel
 
 
-def _key_column_like_vaex(values, source_kind=None):
+def _key_column_like_vaex(values, source_kind=None, has_null=False):
     """a key column of the result typed the way vaex's groupers hand it back (vaex/groupby.py:147-205, :263-277) — decided per key
     from its distinct values: BinnerInteger (range <= 4/3 of the distinct keys) -> int64 with an (empty) mask; else Grouper -> the
     narrowest signed integer type that holds the range.  bool / int8 / uint8 keys are BinnerInteger from the start (vaex/groupby.py:
-    593-595): bin_values [False, True, null] resp. arange + null as a masked int64 array (:166-187)"""
+    593-595): bin_values [False, True, null] resp. arange + null as a masked int64 array (:166-187).  `has_null`: the key has a group of
+    missing values — the reference's hash map hands that key back among its `bin_values`, so `bins = len(self.bin_values)` (:266) counts it."""
     k = np.asarray(values)
     if source_kind == "bool":
         return np.ma.array(k.astype(bool), mask=np.zeros(len(k), dtype=bool), shrink=False)
@@ -669,7 +670,7 @@ def _key_column_like_vaex(values, source_kind=None):
     if len(k) == 0:   # (no group: vaex hands back an empty column of the key's own type)
         return k.astype(source_kind) if source_kind else k
     vmin, vmax = int(k.min()), int(k.max())
-    distinct = len(k) if np.all(k[1:] > k[:-1]) or np.all(k[1:] < k[:-1]) else len(np.unique(k))
+    distinct = (len(k) if np.all(k[1:] > k[:-1]) or np.all(k[1:] < k[:-1]) else len(np.unique(k))) + (1 if has_null else 0)
     if vmax - vmin + 1 <= distinct * 4 / 3:
         return np.ma.array(k.astype(np.int64), mask=np.zeros(len(k), dtype=bool), shrink=False)
     for dt in (np.int8, np.int16, np.int32, np.int64):
@@ -959,6 +960,21 @@ def _finish_general(df, plan, frame, res):
     key_names, columns, actions, metas = plan.key_names, plan.columns, plan.actions, plan.key_meta
     codes = {name: np.asarray(res[name]).astype(np.int64) for name in key_names}
     n = len(codes[key_names[0]])
+    for name in key_names:
+        # a key by name with a group of missing values: the reference's Grouper counts that group among its bins when it decides whether the values are a
+        # dense integer range (vaex/groupby.py:263-272: `bins = len(self.bin_values)`, `dense = bins == int_range`).  Two corners follow that are left to
+        # the reference itself (seen once each in 10000 random calls): every row missing — `bin_values.min()` is the masked constant and BinnerInteger raises
+        # "Cannot store the range" — and a range with exactly ONE integer no row has: null + values == range, the lone key is "dense" and the absent integer
+        # is handed back as a group without a row (count 0, mean NaN, min inf)
+        m = metas.get(name)
+        if m is not None and m["kind"] == "coded" and "in_order" not in m and not m.get("float") and not m.get("tiny") and n:
+            real = codes[name] != m["null_code"]
+            if not real.all():
+                if not real.any():
+                    raise _Decline(f"group key {name!r}: every row is missing (the reference raises)")
+                u = np.unique(codes[name][real])
+                if len(key_names) == 1 and int(u[-1]) - int(u[0]) + 1 == len(u) + 1:
+                    raise _Decline(f"group key {name!r}: missing values next to a range with one absent integer (the reference hands that integer back as a group without a row)")
     keep = np.ones(n, dtype=bool)
     at = {}
     for name in key_names:
@@ -1047,7 +1063,7 @@ def _finish_general(df, plan, frame, res):
         elif m is not None:
             c = codes[name][pick]
             real = c != m["null_code"]
-            typed = _key_column_like_vaex(c[real], m["source"])
+            typed = _key_column_like_vaex(c[real], m["source"], has_null=not real.all() and not m.get("tiny"))
             if real.all():
                 k = np.ma.getdata(typed) if combined else typed
             else:
