@@ -193,6 +193,17 @@ if bad and gpu:
         if hip_stable and agree_now and not ref_stable:
             bad = [b for b in bad if b[0] != name]
             print("the reference's own answer moved between two runs (the HIP answer did not):", name)
+        elif hip_stable and not ref_stable:
+            # both of the reference's answers differ, from each other and from the stable HIP answer (tests/test_vaex_random_calls.py, call 50 of its 4e6-row form): the
+            # reference once more with ONE pool thread, where its per-thread grids cannot race
+            import vaex.execution, vaex.multithreading
+            df1 = make()
+            df1.executor = vaex.execution.ExecutorLocal(vaex.multithreading.ThreadPoolIndex(max_workers=1))
+            alone = flat(calls[name](df1))
+            print("AGAIN", name, "| the reference on ONE pool thread == both HIP runs:", same(again_hip[name], alone, name))
+            if same(again_hip[name], alone, name):
+                bad = [b for b in bad if b[0] != name]
+                print("the reference's own answer moved between two runs (the HIP answer did not):", name)
 assert not bad, bad
 if gpu:
     print("task parts built on the HIP classes:", vaex_amd.task_stats["hip"], " on vaex's C++:", vaex_amd.task_stats["cpu"], vaex_amd.task_stats["cpu_reasons"])

@@ -193,6 +193,9 @@ bad, excs, known = [], 0, 0
 # selections and limits="minmax" that is a BinnerScalar whose limits are arrays, which vaex cannot hash when it merges the pass's tasks (TypeError in
 # vaex/execution.py _merge: the same call would fail there on the reference too, had its minmax not raised first) — and the failed execute() leaves the OTHER
 # delayed calls of the same batch pending on the HIP side.  A pending promise next to such a call is counted with it.
+_force = os.environ.get("VAEX_AMD_RANDOM_FORCE_MOVED")   # (a check of the tie-break below itself: the reference's two answers of this call are spoilt on purpose)
+if _force and not isinstance(second[int(_force)], tuple):
+    second[int(_force)] = np.asarray(second[int(_force)], dtype="f8") + 1.0
 defect_at = {i for i in call_range if any(isinstance(q, tuple) and KNOWN_DEFECT in q[2] for q in flat(second[i]))}
 for i in call_range:
     c = draw(i)
@@ -243,10 +246,22 @@ if bad and gpu:
     # the masked column with a selection on a filtered frame — that no repeat of the call alone reproduces: tools/r07_var_masked_stress.py)
     fr2 = frames(make())
     again_ref = {b[0]: flat(call(fr2[draw(b[0])["frame"]], draw(b[0]))) for b in bad if not draw(b[0])["delayed"]}
+    if _force and int(_force) in again_ref:
+        again_ref[int(_force)] = [q + 2.0 for q in again_ref[int(_force)]]
     vaex_amd.install()
     again_hip = {i: flat(call(fr2[draw(i)["frame"]], draw(i))) for i in again_ref}
     vaex_amd.uninstall()
     moved = 0
+    def reference_on_one_thread(i):
+        # the tie-break when the reference's two answers differ from each other AND from the (stable) HIP answer — seen on the 4e6-row form of this test, call 50, a
+        # variance of the masked column: the reference once more with ONE pool thread, where `grid_used` (src/agg_base.hpp:17, a vector<bool> the pool's threads write
+        # concurrently) cannot lose a thread's grid
+        import vaex.execution, vaex.multithreading
+        ex1 = vaex.execution.ExecutorLocal(vaex.multithreading.ThreadPoolIndex(max_workers=1))
+        fr1 = frames(make())
+        for f in fr1.values():
+            f.executor = ex1
+        return flat(call(fr1[draw(i)["frame"]], draw(i)))
     for i in again_ref:
         eq = lambda u, w: all(isinstance(p, np.ndarray) and isinstance(q, np.ndarray) and p.shape == q.shape and np.allclose(p, q, rtol=1e-9, atol=1e-12, equal_nan=True) for p, q in zip(u, w))
         hip_stable, ref_stable, agree_now = eq(flat(first[i]), again_hip[i]), eq(flat(second[i]), again_ref[i]), eq(again_hip[i], again_ref[i])
@@ -258,6 +273,12 @@ if bad and gpu:
             # written by concurrent threads).  Counted, not compared.
             moved += 1
             bad = [b for b in bad if b[0] != i]
+        elif hip_stable and not ref_stable:
+            alone = reference_on_one_thread(i)
+            print("AGAIN", i, "| the reference on ONE pool thread == both HIP runs:", eq(again_hip[i], alone), "| == its own first / second answer:", eq(flat(second[i]), alone), eq(again_ref[i], alone))
+            if eq(again_hip[i], alone):
+                moved += 1
+                bad = [b for b in bad if b[0] != i]
     if moved:
         print("the reference's own answer moved between two runs (the HIP answer did not):", moved)
 print("calls", ncalls, "of which raised on both sides alike:", excs - known, "| the reference raised on an empty selected chunk, the HIP entry answered:", known, "| different:", len(bad))
