@@ -183,6 +183,9 @@ for seed in (only or range(ncalls)):
             got = d.groupby(make_by(), agg=agg, **kw)
     except Exception as e:
         got = e
+        if only:
+            import traceback
+            traceback.print_exc(file=sys.stdout)
     kw = kwc
     paths[vg.last.get("path")] = paths.get(vg.last.get("path"), 0) + 1
     if isinstance(want, Exception):
@@ -194,6 +197,12 @@ for seed in (only or range(ncalls)):
             bad.append((what, "the reference raises", type(want).__name__, str(want)[:100], "here", type(got).__name__, str(got)[:200]))
         continue
     if isinstance(got, Exception):
+        if nkeys >= 2 and "masked" in special and isinstance(got, IndexError) and vg.last.get("path") != "device":
+            # a call the wrapper DECLINED: vaex's own combined groupers over a key with missing values (see below: not deterministic there) — one of their outcomes is
+            # an IndexError in GrouperCombined's `parent.bin_values.take(indices)` (vaex/groupby.py:383; seed 24616, once in three runs of the same process)
+            label = "reference: combined groupers over a key with missing values (not deterministic there)"
+            known[label] = known.get(label, 0) + 1
+            continue
         bad.append((what, "raises here only", type(got).__name__, str(got)[:300])); continue
     wraps = any(st == "extreme" and kd in ("i2", "i4", "u2", "u4") for st, kd in zip(styles, kinds))
     if (len(want) == 0 or (wraps and "masked" in special and len(want) < len(got))) and len(d) > 0 and len(got) > 0 and vg.last.get("path") == "device":   # (with a missing-value group the reference keeps that one)
