@@ -468,6 +468,21 @@ def other_configs(sa, torch, rows, sample_rows):
             ln["roofline"]["floor"] = {"structural_bytes_per_row": 16 + 2 * rec, "record_bytes": rec, "mixed_traffic_rate_GBs": 6290.0,
                                         "floor_frac": 16.0 / (16 + 2 * rec) * 6290.0 / HBM_PEAK_GBS,
                                         "note": "two-pass partition: 16 B read + record written + record read back per row, at the measured copy rate"}
+        if flavour == "dense":
+            # what a 20 GB allocation costs on THIS box right now (a fresh block from the runtime through torch's allocator, handed straight back): the dense groupby's
+            # process-first call is 14-16 ms on some boxes and 0.7-0.9 s on others — the first call that asks for the record streams; this probe,
+            # behind it, says whether every large allocation is slow on the box or only a process's first
+            torch.cuda.empty_cache()
+            torch.cuda.synchronize()
+            tq = time.perf_counter()
+            blk = torch.empty(20 << 30, dtype=torch.uint8, device="cuda")
+            torch.cuda.synchronize()
+            t_alloc = (time.perf_counter() - tq) * 1e3
+            del blk
+            tq = time.perf_counter()
+            torch.cuda.empty_cache()
+            torch.cuda.synchronize()
+            ln["large_alloc_probe"] = {"gb": 20, "ms_alloc": round(t_alloc, 3), "ms_free": round((time.perf_counter() - tq) * 1e3, 3), "when": "behind this config's calls"}
         out.append(ln)
         del df, res
     return out

@@ -13,6 +13,10 @@ if "allreduce_world1_ms" in d or "allreduce_world1" in d:
 for c in d.get("configs") or []:
     print("  %-12s %.3g rows/s kernel_ms %.3f frac %.3f first_call_ms %s ok %s %s" % (c.get("config"), c.get("rows_per_s", 0), c.get("kernel_ms", 0), c.get("roofline", {}).get("frac", 0),
           c.get("ms_first_call"), (c.get("parity_on_sample") or {}).get("ok"), c.get("groupby_kernels_ms", "")))
+    pf = c.get("first_call_in_process") or {}
+    if c.get("ms_first_call_in_process") is not None:
+        print("      process-first %.1f ms  pool hipMalloc %s us over %s bytes  calls %s  %s" % (c["ms_first_call_in_process"], (pf.get("pool") or {}).get("pool_malloc_us"), (pf.get("pool") or {}).get("pool_malloc_bytes"),
+              pf.get("library_calls_ms"), c.get("large_alloc_probe", "")))
 cb = d.get("cpu_baseline") or {}
 if cb:
     print("  cpu %.4g rows/s on %s cores (%s) parity %s  vaex: %s" % (cb.get("value", 0), cb.get("cores"), cb.get("kind"), cb.get("parity_on_sample"), ({k: cb["through_vaex"].get(k) for k in ("value", "threads", "runs", "error")} if cb.get("through_vaex") else None)))
