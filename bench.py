@@ -220,6 +220,25 @@ def cpu_baseline(x, y, v, shape, rows):
                 sample=f"{rows:.3g} of the GPU's own rows (x,y,v float64), same 2-D {shape}x{shape} count+sum+count pass, best of {reps} passes, 1Mi-row chunks over a {nthreads}-thread pool"), res, rows, sabs
 
 
+def alloc_probe(torch, when, gb=20):
+    """what a 20 GB allocation costs in THIS process right now (a fresh block from the runtime through torch's allocator, handed straight back).  The dense groupby's
+    process-first call — the first that asks for the record streams — was 14-16 ms on some runs and 0.5-3.7 s on others, all of it inside ONE hipMalloc (the line's
+    `first_call_in_process.pool`); runs with --no-cpu never showed it: the probe is taken behind the configs AND behind the CPU baseline (hundreds of host threads,
+    gigabytes of host arrays made and dropped) to say which state of the process makes the runtime's allocator slow."""
+    import time as _t
+    torch.cuda.empty_cache()
+    torch.cuda.synchronize()
+    tq = _t.perf_counter()
+    blk = torch.empty(gb << 30, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    t_alloc = (_t.perf_counter() - tq) * 1e3
+    del blk
+    tq = _t.perf_counter()
+    torch.cuda.empty_cache()
+    torch.cuda.synchronize()
+    return {"gb": gb, "ms_alloc": round(t_alloc, 3), "ms_free": round((_t.perf_counter() - tq) * 1e3, 3), "when": when}
+
+
 def other_configs(sa, torch, rows, sample_rows):
     """BASELINE configs[2] (3-D 128^3 histogram with a boolean selection) and configs[3] (groupby on a 1e6-cardinality int64
     key, sum / mean / std — dense keys and scattered keys) at `rows` rows through vaex_amd.binned.Frame, each with its wall
@@ -469,20 +488,7 @@ def other_configs(sa, torch, rows, sample_rows):
                                         "floor_frac": 16.0 / (16 + 2 * rec) * 6290.0 / HBM_PEAK_GBS,
                                         "note": "two-pass partition: 16 B read + record written + record read back per row, at the measured copy rate"}
         if flavour == "dense":
-            # what a 20 GB allocation costs on THIS box right now (a fresh block from the runtime through torch's allocator, handed straight back): the dense groupby's
-            # process-first call is 14-16 ms on some boxes and 0.7-0.9 s on others — the first call that asks for the record streams; this probe,
-            # behind it, says whether every large allocation is slow on the box or only a process's first
-            torch.cuda.empty_cache()
-            torch.cuda.synchronize()
-            tq = time.perf_counter()
-            blk = torch.empty(20 << 30, dtype=torch.uint8, device="cuda")
-            torch.cuda.synchronize()
-            t_alloc = (time.perf_counter() - tq) * 1e3
-            del blk
-            tq = time.perf_counter()
-            torch.cuda.empty_cache()
-            torch.cuda.synchronize()
-            ln["large_alloc_probe"] = {"gb": 20, "ms_alloc": round(t_alloc, 3), "ms_free": round((time.perf_counter() - tq) * 1e3, 3), "when": "behind this config's calls"}
+            ln["large_alloc_probe"] = alloc_probe(torch, "behind this config's calls")
         out.append(ln)
         del df, res
     return out
@@ -830,6 +836,12 @@ def run(args):
                 del comm1
             except Exception as e:   # (the bench line must not depend on it)
                 out["allreduce_world1"] = {"error": repr(e)}
+        if count2d is not None:
+            out["configs"] = [count2d]
+        if world == 1 and not args.no_configs:
+            # (in front of the CPU baseline since late round 6: behind it the runtime's allocator was slow — a 20 GB hipMalloc 2.3-3.7 s instead of 0.4 ms, see
+            #  alloc_probe — and the configs' process-first calls were measuring that; the bench's own columns stay where they are: 24 of 288 GB)
+            out["configs"] = other_configs(sa, torch, rows, 1e7)
         if not args.no_cpu:
             # (at N > 1 too: rank 0's own shard is the sample — the other ranks wait at the end of the job, outside every timed region)
             cb, cpu_res, cpu_rows, sabs = cpu_baseline(x, y, v, shape, args.cpu_rows if world == 1 else min(args.cpu_rows, 5e7))
@@ -852,12 +864,8 @@ def run(args):
                       "sum_cells_over_tol": int(bad_sum.sum()), "rows_counted": [int(g[0].sum()), int(cpu_res[0].sum())]}
             out["cpu_baseline"]["parity_on_sample"] = not any(detail[k] for k in ("count_cells_differ", "countv_cells_differ", "sum_cells_over_tol"))
             out["cpu_baseline"]["parity_detail"] = detail
-        if count2d is not None:
-            out["configs"] = [count2d]
-        if world == 1 and not args.no_configs:
-            del x, y, v
-            torch.cuda.empty_cache()
-            out["configs"] = other_configs(sa, torch, rows, 1e7)
+            if world == 1:
+                out["large_alloc_probe_behind_cpu_baseline"] = alloc_probe(torch, "behind the CPU baseline")
         json_out.write(json.dumps(out) + "\n")
         json_out.flush()
     if world > 1:

@@ -1088,7 +1088,15 @@ unsigned run_pipeline(GbArgs &G, int nv, bool merge, uint64_t n, uint64_t groups
         G.kc_min = key_min;
         if (res) { res->compact = compact ? 1 : 0; res->direct = G.direct; }
         G.ng = (uint32_t)NG; G.cap = cap;
-        S.queues.need(total_records * 8 * (size_t)(1 + w));
+        // (round 6, late: the streams are sized for the records this attempt writes — 12 bytes for compact records (10 behind a direct table: the same room, so that
+        //  a dense and a scattered call of one size share it), 8 (1 + w) otherwise — plus 1/16, rounded up to 2 GB: 18 GB instead of 24.5 per 1e9 rows, and calls
+        //  whose stream counts differ a little do not make the grow-only scratch grow again — every growth is a hipFree + hipMalloc of gigabytes)
+        {
+            size_t qbytes = total_records * (compact ? (size_t)12 : 8 * (size_t)(1 + w)) + 64;
+            qbytes += qbytes / 16;
+            if (qbytes > ((size_t)1 << 30)) qbytes = (qbytes + ((size_t)2 << 30) - 1) & ~(((size_t)2 << 30) - 1);
+            S.queues.need(qbytes);
+        }
         const size_t starts_bytes = (NG * NB + 1) * 8;
         const size_t tabs_bytes = (NG * NB * 8 + 64 + starts_bytes + 15) & ~(size_t)15; // stream counters | flags | stream starts (exact layout)
         const bool peel = n_heavy > 0 && !merge && nv <= 2;
