@@ -1279,9 +1279,16 @@ int vxh_groupby_run_peeled(int key_dtype, const void *keys, int n_values, const 
         long long *keys_sorted = (long long *)res->cols.p;
         hipLaunchKernelGGL(gb_iota, dim3(gb_grid(ng)), dim3(256), 0, slot.stream, iota, ng);
         size_t tmp_bytes = 0;
-        HIP_CHECK(rocprim::radix_sort_pairs(nullptr, tmp_bytes, G.out_key, keys_sorted, iota, perm, ng, 0, 64, slot.stream));
+        // (a known range of non-negative keys: the bits above the largest key are zero in every key — the radix sort takes the digits below only.  1e6 groups
+        //  of 40-bit keys: 5 passes instead of 8)
+        int end_bit = 64;
+        if (key_min <= key_max && key_min >= 0) {
+            end_bit = 1;
+            while (end_bit < 64 && ((uint64_t)key_max >> end_bit)) end_bit++;
+        }
+        HIP_CHECK(rocprim::radix_sort_pairs(nullptr, tmp_bytes, G.out_key, keys_sorted, iota, perm, ng, 0, end_bit, slot.stream));
         S.sort_tmp.need(tmp_bytes + 16);
-        HIP_CHECK(rocprim::radix_sort_pairs(S.sort_tmp.p, tmp_bytes, G.out_key, keys_sorted, iota, perm, ng, 0, 64, slot.stream));
+        HIP_CHECK(rocprim::radix_sort_pairs(S.sort_tmp.p, tmp_bytes, G.out_key, keys_sorted, iota, perm, ng, 0, end_bit, slot.stream));
         for (int k = 0; k < wout; k++)
             hipLaunchKernelGGL(gb_gather, dim3(gb_grid(ng)), dim3(256), 0, slot.stream, G.out_w[k], perm, (uint64_t *)res->cols.p + res->stride * (size_t)(1 + k), ng);
         HIP_CHECK(hipGetLastError());
