@@ -465,6 +465,20 @@ int vxh_groupby_run_ranged(int key_dtype, const void *keys, int n_values, const 
 int vxh_groupby_run_peeled(int key_dtype, const void *keys, int n_values, const void *const *values, const uint8_t *keep, uint64_t n, int mem,
                            uint64_t groups_hint, uint64_t max_groups, int64_t key_min, int64_t key_max, const int64_t *heavy_keys, int n_heavy,
                            vxh_groupby **out);
+/* ... with the filter given as TERMS over the call's own value columns — `df[df.v > 3].groupby(key, agg={'s': vaex.agg.sum('v')})`: vaex
+ * evaluates the filter into a mask per chunk and compacts the chunk before its passes see it (vaex/dataframe.py _filter / vaex/execution.py:515-523,
+ * expression evaluation vaex/scopes.py:138-177); here gb_scatter evaluates the terms on the payload words it loads anyway — no mask pass
+ * in front, no keep byte per row written and read back.  Term t holds when `values[value_index] <op> constant` does (vxh_cmp; float64
+ * comparison with numpy's NaN rules, as the binning kernels' fused selections); the row takes part when bit (outcomes of the terms,
+ * term 0 = bit 0) of `truth` is set — and, if `keep` is given too, its byte is 1.  n_terms = 0: vxh_groupby_run_peeled. */
+typedef struct vxh_groupby_term {
+    int32_t value_index; /* 0 or 1: which of the call's value columns the term reads */
+    int32_t op;          /* vxh_cmp */
+    double constant;
+} vxh_groupby_term;
+int vxh_groupby_run_selected(int key_dtype, const void *keys, int n_values, const void *const *values, const uint8_t *keep, uint64_t n, int mem,
+                             uint64_t groups_hint, uint64_t max_groups, int64_t key_min, int64_t key_max, const int64_t *heavy_keys, int n_heavy,
+                             int n_terms, const vxh_groupby_term *terms, uint32_t truth, vxh_groupby **out);
 /* the same aggregation over PARTIAL results (other chunks', other ranks'): host arrays of n partial groups */
 int vxh_groupby_merge(int n_values, const int64_t *keys, const int64_t *rows, const int64_t *const *counts,
                       const double *const *sums, const double *const *sums2, uint64_t n, uint64_t groups_hint, vxh_groupby **out);

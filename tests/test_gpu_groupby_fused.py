@@ -701,3 +701,113 @@ def test_code_column_makes_key_codes_and_nan_filled_values(sa, gpu_ready, kind):
         if kind.startswith("f"):
             unmasked[np.isnan(data)] = nan_code
         np.testing.assert_array_equal(nomask, unmasked)
+
+
+_NP_CMP = [np.less, np.less_equal, np.greater, np.greater_equal, np.equal, np.not_equal]   # vxh_cmp 0..5
+
+
+def _pred_mask(pred, cols):
+    """numpy's answer for a (terms, truth) pair of vxh_groupby_run_selected"""
+    terms, truth = pred
+    bits = np.zeros(len(cols[0]), dtype=np.uint32)
+    with np.errstate(invalid="ignore"):
+        for t, (vi, op, c) in enumerate(terms):
+            bits |= _NP_CMP[op](cols[vi], np.float64(c)).astype(np.uint32) << t
+    return ((truth >> bits) & 1).astype(bool)
+
+
+@pytest.mark.parametrize("where", ["host", "device"])
+@pytest.mark.parametrize("keys", ["scattered", "dense", "int32", "heavy"])
+def test_groupby_run_selected_terms_over_the_value_columns(sa, gpu_ready, where, keys):
+    """vxh_groupby_run_selected (round 6): the filter as terms over the call's own value columns, evaluated by gb_scatter on the payload it
+    loads — the groups are those of numpy's mask over the same rows: every comparison, NaN / inf / signed zeros in the values, truth tables
+    other than AND, a term per value column, and a keep-mask next to the terms"""
+    import torch
+    rng = np.random.default_rng({"scattered": 1, "dense": 2, "int32": 3, "heavy": 4}[keys])
+    n = 1_200_000
+    if keys == "scattered":
+        k = (rng.integers(0, 150_000, n) * 2654435761) % (1 << 40) - (1 << 39)
+    elif keys == "dense":
+        k = rng.integers(0, 300_000, n)
+    elif keys == "int32":
+        k = rng.integers(-70_000, 70_000, n).astype(np.int32)
+    else:
+        k = np.where(rng.random(n) < 0.4, 12345, rng.integers(0, 50_000, n)).astype(np.int64)
+    v = rng.normal(3, 2, n)
+    v[::311] = np.nan; v[11::977] = 0.0; v[13::977] = -0.0; v[17::977] = 3.0; v[7::1013] = 5e-324   # (no infinities among the VALUES: a group's sum would be inf - inf)
+    w = rng.normal(0, 1, n); w[::401] = np.nan
+    kt = str(k.dtype)
+    put = (lambda a: torch.from_numpy(a).cuda()) if where == "device" else (lambda a: a)
+    dk, dv, dw = put(k), put(v), put(w)
+    kr = (int(k.min()), int(k.max()))
+    heavy = np.array([12345], dtype=np.int64) if keys == "heavy" else None
+    AND2, OR2, ONLY0_NOT1 = 0b1000, 0b1110, 0b0010
+    cases = [([dv], ([(0, op, c)], 0b10)) for op, c in [(0, 3.0), (1, 3.0), (2, 3.0), (3, 3.0), (4, 3.0), (5, 3.0), (4, 0.0), (2, np.inf), (3, -np.inf), (5, np.nan)]]
+    cases += [([dv], ([(0, 2, 1.0), (0, 0, 5.0)], AND2)), ([dv], ([(0, 0, 1.0), (0, 2, 5.0)], OR2)), ([dv], ([(0, 2, 1.0)], 0b01)),
+              ([dv, dw], ([(0, 2, 3.0), (1, 0, 1.0)], AND2)), ([dv, dw], ([(1, 3, 0.0), (0, 1, 2.5)], ONLY0_NOT1)),
+              ([dv, dw], ([(0, 2, 0.0), (1, 2, 0.0), (0, 0, 6.0), (1, 0, 2.0)], 1 << 15))]
+    host = {id(dv): v, id(dw): w}
+    for values, pred in cases:
+        hv = [host[id(a)] for a in values]
+        kept = _pred_mask(pred, hv)
+        for key_range in (None, kr):
+            res = sa.groupby_run(dk, values, _DT[kt], key_range=key_range, heavy=heavy, pred=pred)
+            _check(sa, res, _want(k[kept], [a[kept] for a in hv]))
+    # a keep-mask next to the terms: both must hold (bytes other than 1 do not keep)
+    m = rng.integers(0, 3, n).astype(np.uint8)
+    pred = ([(0, 2, 2.0)], 0b10)
+    res = sa.groupby_run(dk, [dv], _DT[kt], keep=put(m), key_range=kr, heavy=heavy, pred=pred)
+    kept = _pred_mask(pred, [v]) & (m == 1)
+    _check(sa, res, _want(k[kept], [v[kept]]))
+    # nothing kept: no group
+    assert len(sa.groupby_run(dk, [dv], _DT[kt], pred=([(0, 0, -np.inf)], 0b10))) == 0
+    with pytest.raises(RuntimeError, match="groupby"):
+        sa.groupby_run(dk, [dv], _DT[kt], pred=([(1, 2, 0.0)], 0b10))   # (a term over a value column the call does not have)
+
+
+def test_frame_groupby_filter_over_its_value_column_is_evaluated_in_the_pass(sa, gpu_ready):
+    """Frame.groupby(selection=) whose terms all read the aggregated float64 columns: no mask is made (Frame._mask_array is never asked),
+    the result is the keep-mask road's (`groupby_fused_predicate = False`) and numpy's"""
+    import torch
+    from vaex_amd import binned
+    rng = np.random.default_rng(19)
+    n = 1_500_000
+    k = (rng.integers(0, 200_000, n) * 2654435761) % (1 << 40)
+    v = rng.normal(3, 2, n); v[::313] = np.nan
+    w = rng.normal(0, 1, n)
+    x = rng.normal(0, 1, n)
+    spec1 = {"c": binned.agg.count(), "cv": binned.agg.count("v"), "s": binned.agg.sum("v"), "m": binned.agg.mean("v"), "sd": binned.agg.std("v")}
+    for device in (False, True):
+        cols = dict(k=k, v=v, w=w, x=x)
+        if device:
+            cols = {c: torch.from_numpy(a).cuda() for c, a in cols.items()}
+        for selection, kept in [("(v > 1) & (v < 5)", (v > 1) & (v < 5)), ("v >= 3", v >= 3), ("~(v < 2)", ~(v < 2)), ("(v > 4) | (v < 0)", (v > 4) | (v < 0)), ("v > 2", v > 2)]:
+            f = binned.Frame(cols, superagg=sa)
+            f.last_groupby_info = None
+            asked = []
+            real = f._mask_array
+            f._mask_array = lambda s, real=real: (asked.append(s), real(s))[1]
+            got = f.groupby("k", spec1, selection=selection)
+            assert f.last_groupby_info is not None, "the fused pass did not run"
+            assert not asked, "a keep-mask was made for a filter over the value column"
+            want = _want(k[kept], [v[kept]])
+            np.testing.assert_array_equal(got["k"], want["k"]); np.testing.assert_array_equal(got["c"], want["rows"]); np.testing.assert_array_equal(got["cv"], want["v"][0]["cnt"])
+            assert np.all(np.abs(got["s"] - want["v"][0]["s"]) <= 1e-12 * want["v"][0]["sabs"])
+            plain = binned.Frame(cols, superagg=sa)
+            plain.groupby_fused_predicate = False
+            ref = plain.groupby("k", spec1, selection=selection)
+            for name in got:   # the same rows in the same pass (its LDS atomics add in an order of their own: the float columns agree to rounding)
+                if np.asarray(got[name]).dtype.kind == "f":
+                    np.testing.assert_allclose(np.asarray(got[name]), np.asarray(ref[name]), rtol=1e-6 if name == "sd" else 1e-10, atol=0, equal_nan=True)   # (std: sum2 / n - mean^2 cancels)
+                else:
+                    np.testing.assert_array_equal(np.asarray(got[name]), np.asarray(ref[name]))
+        # a term over a column that is not aggregated, or an arithmetic term: the keep-mask road as before
+        for selection, kept in [("(v > 1) & (x < 0.5)", (v > 1) & (x < 0.5)), ("2 * v + 1 > 6", 2 * v + 1 > 6)]:
+            f = binned.Frame(cols, superagg=sa)
+            asked = []
+            real = f._mask_array
+            f._mask_array = lambda s, real=real: (asked.append(s), real(s))[1]
+            got = f.groupby("k", spec1, selection=selection)
+            assert asked
+            want = _want(k[kept], [v[kept]])
+            np.testing.assert_array_equal(got["k"], want["k"]); np.testing.assert_array_equal(got["c"], want["rows"])

@@ -330,7 +330,8 @@ filtered = [
 ]
 if gpu:
     filtered += [(df[df.v > 2], ["k", "k32"], {"c": A.count(), "s": A.sum("v")}, {}),
-                 (df[df.i > 0], "ks", {"s": A.sum("v"), "c": A.count(), "m": A.mean("v")}, {})]                          # scattered keys: the hash binner + presence count
+                 (df[df.i > 0], "ks", {"s": A.sum("v"), "c": A.count(), "m": A.mean("v")}, {}),                          # scattered keys: the hash binner + presence count
+                 (df[(df.v > 2) & (df.v < 6)], "ks", {"s": A.sum("v"), "c": A.count(), "sd": A.std("v")}, {})]             # the filter reads the aggregated column: its terms ride inside gb_scatter
 for d, by, agg, kw in filtered:
     vg.last.clear()
     got = d.groupby(by, agg=agg, **kw)
@@ -342,6 +343,7 @@ for d, by, agg, kw in filtered:
         assert np.array_equal(np.ma.getdata(got[keys[0]].to_numpy()), np.ma.getdata(want[keys[0]].to_numpy())), (by, kw)
     print("ok-device-filtered", by, len(got), vg.last.get("kernel"))
     assert by != "ks" or vg.last.get("kernel") == "gb_scatter+gb_reduce", vg.last   # (scattered keys: the fused hash aggregation with the filter as its keep-mask)
+    assert not (by == "ks" and "sd" in agg) or (vg.last.get("info") or {}).get("selection_in_pass") == 2, vg.last   # (... or as two terms over the payload, vxh_groupby_run_selected)
 vg.last.clear(); df[(df.k * 2) > 3].groupby("k", agg="count"); assert vg.last.get("path") == "vaex" and "filter outside" in vg.last["why"], vg.last
 vg.last.clear(); df.dropnan(column_names=["v"]).groupby("k", agg="count"); assert vg.last.get("path") == "vaex" and "filter outside" in vg.last["why"], vg.last
 # without agg: a GroupBy whose groupers are only built when something other than a device-servable .agg() is asked of it
@@ -561,6 +563,6 @@ def test_groupby_host_logic_against_vaex_on_the_reference_cpp():
 @pytest.mark.skipif(not os.path.isdir(os.path.join(PKG, "vaex")), reason="real vaex package not built (oracle/build_ref.sh needs /root/reference)")
 def test_groupby_of_real_vaex_runs_on_the_device_groupby():
     out = _run(1, 900)
-    assert "DONE" in out and out.count("ok-device ") == 34 and out.count("ok-device-filtered") == 7 and out.count("ok-declined") == 8 and out.count("ok-task") == 9, out
+    assert "DONE" in out and out.count("ok-device ") == 34 and out.count("ok-device-filtered") == 8 and out.count("ok-declined") == 8 and out.count("ok-task") == 9, out
     assert out.count("ok-general") == 5 and "declined here" not in out, out   # (round 6, late: categorical / missing-value / float keys, binner objects — all on the device)
     assert "gb_scatter+gb_reduce" in out and "bin_lds" in out and out.count("ok-streamed") == 6, out   # (the fused hash aggregation, and — few groups — the LDS-resident grid)

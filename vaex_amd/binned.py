@@ -1133,6 +1133,34 @@ class Frame:
             out_keys, vals = out_keys[present], [np.asarray(v)[present] for v in vals[:-1]]
         return {by: out_keys, **dict(zip(names, vals))}
 
+    #: False: a filter over the groupby's own value columns goes through the keep-mask like any other (tests / timing comparison)
+    groupby_fused_predicate = True
+
+    def _groupby_pred_terms(self, selection, vcols):
+        """([(value index, op, constant), ...], truth) when `selection` is a predicate of 1..4 plain terms `column <op> constant` whose
+        columns are all among the first two float64 value columns `vcols` of the fused groupby — what vxh_groupby_run_selected evaluates
+        inside gb_scatter — else None (arithmetic terms, other columns, a ready-made mask: the keep-mask road)."""
+        if not self.groupby_fused_predicate or not getattr(self.sa, "GROUPBY_PRED", 0):
+            return None
+        try:
+            sel = self._selection_mask(selection)
+        except _predicate.Unsupported:
+            return None
+        if not isinstance(sel, _predicate.Predicate) or sel.programs or not 1 <= len(sel.terms) <= 4:
+            return None
+        terms = []
+        for c, op, value in sel.terms:
+            name = sel.columns[c]
+            if name not in vcols[:2] or isinstance(value, bool):
+                return None
+            col = self.columns[name]
+            if np.ma.isMaskedArray(col) or str(col.dtype).replace("torch.", "") != "float64":
+                return None
+            if isinstance(value, int) and abs(value) >= 2 ** 63:   # (the device selections take integer constants as int64 first: sel_eval's rule)
+                return None
+            terms.append((vcols.index(name), int(op), float(value)))
+        return terms, int(sel.truth)
+
     def _groupby_fused(self, by, pf, descs, names, comm, key_range=None, filter_sel=None):
         """the vxh_groupby_run path, or None when the call is outside its signature (then: ordered_set + BinnerHash).
 
@@ -1180,7 +1208,11 @@ class Frame:
             vcols = ["__payload__"]
             values = [key if _is_device(key) else np.ascontiguousarray(key)]
         keep = None
-        if shared is not None:
+        # Round 6 (late): a filter whose terms all read the pass's own float64 value columns (`df[df.v > 3].groupby(k, agg=sum(v))`) is evaluated
+        # by gb_scatter on the payload words it loads anyway (vxh_groupby_run_selected) — no sel_eval pass in front, no keep byte per row.
+        # (What the terms are depends on the call alone, not on a rank's rows: every rank takes the same branch.)
+        pred = self._groupby_pred_terms(shared, vcols) if shared is not None and self.one_kernel_peel else None   # (the three-pass peel behind the knob works on masks)
+        if shared is not None and pred is None:
             keep = self._mask_array(shared)
             usable = keep is not None and _is_device(keep) == _is_device(key)
             # (what a rank's mask turns out to be is rank-local; leaving alone here would strand the other ranks in the pass's
@@ -1227,15 +1259,16 @@ class Frame:
         # the number of groups of an earlier call over the same key column (remembered like the key range): the pass sizes its
         # bucket tables for a known count at 80 % load instead of a guessed 2^20 at 50 % — half the buckets for 1e6 keys
         seen = self.__dict__.setdefault("_group_count_cache", {}).get(by)
-        hint = int(seen[1]) if _memo_hit(seen, key) and keep is None else 0
+        hint = int(seen[1]) if _memo_hit(seen, key) and keep is None and pred is None else 0
         if heavy is not None:
             hint = 0   # (skewed keys: as many buckets as the default gives — the light keys are still uneven, and a bucket is one workgroup's work)
         try:
             # (the measured key range: where it leaves a remainder of <= 32 bits below the bucket bits, the pass moves 12-byte records)
             kr = None if key_range is None or key_range[0] > key_range[1] else (int(key_range[0]), int(key_range[1]))
-            res = (sa.groupby_run(key if _is_device(key) else np.ascontiguousarray(key), values, _DT_CODE[pf], keep=keep, key_range=kr, heavy=heavy) if keep is not None else
+            res = (sa.groupby_run(key if _is_device(key) else np.ascontiguousarray(key), values, _DT_CODE[pf], key_range=kr, heavy=heavy, pred=pred) if pred is not None else
+                   sa.groupby_run(key if _is_device(key) else np.ascontiguousarray(key), values, _DT_CODE[pf], keep=keep, key_range=kr, heavy=heavy) if keep is not None else
                    sa.groupby_run(key if _is_device(key) else np.ascontiguousarray(key), values, _DT_CODE[pf], hint, key_range=kr, heavy=heavy)) if self.n else None
-            if res is not None and keep is None:
+            if res is not None and keep is None and pred is None:
                 self.__dict__["_group_count_cache"][by] = _memo(key, len(res))
             peeled_here = int(res.info().get("heavy_keys_in_pass", 0)) if res is not None else 0
         except RuntimeError as e:
@@ -1267,6 +1300,8 @@ class Frame:
             else:
                 out[name] = np.asarray(res.column(which[d.name], vcols.index(d.column)))
         self.last_groupby_info = res.info()
+        if pred is not None:
+            self.last_groupby_info.update(selection_in_pass=len(pred[0]))   # (the filter's terms were evaluated by gb_scatter: no keep-mask)
         if heavy is not None:
             self.last_groupby_info.update(heavy_keys=peeled_here)   # (of THIS rank's pass; a cross-rank merge has none)
         return out

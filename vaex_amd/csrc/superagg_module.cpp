@@ -1044,7 +1044,15 @@ PYBIND11_MODULE(superagg, m) {
         return out;
     }, py::arg("keys"), py::arg("key_dtype") = (int)VXH_I64, py::arg("sample") = 1u << 17, py::arg("min_count") = 8, py::arg("max_keys") = 128,
        "heavy hitters of a device-resident integer key column from a strided sample (vxh_sample_heavy_keys)");
-    m.def("groupby_run", [](const py::object &keys, const std::vector<py::object> &values, int key_dtype, uint64_t hint, uint64_t max_groups, const py::object &keep, const py::object &key_range, const py::object &heavy) {
+    m.def("groupby_run", [](const py::object &keys, const std::vector<py::object> &values, int key_dtype, uint64_t hint, uint64_t max_groups, const py::object &keep, const py::object &key_range, const py::object &heavy, const py::object &pred) {
+        // pred = ([(value index, vxh_cmp op, constant), ...], truth): the filter as terms over the call's own value columns (vxh_groupby_run_selected)
+        std::vector<vxh_groupby_term> terms;
+        uint32_t truth = 0;
+        if (!pred.is_none()) {
+            auto pr = pred.cast<std::pair<std::vector<std::tuple<int, int, double>>, uint32_t>>();
+            for (auto &t : pr.first) terms.push_back(vxh_groupby_term{std::get<0>(t), std::get<1>(t), std::get<2>(t)});
+            truth = pr.second;
+        }
         std::vector<int64_t> hv; // heavy keys peeled inside the pass (vxh_groupby_run_peeled)
         if (!heavy.is_none()) for (auto item : py::array_t<int64_t, py::array::c_style | py::array::forcecast>::ensure(heavy).cast<std::vector<int64_t>>()) hv.push_back(item);
         int64_t key_min = 1, key_max = 0; // (unknown)
@@ -1072,11 +1080,14 @@ PYBIND11_MODULE(superagg, m) {
         int rc;
         {
             py::gil_scoped_release release;
-            rc = vxh_groupby_run_peeled(key_dtype, k.ptr, (int)vp.size(), vp.data(), keep_ptr, k.n, k.mem, hint, max_groups, key_min, key_max, hv.data(), (int)hv.size(), &res->h);
+            rc = vxh_groupby_run_selected(key_dtype, k.ptr, (int)vp.size(), vp.data(), keep_ptr, k.n, k.mem, hint, max_groups, key_min, key_max, hv.data(), (int)hv.size(),
+                                          (int)terms.size(), terms.data(), truth, &res->h);
         }
         check(rc);
         return res;
-    }, py::arg("keys"), py::arg("values"), py::arg("key_dtype") = (int)VXH_I64, py::arg("groups_hint") = 0, py::arg("max_groups") = 0, py::arg("keep") = py::none(), py::arg("key_range") = py::none(), py::arg("heavy") = py::none());
+    }, py::arg("keys"), py::arg("values"), py::arg("key_dtype") = (int)VXH_I64, py::arg("groups_hint") = 0, py::arg("max_groups") = 0, py::arg("keep") = py::none(), py::arg("key_range") = py::none(), py::arg("heavy") = py::none(),
+       py::arg("pred") = py::none());
+    m.attr("GROUPBY_PRED") = 1; // groupby_run takes `pred`
     // groupby_merge(keys, rows, [count_j], [sum_j], [sum2_j]): partial results (host arrays) -> one result
     m.def("groupby_merge", [](py::array_t<int64_t, py::array::c_style | py::array::forcecast> keys, py::array_t<int64_t, py::array::c_style | py::array::forcecast> rows,
                               const std::vector<py::array_t<int64_t, py::array::c_style | py::array::forcecast>> &counts,

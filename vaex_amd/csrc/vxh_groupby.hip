@@ -88,12 +88,31 @@ __device__ __forceinline__ long long gb_fix_key(long long raw, int dt) {
     }
 }
 
+// the filter's terms on a row's value columns (GbArgs::pred; the rule of vxh_kernels.hip pred_keep2 / vxh_select.hip cmp_f64: a term
+// `x <op> c` holds iff bit (relation of x to c: 0 less, 1 equal, 2 greater, 3 unordered) of its code is set — numpy's NaN rules)
+__device__ __forceinline__ bool gb_pred_keep(const PredDesc &Q, double x0, double x1) {
+    uint32_t bits = 0;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        if (t < Q.nterms) {
+            const double c = Q.c[t], x = Q.tcol[t] ? x1 : x0;
+            const uint32_t rel = x < c ? 0u : (x == c ? 1u : (x > c ? 2u : 3u));
+            bits |= ((Q.code[t] >> rel) & 1u) << t;
+        }
+    }
+    return ((Q.truth >> bits) & 1u) != 0u;
+}
+
 struct GbArgs {
     // input rows
     const void *keys;
     int32_t key_dtype, nv, w, merge; // w payload words per record; merge: payload = partial results (rows, count, sum, sum2 ...)
     const uint64_t *payload[GB_MAX_W]; // RAW: the value columns (float64 bits); MERGE: rows, count_0, sum_0, sum2_0, ...
     const uint8_t *keep;               // RAW: one byte per row, 1 = the row takes part (a filter / selection over the whole call), or null
+    // RAW (round 6, late): the filter as TERMS over the pass's own value columns (vxh_groupby_run_selected) — `pred.on`; term t reads value
+    // column pred.tcol[t] (pred.col / col2 are unused: the payload words the row carries anyway are the columns).  gb_scatter evaluates
+    // it on the rows it loads: no sel_eval pass in front, no keep byte written and read back.  With `keep` as well: both must hold.
+    PredDesc pred;
     uint64_t n;
     // Queues (round 4, late): `ng` SETS of NB record streams; workgroup w appends to the streams of set w % ng — blocks are dealt to
     // the 8 XCDs round robin, so with ng = 8 the 32 workgroups of ONE XCD share a set.  Every tile's segment of a stream is reserved
@@ -258,7 +277,7 @@ __global__ void __launch_bounds__(1024) gb_scatter(const GbArgs G) {
             }
             return;
         }
-        if (KEEP) {
+        if (KEEP && G.keep) { // (KEEP without a mask: the filter is G.pred alone)
 #pragma unroll
             for (int r = 0; r < R; ++r) b[r] = G.keep[ic[r]]; // (a row outside the filter leaves no record: a group without a row inside does not exist)
         }
@@ -297,6 +316,7 @@ __global__ void __launch_bounds__(1024) gb_scatter(const GbArgs G) {
         for (int r = 0; r < R; ++r) {
             if (!K64) key[r] = gb_fix_key(key[r], G.key_dtype);
             if (KEEP) ok[r] = ok[r] && kb[r] == 1u;
+            if (KEEP && G.pred.on) ok[r] = ok[r] && gb_pred_keep(G.pred, __longlong_as_double((long long)pay[0][r]), __longlong_as_double((long long)pay[W > 1 ? 1 : 0][r]));
             if (HEAVY) { // a heavy key's row goes to the workgroup's partials and leaves no record
                 const unsigned long long k = (unsigned long long)key[r];
                 uint32_t sl = heavy_home(k), h = 0xffffffffu;
@@ -966,7 +986,7 @@ void launch_scatter(const GbArgs &G, int blocks, hipStream_t st) {
     const bool heavy = CAN_PEEL && G.n_heavy > 0 && !G.merge;
     const size_t lds = scatter_lds<W, R>(G.nb_log2) + (heavy ? gb_heavy_lds(W) : 0);
     if (lds > GB_LDS_MAX) throw std::runtime_error("groupby: internal: gb_scatter staging exceeds the LDS");
-    const bool k64 = G.key_dtype == VXH_I64 || G.key_dtype == VXH_U64, keep = G.keep != nullptr;
+    const bool k64 = G.key_dtype == VXH_I64 || G.key_dtype == VXH_U64, keep = G.keep != nullptr || G.pred.on;
     if (heavy) {
         if (k64) { if (keep) launch_scatter_as<W, R, true, true, CAN_PEEL>(G, blocks, lds, st); else launch_scatter_as<W, R, true, false, CAN_PEEL>(G, blocks, lds, st); }
         else { if (keep) launch_scatter_as<W, R, false, true, CAN_PEEL>(G, blocks, lds, st); else launch_scatter_as<W, R, false, false, CAN_PEEL>(G, blocks, lds, st); }
@@ -1203,7 +1223,27 @@ int vxh_groupby_run_ranged(int key_dtype, const void *keys, int n_values, const 
 
 int vxh_groupby_run_peeled(int key_dtype, const void *keys, int n_values, const void *const *values, const uint8_t *keep, uint64_t n, int mem, uint64_t groups_hint, uint64_t max_groups,
                            int64_t key_min, int64_t key_max, const int64_t *heavy_keys, int n_heavy, vxh_groupby **out) {
+    return vxh_groupby_run_selected(key_dtype, keys, n_values, values, keep, n, mem, groups_hint, max_groups, key_min, key_max, heavy_keys, n_heavy, 0, nullptr, 0, out);
+}
+
+int vxh_groupby_run_selected(int key_dtype, const void *keys, int n_values, const void *const *values, const uint8_t *keep, uint64_t n, int mem, uint64_t groups_hint, uint64_t max_groups,
+                             int64_t key_min, int64_t key_max, const int64_t *heavy_keys, int n_heavy, int n_terms, const vxh_groupby_term *terms, uint32_t truth, vxh_groupby **out) {
     GB_BEGIN
+    // the filter's terms over the call's own value columns (gb_scatter evaluates them on the payload words of the rows it loads)
+    PredDesc pred{};
+    if (n_terms < 0 || n_terms > 4 || (n_terms > 0 && !terms)) throw std::runtime_error("groupby: 0 to 4 selection terms");
+    for (int t = 0; t < n_terms; t++) {
+        static const uint32_t rel_code[6] = {/*LT*/ 1u, /*LE*/ 3u, /*GT*/ 4u, /*GE*/ 6u, /*EQ*/ 2u, /*NE*/ 13u}; // bits: 0 less, 1 equal, 2 greater, 3 unordered (as vxh_grid_bin's fused selections)
+        if (terms[t].op < VXH_CMP_LT || terms[t].op > VXH_CMP_NE) throw std::runtime_error("groupby: unknown comparison in a selection term");
+        if (terms[t].value_index < 0 || terms[t].value_index >= n_values || terms[t].value_index > 1) throw std::runtime_error("groupby: a selection term reads one of the call's (first two) value columns");
+        pred.code[t] = rel_code[terms[t].op - VXH_CMP_LT];
+        pred.op[t] = terms[t].op;
+        pred.c[t] = terms[t].constant;
+        pred.tcol[t] = (uint8_t)terms[t].value_index;
+    }
+    pred.on = n_terms > 0;
+    pred.nterms = n_terms;
+    pred.truth = truth;
     // the heavy keys as the pass wants them: distinct, none the table's EMPTY marker, at most GB_HEAVY_MAX (more: the first ones — a
     // heavy key that is not peeled only costs time)
     std::vector<long long> heavy;
@@ -1233,6 +1273,7 @@ int vxh_groupby_run_peeled(int key_dtype, const void *keys, int n_values, const 
     const size_t ks = (size_t)vxh_dtype_size(key_dtype);
     GbArgs G{};
     G.key_dtype = key_dtype;
+    G.pred = pred;
     if (mem == VXH_MEM_DEVICE) {
         order_after_producers(slot);
         G.keys = keys;
