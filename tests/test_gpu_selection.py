@@ -410,3 +410,45 @@ def test_random_calls_with_predicates_over_every_column_kind_and_kernel_form(blo
     finally:
         for k, val in defaults.items():
             sa.config_set(k, val)
+
+
+@pytest.mark.parametrize("ncols", [1, 2, 3, 4])
+def test_the_float64_form_of_sel_eval_keeps_the_rows_numpy_keeps(ncols):
+    """round 6 (late): selections whose terms all compare float64 columns with constants take sel_eval_f64 (whole quads of rows, every load
+    issued before the first comparison) — the same bytes as numpy for every length around a quad, for columns that start off a 16-byte
+    boundary (those go through the generic kernel), for NaN / signed zeros / infinities, with every comparison and truth table"""
+    import torch
+    import vaex_amd
+    sa = vaex_amd.superagg
+    rng = np.random.default_rng(40 + ncols)
+    ops = [np.less, np.less_equal, np.greater, np.greater_equal, np.equal, np.not_equal]
+    for n in (1, 3, 4, 5, 7, 8, 1023, 1024, 100_003, 3_000_001):
+        for offset in (0, 1):   # (1: the columns start 8 bytes off a 16-byte boundary)
+            host = []
+            for c in range(ncols):
+                a = rng.normal(0, 1, n + offset)
+                a[rng.random(n + offset) < 0.05] = np.nan
+                a[rng.random(n + offset) < 0.05] = 0.0
+                a[rng.random(n + offset) < 0.02] = -0.0
+                a[rng.random(n + offset) < 0.01] = np.inf
+                a[rng.random(n + offset) < 0.01] = -np.inf
+                host.append(a)
+            dev = [torch.from_numpy(a).cuda()[offset:] for a in host]
+            host = [a[offset:] for a in host]
+            for trial in range(6):
+                nterms = int(rng.integers(max(1, ncols), 5))
+                cols_of = list(range(ncols)) + [int(rng.integers(0, ncols)) for _ in range(nterms - ncols)]   # every column is read by a term
+                terms = [(cols_of[t], int(rng.integers(0, 6)), float(rng.choice([0.0, -0.0, 0.5, -1.0, np.inf, -np.inf, np.nan, 1e-300]))) for t in range(nterms)]
+                truth = int(rng.integers(0, 1 << (1 << nterms)))
+                sel = sa.Selection(1, [0] * ncols, terms, truth)
+                for c in range(ncols):
+                    sel.set_data(0, c, dev[c])
+                out = torch.full(((n + 3) & ~3,), 7, dtype=torch.uint8, device="cuda")
+                sel.evaluate(0, n, out)
+                sa.slot_wait(0)
+                bits = np.zeros(n, dtype=np.uint32)
+                with np.errstate(invalid="ignore"):
+                    for t, (c, op, value) in enumerate(terms):
+                        bits |= ops[op](host[c], np.float64(value)).astype(np.uint32) << t
+                want = ((truth >> bits) & 1).astype(np.uint8)
+                np.testing.assert_array_equal(out[:n].cpu().numpy(), want, err_msg=f"n={n} offset={offset} terms={terms} truth={truth}")

@@ -115,6 +115,77 @@ __global__ __launch_bounds__(256) void sel_eval(SelArgs A) {
     }
 }
 
+// The same mask where every term compares a float64 column as it is with a constant (no program) — what filters and selections mostly are
+// (round 6, late: the generic kernel above loads one row at a time behind a dtype switch, every load waited for by its comparison:
+// 2.95 ms per 1e9 rows x one column = 3.0 TB/s of its 9 bytes a row, profiles/r06_groupby_predicate.txt).  A lane takes U quads of four
+// consecutive rows a round; the 16-byte loads of ALL of them (NC columns, clamped to the last quad so that none is conditional) are issued
+// before the first comparison; one 4-byte store of mask bytes per quad.  The rows behind the last full quad go one by one.
+template <int NC, int U>
+__global__ __launch_bounds__(256) void sel_eval_f64(SelArgs A) {
+    const uint64_t quads = A.n / 4, stride = (uint64_t)gridDim.x * 256u;
+    for (uint64_t q0 = (uint64_t)blockIdx.x * 256u + threadIdx.x; q0 < quads; q0 += stride * U) {
+        double x[NC][U][4];
+        uint32_t am[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint64_t q = q0 + (uint64_t)u * stride, qc = q < quads ? q : quads - 1;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const double2 *p = (const double2 *)((const double *)A.col[c] + qc * 4);
+                const double2 lo = p[0], hi = p[1];
+                x[c][u][0] = lo.x; x[c][u][1] = lo.y; x[c][u][2] = hi.x; x[c][u][3] = hi.y;
+            }
+            am[u] = A.and_mask ? *(const uint32_t *)(A.and_mask + qc * 4) : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint64_t q = q0 + (uint64_t)u * stride;
+            if (q < quads) {
+                uint32_t packed = 0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    uint32_t bits = 0;
+#pragma unroll
+                    for (int t = 0; t < VXH_SEL_MAX_TERMS; ++t) {
+                        if (t < A.nterms) {
+                            double v = x[0][u][r];
+#pragma unroll
+                            for (int c = 1; c < NC; ++c) v = A.t[t].column == c ? x[c][u][r] : v; // (wave-uniform)
+                            bits |= (cmp_f64(v, A.t[t].op, A.t[t].value) ? 1u : 0u) << t;
+                        }
+                    }
+                    uint32_t keep = (A.truth >> bits) & 1u;
+                    if (A.and_mask) keep &= ((am[u] >> (8 * r)) & 0xffu) != 0u ? 1u : 0u;
+                    packed |= keep << (8 * r);
+                }
+                *(uint32_t *)(A.out + q * 4) = packed; // (out is 256-byte aligned scratch)
+            }
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (uint32_t)(A.n & 3u)) {
+        const uint64_t i = quads * 4 + threadIdx.x;
+        uint32_t bits = 0;
+        for (int t = 0; t < A.nterms; t++) bits |= (term_at(A, t, i) ? 1u : 0u) << t;
+        uint32_t keep = (A.truth >> bits) & 1u;
+        if (A.and_mask) keep &= A.and_mask[i] != 0 ? 1u : 0u;
+        A.out[i] = (uint8_t)keep;
+    }
+}
+// number of columns the fast form would read (1..4), or 0 when the selection is not of its kind
+static int sel_eval_f64_columns(const SelArgs &A) {
+    if (A.nterms < 1 || A.nterms > VXH_SEL_MAX_TERMS || A.n < 4) return 0;
+    int nc = 0;
+    for (int t = 0; t < A.nterms; t++) {
+        const int c = A.t[t].column;
+        if (A.nsteps[t] > 0 || c < 0 || c >= VXH_SEL_MAX_COLUMNS || A.dtype[c] != VXH_F64) return 0;
+        nc = std::max(nc, c + 1);
+    }
+    for (int c = 0; c < nc; c++) // (a column no term reads is loaded all the same: it must be one)
+        if (!A.col[c] || A.dtype[c] != VXH_F64 || ((uintptr_t)A.col[c] & 15u)) return 0;
+    if (((uintptr_t)A.and_mask & 3u) || ((uintptr_t)A.out & 3u)) return 0;
+    return nc;
+}
+
 // packed group key of a multi-key groupby: sum_i (key_i - min_i) * multiplier_i as int64 — the expression vaex's
 // GrouperCombined builds out of its parents' ordinals (vaex/groupby.py:526-584 `_combine`)
 __device__ __forceinline__ int64_t load_i64(const void *p, int dtype, uint64_t i) {
@@ -312,6 +383,13 @@ void vxh_launch_sel_eval(const SelArgs &A, hipStream_t stream) {
     if (!A.n) return;
     const uint64_t quads = (A.n + 3) / 4;
     const int blocks = (int)std::min<uint64_t>((quads + 255) / 256, 256 * 16);
+    switch (sel_eval_f64_columns(A)) {
+    case 1: hipLaunchKernelGGL((sel_eval_f64<1, 4>), dim3(blocks), dim3(256), 0, stream, A); return;
+    case 2: hipLaunchKernelGGL((sel_eval_f64<2, 2>), dim3(blocks), dim3(256), 0, stream, A); return;
+    case 3: hipLaunchKernelGGL((sel_eval_f64<3, 1>), dim3(blocks), dim3(256), 0, stream, A); return;
+    case 4: hipLaunchKernelGGL((sel_eval_f64<4, 1>), dim3(blocks), dim3(256), 0, stream, A); return;
+    default: break;
+    }
     hipLaunchKernelGGL(sel_eval, dim3(blocks), dim3(256), 0, stream, A);
 }
 
