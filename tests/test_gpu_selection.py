@@ -413,9 +413,9 @@ def test_random_calls_with_predicates_over_every_column_kind_and_kernel_form(blo
 
 
 @pytest.mark.parametrize("ncols", [1, 2, 3, 4])
-def test_the_float64_form_of_sel_eval_keeps_the_rows_numpy_keeps(ncols):
-    """round 6 (late): selections whose terms all compare float64 columns with constants take sel_eval_f64 (whole quads of rows, every load
-    issued before the first comparison) — the same bytes as numpy for every length around a quad, for columns that start off a 16-byte
+def test_the_quad_form_of_sel_eval_keeps_the_rows_numpy_keeps(ncols):
+    """round 6 (late): selections whose terms all compare columns with constants take sel_eval_vec (whole quads of rows, every load
+    issued before the first comparison; one or two columns — more go through the generic kernel) — here float64 columns: the same bytes as numpy for every length around a quad, for columns that start off a 16-byte
     boundary (those go through the generic kernel), for NaN / signed zeros / infinities, with every comparison and truth table"""
     import torch
     import vaex_amd
@@ -452,3 +452,54 @@ def test_the_float64_form_of_sel_eval_keeps_the_rows_numpy_keeps(ncols):
                         bits |= ops[op](host[c], np.float64(value)).astype(np.uint32) << t
                 want = ((truth >> bits) & 1).astype(np.uint8)
                 np.testing.assert_array_equal(out[:n].cpu().numpy(), want, err_msg=f"n={n} offset={offset} terms={terms} truth={truth}")
+
+
+def test_the_quad_form_of_sel_eval_is_the_generic_kernel_for_every_dtype():
+    """sel_eval_vec compares from registers by the generic kernel's own rule (term_cmp_bits): the same selection over the same values held
+    ONE ELEMENT off the quad form's alignment goes through the generic kernel — the two masks are the same bytes, for every column dtype,
+    integer and float constants, one and two columns, with and without the missing-value mask behind it"""
+    import torch
+    import vaex_amd
+    sa = vaex_amd.superagg
+    rng = np.random.default_rng(77)
+    kinds = [("float64", 0), ("float32", 1), ("int64", 2), ("int32", 3), ("int16", 4), ("int8", 5), ("uint64", 6), ("uint32", 7), ("uint16", 8), ("uint8", 9), ("bool", 10)]
+
+    def column(kind, n):
+        if kind.startswith("float"):
+            a = rng.normal(0, 2, n).astype(kind)
+            a[rng.random(n) < 0.05] = np.nan
+            a[rng.random(n) < 0.05] = 0.0
+            return a
+        if kind == "bool":
+            return rng.random(n) < 0.5
+        info = np.iinfo(kind)
+        a = rng.integers(max(info.min, -4), min(info.max, 4) + 1, n).astype(kind)
+        a[rng.random(n) < 0.02] = info.max
+        a[rng.random(n) < 0.02] = info.min
+        return a
+    checked = 0
+    for trial in range(120):
+        ncols = 1 + trial % 2
+        n = int(rng.choice([4, 5, 63, 1024, 100_003, 1_000_001]))
+        picked = [kinds[int(rng.integers(0, len(kinds)))] for _ in range(ncols)]
+        host = [column(k, n + 1) for k, _ in picked]
+        on_quads = [torch.from_numpy(a[1:].copy()).cuda() for a in host]       # (fresh allocations: aligned)
+        off_quads = [torch.from_numpy(a).cuda()[1:] for a in host]              # (the same values one element further)
+        nterms = int(rng.integers(ncols, 5))
+        cols_of = list(range(ncols)) + [int(rng.integers(0, ncols)) for _ in range(nterms - ncols)]
+        consts = [0, 1, -1, 2, 3, -4, 127, -128, 255, 65535, 2 ** 31 - 1, -2 ** 31, 2 ** 63 - 1, -2 ** 63, 0.0, 0.5, -1.5, 2.0, float("nan"), float("inf"), 1e-3]
+        terms = [(cols_of[t], int(rng.integers(0, 6)), consts[int(rng.integers(0, len(consts)))]) for t in range(nterms)]
+        truth = int(rng.integers(0, 1 << (1 << nterms)))
+        outs = []
+        for cols in (on_quads, off_quads):
+            sel = sa.Selection(1, [code for _, code in picked], terms, truth)
+            for c in range(ncols):
+                sel.set_data(0, c, cols[c])
+            out = torch.full(((n + 3) & ~3,), 9, dtype=torch.uint8, device="cuda")
+            sel.evaluate(0, n, out)
+            sa.slot_wait(0)
+            outs.append(out[:n].cpu().numpy())
+        np.testing.assert_array_equal(outs[0], outs[1], err_msg=f"n={n} dtypes={[k for k, _ in picked]} terms={terms} truth={truth}")
+        assert set(np.unique(outs[0])) <= {0, 1}
+        checked += 1
+    assert checked == 120

@@ -12,6 +12,7 @@
 // (the constant is rounded first: `f4 <= 0.3` holds for float32(0.3), as in numpy).
 #include "vxh_internal.hpp"
 #include "vxh_kernels.hpp"
+#include <type_traits>
 
 namespace {
 
@@ -66,31 +67,52 @@ __device__ __forceinline__ double eval_program(const SelArgs &A, int t, uint64_t
     return s0;
 }
 
+__device__ __forceinline__ bool term_cmp(const SelTerm &T, int dtype, const void *p, uint64_t i);
 __device__ __forceinline__ bool term_at(const SelArgs &A, int t, uint64_t i) {
     const SelTerm &T = A.t[t];
     if (A.nsteps[t] > 0) return cmp_f64(eval_program(A, t, i), T.op, T.value);
-    const void *p = A.col[T.column];
+    return term_cmp(T, A.dtype[T.column], A.col[T.column], i);
+}
+// an element of a column of `dtype`, given as its bytes (zero-extended), against the term's constant
+__device__ __forceinline__ bool term_cmp_bits(const SelTerm &T, int dtype, uint64_t b) {
     const int op = T.op;
-    switch (A.dtype[T.column]) {
-    case VXH_F64: return cmp_f64(((const double *)p)[i], op, T.value);
-    case VXH_F32: return cmp_f64((double)((const float *)p)[i], op, (double)(float)T.value); // numpy compares a float32 column with the constant ROUNDED to float32
-    case VXH_I64: {
-        const int64_t x = ((const int64_t *)p)[i];
-        return T.is_int ? cmp_int<int64_t>(x, op, T.ivalue) : cmp_f64((double)x, op, T.value);
-    }
+    switch (dtype) {
+    case VXH_F64: return cmp_f64(__longlong_as_double((long long)b), op, T.value);
+    case VXH_F32: return cmp_f64((double)__uint_as_float((uint32_t)b), op, (double)(float)T.value); // numpy compares a float32 column with the constant ROUNDED to float32
     case VXH_U64: {
-        const uint64_t x = ((const uint64_t *)p)[i];
+        const uint64_t x = b;
         if (!T.is_int) return cmp_f64((double)x, op, T.value);
         if (T.ivalue < 0) return op == VXH_CMP_GT || op == VXH_CMP_GE || op == VXH_CMP_NE; // every uint64 is above a negative constant
         return cmp_int<uint64_t>(x, op, (uint64_t)T.ivalue);
     }
-    case VXH_I32: { const int64_t x = ((const int32_t *)p)[i]; return T.is_int ? cmp_int<int64_t>(x, op, T.ivalue) : cmp_f64((double)x, op, T.value); }
-    case VXH_I16: { const int64_t x = ((const int16_t *)p)[i]; return T.is_int ? cmp_int<int64_t>(x, op, T.ivalue) : cmp_f64((double)x, op, T.value); }
-    case VXH_I8: { const int64_t x = ((const int8_t *)p)[i]; return T.is_int ? cmp_int<int64_t>(x, op, T.ivalue) : cmp_f64((double)x, op, T.value); }
-    case VXH_U32: { const int64_t x = ((const uint32_t *)p)[i]; return T.is_int ? cmp_int<int64_t>(x, op, T.ivalue) : cmp_f64((double)x, op, T.value); }
-    case VXH_U16: { const int64_t x = ((const uint16_t *)p)[i]; return T.is_int ? cmp_int<int64_t>(x, op, T.ivalue) : cmp_f64((double)x, op, T.value); }
-    default: { const int64_t x = ((const uint8_t *)p)[i]; return T.is_int ? cmp_int<int64_t>(x, op, T.ivalue) : cmp_f64((double)x, op, T.value); } // U8 / BOOL
+    default: {
+        int64_t x;
+        switch (dtype) {
+        case VXH_I64: x = (int64_t)b; break;
+        case VXH_I32: x = (int32_t)(uint32_t)b; break;
+        case VXH_I16: x = (int16_t)(uint16_t)b; break;
+        case VXH_I8: x = (int8_t)(uint8_t)b; break;
+        case VXH_U32: x = (int64_t)(uint32_t)b; break;
+        case VXH_U16: x = (int64_t)(uint16_t)b; break;
+        default: x = (int64_t)(uint8_t)b; break; // U8 / BOOL
+        }
+        return T.is_int ? cmp_int<int64_t>(x, op, T.ivalue) : cmp_f64((double)x, op, T.value);
     }
+    }
+}
+__device__ __forceinline__ int sel_itemsize(int dtype) {
+    return dtype == VXH_F64 || dtype == VXH_I64 || dtype == VXH_U64 ? 8 : (dtype == VXH_F32 || dtype == VXH_I32 || dtype == VXH_U32 ? 4 : (dtype == VXH_I16 || dtype == VXH_U16 ? 2 : 1));
+}
+// element i of a column of `dtype` at p against the term's constant
+__device__ __forceinline__ bool term_cmp(const SelTerm &T, int dtype, const void *p, uint64_t i) {
+    uint64_t b;
+    switch (sel_itemsize(dtype)) {
+    case 8: b = ((const uint64_t *)p)[i]; break;
+    case 4: b = ((const uint32_t *)p)[i]; break;
+    case 2: b = ((const uint16_t *)p)[i]; break;
+    default: b = ((const uint8_t *)p)[i]; break;
+    }
+    return term_cmp_bits(T, dtype, b);
 }
 
 // four consecutive rows per thread: one 32-bit store of four mask bytes (the tail rows one by one)
@@ -115,73 +137,198 @@ __global__ __launch_bounds__(256) void sel_eval(SelArgs A) {
     }
 }
 
-// The same mask where every term compares a float64 column as it is with a constant (no program) — what filters and selections mostly are
+// The same mask where every term compares a COLUMN as it is with a constant (no program) — what filters and selections mostly are
 // (round 6, late: the generic kernel above loads one row at a time behind a dtype switch, every load waited for by its comparison:
-// 2.95 ms per 1e9 rows x one column = 3.0 TB/s of its 9 bytes a row, profiles/r06_groupby_predicate.txt).  A lane takes U quads of four
-// consecutive rows a round; the 16-byte loads of ALL of them (NC columns, clamped to the last quad so that none is conditional) are issued
-// before the first comparison; one 4-byte store of mask bytes per quad.  The rows behind the last full quad go one by one.
+// 2.95 ms per 1e9 rows x one float64 column = 3.0 TB/s of its 9 bytes a row, profiles/r06_groupby_predicate.txt).  A lane takes U quads
+// of four consecutive rows a round; ONE load of 4 x itemsize bytes per column and quad (two for 8-byte columns), ALL of them — NC columns,
+// clamped to the last quad so that none is conditional — issued before the first comparison, the elements compared from registers by
+// the generic kernel's own rule (term_cmp); one 4-byte store of mask bytes per quad.  The rows behind the last full quad go one by one.
+// element r (0..3, a compile-time number where it is called) of a quad held as its dwords
+__device__ __forceinline__ uint64_t sel_quad_element(const uint32_t (&w)[8], int isz, int r) {
+    if (isz == 8) return (uint64_t)w[2 * r] | ((uint64_t)w[2 * r + 1] << 32);
+    if (isz == 4) return w[r];
+    if (isz == 2) return (w[r >> 1] >> (16 * (r & 1))) & 0xffffu;
+    return (w[0] >> (8 * r)) & 0xffu;
+}
+// (first form of this kernel: term_cmp_bits per row and term — a dtype switch, an is-integer branch and a comparison switch, all wave-uniform,
+//  all taken per row: 2-3.3 ms per 1e9 rows WHATEVER the column's width, +1.2 ms per further term — bound by its scalar branches, not by
+//  memory, profiles/r06_sel_eval.txt.  Now the dtype switch runs once per quad and column and leaves every element in two forms — a double,
+//  and its integer value with the sign bit flipped (an unsigned order) — and a term is straight-line code: the relation (less / equal /
+//  greater / unordered) of the form the term compares in, one bit of the comparison's 4-bit code; nothing per term is decided per row.)
+struct SelTermReg {   // what a term needs, per thread in scalar registers
+    double cd;        // the constant as the double the column's values are compared with
+    uint64_t cb;      // the constant as an integer, sign bit flipped
+    uint32_t code;    // bit `relation` set: the term holds (0 for a term that does not exist: never)
+    bool use_int;     // compare the integer forms (integer column and integer constant)
+    bool all_greater; // ... an unsigned 64-bit column against a negative constant: every value is greater
+    int column;
+};
 template <int NC, int U>
-__global__ __launch_bounds__(256) void sel_eval_f64(SelArgs A) {
+__global__ __launch_bounds__(256) void sel_eval_vec(SelArgs A) {
     const uint64_t quads = A.n / 4, stride = (uint64_t)gridDim.x * 256u;
+    SelTermReg T[VXH_SEL_MAX_TERMS];
+#pragma unroll
+    for (int t = 0; t < VXH_SEL_MAX_TERMS; ++t) {
+        const SelTerm &S = A.t[t];
+        const int c = t < A.nterms ? S.column : 0;
+        int d = A.dtype[0];
+#pragma unroll
+        for (int k = 1; k < NC; ++k) d = c == k ? A.dtype[k] : d;
+        const int op = S.op;
+        const uint32_t code = op == VXH_CMP_LT ? 1u : op == VXH_CMP_LE ? 3u : op == VXH_CMP_GT ? 4u : op == VXH_CMP_GE ? 6u : op == VXH_CMP_EQ ? 2u : 13u; // bits: 0 less, 1 equal, 2 greater, 3 unordered
+        T[t].code = t < A.nterms ? code : 0u;
+        T[t].column = c;
+        T[t].cd = d == VXH_F32 ? (double)(float)S.value : S.value; // numpy compares a float32 column with the constant ROUNDED to float32
+        T[t].use_int = S.is_int && d != VXH_F64 && d != VXH_F32;
+        T[t].all_greater = d == VXH_U64 && S.ivalue < 0;
+        T[t].cb = d == VXH_U64 ? (uint64_t)S.ivalue : (uint64_t)S.ivalue ^ 0x8000000000000000ull;
+    }
+    bool need_d = false, need_i = false; // does any term compare doubles / integers (a form nobody compares is not made)
+#pragma unroll
+    for (int t = 0; t < VXH_SEL_MAX_TERMS; ++t) {
+        if (t < A.nterms) { need_d = need_d || !T[t].use_int; need_i = need_i || T[t].use_int; }
+    }
     for (uint64_t q0 = (uint64_t)blockIdx.x * 256u + threadIdx.x; q0 < quads; q0 += stride * U) {
-        double x[NC][U][4];
+        uint32_t raw[NC][U][8]; // a quad's bytes as dwords (only ever indexed by compile-time numbers: registers)
         uint32_t am[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const uint64_t q = q0 + (uint64_t)u * stride, qc = q < quads ? q : quads - 1;
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
-                const double2 *p = (const double2 *)((const double *)A.col[c] + qc * 4);
-                const double2 lo = p[0], hi = p[1];
-                x[c][u][0] = lo.x; x[c][u][1] = lo.y; x[c][u][2] = hi.x; x[c][u][3] = hi.y;
+                const int isz = sel_itemsize(A.dtype[c]); // (wave-uniform)
+                const char *p = (const char *)A.col[c] + qc * 4 * (uint64_t)isz;
+                uint32_t (&w)[8] = raw[c][u];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) w[k] = 0u;
+                if (isz == 8) {
+                    const uint4 lo = ((const uint4 *)p)[0], hi = ((const uint4 *)p)[1];
+                    w[0] = lo.x; w[1] = lo.y; w[2] = lo.z; w[3] = lo.w; w[4] = hi.x; w[5] = hi.y; w[6] = hi.z; w[7] = hi.w;
+                } else if (isz == 4) {
+                    const uint4 lo = *(const uint4 *)p;
+                    w[0] = lo.x; w[1] = lo.y; w[2] = lo.z; w[3] = lo.w;
+                } else if (isz == 2) {
+                    const uint2 lo = *(const uint2 *)p;
+                    w[0] = lo.x; w[1] = lo.y;
+                } else {
+                    w[0] = *(const uint32_t *)p;
+                }
             }
             am[u] = A.and_mask ? *(const uint32_t *)(A.and_mask + qc * 4) : 0u;
         }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
+        // (the quads one by one through a generic lambda with a compile-time number: as a `#pragma unroll` loop over u the compiler left the
+        //  loop rolled — "unable to perform the requested transformation" — and `raw` went to scratch memory, 144 bytes a lane)
+        auto emit = [&](auto uc) {
+            constexpr int u = decltype(uc)::value;
             const uint64_t q = q0 + (uint64_t)u * stride;
             if (q < quads) {
+                double xd[NC][4];   // the elements as the doubles a float constant is compared with
+                uint64_t xb[NC][4]; // ... as integers in an unsigned order (integer columns)
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    const int d = A.dtype[c], isz = sel_itemsize(d);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const uint64_t b = sel_quad_element(raw[c][u], isz, r);
+                        int64_t x;
+                        switch (d) { // (once per quad and column; wave-uniform)
+                        case VXH_F64: xd[c][r] = __longlong_as_double((long long)b); xb[c][r] = 0; break;
+                        case VXH_F32: xd[c][r] = (double)__uint_as_float((uint32_t)b); xb[c][r] = 0; break;
+                        case VXH_U64: xd[c][r] = need_d ? (double)b : 0.0; xb[c][r] = b; break;
+                        default:
+                            switch (d) {
+                            case VXH_I64: x = (int64_t)b; break;
+                            case VXH_I32: x = (int32_t)(uint32_t)b; break;
+                            case VXH_I16: x = (int16_t)(uint16_t)b; break;
+                            case VXH_I8: x = (int8_t)(uint8_t)b; break;
+                            case VXH_U32: x = (int64_t)(uint32_t)b; break;
+                            case VXH_U16: x = (int64_t)(uint16_t)b; break;
+                            default: x = (int64_t)(uint8_t)b; break; // U8 / BOOL
+                            }
+                            xd[c][r] = need_d ? (double)x : 0.0; xb[c][r] = (uint64_t)x ^ 0x8000000000000000ull;
+                            break;
+                        }
+                    }
+                }
+                uint32_t bits[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+                for (int t = 0; t < VXH_SEL_MAX_TERMS; ++t) {
+                    if (t < A.nterms) { // (wave-uniform, like the two branches below: decided per term and quad, not per row)
+                        if (T[t].use_int) {
+                            if (T[t].all_greater) {
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) bits[r] |= ((T[t].code >> 2) & 1u) << t;
+                            } else {
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) {
+                                    uint64_t vb = xb[0][r];
+#pragma unroll
+                                    for (int c = 1; c < NC; ++c) vb = T[t].column == c ? xb[c][r] : vb;
+                                    const uint32_t rel = vb < T[t].cb ? 0u : (vb == T[t].cb ? 1u : 2u);
+                                    bits[r] |= ((T[t].code >> rel) & 1u) << t;
+                                }
+                            }
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                double vd = xd[0][r];
+#pragma unroll
+                                for (int c = 1; c < NC; ++c) vd = T[t].column == c ? xd[c][r] : vd;
+                                const uint32_t rel = vd < T[t].cd ? 0u : (vd == T[t].cd ? 1u : (vd > T[t].cd ? 2u : 3u));
+                                bits[r] |= ((T[t].code >> rel) & 1u) << t;
+                            }
+                        }
+                    }
+                }
                 uint32_t packed = 0;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    uint32_t bits = 0;
-#pragma unroll
-                    for (int t = 0; t < VXH_SEL_MAX_TERMS; ++t) {
-                        if (t < A.nterms) {
-                            double v = x[0][u][r];
-#pragma unroll
-                            for (int c = 1; c < NC; ++c) v = A.t[t].column == c ? x[c][u][r] : v; // (wave-uniform)
-                            bits |= (cmp_f64(v, A.t[t].op, A.t[t].value) ? 1u : 0u) << t;
-                        }
-                    }
-                    uint32_t keep = (A.truth >> bits) & 1u;
+                    uint32_t keep = (A.truth >> bits[r]) & 1u;
                     if (A.and_mask) keep &= ((am[u] >> (8 * r)) & 0xffu) != 0u ? 1u : 0u;
                     packed |= keep << (8 * r);
                 }
                 *(uint32_t *)(A.out + q * 4) = packed; // (out is 256-byte aligned scratch)
             }
-        }
+        };
+        emit(std::integral_constant<int, 0>{});
+        if constexpr (U > 1) emit(std::integral_constant<int, 1>{});
+        if constexpr (U > 2) emit(std::integral_constant<int, 2>{});
+        if constexpr (U > 3) emit(std::integral_constant<int, 3>{});
+        static_assert(U <= 4, "emit() is spelled out for four quads");
     }
     if (blockIdx.x == 0 && threadIdx.x < (uint32_t)(A.n & 3u)) {
         const uint64_t i = quads * 4 + threadIdx.x;
         uint32_t bits = 0;
-        for (int t = 0; t < A.nterms; t++) bits |= (term_at(A, t, i) ? 1u : 0u) << t;
+#pragma unroll
+        for (int t = 0; t < VXH_SEL_MAX_TERMS; ++t) { // (compile-time term and column numbers: the descriptor stays where the kernel arguments are)
+            if (t < A.nterms) {
+                bool hit = false;
+#pragma unroll
+                for (int c = 0; c < NC; ++c)
+                    if (A.t[t].column == c) hit = term_cmp(A.t[t], A.dtype[c], A.col[c], i);
+                bits |= (hit ? 1u : 0u) << t;
+            }
+        }
         uint32_t keep = (A.truth >> bits) & 1u;
         if (A.and_mask) keep &= A.and_mask[i] != 0 ? 1u : 0u;
         A.out[i] = (uint8_t)keep;
     }
 }
-// number of columns the fast form would read (1..4), or 0 when the selection is not of its kind
-static int sel_eval_f64_columns(const SelArgs &A) {
+// number of columns the quad form would read (1..4), or 0 when the selection is not of its kind
+static int sel_eval_vec_columns(const SelArgs &A) {
     if (A.nterms < 1 || A.nterms > VXH_SEL_MAX_TERMS || A.n < 4) return 0;
     int nc = 0;
     for (int t = 0; t < A.nterms; t++) {
         const int c = A.t[t].column;
-        if (A.nsteps[t] > 0 || c < 0 || c >= VXH_SEL_MAX_COLUMNS || A.dtype[c] != VXH_F64) return 0;
+        if (A.nsteps[t] > 0 || c < 0 || c >= VXH_SEL_MAX_COLUMNS) return 0;
         nc = std::max(nc, c + 1);
     }
-    for (int c = 0; c < nc; c++) // (a column no term reads is loaded all the same: it must be one)
-        if (!A.col[c] || A.dtype[c] != VXH_F64 || ((uintptr_t)A.col[c] & 15u)) return 0;
+    for (int c = 0; c < nc; c++) { // (a column no term reads is loaded all the same: it must be one; a quad of it must be one aligned load)
+        if (!A.col[c] || A.dtype[c] >= VXH_DTYPE_COUNT) return 0;
+        const int d = A.dtype[c];
+        const int isz = d == VXH_F64 || d == VXH_I64 || d == VXH_U64 ? 8 : (d == VXH_F32 || d == VXH_I32 || d == VXH_U32 ? 4 : (d == VXH_I16 || d == VXH_U16 ? 2 : 1));
+        if ((uintptr_t)A.col[c] & (uintptr_t)(isz == 8 ? 15 : 4 * isz - 1)) return 0;
+    }
     if (((uintptr_t)A.and_mask & 3u) || ((uintptr_t)A.out & 3u)) return 0;
     return nc;
 }
@@ -383,12 +530,10 @@ void vxh_launch_sel_eval(const SelArgs &A, hipStream_t stream) {
     if (!A.n) return;
     const uint64_t quads = (A.n + 3) / 4;
     const int blocks = (int)std::min<uint64_t>((quads + 255) / 256, 256 * 16);
-    switch (sel_eval_f64_columns(A)) {
-    case 1: hipLaunchKernelGGL((sel_eval_f64<1, 4>), dim3(blocks), dim3(256), 0, stream, A); return;
-    case 2: hipLaunchKernelGGL((sel_eval_f64<2, 2>), dim3(blocks), dim3(256), 0, stream, A); return;
-    case 3: hipLaunchKernelGGL((sel_eval_f64<3, 1>), dim3(blocks), dim3(256), 0, stream, A); return;
-    case 4: hipLaunchKernelGGL((sel_eval_f64<4, 1>), dim3(blocks), dim3(256), 0, stream, A); return;
-    default: break;
+    switch (sel_eval_vec_columns(A)) {
+    case 1: hipLaunchKernelGGL((sel_eval_vec<1, 4>), dim3(blocks), dim3(256), 0, stream, A); return;
+    case 2: hipLaunchKernelGGL((sel_eval_vec<2, 2>), dim3(blocks), dim3(256), 0, stream, A); return;
+    default: break; // (three or four columns: the compiler turns the choice of a term's registers into an indexed access and the quads go to scratch memory — the generic kernel)
     }
     hipLaunchKernelGGL(sel_eval, dim3(blocks), dim3(256), 0, stream, A);
 }
