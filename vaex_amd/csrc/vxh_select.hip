@@ -12,6 +12,7 @@
 // (the constant is rounded first: `f4 <= 0.3` holds for float32(0.3), as in numpy).
 #include "vxh_internal.hpp"
 #include "vxh_kernels.hpp"
+#include <cstdlib>
 #include <type_traits>
 
 namespace {
@@ -354,6 +355,65 @@ __global__ __launch_bounds__(256) void pack_keys(PackArgs A) {
     }
 }
 
+// ... for the usual handful of keys (round 6, late): the kernel above loads one element per key at a time — every load behind a dtype
+// switch, waited for by the multiply-add that uses it.  Here a lane takes U rows a round (a wave's rows of a round are consecutive: every
+// load is one coalesced line per key), the dtype switch runs once per key and round AROUND the U loads of that key, and all NK x U loads are
+// in flight before the first multiply (profiles/r06_pack_keys.txt).
+template <int NK, int U>
+__global__ __launch_bounds__(256) void pack_keys_n(PackArgs A) {
+    const uint64_t stride = (uint64_t)gridDim.x * 256u;
+    for (uint64_t i0 = (uint64_t)blockIdx.x * 256u + threadIdx.x; i0 < A.n; i0 += stride * U) {
+        int64_t x[NK][U];
+        uint64_t ic[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) { const uint64_t i = i0 + (uint64_t)u * stride; ic[u] = i < A.n ? i : A.n - 1; } // (clamped: no load is conditional)
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            const void *p = A.col[k];
+            switch (A.dtype[k]) { // (wave-uniform; the U loads of a case back to back)
+            case VXH_I64: case VXH_U64:
+#pragma unroll
+                for (int u = 0; u < U; ++u) x[k][u] = ((const int64_t *)p)[ic[u]];
+                break;
+            case VXH_I32:
+#pragma unroll
+                for (int u = 0; u < U; ++u) x[k][u] = ((const int32_t *)p)[ic[u]];
+                break;
+            case VXH_U32:
+#pragma unroll
+                for (int u = 0; u < U; ++u) x[k][u] = ((const uint32_t *)p)[ic[u]];
+                break;
+            case VXH_I16:
+#pragma unroll
+                for (int u = 0; u < U; ++u) x[k][u] = ((const int16_t *)p)[ic[u]];
+                break;
+            case VXH_U16:
+#pragma unroll
+                for (int u = 0; u < U; ++u) x[k][u] = ((const uint16_t *)p)[ic[u]];
+                break;
+            case VXH_I8:
+#pragma unroll
+                for (int u = 0; u < U; ++u) x[k][u] = ((const int8_t *)p)[ic[u]];
+                break;
+            default:
+#pragma unroll
+                for (int u = 0; u < U; ++u) x[k][u] = ((const uint8_t *)p)[ic[u]];
+                break;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint64_t i = i0 + (uint64_t)u * stride;
+            if (i < A.n) {
+                int64_t packed = 0;
+#pragma unroll
+                for (int k = 0; k < NK; ++k) packed += (int64_t)((uint64_t)(x[k][u] - A.min_value[k]) * (uint64_t)A.multiplier[k]);
+                A.out[i] = packed;
+            }
+        }
+    }
+}
+
 // row-wise product of two float64 columns (NaN where either is NaN): the off-diagonal inputs of OP_COV (src/vaexfast.cpp:1117-1153)
 __global__ __launch_bounds__(256) void product_f64(const double *a, const double *b, double *out, uint64_t n) {
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) out[i] = a[i] * b[i];
@@ -518,6 +578,16 @@ void vxh_launch_column_convert(const void *data, const uint8_t *mask, int dtype,
 void vxh_launch_pack_keys(const PackArgs &A, hipStream_t stream) {
     if (!A.n) return;
     const int blocks = (int)std::min<uint64_t>((A.n + 255) / 256, 256 * 16);
+    static const bool generic_only = getenv("VAEX_HIP_PACK_KEYS_GENERIC") != nullptr; // (timing comparison: tools/r09_pack_keys.py)
+    if (!generic_only) {
+        switch (A.nkeys) {
+        case 1: hipLaunchKernelGGL((pack_keys_n<1, 4>), dim3(blocks), dim3(256), 0, stream, A); return;
+        case 2: hipLaunchKernelGGL((pack_keys_n<2, 4>), dim3(blocks), dim3(256), 0, stream, A); return;
+        case 3: hipLaunchKernelGGL((pack_keys_n<3, 4>), dim3(blocks), dim3(256), 0, stream, A); return;
+        case 4: hipLaunchKernelGGL((pack_keys_n<4, 2>), dim3(blocks), dim3(256), 0, stream, A); return;
+        default: break;
+        }
+    }
     hipLaunchKernelGGL(pack_keys, dim3(blocks), dim3(256), 0, stream, A);
 }
 void vxh_launch_product_f64(const double *a, const double *b, double *out, uint64_t n, hipStream_t stream) {
