@@ -1,5 +1,6 @@
 """Round 6 (late): the key-packing pass of a multi-key groupby (vxh_pack_keys) — pack_keys_n (loads of a round issued up front) against the
-row-at-a-time kernel (VAEX_HIP_PACK_KEYS_GENERIC=1 in the environment of a second run of this script), 1e9 rows, best of 10.
+row-at-a-time kernel, 1e9 rows, best of 10.  (The comparison in profiles/r06_pack_keys.txt was taken with a build that could still be told to launch
+the old kernel for 1-4 keys — VAEX_HIP_PACK_KEYS_GENERIC — a switch the product library no longer has; five keys and more still take the old kernel.)
     python tools/r09_pack_keys.py [rows]"""
 import sys, os, time
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
@@ -9,7 +10,7 @@ sa.warmup()
 n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 1_000_000_000
 DT = {"int64": 2, "int32": 3, "int16": 4, "int8": 5, "uint8": 9}
 TD = {"int64": torch.int64, "int32": torch.int32, "int16": torch.int16, "int8": torch.int8, "uint8": torch.uint8}
-which = "row-at-a-time kernel" if os.environ.get("VAEX_HIP_PACK_KEYS_GENERIC") else "pack_keys_n"
+which = "pack_keys_n (1-4 keys)"
 for kinds in (["int64", "int32"], ["int64", "int64"], ["int32", "int32", "int16"], ["int32", "int16", "int8", "uint8"], ["int64"]):
     cols = [torch.randint(0, 100, (n,), device="cuda", dtype=torch.int32).to(TD[k]) for k in kinds]
     mins = [0] * len(kinds)

@@ -12,7 +12,6 @@
 // (the constant is rounded first: `f4 <= 0.3` holds for float32(0.3), as in numpy).
 #include "vxh_internal.hpp"
 #include "vxh_kernels.hpp"
-#include <cstdlib>
 #include <type_traits>
 
 namespace {
@@ -578,15 +577,12 @@ void vxh_launch_column_convert(const void *data, const uint8_t *mask, int dtype,
 void vxh_launch_pack_keys(const PackArgs &A, hipStream_t stream) {
     if (!A.n) return;
     const int blocks = (int)std::min<uint64_t>((A.n + 255) / 256, 256 * 16);
-    static const bool generic_only = getenv("VAEX_HIP_PACK_KEYS_GENERIC") != nullptr; // (timing comparison: tools/r09_pack_keys.py)
-    if (!generic_only) {
-        switch (A.nkeys) {
-        case 1: hipLaunchKernelGGL((pack_keys_n<1, 4>), dim3(blocks), dim3(256), 0, stream, A); return;
-        case 2: hipLaunchKernelGGL((pack_keys_n<2, 4>), dim3(blocks), dim3(256), 0, stream, A); return;
-        case 3: hipLaunchKernelGGL((pack_keys_n<3, 4>), dim3(blocks), dim3(256), 0, stream, A); return;
-        case 4: hipLaunchKernelGGL((pack_keys_n<4, 2>), dim3(blocks), dim3(256), 0, stream, A); return;
-        default: break;
-        }
+    switch (A.nkeys) { // (the row-at-a-time kernel below: five to eight keys; what it cost for fewer is in profiles/r06_pack_keys.txt)
+    case 1: hipLaunchKernelGGL((pack_keys_n<1, 4>), dim3(blocks), dim3(256), 0, stream, A); return;
+    case 2: hipLaunchKernelGGL((pack_keys_n<2, 4>), dim3(blocks), dim3(256), 0, stream, A); return;
+    case 3: hipLaunchKernelGGL((pack_keys_n<3, 4>), dim3(blocks), dim3(256), 0, stream, A); return;
+    case 4: hipLaunchKernelGGL((pack_keys_n<4, 2>), dim3(blocks), dim3(256), 0, stream, A); return;
+    default: break;
     }
     hipLaunchKernelGGL(pack_keys, dim3(blocks), dim3(256), 0, stream, A);
 }
